@@ -1,0 +1,113 @@
+/* msorb — MI355X-native ORB front-end for MS-SLAM: C ABI of libmsorb.so.
+ *
+ * This is the drop-in boundary.  Every entry point is `extern "C"`, takes plain
+ * pointers and sizes, never throws, never allocates across the boundary, and returns MSORB_OK (0)
+ * or a negative MSORB_E_* code (msorb_last_error() gives the thread-local detail string).
+ * Each function names the reference interface it replaces (paths are into fishmarch/MS-SLAM).
+ *
+ * The kernels are hand-written HIP for gfx950; there is NO CPU fallback: on a machine without a
+ * usable GPU every compute entry returns MSORB_E_NO_DEVICE.
+ */
+#ifndef MSORB_H
+#define MSORB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSORB_OK 0
+#define MSORB_E_INVALID -1    /* bad argument */
+#define MSORB_E_NO_DEVICE -2  /* no HIP device / HIP runtime error at init */
+#define MSORB_E_HIP -3        /* HIP runtime error during the call */
+#define MSORB_E_CAPACITY -4   /* caller-provided buffer too small */
+#define MSORB_E_GEOMETRY -5   /* image too small for the reference's cell arithmetic (it would divide by zero) */
+#define MSORB_E_EMPTY -6      /* empty input image: ORBextractor::operator() returns -1 (ORBextractor.cc:1090-1091) */
+
+#define MSORB_MAX_LEVELS 16
+#define MSORB_DESC_BYTES 32
+
+/* Same 28-byte layout as cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id). */
+typedef struct msorb_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} msorb_keypoint;
+
+const char* msorb_last_error(void);
+int msorb_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Extractor — replaces ORB_SLAM3::ORBextractor (include/ORBextractor.h:43-109, src/ORBextractor.cc)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct msorb_extractor msorb_extractor;
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+ * (ORBextractor.cc:409-469).  `device` is the HIP device ordinal the handle lives on.  One handle per
+ * extractor object; a handle owns its stream, device pyramid and pinned staging and must not be
+ * entered concurrently (the reference never does: Frame.cc:122-125 uses one object per eye). */
+int msorb_extractor_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast,
+                           int device, msorb_extractor** out);
+void msorb_extractor_destroy(msorb_extractor* h);
+
+/* GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares / GetInverseScaleSigmaSquares
+ * (ORBextractor.h:61-81) and mnFeaturesPerLevel; each array has nlevels entries; NULL = skip. */
+int msorb_extractor_tables(const msorb_extractor* h, float* scale, float* inv_scale, float* sigma2,
+                           float* inv_sigma2, int* features_per_level);
+
+/* Upper bound on keypoints one image can return: nfeatures + 3*nlevels. */
+int msorb_extractor_capacity(const msorb_extractor* h);
+
+/* ORBextractor::operator()(image, mask, keypoints, descriptors, vLappingArea) (ORBextractor.cc:1086-1168)
+ * on one HOST image (8-bit, 1 channel, `stride` bytes per row).  Writes *n_keypoints keypoints
+ * (reference order: keypoints outside [lap0,lap1] from the front, inside from the back) and
+ * *n_keypoints x 32 descriptor bytes into caller buffers of `capacity` rows; *mono_index is the
+ * operator()'s return value.  Returns MSORB_E_EMPTY for rows==0||cols==0||image==NULL. */
+int msorb_extract(msorb_extractor* h, const uint8_t* image, int rows, int cols, size_t stride, int lap0, int lap1,
+                  msorb_keypoint* keypoints, uint8_t* descriptors, int capacity, int* n_keypoints,
+                  int* mono_index);
+
+/* mvImagePyramid[level] (ORBextractor.h:83) of the last msorb_extract() call as a host-visible plane
+ * (interior pixels; the 19-px border of ORBextractor.cc:1185-1191 is not materialised).  The memory
+ * is owned by the handle and valid until the next extract call. */
+int msorb_pyramid_level(msorb_extractor* h, int level, const uint8_t** data, int* rows, int* cols, size_t* stride);
+
+/* Batched operator() over n_images same-sized DEVICE-resident images (image i at d_images +
+ * i*image_stride, rows of row_stride bytes).  Outputs stay on the device: image i's keypoints at
+ * d_keypoints + i*capacity, descriptors at d_descriptors + i*capacity*32.  h_counts[i] / h_mono[i]
+ * (host arrays, n_images entries, h_mono may be NULL) receive n_keypoints / mono_index.
+ * Level 0 is read in place from d_images (it must stay valid until the call returns). */
+int msorb_extract_batch(msorb_extractor* h, const uint8_t* d_images, int n_images, int rows, int cols,
+                        size_t row_stride, size_t image_stride, int lap0, int lap1, msorb_keypoint* d_keypoints,
+                        uint8_t* d_descriptors, int capacity, int* h_counts, int* h_mono);
+
+/* Stage timing of the last batch call, measured with HIP events on the handle's stream.
+ * enable!=0 switches recording on.  Stage order: MSORB_STAGE_* below; ms[] has MSORB_N_STAGES slots. */
+#define MSORB_STAGE_PYRAMID 0
+#define MSORB_STAGE_FAST 1
+#define MSORB_STAGE_COMPACT 2
+#define MSORB_STAGE_BLUR 3
+#define MSORB_STAGE_SELECT 4   /* D2H candidates + quadtree + H2D selection (host-inclusive wall time) */
+#define MSORB_STAGE_DESCRIBE 5 /* IC-angle + rBRIEF */
+#define MSORB_N_STAGES 6
+int msorb_extractor_set_profiling(msorb_extractor* h, int enable);
+int msorb_extractor_stage_ms(const msorb_extractor* h, float* ms);
+
+/* Test/inspection hooks (device -> host copies of intermediate products of the last call). */
+int msorb_debug_level_size(const msorb_extractor* h, int level, int* rows, int* cols);
+int msorb_debug_copy_level(msorb_extractor* h, int image, int level, int blurred, uint8_t* dst /* rows*cols */);
+/* FAST candidates handed to the quadtree (vToDistributeKeys, ORBextractor.cc:795-869) of one image
+ * and level, reference order; coordinates relative to (16,16); xyscore[3*i..3*i+2]. */
+int msorb_debug_candidates(msorb_extractor* h, int image, int level, int* xyscore, int capacity, int* n);
+
+/* Host-only: DistributeOctTree (ORBextractor.cc:555-779) on explicit candidates; writes the indices of
+ * the kept candidates in result order.  Needs no GPU. */
+int msorb_distribute_quadtree(const uint16_t* xs, const uint16_t* ys, const uint16_t* scores, int n, int min_x,
+                              int max_x, int min_y, int max_y, int n_features, int* kept_idx, int capacity,
+                              int* n_kept);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSORB_H */

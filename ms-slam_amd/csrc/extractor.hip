@@ -1,0 +1,596 @@
+// libmsorb.so — extractor handle, host orchestration and the C ABI of include/msorb.h.
+//
+// Per call (one stream, n_images same-sized frames):
+//   pyramid (nlevels-1 launches) -> FAST cells -> candidate compaction -> [copy stream: D2H candidates]
+//   -> Gaussian blur (overlaps the host stage) -> host quadtree selection (thread pool, one task per image)
+//   -> H2D selection -> IC-angle + rBRIEF -> keypoints/descriptors in device memory.
+// The quadtree (DistributeOctTree, ORBextractor.cc:555-779) is serial and order-defining; it stays on the
+// host (orb_host.cc) in this version.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "orb_device.h"
+
+using namespace msorb;
+
+namespace {
+
+thread_local std::string g_last_error;
+void set_error(const std::string& s) { g_last_error = s; }
+
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) {                                                                       \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                             \
+            return MSORB_E_HIP;                                                                       \
+        }                                                                                             \
+    } while (0)
+
+const int8_t kPattern[1024] = {
+#include "orb_pattern.inc"
+};
+
+// Minimal persistent worker pool: parallel_for(n, fn) runs fn(i) for i in [0,n) on the workers + caller.
+class Pool {
+    struct Job {
+        const std::function<void(int)>* fn;
+        int n;
+        std::atomic<int> next{0}, done{0};
+    };
+
+public:
+    explicit Pool(int nthreads) {
+        for (int i = 0; i < nthreads - 1; i++) workers_.emplace_back([this] { loop(); });
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    void parallel_for(int n, const std::function<void(int)>& fn) {
+        if (n <= 0) return;
+        auto job = std::make_shared<Job>();
+        job->fn = &fn;
+        job->n = n;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            cur_ = job;
+            gen_++;
+        }
+        cv_.notify_all();
+        work(*job);
+        std::unique_lock<std::mutex> lk(m_);
+        done_cv_.wait(lk, [&] { return job->done.load() >= n; });
+        cur_.reset();
+    }
+
+private:
+    void work(Job& job) {
+        for (;;) {
+            const int i = job.next.fetch_add(1);
+            if (i >= job.n) break;
+            (*job.fn)(i);
+            if (job.done.fetch_add(1) + 1 == job.n) {
+                std::lock_guard<std::mutex> lk(m_);
+                done_cv_.notify_all();
+            }
+        }
+    }
+    void loop() {
+        unsigned seen = 0;
+        for (;;) {
+            std::shared_ptr<Job> job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                job = cur_;
+            }
+            if (job) work(*job);
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_cv_;
+    std::shared_ptr<Job> cur_;
+    unsigned gen_ = 0;
+    bool stop_ = false;
+};
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count) {
+        if (count <= n) return MSORB_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        HIPCHK(hipMalloc((void**)&p, count * sizeof(T)));
+        n = count;
+        return MSORB_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+template <typename T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count) {
+        if (count <= n) return MSORB_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; n = 0;
+        HIPCHK(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
+        n = count;
+        return MSORB_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct msorb_extractor {
+    int device = 0;
+    OrbParams P;
+    hipStream_t stream = nullptr, copy_stream = nullptr;
+    hipEvent_t ev_compact = nullptr;
+    hipEvent_t pe[8] = {};
+    bool profiling = false;
+    float stage_ms[MSORB_N_STAGES] = {};
+
+    FrameGeom G;
+    bool geom_valid = false;
+    std::vector<int> level_cell_begin;
+    LevelScale scales;
+
+    // device state
+    DevBuf<uint8_t> d_pyr, d_blur, d_desc1;
+    DevBuf<ResizeTap> d_taps;
+    std::vector<size_t> tap_x_off, tap_y_off;
+    DevBuf<CellDesc> d_cells;
+    DevBuf<int> d_level_cell_begin, d_cell_count, d_cell_off, d_level_count, d_img_total, d_img_base, d_sel_count;
+    DevBuf<Cand16> d_slots, d_compact;
+    DevBuf<SelRec> d_sel;
+    DevBuf<msorb_keypoint> d_kps1;
+    // pinned host state
+    PinBuf<int> h_level_count, h_img_base, h_sel_count;
+    PinBuf<Cand16> h_compact;
+    PinBuf<SelRec> h_sel;
+    PinBuf<uint8_t> h_pyr;
+    bool h_pyr_valid = false;
+
+    // last call
+    PyramidView last_pyr{}, last_blur{};
+    int last_n_images = 0;
+    int sel_stride = 0;
+
+    std::unique_ptr<Pool> pool;
+    std::vector<std::vector<int>> kept_scratch;  // per worker-task scratch is allocated inside tasks
+};
+
+namespace {
+
+int capacity_of(const msorb_extractor* h) { return h->P.nfeatures + 3 * h->P.nlevels; }
+
+int ensure_geometry(msorb_extractor* h, int rows, int cols) {
+    if (h->geom_valid && h->G.rows == rows && h->G.cols == cols) return MSORB_OK;
+    h->geom_valid = false;
+    FrameGeom g;
+    if (!g.build(h->P, rows, cols)) {
+        set_error("image too small for the reference's 35-px cell grid at some pyramid level");
+        return MSORB_E_GEOMETRY;
+    }
+    for (const CellDesc& c : g.cells)
+        if (c.rw > 76 || c.rh > 76) { set_error("cell ROI larger than 76 px"); return MSORB_E_GEOMETRY; }
+    h->G = g;
+    // resize taps for levels 1..n-1
+    std::vector<ResizeTap> all;
+    h->tap_x_off.assign(g.nlevels, 0);
+    h->tap_y_off.assign(g.nlevels, 0);
+    for (int l = 1; l < g.nlevels; l++) {
+        auto tx = make_resize_taps(g.lv[l].w, g.lv[l - 1].w, true);
+        auto ty = make_resize_taps(g.lv[l].h, g.lv[l - 1].h, false);
+        h->tap_x_off[l] = all.size();
+        all.insert(all.end(), tx.begin(), tx.end());
+        h->tap_y_off[l] = all.size();
+        all.insert(all.end(), ty.begin(), ty.end());
+    }
+    int rc;
+    if ((rc = h->d_taps.ensure(std::max<size_t>(all.size(), 1)))) return rc;
+    if (!all.empty()) HIPCHK(hipMemcpy(h->d_taps.p, all.data(), all.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
+    if ((rc = h->d_cells.ensure(g.cells.size()))) return rc;
+    HIPCHK(hipMemcpy(h->d_cells.p, g.cells.data(), g.cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
+    h->level_cell_begin.assign(g.nlevels + 1, 0);
+    for (int l = 0; l < g.nlevels; l++) h->level_cell_begin[l] = g.lv[l].cell_begin;
+    h->level_cell_begin[g.nlevels] = (int)g.cells.size();
+    if ((rc = h->d_level_cell_begin.ensure(g.nlevels + 1))) return rc;
+    HIPCHK(hipMemcpy(h->d_level_cell_begin.p, h->level_cell_begin.data(), (g.nlevels + 1) * sizeof(int),
+                     hipMemcpyHostToDevice));
+    h->geom_valid = true;
+    h->last_n_images = 0;
+    return MSORB_OK;
+}
+
+int ensure_batch(msorb_extractor* h, int n_images) {
+    const FrameGeom& g = h->G;
+    const size_t ncells = g.cells.size();
+    int rc;
+    if ((rc = h->d_pyr.ensure((size_t)n_images * g.pyramid_bytes))) return rc;
+    if ((rc = h->d_blur.ensure((size_t)n_images * g.pyramid_bytes))) return rc;
+    if ((rc = h->d_slots.ensure((size_t)n_images * g.slots_per_image))) return rc;
+    if ((rc = h->d_compact.ensure((size_t)n_images * g.slots_per_image))) return rc;
+    if ((rc = h->d_cell_count.ensure((size_t)n_images * ncells))) return rc;
+    if ((rc = h->d_cell_off.ensure((size_t)n_images * ncells))) return rc;
+    if ((rc = h->d_level_count.ensure((size_t)n_images * g.nlevels))) return rc;
+    if ((rc = h->d_img_total.ensure(n_images))) return rc;
+    if ((rc = h->d_img_base.ensure(n_images + 1))) return rc;
+    if ((rc = h->d_sel_count.ensure(n_images))) return rc;
+    h->sel_stride = capacity_of(h);
+    if ((rc = h->d_sel.ensure((size_t)n_images * h->sel_stride))) return rc;
+    if ((rc = h->h_level_count.ensure((size_t)n_images * g.nlevels))) return rc;
+    if ((rc = h->h_img_base.ensure(n_images + 1))) return rc;
+    if ((rc = h->h_sel_count.ensure(n_images))) return rc;
+    if ((rc = h->h_sel.ensure((size_t)n_images * h->sel_stride))) return rc;
+    return MSORB_OK;
+}
+
+PyramidView make_view(const msorb_extractor* h, const uint8_t* base, const LevelView* level0) {
+    PyramidView v{};
+    const FrameGeom& g = h->G;
+    v.nlevels = g.nlevels;
+    for (int l = 0; l < g.nlevels; l++) {
+        v.lv[l].base = base + g.lv[l].plane_off;
+        v.lv[l].img_stride = g.pyramid_bytes;
+        v.lv[l].pitch = g.lv[l].pitch;
+        v.lv[l].w = g.lv[l].w;
+        v.lv[l].h = g.lv[l].h;
+    }
+    if (level0) v.lv[0] = *level0;
+    return v;
+}
+
+// The pipeline proper.  level0: where level 0 of every image lives (device memory).
+int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int lap0, int lap1,
+                 msorb_keypoint* d_kps, uint8_t* d_desc, int capacity, int* h_counts, int* h_mono) {
+    const FrameGeom& g = h->G;
+    const int nl = g.nlevels;
+    const int ncells = (int)g.cells.size();
+    hipStream_t s = h->stream;
+    const bool prof = h->profiling;
+    auto mark = [&](int i) { if (prof) (void)hipEventRecord(h->pe[i], s); };
+
+    const PyramidView pyr = make_view(h, h->d_pyr.p, &level0);
+    const PyramidView blur = make_view(h, h->d_blur.p, nullptr);
+    h->last_pyr = pyr; h->last_blur = blur; h->last_n_images = n_images;
+    h->h_pyr_valid = false;
+
+    mark(0);
+    for (int l = 1; l < nl; l++)
+        launch_pyr_resize(pyr.lv[l - 1], pyr.lv[l], h->d_pyr.p + g.lv[l].plane_off, h->d_taps.p + h->tap_x_off[l],
+                          h->d_taps.p + h->tap_y_off[l], n_images, s);
+    mark(1);
+    launch_fast_cells(pyr, h->d_cells.p, ncells, h->P.ini_th, h->P.min_th, g.slots_per_image, h->d_slots.p,
+                      h->d_cell_count.p, n_images, s);
+    mark(2);
+    launch_cand_compact(h->d_cells.p, ncells, h->d_level_cell_begin.p, nl, g.slots_per_image, h->d_slots.p,
+                        h->d_cell_count.p, h->d_cell_off.p, h->d_level_count.p, h->d_img_total.p, h->d_img_base.p,
+                        h->d_compact.p, n_images, s);
+    mark(3);
+    HIPCHK(hipEventRecord(h->ev_compact, s));
+    // blur runs on the main stream while the copy stream + host do the selection
+    for (int l = 0; l < nl; l++) launch_gauss7(pyr.lv[l], blur.lv[l], h->d_blur.p + g.lv[l].plane_off, n_images, s);
+    mark(4);
+
+    const auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_compact, 0));
+    HIPCHK(hipMemcpyAsync(h->h_level_count.p, h->d_level_count.p, (size_t)n_images * nl * sizeof(int),
+                          hipMemcpyDeviceToHost, h->copy_stream));
+    HIPCHK(hipMemcpyAsync(h->h_img_base.p, h->d_img_base.p, (size_t)(n_images + 1) * sizeof(int),
+                          hipMemcpyDeviceToHost, h->copy_stream));
+    HIPCHK(hipStreamSynchronize(h->copy_stream));
+    const int total = h->h_img_base.p[n_images];
+    int rc;
+    if ((rc = h->h_compact.ensure(std::max<size_t>((size_t)total + total / 4, 1024)))) return rc;
+    if (total > 0) {
+        HIPCHK(hipMemcpyAsync(h->h_compact.p, h->d_compact.p, (size_t)total * sizeof(Cand16), hipMemcpyDeviceToHost,
+                              h->copy_stream));
+        HIPCHK(hipStreamSynchronize(h->copy_stream));
+    }
+
+    // host selection, one task per image
+    std::atomic<int> overflow{0};
+    const int sel_stride = h->sel_stride;
+    std::function<void(int)> task = [&](int img) {
+        const Cand16* c = h->h_compact.p + h->h_img_base.p[img];
+        const int* lc = h->h_level_count.p + (size_t)img * nl;
+        SelRec* out = h->h_sel.p + (size_t)img * sel_stride;
+        std::vector<int> kept;
+        int n = 0;
+        // pass 1: quadtree per level, records in level-major / quadtree order
+        for (int l = 0; l < nl; l++) {
+            const LevelGeom& lg = g.lv[l];
+            distribute_quadtree(c, lc[l], lg.min_x, lg.max_x, lg.min_y, lg.max_y, lg.quota, kept);
+            for (int k : kept) {
+                if (n >= sel_stride || n >= capacity) { overflow.store(1); break; }
+                SelRec r;
+                r.x = (uint16_t)(c[k].x + kMinBorder);
+                r.y = (uint16_t)(c[k].y + kMinBorder);
+                r.score = c[k].score;
+                r.level = (uint8_t)l;
+                r.pad = 0;
+                r.dst = 0;
+                out[n++] = r;
+            }
+            c += lc[l];
+        }
+        // pass 2: output rows (ORBextractor.cc:1122-1163): inside [lap0,lap1] from the back, else from the front
+        int mono = 0, stereo = n - 1;
+        for (int i = 0; i < n; i++) {
+            SelRec& r = out[i];
+            const float fx = r.level ? (float)r.x * h->P.scale[r.level] : (float)r.x;
+            if (fx >= (float)lap0 && fx <= (float)lap1) r.dst = stereo--;
+            else r.dst = mono++;
+        }
+        h->h_sel_count.p[img] = n;
+        h_counts[img] = n;
+        if (h_mono) h_mono[img] = mono;
+    };
+    h->pool->parallel_for(n_images, task);
+    if (overflow.load()) { set_error("keypoint capacity exceeded"); return MSORB_E_CAPACITY; }
+    int max_sel = 0;
+    for (int i = 0; i < n_images; i++) max_sel = std::max(max_sel, h->h_sel_count.p[i]);
+
+    HIPCHK(hipMemcpyAsync(h->d_sel.p, h->h_sel.p, (size_t)n_images * sel_stride * sizeof(SelRec), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->d_sel_count.p, h->h_sel_count.p, (size_t)n_images * sizeof(int), hipMemcpyHostToDevice, s));
+    const auto t1 = std::chrono::steady_clock::now();
+    mark(5);
+    launch_describe(pyr, blur, h->d_sel.p, h->d_sel_count.p, sel_stride, h->scales, d_kps, d_desc, capacity, max_sel,
+                    n_images, s);
+    mark(6);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    if (prof) {
+        float ms = 0;
+        const int map[5][3] = {{MSORB_STAGE_PYRAMID, 0, 1}, {MSORB_STAGE_FAST, 1, 2}, {MSORB_STAGE_COMPACT, 2, 3},
+                               {MSORB_STAGE_BLUR, 3, 4}, {MSORB_STAGE_DESCRIBE, 5, 6}};
+        for (auto& m : map) {
+            HIPCHK(hipEventElapsedTime(&ms, h->pe[m[1]], h->pe[m[2]]));
+            h->stage_ms[m[0]] = ms;
+        }
+        h->stage_ms[MSORB_STAGE_SELECT] = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    }
+    return MSORB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* msorb_last_error(void) { return g_last_error.c_str(); }
+
+int msorb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int msorb_extractor_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, int device,
+                           msorb_extractor** out) {
+    if (!out) return MSORB_E_INVALID;
+    *out = nullptr;
+    if (nfeatures <= 0 || nlevels < 1 || nlevels > MSORB_MAX_LEVELS || !(scale_factor > 1.0f) || ini_th < 0 ||
+        min_th < 0 || ini_th > 255 || min_th > ini_th) {
+        set_error("invalid extractor parameters");
+        return MSORB_E_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        set_error("no usable HIP device (libmsorb has no CPU fallback)");
+        return MSORB_E_NO_DEVICE;
+    }
+    HIPCHK(hipSetDevice(device));
+    msorb_extractor* h = new msorb_extractor();
+    h->device = device;
+    h->P.init(nfeatures, scale_factor, nlevels, ini_th, min_th);
+    for (int l = 0; l < nlevels; l++) {
+        h->scales.scale[l] = h->P.scale[l];
+        h->scales.patch[l] = (float)(int)(kPatchSize * h->P.scale[l]);
+    }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_compact, hipEventDisableTiming) != hipSuccess) {
+        set_error("stream/event creation failed");
+        delete h;
+        return MSORB_E_HIP;
+    }
+    for (auto& e : h->pe)
+        if (hipEventCreate(&e) != hipSuccess) { delete h; return MSORB_E_HIP; }
+    upload_patch_tables(kPattern, h->P.umax, h->stream);
+    int nthreads = (int)std::thread::hardware_concurrency();
+    if (const char* e = getenv("MSORB_HOST_THREADS")) nthreads = atoi(e);
+    nthreads = std::max(1, std::min(nthreads, 64));
+    h->pool.reset(new Pool(nthreads));
+    *out = h;
+    return MSORB_OK;
+}
+
+void msorb_extractor_destroy(msorb_extractor* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->pool.reset();
+    h->d_pyr.release(); h->d_blur.release(); h->d_desc1.release(); h->d_taps.release(); h->d_cells.release();
+    h->d_level_cell_begin.release(); h->d_cell_count.release(); h->d_cell_off.release(); h->d_level_count.release();
+    h->d_img_total.release(); h->d_img_base.release(); h->d_sel_count.release(); h->d_slots.release();
+    h->d_compact.release(); h->d_sel.release(); h->d_kps1.release();
+    h->h_level_count.release(); h->h_img_base.release(); h->h_sel_count.release(); h->h_compact.release();
+    h->h_sel.release(); h->h_pyr.release();
+    for (auto& e : h->pe) if (e) (void)hipEventDestroy(e);
+    if (h->ev_compact) (void)hipEventDestroy(h->ev_compact);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    delete h;
+}
+
+int msorb_extractor_tables(const msorb_extractor* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                           int* per_level) {
+    if (!h) return MSORB_E_INVALID;
+    for (int l = 0; l < h->P.nlevels; l++) {
+        if (scale) scale[l] = h->P.scale[l];
+        if (inv_scale) inv_scale[l] = h->P.inv_scale[l];
+        if (sigma2) sigma2[l] = h->P.sigma2[l];
+        if (inv_sigma2) inv_sigma2[l] = h->P.inv_sigma2[l];
+        if (per_level) per_level[l] = h->P.per_level[l];
+    }
+    return MSORB_OK;
+}
+
+int msorb_extractor_capacity(const msorb_extractor* h) { return h ? capacity_of(h) : MSORB_E_INVALID; }
+
+int msorb_extractor_set_profiling(msorb_extractor* h, int enable) {
+    if (!h) return MSORB_E_INVALID;
+    h->profiling = enable != 0;
+    return MSORB_OK;
+}
+int msorb_extractor_stage_ms(const msorb_extractor* h, float* ms) {
+    if (!h || !ms) return MSORB_E_INVALID;
+    for (int i = 0; i < MSORB_N_STAGES; i++) ms[i] = h->stage_ms[i];
+    return MSORB_OK;
+}
+
+int msorb_extract_batch(msorb_extractor* h, const uint8_t* d_images, int n_images, int rows, int cols,
+                        size_t row_stride, size_t image_stride, int lap0, int lap1, msorb_keypoint* d_kps,
+                        uint8_t* d_desc, int capacity, int* h_counts, int* h_mono) {
+    if (!h || !d_kps || !d_desc || !h_counts || n_images < 0) { set_error("null argument"); return MSORB_E_INVALID; }
+    if (!d_images || rows <= 0 || cols <= 0) return MSORB_E_EMPTY;
+    if (n_images == 0) return MSORB_OK;
+    if ((int)row_stride < cols || (n_images > 1 && image_stride < row_stride * (size_t)rows)) {
+        set_error("bad strides");
+        return MSORB_E_INVALID;
+    }
+    HIPCHK(hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure_geometry(h, rows, cols))) return rc;
+    if ((rc = ensure_batch(h, n_images))) return rc;
+    LevelView l0{d_images, image_stride, (int)row_stride, cols, rows};
+    return run_pipeline(h, l0, n_images, lap0, lap1, d_kps, d_desc, capacity, h_counts, h_mono);
+}
+
+int msorb_extract(msorb_extractor* h, const uint8_t* image, int rows, int cols, size_t stride, int lap0, int lap1,
+                  msorb_keypoint* keypoints, uint8_t* descriptors, int capacity, int* n_keypoints, int* mono_index) {
+    if (!h || !n_keypoints || !mono_index) return MSORB_E_INVALID;
+    *n_keypoints = 0;
+    *mono_index = -1;
+    if (!image || rows <= 0 || cols <= 0) return MSORB_E_EMPTY;  // ORBextractor.cc:1090-1091
+    if (!keypoints || !descriptors || (int)stride < cols) return MSORB_E_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure_geometry(h, rows, cols))) return rc;
+    if ((rc = ensure_batch(h, 1))) return rc;
+    const int cap = capacity_of(h);
+    if ((rc = h->d_kps1.ensure(cap))) return rc;
+    if ((rc = h->d_desc1.ensure((size_t)cap * 32))) return rc;
+    const LevelGeom& g0 = h->G.lv[0];
+    // level 0 = copy of the caller's image (ORBextractor.cc:1190: the input is never modified or aliased)
+    HIPCHK(hipMemcpy2DAsync(h->d_pyr.p + g0.plane_off, g0.pitch, image, stride, cols, rows, hipMemcpyHostToDevice,
+                            h->stream));
+    LevelView l0{h->d_pyr.p + g0.plane_off, h->G.pyramid_bytes, g0.pitch, cols, rows};
+    int n = 0, mono = 0;
+    if ((rc = run_pipeline(h, l0, 1, lap0, lap1, h->d_kps1.p, h->d_desc1.p, cap, &n, &mono))) return rc;
+    if (n > capacity) { set_error("caller capacity too small"); return MSORB_E_CAPACITY; }
+    if (n > 0) {
+        HIPCHK(hipMemcpy(keypoints, h->d_kps1.p, (size_t)n * sizeof(msorb_keypoint), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(descriptors, h->d_desc1.p, (size_t)n * 32, hipMemcpyDeviceToHost));
+    }
+    *n_keypoints = n;
+    *mono_index = mono;
+    return MSORB_OK;
+}
+
+int msorb_pyramid_level(msorb_extractor* h, int level, const uint8_t** data, int* rows, int* cols, size_t* stride) {
+    if (!h || !data || !h->geom_valid || h->last_n_images < 1 || level < 0 || level >= h->G.nlevels)
+        return MSORB_E_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    const FrameGeom& g = h->G;
+    if (!h->h_pyr_valid) {
+        int rc;
+        if ((rc = h->h_pyr.ensure(g.pyramid_bytes))) return rc;
+        for (int l = 0; l < g.nlevels; l++) {
+            const LevelView& v = h->last_pyr.lv[l];
+            HIPCHK(hipMemcpy2D(h->h_pyr.p + g.lv[l].plane_off, g.lv[l].pitch, v.base, v.pitch, v.w, v.h,
+                               hipMemcpyDeviceToHost));
+        }
+        h->h_pyr_valid = true;
+    }
+    *data = h->h_pyr.p + g.lv[level].plane_off;
+    if (rows) *rows = g.lv[level].h;
+    if (cols) *cols = g.lv[level].w;
+    if (stride) *stride = g.lv[level].pitch;
+    return MSORB_OK;
+}
+
+int msorb_debug_level_size(const msorb_extractor* h, int level, int* rows, int* cols) {
+    if (!h || !h->geom_valid || level < 0 || level >= h->G.nlevels) return MSORB_E_INVALID;
+    *rows = h->G.lv[level].h;
+    *cols = h->G.lv[level].w;
+    return MSORB_OK;
+}
+
+int msorb_debug_copy_level(msorb_extractor* h, int image, int level, int blurred, uint8_t* dst) {
+    if (!h || !dst || !h->geom_valid || image < 0 || image >= h->last_n_images || level < 0 || level >= h->G.nlevels)
+        return MSORB_E_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    const LevelView& v = blurred ? h->last_blur.lv[level] : h->last_pyr.lv[level];
+    HIPCHK(hipMemcpy2D(dst, v.w, v.base + (size_t)image * v.img_stride, v.pitch, v.w, v.h, hipMemcpyDeviceToHost));
+    return MSORB_OK;
+}
+
+int msorb_debug_candidates(msorb_extractor* h, int image, int level, int* xyscore, int capacity, int* n) {
+    if (!h || !n || !h->geom_valid || image < 0 || image >= h->last_n_images || level < 0 || level >= h->G.nlevels)
+        return MSORB_E_INVALID;
+    const int nl = h->G.nlevels;
+    const int* lc = h->h_level_count.p + (size_t)image * nl;
+    const Cand16* c = h->h_compact.p + h->h_img_base.p[image];
+    for (int l = 0; l < level; l++) c += lc[l];
+    *n = lc[level];
+    for (int i = 0; i < lc[level] && i < capacity; i++) {
+        xyscore[3 * i] = c[i].x; xyscore[3 * i + 1] = c[i].y; xyscore[3 * i + 2] = c[i].score;
+    }
+    return MSORB_OK;
+}
+
+int msorb_distribute_quadtree(const uint16_t* xs, const uint16_t* ys, const uint16_t* scores, int n, int min_x,
+                              int max_x, int min_y, int max_y, int n_features, int* kept_idx, int capacity,
+                              int* n_kept) {
+    if (!n_kept || n < 0 || (n > 0 && (!xs || !ys || !scores)) || max_x <= min_x || max_y <= min_y ||
+        (int)std::round(static_cast<float>(max_x - min_x) / (max_y - min_y)) < 1)
+        return MSORB_E_INVALID;
+    std::vector<Cand16> c(n);
+    for (int i = 0; i < n; i++) c[i] = Cand16{xs[i], ys[i], scores[i], 0};
+    std::vector<int> kept;
+    distribute_quadtree(c.data(), n, min_x, max_x, min_y, max_y, n_features, kept);
+    *n_kept = (int)kept.size();
+    if ((int)kept.size() > capacity) return MSORB_E_CAPACITY;
+    for (size_t i = 0; i < kept.size(); i++) kept_idx[i] = kept[i];
+    return MSORB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// Structures shared by the host orchestration (extractor.hip) and the kernels (orb_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/msorb.h"
+#include "orb_host.h"
+
+namespace msorb {
+
+struct LevelView {  // one pyramid level of a batch: image i's plane at base + i*img_stride
+    const uint8_t* base;
+    size_t img_stride;
+    int pitch, w, h;
+};
+struct PyramidView {
+    LevelView lv[kMaxLevels];
+    int nlevels;
+};
+struct LevelScale {
+    float scale[kMaxLevels];  // mvScaleFactor
+    float patch[kMaxLevels];  // (float)(int)(31*scale), ORBextractor.cc:880,889
+};
+struct SelRec {  // one keypoint kept by the quadtree, level coordinates (border added back)
+    uint16_t x, y, score;
+    uint8_t level, pad;
+    int32_t dst;  // output row (mono from the front / stereo from the back, ORBextractor.cc:1153-1162)
+};
+
+void upload_patch_tables(const int8_t* pattern, const int* umax, hipStream_t stream);
+void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_base, const ResizeTap* tx,
+                       const ResizeTap* ty, int n_images, hipStream_t s);
+void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cells, int ini_th, int min_th,
+                       int slots_per_image, Cand16* slots, int* cell_count, int n_images, hipStream_t s);
+void launch_cand_compact(const CellDesc* cells, int n_cells, const int* level_cell_begin, int nlevels,
+                         int slots_per_image, const Cand16* slots, const int* cell_count, int* cell_off,
+                         int* level_count, int* img_total, int* img_base, Cand16* compact, int n_images,
+                         hipStream_t s);
+void launch_gauss7(const LevelView& src, const LevelView& dst, uint8_t* dst_base, int n_images, hipStream_t s);
+void launch_describe(const PyramidView& pyr, const PyramidView& blur, const SelRec* sel, const int* sel_count,
+                     int sel_stride, const LevelScale& scales, msorb_keypoint* kps, uint8_t* desc, int out_stride,
+                     int max_sel, int n_images, hipStream_t s);
+
+}  // namespace msorb

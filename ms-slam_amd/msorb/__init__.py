@@ -1,0 +1,219 @@
+"""Python (ctypes) binding of libmsorb.so — the C ABI in include/msorb.h.
+
+Used by tests/ and bench.py.  PyTorch is only plumbing here (device buffers, streams, torch.distributed);
+every computation happens in the hand-written HIP kernels behind the C ABI.  There is no CPU fallback:
+if the library or a GPU is missing, the calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "libmsorb.so")
+_LIB = None
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+STAGES = ("pyramid", "fast", "compact", "blur", "select", "describe")
+
+OK, E_INVALID, E_NO_DEVICE, E_HIP, E_CAPACITY, E_GEOMETRY, E_EMPTY = 0, -1, -2, -3, -4, -5, -6
+
+# every symbol include/msorb.h declares (tests check the library exports them all)
+EXPORTS = (
+    "msorb_last_error", "msorb_device_count", "msorb_extractor_create", "msorb_extractor_destroy",
+    "msorb_extractor_tables", "msorb_extractor_capacity", "msorb_extract", "msorb_pyramid_level",
+    "msorb_extract_batch", "msorb_extractor_set_profiling", "msorb_extractor_stage_ms", "msorb_debug_level_size",
+    "msorb_debug_copy_level", "msorb_debug_candidates", "msorb_distribute_quadtree",
+)
+
+
+class MsorbError(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__(f"{what}: error {code}: {lib().msorb_last_error().decode()}")
+        self.code = code
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_PKG, "csrc")])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc) first; "
+                               "msorb has no CPU fallback")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7; if torch is going to be
+        # used in this process (device buffers, torch.distributed) it must be loaded BEFORE libmsorb.so so that
+        # libmsorb's NEEDED libamdhip64.so.7 resolves to the already-loaded copy instead of /opt/rocm's.
+        if not os.environ.get("MSORB_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
+        L = C.CDLL(LIB_PATH)
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        L.msorb_last_error.restype = C.c_char_p
+        L.msorb_extractor_create.argtypes = [ci, cf, ci, ci, ci, ci, C.POINTER(vp)]
+        L.msorb_extractor_destroy.argtypes = [vp]
+        L.msorb_extractor_destroy.restype = None
+        L.msorb_extractor_tables.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.msorb_extractor_capacity.argtypes = [vp]
+        L.msorb_extract.argtypes = [vp, vp, ci, ci, C.c_size_t, ci, ci, vp, vp, ci, C.POINTER(ci), C.POINTER(ci)]
+        L.msorb_pyramid_level.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci), C.POINTER(C.c_size_t)]
+        L.msorb_extract_batch.argtypes = [vp, vp, ci, ci, ci, C.c_size_t, C.c_size_t, ci, ci, vp, vp, ci, vp, vp]
+        L.msorb_extractor_set_profiling.argtypes = [vp, ci]
+        L.msorb_extractor_stage_ms.argtypes = [vp, vp]
+        L.msorb_debug_level_size.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
+        L.msorb_debug_copy_level.argtypes = [vp, ci, ci, ci, vp]
+        L.msorb_debug_candidates.argtypes = [vp, ci, ci, vp, ci, C.POINTER(ci)]
+        L.msorb_distribute_quadtree.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, ci, C.POINTER(ci)]
+        _LIB = L
+    return _LIB
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _check(rc, what):
+    if rc != OK:
+        raise MsorbError(rc, what)
+
+
+class ORBextractor:
+    """Mirror of ORB_SLAM3::ORBextractor (reference include/ORBextractor.h:43-109): same constructor
+    arguments, `__call__` = operator(), getters with the reference's names."""
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device=0):
+        self.L = lib()
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+        h = C.c_void_p()
+        _check(self.L.msorb_extractor_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device,
+                                             C.byref(h)), "msorb_extractor_create")
+        self.h = h
+        self.capacity = self.L.msorb_extractor_capacity(self.h)
+        self._tables = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.msorb_extractor_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    # --- getters (ORBextractor.h:61-81) ---
+    def _tab(self):
+        if self._tables is None:
+            n = self.nlevels
+            sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+            per = np.zeros(n, np.int32)
+            _check(self.L.msorb_extractor_tables(self.h, _np_ptr(sc), _np_ptr(isc), _np_ptr(s2), _np_ptr(is2),
+                                                 _np_ptr(per)), "msorb_extractor_tables")
+            self._tables = dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2, per_level=per)
+        return self._tables
+
+    def GetLevels(self):
+        return self.nlevels
+
+    def GetScaleFactors(self):
+        return self._tab()["scale"]
+
+    def GetInverseScaleFactors(self):
+        return self._tab()["inv_scale"]
+
+    def GetScaleSigmaSquares(self):
+        return self._tab()["sigma2"]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._tab()["inv_sigma2"]
+
+    def features_per_level(self):
+        return self._tab()["per_level"]
+
+    # --- operator() on one host image (ORBextractor.cc:1086-1168) ---
+    def __call__(self, image, lapping=(0, 0)):
+        """-> (monoIndex, keypoints[KP_DTYPE], descriptors[n,32] u8); monoIndex == -1 for an empty image."""
+        image = np.ascontiguousarray(image, np.uint8)
+        rows, cols = image.shape if image.ndim == 2 and image.size else (0, 0)
+        kps = np.zeros(self.capacity, KP_DTYPE)
+        desc = np.zeros((self.capacity, 32), np.uint8)
+        n, mono = C.c_int(0), C.c_int(0)
+        rc = self.L.msorb_extract(self.h, _np_ptr(image) if image.size else None, rows, cols, cols, lapping[0],
+                                  lapping[1], _np_ptr(kps), _np_ptr(desc), self.capacity, C.byref(n), C.byref(mono))
+        if rc == E_EMPTY:
+            return -1, kps[:0], desc[:0]
+        _check(rc, "msorb_extract")
+        return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def pyramid_level(self, level):
+        """mvImagePyramid[level] of the last __call__ as a numpy array (copy)."""
+        p, r, c, s = C.c_void_p(), C.c_int(), C.c_int(), C.c_size_t()
+        _check(self.L.msorb_pyramid_level(self.h, level, C.byref(p), C.byref(r), C.byref(c), C.byref(s)),
+               "msorb_pyramid_level")
+        buf = (C.c_uint8 * (s.value * r.value)).from_address(p.value)
+        return np.frombuffer(buf, np.uint8).reshape(r.value, s.value)[:, :c.value].copy()
+
+    # --- batched operator() on device-resident images ---
+    def extract_batch(self, images, lapping=(0, 0), out=None):
+        """images: torch.uint8 CUDA tensor [n, rows, cols] (contiguous rows).  Returns
+        (counts[n] np.int32, mono[n] np.int32, d_keypoints torch.uint8 [n, cap, 28], d_desc torch.uint8 [n, cap, 32]).
+        Outputs stay on the device."""
+        import torch
+        assert images.is_cuda and images.dtype == torch.uint8 and images.dim() == 3 and images.stride(2) == 1
+        n, rows, cols = images.shape
+        if out is None:
+            d_kps = torch.empty((n, self.capacity, 28), dtype=torch.uint8, device=images.device)
+            d_desc = torch.empty((n, self.capacity, 32), dtype=torch.uint8, device=images.device)
+        else:
+            d_kps, d_desc = out
+        counts = np.zeros(n, np.int32)
+        mono = np.zeros(n, np.int32)
+        _check(self.L.msorb_extract_batch(self.h, images.data_ptr(), n, rows, cols, images.stride(1), images.stride(0),
+                                          lapping[0], lapping[1], d_kps.data_ptr(), d_desc.data_ptr(), self.capacity,
+                                          _np_ptr(counts), _np_ptr(mono)), "msorb_extract_batch")
+        return counts, mono, d_kps, d_desc
+
+    def set_profiling(self, on=True):
+        _check(self.L.msorb_extractor_set_profiling(self.h, int(on)), "set_profiling")
+
+    def stage_ms(self):
+        ms = np.zeros(len(STAGES), np.float32)
+        _check(self.L.msorb_extractor_stage_ms(self.h, _np_ptr(ms)), "stage_ms")
+        return dict(zip(STAGES, ms.tolist()))
+
+    # --- inspection hooks ---
+    def debug_level(self, image, level, blurred=False):
+        r, c = C.c_int(), C.c_int()
+        _check(self.L.msorb_debug_level_size(self.h, level, C.byref(r), C.byref(c)), "debug_level_size")
+        out = np.zeros((r.value, c.value), np.uint8)
+        _check(self.L.msorb_debug_copy_level(self.h, image, level, int(blurred), _np_ptr(out)), "debug_copy_level")
+        return out
+
+    def debug_candidates(self, image, level):
+        cap = 1 << 18
+        buf = np.zeros((cap, 3), np.int32)
+        n = C.c_int()
+        _check(self.L.msorb_debug_candidates(self.h, image, level, _np_ptr(buf), cap, C.byref(n)), "debug_candidates")
+        return buf[:n.value].copy()
+
+
+def keypoints_from_device(d_kps, counts):
+    """torch uint8 [n, cap, 28] -> list of numpy KP_DTYPE arrays."""
+    host = d_kps.cpu().numpy()
+    return [host[i, :counts[i]].copy().view(KP_DTYPE).reshape(-1) for i in range(len(counts))]
+
+
+def distribute_quadtree(xs, ys, scores, min_x, max_x, min_y, max_y, n_features):
+    """Host-only DistributeOctTree (ORBextractor.cc:555-779); returns kept candidate indices in result order."""
+    xs, ys, scores = (np.ascontiguousarray(v, np.uint16) for v in (xs, ys, scores))
+    n = len(xs)
+    kept = np.zeros(n + 8, np.int32)
+    nk = C.c_int()
+    _check(lib().msorb_distribute_quadtree(_np_ptr(xs), _np_ptr(ys), _np_ptr(scores), n, min_x, max_x, min_y, max_y,
+                                           n_features, _np_ptr(kept), len(kept), C.byref(nk)), "distribute_quadtree")
+    return kept[:nk.value].copy()

@@ -1,0 +1,73 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol include/msorb.h declares, the host
+logic (parameter tables, geometry, quadtree) agrees with the oracle, and there is no CPU fallback."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from msorb import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(msorb_mod):
+    hdr = open(os.path.join(ROOT, "include", "msorb.h")).read()
+    declared = sorted(set(re.findall(r"\b(msorb_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 15
+    lib = C.CDLL(msorb_mod.LIB_PATH)
+    for sym in declared:
+        assert hasattr(lib, sym), f"libmsorb.so does not export {sym}"
+    assert set(declared) == set(msorb_mod.EXPORTS), set(declared) ^ set(msorb_mod.EXPORTS)
+
+
+def test_no_cpu_fallback_without_gpu(msorb_mod):
+    if msorb_mod.lib().msorb_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(msorb_mod.MsorbError) as e:
+        msorb_mod.ORBextractor(1000, 1.2, 8, 20, 7)
+    assert e.value.code == msorb_mod.E_NO_DEVICE
+
+
+def test_invalid_parameters_rejected(msorb_mod):
+    for args in ((0, 1.2, 8, 20, 7), (1000, 1.0, 8, 20, 7), (1000, 1.2, 0, 20, 7), (1000, 1.2, 17, 20, 7),
+                 (1000, 1.2, 8, 7, 20)):
+        with pytest.raises(msorb_mod.MsorbError) as e:
+            msorb_mod.ORBextractor(*args)
+        assert e.value.code == msorb_mod.E_INVALID
+
+
+@pytest.mark.parametrize("seed,rows,cols,nfeat", [(0, 376, 1241, 2000), (1, 480, 752, 1000), (2, 400, 800, 2000),
+                                                  (3, 240, 320, 500), (4, 320, 240, 500), (5, 376, 1241, 300)])
+def test_host_quadtree_matches_oracle(msorb_mod, oracle, seed, rows, cols, nfeat):
+    """Product host quadtree (orb_host.cc, index pool) vs oracle (std::list restatement of
+    ORBextractor.cc:555-779) on real FAST candidates: same keypoints in the same order."""
+    img = synth.image(seed, rows, cols)
+    ex = oracle.OracleExtractor(nfeat, 1.2, 8, 20, 7)
+    ex(img)
+    quota = ex.tables()["per_level"]
+    for l in range(8):
+        c, sel = ex.candidates(l), ex.selected(l)
+        h, w = ex.level(l).shape
+        kept = msorb_mod.distribute_quadtree(c[:, 0], c[:, 1], c[:, 2], 16, w - 16, 16, h - 16, int(quota[l]))
+        want = np.stack([sel["x"] - 16, sel["y"] - 16, sel["response"]], 1).astype(np.int32)
+        assert np.array_equal(c[kept], want), f"level {l}"
+        assert len(kept) <= quota[l] + 3
+
+
+def test_host_quadtree_degenerate_inputs(msorb_mod, oracle):
+    rng = np.random.Generator(np.random.PCG64(11))
+    cases = []
+    # all candidates on one pixel, ties everywhere, a single candidate, dense grid
+    cases.append((np.full(50, 100), np.full(50, 40), np.full(50, 30)))
+    cases.append((np.array([5]), np.array([7]), np.array([20])))
+    gx, gy = np.meshgrid(np.arange(0, 600, 2), np.arange(0, 150, 2))
+    cases.append((gx.ravel(), gy.ravel(), np.full(gx.size, 25)))
+    cases.append((rng.integers(0, 1200, 5000), rng.integers(0, 340, 5000), rng.integers(7, 120, 5000)))
+    for xs, ys, sc in cases:
+        for N in (1, 5, 60, 434):
+            kept = msorb_mod.distribute_quadtree(xs, ys, sc, 16, 1225, 16, 360, N)
+            ref = oracle.distribute_quadtree(xs, ys, sc, 16, 1225, 16, 360, N)
+            got = np.stack([xs[kept], ys[kept], sc[kept]], 1).astype(np.float32)
+            assert np.array_equal(got, ref)
