@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — ORB front-end throughput on MI355X (BASELINE.json metric, configs[1] workload).
+
+A "step" = one pass of the hot path (ORBextractor::operator(): pyramid -> FAST+NMS -> quadtree -> blur ->
+IC-angle -> rBRIEF) over one batch of synthetic KITTI-00-like stereo pairs (1241x376, 2000 features/frame),
+inputs already resident in HBM.  value = keypoints returned per second, whole job.
+
+  python bench.py --gpus N --steps K --warmup W [--pairs B]
+
+N=1: both eyes of every pair on the one GPU.  N>1 (launched by torch.distributed.run, one rank per GPU):
+stereo left/right split — even ranks extract the left eyes, odd ranks the right eyes of their pair group,
+then the odd rank sends counts/keypoints/descriptors to its even partner over RCCL (xGMI point-to-point);
+per-GPU work is fixed (weak scaling).
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed) and `cpu_baseline`
+(the CPU oracle timed on a bounded sample of the same workload on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(ROOT, "ms-slam_amd")]
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def level_bytes(cfg):
+    """Algorithmic bytes per image: sum of level pixels etc."""
+    import math
+    sc = np.float32(1.0)
+    px = []
+    for l in range(cfg["nlevels"]):
+        inv = np.float32(1.0) / sc
+        w = int(np.rint(np.float32(cfg["cols"]) * inv))
+        h = int(np.rint(np.float32(cfg["rows"]) * inv))
+        px.append(w * h)
+        sc = np.float32(np.float64(sc) * np.float64(np.float32(cfg["scale"])))
+    return px
+
+
+def cpu_baseline(cfg, sample_pairs, seed0):
+    """Oracle (CPU restatement, kind=port) on `sample_pairs` stereo pairs, 2 threads = one per eye like
+    the reference (Frame.cc:122-125)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orb_oracle
+    from msorb import synth
+    exs = [orb_oracle.OracleExtractor(cfg["nfeatures"], cfg["scale"], cfg["nlevels"], cfg["ini_th"], cfg["min_th"])
+           for _ in range(2)]
+    pairs = [synth.stereo_pair(seed0 + i, cfg["rows"], cfg["cols"]) for i in range(sample_pairs)]
+    counts = [0, 0]
+
+    def eye(e):
+        for p in pairs:
+            _, kps, _ = exs[e](p[e])
+            counts[e] += len(kps)
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=eye, args=(e,)) for e in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    return dict(value=round(sum(counts) / dt / 1e6, 5), unit="Mkeypoints/s", cores=2, kind="port",
+                sample=f"{sample_pairs} KITTI-like stereo pairs, oracle/ (scalar C++ restatement, not OpenCV SIMD), "
+                       f"2 threads (one per eye), {dt:.1f} s",
+                host_cpus=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU-pair group")
+    ap.add_argument("--cpu-pairs", type=int, default=24, help="stereo pairs in the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import msorb
+    from msorb import synth
+
+    cfg = synth.KITTI
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    B = args.pairs
+    # images of this rank: N=1 -> L,R interleaved (2B images); N>1 -> one eye of 2B pairs (2B images): fixed per-GPU work
+    group, eye = (rank // 2, rank % 2) if world > 1 else (0, None)
+    uniq = min(B, 8)  # distinct synthetic pairs, tiled to the batch size (content repeats, bytes do not alias)
+    base = synth.stereo_batch(uniq, cfg["rows"], cfg["cols"], seed0=1000 * group)
+    if world == 1:
+        host = np.concatenate([base] * (B // uniq + 1))[:2 * B]
+    else:
+        one_eye = base[eye::2]
+        host = np.concatenate([one_eye] * (2 * B // uniq + 1))[:2 * B]
+    images = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
+    n_img = images.shape[0]
+
+    ex = msorb.ORBextractor(cfg["nfeatures"], cfg["scale"], cfg["nlevels"], cfg["ini_th"], cfg["min_th"], device=local)
+    cap = ex.capacity
+    d_kps = torch.empty((n_img, cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.empty((n_img, cap, 32), dtype=torch.uint8, device=dev)
+    d_cnt = torch.empty(n_img, dtype=torch.int32, device=dev)
+    if world > 1 and eye == 0:
+        r_kps, r_desc, r_cnt = torch.empty_like(d_kps), torch.empty_like(d_desc), torch.empty_like(d_cnt)
+
+    def step():
+        counts, mono, _, _ = ex.extract_batch(images, (0, 0), out=(d_kps, d_desc))
+        if world > 1:  # stereo split: right-eye rank -> left-eye rank (replaces the join of Frame.cc:122-125)
+            d_cnt.copy_(torch.from_numpy(counts))
+            partner = rank ^ 1
+            if partner < world:
+                if eye == 1:
+                    dist.send(d_cnt, partner); dist.send(d_kps, partner); dist.send(d_desc, partner)
+                else:
+                    dist.recv(r_cnt, partner); dist.recv(r_kps, partner); dist.recv(r_desc, partner)
+        return int(counts.sum())
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ex.set_profiling(True)
+    stage_acc = {k: 0.0 for k in msorb.STAGES}
+    fence()
+    t0 = time.perf_counter()
+    kp_total = 0
+    for _ in range(args.steps):
+        kp_total += step()
+        for k, v in ex.stage_ms().items():
+            stage_acc[k] += v
+    fence()
+    dt = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([dt, float(kp_total)], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, kp_total = float(tmax[0]), int(t[1])
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        stages = {k: v / steps for k, v in stage_acc.items()}
+        px = level_bytes(cfg)
+        # dominant GPU kernel: FAST cells (one launch per step).  Algorithmic bytes per launch:
+        # every level pixel read once + 8 B per emitted candidate (not counted: unknown a priori) per image.
+        gpu_stages = {k: stages[k] for k in ("pyramid", "fast", "blur", "describe", "compact")}
+        dom = max(gpu_stages, key=gpu_stages.get)
+        alg_per_image = {
+            "fast": sum(px),                                 # read every level once
+            "pyramid": sum(px[:-1]) + sum(px[1:]),           # read L0..L6, write L1..L7 (L0 consumed in place)
+            "blur": 2 * sum(px),                             # read + write every level
+            "describe": cfg["nfeatures"] * (749 + 512 + 32 + 28),
+            "compact": 0,
+        }[dom]
+        alg_bytes = alg_per_image * n_img
+        achieved = alg_bytes / (stages[dom] * 1e-3) / 1e9 if stages[dom] > 0 else 0.0
+        pf_bytes = (alg_per_image if dom in ("fast", "pyramid") else 0)
+        out = {
+            "metric": "Mkeypoints/s extract+describe, KITTI-00-like stereo 1241x376, 2000 feat/frame",
+            "value": round(kp_total / dt / 1e6, 4),
+            "unit": "Mkeypoints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: KITTI-00 stereo 1241x376, 2000 feat/frame, pyramid+FAST+rBRIEF",
+                       "pairs_per_step_per_gpu": B if world == 1 else B, "images_per_step_per_gpu": n_img,
+                       "parallelism": "1 GPU, both eyes" if world == 1 else f"stereo L/R split over {world} GPUs, RCCL send/recv"},
+            "stage_ms_per_step": {k: round(v, 4) for k, v in stages.items()},
+            "roofline": {"bound": "hbm", "kernel": {"fast": "fast_cells_kernel", "pyramid": "pyr_resize_kernel (x7)",
+                                                    "blur": "gauss7_kernel (x8)", "describe": "describe_kernel",
+                                                    "compact": "cand_*"}[dom],
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+            "pyramid_fast_gbs": round((sum(px[:-1]) + sum(px[1:]) + sum(px)) * n_img /
+                                      ((stages["pyramid"] + stages["fast"]) * 1e-3) / 1e9, 2),
+        }
+        if world == 1 and args.cpu_pairs > 0:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_pairs, 5000)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    ex.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
