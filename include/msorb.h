@@ -107,6 +107,74 @@ int msorb_distribute_quadtree(const uint16_t* xs, const uint16_t* ys, const uint
                               int max_x, int min_y, int max_y, int n_features, int* kept_idx, int capacity,
                               int* n_kept);
 
+/* ------------------------------------------------------------------------------------------------
+ * Matcher — the data-parallel core of ORB_SLAM3::ORBmatcher (include/ORBmatcher.h:36-112,
+ * src/ORBmatcher.cc) and Frame::ComputeStereoMatches (src/Frame.cc:743-913) on flat arrays.
+ * The graph/mutex side of the reference (shared_ptr<MapPoint>, Observations(), pose projection with
+ * Sophus/Eigen) stays in the caller; these entries start from projected coordinates and descriptor
+ * arrays and return exactly the assignments the reference's loops would make (same candidate sets,
+ * same scan order, same tie-breaks, same sequential side effects).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct msorb_frame msorb_frame;
+
+/* A frame's features on the device plus its 64x48 feature grid.  One handle per thread of use. */
+int msorb_frame_create(int device, msorb_frame** out);
+void msorb_frame_destroy(msorb_frame* f);
+
+/* Frame members the matcher reads: mvKeysUn, mDescriptors, mvuRight (NULL = all -1), image bounds
+ * mnMinX..mnMaxY, mvScaleFactors.  Builds mGrid like Frame::AssignFeaturesToGrid (Frame.cc:385-416,
+ * PosInGrid :657-667).  Host arrays. */
+int msorb_frame_set(msorb_frame* f, const msorb_keypoint* keypoints, int n, const uint8_t* descriptors,
+                    const float* u_right, float min_x, float max_x, float min_y, float max_y,
+                    const float* scale_factors, int nlevels);
+
+/* Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel) (Frame.cc:589-655): indices in the reference's
+ * order (cells ix outer / iy inner, insertion order inside a cell).  Host-side walk of the same grid
+ * the kernels use. */
+int msorb_frame_features_in_area(const msorb_frame* f, float x, float y, float r, int min_level, int max_level,
+                                 int* out_idx, int capacity, int* n);
+
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint>&, th, bFarPoints, thFarPoints)
+ * (ORBmatcher.cc:43-142, rectified branch).  Map-point table of m entries visited in index order:
+ *   track_in_view=mbTrackInView  bad=isBad()  sparsified=mbSparsified  proj_x/proj_y/proj_xr=mTrackProjX/Y/XR
+ *   track_depth=mTrackDepth  level=mnTrackScaleLevel  view_cos=mTrackViewCos  mp_desc=GetDescriptor() (m x 32)
+ *   obs=Observations().
+ * frame_mp[n]: F.mvpMapPoints as table indices (-1 = none), updated in place.  *nmatches = return value. */
+int msorb_search_by_projection_mps(msorb_frame* f, int m, const uint8_t* track_in_view, const uint8_t* bad,
+                                   const uint8_t* sparsified, const float* proj_x, const float* proj_y,
+                                   const float* proj_xr, const float* track_depth, const int* level,
+                                   const float* view_cos, const uint8_t* mp_desc, const int* obs, int* frame_mp,
+                                   float th, int far_points, float th_far_points, float nnratio, int* nmatches);
+
+/* ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, th, bMono) (ORBmatcher.cc:1941-2057,
+ * 2129-2152) from the projected coordinates on.  Per last-frame keypoint i: valid (map point present, not
+ * outlier, positive depth, inside the image), u,v (projection), ur (u - mbf/z), last_octave, last_angle,
+ * mp_desc (n_last x 32), last_mp (id stored into cur_mp), obs[id].  cur_mp[n] in/out. */
+int msorb_search_by_projection_frames(msorb_frame* cur, int n_last, const uint8_t* valid, const float* u,
+                                      const float* v, const float* ur, const int* last_octave,
+                                      const float* last_angle, const uint8_t* mp_desc, const int* last_mp,
+                                      const int* obs, int* cur_mp, float th, int forward, int backward,
+                                      int check_orientation, int* nmatches);
+
+/* Best / second-best Hamming match of each query over an explicit candidate list (CSR: candidates of
+ * query i are cand_idx[cand_begin[i] .. cand_begin[i+1])), scanned in list order with strict '<' — the
+ * inner loop of SearchByBoW / SearchForTriangulation / Fuse (e.g. ORBmatcher.cc:288-330).  Host arrays. */
+int msorb_hamming_top2(int device, const uint8_t* query_desc, int n_queries, const uint8_t* train_desc, int n_train,
+                       const int* cand_begin, const int* cand_idx, int* best_idx, int* best_dist, int* second_idx,
+                       int* second_dist);
+
+/* Frame::ComputeStereoMatches (Frame.cc:743-913).  left/right are the two extractor handles whose last
+ * msorb_extract() call produced the images' pyramids (mpORBextractorLeft/Right->mvImagePyramid stay on
+ * the device).  Keypoint/descriptor arrays are host arrays as returned by msorb_extract.  Writes
+ * mvuRight / mvDepth (n_left entries, -1 = none).  *n_oob counts keypoints whose SAD window would leave
+ * the pyramid plane (the reference would hit a CV_Assert there; they are skipped). */
+int msorb_stereo_matches(msorb_extractor* left, msorb_extractor* right, const msorb_keypoint* kps_left, int n_left,
+                         const uint8_t* desc_left, const msorb_keypoint* kps_right, int n_right,
+                         const uint8_t* desc_right, float mb, float mbf, float* u_right, float* depth, int* n_oob);
+
+/* ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:2277-2318) on histogram bin sizes; ind[3]. Host only. */
+int msorb_three_maxima(const int* bin_sizes, int n_bins, int* ind);
+
 #ifdef __cplusplus
 }
 #endif

@@ -382,6 +382,25 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
 
 }  // namespace
 
+namespace msorb {
+void set_last_error(const std::string& s) { g_last_error = s; }
+// Device views of the last call's pyramid (used by the stereo matcher, which reads both eyes' levels).
+int extractor_last_view(msorb_extractor* h, PyramidView* pyr, LevelScale* sc, float* inv_scale, int* device,
+                        hipStream_t* stream) {
+    if (!h || !h->geom_valid || h->last_n_images < 1) {
+        set_error("extractor has no pyramid yet (call msorb_extract first)");
+        return MSORB_E_INVALID;
+    }
+    *pyr = h->last_pyr;
+    if (sc) *sc = h->scales;
+    if (inv_scale)
+        for (int l = 0; l < h->P.nlevels; l++) inv_scale[l] = h->P.inv_scale[l];
+    *device = h->device;
+    *stream = h->stream;
+    return MSORB_OK;
+}
+}  // namespace msorb
+
 extern "C" {
 
 const char* msorb_last_error(void) { return g_last_error.c_str(); }

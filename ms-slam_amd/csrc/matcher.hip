@@ -1,0 +1,278 @@
+// Hamming matching kernels + the flat C ABI that ORBmatcher::SearchBy* and Frame::ComputeStereoMatches
+// call into (include/msorb.h, "Matcher" section).  Integer / bit work: XOR + popcount, wave64 reductions.
+//
+//   window_topk_kernel   GetFeaturesInArea + best/second argmin   Frame.cc:589-655, ORBmatcher.cc:84-120, 2006-2033
+//   list_top2_kernel     explicit candidate lists (BoW searches)   ORBmatcher.cc:288-330 idiom
+//   stereo_match_kernel  row-band argmin + 11-offset SAD           Frame.cc:743-897
+//
+// Tie-breaks: the reference scans candidates sequentially with strict '<'.  That equals a lexicographic
+// minimum over (distance, position-in-scan), so every lane keeps packed 64-bit keys
+// dist<<40 | scan position and the wave reduces with min — exact, order independent.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/msorb.h"
+#include "matcher_device.h"
+
+namespace msorb {
+
+__device__ __forceinline__ int hamming256(const uint64_t a[4], const uint64_t* __restrict__ b) {
+    return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
+}
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t t = __shfl_xor(v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+constexpr uint64_t kNoKey = ~0ull;
+
+// per-lane sorted insertion into a 4-deep (key, idx) list
+__device__ __forceinline__ void topk_insert(uint64_t key, int idx, uint64_t k[kTopK], int id[kTopK]) {
+    if (key >= k[kTopK - 1]) return;
+    k[kTopK - 1] = key; id[kTopK - 1] = idx;
+#pragma unroll
+    for (int i = kTopK - 1; i > 0; i--) {
+        if (k[i] < k[i - 1]) {
+            const uint64_t tk = k[i]; k[i] = k[i - 1]; k[i - 1] = tk;
+            const int ti = id[i]; id[i] = id[i - 1]; id[i - 1] = ti;
+        }
+    }
+}
+
+// One wave per query.  Walks the query's grid window exactly like Frame::GetFeaturesInArea: cells ix
+// (outer) / iy (inner) ascending, cell contents in insertion order; lane c owns window cell c, c+64, ...
+__global__ __launch_bounds__(256) void window_topk_kernel(FrameView F, const WinQuery* __restrict__ q,
+                                                          const uint8_t* __restrict__ qdesc, int q_begin, int q_end,
+                                                          TopK* __restrict__ out) {
+    const int qi = q_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (qi >= q_end) return;
+    const WinQuery Q = q[qi];
+    uint64_t k[kTopK];
+    int id[kTopK];
+#pragma unroll
+    for (int i = 0; i < kTopK; i++) { k[i] = kNoKey; id[i] = -1; }
+    bool any = (Q.flags & kQValid) != 0;
+    int minCX = 0, maxCX = -1, minCY = 0, maxCY = -1;
+    if (any) {  // Frame.cc:597-619
+        minCX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.x, F.minX), Q.r), F.gridWInv)));
+        maxCX = min(kGridCols - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.x, F.minX), Q.r), F.gridWInv)));
+        minCY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.y, F.minY), Q.r), F.gridHInv)));
+        maxCY = min(kGridRows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.y, F.minY), Q.r), F.gridHInv)));
+        any = !(minCX >= kGridCols || maxCX < 0 || minCY >= kGridRows || maxCY < 0);
+    }
+    if (any) {
+        const uint64_t* qd = reinterpret_cast<const uint64_t*>(qdesc + (size_t)qi * 32);
+        const uint64_t a[4] = {qd[0], qd[1], qd[2], qd[3]};
+        const int ncy = maxCY - minCY + 1;
+        const int ncell = (maxCX - minCX + 1) * ncy;
+        const bool check_levels = (Q.min_level > 0) || (Q.max_level >= 0);
+        for (int c = lane; c < ncell; c += 64) {
+            const int ix = minCX + c / ncy, iy = minCY + c % ncy;
+            const int cell = ix * kGridRows + iy;
+            const int b = F.cell_begin[cell], e = F.cell_begin[cell + 1];
+            for (int j = b; j < e; j++) {
+                const int idx = F.cell_idx[j];
+                const KpLite kp = F.kp[idx];
+                if (check_levels) {
+                    if (kp.octave < Q.min_level) continue;
+                    if (Q.max_level >= 0 && kp.octave > Q.max_level) continue;
+                }
+                if (!(fabsf(__fsub_rn(kp.x, Q.x)) < Q.r && fabsf(__fsub_rn(kp.y, Q.y)) < Q.r)) continue;
+                if ((Q.flags & kQSkipOccupied) && F.occupied[idx]) continue;       // ORBmatcher.cc:88-90
+                if (kp.u_right > 0 && fabsf(__fsub_rn(Q.ur, kp.u_right)) > Q.r) continue;  // :92-97
+                const int d = hamming256(a, reinterpret_cast<const uint64_t*>(F.desc + (size_t)idx * 32));
+                topk_insert(((uint64_t)d << 40) | ((uint64_t)c << 20) | (uint64_t)(j - b), idx, k, id);
+            }
+        }
+    }
+    // merge the 64 sorted lists: kTopK rounds of "global minimum head pops"
+    TopK res;
+#pragma unroll
+    for (int r = 0; r < kTopK; r++) {
+        const uint64_t m = wave_min_u64(k[0]);
+        int widx = -1;
+        if (m != kNoKey && k[0] == m) {  // keys are unique (scan position), exactly one lane matches
+            widx = id[0];
+#pragma unroll
+            for (int i = 0; i < kTopK - 1; i++) { k[i] = k[i + 1]; id[i] = id[i + 1]; }
+            k[kTopK - 1] = kNoKey; id[kTopK - 1] = -1;
+        }
+        const unsigned long long owner = __ballot(widx >= 0);
+        const int src = owner ? __ffsll((long long)owner) - 1 : 0;
+        res.idx[r] = owner ? __shfl(widx, src) : -1;
+        res.dist[r] = owner ? (int)(m >> 40) : 256;
+    }
+    if (lane == 0) out[qi] = res;
+}
+
+// Explicit candidate lists (CSR): best / second-best in list order.
+__global__ __launch_bounds__(256) void list_top2_kernel(const uint8_t* __restrict__ qdesc, const uint8_t* __restrict__ tdesc,
+                                                        const int* __restrict__ cand_begin, const int* __restrict__ cand_idx,
+                                                        int n_queries, int* __restrict__ best_idx, int* __restrict__ best_dist,
+                                                        int* __restrict__ second_idx, int* __restrict__ second_dist) {
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (qi >= n_queries) return;
+    const uint64_t* qd = reinterpret_cast<const uint64_t*>(qdesc + (size_t)qi * 32);
+    const uint64_t a[4] = {qd[0], qd[1], qd[2], qd[3]};
+    uint64_t k0 = kNoKey, k1 = kNoKey;
+    const int b = cand_begin[qi], e = cand_begin[qi + 1];
+    for (int j = b + lane; j < e; j += 64) {
+        const int idx = cand_idx[j];
+        const int d = hamming256(a, reinterpret_cast<const uint64_t*>(tdesc + (size_t)idx * 32));
+        const uint64_t key = ((uint64_t)d << 40) | (uint64_t)(j - b);
+        if (key < k0) { k1 = k0; k0 = key; } else if (key < k1) k1 = key;
+    }
+    const uint64_t m0 = wave_min_u64(k0);
+    if (k0 == m0 && m0 != kNoKey) { k0 = k1; k1 = kNoKey; }  // owner pops
+    const uint64_t m1 = wave_min_u64(k0);
+    if (lane == 0) {
+        best_idx[qi] = m0 == kNoKey ? -1 : cand_idx[b + (int)(m0 & 0xffffffffffull)];
+        best_dist[qi] = m0 == kNoKey ? 256 : (int)(m0 >> 40);
+        second_idx[qi] = m1 == kNoKey ? -1 : cand_idx[b + (int)(m1 & 0xffffffffffull)];
+        second_dist[qi] = m1 == kNoKey ? 256 : (int)(m1 >> 40);
+    }
+}
+
+// Frame::ComputeStereoMatches (Frame.cc:743-897), one wave per left keypoint.
+//  1. candidates = right keypoints whose row band [floor(y-r), ceil(y+r)], r = 2*scale[octave], contains
+//     row (int)vL (the reference's vRowIndices table, ascending iR), octave within +-1, uR in [uL-maxD, uL];
+//     best = lexicographic min (dist, iR), accepted if dist < TH_HIGH(100)            (:805-826)
+//  2. if best < 75: L1 SAD of the 11x11 window at 11 horizontal offsets on the pyramid level, parabola
+//     sub-pixel fit, disparity gates                                                  (:829-897)
+// The median-based rejection (:899-912) is serial and done by the host on the SAD values written here.
+__global__ __launch_bounds__(256) void stereo_match_kernel(StereoArgs A) {
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (iL >= A.nL) return;
+    const msorb_keypoint kpL = A.kpL[iL];
+    const int levelL = kpL.octave;
+    const float vL = kpL.y, uL = kpL.x;
+    float out_u = -1.0f, out_d = -1.0f;
+    int out_sad = -1;
+    const int row = (int)vL;
+    const float minD = 0.f, maxD = __fdiv_rn(A.mbf, A.mb);
+    const float minU = __fsub_rn(uL, maxD), maxU = __fsub_rn(uL, minD);
+    uint64_t best = kNoKey;
+    if (row >= 0 && row < A.rows0 && !(maxU < 0)) {
+        const uint64_t* dl = reinterpret_cast<const uint64_t*>(A.descL + (size_t)iL * 32);
+        const uint64_t a[4] = {dl[0], dl[1], dl[2], dl[3]};
+        for (int iR = lane; iR < A.nR; iR += 64) {
+            const msorb_keypoint kr = A.kpR[iR];
+            const float r = __fmul_rn(2.0f, A.scale[kr.octave]);
+            const int maxr = (int)ceilf(__fadd_rn(kr.y, r)), minr = (int)floorf(__fsub_rn(kr.y, r));
+            if (row < minr || row > maxr) continue;
+            if (kr.octave < levelL - 1 || kr.octave > levelL + 1) continue;
+            if (!(kr.x >= minU && kr.x <= maxU)) continue;
+            const int d = hamming256(a, reinterpret_cast<const uint64_t*>(A.descR + (size_t)iR * 32));
+            const uint64_t key = ((uint64_t)d << 32) | (uint32_t)iR;
+            best = key < best ? key : best;
+        }
+    }
+    best = wave_min_u64(best);
+    const int bestDist = best == kNoKey ? 256 : (int)(best >> 32);
+    if (bestDist < kThHigh && bestDist < (kThHigh + kThLow) / 2) {
+        const int bestIdxR = (int)(best & 0xffffffffu);
+        const float uR0 = A.kpR[bestIdxR].x;
+        const float sf = A.inv_scale[levelL];
+        const float scaleduL = roundf(__fmul_rn(kpL.x, sf));
+        const float scaledvL = roundf(__fmul_rn(kpL.y, sf));
+        const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
+        const int w = 5, L = 5;
+        const int cols = A.cols[levelL], rows = A.rows[levelL];
+        const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+        const int y0 = (int)(scaledvL - w), xL0 = (int)(scaleduL - w), xR0 = (int)(scaleduR0 - L - w);
+        const bool ok = !(iniu < 0 || endu >= cols) && y0 >= 0 && y0 + 2 * w + 1 <= rows && xL0 >= 0 &&
+                        xL0 + 2 * w + 1 <= cols && xR0 >= 0 && (int)(scaleduR0 + L + w + 1) <= cols;
+        if (ok) {
+            const uint8_t* pl = A.pyrL[levelL] + (size_t)y0 * A.pitchL[levelL] + xL0;
+            const uint8_t* pr = A.pyrR[levelL] + (size_t)y0 * A.pitchR[levelL] + xR0;
+            // lane -> window pixel(s): 121 pixels over 64 lanes (two passes)
+            int vl0 = 0, vl1 = 0, o0 = 0, o1 = 0;
+            const int p0 = lane, p1 = lane + 64;
+            {
+                const int yy = p0 / 11, xx = p0 - yy * 11;
+                vl0 = pl[(size_t)yy * A.pitchL[levelL] + xx];
+                o0 = yy * A.pitchR[levelL] + xx;
+            }
+            if (p1 < 121) {
+                const int yy = p1 / 11, xx = p1 - yy * 11;
+                vl1 = pl[(size_t)yy * A.pitchL[levelL] + xx];
+                o1 = yy * A.pitchR[levelL] + xx;
+            }
+            int sad[11];
+#pragma unroll
+            for (int inc = 0; inc < 11; inc++) {
+                int s = abs(vl0 - (int)pr[o0 + inc]);
+                if (p1 < 121) s += abs(vl1 - (int)pr[o1 + inc]);
+                sad[inc] = wave_sum_i32(s);
+            }
+            int bestS = 0x7fffffff, bestinc = 0;
+#pragma unroll
+            for (int inc = 0; inc < 11; inc++)
+                if (sad[inc] < bestS) { bestS = sad[inc]; bestinc = inc - L; }
+            if (!(bestinc == -L || bestinc == L)) {
+                float d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+                for (int inc = 1; inc < 10; inc++)
+                    if (inc == bestinc + L) { d1 = (float)sad[inc - 1]; d2 = (float)sad[inc]; d3 = (float)sad[inc + 1]; }
+                const float deltaR = __fdiv_rn(__fsub_rn(d1, d3),
+                                               __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
+                if (!(deltaR < -1 || deltaR > 1)) {
+                    float bestuR = __fmul_rn(A.scale[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
+                    float disparity = __fsub_rn(uL, bestuR);
+                    if (disparity >= minD && disparity < maxD) {
+                        if (disparity <= 0) {
+                            disparity = (float)0.01;
+                            bestuR = (float)((double)uL - 0.01);
+                        }
+                        out_d = __fdiv_rn(A.mbf, disparity);
+                        out_u = bestuR;
+                        out_sad = bestS;
+                    }
+                }
+            }
+        } else if (lane == 0 && !(iniu < 0 || endu >= cols)) {
+            atomicAdd(A.n_oob, 1);
+        }
+    }
+    if (lane == 0) {
+        A.u_right[iL] = out_u;
+        A.depth[iL] = out_d;
+        A.sad[iL] = out_sad;
+    }
+}
+
+void launch_window_topk(const FrameView& F, const WinQuery* q, const uint8_t* qdesc, int q_begin, int q_end,
+                        TopK* out, hipStream_t s) {
+    const int n = q_end - q_begin;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(window_topk_kernel, dim3((n + 3) / 4), dim3(256), 0, s, F, q, qdesc, q_begin, q_end, out);
+}
+void launch_list_top2(const uint8_t* qdesc, const uint8_t* tdesc, const int* cand_begin, const int* cand_idx, int nq,
+                      int* bi, int* bd, int* si, int* sd, hipStream_t s) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(list_top2_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, qdesc, tdesc, cand_begin, cand_idx, nq, bi,
+                       bd, si, sd);
+}
+void launch_stereo_match(const StereoArgs& a, hipStream_t s) {
+    if (a.nL <= 0) return;
+    hipLaunchKernelGGL(stereo_match_kernel, dim3((a.nL + 3) / 4), dim3(256), 0, s, a);
+}
+
+}  // namespace msorb

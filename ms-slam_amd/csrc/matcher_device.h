@@ -1,0 +1,56 @@
+// Structures shared by matcher.hip (kernels) and matcher_host.hip (frame handle, replay logic, C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/msorb.h"
+
+namespace msorb {
+
+constexpr int kGridCols = 64, kGridRows = 48;  // FRAME_GRID_COLS / FRAME_GRID_ROWS, Frame.h:44-45
+constexpr int kThHigh = 100, kThLow = 50, kHistoLength = 30;  // ORBmatcher.cc:35-37
+constexpr int kTopK = 4;
+
+struct KpLite {  // what the window search needs of one train keypoint (16 B, one load)
+    float x, y, u_right;
+    int octave;
+};
+struct FrameView {
+    const KpLite* kp;
+    const uint8_t* desc;
+    const int* cell_begin;  // kGridCols*kGridRows + 1, cell = ix*kGridRows + iy (mGrid[ix][iy])
+    const int* cell_idx;    // keypoint indices, insertion (ascending index) order inside a cell
+    const uint8_t* occupied;  // F.mvpMapPoints[idx] && Observations() > 0
+    float minX, minY, gridWInv, gridHInv;
+    int n;
+};
+constexpr uint8_t kQValid = 1, kQSkipOccupied = 2;
+struct WinQuery {
+    float x, y, r, ur;
+    int16_t min_level, max_level;
+    uint8_t flags, pad[3];
+};
+struct TopK {
+    int idx[kTopK];
+    int dist[kTopK];
+};
+struct StereoArgs {
+    const msorb_keypoint *kpL, *kpR;
+    const uint8_t *descL, *descR;
+    int nL, nR, rows0;
+    const uint8_t* pyrL[MSORB_MAX_LEVELS];
+    const uint8_t* pyrR[MSORB_MAX_LEVELS];
+    int pitchL[MSORB_MAX_LEVELS], pitchR[MSORB_MAX_LEVELS], rows[MSORB_MAX_LEVELS], cols[MSORB_MAX_LEVELS];
+    float scale[MSORB_MAX_LEVELS], inv_scale[MSORB_MAX_LEVELS];
+    float mb, mbf;
+    float *u_right, *depth;
+    int *sad, *n_oob;
+};
+
+void launch_window_topk(const FrameView& F, const WinQuery* q, const uint8_t* qdesc, int q_begin, int q_end,
+                        TopK* out, hipStream_t s);
+void launch_list_top2(const uint8_t* qdesc, const uint8_t* tdesc, const int* cand_begin, const int* cand_idx, int nq,
+                      int* bi, int* bd, int* si, int* sd, hipStream_t s);
+void launch_stereo_match(const StereoArgs& a, hipStream_t s);
+
+}  // namespace msorb

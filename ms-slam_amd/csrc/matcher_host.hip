@@ -1,0 +1,492 @@
+// Matcher side of the C ABI: frame handle (features + 64x48 grid on the device), the sequential replay
+// that reproduces the reference's in-loop side effects, stereo matching orchestration.
+//
+// Sequential side effects.  SearchByProjection assigns F.mvpMapPoints[bestIdx] inside
+// its loop and later map points skip keypoints that hold a map point with Observations() > 0
+// (ORBmatcher.cc:88-90,129).  The device computes, for every query at once, the kTopK best candidates
+// against an occupancy SNAPSHOT; the host then replays the accept rules in query order, dropping
+// candidates claimed since the snapshot.  If a query's list is exhausted (all but <2 of a full list were
+// claimed) or a keypoint was freed (only possible through the mbSparsified bypass), the snapshot is
+// refreshed and the kernel re-run from that query on — the result is always the reference's.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "matcher_device.h"
+#include "orb_device.h"
+
+using namespace msorb;
+
+namespace msorb {
+void set_last_error(const std::string& s);
+int extractor_last_view(msorb_extractor* h, PyramidView* pyr, LevelScale* sc, float* inv_scale, int* device,
+                        hipStream_t* stream);
+}  // namespace msorb
+
+#define HIPCHK(expr)                                                               \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) {                                                    \
+            set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e));     \
+            return MSORB_E_HIP;                                                    \
+        }                                                                          \
+    } while (0)
+
+namespace {
+template <typename T>
+struct DBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count) {
+        if (count <= n) return MSORB_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        HIPCHK(hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)));
+        n = std::max<size_t>(count, 1);
+        return MSORB_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+}  // namespace
+
+struct msorb_frame {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int N = 0, nlevels = 0;
+    float minX = 0, minY = 0, maxX = 0, maxY = 0, gridWInv = 0, gridHInv = 0;
+    std::vector<msorb_keypoint> kps;
+    std::vector<float> u_right, scale;
+    std::vector<int> cell_begin, cell_idx;
+    DBuf<KpLite> d_kp;
+    DBuf<uint8_t> d_desc, d_occ, d_qdesc;
+    DBuf<int> d_cell_begin, d_cell_idx;
+    DBuf<WinQuery> d_q;
+    DBuf<TopK> d_topk;
+    FrameView view() const {
+        FrameView v;
+        v.kp = d_kp.p; v.desc = d_desc.p; v.cell_begin = d_cell_begin.p; v.cell_idx = d_cell_idx.p;
+        v.occupied = d_occ.p; v.minX = minX; v.minY = minY; v.gridWInv = gridWInv; v.gridHInv = gridHInv; v.n = N;
+        return v;
+    }
+};
+
+namespace {
+
+// Shared replay driver.  accept(q, list, n) is called in query order with the query's exact candidate
+// prefix (>= need entries unless the true candidate set is smaller); it returns the keypoint index it
+// assigned (or -1) and the new occupancy of that keypoint through *new_occ.
+template <typename Accept>
+int run_window_search(msorb_frame* f, const std::vector<WinQuery>& q, const uint8_t* qdesc, std::vector<uint8_t>& occ,
+                      int need, Accept accept) {
+    const int M = (int)q.size();
+    if (M == 0) return MSORB_OK;
+    int rc;
+    if ((rc = f->d_q.ensure(M)) || (rc = f->d_qdesc.ensure((size_t)M * 32)) || (rc = f->d_topk.ensure(M)) ||
+        (rc = f->d_occ.ensure(f->N)))
+        return rc;
+    hipStream_t s = f->stream;
+    HIPCHK(hipMemcpyAsync(f->d_q.p, q.data(), (size_t)M * sizeof(WinQuery), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(f->d_qdesc.p, qdesc, (size_t)M * 32, hipMemcpyHostToDevice, s));
+    std::vector<TopK> topk(M);
+    std::vector<int8_t> diff(f->N, 0);  // occupancy now vs snapshot: +1 claimed since, -1 freed since
+    int q0 = 0;
+    while (q0 < M) {
+        if (f->N) HIPCHK(hipMemcpyAsync(f->d_occ.p, occ.data(), f->N, hipMemcpyHostToDevice, s));
+        std::vector<uint8_t> snap = occ;
+        std::fill(diff.begin(), diff.end(), 0);
+        int n_freed = 0;
+        launch_window_topk(f->view(), f->d_q.p, f->d_qdesc.p, q0, M, f->d_topk.p, s);
+        HIPCHK(hipMemcpyAsync(topk.data() + q0, f->d_topk.p + q0, (size_t)(M - q0) * sizeof(TopK), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        int qi = q0;
+        bool resync = false;
+        for (; qi < M; qi++) {
+            if (!(q[qi].flags & kQValid)) continue;
+            const bool skip = q[qi].flags & kQSkipOccupied;
+            if (skip && n_freed > 0 && qi > q0) { resync = true; break; }
+            const TopK& t = topk[qi];
+            int idx[kTopK], dist[kTopK], n = 0, n_dev = 0;
+            for (int k = 0; k < kTopK; k++) {
+                if (t.idx[k] < 0) break;
+                n_dev++;
+                if (skip && diff[t.idx[k]] > 0) continue;
+                idx[n] = t.idx[k]; dist[n] = t.dist[k]; n++;
+            }
+            if (n < need && n < n_dev && n_dev == kTopK && qi > q0) { resync = true; break; }
+            int new_occ = 0;
+            const int assigned = accept(qi, idx, dist, n, &new_occ);
+            if (assigned >= 0) {
+                occ[assigned] = (uint8_t)new_occ;
+                const int8_t d = (int8_t)((int)occ[assigned] - (int)snap[assigned]);
+                if (diff[assigned] < 0) n_freed--;
+                diff[assigned] = d;
+                if (d < 0) n_freed++;
+            }
+        }
+        if (!resync) break;
+        q0 = qi;
+    }
+    return MSORB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msorb_frame_create(int device, msorb_frame** out) {
+    if (!out) return MSORB_E_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        set_last_error("no usable HIP device (libmsorb has no CPU fallback)");
+        return MSORB_E_NO_DEVICE;
+    }
+    HIPCHK(hipSetDevice(device));
+    msorb_frame* f = new msorb_frame();
+    f->device = device;
+    if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) { delete f; return MSORB_E_HIP; }
+    *out = f;
+    return MSORB_OK;
+}
+
+void msorb_frame_destroy(msorb_frame* f) {
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
+    f->d_kp.release(); f->d_desc.release(); f->d_occ.release(); f->d_qdesc.release(); f->d_cell_begin.release();
+    f->d_cell_idx.release(); f->d_q.release(); f->d_topk.release();
+    delete f;
+}
+
+int msorb_frame_set(msorb_frame* f, const msorb_keypoint* kps, int n, const uint8_t* desc, const float* u_right,
+                    float min_x, float max_x, float min_y, float max_y, const float* scale_factors, int nlevels) {
+    if (!f || n < 0 || (n > 0 && (!kps || !desc)) || !scale_factors || nlevels < 1 || nlevels > MSORB_MAX_LEVELS ||
+        !(max_x > min_x) || !(max_y > min_y))
+        return MSORB_E_INVALID;
+    HIPCHK(hipSetDevice(f->device));
+    f->N = n; f->nlevels = nlevels;
+    f->minX = min_x; f->maxX = max_x; f->minY = min_y; f->maxY = max_y;
+    f->gridWInv = static_cast<float>(kGridCols) / (max_x - min_x);  // Frame.cc:147-148
+    f->gridHInv = static_cast<float>(kGridRows) / (max_y - min_y);
+    f->kps.assign(kps, kps + n);
+    if (u_right) f->u_right.assign(u_right, u_right + n); else f->u_right.assign(n, -1.0f);
+    f->scale.assign(scale_factors, scale_factors + nlevels);
+    // AssignFeaturesToGrid (Frame.cc:385-416): counting sort by cell keeps ascending index inside a cell
+    const int ncell = kGridCols * kGridRows;
+    std::vector<int> cell(n, -1);
+    f->cell_begin.assign(ncell + 1, 0);
+    for (int i = 0; i < n; i++) {
+        const int px = (int)std::round((kps[i].x - min_x) * f->gridWInv);  // PosInGrid, Frame.cc:657-667
+        const int py = (int)std::round((kps[i].y - min_y) * f->gridHInv);
+        if (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) continue;
+        cell[i] = px * kGridRows + py;
+        f->cell_begin[cell[i] + 1]++;
+    }
+    for (int c = 0; c < ncell; c++) f->cell_begin[c + 1] += f->cell_begin[c];
+    f->cell_idx.assign(f->cell_begin[ncell], 0);
+    std::vector<int> cur(f->cell_begin.begin(), f->cell_begin.end() - 1);
+    for (int i = 0; i < n; i++)
+        if (cell[i] >= 0) f->cell_idx[cur[cell[i]]++] = i;
+    std::vector<KpLite> lite(n);
+    for (int i = 0; i < n; i++) lite[i] = KpLite{kps[i].x, kps[i].y, f->u_right[i], kps[i].octave};
+    int rc;
+    if ((rc = f->d_kp.ensure(n)) || (rc = f->d_desc.ensure((size_t)n * 32)) || (rc = f->d_cell_begin.ensure(ncell + 1)) ||
+        (rc = f->d_cell_idx.ensure(f->cell_idx.size())) || (rc = f->d_occ.ensure(n)))
+        return rc;
+    hipStream_t s = f->stream;
+    if (n) {
+        HIPCHK(hipMemcpyAsync(f->d_kp.p, lite.data(), (size_t)n * sizeof(KpLite), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(f->d_desc.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
+        if (!f->cell_idx.empty())
+            HIPCHK(hipMemcpyAsync(f->d_cell_idx.p, f->cell_idx.data(), f->cell_idx.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(hipMemcpyAsync(f->d_cell_begin.p, f->cell_begin.data(), (size_t)(ncell + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return MSORB_OK;
+}
+
+int msorb_frame_features_in_area(const msorb_frame* f, float x, float y, float r, int min_level, int max_level,
+                                 int* out, int capacity, int* n_out) {
+    if (!f || !n_out) return MSORB_E_INVALID;
+    int n = 0;
+    *n_out = 0;
+    const int minCX = std::max(0, (int)std::floor((x - f->minX - r) * f->gridWInv));
+    if (minCX >= kGridCols) return MSORB_OK;
+    const int maxCX = std::min(kGridCols - 1, (int)std::ceil((x - f->minX + r) * f->gridWInv));
+    if (maxCX < 0) return MSORB_OK;
+    const int minCY = std::max(0, (int)std::floor((y - f->minY - r) * f->gridHInv));
+    if (minCY >= kGridRows) return MSORB_OK;
+    const int maxCY = std::min(kGridRows - 1, (int)std::ceil((y - f->minY + r) * f->gridHInv));
+    if (maxCY < 0) return MSORB_OK;
+    const bool check = (min_level > 0) || (max_level >= 0);
+    for (int ix = minCX; ix <= maxCX; ix++)
+        for (int iy = minCY; iy <= maxCY; iy++) {
+            const int c = ix * kGridRows + iy;
+            for (int j = f->cell_begin[c]; j < f->cell_begin[c + 1]; j++) {
+                const msorb_keypoint& kp = f->kps[f->cell_idx[j]];
+                if (check) {
+                    if (kp.octave < min_level) continue;
+                    if (max_level >= 0 && kp.octave > max_level) continue;
+                }
+                if (std::fabs(kp.x - x) < r && std::fabs(kp.y - y) < r) {
+                    if (n < capacity) out[n] = f->cell_idx[j];
+                    n++;
+                }
+            }
+        }
+    *n_out = n;
+    return n > capacity ? MSORB_E_CAPACITY : MSORB_OK;
+}
+
+int msorb_search_by_projection_mps(msorb_frame* f, int M, const uint8_t* track_in_view, const uint8_t* bad,
+                                   const uint8_t* sparsified, const float* proj_x, const float* proj_y,
+                                   const float* proj_xr, const float* track_depth, const int* level,
+                                   const float* view_cos, const uint8_t* mp_desc, const int* obs, int* frame_mp,
+                                   float th, int far_points, float th_far, float nnratio, int* nmatches) {
+    if (!f || M < 0 || !nmatches || (M > 0 && (!track_in_view || !bad || !sparsified || !proj_x || !proj_y || !proj_xr ||
+                                               !track_depth || !level || !view_cos || !mp_desc || !obs)) ||
+        (f->N > 0 && !frame_mp))
+        return MSORB_E_INVALID;
+    HIPCHK(hipSetDevice(f->device));
+    *nmatches = 0;
+    const bool bFactor = th != 1.0;
+    std::vector<WinQuery> q(M);
+    for (int i = 0; i < M; i++) {
+        WinQuery w{};
+        bool valid = track_in_view[i] && !(far_points && track_depth[i] > th_far) && !bad[i];
+        if (valid && (level[i] < 0 || level[i] >= f->nlevels)) { set_last_error("predicted level out of range"); return MSORB_E_INVALID; }
+        if (valid) {
+            float r = (view_cos[i] > 0.998) ? 2.5 : 4.0;  // RadiusByViewingCos, ORBmatcher.cc:215-221
+            if (bFactor) r *= th;
+            w.x = proj_x[i]; w.y = proj_y[i];
+            w.r = r * f->scale[level[i]];
+            w.ur = proj_xr[i];
+            w.min_level = (int16_t)(level[i] - 1);
+            w.max_level = (int16_t)level[i];
+            w.flags = kQValid | (sparsified[i] ? 0 : kQSkipOccupied);
+        }
+        q[i] = w;
+    }
+    std::vector<uint8_t> occ(f->N);
+    for (int i = 0; i < f->N; i++) occ[i] = frame_mp[i] >= 0 && obs[frame_mp[i]] > 0;
+    int nm = 0;
+    auto accept = [&](int qi, const int* idx, const int* dist, int n, int* new_occ) -> int {
+        if (n == 0) return -1;
+        const int bestDist = dist[0], bestIdx = idx[0];
+        const int bestLevel = f->kps[bestIdx].octave;
+        const int bestDist2 = n > 1 ? dist[1] : 256;
+        const int bestLevel2 = n > 1 ? f->kps[idx[1]].octave : -1;
+        if (bestDist <= kThHigh) {  // ORBmatcher.cc:122-141
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) return -1;
+            if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+                frame_mp[bestIdx] = qi;
+                nm++;
+                *new_occ = obs[qi] > 0;
+                return bestIdx;
+            }
+        }
+        return -1;
+    };
+    const int rc = run_window_search(f, q, mp_desc, occ, 2, accept);
+    *nmatches = nm;
+    return rc;
+}
+
+int msorb_search_by_projection_frames(msorb_frame* f, int NL, const uint8_t* valid, const float* u, const float* v,
+                                      const float* ur, const int* last_octave, const float* last_angle,
+                                      const uint8_t* mp_desc, const int* last_mp, const int* obs, int* cur_mp, float th,
+                                      int forward, int backward, int check_orientation, int* nmatches) {
+    if (!f || NL < 0 || !nmatches || (NL > 0 && (!valid || !u || !v || !ur || !last_octave || !last_angle || !mp_desc ||
+                                                 !last_mp || !obs)) || (f->N > 0 && !cur_mp))
+        return MSORB_E_INVALID;
+    HIPCHK(hipSetDevice(f->device));
+    *nmatches = 0;
+    std::vector<WinQuery> q(NL);
+    for (int i = 0; i < NL; i++) {
+        WinQuery w{};
+        if (valid[i]) {
+            const int oct = last_octave[i];
+            if (oct < 0 || oct >= f->nlevels) { set_last_error("octave out of range"); return MSORB_E_INVALID; }
+            w.x = u[i]; w.y = v[i];
+            w.r = th * f->scale[oct];  // ORBmatcher.cc:1989
+            w.ur = ur[i];
+            if (forward) { w.min_level = (int16_t)oct; w.max_level = -1; }
+            else if (backward) { w.min_level = 0; w.max_level = (int16_t)oct; }
+            else { w.min_level = (int16_t)(oct - 1); w.max_level = (int16_t)(oct + 1); }
+            w.flags = kQValid | kQSkipOccupied;
+        }
+        q[i] = w;
+    }
+    std::vector<uint8_t> occ(f->N);
+    for (int i = 0; i < f->N; i++) occ[i] = cur_mp[i] >= 0 && obs[cur_mp[i]] > 0;
+    int nm = 0;
+    std::vector<int> rotHist[kHistoLength];
+    const float factor = 1.0f / kHistoLength;
+    auto accept = [&](int qi, const int* idx, const int* dist, int n, int* new_occ) -> int {
+        if (n == 0) return -1;
+        if (dist[0] <= kThHigh) {  // ORBmatcher.cc:2035-2057
+            const int bestIdx2 = idx[0];
+            cur_mp[bestIdx2] = last_mp[qi];
+            nm++;
+            if (check_orientation) {
+                float rot = last_angle[qi] - f->kps[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == kHistoLength) bin = 0;
+                if (bin >= 0 && bin < kHistoLength) rotHist[bin].push_back(bestIdx2);
+            }
+            *new_occ = obs[last_mp[qi]] > 0;
+            return bestIdx2;
+        }
+        return -1;
+    };
+    const int rc = run_window_search(f, q, mp_desc, occ, 1, accept);
+    if (rc) return rc;
+    if (check_orientation) {  // ORBmatcher.cc:2129-2149
+        int sizes[kHistoLength], ind[3];
+        for (int i = 0; i < kHistoLength; i++) sizes[i] = (int)rotHist[i].size();
+        msorb_three_maxima(sizes, kHistoLength, ind);
+        for (int i = 0; i < kHistoLength; i++)
+            if (i != ind[0] && i != ind[1] && i != ind[2])
+                for (int k : rotHist[i]) { cur_mp[k] = -1; nm--; }
+    }
+    *nmatches = nm;
+    return MSORB_OK;
+}
+
+int msorb_three_maxima(const int* sizes, int L, int* ind) {
+    if (!sizes || !ind || L < 0) return MSORB_E_INVALID;
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = sizes[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+    ind[0] = ind1; ind[1] = ind2; ind[2] = ind3;
+    return MSORB_OK;
+}
+
+int msorb_hamming_top2(int device, const uint8_t* qdesc, int nq, const uint8_t* tdesc, int nt, const int* cand_begin,
+                       const int* cand_idx, int* best_idx, int* best_dist, int* second_idx, int* second_dist) {
+    if (nq < 0 || nt < 0 || (nq > 0 && (!qdesc || !cand_begin || !best_idx || !best_dist || !second_idx || !second_dist)))
+        return MSORB_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        set_last_error("no usable HIP device (libmsorb has no CPU fallback)");
+        return MSORB_E_NO_DEVICE;
+    }
+    if (nq == 0) return MSORB_OK;
+    HIPCHK(hipSetDevice(device));
+    const int total = cand_begin[nq];
+    for (int i = 0; i < total; i++)
+        if (cand_idx[i] < 0 || cand_idx[i] >= nt) { set_last_error("candidate index out of range"); return MSORB_E_INVALID; }
+    DBuf<uint8_t> dq, dt;
+    DBuf<int> dcb, dci, dout;
+    int rc;
+    if ((rc = dq.ensure((size_t)nq * 32)) || (rc = dt.ensure((size_t)nt * 32)) || (rc = dcb.ensure(nq + 1)) ||
+        (rc = dci.ensure(total)) || (rc = dout.ensure((size_t)4 * nq)))
+        return rc;
+    auto cleanup = [&] { dq.release(); dt.release(); dcb.release(); dci.release(); dout.release(); };
+    hipError_t e = hipMemcpy(dq.p, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nt) e = hipMemcpy(dt.p, tdesc, (size_t)nt * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dcb.p, cand_begin, (size_t)(nq + 1) * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess && total) e = hipMemcpy(dci.p, cand_idx, (size_t)total * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_list_top2(dq.p, dt.p, dcb.p, dci.p, nq, dout.p, dout.p + nq, dout.p + 2 * nq, dout.p + 3 * nq, nullptr);
+        e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess) e = hipMemcpy(best_idx, dout.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(best_dist, dout.p + nq, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(second_idx, dout.p + 2 * nq, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(second_dist, dout.p + 3 * nq, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return MSORB_E_HIP; }
+    return MSORB_OK;
+}
+
+int msorb_stereo_matches(msorb_extractor* left, msorb_extractor* right, const msorb_keypoint* kpsL, int nL,
+                         const uint8_t* descL, const msorb_keypoint* kpsR, int nR, const uint8_t* descR, float mb,
+                         float mbf, float* u_right, float* depth, int* n_oob) {
+    if (!left || !right || nL < 0 || nR < 0 || (nL > 0 && (!kpsL || !descL || !u_right || !depth)) ||
+        (nR > 0 && (!kpsR || !descR)))
+        return MSORB_E_INVALID;
+    PyramidView pl, pr;
+    LevelScale sc;
+    float inv_scale[MSORB_MAX_LEVELS];
+    int devL = 0, devR = 0;
+    hipStream_t s = nullptr, s2 = nullptr;
+    int rc;
+    if ((rc = extractor_last_view(left, &pl, &sc, inv_scale, &devL, &s))) return rc;
+    if ((rc = extractor_last_view(right, &pr, nullptr, nullptr, &devR, &s2))) return rc;
+    if (devL != devR) { set_last_error("stereo matching needs both pyramids on one device"); return MSORB_E_INVALID; }
+    if (pl.nlevels != pr.nlevels || pl.lv[0].w != pr.lv[0].w || pl.lv[0].h != pr.lv[0].h) {
+        set_last_error("left/right pyramids differ in geometry");
+        return MSORB_E_INVALID;
+    }
+    if (n_oob) *n_oob = 0;
+    if (nL == 0) return MSORB_OK;
+    HIPCHK(hipSetDevice(devL));
+    for (int i = 0; i < nL; i++)
+        if (kpsL[i].octave < 0 || kpsL[i].octave >= pl.nlevels) return MSORB_E_INVALID;
+    for (int i = 0; i < nR; i++)
+        if (kpsR[i].octave < 0 || kpsR[i].octave >= pl.nlevels) return MSORB_E_INVALID;
+    DBuf<msorb_keypoint> dkl, dkr;
+    DBuf<uint8_t> ddl, ddr;
+    DBuf<float> dout;
+    DBuf<int> dint;
+    if ((rc = dkl.ensure(nL)) || (rc = dkr.ensure(nR)) || (rc = ddl.ensure((size_t)nL * 32)) ||
+        (rc = ddr.ensure((size_t)nR * 32)) || (rc = dout.ensure((size_t)2 * nL)) || (rc = dint.ensure((size_t)nL + 1)))
+        return rc;
+    auto cleanup = [&] { dkl.release(); dkr.release(); ddl.release(); ddr.release(); dout.release(); dint.release(); };
+    std::vector<int> sad(nL + 1);
+    hipError_t e = hipMemcpyAsync(dkl.p, kpsL, (size_t)nL * sizeof(msorb_keypoint), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(ddl.p, descL, (size_t)nL * 32, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && nR) e = hipMemcpyAsync(dkr.p, kpsR, (size_t)nR * sizeof(msorb_keypoint), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && nR) e = hipMemcpyAsync(ddr.p, descR, (size_t)nR * 32, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(dint.p + nL, 0, sizeof(int), s);
+    if (e == hipSuccess) {
+        StereoArgs a{};
+        a.kpL = dkl.p; a.kpR = dkr.p; a.descL = ddl.p; a.descR = ddr.p;
+        a.nL = nL; a.nR = nR; a.rows0 = pl.lv[0].h;
+        for (int l = 0; l < pl.nlevels; l++) {
+            a.pyrL[l] = pl.lv[l].base; a.pyrR[l] = pr.lv[l].base;
+            a.pitchL[l] = pl.lv[l].pitch; a.pitchR[l] = pr.lv[l].pitch;
+            a.rows[l] = pl.lv[l].h; a.cols[l] = pl.lv[l].w;
+            a.scale[l] = sc.scale[l]; a.inv_scale[l] = inv_scale[l];
+        }
+        a.mb = mb; a.mbf = mbf;
+        a.u_right = dout.p; a.depth = dout.p + nL; a.sad = dint.p; a.n_oob = dint.p + nL;
+        launch_stereo_match(a, s);
+        e = hipMemcpyAsync(u_right, dout.p, (size_t)nL * sizeof(float), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(depth, dout.p + nL, (size_t)nL * sizeof(float), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(sad.data(), dint.p, (size_t)(nL + 1) * sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    cleanup();
+    if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return MSORB_E_HIP; }
+    if (n_oob) *n_oob = sad[nL];
+    // median-based rejection, Frame.cc:899-912 (serial; vDistIdx is built in ascending iL order)
+    std::vector<std::pair<int, int>> vDistIdx;
+    for (int i = 0; i < nL; i++)
+        if (sad[i] >= 0) vDistIdx.push_back(std::make_pair(sad[i], i));
+    if (vDistIdx.empty()) return MSORB_OK;
+    std::sort(vDistIdx.begin(), vDistIdx.end());
+    const float median = vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+        if (vDistIdx[i].first < thDist) break;
+        u_right[vDistIdx[i].second] = -1;
+        depth[vDistIdx[i].second] = -1;
+    }
+    return MSORB_OK;
+}
+
+}  // extern "C"

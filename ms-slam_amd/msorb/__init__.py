@@ -217,3 +217,136 @@ def distribute_quadtree(xs, ys, scores, min_x, max_x, min_y, max_y, n_features):
     _check(lib().msorb_distribute_quadtree(_np_ptr(xs), _np_ptr(ys), _np_ptr(scores), n, min_x, max_x, min_y, max_y,
                                            n_features, _np_ptr(kept), len(kept), C.byref(nk)), "distribute_quadtree")
     return kept[:nk.value].copy()
+
+
+# ------------------------------------------------------------------------------------------------
+# Matcher (include/msorb.h "Matcher" section)
+# ------------------------------------------------------------------------------------------------
+EXPORTS = EXPORTS + (
+    "msorb_frame_create", "msorb_frame_destroy", "msorb_frame_set", "msorb_frame_features_in_area",
+    "msorb_search_by_projection_mps", "msorb_search_by_projection_frames", "msorb_hamming_top2",
+    "msorb_stereo_matches", "msorb_three_maxima",
+)
+TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30   # ORBmatcher.cc:35-37
+
+
+def _setup_matcher(L):
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    L.msorb_frame_create.argtypes = [ci, C.POINTER(vp)]
+    L.msorb_frame_destroy.argtypes = [vp]
+    L.msorb_frame_destroy.restype = None
+    L.msorb_frame_set.argtypes = [vp, vp, ci, vp, vp, cf, cf, cf, cf, vp, ci]
+    L.msorb_frame_features_in_area.argtypes = [vp, cf, cf, cf, ci, ci, vp, ci, C.POINTER(ci)]
+    L.msorb_search_by_projection_mps.argtypes = [vp, ci] + [vp] * 12 + [cf, ci, cf, cf, C.POINTER(ci)]
+    L.msorb_search_by_projection_frames.argtypes = [vp, ci] + [vp] * 10 + [cf, ci, ci, ci, C.POINTER(ci)]
+    L.msorb_hamming_top2.argtypes = [ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp]
+    L.msorb_stereo_matches.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, cf, cf, vp, vp, C.POINTER(ci)]
+    L.msorb_three_maxima.argtypes = [vp, ci, vp]
+
+
+_matcher_ready = False
+
+
+def _mlib():
+    global _matcher_ready
+    L = lib()
+    if not _matcher_ready:
+        _setup_matcher(L)
+        _matcher_ready = True
+    return L
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dt)
+
+
+class Frame:
+    """The members of ORB_SLAM3::Frame that ORBmatcher reads (mvKeysUn, mDescriptors, mvuRight, mGrid,
+    image bounds, mvScaleFactors), resident on the device."""
+
+    def __init__(self, keypoints, descriptors, u_right, bounds, scale_factors, device=0):
+        self.L = _mlib()
+        h = C.c_void_p()
+        _check(self.L.msorb_frame_create(device, C.byref(h)), "msorb_frame_create")
+        self.h = h
+        self.kps = _c(keypoints, KP_DTYPE)
+        self.desc = _c(descriptors, np.uint8)
+        self.n = len(self.kps)
+        ur = None if u_right is None else _c(u_right, np.float32)
+        sf = _c(scale_factors, np.float32)
+        min_x, max_x, min_y, max_y = bounds
+        _check(self.L.msorb_frame_set(self.h, _np_ptr(self.kps), self.n, _np_ptr(self.desc),
+                                      None if ur is None else _np_ptr(ur), min_x, max_x, min_y, max_y, _np_ptr(sf),
+                                      len(sf)), "msorb_frame_set")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.msorb_frame_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def GetFeaturesInArea(self, x, y, r, minLevel=-1, maxLevel=-1):
+        out = np.zeros(max(self.n, 1), np.int32)
+        n = C.c_int()
+        _check(self.L.msorb_frame_features_in_area(self.h, x, y, r, minLevel, maxLevel, _np_ptr(out), len(out),
+                                                   C.byref(n)), "features_in_area")
+        return out[:n.value].copy()
+
+    def SearchByProjection_mps(self, mp, frame_mp, th, bFarPoints=False, thFarPoints=50.0, nnratio=0.8):
+        """ORBmatcher(nnratio).SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints); mp is a dict of
+        per-map-point arrays (see include/msorb.h); frame_mp is updated in place. Returns nmatches."""
+        M = len(mp["proj_x"])
+        arrs = [_c(mp["track_in_view"], np.uint8), _c(mp["bad"], np.uint8), _c(mp["sparsified"], np.uint8),
+                _c(mp["proj_x"], np.float32), _c(mp["proj_y"], np.float32), _c(mp["proj_xr"], np.float32),
+                _c(mp["track_depth"], np.float32), _c(mp["level"], np.int32), _c(mp["view_cos"], np.float32),
+                _c(mp["desc"], np.uint8), _c(mp["obs"], np.int32)]
+        assert frame_mp.dtype == np.int32 and frame_mp.flags.c_contiguous
+        nm = C.c_int()
+        _check(self.L.msorb_search_by_projection_mps(self.h, M, *[_np_ptr(a) for a in arrs], _np_ptr(frame_mp), th,
+                                                     int(bFarPoints), thFarPoints, nnratio, C.byref(nm)),
+               "search_by_projection_mps")
+        return nm.value
+
+    def SearchByProjection_frames(self, last, cur_mp, th, forward=False, backward=False, check_orientation=True):
+        NL = len(last["u"])
+        arrs = [_c(last["valid"], np.uint8), _c(last["u"], np.float32), _c(last["v"], np.float32),
+                _c(last["ur"], np.float32), _c(last["octave"], np.int32), _c(last["angle"], np.float32),
+                _c(last["desc"], np.uint8), _c(last["mp"], np.int32), _c(last["obs"], np.int32)]
+        assert cur_mp.dtype == np.int32 and cur_mp.flags.c_contiguous
+        nm = C.c_int()
+        _check(self.L.msorb_search_by_projection_frames(self.h, NL, *[_np_ptr(a) for a in arrs], _np_ptr(cur_mp), th,
+                                                        int(forward), int(backward), int(check_orientation),
+                                                        C.byref(nm)), "search_by_projection_frames")
+        return nm.value
+
+
+def hamming_top2(query_desc, train_desc, cand_begin, cand_idx, device=0):
+    q, t = _c(query_desc, np.uint8), _c(train_desc, np.uint8)
+    cb, ci_ = _c(cand_begin, np.int32), _c(cand_idx, np.int32)
+    nq = len(q)
+    outs = [np.zeros(nq, np.int32) for _ in range(4)]
+    _check(_mlib().msorb_hamming_top2(device, _np_ptr(q), nq, _np_ptr(t), len(t), _np_ptr(cb), _np_ptr(ci_),
+                                      *[_np_ptr(o) for o in outs]), "hamming_top2")
+    return outs
+
+
+def stereo_matches(ex_left, ex_right, kps_l, desc_l, kps_r, desc_r, mb, mbf):
+    """Frame::ComputeStereoMatches on the pyramids of the two extractors' last __call__.
+    -> (mvuRight, mvDepth, n_oob)"""
+    kl, kr = _c(kps_l, KP_DTYPE), _c(kps_r, KP_DTYPE)
+    dl, dr = _c(desc_l, np.uint8), _c(desc_r, np.uint8)
+    ur = np.zeros(len(kl), np.float32)
+    dp = np.zeros(len(kl), np.float32)
+    oob = C.c_int()
+    _check(_mlib().msorb_stereo_matches(ex_left.h, ex_right.h, _np_ptr(kl), len(kl), _np_ptr(dl), _np_ptr(kr), len(kr),
+                                        _np_ptr(dr), mb, mbf, _np_ptr(ur), _np_ptr(dp), C.byref(oob)),
+           "stereo_matches")
+    return ur, dp, oob.value
+
+
+def three_maxima(sizes):
+    s = _c(sizes, np.int32)
+    ind = np.zeros(3, np.int32)
+    _check(_mlib().msorb_three_maxima(_np_ptr(s), len(s), _np_ptr(ind)), "three_maxima")
+    return ind

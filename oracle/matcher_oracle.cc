@@ -1,0 +1,376 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see cvprims.h header).
+//
+// CPU restatement of the Hamming-matching path of fishmarch/MS-SLAM on flat stand-in arrays (the
+// reference's Frame/KeyFrame/MapPoint need OpenCV+Eigen+Sophus and cannot be compiled here, SURVEY.md
+// §8c).  Hamming distance is exact integer arithmetic, so the parity content is the candidate SET, the
+// candidate ORDER (tie-breaks) and the accept rules; each function cites the lines it follows.
+// Only the rectified-stereo branch (Nleft == -1) is restated: every BASELINE config takes it
+// (SURVEY.md §3.1); the fisheye branches (ORBmatcher.cc:144-210, 2059-2124) are out of scope.
+//
+// PARITY UNPINNED for anything float that the reference leaves to Eigen/Sophus (projection of 3-D
+// points): those steps stay on the caller's side of the boundary — the functions here start from the
+// projected coordinates, as the C ABI does.
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+namespace orc {
+
+static const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;  // ORBmatcher.cc:35-37
+static const int GRID_COLS = 64, GRID_ROWS = 48;                  // Frame.h:44-45
+
+struct KeyPoint { float x, y, size, angle, response; int octave, class_id; };
+
+// ORBmatcher::DescriptorDistance, ORBmatcher.cc:2323-2339 (SWAR popcount over 8 x 32 bit)
+static int descriptor_distance(const uint8_t* a, const uint8_t* b) {
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t pa, pb;
+        memcpy(&pa, a + 4 * i, 4);
+        memcpy(&pb, b + 4 * i, 4);
+        unsigned int v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+// Stand-in for the parts of Frame the matcher touches.
+struct FrameSoA {
+    int N = 0;
+    std::vector<KeyPoint> kps;     // mvKeysUn (== mvKeys: rectified, k1 == 0, Frame.cc:681-685)
+    std::vector<uint8_t> desc;     // mDescriptors, N x 32
+    std::vector<float> uRight;     // mvuRight
+    float minX, minY, maxX, maxY, gridWInv, gridHInv;  // mnMinX.. / mfGridElementWidthInv.. (Frame.cc:147-148)
+    std::vector<float> scaleFactors;
+    std::vector<int> grid[GRID_COLS][GRID_ROWS];
+
+    bool pos_in_grid(const KeyPoint& kp, int& px, int& py) const {  // Frame.cc:657-667
+        px = (int)std::round((kp.x - minX) * gridWInv);
+        py = (int)std::round((kp.y - minY) * gridHInv);
+        return !(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS);
+    }
+    void assign_features_to_grid() {  // Frame.cc:385-416
+        for (int i = 0; i < N; i++) {
+            int gx, gy;
+            if (pos_in_grid(kps[i], gx, gy)) grid[gx][gy].push_back(i);
+        }
+    }
+    // Frame::GetFeaturesInArea, Frame.cc:589-655
+    std::vector<size_t> features_in_area(float x, float y, float r, int minLevel, int maxLevel) const {
+        std::vector<size_t> idx;
+        const float factorX = r, factorY = r;
+        const int nMinCellX = std::max(0, (int)std::floor((x - minX - factorX) * gridWInv));
+        if (nMinCellX >= GRID_COLS) return idx;
+        const int nMaxCellX = std::min(GRID_COLS - 1, (int)std::ceil((x - minX + factorX) * gridWInv));
+        if (nMaxCellX < 0) return idx;
+        const int nMinCellY = std::max(0, (int)std::floor((y - minY - factorY) * gridHInv));
+        if (nMinCellY >= GRID_ROWS) return idx;
+        const int nMaxCellY = std::min(GRID_ROWS - 1, (int)std::ceil((y - minY + factorY) * gridHInv));
+        if (nMaxCellY < 0) return idx;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                const std::vector<int>& cell = grid[ix][iy];
+                for (size_t j = 0; j < cell.size(); j++) {
+                    const KeyPoint& kp = kps[cell[j]];
+                    if (bCheckLevels) {
+                        if (kp.octave < minLevel) continue;
+                        if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                    }
+                    const float distx = kp.x - x, disty = kp.y - y;
+                    if (std::fabs(distx) < factorX && std::fabs(disty) < factorY) idx.push_back(cell[j]);
+                }
+            }
+        return idx;
+    }
+};
+
+// ORBmatcher::ComputeThreeMaxima, ORBmatcher.cc:2277-2318
+static void three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+}  // namespace orc
+
+using orc::FrameSoA;
+using orc::KeyPoint;
+
+extern "C" {
+
+int orc_descriptor_distance(const uint8_t* a, const uint8_t* b) { return orc::descriptor_distance(a, b); }
+
+void* orc_frame_create(const void* kps, int N, const uint8_t* desc, const float* uRight, float minX, float maxX,
+                       float minY, float maxY, const float* scaleFactors, int nlevels) {
+    FrameSoA* f = new FrameSoA();
+    f->N = N;
+    f->kps.assign((const KeyPoint*)kps, (const KeyPoint*)kps + N);
+    f->desc.assign(desc, desc + (size_t)N * 32);
+    if (uRight) f->uRight.assign(uRight, uRight + N); else f->uRight.assign(N, -1.0f);
+    f->minX = minX; f->maxX = maxX; f->minY = minY; f->maxY = maxY;
+    f->gridWInv = static_cast<float>(orc::GRID_COLS) / (maxX - minX);
+    f->gridHInv = static_cast<float>(orc::GRID_ROWS) / (maxY - minY);
+    f->scaleFactors.assign(scaleFactors, scaleFactors + nlevels);
+    f->assign_features_to_grid();
+    return f;
+}
+void orc_frame_destroy(void* f) { delete (FrameSoA*)f; }
+
+int orc_features_in_area(void* fp, float x, float y, float r, int minLevel, int maxLevel, int* out, int cap) {
+    const std::vector<size_t> v = ((FrameSoA*)fp)->features_in_area(x, y, r, minLevel, maxLevel);
+    for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = (int)v[i];
+    return (int)v.size();
+}
+
+// Grid cell of every keypoint (-1 when outside), for the rank key of SURVEY.md B.1.
+void orc_frame_cells(void* fp, int* cx, int* cy) {
+    FrameSoA* f = (FrameSoA*)fp;
+    for (int i = 0; i < f->N; i++) {
+        int gx, gy;
+        if (f->pos_in_grid(f->kps[i], gx, gy)) { cx[i] = gx; cy[i] = gy; } else { cx[i] = cy[i] = -1; }
+    }
+}
+
+// ORBmatcher::SearchByProjection(Frame&, vector<MapPoint>, th, bFarPoints, thFarPoints), ORBmatcher.cc:43-142
+// (left-eye / rectified part).  Map point table of M entries, visited in index order:
+//   track_in_view  mbTrackInView          bad          isBad()              sparsified  mbSparsified
+//   proj_x/y/xr    mTrackProjX/Y/XR       track_depth  mTrackDepth          level       mnTrackScaleLevel
+//   view_cos       mTrackViewCos          mp_desc      GetDescriptor()      obs         Observations()
+// frame_mp[N]: F.mvpMapPoints as map-point ids (-1 = empty); updated in place exactly like the reference
+// (a later map point sees earlier assignments).  Returns nmatches.
+int orc_search_by_projection_mps(void* fp, int M, const uint8_t* track_in_view, const uint8_t* bad,
+                                 const uint8_t* sparsified, const float* proj_x, const float* proj_y,
+                                 const float* proj_xr, const float* track_depth, const int* level,
+                                 const float* view_cos, const uint8_t* mp_desc, const int* obs, int* frame_mp,
+                                 float th, int bFarPoints, float thFarPoints, float nnratio) {
+    FrameSoA& F = *(FrameSoA*)fp;
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    for (int iMP = 0; iMP < M; iMP++) {
+        if (!track_in_view[iMP]) continue;
+        if (bFarPoints && track_depth[iMP] > thFarPoints) continue;
+        if (bad[iMP]) continue;
+        const int nPredictedLevel = level[iMP];
+        float r = (view_cos[iMP] > 0.998) ? 2.5 : 4.0;  // RadiusByViewingCos, :215-221 (float vs double compare)
+        if (bFactor) r *= th;
+        const std::vector<size_t> vIndices = F.features_in_area(
+            proj_x[iMP], proj_y[iMP], r * F.scaleFactors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel);
+        if (vIndices.empty()) continue;
+        const uint8_t* MPdescriptor = mp_desc + (size_t)iMP * 32;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (size_t k = 0; k < vIndices.size(); k++) {
+            const size_t idx = vIndices[k];
+            if (frame_mp[idx] >= 0 && !sparsified[iMP])
+                if (obs[frame_mp[idx]] > 0) continue;
+            if (F.uRight[idx] > 0) {
+                const float er = std::fabs(proj_xr[iMP] - F.uRight[idx]);
+                if (er > r * F.scaleFactors[nPredictedLevel]) continue;
+            }
+            const int dist = orc::descriptor_distance(MPdescriptor, &F.desc[idx * 32]);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist;
+                bestLevel2 = bestLevel; bestLevel = F.kps[idx].octave;
+                bestIdx = (int)idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = F.kps[idx].octave;
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= orc::TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+                frame_mp[bestIdx] = iMP;
+                nmatches++;
+            }
+        }
+    }
+    return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono), ORBmatcher.cc:1941-2057 and
+// 2129-2152, from the projected coordinates onward.  One entry per last-frame keypoint i:
+//   valid[i]   pMP exists, !mvbOutlier, invzc >= 0, uv inside the image bounds (:1961-1983)
+//   u,v        uv = mpCamera->project(Tcw * x3Dw)        ur = uv(0) - mbf*invzc (:2018)
+//   last_octave, last_angle   LastFrame.mvKeys(Un)[i]    mp_desc[i] = pMP->GetDescriptor()
+//   last_mp[i] map point id written into cur_mp;  obs[id] = Observations() of map point id
+// cur_mp[N]: CurrentFrame.mvpMapPoints as ids (-1 empty), updated in place.  Returns nmatches.
+int orc_search_by_projection_frames(void* fp, int NL, const uint8_t* valid, const float* u, const float* v,
+                                    const float* ur, const int* last_octave, const float* last_angle,
+                                    const uint8_t* mp_desc, const int* last_mp, const int* obs, int* cur_mp,
+                                    float th, int bForward, int bBackward, int check_orientation) {
+    FrameSoA& C = *(FrameSoA*)fp;
+    int nmatches = 0;
+    std::vector<int> rotHist[orc::HISTO_LENGTH];
+    const float factor = 1.0f / orc::HISTO_LENGTH;
+    for (int i = 0; i < NL; i++) {
+        if (!valid[i]) continue;
+        const int nLastOctave = last_octave[i];
+        const float radius = th * C.scaleFactors[nLastOctave];
+        std::vector<size_t> vIndices2;
+        if (bForward) vIndices2 = C.features_in_area(u[i], v[i], radius, nLastOctave, -1);
+        else if (bBackward) vIndices2 = C.features_in_area(u[i], v[i], radius, 0, nLastOctave);
+        else vIndices2 = C.features_in_area(u[i], v[i], radius, nLastOctave - 1, nLastOctave + 1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* dMP = mp_desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx2 = -1;
+        for (size_t k = 0; k < vIndices2.size(); k++) {
+            const size_t i2 = vIndices2[k];
+            if (cur_mp[i2] >= 0)
+                if (obs[cur_mp[i2]] > 0) continue;
+            if (C.uRight[i2] > 0) {
+                const float er = std::fabs(ur[i] - C.uRight[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = orc::descriptor_distance(dMP, &C.desc[i2 * 32]);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+        }
+        if (bestDist <= orc::TH_HIGH) {
+            cur_mp[bestIdx2] = last_mp[i];
+            nmatches++;
+            if (check_orientation) {
+                float rot = last_angle[i] - C.kps[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == orc::HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (check_orientation) {  // :2129-2149
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc::three_maxima(rotHist, orc::HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < orc::HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0; j < rotHist[i].size(); j++) { cur_mp[rotHist[i][j]] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
+void orc_three_maxima(const int* sizes, int L, int* ind) {
+    std::vector<std::vector<int>> h(L);
+    for (int i = 0; i < L; i++) h[i].resize(sizes[i]);
+    ind[0] = ind[1] = ind[2] = -1;
+    orc::three_maxima(h.data(), L, ind[0], ind[1], ind[2]);
+}
+
+// Frame::ComputeStereoMatches, Frame.cc:743-913.  left/right: keypoints + descriptors of the two eyes;
+// pyrL/pyrR: the extractors' mvImagePyramid planes (interior pixels; plane l has rows[l] x cols[l], row
+// stride strides[l]).  Outputs mvuRight / mvDepth (N entries, -1 = no match).
+// The reference indexes cv::Mat ranges unchecked against the interior (an out-of-range window would trip
+// a CV_Assert there); this restatement skips such a keypoint instead and reports the count in *n_oob.
+void orc_compute_stereo_matches(const void* kpsL_, int N, const uint8_t* descL, const void* kpsR_, int Nr,
+                                const uint8_t* descR, const uint8_t* const* pyrL, const uint8_t* const* pyrR,
+                                const int* rows, const int* cols, const int* strides, const float* scaleFactors,
+                                const float* invScaleFactors, float mb, float mbf, float* uRight, float* depth,
+                                int* n_oob) {
+    const KeyPoint* kpsL = (const KeyPoint*)kpsL_;
+    const KeyPoint* kpsR = (const KeyPoint*)kpsR_;
+    for (int i = 0; i < N; i++) { uRight[i] = -1.0f; depth[i] = -1.0f; }
+    if (n_oob) *n_oob = 0;
+    const int thOrbDist = (orc::TH_HIGH + orc::TH_LOW) / 2;
+    const int nRows = rows[0];
+    std::vector<std::vector<size_t>> vRowIndices(nRows);
+    for (int iR = 0; iR < Nr; iR++) {  // :758-771
+        const KeyPoint& kp = kpsR[iR];
+        const float kpY = kp.y;
+        const float r = 2.0f * scaleFactors[kp.octave];
+        const int maxr = (int)std::ceil(kpY + r);
+        const int minr = (int)std::floor(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++)
+            if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back(iR);  // guard: reference indexes unchecked
+    }
+    const float minZ = mb, minD = 0, maxD = mbf / minZ;
+    std::vector<std::pair<int, int>> vDistIdx;
+    for (int iL = 0; iL < N; iL++) {
+        const KeyPoint& kpL = kpsL[iL];
+        const int levelL = kpL.octave;
+        const float vL = kpL.y, uL = kpL.x;
+        const int row = (int)vL;  // vRowIndices[vL]: float -> size_t truncation
+        if (row < 0 || row >= nRows) continue;
+        const std::vector<size_t>& vCandidates = vRowIndices[row];
+        if (vCandidates.empty()) continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = orc::TH_HIGH;
+        size_t bestIdxR = 0;
+        const uint8_t* dL = descL + (size_t)iL * 32;
+        for (size_t iC = 0; iC < vCandidates.size(); iC++) {
+            const size_t iR = vCandidates[iC];
+            const KeyPoint& kpR = kpsR[iR];
+            if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+            const float uR = kpR.x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = orc::descriptor_distance(dL, descR + iR * 32);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        if (bestDist < thOrbDist) {  // :829-897
+            const float uR0 = kpsR[bestIdxR].x;
+            const float scaleFactor = invScaleFactors[kpL.octave];
+            const float scaleduL = std::round(kpL.x * scaleFactor);
+            const float scaledvL = std::round(kpL.y * scaleFactor);
+            const float scaleduR0 = std::round(uR0 * scaleFactor);
+            const int w = 5, L = 5;
+            const int lv = kpL.octave;
+            int bestDistS = INT_MAX, bestincR = 0;
+            float vDists[2 * 5 + 1];
+            const float iniu = scaleduR0 + L - w;
+            const float endu = scaleduR0 + L + w + 1;
+            if (iniu < 0 || endu >= cols[lv]) continue;
+            const int y0 = (int)(scaledvL - w), xL0 = (int)(scaleduL - w);
+            const int xR0 = (int)(scaleduR0 - L - w);
+            if (y0 < 0 || y0 + 2 * w + 1 > rows[lv] || xL0 < 0 || xL0 + 2 * w + 1 > cols[lv] || xR0 < 0 ||
+                (int)(scaleduR0 + L + w + 1) > cols[lv]) {
+                if (n_oob) (*n_oob)++;
+                continue;
+            }
+            for (int incR = -L; incR <= +L; incR++) {
+                int sad = 0;  // cv::norm(IL, IR, NORM_L1) on 11x11 8-bit windows
+                for (int yy = 0; yy < 2 * w + 1; yy++) {
+                    const uint8_t* pl = pyrL[lv] + (size_t)(y0 + yy) * strides[lv] + xL0;
+                    const uint8_t* pr = pyrR[lv] + (size_t)(y0 + yy) * strides[lv] + (int)(scaleduR0 + incR - w);
+                    for (int xx = 0; xx < 2 * w + 1; xx++) sad += std::abs((int)pl[xx] - (int)pr[xx]);
+                }
+                const float dist = (float)(double)sad;
+                if (dist < bestDistS) { bestDistS = dist; bestincR = incR; }
+                vDists[L + incR] = dist;
+            }
+            if (bestincR == -L || bestincR == L) continue;
+            const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = scaleFactors[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+            float disparity = (uL - bestuR);
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) { disparity = 0.01; bestuR = uL - 0.01; }
+                depth[iL] = mbf / disparity;
+                uRight[iL] = bestuR;
+                vDistIdx.push_back(std::pair<int, int>(bestDistS, iL));
+            }
+        }
+    }
+    if (vDistIdx.empty()) return;  // the reference reads vDistIdx[0] of an empty vector here (UB)
+    std::sort(vDistIdx.begin(), vDistIdx.end());  // :899-912
+    const float median = vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+        if (vDistIdx[i].first < thDist) break;
+        uRight[vDistIdx[i].second] = -1;
+        depth[vDistIdx[i].second] = -1;
+    }
+}
+
+}  // extern "C"

@@ -150,3 +150,104 @@ def distribute_quadtree(xs, ys, resp, minX, maxX, minY, maxY, N):
     m = lib().orc_distribute_quadtree(_ptr(xs), _ptr(ys), _ptr(resp), n, minX, maxX, minY, maxY, N, _ptr(ox),
                                       _ptr(oy), _ptr(orr), cap)
     return np.stack([ox[:m], oy[:m], orr[:m]], 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# matcher oracle (oracle/matcher_oracle.cc)
+# ------------------------------------------------------------------------------------------------
+_mready = False
+
+
+def _mlib():
+    global _mready
+    L = lib()
+    if not _mready:
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        L.orc_descriptor_distance.argtypes = [vp, vp]
+        L.orc_frame_create.restype = vp
+        L.orc_frame_create.argtypes = [vp, ci, vp, vp, cf, cf, cf, cf, vp, ci]
+        L.orc_frame_destroy.argtypes = [vp]
+        L.orc_features_in_area.argtypes = [vp, cf, cf, cf, ci, ci, vp, ci]
+        L.orc_search_by_projection_mps.argtypes = [vp, ci] + [vp] * 12 + [cf, ci, cf, cf]
+        L.orc_search_by_projection_frames.argtypes = [vp, ci] + [vp] * 10 + [cf, ci, ci, ci]
+        L.orc_three_maxima.argtypes = [vp, ci, vp]
+        L.orc_compute_stereo_matches.argtypes = [vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp]
+        _mready = True
+    return L
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dt)
+
+
+def descriptor_distance(a, b):
+    a, b = _c(a, np.uint8), _c(b, np.uint8)
+    return _mlib().orc_descriptor_distance(_ptr(a), _ptr(b))
+
+
+class OracleFrame:
+    def __init__(self, keypoints, descriptors, u_right, bounds, scale_factors):
+        self.L = _mlib()
+        self.kps = _c(keypoints, KP_DTYPE)
+        self.desc = _c(descriptors, np.uint8)
+        self.n = len(self.kps)
+        ur = None if u_right is None else _c(u_right, np.float32)
+        sf = _c(scale_factors, np.float32)
+        self.h = self.L.orc_frame_create(_ptr(self.kps), self.n, _ptr(self.desc), None if ur is None else _ptr(ur),
+                                         bounds[0], bounds[1], bounds[2], bounds[3], _ptr(sf), len(sf))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_frame_destroy(self.h)
+            self.h = None
+
+    def GetFeaturesInArea(self, x, y, r, minLevel=-1, maxLevel=-1):
+        out = np.zeros(max(self.n, 1), np.int32)
+        n = self.L.orc_features_in_area(self.h, x, y, r, minLevel, maxLevel, _ptr(out), len(out))
+        return out[:n].copy()
+
+    def SearchByProjection_mps(self, mp, frame_mp, th, bFarPoints=False, thFarPoints=50.0, nnratio=0.8):
+        M = len(mp["proj_x"])
+        arrs = [_c(mp["track_in_view"], np.uint8), _c(mp["bad"], np.uint8), _c(mp["sparsified"], np.uint8),
+                _c(mp["proj_x"], np.float32), _c(mp["proj_y"], np.float32), _c(mp["proj_xr"], np.float32),
+                _c(mp["track_depth"], np.float32), _c(mp["level"], np.int32), _c(mp["view_cos"], np.float32),
+                _c(mp["desc"], np.uint8), _c(mp["obs"], np.int32)]
+        return self.L.orc_search_by_projection_mps(self.h, M, *[_ptr(a) for a in arrs], _ptr(frame_mp), th,
+                                                   int(bFarPoints), thFarPoints, nnratio)
+
+    def SearchByProjection_frames(self, last, cur_mp, th, forward=False, backward=False, check_orientation=True):
+        NL = len(last["u"])
+        arrs = [_c(last["valid"], np.uint8), _c(last["u"], np.float32), _c(last["v"], np.float32),
+                _c(last["ur"], np.float32), _c(last["octave"], np.int32), _c(last["angle"], np.float32),
+                _c(last["desc"], np.uint8), _c(last["mp"], np.int32), _c(last["obs"], np.int32)]
+        return self.L.orc_search_by_projection_frames(self.h, NL, *[_ptr(a) for a in arrs], _ptr(cur_mp), th,
+                                                      int(forward), int(backward), int(check_orientation))
+
+
+def three_maxima(sizes):
+    s = _c(sizes, np.int32)
+    ind = np.zeros(3, np.int32)
+    _mlib().orc_three_maxima(_ptr(s), len(s), _ptr(ind))
+    return ind
+
+
+def compute_stereo_matches(kps_l, desc_l, kps_r, desc_r, pyr_l, pyr_r, scale, inv_scale, mb, mbf):
+    """pyr_l / pyr_r: lists of contiguous uint8 planes (interior pixels). -> (mvuRight, mvDepth, n_oob)"""
+    kl, kr = _c(kps_l, KP_DTYPE), _c(kps_r, KP_DTYPE)
+    dl, dr = _c(desc_l, np.uint8), _c(desc_r, np.uint8)
+    pl = [_c(p, np.uint8) for p in pyr_l]
+    pr = [_c(p, np.uint8) for p in pyr_r]
+    n = len(pl)
+    PL = (C.c_void_p * n)(*[p.ctypes.data for p in pl])
+    PR = (C.c_void_p * n)(*[p.ctypes.data for p in pr])
+    rows = np.array([p.shape[0] for p in pl], np.int32)
+    cols = np.array([p.shape[1] for p in pl], np.int32)
+    strides = cols.copy()
+    sc, isc = _c(scale, np.float32), _c(inv_scale, np.float32)
+    ur = np.zeros(len(kl), np.float32)
+    dp = np.zeros(len(kl), np.float32)
+    oob = C.c_int()
+    _mlib().orc_compute_stereo_matches(_ptr(kl), len(kl), _ptr(dl), _ptr(kr), len(kr), _ptr(dr), PL, PR, _ptr(rows),
+                                       _ptr(cols), _ptr(strides), _ptr(sc), _ptr(isc), mb, mbf, _ptr(ur), _ptr(dp),
+                                       C.byref(oob))
+    return ur, dp, oob.value

@@ -1,0 +1,119 @@
+"""GPU parity tests of the matcher path: device kernels + host replay (through the C ABI) vs the CPU oracle.
+Everything here is integer/index work: match indices, counts and the stereo uRight/depth floats must be
+bit-identical."""
+import numpy as np
+import pytest
+
+from msorb import synth
+import matcher_cases as mc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def stereo_frame(msorb_mod, oracle):
+    cfg = synth.KITTI
+    L, R = synth.stereo_pair(11, cfg["rows"], cfg["cols"])
+    exl = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7)
+    exr = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7)
+    _, kl, dl = exl(L)
+    _, kr, dr = exr(R)
+    return dict(cfg=cfg, L=L, R=R, exl=exl, exr=exr, kl=kl, dl=dl, kr=kr, dr=dr, scale=exl.GetScaleFactors(),
+                inv_scale=exl.GetInverseScaleFactors())
+
+
+def test_stereo_matches_bit_exact(msorb_mod, oracle, stereo_frame):
+    s = stereo_frame
+    mbf, mb = mc.KITTI_BF, mc.KITTI_BF / mc.KITTI_FX
+    ur, dp, oob = msorb_mod.stereo_matches(s["exl"], s["exr"], s["kl"], s["dl"], s["kr"], s["dr"], mb, mbf)
+    pl = [s["exl"].pyramid_level(l) for l in range(8)]
+    pr = [s["exr"].pyramid_level(l) for l in range(8)]
+    rur, rdp, roob = oracle.compute_stereo_matches(s["kl"], s["dl"], s["kr"], s["dr"], pl, pr, s["scale"],
+                                                   s["inv_scale"], mb, mbf)
+    assert (rur > 0).sum() > 500
+    assert np.array_equal(ur.view(np.uint32), rur.view(np.uint32))
+    assert np.array_equal(dp.view(np.uint32), rdp.view(np.uint32))
+    assert oob == roob
+    # degenerate: no right keypoints / no left keypoints
+    ur0, dp0, _ = msorb_mod.stereo_matches(s["exl"], s["exr"], s["kl"], s["dl"], s["kr"][:0], s["dr"][:0], mb, mbf)
+    assert np.all(ur0 == -1) and np.all(dp0 == -1)
+    ur1, _, _ = msorb_mod.stereo_matches(s["exl"], s["exr"], s["kl"][:0], s["dl"][:0], s["kr"], s["dr"], mb, mbf)
+    assert len(ur1) == 0
+
+
+def _frames(msorb_mod, oracle, s, ur):
+    bounds = (0.0, float(s["cfg"]["cols"]), 0.0, float(s["cfg"]["rows"]))
+    return (msorb_mod.Frame(s["kl"], s["dl"], ur, bounds, s["scale"]),
+            oracle.OracleFrame(s["kl"], s["dl"], ur, bounds, s["scale"]))
+
+
+def test_features_in_area_order(msorb_mod, oracle, stereo_frame):
+    s = stereo_frame
+    f, rf = _frames(msorb_mod, oracle, s, None)
+    rng = np.random.Generator(np.random.PCG64(5))
+    for _ in range(300):
+        x, y = rng.uniform(-50, 1300), rng.uniform(-50, 420)
+        r = rng.uniform(1, 120)
+        lv = [(-1, -1), (0, 2), (3, -1), (2, 3), (0, 0)][rng.integers(0, 5)]
+        assert np.array_equal(f.GetFeaturesInArea(x, y, r, *lv), rf.GetFeaturesInArea(x, y, r, *lv))
+
+
+@pytest.mark.parametrize("seed,M,th,obs_zero,spars", [(1, 4096, 1.0, 0.15, 0.05), (2, 4096, 3.0, 0.0, 0.0),
+                                                      (3, 6000, 5.0, 0.5, 0.3), (4, 1500, 15.0, 0.1, 0.02)])
+def test_search_by_projection_map_points(msorb_mod, oracle, stereo_frame, seed, M, th, obs_zero, spars):
+    s = stereo_frame
+    rng = np.random.Generator(np.random.PCG64(seed))
+    mbf, mb = mc.KITTI_BF, mc.KITTI_BF / mc.KITTI_FX
+    ur, _, _ = msorb_mod.stereo_matches(s["exl"], s["exr"], s["kl"], s["dl"], s["kr"], s["dr"], mb, mbf)
+    f, rf = _frames(msorb_mod, oracle, s, ur)
+    mp = mc.map_point_table(rng, s["kl"], s["dl"], ur, s["scale"], M, obs_zero, spars)
+    init = np.where(rng.random(len(s["kl"])) < 0.2, rng.integers(0, M, len(s["kl"])), -1).astype(np.int32)
+    got, want = init.copy(), init.copy()
+    n = f.SearchByProjection_mps(mp, got, th, bFarPoints=True, thFarPoints=60.0, nnratio=0.8)
+    rn = rf.SearchByProjection_mps(mp, want, th, bFarPoints=True, thFarPoints=60.0, nnratio=0.8)
+    assert rn > 100
+    assert n == rn and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("seed,NL,th,mode", [(1, 2000, 7.0, "none"), (2, 2000, 15.0, "fwd"), (3, 3000, 14.0, "bwd"),
+                                             (4, 500, 30.0, "none")])
+def test_search_by_projection_last_frame(msorb_mod, oracle, stereo_frame, seed, NL, th, mode):
+    s = stereo_frame
+    rng = np.random.Generator(np.random.PCG64(100 + seed))
+    ur = np.where(rng.random(len(s["kl"])) < 0.6, s["kl"]["x"] - rng.uniform(1, 40, len(s["kl"])), -1).astype(np.float32)
+    f, rf = _frames(msorb_mod, oracle, s, ur)
+    last = mc.last_frame_table(rng, s["kl"], s["dl"], ur, s["scale"], NL)
+    init = np.where(rng.random(len(s["kl"])) < 0.1, rng.integers(0, NL, len(s["kl"])), -1).astype(np.int32)
+    for check in (True, False):
+        got, want = init.copy(), init.copy()
+        kw = dict(forward=mode == "fwd", backward=mode == "bwd", check_orientation=check)
+        n = f.SearchByProjection_frames(last, got, th, **kw)
+        rn = rf.SearchByProjection_frames(last, want, th, **kw)
+        assert n == rn and np.array_equal(got, want)
+    assert rn > 50
+
+
+def test_hamming_top2_lists(msorb_mod, oracle):
+    rng = np.random.Generator(np.random.PCG64(9))
+    T, Q = 1500, 700
+    t = rng.integers(0, 256, (T, 32), dtype=np.uint8)
+    t[100:140] = t[100]                       # exact duplicates -> ties broken by list order
+    q = t[rng.integers(0, T, Q)].copy()
+    q[::3, 5] ^= 0x11
+    lens = rng.integers(0, 90, Q)
+    lens[:5] = [0, 1, 1, 2, 300]
+    cb = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = rng.integers(0, T, cb[-1]).astype(np.int32)
+    bi, bd, si, sd = msorb_mod.hamming_top2(q, t, cb, ci)
+    for i in range(Q):
+        best, bdist, sec, sdist = -1, 256, -1, 256     # ORBmatcher.cc:300-318 idiom
+        for j in ci[cb[i]:cb[i + 1]]:
+            d = oracle.descriptor_distance(q[i], t[j])
+            if d < bdist:
+                sec, sdist = best, bdist
+                best, bdist = j, d
+            elif d < sdist:
+                sec, sdist = j, d
+        assert (bi[i], bd[i], sd[i]) == (best, bdist, sdist)
+        if sec >= 0:
+            assert oracle.descriptor_distance(q[i], t[si[i]]) == sdist
