@@ -116,20 +116,19 @@ def main():
     cap = ex.capacity
     d_kps = torch.empty((n_img, cap, 28), dtype=torch.uint8, device=dev)
     d_desc = torch.empty((n_img, cap, 32), dtype=torch.uint8, device=dev)
-    d_cnt = torch.empty(n_img, dtype=torch.int32, device=dev)
-    if world > 1 and eye == 0:
-        r_kps, r_desc, r_cnt = torch.empty_like(d_kps), torch.empty_like(d_desc), torch.empty_like(d_cnt)
+    from msorb import stereo_split
+    mine = theirs = None
+    if world > 1:
+        mine = stereo_split.FeatureBlock(n_img, cap, dev)
+        d_kps, d_desc = mine.kps, mine.desc          # the extractor writes straight into the send block
+        if eye == 0:
+            theirs = stereo_split.FeatureBlock(n_img, cap, dev)
 
     def step():
         counts, mono, _, _ = ex.extract_batch(images, (0, 0), out=(d_kps, d_desc))
         if world > 1:  # stereo split: right-eye rank -> left-eye rank (replaces the join of Frame.cc:122-125)
-            d_cnt.copy_(torch.from_numpy(counts))
-            partner = rank ^ 1
-            if partner < world:
-                if eye == 1:
-                    dist.send(d_cnt, partner); dist.send(d_kps, partner); dist.send(d_desc, partner)
-                else:
-                    dist.recv(r_cnt, partner); dist.recv(r_kps, partner); dist.recv(r_desc, partner)
+            mine.counts.copy_(torch.from_numpy(counts))
+            stereo_split.exchange(dist, rank, world, mine, theirs)
         return int(counts.sum())
 
     def fence():

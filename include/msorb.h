@@ -175,6 +175,31 @@ int msorb_stereo_matches(msorb_extractor* left, msorb_extractor* right, const ms
 /* ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:2277-2318) on histogram bin sizes; ind[3]. Host only. */
 int msorb_three_maxima(const int* bin_sizes, int n_bins, int* ind);
 
+/* ------------------------------------------------------------------------------------------------
+ * Map sparsification — constraint-matrix assembly of MapSparsification::Sparsifying
+ * (src/MapSparsification.cc:58-151) as CSR, built on the device.  The caller flattens, under the
+ * reference's locks, what the loop reads:
+ *   window keyframe k (vpKFs order) owns slots [kf_slot_begin[k], kf_slot_begin[k+1]) in the grid walk
+ *   order of :82-84 (grid column, grid row, cell index list): slot_point = map point id or -1 (null or
+ *   isBad()), slot_cell = column*rows+row;  point_nobs = Observations(); obs_begin/obs_kf = GetObservations()
+ *   keyframe ids per point; kf_in_window = (mnMapSaprsificationId == mnId); kf_num_mps = GetNumberMPs().
+ * Outputs (host arrays): columns = map points in first-encounter order (col_point, obj_coef = nMaxObs -
+ * Observations()); rows in the order the reference adds constraints: per window keyframe its valid cells
+ * (row_kind 0, rhs 1) then the keyframe row (kind 1, rhs N), then one row per outside keyframe observing a
+ * column point (kind 2, rhs count/GetNumberMPs()*N) in ascending keyframe id (the reference walks a
+ * std::map keyed by shared_ptr there, i.e. run-dependent order).  row_begin has *n_rows+1 entries; col_idx
+ * lists column indices in the order the reference accumulates the terms.  Every row owns one implicit slack
+ * variable (th_grid: binary, cost GridLambda; th: integer 0..1000, cost Lambda) — see INTEGRATION.md for the
+ * GUROBI C-API mapping.  n_max_obs_floor: max Observations() over map points of window keyframes that are in
+ * no grid cell (normally 0).
+ * ---------------------------------------------------------------------------------------------- */
+int msorb_visibility_csr(int device, int n_window_kf, const int* kf_slot_begin, const int* slot_point,
+                         const int* slot_cell, int n_points, const int* point_nobs, const int* obs_begin,
+                         const int* obs_kf, int n_kf_total, const uint8_t* kf_in_window, const int* kf_num_mps, int n,
+                         int n_max_obs_floor, int* n_cols, int* col_point, int cap_cols, int* n_rows, int* row_begin,
+                         int* row_kind, int* row_owner, float* row_rhs, int cap_rows, int* col_idx, int cap_nnz,
+                         int* nnz, float* obj_coef, int* n_max_obs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -350,3 +350,40 @@ def three_maxima(sizes):
     ind = np.zeros(3, np.int32)
     _check(_mlib().msorb_three_maxima(_np_ptr(s), len(s), _np_ptr(ind)), "three_maxima")
     return ind
+
+
+# ------------------------------------------------------------------------------------------------
+# Map sparsification constraint matrix (include/msorb.h)
+# ------------------------------------------------------------------------------------------------
+EXPORTS = EXPORTS + ("msorb_visibility_csr",)
+
+
+def visibility_csr(kf_slot_begin, slot_point, slot_cell, point_nobs, obs_begin, obs_kf, kf_in_window, kf_num_mps, N,
+                   n_max_obs_floor=0, device=0):
+    """MapSparsification::Sparsifying matrix assembly (MapSparsification.cc:58-151) on the device.
+    -> dict(n_cols, col_point, obj_coef, n_rows, row_begin, row_kind, row_owner, row_rhs, col_idx, n_max_obs)"""
+    L = lib()
+    L.msorb_visibility_csr.argtypes = ([C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] +
+                                       [C.c_void_p] * 2 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int] +
+                                       [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 3)
+    ksb, sp, sc = _c(kf_slot_begin, np.int32), _c(slot_point, np.int32), _c(slot_cell, np.int32)
+    pn, ob, ok = _c(point_nobs, np.int32), _c(obs_begin, np.int32), _c(obs_kf, np.int32)
+    kw, km = _c(kf_in_window, np.uint8), _c(kf_num_mps, np.int32)
+    K, S, P, KT = len(ksb) - 1, len(sp), len(pn), len(kw)
+    cap_cols, cap_rows, cap_nnz = S + 1, S + K + KT + 1, 2 * S + len(ok) + 1
+    col_point = np.zeros(cap_cols, np.int32)
+    obj = np.zeros(cap_cols, np.float32)
+    row_begin = np.zeros(cap_rows + 1, np.int32)
+    row_kind, row_owner = np.zeros(cap_rows, np.int32), np.zeros(cap_rows, np.int32)
+    row_rhs = np.zeros(cap_rows, np.float32)
+    col_idx = np.zeros(cap_nnz, np.int32)
+    n_cols, n_rows, nnz, nmax = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    _check(L.msorb_visibility_csr(device, K, _np_ptr(ksb), _np_ptr(sp), _np_ptr(sc), P, _np_ptr(pn), _np_ptr(ob),
+                                  _np_ptr(ok), KT, _np_ptr(kw), _np_ptr(km), N, n_max_obs_floor, C.byref(n_cols),
+                                  _np_ptr(col_point), cap_cols, C.byref(n_rows), _np_ptr(row_begin), _np_ptr(row_kind),
+                                  _np_ptr(row_owner), _np_ptr(row_rhs), cap_rows, _np_ptr(col_idx), cap_nnz,
+                                  C.byref(nnz), _np_ptr(obj), C.byref(nmax)), "msorb_visibility_csr")
+    nc, nr, nz = n_cols.value, n_rows.value, nnz.value
+    return dict(n_cols=nc, col_point=col_point[:nc], obj_coef=obj[:nc], n_rows=nr, row_begin=row_begin[:nr + 1],
+                row_kind=row_kind[:nr], row_owner=row_owner[:nr], row_rhs=row_rhs[:nr], col_idx=col_idx[:nz],
+                n_max_obs=nmax.value)

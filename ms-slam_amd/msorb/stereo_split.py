@@ -1,0 +1,50 @@
+"""2-GPU stereo split (BASELINE.json configs[3]): the left eye's ORBextractor lives on one GPU, the right
+eye's on its partner; after extraction the right-eye rank sends its fixed-capacity feature block
+(counts, keypoints, descriptors) to the left-eye rank over RCCL point-to-point (xGMI), which replaces the
+join of the two extraction threads in Frame.cc:122-125.  No collective on the data path: one send/recv
+pair per step.  Works with any torch.distributed backend (gloo on CPU for the tests)."""
+import torch
+
+
+def eye_of(rank):
+    """0 = left-eye rank (receiver), 1 = right-eye rank (sender)."""
+    return rank % 2
+
+
+def partner_of(rank, world):
+    p = rank ^ 1
+    return p if p < world else None
+
+
+def pair_group(rank):
+    return rank // 2
+
+
+class FeatureBlock:
+    """Fixed-capacity per-step payload: counts[n] int32, keypoints[n,cap,28] u8, descriptors[n,cap,32] u8."""
+
+    def __init__(self, n_images, capacity, device):
+        self.counts = torch.zeros(n_images, dtype=torch.int32, device=device)
+        self.kps = torch.zeros((n_images, capacity, 28), dtype=torch.uint8, device=device)
+        self.desc = torch.zeros((n_images, capacity, 32), dtype=torch.uint8, device=device)
+
+    def tensors(self):
+        return (self.counts, self.kps, self.desc)
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self.tensors())
+
+
+def exchange(dist, rank, world, mine, theirs):
+    """Right-eye ranks send `mine`; left-eye ranks receive into `theirs`.  Returns True if this rank now holds
+    both eyes' features (left-eye rank with a partner)."""
+    p = partner_of(rank, world)
+    if p is None:
+        return False
+    if eye_of(rank) == 1:
+        for t in mine.tensors():
+            dist.send(t, p)
+        return False
+    for t in theirs.tensors():
+        dist.recv(t, p)
+    return True

@@ -251,3 +251,29 @@ def compute_stereo_matches(kps_l, desc_l, kps_r, desc_r, pyr_l, pyr_r, scale, in
                                        _ptr(cols), _ptr(strides), _ptr(sc), _ptr(isc), mb, mbf, _ptr(ur), _ptr(dp),
                                        C.byref(oob))
     return ur, dp, oob.value
+
+
+def visibility_csr(kf_slot_begin, slot_point, slot_cell, point_nobs, obs_begin, obs_kf, kf_in_window, kf_num_mps, N,
+                   n_max_obs_floor=0):
+    """oracle/sparsify_oracle.cc — same outputs as msorb.visibility_csr."""
+    L = lib()
+    L.orc_visibility_csr.argtypes = ([C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] +
+                                     [C.c_void_p] * 2 + [C.c_int, C.c_int] + [C.c_void_p] * 10)
+    ksb, sp, sc = _c(kf_slot_begin, np.int32), _c(slot_point, np.int32), _c(slot_cell, np.int32)
+    pn, ob, ok = _c(point_nobs, np.int32), _c(obs_begin, np.int32), _c(obs_kf, np.int32)
+    kw, km = _c(kf_in_window, np.uint8), _c(kf_num_mps, np.int32)
+    K, S, KT = len(ksb) - 1, len(sp), len(kw)
+    cap_rows, cap_nnz = S + K + KT + 1, 2 * S + len(ok) + 1
+    col_point, obj = np.zeros(S + 1, np.int32), np.zeros(S + 1, np.float32)
+    row_begin = np.zeros(cap_rows + 1, np.int32)
+    row_kind, row_owner, row_rhs = np.zeros(cap_rows, np.int32), np.zeros(cap_rows, np.int32), np.zeros(cap_rows, np.float32)
+    col_idx = np.zeros(cap_nnz, np.int32)
+    n_cols, n_rows, nmax = C.c_int(), C.c_int(), C.c_int()
+    nz = L.orc_visibility_csr(K, _ptr(ksb), _ptr(sp), _ptr(sc), len(pn), _ptr(pn), _ptr(ob), _ptr(ok), KT, _ptr(kw),
+                              _ptr(km), N, n_max_obs_floor, C.byref(n_cols), _ptr(col_point), C.byref(n_rows),
+                              _ptr(row_begin), _ptr(row_kind), _ptr(row_owner), _ptr(row_rhs), _ptr(col_idx), _ptr(obj),
+                              C.byref(nmax))
+    nc, nr = n_cols.value, n_rows.value
+    return dict(n_cols=nc, col_point=col_point[:nc], obj_coef=obj[:nc], n_rows=nr, row_begin=row_begin[:nr + 1],
+                row_kind=row_kind[:nr], row_owner=row_owner[:nr], row_rhs=row_rhs[:nr], col_idx=col_idx[:nz],
+                n_max_obs=nmax.value)
