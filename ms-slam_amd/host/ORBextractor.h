@@ -1,0 +1,55 @@
+// Drop-in replacement for MS-SLAM's include/ORBextractor.h: the same class name, namespace, constructor,
+// call operator, getters and public pyramid member that Tracking.cc (:595-601, :1283-1289) and Frame.cc
+// (:110-125, :418-425, :750, :840-855) use, implemented on libmsorb.so (HIP kernels for gfx950) through the
+// C ABI of include/msorb.h.  Build MS-SLAM with this directory ahead of its own include/ and link -lmsorb;
+// no other source file changes.
+#ifndef ORBEXTRACTOR_H
+#define ORBEXTRACTOR_H
+
+#include <opencv2/opencv.hpp>
+#include <vector>
+
+struct msorb_extractor;
+
+namespace ORB_SLAM3 {
+
+class ORBextractor {
+public:
+    enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+    // Same argument meaning as the reference constructor (ORBextractor.cc:409-412).  The HIP device is taken
+    // from the environment variable MSORB_DEVICE (default 0) so that call sites stay unchanged.
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+    ~ORBextractor();
+    ORBextractor(const ORBextractor&) = delete;
+    ORBextractor& operator=(const ORBextractor&) = delete;
+
+    // ORB features of one 8-bit single-channel image; `mask` is ignored like in the reference.  Returns the
+    // number of keypoints outside vLappingArea (monoIndex), or -1 for an empty image.
+    int operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint>& keypoints,
+                   cv::OutputArray descriptors, std::vector<int>& vLappingArea);
+
+    int GetLevels() { return mLevels; }
+    float GetScaleFactor() { return mScaleFactor; }
+    std::vector<float> GetScaleFactors() { return mvScaleFactor; }
+    std::vector<float> GetInverseScaleFactors() { return mvInvScaleFactor; }
+    std::vector<float> GetScaleSigmaSquares() { return mvLevelSigma2; }
+    std::vector<float> GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+    // Host views of the device pyramid of the last call (interior pixels).  Valid until the next call.
+    std::vector<cv::Mat> mvImagePyramid;
+
+    // The underlying handle, for msorb_stereo_matches() (Frame::ComputeStereoMatches on the device).
+    msorb_extractor* handle() const { return mHandle; }
+
+private:
+    msorb_extractor* mHandle;
+    int mLevels, mCapacity;
+    float mScaleFactor;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    std::vector<unsigned char> mKpScratch;
+};
+
+}  // namespace ORB_SLAM3
+
+#endif
