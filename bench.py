@@ -109,8 +109,13 @@ def main():
     else:
         one_eye = base[eye::2]
         host = np.concatenate([one_eye] * (2 * B // uniq + 1))[:2 * B]
-    images = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
-    n_img = images.shape[0]
+    # device-resident input batch with a 64-byte row pitch (what hipMemcpy2D / a camera DMA would produce);
+    # the API accepts any stride, aligned rows take the fast kernel variants
+    n_img = host.shape[0]
+    pitch = (cfg["cols"] + 63) // 64 * 64
+    storage = torch.zeros((n_img, cfg["rows"], pitch), dtype=torch.uint8, device=dev)
+    images = storage[:, :, :cfg["cols"]]
+    images.copy_(torch.from_numpy(np.ascontiguousarray(host)).to(dev))
 
     ex = msorb.ORBextractor(cfg["nfeatures"], cfg["scale"], cfg["nlevels"], cfg["ini_th"], cfg["min_th"], device=local)
     cap = ex.capacity

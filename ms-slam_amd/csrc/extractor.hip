@@ -296,7 +296,7 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
     mark(3);
     HIPCHK(hipEventRecord(h->ev_compact, s));
     // blur runs on the main stream while the copy stream + host do the selection
-    for (int l = 0; l < nl; l++) launch_gauss7(pyr.lv[l], blur.lv[l], h->d_blur.p + g.lv[l].plane_off, n_images, s);
+    launch_gauss7(pyr, blur, n_images, s);
     mark(4);
 
     const auto t0 = std::chrono::steady_clock::now();

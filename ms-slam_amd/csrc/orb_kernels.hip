@@ -3,12 +3,13 @@
 //   pyr_resize_kernel   ComputePyramid            ORBextractor.cc:1170-1195  (cv::resize INTER_LINEAR, 8-bit)
 //   fast_cells_kernel   cell loop + cv::FAST      ORBextractor.cc:805-872    (FAST-9/16 score, 3x3 NMS, th fallback)
 //   cand_* kernels      vToDistributeKeys order   ORBextractor.cc:863-867    (row-major cell / scan order compaction)
-//   gauss7_kernel       GaussianBlur 7x7 s=2      ORBextractor.cc:1132-1133  (Q8.8 separable, reflect-101)
+//   gauss7_kernel       GaussianBlur 7x7 s=2      ORBextractor.cc:1132-1133  (Q8.8 separable, reflect-101; LDS-free strips)
 //   describe_kernel     IC_Angle + rBRIEF         ORBextractor.cc:76-146,894-895,1138
 //
 // Arithmetic follows SURVEY.md Appendix A / oracle/cvprims.h exactly (bit-exact contract).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "orb_device.h"
 #include "sincosf_restated.h"
@@ -47,174 +48,284 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(LevelView src, LevelVie
 }
 
 // ------------------------------------------------------------------------------------------------
-// FAST-9/16 on one reference cell ROI per workgroup.
-//   phase 0  stage the ROI (<= 76x76 bytes) in LDS
-//   phase 1  cheap necessary test on the two antipodal compass pairs at minTh; survivors -> LDS list
-//   phase 2  full score S = max(A,-B)-1 for survivors only (all lanes busy); S>=minTh -> score plane
+// FAST-9/16 on one reference cell ROI per workgroup (cell loop + cv::FAST, ORBextractor.cc:805-872).
+//   phase 0  stage the ROI (<= 76x76 bytes) in LDS, keeping the global 4-byte column phase so that every
+//            later access to a group of 4 horizontally adjacent pixels is one aligned ds_read_b32
+//   phase 1  per 4-pixel group: cheap necessary test on the two antipodal compass pairs at minTh from five
+//            dwords (rows -3, 0, +3 and the +-3 column shifts by v_alignbyte); every (pixel, polarity) that
+//            passes is appended to an LDS work list (wave prefix sum, one LDS atomic per wave)
+//   phase 2  full arc test for the work list only — all lanes busy; one polarity per entry: a pixel cannot
+//            be a dark and a bright corner at once, so S = A' - 1 with A' = max over the 16 arcs of the min
+//            over 9 contiguous signed contrasts of the entry's polarity (v_min3/v_max3 network)
 //   phase 3  strict 3x3 NMS inside the ROI's detection area; iniTh set if non-empty, else minTh set;
 //            survivors written in scan order (ascending y, then x) to the cell's fixed slot run
 // The FAST score is threshold independent for detected corners (cornerScore returns
 // max(th, A, -B) - 1 and a corner has max(A,-B) > th), so one score plane serves both thresholds:
 // corner at th  <=>  S >= th, and NMS at iniTh keeps exactly the minTh survivors with S >= iniTh.
 // ------------------------------------------------------------------------------------------------
-constexpr int kTileMax = 80;                 // max ROI edge supported (w_cell, h_cell <= 70 + 6)
-constexpr int kTilePitch = kTileMax;         // bytes
-constexpr int kScorePitch = kTileMax;        // (rw-6)+2 <= 72
+constexpr int kTileRows = 77;        // ROI rows <= 76 (+1 spare row for harmless over-reads)
+constexpr int kTilePitch = 84;       // bytes: 3 (column phase) + 76 (ROI) + over-read slack, multiple of 4
+constexpr int kTileFront = 4;        // bytes in front of the tile so that column -4..-1 reads stay in bounds
+constexpr int kScorePitch = 88;      // 4 (apron group) + 4*20 (groups) + 4
+constexpr int kScoreRows = 73;       // detection rows <= 70, +1 apron above, +1 below, +1 spare
+constexpr int kMaxDet = 70;          // max detection width / height
+constexpr int kMaxGroups = 20;       // 4-pixel groups per detection row
+constexpr int kWorkCap = 4096;       // work-list entries; one phase-1 round adds at most 256 * 8
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(a, min(b, c)); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(a, max(b, c)); }
 
-__device__ __forceinline__ int fast_score16(const uint8_t* p /* LDS, centre */) {
+// max over the 16 arcs of 9 contiguous circle pixels of min(sgn * (v - p)); p = LDS pointer to the centre
+__device__ __forceinline__ int fast_arc_contrast(const uint8_t* p, int sgn) {
     // circle offsets (x,y): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
-    const int v = p[0];
+    const int sv = sgn * (int)p[0], ns = -sgn;
     int d[16];
-    d[0] = v - p[3 * kTilePitch];
-    d[1] = v - p[3 * kTilePitch + 1];
-    d[2] = v - p[2 * kTilePitch + 2];
-    d[3] = v - p[1 * kTilePitch + 3];
-    d[4] = v - p[3];
-    d[5] = v - p[-1 * kTilePitch + 3];
-    d[6] = v - p[-2 * kTilePitch + 2];
-    d[7] = v - p[-3 * kTilePitch + 1];
-    d[8] = v - p[-3 * kTilePitch];
-    d[9] = v - p[-3 * kTilePitch - 1];
-    d[10] = v - p[-2 * kTilePitch - 2];
-    d[11] = v - p[-1 * kTilePitch - 3];
-    d[12] = v - p[-3];
-    d[13] = v - p[1 * kTilePitch - 3];
-    d[14] = v - p[2 * kTilePitch - 2];
-    d[15] = v - p[3 * kTilePitch - 1];
-    int mn3[16], mx3[16];
+    d[0] = (int)p[3 * kTilePitch] * ns + sv;
+    d[1] = (int)p[3 * kTilePitch + 1] * ns + sv;
+    d[2] = (int)p[2 * kTilePitch + 2] * ns + sv;
+    d[3] = (int)p[1 * kTilePitch + 3] * ns + sv;
+    d[4] = (int)p[3] * ns + sv;
+    d[5] = (int)p[-1 * kTilePitch + 3] * ns + sv;
+    d[6] = (int)p[-2 * kTilePitch + 2] * ns + sv;
+    d[7] = (int)p[-3 * kTilePitch + 1] * ns + sv;
+    d[8] = (int)p[-3 * kTilePitch] * ns + sv;
+    d[9] = (int)p[-3 * kTilePitch - 1] * ns + sv;
+    d[10] = (int)p[-2 * kTilePitch - 2] * ns + sv;
+    d[11] = (int)p[-1 * kTilePitch - 3] * ns + sv;
+    d[12] = (int)p[-3] * ns + sv;
+    d[13] = (int)p[1 * kTilePitch - 3] * ns + sv;
+    d[14] = (int)p[2 * kTilePitch - 2] * ns + sv;
+    d[15] = (int)p[3 * kTilePitch - 1] * ns + sv;
+    int mn3[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        mn3[i] = min3i(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
-        mx3[i] = max3i(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
-    }
-    int A = -512, B = 512;
+    for (int i = 0; i < 16; i++) mn3[i] = min3i(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
+    int A = -512;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {  // arc i..i+8
-        A = max(A, min3i(mn3[i], mn3[(i + 3) & 15], mn3[(i + 6) & 15]));
-        B = min(B, max3i(mx3[i], mx3[(i + 3) & 15], mx3[(i + 6) & 15]));
+    for (int i = 0; i < 16; i += 2) {  // arcs i..i+8 and i+1..i+9
+        const int a0 = min3i(mn3[i], mn3[(i + 3) & 15], mn3[(i + 6) & 15]);
+        const int a1 = min3i(mn3[(i + 1) & 15], mn3[(i + 4) & 15], mn3[(i + 7) & 15]);
+        A = max3i(A, a0, a1);
     }
-    return max(A, -B) - 1;
+    return A;
 }
 
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ short2v as_s2(uint32_t v) { return __builtin_bit_cast(short2v, v); }
+__device__ __forceinline__ uint32_t as_u32(short2v v) { return __builtin_bit_cast(uint32_t, v); }
+
+constexpr int kMaxRounds = 6;  // tasks per thread: ceil(70 * 20 / 256)
+
+// block-wide exclusive prefix of a per-thread count (4 waves); returns the grand total through *total
+__device__ __forceinline__ int block_excl_scan(int cnt, int lane, int wave, int* wave_tot /* LDS[4] */, int* total) {
+    const int incl = wave_incl_scan(cnt, lane);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const int c = wave_tot[w];
+        if (w < wave) before += c;
+        tot += c;
+    }
+    *total = tot;
+    return before + incl - cnt;
+}
+
+template <bool ALIGNED>
 __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const CellDesc* __restrict__ cells,
                                                          int ini_th, int min_th, int slots_per_image,
                                                          Cand16* __restrict__ slots, int* __restrict__ cell_count,
-                                                         int n_cells) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[kTileMax * kTilePitch];
-    __shared__ uint8_t score[kTileMax * kScorePitch];
-    __shared__ uint16_t surv[(kTileMax - 6) * (kTileMax - 6)];
-    __shared__ int n_surv;
-    __shared__ int wave_cnt[2][4];
+                                                         int n_cells, int debug_stop) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile_mem[kTileFront + kTileRows * kTilePitch + 8];
+    __shared__ __attribute__((aligned(16))) uint8_t score[kScoreRows * kScorePitch];
+    __shared__ uint16_t work[kWorkCap];
+    __shared__ int wave_tot[2][4];
+    uint8_t* const tile = tile_mem + kTileFront;
 
     const int cell_id = blockIdx.x;
     const int img = blockIdx.y;
     const CellDesc cd = cells[cell_id];
     const LevelView lv = pyr.lv[cd.level];
     const int rw = cd.rw, rh = cd.rh;
-    const int dw = rw - 6, dh = rh - 6;  // detection area (FAST skips 3 px on every side of its input)
+    const int dh = rh - 6;                // detection rows (FAST skips 3 px on every side of its input)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ga = cd.x0 & ~3;            // tile column 0 = level column ga (keeps the 4-byte phase)
+    const int x_lo = cd.x0 + 3, x_hi = cd.x0 + rw - 3;
+    const int gx0 = x_lo & ~3;            // first 4-pixel group (may start left of x_lo)
+    const int G = (x_hi - gx0 + 3) >> 2;  // groups per detection row
+    const int c_lo = gx0 - ga;            // tile column of the first group (multiple of 4)
+    const int n_task = dh * G;            // one task = one group of one detection row, scan order
+    const uint32_t magic = ((1u << 20) + G - 1) / G;  // task / G == (task * magic) >> 20 for task < 2^20 / G
+    // balanced consecutive task ranges: thread t owns tasks [t*n/256, (t+1)*n/256)  (<= kMaxRounds each)
+    const int t_begin = (tid * n_task) >> 8, t_end = ((tid + 1) * n_task) >> 8;
 
     // phase 0
-    const uint8_t* src = lv.base + (size_t)img * lv.img_stride + (size_t)cd.y0 * lv.pitch + cd.x0;
-    for (int i = tid; i < rw * rh; i += 256) {
-        const int y = i / rw, x = i - y * rw;
-        tile[y * kTilePitch + x] = src[(size_t)y * lv.pitch + x];
-    }
-    for (int i = tid; i < (dh + 2) * kScorePitch; i += 256) score[i] = 0;
-    if (tid == 0) n_surv = 0;
-    __syncthreads();
-
-    const int n_det = dw * dh;
-    // phase 1
-    for (int p0 = 0; p0 < n_det; p0 += 256) {
-        const int p = p0 + tid;
-        bool pass = false;
-        int y = 0, x = 0;
-        if (p < n_det) {
-            y = p / dw; x = p - y * dw;
-            const uint8_t* c = &tile[(y + 3) * kTilePitch + x + 3];
-            const int v = c[0];
-            const int d0 = v - c[3 * kTilePitch], d8 = v - c[-3 * kTilePitch];
-            const int d4 = v - c[3], d12 = v - c[-3];
-            // every 9-arc contains one pixel of each antipodal pair
-            const bool dark = max(d0, d8) > min_th && max(d4, d12) > min_th;
-            const bool bright = min(d0, d8) < -min_th && min(d4, d12) < -min_th;
-            pass = dark || bright;
+    const uint8_t* src = lv.base + (size_t)img * lv.img_stride + (size_t)cd.y0 * lv.pitch;
+    if (ALIGNED) {
+        const int ndw = (cd.x0 + rw - ga + 3) >> 2;  // dwords per tile row
+        const uint32_t dmagic = ((1u << 20) + ndw - 1) / ndw;
+        for (int i = tid; i < rh * ndw; i += 256) {
+            const int y = (i * dmagic) >> 20, c = i - y * ndw;
+            *reinterpret_cast<uint32_t*>(&tile[y * kTilePitch + 4 * c]) =
+                *reinterpret_cast<const uint32_t*>(src + (size_t)y * lv.pitch + ga + 4 * c);
         }
-        const unsigned long long m = __ballot(pass);
-        int base = 0;
-        if (lane == 0 && m) base = atomicAdd(&n_surv, __popcll(m));
-        base = __shfl(base, 0);
-        if (pass) surv[base + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)((y << 8) | x);
+    } else {
+        const int off = cd.x0 - ga;
+        const uint32_t bmagic = ((1u << 20) + rw - 1) / rw;
+        for (int i = tid; i < rh * rw; i += 256) {
+            const int y = (i * bmagic) >> 20, x = i - y * rw;
+            tile[y * kTilePitch + off + x] = src[(size_t)y * lv.pitch + cd.x0 + x];
+        }
     }
+    for (int i = tid; i < (dh + 2) * (kScorePitch / 4); i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
     __syncthreads();
+    if (debug_stop == 1) return;
 
-    // phase 2
-    const int ns = n_surv;
-    for (int i = tid; i < ns; i += 256) {
-        const int yx = surv[i];
-        const int y = yx >> 8, x = yx & 255;
-        const int s = fast_score16(&tile[(y + 3) * kTilePitch + x + 3]);
-        if (s >= min_th) score[(y + 1) * kScorePitch + x + 1] = (uint8_t)s;
+    // phase 1: quick test, two pixels per packed 16-bit lane; 8 result bits per task (dark 0..3, bright 4..7)
+    uint64_t M = 0;
+    int cnt = 0;
+    const short2v T2 = {(short)min_th, (short)min_th};
+    {
+        int y = (t_begin * magic) >> 20;
+        int g = t_begin - y * G;
+        for (int task = t_begin, k = 0; task < t_end; task++, k++) {
+            const int c0 = c_lo + 4 * g;
+            const uint8_t* row = &tile[(y + 3) * kTilePitch + c0];
+            const uint32_t C = *reinterpret_cast<const uint32_t*>(row);
+            const uint32_t Lw = *reinterpret_cast<const uint32_t*>(row - 4);
+            const uint32_t Rw = *reinterpret_cast<const uint32_t*>(row + 4);
+            const uint32_t U = *reinterpret_cast<const uint32_t*>(row - 3 * kTilePitch);
+            const uint32_t D = *reinterpret_cast<const uint32_t*>(row + 3 * kTilePitch);
+            const uint32_t R3 = __builtin_amdgcn_alignbyte(Rw, C, 3);  // p[x+3] per byte
+            const uint32_t L3 = __builtin_amdgcn_alignbyte(C, Lw, 1);  // p[x-3] per byte
+            uint32_t dk[2], br[2];
+#pragma unroll
+            for (int hsel = 0; hsel < 2; hsel++) {  // even pixels (0,2) / odd pixels (1,3)
+                const int sh = 8 * hsel;
+                const short2v v = as_s2((C >> sh) & 0x00ff00ffu), pu = as_s2((U >> sh) & 0x00ff00ffu),
+                              pd = as_s2((D >> sh) & 0x00ff00ffu), pr = as_s2((R3 >> sh) & 0x00ff00ffu),
+                              pl = as_s2((L3 >> sh) & 0x00ff00ffu);
+                const short2v lo = v - T2, hi = v + T2;
+                // every 9-arc contains one pixel of each antipodal pair: a dark corner needs min(pair) < v - t for
+                // both compass pairs, a bright corner max(pair) > v + t; sign bit of the difference = predicate
+                dk[hsel] = as_u32(__builtin_elementwise_min(pu, pd) - lo) & as_u32(__builtin_elementwise_min(pl, pr) - lo);
+                br[hsel] = as_u32(hi - __builtin_elementwise_max(pu, pd)) & as_u32(hi - __builtin_elementwise_max(pl, pr));
+            }
+            // sign bits: even half -> px0 (bit 15), px2 (bit 31); odd half -> px1, px3
+            const uint32_t d4 = ((dk[0] >> 15) & 1u) | ((dk[1] >> 14) & 2u) | ((dk[0] >> 29) & 4u) | ((dk[1] >> 28) & 8u);
+            const uint32_t b4 = ((br[0] >> 15) & 1u) | ((br[1] >> 14) & 2u) | ((br[0] >> 29) & 4u) | ((br[1] >> 28) & 8u);
+            const int xg = ga + c0;  // level column of pixel 0 of the group
+            const int vlo = min(max(x_lo - xg, 0), 4), vhi = min(max(x_hi - xg, 0), 4);
+            const uint32_t m4 = ((1u << vhi) - 1u) & ~((1u << vlo) - 1u);
+            const uint32_t bits = (d4 & m4) | ((b4 & m4) << 4);
+            M |= (uint64_t)bits << (8 * k);
+            cnt += __popc(bits);
+            if (++g == G) { g = 0; y++; }
+        }
     }
-    __syncthreads();
+    int n_work = 0;
+    const int my_base = block_excl_scan(cnt, lane, wave, wave_tot[0], &n_work);
+    if (debug_stop == 2) return;
 
-    // phase 3a: NMS flags per owned pixel (bit k = chunk k), counts of the iniTh set
+    // phase 2: the work list is processed in chunks of kWorkCap entries (one chunk unless the cell is saturated)
+    const int sc_off = 4 - c_lo;  // score column = tile column + sc_off  (first group at score column 4)
+    for (int cb = 0; cb < n_work; cb += kWorkCap) {
+        if (cnt && my_base < cb + kWorkCap && my_base + cnt > cb) {
+            int idx = my_base - cb;
+            int y = (t_begin * magic) >> 20;
+            int g = t_begin - y * G;
+            uint64_t m = M;
+            for (int task = t_begin; task < t_end; task++, m >>= 8) {
+                const uint32_t bits = (uint32_t)m & 255u;
+                if (bits) {
+                    const int e0 = ((y + 3) << 7) | (c_lo + 4 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (bits & (1u << j)) { if ((unsigned)idx < (unsigned)kWorkCap) work[idx] = (uint16_t)(e0 + j); idx++; }
+                        if (bits & (16u << j)) { if ((unsigned)idx < (unsigned)kWorkCap) work[idx] = (uint16_t)(0x8000 | (e0 + j)); idx++; }
+                    }
+                }
+                if (++g == G) { g = 0; y++; }
+            }
+        }
+        __syncthreads();
+        if (debug_stop == 3) return;
+        const int nw = min(n_work - cb, kWorkCap);
+        for (int i = tid; i < nw; i += 256) {
+            const int e = work[i];
+            const int ty = (e >> 7) & 127, tx = e & 127;
+            const int A = fast_arc_contrast(&tile[ty * kTilePitch + tx], (e & 0x8000) ? -1 : 1);
+            if (A > min_th) score[(ty - 2) * kScorePitch + tx + sc_off] = (uint8_t)(A - 1);  // score row = y + 1
+        }
+        __syncthreads();
+    }
+    if (debug_stop == 4) return;
+
+    // phase 3a: strict 3x3 NMS, 4 flag bits per task
     uint32_t keep = 0, keep_ini = 0;
-    int chunk = 0;
-    for (int p0 = 0; p0 < n_det; p0 += 256, chunk++) {
-        const int p = p0 + tid;
-        if (p < n_det) {
-            const int y = p / dw, x = p - y * dw;
-            const uint8_t* sp = &score[(y + 1) * kScorePitch + x + 1];
-            const int s = sp[0];
-            if (s) {
-                int m = max3i(sp[-kScorePitch - 1], sp[-kScorePitch], sp[-kScorePitch + 1]);
-                m = max3i(m, sp[-1], sp[1]);
-                m = max(m, max3i(sp[kScorePitch - 1], sp[kScorePitch], sp[kScorePitch + 1]));
-                if (s > m) {
-                    keep |= 1u << chunk;
-                    if (s >= ini_th) keep_ini |= 1u << chunk;
+    {
+        int y = (t_begin * magic) >> 20;
+        int g = t_begin - y * G;
+        for (int task = t_begin, k = 0; task < t_end; task++, k++) {
+            const uint8_t* sp = &score[(y + 1) * kScorePitch + 4 + 4 * g];
+            const uint32_t S = *reinterpret_cast<const uint32_t*>(sp);
+            if (S) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int sv = (S >> (8 * j)) & 255;
+                    if (sv) {
+                        const uint8_t* q = sp + j;
+                        int m = max3i(q[-kScorePitch - 1], q[-kScorePitch], q[-kScorePitch + 1]);
+                        m = max3i(m, q[-1], q[1]);
+                        m = max(m, max3i(q[kScorePitch - 1], q[kScorePitch], q[kScorePitch + 1]));
+                        if (sv > m) {
+                            keep |= 1u << (4 * k + j);
+                            if (sv >= ini_th) keep_ini |= 1u << (4 * k + j);
+                        }
+                    }
                 }
             }
+            if (++g == G) { g = 0; y++; }
         }
     }
     const int any_ini = __syncthreads_or(keep_ini != 0);
     const uint32_t sel = any_ini ? keep_ini : keep;
+    if (debug_stop == 5) return;
 
-    // phase 3b: ordered emission — pixel index p = chunk*256 + tid ascends with (chunk, wave, lane)
-    Cand16* out = slots + (size_t)img * slots_per_image + cd.slot_off;
-    int running = 0;
-    chunk = 0;
-    for (int p0 = 0; p0 < n_det; p0 += 256, chunk++) {
-        const bool f = (sel >> chunk) & 1u;
-        const unsigned long long m = __ballot(f);
-        const int buf = chunk & 1;
-        if (lane == 0) wave_cnt[buf][wave] = __popcll(m);
-        __syncthreads();
-        int before = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            const int cw = wave_cnt[buf][w];
-            if (w < wave) before += cw;
-            total += cw;
+    // phase 3b: ordered emission — a thread's tasks are consecutive in scan order, so the block-wide prefix of the
+    // per-thread counts is the rank in (ascending y, then x) order
+    int n_out = 0;
+    int pos = block_excl_scan(__popc(sel), lane, wave, wave_tot[1], &n_out);
+    if (sel) {
+        Cand16* out = slots + (size_t)img * slots_per_image + cd.slot_off;
+        int y = (t_begin * magic) >> 20;
+        int g = t_begin - y * G;
+        uint32_t m = sel;
+        for (int task = t_begin; task < t_end; task++, m >>= 4) {
+            uint32_t m4 = m & 15u;
+            while (m4) {
+                const int j = __ffs(m4) - 1;
+                m4 &= m4 - 1;
+                Cand16 c;
+                c.x = (uint16_t)(gx0 + 4 * g + j - kMinBorder);
+                c.y = (uint16_t)(cd.y0 + 3 + y - kMinBorder);
+                c.score = score[(y + 1) * kScorePitch + 4 + 4 * g + j];
+                c.pad = 0;
+                out[pos++] = c;
+            }
+            if (++g == G) { g = 0; y++; }
         }
-        if (f) {
-            const int p = p0 + tid;
-            const int y = p / dw, x = p - y * dw;
-            Cand16 c;
-            c.x = (uint16_t)(cd.x0 + 3 + x - kMinBorder);
-            c.y = (uint16_t)(cd.y0 + 3 + y - kMinBorder);
-            c.score = score[(y + 1) * kScorePitch + x + 1];
-            c.pad = 0;
-            out[running + before + __popcll(m & ((1ull << lane) - 1))] = c;
-        }
-        running += total;
     }
-    if (tid == 0) cell_count[(size_t)img * n_cells + cell_id] = running;
+    if (tid == 0) cell_count[(size_t)img * n_cells + cell_id] = n_out;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -293,41 +404,146 @@ __global__ __launch_bounds__(64) void cand_gather_kernel(const CellDesc* __restr
 // 7x7 Gaussian, sigma 2, Q8.8 fixed point [18,34,48,56,48,34,18], BORDER_REFLECT_101, per level.
 // Tile = 64 x 16 output pixels per 256-thread block; 70 x 22 input pixels staged in LDS.
 // ------------------------------------------------------------------------------------------------
+// LDS-free streaming form: one thread owns a 4-pixel-wide column strip and walks kGaussRows + 6 input
+// rows.  Per row it loads the 12 bytes [x0-4, x0+8) as aligned dwords (each load instruction is one fully
+// coalesced 256-byte request per wave), forms the four horizontal sums with v_alignbyte + v_dot4_u32_u8 and
+// scatters them into seven rotating vertical accumulators; a row is complete six input rows later and is
+// stored as one aligned dword.  All levels of all images go in ONE launch (block -> level table).
+// ALIGNED = every source row starts on a 4-byte boundary (our own planes, or a caller buffer with such a
+// pitch); otherwise a fourth dword + funnel shift by the row's byte phase.  Column groups whose window
+// reaches the right border (reflect-101 gather, byte loads) are left to gauss7_edge_kernel so that the
+// streaming waves stay divergence free and the unrolled body stays small (instruction cache).
+constexpr int kGaussRows = 35;  // 6 warm-up rows + 5 x 7 steady rows
+constexpr uint32_t kGaussLo = 18u | (34u << 8) | (48u << 16) | (56u << 24);
+constexpr uint32_t kGaussHi = 48u | (34u << 8) | (18u << 16);
+
+struct BlurPlan {
+    int block_begin[kMaxLevels + 1];  // first blockIdx.x of each level
+    int bx_count[kMaxLevels];         // blocks per strip-row of the level
+    int nlevels;
+};
+
 __device__ __forceinline__ int refl101(int p, int len) { return p < 0 ? -p : (p >= len ? 2 * (len - 1) - p : p); }
 
-__global__ __launch_bounds__(256) void gauss7_kernel(LevelView src, LevelView dst, uint8_t* __restrict__ dst_base) {
-    constexpr int TW = 64, TH = 16, IW = TW + 6, IH = TH + 6;
-    __shared__ uint8_t in[IH][IW + 2];
-    __shared__ uint16_t hz[IH][TW];
-    const int img = blockIdx.z;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const uint8_t* s = src.base + (size_t)img * src.img_stride;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < IW * IH; i += 256) {
-        const int ty = i / IW, tx = i - ty * IW;
-        const int gy = refl101(min(y0 + ty - 3, src.h + 2), src.h);  // rows past the image are never used
-        const int gx = refl101(min(x0 + tx - 3, src.w + 2), src.w);
-        in[ty][tx] = s[(size_t)gy * src.pitch + gx];
+template <bool ALIGNED>
+__device__ __forceinline__ void gauss_row_sums(const uint8_t* __restrict__ sb, int pitch, int h, int yy, int x0,
+                                               uint32_t hsum[4]) {
+    yy = refl101(yy, h);
+    yy = min(max(yy, 0), h - 1);  // rows past the image only feed outputs that are never stored
+    const uint8_t* rp = sb + (size_t)yy * pitch;
+    uint32_t w0, w1, w2;
+    if (ALIGNED) {
+        const uint32_t* ap = reinterpret_cast<const uint32_t*>(rp + x0);
+        w1 = ap[0]; w2 = ap[1];
+        w0 = x0 ? ap[-1] : 0u;
+    } else {
+        const uint32_t ph = (uint32_t)(reinterpret_cast<uintptr_t>(rp) & 3);
+        const uint32_t* ap = reinterpret_cast<const uint32_t*>(rp - ph + x0);
+        const uint32_t d1 = ap[0], d2 = ap[1], d3 = ap[2];
+        const uint32_t d0 = x0 ? ap[-1] : 0u;
+        w0 = __builtin_amdgcn_alignbyte(d1, d0, ph);
+        w1 = __builtin_amdgcn_alignbyte(d2, d1, ph);
+        w2 = __builtin_amdgcn_alignbyte(d3, d2, ph);
     }
-    __syncthreads();
-    for (int i = tid; i < TW * IH; i += 256) {
-        const int ty = i >> 6, tx = i & 63;
-        const uint8_t* r = &in[ty][tx];
-        hz[ty][tx] = (uint16_t)(18 * (r[0] + r[6]) + 34 * (r[1] + r[5]) + 48 * (r[2] + r[4]) + 56 * r[3]);
-    }
-    __syncthreads();
-    // each thread: 4 adjacent output pixels of one row
-    const int ty = tid >> 4, tx = (tid & 15) * 4;
-    const int gy = y0 + ty, gx = x0 + tx;
-    if (gy < src.h && gx < dst.pitch) {
-        uint32_t packed = 0;
+    if (x0 == 0) w0 = __builtin_amdgcn_perm(0u, w1, 0x01020300u);  // p[-1..-3] = p[1..3]
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t acc = 18u * (hz[ty][tx + i] + hz[ty + 6][tx + i]) + 34u * (hz[ty + 1][tx + i] + hz[ty + 5][tx + i]) +
-                                 48u * (hz[ty + 2][tx + i] + hz[ty + 4][tx + i]) + 56u * hz[ty + 3][tx + i];
-            packed |= (((acc + 32768u) >> 16) & 255u) << (8 * i);
+    for (int j = 0; j < 4; j++) {
+        const uint32_t a = j == 3 ? w1 : __builtin_amdgcn_alignbyte(w1, w0, j + 1);
+        const uint32_t b = j == 3 ? w2 : __builtin_amdgcn_alignbyte(w2, w1, j + 1);
+        hsum[j] = __builtin_amdgcn_udot4(b, kGaussHi, __builtin_amdgcn_udot4(a, kGaussLo, 0u, false), false);
+    }
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void gauss7_kernel(PyramidView src, PyramidView dst, BlurPlan plan) {
+    constexpr uint32_t K[7] = {18, 34, 48, 56, 48, 34, 18};
+    int level = 0;
+    while (level + 1 < plan.nlevels && (int)blockIdx.x >= plan.block_begin[level + 1]) level++;
+    const int rem = blockIdx.x - plan.block_begin[level];
+    const int bx = rem % plan.bx_count[level], by = rem / plan.bx_count[level];
+    const LevelView sv = src.lv[level], dv = dst.lv[level];
+    const int img = blockIdx.y;
+    const int x0 = (bx * 64 + (threadIdx.x & 63)) * 4;
+    const int y0 = (by * 4 + (threadIdx.x >> 6)) * kGaussRows;
+    if (x0 + 16 > sv.w || y0 >= sv.h) return;  // right-border groups belong to gauss7_edge_kernel
+    const uint8_t* sb = sv.base + (size_t)img * sv.img_stride;
+    uint8_t* db = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride + x0;
+    uint32_t acc[7][4];
+    uint32_t hs[4];
+    // warm-up: input rows 0..5 (image rows y0-3 .. y0+2) open accumulators 0..5
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        gauss_row_sums<ALIGNED>(sb, sv.pitch, sv.h, y0 - 3 + r, x0, hs);
+#pragma unroll
+        for (int t = 0; t <= r; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[r - t][j] = (t == 0 ? 0u : acc[r - t][j]) + K[t] * hs[j];
+    }
+    // steady state: input row r = 6 + 7*it + u completes output row o = r - 6 and opens accumulator r % 7
+    for (int it = 0; it < kGaussRows / 7; it++) {
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            const int r = 6 + 7 * it + u;
+            gauss_row_sums<ALIGNED>(sb, sv.pitch, sv.h, y0 - 3 + r, x0, hs);
+#pragma unroll
+            for (int t = 0; t < 7; t++) {
+                const int a = (6 + u - t) % 7;  // == (r - t) % 7
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[a][j] = (t == 0 ? 0u : acc[a][j]) + K[t] * hs[j];
+            }
+            const int o = r - 6, a = u % 7;  // (r - 6) % 7 == u
+            if (y0 + o < sv.h) {
+                uint32_t packed = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) packed |= ((acc[a][j] + 32768u) >> 16) << (8 * j);
+                *reinterpret_cast<uint32_t*>(db + (size_t)(y0 + o) * dv.pitch) = packed;
+            }
         }
-        *reinterpret_cast<uint32_t*>(dst_base + (size_t)img * dst.img_stride + (size_t)gy * dst.pitch + gx) = packed;
+    }
+}
+
+// Right-border column groups (x0 + 16 > w: at most four per row): per-byte reflect-101 gather, one thread per
+// (row strip, group), scalar form of the same arithmetic.
+__global__ __launch_bounds__(64) void gauss7_edge_kernel(PyramidView src, PyramidView dst) {
+    const int level = blockIdx.y, img = blockIdx.z;
+    const LevelView sv = src.lv[level], dv = dst.lv[level];
+    const int first = sv.w >= 16 ? ((sv.w - 16) / 4 + 1) * 4 : 0;  // first x0 with x0 + 16 > w
+    const int ngroups = (sv.w - first + 3) / 4;
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int strip = t / 4, g = t % 4;
+    const int x0 = first + 4 * g, y0 = strip * kGaussRows;
+    if (g >= ngroups || y0 >= sv.h) return;
+    const uint8_t* sb = sv.base + (size_t)img * sv.img_stride;
+    uint8_t* db = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride;
+    const int K[7] = {18, 34, 48, 56, 48, 34, 18};
+    int col[10];
+#pragma unroll
+    for (int o = 0; o < 10; o++) col[o] = refl101(x0 - 3 + o, sv.w);
+    uint32_t ring[7][4];
+    for (int r = 0; r < kGaussRows + 6; r++) {
+        int yy = refl101(y0 - 3 + r, sv.h);
+        yy = min(max(yy, 0), sv.h - 1);
+        const uint8_t* rp = sb + (size_t)yy * sv.pitch;
+        uint32_t px[10];
+#pragma unroll
+        for (int o = 0; o < 10; o++) px[o] = rp[col[o]];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t hsum = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) hsum += K[k] * px[j + k];
+            ring[r % 7][j] = hsum;
+        }
+        const int o = r - 6;
+        if (o >= 0 && y0 + o < sv.h) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t accv = 0;
+#pragma unroll
+                for (int k = 0; k < 7; k++) accv += K[k] * ring[(o + k) % 7][j];
+                if (x0 + j < sv.w) db[(size_t)(y0 + o) * dv.pitch + x0 + j] = (uint8_t)((accv + 32768u) >> 16);
+            }
+        }
     }
 }
 
@@ -449,8 +665,18 @@ void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_
 }
 void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cells, int ini_th, int min_th,
                        int slots_per_image, Cand16* slots, int* cell_count, int n_images, hipStream_t s) {
-    hipLaunchKernelGGL(fast_cells_kernel, dim3(n_cells, n_images), dim3(256), 0, s, pyr, cells, ini_th, min_th,
-                       slots_per_image, slots, cell_count, n_cells);
+    bool aligned = true;
+    for (int l = 0; l < pyr.nlevels; l++) {
+        const LevelView& v = pyr.lv[l];
+        aligned = aligned && (reinterpret_cast<uintptr_t>(v.base) & 3) == 0 && (v.pitch & 3) == 0 && (v.img_stride & 3) == 0;
+    }
+    static const int dbg = getenv("MSORB_FAST_DEBUG_STOP") ? atoi(getenv("MSORB_FAST_DEBUG_STOP")) : 0;  // profiling only
+    if (aligned)
+        hipLaunchKernelGGL(fast_cells_kernel<true>, dim3(n_cells, n_images), dim3(256), 0, s, pyr, cells, ini_th, min_th,
+                           slots_per_image, slots, cell_count, n_cells, dbg);
+    else
+        hipLaunchKernelGGL(fast_cells_kernel<false>, dim3(n_cells, n_images), dim3(256), 0, s, pyr, cells, ini_th, min_th,
+                           slots_per_image, slots, cell_count, n_cells, dbg);
 }
 void launch_cand_compact(const CellDesc* cells, int n_cells, const int* level_cell_begin, int nlevels,
                          int slots_per_image, const Cand16* slots, const int* cell_count, int* cell_off,
@@ -462,9 +688,24 @@ void launch_cand_compact(const CellDesc* cells, int n_cells, const int* level_ce
     hipLaunchKernelGGL(cand_gather_kernel, dim3(n_cells, n_images), dim3(64), 0, s, cells, n_cells, slots_per_image,
                        slots, cell_count, cell_off, img_base, compact);
 }
-void launch_gauss7(const LevelView& src, const LevelView& dst, uint8_t* dst_base, int n_images, hipStream_t s) {
-    dim3 grid((src.w + 63) / 64, (src.h + 15) / 16, n_images);
-    hipLaunchKernelGGL(gauss7_kernel, grid, dim3(256), 0, s, src, dst, dst_base);
+void launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images, hipStream_t s) {
+    BlurPlan plan{};
+    plan.nlevels = src.nlevels;
+    bool aligned = true;
+    int total = 0, max_edge_threads = 0;
+    for (int l = 0; l < src.nlevels; l++) {
+        const LevelView& v = src.lv[l];
+        plan.block_begin[l] = total;
+        plan.bx_count[l] = (v.w + 255) / 256;
+        const int strips = (v.h + kGaussRows - 1) / kGaussRows;
+        total += plan.bx_count[l] * ((strips + 3) / 4);
+        max_edge_threads = max(max_edge_threads, strips * 4);
+        aligned = aligned && (reinterpret_cast<uintptr_t>(v.base) & 3) == 0 && (v.pitch & 3) == 0 && (v.img_stride & 3) == 0;
+    }
+    plan.block_begin[src.nlevels] = total;
+    if (aligned) hipLaunchKernelGGL(gauss7_kernel<true>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
+    else hipLaunchKernelGGL(gauss7_kernel<false>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
+    hipLaunchKernelGGL(gauss7_edge_kernel, dim3((max_edge_threads + 63) / 64, src.nlevels, n_images), dim3(64), 0, s, src, dst);
 }
 void launch_describe(const PyramidView& pyr, const PyramidView& blur, const SelRec* sel, const int* sel_count,
                      int sel_stride, const LevelScale& scales, msorb_keypoint* kps, uint8_t* desc, int out_stride,
