@@ -170,8 +170,13 @@ struct msorb_extractor {
     DevBuf<Cand16> d_slots, d_compact;
     DevBuf<SelRec> d_sel;
     DevBuf<msorb_keypoint> d_kps1;
+    DevBuf<uint16_t> d_label;
+    DevBuf<int> d_sel_pt, d_sel_n, d_mono;
+    QtLevels qt{};
+    bool device_quadtree = true;
+    bool compact_on_host = false;  // h_compact / h_level_count / h_img_base hold the last call's candidates
     // pinned host state
-    PinBuf<int> h_level_count, h_img_base, h_sel_count;
+    PinBuf<int> h_level_count, h_img_base, h_sel_count, h_mono;
     PinBuf<Cand16> h_compact;
     PinBuf<SelRec> h_sel;
     PinBuf<uint8_t> h_pyr;
@@ -224,6 +229,22 @@ int ensure_geometry(msorb_extractor* h, int rows, int cols) {
     if ((rc = h->d_level_cell_begin.ensure(g.nlevels + 1))) return rc;
     HIPCHK(hipMemcpy(h->d_level_cell_begin.p, h->level_cell_begin.data(), (g.nlevels + 1) * sizeof(int),
                      hipMemcpyHostToDevice));
+    int sel_off = 0;
+    h->qt.nlevels = g.nlevels;
+    for (int l = 0; l < g.nlevels; l++) {
+        const LevelGeom& lg = g.lv[l];
+        h->qt.W[l] = lg.max_x - lg.min_x;
+        h->qt.H[l] = lg.max_y - lg.min_y;
+        h->qt.quota[l] = lg.quota;
+        h->qt.n_ini[l] = (int)std::round(static_cast<float>(h->qt.W[l]) / h->qt.H[l]);
+        h->qt.sel_off[l] = sel_off;
+        sel_off += std::max(lg.quota, h->qt.n_ini[l]) + 8 + 4 * h->qt.n_ini[l];
+    }
+    h->sel_stride = sel_off;
+    {
+        const char* e = getenv("MSORB_QUADTREE");
+        h->device_quadtree = !(e && std::string(e) == "host") && quadtree_lds_bytes(h->qt) <= 60 * 1024;
+    }
     h->geom_valid = true;
     h->last_n_images = 0;
     return MSORB_OK;
@@ -243,12 +264,16 @@ int ensure_batch(msorb_extractor* h, int n_images) {
     if ((rc = h->d_img_total.ensure(n_images))) return rc;
     if ((rc = h->d_img_base.ensure(n_images + 1))) return rc;
     if ((rc = h->d_sel_count.ensure(n_images))) return rc;
-    h->sel_stride = capacity_of(h);
     if ((rc = h->d_sel.ensure((size_t)n_images * h->sel_stride))) return rc;
     if ((rc = h->h_level_count.ensure((size_t)n_images * g.nlevels))) return rc;
     if ((rc = h->h_img_base.ensure(n_images + 1))) return rc;
     if ((rc = h->h_sel_count.ensure(n_images))) return rc;
     if ((rc = h->h_sel.ensure((size_t)n_images * h->sel_stride))) return rc;
+    if ((rc = h->h_mono.ensure(n_images))) return rc;
+    if ((rc = h->d_label.ensure((size_t)n_images * g.slots_per_image))) return rc;
+    if ((rc = h->d_sel_pt.ensure((size_t)n_images * h->sel_stride))) return rc;
+    if ((rc = h->d_sel_n.ensure((size_t)n_images * g.nlevels))) return rc;
+    if ((rc = h->d_mono.ensure(n_images))) return rc;
     return MSORB_OK;
 }
 
@@ -265,6 +290,27 @@ PyramidView make_view(const msorb_extractor* h, const uint8_t* base, const Level
     }
     if (level0) v.lv[0] = *level0;
     return v;
+}
+
+// Copy the compacted FAST candidates of the last launch to pinned host memory (host-quadtree mode, debug hook).
+int fetch_candidates(msorb_extractor* h, int n_images) {
+    const int nl = h->G.nlevels;
+    HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_compact, 0));
+    HIPCHK(hipMemcpyAsync(h->h_level_count.p, h->d_level_count.p, (size_t)n_images * nl * sizeof(int),
+                          hipMemcpyDeviceToHost, h->copy_stream));
+    HIPCHK(hipMemcpyAsync(h->h_img_base.p, h->d_img_base.p, (size_t)(n_images + 1) * sizeof(int),
+                          hipMemcpyDeviceToHost, h->copy_stream));
+    HIPCHK(hipStreamSynchronize(h->copy_stream));
+    const int total = h->h_img_base.p[n_images];
+    int rc;
+    if ((rc = h->h_compact.ensure(std::max<size_t>((size_t)total + total / 4, 1024)))) return rc;
+    if (total > 0) {
+        HIPCHK(hipMemcpyAsync(h->h_compact.p, h->d_compact.p, (size_t)total * sizeof(Cand16), hipMemcpyDeviceToHost,
+                              h->copy_stream));
+        HIPCHK(hipStreamSynchronize(h->copy_stream));
+    }
+    h->compact_on_host = true;
+    return MSORB_OK;
 }
 
 // The pipeline proper.  level0: where level 0 of every image lives (device memory).
@@ -295,78 +341,84 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
                         h->d_compact.p, n_images, s);
     mark(3);
     HIPCHK(hipEventRecord(h->ev_compact, s));
-    // blur runs on the main stream while the copy stream + host do the selection
     launch_gauss7(pyr, blur, n_images, s);
     mark(4);
-
-    const auto t0 = std::chrono::steady_clock::now();
-    HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_compact, 0));
-    HIPCHK(hipMemcpyAsync(h->h_level_count.p, h->d_level_count.p, (size_t)n_images * nl * sizeof(int),
-                          hipMemcpyDeviceToHost, h->copy_stream));
-    HIPCHK(hipMemcpyAsync(h->h_img_base.p, h->d_img_base.p, (size_t)(n_images + 1) * sizeof(int),
-                          hipMemcpyDeviceToHost, h->copy_stream));
-    HIPCHK(hipStreamSynchronize(h->copy_stream));
-    const int total = h->h_img_base.p[n_images];
-    int rc;
-    if ((rc = h->h_compact.ensure(std::max<size_t>((size_t)total + total / 4, 1024)))) return rc;
-    if (total > 0) {
-        HIPCHK(hipMemcpyAsync(h->h_compact.p, h->d_compact.p, (size_t)total * sizeof(Cand16), hipMemcpyDeviceToHost,
-                              h->copy_stream));
-        HIPCHK(hipStreamSynchronize(h->copy_stream));
-    }
-
-    // host selection, one task per image
-    std::atomic<int> overflow{0};
+    h->compact_on_host = false;
     const int sel_stride = h->sel_stride;
-    std::function<void(int)> task = [&](int img) {
-        const Cand16* c = h->h_compact.p + h->h_img_base.p[img];
-        const int* lc = h->h_level_count.p + (size_t)img * nl;
-        SelRec* out = h->h_sel.p + (size_t)img * sel_stride;
-        std::vector<int> kept;
-        int n = 0;
-        // pass 1: quadtree per level, records in level-major / quadtree order
-        for (int l = 0; l < nl; l++) {
-            const LevelGeom& lg = g.lv[l];
-            distribute_quadtree(c, lc[l], lg.min_x, lg.max_x, lg.min_y, lg.max_y, lg.quota, kept);
-            for (int k : kept) {
-                if (n >= sel_stride || n >= capacity) { overflow.store(1); break; }
-                SelRec r;
-                r.x = (uint16_t)(c[k].x + kMinBorder);
-                r.y = (uint16_t)(c[k].y + kMinBorder);
-                r.score = c[k].score;
-                r.level = (uint8_t)l;
-                r.pad = 0;
-                r.dst = 0;
-                out[n++] = r;
-            }
-            c += lc[l];
-        }
-        // pass 2: output rows (ORBextractor.cc:1122-1163): inside [lap0,lap1] from the back, else from the front
-        int mono = 0, stereo = n - 1;
-        for (int i = 0; i < n; i++) {
-            SelRec& r = out[i];
-            const float fx = r.level ? (float)r.x * h->P.scale[r.level] : (float)r.x;
-            if (fx >= (float)lap0 && fx <= (float)lap1) r.dst = stereo--;
-            else r.dst = mono++;
-        }
-        h->h_sel_count.p[img] = n;
-        h_counts[img] = n;
-        if (h_mono) h_mono[img] = mono;
-    };
-    h->pool->parallel_for(n_images, task);
-    if (overflow.load()) { set_error("keypoint capacity exceeded"); return MSORB_E_CAPACITY; }
-    int max_sel = 0;
-    for (int i = 0; i < n_images; i++) max_sel = std::max(max_sel, h->h_sel_count.p[i]);
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), t1 = t0;
 
-    HIPCHK(hipMemcpyAsync(h->d_sel.p, h->h_sel.p, (size_t)n_images * sel_stride * sizeof(SelRec), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->d_sel_count.p, h->h_sel_count.p, (size_t)n_images * sizeof(int), hipMemcpyHostToDevice, s));
-    const auto t1 = std::chrono::steady_clock::now();
-    mark(5);
-    launch_describe(pyr, blur, h->d_sel.p, h->d_sel_count.p, sel_stride, h->scales, d_kps, d_desc, capacity, max_sel,
-                    n_images, s);
-    mark(6);
-    HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipGetLastError());
+    if (h->device_quadtree) {
+        // selection stays on the device: quadtree per (level, image), output layout per image
+        launch_quadtree(h->qt, h->d_compact.p, h->d_img_base.p, h->d_level_count.p, h->d_label.p, h->d_sel_pt.p,
+                        h->d_sel_n.p, sel_stride, h->scales, lap0, lap1, capacity, h->d_sel.p, h->d_sel_count.p,
+                        h->d_mono.p, n_images, s);
+        mark(5);
+        launch_describe(pyr, blur, h->d_sel.p, h->d_sel_count.p, sel_stride, h->scales, d_kps, d_desc, capacity,
+                        std::min(capacity, sel_stride), n_images, s);
+        mark(6);
+        HIPCHK(hipMemcpyAsync(h->h_sel_count.p, h->d_sel_count.p, (size_t)n_images * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h->h_mono.p, h->d_mono.p, (size_t)n_images * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipGetLastError());
+        for (int i = 0; i < n_images; i++) {
+            if (h->h_sel_count.p[i] < 0) { set_error("keypoint capacity exceeded"); return MSORB_E_CAPACITY; }
+            h_counts[i] = h->h_sel_count.p[i];
+            if (h_mono) h_mono[i] = h->h_mono.p[i];
+        }
+    } else {
+        int rc;
+        if ((rc = fetch_candidates(h, n_images))) return rc;
+        // host selection, one task per image
+        std::atomic<int> overflow{0};
+        std::function<void(int)> task = [&](int img) {
+            const Cand16* c = h->h_compact.p + h->h_img_base.p[img];
+            const int* lc = h->h_level_count.p + (size_t)img * nl;
+            SelRec* out = h->h_sel.p + (size_t)img * sel_stride;
+            std::vector<int> kept;
+            int n = 0;
+            // pass 1: quadtree per level, records in level-major / quadtree order
+            for (int l = 0; l < nl; l++) {
+                const LevelGeom& lg = g.lv[l];
+                distribute_quadtree(c, lc[l], lg.min_x, lg.max_x, lg.min_y, lg.max_y, lg.quota, kept);
+                for (int k : kept) {
+                    if (n >= sel_stride || n >= capacity) { overflow.store(1); break; }
+                    SelRec r;
+                    r.x = (uint16_t)(c[k].x + kMinBorder);
+                    r.y = (uint16_t)(c[k].y + kMinBorder);
+                    r.score = c[k].score;
+                    r.level = (uint8_t)l;
+                    r.pad = 0;
+                    r.dst = 0;
+                    out[n++] = r;
+                }
+                c += lc[l];
+            }
+            // pass 2: output rows (ORBextractor.cc:1122-1163): inside [lap0,lap1] from the back, else from the front
+            int mono = 0, stereo = n - 1;
+            for (int i = 0; i < n; i++) {
+                SelRec& r = out[i];
+                const float fx = r.level ? (float)r.x * h->P.scale[r.level] : (float)r.x;
+                if (fx >= (float)lap0 && fx <= (float)lap1) r.dst = stereo--;
+                else r.dst = mono++;
+            }
+            h->h_sel_count.p[img] = n;
+            h_counts[img] = n;
+            if (h_mono) h_mono[img] = mono;
+        };
+        h->pool->parallel_for(n_images, task);
+        if (overflow.load()) { set_error("keypoint capacity exceeded"); return MSORB_E_CAPACITY; }
+        int max_sel = 0;
+        for (int i = 0; i < n_images; i++) max_sel = std::max(max_sel, h->h_sel_count.p[i]);
+        HIPCHK(hipMemcpyAsync(h->d_sel.p, h->h_sel.p, (size_t)n_images * sel_stride * sizeof(SelRec), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->d_sel_count.p, h->h_sel_count.p, (size_t)n_images * sizeof(int), hipMemcpyHostToDevice, s));
+        t1 = std::chrono::steady_clock::now();
+        mark(5);
+        launch_describe(pyr, blur, h->d_sel.p, h->d_sel_count.p, sel_stride, h->scales, d_kps, d_desc, capacity, max_sel,
+                        n_images, s);
+        mark(6);
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipGetLastError());
+    }
     if (prof) {
         float ms = 0;
         const int map[5][3] = {{MSORB_STAGE_PYRAMID, 0, 1}, {MSORB_STAGE_FAST, 1, 2}, {MSORB_STAGE_COMPACT, 2, 3},
@@ -375,7 +427,12 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
             HIPCHK(hipEventElapsedTime(&ms, h->pe[m[1]], h->pe[m[2]]));
             h->stage_ms[m[0]] = ms;
         }
-        h->stage_ms[MSORB_STAGE_SELECT] = std::chrono::duration<float, std::milli>(t1 - t0).count();
+        if (h->device_quadtree) {
+            HIPCHK(hipEventElapsedTime(&ms, h->pe[4], h->pe[5]));
+            h->stage_ms[MSORB_STAGE_SELECT] = ms;
+        } else {
+            h->stage_ms[MSORB_STAGE_SELECT] = std::chrono::duration<float, std::milli>(t1 - t0).count();
+        }
     }
     return MSORB_OK;
 }
@@ -586,6 +643,11 @@ int msorb_debug_candidates(msorb_extractor* h, int image, int level, int* xyscor
     if (!h || !n || !h->geom_valid || image < 0 || image >= h->last_n_images || level < 0 || level >= h->G.nlevels)
         return MSORB_E_INVALID;
     const int nl = h->G.nlevels;
+    if (!h->compact_on_host) {
+        HIPCHK(hipSetDevice(h->device));
+        int rc;
+        if ((rc = fetch_candidates(h, h->last_n_images))) return rc;
+    }
     const int* lc = h->h_level_count.p + (size_t)image * nl;
     const Cand16* c = h->h_compact.p + h->h_img_base.p[image];
     for (int l = 0; l < level; l++) c += lc[l];

@@ -27,6 +27,16 @@ struct SelRec {  // one keypoint kept by the quadtree, level coordinates (border
     int32_t dst;  // output row (mono from the front / stereo from the back, ORBextractor.cc:1153-1162)
 };
 
+struct QtLevels {  // per-level geometry of the quadtree stage
+    int W[kMaxLevels], H[kMaxLevels], quota[kMaxLevels], n_ini[kMaxLevels];
+    int sel_off[kMaxLevels];  // first entry of the level inside one image's selection block
+    int nlevels;
+};
+
+void launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_base, const int* level_count,
+                     uint16_t* label, int* sel_pt, int* sel_n, int sel_stride, const LevelScale& scales, int lap0,
+                     int lap1, int capacity, SelRec* sel, int* sel_count, int* mono, int n_images, hipStream_t s);
+size_t quadtree_lds_bytes(const QtLevels& lv);
 void upload_patch_tables(const int8_t* pattern, const int* umax, hipStream_t stream);
 void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_base, const ResizeTap* tx,
                        const ResizeTap* ty, int n_images, hipStream_t s);

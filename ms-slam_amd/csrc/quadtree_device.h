@@ -1,0 +1,420 @@
+// DistributeOctTree (ORBextractor.cc:555-779) as a generation-synchronous, label-based algorithm that one
+// workgroup executes per (image, pyramid level) on the device.  Same observable result as the reference's
+// std::list walk (and as orb_host.cc's index-pool version): which keypoints survive, in which order.
+//
+// How the list semantics map onto flat arrays
+//  * Every node created after the initial columns is push_front'ed, so the final list order is "descending
+//    creation time", followed by the surviving initial columns in ascending order.  Each node therefore only
+//    needs a creation sequence number `seq`; the list itself is never materialised.
+//  * One pass of the reference's main loop splits every multi-point node of the previous pass, walking the list
+//    from the front = in reverse creation order.  A generation is an array of child slots indexed
+//    4*(parent's processing rank) + quadrant, i.e. already in creation order; empty quadrants leave gaps,
+//    which is harmless because only the relative order of seq matters.
+//  * Points are never moved: a point carries the label of the node that currently owns it; a node's point list
+//    "in insertion order" is the set of points with its label in candidate order, and the only order-sensitive
+//    use (first strictly greater response wins, :757-776) is a max over the key (response, -candidate index).
+//  * The "careful" phase (:689-753) sorts (count, UL.x) with std::sort — unstable, libstdc++ introsort — and
+//    the tie order decides which nodes are split before the quota is hit.  lsort() below restates libstdc++'s
+//    algorithm (introsort loop, median-of-three to first, unguarded partition, heapsort fallback, final
+//    insertion sort with threshold 16) so the permutation is the same for the same comparison outcomes.
+//
+// The code is written once against a tiny execution interface (Ex: tid/nthreads/sync/atomics) and compiled
+// for the device (256-thread workgroup, LDS workspace) and for the host (1 "thread"; tests/qt_host_check.cc
+// compares it with orb_host.cc::distribute_quadtree on thousands of inputs).
+#pragma once
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define QT_HD __host__ __device__ __forceinline__
+#else
+#define QT_HD inline
+#endif
+
+namespace msorb {
+namespace qt {
+
+struct Pt {  // same layout as Cand16
+    uint16_t x, y, score, pad;
+};
+struct SortItem {  // one element of vSizeAndPointerToNode: key = count << 16 | UL.x (compareNodes order), node
+    uint32_t key, node;
+};
+
+constexpr int kLabelSettled = 0xFFFF;
+constexpr int kParityBit = 0x4000;
+constexpr int kSlotMask = 0x3FFF;
+
+// ---- libstdc++ std::sort restated for SortItem with compareNodes (ORBextractor.cc:538-553) -------------
+QT_HD bool sort_less(const SortItem& a, const SortItem& b) { return a.key < b.key; }
+QT_HD void sort_swap(SortItem* v, int i, int j) { const SortItem t = v[i]; v[i] = v[j]; v[j] = t; }
+
+QT_HD void adjust_heap(SortItem* v, int first, int hole, int len, SortItem value) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (sort_less(v[first + child], v[first + child - 1])) child--;
+        v[first + hole] = v[first + child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        v[first + hole] = v[first + child - 1];
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;  // __push_heap
+    while (hole > top && sort_less(v[first + parent], value)) {
+        v[first + hole] = v[first + parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    v[first + hole] = value;
+}
+QT_HD void heap_sort(SortItem* v, int first, int last) {  // __partial_sort(first, last, last)
+    const int len = last - first;
+    if (len >= 2) {
+        int parent = (len - 2) / 2;
+        for (;;) {
+            const SortItem value = v[first + parent];
+            adjust_heap(v, first, parent, len, value);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    int l = last;
+    while (l - first > 1) {
+        --l;
+        const SortItem value = v[l];
+        v[l] = v[first];
+        adjust_heap(v, first, 0, l - first, value);
+    }
+}
+QT_HD void unguarded_linear_insert(SortItem* v, int last) {
+    const SortItem val = v[last];
+    int next = last - 1;
+    while (sort_less(val, v[next])) {
+        v[last] = v[next];
+        last = next;
+        --next;
+    }
+    v[last] = val;
+}
+QT_HD void insertion_sort(SortItem* v, int first, int last) {
+    if (first == last) return;
+    for (int i = first + 1; i != last; ++i) {
+        if (sort_less(v[i], v[first])) {
+            const SortItem val = v[i];
+            for (int k = i; k > first; --k) v[k] = v[k - 1];
+            v[first] = val;
+        } else {
+            unguarded_linear_insert(v, i);
+        }
+    }
+}
+// std::sort(v, v + n, compareNodes).  The two sub-ranges produced by a partition are disjoint, so the order in
+// which __introsort_loop's recursion visits them does not affect the result; only the depth budget each range
+// inherits does.  `stack` holds (first, last, depth) records: 3 * 64 ints.
+QT_HD void lsort(SortItem* v, int n, int* stack) {
+    if (n <= 0) return;
+    int lg = 0;
+    for (int t = n; t > 1; t >>= 1) lg++;
+    int sp = 0;
+    stack[0] = 0; stack[1] = n; stack[2] = 2 * lg;
+    sp = 1;
+    while (sp > 0) {
+        sp--;
+        const int first = stack[3 * sp];
+        int last = stack[3 * sp + 1], depth = stack[3 * sp + 2];
+        while (last - first > 16) {  // __introsort_loop
+            if (depth == 0) {
+                heap_sort(v, first, last);
+                break;
+            }
+            --depth;
+            const int mid = first + (last - first) / 2;
+            {  // __move_median_to_first(first, first+1, mid, last-1)
+                const int a = first + 1, b = mid, c = last - 1;
+                if (sort_less(v[a], v[b])) {
+                    if (sort_less(v[b], v[c])) sort_swap(v, first, b);
+                    else if (sort_less(v[a], v[c])) sort_swap(v, first, c);
+                    else sort_swap(v, first, a);
+                } else if (sort_less(v[a], v[c])) sort_swap(v, first, a);
+                else if (sort_less(v[b], v[c])) sort_swap(v, first, c);
+                else sort_swap(v, first, b);
+            }
+            int lo = first + 1, hi = last;  // __unguarded_partition(first+1, last, pivot = *first)
+            for (;;) {
+                while (sort_less(v[lo], v[first])) ++lo;
+                --hi;
+                while (sort_less(v[first], v[hi])) --hi;
+                if (!(lo < hi)) break;
+                sort_swap(v, lo, hi);
+                ++lo;
+            }
+            stack[3 * sp] = lo; stack[3 * sp + 1] = last; stack[3 * sp + 2] = depth;  // [cut, last) later
+            sp++;
+            last = lo;
+        }
+    }
+    if (n > 16) {  // __final_insertion_sort
+        insertion_sort(v, 0, 16);
+        for (int i = 16; i < n; ++i) unguarded_linear_insert(v, i);
+    } else {
+        insertion_sort(v, 0, n);
+    }
+}
+
+
+// ---- the selection itself ----------------------------------------------------------------------------
+struct NodeB {  // a multi-point ("splittable") node of the current generation, stored by processing rank
+    int16_t x0, x1, y0, y1;
+    int32_t seq;    // creation sequence number (final list order = descending seq)
+    uint16_t slot;  // slot in its generation (creation order)
+    uint16_t pad;
+};
+struct Workspace {       // LDS on the device; `cap` = 4 * max(N, nIni) child slots per generation
+    int* cnt[2];         // points per child slot (re-used as best-point keys at the end)
+    uint16_t* rankof[2]; // child slot -> processing rank among multi-point nodes (0xFFFF = none)
+    NodeB* nb[2];        // multi-point nodes by rank, capacity N + 4
+    SortItem* items;     // capacity N + 4
+    int* stack;          // 3 * 64
+    int* res_seq;        // capacity res_cap
+    int* res_pt;
+    int* sc;             // scalars: see enum below
+    int* scan_tmp;       // 16 ints for the block-wide scans
+    int cap, res_cap;
+};
+enum { kScSize = 0, kScS0, kScS1, kScNres, kScNToExpand, kScNsplit, kScFinish, kScCareful, kScGenBase, kScCount };
+
+QT_HD size_t workspace_bytes(int N, int n_ini) {
+    const int m = N > n_ini ? N : n_ini;
+    const size_t cap = 4 * (size_t)m;
+    size_t b = 2 * cap * sizeof(int) + 2 * cap * sizeof(uint16_t) + 2 * (size_t)(m + 4) * sizeof(NodeB) +
+               (size_t)(m + 4) * sizeof(SortItem) + 3 * 64 * sizeof(int) + 2 * (size_t)(m + 8 + 4 * n_ini) * sizeof(int) +
+               (kScCount + 16) * sizeof(int);
+    return (b + 15) & ~size_t(15);
+}
+QT_HD void workspace_carve(Workspace& w, void* mem, int N, int n_ini) {
+    const int m = N > n_ini ? N : n_ini;
+    w.cap = 4 * m;
+    w.res_cap = m + 8 + 4 * n_ini;
+    char* p = (char*)mem;
+    w.cnt[0] = (int*)p; p += w.cap * sizeof(int);
+    w.cnt[1] = (int*)p; p += w.cap * sizeof(int);
+    w.nb[0] = (NodeB*)p; p += (m + 4) * sizeof(NodeB);
+    w.nb[1] = (NodeB*)p; p += (m + 4) * sizeof(NodeB);
+    w.items = (SortItem*)p; p += (m + 4) * sizeof(SortItem);
+    w.stack = (int*)p; p += 3 * 64 * sizeof(int);
+    w.res_seq = (int*)p; p += w.res_cap * sizeof(int);
+    w.res_pt = (int*)p; p += w.res_cap * sizeof(int);
+    w.sc = (int*)p; p += kScCount * sizeof(int);
+    w.scan_tmp = (int*)p; p += 16 * sizeof(int);
+    w.rankof[0] = (uint16_t*)p; p += w.cap * sizeof(uint16_t);
+    w.rankof[1] = (uint16_t*)p;
+}
+
+QT_HD int quadrant_of(const Pt& p, const NodeB& b) {  // DivideNode's assignment (:511-525)
+    const int mx = b.x0 + ((b.x1 - b.x0 + 1) >> 1), my = b.y0 + ((b.y1 - b.y0 + 1) >> 1);  // ceil(w/2), ceil(h/2)
+    return ((int)p.x < mx ? 0 : 1) + ((int)p.y < my ? 0 : 2);
+}
+
+// Returns the number of kept candidates; out_pt[i] = candidate index of the i-th keypoint in the reference's
+// result order.  `label` is an n-entry scratch array (global memory on the device).
+template <class Ex>
+QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, int N, Workspace& w, int* out_pt) {
+    if (n <= 0) return 0;
+    const int tid = ex.tid(), nt = ex.nthreads();
+    const int n_ini = (int)roundf((float)W / (float)H);           // :559
+    const float hX = (float)W / (float)n_ini;                      // :561
+    int* sc = w.sc;
+
+    // ---- initial columns (:568-601) = generation of parity 0, processing order = ascending column ----
+    for (int i = tid; i < n_ini; i += nt) w.cnt[0][i] = 0;
+    if (tid == 0) { sc[kScNres] = 0; sc[kScFinish] = 0; sc[kScCareful] = 0; sc[kScGenBase] = 0; }
+    ex.sync();
+    for (int p = tid; p < n; p += nt) {
+        const int c = (int)((float)pts[p].x / hX);                 // vpIniNodes[kp.pt.x/hX]
+        label[p] = (uint16_t)c;
+        ex.atomic_add(&w.cnt[0][c], 1);
+    }
+    ex.sync();
+    if (tid == 0) {
+        int size = 0, S = 0;
+        for (int i = 0; i < n_ini; i++) {
+            const int c = w.cnt[0][i];
+            w.rankof[0][i] = 0xFFFF;
+            if (c > 0) size++;
+            if (c > 1) {
+                NodeB b;
+                b.x0 = (int16_t)(int)(hX * (float)i); b.x1 = (int16_t)(int)(hX * (float)(i + 1));
+                b.y0 = 0; b.y1 = (int16_t)H;
+                b.seq = -1 - i; b.slot = (uint16_t)i; b.pad = 0;
+                w.rankof[0][i] = (uint16_t)S;
+                w.nb[0][S++] = b;
+            }
+        }
+        sc[kScSize] = size; sc[kScS0] = S;
+    }
+    ex.sync();
+    for (int p = tid; p < n; p += nt) {  // single-point columns are final (bNoMore, :590-594)
+        const int c = label[p];
+        if (w.cnt[0][c] == 1) {
+            const int r = ex.atomic_add(&sc[kScNres], 1);
+            w.res_seq[r] = -1 - c; w.res_pt[r] = p;
+            label[p] = kLabelSettled;
+        }
+    }
+    ex.sync();
+
+    int par = 0;
+    for (;;) {  // one iteration = one pass of the main loop (:610-681) or one sweep of the careful loop (:689-753)
+        const int np = par ^ 1;
+        const int S = sc[par ? kScS1 : kScS0];
+        const int careful = sc[kScCareful];
+        const int prev_size = sc[kScSize];
+        if (careful) {
+            // vPrevSizeAndPointerToNode in creation order = descending rank; sort; walk from the back
+            for (int i = tid; i < S; i += nt) {
+                const NodeB& b = w.nb[par][S - 1 - i];
+                w.items[i].key = ((uint32_t)w.cnt[par][b.slot] << 16) | (uint32_t)(uint16_t)b.x0;
+                w.items[i].node = (uint32_t)(S - 1 - i);
+            }
+            ex.sync();
+            if (tid == 0) lsort(w.items, S, w.stack);
+            ex.sync();
+            // new processing order r: items[S-1-r]; permute nb[par] accordingly (via nb[np] as scratch)
+            for (int r = tid; r < S; r += nt) w.nb[np][r] = w.nb[par][w.items[S - 1 - r].node];
+            ex.sync();
+            for (int r = tid; r < S; r += nt) { w.nb[par][r] = w.nb[np][r]; w.rankof[par][w.nb[par][r].slot] = (uint16_t)r; }
+        }
+        for (int i = tid; i < 4 * S; i += nt) w.cnt[np][i] = 0;
+        if (tid == 0) sc[kScNsplit] = S;
+        ex.sync();
+        // pass A: children counts of every multi-point node (speculative for the careful sweep)
+        for (int p = tid; p < n; p += nt) {
+            const int lab = label[p];
+            if (lab == kLabelSettled || ((lab & kParityBit) != 0) != (par != 0)) continue;
+            const int r = w.rankof[par][lab & kSlotMask];
+            ex.atomic_add(&w.cnt[np][4 * r + quadrant_of(pts[p], w.nb[par][r])], 1);
+        }
+        ex.sync();
+        if (careful) {  // :701-748: split from the largest until the quota is reached -> nsplit
+            const int kp = (S + nt - 1) / nt;
+            const int pb = tid * kp, pe = pb + kp < S ? pb + kp : S;
+            int local = 0;
+            for (int r = pb; r < pe; r++) {
+                int nch = 0;
+                for (int q = 0; q < 4; q++) nch += w.cnt[np][4 * r + q] > 0;
+                local += nch - 1;
+            }
+            int tot = 0;
+            int running = prev_size + ex.excl_scan(local, w.scan_tmp, &tot);
+            for (int r = pb; r < pe; r++) {
+                int nch = 0;
+                for (int q = 0; q < 4; q++) nch += w.cnt[np][4 * r + q] > 0;
+                running += nch - 1;
+                if (running >= N) { ex.atomic_min(&sc[kScNsplit], r + 1); break; }
+            }
+            ex.sync();
+        }
+        {
+            // next generation: children with more than one point, processing order = reverse creation order
+            const int nsplit_ = sc[kScNsplit];
+            const int genbase_ = sc[kScGenBase];
+            const int kk = (4 * nsplit_ + nt - 1) / nt;
+            const int sb = tid * kk, se = sb + kk < 4 * nsplit_ ? sb + kk : 4 * nsplit_;
+            int nz = 0, nx = 0;
+            for (int i = sb; i < se; i++) { nz += w.cnt[np][i] > 0; nx += w.cnt[np][i] > 1; }
+            int NZ = 0, NX = 0;
+            ex.excl_scan(nz, w.scan_tmp, &NZ);
+            int before = ex.excl_scan(nx, w.scan_tmp + 8, &NX);
+            for (int i = sb; i < se; i++) {
+                w.rankof[np][i] = 0xFFFF;
+                if (w.cnt[np][i] > 1) {
+                    const NodeB& pb_ = w.nb[par][i >> 2];
+                    const int q = i & 3;
+                    const int mx = pb_.x0 + ((pb_.x1 - pb_.x0 + 1) >> 1), my = pb_.y0 + ((pb_.y1 - pb_.y0 + 1) >> 1);
+                    NodeB b;
+                    b.x0 = (int16_t)((q & 1) ? mx : pb_.x0); b.x1 = (int16_t)((q & 1) ? pb_.x1 : mx);
+                    b.y0 = (int16_t)((q & 2) ? my : pb_.y0); b.y1 = (int16_t)((q & 2) ? pb_.y1 : my);
+                    b.seq = genbase_ + i; b.slot = (uint16_t)i; b.pad = 0;
+                    const int rank = NX - 1 - before;  // number of multi-point children created after this one
+                    before++;
+                    w.rankof[np][i] = (uint16_t)rank;
+                    w.nb[np][rank] = b;
+                }
+            }
+            if (tid == 0) {
+                const int size = prev_size - nsplit_ + NZ;
+                sc[np ? kScS1 : kScS0] = NX;
+                sc[kScNToExpand] = NX;
+                sc[kScSize] = size;
+                int finish = 0;
+                if (size >= N || size == prev_size) finish = 1;                      // :685 / :751
+                else if (!careful && size + 3 * NX > N) sc[kScCareful] = 1;          // :689
+                sc[kScFinish] = finish;
+            }
+        }
+        ex.sync();
+        const int nsplit = sc[kScNsplit], genbase = sc[kScGenBase];
+        // pass B: move the points of split nodes to their child; single-point children are final
+        for (int p = tid; p < n; p += nt) {
+            const int lab = label[p];
+            if (lab == kLabelSettled || ((lab & kParityBit) != 0) != (par != 0)) continue;
+            const int r = w.rankof[par][lab & kSlotMask];
+            if (r >= nsplit) continue;  // careful sweep stopped before this node: it stays whole
+            const int slot = 4 * r + quadrant_of(pts[p], w.nb[par][r]);
+            if (w.cnt[np][slot] == 1) {
+                const int k = ex.atomic_add(&sc[kScNres], 1);
+                w.res_seq[k] = genbase + slot; w.res_pt[k] = p;
+                label[p] = kLabelSettled;
+            } else {
+                label[p] = (uint16_t)((np ? kParityBit : 0) | slot);
+            }
+        }
+        ex.sync();
+        if (tid == 0) sc[kScGenBase] = genbase + 4 * S;
+        const int finish = sc[kScFinish];
+        ex.sync();
+        if (finish) {
+            // alive multi-point nodes: unsplit nodes of `par` (ranks nsplit..S) and the new children in `np`
+            const int Sn = sc[np ? kScS1 : kScS0];
+            for (int i = tid; i < S; i += nt) w.cnt[par][i] = 0;   // re-used as best-point keys, by rank
+            for (int i = tid; i < Sn; i += nt) w.cnt[np][i] = 0;
+            ex.sync();
+            for (int p = tid; p < n; p += nt) {  // first strictly greater response wins (:757-776)
+                const int lab = label[p];
+                if (lab == kLabelSettled) continue;
+                const int lp = (lab & kParityBit) ? 1 : 0;
+                const int r = w.rankof[lp][lab & kSlotMask];
+                ex.atomic_max(&w.cnt[lp][r], (int)(((uint32_t)pts[p].score << 22) | (uint32_t)(0x3FFFFF - p)));
+            }
+            ex.sync();
+            for (int i = tid; i < S - nsplit + Sn; i += nt) {
+                const int lp = i < S - nsplit ? par : np;
+                const int r = i < S - nsplit ? nsplit + i : i - (S - nsplit);
+                const int k = ex.atomic_add(&sc[kScNres], 1);
+                w.res_seq[k] = w.nb[lp][r].seq;
+                w.res_pt[k] = 0x3FFFFF - (w.cnt[lp][r] & 0x3FFFFF);
+            }
+            ex.sync();
+            break;
+        }
+        par = np;
+    }
+    // result order = descending creation sequence: rank sort (all seq are distinct)
+    const int nres = sc[kScNres];
+    for (int i = tid; i < nres; i += nt) {
+        const int s = w.res_seq[i];
+        int rank = 0;
+        for (int j = 0; j < nres; j++) rank += w.res_seq[j] > s;
+        out_pt[rank] = w.res_pt[i];
+    }
+    ex.sync();
+    return nres;
+}
+
+}  // namespace qt
+}  // namespace msorb

@@ -1,0 +1,138 @@
+// Device-side keypoint selection: one workgroup per (pyramid level, image) runs the generation-synchronous
+// DistributeOctTree of quadtree_device.h on the compacted FAST candidates, then one workgroup per image lays
+// out the selected keypoints in ORBextractor::operator()'s output order (ORBextractor.cc:1122-1163).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "orb_device.h"
+#include "quadtree_device.h"
+
+namespace msorb {
+
+struct DevEx {
+    __device__ int tid() const { return threadIdx.x; }
+    __device__ int nthreads() const { return blockDim.x; }
+    __device__ void sync() { __syncthreads(); }
+    __device__ int atomic_add(int* p, int v) { return atomicAdd(p, v); }
+    __device__ void atomic_max(int* p, int v) { atomicMax(p, v); }
+    __device__ void atomic_min(int* p, int v) { atomicMin(p, v); }
+    // block-wide exclusive prefix of v over threads (4 waves); tmp = 8 ints of LDS
+    __device__ int excl_scan(int v, int* tmp, int* total) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        __syncthreads();  // tmp may still be read by a previous scan
+        if (lane == 63) tmp[wave] = incl;
+        __syncthreads();
+        int before = 0, tot = 0;
+        for (int w = 0; w < 4; w++) {
+            const int c = tmp[w];
+            if (w < wave) before += c;
+            tot += c;
+        }
+        *total = tot;
+        return before + incl - v;
+    }
+};
+
+__global__ __launch_bounds__(256) void quadtree_select_kernel(QtLevels lv, const Cand16* __restrict__ compact,
+                                                              const int* __restrict__ img_base,
+                                                              const int* __restrict__ level_count, uint16_t* __restrict__ label,
+                                                              int* __restrict__ sel_pt /* [img][sel_stride] candidate idx */,
+                                                              int* __restrict__ sel_n /* [img][nlevels] */, int sel_stride,
+                                                              int ws_N, int ws_nini) {
+    extern __shared__ __attribute__((aligned(16))) char qt_mem[];
+    const int level = blockIdx.x, img = blockIdx.y;
+    const int* lc = level_count + (size_t)img * lv.nlevels;
+    int off = img_base[img];
+    for (int l = 0; l < level; l++) off += lc[l];
+    const int n = lc[level];
+    qt::Workspace w;
+    qt::workspace_carve(w, qt_mem, ws_N, ws_nini);
+    DevEx ex;
+    int* out = sel_pt + (size_t)img * sel_stride + lv.sel_off[level];
+    const int kept = qt::select(ex, reinterpret_cast<const qt::Pt*>(compact + off), n, label + off, lv.W[level], lv.H[level],
+                                lv.quota[level], w, out);
+    if (threadIdx.x == 0) sel_n[(size_t)img * lv.nlevels + level] = kept;
+}
+
+// One workgroup per image: records in level-major / quadtree order; output row = mono index from the front for
+// keypoints outside [lap0, lap1], stereo index from the back for those inside (ORBextractor.cc:1153-1162).
+__global__ __launch_bounds__(256) void quadtree_layout_kernel(QtLevels lv, const Cand16* __restrict__ compact,
+                                                              const int* __restrict__ img_base,
+                                                              const int* __restrict__ level_count,
+                                                              const int* __restrict__ sel_pt, const int* __restrict__ sel_n,
+                                                              int sel_stride, LevelScale scales, int lap0, int lap1,
+                                                              int capacity, SelRec* __restrict__ sel,
+                                                              int* __restrict__ sel_count, int* __restrict__ mono_out) {
+    __shared__ int lvl_begin[kMaxLevels + 1], cand_begin[kMaxLevels + 1];
+    __shared__ int part[256];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int a = 0, c = img_base[img];
+        for (int l = 0; l < lv.nlevels; l++) {
+            lvl_begin[l] = a; cand_begin[l] = c;
+            a += sel_n[(size_t)img * lv.nlevels + l];
+            c += level_count[(size_t)img * lv.nlevels + l];
+        }
+        lvl_begin[lv.nlevels] = a;
+    }
+    __syncthreads();
+    const int n_all = lvl_begin[lv.nlevels];
+    const int n = min(n_all, min(capacity, sel_stride));
+    const int per = (n + 255) / 256;
+    const int b = tid * per, e = min(b + per, n);
+    SelRec* out = sel + (size_t)img * sel_stride;
+    int lap_cnt = 0;
+    for (int g = b; g < e; g++) {
+        int l = 0;
+        while (g >= lvl_begin[l + 1]) l++;
+        const int pt = sel_pt[(size_t)img * sel_stride + lv.sel_off[l] + (g - lvl_begin[l])];
+        const Cand16 c = compact[cand_begin[l] + pt];
+        SelRec r;
+        r.x = (uint16_t)(c.x + kMinBorder); r.y = (uint16_t)(c.y + kMinBorder);
+        r.score = c.score; r.level = (uint8_t)l; r.pad = 0;
+        const float fx = l ? __fmul_rn((float)r.x, scales.scale[l]) : (float)r.x;
+        const bool lap = fx >= (float)lap0 && fx <= (float)lap1;
+        r.dst = lap ? -1 : 0;  // provisional
+        lap_cnt += lap;
+        out[g] = r;
+    }
+    part[tid] = lap_cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int i = 0; i < 256; i++) { const int v = part[i]; part[i] = acc; acc += v; }
+        sel_count[img] = n_all > n ? -n_all : n;   // negative = capacity exceeded (host turns it into an error)
+        mono_out[img] = n - acc;
+    }
+    __syncthreads();
+    int laps = part[tid];
+    for (int g = b; g < e; g++) {
+        if (out[g].dst < 0) { out[g].dst = n - 1 - laps; laps++; }
+        else out[g].dst = g - laps;
+    }
+}
+
+void launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_base, const int* level_count,
+                     uint16_t* label, int* sel_pt, int* sel_n, int sel_stride, const LevelScale& scales, int lap0,
+                     int lap1, int capacity, SelRec* sel, int* sel_count, int* mono, int n_images, hipStream_t s) {
+    int maxN = 1, max_ini = 1;
+    for (int l = 0; l < lv.nlevels; l++) { maxN = max(maxN, lv.quota[l]); max_ini = max(max_ini, lv.n_ini[l]); }
+    const size_t lds = qt::workspace_bytes(maxN, max_ini);
+    hipLaunchKernelGGL(quadtree_select_kernel, dim3(lv.nlevels, n_images), dim3(256), lds, s, lv, compact, img_base,
+                       level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini);
+    hipLaunchKernelGGL(quadtree_layout_kernel, dim3(n_images), dim3(256), 0, s, lv, compact, img_base, level_count, sel_pt,
+                       sel_n, sel_stride, scales, lap0, lap1, capacity, sel, sel_count, mono);
+}
+size_t quadtree_lds_bytes(const QtLevels& lv) {
+    int maxN = 1, max_ini = 1;
+    for (int l = 0; l < lv.nlevels; l++) { maxN = max(maxN, lv.quota[l]); max_ini = max(max_ini, lv.n_ini[l]); }
+    return qt::workspace_bytes(maxN, max_ini);
+}
+
+}  // namespace msorb

@@ -71,3 +71,15 @@ def test_host_quadtree_degenerate_inputs(msorb_mod, oracle):
             ref = oracle.distribute_quadtree(xs, ys, sc, 16, 1225, 16, 360, N)
             got = np.stack([xs[kept], ys[kept], sc[kept]], 1).astype(np.float32)
             assert np.array_equal(got, ref)
+
+
+def test_device_quadtree_algorithm_on_host(tmp_path):
+    """quadtree_device.h (the generation-synchronous DistributeOctTree the GPU runs, incl. the libstdc++
+    std::sort restatement) executed with one host 'thread' must reproduce orb_host.cc's result on thousands of
+    random / clustered / tie-heavy candidate sets."""
+    import subprocess
+    exe = tmp_path / "qt_host_check"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", os.path.join(ROOT, "tests", "qt_host_check.cc"),
+                           os.path.join(ROOT, "ms-slam_amd", "csrc", "orb_host.cc"), "-o", str(exe)])
+    out = subprocess.check_output([str(exe), "1500"]).decode()
+    assert "bad=0" in out, out
