@@ -48,36 +48,49 @@ constexpr int kSlotMask = 0x3FFF;
 
 // ---- libstdc++ std::sort restated for SortItem with compareNodes (ORBextractor.cc:538-553) -------------
 QT_HD bool sort_less(const SortItem& a, const SortItem& b) { return a.key < b.key; }
-QT_HD void sort_swap(SortItem* v, int i, int j) { const SortItem t = v[i]; v[i] = v[j]; v[j] = t; }
+// Storage accessor: the same sort runs on a plain array (host, LDS) or on items spread over the lanes of one
+// wave (device: element i lives in lane i & 63 of register i >> 6 and is reached with v_readlane / v_writelane,
+// so the serial comparison chain costs a few cycles per step instead of an LDS round trip).
+struct ArrayAcc {
+    SortItem* v;
+    QT_HD SortItem get(int i) const { return v[i]; }
+    QT_HD uint32_t key(int i) const { return v[i].key; }
+    QT_HD void set(int i, const SortItem& x) { v[i] = x; }
+};
 
-QT_HD void adjust_heap(SortItem* v, int first, int hole, int len, SortItem value) {
+template <class A>
+QT_HD void sort_swap(A& v, int i, int j) { const SortItem t = v.get(i); v.set(i, v.get(j)); v.set(j, t); }
+
+template <class A>
+QT_HD void adjust_heap(A& v, int first, int hole, int len, SortItem value) {
     const int top = hole;
     int child = hole;
     while (child < (len - 1) / 2) {
         child = 2 * (child + 1);
-        if (sort_less(v[first + child], v[first + child - 1])) child--;
-        v[first + hole] = v[first + child];
+        if (v.key(first + child) < v.key(first + child - 1)) child--;
+        v.set(first + hole, v.get(first + child));
         hole = child;
     }
     if ((len & 1) == 0 && child == (len - 2) / 2) {
         child = 2 * (child + 1);
-        v[first + hole] = v[first + child - 1];
+        v.set(first + hole, v.get(first + child - 1));
         hole = child - 1;
     }
     int parent = (hole - 1) / 2;  // __push_heap
-    while (hole > top && sort_less(v[first + parent], value)) {
-        v[first + hole] = v[first + parent];
+    while (hole > top && v.key(first + parent) < value.key) {
+        v.set(first + hole, v.get(first + parent));
         hole = parent;
         parent = (hole - 1) / 2;
     }
-    v[first + hole] = value;
+    v.set(first + hole, value);
 }
-QT_HD void heap_sort(SortItem* v, int first, int last) {  // __partial_sort(first, last, last)
+template <class A>
+QT_HD void heap_sort(A& v, int first, int last) {  // __partial_sort(first, last, last)
     const int len = last - first;
     if (len >= 2) {
         int parent = (len - 2) / 2;
         for (;;) {
-            const SortItem value = v[first + parent];
+            const SortItem value = v.get(first + parent);
             adjust_heap(v, first, parent, len, value);
             if (parent == 0) break;
             parent--;
@@ -86,28 +99,37 @@ QT_HD void heap_sort(SortItem* v, int first, int last) {  // __partial_sort(firs
     int l = last;
     while (l - first > 1) {
         --l;
-        const SortItem value = v[l];
-        v[l] = v[first];
+        const SortItem value = v.get(l);
+        v.set(l, v.get(first));
         adjust_heap(v, first, 0, l - first, value);
     }
 }
-QT_HD void unguarded_linear_insert(SortItem* v, int last) {
-    const SortItem val = v[last];
+template <class A>
+QT_HD void unguarded_linear_insert(A& v, int last) {
+    const SortItem val = v.get(last);
     int next = last - 1;
-    while (sort_less(val, v[next])) {
-        v[last] = v[next];
+    for (;;) {  // while (val < v[next]) { v[last] = v[next]; last = next; --next; }  with two items read ahead
+        const int j1 = next - 1 > 0 ? next - 1 : 0;
+        const SortItem a0 = v.get(next), a1 = v.get(j1);
+        if (!(val.key < a0.key)) break;
+        v.set(last, a0);
+        last = next;
+        --next;
+        if (!(val.key < a1.key)) break;
+        v.set(last, a1);
         last = next;
         --next;
     }
-    v[last] = val;
+    v.set(last, val);
 }
-QT_HD void insertion_sort(SortItem* v, int first, int last) {
+template <class A>
+QT_HD void insertion_sort(A& v, int first, int last) {
     if (first == last) return;
     for (int i = first + 1; i != last; ++i) {
-        if (sort_less(v[i], v[first])) {
-            const SortItem val = v[i];
-            for (int k = i; k > first; --k) v[k] = v[k - 1];
-            v[first] = val;
+        if (v.key(i) < v.key(first)) {
+            const SortItem val = v.get(i);
+            for (int k = i; k > first; --k) v.set(k, v.get(k - 1));
+            v.set(first, val);
         } else {
             unguarded_linear_insert(v, i);
         }
@@ -116,7 +138,8 @@ QT_HD void insertion_sort(SortItem* v, int first, int last) {
 // std::sort(v, v + n, compareNodes).  The two sub-ranges produced by a partition are disjoint, so the order in
 // which __introsort_loop's recursion visits them does not affect the result; only the depth budget each range
 // inherits does.  `stack` holds (first, last, depth) records: 3 * 64 ints.
-QT_HD void lsort(SortItem* v, int n, int* stack) {
+template <class A>
+QT_HD void lsort_acc(A& v, int n, int* stack) {
     if (n <= 0) return;
     int lg = 0;
     for (int t = n; t > 1; t >>= 1) lg++;
@@ -136,19 +159,45 @@ QT_HD void lsort(SortItem* v, int n, int* stack) {
             const int mid = first + (last - first) / 2;
             {  // __move_median_to_first(first, first+1, mid, last-1)
                 const int a = first + 1, b = mid, c = last - 1;
-                if (sort_less(v[a], v[b])) {
-                    if (sort_less(v[b], v[c])) sort_swap(v, first, b);
-                    else if (sort_less(v[a], v[c])) sort_swap(v, first, c);
+                const uint32_t ka = v.key(a), kb = v.key(b), kc = v.key(c);
+                if (ka < kb) {
+                    if (kb < kc) sort_swap(v, first, b);
+                    else if (ka < kc) sort_swap(v, first, c);
                     else sort_swap(v, first, a);
-                } else if (sort_less(v[a], v[c])) sort_swap(v, first, a);
-                else if (sort_less(v[b], v[c])) sort_swap(v, first, c);
+                } else if (ka < kc) sort_swap(v, first, a);
+                else if (kb < kc) sort_swap(v, first, c);
                 else sort_swap(v, first, b);
             }
             int lo = first + 1, hi = last;  // __unguarded_partition(first+1, last, pivot = *first)
+            const uint32_t pivot = v.key(first);
             for (;;) {
-                while (sort_less(v[lo], v[first])) ++lo;
+                // scans read four keys ahead (independent LDS reads in flight); positions past the range are clamped
+                // and only ever inspected after an in-range key has already stopped the scan
+                for (;;) {
+                    const int i1 = lo + 1 < n ? lo + 1 : n - 1, i2 = lo + 2 < n ? lo + 2 : n - 1, i3 = lo + 3 < n ? lo + 3 : n - 1;
+                    const uint32_t k0 = v.key(lo), k1 = v.key(i1), k2 = v.key(i2), k3 = v.key(i3);
+                    if (!(k0 < pivot)) break;
+                    ++lo;
+                    if (!(k1 < pivot)) break;
+                    ++lo;
+                    if (!(k2 < pivot)) break;
+                    ++lo;
+                    if (!(k3 < pivot)) break;
+                    ++lo;
+                }
                 --hi;
-                while (sort_less(v[first], v[hi])) --hi;
+                for (;;) {
+                    const int i1 = hi - 1 > 0 ? hi - 1 : 0, i2 = hi - 2 > 0 ? hi - 2 : 0, i3 = hi - 3 > 0 ? hi - 3 : 0;
+                    const uint32_t k0 = v.key(hi), k1 = v.key(i1), k2 = v.key(i2), k3 = v.key(i3);
+                    if (!(pivot < k0)) break;
+                    --hi;
+                    if (!(pivot < k1)) break;
+                    --hi;
+                    if (!(pivot < k2)) break;
+                    --hi;
+                    if (!(pivot < k3)) break;
+                    --hi;
+                }
                 if (!(lo < hi)) break;
                 sort_swap(v, lo, hi);
                 ++lo;
@@ -165,7 +214,120 @@ QT_HD void lsort(SortItem* v, int n, int* stack) {
         insertion_sort(v, 0, n);
     }
 }
+QT_HD void lsort(SortItem* v, int n, int* stack) {
+    ArrayAcc a{v};
+    lsort_acc(a, n, stack);
+}
 
+// ---- the same sort, data-parallel ------------------------------------------------------------------------
+// std::sort's result is a deterministic function of the key sequence, so it can be reproduced without walking
+// the comparison chain one element at a time:
+//  * __unguarded_partition(first+1, last, pivot): let G = positions holding a key >= pivot in ascending order and
+//    L = positions holding a key <= pivot in descending order.  The sequential scan swaps (G[t], L[t]) for
+//    t = 0, 1, ... while G[t] < L[t]; with k such swaps the returned cut is min(G[k], L[k-1]).  Ranks in G / L are
+//    prefix counts, so one scan + one scatter + one count replace the serial loop.
+//  * __final_insertion_sort is a sequence of stable insertions, i.e. a stable sort of whatever the introsort
+//    loop left behind: rank(i) = #{key < key_i} + #{j < i : key_j == key_i}.
+//  * median-of-three and the heapsort fallback (never reached on these inputs in practice) stay serial.
+// Ex: tid / nthreads / sync / excl_scan over the participating threads (one wave on the device).
+struct ParScratch {
+    uint16_t* gpos;   // capacity n
+    uint16_t* lpos;   // capacity n
+    SortItem* tmp;    // capacity n
+    int* scan_tmp;    // 16 ints
+    int* sc;          // 4 ints
+};
+
+template <class Ex>
+QT_HD int partition_par(Ex& ex, SortItem* v, int first, int last, ParScratch& ps) {
+    const int tid = ex.tid(), nt = ex.nthreads();
+    const uint32_t pivot = v[first].key;
+    const int m = last - (first + 1);
+    const int per = (m + nt - 1) / nt;
+    const int cb = first + 1 + tid * per, ce = cb + per < last ? cb + per : last;
+    int ng = 0, nl = 0;
+    for (int i = cb; i < ce; i++) { ng += v[i].key >= pivot; nl += v[i].key <= pivot; }
+    int tot = 0;
+    const int ex_packed = ex.excl_scan(ng | (nl << 16), ps.scan_tmp, &tot);
+    const int NG = tot & 0xFFFF, NL = tot >> 16;
+    int rg = ex_packed & 0xFFFF, ra = ex_packed >> 16;  // ascending exclusive ranks
+    for (int i = cb; i < ce; i++) {
+        if (v[i].key >= pivot) ps.gpos[rg++] = (uint16_t)i;
+        if (v[i].key <= pivot) { ps.lpos[NL - 1 - ra] = (uint16_t)i; ra++; }  // descending rank
+    }
+    if (tid == 0) ps.sc[0] = 0;
+    ex.sync();
+    const int T = NG < NL ? NG : NL;
+    int cnt = 0;
+    for (int t = tid; t < T; t += nt) cnt += ps.gpos[t] < ps.lpos[t];
+    int k = 0;
+    ex.excl_scan(cnt, ps.scan_tmp, &k);   // G[t] < L[t] is monotone in t: the count is the number of swaps
+    for (int t = tid; t < k; t += nt) {
+        const int a = ps.gpos[t], b = ps.lpos[t];
+        const SortItem x = v[a]; v[a] = v[b]; v[b] = x;
+    }
+    int cut = last;
+    if (k < NG) cut = ps.gpos[k];
+    if (k > 0 && (int)ps.lpos[k - 1] < cut) cut = ps.lpos[k - 1];
+    ex.sync();
+    return cut;
+}
+
+template <class Ex>
+QT_HD void lsort_par(Ex& ex, SortItem* v, int n, int* stack, ParScratch& ps) {
+    if (n <= 0) return;
+    const int tid = ex.tid(), nt = ex.nthreads();
+    int lg = 0;
+    for (int t = n; t > 1; t >>= 1) lg++;
+    int sp = 1;
+    if (tid == 0) { stack[0] = 0; stack[1] = n; stack[2] = 2 * lg; }
+    ex.sync();
+    while (sp > 0) {
+        sp--;
+        const int first = stack[3 * sp];
+        int last = stack[3 * sp + 1], depth = stack[3 * sp + 2];
+        ex.sync();
+        while (last - first > 16) {
+            if (depth == 0) {
+                if (tid == 0) { ArrayAcc a{v}; heap_sort(a, first, last); }
+                ex.sync();
+                break;
+            }
+            --depth;
+            if (tid == 0) {  // __move_median_to_first(first, first+1, mid, last-1)
+                ArrayAcc acc{v};
+                const int a = first + 1, b = first + (last - first) / 2, c = last - 1;
+                const uint32_t ka = v[a].key, kb = v[b].key, kc = v[c].key;
+                if (ka < kb) {
+                    if (kb < kc) sort_swap(acc, first, b);
+                    else if (ka < kc) sort_swap(acc, first, c);
+                    else sort_swap(acc, first, a);
+                } else if (ka < kc) sort_swap(acc, first, a);
+                else if (kb < kc) sort_swap(acc, first, c);
+                else sort_swap(acc, first, b);
+            }
+            ex.sync();
+            const int cut = partition_par(ex, v, first, last, ps);
+            if (tid == 0) { stack[3 * sp] = cut; stack[3 * sp + 1] = last; stack[3 * sp + 2] = depth; }
+            sp++;
+            ex.sync();
+            last = cut;
+        }
+    }
+    // __final_insertion_sort == stable sort of the current arrangement
+    for (int i = tid; i < n; i += nt) {
+        const uint32_t key = v[i].key;
+        int rank = 0;
+        for (int j = 0; j < n; j++) {
+            const uint32_t kj = v[j].key;
+            rank += (kj < key) || (kj == key && j < i);
+        }
+        ps.tmp[rank] = v[i];
+    }
+    ex.sync();
+    for (int i = tid; i < n; i += nt) v[i] = ps.tmp[i];
+    ex.sync();
+}
 
 // ---- the selection itself ----------------------------------------------------------------------------
 struct NodeB {  // a multi-point ("splittable") node of the current generation, stored by processing rank
@@ -183,7 +345,8 @@ struct Workspace {       // LDS on the device; `cap` = 4 * max(N, nIni) child sl
     int* res_seq;        // capacity res_cap
     int* res_pt;
     int* sc;             // scalars: see enum below
-    int* scan_tmp;       // 16 ints for the block-wide scans
+    int* scan_tmp;       // 2 x 16 ints for the block-wide scans
+    ParScratch ps;       // scratch of the data-parallel sort
     int cap, res_cap;
 };
 enum { kScSize = 0, kScS0, kScS1, kScNres, kScNToExpand, kScNsplit, kScFinish, kScCareful, kScGenBase, kScCount };
@@ -193,7 +356,7 @@ QT_HD size_t workspace_bytes(int N, int n_ini) {
     const size_t cap = 4 * (size_t)m;
     size_t b = 2 * cap * sizeof(int) + 2 * cap * sizeof(uint16_t) + 2 * (size_t)(m + 4) * sizeof(NodeB) +
                (size_t)(m + 4) * sizeof(SortItem) + 3 * 64 * sizeof(int) + 2 * (size_t)(m + 8 + 4 * n_ini) * sizeof(int) +
-               (kScCount + 16) * sizeof(int);
+               (kScCount + 32 + 16 + 4) * sizeof(int) + (size_t)(m + 4) * (sizeof(SortItem) + 2 * sizeof(uint16_t));
     return (b + 15) & ~size_t(15);
 }
 QT_HD void workspace_carve(Workspace& w, void* mem, int N, int n_ini) {
@@ -210,9 +373,14 @@ QT_HD void workspace_carve(Workspace& w, void* mem, int N, int n_ini) {
     w.res_seq = (int*)p; p += w.res_cap * sizeof(int);
     w.res_pt = (int*)p; p += w.res_cap * sizeof(int);
     w.sc = (int*)p; p += kScCount * sizeof(int);
-    w.scan_tmp = (int*)p; p += 16 * sizeof(int);
+    w.scan_tmp = (int*)p; p += 32 * sizeof(int);
+    w.ps.scan_tmp = (int*)p; p += 16 * sizeof(int);
+    w.ps.sc = (int*)p; p += 4 * sizeof(int);
+    w.ps.tmp = (SortItem*)p; p += (m + 4) * sizeof(SortItem);
     w.rankof[0] = (uint16_t*)p; p += w.cap * sizeof(uint16_t);
-    w.rankof[1] = (uint16_t*)p;
+    w.rankof[1] = (uint16_t*)p; p += w.cap * sizeof(uint16_t);
+    w.ps.gpos = (uint16_t*)p; p += (m + 4) * sizeof(uint16_t);
+    w.ps.lpos = (uint16_t*)p;
 }
 
 QT_HD int quadrant_of(const Pt& p, const NodeB& b) {  // DivideNode's assignment (:511-525)
@@ -223,7 +391,8 @@ QT_HD int quadrant_of(const Pt& p, const NodeB& b) {  // DivideNode's assignment
 // Returns the number of kept candidates; out_pt[i] = candidate index of the i-th keypoint in the reference's
 // result order.  `label` is an n-entry scratch array (global memory on the device).
 template <class Ex>
-QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, int N, Workspace& w, int* out_pt) {
+QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, int N, Workspace& w, int* out_pt,
+                 int debug = 0) {
     if (n <= 0) return 0;
     const int tid = ex.tid(), nt = ex.nthreads();
     const int n_ini = (int)roundf((float)W / (float)H);           // :559
@@ -268,8 +437,11 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
     }
     ex.sync();
 
+    if (debug == 2) return 0;
     int par = 0;
-    for (;;) {  // one iteration = one pass of the main loop (:610-681) or one sweep of the careful loop (:689-753)
+    int iter = 0;
+    for (;;) {
+        if (debug >= 10 && iter++ >= debug - 10) return 0;  // one iteration = one pass of the main loop (:610-681) or one sweep of the careful loop (:689-753)
         const int np = par ^ 1;
         const int S = sc[par ? kScS1 : kScS0];
         const int careful = sc[kScCareful];
@@ -282,24 +454,36 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
                 w.items[i].node = (uint32_t)(S - 1 - i);
             }
             ex.sync();
-            if (tid == 0) lsort(w.items, S, w.stack);
+            if (debug != 1) ex.sort(w.items, S, w.stack, w.ps);  // std::sort(vPrevSizeAndPointerToNode, compareNodes), :700
             ex.sync();
             // new processing order r: items[S-1-r]; permute nb[par] accordingly (via nb[np] as scratch)
             for (int r = tid; r < S; r += nt) w.nb[np][r] = w.nb[par][w.items[S - 1 - r].node];
             ex.sync();
             for (int r = tid; r < S; r += nt) { w.nb[par][r] = w.nb[np][r]; w.rankof[par][w.nb[par][r].slot] = (uint16_t)r; }
         }
+        ex.mark(0);
         for (int i = tid; i < 4 * S; i += nt) w.cnt[np][i] = 0;
         if (tid == 0) sc[kScNsplit] = S;
         ex.sync();
+        ex.mark(1);
         // pass A: children counts of every multi-point node (speculative for the careful sweep)
-        for (int p = tid; p < n; p += nt) {
-            const int lab = label[p];
-            if (lab == kLabelSettled || ((lab & kParityBit) != 0) != (par != 0)) continue;
-            const int r = w.rankof[par][lab & kSlotMask];
-            ex.atomic_add(&w.cnt[np][4 * r + quadrant_of(pts[p], w.nb[par][r])], 1);
+        for (int p0 = tid; p0 < n; p0 += 4 * nt) {  // 4 points per trip: the global loads are issued back to back
+            int lab4[4];
+            Pt pt4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int p = p0 + u * nt; lab4[u] = p < n ? label[p] : kLabelSettled; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int p = p0 + u * nt; pt4[u] = pts[p < n ? p : 0]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int lab = lab4[u];
+                if (lab == kLabelSettled || ((lab & kParityBit) != 0) != (par != 0)) continue;
+                const int r = w.rankof[par][lab & kSlotMask];
+                ex.atomic_add(&w.cnt[np][4 * r + quadrant_of(pt4[u], w.nb[par][r])], 1);
+            }
         }
         ex.sync();
+        ex.mark(2);
         if (careful) {  // :701-748: split from the largest until the quota is reached -> nsplit
             const int kp = (S + nt - 1) / nt;
             const int pb = tid * kp, pe = pb + kp < S ? pb + kp : S;
@@ -329,7 +513,7 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
             for (int i = sb; i < se; i++) { nz += w.cnt[np][i] > 0; nx += w.cnt[np][i] > 1; }
             int NZ = 0, NX = 0;
             ex.excl_scan(nz, w.scan_tmp, &NZ);
-            int before = ex.excl_scan(nx, w.scan_tmp + 8, &NX);
+            int before = ex.excl_scan(nx, w.scan_tmp + 16, &NX);
             for (int i = sb; i < se; i++) {
                 w.rankof[np][i] = 0xFFFF;
                 if (w.cnt[np][i] > 1) {
@@ -358,23 +542,35 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
             }
         }
         ex.sync();
+        ex.mark(3);
         const int nsplit = sc[kScNsplit], genbase = sc[kScGenBase];
         // pass B: move the points of split nodes to their child; single-point children are final
-        for (int p = tid; p < n; p += nt) {
-            const int lab = label[p];
-            if (lab == kLabelSettled || ((lab & kParityBit) != 0) != (par != 0)) continue;
-            const int r = w.rankof[par][lab & kSlotMask];
-            if (r >= nsplit) continue;  // careful sweep stopped before this node: it stays whole
-            const int slot = 4 * r + quadrant_of(pts[p], w.nb[par][r]);
-            if (w.cnt[np][slot] == 1) {
-                const int k = ex.atomic_add(&sc[kScNres], 1);
-                w.res_seq[k] = genbase + slot; w.res_pt[k] = p;
-                label[p] = kLabelSettled;
-            } else {
-                label[p] = (uint16_t)((np ? kParityBit : 0) | slot);
+        for (int p0 = tid; p0 < n; p0 += 4 * nt) {
+            int lab4[4];
+            Pt pt4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int p = p0 + u * nt; lab4[u] = p < n ? label[p] : kLabelSettled; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int p = p0 + u * nt; pt4[u] = pts[p < n ? p : 0]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int p = p0 + u * nt;
+                const int lab = lab4[u];
+                if (lab == kLabelSettled || ((lab & kParityBit) != 0) != (par != 0)) continue;
+                const int r = w.rankof[par][lab & kSlotMask];
+                if (r >= nsplit) continue;  // careful sweep stopped before this node: it stays whole
+                const int slot = 4 * r + quadrant_of(pt4[u], w.nb[par][r]);
+                if (w.cnt[np][slot] == 1) {
+                    const int k = ex.atomic_add(&sc[kScNres], 1);
+                    w.res_seq[k] = genbase + slot; w.res_pt[k] = p;
+                    label[p] = kLabelSettled;
+                } else {
+                    label[p] = (uint16_t)((np ? kParityBit : 0) | slot);
+                }
             }
         }
         ex.sync();
+        ex.mark(4);
         if (tid == 0) sc[kScGenBase] = genbase + 4 * S;
         const int finish = sc[kScFinish];
         ex.sync();

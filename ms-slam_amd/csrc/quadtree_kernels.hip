@@ -3,20 +3,59 @@
 // out the selected keypoints in ORBextractor::operator()'s output order (ORBextractor.cc:1122-1163).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "orb_device.h"
 #include "quadtree_device.h"
 
 namespace msorb {
 
+constexpr int kQtThreads = 512;
+
 struct DevEx {
+    // std::sort restatement, data-parallel form (quadtree_device.h lsort_par), executed by wave 0 only: inside one
+    // wave there is no s_barrier to pay and LDS operations complete in program order.
+    struct WaveEx {
+        __device__ int tid() const { return threadIdx.x & 63; }
+        __device__ int nthreads() const { return 64; }
+        __device__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        __device__ int excl_scan(int v, int*, int* total) {
+            const int lane = threadIdx.x & 63;
+            int incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            *total = __shfl(incl, 63);
+            return incl - v;
+        }
+    };
+    __device__ void sort(qt::SortItem* items, int n, int* stack, qt::ParScratch& ps) {
+        if (threadIdx.x < 64) {
+            WaveEx wex;
+            qt::lsort_par(wex, items, n, stack, ps);
+        }
+    }
+    int dbg = 0, n_marks = 0;
+    long long t_mark[48];
+    int id_mark[48];
+    __device__ void mark(int id) {
+        if (dbg == 3 && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && n_marks < 48) {
+            t_mark[n_marks] = wall_clock64(); id_mark[n_marks] = id; n_marks++;
+        }
+    }
+    __device__ void dump() {
+        if (dbg == 3 && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0)
+            for (int i = 1; i < n_marks; i++) printf("mark %d dt_us=%.2f\n", id_mark[i], (double)(t_mark[i] - t_mark[i - 1]) * 0.01);
+    }
     __device__ int tid() const { return threadIdx.x; }
     __device__ int nthreads() const { return blockDim.x; }
     __device__ void sync() { __syncthreads(); }
     __device__ int atomic_add(int* p, int v) { return atomicAdd(p, v); }
     __device__ void atomic_max(int* p, int v) { atomicMax(p, v); }
     __device__ void atomic_min(int* p, int v) { atomicMin(p, v); }
-    // block-wide exclusive prefix of v over threads (4 waves); tmp = 8 ints of LDS
+    // block-wide exclusive prefix of v over threads (<= 16 waves); tmp = 16 ints of LDS
     __device__ int excl_scan(int v, int* tmp, int* total) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         int incl = v;
@@ -29,7 +68,8 @@ struct DevEx {
         if (lane == 63) tmp[wave] = incl;
         __syncthreads();
         int before = 0, tot = 0;
-        for (int w = 0; w < 4; w++) {
+        const int nw = blockDim.x >> 6;
+        for (int w = 0; w < nw; w++) {
             const int c = tmp[w];
             if (w < wave) before += c;
             tot += c;
@@ -39,12 +79,12 @@ struct DevEx {
     }
 };
 
-__global__ __launch_bounds__(256) void quadtree_select_kernel(QtLevels lv, const Cand16* __restrict__ compact,
+__global__ __launch_bounds__(kQtThreads) void quadtree_select_kernel(QtLevels lv, const Cand16* __restrict__ compact,
                                                               const int* __restrict__ img_base,
                                                               const int* __restrict__ level_count, uint16_t* __restrict__ label,
                                                               int* __restrict__ sel_pt /* [img][sel_stride] candidate idx */,
                                                               int* __restrict__ sel_n /* [img][nlevels] */, int sel_stride,
-                                                              int ws_N, int ws_nini) {
+                                                              int ws_N, int ws_nini, int debug) {
     extern __shared__ __attribute__((aligned(16))) char qt_mem[];
     const int level = blockIdx.x, img = blockIdx.y;
     const int* lc = level_count + (size_t)img * lv.nlevels;
@@ -54,10 +94,12 @@ __global__ __launch_bounds__(256) void quadtree_select_kernel(QtLevels lv, const
     qt::Workspace w;
     qt::workspace_carve(w, qt_mem, ws_N, ws_nini);
     DevEx ex;
+    ex.dbg = debug;
     int* out = sel_pt + (size_t)img * sel_stride + lv.sel_off[level];
     const int kept = qt::select(ex, reinterpret_cast<const qt::Pt*>(compact + off), n, label + off, lv.W[level], lv.H[level],
-                                lv.quota[level], w, out);
+                                lv.quota[level], w, out, debug);
     if (threadIdx.x == 0) sel_n[(size_t)img * lv.nlevels + level] = kept;
+    ex.dump();
 }
 
 // One workgroup per image: records in level-major / quadtree order; output row = mono index from the front for
@@ -124,8 +166,9 @@ void launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_b
     int maxN = 1, max_ini = 1;
     for (int l = 0; l < lv.nlevels; l++) { maxN = max(maxN, lv.quota[l]); max_ini = max(max_ini, lv.n_ini[l]); }
     const size_t lds = qt::workspace_bytes(maxN, max_ini);
-    hipLaunchKernelGGL(quadtree_select_kernel, dim3(lv.nlevels, n_images), dim3(256), lds, s, lv, compact, img_base,
-                       level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini);
+    static const int dbg = getenv("MSORB_QT_DEBUG") ? atoi(getenv("MSORB_QT_DEBUG")) : 0;  // profiling only
+    hipLaunchKernelGGL(quadtree_select_kernel, dim3(lv.nlevels, n_images), dim3(kQtThreads), lds, s, lv, compact, img_base,
+                       level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg);
     hipLaunchKernelGGL(quadtree_layout_kernel, dim3(n_images), dim3(256), 0, s, lv, compact, img_base, level_count, sel_pt,
                        sel_n, sel_stride, scales, lap0, lap1, capacity, sel, sel_count, mono);
 }

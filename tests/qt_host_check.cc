@@ -17,10 +17,12 @@ struct HostEx {
     int tid() const { return 0; }
     int nthreads() const { return 1; }
     void sync() {}
+    void mark(int) {}
     int atomic_add(int* p, int v) { const int o = *p; *p = o + v; return o; }
     void atomic_max(int* p, int v) { if (v > *p) *p = v; }
     void atomic_min(int* p, int v) { if (v < *p) *p = v; }
     int excl_scan(int v, int*, int* total) { *total = v; return 0; }
+    void sort(qt::SortItem* v, int n, int* stack, qt::ParScratch&) { qt::lsort(v, n, stack); }
 };
 
 static int run_case(const std::vector<Cand16>& c, int W, int H, int N, bool verbose) {
@@ -53,8 +55,18 @@ int main(int argc, char** argv) {
         std::vector<qt::SortItem> b = a;
         std::sort(b.begin(), b.end(), [](const qt::SortItem& x, const qt::SortItem& y) { return x.key < y.key; });
         int stack[3 * 64];
+        std::vector<qt::SortItem> a2 = a;
         qt::lsort(a.data(), n, stack);
         for (int i = 0; i < n; i++) if (a[i].node != b[i].node) { bad++; break; }
+        total++;
+        // data-parallel formulation (what the GPU runs), executed by one host "thread"
+        std::vector<uint16_t> gp(n + 1), lp(n + 1);
+        std::vector<qt::SortItem> tmp(n + 1);
+        int scan_tmp[16], scs[4];
+        qt::ParScratch ps{gp.data(), lp.data(), tmp.data(), scan_tmp, scs};
+        HostEx hex;
+        qt::lsort_par(hex, a2.data(), n, stack, ps);
+        for (int i = 0; i < n; i++) if (a2[i].node != b[i].node) { bad++; if (bad < 4) fprintf(stderr, "lsort_par mismatch n=%d\n", n); break; }
         total++;
     }
     // 2. selection
