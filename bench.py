@@ -162,6 +162,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dt, kp_total = float(tmax[0]), int(t[1])
 
+    # second half of the metric: Gpairs/s of the brute-force Hamming match (left-eye descriptors of every pair
+    # against the right-eye descriptors of the same pair, dense top-2), on the descriptors just extracted
+    hamming = None
+    if world == 1:
+        counts_h, _, _, _ = ex.extract_batch(images, (0, 0), out=(d_kps, d_desc))
+        dq = d_desc[0::2].contiguous()
+        dtr = d_desc[1::2].contiguous()
+        nq = torch.from_numpy(np.ascontiguousarray(counts_h[0::2])).to(dev)
+        nt = torch.from_numpy(np.ascontiguousarray(counts_h[1::2])).to(dev)
+        msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=2, device=local)   # warm-up
+        reps = 20
+        _, _, _, ms = msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=reps, device=local)
+        pairs = int((counts_h[0::2].astype(np.int64) * counts_h[1::2].astype(np.int64)).sum())
+        hamming = {"gpairs_per_s": round(pairs * reps / (ms * 1e-3) / 1e9, 2), "pairs_per_launch": pairs,
+                   "ms_per_launch": round(ms / reps, 4), "kernel": "dense_top2_kernel",
+                   "bound": "integer VALU (xor + popcount), not HBM: (Q+T)*32 B per frame are reused Q*T times"}
+
     if rank == 0:
         steps = max(args.steps, 1)
         stages = {k: v / steps for k, v in stage_acc.items()}
@@ -206,6 +223,7 @@ def main():
             "pyramid_fast_gbs": round((sum(px[:-1]) + sum(px[1:]) + sum(px)) * n_img /
                                       ((stages["pyramid"] + stages["fast"]) * 1e-3) / 1e9, 2),
         }
+        out["hamming_match"] = hamming
         if world == 1 and args.cpu_pairs > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_pairs, 5000)
         else:

@@ -163,6 +163,17 @@ int msorb_hamming_top2(int device, const uint8_t* query_desc, int n_queries, con
                        const int* cand_begin, const int* cand_idx, int* best_idx, int* best_dist, int* second_idx,
                        int* second_dist);
 
+/* Dense brute-force top-2 Hamming match, batched and device resident (the knnMatch(k=2) shape of Frame.cc:1076
+ * and the dense mode of the matcher kernels): for each of n_frames frames, every query row against every train
+ * row of the same frame; candidates scanned in index order with strict '<' (ties -> lowest index).  d_* are
+ * DEVICE pointers: descriptors [n_frames][stride][32], counts [n_frames], outputs [n_frames][query_stride].
+ * The launch is repeated `repeats` times on a private stream between two HIP events; *elapsed_ms (may be NULL)
+ * receives the total.  max_train <= 2048. */
+int msorb_hamming_dense_top2_batch(int device, const uint8_t* d_query, const uint8_t* d_train, const int* d_n_query,
+                                   const int* d_n_train, int n_frames, int query_stride, int train_stride, int max_query,
+                                   int max_train, int* d_best_idx, int* d_best_dist, int* d_second_dist, int repeats,
+                                   float* elapsed_ms);
+
 /* Frame::ComputeStereoMatches (Frame.cc:743-913).  left/right are the two extractor handles whose last
  * msorb_extract() call produced the images' pyramids (mpORBextractorLeft/Right->mvImagePyramid stay on
  * the device).  Keypoint/descriptor arrays are host arrays as returned by msorb_extract.  Writes

@@ -275,4 +275,48 @@ void launch_stereo_match(const StereoArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(stereo_match_kernel, dim3((a.nL + 3) / 4), dim3(256), 0, s, a);
 }
 
+// Dense brute-force top-2 (SURVEY.md K6 "dense mode"; the knnMatch(k=2) shape of Frame.cc:1076): every query
+// of a frame against every train descriptor of the same frame, candidates scanned in index order with strict
+// '<' (best = lexicographic min of (distance, index), second = the runner-up).  One thread per query, the
+// frame's train descriptors staged once per workgroup in LDS (<= 2048 x 32 B = 64 KB) and broadcast-read.
+constexpr int kDenseMaxTrain = 2048;
+__global__ __launch_bounds__(256) void dense_top2_kernel(const uint8_t* __restrict__ q, const uint8_t* __restrict__ t,
+                                                        const int* __restrict__ n_q, const int* __restrict__ n_t,
+                                                        int q_stride, int t_stride, int* __restrict__ best_idx,
+                                                        int* __restrict__ best_dist, int* __restrict__ second_dist) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t tile[];
+    const int frame = blockIdx.y;
+    const int nq = n_q[frame], nt = min(n_t[frame], kDenseMaxTrain);
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= nq) return;
+    const uint64_t* ts = reinterpret_cast<const uint64_t*>(t + (size_t)frame * t_stride * 32);
+    for (int i = threadIdx.x; i < nt * 4; i += 256) tile[i] = ts[i];
+    __syncthreads();
+    if (qi >= nq) return;
+    const uint64_t* qp = reinterpret_cast<const uint64_t*>(q + ((size_t)frame * q_stride + qi) * 32);
+    const uint64_t a0 = qp[0], a1 = qp[1], a2 = qp[2], a3 = qp[3];
+    uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;  // (dist << 16) | index
+#pragma unroll 4
+    for (int j = 0; j < nt; j++) {
+        const int d = __popcll(a0 ^ tile[4 * j]) + __popcll(a1 ^ tile[4 * j + 1]) + __popcll(a2 ^ tile[4 * j + 2]) +
+                      __popcll(a3 ^ tile[4 * j + 3]);
+        const uint32_t key = ((uint32_t)d << 16) | (uint32_t)j;
+        const uint32_t lo = min(key, k0), hi = max(key, k0);
+        k0 = lo;
+        k1 = min(k1, hi);
+    }
+    const size_t o = (size_t)frame * q_stride + qi;
+    best_idx[o] = k0 == 0xFFFFFFFFu ? -1 : (int)(k0 & 0xFFFF);
+    best_dist[o] = k0 == 0xFFFFFFFFu ? 256 : (int)(k0 >> 16);
+    second_dist[o] = k1 == 0xFFFFFFFFu ? 256 : (int)(k1 >> 16);
+}
+
+void launch_dense_top2(const uint8_t* q, const uint8_t* t, const int* n_q, const int* n_t, int n_frames, int q_stride,
+                       int t_stride, int max_q, int max_t, int* bi, int* bd, int* sd, hipStream_t s) {
+    if (n_frames <= 0 || max_q <= 0) return;
+    const size_t lds = (size_t)min(max_t, kDenseMaxTrain) * 32;
+    hipLaunchKernelGGL(dense_top2_kernel, dim3((max_q + 255) / 256, n_frames), dim3(256), lds, s, q, t, n_q, n_t, q_stride,
+                       t_stride, bi, bd, sd);
+}
+
 }  // namespace msorb

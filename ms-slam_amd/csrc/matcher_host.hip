@@ -412,6 +412,41 @@ int msorb_hamming_top2(int device, const uint8_t* qdesc, int nq, const uint8_t* 
     return MSORB_OK;
 }
 
+int msorb_hamming_dense_top2_batch(int device, const uint8_t* d_query, const uint8_t* d_train, const int* d_n_query,
+                                   const int* d_n_train, int n_frames, int query_stride, int train_stride, int max_query,
+                                   int max_train, int* d_best_idx, int* d_best_dist, int* d_second_dist, int repeats,
+                                   float* elapsed_ms) {
+    if (n_frames < 0 || query_stride < max_query || train_stride < max_train || max_train > 2048 || max_query < 0 ||
+        (n_frames > 0 && (!d_query || !d_train || !d_n_query || !d_n_train || !d_best_idx || !d_best_dist || !d_second_dist)))
+        return MSORB_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        set_last_error("no usable HIP device (libmsorb has no CPU fallback)");
+        return MSORB_E_NO_DEVICE;
+    }
+    HIPCHK(hipSetDevice(device));
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, s);
+    for (int r = 0; e == hipSuccess && r < (repeats > 0 ? repeats : 1); r++)
+        launch_dense_top2(d_query, d_train, d_n_query, d_n_train, n_frames, query_stride, train_stride, max_query, max_train,
+                          d_best_idx, d_best_dist, d_second_dist, s);
+    if (e == hipSuccess) e = hipEventRecord(e1, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipGetLastError();
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (elapsed_ms) *elapsed_ms = ms;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(s);
+    if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return MSORB_E_HIP; }
+    return MSORB_OK;
+}
+
 int msorb_stereo_matches(msorb_extractor* left, msorb_extractor* right, const msorb_keypoint* kpsL, int nL,
                          const uint8_t* descL, const msorb_keypoint* kpsR, int nR, const uint8_t* descR, float mb,
                          float mbf, float* u_right, float* depth, int* n_oob) {

@@ -387,3 +387,23 @@ def visibility_csr(kf_slot_begin, slot_point, slot_cell, point_nobs, obs_begin, 
     return dict(n_cols=nc, col_point=col_point[:nc], obj_coef=obj[:nc], n_rows=nr, row_begin=row_begin[:nr + 1],
                 row_kind=row_kind[:nr], row_owner=row_owner[:nr], row_rhs=row_rhs[:nr], col_idx=col_idx[:nz],
                 n_max_obs=nmax.value)
+
+
+EXPORTS = EXPORTS + ("msorb_hamming_dense_top2_batch",)
+
+
+def hamming_dense_top2_batch(d_query, d_train, d_nq, d_nt, repeats=1, device=0):
+    """Dense brute-force top-2 on device tensors: d_query/d_train torch.uint8 [F, stride, 32], d_nq/d_nt torch.int32 [F].
+    -> (best_idx, best_dist, second_dist) torch.int32 [F, q_stride], elapsed_ms over `repeats` launches."""
+    import torch
+    L = lib()
+    L.msorb_hamming_dense_top2_batch.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]
+    F, qs, _ = d_query.shape
+    ts = d_train.shape[1]
+    outs = [torch.empty((F, qs), dtype=torch.int32, device=d_query.device) for _ in range(3)]
+    ms = C.c_float()
+    _check(L.msorb_hamming_dense_top2_batch(device, d_query.data_ptr(), d_train.data_ptr(), d_nq.data_ptr(), d_nt.data_ptr(),
+                                            F, qs, ts, int(d_nq.max()), int(d_nt.max()), outs[0].data_ptr(),
+                                            outs[1].data_ptr(), outs[2].data_ptr(), repeats, C.byref(ms)),
+           "msorb_hamming_dense_top2_batch")
+    return outs[0], outs[1], outs[2], ms.value

@@ -117,3 +117,27 @@ def test_hamming_top2_lists(msorb_mod, oracle):
         assert (bi[i], bd[i], sd[i]) == (best, bdist, sdist)
         if sec >= 0:
             assert oracle.descriptor_distance(q[i], t[si[i]]) == sdist
+
+
+def test_dense_top2_batch(msorb_mod, oracle):
+    import torch
+    rng = np.random.Generator(np.random.PCG64(21))
+    F, cap = 3, 512
+    nq = np.array([500, 37, 0], np.int32)
+    nt = np.array([450, 512, 100], np.int32)
+    q = rng.integers(0, 256, (F, cap, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (F, cap, 32), dtype=np.uint8)
+    t[0, 100:110] = t[0, 100]                       # duplicates: lowest index must win
+    q[0, :50] = t[0, rng.integers(0, 450, 50)]      # exact matches
+    bi, bd, sd, ms = msorb_mod.hamming_dense_top2_batch(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda(),
+                                                       torch.from_numpy(nq).cuda(), torch.from_numpy(nt).cuda())
+    bi, bd, sd = bi.cpu().numpy(), bd.cpu().numpy(), sd.cpu().numpy()
+    for f in range(F):
+        if nq[f] == 0:
+            continue
+        d = np.unpackbits(q[f, :nq[f], None, :] ^ t[f, None, :nt[f], :], axis=2).sum(2)     # [nq, nt]
+        order = np.argsort(d, axis=1, kind="stable")
+        assert np.array_equal(bi[f, :nq[f]], order[:, 0])
+        assert np.array_equal(bd[f, :nq[f]], np.take_along_axis(d, order[:, :1], 1)[:, 0])
+        assert np.array_equal(sd[f, :nq[f]], np.take_along_axis(d, order[:, 1:2], 1)[:, 0])
+    assert oracle.descriptor_distance(q[0, 0], t[0, bi[0, 0]]) == bd[0, 0] == 0
