@@ -213,8 +213,10 @@ int ensure_geometry(msorb_extractor* h, int rows, int cols) {
     for (int l = 1; l < g.nlevels; l++) {
         auto tx = make_resize_taps(g.lv[l].w, g.lv[l - 1].w, true);
         auto ty = make_resize_taps(g.lv[l].h, g.lv[l - 1].h, false);
+        while (all.size() & 3) all.push_back(ResizeTap{0, 0, 0, 0});  // 32-byte aligned x tables (uint4 loads)
         h->tap_x_off[l] = all.size();
         all.insert(all.end(), tx.begin(), tx.end());
+        while (all.size() & 3) all.push_back(tx.back());             // a group of 4 taps may run past the last column
         h->tap_y_off[l] = all.size();
         all.insert(all.end(), ty.begin(), ty.end());
     }

@@ -47,6 +47,53 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(LevelView src, LevelVie
     *reinterpret_cast<uint32_t*>(d) = packed;
 }
 
+// Aligned streaming variant: the six source pixels a 4-pixel group can touch ([sx(dx0), sx(dx0+3)+1]) lie inside
+// three aligned dwords per source row, so a thread issues 6 coalesced dword loads + 2 x 16-byte tap loads instead
+// of 16 byte loads; taps pick their two neighbouring bytes with v_alignbyte on a selected dword pair.
+__device__ __forceinline__ uint32_t pick2(uint32_t w0, uint32_t w1, uint32_t w2, int o) {
+    // bytes o, o+1 of the 12-byte window {w2,w1,w0} in the low 16 bits (o in [0, 10])
+    const uint32_t lo = o < 4 ? w0 : (o < 8 ? w1 : w2);
+    const uint32_t hi = o < 4 ? w1 : (o < 8 ? w2 : 0u);
+    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(o & 3));
+}
+__global__ __launch_bounds__(256) void pyr_resize_aligned_kernel(LevelView src, LevelView dst, uint8_t* __restrict__ dst_base,
+                                                                 const ResizeTap* __restrict__ tx,
+                                                                 const ResizeTap* __restrict__ ty) {
+    const int img = blockIdx.z;
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    if (dy >= dst.h || dx0 >= dst.w) return;
+    const ResizeTap vy = ty[dy];
+    // the 4 x-taps of this group: 32 contiguous bytes (the table is padded to a multiple of 4 entries)
+    const uint4 ta = reinterpret_cast<const uint4*>(tx + dx0)[0];
+    const uint4 tb = reinterpret_cast<const uint4*>(tx + dx0)[1];
+    const uint32_t tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};  // per tap: {i0|i1<<16, c0|c1<<16}
+    const int base = (int)(tw[0] & 0xffffu) & ~3;  // aligned column of the first source pixel
+    const uint8_t* s0 = src.base + (size_t)img * src.img_stride + (size_t)vy.i0 * src.pitch + base;
+    const uint8_t* s1 = src.base + (size_t)img * src.img_stride + (size_t)vy.i1 * src.pitch + base;
+    const uint32_t a0 = reinterpret_cast<const uint32_t*>(s0)[0], a1 = reinterpret_cast<const uint32_t*>(s0)[1],
+                   a2 = reinterpret_cast<const uint32_t*>(s0)[2];
+    const uint32_t b0w = reinterpret_cast<const uint32_t*>(s1)[0], b1w = reinterpret_cast<const uint32_t*>(s1)[1],
+                   b2w = reinterpret_cast<const uint32_t*>(s1)[2];
+    const int b0 = vy.c0, b1 = vy.c1;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int i0 = (int)(tw[2 * i] & 0xffffu), i1 = (int)(tw[2 * i] >> 16);
+        const int c0 = (int)(int16_t)(tw[2 * i + 1] & 0xffffu), c1 = (int)(int16_t)(tw[2 * i + 1] >> 16);
+        const int o = i0 - base;
+        const uint32_t pa = pick2(a0, a1, a2, o), pb = pick2(b0w, b1w, b2w, o);
+        // second tap = next pixel, except at the right edge where i1 == i0 (and c1 == 0)
+        const int sh = (i1 != i0) ? 8 : 0;
+        const int h0 = (int)(pa & 255u) * c0 + (int)((pa >> sh) & 255u) * c1;
+        const int h1 = (int)(pb & 255u) * c0 + (int)((pb >> sh) & 255u) * c1;
+        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        packed |= (uint32_t)(v & 255) << (8 * i);
+    }
+    uint8_t* d = dst_base + (size_t)img * dst.img_stride + (size_t)dy * dst.pitch + dx0;
+    *reinterpret_cast<uint32_t*>(d) = packed;
+}
+
 // ------------------------------------------------------------------------------------------------
 // FAST-9/16 on one reference cell ROI per workgroup (cell loop + cv::FAST, ORBextractor.cc:805-872).
 //   phase 0  stage the ROI (<= 76x76 bytes) in LDS, keeping the global 4-byte column phase so that every
@@ -151,8 +198,15 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
     __shared__ int wave_tot[2][4];
     uint8_t* const tile = tile_mem + kTileFront;
 
-    const int cell_id = blockIdx.x;
-    const int img = blockIdx.y;
+    // XCD-aware order: consecutive workgroups are dealt round-robin to the 8 XCDs (each with a private L2); remap
+    // the linear id so that every XCD works through one contiguous run of (image, cell) pairs and neighbouring
+    // cells — which share their 3-pixel halo and 128-byte lines — hit the same L2.
+    const unsigned total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned chunk = (total + 7) >> 3;
+    unsigned wg = (lin & 7u) * chunk + (lin >> 3);
+    if (total & 7u) wg = lin;  // ragged totals keep the plain order (bench / test geometries are multiples of 8 images)
+    const int cell_id = wg % gridDim.x;
+    const int img = wg / gridDim.x;
     const CellDesc cd = cells[cell_id];
     const LevelView lv = pyr.lv[cd.level];
     const int rw = cd.rw, rh = cd.rh;
@@ -661,7 +715,12 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
 void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_base, const ResizeTap* tx,
                        const ResizeTap* ty, int n_images, hipStream_t s) {
     dim3 grid((dst.w + 255) / 256, (dst.h + 3) / 4, n_images);
-    hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
+    // aligned variant: source rows start on 4-byte boundaries and may be read up to the next multiple of 4 past w
+    const bool aligned = (reinterpret_cast<uintptr_t>(src.base) & 3) == 0 && (src.pitch & 3) == 0 &&
+                         (src.img_stride & 3) == 0 && src.pitch >= ((src.w + 3) & ~3) + 8 &&
+                         (reinterpret_cast<uintptr_t>(tx) & 15) == 0;
+    if (aligned) hipLaunchKernelGGL(pyr_resize_aligned_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
+    else hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
 }
 void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cells, int ini_th, int min_th,
                        int slots_per_image, Cand16* slots, int* cell_count, int n_images, hipStream_t s) {
