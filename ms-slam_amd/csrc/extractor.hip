@@ -147,12 +147,22 @@ struct PinBuf {
 
 }  // namespace
 
+constexpr int kMaxGroups = 4;
+struct StreamGroup {  // one sub-batch pipeline: main stream, blur stream, sync + timing events
+    hipStream_t s = nullptr, s2 = nullptr;
+    hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
+    hipEvent_t pe[10] = {};
+    bool ready = false;
+};
+
 struct msorb_extractor {
     int device = 0;
+    StreamGroup grp[kMaxGroups];
+    int n_groups = 2;
     OrbParams P;
     hipStream_t stream = nullptr, copy_stream = nullptr;
-    hipEvent_t ev_compact = nullptr;
-    hipEvent_t pe[8] = {};
+    hipEvent_t ev_compact = nullptr, ev_pyramid = nullptr, ev_blur = nullptr;
+    hipEvent_t pe[10] = {};
     bool profiling = false;
     float stage_ms[MSORB_N_STAGES] = {};
 
@@ -185,6 +195,7 @@ struct msorb_extractor {
     // last call
     PyramidView last_pyr{}, last_blur{};
     int last_n_images = 0;
+    int last_groups = 1;
     int sel_stride = 0;
 
     std::unique_ptr<Pool> pool;
@@ -264,7 +275,7 @@ int ensure_batch(msorb_extractor* h, int n_images) {
     if ((rc = h->d_cell_off.ensure((size_t)n_images * ncells))) return rc;
     if ((rc = h->d_level_count.ensure((size_t)n_images * g.nlevels))) return rc;
     if ((rc = h->d_img_total.ensure(n_images))) return rc;
-    if ((rc = h->d_img_base.ensure(n_images + 1))) return rc;
+    if ((rc = h->d_img_base.ensure(n_images + 1 + kMaxGroups))) return rc;
     if ((rc = h->d_sel_count.ensure(n_images))) return rc;
     if ((rc = h->d_sel.ensure((size_t)n_images * h->sel_stride))) return rc;
     if ((rc = h->h_level_count.ensure((size_t)n_images * g.nlevels))) return rc;
@@ -315,9 +326,113 @@ int fetch_candidates(msorb_extractor* h, int n_images) {
     return MSORB_OK;
 }
 
+int ensure_group(msorb_extractor* h, int gi) {
+    StreamGroup& G = h->grp[gi];
+    if (G.ready) return MSORB_OK;
+    HIPCHK(hipStreamCreateWithFlags(&G.s, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&G.s2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&G.ev_pyr, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&G.ev_blur, hipEventDisableTiming));
+    for (auto& e : G.pe) HIPCHK(hipEventCreate(&e));
+    G.ready = true;
+    return MSORB_OK;
+}
+
+// Device-only pipeline (device quadtree) over several sub-batches, each on its own pair of streams, so that the
+// latency-bound quadtree of one sub-batch overlaps the FAST / pyramid kernels of the next; inside a sub-batch
+// the blur runs on the second stream.  No host work between the stages; one read-back of the counts at the end.
+int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_images, int lap0, int lap1,
+                        msorb_keypoint* d_kps, uint8_t* d_desc, int capacity, int* h_counts, int* h_mono) {
+    const FrameGeom& g = h->G;
+    const int nl = g.nlevels;
+    const int ncells = (int)g.cells.size();
+    const bool prof = h->profiling;
+    const int sel_stride = h->sel_stride;
+    int ng = n_images >= 16 ? std::min(h->n_groups, kMaxGroups) : 1;
+    ng = std::max(1, std::min(ng, n_images));
+    const PyramidView pyr_all = make_view(h, h->d_pyr.p, &level0);
+    const PyramidView blur_all = make_view(h, h->d_blur.p, nullptr);
+    h->last_pyr = pyr_all; h->last_blur = blur_all; h->last_n_images = n_images;
+    h->h_pyr_valid = false;
+    h->compact_on_host = false;
+    h->last_groups = ng;
+    // the new call must not start before the handle's own stream has drained (H2D of level 0 in msorb_extract)
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int first = 0;
+    for (int gi = 0; gi < ng; gi++) {
+        int rc;
+        if ((rc = ensure_group(h, gi))) return rc;
+        StreamGroup& G = h->grp[gi];
+        const int n = (n_images - first) / (ng - gi);
+        hipStream_t s = G.s;
+        auto mark = [&](int i, hipStream_t st) { if (prof) (void)hipEventRecord(G.pe[i], st); };
+        LevelView l0 = level0;
+        l0.base = level0.base + (size_t)first * level0.img_stride;
+        uint8_t* pyr_base = h->d_pyr.p + (size_t)first * g.pyramid_bytes;
+        const PyramidView pyr = make_view(h, pyr_base, &l0);
+        const PyramidView blur = make_view(h, h->d_blur.p + (size_t)first * g.pyramid_bytes, nullptr);
+        int* img_base = h->d_img_base.p + first + gi;
+        const size_t cslot = (size_t)first * g.slots_per_image;
+        mark(0, s);
+        for (int l = 1; l < nl; l++)
+            launch_pyr_resize(pyr.lv[l - 1], pyr.lv[l], pyr_base + g.lv[l].plane_off, h->d_taps.p + h->tap_x_off[l],
+                              h->d_taps.p + h->tap_y_off[l], n, s);
+        mark(1, s);
+        HIPCHK(hipEventRecord(G.ev_pyr, s));
+        HIPCHK(hipStreamWaitEvent(G.s2, G.ev_pyr, 0));
+        mark(7, G.s2);
+        launch_gauss7(pyr, blur, n, G.s2);
+        mark(8, G.s2);
+        HIPCHK(hipEventRecord(G.ev_blur, G.s2));
+        launch_fast_cells(pyr, h->d_cells.p, ncells, h->P.ini_th, h->P.min_th, g.slots_per_image, h->d_slots.p + cslot,
+                          h->d_cell_count.p + (size_t)first * ncells, n, s);
+        mark(2, s);
+        launch_cand_compact(h->d_cells.p, ncells, h->d_level_cell_begin.p, nl, g.slots_per_image, h->d_slots.p + cslot,
+                            h->d_cell_count.p + (size_t)first * ncells, h->d_cell_off.p + (size_t)first * ncells,
+                            h->d_level_count.p + (size_t)first * nl, h->d_img_total.p + first, img_base,
+                            h->d_compact.p + cslot, n, s);
+        mark(3, s);
+        launch_quadtree(h->qt, h->d_compact.p + cslot, img_base, h->d_level_count.p + (size_t)first * nl,
+                        h->d_label.p + cslot, h->d_sel_pt.p + (size_t)first * sel_stride, h->d_sel_n.p + (size_t)first * nl,
+                        sel_stride, h->scales, lap0, lap1, capacity, h->d_sel.p + (size_t)first * sel_stride,
+                        h->d_sel_count.p + first, h->d_mono.p + first, n, s);
+        mark(5, s);
+        HIPCHK(hipStreamWaitEvent(s, G.ev_blur, 0));
+        launch_describe(pyr, blur, h->d_sel.p + (size_t)first * sel_stride, h->d_sel_count.p + first, sel_stride, h->scales,
+                        d_kps + (size_t)first * capacity, d_desc + (size_t)first * capacity * 32, capacity,
+                        std::min(capacity, sel_stride), n, s);
+        mark(6, s);
+        HIPCHK(hipMemcpyAsync(h->h_sel_count.p + first, h->d_sel_count.p + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h->h_mono.p + first, h->d_mono.p + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+        first += n;
+    }
+    for (int gi = 0; gi < ng; gi++) HIPCHK(hipStreamSynchronize(h->grp[gi].s));
+    HIPCHK(hipGetLastError());
+    for (int i = 0; i < n_images; i++) {
+        if (h->h_sel_count.p[i] < 0) { set_error("keypoint capacity exceeded"); return MSORB_E_CAPACITY; }
+        h_counts[i] = h->h_sel_count.p[i];
+        if (h_mono) h_mono[i] = h->h_mono.p[i];
+    }
+    if (prof) {  // stage time = sum over the sub-batches of the stage's HIP-event interval on its own stream
+        const int map[6][3] = {{MSORB_STAGE_PYRAMID, 0, 1}, {MSORB_STAGE_FAST, 1, 2}, {MSORB_STAGE_COMPACT, 2, 3},
+                               {MSORB_STAGE_BLUR, 7, 8}, {MSORB_STAGE_SELECT, 3, 5}, {MSORB_STAGE_DESCRIBE, 5, 6}};
+        for (auto& m : map) h->stage_ms[m[0]] = 0;
+        for (int gi = 0; gi < ng; gi++)
+            for (auto& m : map) {
+                float ms = 0;
+                HIPCHK(hipEventElapsedTime(&ms, h->grp[gi].pe[m[1]], h->grp[gi].pe[m[2]]));
+                h->stage_ms[m[0]] += ms;
+            }
+    }
+    return MSORB_OK;
+}
+
 // The pipeline proper.  level0: where level 0 of every image lives (device memory).
 int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int lap0, int lap1,
                  msorb_keypoint* d_kps, uint8_t* d_desc, int capacity, int* h_counts, int* h_mono) {
+    if (h->device_quadtree && !getenv("MSORB_SERIAL_PIPELINE"))
+        return run_pipeline_groups(h, level0, n_images, lap0, lap1, d_kps, d_desc, capacity, h_counts, h_mono);
+    h->last_groups = 1;
     const FrameGeom& g = h->G;
     const int nl = g.nlevels;
     const int ncells = (int)g.cells.size();
@@ -335,6 +450,17 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
         launch_pyr_resize(pyr.lv[l - 1], pyr.lv[l], h->d_pyr.p + g.lv[l].plane_off, h->d_taps.p + h->tap_x_off[l],
                           h->d_taps.p + h->tap_y_off[l], n_images, s);
     mark(1);
+    // the blur only feeds the descriptor stage: unless stage timing is on, it runs on the second stream, overlapping
+    // the (VALU-bound) FAST kernel and the (latency-bound) quadtree with a bandwidth-bound kernel
+    const bool overlap_blur = !(getenv("MSORB_SERIAL_BLUR") != nullptr);
+    if (overlap_blur) {
+        HIPCHK(hipEventRecord(h->ev_pyramid, s));
+        HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_pyramid, 0));
+        if (prof) (void)hipEventRecord(h->pe[7], h->copy_stream);
+        launch_gauss7(pyr, blur, n_images, h->copy_stream);
+        if (prof) (void)hipEventRecord(h->pe[8], h->copy_stream);
+        HIPCHK(hipEventRecord(h->ev_blur, h->copy_stream));
+    }
     launch_fast_cells(pyr, h->d_cells.p, ncells, h->P.ini_th, h->P.min_th, g.slots_per_image, h->d_slots.p,
                       h->d_cell_count.p, n_images, s);
     mark(2);
@@ -343,7 +469,7 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
                         h->d_compact.p, n_images, s);
     mark(3);
     HIPCHK(hipEventRecord(h->ev_compact, s));
-    launch_gauss7(pyr, blur, n_images, s);
+    if (!overlap_blur) launch_gauss7(pyr, blur, n_images, s);
     mark(4);
     h->compact_on_host = false;
     const int sel_stride = h->sel_stride;
@@ -355,6 +481,7 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
                         h->d_sel_n.p, sel_stride, h->scales, lap0, lap1, capacity, h->d_sel.p, h->d_sel_count.p,
                         h->d_mono.p, n_images, s);
         mark(5);
+        if (overlap_blur) HIPCHK(hipStreamWaitEvent(s, h->ev_blur, 0));
         launch_describe(pyr, blur, h->d_sel.p, h->d_sel_count.p, sel_stride, h->scales, d_kps, d_desc, capacity,
                         std::min(capacity, sel_stride), n_images, s);
         mark(6);
@@ -415,6 +542,7 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
         HIPCHK(hipMemcpyAsync(h->d_sel_count.p, h->h_sel_count.p, (size_t)n_images * sizeof(int), hipMemcpyHostToDevice, s));
         t1 = std::chrono::steady_clock::now();
         mark(5);
+        if (overlap_blur) HIPCHK(hipStreamWaitEvent(s, h->ev_blur, 0));
         launch_describe(pyr, blur, h->d_sel.p, h->d_sel_count.p, sel_stride, h->scales, d_kps, d_desc, capacity, max_sel,
                         n_images, s);
         mark(6);
@@ -424,7 +552,7 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
     if (prof) {
         float ms = 0;
         const int map[5][3] = {{MSORB_STAGE_PYRAMID, 0, 1}, {MSORB_STAGE_FAST, 1, 2}, {MSORB_STAGE_COMPACT, 2, 3},
-                               {MSORB_STAGE_BLUR, 3, 4}, {MSORB_STAGE_DESCRIBE, 5, 6}};
+                               {MSORB_STAGE_BLUR, overlap_blur ? 7 : 3, overlap_blur ? 8 : 4}, {MSORB_STAGE_DESCRIBE, 5, 6}};
         for (auto& m : map) {
             HIPCHK(hipEventElapsedTime(&ms, h->pe[m[1]], h->pe[m[2]]));
             h->stage_ms[m[0]] = ms;
@@ -494,7 +622,9 @@ int msorb_extractor_create(int nfeatures, float scale_factor, int nlevels, int i
     }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_compact, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->ev_compact, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_pyramid, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming) != hipSuccess) {
         set_error("stream/event creation failed");
         delete h;
         return MSORB_E_HIP;
@@ -506,6 +636,7 @@ int msorb_extractor_create(int nfeatures, float scale_factor, int nlevels, int i
     if (const char* e = getenv("MSORB_HOST_THREADS")) nthreads = atoi(e);
     nthreads = std::max(1, std::min(nthreads, 64));
     h->pool.reset(new Pool(nthreads));
+    if (const char* e = getenv("MSORB_GROUPS")) h->n_groups = std::max(1, std::min(atoi(e), kMaxGroups));
     *out = h;
     return MSORB_OK;
 }
@@ -521,8 +652,17 @@ void msorb_extractor_destroy(msorb_extractor* h) {
     h->d_compact.release(); h->d_sel.release(); h->d_kps1.release();
     h->h_level_count.release(); h->h_img_base.release(); h->h_sel_count.release(); h->h_compact.release();
     h->h_sel.release(); h->h_pyr.release();
+    for (auto& G : h->grp) {
+        if (!G.ready) continue;
+        (void)hipStreamSynchronize(G.s); (void)hipStreamSynchronize(G.s2);
+        for (auto& e : G.pe) if (e) (void)hipEventDestroy(e);
+        (void)hipEventDestroy(G.ev_pyr); (void)hipEventDestroy(G.ev_blur);
+        (void)hipStreamDestroy(G.s); (void)hipStreamDestroy(G.s2);
+    }
     for (auto& e : h->pe) if (e) (void)hipEventDestroy(e);
     if (h->ev_compact) (void)hipEventDestroy(h->ev_compact);
+    if (h->ev_pyramid) (void)hipEventDestroy(h->ev_pyramid);
+    if (h->ev_blur) (void)hipEventDestroy(h->ev_blur);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     delete h;
@@ -645,6 +785,7 @@ int msorb_debug_candidates(msorb_extractor* h, int image, int level, int* xyscor
     if (!h || !n || !h->geom_valid || image < 0 || image >= h->last_n_images || level < 0 || level >= h->G.nlevels)
         return MSORB_E_INVALID;
     const int nl = h->G.nlevels;
+    if (h->last_groups != 1) { set_error("candidate inspection needs a single sub-batch (n_images < 16 or MSORB_GROUPS=1)"); return MSORB_E_INVALID; }
     if (!h->compact_on_host) {
         HIPCHK(hipSetDevice(h->device));
         int rc;
