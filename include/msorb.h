@@ -92,6 +92,10 @@ int msorb_extract_batch(msorb_extractor* h, const uint8_t* d_images, int n_image
 #define MSORB_STAGE_DESCRIBE 5 /* IC-angle + rBRIEF */
 #define MSORB_N_STAGES 6
 int msorb_extractor_set_profiling(msorb_extractor* h, int enable);
+/* Execution shape of msorb_extract_batch: number of concurrently scheduled sub-batches (1..4, default 2; batches
+ * of fewer than 16 images always use 1) and whether the blur runs on a second stream (default yes).  (1, 0) runs
+ * every kernel alone on the GPU — the setting used for per-kernel roofline measurements. */
+int msorb_extractor_set_overlap(msorb_extractor* h, int sub_batches, int blur_on_second_stream);
 int msorb_extractor_stage_ms(const msorb_extractor* h, float* ms);
 
 /* Test/inspection hooks (device -> host copies of intermediate products of the last call). */

@@ -159,6 +159,7 @@ struct msorb_extractor {
     int device = 0;
     StreamGroup grp[kMaxGroups];
     int n_groups = 2;
+    bool overlap_blur = true;
     OrbParams P;
     hipStream_t stream = nullptr, copy_stream = nullptr;
     hipEvent_t ev_compact = nullptr, ev_pyramid = nullptr, ev_blur = nullptr;
@@ -378,12 +379,15 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
             launch_pyr_resize(pyr.lv[l - 1], pyr.lv[l], pyr_base + g.lv[l].plane_off, h->d_taps.p + h->tap_x_off[l],
                               h->d_taps.p + h->tap_y_off[l], n, s);
         mark(1, s);
-        HIPCHK(hipEventRecord(G.ev_pyr, s));
-        HIPCHK(hipStreamWaitEvent(G.s2, G.ev_pyr, 0));
-        mark(7, G.s2);
-        launch_gauss7(pyr, blur, n, G.s2);
-        mark(8, G.s2);
-        HIPCHK(hipEventRecord(G.ev_blur, G.s2));
+        hipStream_t sb = h->overlap_blur ? G.s2 : s;
+        if (h->overlap_blur) {
+            HIPCHK(hipEventRecord(G.ev_pyr, s));
+            HIPCHK(hipStreamWaitEvent(G.s2, G.ev_pyr, 0));
+        }
+        mark(7, sb);
+        launch_gauss7(pyr, blur, n, sb);
+        mark(8, sb);
+        if (h->overlap_blur) HIPCHK(hipEventRecord(G.ev_blur, G.s2));
         launch_fast_cells(pyr, h->d_cells.p, ncells, h->P.ini_th, h->P.min_th, g.slots_per_image, h->d_slots.p + cslot,
                           h->d_cell_count.p + (size_t)first * ncells, n, s);
         mark(2, s);
@@ -397,7 +401,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
                         sel_stride, h->scales, lap0, lap1, capacity, h->d_sel.p + (size_t)first * sel_stride,
                         h->d_sel_count.p + first, h->d_mono.p + first, n, s);
         mark(5, s);
-        HIPCHK(hipStreamWaitEvent(s, G.ev_blur, 0));
+        if (h->overlap_blur) HIPCHK(hipStreamWaitEvent(s, G.ev_blur, 0));
         launch_describe(pyr, blur, h->d_sel.p + (size_t)first * sel_stride, h->d_sel_count.p + first, sel_stride, h->scales,
                         d_kps + (size_t)first * capacity, d_desc + (size_t)first * capacity * 32, capacity,
                         std::min(capacity, sel_stride), n, s);
@@ -414,7 +418,9 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
         if (h_mono) h_mono[i] = h->h_mono.p[i];
     }
     if (prof) {  // stage time = sum over the sub-batches of the stage's HIP-event interval on its own stream
-        const int map[6][3] = {{MSORB_STAGE_PYRAMID, 0, 1}, {MSORB_STAGE_FAST, 1, 2}, {MSORB_STAGE_COMPACT, 2, 3},
+        // (with the blur on the main stream its interval sits between pyramid and FAST: FAST = 8 -> 2)
+        const int fast_from = h->overlap_blur ? 1 : 8;
+        const int map[6][3] = {{MSORB_STAGE_PYRAMID, 0, 1}, {MSORB_STAGE_FAST, fast_from, 2}, {MSORB_STAGE_COMPACT, 2, 3},
                                {MSORB_STAGE_BLUR, 7, 8}, {MSORB_STAGE_SELECT, 3, 5}, {MSORB_STAGE_DESCRIBE, 5, 6}};
         for (auto& m : map) h->stage_ms[m[0]] = 0;
         for (int gi = 0; gi < ng; gi++)
@@ -686,6 +692,12 @@ int msorb_extractor_capacity(const msorb_extractor* h) { return h ? capacity_of(
 int msorb_extractor_set_profiling(msorb_extractor* h, int enable) {
     if (!h) return MSORB_E_INVALID;
     h->profiling = enable != 0;
+    return MSORB_OK;
+}
+int msorb_extractor_set_overlap(msorb_extractor* h, int sub_batches, int blur_on_second_stream) {
+    if (!h || sub_batches < 1 || sub_batches > kMaxGroups) return MSORB_E_INVALID;
+    h->n_groups = sub_batches;
+    h->overlap_blur = blur_on_second_stream != 0;
     return MSORB_OK;
 }
 int msorb_extractor_stage_ms(const msorb_extractor* h, float* ms) {

@@ -26,7 +26,7 @@ OK, E_INVALID, E_NO_DEVICE, E_HIP, E_CAPACITY, E_GEOMETRY, E_EMPTY = 0, -1, -2, 
 EXPORTS = (
     "msorb_last_error", "msorb_device_count", "msorb_extractor_create", "msorb_extractor_destroy",
     "msorb_extractor_tables", "msorb_extractor_capacity", "msorb_extract", "msorb_pyramid_level",
-    "msorb_extract_batch", "msorb_extractor_set_profiling", "msorb_extractor_stage_ms", "msorb_debug_level_size",
+    "msorb_extract_batch", "msorb_extractor_set_profiling", "msorb_extractor_set_overlap", "msorb_extractor_stage_ms", "msorb_debug_level_size",
     "msorb_debug_copy_level", "msorb_debug_candidates", "msorb_distribute_quadtree",
 )
 
@@ -68,6 +68,7 @@ def lib():
         L.msorb_extract_batch.argtypes = [vp, vp, ci, ci, ci, C.c_size_t, C.c_size_t, ci, ci, vp, vp, ci, vp, vp]
         L.msorb_extractor_set_profiling.argtypes = [vp, ci]
         L.msorb_extractor_stage_ms.argtypes = [vp, vp]
+        L.msorb_extractor_set_overlap.argtypes = [vp, ci, ci]
         L.msorb_debug_level_size.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
         L.msorb_debug_copy_level.argtypes = [vp, ci, ci, ci, vp]
         L.msorb_debug_candidates.argtypes = [vp, ci, ci, vp, ci, C.POINTER(ci)]
@@ -180,6 +181,9 @@ class ORBextractor:
 
     def set_profiling(self, on=True):
         _check(self.L.msorb_extractor_set_profiling(self.h, int(on)), "set_profiling")
+
+    def set_overlap(self, sub_batches=2, blur_on_second_stream=True):
+        _check(self.L.msorb_extractor_set_overlap(self.h, sub_batches, int(blur_on_second_stream)), "set_overlap")
 
     def stage_ms(self):
         ms = np.zeros(len(STAGES), np.float32)
