@@ -390,7 +390,7 @@ QT_HD int quadrant_of(const Pt& p, const NodeB& b) {  // DivideNode's assignment
 
 // Returns the number of kept candidates; out_pt[i] = candidate index of the i-th keypoint in the reference's
 // result order.  `label` is an n-entry scratch array (global memory on the device).
-template <class Ex>
+template <int PC, class Ex>
 QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, int N, Workspace& w, int* out_pt,
                  int debug = 0) {
     if (n <= 0) return 0;
@@ -399,15 +399,36 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
     const float hX = (float)W / (float)n_ini;                      // :561
     int* sc = w.sc;
 
+    // Point ownership: thread t owns candidates t, t + nt, ...; the first PC of them live in registers for the whole
+    // selection (coordinates + label), the rest (only when n > PC * nt) go through global memory.
+    Pt cpt[PC > 0 ? PC : 1];
+    uint16_t clab[PC > 0 ? PC : 1];
+#pragma unroll
+    for (int k = 0; k < PC; k++) { const int p = tid + k * nt; cpt[k] = pts[p < n ? p : 0]; clab[k] = kLabelSettled; }
+    auto for_points = [&](auto&& body) {
+#pragma unroll
+        for (int k = 0; k < PC; k++) {
+            const int p = tid + k * nt;
+            if (p < n) body(p, cpt[k], clab[k]);
+        }
+        for (int p = tid + PC * nt; p < n; p += nt) {
+            const Pt q = pts[p];
+            uint16_t l = label[p];
+            const uint16_t l0 = l;
+            body(p, q, l);
+            if (l != l0) label[p] = l;
+        }
+    };
+
     // ---- initial columns (:568-601) = generation of parity 0, processing order = ascending column ----
     for (int i = tid; i < n_ini; i += nt) w.cnt[0][i] = 0;
     if (tid == 0) { sc[kScNres] = 0; sc[kScFinish] = 0; sc[kScCareful] = 0; sc[kScGenBase] = 0; }
     ex.sync();
-    for (int p = tid; p < n; p += nt) {
-        const int c = (int)((float)pts[p].x / hX);                 // vpIniNodes[kp.pt.x/hX]
-        label[p] = (uint16_t)c;
+    for_points([&](int, const Pt& q, uint16_t& lab) {
+        const int c = (int)((float)q.x / hX);                      // vpIniNodes[kp.pt.x/hX]
+        lab = (uint16_t)c;
         ex.atomic_add(&w.cnt[0][c], 1);
-    }
+    });
     ex.sync();
     if (tid == 0) {
         int size = 0, S = 0;
@@ -427,14 +448,14 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
         sc[kScSize] = size; sc[kScS0] = S;
     }
     ex.sync();
-    for (int p = tid; p < n; p += nt) {  // single-point columns are final (bNoMore, :590-594)
-        const int c = label[p];
+    for_points([&](int p, const Pt&, uint16_t& lab) {  // single-point columns are final (bNoMore, :590-594)
+        const int c = lab;
         if (w.cnt[0][c] == 1) {
             const int r = ex.atomic_add(&sc[kScNres], 1);
             w.res_seq[r] = -1 - c; w.res_pt[r] = p;
-            label[p] = kLabelSettled;
+            lab = kLabelSettled;
         }
-    }
+    });
     ex.sync();
 
     if (debug == 2) return 0;
@@ -467,21 +488,12 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
         ex.sync();
         ex.mark(1);
         // pass A: children counts of every multi-point node (speculative for the careful sweep)
-        for (int p0 = tid; p0 < n; p0 += 4 * nt) {  // 4 points per trip: the global loads are issued back to back
-            int lab4[4];
-            Pt pt4[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int p = p0 + u * nt; lab4[u] = p < n ? label[p] : kLabelSettled; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int p = p0 + u * nt; pt4[u] = pts[p < n ? p : 0]; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int lab = lab4[u];
-                if (lab == kLabelSettled || ((lab & kParityBit) != 0) != (par != 0)) continue;
-                const int r = w.rankof[par][lab & kSlotMask];
-                ex.atomic_add(&w.cnt[np][4 * r + quadrant_of(pt4[u], w.nb[par][r])], 1);
-            }
-        }
+        for_points([&](int, const Pt& q, uint16_t& lab_) {
+            const int lab = lab_;
+            if (lab == kLabelSettled || ((lab & kParityBit) != 0) != (par != 0)) return;
+            const int r = w.rankof[par][lab & kSlotMask];
+            ex.atomic_add(&w.cnt[np][4 * r + quadrant_of(q, w.nb[par][r])], 1);
+        });
         ex.sync();
         ex.mark(2);
         if (careful) {  // :701-748: split from the largest until the quota is reached -> nsplit
@@ -545,30 +557,20 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
         ex.mark(3);
         const int nsplit = sc[kScNsplit], genbase = sc[kScGenBase];
         // pass B: move the points of split nodes to their child; single-point children are final
-        for (int p0 = tid; p0 < n; p0 += 4 * nt) {
-            int lab4[4];
-            Pt pt4[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int p = p0 + u * nt; lab4[u] = p < n ? label[p] : kLabelSettled; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int p = p0 + u * nt; pt4[u] = pts[p < n ? p : 0]; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int p = p0 + u * nt;
-                const int lab = lab4[u];
-                if (lab == kLabelSettled || ((lab & kParityBit) != 0) != (par != 0)) continue;
-                const int r = w.rankof[par][lab & kSlotMask];
-                if (r >= nsplit) continue;  // careful sweep stopped before this node: it stays whole
-                const int slot = 4 * r + quadrant_of(pt4[u], w.nb[par][r]);
-                if (w.cnt[np][slot] == 1) {
-                    const int k = ex.atomic_add(&sc[kScNres], 1);
-                    w.res_seq[k] = genbase + slot; w.res_pt[k] = p;
-                    label[p] = kLabelSettled;
-                } else {
-                    label[p] = (uint16_t)((np ? kParityBit : 0) | slot);
-                }
+        for_points([&](int p, const Pt& q, uint16_t& lab_) {
+            const int lab = lab_;
+            if (lab == kLabelSettled || ((lab & kParityBit) != 0) != (par != 0)) return;
+            const int r = w.rankof[par][lab & kSlotMask];
+            if (r >= nsplit) return;  // careful sweep stopped before this node: it stays whole
+            const int slot = 4 * r + quadrant_of(q, w.nb[par][r]);
+            if (w.cnt[np][slot] == 1) {
+                const int k = ex.atomic_add(&sc[kScNres], 1);
+                w.res_seq[k] = genbase + slot; w.res_pt[k] = p;
+                lab_ = kLabelSettled;
+            } else {
+                lab_ = (uint16_t)((np ? kParityBit : 0) | slot);
             }
-        }
+        });
         ex.sync();
         ex.mark(4);
         if (tid == 0) sc[kScGenBase] = genbase + 4 * S;
@@ -580,13 +582,13 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
             for (int i = tid; i < S; i += nt) w.cnt[par][i] = 0;   // re-used as best-point keys, by rank
             for (int i = tid; i < Sn; i += nt) w.cnt[np][i] = 0;
             ex.sync();
-            for (int p = tid; p < n; p += nt) {  // first strictly greater response wins (:757-776)
-                const int lab = label[p];
-                if (lab == kLabelSettled) continue;
+            for_points([&](int p, const Pt& q, uint16_t& lab_) {  // first strictly greater response wins (:757-776)
+                const int lab = lab_;
+                if (lab == kLabelSettled) return;
                 const int lp = (lab & kParityBit) ? 1 : 0;
                 const int r = w.rankof[lp][lab & kSlotMask];
-                ex.atomic_max(&w.cnt[lp][r], (int)(((uint32_t)pts[p].score << 22) | (uint32_t)(0x3FFFFF - p)));
-            }
+                ex.atomic_max(&w.cnt[lp][r], (int)(((uint32_t)q.score << 22) | (uint32_t)(0x3FFFFF - p)));
+            });
             ex.sync();
             for (int i = tid; i < S - nsplit + Sn; i += nt) {
                 const int lp = i < S - nsplit ? par : np;

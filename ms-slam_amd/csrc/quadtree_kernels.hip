@@ -11,6 +11,7 @@
 namespace msorb {
 
 constexpr int kQtThreads = 512;
+constexpr int kQtPointsPerThread = 0;  // register-resident candidates per thread: measured slower (VGPR pressure halves the resident workgroups)
 
 struct DevEx {
     // std::sort restatement, data-parallel form (quadtree_device.h lsort_par), executed by wave 0 only: inside one
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_select_kernel(QtLevels lv
     DevEx ex;
     ex.dbg = debug;
     int* out = sel_pt + (size_t)img * sel_stride + lv.sel_off[level];
-    const int kept = qt::select(ex, reinterpret_cast<const qt::Pt*>(compact + off), n, label + off, lv.W[level], lv.H[level],
+    const int kept = qt::select<kQtPointsPerThread>(ex, reinterpret_cast<const qt::Pt*>(compact + off), n, label + off, lv.W[level], lv.H[level],
                                 lv.quota[level], w, out, debug);
     if (threadIdx.x == 0) sel_n[(size_t)img * lv.nlevels + level] = kept;
     ex.dump();

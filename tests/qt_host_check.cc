@@ -35,7 +35,12 @@ static int run_case(const std::vector<Cand16>& c, int W, int H, int N, bool verb
     std::vector<uint16_t> label(c.size() + 1);
     std::vector<int> out(c.size() + 8);
     HostEx ex;
-    const int n = qt::select(ex, reinterpret_cast<const qt::Pt*>(c.data()), (int)c.size(), label.data(), W, H, N, w, out.data());
+    std::vector<int> out2(c.size() + 8);
+    const int n = qt::select<0>(ex, reinterpret_cast<const qt::Pt*>(c.data()), (int)c.size(), label.data(), W, H, N, w, out.data());
+    // register-cached variant (what the GPU instantiates): the first 16 points of the single host 'thread' are cached
+    const int n2 = qt::select<16>(ex, reinterpret_cast<const qt::Pt*>(c.data()), (int)c.size(), label.data(), W, H, N, w, out2.data());
+    if (n2 != n) return 1;
+    for (int i = 0; i < n; i++) if (out[i] != out2[i]) return 1;
     bool ok = n == (int)kept.size();
     for (int i = 0; ok && i < n; i++) ok = out[i] == kept[i];
     if (!ok && verbose) fprintf(stderr, "MISMATCH n=%zu W=%d H=%d N=%d got=%d want=%zu\n", c.size(), W, H, N, n, kept.size());
