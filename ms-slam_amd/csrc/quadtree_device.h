@@ -347,28 +347,27 @@ struct Workspace {       // LDS on the device; `cap` = 4 * max(N, nIni) child sl
     int* sc;             // scalars: see enum below
     int* scan_tmp;       // 2 x 16 ints for the block-wide scans
     ParScratch ps;       // scratch of the data-parallel sort
-    int cap, res_cap;
+    int cap, res_cap, m;
 };
 enum { kScSize = 0, kScS0, kScS1, kScNres, kScNToExpand, kScNsplit, kScFinish, kScCareful, kScGenBase, kScCount };
 
 QT_HD size_t workspace_bytes(int N, int n_ini) {
     const int m = N > n_ini ? N : n_ini;
-    const size_t cap = 4 * (size_t)m;
+    const size_t cap = 4 * (size_t)m + 16;
     size_t b = 2 * cap * sizeof(int) + 2 * cap * sizeof(uint16_t) + 2 * (size_t)(m + 4) * sizeof(NodeB) +
-               (size_t)(m + 4) * sizeof(SortItem) + 3 * 64 * sizeof(int) + 2 * (size_t)(m + 8 + 4 * n_ini) * sizeof(int) +
-               (kScCount + 32 + 16 + 4) * sizeof(int) + (size_t)(m + 4) * (sizeof(SortItem) + 2 * sizeof(uint16_t));
+               3 * 64 * sizeof(int) + 2 * (size_t)(m + 8 + 4 * n_ini) * sizeof(int) + (kScCount + 32 + 16 + 4) * sizeof(int);
     return (b + 15) & ~size_t(15);
 }
 QT_HD void workspace_carve(Workspace& w, void* mem, int N, int n_ini) {
     const int m = N > n_ini ? N : n_ini;
-    w.cap = 4 * m;
+    w.cap = 4 * m + 16;
     w.res_cap = m + 8 + 4 * n_ini;
+    w.m = m;
     char* p = (char*)mem;
     w.cnt[0] = (int*)p; p += w.cap * sizeof(int);
     w.cnt[1] = (int*)p; p += w.cap * sizeof(int);
     w.nb[0] = (NodeB*)p; p += (m + 4) * sizeof(NodeB);
     w.nb[1] = (NodeB*)p; p += (m + 4) * sizeof(NodeB);
-    w.items = (SortItem*)p; p += (m + 4) * sizeof(SortItem);
     w.stack = (int*)p; p += 3 * 64 * sizeof(int);
     w.res_seq = (int*)p; p += w.res_cap * sizeof(int);
     w.res_pt = (int*)p; p += w.res_cap * sizeof(int);
@@ -376,11 +375,17 @@ QT_HD void workspace_carve(Workspace& w, void* mem, int N, int n_ini) {
     w.scan_tmp = (int*)p; p += 32 * sizeof(int);
     w.ps.scan_tmp = (int*)p; p += 16 * sizeof(int);
     w.ps.sc = (int*)p; p += 4 * sizeof(int);
-    w.ps.tmp = (SortItem*)p; p += (m + 4) * sizeof(SortItem);
     w.rankof[0] = (uint16_t*)p; p += w.cap * sizeof(uint16_t);
-    w.rankof[1] = (uint16_t*)p; p += w.cap * sizeof(uint16_t);
-    w.ps.gpos = (uint16_t*)p; p += (m + 4) * sizeof(uint16_t);
-    w.ps.lpos = (uint16_t*)p;
+    w.rankof[1] = (uint16_t*)p;
+    w.items = nullptr; w.ps.tmp = nullptr; w.ps.gpos = nullptr; w.ps.lpos = nullptr;  // aliased per sweep, see sort_scratch()
+}
+// The sort of a careful sweep runs before the other generation's arrays are (re)initialised: its items, the
+// stable-finish buffer and the partition position lists live in cnt[np] / rankof[np].
+QT_HD void sort_scratch(Workspace& w, int np) {
+    w.items = (SortItem*)w.cnt[np];
+    w.ps.tmp = w.items + (w.m + 4);
+    w.ps.gpos = w.rankof[np];
+    w.ps.lpos = w.ps.gpos + (w.m + 4);
 }
 
 QT_HD int quadrant_of(const Pt& p, const NodeB& b) {  // DivideNode's assignment (:511-525)
@@ -468,6 +473,7 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
         const int careful = sc[kScCareful];
         const int prev_size = sc[kScSize];
         if (careful) {
+            sort_scratch(w, np);
             // vPrevSizeAndPointerToNode in creation order = descending rank; sort; walk from the back
             for (int i = tid; i < S; i += nt) {
                 const NodeB& b = w.nb[par][S - 1 - i];

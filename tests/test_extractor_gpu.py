@@ -129,3 +129,38 @@ def test_rotated_images_cover_all_orientations(msorb_mod, oracle):
         assert mono == rmono and len(kps) > 100
         _assert_same(kps, desc, rkps, rdesc)
     ex.close()
+
+
+def test_large_batch_uses_overlapped_sub_batches(msorb_mod, oracle):
+    """>= 16 images take the multi-stream sub-batch pipeline (2 groups by default, also 3 and 1): every image must
+    still equal the oracle, independent of the grouping."""
+    import torch
+    cfg = CONFIGS["small"]
+    ex, ref = _pair(msorb_mod, oracle, cfg)
+    n = 21
+    batch = np.stack([synth.image(300 + i, cfg["rows"], cfg["cols"]) for i in range(n)])
+    want = [ref(batch[i]) for i in range(n)]
+    d = torch.from_numpy(batch).cuda()
+    for groups, blur2 in ((2, True), (3, True), (1, False), (4, False)):
+        ex.set_overlap(groups, blur2)
+        counts, mono, d_kps, d_desc = ex.extract_batch(d)
+        kps_list = msorb_mod.keypoints_from_device(d_kps, counts)
+        desc_all = d_desc.cpu().numpy()
+        for i in range(n):
+            rmono, rkps, rdesc = want[i]
+            assert counts[i] == len(rkps) and mono[i] == rmono, (groups, i)
+            _assert_same(kps_list[i], desc_all[i, :counts[i]], rkps, rdesc)
+    ex.close()
+
+
+def test_host_quadtree_mode_matches(msorb_mod, oracle, monkeypatch):
+    """MSORB_QUADTREE=host keeps the selection on the host thread pool (orb_host.cc); same result."""
+    monkeypatch.setenv("MSORB_QUADTREE", "host")
+    cfg = CONFIGS["euroc"]
+    ex, ref = _pair(msorb_mod, oracle, cfg)
+    img = synth.image(55, cfg["rows"], cfg["cols"])
+    mono, kps, desc = ex(img)
+    rmono, rkps, rdesc = ref(img)
+    assert mono == rmono
+    _assert_same(kps, desc, rkps, rdesc)
+    ex.close()
