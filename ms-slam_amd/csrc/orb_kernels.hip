@@ -196,6 +196,8 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
     __shared__ __attribute__((aligned(16))) uint8_t score[kScoreRows * kScorePitch];
     __shared__ uint16_t work[kWorkCap];
     __shared__ int wave_tot[2][4];
+    __shared__ uint32_t kbits[2 * 3 * kMaxDet];
+    __shared__ int kprefix[3 * kMaxDet];
     uint8_t* const tile = tile_mem + kTileFront;
 
     // XCD-aware order: consecutive workgroups are dealt round-robin to the 8 XCDs (each with a private L2); remap
@@ -240,6 +242,12 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
             tile[y * kTilePitch + off + x] = src[(size_t)y * lv.pitch + cd.x0 + x];
         }
     }
+    // Threshold passes (ORBextractor.cc:826,843-847): iniThFAST first; only a cell that ends up with no keypoint at all
+    // is redone at minThFAST.  NMS at a threshold only sees the corners of that threshold (the others score 0 there),
+    // so the first pass needs nothing below iniThFAST — half the quick-test survivors and arc tests of a minTh pass.
+    int n_emitted = 0;
+    for (int pass = 0; pass < 2; pass++) {
+    const int th = pass ? min_th : ini_th;
     for (int i = tid; i < (dh + 2) * (kScorePitch / 4); i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
     __syncthreads();
     if (debug_stop == 1) return;
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
     // phase 1: quick test, two pixels per packed 16-bit lane; 8 result bits per task (dark 0..3, bright 4..7)
     uint64_t M = 0;
     int cnt = 0;
-    const short2v T2 = {(short)min_th, (short)min_th};
+    const short2v T2 = {(short)th, (short)th};
     {
         int y = (t_begin * magic) >> 20;
         int g = t_begin - y * G;
@@ -318,11 +326,70 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
             const int e = work[i];
             const int ty = (e >> 7) & 127, tx = e & 127;
             const int A = fast_arc_contrast(&tile[ty * kTilePitch + tx], (e & 0x8000) ? -1 : 1);
-            if (A > min_th) score[(ty - 2) * kScorePitch + tx + sc_off] = (uint8_t)(A - 1);  // score row = y + 1
+            if (A > th) score[(ty - 2) * kScorePitch + tx + sc_off] = (uint8_t)(A - 1);  // score row = y + 1
+            work[i] = A > th ? (uint16_t)(e & 0x3FFF) : (uint16_t)0xFFFF;  // the list now holds the corners
         }
         __syncthreads();
     }
     if (debug_stop == 4) return;
+
+    Cand16* out = slots + (size_t)img * slots_per_image + cd.slot_off;
+    if (n_work <= kWorkCap) {
+        // phase 3 (common case: the whole work list fitted): NMS and ordered emission driven by the corner list.
+        // kept corners set a bit in a row-major bitmap of the detection area; the rank of a corner in scan order is
+        // the popcount of the bits before it (prefix over the bitmap words).
+        const int wpr = 3;                      // bitmap words per detection row (<= 96 columns incl. the group pad)
+        const int nwords = dh * wpr;
+        for (int i = tid; i < nwords; i += 256) kbits[i] = 0;
+        __syncthreads();
+        uint32_t mine_keep = 0;  // per-thread record of the corners it owns: up to 16 list slots (4096 / 256)
+        {
+            int slot = 0;
+            for (int i = tid; i < n_work; i += 256, slot++) {
+                const int e = work[i];
+                if (e == 0xFFFF) continue;
+                const int ty = e >> 7, tx = e & 127;
+                const uint8_t* q = &score[(ty - 2) * kScorePitch + tx + sc_off];
+                const int sv = q[0];
+                int m = max3i(q[-kScorePitch - 1], q[-kScorePitch], q[-kScorePitch + 1]);
+                m = max3i(m, q[-1], q[1]);
+                m = max(m, max3i(q[kScorePitch - 1], q[kScorePitch], q[kScorePitch + 1]));
+                if (sv > m) {
+                    const int bx = tx - c_lo, by = ty - 3;       // column inside the group span, detection row
+                    const int b = by * (32 * wpr) + bx;
+                    atomicOr(&kbits[b >> 5], 1u << (b & 31));
+                    mine_keep |= 1u << slot;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t* sel_bits = kbits;
+        // prefix popcount over the selected bitmap
+        int n_out2 = 0;
+        const int wcount = tid < nwords ? __popc(sel_bits[tid]) : 0;
+        const int wprefix = block_excl_scan(wcount, lane, wave, wave_tot[1], &n_out2);
+        if (tid < nwords) kprefix[tid] = wprefix;
+        __syncthreads();
+        {
+            int slot = 0;
+            for (int i = tid; i < n_work; i += 256, slot++) {
+                if (!(mine_keep & (1u << slot))) continue;
+                const int e = work[i];
+                const int ty = e >> 7, tx = e & 127;
+                const int b = (ty - 3) * (32 * wpr) + (tx - c_lo);
+                const uint32_t wbits = sel_bits[b >> 5];
+                const int rank = kprefix[b >> 5] + __popc(wbits & ((1u << (b & 31)) - 1u));
+                Cand16 c;
+                c.x = (uint16_t)(ga + tx - kMinBorder);
+                c.y = (uint16_t)(cd.y0 + ty - kMinBorder);
+                c.score = score[(ty - 2) * kScorePitch + tx + sc_off];
+                c.pad = 0;
+                out[rank] = c;
+            }
+        }
+        n_emitted = n_out2;
+    } else {
+    // saturated cell (more quick-test survivors than the work list holds): scan the score plane by tasks
 
     // phase 3a: strict 3x3 NMS, 4 flag bits per task
     uint32_t keep = 0, keep_ini = 0;
@@ -343,7 +410,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
                         m = max(m, max3i(q[kScorePitch - 1], q[kScorePitch], q[kScorePitch + 1]));
                         if (sv > m) {
                             keep |= 1u << (4 * k + j);
-                            if (sv >= ini_th) keep_ini |= 1u << (4 * k + j);
+                            keep_ini |= 1u << (4 * k + j);
                         }
                     }
                 }
@@ -353,14 +420,12 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
     }
     const int any_ini = __syncthreads_or(keep_ini != 0);
     const uint32_t sel = any_ini ? keep_ini : keep;
-    if (debug_stop == 5) return;
 
     // phase 3b: ordered emission — a thread's tasks are consecutive in scan order, so the block-wide prefix of the
     // per-thread counts is the rank in (ascending y, then x) order
     int n_out = 0;
     int pos = block_excl_scan(__popc(sel), lane, wave, wave_tot[1], &n_out);
     if (sel) {
-        Cand16* out = slots + (size_t)img * slots_per_image + cd.slot_off;
         int y = (t_begin * magic) >> 20;
         int g = t_begin - y * G;
         uint32_t m = sel;
@@ -379,7 +444,12 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
             if (++g == G) { g = 0; y++; }
         }
     }
-    if (tid == 0) cell_count[(size_t)img * n_cells + cell_id] = n_out;
+    n_emitted = n_out;
+    }
+    if (n_emitted > 0 || pass == 1 || ini_th == min_th) break;
+    __syncthreads();
+    }
+    if (tid == 0) cell_count[(size_t)img * n_cells + cell_id] = n_emitted;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -164,3 +164,19 @@ def test_host_quadtree_mode_matches(msorb_mod, oracle, monkeypatch):
     assert mono == rmono
     _assert_same(kps, desc, rkps, rdesc)
     ex.close()
+
+
+def test_saturated_single_cell(msorb_mod, oracle):
+    """One 69x69-pixel cell of pure noise: more quick-test survivors than the FAST kernel's LDS work list holds,
+    which takes the chunked / task-scan path of the kernel (nlevels = 1 keeps the tiny image legal)."""
+    rng = np.random.Generator(np.random.PCG64(8))
+    for rows, cols in ((101, 101), (101, 171), (90, 240)):
+        img = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+        ex = msorb_mod.ORBextractor(300, 1.2, 1, 20, 7)
+        ref = oracle.OracleExtractor(300, 1.2, 1, 20, 7)
+        mono, kps, desc = ex(img)
+        rmono, rkps, rdesc = ref(img)
+        assert np.array_equal(ex.debug_candidates(0, 0), ref.candidates(0))
+        assert mono == rmono and len(kps) > 50
+        _assert_same(kps, desc, rkps, rdesc)
+        ex.close()
