@@ -268,8 +268,9 @@ int ensure_batch(msorb_extractor* h, int n_images) {
     const FrameGeom& g = h->G;
     const size_t ncells = g.cells.size();
     int rc;
-    if ((rc = h->d_pyr.ensure((size_t)n_images * g.pyramid_bytes))) return rc;
-    if ((rc = h->d_blur.ensure((size_t)n_images * g.pyramid_bytes))) return rc;
+    // +256: row-coherent dword loads may run a few bytes past the last row of the last plane
+    if ((rc = h->d_pyr.ensure((size_t)n_images * g.pyramid_bytes + 256))) return rc;
+    if ((rc = h->d_blur.ensure((size_t)n_images * g.pyramid_bytes + 256))) return rc;
     if ((rc = h->d_slots.ensure((size_t)n_images * g.slots_per_image))) return rc;
     if ((rc = h->d_compact.ensure((size_t)n_images * g.slots_per_image))) return rc;
     if ((rc = h->d_cell_count.ensure((size_t)n_images * ncells))) return rc;

@@ -716,68 +716,118 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
+constexpr int kPatchPitch = 44;  // bytes per staged patch row: 11 dwords
+constexpr int kKpPerWave = 4;  // keypoints handled back to back by one wave (amortises the per-lane table loads)
+
 __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidView blur, const SelRec* __restrict__ sel,
                                                        const int* __restrict__ sel_count, int sel_stride,
                                                        LevelScale scales, msorb_keypoint* __restrict__ kps,
                                                        uint8_t* __restrict__ desc, int out_stride) {
+    __shared__ __attribute__((aligned(16))) uint8_t patch[4][37 * kPatchPitch + 4];
     const int img = blockIdx.y;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (k >= sel_count[img]) return;
-    const SelRec r = sel[(size_t)img * sel_stride + k];
-    const LevelView lv = pyr.lv[r.level];
-    const uint8_t* center = lv.base + (size_t)img * lv.img_stride + (size_t)r.y * lv.pitch + r.x;
-
-    // IC_Angle: integer moments over the 749-pixel circular patch (un-blurred level)
-    int m10 = 0, m01 = 0;
-    for (int i = lane; i < kPatchPixels; i += 64) {
-        const int u = c_tab.pu[i], v = c_tab.pv[i];
-        const int val = center[v * lv.pitch + u];
-        m10 += u * val;
-        m01 += v * val;
-    }
+    const int k_first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kKpPerWave;
+    const int n_sel = sel_count[img];
+    if (k_first >= n_sel) return;
+    // per-lane constants, loaded once: the 12 patch offsets lane, lane+64, ... and the 4 pattern pairs of this lane
+    int uv[12];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        m10 += __shfl_xor(m10, o);
-        m01 += __shfl_xor(m01, o);
+    for (int t = 0; t < 12; t++) {
+        const int i = lane + 64 * t;
+        uv[t] = i < kPatchPixels ? (((int)c_tab.pu[i] & 0xffff) | ((int)c_tab.pv[i] << 16)) : 0x7fff7fff;
     }
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-
-    // steered BRIEF on the blurred level
+    uint32_t pat[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) pat[w] = *reinterpret_cast<const uint32_t*>(&c_tab.pattern[(w * 64 + lane) * 4]);
     const float factor_pi = (float)(3.1415926535897932384626433832795 / 180.0);
-    float a, b;
-    glibc_sincosf<true>(__fmul_rn(angle, factor_pi), &b, &a);  // a = cos, b = sin (ORBextractor.cc:112)
-    const LevelView bv = blur.lv[r.level];
-    const uint8_t* bc = bv.base + (size_t)img * bv.img_stride + (size_t)r.y * bv.pitch + r.x;
-    unsigned long long word[4];
+
+    SelRec r_next = sel[(size_t)img * sel_stride + k_first];
+    for (int kk = 0; kk < kKpPerWave; kk++) {
+        const int k = k_first + kk;
+        if (k >= n_sel) break;
+        const SelRec r = r_next;
+        if (k + 1 < n_sel && kk + 1 < kKpPerWave) r_next = sel[(size_t)img * sel_stride + k + 1];  // prefetch
+        const LevelView lv = pyr.lv[r.level];
+        const uint8_t* center = lv.base + (size_t)img * lv.img_stride + (size_t)r.y * lv.pitch + r.x;
+
+        // Both patches depend only on (x, y, level): issue the blurred-patch loads together with the IC-angle loads so
+        // their latencies overlap.  The 256 test pairs gather 512 bytes from the 37x37 neighbourhood (|offset| <= 18
+        // after rotation); a direct gather touches ~35 cache lines per load instruction, so the patch goes to LDS with
+        // row-coherent dword loads (11 dwords cover one row from the 4-byte boundary below x-18; 5 rows per load).
+        const LevelView bv = blur.lv[r.level];
+        const int px0 = (r.x - 18) & ~3, poff = (r.x - 18) - px0;
+        const uint8_t* brow = bv.base + (size_t)img * bv.img_stride + (size_t)(r.y - 18) * bv.pitch + px0;
+        const int prow = lane / 11, pcol = lane % 11;
+        int pix[12];
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const int8_t* pt = &c_tab.pattern[(w * 64 + lane) * 4];
-        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
-        // cvRound(x*b + y*a), cvRound(x*a - y*b) with the contraction order of oracle/orb_extractor_oracle.cc
-        const int r0 = __float2int_rn(__fmaf_rn(x0, b, __fmul_rn(y0, a)));
-        const int q0 = __float2int_rn(__fmaf_rn(x0, a, -__fmul_rn(y0, b)));
-        const int r1 = __float2int_rn(__fmaf_rn(x1, b, __fmul_rn(y1, a)));
-        const int q1 = __float2int_rn(__fmaf_rn(x1, a, -__fmul_rn(y1, b)));
-        const int t0 = bc[r0 * bv.pitch + q0];
-        const int t1 = bc[r1 * bv.pitch + q1];
-        word[w] = __ballot(t0 < t1);
-    }
-    if (lane < 4) {
-        unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)img * out_stride + r.dst) * 32);
-        d[lane] = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
-    }
-    if (lane == 0) {
-        msorb_keypoint kp;
-        const float sc = scales.scale[r.level];
-        kp.x = r.level ? __fmul_rn((float)r.x, sc) : (float)r.x;   // keypoint->pt *= scale (ORBextractor.cc:1149-1151)
-        kp.y = r.level ? __fmul_rn((float)r.y, sc) : (float)r.y;
-        kp.size = scales.patch[r.level];
-        kp.angle = angle;
-        kp.response = (float)r.score;
-        kp.octave = r.level;
-        kp.class_id = -1;
-        kps[(size_t)img * out_stride + r.dst] = kp;
+        for (int t = 0; t < 12; t++) {
+            const int u = (int)(int16_t)(uv[t] & 0xffff), v = uv[t] >> 16;
+            pix[t] = uv[t] != 0x7fff7fff ? (int)center[v * lv.pitch + u] : 0;
+        }
+        uint32_t bp[8];
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int row = it * 5 + prow;
+            bp[it] = (lane < 55 && row < 37) ? *reinterpret_cast<const uint32_t*>(brow + (size_t)row * bv.pitch + 4 * pcol) : 0u;
+        }
+
+        // IC_Angle: integer moments over the 749-pixel circular patch (un-blurred level)
+        int m10 = 0, m01 = 0;
+#pragma unroll
+        for (int t = 0; t < 12; t++) {
+            const int u = (int)(int16_t)(uv[t] & 0xffff), v = uv[t] >> 16;
+            if (uv[t] != 0x7fff7fff) { m10 += u * pix[t]; m01 += v * pix[t]; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            m10 += __shfl_xor(m10, o);
+            m01 += __shfl_xor(m01, o);
+        }
+        const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+        // steered BRIEF on the blurred level
+        float a, b;
+        glibc_sincosf<true>(__fmul_rn(angle, factor_pi), &b, &a);  // a = cos, b = sin (ORBextractor.cc:112)
+        uint8_t* lp = patch[threadIdx.x >> 6];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int row = it * 5 + prow;
+            if (lane < 55 && row < 37) *reinterpret_cast<uint32_t*>(lp + row * kPatchPitch + 4 * pcol) = bp[it];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint8_t* bc = lp + 18 * kPatchPitch + 18 + poff;
+        unsigned long long word[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const float x0 = (float)(int8_t)(pat[w] & 255u), y0 = (float)(int8_t)((pat[w] >> 8) & 255u);
+            const float x1 = (float)(int8_t)((pat[w] >> 16) & 255u), y1 = (float)(int8_t)(pat[w] >> 24);
+            // cvRound(x*b + y*a), cvRound(x*a - y*b) with the contraction order of oracle/orb_extractor_oracle.cc
+            const int r0 = __float2int_rn(__fmaf_rn(x0, b, __fmul_rn(y0, a)));
+            const int q0 = __float2int_rn(__fmaf_rn(x0, a, -__fmul_rn(y0, b)));
+            const int r1 = __float2int_rn(__fmaf_rn(x1, b, __fmul_rn(y1, a)));
+            const int q1 = __float2int_rn(__fmaf_rn(x1, a, -__fmul_rn(y1, b)));
+            const int t0 = bc[r0 * kPatchPitch + q0];
+            const int t1 = bc[r1 * kPatchPitch + q1];
+            word[w] = __ballot(t0 < t1);
+        }
+        if (lane < 4) {
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)img * out_stride + r.dst) * 32);
+            d[lane] = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
+        }
+        if (lane == 0) {
+            msorb_keypoint kp;
+            const float sc = scales.scale[r.level];
+            kp.x = r.level ? __fmul_rn((float)r.x, sc) : (float)r.x;   // keypoint->pt *= scale (ORBextractor.cc:1149-1151)
+            kp.y = r.level ? __fmul_rn((float)r.y, sc) : (float)r.y;
+            kp.size = scales.patch[r.level];
+            kp.angle = angle;
+            kp.response = (float)r.score;
+            kp.octave = r.level;
+            kp.class_id = -1;
+            kps[(size_t)img * out_stride + r.dst] = kp;
+        }
     }
 }
 
@@ -840,7 +890,7 @@ void launch_describe(const PyramidView& pyr, const PyramidView& blur, const SelR
                      int sel_stride, const LevelScale& scales, msorb_keypoint* kps, uint8_t* desc, int out_stride,
                      int max_sel, int n_images, hipStream_t s) {
     if (max_sel <= 0) return;
-    hipLaunchKernelGGL(describe_kernel, dim3((max_sel + 3) / 4, n_images), dim3(256), 0, s, pyr, blur, sel, sel_count,
+    hipLaunchKernelGGL(describe_kernel, dim3((max_sel + 4 * kKpPerWave - 1) / (4 * kKpPerWave), n_images), dim3(256), 0, s, pyr, blur, sel, sel_count,
                        sel_stride, scales, kps, desc, out_stride);
 }
 
