@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU-pair group")
     ap.add_argument("--cpu-pairs", type=int, default=24, help="stereo pairs in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--isolated", action="store_true",
+                    help="profiling aid: no sub-batch / blur overlap anywhere, so every kernel launch covers the whole "
+                         "batch and runs alone (rocprofv3 per-kernel durations and PMC traffic are then per-launch clean)")
     args = ap.parse_args()
 
     import torch
@@ -119,6 +122,8 @@ def main():
 
     ex = msorb.ORBextractor(cfg["nfeatures"], cfg["scale"], cfg["nlevels"], cfg["ini_th"], cfg["min_th"], device=local)
     cap = ex.capacity
+    if args.isolated:
+        ex.set_overlap(1, False)
     d_kps = torch.empty((n_img, cap, 28), dtype=torch.uint8, device=dev)
     d_desc = torch.empty((n_img, cap, 32), dtype=torch.uint8, device=dev)
     from msorb import stereo_split
@@ -166,7 +171,8 @@ def main():
         step()
         for k, v in ex.stage_ms().items():
             stage_acc[k] += v
-    ex.set_overlap(2, True)
+    if not args.isolated:
+        ex.set_overlap(2, True)
     fence()
 
     if world > 1:

@@ -724,9 +724,17 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
                                                        LevelScale scales, msorb_keypoint* __restrict__ kps,
                                                        uint8_t* __restrict__ desc, int out_stride) {
     __shared__ __attribute__((aligned(16))) uint8_t patch[4][37 * kPatchPitch + 4];
-    const int img = blockIdx.y;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs; give every image to ONE XCD so that the
+    // overlapping keypoint patches of an image are served by a single L2 instead of being fetched by all eight.
+    int img = blockIdx.y, bx = blockIdx.x;
+    if ((gridDim.y & 7u) == 0) {
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned xcd = lin & 7u, j = lin >> 3;
+        img = (int)((j / gridDim.x) * 8 + xcd);
+        bx = (int)(j % gridDim.x);
+    }
     const int lane = threadIdx.x & 63;
-    const int k_first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kKpPerWave;
+    const int k_first = (bx * 4 + (threadIdx.x >> 6)) * kKpPerWave;
     const int n_sel = sel_count[img];
     if (k_first >= n_sel) return;
     // per-lane constants, loaded once: the 12 patch offsets lane, lane+64, ... and the 4 pattern pairs of this lane

@@ -87,7 +87,9 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_select_kernel(QtLevels lv
                                                               int* __restrict__ sel_n /* [img][nlevels] */, int sel_stride,
                                                               int ws_N, int ws_nini, int debug) {
     extern __shared__ __attribute__((aligned(16))) char qt_mem[];
-    const int level = blockIdx.x, img = blockIdx.y;
+    // grid = (image, level): consecutive workgroups (dealt round-robin to the 8 XCDs) are different images of one
+    // level, so the heavy level-0 instances are spread over all XCDs instead of piling up on one
+    const int level = blockIdx.y, img = blockIdx.x;
     const int* lc = level_count + (size_t)img * lv.nlevels;
     int off = img_base[img];
     for (int l = 0; l < level; l++) off += lc[l];
@@ -168,7 +170,7 @@ void launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_b
     for (int l = 0; l < lv.nlevels; l++) { maxN = max(maxN, lv.quota[l]); max_ini = max(max_ini, lv.n_ini[l]); }
     const size_t lds = qt::workspace_bytes(maxN, max_ini);
     static const int dbg = getenv("MSORB_QT_DEBUG") ? atoi(getenv("MSORB_QT_DEBUG")) : 0;  // profiling only
-    hipLaunchKernelGGL(quadtree_select_kernel, dim3(lv.nlevels, n_images), dim3(kQtThreads), lds, s, lv, compact, img_base,
+    hipLaunchKernelGGL(quadtree_select_kernel, dim3(n_images, lv.nlevels), dim3(kQtThreads), lds, s, lv, compact, img_base,
                        level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg);
     hipLaunchKernelGGL(quadtree_layout_kernel, dim3(n_images), dim3(256), 0, s, lv, compact, img_base, level_count, sel_pt,
                        sel_n, sel_stride, scales, lap0, lap1, capacity, sel, sel_count, mono);

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$1
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT -o p -- python $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 > $OUT/bench.log 2>&1
+rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT -o p -- python $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --isolated > $OUT/bench.log 2>&1
 python - <<PY
 import csv,collections
 rows=list(csv.DictReader(open("$OUT/p_counter_collection.csv")))
