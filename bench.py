@@ -218,6 +218,18 @@ def main():
         alg_bytes = alg_per_image * n_img
         achieved = alg_bytes / (stages[dom] * 1e-3) / 1e9 if stages[dom] > 0 else 0.0
         pf_bytes = (alg_per_image if dom in ("fast", "pyramid") else 0)
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the value is the
+        # committed rocprofv3 --pmc measurement of the same command (profiles/round1_pmc_summary.json, separate
+        # FETCH_SIZE / WRITE_SIZE passes, per launch) — only quoted when the batch shape matches
+        traffic = None
+        kname = {"fast": "fast_cells_kernel<true>", "pyramid": "pyr_resize_aligned_kernel", "blur": "gauss7_kernel<true>",
+                 "describe": "describe_kernel", "compact": "cand_gather_kernel"}[dom]
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_summary.json")))["kernels"][kname]
+            if B == 64 and world == 1:
+                traffic = int((pm["FETCH_SIZE_KB"] + pm["WRITE_SIZE_KB"]) * 1024) * (7 if dom == "pyramid" else 1)
+        except Exception:
+            traffic = None
         out = {
             "metric": "Mkeypoints/s extract+describe, KITTI-00-like stereo 1241x376, 2000 feat/frame",
             "value": round(kp_total / dt / 1e6, 4),
@@ -244,7 +256,9 @@ def main():
                                                     "blur": "gauss7_kernel (x8)", "describe": "describe_kernel",
                                                     "compact": "cand_*"}[dom],
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (profiles/round1_pmc_summary.json); "
+                                         "below the algorithmic bytes because the pyramid written just before is still in the 256 MB Infinity Cache",
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
             "pyramid_fast_gbs": round((sum(px[:-1]) + sum(px[1:]) + sum(px)) * n_img /
                                       ((stages["pyramid"] + stages["fast"]) * 1e-3) / 1e9, 2),
