@@ -190,7 +190,7 @@ struct msorb_extractor {
     PinBuf<int> h_level_count, h_img_base, h_sel_count, h_mono;
     PinBuf<Cand16> h_compact;
     PinBuf<SelRec> h_sel;
-    PinBuf<uint8_t> h_pyr;
+    PinBuf<uint8_t> h_pyr, h_img_pin, h_out_pin;
     bool h_pyr_valid = false;
 
     // last call
@@ -658,7 +658,7 @@ void msorb_extractor_destroy(msorb_extractor* h) {
     h->d_img_total.release(); h->d_img_base.release(); h->d_sel_count.release(); h->d_slots.release();
     h->d_compact.release(); h->d_sel.release(); h->d_kps1.release();
     h->h_level_count.release(); h->h_img_base.release(); h->h_sel_count.release(); h->h_compact.release();
-    h->h_sel.release(); h->h_pyr.release();
+    h->h_sel.release(); h->h_pyr.release(); h->h_img_pin.release(); h->h_out_pin.release();
     for (auto& G : h->grp) {
         if (!G.ready) continue;
         (void)hipStreamSynchronize(G.s); (void)hipStreamSynchronize(G.s2);
@@ -740,16 +740,26 @@ int msorb_extract(msorb_extractor* h, const uint8_t* image, int rows, int cols, 
     if ((rc = h->d_kps1.ensure(cap))) return rc;
     if ((rc = h->d_desc1.ensure((size_t)cap * 32))) return rc;
     const LevelGeom& g0 = h->G.lv[0];
-    // level 0 = copy of the caller's image (ORBextractor.cc:1190: the input is never modified or aliased)
-    HIPCHK(hipMemcpy2DAsync(h->d_pyr.p + g0.plane_off, g0.pitch, image, stride, cols, rows, hipMemcpyHostToDevice,
-                            h->stream));
+    // level 0 = copy of the caller's image (ORBextractor.cc:1190: the input is never modified or aliased).  Pageable
+    // memory is staged through pinned buffers owned by the handle: a plain hipMemcpy from pageable memory makes the
+    // driver pin/unpin per call, which costs more than the whole kernel chain.
+    if ((rc = h->h_img_pin.ensure((size_t)g0.pitch * rows))) return rc;
+    if ((rc = h->h_out_pin.ensure((size_t)cap * (sizeof(msorb_keypoint) + 32)))) return rc;
+    for (int y = 0; y < rows; y++) memcpy(h->h_img_pin.p + (size_t)y * g0.pitch, image + (size_t)y * stride, cols);
+    HIPCHK(hipMemcpyAsync(h->d_pyr.p + g0.plane_off, h->h_img_pin.p, (size_t)g0.pitch * rows, hipMemcpyHostToDevice,
+                          h->stream));
     LevelView l0{h->d_pyr.p + g0.plane_off, h->G.pyramid_bytes, g0.pitch, cols, rows};
     int n = 0, mono = 0;
     if ((rc = run_pipeline(h, l0, 1, lap0, lap1, h->d_kps1.p, h->d_desc1.p, cap, &n, &mono))) return rc;
     if (n > capacity) { set_error("caller capacity too small"); return MSORB_E_CAPACITY; }
     if (n > 0) {
-        HIPCHK(hipMemcpy(keypoints, h->d_kps1.p, (size_t)n * sizeof(msorb_keypoint), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(descriptors, h->d_desc1.p, (size_t)n * 32, hipMemcpyDeviceToHost));
+        msorb_keypoint* pk = reinterpret_cast<msorb_keypoint*>(h->h_out_pin.p);
+        uint8_t* pd = h->h_out_pin.p + (size_t)cap * sizeof(msorb_keypoint);
+        HIPCHK(hipMemcpyAsync(pk, h->d_kps1.p, (size_t)n * sizeof(msorb_keypoint), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(pd, h->d_desc1.p, (size_t)n * 32, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        memcpy(keypoints, pk, (size_t)n * sizeof(msorb_keypoint));
+        memcpy(descriptors, pd, (size_t)n * 32);
     }
     *n_keypoints = n;
     *mono_index = mono;
