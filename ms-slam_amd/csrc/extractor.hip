@@ -185,6 +185,7 @@ struct msorb_extractor {
     DevBuf<int> d_sel_pt, d_sel_n, d_mono;
     QtLevels qt{};
     bool device_quadtree = true;
+    bool small_cells = false;  // every cell ROI <= 46 x 57: the FAST kernel's compact LDS geometry applies
     bool compact_on_host = false;  // h_compact / h_level_count / h_img_base hold the last call's candidates
     // pinned host state
     PinBuf<int> h_level_count, h_img_base, h_sel_count, h_mono;
@@ -218,6 +219,8 @@ int ensure_geometry(msorb_extractor* h, int rows, int cols) {
     for (const CellDesc& c : g.cells)
         if (c.rw > 76 || c.rh > 76) { set_error("cell ROI larger than 76 px"); return MSORB_E_GEOMETRY; }
     h->G = g;
+    h->small_cells = true;
+    for (const CellDesc& c : g.cells) h->small_cells = h->small_cells && c.rw <= 46 && c.rh <= 57;
     // resize taps for levels 1..n-1
     std::vector<ResizeTap> all;
     h->tap_x_off.assign(g.nlevels, 0);
@@ -390,7 +393,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
         mark(8, sb);
         if (h->overlap_blur) HIPCHK(hipEventRecord(G.ev_blur, G.s2));
         launch_fast_cells(pyr, h->d_cells.p, ncells, h->P.ini_th, h->P.min_th, g.slots_per_image, h->d_slots.p + cslot,
-                          h->d_cell_count.p + (size_t)first * ncells, n, s);
+                          h->d_cell_count.p + (size_t)first * ncells, n, h->small_cells, s);
         mark(2, s);
         launch_cand_compact(h->d_cells.p, ncells, h->d_level_cell_begin.p, nl, g.slots_per_image, h->d_slots.p + cslot,
                             h->d_cell_count.p + (size_t)first * ncells, h->d_cell_off.p + (size_t)first * ncells,
@@ -469,7 +472,7 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
         HIPCHK(hipEventRecord(h->ev_blur, h->copy_stream));
     }
     launch_fast_cells(pyr, h->d_cells.p, ncells, h->P.ini_th, h->P.min_th, g.slots_per_image, h->d_slots.p,
-                      h->d_cell_count.p, n_images, s);
+                      h->d_cell_count.p, n_images, h->small_cells, s);
     mark(2);
     launch_cand_compact(h->d_cells.p, ncells, h->d_level_cell_begin.p, nl, g.slots_per_image, h->d_slots.p,
                         h->d_cell_count.p, h->d_cell_off.p, h->d_level_count.p, h->d_img_total.p, h->d_img_base.p,

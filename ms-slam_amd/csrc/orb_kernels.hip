@@ -110,39 +110,52 @@ __global__ __launch_bounds__(256) void pyr_resize_aligned_kernel(LevelView src, 
 // max(th, A, -B) - 1 and a corner has max(A,-B) > th), so one score plane serves both thresholds:
 // corner at th  <=>  S >= th, and NMS at iniTh keeps exactly the minTh survivors with S >= iniTh.
 // ------------------------------------------------------------------------------------------------
-constexpr int kTileRows = 77;        // ROI rows <= 76 (+1 spare row for harmless over-reads)
-constexpr int kTilePitch = 84;       // bytes: 3 (column phase) + 76 (ROI) + over-read slack, multiple of 4
 constexpr int kTileFront = 4;        // bytes in front of the tile so that column -4..-1 reads stay in bounds
-constexpr int kScorePitch = 88;      // 4 (apron group) + 4*20 (groups) + 4
-constexpr int kScoreRows = 73;       // detection rows <= 70, +1 apron above, +1 below, +1 spare
-constexpr int kMaxDet = 70;          // max detection width / height
-constexpr int kMaxGroups = 20;       // 4-pixel groups per detection row
-constexpr int kWorkCap = 4096;       // work-list entries; one phase-1 round adds at most 256 * 8
+// LDS geometry of the FAST kernel.  GeoLarge covers any legal cell (ROI <= 76 x 76); GeoSmall covers ROIs up to
+// 46 x 57 — every cell of the KITTI / EuRoC / 4Seasons geometries — in 11 KB instead of 23 KB, which lifts the
+// residency from 6 to 8 workgroups per CU.
+struct GeoLarge {
+    static constexpr int kTileRows = 77;    // ROI rows <= 76 (+1 spare row for harmless over-reads)
+    static constexpr int kTilePitch = 84;   // bytes: 3 (column phase) + 76 (ROI) + over-read slack, multiple of 4
+    static constexpr int kScorePitch = 88;  // 4 (apron group) + 4*20 (groups) + 4
+    static constexpr int kScoreRows = 73;   // detection rows <= 70, +1 apron above, +1 below, +1 spare
+    static constexpr int kMaxDet = 70;      // max detection height
+    static constexpr int kWorkCap = 4096;   // work-list entries per chunk
+};
+struct GeoSmall {
+    static constexpr int kTileRows = 58;    // ROI rows <= 57
+    static constexpr int kTilePitch = 52;   // 4 (first group offset) + 4*11 (groups) + 4
+    static constexpr int kScorePitch = 52;
+    static constexpr int kScoreRows = 54;   // detection rows <= 51
+    static constexpr int kMaxDet = 51;
+    static constexpr int kWorkCap = 2048;
+};
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(a, min(b, c)); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(a, max(b, c)); }
 
 // max over the 16 arcs of 9 contiguous circle pixels of min(sgn * (v - p)); p = LDS pointer to the centre
+template <class GEO>
 __device__ __forceinline__ int fast_arc_contrast(const uint8_t* p, int sgn) {
     // circle offsets (x,y): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
     const int sv = sgn * (int)p[0], ns = -sgn;
     int d[16];
-    d[0] = (int)p[3 * kTilePitch] * ns + sv;
-    d[1] = (int)p[3 * kTilePitch + 1] * ns + sv;
-    d[2] = (int)p[2 * kTilePitch + 2] * ns + sv;
-    d[3] = (int)p[1 * kTilePitch + 3] * ns + sv;
+    d[0] = (int)p[3 * GEO::kTilePitch] * ns + sv;
+    d[1] = (int)p[3 * GEO::kTilePitch + 1] * ns + sv;
+    d[2] = (int)p[2 * GEO::kTilePitch + 2] * ns + sv;
+    d[3] = (int)p[1 * GEO::kTilePitch + 3] * ns + sv;
     d[4] = (int)p[3] * ns + sv;
-    d[5] = (int)p[-1 * kTilePitch + 3] * ns + sv;
-    d[6] = (int)p[-2 * kTilePitch + 2] * ns + sv;
-    d[7] = (int)p[-3 * kTilePitch + 1] * ns + sv;
-    d[8] = (int)p[-3 * kTilePitch] * ns + sv;
-    d[9] = (int)p[-3 * kTilePitch - 1] * ns + sv;
-    d[10] = (int)p[-2 * kTilePitch - 2] * ns + sv;
-    d[11] = (int)p[-1 * kTilePitch - 3] * ns + sv;
+    d[5] = (int)p[-1 * GEO::kTilePitch + 3] * ns + sv;
+    d[6] = (int)p[-2 * GEO::kTilePitch + 2] * ns + sv;
+    d[7] = (int)p[-3 * GEO::kTilePitch + 1] * ns + sv;
+    d[8] = (int)p[-3 * GEO::kTilePitch] * ns + sv;
+    d[9] = (int)p[-3 * GEO::kTilePitch - 1] * ns + sv;
+    d[10] = (int)p[-2 * GEO::kTilePitch - 2] * ns + sv;
+    d[11] = (int)p[-1 * GEO::kTilePitch - 3] * ns + sv;
     d[12] = (int)p[-3] * ns + sv;
-    d[13] = (int)p[1 * kTilePitch - 3] * ns + sv;
-    d[14] = (int)p[2 * kTilePitch - 2] * ns + sv;
-    d[15] = (int)p[3 * kTilePitch - 1] * ns + sv;
+    d[13] = (int)p[1 * GEO::kTilePitch - 3] * ns + sv;
+    d[14] = (int)p[2 * GEO::kTilePitch - 2] * ns + sv;
+    d[15] = (int)p[3 * GEO::kTilePitch - 1] * ns + sv;
     int mn3[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) mn3[i] = min3i(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
@@ -187,17 +200,17 @@ __device__ __forceinline__ int block_excl_scan(int cnt, int lane, int wave, int*
     return before + incl - cnt;
 }
 
-template <bool ALIGNED>
+template <bool ALIGNED, class GEO>
 __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const CellDesc* __restrict__ cells,
                                                          int ini_th, int min_th, int slots_per_image,
                                                          Cand16* __restrict__ slots, int* __restrict__ cell_count,
                                                          int n_cells, int debug_stop) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile_mem[kTileFront + kTileRows * kTilePitch + 8];
-    __shared__ __attribute__((aligned(16))) uint8_t score[kScoreRows * kScorePitch];
-    __shared__ uint16_t work[kWorkCap];
+    __shared__ __attribute__((aligned(16))) uint8_t tile_mem[kTileFront + GEO::kTileRows * GEO::kTilePitch + 8];
+    __shared__ __attribute__((aligned(16))) uint8_t score[GEO::kScoreRows * GEO::kScorePitch];
+    __shared__ uint16_t work[GEO::kWorkCap];
     __shared__ int wave_tot[2][4];
-    __shared__ uint32_t kbits[2 * 3 * kMaxDet];
-    __shared__ int kprefix[3 * kMaxDet];
+    __shared__ uint32_t kbits[2 * 3 * GEO::kMaxDet];
+    __shared__ int kprefix[3 * GEO::kMaxDet];
     uint8_t* const tile = tile_mem + kTileFront;
 
     // XCD-aware order: consecutive workgroups are dealt round-robin to the 8 XCDs (each with a private L2); remap
@@ -231,7 +244,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
         const uint32_t dmagic = ((1u << 20) + ndw - 1) / ndw;
         for (int i = tid; i < rh * ndw; i += 256) {
             const int y = (i * dmagic) >> 20, c = i - y * ndw;
-            *reinterpret_cast<uint32_t*>(&tile[y * kTilePitch + 4 * c]) =
+            *reinterpret_cast<uint32_t*>(&tile[y * GEO::kTilePitch + 4 * c]) =
                 *reinterpret_cast<const uint32_t*>(src + (size_t)y * lv.pitch + ga + 4 * c);
         }
     } else {
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
         const uint32_t bmagic = ((1u << 20) + rw - 1) / rw;
         for (int i = tid; i < rh * rw; i += 256) {
             const int y = (i * bmagic) >> 20, x = i - y * rw;
-            tile[y * kTilePitch + off + x] = src[(size_t)y * lv.pitch + cd.x0 + x];
+            tile[y * GEO::kTilePitch + off + x] = src[(size_t)y * lv.pitch + cd.x0 + x];
         }
     }
     // Threshold passes (ORBextractor.cc:826,843-847): iniThFAST first; only a cell that ends up with no keypoint at all
@@ -248,7 +261,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
     int n_emitted = 0;
     for (int pass = 0; pass < 2; pass++) {
     const int th = pass ? min_th : ini_th;
-    for (int i = tid; i < (dh + 2) * (kScorePitch / 4); i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
+    for (int i = tid; i < (dh + 2) * (GEO::kScorePitch / 4); i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
     __syncthreads();
     if (debug_stop == 1) return;
 
@@ -261,12 +274,12 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
         int g = t_begin - y * G;
         for (int task = t_begin, k = 0; task < t_end; task++, k++) {
             const int c0 = c_lo + 4 * g;
-            const uint8_t* row = &tile[(y + 3) * kTilePitch + c0];
+            const uint8_t* row = &tile[(y + 3) * GEO::kTilePitch + c0];
             const uint32_t C = *reinterpret_cast<const uint32_t*>(row);
             const uint32_t Lw = *reinterpret_cast<const uint32_t*>(row - 4);
             const uint32_t Rw = *reinterpret_cast<const uint32_t*>(row + 4);
-            const uint32_t U = *reinterpret_cast<const uint32_t*>(row - 3 * kTilePitch);
-            const uint32_t D = *reinterpret_cast<const uint32_t*>(row + 3 * kTilePitch);
+            const uint32_t U = *reinterpret_cast<const uint32_t*>(row - 3 * GEO::kTilePitch);
+            const uint32_t D = *reinterpret_cast<const uint32_t*>(row + 3 * GEO::kTilePitch);
             const uint32_t R3 = __builtin_amdgcn_alignbyte(Rw, C, 3);  // p[x+3] per byte
             const uint32_t L3 = __builtin_amdgcn_alignbyte(C, Lw, 1);  // p[x-3] per byte
             uint32_t dk[2], br[2];
@@ -298,10 +311,10 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
     const int my_base = block_excl_scan(cnt, lane, wave, wave_tot[0], &n_work);
     if (debug_stop == 2) return;
 
-    // phase 2: the work list is processed in chunks of kWorkCap entries (one chunk unless the cell is saturated)
+    // phase 2: the work list is processed in chunks of GEO::kWorkCap entries (one chunk unless the cell is saturated)
     const int sc_off = 4 - c_lo;  // score column = tile column + sc_off  (first group at score column 4)
-    for (int cb = 0; cb < n_work; cb += kWorkCap) {
-        if (cnt && my_base < cb + kWorkCap && my_base + cnt > cb) {
+    for (int cb = 0; cb < n_work; cb += GEO::kWorkCap) {
+        if (cnt && my_base < cb + GEO::kWorkCap && my_base + cnt > cb) {
             int idx = my_base - cb;
             int y = (t_begin * magic) >> 20;
             int g = t_begin - y * G;
@@ -312,8 +325,8 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
                     const int e0 = ((y + 3) << 7) | (c_lo + 4 * g);
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        if (bits & (1u << j)) { if ((unsigned)idx < (unsigned)kWorkCap) work[idx] = (uint16_t)(e0 + j); idx++; }
-                        if (bits & (16u << j)) { if ((unsigned)idx < (unsigned)kWorkCap) work[idx] = (uint16_t)(0x8000 | (e0 + j)); idx++; }
+                        if (bits & (1u << j)) { if ((unsigned)idx < (unsigned)GEO::kWorkCap) work[idx] = (uint16_t)(e0 + j); idx++; }
+                        if (bits & (16u << j)) { if ((unsigned)idx < (unsigned)GEO::kWorkCap) work[idx] = (uint16_t)(0x8000 | (e0 + j)); idx++; }
                     }
                 }
                 if (++g == G) { g = 0; y++; }
@@ -321,12 +334,12 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
         }
         __syncthreads();
         if (debug_stop == 3) return;
-        const int nw = min(n_work - cb, kWorkCap);
+        const int nw = min(n_work - cb, GEO::kWorkCap);
         for (int i = tid; i < nw; i += 256) {
             const int e = work[i];
             const int ty = (e >> 7) & 127, tx = e & 127;
-            const int A = fast_arc_contrast(&tile[ty * kTilePitch + tx], (e & 0x8000) ? -1 : 1);
-            if (A > th) score[(ty - 2) * kScorePitch + tx + sc_off] = (uint8_t)(A - 1);  // score row = y + 1
+            const int A = fast_arc_contrast<GEO>(&tile[ty * GEO::kTilePitch + tx], (e & 0x8000) ? -1 : 1);
+            if (A > th) score[(ty - 2) * GEO::kScorePitch + tx + sc_off] = (uint8_t)(A - 1);  // score row = y + 1
             work[i] = A > th ? (uint16_t)(e & 0x3FFF) : (uint16_t)0xFFFF;  // the list now holds the corners
         }
         __syncthreads();
@@ -334,7 +347,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
     if (debug_stop == 4) return;
 
     Cand16* out = slots + (size_t)img * slots_per_image + cd.slot_off;
-    if (n_work <= kWorkCap) {
+    if (n_work <= GEO::kWorkCap) {
         // phase 3 (common case: the whole work list fitted): NMS and ordered emission driven by the corner list.
         // kept corners set a bit in a row-major bitmap of the detection area; the rank of a corner in scan order is
         // the popcount of the bits before it (prefix over the bitmap words).
@@ -349,11 +362,11 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
                 const int e = work[i];
                 if (e == 0xFFFF) continue;
                 const int ty = e >> 7, tx = e & 127;
-                const uint8_t* q = &score[(ty - 2) * kScorePitch + tx + sc_off];
+                const uint8_t* q = &score[(ty - 2) * GEO::kScorePitch + tx + sc_off];
                 const int sv = q[0];
-                int m = max3i(q[-kScorePitch - 1], q[-kScorePitch], q[-kScorePitch + 1]);
+                int m = max3i(q[-GEO::kScorePitch - 1], q[-GEO::kScorePitch], q[-GEO::kScorePitch + 1]);
                 m = max3i(m, q[-1], q[1]);
-                m = max(m, max3i(q[kScorePitch - 1], q[kScorePitch], q[kScorePitch + 1]));
+                m = max(m, max3i(q[GEO::kScorePitch - 1], q[GEO::kScorePitch], q[GEO::kScorePitch + 1]));
                 if (sv > m) {
                     const int bx = tx - c_lo, by = ty - 3;       // column inside the group span, detection row
                     const int b = by * (32 * wpr) + bx;
@@ -382,7 +395,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
                 Cand16 c;
                 c.x = (uint16_t)(ga + tx - kMinBorder);
                 c.y = (uint16_t)(cd.y0 + ty - kMinBorder);
-                c.score = score[(ty - 2) * kScorePitch + tx + sc_off];
+                c.score = score[(ty - 2) * GEO::kScorePitch + tx + sc_off];
                 c.pad = 0;
                 out[rank] = c;
             }
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
         int y = (t_begin * magic) >> 20;
         int g = t_begin - y * G;
         for (int task = t_begin, k = 0; task < t_end; task++, k++) {
-            const uint8_t* sp = &score[(y + 1) * kScorePitch + 4 + 4 * g];
+            const uint8_t* sp = &score[(y + 1) * GEO::kScorePitch + 4 + 4 * g];
             const uint32_t S = *reinterpret_cast<const uint32_t*>(sp);
             if (S) {
 #pragma unroll
@@ -405,9 +418,9 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
                     const int sv = (S >> (8 * j)) & 255;
                     if (sv) {
                         const uint8_t* q = sp + j;
-                        int m = max3i(q[-kScorePitch - 1], q[-kScorePitch], q[-kScorePitch + 1]);
+                        int m = max3i(q[-GEO::kScorePitch - 1], q[-GEO::kScorePitch], q[-GEO::kScorePitch + 1]);
                         m = max3i(m, q[-1], q[1]);
-                        m = max(m, max3i(q[kScorePitch - 1], q[kScorePitch], q[kScorePitch + 1]));
+                        m = max(m, max3i(q[GEO::kScorePitch - 1], q[GEO::kScorePitch], q[GEO::kScorePitch + 1]));
                         if (sv > m) {
                             keep |= 1u << (4 * k + j);
                             keep_ini |= 1u << (4 * k + j);
@@ -437,7 +450,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
                 Cand16 c;
                 c.x = (uint16_t)(gx0 + 4 * g + j - kMinBorder);
                 c.y = (uint16_t)(cd.y0 + 3 + y - kMinBorder);
-                c.score = score[(y + 1) * kScorePitch + 4 + 4 * g + j];
+                c.score = score[(y + 1) * GEO::kScorePitch + 4 + 4 * g + j];
                 c.pad = 0;
                 out[pos++] = c;
             }
@@ -851,19 +864,20 @@ void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_
     else hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
 }
 void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cells, int ini_th, int min_th,
-                       int slots_per_image, Cand16* slots, int* cell_count, int n_images, hipStream_t s) {
+                       int slots_per_image, Cand16* slots, int* cell_count, int n_images, bool small_cells, hipStream_t s) {
     bool aligned = true;
     for (int l = 0; l < pyr.nlevels; l++) {
         const LevelView& v = pyr.lv[l];
         aligned = aligned && (reinterpret_cast<uintptr_t>(v.base) & 3) == 0 && (v.pitch & 3) == 0 && (v.img_stride & 3) == 0;
     }
     static const int dbg = getenv("MSORB_FAST_DEBUG_STOP") ? atoi(getenv("MSORB_FAST_DEBUG_STOP")) : 0;  // profiling only
-    if (aligned)
-        hipLaunchKernelGGL(fast_cells_kernel<true>, dim3(n_cells, n_images), dim3(256), 0, s, pyr, cells, ini_th, min_th,
-                           slots_per_image, slots, cell_count, n_cells, dbg);
-    else
-        hipLaunchKernelGGL(fast_cells_kernel<false>, dim3(n_cells, n_images), dim3(256), 0, s, pyr, cells, ini_th, min_th,
-                           slots_per_image, slots, cell_count, n_cells, dbg);
+    const dim3 grid(n_cells, n_images), block(256);
+#define MSORB_FAST_LAUNCH(AL, GEO)                                                                                        \
+    hipLaunchKernelGGL((fast_cells_kernel<AL, GEO>), grid, block, 0, s, pyr, cells, ini_th, min_th, slots_per_image, slots, \
+                       cell_count, n_cells, dbg)
+    if (small_cells) { if (aligned) MSORB_FAST_LAUNCH(true, GeoSmall); else MSORB_FAST_LAUNCH(false, GeoSmall); }
+    else { if (aligned) MSORB_FAST_LAUNCH(true, GeoLarge); else MSORB_FAST_LAUNCH(false, GeoLarge); }
+#undef MSORB_FAST_LAUNCH
 }
 void launch_cand_compact(const CellDesc* cells, int n_cells, const int* level_cell_begin, int nlevels,
                          int slots_per_image, const Cand16* slots, const int* cell_count, int* cell_off,
