@@ -150,6 +150,16 @@ int msorb_search_by_projection_mps(msorb_frame* f, int m, const uint8_t* track_i
                                    const float* view_cos, const uint8_t* mp_desc, const int* obs, int* frame_mp,
                                    float th, int far_points, float th_far_points, float nnratio, int* nmatches);
 
+/* The window search on its own, for the SearchByProjection variants that keep their accept rules in the caller
+ * (KeyFrame / Sim3 / relocalisation forms, ORBmatcher.cc:423-753, 2154-2275): for each query the 4 nearest
+ * descriptors among GetFeaturesInArea(x, y, r, min_level, max_level) in the reference's scan order (ties ->
+ * earlier in the scan), skipping keypoints flagged in occupied[n] when skip_occupied[i] != 0 and keypoints whose
+ * mvuRight differs from ur[i] by more than r[i] (ur == NULL disables nothing: pass a frame without mvuRight).
+ * best_idx / best_dist have 4 entries per query (-1 / 256 = none). */
+int msorb_window_top4(msorb_frame* f, int n_queries, const float* x, const float* y, const float* r, const float* ur,
+                      const int* min_level, const int* max_level, const uint8_t* skip_occupied, const uint8_t* query_desc,
+                      const uint8_t* occupied, int* best_idx, int* best_dist);
+
 /* ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, th, bMono) (ORBmatcher.cc:1941-2057,
  * 2129-2152) from the projected coordinates on.  Per last-frame keypoint i: valid (map point present, not
  * outlier, positive depth, inside the image), u,v (projection), ur (u - mbf/z), last_octave, last_angle,

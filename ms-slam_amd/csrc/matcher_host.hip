@@ -359,6 +359,43 @@ int msorb_search_by_projection_frames(msorb_frame* f, int NL, const uint8_t* val
     return MSORB_OK;
 }
 
+int msorb_window_top4(msorb_frame* f, int n_queries, const float* x, const float* y, const float* r, const float* ur,
+                      const int* min_level, const int* max_level, const uint8_t* skip_occupied, const uint8_t* query_desc,
+                      const uint8_t* occupied, int* best_idx, int* best_dist) {
+    if (!f || n_queries < 0 || (n_queries > 0 && (!x || !y || !r || !min_level || !max_level || !query_desc || !best_idx ||
+                                                  !best_dist)))
+        return MSORB_E_INVALID;
+    if (n_queries == 0) return MSORB_OK;
+    HIPCHK(hipSetDevice(f->device));
+    std::vector<WinQuery> q(n_queries);
+    for (int i = 0; i < n_queries; i++) {
+        WinQuery w{};
+        w.x = x[i]; w.y = y[i]; w.r = r[i];
+        w.ur = ur ? ur[i] : 0.f;
+        w.min_level = (int16_t)min_level[i]; w.max_level = (int16_t)max_level[i];
+        w.flags = kQValid | ((skip_occupied && skip_occupied[i]) ? kQSkipOccupied : 0);
+        q[i] = w;
+    }
+    int rc;
+    if ((rc = f->d_q.ensure(n_queries)) || (rc = f->d_qdesc.ensure((size_t)n_queries * 32)) ||
+        (rc = f->d_topk.ensure(n_queries)) || (rc = f->d_occ.ensure(f->N)))
+        return rc;
+    hipStream_t s = f->stream;
+    std::vector<TopK> topk(n_queries);
+    HIPCHK(hipMemcpyAsync(f->d_q.p, q.data(), (size_t)n_queries * sizeof(WinQuery), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(f->d_qdesc.p, query_desc, (size_t)n_queries * 32, hipMemcpyHostToDevice, s));
+    if (f->N) {
+        if (occupied) HIPCHK(hipMemcpyAsync(f->d_occ.p, occupied, f->N, hipMemcpyHostToDevice, s));
+        else HIPCHK(hipMemsetAsync(f->d_occ.p, 0, f->N, s));
+    }
+    launch_window_topk(f->view(), f->d_q.p, f->d_qdesc.p, 0, n_queries, f->d_topk.p, s);
+    HIPCHK(hipMemcpyAsync(topk.data(), f->d_topk.p, (size_t)n_queries * sizeof(TopK), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int i = 0; i < n_queries; i++)
+        for (int k = 0; k < kTopK; k++) { best_idx[4 * i + k] = topk[i].idx[k]; best_dist[4 * i + k] = topk[i].dist[k]; }
+    return MSORB_OK;
+}
+
 int msorb_three_maxima(const int* sizes, int L, int* ind) {
     if (!sizes || !ind || L < 0) return MSORB_E_INVALID;
     int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;

@@ -411,3 +411,24 @@ def hamming_dense_top2_batch(d_query, d_train, d_nq, d_nt, repeats=1, device=0):
                                             outs[1].data_ptr(), outs[2].data_ptr(), repeats, C.byref(ms)),
            "msorb_hamming_dense_top2_batch")
     return outs[0], outs[1], outs[2], ms.value
+
+
+EXPORTS = EXPORTS + ("msorb_window_top4",)
+
+
+def window_top4(frame, x, y, r, min_level, max_level, query_desc, ur=None, skip_occupied=None, occupied=None):
+    """msorb_window_top4: -> (idx[nq,4], dist[nq,4])"""
+    L = _mlib()
+    L.msorb_window_top4.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 11
+    xs, ys, rs = _c(x, np.float32), _c(y, np.float32), _c(r, np.float32)
+    mn, mx = _c(min_level, np.int32), _c(max_level, np.int32)
+    qd = _c(query_desc, np.uint8)
+    nq = len(xs)
+    urs = None if ur is None else _c(ur, np.float32)
+    sk = None if skip_occupied is None else _c(skip_occupied, np.uint8)
+    oc = None if occupied is None else _c(occupied, np.uint8)
+    bi, bd = np.zeros((nq, 4), np.int32), np.zeros((nq, 4), np.int32)
+    _check(L.msorb_window_top4(frame.h, nq, _np_ptr(xs), _np_ptr(ys), _np_ptr(rs), None if urs is None else _np_ptr(urs),
+                               _np_ptr(mn), _np_ptr(mx), None if sk is None else _np_ptr(sk), _np_ptr(qd),
+                               None if oc is None else _np_ptr(oc), _np_ptr(bi), _np_ptr(bd)), "msorb_window_top4")
+    return bi, bd

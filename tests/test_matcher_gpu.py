@@ -141,3 +141,29 @@ def test_dense_top2_batch(msorb_mod, oracle):
         assert np.array_equal(bd[f, :nq[f]], np.take_along_axis(d, order[:, :1], 1)[:, 0])
         assert np.array_equal(sd[f, :nq[f]], np.take_along_axis(d, order[:, 1:2], 1)[:, 0])
     assert oracle.descriptor_distance(q[0, 0], t[0, bi[0, 0]]) == bd[0, 0] == 0
+
+
+def test_window_top4_against_features_in_area(msorb_mod, oracle, stereo_frame):
+    """The raw window search: top-4 of DescriptorDistance over GetFeaturesInArea in scan order."""
+    s = stereo_frame
+    f, rf = _frames(msorb_mod, oracle, s, None)
+    rng = np.random.Generator(np.random.PCG64(31))
+    nq = 400
+    src = rng.integers(0, len(s["kl"]), nq)
+    x = s["kl"]["x"][src] + rng.normal(0, 5, nq).astype(np.float32)
+    y = s["kl"]["y"][src] + rng.normal(0, 5, nq).astype(np.float32)
+    r = rng.uniform(5, 60, nq).astype(np.float32)
+    mn = rng.integers(-1, 4, nq).astype(np.int32)
+    mx = np.where(rng.random(nq) < 0.5, -1, mn + rng.integers(0, 3, nq)).astype(np.int32)
+    qd = mc.flip_bits(rng, s["dl"][src], 60)
+    occ = (rng.random(len(s["kl"])) < 0.3).astype(np.uint8)
+    skip = (rng.random(nq) < 0.5).astype(np.uint8)
+    bi, bd = msorb_mod.window_top4(f, x, y, r, mn, mx, qd, skip_occupied=skip, occupied=occ)
+    for i in range(nq):
+        cand = [c for c in rf.GetFeaturesInArea(float(x[i]), float(y[i]), float(r[i]), int(mn[i]), int(mx[i]))
+                if not (skip[i] and occ[c])]
+        d = [oracle.descriptor_distance(qd[i], s["dl"][c]) for c in cand]
+        order = sorted(range(len(cand)), key=lambda k: (d[k], k))[:4]
+        want_i = [cand[k] for k in order] + [-1] * (4 - len(order))
+        want_d = [d[k] for k in order] + [256] * (4 - len(order))
+        assert bi[i].tolist() == want_i and bd[i].tolist() == want_d
