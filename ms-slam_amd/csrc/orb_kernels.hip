@@ -121,6 +121,8 @@ struct GeoLarge {
     static constexpr int kScoreRows = 73;   // detection rows <= 70, +1 apron above, +1 below, +1 spare
     static constexpr int kMaxDet = 70;      // max detection height
     static constexpr int kWorkCap = 4096;   // work-list entries per chunk
+    static constexpr int kThreads = 256;    // <= 6 tasks per thread (8 mask bits each in a 64-bit word)
+    static constexpr int kWordsPerRow = 3;  // bitmap words per detection row (<= 80 columns)
 };
 struct GeoSmall {
     static constexpr int kTileRows = 58;    // ROI rows <= 57
@@ -129,6 +131,8 @@ struct GeoSmall {
     static constexpr int kScoreRows = 54;   // detection rows <= 51
     static constexpr int kMaxDet = 51;
     static constexpr int kWorkCap = 2048;
+    static constexpr int kThreads = 128;    // 2 waves per cell: the task / work-list loops run fuller than with 4
+    static constexpr int kWordsPerRow = 2;  // <= 44 columns
 };
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(a, min(b, c)); }
@@ -182,16 +186,16 @@ typedef short short2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ short2v as_s2(uint32_t v) { return __builtin_bit_cast(short2v, v); }
 __device__ __forceinline__ uint32_t as_u32(short2v v) { return __builtin_bit_cast(uint32_t, v); }
 
-constexpr int kMaxRounds = 6;  // tasks per thread: ceil(70 * 20 / 256)
 
 // block-wide exclusive prefix of a per-thread count (4 waves); returns the grand total through *total
-__device__ __forceinline__ int block_excl_scan(int cnt, int lane, int wave, int* wave_tot /* LDS[4] */, int* total) {
+template <int WAVES>
+__device__ __forceinline__ int block_excl_scan(int cnt, int lane, int wave, int* wave_tot /* LDS[WAVES] */, int* total) {
     const int incl = wave_incl_scan(cnt, lane);
     if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
     int before = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
+    for (int w = 0; w < WAVES; w++) {
         const int c = wave_tot[w];
         if (w < wave) before += c;
         tot += c;
@@ -201,16 +205,16 @@ __device__ __forceinline__ int block_excl_scan(int cnt, int lane, int wave, int*
 }
 
 template <bool ALIGNED, class GEO>
-__global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const CellDesc* __restrict__ cells,
+__global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView pyr, const CellDesc* __restrict__ cells,
                                                          int ini_th, int min_th, int slots_per_image,
                                                          Cand16* __restrict__ slots, int* __restrict__ cell_count,
                                                          int n_cells, int debug_stop) {
     __shared__ __attribute__((aligned(16))) uint8_t tile_mem[kTileFront + GEO::kTileRows * GEO::kTilePitch + 8];
     __shared__ __attribute__((aligned(16))) uint8_t score[GEO::kScoreRows * GEO::kScorePitch];
     __shared__ uint16_t work[GEO::kWorkCap];
-    __shared__ int wave_tot[2][4];
-    __shared__ uint32_t kbits[2 * 3 * GEO::kMaxDet];
-    __shared__ int kprefix[3 * GEO::kMaxDet];
+    __shared__ int wave_tot[2][GEO::kThreads / 64];
+    __shared__ uint32_t kbits[GEO::kWordsPerRow * GEO::kMaxDet];
+    __shared__ int kprefix[GEO::kWordsPerRow * GEO::kMaxDet];
     uint8_t* const tile = tile_mem + kTileFront;
 
     // XCD-aware order: consecutive workgroups are dealt round-robin to the 8 XCDs (each with a private L2); remap
@@ -234,15 +238,15 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
     const int c_lo = gx0 - ga;            // tile column of the first group (multiple of 4)
     const int n_task = dh * G;            // one task = one group of one detection row, scan order
     const uint32_t magic = ((1u << 20) + G - 1) / G;  // task / G == (task * magic) >> 20 for task < 2^20 / G
-    // balanced consecutive task ranges: thread t owns tasks [t*n/256, (t+1)*n/256)  (<= kMaxRounds each)
-    const int t_begin = (tid * n_task) >> 8, t_end = ((tid + 1) * n_task) >> 8;
+    // balanced consecutive task ranges: thread t owns tasks [t*n/T, (t+1)*n/T)  (<= kMaxRounds each)
+    const int t_begin = (tid * n_task) / GEO::kThreads, t_end = ((tid + 1) * n_task) / GEO::kThreads;
 
     // phase 0
     const uint8_t* src = lv.base + (size_t)img * lv.img_stride + (size_t)cd.y0 * lv.pitch;
     if (ALIGNED) {
         const int ndw = (cd.x0 + rw - ga + 3) >> 2;  // dwords per tile row
         const uint32_t dmagic = ((1u << 20) + ndw - 1) / ndw;
-        for (int i = tid; i < rh * ndw; i += 256) {
+        for (int i = tid; i < rh * ndw; i += GEO::kThreads) {
             const int y = (i * dmagic) >> 20, c = i - y * ndw;
             *reinterpret_cast<uint32_t*>(&tile[y * GEO::kTilePitch + 4 * c]) =
                 *reinterpret_cast<const uint32_t*>(src + (size_t)y * lv.pitch + ga + 4 * c);
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
     } else {
         const int off = cd.x0 - ga;
         const uint32_t bmagic = ((1u << 20) + rw - 1) / rw;
-        for (int i = tid; i < rh * rw; i += 256) {
+        for (int i = tid; i < rh * rw; i += GEO::kThreads) {
             const int y = (i * bmagic) >> 20, x = i - y * rw;
             tile[y * GEO::kTilePitch + off + x] = src[(size_t)y * lv.pitch + cd.x0 + x];
         }
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
     int n_emitted = 0;
     for (int pass = 0; pass < 2; pass++) {
     const int th = pass ? min_th : ini_th;
-    for (int i = tid; i < (dh + 2) * (GEO::kScorePitch / 4); i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
+    for (int i = tid; i < (dh + 2) * (GEO::kScorePitch / 4); i += GEO::kThreads) reinterpret_cast<uint32_t*>(score)[i] = 0;
     __syncthreads();
     if (debug_stop == 1) return;
 
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
         }
     }
     int n_work = 0;
-    const int my_base = block_excl_scan(cnt, lane, wave, wave_tot[0], &n_work);
+    const int my_base = block_excl_scan<GEO::kThreads / 64>(cnt, lane, wave, wave_tot[0], &n_work);
     if (debug_stop == 2) return;
 
     // phase 2: the work list is processed in chunks of GEO::kWorkCap entries (one chunk unless the cell is saturated)
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
         __syncthreads();
         if (debug_stop == 3) return;
         const int nw = min(n_work - cb, GEO::kWorkCap);
-        for (int i = tid; i < nw; i += 256) {
+        for (int i = tid; i < nw; i += GEO::kThreads) {
             const int e = work[i];
             const int ty = (e >> 7) & 127, tx = e & 127;
             const int A = fast_arc_contrast<GEO>(&tile[ty * GEO::kTilePitch + tx], (e & 0x8000) ? -1 : 1);
@@ -351,14 +355,14 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
         // phase 3 (common case: the whole work list fitted): NMS and ordered emission driven by the corner list.
         // kept corners set a bit in a row-major bitmap of the detection area; the rank of a corner in scan order is
         // the popcount of the bits before it (prefix over the bitmap words).
-        const int wpr = 3;                      // bitmap words per detection row (<= 96 columns incl. the group pad)
+        constexpr int wpr = GEO::kWordsPerRow;  // bitmap words per detection row
         const int nwords = dh * wpr;
-        for (int i = tid; i < nwords; i += 256) kbits[i] = 0;
+        for (int i = tid; i < nwords; i += GEO::kThreads) kbits[i] = 0;
         __syncthreads();
-        uint32_t mine_keep = 0;  // per-thread record of the corners it owns: up to 16 list slots (4096 / 256)
+        uint32_t mine_keep = 0;  // per-thread record of the corners it owns: up to 16 list slots (cap / threads <= 32)
         {
             int slot = 0;
-            for (int i = tid; i < n_work; i += 256, slot++) {
+            for (int i = tid; i < n_work; i += GEO::kThreads, slot++) {
                 const int e = work[i];
                 if (e == 0xFFFF) continue;
                 const int ty = e >> 7, tx = e & 127;
@@ -380,12 +384,12 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
         // prefix popcount over the selected bitmap
         int n_out2 = 0;
         const int wcount = tid < nwords ? __popc(sel_bits[tid]) : 0;
-        const int wprefix = block_excl_scan(wcount, lane, wave, wave_tot[1], &n_out2);
+        const int wprefix = block_excl_scan<GEO::kThreads / 64>(wcount, lane, wave, wave_tot[1], &n_out2);
         if (tid < nwords) kprefix[tid] = wprefix;
         __syncthreads();
         {
             int slot = 0;
-            for (int i = tid; i < n_work; i += 256, slot++) {
+            for (int i = tid; i < n_work; i += GEO::kThreads, slot++) {
                 if (!(mine_keep & (1u << slot))) continue;
                 const int e = work[i];
                 const int ty = e >> 7, tx = e & 127;
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyramidView pyr, const 
     // phase 3b: ordered emission — a thread's tasks are consecutive in scan order, so the block-wide prefix of the
     // per-thread counts is the rank in (ascending y, then x) order
     int n_out = 0;
-    int pos = block_excl_scan(__popc(sel), lane, wave, wave_tot[1], &n_out);
+    int pos = block_excl_scan<GEO::kThreads / 64>(__popc(sel), lane, wave, wave_tot[1], &n_out);
     if (sel) {
         int y = (t_begin * magic) >> 20;
         int g = t_begin - y * G;
@@ -871,9 +875,9 @@ void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cell
         aligned = aligned && (reinterpret_cast<uintptr_t>(v.base) & 3) == 0 && (v.pitch & 3) == 0 && (v.img_stride & 3) == 0;
     }
     static const int dbg = getenv("MSORB_FAST_DEBUG_STOP") ? atoi(getenv("MSORB_FAST_DEBUG_STOP")) : 0;  // profiling only
-    const dim3 grid(n_cells, n_images), block(256);
+    const dim3 grid(n_cells, n_images);
 #define MSORB_FAST_LAUNCH(AL, GEO)                                                                                        \
-    hipLaunchKernelGGL((fast_cells_kernel<AL, GEO>), grid, block, 0, s, pyr, cells, ini_th, min_th, slots_per_image, slots, \
+    hipLaunchKernelGGL((fast_cells_kernel<AL, GEO>), grid, dim3(GEO::kThreads), 0, s, pyr, cells, ini_th, min_th, slots_per_image, slots, \
                        cell_count, n_cells, dbg)
     if (small_cells) { if (aligned) MSORB_FAST_LAUNCH(true, GeoSmall); else MSORB_FAST_LAUNCH(false, GeoSmall); }
     else { if (aligned) MSORB_FAST_LAUNCH(true, GeoLarge); else MSORB_FAST_LAUNCH(false, GeoLarge); }
