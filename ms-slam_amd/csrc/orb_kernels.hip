@@ -130,8 +130,8 @@ struct GeoSmall {
     static constexpr int kScorePitch = 52;
     static constexpr int kScoreRows = 54;   // detection rows <= 51
     static constexpr int kMaxDet = 51;
-    static constexpr int kWorkCap = 2048;
-    static constexpr int kThreads = 128;    // 2 waves per cell: the task / work-list loops run fuller than with 4
+    static constexpr int kWorkCap = 1536;   // 9.7 KB per workgroup in total -> 16 workgroups (32 waves) per CU
+    static constexpr int kThreads = 128;    // 2 waves per cell: the task / work-list loops run fuller than with 4 (64 measured slower)
     static constexpr int kWordsPerRow = 2;  // <= 44 columns
 };
 
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
     if (debug_stop == 1) return;
 
     // phase 1: quick test, two pixels per packed 16-bit lane; 8 result bits per task (dark 0..3, bright 4..7)
-    uint64_t M = 0;
+    uint64_t M = 0;  // 8 bits per owned task (<= 6 tasks with GeoLarge, <= 5 with GeoSmall)
     int cnt = 0;
     const short2v T2 = {(short)th, (short)th};
     {
@@ -383,9 +383,12 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
         const uint32_t* sel_bits = kbits;
         // prefix popcount over the selected bitmap
         int n_out2 = 0;
-        const int wcount = tid < nwords ? __popc(sel_bits[tid]) : 0;
-        const int wprefix = block_excl_scan<GEO::kThreads / 64>(wcount, lane, wave, wave_tot[1], &n_out2);
-        if (tid < nwords) kprefix[tid] = wprefix;
+        const int wper = (nwords + GEO::kThreads - 1) / GEO::kThreads;  // consecutive bitmap words per thread
+        const int wb = tid * wper, we = min(wb + wper, nwords);
+        int wcount = 0;
+        for (int i = wb; i < we; i++) wcount += __popc(sel_bits[i]);
+        int wprefix = block_excl_scan<GEO::kThreads / 64>(wcount, lane, wave, wave_tot[1], &n_out2);
+        for (int i = wb; i < we; i++) { kprefix[i] = wprefix; wprefix += __popc(sel_bits[i]); }
         __syncthreads();
         {
             int slot = 0;
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
     // saturated cell (more quick-test survivors than the work list holds): scan the score plane by tasks
 
     // phase 3a: strict 3x3 NMS, 4 flag bits per task
-    uint32_t keep = 0, keep_ini = 0;
+    uint64_t keep = 0, keep_ini = 0;
     {
         int y = (t_begin * magic) >> 20;
         int g = t_begin - y * G;
@@ -426,8 +429,8 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
                         m = max3i(m, q[-1], q[1]);
                         m = max(m, max3i(q[GEO::kScorePitch - 1], q[GEO::kScorePitch], q[GEO::kScorePitch + 1]));
                         if (sv > m) {
-                            keep |= 1u << (4 * k + j);
-                            keep_ini |= 1u << (4 * k + j);
+                            keep |= 1ull << (4 * k + j);
+                            keep_ini |= 1ull << (4 * k + j);
                         }
                     }
                 }
@@ -436,18 +439,18 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
         }
     }
     const int any_ini = __syncthreads_or(keep_ini != 0);
-    const uint32_t sel = any_ini ? keep_ini : keep;
+    const uint64_t sel = any_ini ? keep_ini : keep;
 
     // phase 3b: ordered emission — a thread's tasks are consecutive in scan order, so the block-wide prefix of the
     // per-thread counts is the rank in (ascending y, then x) order
     int n_out = 0;
-    int pos = block_excl_scan<GEO::kThreads / 64>(__popc(sel), lane, wave, wave_tot[1], &n_out);
+    int pos = block_excl_scan<GEO::kThreads / 64>(__popcll(sel), lane, wave, wave_tot[1], &n_out);
     if (sel) {
         int y = (t_begin * magic) >> 20;
         int g = t_begin - y * G;
-        uint32_t m = sel;
+        uint64_t m = sel;
         for (int task = t_begin; task < t_end; task++, m >>= 4) {
-            uint32_t m4 = m & 15u;
+            uint32_t m4 = (uint32_t)m & 15u;
             while (m4) {
                 const int j = __ffs(m4) - 1;
                 m4 &= m4 - 1;
