@@ -646,47 +646,44 @@ __global__ __launch_bounds__(256) void gauss7_kernel(PyramidView src, PyramidVie
     }
 }
 
-// Right-border column groups (x0 + 16 > w: at most four per row): per-byte reflect-101 gather, one thread per
-// (row strip, group), scalar form of the same arithmetic.
+// Right-border column groups (x0 + 16 > w: at most four groups = 16 columns per row): per-byte reflect-101 gather.
+// One 64-thread block covers 58 output rows: thread r first forms the horizontal sums of input row y0-3+r for the
+// border columns (all rows in parallel: one memory round trip), then thread r < 58 finishes output row y0+r from LDS.
+constexpr int kEdgeRows = 58;
 __global__ __launch_bounds__(64) void gauss7_edge_kernel(PyramidView src, PyramidView dst) {
+    __shared__ uint16_t hs[64][16];
     const int level = blockIdx.y, img = blockIdx.z;
     const LevelView sv = src.lv[level], dv = dst.lv[level];
     const int first = sv.w >= 16 ? ((sv.w - 16) / 4 + 1) * 4 : 0;  // first x0 with x0 + 16 > w
-    const int ngroups = (sv.w - first + 3) / 4;
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    const int strip = t / 4, g = t % 4;
-    const int x0 = first + 4 * g, y0 = strip * kGaussRows;
-    if (g >= ngroups || y0 >= sv.h) return;
+    const int ncol = sv.w - first;                                  // 1..16 border columns
+    const int y0 = blockIdx.x * kEdgeRows;
+    if (y0 >= sv.h) return;
+    const int r = threadIdx.x;
     const uint8_t* sb = sv.base + (size_t)img * sv.img_stride;
     uint8_t* db = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride;
     const int K[7] = {18, 34, 48, 56, 48, 34, 18};
-    int col[10];
-#pragma unroll
-    for (int o = 0; o < 10; o++) col[o] = refl101(x0 - 3 + o, sv.w);
-    uint32_t ring[7][4];
-    for (int r = 0; r < kGaussRows + 6; r++) {
+    {
         int yy = refl101(y0 - 3 + r, sv.h);
         yy = min(max(yy, 0), sv.h - 1);
         const uint8_t* rp = sb + (size_t)yy * sv.pitch;
-        uint32_t px[10];
+        uint32_t px[22];
 #pragma unroll
-        for (int o = 0; o < 10; o++) px[o] = rp[col[o]];
+        for (int o = 0; o < 22; o++) px[o] = rp[min(max(refl101(first - 3 + o, sv.w), 0), sv.w - 1)];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint32_t hsum = 0;
+        for (int j = 0; j < 16; j++) {
+            uint32_t a = 0;
 #pragma unroll
-            for (int k = 0; k < 7; k++) hsum += K[k] * px[j + k];
-            ring[r % 7][j] = hsum;
+            for (int k = 0; k < 7; k++) a += K[k] * px[j + k];
+            hs[r][j] = (uint16_t)a;
         }
-        const int o = r - 6;
-        if (o >= 0 && y0 + o < sv.h) {
+    }
+    __syncthreads();
+    if (r < kEdgeRows && y0 + r < sv.h) {
+        for (int j = 0; j < ncol; j++) {
+            uint32_t acc = 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                uint32_t accv = 0;
-#pragma unroll
-                for (int k = 0; k < 7; k++) accv += K[k] * ring[(o + k) % 7][j];
-                if (x0 + j < sv.w) db[(size_t)(y0 + o) * dv.pitch + x0 + j] = (uint8_t)((accv + 32768u) >> 16);
-            }
+            for (int k = 0; k < 7; k++) acc += (uint32_t)K[k] * hs[r + k][j];
+            db[(size_t)(y0 + r) * dv.pitch + first + j] = (uint8_t)((acc + 32768u) >> 16);
         }
     }
 }
@@ -900,20 +897,20 @@ void launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images,
     BlurPlan plan{};
     plan.nlevels = src.nlevels;
     bool aligned = true;
-    int total = 0, max_edge_threads = 0;
+    int total = 0, max_h = 0;
     for (int l = 0; l < src.nlevels; l++) {
         const LevelView& v = src.lv[l];
         plan.block_begin[l] = total;
         plan.bx_count[l] = (v.w + 255) / 256;
         const int strips = (v.h + kGaussRows - 1) / kGaussRows;
         total += plan.bx_count[l] * ((strips + 3) / 4);
-        max_edge_threads = max(max_edge_threads, strips * 4);
+        max_h = max(max_h, v.h);
         aligned = aligned && (reinterpret_cast<uintptr_t>(v.base) & 3) == 0 && (v.pitch & 3) == 0 && (v.img_stride & 3) == 0;
     }
     plan.block_begin[src.nlevels] = total;
     if (aligned) hipLaunchKernelGGL(gauss7_kernel<true>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
     else hipLaunchKernelGGL(gauss7_kernel<false>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
-    hipLaunchKernelGGL(gauss7_edge_kernel, dim3((max_edge_threads + 63) / 64, src.nlevels, n_images), dim3(64), 0, s, src, dst);
+    hipLaunchKernelGGL(gauss7_edge_kernel, dim3((max_h + kEdgeRows - 1) / kEdgeRows, src.nlevels, n_images), dim3(64), 0, s, src, dst);
 }
 void launch_describe(const PyramidView& pyr, const PyramidView& blur, const SelRec* sel, const int* sel_count,
                      int sel_stride, const LevelScale& scales, msorb_keypoint* kps, uint8_t* desc, int out_stride,
