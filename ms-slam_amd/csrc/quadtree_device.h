@@ -245,27 +245,44 @@ QT_HD int partition_par(Ex& ex, SortItem* v, int first, int last, ParScratch& ps
     const int m = last - (first + 1);
     const int per = (m + nt - 1) / nt;
     const int cb = first + 1 + tid * per, ce = cb + per < last ? cb + per : last;
-    int ng = 0, nl = 0;
-    for (int i = cb; i < ce; i++) { ng += v[i].key >= pivot; nl += v[i].key <= pivot; }
-    int tot = 0;
-    const int ex_packed = ex.excl_scan(ng | (nl << 16), ps.scan_tmp, &tot);
-    const int NG = tot & 0xFFFF, NL = tot >> 16;
-    int rg = ex_packed & 0xFFFF, ra = ex_packed >> 16;  // ascending exclusive ranks
-    for (int i = cb; i < ce; i++) {
-        if (v[i].key >= pivot) ps.gpos[rg++] = (uint16_t)i;
-        if (v[i].key <= pivot) { ps.lpos[NL - 1 - ra] = (uint16_t)i; ra++; }  // descending rank
+    int NG, NL, k = 0;
+    if (per == 1) {
+        // one element per thread: prefix counts are ballots (no shuffle chain)
+        const bool in = cb < ce;
+        const bool is_g = in && v[in ? cb : first].key >= pivot, is_l = in && v[in ? cb : first].key <= pivot;
+        const int rg = ex.excl_count(is_g, &NG), ra = ex.excl_count(is_l, &NL);
+        if (is_g) ps.gpos[rg] = (uint16_t)cb;
+        if (is_l) ps.lpos[NL - 1 - ra] = (uint16_t)cb;
+        ex.sync();
+        const int T = NG < NL ? NG : NL;
+        const bool sw = tid < T && ps.gpos[tid < T ? tid : 0] < ps.lpos[tid < T ? tid : 0];
+        ex.excl_count(sw, &k);  // monotone predicate: the count is the number of swaps, and the swapping threads are 0..k-1
+        if (sw) {
+            const int a = ps.gpos[tid], b = ps.lpos[tid];
+            const SortItem x = v[a]; v[a] = v[b]; v[b] = x;
+        }
+    } else {
+        int ng = 0, nl = 0;
+        for (int i = cb; i < ce; i++) { ng += v[i].key >= pivot; nl += v[i].key <= pivot; }
+        int tot = 0;
+        const int ex_packed = ex.excl_scan(ng | (nl << 16), ps.scan_tmp, &tot);
+        NG = tot & 0xFFFF; NL = tot >> 16;
+        int rg = ex_packed & 0xFFFF, ra = ex_packed >> 16;  // ascending exclusive ranks
+        for (int i = cb; i < ce; i++) {
+            if (v[i].key >= pivot) ps.gpos[rg++] = (uint16_t)i;
+            if (v[i].key <= pivot) { ps.lpos[NL - 1 - ra] = (uint16_t)i; ra++; }  // descending rank
+        }
+        ex.sync();
+        const int T = NG < NL ? NG : NL;
+        int cnt = 0;
+        for (int t = tid; t < T; t += nt) cnt += ps.gpos[t] < ps.lpos[t];
+        ex.excl_scan(cnt, ps.scan_tmp, &k);   // G[t] < L[t] is monotone in t: the count is the number of swaps
+        for (int t = tid; t < k; t += nt) {
+            const int a = ps.gpos[t], b = ps.lpos[t];
+            const SortItem x = v[a]; v[a] = v[b]; v[b] = x;
+        }
     }
-    if (tid == 0) ps.sc[0] = 0;
     ex.sync();
-    const int T = NG < NL ? NG : NL;
-    int cnt = 0;
-    for (int t = tid; t < T; t += nt) cnt += ps.gpos[t] < ps.lpos[t];
-    int k = 0;
-    ex.excl_scan(cnt, ps.scan_tmp, &k);   // G[t] < L[t] is monotone in t: the count is the number of swaps
-    for (int t = tid; t < k; t += nt) {
-        const int a = ps.gpos[t], b = ps.lpos[t];
-        const SortItem x = v[a]; v[a] = v[b]; v[b] = x;
-    }
     int cut = last;
     if (k < NG) cut = ps.gpos[k];
     if (k > 0 && (int)ps.lpos[k - 1] < cut) cut = ps.lpos[k - 1];
@@ -274,9 +291,9 @@ QT_HD int partition_par(Ex& ex, SortItem* v, int first, int last, ParScratch& ps
 }
 
 template <class Ex>
-QT_HD void lsort_par(Ex& ex, SortItem* v, int n, int* stack, ParScratch& ps) {
+QT_HD void lsort_par_partitions(Ex& ex, SortItem* v, int n, int* stack, ParScratch& ps) {
     if (n <= 0) return;
-    const int tid = ex.tid(), nt = ex.nthreads();
+    const int tid = ex.tid();
     int lg = 0;
     for (int t = n; t > 1; t >>= 1) lg++;
     int sp = 1;
@@ -314,7 +331,13 @@ QT_HD void lsort_par(Ex& ex, SortItem* v, int n, int* stack, ParScratch& ps) {
             last = cut;
         }
     }
-    // __final_insertion_sort == stable sort of the current arrangement
+}
+
+// __final_insertion_sort == stable sort of the arrangement the introsort loop left behind (rank counting); any
+// number of threads
+template <class Ex>
+QT_HD void final_stable_sort(Ex& ex, SortItem* v, int n, ParScratch& ps) {
+    const int tid = ex.tid(), nt = ex.nthreads();
     for (int i = tid; i < n; i += nt) {
         const uint32_t key = v[i].key;
         int rank = 0;
@@ -327,6 +350,12 @@ QT_HD void lsort_par(Ex& ex, SortItem* v, int n, int* stack, ParScratch& ps) {
     ex.sync();
     for (int i = tid; i < n; i += nt) v[i] = ps.tmp[i];
     ex.sync();
+}
+
+template <class Ex>
+QT_HD void lsort_par(Ex& ex, SortItem* v, int n, int* stack, ParScratch& ps) {
+    lsort_par_partitions(ex, v, n, stack, ps);
+    final_stable_sort(ex, v, n, ps);
 }
 
 // ---- the selection itself ----------------------------------------------------------------------------

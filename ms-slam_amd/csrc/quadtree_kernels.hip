@@ -20,6 +20,11 @@ struct DevEx {
         __device__ int tid() const { return threadIdx.x & 63; }
         __device__ int nthreads() const { return 64; }
         __device__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        __device__ int excl_count(bool p, int* total) {
+            const unsigned long long m = __ballot(p);
+            *total = __popcll(m);
+            return __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+        }
         __device__ int excl_scan(int v, int*, int* total) {
             const int lane = threadIdx.x & 63;
             int incl = v;
@@ -33,10 +38,12 @@ struct DevEx {
         }
     };
     __device__ void sort(qt::SortItem* items, int n, int* stack, qt::ParScratch& ps) {
-        if (threadIdx.x < 64) {
+        if (threadIdx.x < 64) {  // introsort loop: wave 0 (partitions are sequential, each one data-parallel)
             WaveEx wex;
-            qt::lsort_par(wex, items, n, stack, ps);
+            qt::lsort_par_partitions(wex, items, n, stack, ps);
         }
+        __syncthreads();
+        qt::final_stable_sort(*this, items, n, ps);  // rank counting: all threads
     }
     int dbg = 0, n_marks = 0;
     long long t_mark[48];
@@ -56,6 +63,7 @@ struct DevEx {
     __device__ int atomic_add(int* p, int v) { return atomicAdd(p, v); }
     __device__ void atomic_max(int* p, int v) { atomicMax(p, v); }
     __device__ void atomic_min(int* p, int v) { atomicMin(p, v); }
+    __device__ int excl_count(bool p, int* total) { int t = 0; const int r = excl_scan((int)p, nullptr, &t); *total = t; return r; }  // unused
     // block-wide exclusive prefix of v over threads (<= 16 waves); tmp = 16 ints of LDS
     __device__ int excl_scan(int v, int* tmp, int* total) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

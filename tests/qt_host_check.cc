@@ -22,6 +22,7 @@ struct HostEx {
     void atomic_max(int* p, int v) { if (v > *p) *p = v; }
     void atomic_min(int* p, int v) { if (v < *p) *p = v; }
     int excl_scan(int v, int*, int* total) { *total = v; return 0; }
+    int excl_count(bool p, int* total) { *total = p; return 0; }
     void sort(qt::SortItem* v, int n, int* stack, qt::ParScratch&) { qt::lsort(v, n, stack); }
 };
 
