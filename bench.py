@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU-pair group")
+    ap.add_argument("--pairs", type=int, default=128, help="stereo pairs per step per GPU-pair group")
     ap.add_argument("--cpu-pairs", type=int, default=24, help="stereo pairs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--isolated", action="store_true",
                     help="profiling aid: no sub-batch / blur overlap anywhere, so every kernel launch covers the whole "
@@ -222,11 +222,11 @@ def main():
         # committed rocprofv3 --pmc measurement of the same command (profiles/round1_pmc_summary.json, separate
         # FETCH_SIZE / WRITE_SIZE passes, per launch) — only quoted when the batch shape matches
         traffic = None
-        kname = {"fast": "fast_cells_kernel<true>", "pyramid": "pyr_resize_aligned_kernel", "blur": "gauss7_kernel<true>",
+        kname = {"fast": "fast_cells_kernel<true, GeoSmall>", "pyramid": "pyr_resize_aligned_kernel", "blur": "gauss7_kernel<true>",
                  "describe": "describe_kernel", "compact": "cand_gather_kernel"}[dom]
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_summary.json")))["kernels"][kname]
-            if B == 64 and world == 1:
+            if B == 128 and world == 1:
                 traffic = int((pm["FETCH_SIZE_KB"] + pm["WRITE_SIZE_KB"]) * 1024) * (7 if dom == "pyramid" else 1)
         except Exception:
             traffic = None
