@@ -225,6 +225,53 @@ int msorb_visibility_csr(int device, int n_window_kf, const int* kf_slot_begin, 
                          int* row_kind, int* row_owner, float* row_rhs, int cap_rows, int* col_idx, int cap_nnz,
                          int* nnz, float* obj_coef, int* n_max_obs);
 
+/* ------------------------------------------------------------------------------------------------
+ * Bag of words — DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>::transform(features, BowVector&,
+ * FeatureVector&, levelsup) (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1123-1191, descent :1218-1259) as
+ * called by Frame::ComputeBoW (src/Frame.cc:670-677) and KeyFrame::ComputeBoW with levelsup = 4.
+ * The vocabulary tree lives on the device (children of a node contiguous); the descent is one 16/32-lane
+ * group per descriptor, the two std::map containers are assembled per frame by a sort + run-length pass
+ * that repeats the reference's accumulation order (sequential double adds), so values are bit-identical.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct msorb_vocabulary msorb_vocabulary;
+
+/* Tree as loadFromTextFile (TemplatedVocabulary.h:1338-1423) builds it: n_nodes nodes, node 0 = root;
+ * for i >= 1: parent[i] (< i is not required), is_leaf[i] = the file's leaf flag (word ids are handed out to
+ * flagged nodes in node order), descriptors[i*32..], weights[i].  scoring / weighting = the file header's
+ * ScoringType / WeightingType (BowVector.h:39-56); ORBvoc.txt is k=10, L=6, L1_NORM(0), TF_IDF(0). */
+int msorb_vocabulary_create(int device, int k, int L, int scoring, int weighting, int n_nodes, const int* parent,
+                            const uint8_t* is_leaf, const uint8_t* descriptors, const double* weights,
+                            msorb_vocabulary** out);
+/* Reads the ORBvoc.txt text format (header "k L scoring weighting", then one line per node:
+ * "parent is_leaf b0 .. b31 weight").  Empty lines are skipped (the reference's `while(!f.eof())` loop turns a
+ * trailing newline into a phantom child of the root with an indeterminate descriptor; not reproduced). */
+int msorb_vocabulary_load_text(int device, const char* path, msorb_vocabulary** out);
+void msorb_vocabulary_destroy(msorb_vocabulary* v);
+int msorb_vocabulary_info(const msorb_vocabulary* v, int* k, int* L, int* n_nodes, int* n_words);
+
+/* transform() for n_frames frames whose descriptors are DEVICE resident (frame i: d_descriptors +
+ * i*desc_stride*32, h_counts[i] rows — exactly msorb_extract_batch's outputs).  Device outputs, `stride` entries
+ * per frame (stride >= max count, <= 8192): BowVector as ascending (d_bow_word, d_bow_value) with d_n_bow[i]
+ * entries; FeatureVector as ascending node ids d_fv_node with CSR d_fv_begin (stride+1 per frame) into d_fv_feat
+ * (feature indices, ascending inside a node) and d_n_fv[i] nodes.  elapsed_ms (may be NULL): kernel time. */
+int msorb_bow_transform_batch(msorb_vocabulary* v, const uint8_t* d_descriptors, const int* h_counts, int n_frames,
+                              int desc_stride, int levelsup, int stride, int* d_bow_word, double* d_bow_value,
+                              int* d_n_bow, int* d_fv_node, int* d_fv_begin, int* d_fv_feat, int* d_n_fv,
+                              float* elapsed_ms);
+/* One frame, HOST arrays in and out (capacity n entries each, fv_begin n+1).  feat_word / feat_node /
+ * feat_weight (may be NULL): per-feature result of the descent (:1218-1259). */
+int msorb_bow_transform(msorb_vocabulary* v, const uint8_t* descriptors, int n, int levelsup, int* bow_word,
+                        double* bow_value, int* n_bow, int* fv_node, int* fv_begin, int* fv_feat, int* n_fv,
+                        int* feat_word, int* feat_node, double* feat_weight);
+
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:351-429) batched over map points: point p owns the
+ * descriptors [obs_begin[p], obs_begin[p+1]) of `descriptors` (32 B rows, in the order the reference collects
+ * vDescriptors).  best_idx[p] = position inside the point's list of the descriptor with the least median
+ * distance to the others (first minimum; -1 for a point without descriptors), best_median[p] (may be NULL) that
+ * median.  Host arrays; elapsed_ms (may be NULL): kernel time. */
+int msorb_distinctive_descriptors(int device, const uint8_t* descriptors, const int* obs_begin, int n_points,
+                                  int* best_idx, int* best_median, float* elapsed_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -432,3 +432,98 @@ def window_top4(frame, x, y, r, min_level, max_level, query_desc, ur=None, skip_
                                _np_ptr(mn), _np_ptr(mx), None if sk is None else _np_ptr(sk), _np_ptr(qd),
                                None if oc is None else _np_ptr(oc), _np_ptr(bi), _np_ptr(bd)), "msorb_window_top4")
     return bi, bd
+
+
+EXPORTS = EXPORTS + ("msorb_vocabulary_create", "msorb_vocabulary_load_text", "msorb_vocabulary_destroy",
+                     "msorb_vocabulary_info", "msorb_bow_transform_batch", "msorb_bow_transform",
+                     "msorb_distinctive_descriptors")
+
+
+class Vocabulary:
+    """DBoW2 ORB vocabulary tree on the device (msorb_vocabulary_*): transform() = TemplatedVocabulary::transform
+    (features, BowVector, FeatureVector, levelsup) as Frame::ComputeBoW calls it (Frame.cc:670-677)."""
+
+    def __init__(self, k=None, L=None, scoring=0, weighting=0, parent=None, is_leaf=None, descriptors=None, weights=None,
+                 path=None, device=0):
+        lb = lib()
+        lb.msorb_vocabulary_create.argtypes = [C.c_int] * 6 + [C.c_void_p] * 4 + [C.POINTER(C.c_void_p)]
+        lb.msorb_vocabulary_load_text.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
+        lb.msorb_vocabulary_destroy.argtypes = [C.c_void_p]
+        lb.msorb_vocabulary_destroy.restype = None
+        lb.msorb_vocabulary_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+        lb.msorb_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 10
+        lb.msorb_bow_transform_batch.argtypes = ([C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 +
+                                                 [C.c_void_p] * 8)
+        self.h = None
+        h = C.c_void_p()
+        if path is not None:
+            _check(lb.msorb_vocabulary_load_text(device, str(path).encode(), C.byref(h)), "msorb_vocabulary_load_text")
+        else:
+            par, lf = _c(parent, np.int32), _c(is_leaf, np.uint8)
+            ds, ws = _c(descriptors, np.uint8), _c(weights, np.float64)
+            _check(lb.msorb_vocabulary_create(device, k, L, scoring, weighting, len(par), _np_ptr(par), _np_ptr(lf),
+                                              _np_ptr(ds), _np_ptr(ws), C.byref(h)), "msorb_vocabulary_create")
+        self.h = h
+        self.device = device
+        a = [C.c_int() for _ in range(4)]
+        lb.msorb_vocabulary_info(h, *[C.byref(x) for x in a])
+        self.k, self.L, self.n_nodes, self.n_words = [x.value for x in a]
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().msorb_vocabulary_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def transform(self, descriptors, levelsup=4):
+        """One frame, host arrays. -> dict(bow_word, bow_value, fv_node, fv_begin, fv_feat, feat_word, feat_node,
+        feat_weight)"""
+        d = _c(descriptors, np.uint8).reshape(-1, 32)
+        n = len(d)
+        cap = max(n, 1)
+        bw, bv = np.zeros(cap, np.int32), np.zeros(cap, np.float64)
+        fn, fb, ff = np.zeros(cap, np.int32), np.zeros(cap + 1, np.int32), np.zeros(cap, np.int32)
+        fw, fnode, fwt = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.float64)
+        nb, nf = C.c_int(), C.c_int()
+        _check(lib().msorb_bow_transform(self.h, _np_ptr(d) if n else None, n, levelsup, _np_ptr(bw), _np_ptr(bv),
+                                         C.addressof(nb), _np_ptr(fn), _np_ptr(fb), _np_ptr(ff), C.addressof(nf),
+                                         _np_ptr(fw), _np_ptr(fnode), _np_ptr(fwt)), "msorb_bow_transform")
+        nb, nf = nb.value, nf.value
+        return dict(bow_word=bw[:nb], bow_value=bv[:nb], fv_node=fn[:nf], fv_begin=fb[:nf + 1], fv_feat=ff[:fb[nf]],
+                    feat_word=fw[:n], feat_node=fnode[:n], feat_weight=fwt[:n])
+
+    def transform_batch(self, d_desc, counts, levelsup=4):
+        """Device-resident batch: d_desc torch.uint8 [F, stride, 32] (msorb_extract_batch's descriptors), counts
+        host int array [F].  -> dict of torch tensors (bow_word [F,S], bow_value [F,S] f64, n_bow [F], fv_node [F,S],
+        fv_begin [F,S+1], fv_feat [F,S], n_fv [F]) and elapsed_ms (kernels only)."""
+        import torch
+        F, S, _ = d_desc.shape
+        cnt = _c(counts, np.int32)
+        dev = d_desc.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        out = dict(bow_word=torch.empty((F, S), **i32), bow_value=torch.empty((F, S), dtype=torch.float64, device=dev),
+                   n_bow=torch.empty(F, **i32), fv_node=torch.empty((F, S), **i32), fv_begin=torch.empty((F, S + 1), **i32),
+                   fv_feat=torch.empty((F, S), **i32), n_fv=torch.empty(F, **i32))
+        ms = C.c_float()
+        _check(lib().msorb_bow_transform_batch(self.h, d_desc.data_ptr(), _np_ptr(cnt), F, S, levelsup, S,
+                                               out["bow_word"].data_ptr(), out["bow_value"].data_ptr(),
+                                               out["n_bow"].data_ptr(), out["fv_node"].data_ptr(),
+                                               out["fv_begin"].data_ptr(), out["fv_feat"].data_ptr(),
+                                               out["n_fv"].data_ptr(), C.addressof(ms)), "msorb_bow_transform_batch")
+        out["elapsed_ms"] = ms.value
+        return out
+
+
+def distinctive_descriptors(descriptors, obs_begin, device=0):
+    """msorb_distinctive_descriptors -> (best_idx, best_median, kernel_ms)"""
+    lb = lib()
+    lb.msorb_distinctive_descriptors.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 3
+    d = _c(descriptors, np.uint8).reshape(-1, 32)
+    ob = _c(obs_begin, np.int32)
+    n = len(ob) - 1
+    bi, bm = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    ms = C.c_float()
+    _check(lb.msorb_distinctive_descriptors(device, _np_ptr(d) if len(d) else None, _np_ptr(ob), n, _np_ptr(bi),
+                                            _np_ptr(bm), C.addressof(ms)), "msorb_distinctive_descriptors")
+    return bi[:n], bm[:n], ms.value

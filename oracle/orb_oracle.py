@@ -277,3 +277,49 @@ def visibility_csr(kf_slot_begin, slot_point, slot_cell, point_nobs, obs_begin, 
     return dict(n_cols=nc, col_point=col_point[:nc], obj_coef=obj[:nc], n_rows=nr, row_begin=row_begin[:nr + 1],
                 row_kind=row_kind[:nr], row_owner=row_owner[:nr], row_rhs=row_rhs[:nr], col_idx=col_idx[:nz],
                 n_max_obs=nmax.value)
+
+
+class OracleVocabulary:
+    """oracle/bow_oracle.cc — DBoW2 tree + transform() on the reference's own containers."""
+
+    def __init__(self, k, L, scoring, weighting, parent, is_leaf, descriptors, weights):
+        Lb = lib()
+        Lb.orc_vocab_create.restype = C.c_void_p
+        Lb.orc_vocab_create.argtypes = [C.c_int] * 5 + [C.c_void_p] * 4
+        Lb.orc_vocab_destroy.argtypes = [C.c_void_p]
+        Lb.orc_vocab_destroy.restype = None
+        Lb.orc_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 10
+        par, lf = _c(parent, np.int32), _c(is_leaf, np.uint8)
+        ds, ws = _c(descriptors, np.uint8), _c(weights, np.float64)
+        self.h = Lb.orc_vocab_create(k, L, scoring, weighting, len(par), _ptr(par), _ptr(lf), _ptr(ds), _ptr(ws))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_vocab_destroy(self.h)
+            self.h = None
+
+    def transform(self, descriptors, levelsup=4):
+        d = _c(descriptors, np.uint8).reshape(-1, 32)
+        n = len(d)
+        cap = max(n, 1)
+        bw, bv = np.zeros(cap, np.int32), np.zeros(cap, np.float64)
+        fn, fb, ff = np.zeros(cap, np.int32), np.zeros(cap + 1, np.int32), np.zeros(cap, np.int32)
+        fw, fnode, fwt = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.float64)
+        nb, nf = C.c_int(), C.c_int()
+        lib().orc_bow_transform(self.h, _ptr(d), n, levelsup, _ptr(bw), _ptr(bv), C.addressof(nb), _ptr(fn), _ptr(fb),
+                                _ptr(ff), C.addressof(nf), _ptr(fw), _ptr(fnode), _ptr(fwt))
+        nb, nf = nb.value, nf.value
+        return dict(bow_word=bw[:nb], bow_value=bv[:nb], fv_node=fn[:nf], fv_begin=fb[:nf + 1], fv_feat=ff[:fb[nf]],
+                    feat_word=fw[:n], feat_node=fnode[:n], feat_weight=fwt[:n])
+
+
+def distinctive_descriptors(descriptors, obs_begin):
+    Lb = lib()
+    Lb.orc_distinctive_descriptors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    Lb.orc_distinctive_descriptors.restype = None
+    d = _c(descriptors, np.uint8).reshape(-1, 32)
+    ob = _c(obs_begin, np.int32)
+    n = len(ob) - 1
+    bi, bm = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    Lb.orc_distinctive_descriptors(_ptr(d), _ptr(ob), n, _ptr(bi), _ptr(bm))
+    return bi[:n], bm[:n]
