@@ -272,6 +272,34 @@ int msorb_bow_transform(msorb_vocabulary* v, const uint8_t* descriptors, int n, 
 int msorb_distinctive_descriptors(int device, const uint8_t* descriptors, const int* obs_begin, int n_points,
                                   int* best_idx, int* best_median, float* elapsed_ms);
 
+/* ------------------------------------------------------------------------------------------------
+ * Frame::isInFrustum (src/Frame.cc:512-571, pinhole / Nleft == -1) over n map points — the pre-pass of
+ * Tracking::SearchLocalPoints (src/Tracking.cc:3343-3361); its outputs are exactly the per-point arrays
+ * msorb_search_by_projection_mps takes.  The caller skips nothing: points the reference does not visit
+ * (mnLastFrameSeen == frame id, isBad()) are simply not passed.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct msorb_frustum {
+    float Rcw[9];                       /* mRcw, row major */
+    float tcw[3];                       /* mtcw */
+    float Ow[3];                        /* mOw (camera centre) */
+    float fx, fy, cx, cy;               /* Pinhole mvParameters[0..3] */
+    float min_x, max_x, min_y, max_y;   /* mnMinX, mnMaxX, mnMinY, mnMaxY */
+    float mbf;                          /* baseline * fx */
+    float log_scale_factor;             /* mfLogScaleFactor */
+    int n_scale_levels;                 /* mnScaleLevels */
+} msorb_frustum;
+
+/* Inputs: pos_w / normal = GetWorldPos() / GetNormal() (3 floats per point), max_distance / min_distance =
+ * mfMaxDistance / mfMinDistance (the 1.2 / 0.8 invariance factors are applied inside, MapPoint.cc:528-538).
+ * Outputs (host, n entries): track_in_view = the return value / mbTrackInView; proj_x, proj_y = mTrackProjX/Y
+ * (-1 when the point is behind the camera or outside the image, the projection otherwise, like :515-540);
+ * proj_xr, track_depth, scale_level (PredictScale, MapPoint.cc:557-572), view_cos — written when in view, 0
+ * otherwise (the reference leaves stale values there that no caller reads).  elapsed_ms may be NULL. */
+int msorb_is_in_frustum(int device, const msorb_frustum* f, float viewing_cos_limit, int n, const float* pos_w,
+                        const float* normal, const float* max_distance, const float* min_distance,
+                        uint8_t* track_in_view, float* proj_x, float* proj_y, float* proj_xr, float* track_depth,
+                        int* scale_level, float* view_cos, float* elapsed_ms);
+
 #ifdef __cplusplus
 }
 #endif

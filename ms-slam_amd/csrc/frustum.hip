@@ -1,0 +1,149 @@
+// Frame::isInFrustum (src/Frame.cc:512-571, pinhole / Nleft == -1 branch) over a batch of map points — the
+// pre-pass of Tracking::SearchLocalPoints (src/Tracking.cc:3343-3361) that fills the per-point scratch
+// (mbTrackInView, mTrackProjX/Y/XR, mTrackDepth, mnTrackScaleLevel, mTrackViewCos) msorb_search_by_projection_mps
+// consumes.  One thread per point, SoA in / SoA out: a pure stream (32 B in, 25 B out per point).
+// Float expressions are written with explicit fmaf / __fdiv_rn and sqrtf (correctly rounded in hipcc's default mode;
+// __fsqrt_rn is the bare 1-ulp v_sqrt_f32 and is NOT used) in the association
+// the reference compiles to (see oracle/frustum_oracle.cc header); log() is glibc's logf restated
+// (logf_restated.h).  The library is built with -ffp-contract=off, nothing else is fused.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/msorb.h"
+#include "logf_restated.h"
+
+namespace msorb {
+void set_last_error(const std::string& s);
+}
+using msorb::set_last_error;
+
+namespace {
+
+__device__ __forceinline__ float dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
+    return __fmaf_rn(a0, b0, __fmaf_rn(a1, b1, __fmul_rn(a2, b2)));
+}
+__device__ __forceinline__ int x86_float_to_int(float v) {
+    if (!(v > -2147483904.0f && v < 2147483648.0f)) return INT_MIN;
+    return (int)v;
+}
+
+__global__ __launch_bounds__(256) void frustum_kernel(msorb_frustum F, float cos_limit, int n,
+                                                      const float* __restrict__ pos_w, const float* __restrict__ normal,
+                                                      const float* __restrict__ max_distance,
+                                                      const float* __restrict__ min_distance,
+                                                      uint8_t* __restrict__ track_in_view, float* __restrict__ proj_x,
+                                                      float* __restrict__ proj_y, float* __restrict__ proj_xr,
+                                                      float* __restrict__ track_depth, int* __restrict__ scale_level,
+                                                      float* __restrict__ view_cos) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t in_view = 0;
+    float px = -1.0f, py = -1.0f, pxr = 0.0f, depth = 0.0f, vc = 0.0f;
+    int level = 0;
+    const float P0 = pos_w[3 * i], P1 = pos_w[3 * i + 1], P2 = pos_w[3 * i + 2];
+    const float Pc0 = __fadd_rn(dot3(F.Rcw[0], P0, F.Rcw[1], P1, F.Rcw[2], P2), F.tcw[0]);
+    const float Pc1 = __fadd_rn(dot3(F.Rcw[3], P0, F.Rcw[4], P1, F.Rcw[5], P2), F.tcw[1]);
+    const float PcZ = __fadd_rn(dot3(F.Rcw[6], P0, F.Rcw[7], P1, F.Rcw[8], P2), F.tcw[2]);
+    do {
+        if (PcZ < 0.0f) break;
+        const float u = __fadd_rn(__fdiv_rn(__fmul_rn(F.fx, Pc0), PcZ), F.cx);
+        const float v = __fadd_rn(__fdiv_rn(__fmul_rn(F.fy, Pc1), PcZ), F.cy);
+        if (u < F.min_x || u > F.max_x) break;
+        if (v < F.min_y || v > F.max_y) break;
+        px = u;
+        py = v;
+        const float maxD = __fmul_rn(1.2f, max_distance[i]);
+        const float minD = __fmul_rn(0.8f, min_distance[i]);
+        const float PO0 = __fsub_rn(P0, F.Ow[0]), PO1 = __fsub_rn(P1, F.Ow[1]), PO2 = __fsub_rn(P2, F.Ow[2]);
+        const float dist = sqrtf(dot3(PO0, PO0, PO1, PO1, PO2, PO2));
+        if (dist < minD || dist > maxD) break;
+        const float viewCos = __fdiv_rn(dot3(PO0, normal[3 * i], PO1, normal[3 * i + 1], PO2, normal[3 * i + 2]), dist);
+        if (viewCos < cos_limit) break;
+        const float ratio = __fdiv_rn(max_distance[i], dist);
+        int nScale = x86_float_to_int(ceilf(__fdiv_rn(msorb::glibc_logf(ratio), F.log_scale_factor)));
+        if (nScale < 0) nScale = 0;
+        else if (nScale >= F.n_scale_levels) nScale = F.n_scale_levels - 1;
+        in_view = 1;
+        pxr = __fmaf_rn(-F.mbf, __fdiv_rn(1.0f, PcZ), u);
+        depth = sqrtf(dot3(Pc0, Pc0, Pc1, Pc1, PcZ, PcZ));
+        level = nScale;
+        vc = viewCos;
+    } while (0);
+    track_in_view[i] = in_view;
+    proj_x[i] = px;
+    proj_y[i] = py;
+    proj_xr[i] = pxr;
+    track_depth[i] = depth;
+    scale_level[i] = level;
+    view_cos[i] = vc;
+}
+
+}  // namespace
+
+extern "C" int msorb_is_in_frustum(int device, const msorb_frustum* f, float viewing_cos_limit, int n, const float* pos_w,
+                                   const float* normal, const float* max_distance, const float* min_distance,
+                                   uint8_t* track_in_view, float* proj_x, float* proj_y, float* proj_xr,
+                                   float* track_depth, int* scale_level, float* view_cos, float* elapsed_ms) {
+    if (elapsed_ms) *elapsed_ms = 0;
+    if (!f || n < 0 || f->n_scale_levels < 1 ||
+        (n > 0 && (!pos_w || !normal || !max_distance || !min_distance || !track_in_view || !proj_x || !proj_y ||
+                   !proj_xr || !track_depth || !scale_level || !view_cos)))
+        return MSORB_E_INVALID;
+    if (n == 0) return MSORB_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        set_last_error("no usable HIP device (libmsorb has no CPU fallback)");
+        return MSORB_E_NO_DEVICE;
+    }
+    // one allocation: inputs (8 floats / point) then outputs (6 x 4 B + 1 B / point)
+    const size_t N = (size_t)n;
+    const size_t in_bytes = N * 8 * sizeof(float), out_bytes = N * 6 * 4 + N;
+    char* d = nullptr;
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipMalloc((void**)&d, in_bytes + out_bytes);
+    float* d_pos = (float*)d;
+    float* d_nrm = d_pos + 3 * N;
+    float* d_max = d_nrm + 3 * N;
+    float* d_min = d_max + N;
+    float* d_px = d_min + N;
+    float* d_py = d_px + N;
+    float* d_pxr = d_py + N;
+    float* d_depth = d_pxr + N;
+    int* d_level = (int*)(d_depth + N);
+    float* d_vc = (float*)(d_level + N);
+    uint8_t* d_in = (uint8_t*)(d_vc + N);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pos, pos_w, N * 12, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_nrm, normal, N * 12, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_max, max_distance, N * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_min, min_distance, N * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipEventRecord(e0, s);
+    if (e == hipSuccess)
+        hipLaunchKernelGGL(frustum_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, *f, viewing_cos_limit, n, d_pos,
+                           d_nrm, d_max, d_min, d_in, d_px, d_py, d_pxr, d_depth, d_level, d_vc);
+    if (e == hipSuccess) e = hipEventRecord(e1, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(proj_x, d_px, N * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(proj_y, d_py, N * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(proj_xr, d_pxr, N * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(track_depth, d_depth, N * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(scale_level, d_level, N * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(view_cos, d_vc, N * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(track_in_view, d_in, N, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess && elapsed_ms) e = hipEventElapsedTime(elapsed_ms, e0, e1);
+    if (d) (void)hipFree(d);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (s) (void)hipStreamDestroy(s);
+    if (e != hipSuccess) {
+        set_last_error(std::string("is_in_frustum: ") + hipGetErrorString(e));
+        return MSORB_E_HIP;
+    }
+    return MSORB_OK;
+}

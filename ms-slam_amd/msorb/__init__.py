@@ -527,3 +527,43 @@ def distinctive_descriptors(descriptors, obs_begin, device=0):
     _check(lb.msorb_distinctive_descriptors(device, _np_ptr(d) if len(d) else None, _np_ptr(ob), n, _np_ptr(bi),
                                             _np_ptr(bm), C.addressof(ms)), "msorb_distinctive_descriptors")
     return bi[:n], bm[:n], ms.value
+
+
+EXPORTS = EXPORTS + ("msorb_is_in_frustum",)
+
+
+class Frustum(C.Structure):
+    """msorb_frustum (include/msorb.h): the Frame members isInFrustum reads."""
+    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float),
+                ("max_y", C.c_float), ("mbf", C.c_float), ("log_scale_factor", C.c_float), ("n_scale_levels", C.c_int)]
+
+    @classmethod
+    def make(cls, Rcw, tcw, Ow, fx, fy, cx, cy, bounds, mbf, log_scale_factor, n_scale_levels):
+        f = cls()
+        f.Rcw[:] = [float(x) for x in np.asarray(Rcw, np.float32).reshape(9)]
+        f.tcw[:] = [float(x) for x in np.asarray(tcw, np.float32).reshape(3)]
+        f.Ow[:] = [float(x) for x in np.asarray(Ow, np.float32).reshape(3)]
+        f.fx, f.fy, f.cx, f.cy = fx, fy, cx, cy
+        f.min_x, f.max_x, f.min_y, f.max_y = bounds
+        f.mbf, f.log_scale_factor, f.n_scale_levels = mbf, log_scale_factor, n_scale_levels
+        return f
+
+
+def is_in_frustum(frustum, pos_w, normal, max_distance, min_distance, viewing_cos_limit=0.5, device=0):
+    """msorb_is_in_frustum -> dict(track_in_view, proj_x, proj_y, proj_xr, track_depth, level, view_cos, kernel_ms)"""
+    lb = lib()
+    lb.msorb_is_in_frustum.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_int] + [C.c_void_p] * 12
+    P, Nn = _c(pos_w, np.float32).reshape(-1, 3), _c(normal, np.float32).reshape(-1, 3)
+    mx, mn = _c(max_distance, np.float32), _c(min_distance, np.float32)
+    n = len(P)
+    cap = max(n, 1)
+    inv = np.zeros(cap, np.uint8)
+    px, py, pxr, dep, vc = [np.zeros(cap, np.float32) for _ in range(5)]
+    lvl = np.zeros(cap, np.int32)
+    ms = C.c_float()
+    _check(lb.msorb_is_in_frustum(device, C.addressof(frustum), viewing_cos_limit, n, _np_ptr(P), _np_ptr(Nn), _np_ptr(mx),
+                                  _np_ptr(mn), _np_ptr(inv), _np_ptr(px), _np_ptr(py), _np_ptr(pxr), _np_ptr(dep),
+                                  _np_ptr(lvl), _np_ptr(vc), C.addressof(ms)), "msorb_is_in_frustum")
+    return dict(track_in_view=inv[:n], proj_x=px[:n], proj_y=py[:n], proj_xr=pxr[:n], track_depth=dep[:n], level=lvl[:n],
+                view_cos=vc[:n], kernel_ms=ms.value)

@@ -323,3 +323,21 @@ def distinctive_descriptors(descriptors, obs_begin):
     bi, bm = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
     Lb.orc_distinctive_descriptors(_ptr(d), _ptr(ob), n, _ptr(bi), _ptr(bm))
     return bi[:n], bm[:n]
+
+
+def is_in_frustum(frustum, pos_w, normal, max_distance, min_distance, viewing_cos_limit=0.5):
+    """oracle/frustum_oracle.cc; `frustum` is any ctypes struct with msorb_frustum's layout (msorb.Frustum)."""
+    Lb = lib()
+    Lb.orc_is_in_frustum.argtypes = [C.c_void_p, C.c_float, C.c_int] + [C.c_void_p] * 11
+    Lb.orc_is_in_frustum.restype = None
+    P, Nn = _c(pos_w, np.float32).reshape(-1, 3), _c(normal, np.float32).reshape(-1, 3)
+    mx, mn = _c(max_distance, np.float32), _c(min_distance, np.float32)
+    n = len(P)
+    cap = max(n, 1)
+    inv = np.zeros(cap, np.uint8)
+    px, py, pxr, dep, vc = [np.zeros(cap, np.float32) for _ in range(5)]
+    lvl = np.zeros(cap, np.int32)
+    Lb.orc_is_in_frustum(C.addressof(frustum), viewing_cos_limit, n, _ptr(P), _ptr(Nn), _ptr(mx), _ptr(mn), _ptr(inv),
+                         _ptr(px), _ptr(py), _ptr(pxr), _ptr(dep), _ptr(lvl), _ptr(vc))
+    return dict(track_in_view=inv[:n], proj_x=px[:n], proj_y=py[:n], proj_xr=pxr[:n], track_depth=dep[:n], level=lvl[:n],
+                view_cos=vc[:n])
