@@ -148,9 +148,10 @@ struct PinBuf {
 }  // namespace
 
 constexpr int kMaxGroups = 4;
-struct StreamGroup {  // one sub-batch pipeline: main stream, blur stream, sync + timing events
-    hipStream_t s = nullptr, s2 = nullptr;
-    hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
+struct StreamGroup {  // one sub-batch pipeline: main stream (group 0 uses the handle's own), sync + timing events
+    hipStream_t s = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_fast = nullptr;
     hipEvent_t pe[10] = {};
     bool ready = false;
 };
@@ -334,10 +335,14 @@ int fetch_candidates(msorb_extractor* h, int n_images) {
 int ensure_group(msorb_extractor* h, int gi) {
     StreamGroup& G = h->grp[gi];
     if (G.ready) return MSORB_OK;
-    HIPCHK(hipStreamCreateWithFlags(&G.s, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&G.s2, hipStreamNonBlocking));
+    // The GPU exposes 4 hardware queues per process and HIP deals streams onto them; streams that share a queue
+    // serialise.  Keep the number of live streams minimal: group 0 runs on the handle's stream, every group's blur on
+    // the one auxiliary stream, only groups >= 1 get a stream of their own (2 groups -> 3 streams + the null stream).
+    if (gi == 0) G.s = h->stream;
+    else { HIPCHK(hipStreamCreateWithFlags(&G.s, hipStreamNonBlocking)); G.own_stream = true; }
     HIPCHK(hipEventCreateWithFlags(&G.ev_pyr, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&G.ev_blur, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&G.ev_fast, hipEventDisableTiming));
     for (auto& e : G.pe) HIPCHK(hipEventCreate(&e));
     G.ready = true;
     return MSORB_OK;
@@ -361,6 +366,8 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
     h->h_pyr_valid = false;
     h->compact_on_host = false;
     h->last_groups = ng;
+    static const bool stagger_env = getenv("MSORB_STAGGER") != nullptr;  // measured: no gain (2.648 vs 2.653 ms), off by default
+    const bool stagger = stagger_env && ng > 1;
     // the new call must not start before the handle's own stream has drained (H2D of level 0 in msorb_extract)
     HIPCHK(hipStreamSynchronize(h->stream));
     int first = 0;
@@ -383,18 +390,22 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
             launch_pyr_resize(pyr.lv[l - 1], pyr.lv[l], pyr_base + g.lv[l].plane_off, h->d_taps.p + h->tap_x_off[l],
                               h->d_taps.p + h->tap_y_off[l], n, s);
         mark(1, s);
-        hipStream_t sb = h->overlap_blur ? G.s2 : s;
+        hipStream_t sb = h->overlap_blur ? h->copy_stream : s;
         if (h->overlap_blur) {
             HIPCHK(hipEventRecord(G.ev_pyr, s));
-            HIPCHK(hipStreamWaitEvent(G.s2, G.ev_pyr, 0));
+            HIPCHK(hipStreamWaitEvent(sb, G.ev_pyr, 0));
         }
         mark(7, sb);
         launch_gauss7(pyr, blur, n, sb);
         mark(8, sb);
-        if (h->overlap_blur) HIPCHK(hipEventRecord(G.ev_blur, G.s2));
+        if (h->overlap_blur) HIPCHK(hipEventRecord(G.ev_blur, sb));
+        // optional (MSORB_STAGGER): run the sub-batches' FAST kernels one after the other, so that the memory- and
+        // latency-bound stages of one sub-batch sit beside another one's FAST instead of two FAST kernels in lock-step
+        if (stagger && gi > 0) HIPCHK(hipStreamWaitEvent(s, h->grp[gi - 1].ev_fast, 0));
         launch_fast_cells(pyr, h->d_cells.p, ncells, h->P.ini_th, h->P.min_th, g.slots_per_image, h->d_slots.p + cslot,
                           h->d_cell_count.p + (size_t)first * ncells, n, h->small_cells, s);
         mark(2, s);
+        if (stagger) HIPCHK(hipEventRecord(G.ev_fast, s));
         launch_cand_compact(h->d_cells.p, ncells, h->d_level_cell_begin.p, nl, g.slots_per_image, h->d_slots.p + cslot,
                             h->d_cell_count.p + (size_t)first * ncells, h->d_cell_off.p + (size_t)first * ncells,
                             h->d_level_count.p + (size_t)first * nl, h->d_img_total.p + first, img_base,
@@ -664,10 +675,10 @@ void msorb_extractor_destroy(msorb_extractor* h) {
     h->h_sel.release(); h->h_pyr.release(); h->h_img_pin.release(); h->h_out_pin.release();
     for (auto& G : h->grp) {
         if (!G.ready) continue;
-        (void)hipStreamSynchronize(G.s); (void)hipStreamSynchronize(G.s2);
+        (void)hipStreamSynchronize(G.s);
         for (auto& e : G.pe) if (e) (void)hipEventDestroy(e);
-        (void)hipEventDestroy(G.ev_pyr); (void)hipEventDestroy(G.ev_blur);
-        (void)hipStreamDestroy(G.s); (void)hipStreamDestroy(G.s2);
+        (void)hipEventDestroy(G.ev_pyr); (void)hipEventDestroy(G.ev_blur); (void)hipEventDestroy(G.ev_fast);
+        if (G.own_stream) (void)hipStreamDestroy(G.s);
     }
     for (auto& e : h->pe) if (e) (void)hipEventDestroy(e);
     if (h->ev_compact) (void)hipEventDestroy(h->ev_compact);

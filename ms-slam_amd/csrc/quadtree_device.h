@@ -445,12 +445,28 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
             const int p = tid + k * nt;
             if (p < n) body(p, cpt[k], clab[k]);
         }
-        for (int p = tid + PC * nt; p < n; p += nt) {
-            const Pt q = pts[p];
-            uint16_t l = label[p];
-            const uint16_t l0 = l;
-            body(p, q, l);
-            if (l != l0) label[p] = l;
+        // four candidates in flight per thread: the loads of a batch are issued together, so the pass pays the global
+        // latency once per four points instead of once per point (the per-point bodies hold LDS atomics, which keep
+        // the compiler from overlapping iterations on its own)
+        constexpr int kBatch = 4;
+        for (int p0 = tid + PC * nt; p0 < n; p0 += kBatch * nt) {
+            Pt q[kBatch];
+            uint16_t l[kBatch], l0[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) {
+                const int p = p0 + u * nt;
+                const int pc = p < n ? p : p0;
+                q[u] = pts[pc];
+                l0[u] = l[u] = label[pc];
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) {
+                const int p = p0 + u * nt;
+                if (p < n) {
+                    body(p, q[u], l[u]);
+                    if (l[u] != l0[u]) label[p] = l[u];
+                }
+            }
         }
     };
 

@@ -10,7 +10,7 @@
 
 namespace msorb {
 
-constexpr int kQtThreads = 512;
+constexpr int kQtThreads = 256;  // 256 beats 512 (0.39 vs 0.47 ms per 256 images): fewer idle waves waiting at barriers
 constexpr int kQtPointsPerThread = 0;  // register-resident candidates per thread: measured slower (VGPR pressure halves the resident workgroups)
 
 struct DevEx {
@@ -88,7 +88,7 @@ struct DevEx {
     }
 };
 
-__global__ __launch_bounds__(kQtThreads) void quadtree_select_kernel(QtLevels lv, const Cand16* __restrict__ compact,
+__global__ __launch_bounds__(1024) void quadtree_select_kernel(QtLevels lv, const Cand16* __restrict__ compact,
                                                               const int* __restrict__ img_base,
                                                               const int* __restrict__ level_count, uint16_t* __restrict__ label,
                                                               int* __restrict__ sel_pt /* [img][sel_stride] candidate idx */,
@@ -178,7 +178,12 @@ void launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_b
     for (int l = 0; l < lv.nlevels; l++) { maxN = max(maxN, lv.quota[l]); max_ini = max(max_ini, lv.n_ini[l]); }
     const size_t lds = qt::workspace_bytes(maxN, max_ini);
     static const int dbg = getenv("MSORB_QT_DEBUG") ? atoi(getenv("MSORB_QT_DEBUG")) : 0;  // profiling only
-    hipLaunchKernelGGL(quadtree_select_kernel, dim3(n_images, lv.nlevels), dim3(kQtThreads), lds, s, lv, compact, img_base,
+    // Workgroup size by batch size: the generations are chains of dependent LDS round trips, hidden only by other
+    // waves.  A big batch has other workgroups on the CU for that (256 threads: least barrier idling, best
+    // throughput); a frame or two has nothing else, so the instance itself brings the waves (1024 threads).
+    static const int qt_env = getenv("MSORB_QT_THREADS") ? atoi(getenv("MSORB_QT_THREADS")) : 0;  // tuning only
+    const int qt_threads = qt_env ? qt_env : n_images <= 4 ? 1024 : n_images <= 16 ? 512 : kQtThreads;
+    hipLaunchKernelGGL(quadtree_select_kernel, dim3(n_images, lv.nlevels), dim3(qt_threads), lds, s, lv, compact, img_base,
                        level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg);
     hipLaunchKernelGGL(quadtree_layout_kernel, dim3(n_images), dim3(256), 0, s, lv, compact, img_base, level_count, sel_pt,
                        sel_n, sel_stride, scales, lap0, lap1, capacity, sel, sel_count, mono);
