@@ -693,23 +693,17 @@ __global__ __launch_bounds__(64) void gauss7_edge_kernel(PyramidView src, Pyrami
 // ------------------------------------------------------------------------------------------------
 struct PatchTables {
     int8_t pattern[256 * 4];  // (x0,y0,x1,y1) per pair
-    int8_t pu[768], pv[768];  // the 749 (u,v) offsets of the circular patch, padded
+    int8_t umax[16];          // half-width of the circular patch per |v| (ORBextractor.cc:447-468)
 };
 __constant__ PatchTables c_tab;
 
 void upload_patch_tables(const int8_t* pattern, const int* umax, hipStream_t stream) {
     PatchTables t;
     for (int i = 0; i < 1024; i++) t.pattern[i] = pattern[i];
-    int n = 0;
-    for (int v = -kHalfPatch; v <= kHalfPatch; v++) {
-        const int d = umax[v < 0 ? -v : v];
-        for (int u = -d; u <= d; u++) { t.pu[n] = (int8_t)u; t.pv[n] = (int8_t)v; n++; }
-    }
-    for (; n < 768; n++) { t.pu[n] = 0; t.pv[n] = 0; }
+    for (int v = 0; v <= kHalfPatch; v++) t.umax[v] = (int8_t)umax[v];
     (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tab), &t, sizeof(t), 0, hipMemcpyHostToDevice, stream);
     (void)hipStreamSynchronize(stream);
 }
-constexpr int kPatchPixels = 749;
 
 // cv::fastAtan2 — separate multiply/add, no contraction (oracle/cvprims.h fast_atan2).
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
@@ -754,12 +748,26 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
     const int k_first = (bx * 4 + (threadIdx.x >> 6)) * kKpPerWave;
     const int n_sel = sel_count[img];
     if (k_first >= n_sel) return;
-    // per-lane constants, loaded once: the 12 patch offsets lane, lane+64, ... and the 4 pattern pairs of this lane
-    int uv[12];
+    // per-lane constants, loaded once.  IC-angle patch: the 31 rows are read as 9 aligned dwords each (279 slots, slot =
+    // lane + 64 t); after the byte re-alignment below, slot (row, col < 8) holds the pixels u = 4 col - 15 .. 4 col - 12 of
+    // row v = row - 15.  wu = (u + 16) per byte inside the circle (0 outside), vm = 1 / 0: two udot4 give sum(u I), sum(I).
+    uint32_t wu[5], vm[5];
+    uint32_t vrow03 = 0;  // v of slots 0..3, one signed byte each
+    int vrow4 = 0;
 #pragma unroll
-    for (int t = 0; t < 12; t++) {
-        const int i = lane + 64 * t;
-        uv[t] = i < kPatchPixels ? (((int)c_tab.pu[i] & 0xffff) | ((int)c_tab.pv[i] << 16)) : 0x7fff7fff;
+    for (int t = 0; t < 5; t++) {
+        const int idx = lane + 64 * t, row = idx / 9, col = idx % 9;
+        uint32_t a = 0, m = 0;
+        if (row < 31 && col < 8) {
+            const int d = c_tab.umax[row < 15 ? 15 - row : row - 15];
+            for (int bb = 0; bb < 4; bb++) {
+                const int u = 4 * col + bb - 15;
+                if (u >= -d && u <= d) { a |= (uint32_t)(u + 16) << (8 * bb); m |= 1u << (8 * bb); }
+            }
+        }
+        wu[t] = a; vm[t] = m;
+        if (t < 4) vrow03 |= (uint32_t)((row - 15) & 255) << (8 * t);
+        else vrow4 = row - 15;
     }
     uint32_t pat[4];
 #pragma unroll
@@ -770,10 +778,17 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
     for (int kk = 0; kk < kKpPerWave; kk++) {
         const int k = k_first + kk;
         if (k >= n_sel) break;
-        const SelRec r = r_next;
+        // every lane loaded the same record: move it to scalar registers so that everything derived from it (level
+        // view, row pointers, strides) is SALU work and the loads use an SGPR base + 32-bit lane offset
+        SelRec r;
+        {
+            uint32_t w[3];
+            memcpy(w, &r_next, sizeof(w));
+            for (int i = 0; i < 3; i++) w[i] = __builtin_amdgcn_readfirstlane(w[i]);
+            memcpy(&r, w, sizeof(w));
+        }
         if (k + 1 < n_sel && kk + 1 < kKpPerWave) r_next = sel[(size_t)img * sel_stride + k + 1];  // prefetch
         const LevelView lv = pyr.lv[r.level];
-        const uint8_t* center = lv.base + (size_t)img * lv.img_stride + (size_t)r.y * lv.pitch + r.x;
 
         // Both patches depend only on (x, y, level): issue the blurred-patch loads together with the IC-angle loads so
         // their latencies overlap.  The 256 test pairs gather 512 bytes from the 37x37 neighbourhood (|offset| <= 18
@@ -782,44 +797,57 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
         const LevelView bv = blur.lv[r.level];
         const int px0 = (r.x - 18) & ~3, poff = (r.x - 18) - px0;
         const uint8_t* brow = bv.base + (size_t)img * bv.img_stride + (size_t)(r.y - 18) * bv.pitch + px0;
-        const int prow = lane / 11, pcol = lane % 11;
-        int pix[12];
+        // (level 0 may be the caller's own image with any row stride: the 4-byte phase is taken per row)
+        // addresses = scalar base + 32-bit lane offset (the global_load saddr form: no 64-bit VALU address math)
+        const uint8_t* rrow = lv.base + (size_t)img * lv.img_stride + (size_t)(r.y - 15) * lv.pitch + (r.x - 15) - 4;
+        const uint32_t rlow = (uint32_t)reinterpret_cast<uintptr_t>(rrow);
+        uint32_t rp[5], rsh[5];
 #pragma unroll
-        for (int t = 0; t < 12; t++) {
-            const int u = (int)(int16_t)(uv[t] & 0xffff), v = uv[t] >> 16;
-            pix[t] = uv[t] != 0x7fff7fff ? (int)center[v * lv.pitch + u] : 0;
+        for (int t = 0; t < 5; t++) {
+            const int idx = lane + 64 * t, row = idx / 9, col = idx % 9;
+            const uint32_t o = (uint32_t)(row * lv.pitch);
+            rsh[t] = (rlow + o) & 3u;
+            rp[t] = row < 31 ? *reinterpret_cast<const uint32_t*>(rrow + (size_t)(o + 4u - rsh[t] + 4u * col)) : 0u;
         }
-        uint32_t bp[8];
+        uint32_t bp[6];  // 37 rows x 10 dwords (x-18 .. x+18 from the 4-byte boundary below) = 370 slots, slot = lane + 64 it
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int row = it * 5 + prow;
-            bp[it] = (lane < 55 && row < 37) ? *reinterpret_cast<const uint32_t*>(brow + (size_t)row * bv.pitch + 4 * pcol) : 0u;
+        for (int it = 0; it < 6; it++) {
+            const int idx = lane + 64 * it, row = idx / 10, col = idx % 10;
+            bp[it] = row < 37 ? *reinterpret_cast<const uint32_t*>(brow + (size_t)(uint32_t)(row * bv.pitch + 4 * col)) : 0u;
         }
 
-        // IC_Angle: integer moments over the 749-pixel circular patch (un-blurred level)
+        // IC_Angle: integer moments over the 749-pixel circular patch (un-blurred level).  Slot + 1 (the next lane, or
+        // lane 0 of the next register for lane 63) holds the following 4 bytes of the row: alignbyte undoes the 4-byte
+        // alignment of the loads, so the per-lane weights do not depend on the keypoint.
         int m10 = 0, m01 = 0;
 #pragma unroll
-        for (int t = 0; t < 12; t++) {
-            const int u = (int)(int16_t)(uv[t] & 0xffff), v = uv[t] >> 16;
-            if (uv[t] != 0x7fff7fff) { m10 += u * pix[t]; m01 += v * pix[t]; }
+        for (int t = 0; t < 5; t++) {
+            uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rp[t], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+            if (t < 4) { const uint32_t first = __builtin_amdgcn_readfirstlane(rp[t + 1]); if (lane == 63) nx = first; }
+            const uint32_t px = __builtin_amdgcn_alignbyte(nx, rp[t], rsh[t]);
+            const int sI = (int)__builtin_amdgcn_udot4(px, vm[t], 0u, false);
+            m10 += (int)__builtin_amdgcn_udot4(px, wu[t], 0u, false) - 16 * sI;
+            m01 += (t < 4 ? (int)(int8_t)(vrow03 >> (8 * t)) : vrow4) * sI;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             m10 += __shfl_xor(m10, o);
             m01 += __shfl_xor(m01, o);
         }
+        // stage the blurred patch now (the previous keypoint's LDS reads are done: same wave, program order), so the
+        // six data registers are free during the angle / sincos arithmetic
+        uint8_t* lp = patch[threadIdx.x >> 6];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            const int idx = lane + 64 * it, row = idx / 10, col = idx % 10;
+            if (row < 37) *reinterpret_cast<uint32_t*>(lp + row * kPatchPitch + 4 * col) = bp[it];
+        }
         const float angle = fast_atan2_deg((float)m01, (float)m10);
 
         // steered BRIEF on the blurred level
         float a, b;
         glibc_sincosf<true>(__fmul_rn(angle, factor_pi), &b, &a);  // a = cos, b = sin (ORBextractor.cc:112)
-        uint8_t* lp = patch[threadIdx.x >> 6];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int row = it * 5 + prow;
-            if (lane < 55 && row < 37) *reinterpret_cast<uint32_t*>(lp + row * kPatchPitch + 4 * pcol) = bp[it];
-        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint8_t* bc = lp + 18 * kPatchPitch + 18 + poff;
