@@ -727,6 +727,18 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
+// Sum over the 64 lanes with DPP adds only (no LDS crossbar): xor-butterfly inside each row of 16 lanes, then the row
+// totals are chained through lanes 15 / 31 into row 3; lane 63 holds the total, returned as a scalar.
+__device__ __forceinline__ int wave_sum_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141 /* row_half_mirror */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140 /* row_mirror */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 constexpr int kPatchPitch = 44;  // bytes per staged patch row: 11 dwords
 constexpr int kKpPerWave = 4;  // keypoints handled back to back by one wave (amortises the per-lane table loads)
 
@@ -745,7 +757,7 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
         bx = (int)(j % gridDim.x);
     }
     const int lane = threadIdx.x & 63;
-    const int k_first = (bx * 4 + (threadIdx.x >> 6)) * kKpPerWave;
+    const int k_first = __builtin_amdgcn_readfirstlane((bx * 4 + (int)(threadIdx.x >> 6)) * kKpPerWave);  // wave-uniform -> SALU
     const int n_sel = sel_count[img];
     if (k_first >= n_sel) return;
     // per-lane constants, loaded once.  IC-angle patch: the 31 rows are read as 9 aligned dwords each (279 slots, slot =
@@ -774,47 +786,67 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
     for (int w = 0; w < 4; w++) pat[w] = *reinterpret_cast<const uint32_t*>(&c_tab.pattern[(w * 64 + lane) * 4]);
     const float factor_pi = (float)(3.1415926535897932384626433832795 / 180.0);
 
-    SelRec r_next = sel[(size_t)img * sel_stride + k_first];
-    for (int kk = 0; kk < kKpPerWave; kk++) {
-        const int k = k_first + kk;
-        if (k >= n_sel) break;
-        // every lane loaded the same record: move it to scalar registers so that everything derived from it (level
-        // view, row pointers, strides) is SALU work and the loads use an SGPR base + 32-bit lane offset
+    // Software pipeline over the wave's keypoints: while keypoint k is being processed the 11 patch loads of keypoint
+    // k+1 are already in flight (and the record of k+2 is being fetched) — the kernel is bound by the latency of these
+    // scattered loads, not by arithmetic.
+    struct Loads { uint32_t rp[5], rsh[5], bp[6]; int poff; };
+    auto scalar_rec = [](const SelRec& v) {
+        // every lane loaded the same record: move it to scalar registers so that everything derived from it (level view,
+        // row pointers, strides) is SALU work and the loads use an SGPR base + 32-bit lane offset
         SelRec r;
-        {
-            uint32_t w[3];
-            memcpy(w, &r_next, sizeof(w));
-            for (int i = 0; i < 3; i++) w[i] = __builtin_amdgcn_readfirstlane(w[i]);
-            memcpy(&r, w, sizeof(w));
-        }
-        if (k + 1 < n_sel && kk + 1 < kKpPerWave) r_next = sel[(size_t)img * sel_stride + k + 1];  // prefetch
+        uint32_t w[3];
+        memcpy(w, &v, sizeof(w));
+        for (int i = 0; i < 3; i++) w[i] = __builtin_amdgcn_readfirstlane(w[i]);
+        memcpy(&r, w, sizeof(w));
+        return r;
+    };
+    auto issue = [&](const SelRec& r, Loads& L) {
+        // Both patches depend only on (x, y, level).  The 256 test pairs gather 512 bytes from the blurred 37x37
+        // neighbourhood (|offset| <= 18 after rotation); a direct gather touches ~35 cache lines per load instruction,
+        // so that patch goes to LDS with row-coherent dword loads: 37 rows x 10 dwords from the 4-byte boundary below
+        // x-18 = 370 slots, slot = lane + 64 it.  The 31x31 IC-angle patch: 31 rows x 9 dwords, slot = lane + 64 t.
         const LevelView lv = pyr.lv[r.level];
-
-        // Both patches depend only on (x, y, level): issue the blurred-patch loads together with the IC-angle loads so
-        // their latencies overlap.  The 256 test pairs gather 512 bytes from the 37x37 neighbourhood (|offset| <= 18
-        // after rotation); a direct gather touches ~35 cache lines per load instruction, so the patch goes to LDS with
-        // row-coherent dword loads (11 dwords cover one row from the 4-byte boundary below x-18; 5 rows per load).
         const LevelView bv = blur.lv[r.level];
-        const int px0 = (r.x - 18) & ~3, poff = (r.x - 18) - px0;
+        const int px0 = (r.x - 18) & ~3;
+        L.poff = (r.x - 18) - px0;
         const uint8_t* brow = bv.base + (size_t)img * bv.img_stride + (size_t)(r.y - 18) * bv.pitch + px0;
         // (level 0 may be the caller's own image with any row stride: the 4-byte phase is taken per row)
         // addresses = scalar base + 32-bit lane offset (the global_load saddr form: no 64-bit VALU address math)
         const uint8_t* rrow = lv.base + (size_t)img * lv.img_stride + (size_t)(r.y - 15) * lv.pitch + (r.x - 15) - 4;
         const uint32_t rlow = (uint32_t)reinterpret_cast<uintptr_t>(rrow);
-        uint32_t rp[5], rsh[5];
 #pragma unroll
         for (int t = 0; t < 5; t++) {
             const int idx = lane + 64 * t, row = idx / 9, col = idx % 9;
-            const uint32_t o = (uint32_t)(row * lv.pitch);
-            rsh[t] = (rlow + o) & 3u;
-            rp[t] = row < 31 ? *reinterpret_cast<const uint32_t*>(rrow + (size_t)(o + 4u - rsh[t] + 4u * col)) : 0u;
+            const uint32_t o = __umul24((uint32_t)row, (uint32_t)lv.pitch);  // full-rate 24-bit multiply
+            L.rsh[t] = (rlow + o) & 3u;
+            // slots 0..255 are always inside the 279-slot patch: only the last register needs the predicate
+            L.rp[t] = (t < 4 || row < 31) ? *reinterpret_cast<const uint32_t*>(rrow + (size_t)(o + 4u - L.rsh[t] + 4u * col)) : 0u;
         }
-        uint32_t bp[6];  // 37 rows x 10 dwords (x-18 .. x+18 from the 4-byte boundary below) = 370 slots, slot = lane + 64 it
 #pragma unroll
         for (int it = 0; it < 6; it++) {
             const int idx = lane + 64 * it, row = idx / 10, col = idx % 10;
-            bp[it] = row < 37 ? *reinterpret_cast<const uint32_t*>(brow + (size_t)(uint32_t)(row * bv.pitch + 4 * col)) : 0u;
+            L.bp[it] = (it < 5 || row < 37) ? *reinterpret_cast<const uint32_t*>(brow + (size_t)(__umul24((uint32_t)row, (uint32_t)bv.pitch) + 4u * col)) : 0u;
         }
+    };
+    const SelRec* recs = sel + (size_t)img * sel_stride;
+    SelRec r_cur = scalar_rec(recs[k_first]);
+    Loads L_next;
+    issue(r_cur, L_next);
+    SelRec r_pre = recs[min(k_first + 1, n_sel - 1)];
+    for (int kk = 0; kk < kKpPerWave; kk++) {
+        const int k = k_first + kk;
+        if (k >= n_sel) break;
+        const SelRec r = r_cur;
+        const Loads L = L_next;
+        if (k + 1 < n_sel && kk + 1 < kKpPerWave) {
+            r_cur = scalar_rec(r_pre);
+            issue(r_cur, L_next);
+            r_pre = recs[min(k + 2, n_sel - 1)];
+        }
+        const uint32_t* rp = L.rp;
+        const uint32_t* rsh = L.rsh;
+        const uint32_t* bp = L.bp;
+        const int poff = L.poff;
 
         // IC_Angle: integer moments over the 749-pixel circular patch (un-blurred level).  Slot + 1 (the next lane, or
         // lane 0 of the next register for lane 63) holds the following 4 bytes of the row: alignbyte undoes the 4-byte
@@ -829,11 +861,8 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
             m10 += (int)__builtin_amdgcn_udot4(px, wu[t], 0u, false) - 16 * sI;
             m01 += (t < 4 ? (int)(int8_t)(vrow03 >> (8 * t)) : vrow4) * sI;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            m10 += __shfl_xor(m10, o);
-            m01 += __shfl_xor(m01, o);
-        }
+        m10 = wave_sum_dpp(m10);  // wave-uniform (SGPR) totals
+        m01 = wave_sum_dpp(m01);
         // stage the blurred patch now (the previous keypoint's LDS reads are done: same wave, program order), so the
         // six data registers are free during the angle / sincos arithmetic
         uint8_t* lp = patch[threadIdx.x >> 6];
@@ -841,7 +870,7 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
 #pragma unroll
         for (int it = 0; it < 6; it++) {
             const int idx = lane + 64 * it, row = idx / 10, col = idx % 10;
-            if (row < 37) *reinterpret_cast<uint32_t*>(lp + row * kPatchPitch + 4 * col) = bp[it];
+            if (it < 5 || row < 37) *reinterpret_cast<uint32_t*>(lp + row * kPatchPitch + 4 * col) = bp[it];
         }
         const float angle = fast_atan2_deg((float)m01, (float)m10);
 
