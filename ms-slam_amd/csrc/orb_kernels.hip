@@ -173,12 +173,15 @@ __device__ __forceinline__ int fast_arc_contrast(const uint8_t* p, int sgn) {
     return A;
 }
 
-__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
+// inclusive prefix sum over the wave with DPP adds only (no LDS crossbar round trips): shifts inside each row of 16
+// lanes, then the row totals are chained through lanes 15 / 31 (lanes shifted in from outside a row read 0)
+__device__ __forceinline__ int wave_incl_scan(int v, int) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118 /* row_shr:8 */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
     return v;
 }
 
@@ -239,7 +242,8 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
     const int n_task = dh * G;            // one task = one group of one detection row, scan order
     const uint32_t magic = ((1u << 20) + G - 1) / G;  // task / G == (task * magic) >> 20 for task < 2^20 / G
     // balanced consecutive task ranges: thread t owns tasks [t*n/T, (t+1)*n/T)  (<= kMaxRounds each)
-    const int t_begin = (tid * n_task) / GEO::kThreads, t_end = ((tid + 1) * n_task) / GEO::kThreads;
+    const int t_begin = (int)(__umul24((uint32_t)tid, (uint32_t)n_task) / GEO::kThreads),
+              t_end = (int)(__umul24((uint32_t)tid + 1u, (uint32_t)n_task) / GEO::kThreads);
 
     // phase 0
     const uint8_t* src = lv.base + (size_t)img * lv.img_stride + (size_t)cd.y0 * lv.pitch;
@@ -247,16 +251,17 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
         const int ndw = (cd.x0 + rw - ga + 3) >> 2;  // dwords per tile row
         const uint32_t dmagic = ((1u << 20) + ndw - 1) / ndw;
         for (int i = tid; i < rh * ndw; i += GEO::kThreads) {
-            const int y = (i * dmagic) >> 20, c = i - y * ndw;
-            *reinterpret_cast<uint32_t*>(&tile[y * GEO::kTilePitch + 4 * c]) =
-                *reinterpret_cast<const uint32_t*>(src + (size_t)y * lv.pitch + ga + 4 * c);
+            // 24-bit multiplies are full rate (v_mul_lo_u32 / 64-bit mads are quarter rate); scalar base + 32-bit offset
+            const int y = (int)(__umul24((uint32_t)i, dmagic) >> 20), c = i - (int)__umul24((uint32_t)y, (uint32_t)ndw);
+            *reinterpret_cast<uint32_t*>(&tile[(int)__umul24((uint32_t)y, GEO::kTilePitch) + 4 * c]) =
+                *reinterpret_cast<const uint32_t*>(src + (size_t)(__umul24((uint32_t)y, (uint32_t)lv.pitch) + (uint32_t)(ga + 4 * c)));
         }
     } else {
         const int off = cd.x0 - ga;
         const uint32_t bmagic = ((1u << 20) + rw - 1) / rw;
         for (int i = tid; i < rh * rw; i += GEO::kThreads) {
-            const int y = (i * bmagic) >> 20, x = i - y * rw;
-            tile[y * GEO::kTilePitch + off + x] = src[(size_t)y * lv.pitch + cd.x0 + x];
+            const int y = (int)(__umul24((uint32_t)i, bmagic) >> 20), x = i - (int)__umul24((uint32_t)y, (uint32_t)rw);
+            tile[(int)__umul24((uint32_t)y, GEO::kTilePitch) + off + x] = src[(size_t)(__umul24((uint32_t)y, (uint32_t)lv.pitch) + (uint32_t)(cd.x0 + x))];
         }
     }
     // Threshold passes (ORBextractor.cc:826,843-847): iniThFAST first; only a cell that ends up with no keypoint at all
@@ -274,11 +279,11 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
     int cnt = 0;
     const short2v T2 = {(short)th, (short)th};
     {
-        int y = (t_begin * magic) >> 20;
+        int y = (int)(__umul24((uint32_t)t_begin, magic) >> 20);
         int g = t_begin - y * G;
         for (int task = t_begin, k = 0; task < t_end; task++, k++) {
             const int c0 = c_lo + 4 * g;
-            const uint8_t* row = &tile[(y + 3) * GEO::kTilePitch + c0];
+            const uint8_t* row = &tile[(int)__umul24((uint32_t)(y + 3), GEO::kTilePitch) + c0];
             const uint32_t C = *reinterpret_cast<const uint32_t*>(row);
             const uint32_t Lw = *reinterpret_cast<const uint32_t*>(row - 4);
             const uint32_t Rw = *reinterpret_cast<const uint32_t*>(row + 4);
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
     for (int cb = 0; cb < n_work; cb += GEO::kWorkCap) {
         if (cnt && my_base < cb + GEO::kWorkCap && my_base + cnt > cb) {
             int idx = my_base - cb;
-            int y = (t_begin * magic) >> 20;
+            int y = (int)(__umul24((uint32_t)t_begin, magic) >> 20);
             int g = t_begin - y * G;
             uint64_t m = M;
             for (int task = t_begin; task < t_end; task++, m >>= 8) {
@@ -342,8 +347,8 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
         for (int i = tid; i < nw; i += GEO::kThreads) {
             const int e = work[i];
             const int ty = (e >> 7) & 127, tx = e & 127;
-            const int A = fast_arc_contrast<GEO>(&tile[ty * GEO::kTilePitch + tx], (e & 0x8000) ? -1 : 1);
-            if (A > th) score[(ty - 2) * GEO::kScorePitch + tx + sc_off] = (uint8_t)(A - 1);  // score row = y + 1
+            const int A = fast_arc_contrast<GEO>(&tile[(int)__umul24((uint32_t)ty, GEO::kTilePitch) + tx], (e & 0x8000) ? -1 : 1);
+            if (A > th) score[(int)__umul24((uint32_t)(ty - 2), GEO::kScorePitch) + tx + sc_off] = (uint8_t)(A - 1);  // score row = y + 1
             work[i] = A > th ? (uint16_t)(e & 0x3FFF) : (uint16_t)0xFFFF;  // the list now holds the corners
         }
         __syncthreads();
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
                 const int e = work[i];
                 if (e == 0xFFFF) continue;
                 const int ty = e >> 7, tx = e & 127;
-                const uint8_t* q = &score[(ty - 2) * GEO::kScorePitch + tx + sc_off];
+                const uint8_t* q = &score[(int)__umul24((uint32_t)(ty - 2), GEO::kScorePitch) + tx + sc_off];
                 const int sv = q[0];
                 int m = max3i(q[-GEO::kScorePitch - 1], q[-GEO::kScorePitch], q[-GEO::kScorePitch + 1]);
                 m = max3i(m, q[-1], q[1]);
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
                 Cand16 c;
                 c.x = (uint16_t)(ga + tx - kMinBorder);
                 c.y = (uint16_t)(cd.y0 + ty - kMinBorder);
-                c.score = score[(ty - 2) * GEO::kScorePitch + tx + sc_off];
+                c.score = score[(int)__umul24((uint32_t)(ty - 2), GEO::kScorePitch) + tx + sc_off];
                 c.pad = 0;
                 out[rank] = c;
             }
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
     // phase 3a: strict 3x3 NMS, 4 flag bits per task
     uint64_t keep = 0, keep_ini = 0;
     {
-        int y = (t_begin * magic) >> 20;
+        int y = (int)(__umul24((uint32_t)t_begin, magic) >> 20);
         int g = t_begin - y * G;
         for (int task = t_begin, k = 0; task < t_end; task++, k++) {
             const uint8_t* sp = &score[(y + 1) * GEO::kScorePitch + 4 + 4 * g];
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
     int n_out = 0;
     int pos = block_excl_scan<GEO::kThreads / 64>(__popcll(sel), lane, wave, wave_tot[1], &n_out);
     if (sel) {
-        int y = (t_begin * magic) >> 20;
+        int y = (int)(__umul24((uint32_t)t_begin, magic) >> 20);
         int g = t_begin - y * G;
         uint64_t m = sel;
         for (int task = t_begin; task < t_end; task++, m >>= 4) {
@@ -764,6 +769,9 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
     // lane + 64 t); after the byte re-alignment below, slot (row, col < 8) holds the pixels u = 4 col - 15 .. 4 col - 12 of
     // row v = row - 15.  wu = (u + 16) per byte inside the circle (0 outside), vm = 1 / 0: two udot4 give sum(u I), sum(I).
     uint32_t wu[5], vm[5];
+    uint32_t rc[5], bc[6];  // slot -> row | byte column << 8 (lane constants; keeps the /9, /10 out of the keypoint loop)
+#pragma unroll
+    for (int it = 0; it < 6; it++) { const int idx = lane + 64 * it; bc[it] = (uint32_t)(idx / 10) | ((uint32_t)(4 * (idx % 10)) << 8); }
     uint32_t vrow03 = 0;  // v of slots 0..3, one signed byte each
     int vrow4 = 0;
 #pragma unroll
@@ -778,6 +786,7 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
             }
         }
         wu[t] = a; vm[t] = m;
+        rc[t] = (uint32_t)row | ((uint32_t)(4 * col + 4) << 8);
         if (t < 4) vrow03 |= (uint32_t)((row - 15) & 255) << (8 * t);
         else vrow4 = row - 15;
     }
@@ -816,16 +825,16 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
         const uint32_t rlow = (uint32_t)reinterpret_cast<uintptr_t>(rrow);
 #pragma unroll
         for (int t = 0; t < 5; t++) {
-            const int idx = lane + 64 * t, row = idx / 9, col = idx % 9;
-            const uint32_t o = __umul24((uint32_t)row, (uint32_t)lv.pitch);  // full-rate 24-bit multiply
+            const uint32_t row = rc[t] & 255u, col4p4 = rc[t] >> 8;
+            const uint32_t o = __umul24(row, (uint32_t)lv.pitch);  // full-rate 24-bit multiply
             L.rsh[t] = (rlow + o) & 3u;
             // slots 0..255 are always inside the 279-slot patch: only the last register needs the predicate
-            L.rp[t] = (t < 4 || row < 31) ? *reinterpret_cast<const uint32_t*>(rrow + (size_t)(o + 4u - L.rsh[t] + 4u * col)) : 0u;
+            L.rp[t] = (t < 4 || row < 31) ? *reinterpret_cast<const uint32_t*>(rrow + (size_t)(o + col4p4 - L.rsh[t])) : 0u;
         }
 #pragma unroll
         for (int it = 0; it < 6; it++) {
-            const int idx = lane + 64 * it, row = idx / 10, col = idx % 10;
-            L.bp[it] = (it < 5 || row < 37) ? *reinterpret_cast<const uint32_t*>(brow + (size_t)(__umul24((uint32_t)row, (uint32_t)bv.pitch) + 4u * col)) : 0u;
+            const uint32_t row = bc[it] & 255u, col4 = bc[it] >> 8;
+            L.bp[it] = (it < 5 || row < 37) ? *reinterpret_cast<const uint32_t*>(brow + (size_t)(__umul24(row, (uint32_t)bv.pitch) + col4)) : 0u;
         }
     };
     const SelRec* recs = sel + (size_t)img * sel_stride;
@@ -869,8 +878,8 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int it = 0; it < 6; it++) {
-            const int idx = lane + 64 * it, row = idx / 10, col = idx % 10;
-            if (it < 5 || row < 37) *reinterpret_cast<uint32_t*>(lp + row * kPatchPitch + 4 * col) = bp[it];
+            const uint32_t row = bc[it] & 255u, col4 = bc[it] >> 8;
+            if (it < 5 || row < 37) *reinterpret_cast<uint32_t*>(lp + row * kPatchPitch + col4) = bp[it];
         }
         const float angle = fast_atan2_deg((float)m01, (float)m10);
 
