@@ -13,6 +13,17 @@ namespace msorb {
 constexpr int kQtThreads = 256;  // 256 beats 512 (0.39 vs 0.47 ms per 256 images): fewer idle waves waiting at barriers
 constexpr int kQtPointsPerThread = 0;  // register-resident candidates per thread: measured slower (VGPR pressure halves the resident workgroups)
 
+// inclusive prefix sum over the wave with DPP adds only (no LDS crossbar round trips)
+__device__ __forceinline__ int wave_incl_scan_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118 /* row_shr:8 */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+    return v;
+}
+
 struct DevEx {
     // std::sort restatement, data-parallel form (quadtree_device.h lsort_par), executed by wave 0 only: inside one
     // wave there is no s_barrier to pay and LDS operations complete in program order.
@@ -26,14 +37,8 @@ struct DevEx {
             return __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
         }
         __device__ int excl_scan(int v, int*, int* total) {
-            const int lane = threadIdx.x & 63;
-            int incl = v;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t = __shfl_up(incl, o);
-                if (lane >= o) incl += t;
-            }
-            *total = __shfl(incl, 63);
+            const int incl = wave_incl_scan_dpp(v);
+            *total = __builtin_amdgcn_readlane(incl, 63);
             return incl - v;
         }
     };
@@ -67,12 +72,7 @@ struct DevEx {
     // block-wide exclusive prefix of v over threads (<= 16 waves); tmp = 16 ints of LDS
     __device__ int excl_scan(int v, int* tmp, int* total) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        int incl = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o);
-            if (lane >= o) incl += t;
-        }
+        const int incl = wave_incl_scan_dpp(v);
         __syncthreads();  // tmp may still be read by a previous scan
         if (lane == 63) tmp[wave] = incl;
         __syncthreads();
