@@ -651,6 +651,89 @@ __global__ __launch_bounds__(256) void gauss7_kernel(PyramidView src, PyramidVie
     }
 }
 
+// Aligned fast path of the blur: the same strips, but a lane loads only ITS dword of a row and takes the 4 bytes on
+// either side from the neighbouring lanes (DPP wave shifts) — one global load per row instead of three — and the loads
+// of the next seven rows are in flight while the current seven are accumulated.  Lanes 0 and 63 of a wave only provide
+// halo bytes: a wave stores 62 four-pixel groups per row.
+constexpr int kGaussLanesOut = 62;
+__global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, PyramidView dst, BlurPlan plan) {
+    constexpr uint32_t K[7] = {18, 34, 48, 56, 48, 34, 18};
+    int level = 0;
+    while (level + 1 < plan.nlevels && (int)blockIdx.x >= plan.block_begin[level + 1]) level++;
+    const int rem = blockIdx.x - plan.block_begin[level];
+    const int bx = rem % plan.bx_count[level], by = rem / plan.bx_count[level];
+    const LevelView sv = src.lv[level], dv = dst.lv[level];
+    const int img = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int x0 = (bx * kGaussLanesOut + lane - 1) * 4;
+    const int y0 = (by * 4 + (int)(threadIdx.x >> 6)) * kGaussRows;
+    if (y0 >= sv.h) return;  // wave-uniform
+    const bool store = lane >= 1 && lane <= kGaussLanesOut && x0 + 16 <= sv.w;  // the rest: gauss7_edge_kernel / halo lanes
+    const uint32_t xl = (uint32_t)min(max(x0, 0), sv.pitch - 4);
+    const uint8_t* sb = sv.base + (size_t)img * sv.img_stride;
+    uint8_t* db = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride;
+    auto load_row = [&](int r) {  // input row r of the strip = image row y0 - 3 + r (reflect-101, then clamped)
+        int yy = refl101(y0 - 3 + r, sv.h);
+        yy = min(max(yy, 0), sv.h - 1);
+        return *reinterpret_cast<const uint32_t*>(sb + (size_t)yy * sv.pitch + (size_t)xl);
+    };
+    auto row_sums = [&](uint32_t w1, uint32_t hs[4]) {
+        uint32_t w0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        const uint32_t w2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+        if (x0 == 0) w0 = __builtin_amdgcn_perm(0u, w1, 0x01020300u);  // p[-1..-3] = p[1..3]
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t a = j == 3 ? w1 : __builtin_amdgcn_alignbyte(w1, w0, j + 1);
+            const uint32_t b = j == 3 ? w2 : __builtin_amdgcn_alignbyte(w2, w1, j + 1);
+            hs[j] = __builtin_amdgcn_udot4(b, kGaussHi, __builtin_amdgcn_udot4(a, kGaussLo, 0u, false), false);
+        }
+    };
+    uint32_t acc[7][4];
+    uint32_t hs[4];
+    uint32_t warm[6], nxt[7];
+#pragma unroll
+    for (int r = 0; r < 6; r++) warm[r] = load_row(r);
+#pragma unroll
+    for (int u = 0; u < 7; u++) nxt[u] = load_row(6 + u);
+    // warm-up: input rows 0..5 open accumulators 0..5
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        row_sums(warm[r], hs);
+#pragma unroll
+        for (int t = 0; t <= r; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[r - t][j] = (t == 0 ? 0u : acc[r - t][j]) + K[t] * hs[j];
+    }
+    // steady state: input row r = 6 + 7*it + u completes output row o = r - 6 and opens accumulator r % 7
+    for (int it = 0; it < kGaussRows / 7; it++) {
+        uint32_t cur[7];
+#pragma unroll
+        for (int u = 0; u < 7; u++) cur[u] = nxt[u];
+        if (it + 1 < kGaussRows / 7) {
+#pragma unroll
+            for (int u = 0; u < 7; u++) nxt[u] = load_row(6 + 7 * (it + 1) + u);
+        }
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            const int r = 6 + 7 * it + u;
+            row_sums(cur[u], hs);
+#pragma unroll
+            for (int t = 0; t < 7; t++) {
+                const int a = (6 + u - t) % 7;  // == (r - t) % 7
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[a][j] = (t == 0 ? 0u : acc[a][j]) + K[t] * hs[j];
+            }
+            const int o = r - 6, a = u % 7;  // (r - 6) % 7 == u
+            if (store && y0 + o < sv.h) {
+                uint32_t packed = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) packed |= ((acc[a][j] + 32768u) >> 16) << (8 * j);
+                *reinterpret_cast<uint32_t*>(db + (size_t)(y0 + o) * dv.pitch + (size_t)(uint32_t)x0) = packed;
+            }
+        }
+    }
+}
+
 // Right-border column groups (x0 + 16 > w: at most four groups = 16 columns per row): per-byte reflect-101 gather.
 // One 64-thread block covers 58 output rows: thread r first forms the horizontal sums of input row y0-3+r for the
 // border columns (all rows in parallel: one memory round trip), then thread r < 58 finishes output row y0+r from LDS.
@@ -963,18 +1046,26 @@ void launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images,
     BlurPlan plan{};
     plan.nlevels = src.nlevels;
     bool aligned = true;
+    for (int l = 0; l < src.nlevels; l++) {
+        const LevelView& v = src.lv[l];
+        aligned = aligned && (reinterpret_cast<uintptr_t>(v.base) & 3) == 0 && (v.pitch & 3) == 0 && (v.img_stride & 3) == 0;
+    }
+    static const bool stream_env = !getenv("MSORB_BLUR_GENERIC");  // tuning / test aid
+    const bool stream = aligned && stream_env;
     int total = 0, max_h = 0;
     for (int l = 0; l < src.nlevels; l++) {
         const LevelView& v = src.lv[l];
         plan.block_begin[l] = total;
-        plan.bx_count[l] = (v.w + 255) / 256;
+        // aligned path: 62 stored groups per wave; generic path: 64 groups per wave
+        const int main_groups = v.w >= 16 ? (v.w - 16) / 4 + 1 : 0;  // groups with x0 + 16 <= w
+        plan.bx_count[l] = stream ? max(1, (main_groups + kGaussLanesOut - 1) / kGaussLanesOut) : (v.w + 255) / 256;
         const int strips = (v.h + kGaussRows - 1) / kGaussRows;
         total += plan.bx_count[l] * ((strips + 3) / 4);
         max_h = max(max_h, v.h);
-        aligned = aligned && (reinterpret_cast<uintptr_t>(v.base) & 3) == 0 && (v.pitch & 3) == 0 && (v.img_stride & 3) == 0;
     }
     plan.block_begin[src.nlevels] = total;
-    if (aligned) hipLaunchKernelGGL(gauss7_kernel<true>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
+    if (stream) hipLaunchKernelGGL(gauss7_stream_kernel, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
+    else if (aligned) hipLaunchKernelGGL(gauss7_kernel<true>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
     else hipLaunchKernelGGL(gauss7_kernel<false>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
     hipLaunchKernelGGL(gauss7_edge_kernel, dim3((max_h + kEdgeRows - 1) / kEdgeRows, src.nlevels, n_images), dim3(64), 0, s, src, dst);
 }
