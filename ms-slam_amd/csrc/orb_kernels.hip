@@ -656,6 +656,7 @@ __global__ __launch_bounds__(256) void gauss7_kernel(PyramidView src, PyramidVie
 // of the next seven rows are in flight while the current seven are accumulated.  Lanes 0 and 63 of a wave only provide
 // halo bytes: a wave stores 62 four-pixel groups per row.
 constexpr int kGaussLanesOut = 62;
+template <int ROWS>
 __global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, PyramidView dst, BlurPlan plan) {
     constexpr uint32_t K[7] = {18, 34, 48, 56, 48, 34, 18};
     int level = 0;
@@ -666,7 +667,7 @@ __global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, Pyr
     const int img = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int x0 = (bx * kGaussLanesOut + lane - 1) * 4;
-    const int y0 = (by * 4 + (int)(threadIdx.x >> 6)) * kGaussRows;
+    const int y0 = (by * 4 + (int)(threadIdx.x >> 6)) * ROWS;
     if (y0 >= sv.h) return;  // wave-uniform
     const bool store = lane >= 1 && lane <= kGaussLanesOut && x0 + 16 <= sv.w;  // the rest: gauss7_edge_kernel / halo lanes
     const uint32_t xl = (uint32_t)min(max(x0, 0), sv.pitch - 4);
@@ -705,11 +706,11 @@ __global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, Pyr
             for (int j = 0; j < 4; j++) acc[r - t][j] = (t == 0 ? 0u : acc[r - t][j]) + K[t] * hs[j];
     }
     // steady state: input row r = 6 + 7*it + u completes output row o = r - 6 and opens accumulator r % 7
-    for (int it = 0; it < kGaussRows / 7; it++) {
+    for (int it = 0; it < ROWS / 7; it++) {
         uint32_t cur[7];
 #pragma unroll
         for (int u = 0; u < 7; u++) cur[u] = nxt[u];
-        if (it + 1 < kGaussRows / 7) {
+        if (it + 1 < ROWS / 7) {
 #pragma unroll
             for (int u = 0; u < 7; u++) nxt[u] = load_row(6 + 7 * (it + 1) + u);
         }
@@ -1052,6 +1053,8 @@ void launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images,
     }
     static const bool stream_env = !getenv("MSORB_BLUR_GENERIC");  // tuning / test aid
     const bool stream = aligned && stream_env;
+    // strip height 35: 21..35 rows measure the same (0.29 ms / 256 images), 70 and 140 are slower (too few waves)
+    const int rows = kGaussRows;
     int total = 0, max_h = 0;
     for (int l = 0; l < src.nlevels; l++) {
         const LevelView& v = src.lv[l];
@@ -1059,12 +1062,12 @@ void launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images,
         // aligned path: 62 stored groups per wave; generic path: 64 groups per wave
         const int main_groups = v.w >= 16 ? (v.w - 16) / 4 + 1 : 0;  // groups with x0 + 16 <= w
         plan.bx_count[l] = stream ? max(1, (main_groups + kGaussLanesOut - 1) / kGaussLanesOut) : (v.w + 255) / 256;
-        const int strips = (v.h + kGaussRows - 1) / kGaussRows;
+        const int strips = (v.h + rows - 1) / rows;
         total += plan.bx_count[l] * ((strips + 3) / 4);
         max_h = max(max_h, v.h);
     }
     plan.block_begin[src.nlevels] = total;
-    if (stream) hipLaunchKernelGGL(gauss7_stream_kernel, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
+    if (stream) hipLaunchKernelGGL(gauss7_stream_kernel<kGaussRows>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
     else if (aligned) hipLaunchKernelGGL(gauss7_kernel<true>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
     else hipLaunchKernelGGL(gauss7_kernel<false>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
     hipLaunchKernelGGL(gauss7_edge_kernel, dim3((max_h + kEdgeRows - 1) / kEdgeRows, src.nlevels, n_images), dim3(64), 0, s, src, dst);
