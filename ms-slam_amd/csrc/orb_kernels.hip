@@ -94,6 +94,85 @@ __global__ __launch_bounds__(256) void pyr_resize_aligned_kernel(LevelView src, 
     *reinterpret_cast<uint32_t*>(d) = packed;
 }
 
+// Row-streaming variant for batches: a wave produces R consecutive output rows of its 64 column groups.  The x taps
+// are decoded once per thread instead of once per output dword, and the horizontally interpolated source rows are
+// kept in registers: at scale 1.2 consecutive output rows share one of their two source rows (i0(dy+1) == i1(dy) five
+// times out of six), so each source row is fetched and interpolated once, not twice.  The raw dwords of the next
+// source row are prefetched while the current output row is blended.  Same integer arithmetic as the kernels above.
+template <int R>
+__global__ __launch_bounds__(256) void pyr_resize_rows_kernel(LevelView src, LevelView dst, uint8_t* __restrict__ dst_base,
+                                                              const ResizeTap* __restrict__ tx,
+                                                              const ResizeTap* __restrict__ ty) {
+    const int img = blockIdx.z;
+    const int dy0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + (threadIdx.x >> 6)) * R);
+    const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    if (dy0 >= dst.h || dx0 >= dst.w) return;
+    const int dy_end = min(dy0 + R, dst.h);
+    const uint4 ta = reinterpret_cast<const uint4*>(tx + dx0)[0];
+    const uint4 tb = reinterpret_cast<const uint4*>(tx + dx0)[1];
+    const uint32_t tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};  // per tap: {i0|i1<<16, c0|c1<<16}
+    const int base = (int)(tw[0] & 0xffffu) & ~3;  // aligned column of the first source pixel
+    int off[4], sh[4], c0[4], c1[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int i0 = (int)(tw[2 * i] & 0xffffu), i1 = (int)(tw[2 * i] >> 16);
+        off[i] = i0 - base;
+        sh[i] = (i1 != i0) ? 8 : 0;  // second tap = next pixel, except at the right edge where i1 == i0 (and c1 == 0)
+        c0[i] = (int)(int16_t)(tw[2 * i + 1] & 0xffffu);
+        c1[i] = (int)(int16_t)(tw[2 * i + 1] >> 16);
+    }
+    const uint8_t* sb = src.base + (size_t)img * src.img_stride;
+    struct Raw { uint32_t w0, w1, w2; };
+    auto fetch = [&](int sy) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(sb + (size_t)sy * src.pitch + (size_t)(uint32_t)base);
+        return Raw{q[0], q[1], q[2]};
+    };
+    auto hrow = [&](const Raw& r, int H[4]) {  // (src[i0]*c0 + src[i1]*c1) >> 4 for the 4 columns of this thread
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t pa = pick2(r.w0, r.w1, r.w2, off[i]);
+            H[i] = ((int)(pa & 255u) * c0[i] + (int)((pa >> sh[i]) & 255u) * c1[i]) >> 4;
+        }
+    };
+    uint8_t* d = dst_base + (size_t)img * dst.img_stride + (size_t)(uint32_t)dx0;
+    const int last_src = src.h - 1;
+    int HA[4], HB[4];   // interpolated source rows ia (upper) and ib (lower) of the current output row
+    int ia = -1, ib = -1;
+    Raw pre = fetch(ty[dy0].i0);
+    int ipre = ty[dy0].i0;  // source row held raw in `pre`
+    for (int dy = dy0; dy < dy_end; dy++) {
+        const ResizeTap vy = ty[dy];  // wave-uniform: scalar loads
+        const int n0 = vy.i0, n1 = vy.i1;
+        if (n0 == ib) {               // common case: the lower row of the previous output row becomes the upper one
+#pragma unroll
+            for (int i = 0; i < 4; i++) HA[i] = HB[i];
+        } else if (n0 != ia) {
+            const Raw r = (n0 == ipre) ? pre : fetch(n0);
+            hrow(r, HA);
+        }
+        ia = n0;
+        if (n1 == n0) {               // bottom clamp: both taps on one row
+#pragma unroll
+            for (int i = 0; i < 4; i++) HB[i] = HA[i];
+        } else {
+            const Raw r = (n1 == ipre) ? pre : fetch(n1);
+            hrow(r, HB);
+        }
+        ib = n1;
+        if (dy + 1 < dy_end) {        // the next output row needs ib (held) and, almost always, ib + 1
+            ipre = min(ib + 1, last_src);
+            pre = fetch(ipre);
+        }
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int v = (((vy.c0 * HA[i]) >> 16) + ((vy.c1 * HB[i]) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 255) << (8 * i);
+        }
+        *reinterpret_cast<uint32_t*>(d + (size_t)dy * dst.pitch) = packed;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // FAST-9/16 on one reference cell ROI per workgroup (cell loop + cv::FAST, ORBextractor.cc:805-872).
 //   phase 0  stage the ROI (<= 76x76 bytes) in LDS, keeping the global 4-byte column phase so that every
@@ -1014,7 +1093,12 @@ void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_
     const bool aligned = (reinterpret_cast<uintptr_t>(src.base) & 3) == 0 && (src.pitch & 3) == 0 &&
                          (src.img_stride & 3) == 0 && src.pitch >= ((src.w + 3) & ~3) + 8 &&
                          (reinterpret_cast<uintptr_t>(tx) & 15) == 0;
-    if (aligned) hipLaunchKernelGGL(pyr_resize_aligned_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
+    constexpr int R = 8;  // rows per wave: 4 / 8 / 16 / 32 measure 0.247 / 0.237 / 0.244 / 0.285 ms per 256 KITTI images
+    static const bool rows_env = !getenv("MSORB_PYR_SINGLE");  // test aid
+    if (aligned && rows_env && n_images >= 16)
+        hipLaunchKernelGGL(pyr_resize_rows_kernel<R>, dim3((dst.w + 255) / 256, (dst.h + 4 * R - 1) / (4 * R), n_images), dim3(256),
+                           0, s, src, dst, dst_base, tx, ty);
+    else if (aligned) hipLaunchKernelGGL(pyr_resize_aligned_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
     else hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
 }
 void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cells, int ini_th, int min_th,

@@ -153,6 +153,35 @@ def test_large_batch_uses_overlapped_sub_batches(msorb_mod, oracle):
     ex.close()
 
 
+def test_batch_kernels_full_size(msorb_mod, oracle):
+    """Batches of >= 16 images switch to the row-streaming pyramid kernel (and the streaming blur): KITTI geometry,
+    one sub-batch, checked against the oracle on a sample of the images and against each other on all."""
+    import torch
+    cfg = CONFIGS["kitti"]
+    ex, ref = _pair(msorb_mod, oracle, cfg)
+    n = 16
+    batch = np.stack([synth.image(700 + (i % 4), cfg["rows"], cfg["cols"]) for i in range(n)])
+    d = torch.from_numpy(batch).cuda()
+    ex.set_overlap(1, False)
+    counts, mono, d_kps, d_desc = ex.extract_batch(d)
+    kps_list = msorb_mod.keypoints_from_device(d_kps, counts)
+    desc_all = d_desc.cpu().numpy()
+    for i in (0, 1, 2, 3):
+        rmono, rkps, rdesc = ref(batch[i])
+        assert counts[i] == len(rkps) and mono[i] == rmono
+        _assert_same(kps_list[i], desc_all[i, :counts[i]], rkps, rdesc)
+    for i in range(4, n):   # copies of the first four images
+        assert counts[i] == counts[i % 4]
+        assert np.array_equal(desc_all[i, :counts[i]], desc_all[i % 4, :counts[i]])
+    ex2, ref2 = _pair(msorb_mod, oracle, cfg)
+    ref2(batch[n - 1])
+    for lvl in range(1, cfg["nlevels"]):   # pyramid / blurred planes of the last image vs the oracle
+        assert np.array_equal(ex.debug_level(n - 1, lvl), ref2.level(lvl)), lvl
+        assert np.array_equal(ex.debug_level(n - 1, lvl, blurred=True), ref2.level(lvl, blurred=True)), lvl
+    ex2.close()
+    ex.close()
+
+
 def test_host_quadtree_mode_matches(msorb_mod, oracle, monkeypatch):
     """MSORB_QUADTREE=host keeps the selection on the host thread pool (orb_host.cc); same result."""
     monkeypatch.setenv("MSORB_QUADTREE", "host")
