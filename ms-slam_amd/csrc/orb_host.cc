@@ -122,6 +122,15 @@ bool FrameGeom::build(const OrbParams& p, int rows_, int cols_) {
                 c.slot_off = slot;
                 c.slot_cap = ((dw + 1) / 2) * ((dh + 1) / 2);  // strict 3x3 NMS: no two survivors are 8-adjacent
                 slot += c.slot_cap;
+                {
+                    const int ga = c.x0 & ~3, x_lo = c.x0 + 3, x_hi = c.x0 + c.rw - 3, gx0 = x_lo & ~3;
+                    const int G = std::max((x_hi - gx0 + 3) >> 2, 1), ndw = std::max((c.x0 + c.rw - ga + 3) >> 2, 1);
+                    c.G = (int16_t)G;
+                    c.ndw = (int16_t)ndw;
+                    c.g_magic = ((1u << 20) + G - 1) / G;
+                    c.ndw_magic = ((1u << 20) + ndw - 1) / ndw;
+                    c.rw_magic = ((1u << 20) + std::max<int>(c.rw, 1) - 1) / std::max<int>(c.rw, 1);
+                }
                 cells.push_back(c);
             }
         }

@@ -40,6 +40,11 @@ struct CellDesc {  // one FAST cell of ComputeKeyPointsOctTree (ORBextractor.cc:
     int16_t pad;
     int32_t slot_off;  // first candidate slot of this cell inside one image's slot block
     int32_t slot_cap;  // worst-case number of NMS survivors
+    // FAST kernel constants of the cell, precomputed here so that no workgroup spends instructions on integer division:
+    // G = 4-pixel groups per detection row, ndw = dwords per staged ROI row, *_magic = ceil(2^20 / divisor)
+    // (q = (n * magic) >> 20 is exact for the kernel's ranges: n < 2^12)
+    uint32_t g_magic, ndw_magic, rw_magic;
+    int16_t G, ndw;
 };
 
 struct LevelGeom {

@@ -290,7 +290,7 @@ template <bool ALIGNED, class GEO>
 __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView pyr, const CellDesc* __restrict__ cells,
                                                          int ini_th, int min_th, int slots_per_image,
                                                          Cand16* __restrict__ slots, int* __restrict__ cell_count,
-                                                         int n_cells, int debug_stop) {
+                                                         int n_cells, uint32_t gx_magic, int debug_stop) {
     __shared__ __attribute__((aligned(16))) uint8_t tile_mem[kTileFront + GEO::kTileRows * GEO::kTilePitch + 8];
     __shared__ __attribute__((aligned(16))) uint8_t score[GEO::kScoreRows * GEO::kScorePitch];
     __shared__ uint16_t work[GEO::kWorkCap];
@@ -306,8 +306,8 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
     const unsigned chunk = (total + 7) >> 3;
     unsigned wg = (lin & 7u) * chunk + (lin >> 3);
     if (total & 7u) wg = lin;  // ragged totals keep the plain order (bench / test geometries are multiples of 8 images)
-    const int cell_id = wg % gridDim.x;
-    const int img = wg / gridDim.x;
+    const int img = gx_magic ? (int)__umulhi(wg, gx_magic) : (int)(wg / gridDim.x);  // host-checked exact reciprocal
+    const int cell_id = (int)(wg - (unsigned)img * gridDim.x);
     const CellDesc cd = cells[cell_id];
     const LevelView lv = pyr.lv[cd.level];
     const int rw = cd.rw, rh = cd.rh;
@@ -316,10 +316,10 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
     const int ga = cd.x0 & ~3;            // tile column 0 = level column ga (keeps the 4-byte phase)
     const int x_lo = cd.x0 + 3, x_hi = cd.x0 + rw - 3;
     const int gx0 = x_lo & ~3;            // first 4-pixel group (may start left of x_lo)
-    const int G = (x_hi - gx0 + 3) >> 2;  // groups per detection row
+    const int G = cd.G;                   // groups per detection row = (x_hi - gx0 + 3) >> 2
     const int c_lo = gx0 - ga;            // tile column of the first group (multiple of 4)
     const int n_task = dh * G;            // one task = one group of one detection row, scan order
-    const uint32_t magic = ((1u << 20) + G - 1) / G;  // task / G == (task * magic) >> 20 for task < 2^20 / G
+    const uint32_t magic = cd.g_magic;    // task / G == (task * magic) >> 20 for task < 2^20 / G
     // balanced consecutive task ranges: thread t owns tasks [t*n/T, (t+1)*n/T)  (<= kMaxRounds each)
     const int t_begin = (int)(__umul24((uint32_t)tid, (uint32_t)n_task) / GEO::kThreads),
               t_end = (int)(__umul24((uint32_t)tid + 1u, (uint32_t)n_task) / GEO::kThreads);
@@ -327,8 +327,8 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
     // phase 0
     const uint8_t* src = lv.base + (size_t)img * lv.img_stride + (size_t)cd.y0 * lv.pitch;
     if (ALIGNED) {
-        const int ndw = (cd.x0 + rw - ga + 3) >> 2;  // dwords per tile row
-        const uint32_t dmagic = ((1u << 20) + ndw - 1) / ndw;
+        const int ndw = cd.ndw;  // dwords per tile row = (x0 + rw - ga + 3) >> 2
+        const uint32_t dmagic = cd.ndw_magic;
         for (int i = tid; i < rh * ndw; i += GEO::kThreads) {
             // 24-bit multiplies are full rate (v_mul_lo_u32 / 64-bit mads are quarter rate); scalar base + 32-bit offset
             const int y = (int)(__umul24((uint32_t)i, dmagic) >> 20), c = i - (int)__umul24((uint32_t)y, (uint32_t)ndw);
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
         }
     } else {
         const int off = cd.x0 - ga;
-        const uint32_t bmagic = ((1u << 20) + rw - 1) / rw;
+        const uint32_t bmagic = cd.rw_magic;
         for (int i = tid; i < rh * rw; i += GEO::kThreads) {
             const int y = (int)(__umul24((uint32_t)i, bmagic) >> 20), x = i - (int)__umul24((uint32_t)y, (uint32_t)rw);
             tile[(int)__umul24((uint32_t)y, GEO::kTilePitch) + off + x] = src[(size_t)(__umul24((uint32_t)y, (uint32_t)lv.pitch) + (uint32_t)(cd.x0 + x))];
@@ -1110,9 +1110,16 @@ void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cell
     }
     static const int dbg = getenv("MSORB_FAST_DEBUG_STOP") ? atoi(getenv("MSORB_FAST_DEBUG_STOP")) : 0;  // profiling only
     const dim3 grid(n_cells, n_images);
+    // q = mulhi(n, gx_magic) == n / n_cells for every n < n_cells * n_images (checked here, once per shape)
+    uint32_t gx_magic = (uint32_t)((0x100000000ull + (unsigned)n_cells - 1) / (unsigned)n_cells);
+    {
+        const unsigned long long total = (unsigned long long)n_cells * (unsigned)n_images;
+        const unsigned long long e = (unsigned long long)gx_magic * (unsigned)n_cells - 0x100000000ull;  // < n_cells
+        if (n_cells < 2 || total >= 0x100000000ull || e * total >= 0x100000000ull) gx_magic = 0;  // kernel divides instead
+    }
 #define MSORB_FAST_LAUNCH(AL, GEO)                                                                                        \
     hipLaunchKernelGGL((fast_cells_kernel<AL, GEO>), grid, dim3(GEO::kThreads), 0, s, pyr, cells, ini_th, min_th, slots_per_image, slots, \
-                       cell_count, n_cells, dbg)
+                       cell_count, n_cells, gx_magic, dbg)
     if (small_cells) { if (aligned) MSORB_FAST_LAUNCH(true, GeoSmall); else MSORB_FAST_LAUNCH(false, GeoSmall); }
     else { if (aligned) MSORB_FAST_LAUNCH(true, GeoLarge); else MSORB_FAST_LAUNCH(false, GeoLarge); }
 #undef MSORB_FAST_LAUNCH
