@@ -280,43 +280,84 @@ void launch_stereo_match(const StereoArgs& a, hipStream_t s) {
 // '<' (best = lexicographic min of (distance, index), second = the runner-up).  One thread per query, the
 // frame's train descriptors staged once per workgroup in LDS (<= 2048 x 32 B = 64 KB) and broadcast-read.
 constexpr int kDenseMaxTrain = 2048;
-__global__ __launch_bounds__(256) void dense_top2_kernel(const uint8_t* __restrict__ q, const uint8_t* __restrict__ t,
+constexpr int kDenseQPL = 2;    // queries per lane: one LDS broadcast read of a train descriptor serves two pairs per lane
+constexpr int kDenseSplit = 2;  // the train range is split over this many 256-thread halves of a workgroup (merged at the
+                                // end): twice the waves for the same LDS tile — a batch of 128 frames has only 2 waves per
+                                // SIMD otherwise, too few to cover the popcount-accumulate dependency chains
+__global__ __launch_bounds__(256 * kDenseSplit) void dense_top2_kernel(const uint8_t* __restrict__ q, const uint8_t* __restrict__ t,
                                                         const int* __restrict__ n_q, const int* __restrict__ n_t,
                                                         int q_stride, int t_stride, int* __restrict__ best_idx,
                                                         int* __restrict__ best_dist, int* __restrict__ second_dist) {
     extern __shared__ __attribute__((aligned(16))) uint64_t tile[];
     const int frame = blockIdx.y;
     const int nq = n_q[frame], nt = min(n_t[frame], kDenseMaxTrain);
-    const int qi = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x * 256 >= nq) return;
+    const int q0 = blockIdx.x * (256 * kDenseQPL);
+    if (q0 >= nq) return;
     const uint64_t* ts = reinterpret_cast<const uint64_t*>(t + (size_t)frame * t_stride * 32);
-    for (int i = threadIdx.x; i < nt * 4; i += 256) tile[i] = ts[i];
+    for (int i = threadIdx.x; i < nt * 4; i += 256 * kDenseSplit) tile[i] = ts[i];
     __syncthreads();
-    if (qi >= nq) return;
-    const uint64_t* qp = reinterpret_cast<const uint64_t*>(q + ((size_t)frame * q_stride + qi) * 32);
-    const uint64_t a0 = qp[0], a1 = qp[1], a2 = qp[2], a3 = qp[3];
-    uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;  // (dist << 16) | index
-#pragma unroll 4
-    for (int j = 0; j < nt; j++) {
-        const int d = __popcll(a0 ^ tile[4 * j]) + __popcll(a1 ^ tile[4 * j + 1]) + __popcll(a2 ^ tile[4 * j + 2]) +
-                      __popcll(a3 ^ tile[4 * j + 3]);
-        const uint32_t key = ((uint32_t)d << 16) | (uint32_t)j;
-        const uint32_t lo = min(key, k0), hi = max(key, k0);
-        k0 = lo;
-        k1 = min(k1, hi);
+    const int part = threadIdx.x >> 8, l = threadIdx.x & 255;
+    const int per = (nt + kDenseSplit - 1) / kDenseSplit;
+    const int jb = part * per, je = min(jb + per, nt);
+    uint64_t a[kDenseQPL][4];
+    uint32_t k0[kDenseQPL], k1[kDenseQPL];  // (dist << 16) | index
+#pragma unroll
+    for (int u = 0; u < kDenseQPL; u++) {
+        const int qi = min(q0 + u * 256 + l, nq - 1);  // lanes past the end repeat the last query, no store
+        const uint64_t* qp = reinterpret_cast<const uint64_t*>(q + ((size_t)frame * q_stride + qi) * 32);
+        a[u][0] = qp[0]; a[u][1] = qp[1]; a[u][2] = qp[2]; a[u][3] = qp[3];
+        k0[u] = k1[u] = 0xFFFFFFFFu;
     }
-    const size_t o = (size_t)frame * q_stride + qi;
-    best_idx[o] = k0 == 0xFFFFFFFFu ? -1 : (int)(k0 & 0xFFFF);
-    best_dist[o] = k0 == 0xFFFFFFFFu ? 256 : (int)(k0 >> 16);
-    second_dist[o] = k1 == 0xFFFFFFFFu ? 256 : (int)(k1 >> 16);
+#pragma unroll 4
+    for (int j = jb; j < je; j++) {
+        const uint64_t t0 = tile[4 * j], t1 = tile[4 * j + 1], t2 = tile[4 * j + 2], t3 = tile[4 * j + 3];
+#pragma unroll
+        for (int u = 0; u < kDenseQPL; u++) {
+            const int d = __popcll(a[u][0] ^ t0) + __popcll(a[u][1] ^ t1) + __popcll(a[u][2] ^ t2) + __popcll(a[u][3] ^ t3);
+            const uint32_t key = ((uint32_t)d << 16) | (uint32_t)j;
+            const uint32_t lo = min(key, k0[u]), hi = max(key, k0[u]);
+            k0[u] = lo;
+            k1[u] = min(k1[u], hi);
+        }
+    }
+    // merge the parts: keys are unique (distinct indices), so top-2 of the union = {min(a0,b0), min(max(a0,b0), min(a1,b1))}
+    __syncthreads();  // everyone is done reading the tile; it becomes the exchange buffer
+    uint32_t* xch = reinterpret_cast<uint32_t*>(tile);
+    if (part > 0) {
+#pragma unroll
+        for (int u = 0; u < kDenseQPL; u++) {
+            xch[((part - 1) * kDenseQPL + u) * 512 + l] = k0[u];
+            xch[((part - 1) * kDenseQPL + u) * 512 + 256 + l] = k1[u];
+        }
+    }
+    __syncthreads();
+    if (part > 0) return;
+#pragma unroll
+    for (int u = 0; u < kDenseQPL; u++) {
+#pragma unroll
+        for (int p2 = 1; p2 < kDenseSplit; p2++) {
+            const uint32_t b0 = xch[((p2 - 1) * kDenseQPL + u) * 512 + l], b1 = xch[((p2 - 1) * kDenseQPL + u) * 512 + 256 + l];
+            const uint32_t lo = min(k0[u], b0), hi = max(k0[u], b0);
+            k1[u] = min(hi, min(k1[u], b1));
+            k0[u] = lo;
+        }
+        const int qi = q0 + u * 256 + l;
+        if (qi >= nq) continue;
+        const size_t o = (size_t)frame * q_stride + qi;
+        best_idx[o] = k0[u] == 0xFFFFFFFFu ? -1 : (int)(k0[u] & 0xFFFF);
+        best_dist[o] = k0[u] == 0xFFFFFFFFu ? 256 : (int)(k0[u] >> 16);
+        second_dist[o] = k1[u] == 0xFFFFFFFFu ? 256 : (int)(k1[u] >> 16);
+    }
 }
 
 void launch_dense_top2(const uint8_t* q, const uint8_t* t, const int* n_q, const int* n_t, int n_frames, int q_stride,
                        int t_stride, int max_q, int max_t, int* bi, int* bd, int* sd, hipStream_t s) {
     if (n_frames <= 0 || max_q <= 0) return;
-    const size_t lds = (size_t)min(max_t, kDenseMaxTrain) * 32;
-    hipLaunchKernelGGL(dense_top2_kernel, dim3((max_q + 255) / 256, n_frames), dim3(256), lds, s, q, t, n_q, n_t, q_stride,
-                       t_stride, bi, bd, sd);
+    // tile of the train descriptors; at least the exchange buffer of the final merge
+    const size_t lds = std::max<size_t>((size_t)min(max_t, kDenseMaxTrain) * 32, (size_t)(kDenseSplit - 1) * kDenseQPL * 512 * 4);
+    const int per_block = 256 * kDenseQPL;
+    hipLaunchKernelGGL(dense_top2_kernel, dim3((max_q + per_block - 1) / per_block, n_frames), dim3(256 * kDenseSplit), lds, s, q, t,
+                       n_q, n_t, q_stride, t_stride, bi, bd, sd);
 }
 
 }  // namespace msorb
