@@ -222,12 +222,14 @@ def main():
         # committed rocprofv3 --pmc measurement of the same command (profiles/round1_pmc_summary.json, separate
         # FETCH_SIZE / WRITE_SIZE passes, per launch) — only quoted when the batch shape matches
         traffic = None
-        kname = {"fast": "fast_cells_kernel<true, GeoSmall>", "pyramid": "pyr_resize_aligned_kernel", "blur": "gauss7_kernel<true>",
+        kname = {"fast": "fast_cells_kernel<true, GeoSmall>", "pyramid": "pyr_resize_rows_kernel<8>", "blur": "gauss7_stream_kernel<35>",
                  "describe": "describe_kernel", "compact": "cand_gather_kernel"}[dom]
+        valu_frac = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_summary.json")))["kernels"][kname]
             if B == 128 and world == 1:
                 traffic = int((pm["FETCH_SIZE_KB"] + pm["WRITE_SIZE_KB"]) * 1024) * (7 if dom == "pyramid" else 1)
+                valu_frac = pm.get("valu_fraction_of_measured_peak")
         except Exception:
             traffic = None
         out = {
@@ -259,7 +261,10 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (profiles/round1_pmc_summary.json); "
                                          "below the algorithmic bytes because the pyramid written just before is still in the 256 MB Infinity Cache",
-                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "valu_fraction_of_measured_peak": valu_frac,
+                         "valu_note": "what actually bounds this kernel: 64 x SQ_INSTS_VALU / duration against the 51.5 T lane-ops/s "
+                                      "the VALUs sustain (103 TFLOP/s v_fma_f32), from the committed PMC pass of the same command"},
             "pyramid_fast_gbs": round((sum(px[:-1]) + sum(px[1:]) + sum(px)) * n_img /
                                       ((stages["pyramid"] + stages["fast"]) * 1e-3) / 1e9, 2),
         }

@@ -1,1 +1,9 @@
-for v in 2_4 4_4 4_2; do cp ms-slam_amd/libmsorb_$v.so ms-slam_amd/libmsorb.so; echo "QPL_SPLIT=$v $(python bench.py --steps 3 --warmup 1 --cpu-pairs 0 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.readline()); print(d["hamming_match"]["gpairs_per_s"])')"; done
+set -x
+python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+python bench.py > gpurun_out/bench_r1.json 2> gpurun_out/bench_r1.err; tail -c 1500 gpurun_out/bench_r1.json
+tools/gpu_trace.sh prof_r1g > gpurun_out/trace_r1g.txt 2>&1; tail -25 gpurun_out/trace_r1g.txt
+tools/gpu_pmc.sh pmc_fetch "FETCH_SIZE" "" > gpurun_out/pmc_fetch.txt 2>&1
+tools/gpu_pmc.sh pmc_write "WRITE_SIZE" "" > gpurun_out/pmc_write.txt 2>&1
+tools/gpu_pmc.sh pmc_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE" "" > gpurun_out/pmc_valu.txt 2>&1
+python tools/latency_bench.py > gpurun_out/latency_r1.json 2>gpurun_out/latency_r1.err; cat gpurun_out/latency_r1.json
+python tools/bow_bench.py > gpurun_out/bow_bench.json 2>/dev/null; cat gpurun_out/bow_bench.json
