@@ -1,6 +1,8 @@
-set -x
+#!/bin/bash
+# The full measurement run of a round, on the GPU box:  gpurun --timeout 1500 -- 'bash tools/round_run.sh'
+# then, back in the container:  python tools/collect_profiles.py round1   (copies the summaries into profiles/)
 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-python bench.py > gpurun_out/bench_r1.json 2> gpurun_out/bench_r1.err; tail -c 1500 gpurun_out/bench_r1.json
+python bench.py > gpurun_out/bench_r1.json 2> gpurun_out/bench_r1.err; tail -c 600 gpurun_out/bench_r1.json
 tools/gpu_trace.sh prof_r1g > gpurun_out/trace_r1g.txt 2>&1; tail -25 gpurun_out/trace_r1g.txt
 tools/gpu_pmc.sh pmc_fetch "FETCH_SIZE" "" > gpurun_out/pmc_fetch.txt 2>&1
 tools/gpu_pmc.sh pmc_write "WRITE_SIZE" "" > gpurun_out/pmc_write.txt 2>&1
