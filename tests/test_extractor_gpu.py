@@ -153,11 +153,13 @@ def test_large_batch_uses_overlapped_sub_batches(msorb_mod, oracle):
     ex.close()
 
 
-def test_batch_kernels_full_size(msorb_mod, oracle):
-    """Batches of >= 16 images switch to the row-streaming pyramid kernel (and the streaming blur): KITTI geometry,
-    one sub-batch, checked against the oracle on a sample of the images and against each other on all."""
+@pytest.mark.parametrize("name", ["kitti", "euroc", "fourseasons", "odd"])
+def test_batch_kernels_full_size(msorb_mod, oracle, name):
+    """Batches of >= 16 images switch to the row-streaming pyramid kernel (and the streaming blur): every dataset
+    geometry plus an odd-sized one (width not a multiple of 4), one sub-batch, checked against the oracle on a sample
+    of the images and against each other on all."""
     import torch
-    cfg = CONFIGS["kitti"]
+    cfg = CONFIGS[name] if name != "odd" else dict(rows=333, cols=517, nfeatures=700, scale=1.2, nlevels=8, ini_th=20, min_th=7)
     ex, ref = _pair(msorb_mod, oracle, cfg)
     n = 16
     batch = np.stack([synth.image(700 + (i % 4), cfg["rows"], cfg["cols"]) for i in range(n)])

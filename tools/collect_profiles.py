@@ -47,7 +47,14 @@ json.dump({"note": "rocprofv3 --pmc, per-launch averages of `bench.py --isolated
                    "same command's kernel trace; its fraction is against 51.5 T lane-ops/s (the guide's measured 103 TFLOP/s "
                    "v_fma_f32 = the VALU issue rate the chip sustains)", "kernels": kern},
           open(os.path.join(P, f"{rnd}_pmc_summary.json"), "w"), indent=1)
-shutil.copy(os.path.join(G, "latency_r1.json"), os.path.join(P, f"{rnd}_latency_per_frame.json"))
+lat = json.load(open(os.path.join(G, "latency_r1.json")))
+try:
+    lat["cpp_two_threads"] = json.load(open(os.path.join(G, "latency_pair.json")))
+    lat["cpp_two_threads"]["note"] = ("tools/latency_pair.cc: msorb_extract from two fresh std::threads per frame, one handle per "
+                                      "eye, like Frame.cc:122-125; the Python figure above includes interpreter thread overhead")
+except Exception:
+    pass
+json.dump(lat, open(os.path.join(P, f"{rnd}_latency_per_frame.json"), "w"), indent=1)
 shutil.copy(os.path.join(G, "bow_bench.json"), os.path.join(P, f"{rnd}_bow_bench.json"))
 print("value", bench["value"], "ms/step", bench["ms_per_step"], bench["stage_ms_per_step"])
 for k, e in kern.items():

@@ -9,3 +9,4 @@ tools/gpu_pmc.sh pmc_write "WRITE_SIZE" "" > gpurun_out/pmc_write.txt 2>&1
 tools/gpu_pmc.sh pmc_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE" "" > gpurun_out/pmc_valu.txt 2>&1
 python tools/latency_bench.py > gpurun_out/latency_r1.json 2>gpurun_out/latency_r1.err; cat gpurun_out/latency_r1.json
 python tools/bow_bench.py > gpurun_out/bow_bench.json 2>/dev/null; cat gpurun_out/bow_bench.json
+g++ -O2 -std=c++17 tools/latency_pair.cc -Iinclude -Lms-slam_amd -lmsorb -lpthread -o /tmp/latency_pair 2>/dev/null && LD_LIBRARY_PATH=ms-slam_amd:/opt/rocm/lib /tmp/latency_pair 300 > gpurun_out/latency_pair.json; cat gpurun_out/latency_pair.json
