@@ -118,12 +118,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    # test aid: MSORB_DIST_BACKEND=gloo lets the N>1 path run with several ranks on ONE GPU (ranks share cuda:0, the
+    # exchange goes through gloo) — how the stereo-split code path is exercised on the 1-GPU development box
+    backend = os.environ.get("MSORB_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     B = args.pairs
     # images of this rank: N=1 -> L,R interleaved (2B images); N>1 -> one eye of 2B pairs (2B images): fixed per-GPU work
@@ -150,22 +158,35 @@ def main():
     d_kps = torch.empty((n_img, cap, 28), dtype=torch.uint8, device=dev)
     d_desc = torch.empty((n_img, cap, 32), dtype=torch.uint8, device=dev)
     from msorb import stereo_split
+    # N>1: two send/receive blocks used alternately, so that the exchange of step k (RCCL, torch's communication stream)
+    # overlaps the extraction of step k+1 (the library's own streams) without the two touching the same memory
     mine = theirs = None
+    pending = [[], []]
     if world > 1:
-        mine = stereo_split.FeatureBlock(n_img, cap, dev)
-        d_kps, d_desc = mine.kps, mine.desc          # the extractor writes straight into the send block
-        if eye == 0:
-            theirs = stereo_split.FeatureBlock(n_img, cap, dev)
+        mine = [stereo_split.FeatureBlock(n_img, cap, dev) for _ in range(2)]
+        theirs = [stereo_split.FeatureBlock(n_img, cap, dev) if eye == 0 else None for _ in range(2)]
+    step_no = [0]
 
     def step():
-        counts, mono, _, _ = ex.extract_batch(images, (0, 0), out=(d_kps, d_desc))
-        if world > 1:  # stereo split: right-eye rank -> left-eye rank (replaces the join of Frame.cc:122-125)
-            mine.counts.copy_(torch.from_numpy(counts))
-            stereo_split.exchange(dist, rank, world, mine, theirs)
+        if world == 1:
+            counts, mono, _, _ = ex.extract_batch(images, (0, 0), out=(d_kps, d_desc))
+            return int(counts.sum())
+        b = step_no[0] & 1
+        step_no[0] += 1
+        stereo_split.finish(pending[b])          # the block's previous exchange (two steps ago) must be over
+        pending[b] = []
+        # the extractor writes straight into the send block
+        counts, mono, _, _ = ex.extract_batch(images, (0, 0), out=(mine[b].kps, mine[b].desc))
+        # stereo split: right-eye rank -> left-eye rank (replaces the join of Frame.cc:122-125)
+        mine[b].counts.copy_(torch.from_numpy(counts))
+        pending[b] = stereo_split.exchange_async(dist, rank, world, mine[b], theirs[b])
         return int(counts.sum())
 
     def fence():
         if world > 1:
+            for b in range(2):
+                stereo_split.finish(pending[b])
+                pending[b] = []
             dist.barrier()
         torch.cuda.synchronize()
 

@@ -48,3 +48,24 @@ def exchange(dist, rank, world, mine, theirs):
     for t in theirs.tensors():
         dist.recv(t, p)
     return True
+
+
+def exchange_async(dist, rank, world, mine, theirs):
+    """Non-blocking form of exchange(): returns the list of Work handles (empty without a partner).  The caller must
+    not touch `mine` (sender) / `theirs` (receiver) until finish() has returned for these handles — the extraction
+    kernels run on the library's own HIP streams, which torch does not order against its communication stream."""
+    p = partner_of(rank, world)
+    if p is None:
+        return []
+    if eye_of(rank) == 1:
+        return [dist.isend(t, p) for t in mine.tensors()]
+    return [dist.irecv(t, p) for t in theirs.tensors()]
+
+
+def finish(works):
+    """Host-level completion of exchange_async handles (Work.wait() alone only orders torch's current stream)."""
+    import torch
+    for w in works:
+        w.wait()
+    if works and torch.cuda.is_available():
+        torch.cuda.current_stream().synchronize()

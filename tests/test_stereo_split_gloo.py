@@ -39,6 +39,62 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_async(rank, world, port, q):
+    """bench.py's N>1 step loop: two blocks used alternately, exchange of step k in flight during step k+1."""
+    sys.path.insert(0, os.path.join(ROOT, "ms-slam_amd"))
+    os.environ["MSORB_NO_TORCH"] = "1"
+    from msorb import stereo_split as ss
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, cap = 4, 300
+    mine = [ss.FeatureBlock(n, cap, "cpu") for _ in range(2)]
+    theirs = [ss.FeatureBlock(n, cap, "cpu") for _ in range(2)]
+    pending = [[], []]
+    ok = True
+
+    def fill(blk, who, step):
+        g = torch.Generator().manual_seed(1000 * who + step)
+        blk.counts.copy_(torch.randint(0, cap, (n,), generator=g, dtype=torch.int32))
+        blk.kps.copy_(torch.randint(0, 256, blk.kps.shape, generator=g, dtype=torch.uint8))
+        blk.desc.copy_(torch.randint(0, 256, blk.desc.shape, generator=g, dtype=torch.uint8))
+
+    def check(b, step):
+        want = ss.FeatureBlock(n, cap, "cpu")
+        fill(want, ss.partner_of(rank, world), step)
+        return all(torch.equal(a, c) for a, c in zip(theirs[b].tensors(), want.tensors()))
+
+    steps = 5
+    for step in range(steps):
+        b = step & 1
+        ss.finish(pending[b])
+        if pending[b] and ss.eye_of(rank) == 0:
+            ok = ok and check(b, step - 2)       # what arrived two steps ago, before the block is reused
+        pending[b] = []
+        fill(mine[b], rank, step)                # "extraction" of this step into the free block
+        pending[b] = ss.exchange_async(dist, rank, world, mine[b], theirs[b])
+    for b in range(2):
+        ss.finish(pending[b])
+    if ss.eye_of(rank) == 0 and ss.partner_of(rank, world) is not None:
+        ok = ok and check((steps - 1) & 1, steps - 1) and check((steps - 2) & 1, steps - 2)
+    dist.barrier()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_stereo_split_async_double_buffer(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker_async, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(30)
+    assert res == {r: True for r in range(world)}
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_stereo_split_exchange(world):
     ctx = mp.get_context("spawn")
