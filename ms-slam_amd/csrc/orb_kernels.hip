@@ -384,12 +384,15 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
                 br[hsel] = as_u32(hi - __builtin_elementwise_max(pu, pd)) & as_u32(hi - __builtin_elementwise_max(pl, pr));
             }
             // sign bits: even half -> px0 (bit 15), px2 (bit 31); odd half -> px1, px3
-            const uint32_t d4 = ((dk[0] >> 15) & 1u) | ((dk[1] >> 14) & 2u) | ((dk[0] >> 29) & 4u) | ((dk[1] >> 28) & 8u);
-            const uint32_t b4 = ((br[0] >> 15) & 1u) | ((br[1] >> 14) & 2u) | ((br[0] >> 29) & 4u) | ((br[1] >> 28) & 8u);
+            // gather both halves at once: bits {0,1} = px0,px1 and {16,17} = px2,px3 (dark), the same 4 bits higher
+            // (bright); then fold the upper half down by 14
+            const uint32_t dz = ((dk[1] >> 14) & 0x00020002u) | ((dk[0] >> 15) & 0x00010001u);
+            const uint32_t bz = ((br[1] >> 14) & 0x00020002u) | ((br[0] >> 15) & 0x00010001u);
+            const uint32_t z = (bz << 4) | dz;
             const int xg = ga + c0;  // level column of pixel 0 of the group
             const int vlo = min(max(x_lo - xg, 0), 4), vhi = min(max(x_hi - xg, 0), 4);
-            const uint32_t m4 = ((1u << vhi) - 1u) & ~((1u << vlo) - 1u);
-            const uint32_t bits = (d4 & m4) | ((b4 & m4) << 4);
+            const uint32_t m4 = (0xFu << vlo) & (0xFu >> (4 - vhi)) & 0xFu;
+            const uint32_t bits = (z | (z >> 14)) & (m4 * 0x11u);
             M |= (uint64_t)bits << (8 * k);
             cnt += __popc(bits);
             if (++g == G) { g = 0; y++; }
