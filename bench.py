@@ -242,6 +242,22 @@ def main():
         hamming = {"gpairs_per_s": round(pairs * reps / (ms * 1e-3) / 1e9, 2), "pairs_per_launch": pairs,
                    "ms_per_launch": round(ms / reps, 4), "kernel": "dense_top2_kernel",
                    "bound": "integer VALU (xor + popcount), not HBM: (Q+T)*32 B per frame are reused Q*T times"}
+        if args.cpu_pairs > 0 and rank == 0:
+            # CPU leg of the matcher on a bounded sample: ORBmatcher::DescriptorDistance brute force (oracle, 1 thread) on
+            # the first stereo pair's descriptors; its result also cross-checks the GPU's indices and distances
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import orb_oracle
+            bi_g, bd_g, sd_g, _ = msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=1, device=local)
+            n0, n1 = int(counts_h[0]), int(counts_h[1])
+            q0, t0_ = dq[0, :n0].cpu().numpy(), dtr[0, :n1].cpu().numpy()
+            tc = time.perf_counter()
+            bi_c, bd_c, sd_c = orb_oracle.dense_top2(q0, t0_)
+            dtc = time.perf_counter() - tc
+            same = (np.array_equal(bi_c, bi_g[0, :n0].cpu().numpy()) and np.array_equal(bd_c, bd_g[0, :n0].cpu().numpy()) and
+                    np.array_equal(sd_c, sd_g[0, :n0].cpu().numpy()))
+            hamming["cpu_baseline"] = {"gpairs_per_s": round(n0 * n1 / dtc / 1e9, 4), "cores": 1, "kind": "port",
+                                       "sample": f"{n0} x {n1} descriptors of one stereo pair, {dtc * 1e3:.1f} ms",
+                                       "gpu_matches_cpu": bool(same)}
 
     if rank == 0:
         steps = max(args.steps, 1)

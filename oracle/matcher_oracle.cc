@@ -373,4 +373,18 @@ void orc_compute_stereo_matches(const void* kpsL_, int N, const uint8_t* descL, 
     }
 }
 
+// Dense brute-force top-2 (the BFMatcher::knnMatch(k=2) shape of Frame.cc:1076 on ORBmatcher::DescriptorDistance,
+// ORBmatcher.cc:2323-2339): candidates scanned in index order, strict '<'.  best_idx -1 / distances 256 when absent.
+void orc_dense_top2(const uint8_t* q, int nq, const uint8_t* t, int nt, int* best_idx, int* best_dist, int* second_dist) {
+    for (int i = 0; i < nq; i++) {
+        int b1 = 256, b2 = 256, bi = -1;
+        for (int j = 0; j < nt; j++) {
+            const int d = orc::descriptor_distance(q + (size_t)i * 32, t + (size_t)j * 32);
+            if (d < b1) { b2 = b1; b1 = d; bi = j; }
+            else if (d < b2) b2 = d;
+        }
+        best_idx[i] = bi; best_dist[i] = b1; second_dist[i] = b2;
+    }
+}
+
 }  // extern "C"

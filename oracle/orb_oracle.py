@@ -341,3 +341,15 @@ def is_in_frustum(frustum, pos_w, normal, max_distance, min_distance, viewing_co
                          _ptr(px), _ptr(py), _ptr(pxr), _ptr(dep), _ptr(lvl), _ptr(vc))
     return dict(track_in_view=inv[:n], proj_x=px[:n], proj_y=py[:n], proj_xr=pxr[:n], track_depth=dep[:n], level=lvl[:n],
                 view_cos=vc[:n])
+
+
+def dense_top2(q, t):
+    """oracle/matcher_oracle.cc orc_dense_top2 -> (best_idx, best_dist, second_dist)"""
+    Lb = _mlib()
+    Lb.orc_dense_top2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    Lb.orc_dense_top2.restype = None
+    qq, tt = _c(q, np.uint8).reshape(-1, 32), _c(t, np.uint8).reshape(-1, 32)
+    n = len(qq)
+    bi, bd, sd = (np.zeros(max(n, 1), np.int32) for _ in range(3))
+    Lb.orc_dense_top2(_ptr(qq), n, _ptr(tt), len(tt), _ptr(bi), _ptr(bd), _ptr(sd))
+    return bi[:n], bd[:n], sd[:n]
