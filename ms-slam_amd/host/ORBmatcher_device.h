@@ -1,0 +1,125 @@
+// Device back-end for the per-frame matcher call sites of MS-SLAM's tracking thread, written against the reference's
+// own types by name (templates: this header compiles inside MS-SLAM, where Frame / MapPoint / cv::Mat are the real
+// classes, and in tests/dropin_matcher_main.cc, where they are minimal stand-ins with the same member names).
+//
+//   ORB_SLAM3::msorb_host::DeviceFrame<Frame>            the members of Frame the matcher reads, resident on the GPU
+//   ORB_SLAM3::msorb_host::SearchByProjection(...)       body of ORBmatcher::SearchByProjection(Frame&, const
+//                                                        vector<shared_ptr<MapPoint>>&, th, bFarPoints, thFarPoints)
+//                                                        (src/ORBmatcher.cc:43-142, rectified / Nleft == -1 branch)
+//   ORB_SLAM3::msorb_host::ComputeStereoMatches(...)     body of Frame::ComputeStereoMatches (src/Frame.cc:743-913)
+//
+// Use inside the reference: ORBmatcher::SearchByProjection keeps its signature and becomes
+//     static thread_local msorb_host::DeviceFrame<Frame> dev;
+//     dev.Upload(F);
+//     return msorb_host::SearchByProjection(dev, F, vpMapPoints, th, bFarPoints, thFarPoints, mfNNratio);
+// Same return value, same F.mvpMapPoints afterwards (same candidate sets, scan order, ratio test, sequential claims).
+#ifndef MSORB_ORBMATCHER_DEVICE_H
+#define MSORB_ORBMATCHER_DEVICE_H
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "msorb.h"
+
+namespace ORB_SLAM3 {
+namespace msorb_host {
+
+inline void check(int rc, const char* what) {
+    if (rc != MSORB_OK) throw std::runtime_error(std::string(what) + ": " + msorb_last_error());
+}
+
+template <class FrameT>
+class DeviceFrame {
+public:
+    explicit DeviceFrame(int device = 0) { check(msorb_frame_create(device, &h_), "msorb_frame_create"); }
+    ~DeviceFrame() { msorb_frame_destroy(h_); }
+    DeviceFrame(const DeviceFrame&) = delete;
+    DeviceFrame& operator=(const DeviceFrame&) = delete;
+
+    // mvKeysUn, mDescriptors, mvuRight, mnMinX..mnMaxY, mvScaleFactors -> device + 64x48 grid (Frame.cc:385-416)
+    void Upload(const FrameT& F) {
+        static_assert(sizeof(F.mvKeysUn[0]) == sizeof(msorb_keypoint), "cv::KeyPoint must be the 28-byte layout");
+        const int n = (int)F.mvKeysUn.size();
+        desc_.resize((size_t)n * 32);
+        for (int i = 0; i < n; i++) std::memcpy(&desc_[(size_t)i * 32], F.mDescriptors.template ptr<unsigned char>(i), 32);
+        check(msorb_frame_set(h_, reinterpret_cast<const msorb_keypoint*>(F.mvKeysUn.data()), n, desc_.data(),
+                              F.mvuRight.empty() ? nullptr : F.mvuRight.data(), F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY,
+                              F.mvScaleFactors.data(), (int)F.mvScaleFactors.size()),
+              "msorb_frame_set");
+    }
+    msorb_frame* get() const { return h_; }
+
+private:
+    msorb_frame* h_ = nullptr;
+    std::vector<uint8_t> desc_;
+};
+
+// ORBmatcher::SearchByProjection(Frame &F, const vector<shared_ptr<MapPoint>> &vpMapPoints, th, bFarPoints, thFarPoints)
+template <class FrameT, class MapPointPtr>
+int SearchByProjection(DeviceFrame<FrameT>& dev, FrameT& F, const std::vector<MapPointPtr>& vpMapPoints, const float th,
+                       const bool bFarPoints, const float thFarPoints, const float mfNNratio) {
+    const int M = (int)vpMapPoints.size(), N = (int)F.mvpMapPoints.size();
+    // table = the local map points in call order, then the map points the frame already holds that are not among them
+    // (they are never queries — track_in_view 0 — but their Observations() decides whether a keypoint is taken, :89-91)
+    std::unordered_map<const void*, int> index;
+    index.reserve((size_t)M * 2);
+    for (int i = 0; i < M; i++) index.emplace(vpMapPoints[i].get(), i);  // first occurrence wins, like the scan order
+    std::vector<int> frameMp(N, -1), extraObs;
+    for (int i = 0; i < N; i++) {
+        if (!F.mvpMapPoints[i]) continue;
+        auto it = index.find(F.mvpMapPoints[i].get());
+        if (it != index.end()) { frameMp[i] = it->second; continue; }
+        frameMp[i] = M + (int)extraObs.size();
+        index.emplace(F.mvpMapPoints[i].get(), frameMp[i]);
+        extraObs.push_back(F.mvpMapPoints[i]->Observations());
+    }
+    const int T = M + (int)extraObs.size();
+    std::vector<uint8_t> inView(T, 0), bad(T, 0), spars(T, 0), desc((size_t)T * 32, 0);
+    std::vector<float> px(T, 0), py(T, 0), pxr(T, 0), depth(T, 0), vcos(T, 0);
+    std::vector<int> level(T, 0), obs(T, 0);
+    for (int i = 0; i < M; i++) {
+        const auto& p = vpMapPoints[i];
+        inView[i] = p->mbTrackInView; bad[i] = p->isBad(); spars[i] = p->mbSparsified;
+        px[i] = p->mTrackProjX; py[i] = p->mTrackProjY; pxr[i] = p->mTrackProjXR; depth[i] = p->mTrackDepth;
+        level[i] = p->mnTrackScaleLevel; vcos[i] = p->mTrackViewCos; obs[i] = p->Observations();
+        const auto d = p->GetDescriptor();
+        std::memcpy(&desc[(size_t)i * 32], d.template ptr<unsigned char>(0), 32);
+    }
+    for (int k = 0; k < (int)extraObs.size(); k++) obs[M + k] = extraObs[k];
+    const std::vector<int> before = frameMp;
+    int nmatches = 0;
+    check(msorb_search_by_projection_mps(dev.get(), T, inView.data(), bad.data(), spars.data(), px.data(), py.data(),
+                                         pxr.data(), depth.data(), level.data(), vcos.data(), desc.data(), obs.data(),
+                                         frameMp.data(), th, bFarPoints ? 1 : 0, thFarPoints, mfNNratio, &nmatches),
+          "msorb_search_by_projection_mps");
+    for (int i = 0; i < N; i++)
+        if (frameMp[i] != before[i] && frameMp[i] >= 0 && frameMp[i] < M) F.mvpMapPoints[i] = vpMapPoints[frameMp[i]];
+    return nmatches;
+}
+
+// Frame::ComputeStereoMatches(): fills F.mvuRight / F.mvDepth from the two extractors' device pyramids.
+// ExtractorT = the drop-in ORB_SLAM3::ORBextractor of this directory (handle()).
+template <class FrameT, class ExtractorT>
+void ComputeStereoMatches(FrameT& F, const ExtractorT& left, const ExtractorT& right) {
+    const int N = (int)F.mvKeys.size(), Nr = (int)F.mvKeysRight.size();
+    F.mvuRight.assign(N, -1.0f);
+    F.mvDepth.assign(N, -1.0f);
+    std::vector<uint8_t> dl((size_t)N * 32), dr((size_t)Nr * 32);
+    for (int i = 0; i < N; i++) std::memcpy(&dl[(size_t)i * 32], F.mDescriptors.template ptr<unsigned char>(i), 32);
+    for (int i = 0; i < Nr; i++) std::memcpy(&dr[(size_t)i * 32], F.mDescriptorsRight.template ptr<unsigned char>(i), 32);
+    int oob = 0;
+    check(msorb_stereo_matches(left.handle(), right.handle(), reinterpret_cast<const msorb_keypoint*>(F.mvKeys.data()), N,
+                               dl.data(), reinterpret_cast<const msorb_keypoint*>(F.mvKeysRight.data()), Nr, dr.data(), F.mb,
+                               F.mbf, F.mvuRight.data(), F.mvDepth.data(), &oob),
+          "msorb_stereo_matches");
+}
+
+}  // namespace msorb_host
+}  // namespace ORB_SLAM3
+
+#endif

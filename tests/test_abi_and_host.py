@@ -83,3 +83,10 @@ def test_device_quadtree_algorithm_on_host(tmp_path):
                            os.path.join(ROOT, "ms-slam_amd", "csrc", "orb_host.cc"), "-o", str(exe)])
     out = subprocess.check_output([str(exe), "1500"]).decode()
     assert "bad=0" in out, out
+
+
+def test_matcher_adapter_header_compiles(tmp_path):
+    """ms-slam_amd/host/ORBmatcher_device.h against the stand-in Frame / MapPoint of tests/dropin_matcher_main.cc
+    (syntax + template instantiation only: no GPU, no link)."""
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", f"-I{ROOT}/tests/cv_stub", f"-I{ROOT}/ms-slam_amd/host",
+                           f"-I{ROOT}/include", os.path.join(ROOT, "tests", "dropin_matcher_main.cc")])
