@@ -3,6 +3,7 @@ logic (parameter tables, geometry, quadtree) agrees with the oracle, and there i
 import ctypes as C
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
