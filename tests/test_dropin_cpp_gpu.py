@@ -81,3 +81,67 @@ def test_cpp_matcher_adapter_matches_oracle(tmp_path, oracle, msorb_mod):
     rn = rf.SearchByProjection_mps(mp_o, want, th, bFarPoints=bool(far), thFarPoints=th_far, nnratio=nnratio)
     assert rn > 200
     assert nmatches == rn and np.array_equal(got, want)
+
+
+def test_cpp_sparsification_adapter_matches_oracle(tmp_path, oracle, msorb_mod):
+    """ms-slam_amd/host/MapSparsification_device.h over stand-in KeyFrame / MapPoint objects vs the oracle on the flat
+    arrays the object graph was built from (outside-keyframe rows compared by owner: their order is run dependent in
+    the reference, a std::map keyed by shared_ptr)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import sparsify_cases as sc
+    exe = tmp_path / "dropin_sparsify"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", f"-I{ROOT}/ms-slam_amd/host", f"-I{ROOT}/include",
+                           f"{ROOT}/tests/dropin_sparsify_main.cc", f"-L{ROOT}/ms-slam_amd", "-lmsorb",
+                           f"-Wl,-rpath,{ROOT}/ms-slam_amd", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    w = sc.window(5, n_window=12, n_outside=40, n_points=3000, slots_per_kf=800)
+    N = 100
+    window_ids = np.nonzero(w["kf_in_window"])[0].astype(np.int32)
+    # the generator folds isBad() into slot_point = -1; the object graph needs the held point + a bad flag: mark 3 % of the
+    # tracked slots' points bad afterwards and rebuild the flat view the oracle sees
+    rng = np.random.Generator(np.random.PCG64(3))
+    slot_true = w["slot_point"].copy()
+    bad = np.zeros(len(w["point_nobs"]), np.uint8)
+    held = np.unique(slot_true[slot_true >= 0])
+    bad[rng.choice(held, len(held) // 30, replace=False)] = 1
+    flat = dict(w)
+    flat["slot_point"] = np.where((slot_true >= 0) & (bad[np.maximum(slot_true, 0)] == 0), slot_true, -1).astype(np.int32)
+    valid_pts = flat["slot_point"][flat["slot_point"] >= 0]
+    blob, out = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(blob, "wb") as f:
+        f.write(struct.pack("<7i", len(window_ids), len(slot_true), len(bad), len(w["obs_kf"]), len(w["kf_in_window"]), N, 48))
+        for a in (w["kf_slot_begin"], flat["slot_point"], w["slot_cell"], w["point_nobs"], w["obs_begin"], w["obs_kf"],
+                  w["kf_num_mps"], window_ids, slot_true, bad):
+            f.write(np.ascontiguousarray(a).tobytes())
+    subprocess.check_call([str(exe), str(blob), str(out)])
+    raw = out.read_bytes()
+    n_cols, n_rows, nnz, nmax = struct.unpack_from("<4i", raw, 0)
+    off = 16
+
+    def take(dt, n):
+        nonlocal off
+        a = np.frombuffer(raw, dt, n, off)
+        off += a.nbytes
+        return a
+    col_point, obj = take(np.int32, n_cols), take(np.float32, n_cols)
+    row_begin, row_kind, row_kf, row_cell = take(np.int32, n_rows + 1), take(np.int32, n_rows), take(np.int32, n_rows), take(np.int32, n_rows)
+    row_rhs, col_idx = take(np.float32, n_rows), take(np.int32, nnz)
+    assert take(np.int32, 1)[0] == 1                                      # side effects
+    # bad-but-held points still count for nMaxObsevation? no: :70 skips isBad() — the floor only sees valid ones
+    floor = int(w["point_nobs"][valid_pts].max())
+    want = oracle.visibility_csr(N=N, n_max_obs_floor=floor, **flat)
+    assert (n_cols, nmax) == (want["n_cols"], want["n_max_obs"]) and n_rows == want["n_rows"]
+    assert np.array_equal(col_point, want["col_point"]) and np.array_equal(obj, want["obj_coef"])
+    inner = want["row_kind"] != 2
+    n_in = int(inner.sum())
+    assert np.array_equal(row_kind[:n_in], want["row_kind"][:n_in]) and np.array_equal(row_rhs[:n_in], want["row_rhs"][:n_in])
+    assert np.array_equal(row_begin[:n_in + 1], want["row_begin"][:n_in + 1])
+    assert np.array_equal(col_idx[:row_begin[n_in]], want["col_idx"][:row_begin[n_in]])
+    k1 = row_kind[:n_in] == 1
+    assert np.array_equal(row_kf[:n_in][k1], window_ids[want["row_owner"][:n_in][k1]])
+    assert np.array_equal(row_cell[:n_in][~k1], want["row_owner"][:n_in][~k1])
+
+    def outside(kind, owner, rb, rhs, ci):
+        return {int(owner[r]): (float(rhs[r]), ci[rb[r]:rb[r + 1]].tolist()) for r in range(len(kind)) if kind[r] == 2}
+    assert outside(row_kind, row_kf, row_begin, row_rhs, col_idx) == \
+        outside(want["row_kind"], want["row_owner"], want["row_begin"], want["row_rhs"], want["col_idx"])
