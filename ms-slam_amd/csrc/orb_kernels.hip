@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void pyr_resize_aligned_kernel(LevelView src, 
 // kept in registers: at scale 1.2 consecutive output rows share one of their two source rows (i0(dy+1) == i1(dy) five
 // times out of six), so each source row is fetched and interpolated once, not twice.  The raw dwords of the next
 // source row are prefetched while the current output row is blended.  Same integer arithmetic as the kernels above.
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
 template <int R>
 __global__ __launch_bounds__(256) void pyr_resize_rows_kernel(LevelView src, LevelView dst, uint8_t* __restrict__ dst_base,
                                                               const ResizeTap* __restrict__ tx,
@@ -112,14 +113,19 @@ __global__ __launch_bounds__(256) void pyr_resize_rows_kernel(LevelView src, Lev
     const uint4 tb = reinterpret_cast<const uint4*>(tx + dx0)[1];
     const uint32_t tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};  // per tap: {i0|i1<<16, c0|c1<<16}
     const int base = (int)(tw[0] & 0xffffu) & ~3;  // aligned column of the first source pixel
-    int off[4], sh[4], c0[4], c1[4];
+    // per tap: two byte-permute selectors that fetch the tap's two source pixels out of the 12-byte window {w2,w1,w0}
+    // into the low bytes of the two 16-bit halves (0x0c = constant zero), and the weights as a u16 pair: the horizontal
+    // interpolation is then perm, perm, or, dot2.  At the right edge i1 == i0 and c1 == 0: whatever the second selector
+    // picks is multiplied by zero.
+    uint32_t sel01[4], sel2[4], cw[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int i0 = (int)(tw[2 * i] & 0xffffu), i1 = (int)(tw[2 * i] >> 16);
-        off[i] = i0 - base;
-        sh[i] = (i1 != i0) ? 8 : 0;  // second tap = next pixel, except at the right edge where i1 == i0 (and c1 == 0)
-        c0[i] = (int)(int16_t)(tw[2 * i + 1] & 0xffffu);
-        c1[i] = (int)(int16_t)(tw[2 * i + 1] >> 16);
+        const uint32_t o = (tw[2 * i] & 0xffffu) - (uint32_t)base;  // 0..10
+        const uint32_t a1 = o < 8 ? o : 0x0cu, b1 = o + 1 < 8 ? o + 1 : 0x0cu;
+        const uint32_t a2 = o >= 8 ? o - 8 : 0x0cu, b2 = o + 1 >= 8 ? o + 1 - 8 : 0x0cu;
+        sel01[i] = a1 | (0x0cu << 8) | (b1 << 16) | (0x0cu << 24);
+        sel2[i] = a2 | (0x0cu << 8) | (b2 << 16) | (0x0cu << 24);
+        cw[i] = tw[2 * i + 1];  // c0 | c1 << 16, both in [0, 2048]
     }
     const uint8_t* sb = src.base + (size_t)img * src.img_stride;
     struct Raw { uint32_t w0, w1, w2; };
@@ -130,8 +136,8 @@ __global__ __launch_bounds__(256) void pyr_resize_rows_kernel(LevelView src, Lev
     auto hrow = [&](const Raw& r, int H[4]) {  // (src[i0]*c0 + src[i1]*c1) >> 4 for the 4 columns of this thread
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t pa = pick2(r.w0, r.w1, r.w2, off[i]);
-            H[i] = ((int)(pa & 255u) * c0[i] + (int)((pa >> sh[i]) & 255u) * c1[i]) >> 4;
+            const uint32_t px = __builtin_amdgcn_perm(r.w1, r.w0, sel01[i]) | __builtin_amdgcn_perm(0u, r.w2, sel2[i]);
+            H[i] = (int)(__builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, px), __builtin_bit_cast(ushort2v, cw[i]), 0u, false) >> 4);
         }
     };
     uint8_t* d = dst_base + (size_t)img * dst.img_stride + (size_t)(uint32_t)dx0;
@@ -956,9 +962,14 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
         if (t < 4) vrow03 |= (uint32_t)((row - 15) & 255) << (8 * t);
         else vrow4 = row - 15;
     }
-    uint32_t pat[4];
+    // the 4 pattern pairs of this lane as floats (lane constants: decoded once per wave, not once per keypoint)
+    float patx0[4], paty0[4], patx1[4], paty1[4];
 #pragma unroll
-    for (int w = 0; w < 4; w++) pat[w] = *reinterpret_cast<const uint32_t*>(&c_tab.pattern[(w * 64 + lane) * 4]);
+    for (int w = 0; w < 4; w++) {
+        const uint32_t pw = *reinterpret_cast<const uint32_t*>(&c_tab.pattern[(w * 64 + lane) * 4]);
+        patx0[w] = (float)(int8_t)(pw & 255u); paty0[w] = (float)(int8_t)((pw >> 8) & 255u);
+        patx1[w] = (float)(int8_t)((pw >> 16) & 255u); paty1[w] = (float)(int8_t)(pw >> 24);
+    }
     const float factor_pi = (float)(3.1415926535897932384626433832795 / 180.0);
 
     // Software pipeline over the wave's keypoints: while keypoint k is being processed the 11 patch loads of keypoint
@@ -1058,8 +1069,7 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
         unsigned long long word[4];
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-            const float x0 = (float)(int8_t)(pat[w] & 255u), y0 = (float)(int8_t)((pat[w] >> 8) & 255u);
-            const float x1 = (float)(int8_t)((pat[w] >> 16) & 255u), y1 = (float)(int8_t)(pat[w] >> 24);
+            const float x0 = patx0[w], y0 = paty0[w], x1 = patx1[w], y1 = paty1[w];
             // cvRound(x*b + y*a), cvRound(x*a - y*b) with the contraction order of oracle/orb_extractor_oracle.cc
             const int r0 = __float2int_rn(__fmaf_rn(x0, b, __fmul_rn(y0, a)));
             const int q0 = __float2int_rn(__fmaf_rn(x0, a, -__fmul_rn(y0, b)));
