@@ -746,7 +746,6 @@ __global__ __launch_bounds__(256) void gauss7_kernel(PyramidView src, PyramidVie
 constexpr int kGaussLanesOut = 62;
 template <int ROWS>
 __global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, PyramidView dst, BlurPlan plan) {
-    constexpr uint32_t K[7] = {18, 34, 48, 56, 48, 34, 18};
     int level = 0;
     while (level + 1 < plan.nlevels && (int)blockIdx.x >= plan.block_begin[level + 1]) level++;
     const int rem = blockIdx.x - plan.block_begin[level];
@@ -777,7 +776,11 @@ __global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, Pyr
             hs[j] = __builtin_amdgcn_udot4(b, kGaussHi, __builtin_amdgcn_udot4(a, kGaussLo, 0u, false), false);
         }
     };
-    uint32_t acc[7][4];
+    // The vertical pass runs in fp32: every product and partial sum is an integer below 2^24 (<= 256 * 255 * 256), so
+    // v_fma_f32 is exact — and on gfx950 it issues at the fast VALU rate (2.5 cycles per wave-instruction) while the
+    // integer v_mad_u32_u24 takes 4.4 (micro-benchmark of this round).
+    constexpr float Kf[7] = {18.f, 34.f, 48.f, 56.f, 48.f, 34.f, 18.f};
+    float acc[7][4];
     uint32_t hs[4];
     uint32_t warm[6], nxt[7];
 #pragma unroll
@@ -788,10 +791,13 @@ __global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, Pyr
 #pragma unroll
     for (int r = 0; r < 6; r++) {
         row_sums(warm[r], hs);
+        float hf[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) hf[j] = (float)hs[j];
 #pragma unroll
         for (int t = 0; t <= r; t++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc[r - t][j] = (t == 0 ? 0u : acc[r - t][j]) + K[t] * hs[j];
+            for (int j = 0; j < 4; j++) acc[r - t][j] = t == 0 ? __fmul_rn(Kf[0], hf[j]) : __fmaf_rn(Kf[t], hf[j], acc[r - t][j]);
     }
     // steady state: input row r = 6 + 7*it + u completes output row o = r - 6 and opens accumulator r % 7
     for (int it = 0; it < ROWS / 7; it++) {
@@ -806,17 +812,21 @@ __global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, Pyr
         for (int u = 0; u < 7; u++) {
             const int r = 6 + 7 * it + u;
             row_sums(cur[u], hs);
+            float hf[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) hf[j] = (float)hs[j];
 #pragma unroll
             for (int t = 0; t < 7; t++) {
                 const int a = (6 + u - t) % 7;  // == (r - t) % 7
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[a][j] = (t == 0 ? 0u : acc[a][j]) + K[t] * hs[j];
+                for (int j = 0; j < 4; j++) acc[a][j] = t == 0 ? __fmul_rn(Kf[0], hf[j]) : __fmaf_rn(Kf[t], hf[j], acc[a][j]);
             }
             const int o = r - 6, a = u % 7;  // (r - 6) % 7 == u
             if (store && y0 + o < sv.h) {
                 uint32_t packed = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) packed |= ((acc[a][j] + 32768u) >> 16) << (8 * j);
+                for (int j = 0; j < 4; j++)  // (acc + 32768) >> 16 == trunc(acc * 2^-16 + 0.5): exact in fp32, acc < 2^24
+                    packed |= (uint32_t)__fmaf_rn(acc[a][j], 1.0f / 65536.0f, 0.5f) << (8 * j);
                 *reinterpret_cast<uint32_t*>(db + (size_t)(y0 + o) * dv.pitch + (size_t)(uint32_t)x0) = packed;
             }
         }
