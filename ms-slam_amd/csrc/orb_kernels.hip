@@ -926,6 +926,10 @@ __device__ __forceinline__ int wave_sum_dpp(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// cvRound for |x| < 2^22 as one fp32 add and one integer subtract (both fast-class VALU ops; v_rndne_f32 + v_cvt_i32_f32
+// are two slow-class ones): adding 1.5 * 2^23 leaves round-to-nearest-even of x in the low mantissa bits.
+__device__ __forceinline__ int rint_small(float x) { return __float_as_int(__fadd_rn(x, 12582912.0f)) - 0x4B400000; }
+
 constexpr int kPatchPitch = 44;  // bytes per staged patch row: 11 dwords
 constexpr int kKpPerWave = 4;  // keypoints handled back to back by one wave (amortises the per-lane table loads)
 
@@ -1081,10 +1085,10 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
         for (int w = 0; w < 4; w++) {
             const float x0 = patx0[w], y0 = paty0[w], x1 = patx1[w], y1 = paty1[w];
             // cvRound(x*b + y*a), cvRound(x*a - y*b) with the contraction order of oracle/orb_extractor_oracle.cc
-            const int r0 = __float2int_rn(__fmaf_rn(x0, b, __fmul_rn(y0, a)));
-            const int q0 = __float2int_rn(__fmaf_rn(x0, a, -__fmul_rn(y0, b)));
-            const int r1 = __float2int_rn(__fmaf_rn(x1, b, __fmul_rn(y1, a)));
-            const int q1 = __float2int_rn(__fmaf_rn(x1, a, -__fmul_rn(y1, b)));
+            const int r0 = rint_small(__fmaf_rn(x0, b, __fmul_rn(y0, a)));
+            const int q0 = rint_small(__fmaf_rn(x0, a, -__fmul_rn(y0, b)));
+            const int r1 = rint_small(__fmaf_rn(x1, b, __fmul_rn(y1, a)));
+            const int q1 = rint_small(__fmaf_rn(x1, a, -__fmul_rn(y1, b)));
             const int t0 = bc[r0 * kPatchPitch + q0];
             const int t1 = bc[r1 * kPatchPitch + q1];
             word[w] = __ballot(t0 < t1);
