@@ -362,7 +362,8 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
     // phase 1: quick test, two pixels per packed 16-bit lane; 8 result bits per task (dark 0..3, bright 4..7)
     uint64_t M = 0;  // 8 bits per owned task (<= 6 tasks with GeoLarge, <= 5 with GeoSmall)
     int cnt = 0;
-    const short2v T2 = {(short)th, (short)th};
+    const uint32_t t2 = (uint32_t)th * 0x00010001u;
+    const uint32_t cdark = 0x80008000u - t2 - 0x00010001u, cbright = 0x80008000u - t2 - 0x00010001u;
     {
         int y = (int)(__umul24((uint32_t)t_begin, magic) >> 20);
         int g = t_begin - y * G;
@@ -383,11 +384,17 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
                 const short2v v = as_s2((C >> sh) & 0x00ff00ffu), pu = as_s2((U >> sh) & 0x00ff00ffu),
                               pd = as_s2((D >> sh) & 0x00ff00ffu), pr = as_s2((R3 >> sh) & 0x00ff00ffu),
                               pl = as_s2((L3 >> sh) & 0x00ff00ffu);
-                const short2v lo = v - T2, hi = v + T2;
-                // every 9-arc contains one pixel of each antipodal pair: a dark corner needs min(pair) < v - t for
-                // both compass pairs, a bright corner max(pair) > v + t; sign bit of the difference = predicate
-                dk[hsel] = as_u32(__builtin_elementwise_min(pu, pd) - lo) & as_u32(__builtin_elementwise_min(pl, pr) - lo);
-                br[hsel] = as_u32(hi - __builtin_elementwise_max(pu, pd)) & as_u32(hi - __builtin_elementwise_max(pl, pr));
+                // Compare by carry-free 32-bit arithmetic on the two 16-bit halves (v_add/v_sub/v_or/v_and issue at the fast
+                // VALU rate on gfx950, the packed v_pk_* ops at the slow one): with a 0x8000 guard in each half,
+                //   (v - t - 1 + 0x8000) - p   has bit 15 set  <=>  p < v - t      (dark),
+                //   p + (0x8000 - (v + t + 1)) has bit 15 set  <=>  p > v + t      (bright),
+                // and no half ever borrows from / carries into its neighbour (|v - p| + t + 1 < 0x8000).
+                // Every 9-arc contains one pixel of each antipodal pair: a corner needs the predicate for (up OR down) AND
+                // (left OR right).
+                const uint32_t vv = as_u32(v);
+                const uint32_t Ld = vv + cdark, Hb = cbright - vv;
+                dk[hsel] = ((Ld - as_u32(pu)) | (Ld - as_u32(pd))) & ((Ld - as_u32(pl)) | (Ld - as_u32(pr)));
+                br[hsel] = ((as_u32(pu) + Hb) | (as_u32(pd) + Hb)) & ((as_u32(pl) + Hb) | (as_u32(pr) + Hb));
             }
             // sign bits: even half -> px0 (bit 15), px2 (bit 31); odd half -> px1, px3
             // gather both halves at once: bits {0,1} = px0,px1 and {16,17} = px2,px3 (dark), the same 4 bits higher
