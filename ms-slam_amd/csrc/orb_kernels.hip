@@ -775,7 +775,9 @@ __global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, Pyr
     auto row_sums = [&](uint32_t w1, uint32_t hs[4]) {
         uint32_t w0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
         const uint32_t w2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-        if (x0 == 0) w0 = __builtin_amdgcn_perm(0u, w1, 0x01020300u);  // p[-1..-3] = p[1..3]
+        if (bx == 0) {  // block-uniform: only the first column block holds the group at x0 == 0
+            if (x0 == 0) w0 = __builtin_amdgcn_perm(0u, w1, 0x01020300u);  // p[-1..-3] = p[1..3]
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t a = j == 3 ? w1 : __builtin_amdgcn_alignbyte(w1, w0, j + 1);

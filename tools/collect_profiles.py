@@ -56,6 +56,8 @@ except Exception:
     pass
 json.dump(lat, open(os.path.join(P, f"{rnd}_latency_per_frame.json"), "w"), indent=1)
 shutil.copy(os.path.join(G, "bow_bench.json"), os.path.join(P, f"{rnd}_bow_bench.json"))
+if os.path.exists(os.path.join(G, "valu_ubench.txt")):
+    shutil.copy(os.path.join(G, "valu_ubench.txt"), os.path.join(P, f"{rnd}_valu_ubench.txt"))
 print("value", bench["value"], "ms/step", bench["ms_per_step"], bench["stage_ms_per_step"])
 for k, e in kern.items():
     print(f"{k:36s} {e['avg_duration_us']} us  fetch {e['FETCH_SIZE_KB']} KB write {e['WRITE_SIZE_KB']} KB  valu {e.get('valu_fraction_of_measured_peak')}")

@@ -10,3 +10,4 @@ tools/gpu_pmc.sh pmc_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES GRB
 python tools/latency_bench.py > gpurun_out/latency_r1.json 2>gpurun_out/latency_r1.err; cat gpurun_out/latency_r1.json
 python tools/bow_bench.py > gpurun_out/bow_bench.json 2>/dev/null; cat gpurun_out/bow_bench.json
 g++ -O2 -std=c++17 tools/latency_pair.cc -Iinclude -Lms-slam_amd -lmsorb -lpthread -o /tmp/latency_pair 2>/dev/null && LD_LIBRARY_PATH=ms-slam_amd:/opt/rocm/lib /tmp/latency_pair 300 > gpurun_out/latency_pair.json; cat gpurun_out/latency_pair.json
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/valu_ubench.hip -o /tmp/valu_ubench 2>/dev/null && /tmp/valu_ubench > gpurun_out/valu_ubench.txt; tail -3 gpurun_out/valu_ubench.txt
