@@ -946,7 +946,7 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
                                                        const int* __restrict__ sel_count, int sel_stride,
                                                        LevelScale scales, msorb_keypoint* __restrict__ kps,
                                                        uint8_t* __restrict__ desc, int out_stride) {
-    __shared__ __attribute__((aligned(16))) uint8_t patch[4][37 * kPatchPitch + 4];
+    __shared__ __attribute__((aligned(16))) uint8_t patch[4 * kKpPerWave][37 * kPatchPitch + 4];  // one slot per (wave, keypoint)
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs; give every image to ONE XCD so that the
     // overlapping keypoint patches of an image are served by a single L2 instead of being fetched by all eight.
     int img = blockIdx.y, bx = blockIdx.x;
@@ -1042,10 +1042,22 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
     Loads L_next;
     issue(r_cur, L_next);
     SelRec r_pre = recs[min(k_first + 1, n_sel - 1)];
+    // Phase A, per keypoint: moments of the IC-angle patch (wave-uniform totals) and the blurred patch into the keypoint's
+    // own LDS slot.  Phase V, once per wave: angle, cos, sin of all four keypoints at once — lane kk computes keypoint kk,
+    // so the atan2 polynomial and the double-precision sincos run once per wave instead of once per keypoint.
+    // Phase B, per keypoint: steered BRIEF from its LDS slot.
+    SelRec R[kKpPerWave];
+    int M10[kKpPerWave], M01[kKpPerWave], POFF[kKpPerWave];
+    int n_here = 0;
+#pragma unroll
+    for (int kk = 0; kk < kKpPerWave; kk++) { M10[kk] = 0; M01[kk] = 0; POFF[kk] = 0; R[kk] = r_cur; }
+    uint8_t* const lp0 = patch[(threadIdx.x >> 6) * kKpPerWave];
+#pragma unroll
     for (int kk = 0; kk < kKpPerWave; kk++) {
         const int k = k_first + kk;
         if (k >= n_sel) break;
-        const SelRec r = r_cur;
+        n_here = kk + 1;
+        R[kk] = r_cur;
         const Loads L = L_next;
         if (k + 1 < n_sel && kk + 1 < kKpPerWave) {
             r_cur = scalar_rec(r_pre);
@@ -1055,7 +1067,7 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
         const uint32_t* rp = L.rp;
         const uint32_t* rsh = L.rsh;
         const uint32_t* bp = L.bp;
-        const int poff = L.poff;
+        POFF[kk] = L.poff;
 
         // IC_Angle: integer moments over the 749-pixel circular patch (un-blurred level).  Slot + 1 (the next lane, or
         // lane 0 of the next register for lane 63) holds the following 4 bytes of the row: alignbyte undoes the 4-byte
@@ -1070,25 +1082,34 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
             m10 += (int)__builtin_amdgcn_udot4(px, wu[t], 0u, false) - 16 * sI;
             m01 += (t < 4 ? (int)(int8_t)(vrow03 >> (8 * t)) : vrow4) * sI;
         }
-        m10 = wave_sum_dpp(m10);  // wave-uniform (SGPR) totals
-        m01 = wave_sum_dpp(m01);
-        // stage the blurred patch now (the previous keypoint's LDS reads are done: same wave, program order), so the
-        // six data registers are free during the angle / sincos arithmetic
-        uint8_t* lp = patch[threadIdx.x >> 6];
-        __builtin_amdgcn_wave_barrier();
+        M10[kk] = wave_sum_dpp(m10);  // wave-uniform (SGPR) totals
+        M01[kk] = wave_sum_dpp(m01);
+        uint8_t* lp = lp0 + kk * (37 * kPatchPitch + 4);
 #pragma unroll
         for (int it = 0; it < 6; it++) {
             const uint32_t row = bc[it] & 255u, col4 = bc[it] >> 8;
             if (it < 5 || row < 37) *reinterpret_cast<uint32_t*>(lp + row * kPatchPitch + col4) = bp[it];
         }
-        const float angle = fast_atan2_deg((float)m01, (float)m10);
-
-        // steered BRIEF on the blurred level
-        float a, b;
-        glibc_sincosf<true>(__fmul_rn(angle, factor_pi), &b, &a);  // a = cos, b = sin (ORBextractor.cc:112)
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint8_t* bc = lp + 18 * kPatchPitch + 18 + poff;
+    }
+    // Phase V
+    int m10v = M10[0], m01v = M01[0];
+#pragma unroll
+    for (int kk = 1; kk < kKpPerWave; kk++)
+        if (lane == kk) { m10v = M10[kk]; m01v = M01[kk]; }
+    const float angle_v = fast_atan2_deg((float)m01v, (float)m10v);
+    float a_v, b_v;
+    glibc_sincosf<true>(__fmul_rn(angle_v, factor_pi), &b_v, &a_v);  // a = cos, b = sin (ORBextractor.cc:112)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // Phase B
+#pragma unroll
+    for (int kk = 0; kk < kKpPerWave; kk++) {
+        if (kk >= n_here) break;
+        const SelRec r = R[kk];
+        const float angle = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angle_v), kk));
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_v), kk));
+        const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_v), kk));
+        const uint8_t* bc = lp0 + kk * (37 * kPatchPitch + 4) + 18 * kPatchPitch + 18 + POFF[kk];
         unsigned long long word[4];
 #pragma unroll
         for (int w = 0; w < 4; w++) {
