@@ -315,9 +315,11 @@ __global__ __launch_bounds__(256 * kDenseSplit) void dense_top2_kernel(const uin
         for (int u = 0; u < kDenseQPL; u++) {
             const int d = __popcll(a[u][0] ^ t0) + __popcll(a[u][1] ^ t1) + __popcll(a[u][2] ^ t2) + __popcll(a[u][3] ^ t3);
             const uint32_t key = ((uint32_t)d << 16) | (uint32_t)j;
-            const uint32_t lo = min(key, k0[u]), hi = max(key, k0[u]);
-            k0[u] = lo;
-            k1[u] = min(k1[u], hi);
+            // (k0 <= k1) + key -> the two smallest: second = median of the three (one v_med3_u32 instead of max + min)
+            // (written in the min/max form the backend folds into v_med3_u32)
+            const uint32_t m = min(max(k0[u], k1[u]), max(min(k0[u], k1[u]), key));
+            k0[u] = min(k0[u], key);
+            k1[u] = m;
         }
     }
     // merge the parts: keys are unique (distinct indices), so top-2 of the union = {min(a0,b0), min(max(a0,b0), min(a1,b1))}
