@@ -31,6 +31,13 @@
 #else
 #define QT_HD inline
 #endif
+// The workspace lives in LDS on the device.  Its pointers carry the LDS address space in the device pass: through generic
+// pointers every access becomes a FLAT instruction (and the LDS atomics flat atomics), several times slower than ds_*.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define QT_LDS __attribute__((address_space(3)))
+#else
+#define QT_LDS
+#endif
 
 namespace msorb {
 namespace qt {
@@ -52,7 +59,7 @@ QT_HD bool sort_less(const SortItem& a, const SortItem& b) { return a.key < b.ke
 // wave (device: element i lives in lane i & 63 of register i >> 6 and is reached with v_readlane / v_writelane,
 // so the serial comparison chain costs a few cycles per step instead of an LDS round trip).
 struct ArrayAcc {
-    SortItem* v;
+    QT_LDS SortItem* v;
     QT_HD SortItem get(int i) const { return v[i]; }
     QT_HD uint32_t key(int i) const { return v[i].key; }
     QT_HD void set(int i, const SortItem& x) { v[i] = x; }
@@ -139,7 +146,7 @@ QT_HD void insertion_sort(A& v, int first, int last) {
 // which __introsort_loop's recursion visits them does not affect the result; only the depth budget each range
 // inherits does.  `stack` holds (first, last, depth) records: 3 * 64 ints.
 template <class A>
-QT_HD void lsort_acc(A& v, int n, int* stack) {
+QT_HD void lsort_acc(A& v, int n, QT_LDS int* stack) {
     if (n <= 0) return;
     int lg = 0;
     for (int t = n; t > 1; t >>= 1) lg++;
@@ -214,7 +221,7 @@ QT_HD void lsort_acc(A& v, int n, int* stack) {
         insertion_sort(v, 0, n);
     }
 }
-QT_HD void lsort(SortItem* v, int n, int* stack) {
+QT_HD void lsort(QT_LDS SortItem* v, int n, QT_LDS int* stack) {
     ArrayAcc a{v};
     lsort_acc(a, n, stack);
 }
@@ -231,15 +238,15 @@ QT_HD void lsort(SortItem* v, int n, int* stack) {
 //  * median-of-three and the heapsort fallback (never reached on these inputs in practice) stay serial.
 // Ex: tid / nthreads / sync / excl_scan over the participating threads (one wave on the device).
 struct ParScratch {
-    uint16_t* gpos;   // capacity n
-    uint16_t* lpos;   // capacity n
-    SortItem* tmp;    // capacity n
-    int* scan_tmp;    // 16 ints
-    int* sc;          // 4 ints
+    QT_LDS uint16_t* gpos;   // capacity n
+    QT_LDS uint16_t* lpos;   // capacity n
+    QT_LDS SortItem* tmp;    // capacity n
+    QT_LDS int* scan_tmp;    // 16 ints
+    QT_LDS int* sc;          // 4 ints
 };
 
 template <class Ex>
-QT_HD int partition_par(Ex& ex, SortItem* v, int first, int last, ParScratch& ps) {
+QT_HD int partition_par(Ex& ex, QT_LDS SortItem* v, int first, int last, ParScratch& ps) {
     const int tid = ex.tid(), nt = ex.nthreads();
     const uint32_t pivot = v[first].key;
     const int m = last - (first + 1);
@@ -291,7 +298,7 @@ QT_HD int partition_par(Ex& ex, SortItem* v, int first, int last, ParScratch& ps
 }
 
 template <class Ex>
-QT_HD void lsort_par_partitions(Ex& ex, SortItem* v, int n, int* stack, ParScratch& ps) {
+QT_HD void lsort_par_partitions(Ex& ex, QT_LDS SortItem* v, int n, QT_LDS int* stack, ParScratch& ps) {
     if (n <= 0) return;
     const int tid = ex.tid();
     int lg = 0;
@@ -336,7 +343,7 @@ QT_HD void lsort_par_partitions(Ex& ex, SortItem* v, int n, int* stack, ParScrat
 // __final_insertion_sort == stable sort of the arrangement the introsort loop left behind (rank counting); any
 // number of threads
 template <class Ex>
-QT_HD void final_stable_sort(Ex& ex, SortItem* v, int n, ParScratch& ps) {
+QT_HD void final_stable_sort(Ex& ex, QT_LDS SortItem* v, int n, ParScratch& ps) {
     const int tid = ex.tid(), nt = ex.nthreads();
     for (int i = tid; i < n; i += nt) {
         const uint32_t key = v[i].key;
@@ -353,7 +360,7 @@ QT_HD void final_stable_sort(Ex& ex, SortItem* v, int n, ParScratch& ps) {
 }
 
 template <class Ex>
-QT_HD void lsort_par(Ex& ex, SortItem* v, int n, int* stack, ParScratch& ps) {
+QT_HD void lsort_par(Ex& ex, QT_LDS SortItem* v, int n, QT_LDS int* stack, ParScratch& ps) {
     lsort_par_partitions(ex, v, n, stack, ps);
     final_stable_sort(ex, v, n, ps);
 }
@@ -366,15 +373,15 @@ struct NodeB {  // a multi-point ("splittable") node of the current generation, 
     uint16_t pad;
 };
 struct Workspace {       // LDS on the device; `cap` = 4 * max(N, nIni) child slots per generation
-    int* cnt[2];         // points per child slot (re-used as best-point keys at the end)
-    uint16_t* rankof[2]; // child slot -> processing rank among multi-point nodes (0xFFFF = none)
-    NodeB* nb[2];        // multi-point nodes by rank, capacity N + 4
-    SortItem* items;     // capacity N + 4
-    int* stack;          // 3 * 64
-    int* res_seq;        // capacity res_cap
-    int* res_pt;
-    int* sc;             // scalars: see enum below
-    int* scan_tmp;       // 2 x 16 ints for the block-wide scans
+    QT_LDS int* cnt[2];         // points per child slot (re-used as best-point keys at the end)
+    QT_LDS uint16_t* rankof[2]; // child slot -> processing rank among multi-point nodes (0xFFFF = none)
+    QT_LDS NodeB* nb[2];        // multi-point nodes by rank, capacity N + 4
+    QT_LDS SortItem* items;     // capacity N + 4
+    QT_LDS int* stack;          // 3 * 64
+    QT_LDS int* res_seq;        // capacity res_cap
+    QT_LDS int* res_pt;
+    QT_LDS int* sc;             // scalars: see enum below
+    QT_LDS int* scan_tmp;       // 2 x 16 ints for the block-wide scans
     ParScratch ps;       // scratch of the data-parallel sort
     int cap, res_cap, m;
 };
@@ -393,29 +400,31 @@ QT_HD void workspace_carve(Workspace& w, void* mem, int N, int n_ini) {
     w.res_cap = m + 8 + 4 * n_ini;
     w.m = m;
     char* p = (char*)mem;
-    w.cnt[0] = (int*)p; p += w.cap * sizeof(int);
-    w.cnt[1] = (int*)p; p += w.cap * sizeof(int);
-    w.nb[0] = (NodeB*)p; p += (m + 4) * sizeof(NodeB);
-    w.nb[1] = (NodeB*)p; p += (m + 4) * sizeof(NodeB);
-    w.stack = (int*)p; p += 3 * 64 * sizeof(int);
-    w.res_seq = (int*)p; p += w.res_cap * sizeof(int);
-    w.res_pt = (int*)p; p += w.res_cap * sizeof(int);
-    w.sc = (int*)p; p += kScCount * sizeof(int);
-    w.scan_tmp = (int*)p; p += 32 * sizeof(int);
-    w.ps.scan_tmp = (int*)p; p += 16 * sizeof(int);
-    w.ps.sc = (int*)p; p += 4 * sizeof(int);
-    w.rankof[0] = (uint16_t*)p; p += w.cap * sizeof(uint16_t);
-    w.rankof[1] = (uint16_t*)p;
+    w.cnt[0] = (QT_LDS int*)p; p += w.cap * sizeof(int);
+    w.cnt[1] = (QT_LDS int*)p; p += w.cap * sizeof(int);
+    w.nb[0] = (QT_LDS NodeB*)p; p += (m + 4) * sizeof(NodeB);
+    w.nb[1] = (QT_LDS NodeB*)p; p += (m + 4) * sizeof(NodeB);
+    w.stack = (QT_LDS int*)p; p += 3 * 64 * sizeof(int);
+    w.res_seq = (QT_LDS int*)p; p += w.res_cap * sizeof(int);
+    w.res_pt = (QT_LDS int*)p; p += w.res_cap * sizeof(int);
+    w.sc = (QT_LDS int*)p; p += kScCount * sizeof(int);
+    w.scan_tmp = (QT_LDS int*)p; p += 32 * sizeof(int);
+    w.ps.scan_tmp = (QT_LDS int*)p; p += 16 * sizeof(int);
+    w.ps.sc = (QT_LDS int*)p; p += 4 * sizeof(int);
+    w.rankof[0] = (QT_LDS uint16_t*)p; p += w.cap * sizeof(uint16_t);
+    w.rankof[1] = (QT_LDS uint16_t*)p;
     w.items = nullptr; w.ps.tmp = nullptr; w.ps.gpos = nullptr; w.ps.lpos = nullptr;  // aliased per sweep, see sort_scratch()
 }
 // The sort of a careful sweep runs before the other generation's arrays are (re)initialised: its items, the
 // stable-finish buffer and the partition position lists live in cnt[np] / rankof[np].
-QT_HD void sort_scratch(Workspace& w, int np) {
-    w.items = (SortItem*)w.cnt[np];
+QT_HD void sort_scratch(Workspace& w, QT_LDS int* cnt_np, QT_LDS uint16_t* rankof_np) {
+    w.items = (QT_LDS SortItem*)cnt_np;
     w.ps.tmp = w.items + (w.m + 4);
-    w.ps.gpos = w.rankof[np];
+    w.ps.gpos = rankof_np;
     w.ps.lpos = w.ps.gpos + (w.m + 4);
 }
+
+constexpr int kPassBatch = 4;  // points per thread whose LDS stages are issued together in the phased passes
 
 QT_HD int quadrant_of(const Pt& p, const NodeB& b) {  // DivideNode's assignment (:511-525)
     const int mx = b.x0 + ((b.x1 - b.x0 + 1) >> 1), my = b.y0 + ((b.y1 - b.y0 + 1) >> 1);  // ceil(w/2), ceil(h/2)
@@ -431,7 +440,7 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
     const int tid = ex.tid(), nt = ex.nthreads();
     const int n_ini = (int)roundf((float)W / (float)H);           // :559
     const float hX = (float)W / (float)n_ini;                      // :561
-    int* sc = w.sc;
+    QT_LDS int* const sc = w.sc;
 
     // Point ownership: thread t owns candidates t, t + nt, ...; the first PC of them live in registers for the whole
     // selection (coordinates + label), the rest (only when n > PC * nt) go through global memory.
@@ -514,37 +523,70 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
     for (;;) {
         if (debug >= 10 && iter++ >= debug - 10) return 0;  // one iteration = one pass of the main loop (:610-681) or one sweep of the careful loop (:689-753)
         const int np = par ^ 1;
+        // this generation's / the next generation's arrays as plain pointers (indexing the pointer arrays with a runtime
+        // parity would put them into scratch memory)
+        QT_LDS int* const cnt_par = par ? w.cnt[1] : w.cnt[0];
+        QT_LDS int* const cnt_np = par ? w.cnt[0] : w.cnt[1];
+        QT_LDS uint16_t* const rk_par = par ? w.rankof[1] : w.rankof[0];
+        QT_LDS uint16_t* const rk_np = par ? w.rankof[0] : w.rankof[1];
+        QT_LDS NodeB* const nb_par = par ? w.nb[1] : w.nb[0];
+        QT_LDS NodeB* const nb_np = par ? w.nb[0] : w.nb[1];
         const int S = sc[par ? kScS1 : kScS0];
         const int careful = sc[kScCareful];
         const int prev_size = sc[kScSize];
         if (careful) {
-            sort_scratch(w, np);
+            sort_scratch(w, cnt_np, rk_np);
             // vPrevSizeAndPointerToNode in creation order = descending rank; sort; walk from the back
             for (int i = tid; i < S; i += nt) {
-                const NodeB& b = w.nb[par][S - 1 - i];
-                w.items[i].key = ((uint32_t)w.cnt[par][b.slot] << 16) | (uint32_t)(uint16_t)b.x0;
+                const NodeB& b = nb_par[S - 1 - i];
+                w.items[i].key = ((uint32_t)cnt_par[b.slot] << 16) | (uint32_t)(uint16_t)b.x0;
                 w.items[i].node = (uint32_t)(S - 1 - i);
             }
             ex.sync();
             if (debug != 1) ex.sort(w.items, S, w.stack, w.ps);  // std::sort(vPrevSizeAndPointerToNode, compareNodes), :700
             ex.sync();
             // new processing order r: items[S-1-r]; permute nb[par] accordingly (via nb[np] as scratch)
-            for (int r = tid; r < S; r += nt) w.nb[np][r] = w.nb[par][w.items[S - 1 - r].node];
+            for (int r = tid; r < S; r += nt) nb_np[r] = nb_par[w.items[S - 1 - r].node];
             ex.sync();
-            for (int r = tid; r < S; r += nt) { w.nb[par][r] = w.nb[np][r]; w.rankof[par][w.nb[par][r].slot] = (uint16_t)r; }
+            for (int r = tid; r < S; r += nt) { nb_par[r] = nb_np[r]; rk_par[nb_par[r].slot] = (uint16_t)r; }
         }
         ex.mark(0);
-        for (int i = tid; i < 4 * S; i += nt) w.cnt[np][i] = 0;
+        for (int i = tid; i < 4 * S; i += nt) cnt_np[i] = 0;
         if (tid == 0) sc[kScNsplit] = S;
         ex.sync();
         ex.mark(1);
         // pass A: children counts of every multi-point node (speculative for the careful sweep)
+        if (PC == 0) {
+            // phased form: the rank lookups of a batch are issued together, then the node boxes, then the atomics — a
+            // per-point body is a chain of three dependent LDS round trips, and nothing else hides them in one instance
+            for (int p0 = tid; p0 < n; p0 += kPassBatch * nt) {
+                Pt q[kPassBatch];
+                int lab[kPassBatch], r[kPassBatch];
+                bool act[kPassBatch];
+#pragma unroll
+                for (int u = 0; u < kPassBatch; u++) {
+                    const int p = p0 + u * nt, pc = p < n ? p : p0;
+                    q[u] = pts[pc];
+                    lab[u] = label[pc];
+                    act[u] = p < n && lab[u] != kLabelSettled && (((lab[u] & kParityBit) != 0) == (par != 0));
+                }
+#pragma unroll
+                for (int u = 0; u < kPassBatch; u++) r[u] = act[u] ? (int)rk_par[lab[u] & kSlotMask] : 0;
+                NodeB b[kPassBatch];
+#pragma unroll
+                for (int u = 0; u < kPassBatch; u++) b[u] = nb_par[r[u]];
+#pragma unroll
+                for (int u = 0; u < kPassBatch; u++)
+                    if (act[u]) ex.atomic_add(&cnt_np[4 * r[u] + quadrant_of(q[u], b[u])], 1);
+            }
+        } else {
         for_points([&](int, const Pt& q, uint16_t& lab_) {
             const int lab = lab_;
             if (lab == kLabelSettled || ((lab & kParityBit) != 0) != (par != 0)) return;
-            const int r = w.rankof[par][lab & kSlotMask];
-            ex.atomic_add(&w.cnt[np][4 * r + quadrant_of(q, w.nb[par][r])], 1);
+            const int r = rk_par[lab & kSlotMask];
+            ex.atomic_add(&cnt_np[4 * r + quadrant_of(q, nb_par[r])], 1);
         });
+        }
         ex.sync();
         ex.mark(2);
         if (careful) {  // :701-748: split from the largest until the quota is reached -> nsplit
@@ -553,14 +595,14 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
             int local = 0;
             for (int r = pb; r < pe; r++) {
                 int nch = 0;
-                for (int q = 0; q < 4; q++) nch += w.cnt[np][4 * r + q] > 0;
+                for (int q = 0; q < 4; q++) nch += cnt_np[4 * r + q] > 0;
                 local += nch - 1;
             }
             int tot = 0;
             int running = prev_size + ex.excl_scan(local, w.scan_tmp, &tot);
             for (int r = pb; r < pe; r++) {
                 int nch = 0;
-                for (int q = 0; q < 4; q++) nch += w.cnt[np][4 * r + q] > 0;
+                for (int q = 0; q < 4; q++) nch += cnt_np[4 * r + q] > 0;
                 running += nch - 1;
                 if (running >= N) { ex.atomic_min(&sc[kScNsplit], r + 1); break; }
             }
@@ -573,14 +615,14 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
             const int kk = (4 * nsplit_ + nt - 1) / nt;
             const int sb = tid * kk, se = sb + kk < 4 * nsplit_ ? sb + kk : 4 * nsplit_;
             int nz = 0, nx = 0;
-            for (int i = sb; i < se; i++) { nz += w.cnt[np][i] > 0; nx += w.cnt[np][i] > 1; }
+            for (int i = sb; i < se; i++) { nz += cnt_np[i] > 0; nx += cnt_np[i] > 1; }
             int NZ = 0, NX = 0;
             ex.excl_scan(nz, w.scan_tmp, &NZ);
             int before = ex.excl_scan(nx, w.scan_tmp + 16, &NX);
             for (int i = sb; i < se; i++) {
-                w.rankof[np][i] = 0xFFFF;
-                if (w.cnt[np][i] > 1) {
-                    const NodeB& pb_ = w.nb[par][i >> 2];
+                rk_np[i] = 0xFFFF;
+                if (cnt_np[i] > 1) {
+                    const NodeB& pb_ = nb_par[i >> 2];
                     const int q = i & 3;
                     const int mx = pb_.x0 + ((pb_.x1 - pb_.x0 + 1) >> 1), my = pb_.y0 + ((pb_.y1 - pb_.y0 + 1) >> 1);
                     NodeB b;
@@ -589,8 +631,8 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
                     b.seq = genbase_ + i; b.slot = (uint16_t)i; b.pad = 0;
                     const int rank = NX - 1 - before;  // number of multi-point children created after this one
                     before++;
-                    w.rankof[np][i] = (uint16_t)rank;
-                    w.nb[np][rank] = b;
+                    rk_np[i] = (uint16_t)rank;
+                    nb_np[rank] = b;
                 }
             }
             if (tid == 0) {
@@ -608,13 +650,54 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
         ex.mark(3);
         const int nsplit = sc[kScNsplit], genbase = sc[kScGenBase];
         // pass B: move the points of split nodes to their child; single-point children are final
+        if (PC == 0) {
+            for (int p0 = tid; p0 < n; p0 += kPassBatch * nt) {  // phased like pass A
+                Pt q[kPassBatch];
+                int lab[kPassBatch], r[kPassBatch], slot[kPassBatch], c[kPassBatch];
+                bool act[kPassBatch];
+#pragma unroll
+                for (int u = 0; u < kPassBatch; u++) {
+                    const int p = p0 + u * nt, pc = p < n ? p : p0;
+                    q[u] = pts[pc];
+                    lab[u] = label[pc];
+                    act[u] = p < n && lab[u] != kLabelSettled && (((lab[u] & kParityBit) != 0) == (par != 0));
+                }
+#pragma unroll
+                for (int u = 0; u < kPassBatch; u++) {
+                    r[u] = act[u] ? (int)rk_par[lab[u] & kSlotMask] : 0;
+                }
+                NodeB b[kPassBatch];
+#pragma unroll
+                for (int u = 0; u < kPassBatch; u++) {
+                    act[u] = act[u] && r[u] < nsplit;  // careful sweep stopped before this node: it stays whole
+                    b[u] = nb_par[act[u] ? r[u] : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < kPassBatch; u++) {
+                    slot[u] = 4 * r[u] + quadrant_of(q[u], b[u]);
+                    c[u] = act[u] ? cnt_np[slot[u]] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < kPassBatch; u++) {
+                    if (!act[u]) continue;
+                    const int p = p0 + u * nt;
+                    if (c[u] == 1) {
+                        const int k = ex.atomic_add(&sc[kScNres], 1);
+                        w.res_seq[k] = genbase + slot[u]; w.res_pt[k] = p;
+                        label[p] = kLabelSettled;
+                    } else {
+                        label[p] = (uint16_t)((np ? kParityBit : 0) | slot[u]);
+                    }
+                }
+            }
+        } else {
         for_points([&](int p, const Pt& q, uint16_t& lab_) {
             const int lab = lab_;
             if (lab == kLabelSettled || ((lab & kParityBit) != 0) != (par != 0)) return;
-            const int r = w.rankof[par][lab & kSlotMask];
+            const int r = rk_par[lab & kSlotMask];
             if (r >= nsplit) return;  // careful sweep stopped before this node: it stays whole
-            const int slot = 4 * r + quadrant_of(q, w.nb[par][r]);
-            if (w.cnt[np][slot] == 1) {
+            const int slot = 4 * r + quadrant_of(q, nb_par[r]);
+            if (cnt_np[slot] == 1) {
                 const int k = ex.atomic_add(&sc[kScNres], 1);
                 w.res_seq[k] = genbase + slot; w.res_pt[k] = p;
                 lab_ = kLabelSettled;
@@ -622,6 +705,7 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
                 lab_ = (uint16_t)((np ? kParityBit : 0) | slot);
             }
         });
+        }
         ex.sync();
         ex.mark(4);
         if (tid == 0) sc[kScGenBase] = genbase + 4 * S;
@@ -630,23 +714,23 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
         if (finish) {
             // alive multi-point nodes: unsplit nodes of `par` (ranks nsplit..S) and the new children in `np`
             const int Sn = sc[np ? kScS1 : kScS0];
-            for (int i = tid; i < S; i += nt) w.cnt[par][i] = 0;   // re-used as best-point keys, by rank
-            for (int i = tid; i < Sn; i += nt) w.cnt[np][i] = 0;
+            for (int i = tid; i < S; i += nt) cnt_par[i] = 0;   // re-used as best-point keys, by rank
+            for (int i = tid; i < Sn; i += nt) cnt_np[i] = 0;
             ex.sync();
             for_points([&](int p, const Pt& q, uint16_t& lab_) {  // first strictly greater response wins (:757-776)
                 const int lab = lab_;
                 if (lab == kLabelSettled) return;
                 const int lp = (lab & kParityBit) ? 1 : 0;
-                const int r = w.rankof[lp][lab & kSlotMask];
-                ex.atomic_max(&w.cnt[lp][r], (int)(((uint32_t)q.score << 22) | (uint32_t)(0x3FFFFF - p)));
+                const int r = (lp == par ? rk_par : rk_np)[lab & kSlotMask];
+                ex.atomic_max(&(lp == par ? cnt_par : cnt_np)[r], (int)(((uint32_t)q.score << 22) | (uint32_t)(0x3FFFFF - p)));
             });
             ex.sync();
             for (int i = tid; i < S - nsplit + Sn; i += nt) {
                 const int lp = i < S - nsplit ? par : np;
                 const int r = i < S - nsplit ? nsplit + i : i - (S - nsplit);
                 const int k = ex.atomic_add(&sc[kScNres], 1);
-                w.res_seq[k] = w.nb[lp][r].seq;
-                w.res_pt[k] = 0x3FFFFF - (w.cnt[lp][r] & 0x3FFFFF);
+                w.res_seq[k] = (lp == par ? nb_par : nb_np)[r].seq;
+                w.res_pt[k] = 0x3FFFFF - ((lp == par ? cnt_par : cnt_np)[r] & 0x3FFFFF);
             }
             ex.sync();
             break;

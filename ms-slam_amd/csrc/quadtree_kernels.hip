@@ -36,13 +36,13 @@ struct DevEx {
             *total = __popcll(m);
             return __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
         }
-        __device__ int excl_scan(int v, int*, int* total) {
+        __device__ int excl_scan(int v, QT_LDS int*, int* total) {
             const int incl = wave_incl_scan_dpp(v);
             *total = __builtin_amdgcn_readlane(incl, 63);
             return incl - v;
         }
     };
-    __device__ void sort(qt::SortItem* items, int n, int* stack, qt::ParScratch& ps) {
+    __device__ void sort(QT_LDS qt::SortItem* items, int n, QT_LDS int* stack, qt::ParScratch& ps) {
         if (threadIdx.x < 64) {  // introsort loop: wave 0 (partitions are sequential, each one data-parallel)
             WaveEx wex;
             qt::lsort_par_partitions(wex, items, n, stack, ps);
@@ -50,7 +50,9 @@ struct DevEx {
         __syncthreads();
         qt::final_stable_sort(*this, items, n, ps);  // rank counting: all threads
     }
-    int dbg = 0, n_marks = 0;
+    int dbg = 0;
+#ifdef MSORB_QT_MARKS  // per-phase timestamps of instance (0,0) (build with -DMSORB_QT_MARKS, run with MSORB_QT_DEBUG=3):
+    int n_marks = 0;   // compiled out by default, the arrays would cost every wave 600 bytes of scratch
     long long t_mark[48];
     int id_mark[48];
     __device__ void mark(int id) {
@@ -62,15 +64,19 @@ struct DevEx {
         if (dbg == 3 && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0)
             for (int i = 1; i < n_marks; i++) printf("mark %d dt_us=%.2f\n", id_mark[i], (double)(t_mark[i] - t_mark[i - 1]) * 0.01);
     }
+#else
+    __device__ void mark(int) {}
+    __device__ void dump() {}
+#endif
     __device__ int tid() const { return threadIdx.x; }
     __device__ int nthreads() const { return blockDim.x; }
     __device__ void sync() { __syncthreads(); }
-    __device__ int atomic_add(int* p, int v) { return atomicAdd(p, v); }
-    __device__ void atomic_max(int* p, int v) { atomicMax(p, v); }
-    __device__ void atomic_min(int* p, int v) { atomicMin(p, v); }
+    __device__ int atomic_add(QT_LDS int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __device__ void atomic_max(QT_LDS int* p, int v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __device__ void atomic_min(QT_LDS int* p, int v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     __device__ int excl_count(bool p, int* total) { int t = 0; const int r = excl_scan((int)p, nullptr, &t); *total = t; return r; }  // unused
     // block-wide exclusive prefix of v over threads (<= 16 waves); tmp = 16 ints of LDS
-    __device__ int excl_scan(int v, int* tmp, int* total) {
+    __device__ int excl_scan(int v, QT_LDS int* tmp, int* total) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int incl = wave_incl_scan_dpp(v);
         __syncthreads();  // tmp may still be read by a previous scan
