@@ -763,7 +763,26 @@ __global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, Pyr
     const int x0 = (bx * kGaussLanesOut + lane - 1) * 4;
     const int y0 = (by * 4 + (int)(threadIdx.x >> 6)) * ROWS;
     if (y0 >= sv.h) return;  // wave-uniform
-    const bool store = lane >= 1 && lane <= kGaussLanesOut && x0 + 16 <= sv.w;  // the rest: gauss7_edge_kernel / halo lanes
+    const bool store = lane >= 1 && lane <= kGaussLanesOut && x0 < sv.w;  // lanes 0 / 63 and lanes past the row: halo only
+    // Right border (reflect-101): a group with x0 + 7 > w needs pixels beyond column w-1.  Their mirror images
+    // p[2(w-1) - x] lie at most 3 columns left of w-1, i.e. inside the lane's own 12-byte window {w2,w1,w0} = columns
+    // x0-4 .. x0+7, so the fix is a byte permutation of the window that depends on w - x0 only: three selectors per lane,
+    // computed once; applied only in the column block that contains the border (block-uniform branch).
+    const bool border_block = (bx + 1) * kGaussLanesOut * 4 + 7 > sv.w;  // some stored lane of this block has x0 + 7 > w
+    uint32_t sel_w1 = 0x07060504u, sel_w2a = 0x0c0c0c0cu, sel_w2b = 0x03020100u;  // identity: w1 = w1, w2 = w2
+    if (border_block && x0 + 7 > sv.w && x0 < sv.w) {
+        sel_w1 = 0; sel_w2a = 0; sel_w2b = 0;
+        for (int b = 0; b < 8; b++) {
+            const int x = x0 + b;
+            int idx = b + 4;                                        // window index of column x (x0-4 -> 0)
+            if (x >= sv.w) idx = max(2 * (sv.w - 1) - x, x0 - 4) - x0 + 4;
+            if (b < 4) sel_w1 |= (uint32_t)idx << (8 * b);          // sources of w1 lie in {w1,w0}: index 0..7
+            else {
+                sel_w2a |= (uint32_t)(idx < 8 ? idx : 0x0c) << (8 * (b - 4));       // from {w1,w0}
+                sel_w2b |= (uint32_t)(idx >= 8 ? idx - 8 : 0x0c) << (8 * (b - 4));  // from w2
+            }
+        }
+    }
     const uint32_t xl = (uint32_t)min(max(x0, 0), sv.pitch - 4);
     const uint8_t* sb = sv.base + (size_t)img * sv.img_stride;
     uint8_t* db = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride;
@@ -774,9 +793,14 @@ __global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, Pyr
     };
     auto row_sums = [&](uint32_t w1, uint32_t hs[4]) {
         uint32_t w0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-        const uint32_t w2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+        uint32_t w2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
         if (bx == 0) {  // block-uniform: only the first column block holds the group at x0 == 0
             if (x0 == 0) w0 = __builtin_amdgcn_perm(0u, w1, 0x01020300u);  // p[-1..-3] = p[1..3]
+        }
+        if (border_block) {  // block-uniform; identity selectors in the lanes that need no fix
+            const uint32_t n2 = __builtin_amdgcn_perm(w1, w0, sel_w2a) | __builtin_amdgcn_perm(0u, w2, sel_w2b);
+            w1 = __builtin_amdgcn_perm(w1, w0, sel_w1);
+            w2 = n2;
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -1208,7 +1232,7 @@ void launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images,
         const LevelView& v = src.lv[l];
         plan.block_begin[l] = total;
         // aligned path: 62 stored groups per wave; generic path: 64 groups per wave
-        const int main_groups = v.w >= 16 ? (v.w - 16) / 4 + 1 : 0;  // groups with x0 + 16 <= w
+        const int main_groups = stream ? (v.w + 3) / 4 : (v.w >= 16 ? (v.w - 16) / 4 + 1 : 0);  // stream kernel: every group
         plan.bx_count[l] = stream ? max(1, (main_groups + kGaussLanesOut - 1) / kGaussLanesOut) : (v.w + 255) / 256;
         const int strips = (v.h + rows - 1) / rows;
         total += plan.bx_count[l] * ((strips + 3) / 4);
@@ -1218,7 +1242,8 @@ void launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images,
     if (stream) hipLaunchKernelGGL(gauss7_stream_kernel<kGaussRows>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
     else if (aligned) hipLaunchKernelGGL(gauss7_kernel<true>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
     else hipLaunchKernelGGL(gauss7_kernel<false>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
-    hipLaunchKernelGGL(gauss7_edge_kernel, dim3((max_h + kEdgeRows - 1) / kEdgeRows, src.nlevels, n_images), dim3(64), 0, s, src, dst);
+    if (!stream)  // the streaming kernel handles the right border itself
+        hipLaunchKernelGGL(gauss7_edge_kernel, dim3((max_h + kEdgeRows - 1) / kEdgeRows, src.nlevels, n_images), dim3(64), 0, s, src, dst);
 }
 void launch_describe(const PyramidView& pyr, const PyramidView& blur, const SelRec* sel, const int* sel_count,
                      int sel_stride, const LevelScale& scales, msorb_keypoint* kps, uint8_t* desc, int out_stride,
