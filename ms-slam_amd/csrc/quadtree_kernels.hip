@@ -42,12 +42,70 @@ struct DevEx {
             return incl - v;
         }
     };
+    // The introsort loop as level-synchronous rounds: the sub-ranges a partition leaves behind are independent, so every
+    // round hands the current ranges (> 16 elements) to the workgroup's waves, one range per wave at a time; inside a wave
+    // a partition is data-parallel (ballots, no s_barrier).  Which wave partitions which range, and in which order, cannot
+    // change the result: ranges are disjoint and a partition only looks at its own range.  `stack` holds two range lists
+    // of 32 entries (first, last, depth); ps.sc[0/1] their lengths.
     __device__ void sort(QT_LDS qt::SortItem* items, int n, QT_LDS int* stack, qt::ParScratch& ps) {
-        if (threadIdx.x < 64) {  // introsort loop: wave 0 (partitions are sequential, each one data-parallel)
-            WaveEx wex;
-            qt::lsort_par_partitions(wex, items, n, stack, ps);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+        int lg = 0;
+        for (int t = n; t > 1; t >>= 1) lg++;
+        if (threadIdx.x == 0) {
+            stack[0] = 0; stack[1] = n; stack[2] = 2 * lg;
+            ps.sc[0] = n > 16 ? 1 : 0;
+            ps.sc[1] = 0;
         }
         __syncthreads();
+        int which = 0;
+        for (;;) {
+            const int nr = ps.sc[which];
+            if (nr == 0) break;
+            QT_LDS int* cur = stack + which * 96;
+            QT_LDS int* nxt = stack + (which ^ 1) * 96;
+            WaveEx wex;
+            for (int i = wave; i < nr; i += nwaves) {
+                const int first = cur[3 * i], last = cur[3 * i + 1];
+                int depth = cur[3 * i + 2];
+                if (depth == 0) {  // __partial_sort fallback (:introsort depth limit)
+                    if (lane == 0) { qt::ArrayAcc a{items}; qt::heap_sort(a, first, last); }
+                    wex.sync();
+                    continue;
+                }
+                --depth;
+                if (lane == 0) {  // __move_median_to_first(first, first+1, mid, last-1)
+                    qt::ArrayAcc acc{items};
+                    const int a = first + 1, b = first + (last - first) / 2, c = last - 1;
+                    const uint32_t ka = items[a].key, kb = items[b].key, kc = items[c].key;
+                    if (ka < kb) {
+                        if (kb < kc) qt::sort_swap(acc, first, b);
+                        else if (ka < kc) qt::sort_swap(acc, first, c);
+                        else qt::sort_swap(acc, first, a);
+                    } else if (ka < kc) qt::sort_swap(acc, first, a);
+                    else if (kb < kc) qt::sort_swap(acc, first, c);
+                    else qt::sort_swap(acc, first, b);
+                }
+                wex.sync();
+                qt::ParScratch pl = ps;  // this range's private stretch of the position lists
+                pl.gpos = ps.gpos + first;
+                pl.lpos = ps.lpos + first;
+                const int cut = qt::partition_par(wex, items, first, last, pl);
+                if (lane == 0) {
+                    if (last - cut > 16) {
+                        const int k = __hip_atomic_fetch_add(&ps.sc[which ^ 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        nxt[3 * k] = cut; nxt[3 * k + 1] = last; nxt[3 * k + 2] = depth;
+                    }
+                    if (cut - first > 16) {
+                        const int k = __hip_atomic_fetch_add(&ps.sc[which ^ 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        nxt[3 * k] = first; nxt[3 * k + 1] = cut; nxt[3 * k + 2] = depth;
+                    }
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) ps.sc[which] = 0;
+            which ^= 1;
+            __syncthreads();
+        }
         qt::final_stable_sort(*this, items, n, ps);  // rank counting: all threads
     }
     int dbg = 0;
