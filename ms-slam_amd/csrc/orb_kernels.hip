@@ -995,7 +995,9 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
     int vrow4 = 0;
 #pragma unroll
     for (int t = 0; t < 5; t++) {
-        const int idx = lane + 64 * t, row = idx / 9, col = idx % 9;
+        // slot layout: a load instruction covers 7 whole rows of 9 dwords in lanes 0..62 (lane 63 idles), so "the next
+        // dword of the row" is always the next lane of the same register: 5 x 7 = 35 >= 31 rows in the same 5 loads
+        const int row = lane < 63 ? 7 * t + lane / 9 : 31, col = lane % 9;
         uint32_t a = 0, m = 0;
         if (row < 31 && col < 8) {
             const int d = c_tab.umax[row < 15 ? 15 - row : row - 15];
@@ -1005,7 +1007,7 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
             }
         }
         wu[t] = a; vm[t] = m;
-        rc[t] = (uint32_t)row | ((uint32_t)(4 * col + 4) << 8);
+        rc[t] = (uint32_t)min(row, 31) | ((uint32_t)(4 * col + 4) << 8);
         if (t < 4) vrow03 |= (uint32_t)((row - 15) & 255) << (8 * t);
         else vrow4 = row - 15;
     }
@@ -1052,8 +1054,7 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
             const uint32_t row = rc[t] & 255u, col4p4 = rc[t] >> 8;
             const uint32_t o = __umul24(row, (uint32_t)lv.pitch);  // full-rate 24-bit multiply
             L.rsh[t] = (rlow + o) & 3u;
-            // slots 0..255 are always inside the 279-slot patch: only the last register needs the predicate
-            L.rp[t] = (t < 4 || row < 31) ? *reinterpret_cast<const uint32_t*>(rrow + (size_t)(o + col4p4 - L.rsh[t])) : 0u;
+            L.rp[t] = row < 31 ? *reinterpret_cast<const uint32_t*>(rrow + (size_t)(o + col4p4 - L.rsh[t])) : 0u;
         }
 #pragma unroll
         for (int it = 0; it < 6; it++) {
@@ -1093,14 +1094,13 @@ __global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidV
         const uint32_t* bp = L.bp;
         POFF[kk] = L.poff;
 
-        // IC_Angle: integer moments over the 749-pixel circular patch (un-blurred level).  Slot + 1 (the next lane, or
-        // lane 0 of the next register for lane 63) holds the following 4 bytes of the row: alignbyte undoes the 4-byte
+        // IC_Angle: integer moments over the 749-pixel circular patch (un-blurred level).  The next lane holds the
+        // following 4 bytes of the row: alignbyte undoes the 4-byte
         // alignment of the loads, so the per-lane weights do not depend on the keypoint.
         int m10 = 0, m01 = 0;
 #pragma unroll
         for (int t = 0; t < 5; t++) {
             uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rp[t], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-            if (t < 4) { const uint32_t first = __builtin_amdgcn_readfirstlane(rp[t + 1]); if (lane == 63) nx = first; }
             const uint32_t px = __builtin_amdgcn_alignbyte(nx, rp[t], rsh[t]);
             const int sI = (int)__builtin_amdgcn_udot4(px, vm[t], 0u, false);
             m10 += (int)__builtin_amdgcn_udot4(px, wu[t], 0u, false) - 16 * sI;
