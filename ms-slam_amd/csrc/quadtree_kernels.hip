@@ -11,7 +11,10 @@
 namespace msorb {
 
 constexpr int kQtThreads = 256;  // 256 beats 512 (0.39 vs 0.47 ms per 256 images): fewer idle waves waiting at barriers
-constexpr int kQtPointsPerThread = 0;  // register-resident candidates per thread: measured slower (VGPR pressure halves the resident workgroups)
+// register-resident candidates per thread: 0 for batches (with 16 the VGPR pressure halved the resident workgroups and
+// measured slower); 8 for single frames, where a 1024-thread instance then holds a whole level (<= 8192 candidates) in
+// registers and the point passes stop waiting on global memory
+constexpr int kQtPointsPerThreadFrame = 8;
 
 // inclusive prefix sum over the wave with DPP adds only (no LDS crossbar round trips)
 __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
@@ -152,6 +155,7 @@ struct DevEx {
     }
 };
 
+template <int PC>
 __global__ __launch_bounds__(1024) void quadtree_select_kernel(QtLevels lv, const Cand16* __restrict__ compact,
                                                               const int* __restrict__ img_base,
                                                               const int* __restrict__ level_count, uint16_t* __restrict__ label,
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(1024) void quadtree_select_kernel(QtLevels lv, cons
     DevEx ex;
     ex.dbg = debug;
     int* out = sel_pt + (size_t)img * sel_stride + lv.sel_off[level];
-    const int kept = qt::select<kQtPointsPerThread>(ex, reinterpret_cast<const qt::Pt*>(compact + off), n, label + off, lv.W[level], lv.H[level],
+    const int kept = qt::select<PC>(ex, reinterpret_cast<const qt::Pt*>(compact + off), n, label + off, lv.W[level], lv.H[level],
                                 lv.quota[level], w, out, debug);
     if (threadIdx.x == 0) sel_n[(size_t)img * lv.nlevels + level] = kept;
     ex.dump();
@@ -247,8 +251,13 @@ void launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_b
     // throughput); a frame or two has nothing else, so the instance itself brings the waves (1024 threads).
     static const int qt_env = getenv("MSORB_QT_THREADS") ? atoi(getenv("MSORB_QT_THREADS")) : 0;  // tuning only
     const int qt_threads = qt_env ? qt_env : n_images <= 4 ? 1024 : n_images <= 16 ? 512 : kQtThreads;
-    hipLaunchKernelGGL(quadtree_select_kernel, dim3(n_images, lv.nlevels), dim3(qt_threads), lds, s, lv, compact, img_base,
-                       level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg);
+    static const bool regs_env = !getenv("MSORB_QT_NO_REGS");  // tuning / test aid
+    if (qt_threads == 1024 && regs_env)
+        hipLaunchKernelGGL(quadtree_select_kernel<kQtPointsPerThreadFrame>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds, s, lv,
+                           compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg);
+    else
+        hipLaunchKernelGGL(quadtree_select_kernel<0>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds, s, lv, compact, img_base,
+                           level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg);
     hipLaunchKernelGGL(quadtree_layout_kernel, dim3(n_images), dim3(256), 0, s, lv, compact, img_base, level_count, sel_pt,
                        sel_n, sel_stride, scales, lap0, lap1, capacity, sel, sel_count, mono);
 }
