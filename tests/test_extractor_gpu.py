@@ -211,3 +211,45 @@ def test_saturated_single_cell(msorb_mod, oracle):
         assert mono == rmono and len(kps) > 50
         _assert_same(kps, desc, rkps, rdesc)
         ex.close()
+
+
+def test_full_bench_size_properties(msorb_mod, oracle):
+    """BASELINE.json configs[1] at bench.py's batch size (128 stereo pairs = 256 images, default 2 sub-batches): too
+    big for the oracle image by image, so size-independent properties carry the check — copies of an image must give
+    bit-identical outputs wherever they sit in the batch, the output contract holds for every image, a sample is
+    compared with the oracle, and matching the descriptors against themselves must return the identity."""
+    import torch
+    cfg = CONFIGS["kitti"]
+    ex, ref = _pair(msorb_mod, oracle, cfg)
+    uniq, n = 8, 256
+    base = synth.stereo_batch(uniq // 2, cfg["rows"], cfg["cols"], seed0=1000)          # 8 distinct images
+    batch = np.concatenate([base] * (n // uniq))
+    d = torch.from_numpy(batch).cuda()
+    counts, mono, d_kps, d_desc = ex.extract_batch(d)
+    kps_all = msorb_mod.keypoints_from_device(d_kps, counts)
+    desc_all = d_desc.cpu().numpy()
+    assert counts.min() > 1800 and counts.max() <= cfg["nfeatures"] + 2 * cfg["nlevels"]
+    assert np.array_equal(mono, counts)                                                  # vLappingArea = {0, 0}
+    for i in range(n):
+        k = kps_all[i]
+        assert np.all(np.diff(k["octave"]) >= 0) and np.all(k["class_id"] == -1)
+        j = i % uniq
+        if i >= uniq:
+            assert counts[i] == counts[j]
+            assert np.array_equal(k.view(np.uint8), kps_all[j].view(np.uint8))
+            assert np.array_equal(desc_all[i, :counts[i]], desc_all[j, :counts[j]])
+    for i in (3, 6):                                                                     # oracle on a sample
+        rmono, rkps, rdesc = ref(batch[i])
+        assert counts[i] == len(rkps)
+        _assert_same(kps_all[i], desc_all[i, :counts[i]], rkps, rdesc)
+    # descriptors against themselves: best = self at distance 0 unless an earlier row is identical
+    cnt = torch.from_numpy(counts.astype(np.int32)).cuda()
+    bi, bd, sd, _ = msorb_mod.hamming_dense_top2_batch(d_desc, d_desc, cnt, cnt)
+    bi, bd = bi.cpu().numpy(), bd.cpu().numpy()
+    for i in range(0, n, 37):
+        c = counts[i]
+        assert np.all(bd[i, :c] == 0)
+        dup = bi[i, :c] != np.arange(c)
+        assert np.all(bi[i, :c][dup] < np.arange(c)[dup])
+        assert all(np.array_equal(desc_all[i, a], desc_all[i, b]) for a, b in zip(np.arange(c)[dup], bi[i, :c][dup]))
+    ex.close()
