@@ -174,3 +174,82 @@ def test_oracle_matches_committed_golden_fixtures(oracle):
         assert _digest(mono, kps, desc) == case["digest"]
         first = np.load(os.path.join(GOLDEN, case["head_file"]))
         assert np.array_equal(first["desc"], desc[:16]) and np.array_equal(first["kps"], kps[:16].view(np.uint8).reshape(16, 28))
+
+
+# ---- second, independently structured numpy formulations of the three OpenCV primitives -------------------------
+# (same published semantics as SURVEY.md Appendix A, written from the definitions rather than from the oracle's loops:
+# they cannot pin the oracle to real OpenCV, but they do rule out slips inside the oracle's own restatement)
+
+def _np_resize_linear(src, drows, dcols):
+    def taps(dn, sn):
+        scale = 1.0 / (float(dn) / sn)
+        f = ((np.arange(dn) + 0.5) * scale - 0.5).astype(np.float32)
+        i = np.floor(f).astype(np.int64)
+        f = (f - i).astype(np.float32)
+        f[i < 0] = 0
+        i[i < 0] = 0
+        hi = i >= sn - 1
+        f[hi] = 0
+        i[hi] = sn - 1
+        a0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)    # saturate_cast<short>(cvRound)
+        a1 = np.rint(f * np.float32(2048)).astype(np.int64)
+        return i, np.minimum(i + 1, sn - 1), a0, a1
+    x0, x1, ca0, ca1 = taps(dcols, src.shape[1])
+    y0, y1, cb0, cb1 = taps(drows, src.shape[0])
+    s = src.astype(np.int64)
+    H = s[:, x0] * ca0 + s[:, x1] * ca1
+    return ((((cb0[:, None] * (H[y0] >> 4)) >> 16) + ((cb1[:, None] * (H[y1] >> 4)) >> 16) + 2) >> 2).astype(np.uint8)
+
+
+def _np_gaussian7(src):
+    k = np.array([18, 34, 48, 56, 48, 34, 18], np.int64)
+
+    def refl(n):
+        p = np.arange(-3, n + 3)
+        p = np.where(p < 0, -p, p)
+        return np.where(p >= n, 2 * (n - 1) - p, p)
+    s = src.astype(np.int64)
+    h = sum(k[t] * s[:, refl(src.shape[1])[t:t + src.shape[1]]] for t in range(7))
+    v = sum(k[t] * h[refl(src.shape[0])[t:t + src.shape[0]], :] for t in range(7))
+    return ((v + 32768) >> 16).astype(np.uint8)
+
+
+def _np_fast_nms(img, th):
+    """FAST-9/16 from the definition: corner(t) = some 9 contiguous circle pixels all > p+t or all < p-t; the score is
+    the largest t for which the pixel is still a corner; keep strict 3x3 maxima; rows 3..h-4, cols 3..w-4."""
+    circ = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+            (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    h, w = img.shape
+    s = img.astype(np.int64)
+    c = s[3:h - 3, 3:w - 3]
+    ring = np.stack([s[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx] for dx, dy in circ])      # [16, h-6, w-6]
+    score = np.zeros_like(c)
+    for sign in (1, -1):
+        d = sign * (ring - c[None])                                                     # > t  <=> brighter / darker by t
+        d2 = np.concatenate([d, d[:8]])
+        arc_min = np.stack([d2[i:i + 9].min(0) for i in range(16)])                     # min over each 9-arc
+        score = np.maximum(score, arc_min.max(0) - 1)                                   # largest t with min > t
+    is_corner = score >= th                                                             # corner at th <=> max t >= th
+    sc = np.where(is_corner, score, 0)
+    pad = np.pad(sc, 1)
+    nb = np.stack([pad[1 + dy:1 + dy + sc.shape[0], 1 + dx:1 + dx + sc.shape[1]]
+                   for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dx, dy) != (0, 0)])
+    keep = is_corner & (sc > nb.max(0))
+    ys, xs = np.nonzero(keep)
+    return np.stack([xs + 3, ys + 3, sc[ys, xs]], 1)
+
+
+def test_oracle_primitives_against_definition_level_numpy(oracle):
+    rng = np.random.default_rng(5)
+    img = synth.image(11, 120, 173)
+    noisy = np.clip(img.astype(np.int64) + rng.integers(-40, 41, img.shape), 0, 255).astype(np.uint8)
+    for im in (img, noisy):
+        for dr, dc in ((100, 144), (83, 120), (119, 172)):
+            assert np.array_equal(oracle.resize_linear_u8(im, dr, dc), _np_resize_linear(im, dr, dc)), (dr, dc)
+        assert np.array_equal(oracle.gaussian7(im), _np_gaussian7(im))
+        for th in (7, 20, 60):
+            got = oracle.fast9_nms(im, th)
+            want = _np_fast_nms(im, th)
+            order = np.lexsort((got[:, 0], got[:, 1])) if len(got) else []
+            assert np.array_equal(got[order] if len(got) else got, want), th
+    assert len(oracle.fast9_nms(noisy, 20)) > 50
