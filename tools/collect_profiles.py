@@ -50,8 +50,10 @@ json.dump({"note": "rocprofv3 --pmc, per-launch averages of `bench.py --isolated
 lat = json.load(open(os.path.join(G, "latency_r1.json")))
 try:
     lat["cpp_two_threads"] = json.load(open(os.path.join(G, "latency_pair.json")))
-    lat["cpp_two_threads"]["note"] = ("tools/latency_pair.cc: msorb_extract from two fresh std::threads per frame, one handle per "
-                                      "eye, like Frame.cc:122-125; the Python figure above includes interpreter thread overhead")
+    lat["cpp_two_threads"]["note"] = ("tools/latency_pair.cc: the per-frame front-end of the tracking loop (BASELINE configs[2]) in C++ "
+                                      "through the C ABI — msorb_extract from two fresh std::threads per frame, one handle per eye, like "
+                                      "Frame.cc:122-125, then stereo matching, frame upload and SearchByProjection over 4096 map points; "
+                                      "the Python figures above include interpreter and numpy overhead")
 except Exception:
     pass
 json.dump(lat, open(os.path.join(P, f"{rnd}_latency_per_frame.json"), "w"), indent=1)

@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -48,8 +49,57 @@ int main(int argc, char** argv) {
         single_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
     std::sort(pair_ms.begin(), pair_ms.end()); std::sort(single_ms.begin(), single_ms.end());
-    printf("{\"keypoints\": [%d, %d], \"ms_stereo_pair_two_threads_median\": %.4f, \"ms_single_image_median\": %.4f}\n", n[0], n[1],
-           pair_ms[iters / 2], single_ms[iters / 2]);
+    // the rest of a tracking frame (BASELINE.json configs[2]): stereo matches, frame upload (grid), SearchLocalPoints'
+    // isInFrustum-style table of 4096 map points + SearchByProjection — all through the C ABI, host arrays in and out
+    float scale[8];
+    msorb_extractor_tables(ex[0], scale, nullptr, nullptr, nullptr, nullptr);
+    const float mbf = 386.1448f, mb = mbf / 718.856f;
+    std::vector<float> ur(cap), depth(cap);
+    msorb_frame* fr = nullptr;
+    msorb_frame_create(0, &fr);
+    const int M = 4096;
+    std::vector<uint8_t> inView(M, 1), bad(M, 0), spars(M, 0), mdesc((size_t)M * 32);
+    std::vector<float> px(M), py(M), pxr(M), mdepth(M, 10.f), vcos(M, 0.999f);
+    std::vector<int> level(M), obs(M, 3), frameMp(cap);
+    std::vector<double> t_st, t_fs, t_sp, t_all;
+    unsigned s = 777;
+    int nm = 0, oob = 0;
+    for (int i = 0; i < iters / 3; i++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::thread a(eye, 0), b(eye, 1);
+        a.join(); b.join();
+        const auto t1 = std::chrono::steady_clock::now();
+        msorb_stereo_matches(ex[0], ex[1], kps[0].data(), n[0], desc[0].data(), kps[1].data(), n[1], desc[1].data(), mb, mbf,
+                             ur.data(), depth.data(), &oob);
+        const auto t2 = std::chrono::steady_clock::now();
+        msorb_frame_set(fr, kps[0].data(), n[0], desc[0].data(), ur.data(), 0.f, (float)cols, 0.f, (float)rows, scale, 8);
+        const auto t3 = std::chrono::steady_clock::now();
+        for (int m = 0; m < M; m++) {  // map points = noisy copies of frame features (not timed)
+            s = s * 1664525u + 1013904223u;
+            const int src = (s >> 8) % n[0];
+            memcpy(&mdesc[(size_t)m * 32], &desc[0][(size_t)src * 32], 32);
+            s = s * 1664525u + 1013904223u;
+            for (int f = 0; f < (int)((s >> 20) % 24); f++) { s = s * 1664525u + 1013904223u; mdesc[(size_t)m * 32 + ((s >> 8) & 31)] ^= (uint8_t)(1u << ((s >> 16) & 7)); }
+            px[m] = kps[0][src].x + (float)((int)((s >> 4) % 7) - 3);
+            py[m] = kps[0][src].y + (float)((int)((s >> 9) % 7) - 3);
+            pxr[m] = ur[src] > 0 ? ur[src] : px[m] - 20.f;
+            level[m] = kps[0][src].octave;
+        }
+        std::fill(frameMp.begin(), frameMp.end(), -1);
+        const auto t4 = std::chrono::steady_clock::now();
+        msorb_search_by_projection_mps(fr, M, inView.data(), bad.data(), spars.data(), px.data(), py.data(), pxr.data(), mdepth.data(),
+                                       level.data(), vcos.data(), mdesc.data(), obs.data(), frameMp.data(), 3.0f, 0, 50.f, 0.8f, &nm);
+        const auto t5 = std::chrono::steady_clock::now();
+        auto ms = [](auto a_, auto b_) { return std::chrono::duration<double, std::milli>(b_ - a_).count(); };
+        t_st.push_back(ms(t1, t2)); t_fs.push_back(ms(t2, t3)); t_sp.push_back(ms(t4, t5));
+        t_all.push_back(ms(t0, t3) + ms(t4, t5));
+    }
+    msorb_frame_destroy(fr);
+    auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    printf("{\"keypoints\": [%d, %d], \"ms_stereo_pair_two_threads_median\": %.4f, \"ms_single_image_median\": %.4f, "
+           "\"ms_stereo_matches\": %.4f, \"ms_frame_grid_upload\": %.4f, \"ms_search_by_projection_4096\": %.4f, "
+           "\"ms_tracking_frame_front_end\": %.4f, \"projection_matches\": %d}\n",
+           n[0], n[1], pair_ms[iters / 2], single_ms[iters / 2], med(t_st), med(t_fs), med(t_sp), med(t_all), nm);
     for (auto& e : ex) msorb_extractor_destroy(e);
     return 0;
 }
