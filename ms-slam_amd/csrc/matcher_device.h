@@ -9,7 +9,7 @@ namespace msorb {
 
 constexpr int kGridCols = 64, kGridRows = 48;  // FRAME_GRID_COLS / FRAME_GRID_ROWS, Frame.h:44-45
 constexpr int kThHigh = 100, kThLow = 50, kHistoLength = 30;  // ORBmatcher.cc:35-37
-constexpr int kTopK = 4;
+constexpr int kTopK = 8;  // candidates kept per query: with 4 a busy frame needed 4-5 device rounds (exhausted lists), with 8 fewer
 
 struct KpLite {  // what the window search needs of one train keypoint (16 B, one load)
     float x, y, u_right;

@@ -52,6 +52,21 @@ struct DBuf {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
+// pinned host staging: hipMemcpyAsync from / to pageable memory makes the driver stage and synchronise per call
+template <typename T>
+struct HBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count) {
+        if (count <= n) return MSORB_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; n = 0;
+        HIPCHK(hipHostMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault));
+        n = std::max<size_t>(count, 1);
+        return MSORB_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
+};
 }  // namespace
 
 struct msorb_frame {
@@ -67,6 +82,8 @@ struct msorb_frame {
     DBuf<int> d_cell_begin, d_cell_idx;
     DBuf<WinQuery> d_q;
     DBuf<TopK> d_topk;
+    HBuf<uint8_t> h_in;    // queries + query descriptors + occupancy, staged
+    HBuf<TopK> h_topk;
     FrameView view() const {
         FrameView v;
         v.kp = d_kp.p; v.desc = d_desc.p; v.cell_begin = d_cell_begin.p; v.cell_idx = d_cell_idx.p;
@@ -90,18 +107,26 @@ int run_window_search(msorb_frame* f, const std::vector<WinQuery>& q, const uint
         (rc = f->d_occ.ensure(f->N)))
         return rc;
     hipStream_t s = f->stream;
-    HIPCHK(hipMemcpyAsync(f->d_q.p, q.data(), (size_t)M * sizeof(WinQuery), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(f->d_qdesc.p, qdesc, (size_t)M * 32, hipMemcpyHostToDevice, s));
-    std::vector<TopK> topk(M);
+    const size_t qb = (size_t)M * sizeof(WinQuery), db = (size_t)M * 32;
+    if ((rc = f->h_in.ensure(qb + db + (size_t)f->N + 64)) || (rc = f->h_topk.ensure(M))) return rc;
+    std::memcpy(f->h_in.p, q.data(), qb);
+    std::memcpy(f->h_in.p + qb, qdesc, db);
+    uint8_t* const h_occ = f->h_in.p + qb + db;
+    HIPCHK(hipMemcpyAsync(f->d_q.p, f->h_in.p, qb, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(f->d_qdesc.p, f->h_in.p + qb, db, hipMemcpyHostToDevice, s));
+    TopK* const topk = f->h_topk.p;
     std::vector<int8_t> diff(f->N, 0);  // occupancy now vs snapshot: +1 claimed since, -1 freed since
-    int q0 = 0;
+    int q0 = 0, n_rounds = 0;
     while (q0 < M) {
-        if (f->N) HIPCHK(hipMemcpyAsync(f->d_occ.p, occ.data(), f->N, hipMemcpyHostToDevice, s));
+        if (f->N) {
+            std::memcpy(h_occ, occ.data(), f->N);  // the previous round's copy has completed (stream synchronised below)
+            HIPCHK(hipMemcpyAsync(f->d_occ.p, h_occ, f->N, hipMemcpyHostToDevice, s));
+        }
         std::vector<uint8_t> snap = occ;
         std::fill(diff.begin(), diff.end(), 0);
         int n_freed = 0;
         launch_window_topk(f->view(), f->d_q.p, f->d_qdesc.p, q0, M, f->d_topk.p, s);
-        HIPCHK(hipMemcpyAsync(topk.data() + q0, f->d_topk.p + q0, (size_t)(M - q0) * sizeof(TopK), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(topk + q0, f->d_topk.p + q0, (size_t)(M - q0) * sizeof(TopK), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         int qi = q0;
         bool resync = false;
@@ -128,9 +153,12 @@ int run_window_search(msorb_frame* f, const std::vector<WinQuery>& q, const uint
                 if (d < 0) n_freed++;
             }
         }
+        n_rounds++;
         if (!resync) break;
         q0 = qi;
     }
+    static const bool dbg_rounds = getenv("MSORB_DEBUG_ROUNDS") != nullptr;
+    if (dbg_rounds) fprintf(stderr, "window search: %d queries, %d device rounds\n", M, n_rounds);
     return MSORB_OK;
 }
 
@@ -159,7 +187,7 @@ void msorb_frame_destroy(msorb_frame* f) {
     (void)hipSetDevice(f->device);
     if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
     f->d_kp.release(); f->d_desc.release(); f->d_occ.release(); f->d_qdesc.release(); f->d_cell_begin.release();
-    f->d_cell_idx.release(); f->d_q.release(); f->d_topk.release();
+    f->d_cell_idx.release(); f->d_q.release(); f->d_topk.release(); f->h_in.release(); f->h_topk.release();
     delete f;
 }
 
@@ -392,7 +420,7 @@ int msorb_window_top4(msorb_frame* f, int n_queries, const float* x, const float
     HIPCHK(hipMemcpyAsync(topk.data(), f->d_topk.p, (size_t)n_queries * sizeof(TopK), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     for (int i = 0; i < n_queries; i++)
-        for (int k = 0; k < kTopK; k++) { best_idx[4 * i + k] = topk[i].idx[k]; best_dist[4 * i + k] = topk[i].dist[k]; }
+        for (int k = 0; k < 4; k++) { best_idx[4 * i + k] = topk[i].idx[k]; best_dist[4 * i + k] = topk[i].dist[k]; }
     return MSORB_OK;
 }
 
