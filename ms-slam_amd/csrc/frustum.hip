@@ -8,6 +8,7 @@
 // (logf_restated.h).  The library is built with -ffp-contract=off, nothing else is fused.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
 #include <string>
 
 #include "../../include/msorb.h"
@@ -96,51 +97,83 @@ extern "C" int msorb_is_in_frustum(int device, const msorb_frustum* f, float vie
         set_last_error("no usable HIP device (libmsorb has no CPU fallback)");
         return MSORB_E_NO_DEVICE;
     }
-    // one allocation: inputs (8 floats / point) then outputs (6 x 4 B + 1 B / point)
+    // Called once per frame (Tracking::SearchLocalPoints): stream, events, device buffer and pinned staging are kept per
+    // calling thread and device.  One buffer: inputs (8 floats / point) then outputs (6 x 4 B + 1 B / point).
+    struct Scratch {
+        int device = -1;
+        hipStream_t s = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        char *d = nullptr, *h = nullptr;
+        size_t cap = 0;
+        void release() {
+            if (device < 0 || hipSetDevice(device) != hipSuccess) return;
+            if (d) (void)hipFree(d);
+            if (h) (void)hipHostFree(h);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            if (s) (void)hipStreamDestroy(s);
+            d = h = nullptr; s = nullptr; e0 = e1 = nullptr; cap = 0; device = -1;
+        }
+        ~Scratch() { release(); }
+    };
+    static thread_local Scratch scr;
     const size_t N = (size_t)n;
-    const size_t in_bytes = N * 8 * sizeof(float), out_bytes = N * 6 * 4 + N;
-    char* d = nullptr;
-    hipStream_t s = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const size_t in_bytes = N * 8 * sizeof(float), out_bytes = N * 6 * 4 + N, total = in_bytes + out_bytes;
     hipError_t e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreate(&e0);
-    if (e == hipSuccess) e = hipEventCreate(&e1);
-    if (e == hipSuccess) e = hipMalloc((void**)&d, in_bytes + out_bytes);
-    float* d_pos = (float*)d;
-    float* d_nrm = d_pos + 3 * N;
-    float* d_max = d_nrm + 3 * N;
-    float* d_min = d_max + N;
-    float* d_px = d_min + N;
-    float* d_py = d_px + N;
-    float* d_pxr = d_py + N;
-    float* d_depth = d_pxr + N;
-    int* d_level = (int*)(d_depth + N);
-    float* d_vc = (float*)(d_level + N);
-    uint8_t* d_in = (uint8_t*)(d_vc + N);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_pos, pos_w, N * 12, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_nrm, normal, N * 12, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_max, max_distance, N * 4, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_min, min_distance, N * 4, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipEventRecord(e0, s);
-    if (e == hipSuccess)
-        hipLaunchKernelGGL(frustum_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, *f, viewing_cos_limit, n, d_pos,
-                           d_nrm, d_max, d_min, d_in, d_px, d_py, d_pxr, d_depth, d_level, d_vc);
-    if (e == hipSuccess) e = hipEventRecord(e1, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(proj_x, d_px, N * 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(proj_y, d_py, N * 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(proj_xr, d_pxr, N * 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(track_depth, d_depth, N * 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(scale_level, d_level, N * 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(view_cos, d_vc, N * 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(track_in_view, d_in, N, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess && elapsed_ms) e = hipEventElapsedTime(elapsed_ms, e0, e1);
-    if (d) (void)hipFree(d);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (s) (void)hipStreamDestroy(s);
+    if (e == hipSuccess && scr.device != device) {
+        scr.release();
+        scr.device = device;
+        e = hipStreamCreateWithFlags(&scr.s, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreate(&scr.e0);
+        if (e == hipSuccess) e = hipEventCreate(&scr.e1);
+    }
+    if (e == hipSuccess && total > scr.cap) {
+        if (scr.d) (void)hipFree(scr.d);
+        if (scr.h) (void)hipHostFree(scr.h);
+        scr.d = scr.h = nullptr; scr.cap = 0;
+        e = hipMalloc((void**)&scr.d, total + total / 2);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&scr.h, total + total / 2, hipHostMallocDefault);
+        if (e == hipSuccess) scr.cap = total + total / 2;
+    }
+    if (e == hipSuccess) {
+        hipStream_t s = scr.s;
+        float* d_pos = (float*)scr.d;
+        float* d_nrm = d_pos + 3 * N;
+        float* d_max = d_nrm + 3 * N;
+        float* d_min = d_max + N;
+        float* d_px = d_min + N;
+        float* d_py = d_px + N;
+        float* d_pxr = d_py + N;
+        float* d_depth = d_pxr + N;
+        int* d_level = (int*)(d_depth + N);
+        float* d_vc = (float*)(d_level + N);
+        uint8_t* d_in = (uint8_t*)(d_vc + N);
+        float* h_f = (float*)scr.h;
+        std::memcpy(h_f, pos_w, N * 12);
+        std::memcpy(h_f + 3 * N, normal, N * 12);
+        std::memcpy(h_f + 6 * N, max_distance, N * 4);
+        std::memcpy(h_f + 7 * N, min_distance, N * 4);
+        e = hipMemcpyAsync(scr.d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipEventRecord(scr.e0, s);
+        if (e == hipSuccess)
+            hipLaunchKernelGGL(frustum_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, *f, viewing_cos_limit, n, d_pos,
+                               d_nrm, d_max, d_min, d_in, d_px, d_py, d_pxr, d_depth, d_level, d_vc);
+        if (e == hipSuccess) e = hipEventRecord(scr.e1, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(scr.h + in_bytes, scr.d + in_bytes, out_bytes, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess && elapsed_ms) e = hipEventElapsedTime(elapsed_ms, scr.e0, scr.e1);
+        if (e == hipSuccess) {
+            const char* ho = scr.h + in_bytes;
+            std::memcpy(proj_x, ho, N * 4);
+            std::memcpy(proj_y, ho + N * 4, N * 4);
+            std::memcpy(proj_xr, ho + N * 8, N * 4);
+            std::memcpy(track_depth, ho + N * 12, N * 4);
+            std::memcpy(scale_level, ho + N * 16, N * 4);
+            std::memcpy(view_cos, ho + N * 20, N * 4);
+            std::memcpy(track_in_view, ho + N * 24, N);
+        }
+    }
     if (e != hipSuccess) {
         set_last_error(std::string("is_in_frustum: ") + hipGetErrorString(e));
         return MSORB_E_HIP;

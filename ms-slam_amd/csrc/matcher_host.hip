@@ -538,23 +538,40 @@ int msorb_stereo_matches(msorb_extractor* left, msorb_extractor* right, const ms
         if (kpsL[i].octave < 0 || kpsL[i].octave >= pl.nlevels) return MSORB_E_INVALID;
     for (int i = 0; i < nR; i++)
         if (kpsR[i].octave < 0 || kpsR[i].octave >= pl.nlevels) return MSORB_E_INVALID;
-    DBuf<msorb_keypoint> dkl, dkr;
-    DBuf<uint8_t> ddl, ddr;
-    DBuf<float> dout;
-    DBuf<int> dint;
-    if ((rc = dkl.ensure(nL)) || (rc = dkr.ensure(nR)) || (rc = ddl.ensure((size_t)nL * 32)) ||
-        (rc = ddr.ensure((size_t)nR * 32)) || (rc = dout.ensure((size_t)2 * nL)) || (rc = dint.ensure((size_t)nL + 1)))
+    // scratch kept per calling thread and device (this runs once per frame: allocating and freeing six device buffers per
+    // call cost more than the kernel); inputs and outputs go through pinned staging
+    struct Scratch {
+        int device = -1;
+        DBuf<uint8_t> d_in, d_out;
+        HBuf<uint8_t> h_in, h_out;
+        ~Scratch() {
+            if (device >= 0 && hipSetDevice(device) == hipSuccess) { d_in.release(); d_out.release(); h_in.release(); h_out.release(); }
+        }
+    };
+    static thread_local Scratch scr;
+    if (scr.device != devL) { scr.d_in.release(); scr.d_out.release(); scr.h_in.release(); scr.h_out.release(); scr.device = devL; }
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_kl = 0, o_dl = up16(o_kl + (size_t)nL * sizeof(msorb_keypoint)), o_kr = up16(o_dl + (size_t)nL * 32),
+                 o_dr = up16(o_kr + (size_t)nR * sizeof(msorb_keypoint)), in_bytes = up16(o_dr + (size_t)nR * 32);
+    const size_t out_bytes = (size_t)(3 * nL + 1) * 4;  // u_right, depth, sad[nL] + n_oob
+    if ((rc = scr.d_in.ensure(in_bytes)) || (rc = scr.h_in.ensure(in_bytes)) || (rc = scr.d_out.ensure(out_bytes)) ||
+        (rc = scr.h_out.ensure(out_bytes)))
         return rc;
-    auto cleanup = [&] { dkl.release(); dkr.release(); ddl.release(); ddr.release(); dout.release(); dint.release(); };
-    std::vector<int> sad(nL + 1);
-    hipError_t e = hipMemcpyAsync(dkl.p, kpsL, (size_t)nL * sizeof(msorb_keypoint), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(ddl.p, descL, (size_t)nL * 32, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess && nR) e = hipMemcpyAsync(dkr.p, kpsR, (size_t)nR * sizeof(msorb_keypoint), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess && nR) e = hipMemcpyAsync(ddr.p, descR, (size_t)nR * 32, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemsetAsync(dint.p + nL, 0, sizeof(int), s);
+    std::memcpy(scr.h_in.p + o_kl, kpsL, (size_t)nL * sizeof(msorb_keypoint));
+    std::memcpy(scr.h_in.p + o_dl, descL, (size_t)nL * 32);
+    if (nR) {
+        std::memcpy(scr.h_in.p + o_kr, kpsR, (size_t)nR * sizeof(msorb_keypoint));
+        std::memcpy(scr.h_in.p + o_dr, descR, (size_t)nR * 32);
+    }
+    float* d_ur = reinterpret_cast<float*>(scr.d_out.p);
+    int* d_sad = reinterpret_cast<int*>(scr.d_out.p) + 2 * nL;
+    hipError_t e = hipMemcpyAsync(scr.d_in.p, scr.h_in.p, in_bytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_sad + nL, 0, sizeof(int), s);
     if (e == hipSuccess) {
         StereoArgs a{};
-        a.kpL = dkl.p; a.kpR = dkr.p; a.descL = ddl.p; a.descR = ddr.p;
+        a.kpL = reinterpret_cast<const msorb_keypoint*>(scr.d_in.p + o_kl);
+        a.kpR = reinterpret_cast<const msorb_keypoint*>(scr.d_in.p + o_kr);
+        a.descL = scr.d_in.p + o_dl; a.descR = scr.d_in.p + o_dr;
         a.nL = nL; a.nR = nR; a.rows0 = pl.lv[0].h;
         for (int l = 0; l < pl.nlevels; l++) {
             a.pyrL[l] = pl.lv[l].base; a.pyrR[l] = pr.lv[l].base;
@@ -563,15 +580,15 @@ int msorb_stereo_matches(msorb_extractor* left, msorb_extractor* right, const ms
             a.scale[l] = sc.scale[l]; a.inv_scale[l] = inv_scale[l];
         }
         a.mb = mb; a.mbf = mbf;
-        a.u_right = dout.p; a.depth = dout.p + nL; a.sad = dint.p; a.n_oob = dint.p + nL;
+        a.u_right = d_ur; a.depth = d_ur + nL; a.sad = d_sad; a.n_oob = d_sad + nL;
         launch_stereo_match(a, s);
-        e = hipMemcpyAsync(u_right, dout.p, (size_t)nL * sizeof(float), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(depth, dout.p + nL, (size_t)nL * sizeof(float), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(sad.data(), dint.p, (size_t)(nL + 1) * sizeof(int), hipMemcpyDeviceToHost, s);
+        e = hipMemcpyAsync(scr.h_out.p, scr.d_out.p, out_bytes, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
     }
-    cleanup();
     if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return MSORB_E_HIP; }
+    std::memcpy(u_right, scr.h_out.p, (size_t)nL * sizeof(float));
+    std::memcpy(depth, scr.h_out.p + (size_t)nL * 4, (size_t)nL * sizeof(float));
+    const int* sad = reinterpret_cast<const int*>(scr.h_out.p) + 2 * nL;
     if (n_oob) *n_oob = sad[nL];
     // median-based rejection, Frame.cc:899-912 (serial; vDistIdx is built in ascending iL order)
     std::vector<std::pair<int, int>> vDistIdx;
