@@ -163,6 +163,13 @@ struct msorb_extractor {
     bool overlap_blur = true;
     OrbParams P;
     hipStream_t stream = nullptr, copy_stream = nullptr;
+    // msorb_extract (one host image per call) replays the whole chain — H2D, ~20 kernels on two streams, D2H — as ONE
+    // captured HIP graph: per frame the kernels are microseconds long and the launch calls dominate the host side
+    struct FrameGraph { hipGraphExec_t exec = nullptr; int lap0 = 0, lap1 = 0, rows = 0, cols = 0; };
+    FrameGraph fgraph[2];        // two cached variants (e.g. mono + stereo lapping settings)
+    bool capturing = false;      // enqueue only: no host synchronisation inside the pipeline
+    unsigned long long buffers_epoch = 0;  // bumped whenever a device / pinned buffer may have moved
+    unsigned long long graph_epoch = 0;
     hipEvent_t ev_compact = nullptr, ev_pyramid = nullptr, ev_blur = nullptr;
     hipEvent_t pe[10] = {};
     bool profiling = false;
@@ -369,7 +376,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
     static const bool stagger_env = getenv("MSORB_STAGGER") != nullptr;  // measured: no gain (2.648 vs 2.653 ms), off by default
     const bool stagger = stagger_env && ng > 1;
     // the new call must not start before the handle's own stream has drained (H2D of level 0 in msorb_extract)
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (!h->capturing) HIPCHK(hipStreamSynchronize(h->stream));
     int first = 0;
     for (int gi = 0; gi < ng; gi++) {
         int rc;
@@ -425,6 +432,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
         HIPCHK(hipMemcpyAsync(h->h_mono.p + first, h->d_mono.p + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
         first += n;
     }
+    if (h->capturing) return MSORB_OK;  // graph capture: the caller ends the capture, launches and reads back
     for (int gi = 0; gi < ng; gi++) HIPCHK(hipStreamSynchronize(h->grp[gi].s));
     HIPCHK(hipGetLastError());
     for (int i = 0; i < n_images; i++) {
@@ -680,6 +688,7 @@ void msorb_extractor_destroy(msorb_extractor* h) {
         (void)hipEventDestroy(G.ev_pyr); (void)hipEventDestroy(G.ev_blur); (void)hipEventDestroy(G.ev_fast);
         if (G.own_stream) (void)hipStreamDestroy(G.s);
     }
+    for (auto& fgx : h->fgraph) if (fgx.exec) (void)hipGraphExecDestroy(fgx.exec);
     for (auto& e : h->pe) if (e) (void)hipEventDestroy(e);
     if (h->ev_compact) (void)hipEventDestroy(h->ev_compact);
     if (h->ev_pyramid) (void)hipEventDestroy(h->ev_pyramid);
@@ -760,18 +769,88 @@ int msorb_extract(msorb_extractor* h, const uint8_t* image, int rows, int cols, 
     if ((rc = h->h_img_pin.ensure((size_t)g0.pitch * rows))) return rc;
     if ((rc = h->h_out_pin.ensure((size_t)cap * (sizeof(msorb_keypoint) + 32)))) return rc;
     for (int y = 0; y < rows; y++) memcpy(h->h_img_pin.p + (size_t)y * g0.pitch, image + (size_t)y * stride, cols);
-    HIPCHK(hipMemcpyAsync(h->d_pyr.p + g0.plane_off, h->h_img_pin.p, (size_t)g0.pitch * rows, hipMemcpyHostToDevice,
-                          h->stream));
     LevelView l0{h->d_pyr.p + g0.plane_off, h->G.pyramid_bytes, g0.pitch, cols, rows};
+    msorb_keypoint* pk = reinterpret_cast<msorb_keypoint*>(h->h_out_pin.p);
+    uint8_t* pd = h->h_out_pin.p + (size_t)cap * sizeof(msorb_keypoint);
     int n = 0, mono = 0;
-    if ((rc = run_pipeline(h, l0, 1, lap0, lap1, h->d_kps1.p, h->d_desc1.p, cap, &n, &mono))) return rc;
-    if (n > capacity) { set_error("caller capacity too small"); return MSORB_E_CAPACITY; }
-    if (n > 0) {
-        msorb_keypoint* pk = reinterpret_cast<msorb_keypoint*>(h->h_out_pin.p);
-        uint8_t* pd = h->h_out_pin.p + (size_t)cap * sizeof(msorb_keypoint);
-        HIPCHK(hipMemcpyAsync(pk, h->d_kps1.p, (size_t)n * sizeof(msorb_keypoint), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(pd, h->d_desc1.p, (size_t)n * 32, hipMemcpyDeviceToHost, h->stream));
+
+    // Graph path: the chain of one frame is fixed (same buffers, same grids, device-side counts), so it is captured once
+    // per (geometry, lapping area) and replayed with a single launch; everything the host needs comes back in the same
+    // graph (counts, mono index, and the full-capacity keypoint / descriptor block: 120 KB, cheaper than a second round
+    // trip for the exact count).  Opt-in (MSORB_GRAPH=1): measured on MI355X / ROCm 7.2 it takes a single caller from 0.243
+    // to 0.233 ms per frame, but two host threads replaying graphs at the same time — the reference's left / right eye
+    // threads, Frame.cc:122-125 — serialise inside hipGraphLaunch: 0.49 ms per stereo pair instead of 0.33 ms with plain
+    // launches.  Never used while profiling (stage events) or in the host-quadtree mode.
+    static const bool graph_env = getenv("MSORB_GRAPH") != nullptr && !getenv("MSORB_SERIAL_PIPELINE");
+    const bool graph_ok = graph_env && h->device_quadtree && !h->profiling;
+    // any buffer the graph touches may have been re-allocated since it was captured
+    unsigned long long sig = 1469598103934665603ull;
+    for (const void* q : {(const void*)h->d_pyr.p, (const void*)h->d_blur.p, (const void*)h->d_slots.p, (const void*)h->d_compact.p,
+                          (const void*)h->d_cell_count.p, (const void*)h->d_cell_off.p, (const void*)h->d_level_count.p,
+                          (const void*)h->d_img_total.p, (const void*)h->d_img_base.p, (const void*)h->d_sel_count.p,
+                          (const void*)h->d_sel.p, (const void*)h->d_label.p, (const void*)h->d_sel_pt.p, (const void*)h->d_sel_n.p,
+                          (const void*)h->d_mono.p, (const void*)h->d_kps1.p, (const void*)h->d_desc1.p, (const void*)h->d_taps.p,
+                          (const void*)h->d_cells.p, (const void*)h->h_img_pin.p, (const void*)h->h_out_pin.p,
+                          (const void*)h->h_sel_count.p, (const void*)h->h_mono.p})
+        sig = (sig ^ (unsigned long long)(uintptr_t)q) * 1099511628211ull;
+    if (sig != h->graph_epoch) {
+        for (auto& fg : h->fgraph) { if (fg.exec) (void)hipGraphExecDestroy(fg.exec); fg = msorb_extractor::FrameGraph{}; }
+        h->graph_epoch = sig;
+    }
+    msorb_extractor::FrameGraph* fg = nullptr;
+    if (graph_ok) {
+        for (auto& c : h->fgraph)
+            if (c.exec && c.lap0 == lap0 && c.lap1 == lap1 && c.rows == rows && c.cols == cols) fg = &c;
+        if (!fg && h->last_n_images == 1 && h->last_groups == 1) {  // not on the very first call: lazy initialisations are over
+            msorb_extractor::FrameGraph* slot = h->fgraph[0].exec ? &h->fgraph[1] : &h->fgraph[0];
+            if (slot->exec) { (void)hipGraphExecDestroy(slot->exec); *slot = msorb_extractor::FrameGraph{}; }
+            HIPCHK(hipStreamSynchronize(h->stream));
+            hipGraph_t graph = nullptr;
+            HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            h->capturing = true;
+            hipError_t ce = hipMemcpyAsync(h->d_pyr.p + g0.plane_off, h->h_img_pin.p, (size_t)g0.pitch * rows, hipMemcpyHostToDevice,
+                                           h->stream);
+            int prc = MSORB_OK;
+            if (ce == hipSuccess) prc = run_pipeline(h, l0, 1, lap0, lap1, h->d_kps1.p, h->d_desc1.p, cap, &n, &mono);
+            if (ce == hipSuccess && prc == MSORB_OK)
+                ce = hipMemcpyAsync(pk, h->d_kps1.p, (size_t)cap * sizeof(msorb_keypoint), hipMemcpyDeviceToHost, h->stream);
+            if (ce == hipSuccess && prc == MSORB_OK)
+                ce = hipMemcpyAsync(pd, h->d_desc1.p, (size_t)cap * 32, hipMemcpyDeviceToHost, h->stream);
+            h->capturing = false;
+            const hipError_t ee = hipStreamEndCapture(h->stream, &graph);
+            if (ce == hipSuccess && prc == MSORB_OK && ee == hipSuccess && graph &&
+                hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                slot->lap0 = lap0; slot->lap1 = lap1; slot->rows = rows; slot->cols = cols;
+                fg = slot;
+            } else {
+                slot->exec = nullptr;
+                (void)hipGetLastError();  // capture failed: fall back to plain launches below
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+    }
+    if (fg) {
+        h->h_pyr_valid = false;       // the same bookkeeping run_pipeline does for a call
+        h->compact_on_host = false;
+        HIPCHK(hipGraphLaunch(fg->exec, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipGetLastError());
+        n = h->h_sel_count.p[0];
+        mono = h->h_mono.p[0];
+        if (n < 0) { set_error("keypoint capacity exceeded"); return MSORB_E_CAPACITY; }
+        if (n > capacity) { set_error("caller capacity too small"); return MSORB_E_CAPACITY; }
+    } else {
+        HIPCHK(hipMemcpyAsync(h->d_pyr.p + g0.plane_off, h->h_img_pin.p, (size_t)g0.pitch * rows, hipMemcpyHostToDevice,
+                              h->stream));
+        if ((rc = run_pipeline(h, l0, 1, lap0, lap1, h->d_kps1.p, h->d_desc1.p, cap, &n, &mono))) return rc;
+        if (n > capacity) { set_error("caller capacity too small"); return MSORB_E_CAPACITY; }
+        if (n > 0) {
+            HIPCHK(hipMemcpyAsync(pk, h->d_kps1.p, (size_t)n * sizeof(msorb_keypoint), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(pd, h->d_desc1.p, (size_t)n * 32, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+    }
+    if (n > 0) {
         memcpy(keypoints, pk, (size_t)n * sizeof(msorb_keypoint));
         memcpy(descriptors, pd, (size_t)n * 32);
     }

@@ -253,3 +253,38 @@ def test_full_bench_size_properties(msorb_mod, oracle):
         assert np.all(bi[i, :c][dup] < np.arange(c)[dup])
         assert all(np.array_equal(desc_all[i, a], desc_all[i, b]) for a, b in zip(np.arange(c)[dup], bi[i, :c][dup]))
     ex.close()
+
+
+def test_graph_replay_path_matches(tmp_path):
+    """MSORB_GRAPH=1: msorb_extract replays the captured chain (third call onwards); results must equal the plain path and
+    the oracle, also across a change of the lapping area (second cached graph) and of the geometry (graphs dropped)."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys
+import numpy as np
+sys.path[:0] = [os.path.join(ROOT, "ms-slam_amd"), os.path.join(ROOT, "oracle")]
+import msorb, orb_oracle
+from msorb import synth
+ex = msorb.ORBextractor(1000, 1.2, 8, 20, 7)
+ref = orb_oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+def same(a, b):
+    return a[0] == b[0] and np.array_equal(a[1].view(np.uint8), b[1].view(np.uint8)) and np.array_equal(a[2], b[2])
+imgs = [synth.image(50 + i, 240, 320) for i in range(4)]
+for rep in range(3):
+    for i, im in enumerate(imgs):
+        assert same(ex(im), ref(im)), (rep, i)
+        assert same(ex(im, (100, 200)), ref(im, (100, 200))), (rep, i, "lap")
+big = synth.image(9, 376, 1241)
+for rep in range(3):
+    assert same(ex(big), ref(big))
+    assert same(ex(imgs[0]), ref(imgs[0]))
+lvl = ex.debug_level(0, 3)
+assert lvl.shape == ref.level(3).shape
+print("graph-ok")
+'''.replace("ROOT", repr(ROOT))
+    env = dict(os.environ, MSORB_GRAPH="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "graph-ok" in out.stdout, out.stdout + out.stderr
