@@ -966,7 +966,7 @@ __device__ __forceinline__ int rint_small(float x) { return __float_as_int(__fad
 constexpr int kPatchPitch = 44;  // bytes per staged patch row: 11 dwords
 constexpr int kKpPerWave = 4;  // keypoints handled back to back by one wave (amortises the per-lane table loads)
 
-__global__ __launch_bounds__(256) void describe_kernel(PyramidView pyr, PyramidView blur, const SelRec* __restrict__ sel,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void describe_kernel(PyramidView pyr, PyramidView blur, const SelRec* __restrict__ sel,
                                                        const int* __restrict__ sel_count, int sel_stride,
                                                        LevelScale scales, msorb_keypoint* __restrict__ kps,
                                                        uint8_t* __restrict__ desc, int out_stride) {
