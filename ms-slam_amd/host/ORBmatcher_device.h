@@ -6,6 +6,8 @@
 //   ORB_SLAM3::msorb_host::SearchByProjection(...)       body of ORBmatcher::SearchByProjection(Frame&, const
 //                                                        vector<shared_ptr<MapPoint>>&, th, bFarPoints, thFarPoints)
 //                                                        (src/ORBmatcher.cc:43-142, rectified / Nleft == -1 branch)
+//   ORB_SLAM3::msorb_host::SearchLocalPointsPrepass(...) the isInFrustum loop of Tracking::SearchLocalPoints
+//                                                        (src/Tracking.cc:3343-3361, src/Frame.cc:512-571)
 //   ORB_SLAM3::msorb_host::ComputeStereoMatches(...)     body of Frame::ComputeStereoMatches (src/Frame.cc:743-913)
 //
 // Use inside the reference: ORBmatcher::SearchByProjection keeps its signature and becomes
@@ -100,6 +102,72 @@ int SearchByProjection(DeviceFrame<FrameT>& dev, FrameT& F, const std::vector<Ma
     for (int i = 0; i < N; i++)
         if (frameMp[i] != before[i] && frameMp[i] >= 0 && frameMp[i] < M) F.mvpMapPoints[i] = vpMapPoints[frameMp[i]];
     return nmatches;
+}
+
+// The projection loop of Tracking::SearchLocalPoints (src/Tracking.cc:3343-3361): mCurrentFrame.isInFrustum(pMP, 0.5)
+// (src/Frame.cc:512-571, pinhole branch) for every local map point that is not already matched in this frame and not
+// bad, in one device call.  Writes the same MapPoint scratch fields, calls IncreaseVisible() and fills
+// F.mmProjectPoints exactly like the loop; returns nToMatch.  MapPoint needs two trivial accessors next to
+// GetMaxDistanceInvariance(): `float GetMaxDistance()` / `float GetMinDistance()` returning mfMaxDistance / mfMinDistance
+// (PredictScale divides the raw value, MapPoint.cc:562; the members are protected).
+template <class FrameT, class MapPointPtr>
+int SearchLocalPointsPrepass(FrameT& F, const std::vector<MapPointPtr>& vpLocalMapPoints, float viewingCosLimit = 0.5f,
+                             int device = 0) {
+    std::vector<int> which;
+    which.reserve(vpLocalMapPoints.size());
+    for (int i = 0; i < (int)vpLocalMapPoints.size(); i++) {
+        const auto& p = vpLocalMapPoints[i];
+        if (p->mnLastFrameSeen == F.mnId) continue;  // :3347-3348
+        if (p->isBad()) continue;                    // :3349-3350
+        which.push_back(i);
+    }
+    const int n = (int)which.size();
+    if (n == 0) return 0;
+    msorb_frustum fr{};
+    const auto Tcw = F.GetPose();
+    const auto R = Tcw.rotationMatrix();             // == mRcw (Frame::UpdatePoseMatrices, Frame.cc:472-479)
+    const auto t = Tcw.translation();                // == mtcw
+    const auto Ow = F.GetCameraCenter();             // == mOw
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) fr.Rcw[3 * r + c] = R(r, c);
+        fr.tcw[r] = t(r);
+        fr.Ow[r] = Ow(r);
+    }
+    fr.fx = F.mpCamera->getParameter(0); fr.fy = F.mpCamera->getParameter(1);
+    fr.cx = F.mpCamera->getParameter(2); fr.cy = F.mpCamera->getParameter(3);
+    fr.min_x = F.mnMinX; fr.max_x = F.mnMaxX; fr.min_y = F.mnMinY; fr.max_y = F.mnMaxY;
+    fr.mbf = F.mbf; fr.log_scale_factor = F.mfLogScaleFactor; fr.n_scale_levels = F.mnScaleLevels;
+    std::vector<float> pos((size_t)3 * n), nrm((size_t)3 * n), maxd(n), mind(n), px(n), py(n), pxr(n), depth(n), vcos(n);
+    std::vector<int> level(n);
+    std::vector<uint8_t> inView(n);
+    for (int k = 0; k < n; k++) {
+        const auto& p = vpLocalMapPoints[which[k]];
+        const auto P = p->GetWorldPos();
+        const auto N = p->GetNormal();
+        for (int c = 0; c < 3; c++) { pos[3 * k + c] = P(c); nrm[3 * k + c] = N(c); }
+        maxd[k] = p->GetMaxDistance();
+        mind[k] = p->GetMinDistance();
+    }
+    check(msorb_is_in_frustum(device, &fr, viewingCosLimit, n, pos.data(), nrm.data(), maxd.data(), mind.data(), inView.data(),
+                              px.data(), py.data(), pxr.data(), depth.data(), level.data(), vcos.data(), nullptr),
+          "msorb_is_in_frustum");
+    int nToMatch = 0;
+    for (int k = 0; k < n; k++) {
+        const auto& p = vpLocalMapPoints[which[k]];
+        p->mbTrackInView = inView[k] != 0;           // Frame.cc:515-517, 563
+        p->mTrackProjX = px[k];
+        p->mTrackProjY = py[k];
+        if (inView[k]) {                             // :563-571
+            p->mTrackProjXR = pxr[k];
+            p->mTrackDepth = depth[k];
+            p->mnTrackScaleLevel = level[k];
+            p->mTrackViewCos = vcos[k];
+            p->IncreaseVisible();                    // Tracking.cc:3354-3355
+            nToMatch++;
+            F.mmProjectPoints[p->mnId] = {p->mTrackProjX, p->mTrackProjY};  // :3357-3360
+        }
+    }
+    return nToMatch;
 }
 
 // Frame::ComputeStereoMatches(): fills F.mvuRight / F.mvDepth from the two extractors' device pyramids.

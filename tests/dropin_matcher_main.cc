@@ -4,6 +4,8 @@
 // output: nmatches + the map-point index every keypoint holds afterwards.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <map>
 #include <memory>
 #include <vector>
 
@@ -12,22 +14,43 @@
 #include "ORBmatcher_device.h"
 
 namespace ORB_SLAM3 {
-struct MapPoint {  // the members ORBmatcher.cc:43-142 touches
+struct Vec3 { float v[3]; float operator()(int i) const { return v[i]; } };                       // Eigen::Vector3f stand-in
+struct Mat3 { float m[9]; float operator()(int r, int c) const { return m[3 * r + c]; } };       // Eigen::Matrix3f stand-in
+struct SE3 { Mat3 R; Vec3 t; Mat3 rotationMatrix() const { return R; } Vec3 translation() const { return t; } };  // Sophus::SE3f
+struct Camera { std::vector<float> p; float getParameter(int i) { return p[i]; } };              // GeometricCamera
+struct MapPoint {  // the members ORBmatcher.cc:43-142 and Frame::isInFrustum touch
     bool mbTrackInView = false, mbTrackInViewR = false, mbSparsified = false, mbBad = false;
     float mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0, mTrackDepth = 0, mTrackViewCos = 0;
-    int mnTrackScaleLevel = 0, nObs = 0, id = -1;
+    int mnTrackScaleLevel = 0, nObs = 0, id = -1, nVisible = 0;
+    long unsigned int mnLastFrameSeen = 0, mnId = 0;
+    Vec3 pos{}, normal{};
+    float mfMaxDistance = 0, mfMinDistance = 0;
     unsigned char descriptor[32];
     bool isBad() const { return mbBad; }
     int Observations() const { return nObs; }
     cv::Mat GetDescriptor() { return cv::Mat(1, 32, CV_8UC1, descriptor, 32); }
+    Vec3 GetWorldPos() const { return pos; }
+    Vec3 GetNormal() const { return normal; }
+    float GetMaxDistance() const { return mfMaxDistance; }
+    float GetMinDistance() const { return mfMinDistance; }
+    void IncreaseVisible(int n = 1) { nVisible += n; }
 };
 struct Frame {
     int N = 0, Nleft = -1;
+    long unsigned int mnId = 0;
     std::vector<cv::KeyPoint> mvKeysUn;
     cv::Mat mDescriptors;
     std::vector<float> mvuRight, mvScaleFactors;
     std::vector<std::shared_ptr<MapPoint>> mvpMapPoints;
     static float mnMinX, mnMaxX, mnMinY, mnMaxY;
+    SE3 mTcw{};
+    Vec3 mOw{};
+    Camera* mpCamera = nullptr;
+    float mbf = 0, mfLogScaleFactor = 0;
+    int mnScaleLevels = 0;
+    std::map<long unsigned int, cv::Point2f> mmProjectPoints;
+    SE3 GetPose() const { return mTcw; }
+    Vec3 GetCameraCenter() const { return mOw; }
 };
 float Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY;
 }  // namespace ORB_SLAM3
@@ -39,9 +62,51 @@ static std::vector<T> rd(FILE* f, size_t n) {
     return v;
 }
 
+// mode "prepass": Tracking::SearchLocalPoints' isInFrustum loop through msorb_host::SearchLocalPointsPrepass
+static int prepass_main(const char* in, const char* out) {
+    using namespace ORB_SLAM3;
+    FILE* f = fopen(in, "rb");
+    if (!f) return 3;
+    const auto hdr = rd<int>(f, 2);  // M, nlevels
+    const int M = hdr[0];
+    const auto fl = rd<float>(f, 9 + 3 + 3 + 4 + 4 + 2);  // R, t, Ow, fx fy cx cy, bounds, mbf, logScale
+    const auto pos = rd<float>(f, (size_t)3 * M), nrm = rd<float>(f, (size_t)3 * M), maxd = rd<float>(f, M), mind = rd<float>(f, M);
+    const auto skip_seen = rd<unsigned char>(f, M), bad = rd<unsigned char>(f, M);
+    fclose(f);
+    Frame F;
+    F.mnId = 42;
+    memcpy(F.mTcw.R.m, &fl[0], 36); memcpy(F.mTcw.t.v, &fl[9], 12); memcpy(F.mOw.v, &fl[12], 12);
+    Camera cam{{fl[15], fl[16], fl[17], fl[18]}};
+    F.mpCamera = &cam;
+    Frame::mnMinX = fl[19]; Frame::mnMaxX = fl[20]; Frame::mnMinY = fl[21]; Frame::mnMaxY = fl[22];
+    F.mbf = fl[23]; F.mfLogScaleFactor = fl[24]; F.mnScaleLevels = hdr[1];
+    std::vector<std::shared_ptr<MapPoint>> local(M);
+    for (int i = 0; i < M; i++) {
+        auto p = std::make_shared<MapPoint>();
+        p->mnId = 1000 + i;
+        memcpy(p->pos.v, &pos[3 * i], 12); memcpy(p->normal.v, &nrm[3 * i], 12);
+        p->mfMaxDistance = maxd[i]; p->mfMinDistance = mind[i];
+        p->mnLastFrameSeen = skip_seen[i] ? F.mnId : 7; p->mbBad = bad[i];
+        p->mTrackProjX = -7.f; p->mnTrackScaleLevel = -7;  // sentinels: untouched points keep them
+        local[i] = p;
+    }
+    const int nToMatch = msorb_host::SearchLocalPointsPrepass(F, local);
+    FILE* o = fopen(out, "wb");
+    fwrite(&nToMatch, 4, 1, o);
+    for (int i = 0; i < M; i++) {
+        const auto& p = local[i];
+        const int iv = p->mbTrackInView, pp = (int)F.mmProjectPoints.count(p->mnId);
+        const float v[5] = {p->mTrackProjX, p->mTrackProjY, p->mTrackProjXR, p->mTrackDepth, p->mTrackViewCos};
+        fwrite(&iv, 4, 1, o); fwrite(v, 4, 5, o); fwrite(&p->mnTrackScaleLevel, 4, 1, o); fwrite(&p->nVisible, 4, 1, o); fwrite(&pp, 4, 1, o);
+    }
+    fclose(o);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     using namespace ORB_SLAM3;
     if (argc < 3) return 2;
+    if (argc > 3 && std::string(argv[3]) == "prepass") return prepass_main(argv[1], argv[2]);
     FILE* f = fopen(argv[1], "rb");
     if (!f) return 3;
     const auto hdr = rd<int>(f, 4);  // N, nlevels, M, bFarPoints

@@ -145,3 +145,48 @@ def test_cpp_sparsification_adapter_matches_oracle(tmp_path, oracle, msorb_mod):
         return {int(owner[r]): (float(rhs[r]), ci[rb[r]:rb[r + 1]].tolist()) for r in range(len(kind)) if kind[r] == 2}
     assert outside(row_kind, row_kf, row_begin, row_rhs, col_idx) == \
         outside(want["row_kind"], want["row_owner"], want["row_begin"], want["row_rhs"], want["col_idx"])
+
+
+def test_cpp_search_local_points_prepass_matches_oracle(tmp_path, oracle, msorb_mod):
+    """msorb_host::SearchLocalPointsPrepass (the isInFrustum loop of Tracking::SearchLocalPoints over stand-in Frame /
+    MapPoint objects) vs the oracle's Frame::isInFrustum restatement; skipped points must stay untouched."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import frustum_cases as fc
+    exe = tmp_path / "dropin_matcher"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", f"-I{ROOT}/tests/cv_stub", f"-I{ROOT}/ms-slam_amd/host",
+                           f"-I{ROOT}/include", f"{ROOT}/tests/dropin_matcher_main.cc", f"-L{ROOT}/ms-slam_amd", "-lmsorb",
+                           f"-Wl,-rpath,{ROOT}/ms-slam_amd", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    M, nlev = 5000, 8
+    R, t, Ow = fc.pose(4)
+    P, Nn, maxd, mind = fc.points(4, M, R, t, Ow)
+    rng = np.random.Generator(np.random.PCG64(2))
+    seen = (rng.random(M) < 0.2).astype(np.uint8)
+    bad = (rng.random(M) < 0.05).astype(np.uint8)
+    c = fc.KITTI_CAM
+    logs = float(np.log(np.float32(1.2)))
+    blob, out = tmp_path / "pin.bin", tmp_path / "pout.bin"
+    with open(blob, "wb") as f:
+        f.write(struct.pack("<ii", M, nlev))
+        f.write(np.asarray(R, np.float32).tobytes() + np.asarray(t, np.float32).tobytes() + np.asarray(Ow, np.float32).tobytes())
+        f.write(struct.pack("<4f4f2f", c["fx"], c["fy"], c["cx"], c["cy"], *c["bounds"], c["mbf"], logs))
+        for a in (P, Nn, maxd, mind, seen, bad):
+            f.write(np.ascontiguousarray(a).tobytes())
+    subprocess.check_call([str(exe), str(blob), str(out), "prepass"])
+    raw = out.read_bytes()
+    n_to_match = struct.unpack_from("<i", raw, 0)[0]
+    rec = np.frombuffer(raw, np.dtype([("inview", "<i4"), ("f", "<f4", 5), ("level", "<i4"), ("visible", "<i4"), ("proj", "<i4")]), M, 4)
+    F = msorb_mod.Frustum.make(R, t, Ow, c["fx"], c["fy"], c["cx"], c["cy"], c["bounds"], c["mbf"], logs, nlev)
+    visit = (seen == 0) & (bad == 0)
+    want = oracle.is_in_frustum(F, P[visit], Nn[visit], maxd[visit], mind[visit])
+    got = rec[visit]
+    assert np.array_equal(got["inview"], want["track_in_view"].astype(np.int32))
+    assert got["f"][:, 0].tobytes() == want["proj_x"].tobytes() and got["f"][:, 1].tobytes() == want["proj_y"].tobytes()
+    iv = want["track_in_view"] > 0
+    assert 200 < iv.sum() < len(iv) and n_to_match == int(iv.sum())
+    for col, key in ((2, "proj_xr"), (3, "track_depth"), (4, "view_cos")):
+        assert got["f"][iv, col].tobytes() == want[key][iv].tobytes(), key
+    assert np.array_equal(got["level"][iv], want["level"][iv])
+    assert np.array_equal(got["visible"], iv.astype(np.int32)) and np.array_equal(got["proj"], iv.astype(np.int32))
+    untouched = rec[~visit]                                   # mnLastFrameSeen == frame id or isBad(): not visited
+    assert np.all(untouched["f"][:, 0] == -7) and np.all(untouched["level"] == -7) and np.all(untouched["visible"] == 0)
