@@ -190,3 +190,55 @@ def test_cpp_search_local_points_prepass_matches_oracle(tmp_path, oracle, msorb_
     assert np.array_equal(got["visible"], iv.astype(np.int32)) and np.array_equal(got["proj"], iv.astype(np.int32))
     untouched = rec[~visit]                                   # mnLastFrameSeen == frame id or isBad(): not visited
     assert np.all(untouched["f"][:, 0] == -7) and np.all(untouched["level"] == -7) and np.all(untouched["visible"] == 0)
+
+
+def test_cpp_bow_adapters_match_oracle(tmp_path, oracle, msorb_mod):
+    """ms-slam_amd/host/BoW_device.h (Frame::ComputeBoW body + the ComputeDistinctiveDescriptors choice) compiled against
+    stand-in Frame / DBoW2 container types, vs oracle/bow_oracle.cc."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bow_cases
+    import orb_oracle
+    exe = tmp_path / "dropin_bow"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", f"-I{ROOT}/tests/cv_stub", f"-I{ROOT}/ms-slam_amd/host",
+                           f"-I{ROOT}/include", f"{ROOT}/tests/dropin_bow_main.cc", f"-L{ROOT}/ms-slam_amd", "-lmsorb",
+                           f"-Wl,-rpath,{ROOT}/ms-slam_amd", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    voc = bow_cases.make_vocabulary(3, k=10, L=4, irregular=True, stop_frac=0.1)
+    bow_cases.write_text(tmp_path / "voc.txt", voc)
+    feats = bow_cases.make_features(21, voc, 1800)
+    obs, ob = bow_cases.make_observations(4, [0, 1, 2, 5, 9, 20, 40, 70] + list(range(3, 30)))
+    P = len(ob) - 1
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(struct.pack("<ii", len(feats), P))
+        f.write(feats.tobytes())
+        f.write(ob.tobytes())
+        f.write(obs.tobytes())
+    subprocess.check_call([str(exe), str(tmp_path / "voc.txt"), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")])
+    blob = (tmp_path / "out.bin").read_bytes()
+    nb, nf, same = struct.unpack_from("<iii", blob, 0)
+    pos = 12
+    words, values = [], []
+    for _ in range(nb):
+        w, v = struct.unpack_from("<Id", blob, pos)
+        pos += 12
+        words.append(w)
+        values.append(v)
+    nodes, lists = [], []
+    for _ in range(nf):
+        node, cnt = struct.unpack_from("<Ii", blob, pos)
+        pos += 8
+        lists.append(np.frombuffer(blob, np.uint32, cnt, pos).tolist())
+        pos += 4 * cnt
+        nodes.append(node)
+    best = np.frombuffer(blob, np.int32, P, pos)
+    orc = orb_oracle.OracleVocabulary(voc["k"], voc["L"], 0, 0, voc["parent"], voc["is_leaf"], voc["descriptors"],
+                                      voc["weights"])
+    want = orc.transform(feats, 4)
+    assert same == 1 and nb > 100
+    assert words == want["bow_word"].tolist()
+    assert np.asarray(values, np.float64).tobytes() == want["bow_value"].tobytes()
+    assert nodes == want["fv_node"].tolist()
+    fb = want["fv_begin"]
+    assert lists == [want["fv_feat"][fb[r]:fb[r + 1]].tolist() for r in range(len(nodes))]
+    ei, _ = orb_oracle.distinctive_descriptors(obs, ob)
+    assert best.tolist() == ei.tolist()
