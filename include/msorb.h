@@ -197,6 +197,36 @@ int msorb_stereo_matches(msorb_extractor* left, msorb_extractor* right, const ms
                          const uint8_t* desc_left, const msorb_keypoint* kps_right, int n_right,
                          const uint8_t* desc_right, float mb, float mbf, float* u_right, float* depth, int* n_oob);
 
+/* ORBmatcher::SearchByBoW — the three forms: (pKF, F, vpMapPointMatches) ORBmatcher.cc:223-421 (pinhole branch,
+ * F.Nleft == -1; TrackReferenceKeyFrame Tracking.cc:2727, Relocalization :3585) and the two KeyFrame-KeyFrame forms
+ * :872-1016, :1018-1166 (LoopClosing).  One msorb_bow_pair per call of the reference; a batch of pairs (all
+ * relocalisation / loop candidates of one frame) is matched by ONE launch, one wavefront per (pair, common node).
+ * Set 1 = the queries (pKF / pKF1), set 2 = the trains (F / pKF2):
+ *   desc1/desc2     n x 32 descriptor rows
+ *   valid1[n1]      1 = the query is visited (map point present and not bad, descriptor not empty, :253-263 /
+ *                   :910-920 / :1066-1078)
+ *   avail2[n2]      1 = the train may be chosen (:934-944 / :1090-1103); NULL = all (the Frame form, :227)
+ *   fvK_*           DBoW2::FeatureVector as CSR: node ids ascending (std::map order), features of node r are
+ *                   fvK_feat[fvK_begin[r] .. fvK_begin[r+1]); a feature index appears at most once per vector
+ *   angle1/angle2   keypoint angles for the rotation histogram (may be NULL when check_orientation == 0)
+ * Outputs: match12[n1] = index of the matched train or -1, match21[n2] (may be NULL) the inverse, nmatches — all
+ * after the histogram filter (:396-418).  th_low / inclusive: bestDist1 <= TH_LOW (:332) or bestDist1 < TH_LOW
+ * (:959, :1118).  Host arrays; *elapsed_ms (may be NULL) = device time of the launch. */
+typedef struct msorb_bow_pair {
+    int n1, n2;
+    const uint8_t *desc1, *desc2;
+    const uint8_t *valid1, *avail2;
+    int fv1_nodes;
+    const int *fv1_node, *fv1_begin, *fv1_feat;
+    int fv2_nodes;
+    const int *fv2_node, *fv2_begin, *fv2_feat;
+    const float *angle1, *angle2;
+    int *match12, *match21;
+    int nmatches;
+} msorb_bow_pair;
+int msorb_search_by_bow(int device, msorb_bow_pair* pairs, int n_pairs, int th_low, int inclusive, float nnratio,
+                        int check_orientation, float* elapsed_ms);
+
 /* ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:2277-2318) on histogram bin sizes; ind[3]. Host only. */
 int msorb_three_maxima(const int* bin_sizes, int n_bins, int* ind);
 

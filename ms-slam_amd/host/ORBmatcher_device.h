@@ -9,6 +9,11 @@
 //   ORB_SLAM3::msorb_host::SearchLocalPointsPrepass(...) the isInFrustum loop of Tracking::SearchLocalPoints
 //                                                        (src/Tracking.cc:3343-3361, src/Frame.cc:512-571)
 //   ORB_SLAM3::msorb_host::ComputeStereoMatches(...)     body of Frame::ComputeStereoMatches (src/Frame.cc:743-913)
+//   ORB_SLAM3::msorb_host::SearchByBoW(...)              bodies of ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches)
+//                                                        (src/ORBmatcher.cc:223-421, Nleft == -1 branch) and
+//                                                        SearchByBoW(pKF1, pKF2, vpMatches12) (:872-1016,
+//                                                        SearchByBoWKeyFrames here); the batch form
+//                                                        serves Relocalization's candidate loop (Tracking.cc:3577-3600)
 //
 // Use inside the reference: ORBmatcher::SearchByProjection keeps its signature and becomes
 //     static thread_local msorb_host::DeviceFrame<Frame> dev;
@@ -168,6 +173,105 @@ int SearchLocalPointsPrepass(FrameT& F, const std::vector<MapPointPtr>& vpLocalM
         }
     }
     return nToMatch;
+}
+
+// ---- SearchByBoW ----------------------------------------------------------------------------------------------
+struct BowSide {  // one KeyFrame / Frame flattened for msorb_bow_pair
+    std::vector<uint8_t> desc, flag;
+    std::vector<int> node, begin, feat;
+    std::vector<float> angle;
+    template <class MatT, class FeatVecT, class KeysT>
+    void Fill(const MatT& descriptors, const FeatVecT& fv, const KeysT& keys) {
+        const int n = descriptors.rows;
+        desc.resize((size_t)n * 32);
+        for (int i = 0; i < n; i++) std::memcpy(&desc[(size_t)i * 32], descriptors.template ptr<unsigned char>(i), 32);
+        angle.resize(n);
+        for (int i = 0; i < n; i++) angle[i] = keys[i].angle;
+        node.clear(); feat.clear(); begin.assign(1, 0);
+        for (const auto& e : fv) {  // std::map: ascending node id
+            node.push_back((int)e.first);
+            for (unsigned idx : e.second) feat.push_back((int)idx);
+            begin.push_back((int)feat.size());
+        }
+    }
+    template <class MapPointPtr>
+    void FlagGood(const std::vector<MapPointPtr>& mps) {  // pMP && !pMP->isBad()
+        flag.assign(desc.size() / 32, 0);
+        for (size_t i = 0; i < mps.size() && i < flag.size(); i++) flag[i] = mps[i] && !mps[i]->isBad();
+    }
+};
+inline void bind(msorb_bow_pair& P, const BowSide& a, const BowSide& b, bool b_all_available, std::vector<int>& m12,
+                 std::vector<int>& m21) {
+    P = msorb_bow_pair{};
+    P.n1 = (int)a.angle.size(); P.n2 = (int)b.angle.size();
+    m12.assign(P.n1, -1); m21.assign(P.n2, -1);
+    P.desc1 = a.desc.data(); P.desc2 = b.desc.data();
+    P.valid1 = a.flag.data(); P.avail2 = b_all_available ? nullptr : b.flag.data();
+    P.fv1_nodes = (int)a.node.size(); P.fv1_node = a.node.data(); P.fv1_begin = a.begin.data(); P.fv1_feat = a.feat.data();
+    P.fv2_nodes = (int)b.node.size(); P.fv2_node = b.node.data(); P.fv2_begin = b.begin.data(); P.fv2_feat = b.feat.data();
+    P.angle1 = a.angle.data(); P.angle2 = b.angle.data();
+    P.match12 = m12.data(); P.match21 = m21.data();
+}
+
+// for(each candidate pKF) nmatches = matcher.SearchByBoW(pKF, F, vvpMapPointMatches[i]) in ONE device launch
+// (Tracking::Relocalization, Tracking.cc:3577-3600; one candidate = ORBmatcher::SearchByBoW(pKF, F, ...), :223-421).
+template <class KeyFramePtr, class FrameT, class MapPointPtr>
+std::vector<int> SearchByBoWBatch(const std::vector<KeyFramePtr>& vpKFs, FrameT& F,
+                                  std::vector<std::vector<MapPointPtr>>& vvpMapPointMatches, float mfNNratio,
+                                  bool mbCheckOrientation, int device = 0) {
+    const size_t K = vpKFs.size();
+    BowSide frame;
+    frame.Fill(F.mDescriptors, F.mFeatVec, F.mvKeys);
+    std::vector<BowSide> kf(K);
+    std::vector<std::vector<MapPointPtr>> mpsKF(K);
+    std::vector<msorb_bow_pair> pairs(K);
+    std::vector<std::vector<int>> m12(K), m21(K);
+    for (size_t k = 0; k < K; k++) {
+        mpsKF[k] = vpKFs[k]->GetMapPointMatches();                         // :225
+        kf[k].Fill(vpKFs[k]->mDescriptors, vpKFs[k]->GetFeatureVector(), vpKFs[k]->mvKeys);
+        kf[k].FlagGood(mpsKF[k]);                                          // :253-259
+        bind(pairs[k], kf[k], frame, true, m12[k], m21[k]);
+    }
+    check(msorb_search_by_bow(device, pairs.data(), (int)K, 50 /* TH_LOW */, 1, mfNNratio, mbCheckOrientation, nullptr),
+          "msorb_search_by_bow");
+    std::vector<int> nmatches(K);
+    vvpMapPointMatches.resize(K);
+    for (size_t k = 0; k < K; k++) {
+        vvpMapPointMatches[k].assign(F.N, MapPointPtr());                  // :227
+        for (int j = 0; j < (int)m21[k].size() && j < F.N; j++)
+            if (m21[k][j] >= 0) vvpMapPointMatches[k][j] = mpsKF[k][m21[k][j]];   // :336
+        nmatches[k] = pairs[k].nmatches;
+    }
+    return nmatches;
+}
+template <class KeyFramePtr, class FrameT, class MapPointPtr>
+int SearchByBoW(const KeyFramePtr& pKF, FrameT& F, std::vector<MapPointPtr>& vpMapPointMatches, float mfNNratio,
+                bool mbCheckOrientation, int device = 0) {
+    std::vector<std::vector<MapPointPtr>> out;
+    const int n = SearchByBoWBatch(std::vector<KeyFramePtr>{pKF}, F, out, mfNNratio, mbCheckOrientation, device)[0];
+    vpMapPointMatches = std::move(out[0]);
+    return n;
+}
+// ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (:872-1016, GetNLeft() == -1)
+template <class KeyFramePtr, class MapPointPtr>
+int SearchByBoWKeyFrames(const KeyFramePtr& pKF1, const KeyFramePtr& pKF2, std::vector<MapPointPtr>& vpMatches12, float mfNNratio,
+                bool mbCheckOrientation, int device = 0) {
+    const auto mps1 = pKF1->GetMapPointMatches();
+    const auto mps2 = pKF2->GetMapPointMatches();
+    BowSide a, b;
+    a.Fill(pKF1->mDescriptors, pKF1->GetFeatureVector(), pKF1->GetAllKeyUn());
+    b.Fill(pKF2->mDescriptors, pKF2->GetFeatureVector(), pKF2->GetAllKeyUn());
+    a.FlagGood(mps1);
+    b.FlagGood(mps2);                                                      // :934-944
+    msorb_bow_pair P;
+    std::vector<int> m12, m21;
+    bind(P, a, b, false, m12, m21);
+    check(msorb_search_by_bow(device, &P, 1, 50 /* TH_LOW */, 0 /* '<', :959 */, mfNNratio, mbCheckOrientation, nullptr),
+          "msorb_search_by_bow");
+    vpMatches12.assign(mps1.size(), MapPointPtr());                        // :884
+    for (size_t i = 0; i < m12.size() && i < mps1.size(); i++)
+        if (m12[i] >= 0) vpMatches12[i] = mps2[m12[i]];                    // :963
+    return P.nmatches;
 }
 
 // Frame::ComputeStereoMatches(): fills F.mvuRight / F.mvDepth from the two extractors' device pyramids.

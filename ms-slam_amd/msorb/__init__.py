@@ -567,3 +567,45 @@ def is_in_frustum(frustum, pos_w, normal, max_distance, min_distance, viewing_co
                                   _np_ptr(lvl), _np_ptr(vc), C.addressof(ms)), "msorb_is_in_frustum")
     return dict(track_in_view=inv[:n], proj_x=px[:n], proj_y=py[:n], proj_xr=pxr[:n], track_depth=dep[:n], level=lvl[:n],
                 view_cos=vc[:n], kernel_ms=ms.value)
+
+
+EXPORTS = EXPORTS + ("msorb_search_by_bow",)
+
+
+class BowPair(C.Structure):
+    """msorb_bow_pair (include/msorb.h)."""
+    _fields_ = [("n1", C.c_int), ("n2", C.c_int), ("desc1", C.c_void_p), ("desc2", C.c_void_p), ("valid1", C.c_void_p),
+                ("avail2", C.c_void_p), ("fv1_nodes", C.c_int), ("fv1_node", C.c_void_p), ("fv1_begin", C.c_void_p),
+                ("fv1_feat", C.c_void_p), ("fv2_nodes", C.c_int), ("fv2_node", C.c_void_p), ("fv2_begin", C.c_void_p),
+                ("fv2_feat", C.c_void_p), ("angle1", C.c_void_p), ("angle2", C.c_void_p), ("match12", C.c_void_p),
+                ("match21", C.c_void_p), ("nmatches", C.c_int)]
+
+
+def search_by_bow(pairs, th_low=50, inclusive=True, nnratio=0.7, check_orientation=True, device=0):
+    """msorb_search_by_bow over a batch.  pairs: list of dicts with desc1, desc2, valid1, avail2 (or None),
+    fv1 / fv2 = (node, begin, feat), angle1, angle2.  -> (list of (nmatches, match12, match21), kernel_ms)"""
+    lb = lib()
+    lb.msorb_search_by_bow.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    arr = (BowPair * max(len(pairs), 1))()
+    keep, outs = [], []
+    for k, p in enumerate(pairs):
+        d1, d2 = _c(p["desc1"], np.uint8).reshape(-1, 32), _c(p["desc2"], np.uint8).reshape(-1, 32)
+        v1 = _c(p["valid1"], np.uint8)
+        a2 = None if p.get("avail2") is None else _c(p["avail2"], np.uint8)
+        f1 = [_c(a, np.int32) for a in p["fv1"]]
+        f2 = [_c(a, np.int32) for a in p["fv2"]]
+        g1, g2 = _c(p["angle1"], np.float32), _c(p["angle2"], np.float32)
+        m12, m21 = np.zeros(max(len(d1), 1), np.int32), np.zeros(max(len(d2), 1), np.int32)
+        keep.append((d1, d2, v1, a2, f1, f2, g1, g2))
+        outs.append((m12, m21, len(d1), len(d2)))
+        q = arr[k]
+        q.n1, q.n2 = len(d1), len(d2)
+        q.desc1, q.desc2, q.valid1 = _np_ptr(d1), _np_ptr(d2), _np_ptr(v1)
+        q.avail2 = None if a2 is None else _np_ptr(a2)
+        q.fv1_nodes, q.fv1_node, q.fv1_begin, q.fv1_feat = len(f1[0]), _np_ptr(f1[0]), _np_ptr(f1[1]), _np_ptr(f1[2])
+        q.fv2_nodes, q.fv2_node, q.fv2_begin, q.fv2_feat = len(f2[0]), _np_ptr(f2[0]), _np_ptr(f2[1]), _np_ptr(f2[2])
+        q.angle1, q.angle2, q.match12, q.match21 = _np_ptr(g1), _np_ptr(g2), _np_ptr(m12), _np_ptr(m21)
+    ms = C.c_float()
+    _check(lb.msorb_search_by_bow(device, C.addressof(arr), len(pairs), int(th_low), int(bool(inclusive)), float(nnratio),
+                                  int(bool(check_orientation)), C.addressof(ms)), "msorb_search_by_bow")
+    return [(arr[k].nmatches, o[0][:o[2]], o[1][:o[3]]) for k, o in enumerate(outs)], ms.value

@@ -387,4 +387,74 @@ void orc_dense_top2(const uint8_t* q, int nq, const uint8_t* t, int nt, int* bes
     }
 }
 
+// ORBmatcher::SearchByBoW, the three forms (ORBmatcher.cc:223-421 KeyFrame->Frame with Nleft == -1, :872-1016 and
+// :1018-1166 KeyFrame->KeyFrame).  Set 1 = the queries (pKF / pKF1), set 2 = the trains (F / pKF2).
+// valid1[i]: the query is visited (:253-263 / :910-920 / :1066-1078: map point present, not bad, ..., descriptor not
+// empty).  avail2[j]: the train may be chosen at all (:934-944 / :1090-1103; all ones for the Frame form, whose
+// vpMapPointMatches starts empty, :227).  FeatureVectors as CSR with ascending node ids (std::map order).
+// inclusive: bestDist1 <= TH_LOW (:332) vs bestDist1 < TH_LOW (:959, :1118).  The rotation histogram stores the pair
+// (the Frame form pushes bestIdxF and resets that entry, the KeyFrame forms push idx1: the same pair either way).
+// match12[n1] / match21[n2]: partner index or -1, after the histogram filter.  Returns nmatches.
+int orc_search_by_bow(int n1, int n2, const uint8_t* desc1, const uint8_t* desc2, const uint8_t* valid1,
+                      const uint8_t* avail2, int nn1, const int* node1, const int* begin1, const int* feat1, int nn2,
+                      const int* node2, const int* begin2, const int* feat2, const float* angle1, const float* angle2,
+                      int th_low, int inclusive, float nnratio, int check_orientation, int* match12, int* match21) {
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    std::vector<char> matched2(n2, 0);
+    std::vector<int> rotHist[orc::HISTO_LENGTH];
+    const float factor = 1.0f / orc::HISTO_LENGTH;
+    int nmatches = 0;
+    int it1 = 0, it2 = 0;
+    while (it1 != nn1 && it2 != nn2) {
+        if (node1[it1] == node2[it2]) {
+            for (int k1 = begin1[it1]; k1 < begin1[it1 + 1]; k1++) {
+                const int idx1 = feat1[k1];
+                if (!valid1[idx1]) continue;
+                const uint8_t* d1 = desc1 + (size_t)idx1 * 32;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int k2 = begin2[it2]; k2 < begin2[it2 + 1]; k2++) {
+                    const int idx2 = feat2[k2];
+                    if (matched2[idx2] || (avail2 && !avail2[idx2])) continue;
+                    const int dist = orc::descriptor_distance(d1, desc2 + (size_t)idx2 * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (inclusive ? bestDist1 <= th_low : bestDist1 < th_low) {
+                    if ((float)bestDist1 < nnratio * (float)bestDist2) {
+                        match12[idx1] = bestIdx2;
+                        matched2[bestIdx2] = 1;
+                        if (check_orientation) {
+                            float rot = angle1[idx1] - angle2[bestIdx2];
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)std::round(rot * factor);
+                            if (bin == orc::HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back(idx1);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            it1++;
+            it2++;
+        } else if (node1[it1] < node2[it2]) {
+            it1 = (int)(std::lower_bound(node1, node1 + nn1, node2[it2]) - node1);
+        } else {
+            it2 = (int)(std::lower_bound(node2, node2 + nn2, node1[it1]) - node2);
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc::three_maxima(rotHist, orc::HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < orc::HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { match12[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    if (match21) {
+        for (int j = 0; j < n2; j++) match21[j] = -1;
+        for (int i = 0; i < n1; i++) if (match12[i] >= 0) match21[match12[i]] = i;
+    }
+    return nmatches;
+}
+
 }  // extern "C"

@@ -353,3 +353,26 @@ def dense_top2(q, t):
     bi, bd, sd = (np.zeros(max(n, 1), np.int32) for _ in range(3))
     Lb.orc_dense_top2(_ptr(qq), n, _ptr(tt), len(tt), _ptr(bi), _ptr(bd), _ptr(sd))
     return bi[:n], bd[:n], sd[:n]
+
+
+def search_by_bow(desc1, desc2, valid1, avail2, fv1, fv2, angle1, angle2, th_low=50, inclusive=True, nnratio=0.7,
+                  check_orientation=True):
+    """oracle/matcher_oracle.cc orc_search_by_bow (ORBmatcher.cc:223-421, 872-1166).  fv = (node, begin, feat) CSR.
+    -> (nmatches, match12, match21)"""
+    Lb = _mlib()
+    Lb.orc_search_by_bow.argtypes = ([C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] +
+                                     [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p])
+    Lb.orc_search_by_bow.restype = C.c_int
+    d1, d2 = _c(desc1, np.uint8).reshape(-1, 32), _c(desc2, np.uint8).reshape(-1, 32)
+    n1, n2 = len(d1), len(d2)
+    v1 = _c(valid1, np.uint8)
+    a2 = None if avail2 is None else _c(avail2, np.uint8)
+    f1 = [_c(a, np.int32) for a in fv1]
+    f2 = [_c(a, np.int32) for a in fv2]
+    g1, g2 = _c(angle1, np.float32), _c(angle2, np.float32)
+    m12, m21 = np.zeros(max(n1, 1), np.int32), np.zeros(max(n2, 1), np.int32)
+    nm = Lb.orc_search_by_bow(n1, n2, _ptr(d1), _ptr(d2), _ptr(v1), None if a2 is None else _ptr(a2), len(f1[0]),
+                              _ptr(f1[0]), _ptr(f1[1]), _ptr(f1[2]), len(f2[0]), _ptr(f2[0]), _ptr(f2[1]), _ptr(f2[2]),
+                              _ptr(g1), _ptr(g2), int(th_low), int(bool(inclusive)), float(nnratio),
+                              int(bool(check_orientation)), _ptr(m12), _ptr(m21))
+    return nm, m12[:n1], m21[:n2]

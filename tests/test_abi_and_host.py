@@ -95,3 +95,5 @@ def test_matcher_adapter_header_compiles(tmp_path):
                            os.path.join(ROOT, "tests", "dropin_sparsify_main.cc")])
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", f"-I{ROOT}/tests/cv_stub", f"-I{ROOT}/ms-slam_amd/host",
                            f"-I{ROOT}/include", os.path.join(ROOT, "tests", "dropin_bow_main.cc")])
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", f"-I{ROOT}/tests/cv_stub", f"-I{ROOT}/ms-slam_amd/host",
+                           f"-I{ROOT}/include", os.path.join(ROOT, "tests", "dropin_bowmatch_main.cc")])

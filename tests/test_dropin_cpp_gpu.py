@@ -242,3 +242,59 @@ def test_cpp_bow_adapters_match_oracle(tmp_path, oracle, msorb_mod):
     assert lists == [want["fv_feat"][fb[r]:fb[r + 1]].tolist() for r in range(len(nodes))]
     ei, _ = orb_oracle.distinctive_descriptors(obs, ob)
     assert best.tolist() == ei.tolist()
+
+
+def test_cpp_search_by_bow_adapters_match_oracle(tmp_path, oracle, msorb_mod):
+    """SearchByBoWBatch / SearchByBoW / SearchByBoWKeyFrames of ms-slam_amd/host/ORBmatcher_device.h against stand-in
+    KeyFrame / Frame / MapPoint types, vs the oracle's restatement of ORBmatcher.cc:223-421 and :872-1016."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bow_match_cases as bmc
+    import orb_oracle
+    exe = tmp_path / "dropin_bowmatch"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", f"-I{ROOT}/tests/cv_stub", f"-I{ROOT}/ms-slam_amd/host",
+                           f"-I{ROOT}/include", f"{ROOT}/tests/dropin_bowmatch_main.cc", f"-L{ROOT}/ms-slam_amd", "-lmsorb",
+                           f"-Wl,-rpath,{ROOT}/ms-slam_amd", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    rng = np.random.default_rng(5)
+    K, ratio, ori = 4, 0.75, 1
+    nF = 1500
+    descF = rng.integers(0, 256, (nF, 32), dtype=np.uint8)
+    nodeF = (rng.integers(0, 40, nF) * 2 + 3).astype(np.int32)
+    nodeF[rng.random(nF) < 0.02] = -1
+    angF = rng.uniform(0, 360, nF).astype(np.float32)
+    sides = [(descF, angF, nodeF, np.zeros(nF, np.uint8))]
+    for k in range(K):
+        n = 900 + 150 * k
+        src = rng.integers(0, nF, n)
+        d = bmc.bow_cases._flip_bits(rng, descF[src], rng.integers(0, 30, n))
+        node = nodeF[src].copy()
+        node[rng.random(n) < 0.1] = 1000
+        ang = np.mod(angF[src] + 33.0 + rng.normal(0, 5, n), 360).astype(np.float32)
+        ang[rng.random(n) < 0.3] = rng.uniform(0, 360)
+        mp = rng.choice([0, 1, 2], n, p=[0.2, 0.7, 0.1]).astype(np.uint8)
+        sides.append((np.ascontiguousarray(d), ang, node.astype(np.int32), mp))
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(struct.pack("<iif", K, ori, ratio))
+        for d, a, nd, mp in sides:
+            f.write(struct.pack("<i", len(d)))
+            for arr in (d, a, nd, mp):
+                f.write(np.ascontiguousarray(arr).tobytes())
+    subprocess.check_call([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")])
+    res = np.frombuffer((tmp_path / "out.bin").read_bytes(), np.int32)
+    fvF = bmc.feature_vector_from_nodes(nodeF)
+    pos = 0
+    for k in range(K):
+        d, a, nd, mp = sides[1 + k]
+        nm, m12, m21 = orb_oracle.search_by_bow(d, descF, mp == 1, None, bmc.feature_vector_from_nodes(nd), fvF, a, angF,
+                                                50, True, ratio, bool(ori))
+        assert res[pos] == nm and nm > 50
+        assert res[pos + 1:pos + 1 + nF].tolist() == m21.tolist()
+        pos += 1 + nF
+    assert res[pos] == 1
+    pos += 1
+    d0, a0, n0, mp0 = sides[1]
+    d1, a1, n1, mp1 = sides[2]
+    nm, m12, _ = orb_oracle.search_by_bow(d0, d1, mp0 == 1, mp1 == 1, bmc.feature_vector_from_nodes(n0),
+                                          bmc.feature_vector_from_nodes(n1), a0, a1, 50, False, ratio, bool(ori))
+    assert res[pos] == nm and nm > 20
+    assert res[pos + 1:pos + 1 + len(d0)].tolist() == m12.tolist()

@@ -94,6 +94,30 @@ def main(pairs=128, L=6):
                                           gpairs_per_s=round(pairs_n / kms / 1e6, 2),
                                           cpu_oracle_mpoints_per_s=round(20000 / dt / 1e6, 4),
                                           cpu_sample=f"20000 points, 1 thread, {dt:.2f} s")
+    # SearchByBoW: one reference-frame pair (TrackReferenceKeyFrame) and a relocalisation batch of 32 candidates,
+    # 2000 features a side, 100 level-2 nodes (levelsup 4 of L 6)
+    import bow_match_cases as bmc
+    cand = [bmc.make_pair(40 + i, n1=2000, n2=2000, n_nodes=100, mask_frac=0.2) for i in range(32)]
+    for p in cand:
+        p["avail2"] = None
+        p["desc2"], p["fv2"], p["angle2"] = cand[0]["desc2"], cand[0]["fv2"], cand[0]["angle2"]   # one frame, many KFs
+    sb = {}
+    for name, batch in (("pair", cand[:1]), ("batch32", cand)):
+        msorb.search_by_bow(batch)
+        kms = [msorb.search_by_bow(batch)[1] for _ in range(10)]
+        t0 = time.perf_counter()
+        for _ in range(10):
+            out, _ = msorb.search_by_bow(batch)
+        wall = (time.perf_counter() - t0) / 10
+        t0 = time.perf_counter()
+        for p, o in zip(batch, out):
+            nm, m12, _ = orb_oracle.search_by_bow(p["desc1"], p["desc2"], p["valid1"], None, p["fv1"], p["fv2"], p["angle1"],
+                                                  p["angle2"], 50, True, 0.7, True)
+            assert nm == o[0] and m12.tolist() == o[1].tolist()
+        dt = (time.perf_counter() - t0) / len(batch)
+        sb[name] = dict(pairs=len(batch), kernel_ms=round(float(np.median(kms)), 4), wall_ms_python=round(wall * 1e3, 3),
+                        matches_first=int(out[0][0]), cpu_oracle_ms_per_pair=round(dt * 1e3, 3))
+    res["search_by_bow"] = sb
     print(json.dumps(res))
 
 
