@@ -227,6 +227,38 @@ typedef struct msorb_bow_pair {
 int msorb_search_by_bow(int device, msorb_bow_pair* pairs, int n_pairs, int th_low, int inclusive, float nnratio,
                         int check_orientation, float* elapsed_ms);
 
+/* ORBmatcher::SearchForTriangulation (ORBmatcher.cc:1168-1402; LocalMapping::CreateNewMapPoints, LocalMapping.cc:492)
+ * for pinhole KeyFrames without a second camera.  One msorb_triangulation_pair per (mpCurrentKeyFrame, neighbour)
+ * call; all neighbours of one CreateNewMapPoints pass are matched by ONE launch.
+ *   valid1[n1]   1 = the query is visited: no map point (:1237-1241), stereo when bOnlyStereo (:1245-1247), descriptor
+ *                not empty;   avail2[n2]  1 = the train is eligible: no map point, stereo when bOnlyStereo (:1264-1271)
+ *   stereo1/2    GetuRight(idx) >= 0 (:1243, :1267)
+ *   kp1 / kp2    GetKeyPoint(idx) for every feature (cv::KeyPoint layout: pt, angle and octave are read)
+ *   scale_factors2 / level_sigma2_2 [n_levels2]   pKF2->mvScaleFactors / mvLevelSigma2 (:1287, :1332)
+ *   F12          K1^-T [t12]x R12 K2^-1, row major, exactly the Eigen expression of Pinhole::epipolarConstrain
+ *                (Pinhole.cpp:109-112) — constant per pair, so the caller evaluates it once instead of per candidate
+ *   ep           pKF2->mpCamera->project(T2w * pKF1->GetCameraCenter()) (:1177-1181)
+ * coarse = bCoarse (:1332 skips the epipolar test).  match12[n1] = vMatches12 after the orientation filter
+ * (:1360-1381); nmatches = the return value; vMatchedPairs = the (i, match12[i]) with match12[i] >= 0 in index order. */
+typedef struct msorb_triangulation_pair {
+    int n1, n2;
+    const uint8_t *desc1, *desc2;
+    const uint8_t *valid1, *avail2, *stereo1, *stereo2;
+    int fv1_nodes;
+    const int *fv1_node, *fv1_begin, *fv1_feat;
+    int fv2_nodes;
+    const int *fv2_node, *fv2_begin, *fv2_feat;
+    const msorb_keypoint *kp1, *kp2;
+    const float *scale_factors2, *level_sigma2_2;
+    int n_levels2;
+    float F12[9];
+    float ep[2];
+    int* match12;
+    int nmatches;
+} msorb_triangulation_pair;
+int msorb_search_for_triangulation(int device, msorb_triangulation_pair* pairs, int n_pairs, int coarse,
+                                   int check_orientation, float* elapsed_ms);
+
 /* ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:2277-2318) on histogram bin sizes; ind[3]. Host only. */
 int msorb_three_maxima(const int* bin_sizes, int n_bins, int* ind);
 

@@ -14,6 +14,9 @@
 //                                                        SearchByBoW(pKF1, pKF2, vpMatches12) (:872-1016,
 //                                                        SearchByBoWKeyFrames here); the batch form
 //                                                        serves Relocalization's candidate loop (Tracking.cc:3577-3600)
+//   ORB_SLAM3::msorb_host::SearchForTriangulation(...)   body of ORBmatcher::SearchForTriangulation (:1168-1402, no second
+//                                                        camera); SearchForTriangulationBatch = all neighbours of one
+//                                                        LocalMapping::CreateNewMapPoints pass (LocalMapping.cc:430-492)
 //
 // Use inside the reference: ORBmatcher::SearchByProjection keeps its signature and becomes
 //     static thread_local msorb_host::DeviceFrame<Frame> dev;
@@ -28,7 +31,9 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "msorb.h"
@@ -180,11 +185,15 @@ struct BowSide {  // one KeyFrame / Frame flattened for msorb_bow_pair
     std::vector<uint8_t> desc, flag;
     std::vector<int> node, begin, feat;
     std::vector<float> angle;
-    template <class MatT, class FeatVecT, class KeysT>
-    void Fill(const MatT& descriptors, const FeatVecT& fv, const KeysT& keys) {
-        const int n = descriptors.rows;
-        desc.resize((size_t)n * 32);
-        for (int i = 0; i < n; i++) std::memcpy(&desc[(size_t)i * 32], descriptors.template ptr<unsigned char>(i), 32);
+    // row(i) -> cv::Mat with the 32 descriptor bytes of feature i (Frame: mDescriptors.row(i); KeyFrame: GetDescriptor(i),
+    // the public accessor — mDescriptors / mvKeysUn / mvuRight are protected members of MS-SLAM's KeyFrame)
+    template <class RowFn, class FeatVecT, class KeysT>
+    void Fill(int n, RowFn row, const FeatVecT& fv, const KeysT& keys) {
+        desc.assign((size_t)n * 32, 0);
+        for (int i = 0; i < n; i++) {
+            const auto d = row(i);
+            if (!d.empty()) std::memcpy(&desc[(size_t)i * 32], d.template ptr<unsigned char>(0), 32);
+        }
         angle.resize(n);
         for (int i = 0; i < n; i++) angle[i] = keys[i].angle;
         node.clear(); feat.clear(); begin.assign(1, 0);
@@ -193,6 +202,10 @@ struct BowSide {  // one KeyFrame / Frame flattened for msorb_bow_pair
             for (unsigned idx : e.second) feat.push_back((int)idx);
             begin.push_back((int)feat.size());
         }
+    }
+    template <class KeyFramePtr>
+    void FillKeyFrame(const KeyFramePtr& pKF) {
+        Fill(pKF->GetN(), [&](int i) { return pKF->GetDescriptor(i); }, pKF->GetFeatureVector(), pKF->GetAllKeyUn());
     }
     template <class MapPointPtr>
     void FlagGood(const std::vector<MapPointPtr>& mps) {  // pMP && !pMP->isBad()
@@ -221,14 +234,14 @@ std::vector<int> SearchByBoWBatch(const std::vector<KeyFramePtr>& vpKFs, FrameT&
                                   bool mbCheckOrientation, int device = 0) {
     const size_t K = vpKFs.size();
     BowSide frame;
-    frame.Fill(F.mDescriptors, F.mFeatVec, F.mvKeys);
+    frame.Fill(F.N, [&](int i) { return F.mDescriptors.row(i); }, F.mFeatVec, F.mvKeys);
     std::vector<BowSide> kf(K);
     std::vector<std::vector<MapPointPtr>> mpsKF(K);
     std::vector<msorb_bow_pair> pairs(K);
     std::vector<std::vector<int>> m12(K), m21(K);
     for (size_t k = 0; k < K; k++) {
         mpsKF[k] = vpKFs[k]->GetMapPointMatches();                         // :225
-        kf[k].Fill(vpKFs[k]->mDescriptors, vpKFs[k]->GetFeatureVector(), vpKFs[k]->mvKeys);
+        kf[k].FillKeyFrame(vpKFs[k]);
         kf[k].FlagGood(mpsKF[k]);                                          // :253-259
         bind(pairs[k], kf[k], frame, true, m12[k], m21[k]);
     }
@@ -259,8 +272,8 @@ int SearchByBoWKeyFrames(const KeyFramePtr& pKF1, const KeyFramePtr& pKF2, std::
     const auto mps1 = pKF1->GetMapPointMatches();
     const auto mps2 = pKF2->GetMapPointMatches();
     BowSide a, b;
-    a.Fill(pKF1->mDescriptors, pKF1->GetFeatureVector(), pKF1->GetAllKeyUn());
-    b.Fill(pKF2->mDescriptors, pKF2->GetFeatureVector(), pKF2->GetAllKeyUn());
+    a.FillKeyFrame(pKF1);
+    b.FillKeyFrame(pKF2);
     a.FlagGood(mps1);
     b.FlagGood(mps2);                                                      // :934-944
     msorb_bow_pair P;
@@ -272,6 +285,105 @@ int SearchByBoWKeyFrames(const KeyFramePtr& pKF1, const KeyFramePtr& pKF2, std::
     for (size_t i = 0; i < m12.size() && i < mps1.size(); i++)
         if (m12[i] >= 0) vpMatches12[i] = mps2[m12[i]];                    // :963
     return P.nmatches;
+}
+
+// ---- SearchForTriangulation ---------------------------------------------------------------------------------
+// The per-pair geometry of ORBmatcher.cc:1174-1194 and the fundamental matrix Pinhole::epipolarConstrain rebuilds for
+// every candidate (Pinhole.cpp:109-112) — the reference's own Eigen / Sophus expressions, evaluated once per pair.
+template <class KeyFramePtr>
+void TriangulationGeometry(const KeyFramePtr& pKF1, const KeyFramePtr& pKF2, float F12[9], float ep[2]) {
+    const auto T1w = pKF1->GetPose();
+    const auto T2w = pKF2->GetPose();
+    const auto Tw2 = pKF2->GetPoseInverse();
+    const auto Cw = pKF1->GetCameraCenter();
+    const auto C2 = T2w * Cw;
+    const auto e = pKF2->mpCamera->project(C2);
+    ep[0] = e(0); ep[1] = e(1);
+    const auto T12 = T1w * Tw2;
+    const auto R12 = T12.rotationMatrix();
+    const auto t12 = T12.translation();
+    using SO3 = typename std::decay<decltype(T12.so3())>::type;
+    const auto t12x = SO3::hat(t12);
+    const auto K1 = pKF1->mpCamera->toK_();
+    const auto K2 = pKF2->mpCamera->toK_();
+    const auto F = K1.transpose().inverse() * t12x * R12 * K2.inverse();
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) F12[3 * r + c] = F(r, c);
+}
+
+struct TriSide {  // one KeyFrame flattened for msorb_triangulation_pair
+    BowSide bow;
+    std::vector<uint8_t> free_, stereo;
+    std::vector<msorb_keypoint> kp;
+    template <class KeyFramePtr>
+    void Fill(const KeyFramePtr& pKF, bool bOnlyStereo) {
+        static_assert(sizeof(pKF->GetAllKeyUn()[0]) == sizeof(msorb_keypoint), "cv::KeyPoint must be the 28-byte layout");
+        bow.FillKeyFrame(pKF);
+        const auto keys = pKF->GetAllKeyUn();                             // GetKeyPoint(idx) for NLeft == -1
+        const auto mps = pKF->GetMapPointMatches();                       // GetMapPoint(idx) for every idx, one lock
+        const int n = (int)keys.size();
+        kp.resize(n);
+        if (n) std::memcpy(kp.data(), keys.data(), (size_t)n * sizeof(msorb_keypoint));
+        free_.assign(n, 0);
+        stereo.assign(n, 0);
+        for (int i = 0; i < n; i++) {
+            stereo[i] = pKF->GetuRight(i) >= 0;                           // :1243 / :1267 (mpCamera2 == nullptr)
+            free_[i] = !mps[i] && (!bOnlyStereo || stereo[i]);            // :1237-1247 / :1264-1271
+        }
+    }
+};
+
+// for(each neighbour pKF2) matcher.SearchForTriangulation(pKF1, pKF2, vMatchedIndices, bOnlyStereo, bCoarse) in ONE launch
+template <class KeyFramePtr>
+std::vector<int> SearchForTriangulationBatch(const KeyFramePtr& pKF1, const std::vector<KeyFramePtr>& vpKF2,
+                                             std::vector<std::vector<std::pair<size_t, size_t>>>& vvMatchedPairs,
+                                             bool bOnlyStereo, bool bCoarse, bool mbCheckOrientation, int device = 0) {
+    const size_t K = vpKF2.size();
+    TriSide a;
+    a.Fill(pKF1, bOnlyStereo);
+    std::vector<TriSide> b(K);
+    std::vector<msorb_triangulation_pair> pairs(K);
+    std::vector<std::vector<int>> m12(K);
+    for (size_t k = 0; k < K; k++) {
+        b[k].Fill(vpKF2[k], bOnlyStereo);
+        msorb_triangulation_pair& P = pairs[k];
+        P = msorb_triangulation_pair{};
+        P.n1 = (int)a.kp.size(); P.n2 = (int)b[k].kp.size();
+        m12[k].assign(P.n1, -1);
+        P.desc1 = a.bow.desc.data(); P.desc2 = b[k].bow.desc.data();
+        P.valid1 = a.free_.data(); P.avail2 = b[k].free_.data();
+        P.stereo1 = a.stereo.data(); P.stereo2 = b[k].stereo.data();
+        P.fv1_nodes = (int)a.bow.node.size(); P.fv1_node = a.bow.node.data(); P.fv1_begin = a.bow.begin.data();
+        P.fv1_feat = a.bow.feat.data();
+        P.fv2_nodes = (int)b[k].bow.node.size(); P.fv2_node = b[k].bow.node.data(); P.fv2_begin = b[k].bow.begin.data();
+        P.fv2_feat = b[k].bow.feat.data();
+        P.kp1 = a.kp.data(); P.kp2 = b[k].kp.data();
+        P.scale_factors2 = vpKF2[k]->mvScaleFactors.data();
+        P.level_sigma2_2 = vpKF2[k]->mvLevelSigma2.data();
+        P.n_levels2 = (int)vpKF2[k]->mvScaleFactors.size();
+        TriangulationGeometry(pKF1, vpKF2[k], P.F12, P.ep);
+        P.match12 = m12[k].data();
+    }
+    check(msorb_search_for_triangulation(device, pairs.data(), (int)K, bCoarse, mbCheckOrientation, nullptr),
+          "msorb_search_for_triangulation");
+    std::vector<int> nmatches(K);
+    vvMatchedPairs.assign(K, {});
+    for (size_t k = 0; k < K; k++) {
+        nmatches[k] = pairs[k].nmatches;
+        vvMatchedPairs[k].reserve(nmatches[k]);                            // :1385-1393
+        for (size_t i = 0; i < m12[k].size(); i++)
+            if (m12[k][i] >= 0) vvMatchedPairs[k].push_back(std::make_pair(i, (size_t)m12[k][i]));
+    }
+    return nmatches;
+}
+template <class KeyFramePtr>
+int SearchForTriangulation(const KeyFramePtr& pKF1, const KeyFramePtr& pKF2, std::vector<std::pair<size_t, size_t>>& vMatchedPairs,
+                           bool bOnlyStereo, bool bCoarse, bool mbCheckOrientation, int device = 0) {
+    std::vector<std::vector<std::pair<size_t, size_t>>> out;
+    const int n = SearchForTriangulationBatch(pKF1, std::vector<KeyFramePtr>{pKF2}, out, bOnlyStereo, bCoarse,
+                                              mbCheckOrientation, device)[0];
+    vMatchedPairs = std::move(out[0]);
+    return n;
 }
 
 // Frame::ComputeStereoMatches(): fills F.mvuRight / F.mvDepth from the two extractors' device pyramids.

@@ -609,3 +609,51 @@ def search_by_bow(pairs, th_low=50, inclusive=True, nnratio=0.7, check_orientati
     _check(lb.msorb_search_by_bow(device, C.addressof(arr), len(pairs), int(th_low), int(bool(inclusive)), float(nnratio),
                                   int(bool(check_orientation)), C.addressof(ms)), "msorb_search_by_bow")
     return [(arr[k].nmatches, o[0][:o[2]], o[1][:o[3]]) for k, o in enumerate(outs)], ms.value
+
+
+EXPORTS = EXPORTS + ("msorb_search_for_triangulation",)
+
+
+class TriangulationPair(C.Structure):
+    """msorb_triangulation_pair (include/msorb.h)."""
+    _fields_ = [("n1", C.c_int), ("n2", C.c_int), ("desc1", C.c_void_p), ("desc2", C.c_void_p), ("valid1", C.c_void_p),
+                ("avail2", C.c_void_p), ("stereo1", C.c_void_p), ("stereo2", C.c_void_p), ("fv1_nodes", C.c_int),
+                ("fv1_node", C.c_void_p), ("fv1_begin", C.c_void_p), ("fv1_feat", C.c_void_p), ("fv2_nodes", C.c_int),
+                ("fv2_node", C.c_void_p), ("fv2_begin", C.c_void_p), ("fv2_feat", C.c_void_p), ("kp1", C.c_void_p),
+                ("kp2", C.c_void_p), ("scale_factors2", C.c_void_p), ("level_sigma2_2", C.c_void_p), ("n_levels2", C.c_int),
+                ("F12", C.c_float * 9), ("ep", C.c_float * 2), ("match12", C.c_void_p), ("nmatches", C.c_int)]
+
+
+def search_for_triangulation(pairs, coarse=False, check_orientation=True, device=0):
+    """msorb_search_for_triangulation over a batch.  pairs: dicts with desc1/2, valid1, avail2, stereo1/2, fv1/fv2,
+    kp1/kp2 (KP_DTYPE records), scale_factors2, level_sigma2_2, F12 (9), ep (2).
+    -> (list of (nmatches, match12), kernel_ms)"""
+    lb = lib()
+    lb.msorb_search_for_triangulation.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    arr = (TriangulationPair * max(len(pairs), 1))()
+    keep, outs = [], []
+    for k, p in enumerate(pairs):
+        d1, d2 = _c(p["desc1"], np.uint8).reshape(-1, 32), _c(p["desc2"], np.uint8).reshape(-1, 32)
+        fl = [_c(p[key], np.uint8) for key in ("valid1", "avail2", "stereo1", "stereo2")]
+        f1 = [_c(a, np.int32) for a in p["fv1"]]
+        f2 = [_c(a, np.int32) for a in p["fv2"]]
+        k1, k2 = np.ascontiguousarray(p["kp1"], KP_DTYPE), np.ascontiguousarray(p["kp2"], KP_DTYPE)
+        sc, sg = _c(p["scale_factors2"], np.float32), _c(p["level_sigma2_2"], np.float32)
+        m12 = np.zeros(max(len(d1), 1), np.int32)
+        keep.append((d1, d2, fl, f1, f2, k1, k2, sc, sg))
+        outs.append((m12, len(d1)))
+        q = arr[k]
+        q.n1, q.n2 = len(d1), len(d2)
+        q.desc1, q.desc2 = _np_ptr(d1), _np_ptr(d2)
+        q.valid1, q.avail2, q.stereo1, q.stereo2 = (_np_ptr(a) for a in fl)
+        q.fv1_nodes, q.fv1_node, q.fv1_begin, q.fv1_feat = len(f1[0]), _np_ptr(f1[0]), _np_ptr(f1[1]), _np_ptr(f1[2])
+        q.fv2_nodes, q.fv2_node, q.fv2_begin, q.fv2_feat = len(f2[0]), _np_ptr(f2[0]), _np_ptr(f2[1]), _np_ptr(f2[2])
+        q.kp1, q.kp2 = _np_ptr(k1), _np_ptr(k2)
+        q.scale_factors2, q.level_sigma2_2, q.n_levels2 = _np_ptr(sc), _np_ptr(sg), len(sc)
+        q.F12[:] = [float(x) for x in np.asarray(p["F12"], np.float32).reshape(9)]
+        q.ep[:] = [float(x) for x in np.asarray(p["ep"], np.float32).reshape(2)]
+        q.match12 = _np_ptr(m12)
+    ms = C.c_float()
+    _check(lb.msorb_search_for_triangulation(device, C.addressof(arr), len(pairs), int(bool(coarse)),
+                                             int(bool(check_orientation)), C.addressof(ms)), "msorb_search_for_triangulation")
+    return [(arr[k].nmatches, o[0][:o[1]]) for k, o in enumerate(outs)], ms.value

@@ -457,4 +457,93 @@ int orc_search_by_bow(int n1, int n2, const uint8_t* desc1, const uint8_t* desc2
     return nmatches;
 }
 
+// ORBmatcher::SearchForTriangulation (ORBmatcher.cc:1168-1402), pinhole cameras without a second camera
+// (mpCamera2 == nullptr).  valid1[i]: the query is visited (no map point :1237-1241, stereo when bOnlyStereo :1245-1247,
+// descriptor not empty); avail2[j]: the train is eligible apart from the running vbMatched2 (:1264, 1269-1271);
+// stereo1/stereo2 = GetuRight(idx) >= 0 (:1243, :1267).  kp1/kp2 = GetKeyPoint (x, y per feature), ep_thresh2[j] =
+// 100*pKF2->mvScaleFactors[kp2.octave] (:1287), unc2[j] = pKF2->mvLevelSigma2[kp2.octave] (:1332), F12 = the matrix
+// Pinhole::epipolarConstrain builds from R12, t12 and the two K (Pinhole.cpp:109-112; the same for every candidate of
+// a pair, so the caller evaluates that Eigen expression once), ep = the epipole (:1179-1181).
+// Scalar float expressions: products contracted the way the reference's -O3 -march=native build does it (first
+// product of a sum fused, the other one rounded: x*p + y*q + r -> fmaf(x, p, y*q) + r) — stated convention.
+// Returns nmatches; match12[n1] after the orientation filter.
+int orc_search_for_triangulation(int n1, int n2, const uint8_t* desc1, const uint8_t* desc2, const uint8_t* valid1,
+                                 const uint8_t* avail2, const uint8_t* stereo1, const uint8_t* stereo2, int nn1,
+                                 const int* node1, const int* begin1, const int* feat1, int nn2, const int* node2,
+                                 const int* begin2, const int* feat2, const float* xy1, const float* xy2,
+                                 const float* angle1, const float* angle2, const float* ep_thresh2, const float* unc2,
+                                 const float* F12, const float* ep, int coarse, int check_orientation, int* match12) {
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    std::vector<char> matched2(n2, 0);
+    std::vector<int> rotHist[orc::HISTO_LENGTH];
+    const float factor = 1.0f / orc::HISTO_LENGTH;
+    int nmatches = 0;
+    int it1 = 0, it2 = 0;
+    while (it1 != nn1 && it2 != nn2) {
+        if (node1[it1] == node2[it2]) {
+            for (int k1 = begin1[it1]; k1 < begin1[it1 + 1]; k1++) {
+                const int idx1 = feat1[k1];
+                if (!valid1[idx1]) continue;
+                const bool bStereo1 = stereo1[idx1] != 0;
+                const float x1 = xy1[2 * idx1], y1 = xy1[2 * idx1 + 1];
+                const uint8_t* d1 = desc1 + (size_t)idx1 * 32;
+                int bestDist = orc::TH_LOW, bestIdx2 = -1;
+                for (int k2 = begin2[it2]; k2 < begin2[it2 + 1]; k2++) {
+                    const int idx2 = feat2[k2];
+                    if (matched2[idx2] || !avail2[idx2]) continue;
+                    const bool bStereo2 = stereo2[idx2] != 0;
+                    const int dist = orc::descriptor_distance(d1, desc2 + (size_t)idx2 * 32);
+                    if (dist > orc::TH_LOW || dist > bestDist) continue;
+                    const float x2 = xy2[2 * idx2], y2 = xy2[2 * idx2 + 1];
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = ep[0] - x2, distey = ep[1] - y2;
+                        if (fmaf(distex, distex, distey * distey) < ep_thresh2[idx2]) continue;
+                    }
+                    bool ok = coarse != 0;
+                    if (!ok) {  // Pinhole::epipolarConstrain, Pinhole.cpp:114-131
+                        const float a = fmaf(x1, F12[0], y1 * F12[3]) + F12[6];
+                        const float b = fmaf(x1, F12[1], y1 * F12[4]) + F12[7];
+                        const float c = fmaf(x1, F12[2], y1 * F12[5]) + F12[8];
+                        const float num = fmaf(a, x2, b * y2) + c;
+                        const float den = fmaf(a, a, b * b);
+                        if (den == 0) ok = false;
+                        else {
+                            const float dsqr = num * num / den;
+                            ok = (double)dsqr < 3.84 * (double)unc2[idx2];
+                        }
+                    }
+                    if (ok) { bestIdx2 = idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    match12[idx1] = bestIdx2;
+                    matched2[bestIdx2] = 1;
+                    nmatches++;
+                    if (check_orientation) {
+                        float rot = angle1[idx1] - angle2[bestIdx2];
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)std::round(rot * factor);
+                        if (bin == orc::HISTO_LENGTH) bin = 0;
+                        rotHist[bin].push_back(idx1);
+                    }
+                }
+            }
+            it1++;
+            it2++;
+        } else if (node1[it1] < node2[it2]) {
+            it1 = (int)(std::lower_bound(node1, node1 + nn1, node2[it2]) - node1);
+        } else {
+            it2 = (int)(std::lower_bound(node2, node2 + nn2, node1[it1]) - node2);
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc::three_maxima(rotHist, orc::HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < orc::HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { match12[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 }  // extern "C"

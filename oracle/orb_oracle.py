@@ -376,3 +376,31 @@ def search_by_bow(desc1, desc2, valid1, avail2, fv1, fv2, angle1, angle2, th_low
                               _ptr(g1), _ptr(g2), int(th_low), int(bool(inclusive)), float(nnratio),
                               int(bool(check_orientation)), _ptr(m12), _ptr(m21))
     return nm, m12[:n1], m21[:n2]
+
+
+def search_for_triangulation(p, coarse=False, check_orientation=True):
+    """oracle/matcher_oracle.cc orc_search_for_triangulation (ORBmatcher.cc:1168-1402).  p: dict as made by
+    tests/bow_match_cases.make_triangulation_pair.  -> (nmatches, match12)"""
+    Lb = _mlib()
+    Lb.orc_search_for_triangulation.argtypes = ([C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 3 +
+                                                [C.c_int] + [C.c_void_p] * 11 + [C.c_int, C.c_int, C.c_void_p])
+    Lb.orc_search_for_triangulation.restype = C.c_int
+    d1, d2 = _c(p["desc1"], np.uint8).reshape(-1, 32), _c(p["desc2"], np.uint8).reshape(-1, 32)
+    n1, n2 = len(d1), len(d2)
+    v1, a2, s1, s2 = (_c(p[k], np.uint8) for k in ("valid1", "avail2", "stereo1", "stereo2"))
+    f1 = [_c(a, np.int32) for a in p["fv1"]]
+    f2 = [_c(a, np.int32) for a in p["fv2"]]
+    k1, k2 = p["kp1"], p["kp2"]
+    xy1 = _c(np.stack([k1["x"], k1["y"]], 1), np.float32)
+    xy2 = _c(np.stack([k2["x"], k2["y"]], 1), np.float32)
+    g1, g2 = _c(k1["angle"], np.float32), _c(k2["angle"], np.float32)
+    sc, sg = _c(p["scale_factors2"], np.float32), _c(p["level_sigma2_2"], np.float32)
+    epth = _c(np.float32(100) * sc[k2["octave"]], np.float32)
+    unc = _c(sg[k2["octave"]], np.float32)
+    F, ep = _c(p["F12"], np.float32).reshape(9), _c(p["ep"], np.float32)
+    m12 = np.zeros(max(n1, 1), np.int32)
+    nm = Lb.orc_search_for_triangulation(n1, n2, _ptr(d1), _ptr(d2), _ptr(v1), _ptr(a2), _ptr(s1), _ptr(s2), len(f1[0]),
+                                         _ptr(f1[0]), _ptr(f1[1]), _ptr(f1[2]), len(f2[0]), _ptr(f2[0]), _ptr(f2[1]),
+                                         _ptr(f2[2]), _ptr(xy1), _ptr(xy2), _ptr(g1), _ptr(g2), _ptr(epth), _ptr(unc), _ptr(F),
+                                         _ptr(ep), int(bool(coarse)), int(bool(check_orientation)), _ptr(m12))
+    return nm, m12[:n1]

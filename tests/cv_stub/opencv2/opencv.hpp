@@ -22,6 +22,7 @@ public:
     void release() { rows = cols = 0; step = 0; own.clear(); data = nullptr; }
     bool empty() const { return rows == 0 || cols == 0 || !data; }
     int type() const { return CV_8UC1; }
+    Mat row(int r) const { return Mat(1, cols, CV_8UC1, data + (size_t)r * step, step); }
     template <typename T> T* ptr(int r) { return (T*)(data + (size_t)r * step); }
     template <typename T> const T* ptr(int r) const { return (const T*)(data + (size_t)r * step); }
 };

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <map>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include <opencv2/opencv.hpp>
@@ -24,6 +25,45 @@ public:
 };
 }  // namespace DBoW2
 namespace ORB_SLAM3 {
+// Eigen / Sophus stand-ins (float, straightforward loops): just enough surface for TriangulationGeometry
+struct Vec2 { float v[2]; float operator()(int i) const { return v[i]; } };
+struct Vec3 { float v[3]; float operator()(int i) const { return v[i]; } };
+struct Mat3 {
+    float m[9];
+    float operator()(int r, int c) const { return m[3 * r + c]; }
+    Mat3 transpose() const { Mat3 o; for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) o.m[3 * r + c] = m[3 * c + r]; return o; }
+    Mat3 inverse() const {
+        const float a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+        const float det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g), id = 1.0f / det;
+        return Mat3{{(e * i - f * h) * id, (c * h - b * i) * id, (b * f - c * e) * id, (f * g - d * i) * id, (a * i - c * g) * id,
+                     (c * d - a * f) * id, (d * h - e * g) * id, (b * g - a * h) * id, (a * e - b * d) * id}};
+    }
+    Mat3 operator*(const Mat3& o) const {
+        Mat3 r{};
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) r.m[3 * i + j] += m[3 * i + k] * o.m[3 * k + j];
+        return r;
+    }
+    Vec3 operator*(const Vec3& x) const {
+        Vec3 r{};
+        for (int i = 0; i < 3; i++) r.v[i] = m[3 * i] * x.v[0] + m[3 * i + 1] * x.v[1] + m[3 * i + 2] * x.v[2];
+        return r;
+    }
+};
+struct SO3 { static Mat3 hat(const Vec3& t) { return Mat3{{0, -t.v[2], t.v[1], t.v[2], 0, -t.v[0], -t.v[1], t.v[0], 0}}; } };
+struct SE3 {
+    Mat3 R; Vec3 t;
+    Mat3 rotationMatrix() const { return R; }
+    Vec3 translation() const { return t; }
+    SO3 so3() const { return SO3{}; }
+    SE3 operator*(const SE3& o) const { SE3 r; r.R = R * o.R; const Vec3 x = R * o.t; r.t = Vec3{{x.v[0] + t.v[0], x.v[1] + t.v[1], x.v[2] + t.v[2]}}; return r; }
+    Vec3 operator*(const Vec3& p) const { const Vec3 x = R * p; return Vec3{{x.v[0] + t.v[0], x.v[1] + t.v[1], x.v[2] + t.v[2]}}; }
+    SE3 inverse() const { SE3 r; r.R = R.transpose(); const Vec3 x = r.R * t; r.t = Vec3{{-x.v[0], -x.v[1], -x.v[2]}}; return r; }
+};
+struct Camera {  // GeometricCamera / Pinhole
+    float fx, fy, cx, cy;
+    Vec2 project(const Vec3& p) { return Vec2{{fx * p.v[0] / p.v[2] + cx, fy * p.v[1] / p.v[2] + cy}}; }
+    Mat3 toK_() { return Mat3{{fx, 0, cx, 0, fy, cy, 0, 0, 1}}; }
+};
 struct MapPoint {
     bool mbBad = false;
     int id = -1;
@@ -37,10 +77,22 @@ struct Side {
     DBoW2::FeatureVector mFeatVec;
     std::vector<std::shared_ptr<MapPoint>> mvpMapPoints;
 };
-struct KeyFrame : Side {
+struct KeyFrame : protected Side {  // the feature arrays are protected in MS-SLAM's KeyFrame: accessors only
+    friend void read_kf(FILE*, KeyFrame&, int&, bool);
+    std::vector<float> mvuRight_;
+    SE3 Tcw;
+    Camera* mpCamera = nullptr;
+    Camera* mpCamera2 = nullptr;
+    std::vector<float> mvScaleFactors, mvLevelSigma2;
+    int GetN() { return N; }
+    cv::Mat GetDescriptor(const int& idx) { return idx >= mDescriptors.rows ? cv::Mat() : mDescriptors.row(idx); }
     std::vector<std::shared_ptr<MapPoint>> GetMapPointMatches() { return mvpMapPoints; }
     DBoW2::FeatureVector GetFeatureVector() { return mFeatVec; }
     std::vector<cv::KeyPoint> GetAllKeyUn() { return mvKeys; }
+    float GetuRight(size_t idx) { return mvuRight_[idx]; }
+    SE3 GetPose() { return Tcw; }
+    SE3 GetPoseInverse() { return Tcw.inverse(); }
+    Vec3 GetCameraCenter() { return Tcw.inverse().t; }
 };
 struct Frame : Side {};
 }  // namespace ORB_SLAM3
@@ -75,9 +127,74 @@ static void read_side(FILE* f, ORB_SLAM3::Side& s, int& next_id) {
     }
 }
 
+namespace ORB_SLAM3 {
+void read_kf(FILE* f, KeyFrame& kf, int& next_id, bool full_kp) {
+    if (!full_kp) { read_side(f, kf, next_id); return; }
+    const int n = rd<int>(f, 1)[0];
+    kf.N = n;
+    kf.bytes = rd<unsigned char>(f, (size_t)n * 32);
+    kf.mDescriptors = cv::Mat(n, 32, CV_8UC1, kf.bytes.data(), 32);
+    kf.mvKeys = rd<cv::KeyPoint>(f, n);
+    const auto node = rd<int>(f, n);
+    const auto mp = rd<unsigned char>(f, n);
+    kf.mvuRight_ = rd<float>(f, n);
+    kf.mvpMapPoints.resize(n);
+    for (int i = 0; i < n; i++) {
+        if (node[i] >= 0) kf.mFeatVec.addFeature((unsigned)node[i], (unsigned)i);
+        if (mp[i]) kf.mvpMapPoints[i] = std::make_shared<MapPoint>();
+    }
+    const auto pose = rd<float>(f, 12);
+    for (int i = 0; i < 9; i++) kf.Tcw.R.m[i] = pose[i];
+    for (int i = 0; i < 3; i++) kf.Tcw.t.v[i] = pose[9 + i];
+    const int L = rd<int>(f, 1)[0];
+    kf.mvScaleFactors = rd<float>(f, L);
+    kf.mvLevelSigma2 = rd<float>(f, L);
+}
+}  // namespace ORB_SLAM3
+
+// (pKF1, K neighbours) -> per neighbour F12, ep, nmatches, pairs
+static int triangulation_main(const char* in, const char* out) {
+    using namespace ORB_SLAM3;
+    FILE* f = fopen(in, "rb");
+    if (!f) return 3;
+    const auto hdr = rd<int>(f, 4);
+    const int K = hdr[0], only_stereo = hdr[1], coarse = hdr[2], ori = hdr[3];
+    const auto cam = rd<float>(f, 4);
+    Camera camera{cam[0], cam[1], cam[2], cam[3]};
+    int dummy = 0;
+    auto kf1 = std::make_shared<KeyFrame>();
+    read_kf(f, *kf1, dummy, true);
+    kf1->mpCamera = &camera;
+    std::vector<std::shared_ptr<KeyFrame>> nb(K);
+    for (int k = 0; k < K; k++) {
+        nb[k] = std::make_shared<KeyFrame>();
+        read_kf(f, *nb[k], dummy, true);
+        nb[k]->mpCamera = &camera;
+    }
+    fclose(f);
+    std::vector<std::vector<std::pair<size_t, size_t>>> vv;
+    const std::vector<int> nm = msorb_host::SearchForTriangulationBatch(kf1, nb, vv, only_stereo != 0, coarse != 0, ori != 0);
+    std::vector<std::pair<size_t, size_t>> single;
+    const int nm0 = K ? msorb_host::SearchForTriangulation(kf1, nb[0], single, only_stereo != 0, coarse != 0, ori != 0) : 0;
+    FILE* o = fopen(out, "wb");
+    for (int k = 0; k < K; k++) {
+        float F[9], ep[2];
+        msorb_host::TriangulationGeometry(kf1, nb[k], F, ep);
+        fwrite(F, 4, 9, o); fwrite(ep, 4, 2, o);
+        const int cnt = (int)vv[k].size();
+        fwrite(&nm[k], 4, 1, o); fwrite(&cnt, 4, 1, o);
+        for (auto& pr : vv[k]) { const int a = (int)pr.first, b = (int)pr.second; fwrite(&a, 4, 1, o); fwrite(&b, 4, 1, o); }
+    }
+    const int same = K == 0 || (nm0 == nm[0] && single == vv[0]);
+    fwrite(&same, 4, 1, o);
+    fclose(o);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     using namespace ORB_SLAM3;
     if (argc < 3) return 2;
+    if (argc > 3 && std::string(argv[3]) == "tri") return triangulation_main(argv[1], argv[2]);
     FILE* f = fopen(argv[1], "rb");
     if (!f) return 3;
     const auto hdr = rd<int>(f, 2);
@@ -91,7 +208,7 @@ int main(int argc, char** argv) {
     for (int k = 0; k < K; k++) {
         kfs[k] = std::make_shared<KeyFrame>();
         first_id[k] = next_id;
-        read_side(f, *kfs[k], next_id);
+        read_kf(f, *kfs[k], next_id, false);
     }
     fclose(f);
     std::vector<std::vector<std::shared_ptr<MapPoint>>> vvp;

@@ -79,3 +79,53 @@ def test_batch_equals_singles_and_rejects_bad_vectors():
     bad["fv1"] = tuple(f)
     with pytest.raises(msorb.MsorbError):
         msorb.search_by_bow([bad])
+
+
+# ---- SearchForTriangulation (ORBmatcher.cc:1168-1402) ----
+@pytest.mark.parametrize("seed", [0, 1])
+def test_triangulation_oracle_matches_definition(seed):
+    import orb_oracle
+    p = bmc.make_triangulation_pair(seed, n1=300, n2=330, n_nodes=10)
+    for coarse, ori in ((False, True), (True, True), (False, False)):
+        nm, m12 = orb_oracle.search_for_triangulation(p, coarse, ori)
+        wn, w12 = bmc.naive_triangulation(p, coarse, ori)
+        assert nm == wn and m12.tolist() == w12.tolist()
+        assert nm > 15
+    # the gates must bite: the fine search keeps fewer pairs than the coarse one
+    assert orb_oracle.search_for_triangulation(p, False, False)[0] < orb_oracle.search_for_triangulation(p, True, False)[0]
+
+
+TCASES = [dict(n1=900, n2=1000, n_nodes=40), dict(n1=2000, n2=2000, n_nodes=100, pix_noise=0.7),
+          dict(n1=600, n2=1500, n_nodes=2), dict(n1=200, n2=4000, n_nodes=1, mask_frac=0.5), dict(n1=30, n2=0, n_nodes=3),
+          dict(n1=0, n2=30, n_nodes=3)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(len(TCASES)))
+def test_triangulation_device_matches_oracle(case):
+    import msorb
+    import orb_oracle
+    p = bmc.make_triangulation_pair(200 + case, **TCASES[case])
+    for coarse, ori in ((False, True), (True, True), (False, False)):
+        (got,), ms = msorb.search_for_triangulation([p], coarse, ori)
+        nm, m12 = orb_oracle.search_for_triangulation(p, coarse, ori)
+        assert got[0] == nm and got[1].tolist() == m12.tolist()
+    if TCASES[case]["n1"] >= 200 and TCASES[case]["n2"] >= 1000:
+        assert nm > 10
+
+
+@pytest.mark.gpu
+def test_triangulation_batch_equals_singles():
+    import msorb
+    import orb_oracle
+    pairs = [bmc.make_triangulation_pair(300 + i, n1=500 + 300 * i, n2=1900 - 250 * i, n_nodes=8 + 20 * i) for i in range(5)]
+    res, ms = msorb.search_for_triangulation(pairs)
+    assert ms > 0
+    for p, r in zip(pairs, res):
+        nm, m12 = orb_oracle.search_for_triangulation(p)
+        assert r[0] == nm and r[1].tolist() == m12.tolist()
+    bad = dict(pairs[0])
+    bad["kp2"] = bad["kp2"].copy()
+    bad["kp2"]["octave"][3] = 8                          # octave outside pKF2->mvScaleFactors
+    with pytest.raises(msorb.MsorbError):
+        msorb.search_for_triangulation([bad])

@@ -298,3 +298,86 @@ def test_cpp_search_by_bow_adapters_match_oracle(tmp_path, oracle, msorb_mod):
                                           bmc.feature_vector_from_nodes(n1), a0, a1, 50, False, ratio, bool(ori))
     assert res[pos] == nm and nm > 20
     assert res[pos + 1:pos + 1 + len(d0)].tolist() == m12.tolist()
+
+
+def test_cpp_search_for_triangulation_adapter_matches_oracle(tmp_path, oracle, msorb_mod):
+    """SearchForTriangulationBatch / SearchForTriangulation / TriangulationGeometry of ORBmatcher_device.h against
+    stand-in KeyFrame / SE3 / camera types (accessor-only KeyFrame, like MS-SLAM's), vs the oracle's restatement of
+    ORBmatcher.cc:1168-1402 fed with the F12 / epipole the C++ side computed."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bow_match_cases as bmc
+    import orb_oracle
+    exe = tmp_path / "dropin_bowmatch"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", f"-I{ROOT}/tests/cv_stub", f"-I{ROOT}/ms-slam_amd/host",
+                           f"-I{ROOT}/include", f"{ROOT}/tests/dropin_bowmatch_main.cc", f"-L{ROOT}/ms-slam_amd", "-lmsorb",
+                           f"-Wl,-rpath,{ROOT}/ms-slam_amd", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    rng = np.random.default_rng(11)
+    K = 3
+    fx, fy, cx, cy = 718.856, 718.856, 607.19, 185.21
+    scale = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    sigma2 = (scale * scale).astype(np.float32)
+    # world points seen by every KeyFrame; KeyFrame poses: small rotations, mostly forward translation
+    n_pts = 2500
+    Xw = np.stack([rng.uniform(-12, 12, n_pts), rng.uniform(-3, 3, n_pts), rng.uniform(6, 45, n_pts)], 1)
+    base_desc = rng.integers(0, 256, (n_pts, 32), dtype=np.uint8)
+    base_node = (rng.integers(0, 50, n_pts) * 3 + 1).astype(np.int32)
+
+    def make_kf(seed, shift):
+        r = np.random.default_rng(seed)
+        a = r.normal(0, 0.02, 3)
+        Rz = np.array([[np.cos(a[2]), -np.sin(a[2]), 0], [np.sin(a[2]), np.cos(a[2]), 0], [0, 0, 1]])
+        Ry = np.array([[np.cos(a[1]), 0, np.sin(a[1])], [0, 1, 0], [-np.sin(a[1]), 0, np.cos(a[1])]])
+        R = (Rz @ Ry).astype(np.float32)
+        t = np.array([0.1 * shift, 0.01, -0.7 * shift], np.float32) + r.normal(0, 0.03, 3).astype(np.float32)
+        Xc = Xw @ R.T.astype(np.float64) + t
+        u = fx * Xc[:, 0] / Xc[:, 2] + cx + r.normal(0, 0.8, n_pts)
+        v = fy * Xc[:, 1] / Xc[:, 2] + cy + r.normal(0, 0.8, n_pts)
+        vis = np.nonzero((Xc[:, 2] > 1) & (u > 0) & (u < 1241) & (v > 0) & (v < 376) & (r.random(n_pts) < 0.8))[0]
+        n = len(vis)
+        kp = np.zeros(n, bmc.KP_DTYPE)
+        kp["x"], kp["y"] = u[vis], v[vis]
+        kp["octave"] = r.integers(0, 8, n)
+        kp["angle"] = np.mod(vis * 0.37 + 5.0 * shift + r.normal(0, 4, n), 360)
+        desc = bmc.bow_cases._flip_bits(r, base_desc[vis], r.integers(0, 18, n))
+        node = base_node[vis].copy()
+        node[r.random(n) < 0.05] = -1
+        mp = (r.random(n) < 0.35).astype(np.uint8)
+        ur = np.where(r.random(n) < 0.5, kp["x"] - r.uniform(1, 30, n), -1).astype(np.float32)
+        return dict(desc=np.ascontiguousarray(desc), kp=kp, node=node, mp=mp, ur=ur, R=R, t=t)
+
+    kfs = [make_kf(50, 0)] + [make_kf(51 + k, k + 1) for k in range(K)]
+    for only_stereo, coarse, ori in ((0, 0, 1), (1, 0, 1), (0, 1, 0)):
+        with open(tmp_path / "tri.bin", "wb") as f:
+            f.write(struct.pack("<iiii", K, only_stereo, coarse, ori))
+            f.write(struct.pack("<4f", fx, fy, cx, cy))
+            for kf in kfs:
+                f.write(struct.pack("<i", len(kf["desc"])))
+                for arr in (kf["desc"], kf["kp"], kf["node"], kf["mp"], kf["ur"], kf["R"].reshape(9), kf["t"]):
+                    f.write(np.ascontiguousarray(arr).tobytes())
+                f.write(struct.pack("<i", 8))
+                f.write(scale.tobytes())
+                f.write(sigma2.tobytes())
+        subprocess.check_call([str(exe), str(tmp_path / "tri.bin"), str(tmp_path / "tri_out.bin"), "tri"])
+        blob = (tmp_path / "tri_out.bin").read_bytes()
+        pos = 0
+        a = kfs[0]
+        for k in range(K):
+            b = kfs[1 + k]
+            F12 = np.frombuffer(blob, np.float32, 9, pos)
+            ep = np.frombuffer(blob, np.float32, 2, pos + 36)
+            nm, cnt = struct.unpack_from("<ii", blob, pos + 44)
+            got = np.frombuffer(blob, np.int32, 2 * cnt, pos + 52).reshape(cnt, 2)
+            pos += 52 + 8 * cnt
+            st1, st2 = a["ur"] >= 0, b["ur"] >= 0
+            p = dict(desc1=a["desc"], desc2=b["desc"], valid1=(a["mp"] == 0) & (st1 | (not only_stereo)),
+                     avail2=(b["mp"] == 0) & (st2 | (not only_stereo)), stereo1=st1, stereo2=st2,
+                     fv1=bmc.feature_vector_from_nodes(a["node"]), fv2=bmc.feature_vector_from_nodes(b["node"]),
+                     kp1=a["kp"], kp2=b["kp"], scale_factors2=scale, level_sigma2_2=sigma2, F12=F12, ep=ep)
+            wn, w12 = orb_oracle.search_for_triangulation(p, bool(coarse), bool(ori))
+            want = np.stack([np.nonzero(w12 >= 0)[0], w12[w12 >= 0]], 1)
+            assert nm == wn == cnt and got.tolist() == want.tolist()
+            assert nm > 30
+            # geometry sanity: the C++ side's epipole is the projection of camera 1's centre into camera 2
+            assert np.all(np.isfinite(F12)) and np.all(np.isfinite(ep))
+        assert struct.unpack_from("<i", blob, pos)[0] == 1

@@ -118,6 +118,24 @@ def main(pairs=128, L=6):
         sb[name] = dict(pairs=len(batch), kernel_ms=round(float(np.median(kms)), 4), wall_ms_python=round(wall * 1e3, 3),
                         matches_first=int(out[0][0]), cpu_oracle_ms_per_pair=round(dt * 1e3, 3))
     res["search_by_bow"] = sb
+    # SearchForTriangulation: one CreateNewMapPoints pass = the new KeyFrame against 16 neighbours, 2000 features a side
+    tri = [bmc.make_triangulation_pair(60 + i, n1=2000, n2=2000, n_nodes=100, mask_frac=0.35) for i in range(16)]
+    st = {}
+    for name, batch in (("pair", tri[:1]), ("neighbours16", tri)):
+        msorb.search_for_triangulation(batch)
+        kms = [msorb.search_for_triangulation(batch)[1] for _ in range(10)]
+        t0 = time.perf_counter()
+        for _ in range(10):
+            out, _ = msorb.search_for_triangulation(batch)
+        wall = (time.perf_counter() - t0) / 10
+        t0 = time.perf_counter()
+        for p, o in zip(batch, out):
+            nm, m12 = orb_oracle.search_for_triangulation(p)
+            assert nm == o[0] and m12.tolist() == o[1].tolist()
+        dt = (time.perf_counter() - t0) / len(batch)
+        st[name] = dict(pairs=len(batch), kernel_ms=round(float(np.median(kms)), 4), wall_ms_python=round(wall * 1e3, 3),
+                        matches_first=int(out[0][0]), cpu_oracle_ms_per_pair=round(dt * 1e3, 3))
+    res["search_for_triangulation"] = st
     print(json.dumps(res))
 
 
