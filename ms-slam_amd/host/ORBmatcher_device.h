@@ -6,6 +6,9 @@
 //   ORB_SLAM3::msorb_host::SearchByProjection(...)       body of ORBmatcher::SearchByProjection(Frame&, const
 //                                                        vector<shared_ptr<MapPoint>>&, th, bFarPoints, thFarPoints)
 //                                                        (src/ORBmatcher.cc:43-142, rectified / Nleft == -1 branch)
+//   ORB_SLAM3::msorb_host::SearchByProjection(dev, Cur, Last, th, bMono, ...)
+//                                                        body of ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)
+//                                                        (src/ORBmatcher.cc:1941-2152, Nleft == -1; TrackWithMotionModel)
 //   ORB_SLAM3::msorb_host::SearchLocalPointsPrepass(...) the isInFrustum loop of Tracking::SearchLocalPoints
 //                                                        (src/Tracking.cc:3343-3361, src/Frame.cc:512-571)
 //   ORB_SLAM3::msorb_host::ComputeStereoMatches(...)     body of Frame::ComputeStereoMatches (src/Frame.cc:743-913)
@@ -111,6 +114,79 @@ int SearchByProjection(DeviceFrame<FrameT>& dev, FrameT& F, const std::vector<Ma
           "msorb_search_by_projection_mps");
     for (int i = 0; i < N; i++)
         if (frameMp[i] != before[i] && frameMp[i] >= 0 && frameMp[i] < M) F.mvpMapPoints[i] = vpMapPoints[frameMp[i]];
+    return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
+// (:1941-2152, rectified / Nleft == -1): the per-keypoint projection of :1962-1990 stays the reference's own code (same
+// expressions, compiled with the application's flags); window search, sequential claims and the rotation histogram
+// run behind msorb_search_by_projection_frames.  `dev` holds CurrentFrame (dev.Upload(CurrentFrame) after extraction).
+struct LastFrameProjection {  // what :1962-1990 computes per last-frame keypoint
+    std::vector<uint8_t> valid, desc;
+    std::vector<float> u, v, ur, angle;
+    std::vector<int> octave, obs;
+    bool forward = false, backward = false;
+};
+template <class FrameT>
+void ProjectLastFrame(const FrameT& CurrentFrame, const FrameT& LastFrame, bool bMono, LastFrameProjection& P) {
+    const auto Tcw = CurrentFrame.GetPose();
+    const auto twc = Tcw.inverse().translation();
+    const auto Tlw = LastFrame.GetPose();
+    const auto tlc = Tlw * twc;
+    P.forward = tlc(2) > CurrentFrame.mb && !bMono;                       // :1957
+    P.backward = -tlc(2) > CurrentFrame.mb && !bMono;                     // :1958
+    const int n = LastFrame.N;
+    P.valid.assign(n, 0); P.desc.assign((size_t)n * 32, 0);
+    P.u.assign(n, 0); P.v.assign(n, 0); P.ur.assign(n, 0); P.angle.assign(n, 0);
+    P.octave.assign(n, 0); P.obs.assign(n, 0);
+    for (int i = 0; i < n; i++) {
+        const auto& pMP = LastFrame.mvpMapPoints[i];
+        if (!pMP) continue;
+        if (LastFrame.mvbOutlier[i]) continue;
+        const auto x3Dw = pMP->GetWorldPos();
+        const auto x3Dc = Tcw * x3Dw;
+        const float invzc = 1.0 / x3Dc(2);                                // :1973
+        if (invzc < 0) continue;
+        const auto uv = CurrentFrame.mpCamera->project(x3Dc);
+        if (uv(0) < CurrentFrame.mnMinX || uv(0) > CurrentFrame.mnMaxX) continue;
+        if (uv(1) < CurrentFrame.mnMinY || uv(1) > CurrentFrame.mnMaxY) continue;
+        P.valid[i] = 1;
+        P.u[i] = uv(0);
+        P.v[i] = uv(1);
+        P.ur[i] = uv(0) - CurrentFrame.mbf * invzc;                       // :2019
+        P.octave[i] = LastFrame.mvKeys[i].octave;                         // :1986
+        P.angle[i] = LastFrame.mvKeysUn[i].angle;                         // :2044
+        P.obs[i] = pMP->Observations();
+        const auto d = pMP->GetDescriptor();
+        std::memcpy(&P.desc[(size_t)i * 32], d.template ptr<unsigned char>(0), 32);
+    }
+}
+template <class FrameT>
+int SearchByProjection(DeviceFrame<FrameT>& dev, FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono,
+                       const bool mbCheckOrientation) {
+    LastFrameProjection P;
+    ProjectLastFrame(CurrentFrame, LastFrame, bMono, P);
+    const int nL = LastFrame.N, N = CurrentFrame.N;
+    // ids: last-frame keypoint i -> i; map points the current frame already holds -> nL + k (only their Observations()
+    // matter: a keypoint whose point has observations is never overwritten, :2011-2013)
+    std::vector<int> lastMp(nL), obs(P.obs), curMp(N, -1);
+    for (int i = 0; i < nL; i++) lastMp[i] = i;
+    for (int j = 0; j < N; j++)
+        if (CurrentFrame.mvpMapPoints[j]) {
+            curMp[j] = (int)obs.size();
+            obs.push_back(CurrentFrame.mvpMapPoints[j]->Observations());
+        }
+    const std::vector<int> before(curMp);
+    int nmatches = 0;
+    check(msorb_search_by_projection_frames(dev.get(), nL, P.valid.data(), P.u.data(), P.v.data(), P.ur.data(), P.octave.data(),
+                                            P.angle.data(), P.desc.data(), lastMp.data(), obs.data(), curMp.data(), th,
+                                            P.forward, P.backward, mbCheckOrientation, &nmatches),
+          "msorb_search_by_projection_frames");
+    for (int j = 0; j < N; j++) {
+        if (curMp[j] == before[j]) continue;
+        if (curMp[j] < 0) CurrentFrame.mvpMapPoints[j] = nullptr;         // removed by the histogram filter (:2143)
+        else CurrentFrame.mvpMapPoints[j] = LastFrame.mvpMapPoints[curMp[j]];   // :2037
+    }
     return nmatches;
 }
 

@@ -14,10 +14,35 @@
 #include "ORBmatcher_device.h"
 
 namespace ORB_SLAM3 {
+struct Vec2 { float v[2]; float operator()(int i) const { return v[i]; } };                       // Eigen::Vector2f stand-in
 struct Vec3 { float v[3]; float operator()(int i) const { return v[i]; } };                       // Eigen::Vector3f stand-in
-struct Mat3 { float m[9]; float operator()(int r, int c) const { return m[3 * r + c]; } };       // Eigen::Matrix3f stand-in
-struct SE3 { Mat3 R; Vec3 t; Mat3 rotationMatrix() const { return R; } Vec3 translation() const { return t; } };  // Sophus::SE3f
-struct Camera { std::vector<float> p; float getParameter(int i) { return p[i]; } };              // GeometricCamera
+struct Mat3 {                                                                                     // Eigen::Matrix3f stand-in
+    float m[9];
+    float operator()(int r, int c) const { return m[3 * r + c]; }
+    Vec3 operator*(const Vec3& x) const {
+        Vec3 r{};
+        for (int i = 0; i < 3; i++) r.v[i] = m[3 * i] * x.v[0] + m[3 * i + 1] * x.v[1] + m[3 * i + 2] * x.v[2];
+        return r;
+    }
+};
+struct SE3 {                                                                                      // Sophus::SE3f stand-in
+    Mat3 R; Vec3 t;
+    Mat3 rotationMatrix() const { return R; }
+    Vec3 translation() const { return t; }
+    Vec3 operator*(const Vec3& p) const { const Vec3 x = R * p; return Vec3{{x.v[0] + t.v[0], x.v[1] + t.v[1], x.v[2] + t.v[2]}}; }
+    SE3 inverse() const {
+        SE3 r;
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.R.m[3 * i + j] = R.m[3 * j + i];
+        const Vec3 x = r.R * t;
+        r.t = Vec3{{-x.v[0], -x.v[1], -x.v[2]}};
+        return r;
+    }
+};
+struct Camera {                                                                                   // GeometricCamera / Pinhole
+    std::vector<float> p;
+    float getParameter(int i) { return p[i]; }
+    Vec2 project(const Vec3& x) { return Vec2{{p[0] * x.v[0] / x.v[2] + p[2], p[1] * x.v[1] / x.v[2] + p[3]}}; }
+};
 struct MapPoint {  // the members ORBmatcher.cc:43-142 and Frame::isInFrustum touch
     bool mbTrackInView = false, mbTrackInViewR = false, mbSparsified = false, mbBad = false;
     float mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0, mTrackDepth = 0, mTrackViewCos = 0;
@@ -38,7 +63,9 @@ struct MapPoint {  // the members ORBmatcher.cc:43-142 and Frame::isInFrustum to
 struct Frame {
     int N = 0, Nleft = -1;
     long unsigned int mnId = 0;
-    std::vector<cv::KeyPoint> mvKeysUn;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
+    std::vector<bool> mvbOutlier;
+    float mb = 0;
     cv::Mat mDescriptors;
     std::vector<float> mvuRight, mvScaleFactors;
     std::vector<std::shared_ptr<MapPoint>> mvpMapPoints;
@@ -103,10 +130,70 @@ static int prepass_main(const char* in, const char* out) {
     return 0;
 }
 
+// mode "frames": ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) through msorb_host::SearchByProjection
+static int frames_main(const char* in, const char* out) {
+    using namespace ORB_SLAM3;
+    FILE* f = fopen(in, "rb");
+    if (!f) return 3;
+    const auto hdr = rd<int>(f, 5);  // N, nlevels, NL, bMono, check orientation
+    const int N = hdr[0], nlev = hdr[1], NL = hdr[2];
+    const auto fl = rd<float>(f, 4 + 4 + 3);  // bounds, fx fy cx cy, mb, mbf, th
+    Camera cam{{fl[4], fl[5], fl[6], fl[7]}};
+    Frame C, L;
+    Frame::mnMinX = fl[0]; Frame::mnMaxX = fl[1]; Frame::mnMinY = fl[2]; Frame::mnMaxY = fl[3];
+    C.N = N; C.mpCamera = &cam; C.mb = fl[8]; C.mbf = fl[9];
+    C.mvKeysUn = rd<cv::KeyPoint>(f, N);
+    C.mvKeys = C.mvKeysUn;
+    std::vector<unsigned char> desc = rd<unsigned char>(f, (size_t)N * 32);
+    C.mDescriptors = cv::Mat(N, 32, CV_8UC1, desc.data(), 32);
+    C.mvuRight = rd<float>(f, N);
+    C.mvScaleFactors = rd<float>(f, nlev);
+    const auto cpose = rd<float>(f, 12);
+    memcpy(C.mTcw.R.m, &cpose[0], 36); memcpy(C.mTcw.t.v, &cpose[9], 12);
+    const auto held = rd<int>(f, N);  // Observations() of the map point keypoint j already holds, -1 = none
+    C.mvpMapPoints.resize(N);
+    for (int j = 0; j < N; j++)
+        if (held[j] >= 0) { C.mvpMapPoints[j] = std::make_shared<MapPoint>(); C.mvpMapPoints[j]->nObs = held[j]; C.mvpMapPoints[j]->id = -2; }
+    L.N = NL; L.mpCamera = &cam;
+    L.mvKeysUn = rd<cv::KeyPoint>(f, NL);
+    L.mvKeys = L.mvKeysUn;
+    const auto lpose = rd<float>(f, 12);
+    memcpy(L.mTcw.R.m, &lpose[0], 36); memcpy(L.mTcw.t.v, &lpose[9], 12);
+    const auto has = rd<unsigned char>(f, NL), outl = rd<unsigned char>(f, NL);
+    const auto pw = rd<float>(f, (size_t)3 * NL);
+    const auto obs = rd<int>(f, NL);
+    const auto mdesc = rd<unsigned char>(f, (size_t)NL * 32);
+    fclose(f);
+    L.mvpMapPoints.resize(NL);
+    L.mvbOutlier.assign(NL, false);
+    for (int i = 0; i < NL; i++) {
+        L.mvbOutlier[i] = outl[i] != 0;
+        if (!has[i]) continue;
+        auto p = std::make_shared<MapPoint>();
+        p->id = i; p->nObs = obs[i];
+        memcpy(p->pos.v, &pw[3 * i], 12);
+        memcpy(p->descriptor, &mdesc[(size_t)i * 32], 32);
+        L.mvpMapPoints[i] = p;
+    }
+    msorb_host::DeviceFrame<Frame> dev;
+    dev.Upload(C);
+    msorb_host::LastFrameProjection P;
+    msorb_host::ProjectLastFrame(C, L, hdr[3] != 0, P);
+    const int nm = msorb_host::SearchByProjection(dev, C, L, fl[10], hdr[3] != 0, hdr[4] != 0);
+    FILE* o = fopen(out, "wb");
+    const int fb[2] = {P.forward, P.backward};
+    fwrite(&nm, 4, 1, o); fwrite(fb, 4, 2, o);
+    for (int j = 0; j < N; j++) { const int v = C.mvpMapPoints[j] ? C.mvpMapPoints[j]->id : -1; fwrite(&v, 4, 1, o); }
+    fwrite(P.valid.data(), 1, NL, o); fwrite(P.u.data(), 4, NL, o); fwrite(P.v.data(), 4, NL, o); fwrite(P.ur.data(), 4, NL, o);
+    fclose(o);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     using namespace ORB_SLAM3;
     if (argc < 3) return 2;
     if (argc > 3 && std::string(argv[3]) == "prepass") return prepass_main(argv[1], argv[2]);
+    if (argc > 3 && std::string(argv[3]) == "frames") return frames_main(argv[1], argv[2]);
     FILE* f = fopen(argv[1], "rb");
     if (!f) return 3;
     const auto hdr = rd<int>(f, 4);  // N, nlevels, M, bFarPoints

@@ -381,3 +381,90 @@ def test_cpp_search_for_triangulation_adapter_matches_oracle(tmp_path, oracle, m
             # geometry sanity: the C++ side's epipole is the projection of camera 1's centre into camera 2
             assert np.all(np.isfinite(F12)) and np.all(np.isfinite(ep))
         assert struct.unpack_from("<i", blob, pos)[0] == 1
+
+
+@pytest.mark.parametrize("motion", ["forward", "backward", "sideways", "mono"])
+def test_cpp_search_by_projection_frames_adapter_matches_oracle(tmp_path, oracle, msorb_mod, motion):
+    """msorb_host::SearchByProjection(dev, CurrentFrame, LastFrame, th, bMono) (TrackWithMotionModel's matcher call,
+    ORBmatcher.cc:1941-2152) over stand-in Frame / MapPoint / SE3 types vs the oracle, which is fed the projections the
+    C++ side computed (checked against a float64 projection here)."""
+    exe = tmp_path / "dropin_matcher"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", f"-I{ROOT}/tests/cv_stub", f"-I{ROOT}/ms-slam_amd/host",
+                           f"-I{ROOT}/include", f"{ROOT}/tests/dropin_matcher_main.cc", f"-L{ROOT}/ms-slam_amd", "-lmsorb",
+                           f"-Wl,-rpath,{ROOT}/ms-slam_amd", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    cfg = synth.KITTI
+    ex = msorb_mod.ORBextractor(cfg["nfeatures"], cfg["scale"], cfg["nlevels"], cfg["ini_th"], cfg["min_th"])
+    try:
+        _, kps, desc = ex(synth.image(6, cfg["rows"], cfg["cols"]))
+        scale = np.asarray(ex.GetScaleFactors(), np.float32)
+    finally:
+        ex.close()
+    rng = np.random.default_rng(3)
+    N = len(kps)
+    fx, fy, cx, cy, mb, mbf = 718.856, 718.856, 607.19, 185.21, 0.54, 386.1448
+    bounds = (0.0, float(cfg["cols"]), 0.0, float(cfg["rows"]))
+    ur_cur = np.where(rng.random(N) < 0.6, kps["x"] - rng.uniform(1, 40, N), -1).astype(np.float32)
+    # current pose = identity-ish; world points = back-projections of the current keypoints (+ noise) so windows hit
+    a = 0.01
+    Rc = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+    tc = np.array([0.05, -0.02, 0.1], np.float32)
+    NL = 1800
+    src = rng.integers(0, N, NL)
+    z = rng.uniform(4, 50, NL)
+    uu = kps["x"][src] + rng.normal(0, 3, NL)
+    vv = kps["y"][src] + rng.normal(0, 3, NL)
+    Xc = np.stack([(uu - cx) / fx * z, (vv - cy) / fy * z, z], 1)
+    behind = rng.random(NL) < 0.03
+    Xc[behind, 2] *= -1
+    Xw = ((Xc - tc) @ Rc.astype(np.float64)).astype(np.float32)          # Rc^T (Xc - tc)
+    dz = dict(forward=1.5, backward=-1.5, sideways=0.1, mono=1.5)[motion]
+    Rl = np.eye(3, dtype=np.float32)
+    tl = (tc + np.array([0.0, 0.0, dz], np.float32)).astype(np.float32)   # last camera sits dz behind/ahead along z
+    lk = np.zeros(NL, oracle.KP_DTYPE)
+    lk["octave"] = np.clip(kps["octave"][src] + rng.integers(-1, 2, NL), 0, 7)
+    lk["angle"] = np.mod(kps["angle"][src] + 7.0 + rng.normal(0, 6, NL), 360)
+    lk["angle"][rng.random(NL) < 0.2] = rng.uniform(0, 360)
+    has = (rng.random(NL) < 0.85).astype(np.uint8)
+    outl = (rng.random(NL) < 0.05).astype(np.uint8)
+    obs = rng.integers(0, 4, NL).astype(np.int32)
+    import bow_cases
+    mdesc = bow_cases._flip_bits(rng, desc[src], rng.integers(0, 40, NL))
+    held = np.where(rng.random(N) < 0.1, rng.integers(0, 3, N), -1).astype(np.int32)
+    th, mono, ori = (15.0, 1, 1) if motion == "mono" else (7.0, 0, 1)
+    with open(tmp_path / "fr.bin", "wb") as f:
+        f.write(struct.pack("<5i", N, len(scale), NL, mono, ori))
+        f.write(struct.pack("<11f", *bounds, fx, fy, cx, cy, mb, mbf, th))
+        for arr in (kps, desc, ur_cur, scale, Rc.reshape(9), tc, held, lk, Rl.reshape(9), tl, has, outl, Xw, obs, mdesc):
+            f.write(np.ascontiguousarray(arr).tobytes())
+    subprocess.check_call([str(exe), str(tmp_path / "fr.bin"), str(tmp_path / "fr_out.bin"), "frames"])
+    blob = (tmp_path / "fr_out.bin").read_bytes()
+    nm, fwd, bwd = struct.unpack_from("<iii", blob, 0)
+    got = np.frombuffer(blob, np.int32, N, 12)
+    pos = 12 + 4 * N
+    valid = np.frombuffer(blob, np.uint8, NL, pos)
+    u = np.frombuffer(blob, np.float32, NL, pos + NL)
+    v = np.frombuffer(blob, np.float32, NL, pos + 5 * NL)
+    ur = np.frombuffer(blob, np.float32, NL, pos + 9 * NL)
+    assert (fwd, bwd) == dict(forward=(1, 0), backward=(0, 1), sideways=(0, 0), mono=(0, 0))[motion]
+    # the projections the adapter computed, against float64
+    Xc64 = Xw.astype(np.float64) @ Rc.astype(np.float64).T + tc
+    u64 = fx * Xc64[:, 0] / Xc64[:, 2] + cx
+    v64 = fy * Xc64[:, 1] / Xc64[:, 2] + cy
+    want_valid = (has > 0) & (outl == 0) & (Xc64[:, 2] > 0) & (u64 >= 0) & (u64 <= bounds[1]) & (v64 >= 0) & (v64 <= bounds[3])
+    edge = (np.abs(u64) < 1e-2) | (np.abs(u64 - bounds[1]) < 1e-2) | (np.abs(v64) < 1e-2) | (np.abs(v64 - bounds[3]) < 1e-2)
+    assert np.array_equal(valid[~edge] > 0, want_valid[~edge])
+    ok = valid > 0
+    assert np.allclose(u[ok], u64[ok], atol=2e-2) and np.allclose(v[ok], v64[ok], atol=2e-2)
+    assert np.allclose(ur[ok], u64[ok] - mbf / Xc64[ok, 2], atol=5e-2)
+    # oracle on the same projections; ids: last keypoint i -> i, points already held -> NL + k
+    rf = oracle.OracleFrame(kps, desc, ur_cur, bounds, scale)
+    cur = np.full(N, -1, np.int32)
+    hk = np.nonzero(held >= 0)[0]
+    cur[hk] = NL + np.arange(len(hk))
+    obs_all = np.concatenate([obs, held[hk]]).astype(np.int32)
+    last = dict(valid=valid, u=u, v=v, ur=ur, octave=lk["octave"], angle=lk["angle"], desc=mdesc,
+                mp=np.arange(NL, dtype=np.int32), obs=obs_all)
+    wn = rf.SearchByProjection_frames(last, cur, th, bool(fwd), bool(bwd), bool(ori))
+    want = np.where(cur >= NL, -2, cur)                 # the C++ side reports -2 for a point it held before and kept
+    assert nm == wn and nm > 100
+    assert got.tolist() == want.tolist()
