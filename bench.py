@@ -25,6 +25,8 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+KITTI_MBF = 386.1448            # Camera.bf of Examples/Stereo/KITTI00-02.yaml
+KITTI_MB = KITTI_MBF / 718.856  # mb = mbf / fx
 sys.path[:0] = [os.path.join(ROOT, "ms-slam_amd")]
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
@@ -259,6 +261,19 @@ def main():
                                        "sample": f"{n0} x {n1} descriptors of one stereo pair, {dtc * 1e3:.1f} ms",
                                        "gpu_matches_cpu": bool(same)}
 
+    # third: Frame::ComputeStereoMatches for the whole batch, device resident (pair p = images 2p / 2p+1), median
+    # rejection included; the outputs of the extraction above are its inputs
+    stereo = None
+    if world == 1:
+        msorb.stereo_matches_batch(ex, counts_h, d_kps, d_desc, KITTI_MB, KITTI_MBF)
+        sms = [msorb.stereo_matches_batch(ex, counts_h, d_kps, d_desc, KITTI_MB, KITTI_MBF)[3] for _ in range(5)]
+        d_ur, _, _, _ = msorb.stereo_matches_batch(ex, counts_h, d_kps, d_desc, KITTI_MB, KITTI_MBF)
+        m = float(np.median(sms))
+        n_left = int(counts_h[0::2].sum())
+        stereo = {"pairs": int(len(counts_h) // 2), "left_keypoints": n_left, "matched": int((d_ur > 0).sum().item()),
+                  "ms_per_batch": round(m, 4), "mkeypoints_per_s": round(n_left / (m * 1e-3) / 1e6, 2),
+                  "kernels": "stereo_match_batch_kernel + stereo_median_kernel"}
+
     if rank == 0:
         steps = max(args.steps, 1)
         stages = {k: v / iso_steps for k, v in stage_acc.items()}
@@ -329,6 +344,7 @@ def main():
                                       ((stages["pyramid"] + stages["fast"]) * 1e-3) / 1e9, 2),
         }
         out["hamming_match"] = hamming
+        out["stereo_match"] = stereo
         if world == 1 and args.cpu_pairs > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_pairs, 5000)
         else:

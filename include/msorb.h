@@ -259,6 +259,17 @@ typedef struct msorb_triangulation_pair {
 int msorb_search_for_triangulation(int device, msorb_triangulation_pair* pairs, int n_pairs, int coarse,
                                    int check_orientation, float* elapsed_ms);
 
+/* Frame::ComputeStereoMatches (Frame.cc:743-913, median rejection :899-912 included) for every stereo pair of the last
+ * msorb_extract_batch() call of `h`, all on the device: pair p = images 2p (left) and 2p+1 (right) of that batch.
+ * d_keypoints / d_descriptors / capacity are the arrays that call filled, d_counts[2*n_pairs] the keypoint counts as a
+ * DEVICE array.  Outputs (device): d_u_right / d_depth [n_pairs][capacity] (mvuRight / mvDepth of the left image, -1 =
+ * none; entries past the left count are not written), d_n_oob[n_pairs] (may be NULL; see msorb_stereo_matches).
+ * The pyramids of the batch must still be alive (no other extract call on `h` in between).  *elapsed_ms (may be NULL) =
+ * device time of the two kernels. */
+int msorb_stereo_matches_batch(msorb_extractor* h, int n_pairs, const msorb_keypoint* d_keypoints,
+                               const uint8_t* d_descriptors, int capacity, const int* d_counts, int max_left, float mb,
+                               float mbf, float* d_u_right, float* d_depth, int* d_n_oob, float* elapsed_ms);
+
 /* ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:2277-2318) on histogram bin sizes; ind[3]. Host only. */
 int msorb_three_maxima(const int* bin_sizes, int n_bins, int* ind);
 

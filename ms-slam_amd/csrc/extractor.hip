@@ -602,7 +602,7 @@ namespace msorb {
 void set_last_error(const std::string& s) { g_last_error = s; }
 // Device views of the last call's pyramid (used by the stereo matcher, which reads both eyes' levels).
 int extractor_last_view(msorb_extractor* h, PyramidView* pyr, LevelScale* sc, float* inv_scale, int* device,
-                        hipStream_t* stream) {
+                        hipStream_t* stream, int* n_images) {
     if (!h || !h->geom_valid || h->last_n_images < 1) {
         set_error("extractor has no pyramid yet (call msorb_extract first)");
         return MSORB_E_INVALID;
@@ -613,6 +613,7 @@ int extractor_last_view(msorb_extractor* h, PyramidView* pyr, LevelScale* sc, fl
         for (int l = 0; l < h->P.nlevels; l++) inv_scale[l] = h->P.inv_scale[l];
     *device = h->device;
     *stream = h->stream;
+    if (n_images) *n_images = h->last_n_images;
     return MSORB_OK;
 }
 }  // namespace msorb

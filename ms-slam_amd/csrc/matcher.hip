@@ -156,27 +156,42 @@ __global__ __launch_bounds__(256) void list_top2_kernel(const uint8_t* __restric
 //  2. if best < 75: L1 SAD of the 11x11 window at 11 horizontal offsets on the pyramid level, parabola
 //     sub-pixel fit, disparity gates                                                  (:829-897)
 // The median-based rejection (:899-912) is serial and done by the host on the SAD values written here.
-__global__ __launch_bounds__(256) void stereo_match_kernel(StereoArgs A) {
-    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (iL >= A.nL) return;
+// G = the geometry tables (kernel argument memory: indexed by level without a private copy), V = this image pair
+struct StereoPairView {
+    const msorb_keypoint *kpL, *kpR;
+    const uint8_t *descL, *descR;
+    int nR;
+    float *u_right, *depth;
+    int *sad, *n_oob;
+    const int *row_begin, *row_list;
+    size_t imgL, imgR;          // image index of the left / right eye inside the batch (0 for the per-frame call)
+    const size_t* img_stride;   // per level, nullptr for the per-frame call
+};
+__device__ __forceinline__ void stereo_match_one(const StereoArgs& G, const StereoPairView& A, const int iL, const int lane) {
     const msorb_keypoint kpL = A.kpL[iL];
     const int levelL = kpL.octave;
     const float vL = kpL.y, uL = kpL.x;
     float out_u = -1.0f, out_d = -1.0f;
     int out_sad = -1;
     const int row = (int)vL;
-    const float minD = 0.f, maxD = __fdiv_rn(A.mbf, A.mb);
+    const float minD = 0.f, maxD = __fdiv_rn(G.mbf, G.mb);
     const float minU = __fsub_rn(uL, maxD), maxU = __fsub_rn(uL, minD);
     uint64_t best = kNoKey;
-    if (row >= 0 && row < A.rows0 && !(maxU < 0)) {
+    if (row >= 0 && row < G.rows0 && !(maxU < 0)) {
         const uint64_t* dl = reinterpret_cast<const uint64_t*>(A.descL + (size_t)iL * 32);
         const uint64_t a[4] = {dl[0], dl[1], dl[2], dl[3]};
-        for (int iR = lane; iR < A.nR; iR += 64) {
+        // candidates: the row's entry of the vRowIndices table (:760-770) when one was built (any order: the result is
+        // the lexicographic minimum of (distance, iR)), else every right keypoint with the band test done here
+        const int* list = A.row_begin ? A.row_list + A.row_begin[row] : nullptr;
+        const int n_cand = A.row_begin ? A.row_begin[row + 1] - A.row_begin[row] : A.nR;
+        for (int j = lane; j < n_cand; j += 64) {
+            const int iR = list ? list[j] : j;
             const msorb_keypoint kr = A.kpR[iR];
-            const float r = __fmul_rn(2.0f, A.scale[kr.octave]);
-            const int maxr = (int)ceilf(__fadd_rn(kr.y, r)), minr = (int)floorf(__fsub_rn(kr.y, r));
-            if (row < minr || row > maxr) continue;
+            if (!list) {
+                const float r = __fmul_rn(2.0f, G.scale[kr.octave]);
+                const int maxr = (int)ceilf(__fadd_rn(kr.y, r)), minr = (int)floorf(__fsub_rn(kr.y, r));
+                if (row < minr || row > maxr) continue;
+            }
             if (kr.octave < levelL - 1 || kr.octave > levelL + 1) continue;
             if (!(kr.x >= minU && kr.x <= maxU)) continue;
             const int d = hamming256(a, reinterpret_cast<const uint64_t*>(A.descR + (size_t)iR * 32));
@@ -189,31 +204,31 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoArgs A) {
     if (bestDist < kThHigh && bestDist < (kThHigh + kThLow) / 2) {
         const int bestIdxR = (int)(best & 0xffffffffu);
         const float uR0 = A.kpR[bestIdxR].x;
-        const float sf = A.inv_scale[levelL];
+        const float sf = G.inv_scale[levelL];
         const float scaleduL = roundf(__fmul_rn(kpL.x, sf));
         const float scaledvL = roundf(__fmul_rn(kpL.y, sf));
         const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
         const int w = 5, L = 5;
-        const int cols = A.cols[levelL], rows = A.rows[levelL];
+        const int cols = G.cols[levelL], rows = G.rows[levelL];
         const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
         const int y0 = (int)(scaledvL - w), xL0 = (int)(scaleduL - w), xR0 = (int)(scaleduR0 - L - w);
         const bool ok = !(iniu < 0 || endu >= cols) && y0 >= 0 && y0 + 2 * w + 1 <= rows && xL0 >= 0 &&
                         xL0 + 2 * w + 1 <= cols && xR0 >= 0 && (int)(scaleduR0 + L + w + 1) <= cols;
         if (ok) {
-            const uint8_t* pl = A.pyrL[levelL] + (size_t)y0 * A.pitchL[levelL] + xL0;
-            const uint8_t* pr = A.pyrR[levelL] + (size_t)y0 * A.pitchR[levelL] + xR0;
+            const uint8_t* pl = G.pyrL[levelL] + (A.img_stride ? A.imgL * A.img_stride[levelL] : 0) + (size_t)y0 * G.pitchL[levelL] + xL0;
+            const uint8_t* pr = G.pyrR[levelL] + (A.img_stride ? A.imgR * A.img_stride[levelL] : 0) + (size_t)y0 * G.pitchR[levelL] + xR0;
             // lane -> window pixel(s): 121 pixels over 64 lanes (two passes)
             int vl0 = 0, vl1 = 0, o0 = 0, o1 = 0;
             const int p0 = lane, p1 = lane + 64;
             {
                 const int yy = p0 / 11, xx = p0 - yy * 11;
-                vl0 = pl[(size_t)yy * A.pitchL[levelL] + xx];
-                o0 = yy * A.pitchR[levelL] + xx;
+                vl0 = pl[(size_t)yy * G.pitchL[levelL] + xx];
+                o0 = yy * G.pitchR[levelL] + xx;
             }
             if (p1 < 121) {
                 const int yy = p1 / 11, xx = p1 - yy * 11;
-                vl1 = pl[(size_t)yy * A.pitchL[levelL] + xx];
-                o1 = yy * A.pitchR[levelL] + xx;
+                vl1 = pl[(size_t)yy * G.pitchL[levelL] + xx];
+                o1 = yy * G.pitchR[levelL] + xx;
             }
             int sad[11];
 #pragma unroll
@@ -234,14 +249,14 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoArgs A) {
                 const float deltaR = __fdiv_rn(__fsub_rn(d1, d3),
                                                __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
                 if (!(deltaR < -1 || deltaR > 1)) {
-                    float bestuR = __fmul_rn(A.scale[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
+                    float bestuR = __fmul_rn(G.scale[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
                     float disparity = __fsub_rn(uL, bestuR);
                     if (disparity >= minD && disparity < maxD) {
                         if (disparity <= 0) {
                             disparity = (float)0.01;
                             bestuR = (float)((double)uL - 0.01);
                         }
-                        out_d = __fdiv_rn(A.mbf, disparity);
+                        out_d = __fdiv_rn(G.mbf, disparity);
                         out_u = bestuR;
                         out_sad = bestS;
                     }
@@ -255,6 +270,147 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoArgs A) {
         A.u_right[iL] = out_u;
         A.depth[iL] = out_d;
         A.sad[iL] = out_sad;
+    }
+}
+
+__global__ __launch_bounds__(256) void stereo_match_kernel(StereoArgs A) {
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (iL >= A.nL) return;
+    StereoPairView V{};
+    V.kpL = A.kpL; V.kpR = A.kpR; V.descL = A.descL; V.descR = A.descR; V.nR = A.nR;
+    V.u_right = A.u_right; V.depth = A.depth; V.sad = A.sad; V.n_oob = A.n_oob;
+    V.row_begin = A.row_begin; V.row_list = A.row_list;
+    stereo_match_one(A, V, iL, threadIdx.x & 63);
+}
+
+// vRowIndices (Frame.cc:756-770) for one right image per workgroup, as CSR over the image rows: thread per right
+// keypoint, LDS counters per row, block scan, fill.  The order inside a row is arbitrary (see stereo_match_one).
+__global__ __launch_bounds__(256) void stereo_rowtable_kernel(StereoBatchArgs B) {
+    extern __shared__ int rt[];  // [rows0] counts -> cursors, [rows0 + 1] begins
+    const int pair = blockIdx.x, t = threadIdx.x;
+    const int rows0 = B.A.rows0;
+    int* cnt = rt;
+    int* beg = rt + rows0;
+    const int nR = B.counts ? B.counts[2 * pair + 1] : B.A.nR;
+    const msorb_keypoint* kpR = B.counts ? B.A.kpL + ((size_t)2 * pair + 1) * B.capacity : B.A.kpR;
+    int* row_begin = B.row_begin + (size_t)pair * (rows0 + 1);
+    int* row_list = B.row_list + (size_t)pair * B.row_cap;
+    for (int r = t; r < rows0; r += 256) cnt[r] = 0;
+    __syncthreads();
+    for (int iR = t; iR < nR; iR += 256) {
+        const msorb_keypoint kr = kpR[iR];
+        const float r = __fmul_rn(2.0f, B.A.scale[kr.octave]);
+        const int maxr = min((int)ceilf(__fadd_rn(kr.y, r)), rows0 - 1), minr = max((int)floorf(__fsub_rn(kr.y, r)), 0);
+        for (int y = minr; y <= maxr; y++) atomicAdd(&cnt[y], 1);
+    }
+    __syncthreads();
+    // exclusive scan of cnt over the rows (rows0 is a few hundred: one wave, sequential chunks)
+    if (t < 64) {
+        int carry = 0;
+        for (int base = 0; base < rows0; base += 64) {
+            const int r = base + t;
+            const int v = r < rows0 ? cnt[r] : 0;
+            int inc = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int u = __shfl_up(inc, off);
+                if (t >= off) inc += u;
+            }
+            if (r < rows0) beg[r] = carry + inc - v;
+            carry += __shfl(inc, 63);
+        }
+        if (t == 0) beg[rows0] = carry;
+    }
+    __syncthreads();
+    for (int r = t; r <= rows0; r += 256) row_begin[r] = beg[r];
+    for (int r = t; r < rows0; r += 256) cnt[r] = beg[r];
+    __syncthreads();
+    for (int iR = t; iR < nR; iR += 256) {
+        const msorb_keypoint kr = kpR[iR];
+        const float r = __fmul_rn(2.0f, B.A.scale[kr.octave]);
+        const int maxr = min((int)ceilf(__fadd_rn(kr.y, r)), rows0 - 1), minr = max((int)floorf(__fsub_rn(kr.y, r)), 0);
+        for (int y = minr; y <= maxr; y++) {
+            const int pos = atomicAdd(&cnt[y], 1);
+            if (pos < B.row_cap) row_list[pos] = iR;
+        }
+    }
+}
+
+// The same for every stereo pair of a batch (pair p = images 2p / 2p+1 of msorb_extract_batch): blockIdx.y = pair.
+__global__ __launch_bounds__(256) void stereo_match_batch_kernel(StereoBatchArgs B) {
+    const int pair = blockIdx.y;
+    const int nL = B.counts[2 * pair], nR = B.counts[2 * pair + 1];
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (iL >= nL) return;
+    const size_t L = (size_t)2 * pair, R = L + 1;
+    StereoPairView V{};
+    V.kpL = B.A.kpL + L * B.capacity;
+    V.kpR = B.A.kpL + R * B.capacity;
+    V.descL = B.A.descL + L * B.capacity * 32;
+    V.descR = B.A.descL + R * B.capacity * 32;
+    V.nR = nR;
+    V.u_right = B.A.u_right + (size_t)pair * B.capacity;
+    V.depth = B.A.depth + (size_t)pair * B.capacity;
+    V.sad = B.A.sad + (size_t)pair * B.capacity;
+    V.n_oob = B.A.n_oob + pair;
+    V.row_begin = B.row_begin + (size_t)pair * (B.A.rows0 + 1);
+    V.row_list = B.row_list + (size_t)pair * B.row_cap;
+    V.imgL = L; V.imgR = R;
+    V.img_stride = B.img_stride;
+    stereo_match_one(B.A, V, iL, threadIdx.x & 63);
+}
+
+// Frame.cc:899-912 for one pair per workgroup: median = vDistIdx[size/2].first of the ascending (SAD, iL) list — the
+// value of rank size/2 — found by a two-level histogram select (SAD <= 121*255 < 2^15); every match whose SAD is not
+// below thDist = 1.5f*1.4f*median is withdrawn (the reference walks the sorted list from the end and stops at the first
+// smaller value: the same set).
+__global__ __launch_bounds__(256) void stereo_median_kernel(const int* __restrict__ counts, int capacity,
+                                                            const int* __restrict__ sad_all, float* __restrict__ u_right_all,
+                                                            float* __restrict__ depth_all) {
+    __shared__ int hist[256];
+    __shared__ int sel[3];  // chosen high bin, rank inside it, number of valid SADs
+    const int pair = blockIdx.x, t = threadIdx.x;
+    const int nL = counts[2 * pair];
+    const int* sad = sad_all + (size_t)pair * capacity;
+    float* u_right = u_right_all + (size_t)pair * capacity;
+    float* depth = depth_all + (size_t)pair * capacity;
+    hist[t] = 0;
+    __syncthreads();
+    for (int i = t; i < nL; i += 256) {
+        const int v = sad[i];
+        if (v >= 0) atomicAdd(&hist[v >> 7], 1);
+    }
+    __syncthreads();
+    if (t == 0) {
+        int total = 0;
+        for (int b = 0; b < 256; b++) total += hist[b];
+        int k = total / 2, b = 0;
+        if (total > 0)
+            while (k >= hist[b]) { k -= hist[b]; b++; }
+        sel[0] = b; sel[1] = k; sel[2] = total;
+    }
+    __syncthreads();
+    const int hb = sel[0], kk = sel[1], total = sel[2];
+    if (total == 0) return;  // vDistIdx empty: nothing to reject (the reference would index an empty vector)
+    __syncthreads();
+    if (t < 128) hist[t] = 0;
+    __syncthreads();
+    for (int i = t; i < nL; i += 256) {
+        const int v = sad[i];
+        if (v >= 0 && (v >> 7) == hb) atomicAdd(&hist[v & 127], 1);
+    }
+    __syncthreads();
+    if (t == 0) {
+        int k = kk, b = 0;
+        while (k >= hist[b]) { k -= hist[b]; b++; }
+        sel[0] = (hb << 7) | b;
+    }
+    __syncthreads();
+    const float median = (float)sel[0];
+    const float thDist = __fmul_rn(__fmul_rn(1.5f, 1.4f), median);
+    for (int i = t; i < nL; i += 256) {
+        const int v = sad[i];
+        if (v >= 0 && !((float)v < thDist)) { u_right[i] = -1.0f; depth[i] = -1.0f; }
     }
 }
 
@@ -273,6 +429,13 @@ void launch_list_top2(const uint8_t* qdesc, const uint8_t* tdesc, const int* can
 void launch_stereo_match(const StereoArgs& a, hipStream_t s) {
     if (a.nL <= 0) return;
     hipLaunchKernelGGL(stereo_match_kernel, dim3((a.nL + 3) / 4), dim3(256), 0, s, a);
+}
+void launch_stereo_match_batch(const StereoBatchArgs& b, int n_pairs, int max_left, hipStream_t s) {
+    if (n_pairs <= 0 || max_left <= 0) return;
+    hipLaunchKernelGGL(stereo_rowtable_kernel, dim3(n_pairs), dim3(256), (size_t)(2 * b.A.rows0 + 1) * sizeof(int), s, b);
+    hipLaunchKernelGGL(stereo_match_batch_kernel, dim3((max_left + 3) / 4, n_pairs), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(stereo_median_kernel, dim3(n_pairs), dim3(256), 0, s, b.counts, b.capacity, b.A.sad, b.A.u_right,
+                       b.A.depth);
 }
 
 // Dense brute-force top-2 (SURVEY.md K6 "dense mode"; the knnMatch(k=2) shape of Frame.cc:1076): every query

@@ -45,6 +45,16 @@ struct StereoArgs {
     float mb, mbf;
     float *u_right, *depth;
     int *sad, *n_oob;
+    const int *row_begin, *row_list;  // vRowIndices as CSR over the rows of level 0 (nullptr: band test per candidate)
+};
+
+struct StereoBatchArgs {  // A: the pointers of image 0 / pair 0; everything else by stride
+    StereoArgs A;
+    size_t img_stride[MSORB_MAX_LEVELS];
+    int capacity;
+    const int* counts;  // device: n_keypoints per image
+    int *row_begin, *row_list;  // per pair: [rows0 + 1] and [row_cap]
+    int row_cap;
 };
 
 void launch_window_topk(const FrameView& F, const WinQuery* q, const uint8_t* qdesc, int q_begin, int q_end,
@@ -52,6 +62,7 @@ void launch_window_topk(const FrameView& F, const WinQuery* q, const uint8_t* qd
 void launch_list_top2(const uint8_t* qdesc, const uint8_t* tdesc, const int* cand_begin, const int* cand_idx, int nq,
                       int* bi, int* bd, int* si, int* sd, hipStream_t s);
 void launch_stereo_match(const StereoArgs& a, hipStream_t s);
+void launch_stereo_match_batch(const StereoBatchArgs& b, int n_pairs, int max_left, hipStream_t s);
 void launch_dense_top2(const uint8_t* q, const uint8_t* t, const int* n_q, const int* n_t, int n_frames, int q_stride,
                        int t_stride, int max_q, int max_t, int* bi, int* bd, int* sd, hipStream_t s);
 

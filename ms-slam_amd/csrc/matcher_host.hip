@@ -25,7 +25,7 @@ using namespace msorb;
 namespace msorb {
 void set_last_error(const std::string& s);
 int extractor_last_view(msorb_extractor* h, PyramidView* pyr, LevelScale* sc, float* inv_scale, int* device,
-                        hipStream_t* stream);
+                        hipStream_t* stream, int* n_images);
 }  // namespace msorb
 
 #define HIPCHK(expr)                                                               \
@@ -524,8 +524,8 @@ int msorb_stereo_matches(msorb_extractor* left, msorb_extractor* right, const ms
     int devL = 0, devR = 0;
     hipStream_t s = nullptr, s2 = nullptr;
     int rc;
-    if ((rc = extractor_last_view(left, &pl, &sc, inv_scale, &devL, &s))) return rc;
-    if ((rc = extractor_last_view(right, &pr, nullptr, nullptr, &devR, &s2))) return rc;
+    if ((rc = extractor_last_view(left, &pl, &sc, inv_scale, &devL, &s, nullptr))) return rc;
+    if ((rc = extractor_last_view(right, &pr, nullptr, nullptr, &devR, &s2, nullptr))) return rc;
     if (devL != devR) { set_last_error("stereo matching needs both pyramids on one device"); return MSORB_E_INVALID; }
     if (pl.nlevels != pr.nlevels || pl.lv[0].w != pr.lv[0].w || pl.lv[0].h != pr.lv[0].h) {
         set_last_error("left/right pyramids differ in geometry");
@@ -603,6 +603,85 @@ int msorb_stereo_matches(msorb_extractor* left, msorb_extractor* right, const ms
         u_right[vDistIdx[i].second] = -1;
         depth[vDistIdx[i].second] = -1;
     }
+    return MSORB_OK;
+}
+
+int msorb_stereo_matches_batch(msorb_extractor* h, int n_pairs, const msorb_keypoint* d_keypoints,
+                               const uint8_t* d_descriptors, int capacity, const int* d_counts, int max_left, float mb,
+                               float mbf, float* d_u_right, float* d_depth, int* d_n_oob, float* elapsed_ms) {
+    if (elapsed_ms) *elapsed_ms = 0;
+    if (!h || n_pairs < 0 || capacity <= 0 || max_left < 0 || max_left > capacity ||
+        (n_pairs > 0 && (!d_keypoints || !d_descriptors || !d_counts || !d_u_right || !d_depth)))
+        return MSORB_E_INVALID;
+    if (n_pairs == 0 || max_left == 0) return MSORB_OK;
+    PyramidView pv;
+    LevelScale sc;
+    float inv_scale[MSORB_MAX_LEVELS];
+    int dev = 0, n_images = 0;
+    hipStream_t s = nullptr;
+    int rc;
+    if ((rc = extractor_last_view(h, &pv, &sc, inv_scale, &dev, &s, &n_images))) return rc;
+    if (2 * n_pairs > n_images) {
+        set_last_error("stereo_matches_batch: the last extract call of this handle holds fewer than 2*n_pairs images");
+        return MSORB_E_INVALID;
+    }
+    HIPCHK(hipSetDevice(dev));
+    struct Scratch {
+        int device = -1;
+        DBuf<int> sad, oob, row_begin, row_list;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        void release() {
+            if (device < 0 || hipSetDevice(device) != hipSuccess) return;
+            sad.release(); oob.release(); row_begin.release(); row_list.release();
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            e0 = e1 = nullptr; device = -1;
+        }
+        ~Scratch() { release(); }
+    };
+    static thread_local Scratch scr;
+    if (scr.device != dev) {
+        scr.release();
+        scr.device = dev;
+        HIPCHK(hipEventCreate(&scr.e0));
+        HIPCHK(hipEventCreate(&scr.e1));
+    }
+    // a right keypoint enters rows floor(y - r) .. ceil(y + r), r = 2*scale[octave] (:762-768): at most 2r + 3 rows
+    float smax = 0;
+    for (int l = 0; l < pv.nlevels; l++) smax = std::max(smax, sc.scale[l]);
+    const int row_cap = capacity * ((int)std::ceil(4.0f * smax) + 3);
+    const int rows0 = pv.lv[0].h;
+    if ((size_t)(2 * rows0 + 1) * sizeof(int) > 60000) {
+        set_last_error("stereo_matches_batch: image too tall for the row table in LDS");
+        return MSORB_E_INVALID;
+    }
+    if ((rc = scr.sad.ensure((size_t)n_pairs * capacity)) || (rc = scr.oob.ensure((size_t)n_pairs)) ||
+        (rc = scr.row_begin.ensure((size_t)n_pairs * (rows0 + 1))) || (rc = scr.row_list.ensure((size_t)n_pairs * row_cap)))
+        return rc;
+    int* oob = d_n_oob ? d_n_oob : scr.oob.p;
+    StereoBatchArgs b{};
+    b.A.kpL = d_keypoints;
+    b.A.descL = d_descriptors;
+    b.A.rows0 = pv.lv[0].h;
+    for (int l = 0; l < pv.nlevels; l++) {
+        b.A.pyrL[l] = b.A.pyrR[l] = pv.lv[l].base;
+        b.A.pitchL[l] = b.A.pitchR[l] = pv.lv[l].pitch;
+        b.A.rows[l] = pv.lv[l].h; b.A.cols[l] = pv.lv[l].w;
+        b.A.scale[l] = sc.scale[l]; b.A.inv_scale[l] = inv_scale[l];
+        b.img_stride[l] = pv.lv[l].img_stride;
+    }
+    b.A.mb = mb; b.A.mbf = mbf;
+    b.A.u_right = d_u_right; b.A.depth = d_depth; b.A.sad = scr.sad.p; b.A.n_oob = oob;
+    b.capacity = capacity;
+    b.counts = d_counts;
+    b.row_begin = scr.row_begin.p; b.row_list = scr.row_list.p; b.row_cap = row_cap;
+    HIPCHK(hipMemsetAsync(oob, 0, (size_t)n_pairs * sizeof(int), s));
+    HIPCHK(hipEventRecord(scr.e0, s));
+    launch_stereo_match_batch(b, n_pairs, max_left, s);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(scr.e1, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (elapsed_ms) HIPCHK(hipEventElapsedTime(elapsed_ms, scr.e0, scr.e1));
     return MSORB_OK;
 }
 

@@ -657,3 +657,30 @@ def search_for_triangulation(pairs, coarse=False, check_orientation=True, device
     _check(lb.msorb_search_for_triangulation(device, C.addressof(arr), len(pairs), int(bool(coarse)),
                                              int(bool(check_orientation)), C.addressof(ms)), "msorb_search_for_triangulation")
     return [(arr[k].nmatches, o[0][:o[1]]) for k, o in enumerate(outs)], ms.value
+
+
+EXPORTS = EXPORTS + ("msorb_stereo_matches_batch",)
+
+
+def stereo_matches_batch(ex, counts, d_kps, d_desc, mb, mbf):
+    """msorb_stereo_matches_batch on the outputs of ex.extract_batch (images 2p / 2p+1 = left / right of pair p).
+    -> (d_u_right, d_depth torch.float32 [n_pairs, cap], n_oob np.int32 [n_pairs], kernel_ms); the outputs stay on the
+    device, entries at and past counts[2p] are -1."""
+    import torch
+    lb = lib()
+    lb.msorb_stereo_matches_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                              C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    counts = np.ascontiguousarray(counts, np.int32)
+    n_pairs = len(counts) // 2
+    cap = d_kps.shape[1]
+    d_counts = torch.from_numpy(counts).to(d_kps.device)
+    d_ur = torch.full((n_pairs, cap), -1.0, dtype=torch.float32, device=d_kps.device)
+    d_dp = torch.full((n_pairs, cap), -1.0, dtype=torch.float32, device=d_kps.device)
+    d_oob = torch.zeros(max(n_pairs, 1), dtype=torch.int32, device=d_kps.device)
+    torch.cuda.synchronize()
+    ms = C.c_float()
+    max_left = int(counts[0::2][:n_pairs].max()) if n_pairs else 0
+    _check(lb.msorb_stereo_matches_batch(ex.h, n_pairs, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_counts.data_ptr(),
+                                         max_left, mb, mbf, d_ur.data_ptr(), d_dp.data_ptr(), d_oob.data_ptr(),
+                                         C.addressof(ms)), "msorb_stereo_matches_batch")
+    return d_ur, d_dp, d_oob[:n_pairs].cpu().numpy(), ms.value

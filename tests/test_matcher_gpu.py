@@ -167,3 +167,50 @@ def test_window_top4_against_features_in_area(msorb_mod, oracle, stereo_frame):
         want_i = [cand[k] for k in order] + [-1] * (4 - len(order))
         want_d = [d[k] for k in order] + [256] * (4 - len(order))
         assert bi[i].tolist() == want_i and bd[i].tolist() == want_d
+
+
+def test_stereo_matches_batch_equals_per_frame_and_oracle(msorb_mod, oracle):
+    """msorb_stereo_matches_batch (device-resident, median rejection on the device) on a batch of stereo pairs: every
+    pair equals the per-frame msorb_stereo_matches on the same images, and pair 0 equals the oracle directly."""
+    import torch
+    cfg = synth.KITTI
+    n_pairs = 5
+    host = synth.stereo_batch(n_pairs, cfg["rows"], cfg["cols"], seed0=30)
+    host[6] = 0                                            # pair 3: empty left image -> no left keypoints
+    host[9] = 0                                            # pair 4: empty right image -> no candidates
+    mbf, mb = mc.KITTI_BF, mc.KITTI_BF / mc.KITTI_FX
+    ex = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7)
+    exl = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7)
+    exr = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7)
+    try:
+        d_img = torch.from_numpy(host).cuda()
+        counts, _, d_kps, d_desc = ex.extract_batch(d_img, (0, 0))
+        d_ur, d_dp, oob, ms = msorb_mod.stereo_matches_batch(ex, counts, d_kps, d_desc, mb, mbf)
+        assert ms > 0
+        kps = d_kps.cpu().numpy().view(oracle.KP_DTYPE)[..., 0]
+        desc = d_desc.cpu().numpy()
+        ur, dp = d_ur.cpu().numpy(), d_dp.cpu().numpy()
+        assert counts[6] == 0 and counts[9] == 0
+        for p in range(n_pairs):
+            nl, nr = int(counts[2 * p]), int(counts[2 * p + 1])
+            _, kl, dl = exl(host[2 * p])
+            _, kr, dr = exr(host[2 * p + 1])
+            assert np.array_equal(kl.view(np.uint8), kps[2 * p, :nl].view(np.uint8)) and len(kr) == nr
+            if nl == 0:
+                continue
+            wur, wdp, woob = msorb_mod.stereo_matches(exl, exr, kl, dl, kr, dr, mb, mbf)
+            assert np.array_equal(ur[p, :nl].view(np.uint32), wur.view(np.uint32)), p
+            assert np.array_equal(dp[p, :nl].view(np.uint32), wdp.view(np.uint32)), p
+            assert oob[p] == woob
+            assert np.all(ur[p, nl:] == -1)
+            if p == 0:
+                pl = [exl.pyramid_level(l) for l in range(8)]
+                pr = [exr.pyramid_level(l) for l in range(8)]
+                rur, rdp, _ = oracle.compute_stereo_matches(kl, dl, kr, dr, pl, pr, exl.GetScaleFactors(),
+                                                            exl.GetInverseScaleFactors(), mb, mbf)
+                assert (rur > 0).sum() > 500
+                assert np.array_equal(ur[0, :nl].view(np.uint32), rur.view(np.uint32))
+                assert np.array_equal(dp[0, :nl].view(np.uint32), rdp.view(np.uint32))
+        assert np.all(ur[4, :counts[8]] == -1)
+    finally:
+        ex.close(); exl.close(); exr.close()
