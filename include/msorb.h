@@ -160,6 +160,19 @@ int msorb_window_top4(msorb_frame* f, int n_queries, const float* x, const float
                       const int* min_level, const int* max_level, const uint8_t* skip_occupied, const uint8_t* query_desc,
                       const uint8_t* occupied, int* best_idx, int* best_dist);
 
+/* The search of ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight = false) (ORBmatcher.cc:1404-1597; LocalMapping::
+ * SearchInNeighbors, LocalMapping.cc:793-826): for every map point the best keypoint of the KeyFrame inside
+ * GetFeaturesInArea(u, v, radius) (KeyFrame.cc:796-845) at level predicted-1 .. predicted (:1513-1514) that passes the
+ * reprojection-error gate (:1517-1545: e2 * mvInvLevelSigma2[level] <= 7.8 with the stereo term when mvuRight >= 0,
+ * <= 5.99 otherwise), first strict minimum in scan order (:1555-1559).  `f` = the KeyFrame as a msorb_frame (mvKeysUn,
+ * mDescriptors, mvuRight, image bounds, scale factors).  Per point: valid (it survived :1436-1497), u, v (projection),
+ * ur (u - bf*invz), predicted_level (PredictScale), radius (th * mvScaleFactors[level]), mp_desc.  best_idx / best_dist
+ * (-1 / 256 = none).  What happens with a match (Replace / AddObservation, :1563-1588) mutates the map and stays with
+ * the caller, which also re-checks isBad() / IsInKeyFrame() at that time like the reference's loop does. */
+int msorb_fuse_search(msorb_frame* f, const float* inv_level_sigma2, int n_levels, int n, const uint8_t* valid,
+                      const float* u, const float* v, const float* ur, const int* predicted_level, const float* radius,
+                      const uint8_t* mp_desc, int* best_idx, int* best_dist);
+
 /* ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, th, bMono) (ORBmatcher.cc:1941-2057,
  * 2129-2152) from the projected coordinates on.  Per last-frame keypoint i: valid (map point present, not
  * outlier, positive depth, inside the image), u,v (projection), ur (u - mbf/z), last_octave, last_angle,

@@ -94,7 +94,17 @@ __global__ __launch_bounds__(256) void window_topk_kernel(FrameView F, const Win
                 }
                 if (!(fabsf(__fsub_rn(kp.x, Q.x)) < Q.r && fabsf(__fsub_rn(kp.y, Q.y)) < Q.r)) continue;
                 if ((Q.flags & kQSkipOccupied) && F.occupied[idx]) continue;       // ORBmatcher.cc:88-90
-                if (kp.u_right > 0 && fabsf(__fsub_rn(Q.ur, kp.u_right)) > Q.r) continue;  // :92-97
+                if (Q.flags & kQFuseGate) {  // reprojection-error gate of ORBmatcher::Fuse, ORBmatcher.cc:1520-1545
+                    const float ex = __fsub_rn(Q.x, kp.x), ey = __fsub_rn(Q.y, kp.y);
+                    float e2 = __fmaf_rn(ex, ex, __fmul_rn(ey, ey));
+                    double lim = 5.99;
+                    if (kp.u_right >= 0) {
+                        const float er = __fsub_rn(Q.ur, kp.u_right);
+                        e2 = __fmaf_rn(er, er, e2);
+                        lim = 7.8;
+                    }
+                    if ((double)__fmul_rn(e2, F.inv_sigma2[kp.octave]) > lim) continue;
+                } else if (kp.u_right > 0 && fabsf(__fsub_rn(Q.ur, kp.u_right)) > Q.r) continue;  // :92-97
                 const int d = hamming256(a, reinterpret_cast<const uint64_t*>(F.desc + (size_t)idx * 32));
                 topk_insert(((uint64_t)d << 40) | ((uint64_t)c << 20) | (uint64_t)(j - b), idx, k, id);
             }

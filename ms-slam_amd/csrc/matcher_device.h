@@ -23,8 +23,9 @@ struct FrameView {
     const uint8_t* occupied;  // F.mvpMapPoints[idx] && Observations() > 0
     float minX, minY, gridWInv, gridHInv;
     int n;
+    float inv_sigma2[MSORB_MAX_LEVELS];  // mvInvLevelSigma2, read by the kQFuseGate queries only
 };
-constexpr uint8_t kQValid = 1, kQSkipOccupied = 2;
+constexpr uint8_t kQValid = 1, kQSkipOccupied = 2, kQFuseGate = 4;
 struct WinQuery {
     float x, y, r, ur;
     int16_t min_level, max_level;

@@ -88,6 +88,7 @@ struct msorb_frame {
         FrameView v;
         v.kp = d_kp.p; v.desc = d_desc.p; v.cell_begin = d_cell_begin.p; v.cell_idx = d_cell_idx.p;
         v.occupied = d_occ.p; v.minX = minX; v.minY = minY; v.gridWInv = gridWInv; v.gridHInv = gridHInv; v.n = N;
+        for (int l = 0; l < MSORB_MAX_LEVELS; l++) v.inv_sigma2[l] = 0.0f;
         return v;
     }
 };
@@ -421,6 +422,45 @@ int msorb_window_top4(msorb_frame* f, int n_queries, const float* x, const float
     HIPCHK(hipStreamSynchronize(s));
     for (int i = 0; i < n_queries; i++)
         for (int k = 0; k < 4; k++) { best_idx[4 * i + k] = topk[i].idx[k]; best_dist[4 * i + k] = topk[i].dist[k]; }
+    return MSORB_OK;
+}
+
+int msorb_fuse_search(msorb_frame* f, const float* inv_level_sigma2, int n_levels, int n, const uint8_t* valid,
+                      const float* u, const float* v, const float* ur, const int* predicted_level, const float* radius,
+                      const uint8_t* mp_desc, int* best_idx, int* best_dist) {
+    if (!f || n < 0 || !inv_level_sigma2 || n_levels < 1 || n_levels > MSORB_MAX_LEVELS ||
+        (n > 0 && (!valid || !u || !v || !ur || !predicted_level || !radius || !mp_desc || !best_idx || !best_dist)))
+        return MSORB_E_INVALID;
+    if (n == 0) return MSORB_OK;
+    for (int i = 0; i < f->N; i++)
+        if (f->kps[i].octave < 0 || f->kps[i].octave >= n_levels) { set_last_error("fuse_search: keypoint octave outside inv_level_sigma2"); return MSORB_E_INVALID; }
+    HIPCHK(hipSetDevice(f->device));
+    std::vector<WinQuery> q(n);
+    for (int i = 0; i < n; i++) {
+        WinQuery w{};
+        if (valid[i]) {
+            w.x = u[i]; w.y = v[i]; w.r = radius[i]; w.ur = ur[i];
+            w.min_level = (int16_t)(predicted_level[i] - 1);  // :1513-1514
+            w.max_level = (int16_t)predicted_level[i];
+            w.flags = kQValid | kQFuseGate;
+        }
+        q[i] = w;
+    }
+    int rc;
+    if ((rc = f->d_q.ensure(n)) || (rc = f->d_qdesc.ensure((size_t)n * 32)) || (rc = f->d_topk.ensure(n)) ||
+        (rc = f->d_occ.ensure(std::max(f->N, 1))))
+        return rc;
+    hipStream_t s = f->stream;
+    std::vector<TopK> topk(n);
+    HIPCHK(hipMemcpyAsync(f->d_q.p, q.data(), (size_t)n * sizeof(WinQuery), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(f->d_qdesc.p, mp_desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
+    FrameView view = f->view();
+    for (int l = 0; l < n_levels; l++) view.inv_sigma2[l] = inv_level_sigma2[l];
+    launch_window_topk(view, f->d_q.p, f->d_qdesc.p, 0, n, f->d_topk.p, s);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(topk.data(), f->d_topk.p, (size_t)n * sizeof(TopK), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int i = 0; i < n; i++) { best_idx[i] = topk[i].idx[0]; best_dist[i] = topk[i].dist[0]; }
     return MSORB_OK;
 }
 

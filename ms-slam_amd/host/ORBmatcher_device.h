@@ -17,6 +17,10 @@
 //                                                        SearchByBoW(pKF1, pKF2, vpMatches12) (:872-1016,
 //                                                        SearchByBoWKeyFrames here); the batch form
 //                                                        serves Relocalization's candidate loop (Tracking.cc:3577-3600)
+//   ORB_SLAM3::msorb_host::Fuse(dev, pKF, vpMapPoints, th)
+//                                                        body of ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight = false)
+//                                                        (:1404-1597): geometry and the map mutation stay the reference's
+//                                                        code, the window search + error gates run on the device
 //   ORB_SLAM3::msorb_host::SearchForTriangulation(...)   body of ORBmatcher::SearchForTriangulation (:1168-1402, no second
 //                                                        camera); SearchForTriangulationBatch = all neighbours of one
 //                                                        LocalMapping::CreateNewMapPoints pass (LocalMapping.cc:430-492)
@@ -65,6 +69,25 @@ public:
         check(msorb_frame_set(h_, reinterpret_cast<const msorb_keypoint*>(F.mvKeysUn.data()), n, desc_.data(),
                               F.mvuRight.empty() ? nullptr : F.mvuRight.data(), F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY,
                               F.mvScaleFactors.data(), (int)F.mvScaleFactors.size()),
+              "msorb_frame_set");
+    }
+    // the same from a KeyFrame through its public accessors (the feature arrays are protected there).  KeyFrame keeps the
+    // image bounds as ints (KeyFrame.h:251-254) next to Frame's float grid constants: identical for rectified input.
+    template <class KeyFramePtr>
+    void UploadKeyFrame(const KeyFramePtr& pKF) {
+        const auto keys = pKF->GetAllKeyUn();
+        static_assert(sizeof(keys[0]) == sizeof(msorb_keypoint), "cv::KeyPoint must be the 28-byte layout");
+        const int n = (int)keys.size();
+        desc_.assign((size_t)n * 32, 0);
+        std::vector<float> ur(n);
+        for (int i = 0; i < n; i++) {
+            const auto d = pKF->GetDescriptor(i);
+            if (!d.empty()) std::memcpy(&desc_[(size_t)i * 32], d.template ptr<unsigned char>(0), 32);
+            ur[i] = pKF->GetuRight(i);
+        }
+        check(msorb_frame_set(h_, reinterpret_cast<const msorb_keypoint*>(keys.data()), n, desc_.data(), ur.data(),
+                              (float)pKF->mnMinX, (float)pKF->mnMaxX, (float)pKF->mnMinY, (float)pKF->mnMaxY,
+                              pKF->mvScaleFactors.data(), (int)pKF->mvScaleFactors.size()),
               "msorb_frame_set");
     }
     msorb_frame* get() const { return h_; }
@@ -361,6 +384,93 @@ int SearchByBoWKeyFrames(const KeyFramePtr& pKF1, const KeyFramePtr& pKF2, std::
     for (size_t i = 0; i < m12.size() && i < mps1.size(); i++)
         if (m12[i] >= 0) vpMatches12[i] = mps2[m12[i]];                    // :963
     return P.nmatches;
+}
+
+// ---- Fuse ---------------------------------------------------------------------------------------------------
+// ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight = false), :1404-1597.  `dev` holds pKF (dev.UploadKeyFrame(pKF)).
+// Pass 1 evaluates the reference's own geometric tests (:1448-1500) for every point that is alive now; the window
+// search with the level band and the reprojection-error gates (:1502-1561) runs on the device for all of them at once
+// (it reads only the KeyFrame's features, which the loop never changes); pass 2 is the reference's loop again with the
+// search replaced by a lookup: the isBad() / IsInKeyFrame() tests are repeated there because earlier iterations
+// mutate the map (Replace / AddObservation, :1563-1588) — points can only become bad or observed, never the reverse,
+// so the points searched in pass 1 are a superset of the points the loop reaches.
+struct FuseQueries {  // what :1448-1500 computes per map point
+    std::vector<uint8_t> valid, desc;
+    std::vector<float> u, v, ur, radius;
+    std::vector<int> level;
+};
+template <class KeyFramePtr, class MapPointPtr>
+void FuseGeometry(const KeyFramePtr& pKF, const std::vector<MapPointPtr>& vpMapPoints, const float th, FuseQueries& Q) {
+    const auto Tcw = pKF->GetPose();
+    const auto Ow = pKF->GetCameraCenter();
+    auto* pCamera = pKF->mpCamera;
+    const float& bf = pKF->mbf;
+    const int nMPs = (int)vpMapPoints.size();
+    Q.valid.assign(nMPs, 0); Q.desc.assign((size_t)nMPs * 32, 0);
+    Q.u.assign(nMPs, 0); Q.v.assign(nMPs, 0); Q.ur.assign(nMPs, 0); Q.radius.assign(nMPs, 0);
+    Q.level.assign(nMPs, 0);
+    for (int i = 0; i < nMPs; i++) {
+        const MapPointPtr& pMP = vpMapPoints[i];
+        if (!pMP) continue;
+        if (pMP->isBad()) continue;
+        else if (pMP->IsInKeyFrame(pKF)) continue;
+        const auto p3Dw = pMP->GetWorldPos();
+        const auto p3Dc = Tcw * p3Dw;
+        if (p3Dc(2) < 0.0f) continue;                                      // :1451
+        const float invz = 1 / p3Dc(2);
+        const auto uv = pCamera->project(p3Dc);
+        if (!pKF->IsInImage(uv(0), uv(1))) continue;                       // :1462
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        const auto PO = p3Dw - Ow;
+        const float dist3D = PO.norm();
+        if (dist3D < minDistance || dist3D > maxDistance) continue;        // :1476
+        const auto Pn = pMP->GetNormal();
+        if (PO.dot(Pn) < 0.5 * dist3D) continue;                           // :1484
+        const int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
+        Q.valid[i] = 1;
+        Q.u[i] = uv(0);
+        Q.v[i] = uv(1);
+        Q.ur[i] = uv(0) - bf * invz;                                       // :1468
+        Q.level[i] = nPredictedLevel;
+        Q.radius[i] = th * pKF->mvScaleFactors[nPredictedLevel];           // :1495
+        const auto dMP = pMP->GetDescriptor();
+        std::memcpy(&Q.desc[(size_t)i * 32], dMP.template ptr<unsigned char>(0), 32);
+    }
+}
+template <class FrameT, class KeyFramePtr, class MapPointPtr>
+int Fuse(DeviceFrame<FrameT>& dev, const KeyFramePtr& pKF, const std::vector<MapPointPtr>& vpMapPoints, const float th) {
+    FuseQueries Q;
+    FuseGeometry(pKF, vpMapPoints, th, Q);
+    const int nMPs = (int)vpMapPoints.size();
+    std::vector<int> bestIdx(nMPs, -1), bestDist(nMPs, 256);
+    const std::vector<uint8_t>& valid = Q.valid;
+    check(msorb_fuse_search(dev.get(), pKF->mvInvLevelSigma2.data(), (int)pKF->mvInvLevelSigma2.size(), nMPs, Q.valid.data(),
+                            Q.u.data(), Q.v.data(), Q.ur.data(), Q.level.data(), Q.radius.data(), Q.desc.data(),
+                            bestIdx.data(), bestDist.data()),
+          "msorb_fuse_search");
+    int nFused = 0;
+    for (int i = 0; i < nMPs; i++) {
+        MapPointPtr pMP = vpMapPoints[i];
+        if (!pMP) continue;
+        if (pMP->isBad()) continue;
+        else if (pMP->IsInKeyFrame(pKF)) continue;
+        if (!valid[i]) continue;
+        if (bestDist[i] <= 50 /* TH_LOW */) {                              // :1563-1590
+            auto pMPinKF = pKF->GetMapPoint(bestIdx[i]);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) {
+                    if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                    else pMPinKF->Replace(pMP);
+                }
+            } else {
+                pMP->AddObservation(pKF, bestIdx[i]);
+                pKF->AddMapPoint(pMP, bestIdx[i]);
+            }
+            nFused++;
+        }
+    }
+    return nFused;
 }
 
 // ---- SearchForTriangulation ---------------------------------------------------------------------------------

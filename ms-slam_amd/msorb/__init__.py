@@ -324,6 +324,18 @@ class Frame:
                                                         C.byref(nm)), "search_by_projection_frames")
         return nm.value
 
+    def FuseSearch(self, inv_level_sigma2, valid, u, v, ur, predicted_level, radius, mp_desc):
+        """msorb_fuse_search: the window search of ORBmatcher::Fuse on this KeyFrame.  -> (best_idx, best_dist)"""
+        arrs = [_c(valid, np.uint8), _c(u, np.float32), _c(v, np.float32), _c(ur, np.float32), _c(predicted_level, np.int32),
+                _c(radius, np.float32), _c(mp_desc, np.uint8)]
+        n = len(arrs[0])
+        inv = _c(inv_level_sigma2, np.float32)
+        bi, bd = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        self.L.msorb_fuse_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 9
+        _check(self.L.msorb_fuse_search(self.h, _np_ptr(inv), len(inv), n, *[_np_ptr(a) for a in arrs], _np_ptr(bi),
+                                        _np_ptr(bd)), "fuse_search")
+        return bi[:n], bd[:n]
+
 
 def hamming_top2(query_desc, train_desc, cand_begin, cand_idx, device=0):
     q, t = _c(query_desc, np.uint8), _c(train_desc, np.uint8)
@@ -684,3 +696,6 @@ def stereo_matches_batch(ex, counts, d_kps, d_desc, mb, mbf):
                                          max_left, mb, mbf, d_ur.data_ptr(), d_dp.data_ptr(), d_oob.data_ptr(),
                                          C.addressof(ms)), "msorb_stereo_matches_batch")
     return d_ur, d_dp, d_oob[:n_pairs].cpu().numpy(), ms.value
+
+
+EXPORTS = EXPORTS + ("msorb_fuse_search",)

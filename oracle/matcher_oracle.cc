@@ -259,6 +259,46 @@ int orc_search_by_projection_frames(void* fp, int NL, const uint8_t* valid, cons
     return nmatches;
 }
 
+// The search of ORBmatcher::Fuse(pKF, vpMapPoints, th, false), ORBmatcher.cc:1499-1561, for map points that passed
+// the geometric tests of :1436-1497.  fp = the KeyFrame's features (KeyFrame::GetFeaturesInArea, KeyFrame.cc:796-845,
+// is Frame::GetFeaturesInArea without level arguments).  Float convention as elsewhere in this file: the products of a
+// sum contracted like the reference's -O3 -march=native build (ex*ex+ey*ey+er*er -> fma(er,er,fma(ex,ex,ey*ey))).
+void orc_fuse_search(void* fp, const float* inv_level_sigma2, int n, const uint8_t* valid, const float* u, const float* v,
+                     const float* ur, const int* predicted_level, const float* radius, const uint8_t* mp_desc, int* best_idx,
+                     int* best_dist) {
+    const FrameSoA& K = *(const FrameSoA*)fp;
+    for (int i = 0; i < n; i++) {
+        best_idx[i] = -1;
+        best_dist[i] = 256;
+        if (!valid[i]) continue;
+        const int nPredictedLevel = predicted_level[i];
+        const std::vector<size_t> vIndices = K.features_in_area(u[i], v[i], radius[i], -1, -1);
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = mp_desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx = -1;
+        for (size_t k = 0; k < vIndices.size(); k++) {
+            const size_t idx = vIndices[k];
+            const KeyPoint& kp = K.kps[idx];
+            const int kpLevel = kp.octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            const float kpr = K.uRight[idx];
+            const float ex = u[i] - kp.x, ey = v[i] - kp.y;
+            if (kpr >= 0) {
+                const float er = ur[i] - kpr;
+                const float e2 = fmaf(er, er, fmaf(ex, ex, ey * ey));
+                if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+            } else {
+                const float e2 = fmaf(ex, ex, ey * ey);
+                if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+            }
+            const int dist = orc::descriptor_distance(dMP, &K.desc[idx * 32]);
+            if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+        }
+        best_idx[i] = bestIdx;
+        best_dist[i] = bestDist;
+    }
+}
+
 void orc_three_maxima(const int* sizes, int L, int* ind) {
     std::vector<std::vector<int>> h(L);
     for (int i = 0; i < L; i++) h[i].resize(sizes[i]);

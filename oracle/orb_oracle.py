@@ -223,6 +223,18 @@ class OracleFrame:
         return self.L.orc_search_by_projection_frames(self.h, NL, *[_ptr(a) for a in arrs], _ptr(cur_mp), th,
                                                       int(forward), int(backward), int(check_orientation))
 
+    def FuseSearch(self, inv_level_sigma2, valid, u, v, ur, predicted_level, radius, mp_desc):
+        """orc_fuse_search (ORBmatcher.cc:1499-1561) -> (best_idx, best_dist)"""
+        arrs = [_c(valid, np.uint8), _c(u, np.float32), _c(v, np.float32), _c(ur, np.float32), _c(predicted_level, np.int32),
+                _c(radius, np.float32), _c(mp_desc, np.uint8)]
+        n = len(arrs[0])
+        inv = _c(inv_level_sigma2, np.float32)
+        bi, bd = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        self.L.orc_fuse_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 9
+        self.L.orc_fuse_search.restype = None
+        self.L.orc_fuse_search(self.h, _ptr(inv), n, *[_ptr(a) for a in arrs], _ptr(bi), _ptr(bd))
+        return bi[:n], bd[:n]
+
 
 def three_maxima(sizes):
     s = _c(sizes, np.int32)

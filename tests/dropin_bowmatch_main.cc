@@ -2,8 +2,11 @@
 // MapPoint (member names of include/KeyFrame.h, include/Frame.h) and runs (a) the relocalisation candidate loop
 // (K KeyFrames against one Frame, Tracking.cc:3577-3600) and (b) SearchByBoW(pKF1, pKF2, ...) on the first two.
 // usage: dropin_bowmatch <in.bin> <out.bin>
+#include <cmath>
 #include <cstdio>
+#include <set>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <string>
@@ -27,7 +30,13 @@ public:
 namespace ORB_SLAM3 {
 // Eigen / Sophus stand-ins (float, straightforward loops): just enough surface for TriangulationGeometry
 struct Vec2 { float v[2]; float operator()(int i) const { return v[i]; } };
-struct Vec3 { float v[3]; float operator()(int i) const { return v[i]; } };
+struct Vec3 {
+    float v[3];
+    float operator()(int i) const { return v[i]; }
+    Vec3 operator-(const Vec3& o) const { return Vec3{{v[0] - o.v[0], v[1] - o.v[1], v[2] - o.v[2]}}; }
+    float dot(const Vec3& o) const { return v[0] * o.v[0] + v[1] * o.v[1] + v[2] * o.v[2]; }
+    float norm() const { return std::sqrt(dot(*this)); }
+};
 struct Mat3 {
     float m[9];
     float operator()(int r, int c) const { return m[3 * r + c]; }
@@ -64,11 +73,37 @@ struct Camera {  // GeometricCamera / Pinhole
     Vec2 project(const Vec3& p) { return Vec2{{fx * p.v[0] / p.v[2] + cx, fy * p.v[1] / p.v[2] + cy}}; }
     Mat3 toK_() { return Mat3{{fx, 0, cx, 0, fy, cy, 0, 0, 1}}; }
 };
-struct MapPoint {
+struct KeyFrame;
+struct MapPoint {  // the members ORBmatcher::Fuse touches; Replace / AddObservation keep a small model of the map and a log
     bool mbBad = false;
-    int id = -1;
+    int id = -1, nObs = 0;
+    std::set<const KeyFrame*> inKF;
+    Vec3 pos{}, normal{};
+    float mfMaxDistance = 0, mfMinDistance = 0;
+    unsigned char descriptor[32] = {0};
+    static std::vector<int>* log;  // (kind, a, b): 1 = a->Replace(b), 2 = a->AddObservation(kf, idx b)
     bool isBad() const { return mbBad; }
+    int Observations() const { return nObs; }
+    bool IsInKeyFrame(const std::shared_ptr<KeyFrame>& kf) const { return inKF.count(kf.get()) != 0; }
+    Vec3 GetWorldPos() const { return pos; }
+    Vec3 GetNormal() const { return normal; }
+    float GetMaxDistanceInvariance() const { return 1.2f * mfMaxDistance; }
+    float GetMinDistanceInvariance() const { return 0.8f * mfMinDistance; }
+    cv::Mat GetDescriptor() { return cv::Mat(1, 32, CV_8UC1, descriptor, 32); }
+    int PredictScale(const float& currentDist, const std::shared_ptr<KeyFrame>& kf);
+    void Replace(const std::shared_ptr<MapPoint>& p) {
+        if (log) { log->push_back(1); log->push_back(id); log->push_back(p->id); }
+        mbBad = true;
+        p->nObs += nObs;
+        for (auto k : inKF) p->inKF.insert(k);
+    }
+    void AddObservation(const std::shared_ptr<KeyFrame>& kf, int idx) {
+        if (log) { log->push_back(2); log->push_back(id); log->push_back(idx); }
+        inKF.insert(kf.get());
+        nObs += 2;
+    }
 };
+std::vector<int>* MapPoint::log = nullptr;
 struct Side {
     int N = 0;
     std::vector<unsigned char> bytes;
@@ -90,11 +125,24 @@ struct KeyFrame : protected Side {  // the feature arrays are protected in MS-SL
     DBoW2::FeatureVector GetFeatureVector() { return mFeatVec; }
     std::vector<cv::KeyPoint> GetAllKeyUn() { return mvKeys; }
     float GetuRight(size_t idx) { return mvuRight_[idx]; }
+    int mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0, mnScaleLevels = 8;
+    float mbf = 0, mfLogScaleFactor = 0;
+    std::vector<float> mvInvLevelSigma2;
+    bool IsInImage(const float& x, const float& y) const { return x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY; }
+    std::shared_ptr<MapPoint> GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }
+    void AddMapPoint(std::shared_ptr<MapPoint> p, const size_t& idx) { mvpMapPoints[idx] = p; }
     SE3 GetPose() { return Tcw; }
     SE3 GetPoseInverse() { return Tcw.inverse(); }
     Vec3 GetCameraCenter() { return Tcw.inverse().t; }
 };
 struct Frame : Side {};
+inline int MapPoint::PredictScale(const float& currentDist, const std::shared_ptr<KeyFrame>& kf) {  // MapPoint.cc:540-555
+    const float ratio = mfMaxDistance / currentDist;
+    int nScale = (int)std::ceil(std::log(ratio) / kf->mfLogScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= kf->mnScaleLevels) nScale = kf->mnScaleLevels - 1;
+    return nScale;
+}
 }  // namespace ORB_SLAM3
 
 template <class T>
@@ -191,10 +239,67 @@ static int triangulation_main(const char* in, const char* out) {
     return 0;
 }
 
+// ORBmatcher::Fuse through msorb_host::Fuse: one KeyFrame, M map points; dumps the geometry, nFused and the mutation log
+static int fuse_main(const char* in, const char* out) {
+    using namespace ORB_SLAM3;
+    FILE* f = fopen(in, "rb");
+    if (!f) return 3;
+    const auto hdr = rd<int>(f, 5);  // M, minX, maxX, minY, maxY
+    const int M = hdr[0];
+    const auto cam = rd<float>(f, 7);  // fx fy cx cy mbf logScale th
+    Camera camera{cam[0], cam[1], cam[2], cam[3]};
+    int dummy = 0;
+    auto kf = std::make_shared<KeyFrame>();
+    read_kf(f, *kf, dummy, true);
+    kf->mpCamera = &camera;
+    kf->mnMinX = hdr[1]; kf->mnMaxX = hdr[2]; kf->mnMinY = hdr[3]; kf->mnMaxY = hdr[4];
+    kf->mbf = cam[4]; kf->mfLogScaleFactor = cam[5];
+    kf->mnScaleLevels = (int)kf->mvScaleFactors.size();
+    for (float s2 : kf->mvLevelSigma2) kf->mvInvLevelSigma2.push_back(1.0f / s2);
+    const auto state = rd<unsigned char>(f, M);  // 0 null, 1 alive, 2 bad, 3 already in the KeyFrame
+    const auto pos = rd<float>(f, (size_t)3 * M), nrm = rd<float>(f, (size_t)3 * M), maxd = rd<float>(f, M), mind = rd<float>(f, M);
+    const auto obs = rd<int>(f, M);
+    const auto desc = rd<unsigned char>(f, (size_t)M * 32);
+    const auto kf_obs = rd<int>(f, kf->GetN());  // Observations() of the map point each KeyFrame feature holds (if it holds one)
+    fclose(f);
+    {
+        auto held = kf->GetMapPointMatches();
+        for (int j = 0; j < kf->GetN(); j++)
+            if (held[j]) { held[j]->id = 100000 + j; held[j]->nObs = kf_obs[j]; held[j]->inKF.insert(kf.get()); }
+    }
+    std::vector<std::shared_ptr<MapPoint>> pts(M);
+    for (int i = 0; i < M; i++) {
+        if (!state[i]) continue;
+        auto p = std::make_shared<MapPoint>();
+        p->id = i; p->nObs = obs[i]; p->mbBad = state[i] == 2;
+        if (state[i] == 3) p->inKF.insert(kf.get());
+        memcpy(p->pos.v, &pos[3 * i], 12); memcpy(p->normal.v, &nrm[3 * i], 12);
+        p->mfMaxDistance = maxd[i]; p->mfMinDistance = mind[i];
+        memcpy(p->descriptor, &desc[(size_t)i * 32], 32);
+        pts[i] = p;
+    }
+    msorb_host::FuseQueries Q;
+    msorb_host::FuseGeometry(kf, pts, cam[6], Q);
+    std::vector<int> log;
+    MapPoint::log = &log;
+    msorb_host::DeviceFrame<Frame> dev;
+    dev.UploadKeyFrame(kf);
+    const int nFused = msorb_host::Fuse(dev, kf, pts, cam[6]);
+    FILE* o = fopen(out, "wb");
+    const int nlog = (int)log.size();
+    fwrite(&nFused, 4, 1, o); fwrite(&nlog, 4, 1, o);
+    fwrite(log.data(), 4, nlog, o);
+    fwrite(Q.valid.data(), 1, M, o); fwrite(Q.u.data(), 4, M, o); fwrite(Q.v.data(), 4, M, o); fwrite(Q.ur.data(), 4, M, o);
+    fwrite(Q.level.data(), 4, M, o); fwrite(Q.radius.data(), 4, M, o);
+    fclose(o);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     using namespace ORB_SLAM3;
     if (argc < 3) return 2;
     if (argc > 3 && std::string(argv[3]) == "tri") return triangulation_main(argv[1], argv[2]);
+    if (argc > 3 && std::string(argv[3]) == "fuse") return fuse_main(argv[1], argv[2]);
     FILE* f = fopen(argv[1], "rb");
     if (!f) return 3;
     const auto hdr = rd<int>(f, 2);

@@ -468,3 +468,114 @@ def test_cpp_search_by_projection_frames_adapter_matches_oracle(tmp_path, oracle
     want = np.where(cur >= NL, -2, cur)                 # the C++ side reports -2 for a point it held before and kept
     assert nm == wn and nm > 100
     assert got.tolist() == want.tolist()
+
+
+def test_cpp_fuse_adapter_matches_oracle(tmp_path, oracle, msorb_mod):
+    """msorb_host::Fuse (ORBmatcher::Fuse, ORBmatcher.cc:1404-1597) over stand-in KeyFrame / MapPoint types: the device
+    search is checked against the oracle's orc_fuse_search on the geometry the C++ side computed, and the mutation log
+    (Replace / AddObservation order) against a replay of the reference's loop on the oracle's matches."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bow_match_cases as bmc
+    import matcher_cases as mc
+    exe = tmp_path / "dropin_bowmatch"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", f"-I{ROOT}/tests/cv_stub", f"-I{ROOT}/ms-slam_amd/host",
+                           f"-I{ROOT}/include", f"{ROOT}/tests/dropin_bowmatch_main.cc", f"-L{ROOT}/ms-slam_amd", "-lmsorb",
+                           f"-Wl,-rpath,{ROOT}/ms-slam_amd", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    cfg = synth.KITTI
+    ex = msorb_mod.ORBextractor(cfg["nfeatures"], cfg["scale"], cfg["nlevels"], cfg["ini_th"], cfg["min_th"])
+    try:
+        _, kps, desc = ex(synth.image(8, cfg["rows"], cfg["cols"]))
+        scale = np.asarray(ex.GetScaleFactors(), np.float32)
+    finally:
+        ex.close()
+    rng = np.random.default_rng(21)
+    N = len(kps)
+    fx, fy, cx, cy, mbf, th = 718.856, 718.856, 607.19, 185.21, 386.1448, 3.0
+    logs = float(np.log(np.float32(1.2)))
+    sigma2 = (scale * scale).astype(np.float32)
+    ur_kf = np.where(rng.random(N) < 0.6, kps["x"] - rng.uniform(1, 40, N), -1).astype(np.float32)
+    kf_has = (rng.random(N) < 0.4).astype(np.uint8)
+    kf_obs = rng.integers(1, 6, N).astype(np.int32)
+    R = np.eye(3, dtype=np.float32)
+    t = np.array([0.2, -0.1, 0.3], np.float32)
+    M = 2500
+    src = rng.integers(0, N, M)
+    z = rng.uniform(5, 40, M)
+    uu = kps["x"][src] + rng.normal(0, 1.0, M)
+    vv = kps["y"][src] + rng.normal(0, 1.0, M)
+    Xc = np.stack([(uu - cx) / fx * z, (vv - cy) / fy * z, z], 1)
+    Xc[rng.random(M) < 0.03, 2] *= -1
+    Xw = (Xc - t).astype(np.float32)                          # R = I
+    Ow = (-t).astype(np.float32)
+    PO = Xw - Ow
+    dist = np.linalg.norm(PO, axis=1)
+    normal = (PO / dist[:, None] + rng.normal(0, 0.4, (M, 3))).astype(np.float32)
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    lvl = kps["octave"][src]
+    maxd = (dist * scale[lvl] * rng.uniform(0.9, 1.1, M)).astype(np.float32)
+    mind = (maxd / scale[7] * rng.uniform(0.5, 1.5, M)).astype(np.float32)
+    state = rng.choice([0, 1, 2, 3], M, p=[0.03, 0.87, 0.05, 0.05]).astype(np.uint8)
+    obs = rng.integers(0, 6, M).astype(np.int32)
+    mdesc = mc.flip_bits(rng, desc[src], 30)
+    node = np.zeros(N, np.int32)
+    with open(tmp_path / "fuse.bin", "wb") as f:
+        f.write(struct.pack("<5i", M, 0, cfg["cols"], 0, cfg["rows"]))
+        f.write(struct.pack("<7f", fx, fy, cx, cy, mbf, logs, th))
+        f.write(struct.pack("<i", N))
+        for arr in (desc, kps, node, kf_has, ur_kf, R.reshape(9), t):
+            f.write(np.ascontiguousarray(arr).tobytes())
+        f.write(struct.pack("<i", 8))
+        f.write(scale.tobytes())
+        f.write(sigma2.tobytes())
+        for arr in (state, Xw, normal, maxd, mind, obs, mdesc, kf_obs):
+            f.write(np.ascontiguousarray(arr).tobytes())
+    subprocess.check_call([str(exe), str(tmp_path / "fuse.bin"), str(tmp_path / "fuse_out.bin"), "fuse"])
+    blob = (tmp_path / "fuse_out.bin").read_bytes()
+    n_fused, nlog = struct.unpack_from("<ii", blob, 0)
+    log = np.frombuffer(blob, np.int32, nlog, 8).reshape(-1, 3)
+    pos = 8 + 4 * nlog
+    valid = np.frombuffer(blob, np.uint8, M, pos)
+    u, v, ur = (np.frombuffer(blob, np.float32, M, pos + M + 4 * M * k) for k in range(3))
+    level = np.frombuffer(blob, np.int32, M, pos + M + 12 * M)
+    radius = np.frombuffer(blob, np.float32, M, pos + M + 16 * M)
+    assert 1000 < valid.sum() < (state == 1).sum() and np.all(valid[state != 1] == 0)
+    # the geometry the C++ side computed, against float64
+    ok = valid > 0
+    assert np.allclose(u[ok], fx * Xc[ok, 0] / Xc[ok, 2] + cx, atol=2e-2) and np.allclose(v[ok], fy * Xc[ok, 1] / Xc[ok, 2] + cy, atol=2e-2)
+    assert np.allclose(radius[ok], th * scale[level[ok]])
+    inv_sigma2 = (np.float32(1.0) / sigma2).astype(np.float32)
+    rf = oracle.OracleFrame(kps, desc, ur_kf, (0.0, float(cfg["cols"]), 0.0, float(cfg["rows"])), scale)
+    bi, bd = rf.FuseSearch(inv_sigma2, valid, u, v, ur, level, radius, mdesc)
+    # replay of :1430-1592 with the stand-in map model (Replace: the replaced point turns bad and hands over its
+    # observations; AddObservation: +2 observations, the point is now in the KeyFrame)
+    pts = {i: dict(obs=int(obs[i]), bad=state[i] == 2, inkf=state[i] == 3) for i in range(M) if state[i]}
+    kf_mp = {}
+    for j in range(N):
+        if kf_has[j]:
+            pts[100000 + j] = dict(obs=int(kf_obs[j]), bad=False, inkf=True)
+            kf_mp[j] = 100000 + j
+    want_log, want_fused = [], 0
+    for i in range(M):
+        if not state[i] or pts[i]["bad"] or pts[i]["inkf"] or not valid[i]:
+            continue
+        if bd[i] <= 50:
+            j = int(bi[i])
+            if j in kf_mp:
+                x = kf_mp[j]
+                if not pts[x]["bad"]:
+                    a, b = (i, x) if pts[x]["obs"] > pts[i]["obs"] else (x, i)       # a->Replace(b)
+                    want_log.append((1, a, b))
+                    pts[a]["bad"] = True
+                    pts[b]["obs"] += pts[a]["obs"]
+                    pts[b]["inkf"] = pts[b]["inkf"] or pts[a]["inkf"]
+            else:
+                want_log.append((2, i, j))
+                pts[i]["inkf"] = True
+                pts[i]["obs"] += 2
+                kf_mp[j] = i
+            want_fused += 1
+    assert n_fused == want_fused and n_fused > 300
+    assert log.tolist() == [list(e) for e in want_log]
+    kinds = log[:, 0]
+    assert (kinds == 1).sum() > 50 and (kinds == 2).sum() > 50

@@ -214,3 +214,40 @@ def test_stereo_matches_batch_equals_per_frame_and_oracle(msorb_mod, oracle):
         assert np.all(ur[4, :counts[8]] == -1)
     finally:
         ex.close(); exl.close(); exr.close()
+
+
+@pytest.mark.parametrize("seed,th", [(0, 3.0), (1, 4.0), (2, 2.5)])
+def test_fuse_search_matches_oracle(msorb_mod, oracle, stereo_frame, seed, th):
+    """msorb_fuse_search (window search + reprojection-error gate of ORBmatcher::Fuse, ORBmatcher.cc:1499-1561) vs oracle."""
+    s = stereo_frame
+    rng = np.random.Generator(np.random.PCG64(seed))
+    N = len(s["kl"])
+    ur_kf = np.where(rng.random(N) < 0.6, s["kl"]["x"] - rng.uniform(1, 40, N), -1).astype(np.float32)
+    if seed == 2:
+        ur_kf[rng.random(N) < 0.1] = 0.0                   # mvuRight == 0 is stereo for Fuse (>= 0) but not for the trackers (> 0)
+    F, R = _frames(msorb_mod, oracle, s, ur_kf)
+    scale = np.asarray(s["scale"], np.float32)
+    inv_sigma2 = (np.float32(1.0) / (scale * scale)).astype(np.float32)
+    M = 3000
+    src = rng.integers(0, N, M)
+    sig = rng.choice([0.3, 1.0, 3.0], M)
+    u = (s["kl"]["x"][src] + rng.normal(0, sig)).astype(np.float32)
+    v = (s["kl"]["y"][src] + rng.normal(0, sig)).astype(np.float32)
+    ur = np.where(ur_kf[src] >= 0, ur_kf[src] + rng.normal(0, sig), u - 20).astype(np.float32)
+    level = np.clip(s["kl"]["octave"][src] + rng.integers(0, 2, M), 0, 7).astype(np.int32)
+    radius = (np.float32(th) * scale[level]).astype(np.float32)
+    valid = (rng.random(M) < 0.9).astype(np.uint8)
+    u[rng.random(M) < 0.02] = -50.0                        # window entirely outside the grid
+    desc = mc.flip_bits(rng, s["dl"][src], 40)
+    try:
+        bi, bd = F.FuseSearch(inv_sigma2, valid, u, v, ur, level, radius, desc)
+        wi, wd = R.FuseSearch(inv_sigma2, valid, u, v, ur, level, radius, desc)
+        assert np.array_equal(bi, wi) and np.array_equal(bd, wd)
+        hit = wi >= 0
+        assert 300 < hit.sum() < valid.sum()               # the gate and the level band reject a good share
+        assert np.all(bi[valid == 0] == -1)
+        # the gate matters: with mvInvLevelSigma2 = 0 it never rejects and more points find a keypoint
+        gi, _ = F.FuseSearch(np.zeros(8, np.float32), valid, u, v, ur, level, radius, desc)
+        assert (gi >= 0).sum() > hit.sum() + 50
+    finally:
+        F.close()
