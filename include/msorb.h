@@ -164,8 +164,8 @@ int msorb_window_top4(msorb_frame* f, int n_queries, const float* x, const float
  * SearchInNeighbors, LocalMapping.cc:793-826): for every map point the best keypoint of the KeyFrame inside
  * GetFeaturesInArea(u, v, radius) (KeyFrame.cc:796-845) at level predicted-1 .. predicted (:1513-1514) that passes the
  * reprojection-error gate (:1517-1545: e2 * mvInvLevelSigma2[level] <= 7.8 with the stereo term when mvuRight >= 0,
- * <= 5.99 otherwise), first strict minimum in scan order (:1555-1559).  `f` = the KeyFrame as a msorb_frame (mvKeysUn,
- * mDescriptors, mvuRight, image bounds, scale factors).  Per point: valid (it survived :1436-1497), u, v (projection),
+ * <= 5.99 otherwise), first strict minimum in scan order (:1555-1559).  `f` = the KeyFrame loaded with msorb_frame_set: mvKeysUn,
+ * mDescriptors, mvuRight, image bounds, scale factors.  Per point: valid (it survived :1436-1497), u, v (projection),
  * ur (u - bf*invz), predicted_level (PredictScale), radius (th * mvScaleFactors[level]), mp_desc.  best_idx / best_dist
  * (-1 / 256 = none).  What happens with a match (Replace / AddObservation, :1563-1588) mutates the map and stays with
  * the caller, which also re-checks isBad() / IsInKeyFrame() at that time like the reference's loop does. */
