@@ -183,6 +183,17 @@ int msorb_search_by_projection_frames(msorb_frame* cur, int n_last, const uint8_
                                       const int* obs, int* cur_mp, float th, int forward, int backward,
                                       int check_orientation, int* nmatches);
 
+/* ORBmatcher::SearchByProjection(Frame& Current, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:2154-2275,
+ * Tracking::Relocalization :3672, :3695) from the projected coordinates on.  Per map point of the KeyFrame that the
+ * loop reaches (not bad, not in sAlreadyFound, inside the image, distance inside the scale pyramid, :2173-2196):
+ * valid, u, v, predicted_level (PredictScale, :2198), kf_angle (pKF->GetKeyUn(i).angle, :2237), mp_desc, mp_id (stored
+ * into cur_mp).  A keypoint of the frame that holds ANY map point is never taken (:2214-2215); accept bestDist <=
+ * orb_dist (:2229); cur_mp[n] in/out (-1 = none). */
+int msorb_search_by_projection_kf(msorb_frame* cur, int n, const uint8_t* valid, const float* u, const float* v,
+                                  const int* predicted_level, const float* kf_angle, const uint8_t* mp_desc,
+                                  const int* mp_id, int* cur_mp, float th, int orb_dist, int check_orientation,
+                                  int* nmatches);
+
 /* Best / second-best Hamming match of each query over an explicit candidate list (CSR: candidates of
  * query i are cand_idx[cand_begin[i] .. cand_begin[i+1])), scanned in list order with strict '<' — the
  * inner loop of SearchByBoW / SearchForTriangulation / Fuse (e.g. ORBmatcher.cc:288-330).  Host arrays. */

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void window_topk_kernel(FrameView F, const Win
                         lim = 7.8;
                     }
                     if ((double)__fmul_rn(e2, F.inv_sigma2[kp.octave]) > lim) continue;
-                } else if (kp.u_right > 0 && fabsf(__fsub_rn(Q.ur, kp.u_right)) > Q.r) continue;  // :92-97
+                } else if (!(Q.flags & kQNoUr) && kp.u_right > 0 && fabsf(__fsub_rn(Q.ur, kp.u_right)) > Q.r) continue;  // :92-97
                 const int d = hamming256(a, reinterpret_cast<const uint64_t*>(F.desc + (size_t)idx * 32));
                 topk_insert(((uint64_t)d << 40) | ((uint64_t)c << 20) | (uint64_t)(j - b), idx, k, id);
             }

@@ -25,7 +25,7 @@ struct FrameView {
     int n;
     float inv_sigma2[MSORB_MAX_LEVELS];  // mvInvLevelSigma2, read by the kQFuseGate queries only
 };
-constexpr uint8_t kQValid = 1, kQSkipOccupied = 2, kQFuseGate = 4;
+constexpr uint8_t kQValid = 1, kQSkipOccupied = 2, kQFuseGate = 4, kQNoUr = 8;
 struct WinQuery {
     float x, y, r, ur;
     int16_t min_level, max_level;

@@ -326,57 +326,57 @@ int msorb_search_by_projection_mps(msorb_frame* f, int M, const uint8_t* track_i
     return rc;
 }
 
-int msorb_search_by_projection_frames(msorb_frame* f, int NL, const uint8_t* valid, const float* u, const float* v,
-                                      const float* ur, const int* last_octave, const float* last_angle,
-                                      const uint8_t* mp_desc, const int* last_mp, const int* obs, int* cur_mp, float th,
-                                      int forward, int backward, int check_orientation, int* nmatches) {
-    if (!f || NL < 0 || !nmatches || (NL > 0 && (!valid || !u || !v || !ur || !last_octave || !last_angle || !mp_desc ||
-                                                 !last_mp || !obs)) || (f->N > 0 && !cur_mp))
-        return MSORB_E_INVALID;
-    HIPCHK(hipSetDevice(f->device));
+namespace {
+// Shared body of the two frame-against-projected-points searches: SearchByProjection(Current, Last, th, bMono)
+// (:1941-2152) and SearchByProjection(Current, pKF, sAlreadyFound, th, ORBdist) (:2154-2275).  ur == nullptr: no
+// mvuRight test (the KeyFrame form has none); obs == nullptr: a keypoint holding any map point is taken (:2214-2215)
+// instead of "a map point with observations" (:2011-2013).
+int search_projected(msorb_frame* f, int NL, const uint8_t* valid, const float* u, const float* v, const float* ur,
+                     const int* octave, const float* angle, const uint8_t* mp_desc, const int* ids, const int* obs,
+                     int* cur_mp, float th, int forward, int backward, int check_orientation, int accept_dist, int* nmatches) {
     *nmatches = 0;
     std::vector<WinQuery> q(NL);
     for (int i = 0; i < NL; i++) {
         WinQuery w{};
         if (valid[i]) {
-            const int oct = last_octave[i];
+            const int oct = octave[i];
             if (oct < 0 || oct >= f->nlevels) { set_last_error("octave out of range"); return MSORB_E_INVALID; }
             w.x = u[i]; w.y = v[i];
-            w.r = th * f->scale[oct];  // ORBmatcher.cc:1989
-            w.ur = ur[i];
+            w.r = th * f->scale[oct];  // ORBmatcher.cc:1989 / :2202
+            w.ur = ur ? ur[i] : 0.0f;
             if (forward) { w.min_level = (int16_t)oct; w.max_level = -1; }
             else if (backward) { w.min_level = 0; w.max_level = (int16_t)oct; }
             else { w.min_level = (int16_t)(oct - 1); w.max_level = (int16_t)(oct + 1); }
-            w.flags = kQValid | kQSkipOccupied;
+            w.flags = kQValid | kQSkipOccupied | (ur ? 0 : kQNoUr);
         }
         q[i] = w;
     }
     std::vector<uint8_t> occ(f->N);
-    for (int i = 0; i < f->N; i++) occ[i] = cur_mp[i] >= 0 && obs[cur_mp[i]] > 0;
+    for (int i = 0; i < f->N; i++) occ[i] = cur_mp[i] >= 0 && (!obs || obs[cur_mp[i]] > 0);
     int nm = 0;
     std::vector<int> rotHist[kHistoLength];
     const float factor = 1.0f / kHistoLength;
     auto accept = [&](int qi, const int* idx, const int* dist, int n, int* new_occ) -> int {
         if (n == 0) return -1;
-        if (dist[0] <= kThHigh) {  // ORBmatcher.cc:2035-2057
+        if (dist[0] <= accept_dist) {  // ORBmatcher.cc:2035-2057 / :2229-2247
             const int bestIdx2 = idx[0];
-            cur_mp[bestIdx2] = last_mp[qi];
+            cur_mp[bestIdx2] = ids[qi];
             nm++;
             if (check_orientation) {
-                float rot = last_angle[qi] - f->kps[bestIdx2].angle;
+                float rot = angle[qi] - f->kps[bestIdx2].angle;
                 if (rot < 0.0) rot += 360.0f;
                 int bin = (int)std::round(rot * factor);
                 if (bin == kHistoLength) bin = 0;
                 if (bin >= 0 && bin < kHistoLength) rotHist[bin].push_back(bestIdx2);
             }
-            *new_occ = obs[last_mp[qi]] > 0;
+            *new_occ = !obs || obs[ids[qi]] > 0;
             return bestIdx2;
         }
         return -1;
     };
     const int rc = run_window_search(f, q, mp_desc, occ, 1, accept);
     if (rc) return rc;
-    if (check_orientation) {  // ORBmatcher.cc:2129-2149
+    if (check_orientation) {  // ORBmatcher.cc:2129-2149 / :2253-2272
         int sizes[kHistoLength], ind[3];
         for (int i = 0; i < kHistoLength; i++) sizes[i] = (int)rotHist[i].size();
         msorb_three_maxima(sizes, kHistoLength, ind);
@@ -386,6 +386,30 @@ int msorb_search_by_projection_frames(msorb_frame* f, int NL, const uint8_t* val
     }
     *nmatches = nm;
     return MSORB_OK;
+}
+}  // namespace
+
+int msorb_search_by_projection_frames(msorb_frame* f, int NL, const uint8_t* valid, const float* u, const float* v,
+                                      const float* ur, const int* last_octave, const float* last_angle,
+                                      const uint8_t* mp_desc, const int* last_mp, const int* obs, int* cur_mp, float th,
+                                      int forward, int backward, int check_orientation, int* nmatches) {
+    if (!f || NL < 0 || !nmatches || (NL > 0 && (!valid || !u || !v || !ur || !last_octave || !last_angle || !mp_desc ||
+                                                 !last_mp || !obs)) || (f->N > 0 && !cur_mp))
+        return MSORB_E_INVALID;
+    HIPCHK(hipSetDevice(f->device));
+    return search_projected(f, NL, valid, u, v, ur, last_octave, last_angle, mp_desc, last_mp, obs, cur_mp, th, forward,
+                            backward, check_orientation, kThHigh, nmatches);
+}
+
+int msorb_search_by_projection_kf(msorb_frame* f, int n, const uint8_t* valid, const float* u, const float* v,
+                                  const int* predicted_level, const float* kf_angle, const uint8_t* mp_desc, const int* mp_id,
+                                  int* cur_mp, float th, int orb_dist, int check_orientation, int* nmatches) {
+    if (!f || n < 0 || !nmatches || (n > 0 && (!valid || !u || !v || !predicted_level || !kf_angle || !mp_desc || !mp_id)) ||
+        (f->N > 0 && !cur_mp))
+        return MSORB_E_INVALID;
+    HIPCHK(hipSetDevice(f->device));
+    return search_projected(f, n, valid, u, v, nullptr, predicted_level, kf_angle, mp_desc, mp_id, nullptr, cur_mp, th, 0, 0,
+                            check_orientation, orb_dist, nmatches);
 }
 
 int msorb_window_top4(msorb_frame* f, int n_queries, const float* x, const float* y, const float* r, const float* ur,
