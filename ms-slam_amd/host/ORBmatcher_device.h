@@ -9,6 +9,8 @@
 //   ORB_SLAM3::msorb_host::SearchByProjection(dev, Cur, Last, th, bMono, ...)
 //                                                        body of ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)
 //                                                        (src/ORBmatcher.cc:1941-2152, Nleft == -1; TrackWithMotionModel)
+//   ORB_SLAM3::msorb_host::SearchByProjection(dev, Cur, pKF, sAlreadyFound, th, ORBdist, ...)
+//                                                        body of the relocalisation form (src/ORBmatcher.cc:2154-2275)
 //   ORB_SLAM3::msorb_host::SearchLocalPointsPrepass(...) the isInFrustum loop of Tracking::SearchLocalPoints
 //                                                        (src/Tracking.cc:3343-3361, src/Frame.cc:512-571)
 //   ORB_SLAM3::msorb_host::ComputeStereoMatches(...)     body of Frame::ComputeStereoMatches (src/Frame.cc:743-913)
@@ -384,6 +386,70 @@ int SearchByBoWKeyFrames(const KeyFramePtr& pKF1, const KeyFramePtr& pKF2, std::
     for (size_t i = 0; i < m12.size() && i < mps1.size(); i++)
         if (m12[i] >= 0) vpMatches12[i] = mps2[m12[i]];                    // :963
     return P.nmatches;
+}
+
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, shared_ptr<KeyFrame> pKF, const set<shared_ptr<MapPoint>>
+// &sAlreadyFound, const float th, const int ORBdist) (:2154-2275; Tracking::Relocalization).  Projection, distance test
+// and PredictScale are the reference's code; the search runs behind msorb_search_by_projection_kf.  `dev` holds
+// CurrentFrame.
+struct KeyFrameProjection {
+    std::vector<uint8_t> valid, desc;
+    std::vector<float> u, v, angle;
+    std::vector<int> level;
+};
+template <class FrameT, class KeyFramePtr, class MapPointSet>
+void ProjectKeyFramePoints(FrameT& CurrentFrame, const KeyFramePtr& pKF, const MapPointSet& sAlreadyFound, KeyFrameProjection& P) {
+    const auto Tcw = CurrentFrame.GetPose();
+    const auto Ow = Tcw.inverse().translation();
+    const auto vpMPs = pKF->GetMapPointMatches();
+    const int n = (int)vpMPs.size();
+    P.valid.assign(n, 0); P.desc.assign((size_t)n * 32, 0);
+    P.u.assign(n, 0); P.v.assign(n, 0); P.angle.assign(n, 0); P.level.assign(n, 0);
+    for (int i = 0; i < n; i++) {
+        const auto& pMP = vpMPs[i];
+        if (!pMP) continue;
+        if (pMP->isBad() || sAlreadyFound.count(pMP)) continue;            // :2175
+        const auto x3Dw = pMP->GetWorldPos();
+        const auto x3Dc = Tcw * x3Dw;
+        const auto uv = CurrentFrame.mpCamera->project(x3Dc);
+        if (uv(0) < CurrentFrame.mnMinX || uv(0) > CurrentFrame.mnMaxX) continue;
+        if (uv(1) < CurrentFrame.mnMinY || uv(1) > CurrentFrame.mnMaxY) continue;
+        const auto PO = x3Dw - Ow;
+        const float dist3D = PO.norm();
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        if (dist3D < minDistance || dist3D > maxDistance) continue;        // :2195
+        P.valid[i] = 1;
+        P.u[i] = uv(0);
+        P.v[i] = uv(1);
+        P.level[i] = pMP->PredictScale(dist3D, &CurrentFrame);             // :2198
+        P.angle[i] = pKF->GetKeyUn(i).angle;                               // :2237
+        const auto d = pMP->GetDescriptor();
+        std::memcpy(&P.desc[(size_t)i * 32], d.template ptr<unsigned char>(0), 32);
+    }
+}
+template <class FrameT, class KeyFramePtr, class MapPointSet>
+int SearchByProjection(DeviceFrame<FrameT>& dev, FrameT& CurrentFrame, const KeyFramePtr& pKF, const MapPointSet& sAlreadyFound,
+                       const float th, const int ORBdist, const bool mbCheckOrientation) {
+    KeyFrameProjection P;
+    ProjectKeyFramePoints(CurrentFrame, pKF, sAlreadyFound, P);
+    const auto vpMPs = pKF->GetMapPointMatches();
+    const int n = (int)vpMPs.size(), N = CurrentFrame.N;
+    std::vector<int> ids(n), curMp(N, -1);
+    for (int i = 0; i < n; i++) ids[i] = i;
+    for (int j = 0; j < N; j++)
+        if (CurrentFrame.mvpMapPoints[j]) curMp[j] = n + j;               // any held keypoint is taken, :2214-2215
+    const std::vector<int> before(curMp);
+    int nmatches = 0;
+    check(msorb_search_by_projection_kf(dev.get(), n, P.valid.data(), P.u.data(), P.v.data(), P.level.data(), P.angle.data(),
+                                        P.desc.data(), ids.data(), curMp.data(), th, ORBdist, mbCheckOrientation, &nmatches),
+          "msorb_search_by_projection_kf");
+    for (int j = 0; j < N; j++) {
+        if (curMp[j] == before[j]) continue;
+        if (curMp[j] < 0) CurrentFrame.mvpMapPoints[j] = nullptr;         // :2266
+        else CurrentFrame.mvpMapPoints[j] = vpMPs[curMp[j]];              // :2231
+    }
+    return nmatches;
 }
 
 // ---- Fuse ---------------------------------------------------------------------------------------------------

@@ -324,6 +324,20 @@ class Frame:
                                                         C.byref(nm)), "search_by_projection_frames")
         return nm.value
 
+    def SearchByProjection_kf(self, pts, cur_mp, th, orb_dist, check_orientation=True):
+        """msorb_search_by_projection_kf (relocalisation form, ORBmatcher.cc:2154-2275); pts: dict valid,u,v,level,angle,
+        desc,mp; cur_mp updated in place.  Returns nmatches."""
+        arrs = [_c(pts["valid"], np.uint8), _c(pts["u"], np.float32), _c(pts["v"], np.float32), _c(pts["level"], np.int32),
+                _c(pts["angle"], np.float32), _c(pts["desc"], np.uint8), _c(pts["mp"], np.int32)]
+        assert cur_mp.dtype == np.int32 and cur_mp.flags.c_contiguous
+        nm = C.c_int()
+        self.L.msorb_search_by_projection_kf.argtypes = ([C.c_void_p, C.c_int] + [C.c_void_p] * 8 +
+                                                         [C.c_float, C.c_int, C.c_int, C.c_void_p])
+        _check(self.L.msorb_search_by_projection_kf(self.h, len(arrs[0]), *[_np_ptr(a) for a in arrs], _np_ptr(cur_mp), th,
+                                                    int(orb_dist), int(check_orientation), C.byref(nm)),
+               "search_by_projection_kf")
+        return nm.value
+
     def FuseSearch(self, inv_level_sigma2, valid, u, v, ur, predicted_level, radius, mp_desc):
         """msorb_fuse_search: the window search of ORBmatcher::Fuse on this KeyFrame.  -> (best_idx, best_dist)"""
         arrs = [_c(valid, np.uint8), _c(u, np.float32), _c(v, np.float32), _c(ur, np.float32), _c(predicted_level, np.int32),
@@ -698,4 +712,4 @@ def stereo_matches_batch(ex, counts, d_kps, d_desc, mb, mbf):
     return d_ur, d_dp, d_oob[:n_pairs].cpu().numpy(), ms.value
 
 
-EXPORTS = EXPORTS + ("msorb_fuse_search",)
+EXPORTS = EXPORTS + ("msorb_fuse_search", "msorb_search_by_projection_kf")

@@ -299,6 +299,52 @@ void orc_fuse_search(void* fp, const float* inv_level_sigma2, int n, const uint8
     }
 }
 
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, pKF, sAlreadyFound, th, ORBdist), ORBmatcher.cc:2154-2275, from the
+// projected coordinates on.  One entry per KeyFrame map point that passed :2173-2196 (valid), with its projection u, v,
+// predicted level (:2198), the KeyFrame keypoint's angle (:2237), descriptor and id.  cur_mp[N] in/out.
+int orc_search_by_projection_kf(void* fp, int n, const uint8_t* valid, const float* u, const float* v,
+                                const int* predicted_level, const float* kf_angle, const uint8_t* mp_desc, const int* mp_id,
+                                int* cur_mp, float th, int ORBdist, int check_orientation) {
+    FrameSoA& C = *(FrameSoA*)fp;
+    int nmatches = 0;
+    std::vector<int> rotHist[orc::HISTO_LENGTH];
+    const float factor = 1.0f / orc::HISTO_LENGTH;
+    for (int i = 0; i < n; i++) {
+        if (!valid[i]) continue;
+        const int nPredictedLevel = predicted_level[i];
+        const float radius = th * C.scaleFactors[nPredictedLevel];
+        const std::vector<size_t> vIndices2 = C.features_in_area(u[i], v[i], radius, nPredictedLevel - 1, nPredictedLevel + 1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* dMP = mp_desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx2 = -1;
+        for (size_t k = 0; k < vIndices2.size(); k++) {
+            const size_t i2 = vIndices2[k];
+            if (cur_mp[i2] >= 0) continue;  // :2214-2215
+            const int dist = orc::descriptor_distance(dMP, &C.desc[i2 * 32]);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+        }
+        if (bestDist <= ORBdist) {
+            cur_mp[bestIdx2] = mp_id[i];
+            nmatches++;
+            if (check_orientation) {
+                float rot = kf_angle[i] - C.kps[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == orc::HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc::three_maxima(rotHist, orc::HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < orc::HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0; j < rotHist[i].size(); j++) { cur_mp[rotHist[i][j]] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
 void orc_three_maxima(const int* sizes, int L, int* ind) {
     std::vector<std::vector<int>> h(L);
     for (int i = 0; i < L; i++) h[i].resize(sizes[i]);

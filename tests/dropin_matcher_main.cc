@@ -2,7 +2,9 @@
 // member names as include/Frame.h / include/MapPoint.h; tests/cv_stub for cv::Mat / cv::KeyPoint) and runs the
 // SearchLocalPoints matcher call the way Tracking.cc:3388 does.  Input: one binary blob written by the pytest;
 // output: nmatches + the map-point index every keypoint holds afterwards.
+#include <cmath>
 #include <cstdio>
+#include <set>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -15,7 +17,12 @@
 
 namespace ORB_SLAM3 {
 struct Vec2 { float v[2]; float operator()(int i) const { return v[i]; } };                       // Eigen::Vector2f stand-in
-struct Vec3 { float v[3]; float operator()(int i) const { return v[i]; } };                       // Eigen::Vector3f stand-in
+struct Vec3 {                                                                                     // Eigen::Vector3f stand-in
+    float v[3];
+    float operator()(int i) const { return v[i]; }
+    Vec3 operator-(const Vec3& o) const { return Vec3{{v[0] - o.v[0], v[1] - o.v[1], v[2] - o.v[2]}}; }
+    float norm() const { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+};
 struct Mat3 {                                                                                     // Eigen::Matrix3f stand-in
     float m[9];
     float operator()(int r, int c) const { return m[3 * r + c]; }
@@ -56,6 +63,16 @@ struct MapPoint {  // the members ORBmatcher.cc:43-142 and Frame::isInFrustum to
     cv::Mat GetDescriptor() { return cv::Mat(1, 32, CV_8UC1, descriptor, 32); }
     Vec3 GetWorldPos() const { return pos; }
     Vec3 GetNormal() const { return normal; }
+    float GetMaxDistanceInvariance() const { return 1.2f * mfMaxDistance; }
+    float GetMinDistanceInvariance() const { return 0.8f * mfMinDistance; }
+    template <class FrameP>
+    int PredictScale(const float& currentDist, FrameP* pF) {  // MapPoint.cc:557-572
+        const float ratio = mfMaxDistance / currentDist;
+        int nScale = (int)std::ceil(std::log(ratio) / pF->mfLogScaleFactor);
+        if (nScale < 0) nScale = 0;
+        else if (nScale >= pF->mnScaleLevels) nScale = pF->mnScaleLevels - 1;
+        return nScale;
+    }
     float GetMaxDistance() const { return mfMaxDistance; }
     float GetMinDistance() const { return mfMinDistance; }
     void IncreaseVisible(int n = 1) { nVisible += n; }
@@ -80,6 +97,12 @@ struct Frame {
     Vec3 GetCameraCenter() const { return mOw; }
 };
 float Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY;
+struct KeyFrame {  // what the relocalisation search reads of the candidate KeyFrame
+    std::vector<std::shared_ptr<MapPoint>> mps;
+    std::vector<cv::KeyPoint> keysUn;
+    std::vector<std::shared_ptr<MapPoint>> GetMapPointMatches() { return mps; }
+    cv::KeyPoint GetKeyUn(size_t idx) { return keysUn[idx]; }
+};
 }  // namespace ORB_SLAM3
 
 template <class T>
@@ -189,10 +212,66 @@ static int frames_main(const char* in, const char* out) {
     return 0;
 }
 
+// mode "reloc": ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist)
+static int reloc_main(const char* in, const char* out) {
+    using namespace ORB_SLAM3;
+    FILE* f = fopen(in, "rb");
+    if (!f) return 3;
+    const auto hdr = rd<int>(f, 5);  // N, nlevels, n (KeyFrame features), ORBdist, check orientation
+    const int N = hdr[0], nlev = hdr[1], n = hdr[2];
+    const auto fl = rd<float>(f, 4 + 4 + 2);  // bounds, fx fy cx cy, logScale, th
+    Camera cam{{fl[4], fl[5], fl[6], fl[7]}};
+    Frame C;
+    Frame::mnMinX = fl[0]; Frame::mnMaxX = fl[1]; Frame::mnMinY = fl[2]; Frame::mnMaxY = fl[3];
+    C.N = N; C.mpCamera = &cam; C.mfLogScaleFactor = fl[8]; C.mnScaleLevels = nlev;
+    C.mvKeysUn = rd<cv::KeyPoint>(f, N);
+    C.mvKeys = C.mvKeysUn;
+    std::vector<unsigned char> desc = rd<unsigned char>(f, (size_t)N * 32);
+    C.mDescriptors = cv::Mat(N, 32, CV_8UC1, desc.data(), 32);
+    C.mvuRight = rd<float>(f, N);
+    C.mvScaleFactors = rd<float>(f, nlev);
+    const auto cpose = rd<float>(f, 12);
+    memcpy(C.mTcw.R.m, &cpose[0], 36); memcpy(C.mTcw.t.v, &cpose[9], 12);
+    const auto held = rd<unsigned char>(f, N);
+    C.mvpMapPoints.resize(N);
+    for (int j = 0; j < N; j++)
+        if (held[j]) { C.mvpMapPoints[j] = std::make_shared<MapPoint>(); C.mvpMapPoints[j]->id = -2; }
+    auto kf = std::make_shared<KeyFrame>();
+    kf->keysUn = rd<cv::KeyPoint>(f, n);
+    const auto state = rd<unsigned char>(f, n);  // 0 none, 1 alive, 2 bad, 3 already found
+    const auto pw = rd<float>(f, (size_t)3 * n), maxd = rd<float>(f, n), mind = rd<float>(f, n);
+    const auto mdesc = rd<unsigned char>(f, (size_t)n * 32);
+    fclose(f);
+    std::set<std::shared_ptr<MapPoint>> found;
+    kf->mps.resize(n);
+    for (int i = 0; i < n; i++) {
+        if (!state[i]) continue;
+        auto p = std::make_shared<MapPoint>();
+        p->id = i; p->mbBad = state[i] == 2;
+        memcpy(p->pos.v, &pw[3 * i], 12);
+        p->mfMaxDistance = maxd[i]; p->mfMinDistance = mind[i];
+        memcpy(p->descriptor, &mdesc[(size_t)i * 32], 32);
+        kf->mps[i] = p;
+        if (state[i] == 3) found.insert(p);
+    }
+    msorb_host::DeviceFrame<Frame> dev;
+    dev.Upload(C);
+    msorb_host::KeyFrameProjection P;
+    msorb_host::ProjectKeyFramePoints(C, kf, found, P);
+    const int nm = msorb_host::SearchByProjection(dev, C, kf, found, fl[9], hdr[3], hdr[4] != 0);
+    FILE* o = fopen(out, "wb");
+    fwrite(&nm, 4, 1, o);
+    for (int j = 0; j < N; j++) { const int v = C.mvpMapPoints[j] ? C.mvpMapPoints[j]->id : -1; fwrite(&v, 4, 1, o); }
+    fwrite(P.valid.data(), 1, n, o); fwrite(P.u.data(), 4, n, o); fwrite(P.v.data(), 4, n, o); fwrite(P.level.data(), 4, n, o);
+    fclose(o);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     using namespace ORB_SLAM3;
     if (argc < 3) return 2;
     if (argc > 3 && std::string(argv[3]) == "prepass") return prepass_main(argv[1], argv[2]);
+    if (argc > 3 && std::string(argv[3]) == "reloc") return reloc_main(argv[1], argv[2]);
     if (argc > 3 && std::string(argv[3]) == "frames") return frames_main(argv[1], argv[2]);
     FILE* f = fopen(argv[1], "rb");
     if (!f) return 3;

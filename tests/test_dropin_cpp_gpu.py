@@ -579,3 +579,71 @@ def test_cpp_fuse_adapter_matches_oracle(tmp_path, oracle, msorb_mod):
     assert log.tolist() == [list(e) for e in want_log]
     kinds = log[:, 0]
     assert (kinds == 1).sum() > 50 and (kinds == 2).sum() > 50
+
+
+def test_cpp_relocalisation_search_adapter_matches_oracle(tmp_path, oracle, msorb_mod):
+    """msorb_host::SearchByProjection(dev, CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:2154-2275) over
+    stand-in Frame / KeyFrame / MapPoint types vs the oracle, fed with the projections the C++ side computed."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import matcher_cases as mc
+    exe = tmp_path / "dropin_matcher"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", f"-I{ROOT}/tests/cv_stub", f"-I{ROOT}/ms-slam_amd/host",
+                           f"-I{ROOT}/include", f"{ROOT}/tests/dropin_matcher_main.cc", f"-L{ROOT}/ms-slam_amd", "-lmsorb",
+                           f"-Wl,-rpath,{ROOT}/ms-slam_amd", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    cfg = synth.KITTI
+    ex = msorb_mod.ORBextractor(cfg["nfeatures"], cfg["scale"], cfg["nlevels"], cfg["ini_th"], cfg["min_th"])
+    try:
+        _, kps, desc = ex(synth.image(9, cfg["rows"], cfg["cols"]))
+        scale = np.asarray(ex.GetScaleFactors(), np.float32)
+    finally:
+        ex.close()
+    rng = np.random.default_rng(31)
+    N = len(kps)
+    fx, fy, cx, cy, th, orb_dist, ori = 718.856, 718.856, 607.19, 185.21, 10.0, 100, 1
+    bounds = (0.0, float(cfg["cols"]), 0.0, float(cfg["rows"]))
+    logs = float(np.log(np.float32(1.2)))
+    ur_cur = np.where(rng.random(N) < 0.6, kps["x"] - rng.uniform(1, 40, N), -1).astype(np.float32)
+    Rc = np.eye(3, dtype=np.float32)
+    tc = np.array([0.1, 0.05, -0.2], np.float32)
+    n = 1700
+    src = rng.integers(0, N, n)
+    z = rng.uniform(4, 50, n)
+    uu = kps["x"][src] + rng.normal(0, 4, n)
+    vv = kps["y"][src] + rng.normal(0, 4, n)
+    Xc = np.stack([(uu - cx) / fx * z, (vv - cy) / fy * z, z], 1)
+    Xw = (Xc - tc).astype(np.float32)
+    dist = np.linalg.norm(Xw - (-tc), axis=1)
+    lvl = kps["octave"][src]
+    maxd = (dist * scale[lvl] * rng.uniform(0.85, 1.15, n)).astype(np.float32)
+    mind = (maxd / scale[7] * rng.uniform(0.5, 1.4, n)).astype(np.float32)
+    kk = np.zeros(n, oracle.KP_DTYPE)
+    kk["angle"] = np.mod(kps["angle"][src] + 20.0 + rng.normal(0, 6, n), 360)
+    kk["angle"][rng.random(n) < 0.2] = rng.uniform(0, 360)
+    state = rng.choice([0, 1, 2, 3], n, p=[0.1, 0.75, 0.05, 0.1]).astype(np.uint8)
+    mdesc = mc.flip_bits(rng, desc[src], 40)
+    held = (rng.random(N) < 0.15).astype(np.uint8)
+    with open(tmp_path / "rl.bin", "wb") as f:
+        f.write(struct.pack("<5i", N, len(scale), n, orb_dist, ori))
+        f.write(struct.pack("<10f", *bounds, fx, fy, cx, cy, logs, th))
+        for arr in (kps, desc, ur_cur, scale, Rc.reshape(9), tc, held, kk, state, Xw, maxd, mind, mdesc):
+            f.write(np.ascontiguousarray(arr).tobytes())
+    subprocess.check_call([str(exe), str(tmp_path / "rl.bin"), str(tmp_path / "rl_out.bin"), "reloc"])
+    blob = (tmp_path / "rl_out.bin").read_bytes()
+    nm = struct.unpack_from("<i", blob, 0)[0]
+    got = np.frombuffer(blob, np.int32, N, 4)
+    pos = 4 + 4 * N
+    valid = np.frombuffer(blob, np.uint8, n, pos)
+    u = np.frombuffer(blob, np.float32, n, pos + n)
+    v = np.frombuffer(blob, np.float32, n, pos + 5 * n)
+    level = np.frombuffer(blob, np.int32, n, pos + 9 * n)
+    assert 500 < valid.sum() < (state == 1).sum() and np.all(valid[state != 1] == 0)
+    ok = valid > 0
+    assert np.allclose(u[ok], fx * Xc[ok, 0] / Xc[ok, 2] + cx, atol=2e-2) and np.allclose(v[ok], fy * Xc[ok, 1] / Xc[ok, 2] + cy, atol=2e-2)
+    rf = oracle.OracleFrame(kps, desc, ur_cur, bounds, scale)
+    cur = np.where(held > 0, n + np.arange(N), -1).astype(np.int32)
+    pts = dict(valid=valid, u=u, v=v, level=level, angle=kk["angle"], desc=mdesc, mp=np.arange(n, dtype=np.int32))
+    wn = rf.SearchByProjection_kf(pts, cur, th, orb_dist, bool(ori))
+    want = np.where(cur >= n, -2, cur)
+    assert nm == wn and nm > 100
+    assert got.tolist() == want.tolist()

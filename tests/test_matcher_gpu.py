@@ -251,3 +251,32 @@ def test_fuse_search_matches_oracle(msorb_mod, oracle, stereo_frame, seed, th):
         assert (gi >= 0).sum() > hit.sum() + 50
     finally:
         F.close()
+
+
+@pytest.mark.parametrize("seed,n,th,orb_dist", [(1, 2500, 10.0, 100), (2, 1500, 3.0, 64), (3, 4000, 15.0, 100)])
+def test_search_by_projection_keyframe_relocalisation(msorb_mod, oracle, stereo_frame, seed, n, th, orb_dist):
+    """msorb_search_by_projection_kf (Tracking::Relocalization's SearchByProjection(Frame, pKF, sFound, th, ORBdist),
+    ORBmatcher.cc:2154-2275): any held keypoint is taken, no mvuRight test, bestDist <= ORBdist."""
+    s = stereo_frame
+    rng = np.random.Generator(np.random.PCG64(200 + seed))
+    N = len(s["kl"])
+    ur = np.where(rng.random(N) < 0.6, s["kl"]["x"] - rng.uniform(1, 40, N), -1).astype(np.float32)
+    f, rf = _frames(msorb_mod, oracle, s, ur)
+    t = mc.last_frame_table(rng, s["kl"], s["dl"], ur, s["scale"], n)
+    pts = dict(valid=t["valid"], u=t["u"], v=t["v"], level=t["octave"], angle=t["angle"], desc=t["desc"], mp=t["mp"])
+    init = np.where(rng.random(N) < 0.15, 100000 + rng.integers(0, 50, N), -1).astype(np.int32)   # found by the PnP stage before
+    try:
+        for check in (True, False):
+            got, want = init.copy(), init.copy()
+            nm = f.SearchByProjection_kf(pts, got, th, orb_dist, check)
+            rn = rf.SearchByProjection_kf(pts, want, th, orb_dist, check)
+            assert nm == rn and np.array_equal(got, want)
+        assert rn > 50
+        # differs from the last-frame form where that form would test mvuRight / look at Observations()
+        last = dict(t)
+        alt = init.copy()
+        alt[alt >= 0] = -1
+        rf.SearchByProjection_frames(last, alt, th, False, False, True)
+        assert not np.array_equal(alt[init < 0], want[init < 0])
+    finally:
+        f.close()
