@@ -194,6 +194,19 @@ int msorb_search_by_projection_kf(msorb_frame* cur, int n, const uint8_t* valid,
                                   const int* mp_id, int* cur_mp, float th, int orb_dist, int check_orientation,
                                   int* nmatches);
 
+/* The Sim3 / loop-closing window searches: SearchByProjection(pKF, Scw, vpPoints, vpMatched, th, ratioHamming)
+ * (ORBmatcher.cc:423-530), SearchByProjectionLoop (:532-637) and the (pKF, Scw, vpPoints, vpPointsKFs, ...) form
+ * (:639-753), from the projected coordinates on.  `kf` = the KeyFrame loaded with msorb_frame_set.  Per candidate point
+ * that passed :446-480: valid, u, v, predicted_level, mp_desc, mp_id.  Keypoints with matched[idx] >= 0 are skipped
+ * (:499-500), level band predicted-1 .. predicted (:505-507), first strict minimum, accepted when
+ * (float)bestDist <= max_dist (= TH_LOW * ratioHamming, :521) and then claimed: matched[bestIdx] = mp_id (in/out).
+ * The window searches of Fuse(pKF, Scw, ...) (:1599-1716) and of the two passes of SearchBySim3 (:1718-1939) have no
+ * claims and no error gates: msorb_fuse_search with an all-zero inv_level_sigma2 table returns exactly their
+ * bestIdx / bestDist. */
+int msorb_search_by_projection_sim3(msorb_frame* kf, int n, const uint8_t* valid, const float* u, const float* v,
+                                    const int* predicted_level, const uint8_t* mp_desc, const int* mp_id, int* matched,
+                                    float th, float max_dist, int* nmatches);
+
 /* Best / second-best Hamming match of each query over an explicit candidate list (CSR: candidates of
  * query i are cand_idx[cand_begin[i] .. cand_begin[i+1])), scanned in list order with strict '<' — the
  * inner loop of SearchByBoW / SearchForTriangulation / Fuse (e.g. ORBmatcher.cc:288-330).  Host arrays. */

@@ -333,7 +333,8 @@ namespace {
 // instead of "a map point with observations" (:2011-2013).
 int search_projected(msorb_frame* f, int NL, const uint8_t* valid, const float* u, const float* v, const float* ur,
                      const int* octave, const float* angle, const uint8_t* mp_desc, const int* ids, const int* obs,
-                     int* cur_mp, float th, int forward, int backward, int check_orientation, int accept_dist, int* nmatches) {
+                     int* cur_mp, float th, int forward, int backward, int check_orientation, float accept_dist, int* nmatches,
+                     bool band_below = false) {
     *nmatches = 0;
     std::vector<WinQuery> q(NL);
     for (int i = 0; i < NL; i++) {
@@ -346,6 +347,7 @@ int search_projected(msorb_frame* f, int NL, const uint8_t* valid, const float* 
             w.ur = ur ? ur[i] : 0.0f;
             if (forward) { w.min_level = (int16_t)oct; w.max_level = -1; }
             else if (backward) { w.min_level = 0; w.max_level = (int16_t)oct; }
+            else if (band_below) { w.min_level = (int16_t)(oct - 1); w.max_level = (int16_t)oct; }  // :505-507
             else { w.min_level = (int16_t)(oct - 1); w.max_level = (int16_t)(oct + 1); }
             w.flags = kQValid | kQSkipOccupied | (ur ? 0 : kQNoUr);
         }
@@ -358,11 +360,11 @@ int search_projected(msorb_frame* f, int NL, const uint8_t* valid, const float* 
     const float factor = 1.0f / kHistoLength;
     auto accept = [&](int qi, const int* idx, const int* dist, int n, int* new_occ) -> int {
         if (n == 0) return -1;
-        if (dist[0] <= accept_dist) {  // ORBmatcher.cc:2035-2057 / :2229-2247
+        if ((float)dist[0] <= accept_dist) {  // ORBmatcher.cc:2035-2057 / :2229-2247 / :521
             const int bestIdx2 = idx[0];
             cur_mp[bestIdx2] = ids[qi];
             nm++;
-            if (check_orientation) {
+            if (check_orientation && angle) {
                 float rot = angle[qi] - f->kps[bestIdx2].angle;
                 if (rot < 0.0) rot += 360.0f;
                 int bin = (int)std::round(rot * factor);
@@ -398,7 +400,7 @@ int msorb_search_by_projection_frames(msorb_frame* f, int NL, const uint8_t* val
         return MSORB_E_INVALID;
     HIPCHK(hipSetDevice(f->device));
     return search_projected(f, NL, valid, u, v, ur, last_octave, last_angle, mp_desc, last_mp, obs, cur_mp, th, forward,
-                            backward, check_orientation, kThHigh, nmatches);
+                            backward, check_orientation, (float)kThHigh, nmatches);
 }
 
 int msorb_search_by_projection_kf(msorb_frame* f, int n, const uint8_t* valid, const float* u, const float* v,
@@ -409,7 +411,18 @@ int msorb_search_by_projection_kf(msorb_frame* f, int n, const uint8_t* valid, c
         return MSORB_E_INVALID;
     HIPCHK(hipSetDevice(f->device));
     return search_projected(f, n, valid, u, v, nullptr, predicted_level, kf_angle, mp_desc, mp_id, nullptr, cur_mp, th, 0, 0,
-                            check_orientation, orb_dist, nmatches);
+                            check_orientation, (float)orb_dist, nmatches);
+}
+
+int msorb_search_by_projection_sim3(msorb_frame* f, int n, const uint8_t* valid, const float* u, const float* v,
+                                    const int* predicted_level, const uint8_t* mp_desc, const int* mp_id, int* matched,
+                                    float th, float max_dist, int* nmatches) {
+    if (!f || n < 0 || !nmatches || (n > 0 && (!valid || !u || !v || !predicted_level || !mp_desc || !mp_id)) ||
+        (f->N > 0 && !matched))
+        return MSORB_E_INVALID;
+    HIPCHK(hipSetDevice(f->device));
+    return search_projected(f, n, valid, u, v, nullptr, predicted_level, nullptr, mp_desc, mp_id, nullptr, matched, th, 0, 0, 0,
+                            max_dist, nmatches, true);
 }
 
 int msorb_window_top4(msorb_frame* f, int n_queries, const float* x, const float* y, const float* r, const float* ur,

@@ -338,6 +338,18 @@ class Frame:
                "search_by_projection_kf")
         return nm.value
 
+    def SearchByProjection_sim3(self, pts, matched, th, max_dist):
+        """msorb_search_by_projection_sim3 (loop-closing forms, ORBmatcher.cc:423-753); matched updated in place."""
+        arrs = [_c(pts["valid"], np.uint8), _c(pts["u"], np.float32), _c(pts["v"], np.float32), _c(pts["level"], np.int32),
+                _c(pts["desc"], np.uint8), _c(pts["mp"], np.int32)]
+        assert matched.dtype == np.int32 and matched.flags.c_contiguous
+        nm = C.c_int()
+        self.L.msorb_search_by_projection_sim3.argtypes = ([C.c_void_p, C.c_int] + [C.c_void_p] * 7 +
+                                                           [C.c_float, C.c_float, C.c_void_p])
+        _check(self.L.msorb_search_by_projection_sim3(self.h, len(arrs[0]), *[_np_ptr(a) for a in arrs], _np_ptr(matched), th,
+                                                      max_dist, C.byref(nm)), "search_by_projection_sim3")
+        return nm.value
+
     def FuseSearch(self, inv_level_sigma2, valid, u, v, ur, predicted_level, radius, mp_desc):
         """msorb_fuse_search: the window search of ORBmatcher::Fuse on this KeyFrame.  -> (best_idx, best_dist)"""
         arrs = [_c(valid, np.uint8), _c(u, np.float32), _c(v, np.float32), _c(ur, np.float32), _c(predicted_level, np.int32),
@@ -712,4 +724,4 @@ def stereo_matches_batch(ex, counts, d_kps, d_desc, mb, mbf):
     return d_ur, d_dp, d_oob[:n_pairs].cpu().numpy(), ms.value
 
 
-EXPORTS = EXPORTS + ("msorb_fuse_search", "msorb_search_by_projection_kf")
+EXPORTS = EXPORTS + ("msorb_fuse_search", "msorb_search_by_projection_kf", "msorb_search_by_projection_sim3")

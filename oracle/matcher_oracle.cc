@@ -345,6 +345,37 @@ int orc_search_by_projection_kf(void* fp, int n, const uint8_t* valid, const flo
     return nmatches;
 }
 
+// ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th, ratioHamming), ORBmatcher.cc:482-527 (the same
+// search in SearchByProjectionLoop :591-634 and the vpPointsKFs form :700-749), from the projected coordinates on.
+int orc_search_by_projection_sim3(void* fp, int n, const uint8_t* valid, const float* u, const float* v,
+                                  const int* predicted_level, const uint8_t* mp_desc, const int* mp_id, int* matched, float th,
+                                  float max_dist) {
+    FrameSoA& K = *(FrameSoA*)fp;
+    int nmatches = 0;
+    for (int i = 0; i < n; i++) {
+        if (!valid[i]) continue;
+        const int nPredictedLevel = predicted_level[i];
+        const float radius = th * K.scaleFactors[nPredictedLevel];
+        const std::vector<size_t> vIndices = K.features_in_area(u[i], v[i], radius, -1, -1);
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = mp_desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx = -1;
+        for (size_t k = 0; k < vIndices.size(); k++) {
+            const size_t idx = vIndices[k];
+            if (matched[idx] >= 0) continue;
+            const int kpLevel = K.kps[idx].octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            const int dist = orc::descriptor_distance(dMP, &K.desc[idx * 32]);
+            if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+        }
+        if ((float)bestDist <= max_dist) {
+            matched[bestIdx] = mp_id[i];
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
+
 void orc_three_maxima(const int* sizes, int L, int* ind) {
     std::vector<std::vector<int>> h(L);
     for (int i = 0; i < L; i++) h[i].resize(sizes[i]);

@@ -231,6 +231,13 @@ class OracleFrame:
         return self.L.orc_search_by_projection_kf(self.h, len(arrs[0]), *[_ptr(a) for a in arrs], _ptr(cur_mp), th,
                                                   int(orb_dist), int(check_orientation))
 
+    def SearchByProjection_sim3(self, pts, matched, th, max_dist):
+        """orc_search_by_projection_sim3 (ORBmatcher.cc:423-530); pts: dict valid,u,v,level,desc,mp"""
+        arrs = [_c(pts["valid"], np.uint8), _c(pts["u"], np.float32), _c(pts["v"], np.float32), _c(pts["level"], np.int32),
+                _c(pts["desc"], np.uint8), _c(pts["mp"], np.int32)]
+        self.L.orc_search_by_projection_sim3.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_float, C.c_float]
+        return self.L.orc_search_by_projection_sim3(self.h, len(arrs[0]), *[_ptr(a) for a in arrs], _ptr(matched), th, max_dist)
+
     def FuseSearch(self, inv_level_sigma2, valid, u, v, ur, predicted_level, radius, mp_desc):
         """orc_fuse_search (ORBmatcher.cc:1499-1561) -> (best_idx, best_dist)"""
         arrs = [_c(valid, np.uint8), _c(u, np.float32), _c(v, np.float32), _c(ur, np.float32), _c(predicted_level, np.int32),

@@ -280,3 +280,36 @@ def test_search_by_projection_keyframe_relocalisation(msorb_mod, oracle, stereo_
         assert not np.array_equal(alt[init < 0], want[init < 0])
     finally:
         f.close()
+
+
+@pytest.mark.parametrize("seed,n,th,ratio", [(1, 3000, 8.0, 1.5), (2, 1200, 4.0, 1.0), (3, 5000, 10.0, 0.73)])
+def test_search_by_projection_sim3_forms(msorb_mod, oracle, stereo_frame, seed, n, th, ratio):
+    """msorb_search_by_projection_sim3 (loop-closing window searches, ORBmatcher.cc:423-753): claims through vpMatched,
+    level band predicted-1 .. predicted, (float)bestDist <= TH_LOW * ratioHamming."""
+    s = stereo_frame
+    rng = np.random.Generator(np.random.PCG64(300 + seed))
+    N = len(s["kl"])
+    f, rf = _frames(msorb_mod, oracle, s, None)
+    t = mc.last_frame_table(rng, s["kl"], s["dl"], np.full(N, -1, np.float32), s["scale"], n)
+    level = np.clip(t["octave"] + rng.integers(0, 2, n), 0, 7).astype(np.int32)
+    pts = dict(valid=t["valid"], u=t["u"], v=t["v"], level=level, desc=t["desc"], mp=t["mp"])
+    init = np.where(rng.random(N) < 0.2, 100000 + rng.integers(0, 50, N), -1).astype(np.int32)
+    max_dist = float(np.float32(50) * np.float32(ratio))
+    try:
+        got, want = init.copy(), init.copy()
+        nm = f.SearchByProjection_sim3(pts, got, th, max_dist)
+        rn = rf.SearchByProjection_sim3(pts, want, th, max_dist)
+        assert nm == rn and np.array_equal(got, want)
+        assert rn > 50 and np.array_equal(got[init >= 0], init[init >= 0])
+        # Fuse(pKF, Scw, ...) / SearchBySim3 window search = msorb_fuse_search with a zero gate table: same best as a
+        # claim-free sim3 search restricted to one query
+        bi, bd = f.FuseSearch(np.zeros(8, np.float32), t["valid"], t["u"], t["v"], t["u"], level,
+                              (np.float32(th) * np.asarray(s["scale"], np.float32)[level]).astype(np.float32), t["desc"])
+        for i in np.nonzero(t["valid"])[0][:60]:
+            one = {k: a[i:i + 1] for k, a in pts.items()}
+            m = np.full(N, -1, np.int32)
+            rf.SearchByProjection_sim3(one, m, th, 255.0)     # (256 would accept the 'no candidate' state, like the reference)
+            hit = np.nonzero(m >= 0)[0]
+            assert (bi[i] == hit[0]) if len(hit) else bi[i] == -1
+    finally:
+        f.close()
