@@ -414,7 +414,7 @@ void ProjectKeyFramePoints(FrameT& CurrentFrame, const KeyFramePtr& pKF, const M
         const auto uv = CurrentFrame.mpCamera->project(x3Dc);
         if (uv(0) < CurrentFrame.mnMinX || uv(0) > CurrentFrame.mnMaxX) continue;
         if (uv(1) < CurrentFrame.mnMinY || uv(1) > CurrentFrame.mnMaxY) continue;
-        const auto PO = x3Dw - Ow;
+        const auto PO = (x3Dw - Ow).eval();                                // Eigen::Vector3f PO = x3Dw-Ow
         const float dist3D = PO.norm();
         const float maxDistance = pMP->GetMaxDistanceInvariance();
         const float minDistance = pMP->GetMinDistanceInvariance();
@@ -488,7 +488,7 @@ void FuseGeometry(const KeyFramePtr& pKF, const std::vector<MapPointPtr>& vpMapP
         if (!pKF->IsInImage(uv(0), uv(1))) continue;                       // :1462
         const float maxDistance = pMP->GetMaxDistanceInvariance();
         const float minDistance = pMP->GetMinDistanceInvariance();
-        const auto PO = p3Dw - Ow;
+        const auto PO = (p3Dw - Ow).eval();                                // Eigen::Vector3f PO = p3Dw-Ow
         const float dist3D = PO.norm();
         if (dist3D < minDistance || dist3D > maxDistance) continue;        // :1476
         const auto Pn = pMP->GetNormal();
@@ -558,7 +558,9 @@ void TriangulationGeometry(const KeyFramePtr& pKF1, const KeyFramePtr& pKF2, flo
     const auto t12x = SO3::hat(t12);
     const auto K1 = pKF1->mpCamera->toK_();
     const auto K2 = pKF2->mpCamera->toK_();
-    const auto F = K1.transpose().inverse() * t12x * R12 * K2.inverse();
+    // .eval(): the product is an expression template in Eigen (no coefficient access, operands held by reference); evaluating it
+    // into a plain matrix is what the reference's `Eigen::Matrix3f F12 = ...` does
+    const auto F = (K1.transpose().inverse() * t12x * R12 * K2.inverse()).eval();
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) F12[3 * r + c] = F(r, c);
 }

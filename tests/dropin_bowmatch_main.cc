@@ -33,6 +33,7 @@ struct Vec2 { float v[2]; float operator()(int i) const { return v[i]; } };
 struct Vec3 {
     float v[3];
     float operator()(int i) const { return v[i]; }
+    Vec3 eval() const { return *this; }
     Vec3 operator-(const Vec3& o) const { return Vec3{{v[0] - o.v[0], v[1] - o.v[1], v[2] - o.v[2]}}; }
     float dot(const Vec3& o) const { return v[0] * o.v[0] + v[1] * o.v[1] + v[2] * o.v[2]; }
     float norm() const { return std::sqrt(dot(*this)); }
@@ -40,6 +41,7 @@ struct Vec3 {
 struct Mat3 {
     float m[9];
     float operator()(int r, int c) const { return m[3 * r + c]; }
+    Mat3 eval() const { return *this; }
     Mat3 transpose() const { Mat3 o; for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) o.m[3 * r + c] = m[3 * c + r]; return o; }
     Mat3 inverse() const {
         const float a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];

@@ -20,6 +20,7 @@ struct Vec2 { float v[2]; float operator()(int i) const { return v[i]; } };     
 struct Vec3 {                                                                                     // Eigen::Vector3f stand-in
     float v[3];
     float operator()(int i) const { return v[i]; }
+    Vec3 eval() const { return *this; }
     Vec3 operator-(const Vec3& o) const { return Vec3{{v[0] - o.v[0], v[1] - o.v[1], v[2] - o.v[2]}}; }
     float norm() const { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 };
