@@ -97,3 +97,35 @@ def test_matcher_adapter_header_compiles(tmp_path):
                            f"-I{ROOT}/include", os.path.join(ROOT, "tests", "dropin_bow_main.cc")])
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", f"-I{ROOT}/tests/cv_stub", f"-I{ROOT}/ms-slam_amd/host",
                            f"-I{ROOT}/include", os.path.join(ROOT, "tests", "dropin_bowmatch_main.cc")])
+
+
+def test_host_array_entries_validate_before_touching_a_device(msorb_mod):
+    """The host-array matcher entries check their arguments on the host first: malformed input is MSORB_E_INVALID with or
+    without a GPU, and well-formed input without a GPU is MSORB_E_NO_DEVICE (never a CPU answer)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bow_match_cases as bmc
+    gpu = msorb_mod.lib().msorb_device_count() > 0
+    p = bmc.make_pair(1, n1=60, n2=70, n_nodes=4)
+    bad = dict(p)
+    f = [a.copy() for a in bad["fv1"]]
+    f[2][0] = 10 ** 6                                   # feature index out of range
+    bad["fv1"] = tuple(f)
+    with pytest.raises(msorb_mod.MsorbError) as e:
+        msorb_mod.search_by_bow([bad])
+    assert e.value.code == msorb_mod.E_INVALID
+    t = bmc.make_triangulation_pair(1, n1=60, n2=70, n_nodes=4)
+    badt = dict(t)
+    badt["kp2"] = t["kp2"].copy()
+    badt["kp2"]["octave"][0] = -1
+    with pytest.raises(msorb_mod.MsorbError) as e:
+        msorb_mod.search_for_triangulation([badt])
+    assert e.value.code == msorb_mod.E_INVALID
+    assert msorb_mod.search_by_bow([])[0] == [] and msorb_mod.search_for_triangulation([])[0] == []
+    empty = bmc.make_pair(2, n1=0, n2=0)
+    assert msorb_mod.search_by_bow([empty])[0][0][0] == 0      # nothing to match: answered without a device
+    if not gpu:
+        for call in (lambda: msorb_mod.search_by_bow([p]), lambda: msorb_mod.search_for_triangulation([t])):
+            with pytest.raises(msorb_mod.MsorbError) as e:
+                call()
+            assert e.value.code == msorb_mod.E_NO_DEVICE
