@@ -102,8 +102,8 @@ def cpu_baseline(cfg, sample_pairs, seed0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--pairs", type=int, default=128, help="stereo pairs per step per GPU-pair group")
     ap.add_argument("--cpu-pairs", type=int, default=160, help="stereo pairs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--isolated", action="store_true",
