@@ -68,6 +68,17 @@ int msorb_extract(msorb_extractor* h, const uint8_t* image, int rows, int cols, 
                   msorb_keypoint* keypoints, uint8_t* descriptors, int capacity, int* n_keypoints,
                   int* mono_index);
 
+/* One stereo frame in one call — what Frame::Frame(imLeft, imRight, ...) does with two extractor threads and
+ * ComputeStereoMatches (Frame.cc:119-137): both images go through the batch pipeline together, the stereo association
+ * (Frame.cc:743-913, median rejection included) runs on the device-resident outputs, and keypoints, descriptors,
+ * mvuRight and mvDepth come back with a single synchronisation.  Lapping areas are 0 (rectified stereo).  Results are
+ * identical to two msorb_extract calls followed by msorb_stereo_matches.  capacity = entries available in each of the
+ * caller's arrays (>= msorb_extractor_capacity). */
+int msorb_extract_stereo(msorb_extractor* h, const uint8_t* left, const uint8_t* right, int rows, int cols,
+                         size_t stride_left, size_t stride_right, float mb, float mbf, msorb_keypoint* kps_left,
+                         uint8_t* desc_left, int* n_left, msorb_keypoint* kps_right, uint8_t* desc_right, int* n_right,
+                         int capacity, float* u_right, float* depth, int* n_oob);
+
 /* mvImagePyramid[level] (ORBextractor.h:83) of the last msorb_extract() call as a host-visible plane
  * (interior pixels; the 19-px border of ORBextractor.cc:1185-1191 is not materialised).  The memory
  * is owned by the handle and valid until the next extract call. */

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "orb_device.h"
+#include "matcher_device.h"
 
 using namespace msorb;
 
@@ -168,6 +169,9 @@ struct msorb_extractor {
     struct FrameGraph { hipGraphExec_t exec = nullptr; int lap0 = 0, lap1 = 0, rows = 0, cols = 0; };
     FrameGraph fgraph[2];        // two cached variants (e.g. mono + stereo lapping settings)
     bool capturing = false;      // enqueue only: no host synchronisation inside the pipeline
+    bool defer_sync = false;     // enqueue only, the caller appends more work and synchronises (msorb_extract_stereo)
+    DevBuf<int> d_st_sad, d_st_rows, d_st_list, d_st_oob;  // stereo association scratch of msorb_extract_stereo
+    DevBuf<float> d_st_out;
     unsigned long long buffers_epoch = 0;  // bumped whenever a device / pinned buffer may have moved
     unsigned long long graph_epoch = 0;
     hipEvent_t ev_compact = nullptr, ev_pyramid = nullptr, ev_blur = nullptr;
@@ -432,7 +436,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
         HIPCHK(hipMemcpyAsync(h->h_mono.p + first, h->d_mono.p + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
         first += n;
     }
-    if (h->capturing) return MSORB_OK;  // graph capture: the caller ends the capture, launches and reads back
+    if (h->capturing || h->defer_sync) return MSORB_OK;  // graph capture / fused call: the caller synchronises and reads back
     for (int gi = 0; gi < ng; gi++) HIPCHK(hipStreamSynchronize(h->grp[gi].s));
     HIPCHK(hipGetLastError());
     for (int i = 0; i < n_images; i++) {
@@ -680,6 +684,7 @@ void msorb_extractor_destroy(msorb_extractor* h) {
     h->d_level_cell_begin.release(); h->d_cell_count.release(); h->d_cell_off.release(); h->d_level_count.release();
     h->d_img_total.release(); h->d_img_base.release(); h->d_sel_count.release(); h->d_slots.release();
     h->d_compact.release(); h->d_sel.release(); h->d_kps1.release();
+    h->d_st_sad.release(); h->d_st_rows.release(); h->d_st_list.release(); h->d_st_oob.release(); h->d_st_out.release();
     h->h_level_count.release(); h->h_img_base.release(); h->h_sel_count.release(); h->h_compact.release();
     h->h_sel.release(); h->h_pyr.release(); h->h_img_pin.release(); h->h_out_pin.release();
     for (auto& G : h->grp) {
@@ -857,6 +862,99 @@ int msorb_extract(msorb_extractor* h, const uint8_t* image, int rows, int cols, 
     }
     *n_keypoints = n;
     *mono_index = mono;
+    return MSORB_OK;
+}
+
+// Both eyes of one stereo frame in one call: the two images go through the batch pipeline together (one chain of
+// launches instead of two racing on two host threads), Frame::ComputeStereoMatches runs on the device outputs
+// (row table + match + median kernels of msorb_stereo_matches_batch) and everything comes back with one synchronisation.
+int msorb_extract_stereo(msorb_extractor* h, const uint8_t* left, const uint8_t* right, int rows, int cols, size_t stride_left,
+                         size_t stride_right, float mb, float mbf, msorb_keypoint* kps_left, uint8_t* desc_left, int* n_left,
+                         msorb_keypoint* kps_right, uint8_t* desc_right, int* n_right, int capacity, float* u_right,
+                         float* depth, int* n_oob) {
+    if (!h || !n_left || !n_right) return MSORB_E_INVALID;
+    *n_left = *n_right = 0;
+    if (n_oob) *n_oob = 0;
+    if (!left || !right || rows <= 0 || cols <= 0) return MSORB_E_EMPTY;
+    if (!kps_left || !desc_left || !kps_right || !desc_right || !u_right || !depth || (int)stride_left < cols ||
+        (int)stride_right < cols)
+        return MSORB_E_INVALID;
+    if (!h->device_quadtree || getenv("MSORB_SERIAL_PIPELINE")) {
+        set_error("msorb_extract_stereo needs the device pipeline");
+        return MSORB_E_INVALID;
+    }
+    HIPCHK(hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure_geometry(h, rows, cols))) return rc;
+    if ((rc = ensure_batch(h, 2))) return rc;
+    const int cap = capacity_of(h);
+    const FrameGeom& g = h->G;
+    const LevelGeom& g0 = g.lv[0];
+    float smax = 0;
+    for (int l = 0; l < g.nlevels; l++) smax = std::max(smax, h->scales.scale[l]);
+    const int row_cap = cap * ((int)std::ceil(4.0f * smax) + 3);
+    if ((size_t)(2 * rows + 1) * sizeof(int) > 60000) { set_error("image too tall for the stereo row table"); return MSORB_E_INVALID; }
+    const size_t kp_bytes = (size_t)cap * sizeof(msorb_keypoint), out_bytes = 2 * kp_bytes + (size_t)2 * cap * 32 + (size_t)2 * cap * 4 + 16;
+    if ((rc = h->d_kps1.ensure((size_t)2 * cap)) || (rc = h->d_desc1.ensure((size_t)2 * cap * 32)) ||
+        (rc = h->h_img_pin.ensure((size_t)2 * g0.pitch * rows)) || (rc = h->h_out_pin.ensure(out_bytes)) ||
+        (rc = h->d_st_sad.ensure(cap)) || (rc = h->d_st_rows.ensure((size_t)rows + 1)) || (rc = h->d_st_list.ensure(row_cap)) ||
+        (rc = h->d_st_oob.ensure(1)) || (rc = h->d_st_out.ensure((size_t)2 * cap)))
+        return rc;
+    const size_t plane = (size_t)g0.pitch * rows;
+    for (int y = 0; y < rows; y++) {
+        memcpy(h->h_img_pin.p + (size_t)y * g0.pitch, left + (size_t)y * stride_left, cols);
+        memcpy(h->h_img_pin.p + plane + (size_t)y * g0.pitch, right + (size_t)y * stride_right, cols);
+    }
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->d_pyr.p + g0.plane_off, h->h_img_pin.p, plane, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->d_pyr.p + g.pyramid_bytes + g0.plane_off, h->h_img_pin.p + plane, plane, hipMemcpyHostToDevice, s));
+    LevelView l0{h->d_pyr.p + g0.plane_off, g.pyramid_bytes, g0.pitch, cols, rows};
+    int counts[2] = {0, 0}, mono[2] = {0, 0};
+    h->defer_sync = true;
+    rc = run_pipeline(h, l0, 2, 0, 0, h->d_kps1.p, h->d_desc1.p, cap, counts, mono);
+    h->defer_sync = false;
+    if (rc) return rc;
+    // stereo association on the device outputs (pair 0 = images 0 / 1)
+    StereoBatchArgs b{};
+    b.A.kpL = h->d_kps1.p;
+    b.A.descL = h->d_desc1.p;
+    b.A.rows0 = rows;
+    for (int l = 0; l < g.nlevels; l++) {
+        const LevelView& v = h->last_pyr.lv[l];
+        b.A.pyrL[l] = b.A.pyrR[l] = v.base;
+        b.A.pitchL[l] = b.A.pitchR[l] = v.pitch;
+        b.A.rows[l] = v.h; b.A.cols[l] = v.w;
+        b.A.scale[l] = h->scales.scale[l]; b.A.inv_scale[l] = h->P.inv_scale[l];
+        b.img_stride[l] = v.img_stride;
+    }
+    b.A.mb = mb; b.A.mbf = mbf;
+    b.A.u_right = h->d_st_out.p; b.A.depth = h->d_st_out.p + cap; b.A.sad = h->d_st_sad.p; b.A.n_oob = h->d_st_oob.p;
+    b.capacity = cap;
+    b.counts = h->d_sel_count.p;
+    b.row_begin = h->d_st_rows.p; b.row_list = h->d_st_list.p; b.row_cap = row_cap;
+    HIPCHK(hipMemsetAsync(h->d_st_oob.p, 0, sizeof(int), s));
+    launch_stereo_match_batch(b, 1, cap, s);
+    // everything back in one go (full-capacity blocks: cheaper than a round trip for the counts first)
+    uint8_t* o = h->h_out_pin.p;
+    HIPCHK(hipMemcpyAsync(o, h->d_kps1.p, 2 * kp_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(o + 2 * kp_bytes, h->d_desc1.p, (size_t)2 * cap * 32, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(o + 2 * kp_bytes + (size_t)2 * cap * 32, h->d_st_out.p, (size_t)2 * cap * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(o + 2 * kp_bytes + (size_t)2 * cap * 32 + (size_t)2 * cap * 4, h->d_st_oob.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    const int nl = h->h_sel_count.p[0], nr = h->h_sel_count.p[1];
+    if (nl < 0 || nr < 0) { set_error("keypoint capacity exceeded"); return MSORB_E_CAPACITY; }
+    if (nl > capacity || nr > capacity) { set_error("caller capacity too small"); return MSORB_E_CAPACITY; }
+    memcpy(kps_left, o, (size_t)nl * sizeof(msorb_keypoint));
+    memcpy(kps_right, o + kp_bytes, (size_t)nr * sizeof(msorb_keypoint));
+    memcpy(desc_left, o + 2 * kp_bytes, (size_t)nl * 32);
+    memcpy(desc_right, o + 2 * kp_bytes + (size_t)cap * 32, (size_t)nr * 32);
+    const float* fo = reinterpret_cast<const float*>(o + 2 * kp_bytes + (size_t)2 * cap * 32);
+    memcpy(u_right, fo, (size_t)nl * sizeof(float));
+    memcpy(depth, fo + cap, (size_t)nl * sizeof(float));
+    if (n_oob) *n_oob = *reinterpret_cast<const int*>(fo + 2 * cap);
+    *n_left = nl;
+    *n_right = nr;
     return MSORB_OK;
 }
 

@@ -14,6 +14,9 @@
 //   ORB_SLAM3::msorb_host::SearchLocalPointsPrepass(...) the isInFrustum loop of Tracking::SearchLocalPoints
 //                                                        (src/Tracking.cc:3343-3361, src/Frame.cc:512-571)
 //   ORB_SLAM3::msorb_host::ComputeStereoMatches(...)     body of Frame::ComputeStereoMatches (src/Frame.cc:743-913)
+//   ORB_SLAM3::msorb_host::ExtractStereo(F, left, imLeft, imRight)
+//                                                        the two ExtractORB threads + ComputeStereoMatches of the stereo
+//                                                        Frame constructor (src/Frame.cc:119-137) as ONE device call
 //   ORB_SLAM3::msorb_host::SearchByBoW(...)              bodies of ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches)
 //                                                        (src/ORBmatcher.cc:223-421, Nleft == -1 branch) and
 //                                                        SearchByBoW(pKF1, pKF2, vpMatches12) (:872-1016,
@@ -655,6 +658,34 @@ void ComputeStereoMatches(FrameT& F, const ExtractorT& left, const ExtractorT& r
                                dl.data(), reinterpret_cast<const msorb_keypoint*>(F.mvKeysRight.data()), Nr, dr.data(), F.mb,
                                F.mbf, F.mvuRight.data(), F.mvDepth.data(), &oob),
           "msorb_stereo_matches");
+}
+
+// Frame::Frame(imLeft, imRight, ...), Frame.cc:119-137: `thread threadLeft(&Frame::ExtractORB, this, 0, imLeft, 0, 0);
+// thread threadRight(&Frame::ExtractORB, this, 1, imRight, 0, 0); join; ... ComputeStereoMatches();` becomes one call that
+// fills mvKeys / mDescriptors, mvKeysRight / mDescriptorsRight, mvuRight and mvDepth (the caller keeps N = mvKeys.size(),
+// UndistortKeyPoints() etc. in between: they do not feed the stereo association for rectified input).  Identical results.
+template <class FrameT, class ExtractorT, class MatT>
+void ExtractStereo(FrameT& F, const ExtractorT& left, const MatT& imLeft, const MatT& imRight) {
+    const int cap = msorb_extractor_capacity(left.handle());
+    F.mvKeys.resize(cap);
+    F.mvKeysRight.resize(cap);
+    static_assert(sizeof(F.mvKeys[0]) == sizeof(msorb_keypoint), "cv::KeyPoint must be the 28-byte layout");
+    std::vector<uint8_t> dl((size_t)cap * 32), dr((size_t)cap * 32);
+    std::vector<float> ur(cap), depth(cap);
+    int nl = 0, nr = 0, oob = 0;
+    check(msorb_extract_stereo(left.handle(), imLeft.data, imRight.data, imLeft.rows, imLeft.cols, (size_t)imLeft.step,
+                               (size_t)imRight.step, F.mb, F.mbf, reinterpret_cast<msorb_keypoint*>(F.mvKeys.data()), dl.data(),
+                               &nl, reinterpret_cast<msorb_keypoint*>(F.mvKeysRight.data()), dr.data(), &nr, cap, ur.data(),
+                               depth.data(), &oob),
+          "msorb_extract_stereo");
+    F.mvKeys.resize(nl);
+    F.mvKeysRight.resize(nr);
+    F.mDescriptors.create(nl, 32, 0 /* CV_8U */);
+    F.mDescriptorsRight.create(nr, 32, 0 /* CV_8U */);
+    for (int i = 0; i < nl; i++) std::memcpy(F.mDescriptors.template ptr<unsigned char>(i), &dl[(size_t)i * 32], 32);
+    for (int i = 0; i < nr; i++) std::memcpy(F.mDescriptorsRight.template ptr<unsigned char>(i), &dr[(size_t)i * 32], 32);
+    F.mvuRight.assign(ur.begin(), ur.begin() + nl);
+    F.mvDepth.assign(depth.begin(), depth.begin() + nl);
 }
 
 }  // namespace msorb_host

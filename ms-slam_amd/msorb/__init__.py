@@ -27,7 +27,7 @@ EXPORTS = (
     "msorb_last_error", "msorb_device_count", "msorb_extractor_create", "msorb_extractor_destroy",
     "msorb_extractor_tables", "msorb_extractor_capacity", "msorb_extract", "msorb_pyramid_level",
     "msorb_extract_batch", "msorb_extractor_set_profiling", "msorb_extractor_set_overlap", "msorb_extractor_stage_ms", "msorb_debug_level_size",
-    "msorb_debug_copy_level", "msorb_debug_candidates", "msorb_distribute_quadtree",
+    "msorb_debug_copy_level", "msorb_debug_candidates", "msorb_distribute_quadtree", "msorb_extract_stereo",
 )
 
 
@@ -150,6 +150,26 @@ class ORBextractor:
             return -1, kps[:0], desc[:0]
         _check(rc, "msorb_extract")
         return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_stereo(self, left, right, mb, mbf):
+        """msorb_extract_stereo: both eyes + Frame::ComputeStereoMatches in one call.
+        -> (kps_left, desc_left, kps_right, desc_right, mvuRight, mvDepth, n_oob)"""
+        left, right = np.ascontiguousarray(left, np.uint8), np.ascontiguousarray(right, np.uint8)
+        assert left.shape == right.shape and left.ndim == 2
+        rows, cols = left.shape
+        cap = self.capacity
+        kl, kr = np.zeros(cap, KP_DTYPE), np.zeros(cap, KP_DTYPE)
+        dl, dr = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
+        ur, dp = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+        nl, nr, oob = C.c_int(0), C.c_int(0), C.c_int(0)
+        self.L.msorb_extract_stereo.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
+                                                C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(self.L.msorb_extract_stereo(self.h, _np_ptr(left), _np_ptr(right), rows, cols, cols, cols, mb, mbf, _np_ptr(kl),
+                                           _np_ptr(dl), C.byref(nl), _np_ptr(kr), _np_ptr(dr), C.byref(nr), cap, _np_ptr(ur),
+                                           _np_ptr(dp), C.byref(oob)), "msorb_extract_stereo")
+        a, b = nl.value, nr.value
+        return kl[:a].copy(), dl[:a].copy(), kr[:b].copy(), dr[:b].copy(), ur[:a].copy(), dp[:a].copy(), oob.value
 
     def pyramid_level(self, level):
         """mvImagePyramid[level] of the last __call__ as a numpy array (copy)."""

@@ -3,13 +3,60 @@
 // usage: dropin_extractor <rows> <cols> <in.raw> <out.bin> <nfeatures>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "ORBextractor.h"
+#include "ORBmatcher_device.h"
+
+namespace ORB_SLAM3 {
+struct Frame {  // the members the stereo constructor fills (include/Frame.h)
+    std::vector<cv::KeyPoint> mvKeys, mvKeysRight;
+    cv::Mat mDescriptors, mDescriptorsRight;
+    std::vector<float> mvuRight, mvDepth;
+    float mb = 0, mbf = 0;
+};
+}  // namespace ORB_SLAM3
+
+// mode "stereo": <rows> <cols> <left.raw> <out.bin> <nfeatures> stereo <right.raw> <mb> <mbf> — the stereo Frame constructor
+// once through msorb_host::ExtractStereo and once the reference's way (two operator() calls + ComputeStereoMatches)
+static int stereo_main(int rows, int cols, const char* lp, const char* rp, const char* out, int nf, float mb, float mbf) {
+    using namespace ORB_SLAM3;
+    std::vector<unsigned char> bl((size_t)rows * cols), br((size_t)rows * cols);
+    FILE* f = fopen(lp, "rb");
+    if (!f || fread(bl.data(), 1, bl.size(), f) != bl.size()) return 3;
+    fclose(f);
+    f = fopen(rp, "rb");
+    if (!f || fread(br.data(), 1, br.size(), f) != br.size()) return 3;
+    fclose(f);
+    cv::Mat imL(rows, cols, CV_8UC1, bl.data(), (size_t)cols), imR(rows, cols, CV_8UC1, br.data(), (size_t)cols);
+    ORBextractor exL(nf, 1.2f, 8, 20, 7), exR(nf, 1.2f, 8, 20, 7), exF(nf, 1.2f, 8, 20, 7);
+    Frame A, B;
+    A.mb = B.mb = mb; A.mbf = B.mbf = mbf;
+    msorb_host::ExtractStereo(A, exF, imL, imR);
+    std::vector<int> lap = {0, 0};
+    exL(imL, cv::Mat(), B.mvKeys, B.mDescriptors, lap);
+    exR(imR, cv::Mat(), B.mvKeysRight, B.mDescriptorsRight, lap);
+    msorb_host::ComputeStereoMatches(B, exL, exR);
+    FILE* o = fopen(out, "wb");
+    for (Frame* F : {&A, &B}) {
+        const int n = (int)F->mvKeys.size(), nr = (int)F->mvKeysRight.size();
+        fwrite(&n, 4, 1, o); fwrite(&nr, 4, 1, o);
+        fwrite(F->mvKeys.data(), sizeof(cv::KeyPoint), n, o);
+        fwrite(F->mvKeysRight.data(), sizeof(cv::KeyPoint), nr, o);
+        for (int i = 0; i < n; i++) fwrite(F->mDescriptors.ptr<unsigned char>(i), 1, 32, o);
+        for (int i = 0; i < nr; i++) fwrite(F->mDescriptorsRight.ptr<unsigned char>(i), 1, 32, o);
+        fwrite(F->mvuRight.data(), 4, n, o); fwrite(F->mvDepth.data(), 4, n, o);
+    }
+    fclose(o);
+    return 0;
+}
 
 int main(int argc, char** argv) {
     if (argc < 6) return 2;
     const int rows = atoi(argv[1]), cols = atoi(argv[2]), nf = atoi(argv[5]);
+    if (argc >= 10 && std::string(argv[6]) == "stereo")
+        return stereo_main(rows, cols, argv[3], argv[7], argv[4], nf, (float)atof(argv[8]), (float)atof(argv[9]));
     std::vector<unsigned char> buf((size_t)rows * cols);
     FILE* f = fopen(argv[3], "rb");
     if (!f || fread(buf.data(), 1, buf.size(), f) != buf.size()) return 3;

@@ -647,3 +647,39 @@ def test_cpp_relocalisation_search_adapter_matches_oracle(tmp_path, oracle, msor
     want = np.where(cur >= n, -2, cur)
     assert nm == wn and nm > 100
     assert got.tolist() == want.tolist()
+
+
+def test_cpp_stereo_frame_constructor_one_call(tmp_path, oracle, msorb_mod):
+    """msorb_host::ExtractStereo (the two ExtractORB threads + ComputeStereoMatches of Frame.cc:119-137 as one device call)
+    fills the Frame exactly like the reference's sequence through the drop-in class, and like the oracle."""
+    import matcher_cases as mc
+    exe = tmp_path / "dropin_extractor"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", f"-I{ROOT}/tests/cv_stub", f"-I{ROOT}/ms-slam_amd/host",
+                           f"-I{ROOT}/include", f"{ROOT}/tests/dropin_extractor_main.cc",
+                           f"{ROOT}/ms-slam_amd/host/ORBextractor.cc", f"-L{ROOT}/ms-slam_amd", "-lmsorb",
+                           f"-Wl,-rpath,{ROOT}/ms-slam_amd", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    cfg = synth.KITTI
+    L, R = synth.stereo_pair(55, cfg["rows"], cfg["cols"])
+    L.tofile(tmp_path / "l.raw")
+    R.tofile(tmp_path / "r.raw")
+    mbf, mb = mc.KITTI_BF, mc.KITTI_BF / mc.KITTI_FX
+    subprocess.check_call([str(exe), str(cfg["rows"]), str(cfg["cols"]), str(tmp_path / "l.raw"), str(tmp_path / "out.bin"), "2000",
+                           "stereo", str(tmp_path / "r.raw"), repr(float(np.float32(mb))), repr(float(np.float32(mbf)))])
+    blob = (tmp_path / "out.bin").read_bytes()
+    pos, frames = 0, []
+    for _ in range(2):
+        n, nr = struct.unpack_from("<ii", blob, pos)
+        pos += 8
+        kl = np.frombuffer(blob, oracle.KP_DTYPE, n, pos); pos += 28 * n
+        kr = np.frombuffer(blob, oracle.KP_DTYPE, nr, pos); pos += 28 * nr
+        dl = np.frombuffer(blob, np.uint8, 32 * n, pos).reshape(n, 32); pos += 32 * n
+        dr = np.frombuffer(blob, np.uint8, 32 * nr, pos).reshape(nr, 32); pos += 32 * nr
+        ur = np.frombuffer(blob, np.float32, n, pos); pos += 4 * n
+        dp = np.frombuffer(blob, np.float32, n, pos); pos += 4 * n
+        frames.append((kl, kr, dl, dr, ur, dp))
+    a, b = frames
+    for x, y in zip(a, b):
+        assert x.tobytes() == y.tobytes()
+    _, okl, odl = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)(L)
+    assert np.array_equal(a[0].view(np.uint8), okl.view(np.uint8)) and np.array_equal(a[2], odl)
+    assert (a[4] > 0).sum() > 500

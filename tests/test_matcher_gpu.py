@@ -313,3 +313,30 @@ def test_search_by_projection_sim3_forms(msorb_mod, oracle, stereo_frame, seed, 
             assert (bi[i] == hit[0]) if len(hit) else bi[i] == -1
     finally:
         f.close()
+
+
+def test_extract_stereo_equals_two_extractions_plus_stereo_matches(msorb_mod, oracle):
+    """msorb_extract_stereo (both eyes through the batch pipeline + device-resident ComputeStereoMatches, one call) gives
+    exactly what two msorb_extract calls followed by msorb_stereo_matches give (which is pinned to the oracle above)."""
+    mbf, mb = mc.KITTI_BF, mc.KITTI_BF / mc.KITTI_FX
+    for seed, (rows, cols), nfeat in ((40, (376, 1241), 2000), (41, (480, 752), 1000), (42, (240, 320), 500)):
+        L, R = synth.stereo_pair(seed, rows, cols)
+        ex = msorb_mod.ORBextractor(nfeat, 1.2, 8, 20, 7)
+        exl = msorb_mod.ORBextractor(nfeat, 1.2, 8, 20, 7)
+        exr = msorb_mod.ORBextractor(nfeat, 1.2, 8, 20, 7)
+        try:
+            for rep in range(2):                 # second call: warmed handle, same answer
+                kl, dl, kr, dr, ur, dp, oob = ex.extract_stereo(L, R, mb, mbf)
+                _, wkl, wdl = exl(L)
+                _, wkr, wdr = exr(R)
+                assert np.array_equal(kl.view(np.uint8), wkl.view(np.uint8)) and np.array_equal(dl, wdl)
+                assert np.array_equal(kr.view(np.uint8), wkr.view(np.uint8)) and np.array_equal(dr, wdr)
+                wur, wdp, woob = msorb_mod.stereo_matches(exl, exr, wkl, wdl, wkr, wdr, mb, mbf)
+                assert np.array_equal(ur.view(np.uint32), wur.view(np.uint32))
+                assert np.array_equal(dp.view(np.uint32), wdp.view(np.uint32))
+                assert oob == woob and (ur > 0).sum() > 50
+            # a single-image call on the same handle afterwards still works (buffers are shared)
+            _, k1, d1 = ex(L)
+            assert np.array_equal(k1.view(np.uint8), wkl.view(np.uint8)) and np.array_equal(d1, wdl)
+        finally:
+            ex.close(); exl.close(); exr.close()

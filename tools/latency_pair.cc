@@ -111,10 +111,28 @@ int main(int argc, char** argv) {
     }
     msorb_frame_destroy(fr);
     auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    // the fused call: both eyes + stereo association, one synchronisation (msorb_extract_stereo)
+    std::vector<double> t_fused;
+    {
+        msorb_extractor* fx = nullptr;
+        if (msorb_extractor_create(2000, 1.2f, 8, 20, 7, 0, &fx)) { printf("create: %s\n", msorb_last_error()); return 1; }
+        int nl = 0, nr2 = 0, oob2 = 0;
+        for (int i = 0; i < 5 + iters; i++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            if (msorb_extract_stereo(fx, img[0].data(), img[1].data(), rows, cols, cols, cols, mb, mbf, kps[0].data(), desc[0].data(), &nl,
+                                     kps[1].data(), desc[1].data(), &nr2, cap, ur.data(), depth.data(), &oob2)) {
+                printf("extract_stereo: %s\n", msorb_last_error());
+                return 1;
+            }
+            if (i >= 5) t_fused.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+        msorb_extractor_destroy(fx);
+    }
     printf("{\"keypoints\": [%d, %d], \"ms_stereo_pair_two_threads_median\": %.4f, \"ms_single_image_median\": %.4f, "
            "\"ms_stereo_matches\": %.4f, \"ms_frame_grid_upload\": %.4f, \"ms_search_by_projection_4096\": %.4f, "
-           "\"ms_is_in_frustum_4096\": %.4f, \"ms_tracking_frame_front_end\": %.4f, \"projection_matches\": %d}\n",
-           n[0], n[1], pair_ms[iters / 2], single_ms[iters / 2], med(t_st), med(t_fs), med(t_sp), med(t_fr), med(t_all), nm);
+           "\"ms_is_in_frustum_4096\": %.4f, \"ms_tracking_frame_front_end\": %.4f, \"projection_matches\": %d, "
+           "\"ms_extract_stereo_fused\": %.4f}\n",
+           n[0], n[1], pair_ms[iters / 2], single_ms[iters / 2], med(t_st), med(t_fs), med(t_sp), med(t_fr), med(t_all), nm, med(t_fused));
     for (auto& e : ex) msorb_extractor_destroy(e);
     return 0;
 }
