@@ -170,8 +170,8 @@ struct msorb_extractor {
     FrameGraph fgraph[2];        // two cached variants (e.g. mono + stereo lapping settings)
     bool capturing = false;      // enqueue only: no host synchronisation inside the pipeline
     bool defer_sync = false;     // enqueue only, the caller appends more work and synchronises (msorb_extract_stereo)
-    DevBuf<int> d_st_sad, d_st_rows, d_st_list, d_st_oob;  // stereo association scratch of msorb_extract_stereo
-    DevBuf<float> d_st_out;
+    DevBuf<int> d_st_sad, d_st_rows, d_st_list;  // stereo association scratch of msorb_extract_stereo
+    DevBuf<uint8_t> d_st_block, d_st_img;        // its output block and its two level-0 planes
     unsigned long long buffers_epoch = 0;  // bumped whenever a device / pinned buffer may have moved
     unsigned long long graph_epoch = 0;
     hipEvent_t ev_compact = nullptr, ev_pyramid = nullptr, ev_blur = nullptr;
@@ -684,7 +684,7 @@ void msorb_extractor_destroy(msorb_extractor* h) {
     h->d_level_cell_begin.release(); h->d_cell_count.release(); h->d_cell_off.release(); h->d_level_count.release();
     h->d_img_total.release(); h->d_img_base.release(); h->d_sel_count.release(); h->d_slots.release();
     h->d_compact.release(); h->d_sel.release(); h->d_kps1.release();
-    h->d_st_sad.release(); h->d_st_rows.release(); h->d_st_list.release(); h->d_st_oob.release(); h->d_st_out.release();
+    h->d_st_sad.release(); h->d_st_rows.release(); h->d_st_list.release(); h->d_st_block.release(); h->d_st_img.release();
     h->h_level_count.release(); h->h_img_base.release(); h->h_sel_count.release(); h->h_compact.release();
     h->h_sel.release(); h->h_pyr.release(); h->h_img_pin.release(); h->h_out_pin.release();
     for (auto& G : h->grp) {
@@ -894,30 +894,36 @@ int msorb_extract_stereo(msorb_extractor* h, const uint8_t* left, const uint8_t*
     for (int l = 0; l < g.nlevels; l++) smax = std::max(smax, h->scales.scale[l]);
     const int row_cap = cap * ((int)std::ceil(4.0f * smax) + 3);
     if ((size_t)(2 * rows + 1) * sizeof(int) > 60000) { set_error("image too tall for the stereo row table"); return MSORB_E_INVALID; }
-    const size_t kp_bytes = (size_t)cap * sizeof(msorb_keypoint), out_bytes = 2 * kp_bytes + (size_t)2 * cap * 32 + (size_t)2 * cap * 4 + 16;
-    if ((rc = h->d_kps1.ensure((size_t)2 * cap)) || (rc = h->d_desc1.ensure((size_t)2 * cap * 32)) ||
-        (rc = h->h_img_pin.ensure((size_t)2 * g0.pitch * rows)) || (rc = h->h_out_pin.ensure(out_bytes)) ||
-        (rc = h->d_st_sad.ensure(cap)) || (rc = h->d_st_rows.ensure((size_t)rows + 1)) || (rc = h->d_st_list.ensure(row_cap)) ||
-        (rc = h->d_st_oob.ensure(1)) || (rc = h->d_st_out.ensure((size_t)2 * cap)))
-        return rc;
+    // one device block for everything that travels back: [kps 2*cap][desc 2*cap*32][u_right cap][depth cap][n_oob], and
+    // one device block for the two level-0 planes (read in place by the pipeline): one copy each way
+    const size_t kp_bytes = (size_t)cap * sizeof(msorb_keypoint);
+    const size_t o_desc = 2 * kp_bytes, o_ur = o_desc + (size_t)2 * cap * 32, o_dp = o_ur + (size_t)cap * 4,
+                 o_oob = o_dp + (size_t)cap * 4, out_bytes = o_oob + 16;
     const size_t plane = (size_t)g0.pitch * rows;
+    if ((rc = h->d_st_block.ensure(out_bytes)) || (rc = h->d_st_img.ensure(2 * plane + 256)) ||
+        (rc = h->h_img_pin.ensure(2 * plane)) || (rc = h->h_out_pin.ensure(out_bytes)) || (rc = h->d_st_sad.ensure(cap)) ||
+        (rc = h->d_st_rows.ensure((size_t)rows + 1)) || (rc = h->d_st_list.ensure(row_cap)))
+        return rc;
     for (int y = 0; y < rows; y++) {
         memcpy(h->h_img_pin.p + (size_t)y * g0.pitch, left + (size_t)y * stride_left, cols);
         memcpy(h->h_img_pin.p + plane + (size_t)y * g0.pitch, right + (size_t)y * stride_right, cols);
     }
     hipStream_t s = h->stream;
-    HIPCHK(hipMemcpyAsync(h->d_pyr.p + g0.plane_off, h->h_img_pin.p, plane, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->d_pyr.p + g.pyramid_bytes + g0.plane_off, h->h_img_pin.p + plane, plane, hipMemcpyHostToDevice, s));
-    LevelView l0{h->d_pyr.p + g0.plane_off, g.pyramid_bytes, g0.pitch, cols, rows};
+    HIPCHK(hipMemcpyAsync(h->d_st_img.p, h->h_img_pin.p, 2 * plane, hipMemcpyHostToDevice, s));
+    LevelView l0{h->d_st_img.p, plane, g0.pitch, cols, rows};
+    uint8_t* const blk = h->d_st_block.p;
+    msorb_keypoint* const d_kps = reinterpret_cast<msorb_keypoint*>(blk);
+    uint8_t* const d_desc = blk + o_desc;
     int counts[2] = {0, 0}, mono[2] = {0, 0};
+    HIPCHK(hipMemsetAsync(blk + o_oob, 0, sizeof(int), s));
     h->defer_sync = true;
-    rc = run_pipeline(h, l0, 2, 0, 0, h->d_kps1.p, h->d_desc1.p, cap, counts, mono);
+    rc = run_pipeline(h, l0, 2, 0, 0, d_kps, d_desc, cap, counts, mono);
     h->defer_sync = false;
     if (rc) return rc;
     // stereo association on the device outputs (pair 0 = images 0 / 1)
     StereoBatchArgs b{};
-    b.A.kpL = h->d_kps1.p;
-    b.A.descL = h->d_desc1.p;
+    b.A.kpL = d_kps;
+    b.A.descL = d_desc;
     b.A.rows0 = rows;
     for (int l = 0; l < g.nlevels; l++) {
         const LevelView& v = h->last_pyr.lv[l];
@@ -928,18 +934,14 @@ int msorb_extract_stereo(msorb_extractor* h, const uint8_t* left, const uint8_t*
         b.img_stride[l] = v.img_stride;
     }
     b.A.mb = mb; b.A.mbf = mbf;
-    b.A.u_right = h->d_st_out.p; b.A.depth = h->d_st_out.p + cap; b.A.sad = h->d_st_sad.p; b.A.n_oob = h->d_st_oob.p;
+    b.A.u_right = reinterpret_cast<float*>(blk + o_ur); b.A.depth = reinterpret_cast<float*>(blk + o_dp);
+    b.A.sad = h->d_st_sad.p; b.A.n_oob = reinterpret_cast<int*>(blk + o_oob);
     b.capacity = cap;
     b.counts = h->d_sel_count.p;
     b.row_begin = h->d_st_rows.p; b.row_list = h->d_st_list.p; b.row_cap = row_cap;
-    HIPCHK(hipMemsetAsync(h->d_st_oob.p, 0, sizeof(int), s));
     launch_stereo_match_batch(b, 1, cap, s);
-    // everything back in one go (full-capacity blocks: cheaper than a round trip for the counts first)
     uint8_t* o = h->h_out_pin.p;
-    HIPCHK(hipMemcpyAsync(o, h->d_kps1.p, 2 * kp_bytes, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(o + 2 * kp_bytes, h->d_desc1.p, (size_t)2 * cap * 32, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(o + 2 * kp_bytes + (size_t)2 * cap * 32, h->d_st_out.p, (size_t)2 * cap * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(o + 2 * kp_bytes + (size_t)2 * cap * 32 + (size_t)2 * cap * 4, h->d_st_oob.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(o, blk, out_bytes, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     const int nl = h->h_sel_count.p[0], nr = h->h_sel_count.p[1];
@@ -947,12 +949,11 @@ int msorb_extract_stereo(msorb_extractor* h, const uint8_t* left, const uint8_t*
     if (nl > capacity || nr > capacity) { set_error("caller capacity too small"); return MSORB_E_CAPACITY; }
     memcpy(kps_left, o, (size_t)nl * sizeof(msorb_keypoint));
     memcpy(kps_right, o + kp_bytes, (size_t)nr * sizeof(msorb_keypoint));
-    memcpy(desc_left, o + 2 * kp_bytes, (size_t)nl * 32);
-    memcpy(desc_right, o + 2 * kp_bytes + (size_t)cap * 32, (size_t)nr * 32);
-    const float* fo = reinterpret_cast<const float*>(o + 2 * kp_bytes + (size_t)2 * cap * 32);
-    memcpy(u_right, fo, (size_t)nl * sizeof(float));
-    memcpy(depth, fo + cap, (size_t)nl * sizeof(float));
-    if (n_oob) *n_oob = *reinterpret_cast<const int*>(fo + 2 * cap);
+    memcpy(desc_left, o + o_desc, (size_t)nl * 32);
+    memcpy(desc_right, o + o_desc + (size_t)cap * 32, (size_t)nr * 32);
+    memcpy(u_right, o + o_ur, (size_t)nl * sizeof(float));
+    memcpy(depth, o + o_dp, (size_t)nl * sizeof(float));
+    if (n_oob) *n_oob = *reinterpret_cast<const int*>(o + o_oob);
     *n_left = nl;
     *n_right = nr;
     return MSORB_OK;
