@@ -306,12 +306,30 @@ __global__ __launch_bounds__(256) void stereo_rowtable_kernel(StereoBatchArgs B)
     int* row_begin = B.row_begin + (size_t)pair * (rows0 + 1);
     int* row_list = B.row_list + (size_t)pair * B.row_cap;
     for (int r = t; r < rows0; r += 256) cnt[r] = 0;
-    __syncthreads();
-    for (int iR = t; iR < nR; iR += 256) {
+    // each right keypoint's row band, computed once: the first kBandCache rounds of the 256-strided loop keep it in
+    // registers (all their loads in flight together), later rounds (more than 2048 right keypoints) recompute it
+    constexpr int kBandCache = 8;
+    int band[kBandCache];  // minr | maxr << 16, -1 = no keypoint
+    auto band_of = [&](int iR) -> int {
         const msorb_keypoint kr = kpR[iR];
         const float r = __fmul_rn(2.0f, B.A.scale[kr.octave]);
         const int maxr = min((int)ceilf(__fadd_rn(kr.y, r)), rows0 - 1), minr = max((int)floorf(__fsub_rn(kr.y, r)), 0);
-        for (int y = minr; y <= maxr; y++) atomicAdd(&cnt[y], 1);
+        return maxr >= minr ? (minr | (maxr << 16)) : -1;
+    };
+#pragma unroll
+    for (int k = 0; k < kBandCache; k++) {
+        const int iR = t + k * 256;
+        band[k] = iR < nR ? band_of(iR) : -1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kBandCache; k++)
+        if (band[k] >= 0)
+            for (int y = band[k] & 0xffff; y <= (band[k] >> 16); y++) atomicAdd(&cnt[y], 1);
+    for (int iR = t + kBandCache * 256; iR < nR; iR += 256) {
+        const int bd = band_of(iR);
+        if (bd >= 0)
+            for (int y = bd & 0xffff; y <= (bd >> 16); y++) atomicAdd(&cnt[y], 1);
     }
     __syncthreads();
     // exclusive scan of cnt over the rows (rows0 is a few hundred: one wave, sequential chunks)
@@ -335,14 +353,18 @@ __global__ __launch_bounds__(256) void stereo_rowtable_kernel(StereoBatchArgs B)
     for (int r = t; r <= rows0; r += 256) row_begin[r] = beg[r];
     for (int r = t; r < rows0; r += 256) cnt[r] = beg[r];
     __syncthreads();
-    for (int iR = t; iR < nR; iR += 256) {
-        const msorb_keypoint kr = kpR[iR];
-        const float r = __fmul_rn(2.0f, B.A.scale[kr.octave]);
-        const int maxr = min((int)ceilf(__fadd_rn(kr.y, r)), rows0 - 1), minr = max((int)floorf(__fsub_rn(kr.y, r)), 0);
-        for (int y = minr; y <= maxr; y++) {
+    auto fill = [&](int iR, int bd) {
+        for (int y = bd & 0xffff; y <= (bd >> 16); y++) {
             const int pos = atomicAdd(&cnt[y], 1);
             if (pos < B.row_cap) row_list[pos] = iR;
         }
+    };
+#pragma unroll
+    for (int k = 0; k < kBandCache; k++)
+        if (band[k] >= 0) fill(t + k * 256, band[k]);
+    for (int iR = t + kBandCache * 256; iR < nR; iR += 256) {
+        const int bd = band_of(iR);
+        if (bd >= 0) fill(iR, bd);
     }
 }
 
@@ -385,40 +407,65 @@ __global__ __launch_bounds__(256) void stereo_median_kernel(const int* __restric
     float* u_right = u_right_all + (size_t)pair * capacity;
     float* depth = depth_all + (size_t)pair * capacity;
     hist[t] = 0;
+    constexpr int kSadCache = 8;  // the first 2048 SADs of the pair stay in registers for all three passes
+    int sv[kSadCache];
+#pragma unroll
+    for (int k = 0; k < kSadCache; k++) { const int i = t + k * 256; sv[k] = i < nL ? sad[i] : -1; }
     __syncthreads();
-    for (int i = t; i < nL; i += 256) {
+#pragma unroll
+    for (int k = 0; k < kSadCache; k++)
+        if (sv[k] >= 0) atomicAdd(&hist[sv[k] >> 7], 1);
+    for (int i = t + kSadCache * 256; i < nL; i += 256) {
         const int v = sad[i];
         if (v >= 0) atomicAdd(&hist[v >> 7], 1);
     }
     __syncthreads();
-    if (t == 0) {
-        int total = 0;
-        for (int b = 0; b < 256; b++) total += hist[b];
-        int k = total / 2, b = 0;
-        if (total > 0)
-            while (k >= hist[b]) { k -= hist[b]; b++; }
-        sel[0] = b; sel[1] = k; sel[2] = total;
-    }
-    __syncthreads();
+    // rank search over 256 bins by all threads: inclusive prefix (wave shuffles + wave totals), the bin whose prefix
+    // interval holds rank total/2 announces itself
+    __shared__ int wave_tot[4];
+    auto find_bin = [&](int nbins, int k_or_half) {  // k_or_half < 0: rank = total / 2
+        const int v = t < nbins ? hist[t] : 0;
+        int inc = v;
+        const int lane = t & 63, w = t >> 6;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int u = __shfl_up(inc, off);
+            if (lane >= off) inc += u;
+        }
+        if (lane == 63) wave_tot[w] = inc;
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int c = wave_tot[i]; if (i < w) before += c; total += c; }
+        const int k = k_or_half < 0 ? total / 2 : k_or_half;
+        const int excl = before + inc - v;
+        if (v > 0 && excl <= k && k < excl + v) { sel[0] = t; sel[1] = k - excl; }
+        if (t == 0) sel[2] = total;
+        __syncthreads();
+    };
+    find_bin(256, -1);
     const int hb = sel[0], kk = sel[1], total = sel[2];
     if (total == 0) return;  // vDistIdx empty: nothing to reject (the reference would index an empty vector)
     __syncthreads();
-    if (t < 128) hist[t] = 0;
+    hist[t] = 0;
     __syncthreads();
-    for (int i = t; i < nL; i += 256) {
+#pragma unroll
+    for (int k = 0; k < kSadCache; k++)
+        if (sv[k] >= 0 && (sv[k] >> 7) == hb) atomicAdd(&hist[sv[k] & 127], 1);
+    for (int i = t + kSadCache * 256; i < nL; i += 256) {
         const int v = sad[i];
         if (v >= 0 && (v >> 7) == hb) atomicAdd(&hist[v & 127], 1);
     }
     __syncthreads();
-    if (t == 0) {
-        int k = kk, b = 0;
-        while (k >= hist[b]) { k -= hist[b]; b++; }
-        sel[0] = (hb << 7) | b;
-    }
-    __syncthreads();
-    const float median = (float)sel[0];
+    find_bin(128, kk);
+    const float median = (float)((hb << 7) | sel[0]);
     const float thDist = __fmul_rn(__fmul_rn(1.5f, 1.4f), median);
-    for (int i = t; i < nL; i += 256) {
+#pragma unroll
+    for (int k = 0; k < kSadCache; k++) {
+        const int i = t + k * 256;
+        if (sv[k] >= 0 && !((float)sv[k] < thDist)) { u_right[i] = -1.0f; depth[i] = -1.0f; }
+    }
+    for (int i = t + kSadCache * 256; i < nL; i += 256) {
         const int v = sad[i];
         if (v >= 0 && !((float)v < thDist)) { u_right[i] = -1.0f; depth[i] = -1.0f; }
     }

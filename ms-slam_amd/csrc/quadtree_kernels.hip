@@ -208,6 +208,39 @@ __global__ __launch_bounds__(256) void quadtree_layout_kernel(QtLevels lv, const
     const int per = (n + 255) / 256;
     const int b = tid * per, e = min(b + per, n);
     SelRec* out = sel + (size_t)img * sel_stride;
+    if (lap1 < kMinBorder) {
+        // no lapping area (mono / rectified stereo: every x is >= kMinBorder, so fx <= lap1 never holds): output row =
+        // selection order, no second pass.  Items are taken 256 apart, four at a time, so that the two dependent loads
+        // of an item (selected index -> candidate) are in flight for four items at once.
+        for (int base = 0; base < n; base += 4 * 256) {
+            int gg[4], ll[4], pt[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                gg[u] = base + u * 256 + tid;
+                int l = 0;
+                if (gg[u] < n) while (gg[u] >= lvl_begin[l + 1]) l++;
+                ll[u] = l;
+                pt[u] = gg[u] < n ? sel_pt[(size_t)img * sel_stride + lv.sel_off[l] + (gg[u] - lvl_begin[l])] : 0;
+            }
+            Cand16 cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) cc[u] = gg[u] < n ? compact[cand_begin[ll[u]] + pt[u]] : Cand16{};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (gg[u] >= n) continue;
+                SelRec r;
+                r.x = (uint16_t)(cc[u].x + kMinBorder); r.y = (uint16_t)(cc[u].y + kMinBorder);
+                r.score = cc[u].score; r.level = (uint8_t)ll[u]; r.pad = 0;
+                r.dst = gg[u];
+                out[gg[u]] = r;
+            }
+        }
+        if (tid == 0) {
+            sel_count[img] = n_all > n ? -n_all : n;
+            mono_out[img] = n;
+        }
+        return;
+    }
     int lap_cnt = 0;
     for (int g = b; g < e; g++) {
         int l = 0;
