@@ -592,55 +592,61 @@ __global__ __launch_bounds__(256) void cand_scan_cells_kernel(const int* __restr
                                                               const int* __restrict__ level_cell_begin, int nlevels,
                                                               int* __restrict__ cell_off, int* __restrict__ level_count,
                                                               int* __restrict__ img_total) {
-    __shared__ int part[256];
+    __shared__ int wave_tot[4];
     __shared__ int lvl[kMaxLevels];
-    const int img = blockIdx.x, tid = threadIdx.x;
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int* cnt = cell_count + (size_t)img * n_cells;
     int* off = cell_off + (size_t)img * n_cells;
     const int per = (n_cells + 255) / 256;
     const int b = tid * per, e = min(b + per, n_cells);
+    // the thread's counts are read once (the first kCache of them stay in registers, their loads in flight together)
+    constexpr int kCache = 4;
+    int c[kCache];
+#pragma unroll
+    for (int k = 0; k < kCache; k++) c[k] = b + k < e ? cnt[b + k] : 0;
     int s = 0;
-    for (int i = b; i < e; i++) s += cnt[i];
-    part[tid] = s;
+#pragma unroll
+    for (int k = 0; k < kCache; k++) s += c[k];
+    for (int i = b + kCache; i < e; i++) s += cnt[i];
     if (tid < kMaxLevels) lvl[tid] = 0;
-    __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int i = 0; i < 256; i++) { const int v = part[i]; part[i] = acc; acc += v; }
-        img_total[img] = acc;
-    }
-    __syncthreads();
-    int acc = part[tid];
-    for (int i = b; i < e; i++) { off[i] = acc; acc += cnt[i]; }
-    // per-level totals
-    for (int l = 0; l < nlevels; l++) {
-        const int lb = level_cell_begin[l], le = level_cell_begin[l + 1];
-        int t = 0;
-        for (int i = max(b, lb); i < min(e, le); i++) t += cnt[i];
-        if (t) atomicAdd(&lvl[l], t);
-    }
+    int total = 0;
+    int acc = block_excl_scan<4>(s, lane, wave, wave_tot, &total);
+    if (tid == 0) img_total[img] = total;
+    // offsets + per-level totals (a thread's cells are consecutive: they span at most a few levels)
+    int cur_l = 0, cur_t = 0;
+    auto visit = [&](int i, int v) {
+        off[i] = acc;
+        acc += v;
+        while (i >= level_cell_begin[cur_l + 1]) {
+            if (cur_t) atomicAdd(&lvl[cur_l], cur_t);
+            cur_t = 0;
+            cur_l++;
+        }
+        cur_t += v;
+    };
+#pragma unroll
+    for (int k = 0; k < kCache; k++)
+        if (b + k < e) visit(b + k, c[k]);
+    for (int i = b + kCache; i < e; i++) visit(i, cnt[i]);
+    if (cur_t) atomicAdd(&lvl[cur_l], cur_t);
     __syncthreads();
     if (tid < nlevels) level_count[(size_t)img * nlevels + tid] = lvl[tid];
 }
 
 __global__ __launch_bounds__(256) void cand_scan_images_kernel(const int* __restrict__ img_total, int n_images,
                                                                int* __restrict__ img_base /* n_images+1 */) {
-    __shared__ int part[256];
-    const int tid = threadIdx.x;
+    __shared__ int wave_tot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (n_images + 255) / 256;
     const int b = tid * per, e = min(b + per, n_images);
-    int s = 0;
-    for (int i = b; i < e; i++) s += img_total[i];
-    part[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int i = 0; i < 256; i++) { const int v = part[i]; part[i] = acc; acc += v; }
-        img_base[n_images] = acc;
-    }
-    __syncthreads();
-    int acc = part[tid];
-    for (int i = b; i < e; i++) { img_base[i] = acc; acc += img_total[i]; }
+    const int first = b < e ? img_total[b] : 0;
+    int s = first;
+    for (int i = b + 1; i < e; i++) s += img_total[i];
+    int total = 0;
+    int acc = block_excl_scan<4>(s, lane, wave, wave_tot, &total);
+    if (tid == 0) img_base[n_images] = total;
+    if (b < e) { img_base[b] = acc; acc += first; }
+    for (int i = b + 1; i < e; i++) { img_base[i] = acc; acc += img_total[i]; }
 }
 
 __global__ __launch_bounds__(64) void cand_gather_kernel(const CellDesc* __restrict__ cells, int n_cells,
