@@ -379,8 +379,10 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
     h->last_groups = ng;
     static const bool stagger_env = getenv("MSORB_STAGGER") != nullptr;  // measured: no gain (2.648 vs 2.653 ms), off by default
     const bool stagger = stagger_env && ng > 1;
-    // the new call must not start before the handle's own stream has drained (H2D of level 0 in msorb_extract)
-    if (!h->capturing) HIPCHK(hipStreamSynchronize(h->stream));
+    // sub-batches on streams of their own must not start before the handle's stream has drained (H2D of level 0 in
+    // msorb_extract); a single group runs on that very stream, where the order is implicit — and the launches below are
+    // then issued while the copy is still in flight instead of after it
+    if (!h->capturing && ng > 1) HIPCHK(hipStreamSynchronize(h->stream));
     int first = 0;
     for (int gi = 0; gi < ng; gi++) {
         int rc;
