@@ -434,8 +434,10 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
                         d_kps + (size_t)first * capacity, d_desc + (size_t)first * capacity * 32, capacity,
                         std::min(capacity, sel_stride), n, s);
         mark(6, s);
-        HIPCHK(hipMemcpyAsync(h->h_sel_count.p + first, h->d_sel_count.p + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(h->h_mono.p + first, h->d_mono.p + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+        if (!h->defer_sync) {  // a fused caller takes the counts from the device itself
+            HIPCHK(hipMemcpyAsync(h->h_sel_count.p + first, h->d_sel_count.p + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(h->h_mono.p + first, h->d_mono.p + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+        }
         first += n;
     }
     if (h->capturing || h->defer_sync) return MSORB_OK;  // graph capture / fused call: the caller synchronises and reads back
@@ -900,7 +902,7 @@ int msorb_extract_stereo(msorb_extractor* h, const uint8_t* left, const uint8_t*
     // one device block for the two level-0 planes (read in place by the pipeline): one copy each way
     const size_t kp_bytes = (size_t)cap * sizeof(msorb_keypoint);
     const size_t o_desc = 2 * kp_bytes, o_ur = o_desc + (size_t)2 * cap * 32, o_dp = o_ur + (size_t)cap * 4,
-                 o_oob = o_dp + (size_t)cap * 4, out_bytes = o_oob + 16;
+                 o_oob = o_dp + (size_t)cap * 4, o_cnt = o_oob + 4, out_bytes = o_oob + 16;  // [n_oob][n_left][n_right]
     const size_t plane = (size_t)g0.pitch * rows;
     if ((rc = h->d_st_block.ensure(out_bytes)) || (rc = h->d_st_img.ensure(2 * plane + 256)) ||
         (rc = h->h_img_pin.ensure(2 * plane)) || (rc = h->h_out_pin.ensure(out_bytes)) || (rc = h->d_st_sad.ensure(cap)) ||
@@ -941,12 +943,13 @@ int msorb_extract_stereo(msorb_extractor* h, const uint8_t* left, const uint8_t*
     b.capacity = cap;
     b.counts = h->d_sel_count.p;
     b.row_begin = h->d_st_rows.p; b.row_list = h->d_st_list.p; b.row_cap = row_cap;
+    b.counts_out = reinterpret_cast<int*>(blk + o_cnt);
     launch_stereo_match_batch(b, 1, cap, s);
     uint8_t* o = h->h_out_pin.p;
     HIPCHK(hipMemcpyAsync(o, blk, out_bytes, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
-    const int nl = h->h_sel_count.p[0], nr = h->h_sel_count.p[1];
+    const int nl = reinterpret_cast<const int*>(o + o_cnt)[0], nr = reinterpret_cast<const int*>(o + o_cnt)[1];
     if (nl < 0 || nr < 0) { set_error("keypoint capacity exceeded"); return MSORB_E_CAPACITY; }
     if (nl > capacity || nr > capacity) { set_error("caller capacity too small"); return MSORB_E_CAPACITY; }
     memcpy(kps_left, o, (size_t)nl * sizeof(msorb_keypoint));

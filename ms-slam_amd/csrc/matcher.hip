@@ -398,11 +398,12 @@ __global__ __launch_bounds__(256) void stereo_match_batch_kernel(StereoBatchArgs
 // smaller value: the same set).
 __global__ __launch_bounds__(256) void stereo_median_kernel(const int* __restrict__ counts, int capacity,
                                                             const int* __restrict__ sad_all, float* __restrict__ u_right_all,
-                                                            float* __restrict__ depth_all) {
+                                                            float* __restrict__ depth_all, int* __restrict__ counts_out) {
     __shared__ int hist[256];
     __shared__ int sel[3];  // chosen high bin, rank inside it, number of valid SADs
     const int pair = blockIdx.x, t = threadIdx.x;
     const int nL = counts[2 * pair];
+    if (counts_out && t < 2) counts_out[2 * pair + t] = counts[2 * pair + t];
     const int* sad = sad_all + (size_t)pair * capacity;
     float* u_right = u_right_all + (size_t)pair * capacity;
     float* depth = depth_all + (size_t)pair * capacity;
@@ -492,7 +493,7 @@ void launch_stereo_match_batch(const StereoBatchArgs& b, int n_pairs, int max_le
     hipLaunchKernelGGL(stereo_rowtable_kernel, dim3(n_pairs), dim3(256), (size_t)(2 * b.A.rows0 + 1) * sizeof(int), s, b);
     hipLaunchKernelGGL(stereo_match_batch_kernel, dim3((max_left + 3) / 4, n_pairs), dim3(256), 0, s, b);
     hipLaunchKernelGGL(stereo_median_kernel, dim3(n_pairs), dim3(256), 0, s, b.counts, b.capacity, b.A.sad, b.A.u_right,
-                       b.A.depth);
+                       b.A.depth, b.counts_out);
 }
 
 // Dense brute-force top-2 (SURVEY.md K6 "dense mode"; the knnMatch(k=2) shape of Frame.cc:1076): every query

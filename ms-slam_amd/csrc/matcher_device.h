@@ -56,6 +56,7 @@ struct StereoBatchArgs {  // A: the pointers of image 0 / pair 0; everything els
     const int* counts;  // device: n_keypoints per image
     int *row_begin, *row_list;  // per pair: [rows0 + 1] and [row_cap]
     int row_cap;
+    int* counts_out;            // optional: the median kernel copies counts[2p], counts[2p+1] here (fused per-frame call)
 };
 
 void launch_window_topk(const FrameView& F, const WinQuery* q, const uint8_t* qdesc, int q_begin, int q_end,
