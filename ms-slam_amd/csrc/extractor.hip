@@ -169,9 +169,11 @@ struct msorb_extractor {
     struct FrameGraph { hipGraphExec_t exec = nullptr; int lap0 = 0, lap1 = 0, rows = 0, cols = 0; };
     FrameGraph fgraph[2];        // two cached variants (e.g. mono + stereo lapping settings)
     bool capturing = false;      // enqueue only: no host synchronisation inside the pipeline
-    bool defer_sync = false;     // enqueue only, the caller appends more work and synchronises (msorb_extract_stereo)
+    bool defer_sync = false;     // enqueue only, the caller appends more work and synchronises (msorb_extract[_stereo])
+    bool skip_count_copies = false;  // with defer_sync: the caller fetches the counts from the device itself
     DevBuf<int> d_st_sad, d_st_rows, d_st_list;  // stereo association scratch of msorb_extract_stereo
     DevBuf<uint8_t> d_st_block, d_st_img;        // its output block and its two level-0 planes
+    DevBuf<uint8_t> d_out1;                      // msorb_extract: keypoints + descriptors of one frame as one block
     unsigned long long buffers_epoch = 0;  // bumped whenever a device / pinned buffer may have moved
     unsigned long long graph_epoch = 0;
     hipEvent_t ev_compact = nullptr, ev_pyramid = nullptr, ev_blur = nullptr;
@@ -434,7 +436,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
                         d_kps + (size_t)first * capacity, d_desc + (size_t)first * capacity * 32, capacity,
                         std::min(capacity, sel_stride), n, s);
         mark(6, s);
-        if (!h->defer_sync) {  // a fused caller takes the counts from the device itself
+        if (!h->skip_count_copies) {  // a fused caller takes the counts from the device itself
             HIPCHK(hipMemcpyAsync(h->h_sel_count.p + first, h->d_sel_count.p + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHK(hipMemcpyAsync(h->h_mono.p + first, h->d_mono.p + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
         }
@@ -688,7 +690,7 @@ void msorb_extractor_destroy(msorb_extractor* h) {
     h->d_level_cell_begin.release(); h->d_cell_count.release(); h->d_cell_off.release(); h->d_level_count.release();
     h->d_img_total.release(); h->d_img_base.release(); h->d_sel_count.release(); h->d_slots.release();
     h->d_compact.release(); h->d_sel.release(); h->d_kps1.release();
-    h->d_st_sad.release(); h->d_st_rows.release(); h->d_st_list.release(); h->d_st_block.release(); h->d_st_img.release();
+    h->d_st_sad.release(); h->d_st_rows.release(); h->d_st_list.release(); h->d_st_block.release(); h->d_st_img.release(); h->d_out1.release();
     h->h_level_count.release(); h->h_img_base.release(); h->h_sel_count.release(); h->h_compact.release();
     h->h_sel.release(); h->h_pyr.release(); h->h_img_pin.release(); h->h_out_pin.release();
     for (auto& G : h->grp) {
@@ -849,6 +851,27 @@ int msorb_extract(msorb_extractor* h, const uint8_t* image, int rows, int cols, 
         mono = h->h_mono.p[0];
         if (n < 0) { set_error("keypoint capacity exceeded"); return MSORB_E_CAPACITY; }
         if (n > capacity) { set_error("caller capacity too small"); return MSORB_E_CAPACITY; }
+    } else if (h->device_quadtree && !getenv("MSORB_SERIAL_PIPELINE") && !h->profiling) {
+        // device pipeline: nothing in it needs the host, so the whole frame is enqueued, the full-capacity output block
+        // (keypoints + descriptors, ~120 KB) follows in ONE copy and the call synchronises once
+        const size_t o_desc = ((size_t)cap * sizeof(msorb_keypoint) + 15) & ~(size_t)15, blk_bytes = o_desc + (size_t)cap * 32;
+        if ((rc = h->d_out1.ensure(blk_bytes))) return rc;
+        if ((rc = h->h_out_pin.ensure(blk_bytes))) return rc;
+        pk = reinterpret_cast<msorb_keypoint*>(h->h_out_pin.p);
+        pd = h->h_out_pin.p + o_desc;
+        HIPCHK(hipMemcpyAsync(h->d_pyr.p + g0.plane_off, h->h_img_pin.p, (size_t)g0.pitch * rows, hipMemcpyHostToDevice,
+                              h->stream));
+        h->defer_sync = true;
+        rc = run_pipeline(h, l0, 1, lap0, lap1, reinterpret_cast<msorb_keypoint*>(h->d_out1.p), h->d_out1.p + o_desc, cap, &n, &mono);
+        h->defer_sync = false;
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(h->h_out_pin.p, h->d_out1.p, blk_bytes, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipGetLastError());
+        n = h->h_sel_count.p[0];
+        mono = h->h_mono.p[0];
+        if (n < 0) { set_error("keypoint capacity exceeded"); return MSORB_E_CAPACITY; }
+        if (n > capacity) { set_error("caller capacity too small"); return MSORB_E_CAPACITY; }
     } else {
         HIPCHK(hipMemcpyAsync(h->d_pyr.p + g0.plane_off, h->h_img_pin.p, (size_t)g0.pitch * rows, hipMemcpyHostToDevice,
                               h->stream));
@@ -920,9 +943,9 @@ int msorb_extract_stereo(msorb_extractor* h, const uint8_t* left, const uint8_t*
     uint8_t* const d_desc = blk + o_desc;
     int counts[2] = {0, 0}, mono[2] = {0, 0};
     HIPCHK(hipMemsetAsync(blk + o_oob, 0, sizeof(int), s));
-    h->defer_sync = true;
+    h->defer_sync = h->skip_count_copies = true;
     rc = run_pipeline(h, l0, 2, 0, 0, d_kps, d_desc, cap, counts, mono);
-    h->defer_sync = false;
+    h->defer_sync = h->skip_count_copies = false;
     if (rc) return rc;
     // stereo association on the device outputs (pair 0 = images 0 / 1)
     StereoBatchArgs b{};
