@@ -28,6 +28,7 @@ int main(int argc, char** argv) {
     const int rows = 376, cols = 1241, iters = argc > 1 ? atoi(argv[1]) : 300;
     msorb_extractor* ex[2];
     for (auto& e : ex) if (msorb_extractor_create(2000, 1.2f, 8, 20, 7, 0, &e)) { printf("create: %s\n", msorb_last_error()); return 1; }
+    if (getenv("LAT_SERIAL_BLUR")) for (auto& e : ex) msorb_extractor_set_overlap(e, 2, 0);  // experiment: blur on the main stream
     std::vector<uint8_t> img[2];
     synth(img[0], rows, cols, 1); synth(img[1], rows, cols, 2);
     const int cap = 2000 + 3 * 8 + 64;
@@ -116,6 +117,7 @@ int main(int argc, char** argv) {
     {
         msorb_extractor* fx = nullptr;
         if (msorb_extractor_create(2000, 1.2f, 8, 20, 7, 0, &fx)) { printf("create: %s\n", msorb_last_error()); return 1; }
+        if (getenv("LAT_SERIAL_BLUR")) msorb_extractor_set_overlap(fx, 2, 0);
         int nl = 0, nr2 = 0, oob2 = 0;
         for (int i = 0; i < 5 + iters; i++) {
             const auto t0 = std::chrono::steady_clock::now();
