@@ -88,7 +88,10 @@ int msorb_pyramid_level(msorb_extractor* h, int level, const uint8_t** data, int
  * i*image_stride, rows of row_stride bytes).  Outputs stay on the device: image i's keypoints at
  * d_keypoints + i*capacity, descriptors at d_descriptors + i*capacity*32.  h_counts[i] / h_mono[i]
  * (host arrays, n_images entries, h_mono may be NULL) receive n_keypoints / mono_index.
- * Level 0 is read in place from d_images (it must stay valid until the call returns). */
+ * Level 0 is read in place from d_images (it must stay valid until the call returns); rows that are not 4-byte
+ * aligned work too — big batches of them (>= 128 images) are first copied into aligned planes owned by the handle,
+ * which is faster than running the byte-granular kernel variants (1.88 vs 2.08 ms per 256 KITTI images; 1.72 ms with a
+ * 64-byte row pitch). */
 int msorb_extract_batch(msorb_extractor* h, const uint8_t* d_images, int n_images, int rows, int cols,
                         size_t row_stride, size_t image_stride, int lap0, int lap1, msorb_keypoint* d_keypoints,
                         uint8_t* d_descriptors, int capacity, int* h_counts, int* h_mono);

@@ -1185,6 +1185,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 }
 
 // ---- launch wrappers (called from extractor.hip) --------------------------------------------------
+// Level 0 of a batch whose rows are not 4-byte aligned (e.g. tightly packed 1241-pixel rows): copied once into the
+// handle's aligned level-0 planes, so that every later kernel takes its aligned variant (the byte-granular variants of
+// FAST / blur / pyramid are 1.7-2x slower than this copy costs).
+__global__ __launch_bounds__(256) void stage_level0_kernel(const uint8_t* __restrict__ src, size_t row_stride, size_t image_stride,
+                                                           uint8_t* __restrict__ dst, int dst_pitch, size_t dst_image_stride,
+                                                           int cols) {
+    const int g = blockIdx.x * 256 + threadIdx.x;  // 4-pixel group of the row
+    const int x = 4 * g;
+    if (x >= cols) return;
+    const uint8_t* s = src + (size_t)blockIdx.z * image_stride + (size_t)blockIdx.y * row_stride + x;
+    uint32_t v = s[0];
+    if (x + 1 < cols) v |= (uint32_t)s[1] << 8;
+    if (x + 2 < cols) v |= (uint32_t)s[2] << 16;
+    if (x + 3 < cols) v |= (uint32_t)s[3] << 24;
+    *reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.z * dst_image_stride + (size_t)blockIdx.y * dst_pitch + x) = v;
+}
+void launch_stage_level0(const LevelView& src, uint8_t* dst, int dst_pitch, size_t dst_image_stride, int n_images, hipStream_t s) {
+    hipLaunchKernelGGL(stage_level0_kernel, dim3((src.w + 1023) / 1024, src.h, n_images), dim3(256), 0, s, src.base, (size_t)src.pitch,
+                       src.img_stride, dst, dst_pitch, dst_image_stride, src.w);
+}
 void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_base, const ResizeTap* tx,
                        const ResizeTap* ty, int n_images, hipStream_t s) {
     dim3 grid((dst.w + 255) / 256, (dst.h + 3) / 4, n_images);

@@ -288,3 +288,38 @@ print("graph-ok")
     env = dict(os.environ, MSORB_GRAPH="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert "graph-ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_misaligned_batch_staged_and_in_place(msorb_mod, oracle):
+    """Tightly packed rows that are not 4-byte aligned (KITTI: 1241 pixels): by default level 0 is staged once into the
+    handle's aligned planes and the aligned kernels run; MSORB_NO_STAGE0 keeps the byte-granular in-place variants.
+    Both must equal the oracle."""
+    import os
+    import torch
+    cfg = CONFIGS["kitti"]
+    ex, ref = _pair(msorb_mod, oracle, cfg)
+    n = 16                                             # MSORB_STAGE0_MIN=1 below: staging normally starts at 128 images
+    batch = np.stack([synth.image(800 + (i % 3), cfg["rows"], cfg["cols"]) for i in range(n)])
+    d = torch.from_numpy(batch).cuda()
+    assert d.stride(1) % 4 != 0
+    want = [ref(batch[i]) for i in range(3)]
+    try:
+        for mode in ("staged", "in_place"):
+            os.environ["MSORB_STAGE0_MIN"] = "1"
+            if mode == "in_place":
+                os.environ["MSORB_NO_STAGE0"] = "1"
+            else:
+                os.environ.pop("MSORB_NO_STAGE0", None)
+            counts, mono, d_kps, d_desc = ex.extract_batch(d)
+            kps_list = msorb_mod.keypoints_from_device(d_kps, counts)
+            desc_all = d_desc.cpu().numpy()
+            for i in range(n):
+                rmono, rkps, rdesc = want[i % 3]
+                assert counts[i] == len(rkps) and mono[i] == rmono, (mode, i)
+                _assert_same(kps_list[i], desc_all[i, :counts[i]], rkps, rdesc)
+            # the staged copy must not touch the caller's images
+            assert torch.equal(d, torch.from_numpy(batch).cuda())
+    finally:
+        os.environ.pop("MSORB_NO_STAGE0", None)
+        os.environ.pop("MSORB_STAGE0_MIN", None)
+        ex.close()
