@@ -1,0 +1,170 @@
+"""Consumer of the OpenCV pin kit (tools/pin_opencv.py): compares oracle/ — the CPU restatement every GPU parity test
+is checked against — with outputs of the REAL OpenCV primitives the reference calls
+(ORBextractor.cc:102 fastAtan2, :826/:845 FAST, :1133 GaussianBlur, :1183 resize).
+
+* `test_pins_against_real_opencv` runs when tests/golden/opencv_pins/ holds fixtures produced by one run of the kit on
+  a machine with cv2 (this image has none: the test then SKIPS and parity stays "unpinned" for those four primitives).
+* `test_pins_live_cv2` does the same in-process wherever cv2 happens to be importable.
+* `test_pin_kit_plumbing` proves the kit and this consumer work end to end without cv2, by handing the kit a stand-in
+  "cv" object backed by the oracle — so the first real run cannot fail for plumbing reasons.
+"""
+import hashlib
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PINS = os.path.join(ROOT, "tests", "golden", "opencv_pins")
+
+
+def _kit():
+    spec = importlib.util.spec_from_file_location("pin_opencv", os.path.join(ROOT, "tools", "pin_opencv.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def compare(oracle, pins_dir):
+    """-> list of human-readable mismatches between the oracle and the fixtures in pins_dir (empty = pinned)."""
+    kit = _kit()
+    meta = json.load(open(os.path.join(pins_dir, "meta.json")))
+    bad = []
+    # A.3 resize: 11-bit fixed-point bilinear, coefficient rounding, edge clamp
+    z = np.load(os.path.join(pins_dir, "resize_linear.npz"))
+    for i, (name, sr, sc, dr, dc) in enumerate(kit.RESIZE_CASES):
+        src = kit.pin_image(100 + i, sr, sc)
+        assert kit.sha(src) == meta["resize_inputs_sha256"][name], f"input of {name} differs from the generating run"
+        got = oracle.resize_linear_u8(src, dr, dc)
+        if not np.array_equal(got, z[name]):
+            d = np.argwhere(got != z[name])
+            bad.append(f"resize {name}: {len(d)} of {got.size} pixels differ, first at (y,x)={tuple(d[0])} "
+                       f"oracle {got[tuple(d[0])]} vs OpenCV {z[name][tuple(d[0])]}")
+    # A.5 blur: Q8.8 kernel [18,34,48,56,48,34,18], reflect-101, (x + 2^15) >> 16
+    z = np.load(os.path.join(pins_dir, "gaussian7.npz"))
+    for i, (name, r, c) in enumerate(kit.BLUR_CASES):
+        src = kit.pin_image(200 + i, r, c)
+        assert kit.sha(src) == meta["blur_inputs_sha256"][name]
+        got = oracle.gaussian7(src)
+        if not np.array_equal(got, z[name]):
+            d = np.argwhere(got != z[name])
+            bad.append(f"blur {name}: {len(d)} of {got.size} pixels differ, max |diff| "
+                       f"{int(np.abs(got.astype(int) - z[name].astype(int)).max())}")
+    # A.4 FAST: circle, strict 9-arc test, cornerScore, strict 3x3 NMS inside the call's ROI, scan order
+    z = np.load(os.path.join(pins_dir, "fast9_nms.npz"))
+    rois = kit.fast_inputs()
+    assert kit.sha(np.concatenate([r.ravel() for r in rois])) == meta["fast_inputs_sha256"]
+    for th in kit.FAST_THRESHOLDS:
+        for i, roi in enumerate(rois):
+            want = z[f"th{th}_roi{i}"].reshape(-1, 3)
+            got = oracle.fast9_nms(roi, th).reshape(-1, 3)
+            if got.shape != want.shape or not np.array_equal(got, want):
+                bad.append(f"FAST th={th} roi {i}: oracle {len(got)} keypoints vs OpenCV {len(want)}"
+                           + ("" if got.shape != want.shape else f", first differing row {int(np.argwhere((got != want).any(1))[0][0])}"))
+    # A.6 fastAtan2: polynomial, octant fix-ups, float evaluation order
+    z = np.load(os.path.join(pins_dir, "fast_atan2.npz"))
+    y, x = kit.atan2_inputs()
+    assert kit.sha(np.stack([y, x])) == meta["atan2_inputs_sha256"]
+    got = np.array([oracle.fast_atan2(a, b) for a, b in zip(y, x)], np.float32).view(np.uint32)
+    if not np.array_equal(got, z["bits"]):
+        d = np.flatnonzero(got != z["bits"])
+        bad.append(f"fastAtan2: {len(d)} of {len(got)} bit patterns differ, first (y,x)=({y[d[0]]},{x[d[0]]}) "
+                   f"oracle {got[d[0]:d[0] + 1].view(np.float32)[0]!r} vs OpenCV {z['bits'][d[0]:d[0] + 1].view(np.float32)[0]!r}")
+    return bad, meta
+
+
+def test_pin_inputs_are_machine_independent():
+    """pin_image / atan2_inputs are integer hashes: their bytes are constants of the kit (guards numpy drift)."""
+    kit = _kit()
+    assert hashlib.sha256(kit.pin_image(100, 376, 1241).tobytes()).hexdigest()[:16] == PIN_IMAGE_100_SHA16
+    y, x = kit.atan2_inputs()
+    assert kit.sha(np.stack([y, x]))[:16] == ATAN2_INPUTS_SHA16
+    img = kit.pin_image(500, 57, 46)
+    assert img.min() < 60 and img.max() > 170          # textured: FAST has work at both thresholds
+
+
+def test_pins_against_real_opencv(oracle):
+    if not os.path.exists(os.path.join(PINS, "meta.json")):
+        pytest.skip("no OpenCV pins committed yet: run tools/pin_opencv.py on a machine with cv2 (README) — "
+                    "until then the oracle is PARITY UNPINNED for resize / FAST / GaussianBlur / fastAtan2")
+    bad, meta = compare(oracle, PINS)
+    assert not bad, f"oracle differs from OpenCV {meta['cv2_version']}:\n" + "\n".join(bad)
+
+
+def test_pins_live_cv2(oracle, tmp_path):
+    cv2 = pytest.importorskip("cv2")
+    kit = _kit()
+    kit.generate(cv2, str(tmp_path))
+    bad, meta = compare(oracle, str(tmp_path))
+    assert not bad, f"oracle differs from OpenCV {meta['cv2_version']}:\n" + "\n".join(bad)
+
+
+class _OracleAsCv:
+    """Stand-in with the five cv2 entry points the kit calls, answered by the oracle (plumbing test only)."""
+    __version__ = "oracle-stand-in"
+    INTER_LINEAR = 1
+    BORDER_REFLECT_101 = 4
+    FAST_FEATURE_DETECTOR_TYPE_9_16 = 2
+
+    def __init__(self, oracle):
+        self.o = oracle
+
+    def getBuildInformation(self):
+        return "Version control: stand-in\n"
+
+    def resize(self, src, dsize, interpolation):
+        assert interpolation == self.INTER_LINEAR
+        return self.o.resize_linear_u8(src, dsize[1], dsize[0])
+
+    def GaussianBlur(self, src, ksize, sx, sy, borderType):
+        assert ksize == (7, 7) and sx == 2 and sy == 2 and borderType == self.BORDER_REFLECT_101
+        return self.o.gaussian7(src)
+
+    def fastAtan2(self, y, x):
+        return self.o.fast_atan2(y, x)
+
+    def FastFeatureDetector_create(self, threshold, nonmaxSuppression, type):
+        assert nonmaxSuppression and type == self.FAST_FEATURE_DETECTOR_TYPE_9_16
+        o = self.o
+
+        class KP:
+            def __init__(self, r):
+                self.pt, self.response = (float(r[0]), float(r[1])), float(r[2])
+
+        class Det:
+            def detect(self, roi, mask):
+                return [KP(r) for r in o.fast9_nms(roi, threshold).reshape(-1, 3)]
+        return Det()
+
+
+def test_pin_kit_plumbing(oracle, tmp_path):
+    kit = _kit()
+    meta = kit.generate(_OracleAsCv(oracle), str(tmp_path))
+    assert meta["cv2_version"] == "oracle-stand-in"
+    for f in ("resize_linear.npz", "gaussian7.npz", "fast9_nms.npz", "fast_atan2.npz", "meta.json"):
+        assert os.path.getsize(os.path.join(str(tmp_path), f)) > 0
+    bad, _ = compare(oracle, str(tmp_path))
+    assert bad == []
+    # the comparison has teeth: a one-pixel / one-ulp / one-keypoint change in a fixture is reported
+    z = dict(np.load(os.path.join(str(tmp_path), "gaussian7.npz")))
+    z["tiny"] = z["tiny"].copy()
+    z["tiny"][0, 0] ^= 1
+    np.savez_compressed(os.path.join(str(tmp_path), "gaussian7.npz"), **z)
+    z = dict(np.load(os.path.join(str(tmp_path), "fast_atan2.npz")))
+    z["bits"] = z["bits"].copy()
+    z["bits"][5] += 1
+    np.savez_compressed(os.path.join(str(tmp_path), "fast_atan2.npz"), **z)
+    bad, _ = compare(oracle, str(tmp_path))
+    assert len(bad) == 2 and bad[0].startswith("blur tiny") and bad[1].startswith("fastAtan2")
+    # FAST fixtures are not degenerate: keypoints at both thresholds, and the low-contrast cells only at th 7
+    z = np.load(os.path.join(str(tmp_path), "fast9_nms.npz"))
+    n20 = sum(len(z[f"th20_roi{i}"]) for i in range(kit.FAST_CELLS))
+    n7 = sum(len(z[f"th7_roi{i}"]) for i in range(kit.FAST_CELLS))
+    assert n20 > 200 and n7 > n20
+    assert any(len(z[f"th20_roi{i}"]) == 0 and len(z[f"th7_roi{i}"]) > 0 for i in range(0, kit.FAST_CELLS, 6))
+
+
+PIN_IMAGE_100_SHA16 = "fd55b5ceb08b6542"
+ATAN2_INPUTS_SHA16 = "df68cf345f42270c"
