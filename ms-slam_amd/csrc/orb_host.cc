@@ -117,7 +117,6 @@ bool FrameGeom::build(const OrbParams& p, int rows_, int cols_) {
                 c.x0 = (int16_t)iniX; c.y0 = (int16_t)iniY;
                 c.rw = (int16_t)((int)maxX - (int)iniX);
                 c.rh = (int16_t)((int)maxY - (int)iniY);
-                c.pad = 0;
                 const int dw = std::max(c.rw - 6, 0), dh = std::max(c.rh - 6, 0);
                 c.slot_off = slot;
                 c.slot_cap = ((dw + 1) / 2) * ((dh + 1) / 2);  // strict 3x3 NMS: no two survivors are 8-adjacent
@@ -126,6 +125,9 @@ bool FrameGeom::build(const OrbParams& p, int rows_, int cols_) {
                     const int ga = c.x0 & ~3, x_lo = c.x0 + 3, x_hi = c.x0 + c.rw - 3, gx0 = x_lo & ~3;
                     const int G = std::max((x_hi - gx0 + 3) >> 2, 1), ndw = std::max((c.x0 + c.rw - ga + 3) >> 2, 1);
                     c.G = (int16_t)G;
+                    const int s128 = std::max(128 / G, 1), s256 = std::max(256 / G, 1);
+                    c.R128 = (int8_t)std::min((dh + s128 - 1) / s128, 127);
+                    c.R256 = (int8_t)std::min((dh + s256 - 1) / s256, 127);
                     c.ndw = (int16_t)ndw;
                     c.g_magic = ((1u << 20) + G - 1) / G;
                     c.ndw_magic = ((1u << 20) + ndw - 1) / ndw;

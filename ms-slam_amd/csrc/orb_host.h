@@ -37,7 +37,9 @@ struct CellDesc {  // one FAST cell of ComputeKeyPointsOctTree (ORBextractor.cc:
     int16_t level;
     int16_t x0, y0;  // ROI origin in level pixels (iniX, iniY)
     int16_t rw, rh;  // ROI size (maxX-iniX, maxY-iniY)
-    int16_t pad;
+    // detection rows per thread of the FAST quick test: a thread owns one 4-pixel column group of R consecutive rows;
+    // R = ceil(dh / (threads / G)) for 128- and 256-thread workgroups
+    int8_t R128, R256;
     int32_t slot_off;  // first candidate slot of this cell inside one image's slot block
     int32_t slot_cap;  // worst-case number of NMS survivors
     // FAST kernel constants of the cell, precomputed here so that no workgroup spends instructions on integer division:

@@ -208,6 +208,8 @@ struct GeoLarge {
     static constexpr int kWorkCap = 4096;   // work-list entries per chunk
     static constexpr int kThreads = 256;    // <= 6 tasks per thread (8 mask bits each in a 64-bit word)
     static constexpr int kWordsPerRow = 3;  // bitmap words per detection row (<= 80 columns)
+    static constexpr int kMaxR = 6;         // detection rows per thread: ceil(70 / (256 / 20))
+    static constexpr int kMinWaves = 4;     // waves per SIMD the register allocation must allow
 };
 struct GeoSmall {
     static constexpr int kTileRows = 58;    // ROI rows <= 57
@@ -218,10 +220,17 @@ struct GeoSmall {
     static constexpr int kWorkCap = 1536;   // 9.7 KB per workgroup in total -> 16 workgroups (32 waves) per CU
     static constexpr int kThreads = 128;    // 2 waves per cell: the task / work-list loops run fuller than with 4 (64 measured slower)
     static constexpr int kWordsPerRow = 2;  // <= 44 columns
+    static constexpr int kMaxR = 5;         // detection rows per thread: ceil(51 / (128 / 11))
+    static constexpr int kMinWaves = 8;     // 16 workgroups x 2 waves per CU: <= 64 VGPRs
 };
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(a, min(b, c)); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(a, max(b, c)); }
+// The arc network below is 32 x min3 + 8 x max3.  Written with min()/max() the compiler re-associates it into ~48 two-input
+// v_min_i32 + 12 max (all issue at the same slow-class VALU rate as the three-input forms), so the three-input
+// instructions are spelled out.
+__device__ __forceinline__ int vmin3(int a, int b, int c) { int r; asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ int vmax3(int a, int b, int c) { int r; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
 // max over the 16 arcs of 9 contiguous circle pixels of min(sgn * (v - p)); p = LDS pointer to the centre
 template <class GEO>
@@ -247,13 +256,13 @@ __device__ __forceinline__ int fast_arc_contrast(const uint8_t* p, int sgn) {
     d[15] = (int)p[3 * GEO::kTilePitch - 1] * ns + sv;
     int mn3[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) mn3[i] = min3i(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
+    for (int i = 0; i < 16; i++) mn3[i] = vmin3(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
     int A = -512;
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {  // arcs i..i+8 and i+1..i+9
-        const int a0 = min3i(mn3[i], mn3[(i + 3) & 15], mn3[(i + 6) & 15]);
-        const int a1 = min3i(mn3[(i + 1) & 15], mn3[(i + 4) & 15], mn3[(i + 7) & 15]);
-        A = max3i(A, a0, a1);
+        const int a0 = vmin3(mn3[i], mn3[(i + 3) & 15], mn3[(i + 6) & 15]);
+        const int a1 = vmin3(mn3[(i + 1) & 15], mn3[(i + 4) & 15], mn3[(i + 7) & 15]);
+        A = vmax3(A, a0, a1);
     }
     return A;
 }
@@ -293,7 +302,7 @@ __device__ __forceinline__ int block_excl_scan(int cnt, int lane, int wave, int*
 }
 
 template <bool ALIGNED, class GEO>
-__global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView pyr, const CellDesc* __restrict__ cells,
+__global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kernel(PyramidView pyr, const CellDesc* __restrict__ cells,
                                                          int ini_th, int min_th, int slots_per_image,
                                                          Cand16* __restrict__ slots, int* __restrict__ cell_count,
                                                          int n_cells, uint32_t gx_magic, int debug_stop) {
@@ -303,6 +312,7 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
     __shared__ int wave_tot[2][GEO::kThreads / 64];
     __shared__ uint32_t kbits[GEO::kWordsPerRow * GEO::kMaxDet];
     __shared__ int kprefix[GEO::kWordsPerRow * GEO::kMaxDet];
+    __shared__ uint16_t lut[32];
     uint8_t* const tile = tile_mem + kTileFront;
 
     // XCD-aware order: consecutive workgroups are dealt round-robin to the 8 XCDs (each with a private L2); remap
@@ -361,6 +371,64 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
             tile[(int)__umul24((uint32_t)y, GEO::kTilePitch) + off + x] = src[(size_t)(__umul24((uint32_t)y, (uint32_t)lv.pitch) + (uint32_t)(cd.x0 + x))];
         }
     }
+    // Quick-test mapping: thread (strip, g) owns the 4-pixel column group g of R consecutive detection rows, so the column
+    // clipping is a per-thread constant and the rows above / below come out of one register window.
+    const int strip = (int)(__umul24((uint32_t)tid, magic) >> 20), g_own = tid - strip * G;
+    const int R = GEO::kThreads == 128 ? cd.R128 : cd.R256;
+    const int y_b = strip * R;                          // first detection row of the thread
+    const int nrows = min(max(dh - y_b, 0), R);         // 0 for the threads beyond the last strip
+    const int c_own = c_lo + 4 * g_own;                 // tile column of pixel 0 of the group
+    uint32_t Hm;                                        // 0x80 in every byte whose pixel lies inside [x_lo, x_hi)
+    {
+        const int xg = ga + c_own;
+        const int vlo = min(max(x_lo - xg, 0), 4), vhi = min(max(x_hi - xg, 0), 4);
+        const uint32_t m4 = (0xFu << vlo) & (0xFu >> (4 - vhi)) & 0xFu;
+        Hm = ((m4 & 1u) << 7) | ((m4 & 2u) << 14) | ((m4 & 4u) << 21) | ((m4 & 8u) << 28);
+    }
+    if (tid < 32) lut[tid] = (uint16_t)((((tid >> 1) & 3) << 7) + (tid >> 3) + ((tid & 1) << 15));  // flag bit -> work entry offset
+    // Quick test at threshold th for the thread's rows: wA / wB receive 2 flags (dark, bright) per pixel, bit 8 j + 2 k (+ 1)
+    // for pixel j of row k (rows 0..3 in wA, 4.. in wB).  All four pixels of a group are tested at once on raw bytes:
+    //   A = sat0(v - t), B = sat255(v + t) per byte (v_pk_sub_u16 clamp on the even / odd bytes),
+    //   p < v - t  <=>  p + (255 - A) + 1 <= 255  <=>  bit 7 of v_lerp_u8(P, ~A, 1) clear,
+    //   p > v + t  <=>  p + (255 - B) >= 256      <=>  bit 7 of v_lerp_u8(P, ~B, 0) set          (~B = sat0(~v - t)),
+    // i.e. one instruction per compass point, polarity and 4 pixels.  Every 9-arc contains one pixel of each antipodal
+    // pair: a corner needs the predicate for (up OR down) AND (left OR right).
+    auto quick_test = [&](int th, uint32_t& wA, uint32_t& wB) {
+        wA = 0; wB = 0;
+        const uint8_t* colp = &tile[(int)__umul24((uint32_t)y_b, GEO::kTilePitch) + c_own];
+        uint32_t cw[GEO::kMaxR + 6], lw[GEO::kMaxR], rw_[GEO::kMaxR];
+#pragma unroll
+        for (int r = 0; r < GEO::kMaxR + 6; r++) cw[r] = *reinterpret_cast<const uint32_t*>(colp + r * GEO::kTilePitch);
+#pragma unroll
+        for (int k = 0; k < GEO::kMaxR; k++) {
+            lw[k] = *reinterpret_cast<const uint32_t*>(colp + (k + 3) * GEO::kTilePitch - 4);
+            rw_[k] = *reinterpret_cast<const uint32_t*>(colp + (k + 3) * GEO::kTilePitch + 4);
+        }
+        const ushort2v t2 = __builtin_bit_cast(ushort2v, (uint32_t)th * 0x00010001u);
+#pragma unroll
+        for (int k = 0; k < GEO::kMaxR; k++) {
+            const uint32_t V = cw[k + 3], U = cw[k], D = cw[k + 6];
+            const uint32_t R3 = __builtin_amdgcn_alignbyte(rw_[k], V, 3);  // p[x+3] per byte
+            const uint32_t L3 = __builtin_amdgcn_alignbyte(V, lw[k], 1);   // p[x-3] per byte
+            const uint32_t nV = ~V;
+            const uint32_t Ae = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, V & 0x00ff00ffu), t2));
+            const uint32_t Ao = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, (V >> 8) & 0x00ff00ffu), t2));
+            const uint32_t Qd = ~(Ae | (Ao << 8));
+            const uint32_t Be = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, nV & 0x00ff00ffu), t2));
+            const uint32_t Bo = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, (nV >> 8) & 0x00ff00ffu), t2));
+            const uint32_t Qb = Be | (Bo << 8);
+            const uint32_t one = 0x01010101u;
+            // dark: bit 7 SET means "not darker"
+            const uint32_t X = (__builtin_amdgcn_lerp(U, Qd, one) & __builtin_amdgcn_lerp(D, Qd, one)) |
+                               (__builtin_amdgcn_lerp(L3, Qd, one) & __builtin_amdgcn_lerp(R3, Qd, one));
+            const uint32_t Y = (__builtin_amdgcn_lerp(U, Qb, 0u) | __builtin_amdgcn_lerp(D, Qb, 0u)) &
+                               (__builtin_amdgcn_lerp(L3, Qb, 0u) | __builtin_amdgcn_lerp(R3, Qb, 0u));
+            const uint32_t hm = k < nrows ? Hm : 0u;
+            const uint32_t z = (Y & hm) | ((~X & hm) >> 1);   // bits 8j+6 (dark), 8j+7 (bright)
+            if (k < 4) wA |= z >> (6 - 2 * k);
+            else wB |= z >> (6 - 2 * (k - 4));
+        }
+    };
     // Threshold passes (ORBextractor.cc:826,843-847): iniThFAST first; only a cell that ends up with no keypoint at all
     // is redone at minThFAST.  NMS at a threshold only sees the corners of that threshold (the others score 0 there),
     // so the first pass needs nothing below iniThFAST — half the quick-test survivors and arc tests of a minTh pass.
@@ -371,95 +439,43 @@ __global__ __launch_bounds__(GEO::kThreads) void fast_cells_kernel(PyramidView p
     __syncthreads();
     if (debug_stop == 1) return;
 
-    // phase 1: quick test, two pixels per packed 16-bit lane; 8 result bits per task (dark 0..3, bright 4..7)
-    uint64_t M = 0;  // 8 bits per owned task (<= 6 tasks with GeoLarge, <= 5 with GeoSmall)
-    int cnt = 0;
-    const uint32_t t2 = (uint32_t)th * 0x00010001u;
-    const uint32_t cdark = 0x80008000u - t2 - 0x00010001u, cbright = 0x80008000u - t2 - 0x00010001u;
-    {
-        int y = (int)(__umul24((uint32_t)t_begin, magic) >> 20);
-        int g = t_begin - y * G;
-        for (int task = t_begin, k = 0; task < t_end; task++, k++) {
-            const int c0 = c_lo + 4 * g;
-            const uint8_t* row = &tile[(int)__umul24((uint32_t)(y + 3), GEO::kTilePitch) + c0];
-            const uint32_t C = *reinterpret_cast<const uint32_t*>(row);
-            const uint32_t Lw = *reinterpret_cast<const uint32_t*>(row - 4);
-            const uint32_t Rw = *reinterpret_cast<const uint32_t*>(row + 4);
-            const uint32_t U = *reinterpret_cast<const uint32_t*>(row - 3 * GEO::kTilePitch);
-            const uint32_t D = *reinterpret_cast<const uint32_t*>(row + 3 * GEO::kTilePitch);
-            const uint32_t R3 = __builtin_amdgcn_alignbyte(Rw, C, 3);  // p[x+3] per byte
-            const uint32_t L3 = __builtin_amdgcn_alignbyte(C, Lw, 1);  // p[x-3] per byte
-            uint32_t dk[2], br[2];
-#pragma unroll
-            for (int hsel = 0; hsel < 2; hsel++) {  // even pixels (0,2) / odd pixels (1,3)
-                const int sh = 8 * hsel;
-                const short2v v = as_s2((C >> sh) & 0x00ff00ffu), pu = as_s2((U >> sh) & 0x00ff00ffu),
-                              pd = as_s2((D >> sh) & 0x00ff00ffu), pr = as_s2((R3 >> sh) & 0x00ff00ffu),
-                              pl = as_s2((L3 >> sh) & 0x00ff00ffu);
-                // Compare by carry-free 32-bit arithmetic on the two 16-bit halves (v_add/v_sub/v_or/v_and issue at the fast
-                // VALU rate on gfx950, the packed v_pk_* ops at the slow one): with a 0x8000 guard in each half,
-                //   (v - t - 1 + 0x8000) - p   has bit 15 set  <=>  p < v - t      (dark),
-                //   p + (0x8000 - (v + t + 1)) has bit 15 set  <=>  p > v + t      (bright),
-                // and no half ever borrows from / carries into its neighbour (|v - p| + t + 1 < 0x8000).
-                // Every 9-arc contains one pixel of each antipodal pair: a corner needs the predicate for (up OR down) AND
-                // (left OR right).
-                const uint32_t vv = as_u32(v);
-                const uint32_t Ld = vv + cdark, Hb = cbright - vv;
-                dk[hsel] = ((Ld - as_u32(pu)) | (Ld - as_u32(pd))) & ((Ld - as_u32(pl)) | (Ld - as_u32(pr)));
-                br[hsel] = ((as_u32(pu) + Hb) | (as_u32(pd) + Hb)) & ((as_u32(pl) + Hb) | (as_u32(pr) + Hb));
-            }
-            // sign bits: even half -> px0 (bit 15), px2 (bit 31); odd half -> px1, px3
-            // gather both halves at once: bits {0,1} = px0,px1 and {16,17} = px2,px3 (dark), the same 4 bits higher
-            // (bright); then fold the upper half down by 14
-            const uint32_t dz = ((dk[1] >> 14) & 0x00020002u) | ((dk[0] >> 15) & 0x00010001u);
-            const uint32_t bz = ((br[1] >> 14) & 0x00020002u) | ((br[0] >> 15) & 0x00010001u);
-            const uint32_t z = (bz << 4) | dz;
-            const int xg = ga + c0;  // level column of pixel 0 of the group
-            const int vlo = min(max(x_lo - xg, 0), 4), vhi = min(max(x_hi - xg, 0), 4);
-            const uint32_t m4 = (0xFu << vlo) & (0xFu >> (4 - vhi)) & 0xFu;
-            const uint32_t bits = (z | (z >> 14)) & (m4 * 0x11u);
-            M |= (uint64_t)bits << (8 * k);
-            cnt += __popc(bits);
-            if (++g == G) { g = 0; y++; }
-        }
-    }
+    // phase 1
+    uint32_t wA, wB;
+    quick_test(th, wA, wB);
+    const int cnt = __popc(wA) + __popc(wB);
     int n_work = 0;
     const int my_base = block_excl_scan<GEO::kThreads / 64>(cnt, lane, wave, wave_tot[0], &n_work);
     if (debug_stop == 2) return;
 
-    // phase 2: the work list is processed in chunks of GEO::kWorkCap entries (one chunk unless the cell is saturated)
+    // phase 2: every (pixel, polarity) that passed goes to the work list; the list is then processed with all lanes busy
     const int sc_off = 4 - c_lo;  // score column = tile column + sc_off  (first group at score column 4)
-    for (int cb = 0; cb < n_work; cb += GEO::kWorkCap) {
-        if (cnt && my_base < cb + GEO::kWorkCap && my_base + cnt > cb) {
-            int idx = my_base - cb;
-            int y = (int)(__umul24((uint32_t)t_begin, magic) >> 20);
-            int g = t_begin - y * G;
-            uint64_t m = M;
-            for (int task = t_begin; task < t_end; task++, m >>= 8) {
-                const uint32_t bits = (uint32_t)m & 255u;
-                if (bits) {
-                    const int e0 = ((y + 3) << 7) | (c_lo + 4 * g);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (bits & (1u << j)) { if ((unsigned)idx < (unsigned)GEO::kWorkCap) work[idx] = (uint16_t)(e0 + j); idx++; }
-                        if (bits & (16u << j)) { if ((unsigned)idx < (unsigned)GEO::kWorkCap) work[idx] = (uint16_t)(0x8000 | (e0 + j)); idx++; }
-                    }
-                }
-                if (++g == G) { g = 0; y++; }
-            }
-        }
+    const uint32_t baseA = (uint32_t)(((y_b + 3) << 7) | c_own), baseB = baseA + (4u << 7);
+    if (n_work <= GEO::kWorkCap) {
+        uint16_t* wp = &work[my_base];
+        for (uint32_t w = wA; w; w &= w - 1) *wp++ = (uint16_t)(lut[__builtin_ctz(w)] + baseA);
+        for (uint32_t w = wB; w; w &= w - 1) *wp++ = (uint16_t)(lut[__builtin_ctz(w)] + baseB);
         __syncthreads();
         if (debug_stop == 3) return;
-        const int nw = min(n_work - cb, GEO::kWorkCap);
-        for (int i = tid; i < nw; i += GEO::kThreads) {
+        for (int i = tid; i < n_work; i += GEO::kThreads) {
             const int e = work[i];
             const int ty = (e >> 7) & 127, tx = e & 127;
             const int A = fast_arc_contrast<GEO>(&tile[(int)__umul24((uint32_t)ty, GEO::kTilePitch) + tx], (e & 0x8000) ? -1 : 1);
             if (A > th) score[(int)__umul24((uint32_t)(ty - 2), GEO::kScorePitch) + tx + sc_off] = (uint8_t)(A - 1);  // score row = y + 1
             work[i] = A > th ? (uint16_t)(e & 0x3FFF) : (uint16_t)0xFFFF;  // the list now holds the corners
         }
-        __syncthreads();
+    } else {
+        // saturated cell (more quick-test survivors than the list holds): every thread scores its own survivors
+#pragma unroll 1
+        for (int half = 0; half < 2; half++)
+#pragma unroll 1
+            for (uint32_t w = half ? wB : wA; w; w &= w - 1) {
+                const int e = lut[__builtin_ctz(w)] + (half ? baseB : baseA);
+                const int ty = (e >> 7) & 127, tx = e & 127;
+                const int A = fast_arc_contrast<GEO>(&tile[(int)__umul24((uint32_t)ty, GEO::kTilePitch) + tx], (e & 0x8000) ? -1 : 1);
+                if (A > th) score[(int)__umul24((uint32_t)(ty - 2), GEO::kScorePitch) + tx + sc_off] = (uint8_t)(A - 1);
+            }
     }
+    __syncthreads();
     if (debug_stop == 4) return;
 
     Cand16* out = slots + (size_t)img * slots_per_image + cd.slot_off;

@@ -1,0 +1,20 @@
+#!/bin/bash
+# usage (GPU box): tools/pmc_run.sh <outdir-name> "<counters>" <kernel-substring> -- <command...>
+# One rocprofv3 --pmc pass (counters + kernel trace only) of <command>; prints per-kernel counter averages.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$1; CTR=$2; SUB=$3; shift 4
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+( cd $R && rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $OUT -o p -- "$@" > $OUT/cmd.log 2>&1 )
+python - <<PY
+import csv,collections,glob
+f=glob.glob("$OUT/**/p_counter_collection.csv", recursive=True)[0]
+rows=list(csv.DictReader(open(f)))
+d=collections.defaultdict(lambda: collections.defaultdict(list))
+for r in rows:
+    n=r["Kernel_Name"].split("(")[0].replace("void ","").replace("msorb::","")
+    if "$SUB" and "$SUB" not in n: continue
+    d[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for n,c in sorted(d.items()):
+    print(n, {k: round(sum(v)/len(v)) for k,v in sorted(c.items())}, "n=%d" % len(next(iter(c.values()))))
+PY
