@@ -79,6 +79,27 @@ int msorb_extract_stereo(msorb_extractor* h, const uint8_t* left, const uint8_t*
                          uint8_t* desc_left, int* n_left, msorb_keypoint* kps_right, uint8_t* desc_right, int* n_right,
                          int capacity, float* u_right, float* depth, int* n_oob);
 
+/* The same stereo frame with one extractor object per DEVICE — BASELINE configs[3], "left/right images on 2 MI355X, gather of
+ * keypoints/descriptors over xGMI".  Replaces the two extractor threads + join of Frame::Frame (Frame.cc:122-127) followed by
+ * ComputeStereoMatches (Frame.cc:743-913) when mpORBextractorLeft and mpORBextractorRight (Tracking.cc:595-596) live on
+ * different GPUs: `left` and `right` are two distinct handles (same parameters) created on devices A and B.  Each eye runs
+ * its kernel chain on its own device; the right eye's keypoints, descriptors, count and pyramid are copied device to device
+ * onto A (peer copy over xGMI when A != B), a HIP event orders the two streams, the stereo association runs on A and one
+ * block comes back after one synchronisation.  A == B (two handles on one device) is allowed and takes the same path.
+ * Results are identical to msorb_extract_stereo / to two msorb_extract calls + msorb_stereo_matches. */
+int msorb_extract_stereo_split(msorb_extractor* left, msorb_extractor* right, const uint8_t* img_left,
+                               const uint8_t* img_right, int rows, int cols, size_t stride_left, size_t stride_right,
+                               float mb, float mbf, msorb_keypoint* kps_left, uint8_t* desc_left, int* n_left,
+                               msorb_keypoint* kps_right, uint8_t* desc_right, int* n_right, int capacity, float* u_right,
+                               float* depth, int* n_oob);
+
+/* ComputePyramid (ORBextractor.cc:1170-1195) alone over n_images DEVICE-resident images (arguments as msorb_extract_batch):
+ * fills the handle's pyramid, asynchronously on its stream, so that msorb_stereo_matches_split can read it.  Used on the
+ * device that runs the stereo association when only the other eye's keypoints / descriptors were gathered (60 B per
+ * keypoint) and its levels (1.5 MB per KITTI image) are rebuilt locally instead of being moved. */
+int msorb_pyramid_batch(msorb_extractor* h, const uint8_t* d_images, int n_images, int rows, int cols, size_t row_stride,
+                        size_t image_stride);
+
 /* mvImagePyramid[level] (ORBextractor.h:83) of the last msorb_extract() call as a host-visible plane
  * (interior pixels; the 19-px border of ORBextractor.cc:1185-1191 is not materialised).  The memory
  * is owned by the handle and valid until the next extract call. */
@@ -102,7 +123,7 @@ int msorb_extract_batch(msorb_extractor* h, const uint8_t* d_images, int n_image
 #define MSORB_STAGE_FAST 1
 #define MSORB_STAGE_COMPACT 2
 #define MSORB_STAGE_BLUR 3
-#define MSORB_STAGE_SELECT 4   /* D2H candidates + quadtree + H2D selection (host-inclusive wall time) */
+#define MSORB_STAGE_SELECT 4   /* device quadtree + output layout (MSORB_QUADTREE=host: D2H candidates + host quadtree + H2D, wall time) */
 #define MSORB_STAGE_DESCRIBE 5 /* IC-angle + rBRIEF */
 #define MSORB_N_STAGES 6
 int msorb_extractor_set_profiling(msorb_extractor* h, int enable);
@@ -319,6 +340,14 @@ int msorb_search_for_triangulation(int device, msorb_triangulation_pair* pairs, 
  * device time of the two kernels. */
 int msorb_stereo_matches_batch(msorb_extractor* h, int n_pairs, const msorb_keypoint* d_keypoints,
                                const uint8_t* d_descriptors, int capacity, const int* d_counts, int max_left, float mb,
+                               float mbf, float* d_u_right, float* d_depth, int* d_n_oob, float* elapsed_ms);
+
+/* The same with the two eyes in separate batches: left images = the last msorb_extract_batch() of `left`, right images = the
+ * last msorb_extract_batch() or msorb_pyramid_batch() of `right` (both handles on ONE device; pair p = image p of each).
+ * The right keypoints / descriptors / counts may have been extracted on another device and gathered (RCCL / peer copy). */
+int msorb_stereo_matches_split(msorb_extractor* left, msorb_extractor* right, int n_pairs, const msorb_keypoint* d_kps_left,
+                               const uint8_t* d_desc_left, const int* d_counts_left, const msorb_keypoint* d_kps_right,
+                               const uint8_t* d_desc_right, const int* d_counts_right, int capacity, int max_left, float mb,
                                float mbf, float* d_u_right, float* d_depth, int* d_n_oob, float* elapsed_ms);
 
 /* ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:2277-2318) on histogram bin sizes; ind[3]. Host only. */

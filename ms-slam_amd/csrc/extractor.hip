@@ -174,6 +174,9 @@ struct msorb_extractor {
     DevBuf<int> d_st_sad, d_st_rows, d_st_list;  // stereo association scratch of msorb_extract_stereo
     DevBuf<uint8_t> d_st_block, d_st_img;        // its output block and its two level-0 planes
     DevBuf<uint8_t> d_out1;                      // msorb_extract: keypoints + descriptors of one frame as one block
+    DevBuf<uint8_t> d_gather_pyr;                // msorb_extract_stereo_split: the right eye's pyramid, gathered onto this (left) device
+    DevBuf<int> d_gather_cnt;                    // ... and its keypoint count
+    hipEvent_t ev_split = nullptr;               // ... recorded on the right handle's stream after the gather copies
     unsigned long long buffers_epoch = 0;  // bumped whenever a device / pinned buffer may have moved
     unsigned long long graph_epoch = 0;
     hipEvent_t ev_compact = nullptr, ev_pyramid = nullptr, ev_blur = nullptr;
@@ -691,6 +694,8 @@ void msorb_extractor_destroy(msorb_extractor* h) {
     h->d_img_total.release(); h->d_img_base.release(); h->d_sel_count.release(); h->d_slots.release();
     h->d_compact.release(); h->d_sel.release(); h->d_kps1.release();
     h->d_st_sad.release(); h->d_st_rows.release(); h->d_st_list.release(); h->d_st_block.release(); h->d_st_img.release(); h->d_out1.release();
+    h->d_gather_pyr.release(); h->d_gather_cnt.release();
+    if (h->ev_split) (void)hipEventDestroy(h->ev_split);
     h->h_level_count.release(); h->h_img_base.release(); h->h_sel_count.release(); h->h_compact.release();
     h->h_sel.release(); h->h_pyr.release(); h->h_img_pin.release(); h->h_out_pin.release();
     for (auto& G : h->grp) {
@@ -967,17 +972,19 @@ int msorb_extract_stereo(msorb_extractor* h, const uint8_t* left, const uint8_t*
     b.A.rows0 = rows;
     for (int l = 0; l < g.nlevels; l++) {
         const LevelView& v = h->last_pyr.lv[l];
-        b.A.pyrL[l] = b.A.pyrR[l] = v.base;
+        b.A.pyrL[l] = v.base; b.A.pyrR[l] = v.base + v.img_stride;
         b.A.pitchL[l] = b.A.pitchR[l] = v.pitch;
         b.A.rows[l] = v.h; b.A.cols[l] = v.w;
         b.A.scale[l] = h->scales.scale[l]; b.A.inv_scale[l] = h->P.inv_scale[l];
-        b.img_stride[l] = v.img_stride;
+        b.img_strideL[l] = b.img_strideR[l] = v.img_stride;
     }
     b.A.mb = mb; b.A.mbf = mbf;
     b.A.u_right = reinterpret_cast<float*>(blk + o_ur); b.A.depth = reinterpret_cast<float*>(blk + o_dp);
     b.A.sad = h->d_st_sad.p; b.A.n_oob = reinterpret_cast<int*>(blk + o_oob);
     b.capacity = cap;
-    b.counts = h->d_sel_count.p;
+    b.pair_step = 2;
+    b.A.kpR = d_kps + cap; b.A.descR = d_desc + (size_t)cap * 32;
+    b.countsL = h->d_sel_count.p; b.countsR = h->d_sel_count.p + 1;
     b.row_begin = h->d_st_rows.p; b.row_list = h->d_st_list.p; b.row_cap = row_cap;
     b.counts_out = reinterpret_cast<int*>(blk + o_cnt);
     launch_stereo_match_batch(b, 1, cap, s);
@@ -997,6 +1004,175 @@ int msorb_extract_stereo(msorb_extractor* h, const uint8_t* left, const uint8_t*
     if (n_oob) *n_oob = *reinterpret_cast<const int*>(o + o_oob);
     *n_left = nl;
     *n_right = nr;
+    return MSORB_OK;
+}
+
+// The same frame with one eye per DEVICE (BASELINE config "left/right images on 2 MI355X, gather over xGMI"): what the two
+// extractor threads of Frame.cc:122-125 and the join + ComputeStereoMatches of Frame.cc:126-137 do, with the left object on
+// device A and the right object on device B.  Each eye runs its own kernel chain on its own device and stream; the right
+// eye's keypoints, descriptors, count and pyramid (the SAD of Frame.cc:840-865 reads both pyramids) are then copied
+// device-to-device onto A (hipMemcpyPeerAsync: xGMI when A != B), an event carries the order across the two streams, and the
+// stereo association runs on A.  One synchronisation, one D2H block.  A == B (two handles on one device) takes the same path.
+int msorb_extract_stereo_split(msorb_extractor* L, msorb_extractor* R, const uint8_t* left, const uint8_t* right, int rows,
+                               int cols, size_t stride_left, size_t stride_right, float mb, float mbf,
+                               msorb_keypoint* kps_left, uint8_t* desc_left, int* n_left, msorb_keypoint* kps_right,
+                               uint8_t* desc_right, int* n_right, int capacity, float* u_right, float* depth, int* n_oob) {
+    if (!L || !R || L == R || !n_left || !n_right) return MSORB_E_INVALID;
+    *n_left = *n_right = 0;
+    if (n_oob) *n_oob = 0;
+    if (!left || !right || rows <= 0 || cols <= 0) return MSORB_E_EMPTY;
+    if (!kps_left || !desc_left || !kps_right || !desc_right || !u_right || !depth || (int)stride_left < cols ||
+        (int)stride_right < cols)
+        return MSORB_E_INVALID;
+    if (L->P.nfeatures != R->P.nfeatures || L->P.nlevels != R->P.nlevels || L->P.scale_factor_f != R->P.scale_factor_f) {
+        set_error("msorb_extract_stereo_split: the two extractors differ in their parameters");
+        return MSORB_E_INVALID;
+    }
+    if (getenv("MSORB_SERIAL_PIPELINE")) { set_error("msorb_extract_stereo_split needs the device pipeline"); return MSORB_E_INVALID; }
+    const int cap = capacity_of(L);
+    int rc;
+    // geometry / buffers of both handles (each on its own device)
+    for (msorb_extractor* h : {R, L}) {
+        HIPCHK(hipSetDevice(h->device));
+        if ((rc = ensure_geometry(h, rows, cols))) return rc;
+        if (!h->device_quadtree) { set_error("msorb_extract_stereo_split needs the device pipeline"); return MSORB_E_INVALID; }
+        if ((rc = ensure_batch(h, 1))) return rc;
+        if ((rc = h->h_img_pin.ensure((size_t)h->G.lv[0].pitch * rows))) return rc;
+    }
+    const FrameGeom& g = L->G;
+    const LevelGeom& g0 = g.lv[0];
+    const size_t plane = (size_t)g0.pitch * rows;
+    if ((size_t)(2 * rows + 1) * sizeof(int) > 60000) { set_error("image too tall for the stereo row table"); return MSORB_E_INVALID; }
+    float smax = 0;
+    for (int l = 0; l < g.nlevels; l++) smax = std::max(smax, L->scales.scale[l]);
+    const int row_cap = cap * ((int)std::ceil(4.0f * smax) + 3);
+    // left device: one block for everything that travels back: [kps 2*cap][desc 2*cap*32][u_right cap][depth cap][n_oob][n_left][n_right]
+    const size_t kp_bytes = (size_t)cap * sizeof(msorb_keypoint);
+    const size_t o_desc = 2 * kp_bytes, o_ur = o_desc + (size_t)2 * cap * 32, o_dp = o_ur + (size_t)cap * 4,
+                 o_oob = o_dp + (size_t)cap * 4, o_cnt = o_oob + 4, out_bytes = o_oob + 16;
+    HIPCHK(hipSetDevice(L->device));
+    if ((rc = L->d_st_block.ensure(out_bytes)) || (rc = L->h_out_pin.ensure(out_bytes)) || (rc = L->d_st_sad.ensure(cap)) ||
+        (rc = L->d_st_rows.ensure((size_t)rows + 1)) || (rc = L->d_st_list.ensure(row_cap)) ||
+        (rc = L->d_gather_pyr.ensure(g.pyramid_bytes + 256)) || (rc = L->d_gather_cnt.ensure(4)))
+        return rc;
+    // right device: its outputs as one block [kps cap][desc cap*32]
+    HIPCHK(hipSetDevice(R->device));
+    if ((rc = R->d_out1.ensure(kp_bytes + (size_t)cap * 32 + 16))) return rc;
+    if (!R->ev_split) HIPCHK(hipEventCreateWithFlags(&R->ev_split, hipEventDisableTiming));
+    if (L->device != R->device) {  // direct xGMI copies when the devices can reach each other (else the runtime stages through the host)
+        static std::mutex peer_mu;
+        static std::vector<std::pair<int, int>> enabled;
+        std::lock_guard<std::mutex> lk(peer_mu);
+        if (std::find(enabled.begin(), enabled.end(), std::make_pair(L->device, R->device)) == enabled.end()) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, R->device, L->device) == hipSuccess && can) {
+                (void)hipSetDevice(R->device); (void)hipDeviceEnablePeerAccess(L->device, 0);
+                (void)hipSetDevice(L->device); (void)hipDeviceEnablePeerAccess(R->device, 0);
+                (void)hipGetLastError();  // "already enabled" is fine
+            }
+            enabled.emplace_back(L->device, R->device);
+        }
+    }
+    int counts[1] = {0}, mono[1] = {0};
+    // ---- right eye: upload + chain on device B (enqueued first: the join waits for it)
+    HIPCHK(hipSetDevice(R->device));
+    for (int y = 0; y < rows; y++) memcpy(R->h_img_pin.p + (size_t)y * g0.pitch, right + (size_t)y * stride_right, cols);
+    HIPCHK(hipMemcpyAsync(R->d_pyr.p + R->G.lv[0].plane_off, R->h_img_pin.p, plane, hipMemcpyHostToDevice, R->stream));
+    {
+        LevelView l0{R->d_pyr.p + R->G.lv[0].plane_off, R->G.pyramid_bytes, g0.pitch, cols, rows};
+        R->defer_sync = R->skip_count_copies = true;
+        rc = run_pipeline(R, l0, 1, 0, 0, reinterpret_cast<msorb_keypoint*>(R->d_out1.p), R->d_out1.p + kp_bytes, cap, counts, mono);
+        R->defer_sync = R->skip_count_copies = false;
+        if (rc) return rc;
+    }
+    uint8_t* const blk = L->d_st_block.p;
+    // gather onto device A, on B's stream behind its chain
+    HIPCHK(hipMemcpyPeerAsync(blk + kp_bytes, L->device, R->d_out1.p, R->device, kp_bytes, R->stream));
+    HIPCHK(hipMemcpyPeerAsync(blk + o_desc + (size_t)cap * 32, L->device, R->d_out1.p + kp_bytes, R->device, (size_t)cap * 32, R->stream));
+    HIPCHK(hipMemcpyPeerAsync(L->d_gather_cnt.p, L->device, R->d_sel_count.p, R->device, sizeof(int), R->stream));
+    HIPCHK(hipMemcpyPeerAsync(L->d_gather_pyr.p, L->device, R->d_pyr.p, R->device, g.pyramid_bytes, R->stream));
+    HIPCHK(hipEventRecord(R->ev_split, R->stream));
+    // ---- left eye: upload + chain on device A
+    HIPCHK(hipSetDevice(L->device));
+    for (int y = 0; y < rows; y++) memcpy(L->h_img_pin.p + (size_t)y * g0.pitch, left + (size_t)y * stride_left, cols);
+    hipStream_t s = L->stream;
+    HIPCHK(hipMemcpyAsync(L->d_pyr.p + g0.plane_off, L->h_img_pin.p, plane, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(blk + o_oob, 0, sizeof(int), s));
+    {
+        LevelView l0{L->d_pyr.p + g0.plane_off, g.pyramid_bytes, g0.pitch, cols, rows};
+        L->defer_sync = L->skip_count_copies = true;
+        rc = run_pipeline(L, l0, 1, 0, 0, reinterpret_cast<msorb_keypoint*>(blk), blk + o_desc, cap, counts, mono);
+        L->defer_sync = L->skip_count_copies = false;
+        if (rc) return rc;
+    }
+    // ---- join (Frame.cc:126-127) + ComputeStereoMatches on device A
+    HIPCHK(hipStreamWaitEvent(s, R->ev_split, 0));
+    StereoBatchArgs b{};
+    b.pair_step = 1;
+    b.A.kpL = reinterpret_cast<msorb_keypoint*>(blk);
+    b.A.kpR = b.A.kpL + cap;
+    b.A.descL = blk + o_desc;
+    b.A.descR = b.A.descL + (size_t)cap * 32;
+    b.countsL = L->d_sel_count.p;
+    b.countsR = L->d_gather_cnt.p;
+    b.A.rows0 = rows;
+    for (int l = 0; l < g.nlevels; l++) {
+        const LevelView& v = L->last_pyr.lv[l];
+        b.A.pyrL[l] = v.base;
+        b.A.pyrR[l] = L->d_gather_pyr.p + g.lv[l].plane_off;
+        b.A.pitchL[l] = v.pitch; b.A.pitchR[l] = g.lv[l].pitch;
+        b.A.rows[l] = v.h; b.A.cols[l] = v.w;
+        b.A.scale[l] = L->scales.scale[l]; b.A.inv_scale[l] = L->P.inv_scale[l];
+        b.img_strideL[l] = v.img_stride; b.img_strideR[l] = g.pyramid_bytes;
+    }
+    b.A.mb = mb; b.A.mbf = mbf;
+    b.A.u_right = reinterpret_cast<float*>(blk + o_ur); b.A.depth = reinterpret_cast<float*>(blk + o_dp);
+    b.A.sad = L->d_st_sad.p; b.A.n_oob = reinterpret_cast<int*>(blk + o_oob);
+    b.capacity = cap;
+    b.row_begin = L->d_st_rows.p; b.row_list = L->d_st_list.p; b.row_cap = row_cap;
+    b.counts_out = reinterpret_cast<int*>(blk + o_cnt);
+    launch_stereo_match_batch(b, 1, cap, s);
+    uint8_t* o = L->h_out_pin.p;
+    HIPCHK(hipMemcpyAsync(o, blk, out_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    const int nl = reinterpret_cast<const int*>(o + o_cnt)[0], nr = reinterpret_cast<const int*>(o + o_cnt)[1];
+    if (nl < 0 || nr < 0) { set_error("keypoint capacity exceeded"); return MSORB_E_CAPACITY; }
+    if (nl > capacity || nr > capacity) { set_error("caller capacity too small"); return MSORB_E_CAPACITY; }
+    memcpy(kps_left, o, (size_t)nl * sizeof(msorb_keypoint));
+    memcpy(kps_right, o + kp_bytes, (size_t)nr * sizeof(msorb_keypoint));
+    memcpy(desc_left, o + o_desc, (size_t)nl * 32);
+    memcpy(desc_right, o + o_desc + (size_t)cap * 32, (size_t)nr * 32);
+    memcpy(u_right, o + o_ur, (size_t)nl * sizeof(float));
+    memcpy(depth, o + o_dp, (size_t)nl * sizeof(float));
+    if (n_oob) *n_oob = *reinterpret_cast<const int*>(o + o_oob);
+    *n_left = nl;
+    *n_right = nr;
+    return MSORB_OK;
+}
+
+// ComputePyramid (ORBextractor.cc:1170-1195) alone for a batch of device-resident images: fills the handle's pyramid (level 0
+// read in place) so that msorb_stereo_matches_split can read it — the right eye's levels on the device that runs the stereo
+// association, when only its keypoints / descriptors were gathered from another device.  Asynchronous on the handle's stream.
+int msorb_pyramid_batch(msorb_extractor* h, const uint8_t* d_images, int n_images, int rows, int cols, size_t row_stride,
+                        size_t image_stride) {
+    if (!h || n_images < 0) return MSORB_E_INVALID;
+    if (!d_images || rows <= 0 || cols <= 0) return MSORB_E_EMPTY;
+    if (n_images == 0) return MSORB_OK;
+    if ((int)row_stride < cols || (n_images > 1 && image_stride < row_stride * (size_t)rows)) { set_error("bad strides"); return MSORB_E_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure_geometry(h, rows, cols))) return rc;
+    if ((rc = h->d_pyr.ensure((size_t)n_images * h->G.pyramid_bytes + 256))) return rc;
+    const FrameGeom& g = h->G;
+    LevelView l0{d_images, image_stride, (int)row_stride, cols, rows};
+    const PyramidView pyr = make_view(h, h->d_pyr.p, &l0);
+    for (int l = 1; l < g.nlevels; l++)
+        launch_pyr_resize(pyr.lv[l - 1], pyr.lv[l], h->d_pyr.p + g.lv[l].plane_off, h->d_taps.p + h->tap_x_off[l],
+                          h->d_taps.p + h->tap_y_off[l], n_images, h->stream);
+    HIPCHK(hipGetLastError());
+    h->last_pyr = pyr; h->last_n_images = n_images;
+    h->h_pyr_valid = false; h->compact_on_host = false;
     return MSORB_OK;
 }
 

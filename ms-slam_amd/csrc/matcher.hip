@@ -174,8 +174,8 @@ struct StereoPairView {
     float *u_right, *depth;
     int *sad, *n_oob;
     const int *row_begin, *row_list;
-    size_t imgL, imgR;          // image index of the left / right eye inside the batch (0 for the per-frame call)
-    const size_t* img_stride;   // per level, nullptr for the per-frame call
+    size_t img;                 // image index of the pair inside the batch arrays (0 for the per-frame call)
+    const size_t *img_strideL, *img_strideR;  // per level, nullptr for the per-frame call
 };
 __device__ __forceinline__ void stereo_match_one(const StereoArgs& G, const StereoPairView& A, const int iL, const int lane) {
     const msorb_keypoint kpL = A.kpL[iL];
@@ -225,8 +225,8 @@ __device__ __forceinline__ void stereo_match_one(const StereoArgs& G, const Ster
         const bool ok = !(iniu < 0 || endu >= cols) && y0 >= 0 && y0 + 2 * w + 1 <= rows && xL0 >= 0 &&
                         xL0 + 2 * w + 1 <= cols && xR0 >= 0 && (int)(scaleduR0 + L + w + 1) <= cols;
         if (ok) {
-            const uint8_t* pl = G.pyrL[levelL] + (A.img_stride ? A.imgL * A.img_stride[levelL] : 0) + (size_t)y0 * G.pitchL[levelL] + xL0;
-            const uint8_t* pr = G.pyrR[levelL] + (A.img_stride ? A.imgR * A.img_stride[levelL] : 0) + (size_t)y0 * G.pitchR[levelL] + xR0;
+            const uint8_t* pl = G.pyrL[levelL] + (A.img_strideL ? A.img * A.img_strideL[levelL] : 0) + (size_t)y0 * G.pitchL[levelL] + xL0;
+            const uint8_t* pr = G.pyrR[levelL] + (A.img_strideR ? A.img * A.img_strideR[levelL] : 0) + (size_t)y0 * G.pitchR[levelL] + xR0;
             // lane -> window pixel(s): 121 pixels over 64 lanes (two passes)
             int vl0 = 0, vl1 = 0, o0 = 0, o1 = 0;
             const int p0 = lane, p1 = lane + 64;
@@ -301,8 +301,9 @@ __global__ __launch_bounds__(256) void stereo_rowtable_kernel(StereoBatchArgs B)
     const int rows0 = B.A.rows0;
     int* cnt = rt;
     int* beg = rt + rows0;
-    const int nR = B.counts ? B.counts[2 * pair + 1] : B.A.nR;
-    const msorb_keypoint* kpR = B.counts ? B.A.kpL + ((size_t)2 * pair + 1) * B.capacity : B.A.kpR;
+    const size_t img = (size_t)pair * B.pair_step;
+    const int nR = B.countsR ? B.countsR[img] : B.A.nR;
+    const msorb_keypoint* kpR = B.A.kpR + img * B.capacity;
     int* row_begin = B.row_begin + (size_t)pair * (rows0 + 1);
     int* row_list = B.row_list + (size_t)pair * B.row_cap;
     for (int r = t; r < rows0; r += 256) cnt[r] = 0;
@@ -371,15 +372,15 @@ __global__ __launch_bounds__(256) void stereo_rowtable_kernel(StereoBatchArgs B)
 // The same for every stereo pair of a batch (pair p = images 2p / 2p+1 of msorb_extract_batch): blockIdx.y = pair.
 __global__ __launch_bounds__(256) void stereo_match_batch_kernel(StereoBatchArgs B) {
     const int pair = blockIdx.y;
-    const int nL = B.counts[2 * pair], nR = B.counts[2 * pair + 1];
+    const size_t img = (size_t)pair * B.pair_step;
+    const int nL = B.countsL[img], nR = B.countsR[img];
     const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (iL >= nL) return;
-    const size_t L = (size_t)2 * pair, R = L + 1;
     StereoPairView V{};
-    V.kpL = B.A.kpL + L * B.capacity;
-    V.kpR = B.A.kpL + R * B.capacity;
-    V.descL = B.A.descL + L * B.capacity * 32;
-    V.descR = B.A.descL + R * B.capacity * 32;
+    V.kpL = B.A.kpL + img * B.capacity;
+    V.kpR = B.A.kpR + img * B.capacity;
+    V.descL = B.A.descL + img * B.capacity * 32;
+    V.descR = B.A.descR + img * B.capacity * 32;
     V.nR = nR;
     V.u_right = B.A.u_right + (size_t)pair * B.capacity;
     V.depth = B.A.depth + (size_t)pair * B.capacity;
@@ -387,8 +388,8 @@ __global__ __launch_bounds__(256) void stereo_match_batch_kernel(StereoBatchArgs
     V.n_oob = B.A.n_oob + pair;
     V.row_begin = B.row_begin + (size_t)pair * (B.A.rows0 + 1);
     V.row_list = B.row_list + (size_t)pair * B.row_cap;
-    V.imgL = L; V.imgR = R;
-    V.img_stride = B.img_stride;
+    V.img = img;
+    V.img_strideL = B.img_strideL; V.img_strideR = B.img_strideR;
     stereo_match_one(B.A, V, iL, threadIdx.x & 63);
 }
 
@@ -396,14 +397,15 @@ __global__ __launch_bounds__(256) void stereo_match_batch_kernel(StereoBatchArgs
 // value of rank size/2 — found by a two-level histogram select (SAD <= 121*255 < 2^15); every match whose SAD is not
 // below thDist = 1.5f*1.4f*median is withdrawn (the reference walks the sorted list from the end and stops at the first
 // smaller value: the same set).
-__global__ __launch_bounds__(256) void stereo_median_kernel(const int* __restrict__ counts, int capacity,
+__global__ __launch_bounds__(256) void stereo_median_kernel(const int* __restrict__ countsL, const int* __restrict__ countsR,
+                                                            int pair_step, int capacity,
                                                             const int* __restrict__ sad_all, float* __restrict__ u_right_all,
                                                             float* __restrict__ depth_all, int* __restrict__ counts_out) {
     __shared__ int hist[256];
     __shared__ int sel[3];  // chosen high bin, rank inside it, number of valid SADs
     const int pair = blockIdx.x, t = threadIdx.x;
-    const int nL = counts[2 * pair];
-    if (counts_out && t < 2) counts_out[2 * pair + t] = counts[2 * pair + t];
+    const int nL = countsL[(size_t)pair * pair_step];
+    if (counts_out && t < 2) counts_out[2 * pair + t] = t ? countsR[(size_t)pair * pair_step] : nL;
     const int* sad = sad_all + (size_t)pair * capacity;
     float* u_right = u_right_all + (size_t)pair * capacity;
     float* depth = depth_all + (size_t)pair * capacity;
@@ -492,7 +494,7 @@ void launch_stereo_match_batch(const StereoBatchArgs& b, int n_pairs, int max_le
     if (n_pairs <= 0 || max_left <= 0) return;
     hipLaunchKernelGGL(stereo_rowtable_kernel, dim3(n_pairs), dim3(256), (size_t)(2 * b.A.rows0 + 1) * sizeof(int), s, b);
     hipLaunchKernelGGL(stereo_match_batch_kernel, dim3((max_left + 3) / 4, n_pairs), dim3(256), 0, s, b);
-    hipLaunchKernelGGL(stereo_median_kernel, dim3(n_pairs), dim3(256), 0, s, b.counts, b.capacity, b.A.sad, b.A.u_right,
+    hipLaunchKernelGGL(stereo_median_kernel, dim3(n_pairs), dim3(256), 0, s, b.countsL, b.countsR, b.pair_step, b.capacity, b.A.sad, b.A.u_right,
                        b.A.depth, b.counts_out);
 }
 

@@ -49,14 +49,19 @@ struct StereoArgs {
     const int *row_begin, *row_list;  // vRowIndices as CSR over the rows of level 0 (nullptr: band test per candidate)
 };
 
-struct StereoBatchArgs {  // A: the pointers of image 0 / pair 0; everything else by stride
+// A: the pointers of pair 0 (A.kpL / A.descL / A.pyrL = left eye, A.kpR / A.descR / A.pyrR = right eye).  Pair p lives
+// pair_step images further in every array: pair_step = 2 when both eyes sit interleaved in ONE extract batch (images
+// 2p / 2p+1: the right pointers are the left ones advanced by one image), 1 when the eyes come from two batches (two
+// extractor handles, possibly filled on two devices and gathered).
+struct StereoBatchArgs {
     StereoArgs A;
-    size_t img_stride[MSORB_MAX_LEVELS];
+    size_t img_strideL[MSORB_MAX_LEVELS], img_strideR[MSORB_MAX_LEVELS];
     int capacity;
-    const int* counts;  // device: n_keypoints per image
+    int pair_step;
+    const int *countsL, *countsR;  // device: n_keypoints of the left / right image of pair 0 (pair p at [p * pair_step])
     int *row_begin, *row_list;  // per pair: [rows0 + 1] and [row_cap]
     int row_cap;
-    int* counts_out;            // optional: the median kernel copies counts[2p], counts[2p+1] here (fused per-frame call)
+    int* counts_out;            // optional: the median kernel copies the counts of pair p to [2p], [2p+1] (fused per-frame calls)
 };
 
 void launch_window_topk(const FrameView& F, const WinQuery* q, const uint8_t* qdesc, int q_begin, int q_end,

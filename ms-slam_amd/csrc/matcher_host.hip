@@ -683,23 +683,35 @@ int msorb_stereo_matches(msorb_extractor* left, msorb_extractor* right, const ms
     return MSORB_OK;
 }
 
-int msorb_stereo_matches_batch(msorb_extractor* h, int n_pairs, const msorb_keypoint* d_keypoints,
-                               const uint8_t* d_descriptors, int capacity, const int* d_counts, int max_left, float mb,
-                               float mbf, float* d_u_right, float* d_depth, int* d_n_oob, float* elapsed_ms) {
+// Shared body of the two batch forms: eyes interleaved in one extract batch (right == nullptr) or in two batches.
+static int stereo_batch_impl(msorb_extractor* left, msorb_extractor* right, int n_pairs, const msorb_keypoint* d_kps_left,
+                             const uint8_t* d_desc_left, const int* d_counts_left, const msorb_keypoint* d_kps_right,
+                             const uint8_t* d_desc_right, const int* d_counts_right, int capacity, int max_left, float mb,
+                             float mbf, float* d_u_right, float* d_depth, int* d_n_oob, float* elapsed_ms) {
     if (elapsed_ms) *elapsed_ms = 0;
-    if (!h || n_pairs < 0 || capacity <= 0 || max_left < 0 || max_left > capacity ||
-        (n_pairs > 0 && (!d_keypoints || !d_descriptors || !d_counts || !d_u_right || !d_depth)))
+    if (!left || n_pairs < 0 || capacity <= 0 || max_left < 0 || max_left > capacity ||
+        (n_pairs > 0 && (!d_kps_left || !d_desc_left || !d_counts_left || !d_u_right || !d_depth)) ||
+        (right && n_pairs > 0 && (!d_kps_right || !d_desc_right || !d_counts_right)))
         return MSORB_E_INVALID;
     if (n_pairs == 0 || max_left == 0) return MSORB_OK;
-    PyramidView pv;
+    PyramidView pv, pr;
     LevelScale sc;
     float inv_scale[MSORB_MAX_LEVELS];
-    int dev = 0, n_images = 0;
-    hipStream_t s = nullptr;
+    int dev = 0, n_images = 0, dev_r = 0, n_images_r = 0;
+    hipStream_t s = nullptr, s_r = nullptr;
     int rc;
-    if ((rc = extractor_last_view(h, &pv, &sc, inv_scale, &dev, &s, &n_images))) return rc;
-    if (2 * n_pairs > n_images) {
-        set_last_error("stereo_matches_batch: the last extract call of this handle holds fewer than 2*n_pairs images");
+    if ((rc = extractor_last_view(left, &pv, &sc, inv_scale, &dev, &s, &n_images))) return rc;
+    const int step = right ? 1 : 2;
+    if (right) {
+        if ((rc = extractor_last_view(right, &pr, nullptr, nullptr, &dev_r, &s_r, &n_images_r))) return rc;
+        if (dev_r != dev) { set_last_error("stereo matching needs both pyramids on one device"); return MSORB_E_INVALID; }
+        if (pv.nlevels != pr.nlevels || pv.lv[0].w != pr.lv[0].w || pv.lv[0].h != pr.lv[0].h) {
+            set_last_error("left/right pyramids differ in geometry");
+            return MSORB_E_INVALID;
+        }
+    }
+    if (step * n_pairs > n_images || (right && n_pairs > n_images_r)) {
+        set_last_error("stereo_matches_batch: the last extract call of the handle(s) holds fewer images than n_pairs needs");
         return MSORB_E_INVALID;
     }
     HIPCHK(hipSetDevice(dev));
@@ -737,21 +749,29 @@ int msorb_stereo_matches_batch(msorb_extractor* h, int n_pairs, const msorb_keyp
         return rc;
     int* oob = d_n_oob ? d_n_oob : scr.oob.p;
     StereoBatchArgs b{};
-    b.A.kpL = d_keypoints;
-    b.A.descL = d_descriptors;
+    b.pair_step = step;
+    b.A.kpL = d_kps_left;
+    b.A.descL = d_desc_left;
+    b.A.kpR = right ? d_kps_right : d_kps_left + capacity;
+    b.A.descR = right ? d_desc_right : d_desc_left + (size_t)capacity * 32;
+    b.countsL = d_counts_left;
+    b.countsR = right ? d_counts_right : d_counts_left + 1;
     b.A.rows0 = pv.lv[0].h;
     for (int l = 0; l < pv.nlevels; l++) {
-        b.A.pyrL[l] = b.A.pyrR[l] = pv.lv[l].base;
-        b.A.pitchL[l] = b.A.pitchR[l] = pv.lv[l].pitch;
+        b.A.pyrL[l] = pv.lv[l].base;
+        b.A.pyrR[l] = right ? pr.lv[l].base : pv.lv[l].base + pv.lv[l].img_stride;
+        b.A.pitchL[l] = pv.lv[l].pitch;
+        b.A.pitchR[l] = right ? pr.lv[l].pitch : pv.lv[l].pitch;
         b.A.rows[l] = pv.lv[l].h; b.A.cols[l] = pv.lv[l].w;
         b.A.scale[l] = sc.scale[l]; b.A.inv_scale[l] = inv_scale[l];
-        b.img_stride[l] = pv.lv[l].img_stride;
+        b.img_strideL[l] = pv.lv[l].img_stride;
+        b.img_strideR[l] = right ? pr.lv[l].img_stride : pv.lv[l].img_stride;
     }
     b.A.mb = mb; b.A.mbf = mbf;
     b.A.u_right = d_u_right; b.A.depth = d_depth; b.A.sad = scr.sad.p; b.A.n_oob = oob;
     b.capacity = capacity;
-    b.counts = d_counts;
     b.row_begin = scr.row_begin.p; b.row_list = scr.row_list.p; b.row_cap = row_cap;
+    if (right) HIPCHK(hipStreamSynchronize(s_r));  // the right handle's pyramid was built on its own stream
     HIPCHK(hipMemsetAsync(oob, 0, (size_t)n_pairs * sizeof(int), s));
     HIPCHK(hipEventRecord(scr.e0, s));
     launch_stereo_match_batch(b, n_pairs, max_left, s);
@@ -760,6 +780,22 @@ int msorb_stereo_matches_batch(msorb_extractor* h, int n_pairs, const msorb_keyp
     HIPCHK(hipStreamSynchronize(s));
     if (elapsed_ms) HIPCHK(hipEventElapsedTime(elapsed_ms, scr.e0, scr.e1));
     return MSORB_OK;
+}
+
+int msorb_stereo_matches_batch(msorb_extractor* h, int n_pairs, const msorb_keypoint* d_keypoints,
+                               const uint8_t* d_descriptors, int capacity, const int* d_counts, int max_left, float mb,
+                               float mbf, float* d_u_right, float* d_depth, int* d_n_oob, float* elapsed_ms) {
+    return stereo_batch_impl(h, nullptr, n_pairs, d_keypoints, d_descriptors, d_counts, nullptr, nullptr, nullptr, capacity,
+                             max_left, mb, mbf, d_u_right, d_depth, d_n_oob, elapsed_ms);
+}
+
+int msorb_stereo_matches_split(msorb_extractor* left, msorb_extractor* right, int n_pairs, const msorb_keypoint* d_kps_left,
+                               const uint8_t* d_desc_left, const int* d_counts_left, const msorb_keypoint* d_kps_right,
+                               const uint8_t* d_desc_right, const int* d_counts_right, int capacity, int max_left, float mb,
+                               float mbf, float* d_u_right, float* d_depth, int* d_n_oob, float* elapsed_ms) {
+    if (!right) return MSORB_E_INVALID;
+    return stereo_batch_impl(left, right, n_pairs, d_kps_left, d_desc_left, d_counts_left, d_kps_right, d_desc_right,
+                             d_counts_right, capacity, max_left, mb, mbf, d_u_right, d_depth, d_n_oob, elapsed_ms);
 }
 
 }  // extern "C"

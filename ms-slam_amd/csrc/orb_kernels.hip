@@ -306,13 +306,18 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
                                                          int ini_th, int min_th, int slots_per_image,
                                                          Cand16* __restrict__ slots, int* __restrict__ cell_count,
                                                          int n_cells, uint32_t gx_magic, int debug_stop) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile_mem[kTileFront + GEO::kTileRows * GEO::kTilePitch + 8];
-    __shared__ __attribute__((aligned(16))) uint8_t score[GEO::kScoreRows * GEO::kScorePitch];
+    constexpr int T = GEO::kThreads, P = GEO::kTilePitch, SP = GEO::kScorePitch;
+    constexpr int kScoreBytes = (GEO::kScoreRows * SP + 15) & ~15;
+    constexpr int kBitWords = GEO::kWordsPerRow * GEO::kMaxDet;
+    static_assert(kBitWords <= T, "one bitmap word per thread");
+    __shared__ __attribute__((aligned(16))) uint8_t tile_mem[kTileFront + GEO::kTileRows * P + 8];
+    __shared__ __attribute__((aligned(16))) uint8_t score[kScoreBytes];
     __shared__ uint16_t work[GEO::kWorkCap];
-    __shared__ int wave_tot[2][GEO::kThreads / 64];
-    __shared__ uint32_t kbits[GEO::kWordsPerRow * GEO::kMaxDet];
-    __shared__ int kprefix[GEO::kWordsPerRow * GEO::kMaxDet];
+    __shared__ int wave_tot[2][T / 64];
+    __shared__ uint32_t kbits[kBitWords];
+    __shared__ int kprefix[kBitWords];
     __shared__ uint16_t lut[32];
+    __shared__ uint16_t tbase[T];  // per thread: (tile row of its first detection row) << 7 | tile column of its group
     uint8_t* const tile = tile_mem + kTileFront;
 
     // XCD-aware order: consecutive workgroups are dealt round-robin to the 8 XCDs (each with a private L2); remap
@@ -334,47 +339,54 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
     const int gx0 = x_lo & ~3;            // first 4-pixel group (may start left of x_lo)
     const int G = cd.G;                   // groups per detection row = (x_hi - gx0 + 3) >> 2
     const int c_lo = gx0 - ga;            // tile column of the first group (multiple of 4)
-    const int n_task = dh * G;            // one task = one group of one detection row, scan order
-    const uint32_t magic = cd.g_magic;    // task / G == (task * magic) >> 20 for task < 2^20 / G
-    // balanced consecutive task ranges: thread t owns tasks [t*n/T, (t+1)*n/T)  (<= kMaxRounds each)
-    const int t_begin = (int)(__umul24((uint32_t)tid, (uint32_t)n_task) / GEO::kThreads),
-              t_end = (int)(__umul24((uint32_t)tid + 1u, (uint32_t)n_task) / GEO::kThreads);
+    const uint32_t magic = cd.g_magic;    // n / G == (n * magic) >> 20 for n < 2^20 / G
 
-    // phase 0
-    const uint8_t* src = lv.base + (size_t)img * lv.img_stride + (size_t)cd.y0 * lv.pitch;
+    // phase 0: stage the ROI.  Lane column c = dword of the tile row, kRowsPerPass rows per pass; all passes' loads are issued
+    // back to back (one memory round trip per cell).  Rows past the ROI are clamped to its last row (an unconditional load of
+    // a row that exists; what lands in the tile rows below the ROI is never used), so no pass needs a predicate.
+    const uint8_t* src = lv.base + (size_t)img * lv.img_stride + (size_t)cd.y0 * lv.pitch;  // wave-uniform: SGPR base
     if (ALIGNED) {
-        // 2-D mapping: lane column c = dword of the tile row, kRowsPerPass rows per pass.  All passes' loads are issued
-        // back to back (one memory round trip per cell instead of three) and the addresses are one scalar-offset add
-        // per pass instead of a divide-by-magic per element (13 -> 3 VALU instructions per dword).
-        constexpr int kColLanes = GEO::kTilePitch <= 64 ? 16 : 32;  // dwords per tile row: <= 12 (GeoSmall) / <= 21 (GeoLarge)
-        constexpr int kRowsPerPass = GEO::kThreads / kColLanes;
+        constexpr int kColLanes = P <= 64 ? 16 : 32;  // dwords per tile row: <= 13 (GeoSmall) / <= 21 (GeoLarge)
+        constexpr int kRowsPerPass = T / kColLanes;
         constexpr int kPasses = (GEO::kTileRows - 1 + kRowsPerPass - 1) / kRowsPerPass;  // rh <= kTileRows - 1
-        const int ndw = cd.ndw;  // dwords per tile row = (x0 + rw - ga + 3) >> 2
         const int c = tid & (kColLanes - 1), r0 = tid / kColLanes;
-        if (c < ndw) {
-            const uint8_t* g0 = src + (__umul24((uint32_t)r0, (uint32_t)lv.pitch) + (uint32_t)(ga + 4 * c));
-            uint8_t* l0 = &tile[r0 * GEO::kTilePitch + 4 * c];
+        if (c < cd.ndw) {  // dwords per tile row = (x0 + rw - ga + 3) >> 2
+            const uint32_t col = (uint32_t)(ga + 4 * c);
             uint32_t v[kPasses];
 #pragma unroll
-            for (int p = 0; p < kPasses; p++)
-                if (r0 + p * kRowsPerPass < rh)
-                    v[p] = *reinterpret_cast<const uint32_t*>(g0 + (size_t)(p * kRowsPerPass) * (size_t)lv.pitch);
+            for (int p = 0; p < kPasses; p++) {
+                const uint32_t row = (uint32_t)min(r0 + p * kRowsPerPass, rh - 1);
+                v[p] = *reinterpret_cast<const uint32_t*>(src + (__umul24(row, (uint32_t)lv.pitch) + col));
+            }
+            uint8_t* l0 = &tile[r0 * P + 4 * c];
 #pragma unroll
             for (int p = 0; p < kPasses; p++)
-                if (r0 + p * kRowsPerPass < rh) *reinterpret_cast<uint32_t*>(l0 + p * kRowsPerPass * GEO::kTilePitch) = v[p];
+                if ((p + 1) * kRowsPerPass <= GEO::kTileRows || r0 + p * kRowsPerPass < GEO::kTileRows)
+                    *reinterpret_cast<uint32_t*>(l0 + p * kRowsPerPass * P) = v[p];
         }
     } else {
         const int off = cd.x0 - ga;
         const uint32_t bmagic = cd.rw_magic;
-        for (int i = tid; i < rh * rw; i += GEO::kThreads) {
+        for (int i = tid; i < rh * rw; i += T) {
             const int y = (int)(__umul24((uint32_t)i, bmagic) >> 20), x = i - (int)__umul24((uint32_t)y, (uint32_t)rw);
-            tile[(int)__umul24((uint32_t)y, GEO::kTilePitch) + off + x] = src[(size_t)(__umul24((uint32_t)y, (uint32_t)lv.pitch) + (uint32_t)(cd.x0 + x))];
+            tile[(int)__umul24((uint32_t)y, P) + off + x] = src[(size_t)(__umul24((uint32_t)y, (uint32_t)lv.pitch) + (uint32_t)(cd.x0 + x))];
         }
     }
+    // score plane and keep-bitmap start at zero (16-byte stores, no loop)
+    auto clear_planes = [&]() {
+#pragma unroll
+        for (int k = 0; k < (kScoreBytes / 16 + T - 1) / T; k++)
+            if ((k + 1) * T <= kScoreBytes / 16 || tid + k * T < kScoreBytes / 16)
+                reinterpret_cast<uint4*>(score)[tid + k * T] = uint4{0, 0, 0, 0};
+        if (tid < kBitWords) kbits[tid] = 0;
+    };
+    clear_planes();
+    if (tid < 32) lut[tid] = (uint16_t)((((tid >> 1) & 3) << 7) + (tid >> 3) + ((tid & 1) << 15));  // flag bit -> work entry offset
+
     // Quick-test mapping: thread (strip, g) owns the 4-pixel column group g of R consecutive detection rows, so the column
     // clipping is a per-thread constant and the rows above / below come out of one register window.
     const int strip = (int)(__umul24((uint32_t)tid, magic) >> 20), g_own = tid - strip * G;
-    const int R = GEO::kThreads == 128 ? cd.R128 : cd.R256;
+    const int R = T == 128 ? cd.R128 : cd.R256;         // wave-uniform
     const int y_b = strip * R;                          // first detection row of the thread
     const int nrows = min(max(dh - y_b, 0), R);         // 0 for the threads beyond the last strip
     const int c_own = c_lo + 4 * g_own;                 // tile column of pixel 0 of the group
@@ -382,10 +394,10 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
     {
         const int xg = ga + c_own;
         const int vlo = min(max(x_lo - xg, 0), 4), vhi = min(max(x_hi - xg, 0), 4);
-        const uint32_t m4 = (0xFu << vlo) & (0xFu >> (4 - vhi)) & 0xFu;
-        Hm = ((m4 & 1u) << 7) | ((m4 & 2u) << 14) | ((m4 & 4u) << 21) | ((m4 & 8u) << 28);
+        Hm = (0x80808080u << (8 * vlo)) & (uint32_t)(0x0080808080ull >> (8 * (4 - vhi)));  // shifts by 32 must give 0
+        if (vlo >= 4) Hm = 0;
     }
-    if (tid < 32) lut[tid] = (uint16_t)((((tid >> 1) & 3) << 7) + (tid >> 3) + ((tid & 1) << 15));  // flag bit -> work entry offset
+    tbase[tid] = (uint16_t)(((y_b + 3) << 7) | c_own);
     // Quick test at threshold th for the thread's rows: wA / wB receive 2 flags (dark, bright) per pixel, bit 8 j + 2 k (+ 1)
     // for pixel j of row k (rows 0..3 in wA, 4.. in wB).  All four pixels of a group are tested at once on raw bytes:
     //   A = sat0(v - t), B = sat255(v + t) per byte (v_pk_sub_u16 clamp on the even / odd bytes),
@@ -395,27 +407,31 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
     // pair: a corner needs the predicate for (up OR down) AND (left OR right).
     auto quick_test = [&](int th, uint32_t& wA, uint32_t& wB) {
         wA = 0; wB = 0;
-        const uint8_t* colp = &tile[(int)__umul24((uint32_t)y_b, GEO::kTilePitch) + c_own];
+        const uint8_t* colp = &tile[(int)__umul24((uint32_t)y_b, P) + c_own];
         uint32_t cw[GEO::kMaxR + 6], lw[GEO::kMaxR], rw_[GEO::kMaxR];
 #pragma unroll
-        for (int r = 0; r < GEO::kMaxR + 6; r++) cw[r] = *reinterpret_cast<const uint32_t*>(colp + r * GEO::kTilePitch);
+        for (int r = 0; r < GEO::kMaxR + 6; r++)
+            if (r < 9 || r - 6 < R) cw[r] = *reinterpret_cast<const uint32_t*>(colp + r * P);
 #pragma unroll
-        for (int k = 0; k < GEO::kMaxR; k++) {
-            lw[k] = *reinterpret_cast<const uint32_t*>(colp + (k + 3) * GEO::kTilePitch - 4);
-            rw_[k] = *reinterpret_cast<const uint32_t*>(colp + (k + 3) * GEO::kTilePitch + 4);
-        }
+        for (int k = 0; k < GEO::kMaxR; k++)
+            if (k < 3 || k < R) {
+                lw[k] = *reinterpret_cast<const uint32_t*>(colp + (k + 3) * P - 4);
+                rw_[k] = *reinterpret_cast<const uint32_t*>(colp + (k + 3) * P + 4);
+            }
         const ushort2v t2 = __builtin_bit_cast(ushort2v, (uint32_t)th * 0x00010001u);
 #pragma unroll
         for (int k = 0; k < GEO::kMaxR; k++) {
+            if (k >= 3 && k >= R) break;  // wave-uniform: the cells of the BASELINE geometries have R = 3 or 4
             const uint32_t V = cw[k + 3], U = cw[k], D = cw[k + 6];
             const uint32_t R3 = __builtin_amdgcn_alignbyte(rw_[k], V, 3);  // p[x+3] per byte
             const uint32_t L3 = __builtin_amdgcn_alignbyte(V, lw[k], 1);   // p[x-3] per byte
-            const uint32_t nV = ~V;
-            const uint32_t Ae = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, V & 0x00ff00ffu), t2));
-            const uint32_t Ao = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, (V >> 8) & 0x00ff00ffu), t2));
+            // A = sat0(v - t), ~B = sat0(~v - t) on the even / odd bytes (16-bit lanes cannot borrow from each other)
+            const uint32_t Ve = V & 0x00ff00ffu, Vo = (V >> 8) & 0x00ff00ffu;
+            const uint32_t Ae = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, Ve), t2));
+            const uint32_t Ao = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, Vo), t2));
             const uint32_t Qd = ~(Ae | (Ao << 8));
-            const uint32_t Be = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, nV & 0x00ff00ffu), t2));
-            const uint32_t Bo = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, (nV >> 8) & 0x00ff00ffu), t2));
+            const uint32_t Be = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, Ve ^ 0x00ff00ffu), t2));
+            const uint32_t Bo = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, Vo ^ 0x00ff00ffu), t2));
             const uint32_t Qb = Be | (Bo << 8);
             const uint32_t one = 0x01010101u;
             // dark: bit 7 SET means "not darker"
@@ -429,173 +445,167 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
             else wB |= z >> (6 - 2 * (k - 4));
         }
     };
-    // Threshold passes (ORBextractor.cc:826,843-847): iniThFAST first; only a cell that ends up with no keypoint at all
-    // is redone at minThFAST.  NMS at a threshold only sees the corners of that threshold (the others score 0 there),
-    // so the first pass needs nothing below iniThFAST — half the quick-test survivors and arc tests of a minTh pass.
-    int n_emitted = 0;
-    for (int pass = 0; pass < 2; pass++) {
-    const int th = pass ? min_th : ini_th;
-    for (int i = tid; i < (dh + 2) * (GEO::kScorePitch / 4); i += GEO::kThreads) reinterpret_cast<uint32_t*>(score)[i] = 0;
     __syncthreads();
     if (debug_stop == 1) return;
 
-    // phase 1
-    uint32_t wA, wB;
-    quick_test(th, wA, wB);
-    const int cnt = __popc(wA) + __popc(wB);
-    int n_work = 0;
-    const int my_base = block_excl_scan<GEO::kThreads / 64>(cnt, lane, wave, wave_tot[0], &n_work);
-    if (debug_stop == 2) return;
-
-    // phase 2: every (pixel, polarity) that passed goes to the work list; the list is then processed with all lanes busy
+    // Threshold passes (ORBextractor.cc:826,843-847): iniThFAST first; only a cell that ends up with no keypoint at all
+    // is redone at minThFAST.  NMS at a threshold only sees the corners of that threshold (the others score 0 there),
+    // so the first pass needs nothing below iniThFAST — half the quick-test survivors and arc tests of a minTh pass.
     const int sc_off = 4 - c_lo;  // score column = tile column + sc_off  (first group at score column 4)
-    const uint32_t baseA = (uint32_t)(((y_b + 3) << 7) | c_own), baseB = baseA + (4u << 7);
-    if (n_work <= GEO::kWorkCap) {
-        uint16_t* wp = &work[my_base];
-        for (uint32_t w = wA; w; w &= w - 1) *wp++ = (uint16_t)(lut[__builtin_ctz(w)] + baseA);
-        for (uint32_t w = wB; w; w &= w - 1) *wp++ = (uint16_t)(lut[__builtin_ctz(w)] + baseB);
-        __syncthreads();
-        if (debug_stop == 3) return;
-        for (int i = tid; i < n_work; i += GEO::kThreads) {
-            const int e = work[i];
-            const int ty = (e >> 7) & 127, tx = e & 127;
-            const int A = fast_arc_contrast<GEO>(&tile[(int)__umul24((uint32_t)ty, GEO::kTilePitch) + tx], (e & 0x8000) ? -1 : 1);
-            if (A > th) score[(int)__umul24((uint32_t)(ty - 2), GEO::kScorePitch) + tx + sc_off] = (uint8_t)(A - 1);  // score row = y + 1
-            work[i] = A > th ? (uint16_t)(e & 0x3FFF) : (uint16_t)0xFFFF;  // the list now holds the corners
-        }
-    } else {
-        // saturated cell (more quick-test survivors than the list holds): every thread scores its own survivors
-#pragma unroll 1
-        for (int half = 0; half < 2; half++)
-#pragma unroll 1
-            for (uint32_t w = half ? wB : wA; w; w &= w - 1) {
-                const int e = lut[__builtin_ctz(w)] + (half ? baseB : baseA);
+    Cand16* const out = slots + (size_t)img * slots_per_image + cd.slot_off;
+    int n_emitted = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        const int th = pass ? min_th : ini_th;
+        // phase 1
+        uint32_t wA, wB;
+        quick_test(th, wA, wB);
+        const int cnt = __popc(wA) + __popc(wB);
+        int n_work = 0;
+        const int my_base = block_excl_scan<T / 64>(cnt, lane, wave, wave_tot[0], &n_work);
+        if (debug_stop == 2) return;
+
+        // phase 2: every (pixel, polarity) that passed goes to the work list; the list is then processed with all lanes busy
+        // (S = A' - 1 with A' = max over the 16 arcs of the min over 9 contiguous signed contrasts of the entry's polarity)
+        // (the append loop runs as long as the busiest lane of the wave has flags left, so it only packs thread id and flag
+        // bit; the list's consumers — all lanes busy — turn that into tile coordinates through two small tables)
+        const uint32_t baseA = (uint32_t)(((y_b + 3) << 7) | c_own), baseB = baseA + (4u << 7);
+        if (n_work <= GEO::kWorkCap) {
+            uint16_t* wp = &work[my_base];
+            const uint32_t idA = (uint32_t)tid << 5, idB = idA | (1u << (5 + (T == 128 ? 7 : 8)));
+            for (uint32_t w = wA; w; w &= w - 1) *wp++ = (uint16_t)(idA | (uint32_t)__builtin_ctz(w));
+            for (uint32_t w = wB; w; w &= w - 1) *wp++ = (uint16_t)(idB | (uint32_t)__builtin_ctz(w));
+            __syncthreads();
+            if (debug_stop == 3) return;
+            for (int i = tid; i < n_work; i += T) {
+                const int id = work[i];
+                const int e = tbase[(id >> 5) & (T - 1)] + lut[id & 31] + ((id >> (5 + (T == 128 ? 7 : 8))) << 9);
                 const int ty = (e >> 7) & 127, tx = e & 127;
-                const int A = fast_arc_contrast<GEO>(&tile[(int)__umul24((uint32_t)ty, GEO::kTilePitch) + tx], (e & 0x8000) ? -1 : 1);
-                if (A > th) score[(int)__umul24((uint32_t)(ty - 2), GEO::kScorePitch) + tx + sc_off] = (uint8_t)(A - 1);
+                const int A = fast_arc_contrast<GEO>(&tile[(int)__umul24((uint32_t)ty, P) + tx], (e & 0x8000) ? -1 : 1);
+                if (A > th) score[(int)__umul24((uint32_t)(ty - 2), SP) + tx + sc_off] = (uint8_t)(A - 1);  // score row = y + 1
+                work[i] = A > th ? (uint16_t)(e & 0x3FFF) : (uint16_t)0xFFFF;  // the list now holds the corners
             }
-    }
-    __syncthreads();
-    if (debug_stop == 4) return;
-
-    Cand16* out = slots + (size_t)img * slots_per_image + cd.slot_off;
-    if (n_work <= GEO::kWorkCap) {
-        // phase 3 (common case: the whole work list fitted): NMS and ordered emission driven by the corner list.
-        // kept corners set a bit in a row-major bitmap of the detection area; the rank of a corner in scan order is
-        // the popcount of the bits before it (prefix over the bitmap words).
-        constexpr int wpr = GEO::kWordsPerRow;  // bitmap words per detection row
-        const int nwords = dh * wpr;
-        for (int i = tid; i < nwords; i += GEO::kThreads) kbits[i] = 0;
-        __syncthreads();
-        uint32_t mine_keep = 0;  // per-thread record of the corners it owns: up to 16 list slots (cap / threads <= 32)
-        {
-            int slot = 0;
-            for (int i = tid; i < n_work; i += GEO::kThreads, slot++) {
-                const int e = work[i];
-                if (e == 0xFFFF) continue;
-                const int ty = e >> 7, tx = e & 127;
-                const uint8_t* q = &score[(int)__umul24((uint32_t)(ty - 2), GEO::kScorePitch) + tx + sc_off];
-                const int sv = q[0];
-                int m = max3i(q[-GEO::kScorePitch - 1], q[-GEO::kScorePitch], q[-GEO::kScorePitch + 1]);
-                m = max3i(m, q[-1], q[1]);
-                m = max(m, max3i(q[GEO::kScorePitch - 1], q[GEO::kScorePitch], q[GEO::kScorePitch + 1]));
-                if (sv > m) {
-                    const int bx = tx - c_lo, by = ty - 3;       // column inside the group span, detection row
-                    const int b = by * (32 * wpr) + bx;
-                    atomicOr(&kbits[b >> 5], 1u << (b & 31));
-                    mine_keep |= 1u << slot;
+        } else {
+            // saturated cell (more quick-test survivors than the list holds): every thread scores its own survivors
+#pragma unroll 1
+            for (int half = 0; half < 2; half++)
+#pragma unroll 1
+                for (uint32_t w = half ? wB : wA; w; w &= w - 1) {
+                    const int e = lut[__builtin_ctz(w)] + (half ? baseB : baseA);
+                    const int ty = (e >> 7) & 127, tx = e & 127;
+                    const int A = fast_arc_contrast<GEO>(&tile[(int)__umul24((uint32_t)ty, P) + tx], (e & 0x8000) ? -1 : 1);
+                    if (A > th) score[(int)__umul24((uint32_t)(ty - 2), SP) + tx + sc_off] = (uint8_t)(A - 1);
                 }
-            }
         }
         __syncthreads();
-        const uint32_t* sel_bits = kbits;
-        // prefix popcount over the selected bitmap
-        int n_out2 = 0;
-        const int wper = (nwords + GEO::kThreads - 1) / GEO::kThreads;  // consecutive bitmap words per thread
-        const int wb = tid * wper, we = min(wb + wper, nwords);
-        int wcount = 0;
-        for (int i = wb; i < we; i++) wcount += __popc(sel_bits[i]);
-        int wprefix = block_excl_scan<GEO::kThreads / 64>(wcount, lane, wave, wave_tot[1], &n_out2);
-        for (int i = wb; i < we; i++) { kprefix[i] = wprefix; wprefix += __popc(sel_bits[i]); }
-        __syncthreads();
-        {
-            int slot = 0;
-            for (int i = tid; i < n_work; i += GEO::kThreads, slot++) {
-                if (!(mine_keep & (1u << slot))) continue;
-                const int e = work[i];
-                const int ty = e >> 7, tx = e & 127;
-                const int b = (ty - 3) * (32 * wpr) + (tx - c_lo);
-                const uint32_t wbits = sel_bits[b >> 5];
-                const int rank = kprefix[b >> 5] + __popc(wbits & ((1u << (b & 31)) - 1u));
-                Cand16 c;
-                c.x = (uint16_t)(ga + tx - kMinBorder);
-                c.y = (uint16_t)(cd.y0 + ty - kMinBorder);
-                c.score = score[(int)__umul24((uint32_t)(ty - 2), GEO::kScorePitch) + tx + sc_off];
-                c.pad = 0;
-                out[rank] = c;
-            }
-        }
-        n_emitted = n_out2;
-    } else {
-    // saturated cell (more quick-test survivors than the work list holds): scan the score plane by tasks
+        if (debug_stop == 4) return;
 
-    // phase 3a: strict 3x3 NMS, 4 flag bits per task
-    uint64_t keep = 0, keep_ini = 0;
-    {
-        int y = (int)(__umul24((uint32_t)t_begin, magic) >> 20);
-        int g = t_begin - y * G;
-        for (int task = t_begin, k = 0; task < t_end; task++, k++) {
-            const uint8_t* sp = &score[(y + 1) * GEO::kScorePitch + 4 + 4 * g];
-            const uint32_t S = *reinterpret_cast<const uint32_t*>(sp);
-            if (S) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int sv = (S >> (8 * j)) & 255;
-                    if (sv) {
-                        const uint8_t* q = sp + j;
-                        int m = max3i(q[-GEO::kScorePitch - 1], q[-GEO::kScorePitch], q[-GEO::kScorePitch + 1]);
-                        m = max3i(m, q[-1], q[1]);
-                        m = max(m, max3i(q[GEO::kScorePitch - 1], q[GEO::kScorePitch], q[GEO::kScorePitch + 1]));
-                        if (sv > m) {
-                            keep |= 1ull << (4 * k + j);
-                            keep_ini |= 1ull << (4 * k + j);
-                        }
+        if (n_work <= GEO::kWorkCap) {
+            // phase 3 (common case: the whole work list fitted): NMS and ordered emission driven by the corner list.
+            // kept corners set a bit in a row-major bitmap of the detection area; the rank of a corner in scan order is
+            // the popcount of the bits before it (prefix over the bitmap words, one word per thread).
+            constexpr int wpr = GEO::kWordsPerRow;  // bitmap words per detection row
+            const int nwords = dh * wpr;
+            uint32_t mine_keep = 0;  // per-thread record of the corners it owns: list slots tid, tid + T, ... (cap / T <= 32)
+            {
+                int slot = 0;
+                for (int i = tid; i < n_work; i += T, slot++) {
+                    const int e = work[i];
+                    if (e == 0xFFFF) continue;
+                    const int ty = e >> 7, tx = e & 127;
+                    const uint8_t* q = &score[(int)__umul24((uint32_t)(ty - 2), SP) + tx + sc_off];
+                    const int sv = q[0];
+                    int m = max3i(q[-SP - 1], q[-SP], q[-SP + 1]);
+                    m = max3i(m, q[-1], q[1]);
+                    m = max(m, max3i(q[SP - 1], q[SP], q[SP + 1]));
+                    if (sv > m) {
+                        const int bx = tx - c_lo, by = ty - 3;       // column inside the group span, detection row
+                        const int b = by * (32 * wpr) + bx;
+                        atomicOr(&kbits[b >> 5], 1u << (b & 31));
+                        mine_keep |= 1u << slot;
                     }
                 }
             }
-            if (++g == G) { g = 0; y++; }
-        }
-    }
-    const int any_ini = __syncthreads_or(keep_ini != 0);
-    const uint64_t sel = any_ini ? keep_ini : keep;
-
-    // phase 3b: ordered emission — a thread's tasks are consecutive in scan order, so the block-wide prefix of the
-    // per-thread counts is the rank in (ascending y, then x) order
-    int n_out = 0;
-    int pos = block_excl_scan<GEO::kThreads / 64>(__popcll(sel), lane, wave, wave_tot[1], &n_out);
-    if (sel) {
-        int y = (int)(__umul24((uint32_t)t_begin, magic) >> 20);
-        int g = t_begin - y * G;
-        uint64_t m = sel;
-        for (int task = t_begin; task < t_end; task++, m >>= 4) {
-            uint32_t m4 = (uint32_t)m & 15u;
-            while (m4) {
-                const int j = __ffs(m4) - 1;
-                m4 &= m4 - 1;
-                Cand16 c;
-                c.x = (uint16_t)(gx0 + 4 * g + j - kMinBorder);
-                c.y = (uint16_t)(cd.y0 + 3 + y - kMinBorder);
-                c.score = score[(y + 1) * GEO::kScorePitch + 4 + 4 * g + j];
-                c.pad = 0;
-                out[pos++] = c;
+            __syncthreads();
+            const uint32_t myword = tid < nwords ? kbits[tid] : 0u;
+            int n_out = 0;
+            const int wprefix = block_excl_scan<T / 64>(__popc(myword), lane, wave, wave_tot[1], &n_out);
+            if (tid < nwords) kprefix[tid] = wprefix;
+            __syncthreads();
+            {
+                int slot = 0;
+                for (int i = tid; i < n_work; i += T, slot++) {
+                    if (!(mine_keep & (1u << slot))) continue;
+                    const int e = work[i];
+                    const int ty = e >> 7, tx = e & 127;
+                    const int b = (ty - 3) * (32 * wpr) + (tx - c_lo);
+                    const int rank = kprefix[b >> 5] + __popc(kbits[b >> 5] & ((1u << (b & 31)) - 1u));
+                    Cand16 c;
+                    c.x = (uint16_t)(ga + tx - kMinBorder);
+                    c.y = (uint16_t)(cd.y0 + ty - kMinBorder);
+                    c.score = score[(int)__umul24((uint32_t)(ty - 2), SP) + tx + sc_off];
+                    c.pad = 0;
+                    out[rank] = c;
+                }
             }
-            if (++g == G) { g = 0; y++; }
+            n_emitted = n_out;
+        } else {
+            // saturated cell: strict 3x3 NMS by scanning the score plane; one task = one group of one detection row in scan
+            // order, balanced consecutive task ranges per thread (thread t owns tasks [t*n/T, (t+1)*n/T)), 4 flag bits per task
+            const int n_task = dh * G;
+            const int t_begin = (int)(__umul24((uint32_t)tid, (uint32_t)n_task) / T),
+                      t_end = (int)(__umul24((uint32_t)tid + 1u, (uint32_t)n_task) / T);
+            uint64_t keep = 0;
+            {
+                int y = (int)(__umul24((uint32_t)t_begin, magic) >> 20);
+                int g = t_begin - y * G;
+                for (int task = t_begin, k = 0; task < t_end; task++, k++) {
+                    const uint8_t* sp = &score[(y + 1) * SP + 4 + 4 * g];
+                    const uint32_t S = *reinterpret_cast<const uint32_t*>(sp);
+                    if (S) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int sv = (S >> (8 * j)) & 255;
+                            if (sv) {
+                                const uint8_t* q = sp + j;
+                                int m = max3i(q[-SP - 1], q[-SP], q[-SP + 1]);
+                                m = max3i(m, q[-1], q[1]);
+                                m = max(m, max3i(q[SP - 1], q[SP], q[SP + 1]));
+                                if (sv > m) keep |= 1ull << (4 * k + j);
+                            }
+                        }
+                    }
+                    if (++g == G) { g = 0; y++; }
+                }
+            }
+            // ordered emission — a thread's tasks are consecutive in scan order, so the block-wide prefix of the
+            // per-thread counts is the rank in (ascending y, then x) order
+            int n_out = 0;
+            int pos = block_excl_scan<T / 64>(__popcll(keep), lane, wave, wave_tot[1], &n_out);
+            if (keep) {
+                int y = (int)(__umul24((uint32_t)t_begin, magic) >> 20);
+                int g = t_begin - y * G;
+                uint64_t m = keep;
+                for (int task = t_begin; task < t_end; task++, m >>= 4) {
+                    uint32_t m4 = (uint32_t)m & 15u;
+                    while (m4) {
+                        const int j = __ffs(m4) - 1;
+                        m4 &= m4 - 1;
+                        Cand16 c;
+                        c.x = (uint16_t)(gx0 + 4 * g + j - kMinBorder);
+                        c.y = (uint16_t)(cd.y0 + 3 + y - kMinBorder);
+                        c.score = score[(y + 1) * SP + 4 + 4 * g + j];
+                        c.pad = 0;
+                        out[pos++] = c;
+                    }
+                    if (++g == G) { g = 0; y++; }
+                }
+            }
+            n_emitted = n_out;
         }
-    }
-    n_emitted = n_out;
-    }
-    if (n_emitted > 0 || pass == 1 || ini_th == min_th) break;
-    __syncthreads();
+        if (n_emitted > 0 || pass == 1 || ini_th == min_th) break;
+        __syncthreads();
+        clear_planes();   // (kept corners there were none; the scores of the failed pass must not leak into the next)
+        __syncthreads();
     }
     if (tid == 0) cell_count[(size_t)img * n_cells + cell_id] = n_emitted;
 }

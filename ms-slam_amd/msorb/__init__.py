@@ -28,6 +28,7 @@ EXPORTS = (
     "msorb_extractor_tables", "msorb_extractor_capacity", "msorb_extract", "msorb_pyramid_level",
     "msorb_extract_batch", "msorb_extractor_set_profiling", "msorb_extractor_set_overlap", "msorb_extractor_stage_ms", "msorb_debug_level_size",
     "msorb_debug_copy_level", "msorb_debug_candidates", "msorb_distribute_quadtree", "msorb_extract_stereo",
+    "msorb_extract_stereo_split", "msorb_pyramid_batch", "msorb_stereo_matches_split",
 )
 
 
@@ -170,6 +171,36 @@ class ORBextractor:
                                            _np_ptr(dp), C.byref(oob)), "msorb_extract_stereo")
         a, b = nl.value, nr.value
         return kl[:a].copy(), dl[:a].copy(), kr[:b].copy(), dr[:b].copy(), ur[:a].copy(), dp[:a].copy(), oob.value
+
+    def extract_stereo_split(self, right_ex, left, right, mb, mbf):
+        """msorb_extract_stereo_split: self = the left extractor (device A), right_ex = the right extractor (device B, may
+        equal A): each eye on its own device, gather onto A, Frame::ComputeStereoMatches on A.  Same return as extract_stereo."""
+        left, right = np.ascontiguousarray(left, np.uint8), np.ascontiguousarray(right, np.uint8)
+        assert left.shape == right.shape and left.ndim == 2
+        rows, cols = left.shape
+        cap = self.capacity
+        kl, kr = np.zeros(cap, KP_DTYPE), np.zeros(cap, KP_DTYPE)
+        dl, dr = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
+        ur, dp = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+        nl, nr, oob = C.c_int(0), C.c_int(0), C.c_int(0)
+        vp = C.c_void_p
+        self.L.msorb_extract_stereo_split.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_float,
+                                                      C.c_float, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]
+        _check(self.L.msorb_extract_stereo_split(self.h, right_ex.h, _np_ptr(left), _np_ptr(right), rows, cols, cols, cols, mb,
+                                                 mbf, _np_ptr(kl), _np_ptr(dl), C.byref(nl), _np_ptr(kr), _np_ptr(dr),
+                                                 C.byref(nr), cap, _np_ptr(ur), _np_ptr(dp), C.byref(oob)),
+               "msorb_extract_stereo_split")
+        a, b = nl.value, nr.value
+        return kl[:a].copy(), dl[:a].copy(), kr[:b].copy(), dr[:b].copy(), ur[:a].copy(), dp[:a].copy(), oob.value
+
+    def pyramid_batch(self, images):
+        """msorb_pyramid_batch: ComputePyramid only, for a torch.uint8 CUDA tensor [n, rows, cols] (asynchronous)."""
+        import torch
+        assert images.is_cuda and images.dtype == torch.uint8 and images.dim() == 3 and images.stride(2) == 1
+        n, rows, cols = images.shape
+        self.L.msorb_pyramid_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t]
+        _check(self.L.msorb_pyramid_batch(self.h, images.data_ptr(), n, rows, cols, images.stride(1), images.stride(0)),
+               "msorb_pyramid_batch")
 
     def pyramid_level(self, level):
         """mvImagePyramid[level] of the last __call__ as a numpy array (copy)."""
@@ -741,6 +772,36 @@ def stereo_matches_batch(ex, counts, d_kps, d_desc, mb, mbf):
     _check(lb.msorb_stereo_matches_batch(ex.h, n_pairs, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_counts.data_ptr(),
                                          max_left, mb, mbf, d_ur.data_ptr(), d_dp.data_ptr(), d_oob.data_ptr(),
                                          C.addressof(ms)), "msorb_stereo_matches_batch")
+    return d_ur, d_dp, d_oob[:n_pairs].cpu().numpy(), ms.value
+
+
+def stereo_matches_split(ex_left, ex_right, counts_left, d_kps_left, d_desc_left, counts_right, d_kps_right, d_desc_right,
+                         mb, mbf):
+    """msorb_stereo_matches_split: left images = the last batch of ex_left, right images = the last batch (extract_batch or
+    pyramid_batch) of ex_right, both on one device; the right keypoints / descriptors / counts may come from elsewhere
+    (gathered).  counts_* are numpy arrays or CUDA int32 tensors.  -> (d_u_right, d_depth [n_pairs, cap], n_oob, kernel_ms)."""
+    import torch
+    lb = lib()
+    vp = C.c_void_p
+    lb.msorb_stereo_matches_split.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float,
+                                              vp, vp, vp, vp]
+    dev = d_kps_left.device
+
+    def dcount(c):
+        return c if torch.is_tensor(c) else torch.from_numpy(np.ascontiguousarray(c, np.int32)).to(dev)
+    d_cl, d_cr = dcount(counts_left), dcount(counts_right)
+    n_pairs = int(d_cl.numel())
+    cap = d_kps_left.shape[1]
+    d_ur = torch.full((n_pairs, cap), -1.0, dtype=torch.float32, device=dev)
+    d_dp = torch.full((n_pairs, cap), -1.0, dtype=torch.float32, device=dev)
+    d_oob = torch.zeros(max(n_pairs, 1), dtype=torch.int32, device=dev)
+    max_left = int(d_cl.max().item()) if n_pairs else 0
+    torch.cuda.synchronize(dev)
+    ms = C.c_float()
+    _check(lb.msorb_stereo_matches_split(ex_left.h, ex_right.h, n_pairs, d_kps_left.data_ptr(), d_desc_left.data_ptr(),
+                                         d_cl.data_ptr(), d_kps_right.data_ptr(), d_desc_right.data_ptr(), d_cr.data_ptr(), cap,
+                                         max_left, mb, mbf, d_ur.data_ptr(), d_dp.data_ptr(), d_oob.data_ptr(),
+                                         C.addressof(ms)), "msorb_stereo_matches_split")
     return d_ur, d_dp, d_oob[:n_pairs].cpu().numpy(), ms.value
 
 
