@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--pairs", type=int, default=128, help="stereo pairs per step per GPU-pair group")
     ap.add_argument("--cpu-pairs", type=int, default=160, help="stereo pairs in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--unique-pairs", type=int, default=8, help="distinct synthetic stereo pairs tiled to the batch (<= --pairs)")
     ap.add_argument("--isolated", action="store_true",
                     help="profiling aid: no sub-batch / blur overlap anywhere, so every kernel launch covers the whole "
                          "batch and runs alone (rocprofv3 per-kernel durations and PMC traffic are then per-launch clean)")
@@ -139,36 +140,76 @@ def main():
     B = args.pairs
     # images of this rank: N=1 -> L,R interleaved (2B images); N>1 -> one eye of 2B pairs (2B images): fixed per-GPU work
     group, eye = (rank // 2, rank % 2) if world > 1 else (0, None)
-    uniq = min(B, 8)  # distinct synthetic pairs, tiled to the batch size (content repeats, bytes do not alias)
+    uniq = min(B, args.unique_pairs)  # distinct synthetic pairs, tiled to the batch size (content repeats, bytes do not alias)
     base = synth.stereo_batch(uniq, cfg["rows"], cfg["cols"], seed0=1000 * group)
+    pitch = (cfg["cols"] + 63) // 64 * 64
+
+    def resident(host_imgs):
+        # device-resident input batch with a 64-byte row pitch (what hipMemcpy2D / a camera DMA would produce);
+        # the API accepts any stride, aligned rows take the fast kernel variants
+        st = torch.zeros((host_imgs.shape[0], cfg["rows"], pitch), dtype=torch.uint8, device=dev)
+        v = st[:, :, :cfg["cols"]]
+        v.copy_(torch.from_numpy(np.ascontiguousarray(host_imgs)).to(dev))
+        return v
+
+    other_images = None
     if world == 1:
         host = np.concatenate([base] * (B // uniq + 1))[:2 * B]
     else:
         one_eye = base[eye::2]
         host = np.concatenate([one_eye] * (2 * B // uniq + 1))[:2 * B]
-    # device-resident input batch with a 64-byte row pitch (what hipMemcpy2D / a camera DMA would produce);
-    # the API accepts any stride, aligned rows take the fast kernel variants
+        if eye == 0:
+            # the left-eye rank also holds the right images (the capture DMA delivers both eyes to it): it rebuilds the right
+            # pyramid for the stereo SAD locally (0.22 ms per 256 images) instead of pulling 1.5 MB per frame over xGMI;
+            # only the 60 B per keypoint cross the link (BASELINE configs[3]: "gather of keypoints/descriptors")
+            other = base[1::2]
+            other_images = resident(np.concatenate([other] * (2 * B // uniq + 1))[:2 * B])
     n_img = host.shape[0]
-    pitch = (cfg["cols"] + 63) // 64 * 64
-    storage = torch.zeros((n_img, cfg["rows"], pitch), dtype=torch.uint8, device=dev)
-    images = storage[:, :, :cfg["cols"]]
-    images.copy_(torch.from_numpy(np.ascontiguousarray(host)).to(dev))
+    images = resident(host)
 
-    ex = msorb.ORBextractor(cfg["nfeatures"], cfg["scale"], cfg["nlevels"], cfg["ini_th"], cfg["min_th"], device=local)
+    def make_ex():
+        e = msorb.ORBextractor(cfg["nfeatures"], cfg["scale"], cfg["nlevels"], cfg["ini_th"], cfg["min_th"], device=local)
+        if args.isolated:
+            e.set_overlap(1, False)
+        return e
+
+    ex = make_ex()
     cap = ex.capacity
-    if args.isolated:
-        ex.set_overlap(1, False)
     d_kps = torch.empty((n_img, cap, 28), dtype=torch.uint8, device=dev)
     d_desc = torch.empty((n_img, cap, 32), dtype=torch.uint8, device=dev)
     from msorb import stereo_split
     # N>1: two send/receive blocks used alternately, so that the exchange of step k (RCCL, torch's communication stream)
-    # overlaps the extraction of step k+1 (the library's own streams) without the two touching the same memory
+    # overlaps the extraction of step k+1 (the library's own streams) without the two touching the same memory.  The
+    # left-eye rank alternates two extractor handles the same way: the stereo association of step k (Frame.cc:743-913) runs
+    # when the right eye's features of step k have arrived — two steps later, just before block and handle are reused —
+    # and needs the left pyramid of step k intact.
     mine = theirs = None
     pending = [[], []]
+    exs = [ex, ex]
+    ex_rp = None
+    assoc = {"ms": 0.0, "n": 0, "matched": 0}
     if world > 1:
         mine = [stereo_split.FeatureBlock(n_img, cap, dev) for _ in range(2)]
         theirs = [stereo_split.FeatureBlock(n_img, cap, dev) if eye == 0 else None for _ in range(2)]
+        if eye == 0:
+            exs = [ex, make_ex()]
+            ex_rp = make_ex()   # pyramid-only handle for the right images
     step_no = [0]
+    filled = [False, False]
+    last_ex = [ex]
+    all_ex = [ex] if exs[1] is ex else [exs[0], exs[1]]
+
+    def associate(b):
+        """Left-eye rank: Frame::ComputeStereoMatches for the pairs of block b (its exchange has completed)."""
+        if world == 1 or eye != 0 or not filled[b] or theirs[b] is None:
+            return
+        ex_rp.pyramid_batch(other_images)
+        d_ur, _, _, ms = msorb.stereo_matches_split(exs[b], ex_rp, mine[b].counts, mine[b].kps, mine[b].desc,
+                                                    theirs[b].counts, theirs[b].kps, theirs[b].desc, KITTI_MB, KITTI_MBF)
+        assoc["ms"] += ms
+        assoc["n"] += 1
+        assoc["last"] = d_ur
+        filled[b] = False
 
     def step():
         if world == 1:
@@ -178,11 +219,14 @@ def main():
         step_no[0] += 1
         stereo_split.finish(pending[b])          # the block's previous exchange (two steps ago) must be over
         pending[b] = []
+        associate(b)                              # ... and its pairs are joined before block / handle are reused
         # the extractor writes straight into the send block
-        counts, mono, _, _ = ex.extract_batch(images, (0, 0), out=(mine[b].kps, mine[b].desc))
+        last_ex[0] = exs[b]
+        counts, mono, _, _ = exs[b].extract_batch(images, (0, 0), out=(mine[b].kps, mine[b].desc))
         # stereo split: right-eye rank -> left-eye rank (replaces the join of Frame.cc:122-125)
         mine[b].counts.copy_(torch.from_numpy(counts))
         pending[b] = stereo_split.exchange_async(dist, rank, world, mine[b], theirs[b])
+        filled[b] = bool(pending[b])
         return int(counts.sum())
 
     def fence():
@@ -190,20 +234,23 @@ def main():
             for b in range(2):
                 stereo_split.finish(pending[b])
                 pending[b] = []
+                associate(b)
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     # timed region: the production shape (2 sub-batches in flight, blur on a second stream), stage events on
-    ex.set_profiling(True)
+    for e in all_ex:
+        e.set_profiling(True)
     overlapped_acc = {k: 0.0 for k in msorb.STAGES}
     fence()
+    assoc.update(ms=0.0, n=0)
     t0 = time.perf_counter()
     kp_total = 0
     for _ in range(args.steps):
         kp_total += step()
-        for k, v in ex.stage_ms().items():
+        for k, v in last_ex[0].stage_ms().items():
             overlapped_acc[k] += v
     fence()
     dt = time.perf_counter() - t0
@@ -212,14 +259,19 @@ def main():
     # HIP events on the launching stream, 5 extra steps outside the timed region
     iso_steps = 5
     stage_acc = {k: 0.0 for k in msorb.STAGES}
-    ex.set_overlap(1, False)
+    join = dict(assoc)   # association statistics of the timed region only
+    for e in all_ex:
+        e.set_overlap(1, False)
     step()
+    if world > 1:
+        step()
     for _ in range(iso_steps):
         step()
-        for k, v in ex.stage_ms().items():
+        for k, v in last_ex[0].stage_ms().items():
             stage_acc[k] += v
     if not args.isolated:
-        ex.set_overlap(2, True)
+        for e in all_ex:
+            e.set_overlap(2, True)
     fence()
 
     if world > 1:
@@ -323,7 +375,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: KITTI-00 stereo 1241x376, 2000 feat/frame, pyramid+FAST+rBRIEF",
                        "pairs_per_step_per_gpu": B if world == 1 else B, "images_per_step_per_gpu": n_img,
-                       "parallelism": "1 GPU, both eyes" if world == 1 else f"stereo L/R split over {world} GPUs, RCCL send/recv"},
+                       "parallelism": "1 GPU, both eyes" if world == 1 else f"stereo L/R split over {world} GPUs: right-eye ranks send keypoints/descriptors "
+                                                                             "to their left-eye partner (RCCL send/recv over xGMI), which joins them (stereo association)"},
             "stage_ms_per_step": {k: round(v, 4) for k, v in stages.items()},
             "stage_ms_per_step_note": "each stage's kernels alone on the GPU (5 extra steps, overlap off, HIP events on the "
                                       "launching stream); 'select' = device quadtree + output layout",
@@ -346,12 +399,21 @@ def main():
         }
         out["hamming_match"] = hamming
         out["stereo_match"] = stereo
+        if world > 1:
+            out["stereo_join"] = {
+                "what": "left-eye rank: right pyramid rebuilt from the resident right images (msorb_pyramid_batch) + "
+                        "Frame::ComputeStereoMatches on its own left features and the gathered right features "
+                        "(msorb_stereo_matches_split), inside the timed region, once per step and pair group",
+                "joins": join["n"], "kernel_ms_per_join": round(join["ms"] / max(join["n"], 1), 4),
+                "matched_last": int((join["last"] > 0).sum().item()) if "last" in join else None,
+                "gathered_bytes_per_step": mine[0].nbytes() if mine else None}
         if world == 1 and args.cpu_pairs > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_pairs, 5000)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    ex.close()
+    for e in all_ex + ([ex_rp] if ex_rp is not None else []):
+        e.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -102,8 +102,15 @@ int msorb_pyramid_batch(msorb_extractor* h, const uint8_t* d_images, int n_image
 
 /* mvImagePyramid[level] (ORBextractor.h:83) of the last msorb_extract() call as a host-visible plane
  * (interior pixels; the 19-px border of ORBextractor.cc:1185-1191 is not materialised).  The memory
- * is owned by the handle and valid until the next extract call. */
+ * is owned by the handle and valid until the next extract call.  Without msorb_extractor_set_host_pyramid the first
+ * call after an extraction copies the whole pyramid synchronously (8 x hipMemcpy2D). */
 int msorb_pyramid_level(msorb_extractor* h, int level, const uint8_t** data, int* rows, int* cols, size_t* stride);
+
+/* enable != 0: every msorb_extract() call also brings levels 1.. of the pyramid to pinned host memory, with ONE asynchronous
+ * copy on a stream of its own that starts when the pyramid kernels are done and overlaps FAST / quadtree / describe
+ * (level 0 is the staged input image); msorb_pyramid_level then only hands out pointers.  For callers that keep reading
+ * mvImagePyramid on the host (an unchanged Frame::ComputeStereoMatches, Frame.cc:840-855).  Default off. */
+int msorb_extractor_set_host_pyramid(msorb_extractor* h, int enable);
 
 /* Batched operator() over n_images same-sized DEVICE-resident images (image i at d_images +
  * i*image_stride, rows of row_stride bytes).  Outputs stay on the device: image i's keypoints at
@@ -178,7 +185,7 @@ int msorb_frame_features_in_area(const msorb_frame* f, float x, float y, float r
  *   track_in_view=mbTrackInView  bad=isBad()  sparsified=mbSparsified  proj_x/proj_y/proj_xr=mTrackProjX/Y/XR
  *   track_depth=mTrackDepth  level=mnTrackScaleLevel  view_cos=mTrackViewCos  mp_desc=GetDescriptor() (m x 32)
  *   obs=Observations().
- * frame_mp[n]: F.mvpMapPoints as table indices (-1 = none), updated in place.  *nmatches = return value. */
+ * frame_mp[n]: F.mvpMapPoints as table indices (-1 = none, every entry < m), updated in place.  *nmatches = return value. */
 int msorb_search_by_projection_mps(msorb_frame* f, int m, const uint8_t* track_in_view, const uint8_t* bad,
                                    const uint8_t* sparsified, const float* proj_x, const float* proj_y,
                                    const float* proj_xr, const float* track_depth, const int* level,
@@ -211,11 +218,12 @@ int msorb_fuse_search(msorb_frame* f, const float* inv_level_sigma2, int n_level
 /* ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, th, bMono) (ORBmatcher.cc:1941-2057,
  * 2129-2152) from the projected coordinates on.  Per last-frame keypoint i: valid (map point present, not
  * outlier, positive depth, inside the image), u,v (projection), ur (u - mbf/z), last_octave, last_angle,
- * mp_desc (n_last x 32), last_mp (id stored into cur_mp), obs[id].  cur_mp[n] in/out. */
+ * mp_desc (n_last x 32), last_mp (id stored into cur_mp), obs[id] = Observations() of map point id, n_obs entries: every
+ * id in last_mp (of a valid entry) and in cur_mp must be < n_obs (MSORB_E_INVALID otherwise).  cur_mp[n] in/out. */
 int msorb_search_by_projection_frames(msorb_frame* cur, int n_last, const uint8_t* valid, const float* u,
                                       const float* v, const float* ur, const int* last_octave,
                                       const float* last_angle, const uint8_t* mp_desc, const int* last_mp,
-                                      const int* obs, int* cur_mp, float th, int forward, int backward,
+                                      const int* obs, int n_obs, int* cur_mp, float th, int forward, int backward,
                                       int check_orientation, int* nmatches);
 
 /* ORBmatcher::SearchByProjection(Frame& Current, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:2154-2275,

@@ -177,6 +177,13 @@ struct msorb_extractor {
     DevBuf<uint8_t> d_gather_pyr;                // msorb_extract_stereo_split: the right eye's pyramid, gathered onto this (left) device
     DevBuf<int> d_gather_cnt;                    // ... and its keypoint count
     hipEvent_t ev_split = nullptr;               // ... recorded on the right handle's stream after the gather copies
+    // mvImagePyramid for callers that read it on the host (unchanged Frame::ComputeStereoMatches, Frame.cc:840-855): levels
+    // 1.. are copied to pinned memory on a stream of their own as soon as the pyramid kernels are done — the copy (1 MB
+    // for KITTI) rides PCIe while FAST / quadtree / describe run; level 0 is the staged input image itself
+    bool host_pyramid = false;
+    hipStream_t pyr_stream = nullptr;
+    hipEvent_t ev_pyr_done = nullptr;
+    bool h_pyr_async = false;  // h_pyr holds levels 1.. of the last msorb_extract call, level 0 = h_img_pin
     unsigned long long buffers_epoch = 0;  // bumped whenever a device / pinned buffer may have moved
     unsigned long long graph_epoch = 0;
     hipEvent_t ev_compact = nullptr, ev_pyramid = nullptr, ev_blur = nullptr;
@@ -380,6 +387,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
     const PyramidView blur_all = make_view(h, h->d_blur.p, nullptr);
     h->last_pyr = pyr_all; h->last_blur = blur_all; h->last_n_images = n_images;
     h->h_pyr_valid = false;
+    h->h_pyr_async = false;
     h->compact_on_host = false;
     h->last_groups = ng;
     static const bool stagger_env = getenv("MSORB_STAGGER") != nullptr;  // measured: no gain (2.648 vs 2.653 ms), off by default
@@ -412,6 +420,21 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
         if (h->overlap_blur) {
             HIPCHK(hipEventRecord(G.ev_pyr, s));
             HIPCHK(hipStreamWaitEvent(sb, G.ev_pyr, 0));
+        }
+        if (h->host_pyramid && n_images == 1 && !h->capturing && level0.base == h->d_pyr.p + g.lv[0].plane_off) {
+            // per-frame call with the host pyramid requested: levels 1.. leave for pinned memory now, on their own stream
+            int prc;
+            if ((prc = h->h_pyr.ensure(g.pyramid_bytes))) return prc;
+            if (!h->pyr_stream) {
+                HIPCHK(hipStreamCreateWithFlags(&h->pyr_stream, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&h->ev_pyr_done, hipEventDisableTiming));
+            }
+            if (!h->overlap_blur) HIPCHK(hipEventRecord(G.ev_pyr, s));
+            HIPCHK(hipStreamWaitEvent(h->pyr_stream, G.ev_pyr, 0));
+            if (nl > 1)
+                HIPCHK(hipMemcpyAsync(h->h_pyr.p + g.lv[1].plane_off, h->d_pyr.p + g.lv[1].plane_off,
+                                      g.pyramid_bytes - g.lv[1].plane_off, hipMemcpyDeviceToHost, h->pyr_stream));
+            h->h_pyr_async = true;
         }
         mark(7, sb);
         launch_gauss7(pyr, blur, n, sb);
@@ -696,6 +719,8 @@ void msorb_extractor_destroy(msorb_extractor* h) {
     h->d_st_sad.release(); h->d_st_rows.release(); h->d_st_list.release(); h->d_st_block.release(); h->d_st_img.release(); h->d_out1.release();
     h->d_gather_pyr.release(); h->d_gather_cnt.release();
     if (h->ev_split) (void)hipEventDestroy(h->ev_split);
+    if (h->ev_pyr_done) (void)hipEventDestroy(h->ev_pyr_done);
+    if (h->pyr_stream) { (void)hipStreamSynchronize(h->pyr_stream); (void)hipStreamDestroy(h->pyr_stream); }
     h->h_level_count.release(); h->h_img_base.release(); h->h_sel_count.release(); h->h_compact.release();
     h->h_sel.release(); h->h_pyr.release(); h->h_img_pin.release(); h->h_out_pin.release();
     for (auto& G : h->grp) {
@@ -739,6 +764,11 @@ int msorb_extractor_set_overlap(msorb_extractor* h, int sub_batches, int blur_on
     if (!h || sub_batches < 1 || sub_batches > kMaxGroups) return MSORB_E_INVALID;
     h->n_groups = sub_batches;
     h->overlap_blur = blur_on_second_stream != 0;
+    return MSORB_OK;
+}
+int msorb_extractor_set_host_pyramid(msorb_extractor* h, int enable) {
+    if (!h) return MSORB_E_INVALID;
+    h->host_pyramid = enable != 0;
     return MSORB_OK;
 }
 int msorb_extractor_stage_ms(const msorb_extractor* h, float* ms) {
@@ -885,6 +915,7 @@ int msorb_extract(msorb_extractor* h, const uint8_t* image, int rows, int cols, 
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(h->h_out_pin.p, h->d_out1.p, blk_bytes, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->h_pyr_async) HIPCHK(hipStreamSynchronize(h->pyr_stream));
         HIPCHK(hipGetLastError());
         n = h->h_sel_count.p[0];
         mono = h->h_mono.p[0];
@@ -1181,6 +1212,14 @@ int msorb_pyramid_level(msorb_extractor* h, int level, const uint8_t** data, int
         return MSORB_E_INVALID;
     HIPCHK(hipSetDevice(h->device));
     const FrameGeom& g = h->G;
+    if (h->h_pyr_async) {  // filled by the last msorb_extract call itself (msorb_extractor_set_host_pyramid)
+        HIPCHK(hipStreamSynchronize(h->pyr_stream));
+        *data = level == 0 ? h->h_img_pin.p : h->h_pyr.p + g.lv[level].plane_off;
+        if (rows) *rows = g.lv[level].h;
+        if (cols) *cols = g.lv[level].w;
+        if (stride) *stride = g.lv[level].pitch;
+        return MSORB_OK;
+    }
     if (!h->h_pyr_valid) {
         int rc;
         if ((rc = h->h_pyr.ensure(g.pyramid_bytes))) return rc;

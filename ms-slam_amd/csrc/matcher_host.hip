@@ -302,7 +302,10 @@ int msorb_search_by_projection_mps(msorb_frame* f, int M, const uint8_t* track_i
         q[i] = w;
     }
     std::vector<uint8_t> occ(f->N);
-    for (int i = 0; i < f->N; i++) occ[i] = frame_mp[i] >= 0 && obs[frame_mp[i]] > 0;
+    for (int i = 0; i < f->N; i++) {
+        if (frame_mp[i] >= M) { set_last_error("frame_mp holds an id outside the map-point table"); return MSORB_E_INVALID; }
+        occ[i] = frame_mp[i] >= 0 && obs[frame_mp[i]] > 0;
+    }
     int nm = 0;
     auto accept = [&](int qi, const int* idx, const int* dist, int n, int* new_occ) -> int {
         if (n == 0) return -1;
@@ -332,7 +335,7 @@ namespace {
 // mvuRight test (the KeyFrame form has none); obs == nullptr: a keypoint holding any map point is taken (:2214-2215)
 // instead of "a map point with observations" (:2011-2013).
 int search_projected(msorb_frame* f, int NL, const uint8_t* valid, const float* u, const float* v, const float* ur,
-                     const int* octave, const float* angle, const uint8_t* mp_desc, const int* ids, const int* obs,
+                     const int* octave, const float* angle, const uint8_t* mp_desc, const int* ids, const int* obs, int n_obs,
                      int* cur_mp, float th, int forward, int backward, int check_orientation, float accept_dist, int* nmatches,
                      bool band_below = false) {
     *nmatches = 0;
@@ -354,6 +357,12 @@ int search_projected(msorb_frame* f, int NL, const uint8_t* valid, const float* 
         q[i] = w;
     }
     std::vector<uint8_t> occ(f->N);
+    if (obs) {  // every id that indexes the observation table must lie inside it
+        for (int i = 0; i < f->N; i++)
+            if (cur_mp[i] >= n_obs) { set_last_error("cur_mp holds an id outside the observation table"); return MSORB_E_INVALID; }
+        for (int i = 0; i < NL; i++)
+            if (valid[i] && (ids[i] < 0 || ids[i] >= n_obs)) { set_last_error("map-point id outside the observation table"); return MSORB_E_INVALID; }
+    }
     for (int i = 0; i < f->N; i++) occ[i] = cur_mp[i] >= 0 && (!obs || obs[cur_mp[i]] > 0);
     int nm = 0;
     std::vector<int> rotHist[kHistoLength];
@@ -393,13 +402,13 @@ int search_projected(msorb_frame* f, int NL, const uint8_t* valid, const float* 
 
 int msorb_search_by_projection_frames(msorb_frame* f, int NL, const uint8_t* valid, const float* u, const float* v,
                                       const float* ur, const int* last_octave, const float* last_angle,
-                                      const uint8_t* mp_desc, const int* last_mp, const int* obs, int* cur_mp, float th,
-                                      int forward, int backward, int check_orientation, int* nmatches) {
-    if (!f || NL < 0 || !nmatches || (NL > 0 && (!valid || !u || !v || !ur || !last_octave || !last_angle || !mp_desc ||
+                                      const uint8_t* mp_desc, const int* last_mp, const int* obs, int n_obs, int* cur_mp,
+                                      float th, int forward, int backward, int check_orientation, int* nmatches) {
+    if (!f || NL < 0 || n_obs < 0 || !nmatches || (NL > 0 && (!valid || !u || !v || !ur || !last_octave || !last_angle || !mp_desc ||
                                                  !last_mp || !obs)) || (f->N > 0 && !cur_mp))
         return MSORB_E_INVALID;
     HIPCHK(hipSetDevice(f->device));
-    return search_projected(f, NL, valid, u, v, ur, last_octave, last_angle, mp_desc, last_mp, obs, cur_mp, th, forward,
+    return search_projected(f, NL, valid, u, v, ur, last_octave, last_angle, mp_desc, last_mp, obs, n_obs, cur_mp, th, forward,
                             backward, check_orientation, (float)kThHigh, nmatches);
 }
 
@@ -410,7 +419,7 @@ int msorb_search_by_projection_kf(msorb_frame* f, int n, const uint8_t* valid, c
         (f->N > 0 && !cur_mp))
         return MSORB_E_INVALID;
     HIPCHK(hipSetDevice(f->device));
-    return search_projected(f, n, valid, u, v, nullptr, predicted_level, kf_angle, mp_desc, mp_id, nullptr, cur_mp, th, 0, 0,
+    return search_projected(f, n, valid, u, v, nullptr, predicted_level, kf_angle, mp_desc, mp_id, nullptr, 0, cur_mp, th, 0, 0,
                             check_orientation, (float)orb_dist, nmatches);
 }
 
@@ -421,7 +430,7 @@ int msorb_search_by_projection_sim3(msorb_frame* f, int n, const uint8_t* valid,
         (f->N > 0 && !matched))
         return MSORB_E_INVALID;
     HIPCHK(hipSetDevice(f->device));
-    return search_projected(f, n, valid, u, v, nullptr, predicted_level, nullptr, mp_desc, mp_id, nullptr, matched, th, 0, 0, 0,
+    return search_projected(f, n, valid, u, v, nullptr, predicted_level, nullptr, mp_desc, mp_id, nullptr, 0, matched, th, 0, 0, 0,
                             max_dist, nmatches, true);
 }
 
@@ -567,24 +576,43 @@ int msorb_hamming_dense_top2_batch(int device, const uint8_t* d_query, const uin
         return MSORB_E_NO_DEVICE;
     }
     HIPCHK(hipSetDevice(device));
-    hipStream_t s = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    hipError_t e = hipEventCreate(&e0);
-    if (e == hipSuccess) e = hipEventCreate(&e1);
-    if (e == hipSuccess) e = hipEventRecord(e0, s);
+    // stream and timing events live with the calling thread (created once per device, released with the thread)
+    struct Ctx {
+        int device = -1;
+        hipStream_t s = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        void release() {
+            if (device >= 0 && hipSetDevice(device) == hipSuccess) {
+                if (e0) (void)hipEventDestroy(e0);
+                if (e1) (void)hipEventDestroy(e1);
+                if (s) (void)hipStreamDestroy(s);
+            }
+            s = nullptr; e0 = e1 = nullptr; device = -1;
+        }
+        ~Ctx() { release(); }
+    };
+    static thread_local Ctx ctx;
+    if (ctx.device != device) {
+        ctx.release();
+        ctx.device = device;
+        if (hipStreamCreateWithFlags(&ctx.s, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx.e0) != hipSuccess ||
+            hipEventCreate(&ctx.e1) != hipSuccess) {
+            ctx.release();
+            set_last_error("stream / event creation failed");
+            return MSORB_E_HIP;
+        }
+    }
+    hipStream_t s = ctx.s;
+    hipError_t e = hipEventRecord(ctx.e0, s);
     for (int r = 0; e == hipSuccess && r < (repeats > 0 ? repeats : 1); r++)
         launch_dense_top2(d_query, d_train, d_n_query, d_n_train, n_frames, query_stride, train_stride, max_query, max_train,
                           d_best_idx, d_best_dist, d_second_dist, s);
-    if (e == hipSuccess) e = hipEventRecord(e1, s);
+    if (e == hipSuccess) e = hipEventRecord(ctx.e1, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess) e = hipGetLastError();
     float ms = 0;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ctx.e0, ctx.e1);
     if (elapsed_ms) *elapsed_ms = ms;
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    (void)hipStreamDestroy(s);
     if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return MSORB_E_HIP; }
     return MSORB_OK;
 }

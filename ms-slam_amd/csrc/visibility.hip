@@ -268,9 +268,15 @@ extern "C" int msorb_visibility_csr(int device, int n_window_kf, const int* kf_s
                                     int N, int n_max_obs_floor, int* n_cols, int* col_point, int cap_cols, int* n_rows,
                                     int* row_begin, int* row_kind, int* row_owner, float* row_rhs, int cap_rows,
                                     int* col_idx, int cap_nnz, int* nnz_out, float* obj_coef, int* n_max_obs) {
-    if (n_window_kf < 0 || n_points < 0 || n_kf_total < 0 || !kf_slot_begin || !n_cols || !n_rows || !row_begin ||
-        !nnz_out || !n_max_obs || (n_points > 0 && (!point_nobs || !obs_begin)))
+    if (n_window_kf < 0 || n_points < 0 || n_kf_total < 0 || cap_cols < 0 || cap_rows < 0 || cap_nnz < 0 || !kf_slot_begin ||
+        !n_cols || !n_rows || !row_begin || !nnz_out || !n_max_obs || (n_points > 0 && (!point_nobs || !obs_begin)) ||
+        (cap_rows > 0 && (!row_kind || !row_owner || !row_rhs)) || (cap_nnz > 0 && !col_idx) ||
+        (cap_cols > 0 && (!col_point || !obj_coef)) || (n_kf_total > 0 && (!kf_in_window || !kf_num_mps)) ||
+        (kf_slot_begin[n_window_kf] > 0 && (!slot_point || !slot_cell)) ||
+        (n_points > 0 && obs_begin[n_points] > 0 && !obs_kf)) {
+        set_last_error("msorb_visibility_csr: null argument");
         return MSORB_E_INVALID;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
         set_last_error("no usable HIP device (libmsorb has no CPU fallback)");
@@ -284,6 +290,35 @@ extern "C" int msorb_visibility_csr(int device, int n_window_kf, const int* kf_s
         if (obs_kf[o] < 0 || obs_kf[o] >= n_kf_total) { set_last_error("obs_kf out of range"); return MSORB_E_INVALID; }
     int rc = MSORB_OK;
     if (hipSetDevice(device) != hipSuccess) return MSORB_E_HIP;
+    // scratch kept per calling thread (grow-only) and a private non-blocking stream, like the other per-frame entries
+    struct Scratch {
+        int device = -1;
+        hipStream_t s = nullptr;
+        void* p[4] = {nullptr, nullptr, nullptr, nullptr};
+        size_t cap[4] = {0, 0, 0, 0};
+        void release() {
+            if (device < 0 || hipSetDevice(device) != hipSuccess) return;
+            for (int i = 0; i < 4; i++) { if (p[i]) (void)hipFree(p[i]); p[i] = nullptr; cap[i] = 0; }
+            if (s) (void)hipStreamDestroy(s);
+            s = nullptr; device = -1;
+        }
+        hipError_t ensure(int i, size_t bytes) {
+            if (bytes <= cap[i]) return hipSuccess;
+            if (p[i]) (void)hipFree(p[i]);
+            p[i] = nullptr; cap[i] = 0;
+            const hipError_t e = hipMalloc(&p[i], bytes + bytes / 4);
+            if (e == hipSuccess) cap[i] = bytes + bytes / 4;
+            return e;
+        }
+        ~Scratch() { release(); }
+    };
+    static thread_local Scratch scr;
+    if (scr.device != device) {
+        scr.release();
+        if (hipStreamCreateWithFlags(&scr.s, hipStreamNonBlocking) != hipSuccess) { set_last_error("stream creation failed"); return MSORB_E_HIP; }
+        scr.device = device;
+    }
+    hipStream_t const st = scr.s;
     // one arena of ints
     int *d = nullptr;
     unsigned* d_bitmap = nullptr;
@@ -300,42 +335,43 @@ extern "C" int msorb_visibility_csr(int device, int n_window_kf, const int* kf_s
                  o_nnzbase = take(n_window_kf + 1), o_kfcount = take(n_kf_total), o_kfrow = take(n_kf_total),
                  o_kfoff = take(n_kf_total), o_rowbegin = take((size_t)cap_rows + 1), o_rowkind = take(cap_rows),
                  o_rowowner = take(cap_rows), o_colidx = take(cap_nnz);
-    VCHK(hipMalloc((void**)&d, std::max<size_t>(off, 1) * sizeof(int)));
-    VCHK(hipMalloc((void**)&d_rhs, std::max<size_t>(cap_rows, 1) * sizeof(float)));
-    VCHK(hipMalloc((void**)&d_inwin, std::max(n_kf_total, 1)));
-    VCHK(hipMemcpy(d + o_slot_begin, kf_slot_begin, (n_window_kf + 1) * sizeof(int), hipMemcpyHostToDevice));
+    VCHK(scr.ensure(0, std::max<size_t>(off, 1) * sizeof(int)));
+    VCHK(scr.ensure(1, std::max<size_t>(cap_rows, 1) * sizeof(float)));
+    VCHK(scr.ensure(2, std::max(n_kf_total, 1)));
+    d = static_cast<int*>(scr.p[0]); d_rhs = static_cast<float*>(scr.p[1]); d_inwin = static_cast<uint8_t*>(scr.p[2]);
+    VCHK(hipMemcpyAsync(d + o_slot_begin, kf_slot_begin, (n_window_kf + 1) * sizeof(int), hipMemcpyHostToDevice, st));
     if (S) {
-        VCHK(hipMemcpy(d + o_slot_point, slot_point, S * sizeof(int), hipMemcpyHostToDevice));
-        VCHK(hipMemcpy(d + o_slot_cell, slot_cell, S * sizeof(int), hipMemcpyHostToDevice));
+        VCHK(hipMemcpyAsync(d + o_slot_point, slot_point, S * sizeof(int), hipMemcpyHostToDevice, st));
+        VCHK(hipMemcpyAsync(d + o_slot_cell, slot_cell, S * sizeof(int), hipMemcpyHostToDevice, st));
     }
     if (n_points) {
-        VCHK(hipMemcpy(d + o_nobs, point_nobs, n_points * sizeof(int), hipMemcpyHostToDevice));
-        VCHK(hipMemcpy(d + o_obs_begin, obs_begin, (n_points + 1) * sizeof(int), hipMemcpyHostToDevice));
-        if (n_obs) VCHK(hipMemcpy(d + o_obs_kf, obs_kf, n_obs * sizeof(int), hipMemcpyHostToDevice));
-        VCHK(hipMemset(d + o_first, 0x7f, n_points * sizeof(int)));
+        VCHK(hipMemcpyAsync(d + o_nobs, point_nobs, n_points * sizeof(int), hipMemcpyHostToDevice, st));
+        VCHK(hipMemcpyAsync(d + o_obs_begin, obs_begin, (n_points + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+        if (n_obs) VCHK(hipMemcpyAsync(d + o_obs_kf, obs_kf, n_obs * sizeof(int), hipMemcpyHostToDevice, st));
+        VCHK(hipMemsetAsync(d + o_first, 0x7f, n_points * sizeof(int), st));
     }
     if (n_kf_total) {
-        VCHK(hipMemcpy(d + o_num_mps, kf_num_mps, n_kf_total * sizeof(int), hipMemcpyHostToDevice));
-        VCHK(hipMemcpy(d_inwin, kf_in_window, n_kf_total, hipMemcpyHostToDevice));
-        VCHK(hipMemset(d + o_kfcount, 0, n_kf_total * sizeof(int)));
+        VCHK(hipMemcpyAsync(d + o_num_mps, kf_num_mps, n_kf_total * sizeof(int), hipMemcpyHostToDevice, st));
+        VCHK(hipMemcpyAsync(d_inwin, kf_in_window, n_kf_total, hipMemcpyHostToDevice, st));
+        VCHK(hipMemsetAsync(d + o_kfcount, 0, n_kf_total * sizeof(int), st));
     }
-    VCHK(hipMemset(d + o_scal, 0, 8 * sizeof(int)));
-    VCHK(hipMemcpy(d + o_scal + 1, &n_max_obs_floor, sizeof(int), hipMemcpyHostToDevice));
+    VCHK(hipMemsetAsync(d + o_scal, 0, 8 * sizeof(int), st));
+    VCHK(hipMemcpyAsync(d + o_scal + 1, &n_max_obs_floor, sizeof(int), hipMemcpyHostToDevice, st));
     if (S) {
-        hipLaunchKernelGGL(vis_first_kernel, dim3((S + 255) / 256), dim3(256), 0, 0, d + o_slot_point, S, d + o_first);
-        hipLaunchKernelGGL(vis_scan_first_kernel, dim3(1), dim3(1024), 0, 0, d + o_slot_point, d + o_first, S, d + o_rank,
+        hipLaunchKernelGGL(vis_first_kernel, dim3((S + 255) / 256), dim3(256), 0, st, d + o_slot_point, S, d + o_first);
+        hipLaunchKernelGGL(vis_scan_first_kernel, dim3(1), dim3(1024), 0, st, d + o_slot_point, d + o_first, S, d + o_rank,
                            d + o_scal);
-        hipLaunchKernelGGL(vis_columns_kernel, dim3((S + 255) / 256), dim3(256), 0, 0, d + o_slot_point, d + o_first,
+        hipLaunchKernelGGL(vis_columns_kernel, dim3((S + 255) / 256), dim3(256), 0, st, d + o_slot_point, d + o_first,
                            d + o_rank, S, d + o_nobs, d + o_colofp, d + o_colpoint, d + o_scal + 1);
     }
     if (n_window_kf)
-        hipLaunchKernelGGL(vis_kf_count_kernel, dim3(n_window_kf), dim3(256), 0, 0, d + o_slot_begin, d + o_slot_point,
+        hipLaunchKernelGGL(vis_kf_count_kernel, dim3(n_window_kf), dim3(256), 0, st, d + o_slot_begin, d + o_slot_point,
                            d + o_slot_cell, d + o_kfvalid, d + o_kfcells);
-    VCHK(hipMemcpy(&ncols, d + o_scal, sizeof(int), hipMemcpyDeviceToHost));
-    VCHK(hipMemcpy(&nmax, d + o_scal + 1, sizeof(int), hipMemcpyDeviceToHost));
+    VCHK(hipMemcpyAsync(&ncols, d + o_scal, sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
+    VCHK(hipMemcpyAsync(&nmax, d + o_scal + 1, sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
     if (n_window_kf) {
-        VCHK(hipMemcpy(kf_valid.data(), d + o_kfvalid, n_window_kf * sizeof(int), hipMemcpyDeviceToHost));
-        VCHK(hipMemcpy(kf_cells.data(), d + o_kfcells, n_window_kf * sizeof(int), hipMemcpyDeviceToHost));
+        VCHK(hipMemcpyAsync(kf_valid.data(), d + o_kfvalid, n_window_kf * sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
+        VCHK(hipMemcpyAsync(kf_cells.data(), d + o_kfcells, n_window_kf * sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
     }
     for (int k = 0; k < n_window_kf; k++) {
         row_base[k] = rows_ab; nnz_base[k] = nnz_ab;
@@ -344,51 +380,48 @@ extern "C" int msorb_visibility_csr(int device, int n_window_kf, const int* kf_s
     }
     if (ncols > cap_cols || rows_ab > cap_rows || nnz_ab > cap_nnz) { set_last_error("output capacity too small"); rc = MSORB_E_CAPACITY; goto done; }
     if (n_window_kf) {
-        VCHK(hipMemcpy(d + o_rowbase, row_base.data(), n_window_kf * sizeof(int), hipMemcpyHostToDevice));
-        VCHK(hipMemcpy(d + o_nnzbase, nnz_base.data(), n_window_kf * sizeof(int), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(vis_kf_rows_kernel, dim3(n_window_kf), dim3(256), 0, 0, d + o_slot_begin, d + o_slot_point,
+        VCHK(hipMemcpyAsync(d + o_rowbase, row_base.data(), n_window_kf * sizeof(int), hipMemcpyHostToDevice, st));
+        VCHK(hipMemcpyAsync(d + o_nnzbase, nnz_base.data(), n_window_kf * sizeof(int), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(vis_kf_rows_kernel, dim3(n_window_kf), dim3(256), 0, st, d + o_slot_begin, d + o_slot_point,
                            d + o_slot_cell, d + o_colofp, d + o_rowbase, d + o_nnzbase, d + o_kfvalid, N, d + o_rowbegin,
                            d + o_rowkind, d + o_rowowner, d_rhs, d + o_colidx);
     }
     if (ncols && n_kf_total) {
-        hipLaunchKernelGGL(vis_extra_count_kernel, dim3((ncols + 255) / 256), dim3(256), 0, 0, d + o_colpoint, ncols,
+        hipLaunchKernelGGL(vis_extra_count_kernel, dim3((ncols + 255) / 256), dim3(256), 0, st, d + o_colpoint, ncols,
                            d + o_obs_begin, d + o_obs_kf, d_inwin, d + o_kfcount);
-        hipLaunchKernelGGL(vis_extra_scan_kernel, dim3(1), dim3(1024), 0, 0, d + o_kfcount, n_kf_total, d + o_kfrow,
+        hipLaunchKernelGGL(vis_extra_scan_kernel, dim3(1), dim3(1024), 0, st, d + o_kfcount, n_kf_total, d + o_kfrow,
                            d + o_kfoff, d + o_scal + 2);
-        VCHK(hipMemcpy(totals, d + o_scal + 2, 2 * sizeof(int), hipMemcpyDeviceToHost));
+        VCHK(hipMemcpyAsync(totals, d + o_scal + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
         if (rows_ab + totals[0] > cap_rows || nnz_ab + totals[1] > cap_nnz) { set_last_error("output capacity too small"); rc = MSORB_E_CAPACITY; goto done; }
         if (totals[0]) {
             words = (ncols + 31) / 32;
-            VCHK(hipMalloc((void**)&d_bitmap, (size_t)totals[0] * words * sizeof(unsigned)));
-            VCHK(hipMemset(d_bitmap, 0, (size_t)totals[0] * words * sizeof(unsigned)));
-            hipLaunchKernelGGL(vis_extra_bits_kernel, dim3((ncols + 255) / 256), dim3(256), 0, 0, d + o_colpoint, ncols,
+            VCHK(scr.ensure(3, (size_t)totals[0] * words * sizeof(unsigned)));
+            d_bitmap = static_cast<unsigned*>(scr.p[3]);
+            VCHK(hipMemsetAsync(d_bitmap, 0, (size_t)totals[0] * words * sizeof(unsigned), st));
+            hipLaunchKernelGGL(vis_extra_bits_kernel, dim3((ncols + 255) / 256), dim3(256), 0, st, d + o_colpoint, ncols,
                                d + o_obs_begin, d + o_obs_kf, d_inwin, d + o_kfrow, words, d_bitmap);
-            hipLaunchKernelGGL(vis_extra_emit_kernel, dim3(n_kf_total), dim3(256), 0, 0, n_kf_total, d + o_kfcount,
+            hipLaunchKernelGGL(vis_extra_emit_kernel, dim3(n_kf_total), dim3(256), 0, st, n_kf_total, d + o_kfcount,
                                d + o_kfrow, d + o_kfoff, d + o_num_mps, N, words, d_bitmap, rows_ab, nnz_ab, d + o_rowbegin,
                                d + o_rowkind, d + o_rowowner, d_rhs, d + o_colidx);
         }
     }
-    VCHK(hipDeviceSynchronize());
+    VCHK(hipStreamSynchronize(st));
     {
         const int R = rows_ab + totals[0], NNZ = nnz_ab + totals[1];
         *n_cols = ncols; *n_rows = R; *nnz_out = NNZ; *n_max_obs = nmax;
         if (R) {
-            VCHK(hipMemcpy(row_begin, d + o_rowbegin, R * sizeof(int), hipMemcpyDeviceToHost));
-            VCHK(hipMemcpy(row_kind, d + o_rowkind, R * sizeof(int), hipMemcpyDeviceToHost));
-            VCHK(hipMemcpy(row_owner, d + o_rowowner, R * sizeof(int), hipMemcpyDeviceToHost));
-            VCHK(hipMemcpy(row_rhs, d_rhs, R * sizeof(float), hipMemcpyDeviceToHost));
+            VCHK(hipMemcpyAsync(row_begin, d + o_rowbegin, R * sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
+            VCHK(hipMemcpyAsync(row_kind, d + o_rowkind, R * sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
+            VCHK(hipMemcpyAsync(row_owner, d + o_rowowner, R * sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
+            VCHK(hipMemcpyAsync(row_rhs, d_rhs, R * sizeof(float), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
         }
         row_begin[R] = NNZ;
-        if (NNZ) VCHK(hipMemcpy(col_idx, d + o_colidx, NNZ * sizeof(int), hipMemcpyDeviceToHost));
+        if (NNZ) VCHK(hipMemcpyAsync(col_idx, d + o_colidx, NNZ * sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
         if (ncols) {
-            VCHK(hipMemcpy(col_point, d + o_colpoint, ncols * sizeof(int), hipMemcpyDeviceToHost));
+            VCHK(hipMemcpyAsync(col_point, d + o_colpoint, ncols * sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
             for (int c = 0; c < ncols; c++) obj_coef[c] = (float)(nmax - point_nobs[col_point[c]]);  // MapSparsification.cc:95-96
         }
     }
 done:
-    if (d) (void)hipFree(d);
-    if (d_rhs) (void)hipFree(d_rhs);
-    if (d_inwin) (void)hipFree(d_inwin);
-    if (d_bitmap) (void)hipFree(d_bitmap);
     return rc;
 }

@@ -17,8 +17,10 @@ class ORBextractor {
 public:
     enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
 
-    // Same argument meaning as the reference constructor (ORBextractor.cc:409-412).  The HIP device is taken
-    // from the environment variable MSORB_DEVICE (default 0) so that call sites stay unchanged.
+    // Same argument meaning as the reference constructor (ORBextractor.cc:409-412).  The HIP device comes from the
+    // environment so that call sites stay unchanged: MSORB_DEVICES="0,1" deals the extractor objects of the process onto
+    // the listed devices in construction order (left eye -> 0, right eye -> 1 with Tracking.cc:595-596), MSORB_DEVICE=k
+    // puts all of them on device k (default 0).
     ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
     ~ORBextractor();
     ORBextractor(const ORBextractor&) = delete;
@@ -36,15 +38,19 @@ public:
     std::vector<float> GetScaleSigmaSquares() { return mvLevelSigma2; }
     std::vector<float> GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-    // Host views of the device pyramid of the last call (interior pixels).  Valid until the next call.
+    // Host views of the device pyramid of the last call (interior pixels).  Valid until the next call.  Filled by one
+    // asynchronous copy that overlaps the extraction; left empty with MSORB_HOST_PYRAMID=0 (device-side stereo matching).
     std::vector<cv::Mat> mvImagePyramid;
 
-    // The underlying handle, for msorb_stereo_matches() (Frame::ComputeStereoMatches on the device).
+    // The underlying handle, for msorb_stereo_matches() / msorb_extract_stereo_split() (Frame::ComputeStereoMatches on the
+    // device), and the HIP device it lives on.
     msorb_extractor* handle() const { return mHandle; }
+    int device() const { return mDevice; }
 
 private:
     msorb_extractor* mHandle;
-    int mLevels, mCapacity;
+    int mLevels, mCapacity, mDevice = 0;
+    bool mHostPyramid = true;
     float mScaleFactor;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
     std::vector<unsigned char> mKpScratch;

@@ -17,6 +17,9 @@
 //   ORB_SLAM3::msorb_host::ExtractStereo(F, left, imLeft, imRight)
 //                                                        the two ExtractORB threads + ComputeStereoMatches of the stereo
 //                                                        Frame constructor (src/Frame.cc:119-137) as ONE device call
+//   ORB_SLAM3::msorb_host::ExtractStereoSplit(F, left, right, imLeft, imRight)
+//                                                        the same with one extractor object per GPU (left / right eye on
+//                                                        devices A / B, gather over xGMI, association on A)
 //   ORB_SLAM3::msorb_host::SearchByBoW(...)              bodies of ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches)
 //                                                        (src/ORBmatcher.cc:223-421, Nleft == -1 branch) and
 //                                                        SearchByBoW(pKF1, pKF2, vpMatches12) (:872-1016,
@@ -78,11 +81,14 @@ public:
     }
     // the same from a KeyFrame through its public accessors (the feature arrays are protected there).  KeyFrame keeps the
     // image bounds as ints (KeyFrame.h:251-254) next to Frame's float grid constants: identical for rectified input.
+    // A sparsified KeyFrame (KeyFrame::EraseBadDescriptor, KeyFrame.cc:311-361) has given its grid away (:355), and
+    // KeyFrame::GetFeaturesInArea returns nothing for it (:800-801): every window search on it — Fuse, the Sim3 /
+    // relocalisation projections — finds no candidate in the reference.  It is uploaded without features for the same result.
     template <class KeyFramePtr>
     void UploadKeyFrame(const KeyFramePtr& pKF) {
         const auto keys = pKF->GetAllKeyUn();
         static_assert(sizeof(keys[0]) == sizeof(msorb_keypoint), "cv::KeyPoint must be the 28-byte layout");
-        const int n = (int)keys.size();
+        const int n = pKF->mbSparsified ? 0 : (int)keys.size();
         desc_.assign((size_t)n * 32, 0);
         std::vector<float> ur(n);
         for (int i = 0; i < n; i++) {
@@ -207,7 +213,7 @@ int SearchByProjection(DeviceFrame<FrameT>& dev, FrameT& CurrentFrame, const Fra
     const std::vector<int> before(curMp);
     int nmatches = 0;
     check(msorb_search_by_projection_frames(dev.get(), nL, P.valid.data(), P.u.data(), P.v.data(), P.ur.data(), P.octave.data(),
-                                            P.angle.data(), P.desc.data(), lastMp.data(), obs.data(), curMp.data(), th,
+                                            P.angle.data(), P.desc.data(), lastMp.data(), obs.data(), (int)obs.size(), curMp.data(), th,
                                             P.forward, P.backward, mbCheckOrientation, &nmatches),
           "msorb_search_by_projection_frames");
     for (int j = 0; j < N; j++) {
@@ -678,6 +684,39 @@ void ExtractStereo(FrameT& F, const ExtractorT& left, const MatT& imLeft, const 
                                &nl, reinterpret_cast<msorb_keypoint*>(F.mvKeysRight.data()), dr.data(), &nr, cap, ur.data(),
                                depth.data(), &oob),
           "msorb_extract_stereo");
+    F.mvKeys.resize(nl);
+    F.mvKeysRight.resize(nr);
+    F.mDescriptors.create(nl, 32, 0 /* CV_8U */);
+    F.mDescriptorsRight.create(nr, 32, 0 /* CV_8U */);
+    for (int i = 0; i < nl; i++) std::memcpy(F.mDescriptors.template ptr<unsigned char>(i), &dl[(size_t)i * 32], 32);
+    for (int i = 0; i < nr; i++) std::memcpy(F.mDescriptorsRight.template ptr<unsigned char>(i), &dr[(size_t)i * 32], 32);
+    F.mvuRight.assign(ur.begin(), ur.begin() + nl);
+    F.mvDepth.assign(depth.begin(), depth.begin() + nl);
+}
+
+// The same with one extractor object per GPU (BASELINE configs[3]): `left` lives on device A, `right` on device B
+// (MSORB_DEVICES="0,1": Tracking.cc:595-596 constructs mpORBextractorLeft, then mpORBextractorRight).  Replaces, in the
+// stereo Frame constructor (Frame.cc:119-137),
+//     thread threadLeft(&Frame::ExtractORB,this,0,imLeft,0,0);  thread threadRight(&Frame::ExtractORB,this,1,imRight,0,0);
+//     threadLeft.join(); threadRight.join();  ...  ComputeStereoMatches();
+// by ONE call: each eye's kernel chain runs on its own device, the right eye's features and pyramid cross xGMI to device A
+// (msorb_extract_stereo_split), the association runs there.  Falls back to nothing: both objects on one device take the
+// same path.  Identical results.
+template <class FrameT, class ExtractorT, class MatT>
+void ExtractStereoSplit(FrameT& F, const ExtractorT& left, const ExtractorT& right, const MatT& imLeft, const MatT& imRight) {
+    const int cap = msorb_extractor_capacity(left.handle());
+    F.mvKeys.resize(cap);
+    F.mvKeysRight.resize(cap);
+    static_assert(sizeof(F.mvKeys[0]) == sizeof(msorb_keypoint), "cv::KeyPoint must be the 28-byte layout");
+    std::vector<uint8_t> dl((size_t)cap * 32), dr((size_t)cap * 32);
+    std::vector<float> ur(cap), depth(cap);
+    int nl = 0, nr = 0, oob = 0;
+    check(msorb_extract_stereo_split(left.handle(), right.handle(), imLeft.data, imRight.data, imLeft.rows, imLeft.cols,
+                                     (size_t)imLeft.step, (size_t)imRight.step, F.mb, F.mbf,
+                                     reinterpret_cast<msorb_keypoint*>(F.mvKeys.data()), dl.data(), &nl,
+                                     reinterpret_cast<msorb_keypoint*>(F.mvKeysRight.data()), dr.data(), &nr, cap, ur.data(),
+                                     depth.data(), &oob),
+          "msorb_extract_stereo_split");
     F.mvKeys.resize(nl);
     F.mvKeysRight.resize(nr);
     F.mDescriptors.create(nl, 32, 0 /* CV_8U */);

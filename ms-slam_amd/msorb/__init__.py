@@ -28,7 +28,7 @@ EXPORTS = (
     "msorb_extractor_tables", "msorb_extractor_capacity", "msorb_extract", "msorb_pyramid_level",
     "msorb_extract_batch", "msorb_extractor_set_profiling", "msorb_extractor_set_overlap", "msorb_extractor_stage_ms", "msorb_debug_level_size",
     "msorb_debug_copy_level", "msorb_debug_candidates", "msorb_distribute_quadtree", "msorb_extract_stereo",
-    "msorb_extract_stereo_split", "msorb_pyramid_batch", "msorb_stereo_matches_split",
+    "msorb_extract_stereo_split", "msorb_pyramid_batch", "msorb_stereo_matches_split", "msorb_extractor_set_host_pyramid",
 )
 
 
@@ -230,6 +230,10 @@ class ORBextractor:
                                           _np_ptr(counts), _np_ptr(mono)), "msorb_extract_batch")
         return counts, mono, d_kps, d_desc
 
+    def set_host_pyramid(self, on=True):
+        self.L.msorb_extractor_set_host_pyramid.argtypes = [C.c_void_p, C.c_int]
+        _check(self.L.msorb_extractor_set_host_pyramid(self.h, int(on)), "msorb_extractor_set_host_pyramid")
+
     def set_profiling(self, on=True):
         _check(self.L.msorb_extractor_set_profiling(self.h, int(on)), "set_profiling")
 
@@ -293,7 +297,7 @@ def _setup_matcher(L):
     L.msorb_frame_set.argtypes = [vp, vp, ci, vp, vp, cf, cf, cf, cf, vp, ci]
     L.msorb_frame_features_in_area.argtypes = [vp, cf, cf, cf, ci, ci, vp, ci, C.POINTER(ci)]
     L.msorb_search_by_projection_mps.argtypes = [vp, ci] + [vp] * 12 + [cf, ci, cf, cf, C.POINTER(ci)]
-    L.msorb_search_by_projection_frames.argtypes = [vp, ci] + [vp] * 10 + [cf, ci, ci, ci, C.POINTER(ci)]
+    L.msorb_search_by_projection_frames.argtypes = [vp, ci] + [vp] * 9 + [ci, vp, cf, ci, ci, ci, C.POINTER(ci)]
     L.msorb_hamming_top2.argtypes = [ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp]
     L.msorb_stereo_matches.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, cf, cf, vp, vp, C.POINTER(ci)]
     L.msorb_three_maxima.argtypes = [vp, ci, vp]
@@ -370,7 +374,7 @@ class Frame:
                 _c(last["desc"], np.uint8), _c(last["mp"], np.int32), _c(last["obs"], np.int32)]
         assert cur_mp.dtype == np.int32 and cur_mp.flags.c_contiguous
         nm = C.c_int()
-        _check(self.L.msorb_search_by_projection_frames(self.h, NL, *[_np_ptr(a) for a in arrs], _np_ptr(cur_mp), th,
+        _check(self.L.msorb_search_by_projection_frames(self.h, NL, *[_np_ptr(a) for a in arrs], len(arrs[-1]), _np_ptr(cur_mp), th,
                                                         int(forward), int(backward), int(check_orientation),
                                                         C.byref(nm)), "search_by_projection_frames")
         return nm.value

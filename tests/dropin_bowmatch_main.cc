@@ -128,6 +128,7 @@ struct KeyFrame : protected Side {  // the feature arrays are protected in MS-SL
     std::vector<cv::KeyPoint> GetAllKeyUn() { return mvKeys; }
     float GetuRight(size_t idx) { return mvuRight_[idx]; }
     int mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0, mnScaleLevels = 8;
+    bool mbSparsified = false;  // KeyFrame.h:272 (set by EraseBadDescriptor, which also swaps mGrid away)
     float mbf = 0, mfLogScaleFactor = 0;
     std::vector<float> mvInvLevelSigma2;
     bool IsInImage(const float& x, const float& y) const { return x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY; }
@@ -242,7 +243,7 @@ static int triangulation_main(const char* in, const char* out) {
 }
 
 // ORBmatcher::Fuse through msorb_host::Fuse: one KeyFrame, M map points; dumps the geometry, nFused and the mutation log
-static int fuse_main(const char* in, const char* out) {
+static int fuse_main(const char* in, const char* out, bool sparsified) {
     using namespace ORB_SLAM3;
     FILE* f = fopen(in, "rb");
     if (!f) return 3;
@@ -284,6 +285,7 @@ static int fuse_main(const char* in, const char* out) {
     msorb_host::FuseGeometry(kf, pts, cam[6], Q);
     std::vector<int> log;
     MapPoint::log = &log;
+    kf->mbSparsified = sparsified;  // KeyFrame::GetFeaturesInArea then returns nothing (KeyFrame.cc:800-801): Fuse must not touch the map
     msorb_host::DeviceFrame<Frame> dev;
     dev.UploadKeyFrame(kf);
     const int nFused = msorb_host::Fuse(dev, kf, pts, cam[6]);
@@ -301,7 +303,8 @@ int main(int argc, char** argv) {
     using namespace ORB_SLAM3;
     if (argc < 3) return 2;
     if (argc > 3 && std::string(argv[3]) == "tri") return triangulation_main(argv[1], argv[2]);
-    if (argc > 3 && std::string(argv[3]) == "fuse") return fuse_main(argv[1], argv[2]);
+    if (argc > 3 && std::string(argv[3]) == "fuse") return fuse_main(argv[1], argv[2], false);
+    if (argc > 3 && std::string(argv[3]) == "fuse_sparsified") return fuse_main(argv[1], argv[2], true);
     FILE* f = fopen(argv[1], "rb");
     if (!f) return 3;
     const auto hdr = rd<int>(f, 2);

@@ -38,8 +38,16 @@ static int stereo_main(int rows, int cols, const char* lp, const char* rp, const
     exL(imL, cv::Mat(), B.mvKeys, B.mDescriptors, lap);
     exR(imR, cv::Mat(), B.mvKeysRight, B.mDescriptorsRight, lap);
     msorb_host::ComputeStereoMatches(B, exL, exR);
+    // and with one extractor object per device (MSORB_DEVICES deals exS0 / exS1 onto the listed devices), twice
+    ORBextractor exS0(nf, 1.2f, 8, 20, 7), exS1(nf, 1.2f, 8, 20, 7);
+    Frame C, D;
+    C.mb = D.mb = mb; C.mbf = D.mbf = mbf;
+    msorb_host::ExtractStereoSplit(C, exS0, exS1, imL, imR);
+    msorb_host::ExtractStereoSplit(D, exS0, exS1, imL, imR);
     FILE* o = fopen(out, "wb");
-    for (Frame* F : {&A, &B}) {
+    const int devs[2] = {exS0.device(), exS1.device()};
+    fwrite(devs, 4, 2, o);
+    for (Frame* F : {&A, &B, &C, &D}) {
         const int n = (int)F->mvKeys.size(), nr = (int)F->mvKeysRight.size();
         fwrite(&n, 4, 1, o); fwrite(&nr, 4, 1, o);
         fwrite(F->mvKeys.data(), sizeof(cv::KeyPoint), n, o);
@@ -74,6 +82,12 @@ int main(int argc, char** argv) {
     for (int i = 0; i < n; i++) fwrite(desc.ptr<unsigned char>(i), 1, 32, o);
     int l7r = ex->mvImagePyramid[7].rows, l7c = ex->mvImagePyramid[7].cols, lv = ex->GetLevels();
     fwrite(&l7r, 4, 1, o); fwrite(&l7c, 4, 1, o); fwrite(&lv, 4, 1, o);
+    // mvImagePyramid as Frame::ComputeStereoMatches reads it on the host (Frame.cc:840-855): every level, row by row
+    for (int l = 0; l < lv; l++) {
+        const cv::Mat& m = ex->mvImagePyramid[l];
+        fwrite(&m.rows, 4, 1, o); fwrite(&m.cols, 4, 1, o);
+        for (int y = 0; y < m.rows; y++) fwrite(m.ptr<unsigned char>(y), 1, m.cols, o);
+    }
     fclose(o);
     delete ex;
     return 0;

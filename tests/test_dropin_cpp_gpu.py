@@ -33,6 +33,17 @@ def test_cpp_dropin_matches_oracle(tmp_path, oracle, msorb_mod):
     rmono, rkps, rdesc = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)(img)
     assert (mono, n) == (rmono, len(rkps)) and (l7r, l7c, lv) == (134, 210, 8)
     assert np.array_equal(kps.view(np.uint8), rkps.view(np.uint8)) and np.array_equal(desc, rdesc)
+    # mvImagePyramid (filled by the asynchronous copy that overlaps the extraction) holds the oracle's levels
+    orc = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    orc(img)
+    pos = 8 + 60 * n + 12
+    for l in range(8):
+        r, c = struct.unpack_from("<ii", blob, pos)
+        want = orc.level(l)
+        assert (r, c) == want.shape
+        assert np.array_equal(np.frombuffer(blob, np.uint8, r * c, pos + 8).reshape(r, c), want), l
+        pos += 8 + r * c
+    assert pos == len(blob)
 
 
 def test_cpp_matcher_adapter_matches_oracle(tmp_path, oracle, msorb_mod):
@@ -579,6 +590,12 @@ def test_cpp_fuse_adapter_matches_oracle(tmp_path, oracle, msorb_mod):
     assert log.tolist() == [list(e) for e in want_log]
     kinds = log[:, 0]
     assert (kinds == 1).sum() > 50 and (kinds == 2).sum() > 50
+    # the same KeyFrame after map sparsification (KeyFrame::EraseBadDescriptor swapped mGrid away, KeyFrame.cc:355-358):
+    # KeyFrame::GetFeaturesInArea returns nothing (:800-801), the reference's Fuse hits `continue` for every point
+    # (ORBmatcher.cc:1502-1508) and returns 0 without Replace / AddObservation / AddMapPoint
+    subprocess.check_call([str(exe), str(tmp_path / "fuse.bin"), str(tmp_path / "fuse_sp.bin"), "fuse_sparsified"])
+    n_fused_sp, nlog_sp = struct.unpack_from("<ii", (tmp_path / "fuse_sp.bin").read_bytes(), 0)
+    assert n_fused_sp == 0 and nlog_sp == 0
 
 
 def test_cpp_relocalisation_search_adapter_matches_oracle(tmp_path, oracle, msorb_mod):
@@ -663,11 +680,17 @@ def test_cpp_stereo_frame_constructor_one_call(tmp_path, oracle, msorb_mod):
     L.tofile(tmp_path / "l.raw")
     R.tofile(tmp_path / "r.raw")
     mbf, mb = mc.KITTI_BF, mc.KITTI_BF / mc.KITTI_FX
+    n_dev = msorb_mod.lib().msorb_device_count()
+    # five extractor objects are built before the split pair (exL, exR, exF, then exS0, exS1): the device list is written
+    # so that exS0 / exS1 land on devices 0 / 1 when the box has two GPUs
+    env = dict(os.environ, MSORB_DEVICES="0,0,0,0,1" if n_dev >= 2 else "0")
     subprocess.check_call([str(exe), str(cfg["rows"]), str(cfg["cols"]), str(tmp_path / "l.raw"), str(tmp_path / "out.bin"), "2000",
-                           "stereo", str(tmp_path / "r.raw"), repr(float(np.float32(mb))), repr(float(np.float32(mbf)))])
+                           "stereo", str(tmp_path / "r.raw"), repr(float(np.float32(mb))), repr(float(np.float32(mbf)))], env=env)
     blob = (tmp_path / "out.bin").read_bytes()
-    pos, frames = 0, []
-    for _ in range(2):
+    devs = struct.unpack_from("<ii", blob, 0)
+    assert devs == ((0, 1) if n_dev >= 2 else (0, 0))      # construction order -> device (ORBextractor.cc next_device)
+    pos, frames = 8, []
+    for _ in range(4):
         n, nr = struct.unpack_from("<ii", blob, pos)
         pos += 8
         kl = np.frombuffer(blob, oracle.KP_DTYPE, n, pos); pos += 28 * n
@@ -677,9 +700,10 @@ def test_cpp_stereo_frame_constructor_one_call(tmp_path, oracle, msorb_mod):
         ur = np.frombuffer(blob, np.float32, n, pos); pos += 4 * n
         dp = np.frombuffer(blob, np.float32, n, pos); pos += 4 * n
         frames.append((kl, kr, dl, dr, ur, dp))
-    a, b = frames
-    for x, y in zip(a, b):
-        assert x.tobytes() == y.tobytes()
+    a, b, c, d = frames     # ExtractStereo, the reference's sequence, ExtractStereoSplit (one object per device) twice
+    for other in (b, c, d):
+        for x, y in zip(a, other):
+            assert x.tobytes() == y.tobytes()
     _, okl, odl = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)(L)
     assert np.array_equal(a[0].view(np.uint8), okl.view(np.uint8)) and np.array_equal(a[2], odl)
     assert (a[4] > 0).sum() > 500
