@@ -243,12 +243,41 @@ int msorb_search_by_projection_kf(msorb_frame* cur, int n, const uint8_t* valid,
  * that passed :446-480: valid, u, v, predicted_level, mp_desc, mp_id.  Keypoints with matched[idx] >= 0 are skipped
  * (:499-500), level band predicted-1 .. predicted (:505-507), first strict minimum, accepted when
  * (float)bestDist <= max_dist (= TH_LOW * ratioHamming, :521) and then claimed: matched[bestIdx] = mp_id (in/out).
- * The window searches of Fuse(pKF, Scw, ...) (:1599-1716) and of the two passes of SearchBySim3 (:1718-1939) have no
- * claims and no error gates: msorb_fuse_search with an all-zero inv_level_sigma2 table returns exactly their
- * bestIdx / bestDist. */
+ * The claim-free searches of Fuse(pKF, Scw, ...) (:1599-1716) and SearchBySim3 (:1718-1939) have entries of their own:
+ * msorb_fuse_sim3_search and msorb_search_by_sim3. */
 int msorb_search_by_projection_sim3(msorb_frame* kf, int n, const uint8_t* valid, const float* u, const float* v,
                                     const int* predicted_level, const uint8_t* mp_desc, const int* mp_id, int* matched,
                                     float th, float max_dist, int* nmatches);
+
+/* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (ORBmatcher.cc:1718-1939; LoopClosing) from the projected
+ * coordinates on.  kf1 / kf2 = the two KeyFrames loaded with msorb_frame_set (n1 / n2 = their feature counts).  Per map
+ * point i1 of pKF1 that pass 1 reaches (:1760-1794: present, not already matched, not bad, positive depth after S21 * T1w,
+ * inside pKF2's image, distance inside the scale pyramid): valid1, u1, v1 (projection into pKF2), level1 =
+ * PredictScale(dist3D, pKF2), desc1 = GetDescriptor(); symmetric arrays for pass 2 (:1850-1885).  Each pass searches
+ * GetFeaturesInArea(u, v, th * mvScaleFactors[level]) of the other KeyFrame at levels level-1 .. level, first strict
+ * minimum, accepted when bestDist <= TH_HIGH (:1843-1846, :1915-1918); match12[i1] = idx2 when both passes agree
+ * (:1922-1937), else -1; *nfound = the return value.  vpMatches12[i1] = vpMapPoints2[match12[i1]] stays with the caller. */
+int msorb_search_by_sim3(msorb_frame* kf1, msorb_frame* kf2, int n1, const uint8_t* valid1, const float* u1, const float* v1,
+                         const int* level1, const uint8_t* desc1, int n2, const uint8_t* valid2, const float* u2,
+                         const float* v2, const int* level2, const uint8_t* desc2, float th, int* match12, int* nfound);
+
+/* The search of ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (ORBmatcher.cc:1599-1716; LoopClosing::
+ * SearchAndFuse): for every candidate point that passed :1622-1656 (valid, u, v, predicted_level, mp_desc) the best keypoint
+ * of the KeyFrame inside GetFeaturesInArea(u, v, th * mvScaleFactors[level]) at levels level-1 .. level, first strict
+ * minimum, NO reprojection-error gate (unlike msorb_fuse_search).  best_idx -1 / best_dist INT_MAX = none.  The accept rule
+ * bestDist <= TH_LOW and what follows (vpReplacePoint / AddObservation / AddMapPoint, :1698-1713) stay with the caller:
+ * they read and mutate the map sequentially. */
+int msorb_fuse_sim3_search(msorb_frame* kf, int n, const uint8_t* valid, const float* u, const float* v,
+                           const int* predicted_level, const uint8_t* mp_desc, float th, int* best_idx, int* best_dist);
+
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:755-870; monocular
+ * initialisation).  f1 / f2 = the two frames loaded with msorb_frame_set (both on one device).  prev_xy = vbPrevMatched
+ * (x, y per F1 keypoint; updated in place like :864-867), matches12[N1] = vnMatches12, *nmatches = the return value.  The
+ * device evaluates every (level-0 keypoint of F1, candidate of F2 in the window) Hamming distance in the reference's scan
+ * order; the sequential rule "a train matched at a smaller or equal distance is skipped" (:791-792), the ratio test, the
+ * re-assignment of trains and the rotation histogram are replayed on the host over those lists. */
+int msorb_search_for_initialization(msorb_frame* f1, msorb_frame* f2, float* prev_xy, int window_size, float nnratio,
+                                    int check_orientation, int* matches12, int* nmatches);
 
 /* Best / second-best Hamming match of each query over an explicit candidate list (CSR: candidates of
  * query i are cand_idx[cand_begin[i] .. cand_begin[i+1])), scanned in list order with strict '<' — the

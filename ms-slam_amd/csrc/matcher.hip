@@ -474,6 +474,59 @@ __global__ __launch_bounds__(256) void stereo_median_kernel(const int* __restric
     }
 }
 
+// Every candidate of a window with its distance, in the reference's scan order — for searches whose accept rule depends
+// on what EARLIER queries did to the candidates (ORBmatcher::SearchForInitialization skips a train already matched at a
+// smaller or equal distance, ORBmatcher.cc:791-792): the device evaluates all Hamming distances, the host replays the
+// sequential rule on the lists.  One thread per query walks GetFeaturesInArea (Frame.cc:589-655) itself; FILL = false
+// counts, FILL = true writes (index, distance) pairs at list_begin[q].
+template <bool FILL>
+__global__ __launch_bounds__(64) void window_list_kernel(FrameView F, const WinQuery* __restrict__ q, const uint8_t* __restrict__ qdesc,
+                                                         int n, int* __restrict__ count, const int* __restrict__ list_begin,
+                                                         int2* __restrict__ list) {
+    const int qi = blockIdx.x * 64 + threadIdx.x;
+    if (qi >= n) return;
+    const WinQuery Q = q[qi];
+    int m = 0;
+    if (Q.flags & kQValid) {
+        const int minCX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.x, F.minX), Q.r), F.gridWInv)));
+        const int maxCX = min(kGridCols - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.x, F.minX), Q.r), F.gridWInv)));
+        const int minCY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.y, F.minY), Q.r), F.gridHInv)));
+        const int maxCY = min(kGridRows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.y, F.minY), Q.r), F.gridHInv)));
+        if (!(minCX >= kGridCols || maxCX < 0 || minCY >= kGridRows || maxCY < 0)) {
+            const bool check_levels = (Q.min_level > 0) || (Q.max_level >= 0);
+            uint64_t a[4] = {0, 0, 0, 0};
+            int2* out = nullptr;
+            if (FILL) {
+                const uint64_t* qd = reinterpret_cast<const uint64_t*>(qdesc + (size_t)qi * 32);
+                a[0] = qd[0]; a[1] = qd[1]; a[2] = qd[2]; a[3] = qd[3];
+                out = list + list_begin[qi];
+            }
+            for (int ix = minCX; ix <= maxCX; ix++)
+                for (int iy = minCY; iy <= maxCY; iy++) {
+                    const int cell = ix * kGridRows + iy;
+                    for (int j = F.cell_begin[cell]; j < F.cell_begin[cell + 1]; j++) {
+                        const int idx = F.cell_idx[j];
+                        const KpLite kp = F.kp[idx];
+                        if (check_levels) {
+                            if (kp.octave < Q.min_level) continue;
+                            if (Q.max_level >= 0 && kp.octave > Q.max_level) continue;
+                        }
+                        if (!(fabsf(__fsub_rn(kp.x, Q.x)) < Q.r && fabsf(__fsub_rn(kp.y, Q.y)) < Q.r)) continue;
+                        if (FILL) out[m] = make_int2(idx, hamming256(a, reinterpret_cast<const uint64_t*>(F.desc + (size_t)idx * 32)));
+                        m++;
+                    }
+                }
+        }
+    }
+    if (!FILL) count[qi] = m;
+}
+void launch_window_list(const FrameView& F, const WinQuery* q, const uint8_t* qdesc, int n, int* count, const int* list_begin,
+                        int2* list, bool fill, hipStream_t s) {
+    if (n <= 0) return;
+    if (fill) hipLaunchKernelGGL(window_list_kernel<true>, dim3((n + 63) / 64), dim3(64), 0, s, F, q, qdesc, n, count, list_begin, list);
+    else hipLaunchKernelGGL(window_list_kernel<false>, dim3((n + 63) / 64), dim3(64), 0, s, F, q, qdesc, n, count, list_begin, list);
+}
+
 void launch_window_topk(const FrameView& F, const WinQuery* q, const uint8_t* qdesc, int q_begin, int q_end,
                         TopK* out, hipStream_t s) {
     const int n = q_end - q_begin;

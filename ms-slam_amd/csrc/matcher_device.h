@@ -66,6 +66,8 @@ struct StereoBatchArgs {
 
 void launch_window_topk(const FrameView& F, const WinQuery* q, const uint8_t* qdesc, int q_begin, int q_end,
                         TopK* out, hipStream_t s);
+void launch_window_list(const FrameView& F, const WinQuery* q, const uint8_t* qdesc, int n, int* count, const int* list_begin,
+                        int2* list, bool fill, hipStream_t s);
 void launch_list_top2(const uint8_t* qdesc, const uint8_t* tdesc, const int* cand_begin, const int* cand_idx, int nq,
                       int* bi, int* bd, int* si, int* sd, hipStream_t s);
 void launch_stereo_match(const StereoArgs& a, hipStream_t s);

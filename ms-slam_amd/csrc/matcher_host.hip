@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -507,6 +508,180 @@ int msorb_fuse_search(msorb_frame* f, const float* inv_level_sigma2, int n_level
     HIPCHK(hipMemcpyAsync(topk.data(), f->d_topk.p, (size_t)n * sizeof(TopK), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     for (int i = 0; i < n; i++) { best_idx[i] = topk[i].idx[0]; best_dist[i] = topk[i].dist[0]; }
+    return MSORB_OK;
+}
+
+namespace {
+// Claim-free window search on a KeyFrame: for every valid query the keypoint of f with the smallest distance inside
+// GetFeaturesInArea(u, v, th * mvScaleFactors[level]) (KeyFrame.cc:796-845) at levels level-1 .. level, first strict
+// minimum in scan order; best_idx -1 / best_dist INT_MAX when the band is empty.  The search shared by both passes of
+// SearchBySim3 (ORBmatcher.cc:1796-1841, 1888-1913) and by Fuse(pKF, Scw, ...) (:1661-1696).
+int plain_window_best(msorb_frame* f, int n, const uint8_t* valid, const float* u, const float* v, const int* level, float th,
+                      const uint8_t* desc, int* best_idx, int* best_dist) {
+    for (int i = 0; i < n; i++) { best_idx[i] = -1; best_dist[i] = INT_MAX; }
+    if (n == 0) return MSORB_OK;
+    HIPCHK(hipSetDevice(f->device));
+    std::vector<WinQuery> q(n);
+    for (int i = 0; i < n; i++) {
+        WinQuery w{};
+        if (valid[i]) {
+            if (level[i] < 0 || level[i] >= f->nlevels) { set_last_error("predicted level out of range"); return MSORB_E_INVALID; }
+            w.x = u[i]; w.y = v[i];
+            w.r = th * f->scale[level[i]];
+            w.min_level = (int16_t)(level[i] - 1);
+            w.max_level = (int16_t)level[i];
+            w.flags = kQValid | kQNoUr;
+        }
+        q[i] = w;
+    }
+    int rc;
+    if ((rc = f->d_q.ensure(n)) || (rc = f->d_qdesc.ensure((size_t)n * 32)) || (rc = f->d_topk.ensure(n)) ||
+        (rc = f->d_occ.ensure(std::max(f->N, 1))) || (rc = f->h_topk.ensure(n)))
+        return rc;
+    hipStream_t s = f->stream;
+    HIPCHK(hipMemcpyAsync(f->d_q.p, q.data(), (size_t)n * sizeof(WinQuery), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(f->d_qdesc.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
+    launch_window_topk(f->view(), f->d_q.p, f->d_qdesc.p, 0, n, f->d_topk.p, s);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(f->h_topk.p, f->d_topk.p, (size_t)n * sizeof(TopK), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int i = 0; i < n; i++)
+        if (f->h_topk.p[i].idx[0] >= 0) { best_idx[i] = f->h_topk.p[i].idx[0]; best_dist[i] = f->h_topk.p[i].dist[0]; }
+    return MSORB_OK;
+}
+}  // namespace
+
+int msorb_fuse_sim3_search(msorb_frame* kf, int n, const uint8_t* valid, const float* u, const float* v,
+                           const int* predicted_level, const uint8_t* mp_desc, float th, int* best_idx, int* best_dist) {
+    if (!kf || n < 0 || (n > 0 && (!valid || !u || !v || !predicted_level || !mp_desc || !best_idx || !best_dist)))
+        return MSORB_E_INVALID;
+    return plain_window_best(kf, n, valid, u, v, predicted_level, th, mp_desc, best_idx, best_dist);
+}
+
+int msorb_search_by_sim3(msorb_frame* kf1, msorb_frame* kf2, int n1, const uint8_t* valid1, const float* u1, const float* v1,
+                         const int* level1, const uint8_t* desc1, int n2, const uint8_t* valid2, const float* u2,
+                         const float* v2, const int* level2, const uint8_t* desc2, float th, int* match12, int* nfound) {
+    if (!kf1 || !kf2 || n1 < 0 || n2 < 0 || !nfound || (n1 > 0 && (!valid1 || !u1 || !v1 || !level1 || !desc1 || !match12)) ||
+        (n2 > 0 && (!valid2 || !u2 || !v2 || !level2 || !desc2)))
+        return MSORB_E_INVALID;
+    *nfound = 0;
+    std::vector<int> m1(n1), d1(n1), m2(n2), d2(n2);
+    int rc;
+    if ((rc = plain_window_best(kf2, n1, valid1, u1, v1, level1, th, desc1, m1.data(), d1.data()))) return rc;  // :1758-1848
+    if ((rc = plain_window_best(kf1, n2, valid2, u2, v2, level2, th, desc2, m2.data(), d2.data()))) return rc;  // :1850-1920
+    int nf = 0;
+    for (int i1 = 0; i1 < n1; i1++) {  // :1922-1937
+        match12[i1] = -1;
+        const int idx2 = d1[i1] <= kThHigh ? m1[i1] : -1;
+        if (idx2 >= 0 && idx2 < n2) {
+            const int idx1 = d2[idx2] <= kThHigh ? m2[idx2] : -1;
+            if (idx1 == i1) { match12[i1] = idx2; nf++; }
+        }
+    }
+    *nfound = nf;
+    return MSORB_OK;
+}
+
+int msorb_search_for_initialization(msorb_frame* f1, msorb_frame* f2, float* prev_xy, int window_size, float nnratio,
+                                    int check_orientation, int* matches12, int* nmatches) {
+    if (!f1 || !f2 || !nmatches || (f1->N > 0 && (!prev_xy || !matches12))) return MSORB_E_INVALID;
+    *nmatches = 0;
+    const int N1 = f1->N, N2 = f2->N;
+    for (int i = 0; i < N1; i++) matches12[i] = -1;
+    if (N1 == 0) return MSORB_OK;
+    HIPCHK(hipSetDevice(f2->device));
+    std::vector<WinQuery> q(N1);
+    std::vector<uint8_t> qdesc((size_t)N1 * 32);
+    HIPCHK(hipSetDevice(f1->device));
+    HIPCHK(hipMemcpy(qdesc.data(), f1->d_desc.p, (size_t)N1 * 32, hipMemcpyDeviceToHost));  // F1.mDescriptors as uploaded
+    HIPCHK(hipSetDevice(f2->device));
+    for (int i = 0; i < N1; i++) {
+        WinQuery w{};
+        const int level1 = f1->kps[i].octave;
+        if (level1 <= 0) {                                            // :769-771 (only level-0 keypoints are matched)
+            w.x = prev_xy[2 * i]; w.y = prev_xy[2 * i + 1];
+            w.r = (float)window_size;
+            w.min_level = (int16_t)level1; w.max_level = (int16_t)level1;  // GetFeaturesInArea(x, y, windowSize, level1, level1)
+            w.flags = kQValid | kQNoUr;
+        }
+        q[i] = w;
+    }
+    int rc;
+    DBuf<int> d_cnt, d_beg;
+    DBuf<int2> d_list;
+    if ((rc = f2->d_q.ensure(N1)) || (rc = f2->d_qdesc.ensure((size_t)N1 * 32)) || (rc = d_cnt.ensure(N1)) ||
+        (rc = d_beg.ensure(N1 + 1)))
+        return rc;
+    hipStream_t s = f2->stream;
+    std::vector<int> cnt(N1), beg(N1 + 1, 0);
+    std::vector<int2> list;
+    hipError_t e = hipMemcpyAsync(f2->d_q.p, q.data(), (size_t)N1 * sizeof(WinQuery), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(f2->d_qdesc.p, qdesc.data(), (size_t)N1 * 32, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        launch_window_list(f2->view(), f2->d_q.p, f2->d_qdesc.p, N1, d_cnt.p, nullptr, nullptr, false, s);
+        e = hipMemcpyAsync(cnt.data(), d_cnt.p, (size_t)N1 * sizeof(int), hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) {
+        for (int i = 0; i < N1; i++) beg[i + 1] = beg[i] + cnt[i];
+        list.resize(std::max(beg[N1], 1));
+        rc = d_list.ensure(list.size());
+        if (rc == MSORB_OK && beg[N1] > 0) {
+            e = hipMemcpyAsync(d_beg.p, beg.data(), (size_t)(N1 + 1) * sizeof(int), hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) {
+                launch_window_list(f2->view(), f2->d_q.p, f2->d_qdesc.p, N1, d_cnt.p, d_beg.p, d_list.p, true, s);
+                e = hipMemcpyAsync(list.data(), d_list.p, (size_t)beg[N1] * sizeof(int2), hipMemcpyDeviceToHost, s);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+        }
+    }
+    d_cnt.release(); d_beg.release(); d_list.release();
+    if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return MSORB_E_HIP; }
+    if (rc) return rc;
+    // the reference's loop (:767-835) on the lists: every distance is known, the sequential part is compare / select
+    int nm = 0;
+    std::vector<int> rotHist[kHistoLength];
+    const float factor = 1.0f / kHistoLength;
+    std::vector<int> vMatchedDistance(N2, INT_MAX), vnMatches21(N2, -1);
+    for (int i1 = 0; i1 < N1; i1++) {
+        if (!(q[i1].flags & kQValid) || cnt[i1] == 0) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int k = beg[i1]; k < beg[i1 + 1]; k++) {
+            const int i2 = list[k].x, dist = list[k].y;
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= kThLow) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (vnMatches21[bestIdx2] >= 0) { matches12[vnMatches21[bestIdx2]] = -1; nm--; }
+                matches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nm++;
+                if (check_orientation) {
+                    float rot = f1->kps[i1].angle - f2->kps[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == kHistoLength) bin = 0;
+                    if (bin >= 0 && bin < kHistoLength) rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (check_orientation) {  // :837-861
+        int sizes[kHistoLength], ind[3];
+        for (int i = 0; i < kHistoLength; i++) sizes[i] = (int)rotHist[i].size();
+        msorb_three_maxima(sizes, kHistoLength, ind);
+        for (int i = 0; i < kHistoLength; i++) {
+            if (i == ind[0] || i == ind[1] || i == ind[2]) continue;
+            for (int idx1 : rotHist[i])
+                if (matches12[idx1] >= 0) { matches12[idx1] = -1; nm--; }
+        }
+    }
+    for (int i1 = 0; i1 < N1; i1++)  // :864-867
+        if (matches12[i1] >= 0) { prev_xy[2 * i1] = f2->kps[matches12[i1]].x; prev_xy[2 * i1 + 1] = f2->kps[matches12[i1]].y; }
+    *nmatches = nm;
     return MSORB_OK;
 }
 

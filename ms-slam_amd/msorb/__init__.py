@@ -418,6 +418,54 @@ class Frame:
         return bi[:n], bd[:n]
 
 
+def _sim3_side(p):
+    return [_c(p["valid"], np.uint8), _c(p["u"], np.float32), _c(p["v"], np.float32), _c(p["level"], np.int32),
+            _c(p["desc"], np.uint8)]
+
+
+def search_by_sim3(kf1, kf2, p1, p2, th):
+    """msorb_search_by_sim3: kf1 / kf2 = Frame handles of the two KeyFrames, p1 / p2 = dicts valid, u, v, level, desc of their
+    map points (projected into the other KeyFrame).  -> (match12[n1], nFound)"""
+    L = _mlib()
+    a, b = _sim3_side(p1), _sim3_side(p2)
+    m12 = np.full(max(len(a[0]), 1), -1, np.int32)
+    nf = C.c_int()
+    vp = C.c_void_p
+    L.msorb_search_by_sim3.argtypes = [vp, vp, C.c_int] + [vp] * 5 + [C.c_int] + [vp] * 5 + [C.c_float, vp, vp]
+    _check(L.msorb_search_by_sim3(kf1.h, kf2.h, len(a[0]), *[_np_ptr(x) for x in a], len(b[0]), *[_np_ptr(x) for x in b], th,
+                                  _np_ptr(m12), C.byref(nf)), "msorb_search_by_sim3")
+    return m12[:len(a[0])], nf.value
+
+
+def fuse_sim3_search(kf, pts, th):
+    """msorb_fuse_sim3_search: the search of Fuse(pKF, Scw, ...).  -> (best_idx, best_dist), INT_MAX = none"""
+    L = _mlib()
+    a = _sim3_side(pts)
+    n = len(a[0])
+    bi, bd = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    vp = C.c_void_p
+    L.msorb_fuse_sim3_search.argtypes = [vp, C.c_int] + [vp] * 5 + [C.c_float, vp, vp]
+    _check(L.msorb_fuse_sim3_search(kf.h, n, *[_np_ptr(x) for x in a], th, _np_ptr(bi), _np_ptr(bd)), "msorb_fuse_sim3_search")
+    return bi[:n], bd[:n]
+
+
+def search_for_initialization(f1, f2, prev_xy, window_size=100, nnratio=0.9, check_orientation=True):
+    """msorb_search_for_initialization; prev_xy [N1, 2] float32 updated in place.  -> (vnMatches12, nmatches)"""
+    L = _mlib()
+    assert prev_xy.dtype == np.float32 and prev_xy.flags.c_contiguous
+    n1 = prev_xy.shape[0]
+    m12 = np.full(max(n1, 1), -1, np.int32)
+    nm = C.c_int()
+    vp = C.c_void_p
+    L.msorb_search_for_initialization.argtypes = [vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, vp]
+    _check(L.msorb_search_for_initialization(f1.h, f2.h, _np_ptr(prev_xy), int(window_size), nnratio, int(check_orientation),
+                                             _np_ptr(m12), C.byref(nm)), "msorb_search_for_initialization")
+    return m12[:n1], nm.value
+
+
+EXPORTS = EXPORTS + ("msorb_search_by_sim3", "msorb_fuse_sim3_search", "msorb_search_for_initialization")
+
+
 def hamming_top2(query_desc, train_desc, cand_begin, cand_idx, device=0):
     q, t = _c(query_desc, np.uint8), _c(train_desc, np.uint8)
     cb, ci_ = _c(cand_begin, np.int32), _c(cand_idx, np.int32)

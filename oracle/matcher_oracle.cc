@@ -376,6 +376,138 @@ int orc_search_by_projection_sim3(void* fp, int n, const uint8_t* valid, const f
     return nmatches;
 }
 
+// ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, S12, th), ORBmatcher.cc:1718-1939, from the projected coordinates on.
+// Pass 1 (:1758-1848): every map point i1 of pKF1 the loop reaches (valid1: present, not already matched, not bad, positive
+// depth, inside pKF2's image, distance inside the scale pyramid) is searched in pKF2 — GetFeaturesInArea(u, v,
+// th * mvScaleFactors[level]) (KeyFrame.cc:796-845: no level argument), level band predicted-1 .. predicted, first strict
+// minimum, bestDist <= TH_HIGH -> vnMatch1[i1].  Pass 2 (:1850-1920) the same from pKF2 into pKF1.  Agreement (:1922-1937):
+// a pair survives when both passes point at each other.  match12[i1] = idx2 or -1; returns nFound.
+static void sim3_pass(const FrameSoA& K, int n, const uint8_t* valid, const float* u, const float* v, const int* level,
+                      const uint8_t* desc, float th, std::vector<int>& vnMatch) {
+    vnMatch.assign(n, -1);
+    for (int i = 0; i < n; i++) {
+        if (!valid[i]) continue;
+        const int nPredictedLevel = level[i];
+        const float radius = th * K.scaleFactors[nPredictedLevel];
+        const std::vector<size_t> vIndices = K.features_in_area(u[i], v[i], radius, -1, -1);
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = desc + (size_t)i * 32;
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (size_t k = 0; k < vIndices.size(); k++) {
+            const size_t idx = vIndices[k];
+            const KeyPoint& kp = K.kps[idx];
+            if (kp.octave < nPredictedLevel - 1 || kp.octave > nPredictedLevel) continue;
+            const int dist = orc::descriptor_distance(dMP, &K.desc[idx * 32]);
+            if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+        }
+        if (bestDist <= orc::TH_HIGH) vnMatch[i] = bestIdx;
+    }
+}
+int orc_search_by_sim3(void* kf1, void* kf2, int n1, const uint8_t* valid1, const float* u1, const float* v1, const int* level1,
+                       const uint8_t* desc1, int n2, const uint8_t* valid2, const float* u2, const float* v2, const int* level2,
+                       const uint8_t* desc2, float th, int* match12) {
+    const FrameSoA &K1 = *(const FrameSoA*)kf1, &K2 = *(const FrameSoA*)kf2;
+    std::vector<int> vnMatch1, vnMatch2;
+    sim3_pass(K2, n1, valid1, u1, v1, level1, desc1, th, vnMatch1);  // KF1's points searched in KF2
+    sim3_pass(K1, n2, valid2, u2, v2, level2, desc2, th, vnMatch2);  // KF2's points searched in KF1
+    int nFound = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        match12[i1] = -1;
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0) {
+            const int idx1 = idx2 < n2 ? vnMatch2[idx2] : -1;
+            if (idx1 == i1) { match12[i1] = idx2; nFound++; }
+        }
+    }
+    return nFound;
+}
+
+// The search of ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint), ORBmatcher.cc:1661-1696, for the points that passed
+// :1622-1656 (not bad, not already in the KeyFrame, positive depth, inside the image, distance, viewing angle): no
+// reprojection-error gate in this form; best_dist = INT_MAX when the window holds no keypoint of the level band.
+void orc_fuse_sim3_search(void* fp, int n, const uint8_t* valid, const float* u, const float* v, const int* predicted_level,
+                          const uint8_t* mp_desc, float th, int* best_idx, int* best_dist) {
+    const FrameSoA& K = *(const FrameSoA*)fp;
+    for (int i = 0; i < n; i++) {
+        best_idx[i] = -1;
+        best_dist[i] = INT_MAX;
+        if (!valid[i]) continue;
+        const int nPredictedLevel = predicted_level[i];
+        const float radius = th * K.scaleFactors[nPredictedLevel];
+        const std::vector<size_t> vIndices = K.features_in_area(u[i], v[i], radius, -1, -1);
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = mp_desc + (size_t)i * 32;
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (size_t k = 0; k < vIndices.size(); k++) {
+            const size_t idx = vIndices[k];
+            const int kpLevel = K.kps[idx].octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            const int dist = orc::descriptor_distance(dMP, &K.desc[idx * 32]);
+            if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+        }
+        best_idx[i] = bestIdx;
+        best_dist[i] = bestDist;
+    }
+}
+
+// ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize), ORBmatcher.cc:755-870 (monocular
+// initialisation).  prev = vbPrevMatched (x, y per F1 keypoint, updated in place like :864-867); returns nmatches.
+int orc_search_for_initialization(void* f1, void* f2, float* prev_xy, int window_size, float nnratio, int check_orientation,
+                                  int* vnMatches12) {
+    const FrameSoA &F1 = *(const FrameSoA*)f1, &F2 = *(const FrameSoA*)f2;
+    int nmatches = 0;
+    for (int i = 0; i < F1.N; i++) vnMatches12[i] = -1;
+    std::vector<int> rotHist[orc::HISTO_LENGTH];
+    const float factor = 1.0f / orc::HISTO_LENGTH;
+    std::vector<int> vMatchedDistance(F2.N, INT_MAX), vnMatches21(F2.N, -1);
+    for (int i1 = 0; i1 < F1.N; i1++) {
+        const KeyPoint kp1 = F1.kps[i1];
+        const int level1 = kp1.octave;
+        if (level1 > 0) continue;
+        const std::vector<size_t> vIndices2 = F2.features_in_area(prev_xy[2 * i1], prev_xy[2 * i1 + 1], (float)window_size, level1, level1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* d1 = &F1.desc[(size_t)i1 * 32];
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (size_t k = 0; k < vIndices2.size(); k++) {
+            const size_t i2 = vIndices2[k];
+            const int dist = orc::descriptor_distance(d1, &F2.desc[i2 * 32]);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = (int)i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= orc::TH_LOW) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+                vnMatches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (check_orientation) {
+                    float rot = F1.kps[i1].angle - F2.kps[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == orc::HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc::three_maxima(rotHist, orc::HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < orc::HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) {
+                const int idx1 = rotHist[i][j];
+                if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+            }
+        }
+    }
+    for (int i1 = 0; i1 < F1.N; i1++)
+        if (vnMatches12[i1] >= 0) { prev_xy[2 * i1] = F2.kps[vnMatches12[i1]].x; prev_xy[2 * i1 + 1] = F2.kps[vnMatches12[i1]].y; }
+    return nmatches;
+}
+
 void orc_three_maxima(const int* sizes, int L, int* ind) {
     std::vector<std::vector<int>> h(L);
     for (int i = 0; i < L; i++) h[i].resize(sizes[i]);

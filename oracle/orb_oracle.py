@@ -251,6 +251,46 @@ class OracleFrame:
         return bi[:n], bd[:n]
 
 
+def _sim3_side(p):
+    return [_c(p["valid"], np.uint8), _c(p["u"], np.float32), _c(p["v"], np.float32), _c(p["level"], np.int32),
+            _c(p["desc"], np.uint8)]
+
+
+def search_by_sim3(kf1, kf2, p1, p2, th):
+    """orc_search_by_sim3 (ORBmatcher.cc:1718-1939 from the projections on).  kf1 / kf2: OracleFrame; p1 / p2: dicts valid, u, v,
+    level, desc of the map points of pKF1 / pKF2.  -> (match12[n1], nFound)"""
+    L = _mlib()
+    a, b = _sim3_side(p1), _sim3_side(p2)
+    m12 = np.full(max(len(a[0]), 1), -1, np.int32)
+    L.orc_search_by_sim3.argtypes = ([C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 5 +
+                                     [C.c_float, C.c_void_p])
+    n = L.orc_search_by_sim3(kf1.h, kf2.h, len(a[0]), *[_ptr(x) for x in a], len(b[0]), *[_ptr(x) for x in b], th, _ptr(m12))
+    return m12[:len(a[0])], n
+
+
+def fuse_sim3_search(kf, pts, th):
+    """orc_fuse_sim3_search (ORBmatcher.cc:1661-1696).  -> (best_idx, best_dist), INT_MAX = none"""
+    L = _mlib()
+    a = _sim3_side(pts)
+    n = len(a[0])
+    bi, bd = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    L.orc_fuse_sim3_search.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_void_p, C.c_void_p]
+    L.orc_fuse_sim3_search.restype = None
+    L.orc_fuse_sim3_search(kf.h, n, *[_ptr(x) for x in a], th, _ptr(bi), _ptr(bd))
+    return bi[:n], bd[:n]
+
+
+def search_for_initialization(f1, f2, prev_xy, window_size=100, nnratio=0.9, check_orientation=True):
+    """orc_search_for_initialization (ORBmatcher.cc:755-870).  prev_xy [N1, 2] float32 is updated in place.
+    -> (vnMatches12, nmatches)"""
+    L = _mlib()
+    assert prev_xy.dtype == np.float32 and prev_xy.flags.c_contiguous and prev_xy.shape == (f1.n, 2)
+    m12 = np.full(max(f1.n, 1), -1, np.int32)
+    L.orc_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    n = L.orc_search_for_initialization(f1.h, f2.h, _ptr(prev_xy), int(window_size), nnratio, int(check_orientation), _ptr(m12))
+    return m12[:f1.n], n
+
+
 def three_maxima(sizes):
     s = _c(sizes, np.int32)
     ind = np.zeros(3, np.int32)
