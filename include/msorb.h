@@ -237,9 +237,9 @@ int msorb_search_by_projection_kf(msorb_frame* cur, int n, const uint8_t* valid,
                                   const int* mp_id, int* cur_mp, float th, int orb_dist, int check_orientation,
                                   int* nmatches);
 
-/* The Sim3 / loop-closing window searches: SearchByProjection(pKF, Scw, vpPoints, vpMatched, th, ratioHamming)
- * (ORBmatcher.cc:423-530), SearchByProjectionLoop (:532-637) and the (pKF, Scw, vpPoints, vpPointsKFs, ...) form
- * (:639-753), from the projected coordinates on.  `kf` = the KeyFrame loaded with msorb_frame_set.  Per candidate point
+/* The Sim3 / loop-closing window searches that claim keypoints: SearchByProjection(pKF, Scw, vpPoints, vpMatched, th,
+ * ratioHamming) (ORBmatcher.cc:423-530) and the (pKF, Scw, vpPoints, vpPointsKFs, ...) form (:639-753), from the projected
+ * coordinates on (SearchByProjectionLoop, :532-637, has different rules: msorb_search_by_projection_loop).  `kf` = the KeyFrame loaded with msorb_frame_set.  Per candidate point
  * that passed :446-480: valid, u, v, predicted_level, mp_desc, mp_id.  Keypoints with matched[idx] >= 0 are skipped
  * (:499-500), level band predicted-1 .. predicted (:505-507), first strict minimum, accepted when
  * (float)bestDist <= max_dist (= TH_LOW * ratioHamming, :521) and then claimed: matched[bestIdx] = mp_id (in/out).
@@ -248,6 +248,17 @@ int msorb_search_by_projection_kf(msorb_frame* cur, int n, const uint8_t* valid,
 int msorb_search_by_projection_sim3(msorb_frame* kf, int n, const uint8_t* valid, const float* u, const float* v,
                                     const int* predicted_level, const uint8_t* mp_desc, const int* mp_id, int* matched,
                                     float th, float max_dist, int* nmatches);
+
+/* ORBmatcher::SearchByProjectionLoop(pKF, Scw, vpPoints, vpMatched, vpMatchedKF, th, ratioHamming) (ORBmatcher.cc:532-637;
+ * LoopClosing::DetectCommonRegionsFromBoW :744,:753) from the projected coordinates on.  Per candidate point that passed
+ * :555-588 (not bad, vpMatched[iMP] still empty, positive depth, inside the image, distance, viewing angle): valid, u, v,
+ * predicted_level, mp_desc.  A keypoint is a candidate only when it holds a good map point (train_ok[idx] =
+ * vpMapPointsToMatch[idx] && !isBad(), :609-610), level band predicted-1 .. predicted+1 (:613), first strict minimum,
+ * accepted when bestDist <= max_dist (= TH_LOW * ratioHamming, :626).  Results are per POINT and independent of each other:
+ * best_idx[i] = the keypoint whose map point becomes vpMatched[iMP], or -1; *nmatches = the return value. */
+int msorb_search_by_projection_loop(msorb_frame* kf, int n, const uint8_t* valid, const float* u, const float* v,
+                                    const int* predicted_level, const uint8_t* mp_desc, const uint8_t* train_ok, float th,
+                                    float max_dist, int* best_idx, int* nmatches);
 
 /* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (ORBmatcher.cc:1718-1939; LoopClosing) from the projected
  * coordinates on.  kf1 / kf2 = the two KeyFrames loaded with msorb_frame_set (n1 / n2 = their feature counts).  Per map

@@ -517,7 +517,7 @@ namespace {
 // minimum in scan order; best_idx -1 / best_dist INT_MAX when the band is empty.  The search shared by both passes of
 // SearchBySim3 (ORBmatcher.cc:1796-1841, 1888-1913) and by Fuse(pKF, Scw, ...) (:1661-1696).
 int plain_window_best(msorb_frame* f, int n, const uint8_t* valid, const float* u, const float* v, const int* level, float th,
-                      const uint8_t* desc, int* best_idx, int* best_dist) {
+                      const uint8_t* desc, int* best_idx, int* best_dist, int band_above = 0, const uint8_t* train_skip = nullptr) {
     for (int i = 0; i < n; i++) { best_idx[i] = -1; best_dist[i] = INT_MAX; }
     if (n == 0) return MSORB_OK;
     HIPCHK(hipSetDevice(f->device));
@@ -529,8 +529,8 @@ int plain_window_best(msorb_frame* f, int n, const uint8_t* valid, const float* 
             w.x = u[i]; w.y = v[i];
             w.r = th * f->scale[level[i]];
             w.min_level = (int16_t)(level[i] - 1);
-            w.max_level = (int16_t)level[i];
-            w.flags = kQValid | kQNoUr;
+            w.max_level = (int16_t)(level[i] + band_above);
+            w.flags = kQValid | kQNoUr | (train_skip ? kQSkipOccupied : 0);
         }
         q[i] = w;
     }
@@ -539,6 +539,7 @@ int plain_window_best(msorb_frame* f, int n, const uint8_t* valid, const float* 
         (rc = f->d_occ.ensure(std::max(f->N, 1))) || (rc = f->h_topk.ensure(n)))
         return rc;
     hipStream_t s = f->stream;
+    if (train_skip && f->N) HIPCHK(hipMemcpyAsync(f->d_occ.p, train_skip, (size_t)f->N, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(f->d_q.p, q.data(), (size_t)n * sizeof(WinQuery), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(f->d_qdesc.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
     launch_window_topk(f->view(), f->d_q.p, f->d_qdesc.p, 0, n, f->d_topk.p, s);
@@ -556,6 +557,28 @@ int msorb_fuse_sim3_search(msorb_frame* kf, int n, const uint8_t* valid, const f
     if (!kf || n < 0 || (n > 0 && (!valid || !u || !v || !predicted_level || !mp_desc || !best_idx || !best_dist)))
         return MSORB_E_INVALID;
     return plain_window_best(kf, n, valid, u, v, predicted_level, th, mp_desc, best_idx, best_dist);
+}
+
+int msorb_search_by_projection_loop(msorb_frame* kf, int n, const uint8_t* valid, const float* u, const float* v,
+                                    const int* predicted_level, const uint8_t* mp_desc, const uint8_t* train_ok, float th,
+                                    float max_dist, int* best_idx, int* nmatches) {
+    if (!kf || n < 0 || !nmatches || (n > 0 && (!valid || !u || !v || !predicted_level || !mp_desc || !best_idx)) ||
+        (kf->N > 0 && !train_ok))
+        return MSORB_E_INVALID;
+    *nmatches = 0;
+    std::vector<uint8_t> skip(kf->N);
+    for (int i = 0; i < kf->N; i++) skip[i] = !train_ok[i];             // :609-610
+    std::vector<int> bd(n);
+    const int rc = plain_window_best(kf, n, valid, u, v, predicted_level, th, mp_desc, best_idx, bd.data(), 1, skip.data());
+    if (rc) return rc;
+    int nm = 0;
+    for (int i = 0; i < n; i++) {
+        const int d = best_idx[i] >= 0 ? bd[i] : 256;                   // bestDist starts at 256 (:599)
+        if ((float)d <= max_dist && best_idx[i] >= 0) nm++;             // :626-631
+        else best_idx[i] = -1;
+    }
+    *nmatches = nm;
+    return MSORB_OK;
 }
 
 int msorb_search_by_sim3(msorb_frame* kf1, msorb_frame* kf2, int n1, const uint8_t* valid1, const float* u1, const float* v1,

@@ -1,0 +1,175 @@
+// ORB_SLAM3::ORBmatcher on libmsorb.so — see ORBmatcher.h.  Every method keeps the reference's signature and return
+// value and forwards to the msorb_host templates (ORBmatcher_device.h, ORBmatcher_loop_device.h): the reference's own
+// geometry code on the host, the Hamming searches on the GPU behind the C ABI.  The device copies of the frames /
+// keyframes a thread searches in are kept per calling thread (the matcher is entered from the Tracking, LocalMapping and
+// LoopClosing threads, each with stack-constructed ORBmatcher objects: Tracking.cc:2835, LocalMapping.cc:438,787,
+// LoopClosing.cc:594) and re-uploaded only when the object changes.
+#include "ORBmatcher.h"
+
+#include <cstdint>
+#include <cstdlib>
+
+#include "ORBmatcher_device.h"
+#include "ORBmatcher_loop_device.h"
+
+namespace ORB_SLAM3 {
+
+const int ORBmatcher::TH_HIGH = 100;
+const int ORBmatcher::TH_LOW = 50;
+const int ORBmatcher::HISTO_LENGTH = 30;
+
+namespace {
+int matcher_device() {  // MSORB_MATCHER_DEVICE, else MSORB_DEVICE, else 0
+    static const int dev = [] {
+        const char* e = std::getenv("MSORB_MATCHER_DEVICE");
+        if (!e) e = std::getenv("MSORB_DEVICE");
+        return e ? std::atoi(e) : 0;
+    }();
+    return dev;
+}
+// One device-resident Frame and two device-resident KeyFrames per calling thread, keyed by identity: consecutive searches
+// in the same object (TrackWithMotionModel retries, SearchLocalPoints after TrackReferenceKeyFrame, the covisible loop of
+// SearchInNeighbors) upload once.
+struct ThreadCache {
+    msorb_host::DeviceFrame<Frame> frame{matcher_device()}, frame2{matcher_device()}, kf[2] = {msorb_host::DeviceFrame<Frame>(matcher_device()),
+                                                                                            msorb_host::DeviceFrame<Frame>(matcher_device())};
+    const void* frame_key = nullptr;
+    long unsigned int frame_id = ~0ul;
+    const void* frame2_key = nullptr;
+    long unsigned int frame2_id = ~0ul;
+    const void* kf_key[2] = {nullptr, nullptr};
+    long unsigned int kf_id[2] = {~0ul, ~0ul};
+    bool kf_sparsified[2] = {false, false};
+    int kf_n[2] = {-1, -1};
+};
+ThreadCache& cache() {
+    static thread_local ThreadCache c;
+    return c;
+}
+msorb_host::DeviceFrame<Frame>& device_frame(const Frame& F, bool second = false) {
+    ThreadCache& c = cache();
+    const void*& key = second ? c.frame2_key : c.frame_key;
+    long unsigned int& id = second ? c.frame2_id : c.frame_id;
+    msorb_host::DeviceFrame<Frame>& d = second ? c.frame2 : c.frame;
+    if (key != &F || id != F.mnId) { d.Upload(F); key = &F; id = F.mnId; }
+    return d;
+}
+msorb_host::DeviceFrame<Frame>& device_keyframe(const std::shared_ptr<KeyFrame>& pKF, int slot = 0) {
+    ThreadCache& c = cache();
+    // a KeyFrame's features change once in its life: when map sparsification compacts them (KeyFrame::EraseBadDescriptor)
+    if (c.kf_key[slot] != pKF.get() || c.kf_id[slot] != pKF->mnId || c.kf_sparsified[slot] != pKF->mbSparsified ||
+        c.kf_n[slot] != pKF->GetN()) {
+        c.kf[slot].UploadKeyFrame(pKF);
+        c.kf_key[slot] = pKF.get(); c.kf_id[slot] = pKF->mnId; c.kf_sparsified[slot] = pKF->mbSparsified; c.kf_n[slot] = pKF->GetN();
+    }
+    return c.kf[slot];
+}
+}  // namespace
+
+ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+int ORBmatcher::SearchByProjection(Frame& F, const std::vector<std::shared_ptr<MapPoint>>& vpMapPoints, const float th,
+                                   const bool bFarPoints, const float thFarPoints) {
+    return msorb_host::SearchByProjection(device_frame(F), F, vpMapPoints, th, bFarPoints, thFarPoints, mfNNratio);
+}
+
+int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono) {
+    return msorb_host::SearchByProjection(device_frame(CurrentFrame), CurrentFrame, LastFrame, th, bMono, mbCheckOrientation);
+}
+
+int ORBmatcher::SearchByProjection(Frame& CurrentFrame, std::shared_ptr<KeyFrame> pKF,
+                                   const std::set<std::shared_ptr<MapPoint>>& sAlreadyFound, const float th, const int ORBdist) {
+    return msorb_host::SearchByProjection(device_frame(CurrentFrame), CurrentFrame, pKF, sAlreadyFound, th, ORBdist, mbCheckOrientation);
+}
+
+int ORBmatcher::SearchByProjection(std::shared_ptr<KeyFrame> pKF, Sophus::Sim3<float>& Scw,
+                                   const std::vector<std::shared_ptr<MapPoint>>& vpPoints,
+                                   std::vector<std::shared_ptr<MapPoint>>& vpMatched, int th, float ratioHamming) {
+    return msorb_host::SearchByProjection(device_keyframe(pKF), pKF, Scw, vpPoints, vpMatched, th, ratioHamming);
+}
+
+int ORBmatcher::SearchByProjectionLoop(std::shared_ptr<KeyFrame> pKF, Sophus::Sim3<float>& Scw,
+                                       const std::vector<std::shared_ptr<MapPoint>>& vpPoints,
+                                       std::vector<std::shared_ptr<MapPoint>>& vpMatched,
+                                       std::vector<std::shared_ptr<KeyFrame>>& vpMatchedKF, int th, float ratioHamming) {
+    return msorb_host::SearchByProjectionLoop(device_keyframe(pKF), pKF, Scw, vpPoints, vpMatched, vpMatchedKF, th, ratioHamming);
+}
+
+int ORBmatcher::SearchByProjection(std::shared_ptr<KeyFrame> pKF, Sophus::Sim3<float>& Scw,
+                                   const std::vector<std::shared_ptr<MapPoint>>& vpPoints,
+                                   const std::vector<std::shared_ptr<KeyFrame>>& vpPointsKFs,
+                                   std::vector<std::shared_ptr<MapPoint>>& vpMatched,
+                                   std::vector<std::shared_ptr<KeyFrame>>& vpMatchedKF, int th, float ratioHamming) {
+    return msorb_host::SearchByProjection(device_keyframe(pKF), pKF, Scw, vpPoints, vpPointsKFs, vpMatched, vpMatchedKF, th, ratioHamming);
+}
+
+int ORBmatcher::SearchByBoW(std::shared_ptr<KeyFrame> pKF, Frame& F, std::vector<std::shared_ptr<MapPoint>>& vpMapPointMatches) {
+    return msorb_host::SearchByBoW(pKF, F, vpMapPointMatches, mfNNratio, mbCheckOrientation, matcher_device());
+}
+
+int ORBmatcher::SearchByBoW(std::shared_ptr<KeyFrame> pKF1, std::shared_ptr<KeyFrame> pKF2,
+                            std::vector<std::shared_ptr<MapPoint>>& vpMatches12) {
+    return msorb_host::SearchByBoWKeyFrames(pKF1, pKF2, vpMatches12, mfNNratio, mbCheckOrientation, matcher_device());
+}
+
+int ORBmatcher::SearchByBoW(std::shared_ptr<KeyFrame> pKF1, std::shared_ptr<KeyFrame> pKF2,
+                            std::vector<std::shared_ptr<KeyFrame>>& vpMatchedCurrentKeyFrame,
+                            std::vector<std::shared_ptr<MapPoint>>& vpMatchedCurrentMapPoint,
+                            std::vector<std::shared_ptr<KeyFrame>>& vpMatchedLoopKeyFrame,
+                            std::vector<std::shared_ptr<MapPoint>>& vpMatchedLoopMapPoint, long unsigned int& nCurrentId) {
+    return msorb_host::SearchByBoWLoop(pKF1, pKF2, vpMatchedCurrentKeyFrame, vpMatchedCurrentMapPoint, vpMatchedLoopKeyFrame,
+                                       vpMatchedLoopMapPoint, nCurrentId, mfNNratio, matcher_device());
+}
+
+int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12,
+                                        int windowSize) {
+    return msorb_host::SearchForInitialization(device_frame(F1), device_frame(F2, true), F1, F2, vbPrevMatched, vnMatches12,
+                                               windowSize, mfNNratio, mbCheckOrientation);
+}
+
+int ORBmatcher::SearchForTriangulation(std::shared_ptr<KeyFrame> pKF1, std::shared_ptr<KeyFrame> pKF2,
+                                       std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo, const bool bCoarse) {
+    return msorb_host::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse, mbCheckOrientation, matcher_device());
+}
+
+int ORBmatcher::SearchBySim3(std::shared_ptr<KeyFrame> pKF1, std::shared_ptr<KeyFrame> pKF2,
+                             std::vector<std::shared_ptr<MapPoint>>& vpMatches12, const Sophus::Sim3f& S12, const float th) {
+    return msorb_host::SearchBySim3(device_keyframe(pKF1, 0), device_keyframe(pKF2, 1), pKF1, pKF2, vpMatches12, S12, th);
+}
+
+int ORBmatcher::Fuse(std::shared_ptr<KeyFrame> pKF, const std::vector<std::shared_ptr<MapPoint>>& vpMapPoints, const float th,
+                     const bool bRight) {
+    (void)bRight;  // the right-camera pass (:1421-1426) exists for the fisheye two-camera rig only (NLeft != -1)
+    return msorb_host::Fuse(device_keyframe(pKF), pKF, vpMapPoints, th);
+}
+
+int ORBmatcher::Fuse(std::shared_ptr<KeyFrame> pKF, Sophus::Sim3f& Scw, const std::vector<std::shared_ptr<MapPoint>>& vpPoints, float th,
+                     std::vector<std::shared_ptr<MapPoint>>& vpReplacePoint) {
+    return msorb_host::Fuse(device_keyframe(pKF), pKF, Scw, vpPoints, th, vpReplacePoint);
+}
+
+float ORBmatcher::RadiusByViewingCos(const float& viewCos) {  // ORBmatcher.cc:215-221 (applied inside msorb_search_by_projection_mps)
+    if (viewCos > 0.998) return 2.5;
+    else return 4.0;
+}
+
+void ORBmatcher::ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {  // :2277-2318
+    std::vector<int> sizes(L);
+    for (int i = 0; i < L; i++) sizes[i] = (int)histo[i].size();
+    int ind[3] = {-1, -1, -1};
+    msorb_three_maxima(sizes.data(), L, ind);
+    ind1 = ind[0]; ind2 = ind[1]; ind3 = ind[2];
+}
+
+// Bit set count operation from http://graphics.stanford.edu/~seander/bithacks.html#CountBitsSetParallel in the reference
+// (:2323-2339); a population count of the XOR, 8 x 32 bits.  Host code: MapPoint::ComputeDistinctiveDescriptors and
+// Frame::ComputeStereoMatches call it per pair (MapPoint.cc:403, Frame.cc:818).
+int ORBmatcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b) {
+    const int32_t* pa = a.ptr<int32_t>(0);
+    const int32_t* pb = b.ptr<int32_t>(0);
+    int dist = 0;
+    for (int i = 0; i < 8; i++, pa++, pb++) dist += __builtin_popcount((unsigned)(*pa ^ *pb));
+    return dist;
+}
+
+}  // namespace ORB_SLAM3

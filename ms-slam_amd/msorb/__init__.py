@@ -463,7 +463,23 @@ def search_for_initialization(f1, f2, prev_xy, window_size=100, nnratio=0.9, che
     return m12[:n1], nm.value
 
 
-EXPORTS = EXPORTS + ("msorb_search_by_sim3", "msorb_fuse_sim3_search", "msorb_search_for_initialization")
+def search_by_projection_loop(kf, pts, train_ok, th, max_dist):
+    """msorb_search_by_projection_loop (SearchByProjectionLoop, ORBmatcher.cc:532-637).  -> (best_idx[n], nmatches)"""
+    L = _mlib()
+    a = _sim3_side(pts)
+    n = len(a[0])
+    ok = _c(train_ok, np.uint8)
+    bi = np.full(max(n, 1), -1, np.int32)
+    nm = C.c_int()
+    vp = C.c_void_p
+    L.msorb_search_by_projection_loop.argtypes = [vp, C.c_int] + [vp] * 6 + [C.c_float, C.c_float, vp, vp]
+    _check(L.msorb_search_by_projection_loop(kf.h, n, *[_np_ptr(x) for x in a], _np_ptr(ok), th, max_dist, _np_ptr(bi),
+                                             C.byref(nm)), "msorb_search_by_projection_loop")
+    return bi[:n], nm.value
+
+
+EXPORTS = EXPORTS + ("msorb_search_by_sim3", "msorb_fuse_sim3_search", "msorb_search_for_initialization",
+                     "msorb_search_by_projection_loop")
 
 
 def hamming_top2(query_desc, train_desc, cand_begin, cand_idx, device=0):

@@ -346,7 +346,8 @@ int orc_search_by_projection_kf(void* fp, int n, const uint8_t* valid, const flo
 }
 
 // ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th, ratioHamming), ORBmatcher.cc:482-527 (the same
-// search in SearchByProjectionLoop :591-634 and the vpPointsKFs form :700-749), from the projected coordinates on.
+// search in the vpPointsKFs form :700-749; SearchByProjectionLoop differs, see orc_search_by_projection_loop), from the
+// projected coordinates on.
 int orc_search_by_projection_sim3(void* fp, int n, const uint8_t* valid, const float* u, const float* v,
                                   const int* predicted_level, const uint8_t* mp_desc, const int* mp_id, int* matched, float th,
                                   float max_dist) {
@@ -372,6 +373,38 @@ int orc_search_by_projection_sim3(void* fp, int n, const uint8_t* valid, const f
             matched[bestIdx] = mp_id[i];
             nmatches++;
         }
+    }
+    return nmatches;
+}
+
+// ORBmatcher::SearchByProjectionLoop(pKF, Scw, vpPoints, vpMatched, vpMatchedKF, th, ratioHamming), ORBmatcher.cc:532-637, from
+// the projected coordinates on.  Unlike the other Sim3 forms: a candidate keypoint must HOLD a good map point
+// (train_ok[idx] = vpMapPointsToMatch[idx] && !isBad(), :609-610), the level band is predicted-1 .. predicted+1 (:613), and
+// the result is stored per POINT (vpMatched[iMP] = vpMapPointsToMatch[bestIdx], :626-631): no keypoint is claimed, queries
+// are independent.  valid[i] includes "!vpMatched[iMP]" (:555).  best_idx[i] = accepted keypoint or -1; returns nmatches.
+int orc_search_by_projection_loop(void* fp, int n, const uint8_t* valid, const float* u, const float* v,
+                                  const int* predicted_level, const uint8_t* mp_desc, const uint8_t* train_ok, float th,
+                                  float max_dist, int* best_idx) {
+    const FrameSoA& K = *(const FrameSoA*)fp;
+    int nmatches = 0;
+    for (int i = 0; i < n; i++) {
+        best_idx[i] = -1;
+        if (!valid[i]) continue;
+        const int nPredictedLevel = predicted_level[i];
+        const float radius = th * K.scaleFactors[nPredictedLevel];
+        const std::vector<size_t> vIndices = K.features_in_area(u[i], v[i], radius, -1, -1);
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = mp_desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx = -1;
+        for (size_t k = 0; k < vIndices.size(); k++) {
+            const size_t idx = vIndices[k];
+            if (!train_ok[idx]) continue;
+            const int kpLevel = K.kps[idx].octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel + 1) continue;
+            const int dist = orc::descriptor_distance(dMP, &K.desc[idx * 32]);
+            if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+        }
+        if ((float)bestDist <= max_dist) { best_idx[i] = bestIdx; nmatches++; }
     }
     return nmatches;
 }

@@ -268,6 +268,18 @@ def search_by_sim3(kf1, kf2, p1, p2, th):
     return m12[:len(a[0])], n
 
 
+def search_by_projection_loop(kf, pts, train_ok, th, max_dist):
+    """orc_search_by_projection_loop (ORBmatcher.cc:532-637).  -> (best_idx[n], nmatches)"""
+    L = _mlib()
+    a = _sim3_side(pts)
+    n = len(a[0])
+    ok = _c(train_ok, np.uint8)
+    bi = np.full(max(n, 1), -1, np.int32)
+    L.orc_search_by_projection_loop.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_float, C.c_void_p]
+    nm = L.orc_search_by_projection_loop(kf.h, n, *[_ptr(x) for x in a], _ptr(ok), th, max_dist, _ptr(bi))
+    return bi[:n], nm
+
+
 def fuse_sim3_search(kf, pts, th):
     """orc_fuse_sim3_search (ORBmatcher.cc:1661-1696).  -> (best_idx, best_dist), INT_MAX = none"""
     L = _mlib()

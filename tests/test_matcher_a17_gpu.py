@@ -136,6 +136,32 @@ def test_search_for_initialization_matches_oracle(msorb_mod, oracle, two_keyfram
         f1.close(); f2.close()
 
 
+@pytest.mark.parametrize("seed,th,ratio", [(1, 8.0, 1.5), (2, 3.0, 1.0), (3, 12.0, 1.5)])
+def test_search_by_projection_loop_matches_oracle(msorb_mod, oracle, two_keyframes, seed, th, ratio):
+    """SearchByProjectionLoop (ORBmatcher.cc:532-637): candidates must hold a good map point, band predicted-1 .. predicted+1,
+    per-point results — a different rule set from the claiming Sim3 forms."""
+    s = two_keyframes
+    rng = np.random.Generator(np.random.PCG64(700 + seed))
+    f, r = _kf(msorb_mod, oracle, s, 2)
+    n = 4000
+    src = rng.integers(0, len(s["k1"]), n)
+    pts = _points_from(rng, s["k1"][src], s["d1"][src], (5, 2), 1.5, 35)
+    train_ok = (rng.random(len(s["k2"])) < 0.6).astype(np.uint8)
+    max_dist = float(np.float32(50) * np.float32(ratio))
+    try:
+        bi, nm = msorb_mod.search_by_projection_loop(f, pts, train_ok, th, max_dist)
+        wi, wn = oracle.search_by_projection_loop(r, pts, train_ok, th, max_dist)
+        assert nm == wn and np.array_equal(bi, wi) and nm > 300
+        assert np.all(train_ok[bi[bi >= 0]] == 1)
+        # the +1 level and the map-point filter both matter
+        ci, _ = msorb_mod.fuse_sim3_search(f, pts, th)                # band predicted-1 .. predicted, every keypoint
+        assert not np.array_equal(ci, bi)
+        li, ln = msorb_mod.search_by_projection_loop(f, pts, np.ones(len(s["k2"]), np.uint8), th, max_dist)
+        assert ln > nm
+    finally:
+        f.close()
+
+
 def test_a17_entries_reject_bad_arguments(msorb_mod, two_keyframes):
     s = two_keyframes
     f1, _ = msorb_mod.Frame(s["k1"], s["d1"], None, (0.0, 1241.0, 0.0, 376.0), s["scale"]), None
