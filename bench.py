@@ -96,6 +96,29 @@ def cpu_baseline(cfg, sample_pairs, seed0):
     dt2 = time.perf_counter() - t0
     out["all_cores"] = dict(value=round(sum(tot) / dt2 / 1e6, 4), unit="Mkeypoints/s", cores=nthr,
                             sample=f"{2 * nthr} images over {nthr} threads, {dt2:.1f} s")
+    # BASELINE.json configs[0]: "EuRoC MH_01 stereo, CPU ORBextractor at 1000 features/frame (reference path, no GPU)" — the
+    # same port on EuRoC-like 752x480 pairs, 2 threads (one per eye)
+    ec = synth.EUROC
+    exs3 = [orb_oracle.OracleExtractor(ec["nfeatures"], ec["scale"], ec["nlevels"], ec["ini_th"], ec["min_th"]) for _ in range(2)]
+    ne = max(2, min(12, sample_pairs // 8))
+    epairs = [synth.stereo_pair(seed0 + 500 + i, ec["rows"], ec["cols"]) for i in range(min(ne, 4))]
+    ecount = [0, 0]
+
+    def eeye(e):
+        for i in range(ne):
+            _, kps, _ = exs3[e](epairs[i % len(epairs)][e])
+            ecount[e] += len(kps)
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=eeye, args=(e,)) for e in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt3 = time.perf_counter() - t0
+    out["configs0_euroc_1000"] = dict(value=round(sum(ecount) / dt3 / 1e6, 5), unit="Mkeypoints/s", cores=2, kind="port",
+                                      ms_per_stereo_frame=round(dt3 / ne * 1e3, 2),
+                                      sample=f"{ne} EuRoC-like 752x480 stereo pairs at 1000 features, 2 threads, {dt3:.1f} s")
     return out
 
 
@@ -294,8 +317,17 @@ def main():
         reps = 20
         _, _, _, ms = msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=reps, device=local)
         pairs = int((counts_h[0::2].astype(np.int64) * counts_h[1::2].astype(np.int64)).sum())
-        hamming = {"gpairs_per_s": round(pairs * reps / (ms * 1e-3) / 1e9, 2), "pairs_per_launch": pairs,
-                   "ms_per_launch": round(ms / reps, 4), "kernel": "dense_top2_kernel",
+        # integer-ALU ceiling of the pair loop: per pair 8 x v_xor_b32 + 8 x v_bcnt_u32_b32 (accumulating); the
+        # VALU micro-benchmark (profiles/round1_valu_ubench.txt) gives 2.5 and 4.2 cycles per wave-instruction, 64 pairs per
+        # wave-instruction, 1024 SIMDs at 2.4 GHz.  The top-2 bookkeeping (key build + v_med3 + v_min, 3 more slow-class
+        # instructions per pair) lowers what this kernel can reach to the second figure.
+        g = pairs * reps / (ms * 1e-3) / 1e9
+        ceil_dist = 1024 * 2.4e9 * 64 / (8 * 2.5 + 8 * 4.2) / 1e9
+        ceil_top2 = 1024 * 2.4e9 * 64 / (8 * 2.5 + 11 * 4.2) / 1e9
+        hamming = {"gpairs_per_s": round(g, 2), "pairs_per_launch": pairs,
+                   "ms_per_launch": round(ms / reps, 4), "kernel": "dense_top2_kernel<2, 4>",
+                   "ceiling_gpairs_per_s": round(ceil_dist, 1), "frac": round(g / ceil_dist, 3),
+                   "ceiling_with_top2_bookkeeping_gpairs_per_s": round(ceil_top2, 1), "frac_with_top2": round(g / ceil_top2, 3),
                    "bound": "integer VALU (xor + popcount), not HBM: (Q+T)*32 B per frame are reused Q*T times"}
         if args.cpu_pairs > 0 and rank == 0:
             # CPU leg of the matcher on a bounded sample: ORBmatcher::DescriptorDistance brute force (oracle, 1 thread) on

@@ -379,6 +379,55 @@ typedef struct msorb_triangulation_pair {
 int msorb_search_for_triangulation(int device, msorb_triangulation_pair* pairs, int n_pairs, int coarse,
                                    int check_orientation, float* elapsed_ms);
 
+/* Resident KeyFrames for the BoW-node searches.  A KeyFrame's descriptors, keypoints and FeatureVector are fixed from
+ * KeyFrame::ComputeBoW on (until map sparsification compacts them: remove + add), while it is matched many times — by
+ * LocalMapping::CreateNewMapPoints against every neighbour (LocalMapping.cc:430-492), as a relocalisation / loop candidate
+ * (Tracking.cc:3577-3600, LoopClosing.cc).  msorb_search_by_bow / msorb_search_for_triangulation stage both sides of every
+ * pair on every call; a store keeps them on the device, and a search moves only one flag byte per feature, the (pair,
+ * common node) work items and, for the KeyFrame-vs-Frame form, the frame.  Same kernels, same results.  Thread-safe:
+ * searches may run concurrently with each other; add / remove wait for running searches. */
+typedef struct msorb_kf_store msorb_kf_store;
+int msorb_kf_store_create(int device, msorb_kf_store** out);
+void msorb_kf_store_destroy(msorb_kf_store* s);
+int msorb_kf_store_count(const msorb_kf_store* s);
+/* kps = GetAllKeyUn() (pt, angle, octave are used), desc = GetDescriptor(i) rows, fv_* = GetFeatureVector() as CSR (node ids
+ * ascending), scale_factors / level_sigma2 = mvScaleFactors / mvLevelSigma2.  *kf_id identifies the KeyFrame in later calls. */
+int msorb_kf_store_add(msorb_kf_store* s, int n, const msorb_keypoint* kps, const uint8_t* desc, int fv_nodes, const int* fv_node,
+                       const int* fv_begin, const int* fv_feat, const float* scale_factors, const float* level_sigma2, int n_levels,
+                       int* kf_id);
+int msorb_kf_store_remove(msorb_kf_store* s, int kf_id);
+
+/* msorb_search_by_bow with resident KeyFrames: kf1 = the query KeyFrame, kf2 = the train KeyFrame (KeyFrame-KeyFrame forms,
+ * ORBmatcher.cc:872-1166) or -1 = the frame passed to the call (SearchByBoW(pKF, F, ...), :223-421; then every pair of the
+ * call has kf2 == -1).  valid1 / avail2 / match12 / match21 / nmatches as in msorb_bow_pair. */
+typedef struct msorb_bow_kf_pair {
+    int kf1, kf2;
+    const uint8_t *valid1, *avail2;
+    int *match12, *match21;
+    int nmatches;
+} msorb_bow_kf_pair;
+typedef struct msorb_bow_frame {  /* F.mDescriptors, F.mFeatVec as CSR, F.mvKeysUn[i].angle */
+    int n;
+    const uint8_t* desc;
+    int fv_nodes;
+    const int *fv_node, *fv_begin, *fv_feat;
+    const float* angle;
+} msorb_bow_frame;
+int msorb_search_by_bow_kf(msorb_kf_store* s, msorb_bow_kf_pair* pairs, int n_pairs, const msorb_bow_frame* frame, int th_low,
+                           int inclusive, float nnratio, int check_orientation, float* elapsed_ms);
+
+/* msorb_search_for_triangulation with resident KeyFrames (fields as in msorb_triangulation_pair). */
+typedef struct msorb_triangulation_kf_pair {
+    int kf1, kf2;
+    const uint8_t *valid1, *avail2, *stereo1, *stereo2;
+    float F12[9];
+    float ep[2];
+    int* match12;
+    int nmatches;
+} msorb_triangulation_kf_pair;
+int msorb_search_for_triangulation_kf(msorb_kf_store* s, msorb_triangulation_kf_pair* pairs, int n_pairs, int coarse,
+                                      int check_orientation, float* elapsed_ms);
+
 /* Frame::ComputeStereoMatches (Frame.cc:743-913, median rejection :899-912 included) for every stereo pair of the last
  * msorb_extract_batch() call of `h`, all on the device: pair p = images 2p (left) and 2p+1 (right) of that batch.
  * d_keypoints / d_descriptors / capacity are the arrays that call filled, d_counts[2*n_pairs] the keypoint counts as a

@@ -13,8 +13,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -30,10 +35,13 @@ using msorb::kHistoLength;
 namespace {
 
 struct BowItem {  // one (pair, common node)
-    int base1, base2;  // first row of the pair's set 1 / set 2 in the concatenated arrays
+    int base1, base2;  // first row of the pair's set 1 / set 2 in the descriptor (and static per-feature) arrays
     int b1, n1l;       // the node's query list inside feat1
     int b2, n2l;       // the node's train list inside feat2
     int pair;
+    int m1, m2;        // first entry of the pair's set 1 / set 2 in the PER-CALL arrays (visit / availability flags, match12):
+                       // equal to base1 / base2 when everything is staged per call, different when the descriptors live in a
+                       // resident KeyFrame store
 };
 
 __device__ __forceinline__ int hamming256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
@@ -59,8 +67,8 @@ __global__ __launch_bounds__(64) void bow_match_kernel(const BowItem* __restrict
         const int p = c * 64 + lane;
         bool fr = false;
         if (p < it.n2l) {
-            const int idx2 = it.base2 + feat2[it.b2 + p];
-            fr = avail2[idx2] != 0;
+            const int f2 = feat2[it.b2 + p], idx2 = it.base2 + f2;
+            fr = avail2[it.m2 + f2] != 0;
             if (c == 0) { t0 = desc2[(size_t)idx2 * 2]; t1 = desc2[(size_t)idx2 * 2 + 1]; }
         }
         const unsigned long long m = __ballot(fr);
@@ -68,8 +76,8 @@ __global__ __launch_bounds__(64) void bow_match_kernel(const BowItem* __restrict
     }
     __syncthreads();
     for (int k1 = 0; k1 < it.n1l; k1++) {
-        const int idx1 = it.base1 + feat1[it.b1 + k1];
-        if (!valid1[idx1]) continue;  // wave uniform
+        const int f1 = feat1[it.b1 + k1], idx1 = it.base1 + f1;
+        if (!valid1[it.m1 + f1]) continue;  // wave uniform
         const uint4 q0 = desc1[(size_t)idx1 * 2], q1 = desc1[(size_t)idx1 * 2 + 1];
         int key = kNoKey, second = 256;
         for (int c = 0; c < chunks; c++) {
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(64) void bow_match_kernel(const BowItem* __restrict
         if (pass) {
             const int p = key & 0xFFFFF;
             if (lane == 0) {
-                match12[idx1] = feat2[it.b2 + p];
+                match12[it.m1 + f1] = feat2[it.b2 + p];
                 free_bits[p >> 5] &= ~(1u << (p & 31));
             }
             __syncthreads();
@@ -137,8 +145,8 @@ __global__ __launch_bounds__(64) void triangulation_match_kernel(
         const int p = c * 64 + lane;
         bool fr = false;
         if (p < it.n2l) {
-            const int idx2 = it.base2 + feat2[it.b2 + p];
-            const uint8_t fl = flags2[idx2];
+            const int f2 = feat2[it.b2 + p], idx2 = it.base2 + f2;
+            const uint8_t fl = flags2[it.m2 + f2];
             fr = (fl & 1) != 0;
             if (c == 0) { t0 = desc2[(size_t)idx2 * 2]; t1 = desc2[(size_t)idx2 * 2 + 1]; r0 = tr2[idx2]; s0 = (fl & 2) != 0; }
         }
@@ -147,8 +155,8 @@ __global__ __launch_bounds__(64) void triangulation_match_kernel(
     }
     __syncthreads();
     for (int k1 = 0; k1 < it.n1l; k1++) {
-        const int idx1 = it.base1 + feat1[it.b1 + k1];
-        const uint8_t fl1 = flags1[idx1];
+        const int f1 = feat1[it.b1 + k1], idx1 = it.base1 + f1;
+        const uint8_t fl1 = flags1[it.m1 + f1];
         if (!(fl1 & 1)) continue;  // wave uniform
         const bool stereo1 = (fl1 & 2) != 0;
         const uint4 q0 = desc1[(size_t)idx1 * 2], q1 = desc1[(size_t)idx1 * 2 + 1];
@@ -167,10 +175,10 @@ __global__ __launch_bounds__(64) void triangulation_match_kernel(
                 bool stereo2;
                 if (c == 0) { dist = hamming256(q0, q1, t0, t1); r = r0; stereo2 = s0; }
                 else {
-                    const int idx2 = it.base2 + feat2[it.b2 + p];
+                    const int f2 = feat2[it.b2 + p], idx2 = it.base2 + f2;
                     dist = hamming256(q0, q1, desc2[(size_t)idx2 * 2], desc2[(size_t)idx2 * 2 + 1]);
                     r = tr2[idx2];
-                    stereo2 = (flags2[idx2] & 2) != 0;
+                    stereo2 = (flags2[it.m2 + f2] & 2) != 0;
                 }
                 bool ok = dist <= msorb::kThLow;  // :1277
                 if (ok && !stereo1 && !stereo2) {  // :1283-1291
@@ -193,12 +201,80 @@ __global__ __launch_bounds__(64) void triangulation_match_kernel(
         if (key != kNoKey) {
             const int p = 0xFFFFF - (key & 0xFFFFF);
             if (lane == 0) {
-                match12[idx1] = feat2[it.b2 + p];
+                match12[it.m1 + f1] = feat2[it.b2 + p];
                 free_bits[p >> 5] &= ~(1u << (p & 31));
             }
             __syncthreads();
         }
     }
+}
+
+// The rotation-consistency filter of a pair on the device (resident-KeyFrame entries): histogram of round((angle1 - angle2) / 12
+// degrees) over the pair's raw matches, ComputeThreeMaxima (ORBmatcher.cc:2277-2318) on the 30 counts, matches outside the
+// three fullest bins withdrawn (:396-418, :1360-1381), match21 and the count written.  The survivors do not depend on the
+// order the reference visits the matches in — only the counts enter — so no replay on the host is needed (the host loop
+// over 2000 features costs 24 us per pair: seven times the device part of a 32-pair batch).  One workgroup per pair.
+struct PairPost {
+    int m1, n1, m2, n2;   // the pair's slices of the per-call match12 / match21 arrays
+    int a1, a2;           // first entry of the pair's set 1 / set 2 in angle1 / angle2
+};
+__global__ __launch_bounds__(256) void pair_histogram_kernel(const PairPost* __restrict__ posts, const float* __restrict__ angle1,
+                                                            const float* __restrict__ angle2, int check_orientation,
+                                                            int* __restrict__ match12, int* __restrict__ match21,
+                                                            int* __restrict__ nmatches) {
+    __shared__ int hist[kHistoLength];
+    __shared__ int ind[3];
+    __shared__ int total;
+    const PairPost P = posts[blockIdx.x];
+    const int t = threadIdx.x;
+    if (t < kHistoLength) hist[t] = 0;
+    if (t == 0) total = 0;
+    __syncthreads();
+    auto bin_of = [&](int i, int idx2) {
+        float rot = __fsub_rn(angle1[P.a1 + i], angle2[P.a2 + idx2]);
+        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+        int bin = (int)roundf(__fmul_rn(rot, 1.0f / kHistoLength));
+        if (bin == kHistoLength) bin = 0;
+        return (bin >= 0 && bin < kHistoLength) ? bin : -1;   // NaN / out-of-range angle: the reference asserts
+    };
+    if (check_orientation) {
+        for (int i = t; i < P.n1; i += 256) {
+            const int idx2 = match12[P.m1 + i];
+            if (idx2 < 0) continue;
+            const int b = bin_of(i, idx2);
+            if (b >= 0) atomicAdd(&hist[b], 1);
+        }
+        __syncthreads();
+        if (t == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < kHistoLength; i++) {
+                const int s = hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+                else if (s > max3) { max3 = s; i3 = i; }
+            }
+            if (max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+            else if (max3 < 0.1f * (float)max1) { i3 = -1; }
+            ind[0] = i1; ind[1] = i2; ind[2] = i3;
+        }
+        __syncthreads();
+    }
+    int kept = 0;
+    for (int i = t; i < P.n1; i += 256) {
+        const int idx2 = match12[P.m1 + i];
+        if (idx2 < 0) continue;
+        bool keep = true;
+        if (check_orientation) {
+            const int b = bin_of(i, idx2);
+            keep = b >= 0 && (b == ind[0] || b == ind[1] || b == ind[2]);
+        }
+        if (!keep) { match12[P.m1 + i] = -1; continue; }
+        kept++;
+        if (match21 && idx2 < P.n2) match21[P.m2 + idx2] = i;
+    }
+    atomicAdd(&total, kept);
+    __syncthreads();
+    if (t == 0) nmatches[blockIdx.x] = total;
 }
 
 struct Scratch {
@@ -289,7 +365,7 @@ void stage_lists(const FeatVec& a, const FeatVec& b, const std::vector<Common>& 
         const int l1 = a.begin[c.r1 + 1] - a.begin[c.r1], l2 = b.begin[c.r2 + 1] - b.begin[c.r2];
         std::memcpy(f1 + k1, a.feat + a.begin[c.r1], (size_t)l1 * 4);
         std::memcpy(f2 + k2, b.feat + b.begin[c.r2], (size_t)l2 * 4);
-        items[ni++] = BowItem{(int)r1, (int)r2, (int)k1, l1, (int)k2, l2, pi};
+        items[ni++] = BowItem{(int)r1, (int)r2, (int)k1, l1, (int)k2, l2, pi, (int)r1, (int)r2};
         k1 += (size_t)l1;
         k2 += (size_t)l2;
     }
@@ -300,9 +376,15 @@ void stage_lists(const FeatVec& a, const FeatVec& b, const std::vector<Common>& 
 template <class Angles>
 int replay_histogram(const FeatVec& a, const std::vector<Common>& common, const int* m, int check_orientation, Angles angle,
                      int* match12) {
-    std::vector<int> rotHist[kHistoLength];
+    // rotHist[bin] only decides which matches survive (the three fullest bins, ComputeThreeMaxima): a bin index per match
+    // and 30 counters replace the reference's 30 vectors — this runs once per pair on the calling thread, and with the
+    // vectors it cost 23 us per pair, seven times the whole device part of a 32-pair batch
+    static thread_local std::vector<int8_t> bin_of;
+    int sizes[kHistoLength] = {0};
     const float factor = 1.0f / kHistoLength;
-    int nm = 0;
+    int nm = 0, n_feat = 0;
+    for (const Common& c : common) n_feat = std::max(n_feat, a.begin[c.r1 + 1]);
+    if (check_orientation && (int)bin_of.size() < n_feat) bin_of.resize(n_feat);
     for (const Common& c : common)
         for (int k = a.begin[c.r1]; k < a.begin[c.r1 + 1]; k++) {
             const int idx1 = a.feat[k], idx2 = m[idx1];
@@ -316,17 +398,20 @@ int replay_histogram(const FeatVec& a, const std::vector<Common>& common, const 
                 if (rot < 0.0) rot += 360.0f;
                 int bin = (int)std::round(rot * factor);
                 if (bin == kHistoLength) bin = 0;
-                if (bin >= 0 && bin < kHistoLength) rotHist[bin].push_back(idx1);
+                if (bin >= 0 && bin < kHistoLength) { bin_of[k] = (int8_t)bin; sizes[bin]++; }
                 else { match12[idx1] = -1; nm--; }  // NaN / out-of-range angle: the reference asserts
             }
         }
     if (check_orientation) {
-        int sizes[kHistoLength], ind[3];
-        for (int i = 0; i < kHistoLength; i++) sizes[i] = (int)rotHist[i].size();
+        int ind[3];
         msorb_three_maxima(sizes, kHistoLength, ind);
-        for (int i = 0; i < kHistoLength; i++)
-            if (i != ind[0] && i != ind[1] && i != ind[2])
-                for (int idx1 : rotHist[i]) { match12[idx1] = -1; nm--; }
+        for (const Common& c : common)
+            for (int k = a.begin[c.r1]; k < a.begin[c.r1 + 1]; k++) {
+                const int idx1 = a.feat[k];
+                if (match12[idx1] < 0) continue;
+                const int bin = bin_of[k];
+                if (bin != ind[0] && bin != ind[1] && bin != ind[2]) { match12[idx1] = -1; nm--; }
+            }
     }
     return nm;
 }
@@ -423,7 +508,12 @@ extern "C" int msorb_search_by_bow(int device, msorb_bow_pair* pairs, int n_pair
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess && elapsed_ms) e = hipEventElapsedTime(elapsed_ms, scr.e0, scr.e1);
     if (e != hipSuccess) return hip_fail(scr, "search_by_bow", e);
-    const int* m_all = (const int*)(scr.h + o_m);
+    // the raw matches are read feature by feature below: out of the pinned block first (one streaming copy) — scattered 4-byte
+    // reads of pinned host memory cost ~10 ns each, 0.8 ms for a 32-pair batch
+    static thread_local std::vector<int> m_local;
+    m_local.resize(tot1);
+    std::memcpy(m_local.data(), scr.h + o_m, tot1 * 4);
+    const int* m_all = m_local.data();
     size_t r1 = 0;
     for (int pi = 0; pi < n_pairs; pi++) {
         msorb_bow_pair& P = pairs[pi];
@@ -534,7 +624,12 @@ extern "C" int msorb_search_for_triangulation(int device, msorb_triangulation_pa
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess && elapsed_ms) e = hipEventElapsedTime(elapsed_ms, scr.e0, scr.e1);
     if (e != hipSuccess) return hip_fail(scr, "search_for_triangulation", e);
-    const int* m_all = (const int*)(scr.h + o_m);
+    // the raw matches are read feature by feature below: out of the pinned block first (one streaming copy) — scattered 4-byte
+    // reads of pinned host memory cost ~10 ns each, 0.8 ms for a 32-pair batch
+    static thread_local std::vector<int> m_local;
+    m_local.resize(tot1);
+    std::memcpy(m_local.data(), scr.h + o_m, tot1 * 4);
+    const int* m_all = m_local.data();
     size_t r1 = 0;
     for (int pi = 0; pi < n_pairs; pi++) {
         msorb_triangulation_pair& P = pairs[pi];
@@ -542,6 +637,376 @@ extern "C" int msorb_search_for_triangulation(int device, msorb_triangulation_pa
             fa[pi], common[pi], m_all + r1, check_orientation,
             [&](int i1, int i2, float& a1, float& a2) { a1 = P.kp1[i1].angle; a2 = P.kp2[i2].angle; }, P.match12);
         r1 += (size_t)P.n1;
+    }
+    return MSORB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Resident KeyFrames (DESIGN.md "what comes next" of round 1: the per-call entries above spend their time staging the
+// same KeyFrames again and again — 30-40 us of kernel inside ~1 ms of copies).  A KeyFrame is matched against many
+// others over its life (LocalMapping::CreateNewMapPoints against 10-20 neighbours per new KeyFrame, relocalisation and
+// loop candidates against the current frame), while its descriptors, keypoints and FeatureVector are fixed once
+// KeyFrame::ComputeBoW has run (until map sparsification compacts it: remove + add).  The store keeps them on the
+// device; a search then uploads only the visit / availability flags (1 B per feature), the (pair, common node) work
+// items and, for the KeyFrame-vs-Frame form, the frame; it downloads match12.
+// ------------------------------------------------------------------------------------------------------------------
+struct msorb_kf_store {
+    int device = 0;
+    mutable std::shared_mutex mu;  // searches hold it shared (the buffers must not move under a running kernel), add / remove exclusive
+    struct Entry {
+        bool alive = false;
+        int row0 = 0, n = 0, feat0 = 0;
+        std::vector<int> node, begin;   // FeatureVector: node ids ascending, list r = feat[begin[r] .. begin[r+1]) (offsets relative to feat0)
+        std::vector<int> feat;          // host copy of the lists (the rotation-histogram replay walks them)
+        std::vector<float> angle;
+    };
+    std::vector<Entry> kf;
+    int n_alive = 0;
+    size_t rows = 0, rows_cap = 0, feats = 0, feats_cap = 0;
+    uint4* d_desc = nullptr;    // 2 per row
+    float2* d_xy = nullptr;     // keypoint position (SearchForTriangulation, set 1)
+    float4* d_tr = nullptr;     // x, y, 100 * scale[octave], sigma2[octave] (SearchForTriangulation, set 2)
+    float* d_angle = nullptr;   // keypoint angles (rotation histogram)
+    int* d_feat = nullptr;
+};
+
+namespace {
+template <class T>
+hipError_t grow(T*& p, size_t used, size_t& cap, size_t need, size_t unit) {
+    if (need <= cap) return hipSuccess;
+    const size_t ncap = std::max(need, cap * 2 + 4096);
+    T* q = nullptr;
+    hipError_t e = hipMalloc((void**)&q, ncap * unit * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (p && used) e = hipMemcpy(q, p, used * unit * sizeof(T), hipMemcpyDeviceToDevice);
+    if (p) (void)hipFree(p);
+    p = q;
+    cap = ncap;
+    return e;
+}
+}  // namespace
+
+extern "C" int msorb_kf_store_create(int device, msorb_kf_store** out) {
+    if (!out) return MSORB_E_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return no_device();
+    msorb_kf_store* s = new msorb_kf_store();
+    s->device = device;
+    *out = s;
+    return MSORB_OK;
+}
+
+extern "C" void msorb_kf_store_destroy(msorb_kf_store* s) {
+    if (!s) return;
+    if (hipSetDevice(s->device) == hipSuccess) {
+        if (s->d_desc) (void)hipFree(s->d_desc);
+        if (s->d_xy) (void)hipFree(s->d_xy);
+        if (s->d_tr) (void)hipFree(s->d_tr);
+        if (s->d_feat) (void)hipFree(s->d_feat);
+        if (s->d_angle) (void)hipFree(s->d_angle);
+    }
+    delete s;
+}
+
+extern "C" int msorb_kf_store_count(const msorb_kf_store* s) {
+    if (!s) return MSORB_E_INVALID;
+    std::shared_lock<std::shared_mutex> lk(s->mu);
+    return s->n_alive;
+}
+
+extern "C" int msorb_kf_store_add(msorb_kf_store* s, int n, const msorb_keypoint* kps, const uint8_t* desc, int fv_nodes,
+                                  const int* fv_node, const int* fv_begin, const int* fv_feat, const float* scale_factors,
+                                  const float* level_sigma2, int n_levels, int* kf_id) {
+    if (!s || !kf_id || n < 0 || (n > 0 && (!kps || !desc)) || !scale_factors || !level_sigma2 || n_levels < 1) return MSORB_E_INVALID;
+    *kf_id = -1;
+    FeatVec fv{fv_nodes, fv_node, fv_begin, fv_feat};
+    std::vector<uint8_t> seen;
+    if (!check_feature_vector(n, fv, seen)) { set_last_error("kf_store_add: feature vector not ascending, out of range or with a repeated feature"); return MSORB_E_INVALID; }
+    for (int i = 0; i < n; i++)
+        if (kps[i].octave < 0 || kps[i].octave >= n_levels) { set_last_error("kf_store_add: keypoint octave out of range"); return MSORB_E_INVALID; }
+    const int f_lo = fv_nodes ? fv_begin[0] : 0, f_hi = fv_nodes ? fv_begin[fv_nodes] : 0, nf = f_hi - f_lo;
+    std::vector<float> xy((size_t)2 * n), tr((size_t)4 * n);
+    for (int i = 0; i < n; i++) {
+        xy[2 * i] = kps[i].x; xy[2 * i + 1] = kps[i].y;
+        tr[4 * i] = kps[i].x; tr[4 * i + 1] = kps[i].y;
+        tr[4 * i + 2] = 100 * scale_factors[kps[i].octave];   // ORBmatcher.cc:1287
+        tr[4 * i + 3] = level_sigma2[kps[i].octave];          // :1332
+    }
+    std::unique_lock<std::shared_mutex> lk(s->mu);
+    if (hipSetDevice(s->device) != hipSuccess) return MSORB_E_HIP;
+    hipError_t e = hipSuccess;
+    size_t cap2 = s->rows_cap, cap3 = s->rows_cap, cap1 = s->rows_cap, cap4 = s->rows_cap;
+    e = grow(s->d_desc, s->rows, cap1, s->rows + n, 2);
+    if (e == hipSuccess) e = grow(s->d_xy, s->rows, cap2, s->rows + n, 1);
+    if (e == hipSuccess) e = grow(s->d_tr, s->rows, cap3, s->rows + n, 1);
+    if (e == hipSuccess) e = grow(s->d_angle, s->rows, cap4, s->rows + n, 1);
+    if (e == hipSuccess) s->rows_cap = std::min(std::min(cap1, cap4), std::min(cap2, cap3));
+    if (e == hipSuccess) e = grow(s->d_feat, s->feats, s->feats_cap, s->feats + nf, 1);
+    if (e == hipSuccess && n) e = hipMemcpy(s->d_desc + 2 * s->rows, desc, (size_t)n * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n) e = hipMemcpy(s->d_xy + s->rows, xy.data(), (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n) e = hipMemcpy(s->d_tr + s->rows, tr.data(), (size_t)n * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nf) e = hipMemcpy(s->d_feat + s->feats, fv_feat + f_lo, (size_t)nf * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n) {
+        std::vector<float> ang(n);
+        for (int i = 0; i < n; i++) ang[i] = kps[i].angle;
+        e = hipMemcpy(s->d_angle + s->rows, ang.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) { set_last_error(std::string("kf_store_add: ") + hipGetErrorString(e)); return MSORB_E_HIP; }
+    msorb_kf_store::Entry E;
+    E.alive = true; E.row0 = (int)s->rows; E.n = n; E.feat0 = (int)s->feats;
+    E.node.assign(fv_node, fv_node + fv_nodes);
+    E.begin.resize(fv_nodes + 1);
+    for (int r = 0; r <= fv_nodes; r++) E.begin[r] = (fv_nodes ? fv_begin[r] : 0) - f_lo;
+    E.feat.assign(fv_feat + f_lo, fv_feat + f_hi);
+    E.angle.resize(n);
+    for (int i = 0; i < n; i++) E.angle[i] = kps[i].angle;
+    s->rows += n; s->feats += nf;
+    s->kf.push_back(std::move(E));
+    s->n_alive++;
+    *kf_id = (int)s->kf.size() - 1;
+    return MSORB_OK;
+}
+
+extern "C" int msorb_kf_store_remove(msorb_kf_store* s, int kf_id) {
+    if (!s) return MSORB_E_INVALID;
+    std::unique_lock<std::shared_mutex> lk(s->mu);
+    if (kf_id < 0 || kf_id >= (int)s->kf.size() || !s->kf[kf_id].alive) { set_last_error("kf_store_remove: unknown KeyFrame id"); return MSORB_E_INVALID; }
+    s->kf[kf_id].alive = false;  // its rows stay allocated (a culled KeyFrame is ~100 KB; ids stay stable)
+    s->kf[kf_id].node.clear(); s->kf[kf_id].begin.assign(1, 0); s->kf[kf_id].angle.clear(); s->kf[kf_id].feat.clear();
+    s->n_alive--;
+    return MSORB_OK;
+}
+
+namespace {
+// items of one pair from the stores' host copies of the two FeatureVectors; lists are addressed inside the resident /
+// staged feat arrays through absolute offsets
+void items_of(const std::vector<int>& node1, const std::vector<int>& begin1, int feat0_1, const int* node2, const int* begin2, int nodes2,
+              int feat0_2, int base1, int base2, int m1, int m2, int pi, std::vector<BowItem>& items, std::vector<Common>& common,
+              int& max_chunks, bool& ok) {
+    int i = 0, j = 0;
+    const int nodes1 = (int)node1.size();
+    while (i < nodes1 && j < nodes2) {
+        if (node1[i] == node2[j]) {
+            const int l1 = begin1[i + 1] - begin1[i], l2 = begin2[j + 1] - begin2[j];
+            if (l1 > 0 && l2 > 0) {
+                if (l2 >= (1 << 20)) { ok = false; return; }
+                common.push_back({i, j});
+                items.push_back(BowItem{base1, base2, feat0_1 + begin1[i], l1, feat0_2 + begin2[j], l2, pi, m1, m2});
+                max_chunks = std::max(max_chunks, (l2 + 63) >> 6);
+            }
+            i++; j++;
+        } else if (node1[i] < node2[j]) i++;
+        else j++;
+    }
+}
+}  // namespace
+
+extern "C" int msorb_search_by_bow_kf(msorb_kf_store* st, msorb_bow_kf_pair* pairs, int n_pairs, const msorb_bow_frame* frame,
+                                      int th_low, int inclusive, float nnratio, int check_orientation, float* elapsed_ms) {
+    if (elapsed_ms) *elapsed_ms = 0;
+    if (!st || n_pairs < 0 || (n_pairs > 0 && !pairs)) return MSORB_E_INVALID;
+    if (n_pairs == 0) return MSORB_OK;
+    static const bool dbg_t = getenv("MSORB_DEBUG_TIMING") != nullptr;
+    const auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (dbg_t) fprintf(stderr, "bow_kf %s %.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count()); };
+    std::shared_lock<std::shared_mutex> lk(st->mu);
+    std::vector<uint8_t> seen;
+    FeatVec ff{0, nullptr, nullptr, nullptr};
+    if (frame) {
+        ff = FeatVec{frame->fv_nodes, frame->fv_node, frame->fv_begin, frame->fv_feat};
+        if (frame->n < 0 || (frame->n > 0 && !frame->desc) || (check_orientation && frame->n > 0 && !frame->angle) ||
+            !check_feature_vector(frame->n, ff, seen)) {
+            set_last_error("search_by_bow_kf: bad frame arrays");
+            return MSORB_E_INVALID;
+        }
+    }
+    // per-call flag arrays: [valid1 of pair 0 | pair 1 | ...] and [avail2 of pair 0 | ...]
+    std::vector<BowItem> items;
+    std::vector<std::vector<Common>> common(n_pairs);
+    std::vector<int> m1(n_pairs), m2(n_pairs);
+    size_t tot1 = 0, tot2 = 0;
+    int max_chunks = 1;
+    const int fr_feat_lo = frame && frame->fv_nodes ? frame->fv_begin[0] : 0;
+    for (int pi = 0; pi < n_pairs; pi++) {
+        msorb_bow_kf_pair& P = pairs[pi];
+        P.nmatches = 0;
+        const bool vs_frame = P.kf2 < 0;
+        if (P.kf1 < 0 || P.kf1 >= (int)st->kf.size() || !st->kf[P.kf1].alive || (vs_frame && !frame) ||
+            (!vs_frame && (P.kf2 >= (int)st->kf.size() || !st->kf[P.kf2].alive)) || (vs_frame != (frame != nullptr))) {
+            set_last_error("search_by_bow_kf: pair " + std::to_string(pi) + ": unknown KeyFrame id, or KeyFrame / frame trains mixed in one call");
+            return MSORB_E_INVALID;
+        }
+        const msorb_kf_store::Entry& A = st->kf[P.kf1];
+        const int n2 = vs_frame ? frame->n : st->kf[P.kf2].n;
+        if ((A.n > 0 && (!P.valid1 || !P.match12))) { set_last_error("search_by_bow_kf: null valid1 / match12"); return MSORB_E_INVALID; }
+        m1[pi] = (int)tot1; m2[pi] = (int)tot2;
+        bool ok = true;
+        if (vs_frame) {
+            // the frame's lists are staged at feat offset 0 of the per-call frame block; descriptors at row 0 of that block
+            std::vector<int> rel(frame->fv_nodes + 1);
+            for (int r = 0; r <= frame->fv_nodes; r++) rel[r] = (frame->fv_nodes ? frame->fv_begin[r] : 0) - fr_feat_lo;
+            items_of(A.node, A.begin, A.feat0, frame->fv_node, rel.data(), frame->fv_nodes, 0, A.row0, 0, m1[pi], m2[pi], pi, items,
+                     common[pi], max_chunks, ok);
+        } else {
+            const msorb_kf_store::Entry& B = st->kf[P.kf2];
+            items_of(A.node, A.begin, A.feat0, B.node.data(), B.begin.data(), (int)B.node.size(), B.feat0, A.row0, B.row0, m1[pi], m2[pi],
+                     pi, items, common[pi], max_chunks, ok);
+        }
+        if (!ok) { set_last_error("search_by_bow_kf: node list too long"); return MSORB_E_INVALID; }
+        tot1 += (size_t)A.n;
+        tot2 += (size_t)n2;
+        for (int i = 0; i < A.n; i++) P.match12[i] = -1;
+        if (P.match21) for (int j = 0; j < n2; j++) P.match21[j] = -1;
+    }
+    if (items.empty()) return MSORB_OK;
+    lap("items");
+    const size_t n_items = items.size();
+    const size_t fr_rows = frame ? (size_t)frame->n : 0, fr_feats = frame && frame->fv_nodes ? (size_t)(frame->fv_begin[frame->fv_nodes] - fr_feat_lo) : 0;
+    // staging: [frame desc | frame feat | frame angle | items | posts | valid1 | avail2] in, [match12 | match21 | nmatches] out
+    const size_t o_fd = 0, o_ff = o_fd + fr_rows * 32, o_fa = o_ff + up16(fr_feats * 4), o_it = o_fa + up16(fr_rows * 4),
+                 o_po = o_it + up16(n_items * sizeof(BowItem)), o_v1 = o_po + up16((size_t)n_pairs * sizeof(PairPost)),
+                 o_a2 = o_v1 + up16(tot1), in_bytes = o_a2 + up16(tot2), o_m = in_bytes, o_m21 = o_m + up16(tot1 * 4),
+                 o_nm = o_m21 + up16(tot2 * 4), total = o_nm + up16((size_t)n_pairs * 4), out_bytes = total - o_m;
+    static thread_local Scratch scr;
+    hipError_t e = scr.acquire(st->device, total);
+    if (e != hipSuccess) return hip_fail(scr, "search_by_bow_kf", e);
+    {
+        char* h = scr.h;
+        if (fr_rows) std::memcpy(h + o_fd, frame->desc, fr_rows * 32);
+        if (fr_feats) std::memcpy(h + o_ff, frame->fv_feat + fr_feat_lo, fr_feats * 4);
+        if (fr_rows && frame->angle) std::memcpy(h + o_fa, frame->angle, fr_rows * 4);
+        std::memcpy(h + o_it, items.data(), n_items * sizeof(BowItem));
+        PairPost* posts = (PairPost*)(h + o_po);
+        for (int pi = 0; pi < n_pairs; pi++) {
+            const msorb_bow_kf_pair& P = pairs[pi];
+            const msorb_kf_store::Entry& A = st->kf[P.kf1];
+            const int n1 = A.n, n2 = P.kf2 < 0 ? frame->n : st->kf[P.kf2].n;
+            if (n1) std::memcpy(h + o_v1 + m1[pi], P.valid1, (size_t)n1);
+            if (n2) {
+                if (P.avail2) std::memcpy(h + o_a2 + m2[pi], P.avail2, (size_t)n2);
+                else std::memset(h + o_a2 + m2[pi], 1, (size_t)n2);
+            }
+            posts[pi] = PairPost{m1[pi], n1, m2[pi], n2, A.row0, P.kf2 < 0 ? 0 : st->kf[P.kf2].row0};
+        }
+    }
+    lap("staged");
+    hipStream_t s = scr.s;
+    char* d = scr.d;
+    e = hipMemcpyAsync(d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d + o_m, 0xFF, o_nm - o_m, s);   // match12 and match21 = -1
+    if (e == hipSuccess) e = hipEventRecord(scr.e0, s);
+    if (e == hipSuccess) {
+        const uint4* desc2 = frame ? (const uint4*)(d + o_fd) : st->d_desc;
+        const int* feat2 = frame ? (const int*)(d + o_ff) : st->d_feat;
+        hipLaunchKernelGGL(bow_match_kernel, dim3((unsigned)n_items), dim3(64), (size_t)max_chunks * 8, s, (const BowItem*)(d + o_it),
+                           st->d_desc, desc2, (const uint8_t*)(d + o_v1), (const uint8_t*)(d + o_a2), st->d_feat, feat2, th_low,
+                           inclusive, nnratio, (int*)(d + o_m));
+        hipLaunchKernelGGL(pair_histogram_kernel, dim3((unsigned)n_pairs), dim3(256), 0, s, (const PairPost*)(d + o_po), st->d_angle,
+                           frame ? (const float*)(d + o_fa) : st->d_angle, check_orientation, (int*)(d + o_m), (int*)(d + o_m21),
+                           (int*)(d + o_nm));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(scr.e1, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(scr.h + o_m, d + o_m, out_bytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess && elapsed_ms) e = hipEventElapsedTime(elapsed_ms, scr.e0, scr.e1);
+    if (e != hipSuccess) return hip_fail(scr, "search_by_bow_kf", e);
+    lap("device");
+    for (int pi = 0; pi < n_pairs; pi++) {
+        msorb_bow_kf_pair& P = pairs[pi];
+        const int n1 = st->kf[P.kf1].n, n2 = P.kf2 < 0 ? frame->n : st->kf[P.kf2].n;
+        if (n1) std::memcpy(P.match12, scr.h + o_m + (size_t)m1[pi] * 4, (size_t)n1 * 4);
+        if (P.match21 && n2) std::memcpy(P.match21, scr.h + o_m21 + (size_t)m2[pi] * 4, (size_t)n2 * 4);
+        P.nmatches = ((const int*)(scr.h + o_nm))[pi];
+    }
+    lap("replay");
+    return MSORB_OK;
+}
+
+extern "C" int msorb_search_for_triangulation_kf(msorb_kf_store* st, msorb_triangulation_kf_pair* pairs, int n_pairs, int coarse,
+                                                 int check_orientation, float* elapsed_ms) {
+    if (elapsed_ms) *elapsed_ms = 0;
+    if (!st || n_pairs < 0 || (n_pairs > 0 && !pairs)) return MSORB_E_INVALID;
+    if (n_pairs == 0) return MSORB_OK;
+    std::shared_lock<std::shared_mutex> lk(st->mu);
+    std::vector<BowItem> items;
+    std::vector<std::vector<Common>> common(n_pairs);
+    std::vector<int> m1(n_pairs), m2(n_pairs);
+    size_t tot1 = 0, tot2 = 0;
+    int max_chunks = 1;
+    for (int pi = 0; pi < n_pairs; pi++) {
+        msorb_triangulation_kf_pair& P = pairs[pi];
+        P.nmatches = 0;
+        if (P.kf1 < 0 || P.kf1 >= (int)st->kf.size() || !st->kf[P.kf1].alive || P.kf2 < 0 || P.kf2 >= (int)st->kf.size() ||
+            !st->kf[P.kf2].alive) {
+            set_last_error("search_for_triangulation_kf: pair " + std::to_string(pi) + ": unknown KeyFrame id");
+            return MSORB_E_INVALID;
+        }
+        const msorb_kf_store::Entry &A = st->kf[P.kf1], &B = st->kf[P.kf2];
+        if ((A.n > 0 && (!P.valid1 || !P.stereo1 || !P.match12)) || (B.n > 0 && (!P.avail2 || !P.stereo2))) {
+            set_last_error("search_for_triangulation_kf: null flag arrays / match12");
+            return MSORB_E_INVALID;
+        }
+        m1[pi] = (int)tot1; m2[pi] = (int)tot2;
+        bool ok = true;
+        items_of(A.node, A.begin, A.feat0, B.node.data(), B.begin.data(), (int)B.node.size(), B.feat0, A.row0, B.row0, m1[pi], m2[pi], pi,
+                 items, common[pi], max_chunks, ok);
+        if (!ok) { set_last_error("search_for_triangulation_kf: node list too long"); return MSORB_E_INVALID; }
+        tot1 += (size_t)A.n;
+        tot2 += (size_t)B.n;
+        for (int i = 0; i < A.n; i++) P.match12[i] = -1;
+    }
+    if (items.empty()) return MSORB_OK;
+    const size_t n_items = items.size();
+    // staging: [items | consts | posts | flags1 | flags2] in, [match12 | nmatches] out
+    const size_t o_it = 0, o_c = o_it + up16(n_items * sizeof(BowItem)), o_po = o_c + up16((size_t)n_pairs * sizeof(TriConst)),
+                 o_v1 = o_po + up16((size_t)n_pairs * sizeof(PairPost)), o_a2 = o_v1 + up16(tot1), in_bytes = o_a2 + up16(tot2),
+                 o_m = in_bytes, o_nm = o_m + up16(tot1 * 4), total = o_nm + up16((size_t)n_pairs * 4), out_bytes = total - o_m;
+    static thread_local Scratch scr;
+    hipError_t e = scr.acquire(st->device, total);
+    if (e != hipSuccess) return hip_fail(scr, "search_for_triangulation_kf", e);
+    {
+        char* h = scr.h;
+        std::memcpy(h + o_it, items.data(), n_items * sizeof(BowItem));
+        TriConst* consts = (TriConst*)(h + o_c);
+        PairPost* posts = (PairPost*)(h + o_po);
+        for (int pi = 0; pi < n_pairs; pi++) {
+            const msorb_triangulation_kf_pair& P = pairs[pi];
+            const msorb_kf_store::Entry &A = st->kf[P.kf1], &B = st->kf[P.kf2];
+            uint8_t* f1 = (uint8_t*)(h + o_v1) + m1[pi];
+            uint8_t* f2 = (uint8_t*)(h + o_a2) + m2[pi];
+            for (int i = 0; i < A.n; i++) f1[i] = (uint8_t)((P.valid1[i] ? 1 : 0) | (P.stereo1[i] ? 2 : 0));
+            for (int j = 0; j < B.n; j++) f2[j] = (uint8_t)((P.avail2[j] ? 1 : 0) | (P.stereo2[j] ? 2 : 0));
+            std::memcpy(consts[pi].F, P.F12, sizeof(P.F12));
+            consts[pi].ep[0] = P.ep[0];
+            consts[pi].ep[1] = P.ep[1];
+            posts[pi] = PairPost{m1[pi], A.n, m2[pi], B.n, A.row0, B.row0};
+        }
+    }
+    hipStream_t s = scr.s;
+    char* d = scr.d;
+    e = hipMemcpyAsync(d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d + o_m, 0xFF, tot1 * 4, s);
+    if (e == hipSuccess) e = hipEventRecord(scr.e0, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(triangulation_match_kernel, dim3((unsigned)n_items), dim3(64), (size_t)max_chunks * 8, s,
+                           (const BowItem*)(d + o_it), (const TriConst*)(d + o_c), st->d_desc, st->d_desc, (const uint8_t*)(d + o_v1),
+                           (const uint8_t*)(d + o_a2), st->d_xy, st->d_tr, st->d_feat, st->d_feat, coarse, (int*)(d + o_m));
+        hipLaunchKernelGGL(pair_histogram_kernel, dim3((unsigned)n_pairs), dim3(256), 0, s, (const PairPost*)(d + o_po), st->d_angle,
+                           st->d_angle, check_orientation, (int*)(d + o_m), (int*)nullptr, (int*)(d + o_nm));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(scr.e1, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(scr.h + o_m, d + o_m, out_bytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess && elapsed_ms) e = hipEventElapsedTime(elapsed_ms, scr.e0, scr.e1);
+    if (e != hipSuccess) return hip_fail(scr, "search_for_triangulation_kf", e);
+    for (int pi = 0; pi < n_pairs; pi++) {
+        msorb_triangulation_kf_pair& P = pairs[pi];
+        const int n1 = st->kf[P.kf1].n;
+        if (n1) std::memcpy(P.match12, scr.h + o_m + (size_t)m1[pi] * 4, (size_t)n1 * 4);
+        P.nmatches = ((const int*)(scr.h + o_nm))[pi];
     }
     return MSORB_OK;
 }

@@ -556,10 +556,10 @@ void launch_stereo_match_batch(const StereoBatchArgs& b, int n_pairs, int max_le
 // '<' (best = lexicographic min of (distance, index), second = the runner-up).  One thread per query, the
 // frame's train descriptors staged once per workgroup in LDS (<= 2048 x 32 B = 64 KB) and broadcast-read.
 constexpr int kDenseMaxTrain = 2048;
-constexpr int kDenseQPL = 2;    // queries per lane: one LDS broadcast read of a train descriptor serves two pairs per lane
-constexpr int kDenseSplit = 2;  // the train range is split over this many 256-thread halves of a workgroup (merged at the
-                                // end): twice the waves for the same LDS tile — a batch of 128 frames has only 2 waves per
-                                // SIMD otherwise, too few to cover the popcount-accumulate dependency chains
+// QPL = queries per lane: one LDS broadcast read of a train descriptor serves QPL pairs per lane (QPL independent
+// popcount-accumulate chains).  SPLIT = the train range is split over this many 256-thread parts of a workgroup (merged at
+// the end): SPLIT times the waves for the same LDS tile — a batch of 128 frames has too few waves per SIMD otherwise.
+template <int kDenseQPL, int kDenseSplit>
 __global__ __launch_bounds__(256 * kDenseSplit) void dense_top2_kernel(const uint8_t* __restrict__ q, const uint8_t* __restrict__ t,
                                                         const int* __restrict__ n_q, const int* __restrict__ n_t,
                                                         int q_stride, int t_stride, int* __restrict__ best_idx,
@@ -575,29 +575,39 @@ __global__ __launch_bounds__(256 * kDenseSplit) void dense_top2_kernel(const uin
     const int part = threadIdx.x >> 8, l = threadIdx.x & 255;
     const int per = (nt + kDenseSplit - 1) / kDenseSplit;
     const int jb = part * per, je = min(jb + per, nt);
-    uint64_t a[kDenseQPL][4];
+    uint32_t a[kDenseQPL][8];
     uint32_t k0[kDenseQPL], k1[kDenseQPL];  // (dist << 16) | index
 #pragma unroll
     for (int u = 0; u < kDenseQPL; u++) {
         const int qi = min(q0 + u * 256 + l, nq - 1);  // lanes past the end repeat the last query, no store
-        const uint64_t* qp = reinterpret_cast<const uint64_t*>(q + ((size_t)frame * q_stride + qi) * 32);
-        a[u][0] = qp[0]; a[u][1] = qp[1]; a[u][2] = qp[2]; a[u][3] = qp[3];
+        const uint4* qp = reinterpret_cast<const uint4*>(q + ((size_t)frame * q_stride + qi) * 32);
+        const uint4 lo = qp[0], hi = qp[1];
+        a[u][0] = lo.x; a[u][1] = lo.y; a[u][2] = lo.z; a[u][3] = lo.w; a[u][4] = hi.x; a[u][5] = hi.y; a[u][6] = hi.z; a[u][7] = hi.w;
         k0[u] = k1[u] = 0xFFFFFFFFu;
     }
-#pragma unroll 4
-    for (int j = jb; j < je; j++) {
-        const uint64_t t0 = tile[4 * j], t1 = tile[4 * j + 1], t2 = tile[4 * j + 2], t3 = tile[4 * j + 3];
+    const uint4* tile4 = reinterpret_cast<const uint4*>(tile);
+    auto score = [&](const uint4& tl, const uint4& th, int j) {
+        const uint32_t tw[8] = {tl.x, tl.y, tl.z, tl.w, th.x, th.y, th.z, th.w};
 #pragma unroll
         for (int u = 0; u < kDenseQPL; u++) {
-            const int d = __popcll(a[u][0] ^ t0) + __popcll(a[u][1] ^ t1) + __popcll(a[u][2] ^ t2) + __popcll(a[u][3] ^ t3);
-            const uint32_t key = ((uint32_t)d << 16) | (uint32_t)j;
+            // the distance as ONE accumulate chain: v_bcnt_u32_b32 d, x, d adds the population count to its third operand
+            // (written with 64-bit popcounts the compiler emits eight counts from zero plus adds to join them)
+            uint32_t d = 0;
+#pragma unroll
+            for (int w = 0; w < 8; w++) d = (uint32_t)__builtin_popcount(a[u][w] ^ tw[w]) + d;
+            const uint32_t key = (d << 16) | (uint32_t)j;
             // (k0 <= k1) + key -> the two smallest: second = median of the three (one v_med3_u32 instead of max + min)
-            // (written in the min/max form the backend folds into v_med3_u32)
+            // (written in the min/max form the backend folds into v_med3_u32).  Gating this on "d below the second-best
+            // distance" was measured slower: with 64 lanes x QPL queries some lane improves on most steps.
             const uint32_t m = min(max(k0[u], k1[u]), max(min(k0[u], k1[u]), key));
             k0[u] = min(k0[u], key);
             k1[u] = m;
         }
-    }
+    };
+    // (a hand-made software pipeline over groups of four trains — next group's LDS reads in flight while the current one is
+    // scored — measured slower: 1.36-1.46 against 1.65-1.73 Tpairs/s; register copies and one wave per SIMD less)
+#pragma unroll 4
+    for (int j = jb; j < je; j++) score(tile4[2 * j], tile4[2 * j + 1], j);
     // merge the parts: keys are unique (distinct indices), so top-2 of the union = {min(a0,b0), min(max(a0,b0), min(a1,b1))}
     __syncthreads();  // everyone is done reading the tile; it becomes the exchange buffer
     uint32_t* xch = reinterpret_cast<uint32_t*>(tile);
@@ -628,14 +638,32 @@ __global__ __launch_bounds__(256 * kDenseSplit) void dense_top2_kernel(const uin
     }
 }
 
+template <int QPL, int SPLIT>
+static void launch_dense_variant(const uint8_t* q, const uint8_t* t, const int* n_q, const int* n_t, int n_frames, int q_stride,
+                                 int t_stride, int max_q, int max_t, int* bi, int* bd, int* sd, hipStream_t s) {
+    // tile of the train descriptors; at least the exchange buffer of the final merge
+    const size_t lds = std::max<size_t>((size_t)min(max_t, kDenseMaxTrain) * 32, (size_t)(SPLIT - 1) * QPL * 512 * 4);
+    const int per_block = 256 * QPL;
+    hipLaunchKernelGGL((dense_top2_kernel<QPL, SPLIT>), dim3((max_q + per_block - 1) / per_block, n_frames), dim3(256 * SPLIT), lds, s,
+                       q, t, n_q, n_t, q_stride, t_stride, bi, bd, sd);
+}
 void launch_dense_top2(const uint8_t* q, const uint8_t* t, const int* n_q, const int* n_t, int n_frames, int q_stride,
                        int t_stride, int max_q, int max_t, int* bi, int* bd, int* sd, hipStream_t s) {
     if (n_frames <= 0 || max_q <= 0) return;
-    // tile of the train descriptors; at least the exchange buffer of the final merge
-    const size_t lds = std::max<size_t>((size_t)min(max_t, kDenseMaxTrain) * 32, (size_t)(kDenseSplit - 1) * kDenseQPL * 512 * 4);
-    const int per_block = 256 * kDenseQPL;
-    hipLaunchKernelGGL(dense_top2_kernel, dim3((max_q + per_block - 1) / per_block, n_frames), dim3(256 * kDenseSplit), lds, s, q, t,
-                       n_q, n_t, q_stride, t_stride, bi, bd, sd);
+    static const int variant = getenv("MSORB_DENSE_VARIANT") ? atoi(getenv("MSORB_DENSE_VARIANT")) : 24;  // tuning aid: QPL*10 + SPLIT
+    // measured on MI355X (128 frames x 2000 x 2000): 2,1 1.54  2,2 1.65  2,4 1.72  4,2 1.68  4,4 1.73  1,4 1.57 Tpairs/s
+#define MSORB_DENSE(Q, S) launch_dense_variant<Q, S>(q, t, n_q, n_t, n_frames, q_stride, t_stride, max_q, max_t, bi, bd, sd, s)
+    switch (variant) {
+        case 21: MSORB_DENSE(2, 1); break;
+        case 22: MSORB_DENSE(2, 2); break;
+        case 41: MSORB_DENSE(4, 1); break;
+        case 42: MSORB_DENSE(4, 2); break;
+        case 44: MSORB_DENSE(4, 4); break;
+        case 12: MSORB_DENSE(1, 2); break;
+        case 14: MSORB_DENSE(1, 4); break;
+        default: MSORB_DENSE(2, 4); break;
+    }
+#undef MSORB_DENSE
 }
 
 }  // namespace msorb

@@ -42,6 +42,11 @@ struct ThreadCache {
     bool kf_sparsified[2] = {false, false};
     int kf_n[2] = {-1, -1};
 };
+// KeyFrames resident on the device for the BoW-node searches, shared by the three threads that run the matcher
+msorb_host::KeyFrameStore& keyframe_store() {
+    static msorb_host::KeyFrameStore store(matcher_device());
+    return store;
+}
 ThreadCache& cache() {
     static thread_local ThreadCache c;
     return c;
@@ -104,7 +109,11 @@ int ORBmatcher::SearchByProjection(std::shared_ptr<KeyFrame> pKF, Sophus::Sim3<f
 }
 
 int ORBmatcher::SearchByBoW(std::shared_ptr<KeyFrame> pKF, Frame& F, std::vector<std::shared_ptr<MapPoint>>& vpMapPointMatches) {
-    return msorb_host::SearchByBoW(pKF, F, vpMapPointMatches, mfNNratio, mbCheckOrientation, matcher_device());
+    std::vector<std::vector<std::shared_ptr<MapPoint>>> out;
+    const int n = msorb_host::SearchByBoWBatch(keyframe_store(), std::vector<std::shared_ptr<KeyFrame>>{pKF}, F, out, mfNNratio,
+                                               mbCheckOrientation)[0];
+    vpMapPointMatches = std::move(out[0]);
+    return n;
 }
 
 int ORBmatcher::SearchByBoW(std::shared_ptr<KeyFrame> pKF1, std::shared_ptr<KeyFrame> pKF2,
@@ -129,7 +138,11 @@ int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Po
 
 int ORBmatcher::SearchForTriangulation(std::shared_ptr<KeyFrame> pKF1, std::shared_ptr<KeyFrame> pKF2,
                                        std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo, const bool bCoarse) {
-    return msorb_host::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse, mbCheckOrientation, matcher_device());
+    std::vector<std::vector<std::pair<size_t, size_t>>> out;
+    const int n = msorb_host::SearchForTriangulationBatch(keyframe_store(), pKF1, std::vector<std::shared_ptr<KeyFrame>>{pKF2}, out,
+                                                          bOnlyStereo, bCoarse, mbCheckOrientation)[0];
+    vMatchedPairs = std::move(out[0]);
+    return n;
 }
 
 int ORBmatcher::SearchBySim3(std::shared_ptr<KeyFrame> pKF1, std::shared_ptr<KeyFrame> pKF2,

@@ -44,6 +44,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -647,6 +648,136 @@ int SearchForTriangulation(const KeyFramePtr& pKF1, const KeyFramePtr& pKF2, std
                                               mbCheckOrientation, device)[0];
     vMatchedPairs = std::move(out[0]);
     return n;
+}
+
+// ---- resident KeyFrames ------------------------------------------------------------------------------------------
+// msorb_kf_store behind the reference's types: a KeyFrame enters the store the first time it is searched (its features are
+// fixed once ComputeBoW has run) and stays until Forget() (KeyFrame::SetBadFlag) — or until map sparsification compacts it
+// (mbSparsified flips, N shrinks: re-added under a new id).  The searches below then move one flag byte per feature per
+// call instead of both KeyFrames: 0.12-0.15 ms instead of 0.65-1.1 ms for 16 neighbours / 32 candidates (profiles/).
+class KeyFrameStore {
+public:
+    explicit KeyFrameStore(int device = 0) { check(msorb_kf_store_create(device, &h_), "msorb_kf_store_create"); }
+    ~KeyFrameStore() { msorb_kf_store_destroy(h_); }
+    KeyFrameStore(const KeyFrameStore&) = delete;
+    KeyFrameStore& operator=(const KeyFrameStore&) = delete;
+    msorb_kf_store* get() const { return h_; }
+
+    template <class KeyFramePtr>
+    int Ensure(const KeyFramePtr& pKF) {
+        const int n = pKF->GetN();
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            auto it = ids_.find(pKF->mnId);
+            if (it != ids_.end() && it->second.sparsified == pKF->mbSparsified && it->second.n == n) return it->second.id;
+        }
+        BowSide side;
+        side.FillKeyFrame(pKF);
+        const auto keys = pKF->GetAllKeyUn();
+        static_assert(sizeof(keys[0]) == sizeof(msorb_keypoint), "cv::KeyPoint must be the 28-byte layout");
+        int id = -1;
+        check(msorb_kf_store_add(h_, n, reinterpret_cast<const msorb_keypoint*>(keys.data()), side.desc.data(), (int)side.node.size(),
+                                 side.node.data(), side.begin.data(), side.feat.data(), pKF->mvScaleFactors.data(),
+                                 pKF->mvLevelSigma2.data(), (int)pKF->mvScaleFactors.size(), &id),
+              "msorb_kf_store_add");
+        std::lock_guard<std::mutex> lk(mu_);
+        auto it = ids_.find(pKF->mnId);
+        if (it != ids_.end()) msorb_kf_store_remove(h_, it->second.id);  // the compacted (or concurrently added) predecessor
+        ids_[pKF->mnId] = Rec{id, pKF->mbSparsified, n};
+        return id;
+    }
+    void Forget(unsigned long mnId) {  // KeyFrame::SetBadFlag
+        std::lock_guard<std::mutex> lk(mu_);
+        auto it = ids_.find(mnId);
+        if (it == ids_.end()) return;
+        msorb_kf_store_remove(h_, it->second.id);
+        ids_.erase(it);
+    }
+
+private:
+    struct Rec { int id; bool sparsified; int n; };
+    msorb_kf_store* h_ = nullptr;
+    std::mutex mu_;
+    std::unordered_map<unsigned long, Rec> ids_;
+};
+
+// SearchForTriangulationBatch with the KeyFrames resident (same results)
+template <class KeyFramePtr>
+std::vector<int> SearchForTriangulationBatch(KeyFrameStore& store, const KeyFramePtr& pKF1, const std::vector<KeyFramePtr>& vpKF2,
+                                             std::vector<std::vector<std::pair<size_t, size_t>>>& vvMatchedPairs, bool bOnlyStereo,
+                                             bool bCoarse, bool mbCheckOrientation) {
+    const size_t K = vpKF2.size();
+    struct Flags { std::vector<uint8_t> free_, stereo; };
+    auto flags_of = [&](const KeyFramePtr& pKF, Flags& f) {
+        const auto mps = pKF->GetMapPointMatches();
+        const int n = (int)mps.size();
+        f.free_.assign(n, 0); f.stereo.assign(n, 0);
+        for (int i = 0; i < n; i++) {
+            f.stereo[i] = pKF->GetuRight(i) >= 0;                          // :1243 / :1267
+            f.free_[i] = !mps[i] && (!bOnlyStereo || f.stereo[i]);         // :1237-1247 / :1264-1271
+        }
+    };
+    Flags a;
+    flags_of(pKF1, a);
+    const int id1 = store.Ensure(pKF1);
+    std::vector<Flags> b(K);
+    std::vector<msorb_triangulation_kf_pair> pairs(K);
+    std::vector<std::vector<int>> m12(K);
+    for (size_t k = 0; k < K; k++) {
+        flags_of(vpKF2[k], b[k]);
+        msorb_triangulation_kf_pair& P = pairs[k];
+        P = msorb_triangulation_kf_pair{};
+        P.kf1 = id1; P.kf2 = store.Ensure(vpKF2[k]);
+        P.valid1 = a.free_.data(); P.avail2 = b[k].free_.data(); P.stereo1 = a.stereo.data(); P.stereo2 = b[k].stereo.data();
+        TriangulationGeometry(pKF1, vpKF2[k], P.F12, P.ep);
+        m12[k].assign(a.free_.size(), -1);
+        P.match12 = m12[k].data();
+    }
+    check(msorb_search_for_triangulation_kf(store.get(), pairs.data(), (int)K, bCoarse, mbCheckOrientation, nullptr),
+          "msorb_search_for_triangulation_kf");
+    std::vector<int> nmatches(K);
+    vvMatchedPairs.assign(K, {});
+    for (size_t k = 0; k < K; k++) {
+        nmatches[k] = pairs[k].nmatches;
+        vvMatchedPairs[k].reserve(nmatches[k]);
+        for (size_t i = 0; i < m12[k].size(); i++)
+            if (m12[k][i] >= 0) vvMatchedPairs[k].push_back(std::make_pair(i, (size_t)m12[k][i]));
+    }
+    return nmatches;
+}
+
+// SearchByBoWBatch (candidate KeyFrames against one Frame) with the KeyFrames resident (same results)
+template <class KeyFramePtr, class FrameT, class MapPointPtr>
+std::vector<int> SearchByBoWBatch(KeyFrameStore& store, const std::vector<KeyFramePtr>& vpKFs, FrameT& F,
+                                  std::vector<std::vector<MapPointPtr>>& vvpMapPointMatches, float mfNNratio, bool mbCheckOrientation) {
+    const size_t K = vpKFs.size();
+    BowSide frame;
+    frame.Fill(F.N, [&](int i) { return F.mDescriptors.row(i); }, F.mFeatVec, F.mvKeys);
+    const msorb_bow_frame bf{F.N, frame.desc.data(), (int)frame.node.size(), frame.node.data(), frame.begin.data(), frame.feat.data(),
+                             frame.angle.data()};
+    std::vector<std::vector<MapPointPtr>> mpsKF(K);
+    std::vector<std::vector<uint8_t>> good(K);
+    std::vector<std::vector<int>> m12(K), m21(K);
+    std::vector<msorb_bow_kf_pair> pairs(K);
+    for (size_t k = 0; k < K; k++) {
+        mpsKF[k] = vpKFs[k]->GetMapPointMatches();
+        good[k].assign(mpsKF[k].size(), 0);
+        for (size_t i = 0; i < mpsKF[k].size(); i++) good[k][i] = mpsKF[k][i] && !mpsKF[k][i]->isBad();   // :253-259
+        m12[k].assign(mpsKF[k].size(), -1);
+        m21[k].assign(F.N, -1);
+        pairs[k] = msorb_bow_kf_pair{store.Ensure(vpKFs[k]), -1, good[k].data(), nullptr, m12[k].data(), m21[k].data(), 0};
+    }
+    check(msorb_search_by_bow_kf(store.get(), pairs.data(), (int)K, &bf, 50 /* TH_LOW */, 1, mfNNratio, mbCheckOrientation, nullptr),
+          "msorb_search_by_bow_kf");
+    std::vector<int> nmatches(K);
+    vvpMapPointMatches.resize(K);
+    for (size_t k = 0; k < K; k++) {
+        vvpMapPointMatches[k].assign(F.N, MapPointPtr());
+        for (int j = 0; j < F.N; j++)
+            if (m21[k][j] >= 0) vvpMapPointMatches[k][j] = mpsKF[k][m21[k][j]];
+        nmatches[k] = pairs[k].nmatches;
+    }
+    return nmatches;
 }
 
 // Frame::ComputeStereoMatches(): fills F.mvuRight / F.mvDepth from the two extractors' device pyramids.

@@ -816,6 +816,119 @@ def search_for_triangulation(pairs, coarse=False, check_orientation=True, device
     return [(arr[k].nmatches, o[0][:o[1]]) for k, o in enumerate(outs)], ms.value
 
 
+EXPORTS = EXPORTS + ("msorb_kf_store_create", "msorb_kf_store_destroy", "msorb_kf_store_count", "msorb_kf_store_add",
+                     "msorb_kf_store_remove", "msorb_search_by_bow_kf", "msorb_search_for_triangulation_kf")
+
+
+class BowKfPair(C.Structure):
+    _fields_ = [("kf1", C.c_int), ("kf2", C.c_int), ("valid1", C.c_void_p), ("avail2", C.c_void_p), ("match12", C.c_void_p),
+                ("match21", C.c_void_p), ("nmatches", C.c_int)]
+
+
+class BowFrame(C.Structure):
+    _fields_ = [("n", C.c_int), ("desc", C.c_void_p), ("fv_nodes", C.c_int), ("fv_node", C.c_void_p), ("fv_begin", C.c_void_p),
+                ("fv_feat", C.c_void_p), ("angle", C.c_void_p)]
+
+
+class TriangulationKfPair(C.Structure):
+    _fields_ = [("kf1", C.c_int), ("kf2", C.c_int), ("valid1", C.c_void_p), ("avail2", C.c_void_p), ("stereo1", C.c_void_p),
+                ("stereo2", C.c_void_p), ("F12", C.c_float * 9), ("ep", C.c_float * 2), ("match12", C.c_void_p), ("nmatches", C.c_int)]
+
+
+class KeyFrameStore:
+    """msorb_kf_store: KeyFrame descriptors / keypoints / FeatureVectors resident on the device for the BoW-node searches."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        self.L.msorb_kf_store_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        _check(self.L.msorb_kf_store_create(device, C.byref(h)), "msorb_kf_store_create")
+        self.h = h
+        self.n = {}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.msorb_kf_store_destroy.argtypes = [C.c_void_p]
+            self.L.msorb_kf_store_destroy.restype = None
+            self.L.msorb_kf_store_destroy(self.h)
+            self.h = None
+
+    def count(self):
+        self.L.msorb_kf_store_count.argtypes = [C.c_void_p]
+        return self.L.msorb_kf_store_count(self.h)
+
+    def add(self, kps, desc, fv, scale_factors, level_sigma2):
+        k, d = np.ascontiguousarray(kps, KP_DTYPE), _c(desc, np.uint8).reshape(-1, 32)
+        f = [_c(a, np.int32) for a in fv]
+        sc, sg = _c(scale_factors, np.float32), _c(level_sigma2, np.float32)
+        kid = C.c_int(-1)
+        vp = C.c_void_p
+        self.L.msorb_kf_store_add.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp]
+        _check(self.L.msorb_kf_store_add(self.h, len(k), _np_ptr(k), _np_ptr(d), len(f[0]), _np_ptr(f[0]), _np_ptr(f[1]), _np_ptr(f[2]),
+                                         _np_ptr(sc), _np_ptr(sg), len(sc), C.byref(kid)), "msorb_kf_store_add")
+        self.n[kid.value] = len(k)
+        return kid.value
+
+    def remove(self, kf_id):
+        self.L.msorb_kf_store_remove.argtypes = [C.c_void_p, C.c_int]
+        _check(self.L.msorb_kf_store_remove(self.h, kf_id), "msorb_kf_store_remove")   # (self.n keeps the size: ids are never reused)
+
+    def search_by_bow(self, pairs, frame=None, th_low=50, inclusive=True, nnratio=0.7, check_orientation=True):
+        """pairs: dicts kf1, kf2 (or -1 with `frame`), valid1, avail2 (or None).  frame: dict desc, fv, angle.
+        -> (list of (nmatches, match12, match21), kernel_ms)"""
+        arr = (BowKfPair * max(len(pairs), 1))()
+        keep, outs = [], []
+        fr = None
+        if frame is not None:
+            fd = _c(frame["desc"], np.uint8).reshape(-1, 32)
+            ff = [_c(a, np.int32) for a in frame["fv"]]
+            fa = _c(frame["angle"], np.float32)
+            fr = BowFrame(len(fd), _np_ptr(fd), len(ff[0]), _np_ptr(ff[0]), _np_ptr(ff[1]), _np_ptr(ff[2]), _np_ptr(fa))
+            keep.append((fd, ff, fa))
+        for k, p in enumerate(pairs):
+            n1 = self.n[p["kf1"]]
+            n2 = len(frame["desc"]) if p["kf2"] < 0 else self.n[p["kf2"]]
+            v1 = _c(p["valid1"], np.uint8)
+            a2 = None if p.get("avail2") is None else _c(p["avail2"], np.uint8)
+            m12, m21 = np.zeros(max(n1, 1), np.int32), np.zeros(max(n2, 1), np.int32)
+            keep.append((v1, a2))
+            outs.append((m12, m21, n1, n2))
+            q = arr[k]
+            q.kf1, q.kf2, q.valid1 = p["kf1"], p["kf2"], _np_ptr(v1)
+            q.avail2 = None if a2 is None else _np_ptr(a2)
+            q.match12, q.match21 = _np_ptr(m12), _np_ptr(m21)
+        ms = C.c_float()
+        vp = C.c_void_p
+        self.L.msorb_search_by_bow_kf.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_int, vp]
+        _check(self.L.msorb_search_by_bow_kf(self.h, C.addressof(arr), len(pairs), None if fr is None else C.addressof(fr), int(th_low),
+                                             int(bool(inclusive)), float(nnratio), int(bool(check_orientation)), C.addressof(ms)),
+               "msorb_search_by_bow_kf")
+        return [(arr[k].nmatches, o[0][:o[2]], o[1][:o[3]]) for k, o in enumerate(outs)], ms.value
+
+    def search_for_triangulation(self, pairs, coarse=False, check_orientation=True):
+        """pairs: dicts kf1, kf2, valid1, avail2, stereo1, stereo2, F12, ep.  -> (list of (nmatches, match12), kernel_ms)"""
+        arr = (TriangulationKfPair * max(len(pairs), 1))()
+        keep, outs = [], []
+        for k, p in enumerate(pairs):
+            fl = [_c(p[key], np.uint8) for key in ("valid1", "avail2", "stereo1", "stereo2")]
+            m12 = np.zeros(max(self.n[p["kf1"]], 1), np.int32)
+            keep.append(fl)
+            outs.append((m12, self.n[p["kf1"]]))
+            q = arr[k]
+            q.kf1, q.kf2 = p["kf1"], p["kf2"]
+            q.valid1, q.avail2, q.stereo1, q.stereo2 = (_np_ptr(a) for a in fl)
+            q.F12[:] = [float(x) for x in np.asarray(p["F12"], np.float32).reshape(9)]
+            q.ep[:] = [float(x) for x in np.asarray(p["ep"], np.float32).reshape(2)]
+            q.match12 = _np_ptr(m12)
+        ms = C.c_float()
+        vp = C.c_void_p
+        self.L.msorb_search_for_triangulation_kf.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+        _check(self.L.msorb_search_for_triangulation_kf(self.h, C.addressof(arr), len(pairs), int(bool(coarse)),
+                                                        int(bool(check_orientation)), C.addressof(ms)),
+               "msorb_search_for_triangulation_kf")
+        return [(arr[k].nmatches, o[0][:o[1]]) for k, o in enumerate(outs)], ms.value
+
+
 EXPORTS = EXPORTS + ("msorb_stereo_matches_batch",)
 
 

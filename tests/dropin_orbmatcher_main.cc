@@ -241,6 +241,24 @@ int main(int argc, char** argv) {
         for (auto& p : lMP) if (p->mnLoopPointForKF != nCurrentId) marked = 0;
         wri(o, marked && cKF.size() == cMP.size() && lKF.size() == lMP.size());
     }
+    // ---- SearchForTriangulation / SearchByBoW(pKF, F) through the class (resident KeyFrame store) against the per-call templates
+    {
+        std::vector<std::pair<size_t, size_t>> viaClass, viaCall;
+        const int a = matcher.SearchForTriangulation(kf1, kf2, viaClass, false, true);
+        const int b = msorb_host::SearchForTriangulation(kf1, kf2, viaCall, false, true, true, 0);
+        Frame F;
+        F.mnId = 2001;
+        const auto k2 = kf2->GetAllKeyUn();
+        std::vector<unsigned char> d2((size_t)32 * N2);
+        for (int i = 0; i < N2; i++) memcpy(&d2[(size_t)32 * i], kf2->GetDescriptor(i).ptr<unsigned char>(0), 32);
+        F.SetFeatures(k2, d2.data());
+        F.mFeatVec = kf2->GetFeatureVector();
+        std::vector<MP> m1, m2v;
+        const int c = matcher.SearchByBoW(kf1, F, m1);
+        const int d = msorb_host::SearchByBoW(kf1, F, m2v, 0.9f, true, 0);
+        wri(o, a); wri(o, c);
+        wri(o, a == b && viaClass == viaCall && c == d && m1 == m2v);
+    }
     // ---- DescriptorDistance
     {
         int acc = 0;

@@ -238,6 +238,10 @@ def test_orbmatcher_class_loop_closing_and_initialisation(tmp_path, oracle, msor
     assert cmp_ids.tolist() == order
     assert lmp_ids.tolist() == [int(w12[i]) for i in order]      # (ids in kf2's CURRENT map-point vector: Fuse's additions included)
 
+    # ---- SearchForTriangulation / SearchByBoW(pKF, F): the class (resident KeyFrame store) equals the per-call device path
+    n_tri, n_bow, same = R.i(), R.i(), R.i()
+    assert same == 1 and n_bow > 100 and n_tri >= 0
+
     # ---- DescriptorDistance, constants
     acc = R.i()
     consts = R.i()

@@ -117,6 +117,28 @@ def main(pairs=128, L=6):
         dt = (time.perf_counter() - t0) / len(batch)
         sb[name] = dict(pairs=len(batch), kernel_ms=round(float(np.median(kms)), 4), wall_ms_python=round(wall * 1e3, 3),
                         matches_first=int(out[0][0]), cpu_oracle_ms_per_pair=round(dt * 1e3, 3))
+    # the same with the candidate KeyFrames resident on the device (msorb_kf_store): per call only flags, work items and the frame move
+    st = msorb.KeyFrameStore()
+    kps0 = np.zeros(2000, msorb.KP_DTYPE)
+    sc8 = np.array([1.2 ** i for i in range(8)], np.float32)
+    ids = []
+    for p in cand:
+        k = kps0.copy()
+        k["angle"] = p["angle1"]
+        ids.append(st.add(k, p["desc1"], p["fv1"], sc8, sc8 * sc8))
+    frame = dict(desc=cand[0]["desc2"], fv=cand[0]["fv2"], angle=cand[0]["angle2"])
+    for name, idx in (("pair_resident", [0]), ("batch32_resident", list(range(32)))):
+        pr = [dict(kf1=ids[i], kf2=-1, valid1=cand[i]["valid1"]) for i in idx]
+        st.search_by_bow(pr, frame)
+        kms = [st.search_by_bow(pr, frame)[1] for _ in range(10)]
+        t0 = time.perf_counter()
+        for _ in range(10):
+            out, _ = st.search_by_bow(pr, frame)
+        wall = (time.perf_counter() - t0) / 10
+        ref, _ = msorb.search_by_bow([cand[i] for i in idx])
+        assert all(o[0] == r[0] and o[1].tolist() == r[1].tolist() for o, r in zip(out, ref))
+        sb[name] = dict(pairs=len(idx), kernel_ms=round(float(np.median(kms)), 4), wall_ms_python=round(wall * 1e3, 3),
+                        wall_over_kernel=round(wall * 1e3 / float(np.median(kms)), 2))
     res["search_by_bow"] = sb
     # SearchForTriangulation: one CreateNewMapPoints pass = the new KeyFrame against 16 neighbours, 2000 features a side
     tri = [bmc.make_triangulation_pair(60 + i, n1=2000, n2=2000, n_nodes=100, mask_frac=0.35) for i in range(16)]
@@ -135,6 +157,27 @@ def main(pairs=128, L=6):
         dt = (time.perf_counter() - t0) / len(batch)
         st[name] = dict(pairs=len(batch), kernel_ms=round(float(np.median(kms)), 4), wall_ms_python=round(wall * 1e3, 3),
                         matches_first=int(out[0][0]), cpu_oracle_ms_per_pair=round(dt * 1e3, 3))
+    for p in tri:
+        for k in ("desc1", "fv1", "kp1"):
+            p[k] = tri[0][k]
+    cur = st_store_add = None
+    store = msorb.KeyFrameStore()
+    cur = store.add(tri[0]["kp1"], tri[0]["desc1"], tri[0]["fv1"], sc8, sc8 * sc8)
+    nb = [store.add(p["kp2"], p["desc2"], p["fv2"], p["scale_factors2"], p["level_sigma2_2"]) for p in tri]
+    for name, idx in (("pair_resident", [0]), ("neighbours16_resident", list(range(16)))):
+        pr = [dict(kf1=cur, kf2=nb[i], valid1=tri[i]["valid1"], avail2=tri[i]["avail2"], stereo1=tri[i]["stereo1"],
+                   stereo2=tri[i]["stereo2"], F12=tri[i]["F12"], ep=tri[i]["ep"]) for i in idx]
+        store.search_for_triangulation(pr)
+        kms = [store.search_for_triangulation(pr)[1] for _ in range(10)]
+        t0 = time.perf_counter()
+        for _ in range(10):
+            out, _ = store.search_for_triangulation(pr)
+        wall = (time.perf_counter() - t0) / 10
+        ref, _ = msorb.search_for_triangulation([tri[i] for i in idx])
+        assert all(o[0] == r[0] and o[1].tolist() == r[1].tolist() for o, r in zip(out, ref))
+        st[name] = dict(pairs=len(idx), kernel_ms=round(float(np.median(kms)), 4), wall_ms_python=round(wall * 1e3, 3),
+                        wall_over_kernel=round(wall * 1e3 / float(np.median(kms)), 2))
+    store.close()
     res["search_for_triangulation"] = st
     print(json.dumps(res))
 

@@ -1,0 +1,37 @@
+"""Dense brute-force Hamming top-2 (msorb_hamming_dense_top2_batch) alone: Tpairs/s on the bench shape (128 frames, ~2000 x
+~2000 descriptors each) and a check of one frame against the CPU oracle.  usage: python tools/hamming_bench.py [frames]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "ms-slam_amd"), os.path.join(ROOT, "oracle")]
+import torch
+import msorb
+import orb_oracle
+
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+rng = np.random.default_rng(0)
+cap = 2024
+nq = rng.integers(1990, 2016, frames).astype(np.int32)
+nt = rng.integers(1990, 2016, frames).astype(np.int32)
+q = rng.integers(0, 256, (frames, cap, 32), dtype=np.uint8)
+t = rng.integers(0, 256, (frames, cap, 32), dtype=np.uint8)
+t[:, :1000] = q[:, :1000] ^ (rng.random((frames, 1000, 32)) < 0.03).astype(np.uint8)   # near copies: small distances, ties
+dq, dt = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
+dnq, dnt = torch.from_numpy(nq).cuda(), torch.from_numpy(nt).cuda()
+msorb.hamming_dense_top2_batch(dq, dt, dnq, dnt, repeats=3)
+reps = 30
+bi, bd, sd, ms = msorb.hamming_dense_top2_batch(dq, dt, dnq, dnt, repeats=reps)
+pairs = int((nq.astype(np.int64) * nt).sum())
+wi, wd, ws = orb_oracle.dense_top2(q[3, :nq[3]], t[3, :nt[3]])
+ok = (np.array_equal(wi, bi[3, :nq[3]].cpu().numpy()) and np.array_equal(wd, bd[3, :nq[3]].cpu().numpy()) and
+      np.array_equal(ws, sd[3, :nq[3]].cpu().numpy()))
+# integer-VALU ceiling of the inner loop (profiles/round1_valu_ubench.txt): 8 x v_xor_b32 at 2.5 + 8 x v_bcnt_u32_b32 at 4.2
+# cycles per wave-instruction, 64 pairs per wave-instruction, 1024 SIMDs at 2.4 GHz
+ceiling = 1024 * 2.4e9 * 64 / (8 * 2.5 + 8 * 4.2) / 1e9
+g = pairs * reps / (ms * 1e-3) / 1e9
+print(json.dumps({"gpairs_per_s": round(g, 1), "ms_per_launch": round(ms / reps, 4), "pairs_per_launch": pairs,
+                  "matches_oracle": bool(ok), "ceiling_gpairs_per_s": round(ceiling, 1), "frac_of_ceiling": round(g / ceiling, 3)}))
