@@ -179,6 +179,221 @@ __global__ __launch_bounds__(256) void pyr_resize_rows_kernel(LevelView src, Lev
     }
 }
 
+// SDWA forms the compiler does not pick by itself: a 24-bit multiply by one u16 half of a register, and the sum of two
+// registers' high halves.  Only source selects are used (a partial destination write would need wait states).
+__device__ __forceinline__ uint32_t sdwa_mul_lo(uint32_t b, uint32_t h) {
+    uint32_t r;
+    asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(b), "v"(h));
+    return r;
+}
+__device__ __forceinline__ uint32_t sdwa_mul_hi(uint32_t b, uint32_t h) {
+    uint32_t r;
+    asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(b), "v"(h));
+    return r;
+}
+__device__ __forceinline__ uint32_t sdwa_hi_sum(uint32_t x, uint32_t y) {   // (x >> 16) + (y >> 16)
+    uint32_t r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
+// Row-band variant (batches, scale factors up to 1.25): a wave produces R consecutive output rows of its 64 column groups in
+// two phases without any data-dependent control flow in between:
+//   A  all source rows the band touches (rows i0(dy0) .. i1(dy0 + R - 1): <= kSrc of them) are fetched with every load in
+//      flight at once, interpolated horizontally (v_perm + v_dot2_u32_u16 per pixel) and parked as 4 x u16 per lane
+//      in LDS — used only as storage a lane can index at run time: a lane reads back exactly what it wrote, so no
+//      barrier and no sharing;
+//   B  every output row reads its two parked rows by (wave-uniform) index and blends them with SDWA half-word operands.
+// The y taps of the band come in up front with the first loads.  Compared with pyr_resize_rows_kernel: no per-row wait for a
+// tap record, no register shuffling between "upper" and "lower" rows, 14 instead of 25 VALU lane-operations per pixel.
+template <int R, int kSrc>
+__global__ __launch_bounds__(256) void pyr_resize_band_kernel(LevelView src, LevelView dst, uint8_t* __restrict__ dst_base,
+                                                              const ResizeTap* __restrict__ tx,
+                                                              const ResizeTap* __restrict__ ty) {
+    __shared__ uint2 park[4][kSrc][64];
+    const int img = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int dy0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + wave) * R);
+    const int dx0 = (blockIdx.x * 64 + lane) * 4;
+    if (dy0 >= dst.h) return;   // wave-uniform
+    const int n_out = min(R, dst.h - dy0);
+    // y taps of the band (wave-uniform addresses: scalar loads)
+    uint32_t ti[R], tc[R];      // i0 | i1 << 16, c0 | c1 << 16
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const uint2 v = reinterpret_cast<const uint2*>(ty)[__builtin_amdgcn_readfirstlane(dy0 + min(k, n_out - 1))];
+        ti[k] = __builtin_amdgcn_readfirstlane(v.x);
+        tc[k] = __builtin_amdgcn_readfirstlane(v.y);
+    }
+    const int s_lo = (int)(ti[0] & 0xffffu);
+    int s_hi = s_lo;
+#pragma unroll
+    for (int k = 0; k < R; k++) s_hi = max(s_hi, (int)(ti[k] >> 16));
+    const int n_src = s_hi - s_lo + 1;   // <= kSrc (checked on the host)
+    const bool active = dx0 < dst.w;
+    // x taps of this column group -> byte selectors and weights (as pyr_resize_rows_kernel)
+    const int dxc = active ? dx0 : 0;
+    const uint4 ta = reinterpret_cast<const uint4*>(tx + dxc)[0];
+    const uint4 tb = reinterpret_cast<const uint4*>(tx + dxc)[1];
+    const uint32_t tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};  // per tap: {i0|i1<<16, c0|c1<<16}
+    const int base = (int)(tw[0] & 0xffffu) & ~3;  // aligned column of the first source pixel
+    // The 4 taps of a lane start within 5 source pixels of the first one (scale <= 1.25): two v_alignbyte bring the 12-byte
+    // window to "first tap at byte 0", then one v_perm per tap puts its two pixels into the u16 halves for v_dot2_u32_u16.
+    const uint32_t o0 = (tw[0] & 0xffffu) - (uint32_t)base;   // 0..3
+    uint32_t sel[4], cw[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t r = (tw[2 * i] & 0xffffu) - (uint32_t)base - o0;  // 0..5; at the right edge i1 == i0 and c1 == 0
+        sel[i] = r | (0x0cu << 8) | ((r + 1) << 16) | (0x0cu << 24);
+        cw[i] = tw[2 * i + 1];  // c0 | c1 << 16, both in [0, 2048]
+    }
+    const uint8_t* sb = src.base + (size_t)img * src.img_stride + (size_t)(uint32_t)base;
+    // phase A
+    uint32_t raw[kSrc][3];
+#pragma unroll
+    for (int r = 0; r < kSrc; r++) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(sb + (size_t)min(s_lo + r, s_hi) * src.pitch);
+        raw[r][0] = q[0]; raw[r][1] = q[1]; raw[r][2] = q[2];
+    }
+#pragma unroll
+    for (int r = 0; r < kSrc; r++) {
+        if (r < n_src) {   // wave-uniform
+            const uint32_t lo = __builtin_amdgcn_alignbyte(raw[r][1], raw[r][0], o0);
+            const uint32_t hi = __builtin_amdgcn_alignbyte(raw[r][2], raw[r][1], o0);
+            uint32_t H[4];   // (src[i0]*c0 + src[i1]*c1) >> 4 <= 32640
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                H[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(hi, lo, sel[i])),
+                                              __builtin_bit_cast(ushort2v, cw[i]), 0u, false) >> 4;
+            park[wave][r][lane] = uint2{H[0] | (H[1] << 16), H[2] | (H[3] << 16)};
+        }
+    }
+    // phase B: ((b0 * H0) >> 16) + ((b1 * H1) >> 16) + 2) >> 2 with the u16 halves picked by SDWA operand selects
+    uint8_t* d = dst_base + (size_t)img * dst.img_stride + (size_t)(uint32_t)dx0;
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        if (k < n_out) {   // wave-uniform
+            const int n0 = (int)(ti[k] & 0xffffu) - s_lo, n1 = (int)(ti[k] >> 16) - s_lo;
+            const uint32_t b0 = tc[k] & 0xffffu, b1 = tc[k] >> 16;
+            const uint2 A = park[wave][n0][lane], B = park[wave][n1][lane];
+            const uint32_t t0 = sdwa_hi_sum(sdwa_mul_lo(b0, A.x), sdwa_mul_lo(b1, B.x));
+            const uint32_t t1 = sdwa_hi_sum(sdwa_mul_hi(b0, A.x), sdwa_mul_hi(b1, B.x));
+            const uint32_t t2 = sdwa_hi_sum(sdwa_mul_lo(b0, A.y), sdwa_mul_lo(b1, B.y));
+            const uint32_t t3 = sdwa_hi_sum(sdwa_mul_hi(b0, A.y), sdwa_mul_hi(b1, B.y));
+            const ushort2v two = {2, 2};
+            const ushort2v p01 = (__builtin_bit_cast(ushort2v, t0 | (t1 << 16)) + two) >> 2;
+            const ushort2v p23 = (__builtin_bit_cast(ushort2v, t2 | (t3 << 16)) + two) >> 2;
+            const uint32_t packed = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p23), __builtin_bit_cast(uint32_t, p01), 0x06040200u);
+            if (active) *reinterpret_cast<uint32_t*>(d + (size_t)(dy0 + k) * dst.pitch) = packed;
+        }
+    }
+}
+
+// LDS-DMA form of the band kernel.  What limits pyr_resize_band_kernel is neither HBM nor VALU but the vector-memory
+// front end: a lane there asks for 12 bytes every 4.8 bytes, i.e. 768 requested bytes per 307 new ones, and the texture
+// addresser retires roughly 16 requested bytes per cycle and CU (tools/fetch_calib.hip: 3.3 TB/s for exactly this pattern
+// against 6.6 TB/s for 16 B/lane).  Here every source byte is requested once: the band's source rows come in as 16-byte
+// granules, 21 per row (336 B) and three rows per global_load_lds_dwordx4, straight into the wave's LDS slab; the lanes then
+// pick their 12-byte windows out of LDS.  From there on it is the band kernel (phase A -> parked u16 rows -> phase B).
+// Needs 16-byte aligned rows (base, pitch, image stride) and a horizontal scale <= 1.22 (the 64 windows of a wave must fit
+// 336 bytes); launch_pyr_resize falls back to the band kernel otherwise.
+template <int R>
+__global__ __launch_bounds__(256) void pyr_resize_dma_kernel(LevelView src, LevelView dst, uint8_t* __restrict__ dst_base,
+                                                             const ResizeTap* __restrict__ tx,
+                                                             const ResizeTap* __restrict__ ty) {
+    constexpr int kRowB = 336, kGran = kRowB / 16, kSrc = 12;   // 3 rows x 21 granules = 63 lanes per LDS-DMA instruction
+    __shared__ __attribute__((aligned(16))) uint8_t slab[4][kSrc * kRowB];
+    __shared__ uint2 park[4][kSrc][64];
+    const int img = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int dy0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + wave) * R);
+    const int dx0 = (blockIdx.x * 64 + lane) * 4;
+    if (dy0 >= dst.h) return;   // wave-uniform
+    const int n_out = min(R, dst.h - dy0);
+    uint32_t ti[R], tc[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const uint2 v = reinterpret_cast<const uint2*>(ty)[__builtin_amdgcn_readfirstlane(dy0 + min(k, n_out - 1))];
+        ti[k] = __builtin_amdgcn_readfirstlane(v.x);
+        tc[k] = __builtin_amdgcn_readfirstlane(v.y);
+    }
+    const int s_lo = (int)(ti[0] & 0xffffu);
+    int s_hi = s_lo;
+#pragma unroll
+    for (int k = 0; k < R; k++) s_hi = max(s_hi, (int)(ti[k] >> 16));
+    const int n_src = s_hi - s_lo + 1;   // <= kSrc (checked on the host)
+    const bool active = dx0 < dst.w;
+    const int dxc = active ? dx0 : 0;
+    const uint4 ta = reinterpret_cast<const uint4*>(tx + dxc)[0];
+    const uint4 tb = reinterpret_cast<const uint4*>(tx + dxc)[1];
+    const uint32_t tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+    const int base = (int)(tw[0] & 0xffffu) & ~3;
+    const int xg = __builtin_amdgcn_readfirstlane(base) & ~15;   // lane 0 (always active): first granule of the chunk
+    const uint32_t o0 = (tw[0] & 0xffffu) - (uint32_t)base;
+    uint32_t sel[4], cw[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t r = (tw[2 * i] & 0xffffu) - (uint32_t)base - o0;
+        sel[i] = r | (0x0cu << 8) | ((r + 1) << 16) | (0x0cu << 24);
+        cw[i] = tw[2 * i + 1];
+    }
+    // stage: lane -> (row within the group of three, granule); granules past the end of the row re-read its last one
+    {
+        const int row3 = (lane * 49) >> 10, col = lane - row3 * kGran;
+        const uint8_t* sb = src.base + (size_t)img * src.img_stride + (size_t)min(xg + col * 16, src.pitch - 16);
+#pragma unroll
+        for (int j = 0; j < kSrc / 3; j++) {
+            if (j < 3 || j * 3 < n_src) {   // wave-uniform; the first 9 rows are always requested (clamped rows are harmless)
+                const uint8_t* g = sb + (size_t)min(s_lo + j * 3 + row3, s_hi) * src.pitch;
+                if (lane < 63)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)&slab[wave][j * 3 * kRowB], 16, 0, 0);
+            }
+        }
+    }
+    const int woff = active ? base - xg : 0;   // this lane's window inside a staged row: 0 .. 324
+    // phase A
+#pragma unroll
+    for (int r = 0; r < kSrc; r++) {
+        if (r < 9 || r < n_src) {   // wave-uniform; rows 0..8 unconditionally, so that their LDS reads can be batched
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(&slab[wave][r * kRowB + woff]);
+            const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
+            const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, o0);
+            const uint32_t hi = __builtin_amdgcn_alignbyte(w2, w1, o0);
+            uint32_t H[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                H[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(hi, lo, sel[i])),
+                                              __builtin_bit_cast(ushort2v, cw[i]), 0u, false) >> 4;
+            park[wave][r][lane] = uint2{H[0] | (H[1] << 16), H[2] | (H[3] << 16)};
+        }
+    }
+    // phase B
+    uint8_t* d = dst_base + (size_t)img * dst.img_stride + (size_t)(uint32_t)dx0;
+    auto out_row = [&](int k) {
+        const int n0 = (int)(ti[k] & 0xffffu) - s_lo, n1 = (int)(ti[k] >> 16) - s_lo;
+        const uint32_t b0 = tc[k] & 0xffffu, b1 = tc[k] >> 16;
+        const uint2 A = park[wave][n0][lane], B = park[wave][n1][lane];
+        const uint32_t t0 = sdwa_hi_sum(sdwa_mul_lo(b0, A.x), sdwa_mul_lo(b1, B.x));
+        const uint32_t t1 = sdwa_hi_sum(sdwa_mul_hi(b0, A.x), sdwa_mul_hi(b1, B.x));
+        const uint32_t t2 = sdwa_hi_sum(sdwa_mul_lo(b0, A.y), sdwa_mul_lo(b1, B.y));
+        const uint32_t t3 = sdwa_hi_sum(sdwa_mul_hi(b0, A.y), sdwa_mul_hi(b1, B.y));
+        const ushort2v two = {2, 2};
+        const ushort2v p01 = (__builtin_bit_cast(ushort2v, t0 | (t1 << 16)) + two) >> 2;
+        const ushort2v p23 = (__builtin_bit_cast(ushort2v, t2 | (t3 << 16)) + two) >> 2;
+        const uint32_t packed = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p23), __builtin_bit_cast(uint32_t, p01), 0x06040200u);
+        if (active) *reinterpret_cast<uint32_t*>(d + (size_t)(dy0 + k) * dst.pitch) = packed;
+    };
+    if (n_out == R) {   // wave-uniform: every band but the last of an image
+#pragma unroll
+        for (int k = 0; k < R; k++) out_row(k);
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; k++)
+            if (k < n_out) out_row(k);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // FAST-9/16 on one reference cell ROI per workgroup (cell loop + cv::FAST, ORBextractor.cc:805-872).
 //   phase 0  stage the ROI (<= 76x76 bytes) in LDS, keeping the global 4-byte column phase so that every
@@ -1238,9 +1453,22 @@ void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_
     const bool aligned = (reinterpret_cast<uintptr_t>(src.base) & 3) == 0 && (src.pitch & 3) == 0 &&
                          (src.img_stride & 3) == 0 && src.pitch >= ((src.w + 3) & ~3) + 8 &&
                          (reinterpret_cast<uintptr_t>(tx) & 15) == 0;
-    constexpr int R = 8;  // rows per wave: 4 / 8 / 16 / 32 measure 0.247 / 0.237 / 0.244 / 0.285 ms per 256 KITTI images
-    static const bool rows_env = !getenv("MSORB_PYR_SINGLE");  // test aid
-    if (aligned && rows_env && n_images >= 16)
+    constexpr int R = 8;  // rows per wave
+    // test aids: MSORB_PYR_SINGLE -> one-row kernels, MSORB_PYR_ROWS -> row-streaming kernel, MSORB_PYR_BAND -> band kernel
+    const bool rows_env = !getenv("MSORB_PYR_SINGLE");
+    const bool band_env = !getenv("MSORB_PYR_ROWS");
+    const bool dma_env = !getenv("MSORB_PYR_BAND");
+    // the band kernels park the source rows of a band of R output rows: at most floor((R - 1) * scale) + 3 of them (<= 12),
+    // and decode the 4 taps of a lane out of an 8-byte window (horizontal scale <= 1.25)
+    const double sy = (double)src.h / (double)dst.h, sx = (double)src.w / (double)dst.w;
+    const bool band_ok = aligned && rows_env && band_env && n_images >= 16 && (int)std::floor((R - 1) * sy) + 3 <= 12 && sx <= 1.25;
+    // the LDS-DMA kernel stages 336-byte row segments as 16-byte granules: 16-byte aligned rows, 64 windows within 336 bytes
+    const bool dma_ok = band_ok && dma_env && (reinterpret_cast<uintptr_t>(src.base) & 15) == 0 && (src.pitch & 15) == 0 &&
+                        (src.img_stride & 15) == 0 && src.pitch >= 336 && 252.0 * sx + 28.0 <= 336.0;
+    const dim3 band_grid((dst.w + 255) / 256, (dst.h + 4 * R - 1) / (4 * R), n_images);
+    if (dma_ok) hipLaunchKernelGGL(pyr_resize_dma_kernel<R>, band_grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
+    else if (band_ok) hipLaunchKernelGGL((pyr_resize_band_kernel<R, 12>), band_grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
+    else if (aligned && rows_env && n_images >= 16)
         hipLaunchKernelGGL(pyr_resize_rows_kernel<R>, dim3((dst.w + 255) / 256, (dst.h + 4 * R - 1) / (4 * R), n_images), dim3(256),
                            0, s, src, dst, dst_base, tx, ty);
     else if (aligned) hipLaunchKernelGGL(pyr_resize_aligned_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);

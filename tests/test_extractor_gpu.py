@@ -184,6 +184,35 @@ def test_batch_kernels_full_size(msorb_mod, oracle, name):
     ex.close()
 
 
+@pytest.mark.parametrize("name", ["kitti", "euroc", "fourseasons", "odd"])
+@pytest.mark.parametrize("kernel", ["dma", "band", "rows"])
+def test_batch_pyramid_kernels_on_padded_rows(msorb_mod, oracle, monkeypatch, name, kernel):
+    """The three batch pyramid kernels (LDS-DMA band kernel = default on 16-byte aligned rows, register band kernel,
+    row-streaming kernel) on a batch whose rows are padded to a multiple of 64 bytes, as bench.py lays its images out:
+    every level of every distinct image is the oracle's cv::resize restatement, bit for bit."""
+    import torch
+    cfg = CONFIGS[name] if name != "odd" else dict(rows=333, cols=517, nfeatures=700, scale=1.2, nlevels=8, ini_th=20, min_th=7)
+    if kernel == "band":
+        monkeypatch.setenv("MSORB_PYR_BAND", "1")
+    elif kernel == "rows":
+        monkeypatch.setenv("MSORB_PYR_ROWS", "1")
+    ex, ref = _pair(msorb_mod, oracle, cfg)
+    n = 16
+    pitch = (cfg["cols"] + 63) // 64 * 64
+    batch = np.stack([synth.image(900 + (i % 3), cfg["rows"], cfg["cols"]) for i in range(n)])
+    store = torch.zeros((n, cfg["rows"], pitch), dtype=torch.uint8, device="cuda")
+    view = store[:, :, :cfg["cols"]]
+    view.copy_(torch.from_numpy(batch).cuda())
+    ex.set_overlap(1, False)
+    ex.pyramid_batch(view)
+    torch.cuda.synchronize()
+    for i in (0, 1, 2, n - 1):
+        ref(batch[i])
+        for lvl in range(1, cfg["nlevels"]):
+            assert np.array_equal(ex.debug_level(i, lvl), ref.level(lvl)), (kernel, i, lvl)
+    ex.close()
+
+
 def test_host_quadtree_mode_matches(msorb_mod, oracle, monkeypatch):
     """MSORB_QUADTREE=host keeps the selection on the host thread pool (orb_host.cc); same result."""
     monkeypatch.setenv("MSORB_QUADTREE", "host")

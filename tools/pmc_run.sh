@@ -5,7 +5,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$1; CTR=$2; SUB=$3; shift 4
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-( cd $R && rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $OUT -o p -- "$@" > $OUT/cmd.log 2>&1 )
+( cd $R && timeout -k 5 ${PMC_TIMEOUT:-240} rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $OUT -o p -- "$@" > $OUT/cmd.log 2>&1 )
+[ -n "$(find $OUT -name p_counter_collection.csv)" ] || { echo "no counters collected: see $OUT/cmd.log"; tail -3 $OUT/cmd.log | cut -c1-300; exit 1; }
 python - <<PY
 import csv,collections,glob
 f=glob.glob("$OUT/**/p_counter_collection.csv", recursive=True)[0]
