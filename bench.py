@@ -379,16 +379,22 @@ def main():
         achieved = alg_bytes / (stages[dom] * 1e-3) / 1e9 if stages[dom] > 0 else 0.0
         pf_bytes = (alg_per_image if dom in ("fast", "pyramid") else 0)
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the value is the
-        # committed rocprofv3 --pmc measurement of the same command (profiles/round1_pmc_summary.json, separate
-        # FETCH_SIZE / WRITE_SIZE passes, per launch) — only quoted when the batch shape matches
+        # committed rocprofv3 --pmc measurement of the same command (latest profiles/roundN_pmc_summary.json: separate
+        # FETCH_SIZE / WRITE_SIZE passes, per launch, FETCH_SIZE scaled by the calibration kernels of the same run) — only
+        # quoted when the batch shape matches
         traffic = None
-        kname = {"fast": "fast_cells_kernel<true, GeoSmall>", "pyramid": "pyr_resize_rows_kernel<8>", "blur": "gauss7_stream_kernel<35>",
+        kname = {"fast": "fast_cells_kernel<true, GeoSmall>", "pyramid": "pyr_resize_dma_kernel<8>", "blur": "gauss7_stream_kernel<35>",
                  "describe": "describe_kernel", "compact": "cand_gather_kernel"}[dom]
         valu_frac = None
+        pmc_file = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_summary.json")))["kernels"][kname]
+            import glob
+            pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_summary.json")))[-1]
+            summ = json.load(open(pmc_file))
+            pm = summ["kernels"][kname]
             if B == 128 and world == 1:
-                traffic = int((pm["FETCH_SIZE_KB"] + pm["WRITE_SIZE_KB"]) * 1024) * (7 if dom == "pyramid" else 1)
+                scale = summ.get("fetch_scale", 2.0)
+                traffic = int((pm["FETCH_SIZE_KB"] * scale + pm["WRITE_SIZE_KB"]) * 1024) * (7 if dom == "pyramid" else 1)
                 valu_frac = pm.get("valu_fraction_of_measured_peak")
         except Exception:
             traffic = None
@@ -415,13 +421,14 @@ def main():
             "stage_ms_per_step_overlapped": {k: round(v, 4) for k, v in stages_overlapped.items()},
             "stage_ms_per_step_overlapped_note": "timed region: sum over the 2 concurrent sub-batches of each stage's event "
                                                  "interval (intervals overlap, so the sum exceeds ms_per_step)",
-            "roofline": {"bound": "hbm", "kernel": {"fast": "fast_cells_kernel", "pyramid": "pyr_resize_kernel (x7)",
+            "roofline": {"bound": "hbm", "kernel": {"fast": "fast_cells_kernel", "pyramid": "pyr_resize_dma_kernel (x7)",
                                                     "blur": "gauss7_kernel (x8)", "describe": "describe_kernel",
                                                     "compact": "cand_*"}[dom],
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (profiles/round1_pmc_summary.json); "
-                                         "below the algorithmic bytes because the pyramid written just before is still in the 256 MB Infinity Cache",
+                         "traffic_note": "HBM bytes per launch from rocprofv3 --pmc: FETCH_SIZE x fetch_scale + WRITE_SIZE (" +
+                                         (os.path.basename(pmc_file) if pmc_file else "no committed PMC summary") + "); FETCH_SIZE reports "
+                                         "half of the bytes a coalesced stream reads on gfx950 (tools/fetch_calib.hip, same run), WRITE_SIZE is exact",
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "valu_fraction_of_measured_peak": valu_frac,
                          "valu_note": "what actually bounds this kernel: 64 x SQ_INSTS_VALU / duration against the 51.5 T lane-ops/s "

@@ -1,13 +1,22 @@
 #!/bin/bash
-# The full measurement run of a round, on the GPU box:  gpurun --timeout 1500 -- 'bash tools/round_run.sh'
-# then, back in the container:  python tools/collect_profiles.py round1   (copies the summaries into profiles/)
-python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-python bench.py > gpurun_out/bench_r1.json 2> gpurun_out/bench_r1.err; tail -c 600 gpurun_out/bench_r1.json
-tools/gpu_trace.sh prof_r1g > gpurun_out/trace_r1g.txt 2>&1; tail -25 gpurun_out/trace_r1g.txt
-tools/gpu_pmc.sh pmc_fetch "FETCH_SIZE" "" > gpurun_out/pmc_fetch.txt 2>&1
-tools/gpu_pmc.sh pmc_write "WRITE_SIZE" "" > gpurun_out/pmc_write.txt 2>&1
-tools/gpu_pmc.sh pmc_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE" "" > gpurun_out/pmc_valu.txt 2>&1
-python tools/latency_bench.py > gpurun_out/latency_r1.json 2>gpurun_out/latency_r1.err; cat gpurun_out/latency_r1.json
-python tools/bow_bench.py > gpurun_out/bow_bench.json 2>/dev/null; cat gpurun_out/bow_bench.json
-g++ -O2 -std=c++17 tools/latency_pair.cc -Iinclude -Lms-slam_amd -lmsorb -lpthread -o /tmp/latency_pair 2>/dev/null && LD_LIBRARY_PATH=ms-slam_amd:/opt/rocm/lib /tmp/latency_pair 300 > gpurun_out/latency_pair.json; cat gpurun_out/latency_pair.json
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/valu_ubench.hip -o /tmp/valu_ubench 2>/dev/null && /tmp/valu_ubench > gpurun_out/valu_ubench.txt; tail -3 gpurun_out/valu_ubench.txt
+# The full measurement run of a round, on the GPU box:  gpurun --timeout 2400 -- 'bash tools/round_run.sh'
+# then, back in the container:  python tools/collect_profiles.py round2   (copies the summaries into profiles/)
+# Every profiler pass runs under its own timeout: a counter set the hardware refuses leaves rocprofv3 waiting forever.
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; O=gpurun_out/round; rm -rf $O; mkdir -p $O
+python -m pytest tests -x -q -m gpu 2>&1 | tail -3 | tee $O/pytest_gpu.txt
+python bench.py > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.json
+python bench.py --unique-pairs 128 --steps 10 --warmup 2 --cpu-pairs 0 > $O/bench_unique128.json 2>/dev/null; tail -c 300 $O/bench_unique128.json
+timeout -k 5 300 tools/gpu_trace.sh round/trace > $O/trace.txt 2>&1; tail -30 $O/trace.txt
+PMC_TIMEOUT=300 tools/pmc_run.sh round/pmc_fetch "FETCH_SIZE" "" -- python bench.py --steps 2 --warmup 1 --cpu-pairs 0 --isolated > $O/pmc_fetch.txt 2>&1
+PMC_TIMEOUT=300 tools/pmc_run.sh round/pmc_write "WRITE_SIZE" "" -- python bench.py --steps 2 --warmup 1 --cpu-pairs 0 --isolated > $O/pmc_write.txt 2>&1
+PMC_TIMEOUT=300 tools/pmc_run.sh round/pmc_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE" "" -- python bench.py --steps 2 --warmup 1 --cpu-pairs 0 --isolated > $O/pmc_valu.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/fetch_calib.hip -o tools/_fetch_calib 2>/dev/null; tools/fetch_calib.sh > $O/fetch_calib.txt 2>&1; cat $O/fetch_calib.txt
+python tools/latency_bench.py > $O/latency.json 2> $O/latency.err; cat $O/latency.json
+python tools/bow_bench.py > $O/bow_bench.json 2>/dev/null; cat $O/bow_bench.json
+python tools/hamming_bench.py > $O/hamming_bench.txt 2>&1; tail -5 $O/hamming_bench.txt
+g++ -O2 -std=c++17 tools/latency_pair.cc -Iinclude -Lms-slam_amd -lmsorb -lpthread -o /tmp/latency_pair 2>/dev/null && LD_LIBRARY_PATH=ms-slam_amd:/opt/rocm/lib /tmp/latency_pair 300 > $O/latency_pair.json; cat $O/latency_pair.json
+g++ -O2 -std=c++17 -Itests/cv_stub -Ims-slam_amd/host -Iinclude tools/latency_class.cc ms-slam_amd/host/ORBextractor.cc -Lms-slam_amd -lmsorb -lpthread -o /tmp/latency_class 2>$O/latency_class.err && {
+  LD_LIBRARY_PATH=ms-slam_amd:/opt/rocm/lib /tmp/latency_class 300 > $O/latency_class_on.json
+  MSORB_HOST_PYRAMID=0 LD_LIBRARY_PATH=ms-slam_amd:/opt/rocm/lib /tmp/latency_class 300 > $O/latency_class_off.json; cat $O/latency_class_on.json $O/latency_class_off.json; }
+g++ -O2 -std=c++17 tools/kf_store_bench.cc -Iinclude -Lms-slam_amd -lmsorb -lpthread -o /tmp/kf_store_bench 2>$O/kf_store.err && LD_LIBRARY_PATH=ms-slam_amd:/opt/rocm/lib /tmp/kf_store_bench > $O/kf_store_bench.json; cat $O/kf_store_bench.json
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/valu_ubench.hip -o /tmp/valu_ubench 2>/dev/null && /tmp/valu_ubench > $O/valu_ubench.txt; tail -3 $O/valu_ubench.txt
