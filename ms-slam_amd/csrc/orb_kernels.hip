@@ -1010,17 +1010,117 @@ __global__ __launch_bounds__(256) void gauss7_kernel(PyramidView src, PyramidVie
 // of the next seven rows are in flight while the current seven are accumulated.  Lanes 0 and 63 of a wave only provide
 // halo bytes: a wave stores 62 four-pixel groups per row.
 constexpr int kGaussLanesOut = 62;
+// One strip of the streaming blur.  EDGE = the column block holds the group at x0 == 0 or the right border (reflect-101
+// fix-ups by byte permutation); the common interior blocks are compiled without them (a block-uniform `if` inside the row
+// loop is if-converted into per-row v_cndmask work by the compiler, so the two cases are separate instantiations).
+// Per row and lane: 2 DPP moves (neighbour dwords), 10 v_dot4 (the 7 taps of the 4 pixels against the three dwords
+// {w0,w1,w2} with the kernel shifted inside the constants: no v_alignbyte), 4 v_cvt, 28 exact fp32 FMAs as 14 v_pk_fma_f32,
+// and for the output row 4 FMAs + 3 v_perm.  Rounding without a conversion: the accumulator is opened with the +32768 of
+// (acc + 32768) >> 16 already in it, and under round-toward-zero fma(acc, 2^-16, 2^23) = 2^23 + floor(acc / 65536) exactly
+// (0 <= acc < 2^24: every product and partial sum is an integer below 2^24, all other FMAs are exact in any rounding
+// mode): the result byte is the low byte of the float's bit pattern.
+template <int ROWS, bool EDGE>
+__device__ __forceinline__ void gauss7_strip(const uint8_t* __restrict__ sb, uint8_t* __restrict__ db, int src_pitch, int dst_pitch,
+                                             int h, int y0, uint32_t xl, int x0, bool store, uint32_t sel_w1, uint32_t sel_w2a,
+                                             uint32_t sel_w2b) {
+    auto load_row = [&](int r) {  // input row r of the strip = image row y0 - 3 + r (reflect-101, then clamped)
+        int yy = refl101(y0 - 3 + r, h);
+        yy = min(max(yy, 0), h - 1);
+        return *reinterpret_cast<const uint32_t*>(sb + (uint32_t)yy * (uint32_t)src_pitch + xl);   // a level plane of one image is < 4 GB
+    };
+    // taps k = {18,34,48,56,48,34,18}; window bytes 0..11 = {w0,w1,w2}; pixel j (byte 4 + j) = sum_t k[t] * B[1 + j + t]
+    constexpr uint32_t k0 = 18, k1 = 34, k2 = 48, k3 = 56;
+    constexpr uint32_t A0 = (k0 << 8) | (k1 << 16) | (k2 << 24), B0 = k3 | (k2 << 8) | (k1 << 16) | (k0 << 24);                 // j = 0
+    constexpr uint32_t A1 = (k0 << 16) | (k1 << 24), B1 = k2 | (k3 << 8) | (k2 << 16) | (k1 << 24), C1 = k0;                    // j = 1
+    constexpr uint32_t A2 = (k0 << 24), B2 = k1 | (k2 << 8) | (k3 << 16) | (k2 << 24), C2 = k1 | (k0 << 8);                     // j = 2
+    constexpr uint32_t B3 = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), C3 = k2 | (k1 << 8) | (k0 << 16);                         // j = 3
+    auto row_sums = [&](uint32_t w1, float hf[4]) {
+        // bound_ctrl: lanes without a source (0 for wave_shr, 63 for wave_shl) read 0 — they only provide halo bytes
+        uint32_t w0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+        uint32_t w2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+        if (EDGE) {
+            if (x0 == 0) w0 = __builtin_amdgcn_perm(0u, w1, 0x01020300u);  // p[-1..-3] = p[1..3]
+            // right border: identity selectors in the lanes that need no fix
+            const uint32_t n2 = __builtin_amdgcn_perm(w1, w0, sel_w2a) | __builtin_amdgcn_perm(0u, w2, sel_w2b);
+            w1 = __builtin_amdgcn_perm(w1, w0, sel_w1);
+            w2 = n2;
+        }
+        const uint32_t h0 = __builtin_amdgcn_udot4(w1, B0, __builtin_amdgcn_udot4(w0, A0, 0u, false), false);
+        const uint32_t h1 = __builtin_amdgcn_udot4(w2, C1, __builtin_amdgcn_udot4(w1, B1, __builtin_amdgcn_udot4(w0, A1, 0u, false), false), false);
+        const uint32_t h2 = __builtin_amdgcn_udot4(w2, C2, __builtin_amdgcn_udot4(w1, B2, __builtin_amdgcn_udot4(w0, A2, 0u, false), false), false);
+        const uint32_t h3 = __builtin_amdgcn_udot4(w2, C3, __builtin_amdgcn_udot4(w1, B3, 0u, false), false);
+        hf[0] = (float)h0; hf[1] = (float)h1; hf[2] = (float)h2; hf[3] = (float)h3;
+    };
+    constexpr float Kf[7] = {18.f, 34.f, 48.f, 56.f, 48.f, 34.f, 18.f};
+    float acc[7][4];
+    float hf[4];
+    uint32_t warm[6], nxt[7];
+#pragma unroll
+    for (int r = 0; r < 6; r++) warm[r] = load_row(r);
+#pragma unroll
+    for (int u = 0; u < 7; u++) nxt[u] = load_row(6 + u);
+    // warm-up: input rows 0..5 open accumulators 0..5
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        row_sums(warm[r], hf);
+#pragma unroll
+        for (int t = 0; t <= r; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[r - t][j] = __fmaf_rn(Kf[t], hf[j], t == 0 ? 32768.0f : acc[r - t][j]);
+    }
+    // steady state: input row r = 6 + 7*it + u completes output row o = r - 6 and opens accumulator r % 7
+    for (int it = 0; it < ROWS / 7; it++) {
+        uint32_t cur[7];
+#pragma unroll
+        for (int u = 0; u < 7; u++) cur[u] = nxt[u];
+        if (it + 1 < ROWS / 7) {
+#pragma unroll
+            for (int u = 0; u < 7; u++) nxt[u] = load_row(6 + 7 * (it + 1) + u);
+        }
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            const int r = 6 + 7 * it + u;
+            row_sums(cur[u], hf);
+#pragma unroll
+            for (int t = 0; t < 7; t++) {
+                const int a = (6 + u - t) % 7;  // == (r - t) % 7
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[a][j] = __fmaf_rn(Kf[t], hf[j], t == 0 ? 32768.0f : acc[a][j]);
+            }
+            const int o = r - 6, a = u % 7;  // (r - 6) % 7 == u
+            if (y0 + o < h) {   // wave-uniform
+                uint32_t q[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) q[j] = __float_as_uint(__fmaf_rn(acc[a][j], 1.0f / 65536.0f, 8388608.0f));   // RTZ (see above)
+                const uint32_t packed = __builtin_amdgcn_perm(__builtin_amdgcn_perm(q[3], q[2], 0x0c0c0400u),
+                                                              __builtin_amdgcn_perm(q[1], q[0], 0x0c0c0400u), 0x05040100u);
+                if (store) *reinterpret_cast<uint32_t*>(db + (uint32_t)(y0 + o) * (uint32_t)dst_pitch + (uint32_t)x0) = packed;
+            }
+        }
+    }
+}
+
 template <int ROWS>
-__global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, PyramidView dst, BlurPlan plan) {
+__global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, PyramidView dst, BlurPlan plan, int per_xcd,
+                                                            int total_blocks) {
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (private L2 each).  A wave-row reads 256 bytes that
+    // start 4 bytes before a multiple of 248, i.e. three 128-byte lines of which the outer two are shared with the
+    // neighbouring column blocks; giving every XCD one contiguous run of (image, block) pairs keeps those neighbours —
+    // and the strips above / below — on one L2 (FETCH_SIZE 334 -> 242 MB per launch).
+    const int tile = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+    if (tile >= total_blocks) return;
+    const int blocks_per_image = plan.block_begin[plan.nlevels];
+    const int img = tile / blocks_per_image, blk = tile - img * blocks_per_image;
     int level = 0;
-    while (level + 1 < plan.nlevels && (int)blockIdx.x >= plan.block_begin[level + 1]) level++;
-    const int rem = blockIdx.x - plan.block_begin[level];
+    while (level + 1 < plan.nlevels && blk >= plan.block_begin[level + 1]) level++;
+    const int rem = blk - plan.block_begin[level];
     const int bx = rem % plan.bx_count[level], by = rem / plan.bx_count[level];
     const LevelView sv = src.lv[level], dv = dst.lv[level];
-    const int img = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int x0 = (bx * kGaussLanesOut + lane - 1) * 4;
-    const int y0 = (by * 4 + (int)(threadIdx.x >> 6)) * ROWS;
+    // the wave index through readfirstlane: everything derived from y0 (row reflection, row offsets, the row bound of the
+    // stores) is then scalar work
+    const int y0 = (by * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * ROWS;
     if (y0 >= sv.h) return;  // wave-uniform
     const bool store = lane >= 1 && lane <= kGaussLanesOut && x0 < sv.w;  // lanes 0 / 63 and lanes past the row: halo only
     // Right border (reflect-101): a group with x0 + 7 > w needs pixels beyond column w-1.  Their mirror images
@@ -1045,84 +1145,11 @@ __global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, Pyr
     const uint32_t xl = (uint32_t)min(max(x0, 0), sv.pitch - 4);
     const uint8_t* sb = sv.base + (size_t)img * sv.img_stride;
     uint8_t* db = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride;
-    auto load_row = [&](int r) {  // input row r of the strip = image row y0 - 3 + r (reflect-101, then clamped)
-        int yy = refl101(y0 - 3 + r, sv.h);
-        yy = min(max(yy, 0), sv.h - 1);
-        return *reinterpret_cast<const uint32_t*>(sb + (size_t)yy * sv.pitch + (size_t)xl);
-    };
-    auto row_sums = [&](uint32_t w1, uint32_t hs[4]) {
-        uint32_t w0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-        uint32_t w2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-        if (bx == 0) {  // block-uniform: only the first column block holds the group at x0 == 0
-            if (x0 == 0) w0 = __builtin_amdgcn_perm(0u, w1, 0x01020300u);  // p[-1..-3] = p[1..3]
-        }
-        if (border_block) {  // block-uniform; identity selectors in the lanes that need no fix
-            const uint32_t n2 = __builtin_amdgcn_perm(w1, w0, sel_w2a) | __builtin_amdgcn_perm(0u, w2, sel_w2b);
-            w1 = __builtin_amdgcn_perm(w1, w0, sel_w1);
-            w2 = n2;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t a = j == 3 ? w1 : __builtin_amdgcn_alignbyte(w1, w0, j + 1);
-            const uint32_t b = j == 3 ? w2 : __builtin_amdgcn_alignbyte(w2, w1, j + 1);
-            hs[j] = __builtin_amdgcn_udot4(b, kGaussHi, __builtin_amdgcn_udot4(a, kGaussLo, 0u, false), false);
-        }
-    };
-    // The vertical pass runs in fp32: every product and partial sum is an integer below 2^24 (<= 256 * 255 * 256), so
-    // v_fma_f32 is exact — and on gfx950 it issues at the fast VALU rate (2.5 cycles per wave-instruction) while the
-    // integer v_mad_u32_u24 takes 4.4 (micro-benchmark of this round).
-    constexpr float Kf[7] = {18.f, 34.f, 48.f, 56.f, 48.f, 34.f, 18.f};
-    float acc[7][4];
-    uint32_t hs[4];
-    uint32_t warm[6], nxt[7];
-#pragma unroll
-    for (int r = 0; r < 6; r++) warm[r] = load_row(r);
-#pragma unroll
-    for (int u = 0; u < 7; u++) nxt[u] = load_row(6 + u);
-    // warm-up: input rows 0..5 open accumulators 0..5
-#pragma unroll
-    for (int r = 0; r < 6; r++) {
-        row_sums(warm[r], hs);
-        float hf[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) hf[j] = (float)hs[j];
-#pragma unroll
-        for (int t = 0; t <= r; t++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[r - t][j] = t == 0 ? __fmul_rn(Kf[0], hf[j]) : __fmaf_rn(Kf[t], hf[j], acc[r - t][j]);
-    }
-    // steady state: input row r = 6 + 7*it + u completes output row o = r - 6 and opens accumulator r % 7
-    for (int it = 0; it < ROWS / 7; it++) {
-        uint32_t cur[7];
-#pragma unroll
-        for (int u = 0; u < 7; u++) cur[u] = nxt[u];
-        if (it + 1 < ROWS / 7) {
-#pragma unroll
-            for (int u = 0; u < 7; u++) nxt[u] = load_row(6 + 7 * (it + 1) + u);
-        }
-#pragma unroll
-        for (int u = 0; u < 7; u++) {
-            const int r = 6 + 7 * it + u;
-            row_sums(cur[u], hs);
-            float hf[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) hf[j] = (float)hs[j];
-#pragma unroll
-            for (int t = 0; t < 7; t++) {
-                const int a = (6 + u - t) % 7;  // == (r - t) % 7
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[a][j] = t == 0 ? __fmul_rn(Kf[0], hf[j]) : __fmaf_rn(Kf[t], hf[j], acc[a][j]);
-            }
-            const int o = r - 6, a = u % 7;  // (r - 6) % 7 == u
-            if (store && y0 + o < sv.h) {
-                uint32_t packed = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++)  // (acc + 32768) >> 16 == trunc(acc * 2^-16 + 0.5): exact in fp32, acc < 2^24
-                    packed |= (uint32_t)__fmaf_rn(acc[a][j], 1.0f / 65536.0f, 0.5f) << (8 * j);
-                *reinterpret_cast<uint32_t*>(db + (size_t)(y0 + o) * dv.pitch + (size_t)(uint32_t)x0) = packed;
-            }
-        }
-    }
+    __builtin_amdgcn_s_setreg(0x801 /* hwreg(HW_REG_MODE, 0, 2): FP32 rounding */, 3 /* toward zero */);
+    if (border_block || bx == 0)   // block-uniform
+        gauss7_strip<ROWS, true>(sb, db, sv.pitch, dv.pitch, sv.h, y0, xl, x0, store, sel_w1, sel_w2a, sel_w2b);
+    else
+        gauss7_strip<ROWS, false>(sb, db, sv.pitch, dv.pitch, sv.h, y0, xl, x0, store, sel_w1, sel_w2a, sel_w2b);
 }
 
 // Right-border column groups (x0 + 16 > w: at most four groups = 16 columns per row): per-byte reflect-101 gather.
@@ -1531,7 +1558,10 @@ void launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images,
         max_h = max(max_h, v.h);
     }
     plan.block_begin[src.nlevels] = total;
-    if (stream) hipLaunchKernelGGL(gauss7_stream_kernel<kGaussRows>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
+    if (stream) {
+        const int all = total * n_images, per_xcd = (all + 7) / 8;
+        hipLaunchKernelGGL(gauss7_stream_kernel<kGaussRows>, dim3(per_xcd * 8), dim3(256), 0, s, src, dst, plan, per_xcd, all);
+    }
     else if (aligned) hipLaunchKernelGGL(gauss7_kernel<true>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
     else hipLaunchKernelGGL(gauss7_kernel<false>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
     if (!stream)  // the streaming kernel handles the right border itself
