@@ -638,6 +638,127 @@ __global__ __launch_bounds__(256 * kDenseSplit) void dense_top2_kernel(const uin
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same dense top-2 on the matrix cores.  A Hamming distance is a dot product in disguise: with train bits encoded as
+// +-32 and query bits as -+32 (int8), sum_k a_k * b_k = 1024 * (2 d - 256), so
+//     v_mfma_i32_32x32x32_i8 x 8 (K = 256 bits)  with  C = 262144 + train index   gives   acc = 2048 * d + train index,
+// i.e. the MFMA accumulator IS the key (d << 11 | j) the top-2 bookkeeping orders by — 8 x 8 xor / popcount VALU
+// instructions per 64 pairs become 8 MFMAs per 1024 pairs, and the VALU is left with v_med3 + v_min per pair.
+//   A operand = 32 trains (rows), B operand = 32 queries (columns): a lane owns query column (lane & 31) and sees the 16 train
+//   rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) of every 32 x 32 tile, so its top-2 update is sequential over its registers;
+//   lanes l and l + 32 are merged at the end.  Both operands use the same lane -> (row / column, k-group) rule, so the k order
+//   inside the instruction does not matter.
+//   Workgroup = 16 waves x 64 queries (two 32-query B fragments per wave, expanded once into 64 VGPRs); the frame's raw train
+//   descriptors are staged in LDS (64 KB), and per tile of 32 trains the workgroup expands 1 KB of bits into the 8 KB A
+//   fragment image (thread t writes exactly the 16 bytes lane t & 63 reads for k-step t >> 6), double buffered.
+constexpr int kMfmaWaves = 16, kMfmaThreads = kMfmaWaves * 64, kMfmaQPerWave = 64;
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// 4 bits -> 4 int8: pair = value for a clear bit | value for a set bit << 8; three instructions (mul24, and, perm)
+__device__ __forceinline__ uint32_t expand4(uint32_t nib, uint32_t pair) {
+    const uint32_t sp = __umul24(nib, 0x00204081u) & 0x01010101u;   // bit k of the nibble -> byte k = 0 / 1 (no collisions, no carries)
+    return __builtin_amdgcn_perm(0u, pair, sp);                     // byte k = pair.byte[sp.byte[k]]
+}
+constexpr uint32_t kTrainPair = 0xE0u | (0x20u << 8);   // train bits: clear = -32, set = +32
+constexpr uint32_t kQueryPair = 0x20u | (0xE0u << 8);   // query bits negated: clear = +32, set = -32
+__device__ __forceinline__ v4i expand16(uint32_t bits, uint32_t pair) {
+    v4i r;
+    r.x = (int)expand4(bits & 15u, pair); r.y = (int)expand4((bits >> 4) & 15u, pair);
+    r.z = (int)expand4((bits >> 8) & 15u, pair); r.w = (int)expand4((bits >> 12) & 15u, pair);
+    return r;
+}
+
+__global__ __launch_bounds__(kMfmaThreads) void dense_top2_mfma_kernel(const uint8_t* __restrict__ q, const uint8_t* __restrict__ t,
+                                                                       const int* __restrict__ n_q, const int* __restrict__ n_t,
+                                                                       int q_stride, int t_stride, int* __restrict__ best_idx,
+                                                                       int* __restrict__ best_dist, int* __restrict__ second_dist) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* raw = smem;                                       // nt x 32 B (<= 64 KB)
+    uint4* frag = reinterpret_cast<uint4*>(smem + kDenseMaxTrain * 32);   // 2 x 512 x 16 B
+    const int frame = blockIdx.y;
+    const int nq = n_q[frame], nt = min(n_t[frame], kDenseMaxTrain);
+    const int q0 = blockIdx.x * (kMfmaWaves * kMfmaQPerWave);
+    if (q0 >= nq) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    {   // stage the raw train descriptors
+        const uint4* ts = reinterpret_cast<const uint4*>(t + (size_t)frame * t_stride * 32);
+        uint4* rs = reinterpret_cast<uint4*>(raw);
+        for (int i = tid; i < nt * 2; i += kMfmaThreads) rs[i] = ts[i];
+    }
+    // B fragments: query column (lane & 31) of the wave's two 32-query blocks, k-group lane >> 5: bits [32 s + 16 g, +16)
+    v4i bq[2][8];
+#pragma unroll
+    for (int blk = 0; blk < 2; blk++) {
+        const int qi = min(q0 + wave * kMfmaQPerWave + blk * 32 + (lane & 31), nq - 1);
+        const uint16_t* qp = reinterpret_cast<const uint16_t*>(q + ((size_t)frame * q_stride + qi) * 32);
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) bq[blk][s8] = expand16(qp[2 * s8 + (lane >> 5)], kQueryPair);
+    }
+    const int n_tiles = (nt + 31) / 32;
+    // the expansion item of this thread: item = tid & 511 -> (k-step item >> 6, lane item & 63 -> train row item & 31,
+    // k-group (item >> 5) & 1); threads 512.. take the upper two dwords of the same item
+    const int item = tid & 511, half = tid >> 9;
+    const int e_row = item & 31, e_byte = 4 * (item >> 6) + 2 * ((item >> 5) & 1);
+    auto expand_tile = [&](int tile, int buf) {
+        const int tr = min(tile * 32 + e_row, nt - 1);   // rows past the end: any data, their keys are forced high below
+        const uint32_t bits = *reinterpret_cast<const uint16_t*>(raw + tr * 32 + e_byte) >> (8 * half);
+        uint2 v;
+        v.x = expand4(bits & 15u, kTrainPair); v.y = expand4((bits >> 4) & 15u, kTrainPair);
+        reinterpret_cast<uint2*>(frag + buf * 512 + item)[half] = v;
+    };
+    __syncthreads();
+    if (n_tiles > 0) expand_tile(0, 0);
+    __syncthreads();
+    // C operand: 262144 + global train index of accumulator register r in this lane; rows past nt get a key no real pair reaches
+    v16i cinit;
+#pragma unroll
+    for (int r = 0; r < 16; r++) cinit[r] = 262144 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    int k0[2] = {0x7FFFFFFF, 0x7FFFFFFF}, k1[2] = {0x7FFFFFFF, 0x7FFFFFFF};
+    for (int tile = 0; tile < n_tiles; tile++) {
+        const int buf = tile & 1;
+        if (tile + 1 < n_tiles) expand_tile(tile + 1, buf ^ 1);
+        v16i c = cinit;
+        if (tile == n_tiles - 1) {   // block-uniform: the last tile may be partial
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                if (cinit[r] - 262144 >= nt) c[r] = 0x40000000;
+        }
+        const uint4* fr = frag + buf * 512 + lane;
+        v16i acc0 = c, acc1 = c;
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) {
+            const uint4 av = fr[s8 * 64];
+            const v4i a = {(int)av.x, (int)av.y, (int)av.z, (int)av.w};
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][s8], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][s8], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {   // (k0 <= k1) + key -> the two smallest: second = median of the three
+            k1[0] = min(max(k0[0], k1[0]), max(min(k0[0], k1[0]), acc0[r])); k0[0] = min(k0[0], acc0[r]);
+            k1[1] = min(max(k0[1], k1[1]), max(min(k0[1], k1[1]), acc1[r])); k0[1] = min(k0[1], acc1[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) cinit[r] += 32;
+        __syncthreads();   // tile + 1 is expanded, and everyone is done reading buffer `buf`
+    }
+    // merge the two halves of the wave (same query, complementary train rows); keys are unique
+#pragma unroll
+    for (int blk = 0; blk < 2; blk++) {
+        const int o0 = __shfl_xor(k0[blk], 32), o1 = __shfl_xor(k1[blk], 32);
+        const int lo = min(k0[blk], o0), hi = max(k0[blk], o0);
+        k1[blk] = min(hi, min(k1[blk], o1));
+        k0[blk] = lo;
+        const int qi = q0 + wave * kMfmaQPerWave + blk * 32 + (lane & 31);
+        if (lane < 32 && qi < nq) {
+            const size_t o = (size_t)frame * q_stride + qi;
+            best_idx[o] = k0[blk] >= 0x40000000 ? -1 : (k0[blk] & 2047);
+            best_dist[o] = k0[blk] >= 0x40000000 ? 256 : (k0[blk] >> 11);
+            second_dist[o] = k1[blk] >= 0x40000000 ? 256 : (k1[blk] >> 11);
+        }
+    }
+}
+
 template <int QPL, int SPLIT>
 static void launch_dense_variant(const uint8_t* q, const uint8_t* t, const int* n_q, const int* n_t, int n_frames, int q_stride,
                                  int t_stride, int max_q, int max_t, int* bi, int* bd, int* sd, hipStream_t s) {
@@ -650,7 +771,13 @@ static void launch_dense_variant(const uint8_t* q, const uint8_t* t, const int* 
 void launch_dense_top2(const uint8_t* q, const uint8_t* t, const int* n_q, const int* n_t, int n_frames, int q_stride,
                        int t_stride, int max_q, int max_t, int* bi, int* bd, int* sd, hipStream_t s) {
     if (n_frames <= 0 || max_q <= 0) return;
-    static const int variant = getenv("MSORB_DENSE_VARIANT") ? atoi(getenv("MSORB_DENSE_VARIANT")) : 24;  // tuning aid: QPL*10 + SPLIT
+    const int variant = getenv("MSORB_DENSE_VARIANT") ? atoi(getenv("MSORB_DENSE_VARIANT")) : 0;  // test / tuning aid: QPL*10 + SPLIT = VALU kernels
+    if (variant == 0) {   // default: matrix cores
+        const int per_block = kMfmaWaves * kMfmaQPerWave;
+        hipLaunchKernelGGL(dense_top2_mfma_kernel, dim3((max_q + per_block - 1) / per_block, n_frames), dim3(kMfmaThreads),
+                           (size_t)kDenseMaxTrain * 32 + 2 * 512 * 16, s, q, t, n_q, n_t, q_stride, t_stride, bi, bd, sd);
+        return;
+    }
     // measured on MI355X (128 frames x 2000 x 2000): 2,1 1.54  2,2 1.65  2,4 1.72  4,2 1.68  4,4 1.73  1,4 1.57 Tpairs/s
 #define MSORB_DENSE(Q, S) launch_dense_variant<Q, S>(q, t, n_q, n_t, n_frames, q_stride, t_stride, max_q, max_t, bi, bd, sd, s)
     switch (variant) {

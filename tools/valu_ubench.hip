@@ -58,10 +58,12 @@ KERNEL(k_bfe, BFE) KERNEL(k_lshlor, LSHLOR) KERNEL(k_andor, ANDOR) KERNEL(k_cnd,
 #define RNDNE(i) "v_rndne_f32 %" #i ", %" #i "\n"
 #define MULF(i) "v_mul_f32 %" #i ", %" #i ", %8\n"
 #define FMA64(i) ""
+#define PKMUL24(i) "v_mul_u32_u24_sdwa %" #i ", %8, %" #i " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+#define LERP(i) "v_lerp_u8 %" #i ", %" #i ", %8, %9\n"
 KERNEL(k_and, AND) KERNEL(k_lshr, LSHR) KERNEL(k_lshrv, LSHRV) KERNEL(k_lshl, LSHL) KERNEL(k_mini, MINI) KERNEL(k_maxu, MAXU) KERNEL(k_sub, SUB)
 KERNEL(k_mul24, MUL24) KERNEL(k_mov, MOV) KERNEL(k_add3, ADD3) KERNEL(k_cmp, CMP) KERNEL(k_cnds, CNDS) KERNEL(k_cnde, CNDE) KERNEL(k_med3, MED3)
 KERNEL(k_dpp, DPP) KERNEL(k_adddpp, ADDDPP) KERNEL(k_pkadd, PKADD) KERNEL(k_max3, MAX3) KERNEL(k_xad, XAD) KERNEL(k_cvtf, CVTF)
-KERNEL(k_rndne, RNDNE) KERNEL(k_mulf, MULF)
+KERNEL(k_rndne, RNDNE) KERNEL(k_mulf, MULF) KERNEL(k_mul24sdwa, PKMUL24) KERNEL(k_lerp, LERP)
 typedef void (*kern_t)(uint32_t*, int);
 static void run(const char* name, kern_t k) {
     static uint32_t* d = nullptr;
@@ -86,6 +88,7 @@ int main() {
     run("v_perm_b32", k_perm); run("v_alignbyte_b32", k_alignb); run("v_sad_u8", k_sad); run("v_dot4_u32_u8", k_dot4); run("v_dot2_u32_u16", k_dot2);
     run("v_pk_add_u16", k_pkadd); run("v_pk_sub_i16", k_pksub); run("v_pk_min_i16", k_pkmin); run("v_cvt_f32_i32", k_cvtf); run("v_rndne_f32", k_rndne);
     run("v_cmp_lt_i32", k_cmp); run("v_cndmask sgpr", k_cnds); run("v_mov_dpp", k_dpp); run("v_add_dpp", k_adddpp);
+    run("v_mul_u32_u24_sdwa", k_mul24sdwa); run("v_lerp_u8", k_lerp);
     printf("-- outlier (unexplained; vcc not written in the loop) --\n");
     run("v_cndmask_e32 vcc", k_cnde);
     return 0;
