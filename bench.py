@@ -317,18 +317,24 @@ def main():
         reps = 20
         _, _, _, ms = msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=reps, device=local)
         pairs = int((counts_h[0::2].astype(np.int64) * counts_h[1::2].astype(np.int64)).sum())
-        # integer-ALU ceiling of the pair loop: per pair 8 x v_xor_b32 + 8 x v_bcnt_u32_b32 (accumulating); the
-        # VALU micro-benchmark (profiles/round1_valu_ubench.txt) gives 2.5 and 4.2 cycles per wave-instruction, 64 pairs per
-        # wave-instruction, 1024 SIMDs at 2.4 GHz.  The top-2 bookkeeping (key build + v_med3 + v_min, 3 more slow-class
-        # instructions per pair) lowers what this kernel can reach to the second figure.
+        # The kernel runs on the matrix cores (matcher.hip dense_top2_mfma_kernel): +-32 int8 encoding, 8 x v_mfma_i32_32x32x32_i8 per
+        # 32 x 32 pairs = 512 int8 operations per pair.  Ceiling = the i8 MFMA rate this chip sustains with nothing else running
+        # (4.3 POPS: 37.5 cycles@2.4GHz per instruction and SIMD, tools/valu_ubench.hip's MFMA companion in DESIGN.md section 4).
+        # For reference the integer-VALU formulation (8 x v_xor at 2.5 cycles + 8 x accumulating v_bcnt at 4.2 per 64 pairs, +
+        # 3 slow-class instructions of top-2 bookkeeping) tops out at the two VALU figures; round 1's kernel reached 1.5-1.7 Tpairs/s.
         g = pairs * reps / (ms * 1e-3) / 1e9
-        ceil_dist = 1024 * 2.4e9 * 64 / (8 * 2.5 + 8 * 4.2) / 1e9
-        ceil_top2 = 1024 * 2.4e9 * 64 / (8 * 2.5 + 11 * 4.2) / 1e9
+        mfma_pops = 4.3e15
+        ceil_mfma = mfma_pops / 512 / 1e9
+        ceil_valu = 1024 * 2.4e9 * 64 / (8 * 2.5 + 8 * 4.2) / 1e9
+        ceil_valu_top2 = 1024 * 2.4e9 * 64 / (8 * 2.5 + 11 * 4.2) / 1e9
         hamming = {"gpairs_per_s": round(g, 2), "pairs_per_launch": pairs,
-                   "ms_per_launch": round(ms / reps, 4), "kernel": "dense_top2_kernel<2, 4>",
-                   "ceiling_gpairs_per_s": round(ceil_dist, 1), "frac": round(g / ceil_dist, 3),
-                   "ceiling_with_top2_bookkeeping_gpairs_per_s": round(ceil_top2, 1), "frac_with_top2": round(g / ceil_top2, 3),
-                   "bound": "integer VALU (xor + popcount), not HBM: (Q+T)*32 B per frame are reused Q*T times"}
+                   "ms_per_launch": round(ms / reps, 4), "kernel": "dense_top2_mfma_kernel (v_mfma_i32_32x32x32_i8)",
+                   "ceiling_gpairs_per_s": round(ceil_mfma, 1), "frac": round(g / ceil_mfma, 3),
+                   "ceiling_note": "i8 MFMA rate measured on this chip (4.3 POPS) / 512 operations per pair",
+                   "valu_formulation_ceiling_gpairs_per_s": round(ceil_valu, 1),
+                   "valu_formulation_ceiling_with_top2_gpairs_per_s": round(ceil_valu_top2, 1),
+                   "bound": "matrix-core issue (MFMA) with the top-2 bookkeeping (v_med3 + v_min per pair) interleaved under it; "
+                            "not HBM: (Q+T)*32 B per frame are reused Q*T times"}
         if args.cpu_pairs > 0 and rank == 0:
             # CPU leg of the matcher on a bounded sample: ORBmatcher::DescriptorDistance brute force (oracle, 1 thread) on
             # the first stereo pair's descriptors; its result also cross-checks the GPU's indices and distances

@@ -632,8 +632,9 @@ __global__ __launch_bounds__(256 * kDenseSplit) void dense_top2_kernel(const uin
         const int qi = q0 + u * 256 + l;
         if (qi >= nq) continue;
         const size_t o = (size_t)frame * q_stride + qi;
-        best_idx[o] = k0[u] == 0xFFFFFFFFu ? -1 : (int)(k0[u] & 0xFFFF);
-        best_dist[o] = k0[u] == 0xFFFFFFFFu ? 256 : (int)(k0[u] >> 16);
+        // a train at distance 256 is never taken: the scan starts from bestDist = 256 with a strict '<' (oracle orc_dense_top2)
+        best_idx[o] = k0[u] >= (256u << 16) ? -1 : (int)(k0[u] & 0xFFFF);
+        best_dist[o] = k0[u] >= (256u << 16) ? 256 : (int)(k0[u] >> 16);
         second_dist[o] = k1[u] == 0xFFFFFFFFu ? 256 : (int)(k1[u] >> 16);
     }
 }
@@ -648,10 +649,12 @@ __global__ __launch_bounds__(256 * kDenseSplit) void dense_top2_kernel(const uin
 //   rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) of every 32 x 32 tile, so its top-2 update is sequential over its registers;
 //   lanes l and l + 32 are merged at the end.  Both operands use the same lane -> (row / column, k-group) rule, so the k order
 //   inside the instruction does not matter.
-//   Workgroup = 16 waves x 64 queries (two 32-query B fragments per wave, expanded once into 64 VGPRs); the frame's raw train
-//   descriptors are staged in LDS (64 KB), and per tile of 32 trains the workgroup expands 1 KB of bits into the 8 KB A
-//   fragment image (thread t writes exactly the 16 bytes lane t & 63 reads for k-step t >> 6), double buffered.
-constexpr int kMfmaWaves = 16, kMfmaThreads = kMfmaWaves * 64, kMfmaQPerWave = 64;
+//   Workgroup = 4 waves x 64 queries (two 32-query B fragments per wave, expanded once into 64 VGPRs).  Per tile of 32 trains
+//   the workgroup expands 1 KB of descriptor bits into the 8 KB A-fragment image in LDS (double buffered): thread (row, k-step)
+//   reads one dword of train `row` — prefetched from L2 four tiles ahead — and turns its four bytes into 4 x 8 int8 through a
+//   256-entry LDS table.  Small workgroups on purpose: four of them share a CU and drift apart, so one's MFMAs run under
+//   another's top-2 / expansion VALU work (one 16-wave workgroup in barrier lock-step measured 4.3 Tpairs/s).
+constexpr int kMfmaWaves = 4, kMfmaThreads = kMfmaWaves * 64, kMfmaAhead = 4;
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
@@ -669,92 +672,129 @@ __device__ __forceinline__ v4i expand16(uint32_t bits, uint32_t pair) {
     return r;
 }
 
-__global__ __launch_bounds__(kMfmaThreads) void dense_top2_mfma_kernel(const uint8_t* __restrict__ q, const uint8_t* __restrict__ t,
-                                                                       const int* __restrict__ n_q, const int* __restrict__ n_t,
-                                                                       int q_stride, int t_stride, int* __restrict__ best_idx,
-                                                                       int* __restrict__ best_dist, int* __restrict__ second_dist) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* raw = smem;                                       // nt x 32 B (<= 64 KB)
-    uint4* frag = reinterpret_cast<uint4*>(smem + kDenseMaxTrain * 32);   // 2 x 512 x 16 B
+// Four 32-query B fragments per wave (128 VGPRs of queries, 64 of accumulators, 32 of A fragments: two waves per SIMD).
+// A wave issues its instructions in order, so MFMAs only run under VALU work that sits BETWEEN them in the instruction
+// stream: the tile is processed block by block (8 dependent MFMAs per 32-query block), and the top-2 update of block b - 1
+// (v_med3 + v_min per pair) is interleaved with the MFMAs of block b — across the tile boundary too: the last block of a
+// tile is consumed under the first block of the next.  sched_group_barrier pins the pattern (1 MFMA, 4 VALU).
+__global__ __launch_bounds__(kMfmaThreads, 2) void dense_top2_mfma_kernel(const uint8_t* __restrict__ q, const uint8_t* __restrict__ t,
+                                                                          const int* __restrict__ n_q, const int* __restrict__ n_t,
+                                                                          int q_stride, int t_stride, int* __restrict__ best_idx,
+                                                                          int* __restrict__ best_dist, int* __restrict__ second_dist) {
+    constexpr int NB = 4;
+    __shared__ __attribute__((aligned(16))) uint4 frag[2][512];   // [buffer][k-step * 64 + lane] = the 16 bytes that lane reads
+    __shared__ uint2 lut[256];                                    // byte of descriptor bits -> 8 int8 (train convention)
     const int frame = blockIdx.y;
     const int nq = n_q[frame], nt = min(n_t[frame], kDenseMaxTrain);
-    const int q0 = blockIdx.x * (kMfmaWaves * kMfmaQPerWave);
+    const int q0 = blockIdx.x * (kMfmaWaves * NB * 32);
     if (q0 >= nq) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    {   // stage the raw train descriptors
-        const uint4* ts = reinterpret_cast<const uint4*>(t + (size_t)frame * t_stride * 32);
-        uint4* rs = reinterpret_cast<uint4*>(raw);
-        for (int i = tid; i < nt * 2; i += kMfmaThreads) rs[i] = ts[i];
-    }
-    // B fragments: query column (lane & 31) of the wave's two 32-query blocks, k-group lane >> 5: bits [32 s + 16 g, +16)
-    v4i bq[2][8];
+    lut[tid] = uint2{expand4(tid & 15u, kTrainPair), expand4((uint32_t)tid >> 4, kTrainPair)};
+    // B fragments: query column (lane & 31) of the wave's 32-query blocks, k-group lane >> 5: bits [32 s + 16 g, +16)
+    v4i bq[NB][8];
 #pragma unroll
-    for (int blk = 0; blk < 2; blk++) {
-        const int qi = min(q0 + wave * kMfmaQPerWave + blk * 32 + (lane & 31), nq - 1);
-        const uint16_t* qp = reinterpret_cast<const uint16_t*>(q + ((size_t)frame * q_stride + qi) * 32);
+    for (int blk = 0; blk < NB; blk++) {
+        const int qi = min(q0 + (wave * NB + blk) * 32 + (lane & 31), nq - 1);
+        const uint4* qp = reinterpret_cast<const uint4*>(q + ((size_t)frame * q_stride + qi) * 32);
+        const uint4 lo = qp[0], hi = qp[1];   // the whole descriptor: dword s8 holds the bits of k-step s8, its half (lane >> 5) this lane's
+        const uint32_t dw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-        for (int s8 = 0; s8 < 8; s8++) bq[blk][s8] = expand16(qp[2 * s8 + (lane >> 5)], kQueryPair);
+        for (int s8 = 0; s8 < 8; s8++) bq[blk][s8] = expand16((dw[s8] >> (16 * (lane >> 5))) & 0xffffu, kQueryPair);
     }
     const int n_tiles = (nt + 31) / 32;
-    // the expansion item of this thread: item = tid & 511 -> (k-step item >> 6, lane item & 63 -> train row item & 31,
-    // k-group (item >> 5) & 1); threads 512.. take the upper two dwords of the same item
-    const int item = tid & 511, half = tid >> 9;
-    const int e_row = item & 31, e_byte = 4 * (item >> 6) + 2 * ((item >> 5) & 1);
-    auto expand_tile = [&](int tile, int buf) {
-        const int tr = min(tile * 32 + e_row, nt - 1);   // rows past the end: any data, their keys are forced high below
-        const uint32_t bits = *reinterpret_cast<const uint16_t*>(raw + tr * 32 + e_byte) >> (8 * half);
-        uint2 v;
-        v.x = expand4(bits & 15u, kTrainPair); v.y = expand4((bits >> 4) & 15u, kTrainPair);
-        reinterpret_cast<uint2*>(frag + buf * 512 + item)[half] = v;
+    // expansion role of this thread: train row tid & 31 of the tile, k-step tid >> 5: descriptor bytes [4 s, 4 s + 4) ->
+    // k-group 0 chunk (bytes 0,1) at frag[s * 64 + row] and k-group 1 chunk (bytes 2,3) at frag[s * 64 + 32 + row]
+    const int e_row = tid & 31, e_step = tid >> 5;
+    const uint8_t* tbase = t + (size_t)frame * t_stride * 32 + 4 * e_step;
+    auto fetch = [&](int tile) {   // rows / tiles past the end re-read the last train: their keys are forced high below
+        return *reinterpret_cast<const uint32_t*>(tbase + (size_t)min(tile * 32 + e_row, nt - 1) * 32);
     };
+    auto expand_tile = [&](uint32_t w, int buf) {
+        const uint2 e0 = lut[w & 255u], e1 = lut[(w >> 8) & 255u], e2 = lut[(w >> 16) & 255u], e3 = lut[w >> 24];
+        frag[buf][e_step * 64 + e_row] = uint4{e0.x, e0.y, e1.x, e1.y};
+        frag[buf][e_step * 64 + 32 + e_row] = uint4{e2.x, e2.y, e3.x, e3.y};
+    };
+    uint32_t pre[kMfmaAhead];
+    if (nt > 0) {
+#pragma unroll
+        for (int i = 0; i < kMfmaAhead; i++) pre[i] = fetch(1 + i);
+        const uint32_t w0 = fetch(0);
+        __syncthreads();   // lut
+        expand_tile(w0, 0);
+    }
     __syncthreads();
-    if (n_tiles > 0) expand_tile(0, 0);
-    __syncthreads();
-    // C operand: 262144 + global train index of accumulator register r in this lane; rows past nt get a key no real pair reaches
-    v16i cinit;
+    const int lane_row = 262144 + 4 * (lane >> 5);   // C operand = 262144 + global train index of accumulator register r
+    int k0[NB], k1[NB];
 #pragma unroll
-    for (int r = 0; r < 16; r++) cinit[r] = 262144 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    int k0[2] = {0x7FFFFFFF, 0x7FFFFFFF}, k1[2] = {0x7FFFFFFF, 0x7FFFFFFF};
-    for (int tile = 0; tile < n_tiles; tile++) {
-        const int buf = tile & 1;
-        if (tile + 1 < n_tiles) expand_tile(tile + 1, buf ^ 1);
-        v16i c = cinit;
-        if (tile == n_tiles - 1) {   // block-uniform: the last tile may be partial
+    for (int blk = 0; blk < NB; blk++) k0[blk] = k1[blk] = 0x7FFFFFFF;
+    v16i acc[NB];
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                if (cinit[r] - 262144 >= nt) c[r] = 0x40000000;
-        }
-        const uint4* fr = frag + buf * 512 + lane;
-        v16i acc0 = c, acc1 = c;
+    for (int blk = 0; blk < NB; blk++)
 #pragma unroll
-        for (int s8 = 0; s8 < 8; s8++) {
-            const uint4 av = fr[s8 * 64];
-            const v4i a = {(int)av.x, (int)av.y, (int)av.z, (int)av.w};
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][s8], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][s8], acc1, 0, 0, 0);
-        }
+        for (int r = 0; r < 16; r++) acc[blk][r] = 0x7FFFFFFF;   // "previous tile" of the first one: no effect on the top-2
+    auto top2 = [&](int blk) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {   // (k0 <= k1) + key -> the two smallest: second = median of the three
-            k1[0] = min(max(k0[0], k1[0]), max(min(k0[0], k1[0]), acc0[r])); k0[0] = min(k0[0], acc0[r]);
-            k1[1] = min(max(k0[1], k1[1]), max(min(k0[1], k1[1]), acc1[r])); k0[1] = min(k0[1], acc1[r]);
+            k1[blk] = min(max(k0[blk], k1[blk]), max(min(k0[blk], k1[blk]), acc[blk][r]));
+            k0[blk] = min(k0[blk], acc[blk][r]);
         }
+    };
+    for (int tile0 = 0; tile0 < n_tiles; tile0 += kMfmaAhead) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) cinit[r] += 32;
-        __syncthreads();   // tile + 1 is expanded, and everyone is done reading buffer `buf`
+        for (int u = 0; u < kMfmaAhead; u++) {
+            const int tile = tile0 + u;
+            if (tile >= n_tiles) break;   // block-uniform
+            const int buf = tile & 1;
+            // all eight A fragments of the tile in flight at once
+            const uint4* fr = &frag[buf][lane];
+            v4i a[8];
+#pragma unroll
+            for (int s8 = 0; s8 < 8; s8++) { const uint4 av = fr[s8 * 64]; a[s8] = v4i{(int)av.x, (int)av.y, (int)av.z, (int)av.w}; }
+            if (tile + 1 < n_tiles) {
+                expand_tile(pre[u], buf ^ 1);
+                pre[u] = fetch(tile + 1 + kMfmaAhead);
+            }
+            v16i c;
+#pragma unroll
+            for (int r = 0; r < 16; r++) c[r] = lane_row + tile * 32 + ((r & 3) + 8 * (r >> 2));
+            if (tile == n_tiles - 1) {   // the last tile may be partial: rows past nt get a key no real pair reaches
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    if (c[r] - 262144 >= nt) c[r] = 0x40000000;
+            }
+#pragma unroll
+            for (int blk = 0; blk < NB; blk++) {
+                // consume the block computed just before (of the previous tile for blk == 0) ...
+                const int prev = (blk + NB - 1) % NB;
+                top2(prev);
+                // ... under this block's MFMAs (they overwrite acc[blk], consumed one step earlier)
+#pragma unroll
+                for (int s8 = 0; s8 < 8; s8++)
+                    acc[blk] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s8], bq[blk][s8], s8 == 0 ? c : acc[blk], 0, 0, 0);
+#pragma unroll
+                for (int s8 = 0; s8 < 8; s8++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 VALU
+                }
+            }
+            __syncthreads();   // tile + 1 is expanded, and everyone is done reading buffer `buf`
+        }
     }
+    top2(NB - 1);   // the last block of the last tile
     // merge the two halves of the wave (same query, complementary train rows); keys are unique
 #pragma unroll
-    for (int blk = 0; blk < 2; blk++) {
+    for (int blk = 0; blk < NB; blk++) {
         const int o0 = __shfl_xor(k0[blk], 32), o1 = __shfl_xor(k1[blk], 32);
         const int lo = min(k0[blk], o0), hi = max(k0[blk], o0);
         k1[blk] = min(hi, min(k1[blk], o1));
         k0[blk] = lo;
-        const int qi = q0 + wave * kMfmaQPerWave + blk * 32 + (lane & 31);
+        const int qi = q0 + (wave * NB + blk) * 32 + (lane & 31);
         if (lane < 32 && qi < nq) {
             const size_t o = (size_t)frame * q_stride + qi;
-            best_idx[o] = k0[blk] >= 0x40000000 ? -1 : (k0[blk] & 2047);
-            best_dist[o] = k0[blk] >= 0x40000000 ? 256 : (k0[blk] >> 11);
-            second_dist[o] = k1[blk] >= 0x40000000 ? 256 : (k1[blk] >> 11);
+            // a train at distance 256 is never taken: the scan starts from bestDist = 256 with a strict '<' (oracle orc_dense_top2)
+            best_idx[o] = k0[blk] >= (256 << 11) ? -1 : (k0[blk] & 2047);
+            best_dist[o] = k0[blk] >= (256 << 11) ? 256 : (k0[blk] >> 11);
+            second_dist[o] = k1[blk] >= (256 << 11) ? 256 : (k1[blk] >> 11);   // also the masked rows: 0x40000000 + (a sum within +-262144)
         }
     }
 }
@@ -773,9 +813,9 @@ void launch_dense_top2(const uint8_t* q, const uint8_t* t, const int* n_q, const
     if (n_frames <= 0 || max_q <= 0) return;
     const int variant = getenv("MSORB_DENSE_VARIANT") ? atoi(getenv("MSORB_DENSE_VARIANT")) : 0;  // test / tuning aid: QPL*10 + SPLIT = VALU kernels
     if (variant == 0) {   // default: matrix cores
-        const int per_block = kMfmaWaves * kMfmaQPerWave;
-        hipLaunchKernelGGL(dense_top2_mfma_kernel, dim3((max_q + per_block - 1) / per_block, n_frames), dim3(kMfmaThreads),
-                           (size_t)kDenseMaxTrain * 32 + 2 * 512 * 16, s, q, t, n_q, n_t, q_stride, t_stride, bi, bd, sd);
+        const int per_block = kMfmaWaves * 128;
+        hipLaunchKernelGGL(dense_top2_mfma_kernel, dim3((max_q + per_block - 1) / per_block, n_frames), dim3(kMfmaThreads), 0, s, q, t, n_q, n_t,
+                           q_stride, t_stride, bi, bd, sd);
         return;
     }
     // measured on MI355X (128 frames x 2000 x 2000): 2,1 1.54  2,2 1.65  2,4 1.72  4,2 1.68  4,4 1.73  1,4 1.57 Tpairs/s

@@ -143,6 +143,45 @@ def test_dense_top2_batch(msorb_mod, oracle):
     assert oracle.descriptor_distance(q[0, 0], t[0, bi[0, 0]]) == bd[0, 0] == 0
 
 
+@pytest.mark.parametrize("kernel", ["mfma", "valu"])
+def test_dense_top2_kernels_edge_cases(msorb_mod, oracle, monkeypatch, kernel):
+    """The matrix-core kernel (default: +-32 int8 encoding, the MFMA accumulator is the (distance << 11 | index) key) and the
+    xor / popcount kernel on the shapes that stress tiling: train counts around the 32-train tile and the 2048 cap, query
+    counts around the 512-query workgroup and 32-query fragment, one train, identical descriptors everywhere (every distance
+    ties: lowest index wins, second = the same distance), all-zero vs all-one descriptors (distance 256)."""
+    import torch
+    if kernel == "valu":
+        monkeypatch.setenv("MSORB_DENSE_VARIANT", "24")
+    rng = np.random.Generator(np.random.PCG64(77))
+    cap = 2048                                       # msorb_hamming_dense_top2_batch: at most 2048 trains per frame
+    shapes = [(1, 1), (31, 33), (33, 31), (64, 32), (513, 2047), (2000, 2048), (2048, 1999), (5, 0), (300, 1), (129, 65)]
+    F = len(shapes) + 2
+    nq = np.array([a for a, _ in shapes] + [200, 100], np.int32)
+    nt = np.array([b for _, b in shapes] + [300, 64], np.int32)
+    q = rng.integers(0, 256, (F, cap, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (F, cap, 32), dtype=np.uint8)
+    q[F - 2] = 0x5A; t[F - 2] = 0x5A                 # every pair at distance 0
+    q[F - 1] = 0x00; t[F - 1] = 0xFF                 # every pair at distance 256
+    t[4, 1000:1040] = t[4, 1000]                     # a run of duplicates across a tile boundary
+    q[4, :100] = t[4, rng.integers(990, 1050, 100)]
+    bi, bd, sd, _ = msorb_mod.hamming_dense_top2_batch(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda(),
+                                                      torch.from_numpy(nq).cuda(), torch.from_numpy(nt).cuda())
+    bi, bd, sd = bi.cpu().numpy(), bd.cpu().numpy(), sd.cpu().numpy()
+    for f in range(F):
+        n_t = int(nt[f])
+        if nq[f] == 0:
+            continue
+        if n_t == 0:
+            assert np.all(bi[f, :nq[f]] == -1) and np.all(bd[f, :nq[f]] == 256) and np.all(sd[f, :nq[f]] == 256)
+            continue
+        wi, wd, ws = oracle.dense_top2(q[f, :nq[f]], t[f, :n_t])
+        assert np.array_equal(bi[f, :nq[f]], wi), (kernel, f)
+        assert np.array_equal(bd[f, :nq[f]], wd), (kernel, f)
+        assert np.array_equal(sd[f, :nq[f]], ws), (kernel, f)
+    assert np.all(bi[F - 2, :200] == 0) and np.all(bd[F - 2, :200] == 0) and np.all(sd[F - 2, :200] == 0)
+    assert np.all(bd[F - 1, :100] == 256) and np.all(sd[F - 1, :100] == 256) and np.all(bi[F - 1, :100] == -1)   # strict '<' from 256
+
+
 def test_window_top4_against_features_in_area(msorb_mod, oracle, stereo_frame):
     """The raw window search: top-4 of DescriptorDistance over GetFeaturesInArea in scan order."""
     s = stereo_frame

@@ -29,9 +29,11 @@ pairs = int((nq.astype(np.int64) * nt).sum())
 wi, wd, ws = orb_oracle.dense_top2(q[3, :nq[3]], t[3, :nt[3]])
 ok = (np.array_equal(wi, bi[3, :nq[3]].cpu().numpy()) and np.array_equal(wd, bd[3, :nq[3]].cpu().numpy()) and
       np.array_equal(ws, sd[3, :nq[3]].cpu().numpy()))
-# integer-VALU ceiling of the inner loop (profiles/round1_valu_ubench.txt): 8 x v_xor_b32 at 2.5 + 8 x v_bcnt_u32_b32 at 4.2
-# cycles per wave-instruction, 64 pairs per wave-instruction, 1024 SIMDs at 2.4 GHz
-ceiling = 1024 * 2.4e9 * 64 / (8 * 2.5 + 8 * 4.2) / 1e9
+# ceiling of the matrix-core kernel: the i8 MFMA rate the chip sustains (4.3 POPS, tools/mfma_rate.hip) / 512 int8 operations per
+# pair; MSORB_DENSE_VARIANT=24 selects the xor / popcount kernel, whose integer-VALU ceiling is 2934 Gpairs/s (2376 with top-2)
+valu = bool(os.environ.get("MSORB_DENSE_VARIANT"))
+ceiling = 1024 * 2.4e9 * 64 / (8 * 2.5 + 8 * 4.2) / 1e9 if valu else 4.3e15 / 512 / 1e9
 g = pairs * reps / (ms * 1e-3) / 1e9
-print(json.dumps({"gpairs_per_s": round(g, 1), "ms_per_launch": round(ms / reps, 4), "pairs_per_launch": pairs,
-                  "matches_oracle": bool(ok), "ceiling_gpairs_per_s": round(ceiling, 1), "frac_of_ceiling": round(g / ceiling, 3)}))
+print(json.dumps({"kernel": "dense_top2_kernel (VALU)" if valu else "dense_top2_mfma_kernel", "gpairs_per_s": round(g, 1),
+                  "ms_per_launch": round(ms / reps, 4), "pairs_per_launch": pairs, "matches_oracle": bool(ok),
+                  "ceiling_gpairs_per_s": round(ceiling, 1), "frac_of_ceiling": round(g / ceiling, 3)}))
