@@ -21,7 +21,8 @@ extern "C" {
 #define MSORB_OK 0
 #define MSORB_E_INVALID -1    /* bad argument */
 #define MSORB_E_NO_DEVICE -2  /* no HIP device / HIP runtime error at init */
-#define MSORB_E_HIP -3        /* HIP runtime error during the call */
+#define MSORB_E_HIP -3        /* HIP runtime error during the call: outputs and in/out arrays (frame_mp, cur_mp, matched, ...)
+                                 are unspecified — the claim-replaying searches may have applied the accepts of earlier rounds */
 #define MSORB_E_CAPACITY -4   /* caller-provided buffer too small */
 #define MSORB_E_GEOMETRY -5   /* image too small for the reference's cell arithmetic (it would divide by zero) */
 #define MSORB_E_EMPTY -6      /* empty input image: ORBextractor::operator() returns -1 (ORBextractor.cc:1090-1091) */
