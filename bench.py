@@ -176,17 +176,26 @@ def main():
         return v
 
     other_images = None
+    half = B   # N>1: images of a rank whose stereo pairs it associates itself (the first `half` of its 2B images)
     if world == 1:
         host = np.concatenate([base] * (B // uniq + 1))[:2 * B]
     else:
-        one_eye = base[eye::2]
-        host = np.concatenate([one_eye] * (2 * B // uniq + 1))[:2 * B]
-        if eye == 0:
-            # the left-eye rank also holds the right images (the capture DMA delivers both eyes to it): it rebuilds the right
-            # pyramid for the stereo SAD locally (0.22 ms per 256 images) instead of pulling 1.5 MB per frame over xGMI;
-            # only the 60 B per keypoint cross the link (BASELINE configs[3]: "gather of keypoints/descriptors")
-            other = base[1::2]
-            other_images = resident(np.concatenate([other] * (2 * B // uniq + 1))[:2 * B])
+        # both ranks of a pair hold the same 2B stereo pairs, one eye each.  The association (Frame::ComputeStereoMatches) is
+        # split evenly: the left-eye rank joins pairs [0, B), the right-eye rank pairs [B, 2B) — so the right-eye rank keeps its
+        # images in the order [B, 2B) + [0, B): every rank joins the pairs of its FIRST B images and ships the features of its
+        # LAST B images to its partner (msorb/stereo_split.swap_halves_async).  A rank also holds the other eye's images of
+        # the pairs it joins (the capture DMA delivers both eyes): it rebuilds that pyramid for the stereo SAD locally
+        # (msorb_pyramid_batch, 0.09 ms per 128 images) instead of pulling 1.5 MB per frame over xGMI; only the 60 B per
+        # keypoint cross the link (BASELINE configs[3]: "gather of keypoints/descriptors")
+        def eye_images(e):
+            one = base[e::2]
+            return np.concatenate([one] * (2 * B // uniq + 1))[:2 * B]
+        own, oth = eye_images(eye), eye_images(1 - eye)
+        if eye == 1:
+            own = np.concatenate([own[B:], own[:B]])
+            oth = np.concatenate([oth[B:], oth[:B]])
+        host = own
+        other_images = resident(oth[:half])
     n_img = host.shape[0]
     images = resident(host)
 
@@ -213,22 +222,26 @@ def main():
     assoc = {"ms": 0.0, "n": 0, "matched": 0}
     if world > 1:
         mine = [stereo_split.FeatureBlock(n_img, cap, dev) for _ in range(2)]
-        theirs = [stereo_split.FeatureBlock(n_img, cap, dev) if eye == 0 else None for _ in range(2)]
-        if eye == 0:
-            exs = [ex, make_ex()]
-            ex_rp = make_ex()   # pyramid-only handle for the right images
+        theirs = [stereo_split.FeatureBlock(half, cap, dev) for _ in range(2)]
+        exs = [ex, make_ex()]
+        ex_rp = make_ex()   # pyramid-only handle for the other eye's images of the pairs this rank joins
     step_no = [0]
     filled = [False, False]
     last_ex = [ex]
     all_ex = [ex] if exs[1] is ex else [exs[0], exs[1]]
 
     def associate(b):
-        """Left-eye rank: Frame::ComputeStereoMatches for the pairs of block b (its exchange has completed)."""
-        if world == 1 or eye != 0 or not filled[b] or theirs[b] is None:
+        """Frame::ComputeStereoMatches for the pairs of block b this rank joins (its exchange has completed): own features of
+        the first `half` images + the partner's features of the same pairs."""
+        if world == 1 or not filled[b]:
             return
         ex_rp.pyramid_batch(other_images)
-        d_ur, _, _, ms = msorb.stereo_matches_split(exs[b], ex_rp, mine[b].counts, mine[b].kps, mine[b].desc,
-                                                    theirs[b].counts, theirs[b].kps, theirs[b].desc, KITTI_MB, KITTI_MBF)
+        own = (mine[b].counts[:half], mine[b].kps[:half], mine[b].desc[:half])
+        got = (theirs[b].counts, theirs[b].kps, theirs[b].desc)
+        if eye == 0:
+            d_ur, _, _, ms = msorb.stereo_matches_split(exs[b], ex_rp, *own, *got, KITTI_MB, KITTI_MBF)
+        else:
+            d_ur, _, _, ms = msorb.stereo_matches_split(ex_rp, exs[b], *got, *own, KITTI_MB, KITTI_MBF)
         assoc["ms"] += ms
         assoc["n"] += 1
         assoc["last"] = d_ur
@@ -248,7 +261,7 @@ def main():
         counts, mono, _, _ = exs[b].extract_batch(images, (0, 0), out=(mine[b].kps, mine[b].desc))
         # stereo split: right-eye rank -> left-eye rank (replaces the join of Frame.cc:122-125)
         mine[b].counts.copy_(torch.from_numpy(counts))
-        pending[b] = stereo_split.exchange_async(dist, rank, world, mine[b], theirs[b])
+        pending[b] = stereo_split.swap_halves_async(dist, rank, world, mine[b], theirs[b])
         filled[b] = bool(pending[b])
         return int(counts.sum())
 
@@ -419,8 +432,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: KITTI-00 stereo 1241x376, 2000 feat/frame, pyramid+FAST+rBRIEF",
                        "pairs_per_step_per_gpu": B if world == 1 else B, "images_per_step_per_gpu": n_img,
-                       "parallelism": "1 GPU, both eyes" if world == 1 else f"stereo L/R split over {world} GPUs: right-eye ranks send keypoints/descriptors "
-                                                                             "to their left-eye partner (RCCL send/recv over xGMI), which joins them (stereo association)"},
+                       "parallelism": "1 GPU, both eyes" if world == 1 else f"stereo L/R split over {world} GPUs: one eye per rank; partners swap the keypoints / "
+                                                                             "descriptors of half of their images (RCCL send/recv over xGMI) and each joins half of the pairs (stereo association)"},
             "stage_ms_per_step": {k: round(v, 4) for k, v in stages.items()},
             "stage_ms_per_step_note": "each stage's kernels alone on the GPU (5 extra steps, overlap off, HIP events on the "
                                       "launching stream); 'select' = device quadtree + output layout",
@@ -446,12 +459,14 @@ def main():
         out["stereo_match"] = stereo
         if world > 1:
             out["stereo_join"] = {
-                "what": "left-eye rank: right pyramid rebuilt from the resident right images (msorb_pyramid_batch) + "
-                        "Frame::ComputeStereoMatches on its own left features and the gathered right features "
-                        "(msorb_stereo_matches_split), inside the timed region, once per step and pair group",
+                "what": "every rank joins half of its pair group's stereo pairs inside the timed region, once per step: the other "
+                        "eye's pyramid of those pairs rebuilt from resident images (msorb_pyramid_batch) + "
+                        "Frame::ComputeStereoMatches on its own features and the features gathered from its partner "
+                        "(msorb_stereo_matches_split); figures of rank 0",
+                "pairs_per_join": half,
                 "joins": join["n"], "kernel_ms_per_join": round(join["ms"] / max(join["n"], 1), 4),
                 "matched_last": int((join["last"] > 0).sum().item()) if "last" in join else None,
-                "gathered_bytes_per_step": mine[0].nbytes() if mine else None}
+                "gathered_bytes_per_step_and_rank": theirs[0].nbytes() if theirs else None}
         if world == 1 and args.cpu_pairs > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_pairs, 5000)
         else:

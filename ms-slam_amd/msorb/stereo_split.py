@@ -62,6 +62,28 @@ def exchange_async(dist, rank, world, mine, theirs):
     return [dist.irecv(t, p) for t in theirs.tensors()]
 
 
+def swap_halves_async(dist, rank, world, mine, theirs):
+    """Symmetric form for load balance: both ranks of a pair hold 2h images of their eye, ordered so that each rank
+    associates the h stereo pairs of its FIRST h images and ships the features of its LAST h images to the partner (who holds
+    those pairs first).  `mine` has 2h images, `theirs` h.  Non-blocking; returns the Work handles (empty without a partner);
+    finish() before touching either block."""
+    p = partner_of(rank, world)
+    if p is None:
+        return []
+    h = theirs.counts.shape[0]
+    sends = [t[h:] for t in mine.tensors()]
+    recvs = list(theirs.tensors())
+    works = []
+    # post the receives first, then the sends (point-to-point pairs are matched in order on both sides)
+    if eye_of(rank) == 0:
+        works += [dist.irecv(t, p) for t in recvs]
+        works += [dist.isend(t, p) for t in sends]
+    else:
+        works += [dist.isend(t, p) for t in sends]
+        works += [dist.irecv(t, p) for t in recvs]
+    return works
+
+
 def finish(works):
     """Host-level completion of exchange_async handles (Work.wait() alone only orders torch's current stream)."""
     import torch

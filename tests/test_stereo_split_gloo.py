@@ -81,6 +81,66 @@ def _worker_async(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_halves(rank, world, port, q):
+    """bench.py's N>1 step loop with the association split over both ranks: every rank ships the upper half of its block and
+    receives its partner's upper half (the pairs it holds first)."""
+    sys.path.insert(0, os.path.join(ROOT, "ms-slam_amd"))
+    os.environ["MSORB_NO_TORCH"] = "1"
+    from msorb import stereo_split as ss
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, cap = 6, 200
+    h = n // 2
+    mine = [ss.FeatureBlock(n, cap, "cpu") for _ in range(2)]
+    theirs = [ss.FeatureBlock(h, cap, "cpu") for _ in range(2)]
+    pending = [[], []]
+    ok = True
+
+    def fill(blk, who, step):
+        g = torch.Generator().manual_seed(1000 * who + step)
+        blk.counts.copy_(torch.randint(0, cap, (n,), generator=g, dtype=torch.int32))
+        blk.kps.copy_(torch.randint(0, 256, blk.kps.shape, generator=g, dtype=torch.uint8))
+        blk.desc.copy_(torch.randint(0, 256, blk.desc.shape, generator=g, dtype=torch.uint8))
+
+    def check(b, step):
+        want = ss.FeatureBlock(n, cap, "cpu")
+        fill(want, ss.partner_of(rank, world), step)
+        return all(torch.equal(a, c[h:]) for a, c in zip(theirs[b].tensors(), want.tensors()))
+
+    steps = 5
+    has_partner = ss.partner_of(rank, world) is not None
+    for step in range(steps):
+        b = step & 1
+        ss.finish(pending[b])
+        if pending[b]:
+            ok = ok and check(b, step - 2)
+        pending[b] = []
+        fill(mine[b], rank, step)
+        pending[b] = ss.swap_halves_async(dist, rank, world, mine[b], theirs[b])
+        ok = ok and (bool(pending[b]) == has_partner)
+    for b in range(2):
+        ss.finish(pending[b])
+    if has_partner:
+        ok = ok and check((steps - 1) & 1, steps - 1) and check((steps - 2) & 1, steps - 2)
+    dist.barrier()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_stereo_split_swap_halves(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker_halves, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(30)
+    assert res == {r: True for r in range(world)}
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_stereo_split_async_double_buffer(world):
     ctx = mp.get_context("spawn")
