@@ -7,7 +7,12 @@
 // /root/reference/CMakeLists.txt:35), which is absent from this image, so neither the reference
 // nor OpenCV can be run here.  Each primitive restates the published OpenCV 4.x algorithm for
 // CV_8UC1 data as recorded in SURVEY.md Appendix A; "bit-exact" in this repo means bit-exact
-// against THIS restatement until one golden run on real OpenCV confirms it.
+// against THIS restatement until one golden run on real OpenCV confirms it (tools/pin_opencv.py is the kit for that run).
+// What IS checked against independent third-party code present in the image (scikit-image 0.18.3 / scipy 1.7.1 under
+// /opt/conda, fixtures in tests/golden/skimage_pins, tests/test_oracle_pins.py): the FAST-9/16 detection set and the
+// cornerScore semantics (exact, over a ladder of thresholds), the sampling geometry / border rules of resize and blur (to within
+// the fixed-point rounding), fastAtan2 (to OpenCV's documented 0.3 degrees).  Still resting on Appendix A alone: the exact
+// fixed-point rounding of resize, the 8-bit Gaussian taps, FAST's 3x3 NMS rule and emission order, fastAtan2's bit patterns.
 //
 // Scalar CPU restatements of the OpenCV primitives that ORBextractor.cc calls:
 //   cvRound/cvFloor/cvCeil        (call sites ORBextractor.cc:80,114,118-119,441,455-456,459,1175)

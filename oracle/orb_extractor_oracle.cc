@@ -445,6 +445,23 @@ int orc_fast9_nms(const uint8_t* img, int stride, int rows, int cols, int thresh
     for (size_t i = 0; i < out.size() && (int)i < cap; i++) { xs[i] = out[i].x; ys[i] = out[i].y; scores[i] = out[i].score; }
     return (int)out.size();
 }
+// The segment test and cornerScore of every pixel of the ROI's detection area, before non-maximum suppression: corner[y][x] =
+// fast_is_corner at `threshold`, score[y][x] = cornerScore (0 where not a corner).  For the independent cross-checks of
+// tests/test_oracle_pins.py (scikit-image's corner_fast has no NMS and another response definition).
+void orc_fast9_planes(const uint8_t* img, int stride, int rows, int cols, int threshold, uint8_t* corner, int* score) {
+    memset(corner, 0, (size_t)rows * cols);
+    for (size_t i = 0; i < (size_t)rows * cols; i++) score[i] = 0;
+    if (rows < 7 || cols < 7) return;
+    threshold = std::min(std::max(threshold, 0), 255);
+    for (int y = 3; y < rows - 3; y++)
+        for (int x = 3; x < cols - 3; x++) {
+            const uint8_t* p = img + (size_t)y * stride + x;
+            if (orc::fast_is_corner(p, stride, threshold)) {
+                corner[(size_t)y * cols + x] = 1;
+                score[(size_t)y * cols + x] = orc::fast_corner_score(p, stride, threshold);
+            }
+        }
+}
 float orc_fast_atan2(float y, float x) { return orc::fast_atan2(y, x); }
 void orc_cos_sin(float angle_deg, float* a, float* b) {
     const float r = angle_deg * orc::kFactorPI;

@@ -132,6 +132,18 @@ def fast9_nms(roi, threshold):
     return np.stack([xs[:n], ys[:n], sc[:n]], 1)
 
 
+def fast9_planes(roi, threshold):
+    """Segment-test mask and cornerScore plane of a ROI before NMS -> (corner u8 [rows, cols], score int32 [rows, cols])."""
+    roi = np.ascontiguousarray(roi, np.uint8)
+    corner = np.zeros(roi.shape, np.uint8)
+    score = np.zeros(roi.shape, np.int32)
+    L = lib()
+    L.orc_fast9_planes.restype = None
+    L.orc_fast9_planes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.orc_fast9_planes(_ptr(roi), roi.shape[1], roi.shape[0], roi.shape[1], int(threshold), _ptr(corner), _ptr(score))
+    return corner, score
+
+
 def fast_atan2(y, x):
     return float(lib().orc_fast_atan2(float(y), float(x)))
 

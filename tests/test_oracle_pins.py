@@ -168,3 +168,88 @@ def test_pin_kit_plumbing(oracle, tmp_path):
 
 PIN_IMAGE_100_SHA16 = "fd55b5ceb08b6542"
 ATAN2_INPUTS_SHA16 = "df68cf345f42270c"
+
+
+# ---- independent third-party cross-checks available in the build image (tools/pin_skimage.py) --------------------------------
+SKPINS = os.path.join(ROOT, "tests", "golden", "skimage_pins")
+
+
+def _skit():
+    spec = importlib.util.spec_from_file_location("pin_skimage", os.path.join(ROOT, "tools", "pin_skimage.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(SKPINS, "meta.json")), reason="run /opt/conda/bin/python3.9 tools/pin_skimage.py")
+def test_fast9_detection_and_score_against_scikit_image(oracle):
+    """scikit-image's corner_fast(n=9) is an independent implementation of the FAST-9/16 segment test.  (a) The oracle's
+    detection set must equal its mask at every threshold; (b) OpenCV's cornerScore is "the largest threshold at which the
+    pixel is still a corner", so the score plane computed once at the lowest threshold must reproduce scikit-image's mask at
+    EVERY threshold of the ladder: mask(t) == (score >= t)."""
+    sk, kit = _skit(), _kit()
+    meta = json.load(open(os.path.join(SKPINS, "meta.json")))
+    z = np.load(os.path.join(SKPINS, "fast9_masks.npz"))
+    rois = kit.fast_inputs()
+    img, cells = rois[kit.FAST_CELLS], rois[:8]
+    assert kit.sha(np.concatenate([img.ravel()] + [c.ravel() for c in cells])) == meta["fast_inputs_sha256"]
+
+    def mask(name, shape):
+        return np.unpackbits(z[name])[:shape[0] * shape[1]].reshape(shape).astype(bool)
+    lowest = min(sk.FAST_LADDER)
+    _, score_lo = oracle.fast9_planes(img, lowest)
+    n_corners = []
+    for t in sk.FAST_LADDER:
+        want = mask(f"image_t{t}", img.shape)
+        corner, score = oracle.fast9_planes(img, t)
+        assert np.array_equal(corner.astype(bool), want), f"detection set at threshold {t}"
+        assert np.array_equal(score_lo >= t, want), f"score semantics at threshold {t}"
+        assert np.array_equal(score[want], score_lo[want])             # the score does not depend on the detection threshold
+        n_corners.append(int(want.sum()))
+    assert n_corners[0] > 2000 and n_corners[-1] < n_corners[0] // 10 and n_corners == sorted(n_corners, reverse=True)
+    for i, c in enumerate(cells):
+        for t in (7, 20):
+            corner, _ = oracle.fast9_planes(c, t)
+            assert np.array_equal(corner.astype(bool), mask(f"cell{i}_t{t}", c.shape)), (i, t)
+    # every keypoint FAST + NMS returns is a detected corner with that score
+    kp = oracle.fast9_nms(img, 20)
+    corner, score = oracle.fast9_planes(img, 20)
+    assert len(kp) > 100 and np.all(corner[kp[:, 1], kp[:, 0]] == 1) and np.array_equal(score[kp[:, 1], kp[:, 0]], kp[:, 2])
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(SKPINS, "meta.json")), reason="run /opt/conda/bin/python3.9 tools/pin_skimage.py")
+def test_resize_and_blur_geometry_against_scikit_image_and_scipy(oracle):
+    """Float references from scikit-image (bilinear resize, half-pixel centres, edge clamp) and scipy (7-tap Gaussian, sigma 2,
+    reflect-101) against the oracle's fixed-point restatements: the sampling geometry, border rules and kernel shape must agree
+    to within the fixed-point rounding.  (A wrong centre convention — x * scale instead of (x + 0.5) * scale - 0.5 — or
+    reflect vs reflect-101 shows up as errors of tens of grey levels on this texture.)"""
+    sk, kit = _skit(), _kit()
+    z = np.load(os.path.join(SKPINS, "resize_float.npz"))
+    for i, (name, sr, sc, dr, dc) in enumerate(sk.RESIZE_CASES):
+        src = kit.pin_image(300 + i, sr, sc)
+        got = oracle.resize_linear_u8(src, dr, dc).astype(np.float64)
+        ref = z[name].astype(np.float64) / 8.0
+        err = np.abs(got - ref)
+        assert err.max() <= 1.0 and err.mean() < 0.30, (name, err.max(), err.mean())
+    z = np.load(os.path.join(SKPINS, "gaussian_float.npz"))
+    for i, (name, r, c) in enumerate(sk.BLUR_CASES):
+        src = kit.pin_image(400 + i, r, c)
+        got = oracle.gaussian7(src).astype(np.float64)
+        ref = z[name].astype(np.float64) / 8.0
+        err = np.abs(got - ref)
+        assert err.max() <= 2.0 and err.mean() < 0.45, (name, err.max(), err.mean())
+
+
+def test_fast_atan2_against_numpy(oracle):
+    """cv::fastAtan2 is documented as accurate to about 0.3 degrees; the oracle's polynomial restatement must stay inside that
+    band of numpy's arctan2 on the kit's inputs (dense integer moments, large moments, fractions, axes)."""
+    kit = _kit()
+    y, x = kit.atan2_inputs()
+    sel = np.r_[0:len(y):7, len(y) - 15:len(y)]
+    got = np.array([oracle.fast_atan2(a, b) for a, b in zip(y[sel], x[sel])], np.float64)
+    ref = np.degrees(np.arctan2(y[sel].astype(np.float64), x[sel].astype(np.float64))) % 360.0
+    nz = (np.abs(y[sel]) + np.abs(x[sel])) > 1e-6     # fastAtan2 adds DBL_EPSILON to the denominator: (1e-30, 1e-30) -> 0, not 45
+    d = np.abs(got - ref)
+    d = np.minimum(d, 360.0 - d)
+    assert d[nz].max() < 0.3, d[nz].max()
+    assert np.all(got[(y[sel] == 0) & (x[sel] == 0)] == 0.0)
