@@ -226,6 +226,7 @@ def main():
         exs = [ex, make_ex()]
         ex_rp = make_ex()   # pyramid-only handle for the other eye's images of the pairs this rank joins
     step_no = [0]
+    fence_kp = [0]
     filled = [False, False]
     last_ex = [ex]
     all_ex = [ex] if exs[1] is ex else [exs[0], exs[1]]
@@ -247,10 +248,48 @@ def main():
         assoc["last"] = d_ur
         filled[b] = False
 
+    # N=1: two batches in flight.  A synchronous msorb_extract_batch per step leaves the GPU under-used across step boundaries
+    # (the last sub-batch's quadtree / descriptors and the next step's small pyramid levels run alone: ~25 % of a step in the
+    # kernel timeline); with msorb_extract_batch_submit / _wait on two alternating handles, step k + 1 is enqueued before step k is
+    # waited for — what a capture pipeline that always has the next batch ready does.  Every step still runs the full chain
+    # on its own batch buffers; the timed region is bracketed by fence() on both sides.  (--isolated / the stage timings use
+    # the synchronous call.)
+    pipelined = world == 1 and not args.isolated and not os.environ.get("MSORB_BENCH_SYNC")
+    mode = {"pipelined": pipelined}
+    depth = int(os.environ.get("MSORB_BENCH_DEPTH", "2")) if pipelined else 1   # batches in flight
+    exp = [ex] + [make_ex() for _ in range(depth - 1)]
+    all_ex.extend(exp[1:])
+    if pipelined:
+        # one sub-batch per handle: the concurrency comes from the two batches (measured: 1.35 ms per step against 1.51 with two
+        # sub-batches per handle — six streams on four hardware queues — and 1.44 for the one-batch-at-a-time loop)
+        for e in exp:
+            e.set_overlap(int(os.environ.get("MSORB_GROUPS", "1")), True)
+    outs = [(d_kps, d_desc)] + [(torch.empty_like(d_kps), torch.empty_like(d_desc)) for _ in range(depth - 1)]
+    inflight = []
+
+    def drain():
+        total = 0
+        while inflight:
+            counts, _, _, _ = inflight.pop(0).extract_batch_wait()
+            total += int(counts.sum())
+        return total
+
     def step():
         if world == 1:
-            counts, mono, _, _ = ex.extract_batch(images, (0, 0), out=(d_kps, d_desc))
-            return int(counts.sum())
+            if not mode["pipelined"]:
+                counts, mono, _, _ = ex.extract_batch(images, (0, 0), out=(d_kps, d_desc))
+                last_ex[0] = ex
+                return int(counts.sum())
+            k = step_no[0] % depth
+            step_no[0] += 1
+            done = 0
+            if len(inflight) == depth:  # handle k still holds the batch submitted `depth` steps ago
+                counts, _, _, _ = inflight.pop(0).extract_batch_wait()
+                done = int(counts.sum())
+            exp[k].extract_batch_submit(images, (0, 0), out=outs[k])
+            inflight.append(exp[k])
+            last_ex[0] = exp[k]
+            return done
         b = step_no[0] & 1
         step_no[0] += 1
         stereo_split.finish(pending[b])          # the block's previous exchange (two steps ago) must be over
@@ -266,6 +305,8 @@ def main():
         return int(counts.sum())
 
     def fence():
+        if mode["pipelined"]:
+            fence_kp[0] += drain()
         if world > 1:
             for b in range(2):
                 stereo_split.finish(pending[b])
@@ -282,20 +323,24 @@ def main():
     overlapped_acc = {k: 0.0 for k in msorb.STAGES}
     fence()
     assoc.update(ms=0.0, n=0)
+    fence_kp[0] = 0
     t0 = time.perf_counter()
     kp_total = 0
     for _ in range(args.steps):
         kp_total += step()
-        for k, v in last_ex[0].stage_ms().items():
-            overlapped_acc[k] += v
+        if not pipelined:
+            for k, v in last_ex[0].stage_ms().items():
+                overlapped_acc[k] += v
     fence()
     dt = time.perf_counter() - t0
+    kp_total += fence_kp[0]
 
     # per-kernel roofline: the same step with every kernel alone on the GPU (1 sub-batch, blur on the main stream),
     # HIP events on the launching stream, 5 extra steps outside the timed region
     iso_steps = 5
     stage_acc = {k: 0.0 for k in msorb.STAGES}
     join = dict(assoc)   # association statistics of the timed region only
+    mode["pipelined"] = False   # the stage timings use the synchronous call on one handle
     for e in all_ex:
         e.set_overlap(1, False)
     step()
@@ -307,7 +352,7 @@ def main():
             stage_acc[k] += v
     if not args.isolated:
         for e in all_ex:
-            e.set_overlap(2, True)
+            e.set_overlap(1 if pipelined else 2, True)
     fence()
 
     if world > 1:
@@ -432,14 +477,17 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: KITTI-00 stereo 1241x376, 2000 feat/frame, pyramid+FAST+rBRIEF",
                        "pairs_per_step_per_gpu": B if world == 1 else B, "images_per_step_per_gpu": n_img,
-                       "parallelism": "1 GPU, both eyes" if world == 1 else f"stereo L/R split over {world} GPUs: one eye per rank; partners swap the keypoints / "
+                       "batches_in_flight": depth,
+                       "parallelism": ("1 GPU, both eyes; msorb_extract_batch_submit / _wait on two alternating handles: step k+1 is enqueued "
+                                       "before step k is waited for" if pipelined else "1 GPU, both eyes") if world == 1 else f"stereo L/R split over {world} GPUs: one eye per rank; partners swap the keypoints / "
                                                                              "descriptors of half of their images (RCCL send/recv over xGMI) and each joins half of the pairs (stereo association)"},
             "stage_ms_per_step": {k: round(v, 4) for k, v in stages.items()},
             "stage_ms_per_step_note": "each stage's kernels alone on the GPU (5 extra steps, overlap off, HIP events on the "
                                       "launching stream); 'select' = device quadtree + output layout",
-            "stage_ms_per_step_overlapped": {k: round(v, 4) for k, v in stages_overlapped.items()},
+            "stage_ms_per_step_overlapped": None if pipelined else {k: round(v, 4) for k, v in stages_overlapped.items()},
             "stage_ms_per_step_overlapped_note": "timed region: sum over the 2 concurrent sub-batches of each stage's event "
-                                                 "interval (intervals overlap, so the sum exceeds ms_per_step)",
+                                                 "interval (intervals overlap, so the sum exceeds ms_per_step); not recorded when "
+                                                 "two batches are in flight (MSORB_BENCH_SYNC=1 for the one-batch-at-a-time loop)",
             "roofline": {"bound": "hbm", "kernel": {"fast": "fast_cells_kernel", "pyramid": "pyr_resize_dma_kernel (x7)",
                                                     "blur": "gauss7_kernel (x8)", "describe": "describe_kernel",
                                                     "compact": "cand_*"}[dom],

@@ -125,6 +125,16 @@ int msorb_extract_batch(msorb_extractor* h, const uint8_t* d_images, int n_image
                         size_t row_stride, size_t image_stride, int lap0, int lap1, msorb_keypoint* d_keypoints,
                         uint8_t* d_descriptors, int capacity, int* h_counts, int* h_mono);
 
+/* msorb_extract_batch in two halves: _submit enqueues the whole chain on the handle's streams and returns, _wait blocks until
+ * it has finished and hands out the counts (same arrays and error codes as msorb_extract_batch).  One batch per handle may be
+ * pending; a caller that alternates two handles keeps the GPU busy across batch boundaries (bench.py does: the next batch's
+ * pyramid / FAST run under the previous batch's quadtree / descriptor tail).  The output arrays and the input images must
+ * stay untouched until _wait returns.  No reference counterpart: the reference processes one frame at a time. */
+int msorb_extract_batch_submit(msorb_extractor* h, const uint8_t* d_images, int n_images, int rows, int cols,
+                               size_t row_stride, size_t image_stride, int lap0, int lap1, msorb_keypoint* d_keypoints,
+                               uint8_t* d_descriptors, int capacity);
+int msorb_extract_batch_wait(msorb_extractor* h, int* h_counts, int* h_mono_index);
+
 /* Stage timing of the last batch call, measured with HIP events on the handle's stream.
  * enable!=0 switches recording on.  Stage order: MSORB_STAGE_* below; ms[] has MSORB_N_STAGES slots. */
 #define MSORB_STAGE_PYRAMID 0

@@ -170,6 +170,8 @@ struct msorb_extractor {
     FrameGraph fgraph[2];        // two cached variants (e.g. mono + stereo lapping settings)
     bool capturing = false;      // enqueue only: no host synchronisation inside the pipeline
     bool defer_sync = false;     // enqueue only, the caller appends more work and synchronises (msorb_extract[_stereo])
+    bool last_prof = false;      // the stage events of the last run_pipeline_groups() call were recorded
+    int pending_batch = 0;       // images of a batch enqueued by msorb_extract_batch_submit and not yet waited for
     bool skip_count_copies = false;  // with defer_sync: the caller fetches the counts from the device itself
     DevBuf<int> d_st_sad, d_st_rows, d_st_list;  // stereo association scratch of msorb_extract_stereo
     DevBuf<uint8_t> d_st_block, d_st_img;        // its output block and its two level-0 planes
@@ -371,6 +373,32 @@ int ensure_group(msorb_extractor* h, int gi) {
     return MSORB_OK;
 }
 
+// End of a run_pipeline_groups() call: waits for the sub-batch streams, hands the counts out, folds the stage events.
+int finish_groups(msorb_extractor* h, int n_images, int* h_counts, int* h_mono) {
+    const int ng = h->last_groups;
+    for (int gi = 0; gi < ng; gi++) HIPCHK(hipStreamSynchronize(h->grp[gi].s));
+    HIPCHK(hipGetLastError());
+    for (int i = 0; i < n_images; i++) {
+        if (h->h_sel_count.p[i] < 0) { set_error("keypoint capacity exceeded"); return MSORB_E_CAPACITY; }
+        h_counts[i] = h->h_sel_count.p[i];
+        if (h_mono) h_mono[i] = h->h_mono.p[i];
+    }
+    if (h->last_prof) {  // stage time = sum over the sub-batches of the stage's HIP-event interval on its own stream
+        // (with the blur on the main stream its interval sits between pyramid and FAST: FAST = 8 -> 2)
+        const int fast_from = h->overlap_blur ? 1 : 8;
+        const int map[6][3] = {{MSORB_STAGE_PYRAMID, 0, 1}, {MSORB_STAGE_FAST, fast_from, 2}, {MSORB_STAGE_COMPACT, 2, 3},
+                               {MSORB_STAGE_BLUR, 7, 8}, {MSORB_STAGE_SELECT, 3, 5}, {MSORB_STAGE_DESCRIBE, 5, 6}};
+        for (auto& m : map) h->stage_ms[m[0]] = 0;
+        for (int gi = 0; gi < ng; gi++)
+            for (auto& m : map) {
+                float ms = 0;
+                HIPCHK(hipEventElapsedTime(&ms, h->grp[gi].pe[m[1]], h->grp[gi].pe[m[2]]));
+                h->stage_ms[m[0]] += ms;
+            }
+    }
+    return MSORB_OK;
+}
+
 // Device-only pipeline (device quadtree) over several sub-batches, each on its own pair of streams, so that the
 // latency-bound quadtree of one sub-batch overlaps the FAST / pyramid kernels of the next; inside a sub-batch
 // the blur runs on the second stream.  No host work between the stages; one read-back of the counts at the end.
@@ -390,6 +418,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
     h->h_pyr_async = false;
     h->compact_on_host = false;
     h->last_groups = ng;
+    h->last_prof = prof;
     static const bool stagger_env = getenv("MSORB_STAGGER") != nullptr;  // measured: no gain (2.648 vs 2.653 ms), off by default
     const bool stagger = stagger_env && ng > 1;
     // sub-batches on streams of their own must not start before the handle's stream has drained (H2D of level 0 in
@@ -468,28 +497,8 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
         }
         first += n;
     }
-    if (h->capturing || h->defer_sync) return MSORB_OK;  // graph capture / fused call: the caller synchronises and reads back
-    for (int gi = 0; gi < ng; gi++) HIPCHK(hipStreamSynchronize(h->grp[gi].s));
-    HIPCHK(hipGetLastError());
-    for (int i = 0; i < n_images; i++) {
-        if (h->h_sel_count.p[i] < 0) { set_error("keypoint capacity exceeded"); return MSORB_E_CAPACITY; }
-        h_counts[i] = h->h_sel_count.p[i];
-        if (h_mono) h_mono[i] = h->h_mono.p[i];
-    }
-    if (prof) {  // stage time = sum over the sub-batches of the stage's HIP-event interval on its own stream
-        // (with the blur on the main stream its interval sits between pyramid and FAST: FAST = 8 -> 2)
-        const int fast_from = h->overlap_blur ? 1 : 8;
-        const int map[6][3] = {{MSORB_STAGE_PYRAMID, 0, 1}, {MSORB_STAGE_FAST, fast_from, 2}, {MSORB_STAGE_COMPACT, 2, 3},
-                               {MSORB_STAGE_BLUR, 7, 8}, {MSORB_STAGE_SELECT, 3, 5}, {MSORB_STAGE_DESCRIBE, 5, 6}};
-        for (auto& m : map) h->stage_ms[m[0]] = 0;
-        for (int gi = 0; gi < ng; gi++)
-            for (auto& m : map) {
-                float ms = 0;
-                HIPCHK(hipEventElapsedTime(&ms, h->grp[gi].pe[m[1]], h->grp[gi].pe[m[2]]));
-                h->stage_ms[m[0]] += ms;
-            }
-    }
-    return MSORB_OK;
+    if (h->capturing || h->defer_sync) return MSORB_OK;  // graph capture / fused / submitted call: the caller synchronises and reads back
+    return finish_groups(h, n_images, h_counts, h_mono);
 }
 
 // The pipeline proper.  level0: where level 0 of every image lives (device memory).
@@ -777,14 +786,19 @@ int msorb_extractor_stage_ms(const msorb_extractor* h, float* ms) {
     return MSORB_OK;
 }
 
-int msorb_extract_batch(msorb_extractor* h, const uint8_t* d_images, int n_images, int rows, int cols,
-                        size_t row_stride, size_t image_stride, int lap0, int lap1, msorb_keypoint* d_kps,
-                        uint8_t* d_desc, int capacity, int* h_counts, int* h_mono) {
-    if (!h || !d_kps || !d_desc || !h_counts || n_images < 0) { set_error("null argument"); return MSORB_E_INVALID; }
+static int extract_batch_common(msorb_extractor* h, const uint8_t* d_images, int n_images, int rows, int cols, size_t row_stride,
+                                size_t image_stride, int lap0, int lap1, msorb_keypoint* d_kps, uint8_t* d_desc, int capacity,
+                                int* h_counts, int* h_mono, bool submit_only) {
+    if (!h || !d_kps || !d_desc || (!submit_only && !h_counts) || n_images < 0) { set_error("null argument"); return MSORB_E_INVALID; }
+    if (h->pending_batch) { set_error("a submitted batch of this handle has not been waited for"); return MSORB_E_INVALID; }
     if (!d_images || rows <= 0 || cols <= 0) return MSORB_E_EMPTY;
     if (n_images == 0) return MSORB_OK;
     if ((int)row_stride < cols || (n_images > 1 && image_stride < row_stride * (size_t)rows)) {
         set_error("bad strides");
+        return MSORB_E_INVALID;
+    }
+    if (submit_only && (!h->device_quadtree || getenv("MSORB_SERIAL_PIPELINE"))) {
+        set_error("msorb_extract_batch_submit needs the device pipeline");
         return MSORB_E_INVALID;
     }
     HIPCHK(hipSetDevice(h->device));
@@ -805,11 +819,40 @@ int msorb_extract_batch(msorb_extractor* h, const uint8_t* d_images, int n_image
         launch_stage_level0(l0, h->d_pyr.p + g0.plane_off, g0.pitch, h->G.pyramid_bytes, n_images, h->stream);
         l0 = LevelView{h->d_pyr.p + g0.plane_off, h->G.pyramid_bytes, g0.pitch, cols, rows};
     }
-    return run_pipeline(h, l0, n_images, lap0, lap1, d_kps, d_desc, capacity, h_counts, h_mono);
+    if (!submit_only) return run_pipeline(h, l0, n_images, lap0, lap1, d_kps, d_desc, capacity, h_counts, h_mono);
+    h->defer_sync = true;
+    rc = run_pipeline(h, l0, n_images, lap0, lap1, d_kps, d_desc, capacity, nullptr, nullptr);
+    h->defer_sync = false;
+    if (rc == MSORB_OK) h->pending_batch = n_images;
+    return rc;
+}
+
+int msorb_extract_batch(msorb_extractor* h, const uint8_t* d_images, int n_images, int rows, int cols,
+                        size_t row_stride, size_t image_stride, int lap0, int lap1, msorb_keypoint* d_kps,
+                        uint8_t* d_desc, int capacity, int* h_counts, int* h_mono) {
+    return extract_batch_common(h, d_images, n_images, rows, cols, row_stride, image_stride, lap0, lap1, d_kps, d_desc, capacity,
+                                h_counts, h_mono, false);
+}
+
+// msorb_extract_batch in two halves, so that a caller can keep several batches in flight (one handle each): submit enqueues the
+// whole chain and returns; wait blocks until it has finished and hands out the counts.
+int msorb_extract_batch_submit(msorb_extractor* h, const uint8_t* d_images, int n_images, int rows, int cols, size_t row_stride,
+                               size_t image_stride, int lap0, int lap1, msorb_keypoint* d_kps, uint8_t* d_desc, int capacity) {
+    return extract_batch_common(h, d_images, n_images, rows, cols, row_stride, image_stride, lap0, lap1, d_kps, d_desc, capacity,
+                                nullptr, nullptr, true);
+}
+int msorb_extract_batch_wait(msorb_extractor* h, int* h_counts, int* h_mono) {
+    if (!h || !h_counts) { set_error("null argument"); return MSORB_E_INVALID; }
+    if (!h->pending_batch) { set_error("no submitted batch to wait for"); return MSORB_E_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    const int n = h->pending_batch;
+    h->pending_batch = 0;
+    return finish_groups(h, n, h_counts, h_mono);
 }
 
 int msorb_extract(msorb_extractor* h, const uint8_t* image, int rows, int cols, size_t stride, int lap0, int lap1,
                   msorb_keypoint* keypoints, uint8_t* descriptors, int capacity, int* n_keypoints, int* mono_index) {
+    if (h && h->pending_batch) { set_error("a submitted batch of this handle has not been waited for"); return MSORB_E_INVALID; }
     if (!h || !n_keypoints || !mono_index) return MSORB_E_INVALID;
     *n_keypoints = 0;
     *mono_index = -1;
@@ -948,6 +991,7 @@ int msorb_extract_stereo(msorb_extractor* h, const uint8_t* left, const uint8_t*
                          size_t stride_right, float mb, float mbf, msorb_keypoint* kps_left, uint8_t* desc_left, int* n_left,
                          msorb_keypoint* kps_right, uint8_t* desc_right, int* n_right, int capacity, float* u_right,
                          float* depth, int* n_oob) {
+    if (h && h->pending_batch) { set_error("a submitted batch of this handle has not been waited for"); return MSORB_E_INVALID; }
     if (!h || !n_left || !n_right) return MSORB_E_INVALID;
     *n_left = *n_right = 0;
     if (n_oob) *n_oob = 0;
@@ -1048,6 +1092,7 @@ int msorb_extract_stereo_split(msorb_extractor* L, msorb_extractor* R, const uin
                                int cols, size_t stride_left, size_t stride_right, float mb, float mbf,
                                msorb_keypoint* kps_left, uint8_t* desc_left, int* n_left, msorb_keypoint* kps_right,
                                uint8_t* desc_right, int* n_right, int capacity, float* u_right, float* depth, int* n_oob) {
+    if ((L && L->pending_batch) || (R && R->pending_batch)) { set_error("a submitted batch of a handle has not been waited for"); return MSORB_E_INVALID; }
     if (!L || !R || L == R || !n_left || !n_right) return MSORB_E_INVALID;
     *n_left = *n_right = 0;
     if (n_oob) *n_oob = 0;
@@ -1187,6 +1232,7 @@ int msorb_extract_stereo_split(msorb_extractor* L, msorb_extractor* R, const uin
 // association, when only its keypoints / descriptors were gathered from another device.  Asynchronous on the handle's stream.
 int msorb_pyramid_batch(msorb_extractor* h, const uint8_t* d_images, int n_images, int rows, int cols, size_t row_stride,
                         size_t image_stride) {
+    if (h && h->pending_batch) { set_error("a submitted batch of this handle has not been waited for"); return MSORB_E_INVALID; }
     if (!h || n_images < 0) return MSORB_E_INVALID;
     if (!d_images || rows <= 0 || cols <= 0) return MSORB_E_EMPTY;
     if (n_images == 0) return MSORB_OK;

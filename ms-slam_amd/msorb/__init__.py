@@ -230,6 +230,30 @@ class ORBextractor:
                                           _np_ptr(counts), _np_ptr(mono)), "msorb_extract_batch")
         return counts, mono, d_kps, d_desc
 
+    def extract_batch_submit(self, images, lapping=(0, 0), out=None):
+        """msorb_extract_batch_submit: enqueue only; images / out must stay alive and untouched until extract_batch_wait()."""
+        import torch
+        assert images.is_cuda and images.dtype == torch.uint8 and images.dim() == 3 and images.stride(2) == 1
+        n, rows, cols = images.shape
+        if out is None:
+            out = (torch.empty((n, self.capacity, 28), dtype=torch.uint8, device=images.device),
+                   torch.empty((n, self.capacity, 32), dtype=torch.uint8, device=images.device))
+        L = self.L
+        L.msorb_extract_batch_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int,
+                                                 C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        _check(L.msorb_extract_batch_submit(self.h, images.data_ptr(), n, rows, cols, images.stride(1), images.stride(0), lapping[0],
+                                            lapping[1], out[0].data_ptr(), out[1].data_ptr(), self.capacity), "msorb_extract_batch_submit")
+        self._pending = (n, images, out)
+
+    def extract_batch_wait(self):
+        """msorb_extract_batch_wait -> (counts, mono, d_keypoints, d_desc) of the submitted batch."""
+        n, _, out = getattr(self, "_pending", None) or (0, None, (None, None))   # nothing pending: the library reports it
+        counts, mono = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        self.L.msorb_extract_batch_wait.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(self.L.msorb_extract_batch_wait(self.h, _np_ptr(counts), _np_ptr(mono)), "msorb_extract_batch_wait")
+        self._pending = None
+        return counts[:n], mono[:n], out[0], out[1]
+
     def set_host_pyramid(self, on=True):
         self.L.msorb_extractor_set_host_pyramid.argtypes = [C.c_void_p, C.c_int]
         _check(self.L.msorb_extractor_set_host_pyramid(self.h, int(on)), "msorb_extractor_set_host_pyramid")
@@ -986,4 +1010,5 @@ def stereo_matches_split(ex_left, ex_right, counts_left, d_kps_left, d_desc_left
     return d_ur, d_dp, d_oob[:n_pairs].cpu().numpy(), ms.value
 
 
-EXPORTS = EXPORTS + ("msorb_fuse_search", "msorb_search_by_projection_kf", "msorb_search_by_projection_sim3")
+EXPORTS = EXPORTS + ("msorb_fuse_search", "msorb_search_by_projection_kf", "msorb_search_by_projection_sim3",
+                     "msorb_extract_batch_submit", "msorb_extract_batch_wait")

@@ -352,3 +352,40 @@ def test_misaligned_batch_staged_and_in_place(msorb_mod, oracle):
         os.environ.pop("MSORB_NO_STAGE0", None)
         os.environ.pop("MSORB_STAGE0_MIN", None)
         ex.close()
+
+
+def test_batch_submit_wait_two_handles_in_flight(msorb_mod, oracle):
+    """msorb_extract_batch_submit / _wait: two handles, four batches kept two deep in flight; every batch equals the synchronous
+    call on the same images; a handle refuses a second submit (or any other entry) while a batch is pending."""
+    import torch
+    cfg = CONFIGS["euroc"]
+    n = 16
+    batches = [torch.from_numpy(np.stack([synth.image(1200 + 10 * b + (i % 4), cfg["rows"], cfg["cols"]) for i in range(n)])).cuda()
+               for b in range(4)]
+    ex = [msorb_mod.ORBextractor(cfg["nfeatures"], cfg["scale"], cfg["nlevels"], cfg["ini_th"], cfg["min_th"]) for _ in range(2)]
+    ref = msorb_mod.ORBextractor(cfg["nfeatures"], cfg["scale"], cfg["nlevels"], cfg["ini_th"], cfg["min_th"])
+    want = []
+    for b in batches:
+        c, m, k, d = ref.extract_batch(b)
+        want.append((c.copy(), m.copy(), k.clone(), d.clone()))
+    got = [None] * 4
+    ex[0].extract_batch_submit(batches[0])
+    with pytest.raises(msorb_mod.MsorbError) as e:
+        ex[0].extract_batch_submit(batches[1])
+    assert e.value.code == msorb_mod.E_INVALID
+    with pytest.raises(msorb_mod.MsorbError):
+        ex[0].pyramid_batch(batches[1])
+    for b in range(1, 4):
+        ex[b & 1].extract_batch_submit(batches[b])          # batch b goes in before batch b - 1 is waited for
+        got[b - 1] = ex[(b - 1) & 1].extract_batch_wait()
+    got[3] = ex[1].extract_batch_wait()
+    with pytest.raises(msorb_mod.MsorbError):
+        ex[1].extract_batch_wait()                           # nothing pending
+    for b in range(4):
+        c, m, k, d = got[b]
+        wc, wm, wk, wd = want[b]
+        assert np.array_equal(c, wc) and np.array_equal(m, wm)
+        for i in range(n):
+            assert torch.equal(k[i, :c[i]], wk[i, :c[i]]) and torch.equal(d[i, :c[i]], wd[i, :c[i]])
+    for e_ in ex + [ref]:
+        e_.close()
