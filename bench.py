@@ -224,6 +224,9 @@ def main():
         mine = [stereo_split.FeatureBlock(n_img, cap, dev) for _ in range(2)]
         theirs = [stereo_split.FeatureBlock(half, cap, dev) for _ in range(2)]
         exs = [ex, make_ex()]
+        if not (args.isolated or os.environ.get("MSORB_BENCH_SYNC")):
+            for e in exs:
+                e.set_overlap(1, True)   # two batches in flight, one sub-batch each (see the N = 1 loop below)
         ex_rp = make_ex()   # pyramid-only handle for the other eye's images of the pairs this rank joins
     step_no = [0]
     fence_kp = [0]
@@ -255,7 +258,8 @@ def main():
     # on its own batch buffers; the timed region is bracketed by fence() on both sides.  (--isolated / the stage timings use
     # the synchronous call.)
     pipelined = world == 1 and not args.isolated and not os.environ.get("MSORB_BENCH_SYNC")
-    mode = {"pipelined": pipelined}
+    mode = {"pipelined": pipelined, "sync_nccl": bool(args.isolated or os.environ.get("MSORB_BENCH_SYNC"))}
+    submitted = [False, False]
     depth = int(os.environ.get("MSORB_BENCH_DEPTH", "2")) if pipelined else 1   # batches in flight
     exp = [ex] + [make_ex() for _ in range(depth - 1)]
     all_ex.extend(exp[1:])
@@ -292,22 +296,41 @@ def main():
             return done
         b = step_no[0] & 1
         step_no[0] += 1
-        stereo_split.finish(pending[b])          # the block's previous exchange (two steps ago) must be over
+        stereo_split.finish(pending[b])          # the block's previous exchange (started one step ago) must be over
         pending[b] = []
         associate(b)                              # ... and its pairs are joined before block / handle are reused
-        # the extractor writes straight into the send block
-        last_ex[0] = exs[b]
-        counts, mono, _, _ = exs[b].extract_batch(images, (0, 0), out=(mine[b].kps, mine[b].desc))
-        # stereo split: right-eye rank -> left-eye rank (replaces the join of Frame.cc:122-125)
+        if mode["sync_nccl"]:                     # stage timings: one batch at a time
+            last_ex[0] = exs[b]
+            counts, mono, _, _ = exs[b].extract_batch(images, (0, 0), out=(mine[b].kps, mine[b].desc))
+            ship(b, counts)
+            return int(counts.sum())
+        # two batches in flight, as at N = 1: this step's extraction is enqueued (the extractor writes straight into the send
+        # block), then the previous step's is waited for and its feature block goes on the wire
+        exs[b].extract_batch_submit(images, (0, 0), out=(mine[b].kps, mine[b].desc))
+        submitted[b] = True
+        return collect(b ^ 1)
+
+    def ship(b, counts):
+        """stereo split: swap the feature blocks of block b with the partner (replaces the join of Frame.cc:122-125)"""
         mine[b].counts.copy_(torch.from_numpy(counts))
         pending[b] = stereo_split.swap_halves_async(dist, rank, world, mine[b], theirs[b])
         filled[b] = bool(pending[b])
+
+    def collect(b):
+        if not submitted[b]:
+            return 0
+        counts, _, _, _ = exs[b].extract_batch_wait()
+        submitted[b] = False
+        last_ex[0] = exs[b]
+        ship(b, counts)
         return int(counts.sum())
 
     def fence():
         if mode["pipelined"]:
             fence_kp[0] += drain()
         if world > 1:
+            for b in range(2):
+                fence_kp[0] += collect(b)
             for b in range(2):
                 stereo_split.finish(pending[b])
                 pending[b] = []
@@ -328,7 +351,7 @@ def main():
     kp_total = 0
     for _ in range(args.steps):
         kp_total += step()
-        if not pipelined:
+        if not pipelined and (world == 1 or mode["sync_nccl"]):
             for k, v in last_ex[0].stage_ms().items():
                 overlapped_acc[k] += v
     fence()
@@ -341,6 +364,7 @@ def main():
     stage_acc = {k: 0.0 for k in msorb.STAGES}
     join = dict(assoc)   # association statistics of the timed region only
     mode["pipelined"] = False   # the stage timings use the synchronous call on one handle
+    mode["sync_nccl"] = True
     for e in all_ex:
         e.set_overlap(1, False)
     step()
@@ -477,14 +501,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: KITTI-00 stereo 1241x376, 2000 feat/frame, pyramid+FAST+rBRIEF",
                        "pairs_per_step_per_gpu": B if world == 1 else B, "images_per_step_per_gpu": n_img,
-                       "batches_in_flight": depth,
+                       "batches_in_flight": depth if world == 1 else (1 if args.isolated or os.environ.get("MSORB_BENCH_SYNC") else 2),
                        "parallelism": ("1 GPU, both eyes; msorb_extract_batch_submit / _wait on two alternating handles: step k+1 is enqueued "
                                        "before step k is waited for" if pipelined else "1 GPU, both eyes") if world == 1 else f"stereo L/R split over {world} GPUs: one eye per rank; partners swap the keypoints / "
                                                                              "descriptors of half of their images (RCCL send/recv over xGMI) and each joins half of the pairs (stereo association)"},
             "stage_ms_per_step": {k: round(v, 4) for k, v in stages.items()},
             "stage_ms_per_step_note": "each stage's kernels alone on the GPU (5 extra steps, overlap off, HIP events on the "
                                       "launching stream); 'select' = device quadtree + output layout",
-            "stage_ms_per_step_overlapped": None if pipelined else {k: round(v, 4) for k, v in stages_overlapped.items()},
+            "stage_ms_per_step_overlapped": None if (pipelined or (world > 1 and not args.isolated and not os.environ.get("MSORB_BENCH_SYNC"))) else {k: round(v, 4) for k, v in stages_overlapped.items()},
             "stage_ms_per_step_overlapped_note": "timed region: sum over the 2 concurrent sub-batches of each stage's event "
                                                  "interval (intervals overlap, so the sum exceeds ms_per_step); not recorded when "
                                                  "two batches are in flight (MSORB_BENCH_SYNC=1 for the one-batch-at-a-time loop)",
