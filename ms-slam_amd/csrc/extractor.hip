@@ -1022,7 +1022,7 @@ int msorb_extract_stereo(msorb_extractor* h, const uint8_t* left, const uint8_t*
     const size_t plane = (size_t)g0.pitch * rows;
     if ((rc = h->d_st_block.ensure(out_bytes)) || (rc = h->d_st_img.ensure(2 * plane + 256)) ||
         (rc = h->h_img_pin.ensure(2 * plane)) || (rc = h->h_out_pin.ensure(out_bytes)) || (rc = h->d_st_sad.ensure(cap)) ||
-        (rc = h->d_st_rows.ensure((size_t)rows + 1)) || (rc = h->d_st_list.ensure(row_cap)))
+        (rc = h->d_st_rows.ensure((size_t)rows + 1)) || (rc = h->d_st_list.ensure((size_t)row_cap * 2)))
         return rc;
     for (int y = 0; y < rows; y++) {
         memcpy(h->h_img_pin.p + (size_t)y * g0.pitch, left + (size_t)y * stride_left, cols);
@@ -1060,7 +1060,7 @@ int msorb_extract_stereo(msorb_extractor* h, const uint8_t* left, const uint8_t*
     b.pair_step = 2;
     b.A.kpR = d_kps + cap; b.A.descR = d_desc + (size_t)cap * 32;
     b.countsL = h->d_sel_count.p; b.countsR = h->d_sel_count.p + 1;
-    b.row_begin = h->d_st_rows.p; b.row_list = h->d_st_list.p; b.row_cap = row_cap;
+    b.row_begin = h->d_st_rows.p; b.row_list = reinterpret_cast<int2*>(h->d_st_list.p); b.row_cap = row_cap;
     b.counts_out = reinterpret_cast<int*>(blk + o_cnt);
     launch_stereo_match_batch(b, 1, cap, s);
     uint8_t* o = h->h_out_pin.p;
@@ -1128,7 +1128,7 @@ int msorb_extract_stereo_split(msorb_extractor* L, msorb_extractor* R, const uin
                  o_oob = o_dp + (size_t)cap * 4, o_cnt = o_oob + 4, out_bytes = o_oob + 16;
     HIPCHK(hipSetDevice(L->device));
     if ((rc = L->d_st_block.ensure(out_bytes)) || (rc = L->h_out_pin.ensure(out_bytes)) || (rc = L->d_st_sad.ensure(cap)) ||
-        (rc = L->d_st_rows.ensure((size_t)rows + 1)) || (rc = L->d_st_list.ensure(row_cap)) ||
+        (rc = L->d_st_rows.ensure((size_t)rows + 1)) || (rc = L->d_st_list.ensure((size_t)row_cap * 2)) ||
         (rc = L->d_gather_pyr.ensure(g.pyramid_bytes + 256)) || (rc = L->d_gather_cnt.ensure(4)))
         return rc;
     // right device: its outputs as one block [kps cap][desc cap*32]
@@ -1205,7 +1205,7 @@ int msorb_extract_stereo_split(msorb_extractor* L, msorb_extractor* R, const uin
     b.A.u_right = reinterpret_cast<float*>(blk + o_ur); b.A.depth = reinterpret_cast<float*>(blk + o_dp);
     b.A.sad = L->d_st_sad.p; b.A.n_oob = reinterpret_cast<int*>(blk + o_oob);
     b.capacity = cap;
-    b.row_begin = L->d_st_rows.p; b.row_list = L->d_st_list.p; b.row_cap = row_cap;
+    b.row_begin = L->d_st_rows.p; b.row_list = reinterpret_cast<int2*>(L->d_st_list.p); b.row_cap = row_cap;
     b.counts_out = reinterpret_cast<int*>(blk + o_cnt);
     launch_stereo_match_batch(b, 1, cap, s);
     uint8_t* o = L->h_out_pin.p;

@@ -38,6 +38,30 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return v;
 }
 
+// The same reductions with DPP row operations only (no LDS crossbar round trip per step): xor-butterfly inside each row of 16
+// lanes, then the row results are chained through lanes 15 / 31 into row 3; lane 63 holds the result, returned wave-uniform.
+__device__ __forceinline__ uint32_t wave_sum_u32_dpp(uint32_t x) {
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141 /* row_half_mirror */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140 /* row_mirror */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ uint32_t wave_min_u32_dpp(uint32_t x) {
+    int v = (int)x;
+    auto mn = [](int a, int b) { return (int)min((uint32_t)a, (uint32_t)b); };
+    v = mn(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+    v = mn(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+    v = mn(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+    v = mn(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+    v = mn(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));   // lanes outside the row mask keep their own value
+    v = mn(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
+
 constexpr uint64_t kNoKey = ~0ull;
 
 // per-lane sorted insertion into a 4-deep (key, idx) list
@@ -173,7 +197,8 @@ struct StereoPairView {
     int nR;
     float *u_right, *depth;
     int *sad, *n_oob;
-    const int *row_begin, *row_list;
+    const int* row_begin;
+    const int2* row_list;
     size_t img;                 // image index of the pair inside the batch arrays (0 for the per-frame call)
     const size_t *img_strideL, *img_strideR;  // per level, nullptr for the per-frame call
 };
@@ -186,34 +211,45 @@ __device__ __forceinline__ void stereo_match_one(const StereoArgs& G, const Ster
     const int row = (int)vL;
     const float minD = 0.f, maxD = __fdiv_rn(G.mbf, G.mb);
     const float minU = __fsub_rn(uL, maxD), maxU = __fsub_rn(uL, minD);
-    uint64_t best = kNoKey;
+    // key = distance << 22 | iR (iR < 2^22): one 32-bit DPP min-reduction gives the reference's (distance, iR) minimum
+    constexpr uint32_t kNoKey32 = 0xFFFFFFFFu;
+    uint32_t best = kNoKey32;
+    float best_x = 0.f;   // x of this lane's best candidate
     if (row >= 0 && row < G.rows0 && !(maxU < 0)) {
         const uint64_t* dl = reinterpret_cast<const uint64_t*>(A.descL + (size_t)iL * 32);
         const uint64_t a[4] = {dl[0], dl[1], dl[2], dl[3]};
         // candidates: the row's entry of the vRowIndices table (:760-770) when one was built (any order: the result is
         // the lexicographic minimum of (distance, iR)), else every right keypoint with the band test done here
-        const int* list = A.row_begin ? A.row_list + A.row_begin[row] : nullptr;
+        const int2* list = A.row_begin ? A.row_list + A.row_begin[row] : nullptr;
         const int n_cand = A.row_begin ? A.row_begin[row + 1] - A.row_begin[row] : A.nR;
         for (int j = lane; j < n_cand; j += 64) {
-            const int iR = list ? list[j] : j;
-            const msorb_keypoint kr = A.kpR[iR];
-            if (!list) {
+            int iR, octR;
+            float xR;
+            if (list) {   // the table entry carries what the filters need: one dependent load less per candidate
+                const int2 e = list[j];
+                iR = e.x & 0xffffff; octR = (int)((uint32_t)e.x >> 24); xR = __int_as_float(e.y);
+            } else {
+                iR = j;
+                const msorb_keypoint kr = A.kpR[iR];
                 const float r = __fmul_rn(2.0f, G.scale[kr.octave]);
                 const int maxr = (int)ceilf(__fadd_rn(kr.y, r)), minr = (int)floorf(__fsub_rn(kr.y, r));
                 if (row < minr || row > maxr) continue;
+                octR = kr.octave; xR = kr.x;
             }
-            if (kr.octave < levelL - 1 || kr.octave > levelL + 1) continue;
-            if (!(kr.x >= minU && kr.x <= maxU)) continue;
+            if (octR < levelL - 1 || octR > levelL + 1) continue;
+            if (!(xR >= minU && xR <= maxU)) continue;
             const int d = hamming256(a, reinterpret_cast<const uint64_t*>(A.descR + (size_t)iR * 32));
-            const uint64_t key = ((uint64_t)d << 32) | (uint32_t)iR;
-            best = key < best ? key : best;
+            const uint32_t key = ((uint32_t)d << 22) | (uint32_t)iR;
+            if (key < best) { best = key; best_x = xR; }
         }
     }
-    best = wave_min_u64(best);
-    const int bestDist = best == kNoKey ? 256 : (int)(best >> 32);
+    const uint32_t mine = best;
+    best = wave_min_u32_dpp(best);
+    const int bestDist = best == kNoKey32 ? 256 : (int)(best >> 22);
     if (bestDist < kThHigh && bestDist < (kThHigh + kThLow) / 2) {
-        const int bestIdxR = (int)(best & 0xffffffffu);
-        const float uR0 = A.kpR[bestIdxR].x;
+        // x of the winner comes from the lane that holds it (keys are unique): no keypoint load behind the reduction
+        const unsigned long long owner = __ballot(mine == best);
+        const float uR0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best_x), (int)__builtin_ctzll(owner)));
         const float sf = G.inv_scale[levelL];
         const float scaleduL = roundf(__fmul_rn(kpL.x, sf));
         const float scaledvL = roundf(__fmul_rn(kpL.y, sf));
@@ -227,25 +263,60 @@ __device__ __forceinline__ void stereo_match_one(const StereoArgs& G, const Ster
         if (ok) {
             const uint8_t* pl = G.pyrL[levelL] + (A.img_strideL ? A.img * A.img_strideL[levelL] : 0) + (size_t)y0 * G.pitchL[levelL] + xL0;
             const uint8_t* pr = G.pyrR[levelL] + (A.img_strideR ? A.img * A.img_strideR[levelL] : 0) + (size_t)y0 * G.pitchR[levelL] + xR0;
-            // lane -> window pixel(s): 121 pixels over 64 lanes (two passes)
-            int vl0 = 0, vl1 = 0, o0 = 0, o1 = 0;
-            const int p0 = lane, p1 = lane + 64;
+            // The 11 x 11 left window and the 11 x 21 right strip go to LDS as whole dwords (3 load instructions per wave; the
+            // byte-per-lane form needed 24, each a separate trip through the texture addresser — that, not the arithmetic,
+            // was the kernel's bottleneck).  Then lane (row r = lane & 15, offset group lane >> 4) forms, in three passes, the
+            // row SAD of offset inc = 4 pass + (lane >> 4) with three v_sad_u8 on byte-aligned dwords (v_alignbyte), and a
+            // 4-step DPP add inside each row of 16 lanes sums the 11 window rows.
+            __shared__ uint32_t win_all[4][11 * 12];   // per wave and window row: 8 right dwords, 4 left dwords
+            uint32_t* win = win_all[threadIdx.x >> 6];
+            const int pitchL = G.pitchL[levelL], pitchR = G.pitchR[levelL];
+            const uint32_t phL = (uint32_t)(reinterpret_cast<uintptr_t>(pl) & 3), phR = (uint32_t)(reinterpret_cast<uintptr_t>(pr) & 3);
+            // last dword that may be read: the end of the level plane of this image (lanes clamped there load bytes beyond the window)
+            const uint8_t* planeL = G.pyrL[levelL] + (A.img_strideL ? A.img * A.img_strideL[levelL] : 0);
+            const uint8_t* planeR = G.pyrR[levelL] + (A.img_strideR ? A.img * A.img_strideR[levelL] : 0);
+            const uintptr_t endL = (reinterpret_cast<uintptr_t>(planeL) + (size_t)rows * pitchL - 4) & ~(uintptr_t)3;
+            const uintptr_t endR = (reinterpret_cast<uintptr_t>(planeR) + (size_t)rows * pitchR - 4) & ~(uintptr_t)3;
             {
-                const int yy = p0 / 11, xx = p0 - yy * 11;
-                vl0 = pl[(size_t)yy * G.pitchL[levelL] + xx];
-                o0 = yy * G.pitchR[levelL] + xx;
+                const int r = lane >> 3, c = lane & 7;
+                const uintptr_t a0 = reinterpret_cast<uintptr_t>(pr - phR) + (size_t)r * pitchR + 4 * c;
+                const uint32_t v0 = *reinterpret_cast<const uint32_t*>(min(a0, endR));            // rows 0..7 of the right strip
+                uint32_t v1 = 0, v2 = 0;
+                const uintptr_t a1 = reinterpret_cast<uintptr_t>(pr - phR) + (size_t)(r + 8) * pitchR + 4 * c;
+                if (lane < 24) v1 = *reinterpret_cast<const uint32_t*>(min(a1, endR));             // rows 8..10
+                const int rl = lane >> 2, cl = lane & 3;
+                const uintptr_t a2 = reinterpret_cast<uintptr_t>(pl - phL) + (size_t)rl * pitchL + 4 * cl;
+                if (lane < 44) v2 = *reinterpret_cast<const uint32_t*>(min(a2, endL));             // the left window
+                win[r * 12 + c] = v0;
+                if (lane < 24) win[(r + 8) * 12 + c] = v1;
+                if (lane < 44) win[rl * 12 + 8 + cl] = v2;
             }
-            if (p1 < 121) {
-                const int yy = p1 / 11, xx = p1 - yy * 11;
-                vl1 = pl[(size_t)yy * G.pitchL[levelL] + xx];
-                o1 = yy * G.pitchR[levelL] + xx;
-            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int wr = lane & 15, grp = lane >> 4;
+            const bool row_ok = wr < 11;
+            const uint32_t* wrow = win + (row_ok ? wr : 0) * 12;
+            const uint32_t l0 = __builtin_amdgcn_alignbyte(wrow[9], wrow[8], phL), l1 = __builtin_amdgcn_alignbyte(wrow[10], wrow[9], phL);
+            const uint32_t l2 = __builtin_amdgcn_alignbyte(wrow[11], wrow[10], phL) & 0x00ffffffu;   // 11 bytes = 4 + 4 + 3
             int sad[11];
 #pragma unroll
-            for (int inc = 0; inc < 11; inc++) {
-                int s = abs(vl0 - (int)pr[o0 + inc]);
-                if (p1 < 121) s += abs(vl1 - (int)pr[o1 + inc]);
-                sad[inc] = wave_sum_i32(s);
+            for (int pass = 0; pass < 3; pass++) {
+                const int inc = 4 * pass + grp;                       // < 11 except group 3 of the last pass
+                const uint32_t off = phR + (uint32_t)min(inc, 10), d0 = off >> 2;
+                const uint32_t r0 = __builtin_amdgcn_alignbyte(wrow[d0 + 1], wrow[d0], off);
+                const uint32_t r1 = __builtin_amdgcn_alignbyte(wrow[d0 + 2], wrow[d0 + 1], off);
+                const uint32_t r2 = __builtin_amdgcn_alignbyte(wrow[d0 + 3], wrow[d0 + 2], off) & 0x00ffffffu;
+                uint32_t sv = __builtin_amdgcn_sad_u8(l0, r0, 0u);
+                sv = __builtin_amdgcn_sad_u8(l1, r1, sv);
+                sv = __builtin_amdgcn_sad_u8(l2, r2, sv);
+                int v = row_ok ? (int)sv : 0;
+                v += __builtin_amdgcn_update_dpp(0, v, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, false);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x141 /* row_half_mirror */, 0xf, 0xf, false);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x140 /* row_mirror */, 0xf, 0xf, false);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (4 * pass + j < 11) sad[4 * pass + j] = __builtin_amdgcn_readlane(v, 16 * j);
             }
             int bestS = 0x7fffffff, bestinc = 0;
 #pragma unroll
@@ -305,14 +376,16 @@ __global__ __launch_bounds__(256) void stereo_rowtable_kernel(StereoBatchArgs B)
     const int nR = B.countsR ? B.countsR[img] : B.A.nR;
     const msorb_keypoint* kpR = B.A.kpR + img * B.capacity;
     int* row_begin = B.row_begin + (size_t)pair * (rows0 + 1);
-    int* row_list = B.row_list + (size_t)pair * B.row_cap;
+    int2* row_list = B.row_list + (size_t)pair * B.row_cap;
     for (int r = t; r < rows0; r += 256) cnt[r] = 0;
     // each right keypoint's row band, computed once: the first kBandCache rounds of the 256-strided loop keep it in
     // registers (all their loads in flight together), later rounds (more than 2048 right keypoints) recompute it
     constexpr int kBandCache = 8;
     int band[kBandCache];  // minr | maxr << 16, -1 = no keypoint
-    auto band_of = [&](int iR) -> int {
+    int2 entry[kBandCache];  // the keypoint's table entry: {iR | octave << 24, bits of x}
+    auto band_of = [&](int iR, int2& e) -> int {
         const msorb_keypoint kr = kpR[iR];
+        e = int2{iR | (kr.octave << 24), __float_as_int(kr.x)};
         const float r = __fmul_rn(2.0f, B.A.scale[kr.octave]);
         const int maxr = min((int)ceilf(__fadd_rn(kr.y, r)), rows0 - 1), minr = max((int)floorf(__fsub_rn(kr.y, r)), 0);
         return maxr >= minr ? (minr | (maxr << 16)) : -1;
@@ -320,7 +393,7 @@ __global__ __launch_bounds__(256) void stereo_rowtable_kernel(StereoBatchArgs B)
 #pragma unroll
     for (int k = 0; k < kBandCache; k++) {
         const int iR = t + k * 256;
-        band[k] = iR < nR ? band_of(iR) : -1;
+        band[k] = iR < nR ? band_of(iR, entry[k]) : -1;
     }
     __syncthreads();
 #pragma unroll
@@ -328,7 +401,8 @@ __global__ __launch_bounds__(256) void stereo_rowtable_kernel(StereoBatchArgs B)
         if (band[k] >= 0)
             for (int y = band[k] & 0xffff; y <= (band[k] >> 16); y++) atomicAdd(&cnt[y], 1);
     for (int iR = t + kBandCache * 256; iR < nR; iR += 256) {
-        const int bd = band_of(iR);
+        int2 e;
+        const int bd = band_of(iR, e);
         if (bd >= 0)
             for (int y = bd & 0xffff; y <= (bd >> 16); y++) atomicAdd(&cnt[y], 1);
     }
@@ -354,18 +428,19 @@ __global__ __launch_bounds__(256) void stereo_rowtable_kernel(StereoBatchArgs B)
     for (int r = t; r <= rows0; r += 256) row_begin[r] = beg[r];
     for (int r = t; r < rows0; r += 256) cnt[r] = beg[r];
     __syncthreads();
-    auto fill = [&](int iR, int bd) {
+    auto fill = [&](const int2& e, int bd) {
         for (int y = bd & 0xffff; y <= (bd >> 16); y++) {
             const int pos = atomicAdd(&cnt[y], 1);
-            if (pos < B.row_cap) row_list[pos] = iR;
+            if (pos < B.row_cap) row_list[pos] = e;
         }
     };
 #pragma unroll
     for (int k = 0; k < kBandCache; k++)
-        if (band[k] >= 0) fill(t + k * 256, band[k]);
+        if (band[k] >= 0) fill(entry[k], band[k]);
     for (int iR = t + kBandCache * 256; iR < nR; iR += 256) {
-        const int bd = band_of(iR);
-        if (bd >= 0) fill(iR, bd);
+        int2 e;
+        const int bd = band_of(iR, e);
+        if (bd >= 0) fill(e, bd);
     }
 }
 

@@ -46,7 +46,8 @@ struct StereoArgs {
     float mb, mbf;
     float *u_right, *depth;
     int *sad, *n_oob;
-    const int *row_begin, *row_list;  // vRowIndices as CSR over the rows of level 0 (nullptr: band test per candidate)
+    const int* row_begin;      // vRowIndices as CSR over the rows of level 0 (nullptr: band test per candidate)
+    const int2* row_list;      // entry = {iR | octave << 24, bits of kpR[iR].x}: the candidate filters need no keypoint load
 };
 
 // A: the pointers of pair 0 (A.kpL / A.descL / A.pyrL = left eye, A.kpR / A.descR / A.pyrR = right eye).  Pair p lives
@@ -59,7 +60,8 @@ struct StereoBatchArgs {
     int capacity;
     int pair_step;
     const int *countsL, *countsR;  // device: n_keypoints of the left / right image of pair 0 (pair p at [p * pair_step])
-    int *row_begin, *row_list;  // per pair: [rows0 + 1] and [row_cap]
+    int* row_begin;             // per pair: [rows0 + 1]
+    int2* row_list;             // per pair: [row_cap] entries {iR | octave << 24, bits of x}
     int row_cap;
     int* counts_out;            // optional: the median kernel copies the counts of pair p to [2p], [2p+1] (fused per-frame calls)
 };

@@ -971,7 +971,7 @@ static int stereo_batch_impl(msorb_extractor* left, msorb_extractor* right, int 
         return MSORB_E_INVALID;
     }
     if ((rc = scr.sad.ensure((size_t)n_pairs * capacity)) || (rc = scr.oob.ensure((size_t)n_pairs)) ||
-        (rc = scr.row_begin.ensure((size_t)n_pairs * (rows0 + 1))) || (rc = scr.row_list.ensure((size_t)n_pairs * row_cap)))
+        (rc = scr.row_begin.ensure((size_t)n_pairs * (rows0 + 1))) || (rc = scr.row_list.ensure((size_t)n_pairs * row_cap * 2)))
         return rc;
     int* oob = d_n_oob ? d_n_oob : scr.oob.p;
     StereoBatchArgs b{};
@@ -996,7 +996,7 @@ static int stereo_batch_impl(msorb_extractor* left, msorb_extractor* right, int 
     b.A.mb = mb; b.A.mbf = mbf;
     b.A.u_right = d_u_right; b.A.depth = d_depth; b.A.sad = scr.sad.p; b.A.n_oob = oob;
     b.capacity = capacity;
-    b.row_begin = scr.row_begin.p; b.row_list = scr.row_list.p; b.row_cap = row_cap;
+    b.row_begin = scr.row_begin.p; b.row_list = reinterpret_cast<int2*>(scr.row_list.p); b.row_cap = row_cap;
     if (right) HIPCHK(hipStreamSynchronize(s_r));  // the right handle's pyramid was built on its own stream
     HIPCHK(hipMemsetAsync(oob, 0, (size_t)n_pairs * sizeof(int), s));
     HIPCHK(hipEventRecord(scr.e0, s));
