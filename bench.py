@@ -409,6 +409,16 @@ def main():
         ceil_mfma = mfma_pops / 512 / 1e9
         ceil_valu = 1024 * 2.4e9 * 64 / (8 * 2.5 + 8 * 4.2) / 1e9
         ceil_valu_top2 = 1024 * 2.4e9 * 64 / (8 * 2.5 + 11 * 4.2) / 1e9
+        # the north_star's own formulation (xor + __builtin_popcount per pair, no MFMA) measured beside it on the same descriptors
+        os.environ["MSORB_DENSE_VARIANT"] = "24"
+        try:
+            msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=2, device=local)
+            bi_v, bd_v, sd_v, ms_v = msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=reps, device=local)
+        finally:
+            del os.environ["MSORB_DENSE_VARIANT"]
+        bi_m, bd_m, sd_m, _ = msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=1, device=local)
+        same_kernels = bool(torch.equal(bi_v, bi_m) and torch.equal(bd_v, bd_m) and torch.equal(sd_v, sd_m))
+        g_v = pairs * reps / (ms_v * 1e-3) / 1e9
         hamming = {"gpairs_per_s": round(g, 2), "pairs_per_launch": pairs,
                    "ms_per_launch": round(ms / reps, 4), "kernel": "dense_top2_mfma_kernel (v_mfma_i32_32x32x32_i8)",
                    "ceiling_gpairs_per_s": round(ceil_mfma, 1), "frac": round(g / ceil_mfma, 3),
@@ -416,7 +426,12 @@ def main():
                    "valu_formulation_ceiling_gpairs_per_s": round(ceil_valu, 1),
                    "valu_formulation_ceiling_with_top2_gpairs_per_s": round(ceil_valu_top2, 1),
                    "bound": "matrix-core issue (MFMA) with the top-2 bookkeeping (v_med3 + v_min per pair) interleaved under it; "
-                            "not HBM: (Q+T)*32 B per frame are reused Q*T times"}
+                            "not HBM: (Q+T)*32 B per frame are reused Q*T times",
+                   "popcount_kernel": {"what": "the north_star's formulation: dense_top2_kernel<2, 4>, v_xor + accumulating v_bcnt per "
+                                               "dword, no MFMA (MSORB_DENSE_VARIANT=24); same inputs, same launch count",
+                                       "gpairs_per_s": round(g_v, 2), "ms_per_launch": round(ms_v / reps, 4),
+                                       "frac_of_valu_ceiling_with_top2": round(g_v / ceil_valu_top2, 3),
+                                       "identical_results": same_kernels}}
         if args.cpu_pairs > 0 and rank == 0:
             # CPU leg of the matcher on a bounded sample: ORBmatcher::DescriptorDistance brute force (oracle, 1 thread) on
             # the first stereo pair's descriptors; its result also cross-checks the GPU's indices and distances
