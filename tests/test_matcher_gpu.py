@@ -143,6 +143,64 @@ def test_dense_top2_batch(msorb_mod, oracle):
     assert oracle.descriptor_distance(q[0, 0], t[0, bi[0, 0]]) == bd[0, 0] == 0
 
 
+def test_stereo_windows_at_the_image_borders(msorb_mod, oracle):
+    """Hand-placed keypoints whose 11 x 11 / 11 x 21 SAD windows touch the last rows and columns of every pyramid level, on a
+    tightly packed batch (row pitch = 1241 bytes, level 0 read in place): the kernel stages the windows as whole dwords, so
+    the reads around the last row of the last image are the ones that must stay inside the buffers — and every result must
+    still equal the oracle's byte-wise restatement of Frame.cc:829-897."""
+    import torch
+    cfg = synth.KITTI
+    host = synth.stereo_batch(2, cfg["rows"], cfg["cols"], seed0=77)
+    nz = np.random.Generator(np.random.PCG64(9)).integers(-3, 4, host[2].shape)
+    host[3] = np.clip(host[2].astype(np.int32) + nz, 0, 255).astype(np.uint8)   # pair 1: the same view + noise (non-zero SADs)
+    mbf, mb = mc.KITTI_BF, mc.KITTI_BF / mc.KITTI_FX
+    ex = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7)
+    try:
+        d_img = torch.from_numpy(host).cuda()
+        counts, _, d_kps, d_desc = ex.extract_batch(d_img, (0, 0))
+        scale = np.asarray(ex.GetScaleFactors(), np.float32)
+        inv = np.asarray(ex.GetInverseScaleFactors(), np.float32)
+        rng = np.random.Generator(np.random.PCG64(3))
+        kl, kr = [], []
+        for o in range(8):
+            lvl = ex.debug_level(2, o)
+            rows_o, cols_o = lvl.shape
+            for dv in range(0, 4):
+                for du in range(0, 4):
+                    sv = rows_o - 6 - dv                     # window rows sv - 5 .. sv + 5: the last one is row rows_o - 1 - dv
+                    suR = cols_o - 11 - du                   # right strip columns suR - 10 .. suR + 10
+                    suL = min(suR + 7 * (o % 3), cols_o - 6 - du)
+                    for su, lst in ((suL, kl), (suR, kr)):
+                        lst.append((np.float32(su) * scale[o], np.float32(sv) * scale[o], o))
+                    # and the top-left corner
+                    kl.append((np.float32(5 + du + 9) * scale[o], np.float32(5 + dv) * scale[o], o))
+                    kr.append((np.float32(10 + du) * scale[o], np.float32(5 + dv) * scale[o], o))
+        n = len(kl)
+        K = oracle.KP_DTYPE
+        kpl, kpr = np.zeros(n, K), np.zeros(n, K)
+        for arr, lst in ((kpl, kl), (kpr, kr)):
+            arr["x"] = [t[0] for t in lst]; arr["y"] = [t[1] for t in lst]; arr["octave"] = [t[2] for t in lst]
+            arr["size"] = 31; arr["angle"] = 0; arr["response"] = 50; arr["class_id"] = -1
+        desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)   # pair i shares one descriptor: distance 0
+        kps_np = d_kps.cpu().numpy().copy()
+        desc_np = d_desc.cpu().numpy().copy()
+        for img, arr in ((2, kpl), (3, kpr)):
+            kps_np[img, :n] = arr.view(np.uint8).reshape(n, 28)
+            desc_np[img, :n] = desc
+        cnt = counts.copy()
+        cnt[2] = cnt[3] = n
+        d_ur, d_dp, oob, _ = msorb_mod.stereo_matches_batch(ex, cnt, torch.from_numpy(kps_np).cuda(), torch.from_numpy(desc_np).cuda(), mb, mbf)
+        pl = [ex.debug_level(2, l) for l in range(8)]
+        pr = [ex.debug_level(3, l) for l in range(8)]
+        rur, rdp, roob = oracle.compute_stereo_matches(kpl, desc, kpr, desc, pl, pr, scale, inv, mb, mbf)
+        ur, dp = d_ur.cpu().numpy()[1, :n], d_dp.cpu().numpy()[1, :n]
+        assert np.array_equal(ur.view(np.uint32), rur.view(np.uint32))
+        assert np.array_equal(dp.view(np.uint32), rdp.view(np.uint32))
+        assert oob[1] == roob and (rur > 0).sum() > n // 8
+    finally:
+        ex.close()
+
+
 @pytest.mark.parametrize("kernel", ["mfma", "valu"])
 def test_dense_top2_kernels_edge_cases(msorb_mod, oracle, monkeypatch, kernel):
     """The matrix-core kernel (default: +-32 int8 encoding, the MFMA accumulator is the (distance << 11 | index) key) and the
