@@ -807,9 +807,6 @@ extern "C" int msorb_search_by_bow_kf(msorb_kf_store* st, msorb_bow_kf_pair* pai
     if (elapsed_ms) *elapsed_ms = 0;
     if (!st || n_pairs < 0 || (n_pairs > 0 && !pairs)) return MSORB_E_INVALID;
     if (n_pairs == 0) return MSORB_OK;
-    static const bool dbg_t = getenv("MSORB_DEBUG_TIMING") != nullptr;
-    const auto T0 = std::chrono::steady_clock::now();
-    auto lap = [&](const char* what) { if (dbg_t) fprintf(stderr, "bow_kf %s %.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count()); };
     std::shared_lock<std::shared_mutex> lk(st->mu);
     std::vector<uint8_t> seen;
     FeatVec ff{0, nullptr, nullptr, nullptr};
@@ -860,7 +857,6 @@ extern "C" int msorb_search_by_bow_kf(msorb_kf_store* st, msorb_bow_kf_pair* pai
         if (P.match21) for (int j = 0; j < n2; j++) P.match21[j] = -1;
     }
     if (items.empty()) return MSORB_OK;
-    lap("items");
     const size_t n_items = items.size();
     const size_t fr_rows = frame ? (size_t)frame->n : 0, fr_feats = frame && frame->fv_nodes ? (size_t)(frame->fv_begin[frame->fv_nodes] - fr_feat_lo) : 0;
     // staging: [frame desc | frame feat | frame angle | items | posts | valid1 | avail2] in, [match12 | match21 | nmatches] out
@@ -890,7 +886,6 @@ extern "C" int msorb_search_by_bow_kf(msorb_kf_store* st, msorb_bow_kf_pair* pai
             posts[pi] = PairPost{m1[pi], n1, m2[pi], n2, A.row0, P.kf2 < 0 ? 0 : st->kf[P.kf2].row0};
         }
     }
-    lap("staged");
     hipStream_t s = scr.s;
     char* d = scr.d;
     e = hipMemcpyAsync(d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
@@ -912,7 +907,6 @@ extern "C" int msorb_search_by_bow_kf(msorb_kf_store* st, msorb_bow_kf_pair* pai
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess && elapsed_ms) e = hipEventElapsedTime(elapsed_ms, scr.e0, scr.e1);
     if (e != hipSuccess) return hip_fail(scr, "search_by_bow_kf", e);
-    lap("device");
     for (int pi = 0; pi < n_pairs; pi++) {
         msorb_bow_kf_pair& P = pairs[pi];
         const int n1 = st->kf[P.kf1].n, n2 = P.kf2 < 0 ? frame->n : st->kf[P.kf2].n;
@@ -920,7 +914,6 @@ extern "C" int msorb_search_by_bow_kf(msorb_kf_store* st, msorb_bow_kf_pair* pai
         if (P.match21 && n2) std::memcpy(P.match21, scr.h + o_m21 + (size_t)m2[pi] * 4, (size_t)n2 * 4);
         P.nmatches = ((const int*)(scr.h + o_nm))[pi];
     }
-    lap("replay");
     return MSORB_OK;
 }
 
