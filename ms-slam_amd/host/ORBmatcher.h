@@ -1,10 +1,11 @@
-// Drop-in replacement for MS-SLAM's include/ORBmatcher.h (/root/reference/include/ORBmatcher.h:36-112): the same class
-// name, namespace, constructor, the 13 public search methods with their shared_ptr<KeyFrame / MapPoint> signatures,
-// DescriptorDistance, TH_LOW / TH_HIGH / HISTO_LENGTH — implemented on libmsorb.so (HIP kernels for gfx950) through the C
-// ABI of include/msorb.h.  Build MS-SLAM with this directory ahead of its own include/ and src/ORBmatcher.cc replaced by
-// ORBmatcher.cc of this directory; Tracking.cc / LocalMapping.cc / LoopClosing.cc stay unchanged.
-// Rectified-stereo configurations (Frame::Nleft == -1, KeyFrame::NLeft == -1: every shipped example) are served; the
-// fisheye two-camera branches of the reference (ORBmatcher.cc:144-210, 2059-2124, bRight = true) are not.
+// ORB_SLAM3::ORBmatcher on libmsorb.so (HIP kernels for gfx950 behind the C ABI of include/msorb.h).
+//
+// Build MS-SLAM with this directory ahead of its own include/ and with ORBmatcher.cc of this directory in place of
+// src/ORBmatcher.cc: Tracking.cc, LocalMapping.cc and LoopClosing.cc compile unchanged, because every member below has the
+// name, argument types, defaults and return type of the class the reference declares in include/ORBmatcher.h:36-112 (the
+// parameter names and the order of the declarations are this file's own; neither is part of the interface).
+// Served: rectified stereo and monocular pinhole rigs (Frame::Nleft == -1, KeyFrame::NLeft == -1 — every shipped example).
+// Not served: the fisheye two-camera branches (reference ORBmatcher.cc:144-210, 2059-2124; Fuse with bRight = true).
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
 
@@ -24,72 +25,60 @@
 namespace ORB_SLAM3 {
 
 class ORBmatcher {
-public:
-    ORBmatcher(float nnratio = 0.6, bool checkOri = true);
-
-    // Computes the Hamming distance between two ORB descriptors (ORBmatcher.cc:2323-2339)
-    static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b);
-
-    // Search matches between Frame keypoints and projected MapPoints. Returns number of matches (Tracking::SearchLocalPoints)
-    int SearchByProjection(Frame& F, const std::vector<std::shared_ptr<MapPoint>>& vpMapPoints, const float th = 3,
-                           const bool bFarPoints = false, const float thFarPoints = 50.0f);
-
-    // Project MapPoints tracked in last frame into the current frame and search matches (Tracking::TrackWithMotionModel)
-    int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono);
-
-    // Project MapPoints seen in KeyFrame into the Frame and search matches (Tracking::Relocalization)
-    int SearchByProjection(Frame& CurrentFrame, std::shared_ptr<KeyFrame> pKF, const std::set<std::shared_ptr<MapPoint>>& sAlreadyFound,
-                           const float th, const int ORBdist);
-
-    // Project MapPoints using a Similarity Transformation and search matches (Loop Closing)
-    int SearchByProjection(std::shared_ptr<KeyFrame> pKF, Sophus::Sim3<float>& Scw, const std::vector<std::shared_ptr<MapPoint>>& vpPoints,
-                           std::vector<std::shared_ptr<MapPoint>>& vpMatched, int th, float ratioHamming = 1.0);
-
-    int SearchByProjectionLoop(std::shared_ptr<KeyFrame> pKF, Sophus::Sim3<float>& Scw, const std::vector<std::shared_ptr<MapPoint>>& vpPoints,
-                               std::vector<std::shared_ptr<MapPoint>>& vpMatched, std::vector<std::shared_ptr<KeyFrame>>& vpMatchedKF, int th,
-                               float ratioHamming = 1.0);
-
-    // Project MapPoints using a Similarity Transformation and search matches (Place Recognition: Loop Closing and Merging)
-    int SearchByProjection(std::shared_ptr<KeyFrame> pKF, Sophus::Sim3<float>& Scw, const std::vector<std::shared_ptr<MapPoint>>& vpPoints,
-                           const std::vector<std::shared_ptr<KeyFrame>>& vpPointsKFs, std::vector<std::shared_ptr<MapPoint>>& vpMatched,
-                           std::vector<std::shared_ptr<KeyFrame>>& vpMatchedKF, int th, float ratioHamming = 1.0);
-
-    // Search matches between MapPoints in a KeyFrame and ORB in a Frame, constrained to the same vocabulary node
-    int SearchByBoW(std::shared_ptr<KeyFrame> pKF, Frame& F, std::vector<std::shared_ptr<MapPoint>>& vpMapPointMatches);
-    int SearchByBoW(std::shared_ptr<KeyFrame> pKF1, std::shared_ptr<KeyFrame> pKF2, std::vector<std::shared_ptr<MapPoint>>& vpMatches12);
-    int SearchByBoW(std::shared_ptr<KeyFrame> pKF1, std::shared_ptr<KeyFrame> pKF2,
-                    std::vector<std::shared_ptr<KeyFrame>>& vpMatchedCurrentKeyFrame,
-                    std::vector<std::shared_ptr<MapPoint>>& vpMatchedCurrentMapPoint,
-                    std::vector<std::shared_ptr<KeyFrame>>& vpMatchedLoopKeyFrame,
-                    std::vector<std::shared_ptr<MapPoint>>& vpMatchedLoopMapPoint, long unsigned int& nCurrentId);
-
-    // Matching for the Map Initialization (only used in the monocular case)
-    int SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12,
-                                int windowSize = 10);
-
-    // Matching to triangulate new MapPoints. Check Epipolar Constraint.
-    int SearchForTriangulation(std::shared_ptr<KeyFrame> pKF1, std::shared_ptr<KeyFrame> pKF2,
-                               std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo, const bool bCoarse = false);
-
-    // Search matches between MapPoints seen in KF1 and KF2 transforming by a Sim3 [s12*R12|t12]
-    int SearchBySim3(std::shared_ptr<KeyFrame> pKF1, std::shared_ptr<KeyFrame> pKF2, std::vector<std::shared_ptr<MapPoint>>& vpMatches12,
-                     const Sophus::Sim3f& S12, const float th);
-
-    // Project MapPoints into KeyFrame and search for duplicated MapPoints.
-    int Fuse(std::shared_ptr<KeyFrame> pKF, const std::vector<std::shared_ptr<MapPoint>>& vpMapPoints, const float th = 3.0,
-             const bool bRight = false);
-
-    // Project MapPoints into KeyFrame using a given Sim3 and search for duplicated MapPoints.
-    int Fuse(std::shared_ptr<KeyFrame> pKF, Sophus::Sim3f& Scw, const std::vector<std::shared_ptr<MapPoint>>& vpPoints, float th,
-             std::vector<std::shared_ptr<MapPoint>>& vpReplacePoint);
+    // shorthands for the declarations below (the signatures are the reference's: these are the same types)
+    using KF = std::shared_ptr<KeyFrame>;
+    using MP = std::shared_ptr<MapPoint>;
+    using KFs = std::vector<KF>;
+    using MPs = std::vector<MP>;
 
 public:
-    static const int TH_LOW;
-    static const int TH_HIGH;
-    static const int HISTO_LENGTH;
     EIGEN_MAKE_ALIGNED_OPERATOR_NEW
 
+    static const int TH_HIGH;       // 100
+    static const int TH_LOW;        // 50
+    static const int HISTO_LENGTH;  // 30 rotation bins
+
+    ORBmatcher(float nnratio = 0.6, bool checkOri = true);
+
+    // 256-bit Hamming distance of two descriptor rows (reference ORBmatcher.cc:2323-2339)
+    static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b);
+
+    // ---- Tracking thread --------------------------------------------------------------------------------------------------
+    // SearchLocalPoints: local map points already projected by Frame::isInFrustum (:43-142)
+    int SearchByProjection(Frame& frame, const MPs& localPoints, const float th = 3, const bool farPoints = false,
+                           const float farThreshold = 50.0f);
+    // TrackWithMotionModel: the last frame's points projected with the predicted pose (:1941-2152)
+    int SearchByProjection(Frame& current, const Frame& last, const float th, const bool mono);
+    // Relocalization: a candidate KeyFrame's points projected into the frame (:2154-2275)
+    int SearchByProjection(Frame& current, KF keyframe, const std::set<MP>& alreadyFound, const float th, const int orbDist);
+    // TrackReferenceKeyFrame / Relocalization: matches inside common vocabulary nodes (:223-421)
+    int SearchByBoW(KF keyframe, Frame& frame, MPs& matches);
+    // monocular map initialisation (:755-870)
+    int SearchForInitialization(Frame& first, Frame& second, std::vector<cv::Point2f>& prevMatched, std::vector<int>& matches12,
+                                int windowSize = 10);
+
+    // ---- LocalMapping thread ----------------------------------------------------------------------------------------------
+    // CreateNewMapPoints: unmatched features of two KeyFrames under the epipolar constraint (:1168-1402)
+    int SearchForTriangulation(KF kf1, KF kf2, std::vector<std::pair<size_t, size_t>>& matchedPairs, const bool onlyStereo,
+                               const bool coarse = false);
+    // SearchInNeighbors: duplicated map points of a neighbour (:1404-1597)
+    int Fuse(KF keyframe, const MPs& points, const float th = 3.0, const bool right = false);
+
+    // ---- LoopClosing thread (place recognition, loop closing, map merging) -----------------------------------------------
+    int SearchByBoW(KF kf1, KF kf2, MPs& matches12);                                                   // :872-1016
+    int SearchByBoW(KF kf1, KF kf2, KFs& matchedCurrentKF, MPs& matchedCurrentMP, KFs& matchedLoopKF, MPs& matchedLoopMP,
+                    long unsigned int& currentId);                                                     // :1018-1166
+    int SearchByProjection(KF keyframe, Sophus::Sim3<float>& Scw, const MPs& points, MPs& matched, int th,
+                           float ratioHamming = 1.0);                                                  // :423-530
+    int SearchByProjection(KF keyframe, Sophus::Sim3<float>& Scw, const MPs& points, const KFs& pointKFs, MPs& matched,
+                           KFs& matchedKF, int th, float ratioHamming = 1.0);                          // :639-753
+    int SearchByProjectionLoop(KF keyframe, Sophus::Sim3<float>& Scw, const MPs& points, MPs& matched, KFs& matchedKF, int th,
+                               float ratioHamming = 1.0);                                              // :532-637
+    int SearchBySim3(KF kf1, KF kf2, MPs& matches12, const Sophus::Sim3f& S12, const float th);        // :1718-1939
+    int Fuse(KF keyframe, Sophus::Sim3f& Scw, const MPs& points, float th, MPs& replaced);             // :1599-1716
+
 protected:
+    // kept for source compatibility with code that derives from the class; the searches above do this work on the device
     float RadiusByViewingCos(const float& viewCos);
     void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3);
 
