@@ -441,9 +441,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
         int* img_base = h->d_img_base.p + first + gi;
         const size_t cslot = (size_t)first * g.slots_per_image;
         mark(0, s);
-        for (int l = 1; l < nl; l++)
-            launch_pyr_resize(pyr.lv[l - 1], pyr.lv[l], pyr_base + g.lv[l].plane_off, h->d_taps.p + h->tap_x_off[l],
-                              h->d_taps.p + h->tap_y_off[l], n, s);
+        launch_pyramid(pyr, h->d_taps.p, h->tap_x_off.data(), h->tap_y_off.data(), n, s);
         mark(1, s);
         hipStream_t sb = h->overlap_blur ? h->copy_stream : s;
         if (h->overlap_blur) {
@@ -520,9 +518,7 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
     h->h_pyr_valid = false;
 
     mark(0);
-    for (int l = 1; l < nl; l++)
-        launch_pyr_resize(pyr.lv[l - 1], pyr.lv[l], h->d_pyr.p + g.lv[l].plane_off, h->d_taps.p + h->tap_x_off[l],
-                          h->d_taps.p + h->tap_y_off[l], n_images, s);
+    launch_pyramid(pyr, h->d_taps.p, h->tap_x_off.data(), h->tap_y_off.data(), n_images, s);
     mark(1);
     // the blur only feeds the descriptor stage: unless stage timing is on, it runs on the second stream, overlapping
     // the (VALU-bound) FAST kernel and the (latency-bound) quadtree with a bandwidth-bound kernel
@@ -1241,12 +1237,9 @@ int msorb_pyramid_batch(msorb_extractor* h, const uint8_t* d_images, int n_image
     int rc;
     if ((rc = ensure_geometry(h, rows, cols))) return rc;
     if ((rc = h->d_pyr.ensure((size_t)n_images * h->G.pyramid_bytes + 256))) return rc;
-    const FrameGeom& g = h->G;
     LevelView l0{d_images, image_stride, (int)row_stride, cols, rows};
     const PyramidView pyr = make_view(h, h->d_pyr.p, &l0);
-    for (int l = 1; l < g.nlevels; l++)
-        launch_pyr_resize(pyr.lv[l - 1], pyr.lv[l], h->d_pyr.p + g.lv[l].plane_off, h->d_taps.p + h->tap_x_off[l],
-                          h->d_taps.p + h->tap_y_off[l], n_images, h->stream);
+    launch_pyramid(pyr, h->d_taps.p, h->tap_x_off.data(), h->tap_y_off.data(), n_images, h->stream);
     HIPCHK(hipGetLastError());
     h->last_pyr = pyr; h->last_n_images = n_images;
     h->h_pyr_valid = false; h->compact_on_host = false;

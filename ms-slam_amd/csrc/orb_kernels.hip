@@ -207,14 +207,10 @@ __device__ __forceinline__ uint32_t sdwa_hi_sum(uint32_t x, uint32_t y) {   // (
 // The y taps of the band come in up front with the first loads.  Compared with pyr_resize_rows_kernel: no per-row wait for a
 // tap record, no register shuffling between "upper" and "lower" rows, 14 instead of 25 VALU lane-operations per pixel.
 template <int R, int kSrc>
-__global__ __launch_bounds__(256) void pyr_resize_band_kernel(LevelView src, LevelView dst, uint8_t* __restrict__ dst_base,
-                                                              const ResizeTap* __restrict__ tx,
-                                                              const ResizeTap* __restrict__ ty) {
-    __shared__ uint2 park[4][kSrc][64];
-    const int img = blockIdx.z;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int dy0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + wave) * R);
-    const int dx0 = (blockIdx.x * 64 + lane) * 4;
+__device__ __forceinline__ void pyr_band_tile(const LevelView& src, const LevelView& dst, uint8_t* __restrict__ dst_base,
+                                              const ResizeTap* __restrict__ tx, const ResizeTap* __restrict__ ty, const int img,
+                                              const int bx, const int dy0, const int lane, uint2 (*park_w)[64]) {
+    const int dx0 = (bx * 64 + lane) * 4;
     if (dy0 >= dst.h) return;   // wave-uniform
     const int n_out = min(R, dst.h - dy0);
     // y taps of the band (wave-uniform addresses: scalar loads)
@@ -265,7 +261,7 @@ __global__ __launch_bounds__(256) void pyr_resize_band_kernel(LevelView src, Lev
             for (int i = 0; i < 4; i++)
                 H[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(hi, lo, sel[i])),
                                               __builtin_bit_cast(ushort2v, cw[i]), 0u, false) >> 4;
-            park[wave][r][lane] = uint2{H[0] | (H[1] << 16), H[2] | (H[3] << 16)};
+            park_w[r][lane] = uint2{H[0] | (H[1] << 16), H[2] | (H[3] << 16)};
         }
     }
     // phase B: ((b0 * H0) >> 16) + ((b1 * H1) >> 16) + 2) >> 2 with the u16 halves picked by SDWA operand selects
@@ -275,7 +271,7 @@ __global__ __launch_bounds__(256) void pyr_resize_band_kernel(LevelView src, Lev
         if (k < n_out) {   // wave-uniform
             const int n0 = (int)(ti[k] & 0xffffu) - s_lo, n1 = (int)(ti[k] >> 16) - s_lo;
             const uint32_t b0 = tc[k] & 0xffffu, b1 = tc[k] >> 16;
-            const uint2 A = park[wave][n0][lane], B = park[wave][n1][lane];
+            const uint2 A = park_w[n0][lane], B = park_w[n1][lane];
             const uint32_t t0 = sdwa_hi_sum(sdwa_mul_lo(b0, A.x), sdwa_mul_lo(b1, B.x));
             const uint32_t t1 = sdwa_hi_sum(sdwa_mul_hi(b0, A.x), sdwa_mul_hi(b1, B.x));
             const uint32_t t2 = sdwa_hi_sum(sdwa_mul_lo(b0, A.y), sdwa_mul_lo(b1, B.y));
@@ -286,6 +282,43 @@ __global__ __launch_bounds__(256) void pyr_resize_band_kernel(LevelView src, Lev
             const uint32_t packed = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p23), __builtin_bit_cast(uint32_t, p01), 0x06040200u);
             if (active) *reinterpret_cast<uint32_t*>(d + (size_t)(dy0 + k) * dst.pitch) = packed;
         }
+    }
+}
+
+template <int R, int kSrc>
+__global__ __launch_bounds__(256) void pyr_resize_band_kernel(LevelView src, LevelView dst, uint8_t* __restrict__ dst_base,
+                                                              const ResizeTap* __restrict__ tx,
+                                                              const ResizeTap* __restrict__ ty) {
+    __shared__ uint2 park[4][kSrc][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int dy0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + wave) * R);
+    pyr_band_tile<R, kSrc>(src, dst, dst_base, tx, ty, blockIdx.z, blockIdx.x, dy0, lane, park[wave]);
+}
+
+// The small top levels in ONE launch: a 16-wave workgroup per image walks down the levels, its waves taking the (band, column
+// chunk) tiles of a level in turn; a workgroup-wide barrier separates the levels.  As separate launches each of these levels costs 13-16 us
+// for 5-9 us of work — ramp-up, tap fetch, load latency and drain of a dependent launch do not shrink with the level.
+struct PyrTailArgs {
+    LevelView lv[4];            // lv[0] = source of the first tail level, lv[i + 1] = i-th tail level
+    const ResizeTap* tx[3];
+    const ResizeTap* ty[3];
+    int nl;                     // tail levels (<= 3)
+};
+template <int R, int kSrc>
+__global__ __launch_bounds__(1024) void pyr_resize_tail_kernel(PyrTailArgs A) {
+    __shared__ uint2 park[16][kSrc][64];
+    const int img = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    for (int li = 0; li < A.nl; li++) {
+        const LevelView src = A.lv[li], dst = A.lv[li + 1];
+        const int gx = (dst.w + 255) / 256, nb = (dst.h + R - 1) / R;
+        for (int t = wave; t < gx * nb; t += 16) {
+            const int band = t / gx, bx = t - band * gx;
+            pyr_band_tile<R, kSrc>(src, dst, const_cast<uint8_t*>(dst.base), A.tx[li], A.ty[li], img, bx, band * R, lane, park[wave]);
+        }
+        __syncthreads();   // workgroup-scope release / acquire: all waves of a workgroup share the CU's L1 (write-through), and
+                           // the level just written was never read before (an agent-scope fence here writes back / invalidates
+                           // the whole L2 per workgroup and level: measured 0.34 ms instead of 0.02)
     }
 }
 
@@ -1500,6 +1533,42 @@ void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_
                            0, s, src, dst, dst_base, tx, ty);
     else if (aligned) hipLaunchKernelGGL(pyr_resize_aligned_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
     else hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
+}
+// ComputePyramid for a batch: levels 1 .. n-1, each from the one above (ORBextractor.cc:1179-1193), one launch per level.
+// MSORB_PYR_TAIL=1 puts the last up to three levels into one launch (pyr_resize_tail_kernel) — measured on MI355X, 256 KITTI
+// images: 33 us instead of 42 us for the three launches with the stage alone on the GPU, but the whole step gets slower
+// (1.366 vs 1.352 ms): a 16-wave workgroup with 98 KB of LDS per CU keeps the other stream's kernels out.  Off by default.
+void launch_pyramid(const PyramidView& pyr, const ResizeTap* taps, const size_t* tap_x_off, const size_t* tap_y_off, int n_images,
+                    hipStream_t s) {
+    const int nl = pyr.nlevels;
+    constexpr int R = 8;
+    int tail = 0;
+    if (n_images >= 64 && getenv("MSORB_PYR_TAIL") && !getenv("MSORB_PYR_SINGLE") && !getenv("MSORB_PYR_ROWS")) {
+        while (tail < 3 && nl - 1 - tail >= 2) {   // at least level 1 stays a launch of its own
+            const int l = nl - 1 - tail;
+            const LevelView &src = pyr.lv[l - 1], &dst = pyr.lv[l];
+            const ResizeTap* tx = taps + tap_x_off[l];
+            const bool aligned = (reinterpret_cast<uintptr_t>(src.base) & 3) == 0 && (src.pitch & 3) == 0 && (src.img_stride & 3) == 0 &&
+                                 src.pitch >= ((src.w + 3) & ~3) + 8 && (reinterpret_cast<uintptr_t>(tx) & 15) == 0;
+            const double sy = (double)src.h / (double)dst.h, sx = (double)src.w / (double)dst.w;
+            if (!aligned || (int)std::floor((R - 1) * sy) + 3 > 12 || sx > 1.25 || (size_t)dst.w * dst.h > 100000) break;
+            tail++;
+        }
+    }
+    for (int l = 1; l < nl - tail; l++)
+        launch_pyr_resize(pyr.lv[l - 1], pyr.lv[l], const_cast<uint8_t*>(pyr.lv[l].base), taps + tap_x_off[l], taps + tap_y_off[l], n_images, s);
+    if (tail) {
+        PyrTailArgs A{};
+        A.nl = tail;
+        const int first = nl - tail;
+        A.lv[0] = pyr.lv[first - 1];
+        for (int i = 0; i < tail; i++) {
+            A.lv[i + 1] = pyr.lv[first + i];
+            A.tx[i] = taps + tap_x_off[first + i];
+            A.ty[i] = taps + tap_y_off[first + i];
+        }
+        hipLaunchKernelGGL((pyr_resize_tail_kernel<R, 12>), dim3(n_images), dim3(1024), 0, s, A);
+    }
 }
 void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cells, int ini_th, int min_th,
                        int slots_per_image, Cand16* slots, int* cell_count, int n_images, bool small_cells, hipStream_t s) {

@@ -213,6 +213,36 @@ def test_batch_pyramid_kernels_on_padded_rows(msorb_mod, oracle, monkeypatch, na
     ex.close()
 
 
+@pytest.mark.parametrize("name", ["kitti", "euroc", "odd"])
+def test_batch_pyramid_fused_tail_levels(msorb_mod, oracle, monkeypatch, name):
+    """MSORB_PYR_TAIL=1: batches of >= 64 images build their last three pyramid levels in one launch (pyr_resize_tail_kernel: a
+    workgroup per image walks down the levels behind workgroup barriers; opt-in, see launch_pyramid): every level of a sample
+    of the images is the oracle's, and the default launch-per-level path gives the same bytes."""
+    import torch
+    cfg = CONFIGS[name] if name != "odd" else dict(rows=333, cols=517, nfeatures=700, scale=1.2, nlevels=8, ini_th=20, min_th=7)
+    ex, ref = _pair(msorb_mod, oracle, cfg)
+    n = 64
+    pitch = (cfg["cols"] + 63) // 64 * 64
+    batch = np.stack([synth.image(950 + (i % 5), cfg["rows"], cfg["cols"]) for i in range(n)])
+    store = torch.zeros((n, cfg["rows"], pitch), dtype=torch.uint8, device="cuda")
+    view = store[:, :, :cfg["cols"]]
+    view.copy_(torch.from_numpy(batch).cuda())
+    monkeypatch.setenv("MSORB_PYR_TAIL", "1")
+    ex.pyramid_batch(view)
+    torch.cuda.synchronize()
+    fused = {(i, l): ex.debug_level(i, l) for i in (0, 3, 4, 37, n - 1) for l in range(1, cfg["nlevels"])}
+    for i in (0, 3, 4, 37, n - 1):
+        ref(batch[i])
+        for lvl in range(1, cfg["nlevels"]):
+            assert np.array_equal(fused[(i, lvl)], ref.level(lvl)), (i, lvl)
+    monkeypatch.delenv("MSORB_PYR_TAIL")
+    ex.pyramid_batch(view)
+    torch.cuda.synchronize()
+    for (i, l), want in fused.items():
+        assert np.array_equal(ex.debug_level(i, l), want), (i, l)
+    ex.close()
+
+
 def test_host_quadtree_mode_matches(msorb_mod, oracle, monkeypatch):
     """MSORB_QUADTREE=host keeps the selection on the host thread pool (orb_host.cc); same result."""
     monkeypatch.setenv("MSORB_QUADTREE", "host")
