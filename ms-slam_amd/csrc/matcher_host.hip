@@ -829,7 +829,6 @@ int msorb_stereo_matches(msorb_extractor* left, msorb_extractor* right, const ms
     int rc;
     if ((rc = extractor_last_view(left, &pl, &sc, inv_scale, &devL, &s, nullptr))) return rc;
     if ((rc = extractor_last_view(right, &pr, nullptr, nullptr, &devR, &s2, nullptr))) return rc;
-    if (devL != devR) { set_last_error("stereo matching needs both pyramids on one device"); return MSORB_E_INVALID; }
     if (pl.nlevels != pr.nlevels || pl.lv[0].w != pr.lv[0].w || pl.lv[0].h != pr.lv[0].h) {
         set_last_error("left/right pyramids differ in geometry");
         return MSORB_E_INVALID;
@@ -837,6 +836,29 @@ int msorb_stereo_matches(msorb_extractor* left, msorb_extractor* right, const ms
     if (n_oob) *n_oob = 0;
     if (nL == 0) return MSORB_OK;
     HIPCHK(hipSetDevice(devL));
+    // One extractor object per GPU (MSORB_DEVICES=0,1: left eye on device A, right eye on device B): the right pyramid of the
+    // frame — 1.5 MB for KITTI — is pulled to the left device, level by level, peer to peer (xGMI), after the right handle's
+    // stream has drained; the association then runs on the left device as usual.  MSORB_FORCE_PEER_PYRAMID takes this path
+    // with both handles on one device (test aid: a peer copy device -> same device is an ordinary copy).
+    if (devL != devR || getenv("MSORB_FORCE_PEER_PYRAMID")) {
+        struct PeerPyr {
+            int device = -1;
+            DBuf<uint8_t> buf;
+            ~PeerPyr() { if (device >= 0 && hipSetDevice(device) == hipSuccess) buf.release(); }
+        };
+        static thread_local PeerPyr pp;
+        if (pp.device != devL) { pp.buf.release(); pp.device = devL; }
+        size_t off[MSORB_MAX_LEVELS], total = 0;
+        for (int l = 0; l < pr.nlevels; l++) { off[l] = total; total += ((size_t)pr.lv[l].pitch * pr.lv[l].h + 255) & ~(size_t)255; }
+        if ((rc = pp.buf.ensure(total + 256))) return rc;
+        HIPCHK(hipSetDevice(devR));
+        HIPCHK(hipStreamSynchronize(s2));          // the right eye's extraction (its own thread has returned, normally a no-op)
+        HIPCHK(hipSetDevice(devL));
+        for (int l = 0; l < pr.nlevels; l++) {
+            HIPCHK(hipMemcpyPeerAsync(pp.buf.p + off[l], devL, pr.lv[l].base, devR, (size_t)pr.lv[l].pitch * pr.lv[l].h, s));
+            pr.lv[l].base = pp.buf.p + off[l];
+        }
+    }
     for (int i = 0; i < nL; i++)
         if (kpsL[i].octave < 0 || kpsL[i].octave >= pl.nlevels) return MSORB_E_INVALID;
     for (int i = 0; i < nR; i++)

@@ -1,6 +1,8 @@
 """GPU parity tests of the matcher path: device kernels + host replay (through the C ABI) vs the CPU oracle.
 Everything here is integer/index work: match indices, counts and the stereo uRight/depth floats must be
 bit-identical."""
+import os
+
 import numpy as np
 import pytest
 
@@ -34,6 +36,14 @@ def test_stereo_matches_bit_exact(msorb_mod, oracle, stereo_frame):
     assert np.array_equal(ur.view(np.uint32), rur.view(np.uint32))
     assert np.array_equal(dp.view(np.uint32), rdp.view(np.uint32))
     assert oob == roob
+    # one extractor per GPU (MSORB_DEVICES=0,1): the right pyramid is pulled to the left device level by level, peer to peer;
+    # forced here with both handles on one device
+    os.environ["MSORB_FORCE_PEER_PYRAMID"] = "1"
+    try:
+        ur2, dp2, oob2 = msorb_mod.stereo_matches(s["exl"], s["exr"], s["kl"], s["dl"], s["kr"], s["dr"], mb, mbf)
+    finally:
+        del os.environ["MSORB_FORCE_PEER_PYRAMID"]
+    assert np.array_equal(ur2.view(np.uint32), rur.view(np.uint32)) and np.array_equal(dp2.view(np.uint32), rdp.view(np.uint32)) and oob2 == roob
     # degenerate: no right keypoints / no left keypoints
     ur0, dp0, _ = msorb_mod.stereo_matches(s["exl"], s["exr"], s["kl"], s["dl"], s["kr"][:0], s["dr"][:0], mb, mbf)
     assert np.all(ur0 == -1) and np.all(dp0 == -1)
