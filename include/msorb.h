@@ -323,8 +323,9 @@ int msorb_hamming_dense_top2_batch(int device, const uint8_t* d_query, const uin
  * msorb_extract() call produced the images' pyramids (mpORBextractorLeft/Right->mvImagePyramid stay on
  * the device).  Keypoint/descriptor arrays are host arrays as returned by msorb_extract.  Writes
  * mvuRight / mvDepth (n_left entries, -1 = none).  *n_oob counts keypoints whose SAD window would leave
- * the pyramid plane (the reference would hit a CV_Assert there; they are skipped).  * The two handles may live on different devices (one extractor object per GPU): the right pyramid is then copied to the
- * left handle's device peer to peer before the kernel runs there. */
+ * the pyramid plane (the reference would hit a CV_Assert there; they are skipped).  The two handles may live on
+ * different devices (one extractor object per GPU): the right pyramid is then copied to the left handle's device peer to
+ * peer before the kernel runs there. */
 int msorb_stereo_matches(msorb_extractor* left, msorb_extractor* right, const msorb_keypoint* kps_left, int n_left,
                          const uint8_t* desc_left, const msorb_keypoint* kps_right, int n_right,
                          const uint8_t* desc_right, float mb, float mbf, float* u_right, float* depth, int* n_oob);
