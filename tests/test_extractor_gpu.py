@@ -243,6 +243,49 @@ def test_batch_pyramid_fused_tail_levels(msorb_mod, oracle, monkeypatch, name):
     ex.close()
 
 
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_geometries_and_strides_batch(msorb_mod, oracle, seed):
+    """Random image sizes, level counts, row pitches (tight, 4-, 16-, 64-byte aligned, odd padding) and buffer offsets
+    through the batch kernels (which pick their aligned / LDS-DMA / staged variants from exactly these properties): keypoints,
+    descriptors, and every pyramid / blurred level of the last image are the oracle's."""
+    import torch
+    rng = np.random.default_rng(seed)
+    done = 0
+    while done < 4:
+        rows, cols = int(rng.integers(240, 480)), int(rng.integers(330, 1100))
+        nfeat, nlev = int(rng.choice([500, 1000])), int(rng.choice([4, 6, 8]))
+        pad = int(rng.choice([0, 3, 4, 16, 21, 64]))
+        if rng.random() < 0.5:
+            pad += (-(cols + pad)) % int(rng.choice([4, 16, 64]))
+        off = int(rng.choice([0, 1, 4, 16]))
+        n = int(rng.choice([16, 17, 64]))
+        pitch = cols + pad
+        ex = msorb_mod.ORBextractor(nfeat, 1.2, nlev, 20, 7)
+        ref = oracle.OracleExtractor(nfeat, 1.2, nlev, 20, 7)
+        try:
+            imgs = np.stack([synth.image(6000 + 13 * done + (i % 3), rows, cols) for i in range(n)])
+            flat = torch.zeros(n * rows * pitch + 64, dtype=torch.uint8, device="cuda")
+            view = flat[off:off + n * rows * pitch].view(n, rows, pitch)[:, :, :cols]
+            view.copy_(torch.from_numpy(imgs).cuda())
+            try:
+                counts, mono, d_kps, d_desc = ex.extract_batch(view)
+            except msorb_mod.MsorbError as e:
+                assert e.code == msorb_mod.E_GEOMETRY         # too small for the reference's cell grid at some level
+                continue
+            kps = msorb_mod.keypoints_from_device(d_kps, counts)
+            desc = d_desc.cpu().numpy()
+            for i in (0, 2, n - 1):
+                rmono, rkps, rdesc = ref(imgs[i])
+                assert counts[i] == len(rkps) and mono[i] == rmono, (rows, cols, pitch, off, n, nlev, i)
+                _assert_same(kps[i], desc[i, :counts[i]], rkps, rdesc)
+            for lvl in range(1, nlev):
+                assert np.array_equal(ex.debug_level(n - 1, lvl), ref.level(lvl)), (rows, cols, pitch, off, lvl)
+                assert np.array_equal(ex.debug_level(n - 1, lvl, blurred=True), ref.level(lvl, blurred=True)), (rows, cols, pitch, off, lvl)
+            done += 1
+        finally:
+            ex.close()
+
+
 def test_host_quadtree_mode_matches(msorb_mod, oracle, monkeypatch):
     """MSORB_QUADTREE=host keeps the selection on the host thread pool (orb_host.cc); same result."""
     monkeypatch.setenv("MSORB_QUADTREE", "host")
