@@ -272,21 +272,29 @@ __device__ __forceinline__ void stereo_match_one(const StereoArgs& G, const Ster
             uint32_t* win = win_all[threadIdx.x >> 6];
             const int pitchL = G.pitchL[levelL], pitchR = G.pitchR[levelL];
             const uint32_t phL = (uint32_t)(reinterpret_cast<uintptr_t>(pl) & 3), phR = (uint32_t)(reinterpret_cast<uintptr_t>(pr) & 3);
-            // last dword that may be read: the end of the level plane of this image (lanes clamped there load bytes beyond the window)
+            // A dword may not reach past the end of the level plane of this image (level 0 can be the caller's own buffer): such a
+            // dword is read 1..3 bytes (or more: then nothing of it is needed) earlier and shifted back, its missing top bytes —
+            // beyond the plane, never part of a window — come out as zero.  With 4-byte aligned rows this never triggers.
             const uint8_t* planeL = G.pyrL[levelL] + (A.img_strideL ? A.img * A.img_strideL[levelL] : 0);
             const uint8_t* planeR = G.pyrR[levelL] + (A.img_strideR ? A.img * A.img_strideR[levelL] : 0);
-            const uintptr_t endL = (reinterpret_cast<uintptr_t>(planeL) + (size_t)rows * pitchL - 4) & ~(uintptr_t)3;
-            const uintptr_t endR = (reinterpret_cast<uintptr_t>(planeR) + (size_t)rows * pitchR - 4) & ~(uintptr_t)3;
+            const uintptr_t limL = reinterpret_cast<uintptr_t>(planeL) + (size_t)rows * pitchL - 4;
+            const uintptr_t limR = reinterpret_cast<uintptr_t>(planeR) + (size_t)rows * pitchR - 4;
+            auto load_dword = [](uintptr_t a, uintptr_t lim) {
+                const uintptr_t b = min(a, lim);
+                const uint32_t v = *reinterpret_cast<const uint32_t*>(b);
+                const uint32_t back = (uint32_t)(a - b);
+                return back == 0 ? v : (back < 4 ? v >> (8 * back) : 0u);
+            };
             {
                 const int r = lane >> 3, c = lane & 7;
                 const uintptr_t a0 = reinterpret_cast<uintptr_t>(pr - phR) + (size_t)r * pitchR + 4 * c;
-                const uint32_t v0 = *reinterpret_cast<const uint32_t*>(min(a0, endR));            // rows 0..7 of the right strip
+                const uint32_t v0 = load_dword(a0, limR);                                          // rows 0..7 of the right strip
                 uint32_t v1 = 0, v2 = 0;
                 const uintptr_t a1 = reinterpret_cast<uintptr_t>(pr - phR) + (size_t)(r + 8) * pitchR + 4 * c;
-                if (lane < 24) v1 = *reinterpret_cast<const uint32_t*>(min(a1, endR));             // rows 8..10
+                if (lane < 24) v1 = load_dword(a1, limR);                                           // rows 8..10
                 const int rl = lane >> 2, cl = lane & 3;
                 const uintptr_t a2 = reinterpret_cast<uintptr_t>(pl - phL) + (size_t)rl * pitchL + 4 * cl;
-                if (lane < 44) v2 = *reinterpret_cast<const uint32_t*>(min(a2, endL));             // the left window
+                if (lane < 44) v2 = load_dword(a2, limL);                                           // the left window
                 win[r * 12 + c] = v0;
                 if (lane < 24) win[(r + 8) * 12 + c] = v1;
                 if (lane < 44) win[rl * 12 + 8 + cl] = v2;
