@@ -1,0 +1,159 @@
+"""Random-parameter sweep over the matcher family's GPU parity tests (not collected by default: run explicitly,
+`python -m pytest tests/_fuzz_matcher.py -q -x` on the GPU box, MSORB_FUZZ_N = cases per entry, MSORB_FUZZ_SEED = base seed).
+Each case calls the body of a regular parity test with drawn sizes / thresholds / seeds; statistical "enough matches"
+asserts of the regular tests are tolerated, any mismatch against the oracle is not."""
+import os
+
+import numpy as np
+import pytest
+
+import test_matcher_gpu as tm
+import test_matcher_a17_gpu as ta
+import test_bow_match as tb
+import test_frustum as tf
+import test_sparsify as ts
+import bow_match_cases as bmc
+import sparsify_cases as sc
+from test_matcher_gpu import stereo_frame          # noqa: F401  (fixtures)
+from test_matcher_a17_gpu import two_keyframes     # noqa: F401
+
+pytestmark = pytest.mark.gpu
+N = int(os.environ.get("MSORB_FUZZ_N", "8"))
+BASE = int(os.environ.get("MSORB_FUZZ_SEED", "1000"))
+
+
+def _rng(i, salt):
+    return np.random.Generator(np.random.PCG64(BASE * 1000 + i * 17 + salt))
+
+
+def _call(fn, *a):
+    """Parity asserts compare arrays; the `rn > 100`-style population asserts are the only ones written with a bare `>`."""
+    try:
+        fn(*a)
+    except AssertionError as e:
+        msg = str(e)
+        if "array_equal" in msg or "==" in msg or "tolist" in msg or "tobytes" in msg:
+            raise
+        print("population assert tolerated:", msg.splitlines()[0] if msg else "")
+
+
+@pytest.mark.parametrize("i", range(N))
+def test_fz_mps(msorb_mod, oracle, stereo_frame, i):
+    r = _rng(i, 1)
+    _call(tm.test_search_by_projection_map_points, msorb_mod, oracle, stereo_frame, int(r.integers(10, 10 ** 6)),
+          int(r.integers(1, 8000)), float(r.uniform(0.5, 20)), float(r.uniform(0, 0.6)), float(r.uniform(0, 0.4)))
+
+
+@pytest.mark.parametrize("i", range(N))
+def test_fz_last_frame(msorb_mod, oracle, stereo_frame, i):
+    r = _rng(i, 2)
+    _call(tm.test_search_by_projection_last_frame, msorb_mod, oracle, stereo_frame, int(r.integers(10, 10 ** 6)),
+          int(r.integers(1, 5000)), float(r.uniform(1, 40)), ["none", "fwd", "bwd"][int(r.integers(0, 3))])
+
+
+@pytest.mark.parametrize("i", range(N))
+def test_fz_fuse(msorb_mod, oracle, stereo_frame, i):
+    r = _rng(i, 3)
+    _call(tm.test_fuse_search_matches_oracle, msorb_mod, oracle, stereo_frame, int(r.integers(10, 10 ** 6)), float(r.uniform(1, 8)))
+
+
+@pytest.mark.parametrize("i", range(N))
+def test_fz_reloc(msorb_mod, oracle, stereo_frame, i):
+    r = _rng(i, 4)
+    _call(tm.test_search_by_projection_keyframe_relocalisation, msorb_mod, oracle, stereo_frame, int(r.integers(10, 10 ** 6)),
+          int(r.integers(1, 6000)), float(r.uniform(1, 20)), int(r.integers(30, 140)))
+
+
+@pytest.mark.parametrize("i", range(N))
+def test_fz_sim3_forms(msorb_mod, oracle, stereo_frame, i):
+    r = _rng(i, 5)
+    _call(tm.test_search_by_projection_sim3_forms, msorb_mod, oracle, stereo_frame, int(r.integers(10, 10 ** 6)),
+          int(r.integers(1, 6000)), float(r.uniform(1, 14)), float(r.uniform(0.6, 1.6)))
+
+
+@pytest.mark.parametrize("i", range(N))
+def test_fz_stereo_random(msorb_mod, oracle, i):
+    r = _rng(i, 6)
+    _call(tm.test_stereo_random_keypoints_against_oracle, msorb_mod, oracle, int(r.integers(10, 10 ** 6)), int(r.integers(0, 70)))
+
+
+@pytest.mark.parametrize("i", range(N))
+def test_fz_by_sim3(msorb_mod, oracle, two_keyframes, i):
+    r = _rng(i, 7)
+    _call(ta.test_search_by_sim3_matches_oracle, msorb_mod, oracle, two_keyframes, int(r.integers(10, 10 ** 6)),
+          float(r.uniform(1, 14)), int(r.integers(0, 90)))
+
+
+@pytest.mark.parametrize("i", range(N))
+def test_fz_fuse_sim3(msorb_mod, oracle, two_keyframes, i):
+    r = _rng(i, 8)
+    _call(ta.test_fuse_sim3_search_matches_oracle, msorb_mod, oracle, two_keyframes, int(r.integers(10, 10 ** 6)), float(r.uniform(1, 9)))
+
+
+@pytest.mark.parametrize("i", range(N))
+def test_fz_initialization(msorb_mod, oracle, two_keyframes, i):
+    r = _rng(i, 9)
+    _call(ta.test_search_for_initialization_matches_oracle, msorb_mod, oracle, two_keyframes, int(r.integers(10, 10 ** 6)),
+          int(r.integers(5, 200)), float(r.uniform(0.5, 1.0)), bool(r.integers(0, 2)))
+
+
+@pytest.mark.parametrize("i", range(N))
+def test_fz_loop(msorb_mod, oracle, two_keyframes, i):
+    r = _rng(i, 10)
+    _call(ta.test_search_by_projection_loop_matches_oracle, msorb_mod, oracle, two_keyframes, int(r.integers(10, 10 ** 6)),
+          float(r.uniform(1, 16)), float(r.uniform(0.6, 1.6)))
+
+
+@pytest.mark.parametrize("i", range(N))
+def test_fz_bow(i):
+    import msorb
+    r = _rng(i, 11)
+    kw = dict(n1=int(r.integers(0, 3000)), n2=int(r.integers(0, 6000)), n_nodes=int(r.integers(1, 500)),
+              flip=int(r.integers(0, 60)), dup_frac=float(r.uniform(0, 0.6)), mask_frac=float(r.uniform(0, 0.7)),
+              shuffle_lists=bool(r.integers(0, 2)))
+    p = bmc.make_pair(int(r.integers(10, 10 ** 6)), **kw)
+    for k, (th, inc, ratio, ori) in enumerate(tb.MODES + [(int(r.integers(20, 120)), bool(r.integers(0, 2)), float(r.uniform(0.5, 1.0)), True)]):
+        q = dict(p)
+        if k == 2:
+            q["avail2"] = None
+        (got,), ms = msorb.search_by_bow([q], th, inc, ratio, ori)
+        nm, m12, m21 = tb._oracle(q, th, inc, ratio, ori)
+        assert got[0] == nm, kw
+        assert got[1].tolist() == m12.tolist(), kw
+        assert got[2].tolist() == m21.tolist(), kw
+
+
+@pytest.mark.parametrize("i", range(N))
+def test_fz_triangulation(i):
+    import msorb
+    import orb_oracle
+    r = _rng(i, 12)
+    kw = dict(n1=int(r.integers(0, 3000)), n2=int(r.integers(0, 4000)), n_nodes=int(r.integers(1, 300)),
+              pix_noise=float(r.uniform(0, 4)), mask_frac=float(r.uniform(0, 0.8)), flip=int(r.integers(0, 60)))
+    p = bmc.make_triangulation_pair(int(r.integers(10, 10 ** 6)), **kw)
+    for coarse, ori in ((False, True), (True, True), (False, False), (True, False)):
+        (got,), ms = msorb.search_for_triangulation([p], coarse, ori)
+        nm, m12 = orb_oracle.search_for_triangulation(p, coarse, ori)
+        assert got[0] == nm and got[1].tolist() == m12.tolist(), kw
+
+
+@pytest.mark.parametrize("i", range(N))
+def test_fz_frustum(i):
+    r = _rng(i, 13)
+    _call(tf.test_device_matches_oracle, int(r.integers(10, 10 ** 6)), int(r.integers(1, 300000)))
+
+
+@pytest.mark.parametrize("i", range(N))
+def test_fz_sparsify(msorb_mod, oracle, i):
+    r = _rng(i, 14)
+    kw = dict(n_window=int(r.integers(1, 40)), n_outside=int(r.integers(0, 300)), n_points=int(r.integers(1, 30000)),
+              slots_per_kf=int(r.integers(10, 2500)), tracked_frac=float(r.uniform(0, 1)))
+    try:
+        w = sc.window(int(r.integers(10, 10 ** 6)), **kw)
+    except ValueError:
+        pytest.skip("the case generator cannot draw this combination")
+    got = msorb_mod.visibility_csr(N=100, **w)
+    want = oracle.visibility_csr(N=100, **w)
+    assert (got["n_cols"], got["n_rows"], got["n_max_obs"]) == (want["n_cols"], want["n_rows"], want["n_max_obs"]), kw
+    for k in ts.KEYS:
+        assert np.array_equal(got[k], want[k]), (k, kw)
