@@ -1309,7 +1309,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     uint32_t wu[5], vm[5];
     uint32_t rc[5], bc[6];  // slot -> row | byte column << 8 (lane constants; keeps the /9, /10 out of the keypoint loop)
 #pragma unroll
-    for (int it = 0; it < 6; it++) { const int idx = lane + 64 * it; bc[it] = (uint32_t)(idx / 10) | ((uint32_t)(4 * (idx % 10)) << 8); }
+    for (int it = 0; it < 6; it++) {  // slots past row 36 repeat a slot of row 36 (same address, same value: no predication)
+        const int idx = lane + 64 * it;
+        bc[it] = (uint32_t)min(idx / 10, 36) | ((uint32_t)(4 * (idx % 10)) << 8);
+    }
     uint32_t vrow03 = 0;  // v of slots 0..3, one signed byte each
     int vrow4 = 0;
 #pragma unroll
@@ -1326,7 +1329,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             }
         }
         wu[t] = a; vm[t] = m;
-        rc[t] = (uint32_t)min(row, 31) | ((uint32_t)(4 * col + 4) << 8);
+        rc[t] = (uint32_t)min(row, 30) | ((uint32_t)(4 * col + 4) << 8);  // slots of no row: weights 0, any valid address
         if (t < 4) vrow03 |= (uint32_t)((row - 15) & 255) << (8 * t);
         else vrow4 = row - 15;
     }
@@ -1373,12 +1376,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             const uint32_t row = rc[t] & 255u, col4p4 = rc[t] >> 8;
             const uint32_t o = __umul24(row, (uint32_t)lv.pitch);  // full-rate 24-bit multiply
             L.rsh[t] = (rlow + o) & 3u;
-            L.rp[t] = row < 31 ? *reinterpret_cast<const uint32_t*>(rrow + (size_t)(o + col4p4 - L.rsh[t])) : 0u;
+            L.rp[t] = *reinterpret_cast<const uint32_t*>(rrow + (size_t)(o + col4p4 - L.rsh[t]));
         }
 #pragma unroll
         for (int it = 0; it < 6; it++) {
             const uint32_t row = bc[it] & 255u, col4 = bc[it] >> 8;
-            L.bp[it] = (it < 5 || row < 37) ? *reinterpret_cast<const uint32_t*>(brow + (size_t)(__umul24(row, (uint32_t)bv.pitch) + col4)) : 0u;
+            L.bp[it] = *reinterpret_cast<const uint32_t*>(brow + (size_t)(__umul24(row, (uint32_t)bv.pitch) + col4));
         }
     };
     const SelRec* recs = sel + (size_t)img * sel_stride;
@@ -1390,20 +1393,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     // own LDS slot.  Phase V, once per wave: angle, cos, sin of all four keypoints at once — lane kk computes keypoint kk,
     // so the atan2 polynomial and the double-precision sincos run once per wave instead of once per keypoint.
     // Phase B, per keypoint: steered BRIEF from its LDS slot.
+    // The last wave of an image repeats the image's last keypoint in its unused places (no exit inside the sequence: the
+    // four keypoints are one straight line of code, so the pre-issued loads stay in flight across them; an early exit made
+    // the compiler copy them at the merge points, i.e. wait for them); only the stores are conditional.
     SelRec R[kKpPerWave];
     int M10[kKpPerWave], M01[kKpPerWave], POFF[kKpPerWave];
-    int n_here = 0;
-#pragma unroll
-    for (int kk = 0; kk < kKpPerWave; kk++) { M10[kk] = 0; M01[kk] = 0; POFF[kk] = 0; R[kk] = r_cur; }
     uint8_t* const lp0 = patch[(threadIdx.x >> 6) * kKpPerWave];
 #pragma unroll
     for (int kk = 0; kk < kKpPerWave; kk++) {
         const int k = k_first + kk;
-        if (k >= n_sel) break;
-        n_here = kk + 1;
         R[kk] = r_cur;
         const Loads L = L_next;
-        if (k + 1 < n_sel && kk + 1 < kKpPerWave) {
+        if (kk + 1 < kKpPerWave) {
             r_cur = scalar_rec(r_pre);
             issue(r_cur, L_next);
             r_pre = recs[min(k + 2, n_sel - 1)];
@@ -1431,7 +1432,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 #pragma unroll
         for (int it = 0; it < 6; it++) {
             const uint32_t row = bc[it] & 255u, col4 = bc[it] >> 8;
-            if (it < 5 || row < 37) *reinterpret_cast<uint32_t*>(lp + row * kPatchPitch + col4) = bp[it];
+            *reinterpret_cast<uint32_t*>(lp + row * kPatchPitch + col4) = bp[it];
         }
     }
     // Phase V
@@ -1447,7 +1448,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     // Phase B
 #pragma unroll
     for (int kk = 0; kk < kKpPerWave; kk++) {
-        if (kk >= n_here) break;
         const SelRec r = R[kk];
         const float angle = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angle_v), kk));
         const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_v), kk));
@@ -1466,6 +1466,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             const int t1 = bc[r1 * kPatchPitch + q1];
             word[w] = __ballot(t0 < t1);
         }
+        if (k_first + kk >= n_sel) break;  // wave-uniform; nothing but the stores is left
         if (lane < 4) {
             unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)img * out_stride + r.dst) * 32);
             d[lane] = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
