@@ -79,7 +79,8 @@ except Exception as ex:
 json.dump(lat, open(os.path.join(P, f"{rnd}_latency_per_frame.json"), "w"), indent=1)
 for src, dst in (("bow_bench.json", "bow_bench.json"), ("valu_ubench.txt", "valu_ubench.txt"), ("kf_store_bench.json", "kf_store_bench.json"),
                  ("bench_unique128.json", "bench_unique128.json"), ("fetch_calib.txt", "fetch_calib.txt"),
-                 ("hamming_bench.txt", "hamming_bench.txt"), ("pytest_gpu.txt", "pytest_gpu.txt")):
+                 ("hamming_bench.txt", "hamming_bench.txt"), ("pytest_gpu.txt", "pytest_gpu.txt"),
+                 ("batch_sweep.jsonl", "batch_sweep.jsonl")):
     if os.path.exists(os.path.join(G, src)):
         shutil.copy(os.path.join(G, src), os.path.join(P, f"{rnd}_{dst}"))
 print("value", bench["value"], "ms/step", bench["ms_per_step"], bench["stage_ms_per_step"])

@@ -14,6 +14,7 @@ PMC_TIMEOUT=300 tools/pmc_run.sh round/pmc_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_
 python tools/latency_bench.py > $O/latency.json 2> $O/latency.err; cat $O/latency.json
 python tools/bow_bench.py > $O/bow_bench.json 2>/dev/null; cat $O/bow_bench.json
 python tools/hamming_bench.py > $O/hamming_bench.txt 2>&1; tail -5 $O/hamming_bench.txt
+tools/batch_sweep.sh > $O/batch_sweep.jsonl 2>/dev/null; cat $O/batch_sweep.jsonl
 g++ -O2 -std=c++17 tools/latency_pair.cc -Iinclude -Lms-slam_amd -lmsorb -lpthread -o /tmp/latency_pair 2>/dev/null && LD_LIBRARY_PATH=ms-slam_amd:/opt/rocm/lib /tmp/latency_pair 300 > $O/latency_pair.json; cat $O/latency_pair.json
 g++ -O2 -std=c++17 -Itests/cv_stub -Ims-slam_amd/host -Iinclude tools/latency_class.cc ms-slam_amd/host/ORBextractor.cc -Lms-slam_amd -lmsorb -lpthread -o /tmp/latency_class 2>$O/latency_class.err && {
   LD_LIBRARY_PATH=ms-slam_amd:/opt/rocm/lib /tmp/latency_class 300 > $O/latency_class_on.json
