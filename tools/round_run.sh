@@ -4,7 +4,8 @@
 # Every profiler pass runs under its own timeout: a counter set the hardware refuses leaves rocprofv3 waiting forever.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; O=gpurun_out/round; rm -rf $O; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.json
-python bench.py --unique-pairs 128 --steps 10 --warmup 2 --cpu-pairs 0 > $O/bench_unique128.json 2>/dev/null; tail -c 300 $O/bench_unique128.json
+python bench.py --unique-pairs 128 --steps 100 --warmup 10 --cpu-pairs 0 > $O/bench_unique128.json 2>/dev/null; tail -c 300 $O/bench_unique128.json
+python bench.py --steps 100 --warmup 10 --cpu-pairs 0 > $O/bench_unique8_same_steps.json 2>/dev/null
 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 | tee $O/pytest_gpu.txt
 timeout -k 5 300 tools/gpu_trace.sh round/trace > $O/trace.txt 2>&1; tail -30 $O/trace.txt
 PMC_TIMEOUT=300 tools/pmc_run.sh round/pmc_fetch "FETCH_SIZE" "" -- python bench.py --steps 2 --warmup 1 --cpu-pairs 0 --isolated > $O/pmc_fetch.txt 2>&1
