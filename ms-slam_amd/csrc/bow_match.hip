@@ -495,7 +495,7 @@ extern "C" int msorb_search_by_bow(int device, msorb_bow_pair* pairs, int n_pair
     char* d = scr.d;
     e = hipMemcpyAsync(d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d + o_m, 0xFF, tot1 * 4, s);
-    if (e == hipSuccess) e = hipEventRecord(scr.e0, s);
+    if (e == hipSuccess && elapsed_ms) e = hipEventRecord(scr.e0, s);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(bow_match_kernel, dim3((unsigned)n_items), dim3(64), (size_t)max_chunks * 8, s,
                            (const BowItem*)(d + o_it), (const uint4*)(d + o_d1), (const uint4*)(d + o_d2),
@@ -503,7 +503,7 @@ extern "C" int msorb_search_by_bow(int device, msorb_bow_pair* pairs, int n_pair
                            (const int*)(d + o_f2), th_low, inclusive, nnratio, (int*)(d + o_m));
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipEventRecord(scr.e1, s);
+    if (e == hipSuccess && elapsed_ms) e = hipEventRecord(scr.e1, s);
     if (e == hipSuccess) e = hipMemcpyAsync(scr.h + o_m, d + o_m, tot1 * 4, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess && elapsed_ms) e = hipEventElapsedTime(elapsed_ms, scr.e0, scr.e1);
@@ -610,7 +610,7 @@ extern "C" int msorb_search_for_triangulation(int device, msorb_triangulation_pa
     char* d = scr.d;
     e = hipMemcpyAsync(d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d + o_m, 0xFF, tot1 * 4, s);
-    if (e == hipSuccess) e = hipEventRecord(scr.e0, s);
+    if (e == hipSuccess && elapsed_ms) e = hipEventRecord(scr.e0, s);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(triangulation_match_kernel, dim3((unsigned)n_items), dim3(64), (size_t)max_chunks * 8, s,
                            (const BowItem*)(d + o_it), (const TriConst*)(d + o_c), (const uint4*)(d + o_d1),
@@ -619,7 +619,7 @@ extern "C" int msorb_search_for_triangulation(int device, msorb_triangulation_pa
                            coarse, (int*)(d + o_m));
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipEventRecord(scr.e1, s);
+    if (e == hipSuccess && elapsed_ms) e = hipEventRecord(scr.e1, s);
     if (e == hipSuccess) e = hipMemcpyAsync(scr.h + o_m, d + o_m, tot1 * 4, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess && elapsed_ms) e = hipEventElapsedTime(elapsed_ms, scr.e0, scr.e1);
@@ -853,10 +853,16 @@ extern "C" int msorb_search_by_bow_kf(msorb_kf_store* st, msorb_bow_kf_pair* pai
         if (!ok) { set_last_error("search_by_bow_kf: node list too long"); return MSORB_E_INVALID; }
         tot1 += (size_t)A.n;
         tot2 += (size_t)n2;
-        for (int i = 0; i < A.n; i++) P.match12[i] = -1;
-        if (P.match21) for (int j = 0; j < n2; j++) P.match21[j] = -1;
     }
-    if (items.empty()) return MSORB_OK;
+    if (items.empty()) {   // no common node anywhere: nothing is launched, every feature stays unmatched
+        for (int pi = 0; pi < n_pairs; pi++) {
+            msorb_bow_kf_pair& P = pairs[pi];
+            const int n1 = st->kf[P.kf1].n, n2 = P.kf2 < 0 ? frame->n : st->kf[P.kf2].n;
+            for (int i = 0; i < n1; i++) P.match12[i] = -1;
+            if (P.match21) for (int j = 0; j < n2; j++) P.match21[j] = -1;
+        }
+        return MSORB_OK;
+    }
     const size_t n_items = items.size();
     const size_t fr_rows = frame ? (size_t)frame->n : 0, fr_feats = frame && frame->fv_nodes ? (size_t)(frame->fv_begin[frame->fv_nodes] - fr_feat_lo) : 0;
     // staging: [frame desc | frame feat | frame angle | items | posts | valid1 | avail2] in, [match12 | match21 | nmatches] out
@@ -890,7 +896,7 @@ extern "C" int msorb_search_by_bow_kf(msorb_kf_store* st, msorb_bow_kf_pair* pai
     char* d = scr.d;
     e = hipMemcpyAsync(d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d + o_m, 0xFF, o_nm - o_m, s);   // match12 and match21 = -1
-    if (e == hipSuccess) e = hipEventRecord(scr.e0, s);
+    if (e == hipSuccess && elapsed_ms) e = hipEventRecord(scr.e0, s);
     if (e == hipSuccess) {
         const uint4* desc2 = frame ? (const uint4*)(d + o_fd) : st->d_desc;
         const int* feat2 = frame ? (const int*)(d + o_ff) : st->d_feat;
@@ -902,7 +908,7 @@ extern "C" int msorb_search_by_bow_kf(msorb_kf_store* st, msorb_bow_kf_pair* pai
                            (int*)(d + o_nm));
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipEventRecord(scr.e1, s);
+    if (e == hipSuccess && elapsed_ms) e = hipEventRecord(scr.e1, s);
     if (e == hipSuccess) e = hipMemcpyAsync(scr.h + o_m, d + o_m, out_bytes, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess && elapsed_ms) e = hipEventElapsedTime(elapsed_ms, scr.e0, scr.e1);
@@ -948,9 +954,12 @@ extern "C" int msorb_search_for_triangulation_kf(msorb_kf_store* st, msorb_trian
         if (!ok) { set_last_error("search_for_triangulation_kf: node list too long"); return MSORB_E_INVALID; }
         tot1 += (size_t)A.n;
         tot2 += (size_t)B.n;
-        for (int i = 0; i < A.n; i++) P.match12[i] = -1;
     }
-    if (items.empty()) return MSORB_OK;
+    if (items.empty()) {
+        for (int pi = 0; pi < n_pairs; pi++)
+            for (int i = 0; i < st->kf[pairs[pi].kf1].n; i++) pairs[pi].match12[i] = -1;
+        return MSORB_OK;
+    }
     const size_t n_items = items.size();
     // staging: [items | consts | posts | flags1 | flags2] in, [match12 | nmatches] out
     const size_t o_it = 0, o_c = o_it + up16(n_items * sizeof(BowItem)), o_po = o_c + up16((size_t)n_pairs * sizeof(TriConst)),
@@ -981,7 +990,7 @@ extern "C" int msorb_search_for_triangulation_kf(msorb_kf_store* st, msorb_trian
     char* d = scr.d;
     e = hipMemcpyAsync(d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d + o_m, 0xFF, tot1 * 4, s);
-    if (e == hipSuccess) e = hipEventRecord(scr.e0, s);
+    if (e == hipSuccess && elapsed_ms) e = hipEventRecord(scr.e0, s);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(triangulation_match_kernel, dim3((unsigned)n_items), dim3(64), (size_t)max_chunks * 8, s,
                            (const BowItem*)(d + o_it), (const TriConst*)(d + o_c), st->d_desc, st->d_desc, (const uint8_t*)(d + o_v1),
@@ -990,7 +999,7 @@ extern "C" int msorb_search_for_triangulation_kf(msorb_kf_store* st, msorb_trian
                            st->d_angle, check_orientation, (int*)(d + o_m), (int*)nullptr, (int*)(d + o_nm));
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipEventRecord(scr.e1, s);
+    if (e == hipSuccess && elapsed_ms) e = hipEventRecord(scr.e1, s);
     if (e == hipSuccess) e = hipMemcpyAsync(scr.h + o_m, d + o_m, out_bytes, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess && elapsed_ms) e = hipEventElapsedTime(elapsed_ms, scr.e0, scr.e1);
