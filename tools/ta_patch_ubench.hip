@@ -1,0 +1,76 @@
+// Vector-memory front-end cost of a patch gather (describe_kernel's access pattern), gfx950:
+//   mode 0: 37 rows x 10 dwords, lane = dword of the patch (6 global_load_dword per patch)
+//   mode 1: 37 rows x 4 x 16 bytes, lane = 16-byte granule (3 global_load_dwordx4 per patch, 16-byte aligned)
+//   mode 2: 37 rows x 3 x 16 bytes (2 instructions; what a 48-byte window would need)
+// Every workgroup works inside one 3 MB "image" chosen by blockIdx % 8, so that the lines come from the XCD's L2 as in the
+// real kernel.  Prints ns per patch and patches/s.
+//   hipcc --offload-arch=gfx950 -O3 tools/ta_patch_ubench.hip -o /tmp/ta_patch && /tmp/ta_patch
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+constexpr int kPitch = 1280, kRows = 376 * 6, kImgBytes = kPitch * kRows;   // ~2.9 MB
+
+__device__ __forceinline__ uint32_t hash(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gather(const uint8_t* __restrict__ base, int n_img, int per_wave, uint32_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint8_t* img = base + (size_t)(blockIdx.x % n_img) * kImgBytes;
+    uint32_t acc = 0;
+    for (int k = 0; k < per_wave; k++) {
+        const uint32_t h = hash((blockIdx.x * 4 + wave) * 977u + k);
+        const int x = 24 + (int)(h % (kPitch - 96)), y = 24 + (int)((h >> 12) % (kRows - 64));
+        const uint8_t* p = img + (size_t)(y - 18) * kPitch;
+        if (MODE == 0) {
+            const int px0 = (x - 18) & ~3;
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const int idx = lane + 64 * it, row = min(idx / 10, 36), col = idx % 10;
+                acc ^= *reinterpret_cast<const uint32_t*>(p + row * kPitch + px0 + 4 * col);
+            }
+        } else if (MODE == 1) {
+            const int px0 = (x - 18) & ~15;
+#pragma unroll
+            for (int it = 0; it < 3; it++) {
+                const int idx = lane + 64 * it, row = min(idx >> 2, 36), col = idx & 3;
+                const uint4 v = *reinterpret_cast<const uint4*>(p + row * kPitch + px0 + 16 * col);
+                acc ^= v.x ^ v.y ^ v.z ^ v.w;
+            }
+        } else {
+            const int px0 = (x - 18) & ~15;
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const int idx = lane + 64 * it, row = min(idx / 3, 36), col = idx % 3;
+                const uint4 v = *reinterpret_cast<const uint4*>(p + row * kPitch + px0 + 16 * col);
+                acc ^= v.x ^ v.y ^ v.z ^ v.w;
+            }
+        }
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+int main() {
+    const int n_img = 8, blocks = 256 * 24, per_wave = 64;
+    uint8_t* d; uint32_t* o;
+    hipMalloc(&d, (size_t)n_img * kImgBytes); hipMalloc(&o, 64);
+    hipMemset(d, 1, (size_t)n_img * kImgBytes);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int mode = 0; mode < 3; mode++) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 5; rep++) {
+            hipEventRecord(e0);
+            if (mode == 0) hipLaunchKernelGGL(gather<0>, dim3(blocks), dim3(256), 0, 0, d, n_img, per_wave, o);
+            if (mode == 1) hipLaunchKernelGGL(gather<1>, dim3(blocks), dim3(256), 0, 0, d, n_img, per_wave, o);
+            if (mode == 2) hipLaunchKernelGGL(gather<2>, dim3(blocks), dim3(256), 0, 0, d, n_img, per_wave, o);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) best = ms;
+        }
+        const double patches = (double)blocks * 4 * per_wave;
+        printf("mode %d: %.3f ms for %.0f patches -> %.1f G patches/s, %.2f cycles@2.4GHz per patch per CU\n", mode, best, patches,
+               patches / best / 1e6, best * 1e-3 * 2.4e9 * 256 / patches);
+    }
+    return 0;
+}
