@@ -2,6 +2,7 @@
 //   mode 0: 37 rows x 10 dwords, lane = dword of the patch (6 global_load_dword per patch)
 //   mode 1: 37 rows x 4 x 16 bytes, lane = 16-byte granule (3 global_load_dwordx4 per patch, 16-byte aligned)
 //   mode 2: 37 rows x 3 x 16 bytes (2 instructions; what a 48-byte window would need)
+//   mode 3 / 4: mode 0 with non-temporal / sc1 loads (mode 4 waits after every load: a lower bound on its rate only)
 // Every workgroup works inside one 3 MB "image" chosen by blockIdx % 8, so that the lines come from the XCD's L2 as in the
 // real kernel.  Prints ns per patch and patches/s.
 //   hipcc --offload-arch=gfx950 -O3 tools/ta_patch_ubench.hip -o /tmp/ta_patch && /tmp/ta_patch
@@ -30,6 +31,23 @@ __global__ __launch_bounds__(256) void gather(const uint8_t* __restrict__ base, 
                 const int idx = lane + 64 * it, row = min(idx / 10, 36), col = idx % 10;
                 acc ^= *reinterpret_cast<const uint32_t*>(p + row * kPitch + px0 + 4 * col);
             }
+        } else if (MODE == 3) {   // mode 0 with non-temporal loads
+            const int px0 = (x - 18) & ~3;
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const int idx = lane + 64 * it, row = min(idx / 10, 36), col = idx % 10;
+                acc ^= __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p + row * kPitch + px0 + 4 * col));
+            }
+        } else if (MODE == 4) {   // mode 0 with sc1 loads (served by L2, no L1 allocation)
+            const int px0 = (x - 18) & ~3;
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const int idx = lane + 64 * it, row = min(idx / 10, 36), col = idx % 10;
+                uint32_t v;
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(p + row * kPitch + px0 + 4 * col);
+                asm volatile("global_load_dword %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(q) : "memory");
+                acc ^= v;
+            }
         } else if (MODE == 1) {
             const int px0 = (x - 18) & ~15;
 #pragma unroll
@@ -57,13 +75,15 @@ int main() {
     hipMalloc(&d, (size_t)n_img * kImgBytes); hipMalloc(&o, 64);
     hipMemset(d, 1, (size_t)n_img * kImgBytes);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 3; mode++) {
+    for (int mode = 0; mode < 5; mode++) {
         float best = 1e9f;
         for (int rep = 0; rep < 5; rep++) {
             hipEventRecord(e0);
             if (mode == 0) hipLaunchKernelGGL(gather<0>, dim3(blocks), dim3(256), 0, 0, d, n_img, per_wave, o);
             if (mode == 1) hipLaunchKernelGGL(gather<1>, dim3(blocks), dim3(256), 0, 0, d, n_img, per_wave, o);
             if (mode == 2) hipLaunchKernelGGL(gather<2>, dim3(blocks), dim3(256), 0, 0, d, n_img, per_wave, o);
+            if (mode == 3) hipLaunchKernelGGL(gather<3>, dim3(blocks), dim3(256), 0, 0, d, n_img, per_wave, o);
+            if (mode == 4) hipLaunchKernelGGL(gather<4>, dim3(blocks), dim3(256), 0, 0, d, n_img, per_wave, o);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (ms < best) best = ms;
