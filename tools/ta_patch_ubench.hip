@@ -21,10 +21,13 @@ __global__ __launch_bounds__(256) void gather(const uint8_t* __restrict__ base, 
     const uint8_t* img = base + (size_t)(blockIdx.x % n_img) * kImgBytes;
     uint32_t acc = 0;
     for (int k = 0; k < per_wave; k++) {
-        const uint32_t h = hash((blockIdx.x * 4 + wave) * 977u + k);
-        const int x = 24 + (int)(h % (kPitch - 96)), y = 24 + (int)((h >> 12) % (kRows - 64));
+        // modes 0..4: every wave its own random patch; mode 5 (= mode 0's loads): the four waves of a workgroup take
+        // neighbouring patches (34 px apart in x, up to 12 rows in y), as keypoints sorted by image tile would be
+        const uint32_t h = MODE == 5 ? hash(blockIdx.x * 977u + k) : hash((blockIdx.x * 4 + wave) * 977u + k);
+        int x = 24 + (int)(h % (kPitch - 200)), y = 24 + (int)((h >> 12) % (kRows - 80));
+        if (MODE == 5) { x += 34 * wave; y += 12 * (wave & 1); }
         const uint8_t* p = img + (size_t)(y - 18) * kPitch;
-        if (MODE == 0) {
+        if (MODE == 0 || MODE == 5) {
             const int px0 = (x - 18) & ~3;
 #pragma unroll
             for (int it = 0; it < 6; it++) {
@@ -75,7 +78,7 @@ int main() {
     hipMalloc(&d, (size_t)n_img * kImgBytes); hipMalloc(&o, 64);
     hipMemset(d, 1, (size_t)n_img * kImgBytes);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 5; mode++) {
+    for (int mode = 0; mode < 6; mode++) {
         float best = 1e9f;
         for (int rep = 0; rep < 5; rep++) {
             hipEventRecord(e0);
@@ -84,6 +87,7 @@ int main() {
             if (mode == 2) hipLaunchKernelGGL(gather<2>, dim3(blocks), dim3(256), 0, 0, d, n_img, per_wave, o);
             if (mode == 3) hipLaunchKernelGGL(gather<3>, dim3(blocks), dim3(256), 0, 0, d, n_img, per_wave, o);
             if (mode == 4) hipLaunchKernelGGL(gather<4>, dim3(blocks), dim3(256), 0, 0, d, n_img, per_wave, o);
+            if (mode == 5) hipLaunchKernelGGL(gather<5>, dim3(blocks), dim3(256), 0, 0, d, n_img, per_wave, o);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (ms < best) best = ms;
