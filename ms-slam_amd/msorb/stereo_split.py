@@ -73,8 +73,14 @@ def swap_halves_async(dist, rank, world, mine, theirs):
     h = theirs.counts.shape[0]
     sends = [t[h:] for t in mine.tensors()]
     recvs = list(theirs.tensors())
+    if hasattr(dist, "batch_isend_irecv"):
+        # one group for the six transfers: on RCCL they become a single grouped launch in which both directions of the xGMI
+        # link are busy at once, and no ordering between the partners' sends and receives can block
+        ops = [dist.P2POp(dist.irecv, t, p) for t in recvs] + [dist.P2POp(dist.isend, t, p) for t in sends]
+        return list(dist.batch_isend_irecv(ops))
     works = []
-    # post the receives first, then the sends (point-to-point pairs are matched in order on both sides)
+    # plain point-to-point calls are matched in order on both sides: the left-eye rank posts its receives first, the
+    # right-eye rank its sends
     if eye_of(rank) == 0:
         works += [dist.irecv(t, p) for t in recvs]
         works += [dist.isend(t, p) for t in sends]
