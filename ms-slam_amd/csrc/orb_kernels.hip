@@ -1103,6 +1103,7 @@ __device__ __forceinline__ void gauss7_strip(const uint8_t* __restrict__ sb, uin
     }
     // steady state: input row r = 6 + 7*it + u completes output row o = r - 6 and opens accumulator r % 7
     for (int it = 0; it < ROWS / 7; it++) {
+        if (y0 + 7 * it >= h) break;   // wave-uniform: the last strip of a level ends with the level (4.8 % of all rows otherwise)
         uint32_t cur[7];
 #pragma unroll
         for (int u = 0; u < 7; u++) cur[u] = nxt[u];
