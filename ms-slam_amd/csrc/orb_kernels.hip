@@ -1156,7 +1156,10 @@ __global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, Pyr
     // stores) is then scalar work
     const int y0 = (by * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * ROWS;
     if (y0 >= sv.h) return;  // wave-uniform
-    const bool store = lane >= 1 && lane <= kGaussLanesOut && x0 < sv.w;  // lanes 0 / 63 and lanes past the row: halo only
+    // lanes 0 / 63 and lanes past the row: halo only — except that lane 63 can take the row's last group: columns x0 + 4 .. are
+    // all beyond the border then, i.e. reflections out of {w1, w0}, and the missing right neighbour is not needed (a row of
+    // 62 k + 1 groups — KITTI's 1241 and 499 pixel levels — takes k blocks instead of k + 1)
+    const bool store = lane >= 1 && (lane <= kGaussLanesOut || x0 + 4 >= sv.w) && x0 < sv.w;
     // Right border (reflect-101): a group with x0 + 7 > w needs pixels beyond column w-1.  Their mirror images
     // p[2(w-1) - x] lie at most 3 columns left of w-1, i.e. inside the lane's own 12-byte window {w2,w1,w0} = columns
     // x0-4 .. x0+7, so the fix is a byte permutation of the window that depends on w - x0 only: three selectors per lane,
@@ -1623,7 +1626,8 @@ void launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images,
         plan.block_begin[l] = total;
         // aligned path: 62 stored groups per wave; generic path: 64 groups per wave
         const int main_groups = stream ? (v.w + 3) / 4 : (v.w >= 16 ? (v.w - 16) / 4 + 1 : 0);  // stream kernel: every group
-        plan.bx_count[l] = stream ? max(1, (main_groups + kGaussLanesOut - 1) / kGaussLanesOut) : (v.w + 255) / 256;
+        // (62 stored lanes per wave, + the row's last group on lane 63 if it is exactly one group more)
+        plan.bx_count[l] = stream ? max(1, (main_groups - 1 + kGaussLanesOut - 1) / kGaussLanesOut) : (v.w + 255) / 256;
         const int strips = (v.h + rows - 1) / rows;
         total += plan.bx_count[l] * ((strips + 3) / 4);
         max_h = max(max_h, v.h);
