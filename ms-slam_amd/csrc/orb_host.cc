@@ -132,6 +132,26 @@ bool FrameGeom::build(const OrbParams& p, int rows_, int cols_) {
                     c.g_magic = ((1u << 20) + G - 1) / G;
                     c.ndw_magic = ((1u << 20) + ndw - 1) / ndw;
                     c.rw_magic = ((1u << 20) + std::max<int>(c.rw, 1) - 1) / std::max<int>(c.rw, 1);
+                    // rows per wave (see CellDesc): iterations of the quick-test loop = max(rows, 3) per wave
+                    const int spw = std::max(64 / G, 1);
+                    c.spw = (uint8_t)std::min(spw, 255);
+                    c.pad_ = 0;
+                    auto split = [&](int waves, int r_uniform, int max_r, uint32_t& rw_out, uint32_t& yw_out) -> uint8_t {
+                        const int S = waves * spw, base = dh / S, rem = dh - base * S, plus = (rem + spw - 1) / spw;
+                        int cost = 0, y = 0, worst = 0;
+                        rw_out = 0; yw_out = 0;
+                        for (int w = 0; w < waves; w++) {
+                            const int r = base + (w < plus ? 1 : 0);
+                            rw_out |= (uint32_t)r << (8 * w);
+                            yw_out |= (uint32_t)std::min(y, dh) << (8 * w);
+                            y += spw * r;
+                            cost += std::max(r, 3);
+                            worst = std::max(worst, r);
+                        }
+                        return (G <= 64 && dh <= 255 && worst <= max_r && cost < waves * std::max(r_uniform, 3)) ? 1 : 0;
+                    };
+                    c.by_wave[0] = split(2, c.R128, 5, c.rw128, c.yw128);   // GeoSmall::kMaxR
+                    c.by_wave[1] = split(4, c.R256, 6, c.rw256, c.yw256);   // GeoLarge::kMaxR
                 }
                 cells.push_back(c);
             }

@@ -47,6 +47,12 @@ struct CellDesc {  // one FAST cell of ComputeKeyPointsOctTree (ORBextractor.cc:
     // (q = (n * magic) >> 20 is exact for the kernel's ranges: n < 2^12)
     uint32_t g_magic, ndw_magic, rw_magic;
     int16_t G, ndw;
+    // Rows per wave (quick test): with spw = 64 / G strips inside every wave, wave w gives its threads rw[w] rows starting at
+    // detection row yw[w] (one byte per wave) — e.g. 39 rows over 2 x 6 strips as 4 + 3 per thread instead of 4 + 4.
+    // by_wave[i] != 0 (i = 0: 128 threads, 1: 256): this split needs fewer row iterations than R128 / R256 and fits the kernel's
+    // register window; otherwise the kernel keeps the uniform split above.
+    uint8_t by_wave[2], spw, pad_;
+    uint32_t rw128, yw128, rw256, yw256;
 };
 
 struct LevelGeom {

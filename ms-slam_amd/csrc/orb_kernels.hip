@@ -633,9 +633,23 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
 
     // Quick-test mapping: thread (strip, g) owns the 4-pixel column group g of R consecutive detection rows, so the column
     // clipping is a per-thread constant and the rows above / below come out of one register window.
-    const int strip = (int)(__umul24((uint32_t)tid, magic) >> 20), g_own = tid - strip * G;
-    const int R = T == 128 ? cd.R128 : cd.R256;         // wave-uniform
-    const int y_b = strip * R;                          // first detection row of the thread
+    // Two ways to deal the detection rows: uniformly (strip = tid / G over the whole workgroup, R rows each), or per wave
+    // (64 / G strips inside every wave; wave w takes rw[w] rows per thread from row yw[w] on) when that needs fewer iterations
+    // of the row loop — 39 rows over 2 x 6 strips are 4 + 3 instead of 4 + 4 (host-decided per cell, block-uniform).
+    int g_own, R, y_b;
+    if ((T == 128 ? cd.by_wave[0] : cd.by_wave[1]) == 0) {
+        const int strip = (int)(__umul24((uint32_t)tid, magic) >> 20);
+        g_own = tid - strip * G;
+        R = T == 128 ? cd.R128 : cd.R256;               // wave-uniform
+        y_b = strip * R;                                // first detection row of the thread
+    } else {
+        const int sw = __builtin_amdgcn_readfirstlane(wave) * 8;
+        const int sl = (int)(__umul24((uint32_t)lane, magic) >> 20);
+        g_own = lane - sl * G;
+        R = (int)(((T == 128 ? cd.rw128 : cd.rw256) >> sw) & 255u);    // wave-uniform (scalar)
+        const int y_w = (int)(((T == 128 ? cd.yw128 : cd.yw256) >> sw) & 255u);
+        y_b = sl < (int)cd.spw ? y_w + sl * R : dh;     // lanes past the wave's last strip: no rows
+    }
     const int nrows = min(max(dh - y_b, 0), R);         // 0 for the threads beyond the last strip
     const int c_own = c_lo + 4 * g_own;                 // tile column of pixel 0 of the group
     uint32_t Hm;                                        // 0x80 in every byte whose pixel lies inside [x_lo, x_hi)
