@@ -939,19 +939,28 @@ __global__ __launch_bounds__(256) void cand_scan_images_kernel(const int* __rest
 
 // 8 cells per 256-thread workgroup, 32 lanes per cell (a cell keeps ~20-40 candidates: one block of 64 threads per cell was
 // 230 k nearly empty workgroups per batch, 56 us of launch machinery for 48 MB)
-constexpr int kGatherCells = 8;
+constexpr int kGatherCells = 16;   // 8 groups of 32 lanes, two cells each (their loads in flight together)
 __global__ __launch_bounds__(256) void cand_gather_kernel(const CellDesc* __restrict__ cells, int n_cells,
                                                           int slots_per_image, const Cand16* __restrict__ slots,
                                                           const int* __restrict__ cell_count,
                                                           const int* __restrict__ cell_off,
                                                           const int* __restrict__ img_base, Cand16* __restrict__ compact) {
-    const int cell_id = blockIdx.x * kGatherCells + (int)(threadIdx.x >> 5), img = blockIdx.y, l = threadIdx.x & 31;
-    if (cell_id >= n_cells) return;
-    const int n = cell_count[(size_t)img * n_cells + cell_id];
-    if (n == 0) return;
-    const Cand16* s = slots + (size_t)img * slots_per_image + cells[cell_id].slot_off;
-    Cand16* d = compact + img_base[img] + cell_off[(size_t)img * n_cells + cell_id];
-    for (int i = l; i < n; i += 32) d[i] = s[i];
+    const int c0 = blockIdx.x * kGatherCells + 2 * (int)(threadIdx.x >> 5), img = blockIdx.y, l = threadIdx.x & 31;
+    if (c0 >= n_cells) return;
+    const int c1 = min(c0 + 1, n_cells - 1);
+    const int* cnt = cell_count + (size_t)img * n_cells;
+    const int* off = cell_off + (size_t)img * n_cells;
+    const int n0 = cnt[c0], n1 = c0 + 1 < n_cells ? cnt[c1] : 0;
+    const int o0 = off[c0], o1 = off[c1], s0 = cells[c0].slot_off, s1 = cells[c1].slot_off, base = img_base[img];
+    const Cand16* sp = slots + (size_t)img * slots_per_image;
+    Cand16* d = compact + base;
+    Cand16 v0{}, v1{};
+    if (l < n0) v0 = sp[s0 + l];
+    if (l < n1) v1 = sp[s1 + l];
+    if (l < n0) d[o0 + l] = v0;
+    if (l < n1) d[o1 + l] = v1;
+    for (int i = l + 32; i < n0; i += 32) d[o0 + i] = sp[s0 + i];
+    for (int i = l + 32; i < n1; i += 32) d[o1 + i] = sp[s1 + i];
 }
 
 // ------------------------------------------------------------------------------------------------
