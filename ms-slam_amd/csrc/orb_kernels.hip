@@ -285,13 +285,13 @@ __device__ __forceinline__ void pyr_band_tile(const LevelView& src, const LevelV
     }
 }
 
-template <int R, int kSrc>
-__global__ __launch_bounds__(256) void pyr_resize_band_kernel(LevelView src, LevelView dst, uint8_t* __restrict__ dst_base,
-                                                              const ResizeTap* __restrict__ tx,
-                                                              const ResizeTap* __restrict__ ty) {
-    __shared__ uint2 park[4][kSrc][64];
+template <int R, int kSrc, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES) void pyr_resize_band_kernel(LevelView src, LevelView dst, uint8_t* __restrict__ dst_base,
+                                                                     const ResizeTap* __restrict__ tx,
+                                                                     const ResizeTap* __restrict__ ty) {
+    __shared__ uint2 park[WAVES][kSrc][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int dy0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + wave) * R);
+    const int dy0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * WAVES + wave) * R);
     pyr_band_tile<R, kSrc>(src, dst, dst_base, tx, ty, blockIdx.z, blockIdx.x, dy0, lane, park[wave]);
 }
 
@@ -1546,10 +1546,12 @@ void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_
                          (src.img_stride & 3) == 0 && src.pitch >= ((src.w + 3) & ~3) + 8 &&
                          (reinterpret_cast<uintptr_t>(tx) & 15) == 0;
     constexpr int R = 8;  // rows per wave
-    // test aids: MSORB_PYR_SINGLE -> one-row kernels, MSORB_PYR_ROWS -> row-streaming kernel, MSORB_PYR_BAND -> band kernel
+    // test aids: MSORB_PYR_SINGLE -> one-row kernels, MSORB_PYR_ROWS -> row-streaming kernel, MSORB_PYR_DMA -> LDS-DMA band kernel
+    // (default = the register band kernel: 0.168 against 0.180 ms per 256 KITTI images for the LDS-DMA form once both share
+    // pyr_band_tile's arithmetic — and 25 instead of 40 KB of LDS per workgroup beside the other batch's kernels)
     const bool rows_env = !getenv("MSORB_PYR_SINGLE");
     const bool band_env = !getenv("MSORB_PYR_ROWS");
-    const bool dma_env = !getenv("MSORB_PYR_BAND");
+    const bool dma_env = getenv("MSORB_PYR_DMA") != nullptr && !getenv("MSORB_PYR_BAND");
     // the band kernels park the source rows of a band of R output rows: at most floor((R - 1) * scale) + 3 of them (<= 12),
     // and decode the 4 taps of a lane out of an 8-byte window (horizontal scale <= 1.25)
     const double sy = (double)src.h / (double)dst.h, sx = (double)src.w / (double)dst.w;
@@ -1559,7 +1561,14 @@ void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_
                         (src.img_stride & 15) == 0 && src.pitch >= 336 && 252.0 * sx + 28.0 <= 336.0;
     const dim3 band_grid((dst.w + 255) / 256, (dst.h + 4 * R - 1) / (4 * R), n_images);
     if (dma_ok) hipLaunchKernelGGL(pyr_resize_dma_kernel<R>, band_grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
-    else if (band_ok) hipLaunchKernelGGL((pyr_resize_band_kernel<R, 12>), band_grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
+    else if (band_ok) {
+        // two waves (12 KB of LDS) per workgroup: beside the other batch's FAST / quadtree / describe, which fill a CU's LDS
+        // to within 5-12 KB, small workgroups find room sooner (1.310 against 1.324 ms per step with 4 waves, 1.336 with 1)
+        static const int bw = getenv("MSORB_PYR_BAND_WAVES") ? atoi(getenv("MSORB_PYR_BAND_WAVES")) : 2;
+        if (bw == 1) hipLaunchKernelGGL((pyr_resize_band_kernel<R, 12, 1>), dim3((dst.w + 255) / 256, (dst.h + R - 1) / R, n_images), dim3(64), 0, s, src, dst, dst_base, tx, ty);
+        else if (bw == 2) hipLaunchKernelGGL((pyr_resize_band_kernel<R, 12, 2>), dim3((dst.w + 255) / 256, (dst.h + 2 * R - 1) / (2 * R), n_images), dim3(128), 0, s, src, dst, dst_base, tx, ty);
+        else hipLaunchKernelGGL((pyr_resize_band_kernel<R, 12, 4>), band_grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
+    }
     else if (aligned && rows_env && n_images >= 16)
         hipLaunchKernelGGL(pyr_resize_rows_kernel<R>, dim3((dst.w + 255) / 256, (dst.h + 4 * R - 1) / (4 * R), n_images), dim3(256),
                            0, s, src, dst, dst_base, tx, ty);

@@ -187,13 +187,13 @@ def test_batch_kernels_full_size(msorb_mod, oracle, name):
 @pytest.mark.parametrize("name", ["kitti", "euroc", "fourseasons", "odd"])
 @pytest.mark.parametrize("kernel", ["dma", "band", "rows"])
 def test_batch_pyramid_kernels_on_padded_rows(msorb_mod, oracle, monkeypatch, name, kernel):
-    """The three batch pyramid kernels (LDS-DMA band kernel = default on 16-byte aligned rows, register band kernel,
+    """The three batch pyramid kernels (register band kernel = default, LDS-DMA band kernel on 16-byte aligned rows,
     row-streaming kernel) on a batch whose rows are padded to a multiple of 64 bytes, as bench.py lays its images out:
     every level of every distinct image is the oracle's cv::resize restatement, bit for bit."""
     import torch
     cfg = CONFIGS[name] if name != "odd" else dict(rows=333, cols=517, nfeatures=700, scale=1.2, nlevels=8, ini_th=20, min_th=7)
-    if kernel == "band":
-        monkeypatch.setenv("MSORB_PYR_BAND", "1")
+    if kernel == "dma":
+        monkeypatch.setenv("MSORB_PYR_DMA", "1")
     elif kernel == "rows":
         monkeypatch.setenv("MSORB_PYR_ROWS", "1")
     ex, ref = _pair(msorb_mod, oracle, cfg)
