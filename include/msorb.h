@@ -180,7 +180,7 @@ void msorb_frame_destroy(msorb_frame* f);
 
 /* Frame members the matcher reads: mvKeysUn, mDescriptors, mvuRight (NULL = all -1), image bounds
  * mnMinX..mnMaxY, mvScaleFactors.  Builds mGrid like Frame::AssignFeaturesToGrid (Frame.cc:385-416,
- * PosInGrid :657-667).  Host arrays. */
+ * PosInGrid :657-667) — on the device, from the uploaded features (frame_grid_kernel).  Host arrays. */
 int msorb_frame_set(msorb_frame* f, const msorb_keypoint* keypoints, int n, const uint8_t* descriptors,
                     const float* u_right, float min_x, float max_x, float min_y, float max_y,
                     const float* scale_factors, int nlevels);
@@ -562,6 +562,83 @@ int msorb_is_in_frustum(int device, const msorb_frustum* f, float viewing_cos_li
                         const float* normal, const float* max_distance, const float* min_distance,
                         uint8_t* track_in_view, float* proj_x, float* proj_y, float* proj_xr, float* track_depth,
                         int* scale_level, float* view_cos, float* elapsed_ms);
+
+/* ------------------------------------------------------------------------------------------------
+ * The tracking front-end of one frame as ONE device-resident chain — BASELINE configs[2] ("extract +
+ * SearchByProjection inside the full Tracking loop"), SURVEY.md 8f-2.  The extractor's outputs do not travel to the host and
+ * back on their way into the matcher: Frame::AssignFeaturesToGrid (src/Frame.cc:385-416, PosInGrid :657-667) runs on the
+ * device keypoints, Frame::isInFrustum writes the window queries of ORBmatcher::SearchByProjection on the device, and one
+ * block comes back for the sequential claim replay.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* msorb_frame_set from DEVICE arrays (e.g. the outputs of msorb_extract_batch): keypoints (cv::KeyPoint layout), 32-byte
+ * descriptors, mvuRight (NULL = all -1), on the frame's device.  The grid is built by a device counting sort that keeps the
+ * ascending keypoint index inside a cell (the reference's push_back order, Frame.cc:405-414). */
+int msorb_frame_set_device(msorb_frame* f, const msorb_keypoint* d_keypoints, int n, const uint8_t* d_descriptors,
+                           const float* d_u_right, float min_x, float max_x, float min_y, float max_y,
+                           const float* scale_factors, int nlevels);
+
+/* Inspection: mGrid of the frame as CSR — cell_begin[64*48 + 1] (cell = ix*48 + iy = mGrid[ix][iy]), cell_idx[*n_assigned]
+ * keypoint indices in the reference's insertion order. */
+int msorb_frame_grid(msorb_frame* f, int* cell_begin, int* cell_idx, int capacity, int* n_assigned);
+
+/* Frame::Frame(imLeft, imRight, ...) up to and including AssignFeaturesToGrid (Frame.cc:119-137, :385-416): msorb_extract_stereo
+ * (same arguments, same host outputs) and, on the same stream before the one synchronisation, the frame handle `f` is filled
+ * from the device-resident left keypoints / descriptors / mvuRight.  min_x .. max_y = mnMinX .. mnMaxY (rectified: 0, cols, 0,
+ * rows).  `h` and `f` must live on one device.  Afterwards `f` serves every msorb_search_* entry like a frame loaded with
+ * msorb_frame_set. */
+int msorb_extract_stereo_frame(msorb_extractor* h, msorb_frame* f, const uint8_t* left, const uint8_t* right, int rows, int cols,
+                               size_t stride_left, size_t stride_right, float mb, float mbf, msorb_keypoint* kps_left,
+                               uint8_t* desc_left, int* n_left, msorb_keypoint* kps_right, uint8_t* desc_right, int* n_right,
+                               int capacity, float* u_right, float* depth, int* n_oob, float min_x, float max_x, float min_y,
+                               float max_y);
+
+/* Tracking::SearchLocalPoints from its second loop on (src/Tracking.cc:3343-3388): Frame::isInFrustum(pMP, viewing_cos_limit)
+ * for the m local map points (Frame.cc:512-571; inputs as msorb_is_in_frustum; visit[i] = the loop reaches the point: not
+ * mnLastFrameSeen == mnId, not isBad(); NULL = all) and ORBmatcher(nnratio).SearchByProjection(F, mvpLocalMapPoints, th,
+ * bFarPoints, thFarPoints) (ORBmatcher.cc:43-142; bad / sparsified / mp_desc / obs / frame_mp as msorb_search_by_projection_mps)
+ * as one chain on the device: one upload, frustum + window queries, window search, one read-back, then the claim replay.
+ * Outputs: the per-point scratch of isInFrustum (any may be NULL) and frame_mp / *nmatches.  Results are identical to
+ * msorb_is_in_frustum followed by msorb_search_by_projection_mps. */
+int msorb_search_local_points(msorb_frame* f, const msorb_frustum* frustum, float viewing_cos_limit, int m, const float* pos_w,
+                              const float* normal, const float* max_distance, const float* min_distance, const uint8_t* visit,
+                              const uint8_t* bad, const uint8_t* sparsified, const uint8_t* mp_desc, const int* obs, int* frame_mp,
+                              float th, int far_points, float th_far_points, float nnratio, uint8_t* track_in_view, float* proj_x,
+                              float* proj_y, float* proj_xr, float* track_depth, int* scale_level, float* view_cos, int* nmatches);
+
+/* msorb_extract_stereo_frame + msorb_search_local_points in ONE call with ONE synchronisation, for a caller that knows the
+ * pose before the images arrive (motion-model or IMU prediction, Tracking.cc:2800-2835 / PredictStateIMU): H2D of the images
+ * and of the map points, extraction of both eyes, ComputeStereoMatches, AssignFeaturesToGrid, isInFrustum, window search and
+ * the read-back are one stream of work; the host only replays the claims.  A new frame holds no map points
+ * (Frame.cc:139), so frame_mp[capacity] is an OUTPUT here (-1 = none).  *rounds (may be NULL) = device rounds of the window
+ * search (1 unless a candidate list was exhausted by earlier claims). */
+int msorb_track_frontend(msorb_extractor* h, msorb_frame* f, const uint8_t* left, const uint8_t* right, int rows, int cols,
+                         size_t stride_left, size_t stride_right, float mb, float mbf, msorb_keypoint* kps_left, uint8_t* desc_left,
+                         int* n_left, msorb_keypoint* kps_right, uint8_t* desc_right, int* n_right, int capacity, float* u_right,
+                         float* depth, int* n_oob, float min_x, float max_x, float min_y, float max_y, const msorb_frustum* frustum,
+                         float viewing_cos_limit, int m, const float* pos_w, const float* normal, const float* max_distance,
+                         const float* min_distance, const uint8_t* visit, const uint8_t* bad, const uint8_t* sparsified,
+                         const uint8_t* mp_desc, const int* obs, int* frame_mp, float th, int far_points, float th_far_points,
+                         float nnratio, uint8_t* track_in_view, float* proj_x, float* proj_y, float* proj_xr, float* track_depth,
+                         int* scale_level, float* view_cos, int* nmatches, int* rounds);
+
+/* The device part of the same chain for a BATCH of frames whose features are device resident (offline throughput and the
+ * measurement of the windowed Hamming rate): frame b's keypoints / descriptors / count are image b*frame_step of an
+ * msorb_extract_batch output (frame_step = 2: the left images of interleaved stereo pairs), d_u_right[b*capacity ..] its
+ * mvuRight (msorb_stereo_matches_batch output; NULL = none).  Per frame: frusta[b] (HOST array) and m map points in the device
+ * arrays d_pos_w [n_frames][3m], d_normal, d_max_distance, d_min_distance [n_frames][m], d_flags (bit 0 visit, bit 1 isBad,
+ * bit 2 mbSparsified), d_mp_desc [n_frames][m][32].  Three launches: grids, frustum + queries, window search against frames
+ * that hold no map points yet.  d_topk[n_frames][m][16]: per map point the 8 best candidates in the reference's scan order —
+ * 8 keypoint indices (-1 = none) then 8 distances; d_track_in_view (may be NULL) [n_frames][m]; d_cell_begin / d_cell_idx (may
+ * be NULL) receive the grids ([n_frames][3073] / [n_frames][capacity]).  elapsed_ms[3] (may be NULL) = device time of the three
+ * launches; *n_pairs (may be NULL; HOST) = Hamming distances evaluated by the window search. */
+int msorb_track_batch(int device, int n_frames, const msorb_keypoint* d_keypoints, const uint8_t* d_descriptors,
+                      const float* d_u_right, const int* d_counts, int frame_step, int capacity, float min_x, float max_x,
+                      float min_y, float max_y, const float* scale_factors, int nlevels, const msorb_frustum* frusta,
+                      float viewing_cos_limit, int m, const float* d_pos_w, const float* d_normal, const float* d_max_distance,
+                      const float* d_min_distance, const uint8_t* d_flags, const uint8_t* d_mp_desc, float th, int far_points,
+                      float th_far_points, int* d_topk, uint8_t* d_track_in_view, int* d_cell_begin, int* d_cell_idx,
+                      float* elapsed_ms, unsigned long long* n_pairs);
 
 #ifdef __cplusplus
 }

@@ -657,6 +657,8 @@ int extractor_last_view(msorb_extractor* h, PyramidView* pyr, LevelScale* sc, fl
     if (n_images) *n_images = h->last_n_images;
     return MSORB_OK;
 }
+int extractor_device(const msorb_extractor* h) { return h->device; }
+int extractor_levels(const msorb_extractor* h) { return h->P.nlevels; }
 }  // namespace msorb
 
 extern "C" {
@@ -994,6 +996,17 @@ int msorb_extract_stereo(msorb_extractor* h, const uint8_t* left, const uint8_t*
                          size_t stride_right, float mb, float mbf, msorb_keypoint* kps_left, uint8_t* desc_left, int* n_left,
                          msorb_keypoint* kps_right, uint8_t* desc_right, int* n_right, int capacity, float* u_right,
                          float* depth, int* n_oob) {
+    return msorb::extract_stereo_sink(h, left, right, rows, cols, stride_left, stride_right, mb, mbf, kps_left, desc_left, n_left,
+                                      kps_right, desc_right, n_right, capacity, u_right, depth, n_oob, nullptr, nullptr);
+}
+}  // extern "C"
+
+// msorb_extract_stereo with a sink for the device outputs (track.hip chains the frame grid and the local-points search
+// behind the stereo association, on the same stream, before the one read-back)
+int msorb::extract_stereo_sink(msorb_extractor* h, const uint8_t* left, const uint8_t* right, int rows, int cols, size_t stride_left,
+                               size_t stride_right, float mb, float mbf, msorb_keypoint* kps_left, uint8_t* desc_left, int* n_left,
+                               msorb_keypoint* kps_right, uint8_t* desc_right, int* n_right, int capacity, float* u_right,
+                               float* depth, int* n_oob, StereoSinkFn sink, void* ctx) {
     if (h && h->pending_batch) { set_error("a submitted batch of this handle has not been waited for"); return MSORB_E_INVALID; }
     if (!h || !n_left || !n_right) return MSORB_E_INVALID;
     *n_left = *n_right = 0;
@@ -1068,6 +1081,10 @@ int msorb_extract_stereo(msorb_extractor* h, const uint8_t* left, const uint8_t*
     launch_stereo_match_batch(b, 1, cap, s);
     uint8_t* o = h->h_out_pin.p;
     HIPCHK(hipMemcpyAsync(o, blk, out_bytes, hipMemcpyDeviceToHost, s));
+    if (sink) {
+        const StereoDeviceOutputs so{d_kps, d_desc, b.A.u_right, reinterpret_cast<const int*>(blk + o_cnt), cap, s};
+        if ((rc = sink(ctx, so))) { (void)hipStreamSynchronize(s); return rc; }
+    }
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     const int nl = reinterpret_cast<const int*>(o + o_cnt)[0], nr = reinterpret_cast<const int*>(o + o_cnt)[1];
@@ -1084,6 +1101,8 @@ int msorb_extract_stereo(msorb_extractor* h, const uint8_t* left, const uint8_t*
     *n_right = nr;
     return MSORB_OK;
 }
+
+extern "C" {
 
 // The same frame with one eye per DEVICE (BASELINE config "left/right images on 2 MI355X, gather over xGMI"): what the two
 // extractor threads of Frame.cc:122-125 and the join + ComputeStereoMatches of Frame.cc:126-137 do, with the left object on

@@ -12,7 +12,7 @@
 #include <string>
 
 #include "../../include/msorb.h"
-#include "logf_restated.h"
+#include "frustum_device.h"
 
 namespace msorb {
 void set_last_error(const std::string& s);
@@ -20,14 +20,6 @@ void set_last_error(const std::string& s);
 using msorb::set_last_error;
 
 namespace {
-
-__device__ __forceinline__ float dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
-    return __fmaf_rn(a0, b0, __fmaf_rn(a1, b1, __fmul_rn(a2, b2)));
-}
-__device__ __forceinline__ int x86_float_to_int(float v) {
-    if (!(v > -2147483904.0f && v < 2147483648.0f)) return INT_MIN;
-    return (int)v;
-}
 
 __global__ __launch_bounds__(256) void frustum_kernel(msorb_frustum F, float cos_limit, int n,
                                                       const float* __restrict__ pos_w, const float* __restrict__ normal,
@@ -39,45 +31,15 @@ __global__ __launch_bounds__(256) void frustum_kernel(msorb_frustum F, float cos
                                                       float* __restrict__ view_cos) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint8_t in_view = 0;
-    float px = -1.0f, py = -1.0f, pxr = 0.0f, depth = 0.0f, vc = 0.0f;
-    int level = 0;
-    const float P0 = pos_w[3 * i], P1 = pos_w[3 * i + 1], P2 = pos_w[3 * i + 2];
-    const float Pc0 = __fadd_rn(dot3(F.Rcw[0], P0, F.Rcw[1], P1, F.Rcw[2], P2), F.tcw[0]);
-    const float Pc1 = __fadd_rn(dot3(F.Rcw[3], P0, F.Rcw[4], P1, F.Rcw[5], P2), F.tcw[1]);
-    const float PcZ = __fadd_rn(dot3(F.Rcw[6], P0, F.Rcw[7], P1, F.Rcw[8], P2), F.tcw[2]);
-    do {
-        if (PcZ < 0.0f) break;
-        const float u = __fadd_rn(__fdiv_rn(__fmul_rn(F.fx, Pc0), PcZ), F.cx);
-        const float v = __fadd_rn(__fdiv_rn(__fmul_rn(F.fy, Pc1), PcZ), F.cy);
-        if (u < F.min_x || u > F.max_x) break;
-        if (v < F.min_y || v > F.max_y) break;
-        px = u;
-        py = v;
-        const float maxD = __fmul_rn(1.2f, max_distance[i]);
-        const float minD = __fmul_rn(0.8f, min_distance[i]);
-        const float PO0 = __fsub_rn(P0, F.Ow[0]), PO1 = __fsub_rn(P1, F.Ow[1]), PO2 = __fsub_rn(P2, F.Ow[2]);
-        const float dist = sqrtf(dot3(PO0, PO0, PO1, PO1, PO2, PO2));
-        if (dist < minD || dist > maxD) break;
-        const float viewCos = __fdiv_rn(dot3(PO0, normal[3 * i], PO1, normal[3 * i + 1], PO2, normal[3 * i + 2]), dist);
-        if (viewCos < cos_limit) break;
-        const float ratio = __fdiv_rn(max_distance[i], dist);
-        int nScale = x86_float_to_int(ceilf(__fdiv_rn(msorb::glibc_logf(ratio), F.log_scale_factor)));
-        if (nScale < 0) nScale = 0;
-        else if (nScale >= F.n_scale_levels) nScale = F.n_scale_levels - 1;
-        in_view = 1;
-        pxr = __fmaf_rn(-F.mbf, __fdiv_rn(1.0f, PcZ), u);
-        depth = sqrtf(dot3(Pc0, Pc0, Pc1, Pc1, PcZ, PcZ));
-        level = nScale;
-        vc = viewCos;
-    } while (0);
-    track_in_view[i] = in_view;
-    proj_x[i] = px;
-    proj_y[i] = py;
-    proj_xr[i] = pxr;
-    track_depth[i] = depth;
-    scale_level[i] = level;
-    view_cos[i] = vc;
+    const msorb::FrustumOut o = msorb::frustum_point(F, cos_limit, pos_w[3 * i], pos_w[3 * i + 1], pos_w[3 * i + 2], normal[3 * i],
+                                                     normal[3 * i + 1], normal[3 * i + 2], max_distance[i], min_distance[i]);
+    track_in_view[i] = o.in_view;
+    proj_x[i] = o.px;
+    proj_y[i] = o.py;
+    proj_xr[i] = o.pxr;
+    track_depth[i] = o.depth;
+    scale_level[i] = o.level;
+    view_cos[i] = o.vc;
 }
 
 }  // namespace

@@ -79,12 +79,23 @@ __device__ __forceinline__ void topk_insert(uint64_t key, int idx, uint64_t k[kT
 
 // One wave per query.  Walks the query's grid window exactly like Frame::GetFeaturesInArea: cells ix
 // (outer) / iy (inner) ascending, cell contents in insertion order; lane c owns window cell c, c+64, ...
+// blockIdx.y = frame of a batch (frame_stride keypoints / q_stride queries apart in every array; 0 / 0 for one frame).
+// kCount: the number of Hamming distances evaluated is added to *n_eval (measurement runs only).
+template <bool kCount>
 __global__ __launch_bounds__(256) void window_topk_kernel(FrameView F, const WinQuery* __restrict__ q,
                                                           const uint8_t* __restrict__ qdesc, int q_begin, int q_end,
-                                                          TopK* __restrict__ out) {
+                                                          TopK* __restrict__ out, int frame_stride, int q_stride,
+                                                          unsigned long long* __restrict__ n_eval) {
     const int qi = q_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (qi >= q_end) return;
+    if (blockIdx.y) {
+        const size_t fo = (size_t)blockIdx.y * frame_stride, qo = (size_t)blockIdx.y * q_stride;
+        F.kp += fo; F.desc += fo * 32; F.cell_idx += fo; F.occupied += fo;
+        F.cell_begin += (size_t)blockIdx.y * (kGridCols * kGridRows + 1);
+        q += qo; qdesc += qo * 32; out += qo;
+    }
+    int n_pairs = 0;
     const WinQuery Q = q[qi];
     uint64_t k[kTopK];
     int id[kTopK];
@@ -130,6 +141,7 @@ __global__ __launch_bounds__(256) void window_topk_kernel(FrameView F, const Win
                     if ((double)__fmul_rn(e2, F.inv_sigma2[kp.octave]) > lim) continue;
                 } else if (!(Q.flags & kQNoUr) && kp.u_right > 0 && fabsf(__fsub_rn(Q.ur, kp.u_right)) > Q.r) continue;  // :92-97
                 const int d = hamming256(a, reinterpret_cast<const uint64_t*>(F.desc + (size_t)idx * 32));
+                if (kCount) n_pairs++;
                 topk_insert(((uint64_t)d << 40) | ((uint64_t)c << 20) | (uint64_t)(j - b), idx, k, id);
             }
         }
@@ -152,6 +164,10 @@ __global__ __launch_bounds__(256) void window_topk_kernel(FrameView F, const Win
         res.dist[r] = owner ? (int)(m >> 40) : 256;
     }
     if (lane == 0) out[qi] = res;
+    if (kCount) {
+        const int tot = wave_sum_i32(n_pairs);
+        if (lane == 0 && tot) atomicAdd(n_eval, (unsigned long long)tot);
+    }
 }
 
 // Explicit candidate lists (CSR): best / second-best in list order.
@@ -611,10 +627,15 @@ void launch_window_list(const FrameView& F, const WinQuery* q, const uint8_t* qd
 }
 
 void launch_window_topk(const FrameView& F, const WinQuery* q, const uint8_t* qdesc, int q_begin, int q_end,
-                        TopK* out, hipStream_t s) {
+                        TopK* out, hipStream_t s, int n_frames, int frame_stride, int q_stride, unsigned long long* n_eval) {
     const int n = q_end - q_begin;
-    if (n <= 0) return;
-    hipLaunchKernelGGL(window_topk_kernel, dim3((n + 3) / 4), dim3(256), 0, s, F, q, qdesc, q_begin, q_end, out);
+    if (n <= 0 || n_frames <= 0) return;
+    if (n_eval)
+        hipLaunchKernelGGL(window_topk_kernel<true>, dim3((n + 3) / 4, n_frames), dim3(256), 0, s, F, q, qdesc, q_begin, q_end, out,
+                           frame_stride, q_stride, n_eval);
+    else
+        hipLaunchKernelGGL(window_topk_kernel<false>, dim3((n + 3) / 4, n_frames), dim3(256), 0, s, F, q, qdesc, q_begin, q_end, out,
+                           frame_stride, q_stride, n_eval);
 }
 void launch_list_top2(const uint8_t* qdesc, const uint8_t* tdesc, const int* cand_begin, const int* cand_idx, int nq,
                       int* bi, int* bd, int* si, int* sd, hipStream_t s) {

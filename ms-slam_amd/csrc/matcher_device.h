@@ -66,8 +66,27 @@ struct StereoBatchArgs {
     int* counts_out;            // optional: the median kernel copies the counts of pair p to [2p], [2p+1] (fused per-frame calls)
 };
 
+// n_frames > 1: a batch, frame b's arrays frame_stride keypoints / q_stride queries behind frame b-1's (grid: 3073 ints);
+// n_eval != nullptr: the kernel adds the number of Hamming distances it evaluated (measurement runs)
 void launch_window_topk(const FrameView& F, const WinQuery* q, const uint8_t* qdesc, int q_begin, int q_end,
-                        TopK* out, hipStream_t s);
+                        TopK* out, hipStream_t s, int n_frames = 1, int frame_stride = 0, int q_stride = 0,
+                        unsigned long long* n_eval = nullptr);
+// msorb_extract_stereo hands its DEVICE outputs to a sink after the last kernel of the frame has been enqueued and before
+// the read-back + synchronisation: whatever the sink enqueues on `stream` completes with the same synchronisation.
+struct StereoDeviceOutputs {
+    const msorb_keypoint* kps_left;  // `capacity` entries
+    const uint8_t* desc_left;
+    const float* u_right;            // mvuRight of the left keypoints
+    const int* n_left;               // device count (negative: capacity exceeded)
+    int capacity;
+    hipStream_t stream;
+};
+using StereoSinkFn = int (*)(void* ctx, const StereoDeviceOutputs& o);
+int extract_stereo_sink(msorb_extractor* h, const uint8_t* left, const uint8_t* right, int rows, int cols, size_t stride_left,
+                        size_t stride_right, float mb, float mbf, msorb_keypoint* kps_left, uint8_t* desc_left, int* n_left,
+                        msorb_keypoint* kps_right, uint8_t* desc_right, int* n_right, int capacity, float* u_right, float* depth,
+                        int* n_oob, StereoSinkFn sink, void* ctx);
+
 void launch_window_list(const FrameView& F, const WinQuery* q, const uint8_t* qdesc, int n, int* count, const int* list_begin,
                         int2* list, bool fill, hipStream_t s);
 void launch_list_top2(const uint8_t* qdesc, const uint8_t* tdesc, const int* cand_begin, const int* cand_idx, int nq,

@@ -23,148 +23,7 @@
 
 using namespace msorb;
 
-namespace msorb {
-void set_last_error(const std::string& s);
-int extractor_last_view(msorb_extractor* h, PyramidView* pyr, LevelScale* sc, float* inv_scale, int* device,
-                        hipStream_t* stream, int* n_images);
-}  // namespace msorb
-
-#define HIPCHK(expr)                                                               \
-    do {                                                                           \
-        hipError_t _e = (expr);                                                    \
-        if (_e != hipSuccess) {                                                    \
-            set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e));     \
-            return MSORB_E_HIP;                                                    \
-        }                                                                          \
-    } while (0)
-
-namespace {
-template <typename T>
-struct DBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    int ensure(size_t count) {
-        if (count <= n) return MSORB_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr; n = 0;
-        HIPCHK(hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)));
-        n = std::max<size_t>(count, 1);
-        return MSORB_OK;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-};
-// pinned host staging: hipMemcpyAsync from / to pageable memory makes the driver stage and synchronise per call
-template <typename T>
-struct HBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    int ensure(size_t count) {
-        if (count <= n) return MSORB_OK;
-        if (p) (void)hipHostFree(p);
-        p = nullptr; n = 0;
-        HIPCHK(hipHostMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault));
-        n = std::max<size_t>(count, 1);
-        return MSORB_OK;
-    }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
-};
-}  // namespace
-
-struct msorb_frame {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    int N = 0, nlevels = 0;
-    float minX = 0, minY = 0, maxX = 0, maxY = 0, gridWInv = 0, gridHInv = 0;
-    std::vector<msorb_keypoint> kps;
-    std::vector<float> u_right, scale;
-    std::vector<int> cell_begin, cell_idx;
-    DBuf<KpLite> d_kp;
-    DBuf<uint8_t> d_desc, d_occ, d_qdesc;
-    DBuf<int> d_cell_begin, d_cell_idx;
-    DBuf<WinQuery> d_q;
-    DBuf<TopK> d_topk;
-    HBuf<uint8_t> h_in;    // queries + query descriptors + occupancy, staged
-    HBuf<TopK> h_topk;
-    FrameView view() const {
-        FrameView v;
-        v.kp = d_kp.p; v.desc = d_desc.p; v.cell_begin = d_cell_begin.p; v.cell_idx = d_cell_idx.p;
-        v.occupied = d_occ.p; v.minX = minX; v.minY = minY; v.gridWInv = gridWInv; v.gridHInv = gridHInv; v.n = N;
-        for (int l = 0; l < MSORB_MAX_LEVELS; l++) v.inv_sigma2[l] = 0.0f;
-        return v;
-    }
-};
-
-namespace {
-
-// Shared replay driver.  accept(q, list, n) is called in query order with the query's exact candidate
-// prefix (>= need entries unless the true candidate set is smaller); it returns the keypoint index it
-// assigned (or -1) and the new occupancy of that keypoint through *new_occ.
-template <typename Accept>
-int run_window_search(msorb_frame* f, const std::vector<WinQuery>& q, const uint8_t* qdesc, std::vector<uint8_t>& occ,
-                      int need, Accept accept) {
-    const int M = (int)q.size();
-    if (M == 0) return MSORB_OK;
-    int rc;
-    if ((rc = f->d_q.ensure(M)) || (rc = f->d_qdesc.ensure((size_t)M * 32)) || (rc = f->d_topk.ensure(M)) ||
-        (rc = f->d_occ.ensure(f->N)))
-        return rc;
-    hipStream_t s = f->stream;
-    const size_t qb = (size_t)M * sizeof(WinQuery), db = (size_t)M * 32;
-    if ((rc = f->h_in.ensure(qb + db + (size_t)f->N + 64)) || (rc = f->h_topk.ensure(M))) return rc;
-    std::memcpy(f->h_in.p, q.data(), qb);
-    std::memcpy(f->h_in.p + qb, qdesc, db);
-    uint8_t* const h_occ = f->h_in.p + qb + db;
-    HIPCHK(hipMemcpyAsync(f->d_q.p, f->h_in.p, qb, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(f->d_qdesc.p, f->h_in.p + qb, db, hipMemcpyHostToDevice, s));
-    TopK* const topk = f->h_topk.p;
-    std::vector<int8_t> diff(f->N, 0);  // occupancy now vs snapshot: +1 claimed since, -1 freed since
-    int q0 = 0, n_rounds = 0;
-    while (q0 < M) {
-        if (f->N) {
-            std::memcpy(h_occ, occ.data(), f->N);  // the previous round's copy has completed (stream synchronised below)
-            HIPCHK(hipMemcpyAsync(f->d_occ.p, h_occ, f->N, hipMemcpyHostToDevice, s));
-        }
-        std::vector<uint8_t> snap = occ;
-        std::fill(diff.begin(), diff.end(), 0);
-        int n_freed = 0;
-        launch_window_topk(f->view(), f->d_q.p, f->d_qdesc.p, q0, M, f->d_topk.p, s);
-        HIPCHK(hipMemcpyAsync(topk + q0, f->d_topk.p + q0, (size_t)(M - q0) * sizeof(TopK), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        int qi = q0;
-        bool resync = false;
-        for (; qi < M; qi++) {
-            if (!(q[qi].flags & kQValid)) continue;
-            const bool skip = q[qi].flags & kQSkipOccupied;
-            if (skip && n_freed > 0 && qi > q0) { resync = true; break; }
-            const TopK& t = topk[qi];
-            int idx[kTopK], dist[kTopK], n = 0, n_dev = 0;
-            for (int k = 0; k < kTopK; k++) {
-                if (t.idx[k] < 0) break;
-                n_dev++;
-                if (skip && diff[t.idx[k]] > 0) continue;
-                idx[n] = t.idx[k]; dist[n] = t.dist[k]; n++;
-            }
-            if (n < need && n < n_dev && n_dev == kTopK && qi > q0) { resync = true; break; }
-            int new_occ = 0;
-            const int assigned = accept(qi, idx, dist, n, &new_occ);
-            if (assigned >= 0) {
-                occ[assigned] = (uint8_t)new_occ;
-                const int8_t d = (int8_t)((int)occ[assigned] - (int)snap[assigned]);
-                if (diff[assigned] < 0) n_freed--;
-                diff[assigned] = d;
-                if (d < 0) n_freed++;
-            }
-        }
-        n_rounds++;
-        if (!resync) break;
-        q0 = qi;
-    }
-    static const bool dbg_rounds = getenv("MSORB_DEBUG_ROUNDS") != nullptr;
-    if (dbg_rounds) fprintf(stderr, "window search: %d queries, %d device rounds\n", M, n_rounds);
-    return MSORB_OK;
-}
-
-}  // namespace
+#include "matcher_host.h"
 
 extern "C" {
 
@@ -189,7 +48,8 @@ void msorb_frame_destroy(msorb_frame* f) {
     (void)hipSetDevice(f->device);
     if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
     f->d_kp.release(); f->d_desc.release(); f->d_occ.release(); f->d_qdesc.release(); f->d_cell_begin.release();
-    f->d_cell_idx.release(); f->d_q.release(); f->d_topk.release(); f->h_in.release(); f->h_topk.release();
+    f->d_cell_idx.release(); f->d_q.release(); f->d_topk.release(); f->h_in.release(); f->h_topk.release(); f->d_n.release(); f->d_stage.release();
+    frame_track_release(f);
     delete f;
 }
 
@@ -199,44 +59,28 @@ int msorb_frame_set(msorb_frame* f, const msorb_keypoint* kps, int n, const uint
         !(max_x > min_x) || !(max_y > min_y))
         return MSORB_E_INVALID;
     HIPCHK(hipSetDevice(f->device));
-    f->N = n; f->nlevels = nlevels;
-    f->minX = min_x; f->maxX = max_x; f->minY = min_y; f->maxY = max_y;
-    f->gridWInv = static_cast<float>(kGridCols) / (max_x - min_x);  // Frame.cc:147-148
-    f->gridHInv = static_cast<float>(kGridRows) / (max_y - min_y);
+    f->N = n;
     f->kps.assign(kps, kps + n);
     if (u_right) f->u_right.assign(u_right, u_right + n); else f->u_right.assign(n, -1.0f);
-    f->scale.assign(scale_factors, scale_factors + nlevels);
-    // AssignFeaturesToGrid (Frame.cc:385-416): counting sort by cell keeps ascending index inside a cell
-    const int ncell = kGridCols * kGridRows;
-    std::vector<int> cell(n, -1);
-    f->cell_begin.assign(ncell + 1, 0);
-    for (int i = 0; i < n; i++) {
-        const int px = (int)std::round((kps[i].x - min_x) * f->gridWInv);  // PosInGrid, Frame.cc:657-667
-        const int py = (int)std::round((kps[i].y - min_y) * f->gridHInv);
-        if (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) continue;
-        cell[i] = px * kGridRows + py;
-        f->cell_begin[cell[i] + 1]++;
-    }
-    for (int c = 0; c < ncell; c++) f->cell_begin[c + 1] += f->cell_begin[c];
-    f->cell_idx.assign(f->cell_begin[ncell], 0);
-    std::vector<int> cur(f->cell_begin.begin(), f->cell_begin.end() - 1);
-    for (int i = 0; i < n; i++)
-        if (cell[i] >= 0) f->cell_idx[cur[cell[i]]++] = i;
-    std::vector<KpLite> lite(n);
-    for (int i = 0; i < n; i++) lite[i] = KpLite{kps[i].x, kps[i].y, f->u_right[i], kps[i].octave};
+    // AssignFeaturesToGrid (Frame.cc:385-416) runs on the device (frame_grid_kernel, track.hip): the features are staged as
+    // they are — cv::KeyPoint records, descriptor rows, mvuRight — and the kernel derives the train arrays and the grid
     int rc;
-    if ((rc = f->d_kp.ensure(n)) || (rc = f->d_desc.ensure((size_t)n * 32)) || (rc = f->d_cell_begin.ensure(ncell + 1)) ||
-        (rc = f->d_cell_idx.ensure(f->cell_idx.size())) || (rc = f->d_occ.ensure(n)))
-        return rc;
+    const size_t kb = (size_t)n * sizeof(msorb_keypoint), db = (size_t)n * 32, ub = u_right ? (size_t)n * sizeof(float) : 0;
+    const size_t o_desc = (kb + 63) & ~(size_t)63, o_ur = o_desc + ((db + 63) & ~(size_t)63), total = o_ur + ub + 64;
+    if ((rc = f->h_in.ensure(total)) || (rc = f->d_stage.ensure(total))) return rc;
     hipStream_t s = f->stream;
     if (n) {
-        HIPCHK(hipMemcpyAsync(f->d_kp.p, lite.data(), (size_t)n * sizeof(KpLite), hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(f->d_desc.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
-        if (!f->cell_idx.empty())
-            HIPCHK(hipMemcpyAsync(f->d_cell_idx.p, f->cell_idx.data(), f->cell_idx.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        std::memcpy(f->h_in.p, kps, kb);
+        std::memcpy(f->h_in.p + o_desc, desc, db);
+        if (u_right) std::memcpy(f->h_in.p + o_ur, u_right, ub);
+        HIPCHK(hipMemcpyAsync(f->d_stage.p, f->h_in.p, o_ur + ub, hipMemcpyHostToDevice, s));
     }
-    HIPCHK(hipMemcpyAsync(f->d_cell_begin.p, f->cell_begin.data(), (size_t)(ncell + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    if ((rc = enqueue_frame_from_device(f, s, reinterpret_cast<const msorb_keypoint*>(f->d_stage.p), f->d_stage.p + o_desc,
+                                        u_right ? reinterpret_cast<const float*>(f->d_stage.p + o_ur) : nullptr, nullptr, n, n, min_x,
+                                        max_x, min_y, max_y, scale_factors, nlevels)))
+        return rc;
     HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
     return MSORB_OK;
 }
 
@@ -245,6 +89,11 @@ int msorb_frame_features_in_area(const msorb_frame* f, float x, float y, float r
     if (!f || !n_out) return MSORB_E_INVALID;
     int n = 0;
     *n_out = 0;
+    if (!f->host_grid_valid) {  // grid built on the device (msorb_frame_set_device / msorb_extract_stereo_frame): fetch it once
+        HIPCHK(hipSetDevice(f->device));
+        const int rc = frame_host_grid(const_cast<msorb_frame*>(f));
+        if (rc) return rc;
+    }
     const int minCX = std::max(0, (int)std::floor((x - f->minX - r) * f->gridWInv));
     if (minCX >= kGridCols) return MSORB_OK;
     const int maxCX = std::min(kGridCols - 1, (int)std::ceil((x - f->minX + r) * f->gridWInv));
@@ -325,7 +174,7 @@ int msorb_search_by_projection_mps(msorb_frame* f, int M, const uint8_t* track_i
         }
         return -1;
     };
-    const int rc = run_window_search(f, q, mp_desc, occ, 2, accept);
+    const int rc = run_window_search(f, M, q.data(), nullptr, mp_desc, occ, 2, accept);
     *nmatches = nm;
     return rc;
 }
@@ -386,7 +235,7 @@ int search_projected(msorb_frame* f, int NL, const uint8_t* valid, const float* 
         }
         return -1;
     };
-    const int rc = run_window_search(f, q, mp_desc, occ, 1, accept);
+    const int rc = run_window_search(f, NL, q.data(), nullptr, mp_desc, occ, 1, accept);
     if (rc) return rc;
     if (check_orientation) {  // ORBmatcher.cc:2129-2149 / :2253-2272
         int sizes[kHistoLength], ind[3];

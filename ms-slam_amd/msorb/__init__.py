@@ -1012,3 +1012,178 @@ def stereo_matches_split(ex_left, ex_right, counts_left, d_kps_left, d_desc_left
 
 EXPORTS = EXPORTS + ("msorb_fuse_search", "msorb_search_by_projection_kf", "msorb_search_by_projection_sim3",
                      "msorb_extract_batch_submit", "msorb_extract_batch_wait")
+
+
+# ------------------------------------------------------------------------------------------------
+# The tracking front-end as one device-resident chain (include/msorb.h, last section; csrc/track.hip)
+# ------------------------------------------------------------------------------------------------
+EXPORTS = EXPORTS + ("msorb_frame_set_device", "msorb_frame_grid", "msorb_extract_stereo_frame", "msorb_search_local_points",
+                     "msorb_track_frontend", "msorb_track_batch")
+GRID_COLS, GRID_ROWS = 64, 48   # FRAME_GRID_COLS / FRAME_GRID_ROWS, Frame.h:44-45
+
+
+def _empty_frame(device=0):
+    f = Frame.__new__(Frame)
+    f.L = _mlib()
+    h = C.c_void_p()
+    _check(f.L.msorb_frame_create(device, C.byref(h)), "msorb_frame_create")
+    f.h = h
+    f.n = 0
+    f.kps = np.zeros(0, KP_DTYPE)
+    f.desc = np.zeros((0, 32), np.uint8)
+    return f
+
+
+def frame_from_device(d_kps, n, d_desc, d_u_right, bounds, scale_factors, device=0):
+    """msorb_frame_set_device: d_kps torch.uint8 [>= n, 28], d_desc torch.uint8 [>= n, 32], d_u_right torch.float32 or None."""
+    f = _empty_frame(device)
+    sf = _c(scale_factors, np.float32)
+    f.L.msorb_frame_set_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                           C.c_float, C.c_void_p, C.c_int]
+    _check(f.L.msorb_frame_set_device(f.h, d_kps.data_ptr(), n, d_desc.data_ptr(), None if d_u_right is None else d_u_right.data_ptr(),
+                                      bounds[0], bounds[1], bounds[2], bounds[3], _np_ptr(sf), len(sf)), "msorb_frame_set_device")
+    f.n = n
+    f.kps = np.frombuffer(d_kps[:n].cpu().numpy().tobytes(), KP_DTYPE).copy()
+    f.desc = d_desc[:n].cpu().numpy().copy()
+    return f
+
+
+def frame_grid(frame):
+    """msorb_frame_grid -> (cell_begin[64*48+1], cell_idx): mGrid as CSR, cell = ix*48 + iy, insertion order inside a cell."""
+    cb = np.zeros(GRID_COLS * GRID_ROWS + 1, np.int32)
+    ci = np.zeros(max(frame.n, 1), np.int32)
+    na = C.c_int()
+    frame.L.msorb_frame_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    _check(frame.L.msorb_frame_grid(frame.h, _np_ptr(cb), _np_ptr(ci), len(ci), C.byref(na)), "msorb_frame_grid")
+    return cb, ci[:na.value].copy()
+
+
+_LP_KEYS = ("pos_w", "normal", "max_distance", "min_distance", "visit", "bad", "sparsified", "desc", "obs")
+
+
+def _lp_arrays(mp):
+    m = len(mp["max_distance"])
+    visit = mp.get("visit")
+    arrs = [_c(mp["pos_w"], np.float32).reshape(-1), _c(mp["normal"], np.float32).reshape(-1), _c(mp["max_distance"], np.float32),
+            _c(mp["min_distance"], np.float32), None if visit is None else _c(visit, np.uint8), _c(mp["bad"], np.uint8),
+            _c(mp["sparsified"], np.uint8), _c(mp["desc"], np.uint8), _c(mp["obs"], np.int32)]
+    return m, arrs
+
+
+def _lp_outputs(m):
+    cap = max(m, 1)
+    return dict(track_in_view=np.zeros(cap, np.uint8), proj_x=np.zeros(cap, np.float32), proj_y=np.zeros(cap, np.float32),
+                proj_xr=np.zeros(cap, np.float32), track_depth=np.zeros(cap, np.float32), level=np.zeros(cap, np.int32),
+                view_cos=np.zeros(cap, np.float32))
+
+
+_LP_OUT_ORDER = ("track_in_view", "proj_x", "proj_y", "proj_xr", "track_depth", "level", "view_cos")
+
+
+def search_local_points(frame, frustum, mp, frame_mp, th, bFarPoints=False, thFarPoints=50.0, nnratio=0.8,
+                        viewing_cos_limit=0.5):
+    """msorb_search_local_points: Tracking::SearchLocalPoints' isInFrustum loop + SearchByProjection as one device chain.
+    mp: dict(pos_w, normal, max_distance, min_distance, [visit], bad, sparsified, desc, obs).  frame_mp updated in place.
+    -> (nmatches, dict of the isInFrustum scratch)."""
+    L = frame.L
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    L.msorb_search_local_points.argtypes = [vp, vp, cf, ci] + [vp] * 10 + [cf, ci, cf, cf] + [vp] * 7 + [C.POINTER(ci)]
+    m, arrs = _lp_arrays(mp)
+    out = _lp_outputs(m)
+    assert frame_mp.dtype == np.int32 and frame_mp.flags.c_contiguous
+    nm = C.c_int()
+    _check(L.msorb_search_local_points(frame.h, C.addressof(frustum), viewing_cos_limit, m,
+                                       *[None if a is None else _np_ptr(a) for a in arrs], _np_ptr(frame_mp), th, int(bFarPoints),
+                                       thFarPoints, nnratio, *[_np_ptr(out[k]) for k in _LP_OUT_ORDER], C.byref(nm)),
+           "msorb_search_local_points")
+    return nm.value, {k: v[:m] for k, v in out.items()}
+
+
+def _stereo_frame_call(ex, fn_name, left, right, mb, mbf, bounds, extra_argtypes, extra_args, device):
+    left, right = np.ascontiguousarray(left, np.uint8), np.ascontiguousarray(right, np.uint8)
+    assert left.shape == right.shape and left.ndim == 2
+    rows, cols = left.shape
+    cap = ex.capacity
+    kl, kr = np.zeros(cap, KP_DTYPE), np.zeros(cap, KP_DTYPE)
+    dl, dr = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
+    ur, dp = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+    nl, nr, oob = C.c_int(0), C.c_int(0), C.c_int(0)
+    f = _empty_frame(device)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    fn = getattr(ex.L, fn_name)
+    fn.argtypes = [vp, vp, vp, vp, ci, ci, C.c_size_t, C.c_size_t, cf, cf, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, cf, cf, cf,
+                   cf] + extra_argtypes
+    _check(fn(ex.h, f.h, _np_ptr(left), _np_ptr(right), rows, cols, cols, cols, mb, mbf, _np_ptr(kl), _np_ptr(dl), C.byref(nl),
+              _np_ptr(kr), _np_ptr(dr), C.byref(nr), cap, _np_ptr(ur), _np_ptr(dp), C.byref(oob), bounds[0], bounds[1], bounds[2],
+              bounds[3], *extra_args), fn_name)
+    a, b = nl.value, nr.value
+    f.n = a
+    f.kps = kl[:a].copy()
+    f.desc = dl[:a].copy()
+    return f, (kl[:a].copy(), dl[:a].copy(), kr[:b].copy(), dr[:b].copy(), ur[:a].copy(), dp[:a].copy(), oob.value)
+
+
+def extract_stereo_frame(ex, left, right, mb, mbf, bounds=None, device=0):
+    """msorb_extract_stereo_frame -> (Frame, (kps_left, desc_left, kps_right, desc_right, mvuRight, mvDepth, n_oob))."""
+    if bounds is None:
+        bounds = (0.0, float(left.shape[1]), 0.0, float(left.shape[0]))
+    return _stereo_frame_call(ex, "msorb_extract_stereo_frame", left, right, mb, mbf, bounds, [], [], device)
+
+
+def track_frontend(ex, left, right, mb, mbf, frustum, mp, th, bFarPoints=False, thFarPoints=50.0, nnratio=0.8,
+                   viewing_cos_limit=0.5, bounds=None, device=0):
+    """msorb_track_frontend -> (Frame, stereo outputs as extract_stereo_frame, frame_mp[n_left], nmatches, scratch dict, rounds)."""
+    if bounds is None:
+        bounds = (0.0, float(left.shape[1]), 0.0, float(left.shape[0]))
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    m, arrs = _lp_arrays(mp)
+    out = _lp_outputs(m)
+    frame_mp = np.full(ex.capacity, -1, np.int32)
+    nm, rounds = C.c_int(), C.c_int()
+    extra_t = [vp, cf, ci] + [vp] * 10 + [cf, ci, cf, cf] + [vp] * 7 + [C.POINTER(ci), C.POINTER(ci)]
+    extra = [C.addressof(frustum), viewing_cos_limit, m] + [None if a is None else _np_ptr(a) for a in arrs] + \
+        [_np_ptr(frame_mp), th, int(bFarPoints), thFarPoints, nnratio] + [_np_ptr(out[k]) for k in _LP_OUT_ORDER] + \
+        [C.byref(nm), C.byref(rounds)]
+    f, st = _stereo_frame_call(ex, "msorb_track_frontend", left, right, mb, mbf, bounds, extra_t, extra, device)
+    return f, st, frame_mp[:f.n].copy(), nm.value, {k: v[:m] for k, v in out.items()}, rounds.value
+
+
+def track_batch(d_kps, d_desc, d_u_right, counts, frame_step, bounds, scale_factors, frusta, d_mp, th, bFarPoints=False,
+                thFarPoints=50.0, viewing_cos_limit=0.5, want_grid=False, count_pairs=False, device=0):
+    """msorb_track_batch.  d_kps / d_desc: extract_batch outputs; counts: their host counts (all images); frame b = image
+    b*frame_step; d_u_right torch.float32 [n_frames, cap] or None; frusta: list of Frustum; d_mp: dict of CUDA tensors pos_w
+    [B, m, 3], normal [B, m, 3], max_distance [B, m], min_distance [B, m], flags uint8 [B, m], desc uint8 [B, m, 32].
+    -> dict(topk_idx [B, m, 8], topk_dist [B, m, 8], in_view [B, m], ms (grid, frustum+queries, window search), n_pairs,
+            [cell_begin, cell_idx])  (torch CUDA tensors)."""
+    import torch
+    lb = lib()
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    lb.msorb_track_batch.argtypes = [ci, ci, vp, vp, vp, vp, ci, ci, cf, cf, cf, cf, vp, ci, vp, cf, ci, vp, vp, vp, vp, vp, vp, cf,
+                                     ci, cf, vp, vp, vp, vp, vp, vp]
+    B = len(frusta)
+    cap = d_kps.shape[1]
+    dev = d_kps.device
+    m = int(d_mp["max_distance"].shape[1]) if B else 0
+    sf = _c(scale_factors, np.float32)
+    d_counts = torch.from_numpy(np.ascontiguousarray(counts, np.int32)).to(dev)
+    fr = (Frustum * max(B, 1))(*frusta)
+    d_topk = torch.empty((B, m, 16), dtype=torch.int32, device=dev)
+    d_inview = torch.empty((B, m), dtype=torch.uint8, device=dev)
+    d_cb = torch.empty((B, GRID_COLS * GRID_ROWS + 1), dtype=torch.int32, device=dev) if want_grid else None
+    d_ci = torch.full((B, cap), -1, dtype=torch.int32, device=dev) if want_grid else None
+    ms = (C.c_float * 3)()
+    npairs = C.c_ulonglong(0)
+    for k in ("pos_w", "normal", "max_distance", "min_distance", "flags", "desc"):
+        assert d_mp[k].is_contiguous()
+    torch.cuda.synchronize(dev)
+    _check(lb.msorb_track_batch(device, B, d_kps.data_ptr(), d_desc.data_ptr(), None if d_u_right is None else d_u_right.data_ptr(),
+                                d_counts.data_ptr(), frame_step, cap, bounds[0], bounds[1], bounds[2], bounds[3], _np_ptr(sf), len(sf),
+                                C.addressof(fr), viewing_cos_limit, m, d_mp["pos_w"].data_ptr(), d_mp["normal"].data_ptr(),
+                                d_mp["max_distance"].data_ptr(), d_mp["min_distance"].data_ptr(), d_mp["flags"].data_ptr(),
+                                d_mp["desc"].data_ptr(), th, int(bFarPoints), thFarPoints, d_topk.data_ptr(), d_inview.data_ptr(),
+                                None if d_cb is None else d_cb.data_ptr(), None if d_ci is None else d_ci.data_ptr(), C.addressof(ms),
+                                C.addressof(npairs) if count_pairs else None), "msorb_track_batch")
+    r = dict(topk_idx=d_topk[:, :, :8], topk_dist=d_topk[:, :, 8:], in_view=d_inview, ms=tuple(ms), n_pairs=npairs.value)
+    if want_grid:
+        r["cell_begin"], r["cell_idx"] = d_cb, d_ci
+    return r

@@ -144,6 +144,20 @@ void orc_frame_cells(void* fp, int* cx, int* cy) {
     }
 }
 
+// mGrid after Frame::AssignFeaturesToGrid (Frame.cc:385-416) as CSR: cell = ix * FRAME_GRID_ROWS + iy = mGrid[ix][iy], the
+// cell's vector in push_back order.  cell_begin has GRID_COLS * GRID_ROWS + 1 entries; returns the number of assigned keypoints.
+int orc_frame_grid_csr(void* fp, int* cell_begin, int* cell_idx) {
+    FrameSoA* f = (FrameSoA*)fp;
+    int n = 0;
+    for (int ix = 0; ix < orc::GRID_COLS; ix++)
+        for (int iy = 0; iy < orc::GRID_ROWS; iy++) {
+            cell_begin[ix * orc::GRID_ROWS + iy] = n;
+            for (int i : f->grid[ix][iy]) cell_idx[n++] = i;
+        }
+    cell_begin[orc::GRID_COLS * orc::GRID_ROWS] = n;
+    return n;
+}
+
 // ORBmatcher::SearchByProjection(Frame&, vector<MapPoint>, th, bFarPoints, thFarPoints), ORBmatcher.cc:43-142
 // (left-eye / rectified part).  Map point table of M entries, visited in index order:
 //   track_in_view  mbTrackInView          bad          isBad()              sparsified  mbSparsified

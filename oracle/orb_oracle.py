@@ -204,6 +204,7 @@ class OracleFrame:
         self.desc = _c(descriptors, np.uint8)
         self.n = len(self.kps)
         ur = None if u_right is None else _c(u_right, np.float32)
+        self.u_right = np.full(self.n, -1.0, np.float32) if ur is None else ur
         sf = _c(scale_factors, np.float32)
         self.h = self.L.orc_frame_create(_ptr(self.kps), self.n, _ptr(self.desc), None if ur is None else _ptr(ur),
                                          bounds[0], bounds[1], bounds[2], bounds[3], _ptr(sf), len(sf))
@@ -212,6 +213,15 @@ class OracleFrame:
         if getattr(self, "h", None):
             self.L.orc_frame_destroy(self.h)
             self.h = None
+
+    def grid_csr(self):
+        """mGrid (Frame.cc:385-416) as CSR: (cell_begin[64*48+1], cell_idx), cell = ix*48 + iy, push_back order."""
+        L = _mlib()
+        cb = np.zeros(64 * 48 + 1, np.int32)
+        ci = np.zeros(max(self.n, 1), np.int32)
+        L.orc_frame_grid_csr.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        n = L.orc_frame_grid_csr(self.h, cb.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p))
+        return cb, ci[:n].copy()
 
     def GetFeaturesInArea(self, x, y, r, minLevel=-1, maxLevel=-1):
         out = np.zeros(max(self.n, 1), np.int32)

@@ -1,0 +1,242 @@
+"""GPU parity tests of the tracking front-end chain (csrc/track.hip; BASELINE configs[2]): the device
+AssignFeaturesToGrid, the fused isInFrustum + SearchByProjection entry, the one-call frame front-end and its batched
+form, all through the C ABI against the CPU oracle.  Index work: everything must be identical."""
+import numpy as np
+import pytest
+
+from msorb import synth
+import frustum_cases as fc
+import matcher_cases as mc
+import track_cases as tc
+
+pytestmark = pytest.mark.gpu
+
+MBF, MB = mc.KITTI_BF, mc.KITTI_BF / mc.KITTI_FX
+BOUNDS = (0.0, 1241.0, 0.0, 376.0)
+
+
+def _frustum(msorb_mod, R, t, Ow, nlevels=8):
+    c = fc.KITTI_CAM
+    return msorb_mod.Frustum.make(R, t, Ow, c["fx"], c["fy"], c["cx"], c["cy"], c["bounds"], c["mbf"], float(np.log(np.float32(1.2))), nlevels)
+
+
+def _near_identity_pose(seed):
+    """A pose close to the identity so that most of a synthetic local map lands inside the image."""
+    rng = np.random.default_rng(seed)
+    w = rng.normal(scale=0.02, size=3)
+    th = np.linalg.norm(w) + 1e-12
+    k = w / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = (np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K).astype(np.float32)
+    t = rng.normal(scale=0.3, size=3).astype(np.float32)
+    Ow = (-(R.T.astype(np.float64) @ t.astype(np.float64))).astype(np.float32)
+    return R, t, Ow
+
+
+@pytest.fixture(scope="module")
+def kitti_frame(msorb_mod, oracle):
+    cfg = synth.KITTI
+    L, R = synth.stereo_pair(21, cfg["rows"], cfg["cols"])
+    ex = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7)
+    kl, dl, kr, dr, ur, dp, oob = ex.extract_stereo(L, R, MB, MBF)
+    return dict(L=L, R=R, ex=ex, kl=kl, dl=dl, kr=kr, dr=dr, ur=ur, dp=dp, oob=oob, scale=ex.GetScaleFactors())
+
+
+def _grid_equal(msorb_mod, oracle, kps, desc, ur, bounds, scale):
+    f = msorb_mod.Frame(kps, desc, ur, bounds, scale)
+    rf = oracle.OracleFrame(kps, desc, ur, bounds, scale)
+    cb, ci = msorb_mod.frame_grid(f)
+    rcb, rci = rf.grid_csr()
+    assert np.array_equal(cb, rcb), "cell_begin differs"
+    assert np.array_equal(ci, rci), "cell contents / order differ"
+    return f, rf, cb
+
+
+def test_device_grid_matches_oracle_on_extracted_frames(msorb_mod, oracle, kitti_frame):
+    s = kitti_frame
+    _, _, cb = _grid_equal(msorb_mod, oracle, s["kl"], s["dl"], s["ur"], BOUNDS, s["scale"])
+    assert cb[-1] == len(s["kl"]) > 1500
+    # other image bounds (undistorted fisheye-style bounds are not the image size, Frame.cc:144-160)
+    _grid_equal(msorb_mod, oracle, s["kl"], s["dl"], None, (-13.5, 1260.25, -7.75, 390.0), s["scale"])
+    _grid_equal(msorb_mod, oracle, s["kr"], s["dr"], None, BOUNDS, s["scale"])
+
+
+@pytest.mark.parametrize("seed,n", [(1, 0), (2, 1), (3, 64), (4, 2000), (5, 5000), (6, 16000)])
+def test_device_grid_random_keypoints(msorb_mod, oracle, seed, n):
+    """Keypoints anywhere, including outside the bounds, exactly on cell borders (x.5 products), and piled up in a few cells
+    (long runs exercise the in-cell order restoration)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    kps = np.zeros(n, msorb_mod.KP_DTYPE)
+    x = rng.uniform(-40, 1290, n)
+    y = rng.uniform(-30, 410, n)
+    pile = rng.random(n) < 0.3
+    x[pile] = rng.choice([100.0, 600.5, 1239.0], int(pile.sum())) + rng.uniform(-3, 3, int(pile.sum()))
+    y[pile] = rng.choice([50.0, 200.0, 370.0], int(pile.sum())) + rng.uniform(-2, 2, int(pile.sum()))
+    on_border = rng.random(n) < 0.2   # (x - min) * 64 / 1241 == k + 0.5 -> round() half away from zero decides the cell
+    kb = rng.integers(0, 66, n)
+    x[on_border] = ((kb[on_border] + 0.5) * 1241.0 / 64.0)
+    kps["x"], kps["y"] = x.astype(np.float32), y.astype(np.float32)
+    kps["octave"] = rng.integers(0, 8, n)
+    kps["size"], kps["angle"] = 31.0, rng.uniform(0, 360, n)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ur = np.where(rng.random(n) < 0.5, x - rng.uniform(1, 40, n), -1).astype(np.float32)
+    scale = (1.2 ** np.arange(8)).astype(np.float32)
+    f, rf, cb = _grid_equal(msorb_mod, oracle, kps, desc, ur, BOUNDS, scale)
+    for _ in range(40):   # the host walk reads the grid it fetched from the device
+        qx, qy, r = rng.uniform(-50, 1300), rng.uniform(-50, 420), rng.uniform(1, 60)
+        assert np.array_equal(f.GetFeaturesInArea(qx, qy, r, 0, 3), rf.GetFeaturesInArea(qx, qy, r, 0, 3))
+
+
+def test_frame_from_device_arrays(msorb_mod, oracle, kitti_frame):
+    import torch
+    s = kitti_frame
+    n = len(s["kl"])
+    d_kps = torch.from_numpy(np.frombuffer(s["kl"].tobytes(), np.uint8).reshape(n, 28).copy()).cuda()
+    d_desc = torch.from_numpy(s["dl"].copy()).cuda()
+    d_ur = torch.from_numpy(s["ur"].copy()).cuda()
+    f = msorb_mod.frame_from_device(d_kps, n, d_desc, d_ur, BOUNDS, s["scale"])
+    rf = oracle.OracleFrame(s["kl"], s["dl"], s["ur"], BOUNDS, s["scale"])
+    cb, ci = msorb_mod.frame_grid(f)
+    rcb, rci = rf.grid_csr()
+    assert np.array_equal(cb, rcb) and np.array_equal(ci, rci)
+    rng = np.random.Generator(np.random.PCG64(9))
+    mp = mc.map_point_table(rng, s["kl"], s["dl"], s["ur"], s["scale"], 3000)
+    a, b = np.full(n, -1, np.int32), np.full(n, -1, np.int32)
+    assert f.SearchByProjection_mps(mp, a, 3.0) == rf.SearchByProjection_mps(mp, b, 3.0) > 300
+    assert np.array_equal(a, b)
+
+
+def test_extract_stereo_frame_equals_separate_calls(msorb_mod, oracle, kitti_frame):
+    s = kitti_frame
+    f, (kl, dl, kr, dr, ur, dp, oob) = msorb_mod.extract_stereo_frame(s["ex"], s["L"], s["R"], MB, MBF)
+    for a, b in ((kl, s["kl"]), (kr, s["kr"])):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    assert np.array_equal(dl, s["dl"]) and np.array_equal(dr, s["dr"]) and oob == s["oob"]
+    assert np.array_equal(ur.view(np.uint32), s["ur"].view(np.uint32)) and np.array_equal(dp.view(np.uint32), s["dp"].view(np.uint32))
+    rf = oracle.OracleFrame(kl, dl, ur, BOUNDS, s["scale"])
+    cb, ci = msorb_mod.frame_grid(f)
+    rcb, rci = rf.grid_csr()
+    assert np.array_equal(cb, rcb) and np.array_equal(ci, rci)
+    # the frame serves the other searches like one loaded from host arrays
+    rng = np.random.Generator(np.random.PCG64(3))
+    last = mc.last_frame_table(rng, kl, dl, ur, s["scale"], 1800)
+    a, b = np.full(len(kl), -1, np.int32), np.full(len(kl), -1, np.int32)
+    assert f.SearchByProjection_frames(last, a, 7.0) == rf.SearchByProjection_frames(last, b, 7.0) > 200
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("seed,M,th,far,pre", [(1, 4096, 1.0, False, 0.0), (2, 4096, 3.0, True, 0.2), (3, 8000, 5.0, False, 0.5),
+                                               (4, 700, 1.0, True, 0.0), (5, 0, 1.0, False, 0.0)])
+def test_search_local_points_vs_oracle(msorb_mod, oracle, kitti_frame, seed, M, th, far, pre):
+    s = kitti_frame
+    n = len(s["kl"])
+    R, t, Ow = _near_identity_pose(seed)
+    fr = _frustum(msorb_mod, R, t, Ow)
+    mp = tc.local_map(seed, s["kl"], s["dl"], s["ur"], s["dp"], R, t, Ow, s["scale"], M)
+    f = msorb_mod.Frame(s["kl"], s["dl"], s["ur"], BOUNDS, s["scale"])
+    rf = oracle.OracleFrame(s["kl"], s["dl"], s["ur"], BOUNDS, s["scale"])
+    rng = np.random.Generator(np.random.PCG64(100 + seed))
+    init = np.where(rng.random(n) < pre, rng.integers(0, max(M, 1), n), -1).astype(np.int32) if M else np.full(n, -1, np.int32)
+    a, b = init.copy(), init.copy()
+    nm, out = msorb_mod.search_local_points(f, fr, mp, a, th, far, 40.0)
+    rnm, r, visit = tc.oracle_local_points(oracle, rf, fr, mp, b, th, far, 40.0)
+    assert nm == rnm
+    assert np.array_equal(a, b)
+    if M:
+        assert nm > M // 20
+        assert np.array_equal(out["track_in_view"].astype(bool), r["track_in_view"].astype(bool) & visit)
+        v = visit & r["track_in_view"].astype(bool)
+        for k in ("proj_x", "proj_y", "proj_xr", "track_depth", "view_cos"):
+            assert np.array_equal(out[k][v].view(np.uint32), r[k][v].view(np.uint32)), k
+        assert np.array_equal(out["level"][v], r["level"][v])
+    # identical to the two separate entries
+    r2 = msorb_mod.is_in_frustum(fr, mp["pos_w"], mp["normal"], mp["max_distance"], mp["min_distance"])
+    tab = dict(track_in_view=(r2["track_in_view"].astype(bool) & visit).astype(np.uint8), bad=mp["bad"], sparsified=mp["sparsified"],
+               proj_x=r2["proj_x"], proj_y=r2["proj_y"], proj_xr=r2["proj_xr"], track_depth=r2["track_depth"], level=r2["level"],
+               view_cos=r2["view_cos"], desc=mp["desc"], obs=mp["obs"])
+    c = init.copy()
+    assert f.SearchByProjection_mps(tab, c, th, far, 40.0) == nm and np.array_equal(c, a)
+
+
+@pytest.mark.parametrize("seed,M,th", [(11, 4096, 1.0), (12, 6000, 3.0)])
+def test_track_frontend_one_call(msorb_mod, oracle, kitti_frame, seed, M, th):
+    s = kitti_frame
+    R, t, Ow = _near_identity_pose(seed)
+    fr = _frustum(msorb_mod, R, t, Ow)
+    mp = tc.local_map(seed, s["kl"], s["dl"], s["ur"], s["dp"], R, t, Ow, s["scale"], M)
+    f, st, frame_mp, nm, out, rounds = msorb_mod.track_frontend(s["ex"], s["L"], s["R"], MB, MBF, fr, mp, th)
+    kl, dl, kr, dr, ur, dp, oob = st
+    assert np.array_equal(kl.view(np.uint8), s["kl"].view(np.uint8)) and np.array_equal(dl, s["dl"])
+    assert np.array_equal(ur.view(np.uint32), s["ur"].view(np.uint32)) and np.array_equal(dp.view(np.uint32), s["dp"].view(np.uint32))
+    rf = oracle.OracleFrame(kl, dl, ur, BOUNDS, s["scale"])
+    b = np.full(len(kl), -1, np.int32)
+    rnm, r, visit = tc.oracle_local_points(oracle, rf, fr, mp, b, th)
+    assert nm == rnm > M // 20 and np.array_equal(frame_mp, b)
+    assert rounds >= 1
+    assert np.array_equal(out["track_in_view"].astype(bool), r["track_in_view"].astype(bool) & visit)
+    # the frame left behind serves the next search (TrackWithMotionModel of the next frame projects INTO a new frame, but
+    # relocalisation / SearchByProjection(F, KF) run against this one)
+    cb, ci = msorb_mod.frame_grid(f)
+    rcb, rci = rf.grid_csr()
+    assert np.array_equal(cb, rcb) and np.array_equal(ci, rci)
+
+
+def test_track_frontend_many_points_per_keypoint_forces_rounds(msorb_mod, oracle, kitti_frame):
+    """20 000 map points on 2000 keypoints: candidate lists get exhausted by earlier claims, the replay re-runs the kernel."""
+    s = kitti_frame
+    R, t, Ow = _near_identity_pose(31)
+    fr = _frustum(msorb_mod, R, t, Ow)
+    mp = tc.local_map(31, s["kl"], s["dl"], s["ur"], s["dp"], R, t, Ow, s["scale"], 20000, copy_frac=0.95, obs_zero_frac=0.0,
+                      spars_frac=0.0)
+    f, st, frame_mp, nm, out, rounds = msorb_mod.track_frontend(s["ex"], s["L"], s["R"], MB, MBF, fr, mp, 3.0)
+    rf = oracle.OracleFrame(st[0], st[1], st[4], BOUNDS, s["scale"])
+    b = np.full(len(st[0]), -1, np.int32)
+    rnm, _, _ = tc.oracle_local_points(oracle, rf, fr, mp, b, 3.0)
+    assert nm == rnm and np.array_equal(frame_mp, b)
+
+
+def test_track_batch_vs_oracle(msorb_mod, oracle):
+    import torch
+    cfg = synth.KITTI
+    n_pairs, M = 3, 1500
+    imgs = []
+    for p in range(n_pairs):
+        L, R = synth.stereo_pair(40 + p, cfg["rows"], cfg["cols"])
+        imgs += [L, R]
+    ex = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7)
+    d_img = torch.from_numpy(np.stack(imgs)).cuda()
+    counts, mono, d_kps, d_desc = ex.extract_batch(d_img)
+    d_ur, d_dp, oob, _ = msorb_mod.stereo_matches_batch(ex, counts, d_kps, d_desc, MB, MBF)
+    scale = ex.GetScaleFactors()
+    kps_all = msorb_mod.keypoints_from_device(d_kps, counts)
+    desc_all = d_desc.cpu().numpy()
+    ur_all, dp_all = d_ur.cpu().numpy(), d_dp.cpu().numpy()
+    frusta, mps, poses = [], [], []
+    for p in range(n_pairs):
+        R, t, Ow = _near_identity_pose(60 + p)
+        n = counts[2 * p]
+        mp = tc.local_map(70 + p, kps_all[2 * p], desc_all[2 * p][:n], ur_all[p][:n], dp_all[p][:n], R, t, Ow, scale, M)
+        mp["flags"] = (mp["visit"] | (mp["bad"] << 1) | (mp["sparsified"] << 2)).astype(np.uint8)
+        frusta.append(_frustum(msorb_mod, R, t, Ow))
+        mps.append(mp)
+    d_mp = {k: torch.from_numpy(np.stack([m[k] for m in mps])).cuda().contiguous()
+            for k in ("pos_w", "normal", "max_distance", "min_distance", "flags", "desc")}
+    r = msorb_mod.track_batch(d_kps, d_desc, d_ur, counts, 2, BOUNDS, scale, frusta, d_mp, 3.0, want_grid=True, count_pairs=True)
+    ti, td = r["topk_idx"].cpu().numpy(), r["topk_dist"].cpu().numpy()
+    cb, ci = r["cell_begin"].cpu().numpy(), r["cell_idx"].cpu().numpy()
+    n_eval = 0
+    for p in range(n_pairs):
+        n = counts[2 * p]
+        rf = oracle.OracleFrame(kps_all[2 * p], desc_all[2 * p][:n], ur_all[p][:n], BOUNDS, scale)
+        rcb, rci = rf.grid_csr()
+        assert np.array_equal(cb[p], rcb) and np.array_equal(ci[p][:len(rci)], rci)
+        oi, od, fr_out = tc.oracle_topk(oracle, rf, frusta[p], mps[p], 3.0, scale)
+        assert np.array_equal(ti[p], oi), f"pair {p}: candidate indices differ"
+        assert np.array_equal(td[p][oi >= 0], od[oi >= 0])
+        assert (oi[:, 0] >= 0).sum() > M // 4
+        inv = r["in_view"][p].cpu().numpy().astype(bool)
+        assert np.array_equal(inv, fr_out["track_in_view"].astype(bool) & mps[p]["visit"].astype(bool))
+    assert r["n_pairs"] > 0 and all(m >= 0 for m in r["ms"])
+    # without the counter the lists are the same
+    r2 = msorb_mod.track_batch(d_kps, d_desc, d_ur, counts, 2, BOUNDS, scale, frusta, d_mp, 3.0)
+    assert torch.equal(r2["topk_idx"], r["topk_idx"]) and torch.equal(r2["topk_dist"], r["topk_dist"])

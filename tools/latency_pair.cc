@@ -3,6 +3,7 @@
 // -Wl,-rpath,$PWD/ms-slam_amd -lpthread -o /tmp/latency_pair ; prints median wall time per pair (both eyes done).
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -130,6 +131,69 @@ int main(int argc, char** argv) {
         }
         msorb_extractor_destroy(fx);
     }
+    // the same tracking frame as ONE device-resident chain (csrc/track.hip): (a) msorb_extract_stereo_frame + msorb_search_local_points
+    // (two calls, two synchronisations: the pose estimate of TrackWithMotionModel sits between them in the reference), (b)
+    // msorb_track_frontend (one call, one synchronisation) — local map of M points on the viewing rays of the keypoints
+    std::vector<double> t_esf, t_slp, t_one;
+    int nm_chain = 0, nm_one = 0, rounds = 0;
+    {
+        msorb_extractor* fx = nullptr;
+        msorb_frame* f2 = nullptr;
+        if (msorb_extractor_create(2000, 1.2f, 8, 20, 7, 0, &fx) || msorb_frame_create(0, &f2)) { printf("create: %s\n", msorb_last_error()); return 1; }
+        int nl = 0, nr2 = 0, oob2 = 0;
+        msorb_extract_stereo(fx, img[0].data(), img[1].data(), rows, cols, cols, cols, mb, mbf, kps[0].data(), desc[0].data(), &nl,
+                             kps[1].data(), desc[1].data(), &nr2, cap, ur.data(), depth.data(), &oob2);
+        const float fxc = 718.856f, cxc = 607.19f, cyc = 185.2f;
+        std::vector<float> pw(3 * M), nrm(3 * M), mxd(M), mnd(M);
+        std::vector<uint8_t> visit(M, 1);
+        for (int m = 0; m < M; m++) {
+            s = s * 1664525u + 1013904223u;
+            const int src = (s >> 8) % nl;
+            memcpy(&mdesc[(size_t)m * 32], &desc[0][(size_t)src * 32], 32);
+            s = s * 1664525u + 1013904223u;
+            for (int f = 0; f < (int)((s >> 20) % 24); f++) { s = s * 1664525u + 1013904223u; mdesc[(size_t)m * 32 + ((s >> 8) & 31)] ^= (uint8_t)(1u << ((s >> 16) & 7)); }
+            const float z = depth[src] > 0 ? depth[src] : 10.f;
+            const float u = kps[0][src].x + (float)((int)((s >> 4) % 5) - 2), v = kps[0][src].y + (float)((int)((s >> 9) % 5) - 2);
+            const float X = (u - cxc) * z / fxc, Y = (v - cyc) * z / fxc, d = std::sqrt(X * X + Y * Y + z * z);
+            pw[3 * m] = X; pw[3 * m + 1] = Y; pw[3 * m + 2] = z;
+            nrm[3 * m] = X / d; nrm[3 * m + 1] = Y / d; nrm[3 * m + 2] = z / d;
+            mxd[m] = d * scale[kps[0][src].octave] * 0.97f; mnd[m] = mxd[m] / scale[7];
+        }
+        msorb_frustum F{};
+        F.Rcw[0] = F.Rcw[4] = F.Rcw[8] = 1.f; F.fx = F.fy = fxc; F.cx = cxc; F.cy = cyc;
+        F.min_x = 0; F.max_x = (float)cols; F.min_y = 0; F.max_y = (float)rows; F.mbf = mbf; F.log_scale_factor = std::log(1.2f); F.n_scale_levels = 8;
+        std::vector<uint8_t> o_v(M);
+        std::vector<float> o_f(5 * M);
+        std::vector<int> o_l(M);
+        for (int i = 0; i < 5 + iters; i++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            if (msorb_extract_stereo_frame(fx, f2, img[0].data(), img[1].data(), rows, cols, cols, cols, mb, mbf, kps[0].data(), desc[0].data(),
+                                           &nl, kps[1].data(), desc[1].data(), &nr2, cap, ur.data(), depth.data(), &oob2, 0.f, (float)cols, 0.f,
+                                           (float)rows)) { printf("extract_stereo_frame: %s\n", msorb_last_error()); return 1; }
+            const auto t1 = std::chrono::steady_clock::now();
+            std::fill(frameMp.begin(), frameMp.end(), -1);
+            if (msorb_search_local_points(f2, &F, 0.5f, M, pw.data(), nrm.data(), mxd.data(), mnd.data(), visit.data(), bad.data(), spars.data(),
+                                          mdesc.data(), obs.data(), frameMp.data(), 1.0f, 0, 50.f, 0.8f, o_v.data(), o_f.data(), o_f.data() + M,
+                                          o_f.data() + 2 * M, o_f.data() + 3 * M, o_l.data(), o_f.data() + 4 * M, &nm_chain)) { printf("search_local_points: %s\n", msorb_last_error()); return 1; }
+            const auto t2 = std::chrono::steady_clock::now();
+            if (i >= 5) { t_esf.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count()); t_slp.push_back(std::chrono::duration<double, std::milli>(t2 - t1).count()); }
+        }
+        for (int i = 0; i < 5 + iters; i++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            if (msorb_track_frontend(fx, f2, img[0].data(), img[1].data(), rows, cols, cols, cols, mb, mbf, kps[0].data(), desc[0].data(), &nl,
+                                     kps[1].data(), desc[1].data(), &nr2, cap, ur.data(), depth.data(), &oob2, 0.f, (float)cols, 0.f, (float)rows,
+                                     &F, 0.5f, M, pw.data(), nrm.data(), mxd.data(), mnd.data(), visit.data(), bad.data(), spars.data(), mdesc.data(),
+                                     obs.data(), frameMp.data(), 1.0f, 0, 50.f, 0.8f, o_v.data(), o_f.data(), o_f.data() + M, o_f.data() + 2 * M,
+                                     o_f.data() + 3 * M, o_l.data(), o_f.data() + 4 * M, &nm_one, &rounds)) { printf("track_frontend: %s\n", msorb_last_error()); return 1; }
+            if (i >= 5) t_one.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+        msorb_frame_destroy(f2);
+        msorb_extractor_destroy(fx);
+    }
+    printf("{\"tracking_chain\": {\"map_points\": %d, \"ms_extract_stereo_frame\": %.4f, \"ms_search_local_points\": %.4f, "
+           "\"ms_two_calls\": %.4f, \"matches_two_calls\": %d, \"ms_track_frontend_one_call\": %.4f, \"matches_one_call\": %d, "
+           "\"window_rounds\": %d}}\n",
+           M, med(t_esf), med(t_slp), med(t_esf) + med(t_slp), nm_chain, med(t_one), nm_one, rounds);
     printf("{\"keypoints\": [%d, %d], \"ms_stereo_pair_two_threads_median\": %.4f, \"ms_single_image_median\": %.4f, "
            "\"ms_stereo_matches\": %.4f, \"ms_frame_grid_upload\": %.4f, \"ms_search_by_projection_4096\": %.4f, "
            "\"ms_is_in_frustum_4096\": %.4f, \"ms_tracking_frame_front_end\": %.4f, \"projection_matches\": %d, "
