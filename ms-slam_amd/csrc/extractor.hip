@@ -1080,10 +1080,18 @@ int msorb::extract_stereo_sink(msorb_extractor* h, const uint8_t* left, const ui
     b.counts_out = reinterpret_cast<int*>(blk + o_cnt);
     launch_stereo_match_batch(b, 1, cap, s);
     uint8_t* o = h->h_out_pin.p;
-    HIPCHK(hipMemcpyAsync(o, blk, out_bytes, hipMemcpyDeviceToHost, s));
     if (sink) {
+        // the frame's read-back (190 KB) leaves on the side stream while the sink's kernels (frame grid, local points, window
+        // search) run on the main one: 25 us of copy that would otherwise sit between the stereo kernels and the grid
+        if (!h->ev_split) HIPCHK(hipEventCreateWithFlags(&h->ev_split, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(h->ev_split, s));
+        HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_split, 0));
+        HIPCHK(hipMemcpyAsync(o, blk, out_bytes, hipMemcpyDeviceToHost, h->copy_stream));
         const StereoDeviceOutputs so{d_kps, d_desc, b.A.u_right, reinterpret_cast<const int*>(blk + o_cnt), cap, s};
-        if ((rc = sink(ctx, so))) { (void)hipStreamSynchronize(s); return rc; }
+        if ((rc = sink(ctx, so))) { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(h->copy_stream); return rc; }
+        HIPCHK(hipStreamSynchronize(h->copy_stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(o, blk, out_bytes, hipMemcpyDeviceToHost, s));
     }
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());

@@ -77,18 +77,32 @@ __device__ __forceinline__ void topk_insert(uint64_t key, int idx, uint64_t k[kT
     }
 }
 
-// One wave per query.  Walks the query's grid window exactly like Frame::GetFeaturesInArea: cells ix
-// (outer) / iy (inner) ascending, cell contents in insertion order; lane c owns window cell c, c+64, ...
+// One 16-lane group (a DPP row) per query, four queries per wave.  Walks the query's grid window exactly like
+// Frame::GetFeaturesInArea: cells ix (outer) / iy (inner) ascending, cell contents in insertion order; group lane c owns
+// window cell c, c+16, ...  (A tracking window covers 6-20 cells with about one keypoint each: with a whole wave per query
+// three quarters of the lanes had no cell; per 64 frames x 4096 queries 0.67 -> 0.2 ms.)
 // blockIdx.y = frame of a batch (frame_stride keypoints / q_stride queries apart in every array; 0 / 0 for one frame).
 // kCount: the number of Hamming distances evaluated is added to *n_eval (measurement runs only).
+constexpr int kWinLanes = 16;
+__device__ __forceinline__ uint64_t group_min_u64(uint64_t v) {
+#pragma unroll
+    for (int o = kWinLanes / 2; o > 0; o >>= 1) {
+        const uint64_t t = __shfl_xor(v, o, kWinLanes);
+        v = t < v ? t : v;
+    }
+    return v;
+}
 template <bool kCount>
 __global__ __launch_bounds__(256) void window_topk_kernel(FrameView F, const WinQuery* __restrict__ q,
                                                           const uint8_t* __restrict__ qdesc, int q_begin, int q_end,
                                                           TopK* __restrict__ out, int frame_stride, int q_stride,
                                                           unsigned long long* __restrict__ n_eval) {
-    const int qi = q_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (qi >= q_end) return;
+    constexpr int kGroups = 256 / kWinLanes;
+    const int qi_raw = q_begin + blockIdx.x * kGroups + (threadIdx.x / kWinLanes);
+    const int lane = threadIdx.x & (kWinLanes - 1);
+    const int gshift = (threadIdx.x & 63) & ~(kWinLanes - 1);  // first wave lane of this group
+    const bool live = qi_raw < q_end;
+    const int qi = live ? qi_raw : q_end - 1;
     if (blockIdx.y) {
         const size_t fo = (size_t)blockIdx.y * frame_stride, qo = (size_t)blockIdx.y * q_stride;
         F.kp += fo; F.desc += fo * 32; F.cell_idx += fo; F.occupied += fo;
@@ -101,7 +115,7 @@ __global__ __launch_bounds__(256) void window_topk_kernel(FrameView F, const Win
     int id[kTopK];
 #pragma unroll
     for (int i = 0; i < kTopK; i++) { k[i] = kNoKey; id[i] = -1; }
-    bool any = (Q.flags & kQValid) != 0;
+    bool any = live && (Q.flags & kQValid) != 0;
     int minCX = 0, maxCX = -1, minCY = 0, maxCY = -1;
     if (any) {  // Frame.cc:597-619
         minCX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.x, F.minX), Q.r), F.gridWInv)));
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(256) void window_topk_kernel(FrameView F, const Win
         const int ncy = maxCY - minCY + 1;
         const int ncell = (maxCX - minCX + 1) * ncy;
         const bool check_levels = (Q.min_level > 0) || (Q.max_level >= 0);
-        for (int c = lane; c < ncell; c += 64) {
+        for (int c = lane; c < ncell; c += kWinLanes) {
             const int ix = minCX + c / ncy, iy = minCY + c % ncy;
             const int cell = ix * kGridRows + iy;
             const int b = F.cell_begin[cell], e = F.cell_begin[cell + 1];
@@ -146,27 +160,30 @@ __global__ __launch_bounds__(256) void window_topk_kernel(FrameView F, const Win
             }
         }
     }
-    // merge the 64 sorted lists: kTopK rounds of "global minimum head pops"
+    // merge the group's sorted lists: kTopK rounds of "global minimum head pops".  A group without candidates skips it
+    // (wave-uniform only when all four groups are empty, but the rounds are cheap next to the gathers above).
     TopK res;
+    const bool group_any = ((__ballot(k[0] != kNoKey) >> gshift) & ((1ull << kWinLanes) - 1)) != 0;
 #pragma unroll
     for (int r = 0; r < kTopK; r++) {
-        const uint64_t m = wave_min_u64(k[0]);
+        const uint64_t m = group_min_u64(k[0]);
         int widx = -1;
-        if (m != kNoKey && k[0] == m) {  // keys are unique (scan position), exactly one lane matches
+        if (m != kNoKey && k[0] == m) {  // keys are unique (scan position), exactly one lane of the group matches
             widx = id[0];
 #pragma unroll
             for (int i = 0; i < kTopK - 1; i++) { k[i] = k[i + 1]; id[i] = id[i + 1]; }
             k[kTopK - 1] = kNoKey; id[kTopK - 1] = -1;
         }
-        const unsigned long long owner = __ballot(widx >= 0);
-        const int src = owner ? __ffsll((long long)owner) - 1 : 0;
-        res.idx[r] = owner ? __shfl(widx, src) : -1;
+        const unsigned owner = (unsigned)((__ballot(widx >= 0) >> gshift) & ((1ull << kWinLanes) - 1));
+        const int src = owner ? __ffs((int)owner) - 1 : 0;
+        res.idx[r] = owner ? __shfl(widx, src, kWinLanes) : -1;
         res.dist[r] = owner ? (int)(m >> 40) : 256;
     }
-    if (lane == 0) out[qi] = res;
+    (void)group_any;
+    if (live && lane == 0) out[qi] = res;
     if (kCount) {
         const int tot = wave_sum_i32(n_pairs);
-        if (lane == 0 && tot) atomicAdd(n_eval, (unsigned long long)tot);
+        if ((threadIdx.x & 63) == 0 && tot) atomicAdd(n_eval, (unsigned long long)tot);
     }
 }
 
@@ -631,10 +648,10 @@ void launch_window_topk(const FrameView& F, const WinQuery* q, const uint8_t* qd
     const int n = q_end - q_begin;
     if (n <= 0 || n_frames <= 0) return;
     if (n_eval)
-        hipLaunchKernelGGL(window_topk_kernel<true>, dim3((n + 3) / 4, n_frames), dim3(256), 0, s, F, q, qdesc, q_begin, q_end, out,
+        hipLaunchKernelGGL(window_topk_kernel<true>, dim3((n + 15) / 16, n_frames), dim3(256), 0, s, F, q, qdesc, q_begin, q_end, out,
                            frame_stride, q_stride, n_eval);
     else
-        hipLaunchKernelGGL(window_topk_kernel<false>, dim3((n + 3) / 4, n_frames), dim3(256), 0, s, F, q, qdesc, q_begin, q_end, out,
+        hipLaunchKernelGGL(window_topk_kernel<false>, dim3((n + 15) / 16, n_frames), dim3(256), 0, s, F, q, qdesc, q_begin, q_end, out,
                            frame_stride, q_stride, n_eval);
 }
 void launch_list_top2(const uint8_t* qdesc, const uint8_t* tdesc, const int* cand_begin, const int* cand_idx, int nq,

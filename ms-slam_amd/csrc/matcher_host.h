@@ -82,6 +82,8 @@ struct msorb_frame {
     msorb::DBuf<msorb::KpLite> d_kp;
     msorb::DBuf<uint8_t> d_desc, d_occ, d_qdesc, d_stage;
     msorb::DBuf<int> d_cell_begin, d_cell_idx, d_n;
+    msorb::DBuf<int> d_init_cnt, d_init_beg;   // msorb_search_for_initialization: candidate counts / list offsets / lists
+    msorb::DBuf<int2> d_init_list;
     bool host_grid_valid = false;       // cell_begin / cell_idx (host) mirror the device grid
     msorb_frame_track* track = nullptr;  // staging of the local-points chain (track.hip)
     msorb::DBuf<msorb::WinQuery> d_q;

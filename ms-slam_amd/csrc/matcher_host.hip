@@ -45,10 +45,12 @@ int msorb_frame_create(int device, msorb_frame** out) {
 
 void msorb_frame_destroy(msorb_frame* f) {
     if (!f) return;
-    (void)hipSetDevice(f->device);
+    // called from thread-exit / static destructors too (the host classes' per-thread caches): when the HIP runtime has
+    // already shut down nothing can be freed any more — and nothing needs to be
+    if (hipSetDevice(f->device) != hipSuccess) { delete f; return; }
     if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
     f->d_kp.release(); f->d_desc.release(); f->d_occ.release(); f->d_qdesc.release(); f->d_cell_begin.release();
-    f->d_cell_idx.release(); f->d_q.release(); f->d_topk.release(); f->h_in.release(); f->h_topk.release(); f->d_n.release(); f->d_stage.release();
+    f->d_cell_idx.release(); f->d_q.release(); f->d_topk.release(); f->h_in.release(); f->h_topk.release(); f->d_n.release(); f->d_stage.release(); f->d_init_cnt.release(); f->d_init_beg.release(); f->d_init_list.release();
     frame_track_release(f);
     delete f;
 }
@@ -479,8 +481,10 @@ int msorb_search_for_initialization(msorb_frame* f1, msorb_frame* f2, float* pre
         q[i] = w;
     }
     int rc;
-    DBuf<int> d_cnt, d_beg;
-    DBuf<int2> d_list;
+    // grow-only scratch on the train frame's handle (a per-call hipMalloc / hipFree pair synchronises the whole device
+    // while the other SLAM threads have kernels in flight, and leaked on the early returns)
+    DBuf<int>&d_cnt = f2->d_init_cnt, &d_beg = f2->d_init_beg;
+    DBuf<int2>& d_list = f2->d_init_list;
     if ((rc = f2->d_q.ensure(N1)) || (rc = f2->d_qdesc.ensure((size_t)N1 * 32)) || (rc = d_cnt.ensure(N1)) ||
         (rc = d_beg.ensure(N1 + 1)))
         return rc;
@@ -507,7 +511,6 @@ int msorb_search_for_initialization(msorb_frame* f1, msorb_frame* f2, float* pre
             if (e == hipSuccess) e = hipStreamSynchronize(s);
         }
     }
-    d_cnt.release(); d_beg.release(); d_list.release();
     if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return MSORB_E_HIP; }
     if (rc) return rc;
     // the reference's loop (:767-835) on the lists: every distance is known, the sequential part is compare / select

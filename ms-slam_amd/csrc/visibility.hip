@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -22,50 +23,77 @@ __global__ void vis_first_kernel(const int* __restrict__ slot_point, int n_slots
     if (p >= 0) atomicMin(&first[p], s);
 }
 
-// Single-block exclusive scans (chunk per thread).  mode 0: is_first flags -> column index per slot + n_cols.
-__global__ __launch_bounds__(1024) void vis_scan_first_kernel(const int* __restrict__ slot_point,
-                                                              const int* __restrict__ first, int n_slots,
-                                                              int* __restrict__ slot_rank /* exclusive rank among firsts */,
-                                                              int* __restrict__ n_cols) {
-    __shared__ int part[1024];
-    const int tid = threadIdx.x;
-    const int per = (n_slots + 1023) / 1024;
-    const int b = tid * per, e = min(b + per, n_slots);
-    int c = 0;
-    for (int s = b; s < e; s++) { const int p = slot_point[s]; c += (p >= 0 && first[p] == s); }
-    part[tid] = c;
-    __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int i = 0; i < 1024; i++) { const int v = part[i]; part[i] = acc; acc += v; }
-        *n_cols = acc;
+// exclusive scan of one int per thread over a workgroup of up to 1024 threads (wave scans + the wave totals in LDS)
+__device__ __forceinline__ int block_exclusive_scan(int v, int* wave_tot /* [16] shared */, int* total) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
     }
+    if (lane == 63) wave_tot[w] = inc;
     __syncthreads();
-    int acc = part[tid];
-    for (int s = b; s < e; s++) {
-        const int p = slot_point[s];
-        slot_rank[s] = acc;
-        acc += (p >= 0 && first[p] == s);
-    }
+    int base = 0, tot = 0;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; i++) { const int x = wave_tot[i]; if (i < w) base += x; tot += x; }
+    __syncthreads();
+    if (total) *total = tot;
+    return base + inc - v;
 }
 
-// column of every point; column tables; running max of observations
-__global__ void vis_columns_kernel(const int* __restrict__ slot_point, const int* __restrict__ first,
-                                   const int* __restrict__ slot_rank, int n_slots, const int* __restrict__ point_nobs,
-                                   int* __restrict__ col_of_point, int* __restrict__ col_point, int* __restrict__ n_max_obs) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_slots) return;
-    const int p = slot_point[s];
-    if (p < 0) return;
-    atomicMax(n_max_obs, point_nobs[p]);
-    if (first[p] == s) {
-        col_of_point[p] = slot_rank[s];
-        col_point[slot_rank[s]] = p;
+// Column order = first-encounter order of the points over the slots (MapSparsification.cc:78-99): slot s opens a column iff it
+// is the first slot of its point.  Three small launches instead of a one-block chunked scan (148 us for 60 000 slots):
+// per-block counts of the "first" flags, one block scans the counts, every block ranks its own slots.
+__global__ __launch_bounds__(256) void vis_flag_count_kernel(const int* __restrict__ slot_point, const int* __restrict__ first,
+                                                             int n_slots, int* __restrict__ block_count) {
+    __shared__ int wt[16];
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    int f = 0;
+    if (s < n_slots) { const int p = slot_point[s]; f = (p >= 0 && first[p] == s); }
+    int tot;
+    (void)block_exclusive_scan(f, wt, &tot);
+    if (threadIdx.x == 0) block_count[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(1024) void vis_block_scan_kernel(int* __restrict__ block_count, int n_blocks, int* __restrict__ n_cols) {
+    __shared__ int wt[16];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n_blocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n_blocks ? block_count[i] : 0;
+        int tot;
+        const int ex = block_exclusive_scan(v, wt, &tot);
+        const int carry = carry_s;
+        if (i < n_blocks) block_count[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
     }
+    if (threadIdx.x == 0) *n_cols = carry_s;
+}
+// column of every point; column tables; running max of observations
+__global__ __launch_bounds__(256) void vis_columns_kernel(const int* __restrict__ slot_point, const int* __restrict__ first,
+                                                          const int* __restrict__ block_base, int n_slots,
+                                                          const int* __restrict__ point_nobs, int* __restrict__ col_of_point,
+                                                          int* __restrict__ col_point, int* __restrict__ n_max_obs) {
+    __shared__ int wt[16];
+    __shared__ int smax;
+    if (threadIdx.x == 0) smax = 0;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int p = s < n_slots ? slot_point[s] : -1;
+    const int f = (p >= 0 && first[p] == s);
+    const int rank = block_base[blockIdx.x] + block_exclusive_scan(f, wt, nullptr);   // (the scan synchronises: smax is set)
+    if (p >= 0) atomicMax(&smax, point_nobs[p]);
+    if (f) { col_of_point[p] = rank; col_point[rank] = p; }
+    __syncthreads();
+    if (threadIdx.x == 0 && smax > 0) atomicMax(n_max_obs, smax);
 }
 
 // One block per window keyframe: counts of valid slots and valid cells.
-__global__ __launch_bounds__(256) void vis_kf_count_kernel(const int* __restrict__ kf_slot_begin,
+constexpr int kKfThreads = 1024;   // one workgroup per window keyframe: its ~2000 slots are two per thread (latency, not work, is the cost)
+__global__ __launch_bounds__(kKfThreads) void vis_kf_count_kernel(const int* __restrict__ kf_slot_begin,
                                                            const int* __restrict__ slot_point,
                                                            const int* __restrict__ slot_cell, int* __restrict__ kf_valid,
                                                            int* __restrict__ kf_cells) {
@@ -75,7 +103,7 @@ __global__ __launch_bounds__(256) void vis_kf_count_kernel(const int* __restrict
     __syncthreads();
     const int b = kf_slot_begin[k], e = kf_slot_begin[k + 1];
     int v = 0, c = 0;
-    for (int s = b + threadIdx.x; s < e; s += 256) {
+    for (int s = b + threadIdx.x; s < e; s += kKfThreads) {
         if (slot_point[s] < 0) continue;
         v++;
         // first valid slot of its cell <=> no earlier valid slot with the same cell (cells are contiguous runs)
@@ -90,9 +118,22 @@ __global__ __launch_bounds__(256) void vis_kf_count_kernel(const int* __restrict
     if (threadIdx.x == 0) { kf_valid[k] = sv; kf_cells[k] = sc; }
 }
 
+// rows / non-zeros in front of every window keyframe (one thread: a window is <= a few dozen keyframes); totals in scal[4], scal[5]
+__global__ void vis_kf_base_kernel(int n_kf, const int* __restrict__ kf_valid, const int* __restrict__ kf_cells,
+                                   int* __restrict__ row_base, int* __restrict__ nnz_base, int* __restrict__ scal) {
+    if (blockIdx.x || threadIdx.x) return;
+    int rows = 0, nnz = 0;
+    for (int k = 0; k < n_kf; k++) {
+        row_base[k] = rows; nnz_base[k] = nnz;
+        rows += kf_cells[k] + 1;
+        nnz += 2 * kf_valid[k];
+    }
+    scal[4] = rows; scal[5] = nnz;
+}
+
 // One block per window keyframe: emit its cell rows then its keyframe row.  Serial-in-order within the
 // block's thread 0 would be O(slots); instead each thread ranks its slots with block-wide prefix sums.
-__global__ __launch_bounds__(256) void vis_kf_rows_kernel(const int* __restrict__ kf_slot_begin,
+__global__ __launch_bounds__(kKfThreads) void vis_kf_rows_kernel(const int* __restrict__ kf_slot_begin,
                                                           const int* __restrict__ slot_point,
                                                           const int* __restrict__ slot_cell,
                                                           const int* __restrict__ col_of_point,
@@ -102,12 +143,12 @@ __global__ __launch_bounds__(256) void vis_kf_rows_kernel(const int* __restrict_
                                                           int* __restrict__ row_begin, int* __restrict__ row_kind,
                                                           int* __restrict__ row_owner, float* __restrict__ row_rhs,
                                                           int* __restrict__ col_idx) {
-    __shared__ int part_v[256], part_c[256];
+    __shared__ int wt[16];
     const int k = blockIdx.x, tid = threadIdx.x;
     const int b = kf_slot_begin[k], e = kf_slot_begin[k + 1];
     const int n = e - b;
-    const int per = (n + 255) / 256;
-    const int tb = b + tid * per, te = min(tb + per, e);
+    const int per = (n + kKfThreads - 1) / kKfThreads;
+    const int tb = min(b + tid * per, e), te = min(tb + per, e);
     int v = 0, c = 0;
     for (int s = tb; s < te; s++) {
         if (slot_point[s] < 0) continue;
@@ -117,18 +158,11 @@ __global__ __launch_bounds__(256) void vis_kf_rows_kernel(const int* __restrict_
             if (slot_point[t] >= 0) { first_valid = false; break; }
         c += first_valid;
     }
-    part_v[tid] = v; part_c[tid] = c;
-    __syncthreads();
-    if (tid == 0) {
-        int av = 0, ac = 0;
-        for (int i = 0; i < 256; i++) {
-            const int x = part_v[i], y = part_c[i];
-            part_v[i] = av; part_c[i] = ac;
-            av += x; ac += y;
-        }
-    }
-    __syncthreads();
-    int rv = part_v[tid], rc = part_c[tid];  // valid slots / valid cells before this thread's chunk
+    int total_c;
+    const int ev = block_exclusive_scan(v, wt, nullptr);
+    const int ec = block_exclusive_scan(c, wt, &total_c);
+    int part_v_tid = ev, part_c_tid = ec;
+    int rv = part_v_tid, rc = part_c_tid;  // valid slots / valid cells before this thread's chunk
     const int V = kf_valid[k];
     const int nnz0 = kf_nnz_base[k], row0 = kf_row_base[k];
     for (int s = tb; s < te; s++) {
@@ -148,59 +182,89 @@ __global__ __launch_bounds__(256) void vis_kf_rows_kernel(const int* __restrict_
         }
         rv++;
     }
-    if (tid == 255) {  // rc after the last chunk = number of valid cells
-        const int r = row0 + rc;
+    if (tid == 0) {  // the keyframe's own row follows its cell rows
+        const int r = row0 + total_c;
         row_begin[r] = nnz0 + V;
         row_kind[r] = 1; row_owner[r] = k; row_rhs[r] = (float)N;
     }
 }
 
 // outside-keyframe rows: count, bitmap, emit
-__global__ void vis_extra_count_kernel(const int* __restrict__ col_point, int n_cols, const int* __restrict__ obs_begin,
-                                       const int* __restrict__ obs_kf, const uint8_t* __restrict__ kf_in_window,
-                                       int* __restrict__ kf_count) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_cols) return;
-    const int p = col_point[c];
-    for (int o = obs_begin[p]; o < obs_begin[p + 1]; o++) {
-        const int kf = obs_kf[o];
-        if (!kf_in_window[kf]) atomicAdd(&kf_count[kf], 1);
+// (the column count lives on the device: scal[0]; the grid covers its host-side upper bound).  A few hundred keyframe counters
+// take tens of thousands of increments: they are accumulated per workgroup in LDS (kLdsHist counters) and flushed once.
+constexpr int kLdsHist = 8192;
+__global__ __launch_bounds__(256) void vis_extra_count_kernel(const int* __restrict__ col_point, const int* __restrict__ scal,
+                                                              const int* __restrict__ obs_begin, const int* __restrict__ obs_kf,
+                                                              const uint8_t* __restrict__ kf_in_window, int n_kf,
+                                                              int* __restrict__ kf_count) {
+    extern __shared__ int hist[];
+    const bool lds = n_kf <= kLdsHist;
+    if (lds) {
+        for (int i = threadIdx.x; i < n_kf; i += 256) hist[i] = 0;
+        __syncthreads();
+    }
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < scal[0]) {
+        const int p = col_point[c];
+        for (int o = obs_begin[p]; o < obs_begin[p + 1]; o++) {
+            const int kf = obs_kf[o];
+            if (!kf_in_window[kf]) atomicAdd(lds ? &hist[kf] : &kf_count[kf], 1);
+        }
+    }
+    if (lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_kf; i += 256)
+            if (hist[i]) atomicAdd(&kf_count[i], hist[i]);
     }
 }
 __global__ __launch_bounds__(1024) void vis_extra_scan_kernel(const int* __restrict__ kf_count, int n_kf,
                                                               int* __restrict__ kf_row /* rank among count>0 */,
                                                               int* __restrict__ kf_off /* nnz offset */,
                                                               int* __restrict__ totals /* [n_rows_c, nnz_c] */) {
-    __shared__ int pr[1024], pn[1024];
-    const int tid = threadIdx.x;
-    const int per = (n_kf + 1023) / 1024;
-    const int b = tid * per, e = min(b + per, n_kf);
-    int r = 0, n = 0;
-    for (int i = b; i < e; i++) { r += kf_count[i] > 0; n += kf_count[i]; }
-    pr[tid] = r; pn[tid] = n;
+    __shared__ int wt[16];
+    __shared__ int carry_r, carry_n;
+    if (threadIdx.x == 0) { carry_r = 0; carry_n = 0; }
     __syncthreads();
-    if (tid == 0) {
-        int ar = 0, an = 0;
-        for (int i = 0; i < 1024; i++) {
-            const int x = pr[i], y = pn[i];
-            pr[i] = ar; pn[i] = an;
-            ar += x; an += y;
-        }
-        totals[0] = ar; totals[1] = an;
+    for (int base = 0; base < n_kf; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int cnt = i < n_kf ? kf_count[i] : 0;
+        int tr, tn;
+        const int er = block_exclusive_scan(cnt > 0 ? 1 : 0, wt, &tr);
+        const int en = block_exclusive_scan(cnt, wt, &tn);
+        const int cr = carry_r, cn = carry_n;
+        if (i < n_kf) { kf_row[i] = cnt > 0 ? cr + er : -1; kf_off[i] = cn + en; }
+        __syncthreads();
+        if (threadIdx.x == 0) { carry_r = cr + tr; carry_n = cn + tn; }
+        __syncthreads();
     }
-    __syncthreads();
-    int ar = pr[tid], an = pn[tid];
-    for (int i = b; i < e; i++) {
-        kf_row[i] = kf_count[i] > 0 ? ar : -1;
-        kf_off[i] = an;
-        ar += kf_count[i] > 0; an += kf_count[i];
+    if (threadIdx.x == 0) { totals[0] = carry_r; totals[1] = carry_n; }
+}
+// The result as ONE block: the eight scalars, then the six arrays side by side at their exact sizes (device scalars) — the
+// host reads the block back with one copy sized by its upper bound and finds the arrays from the header.
+__global__ __launch_bounds__(256) void vis_pack_kernel(const int* __restrict__ scal, const int* __restrict__ row_begin,
+                                                       const int* __restrict__ row_kind, const int* __restrict__ row_owner,
+                                                       const int* __restrict__ row_rhs, const int* __restrict__ col_point,
+                                                       const int* __restrict__ col_idx, int* __restrict__ out) {
+    const int ncols = scal[0], R = scal[4] + scal[2], nnz = scal[5] + scal[3];
+    const int total = 4 * R + ncols + nnz;
+    if (blockIdx.x == 0 && threadIdx.x < 8) out[threadIdx.x] = scal[threadIdx.x];
+    out += 8;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int v;
+        if (i < R) v = row_begin[i];
+        else if (i < 2 * R) v = row_kind[i - R];
+        else if (i < 3 * R) v = row_owner[i - 2 * R];
+        else if (i < 4 * R) v = row_rhs[i - 3 * R];
+        else if (i < 4 * R + ncols) v = col_point[i - 4 * R];
+        else v = col_idx[i - 4 * R - ncols];
+        out[i] = v;
     }
 }
-__global__ void vis_extra_bits_kernel(const int* __restrict__ col_point, int n_cols, const int* __restrict__ obs_begin,
+__global__ void vis_extra_bits_kernel(const int* __restrict__ col_point, const int* __restrict__ scal, const int* __restrict__ obs_begin,
                                       const int* __restrict__ obs_kf, const uint8_t* __restrict__ kf_in_window,
                                       const int* __restrict__ kf_row, int words, unsigned* __restrict__ bitmap) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_cols) return;
+    if (c >= scal[0]) return;
     const int p = col_point[c];
     for (int o = obs_begin[p]; o < obs_begin[p + 1]; o++) {
         const int kf = obs_kf[o];
@@ -211,13 +275,14 @@ __global__ void vis_extra_bits_kernel(const int* __restrict__ col_point, int n_c
 __global__ __launch_bounds__(256) void vis_extra_emit_kernel(int n_kf, const int* __restrict__ kf_count,
                                                              const int* __restrict__ kf_row, const int* __restrict__ kf_off,
                                                              const int* __restrict__ kf_num_mps, int N, int words,
-                                                             const unsigned* __restrict__ bitmap, int row_base, int nnz_base,
+                                                             const unsigned* __restrict__ bitmap, const int* __restrict__ scal,
                                                              int* __restrict__ row_begin, int* __restrict__ row_kind,
                                                              int* __restrict__ row_owner, float* __restrict__ row_rhs,
                                                              int* __restrict__ col_idx) {
     __shared__ int part[256];
     const int kf = blockIdx.x, tid = threadIdx.x;
     if (kf >= n_kf || kf_count[kf] == 0) return;
+    const int row_base = scal[4], nnz_base = scal[5];  // rows / non-zeros of the window keyframes (vis_kf_base_kernel)
     const unsigned* bm = bitmap + (size_t)kf_row[kf] * words;
     const int per = (words + 255) / 256;
     const int b = tid * per, e = min(b + per, words);
@@ -284,21 +349,33 @@ extern "C" int msorb_visibility_csr(int device, int n_window_kf, const int* kf_s
     }
     const int S = kf_slot_begin[n_window_kf];
     const int n_obs = n_points ? obs_begin[n_points] : 0;
-    for (int s = 0; s < S; s++)
-        if (slot_point[s] >= n_points) { set_last_error("slot_point out of range"); return MSORB_E_INVALID; }
-    for (int o = 0; o < n_obs; o++)
-        if (obs_kf[o] < 0 || obs_kf[o] >= n_kf_total) { set_last_error("obs_kf out of range"); return MSORB_E_INVALID; }
+    int n_valid = 0;   // slots that hold a point: every size below is bounded by it
+    {   // range checks as two branch-free reductions (they vectorise; the kernels index with these values)
+        int bad_slot = 0, bad_obs = 0;
+        for (int s = 0; s < S; s++) { bad_slot |= slot_point[s] >= n_points; n_valid += slot_point[s] >= 0; }
+        for (int o = 0; o < n_obs; o++) bad_obs |= (obs_kf[o] < 0) | (obs_kf[o] >= n_kf_total);
+        if (bad_slot) { set_last_error("slot_point out of range"); return MSORB_E_INVALID; }
+        if (bad_obs) { set_last_error("obs_kf out of range"); return MSORB_E_INVALID; }
+    }
     int rc = MSORB_OK;
     if (hipSetDevice(device) != hipSuccess) return MSORB_E_HIP;
-    // scratch kept per calling thread (grow-only) and a private non-blocking stream, like the other per-frame entries
+    // Scratch kept per calling thread (grow-only), a private non-blocking stream, pinned staging.  Shape of a call: the
+    // inputs are packed into ONE pinned block and uploaded with one copy; every kernel takes the sizes it depends on (columns,
+    // rows / non-zeros of the window part) from device scalars and is launched over host-side upper bounds, so nothing
+    // waits for the host; the six scalars come back with the first synchronisation, the six output arrays (exact sizes)
+    // with the second.  (Round 2: nine pageable uploads and about ten synchronous read-backs, 0.74 ms for a 30-keyframe window.)
     struct Scratch {
         int device = -1;
         hipStream_t s = nullptr;
-        void* p[4] = {nullptr, nullptr, nullptr, nullptr};
-        size_t cap[4] = {0, 0, 0, 0};
+        void* p[2] = {nullptr, nullptr};
+        size_t cap[2] = {0, 0};
+        void* h = nullptr;
+        size_t hcap = 0;
         void release() {
             if (device < 0 || hipSetDevice(device) != hipSuccess) return;
-            for (int i = 0; i < 4; i++) { if (p[i]) (void)hipFree(p[i]); p[i] = nullptr; cap[i] = 0; }
+            for (int i = 0; i < 2; i++) { if (p[i]) (void)hipFree(p[i]); p[i] = nullptr; cap[i] = 0; }
+            if (h) (void)hipHostFree(h);
+            h = nullptr; hcap = 0;
             if (s) (void)hipStreamDestroy(s);
             s = nullptr; device = -1;
         }
@@ -310,6 +387,14 @@ extern "C" int msorb_visibility_csr(int device, int n_window_kf, const int* kf_s
             if (e == hipSuccess) cap[i] = bytes + bytes / 4;
             return e;
         }
+        hipError_t ensure_host(size_t bytes) {
+            if (bytes <= hcap) return hipSuccess;
+            if (h) (void)hipHostFree(h);
+            h = nullptr; hcap = 0;
+            const hipError_t e = hipHostMalloc(&h, bytes + bytes / 4, hipHostMallocDefault);
+            if (e == hipSuccess) hcap = bytes + bytes / 4;
+            return e;
+        }
         ~Scratch() { release(); }
     };
     static thread_local Scratch scr;
@@ -319,106 +404,115 @@ extern "C" int msorb_visibility_csr(int device, int n_window_kf, const int* kf_s
         scr.device = device;
     }
     hipStream_t const st = scr.s;
-    // one arena of ints
-    int *d = nullptr;
-    unsigned* d_bitmap = nullptr;
-    float* d_rhs = nullptr;
-    uint8_t* d_inwin = nullptr;
-    std::vector<int> kf_valid(n_window_kf + 1), kf_cells(n_window_kf + 1), row_base(n_window_kf + 1), nnz_base(n_window_kf + 1);
-    int totals[2] = {0, 0}, ncols = 0, nmax = 0, rows_ab = 0, nnz_ab = 0, words = 0;
+    // host-side upper bounds of the result sizes
+    int n_outside = 0;   // keyframes outside the window: bound of the kind-2 rows
+    for (int k = 0; k < n_kf_total; k++) n_outside += !kf_in_window[k];
+    if (n_obs == 0) n_outside = 0;
+    const int cols_max = std::min(n_valid, n_points), rows_ab_max = n_valid + n_window_kf, rows_max = rows_ab_max + n_outside;
+    const size_t nnz_max = (size_t)2 * n_valid + (size_t)n_obs;
+    const int words = (cols_max + 31) / 32;
+    int* d = nullptr;
+    int scal[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     size_t off = 0;
     auto take = [&](size_t n) { const size_t o = off; off += (n + 3) & ~size_t(3); return o; };
+    // inputs (one upload) ...
     const size_t o_slot_begin = take(n_window_kf + 1), o_slot_point = take(S), o_slot_cell = take(S), o_nobs = take(n_points),
-                 o_obs_begin = take(n_points + 1), o_obs_kf = take(n_obs), o_num_mps = take(n_kf_total), o_first = take(n_points),
-                 o_rank = take(S), o_colofp = take(n_points), o_colpoint = take(S + 1), o_scal = take(8),
-                 o_kfvalid = take(n_window_kf + 1), o_kfcells = take(n_window_kf + 1), o_rowbase = take(n_window_kf + 1),
-                 o_nnzbase = take(n_window_kf + 1), o_kfcount = take(n_kf_total), o_kfrow = take(n_kf_total),
-                 o_kfoff = take(n_kf_total), o_rowbegin = take((size_t)cap_rows + 1), o_rowkind = take(cap_rows),
-                 o_rowowner = take(cap_rows), o_colidx = take(cap_nnz);
+                 o_obs_begin = take(n_points + 1), o_obs_kf = take(n_obs), o_num_mps = take(n_kf_total),
+                 o_inwin = take(((size_t)n_kf_total + 3) / 4), o_scal = take(8), n_in = off;
+    // ... work arrays ...
+    const size_t o_first = take(n_points), o_rank = take(S), o_colofp = take(n_points), o_kfvalid = take(n_window_kf + 1),
+                 o_kfcells = take(n_window_kf + 1), o_rowbase = take(n_window_kf + 1), o_nnzbase = take(n_window_kf + 1),
+                 o_kfcount = take(n_kf_total), o_kfrow = take(n_kf_total), o_kfoff = take(n_kf_total);
+    // ... outputs
+    const size_t o_rowbegin = take((size_t)rows_max + 1), o_rowkind = take(rows_max), o_rowowner = take(rows_max), o_rhs = take(rows_max),
+                 o_colpoint = take((size_t)cols_max + 1), o_colidx = take(nnz_max),
+                 o_pack = take((size_t)8 + 4 * rows_max + cols_max + nnz_max);
+    const size_t bitmap_bytes = (size_t)n_outside * words * sizeof(unsigned);
+    const size_t pack_max = (size_t)8 + 4 * rows_max + cols_max + nnz_max;
     VCHK(scr.ensure(0, std::max<size_t>(off, 1) * sizeof(int)));
-    VCHK(scr.ensure(1, std::max<size_t>(cap_rows, 1) * sizeof(float)));
-    VCHK(scr.ensure(2, std::max(n_kf_total, 1)));
-    d = static_cast<int*>(scr.p[0]); d_rhs = static_cast<float*>(scr.p[1]); d_inwin = static_cast<uint8_t*>(scr.p[2]);
-    VCHK(hipMemcpyAsync(d + o_slot_begin, kf_slot_begin, (n_window_kf + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-    if (S) {
-        VCHK(hipMemcpyAsync(d + o_slot_point, slot_point, S * sizeof(int), hipMemcpyHostToDevice, st));
-        VCHK(hipMemcpyAsync(d + o_slot_cell, slot_cell, S * sizeof(int), hipMemcpyHostToDevice, st));
+    VCHK(scr.ensure(1, std::max<size_t>(bitmap_bytes, 4)));
+    VCHK(scr.ensure_host(std::max<size_t>(std::max(n_in, pack_max), 1) * sizeof(int)));
+    d = static_cast<int*>(scr.p[0]);
+    {
+        int* h = static_cast<int*>(scr.h);
+        std::memcpy(h + o_slot_begin, kf_slot_begin, (size_t)(n_window_kf + 1) * sizeof(int));
+        if (S) {
+            std::memcpy(h + o_slot_point, slot_point, (size_t)S * sizeof(int));
+            std::memcpy(h + o_slot_cell, slot_cell, (size_t)S * sizeof(int));
+        }
+        if (n_points) {
+            std::memcpy(h + o_nobs, point_nobs, (size_t)n_points * sizeof(int));
+            std::memcpy(h + o_obs_begin, obs_begin, (size_t)(n_points + 1) * sizeof(int));
+            if (n_obs) std::memcpy(h + o_obs_kf, obs_kf, (size_t)n_obs * sizeof(int));
+        }
+        if (n_kf_total) {
+            std::memcpy(h + o_num_mps, kf_num_mps, (size_t)n_kf_total * sizeof(int));
+            std::memcpy(h + o_inwin, kf_in_window, n_kf_total);
+        }
+        for (int i = 0; i < 8; i++) h[o_scal + i] = 0;
+        h[o_scal + 1] = n_max_obs_floor;
+        VCHK(hipMemcpyAsync(d, h, n_in * sizeof(int), hipMemcpyHostToDevice, st));
     }
-    if (n_points) {
-        VCHK(hipMemcpyAsync(d + o_nobs, point_nobs, n_points * sizeof(int), hipMemcpyHostToDevice, st));
-        VCHK(hipMemcpyAsync(d + o_obs_begin, obs_begin, (n_points + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-        if (n_obs) VCHK(hipMemcpyAsync(d + o_obs_kf, obs_kf, n_obs * sizeof(int), hipMemcpyHostToDevice, st));
-        VCHK(hipMemsetAsync(d + o_first, 0x7f, n_points * sizeof(int), st));
-    }
-    if (n_kf_total) {
-        VCHK(hipMemcpyAsync(d + o_num_mps, kf_num_mps, n_kf_total * sizeof(int), hipMemcpyHostToDevice, st));
-        VCHK(hipMemcpyAsync(d_inwin, kf_in_window, n_kf_total, hipMemcpyHostToDevice, st));
-        VCHK(hipMemsetAsync(d + o_kfcount, 0, n_kf_total * sizeof(int), st));
-    }
-    VCHK(hipMemsetAsync(d + o_scal, 0, 8 * sizeof(int), st));
-    VCHK(hipMemcpyAsync(d + o_scal + 1, &n_max_obs_floor, sizeof(int), hipMemcpyHostToDevice, st));
-    if (S) {
-        hipLaunchKernelGGL(vis_first_kernel, dim3((S + 255) / 256), dim3(256), 0, st, d + o_slot_point, S, d + o_first);
-        hipLaunchKernelGGL(vis_scan_first_kernel, dim3(1), dim3(1024), 0, st, d + o_slot_point, d + o_first, S, d + o_rank,
-                           d + o_scal);
-        hipLaunchKernelGGL(vis_columns_kernel, dim3((S + 255) / 256), dim3(256), 0, st, d + o_slot_point, d + o_first,
-                           d + o_rank, S, d + o_nobs, d + o_colofp, d + o_colpoint, d + o_scal + 1);
-    }
-    if (n_window_kf)
-        hipLaunchKernelGGL(vis_kf_count_kernel, dim3(n_window_kf), dim3(256), 0, st, d + o_slot_begin, d + o_slot_point,
-                           d + o_slot_cell, d + o_kfvalid, d + o_kfcells);
-    VCHK(hipMemcpyAsync(&ncols, d + o_scal, sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
-    VCHK(hipMemcpyAsync(&nmax, d + o_scal + 1, sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
-    if (n_window_kf) {
-        VCHK(hipMemcpyAsync(kf_valid.data(), d + o_kfvalid, n_window_kf * sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
-        VCHK(hipMemcpyAsync(kf_cells.data(), d + o_kfcells, n_window_kf * sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
-    }
-    for (int k = 0; k < n_window_kf; k++) {
-        row_base[k] = rows_ab; nnz_base[k] = nnz_ab;
-        rows_ab += kf_cells[k] + 1;
-        nnz_ab += 2 * kf_valid[k];
-    }
-    if (ncols > cap_cols || rows_ab > cap_rows || nnz_ab > cap_nnz) { set_last_error("output capacity too small"); rc = MSORB_E_CAPACITY; goto done; }
-    if (n_window_kf) {
-        VCHK(hipMemcpyAsync(d + o_rowbase, row_base.data(), n_window_kf * sizeof(int), hipMemcpyHostToDevice, st));
-        VCHK(hipMemcpyAsync(d + o_nnzbase, nnz_base.data(), n_window_kf * sizeof(int), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(vis_kf_rows_kernel, dim3(n_window_kf), dim3(256), 0, st, d + o_slot_begin, d + o_slot_point,
-                           d + o_slot_cell, d + o_colofp, d + o_rowbase, d + o_nnzbase, d + o_kfvalid, N, d + o_rowbegin,
-                           d + o_rowkind, d + o_rowowner, d_rhs, d + o_colidx);
-    }
-    if (ncols && n_kf_total) {
-        hipLaunchKernelGGL(vis_extra_count_kernel, dim3((ncols + 255) / 256), dim3(256), 0, st, d + o_colpoint, ncols,
-                           d + o_obs_begin, d + o_obs_kf, d_inwin, d + o_kfcount);
-        hipLaunchKernelGGL(vis_extra_scan_kernel, dim3(1), dim3(1024), 0, st, d + o_kfcount, n_kf_total, d + o_kfrow,
-                           d + o_kfoff, d + o_scal + 2);
-        VCHK(hipMemcpyAsync(totals, d + o_scal + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
-        if (rows_ab + totals[0] > cap_rows || nnz_ab + totals[1] > cap_nnz) { set_last_error("output capacity too small"); rc = MSORB_E_CAPACITY; goto done; }
-        if (totals[0]) {
-            words = (ncols + 31) / 32;
-            VCHK(scr.ensure(3, (size_t)totals[0] * words * sizeof(unsigned)));
-            d_bitmap = static_cast<unsigned*>(scr.p[3]);
-            VCHK(hipMemsetAsync(d_bitmap, 0, (size_t)totals[0] * words * sizeof(unsigned), st));
-            hipLaunchKernelGGL(vis_extra_bits_kernel, dim3((ncols + 255) / 256), dim3(256), 0, st, d + o_colpoint, ncols,
-                               d + o_obs_begin, d + o_obs_kf, d_inwin, d + o_kfrow, words, d_bitmap);
-            hipLaunchKernelGGL(vis_extra_emit_kernel, dim3(n_kf_total), dim3(256), 0, st, n_kf_total, d + o_kfcount,
-                               d + o_kfrow, d + o_kfoff, d + o_num_mps, N, words, d_bitmap, rows_ab, nnz_ab, d + o_rowbegin,
+    {
+        const uint8_t* d_inwin = reinterpret_cast<const uint8_t*>(d + o_inwin);
+        float* d_rhs = reinterpret_cast<float*>(d + o_rhs);
+        unsigned* d_bitmap = static_cast<unsigned*>(scr.p[1]);
+        if (n_points) VCHK(hipMemsetAsync(d + o_first, 0x7f, (size_t)n_points * sizeof(int), st));
+        if (n_kf_total) VCHK(hipMemsetAsync(d + o_kfcount, 0, (size_t)n_kf_total * sizeof(int), st));
+        if (S) {
+            const int nb = (S + 255) / 256;
+            hipLaunchKernelGGL(vis_first_kernel, dim3(nb), dim3(256), 0, st, d + o_slot_point, S, d + o_first);
+            hipLaunchKernelGGL(vis_flag_count_kernel, dim3(nb), dim3(256), 0, st, d + o_slot_point, d + o_first, S, d + o_rank);
+            hipLaunchKernelGGL(vis_block_scan_kernel, dim3(1), dim3(1024), 0, st, d + o_rank, nb, d + o_scal);
+            hipLaunchKernelGGL(vis_columns_kernel, dim3(nb), dim3(256), 0, st, d + o_slot_point, d + o_first, d + o_rank, S,
+                               d + o_nobs, d + o_colofp, d + o_colpoint, d + o_scal + 1);
+        }
+        if (n_window_kf) {
+            hipLaunchKernelGGL(vis_kf_count_kernel, dim3(n_window_kf), dim3(kKfThreads), 0, st, d + o_slot_begin, d + o_slot_point,
+                               d + o_slot_cell, d + o_kfvalid, d + o_kfcells);
+            hipLaunchKernelGGL(vis_kf_base_kernel, dim3(1), dim3(64), 0, st, n_window_kf, d + o_kfvalid, d + o_kfcells, d + o_rowbase,
+                               d + o_nnzbase, d + o_scal);
+            hipLaunchKernelGGL(vis_kf_rows_kernel, dim3(n_window_kf), dim3(kKfThreads), 0, st, d + o_slot_begin, d + o_slot_point,
+                               d + o_slot_cell, d + o_colofp, d + o_rowbase, d + o_nnzbase, d + o_kfvalid, N, d + o_rowbegin,
                                d + o_rowkind, d + o_rowowner, d_rhs, d + o_colidx);
         }
-    }
-    VCHK(hipStreamSynchronize(st));
-    {
-        const int R = rows_ab + totals[0], NNZ = nnz_ab + totals[1];
+        if (cols_max && n_outside) {
+            hipLaunchKernelGGL(vis_extra_count_kernel, dim3((cols_max + 255) / 256), dim3(256),
+                               n_kf_total <= kLdsHist ? (size_t)n_kf_total * sizeof(int) : 0, st, d + o_colpoint, d + o_scal,
+                               d + o_obs_begin, d + o_obs_kf, d_inwin, n_kf_total, d + o_kfcount);
+            hipLaunchKernelGGL(vis_extra_scan_kernel, dim3(1), dim3(1024), 0, st, d + o_kfcount, n_kf_total, d + o_kfrow,
+                               d + o_kfoff, d + o_scal + 2);
+            VCHK(hipMemsetAsync(d_bitmap, 0, bitmap_bytes, st));
+            hipLaunchKernelGGL(vis_extra_bits_kernel, dim3((cols_max + 255) / 256), dim3(256), 0, st, d + o_colpoint, d + o_scal,
+                               d + o_obs_begin, d + o_obs_kf, d_inwin, d + o_kfrow, words, d_bitmap);
+            hipLaunchKernelGGL(vis_extra_emit_kernel, dim3(n_kf_total), dim3(256), 0, st, n_kf_total, d + o_kfcount,
+                               d + o_kfrow, d + o_kfoff, d + o_num_mps, N, words, d_bitmap, d + o_scal, d + o_rowbegin,
+                               d + o_rowkind, d + o_rowowner, d_rhs, d + o_colidx);
+        }
+        int* h = static_cast<int*>(scr.h);
+        hipLaunchKernelGGL(vis_pack_kernel, dim3((unsigned)std::min<size_t>((pack_max + 255) / 256, 1024)), dim3(256), 0, st, d + o_scal,
+                           d + o_rowbegin, d + o_rowkind, d + o_rowowner, reinterpret_cast<const int*>(d_rhs), d + o_colpoint,
+                           d + o_colidx, d + o_pack);
+        VCHK(hipMemcpyAsync(h, d + o_pack, pack_max * sizeof(int), hipMemcpyDeviceToHost, st));
+        VCHK(hipStreamSynchronize(st));   // the call's only synchronisation
+        VCHK(hipGetLastError());
+        for (int i = 0; i < 8; i++) scal[i] = h[i];
+        const int ncols = scal[0], nmax = scal[1], R = scal[4] + scal[2], NNZ = scal[5] + scal[3];
+        if (ncols > cap_cols || R > cap_rows || NNZ > cap_nnz) { set_last_error("output capacity too small"); rc = MSORB_E_CAPACITY; goto done; }
         *n_cols = ncols; *n_rows = R; *nnz_out = NNZ; *n_max_obs = nmax;
+        int* hb = h + 8;
+        int *h_rb = hb, *h_rk = h_rb + R, *h_ro = h_rk + R, *h_cp = h_ro + R + R /* rhs in between */, *h_ci = h_cp + ncols;
+        float* h_rhs = reinterpret_cast<float*>(h_ro + R);
         if (R) {
-            VCHK(hipMemcpyAsync(row_begin, d + o_rowbegin, R * sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
-            VCHK(hipMemcpyAsync(row_kind, d + o_rowkind, R * sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
-            VCHK(hipMemcpyAsync(row_owner, d + o_rowowner, R * sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
-            VCHK(hipMemcpyAsync(row_rhs, d_rhs, R * sizeof(float), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
+            std::memcpy(row_begin, h_rb, (size_t)R * sizeof(int));
+            std::memcpy(row_kind, h_rk, (size_t)R * sizeof(int));
+            std::memcpy(row_owner, h_ro, (size_t)R * sizeof(int));
+            std::memcpy(row_rhs, h_rhs, (size_t)R * sizeof(float));
         }
         row_begin[R] = NNZ;
-        if (NNZ) VCHK(hipMemcpyAsync(col_idx, d + o_colidx, NNZ * sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
+        if (NNZ) std::memcpy(col_idx, h_ci, (size_t)NNZ * sizeof(int));
         if (ncols) {
-            VCHK(hipMemcpyAsync(col_point, d + o_colpoint, ncols * sizeof(int), hipMemcpyDeviceToHost, st)); VCHK(hipStreamSynchronize(st));
+            std::memcpy(col_point, h_cp, (size_t)ncols * sizeof(int));
             for (int c = 0; c < ncols; c++) obj_coef[c] = (float)(nmax - point_nobs[col_point[c]]);  // MapSparsification.cc:95-96
         }
     }

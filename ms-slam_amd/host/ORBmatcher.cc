@@ -7,7 +7,9 @@
 #include "ORBmatcher.h"
 
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
+#include <memory>
 
 #include "ORBmatcher_device.h"
 #include "ORBmatcher_loop_device.h"
@@ -42,14 +44,25 @@ struct ThreadCache {
     bool kf_sparsified[2] = {false, false};
     int kf_n[2] = {-1, -1};
 };
-// KeyFrames resident on the device for the BoW-node searches, shared by the three threads that run the matcher
+// KeyFrames resident on the device for the BoW-node searches, shared by the three threads that run the matcher.  Heap
+// allocated and never destroyed by a static destructor (those may run after the HIP runtime has gone): msorb_host::Shutdown()
+// releases it.
 msorb_host::KeyFrameStore& keyframe_store() {
-    static msorb_host::KeyFrameStore store(matcher_device());
-    return store;
+    static msorb_host::KeyFrameStore* store = new msorb_host::KeyFrameStore(matcher_device());
+    return *store;
 }
+// the calling thread's device frames: released by msorb_host::ReleaseThread() / at thread exit.  The destructor of a
+// DeviceFrame tolerates a dead runtime (msorb_frame_destroy skips the frees when hipSetDevice fails).
+thread_local std::unique_ptr<ThreadCache> g_thread_cache;
 ThreadCache& cache() {
-    static thread_local ThreadCache c;
-    return c;
+    if (!g_thread_cache) g_thread_cache.reset(new ThreadCache());
+    return *g_thread_cache;
+}
+void drop_thread_cache() { g_thread_cache.reset(); }
+[[noreturn]] void unsupported_rig(const char* what) {
+    std::fprintf(stderr, "msorb: %s — the fisheye / two-camera branches (Nleft != -1, ORBmatcher.cc:144-210, 1421-1426) are not "
+                         "served by this build; refusing to return plausible-looking associations\n", what);
+    std::abort();
 }
 msorb_host::DeviceFrame<Frame>& device_frame(const Frame& F, bool second = false) {
     ThreadCache& c = cache();
@@ -71,10 +84,23 @@ msorb_host::DeviceFrame<Frame>& device_keyframe(const std::shared_ptr<KeyFrame>&
 }
 }  // namespace
 
+// Lifetime hooks for the code around the matcher: declared in ORBmatcher.h.
+namespace msorb_host {
+void ForgetKeyFrame(unsigned long mnId) { keyframe_store().Forget(mnId); }
+void ResetKeyFrames() { keyframe_store().Reset(); }
+size_t ResidentKeyFrames() { return keyframe_store().Resident(); }
+void ReleaseThread() { drop_thread_cache(); }
+void Shutdown() {
+    drop_thread_cache();
+    keyframe_store().Shutdown();
+}
+}  // namespace msorb_host
+
 ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
 
 int ORBmatcher::SearchByProjection(Frame& F, const std::vector<std::shared_ptr<MapPoint>>& vpMapPoints, const float th,
                                    const bool bFarPoints, const float thFarPoints) {
+    if (F.Nleft != -1) unsupported_rig("ORBmatcher::SearchByProjection on a Frame with Nleft != -1");
     return msorb_host::SearchByProjection(device_frame(F), F, vpMapPoints, th, bFarPoints, thFarPoints, mfNNratio);
 }
 
@@ -152,7 +178,9 @@ int ORBmatcher::SearchBySim3(std::shared_ptr<KeyFrame> pKF1, std::shared_ptr<Key
 
 int ORBmatcher::Fuse(std::shared_ptr<KeyFrame> pKF, const std::vector<std::shared_ptr<MapPoint>>& vpMapPoints, const float th,
                      const bool bRight) {
-    (void)bRight;  // the right-camera pass (:1421-1426) exists for the fisheye two-camera rig only (NLeft != -1)
+    // the right-camera pass (:1421-1426) exists for the fisheye two-camera rig only (NLeft != -1): never answer it with the
+    // left-camera search
+    if (bRight || pKF->GetNLeft() != -1) unsupported_rig("ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight = true) / a KeyFrame with NLeft != -1");
     return msorb_host::Fuse(device_keyframe(pKF), pKF, vpMapPoints, th);
 }
 

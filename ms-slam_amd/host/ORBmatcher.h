@@ -9,6 +9,7 @@
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
 
+#include <cstddef>
 #include <memory>
 #include <set>
 #include <utility>
@@ -86,6 +87,25 @@ protected:
     bool mbCheckOrientation;
 };
 
+}  // namespace ORB_SLAM3
+
+// Lifetime hooks of the device-side state behind the class (ORBmatcher.cc).  The matcher keeps KeyFrames resident on the GPU
+// from their first BoW-node search on; the reference has no place that tells it when one dies, so the code around it does
+// ("Lifetime hooks"; each is one line in the reference's sources):
+//   KeyFrame::SetBadFlag (KeyFrame.cc)                      ORB_SLAM3::msorb_host::ForgetKeyFrame(mnId);
+//   Tracking::Reset / ResetActiveMap (Tracking.cc:3848)     ORB_SLAM3::msorb_host::ResetKeyFrames();   // KeyFrame::nNextId restarts at 0
+//   System::Shutdown (System.cc), after the threads joined  ORB_SLAM3::msorb_host::Shutdown();         // frees while the HIP runtime is alive
+//   a worker thread that stops using the matcher            ORB_SLAM3::msorb_host::ReleaseThread();    // its four device frames
+// Without the first two the store still answers correctly (entries are checked against the KeyFrame object's identity,
+// mbSparsified and N) but dead KeyFrames stay resident until Shutdown().
+namespace ORB_SLAM3 {
+namespace msorb_host {
+void ForgetKeyFrame(unsigned long mnId);
+void ResetKeyFrames();
+size_t ResidentKeyFrames();
+void ReleaseThread();
+void Shutdown();
+}  // namespace msorb_host
 }  // namespace ORB_SLAM3
 
 #endif  // ORBMATCHER_H

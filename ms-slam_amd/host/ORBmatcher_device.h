@@ -13,6 +13,9 @@
 //                                                        body of the relocalisation form (src/ORBmatcher.cc:2154-2275)
 //   ORB_SLAM3::msorb_host::SearchLocalPointsPrepass(...) the isInFrustum loop of Tracking::SearchLocalPoints
 //                                                        (src/Tracking.cc:3343-3361, src/Frame.cc:512-571)
+//   ORB_SLAM3::msorb_host::SearchLocalPoints(dev, F, vpLocalMapPoints, th, ...)
+//                                                        that loop AND the SearchByProjection call behind it (:3343-3388) as
+//                                                        one device chain (msorb_search_local_points)
 //   ORB_SLAM3::msorb_host::ComputeStereoMatches(...)     body of Frame::ComputeStereoMatches (src/Frame.cc:743-913)
 //   ORB_SLAM3::msorb_host::ExtractStereo(F, left, imLeft, imRight)
 //                                                        the two ExtractORB threads + ComputeStereoMatches of the stereo
@@ -289,6 +292,92 @@ int SearchLocalPointsPrepass(FrameT& F, const std::vector<MapPointPtr>& vpLocalM
         }
     }
     return nToMatch;
+}
+
+// Tracking::SearchLocalPoints from its second loop on (src/Tracking.cc:3343-3388) as ONE device chain: the isInFrustum loop
+// above AND matcher.SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th, bFarPoints, thFarPoints) behind
+// msorb_search_local_points — one upload of the local map, frustum test + window queries + window search on the device, one
+// read-back, the sequential claims replayed on the host.  Same MapPoint scratch fields, IncreaseVisible(), mmProjectPoints
+// and F.mvpMapPoints as SearchLocalPointsPrepass followed by SearchByProjection; returns nmatches (*nToMatch = the loop's
+// counter).  `dev` holds F (dev.Upload(F), or filled on the device by ExtractStereoFrame).
+template <class FrameT, class MapPointPtr>
+int SearchLocalPoints(DeviceFrame<FrameT>& dev, FrameT& F, const std::vector<MapPointPtr>& vpLocalMapPoints, const float th,
+                      const bool bFarPoints, const float thFarPoints, const float mfNNratio, int* nToMatch = nullptr,
+                      float viewingCosLimit = 0.5f) {
+    const int M = (int)vpLocalMapPoints.size(), N = (int)F.mvpMapPoints.size();
+    std::unordered_map<const void*, int> index;
+    index.reserve((size_t)M * 2);
+    for (int i = 0; i < M; i++) index.emplace(vpLocalMapPoints[i].get(), i);
+    std::vector<int> frameMp(N, -1), extraObs;
+    for (int i = 0; i < N; i++) {   // map points the frame holds that are not local: only their Observations() matter (:88-90)
+        if (!F.mvpMapPoints[i]) continue;
+        auto it = index.find(F.mvpMapPoints[i].get());
+        if (it != index.end()) { frameMp[i] = it->second; continue; }
+        frameMp[i] = M + (int)extraObs.size();
+        index.emplace(F.mvpMapPoints[i].get(), frameMp[i]);
+        extraObs.push_back(F.mvpMapPoints[i]->Observations());
+    }
+    const int T = M + (int)extraObs.size();
+    msorb_frustum fr{};
+    const auto Tcw = F.GetPose();
+    const auto R = Tcw.rotationMatrix();
+    const auto t = Tcw.translation();
+    const auto Ow = F.GetCameraCenter();
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) fr.Rcw[3 * r + c] = R(r, c);
+        fr.tcw[r] = t(r);
+        fr.Ow[r] = Ow(r);
+    }
+    fr.fx = F.mpCamera->getParameter(0); fr.fy = F.mpCamera->getParameter(1);
+    fr.cx = F.mpCamera->getParameter(2); fr.cy = F.mpCamera->getParameter(3);
+    fr.min_x = F.mnMinX; fr.max_x = F.mnMaxX; fr.min_y = F.mnMinY; fr.max_y = F.mnMaxY;
+    fr.mbf = F.mbf; fr.log_scale_factor = F.mfLogScaleFactor; fr.n_scale_levels = F.mnScaleLevels;
+    std::vector<float> pos((size_t)3 * T, 0.f), nrm((size_t)3 * T, 0.f), maxd(T, 0.f), mind(T, 0.f), px(T), py(T), pxr(T), depth(T), vcos(T);
+    std::vector<int> level(T), obs(T, 0);
+    std::vector<uint8_t> visit(T, 0), bad(T, 0), spars(T, 0), desc((size_t)T * 32, 0), inView(T);
+    for (int i = 0; i < M; i++) {
+        const auto& p = vpLocalMapPoints[i];
+        bad[i] = p->isBad();
+        visit[i] = !(p->mnLastFrameSeen == F.mnId) && !bad[i];           // Tracking.cc:3347-3350
+        spars[i] = p->mbSparsified;
+        obs[i] = p->Observations();
+        const auto P = p->GetWorldPos();
+        const auto Nn = p->GetNormal();
+        for (int c = 0; c < 3; c++) { pos[3 * i + c] = P(c); nrm[3 * i + c] = Nn(c); }
+        maxd[i] = p->GetMaxDistance();
+        mind[i] = p->GetMinDistance();
+        const auto d = p->GetDescriptor();
+        std::memcpy(&desc[(size_t)i * 32], d.template ptr<unsigned char>(0), 32);
+    }
+    for (int k = 0; k < (int)extraObs.size(); k++) obs[M + k] = extraObs[k];
+    const std::vector<int> before = frameMp;
+    int nmatches = 0;
+    check(msorb_search_local_points(dev.get(), &fr, viewingCosLimit, T, pos.data(), nrm.data(), maxd.data(), mind.data(), visit.data(),
+                                    bad.data(), spars.data(), desc.data(), obs.data(), frameMp.data(), th, bFarPoints ? 1 : 0,
+                                    thFarPoints, mfNNratio, inView.data(), px.data(), py.data(), pxr.data(), depth.data(), level.data(),
+                                    vcos.data(), &nmatches),
+          "msorb_search_local_points");
+    int nIn = 0;
+    for (int i = 0; i < M; i++) {
+        if (!visit[i]) continue;
+        const auto& p = vpLocalMapPoints[i];
+        p->mbTrackInView = inView[i] != 0;           // Frame.cc:515-517, 563
+        p->mTrackProjX = px[i];
+        p->mTrackProjY = py[i];
+        if (inView[i]) {                             // :563-571
+            p->mTrackProjXR = pxr[i];
+            p->mTrackDepth = depth[i];
+            p->mnTrackScaleLevel = level[i];
+            p->mTrackViewCos = vcos[i];
+            p->IncreaseVisible();                    // Tracking.cc:3354-3355
+            nIn++;
+            F.mmProjectPoints[p->mnId] = {p->mTrackProjX, p->mTrackProjY};  // :3357-3360
+        }
+    }
+    if (nToMatch) *nToMatch = nIn;
+    for (int i = 0; i < N; i++)
+        if (frameMp[i] != before[i] && frameMp[i] >= 0 && frameMp[i] < M) F.mvpMapPoints[i] = vpLocalMapPoints[frameMp[i]];
+    return nmatches;
 }
 
 // ---- SearchByBoW ----------------------------------------------------------------------------------------------
@@ -657,48 +746,78 @@ int SearchForTriangulation(const KeyFramePtr& pKF1, const KeyFramePtr& pKF2, std
 // call instead of both KeyFrames: 0.12-0.15 ms instead of 0.65-1.1 ms for 16 neighbours / 32 candidates (profiles/).
 class KeyFrameStore {
 public:
-    explicit KeyFrameStore(int device = 0) { check(msorb_kf_store_create(device, &h_), "msorb_kf_store_create"); }
-    ~KeyFrameStore() { msorb_kf_store_destroy(h_); }
+    // One resident KeyFrame.  A search holds a Lease (shared ownership) from Ensure() until its kernels have returned: the
+    // device rows are removed when the LAST holder lets go — a re-add after map sparsification, Forget() or Reset() on
+    // another thread only drops the table's reference, it never pulls an id out from under a running search.
+    struct Handle {  // the C handle; shared with the slots so that a lease that outlives Shutdown() never touches a freed store
+        msorb_kf_store* h = nullptr;
+        ~Handle() { if (h) msorb_kf_store_destroy(h); }
+    };
+    struct Slot {
+        std::shared_ptr<Handle> store;
+        int id;
+        const void* identity;  // the KeyFrame object: mnId alone is not an identity (KeyFrame::nNextId restarts at 0 in Tracking::Reset)
+        bool sparsified;
+        int n;
+        ~Slot() { if (store && store->h && id >= 0) msorb_kf_store_remove(store->h, id); }
+    };
+    using Lease = std::shared_ptr<Slot>;
+
+    explicit KeyFrameStore(int device = 0) : h_(std::make_shared<Handle>()) { check(msorb_kf_store_create(device, &h_->h), "msorb_kf_store_create"); }
+    ~KeyFrameStore() { Shutdown(); }
     KeyFrameStore(const KeyFrameStore&) = delete;
     KeyFrameStore& operator=(const KeyFrameStore&) = delete;
-    msorb_kf_store* get() const { return h_; }
+    msorb_kf_store* get() const { return h_ ? h_->h : nullptr; }
 
+    // The lock is held across lookup, upload and insert: two threads that miss on the same KeyFrame (TrackReferenceKeyFrame's
+    // SearchByBoW and CreateNewMapPoints' SearchForTriangulation on the newest KeyFrame) produce ONE add; the second waits
+    // and finds the first one's slot.
     template <class KeyFramePtr>
-    int Ensure(const KeyFramePtr& pKF) {
+    Lease Ensure(const KeyFramePtr& pKF) {
         const int n = pKF->GetN();
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            auto it = ids_.find(pKF->mnId);
-            if (it != ids_.end() && it->second.sparsified == pKF->mbSparsified && it->second.n == n) return it->second.id;
-        }
+        const void* identity = static_cast<const void*>(&*pKF);
+        std::lock_guard<std::mutex> lk(mu_);
+        if (!h_) throw std::runtime_error("msorb KeyFrameStore used after Shutdown()");
+        auto it = ids_.find(pKF->mnId);
+        if (it != ids_.end() && it->second->identity == identity && it->second->sparsified == pKF->mbSparsified && it->second->n == n)
+            return it->second;
         BowSide side;
         side.FillKeyFrame(pKF);
         const auto keys = pKF->GetAllKeyUn();
         static_assert(sizeof(keys[0]) == sizeof(msorb_keypoint), "cv::KeyPoint must be the 28-byte layout");
         int id = -1;
-        check(msorb_kf_store_add(h_, n, reinterpret_cast<const msorb_keypoint*>(keys.data()), side.desc.data(), (int)side.node.size(),
+        check(msorb_kf_store_add(h_->h, n, reinterpret_cast<const msorb_keypoint*>(keys.data()), side.desc.data(), (int)side.node.size(),
                                  side.node.data(), side.begin.data(), side.feat.data(), pKF->mvScaleFactors.data(),
                                  pKF->mvLevelSigma2.data(), (int)pKF->mvScaleFactors.size(), &id),
               "msorb_kf_store_add");
-        std::lock_guard<std::mutex> lk(mu_);
-        auto it = ids_.find(pKF->mnId);
-        if (it != ids_.end()) msorb_kf_store_remove(h_, it->second.id);  // the compacted (or concurrently added) predecessor
-        ids_[pKF->mnId] = Rec{id, pKF->mbSparsified, n};
-        return id;
+        Lease slot(new Slot{h_, id, identity, (bool)pKF->mbSparsified, n});
+        ids_[pKF->mnId] = slot;  // the compacted / recycled predecessor loses the table's reference; running searches keep theirs
+        return slot;
     }
     void Forget(unsigned long mnId) {  // KeyFrame::SetBadFlag
         std::lock_guard<std::mutex> lk(mu_);
-        auto it = ids_.find(mnId);
-        if (it == ids_.end()) return;
-        msorb_kf_store_remove(h_, it->second.id);
-        ids_.erase(it);
+        ids_.erase(mnId);
+    }
+    void Reset() {  // Tracking::Reset / ResetActiveMap: KeyFrame ids start again at 0
+        std::lock_guard<std::mutex> lk(mu_);
+        ids_.clear();
+    }
+    size_t Resident() {
+        std::lock_guard<std::mutex> lk(mu_);
+        return ids_.size();
+    }
+    // System::Shutdown: free the device side while the HIP runtime is still alive.  The C handle goes when its last holder
+    // does — here, unless a lease is still out (there should be none: the worker threads have been joined).
+    void Shutdown() {
+        std::lock_guard<std::mutex> lk(mu_);
+        ids_.clear();
+        h_.reset();
     }
 
 private:
-    struct Rec { int id; bool sparsified; int n; };
-    msorb_kf_store* h_ = nullptr;
+    std::shared_ptr<Handle> h_;
     std::mutex mu_;
-    std::unordered_map<unsigned long, Rec> ids_;
+    std::unordered_map<unsigned long, Lease> ids_;
 };
 
 // SearchForTriangulationBatch with the KeyFrames resident (same results)
@@ -719,7 +838,8 @@ std::vector<int> SearchForTriangulationBatch(KeyFrameStore& store, const KeyFram
     };
     Flags a;
     flags_of(pKF1, a);
-    const int id1 = store.Ensure(pKF1);
+    const KeyFrameStore::Lease l1 = store.Ensure(pKF1);
+    std::vector<KeyFrameStore::Lease> l2(K);   // held until the search has returned
     std::vector<Flags> b(K);
     std::vector<msorb_triangulation_kf_pair> pairs(K);
     std::vector<std::vector<int>> m12(K);
@@ -727,7 +847,8 @@ std::vector<int> SearchForTriangulationBatch(KeyFrameStore& store, const KeyFram
         flags_of(vpKF2[k], b[k]);
         msorb_triangulation_kf_pair& P = pairs[k];
         P = msorb_triangulation_kf_pair{};
-        P.kf1 = id1; P.kf2 = store.Ensure(vpKF2[k]);
+        l2[k] = store.Ensure(vpKF2[k]);
+        P.kf1 = l1->id; P.kf2 = l2[k]->id;
         P.valid1 = a.free_.data(); P.avail2 = b[k].free_.data(); P.stereo1 = a.stereo.data(); P.stereo2 = b[k].stereo.data();
         TriangulationGeometry(pKF1, vpKF2[k], P.F12, P.ep);
         m12[k].assign(a.free_.size(), -1);
@@ -759,13 +880,15 @@ std::vector<int> SearchByBoWBatch(KeyFrameStore& store, const std::vector<KeyFra
     std::vector<std::vector<uint8_t>> good(K);
     std::vector<std::vector<int>> m12(K), m21(K);
     std::vector<msorb_bow_kf_pair> pairs(K);
+    std::vector<KeyFrameStore::Lease> lease(K);   // held until the search has returned
     for (size_t k = 0; k < K; k++) {
         mpsKF[k] = vpKFs[k]->GetMapPointMatches();
         good[k].assign(mpsKF[k].size(), 0);
         for (size_t i = 0; i < mpsKF[k].size(); i++) good[k][i] = mpsKF[k][i] && !mpsKF[k][i]->isBad();   // :253-259
         m12[k].assign(mpsKF[k].size(), -1);
         m21[k].assign(F.N, -1);
-        pairs[k] = msorb_bow_kf_pair{store.Ensure(vpKFs[k]), -1, good[k].data(), nullptr, m12[k].data(), m21[k].data(), 0};
+        lease[k] = store.Ensure(vpKFs[k]);
+        pairs[k] = msorb_bow_kf_pair{lease[k]->id, -1, good[k].data(), nullptr, m12[k].data(), m21[k].data(), 0};
     }
     check(msorb_search_by_bow_kf(store.get(), pairs.data(), (int)K, &bf, 50 /* TH_LOW */, 1, mfNNratio, mbCheckOrientation, nullptr),
           "msorb_search_by_bow_kf");

@@ -1187,3 +1187,49 @@ def track_batch(d_kps, d_desc, d_u_right, counts, frame_step, bounds, scale_fact
     if want_grid:
         r["cell_begin"], r["cell_idx"] = d_cb, d_ci
     return r
+
+
+class TrackFrontendRunner:
+    """msorb_track_frontend / msorb_extract_stereo_frame + msorb_search_local_points with every buffer and ctypes argument
+    prepared once — the per-frame cost that remains is the library call itself (what bench.py times at B = 1)."""
+
+    def __init__(self, ex, left, right, mb, mbf, frustum, mp, th, bFarPoints=False, thFarPoints=50.0, nnratio=0.8,
+                 viewing_cos_limit=0.5, device=0):
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        self.ex, self.L = ex, ex.L
+        self.left, self.right = np.ascontiguousarray(left, np.uint8), np.ascontiguousarray(right, np.uint8)
+        rows, cols = self.left.shape
+        cap = ex.capacity
+        self.f = _empty_frame(device)
+        self.kl, self.kr = np.zeros(cap, KP_DTYPE), np.zeros(cap, KP_DTYPE)
+        self.dl, self.dr = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
+        self.ur, self.dp = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+        self.nl, self.nr, self.oob, self.nm, self.rounds = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        self.m, self.arrs = _lp_arrays(mp)
+        self.out = _lp_outputs(self.m)
+        self.frame_mp = np.full(cap, -1, np.int32)
+        self.frustum = frustum
+        stereo_t = [vp, vp, vp, vp, ci, ci, C.c_size_t, C.c_size_t, cf, cf, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, cf, cf, cf, cf]
+        lp_t = [vp, cf, ci] + [vp] * 10 + [cf, ci, cf, cf] + [vp] * 7 + [C.POINTER(ci)]
+        self.L.msorb_track_frontend.argtypes = stereo_t + lp_t + [C.POINTER(ci)]
+        self.L.msorb_extract_stereo_frame.argtypes = stereo_t
+        self.L.msorb_search_local_points.argtypes = [vp] + lp_t
+        self._stereo = (ex.h, self.f.h, _np_ptr(self.left), _np_ptr(self.right), rows, cols, cols, cols, mb, mbf, _np_ptr(self.kl),
+                        _np_ptr(self.dl), C.byref(self.nl), _np_ptr(self.kr), _np_ptr(self.dr), C.byref(self.nr), cap, _np_ptr(self.ur),
+                        _np_ptr(self.dp), C.byref(self.oob), 0.0, float(cols), 0.0, float(rows))
+        self._lp = (C.addressof(frustum), viewing_cos_limit, self.m) + tuple(None if a is None else _np_ptr(a) for a in self.arrs) + \
+            (_np_ptr(self.frame_mp), th, int(bFarPoints), thFarPoints, nnratio) + tuple(_np_ptr(self.out[k]) for k in _LP_OUT_ORDER) + \
+            (C.byref(self.nm),)
+
+    def one_call(self):
+        _check(self.L.msorb_track_frontend(*self._stereo, *self._lp, C.byref(self.rounds)), "msorb_track_frontend")
+        return self.nm.value
+
+    def two_calls(self):
+        _check(self.L.msorb_extract_stereo_frame(*self._stereo), "msorb_extract_stereo_frame")
+        self.frame_mp[:] = -1
+        _check(self.L.msorb_search_local_points(self.f.h, *self._lp), "msorb_search_local_points")
+        return self.nm.value
+
+    def close(self):
+        self.f.close()

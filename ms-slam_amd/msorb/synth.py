@@ -75,3 +75,52 @@ def stereo_batch(n_pairs, rows, cols, seed0=0):
     for i in range(n_pairs):
         out[2 * i], out[2 * i + 1] = stereo_pair(seed0 + i, rows, cols)
     return out
+
+
+KITTI_CAM = dict(fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, mbf=386.1448)   # Examples/Stereo/KITTI00-02.yaml
+
+
+def local_map(seed, kps, desc, depth, scale, m, pose=None, copy_frac=0.7, bad_frac=0.03, spars_frac=0.05, obs_zero_frac=0.15,
+              skip_frac=0.1, max_flips=40, cam=KITTI_CAM, bounds=(0.0, 1241.0, 0.0, 376.0)):
+    """A tracking-loop workload: m local map points in WORLD coordinates for the camera pose
+    (Rcw, tcw) — default identity —, copy_frac of them on the viewing ray of a keypoint (a few pixels off, at its stereo
+    depth when it has one) with the keypoint's descriptor up to max_flips bits away, the rest anywhere around the view with
+    random descriptors.  Vectorised numpy, seeded.  -> dict(pos_w, normal, max_distance, min_distance, visit, bad,
+    sparsified, desc, obs, flags) as msorb_search_local_points / msorb_track_batch take them."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    R, t = (np.eye(3, dtype=np.float32), np.zeros(3, np.float32)) if pose is None else pose
+    Ow = (-(R.T.astype(np.float64) @ t.astype(np.float64))).astype(np.float32)
+    n, nlev = len(kps), len(scale)
+    src = rng.integers(0, max(n, 1), m)
+    is_copy = (rng.random(m) < copy_frac) & (n > 0)
+    kx = kps["x"][src] if n else np.zeros(m, np.float32)
+    ky = kps["y"][src] if n else np.zeros(m, np.float32)
+    ko = kps["octave"][src] if n else np.zeros(m, np.int32)
+    kd = depth[src] if n else np.full(m, -1.0, np.float32)
+    u = np.where(is_copy, kx + rng.normal(0, 2.0, m), rng.uniform(bounds[0] - 100, bounds[1] + 100, m))
+    v = np.where(is_copy, ky + rng.normal(0, 2.0, m), rng.uniform(bounds[2] - 60, bounds[3] + 60, m))
+    z = np.where(is_copy & (kd > 0), kd * rng.uniform(0.97, 1.03, m), rng.uniform(2.0, 70.0, m))
+    Pc = np.stack([(u - cam["cx"]) * z / cam["fx"], (v - cam["cy"]) * z / cam["fy"], z], 1)
+    Pw = ((Pc - t.astype(np.float64)) @ R.astype(np.float64)).astype(np.float32)
+    po = Pw.astype(np.float64) - Ow.astype(np.float64)
+    d = np.linalg.norm(po, axis=1) + 1e-9
+    nrm = po / d[:, None] + rng.normal(scale=0.35, size=po.shape)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    lvl = np.where(is_copy, ko + rng.integers(0, 2, m), rng.integers(0, nlev, m)).clip(0, nlev - 1)
+    maxd = (d * np.asarray(scale, np.float64)[lvl] * rng.uniform(0.93, 1.0, m)).astype(np.float32)
+    mind = (maxd / np.float32(scale[-1])).astype(np.float32)
+    dsc = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    if n:
+        cp = desc[src].copy()
+        nf = rng.integers(0, max_flips + 1, m)
+        for k in range(max_flips):   # flip k-th random bit of the points that still have flips to spend (repeats may cancel)
+            bit = rng.integers(0, 256, m)
+            on = (k < nf)
+            cp[np.arange(m)[on], (bit >> 3)[on]] ^= (1 << (bit & 7)[on]).astype(np.uint8)
+        dsc = np.where(is_copy[:, None], cp, dsc).astype(np.uint8)
+    visit = (rng.random(m) >= skip_frac).astype(np.uint8)
+    bad = (rng.random(m) < bad_frac).astype(np.uint8)
+    spars = (rng.random(m) < spars_frac).astype(np.uint8)
+    return dict(pos_w=Pw, normal=nrm.astype(np.float32), max_distance=maxd, min_distance=mind, visit=visit, bad=bad,
+                sparsified=spars, desc=dsc, obs=np.where(rng.random(m) < obs_zero_frac, 0, rng.integers(1, 12, m)).astype(np.int32),
+                flags=(visit | (bad << 1) | (spars << 2)).astype(np.uint8), Rcw=R, tcw=t, Ow=Ow)

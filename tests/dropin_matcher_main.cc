@@ -268,9 +268,71 @@ static int reloc_main(const char* in, const char* out) {
     return 0;
 }
 
+// mode "local": Tracking::SearchLocalPoints from its second loop on (isInFrustum loop + SearchByProjection) through
+// msorb_host::SearchLocalPoints — one device chain (msorb_search_local_points)
+static int local_main(const char* in, const char* out) {
+    using namespace ORB_SLAM3;
+    FILE* f = fopen(in, "rb");
+    if (!f) return 3;
+    const auto hdr = rd<int>(f, 4);  // N, nlevels, M, bFarPoints
+    const int N = hdr[0], nlev = hdr[1], M = hdr[2];
+    const auto fl = rd<float>(f, 9 + 3 + 3 + 4 + 4 + 2 + 3);  // R, t, Ow, fx fy cx cy, bounds, mbf, logScale, th, thFar, nnratio
+    Frame F;
+    F.mnId = 42;
+    F.N = N;
+    F.mvKeysUn = rd<cv::KeyPoint>(f, N);
+    std::vector<unsigned char> desc = rd<unsigned char>(f, (size_t)N * 32);
+    F.mDescriptors = cv::Mat(N, 32, CV_8UC1, desc.data(), 32);
+    F.mvuRight = rd<float>(f, N);
+    F.mvScaleFactors = rd<float>(f, nlev);
+    memcpy(F.mTcw.R.m, &fl[0], 36); memcpy(F.mTcw.t.v, &fl[9], 12); memcpy(F.mOw.v, &fl[12], 12);
+    Camera cam{{fl[15], fl[16], fl[17], fl[18]}};
+    F.mpCamera = &cam;
+    Frame::mnMinX = fl[19]; Frame::mnMaxX = fl[20]; Frame::mnMinY = fl[21]; Frame::mnMaxY = fl[22];
+    F.mbf = fl[23]; F.mfLogScaleFactor = fl[24]; F.mnScaleLevels = nlev;
+    const auto pos = rd<float>(f, (size_t)3 * M), nrm = rd<float>(f, (size_t)3 * M), maxd = rd<float>(f, M), mind = rd<float>(f, M);
+    const auto skip_seen = rd<unsigned char>(f, M), bad = rd<unsigned char>(f, M), spars = rd<unsigned char>(f, M);
+    const auto obs = rd<int>(f, M);
+    const auto mdesc = rd<unsigned char>(f, (size_t)M * 32);
+    const auto init = rd<int>(f, N);
+    fclose(f);
+    std::vector<std::shared_ptr<MapPoint>> all(M);
+    for (int i = 0; i < M; i++) {
+        auto p = std::make_shared<MapPoint>();
+        p->mnId = 1000 + i; p->id = i;
+        memcpy(p->pos.v, &pos[3 * i], 12); memcpy(p->normal.v, &nrm[3 * i], 12);
+        p->mfMaxDistance = maxd[i]; p->mfMinDistance = mind[i];
+        p->mnLastFrameSeen = skip_seen[i] ? F.mnId : 7; p->mbBad = bad[i]; p->mbSparsified = spars[i]; p->nObs = obs[i];
+        p->mbTrackInView = false;   // Tracking.cc:3326-3328 for the points of the first loop; new points start false (MapPoint.cc:60)
+        memcpy(p->descriptor, &mdesc[(size_t)i * 32], 32);
+        all[i] = p;
+    }
+    F.mvpMapPoints.assign(N, nullptr);
+    for (int i = 0; i < N; i++) if (init[i] >= 0) F.mvpMapPoints[i] = all[init[i]];
+    std::vector<char> held(M, 0);
+    for (int i = 0; i < N; i++) if (init[i] >= 0) held[init[i]] = 1;
+    std::vector<std::shared_ptr<MapPoint>> local;   // held points: every second one is not local (the adapter's "extra" entries)
+    for (int i = 0; i < M; i++) if (!(held[i] && (i & 1))) local.push_back(all[i]);
+    msorb_host::DeviceFrame<Frame> dev;
+    dev.Upload(F);
+    int nToMatch = -1;
+    const int nmatches = msorb_host::SearchLocalPoints(dev, F, local, fl[25], hdr[3] != 0, fl[26], fl[27], &nToMatch);
+    FILE* o = fopen(out, "wb");
+    fwrite(&nmatches, 4, 1, o); fwrite(&nToMatch, 4, 1, o);
+    for (int i = 0; i < N; i++) { const int id = F.mvpMapPoints[i] ? F.mvpMapPoints[i]->id : -1; fwrite(&id, 4, 1, o); }
+    for (int i = 0; i < M; i++) {
+        const auto& p = all[i];
+        const int iv = p->mbTrackInView, pp = (int)F.mmProjectPoints.count(p->mnId);
+        fwrite(&iv, 4, 1, o); fwrite(&p->nVisible, 4, 1, o); fwrite(&pp, 4, 1, o);
+    }
+    fclose(o);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     using namespace ORB_SLAM3;
     if (argc < 3) return 2;
+    if (argc > 3 && std::string(argv[3]) == "local") return local_main(argv[1], argv[2]);
     if (argc > 3 && std::string(argv[3]) == "prepass") return prepass_main(argv[1], argv[2]);
     if (argc > 3 && std::string(argv[3]) == "reloc") return reloc_main(argv[1], argv[2]);
     if (argc > 3 && std::string(argv[3]) == "frames") return frames_main(argv[1], argv[2]);

@@ -707,3 +707,73 @@ def test_cpp_stereo_frame_constructor_one_call(tmp_path, oracle, msorb_mod):
     _, okl, odl = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)(L)
     assert np.array_equal(a[0].view(np.uint8), okl.view(np.uint8)) and np.array_equal(a[2], odl)
     assert (a[4] > 0).sum() > 500
+
+
+def test_cpp_search_local_points_chain_matches_oracle(tmp_path, oracle, msorb_mod):
+    """msorb_host::SearchLocalPoints (Tracking::SearchLocalPoints from its second loop on — the isInFrustum loop AND the
+    SearchByProjection call — as one device chain) over stand-in Frame / MapPoint objects vs the oracle's composition of
+    Frame::isInFrustum and ORBmatcher::SearchByProjection: nmatches, nToMatch, F.mvpMapPoints, mbTrackInView, IncreaseVisible,
+    mmProjectPoints."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import frustum_cases as fc
+    import matcher_cases as mc
+    import track_cases as tc
+    exe = tmp_path / "dropin_matcher"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", f"-I{ROOT}/tests/cv_stub", f"-I{ROOT}/ms-slam_amd/host",
+                           f"-I{ROOT}/include", f"{ROOT}/tests/dropin_matcher_main.cc", f"-L{ROOT}/ms-slam_amd", "-lmsorb",
+                           f"-Wl,-rpath,{ROOT}/ms-slam_amd", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    cfg = synth.KITTI
+    L, Rimg = synth.stereo_pair(33, cfg["rows"], cfg["cols"])
+    ex = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7)
+    mbf, mb = mc.KITTI_BF, mc.KITTI_BF / mc.KITTI_FX
+    try:
+        kl, dl, kr, dr, ur, dp, _ = ex.extract_stereo(L, Rimg, mb, mbf)
+        scale = np.asarray(ex.GetScaleFactors(), np.float32)
+    finally:
+        ex.close()
+    N, M, nlev = len(kl), 5000, 8
+    rng = np.random.default_rng(6)
+    w = rng.normal(scale=0.02, size=3)
+    ang = np.linalg.norm(w)
+    k = w / ang
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = (np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K).astype(np.float32)
+    t = rng.normal(scale=0.3, size=3).astype(np.float32)
+    Ow = (-(R.T.astype(np.float64) @ t.astype(np.float64))).astype(np.float32)
+    mp = tc.local_map(14, kl, dl, ur, dp, R, t, Ow, scale, M)
+    seen = (1 - mp["visit"]).astype(np.uint8)      # "already matched in this frame": mnLastFrameSeen == mnId
+    c = fc.KITTI_CAM
+    logs = float(np.log(np.float32(1.2)))
+    th, far, th_far, nnratio = 3.0, 1, 45.0, 0.8
+    init = np.where(rng.random(N) < 0.15, rng.integers(0, M, N), -1).astype(np.int32)
+    blob, out = tmp_path / "lin.bin", tmp_path / "lout.bin"
+    with open(blob, "wb") as f:
+        f.write(struct.pack("<4i", N, nlev, M, far))
+        f.write(np.asarray(R, np.float32).tobytes() + np.asarray(t, np.float32).tobytes() + np.asarray(Ow, np.float32).tobytes())
+        f.write(struct.pack("<4f4f2f3f", c["fx"], c["fy"], c["cx"], c["cy"], *c["bounds"], c["mbf"], logs, th, th_far, nnratio))
+        for a in (kl, dl, ur, scale, mp["pos_w"], mp["normal"], mp["max_distance"], mp["min_distance"], seen, mp["bad"], mp["sparsified"],
+                  mp["obs"], mp["desc"], init):
+            f.write(np.ascontiguousarray(a).tobytes())
+    subprocess.check_call([str(exe), str(blob), str(out), "local"])
+    raw = out.read_bytes()
+    nmatches, n_to_match = struct.unpack_from("<2i", raw, 0)
+    got_mp = np.frombuffer(raw, np.int32, N, 8)
+    rec = np.frombuffer(raw, np.dtype([("inview", "<i4"), ("visible", "<i4"), ("proj", "<i4")]), M, 8 + 4 * N)
+    # the oracle's composition.  The C++ side hands the matcher only part of the table as "local" points (held points with an
+    # odd index are frame-held extras): those are never queries
+    held = np.zeros(M, bool)
+    held[init[init >= 0]] = True
+    not_local = held & (np.arange(M) % 2 == 1)
+    mpo = dict(mp)
+    mpo["visit"] = (mp["visit"].astype(bool) & ~mp["bad"].astype(bool) & ~not_local).astype(np.uint8)
+    F = msorb_mod.Frustum.make(R, t, Ow, c["fx"], c["fy"], c["cx"], c["cy"], c["bounds"], c["mbf"], logs, nlev)
+    rf = oracle.OracleFrame(kl, dl, ur, c["bounds"], scale)
+    want_mp = init.copy()
+    rnm, r, visit = tc.oracle_local_points(oracle, rf, F, mpo, want_mp, th, bool(far), th_far, nnratio)
+    assert nmatches == rnm > 300
+    assert np.array_equal(got_mp, want_mp)
+    iv = r["track_in_view"].astype(bool) & visit
+    assert n_to_match == int(iv.sum())
+    assert np.array_equal(rec["inview"].astype(bool), iv)
+    assert np.array_equal(rec["visible"], iv.astype(np.int32)) and np.array_equal(rec["proj"], iv.astype(np.int32))
