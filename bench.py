@@ -218,6 +218,190 @@ def tracking_cpu_leg(tracking, msorb, oracle_dir):
                                           f"{reps} repetitions", "gpu_matches_cpu": bool(g_nm == nm and np.array_equal(g_mp, frame_mp))}
 
 
+def split_self_validation(msorb, torch, dist, stereo_split, rank, world, eye, half, ex_own, ex_other, make_ex, images, other_images,
+                          mine, theirs, rank_value, dev):
+    """Untimed, after the timed region of a --gpus N run: (1) who took part (ranks, devices, backend), (2) one more exchange, after
+    which every rank checks the features it RECEIVED for its pairs against a local extraction of the same images (it holds the
+    other eye's images of the pairs it joins) — bit for bit —, and that the stereo association on (own, gathered) features
+    equals the association on (own, locally extracted) ones: the split path gives the single-GPU result; (3) per-rank rates.
+    An assertion failure here aborts the run: a wrong 2-GPU number is never printed."""
+    backend = dist.get_backend()
+    info = [None] * world
+    dist.all_gather_object(info, {"rank": rank, "device": torch.cuda.get_device_name(dev), "cuda_index": dev.index,
+                                  "mkeypoints_per_s": round(rank_value / 1e6, 3)})
+    ones = torch.ones(1, dtype=torch.int32, device=dev)
+    dist.all_reduce(ones)
+    # fresh extraction of this rank's images + exchange
+    counts, _, _, _ = ex_own.extract_batch(images, (0, 0), out=(mine.kps, mine.desc))
+    mine.counts.copy_(torch.from_numpy(counts))
+    works = stereo_split.swap_halves_async(dist, rank, world, mine, theirs)
+    stereo_split.finish(works)
+    same_features = same_assoc = None
+    if works:
+        ex_chk = make_ex()
+        try:
+            c_loc, _, k_loc, d_loc = ex_chk.extract_batch(other_images)          # the other eye of my pairs, extracted HERE
+            got_c = theirs.counts.cpu().numpy()
+            same_features = bool(np.array_equal(got_c, c_loc[:half]))
+            for i in range(half):
+                n = int(c_loc[i])
+                same_features = same_features and bool(torch.equal(theirs.kps[i, :n], k_loc[i, :n]) and torch.equal(theirs.desc[i, :n], d_loc[i, :n]))
+            own = (mine.counts[:half], mine.kps[:half], mine.desc[:half])
+            got = (theirs.counts, theirs.kps, theirs.desc)
+            loc = (torch.from_numpy(np.ascontiguousarray(c_loc[:half])).to(dev), k_loc[:half], d_loc[:half])
+            ex_other.pyramid_batch(other_images)
+            if eye == 0:
+                ur_split = msorb.stereo_matches_split(ex_own, ex_other, *own, *got, KITTI_MB, KITTI_MBF)[0]
+                ur_local = msorb.stereo_matches_split(ex_own, ex_chk, *own, *loc, KITTI_MB, KITTI_MBF)[0]
+            else:
+                ur_split = msorb.stereo_matches_split(ex_other, ex_own, *got, *own, KITTI_MB, KITTI_MBF)[0]
+                ur_local = msorb.stereo_matches_split(ex_chk, ex_own, *loc, *own, KITTI_MB, KITTI_MBF)[0]
+            same_assoc = bool(torch.equal(ur_split, ur_local))
+            matched = int((ur_split > 0).sum().item())
+        finally:
+            ex_chk.close()
+        assert same_features, f"rank {rank}: the gathered features differ from a local extraction of the same images"
+        assert same_assoc, f"rank {rank}: the split stereo association differs from the single-GPU association"
+    flags = [None] * world
+    dist.all_gather_object(flags, {"rank": rank, "gathered_features_equal_local": same_features, "split_association_equals_local": same_assoc,
+                                   "matched": matched if works else None})
+    return {"backend": backend, "rccl": backend == "nccl", "ranks_seen": int(ones.item()), "ranks": info,
+            "bytes_exchanged_per_step_and_rank": {"sent": sum(t[half:].numel() * t.element_size() for t in mine.tensors()),
+                                                  "received": theirs.nbytes()},
+            "checks": flags}
+
+
+def host_fed_leg(msorb, torch, exs, host_images, dev, cfg, pitch, steps=12):
+    """The same extraction fed from pinned HOST memory: the upload of batch k+1 (one hipMemcpy2D-shaped copy into the 64-byte
+    pitch planes, on a copy stream) runs while batch k is extracted.  What a pipeline that receives frames in host memory gets,
+    next to `value` (inputs already in HBM)."""
+    n = host_images.shape[0]
+    pinned = torch.from_numpy(np.ascontiguousarray(host_images)).pin_memory()
+    bufs = [torch.zeros((n, cfg["rows"], pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
+    views = [b[:, :, :cfg["cols"]] for b in bufs]
+    cs = torch.cuda.Stream(device=dev)
+    outs = [None, None]
+    for e in exs:
+        e.set_overlap(1, True)
+
+    def upload(k):
+        with torch.cuda.stream(cs):
+            views[k].copy_(pinned, non_blocking=True)
+
+    upload(0)
+    cs.synchronize()
+    t_up = time.perf_counter()
+    upload(1)
+    cs.synchronize()
+    t_up = time.perf_counter() - t_up
+    kp, t0 = 0, None
+    for k in range(steps + 2):
+        b = k & 1
+        exs[b].extract_batch_submit(views[b], (0, 0), out=outs[b])
+        outs[b] = exs[b]._pending[2]
+        if k >= 1:
+            counts, _, _, _ = exs[b ^ 1].extract_batch_wait()      # batch k-1 done: its buffer is free ...
+            if k >= 3:
+                kp += int(counts.sum())
+            upload(b ^ 1)                                          # ... for the upload of batch k+1, under batch k's kernels
+        if k == 1:
+            cs.synchronize()
+            t0 = time.perf_counter()                               # steady state from here: every step = one upload + one batch
+        else:
+            cs.synchronize()
+    counts, _, _, _ = exs[(steps + 1) & 1].extract_batch_wait()
+    kp += int(counts.sum())
+    dt = time.perf_counter() - t0
+    nbytes = pinned.numel()
+    return {"what": "extract+describe with every batch uploaded from pinned host memory (pitched copy) while the previous one is extracted",
+            "mkeypoints_per_s": round(kp / dt / 1e6, 2), "ms_per_step": round(dt / (steps + 0) * 1e3, 4),
+            "upload_ms_per_batch": round(t_up * 1e3, 4), "upload_gbs": round(nbytes / t_up / 1e9, 2), "bytes_per_batch": int(nbytes),
+            "bound": "PCIe (the upload of a batch takes longer than its kernels)"}
+
+
+def per_frame_leg(msorb, ex, left, right):
+    """What an unchanged Frame.cc caller sees per frame (host cv::Mat in, host keypoints / descriptors out; the drop-in class adds
+    the cv::Mat / std::vector conversions, ~0.01-0.04 ms, tools/latency_class.cc): msorb_extract on one image, and both eyes +
+    ComputeStereoMatches in one call (msorb_extract_stereo), buffers prepared once."""
+    import ctypes as C
+    L = ex.L
+    cap = ex.capacity
+    rows, cols = left.shape
+    left, right = np.ascontiguousarray(left), np.ascontiguousarray(right)
+    kl, kr = np.zeros(cap, msorb.KP_DTYPE), np.zeros(cap, msorb.KP_DTYPE)
+    dl, dr = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
+    ur, dp = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+    n, mono, nl, nr, oob = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    one = (ex.h, p(left), rows, cols, cols, 0, 0, p(kl), p(dl), cap, C.byref(n), C.byref(mono))
+    L.msorb_extract_stereo.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_float, C.c_float,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]
+    st = (ex.h, p(left), p(right), rows, cols, cols, cols, KITTI_MB, KITTI_MBF, p(kl), p(dl), C.byref(nl), p(kr), p(dr), C.byref(nr), cap,
+          p(ur), p(dp), C.byref(oob))
+    t1, t2 = [], []
+    for i in range(45):
+        t0 = time.perf_counter(); L.msorb_extract(*one); t1.append(time.perf_counter() - t0)
+    for i in range(45):
+        t0 = time.perf_counter(); L.msorb_extract_stereo(*st); t2.append(time.perf_counter() - t0)
+    m1, m2 = float(np.median(t1[5:])), float(np.median(t2[5:]))
+    return {"what": "one frame at a time through the C ABI from host images (B = 1): what the drop-in ORBextractor::operator() costs",
+            "ms_one_image": round(m1 * 1e3, 4), "ms_stereo_frame_one_call": round(m2 * 1e3, 4),
+            "keypoints_stereo_frame": int(nl.value + nr.value), "mkeypoints_per_s_stereo_frame": round((nl.value + nr.value) / m2 / 1e6, 2)}
+
+
+def sparsification_leg(msorb, cpu):
+    """BASELINE configs[4]: the per-window constraint-matrix build of MapSparsification::Sparsifying (MapSparsification.cc:58-151)
+    on a 4Seasons-like sliding window — 30 keyframes x 2000 slots, half of them tracked, 6000 map points, 100 keyframes outside
+    the window —: msorb_visibility_csr through the C ABI (host arrays in, CSR out), every buffer prepared once."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import sparsify_cases as sc
+    w = sc.window(11)
+    L = msorb.lib()
+    arrs = {k: np.ascontiguousarray(w[k], np.uint8 if k == "kf_in_window" else np.int32) for k in
+            ("kf_slot_begin", "slot_point", "slot_cell", "point_nobs", "obs_begin", "obs_kf", "kf_in_window", "kf_num_mps")}
+    K, S, P, KT = len(arrs["kf_slot_begin"]) - 1, len(arrs["slot_point"]), len(arrs["point_nobs"]), len(arrs["kf_in_window"])
+    cc, cr, cn = S + 1, S + K + KT + 1, 2 * S + len(arrs["obs_kf"]) + 1
+    col_point, obj = np.zeros(cc, np.int32), np.zeros(cc, np.float32)
+    row_begin, row_kind, row_owner, row_rhs = np.zeros(cr + 1, np.int32), np.zeros(cr, np.int32), np.zeros(cr, np.int32), np.zeros(cr, np.float32)
+    col_idx = np.zeros(cn, np.int32)
+    n_cols, n_rows, nnz, nmax = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L.msorb_visibility_csr.argtypes = ([C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] +
+                                       [C.c_void_p] * 2 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int] +
+                                       [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 3)
+    call = (0, K, p(arrs["kf_slot_begin"]), p(arrs["slot_point"]), p(arrs["slot_cell"]), P, p(arrs["point_nobs"]), p(arrs["obs_begin"]),
+            p(arrs["obs_kf"]), KT, p(arrs["kf_in_window"]), p(arrs["kf_num_mps"]), 100, 0, C.byref(n_cols), p(col_point), cc, C.byref(n_rows),
+            p(row_begin), p(row_kind), p(row_owner), p(row_rhs), cr, p(col_idx), cn, C.byref(nnz), p(obj), C.byref(nmax))
+    ts = []
+    for i in range(45):
+        t0 = time.perf_counter()
+        rc = L.msorb_visibility_csr(*call)
+        if i >= 5:
+            ts.append(time.perf_counter() - t0)
+        if rc:
+            raise RuntimeError("msorb_visibility_csr: %d" % rc)
+    out = {"what": "configs[4]: constraint matrix of one sparsification window (30 keyframes x 2000 slots, 64x48 grid, 100 outside "
+                   "keyframes) as CSR, msorb_visibility_csr through the C ABI, host arrays in and out",
+           "ms_per_window": round(float(np.median(ts)) * 1e3, 4), "slots": S, "observations": int(len(arrs["obs_kf"])),
+           "cols": n_cols.value, "rows": n_rows.value, "nnz": nnz.value}
+    if cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import orb_oracle
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            want = orb_oracle.visibility_csr(N=100, **w)
+        dt = (time.perf_counter() - t0) / reps
+        nr = n_rows.value
+        same = (want["n_cols"] == n_cols.value and want["n_rows"] == nr and np.array_equal(want["col_point"], col_point[:n_cols.value]) and
+                np.array_equal(want["row_begin"], row_begin[:nr + 1]) and np.array_equal(want["col_idx"], col_idx[:nnz.value]))
+        out["cpu_baseline"] = {"ms_per_window": round(dt * 1e3, 4), "cores": 1, "kind": "port",
+                               "sample": f"oracle/sparsify_oracle.cc on the same window, {reps} repetitions", "gpu_matches_cpu": bool(same)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -503,6 +687,10 @@ def main():
     if world == 1:
         tracking = tracking_loop_leg(msorb, synth, torch, ex, cfg, base, counts_h, d_kps, d_desc, d_ur, dev, local, args)
 
+    per_frame = host_fed = None
+    if world == 1:
+        per_frame = per_frame_leg(msorb, ex, base[0], base[1])
+
     # per-kernel roofline: the same step with every kernel alone on the GPU (1 sub-batch, blur on the main stream),
     # HIP events on the launching stream, 20 recorded steps (after 20 discarded ones) outside the timed region
     iso_steps, iso_discard = 20, 20
@@ -549,12 +737,23 @@ def main():
     kp_total += fence_kp[0]
     join = dict(assoc)   # association statistics of the timed region only
 
+    dt_rank, kp_total_rank = dt, kp_total
     if world > 1:
         t = torch.tensor([dt, float(kp_total)], dtype=torch.float64, device=dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dt, kp_total = float(tmax[0]), int(t[1])
+
+    if world == 1 and not args.isolated:
+        hf_ex = [ex, make_ex()]
+        host_fed = host_fed_leg(msorb, torch, hf_ex, host, dev, cfg, pitch)
+        all_ex.append(hf_ex[1])
+
+    validation = None
+    if world > 1:
+        validation = split_self_validation(msorb, torch, dist, stereo_split, rank, world, eye, half, exs[0], ex_rp, make_ex, images,
+                                           other_images, mine[0], theirs[0], kp_total_rank / dt_rank if dt_rank > 0 else 0.0, dev)
 
     if hamming is not None:
         if args.cpu_pairs > 0 and rank == 0:
@@ -661,6 +860,8 @@ def main():
         if tracking is not None:
             tracking.pop("_cpu", None)
         out["tracking_loop"] = tracking
+        if world == 1:
+            out["sparsification"] = sparsification_leg(msorb, args.cpu_pairs > 0)
         if world > 1:
             out["stereo_join"] = {
                 "what": "every rank joins half of its pair group's stereo pairs inside the timed region, once per step: the other "
@@ -671,6 +872,10 @@ def main():
                 "joins": join["n"], "kernel_ms_per_join": round(join["ms"] / max(join["n"], 1), 4),
                 "matched_last": int((join["last"] > 0).sum().item()) if "last" in join else None,
                 "gathered_bytes_per_step_and_rank": theirs[0].nbytes() if theirs else None}
+        out["per_frame"] = per_frame
+        out["host_fed"] = host_fed
+        if validation is not None:
+            out["split_validation"] = validation
         if world == 1 and args.cpu_pairs > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_pairs, 5000)
         else:

@@ -113,6 +113,25 @@ int msorb_pyramid_level(msorb_extractor* h, int level, const uint8_t** data, int
  * mvImagePyramid on the host (an unchanged Frame::ComputeStereoMatches, Frame.cc:840-855).  Default off. */
 int msorb_extractor_set_host_pyramid(msorb_extractor* h, int enable);
 
+/* The OpenCV primitives the extractor restates (resize, GaussianBlur, fastAtan2) are un-vendored dependencies of the reference
+ * (CMakeLists.txt:35: OpenCV >= 4.4, no pinned version).  Their semantics follow SURVEY.md Appendix A; the three places where
+ * a real OpenCV build could differ are ONE runtime-selectable table, in the kernels (here) and in the oracle
+ * (oracle/cvprims.h Semantics) alike — if a pin run (tools/pin_opencv.py) disagrees with a default, the fix is this call:
+ *   gauss_taps       Q8 taps of GaussianBlur(7x7, sigma 2) (ORBextractor.cc:1133).  Default {18,34,48,56,48,34,18}: the
+ *                    bit-exact fixed-point path of OpenCV >= 4.2; sum(taps) <= 257.  Other taps run the generic blur kernels.
+ *   resize_rounding  vertical pass of resize(INTER_LINEAR, 8U) (ORBextractor.cc:1183).  0 (default): VResizeLinear<uchar>,
+ *                    ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2) >> 2;  1: the generic FixedPtCast form (S0*b0 + S1*b1 + (1<<21)) >> 22
+ *                    (generic resize kernel).
+ *   atan2_fma        polynomial of fastAtan2 (ORBextractor.cc:102).  0 (default): separate multiply / add (x86-64 baseline
+ *                    build); 1: contracted Horner steps (aarch64, -ffp-contract=fast builds).
+ * sem == NULL restores the defaults.  Applies to every later call on the handle. */
+typedef struct msorb_semantics {
+    int gauss_taps[7];
+    int resize_rounding;
+    int atan2_fma;
+} msorb_semantics;
+int msorb_extractor_set_semantics(msorb_extractor* h, const msorb_semantics* sem);
+
 /* Batched operator() over n_images same-sized DEVICE-resident images (image i at d_images +
  * i*image_stride, rows of row_stride bytes).  Outputs stay on the device: image i's keypoints at
  * d_keypoints + i*capacity, descriptors at d_descriptors + i*capacity*32.  h_counts[i] / h_mono[i]

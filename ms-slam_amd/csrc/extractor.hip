@@ -163,6 +163,7 @@ struct msorb_extractor {
     int n_groups = 2;
     bool overlap_blur = true;
     OrbParams P;
+    Semantics sem;   // msorb_extractor_set_semantics: variants of the [OpenCV-recall] primitives (defaults = SURVEY.md Appendix A)
     hipStream_t stream = nullptr, copy_stream = nullptr;
     // msorb_extract (one host image per call) replays the whole chain — H2D, ~20 kernels on two streams, D2H — as ONE
     // captured HIP graph: per frame the kernels are microseconds long and the launch calls dominate the host side
@@ -441,7 +442,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
         int* img_base = h->d_img_base.p + first + gi;
         const size_t cslot = (size_t)first * g.slots_per_image;
         mark(0, s);
-        launch_pyramid(pyr, h->d_taps.p, h->tap_x_off.data(), h->tap_y_off.data(), n, s);
+        launch_pyramid(pyr, h->d_taps.p, h->tap_x_off.data(), h->tap_y_off.data(), n, s, h->sem);
         mark(1, s);
         hipStream_t sb = h->overlap_blur ? h->copy_stream : s;
         if (h->overlap_blur) {
@@ -464,7 +465,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
             h->h_pyr_async = true;
         }
         mark(7, sb);
-        launch_gauss7(pyr, blur, n, sb);
+        launch_gauss7(pyr, blur, n, sb, h->sem);
         mark(8, sb);
         if (h->overlap_blur) HIPCHK(hipEventRecord(G.ev_blur, sb));
         // optional (MSORB_STAGGER): run the sub-batches' FAST kernels one after the other, so that the memory- and
@@ -487,7 +488,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
         if (h->overlap_blur) HIPCHK(hipStreamWaitEvent(s, G.ev_blur, 0));
         launch_describe(pyr, blur, h->d_sel.p + (size_t)first * sel_stride, h->d_sel_count.p + first, sel_stride, h->scales,
                         d_kps + (size_t)first * capacity, d_desc + (size_t)first * capacity * 32, capacity,
-                        std::min(capacity, sel_stride), n, s);
+                        std::min(capacity, sel_stride), n, s, h->sem);
         mark(6, s);
         if (!h->skip_count_copies) {  // a fused caller takes the counts from the device itself
             HIPCHK(hipMemcpyAsync(h->h_sel_count.p + first, h->d_sel_count.p + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -518,7 +519,7 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
     h->h_pyr_valid = false;
 
     mark(0);
-    launch_pyramid(pyr, h->d_taps.p, h->tap_x_off.data(), h->tap_y_off.data(), n_images, s);
+    launch_pyramid(pyr, h->d_taps.p, h->tap_x_off.data(), h->tap_y_off.data(), n_images, s, h->sem);
     mark(1);
     // the blur only feeds the descriptor stage: unless stage timing is on, it runs on the second stream, overlapping
     // the (VALU-bound) FAST kernel and the (latency-bound) quadtree with a bandwidth-bound kernel
@@ -527,7 +528,7 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
         HIPCHK(hipEventRecord(h->ev_pyramid, s));
         HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_pyramid, 0));
         if (prof) (void)hipEventRecord(h->pe[7], h->copy_stream);
-        launch_gauss7(pyr, blur, n_images, h->copy_stream);
+        launch_gauss7(pyr, blur, n_images, h->copy_stream, h->sem);
         if (prof) (void)hipEventRecord(h->pe[8], h->copy_stream);
         HIPCHK(hipEventRecord(h->ev_blur, h->copy_stream));
     }
@@ -539,7 +540,7 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
                         h->d_compact.p, n_images, s);
     mark(3);
     HIPCHK(hipEventRecord(h->ev_compact, s));
-    if (!overlap_blur) launch_gauss7(pyr, blur, n_images, s);
+    if (!overlap_blur) launch_gauss7(pyr, blur, n_images, s, h->sem);
     mark(4);
     h->compact_on_host = false;
     const int sel_stride = h->sel_stride;
@@ -553,7 +554,7 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
         mark(5);
         if (overlap_blur) HIPCHK(hipStreamWaitEvent(s, h->ev_blur, 0));
         launch_describe(pyr, blur, h->d_sel.p, h->d_sel_count.p, sel_stride, h->scales, d_kps, d_desc, capacity,
-                        std::min(capacity, sel_stride), n_images, s);
+                        std::min(capacity, sel_stride), n_images, s, h->sem);
         mark(6);
         HIPCHK(hipMemcpyAsync(h->h_sel_count.p, h->d_sel_count.p, (size_t)n_images * sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(h->h_mono.p, h->d_mono.p, (size_t)n_images * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -614,7 +615,7 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
         mark(5);
         if (overlap_blur) HIPCHK(hipStreamWaitEvent(s, h->ev_blur, 0));
         launch_describe(pyr, blur, h->d_sel.p, h->d_sel_count.p, sel_stride, h->scales, d_kps, d_desc, capacity, max_sel,
-                        n_images, s);
+                        n_images, s, h->sem);
         mark(6);
         HIPCHK(hipStreamSynchronize(s));
         HIPCHK(hipGetLastError());
@@ -780,6 +781,27 @@ int msorb_extractor_set_overlap(msorb_extractor* h, int sub_batches, int blur_on
     h->overlap_blur = blur_on_second_stream != 0;
     return MSORB_OK;
 }
+int msorb_extractor_set_semantics(msorb_extractor* h, const msorb_semantics* sem) {
+    if (!h) return MSORB_E_INVALID;
+    if (h->pending_batch) { set_error("a submitted batch of this handle has not been waited for"); return MSORB_E_INVALID; }
+    Semantics s;
+    if (sem) {
+        int sum = 0;
+        for (int i = 0; i < 7; i++) {
+            if (sem->gauss_taps[i] < 0 || sem->gauss_taps[i] > 255) { set_error("gauss tap outside 0..255"); return MSORB_E_INVALID; }
+            s.gauss_taps[i] = sem->gauss_taps[i];
+            sum += sem->gauss_taps[i];
+        }
+        if (sum < 1 || sum > 257) { set_error("gauss taps: the 16-bit horizontal sums need sum(taps) <= 257"); return MSORB_E_INVALID; }
+        s.resize_single_stage = sem->resize_rounding != 0;
+        s.atan2_fma = sem->atan2_fma != 0;
+    }
+    h->sem = s;
+    for (auto& g : h->fgraph)   // captured per-frame graphs bake the kernel choice in
+        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+    return MSORB_OK;
+}
+
 int msorb_extractor_set_host_pyramid(msorb_extractor* h, int enable) {
     if (!h) return MSORB_E_INVALID;
     h->host_pyramid = enable != 0;
@@ -1273,7 +1295,7 @@ int msorb_pyramid_batch(msorb_extractor* h, const uint8_t* d_images, int n_image
     if ((rc = h->d_pyr.ensure((size_t)n_images * h->G.pyramid_bytes + 256))) return rc;
     LevelView l0{d_images, image_stride, (int)row_stride, cols, rows};
     const PyramidView pyr = make_view(h, h->d_pyr.p, &l0);
-    launch_pyramid(pyr, h->d_taps.p, h->tap_x_off.data(), h->tap_y_off.data(), n_images, h->stream);
+    launch_pyramid(pyr, h->d_taps.p, h->tap_x_off.data(), h->tap_y_off.data(), n_images, h->stream, h->sem);
     HIPCHK(hipGetLastError());
     h->last_pyr = pyr; h->last_n_images = n_images;
     h->h_pyr_valid = false; h->compact_on_host = false;

@@ -39,19 +39,31 @@ void launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_b
 size_t quadtree_lds_bytes(const QtLevels& lv);
 void upload_patch_tables(const int8_t* pattern, const int* umax, hipStream_t stream);
 void launch_stage_level0(const LevelView& src, uint8_t* dst, int dst_pitch, size_t dst_image_stride, int n_images, hipStream_t s);
+// The [OpenCV-recall] semantics that a real OpenCV build could turn out to differ in, as one table (msorb_semantics of the C
+// ABI, oracle/cvprims.h Semantics): non-default entries route to the kernels that take them at run time.
+struct Semantics {
+    int gauss_taps[7] = {18, 34, 48, 56, 48, 34, 18};
+    int resize_single_stage = 0;
+    int atan2_fma = 0;
+    bool default_taps() const {
+        static const int d[7] = {18, 34, 48, 56, 48, 34, 18};
+        for (int i = 0; i < 7; i++) if (gauss_taps[i] != d[i]) return false;
+        return true;
+    }
+};
 void launch_pyramid(const PyramidView& pyr, const ResizeTap* taps, const size_t* tap_x_off, const size_t* tap_y_off, int n_images,
-                    hipStream_t s);
+                    hipStream_t s, const Semantics& sem = Semantics());
 void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_base, const ResizeTap* tx,
-                       const ResizeTap* ty, int n_images, hipStream_t s);
+                       const ResizeTap* ty, int n_images, hipStream_t s, int single_stage = 0);
 void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cells, int ini_th, int min_th,
                        int slots_per_image, Cand16* slots, int* cell_count, int n_images, bool small_cells, hipStream_t s);
 void launch_cand_compact(const CellDesc* cells, int n_cells, const int* level_cell_begin, int nlevels,
                          int slots_per_image, const Cand16* slots, const int* cell_count, int* cell_off,
                          int* level_count, int* img_total, int* img_base, Cand16* compact, int n_images,
                          hipStream_t s);
-void launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images, hipStream_t s);
+void launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images, hipStream_t s, const Semantics& sem = Semantics());
 void launch_describe(const PyramidView& pyr, const PyramidView& blur, const SelRec* sel, const int* sel_count,
                      int sel_stride, const LevelScale& scales, msorb_keypoint* kps, uint8_t* desc, int out_stride,
-                     int max_sel, int n_images, hipStream_t s);
+                     int max_sel, int n_images, hipStream_t s, const Semantics& sem = Semantics());
 
 }  // namespace msorb

@@ -20,9 +20,11 @@ namespace msorb {
 // Pyramid level l from level l-1.  One thread = 4 horizontally adjacent destination pixels of one
 // row, written as one aligned 32-bit store (pitch is a multiple of 64).  block = 64 x 4.
 // ------------------------------------------------------------------------------------------------
+// single_stage: the generic FixedPtCast rounding (S0*b0 + S1*b1 + (1 << 21)) >> 22 instead of VResizeLinear<uchar>'s two
+// stages (Semantics::resize_single_stage; only this kernel serves the variant).
 __global__ __launch_bounds__(256) void pyr_resize_kernel(LevelView src, LevelView dst, uint8_t* __restrict__ dst_base,
                                                          const ResizeTap* __restrict__ tx,
-                                                         const ResizeTap* __restrict__ ty) {
+                                                         const ResizeTap* __restrict__ ty, int single_stage) {
     const int img = blockIdx.z;
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
@@ -39,7 +41,8 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(LevelView src, LevelVie
             const ResizeTap vx = tx[dx];
             const int h0 = s0[vx.i0] * vx.c0 + s0[vx.i1] * vx.c1;
             const int h1 = s1[vx.i0] * vx.c0 + s1[vx.i1] * vx.c1;
-            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            const int v = single_stage ? (h0 * b0 + h1 * b1 + (1 << 21)) >> 22
+                                       : (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
             packed |= (uint32_t)(v & 255) << (8 * i);
         }
     }
@@ -977,8 +980,7 @@ __global__ __launch_bounds__(256) void cand_gather_kernel(const CellDesc* __rest
 // reaches the right border (reflect-101 gather, byte loads) are left to gauss7_edge_kernel so that the
 // streaming waves stay divergence free and the unrolled body stays small (instruction cache).
 constexpr int kGaussRows = 35;  // 6 warm-up rows + 5 x 7 steady rows
-constexpr uint32_t kGaussLo = 18u | (34u << 8) | (48u << 16) | (56u << 24);
-constexpr uint32_t kGaussHi = 48u | (34u << 8) | (18u << 16);
+struct GaussTaps { uint32_t k[7]; };   // the generic blur kernels take the Q8 taps at run time (Semantics::gauss_taps)
 
 struct BlurPlan {
     int block_begin[kMaxLevels + 1];  // first blockIdx.x of each level
@@ -990,7 +992,7 @@ __device__ __forceinline__ int refl101(int p, int len) { return p < 0 ? -p : (p 
 
 template <bool ALIGNED>
 __device__ __forceinline__ void gauss_row_sums(const uint8_t* __restrict__ sb, int pitch, int h, int yy, int x0,
-                                               uint32_t hsum[4]) {
+                                               uint32_t hsum[4], uint32_t kGaussLo, uint32_t kGaussHi) {
     yy = refl101(yy, h);
     yy = min(max(yy, 0), h - 1);  // rows past the image only feed outputs that are never stored
     const uint8_t* rp = sb + (size_t)yy * pitch;
@@ -1018,8 +1020,9 @@ __device__ __forceinline__ void gauss_row_sums(const uint8_t* __restrict__ sb, i
 }
 
 template <bool ALIGNED>
-__global__ __launch_bounds__(256) void gauss7_kernel(PyramidView src, PyramidView dst, BlurPlan plan) {
-    constexpr uint32_t K[7] = {18, 34, 48, 56, 48, 34, 18};
+__global__ __launch_bounds__(256) void gauss7_kernel(PyramidView src, PyramidView dst, BlurPlan plan, GaussTaps T) {
+    const uint32_t K[7] = {T.k[0], T.k[1], T.k[2], T.k[3], T.k[4], T.k[5], T.k[6]};
+    const uint32_t kGaussLo = K[0] | (K[1] << 8) | (K[2] << 16) | (K[3] << 24), kGaussHi = K[4] | (K[5] << 8) | (K[6] << 16);
     int level = 0;
     while (level + 1 < plan.nlevels && (int)blockIdx.x >= plan.block_begin[level + 1]) level++;
     const int rem = blockIdx.x - plan.block_begin[level];
@@ -1036,7 +1039,7 @@ __global__ __launch_bounds__(256) void gauss7_kernel(PyramidView src, PyramidVie
     // warm-up: input rows 0..5 (image rows y0-3 .. y0+2) open accumulators 0..5
 #pragma unroll
     for (int r = 0; r < 6; r++) {
-        gauss_row_sums<ALIGNED>(sb, sv.pitch, sv.h, y0 - 3 + r, x0, hs);
+        gauss_row_sums<ALIGNED>(sb, sv.pitch, sv.h, y0 - 3 + r, x0, hs, kGaussLo, kGaussHi);
 #pragma unroll
         for (int t = 0; t <= r; t++)
 #pragma unroll
@@ -1047,7 +1050,7 @@ __global__ __launch_bounds__(256) void gauss7_kernel(PyramidView src, PyramidVie
 #pragma unroll
         for (int u = 0; u < 7; u++) {
             const int r = 6 + 7 * it + u;
-            gauss_row_sums<ALIGNED>(sb, sv.pitch, sv.h, y0 - 3 + r, x0, hs);
+            gauss_row_sums<ALIGNED>(sb, sv.pitch, sv.h, y0 - 3 + r, x0, hs, kGaussLo, kGaussHi);
 #pragma unroll
             for (int t = 0; t < 7; t++) {
                 const int a = (6 + u - t) % 7;  // == (r - t) % 7
@@ -1058,7 +1061,7 @@ __global__ __launch_bounds__(256) void gauss7_kernel(PyramidView src, PyramidVie
             if (y0 + o < sv.h) {
                 uint32_t packed = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) packed |= ((acc[a][j] + 32768u) >> 16) << (8 * j);
+                for (int j = 0; j < 4; j++) packed |= min((acc[a][j] + 32768u) >> 16, 255u) << (8 * j);   // saturate_cast (taps summing to 257)
                 *reinterpret_cast<uint32_t*>(db + (size_t)(y0 + o) * dv.pitch) = packed;
             }
         }
@@ -1220,7 +1223,7 @@ __global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, Pyr
 // One 64-thread block covers 58 output rows: thread r first forms the horizontal sums of input row y0-3+r for the
 // border columns (all rows in parallel: one memory round trip), then thread r < 58 finishes output row y0+r from LDS.
 constexpr int kEdgeRows = 58;
-__global__ __launch_bounds__(64) void gauss7_edge_kernel(PyramidView src, PyramidView dst) {
+__global__ __launch_bounds__(64) void gauss7_edge_kernel(PyramidView src, PyramidView dst, GaussTaps T) {
     __shared__ uint16_t hs[64][16];
     const int level = blockIdx.y, img = blockIdx.z;
     const LevelView sv = src.lv[level], dv = dst.lv[level];
@@ -1231,7 +1234,7 @@ __global__ __launch_bounds__(64) void gauss7_edge_kernel(PyramidView src, Pyrami
     const int r = threadIdx.x;
     const uint8_t* sb = sv.base + (size_t)img * sv.img_stride;
     uint8_t* db = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride;
-    const int K[7] = {18, 34, 48, 56, 48, 34, 18};
+    const int K[7] = {(int)T.k[0], (int)T.k[1], (int)T.k[2], (int)T.k[3], (int)T.k[4], (int)T.k[5], (int)T.k[6]};
     {
         int yy = refl101(y0 - 3 + r, sv.h);
         yy = min(max(yy, 0), sv.h - 1);
@@ -1253,7 +1256,7 @@ __global__ __launch_bounds__(64) void gauss7_edge_kernel(PyramidView src, Pyrami
             uint32_t acc = 0;
 #pragma unroll
             for (int k = 0; k < 7; k++) acc += (uint32_t)K[k] * hs[r + k][j];
-            db[(size_t)(y0 + r) * dv.pitch + first + j] = (uint8_t)((acc + 32768u) >> 16);
+            db[(size_t)(y0 + r) * dv.pitch + first + j] = (uint8_t)min((acc + 32768u) >> 16, 255u);
         }
     }
 }
@@ -1275,22 +1278,27 @@ void upload_patch_tables(const int8_t* pattern, const int* umax, hipStream_t str
     (void)hipStreamSynchronize(stream);
 }
 
-// cv::fastAtan2 — separate multiply/add, no contraction (oracle/cvprims.h fast_atan2).
-__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+// cv::fastAtan2 — separate multiply/add, no contraction (oracle/cvprims.h fast_atan2); fma != 0: the Horner steps contracted
+// (Semantics::atan2_fma).
+__device__ __forceinline__ float fast_atan2_deg(float y, float x, int fma) {
     const float scale = (float)(180 / 3.1415926535897932384626433832795);
     const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
     const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
     const float eps = (float)2.2204460492503131e-16;
     const float ax = fabsf(x), ay = fabsf(y);
     float a, c, c2;
+    auto poly = [&](float cc, float cc2) {
+        if (fma) return __fmul_rn(__fmaf_rn(__fmaf_rn(__fmaf_rn(p7, cc2, p5), cc2, p3), cc2, p1), cc);
+        return __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, cc2), p5), cc2), p3), cc2), p1), cc);
+    };
     if (ax >= ay) {
         c = __fdiv_rn(ay, __fadd_rn(ax, eps));
         c2 = __fmul_rn(c, c);
-        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+        a = poly(c, c2);
     } else {
         c = __fdiv_rn(ax, __fadd_rn(ay, eps));
         c2 = __fmul_rn(c, c);
-        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+        a = __fsub_rn(90.f, poly(c, c2));
     }
     if (x < 0) a = __fsub_rn(180.f, a);
     if (y < 0) a = __fsub_rn(360.f, a);
@@ -1319,7 +1327,7 @@ constexpr int kKpPerWave = 4;  // keypoints handled back to back by one wave (am
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void describe_kernel(PyramidView pyr, PyramidView blur, const SelRec* __restrict__ sel,
                                                        const int* __restrict__ sel_count, int sel_stride,
                                                        LevelScale scales, msorb_keypoint* __restrict__ kps,
-                                                       uint8_t* __restrict__ desc, int out_stride) {
+                                                       uint8_t* __restrict__ desc, int out_stride, int atan2_fma) {
     __shared__ __attribute__((aligned(16))) uint8_t patch[4 * kKpPerWave][37 * kPatchPitch + 4];  // one slot per (wave, keypoint)
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs; give every image to ONE XCD so that the
     // overlapping keypoint patches of an image are served by a single L2 instead of being fetched by all eight.
@@ -1471,7 +1479,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 #pragma unroll
     for (int kk = 1; kk < kKpPerWave; kk++)
         if (lane == kk) { m10v = M10[kk]; m01v = M01[kk]; }
-    const float angle_v = fast_atan2_deg((float)m01v, (float)m10v);
+    const float angle_v = fast_atan2_deg((float)m01v, (float)m10v, atan2_fma);
     float a_v, b_v;
     glibc_sincosf<true>(__fmul_rn(angle_v, factor_pi), &b_v, &a_v);  // a = cos, b = sin (ORBextractor.cc:112)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1539,8 +1547,12 @@ void launch_stage_level0(const LevelView& src, uint8_t* dst, int dst_pitch, size
                        src.img_stride, dst, dst_pitch, dst_image_stride, src.w);
 }
 void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_base, const ResizeTap* tx,
-                       const ResizeTap* ty, int n_images, hipStream_t s) {
+                       const ResizeTap* ty, int n_images, hipStream_t s, int single_stage) {
     dim3 grid((dst.w + 255) / 256, (dst.h + 3) / 4, n_images);
+    if (single_stage) {   // Semantics::resize_single_stage: served by the generic kernel only
+        hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty, 1);
+        return;
+    }
     // aligned variant: source rows start on 4-byte boundaries and may be read up to the next multiple of 4 past w
     const bool aligned = (reinterpret_cast<uintptr_t>(src.base) & 3) == 0 && (src.pitch & 3) == 0 &&
                          (src.img_stride & 3) == 0 && src.pitch >= ((src.w + 3) & ~3) + 8 &&
@@ -1573,18 +1585,18 @@ void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_
         hipLaunchKernelGGL(pyr_resize_rows_kernel<R>, dim3((dst.w + 255) / 256, (dst.h + 4 * R - 1) / (4 * R), n_images), dim3(256),
                            0, s, src, dst, dst_base, tx, ty);
     else if (aligned) hipLaunchKernelGGL(pyr_resize_aligned_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
-    else hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
+    else hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty, 0);
 }
 // ComputePyramid for a batch: levels 1 .. n-1, each from the one above (ORBextractor.cc:1179-1193), one launch per level.
 // MSORB_PYR_TAIL=1 puts the last up to three levels into one launch (pyr_resize_tail_kernel) — measured on MI355X, 256 KITTI
 // images: 33 us instead of 42 us for the three launches with the stage alone on the GPU, but the whole step gets slower
 // (1.366 vs 1.352 ms): a 16-wave workgroup with 98 KB of LDS per CU keeps the other stream's kernels out.  Off by default.
 void launch_pyramid(const PyramidView& pyr, const ResizeTap* taps, const size_t* tap_x_off, const size_t* tap_y_off, int n_images,
-                    hipStream_t s) {
+                    hipStream_t s, const Semantics& sem) {
     const int nl = pyr.nlevels;
     constexpr int R = 8;
     int tail = 0;
-    if (n_images >= 64 && getenv("MSORB_PYR_TAIL") && !getenv("MSORB_PYR_SINGLE") && !getenv("MSORB_PYR_ROWS")) {
+    if (!sem.resize_single_stage && n_images >= 64 && getenv("MSORB_PYR_TAIL") && !getenv("MSORB_PYR_SINGLE") && !getenv("MSORB_PYR_ROWS")) {
         while (tail < 3 && nl - 1 - tail >= 2) {   // at least level 1 stays a launch of its own
             const int l = nl - 1 - tail;
             const LevelView &src = pyr.lv[l - 1], &dst = pyr.lv[l];
@@ -1597,7 +1609,8 @@ void launch_pyramid(const PyramidView& pyr, const ResizeTap* taps, const size_t*
         }
     }
     for (int l = 1; l < nl - tail; l++)
-        launch_pyr_resize(pyr.lv[l - 1], pyr.lv[l], const_cast<uint8_t*>(pyr.lv[l].base), taps + tap_x_off[l], taps + tap_y_off[l], n_images, s);
+        launch_pyr_resize(pyr.lv[l - 1], pyr.lv[l], const_cast<uint8_t*>(pyr.lv[l].base), taps + tap_x_off[l], taps + tap_y_off[l], n_images, s,
+                          sem.resize_single_stage);
     if (tail) {
         PyrTailArgs A{};
         A.nl = tail;
@@ -1644,7 +1657,7 @@ void launch_cand_compact(const CellDesc* cells, int n_cells, const int* level_ce
     hipLaunchKernelGGL(cand_gather_kernel, dim3((n_cells + kGatherCells - 1) / kGatherCells, n_images), dim3(256), 0, s, cells, n_cells, slots_per_image,
                        slots, cell_count, cell_off, img_base, compact);
 }
-void launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images, hipStream_t s) {
+void launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images, hipStream_t s, const Semantics& sem) {
     BlurPlan plan{};
     plan.nlevels = src.nlevels;
     bool aligned = true;
@@ -1653,7 +1666,11 @@ void launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images,
         aligned = aligned && (reinterpret_cast<uintptr_t>(v.base) & 3) == 0 && (v.pitch & 3) == 0 && (v.img_stride & 3) == 0;
     }
     static const bool stream_env = !getenv("MSORB_BLUR_GENERIC");  // tuning / test aid
-    const bool stream = aligned && stream_env;
+    // the streaming kernel has the default taps folded into its v_dot4 constants; other taps (Semantics::gauss_taps) take the
+    // generic kernels, which read them at run time
+    const bool stream = aligned && stream_env && sem.default_taps();
+    GaussTaps T;
+    for (int i = 0; i < 7; i++) T.k[i] = (uint32_t)sem.gauss_taps[i];
     // strip height 35: 21..35 rows measure the same (0.29 ms / 256 images), 70 and 140 are slower (too few waves)
     const int rows = kGaussRows;
     int total = 0, max_h = 0;
@@ -1673,17 +1690,17 @@ void launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images,
         const int all = total * n_images, per_xcd = (all + 7) / 8;
         hipLaunchKernelGGL(gauss7_stream_kernel<kGaussRows>, dim3(per_xcd * 8), dim3(256), 0, s, src, dst, plan, per_xcd, all);
     }
-    else if (aligned) hipLaunchKernelGGL(gauss7_kernel<true>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
-    else hipLaunchKernelGGL(gauss7_kernel<false>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan);
+    else if (aligned) hipLaunchKernelGGL(gauss7_kernel<true>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan, T);
+    else hipLaunchKernelGGL(gauss7_kernel<false>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan, T);
     if (!stream)  // the streaming kernel handles the right border itself
-        hipLaunchKernelGGL(gauss7_edge_kernel, dim3((max_h + kEdgeRows - 1) / kEdgeRows, src.nlevels, n_images), dim3(64), 0, s, src, dst);
+        hipLaunchKernelGGL(gauss7_edge_kernel, dim3((max_h + kEdgeRows - 1) / kEdgeRows, src.nlevels, n_images), dim3(64), 0, s, src, dst, T);
 }
 void launch_describe(const PyramidView& pyr, const PyramidView& blur, const SelRec* sel, const int* sel_count,
                      int sel_stride, const LevelScale& scales, msorb_keypoint* kps, uint8_t* desc, int out_stride,
-                     int max_sel, int n_images, hipStream_t s) {
+                     int max_sel, int n_images, hipStream_t s, const Semantics& sem) {
     if (max_sel <= 0) return;
     hipLaunchKernelGGL(describe_kernel, dim3((max_sel + 4 * kKpPerWave - 1) / (4 * kKpPerWave), n_images), dim3(256), 0, s, pyr, blur, sel, sel_count,
-                       sel_stride, scales, kps, desc, out_stride);
+                       sel_stride, scales, kps, desc, out_stride, sem.atan2_fma);
 }
 
 }  // namespace msorb

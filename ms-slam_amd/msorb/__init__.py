@@ -29,6 +29,7 @@ EXPORTS = (
     "msorb_extract_batch", "msorb_extractor_set_profiling", "msorb_extractor_set_overlap", "msorb_extractor_stage_ms", "msorb_debug_level_size",
     "msorb_debug_copy_level", "msorb_debug_candidates", "msorb_distribute_quadtree", "msorb_extract_stereo",
     "msorb_extract_stereo_split", "msorb_pyramid_batch", "msorb_stereo_matches_split", "msorb_extractor_set_host_pyramid",
+    "msorb_extractor_set_semantics",
 )
 
 
@@ -253,6 +254,19 @@ class ORBextractor:
         _check(self.L.msorb_extract_batch_wait(self.h, _np_ptr(counts), _np_ptr(mono)), "msorb_extract_batch_wait")
         self._pending = None
         return counts[:n], mono[:n], out[0], out[1]
+
+    def set_semantics(self, gauss_taps=None, resize_single_stage=False, atan2_fma=False):
+        """msorb_extractor_set_semantics: variants of the [OpenCV-recall] primitives; set_semantics() restores the defaults."""
+        class Sem(C.Structure):
+            _fields_ = [("gauss_taps", C.c_int * 7), ("resize_rounding", C.c_int), ("atan2_fma", C.c_int)]
+        self.L.msorb_extractor_set_semantics.argtypes = [C.c_void_p, C.c_void_p]
+        if gauss_taps is None and not resize_single_stage and not atan2_fma:
+            _check(self.L.msorb_extractor_set_semantics(self.h, None), "msorb_extractor_set_semantics")
+            return
+        sm = Sem()
+        sm.gauss_taps[:] = [int(t) for t in (gauss_taps if gauss_taps is not None else (18, 34, 48, 56, 48, 34, 18))]
+        sm.resize_rounding, sm.atan2_fma = int(resize_single_stage), int(atan2_fma)
+        _check(self.L.msorb_extractor_set_semantics(self.h, C.addressof(sm)), "msorb_extractor_set_semantics")
 
     def set_host_pyramid(self, on=True):
         self.L.msorb_extractor_set_host_pyramid.argtypes = [C.c_void_p, C.c_int]

@@ -83,6 +83,18 @@ static inline ResizeTab resize_tab(int dlen, int slen, bool clamp_x) {
     }
     return t;
 }
+// The [OpenCV-recall] semantics that could differ in a real OpenCV build, as ONE runtime-selectable table shared by the oracle
+// and (through msorb_extractor_set_semantics) the kernels: if a pin run on real OpenCV (tools/pin_opencv.py) disagrees with a
+// default, switching the variant is a setting, not a rewrite.  Defaults = SURVEY.md Appendix A.
+struct Semantics {
+    int gauss_taps[7] = {18, 34, 48, 56, 48, 34, 18};  // Q8 taps of GaussianBlur(7x7, sigma 2): bit-exact path of OpenCV >= 4.2 (sum 256);
+                                                       // e.g. {18,34,49,55,49,34,18} (sum 257) for a float-kernel build
+    int resize_single_stage = 0;  // 0: VResizeLinear<uchar>: ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2) >> 2
+                                  // 1: generic FixedPtCast: (S0*b0 + S1*b1 + (1 << 21)) >> 22
+    int atan2_fma = 0;            // 0: separate multiply / add (x86-64 baseline build); 1: contracted Horner steps (aarch64, -ffp-contract=fast)
+};
+static inline Semantics& semantics() { static Semantics s; return s; }
+
 static inline void resize_linear_u8(const Plane& src, Plane& dst) {
     const ResizeTab tx = resize_tab(dst.cols, src.cols, true);
     const ResizeTab ty = resize_tab(dst.rows, src.rows, false);
@@ -107,8 +119,11 @@ static inline void resize_linear_u8(const Plane& src, Plane& dst) {
         }
         int b0 = ty.coef[2 * dy], b1 = ty.coef[2 * dy + 1];
         uint8_t* d = dst.row(dy);
-        for (int dx = 0; dx < dst.cols; dx++)
-            d[dx] = (uint8_t)((((b0 * (h0[dx] >> 4)) >> 16) + ((b1 * (h1[dx] >> 4)) >> 16) + 2) >> 2);
+        if (semantics().resize_single_stage)
+            for (int dx = 0; dx < dst.cols; dx++) d[dx] = (uint8_t)((h0[dx] * b0 + h1[dx] * b1 + (1 << 21)) >> 22);
+        else
+            for (int dx = 0; dx < dst.cols; dx++)
+                d[dx] = (uint8_t)((((b0 * (h0[dx] >> 4)) >> 16) + ((b1 * (h1[dx] >> 4)) >> 16) + 2) >> 2);
     }
 }
 
@@ -193,8 +208,8 @@ static inline void fast9_nms(const uint8_t* img, int stride, int rows, int cols,
 }
 
 // --- A.5 GaussianBlur 7x7 sigma 2, 8UC1, BORDER_REFLECT_101, fixed-point path ----------------
-static const int kGauss7[7] = {18, 34, 48, 56, 48, 34, 18};  // Q8.8, error-diffusion rounding, sum 256
 static inline void gaussian7_q88(const Plane& src, Plane& dst) {
+    const int* kGauss7 = semantics().gauss_taps;  // default {18,34,48,56,48,34,18}: Q8.8, error-diffusion rounding, sum 256
     dst = Plane(src.rows, src.cols);
     std::vector<uint16_t> h((size_t)src.rows * src.cols);
     for (int y = 0; y < src.rows; y++) {
@@ -211,7 +226,8 @@ static inline void gaussian7_q88(const Plane& src, Plane& dst) {
             uint32_t acc = 0;
             for (int j = 0; j < 7; j++)
                 acc += (uint32_t)kGauss7[j] * h[(size_t)reflect101(y + j - 3, src.rows) * src.cols + x];
-            d[x] = (uint8_t)((acc + 32768u) >> 16);
+            const uint32_t v = (acc + 32768u) >> 16;   // taps summing to 257 can reach 256 / 257 on saturated pixels: saturate_cast
+            d[x] = (uint8_t)(v > 255u ? 255u : v);
         }
     }
 }
@@ -228,14 +244,19 @@ static inline float fast_atan2(float y, float x) {
     const float eps = (float)2.2204460492503131e-16;  // (float)DBL_EPSILON
     float ax = std::fabs(x), ay = std::fabs(y);
     float a, c, c2;
+    const bool fma = semantics().atan2_fma != 0;
+    auto poly = [&](float cc, float cc2) {
+        if (fma) return std::fmaf(std::fmaf(std::fmaf(p7, cc2, p5), cc2, p3), cc2, p1) * cc;
+        return (((p7 * cc2 + p5) * cc2 + p3) * cc2 + p1) * cc;
+    };
     if (ax >= ay) {
         c = ay / (ax + eps);
         c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+        a = poly(c, c2);
     } else {
         c = ax / (ay + eps);
         c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+        a = 90.f - poly(c, c2);
     }
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;

@@ -463,6 +463,21 @@ void orc_fast9_planes(const uint8_t* img, int stride, int rows, int cols, int th
         }
 }
 float orc_fast_atan2(float y, float x) { return orc::fast_atan2(y, x); }
+
+// The semantics table of cvprims.h (process-wide in the oracle: test infrastructure).  taps == NULL restores the defaults.
+// Returns 0, or -1 for taps the Q8.8 pipeline cannot hold (horizontal sums are 16 bit: 255 * sum(taps) must stay <= 65535).
+int orc_set_semantics(const int* gauss_taps, int resize_single_stage, int atan2_fma) {
+    orc::Semantics s;
+    if (gauss_taps) {
+        int sum = 0;
+        for (int i = 0; i < 7; i++) { if (gauss_taps[i] < 0 || gauss_taps[i] > 255) return -1; sum += gauss_taps[i]; s.gauss_taps[i] = gauss_taps[i]; }
+        if (sum > 257 || sum < 1) return -1;
+        s.resize_single_stage = resize_single_stage != 0;
+        s.atan2_fma = atan2_fma != 0;
+    }
+    orc::semantics() = s;
+    return 0;
+}
 void orc_cos_sin(float angle_deg, float* a, float* b) {
     const float r = angle_deg * orc::kFactorPI;
     *a = cosf(r); *b = sinf(r);

@@ -144,6 +144,20 @@ def fast9_planes(roi, threshold):
     return corner, score
 
 
+def set_semantics(gauss_taps=None, resize_single_stage=False, atan2_fma=False):
+    """The [OpenCV-recall] variant table of oracle/cvprims.h (process-wide).  set_semantics() restores the defaults."""
+    L = lib()
+    L.orc_set_semantics.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    if gauss_taps is None and not resize_single_stage and not atan2_fma:
+        rc = L.orc_set_semantics(None, 0, 0)
+    else:
+        t = np.ascontiguousarray(gauss_taps if gauss_taps is not None else [18, 34, 48, 56, 48, 34, 18], np.int32)
+        assert len(t) == 7
+        rc = L.orc_set_semantics(_ptr(t), int(resize_single_stage), int(atan2_fma))
+    if rc:
+        raise ValueError("taps outside the Q8.8 pipeline's range")
+
+
 def fast_atan2(y, x):
     return float(lib().orc_fast_atan2(float(y), float(x)))
 
