@@ -410,10 +410,15 @@ def main():
     ap.add_argument("--pairs", type=int, default=128, help="stereo pairs per step per GPU-pair group")
     ap.add_argument("--cpu-pairs", type=int, default=160, help="stereo pairs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--unique-pairs", type=int, default=8, help="distinct synthetic stereo pairs tiled to the batch (<= --pairs)")
+    ap.add_argument("--lean", action="store_true",
+                    help="profiling aid: only the extraction loop (no Hamming / stereo / tracking / per-frame / host-fed / sparsification "
+                         "legs, no CPU baseline), so that a kernel trace or a counter pass holds nothing else")
     ap.add_argument("--isolated", action="store_true",
                     help="profiling aid: no sub-batch / blur overlap anywhere, so every kernel launch covers the whole "
                          "batch and runs alone (rocprofv3 per-kernel durations and PMC traffic are then per-launch clean)")
     args = ap.parse_args()
+    if args.lean:
+        args.cpu_pairs = 0
 
     import torch
     import msorb
@@ -550,6 +555,7 @@ def main():
             e.set_overlap(int(os.environ.get("MSORB_GROUPS", "1")), True)
     outs = [(d_kps, d_desc)] + [(torch.empty_like(d_kps), torch.empty_like(d_desc)) for _ in range(depth - 1)]
     inflight = []
+    stagger_s = float(os.environ.get("MSORB_BENCH_STAGGER_US", "0")) * 1e-6 if pipelined else 0.0
 
     def drain():
         total = 0
@@ -573,6 +579,11 @@ def main():
             exp[k].extract_batch_submit(images, (0, 0), out=outs[k])
             inflight.append(exp[k])
             last_ex[0] = exp[k]
+            if len(inflight) == 1 and stagger_s > 0:
+                # first batch after a fence: hold the second one back by half a step, so that the two chains run out of phase —
+                # one batch's FAST (VALU-bound) beside the other's quadtree (latency-bound) and descriptors (L1-fill-bound) instead
+                # of FAST beside FAST.  Submitted together they stay in lock-step: both finish, and are resubmitted, together.
+                time.sleep(stagger_s)
             return done
         b = step_no[0] & 1
         step_no[0] += 1
@@ -625,7 +636,8 @@ def main():
     # second half of the metric: Gpairs/s of the brute-force Hamming match (left-eye descriptors of every pair
     # against the right-eye descriptors of the same pair, dense top-2), on the descriptors just extracted
     hamming = None
-    if world == 1:
+    aux = world == 1 and not args.lean
+    if aux:
         counts_h, _, _, _ = ex.extract_batch(images, (0, 0), out=(d_kps, d_desc))
         dq = d_desc[0::2].contiguous()
         dtr = d_desc[1::2].contiguous()
@@ -671,7 +683,7 @@ def main():
     # third: Frame::ComputeStereoMatches for the whole batch, device resident (pair p = images 2p / 2p+1), median
     # rejection included; the outputs of the extraction above are its inputs
     stereo = None
-    if world == 1:
+    if aux:
         msorb.stereo_matches_batch(ex, counts_h, d_kps, d_desc, KITTI_MB, KITTI_MBF)
         sms = [msorb.stereo_matches_batch(ex, counts_h, d_kps, d_desc, KITTI_MB, KITTI_MBF)[3] for _ in range(15)]
         d_ur, _, _, _ = msorb.stereo_matches_batch(ex, counts_h, d_kps, d_desc, KITTI_MB, KITTI_MBF)
@@ -684,11 +696,11 @@ def main():
     # fourth: BASELINE configs[2] — the front-end of one tracking frame as a device-resident chain (csrc/track.hip): extraction of
     # both eyes + ComputeStereoMatches + AssignFeaturesToGrid + isInFrustum + the window search of SearchByProjection
     tracking = None
-    if world == 1:
+    if aux:
         tracking = tracking_loop_leg(msorb, synth, torch, ex, cfg, base, counts_h, d_kps, d_desc, d_ur, dev, local, args)
 
     per_frame = host_fed = None
-    if world == 1:
+    if aux:
         per_frame = per_frame_leg(msorb, ex, base[0], base[1])
 
     # per-kernel roofline: the same step with every kernel alone on the GPU (1 sub-batch, blur on the main stream),
@@ -745,7 +757,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dt, kp_total = float(tmax[0]), int(t[1])
 
-    if world == 1 and not args.isolated:
+    if aux and not args.isolated:
         hf_ex = [ex, make_ex()]
         host_fed = host_fed_leg(msorb, torch, hf_ex, host, dev, cfg, pitch)
         all_ex.append(hf_ex[1])
@@ -860,7 +872,7 @@ def main():
         if tracking is not None:
             tracking.pop("_cpu", None)
         out["tracking_loop"] = tracking
-        if world == 1:
+        if aux:
             out["sparsification"] = sparsification_leg(msorb, args.cpu_pairs > 0)
         if world > 1:
             out["stereo_join"] = {

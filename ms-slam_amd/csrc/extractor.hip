@@ -218,7 +218,7 @@ struct msorb_extractor {
     PinBuf<int> h_level_count, h_img_base, h_sel_count, h_mono;
     PinBuf<Cand16> h_compact;
     PinBuf<SelRec> h_sel;
-    PinBuf<uint8_t> h_pyr, h_img_pin, h_out_pin;
+    PinBuf<uint8_t> h_pyr, h_img_pin, h_out_pin, h_gather;
     bool h_pyr_valid = false;
 
     // last call
@@ -737,7 +737,7 @@ void msorb_extractor_destroy(msorb_extractor* h) {
     if (h->ev_pyr_done) (void)hipEventDestroy(h->ev_pyr_done);
     if (h->pyr_stream) { (void)hipStreamSynchronize(h->pyr_stream); (void)hipStreamDestroy(h->pyr_stream); }
     h->h_level_count.release(); h->h_img_base.release(); h->h_sel_count.release(); h->h_compact.release();
-    h->h_sel.release(); h->h_pyr.release(); h->h_img_pin.release(); h->h_out_pin.release();
+    h->h_sel.release(); h->h_pyr.release(); h->h_img_pin.release(); h->h_out_pin.release(); h->h_gather.release();
     for (auto& G : h->grp) {
         if (!G.ready) continue;
         (void)hipStreamSynchronize(G.s);
@@ -1187,19 +1187,34 @@ int msorb_extract_stereo_split(msorb_extractor* L, msorb_extractor* R, const uin
     HIPCHK(hipSetDevice(R->device));
     if ((rc = R->d_out1.ensure(kp_bytes + (size_t)cap * 32 + 16))) return rc;
     if (!R->ev_split) HIPCHK(hipEventCreateWithFlags(&R->ev_split, hipEventDisableTiming));
-    if (L->device != R->device) {  // direct xGMI copies when the devices can reach each other (else the runtime stages through the host)
+    // Direct xGMI copies when the devices can reach each other.  Without peer access (or with MSORB_SPLIT_NO_PEER=1, which
+    // forces this path on any pair of handles so that it is testable on one GPU) the gather is staged through pinned host
+    // memory explicitly: device B -> pinned block on B's stream, event, pinned block -> device A on A's stream.
+    bool peer = true;
+    if (L->device != R->device) {
         static std::mutex peer_mu;
-        static std::vector<std::pair<int, int>> enabled;
+        static std::vector<std::pair<std::pair<int, int>, bool>> known;
         std::lock_guard<std::mutex> lk(peer_mu);
-        if (std::find(enabled.begin(), enabled.end(), std::make_pair(L->device, R->device)) == enabled.end()) {
+        auto it = std::find_if(known.begin(), known.end(), [&](const auto& e) { return e.first == std::make_pair(L->device, R->device); });
+        if (it == known.end()) {
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, R->device, L->device) == hipSuccess && can) {
+            const bool ok = hipDeviceCanAccessPeer(&can, R->device, L->device) == hipSuccess && can;
+            if (ok) {
                 (void)hipSetDevice(R->device); (void)hipDeviceEnablePeerAccess(L->device, 0);
                 (void)hipSetDevice(L->device); (void)hipDeviceEnablePeerAccess(R->device, 0);
                 (void)hipGetLastError();  // "already enabled" is fine
             }
-            enabled.emplace_back(L->device, R->device);
+            known.emplace_back(std::make_pair(L->device, R->device), ok);
+            peer = ok;
+        } else {
+            peer = it->second;
         }
+    }
+    if (getenv("MSORB_SPLIT_NO_PEER")) peer = false;
+    const size_t g_kp = 0, g_desc = kp_bytes, g_cnt = g_desc + (size_t)cap * 32, g_pyr = g_cnt + 16, g_total = g_pyr + g.pyramid_bytes;
+    if (!peer) {
+        HIPCHK(hipSetDevice(L->device));
+        if ((rc = L->h_gather.ensure(g_total))) return rc;
     }
     int counts[1] = {0}, mono[1] = {0};
     // ---- right eye: upload + chain on device B (enqueued first: the join waits for it)
@@ -1215,10 +1230,17 @@ int msorb_extract_stereo_split(msorb_extractor* L, msorb_extractor* R, const uin
     }
     uint8_t* const blk = L->d_st_block.p;
     // gather onto device A, on B's stream behind its chain
-    HIPCHK(hipMemcpyPeerAsync(blk + kp_bytes, L->device, R->d_out1.p, R->device, kp_bytes, R->stream));
-    HIPCHK(hipMemcpyPeerAsync(blk + o_desc + (size_t)cap * 32, L->device, R->d_out1.p + kp_bytes, R->device, (size_t)cap * 32, R->stream));
-    HIPCHK(hipMemcpyPeerAsync(L->d_gather_cnt.p, L->device, R->d_sel_count.p, R->device, sizeof(int), R->stream));
-    HIPCHK(hipMemcpyPeerAsync(L->d_gather_pyr.p, L->device, R->d_pyr.p, R->device, g.pyramid_bytes, R->stream));
+    if (peer) {
+        HIPCHK(hipMemcpyPeerAsync(blk + kp_bytes, L->device, R->d_out1.p, R->device, kp_bytes, R->stream));
+        HIPCHK(hipMemcpyPeerAsync(blk + o_desc + (size_t)cap * 32, L->device, R->d_out1.p + kp_bytes, R->device, (size_t)cap * 32, R->stream));
+        HIPCHK(hipMemcpyPeerAsync(L->d_gather_cnt.p, L->device, R->d_sel_count.p, R->device, sizeof(int), R->stream));
+        HIPCHK(hipMemcpyPeerAsync(L->d_gather_pyr.p, L->device, R->d_pyr.p, R->device, g.pyramid_bytes, R->stream));
+    } else {
+        uint8_t* hg = L->h_gather.p;
+        HIPCHK(hipMemcpyAsync(hg + g_kp, R->d_out1.p, kp_bytes + (size_t)cap * 32, hipMemcpyDeviceToHost, R->stream));   // keypoints + descriptors
+        HIPCHK(hipMemcpyAsync(hg + g_cnt, R->d_sel_count.p, sizeof(int), hipMemcpyDeviceToHost, R->stream));
+        HIPCHK(hipMemcpyAsync(hg + g_pyr, R->d_pyr.p, g.pyramid_bytes, hipMemcpyDeviceToHost, R->stream));
+    }
     HIPCHK(hipEventRecord(R->ev_split, R->stream));
     // ---- left eye: upload + chain on device A
     HIPCHK(hipSetDevice(L->device));
@@ -1235,6 +1257,13 @@ int msorb_extract_stereo_split(msorb_extractor* L, msorb_extractor* R, const uin
     }
     // ---- join (Frame.cc:126-127) + ComputeStereoMatches on device A
     HIPCHK(hipStreamWaitEvent(s, R->ev_split, 0));
+    if (!peer) {   // second half of the staged gather: pinned block -> device A, behind the event
+        const uint8_t* hg = L->h_gather.p;
+        HIPCHK(hipMemcpyAsync(blk + kp_bytes, hg + g_kp, kp_bytes, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(blk + o_desc + (size_t)cap * 32, hg + g_desc, (size_t)cap * 32, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(L->d_gather_cnt.p, hg + g_cnt, sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(L->d_gather_pyr.p, hg + g_pyr, g.pyramid_bytes, hipMemcpyHostToDevice, s));
+    }
     StereoBatchArgs b{};
     b.pair_step = 1;
     b.A.kpL = reinterpret_cast<msorb_keypoint*>(blk);

@@ -288,6 +288,102 @@ __device__ __forceinline__ void pyr_band_tile(const LevelView& src, const LevelV
     }
 }
 
+template <int R, int kSrc>
+__device__ __forceinline__ void pyr_band_tile_reg(const LevelView& src, const LevelView& dst, uint8_t* __restrict__ dst_base,
+                                              const ResizeTap* __restrict__ tx, const ResizeTap* __restrict__ ty, const int img,
+                                              const int bx, const int dy0, const int lane) {
+    const int dx0 = (bx * 64 + lane) * 4;
+    if (dy0 >= dst.h) return;   // wave-uniform
+    const int n_out = min(R, dst.h - dy0);
+    // y taps of the band (wave-uniform addresses: scalar loads)
+    uint32_t ti[R], tc[R];      // i0 | i1 << 16, c0 | c1 << 16
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const uint2 v = reinterpret_cast<const uint2*>(ty)[__builtin_amdgcn_readfirstlane(dy0 + min(k, n_out - 1))];
+        ti[k] = __builtin_amdgcn_readfirstlane(v.x);
+        tc[k] = __builtin_amdgcn_readfirstlane(v.y);
+    }
+    const int s_lo = (int)(ti[0] & 0xffffu);
+    int s_hi = s_lo;
+#pragma unroll
+    for (int k = 0; k < R; k++) s_hi = max(s_hi, (int)(ti[k] >> 16));
+    const int n_src = s_hi - s_lo + 1;   // <= kSrc (checked on the host)
+    const bool active = dx0 < dst.w;
+    // x taps of this column group -> byte selectors and weights (as pyr_resize_rows_kernel)
+    const int dxc = active ? dx0 : 0;
+    const uint4 ta = reinterpret_cast<const uint4*>(tx + dxc)[0];
+    const uint4 tb = reinterpret_cast<const uint4*>(tx + dxc)[1];
+    const uint32_t tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};  // per tap: {i0|i1<<16, c0|c1<<16}
+    const int base = (int)(tw[0] & 0xffffu) & ~3;  // aligned column of the first source pixel
+    // The 4 taps of a lane start within 5 source pixels of the first one (scale <= 1.25): two v_alignbyte bring the 12-byte
+    // window to "first tap at byte 0", then one v_perm per tap puts its two pixels into the u16 halves for v_dot2_u32_u16.
+    const uint32_t o0 = (tw[0] & 0xffffu) - (uint32_t)base;   // 0..3
+    uint32_t sel[4], cw[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t r = (tw[2 * i] & 0xffffu) - (uint32_t)base - o0;  // 0..5; at the right edge i1 == i0 and c1 == 0
+        sel[i] = r | (0x0cu << 8) | ((r + 1) << 16) | (0x0cu << 24);
+        cw[i] = tw[2 * i + 1];  // c0 | c1 << 16, both in [0, 2048]
+    }
+    const uint8_t* sb = src.base + (size_t)img * src.img_stride + (size_t)(uint32_t)base;
+    // phase A (the parked rows live in registers: phase B picks them with wave-uniform indices, which the compiler turns into
+    // s_set_gpr_idx + v_mov — one VALU move per operand instead of an LDS round trip, and the kernel needs no LDS at all)
+    uint32_t park_x[kSrc], park_y[kSrc];
+    uint32_t raw[kSrc][3];
+#pragma unroll
+    for (int r = 0; r < kSrc; r++) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(sb + (size_t)min(s_lo + r, s_hi) * src.pitch);
+        raw[r][0] = q[0]; raw[r][1] = q[1]; raw[r][2] = q[2];
+    }
+#pragma unroll
+    for (int r = 0; r < kSrc; r++) {
+        if (r < n_src) {   // wave-uniform
+            const uint32_t lo = __builtin_amdgcn_alignbyte(raw[r][1], raw[r][0], o0);
+            const uint32_t hi = __builtin_amdgcn_alignbyte(raw[r][2], raw[r][1], o0);
+            uint32_t H[4];   // (src[i0]*c0 + src[i1]*c1) >> 4 <= 32640
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                H[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(hi, lo, sel[i])),
+                                              __builtin_bit_cast(ushort2v, cw[i]), 0u, false) >> 4;
+            park_x[r] = H[0] | (H[1] << 16);
+            park_y[r] = H[2] | (H[3] << 16);
+        } else {
+            park_x[r] = 0; park_y[r] = 0;
+        }
+    }
+    // phase B: ((b0 * H0) >> 16) + ((b1 * H1) >> 16) + 2) >> 2 with the u16 halves picked by SDWA operand selects
+    uint8_t* d = dst_base + (size_t)img * dst.img_stride + (size_t)(uint32_t)dx0;
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        if (k < n_out) {   // wave-uniform
+            const int n0 = (int)(ti[k] & 0xffffu) - s_lo, n1 = (int)(ti[k] >> 16) - s_lo;
+            const uint32_t b0 = tc[k] & 0xffffu, b1 = tc[k] >> 16;
+            const uint2 A = uint2{park_x[n0], park_y[n0]}, B = uint2{park_x[n1], park_y[n1]};
+            const uint32_t t0 = sdwa_hi_sum(sdwa_mul_lo(b0, A.x), sdwa_mul_lo(b1, B.x));
+            const uint32_t t1 = sdwa_hi_sum(sdwa_mul_hi(b0, A.x), sdwa_mul_hi(b1, B.x));
+            const uint32_t t2 = sdwa_hi_sum(sdwa_mul_lo(b0, A.y), sdwa_mul_lo(b1, B.y));
+            const uint32_t t3 = sdwa_hi_sum(sdwa_mul_hi(b0, A.y), sdwa_mul_hi(b1, B.y));
+            const ushort2v two = {2, 2};
+            const ushort2v p01 = (__builtin_bit_cast(ushort2v, t0 | (t1 << 16)) + two) >> 2;
+            const ushort2v p23 = (__builtin_bit_cast(ushort2v, t2 | (t3 << 16)) + two) >> 2;
+            const uint32_t packed = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p23), __builtin_bit_cast(uint32_t, p01), 0x06040200u);
+            if (active) *reinterpret_cast<uint32_t*>(d + (size_t)(dy0 + k) * dst.pitch) = packed;
+        }
+    }
+}
+
+// LDS-free form of the band kernel (same arithmetic, the parked rows in registers): beside the other batch's FAST / quadtree /
+// describe workgroups, which keep a CU's LDS filled to within a few KB, a workgroup that asks for no LDS starts as soon as
+// two wave slots are free — the LDS form's levels were stretched from 0.05 to 0.8 ms there (profiles/round2_timeline_pipelined.txt).
+template <int R, int kSrc, int WAVES = 2>
+__global__ __launch_bounds__(64 * WAVES) void pyr_resize_bandreg_kernel(LevelView src, LevelView dst, uint8_t* __restrict__ dst_base,
+                                                                        const ResizeTap* __restrict__ tx,
+                                                                        const ResizeTap* __restrict__ ty) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int dy0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * WAVES + wave) * R);
+    pyr_band_tile_reg<R, kSrc>(src, dst, dst_base, tx, ty, blockIdx.z, blockIdx.x, dy0, lane);
+}
+
 template <int R, int kSrc, int WAVES = 4>
 __global__ __launch_bounds__(64 * WAVES) void pyr_resize_band_kernel(LevelView src, LevelView dst, uint8_t* __restrict__ dst_base,
                                                                      const ResizeTap* __restrict__ tx,
@@ -1577,7 +1673,13 @@ void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_
         // two waves (12 KB of LDS) per workgroup: beside the other batch's FAST / quadtree / describe, which fill a CU's LDS
         // to within 5-12 KB, small workgroups find room sooner (1.310 against 1.324 ms per step with 4 waves, 1.336 with 1)
         static const int bw = getenv("MSORB_PYR_BAND_WAVES") ? atoi(getenv("MSORB_PYR_BAND_WAVES")) : 2;
-        if (bw == 1) hipLaunchKernelGGL((pyr_resize_band_kernel<R, 12, 1>), dim3((dst.w + 255) / 256, (dst.h + R - 1) / R, n_images), dim3(64), 0, s, src, dst, dst_base, tx, ty);
+        const bool lds_form = getenv("MSORB_PYR_BAND_LDS") != nullptr;   // the round-2 form (rows parked in LDS); test aid
+        if (!lds_form) {
+            if (bw == 1) hipLaunchKernelGGL((pyr_resize_bandreg_kernel<R, 12, 1>), dim3((dst.w + 255) / 256, (dst.h + R - 1) / R, n_images), dim3(64), 0, s, src, dst, dst_base, tx, ty);
+            else if (bw == 4) hipLaunchKernelGGL((pyr_resize_bandreg_kernel<R, 12, 4>), band_grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
+            else hipLaunchKernelGGL((pyr_resize_bandreg_kernel<R, 12, 2>), dim3((dst.w + 255) / 256, (dst.h + 2 * R - 1) / (2 * R), n_images), dim3(128), 0, s, src, dst, dst_base, tx, ty);
+        }
+        else if (bw == 1) hipLaunchKernelGGL((pyr_resize_band_kernel<R, 12, 1>), dim3((dst.w + 255) / 256, (dst.h + R - 1) / R, n_images), dim3(64), 0, s, src, dst, dst_base, tx, ty);
         else if (bw == 2) hipLaunchKernelGGL((pyr_resize_band_kernel<R, 12, 2>), dim3((dst.w + 255) / 256, (dst.h + 2 * R - 1) / (2 * R), n_images), dim3(128), 0, s, src, dst, dst_base, tx, ty);
         else hipLaunchKernelGGL((pyr_resize_band_kernel<R, 12, 4>), band_grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
     }

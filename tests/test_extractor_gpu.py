@@ -185,17 +185,20 @@ def test_batch_kernels_full_size(msorb_mod, oracle, name):
 
 
 @pytest.mark.parametrize("name", ["kitti", "euroc", "fourseasons", "odd"])
-@pytest.mark.parametrize("kernel", ["dma", "band", "rows"])
+@pytest.mark.parametrize("kernel", ["dma", "band", "band_lds", "rows"])
 def test_batch_pyramid_kernels_on_padded_rows(msorb_mod, oracle, monkeypatch, name, kernel):
-    """The three batch pyramid kernels (register band kernel = default, LDS-DMA band kernel on 16-byte aligned rows,
-    row-streaming kernel) on a batch whose rows are padded to a multiple of 64 bytes, as bench.py lays its images out:
-    every level of every distinct image is the oracle's cv::resize restatement, bit for bit."""
+    """The batch pyramid kernels (LDS-free band kernel with the parked rows in registers = default, the same with the rows
+    parked in LDS, LDS-DMA band kernel on 16-byte aligned rows, row-streaming kernel) on a batch whose rows are padded to a
+    multiple of 64 bytes, as bench.py lays its images out: every level of every distinct image is the oracle's cv::resize
+    restatement, bit for bit."""
     import torch
     cfg = CONFIGS[name] if name != "odd" else dict(rows=333, cols=517, nfeatures=700, scale=1.2, nlevels=8, ini_th=20, min_th=7)
     if kernel == "dma":
         monkeypatch.setenv("MSORB_PYR_DMA", "1")
     elif kernel == "rows":
         monkeypatch.setenv("MSORB_PYR_ROWS", "1")
+    elif kernel == "band_lds":
+        monkeypatch.setenv("MSORB_PYR_BAND_LDS", "1")
     ex, ref = _pair(msorb_mod, oracle, cfg)
     n = 16
     pitch = (cfg["cols"] + 63) // 64 * 64

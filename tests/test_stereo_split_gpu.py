@@ -110,3 +110,28 @@ def test_split_batch_equals_interleaved_batch(msorb_mod, oracle):
             assert np.array_equal(exp.debug_level(2, l), exr.debug_level(2, l))
     finally:
         ex.close(); exl.close(); exr.close(); exp.close()
+
+
+def test_extract_stereo_split_without_peer_access(msorb_mod, oracle, monkeypatch):
+    """The gather of msorb_extract_stereo_split when the two devices cannot reach each other over xGMI: staged explicitly through
+    pinned host memory (device B -> pinned block -> device A, ordered by one event).  MSORB_SPLIT_NO_PEER=1 forces that path
+    on any pair of handles — here both on one device, on a multi-GPU box across two — and the results must not change."""
+    rows, cols = 376, 1241
+    mbf, mb = mc.KITTI_BF, mc.KITTI_BF / mc.KITTI_FX
+    dev_a, dev_b = _devices(msorb_mod)
+    L, R = synth.stereo_pair(47, rows, cols)
+    exl = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7, device=dev_a)
+    exr = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7, device=dev_b)
+    try:
+        want = exl.extract_stereo_split(exr, L, R, mb, mbf)          # peer / device-local copies
+        monkeypatch.setenv("MSORB_SPLIT_NO_PEER", "1")
+        for _ in range(2):
+            got = exl.extract_stereo_split(exr, L, R, mb, mbf)
+            for a, b in zip(got[:6], want[:6]):
+                assert np.array_equal(a.view(np.uint8) if a.dtype.fields else a.view(np.uint8), b.view(np.uint8))
+            assert got[6] == want[6] and (got[4] > 0).sum() > 500
+        monkeypatch.delenv("MSORB_SPLIT_NO_PEER")
+        again = exl.extract_stereo_split(exr, L, R, mb, mbf)
+        assert np.array_equal(again[4].view(np.uint32), want[4].view(np.uint32))
+    finally:
+        exl.close(); exr.close()

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$1; shift
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o r -- python $R/bench.py --steps 3 --warmup 1 --cpu-pairs 0 --isolated "$@" > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o r -- python $R/bench.py --steps 3 --warmup 1 --lean --isolated "$@" > $OUT/bench.log 2>&1
 python - <<PY
 import csv,collections
 rows=list(csv.DictReader(open("$OUT/r_kernel_trace.csv")))

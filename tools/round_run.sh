@@ -8,9 +8,9 @@ python bench.py --unique-pairs 128 --steps 100 --warmup 10 --cpu-pairs 0 > $O/be
 python bench.py --steps 100 --warmup 10 --cpu-pairs 0 > $O/bench_unique8_same_steps.json 2>/dev/null
 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 | tee $O/pytest_gpu.txt
 timeout -k 5 300 tools/gpu_trace.sh round/trace > $O/trace.txt 2>&1; tail -30 $O/trace.txt
-PMC_TIMEOUT=300 tools/pmc_run.sh round/pmc_fetch "FETCH_SIZE" "" -- python bench.py --steps 2 --warmup 1 --cpu-pairs 0 --isolated > $O/pmc_fetch.txt 2>&1
-PMC_TIMEOUT=300 tools/pmc_run.sh round/pmc_write "WRITE_SIZE" "" -- python bench.py --steps 2 --warmup 1 --cpu-pairs 0 --isolated > $O/pmc_write.txt 2>&1
-PMC_TIMEOUT=300 tools/pmc_run.sh round/pmc_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE" "" -- python bench.py --steps 2 --warmup 1 --cpu-pairs 0 --isolated > $O/pmc_valu.txt 2>&1
+PMC_TIMEOUT=300 tools/pmc_run.sh round/pmc_fetch "FETCH_SIZE" "" -- python bench.py --steps 2 --warmup 1 --lean --isolated > $O/pmc_fetch.txt 2>&1
+PMC_TIMEOUT=300 tools/pmc_run.sh round/pmc_write "WRITE_SIZE" "" -- python bench.py --steps 2 --warmup 1 --lean --isolated > $O/pmc_write.txt 2>&1
+PMC_TIMEOUT=300 tools/pmc_run.sh round/pmc_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE" "" -- python bench.py --steps 2 --warmup 1 --lean --isolated > $O/pmc_valu.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/fetch_calib.hip -o tools/_fetch_calib 2>/dev/null; tools/fetch_calib.sh > $O/fetch_calib.txt 2>&1; cat $O/fetch_calib.txt
 python tools/latency_bench.py > $O/latency.json 2> $O/latency.err; cat $O/latency.json
 python tools/bow_bench.py > $O/bow_bench.json 2>/dev/null; cat $O/bow_bench.json

@@ -3,5 +3,5 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/timeline; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-( cd $R && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python bench.py --steps 12 --warmup 4 --cpu-pairs 0 > $OUT/bench.log 2>&1 )
+( cd $R && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python bench.py --steps 12 --warmup 4 --lean > $OUT/bench.log 2>&1 )
 ls $OUT
