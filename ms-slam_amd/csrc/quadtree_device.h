@@ -424,7 +424,10 @@ QT_HD void sort_scratch(Workspace& w, QT_LDS int* cnt_np, QT_LDS uint16_t* ranko
     w.ps.lpos = w.ps.gpos + (w.m + 4);
 }
 
-constexpr int kPassBatch = 4;  // points per thread whose LDS stages are issued together in the phased passes
+#ifndef QT_PASS_BATCH
+#define QT_PASS_BATCH 4
+#endif
+constexpr int kPassBatch = QT_PASS_BATCH;  // points per thread whose LDS stages are issued together in the phased passes
 
 QT_HD int quadrant_of(const Pt& p, const NodeB& b) {  // DivideNode's assignment (:511-525)
     const int mx = b.x0 + ((b.x1 - b.x0 + 1) >> 1), my = b.y0 + ((b.y1 - b.y0 + 1) >> 1);  // ceil(w/2), ceil(h/2)
@@ -457,7 +460,7 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
         // four candidates in flight per thread: the loads of a batch are issued together, so the pass pays the global
         // latency once per four points instead of once per point (the per-point bodies hold LDS atomics, which keep
         // the compiler from overlapping iterations on its own)
-        constexpr int kBatch = 4;
+        constexpr int kBatch = kPassBatch;
         for (int p0 = tid + PC * nt; p0 < n; p0 += kBatch * nt) {
             Pt q[kBatch];
             uint16_t l[kBatch], l0[kBatch];

@@ -20,6 +20,9 @@
 //   ORB_SLAM3::msorb_host::ExtractStereo(F, left, imLeft, imRight)
 //                                                        the two ExtractORB threads + ComputeStereoMatches of the stereo
 //                                                        Frame constructor (src/Frame.cc:119-137) as ONE device call
+//   ORB_SLAM3::msorb_host::ExtractStereoFrame(dev, F, left, imLeft, imRight)
+//                                                        ExtractStereo + Frame::AssignFeaturesToGrid (src/Frame.cc:385-416) on the
+//                                                        device: `dev` is ready for the searches without an upload
 //   ORB_SLAM3::msorb_host::ExtractStereoSplit(F, left, right, imLeft, imRight)
 //                                                        the same with one extractor object per GPU (left / right eye on
 //                                                        devices A / B, gather over xGMI, association on A)
@@ -938,6 +941,35 @@ void ExtractStereo(FrameT& F, const ExtractorT& left, const MatT& imLeft, const 
                                &nl, reinterpret_cast<msorb_keypoint*>(F.mvKeysRight.data()), dr.data(), &nr, cap, ur.data(),
                                depth.data(), &oob),
           "msorb_extract_stereo");
+    F.mvKeys.resize(nl);
+    F.mvKeysRight.resize(nr);
+    F.mDescriptors.create(nl, 32, 0 /* CV_8U */);
+    F.mDescriptorsRight.create(nr, 32, 0 /* CV_8U */);
+    for (int i = 0; i < nl; i++) std::memcpy(F.mDescriptors.template ptr<unsigned char>(i), &dl[(size_t)i * 32], 32);
+    for (int i = 0; i < nr; i++) std::memcpy(F.mDescriptorsRight.template ptr<unsigned char>(i), &dr[(size_t)i * 32], 32);
+    F.mvuRight.assign(ur.begin(), ur.begin() + nl);
+    F.mvDepth.assign(depth.begin(), depth.begin() + nl);
+}
+
+// ExtractStereo that also leaves the frame on the DEVICE, ready for the searches: the stereo constructor up to and including
+// AssignFeaturesToGrid (Frame.cc:119-137 + :385-416) — `dev` is filled from the device-resident left keypoints / descriptors /
+// mvuRight (grid by frame_grid_kernel) inside the same call, so the dev.Upload(F) that SearchByProjection / SearchLocalPoints
+// would need is gone.  F.mnMinX .. F.mnMaxY must be set (ComputeImageBounds runs before the extraction for the first frame,
+// Frame.cc:139-160); for rectified input mvKeysUn == mvKeys (Frame.cc:681-685), which is what the device copy holds.
+template <class FrameT, class ExtractorT, class MatT>
+void ExtractStereoFrame(DeviceFrame<FrameT>& dev, FrameT& F, const ExtractorT& left, const MatT& imLeft, const MatT& imRight) {
+    const int cap = msorb_extractor_capacity(left.handle());
+    F.mvKeys.resize(cap);
+    F.mvKeysRight.resize(cap);
+    static_assert(sizeof(F.mvKeys[0]) == sizeof(msorb_keypoint), "cv::KeyPoint must be the 28-byte layout");
+    std::vector<uint8_t> dl((size_t)cap * 32), dr((size_t)cap * 32);
+    std::vector<float> ur(cap), depth(cap);
+    int nl = 0, nr = 0, oob = 0;
+    check(msorb_extract_stereo_frame(left.handle(), dev.get(), imLeft.data, imRight.data, imLeft.rows, imLeft.cols, (size_t)imLeft.step,
+                                     (size_t)imRight.step, F.mb, F.mbf, reinterpret_cast<msorb_keypoint*>(F.mvKeys.data()), dl.data(),
+                                     &nl, reinterpret_cast<msorb_keypoint*>(F.mvKeysRight.data()), dr.data(), &nr, cap, ur.data(),
+                                     depth.data(), &oob, F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY),
+          "msorb_extract_stereo_frame");
     F.mvKeys.resize(nl);
     F.mvKeysRight.resize(nr);
     F.mDescriptors.create(nl, 32, 0 /* CV_8U */);

@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "libmsorb.so")
+LIB_PATH = os.environ.get("MSORB_LIB") or os.path.join(_PKG, "libmsorb.so")   # MSORB_LIB: an experimental build (tools/)
 _LIB = None
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),

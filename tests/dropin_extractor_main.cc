@@ -15,6 +15,7 @@ struct Frame {  // the members the stereo constructor fills (include/Frame.h)
     cv::Mat mDescriptors, mDescriptorsRight;
     std::vector<float> mvuRight, mvDepth;
     float mb = 0, mbf = 0;
+    float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0;
 };
 }  // namespace ORB_SLAM3
 
@@ -44,10 +45,19 @@ static int stereo_main(int rows, int cols, const char* lp, const char* rp, const
     C.mb = D.mb = mb; C.mbf = D.mbf = mbf;
     msorb_host::ExtractStereoSplit(C, exS0, exS1, imL, imR);
     msorb_host::ExtractStereoSplit(D, exS0, exS1, imL, imR);
+    // ... and the constructor up to AssignFeaturesToGrid with the frame left on the device (msorb_host::ExtractStereoFrame)
+    Frame E;
+    E.mb = mb; E.mbf = mbf;
+    E.mnMinX = 0; E.mnMaxX = (float)cols; E.mnMinY = 0; E.mnMaxY = (float)rows;
+    msorb_host::DeviceFrame<Frame> dev;
+    msorb_host::ExtractStereoFrame(dev, E, exF, imL, imR);
+    std::vector<int> cell_begin(64 * 48 + 1), cell_idx(E.mvKeys.size() + 1);
+    int n_assigned = 0;
+    if (msorb_frame_grid(dev.get(), cell_begin.data(), cell_idx.data(), (int)cell_idx.size(), &n_assigned)) return 4;
     FILE* o = fopen(out, "wb");
     const int devs[2] = {exS0.device(), exS1.device()};
     fwrite(devs, 4, 2, o);
-    for (Frame* F : {&A, &B, &C, &D}) {
+    for (Frame* F : {&A, &B, &C, &D, &E}) {
         const int n = (int)F->mvKeys.size(), nr = (int)F->mvKeysRight.size();
         fwrite(&n, 4, 1, o); fwrite(&nr, 4, 1, o);
         fwrite(F->mvKeys.data(), sizeof(cv::KeyPoint), n, o);
@@ -56,6 +66,9 @@ static int stereo_main(int rows, int cols, const char* lp, const char* rp, const
         for (int i = 0; i < nr; i++) fwrite(F->mDescriptorsRight.ptr<unsigned char>(i), 1, 32, o);
         fwrite(F->mvuRight.data(), 4, n, o); fwrite(F->mvDepth.data(), 4, n, o);
     }
+    fwrite(&n_assigned, 4, 1, o);
+    fwrite(cell_begin.data(), 4, cell_begin.size(), o);
+    fwrite(cell_idx.data(), 4, n_assigned, o);
     fclose(o);
     return 0;
 }

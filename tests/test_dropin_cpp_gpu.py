@@ -690,7 +690,7 @@ def test_cpp_stereo_frame_constructor_one_call(tmp_path, oracle, msorb_mod):
     devs = struct.unpack_from("<ii", blob, 0)
     assert devs == ((0, 1) if n_dev >= 2 else (0, 0))      # construction order -> device (ORBextractor.cc next_device)
     pos, frames = 8, []
-    for _ in range(4):
+    for _ in range(5):
         n, nr = struct.unpack_from("<ii", blob, pos)
         pos += 8
         kl = np.frombuffer(blob, oracle.KP_DTYPE, n, pos); pos += 28 * n
@@ -700,13 +700,21 @@ def test_cpp_stereo_frame_constructor_one_call(tmp_path, oracle, msorb_mod):
         ur = np.frombuffer(blob, np.float32, n, pos); pos += 4 * n
         dp = np.frombuffer(blob, np.float32, n, pos); pos += 4 * n
         frames.append((kl, kr, dl, dr, ur, dp))
-    a, b, c, d = frames     # ExtractStereo, the reference's sequence, ExtractStereoSplit (one object per device) twice
-    for other in (b, c, d):
+    a, b, c, d, e = frames  # ExtractStereo, the reference's sequence, ExtractStereoSplit (one object per device) twice, ExtractStereoFrame
+    for other in (b, c, d, e):
         for x, y in zip(a, other):
             assert x.tobytes() == y.tobytes()
     _, okl, odl = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)(L)
     assert np.array_equal(a[0].view(np.uint8), okl.view(np.uint8)) and np.array_equal(a[2], odl)
     assert (a[4] > 0).sum() > 500
+    # the device frame ExtractStereoFrame left behind: its grid is Frame::AssignFeaturesToGrid of the oracle
+    n_assigned = struct.unpack_from("<i", blob, pos)[0]
+    pos += 4
+    cb = np.frombuffer(blob, np.int32, 64 * 48 + 1, pos); pos += 4 * (64 * 48 + 1)
+    ci = np.frombuffer(blob, np.int32, n_assigned, pos)
+    rf = oracle.OracleFrame(e[0], e[2], e[4], (0.0, float(cfg["cols"]), 0.0, float(cfg["rows"])), (np.float32(1.2) ** np.arange(8)).astype(np.float32))
+    rcb, rci = rf.grid_csr()
+    assert np.array_equal(cb, rcb) and np.array_equal(ci, rci) and n_assigned == len(e[0])
 
 
 def test_cpp_search_local_points_chain_matches_oracle(tmp_path, oracle, msorb_mod):

@@ -190,15 +190,16 @@ int main(int argc, char** argv) {
         msorb_frame_destroy(f2);
         msorb_extractor_destroy(fx);
     }
-    printf("{\"tracking_chain\": {\"map_points\": %d, \"ms_extract_stereo_frame\": %.4f, \"ms_search_local_points\": %.4f, "
-           "\"ms_two_calls\": %.4f, \"matches_two_calls\": %d, \"ms_track_frontend_one_call\": %.4f, \"matches_one_call\": %d, "
-           "\"window_rounds\": %d}}\n",
-           M, med(t_esf), med(t_slp), med(t_esf) + med(t_slp), nm_chain, med(t_one), nm_one, rounds);
-    printf("{\"keypoints\": [%d, %d], \"ms_stereo_pair_two_threads_median\": %.4f, \"ms_single_image_median\": %.4f, "
+    char chain[512];
+    snprintf(chain, sizeof chain, "{\"map_points\": %d, \"ms_extract_stereo_frame\": %.4f, \"ms_search_local_points\": %.4f, "
+             "\"ms_two_calls\": %.4f, \"matches_two_calls\": %d, \"ms_track_frontend_one_call\": %.4f, \"matches_one_call\": %d, "
+             "\"window_rounds\": %d}",
+             M, med(t_esf), med(t_slp), med(t_esf) + med(t_slp), nm_chain, med(t_one), nm_one, rounds);
+    printf("{\"tracking_chain\": %s, \"keypoints\": [%d, %d], \"ms_stereo_pair_two_threads_median\": %.4f, \"ms_single_image_median\": %.4f, "
            "\"ms_stereo_matches\": %.4f, \"ms_frame_grid_upload\": %.4f, \"ms_search_by_projection_4096\": %.4f, "
            "\"ms_is_in_frustum_4096\": %.4f, \"ms_tracking_frame_front_end\": %.4f, \"projection_matches\": %d, "
            "\"ms_extract_stereo_fused\": %.4f}\n",
-           n[0], n[1], pair_ms[iters / 2], single_ms[iters / 2], med(t_st), med(t_fs), med(t_sp), med(t_fr), med(t_all), nm, med(t_fused));
+           chain, n[0], n[1], pair_ms[iters / 2], single_ms[iters / 2], med(t_st), med(t_fs), med(t_sp), med(t_fr), med(t_all), nm, med(t_fused));
     for (auto& e : ex) msorb_extractor_destroy(e);
     return 0;
 }
