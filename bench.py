@@ -809,7 +809,7 @@ def main():
         # FETCH_SIZE / WRITE_SIZE passes, per launch, FETCH_SIZE scaled by the calibration kernels of the same run) — only
         # quoted when the batch shape matches
         traffic = None
-        kname = {"fast": "fast_cells_kernel<true, GeoSmall>", "pyramid": "pyr_resize_band_kernel<8, 12, 2>", "blur": "gauss7_stream_kernel<35>",
+        kname = {"fast": "fast_cells_kernel<true, GeoSmall>", "pyramid": "pyr_resize_bandreg_kernel<8, 12, 2>", "blur": "gauss7_stream_kernel<35>",
                  "describe": "describe_kernel", "compact": "cand_gather_kernel"}[dom]
         valu_frac = None
         pmc_file = None
@@ -850,7 +850,7 @@ def main():
             "stage_ms_per_step_overlapped_note": "timed region: sum over the 2 concurrent sub-batches of each stage's event "
                                                  "interval (intervals overlap, so the sum exceeds ms_per_step); not recorded when "
                                                  "two batches are in flight (MSORB_BENCH_SYNC=1 for the one-batch-at-a-time loop)",
-            "roofline": {"bound": "hbm", "kernel": {"fast": "fast_cells_kernel", "pyramid": "pyr_resize_band_kernel (x7)",
+            "roofline": {"bound": "hbm", "kernel": {"fast": "fast_cells_kernel", "pyramid": "pyr_resize_bandreg_kernel (x7)",
                                                     "blur": "gauss7_kernel (x8)", "describe": "describe_kernel",
                                                     "compact": "cand_*"}[dom],
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
