@@ -77,13 +77,13 @@ __device__ __forceinline__ void topk_insert(uint64_t key, int idx, uint64_t k[kT
     }
 }
 
-// One 16-lane group (a DPP row) per query, four queries per wave.  Walks the query's grid window exactly like
+// One group of kWinLanes lanes (16 = a DPP row, or 4) per query.  Walks the query's grid window exactly like
 // Frame::GetFeaturesInArea: cells ix (outer) / iy (inner) ascending, cell contents in insertion order; group lane c owns
 // window cell c, c+16, ...  (A tracking window covers 6-20 cells with about one keypoint each: with a whole wave per query
 // three quarters of the lanes had no cell; per 64 frames x 4096 queries 0.67 -> 0.2 ms.)
 // blockIdx.y = frame of a batch (frame_stride keypoints / q_stride queries apart in every array; 0 / 0 for one frame).
 // kCount: the number of Hamming distances evaluated is added to *n_eval (measurement runs only).
-constexpr int kWinLanes = 16;
+template <int kWinLanes>
 __device__ __forceinline__ uint64_t group_min_u64(uint64_t v) {
 #pragma unroll
     for (int o = kWinLanes / 2; o > 0; o >>= 1) {
@@ -92,7 +92,7 @@ __device__ __forceinline__ uint64_t group_min_u64(uint64_t v) {
     }
     return v;
 }
-template <bool kCount>
+template <bool kCount, int kWinLanes>
 __global__ __launch_bounds__(256) void window_topk_kernel(FrameView F, const WinQuery* __restrict__ q,
                                                           const uint8_t* __restrict__ qdesc, int q_begin, int q_end,
                                                           TopK* __restrict__ out, int frame_stride, int q_stride,
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void window_topk_kernel(FrameView F, const Win
     const bool group_any = ((__ballot(k[0] != kNoKey) >> gshift) & ((1ull << kWinLanes) - 1)) != 0;
 #pragma unroll
     for (int r = 0; r < kTopK; r++) {
-        const uint64_t m = group_min_u64(k[0]);
+        const uint64_t m = group_min_u64<kWinLanes>(k[0]);
         int widx = -1;
         if (m != kNoKey && k[0] == m) {  // keys are unique (scan position), exactly one lane of the group matches
             widx = id[0];
@@ -407,7 +407,10 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoArgs A) {
 
 // vRowIndices (Frame.cc:756-770) for one right image per workgroup, as CSR over the image rows: thread per right
 // keypoint, LDS counters per row, block scan, fill.  The order inside a row is arbitrary (see stereo_match_one).
-__global__ __launch_bounds__(256) void stereo_rowtable_kernel(StereoBatchArgs B) {
+// T threads: 256 for batches (one workgroup per pair, many pairs), 1024 for a frame or two (the table of a single pair is
+// latency: 17 -> ~9 us with four times the threads)
+template <int T>
+__global__ __launch_bounds__(T) void stereo_rowtable_kernel(StereoBatchArgs B) {
     extern __shared__ int rt[];  // [rows0] counts -> cursors, [rows0 + 1] begins
     const int pair = blockIdx.x, t = threadIdx.x;
     const int rows0 = B.A.rows0;
@@ -418,10 +421,10 @@ __global__ __launch_bounds__(256) void stereo_rowtable_kernel(StereoBatchArgs B)
     const msorb_keypoint* kpR = B.A.kpR + img * B.capacity;
     int* row_begin = B.row_begin + (size_t)pair * (rows0 + 1);
     int2* row_list = B.row_list + (size_t)pair * B.row_cap;
-    for (int r = t; r < rows0; r += 256) cnt[r] = 0;
+    for (int r = t; r < rows0; r += T) cnt[r] = 0;
     // each right keypoint's row band, computed once: the first kBandCache rounds of the 256-strided loop keep it in
     // registers (all their loads in flight together), later rounds (more than 2048 right keypoints) recompute it
-    constexpr int kBandCache = 8;
+    constexpr int kBandCache = 2048 / T;
     int band[kBandCache];  // minr | maxr << 16, -1 = no keypoint
     int2 entry[kBandCache];  // the keypoint's table entry: {iR | octave << 24, bits of x}
     auto band_of = [&](int iR, int2& e) -> int {
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(256) void stereo_rowtable_kernel(StereoBatchArgs B)
     };
 #pragma unroll
     for (int k = 0; k < kBandCache; k++) {
-        const int iR = t + k * 256;
+        const int iR = t + k * T;
         band[k] = iR < nR ? band_of(iR, entry[k]) : -1;
     }
     __syncthreads();
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(256) void stereo_rowtable_kernel(StereoBatchArgs B)
     for (int k = 0; k < kBandCache; k++)
         if (band[k] >= 0)
             for (int y = band[k] & 0xffff; y <= (band[k] >> 16); y++) atomicAdd(&cnt[y], 1);
-    for (int iR = t + kBandCache * 256; iR < nR; iR += 256) {
+    for (int iR = t + kBandCache * T; iR < nR; iR += T) {
         int2 e;
         const int bd = band_of(iR, e);
         if (bd >= 0)
@@ -466,8 +469,8 @@ __global__ __launch_bounds__(256) void stereo_rowtable_kernel(StereoBatchArgs B)
         if (t == 0) beg[rows0] = carry;
     }
     __syncthreads();
-    for (int r = t; r <= rows0; r += 256) row_begin[r] = beg[r];
-    for (int r = t; r < rows0; r += 256) cnt[r] = beg[r];
+    for (int r = t; r <= rows0; r += T) row_begin[r] = beg[r];
+    for (int r = t; r < rows0; r += T) cnt[r] = beg[r];
     __syncthreads();
     auto fill = [&](const int2& e, int bd) {
         for (int y = bd & 0xffff; y <= (bd >> 16); y++) {
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(256) void stereo_rowtable_kernel(StereoBatchArgs B)
 #pragma unroll
     for (int k = 0; k < kBandCache; k++)
         if (band[k] >= 0) fill(entry[k], band[k]);
-    for (int iR = t + kBandCache * 256; iR < nR; iR += 256) {
+    for (int iR = t + kBandCache * T; iR < nR; iR += T) {
         int2 e;
         const int bd = band_of(iR, e);
         if (bd >= 0) fill(e, bd);
@@ -644,15 +647,18 @@ void launch_window_list(const FrameView& F, const WinQuery* q, const uint8_t* qd
 }
 
 void launch_window_topk(const FrameView& F, const WinQuery* q, const uint8_t* qdesc, int q_begin, int q_end,
-                        TopK* out, hipStream_t s, int n_frames, int frame_stride, int q_stride, unsigned long long* n_eval) {
+                        TopK* out, hipStream_t s, int n_frames, int frame_stride, int q_stride, unsigned long long* n_eval, int lanes) {
     const int n = q_end - q_begin;
     if (n <= 0 || n_frames <= 0) return;
-    if (n_eval)
-        hipLaunchKernelGGL(window_topk_kernel<true>, dim3((n + 15) / 16, n_frames), dim3(256), 0, s, F, q, qdesc, q_begin, q_end, out,
-                           frame_stride, q_stride, n_eval);
-    else
-        hipLaunchKernelGGL(window_topk_kernel<false>, dim3((n + 15) / 16, n_frames), dim3(256), 0, s, F, q, qdesc, q_begin, q_end, out,
-                           frame_stride, q_stride, n_eval);
+    // lanes per query: 4 for the small windows of SearchLocalPoints (th 1-2: 3-11 grid cells with about one keypoint each —
+    // 64 frames x 4096 queries 0.224 ms with 16 lanes, 0.127 with 4), 16 for the wide ones (motion model, relocalisation, Fuse)
+#define MSORB_WIN_LAUNCH(COUNT, LANES)                                                                                          \
+    hipLaunchKernelGGL((window_topk_kernel<COUNT, LANES>), dim3((n + 256 / LANES - 1) / (256 / LANES), n_frames), dim3(256), 0, s, F, q, \
+                       qdesc, q_begin, q_end, out, frame_stride, q_stride, n_eval)
+    // (a single frame's few thousand queries are latency, not throughput: 12.5 us with 16 lanes, 19.7 with 4)
+    if (lanes <= 4 && (long long)n * n_frames >= 32768) { if (n_eval) MSORB_WIN_LAUNCH(true, 4); else MSORB_WIN_LAUNCH(false, 4); }
+    else { if (n_eval) MSORB_WIN_LAUNCH(true, 16); else MSORB_WIN_LAUNCH(false, 16); }
+#undef MSORB_WIN_LAUNCH
 }
 void launch_list_top2(const uint8_t* qdesc, const uint8_t* tdesc, const int* cand_begin, const int* cand_idx, int nq,
                       int* bi, int* bd, int* si, int* sd, hipStream_t s) {
@@ -666,7 +672,8 @@ void launch_stereo_match(const StereoArgs& a, hipStream_t s) {
 }
 void launch_stereo_match_batch(const StereoBatchArgs& b, int n_pairs, int max_left, hipStream_t s) {
     if (n_pairs <= 0 || max_left <= 0) return;
-    hipLaunchKernelGGL(stereo_rowtable_kernel, dim3(n_pairs), dim3(256), (size_t)(2 * b.A.rows0 + 1) * sizeof(int), s, b);
+    if (n_pairs <= 4) hipLaunchKernelGGL(stereo_rowtable_kernel<1024>, dim3(n_pairs), dim3(1024), (size_t)(2 * b.A.rows0 + 1) * sizeof(int), s, b);
+    else hipLaunchKernelGGL(stereo_rowtable_kernel<256>, dim3(n_pairs), dim3(256), (size_t)(2 * b.A.rows0 + 1) * sizeof(int), s, b);
     hipLaunchKernelGGL(stereo_match_batch_kernel, dim3((max_left + 3) / 4, n_pairs), dim3(256), 0, s, b);
     hipLaunchKernelGGL(stereo_median_kernel, dim3(n_pairs), dim3(256), 0, s, b.countsL, b.countsR, b.pair_step, b.capacity, b.A.sad, b.A.u_right,
                        b.A.depth, b.counts_out);

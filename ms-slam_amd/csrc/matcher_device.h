@@ -70,7 +70,12 @@ struct StereoBatchArgs {
 // n_eval != nullptr: the kernel adds the number of Hamming distances it evaluated (measurement runs)
 void launch_window_topk(const FrameView& F, const WinQuery* q, const uint8_t* qdesc, int q_begin, int q_end,
                         TopK* out, hipStream_t s, int n_frames = 1, int frame_stride = 0, int q_stride = 0,
-                        unsigned long long* n_eval = nullptr);
+                        unsigned long long* n_eval = nullptr, int lanes = 16);
+// lanes per query for a search whose windows have the radius r (pixels) on a frame with these grid constants
+inline int window_lanes_for(float r, float gridWInv, float gridHInv) {
+    const float cells = (2.0f * r * gridWInv + 1.5f) * (2.0f * r * gridHInv + 1.5f);
+    return cells <= 14.0f ? 4 : 16;
+}
 // msorb_extract_stereo hands its DEVICE outputs to a sink after the last kernel of the frame has been enqueued and before
 // the read-back + synchronisation: whatever the sink enqueues on `stream` completes with the same synchronisation.
 struct StereoDeviceOutputs {

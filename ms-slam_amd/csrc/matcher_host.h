@@ -110,12 +110,13 @@ namespace msorb {
 //   flags       kQValid / kQSkipOccupied per query; nullptr: taken from q
 //   ready       round 0 has been run by the caller: f->d_occ holds `occ`, f->h_topk[0, M) the lists (stream synchronised)
 //   d_qdesc     device query descriptors when they do not live in f->d_qdesc (read by the re-runs)
+//   lanes       lanes per query of the window kernel (0: chosen from the mean radius of the host queries)
 // accept(q, idx, dist, n, &new_occ) is called in query order with the query's exact candidate prefix (>= need entries unless
 // the true candidate set is smaller); it returns the keypoint index it assigned (or -1) and that keypoint's new occupancy.
 template <typename Accept>
 int run_window_search(msorb_frame* f, int M, const WinQuery* q, const uint8_t* flags, const uint8_t* qdesc,
                       std::vector<uint8_t>& occ, int need, Accept accept, bool ready = false, int* rounds_out = nullptr,
-                      const uint8_t* d_qdesc = nullptr) {
+                      const uint8_t* d_qdesc = nullptr, int lanes = 0) {
     if (rounds_out) *rounds_out = 0;
     if (M <= 0) return MSORB_OK;
     int rc;
@@ -132,6 +133,16 @@ int run_window_search(msorb_frame* f, int M, const WinQuery* q, const uint8_t* f
         flags_own.resize(M);
         for (int i = 0; i < M; i++) flags_own[i] = q[i].flags;
         flags = flags_own.data();
+    }
+    if (lanes == 0) {   // lanes per query from the mean window radius of the valid queries
+        lanes = 16;
+        if (q) {
+            double sum = 0;
+            int nv = 0;
+            for (int i = 0; i < M; i++)
+                if (q[i].flags & kQValid) { sum += q[i].r; nv++; }
+            if (nv) lanes = window_lanes_for((float)(sum / nv), f->gridWInv, f->gridHInv);
+        }
     }
     if (q) {
         std::memcpy(f->h_in.p, q, qb);
@@ -151,7 +162,7 @@ int run_window_search(msorb_frame* f, int M, const WinQuery* q, const uint8_t* f
                 std::memcpy(h_occ, occ.data(), f->N);  // the previous round's copy has completed (stream synchronised below)
                 HIPCHK(hipMemcpyAsync(f->d_occ.p, h_occ, f->N, hipMemcpyHostToDevice, s));
             }
-            launch_window_topk(f->view(), f->d_q.p, d_qdesc, q0, M, f->d_topk.p, s);
+            launch_window_topk(f->view(), f->d_q.p, d_qdesc, q0, M, f->d_topk.p, s, 1, 0, 0, nullptr, lanes);
             HIPCHK(hipMemcpyAsync(topk + q0, f->d_topk.p + q0, (size_t)(M - q0) * sizeof(TopK), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
         }

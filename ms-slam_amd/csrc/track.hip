@@ -133,10 +133,12 @@ __global__ __launch_bounds__(kGridThreads) void frame_grid_kernel(GridArgs A) {
 int launch_frame_grid(const GridArgs& A, int n_frames, hipStream_t s) {
     if (A.dst_stride > 16384) { set_last_error("frame grid: more than 16384 keypoints per frame"); return MSORB_E_CAPACITY; }
     const size_t lds = (size_t)(2 * kNCell + 1) * sizeof(int) + (size_t)A.dst_stride * 2 * sizeof(uint16_t);
-    if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit (frames of more than ~10 000 keypoints): raise it once
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_grid_kernel),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (attr != hipSuccess) { set_last_error("frame grid: cannot raise the dynamic LDS limit"); return MSORB_E_HIP; }
+    if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit (frames of more than ~10 000 keypoints): raise it (per device)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(frame_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                96 * 1024) != hipSuccess) {
+            set_last_error("frame grid: cannot raise the dynamic LDS limit");
+            return MSORB_E_HIP;
+        }
     }
     hipLaunchKernelGGL(frame_grid_kernel, dim3(n_frames), dim3(kGridThreads), lds, s, A);
     return MSORB_OK;
@@ -337,6 +339,12 @@ int upload_local_points(msorb_frame* f, const LocalPointsCall& c) {
     return MSORB_OK;
 }
 
+// lanes per query of the window kernel for SearchLocalPoints' radii: 4 * th * scale of a middle level (RadiusByViewingCos)
+int local_points_lanes(const msorb_frame* f, float th) {
+    const float mid = f->scale.empty() ? 1.0f : f->scale[f->scale.size() / 2];
+    return window_lanes_for(4.0f * th * mid, f->gridWInv, f->gridHInv);
+}
+
 // frustum + queries + round 0 of the window search + the read-back, enqueued on stream s (which must already be ordered
 // behind the upload and behind whatever produced the frame's device arrays).  d_occ must hold the occupancy snapshot.
 int enqueue_local_points(msorb_frame* f, const LocalPointsCall& c, hipStream_t s) {
@@ -361,7 +369,8 @@ int enqueue_local_points(msorb_frame* f, const LocalPointsCall& c, hipStream_t s
     A.level = reinterpret_cast<int*>(dout + L.o_level); A.view_cos = reinterpret_cast<float*>(dout + L.o_vc);
     A.in_view = dout + L.o_inview;
     hipLaunchKernelGGL(local_points_kernel, dim3((unsigned)((m + 255) / 256), 1), dim3(256), 0, s, A);
-    launch_window_topk(f->view(), f->d_q.p, di + L.o_desc, 0, c.m, reinterpret_cast<TopK*>(dout + L.o_topk), s);
+    launch_window_topk(f->view(), f->d_q.p, di + L.o_desc, 0, c.m, reinterpret_cast<TopK*>(dout + L.o_topk), s, 1, 0, 0, nullptr,
+                       local_points_lanes(f, c.th));
     HIPCHK(hipMemcpyAsync(T.h_out.p, dout, L.out_bytes, hipMemcpyDeviceToHost, s));
     return MSORB_OK;
 }
@@ -418,7 +427,8 @@ int replay_local_points(msorb_frame* f, const LocalPointsCall& c, std::vector<ui
         return -1;
     };
     // resync rounds (rare) read the query descriptors from f->d_qdesc: alias the uploaded block
-    const int rc = run_window_search(f, c.m, nullptr, flags.data(), nullptr, occ, 2, accept, true, rounds, T.d_in.p + L.o_desc);
+    const int rc = run_window_search(f, c.m, nullptr, flags.data(), nullptr, occ, 2, accept, true, rounds, T.d_in.p + L.o_desc,
+                                     local_points_lanes(f, c.th));
     *nmatches = nm;
     return rc;
 }
@@ -673,8 +683,9 @@ int msorb_track_batch(int device, int n_frames, const msorb_keypoint* d_keypoint
         V.minX = min_x; V.minY = min_y; V.gridWInv = G.gridWInv; V.gridHInv = G.gridHInv; V.n = capacity;
         for (int l = 0; l < MSORB_MAX_LEVELS; l++) V.inv_sigma2[l] = 0.0f;
         static_assert(sizeof(TopK) == 16 * sizeof(int), "d_topk layout");
+        const float mid = scale_factors[nlevels / 2];
         launch_window_topk(V, S.q.p, d_mp_desc, 0, m, reinterpret_cast<TopK*>(d_topk), s, n_frames, capacity, m,
-                           n_pairs ? S.cnt.p : nullptr);
+                           n_pairs ? S.cnt.p : nullptr, window_lanes_for(4.0f * th * mid, G.gridWInv, G.gridHInv));
         HIPCHK(hipEventRecord(S.ev[3], s));
     }
     if (n_pairs) HIPCHK(hipMemcpyAsync(n_pairs, S.cnt.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
