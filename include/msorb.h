@@ -211,6 +211,12 @@ int msorb_frame_set(msorb_frame* f, const msorb_keypoint* keypoints, int n, cons
 int msorb_frame_features_in_area(const msorb_frame* f, float x, float y, float r, int min_level, int max_level,
                                  int* out_idx, int capacity, int* n);
 
+/* Telemetry of the searches that replay sequential claims on the host (all SearchByProjection forms on a frame / KeyFrame
+ * handle): returns the number of device rounds the LAST such search on `f` needed — 1 unless a query's candidate list (8
+ * entries) was exhausted by earlier claims, in which case the kernel is re-run from that query on (at most one round per
+ * query) —, and through the optional pointers the totals since msorb_frame_create. */
+int msorb_frame_search_rounds(const msorb_frame* f, long long* total_rounds, long long* total_searches);
+
 /* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint>&, th, bFarPoints, thFarPoints)
  * (ORBmatcher.cc:43-142, rectified branch).  Map-point table of m entries visited in index order:
  *   track_in_view=mbTrackInView  bad=isBad()  sparsified=mbSparsified  proj_x/proj_y/proj_xr=mTrackProjX/Y/XR
@@ -338,6 +344,14 @@ int msorb_hamming_dense_top2_batch(int device, const uint8_t* d_query, const uin
                                    const int* d_n_train, int n_frames, int query_stride, int train_stride, int max_query,
                                    int max_train, int* d_best_idx, int* d_best_dist, int* d_second_dist, int repeats,
                                    float* elapsed_ms);
+
+/* cv::BFMatcher(cv::NORM_HAMMING).knnMatch(query, train, matches, 2) — the brute-force step of
+ * Frame::ComputeStereoFishEyeMatches (Frame.cc:1057-1076: left vs right descriptors of the lapping area) — on HOST arrays of
+ * 32-byte rows: best_idx / best_dist = matches[i][0] (trainIdx, distance), second_dist (and second_idx, may be NULL) =
+ * matches[i][1]; ties go to the lower train index.  -1 / 256 where the train set has fewer than one / two rows.  The Lowe
+ * ratio test and KannalaBrandt8::TriangulateMatches of :1082-1098 stay with the caller. */
+int msorb_knn_match2(int device, const uint8_t* query, int n_query, const uint8_t* train, int n_train, int* best_idx,
+                     int* best_dist, int* second_idx, int* second_dist);
 
 /* Frame::ComputeStereoMatches (Frame.cc:743-913).  left/right are the two extractor handles whose last
  * msorb_extract() call produced the images' pyramids (mpORBextractorLeft/Right->mvImagePyramid stay on

@@ -84,6 +84,8 @@ struct msorb_frame {
     msorb::DBuf<int> d_cell_begin, d_cell_idx, d_n;
     msorb::DBuf<int> d_init_cnt, d_init_beg;   // msorb_search_for_initialization: candidate counts / list offsets / lists
     msorb::DBuf<int2> d_init_list;
+    int last_rounds = 0;                // device rounds of the last claim-replaying search (msorb_frame_search_rounds)
+    long long total_rounds = 0, total_searches = 0;
     bool host_grid_valid = false;       // cell_begin / cell_idx (host) mirror the device grid
     msorb_frame_track* track = nullptr;  // staging of the local-points chain (track.hip)
     msorb::DBuf<msorb::WinQuery> d_q;
@@ -199,6 +201,7 @@ int run_window_search(msorb_frame* f, int M, const WinQuery* q, const uint8_t* f
         q0 = qi;
     }
     if (rounds_out) *rounds_out = n_rounds;
+    f->last_rounds = n_rounds; f->total_rounds += n_rounds; f->total_searches++;
     static const bool dbg_rounds = getenv("MSORB_DEBUG_ROUNDS") != nullptr;
     if (dbg_rounds) fprintf(stderr, "window search: %d queries, %d device rounds\n", M, n_rounds);
     return MSORB_OK;

@@ -1509,14 +1509,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 #pragma unroll
         for (int t = 0; t < 5; t++) {
             const uint32_t row = rc[t] & 255u, col4p4 = rc[t] >> 8;
+#ifdef MSORB_DESC_EXP_RAW_FLAT    // timing experiment only (wrong results): every IC-angle row from one line
+            const uint32_t o = 0u * row;
+#else
             const uint32_t o = __umul24(row, (uint32_t)lv.pitch);  // full-rate 24-bit multiply
+#endif
             L.rsh[t] = (rlow + o) & 3u;
             L.rp[t] = *reinterpret_cast<const uint32_t*>(rrow + (size_t)(o + col4p4 - L.rsh[t]));
         }
 #pragma unroll
         for (int it = 0; it < 6; it++) {
             const uint32_t row = bc[it] & 255u, col4 = bc[it] >> 8;
+#ifdef MSORB_DESC_EXP_BLUR_FLAT   // timing experiment only (wrong results): every blurred row from one line
+            L.bp[it] = *reinterpret_cast<const uint32_t*>(brow + (size_t)(col4));
+            (void)row;
+#else
             L.bp[it] = *reinterpret_cast<const uint32_t*>(brow + (size_t)(__umul24(row, (uint32_t)bv.pitch) + col4));
+#endif
         }
     };
     const SelRec* recs = sel + (size_t)img * sel_stride;

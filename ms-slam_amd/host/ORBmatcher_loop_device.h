@@ -309,7 +309,7 @@ int SearchByBoWLoop(const KeyFramePtr& pKF1, const KeyFramePtr& pKF2, std::vecto
     for (size_t i = 0; i < mps2.size(); i++) b.flag[i] = mps2[i] && !mps2[i]->isBad() && mps2[i]->mnLoopPointForKF != nCurrentId;   // :1086-1096
     msorb_bow_pair P;
     std::vector<int> m12, m21;
-    bind(P, a, b, false, m12, m21);
+    BindBowPair(P, a, b, false, m12, m21);
     check(msorb_search_by_bow(device, &P, 1, 50 /* TH_LOW */, 0 /* '<', :1118 */, mfNNratio, 1 /* histogram always */, nullptr),
           "msorb_search_by_bow");
     // the survivors, pushed bin by bin in the order the merge walk found them (node ascending, list order inside a node)

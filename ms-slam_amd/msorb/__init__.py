@@ -1247,3 +1247,29 @@ class TrackFrontendRunner:
 
     def close(self):
         self.f.close()
+
+
+EXPORTS = EXPORTS + ("msorb_knn_match2",)
+
+
+def knn_match2(query, train, device=0):
+    """msorb_knn_match2: BFMatcher(NORM_HAMMING).knnMatch(k=2) -> (best_idx, best_dist, second_idx, second_dist)."""
+    lb = lib()
+    vp, ci = C.c_void_p, C.c_int
+    lb.msorb_knn_match2.argtypes = [ci, vp, ci, vp, ci, vp, vp, vp, vp]
+    q, t = _c(query, np.uint8).reshape(-1, 32), _c(train, np.uint8).reshape(-1, 32)
+    nq = len(q)
+    out = [np.zeros(max(nq, 1), np.int32) for _ in range(4)]
+    _check(lb.msorb_knn_match2(device, _np_ptr(q), nq, _np_ptr(t), len(t), *[_np_ptr(o) for o in out]), "msorb_knn_match2")
+    return tuple(o[:nq] for o in out)
+
+
+EXPORTS = EXPORTS + ("msorb_frame_search_rounds",)
+
+
+def frame_search_rounds(frame):
+    """msorb_frame_search_rounds -> (rounds of the last claim-replaying search, total rounds, total searches)."""
+    tr, ts = C.c_longlong(), C.c_longlong()
+    frame.L.msorb_frame_search_rounds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    r = frame.L.msorb_frame_search_rounds(frame.h, C.addressof(tr), C.addressof(ts))
+    return r, tr.value, ts.value

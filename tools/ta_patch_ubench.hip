@@ -3,6 +3,8 @@
 //   mode 1: 37 rows x 4 x 16 bytes, lane = 16-byte granule (3 global_load_dwordx4 per patch, 16-byte aligned)
 //   mode 2: 37 rows x 3 x 16 bytes (2 instructions; what a 48-byte window would need)
 //   mode 3 / 4: mode 0 with non-temporal / sc1 loads (mode 4 waits after every load: a lower bound on its rate only)
+//   mode 6: the image stored as 16 x 8 pixel tiles of 128 bytes (one cache line each): the 37 x 37 patch touches 3-4 x 5-6
+//           tiles (18.6 on average) instead of 37 rows x 1.28 lines = 47; a wave loads two whole tiles per instruction
 // Every workgroup works inside one 3 MB "image" chosen by blockIdx % 8, so that the lines come from the XCD's L2 as in the
 // real kernel.  Prints ns per patch and patches/s.
 //   hipcc --offload-arch=gfx950 -O3 tools/ta_patch_ubench.hip -o /tmp/ta_patch && /tmp/ta_patch
@@ -51,6 +53,32 @@ __global__ __launch_bounds__(256) void gather(const uint8_t* __restrict__ base, 
                 asm volatile("global_load_dword %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(q) : "memory");
                 acc ^= v;
             }
+        } else if (MODE == 6) {
+            constexpr int kTilesPerRow = kPitch / 16;
+            const int tx0 = (x - 18) >> 4, ty0 = (y - 18) >> 3;
+            const int ntx = ((x + 18) >> 4) - tx0 + 1, nty = ((y + 18) >> 3) - ty0 + 1, nt = ntx * nty;   // <= 4 x 6
+#pragma unroll
+            for (int it = 0; it < 12; it++) {
+                const int t = min(2 * it + (lane >> 5), nt - 1);
+                const int tq = ntx == 4 ? t >> 2 : (t * 43) >> 7;   // t / ntx for ntx in {3, 4}, t < 24
+                const int ty = ty0 + tq, tx = tx0 + t - tq * ntx;
+                if (2 * it < nt)   // wave-uniform
+                    acc ^= *reinterpret_cast<const uint32_t*>(img + ((size_t)(ty * kTilesPerRow + tx) << 7) + 4 * (lane & 31));
+            }
+        } else if (MODE == 7) {   // tiles again, 16 bytes per lane: eight whole tiles per instruction, 3 instructions
+            constexpr int kTilesPerRow = kPitch / 16;
+            const int tx0 = (x - 18) >> 4, ty0 = (y - 18) >> 3;
+            const int ntx = ((x + 18) >> 4) - tx0 + 1, nty = ((y + 18) >> 3) - ty0 + 1, nt = ntx * nty;
+#pragma unroll
+            for (int it = 0; it < 3; it++) {
+                const int t = min(8 * it + (lane >> 3), nt - 1);
+                const int tq = ntx == 4 ? t >> 2 : (t * 43) >> 7;
+                const int ty = ty0 + tq, tx = tx0 + t - tq * ntx;
+                if (8 * it < nt) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(img + ((size_t)(ty * kTilesPerRow + tx) << 7) + 16 * (lane & 7));
+                    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+                }
+            }
         } else if (MODE == 1) {
             const int px0 = (x - 18) & ~15;
 #pragma unroll
@@ -78,7 +106,7 @@ int main() {
     hipMalloc(&d, (size_t)n_img * kImgBytes); hipMalloc(&o, 64);
     hipMemset(d, 1, (size_t)n_img * kImgBytes);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 6; mode++) {
+    for (int mode = 0; mode < 8; mode++) {
         float best = 1e9f;
         for (int rep = 0; rep < 5; rep++) {
             hipEventRecord(e0);
@@ -88,6 +116,8 @@ int main() {
             if (mode == 3) hipLaunchKernelGGL(gather<3>, dim3(blocks), dim3(256), 0, 0, d, n_img, per_wave, o);
             if (mode == 4) hipLaunchKernelGGL(gather<4>, dim3(blocks), dim3(256), 0, 0, d, n_img, per_wave, o);
             if (mode == 5) hipLaunchKernelGGL(gather<5>, dim3(blocks), dim3(256), 0, 0, d, n_img, per_wave, o);
+            if (mode == 6) hipLaunchKernelGGL(gather<6>, dim3(blocks), dim3(256), 0, 0, d, n_img, per_wave, o);
+            if (mode == 7) hipLaunchKernelGGL(gather<7>, dim3(blocks), dim3(256), 0, 0, d, n_img, per_wave, o);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (ms < best) best = ms;
