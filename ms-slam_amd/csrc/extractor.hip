@@ -287,7 +287,7 @@ int ensure_geometry(msorb_extractor* h, int rows, int cols) {
     h->sel_stride = sel_off;
     {
         const char* e = getenv("MSORB_QUADTREE");
-        h->device_quadtree = !(e && std::string(e) == "host") && quadtree_lds_bytes(h->qt) <= 60 * 1024;
+        h->device_quadtree = !(e && std::string(e) == "host") && quadtree_lds_bytes(h->qt) <= 150 * 1024;   // one workgroup's LDS (160 KB per CU on gfx950): nfeatures up to ~8000
     }
     h->geom_valid = true;
     h->last_n_images = 0;

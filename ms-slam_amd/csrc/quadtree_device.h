@@ -243,6 +243,7 @@ struct ParScratch {
     QT_LDS SortItem* tmp;    // capacity n
     QT_LDS int* scan_tmp;    // 16 ints
     QT_LDS int* sc;          // 4 ints
+    int stack_half = 96;     // ints per range list of the level-synchronous device sort (3 per range)
 };
 
 template <class Ex>
@@ -377,7 +378,7 @@ struct Workspace {       // LDS on the device; `cap` = 4 * max(N, nIni) child sl
     QT_LDS uint16_t* rankof[2]; // child slot -> processing rank among multi-point nodes (0xFFFF = none)
     QT_LDS NodeB* nb[2];        // multi-point nodes by rank, capacity N + 4
     QT_LDS SortItem* items;     // capacity N + 4
-    QT_LDS int* stack;          // 3 * 64
+    QT_LDS int* stack;          // 2 range lists of stack_ranges(m) entries x 3 ints (>= 3 * 64 ints for the serial sort)
     QT_LDS int* res_seq;        // capacity res_cap
     QT_LDS int* res_pt;
     QT_LDS int* sc;             // scalars: see enum below
@@ -387,11 +388,14 @@ struct Workspace {       // LDS on the device; `cap` = 4 * max(N, nIni) child sl
 };
 enum { kScSize = 0, kScS0, kScS1, kScNres, kScNToExpand, kScNsplit, kScFinish, kScCareful, kScGenBase, kScCount };
 
+// ranges longer than 16 elements that can be open at once in the level-synchronous introsort rounds of m + 4 items
+QT_HD int stack_ranges(int m) { const int r = (m + 4) / 17 + 2; return r > 32 ? r : 32; }
+
 QT_HD size_t workspace_bytes(int N, int n_ini) {
     const int m = N > n_ini ? N : n_ini;
     const size_t cap = 4 * (size_t)m + 16;
     size_t b = 2 * cap * sizeof(int) + 2 * cap * sizeof(uint16_t) + 2 * (size_t)(m + 4) * sizeof(NodeB) +
-               3 * 64 * sizeof(int) + 2 * (size_t)(m + 8 + 4 * n_ini) * sizeof(int) + (kScCount + 32 + 16 + 4) * sizeof(int);
+               2 * 3 * (size_t)stack_ranges(m) * sizeof(int) + 2 * (size_t)(m + 8 + 4 * n_ini) * sizeof(int) + (kScCount + 32 + 16 + 4) * sizeof(int);
     return (b + 15) & ~size_t(15);
 }
 QT_HD void workspace_carve(Workspace& w, void* mem, int N, int n_ini) {
@@ -404,7 +408,8 @@ QT_HD void workspace_carve(Workspace& w, void* mem, int N, int n_ini) {
     w.cnt[1] = (QT_LDS int*)p; p += w.cap * sizeof(int);
     w.nb[0] = (QT_LDS NodeB*)p; p += (m + 4) * sizeof(NodeB);
     w.nb[1] = (QT_LDS NodeB*)p; p += (m + 4) * sizeof(NodeB);
-    w.stack = (QT_LDS int*)p; p += 3 * 64 * sizeof(int);
+    w.stack = (QT_LDS int*)p; p += 2 * 3 * stack_ranges(m) * sizeof(int);
+    w.ps.stack_half = 3 * stack_ranges(m);
     w.res_seq = (QT_LDS int*)p; p += w.res_cap * sizeof(int);
     w.res_pt = (QT_LDS int*)p; p += w.res_cap * sizeof(int);
     w.sc = (QT_LDS int*)p; p += kScCount * sizeof(int);

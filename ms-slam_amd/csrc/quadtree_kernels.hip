@@ -49,7 +49,7 @@ struct DevEx {
     // round hands the current ranges (> 16 elements) to the workgroup's waves, one range per wave at a time; inside a wave
     // a partition is data-parallel (ballots, no s_barrier).  Which wave partitions which range, and in which order, cannot
     // change the result: ranges are disjoint and a partition only looks at its own range.  `stack` holds two range lists
-    // of 32 entries (first, last, depth); ps.sc[0/1] their lengths.
+    // of stack_ranges(m) entries (first, last, depth); ps.sc[0/1] their lengths.
     __device__ void sort(QT_LDS qt::SortItem* items, int n, QT_LDS int* stack, qt::ParScratch& ps) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
         int lg = 0;
@@ -64,8 +64,8 @@ struct DevEx {
         for (;;) {
             const int nr = ps.sc[which];
             if (nr == 0) break;
-            QT_LDS int* cur = stack + which * 96;
-            QT_LDS int* nxt = stack + (which ^ 1) * 96;
+            QT_LDS int* cur = stack + which * ps.stack_half;
+            QT_LDS int* nxt = stack + (which ^ 1) * ps.stack_half;
             WaveEx wex;
             for (int i = wave; i < nr; i += nwaves) {
                 const int first = cur[3 * i], last = cur[3 * i + 1];
@@ -285,6 +285,12 @@ void launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_b
     static const int qt_env = getenv("MSORB_QT_THREADS") ? atoi(getenv("MSORB_QT_THREADS")) : 0;  // tuning only
     const int qt_threads = qt_env ? qt_env : n_images <= 4 ? 1024 : n_images <= 16 ? 512 : kQtThreads;
     static const bool regs_env = !getenv("MSORB_QT_NO_REGS");  // tuning / test aid
+    if (lds > 64 * 1024) {   // quotas beyond ~700 keypoints per level (nfeatures > ~3000): past the default dynamic-LDS limit
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quadtree_select_kernel<kQtPointsPerThreadFrame>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quadtree_select_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+    }
     if (qt_threads == 1024 && regs_env)
         hipLaunchKernelGGL(quadtree_select_kernel<kQtPointsPerThreadFrame>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds, s, lv,
                            compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg);

@@ -318,6 +318,36 @@ def test_saturated_single_cell(msorb_mod, oracle):
         ex.close()
 
 
+@pytest.mark.parametrize("nfeat,nlev,kind", [(3500, 8, "scene"), (3500, 8, "noise"), (8000, 8, "noise"), (3000, 2, "noise")])
+def test_large_feature_quota_device_quadtree(msorb_mod, oracle, nfeat, nlev, kind):
+    """Quotas whose quadtree workspace exceeds the 64 KB default LDS window (nfeatures > ~3300 at 1.2 / 8 levels): the
+    select kernel raises its dynamic-LDS limit (160 KB per workgroup on gfx950) and the careful sweep sorts more nodes than
+    the fixed 32-range lists of earlier rounds held (range lists are sized by the quota now).  Noise images saturate every
+    cell, so the node lists reach the quota.  Per frame, batched and the stereo chain (device pipeline required)."""
+    import torch
+    cfg = synth.KITTI
+    rng = np.random.Generator(np.random.PCG64(nfeat + nlev))
+    imgs = [rng.integers(0, 256, (cfg["rows"], cfg["cols"]), dtype=np.uint8) if kind == "noise" else synth.image(90 + i, cfg["rows"], cfg["cols"])
+            for i in range(2)]
+    ex = msorb_mod.ORBextractor(nfeat, 1.2, nlev, 20, 7)
+    ref = oracle.OracleExtractor(nfeat, 1.2, nlev, 20, 7)
+    try:
+        want = [ref(im) for im in imgs]
+        for im, (rmono, rkps, rdesc) in zip(imgs, want):
+            mono, kps, desc = ex(im)
+            assert mono == rmono and len(kps) >= (nfeat * 9 // 10 if kind == "noise" else 1000)
+            _assert_same(kps, desc, rkps, rdesc)
+        d = torch.from_numpy(np.stack(imgs * 8)).cuda()       # 16 images: the batch kernels
+        counts, monos, d_kps, d_desc = ex.extract_batch(d)
+        got = msorb_mod.keypoints_from_device(d_kps, counts)
+        for i in (0, 1, 15):
+            rmono, rkps, rdesc = want[i % 2]
+            assert monos[i] == rmono
+            _assert_same(got[i], d_desc[i, :counts[i]].cpu().numpy(), rkps, rdesc)
+    finally:
+        ex.close()
+
+
 def test_full_bench_size_properties(msorb_mod, oracle):
     """BASELINE.json configs[1] at bench.py's batch size (128 stereo pairs = 256 images, default 2 sub-batches): too
     big for the oracle image by image, so size-independent properties carry the check — copies of an image must give
