@@ -449,40 +449,57 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
     const int n_ini = (int)roundf((float)W / (float)H);           // :559
     const float hX = (float)W / (float)n_ini;                      // :561
     QT_LDS int* const sc = w.sc;
+    ex.mark(9);
 
     // Point ownership: thread t owns candidates t, t + nt, ...; the first PC of them live in registers for the whole
     // selection (coordinates + label), the rest (only when n > PC * nt) go through global memory.
-    Pt cpt[PC > 0 ? PC : 1];
-    uint16_t clab[PC > 0 ? PC : 1];
+    // (two packed dwords per point — x | y << 16 and label | score << 16 —: 28 points per thread of the batch form are 56 VGPRs)
+    uint32_t cxy[PC > 0 ? PC : 1], cls[PC > 0 ? PC : 1];
 #pragma unroll
-    for (int k = 0; k < PC; k++) { const int p = tid + k * nt; cpt[k] = pts[p < n ? p : 0]; clab[k] = kLabelSettled; }
+    for (int k = 0; k < PC; k++) {
+        const int p = tid + k * nt;
+        const Pt t = pts[p < n ? p : 0];
+        cxy[k] = (uint32_t)t.x | ((uint32_t)t.y << 16);
+        cls[k] = (uint32_t)kLabelSettled | ((uint32_t)t.score << 16);
+    }
+    // Every thread of the workgroup makes the same sequence of body() calls (`valid` says whether the call carries a point), so
+    // the bodies may use the wave-collective forms of the counters (Ex::add_runs / Ex::claim).
     auto for_points = [&](auto&& body) {
 #pragma unroll
         for (int k = 0; k < PC; k++) {
+            if (k * nt >= n) break;                            // workgroup-uniform
             const int p = tid + k * nt;
-            if (p < n) body(p, cpt[k], clab[k]);
+            const bool valid = p < n;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(cxy[k]), "+v"(cls[k]));  // opaque: keeps the unpacked fields from being hoisted out of the generation loop (3 more VGPRs per point)
+#endif
+            Pt q;
+            q.x = (uint16_t)(cxy[k] & 0xFFFFu); q.y = (uint16_t)(cxy[k] >> 16); q.score = (uint16_t)(cls[k] >> 16); q.pad = 0;
+            uint16_t lab = (uint16_t)(cls[k] & 0xFFFFu);
+            body(p, valid, q, lab);
+            cls[k] = (cls[k] & 0xFFFF0000u) | lab;
         }
         // four candidates in flight per thread: the loads of a batch are issued together, so the pass pays the global
         // latency once per four points instead of once per point (the per-point bodies hold LDS atomics, which keep
         // the compiler from overlapping iterations on its own)
         constexpr int kBatch = kPassBatch;
-        for (int p0 = tid + PC * nt; p0 < n; p0 += kBatch * nt) {
+        for (int b0 = PC * nt; b0 < n; b0 += kBatch * nt) {    // workgroup-uniform bounds
             Pt q[kBatch];
             uint16_t l[kBatch], l0[kBatch];
 #pragma unroll
             for (int u = 0; u < kBatch; u++) {
-                const int p = p0 + u * nt;
-                const int pc = p < n ? p : p0;
+                const int p = b0 + u * nt + tid;
+                const int pc = p < n ? p : b0;
                 q[u] = pts[pc];
                 l0[u] = l[u] = label[pc];
             }
 #pragma unroll
             for (int u = 0; u < kBatch; u++) {
-                const int p = p0 + u * nt;
-                if (p < n) {
-                    body(p, q[u], l[u]);
-                    if (l[u] != l0[u]) label[p] = l[u];
-                }
+                if (b0 + u * nt >= n) break;                   // workgroup-uniform
+                const int p = b0 + u * nt + tid;
+                const bool valid = p < n;
+                body(p, valid, q[u], l[u]);
+                if (valid && l[u] != l0[u]) label[p] = l[u];
             }
         }
     };
@@ -491,10 +508,10 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
     for (int i = tid; i < n_ini; i += nt) w.cnt[0][i] = 0;
     if (tid == 0) { sc[kScNres] = 0; sc[kScFinish] = 0; sc[kScCareful] = 0; sc[kScGenBase] = 0; }
     ex.sync();
-    for_points([&](int, const Pt& q, uint16_t& lab) {
+    for_points([&](int, bool valid, const Pt& q, uint16_t& lab) {
         const int c = (int)((float)q.x / hX);                      // vpIniNodes[kp.pt.x/hX]
-        lab = (uint16_t)c;
-        ex.atomic_add(&w.cnt[0][c], 1);
+        if (valid) lab = (uint16_t)c;
+        ex.add_runs(w.cnt[0], valid ? c : -1);                     // (candidates arrive in cell order: a wave holds one or two columns)
     });
     ex.sync();
     if (tid == 0) {
@@ -515,16 +532,21 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
         sc[kScSize] = size; sc[kScS0] = S;
     }
     ex.sync();
-    for_points([&](int p, const Pt&, uint16_t& lab) {  // single-point columns are final (bNoMore, :590-594)
-        const int c = lab;
-        if (w.cnt[0][c] == 1) {
-            const int r = ex.atomic_add(&sc[kScNres], 1);
+    for_points([&](int p, bool valid, const Pt&, uint16_t& lab) {  // single-point columns are final (bNoMore, :590-594)
+        const int c = valid ? (int)lab : 0;
+        const int t = w.rankof[0][c];          // 0xFFFF <=> exactly one point (the column holds this one)
+        const bool settle = valid && t == 0xFFFF;
+        const int r = ex.claim(&sc[kScNres], settle);
+        if (settle) {
             w.res_seq[r] = -1 - c; w.res_pt[r] = p;
             lab = kLabelSettled;
+        } else if (valid) {
+            lab = (uint16_t)t;                 // labels name a node by its RANK in its generation's processing order
         }
     });
     ex.sync();
 
+    ex.mark(8);
     if (debug == 2) return 0;
     int par = 0;
     int iter = 0;
@@ -554,9 +576,14 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
             if (debug != 1) ex.sort(w.items, S, w.stack, w.ps);  // std::sort(vPrevSizeAndPointerToNode, compareNodes), :700
             ex.sync();
             // new processing order r: items[S-1-r]; permute nb[par] accordingly (via nb[np] as scratch)
-            for (int r = tid; r < S; r += nt) nb_np[r] = nb_par[w.items[S - 1 - r].node];
+            // (the points' labels still hold the ranks of before the sort: rk_par, free in a careful sweep, maps old -> new)
+            for (int r = tid; r < S; r += nt) {
+                const int old = (int)w.items[S - 1 - r].node;
+                nb_np[r] = nb_par[old];
+                rk_par[old] = (uint16_t)r;
+            }
             ex.sync();
-            for (int r = tid; r < S; r += nt) { nb_par[r] = nb_np[r]; rk_par[nb_par[r].slot] = (uint16_t)r; }
+            for (int r = tid; r < S; r += nt) nb_par[r] = nb_np[r];
         }
         ex.mark(0);
         for (int i = tid; i < 4 * S; i += nt) cnt_np[i] = 0;
@@ -567,32 +594,46 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
         if (PC == 0) {
             // phased form: the rank lookups of a batch are issued together, then the node boxes, then the atomics — a
             // per-point body is a chain of three dependent LDS round trips, and nothing else hides them in one instance
-            for (int p0 = tid; p0 < n; p0 += kPassBatch * nt) {
+            for (int b0 = 0; b0 < n; b0 += kPassBatch * nt) {      // workgroup-uniform bounds: the counters are wave collectives
+                const int p0 = b0 + tid;
                 Pt q[kPassBatch];
                 int lab[kPassBatch], r[kPassBatch];
                 bool act[kPassBatch];
 #pragma unroll
                 for (int u = 0; u < kPassBatch; u++) {
-                    const int p = p0 + u * nt, pc = p < n ? p : p0;
+                    const int p = p0 + u * nt, pc = p < n ? p : b0;
                     q[u] = pts[pc];
                     lab[u] = label[pc];
                     act[u] = p < n && lab[u] != kLabelSettled && (((lab[u] & kParityBit) != 0) == (par != 0));
                 }
+                if (careful) {
 #pragma unroll
-                for (int u = 0; u < kPassBatch; u++) r[u] = act[u] ? (int)rk_par[lab[u] & kSlotMask] : 0;
+                    for (int u = 0; u < kPassBatch; u++) r[u] = act[u] ? (int)rk_par[lab[u] & kSlotMask] : 0;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < kPassBatch; u++) r[u] = act[u] ? (lab[u] & kSlotMask) : 0;
+                }
                 NodeB b[kPassBatch];
 #pragma unroll
                 for (int u = 0; u < kPassBatch; u++) b[u] = nb_par[r[u]];
 #pragma unroll
-                for (int u = 0; u < kPassBatch; u++)
-                    if (act[u]) ex.atomic_add(&cnt_np[4 * r[u] + quadrant_of(q[u], b[u])], 1);
+                for (int u = 0; u < kPassBatch; u++) {
+                    if (b0 + u * nt >= n) break;                       // workgroup-uniform
+                    const int slot = 4 * r[u] + quadrant_of(q[u], b[u]);
+                    // candidates arrive in cell order, so the lanes of a wave fall into a handful of nodes: one atomic per run
+                    // of equal slots instead of 64 serialised ones on the same LDS address
+                    ex.add_runs(cnt_np, act[u] ? slot : -1);
+                    if (act[u]) label[p0 + u * nt] = (uint16_t)((par ? kParityBit : 0) | slot);  // pass B needs neither the point nor the node again
+                }
             }
         } else {
-        for_points([&](int, const Pt& q, uint16_t& lab_) {
+        for_points([&](int, bool valid, const Pt& q, uint16_t& lab_) {
             const int lab = lab_;
-            if (lab == kLabelSettled || ((lab & kParityBit) != 0) != (par != 0)) return;
-            const int r = rk_par[lab & kSlotMask];
-            ex.atomic_add(&cnt_np[4 * r + quadrant_of(q, nb_par[r])], 1);
+            const bool act = valid && lab != kLabelSettled && ((lab & kParityBit) != 0) == (par != 0);
+            const int r = !act ? 0 : careful ? (int)rk_par[lab & kSlotMask] : (lab & kSlotMask);
+            const int slot = 4 * r + quadrant_of(q, nb_par[r]);
+            ex.add_runs(cnt_np, act ? slot : -1);
+            if (act) lab_ = (uint16_t)((par ? kParityBit : 0) | slot);
         });
         }
         ex.sync();
@@ -657,60 +698,58 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
         ex.sync();
         ex.mark(3);
         const int nsplit = sc[kScNsplit], genbase = sc[kScGenBase];
-        // pass B: move the points of split nodes to their child; single-point children are final
+        // pass B: move the points of split nodes to their child; single-point children are final.  Pass A left the child's slot
+        // (4 * rank + quadrant) in the label; rk_np[slot] is the child's rank in the next generation, 0xFFFF for a single point.
         if (PC == 0) {
-            for (int p0 = tid; p0 < n; p0 += kPassBatch * nt) {  // phased like pass A
-                Pt q[kPassBatch];
-                int lab[kPassBatch], r[kPassBatch], slot[kPassBatch], c[kPassBatch];
+            for (int b0 = 0; b0 < n; b0 += kPassBatch * nt) {  // phased like pass A
+                const int p0 = b0 + tid;
+                int lab[kPassBatch], t[kPassBatch];
                 bool act[kPassBatch];
 #pragma unroll
                 for (int u = 0; u < kPassBatch; u++) {
-                    const int p = p0 + u * nt, pc = p < n ? p : p0;
-                    q[u] = pts[pc];
+                    const int p = p0 + u * nt, pc = p < n ? p : b0;
                     lab[u] = label[pc];
                     act[u] = p < n && lab[u] != kLabelSettled && (((lab[u] & kParityBit) != 0) == (par != 0));
                 }
 #pragma unroll
                 for (int u = 0; u < kPassBatch; u++) {
-                    r[u] = act[u] ? (int)rk_par[lab[u] & kSlotMask] : 0;
-                }
-                NodeB b[kPassBatch];
-#pragma unroll
-                for (int u = 0; u < kPassBatch; u++) {
-                    act[u] = act[u] && r[u] < nsplit;  // careful sweep stopped before this node: it stays whole
-                    b[u] = nb_par[act[u] ? r[u] : 0];
+                    const int slot = lab[u] & kSlotMask;
+                    t[u] = act[u] && (slot >> 2) < nsplit ? (int)rk_np[slot] : 0;
                 }
 #pragma unroll
                 for (int u = 0; u < kPassBatch; u++) {
-                    slot[u] = 4 * r[u] + quadrant_of(q[u], b[u]);
-                    c[u] = act[u] ? cnt_np[slot[u]] : 0;
-                }
-#pragma unroll
-                for (int u = 0; u < kPassBatch; u++) {
-                    if (!act[u]) continue;
+                    if (b0 + u * nt >= n) break;                       // workgroup-uniform
                     const int p = p0 + u * nt;
-                    if (c[u] == 1) {
-                        const int k = ex.atomic_add(&sc[kScNres], 1);
-                        w.res_seq[k] = genbase + slot[u]; w.res_pt[k] = p;
+                    const int slot = lab[u] & kSlotMask;
+                    const bool whole = act[u] && (slot >> 2) >= nsplit;  // careful sweep stopped before this node: it stays whole
+                    const bool settle = act[u] && !whole && t[u] == 0xFFFF;
+                    const int k = ex.claim(&sc[kScNres], settle);
+                    if (settle) {
+                        w.res_seq[k] = genbase + slot; w.res_pt[k] = p;
                         label[p] = kLabelSettled;
-                    } else {
-                        label[p] = (uint16_t)((np ? kParityBit : 0) | slot[u]);
+                    } else if (whole) {
+                        label[p] = (uint16_t)((par ? kParityBit : 0) | (slot >> 2));
+                    } else if (act[u]) {
+                        label[p] = (uint16_t)((np ? kParityBit : 0) | t[u]);
                     }
                 }
             }
         } else {
-        for_points([&](int p, const Pt& q, uint16_t& lab_) {
+        for_points([&](int p, bool valid, const Pt&, uint16_t& lab_) {
             const int lab = lab_;
-            if (lab == kLabelSettled || ((lab & kParityBit) != 0) != (par != 0)) return;
-            const int r = rk_par[lab & kSlotMask];
-            if (r >= nsplit) return;  // careful sweep stopped before this node: it stays whole
-            const int slot = 4 * r + quadrant_of(q, nb_par[r]);
-            if (cnt_np[slot] == 1) {
-                const int k = ex.atomic_add(&sc[kScNres], 1);
+            const bool act = valid && lab != kLabelSettled && ((lab & kParityBit) != 0) == (par != 0);
+            const int slot = lab & kSlotMask;
+            const bool whole = act && (slot >> 2) >= nsplit;             // stays whole
+            const int t = act && !whole ? (int)rk_np[slot] : 0;
+            const bool settle = act && !whole && t == 0xFFFF;
+            const int k = ex.claim(&sc[kScNres], settle);
+            if (settle) {
                 w.res_seq[k] = genbase + slot; w.res_pt[k] = p;
                 lab_ = kLabelSettled;
-            } else {
-                lab_ = (uint16_t)((np ? kParityBit : 0) | slot);
+            } else if (whole) {
+                lab_ = (uint16_t)((par ? kParityBit : 0) | (slot >> 2));
+            } else if (act) {
+                lab_ = (uint16_t)((np ? kParityBit : 0) | t);
             }
         });
         }
@@ -725,22 +764,27 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
             for (int i = tid; i < S; i += nt) cnt_par[i] = 0;   // re-used as best-point keys, by rank
             for (int i = tid; i < Sn; i += nt) cnt_np[i] = 0;
             ex.sync();
-            for_points([&](int p, const Pt& q, uint16_t& lab_) {  // first strictly greater response wins (:757-776)
+            for_points([&](int p, bool valid, const Pt& q, uint16_t& lab_) {  // first strictly greater response wins (:757-776)
                 const int lab = lab_;
-                if (lab == kLabelSettled) return;
+                if (!valid || lab == kLabelSettled) return;
                 const int lp = (lab & kParityBit) ? 1 : 0;
-                const int r = (lp == par ? rk_par : rk_np)[lab & kSlotMask];
+                const int r = lab & kSlotMask;
                 ex.atomic_max(&(lp == par ? cnt_par : cnt_np)[r], (int)(((uint32_t)q.score << 22) | (uint32_t)(0x3FFFFF - p)));
             });
             ex.sync();
-            for (int i = tid; i < S - nsplit + Sn; i += nt) {
+            for (int i0 = 0; i0 < S - nsplit + Sn; i0 += nt) {
+                const int i = i0 + tid;
+                const bool in = i < S - nsplit + Sn;
                 const int lp = i < S - nsplit ? par : np;
-                const int r = i < S - nsplit ? nsplit + i : i - (S - nsplit);
-                const int k = ex.atomic_add(&sc[kScNres], 1);
-                w.res_seq[k] = (lp == par ? nb_par : nb_np)[r].seq;
-                w.res_pt[k] = 0x3FFFFF - ((lp == par ? cnt_par : cnt_np)[r] & 0x3FFFFF);
+                const int r = !in ? 0 : i < S - nsplit ? nsplit + i : i - (S - nsplit);
+                const int k = ex.claim(&sc[kScNres], in);
+                if (in) {
+                    w.res_seq[k] = (lp == par ? nb_par : nb_np)[r].seq;
+                    w.res_pt[k] = 0x3FFFFF - ((lp == par ? cnt_par : cnt_np)[r] & 0x3FFFFF);
+                }
             }
             ex.sync();
+            ex.mark(5);
             break;
         }
         par = np;
@@ -754,6 +798,7 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
         out_pt[rank] = w.res_pt[i];
     }
     ex.sync();
+    ex.mark(6);
     return nres;
 }
 

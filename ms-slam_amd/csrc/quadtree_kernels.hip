@@ -15,6 +15,7 @@ constexpr int kQtThreads = 256;  // 256 beats 512 (0.39 vs 0.47 ms per 256 image
 // measured slower); 8 for single frames, where a 1024-thread instance then holds a whole level (<= 8192 candidates) in
 // registers and the point passes stop waiting on global memory
 constexpr int kQtPointsPerThreadFrame = 8;
+constexpr int kQtPointsPerThreadBatch = 28;   // x 256 threads = 7168 candidates of a level in registers
 
 // inclusive prefix sum over the wave with DPP adds only (no LDS crossbar round trips)
 __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
@@ -51,7 +52,7 @@ struct DevEx {
     // change the result: ranges are disjoint and a partition only looks at its own range.  `stack` holds two range lists
     // of stack_ranges(m) entries (first, last, depth); ps.sc[0/1] their lengths.
     __device__ void sort(QT_LDS qt::SortItem* items, int n, QT_LDS int* stack, qt::ParScratch& ps) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = nt >> 6;
         int lg = 0;
         for (int t = n; t > 1; t >>= 1) lg++;
         if (threadIdx.x == 0) {
@@ -112,6 +113,7 @@ struct DevEx {
         qt::final_stable_sort(*this, items, n, ps);  // rank counting: all threads
     }
     int dbg = 0;
+    int nt = 0;  // threads of this instance: blockDim.x, or fewer for the small levels of a mixed launch (the other waves have left)
 #ifdef MSORB_QT_MARKS  // per-phase timestamps of instance (0,0) (build with -DMSORB_QT_MARKS, run with MSORB_QT_DEBUG=3):
     int n_marks = 0;   // compiled out by default, the arrays would cost every wave 600 bytes of scratch
     long long t_mark[48];
@@ -130,9 +132,34 @@ struct DevEx {
     __device__ void dump() {}
 #endif
     __device__ int tid() const { return threadIdx.x; }
-    __device__ int nthreads() const { return blockDim.x; }
+    __device__ int nthreads() const { return nt; }
     __device__ void sync() { __syncthreads(); }
     __device__ int atomic_add(QT_LDS int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    // Wave collectives (every lane of the wave calls them, in convergent code).
+    // add_runs: arr[idx] += 1 for every lane with idx >= 0, one atomic per RUN of equal indices in lane order: neighbouring lanes
+    // hold neighbouring candidates, i.e. mostly the same node — 64 atomics on one LDS address are executed one after the other.
+    __device__ void add_runs(QT_LDS int* arr, int idx) {
+        const int lane = threadIdx.x & 63;
+        const int prev = __builtin_amdgcn_update_dpp(idx, idx, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        const bool head = lane == 0 || prev != idx;
+        const uint64_t heads = __ballot(head);
+        if (head && idx >= 0) {
+            const uint64_t rest = (heads >> lane) >> 1;
+            const int len = rest ? __builtin_ctzll(rest) + 1 : 64 - lane;
+            (void)__hip_atomic_fetch_add(arr + idx, len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    // claim: *ctr += (number of lanes with pred); returns a distinct value of the claimed range to every lane with pred
+    __device__ int claim(QT_LDS int* ctr, bool pred) {
+        const uint64_t m = __ballot(pred);
+        if (m == 0) return 0;                      // wave-uniform
+        const int lane = threadIdx.x & 63;
+        const int leader = __builtin_ctzll(m);
+        int base = 0;
+        if (lane == leader) base = __hip_atomic_fetch_add(ctr, __popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        base = __builtin_amdgcn_readlane(base, leader);
+        return base + __popcll(m & ((1ull << lane) - 1ull));
+    }
     __device__ void atomic_max(QT_LDS int* p, int v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     __device__ void atomic_min(QT_LDS int* p, int v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     __device__ int excl_count(bool p, int* total) { int t = 0; const int r = excl_scan((int)p, nullptr, &t); *total = t; return r; }  // unused
@@ -144,7 +171,7 @@ struct DevEx {
         if (lane == 63) tmp[wave] = incl;
         __syncthreads();
         int before = 0, tot = 0;
-        const int nw = blockDim.x >> 6;
+        const int nw = nt >> 6;
         for (int w = 0; w < nw; w++) {
             const int c = tmp[w];
             if (w < wave) before += c;
@@ -156,12 +183,12 @@ struct DevEx {
 };
 
 template <int PC>
-__global__ __launch_bounds__(1024) void quadtree_select_kernel(QtLevels lv, const Cand16* __restrict__ compact,
-                                                              const int* __restrict__ img_base,
-                                                              const int* __restrict__ level_count, uint16_t* __restrict__ label,
-                                                              int* __restrict__ sel_pt /* [img][sel_stride] candidate idx */,
-                                                              int* __restrict__ sel_n /* [img][nlevels] */, int sel_stride,
-                                                              int ws_N, int ws_nini, int debug) {
+__device__ __forceinline__ void quadtree_select_body(const QtLevels& lv, const Cand16* __restrict__ compact,
+                                                     const int* __restrict__ img_base,
+                                                     const int* __restrict__ level_count, uint16_t* __restrict__ label,
+                                                     int* __restrict__ sel_pt /* [img][sel_stride] candidate idx */,
+                                                     int* __restrict__ sel_n /* [img][nlevels] */, int sel_stride,
+                                                     int ws_N, int ws_nini, int debug, int big_levels, int small_nt) {
     extern __shared__ __attribute__((aligned(16))) char qt_mem[];
     // grid = (image, level): consecutive workgroups (dealt round-robin to the 8 XCDs) are different images of one
     // level, so the heavy level-0 instances are spread over all XCDs instead of piling up on one
@@ -170,15 +197,36 @@ __global__ __launch_bounds__(1024) void quadtree_select_kernel(QtLevels lv, cons
     int off = img_base[img];
     for (int l = 0; l < level; l++) off += lc[l];
     const int n = lc[level];
+    // mixed launch: the levels with many candidates get every wave of the workgroup, the others only the first small_nt threads
+    // (their remaining waves leave at once; s_barrier counts the waves that are still there)
+    const int nt_eff = level < big_levels ? (int)blockDim.x : min((int)blockDim.x, small_nt);
+    if ((int)threadIdx.x >= nt_eff) return;
     qt::Workspace w;
     qt::workspace_carve(w, qt_mem, ws_N, ws_nini);
     DevEx ex;
     ex.dbg = debug;
+    ex.nt = nt_eff;
     int* out = sel_pt + (size_t)img * sel_stride + lv.sel_off[level];
     const int kept = qt::select<PC>(ex, reinterpret_cast<const qt::Pt*>(compact + off), n, label + off, lv.W[level], lv.H[level],
                                 lv.quota[level], w, out, debug);
     if (threadIdx.x == 0) sel_n[(size_t)img * lv.nlevels + level] = kept;
     ex.dump();
+}
+template <int PC>
+__global__ __launch_bounds__(1024) void quadtree_select_kernel(QtLevels lv, const Cand16* __restrict__ compact, const int* __restrict__ img_base,
+                                                              const int* __restrict__ level_count, uint16_t* __restrict__ label,
+                                                              int* __restrict__ sel_pt, int* __restrict__ sel_n, int sel_stride, int ws_N,
+                                                              int ws_nini, int debug, int big_levels, int small_nt) {
+    quadtree_select_body<PC>(lv, compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, ws_N, ws_nini, debug, big_levels, small_nt);
+}
+// Batch form: 256-thread instances whose first PC x 256 candidates stay in registers for the whole selection (a level-0 instance of
+// the BASELINE geometries has ~6 800): the per-generation point passes then touch no global memory at all.
+template <int PC>
+__global__ __launch_bounds__(256, 4) void quadtree_select_batch_kernel(QtLevels lv, const Cand16* __restrict__ compact, const int* __restrict__ img_base,
+                                                                   const int* __restrict__ level_count, uint16_t* __restrict__ label,
+                                                                   int* __restrict__ sel_pt, int* __restrict__ sel_n, int sel_stride, int ws_N,
+                                                                   int ws_nini, int debug, int big_levels, int small_nt) {
+    quadtree_select_body<PC>(lv, compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, ws_N, ws_nini, debug, big_levels, small_nt);
 }
 
 // One workgroup per image: records in level-major / quadtree order; output row = mono index from the front for
@@ -283,7 +331,11 @@ void launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_b
     // waves.  A big batch has other workgroups on the CU for that (256 threads: least barrier idling, best
     // throughput); a frame or two has nothing else, so the instance itself brings the waves (1024 threads).
     static const int qt_env = getenv("MSORB_QT_THREADS") ? atoi(getenv("MSORB_QT_THREADS")) : 0;  // tuning only
-    const int qt_threads = qt_env ? qt_env : n_images <= 4 ? 1024 : n_images <= 16 ? 512 : kQtThreads;
+    int qt_threads = qt_env ? qt_env : n_images <= 4 ? 1024 : n_images <= 16 ? 512 : kQtThreads;
+    static const int big_env = getenv("MSORB_QT_BIG_LEVELS") ? atoi(getenv("MSORB_QT_BIG_LEVELS")) : 0;     // experiment
+    static const int big_nt_env = getenv("MSORB_QT_BIG_THREADS") ? atoi(getenv("MSORB_QT_BIG_THREADS")) : 512;
+    int big_levels = kMaxLevels, small_nt = qt_threads;
+    if (big_env && qt_threads == kQtThreads) { big_levels = big_env; qt_threads = big_nt_env; }
     static const bool regs_env = !getenv("MSORB_QT_NO_REGS");  // tuning / test aid
     if (lds > 64 * 1024) {   // quotas beyond ~700 keypoints per level (nfeatures > ~3000): past the default dynamic-LDS limit
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quadtree_select_kernel<kQtPointsPerThreadFrame>),
@@ -291,12 +343,19 @@ void launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_b
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quadtree_select_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
     }
-    if (qt_threads == 1024 && regs_env)
+    static const int batch_pc = getenv("MSORB_QT_BATCH_REGS") ? atoi(getenv("MSORB_QT_BATCH_REGS")) : 1;  // 0: candidates through global memory in every pass (rounds 1-2)
+    if (qt_threads == 256 && regs_env && batch_pc) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quadtree_select_batch_kernel<kQtPointsPerThreadBatch>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(quadtree_select_batch_kernel<kQtPointsPerThreadBatch>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds, s, lv,
+                           compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt);
+    } else if (qt_threads == 1024 && regs_env)
         hipLaunchKernelGGL(quadtree_select_kernel<kQtPointsPerThreadFrame>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds, s, lv,
-                           compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg);
+                           compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt);
     else
         hipLaunchKernelGGL(quadtree_select_kernel<0>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds, s, lv, compact, img_base,
-                           level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg);
+                           level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt);
     hipLaunchKernelGGL(quadtree_layout_kernel, dim3(n_images), dim3(256), 0, s, lv, compact, img_base, level_count, sel_pt,
                        sel_n, sel_stride, scales, lap0, lap1, capacity, sel, sel_count, mono);
 }

@@ -19,6 +19,8 @@ struct HostEx {
     void sync() {}
     void mark(int) {}
     int atomic_add(int* p, int v) { const int o = *p; *p = o + v; return o; }
+    void add_runs(int* arr, int idx) { if (idx >= 0) arr[idx]++; }
+    int claim(int* ctr, bool pred) { return pred ? (*ctr)++ : 0; }
     void atomic_max(int* p, int v) { if (v > *p) *p = v; }
     void atomic_min(int* p, int v) { if (v < *p) *p = v; }
     int excl_scan(int v, int*, int* total) { *total = v; return 0; }
