@@ -369,10 +369,16 @@ QT_HD void lsort_par(Ex& ex, QT_LDS SortItem* v, int n, QT_LDS int* stack, ParSc
 // ---- the selection itself ----------------------------------------------------------------------------
 struct NodeB {  // a multi-point ("splittable") node of the current generation, stored by processing rank
     int16_t x0, x1, y0, y1;
-    int32_t seq;    // creation sequence number (final list order = descending seq)
-    uint16_t slot;  // slot in its generation (creation order)
-    uint16_t pad;
+    uint32_t mid;   // split point of DivideNode (:511-525): x0 + ceil(w / 2) | (y0 + ceil(h / 2)) << 16 — all a point pass reads of a node
+    uint16_t slot;  // slot in its generation (creation order); the creation sequence number (final list order = descending
+    uint16_t pad;   // sequence) is the generation's base + slot, -1 - slot for the initial columns
 };
+QT_HD uint32_t node_mid(int x0, int x1, int y0, int y1) {
+    return (uint32_t)(x0 + ((x1 - x0 + 1) >> 1)) | ((uint32_t)(y0 + ((y1 - y0 + 1) >> 1)) << 16);
+}
+QT_HD int quadrant_of_mid(uint32_t xy, uint32_t mid) {  // xy = x | y << 16; DivideNode's assignment
+    return ((xy & 0xFFFFu) < (mid & 0xFFFFu) ? 0 : 1) + ((xy >> 16) < (mid >> 16) ? 0 : 2);
+}
 struct Workspace {       // LDS on the device; `cap` = 4 * max(N, nIni) child slots per generation
     QT_LDS int* cnt[2];         // points per child slot (re-used as best-point keys at the end)
     QT_LDS uint16_t* rankof[2]; // child slot -> processing rank among multi-point nodes (0xFFFF = none)
@@ -524,7 +530,7 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
                 NodeB b;
                 b.x0 = (int16_t)(int)(hX * (float)i); b.x1 = (int16_t)(int)(hX * (float)(i + 1));
                 b.y0 = 0; b.y1 = (int16_t)H;
-                b.seq = -1 - i; b.slot = (uint16_t)i; b.pad = 0;
+                b.mid = node_mid(b.x0, b.x1, b.y0, b.y1); b.slot = (uint16_t)i; b.pad = 0;
                 w.rankof[0][i] = (uint16_t)S;
                 w.nb[0][S++] = b;
             }
@@ -550,6 +556,8 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
     if (debug == 2) return 0;
     int par = 0;
     int iter = 0;
+    constexpr int kColumnsBase = -0x40000000;
+    int par_base = kColumnsBase;  // sequence base of the nodes of generation `par` (workgroup-uniform)
     for (;;) {
         if (debug >= 10 && iter++ >= debug - 10) return 0;  // one iteration = one pass of the main loop (:610-681) or one sweep of the careful loop (:689-753)
         const int np = par ^ 1;
@@ -604,7 +612,7 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
                     const int p = p0 + u * nt, pc = p < n ? p : b0;
                     q[u] = pts[pc];
                     lab[u] = label[pc];
-                    act[u] = p < n && lab[u] != kLabelSettled && (((lab[u] & kParityBit) != 0) == (par != 0));
+                    act[u] = p < n && (lab[u] >> 14) == par;   // settled (0xFFFF) has both top bits set
                 }
                 if (careful) {
 #pragma unroll
@@ -613,13 +621,13 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
 #pragma unroll
                     for (int u = 0; u < kPassBatch; u++) r[u] = act[u] ? (lab[u] & kSlotMask) : 0;
                 }
-                NodeB b[kPassBatch];
+                uint32_t mid[kPassBatch];
 #pragma unroll
-                for (int u = 0; u < kPassBatch; u++) b[u] = nb_par[r[u]];
+                for (int u = 0; u < kPassBatch; u++) mid[u] = nb_par[r[u]].mid;
 #pragma unroll
                 for (int u = 0; u < kPassBatch; u++) {
                     if (b0 + u * nt >= n) break;                       // workgroup-uniform
-                    const int slot = 4 * r[u] + quadrant_of(q[u], b[u]);
+                    const int slot = 4 * r[u] + quadrant_of_mid((uint32_t)q[u].x | ((uint32_t)q[u].y << 16), mid[u]);
                     // candidates arrive in cell order, so the lanes of a wave fall into a handful of nodes: one atomic per run
                     // of equal slots instead of 64 serialised ones on the same LDS address
                     ex.add_runs(cnt_np, act[u] ? slot : -1);
@@ -629,9 +637,9 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
         } else {
         for_points([&](int, bool valid, const Pt& q, uint16_t& lab_) {
             const int lab = lab_;
-            const bool act = valid && lab != kLabelSettled && ((lab & kParityBit) != 0) == (par != 0);
+            const bool act = valid && (lab >> 14) == par;   // settled (0xFFFF) has both top bits set
             const int r = !act ? 0 : careful ? (int)rk_par[lab & kSlotMask] : (lab & kSlotMask);
-            const int slot = 4 * r + quadrant_of(q, nb_par[r]);
+            const int slot = 4 * r + quadrant_of_mid((uint32_t)q.x | ((uint32_t)q.y << 16), nb_par[r].mid);
             ex.add_runs(cnt_np, act ? slot : -1);
             if (act) lab_ = (uint16_t)((par ? kParityBit : 0) | slot);
         });
@@ -660,7 +668,6 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
         {
             // next generation: children with more than one point, processing order = reverse creation order
             const int nsplit_ = sc[kScNsplit];
-            const int genbase_ = sc[kScGenBase];
             const int kk = (4 * nsplit_ + nt - 1) / nt;
             const int sb = tid * kk, se = sb + kk < 4 * nsplit_ ? sb + kk : 4 * nsplit_;
             int nz = 0, nx = 0;
@@ -677,7 +684,7 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
                     NodeB b;
                     b.x0 = (int16_t)((q & 1) ? mx : pb_.x0); b.x1 = (int16_t)((q & 1) ? pb_.x1 : mx);
                     b.y0 = (int16_t)((q & 2) ? my : pb_.y0); b.y1 = (int16_t)((q & 2) ? pb_.y1 : my);
-                    b.seq = genbase_ + i; b.slot = (uint16_t)i; b.pad = 0;
+                    b.mid = node_mid(b.x0, b.x1, b.y0, b.y1); b.slot = (uint16_t)i; b.pad = 0;
                     const int rank = NX - 1 - before;  // number of multi-point children created after this one
                     before++;
                     rk_np[i] = (uint16_t)rank;
@@ -709,7 +716,7 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
                 for (int u = 0; u < kPassBatch; u++) {
                     const int p = p0 + u * nt, pc = p < n ? p : b0;
                     lab[u] = label[pc];
-                    act[u] = p < n && lab[u] != kLabelSettled && (((lab[u] & kParityBit) != 0) == (par != 0));
+                    act[u] = p < n && (lab[u] >> 14) == par;   // settled (0xFFFF) has both top bits set
                 }
 #pragma unroll
                 for (int u = 0; u < kPassBatch; u++) {
@@ -737,7 +744,7 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
         } else {
         for_points([&](int p, bool valid, const Pt&, uint16_t& lab_) {
             const int lab = lab_;
-            const bool act = valid && lab != kLabelSettled && ((lab & kParityBit) != 0) == (par != 0);
+            const bool act = valid && (lab >> 14) == par;   // settled (0xFFFF) has both top bits set
             const int slot = lab & kSlotMask;
             const bool whole = act && (slot >> 2) >= nsplit;             // stays whole
             const int t = act && !whole ? (int)rk_np[slot] : 0;
@@ -779,7 +786,8 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
                 const int r = !in ? 0 : i < S - nsplit ? nsplit + i : i - (S - nsplit);
                 const int k = ex.claim(&sc[kScNres], in);
                 if (in) {
-                    w.res_seq[k] = (lp == par ? nb_par : nb_np)[r].seq;
+                    w.res_seq[k] = lp == par ? (par_base == kColumnsBase ? -1 - (int)nb_par[r].slot : par_base + (int)nb_par[r].slot)
+                                             : genbase + (int)nb_np[r].slot;
                     w.res_pt[k] = 0x3FFFFF - ((lp == par ? cnt_par : cnt_np)[r] & 0x3FFFFF);
                 }
             }
@@ -788,6 +796,7 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
             break;
         }
         par = np;
+        par_base = genbase;
     }
     // result order = descending creation sequence: rank sort (all seq are distinct)
     const int nres = sc[kScNres];
