@@ -1523,6 +1523,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 #ifdef MSORB_DESC_EXP_BLUR_FLAT   // timing experiment only (wrong results): every blurred row from one line
             L.bp[it] = *reinterpret_cast<const uint32_t*>(brow + (size_t)(col4));
             (void)row;
+#elif defined(MSORB_DESC_EXP_BLUR_TILED)   // timing experiment only (wrong results): addresses of a 16 x 8-pixel tiled plane
+            {
+                const uint32_t yy = min((uint32_t)(r.y - 18) + row, (uint32_t)((bv.h & ~7) - 1)), xx = (uint32_t)px0 + col4;
+                const uint32_t off = (yy >> 3) * (uint32_t)(bv.pitch * 8) + (xx >> 4) * 128u + (yy & 7u) * 16u + (xx & 15u);
+                L.bp[it] = *reinterpret_cast<const uint32_t*>(bv.base + (size_t)img * bv.img_stride + off);
+            }
 #else
             L.bp[it] = *reinterpret_cast<const uint32_t*>(brow + (size_t)(__umul24(row, (uint32_t)bv.pitch) + col4));
 #endif
