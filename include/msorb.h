@@ -176,6 +176,10 @@ int msorb_debug_copy_level(msorb_extractor* h, int image, int level, int blurred
 /* FAST candidates handed to the quadtree (vToDistributeKeys, ORBextractor.cc:795-869) of one image
  * and level, reference order; coordinates relative to (16,16); xyscore[3*i..3*i+2]. */
 int msorb_debug_candidates(msorb_extractor* h, int image, int level, int* xyscore, int capacity, int* n);
+/* Which form of the FAST stage the last call ran: 0 = one workgroup per reference cell (fast_cells_kernel), 1 = one workgroup
+ * per strip of up to four adjacent cells (fast_strip_kernel: MSORB_FAST_STRIP=1, on geometries whose cells fit it and 4-byte
+ * aligned rows; fewer instructions, slower alone on the GPU: an option).  Both produce the same candidates. */
+int msorb_debug_fast_form(const msorb_extractor* h);
 
 /* Host-only: DistributeOctTree (ORBextractor.cc:555-779) on explicit candidates; writes the indices of
  * the kept candidates in result order.  Needs no GPU. */

@@ -57,6 +57,10 @@ void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_
                        const ResizeTap* ty, int n_images, hipStream_t s, int single_stage = 0);
 void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cells, int ini_th, int min_th,
                        int slots_per_image, Cand16* slots, int* cell_count, int n_images, bool small_cells, hipStream_t s);
+// strip form of the FAST stage (fast_strip_kernel); false = this pyramid / geometry needs launch_fast_cells
+bool launch_fast_strips(const PyramidView& pyr, const StripDesc* strips, int n_strips, int n_small, const int* max_rh, const int* work_cap,
+                        int n_cells, int ini_th, int min_th, int slots_per_image, Cand16* slots, int* cell_count, int n_images,
+                        hipStream_t s);
 void launch_cand_compact(const CellDesc* cells, int n_cells, const int* level_cell_begin, int nlevels,
                          int slots_per_image, const Cand16* slots, const int* cell_count, int* cell_off,
                          int* level_count, int* img_total, int* img_base, Cand16* compact, int n_images,

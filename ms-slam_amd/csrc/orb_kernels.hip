@@ -614,6 +614,42 @@ __device__ __forceinline__ int fast_arc_contrast(const uint8_t* p, int sgn) {
     return A;
 }
 
+// the same with a window pointer w = centre - 3 * pitch - 3: every ds_read offset is non-negative, which matters when the tile
+// lives in dynamic LDS (runtime base: negative offsets cannot be folded into the instruction's unsigned offset field)
+template <class GEO>
+__device__ __forceinline__ int fast_arc_contrast_win(const uint8_t* w, int sgn) {
+    constexpr int P = GEO::kTilePitch;
+    const int sv = sgn * (int)w[3 * P + 3], ns = -sgn;
+    int d[16];
+    d[0] = (int)w[6 * P + 3] * ns + sv;
+    d[1] = (int)w[6 * P + 4] * ns + sv;
+    d[2] = (int)w[5 * P + 5] * ns + sv;
+    d[3] = (int)w[4 * P + 6] * ns + sv;
+    d[4] = (int)w[3 * P + 6] * ns + sv;
+    d[5] = (int)w[2 * P + 6] * ns + sv;
+    d[6] = (int)w[1 * P + 5] * ns + sv;
+    d[7] = (int)w[0 * P + 4] * ns + sv;
+    d[8] = (int)w[0 * P + 3] * ns + sv;
+    d[9] = (int)w[0 * P + 2] * ns + sv;
+    d[10] = (int)w[1 * P + 1] * ns + sv;
+    d[11] = (int)w[2 * P + 0] * ns + sv;
+    d[12] = (int)w[3 * P + 0] * ns + sv;
+    d[13] = (int)w[4 * P + 0] * ns + sv;
+    d[14] = (int)w[5 * P + 1] * ns + sv;
+    d[15] = (int)w[6 * P + 2] * ns + sv;
+    int mn3[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) mn3[i] = vmin3(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
+    int A = -512;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        const int a0 = vmin3(mn3[i], mn3[(i + 3) & 15], mn3[(i + 6) & 15]);
+        const int a1 = vmin3(mn3[(i + 1) & 15], mn3[(i + 4) & 15], mn3[(i + 7) & 15]);
+        A = vmax3(A, a0, a1);
+    }
+    return A;
+}
+
 // inclusive prefix sum over the wave with DPP adds only (no LDS crossbar round trips): shifts inside each row of 16
 // lanes, then the row totals are chained through lanes 15 / 31 (lanes shifted in from outside a row read 0)
 __device__ __forceinline__ int wave_incl_scan(int v, int) {
@@ -969,6 +1005,327 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
         __syncthreads();
     }
     if (tid == 0) cell_count[(size_t)img * n_cells + cell_id] = n_emitted;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST over a STRIP of up to K horizontally adjacent cells (StripDesc, orb_host.h) in one workgroup.
+// The detection areas of the cells of a cell row are contiguous, so staging, the quick test, the work list and the arc scores
+// treat the strip as one wide cell — one set-up and two block scans per wave for K / (T / 64) cells instead of one per
+// two waves and cell, fuller lanes in every loop, the 3-pixel column halo staged once per strip instead of once per cell.
+// What the reference defines per cell stays per cell:
+//   * NMS (cv::FAST runs on the cell's ROI, so a corner on the first / last detection column has no neighbour beyond it):
+//     the score plane gives every cell two apron columns of its own (score column = tile column + 2 * cell), never written;
+//   * emission order and slot run: kept corners set a bit in the cell's own row bitmap (64 bits per cell and detection row);
+//     rank = popcount prefix inside the cell;
+//   * the minThFAST fallback (ORBextractor.cc:843-847): a cell-activity mask selects the cells whose pixels the quick test
+//     lets through; the strip is run again at minThFAST for the cells that came out empty;
+//   * a strip with more quick-test survivors than the work list holds is redone one cell at a time (same mask; the list holds
+//     the flags of any single cell by construction).
+// ------------------------------------------------------------------------------------------------
+template <int K>
+struct StripGeo {
+    static constexpr int kMaxDw = (K * kStripMaxCellW + 6 + 3 + 3) / 4;  // dwords per staged ROI row (4-byte phase included)
+    static constexpr int P = 4 * kMaxDw + 8;                              // tile pitch, bytes
+    static constexpr int SP = (P + 2 * K + 3) & ~3;                       // score pitch (two apron columns per cell)
+    static constexpr int kTilePitch = P;                                  // (fast_arc_contrast's name for it)
+};
+struct StripLds {  // byte offsets of the dynamic LDS carve (host-computed from the geometry's tallest ROI / largest cell)
+    int tile, score, score_bytes, work, work_cap, kbits, kprefix, total;
+};
+template <int K>
+StripLds strip_lds_layout(int max_rh, int work_cap) {
+    StripLds L;
+    int o = 0;
+    // (the tile comes last: the kernel addresses it through a pointer biased by -(3 rows + 3 bytes), which must stay inside LDS)
+    L.score = o; L.score_bytes = ((max_rh - 6 + 3) * StripGeo<K>::SP + 15) & ~15; o += L.score_bytes;
+    L.work_cap = (work_cap + 7) & ~7;
+    L.work = o; o += L.work_cap * 2;
+    // the row bitmaps and their prefix live in the head of the TILE: the tile is dead once the arc scores are written; a strip that
+    // has to run again (cells redone at minThFAST, or one cell at a time) stages its ROI again
+    const int max_words = std::min(K * std::max(max_rh - 6, 1), kStripThreads);   // bitmap rows: cells x detection rows
+    L.tile = o;
+    L.kbits = o;
+    L.kprefix = o + 2 * max_words * 4;
+    o += std::max((kTileFront + (max_rh + 1) * StripGeo<K>::P + 8 + 15) & ~15, 2 * max_words * 4 + (((max_words + 1) * 4 + 15) & ~15));
+    L.total = (o + 15) & ~15;
+    return L;
+}
+
+template <int K, int T>
+__global__ __launch_bounds__(T) void fast_strip_kernel(PyramidView pyr, const StripDesc* __restrict__ strips, int n_strips, int ini_th,
+                                                       int min_th, int slots_per_image, Cand16* __restrict__ slots,
+                                                       int* __restrict__ cell_count, int n_cells, uint32_t gx_magic, StripLds L, int debug_stop) {
+    using GEO = StripGeo<K>;
+    constexpr int P = GEO::P, SP = GEO::SP, kMaxR = kStripMaxR;
+    constexpr int kIdBits = T == 256 ? 8 : 7;
+    static_assert(T == 128 || T == 256, "entry ids hold 7 or 8 thread bits");
+    extern __shared__ __attribute__((aligned(16))) uint8_t strip_mem[];
+    __shared__ int wave_tot[2][T / 64];
+    __shared__ uint16_t lut[32];
+    __shared__ uint16_t tbase[T];
+    __shared__ int slot_off_s[K];
+    uint8_t* const tile = strip_mem + L.tile + kTileFront;
+    const uint8_t* const tile_win = tile - 3 * GEO::P - 3;   // a pixel's 7 x 7 window starts here + its tile offset
+    uint8_t* const score = strip_mem + L.score;
+    uint16_t* const work = reinterpret_cast<uint16_t*>(strip_mem + L.work);
+    uint32_t* const kbits = reinterpret_cast<uint32_t*>(strip_mem + L.kbits);     // [cell * dh + row][2]
+    int* const kprefix = reinterpret_cast<int*>(strip_mem + L.kprefix);           // [cell * dh + row], + total at the end
+
+    // XCD-aware order (see fast_cells_kernel)
+    const unsigned total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned chunk = (total + 7) >> 3;
+    unsigned wg = (lin & 7u) * chunk + (lin >> 3);
+    if (total & 7u) wg = lin;
+    const int img = gx_magic ? (int)__umulhi(wg, gx_magic) : (int)(wg / gridDim.x);
+    const int strip_id = (int)(wg - (unsigned)img * gridDim.x);
+    const StripDesc sd = strips[strip_id];
+    const LevelView lv = pyr.lv[sd.level];
+    const int rw = sd.rw, rh = sd.rh, dh = rh - 6, ncell = sd.ncell, w_cell = sd.w_cell;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ga = sd.x0 & ~3;
+    const int x_lo = sd.x0 + 3, x_hi = sd.x0 + rw - 3;
+    const int gx0 = x_lo & ~3;
+    const int G = sd.G;
+    const int c_lo = gx0 - ga;
+    const uint32_t magic = sd.g_magic, wc_magic = sd.wc_magic;
+
+    // phase 0: stage the ROI with 16-byte lanes: lane (row r0 + 16 p, quad c) copies dwords 4c .. 4c + 3 of its row — 3-4 load
+    // instructions per thread for the whole strip, all in flight at once (the level rows are only 4-byte aligned for these loads,
+    // which the memory pipeline splits; the tile rows are written as dwords).  A quad may run up to 12 bytes past the ROI: still
+    // inside the level row (ROIs end 16 pixels before the border).
+    auto stage_tile = [&]() {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const uint8_t* src = lv.base + (size_t)img * lv.img_stride + (size_t)sd.y0 * lv.pitch + ga;
+        const int nq = (sd.ndw + 3) >> 2;
+        constexpr int kRowsPerPass = T / 16, kPasses = (58 + kRowsPerPass - 1) / kRowsPerPass;
+        const int c = tid & 15, r0 = tid >> 4;
+        if (c < nq) {
+            u32x4 v[kPasses];
+#pragma unroll
+            for (int p = 0; p < kPasses; p++) {
+                const uint32_t row = (uint32_t)min(r0 + p * kRowsPerPass, rh - 1);
+                __builtin_memcpy(&v[p], __builtin_assume_aligned(src + (__umul24(row, (uint32_t)lv.pitch) + 16u * (uint32_t)c), 4), 16);
+            }
+            uint32_t* l0 = reinterpret_cast<uint32_t*>(tile + r0 * P + 16 * c);
+#pragma unroll
+            for (int p = 0; p < kPasses; p++)
+                if (r0 + p * kRowsPerPass < rh) {
+                    uint32_t* d = l0 + p * kRowsPerPass * (P / 4);
+                    d[0] = v[p].x; d[1] = v[p].y; d[2] = v[p].z; d[3] = v[p].w;
+                }
+        }
+    };
+    stage_tile();
+    if (tid < 32) lut[tid] = (uint16_t)((((tid >> 1) & 3) << 8) + (tid >> 3) + ((tid & 1) << 15));  // flag bit -> work entry offset
+    if (tid < K) slot_off_s[tid] = strips[strip_id].slot_off[tid];   // (indexing the register copy by lane would put it in scratch)
+
+    // quick-test mapping: thread (strip of rows, group) — uniform split
+    const int strip = (int)(__umul24((uint32_t)tid, magic) >> 20);
+    const int g_own = tid - strip * G;
+    const int R = sd.R;
+    const int y_b = strip * R;
+    const int nrows = min(max(dh - y_b, 0), R);
+    const int c_own = c_lo + 4 * g_own;
+    // per-pixel masks of the group: 0x80 in the bytes whose pixel lies in the detection range, split by the (at most two) cells
+    // the group touches; cA = cell of the group's first detection pixel
+    uint32_t HmA, HmB;
+    int cA;
+    {
+        const int xg = ga + c_own;
+        const int vlo = min(max(x_lo - xg, 0), 4), vhi = min(max(x_hi - xg, 0), 4);
+        uint32_t Hm = (0x80808080u << (8 * vlo)) & (uint32_t)(0x0080808080ull >> (8 * (4 - vhi)));  // shifts by 32 must give 0
+        if (vlo >= 4) Hm = 0;
+        cA = min((int)(__umul24((uint32_t)max(xg + vlo - x_lo, 0), wc_magic) >> 20), ncell - 1);
+        const int nb = min(max(x_lo + (cA + 1) * w_cell - xg, 0), 4);          // pixels of the group in front of cell cA + 1
+        const uint32_t low = (uint32_t)((1ull << (8 * nb)) - 1ull);
+        HmA = Hm & low; HmB = Hm & ~low;
+    }
+    tbase[tid] = (uint16_t)(((y_b + 3) << 8) | c_own);
+    auto quick_test = [&](int th, uint32_t Hm, uint32_t& wA, uint32_t& wB) {
+        wA = 0; wB = 0;
+        const uint8_t* colp = &tile[(int)__umul24((uint32_t)y_b, P) + c_own];
+        uint32_t cw[kMaxR + 6], lw[kMaxR], rw_[kMaxR];
+#pragma unroll
+        for (int r = 0; r < kMaxR + 6; r++)
+            if (r < 9 || r - 6 < R) cw[r] = *reinterpret_cast<const uint32_t*>(colp + r * P);
+#pragma unroll
+        for (int k = 0; k < kMaxR; k++)
+            if (k < 3 || k < R) {
+                lw[k] = *reinterpret_cast<const uint32_t*>(colp + (k + 3) * P - 4);
+                rw_[k] = *reinterpret_cast<const uint32_t*>(colp + (k + 3) * P + 4);
+            }
+        const ushort2v t2 = __builtin_bit_cast(ushort2v, (uint32_t)th * 0x00010001u);
+#pragma unroll
+        for (int k = 0; k < kMaxR; k++) {
+            if (k >= 3 && k >= R) break;  // workgroup-uniform
+            const uint32_t V = cw[k + 3], U = cw[k], D = cw[k + 6];
+            const uint32_t R3 = __builtin_amdgcn_alignbyte(rw_[k], V, 3);
+            const uint32_t L3 = __builtin_amdgcn_alignbyte(V, lw[k], 1);
+            const uint32_t Ve = V & 0x00ff00ffu, Vo = (V >> 8) & 0x00ff00ffu;
+            const uint32_t Ae = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, Ve), t2));
+            const uint32_t Ao = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, Vo), t2));
+            const uint32_t Qd = ~(Ae | (Ao << 8));
+            const uint32_t Be = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, Ve ^ 0x00ff00ffu), t2));
+            const uint32_t Bo = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, Vo ^ 0x00ff00ffu), t2));
+            const uint32_t Qb = Be | (Bo << 8);
+            const uint32_t one = 0x01010101u;
+            const uint32_t X = (__builtin_amdgcn_lerp(U, Qd, one) & __builtin_amdgcn_lerp(D, Qd, one)) |
+                               (__builtin_amdgcn_lerp(L3, Qd, one) & __builtin_amdgcn_lerp(R3, Qd, one));
+            const uint32_t Y = (__builtin_amdgcn_lerp(U, Qb, 0u) | __builtin_amdgcn_lerp(D, Qb, 0u)) &
+                               (__builtin_amdgcn_lerp(L3, Qb, 0u) | __builtin_amdgcn_lerp(R3, Qb, 0u));
+            const uint32_t hm = k < nrows ? Hm : 0u;
+            const uint32_t z = (Y & hm) | ((~X & hm) >> 1);
+            if (k < 4) wA |= z >> (6 - 2 * k);
+            else wB |= z >> (6 - 2 * (k - 4));
+        }
+    };
+    const int score_words = L.score_bytes >> 4;
+    const int n_words = ncell * dh;          // bitmap rows (64 bits each) of the strip, <= T
+    auto clear_score = [&]() {
+        for (int i = tid; i < score_words; i += T) reinterpret_cast<uint4*>(score)[i] = uint4{0, 0, 0, 0};
+    };
+    const int sc_off = 4 - c_lo;
+    Cand16* const out_img = slots + (size_t)img * slots_per_image;
+    int* const cnt_img = cell_count + (size_t)img * n_cells + sd.cell0;
+
+    // control: cells still to do at the current threshold; a saturated run is repeated one cell at a time
+    uint32_t todo = (1u << ncell) - 1u, empties = 0;
+    int th = ini_th;
+    bool minpass = false, single = false, tile_dirty = false;
+    for (;;) {
+        if (todo == 0) {
+            if (minpass || ini_th == min_th || empties == 0) break;
+            todo = empties; empties = 0; th = min_th; minpass = true; single = false;
+        }
+        const uint32_t mask = single ? (todo & (0u - todo)) : todo;
+        __syncthreads();       // staging done / the previous run's planes, lists and counts are no longer read
+        if (debug_stop == 1) return;
+        if (tile_dirty) {      // a run before this one put its bitmaps into the tile
+            stage_tile();
+            __syncthreads();
+        }
+        tile_dirty = true;
+        clear_score();
+        const uint32_t Hm = (((mask >> cA) & 1u) ? HmA : 0u) | (((mask >> (cA + 1)) & 1u) ? HmB : 0u);
+        uint32_t wA, wB;
+        quick_test(th, Hm, wA, wB);
+        const int cnt = __popc(wA) + __popc(wB);
+        int n_work = 0;
+        const int my_base = block_excl_scan<T / 64>(cnt, lane, wave, wave_tot[0], &n_work);   // (its barrier also covers the clear)
+        if (debug_stop == 2) return;
+        if (n_work > L.work_cap) {
+            tile_dirty = false;   // nothing was written over the tile
+            if (!single) { single = true; continue; }
+            // cannot happen (the list holds any single cell's flags); give the cell up rather than loop
+            if (tid == 0) cnt_img[__builtin_ctz(mask)] = 0;
+            todo &= ~mask;
+            continue;
+        }
+        {
+            uint16_t* wp = &work[my_base];
+            const uint32_t idA = (uint32_t)tid << 5, idB = idA | (1u << (5 + kIdBits));
+            for (uint32_t w = wA; w; w &= w - 1) *wp++ = (uint16_t)(idA | (uint32_t)__builtin_ctz(w));
+            for (uint32_t w = wB; w; w &= w - 1) *wp++ = (uint16_t)(idB | (uint32_t)__builtin_ctz(w));
+        }
+        __syncthreads();
+        if (debug_stop == 3) return;
+        // arc scores, all lanes busy.  A wave works through the chunks wave, wave + T / 64, ... of the list and leaves the corners
+        // it finds (cell << 14 | tile row << 8 | score column) packed at the front of its OWN chunks — it has read more entries
+        // than it writes, so nothing unread is overwritten —: NMS and emission then loop over corners only (a third of the list).
+        const int wbase = wave * 64;
+        int n_corner = 0;                                    // wave-uniform
+        for (int i0 = wbase; i0 < n_work; i0 += T) {
+            const int i = i0 + lane;
+            bool corner = false;
+            int ce = 0;
+            if (i < n_work) {
+                const int id = work[i];
+                const int e = tbase[(id >> 5) & (T - 1)] + lut[id & 31] + ((id >> (5 + kIdBits)) << 10);
+                const int ty = (e >> 8) & 127, tx = e & 255;
+                const int A = fast_arc_contrast_win<GEO>(tile_win + ((int)__umul24((uint32_t)ty, P) + tx), (e & 0x8000) ? -1 : 1);
+                if (A > th) {
+                    const int cell = (int)(__umul24((uint32_t)(tx + (ga - x_lo)), wc_magic) >> 20);
+                    const int sx = tx + sc_off + 2 * cell;
+                    score[(int)__umul24((uint32_t)(ty - 2), SP) + sx] = (uint8_t)(A - 1);
+                    ce = (cell << 14) | ((e & 0x3F00) + sx);
+                    corner = true;
+                }
+            }
+            const unsigned long long bm = __ballot(corner);
+            if (corner) {
+                const int m = n_corner + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                work[(m >> 6) * T + wbase + (m & 63)] = (uint16_t)ce;
+            }
+            n_corner += __popcll(bm);
+        }
+        __syncthreads();
+        if (debug_stop == 4) return;
+        if (tid < n_words) *reinterpret_cast<uint2*>(&kbits[2 * tid]) = uint2{0, 0};   // (in the tile, which is dead from here on)
+        __syncthreads();
+        // NMS over the wave's own corners; kept corners set a bit in their cell's row bitmap
+        uint32_t mine_keep = 0;
+        {
+            int slot = 0;
+            for (int m0 = 0; m0 < n_corner; m0 += 64, slot++) {
+                if (m0 + lane >= n_corner) continue;
+                const int e = work[slot * T + wbase + lane];
+                const int cell = e >> 14, ty = (e >> 8) & 63, sx = e & 255;
+                const uint8_t* q = score + ((int)__umul24((uint32_t)(ty - 3), SP) + sx - 1);   // top-left neighbour
+                const int sv = q[SP + 1];
+                int m = max3i(q[0], q[1], q[2]);
+                m = max3i(m, q[SP], q[SP + 2]);
+                m = max(m, max3i(q[2 * SP], q[2 * SP + 1], q[2 * SP + 2]));
+                if (sv > m) {
+                    const int bit = sx - sc_off - 2 * cell + (ga - x_lo) - cell * w_cell;   // column inside the cell's detection area, < 64
+                    const int wi = cell * dh + (ty - 3);
+                    atomicOr(&kbits[2 * wi + (bit >> 5)], 1u << (bit & 31));
+                    mine_keep |= 1u << slot;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t w0 = tid < n_words ? kbits[2 * tid] : 0u, w1 = tid < n_words ? kbits[2 * tid + 1] : 0u;
+        int n_out = 0;
+        const int wprefix = block_excl_scan<T / 64>(__popc(w0) + __popc(w1), lane, wave, wave_tot[1], &n_out);
+        if (tid < n_words) kprefix[tid] = wprefix;
+        if (tid == 0) kprefix[n_words] = n_out;
+        __syncthreads();
+        {
+            int slot = 0;
+            for (int m0 = 0; m0 < n_corner; m0 += 64, slot++) {
+                if (!(mine_keep & (1u << slot))) continue;
+                const int e = work[slot * T + wbase + lane];
+                const int cell = e >> 14, ty = (e >> 8) & 63, sx = e & 255;
+                const int tx = sx - sc_off - 2 * cell;
+                const int bit = tx + (ga - x_lo) - cell * w_cell;
+                const int wi = cell * dh + (ty - 3);
+                const uint32_t b0 = kbits[2 * wi], b1 = kbits[2 * wi + 1];
+                const int before = bit < 32 ? __popc(b0 & ((1u << bit) - 1u)) : __popc(b0) + __popc(b1 & ((1u << (bit - 32)) - 1u));
+                const int rank = kprefix[wi] - kprefix[cell * dh] + before;
+                Cand16 c;
+                c.x = (uint16_t)(ga + tx - kMinBorder);
+                c.y = (uint16_t)(sd.y0 + ty - kMinBorder);
+                c.score = score[(int)__umul24((uint32_t)(ty - 2), SP) + sx];
+                c.pad = 0;
+                out_img[slot_off_s[cell] + rank] = c;
+            }
+        }
+        // per-cell totals straight from the prefix (every thread reads the K + 1 cell boundaries: no further barrier)
+        {
+            int prev = 0;   // kprefix[0]
+#pragma unroll
+            for (int c = 0; c < K; c++) {
+                if (c >= ncell) break;
+                const int nxt = kprefix[(c + 1) * dh];
+                if ((mask >> c) & 1u) {
+                    if (tid == c) cnt_img[c] = nxt - prev;
+                    if (!minpass && nxt == prev) empties |= 1u << c;
+                }
+                prev = nxt;
+            }
+        }
+        todo &= ~mask;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1763,6 +2120,38 @@ void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cell
     if (small_cells) { if (aligned) MSORB_FAST_LAUNCH(true, GeoSmall); else MSORB_FAST_LAUNCH(false, GeoSmall); }
     else { if (aligned) MSORB_FAST_LAUNCH(true, GeoLarge); else MSORB_FAST_LAUNCH(false, GeoLarge); }
 #undef MSORB_FAST_LAUNCH
+}
+bool launch_fast_strips(const PyramidView& pyr, const StripDesc* strips, int n_strips, int n_small, const int* max_rh, const int* work_cap,
+                        int n_cells, int ini_th, int min_th, int slots_per_image, Cand16* slots, int* cell_count, int n_images,
+                        hipStream_t s) {
+    for (int l = 0; l < pyr.nlevels; l++) {
+        const LevelView& v = pyr.lv[l];
+        if ((reinterpret_cast<uintptr_t>(v.base) & 3) != 0 || (v.pitch & 3) != 0 || (v.img_stride & 3) != 0) return false;  // dword staging
+    }
+    if (n_strips < 1) return false;
+    static const int dbg = getenv("MSORB_FAST_DEBUG_STOP") ? atoi(getenv("MSORB_FAST_DEBUG_STOP")) : 0;  // profiling only
+    static const int cap_env = getenv("MSORB_STRIP_CAP") ? atoi(getenv("MSORB_STRIP_CAP")) : 0;          // tuning only
+    StripLds L[2];
+    const int count[2] = {n_small, n_strips - n_small};
+    for (int c = 0; c < 2; c++) {
+        if (count[c] <= 0) continue;
+        L[c] = strip_lds_layout<kStripCells>(max_rh[c], std::max(work_cap[c], cap_env));
+        if (L[c].total > 60 * 1024 || L[c].work_cap > 8192) return false;
+    }
+    // two launches, one per LDS class (orb_host.cc): first the bulk with the small footprint, then the few tall strips
+    for (int c = 0, first = 0; c < 2; first += count[c], c++) {
+        const int n = count[c];
+        if (n <= 0) continue;
+        uint32_t gx_magic = (uint32_t)((0x100000000ull + (unsigned)n - 1) / (unsigned)n);
+        {
+            const unsigned long long total = (unsigned long long)n * (unsigned)n_images;
+            const unsigned long long e = (unsigned long long)gx_magic * (unsigned)n - 0x100000000ull;
+            if (n < 2 || total >= 0x100000000ull || e * total >= 0x100000000ull) gx_magic = 0;
+        }
+        hipLaunchKernelGGL((fast_strip_kernel<kStripCells, kStripThreads>), dim3(n, n_images), dim3(kStripThreads), (size_t)L[c].total, s, pyr,
+                           strips + first, n, ini_th, min_th, slots_per_image, slots, cell_count, n_cells, gx_magic, L[c], dbg);
+    }
+    return true;
 }
 void launch_cand_compact(const CellDesc* cells, int n_cells, const int* level_cell_begin, int nlevels,
                          int slots_per_image, const Cand16* slots, const int* cell_count, int* cell_off,

@@ -348,6 +348,56 @@ def test_large_feature_quota_device_quadtree(msorb_mod, oracle, nfeat, nlev, kin
         ex.close()
 
 
+@pytest.mark.parametrize("name", ["kitti", "euroc", "fourseasons"])
+def test_fast_strip_and_cell_forms_agree_with_the_oracle(msorb_mod, oracle, monkeypatch, name):
+    """The FAST stage as strips of up to four cells per workgroup (fast_strip_kernel, batches) and as one workgroup per cell
+    (fast_cells_kernel): same candidates in the same order as the oracle's cell loop, on scenes, on noise (every strip has
+    more quick-test survivors than its work list holds: redone cell by cell), on low contrast (cells empty at iniThFAST are
+    redone at minThFAST, per cell), on half-flat images (strips with empty AND full cells) — and the dataset geometries
+    really take the strip form when it is asked for (MSORB_FAST_STRIP=1; the per-cell form is the default)."""
+    import torch
+    cfg = CONFIGS[name]
+    rows, cols = cfg["rows"], cfg["cols"]
+    rng = np.random.Generator(np.random.PCG64(41))
+    scene = synth.image(311, rows, cols)
+    noise = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+    low = (scene.astype(np.int32) // 6 + 100).astype(np.uint8)
+    half = scene.copy(); half[:, : cols // 2] = 77
+    stripes = scene.copy(); stripes[:, ::97] = 255; stripes[::53, :] = 0
+    imgs = [scene, noise, low, half, stripes]
+    ex = msorb_mod.ORBextractor(cfg["nfeatures"], 1.2, 8, 20, 7)
+    ref = oracle.OracleExtractor(cfg["nfeatures"], 1.2, 8, 20, 7)
+    try:
+        want = []
+        for im in imgs:
+            ref(im)
+            want.append([ref.candidates(l) for l in range(8)])
+        # rows padded to a multiple of 64 bytes, as bench.py lays its images out (the strip form stages 16-byte quads: it needs
+        # 4-byte aligned rows; tightly packed 1241-byte rows take the per-cell kernel's byte path until a batch is big enough
+        # to be re-staged)
+        pitch = (cols + 63) // 64 * 64
+        store = torch.zeros((16, rows, pitch), dtype=torch.uint8, device="cuda")
+        d = store[:, :, :cols]
+        d.copy_(torch.from_numpy(np.stack([imgs[i % len(imgs)] for i in range(16)])).cuda())
+        ex.set_overlap(1, False)
+        for form in ("1", "default", "0"):
+            if form == "default":
+                monkeypatch.delenv("MSORB_FAST_STRIP", raising=False)
+            else:
+                monkeypatch.setenv("MSORB_FAST_STRIP", form)
+            monkeypatch.setenv("MSORB_GROUPS", "1")            # candidate inspection needs one sub-batch
+            counts, monos, d_kps, d_desc = ex.extract_batch(d)
+            assert ex.debug_fast_form() == (1 if form == "1" else 0), "the dataset geometries can take the strip form"
+            for i in (0, 1, 2, 3, 4, 15):
+                for l in range(8):
+                    assert np.array_equal(ex.debug_candidates(i, l), want[i % len(imgs)][l]), (form, i, l)
+        monkeypatch.delenv("MSORB_FAST_STRIP", raising=False)
+        mono, kps, desc = ex(scene)                             # one frame: the per-cell form
+        assert ex.debug_fast_form() == 0
+    finally:
+        ex.close()
+
+
 def test_full_bench_size_properties(msorb_mod, oracle):
     """BASELINE.json configs[1] at bench.py's batch size (128 stereo pairs = 256 images, default 2 sub-batches): too
     big for the oracle image by image, so size-independent properties carry the check — copies of an image must give
