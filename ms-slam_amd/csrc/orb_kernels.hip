@@ -866,6 +866,7 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
         // (the append loop runs as long as the busiest lane of the wave has flags left, so it only packs thread id and flag
         // bit; the list's consumers — all lanes busy — turn that into tile coordinates through two small tables)
         const uint32_t baseA = (uint32_t)(((y_b + 3) << 7) | c_own), baseB = baseA + (4u << 7);
+        int w_begin = 0, n_corner = 0;   // this wave's stretch of the list, its corners (wave-uniform)
         if (n_work <= GEO::kWorkCap) {
             uint16_t* wp = &work[my_base];
             const uint32_t idA = (uint32_t)tid << 5, idB = idA | (1u << (5 + (T == 128 ? 7 : 8)));
@@ -873,13 +874,31 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
             for (uint32_t w = wB; w; w &= w - 1) *wp++ = (uint16_t)(idB | (uint32_t)__builtin_ctz(w));
             __syncthreads();
             if (debug_stop == 3) return;
-            for (int i = tid; i < n_work; i += T) {
-                const int id = work[i];
-                const int e = tbase[(id >> 5) & (T - 1)] + lut[id & 31] + ((id >> (5 + (T == 128 ? 7 : 8))) << 9);
-                const int ty = (e >> 7) & 127, tx = e & 127;
-                const int A = fast_arc_contrast<GEO>(&tile[(int)__umul24((uint32_t)ty, P) + tx], (e & 0x8000) ? -1 : 1);
-                if (A > th) score[(int)__umul24((uint32_t)(ty - 2), SP) + tx + sc_off] = (uint8_t)(A - 1);  // score row = y + 1
-                work[i] = A > th ? (uint16_t)(e & 0x3FFF) : (uint16_t)0xFFFF;  // the list now holds the corners
+            // every wave takes one contiguous stretch of the list and leaves the corners it finds packed at the front of that
+            // stretch (it has read more entries than it has written): NMS and emission then loop over corners only — about a
+            // third of the quick-test survivors — instead of skipping the other two thirds lane by lane
+            w_begin = wave * ((((n_work + T / 64 - 1) / (T / 64)) + 63) & ~63);
+            const int w_end = min(w_begin + ((((n_work + T / 64 - 1) / (T / 64)) + 63) & ~63), n_work);
+            n_corner = 0;
+            for (int i0 = w_begin; i0 < w_end; i0 += 64) {   // wave-uniform
+                const int i = i0 + lane;
+                bool corner = false;
+                int ce = 0;
+                if (i < w_end) {
+                    const int id = work[i];
+                    const int e = tbase[(id >> 5) & (T - 1)] + lut[id & 31] + ((id >> (5 + (T == 128 ? 7 : 8))) << 9);
+                    const int ty = (e >> 7) & 127, tx = e & 127;
+                    const int A = fast_arc_contrast<GEO>(&tile[(int)__umul24((uint32_t)ty, P) + tx], (e & 0x8000) ? -1 : 1);
+                    if (A > th) {
+                        score[(int)__umul24((uint32_t)(ty - 2), SP) + tx + sc_off] = (uint8_t)(A - 1);  // score row = y + 1
+                        ce = e & 0x3FFF;
+                        corner = true;
+                    }
+                }
+                const unsigned long long bm = __ballot(corner);
+                if (corner)
+                    work[w_begin + n_corner + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] = (uint16_t)ce;
+                n_corner += __popcll(bm);
             }
         } else {
             // saturated cell (more quick-test survivors than the list holds): every thread scores its own survivors
@@ -905,9 +924,9 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
             uint32_t mine_keep = 0;  // per-thread record of the corners it owns: list slots tid, tid + T, ... (cap / T <= 32)
             {
                 int slot = 0;
-                for (int i = tid; i < n_work; i += T, slot++) {
-                    const int e = work[i];
-                    if (e == 0xFFFF) continue;
+                for (int m0 = 0; m0 < n_corner; m0 += 64, slot++) {
+                    if (m0 + lane >= n_corner) continue;
+                    const int e = work[w_begin + m0 + lane];
                     const int ty = e >> 7, tx = e & 127;
                     const uint8_t* q = &score[(int)__umul24((uint32_t)(ty - 2), SP) + tx + sc_off];
                     const int sv = q[0];
@@ -930,9 +949,9 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
             __syncthreads();
             {
                 int slot = 0;
-                for (int i = tid; i < n_work; i += T, slot++) {
+                for (int m0 = 0; m0 < n_corner; m0 += 64, slot++) {
                     if (!(mine_keep & (1u << slot))) continue;
-                    const int e = work[i];
+                    const int e = work[w_begin + m0 + lane];
                     const int ty = e >> 7, tx = e & 127;
                     const int b = (ty - 3) * (32 * wpr) + (tx - c_lo);
                     const int rank = kprefix[b >> 5] + __popc(kbits[b >> 5] & ((1u << (b & 31)) - 1u));
