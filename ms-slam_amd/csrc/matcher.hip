@@ -720,9 +720,14 @@ __global__ __launch_bounds__(256 * kDenseSplit) void dense_top2_kernel(const uin
         for (int u = 0; u < kDenseQPL; u++) {
             // the distance as ONE accumulate chain: v_bcnt_u32_b32 d, x, d adds the population count to its third operand
             // (written with 64-bit popcounts the compiler emits eight counts from zero plus adds to join them)
+            // (spelled as the instruction: left to the compiler the chain is re-associated into independent counts joined by
+            // v_add3_u32 — three more slow-class instructions per pair, 23 instead of 19 + the top-2 update)
             uint32_t d = 0;
 #pragma unroll
-            for (int w = 0; w < 8; w++) d = (uint32_t)__builtin_popcount(a[u][w] ^ tw[w]) + d;
+            for (int w = 0; w < 8; w++) {
+                const uint32_t x = a[u][w] ^ tw[w];
+                asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(d));
+            }
             const uint32_t key = (d << 16) | (uint32_t)j;
             // (k0 <= k1) + key -> the two smallest: second = median of the three (one v_med3_u32 instead of max + min)
             // (written in the min/max form the backend folds into v_med3_u32).  Gating this on "d below the second-best
@@ -734,8 +739,15 @@ __global__ __launch_bounds__(256 * kDenseSplit) void dense_top2_kernel(const uin
     };
     // (a hand-made software pipeline over groups of four trains — next group's LDS reads in flight while the current one is
     // scored — measured slower: 1.36-1.46 against 1.65-1.73 Tpairs/s; register copies and one wave per SIMD less)
-#pragma unroll 4
-    for (int j = jb; j < je; j++) score(tile4[2 * j], tile4[2 * j + 1], j);
+    // (unrolled by hand: the inline-asm chain keeps the loop unroller away)
+    int j = jb;
+    for (; j + 4 <= je; j += 4) {
+        score(tile4[2 * j], tile4[2 * j + 1], j);
+        score(tile4[2 * j + 2], tile4[2 * j + 3], j + 1);
+        score(tile4[2 * j + 4], tile4[2 * j + 5], j + 2);
+        score(tile4[2 * j + 6], tile4[2 * j + 7], j + 3);
+    }
+    for (; j < je; j++) score(tile4[2 * j], tile4[2 * j + 1], j);
     // merge the parts: keys are unique (distinct indices), so top-2 of the union = {min(a0,b0), min(max(a0,b0), min(a1,b1))}
     __syncthreads();  // everyone is done reading the tile; it becomes the exchange buffer
     uint32_t* xch = reinterpret_cast<uint32_t*>(tile);
