@@ -1,0 +1,82 @@
+// Second VALU issue-cost micro-benchmark for gfx950 (instructions the first one left out or measured oddly):
+//   hipcc --offload-arch=gfx950 -O3 tools/valu_ubench2.hip -o /tmp/valu_ubench2 && /tmp/valu_ubench2
+// 8 waves per SIMD, 8 independent chains per lane; prints cycles per wave-instruction per SIMD at a nominal 2.4 GHz.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#define REP8(X) X X X X X X X X
+#define KERNEL(NAME, NI, ASM)                                                                     \
+    __global__ void NAME(uint32_t* out, int iters) {                                              \
+        uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+        uint32_t b = blockIdx.x * 3 + 1, c = 0x0c020c00u;                                         \
+        for (int it = 0; it < iters; it++) {                                                      \
+            REP8(asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)             \
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
+                              : "v"(b), "v"(c) : "vcc", "s10", "s11", "s12", "s13");)             \
+        }                                                                                         \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;      \
+    }                                                                                             \
+    static const int NAME##_ni = NI;
+#define CMPCND(i) "v_cmp_lt_i32 vcc, %" #i ", %8\nv_cndmask_b32_e32 %" #i ", %" #i ", %8, vcc\n"
+#define CMPCND64(i) "v_cmp_lt_i32 s[10:11], %" #i ", %8\nv_cndmask_b32_e64 %" #i ", %" #i ", %8, s[10:11]\n"
+#define CMPONLY(i) "v_cmp_lt_i32 vcc, %" #i ", %8\nv_add_u32 %" #i ", %" #i ", %8\n"
+#define CNDVCC64(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, vcc\n"
+#define CNDVCC32(i) "v_cndmask_b32_e32 %" #i ", %" #i ", %8, vcc\n"
+#define MAD64(i) "v_mad_u64_u32 v[40:41], s[12:13], %" #i ", 44, v[42:43]\nv_add_u32 %" #i ", %" #i ", v40\n"
+#define MBCNT(i) "v_mbcnt_lo_u32_b32 %" #i ", %8, %" #i "\n"
+#define MBCNTH(i) "v_mbcnt_hi_u32_b32 %" #i ", %8, %" #i "\n"
+#define FFBL(i) "v_ffbl_b32 %" #i ", %" #i "\n"
+#define CVTUB(i) "v_cvt_f32_ubyte1 %" #i ", %" #i "\n"
+#define ADDCO(i) "v_add_co_u32 %" #i ", vcc, %" #i ", %8\n"
+#define READL(i) "v_readfirstlane_b32 s10, %" #i "\nv_add_u32 %" #i ", s10, %" #i "\n"
+#define LSHL64(i) "v_lshlrev_b64 v[40:41], %8, v[42:43]\nv_add_u32 %" #i ", %" #i ", v40\n"
+#define MADI24(i) "v_mad_i32_i24 %" #i ", %" #i ", %8, %9\n"
+#define SUBREV(i) "v_subrev_u32 %" #i ", %8, %" #i "\n"
+#define BFI(i) "v_bfi_b32 %" #i ", %8, %9, %" #i "\n"
+#define OR3(i) "v_or3_b32 %" #i ", %" #i ", %8, %9\n"
+#define PKFMA(i) "v_pk_fma_f32 v[40:41], v[42:43], v[44:45], v[40:41]\n"
+#define ADDF(i) "v_add_f32 %" #i ", %" #i ", %8\n"
+#define SDWAADD(i) "v_add_u32_sdwa %" #i ", %8, %" #i " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n"
+#define ASHR(i) "v_ashrrev_i32 %" #i ", 3, %" #i "\n"
+#define NOT(i) "v_not_b32 %" #i ", %" #i "\n"
+#define OR(i) "v_or_b32 %" #i ", %" #i ", %8\n"
+#define CMPCND2(i) "v_cmp_lt_i32 vcc, %" #i ", %8\nv_cndmask_b32_e32 %" #i ", %" #i ", %8, vcc\nv_cndmask_b32_e32 %" #i ", %" #i ", %9, vcc\n"
+#define CMPXCND(i) "v_cmp_lt_i32 vcc, %" #i ", %8\nv_add_u32 %" #i ", %" #i ", %9\nv_cndmask_b32_e32 %" #i ", %" #i ", %8, vcc\n"
+#define CMPXXCND(i) "v_cmp_lt_i32 vcc, %" #i ", %8\nv_add_u32 %" #i ", %" #i ", %9\nv_xor_b32 %" #i ", %" #i ", %8\nv_cndmask_b32_e32 %" #i ", %" #i ", %8, vcc\n"
+#define SMOVCND(i) "s_mov_b64 vcc, s[12:13]\nv_cndmask_b32_e32 %" #i ", %" #i ", %8, vcc\n"
+#define CMP64CND2(i) "v_cmp_lt_i32 s[10:11], %" #i ", %8\nv_cndmask_b32_e64 %" #i ", %" #i ", %8, s[10:11]\nv_cndmask_b32_e64 %" #i ", %" #i ", %9, s[10:11]\n"
+#define CMPCND2E64(i) "v_cmp_lt_i32 vcc, %" #i ", %8\nv_cndmask_b32_e64 %" #i ", %" #i ", %8, vcc\nv_cndmask_b32_e64 %" #i ", %" #i ", %9, vcc\n"
+#define ADDCOCI(i) "v_add_co_u32 %" #i ", vcc, %" #i ", %8\nv_addc_co_u32 %" #i ", vcc, %" #i ", %9, vcc\n"
+KERNEL(k_cmpcnd2, 3, CMPCND2) KERNEL(k_cmpxcnd, 3, CMPXCND) KERNEL(k_cmpxxcnd, 4, CMPXXCND) KERNEL(k_smovcnd, 1, SMOVCND)
+KERNEL(k_cmp64cnd2, 3, CMP64CND2) KERNEL(k_cmpcnd2e64, 3, CMPCND2E64) KERNEL(k_addcoci, 2, ADDCOCI)
+KERNEL(k_cmpcnd, 2, CMPCND) KERNEL(k_cmpcnd64, 2, CMPCND64) KERNEL(k_cmponly, 2, CMPONLY) KERNEL(k_cndvcc64, 1, CNDVCC64)
+KERNEL(k_cndvcc32, 1, CNDVCC32) KERNEL(k_mad64, 2, MAD64) KERNEL(k_mbcnt, 1, MBCNT) KERNEL(k_mbcnth, 1, MBCNTH) KERNEL(k_ffbl, 1, FFBL)
+KERNEL(k_cvtub, 1, CVTUB) KERNEL(k_addco, 1, ADDCO) KERNEL(k_readl, 2, READL) KERNEL(k_lshl64, 2, LSHL64) KERNEL(k_madi24, 1, MADI24)
+KERNEL(k_subrev, 1, SUBREV) KERNEL(k_bfi, 1, BFI) KERNEL(k_or3, 1, OR3) KERNEL(k_pkfma, 1, PKFMA) KERNEL(k_addf, 1, ADDF)
+KERNEL(k_sdwaadd, 1, SDWAADD) KERNEL(k_ashr, 1, ASHR) KERNEL(k_not, 1, NOT) KERNEL(k_or, 1, OR)
+typedef void (*kern_t)(uint32_t*, int);
+static void run(const char* name, kern_t k, int ni) {
+    static uint32_t* d = nullptr;
+    if (!d) (void)hipMalloc(&d, 2048 * 256 * 4);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const int iters = 1000, blocks = 2048;  // 8 waves per SIMD
+    k<<<blocks, 256>>>(d, 10);
+    (void)hipEventRecord(e0); k<<<blocks, 256>>>(d, iters); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double groups = (double)blocks * 4 * iters * 64;   // instruction groups per SIMD-wave
+    printf("%-44s %7.3f ms  %6.2f cycles@2.4GHz per group of %d instruction(s) per SIMD\n", name, ms, ms * 1e-3 * 2.4e9 * 1024 / groups, ni);
+}
+#define RUN(label, k) run(label, k, k##_ni)
+int main() {
+    RUN("v_cmp (vcc) + v_cndmask_e32 (vcc)", k_cmpcnd); RUN("v_cmp (sgpr pair) + v_cndmask_e64 (sgpr pair)", k_cmpcnd64);
+    RUN("v_cmp (vcc) + 2 x v_cndmask_e32 (vcc)", k_cmpcnd2); RUN("v_cmp (vcc) + v_add + v_cndmask_e32 (vcc)", k_cmpxcnd);
+    RUN("v_cmp (vcc) + v_add + v_xor + v_cndmask_e32", k_cmpxxcnd); RUN("s_mov vcc + v_cndmask_e32 (1 VALU)", k_smovcnd);
+    RUN("v_cmp (sgpr) + 2 x v_cndmask_e64 (sgpr)", k_cmp64cnd2); RUN("v_cmp (vcc) + 2 x v_cndmask_e64 (vcc)", k_cmpcnd2e64);
+    RUN("v_add_co + v_addc_co (vcc chain)", k_addcoci);
+    RUN("v_cmp (vcc) + v_add_u32", k_cmponly); RUN("v_cndmask_e64 ..., vcc (vcc constant)", k_cndvcc64); RUN("v_cndmask_e32 ..., vcc (vcc constant)", k_cndvcc32);
+    RUN("v_mad_u64_u32 + v_add_u32", k_mad64); RUN("v_mbcnt_lo_u32_b32", k_mbcnt); RUN("v_mbcnt_hi_u32_b32", k_mbcnth); RUN("v_ffbl_b32", k_ffbl);
+    RUN("v_cvt_f32_ubyte1", k_cvtub); RUN("v_add_co_u32 (writes vcc)", k_addco); RUN("v_readfirstlane + v_add_u32 (sgpr)", k_readl);
+    RUN("v_lshlrev_b64 + v_add_u32", k_lshl64); RUN("v_mad_i32_i24", k_madi24); RUN("v_subrev_u32", k_subrev); RUN("v_bfi_b32", k_bfi);
+    RUN("v_or3_b32", k_or3); RUN("v_pk_fma_f32 (x8, one chain)", k_pkfma); RUN("v_add_f32", k_addf); RUN("v_add_u32_sdwa", k_sdwaadd);
+    RUN("v_ashrrev_i32 (imm)", k_ashr); RUN("v_not_b32", k_not); RUN("v_or_b32", k_or);
+    return 0;
+}
