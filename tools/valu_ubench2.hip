@@ -46,6 +46,28 @@
 #define CMP64CND2(i) "v_cmp_lt_i32 s[10:11], %" #i ", %8\nv_cndmask_b32_e64 %" #i ", %" #i ", %8, s[10:11]\nv_cndmask_b32_e64 %" #i ", %" #i ", %9, s[10:11]\n"
 #define CMPCND2E64(i) "v_cmp_lt_i32 vcc, %" #i ", %8\nv_cndmask_b32_e64 %" #i ", %" #i ", %8, vcc\nv_cndmask_b32_e64 %" #i ", %" #i ", %9, vcc\n"
 #define ADDCOCI(i) "v_add_co_u32 %" #i ", vcc, %" #i ", %8\nv_addc_co_u32 %" #i ", vcc, %" #i ", %9, vcc\n"
+#define MINF(i) "v_min_f32 %" #i ", %" #i ", %8\n"
+#define MIN3F(i) "v_min3_f32 %" #i ", %" #i ", %8, %9\n"
+#define MAX3F(i) "v_max3_f32 %" #i ", %" #i ", %8, %9\n"
+#define MED3F(i) "v_med3_f32 %" #i ", %" #i ", %8, %9\n"
+#define MAXF(i) "v_max_f32 %" #i ", %" #i ", %8\n"
+#define MINU16(i) "v_min_u16 %" #i ", %" #i ", %8\n"
+#define MIN3I16(i) "v_min3_i16 %" #i ", %" #i ", %8, %9\n"
+#define SUBF(i) "v_sub_f32 %" #i ", %" #i ", %8\n"
+#define MADF(i) "v_mad_f32 %" #i ", %" #i ", %8, %9\n"
+#define FMAMIX(i) "v_fma_mix_f32 %" #i ", %" #i ", %8, %9\n"
+#define PKMINF16(i) "v_pk_min_f16 %" #i ", %" #i ", %8\n"
+#define PKADDF32(i) "v_pk_add_f32 v[40:41], v[42:43], v[40:41]\n"
+#define CVTU0(i) "v_cvt_f32_ubyte0 %" #i ", %" #i "\n"
+#define XOR3(i) "v_xor3_b32 %" #i ", %" #i ", %8, %9\n"
+#define ADDLSHL(i) "v_add_lshl_u32 %" #i ", %" #i ", %8, 2\n"
+#define LSHLADD(i) "v_lshl_add_u32 %" #i ", %" #i ", 2, %8\n"
+#define SADU16(i) "v_sad_u16 %" #i ", %8, %9, %" #i "\n"
+#define MSAD(i) "v_msad_u8 %" #i ", %8, %9, %" #i "\n"
+KERNEL(k_minf, 1, MINF) KERNEL(k_min3f, 1, MIN3F) KERNEL(k_max3f, 1, MAX3F) KERNEL(k_med3f, 1, MED3F) KERNEL(k_maxf, 1, MAXF)
+KERNEL(k_minu16, 1, MINU16) KERNEL(k_min3i16, 1, MIN3I16) KERNEL(k_subf, 1, SUBF) KERNEL(k_pkminf16, 1, PKMINF16)
+KERNEL(k_pkaddf32, 1, PKADDF32) KERNEL(k_cvtu0, 1, CVTU0) KERNEL(k_addlshl, 1, ADDLSHL) KERNEL(k_lshladd, 1, LSHLADD)
+KERNEL(k_sadu16, 1, SADU16) KERNEL(k_msad, 1, MSAD)
 KERNEL(k_cmpcnd2, 3, CMPCND2) KERNEL(k_cmpxcnd, 3, CMPXCND) KERNEL(k_cmpxxcnd, 4, CMPXXCND) KERNEL(k_smovcnd, 1, SMOVCND)
 KERNEL(k_cmp64cnd2, 3, CMP64CND2) KERNEL(k_cmpcnd2e64, 3, CMPCND2E64) KERNEL(k_addcoci, 2, ADDCOCI)
 KERNEL(k_cmpcnd, 2, CMPCND) KERNEL(k_cmpcnd64, 2, CMPCND64) KERNEL(k_cmponly, 2, CMPONLY) KERNEL(k_cndvcc64, 1, CNDVCC64)
@@ -78,5 +100,9 @@ int main() {
     RUN("v_lshlrev_b64 + v_add_u32", k_lshl64); RUN("v_mad_i32_i24", k_madi24); RUN("v_subrev_u32", k_subrev); RUN("v_bfi_b32", k_bfi);
     RUN("v_or3_b32", k_or3); RUN("v_pk_fma_f32 (x8, one chain)", k_pkfma); RUN("v_add_f32", k_addf); RUN("v_add_u32_sdwa", k_sdwaadd);
     RUN("v_ashrrev_i32 (imm)", k_ashr); RUN("v_not_b32", k_not); RUN("v_or_b32", k_or);
+    RUN("v_min_f32", k_minf); RUN("v_max_f32", k_maxf); RUN("v_min3_f32", k_min3f); RUN("v_max3_f32", k_max3f); RUN("v_med3_f32", k_med3f);
+    RUN("v_min_u16", k_minu16); RUN("v_min3_i16", k_min3i16); RUN("v_sub_f32", k_subf); RUN("v_pk_min_f16", k_pkminf16);
+    RUN("v_pk_add_f32 (x8, one chain)", k_pkaddf32); RUN("v_cvt_f32_ubyte0", k_cvtu0); RUN("v_add_lshl_u32", k_addlshl);
+    RUN("v_lshl_add_u32", k_lshladd); RUN("v_sad_u16", k_sadu16); RUN("v_msad_u8", k_msad);
     return 0;
 }
