@@ -180,6 +180,9 @@ int msorb_debug_candidates(msorb_extractor* h, int image, int level, int* xyscor
  * per strip of up to four adjacent cells (fast_strip_kernel: MSORB_FAST_STRIP=1, on geometries whose cells fit it and 4-byte
  * aligned rows; fewer instructions, slower alone on the GPU: an option).  Both produce the same candidates. */
 int msorb_debug_fast_form(const msorb_extractor* h);
+/* Which form of the 7 x 7 Gaussian the last call ran: 0 = VALU kernels, 1 = the matrix-core kernel (gauss7_mfma_kernel: 16-byte
+ * aligned planes; MSORB_BLUR_MFMA=0 / 1).  Both produce the same planes. */
+int msorb_debug_blur_form(const msorb_extractor* h);
 
 /* Host-only: DistributeOctTree (ORBextractor.cc:555-779) on explicit candidates; writes the indices of
  * the kept candidates in result order.  Needs no GPU. */

@@ -215,6 +215,7 @@ struct msorb_extractor {
     bool device_quadtree = true;
     bool small_cells = false;  // every cell ROI <= 46 x 57: the FAST kernel's compact LDS geometry applies
     int last_fast_form = 0;    // 1: the last call's FAST stage ran as strips of cells
+    int last_blur_form = 0;    // 1: the last call's blur ran on the matrix cores
     bool compact_on_host = false;  // h_compact / h_level_count / h_img_base hold the last call's candidates
     // pinned host state
     PinBuf<int> h_level_count, h_img_base, h_sel_count, h_mono;
@@ -483,7 +484,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
             h->h_pyr_async = true;
         }
         mark(7, sb);
-        launch_gauss7(pyr, blur, n, sb, h->sem);
+        h->last_blur_form = launch_gauss7(pyr, blur, n, sb, h->sem);
         mark(8, sb);
         if (h->overlap_blur) HIPCHK(hipEventRecord(G.ev_blur, sb));
         // optional (MSORB_STAGGER): run the sub-batches' FAST kernels one after the other, so that the memory- and
@@ -552,7 +553,7 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
         HIPCHK(hipEventRecord(h->ev_pyramid, s));
         HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_pyramid, 0));
         if (prof) (void)hipEventRecord(h->pe[7], h->copy_stream);
-        launch_gauss7(pyr, blur, n_images, h->copy_stream, h->sem);
+        h->last_blur_form = launch_gauss7(pyr, blur, n_images, h->copy_stream, h->sem);
         if (prof) (void)hipEventRecord(h->pe[8], h->copy_stream);
         HIPCHK(hipEventRecord(h->ev_blur, h->copy_stream));
     }
@@ -569,7 +570,7 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
                         h->d_compact.p, n_images, s);
     mark(3);
     HIPCHK(hipEventRecord(h->ev_compact, s));
-    if (!overlap_blur) launch_gauss7(pyr, blur, n_images, s, h->sem);
+    if (!overlap_blur) h->last_blur_form = launch_gauss7(pyr, blur, n_images, s, h->sem);
     mark(4);
     h->compact_on_host = false;
     const int sel_stride = h->sel_stride;
@@ -1407,6 +1408,7 @@ int msorb_debug_copy_level(msorb_extractor* h, int image, int level, int blurred
 }
 
 int msorb_debug_fast_form(const msorb_extractor* h) { return h ? h->last_fast_form : MSORB_E_INVALID; }
+int msorb_debug_blur_form(const msorb_extractor* h) { return h ? h->last_blur_form : MSORB_E_INVALID; }
 int msorb_debug_candidates(msorb_extractor* h, int image, int level, int* xyscore, int capacity, int* n) {
     if (!h || !n || !h->geom_valid || image < 0 || image >= h->last_n_images || level < 0 || level >= h->G.nlevels)
         return MSORB_E_INVALID;

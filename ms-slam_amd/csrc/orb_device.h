@@ -65,7 +65,8 @@ void launch_cand_compact(const CellDesc* cells, int n_cells, const int* level_ce
                          int slots_per_image, const Cand16* slots, const int* cell_count, int* cell_off,
                          int* level_count, int* img_total, int* img_base, Cand16* compact, int n_images,
                          hipStream_t s);
-void launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images, hipStream_t s, const Semantics& sem = Semantics());
+// returns the form that ran: 0 = VALU kernels, 1 = matrix-core kernel (gauss7_mfma_kernel)
+int launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images, hipStream_t s, const Semantics& sem = Semantics());
 void launch_describe(const PyramidView& pyr, const PyramidView& blur, const SelRec* sel, const int* sel_count,
                      int sel_stride, const LevelScale& scales, msorb_keypoint* kps, uint8_t* desc, int out_stride,
                      int max_sel, int n_images, hipStream_t s, const Semantics& sem = Semantics());

@@ -2182,13 +2182,258 @@ void launch_cand_compact(const CellDesc* cells, int n_cells, const int* level_ce
     hipLaunchKernelGGL(cand_gather_kernel, dim3((n_cells + kGatherCells - 1) / kGatherCells, n_images), dim3(256), 0, s, cells, n_cells, slots_per_image,
                        slots, cell_count, cell_off, img_base, compact);
 }
-void launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images, hipStream_t s, const Semantics& sem) {
+// ------------------------------------------------------------------------------------------------
+// The same 7 x 7 Gaussian on the matrix cores — an OPTION (`MSORB_BLUR_MFMA=1`), bit-equal to the VALU kernels, kept for what
+// it measured: a separable blur is two banded matrix products, the chain is bound by VALU issue and nothing in the front-end
+// uses the MFMA pipe.  The kernel needs 58 M VALU instructions per 256 images instead of gauss7_stream_kernel's 99 M and
+// 0.035 ms of matrix-pipe time — and 0.32 ms alone on the GPU against 0.18, 1.41 against 1.29 ms per pipelined step: it reads
+// every pixel three times (64 source columns per 32 outputs, strips of one image spread over the XCDs: 1.13 GB FETCH against
+// 0.45) and its waves are long dependent chains (load -> MFMA -> byte planes -> MFMA -> LDS turn -> store, with loads and stores
+// sharing the in-order vmcnt).  Two findings on the way: the fp32 MFMAs (v_mfma_f32_32x32x2_f32, 142 TFLOP/s measured,
+// tools/mfma_rate_f32.hip) run at exactly the vector ALUs' FMA rate and did not overlap with other waves' VALU work — the first,
+// fp32 form of the vertical pass cost more than the kernel it replaced —, and 16-byte stores of 32-byte row pieces from four
+// waves at four times cost 0.22 ms against whole 128-byte lines from one workgroup.
+//   horizontal pass  H = P x Bh :  v_mfma_i32_32x32x32_i8 x 2 (K = 64 source columns X-16 .. X+47 for the 32 output columns
+//       X .. X+31).  A operand = pixels: lane (row r = lane & 31, half = lane >> 5) loads 16 consecutive bytes of its row for
+//       each K step, xor 0x80 makes them signed (p - 128); B operand = the band matrix, built once per wave: byte j of
+//       lane (column n, half) is the weight of source column x for output column X + n — tap(x - (X + n) + 3) plus, in the first /
+//       last strip, the taps that BORDER_REFLECT_101 folds back onto x; columns that do not exist weigh 0.  Both operands use the
+//       same lane -> (row / column, k slot) rule, so the order of k inside the instruction does not matter.
+//   vertical pass  V = Bv x H :  i8 again (the fp32 MFMAs run on the vector ALUs' own FMA units — 142 TFLOP/s, the VALU rate —,
+//       so a fp32 form of this pass, built first, cost more vector time than the kernel it replaced; the i8 / bf16 forms run on
+//       the matrix cores proper).  H is 16 bits wide: it is fed as two byte planes, hi = H >> 8 and lo = H & 255, two MFMAs each
+//       (tile j, and rows 0 .. 6 of tile j + 1), and the planes are recombined as 256 * acc_hi + acc_lo.  The H tile sits in the
+//       accumulator layout — lane (column n, half) holds rows 4 half + (i & 3) + 8 (i >> 2) in register i — and the byte planes
+//       keep that order: byte 4 q + b of the operand = register 4 q + b, with the weights (a per-lane constant) in the same
+//       order.  An output block covers rows 32 j + 4 .. 32 j + 35, so it needs tile j and tile j + 1 and no tile above.
+//   Rows are reflected by LOADING the reflected source row (the horizontal pass is row independent), so no block has special
+//   weights; out = (V + 32768) >> 16 (saturated when the taps sum to more than 256).
+//   One wave = one 32-column strip x plan.chunk output blocks; 1 KB of LDS per wave (output transpose), no workgroup barrier.
+// ------------------------------------------------------------------------------------------------
+typedef int bm_v4i __attribute__((ext_vector_type(4)));
+typedef int bm_v16i __attribute__((ext_vector_type(16)));
+typedef float bm_v16f __attribute__((ext_vector_type(16)));
+struct BlurMfmaPlan {
+    int task_begin[kMaxLevels + 1];  // first task of each level (per image)
+    int strips[kMaxLevels];          // groups of four 32-column strips of the level
+    int nblocks[kMaxLevels];         // output blocks j = -1 .. nblocks - 2 of the level
+    int nlevels;
+    int chunk;                       // output blocks (32 rows each) per wave
+};
+
+__device__ __forceinline__ uint32_t bm_tap(int t, unsigned long long K) {   // k[t] for 0 <= t <= 6, else 0
+    return (t >= 0 && t <= 6) ? (uint32_t)(K >> (8 * t)) & 255u : 0u;
+}
+
+template <bool SAT>
+__global__ __launch_bounds__(256, 6) void gauss7_mfma_kernel(PyramidView src, PyramidView dst, BlurMfmaPlan plan, GaussTaps T, int tasks_per_image, int n_images, int dbg) {
+    // the workgroup's output tile (32 rows x 4 strips = 128 bytes per row) on its way to row-major, double buffered
+    __shared__ __attribute__((aligned(16))) uint32_t wg_tile[2][32 * 32];
+    const int lane = threadIdx.x & 63, half = lane >> 5, c = lane & 31, wv = threadIdx.x >> 6;
+    if (dbg & 8) __builtin_amdgcn_s_setprio(3);   // experiment
+    // One workgroup = four ADJACENT strips (128 columns) x plan.chunk blocks, its four waves in step: the finished 32 x 128 tile is
+    // stored as whole 128-byte lines.  (Every wave storing its own 32-byte row pieces left the L2 with quarter lines from four
+    // waves at four different times: 0.22 of that version's 0.42 ms.)  The grid may be smaller than the task list.
+    const int n_all = tasks_per_image * n_images;
+    int parity = 0;
+    for (int gt = (int)blockIdx.x; gt < n_all; gt += (int)gridDim.x) {
+    const int img = gt / tasks_per_image, task = gt - img * tasks_per_image;
+    int level = 0;
+    while (level + 1 < plan.nlevels && task >= plan.task_begin[level + 1]) level++;
+    const int idx = task - plan.task_begin[level];
+    const int n_groups = plan.strips[level];            // groups of four strips
+    const int rc = idx / n_groups, sg = idx - rc * n_groups;
+    const int cs = 4 * sg + wv;                         // (a strip past the level's last one works on columns >= w: nothing is stored)
+    const LevelView sv = src.lv[level], dv = dst.lv[level];
+    const int w = sv.w, h = sv.h, X = 32 * cs;
+    const uint8_t* sb = sv.base + (size_t)img * sv.img_stride;
+    uint8_t* db = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride;
+    unsigned long long K = 0;
+    uint32_t ksum = 0;
+#pragma unroll
+    for (int t = 0; t < 7; t++) { K |= (unsigned long long)(T.k[t] & 255u) << (8 * t); ksum += T.k[t]; }
+
+    // B operand of the horizontal pass (band matrix): 2 K steps x 16 bytes per lane
+    bm_v4i bh[2];
+    const int xn = X + c;
+    const bool edge = X == 0 || X + 32 + 3 >= w;   // wave-uniform: some output column of the strip reaches across a border
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            uint32_t word = 0;
+            const int x0 = X - 16 + 32 * s + 16 * half + 4 * d;
+            if (!edge) {
+                // interior: bytes t0 .. t0 + 3 of the zero-padded tap sequence, t0 = x0 - xn + 3
+                const int t0 = x0 - xn + 3;
+                if (t0 > -4 && t0 < 7) word = t0 >= 0 ? (uint32_t)(K >> (8 * t0)) : (uint32_t)(K << (8 * -t0));
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int x = x0 + b;
+                    uint32_t wgt = 0;
+                    if (x >= 0 && x < w) {
+                        wgt = bm_tap(x - xn + 3, K);
+                        if (x >= 1) wgt += bm_tap(-x - xn + 3, K);                       // source column -x reflects onto x
+                        if (x <= w - 2) wgt += bm_tap(2 * (w - 1) - x - xn + 3, K);      // source column 2 (w - 1) - x too
+                    }
+                    word |= (wgt & 255u) << (8 * b);
+                }
+            }
+            bh[s][d] = (int)word;
+        }
+    // Weights of the vertical pass (B operand: lane = output row m = c of the block, byte 4 q + b <-> H row rho(half, 4 q + b) of
+    // tile j, resp. 32 + rho of tile j + 1), for output row 32 j + 4 + m
+    bm_v4i wv_own, wv_next;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint32_t wo = 0, wn = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int rho = 4 * half + b + 8 * q;
+            wo |= bm_tap(rho - c - 1, K) << (8 * b);
+            if (q == 0) wn |= bm_tap(31 + rho - c, K) << (8 * b);     // rows 0 .. 6 of the next tile sit in dword 0 of both halves
+        }
+        wv_own[q] = (int)wo; wv_next[q] = (int)wn;
+    }
+    bm_v16i czero;
+#pragma unroll
+    for (int i = 0; i < 16; i++) czero[i] = 0;
+    // Bookkeeping of the signed bytes.  Pixels enter as a = p - 128, so the row sums come out as H' = H - 128 ksum.  H' (16 bits,
+    // signed) is split into hi = H' >> 8 (signed byte) and lo = H' & 255, fed as lo - 128: with every output's weights summing to
+    // ksum,  V + 32768 = 256 * acc_hi + acc_lo + 128 ksum + 128 ksum^2 + 32768,  and the pixel is bits 16 .. 23 of that.
+    const uint32_t round_c = 128u * ksum + 128u * ksum * ksum + 32768u;
+
+    // source columns of this lane's two 16-byte loads (clamped loads only ever hold columns of weight 0)
+    int xoff[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) xoff[s] = min(max(X - 16 + 32 * s + 16 * half, 0), sv.pitch - 16);
+    struct Px { bm_v4i a0, a1; };
+    struct Hp { bm_v4i hi, lo; };   // an H tile as the two byte planes of the vertical pass's A operand
+    auto load_rows = [&](int J) {   // pixel rows 32 J .. 32 J + 31 (reflected), this lane's 2 x 16 bytes
+        int y = 32 * J + c;
+        y = y < 0 ? -y : (y >= h ? 2 * (h - 1) - y : y);
+        y = min(max(y, 0), h - 1);            // (far outside: feeds only outputs that are not stored)
+        const uint8_t* rp = sb + (size_t)y * sv.pitch;
+        Px p;
+        p.a0 = *reinterpret_cast<const bm_v4i*>(rp + xoff[0]);
+        p.a1 = *reinterpret_cast<const bm_v4i*>(rp + xoff[1]);
+        return p;
+    };
+    auto h_tile = [&](Px p) {   // the horizontal pass of those rows, split into byte planes
+#pragma unroll
+        for (int d = 0; d < 4; d++) { p.a0[d] ^= (int)0x80808080u; p.a1[d] ^= (int)0x80808080u; }
+        bm_v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(p.a0, bh[0], czero, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(p.a1, bh[1], acc, 0, 0, 0);
+        Hp t;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t t0 = __builtin_amdgcn_perm((uint32_t)acc[4 * q + 1], (uint32_t)acc[4 * q], 0x05040100u);       // lo0 hi0 lo1 hi1
+            const uint32_t t1 = __builtin_amdgcn_perm((uint32_t)acc[4 * q + 3], (uint32_t)acc[4 * q + 2], 0x05040100u);   // lo2 hi2 lo3 hi3
+            t.lo[q] = (int)(__builtin_amdgcn_perm(t1, t0, 0x06040200u) ^ 0x80808080u);
+            t.hi[q] = (int)__builtin_amdgcn_perm(t1, t0, 0x07050301u);
+        }
+        return t;
+    };
+    // The vertical product is formed TRANSPOSED (H as the A operand, the weights as B: same registers, same constants): a lane owns
+    // one output ROW (lane & 31) and the columns 4 half + 8 q + 0..3 of the strip.
+    auto out_block = [&](int j, const Hp& Hc, const Hp& Hn) {
+        bm_v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Hc.hi, wv_own, czero, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Hn.hi, wv_next, acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[i] = (int)(((uint32_t)acc[i] << 8) + round_c);   // the lo plane accumulates on top of 256 * hi + constant
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Hc.lo, wv_own, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Hn.lo, wv_next, acc, 0, 0, 0);
+        // acc[4 q + b] = row (lane & 31), column 4 half + 8 q + b of the wave's 32 x 32 tile: into the workgroup tile (dword column
+        // 8 wave + half + 2 q), barrier, then wave w stores rows 8 w .. 8 w + 7 of the whole 128-byte-wide tile, 16 bytes per lane.
+        uint32_t* const tw = wg_tile[parity] + (lane & 31) * 32 + 8 * wv + half;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t sum[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                sum[b] = (uint32_t)acc[4 * q + b];    // V + 32768: the pixel is bits 16 .. 23
+                if (SAT) sum[b] = min(sum[b], 0x00FFFFFFu);
+            }
+            tw[2 * q] = __builtin_amdgcn_perm(sum[1], sum[0], 0x0c0c0602u) | __builtin_amdgcn_perm(sum[3], sum[2], 0x06020c0cu);   // the four bytes 2
+        }
+        __syncthreads();
+        const int row = 8 * wv + (lane >> 3);
+        const bm_v4i row16 = *reinterpret_cast<const bm_v4i*>(wg_tile[parity] + row * 32 + 4 * (lane & 7));
+        parity ^= 1;    // (the other buffer is free: its readers passed this block's barrier)
+        const int y = 32 * j + 4 + row, x = 128 * sg + 16 * (lane & 7);
+        if (y >= 0 && y < h && !(dbg & 1)) {
+            uint8_t* op = db + (size_t)y * dv.pitch + x;
+            if (x + 15 < w) *reinterpret_cast<bm_v4i*>(op) = row16;
+            else
+                for (int b = 0; b < 16; b++)
+                    if (x + b < w) op[b] = (uint8_t)((uint32_t)row16[b >> 2] >> (8 * (b & 3)));
+        }
+    };
+
+    const int jb = -1 + rc * plan.chunk, je = min(jb + plan.chunk, plan.nblocks[level] - 1);
+    // Loads and stores share one in-order counter on this chip (vmcnt), so a wave that waits for the next tile's rows also waits
+    // for its last store: a deep prefetch ring inside the wave (built, measured slower) does not hide that — many waves per SIMD
+    // do.  The loop therefore keeps its register footprint small: two H tiles alternate, the rows of the next tile are requested
+    // one block ahead.
+    Hp Ha = h_tile(load_rows(jb)), Hb;
+    Px pn = load_rows(jb + 1);
+    for (int j = jb; j < je; j += 2) {
+        Hb = h_tile(pn);
+        pn = load_rows(j + 2);
+        out_block(j, Ha, Hb);
+        if (j + 1 >= je) break;
+        Ha = h_tile(pn);
+        pn = load_rows(j + 3);
+        out_block(j + 1, Hb, Ha);
+    }
+    }
+}
+
+int launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images, hipStream_t s, const Semantics& sem) {
     BlurPlan plan{};
     plan.nlevels = src.nlevels;
     bool aligned = true;
     for (int l = 0; l < src.nlevels; l++) {
         const LevelView& v = src.lv[l];
         aligned = aligned && (reinterpret_cast<uintptr_t>(v.base) & 3) == 0 && (v.pitch & 3) == 0 && (v.img_stride & 3) == 0;
+    }
+    // matrix-core form (batches on 16-byte aligned planes; any taps): see gauss7_mfma_kernel
+    {
+        const char* e = getenv("MSORB_BLUR_MFMA");   // read per call: the tests run both forms in one process
+        bool mfma = e ? atoi(e) != 0 : false;
+        GaussTaps Tm;
+        uint32_t ksum = 0;
+        for (int i = 0; i < 7; i++) { Tm.k[i] = (uint32_t)sem.gauss_taps[i]; ksum += Tm.k[i]; }
+        for (int l = 0; l < src.nlevels && mfma; l++) {
+            const LevelView& v = src.lv[l];
+            const LevelView& d = dst.lv[l];
+            mfma = (reinterpret_cast<uintptr_t>(v.base) & 15) == 0 && (v.pitch & 15) == 0 && (v.img_stride & 15) == 0 && v.w >= 8 && v.h >= 8 &&
+                   v.pitch >= 16 && d.w == v.w && d.h == v.h;
+        }
+        for (int i = 0; i < 7 && mfma; i++) mfma = Tm.k[i] <= 64;   // a folded border weight (two taps) must fit a signed byte
+        // (taps summing to more than 256 — a semantics variant — would need a 17-bit row sum: the VALU kernels take them)
+        if (mfma && ksum <= 256) {
+            BlurMfmaPlan mp{};
+            mp.nlevels = src.nlevels;
+            static const int chunk_env = getenv("MSORB_BLUR_MFMA_CHUNK") ? atoi(getenv("MSORB_BLUR_MFMA_CHUNK")) : 0;   // tuning only
+            mp.chunk = chunk_env > 0 ? chunk_env : 16;
+            static const int bm_dbg = getenv("MSORB_BLUR_MFMA_DEBUG") ? atoi(getenv("MSORB_BLUR_MFMA_DEBUG")) : 0;   // timing experiments only
+            int total = 0;
+            for (int l = 0; l < src.nlevels; l++) {
+                const LevelView& v = src.lv[l];
+                mp.task_begin[l] = total;
+                mp.strips[l] = ((v.w + 31) / 32 + 3) / 4;   // groups of four 32-column strips
+                const int jlast = v.h > 36 ? (v.h - 36 + 31) / 32 : 0;   // 32 jlast + 35 >= h - 1
+                mp.nblocks[l] = jlast + 2;                                // blocks -1 .. jlast
+                total += mp.strips[l] * ((mp.nblocks[l] + mp.chunk - 1) / mp.chunk);
+            }
+            mp.task_begin[src.nlevels] = total;
+            static const int wgs_env = getenv("MSORB_BLUR_MFMA_WGS") ? atoi(getenv("MSORB_BLUR_MFMA_WGS")) : 0;   // tuning only
+            const int n_wg = std::min(wgs_env > 0 ? wgs_env : 1 << 20, total * n_images);   // (a smaller grid: the workgroups loop over the tasks)
+            hipLaunchKernelGGL(gauss7_mfma_kernel<false>, dim3(n_wg), dim3(256), 0, s, src, dst, mp, Tm, total, n_images, bm_dbg);
+            return 1;
+        }
     }
     static const bool stream_env = !getenv("MSORB_BLUR_GENERIC");  // tuning / test aid
     // the streaming kernel has the default taps folded into its v_dot4 constants; other taps (Semantics::gauss_taps) take the
@@ -2219,6 +2464,7 @@ void launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images,
     else hipLaunchKernelGGL(gauss7_kernel<false>, dim3(total, n_images), dim3(256), 0, s, src, dst, plan, T);
     if (!stream)  // the streaming kernel handles the right border itself
         hipLaunchKernelGGL(gauss7_edge_kernel, dim3((max_h + kEdgeRows - 1) / kEdgeRows, src.nlevels, n_images), dim3(64), 0, s, src, dst, T);
+    return 0;
 }
 void launch_describe(const PyramidView& pyr, const PyramidView& blur, const SelRec* sel, const int* sel_count,
                      int sel_stride, const LevelScale& scales, msorb_keypoint* kps, uint8_t* desc, int out_stride,

@@ -27,7 +27,7 @@ EXPORTS = (
     "msorb_last_error", "msorb_device_count", "msorb_extractor_create", "msorb_extractor_destroy",
     "msorb_extractor_tables", "msorb_extractor_capacity", "msorb_extract", "msorb_pyramid_level",
     "msorb_extract_batch", "msorb_extractor_set_profiling", "msorb_extractor_set_overlap", "msorb_extractor_stage_ms", "msorb_debug_level_size",
-    "msorb_debug_copy_level", "msorb_debug_candidates", "msorb_debug_fast_form", "msorb_distribute_quadtree", "msorb_extract_stereo",
+    "msorb_debug_copy_level", "msorb_debug_candidates", "msorb_debug_fast_form", "msorb_debug_blur_form", "msorb_distribute_quadtree", "msorb_extract_stereo",
     "msorb_extract_stereo_split", "msorb_pyramid_batch", "msorb_stereo_matches_split", "msorb_extractor_set_host_pyramid",
     "msorb_extractor_set_semantics",
 )
@@ -75,6 +75,7 @@ def lib():
         L.msorb_debug_copy_level.argtypes = [vp, ci, ci, ci, vp]
         L.msorb_debug_candidates.argtypes = [vp, ci, ci, vp, ci, C.POINTER(ci)]
         L.msorb_debug_fast_form.argtypes = [vp]
+        L.msorb_debug_blur_form.argtypes = [vp]
         L.msorb_distribute_quadtree.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, ci, C.POINTER(ci)]
         _LIB = L
     return _LIB
@@ -295,6 +296,10 @@ class ORBextractor:
     def debug_fast_form(self):
         """0: the last call's FAST stage ran one workgroup per cell, 1: one per strip of cells."""
         return int(self.L.msorb_debug_fast_form(self.h))
+
+    def debug_blur_form(self):
+        """0: the last call's Gaussian ran on the VALU kernels, 1: on the matrix cores."""
+        return int(self.L.msorb_debug_blur_form(self.h))
 
     def debug_candidates(self, image, level):
         cap = 1 << 18

@@ -398,6 +398,46 @@ def test_fast_strip_and_cell_forms_agree_with_the_oracle(msorb_mod, oracle, monk
         ex.close()
 
 
+@pytest.mark.parametrize("name", ["kitti", "euroc", "fourseasons", "odd", "small"])
+def test_blur_on_the_matrix_cores_matches_the_oracle(msorb_mod, oracle, monkeypatch, name):
+    """gauss7_mfma_kernel (banded matrix products: i8 MFMA for the rows, fp32 MFMA for the columns) against the oracle's
+    GaussianBlur restatement, every level of a batch on 64-byte padded rows: scenes, noise, black / white / saturated images
+    (the -128 bias and the 2^24 exactness bound), widths and heights that are not multiples of 32 (partial strips / blocks, both
+    reflected borders inside one tile), default and alternative taps (sum 257: saturation); and the VALU form on the same batch."""
+    import torch
+    cfg = CONFIGS[name] if name != "odd" else dict(rows=333, cols=517, nfeatures=700, scale=1.2, nlevels=8, ini_th=20, min_th=7)
+    rows, cols = cfg["rows"], cfg["cols"]
+    rng = np.random.Generator(np.random.PCG64(5))
+    imgs = [synth.image(411, rows, cols), rng.integers(0, 256, (rows, cols), dtype=np.uint8), np.zeros((rows, cols), np.uint8),
+            np.full((rows, cols), 255, np.uint8), (rng.integers(0, 2, (rows, cols), dtype=np.uint8) * 255)]
+    pitch = (cols + 63) // 64 * 64
+    store = torch.zeros((16, rows, pitch), dtype=torch.uint8, device="cuda")
+    d = store[:, :, :cols]
+    d.copy_(torch.from_numpy(np.stack([imgs[i % len(imgs)] for i in range(16)])).cuda())
+    ex, ref = _pair(msorb_mod, oracle, cfg)
+    try:
+        ex.set_overlap(1, False)
+        for taps in (None, [18, 34, 49, 55, 49, 34, 18], [16, 32, 48, 64, 48, 32, 16]):
+            ex.set_semantics(taps)
+            oracle.set_semantics(taps)
+            want = []
+            for im in imgs:
+                ref(im)   # (an image without keypoints never reaches the oracle's blur: blur its levels directly)
+                want.append([oracle.gaussian7(ref.level(l)) for l in range(cfg["nlevels"])])
+            for form in ("1", "0"):
+                monkeypatch.setenv("MSORB_BLUR_MFMA", form)
+                ex.extract_batch(d)
+                # (taps summing to 257 need a 17-bit row sum: the matrix-core form leaves them to the VALU kernels)
+                assert ex.debug_blur_form() == (int(form) if taps is None or sum(taps) <= 256 else 0)
+                for i in (0, 1, 2, 3, 4, 15):
+                    for l in range(cfg["nlevels"]):
+                        got = ex.debug_level(i, l, blurred=True)
+                        assert np.array_equal(got, want[i % len(imgs)][l]), (name, taps, form, i, l, np.argwhere(got != want[i % len(imgs)][l])[:4])
+    finally:
+        oracle.set_semantics()
+        ex.close()
+
+
 def test_full_bench_size_properties(msorb_mod, oracle):
     """BASELINE.json configs[1] at bench.py's batch size (128 stereo pairs = 256 images, default 2 sub-batches): too
     big for the oracle image by image, so size-independent properties carry the check — copies of an image must give
