@@ -15,14 +15,6 @@
 namespace msorb {
 void set_last_error(const std::string& s);
 
-// first[p] = first slot (in window order) that references point p
-__global__ void vis_first_kernel(const int* __restrict__ slot_point, int n_slots, int* __restrict__ first) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_slots) return;
-    const int p = slot_point[s];
-    if (p >= 0) atomicMin(&first[p], s);
-}
-
 // exclusive scan of one int per thread over a workgroup of up to 1024 threads (wave scans + the wave totals in LDS)
 __device__ __forceinline__ int block_exclusive_scan(int v, int* wave_tot /* [16] shared */, int* total) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -55,50 +47,60 @@ __global__ __launch_bounds__(256) void vis_flag_count_kernel(const int* __restri
     (void)block_exclusive_scan(f, wt, &tot);
     if (threadIdx.x == 0) block_count[blockIdx.x] = tot;
 }
-__global__ __launch_bounds__(1024) void vis_block_scan_kernel(int* __restrict__ block_count, int n_blocks, int* __restrict__ n_cols) {
-    __shared__ int wt[16];
-    __shared__ int carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < n_blocks; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < n_blocks ? block_count[i] : 0;
-        int tot;
-        const int ex = block_exclusive_scan(v, wt, &tot);
-        const int carry = carry_s;
-        if (i < n_blocks) block_count[i] = carry + ex;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = carry + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *n_cols = carry_s;
-}
 // column of every point; column tables; running max of observations
 __global__ __launch_bounds__(256) void vis_columns_kernel(const int* __restrict__ slot_point, const int* __restrict__ first,
                                                           const int* __restrict__ block_base, int n_slots,
                                                           const int* __restrict__ point_nobs, int* __restrict__ col_of_point,
-                                                          int* __restrict__ col_point, int* __restrict__ n_max_obs) {
+                                                          int* __restrict__ col_point, int* __restrict__ n_max_obs, int* __restrict__ n_cols) {
     __shared__ int wt[16];
-    __shared__ int smax;
-    if (threadIdx.x == 0) smax = 0;
+    __shared__ int smax, sbase;
+    if (threadIdx.x == 0) { smax = 0; sbase = 0; }
+    __syncthreads();
+    // columns opened by the blocks in front of this one: block_base holds the per-block COUNTS (vis_flag_count_kernel); a few
+    // hundred values, summed here instead of scanned by a launch of their own
+    {
+        int part = 0;
+        for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) part += block_base[i];
+        if (part) atomicAdd(&sbase, part);
+    }
     const int s = blockIdx.x * 256 + threadIdx.x;
     const int p = s < n_slots ? slot_point[s] : -1;
     const int f = (p >= 0 && first[p] == s);
-    const int rank = block_base[blockIdx.x] + block_exclusive_scan(f, wt, nullptr);   // (the scan synchronises: smax is set)
+    int tot;
+    const int ex = block_exclusive_scan(f, wt, &tot);   // (the scan synchronises: smax and sbase are final)
+    const int rank = sbase + ex;
     if (p >= 0) atomicMax(&smax, point_nobs[p]);
     if (f) { col_of_point[p] = rank; col_point[rank] = p; }
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) *n_cols = sbase + tot;
     __syncthreads();
     if (threadIdx.x == 0 && smax > 0) atomicMax(n_max_obs, smax);
 }
 
-// One block per window keyframe: counts of valid slots and valid cells.
 constexpr int kKfThreads = 1024;   // one workgroup per window keyframe: its ~2000 slots are two per thread (latency, not work, is the cost)
-__global__ __launch_bounds__(kKfThreads) void vis_kf_count_kernel(const int* __restrict__ kf_slot_begin,
-                                                           const int* __restrict__ slot_point,
-                                                           const int* __restrict__ slot_cell, int* __restrict__ kf_valid,
-                                                           int* __restrict__ kf_cells) {
+// Launch fusions (round 3, second half: 15 launches — 12 kernels and 3 memsets — were 90 us of a 196 us call; every dependent
+// launch costs 5-6 us here whatever it does).  The three memsets are one kernel; steps without a dependency between them share a
+// launch (block ranges); the one-block scans over a few hundred values are redone by every block that needs them.
+__global__ __launch_bounds__(256) void vis_init_kernel(int* __restrict__ first, int n_points, int* __restrict__ kf_count, int n_kf,
+                                                       unsigned* __restrict__ bitmap, size_t bitmap_words) {
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    for (size_t i = i0; i < (size_t)n_points; i += stride) first[i] = 0x7f7f7f7f;
+    for (size_t i = i0; i < (size_t)n_kf; i += stride) kf_count[i] = 0;
+    for (size_t i = i0; i < bitmap_words; i += stride) bitmap[i] = 0u;
+}
+// blocks [0, nb_first): vis_first over 1024 slots each; blocks [nb_first, nb_first + n_window_kf): vis_kf_count
+__global__ __launch_bounds__(kKfThreads) void vis_first_kfcount_kernel(int nb_first, const int* __restrict__ slot_point, int n_slots,
+                                                                       int* __restrict__ first, const int* __restrict__ kf_slot_begin,
+                                                                       const int* __restrict__ slot_cell, int* __restrict__ kf_valid,
+                                                                       int* __restrict__ kf_cells) {
     __shared__ int sv, sc;
-    const int k = blockIdx.x;
+    if ((int)blockIdx.x < nb_first) {
+        const int s = blockIdx.x * kKfThreads + threadIdx.x;
+        if (s >= n_slots) return;
+        const int p = slot_point[s];
+        if (p >= 0) atomicMin(&first[p], s);
+        return;
+    }
+    const int k = blockIdx.x - nb_first;
     if (threadIdx.x == 0) { sv = 0; sc = 0; }
     __syncthreads();
     const int b = kf_slot_begin[k], e = kf_slot_begin[k + 1];
@@ -106,7 +108,6 @@ __global__ __launch_bounds__(kKfThreads) void vis_kf_count_kernel(const int* __r
     for (int s = b + threadIdx.x; s < e; s += kKfThreads) {
         if (slot_point[s] < 0) continue;
         v++;
-        // first valid slot of its cell <=> no earlier valid slot with the same cell (cells are contiguous runs)
         bool first_valid = true;
         for (int t = s - 1; t >= b && slot_cell[t] == slot_cell[s]; t--)
             if (slot_point[t] >= 0) { first_valid = false; break; }
@@ -118,33 +119,15 @@ __global__ __launch_bounds__(kKfThreads) void vis_kf_count_kernel(const int* __r
     if (threadIdx.x == 0) { kf_valid[k] = sv; kf_cells[k] = sc; }
 }
 
-// rows / non-zeros in front of every window keyframe (one thread: a window is <= a few dozen keyframes); totals in scal[4], scal[5]
-__global__ void vis_kf_base_kernel(int n_kf, const int* __restrict__ kf_valid, const int* __restrict__ kf_cells,
-                                   int* __restrict__ row_base, int* __restrict__ nnz_base, int* __restrict__ scal) {
-    if (blockIdx.x || threadIdx.x) return;
-    int rows = 0, nnz = 0;
-    for (int k = 0; k < n_kf; k++) {
-        row_base[k] = rows; nnz_base[k] = nnz;
-        rows += kf_cells[k] + 1;
-        nnz += 2 * kf_valid[k];
-    }
-    scal[4] = rows; scal[5] = nnz;
-}
-
 // One block per window keyframe: emit its cell rows then its keyframe row.  Serial-in-order within the
 // block's thread 0 would be O(slots); instead each thread ranks its slots with block-wide prefix sums.
-__global__ __launch_bounds__(kKfThreads) void vis_kf_rows_kernel(const int* __restrict__ kf_slot_begin,
-                                                          const int* __restrict__ slot_point,
-                                                          const int* __restrict__ slot_cell,
-                                                          const int* __restrict__ col_of_point,
-                                                          const int* __restrict__ kf_row_base /* rows before kf */,
-                                                          const int* __restrict__ kf_nnz_base /* nnz before kf */,
-                                                          const int* __restrict__ kf_valid, int N,
-                                                          int* __restrict__ row_begin, int* __restrict__ row_kind,
-                                                          int* __restrict__ row_owner, float* __restrict__ row_rhs,
-                                                          int* __restrict__ col_idx) {
-    __shared__ int wt[16];
-    const int k = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void vis_kf_rows_body(int k, int row0, int nnz0, int* wt /* shared [16] */,
+                                                 const int* __restrict__ kf_slot_begin, const int* __restrict__ slot_point,
+                                                 const int* __restrict__ slot_cell, const int* __restrict__ col_of_point,
+                                                 const int* __restrict__ kf_valid, int N, int* __restrict__ row_begin,
+                                                 int* __restrict__ row_kind, int* __restrict__ row_owner, float* __restrict__ row_rhs,
+                                                 int* __restrict__ col_idx) {
+    const int tid = threadIdx.x;
     const int b = kf_slot_begin[k], e = kf_slot_begin[k + 1];
     const int n = e - b;
     const int per = (n + kKfThreads - 1) / kKfThreads;
@@ -164,7 +147,6 @@ __global__ __launch_bounds__(kKfThreads) void vis_kf_rows_kernel(const int* __re
     int part_v_tid = ev, part_c_tid = ec;
     int rv = part_v_tid, rc = part_c_tid;  // valid slots / valid cells before this thread's chunk
     const int V = kf_valid[k];
-    const int nnz0 = kf_nnz_base[k], row0 = kf_row_base[k];
     for (int s = tb; s < te; s++) {
         const int p = slot_point[s];
         if (p < 0) continue;
@@ -193,17 +175,16 @@ __global__ __launch_bounds__(kKfThreads) void vis_kf_rows_kernel(const int* __re
 // (the column count lives on the device: scal[0]; the grid covers its host-side upper bound).  A few hundred keyframe counters
 // take tens of thousands of increments: they are accumulated per workgroup in LDS (kLdsHist counters) and flushed once.
 constexpr int kLdsHist = 8192;
-__global__ __launch_bounds__(256) void vis_extra_count_kernel(const int* __restrict__ col_point, const int* __restrict__ scal,
-                                                              const int* __restrict__ obs_begin, const int* __restrict__ obs_kf,
-                                                              const uint8_t* __restrict__ kf_in_window, int n_kf,
-                                                              int* __restrict__ kf_count) {
-    extern __shared__ int hist[];
+__device__ __forceinline__ void vis_extra_count_body(int cblock, int* hist /* dynamic LDS, n_kf ints if n_kf <= kLdsHist */,
+                                                     const int* __restrict__ col_point, const int* __restrict__ scal,
+                                                     const int* __restrict__ obs_begin, const int* __restrict__ obs_kf,
+                                                     const uint8_t* __restrict__ kf_in_window, int n_kf, int* __restrict__ kf_count) {
     const bool lds = n_kf <= kLdsHist;
     if (lds) {
-        for (int i = threadIdx.x; i < n_kf; i += 256) hist[i] = 0;
+        for (int i = threadIdx.x; i < n_kf; i += blockDim.x) hist[i] = 0;
         __syncthreads();
     }
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = cblock * (int)blockDim.x + threadIdx.x;
     if (c < scal[0]) {
         const int p = col_point[c];
         for (int o = obs_begin[p]; o < obs_begin[p + 1]; o++) {
@@ -213,9 +194,36 @@ __global__ __launch_bounds__(256) void vis_extra_count_kernel(const int* __restr
     }
     if (lds) {
         __syncthreads();
-        for (int i = threadIdx.x; i < n_kf; i += 256)
+        for (int i = threadIdx.x; i < n_kf; i += blockDim.x)
             if (hist[i]) atomicAdd(&kf_count[i], hist[i]);
     }
+}
+// blocks [0, n_window_kf): the rows of a window keyframe (rows / non-zeros in front of it summed from the counts of the keyframes
+// before it: a window holds a few dozen; the last of them publishes the totals in scal[4], scal[5]);
+// blocks [n_window_kf, ...): vis_extra_count over 1024 columns each.  Both only depend on the column step.
+__global__ __launch_bounds__(kKfThreads) void vis_kf_rows_extra_count_kernel(
+    int n_window_kf, const int* __restrict__ kf_slot_begin, const int* __restrict__ slot_point, const int* __restrict__ slot_cell,
+    const int* __restrict__ col_of_point, const int* __restrict__ kf_valid, const int* __restrict__ kf_cells, int N,
+    int* __restrict__ row_begin, int* __restrict__ row_kind, int* __restrict__ row_owner, float* __restrict__ row_rhs,
+    int* __restrict__ col_idx, int* __restrict__ scal, const int* __restrict__ col_point, const int* __restrict__ obs_begin,
+    const int* __restrict__ obs_kf, const uint8_t* __restrict__ kf_in_window, int n_kf, int* __restrict__ kf_count) {
+    extern __shared__ int hist[];
+    __shared__ int wt[16];
+    __shared__ int s_row0, s_nnz0;
+    if ((int)blockIdx.x >= n_window_kf) {
+        vis_extra_count_body((int)blockIdx.x - n_window_kf, hist, col_point, scal, obs_begin, obs_kf, kf_in_window, n_kf, kf_count);
+        return;
+    }
+    const int k = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int rows = 0, nnz = 0;
+        for (int i = 0; i < k; i++) { rows += kf_cells[i] + 1; nnz += 2 * kf_valid[i]; }
+        s_row0 = rows; s_nnz0 = nnz;
+        if (k == n_window_kf - 1) { scal[4] = rows + kf_cells[k] + 1; scal[5] = nnz + 2 * kf_valid[k]; }
+    }
+    __syncthreads();
+    vis_kf_rows_body(k, s_row0, s_nnz0, wt, kf_slot_begin, slot_point, slot_cell, col_of_point, kf_valid, N, row_begin, row_kind, row_owner,
+                     row_rhs, col_idx);
 }
 __global__ __launch_bounds__(1024) void vis_extra_scan_kernel(const int* __restrict__ kf_count, int n_kf,
                                                               int* __restrict__ kf_row /* rank among count>0 */,
@@ -421,7 +429,7 @@ extern "C" int msorb_visibility_csr(int device, int n_window_kf, const int* kf_s
                  o_inwin = take(((size_t)n_kf_total + 3) / 4), o_scal = take(8), n_in = off;
     // ... work arrays ...
     const size_t o_first = take(n_points), o_rank = take(S), o_colofp = take(n_points), o_kfvalid = take(n_window_kf + 1),
-                 o_kfcells = take(n_window_kf + 1), o_rowbase = take(n_window_kf + 1), o_nnzbase = take(n_window_kf + 1),
+                 o_kfcells = take(n_window_kf + 1),
                  o_kfcount = take(n_kf_total), o_kfrow = take(n_kf_total), o_kfoff = take(n_kf_total);
     // ... outputs
     const size_t o_rowbegin = take((size_t)rows_max + 1), o_rowkind = take(rows_max), o_rowowner = take(rows_max), o_rhs = take(rows_max),
@@ -457,32 +465,38 @@ extern "C" int msorb_visibility_csr(int device, int n_window_kf, const int* kf_s
         const uint8_t* d_inwin = reinterpret_cast<const uint8_t*>(d + o_inwin);
         float* d_rhs = reinterpret_cast<float*>(d + o_rhs);
         unsigned* d_bitmap = static_cast<unsigned*>(scr.p[1]);
-        if (n_points) VCHK(hipMemsetAsync(d + o_first, 0x7f, (size_t)n_points * sizeof(int), st));
-        if (n_kf_total) VCHK(hipMemsetAsync(d + o_kfcount, 0, (size_t)n_kf_total * sizeof(int), st));
+        // 9 launches (round 2: 12 kernels + 3 memsets): init | first + window-keyframe counts | first-flags per block | columns |
+        // window-keyframe rows + outside-keyframe counts | their scan | their bitmaps | their rows | pack
+        const size_t bitmap_words = (cols_max && n_outside) ? bitmap_bytes / sizeof(unsigned) : 0;
+        {
+            const size_t n_init = std::max<size_t>(std::max<size_t>(n_points, n_kf_total), bitmap_words);
+            if (n_init)
+                hipLaunchKernelGGL(vis_init_kernel, dim3((unsigned)std::min<size_t>((n_init + 255) / 256, 2048)), dim3(256), 0, st, d + o_first,
+                                   n_points, d + o_kfcount, n_kf_total, d_bitmap, bitmap_words);
+        }
+        const int nb_first = S ? (S + kKfThreads - 1) / kKfThreads : 0;
+        if (nb_first + n_window_kf > 0)
+            hipLaunchKernelGGL(vis_first_kfcount_kernel, dim3(nb_first + n_window_kf), dim3(kKfThreads), 0, st, nb_first, d + o_slot_point, S,
+                               d + o_first, d + o_slot_begin, d + o_slot_cell, d + o_kfvalid, d + o_kfcells);
         if (S) {
             const int nb = (S + 255) / 256;
-            hipLaunchKernelGGL(vis_first_kernel, dim3(nb), dim3(256), 0, st, d + o_slot_point, S, d + o_first);
             hipLaunchKernelGGL(vis_flag_count_kernel, dim3(nb), dim3(256), 0, st, d + o_slot_point, d + o_first, S, d + o_rank);
-            hipLaunchKernelGGL(vis_block_scan_kernel, dim3(1), dim3(1024), 0, st, d + o_rank, nb, d + o_scal);
             hipLaunchKernelGGL(vis_columns_kernel, dim3(nb), dim3(256), 0, st, d + o_slot_point, d + o_first, d + o_rank, S,
-                               d + o_nobs, d + o_colofp, d + o_colpoint, d + o_scal + 1);
+                               d + o_nobs, d + o_colofp, d + o_colpoint, d + o_scal + 1, d + o_scal);
         }
-        if (n_window_kf) {
-            hipLaunchKernelGGL(vis_kf_count_kernel, dim3(n_window_kf), dim3(kKfThreads), 0, st, d + o_slot_begin, d + o_slot_point,
-                               d + o_slot_cell, d + o_kfvalid, d + o_kfcells);
-            hipLaunchKernelGGL(vis_kf_base_kernel, dim3(1), dim3(64), 0, st, n_window_kf, d + o_kfvalid, d + o_kfcells, d + o_rowbase,
-                               d + o_nnzbase, d + o_scal);
-            hipLaunchKernelGGL(vis_kf_rows_kernel, dim3(n_window_kf), dim3(kKfThreads), 0, st, d + o_slot_begin, d + o_slot_point,
-                               d + o_slot_cell, d + o_colofp, d + o_rowbase, d + o_nnzbase, d + o_kfvalid, N, d + o_rowbegin,
-                               d + o_rowkind, d + o_rowowner, d_rhs, d + o_colidx);
+        const bool extra = cols_max && n_outside;
+        {
+            const int nb_cols = extra ? (cols_max + kKfThreads - 1) / kKfThreads : 0;
+            if (n_window_kf + nb_cols > 0)
+                hipLaunchKernelGGL(vis_kf_rows_extra_count_kernel, dim3(n_window_kf + nb_cols), dim3(kKfThreads),
+                                   n_kf_total <= kLdsHist ? (size_t)n_kf_total * sizeof(int) : 0, st, n_window_kf, d + o_slot_begin,
+                                   d + o_slot_point, d + o_slot_cell, d + o_colofp, d + o_kfvalid, d + o_kfcells, N, d + o_rowbegin,
+                                   d + o_rowkind, d + o_rowowner, d_rhs, d + o_colidx, d + o_scal, d + o_colpoint, d + o_obs_begin,
+                                   d + o_obs_kf, d_inwin, n_kf_total, d + o_kfcount);
         }
-        if (cols_max && n_outside) {
-            hipLaunchKernelGGL(vis_extra_count_kernel, dim3((cols_max + 255) / 256), dim3(256),
-                               n_kf_total <= kLdsHist ? (size_t)n_kf_total * sizeof(int) : 0, st, d + o_colpoint, d + o_scal,
-                               d + o_obs_begin, d + o_obs_kf, d_inwin, n_kf_total, d + o_kfcount);
+        if (extra) {
             hipLaunchKernelGGL(vis_extra_scan_kernel, dim3(1), dim3(1024), 0, st, d + o_kfcount, n_kf_total, d + o_kfrow,
                                d + o_kfoff, d + o_scal + 2);
-            VCHK(hipMemsetAsync(d_bitmap, 0, bitmap_bytes, st));
             hipLaunchKernelGGL(vis_extra_bits_kernel, dim3((cols_max + 255) / 256), dim3(256), 0, st, d + o_colpoint, d + o_scal,
                                d + o_obs_begin, d + o_obs_kf, d_inwin, d + o_kfrow, words, d_bitmap);
             hipLaunchKernelGGL(vis_extra_emit_kernel, dim3(n_kf_total), dim3(256), 0, st, n_kf_total, d + o_kfcount,
