@@ -6,6 +6,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -355,6 +358,10 @@ extern "C" int msorb_visibility_csr(int device, int n_window_kf, const int* kf_s
         set_last_error("no usable HIP device (libmsorb has no CPU fallback)");
         return MSORB_E_NO_DEVICE;
     }
+    static const bool vis_timing = getenv("MSORB_VIS_TIMING") != nullptr;   // wall-clock breakdown on stderr (diagnostics)
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    std::chrono::steady_clock::time_point t1, t2, t3, t4;
+    const auto t0 = now();
     const int S = kf_slot_begin[n_window_kf];
     const int n_obs = n_points ? obs_begin[n_points] : 0;
     int n_valid = 0;   // slots that hold a point: every size below is bounded by it
@@ -365,6 +372,7 @@ extern "C" int msorb_visibility_csr(int device, int n_window_kf, const int* kf_s
         if (bad_slot) { set_last_error("slot_point out of range"); return MSORB_E_INVALID; }
         if (bad_obs) { set_last_error("obs_kf out of range"); return MSORB_E_INVALID; }
     }
+    t1 = now();
     int rc = MSORB_OK;
     if (hipSetDevice(device) != hipSuccess) return MSORB_E_HIP;
     // Scratch kept per calling thread (grow-only), a private non-blocking stream, pinned staging.  Shape of a call: the
@@ -461,6 +469,7 @@ extern "C" int msorb_visibility_csr(int device, int n_window_kf, const int* kf_s
         h[o_scal + 1] = n_max_obs_floor;
         VCHK(hipMemcpyAsync(d, h, n_in * sizeof(int), hipMemcpyHostToDevice, st));
     }
+    t2 = now();
     {
         const uint8_t* d_inwin = reinterpret_cast<const uint8_t*>(d + o_inwin);
         float* d_rhs = reinterpret_cast<float*>(d + o_rhs);
@@ -508,7 +517,9 @@ extern "C" int msorb_visibility_csr(int device, int n_window_kf, const int* kf_s
                            d + o_rowbegin, d + o_rowkind, d + o_rowowner, reinterpret_cast<const int*>(d_rhs), d + o_colpoint,
                            d + o_colidx, d + o_pack);
         VCHK(hipMemcpyAsync(h, d + o_pack, pack_max * sizeof(int), hipMemcpyDeviceToHost, st));
+        t3 = now();
         VCHK(hipStreamSynchronize(st));   // the call's only synchronisation
+        t4 = now();
         VCHK(hipGetLastError());
         for (int i = 0; i < 8; i++) scal[i] = h[i];
         const int ncols = scal[0], nmax = scal[1], R = scal[4] + scal[2], NNZ = scal[5] + scal[3];
@@ -528,6 +539,11 @@ extern "C" int msorb_visibility_csr(int device, int n_window_kf, const int* kf_s
         if (ncols) {
             std::memcpy(col_point, h_cp, (size_t)ncols * sizeof(int));
             for (int c = 0; c < ncols; c++) obj_coef[c] = (float)(nmax - point_nobs[col_point[c]]);  // MapSparsification.cc:95-96
+        }
+        if (vis_timing) {
+            auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+            fprintf(stderr, "vis timing us: checks %.1f  scratch+staging+upload-enqueue %.1f  launches-enqueue %.1f  wait %.1f  copy-out %.1f\n", us(t0, t1),
+                    us(t1, t2), us(t2, t3), us(t3, t4), us(t4, now()));
         }
     }
 done:
