@@ -15,7 +15,10 @@ constexpr int kQtThreads = 256;  // 256 beats 512 (0.39 vs 0.47 ms per 256 image
 // measured slower); 8 for single frames, where a 1024-thread instance then holds a whole level (<= 8192 candidates) in
 // registers and the point passes stop waiting on global memory
 constexpr int kQtPointsPerThreadFrame = 8;
-constexpr int kQtPointsPerThreadBatch = 28;   // x 256 threads = 7168 candidates of a level in registers
+#ifndef QT_BATCH_PC
+#define QT_BATCH_PC 24
+#endif
+constexpr int kQtPointsPerThreadBatch = QT_BATCH_PC;   // x 256 threads = 6144 candidates of a level in registers, the rest through global memory (select stage per 256 images: 12-20: 0.142-0.143, 24: 0.139-0.140, 28: 0.145, 32: 0.167 ms — spills)
 
 // inclusive prefix sum over the wave with DPP adds only (no LDS crossbar round trips)
 __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
