@@ -49,6 +49,16 @@ struct SortItem {  // one element of vSizeAndPointerToNode: key = count << 16 | 
     uint32_t key, node;
 };
 
+struct Int4 { int x, y, z, w; };
+QT_HD Int4 load_int4(QT_LDS const int* p) {   // p is 16-byte aligned
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    const v4i_t v = *reinterpret_cast<QT_LDS const v4i_t*>(p);
+    return Int4{v.x, v.y, v.z, v.w};
+#else
+    return Int4{p[0], p[1], p[2], p[3]};
+#endif
+}
 constexpr int kLabelSettled = 0xFFFF;
 constexpr int kParityBit = 0x4000;
 constexpr int kSlotMask = 0x3FFF;
@@ -395,7 +405,7 @@ struct Workspace {       // LDS on the device; `cap` = 4 * max(N, nIni) child sl
 enum { kScSize = 0, kScS0, kScS1, kScNres, kScNToExpand, kScNsplit, kScFinish, kScCareful, kScGenBase, kScCount };
 
 // ranges longer than 16 elements that can be open at once in the level-synchronous introsort rounds of m + 4 items
-QT_HD int stack_ranges(int m) { const int r = (m + 4) / 17 + 2; return r > 32 ? r : 32; }
+QT_HD int stack_ranges(int m) { const int r = ((m + 4) / 17 + 3) & ~1; return r > 32 ? r : 32; }   // (even: what follows stays 16-byte aligned)
 
 QT_HD size_t workspace_bytes(int N, int n_ini) {
     const int m = N > n_ini ? N : n_ini;
@@ -800,10 +810,16 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
     }
     // result order = descending creation sequence: rank sort (all seq are distinct)
     const int nres = sc[kScNres];
+    // (read four at a time: the list is padded to a multiple of four with a value below every sequence number)
+    for (int i = nres + tid; i < ((nres + 3) & ~3); i += nt) w.res_seq[i] = -0x7FFFFFFF - 1;
+    ex.sync();
     for (int i = tid; i < nres; i += nt) {
         const int s = w.res_seq[i];
         int rank = 0;
-        for (int j = 0; j < nres; j++) rank += w.res_seq[j] > s;
+        for (int j = 0; j < nres; j += 4) {
+            const Int4 v = load_int4(w.res_seq + j);
+            rank += (v.x > s) + (v.y > s) + (v.z > s) + (v.w > s);
+        }
         out_pt[rank] = w.res_pt[i];
     }
     ex.sync();
