@@ -716,7 +716,7 @@ def main():
     for e in all_ex:
         e.set_profiling(True)
     saved_mode = dict(mode)
-    stage_acc = {k: 0.0 for k in msorb.STAGES}
+    stage_acc = {k: [] for k in msorb.STAGES}
     mode["pipelined"] = False   # the stage timings use the synchronous call on one handle
     mode["sync_nccl"] = True
     for e in all_ex:
@@ -726,7 +726,7 @@ def main():
     for _ in range(iso_steps):
         step()
         for k, v in last_ex[0].stage_ms().items():
-            stage_acc[k] += v
+            stage_acc[k].append(v)
     if not args.isolated:
         for e in all_ex:
             e.set_overlap(1 if pipelined else 2, True)
@@ -794,7 +794,8 @@ def main():
 
     if rank == 0:
         steps = max(args.steps, 1)
-        stages = {k: v / iso_steps for k, v in stage_acc.items()}
+        # median over the recorded steps (a mean is at the mercy of a few slow steps: clock ramps, a neighbour on the host)
+        stages = {k: float(np.median(v)) if v else 0.0 for k, v in stage_acc.items()}
         stages_overlapped = {k: v / steps for k, v in overlapped_acc.items()}
         px = level_bytes(cfg)
         # dominant GPU kernel: FAST cells (one launch per step).  Algorithmic bytes per launch:
@@ -851,7 +852,7 @@ def main():
                                        "before step k is waited for" if pipelined else "1 GPU, both eyes") if world == 1 else f"stereo L/R split over {world} GPUs: one eye per rank; partners swap the keypoints / "
                                                                              "descriptors of half of their images (RCCL send/recv over xGMI) and each joins half of the pairs (stereo association)"},
             "stage_ms_per_step": {k: round(v, 4) for k, v in stages.items()},
-            "stage_ms_per_step_note": "each stage's kernels alone on the GPU (5 extra steps, overlap off, HIP events on the "
+            "stage_ms_per_step_note": "each stage's kernels alone on the GPU (20 extra steps after 20 discarded ones, median, overlap off, HIP events on the "
                                       "launching stream); 'select' = device quadtree + output layout",
             "stage_ms_per_step_overlapped": None if (pipelined or (world > 1 and not args.isolated and not os.environ.get("MSORB_BENCH_SYNC"))) else {k: round(v, 4) for k, v in stages_overlapped.items()},
             "stage_ms_per_step_overlapped_note": "timed region: sum over the 2 concurrent sub-batches of each stage's event "
