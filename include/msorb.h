@@ -57,7 +57,9 @@ void msorb_extractor_destroy(msorb_extractor* h);
 int msorb_extractor_tables(const msorb_extractor* h, float* scale, float* inv_scale, float* sigma2,
                            float* inv_sigma2, int* features_per_level);
 
-/* Upper bound on keypoints one image can return: nfeatures + 3*nlevels. */
+/* Upper bound on keypoints one image can return: nfeatures + 19*nlevels — a level overshoots its quota by at most 3 (SURVEY.md §8a
+ * a5), or returns the 4 * nIni children of the quadtree's unconditional first pass when its quota is smaller than that (nIni =
+ * round(width / height) <= 4). */
 int msorb_extractor_capacity(const msorb_extractor* h);
 
 /* ORBextractor::operator()(image, mask, keypoints, descriptors, vLappingArea) (ORBextractor.cc:1086-1168)

@@ -236,7 +236,11 @@ struct msorb_extractor {
 
 namespace {
 
-int capacity_of(const msorb_extractor* h) { return h->P.nfeatures + 3 * h->P.nlevels; }
+// Upper bound of the keypoints one image returns.  DistributeOctTree overshoots a level's quota by at most 3 (the split that
+// reaches it), but its FIRST pass divides every initial column unconditionally (ORBextractor.cc:610-681 runs before any quota
+// check): a level returns up to max(quota + 3, 4 * nIni) keypoints, nIni = round(width / height) <= 4 for every camera the
+// reference is configured for.  16 more rows per level cover that whatever the quota (tiny nfeatures on wide images).
+int capacity_of(const msorb_extractor* h) { return h->P.nfeatures + (3 + 16) * h->P.nlevels; }
 
 // FAST as strips of cells (fast_strip_kernel) or per cell (fast_cells_kernel, the default).  MSORB_FAST_STRIP=1 selects the strip
 // form where the geometry allows (read per call: the tests run both forms in one process).  Measured on 256 KITTI images: 10 %

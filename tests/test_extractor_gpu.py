@@ -438,6 +438,33 @@ def test_blur_on_the_matrix_cores_matches_the_oracle(msorb_mod, oracle, monkeypa
         ex.close()
 
 
+@pytest.mark.parametrize("nfeat,nlev", [(40, 8), (12, 3), (100, 8)])
+def test_tiny_feature_counts_exceed_their_quota_like_the_reference(msorb_mod, oracle, nfeat, nlev):
+    """DistributeOctTree's first pass divides every initial column before any quota check (ORBextractor.cc:610-681): with a
+    quota below 4 * nIni a level returns more keypoints than its quota + 3 — KITTI (nIni = 4 at the wide levels) with 40 features
+    returns more than nfeatures + 3 * nlevels.  The capacity covers it (nfeatures + 19 * nlevels); per frame and batched."""
+    import torch
+    cfg = synth.KITTI
+    imgs = [synth.image(520 + i, cfg["rows"], cfg["cols"]) for i in range(2)]
+    ex = msorb_mod.ORBextractor(nfeat, 1.2, nlev, 20, 7)
+    ref = oracle.OracleExtractor(nfeat, 1.2, nlev, 20, 7)
+    try:
+        assert ex.capacity == nfeat + 19 * nlev
+        want = [ref(im) for im in imgs]
+        for im, (rmono, rkps, rdesc) in zip(imgs, want):
+            mono, kps, desc = ex(im)
+            assert mono == rmono and len(rkps) > nfeat
+            _assert_same(kps, desc, rkps, rdesc)
+        d = torch.from_numpy(np.stack(imgs * 8)).cuda()
+        counts, monos, d_kps, d_desc = ex.extract_batch(d)
+        got = msorb_mod.keypoints_from_device(d_kps, counts)
+        for i in (0, 1, 15):
+            rmono, rkps, rdesc = want[i % 2]
+            _assert_same(got[i], d_desc[i, :counts[i]].cpu().numpy(), rkps, rdesc)
+    finally:
+        ex.close()
+
+
 def test_full_bench_size_properties(msorb_mod, oracle):
     """BASELINE.json configs[1] at bench.py's batch size (128 stereo pairs = 256 images, default 2 sub-batches): too
     big for the oracle image by image, so size-independent properties carry the check — copies of an image must give
