@@ -682,9 +682,10 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
             const int sb = tid * kk, se = sb + kk < 4 * nsplit_ ? sb + kk : 4 * nsplit_;
             int nz = 0, nx = 0;
             for (int i = sb; i < se; i++) { nz += cnt_np[i] > 0; nx += cnt_np[i] > 1; }
-            int NZ = 0, NX = 0;
-            ex.excl_scan(nz, w.scan_tmp, &NZ);
-            int before = ex.excl_scan(nx, w.scan_tmp + 16, &NX);
+            // one scan for both counts (non-empty children in the low half, multi-point children in the high half: <= 4 S < 2^16)
+            int TOT = 0;
+            int before = ex.excl_scan(nz | (nx << 16), w.scan_tmp, &TOT) >> 16;
+            const int NZ = TOT & 0xFFFF, NX = TOT >> 16;
             for (int i = sb; i < se; i++) {
                 rk_np[i] = 0xFFFF;
                 if (cnt_np[i] > 1) {
