@@ -32,6 +32,13 @@ sys.path[:0] = [os.path.join(ROOT, "ms-slam_amd")]
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
+def self_check(ok, what):
+    """Every cross-check the line reports (`*_matches_cpu`, `identical_results`, `same_matches_*`) is enforced: a bench line is
+    only printed when all of them hold, so a `false` can never appear as a result."""
+    if not ok:
+        raise AssertionError("bench self-check failed: " + what)
+
+
 def level_bytes(cfg):
     """Algorithmic bytes per image: sum of level pixels etc."""
     import math
@@ -169,6 +176,7 @@ def tracking_loop_leg(msorb, synth, torch, ex, cfg, base, counts_h, d_kps, d_des
     for _ in range(60):
         t0 = time.perf_counter(); nm2 = run.two_calls(); t2.append(time.perf_counter() - t0)
     n_kp = int(run.nl.value + run.nr.value)
+    self_check(nm1 == nm2, "tracking_loop: msorb_track_frontend and the two-call form return different match counts")
     out = {"what": "configs[2]: front-end of one tracking frame (Frame.cc:119-137 + Tracking::SearchLocalPoints, Tracking.cc:3343-3388) as a "
                    "device-resident chain; local map of %d points per frame (70 %% on keypoint rays, descriptors <= 40 bits off), th = 1" % m_points,
            "per_frame": {"ms_one_call": round(float(np.median(t1)) * 1e3, 4), "ms_two_calls": round(float(np.median(t2)) * 1e3, 4),
@@ -213,6 +221,7 @@ def tracking_cpu_leg(tracking, msorb, oracle_dir):
     g_mp = np.full(len(kps), -1, np.int32)
     g_nm, _ = msorb.search_local_points(f, fr, mp, g_mp, th)
     f.close()
+    self_check(g_nm == nm and np.array_equal(g_mp, frame_mp), "tracking_loop: msorb_search_local_points differs from the CPU oracle")
     tracking["cpu_baseline"] = {"ms_per_frame_matcher_half": round(dt * 1e3, 4), "cores": 1, "kind": "port", "matches": int(nm),
                                 "sample": f"isInFrustum + SearchByProjection over {len(mp['obs'])} map points x {len(kps)} keypoints, oracle, "
                                           f"{reps} repetitions", "gpu_matches_cpu": bool(g_nm == nm and np.array_equal(g_mp, frame_mp))}
@@ -404,6 +413,7 @@ def sparsification_leg(msorb, cpu):
         nr = n_rows.value
         same = (want["n_cols"] == n_cols.value and want["n_rows"] == nr and np.array_equal(want["col_point"], col_point[:n_cols.value]) and
                 np.array_equal(want["row_begin"], row_begin[:nr + 1]) and np.array_equal(want["col_idx"], col_idx[:nnz.value]))
+        self_check(same, "sparsification: msorb_visibility_csr differs from the CPU oracle")
         out["cpu_baseline"] = {"ms_per_window": round(dt * 1e3, 4), "cores": 1, "kind": "port",
                                "sample": f"oracle/sparsify_oracle.cc on the same window, {reps} repetitions", "gpu_matches_cpu": bool(same)}
     return out
@@ -672,7 +682,12 @@ def main():
         finally:
             del os.environ["MSORB_DENSE_VARIANT"]
         bi_m, bd_m, sd_m, _ = msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=1, device=local)
-        same_kernels = bool(torch.equal(bi_v, bi_m) and torch.equal(bd_v, bd_m) and torch.equal(sd_v, sd_m))
+        # rows >= nq[f] of a frame are never written by either kernel: only the valid rows are results
+        live = torch.arange(dq.shape[1], device=dev)[None, :] < nq[:, None]
+        same_kernels = bool(torch.equal(bi_v[live], bi_m[live]) and torch.equal(bd_v[live], bd_m[live]) and
+                            torch.equal(sd_v[live], sd_m[live]))
+        self_check(same_kernels, "hamming_match: the popcount and the MFMA kernel disagree on a valid row")
+        popcount_out = (bi_v, bd_v, sd_v)
         g_v = pairs * reps / (ms_v * 1e-3) / 1e9
         hamming = {"gpairs_per_s": round(g, 2), "pairs_per_launch": pairs,
                    "ms_per_launch": round(ms / reps, 4), "kernel": "dense_top2_mfma_kernel (v_mfma_i32_32x32x32_i8)",
@@ -788,9 +803,12 @@ def main():
             dtc = time.perf_counter() - tc
             same = (np.array_equal(bi_c, bi_g[0, :n0].cpu().numpy()) and np.array_equal(bd_c, bd_g[0, :n0].cpu().numpy()) and
                     np.array_equal(sd_c, sd_g[0, :n0].cpu().numpy()))
+            same_pop = all(np.array_equal(c, g[0, :n0].cpu().numpy()) for c, g in zip((bi_c, bd_c, sd_c), popcount_out))
+            self_check(same, "hamming_match: the MFMA kernel differs from the CPU oracle")
+            self_check(same_pop, "hamming_match: the popcount kernel differs from the CPU oracle")
             hamming["cpu_baseline"] = {"gpairs_per_s": round(n0 * n1 / dtc / 1e9, 4), "cores": 1, "kind": "port",
                                        "sample": f"{n0} x {n1} descriptors of one stereo pair, {dtc * 1e3:.1f} ms",
-                                       "gpu_matches_cpu": bool(same)}
+                                       "gpu_matches_cpu": bool(same), "popcount_kernel_matches_cpu": bool(same_pop)}
 
     if rank == 0:
         steps = max(args.steps, 1)

@@ -609,7 +609,8 @@ def hamming_dense_top2_batch(d_query, d_train, d_nq, d_nt, repeats=1, device=0):
     L.msorb_hamming_dense_top2_batch.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]
     F, qs, _ = d_query.shape
     ts = d_train.shape[1]
-    outs = [torch.empty((F, qs), dtype=torch.int32, device=d_query.device) for _ in range(3)]
+    # rows >= d_nq[f] are not written by the kernels: best_idx -1, distances 256 there (a defined value, never stale memory)
+    outs = [torch.full((F, qs), v, dtype=torch.int32, device=d_query.device) for v in (-1, 256, 256)]
     ms = C.c_float()
     _check(L.msorb_hamming_dense_top2_batch(device, d_query.data_ptr(), d_train.data_ptr(), d_nq.data_ptr(), d_nt.data_ptr(),
                                             F, qs, ts, int(d_nq.max()), int(d_nt.max()), outs[0].data_ptr(),

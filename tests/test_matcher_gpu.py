@@ -306,6 +306,43 @@ def test_dense_top2_kernels_edge_cases(msorb_mod, oracle, monkeypatch, kernel):
     assert np.all(bd[F - 1, :100] == 256) and np.all(sd[F - 1, :100] == 256) and np.all(bi[F - 1, :100] == -1)   # strict '<' from 256
 
 
+def test_dense_top2_kernels_on_extracted_descriptors_at_bench_size(msorb_mod, oracle, monkeypatch):
+    """bench.py's hamming_match leg as a test: 128 stereo pairs of KITTI-sized images through the extractor, the left-eye
+    descriptors of every pair against the right-eye ones (~2000 x ~2000 rBRIEF descriptors per frame, duplicates and all) on
+    BOTH dense kernels — matrix cores and xor / popcount — compared with each other on every valid row and with the CPU oracle
+    on sampled frames (ORBmatcher::DescriptorDistance brute force, ORBmatcher.cc:2323-2339; the knnMatch(k = 2) shape of
+    Frame.cc:1076).  Rows past a frame's query count are not results."""
+    import torch
+    cfg = synth.KITTI
+    base = [img for s in range(8) for img in synth.stereo_pair(s, cfg["rows"], cfg["cols"])]
+    host = np.stack([base[i % 16] for i in range(256)])
+    ex = msorb_mod.ORBextractor(cfg["nfeatures"], cfg["scale"], cfg["nlevels"], cfg["ini_th"], cfg["min_th"])
+    try:
+        images = torch.from_numpy(host).cuda()
+        counts, _, d_kps, d_desc = ex.extract_batch(images, (0, 0))
+        dq, dt = d_desc[0::2].contiguous(), d_desc[1::2].contiguous()
+        nq = torch.from_numpy(np.ascontiguousarray(counts[0::2])).cuda()
+        nt = torch.from_numpy(np.ascontiguousarray(counts[1::2])).cuda()
+        assert int(nq.min()) > 1500 and int(nt.min()) > 1500
+        mfma = msorb_mod.hamming_dense_top2_batch(dq, dt, nq, nt)[:3]
+        monkeypatch.setenv("MSORB_DENSE_VARIANT", "24")
+        valu = msorb_mod.hamming_dense_top2_batch(dq, dt, nq, nt)[:3]
+        monkeypatch.delenv("MSORB_DENSE_VARIANT")
+        live = torch.arange(dq.shape[1], device=dq.device)[None, :] < nq[:, None]
+        for a, b, name in zip(mfma, valu, ("best_idx", "best_dist", "second_dist")):
+            assert torch.equal(a[live], b[live]), name
+            # the wrapper presets the never-written rows: no stale memory in the tensors either
+            assert torch.equal(a, b), name + " (padding rows)"
+        for f in (0, 5, 77, 127):
+            n0, n1 = int(counts[2 * f]), int(counts[2 * f + 1])
+            want = oracle.dense_top2(dq[f, :n0].cpu().numpy(), dt[f, :n1].cpu().numpy())
+            for kern, got in (("mfma", mfma), ("popcount", valu)):
+                for w, g in zip(want, got):
+                    assert np.array_equal(w, g[f, :n0].cpu().numpy()), (kern, f)
+    finally:
+        ex.close()
+
+
 def test_window_top4_against_features_in_area(msorb_mod, oracle, stereo_frame):
     """The raw window search: top-4 of DescriptorDistance over GetFeaturesInArea in scan order."""
     s = stereo_frame
