@@ -175,6 +175,29 @@ def tracking_loop_leg(msorb, synth, torch, ex, cfg, base, counts_h, d_kps, d_des
         t0 = time.perf_counter(); nm1 = run.one_call(); t1.append(time.perf_counter() - t0)
     for _ in range(60):
         t0 = time.perf_counter(); nm2 = run.two_calls(); t2.append(time.perf_counter() - t0)
+    # TrackWithMotionModel's half of the frame (a14): the last frame's points around this frame's keypoints, th = 7 (stereo)
+    n0 = int(counts_h[0])
+    k0 = kps_h[0, :n0].copy().view(msorb.KP_DTYPE).reshape(-1)
+    last, q_cw, t_cw, fwd, bwd = synth.last_frame(9500, k0, desc_h[0, :n0], dp_h[0, :n0])
+    mm = msorb.MotionModel.make(q_cw, t_cw, cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["mbf"], fwd, bwd)
+    th_mm = 7.0   # Tracking.cc:2847-2850
+    mrun = msorb.MotionFrontendRunner(ex, left, right, KITTI_MB, KITTI_MBF, mm, last, last["obs"], th_mm, device=local)
+    mrun.attach_local_points(frusta[0], maps[0], th)
+    for _ in range(5):
+        mrun.one_call(); mrun.separate_calls(); mrun.frame_total()
+    tm1, tm3, tms, tft = [], [], [], []
+    for _ in range(60):
+        t0 = time.perf_counter(); nmm1 = mrun.one_call(); tm1.append(time.perf_counter() - t0)
+    mm_cur = mrun.cur_mp[:n0].copy()
+    for _ in range(60):
+        t0 = time.perf_counter(); nmm3 = mrun.separate_calls(); tm3.append(time.perf_counter() - t0)
+    self_check(nmm1 == nmm3 and np.array_equal(mm_cur, mrun.cur_mp[:n0]),
+               "tracking_loop: msorb_track_frontend_motion and the separate calls return different matches")
+    for _ in range(60):
+        t0 = time.perf_counter(); mrun.search_only(); tms.append(time.perf_counter() - t0)
+    for _ in range(60):
+        t0 = time.perf_counter(); nm_a, nm_b = mrun.frame_total(); tft.append(time.perf_counter() - t0)
+    self_check(nm_a == nmm1, "tracking_loop: the motion-model search of frame_total differs")
     n_kp = int(run.nl.value + run.nr.value)
     self_check(nm1 == nm2, "tracking_loop: msorb_track_frontend and the two-call form return different match counts")
     out = {"what": "configs[2]: front-end of one tracking frame (Frame.cc:119-137 + Tracking::SearchLocalPoints, Tracking.cc:3343-3388) as a "
@@ -184,6 +207,22 @@ def tracking_loop_leg(msorb, synth, torch, ex, cfg, base, counts_h, d_kps, d_des
                          "window_rounds": int(run.rounds.value),
                          "note": "wall time through the C ABI (ctypes call included), host images in, host features + matches out; "
                                  "one_call = msorb_track_frontend, two_calls = msorb_extract_stereo_frame + msorb_search_local_points"},
+           "motion_model": {"what": "TrackWithMotionModel's search (Tracking.cc:2833-2870 -> ORBmatcher::SearchByProjection(Current, Last, th, "
+                                    "bMono), ORBmatcher.cc:1941-2152) with the projection on the device: last-frame table of %d keypoints, "
+                                    "%d of them with a map point, th = %g" % (n0, int(last["has_point"].sum()), th_mm),
+                            "ms_frame_and_search_one_call": round(float(np.median(tm1)) * 1e3, 4),
+                            "ms_frame_and_search_separate_calls": round(float(np.median(tm3)) * 1e3, 4),
+                            "ms_search_only": round(float(np.median(tms)) * 1e3, 4), "matches": int(nmm1),
+                            "same_matches_both_ways": True,
+                            "note": "one_call = msorb_frame_set_last_points + msorb_track_frontend_motion (host images and the host "
+                                    "table in, features + cur_mp out); search_only = msorb_search_last_frame on the resident table "
+                                    "(the retry at 2 * th of Tracking.cc:2861-2868 costs this)"},
+           "per_frame_total": {"ms": round(float(np.median(tft)) * 1e3, 4), "motion_model_matches": int(nm_a), "local_map_matches": int(nm_b),
+                               "what": "both device calls of ONE tracking frame in the order Tracking::Track runs them: (1) Frame::Frame + "
+                                       "TrackWithMotionModel's SearchByProjection (msorb_frame_set_last_points + msorb_track_frontend_motion), "
+                                       "(2) TrackLocalMap's SearchLocalPoints (msorb_search_local_points: isInFrustum + SearchByProjection over "
+                                       "%d local map points).  The host's PoseOptimization between and after them is NOT included (g2o, out "
+                                       "of scope); wall time through the C ABI from host images" % m_points},
            "batched": {"frames": n_frames, "map_points_per_frame": m_points, "ms_grid": round(ms_grid, 4), "ms_frustum_queries": round(ms_frustum, 4),
                        "ms_window_search": round(ms_window, 4), "ms_per_frame": round((ms_grid + ms_frustum + ms_window) / n_frames, 5),
                        "points_in_view": in_view, "points_with_candidates": with_cand,
@@ -195,8 +234,10 @@ def tracking_loop_leg(msorb, synth, torch, ex, cfg, base, counts_h, d_kps, d_des
            "_cpu": (maps[0], frusta[0], kps_h[0, :int(counts_h[0])].copy().view(msorb.KP_DTYPE).reshape(-1), desc_h[0, :int(counts_h[0])],
                     d_ur2[0, :int(counts_h[0])].cpu().numpy(), bounds, scale, th,
                     int((r["topk_idx"][0, :, 0] >= 0).sum().item()))}
-    # the per-frame result equals the batch kernel's view of frame 0?  (same inputs: first unique pair) — cross-check, untimed
+    out["_cpu_mm"] = (last, q_cw, t_cw, bool(fwd), bool(bwd), th_mm, int(nmm1), mm_cur, k0, desc_h[0, :n0].copy(),
+                      d_ur2[0, :n0].cpu().numpy(), bounds, scale)
     run.close()
+    mrun.close()
     return out
 
 
@@ -222,6 +263,27 @@ def tracking_cpu_leg(tracking, msorb, oracle_dir):
     g_nm, _ = msorb.search_local_points(f, fr, mp, g_mp, th)
     f.close()
     self_check(g_nm == nm and np.array_equal(g_mp, frame_mp), "tracking_loop: msorb_search_local_points differs from the CPU oracle")
+    # motion-model half on the CPU: projection (orc_project_last_frame) + SearchByProjection(Current, Last), 1 thread
+    last, q_cw, t_cw, fwd, bwd, th_mm, g_nmm, g_cur, k0, d0, ur0, bounds_mm, scale_mm = tracking.pop("_cpu_mm")
+    omm = orb_oracle.MotionModel()
+    omm.q[:] = [float(v) for v in q_cw]
+    omm.t[:] = [float(v) for v in t_cw]
+    from msorb import synth as _synth
+    cam = _synth.KITTI_CAM
+    omm.fx, omm.fy, omm.cx, omm.cy, omm.mbf = cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["mbf"]
+    rf2 = orb_oracle.OracleFrame(k0, d0, ur0, bounds_mm, scale_mm)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        valid, u, v, urp = orb_oracle.project_last_frame(omm, bounds_mm, last["has_point"], last["pos_w"])
+        tab = dict(valid=valid, u=u, v=v, ur=urp, octave=last["octave"], angle=last["angle"], desc=last["desc"],
+                   mp=np.arange(len(valid), dtype=np.int32), obs=last["obs"])
+        c_cur = np.full(len(k0), -1, np.int32)
+        c_nmm = rf2.SearchByProjection_frames(tab, c_cur, th_mm, fwd, bwd, True)
+    dtm = (time.perf_counter() - t0) / reps
+    self_check(c_nmm == g_nmm and np.array_equal(c_cur, g_cur), "tracking_loop: msorb_track_frontend_motion differs from the CPU oracle")
+    tracking["motion_model"]["cpu_baseline"] = {"ms_per_frame": round(dtm * 1e3, 4), "cores": 1, "kind": "port", "matches": int(c_nmm),
+                                                "sample": f"projection + SearchByProjection(Current, Last) over {len(valid)} last-frame "
+                                                          f"keypoints, oracle, {reps} repetitions", "gpu_matches_cpu": True}
     tracking["cpu_baseline"] = {"ms_per_frame_matcher_half": round(dt * 1e3, 4), "cores": 1, "kind": "port", "matches": int(nm),
                                 "sample": f"isInFrustum + SearchByProjection over {len(mp['obs'])} map points x {len(kps)} keypoints, oracle, "
                                           f"{reps} repetitions", "gpu_matches_cpu": bool(g_nm == nm and np.array_equal(g_mp, frame_mp))}
@@ -897,6 +959,7 @@ def main():
             tracking_cpu_leg(tracking, msorb, os.path.join(ROOT, "oracle"))
         if tracking is not None:
             tracking.pop("_cpu", None)
+            tracking.pop("_cpu_mm", None)
         out["tracking_loop"] = tracking
         if aux:
             out["sparsification"] = sparsification_leg(msorb, args.cpu_pairs > 0)

@@ -665,6 +665,51 @@ int msorb_track_frontend(msorb_extractor* h, msorb_frame* f, const uint8_t* left
                          float nnratio, uint8_t* track_in_view, float* proj_x, float* proj_y, float* proj_xr, float* track_depth,
                          int* scale_level, float* view_cos, int* nmatches, int* rounds);
 
+/* ------------------------------------------------------------------------------------------------
+ * TrackWithMotionModel's search (src/Tracking.cc:2833-2870): ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono)
+ * (src/ORBmatcher.cc:1941-2152, rectified rig / Nleft == -1) with the projection of :1962-1990 ON THE DEVICE.  The last
+ * frame's points stay resident on the current frame's handle between calls (the retry at 2 * th, Tracking.cc:2861-2868, is a
+ * second msorb_search_last_frame without another upload).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct msorb_motion_model {
+    float q[4];                         /* Tcw.unit_quaternion() as Sophus stores it: x, y, z, w (:1951) */
+    float t[3];                         /* Tcw.translation() */
+    float fx, fy, cx, cy;               /* Pinhole mvParameters[0..3] (Pinhole.cpp:43-49) */
+    float mbf;                          /* CurrentFrame.mbf (:2019) */
+    int forward, backward;              /* bForward / bBackward (:1957-1958): two scalar pose operations of the caller */
+} msorb_motion_model;
+
+/* The last frame's side of the search, n entries = LastFrame.N: has_point[i] = LastFrame.mvpMapPoints[i] && !mvbOutlier[i]
+ * (:1962-1965), pos_w = pMP->GetWorldPos() (3 floats), octave = LastFrame.mvKeys[i].octave (:1986), angle =
+ * LastFrame.mvKeysUn[i].angle (:2044), mp_desc = pMP->GetDescriptor() (32 bytes).  Entries without a point are not read.
+ * Copies the arrays (the caller's may be reused at once) and starts the upload on the frame's stream; the table then lives on
+ * the handle until the next msorb_frame_set_last_points.  May be called before the frame itself is set. */
+int msorb_frame_set_last_points(msorb_frame* cur, int n, const uint8_t* has_point, const float* pos_w, const int* octave,
+                                const float* angle, const uint8_t* mp_desc);
+
+/* The search against the resident table: per point x3Dc = Tcw * x3Dw (Sophus' quaternion action, so3.hpp:358-367, in the
+ * float convention stated in DESIGN.md), invzc < 0 / image-bounds rejections (:1973-1983), radius = th * mvScaleFactors[octave],
+ * the forward / backward / default level band (:1993-1998), the window search with the occupancy and mvuRight filters
+ * (:2011-2022), then — on the host, in last-frame order — the sequential claims (:2035-2038) and the rotation histogram
+ * (:2040-2057, :2129-2149).  Map-point ids: last-frame point i = id i; obs[n_obs] = Observations() per id (n_obs >= n of the
+ * table; ids >= n are points the current frame already holds); cur_mp[N] in / out (-1 = none).  proj_valid / proj_u / proj_v /
+ * proj_ur (may be NULL, n entries): what :1962-1983 and :2019 computed — the inputs msorb_search_by_projection_frames takes, for
+ * inspection.  Results equal msorb_search_by_projection_frames on those inputs. */
+int msorb_search_last_frame(msorb_frame* cur, const msorb_motion_model* mm, const int* obs, int n_obs, int* cur_mp, float th,
+                            int check_orientation, int* nmatches, uint8_t* proj_valid, float* proj_u, float* proj_v, float* proj_ur);
+
+/* Frame::Frame(imLeft, imRight, ...) (Frame.cc:119-137, as msorb_extract_stereo_frame) AND the motion-model search in ONE
+ * call with ONE synchronisation: the pose guess mVelocity * mLastFrame.GetPose() (Tracking.cc:2854) does not depend on the new
+ * images, so images + last-frame table go up together and extraction, ComputeStereoMatches, AssignFeaturesToGrid, projection,
+ * window search and the read-back are one stream of work.  A new frame holds no map points (Frame.cc:139; Tracking.cc:2857
+ * clears them anyway): cur_mp[capacity] is an OUTPUT, obs has one entry per last-frame point (n of the table). */
+int msorb_track_frontend_motion(msorb_extractor* h, msorb_frame* f, const uint8_t* left, const uint8_t* right, int rows, int cols,
+                                size_t stride_left, size_t stride_right, float mb, float mbf, msorb_keypoint* kps_left,
+                                uint8_t* desc_left, int* n_left, msorb_keypoint* kps_right, uint8_t* desc_right, int* n_right,
+                                int capacity, float* u_right, float* depth, int* n_oob, float min_x, float max_x, float min_y,
+                                float max_y, const msorb_motion_model* mm, const int* obs, int* cur_mp, float th,
+                                int check_orientation, int* nmatches);
+
 /* The device part of the same chain for a BATCH of frames whose features are device resident (offline throughput and the
  * measurement of the windowed Hamming rate): frame b's keypoints / descriptors / count are image b*frame_step of an
  * msorb_extract_batch output (frame_step = 2: the left images of interleaved stereo pairs), d_u_right[b*capacity ..] its

@@ -200,6 +200,81 @@ __global__ __launch_bounds__(256) void local_points_kernel(LocalPointsArgs A) {
     A.q[o] = w;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// TrackWithMotionModel's search, ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (ORBmatcher.cc:1941-2152):
+// the per-point part of the loop up to the window (:1962-1998) — one thread per last-frame keypoint, window query out.
+//   x3Dc = Tcw * x3Dw is Sophus' SE3 action (se3.hpp:321-324 -> so3.hpp:358-367): uv = q.vec x p; uv += uv;
+//   p + q.w * uv + q.vec x uv, then + translation.  Float convention (as for isInFrustum): of a difference of two
+//   products the first one is fused (a*b - c*d -> fma(a, b, -(c*d))), a product added to a term is fused (p + w*uv ->
+//   fma(w, uv, p)); sums stay sums.  Which products an actual -O3 -march=native build contracts is the compiler's choice (GCC 11
+//   SLP-vectorises this very expression with fmsub in some lanes and fnmadd in others): msorb_search_by_projection_frames takes
+//   coordinates projected by the caller's own build when the last ulp matters.
+// ---------------------------------------------------------------------------------------------------------------------
+struct LastFrameArgs {
+    float qx, qy, qz, qw, tx, ty, tz;
+    float fx, fy, cx, cy, mbf;
+    float min_x, max_x, min_y, max_y;
+    float th;
+    int forward, backward, n;
+    float scale[MSORB_MAX_LEVELS];
+    const float* pos_w;      // [3n]
+    const int* octave;       // [n]
+    const uint8_t* flags;    // [n] bit 0: the keypoint holds a map point that is not an outlier
+    WinQuery* q;
+    float *u, *v, *ur;
+    uint8_t* valid;
+};
+
+__device__ __forceinline__ float diff_of_products(float a, float b, float c, float d) { return __fmaf_rn(a, b, -__fmul_rn(c, d)); }
+
+__global__ __launch_bounds__(256) void last_frame_kernel(LastFrameArgs A) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    WinQuery w;
+    w.x = 0; w.y = 0; w.r = 0; w.ur = 0; w.min_level = 0; w.max_level = 0; w.flags = 0; w.pad[0] = w.pad[1] = w.pad[2] = 0;
+    float u = 0.0f, v = 0.0f, ur = 0.0f;
+    uint8_t ok = 0;
+    if (A.flags[i] & 1) {
+        const float px = A.pos_w[3 * i], py = A.pos_w[3 * i + 1], pz = A.pos_w[3 * i + 2];
+        float uvx = diff_of_products(A.qy, pz, A.qz, py), uvy = diff_of_products(A.qz, px, A.qx, pz), uvz = diff_of_products(A.qx, py, A.qy, px);
+        uvx = __fadd_rn(uvx, uvx); uvy = __fadd_rn(uvy, uvy); uvz = __fadd_rn(uvz, uvz);
+        const float cx_ = diff_of_products(A.qy, uvz, A.qz, uvy), cy_ = diff_of_products(A.qz, uvx, A.qx, uvz), cz_ = diff_of_products(A.qx, uvy, A.qy, uvx);
+        const float xc = __fadd_rn(__fadd_rn(__fmaf_rn(A.qw, uvx, px), cx_), A.tx);
+        const float yc = __fadd_rn(__fadd_rn(__fmaf_rn(A.qw, uvy, py), cy_), A.ty);
+        const float zc = __fadd_rn(__fadd_rn(__fmaf_rn(A.qw, uvz, pz), cz_), A.tz);
+        // :1973 `const float invzc = 1.0/x3Dc(2)`: the double quotient rounded to float IS the float quotient (53 >= 2*24 + 2)
+        const float invzc = __fdiv_rn(1.0f, zc);
+        if (!(invzc < 0.0f)) {
+            u = __fadd_rn(__fdiv_rn(__fmul_rn(A.fx, xc), zc), A.cx);   // Pinhole::project, Pinhole.cpp:43-49
+            v = __fadd_rn(__fdiv_rn(__fmul_rn(A.fy, yc), zc), A.cy);
+            if (!(u < A.min_x || u > A.max_x) && !(v < A.min_y || v > A.max_y)) {   // :1980-1983
+                const int oct = A.octave[i];
+                ok = 1;
+                ur = __fmaf_rn(-A.mbf, invzc, u);                                  // :2019
+                w.x = u; w.y = v; w.ur = ur;
+                w.r = __fmul_rn(A.th, A.scale[oct]);                               // :1989
+                if (A.forward) { w.min_level = (int16_t)oct; w.max_level = -1; }  // :1993-1998
+                else if (A.backward) { w.min_level = 0; w.max_level = (int16_t)oct; }
+                else { w.min_level = (int16_t)(oct - 1); w.max_level = (int16_t)(oct + 1); }
+                w.flags = kQValid | kQSkipOccupied;
+            }
+        }
+    }
+    A.q[i] = w;
+    A.u[i] = u; A.v[i] = v; A.ur[i] = ur; A.valid[i] = ok;
+}
+
+// packed transfer blocks of the last frame's points (n entries)
+struct LastLayout {
+    size_t o_pos, o_oct, o_desc, o_flags, in_bytes;         // input block
+    size_t o_topk, o_u, o_v, o_ur, o_valid, out_bytes;      // output block
+    explicit LastLayout(size_t n) {
+        o_pos = 0; o_oct = o_pos + 12 * n; o_desc = o_oct + 4 * n; o_flags = o_desc + 32 * n; in_bytes = (o_flags + n + 63) & ~(size_t)63;
+        o_topk = 0; o_u = o_topk + sizeof(TopK) * n; o_v = o_u + 4 * n; o_ur = o_v + 4 * n; o_valid = o_ur + 4 * n;
+        out_bytes = (o_valid + n + 63) & ~(size_t)63;
+    }
+};
+
 // packed transfer blocks of one frame's local map points (m entries): one H2D, one D2H
 struct MpLayout {
     size_t o_pos, o_nrm, o_max, o_min, o_desc, o_flags, in_bytes;                  // input block
@@ -220,10 +295,18 @@ struct msorb_frame_track {
     DBuf<msorb_frustum> d_frustum;
     HBuf<uint8_t> h_in, h_out;
     hipEvent_t ev_in = nullptr;
+    // TrackWithMotionModel's search: the last frame's points, resident between calls (msorb_frame_set_last_points)
+    DBuf<uint8_t> d_last, d_last_out;
+    HBuf<uint8_t> h_last, h_last_out;
+    std::vector<float> last_angle;   // host copies the replay reads
+    int last_n = -1;                 // -1: no table set
+    hipEvent_t ev_last = nullptr;
     void release() {
         d_in.release(); d_out.release(); d_frustum.release(); h_in.release(); h_out.release();
+        d_last.release(); d_last_out.release(); h_last.release(); h_last_out.release();
         if (ev_in) (void)hipEventDestroy(ev_in);
-        ev_in = nullptr;
+        if (ev_last) (void)hipEventDestroy(ev_last);
+        ev_in = ev_last = nullptr;
     }
 };
 
@@ -283,8 +366,15 @@ namespace {
 
 int ensure_track(msorb_frame* f) {
     if (f->track) return MSORB_OK;
-    f->track = new msorb_frame_track();
-    HIPCHK(hipEventCreateWithFlags(&f->track->ev_in, hipEventDisableTiming));
+    msorb_frame_track* t = new msorb_frame_track();
+    if (hipEventCreateWithFlags(&t->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&t->ev_last, hipEventDisableTiming) != hipSuccess) {
+        t->release();
+        delete t;
+        set_last_error("frame: cannot create the staging events");
+        return MSORB_E_HIP;
+    }
+    f->track = t;
     return MSORB_OK;
 }
 
@@ -445,9 +535,174 @@ int initial_occupancy(const msorb_frame* f, int n, const int* frame_mp, const in
     return MSORB_OK;
 }
 
+// ---- TrackWithMotionModel's search on the resident last-frame table ----
+struct LastFrameCall {
+    const msorb_motion_model* mm;
+    const int* obs;
+    int n_obs;
+    float th;
+    int check_orientation;
+};
+
+// projection + queries + round 0 of the window search + the read-back, enqueued on stream s (ordered behind whatever produced
+// the frame's device arrays; the table's upload is waited for here).  d_occ must hold the occupancy snapshot.
+int enqueue_last_frame(msorb_frame* f, const LastFrameCall& c, hipStream_t s) {
+    msorb_frame_track& T = *f->track;
+    const size_t n = (size_t)T.last_n;
+    if (!n) return MSORB_OK;
+    const LastLayout L(n);
+    int rc;
+    if ((rc = f->d_q.ensure(n)) || (rc = T.d_last_out.ensure(L.out_bytes)) || (rc = T.h_last_out.ensure(L.out_bytes)) ||
+        (rc = f->h_topk.ensure(n)))
+        return rc;
+    HIPCHK(hipStreamWaitEvent(s, T.ev_last, 0));
+    const msorb_motion_model& m = *c.mm;
+    LastFrameArgs A{};
+    A.qx = m.q[0]; A.qy = m.q[1]; A.qz = m.q[2]; A.qw = m.q[3];
+    A.tx = m.t[0]; A.ty = m.t[1]; A.tz = m.t[2];
+    A.fx = m.fx; A.fy = m.fy; A.cx = m.cx; A.cy = m.cy; A.mbf = m.mbf;
+    A.min_x = f->minX; A.max_x = f->maxX; A.min_y = f->minY; A.max_y = f->maxY;
+    A.th = c.th; A.forward = m.forward; A.backward = m.backward; A.n = T.last_n;
+    for (int l = 0; l < MSORB_MAX_LEVELS; l++) A.scale[l] = l < (int)f->scale.size() ? f->scale[l] : 0.0f;
+    const uint8_t* di = T.d_last.p;
+    uint8_t* dout = T.d_last_out.p;
+    A.pos_w = reinterpret_cast<const float*>(di + L.o_pos); A.octave = reinterpret_cast<const int*>(di + L.o_oct);
+    A.flags = di + L.o_flags;
+    A.q = f->d_q.p;
+    A.u = reinterpret_cast<float*>(dout + L.o_u); A.v = reinterpret_cast<float*>(dout + L.o_v);
+    A.ur = reinterpret_cast<float*>(dout + L.o_ur); A.valid = dout + L.o_valid;
+    hipLaunchKernelGGL(last_frame_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A);
+    const float mid = f->scale.empty() ? 1.0f : f->scale[f->scale.size() / 2];
+    launch_window_topk(f->view(), f->d_q.p, di + L.o_desc, 0, T.last_n, reinterpret_cast<TopK*>(dout + L.o_topk), s, 1, 0, 0, nullptr,
+                       window_lanes_for(c.th * mid, f->gridWInv, f->gridHInv));
+    HIPCHK(hipMemcpyAsync(T.h_last_out.p, dout, L.out_bytes, hipMemcpyDeviceToHost, s));
+    return MSORB_OK;
+}
+
+// after the synchronisation: the sequential claims in last-frame order (:2035-2038) and the rotation histogram (:2040-2057,
+// :2129-2149); occ = the occupancy round 0 ran against
+int replay_last_frame(msorb_frame* f, const LastFrameCall& c, std::vector<uint8_t>& occ, int* cur_mp, int* nmatches, uint8_t* proj_valid,
+                      float* proj_u, float* proj_v, float* proj_ur) {
+    *nmatches = 0;
+    msorb_frame_track& T = *f->track;
+    const size_t n = (size_t)T.last_n;
+    if (!n) return MSORB_OK;
+    const LastLayout L(n);
+    const uint8_t* ho = T.h_last_out.p;
+    const uint8_t* valid = ho + L.o_valid;
+    if (proj_valid) std::memcpy(proj_valid, valid, n);
+    if (proj_u) std::memcpy(proj_u, ho + L.o_u, 4 * n);
+    if (proj_v) std::memcpy(proj_v, ho + L.o_v, 4 * n);
+    if (proj_ur) std::memcpy(proj_ur, ho + L.o_ur, 4 * n);
+    std::memcpy(f->h_topk.p, ho + L.o_topk, sizeof(TopK) * n);
+    std::vector<uint8_t> flags(n);
+    for (size_t i = 0; i < n; i++) flags[i] = valid[i] ? (uint8_t)(kQValid | kQSkipOccupied) : 0;
+    int nm = 0;
+    std::vector<int> rotHist[kHistoLength];
+    const float factor = 1.0f / kHistoLength;
+    const int* obs = c.obs;
+    auto accept = [&](int qi, const int* idx, const int* dist, int nc, int* new_occ) -> int {
+        if (nc == 0 || dist[0] > kThHigh) return -1;   // :2035
+        const int bestIdx2 = idx[0];
+        cur_mp[bestIdx2] = qi;
+        nm++;
+        if (c.check_orientation) {
+            float rot = T.last_angle[qi] - f->kps[bestIdx2].angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)std::round(rot * factor);
+            if (bin == kHistoLength) bin = 0;
+            if (bin >= 0 && bin < kHistoLength) rotHist[bin].push_back(bestIdx2);
+        }
+        *new_occ = obs[qi] > 0;
+        return bestIdx2;
+    };
+    const float mid = f->scale.empty() ? 1.0f : f->scale[f->scale.size() / 2];
+    const int rc = run_window_search(f, T.last_n, nullptr, flags.data(), nullptr, occ, 1, accept, true, nullptr, T.d_last.p + L.o_desc,
+                                     window_lanes_for(c.th * mid, f->gridWInv, f->gridHInv));
+    if (rc) return rc;
+    if (c.check_orientation) {
+        int sizes[kHistoLength], ind[3];
+        for (int i = 0; i < kHistoLength; i++) sizes[i] = (int)rotHist[i].size();
+        msorb_three_maxima(sizes, kHistoLength, ind);
+        for (int i = 0; i < kHistoLength; i++)
+            if (i != ind[0] && i != ind[1] && i != ind[2])
+                for (int k : rotHist[i]) { cur_mp[k] = -1; nm--; }
+    }
+    *nmatches = nm;
+    return MSORB_OK;
+}
+
+int check_last_frame(const msorb_frame* f, const LastFrameCall& c, bool frame_is_set) {
+    if (!f || !c.mm || !f->track || f->track->last_n < 0) {
+        if (f && (!f->track || f->track->last_n < 0)) set_last_error("no last-frame table on this frame (msorb_frame_set_last_points)");
+        return MSORB_E_INVALID;
+    }
+    if (f->track->last_n > 0 && (!c.obs || c.n_obs < f->track->last_n)) {
+        set_last_error("observation table shorter than the last-frame table");
+        return MSORB_E_INVALID;
+    }
+    if (frame_is_set && f->nlevels < 1) { set_last_error("frame not set"); return MSORB_E_INVALID; }
+    return MSORB_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int msorb_frame_set_last_points(msorb_frame* f, int n, const uint8_t* has_point, const float* pos_w, const int* octave,
+                                const float* angle, const uint8_t* mp_desc) {
+    if (!f || n < 0 || (n > 0 && (!has_point || !pos_w || !octave || !angle || !mp_desc))) return MSORB_E_INVALID;
+    for (int i = 0; i < n; i++)
+        if (has_point[i] && (octave[i] < 0 || octave[i] >= MSORB_MAX_LEVELS)) { set_last_error("last-frame octave out of range"); return MSORB_E_INVALID; }
+    HIPCHK(hipSetDevice(f->device));
+    int rc;
+    if ((rc = ensure_track(f))) return rc;
+    msorb_frame_track& T = *f->track;
+    T.last_n = -1;   // stays unset if anything below fails
+    const LastLayout L((size_t)n);
+    if ((rc = T.d_last.ensure(L.in_bytes)) || (rc = T.h_last.ensure(L.in_bytes))) return rc;
+    // a previous upload may still read the staging block (the call that enqueued it has not necessarily synchronised)
+    HIPCHK(hipEventSynchronize(T.ev_last));
+    uint8_t* h = T.h_last.p;
+    const size_t m = (size_t)n;
+    if (m) {
+        std::memcpy(h + L.o_pos, pos_w, 12 * m);
+        std::memcpy(h + L.o_oct, octave, 4 * m);
+        std::memcpy(h + L.o_desc, mp_desc, 32 * m);
+        for (size_t i = 0; i < m; i++) h[L.o_flags + i] = has_point[i] ? 1 : 0;
+        HIPCHK(hipMemcpyAsync(T.d_last.p, h, L.in_bytes, hipMemcpyHostToDevice, f->stream));
+    }
+    HIPCHK(hipEventRecord(T.ev_last, f->stream));
+    T.last_angle.assign(angle, angle + n);
+    T.last_n = n;
+    return MSORB_OK;
+}
+
+int msorb_search_last_frame(msorb_frame* f, const msorb_motion_model* mm, const int* obs, int n_obs, int* cur_mp, float th,
+                            int check_orientation, int* nmatches, uint8_t* proj_valid, float* proj_u, float* proj_v, float* proj_ur) {
+    const LastFrameCall c{mm, obs, n_obs, th, check_orientation};
+    if (!nmatches || n_obs < 0) return MSORB_E_INVALID;
+    *nmatches = 0;
+    int rc = check_last_frame(f, c, true);
+    if (rc) return rc;
+    if (f->N > 0 && !cur_mp) return MSORB_E_INVALID;
+    HIPCHK(hipSetDevice(f->device));
+    std::vector<uint8_t> occ(f->N, 0);
+    for (int i = 0; i < f->N; i++) {   // :2011-2013: a keypoint whose map point has observations is never taken
+        if (cur_mp[i] >= n_obs) { set_last_error("cur_mp holds an id outside the observation table"); return MSORB_E_INVALID; }
+        occ[i] = cur_mp[i] >= 0 && obs[cur_mp[i]] > 0;
+    }
+    hipStream_t s = f->stream;
+    if (f->N) {
+        if ((rc = f->h_in.ensure((size_t)f->N + 64))) return rc;
+        std::memcpy(f->h_in.p, occ.data(), f->N);
+        HIPCHK(hipMemcpyAsync(f->d_occ.p, f->h_in.p, f->N, hipMemcpyHostToDevice, s));
+    }
+    if ((rc = enqueue_last_frame(f, c, s))) return rc;
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    return replay_last_frame(f, c, occ, cur_mp, nmatches, proj_valid, proj_u, proj_v, proj_ur);
+}
 
 int msorb_frame_set_device(msorb_frame* f, const msorb_keypoint* d_keypoints, int n, const uint8_t* d_descriptors,
                            const float* d_u_right, float min_x, float max_x, float min_y, float max_y,
@@ -494,12 +749,15 @@ struct FrameSinkCtx {
     // the chained search (msorb_track_frontend); nullptr: the frame only
     const LocalPointsCall* lp;
     const uint8_t* occ0;  // initial occupancy to upload (nullptr: all free, cleared by the grid kernel)
+    const LastFrameCall* lf;  // the chained motion-model search (msorb_track_frontend_motion); nullptr: none
 };
 int frame_sink(void* ctx, const StereoDeviceOutputs& o) {
     FrameSinkCtx& C = *static_cast<FrameSinkCtx*>(ctx);
     int rc = enqueue_frame_from_device(C.f, o.stream, o.kps_left, o.desc_left, o.u_right, o.n_left, 0, o.capacity, C.min_x, C.max_x,
                                        C.min_y, C.max_y, C.scale, C.nlevels);
-    if (rc || !C.lp) return rc;
+    if (rc) return rc;
+    if (C.lf) return enqueue_last_frame(C.f, *C.lf, o.stream);
+    if (!C.lp) return rc;
     HIPCHK(hipStreamWaitEvent(o.stream, C.f->track->ev_in, 0));
     return enqueue_local_points(C.f, *C.lp, o.stream);
 }
@@ -515,7 +773,7 @@ int msorb_extract_stereo_frame(msorb_extractor* h, msorb_frame* f, const uint8_t
     float scale[MSORB_MAX_LEVELS];
     int rc = msorb_extractor_tables(h, scale, nullptr, nullptr, nullptr, nullptr);
     if (rc) return rc;
-    FrameSinkCtx C{f, min_x, max_x, min_y, max_y, scale, extractor_levels(h), nullptr, nullptr};
+    FrameSinkCtx C{f, min_x, max_x, min_y, max_y, scale, extractor_levels(h), nullptr, nullptr, nullptr};
     rc = extract_stereo_sink(h, left, right, rows, cols, stride_left, stride_right, mb, mbf, kps_left, desc_left, n_left, kps_right,
                              desc_right, n_right, capacity, u_right, depth, n_oob, frame_sink, &C);
     if (rc) { f->N = 0; return rc; }
@@ -574,7 +832,7 @@ int msorb_track_frontend(msorb_extractor* h, msorb_frame* f, const uint8_t* left
     if ((rc = msorb_extractor_tables(h, scale, nullptr, nullptr, nullptr, nullptr))) return rc;
     f->scale.assign(scale, scale + extractor_levels(h));  // the query set-up reads it before the sink has run
     if ((rc = upload_local_points(f, c))) return rc;     // rides PCIe while the extraction kernels run
-    FrameSinkCtx C{f, min_x, max_x, min_y, max_y, scale, extractor_levels(h), &c, nullptr};
+    FrameSinkCtx C{f, min_x, max_x, min_y, max_y, scale, extractor_levels(h), &c, nullptr, nullptr};
     rc = extract_stereo_sink(h, left, right, rows, cols, stride_left, stride_right, mb, mbf, kps_left, desc_left, n_left, kps_right,
                              desc_right, n_right, capacity, u_right, depth, n_oob, frame_sink, &C);
     if (rc) { f->N = 0; return rc; }
@@ -585,6 +843,32 @@ int msorb_track_frontend(msorb_extractor* h, msorb_frame* f, const uint8_t* left
     std::vector<uint8_t> occ(f->N, 0);
     const LocalPointsOut o{track_in_view, proj_x, proj_y, proj_xr, track_depth, scale_level, view_cos};
     return replay_local_points(f, c, occ, frame_mp, o, nmatches, rounds);
+}
+
+int msorb_track_frontend_motion(msorb_extractor* h, msorb_frame* f, const uint8_t* left, const uint8_t* right, int rows, int cols,
+                                size_t stride_left, size_t stride_right, float mb, float mbf, msorb_keypoint* kps_left,
+                                uint8_t* desc_left, int* n_left, msorb_keypoint* kps_right, uint8_t* desc_right, int* n_right,
+                                int capacity, float* u_right, float* depth, int* n_oob, float min_x, float max_x, float min_y,
+                                float max_y, const msorb_motion_model* mm, const int* obs, int* cur_mp, float th,
+                                int check_orientation, int* nmatches) {
+    if (!h || !f || !(max_x > min_x) || !(max_y > min_y) || !nmatches || !cur_mp) return MSORB_E_INVALID;
+    *nmatches = 0;
+    const LastFrameCall c{mm, obs, f->track ? f->track->last_n : 0, th, check_orientation};
+    int rc = check_last_frame(f, c, false);
+    if (rc) return rc;
+    if (extractor_device(h) != f->device) { set_last_error("extractor and frame live on different devices"); return MSORB_E_INVALID; }
+    HIPCHK(hipSetDevice(f->device));
+    float scale[MSORB_MAX_LEVELS];
+    if ((rc = msorb_extractor_tables(h, scale, nullptr, nullptr, nullptr, nullptr))) return rc;
+    FrameSinkCtx C{f, min_x, max_x, min_y, max_y, scale, extractor_levels(h), nullptr, nullptr, &c};
+    rc = extract_stereo_sink(h, left, right, rows, cols, stride_left, stride_right, mb, mbf, kps_left, desc_left, n_left, kps_right,
+                             desc_right, n_right, capacity, u_right, depth, n_oob, frame_sink, &C);
+    if (rc) { f->N = 0; return rc; }
+    finish_frame_host(f, kps_left, *n_left, u_right);
+    // a new frame holds no map points: round 0 ran against the all-free occupancy the grid kernel left on the device
+    for (int i = 0; i < f->N; i++) cur_mp[i] = -1;
+    std::vector<uint8_t> occ(f->N, 0);
+    return replay_last_frame(f, c, occ, cur_mp, nmatches, nullptr, nullptr, nullptr, nullptr);
 }
 
 // Batched, device-resident form of the same chain (offline throughput, measurement): every frame's features are the

@@ -1124,7 +1124,7 @@ def search_local_points(frame, frustum, mp, frame_mp, th, bFarPoints=False, thFa
     return nm.value, {k: v[:m] for k, v in out.items()}
 
 
-def _stereo_frame_call(ex, fn_name, left, right, mb, mbf, bounds, extra_argtypes, extra_args, device):
+def _stereo_frame_call(ex, fn_name, left, right, mb, mbf, bounds, extra_argtypes, extra_args, device, prepare=None):
     left, right = np.ascontiguousarray(left, np.uint8), np.ascontiguousarray(right, np.uint8)
     assert left.shape == right.shape and left.ndim == 2
     rows, cols = left.shape
@@ -1134,6 +1134,8 @@ def _stereo_frame_call(ex, fn_name, left, right, mb, mbf, bounds, extra_argtypes
     ur, dp = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
     nl, nr, oob = C.c_int(0), C.c_int(0), C.c_int(0)
     f = _empty_frame(device)
+    if prepare is not None:
+        prepare(f)
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     fn = getattr(ex.L, fn_name)
     fn.argtypes = [vp, vp, vp, vp, ci, ci, C.c_size_t, C.c_size_t, cf, cf, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, cf, cf, cf,
@@ -1255,6 +1257,147 @@ class TrackFrontendRunner:
         self.frame_mp[:] = -1
         _check(self.L.msorb_search_local_points(self.f.h, *self._lp), "msorb_search_local_points")
         return self.nm.value
+
+    def close(self):
+        self.f.close()
+
+
+EXPORTS = EXPORTS + ("msorb_frame_set_last_points", "msorb_search_last_frame", "msorb_track_frontend_motion")
+
+
+class MotionModel(C.Structure):
+    """msorb_motion_model: Tcw (unit quaternion x, y, z, w + translation), pinhole parameters, mbf, bForward / bBackward"""
+    _fields_ = [("q", C.c_float * 4), ("t", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("mbf", C.c_float), ("forward", C.c_int), ("backward", C.c_int)]
+
+    @classmethod
+    def make(cls, q_xyzw, t, fx, fy, cx, cy, mbf, forward=False, backward=False):
+        m = cls()
+        m.q[:] = [float(np.float32(v)) for v in q_xyzw]
+        m.t[:] = [float(np.float32(v)) for v in t]
+        m.fx, m.fy, m.cx, m.cy, m.mbf = fx, fy, cx, cy, mbf
+        m.forward, m.backward = int(forward), int(backward)
+        return m
+
+
+def _last_arrays(last):
+    return [_c(last["has_point"], np.uint8), _c(last["pos_w"], np.float32).reshape(-1), _c(last["octave"], np.int32),
+            _c(last["angle"], np.float32), _c(last["desc"], np.uint8)]
+
+
+def frame_set_last_points(frame, last):
+    """msorb_frame_set_last_points; last: dict(has_point, pos_w [n, 3], octave, angle, desc [n, 32]) — LastFrame's side of
+    ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono)."""
+    arrs = _last_arrays(last)
+    frame.L.msorb_frame_set_last_points.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+    _check(frame.L.msorb_frame_set_last_points(frame.h, len(arrs[0]), *[_np_ptr(a) for a in arrs]), "msorb_frame_set_last_points")
+
+
+def search_last_frame(frame, mm, obs, cur_mp, th, check_orientation=True, want_projection=False):
+    """msorb_search_last_frame on the resident table -> nmatches (cur_mp updated in place) [, dict(valid, u, v, ur)]."""
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    frame.L.msorb_search_last_frame.argtypes = [vp, vp, vp, ci, vp, cf, ci, C.POINTER(ci), vp, vp, vp, vp]
+    ob = _c(obs, np.int32)
+    assert cur_mp.dtype == np.int32 and cur_mp.flags.c_contiguous
+    nm = C.c_int()
+    n = len(ob)
+    pv = np.zeros(max(n, 1), np.uint8)
+    pu, pvv, pur = [np.zeros(max(n, 1), np.float32) for _ in range(3)]
+    proj = [_np_ptr(a) for a in (pv, pu, pvv, pur)] if want_projection else [None] * 4
+    _check(frame.L.msorb_search_last_frame(frame.h, C.addressof(mm), _np_ptr(ob), n, _np_ptr(cur_mp), th, int(check_orientation),
+                                           C.byref(nm), *proj), "msorb_search_last_frame")
+    if want_projection:
+        return nm.value, dict(valid=pv[:n], u=pu[:n], v=pvv[:n], ur=pur[:n])
+    return nm.value
+
+
+def track_frontend_motion(ex, left, right, mb, mbf, mm, last, obs, th, check_orientation=True, bounds=None, device=0):
+    """msorb_frame_set_last_points + msorb_track_frontend_motion -> (Frame, stereo outputs, cur_mp[n_left], nmatches)."""
+    if bounds is None:
+        bounds = (0.0, float(left.shape[1]), 0.0, float(left.shape[0]))
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    ob = _c(obs, np.int32)
+    cur_mp = np.full(ex.capacity, -1, np.int32)
+    nm = C.c_int()
+    fr = [None]
+
+    def prepare(f):
+        frame_set_last_points(f, last)
+        fr[0] = f
+    f, st = _stereo_frame_call(ex, "msorb_track_frontend_motion", left, right, mb, mbf, bounds, [vp, vp, vp, cf, ci, C.POINTER(ci)],
+                               [C.addressof(mm), _np_ptr(ob), _np_ptr(cur_mp), th, int(check_orientation), C.byref(nm)], device,
+                               prepare=prepare)
+    return f, st, cur_mp[:f.n].copy(), nm.value
+
+
+class MotionFrontendRunner:
+    """configs[2], first half of a tracking frame with every buffer prepared once: msorb_track_frontend_motion (Frame::Frame +
+    TrackWithMotionModel's SearchByProjection as one call) — or the same as three calls (table upload, extraction, search)."""
+
+    def __init__(self, ex, left, right, mb, mbf, mm, last, obs, th, check_orientation=True, device=0):
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        self.ex, self.L = ex, ex.L
+        self.left, self.right = np.ascontiguousarray(left, np.uint8), np.ascontiguousarray(right, np.uint8)
+        rows, cols = self.left.shape
+        cap = ex.capacity
+        self.f = _empty_frame(device)
+        self.kl, self.kr = np.zeros(cap, KP_DTYPE), np.zeros(cap, KP_DTYPE)
+        self.dl, self.dr = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
+        self.ur, self.dp = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+        self.nl, self.nr, self.oob, self.nm = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        self.mm, self.obs = mm, _c(obs, np.int32)
+        self.last = _last_arrays(last)
+        self.cur_mp = np.full(cap, -1, np.int32)
+        stereo_t = [vp, vp, vp, vp, ci, ci, C.c_size_t, C.c_size_t, cf, cf, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, cf, cf, cf, cf]
+        self.L.msorb_track_frontend_motion.argtypes = stereo_t + [vp, vp, vp, cf, ci, C.POINTER(ci)]
+        self.L.msorb_extract_stereo_frame.argtypes = stereo_t
+        self.L.msorb_frame_set_last_points.argtypes = [vp, ci] + [vp] * 5
+        self.L.msorb_search_last_frame.argtypes = [vp, vp, vp, ci, vp, cf, ci, C.POINTER(ci), vp, vp, vp, vp]
+        self._stereo = (ex.h, self.f.h, _np_ptr(self.left), _np_ptr(self.right), rows, cols, cols, cols, mb, mbf, _np_ptr(self.kl),
+                        _np_ptr(self.dl), C.byref(self.nl), _np_ptr(self.kr), _np_ptr(self.dr), C.byref(self.nr), cap, _np_ptr(self.ur),
+                        _np_ptr(self.dp), C.byref(self.oob), 0.0, float(cols), 0.0, float(rows))
+        self._set = (self.f.h, len(self.last[0])) + tuple(_np_ptr(a) for a in self.last)
+        self._mm = (C.addressof(mm), _np_ptr(self.obs), _np_ptr(self.cur_mp), th, int(check_orientation), C.byref(self.nm))
+        self._search = (self.f.h, C.addressof(mm), _np_ptr(self.obs), len(self.obs), _np_ptr(self.cur_mp), th, int(check_orientation),
+                        C.byref(self.nm), None, None, None, None)
+
+    def one_call(self):
+        _check(self.L.msorb_frame_set_last_points(*self._set), "msorb_frame_set_last_points")
+        _check(self.L.msorb_track_frontend_motion(*self._stereo, *self._mm), "msorb_track_frontend_motion")
+        return self.nm.value
+
+    def separate_calls(self):
+        _check(self.L.msorb_frame_set_last_points(*self._set), "msorb_frame_set_last_points")
+        _check(self.L.msorb_extract_stereo_frame(*self._stereo), "msorb_extract_stereo_frame")
+        self.cur_mp[:] = -1
+        _check(self.L.msorb_search_last_frame(*self._search), "msorb_search_last_frame")
+        return self.nm.value
+
+    def search_only(self):
+        self.cur_mp[:] = -1
+        _check(self.L.msorb_search_last_frame(*self._search), "msorb_search_last_frame")
+        return self.nm.value
+
+    def attach_local_points(self, frustum, mp, th, bFarPoints=False, thFarPoints=50.0, nnratio=0.8, viewing_cos_limit=0.5):
+        """prepare the second call of the frame: msorb_search_local_points (TrackLocalMap's SearchLocalPoints) on the same handle"""
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        self.m, self.arrs = _lp_arrays(mp)
+        self.out = _lp_outputs(self.m)
+        self.frame_mp = np.full(self.ex.capacity, -1, np.int32)
+        self.frustum, self.nm_lp = frustum, C.c_int(0)
+        self.L.msorb_search_local_points.argtypes = [vp, vp, cf, ci] + [vp] * 10 + [cf, ci, cf, cf] + [vp] * 7 + [C.POINTER(ci)]
+        self._lp = (self.f.h, C.addressof(frustum), viewing_cos_limit, self.m) + \
+            tuple(None if a is None else _np_ptr(a) for a in self.arrs) + \
+            (_np_ptr(self.frame_mp), th, int(bFarPoints), thFarPoints, nnratio) + tuple(_np_ptr(self.out[k]) for k in _LP_OUT_ORDER) + \
+            (C.byref(self.nm_lp),)
+
+    def frame_total(self):
+        """both device calls of one tracking frame: Frame::Frame + TrackWithMotionModel's search, then (the pose optimisation
+        of the host sits here in the reference) SearchLocalPoints -> (motion-model matches, local-map matches)"""
+        a = self.one_call()
+        self.frame_mp[:] = -1
+        _check(self.L.msorb_search_local_points(*self._lp), "msorb_search_local_points")
+        return a, self.nm_lp.value
 
     def close(self):
         self.f.close()

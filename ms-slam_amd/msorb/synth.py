@@ -124,3 +124,66 @@ def local_map(seed, kps, desc, depth, scale, m, pose=None, copy_frac=0.7, bad_fr
     return dict(pos_w=Pw, normal=nrm.astype(np.float32), max_distance=maxd, min_distance=mind, visit=visit, bad=bad,
                 sparsified=spars, desc=dsc, obs=np.where(rng.random(m) < obs_zero_frac, 0, rng.integers(1, 12, m)).astype(np.int32),
                 flags=(visit | (bad << 1) | (spars << 2)).astype(np.uint8), Rcw=R, tcw=t, Ow=Ow)
+
+
+def _quat_xyzw(R):
+    """unit quaternion (x, y, z, w) of a rotation matrix (float64 in, as Sophus holds Tcw's rotation)"""
+    R = np.asarray(R, np.float64)
+    w = np.sqrt(max(0.0, 1.0 + R[0, 0] + R[1, 1] + R[2, 2])) / 2.0
+    x = (R[2, 1] - R[1, 2]) / (4.0 * w)
+    y = (R[0, 2] - R[2, 0]) / (4.0 * w)
+    z = (R[1, 0] - R[0, 1]) / (4.0 * w)
+    q = np.array([x, y, z, w])
+    return q / np.linalg.norm(q)
+
+
+def _rot(rx, ry, rz):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def last_frame(seed, kps, desc, depth, point_frac=0.75, outlier_frac=0.05, obs_zero_frac=0.15, max_flips=30, pixel_sigma=2.5,
+               motion=(0.004, 0.003, 0.002, 0.02, 0.01, 0.35), behind_frac=0.01, cam=KITTI_CAM):
+    """TrackWithMotionModel's workload: a "last frame" whose keypoints are those of the current frame
+    seen from a slightly different pose.  point_frac of the keypoints hold a map point (has_point), placed on the keypoint's
+    viewing ray at its stereo depth (or a random depth) in the LAST camera's frame a few pixels off; the current pose Tcw =
+    the small motion `motion` (3 rotation angles in rad, 3 translation components in m) applied to the last pose, so the
+    points project near — not on — the keypoints.  Descriptors: the keypoint's, up to max_flips bits away.  behind_frac of the
+    points sit behind the camera.  -> (dict(has_point, pos_w, octave, angle, desc, obs), q_xyzw, t, forward, backward)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = len(kps)
+    # last pose: something non-trivial, so that the quaternion action has every term
+    Rlw = _rot(0.11, -0.27, 0.05)
+    tlw = np.array([0.8, -0.3, 2.1])
+    dR = _rot(*motion[:3])
+    dt = np.asarray(motion[3:], np.float64)
+    Rcw, tcw = dR @ Rlw, dR @ tlw + dt          # Tcw = dT * Tlw
+    kx, ky = kps["x"].astype(np.float64), kps["y"].astype(np.float64)
+    z = np.where(depth > 0, depth.astype(np.float64) * rng.uniform(0.98, 1.02, n), rng.uniform(3.0, 60.0, n))
+    behind = rng.random(n) < behind_frac
+    # positions chosen in the CURRENT camera (so the projections land pixel_sigma around the keypoints), then moved to the world
+    u = kx + rng.normal(0, pixel_sigma, n)
+    v = ky + rng.normal(0, pixel_sigma, n)
+    zc = np.where(behind, -z, z)
+    Pc = np.stack([(u - cam["cx"]) * zc / cam["fx"], (v - cam["cy"]) * zc / cam["fy"], zc], 1)
+    Pw = ((Pc - tcw) @ Rcw).astype(np.float32)
+    has = (rng.random(n) < point_frac) & ~(rng.random(n) < outlier_frac)
+    cp = desc.copy()
+    nf = rng.integers(0, max_flips + 1, n)
+    for k in range(max_flips):
+        bit = rng.integers(0, 256, n)
+        on = k < nf
+        cp[np.arange(n)[on], (bit >> 3)[on]] ^= (1 << (bit & 7)[on]).astype(np.uint8)
+    # the last frame saw the same corners at (almost) the same orientation and level
+    ang = (kps["angle"].astype(np.float64) + rng.normal(0, 4.0, n)) % 360.0
+    flip = rng.random(n) < 0.06                  # a few wild orientations: the rotation histogram has something to drop
+    ang = np.where(flip, rng.uniform(0, 360, n), ang).astype(np.float32)
+    octv = np.clip(kps["octave"].astype(np.int64) + rng.integers(-1, 2, n) * (rng.random(n) < 0.3), 0, 7).astype(np.int32)
+    obs = np.where(rng.random(n) < obs_zero_frac, 0, rng.integers(1, 12, n)).astype(np.int32)
+    tlc_z = float((Rlw @ (-(Rcw.T @ tcw)) + tlw)[2])   # tlc = Tlw * twc (ORBmatcher.cc:1954-1955)
+    mb = cam["mbf"] / cam["fx"]
+    return (dict(has_point=has.astype(np.uint8), pos_w=Pw, octave=octv, angle=ang, desc=cp.astype(np.uint8), obs=obs),
+            _quat_xyzw(Rcw).astype(np.float32), tcw.astype(np.float32), tlc_z > mb, -tlc_z > mb)

@@ -74,3 +74,48 @@ extern "C" void orc_is_in_frustum(const orc_frustum* F, float viewingCosLimit, i
         view_cos[i] = viewCos;
     }
 }
+
+// The per-keypoint projection of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono)
+// (/root/reference/src/ORBmatcher.cc:1951-1990, rectified / Nleft == -1): x3Dc = Tcw * x3Dw, invzc, Pinhole::project, the
+// image-bounds rejections, ur = uv(0) - mbf*invzc (:2019).  Tcw * x3Dw is Sophus' SE3 action,
+//   Thirdparty/Sophus/sophus/se3.hpp:321-324   so3() * p + translation()
+//   Thirdparty/Sophus/sophus/so3.hpp:358-367   uv = q.vec().cross(p); uv += uv; return p + q.w() * uv + q.vec().cross(uv);
+// with Eigen's 3-vector cross product (a1*b2 - a2*b1, a2*b0 - a0*b2, a0*b1 - a1*b0).
+// Float convention — STATED, NOT PINNED (Eigen / Sophus cannot be compiled here): of a difference of two products the first is
+// fused, a*b - c*d -> fma(a, b, -(c*d)); p + w*uv -> fma(w, uv, p); sums stay sums.  A probe of this expression tree with this
+// image's g++ 11 -O3 -march=x86-64-v3 shows the SLP vectoriser choosing fmsub for some components and fnmadd (the SECOND product
+// fused) for others, so no single convention reproduces every build of the reference; the last ulp of u / v decides a match only
+// when a keypoint sits exactly on a window or cell border.  The product keeps msorb_search_by_projection_frames (coordinates
+// projected by the caller's own build) beside the device projection for that reason.
+struct orc_motion_model {
+    float q[4], t[3];
+    float fx, fy, cx, cy, mbf;
+    int forward, backward;
+};
+namespace {
+inline float diff_of_products(float a, float b, float c, float d) { return std::fmaf(a, b, -(c * d)); }
+}
+extern "C" void orc_project_last_frame(const orc_motion_model* M, float min_x, float max_x, float min_y, float max_y, int n,
+                                       const uint8_t* has_point, const float* pos_w, uint8_t* valid, float* u, float* v,
+                                       float* ur) {
+    const float qx = M->q[0], qy = M->q[1], qz = M->q[2], qw = M->q[3];
+    for (int i = 0; i < n; i++) {
+        valid[i] = 0; u[i] = 0; v[i] = 0; ur[i] = 0;
+        if (!has_point[i]) continue;                                           // :1962-1965
+        const float px = pos_w[3 * i], py = pos_w[3 * i + 1], pz = pos_w[3 * i + 2];
+        float uvx = diff_of_products(qy, pz, qz, py), uvy = diff_of_products(qz, px, qx, pz), uvz = diff_of_products(qx, py, qy, px);
+        uvx += uvx; uvy += uvy; uvz += uvz;
+        const float c0 = diff_of_products(qy, uvz, qz, uvy), c1 = diff_of_products(qz, uvx, qx, uvz), c2 = diff_of_products(qx, uvy, qy, uvx);
+        const float xc = (std::fmaf(qw, uvx, px) + c0) + M->t[0];
+        const float yc = (std::fmaf(qw, uvy, py) + c1) + M->t[1];
+        const float zc = (std::fmaf(qw, uvz, pz) + c2) + M->t[2];
+        const float invzc = 1.0 / zc;                                          // :1973 (double quotient, rounded to float)
+        if (invzc < 0) continue;                                               // :1975-1976
+        const float uu = M->fx * xc / zc + M->cx;                              // Pinhole.cpp:45-46
+        const float vv = M->fy * yc / zc + M->cy;
+        if (uu < min_x || uu > max_x) continue;                                // :1980-1983
+        if (vv < min_y || vv > max_y) continue;
+        valid[i] = 1; u[i] = uu; v[i] = vv;
+        ur[i] = std::fmaf(-M->mbf, invzc, uu);                                 // :2019
+    }
+}

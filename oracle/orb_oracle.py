@@ -458,6 +458,28 @@ def is_in_frustum(frustum, pos_w, normal, max_distance, min_distance, viewing_co
                 view_cos=vc[:n])
 
 
+class MotionModel(C.Structure):
+    """layout of msorb_motion_model / orc_motion_model"""
+    _fields_ = [("q", C.c_float * 4), ("t", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("mbf", C.c_float), ("forward", C.c_int), ("backward", C.c_int)]
+
+
+def project_last_frame(mm, bounds, has_point, pos_w):
+    """oracle/frustum_oracle.cc orc_project_last_frame (ORBmatcher.cc:1951-1990, :2019) -> valid, u, v, ur.  `mm`: any ctypes
+    struct with msorb_motion_model's layout; bounds = (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+    Lb = lib()
+    Lb.orc_project_last_frame.argtypes = [C.c_void_p] + [C.c_float] * 4 + [C.c_int] + [C.c_void_p] * 6
+    Lb.orc_project_last_frame.restype = None
+    hp, P = _c(has_point, np.uint8), _c(pos_w, np.float32).reshape(-1, 3)
+    n = len(hp)
+    cap = max(n, 1)
+    valid = np.zeros(cap, np.uint8)
+    u, v, ur = [np.zeros(cap, np.float32) for _ in range(3)]
+    Lb.orc_project_last_frame(C.addressof(mm), *[float(b) for b in bounds], n, _ptr(hp), _ptr(P), _ptr(valid), _ptr(u), _ptr(v),
+                              _ptr(ur))
+    return valid[:n], u[:n], v[:n], ur[:n]
+
+
 def dense_top2(q, t):
     """oracle/matcher_oracle.cc orc_dense_top2 -> (best_idx, best_dist, second_dist)"""
     Lb = _mlib()

@@ -66,3 +66,66 @@ def test_local_map_generator_is_a_tracking_workload(oracle):
     assert nm > 400 and 400 < (frame_mp >= 0).sum() <= nm   # a keypoint holding a point without observations is re-assigned
     oi, od, _ = tc.oracle_topk(oracle, rf, fr, {k: v[:300] for k, v in mp.items()}, 3.0, scale)
     assert (oi[:, 0] >= 0).sum() > 80 and np.all(np.diff(od.astype(np.int64), axis=1)[oi[:, 1:] >= 0] >= 0)
+
+
+def _fma32(a, b, c):
+    """float32 fma: the float64 product of two float32 is exact, the float64 sum with a float32 rounds once to 53 bits and
+    once more to 24 — innocuous unless the sum is a 53-bit tie case of the 24-bit rounding, which this data does not produce
+    (checked by the equality below holding on 10^4 points)."""
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+
+def test_oracle_last_frame_projection_matches_definition(oracle):
+    """orc_project_last_frame (ORBmatcher.cc:1962-1990, :2019) against a numpy restatement of Sophus' SE3 action
+    (so3.hpp:358-367, se3.hpp:321-324) in the stated float convention, and against float64 math within float tolerance."""
+    import msorb
+    from msorb import synth
+    rng = np.random.Generator(np.random.PCG64(12))
+    n = 10000
+    kps = np.zeros(n, KP)
+    kps["x"] = rng.uniform(-30, 1270, n).astype(np.float32)     # some project outside the image
+    kps["y"] = rng.uniform(-20, 396, n).astype(np.float32)
+    kps["octave"] = rng.integers(0, 8, n)
+    kps["angle"] = rng.uniform(0, 360, n)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    depth = np.where(rng.random(n) < 0.6, rng.uniform(3, 50, n), -1).astype(np.float32)
+    last, q, t, fw, bw = synth.last_frame(3, kps, desc, depth, behind_frac=0.05)
+    cam = synth.KITTI_CAM
+    mm = oracle.MotionModel()
+    mm.q[:] = [float(v) for v in q]
+    mm.t[:] = [float(v) for v in t]
+    mm.fx, mm.fy, mm.cx, mm.cy, mm.mbf = cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["mbf"]
+    bounds = (0.0, 1241.0, 0.0, 376.0)
+    valid, u, v, ur = oracle.project_last_frame(mm, bounds, last["has_point"], last["pos_w"])
+    f32 = np.float32
+    qx, qy, qz, qw = [np.full(n, f32(c), f32) for c in q]
+    px, py, pz = [np.ascontiguousarray(last["pos_w"][:, k]) for k in range(3)]
+    dop = lambda a, b, c, d: _fma32(a, b, -(c * d))              # a*b - c*d with the first product fused
+    uvx, uvy, uvz = dop(qy, pz, qz, py), dop(qz, px, qx, pz), dop(qx, py, qy, px)
+    uvx, uvy, uvz = uvx + uvx, uvy + uvy, uvz + uvz
+    c0, c1, c2 = dop(qy, uvz, qz, uvy), dop(qz, uvx, qx, uvz), dop(qx, uvy, qy, uvx)
+    xc = (_fma32(qw, uvx, px) + c0) + f32(t[0])
+    yc = (_fma32(qw, uvy, py) + c1) + f32(t[1])
+    zc = (_fma32(qw, uvz, pz) + c2) + f32(t[2])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        invz = (1.0 / zc.astype(np.float64)).astype(f32)
+        uu = (f32(cam["fx"]) * xc) / zc + f32(cam["cx"])
+        vv = (f32(cam["fy"]) * yc) / zc + f32(cam["cy"])
+    ok = (last["has_point"] > 0) & ~(invz < 0) & ~((uu < bounds[0]) | (uu > bounds[1])) & ~((vv < bounds[2]) | (vv > bounds[3]))
+    assert np.array_equal(valid.astype(bool), ok)
+    assert 0.3 * n < ok.sum() < 0.8 * n and ((last["has_point"] > 0) & ~ok).sum() > 200
+    assert np.array_equal(u[ok].view(np.uint32), uu[ok].view(np.uint32))
+    assert np.array_equal(v[ok].view(np.uint32), vv[ok].view(np.uint32))
+    assert np.array_equal(ur[ok].view(np.uint32), _fma32(np.full(n, -f32(cam["mbf"]), f32), invz, uu)[ok].view(np.uint32))
+    assert (u[~ok] == 0).all() and (ur[~ok] == 0).all()
+    # float64 rotation-matrix math: the same projection within float precision
+    x, y, z, w = [float(c) for c in q]
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    Pc = last["pos_w"].astype(np.float64) @ R.T + t.astype(np.float64)
+    assert np.abs(cam["fx"] * Pc[ok, 0] / Pc[ok, 2] + cam["cx"] - u[ok]).max() < 2e-3
+    # and the generator makes a motion-model workload: projections a few pixels from the keypoints they came from
+    d = np.hypot(u - kps["x"], v - kps["y"])[ok]
+    assert 1.0 < d.mean() < 6.0
+    assert isinstance(fw, (bool, np.bool_)) and isinstance(bw, (bool, np.bool_))

@@ -244,3 +244,168 @@ def test_track_batch_vs_oracle(msorb_mod, oracle, M, th):
     # without the counter the lists are the same
     r2 = msorb_mod.track_batch(d_kps, d_desc, d_ur, counts, 2, BOUNDS, scale, frusta, d_mp, th)
     assert torch.equal(r2["topk_idx"], r["topk_idx"]) and torch.equal(r2["topk_dist"], r["topk_dist"])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# TrackWithMotionModel's search (a14) with the projection on the device: msorb_frame_set_last_points +
+# msorb_search_last_frame / msorb_track_frontend_motion vs the oracle composition orc_project_last_frame +
+# orc_search_by_projection_frames (ORBmatcher.cc:1941-2152; caller Tracking.cc:2833-2870)
+# ----------------------------------------------------------------------------------------------------------------------
+def _motion_model(mod, q, t, forward=False, backward=False):
+    c = synth.KITTI_CAM
+    m = mod.MotionModel()
+    m.q[:] = [float(x) for x in q]
+    m.t[:] = [float(x) for x in t]
+    m.fx, m.fy, m.cx, m.cy, m.mbf = c["fx"], c["fy"], c["cx"], c["cy"], c["mbf"]
+    m.forward, m.backward = int(forward), int(backward)
+    return m
+
+
+def _oracle_last_frame(oracle, rf, last, q, t, forward, backward, cur_mp, th, check_orientation=True, bounds=BOUNDS):
+    omm = _motion_model(oracle, q, t, forward, backward)
+    valid, u, v, ur = oracle.project_last_frame(omm, bounds, last["has_point"], last["pos_w"])
+    n = len(valid)
+    tab = dict(valid=valid, u=u, v=v, ur=ur, octave=last["octave"], angle=last["angle"], desc=last["desc"],
+               mp=np.arange(n, dtype=np.int32), obs=last["obs"])
+    nm = rf.SearchByProjection_frames(tab, cur_mp, th, forward, backward, check_orientation)
+    return nm, dict(valid=valid, u=u, v=v, ur=ur)
+
+
+@pytest.mark.parametrize("th,mode", [(7.0, "none"), (15.0, "none"), (7.0, "forward"), (7.0, "backward"), (15.0, "mono"),
+                                     (14.0, "none"), (30.0, "forward")])
+def test_search_last_frame_device_projection(msorb_mod, oracle, kitti_frame, th, mode):
+    """th = 7 (stereo) / 15 (monocular) and the retry at 2 * th (Tracking.cc:2845-2868); forward / backward level bands
+    (:1993-1998); mono = a frame without mvuRight (no :2015-2022 test, bForward = bBackward = false)."""
+    s = kitti_frame
+    ur = None if mode == "mono" else s["ur"]
+    depth = np.full(len(s["kl"]), -1.0, np.float32) if mode == "mono" else s["dp"]
+    last, q, t, _, _ = synth.last_frame(100 + int(th), s["kl"], s["dl"], depth)
+    fw, bw = mode == "forward", mode == "backward"
+    f = msorb_mod.Frame(s["kl"], s["dl"], ur, BOUNDS, s["scale"])
+    rf = oracle.OracleFrame(s["kl"], s["dl"], ur, BOUNDS, s["scale"])
+    try:
+        mm = _motion_model(msorb_mod, q, t, fw, bw)
+        msorb_mod.frame_set_last_points(f, last)
+        cur = np.full(len(s["kl"]), -1, np.int32)
+        nm, proj = msorb_mod.search_last_frame(f, mm, last["obs"], cur, th, True, want_projection=True)
+        want = np.full(len(s["kl"]), -1, np.int32)
+        wnm, wproj = _oracle_last_frame(oracle, rf, last, q, t, fw, bw, want, th)
+        for k in ("valid", "u", "v", "ur"):
+            a, b = proj[k], wproj[k]
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), k    # bit patterns of the projections
+        assert wnm > 300 and (wproj["valid"] == 0).sum() > 100
+        assert nm == wnm and np.array_equal(cur, want)
+        # the retry of Tracking.cc:2861-2868 on the table already resident: clear, search again at 2 * th
+        cur[:] = -1
+        want[:] = -1
+        nm2 = msorb_mod.search_last_frame(f, mm, last["obs"], cur, 2 * th, True)
+        wnm2, _ = _oracle_last_frame(oracle, rf, last, q, t, fw, bw, want, 2 * th)
+        assert nm2 == wnm2 and np.array_equal(cur, want)
+        # without the orientation check
+        cur[:] = -1
+        want[:] = -1
+        nm3 = msorb_mod.search_last_frame(f, mm, last["obs"], cur, th, False)
+        wnm3, _ = _oracle_last_frame(oracle, rf, last, q, t, fw, bw, want, th, False)
+        assert nm3 == wnm3 >= nm and np.array_equal(cur, want)
+    finally:
+        f.close()
+
+
+def test_search_last_frame_with_points_already_in_the_frame(msorb_mod, oracle, kitti_frame):
+    """The general form of the signature: the current frame already holds map points (ids >= n of the table); those with
+    observations are never overwritten (:2011-2013), the others may be."""
+    s = kitti_frame
+    n = len(s["kl"])
+    last, q, t, _, _ = synth.last_frame(321, s["kl"], s["dl"], s["dp"], pixel_sigma=1.5)
+    rng = np.random.default_rng(5)
+    held = rng.random(n) < 0.3
+    extra_obs = np.where(rng.random(n) < 0.4, 0, rng.integers(1, 9, n)).astype(np.int32)
+    obs = np.concatenate([last["obs"], extra_obs])
+    cur0 = np.where(held, n + np.arange(n), -1).astype(np.int32)
+    f = msorb_mod.Frame(s["kl"], s["dl"], s["ur"], BOUNDS, s["scale"])
+    rf = oracle.OracleFrame(s["kl"], s["dl"], s["ur"], BOUNDS, s["scale"])
+    try:
+        mm = _motion_model(msorb_mod, q, t)
+        msorb_mod.frame_set_last_points(f, last)
+        cur = cur0.copy()
+        nm = msorb_mod.search_last_frame(f, mm, obs, cur, 7.0, True)
+        omm = _motion_model(oracle, q, t)
+        valid, u, v, ur = oracle.project_last_frame(omm, BOUNDS, last["has_point"], last["pos_w"])
+        tab = dict(valid=valid, u=u, v=v, ur=ur, octave=last["octave"], angle=last["angle"], desc=last["desc"],
+                   mp=np.arange(n, dtype=np.int32), obs=obs)
+        want = cur0.copy()
+        wnm = rf.SearchByProjection_frames(tab, want, 7.0, False, False, True)
+        assert nm == wnm and np.array_equal(cur, want)
+        assert (want[held & (extra_obs > 0)] >= n).all()          # protected keypoints kept their points
+        assert ((want >= 0) & (want < n)).sum() > 100
+    finally:
+        f.close()
+
+
+def test_search_last_frame_degenerate_tables(msorb_mod, oracle, kitti_frame):
+    s = kitti_frame
+    n = len(s["kl"])
+    f = msorb_mod.Frame(s["kl"], s["dl"], s["ur"], BOUNDS, s["scale"])
+    try:
+        mm = _motion_model(msorb_mod, [0, 0, 0, 1], [0, 0, 0])
+        cur = np.full(n, -1, np.int32)
+        with pytest.raises(msorb_mod.MsorbError):                 # no table yet
+            msorb_mod.search_last_frame(f, mm, np.zeros(0, np.int32), cur, 7.0)
+        empty = dict(has_point=np.zeros(0, np.uint8), pos_w=np.zeros((0, 3), np.float32), octave=np.zeros(0, np.int32),
+                     angle=np.zeros(0, np.float32), desc=np.zeros((0, 32), np.uint8), obs=np.zeros(0, np.int32))
+        msorb_mod.frame_set_last_points(f, empty)
+        assert msorb_mod.search_last_frame(f, mm, empty["obs"], cur, 7.0) == 0 and (cur == -1).all()
+        # nobody holds a point / everything behind the camera
+        last, q, t, _, _ = synth.last_frame(9, s["kl"], s["dl"], s["dp"], point_frac=0.0)
+        msorb_mod.frame_set_last_points(f, last)
+        assert msorb_mod.search_last_frame(f, _motion_model(msorb_mod, q, t), last["obs"], cur, 7.0) == 0
+        last, q, t, _, _ = synth.last_frame(9, s["kl"], s["dl"], s["dp"], behind_frac=1.0)
+        msorb_mod.frame_set_last_points(f, last)
+        nm, proj = msorb_mod.search_last_frame(f, _motion_model(msorb_mod, q, t), last["obs"], cur, 7.0, want_projection=True)
+        assert nm == 0 and proj["valid"].sum() == 0
+        bad = dict(last, octave=np.full(n, 99, np.int32))
+        with pytest.raises(msorb_mod.MsorbError):
+            msorb_mod.frame_set_last_points(f, bad)
+    finally:
+        f.close()
+
+
+@pytest.mark.parametrize("seed", [21, 3])
+def test_track_frontend_motion_equals_oracle_composition(msorb_mod, oracle, seed):
+    """Frame::Frame + TrackWithMotionModel's SearchByProjection as ONE call from host images; the same as separate calls; both
+    against extraction -> ComputeStereoMatches -> oracle projection -> oracle search."""
+    cfg = synth.KITTI
+    L, R = synth.stereo_pair(seed, cfg["rows"], cfg["cols"])
+    ex = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7)
+    try:
+        kl, dl, kr, dr, ur, dp, oob = ex.extract_stereo(L, R, MB, MBF)
+        scale = ex.GetScaleFactors()
+        last, q, t, _, _ = synth.last_frame(700 + seed, kl, dl, dp)
+        mm = _motion_model(msorb_mod, q, t)
+        f, st, cur, nm = msorb_mod.track_frontend_motion(ex, L, R, MB, MBF, mm, last, last["obs"], 7.0)
+        try:
+            assert np.array_equal(st[0].view(np.uint8), kl.view(np.uint8)) and np.array_equal(st[1], dl)
+            assert np.array_equal(st[4].view(np.uint32), ur.view(np.uint32))
+            rf = oracle.OracleFrame(kl, dl, ur, BOUNDS, scale)
+            want = np.full(len(kl), -1, np.int32)
+            wnm, _ = _oracle_last_frame(oracle, rf, last, q, t, False, False, want, 7.0)
+            assert wnm > 300
+            assert nm == wnm and np.array_equal(cur, want)
+            # the frame handle serves the follow-up searches: retry at 2 * th on the resident table
+            cur2 = np.full(len(kl), -1, np.int32)
+            want[:] = -1
+            nm2 = msorb_mod.search_last_frame(f, mm, last["obs"], cur2, 14.0)
+            wnm2, _ = _oracle_last_frame(oracle, rf, last, q, t, False, False, want, 14.0)
+            assert nm2 == wnm2 and np.array_equal(cur2, want)
+        finally:
+            f.close()
+        r = msorb_mod.MotionFrontendRunner(ex, L, R, MB, MBF, mm, last, last["obs"], 7.0)
+        try:
+            a = r.one_call(); ca = r.cur_mp[:len(kl)].copy()
+            b = r.separate_calls(); cb = r.cur_mp[:len(kl)].copy()
+            c = r.one_call(); cc = r.cur_mp[:len(kl)].copy()
+            assert a == b == c == nm and np.array_equal(ca, cur) and np.array_equal(cb, cur) and np.array_equal(cc, cur)
+        finally:
+            r.close()
+    finally:
+        ex.close()
