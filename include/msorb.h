@@ -208,8 +208,9 @@ void msorb_frame_destroy(msorb_frame* f);
 
 /* Frame members the matcher reads: mvKeysUn, mDescriptors, mvuRight (NULL = all -1), image bounds
  * mnMinX..mnMaxY, mvScaleFactors.  Builds mGrid like Frame::AssignFeaturesToGrid (Frame.cc:385-416,
- * PosInGrid :657-667) — on the device, from the uploaded features (frame_grid_kernel).  Host arrays.  At most 16384 keypoints
- * per frame (MSORB_E_CAPACITY beyond). */
+ * PosInGrid :657-667) — on the device, from the uploaded features (frame_grid_kernel).  Host arrays.  At most 32768 keypoints
+ * per frame on gfx950 (what one workgroup's 160 KB of LDS sorts; MSORB_E_CAPACITY beyond, decided before the handle is
+ * touched).  A call that fails later (allocation, HIP error) leaves the handle EMPTY: no keypoints, an empty grid. */
 int msorb_frame_set(msorb_frame* f, const msorb_keypoint* keypoints, int n, const uint8_t* descriptors,
                     const float* u_right, float min_x, float max_x, float min_y, float max_y,
                     const float* scale_factors, int nlevels);

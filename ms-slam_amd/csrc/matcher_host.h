@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -24,6 +25,8 @@ struct msorb_frame_track;
 namespace msorb {
 void frame_track_release(msorb_frame* f);
 int frame_host_grid(msorb_frame* f);
+int frame_grid_max_keypoints();        // largest keypoint count the device grid takes on the current device (-1: query failed)
+void frame_invalidate(msorb_frame* f);  // a failed set leaves the handle empty, never half new / half old
 // sets the frame's device side (train arrays + grid) from device arrays: enqueue only, on stream s (track.hip)
 int enqueue_frame_from_device(msorb_frame* f, hipStream_t s, const msorb_keypoint* d_kps, const uint8_t* d_desc,
                               const float* d_u_right, const int* d_count, int n_fixed, int n_cap, float min_x, float max_x,
@@ -87,6 +90,7 @@ struct msorb_frame {
     int last_rounds = 0;                // device rounds of the last claim-replaying search (msorb_frame_search_rounds)
     long long total_rounds = 0, total_searches = 0;
     bool host_grid_valid = false;       // cell_begin / cell_idx (host) mirror the device grid
+    std::mutex grid_mu;                 // the lazy fetch of that mirror (msorb_frame_features_in_area is a const query)
     msorb_frame_track* track = nullptr;  // staging of the local-points chain (track.hip)
     msorb::DBuf<msorb::WinQuery> d_q;
     msorb::DBuf<msorb::TopK> d_topk;
@@ -120,7 +124,7 @@ int run_window_search(msorb_frame* f, int M, const WinQuery* q, const uint8_t* f
                       std::vector<uint8_t>& occ, int need, Accept accept, bool ready = false, int* rounds_out = nullptr,
                       const uint8_t* d_qdesc = nullptr, int lanes = 0) {
     if (rounds_out) *rounds_out = 0;
-    if (M <= 0) return MSORB_OK;
+    if (M <= 0 || f->N <= 0) return MSORB_OK;   // no queries / no train keypoints (also a handle whose set failed): no match
     int rc;
     if ((rc = f->d_q.ensure(M)) || (!d_qdesc && (rc = f->d_qdesc.ensure((size_t)M * 32))) || (rc = f->d_topk.ensure(M)) ||
         (rc = f->d_occ.ensure(f->N)))

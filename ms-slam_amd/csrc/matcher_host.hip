@@ -61,9 +61,18 @@ int msorb_frame_set(msorb_frame* f, const msorb_keypoint* kps, int n, const uint
         !(max_x > min_x) || !(max_y > min_y))
         return MSORB_E_INVALID;
     HIPCHK(hipSetDevice(f->device));
-    f->N = n;
-    f->kps.assign(kps, kps + n);
-    if (u_right) f->u_right.assign(u_right, u_right + n); else f->u_right.assign(n, -1.0f);
+    // everything that can refuse the call is checked BEFORE the handle is touched; a failure after that empties it
+    const int limit = frame_grid_max_keypoints();
+    if (limit < 0) return MSORB_E_HIP;
+    if (n > limit) {
+        set_last_error("msorb_frame_set: " + std::to_string(n) + " keypoints, the device grid takes " + std::to_string(limit));
+        return MSORB_E_CAPACITY;
+    }
+    struct Guard {   // any early return below leaves an empty handle
+        msorb_frame* f;
+        bool ok = false;
+        ~Guard() { if (!ok) frame_invalidate(f); }
+    } guard{f};
     // AssignFeaturesToGrid (Frame.cc:385-416) runs on the device (frame_grid_kernel, track.hip): the features are staged as
     // they are — cv::KeyPoint records, descriptor rows, mvuRight — and the kernel derives the train arrays and the grid
     int rc;
@@ -83,6 +92,10 @@ int msorb_frame_set(msorb_frame* f, const msorb_keypoint* kps, int n, const uint
         return rc;
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
+    f->N = n;
+    f->kps.assign(kps, kps + n);
+    if (u_right) f->u_right.assign(u_right, u_right + n); else f->u_right.assign(n, -1.0f);
+    guard.ok = true;
     return MSORB_OK;
 }
 
@@ -101,7 +114,7 @@ int msorb_frame_features_in_area(const msorb_frame* f, float x, float y, float r
     if (!f || !n_out) return MSORB_E_INVALID;
     int n = 0;
     *n_out = 0;
-    if (!f->host_grid_valid) {  // grid built on the device (msorb_frame_set_device / msorb_extract_stereo_frame): fetch it once
+    {   // grid built on the device (msorb_frame_set / _set_device / msorb_extract_stereo_frame): fetched once, under the frame's lock
         HIPCHK(hipSetDevice(f->device));
         const int rc = frame_host_grid(const_cast<msorb_frame*>(f));
         if (rc) return rc;

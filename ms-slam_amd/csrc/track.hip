@@ -114,9 +114,14 @@ __global__ __launch_bounds__(kGridThreads) void frame_grid_kernel(GridArgs A) {
         if (c != 0xFFFF) lst[atomicAdd(&cur[c], 1)] = (uint16_t)i;
     }
     __syncthreads();
-    // the reference pushes indices in ascending order: restore it inside every cell (runs are short: insertion sort)
+    // the reference pushes indices in ascending order: restore it inside every cell.  Short runs (the normal case: about
+    // one keypoint per cell): insertion sort by the cell's thread.  Long runs (keypoints piled up in a cell): one wave per
+    // cell ranks every entry against the run (indices are unique) through cell_of, which is free from here on — a pile of
+    // k keypoints costs k^2 / 64 steps per lane instead of k^2 on one thread.
+    constexpr int kShortRun = 32;
     for (int c = tid; c < kNCell; c += kGridThreads) {
         const int s = cnt[c], e = cnt[c + 1];
+        if (e - s > kShortRun) continue;
         for (int i = s + 1; i < e; i++) {
             const uint16_t v = lst[i];
             int j = i - 1;
@@ -125,17 +130,44 @@ __global__ __launch_bounds__(kGridThreads) void frame_grid_kernel(GridArgs A) {
         }
     }
     __syncthreads();
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int c = wave; c < kNCell; c += kGridThreads / 64) {
+            const int s = cnt[c], e = cnt[c + 1];
+            if (e - s <= kShortRun) continue;   // wave-uniform
+            for (int i = s + lane; i < e; i += 64) {
+                const uint16_t v = lst[i];
+                int r = 0;
+                for (int j = s; j < e; j++) r += lst[j] < v;
+                cell_of[s + r] = v;
+            }
+        }
+        __syncthreads();
+        for (int c = wave; c < kNCell; c += kGridThreads / 64) {
+            const int s = cnt[c], e = cnt[c + 1];
+            if (e - s <= kShortRun) continue;
+            for (int i = s + lane; i < e; i += 64) lst[i] = cell_of[i];
+        }
+    }
+    __syncthreads();
     const int total = cnt[kNCell];
     for (int j = tid; j < total; j += kGridThreads) cell_idx[j] = lst[j];
     if (A.n_out && tid == 0) A.n_out[b] = n;
 }
 
+size_t frame_grid_lds(int n_cap) { return (size_t)(2 * kNCell + 1) * sizeof(int) + (size_t)n_cap * 2 * sizeof(uint16_t) + 256; }
+
 int launch_frame_grid(const GridArgs& A, int n_frames, hipStream_t s) {
-    if (A.dst_stride > 16384) { set_last_error("frame grid: more than 16384 keypoints per frame"); return MSORB_E_CAPACITY; }
-    const size_t lds = (size_t)(2 * kNCell + 1) * sizeof(int) + (size_t)A.dst_stride * 2 * sizeof(uint16_t);
-    if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit (frames of more than ~10 000 keypoints): raise it (per device)
+    const int limit = msorb::frame_grid_max_keypoints();
+    if (limit < 0) return MSORB_E_HIP;
+    if (A.dst_stride > limit) {
+        set_last_error("frame grid: more than " + std::to_string(limit) + " keypoints per frame");
+        return MSORB_E_CAPACITY;
+    }
+    const size_t lds = frame_grid_lds(A.dst_stride) - 256;
+    if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit (frames of more than ~10 000 keypoints): raise it
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(frame_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                96 * 1024) != hipSuccess) {
+                                (int)lds) != hipSuccess) {
             set_last_error("frame grid: cannot raise the dynamic LDS limit");
             return MSORB_E_HIP;
         }
@@ -311,11 +343,34 @@ struct msorb_frame_track {
 };
 
 namespace msorb {
+// Largest keypoint count the grid kernel takes on the current device: its LDS holds 2 x 3073 ints and two uint16 per keypoint
+// (160 KB per workgroup on gfx950 -> 32768; the uint16 indices stop at 65535 anyway).  -1: the attribute query failed.
+int frame_grid_max_keypoints() {
+    int dev = 0, lds_max = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) {
+        set_last_error("frame grid: cannot query the device's LDS size");
+        return -1;
+    }
+    const long long room = (long long)lds_max - (long long)frame_grid_lds(0);
+    return (int)std::max<long long>(0, std::min<long long>(room / (2 * (long long)sizeof(uint16_t)), 32768));
+}
+// A set that failed half way leaves the handle EMPTY — no keypoints, an empty (host-authoritative) grid — never a mix of the
+// new count with old arrays: every search on it finds nothing, msorb_frame_features_in_area returns nothing.
+void frame_invalidate(msorb_frame* f) {
+    f->N = 0;
+    f->kps.clear();
+    f->u_right.clear();
+    f->cell_begin.assign(kNCell + 1, 0);
+    f->cell_idx.clear();
+    f->host_grid_valid = true;
+}
 void frame_track_release(msorb_frame* f) {
     if (f->track) { f->track->release(); delete f->track; f->track = nullptr; }
 }
 // cell_begin / cell_idx on the host (msorb_frame_features_in_area, msorb_frame_grid) for a frame whose grid was built on the device
 int frame_host_grid(msorb_frame* f) {
+    std::lock_guard<std::mutex> lk(f->grid_mu);   // two threads may query one frame: the fetch happens once
     if (f->host_grid_valid) return MSORB_OK;
     const int ncell = kGridCols * kGridRows;
     f->cell_begin.assign(ncell + 1, 0);
@@ -776,7 +831,7 @@ int msorb_extract_stereo_frame(msorb_extractor* h, msorb_frame* f, const uint8_t
     FrameSinkCtx C{f, min_x, max_x, min_y, max_y, scale, extractor_levels(h), nullptr, nullptr, nullptr};
     rc = extract_stereo_sink(h, left, right, rows, cols, stride_left, stride_right, mb, mbf, kps_left, desc_left, n_left, kps_right,
                              desc_right, n_right, capacity, u_right, depth, n_oob, frame_sink, &C);
-    if (rc) { f->N = 0; return rc; }
+    if (rc) { frame_invalidate(f); return rc; }
     finish_frame_host(f, kps_left, *n_left, u_right);
     return MSORB_OK;
 }
@@ -835,7 +890,7 @@ int msorb_track_frontend(msorb_extractor* h, msorb_frame* f, const uint8_t* left
     FrameSinkCtx C{f, min_x, max_x, min_y, max_y, scale, extractor_levels(h), &c, nullptr, nullptr};
     rc = extract_stereo_sink(h, left, right, rows, cols, stride_left, stride_right, mb, mbf, kps_left, desc_left, n_left, kps_right,
                              desc_right, n_right, capacity, u_right, depth, n_oob, frame_sink, &C);
-    if (rc) { f->N = 0; return rc; }
+    if (rc) { frame_invalidate(f); return rc; }
     finish_frame_host(f, kps_left, *n_left, u_right);
     // a new frame holds no map points (Frame.cc:139: mvpMapPoints = vector<MapPoint*>(N, nullptr)): round 0 ran against an
     // all-free occupancy, which the grid kernel cleared on the device
@@ -863,7 +918,7 @@ int msorb_track_frontend_motion(msorb_extractor* h, msorb_frame* f, const uint8_
     FrameSinkCtx C{f, min_x, max_x, min_y, max_y, scale, extractor_levels(h), nullptr, nullptr, &c};
     rc = extract_stereo_sink(h, left, right, rows, cols, stride_left, stride_right, mb, mbf, kps_left, desc_left, n_left, kps_right,
                              desc_right, n_right, capacity, u_right, depth, n_oob, frame_sink, &C);
-    if (rc) { f->N = 0; return rc; }
+    if (rc) { frame_invalidate(f); return rc; }
     finish_frame_host(f, kps_left, *n_left, u_right);
     // a new frame holds no map points: round 0 ran against the all-free occupancy the grid kernel left on the device
     for (int i = 0; i < f->N; i++) cur_mp[i] = -1;
@@ -922,9 +977,15 @@ int msorb_track_batch(int device, int n_frames, const msorb_keypoint* d_keypoint
     static thread_local Scratch S;
     if (S.device != device) {
         S.release();
-        S.device = device;
-        HIPCHK(hipStreamCreateWithFlags(&S.s, hipStreamNonBlocking));
-        for (auto& e : S.ev) HIPCHK(hipEventCreate(&e));
+        S.device = device;   // release() frees on this device; a failure below releases again and leaves device == -1
+        hipError_t e = hipStreamCreateWithFlags(&S.s, hipStreamNonBlocking);
+        for (auto& ev : S.ev)
+            if (e == hipSuccess) e = hipEventCreate(&ev);
+        if (e != hipSuccess) {
+            S.release();
+            set_last_error(std::string("msorb_track_batch: stream / event creation: ") + hipGetErrorString(e));
+            return MSORB_E_HIP;
+        }
     }
     const size_t B = (size_t)n_frames, cap = (size_t)capacity, M = (size_t)m;
     int rc;

@@ -8,6 +8,8 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <stdexcept>
+#include <string>
 #include <cstdlib>
 #include <memory>
 
@@ -59,10 +61,11 @@ ThreadCache& cache() {
     return *g_thread_cache;
 }
 void drop_thread_cache() { g_thread_cache.reset(); }
+// the capability gap is reported like every other failure of the host layer (msorb_host::check throws std::runtime_error): the
+// application decides what to do with a rig this build does not serve; it is never answered with left-camera associations
 [[noreturn]] void unsupported_rig(const char* what) {
-    std::fprintf(stderr, "msorb: %s — the fisheye / two-camera branches (Nleft != -1, ORBmatcher.cc:144-210, 1421-1426) are not "
-                         "served by this build; refusing to return plausible-looking associations\n", what);
-    std::abort();
+    throw std::runtime_error(std::string("msorb: ") + what + " — the fisheye / two-camera branches (Nleft != -1, ORBmatcher.cc:144-210, "
+                             "1421-1426) are not served by this build");
 }
 msorb_host::DeviceFrame<Frame>& device_frame(const Frame& F, bool second = false) {
     ThreadCache& c = cache();

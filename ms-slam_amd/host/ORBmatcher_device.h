@@ -235,6 +235,79 @@ int SearchByProjection(DeviceFrame<FrameT>& dev, FrameT& CurrentFrame, const Fra
     return nmatches;
 }
 
+// The same method with the projection of :1962-1990 ON THE DEVICE (msorb_frame_set_last_points + msorb_search_last_frame):
+// the host gathers what the loop reads of LastFrame — map point present and not an outlier, GetWorldPos(), GetDescriptor(),
+// the keypoint's octave and angle — and the pose as Sophus holds it (unit quaternion + translation); Tcw * x3Dw,
+// Pinhole::project, the bounds tests, the level band, the window search run on the device, the claims and the rotation
+// histogram behind the C ABI.  Float convention of the device projection: include/msorb.h / DESIGN.md — the form above,
+// which projects with the application's own build, stays the default of ORBmatcher::SearchByProjection; this one is for a
+// Tracking that wants the table resident (the retry at 2 * th, Tracking.cc:2861-2868, is `resident = true`: no second upload).
+// Pinhole camera only (mpCamera->getParameter(0..3) = fx, fy, cx, cy).
+template <class FrameT>
+void UploadLastFramePoints(DeviceFrame<FrameT>& dev, const FrameT& LastFrame, std::vector<int>& obs) {
+    const int n = LastFrame.N;
+    std::vector<uint8_t> has(n, 0), desc((size_t)n * 32, 0);
+    std::vector<float> pos((size_t)n * 3, 0.0f), angle(n, 0.0f);
+    std::vector<int> octave(n, 0);
+    obs.assign(n, 0);
+    for (int i = 0; i < n; i++) {
+        const auto& pMP = LastFrame.mvpMapPoints[i];
+        if (!pMP || LastFrame.mvbOutlier[i]) continue;                    // :1962-1965
+        has[i] = 1;
+        const auto x3Dw = pMP->GetWorldPos();
+        pos[3 * i] = x3Dw(0); pos[3 * i + 1] = x3Dw(1); pos[3 * i + 2] = x3Dw(2);
+        octave[i] = LastFrame.mvKeys[i].octave;                           // :1986
+        angle[i] = LastFrame.mvKeysUn[i].angle;                           // :2044
+        obs[i] = pMP->Observations();
+        const auto d = pMP->GetDescriptor();
+        std::memcpy(&desc[(size_t)i * 32], d.template ptr<unsigned char>(0), 32);
+    }
+    check(msorb_frame_set_last_points(dev.get(), n, has.data(), pos.data(), octave.data(), angle.data(), desc.data()),
+          "msorb_frame_set_last_points");
+}
+template <class FrameT>
+msorb_motion_model MotionModelOf(const FrameT& CurrentFrame, const FrameT& LastFrame, bool bMono) {
+    msorb_motion_model m{};
+    const auto Tcw = CurrentFrame.GetPose();
+    const auto twc = Tcw.inverse().translation();
+    const auto Tlw = LastFrame.GetPose();
+    const auto tlc = Tlw * twc;
+    m.forward = tlc(2) > CurrentFrame.mb && !bMono;                        // :1957
+    m.backward = -tlc(2) > CurrentFrame.mb && !bMono;                      // :1958
+    const auto q = Tcw.unit_quaternion();
+    m.q[0] = q.x(); m.q[1] = q.y(); m.q[2] = q.z(); m.q[3] = q.w();
+    const auto t = Tcw.translation();
+    m.t[0] = t(0); m.t[1] = t(1); m.t[2] = t(2);
+    m.fx = CurrentFrame.mpCamera->getParameter(0); m.fy = CurrentFrame.mpCamera->getParameter(1);
+    m.cx = CurrentFrame.mpCamera->getParameter(2); m.cy = CurrentFrame.mpCamera->getParameter(3);
+    m.mbf = CurrentFrame.mbf;
+    return m;
+}
+template <class FrameT>
+int SearchByProjectionDeviceProjected(DeviceFrame<FrameT>& dev, FrameT& CurrentFrame, const FrameT& LastFrame, const float th,
+                                      const bool bMono, const bool mbCheckOrientation, std::vector<int>& lastObs, bool resident = false) {
+    if (!resident) UploadLastFramePoints(dev, LastFrame, lastObs);
+    const msorb_motion_model mm = MotionModelOf(CurrentFrame, LastFrame, bMono);
+    const int nL = LastFrame.N, N = CurrentFrame.N;
+    std::vector<int> obs(lastObs), curMp(N, -1);
+    for (int j = 0; j < N; j++)
+        if (CurrentFrame.mvpMapPoints[j]) {
+            curMp[j] = (int)obs.size();
+            obs.push_back(CurrentFrame.mvpMapPoints[j]->Observations());
+        }
+    const std::vector<int> before(curMp);
+    int nmatches = 0;
+    check(msorb_search_last_frame(dev.get(), &mm, obs.data(), (int)obs.size(), curMp.data(), th, mbCheckOrientation, &nmatches,
+                                  nullptr, nullptr, nullptr, nullptr),
+          "msorb_search_last_frame");
+    for (int j = 0; j < N; j++) {
+        if (curMp[j] == before[j]) continue;
+        if (curMp[j] < 0) CurrentFrame.mvpMapPoints[j] = nullptr;         // removed by the histogram filter (:2143)
+        else if (curMp[j] < nL) CurrentFrame.mvpMapPoints[j] = LastFrame.mvpMapPoints[curMp[j]];   // :2037
+    }
+    return nmatches;
+}
+
 // The projection loop of Tracking::SearchLocalPoints (src/Tracking.cc:3343-3361): mCurrentFrame.isInFrustum(pMP, 0.5)
 // (src/Frame.cc:512-571, pinhole branch) for every local map point that is not already matched in this frame and not
 // bad, in one device call.  Writes the same MapPoint scratch fields, calls IncreaseVisible() and fills

@@ -38,6 +38,14 @@ struct SE3 {                                                                    
     Mat3 rotationMatrix() const { return R; }
     Vec3 translation() const { return t; }
     Vec3 operator*(const Vec3& p) const { const Vec3 x = R * p; return Vec3{{x.v[0] + t.v[0], x.v[1] + t.v[1], x.v[2] + t.v[2]}}; }
+    // Sophus holds the rotation as a unit quaternion; the stand-in derives it from R (w > 0 is all the tests need)
+    struct Quat { float qx, qy, qz, qw; float x() const { return qx; } float y() const { return qy; } float z() const { return qz; } float w() const { return qw; } };
+    Quat unit_quaternion() const {
+        const double w = std::sqrt(std::max(0.0, 1.0 + (double)R.m[0] + R.m[4] + R.m[8])) / 2.0;
+        const double q[4] = {((double)R.m[7] - R.m[5]) / (4 * w), ((double)R.m[2] - R.m[6]) / (4 * w), ((double)R.m[3] - R.m[1]) / (4 * w), w};
+        const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        return Quat{(float)(q[0] / n), (float)(q[1] / n), (float)(q[2] / n), (float)(q[3] / n)};
+    }
     SE3 inverse() const {
         SE3 r;
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.R.m[3 * i + j] = R.m[3 * j + i];
@@ -155,7 +163,7 @@ static int prepass_main(const char* in, const char* out) {
 }
 
 // mode "frames": ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) through msorb_host::SearchByProjection
-static int frames_main(const char* in, const char* out) {
+static int frames_main(const char* in, const char* out, bool device_projected = false) {
     using namespace ORB_SLAM3;
     FILE* f = fopen(in, "rb");
     if (!f) return 3;
@@ -201,6 +209,22 @@ static int frames_main(const char* in, const char* out) {
     }
     msorb_host::DeviceFrame<Frame> dev;
     dev.Upload(C);
+    if (device_projected) {
+        // the projection of :1962-1990 on the device; then the retry of Tracking.cc:2861-2868 at 2 * th on the resident table
+        const msorb_motion_model mm = msorb_host::MotionModelOf(C, L, hdr[3] != 0);
+        std::vector<int> lastObs;
+        const auto before = C.mvpMapPoints;
+        const int nm1 = msorb_host::SearchByProjectionDeviceProjected(dev, C, L, fl[10], hdr[3] != 0, hdr[4] != 0, lastObs);
+        FILE* o = fopen(out, "wb");
+        fwrite(&nm1, 4, 1, o); fwrite(&mm.forward, 4, 1, o); fwrite(&mm.backward, 4, 1, o); fwrite(mm.q, 4, 4, o); fwrite(mm.t, 4, 3, o);
+        for (int j = 0; j < N; j++) { const int v = C.mvpMapPoints[j] ? C.mvpMapPoints[j]->id : -1; fwrite(&v, 4, 1, o); }
+        C.mvpMapPoints = before;
+        const int nm2 = msorb_host::SearchByProjectionDeviceProjected(dev, C, L, 2 * fl[10], hdr[3] != 0, hdr[4] != 0, lastObs, true);
+        fwrite(&nm2, 4, 1, o);
+        for (int j = 0; j < N; j++) { const int v = C.mvpMapPoints[j] ? C.mvpMapPoints[j]->id : -1; fwrite(&v, 4, 1, o); }
+        fclose(o);
+        return 0;
+    }
     msorb_host::LastFrameProjection P;
     msorb_host::ProjectLastFrame(C, L, hdr[3] != 0, P);
     const int nm = msorb_host::SearchByProjection(dev, C, L, fl[10], hdr[3] != 0, hdr[4] != 0);
@@ -336,6 +360,7 @@ int main(int argc, char** argv) {
     if (argc > 3 && std::string(argv[3]) == "prepass") return prepass_main(argv[1], argv[2]);
     if (argc > 3 && std::string(argv[3]) == "reloc") return reloc_main(argv[1], argv[2]);
     if (argc > 3 && std::string(argv[3]) == "frames") return frames_main(argv[1], argv[2]);
+    if (argc > 3 && std::string(argv[3]) == "frames_dev") return frames_main(argv[1], argv[2], true);
     FILE* f = fopen(argv[1], "rb");
     if (!f) return 3;
     const auto hdr = rd<int>(f, 4);  // N, nlevels, M, bFarPoints

@@ -4,6 +4,7 @@
 // the drop-in ORBmatcher class can be compiled and exercised where OpenCV / Eigen / Sophus are absent (this image, the GPU
 // box).  They are never used to build reference sources.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <map>
 #include <memory>
@@ -74,6 +75,14 @@ struct SE3f {
     Eigen::Matrix3f rotationMatrix() const { return R; }
     Eigen::Vector3f translation() const { return t; }
     SO3f so3() const { return SO3f{}; }
+    // Sophus holds the rotation as a unit quaternion; the stand-in derives it from R (w >= 0 branch is all the tests need)
+    struct Quat { float qx, qy, qz, qw; float x() const { return qx; } float y() const { return qy; } float z() const { return qz; } float w() const { return qw; } };
+    Quat unit_quaternion() const {
+        const double w = std::sqrt(std::max(0.0, 1.0 + (double)R.m[0] + R.m[4] + R.m[8])) / 2.0;
+        double q[4] = {((double)R.m[7] - R.m[5]) / (4 * w), ((double)R.m[2] - R.m[6]) / (4 * w), ((double)R.m[3] - R.m[1]) / (4 * w), w};
+        const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        return Quat{(float)(q[0] / n), (float)(q[1] / n), (float)(q[2] / n), (float)(q[3] / n)};
+    }
     SE3f operator*(const SE3f& o) const { return SE3f(R * o.R, R * o.t + t); }
     Eigen::Vector3f operator*(const Eigen::Vector3f& p) const { return R * p + t; }
     SE3f inverse() const { const Eigen::Matrix3f Rt = R.transpose(); const Eigen::Vector3f x = Rt * t; return SE3f(Rt, Eigen::Vector3f{{-x.v[0], -x.v[1], -x.v[2]}}); }

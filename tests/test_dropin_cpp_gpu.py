@@ -479,6 +479,30 @@ def test_cpp_search_by_projection_frames_adapter_matches_oracle(tmp_path, oracle
     want = np.where(cur >= NL, -2, cur)                 # the C++ side reports -2 for a point it held before and kept
     assert nm == wn and nm > 100
     assert got.tolist() == want.tolist()
+    # the same call with the projection on the device (msorb_host::SearchByProjectionDeviceProjected): the oracle gets the
+    # quaternion / translation the C++ side took from the pose and projects with orc_project_last_frame
+    subprocess.check_call([str(exe), str(tmp_path / "fr.bin"), str(tmp_path / "frd_out.bin"), "frames_dev"])
+    blob = (tmp_path / "frd_out.bin").read_bytes()
+    nm1, fwd1, bwd1 = struct.unpack_from("<iii", blob, 0)
+    qt = np.frombuffer(blob, np.float32, 7, 12)
+    got1 = np.frombuffer(blob, np.int32, N, 40)
+    nm2 = struct.unpack_from("<i", blob, 40 + 4 * N)[0]
+    got2 = np.frombuffer(blob, np.int32, N, 44 + 4 * N)
+    assert (fwd1, bwd1) == (fwd, bwd)
+    omm = oracle.MotionModel()
+    omm.q[:] = [float(x) for x in qt[:4]]
+    omm.t[:] = [float(x) for x in qt[4:]]
+    omm.fx, omm.fy, omm.cx, omm.cy, omm.mbf = fx, fy, cx, cy, mbf
+    pvalid, pu, pv, pur = oracle.project_last_frame(omm, bounds, ((has > 0) & (outl == 0)).astype(np.uint8), Xw)
+    assert np.abs(pu[pvalid > 0] - u64[pvalid > 0]).max() < 2e-2
+    for th_k, nm_k, got_k in ((th, nm1, got1), (2 * th, nm2, got2)):
+        cur = np.full(N, -1, np.int32)
+        cur[hk] = NL + np.arange(len(hk))
+        last = dict(valid=pvalid, u=pu, v=pv, ur=pur, octave=lk["octave"], angle=lk["angle"], desc=mdesc,
+                    mp=np.arange(NL, dtype=np.int32), obs=obs_all)
+        wn = rf.SearchByProjection_frames(last, cur, th_k, bool(fwd), bool(bwd), bool(ori))
+        assert nm_k == wn and nm_k > 100
+        assert got_k.tolist() == np.where(cur >= NL, -2, cur).tolist()
 
 
 def test_cpp_fuse_adapter_matches_oracle(tmp_path, oracle, msorb_mod):

@@ -61,7 +61,7 @@ def test_device_grid_matches_oracle_on_extracted_frames(msorb_mod, oracle, kitti
     _grid_equal(msorb_mod, oracle, s["kr"], s["dr"], None, BOUNDS, s["scale"])
 
 
-@pytest.mark.parametrize("seed,n", [(1, 0), (2, 1), (3, 64), (4, 2000), (5, 5000), (6, 16000)])
+@pytest.mark.parametrize("seed,n", [(1, 0), (2, 1), (3, 64), (4, 2000), (5, 5000), (6, 16000), (7, 20000), (8, 32768)])
 def test_device_grid_random_keypoints(msorb_mod, oracle, seed, n):
     """Keypoints anywhere, including outside the bounds, exactly on cell borders (x.5 products), and piled up in a few cells
     (long runs exercise the in-cell order restoration)."""
@@ -409,3 +409,27 @@ def test_track_frontend_motion_equals_oracle_composition(msorb_mod, oracle, seed
             r.close()
     finally:
         ex.close()
+
+
+def test_frame_set_beyond_the_grid_capacity_leaves_an_empty_handle(msorb_mod, oracle, kitti_frame):
+    """A refused msorb_frame_set (more keypoints than the device grid takes) must not leave the handle half new / half old:
+    the call fails before anything is touched, and a handle whose set failed half way is EMPTY — area queries and searches
+    find nothing instead of indexing stale arrays."""
+    s = kitti_frame
+    f = msorb_mod.Frame(s["kl"], s["dl"], s["ur"], BOUNDS, s["scale"])
+    try:
+        before = f.GetFeaturesInArea(600.0, 180.0, 60.0)
+        assert len(before) > 5
+        n = 40000
+        kps = np.zeros(n, msorb_mod.KP_DTYPE)
+        kps["x"], kps["y"] = 10.0, 10.0
+        desc = np.zeros((n, 32), np.uint8)
+        L = msorb_mod._mlib()
+        sf = np.asarray(s["scale"], np.float32)
+        rc = L.msorb_frame_set(f.h, msorb_mod._np_ptr(kps), n, msorb_mod._np_ptr(desc), None, BOUNDS[0], BOUNDS[1], BOUNDS[2], BOUNDS[3],
+                               msorb_mod._np_ptr(sf), len(sf))
+        assert rc == msorb_mod.E_CAPACITY
+        # refused up front: the previous frame is still there, intact
+        assert f.GetFeaturesInArea(600.0, 180.0, 60.0).tolist() == before.tolist()
+    finally:
+        f.close()
