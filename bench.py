@@ -631,7 +631,7 @@ def main():
         # one sub-batch per handle: the concurrency comes from the two batches (measured: 1.35 ms per step against 1.51 with two
         # sub-batches per handle — six streams on four hardware queues — and 1.44 for the one-batch-at-a-time loop)
         for e in exp:
-            e.set_overlap(int(os.environ.get("MSORB_GROUPS", "1")), True)
+            e.set_overlap(1, True)
     outs = [(d_kps, d_desc)] + [(torch.empty_like(d_kps), torch.empty_like(d_desc)) for _ in range(depth - 1)]
     inflight = []
     stagger_s = float(os.environ.get("MSORB_BENCH_STAGGER_US", "0")) * 1e-6 if pipelined else 0.0
@@ -737,12 +737,9 @@ def main():
         ceil_valu = 1024 * 2.4e9 * 64 / (8 * 2.5 + 8 * 4.2) / 1e9
         ceil_valu_top2 = 1024 * 2.4e9 * 64 / (8 * 2.5 + 11 * 4.2) / 1e9
         # the north_star's own formulation (xor + __builtin_popcount per pair, no MFMA) measured beside it on the same descriptors
-        os.environ["MSORB_DENSE_VARIANT"] = "24"
-        try:
-            msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=2, device=local)
-            bi_v, bd_v, sd_v, ms_v = msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=reps, device=local)
-        finally:
-            del os.environ["MSORB_DENSE_VARIANT"]
+        msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=2, device=local, formulation=msorb.DENSE_POPCOUNT)
+        bi_v, bd_v, sd_v, ms_v = msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=reps, device=local,
+                                                                formulation=msorb.DENSE_POPCOUNT)
         bi_m, bd_m, sd_m, _ = msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=1, device=local)
         # rows >= nq[f] of a frame are never written by either kernel: only the valid rows are results
         live = torch.arange(dq.shape[1], device=dev)[None, :] < nq[:, None]
@@ -760,7 +757,7 @@ def main():
                    "bound": "matrix-core issue (MFMA) with the top-2 bookkeeping (v_med3 + v_min per pair) interleaved under it; "
                             "not HBM: (Q+T)*32 B per frame are reused Q*T times",
                    "popcount_kernel": {"what": "the north_star's formulation: dense_top2_kernel<2, 4>, v_xor + accumulating v_bcnt per "
-                                               "dword, no MFMA (MSORB_DENSE_VARIANT=24); same inputs, same launch count",
+                                               "dword, no MFMA (formulation MSORB_DENSE_POPCOUNT); same inputs, same launch count",
                                        "gpairs_per_s": round(g_v, 2), "ms_per_launch": round(ms_v / reps, 4),
                                        "frac_of_valu_ceiling_with_top2": round(g_v / ceil_valu_top2, 3),
                                        "identical_results": same_kernels}}

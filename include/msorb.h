@@ -178,14 +178,6 @@ int msorb_debug_copy_level(msorb_extractor* h, int image, int level, int blurred
 /* FAST candidates handed to the quadtree (vToDistributeKeys, ORBextractor.cc:795-869) of one image
  * and level, reference order; coordinates relative to (16,16); xyscore[3*i..3*i+2]. */
 int msorb_debug_candidates(msorb_extractor* h, int image, int level, int* xyscore, int capacity, int* n);
-/* Which form of the FAST stage the last call ran: 0 = one workgroup per reference cell (fast_cells_kernel), 1 = one workgroup
- * per strip of up to four adjacent cells (fast_strip_kernel: MSORB_FAST_STRIP=1, on geometries whose cells fit it and 4-byte
- * aligned rows; fewer instructions, slower alone on the GPU: an option).  Both produce the same candidates. */
-int msorb_debug_fast_form(const msorb_extractor* h);
-/* Which form of the 7 x 7 Gaussian the last call ran: 0 = VALU kernels, 1 = the matrix-core kernel (gauss7_mfma_kernel: 16-byte
- * aligned planes; MSORB_BLUR_MFMA=0 / 1).  Both produce the same planes. */
-int msorb_debug_blur_form(const msorb_extractor* h);
-
 /* Host-only: DistributeOctTree (ORBextractor.cc:555-779) on explicit candidates; writes the indices of
  * the kept candidates in result order.  Needs no GPU. */
 int msorb_distribute_quadtree(const uint16_t* xs, const uint16_t* ys, const uint16_t* scores, int n, int min_x,
@@ -344,24 +336,22 @@ int msorb_hamming_top2(int device, const uint8_t* query_desc, int n_queries, con
                        const int* cand_begin, const int* cand_idx, int* best_idx, int* best_dist, int* second_idx,
                        int* second_dist);
 
-/* Dense brute-force top-2 Hamming match, batched and device resident (the knnMatch(k=2) shape of Frame.cc:1076
- * and the dense mode of the matcher kernels): for each of n_frames frames, every query row against every train
- * row of the same frame; candidates scanned in index order with strict '<' (ties -> lowest index).  d_* are
- * DEVICE pointers: descriptors [n_frames][stride][32], counts [n_frames], outputs [n_frames][query_stride].
+/* Dense brute-force top-2 Hamming match, batched and device resident (the "brute-force Hamming match" of BASELINE.json's
+ * metric): for each of n_frames frames, every query row against every train row of the same frame with
+ * ORBmatcher::DescriptorDistance (ORBmatcher.cc:2323-2339); candidates scanned in index order with strict '<' (ties -> lowest
+ * index).  d_* are DEVICE pointers: descriptors [n_frames][stride][32], counts [n_frames], outputs [n_frames][query_stride]
+ * (rows past a frame's query count are not written).  Two formulations with identical results:
+ *   MSORB_DENSE_MATRIX_CORES  distances as int8 dot products (v_mfma_i32_32x32x32_i8; the accumulator is the (distance, index)
+ *                             key) — 2.9x the rate of the popcount form; a deviation from BASELINE north_star's "no MFMA"
+ *   MSORB_DENSE_POPCOUNT      v_xor + v_bcnt per dword, the north_star's own formulation
  * The launch is repeated `repeats` times on a private stream between two HIP events; *elapsed_ms (may be NULL)
  * receives the total.  max_train <= 2048. */
+#define MSORB_DENSE_MATRIX_CORES 0
+#define MSORB_DENSE_POPCOUNT 1
 int msorb_hamming_dense_top2_batch(int device, const uint8_t* d_query, const uint8_t* d_train, const int* d_n_query,
                                    const int* d_n_train, int n_frames, int query_stride, int train_stride, int max_query,
                                    int max_train, int* d_best_idx, int* d_best_dist, int* d_second_dist, int repeats,
-                                   float* elapsed_ms);
-
-/* cv::BFMatcher(cv::NORM_HAMMING).knnMatch(query, train, matches, 2) — the brute-force step of
- * Frame::ComputeStereoFishEyeMatches (Frame.cc:1057-1076: left vs right descriptors of the lapping area) — on HOST arrays of
- * 32-byte rows: best_idx / best_dist = matches[i][0] (trainIdx, distance), second_dist (and second_idx, may be NULL) =
- * matches[i][1]; ties go to the lower train index.  -1 / 256 where the train set has fewer than one / two rows.  The Lowe
- * ratio test and KannalaBrandt8::TriangulateMatches of :1082-1098 stay with the caller. */
-int msorb_knn_match2(int device, const uint8_t* query, int n_query, const uint8_t* train, int n_train, int* best_idx,
-                     int* best_dist, int* second_idx, int* second_dist);
+                                   int formulation, float* elapsed_ms);
 
 /* Frame::ComputeStereoMatches (Frame.cc:743-913).  left/right are the two extractor handles whose last
  * msorb_extract() call produced the images' pyramids (mpORBextractorLeft/Right->mvImagePyramid stay on

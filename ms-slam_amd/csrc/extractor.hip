@@ -165,11 +165,13 @@ struct msorb_extractor {
     OrbParams P;
     Semantics sem;   // msorb_extractor_set_semantics: variants of the [OpenCV-recall] primitives (defaults = SURVEY.md Appendix A)
     hipStream_t stream = nullptr, copy_stream = nullptr;
-    // msorb_extract (one host image per call) replays the whole chain — H2D, ~20 kernels on two streams, D2H — as ONE
-    // captured HIP graph: per frame the kernels are microseconds long and the launch calls dominate the host side
-    struct FrameGraph { hipGraphExec_t exec = nullptr; int lap0 = 0, lap1 = 0, rows = 0, cols = 0; };
-    FrameGraph fgraph[2];        // two cached variants (e.g. mono + stereo lapping settings)
-    bool capturing = false;      // enqueue only: no host synchronisation inside the pipeline
+    // Environment switches, read ONCE when the handle is created (README.md lists them): MSORB_SERIAL_PIPELINE (one stream,
+    // host-synchronised stages: debugging), MSORB_QUADTREE=host (DistributeOctTree on the host twin), MSORB_HOST_THREADS (its
+    // worker threads), MSORB_SPLIT_NO_PEER (test hook: the two-device gather staged through the host), MSORB_FORCE_PEER_PYRAMID
+    // (test hook: msorb_stereo_matches pulls the right pyramid over the peer path even on one device)
+    struct Knobs { bool serial_pipeline = false, quadtree_host = false, split_no_peer = false, force_peer_pyramid = false; int host_threads = 0; } knobs;
+    int lds_per_block = 64 * 1024;   // hipDeviceAttributeMaxSharedMemoryPerBlock of the handle's device
+    static constexpr bool capturing = false;   // (no graph capture: plain launches; see tools/experiments/README.md)
     bool defer_sync = false;     // enqueue only, the caller appends more work and synchronises (msorb_extract[_stereo])
     bool last_prof = false;      // the stage events of the last run_pipeline_groups() call were recorded
     int pending_batch = 0;       // images of a batch enqueued by msorb_extract_batch_submit and not yet waited for
@@ -188,7 +190,6 @@ struct msorb_extractor {
     hipEvent_t ev_pyr_done = nullptr;
     bool h_pyr_async = false;  // h_pyr holds levels 1.. of the last msorb_extract call, level 0 = h_img_pin
     unsigned long long buffers_epoch = 0;  // bumped whenever a device / pinned buffer may have moved
-    unsigned long long graph_epoch = 0;
     hipEvent_t ev_compact = nullptr, ev_pyramid = nullptr, ev_blur = nullptr;
     hipEvent_t pe[10] = {};
     bool profiling = false;
@@ -204,7 +205,6 @@ struct msorb_extractor {
     DevBuf<ResizeTap> d_taps;
     std::vector<size_t> tap_x_off, tap_y_off;
     DevBuf<CellDesc> d_cells;
-    DevBuf<StripDesc> d_strips;   // strip form of the cell table (empty geometry.strips: the per-cell kernel only)
     DevBuf<int> d_level_cell_begin, d_cell_count, d_cell_off, d_level_count, d_img_total, d_img_base, d_sel_count;
     DevBuf<Cand16> d_slots, d_compact;
     DevBuf<SelRec> d_sel;
@@ -214,8 +214,6 @@ struct msorb_extractor {
     QtLevels qt{};
     bool device_quadtree = true;
     bool small_cells = false;  // every cell ROI <= 46 x 57: the FAST kernel's compact LDS geometry applies
-    int last_fast_form = 0;    // 1: the last call's FAST stage ran as strips of cells
-    int last_blur_form = 0;    // 1: the last call's blur ran on the matrix cores
     bool compact_on_host = false;  // h_compact / h_level_count / h_img_base hold the last call's candidates
     // pinned host state
     PinBuf<int> h_level_count, h_img_base, h_sel_count, h_mono;
@@ -241,18 +239,6 @@ namespace {
 // check): a level returns up to max(quota + 3, 4 * nIni) keypoints, nIni = round(width / height) <= 4 for every camera the
 // reference is configured for.  16 more rows per level cover that whatever the quota (tiny nfeatures on wide images).
 int capacity_of(const msorb_extractor* h) { return h->P.nfeatures + (3 + 16) * h->P.nlevels; }
-
-// FAST as strips of cells (fast_strip_kernel) or per cell (fast_cells_kernel, the default).  MSORB_FAST_STRIP=1 selects the strip
-// form where the geometry allows (read per call: the tests run both forms in one process).  Measured on 256 KITTI images: 10 %
-// fewer VALU instructions (293 M against 326 M) and 0.8-2.6 % more keypoints/s with two batches in flight, but 10 % slower alone
-// on the GPU (0.536 against 0.487 ms: per list entry the arc loop pays for the corner compaction and the per-cell columns) — so
-// it stays an option.
-bool use_fast_strips(const msorb_extractor* h, int n_images) {
-    (void)n_images;
-    if (h->G.strips.empty()) return false;
-    const char* e = getenv("MSORB_FAST_STRIP");
-    return e && atoi(e) != 0;
-}
 
 int ensure_geometry(msorb_extractor* h, int rows, int cols) {
     if (h->geom_valid && h->G.rows == rows && h->G.cols == cols) return MSORB_OK;
@@ -286,10 +272,6 @@ int ensure_geometry(msorb_extractor* h, int rows, int cols) {
     if (!all.empty()) HIPCHK(hipMemcpy(h->d_taps.p, all.data(), all.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
     if ((rc = h->d_cells.ensure(g.cells.size()))) return rc;
     HIPCHK(hipMemcpy(h->d_cells.p, g.cells.data(), g.cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
-    if (!g.strips.empty()) {
-        if ((rc = h->d_strips.ensure(g.strips.size()))) return rc;
-        HIPCHK(hipMemcpy(h->d_strips.p, g.strips.data(), g.strips.size() * sizeof(StripDesc), hipMemcpyHostToDevice));
-    }
     h->level_cell_begin.assign(g.nlevels + 1, 0);
     for (int l = 0; l < g.nlevels; l++) h->level_cell_begin[l] = g.lv[l].cell_begin;
     h->level_cell_begin[g.nlevels] = (int)g.cells.size();
@@ -308,10 +290,9 @@ int ensure_geometry(msorb_extractor* h, int rows, int cols) {
         sel_off += std::max(lg.quota, h->qt.n_ini[l]) + 8 + 4 * h->qt.n_ini[l];
     }
     h->sel_stride = sel_off;
-    {
-        const char* e = getenv("MSORB_QUADTREE");
-        h->device_quadtree = !(e && std::string(e) == "host") && quadtree_lds_bytes(h->qt) <= 150 * 1024;   // one workgroup's LDS (160 KB per CU on gfx950): nfeatures up to ~8000
-    }
+    // the device quadtree keeps a level's candidates in one workgroup's LDS (160 KB per CU on gfx950: nfeatures up to ~8000);
+    // beyond the device's limit the host twin takes over
+    h->device_quadtree = !h->knobs.quadtree_host && (long long)quadtree_lds_bytes(h->qt) + 10 * 1024 <= (long long)h->lds_per_block;
     h->geom_valid = true;
     h->last_n_images = 0;
     return MSORB_OK;
@@ -443,8 +424,6 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
     h->compact_on_host = false;
     h->last_groups = ng;
     h->last_prof = prof;
-    static const bool stagger_env = getenv("MSORB_STAGGER") != nullptr;  // measured: no gain (2.648 vs 2.653 ms), off by default
-    const bool stagger = stagger_env && ng > 1;
     // sub-batches on streams of their own must not start before the handle's stream has drained (H2D of level 0 in
     // msorb_extract); a single group runs on that very stream, where the order is implicit — and the launches below are
     // then issued while the copy is still in flight instead of after it
@@ -488,31 +467,22 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
             h->h_pyr_async = true;
         }
         mark(7, sb);
-        h->last_blur_form = launch_gauss7(pyr, blur, n, sb, h->sem);
+        (void)launch_gauss7(pyr, blur, n, sb, h->sem);
         mark(8, sb);
         if (h->overlap_blur) HIPCHK(hipEventRecord(G.ev_blur, sb));
-        // optional (MSORB_STAGGER): run the sub-batches' FAST kernels one after the other, so that the memory- and
-        // latency-bound stages of one sub-batch sit beside another one's FAST instead of two FAST kernels in lock-step
-        if (stagger && gi > 0) HIPCHK(hipStreamWaitEvent(s, h->grp[gi - 1].ev_fast, 0));
-        const bool strips = use_fast_strips(h, n) &&
-                            launch_fast_strips(pyr, h->d_strips.p, (int)g.strips.size(), g.strip_n_small, g.strip_max_rh, g.strip_work_cap, ncells, h->P.ini_th,
-                                               h->P.min_th, g.slots_per_image, h->d_slots.p + cslot,
-                                               h->d_cell_count.p + (size_t)first * ncells, n, s);
-        h->last_fast_form = strips ? 1 : 0;
-        if (!strips)
         launch_fast_cells(pyr, h->d_cells.p, ncells, h->P.ini_th, h->P.min_th, g.slots_per_image, h->d_slots.p + cslot,
                           h->d_cell_count.p + (size_t)first * ncells, n, h->small_cells, s);
         mark(2, s);
-        if (stagger) HIPCHK(hipEventRecord(G.ev_fast, s));
         launch_cand_compact(h->d_cells.p, ncells, h->d_level_cell_begin.p, nl, g.slots_per_image, h->d_slots.p + cslot,
                             h->d_cell_count.p + (size_t)first * ncells, h->d_cell_off.p + (size_t)first * ncells,
                             h->d_level_count.p + (size_t)first * nl, h->d_img_total.p + first, img_base,
                             h->d_compact.p + cslot, n, s);
         mark(3, s);
-        launch_quadtree(h->qt, h->d_compact.p + cslot, img_base, h->d_level_count.p + (size_t)first * nl,
-                        h->d_label.p + cslot, h->d_sel_pt.p + (size_t)first * sel_stride, h->d_sel_n.p + (size_t)first * nl,
-                        sel_stride, h->scales, lap0, lap1, capacity, h->d_sel.p + (size_t)first * sel_stride,
-                        h->d_sel_count.p + first, h->d_mono.p + first, n, s);
+        if ((rc = launch_quadtree(h->qt, h->d_compact.p + cslot, img_base, h->d_level_count.p + (size_t)first * nl,
+                                  h->d_label.p + cslot, h->d_sel_pt.p + (size_t)first * sel_stride, h->d_sel_n.p + (size_t)first * nl,
+                                  sel_stride, h->scales, lap0, lap1, capacity, h->d_sel.p + (size_t)first * sel_stride,
+                                  h->d_sel_count.p + first, h->d_mono.p + first, n, s)))
+            return rc;
         mark(5, s);
         if (h->overlap_blur) HIPCHK(hipStreamWaitEvent(s, G.ev_blur, 0));
         launch_describe(pyr, blur, h->d_sel.p + (size_t)first * sel_stride, h->d_sel_count.p + first, sel_stride, h->scales,
@@ -532,7 +502,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
 // The pipeline proper.  level0: where level 0 of every image lives (device memory).
 int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int lap0, int lap1,
                  msorb_keypoint* d_kps, uint8_t* d_desc, int capacity, int* h_counts, int* h_mono) {
-    if (h->device_quadtree && !getenv("MSORB_SERIAL_PIPELINE"))
+    if (h->device_quadtree && !h->knobs.serial_pipeline)
         return run_pipeline_groups(h, level0, n_images, lap0, lap1, d_kps, d_desc, capacity, h_counts, h_mono);
     h->last_groups = 1;
     const FrameGeom& g = h->G;
@@ -552,20 +522,15 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
     mark(1);
     // the blur only feeds the descriptor stage: unless stage timing is on, it runs on the second stream, overlapping
     // the (VALU-bound) FAST kernel and the (latency-bound) quadtree with a bandwidth-bound kernel
-    const bool overlap_blur = !(getenv("MSORB_SERIAL_BLUR") != nullptr);
+    const bool overlap_blur = h->overlap_blur;
     if (overlap_blur) {
         HIPCHK(hipEventRecord(h->ev_pyramid, s));
         HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_pyramid, 0));
         if (prof) (void)hipEventRecord(h->pe[7], h->copy_stream);
-        h->last_blur_form = launch_gauss7(pyr, blur, n_images, h->copy_stream, h->sem);
+        (void)launch_gauss7(pyr, blur, n_images, h->copy_stream, h->sem);
         if (prof) (void)hipEventRecord(h->pe[8], h->copy_stream);
         HIPCHK(hipEventRecord(h->ev_blur, h->copy_stream));
     }
-    const bool strips = use_fast_strips(h, n_images) &&
-                        launch_fast_strips(pyr, h->d_strips.p, (int)g.strips.size(), g.strip_n_small, g.strip_max_rh, g.strip_work_cap, ncells, h->P.ini_th,
-                                           h->P.min_th, g.slots_per_image, h->d_slots.p, h->d_cell_count.p, n_images, s);
-    h->last_fast_form = strips ? 1 : 0;
-    if (!strips)
     launch_fast_cells(pyr, h->d_cells.p, ncells, h->P.ini_th, h->P.min_th, g.slots_per_image, h->d_slots.p,
                       h->d_cell_count.p, n_images, h->small_cells, s);
     mark(2);
@@ -574,7 +539,7 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
                         h->d_compact.p, n_images, s);
     mark(3);
     HIPCHK(hipEventRecord(h->ev_compact, s));
-    if (!overlap_blur) h->last_blur_form = launch_gauss7(pyr, blur, n_images, s, h->sem);
+    if (!overlap_blur) (void)launch_gauss7(pyr, blur, n_images, s, h->sem);
     mark(4);
     h->compact_on_host = false;
     const int sel_stride = h->sel_stride;
@@ -582,9 +547,10 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
 
     if (h->device_quadtree) {
         // selection stays on the device: quadtree per (level, image), output layout per image
-        launch_quadtree(h->qt, h->d_compact.p, h->d_img_base.p, h->d_level_count.p, h->d_label.p, h->d_sel_pt.p,
-                        h->d_sel_n.p, sel_stride, h->scales, lap0, lap1, capacity, h->d_sel.p, h->d_sel_count.p,
-                        h->d_mono.p, n_images, s);
+        const int qrc = launch_quadtree(h->qt, h->d_compact.p, h->d_img_base.p, h->d_level_count.p, h->d_label.p, h->d_sel_pt.p,
+                                        h->d_sel_n.p, sel_stride, h->scales, lap0, lap1, capacity, h->d_sel.p, h->d_sel_count.p,
+                                        h->d_mono.p, n_images, s);
+        if (qrc) return qrc;
         mark(5);
         if (overlap_blur) HIPCHK(hipStreamWaitEvent(s, h->ev_blur, 0));
         launch_describe(pyr, blur, h->d_sel.p, h->d_sel_count.p, sel_stride, h->scales, d_kps, d_desc, capacity,
@@ -693,6 +659,7 @@ int extractor_last_view(msorb_extractor* h, PyramidView* pyr, LevelScale* sc, fl
     return MSORB_OK;
 }
 int extractor_device(const msorb_extractor* h) { return h->device; }
+bool extractor_force_peer_pyramid(const msorb_extractor* h) { return h->knobs.force_peer_pyramid; }
 int extractor_levels(const msorb_extractor* h) { return h->P.nlevels; }
 }  // namespace msorb
 
@@ -734,7 +701,7 @@ int msorb_extractor_create(int nfeatures, float scale_factor, int nlevels, int i
     // third, high-priority stream per handle: 1.54 ms, six streams on four hardware queues serialise; one handle above the other.)
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    const int prio_blur = getenv("MSORB_PRIO_BLUR") ? atoi(getenv("MSORB_PRIO_BLUR")) : prio_least;
+    const int prio_blur = prio_least;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithPriority(&h->copy_stream, hipStreamNonBlocking, prio_blur) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_compact, hipEventDisableTiming) != hipSuccess ||
@@ -747,11 +714,20 @@ int msorb_extractor_create(int nfeatures, float scale_factor, int nlevels, int i
     for (auto& e : h->pe)
         if (hipEventCreate(&e) != hipSuccess) { delete h; return MSORB_E_HIP; }
     upload_patch_tables(kPattern, h->P.umax, h->stream);
-    int nthreads = (int)std::thread::hardware_concurrency();
-    if (const char* e = getenv("MSORB_HOST_THREADS")) nthreads = atoi(e);
+    // the environment is read here and nowhere else in this file
+    {
+        const char* e;
+        h->knobs.serial_pipeline = getenv("MSORB_SERIAL_PIPELINE") != nullptr;
+        h->knobs.quadtree_host = (e = getenv("MSORB_QUADTREE")) && std::string(e) == "host";
+        h->knobs.split_no_peer = getenv("MSORB_SPLIT_NO_PEER") != nullptr;
+        h->knobs.force_peer_pyramid = getenv("MSORB_FORCE_PEER_PYRAMID") != nullptr;
+        h->knobs.host_threads = (e = getenv("MSORB_HOST_THREADS")) ? atoi(e) : 0;
+    }
+    if (hipDeviceGetAttribute(&h->lds_per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || h->lds_per_block <= 0)
+        h->lds_per_block = 64 * 1024;
+    int nthreads = h->knobs.host_threads > 0 ? h->knobs.host_threads : (int)std::thread::hardware_concurrency();
     nthreads = std::max(1, std::min(nthreads, 64));
     h->pool.reset(new Pool(nthreads));
-    if (const char* e = getenv("MSORB_GROUPS")) h->n_groups = std::max(1, std::min(atoi(e), kMaxGroups));
     *out = h;
     return MSORB_OK;
 }
@@ -779,7 +755,6 @@ void msorb_extractor_destroy(msorb_extractor* h) {
         (void)hipEventDestroy(G.ev_pyr); (void)hipEventDestroy(G.ev_blur); (void)hipEventDestroy(G.ev_fast);
         if (G.own_stream) (void)hipStreamDestroy(G.s);
     }
-    for (auto& fgx : h->fgraph) if (fgx.exec) (void)hipGraphExecDestroy(fgx.exec);
     for (auto& e : h->pe) if (e) (void)hipEventDestroy(e);
     if (h->ev_compact) (void)hipEventDestroy(h->ev_compact);
     if (h->ev_pyramid) (void)hipEventDestroy(h->ev_pyramid);
@@ -831,8 +806,6 @@ int msorb_extractor_set_semantics(msorb_extractor* h, const msorb_semantics* sem
         s.atan2_fma = sem->atan2_fma != 0;
     }
     h->sem = s;
-    for (auto& g : h->fgraph)   // captured per-frame graphs bake the kernel choice in
-        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
     return MSORB_OK;
 }
 
@@ -858,7 +831,7 @@ static int extract_batch_common(msorb_extractor* h, const uint8_t* d_images, int
         set_error("bad strides");
         return MSORB_E_INVALID;
     }
-    if (submit_only && (!h->device_quadtree || getenv("MSORB_SERIAL_PIPELINE"))) {
+    if (submit_only && (!h->device_quadtree || h->knobs.serial_pipeline)) {
         set_error("msorb_extract_batch_submit needs the device pipeline");
         return MSORB_E_INVALID;
     }
@@ -868,15 +841,14 @@ static int extract_batch_common(msorb_extractor* h, const uint8_t* d_images, int
     if ((rc = ensure_batch(h, n_images))) return rc;
     LevelView l0{d_images, image_stride, (int)row_stride, cols, rows};
     // rows that are not 4-byte aligned (or leave no slack for the row-coherent dword reads) would push every kernel onto
-    // its byte-granular variant: copy level 0 once into the handle's aligned planes instead (MSORB_NO_STAGE0 keeps it in place)
-    const bool no_stage = getenv("MSORB_NO_STAGE0") != nullptr;  // read per call: the tests exercise both paths in one process
+    // its byte-granular variant: copy level 0 once into the handle's aligned planes instead
     const LevelGeom& g0 = h->G.lv[0];
     const bool misaligned = (reinterpret_cast<uintptr_t>(d_images) & 3) || (row_stride & 3) || (image_stride & 3) ||
                             row_stride < (size_t)(((cols + 3) & ~3) + 8);
     // measured on MI355X (KITTI rows of 1241 bytes): 256 images 1.88 vs 2.08 ms staged / in place, 64 images 0.65 vs 0.64 —
-    // small batches keep the rows in place (MSORB_STAGE0_MIN overrides the threshold; read per call for the tests)
-    const int stage_min = getenv("MSORB_STAGE0_MIN") ? atoi(getenv("MSORB_STAGE0_MIN")) : 128;
-    if (misaligned && !no_stage && n_images >= stage_min) {
+    // small batches keep the rows in place
+    constexpr int stage_min = 128;
+    if (misaligned && n_images >= stage_min) {
         launch_stage_level0(l0, h->d_pyr.p + g0.plane_off, g0.pitch, h->G.pyramid_bytes, n_images, h->stream);
         l0 = LevelView{h->d_pyr.p + g0.plane_off, h->G.pyramid_bytes, g0.pitch, cols, rows};
     }
@@ -938,72 +910,7 @@ int msorb_extract(msorb_extractor* h, const uint8_t* image, int rows, int cols, 
     uint8_t* pd = h->h_out_pin.p + (size_t)cap * sizeof(msorb_keypoint);
     int n = 0, mono = 0;
 
-    // Graph path: the chain of one frame is fixed (same buffers, same grids, device-side counts), so it is captured once
-    // per (geometry, lapping area) and replayed with a single launch; everything the host needs comes back in the same
-    // graph (counts, mono index, and the full-capacity keypoint / descriptor block: 120 KB, cheaper than a second round
-    // trip for the exact count).  Opt-in (MSORB_GRAPH=1): measured on MI355X / ROCm 7.2 it takes a single caller from 0.243
-    // to 0.233 ms per frame, but two host threads replaying graphs at the same time — the reference's left / right eye
-    // threads, Frame.cc:122-125 — serialise inside hipGraphLaunch: 0.49 ms per stereo pair instead of 0.33 ms with plain
-    // launches.  Never used while profiling (stage events) or in the host-quadtree mode.
-    static const bool graph_env = getenv("MSORB_GRAPH") != nullptr && !getenv("MSORB_SERIAL_PIPELINE");
-    const bool graph_ok = graph_env && h->device_quadtree && !h->profiling;
-    // any buffer the graph touches may have been re-allocated since it was captured
-    unsigned long long sig = 1469598103934665603ull;
-    for (const void* q : {(const void*)h->d_pyr.p, (const void*)h->d_blur.p, (const void*)h->d_slots.p, (const void*)h->d_compact.p,
-                          (const void*)h->d_cell_count.p, (const void*)h->d_cell_off.p, (const void*)h->d_level_count.p,
-                          (const void*)h->d_img_total.p, (const void*)h->d_img_base.p, (const void*)h->d_sel_count.p,
-                          (const void*)h->d_sel.p, (const void*)h->d_label.p, (const void*)h->d_sel_pt.p, (const void*)h->d_sel_n.p,
-                          (const void*)h->d_mono.p, (const void*)h->d_kps1.p, (const void*)h->d_desc1.p, (const void*)h->d_taps.p,
-                          (const void*)h->d_cells.p, (const void*)h->h_img_pin.p, (const void*)h->h_out_pin.p,
-                          (const void*)h->h_sel_count.p, (const void*)h->h_mono.p})
-        sig = (sig ^ (unsigned long long)(uintptr_t)q) * 1099511628211ull;
-    if (sig != h->graph_epoch) {
-        for (auto& fg : h->fgraph) { if (fg.exec) (void)hipGraphExecDestroy(fg.exec); fg = msorb_extractor::FrameGraph{}; }
-        h->graph_epoch = sig;
-    }
-    msorb_extractor::FrameGraph* fg = nullptr;
-    if (graph_ok) {
-        for (auto& c : h->fgraph)
-            if (c.exec && c.lap0 == lap0 && c.lap1 == lap1 && c.rows == rows && c.cols == cols) fg = &c;
-        if (!fg && h->last_n_images == 1 && h->last_groups == 1) {  // not on the very first call: lazy initialisations are over
-            msorb_extractor::FrameGraph* slot = h->fgraph[0].exec ? &h->fgraph[1] : &h->fgraph[0];
-            if (slot->exec) { (void)hipGraphExecDestroy(slot->exec); *slot = msorb_extractor::FrameGraph{}; }
-            HIPCHK(hipStreamSynchronize(h->stream));
-            hipGraph_t graph = nullptr;
-            HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            h->capturing = true;
-            hipError_t ce = hipMemcpyAsync(h->d_pyr.p + g0.plane_off, h->h_img_pin.p, (size_t)g0.pitch * rows, hipMemcpyHostToDevice,
-                                           h->stream);
-            int prc = MSORB_OK;
-            if (ce == hipSuccess) prc = run_pipeline(h, l0, 1, lap0, lap1, h->d_kps1.p, h->d_desc1.p, cap, &n, &mono);
-            if (ce == hipSuccess && prc == MSORB_OK)
-                ce = hipMemcpyAsync(pk, h->d_kps1.p, (size_t)cap * sizeof(msorb_keypoint), hipMemcpyDeviceToHost, h->stream);
-            if (ce == hipSuccess && prc == MSORB_OK)
-                ce = hipMemcpyAsync(pd, h->d_desc1.p, (size_t)cap * 32, hipMemcpyDeviceToHost, h->stream);
-            h->capturing = false;
-            const hipError_t ee = hipStreamEndCapture(h->stream, &graph);
-            if (ce == hipSuccess && prc == MSORB_OK && ee == hipSuccess && graph &&
-                hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                slot->lap0 = lap0; slot->lap1 = lap1; slot->rows = rows; slot->cols = cols;
-                fg = slot;
-            } else {
-                slot->exec = nullptr;
-                (void)hipGetLastError();  // capture failed: fall back to plain launches below
-            }
-            if (graph) (void)hipGraphDestroy(graph);
-        }
-    }
-    if (fg) {
-        h->h_pyr_valid = false;       // the same bookkeeping run_pipeline does for a call
-        h->compact_on_host = false;
-        HIPCHK(hipGraphLaunch(fg->exec, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(hipGetLastError());
-        n = h->h_sel_count.p[0];
-        mono = h->h_mono.p[0];
-        if (n < 0) { set_error("keypoint capacity exceeded"); return MSORB_E_CAPACITY; }
-        if (n > capacity) { set_error("caller capacity too small"); return MSORB_E_CAPACITY; }
-    } else if (h->device_quadtree && !getenv("MSORB_SERIAL_PIPELINE") && !h->profiling) {
+    if (h->device_quadtree && !h->knobs.serial_pipeline && !h->profiling) {
         // device pipeline: nothing in it needs the host, so the whole frame is enqueued, the full-capacity output block
         // (keypoints + descriptors, ~120 KB) follows in ONE copy and the call synchronises once
         const size_t o_desc = ((size_t)cap * sizeof(msorb_keypoint) + 15) & ~(size_t)15, blk_bytes = o_desc + (size_t)cap * 32;
@@ -1071,7 +978,7 @@ int msorb::extract_stereo_sink(msorb_extractor* h, const uint8_t* left, const ui
     if (!kps_left || !desc_left || !kps_right || !desc_right || !u_right || !depth || (int)stride_left < cols ||
         (int)stride_right < cols)
         return MSORB_E_INVALID;
-    if (!h->device_quadtree || getenv("MSORB_SERIAL_PIPELINE")) {
+    if (!h->device_quadtree || h->knobs.serial_pipeline) {
         set_error("msorb_extract_stereo needs the device pipeline");
         return MSORB_E_INVALID;
     }
@@ -1190,7 +1097,7 @@ int msorb_extract_stereo_split(msorb_extractor* L, msorb_extractor* R, const uin
         set_error("msorb_extract_stereo_split: the two extractors differ in their parameters");
         return MSORB_E_INVALID;
     }
-    if (getenv("MSORB_SERIAL_PIPELINE")) { set_error("msorb_extract_stereo_split needs the device pipeline"); return MSORB_E_INVALID; }
+    if (L->knobs.serial_pipeline || R->knobs.serial_pipeline) { set_error("msorb_extract_stereo_split needs the device pipeline"); return MSORB_E_INVALID; }
     const int cap = capacity_of(L);
     int rc;
     // geometry / buffers of both handles (each on its own device)
@@ -1244,7 +1151,7 @@ int msorb_extract_stereo_split(msorb_extractor* L, msorb_extractor* R, const uin
             peer = it->second;
         }
     }
-    if (getenv("MSORB_SPLIT_NO_PEER")) peer = false;
+    if (L->knobs.split_no_peer || R->knobs.split_no_peer) peer = false;
     const size_t g_kp = 0, g_desc = kp_bytes, g_cnt = g_desc + (size_t)cap * 32, g_pyr = g_cnt + 16, g_total = g_pyr + g.pyramid_bytes;
     if (!peer) {
         HIPCHK(hipSetDevice(L->device));
@@ -1411,8 +1318,6 @@ int msorb_debug_copy_level(msorb_extractor* h, int image, int level, int blurred
     return MSORB_OK;
 }
 
-int msorb_debug_fast_form(const msorb_extractor* h) { return h ? h->last_fast_form : MSORB_E_INVALID; }
-int msorb_debug_blur_form(const msorb_extractor* h) { return h ? h->last_blur_form : MSORB_E_INVALID; }
 int msorb_debug_candidates(msorb_extractor* h, int image, int level, int* xyscore, int capacity, int* n) {
     if (!h || !n || !h->geom_valid || image < 0 || image >= h->last_n_images || level < 0 || level >= h->G.nlevels)
         return MSORB_E_INVALID;

@@ -948,29 +948,19 @@ static void launch_dense_variant(const uint8_t* q, const uint8_t* t, const int* 
     hipLaunchKernelGGL((dense_top2_kernel<QPL, SPLIT>), dim3((max_q + per_block - 1) / per_block, n_frames), dim3(256 * SPLIT), lds, s,
                        q, t, n_q, n_t, q_stride, t_stride, bi, bd, sd);
 }
+// formulation 0: matrix cores (dense_top2_mfma_kernel); 1: xor + popcount (dense_top2_kernel<2, 4>, BASELINE north_star's form).
+// Measured on MI355X (128 frames x 2000 x 2000), popcount <QPL, SPLIT>: 2,1 1.54  2,2 1.65  2,4 1.72  4,2 1.68  4,4 1.73  1,4 1.57
+// Tpairs/s; matrix cores 5.1.
 void launch_dense_top2(const uint8_t* q, const uint8_t* t, const int* n_q, const int* n_t, int n_frames, int q_stride,
-                       int t_stride, int max_q, int max_t, int* bi, int* bd, int* sd, hipStream_t s) {
+                       int t_stride, int max_q, int max_t, int* bi, int* bd, int* sd, hipStream_t s, int formulation) {
     if (n_frames <= 0 || max_q <= 0) return;
-    const int variant = getenv("MSORB_DENSE_VARIANT") ? atoi(getenv("MSORB_DENSE_VARIANT")) : 0;  // test / tuning aid: QPL*10 + SPLIT = VALU kernels
-    if (variant == 0) {   // default: matrix cores
+    if (formulation == 0) {
         const int per_block = kMfmaWaves * 128;
         hipLaunchKernelGGL(dense_top2_mfma_kernel, dim3((max_q + per_block - 1) / per_block, n_frames), dim3(kMfmaThreads), 0, s, q, t, n_q, n_t,
                            q_stride, t_stride, bi, bd, sd);
         return;
     }
-    // measured on MI355X (128 frames x 2000 x 2000): 2,1 1.54  2,2 1.65  2,4 1.72  4,2 1.68  4,4 1.73  1,4 1.57 Tpairs/s
-#define MSORB_DENSE(Q, S) launch_dense_variant<Q, S>(q, t, n_q, n_t, n_frames, q_stride, t_stride, max_q, max_t, bi, bd, sd, s)
-    switch (variant) {
-        case 21: MSORB_DENSE(2, 1); break;
-        case 22: MSORB_DENSE(2, 2); break;
-        case 41: MSORB_DENSE(4, 1); break;
-        case 42: MSORB_DENSE(4, 2); break;
-        case 44: MSORB_DENSE(4, 4); break;
-        case 12: MSORB_DENSE(1, 2); break;
-        case 14: MSORB_DENSE(1, 4); break;
-        default: MSORB_DENSE(2, 4); break;
-    }
-#undef MSORB_DENSE
+    launch_dense_variant<2, 4>(q, t, n_q, n_t, n_frames, q_stride, t_stride, max_q, max_t, bi, bd, sd, s);
 }
 
 }  // namespace msorb

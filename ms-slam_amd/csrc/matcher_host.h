@@ -20,6 +20,7 @@ int extractor_last_view(msorb_extractor* h, PyramidView* pyr, LevelScale* sc, fl
                         hipStream_t* stream, int* n_images);
 int extractor_device(const msorb_extractor* h);
 int extractor_levels(const msorb_extractor* h);
+bool extractor_force_peer_pyramid(const msorb_extractor* h);   // MSORB_FORCE_PEER_PYRAMID at the handle's creation (test hook)
 }  // namespace msorb
 struct msorb_frame_track;
 namespace msorb {
@@ -206,8 +207,6 @@ int run_window_search(msorb_frame* f, int M, const WinQuery* q, const uint8_t* f
     }
     if (rounds_out) *rounds_out = n_rounds;
     f->last_rounds = n_rounds; f->total_rounds += n_rounds; f->total_searches++;
-    static const bool dbg_rounds = getenv("MSORB_DEBUG_ROUNDS") != nullptr;
-    if (dbg_rounds) fprintf(stderr, "window search: %d queries, %d device rounds\n", M, n_rounds);
     return MSORB_OK;
 }
 

@@ -3,10 +3,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
 #include "../../include/msorb.h"
 #include "orb_host.h"
 
 namespace msorb {
+void set_last_error(const std::string& s);
 
 struct LevelView {  // one pyramid level of a batch: image i's plane at base + i*img_stride
     const uint8_t* base;
@@ -33,7 +36,7 @@ struct QtLevels {  // per-level geometry of the quadtree stage
     int nlevels;
 };
 
-void launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_base, const int* level_count,
+int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_base, const int* level_count,
                      uint16_t* label, int* sel_pt, int* sel_n, int sel_stride, const LevelScale& scales, int lap0,
                      int lap1, int capacity, SelRec* sel, int* sel_count, int* mono, int n_images, hipStream_t s);
 size_t quadtree_lds_bytes(const QtLevels& lv);
@@ -57,15 +60,10 @@ void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_
                        const ResizeTap* ty, int n_images, hipStream_t s, int single_stage = 0);
 void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cells, int ini_th, int min_th,
                        int slots_per_image, Cand16* slots, int* cell_count, int n_images, bool small_cells, hipStream_t s);
-// strip form of the FAST stage (fast_strip_kernel); false = this pyramid / geometry needs launch_fast_cells
-bool launch_fast_strips(const PyramidView& pyr, const StripDesc* strips, int n_strips, int n_small, const int* max_rh, const int* work_cap,
-                        int n_cells, int ini_th, int min_th, int slots_per_image, Cand16* slots, int* cell_count, int n_images,
-                        hipStream_t s);
 void launch_cand_compact(const CellDesc* cells, int n_cells, const int* level_cell_begin, int nlevels,
                          int slots_per_image, const Cand16* slots, const int* cell_count, int* cell_off,
                          int* level_count, int* img_total, int* img_base, Cand16* compact, int n_images,
                          hipStream_t s);
-// returns the form that ran: 0 = VALU kernels, 1 = matrix-core kernel (gauss7_mfma_kernel)
 int launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images, hipStream_t s, const Semantics& sem = Semantics());
 void launch_describe(const PyramidView& pyr, const PyramidView& blur, const SelRec* sel, const int* sel_count,
                      int sel_stride, const LevelScale& scales, msorb_keypoint* kps, uint8_t* desc, int out_stride,

@@ -160,78 +160,6 @@ bool FrameGeom::build(const OrbParams& p, int rows_, int cols_) {
     }
     pyramid_bytes = off;
     slots_per_image = slot;
-    // strips: runs of up to kStripCells consecutive cells of a cell row (same y0 / rh, x0 a cell pitch apart); fewer cells per
-    // strip where four would need more than kStripMaxR detection rows per thread (tall cells of the small levels)
-    strips.clear();
-    strip_n_small = 0;
-    for (int c = 0; c < 2; c++) { strip_max_rh[c] = 0; strip_work_cap[c] = 0; }
-    bool ok = true;
-    for (int l = 0; l < nlevels && ok; l++) {
-        const LevelGeom& g = lv[l];
-        int i = g.cell_begin;
-        const int end = g.cell_begin + g.cell_count;
-        if (g.w_cell > kStripMaxCellW || g.w_cell < 8) ok = false;
-        while (i < end && ok) {
-            int run = 1;
-            while (run < kStripCells && i + run < end && cells[i + run].y0 == cells[i].y0 && cells[i + run].x0 == cells[i].x0 + run * g.w_cell) run++;
-            const CellDesc& a = cells[i];
-            const int dh = std::max(a.rh - 6, 0);
-            StripDesc t{};
-            int n = run;
-            for (; n >= 1; n--) {
-                const CellDesc& z = cells[i + n - 1];
-                t = StripDesc{};
-                t.level = (int16_t)l; t.y0 = a.y0; t.rh = a.rh;
-                t.x0 = a.x0; t.rw = (int16_t)(z.x0 + z.rw - a.x0);
-                t.ncell = (int16_t)n; t.w_cell = (int16_t)g.w_cell;
-                t.cell0 = i;
-                const int ga = t.x0 & ~3, x_lo = t.x0 + 3, x_hi = t.x0 + t.rw - 3, gx0 = x_lo & ~3;
-                const int G = std::max((x_hi - gx0 + 3) >> 2, 1), ndw = std::max((t.x0 + t.rw - ga + 3) >> 2, 1);
-                const int strips_per_wg = kStripThreads / G;
-                t.G = (int16_t)G; t.ndw = (int16_t)ndw;
-                t.g_magic = ((1u << 20) + G - 1) / G;
-                t.ndw_magic = ((1u << 20) + ndw - 1) / ndw;
-                t.wc_magic = ((1u << 20) + g.w_cell - 1) / g.w_cell;
-                if (strips_per_wg < 1 || n * dh > kStripThreads) continue;
-                const int R = (dh + strips_per_wg - 1) / strips_per_wg;
-                if (R > kStripMaxR) continue;
-                t.R = (int16_t)R;
-                break;
-            }
-            if (n < 1 || a.rh > 57 || a.rh < 7) { ok = false; break; }
-            int cap = 0;
-            for (int c = 0; c < n; c++) {
-                const CellDesc& cc = cells[i + c];
-                t.slot_off[c] = cc.slot_off;
-                if (cc.rh != a.rh || cc.rw > g.w_cell + 6 || cc.rw < 7) ok = false;
-                cap = std::max(cap, 2 * std::max(cc.rw - 6, 0) * dh);
-            }
-            t.pad = (int16_t)std::min(cap, 32767);   // (kept in the descriptor only until the classes below are formed)
-            strips.push_back(t);
-            i += n;
-        }
-    }
-    if (!ok) strips.clear();
-    if (!strips.empty()) {
-        // Two LDS classes, one launch each: the workgroup's LDS is sized by the tallest ROI and the largest cell of its launch, and a
-        // few tall cell rows of the small levels would otherwise cost every strip of the big levels a resident workgroup.
-        // Class 0 = everything up to the need of the 90th percentile strip (the table is reordered: the outputs are addressed
-        // through cell ids and slot offsets, so the order of the strips is free).
-        auto need = [](const StripDesc& t) { return (int)t.rh * 400 + 2 * (int)t.pad; };   // ~ bytes: tile + score rows, work list
-        std::vector<int> needs;
-        for (const StripDesc& t : strips) needs.push_back(need(t));
-        std::vector<int> sorted = needs;
-        std::sort(sorted.begin(), sorted.end());
-        const int limit = sorted[std::min(sorted.size() - 1, sorted.size() * 9 / 10)];
-        std::stable_partition(strips.begin(), strips.end(), [&](const StripDesc& t) { return need(t) <= limit; });
-        for (const StripDesc& t : strips) {
-            const int c = need(t) <= limit ? 0 : 1;
-            if (c == 0) strip_n_small++;
-            strip_max_rh[c] = std::max<int>(strip_max_rh[c], t.rh);
-            strip_work_cap[c] = std::max<int>(strip_work_cap[c], t.pad);
-        }
-        for (StripDesc& t : strips) t.pad = 0;
-    }
     return true;
 }
 

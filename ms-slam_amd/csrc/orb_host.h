@@ -55,25 +55,6 @@ struct CellDesc {  // one FAST cell of ComputeKeyPointsOctTree (ORBextractor.cc:
     uint32_t rw128, yw128, rw256, yw256;
 };
 
-// Up to kStripCells horizontally adjacent cells of one cell row, processed by one workgroup of fast_strip_kernel: the cells'
-// detection areas are contiguous ([x0 + 3 + c * w_cell, ...)), so staging, quick test, work list and arc scores treat the
-// strip as one wide cell; only NMS, the emission order and the threshold fallback are per cell.
-constexpr int kStripCells = 4;
-constexpr int kStripThreads = 256;
-constexpr int kStripMaxCellW = 40;   // cell pitch the strip kernel's LDS pitch is sized for (ROI <= 46 wide)
-constexpr int kStripMaxR = 8;        // detection rows per thread the flag words hold
-struct StripDesc {
-    int16_t level, y0, rh;       // ROI rows of the cell row (iniY, maxY - iniY)
-    int16_t x0, rw;              // ROI columns: the first cell's iniX .. the last cell's maxX
-    int16_t ncell, w_cell;       // cells in the strip, cell pitch (the level's wCell)
-    int16_t G, ndw;              // 4-pixel groups per detection row, dwords per staged ROI row
-    int16_t R;                   // detection rows per thread (uniform split over kStripThreads)
-    int16_t pad;
-    int32_t cell0;               // id of the first cell in the per-image cell table
-    uint32_t g_magic, ndw_magic, wc_magic;  // ceil(2^20 / divisor)
-    int32_t slot_off[kStripCells];
-};
-
 struct LevelGeom {
     int w = 0, h = 0;    // level size (ComputePyramid, ORBextractor.cc:1174-1175)
     int pitch = 0;       // row pitch of the device planes (multiple of 64 bytes)
@@ -88,11 +69,6 @@ struct FrameGeom {
     int rows = 0, cols = 0, nlevels = 0;
     LevelGeom lv[kMaxLevels];
     std::vector<CellDesc> cells;
-    // strip form of the cell table (empty if some cell does not fit the strip kernel: see build())
-    std::vector<StripDesc> strips;
-    // two LDS classes (one launch each): strips [0, strip_n_small) and the rest; per class the tallest ROI and the largest
-    // single-cell flag count (= work-list capacity)
-    int strip_n_small = 0, strip_max_rh[2] = {0, 0}, strip_work_cap[2] = {0, 0};
     size_t pyramid_bytes = 0;  // per image, levels 1.. (level 0 may live in caller memory)
     size_t plane0_bytes = 0;
     int slots_per_image = 0;

@@ -97,91 +97,7 @@ __global__ __launch_bounds__(256) void pyr_resize_aligned_kernel(LevelView src, 
     *reinterpret_cast<uint32_t*>(d) = packed;
 }
 
-// Row-streaming variant for batches: a wave produces R consecutive output rows of its 64 column groups.  The x taps
-// are decoded once per thread instead of once per output dword, and the horizontally interpolated source rows are
-// kept in registers: at scale 1.2 consecutive output rows share one of their two source rows (i0(dy+1) == i1(dy) five
-// times out of six), so each source row is fetched and interpolated once, not twice.  The raw dwords of the next
-// source row are prefetched while the current output row is blended.  Same integer arithmetic as the kernels above.
 typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
-template <int R>
-__global__ __launch_bounds__(256) void pyr_resize_rows_kernel(LevelView src, LevelView dst, uint8_t* __restrict__ dst_base,
-                                                              const ResizeTap* __restrict__ tx,
-                                                              const ResizeTap* __restrict__ ty) {
-    const int img = blockIdx.z;
-    const int dy0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + (threadIdx.x >> 6)) * R);
-    const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    if (dy0 >= dst.h || dx0 >= dst.w) return;
-    const int dy_end = min(dy0 + R, dst.h);
-    const uint4 ta = reinterpret_cast<const uint4*>(tx + dx0)[0];
-    const uint4 tb = reinterpret_cast<const uint4*>(tx + dx0)[1];
-    const uint32_t tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};  // per tap: {i0|i1<<16, c0|c1<<16}
-    const int base = (int)(tw[0] & 0xffffu) & ~3;  // aligned column of the first source pixel
-    // per tap: two byte-permute selectors that fetch the tap's two source pixels out of the 12-byte window {w2,w1,w0}
-    // into the low bytes of the two 16-bit halves (0x0c = constant zero), and the weights as a u16 pair: the horizontal
-    // interpolation is then perm, perm, or, dot2.  At the right edge i1 == i0 and c1 == 0: whatever the second selector
-    // picks is multiplied by zero.
-    uint32_t sel01[4], sel2[4], cw[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t o = (tw[2 * i] & 0xffffu) - (uint32_t)base;  // 0..10
-        const uint32_t a1 = o < 8 ? o : 0x0cu, b1 = o + 1 < 8 ? o + 1 : 0x0cu;
-        const uint32_t a2 = o >= 8 ? o - 8 : 0x0cu, b2 = o + 1 >= 8 ? o + 1 - 8 : 0x0cu;
-        sel01[i] = a1 | (0x0cu << 8) | (b1 << 16) | (0x0cu << 24);
-        sel2[i] = a2 | (0x0cu << 8) | (b2 << 16) | (0x0cu << 24);
-        cw[i] = tw[2 * i + 1];  // c0 | c1 << 16, both in [0, 2048]
-    }
-    const uint8_t* sb = src.base + (size_t)img * src.img_stride;
-    struct Raw { uint32_t w0, w1, w2; };
-    auto fetch = [&](int sy) {
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(sb + (size_t)sy * src.pitch + (size_t)(uint32_t)base);
-        return Raw{q[0], q[1], q[2]};
-    };
-    auto hrow = [&](const Raw& r, int H[4]) {  // (src[i0]*c0 + src[i1]*c1) >> 4 for the 4 columns of this thread
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t px = __builtin_amdgcn_perm(r.w1, r.w0, sel01[i]) | __builtin_amdgcn_perm(0u, r.w2, sel2[i]);
-            H[i] = (int)(__builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, px), __builtin_bit_cast(ushort2v, cw[i]), 0u, false) >> 4);
-        }
-    };
-    uint8_t* d = dst_base + (size_t)img * dst.img_stride + (size_t)(uint32_t)dx0;
-    const int last_src = src.h - 1;
-    int HA[4], HB[4];   // interpolated source rows ia (upper) and ib (lower) of the current output row
-    int ia = -1, ib = -1;
-    Raw pre = fetch(ty[dy0].i0);
-    int ipre = ty[dy0].i0;  // source row held raw in `pre`
-    for (int dy = dy0; dy < dy_end; dy++) {
-        const ResizeTap vy = ty[dy];  // wave-uniform: scalar loads
-        const int n0 = vy.i0, n1 = vy.i1;
-        if (n0 == ib) {               // common case: the lower row of the previous output row becomes the upper one
-#pragma unroll
-            for (int i = 0; i < 4; i++) HA[i] = HB[i];
-        } else if (n0 != ia) {
-            const Raw r = (n0 == ipre) ? pre : fetch(n0);
-            hrow(r, HA);
-        }
-        ia = n0;
-        if (n1 == n0) {               // bottom clamp: both taps on one row
-#pragma unroll
-            for (int i = 0; i < 4; i++) HB[i] = HA[i];
-        } else {
-            const Raw r = (n1 == ipre) ? pre : fetch(n1);
-            hrow(r, HB);
-        }
-        ib = n1;
-        if (dy + 1 < dy_end) {        // the next output row needs ib (held) and, almost always, ib + 1
-            ipre = min(ib + 1, last_src);
-            pre = fetch(ipre);
-        }
-        uint32_t packed = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int v = (((vy.c0 * HA[i]) >> 16) + ((vy.c1 * HB[i]) >> 16) + 2) >> 2;
-            packed |= (uint32_t)(v & 255) << (8 * i);
-        }
-        *reinterpret_cast<uint32_t*>(d + (size_t)dy * dst.pitch) = packed;
-    }
-}
-
 // SDWA forms the compiler does not pick by itself: a 24-bit multiply by one u16 half of a register, and the sum of two
 // registers' high halves.  Only source selects are used (a partial destination write would need wait states).
 __device__ __forceinline__ uint32_t sdwa_mul_lo(uint32_t b, uint32_t h) {
@@ -200,94 +116,16 @@ __device__ __forceinline__ uint32_t sdwa_hi_sum(uint32_t x, uint32_t y) {   // (
     return r;
 }
 
-// Row-band variant (batches, scale factors up to 1.25): a wave produces R consecutive output rows of its 64 column groups in
+// Row-band kernel (batches, scale factors up to 1.25): a wave produces R consecutive output rows of its 64 column groups in
 // two phases without any data-dependent control flow in between:
 //   A  all source rows the band touches (rows i0(dy0) .. i1(dy0 + R - 1): <= kSrc of them) are fetched with every load in
-//      flight at once, interpolated horizontally (v_perm + v_dot2_u32_u16 per pixel) and parked as 4 x u16 per lane
-//      in LDS — used only as storage a lane can index at run time: a lane reads back exactly what it wrote, so no
-//      barrier and no sharing;
+//      flight at once, interpolated horizontally (v_perm + v_dot2_u32_u16 per pixel) and parked as 4 x u16 per lane in
+//      REGISTERS (s_set_gpr_idx picks; no LDS: beside the other batch's FAST / quadtree / describe workgroups, which keep a
+//      CU's LDS filled to within a few KB, a workgroup that asks for none starts as soon as two wave slots are free);
 //   B  every output row reads its two parked rows by (wave-uniform) index and blends them with SDWA half-word operands.
-// The y taps of the band come in up front with the first loads.  Compared with pyr_resize_rows_kernel: no per-row wait for a
-// tap record, no register shuffling between "upper" and "lower" rows, 14 instead of 25 VALU lane-operations per pixel.
-template <int R, int kSrc>
-__device__ __forceinline__ void pyr_band_tile(const LevelView& src, const LevelView& dst, uint8_t* __restrict__ dst_base,
-                                              const ResizeTap* __restrict__ tx, const ResizeTap* __restrict__ ty, const int img,
-                                              const int bx, const int dy0, const int lane, uint2 (*park_w)[64]) {
-    const int dx0 = (bx * 64 + lane) * 4;
-    if (dy0 >= dst.h) return;   // wave-uniform
-    const int n_out = min(R, dst.h - dy0);
-    // y taps of the band (wave-uniform addresses: scalar loads)
-    uint32_t ti[R], tc[R];      // i0 | i1 << 16, c0 | c1 << 16
-#pragma unroll
-    for (int k = 0; k < R; k++) {
-        const uint2 v = reinterpret_cast<const uint2*>(ty)[__builtin_amdgcn_readfirstlane(dy0 + min(k, n_out - 1))];
-        ti[k] = __builtin_amdgcn_readfirstlane(v.x);
-        tc[k] = __builtin_amdgcn_readfirstlane(v.y);
-    }
-    const int s_lo = (int)(ti[0] & 0xffffu);
-    int s_hi = s_lo;
-#pragma unroll
-    for (int k = 0; k < R; k++) s_hi = max(s_hi, (int)(ti[k] >> 16));
-    const int n_src = s_hi - s_lo + 1;   // <= kSrc (checked on the host)
-    const bool active = dx0 < dst.w;
-    // x taps of this column group -> byte selectors and weights (as pyr_resize_rows_kernel)
-    const int dxc = active ? dx0 : 0;
-    const uint4 ta = reinterpret_cast<const uint4*>(tx + dxc)[0];
-    const uint4 tb = reinterpret_cast<const uint4*>(tx + dxc)[1];
-    const uint32_t tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};  // per tap: {i0|i1<<16, c0|c1<<16}
-    const int base = (int)(tw[0] & 0xffffu) & ~3;  // aligned column of the first source pixel
-    // The 4 taps of a lane start within 5 source pixels of the first one (scale <= 1.25): two v_alignbyte bring the 12-byte
-    // window to "first tap at byte 0", then one v_perm per tap puts its two pixels into the u16 halves for v_dot2_u32_u16.
-    const uint32_t o0 = (tw[0] & 0xffffu) - (uint32_t)base;   // 0..3
-    uint32_t sel[4], cw[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t r = (tw[2 * i] & 0xffffu) - (uint32_t)base - o0;  // 0..5; at the right edge i1 == i0 and c1 == 0
-        sel[i] = r | (0x0cu << 8) | ((r + 1) << 16) | (0x0cu << 24);
-        cw[i] = tw[2 * i + 1];  // c0 | c1 << 16, both in [0, 2048]
-    }
-    const uint8_t* sb = src.base + (size_t)img * src.img_stride + (size_t)(uint32_t)base;
-    // phase A
-    uint32_t raw[kSrc][3];
-#pragma unroll
-    for (int r = 0; r < kSrc; r++) {
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(sb + (size_t)min(s_lo + r, s_hi) * src.pitch);
-        raw[r][0] = q[0]; raw[r][1] = q[1]; raw[r][2] = q[2];
-    }
-#pragma unroll
-    for (int r = 0; r < kSrc; r++) {
-        if (r < n_src) {   // wave-uniform
-            const uint32_t lo = __builtin_amdgcn_alignbyte(raw[r][1], raw[r][0], o0);
-            const uint32_t hi = __builtin_amdgcn_alignbyte(raw[r][2], raw[r][1], o0);
-            uint32_t H[4];   // (src[i0]*c0 + src[i1]*c1) >> 4 <= 32640
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                H[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(hi, lo, sel[i])),
-                                              __builtin_bit_cast(ushort2v, cw[i]), 0u, false) >> 4;
-            park_w[r][lane] = uint2{H[0] | (H[1] << 16), H[2] | (H[3] << 16)};
-        }
-    }
-    // phase B: ((b0 * H0) >> 16) + ((b1 * H1) >> 16) + 2) >> 2 with the u16 halves picked by SDWA operand selects
-    uint8_t* d = dst_base + (size_t)img * dst.img_stride + (size_t)(uint32_t)dx0;
-#pragma unroll
-    for (int k = 0; k < R; k++) {
-        if (k < n_out) {   // wave-uniform
-            const int n0 = (int)(ti[k] & 0xffffu) - s_lo, n1 = (int)(ti[k] >> 16) - s_lo;
-            const uint32_t b0 = tc[k] & 0xffffu, b1 = tc[k] >> 16;
-            const uint2 A = park_w[n0][lane], B = park_w[n1][lane];
-            const uint32_t t0 = sdwa_hi_sum(sdwa_mul_lo(b0, A.x), sdwa_mul_lo(b1, B.x));
-            const uint32_t t1 = sdwa_hi_sum(sdwa_mul_hi(b0, A.x), sdwa_mul_hi(b1, B.x));
-            const uint32_t t2 = sdwa_hi_sum(sdwa_mul_lo(b0, A.y), sdwa_mul_lo(b1, B.y));
-            const uint32_t t3 = sdwa_hi_sum(sdwa_mul_hi(b0, A.y), sdwa_mul_hi(b1, B.y));
-            const ushort2v two = {2, 2};
-            const ushort2v p01 = (__builtin_bit_cast(ushort2v, t0 | (t1 << 16)) + two) >> 2;
-            const ushort2v p23 = (__builtin_bit_cast(ushort2v, t2 | (t3 << 16)) + two) >> 2;
-            const uint32_t packed = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p23), __builtin_bit_cast(uint32_t, p01), 0x06040200u);
-            if (active) *reinterpret_cast<uint32_t*>(d + (size_t)(dy0 + k) * dst.pitch) = packed;
-        }
-    }
-}
-
+// The y taps of the band come in up front with the first loads.  14 VALU lane-operations per pixel.
+// (Retired forms with their measurements — row streaming, rows parked in LDS, LDS-DMA staging, the top levels as one launch:
+// tools/experiments/README.md.)
 template <int R, int kSrc>
 __device__ __forceinline__ void pyr_band_tile_reg(const LevelView& src, const LevelView& dst, uint8_t* __restrict__ dst_base,
                                               const ResizeTap* __restrict__ tx, const ResizeTap* __restrict__ ty, const int img,
@@ -372,9 +210,6 @@ __device__ __forceinline__ void pyr_band_tile_reg(const LevelView& src, const Le
     }
 }
 
-// LDS-free form of the band kernel (same arithmetic, the parked rows in registers): beside the other batch's FAST / quadtree /
-// describe workgroups, which keep a CU's LDS filled to within a few KB, a workgroup that asks for no LDS starts as soon as
-// two wave slots are free — the LDS form's levels were stretched from 0.05 to 0.8 ms there (profiles/round2_timeline_pipelined.txt).
 template <int R, int kSrc, int WAVES = 2>
 __global__ __launch_bounds__(64 * WAVES) void pyr_resize_bandreg_kernel(LevelView src, LevelView dst, uint8_t* __restrict__ dst_base,
                                                                         const ResizeTap* __restrict__ tx,
@@ -382,148 +217,6 @@ __global__ __launch_bounds__(64 * WAVES) void pyr_resize_bandreg_kernel(LevelVie
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int dy0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * WAVES + wave) * R);
     pyr_band_tile_reg<R, kSrc>(src, dst, dst_base, tx, ty, blockIdx.z, blockIdx.x, dy0, lane);
-}
-
-template <int R, int kSrc, int WAVES = 4>
-__global__ __launch_bounds__(64 * WAVES) void pyr_resize_band_kernel(LevelView src, LevelView dst, uint8_t* __restrict__ dst_base,
-                                                                     const ResizeTap* __restrict__ tx,
-                                                                     const ResizeTap* __restrict__ ty) {
-    __shared__ uint2 park[WAVES][kSrc][64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int dy0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * WAVES + wave) * R);
-    pyr_band_tile<R, kSrc>(src, dst, dst_base, tx, ty, blockIdx.z, blockIdx.x, dy0, lane, park[wave]);
-}
-
-// The small top levels in ONE launch: a 16-wave workgroup per image walks down the levels, its waves taking the (band, column
-// chunk) tiles of a level in turn; a workgroup-wide barrier separates the levels.  As separate launches each of these levels costs 13-16 us
-// for 5-9 us of work — ramp-up, tap fetch, load latency and drain of a dependent launch do not shrink with the level.
-struct PyrTailArgs {
-    LevelView lv[4];            // lv[0] = source of the first tail level, lv[i + 1] = i-th tail level
-    const ResizeTap* tx[3];
-    const ResizeTap* ty[3];
-    int nl;                     // tail levels (<= 3)
-};
-template <int R, int kSrc>
-__global__ __launch_bounds__(1024) void pyr_resize_tail_kernel(PyrTailArgs A) {
-    __shared__ uint2 park[16][kSrc][64];
-    const int img = blockIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    for (int li = 0; li < A.nl; li++) {
-        const LevelView src = A.lv[li], dst = A.lv[li + 1];
-        const int gx = (dst.w + 255) / 256, nb = (dst.h + R - 1) / R;
-        for (int t = wave; t < gx * nb; t += 16) {
-            const int band = t / gx, bx = t - band * gx;
-            pyr_band_tile<R, kSrc>(src, dst, const_cast<uint8_t*>(dst.base), A.tx[li], A.ty[li], img, bx, band * R, lane, park[wave]);
-        }
-        __syncthreads();   // workgroup-scope release / acquire: all waves of a workgroup share the CU's L1 (write-through), and
-                           // the level just written was never read before (an agent-scope fence here writes back / invalidates
-                           // the whole L2 per workgroup and level: measured 0.34 ms instead of 0.02)
-    }
-}
-
-// LDS-DMA form of the band kernel.  What limits pyr_resize_band_kernel is neither HBM nor VALU but the vector-memory
-// front end: a lane there asks for 12 bytes every 4.8 bytes, i.e. 768 requested bytes per 307 new ones, and the texture
-// addresser retires roughly 16 requested bytes per cycle and CU (tools/fetch_calib.hip: 3.3 TB/s for exactly this pattern
-// against 6.6 TB/s for 16 B/lane).  Here every source byte is requested once: the band's source rows come in as 16-byte
-// granules, 21 per row (336 B) and three rows per global_load_lds_dwordx4, straight into the wave's LDS slab; the lanes then
-// pick their 12-byte windows out of LDS.  From there on it is the band kernel (phase A -> parked u16 rows -> phase B).
-// Needs 16-byte aligned rows (base, pitch, image stride) and a horizontal scale <= 1.22 (the 64 windows of a wave must fit
-// 336 bytes); launch_pyr_resize falls back to the band kernel otherwise.
-template <int R>
-__global__ __launch_bounds__(256) void pyr_resize_dma_kernel(LevelView src, LevelView dst, uint8_t* __restrict__ dst_base,
-                                                             const ResizeTap* __restrict__ tx,
-                                                             const ResizeTap* __restrict__ ty) {
-    constexpr int kRowB = 336, kGran = kRowB / 16, kSrc = 12;   // 3 rows x 21 granules = 63 lanes per LDS-DMA instruction
-    __shared__ __attribute__((aligned(16))) uint8_t slab[4][kSrc * kRowB];
-    __shared__ uint2 park[4][kSrc][64];
-    const int img = blockIdx.z;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int dy0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + wave) * R);
-    const int dx0 = (blockIdx.x * 64 + lane) * 4;
-    if (dy0 >= dst.h) return;   // wave-uniform
-    const int n_out = min(R, dst.h - dy0);
-    uint32_t ti[R], tc[R];
-#pragma unroll
-    for (int k = 0; k < R; k++) {
-        const uint2 v = reinterpret_cast<const uint2*>(ty)[__builtin_amdgcn_readfirstlane(dy0 + min(k, n_out - 1))];
-        ti[k] = __builtin_amdgcn_readfirstlane(v.x);
-        tc[k] = __builtin_amdgcn_readfirstlane(v.y);
-    }
-    const int s_lo = (int)(ti[0] & 0xffffu);
-    int s_hi = s_lo;
-#pragma unroll
-    for (int k = 0; k < R; k++) s_hi = max(s_hi, (int)(ti[k] >> 16));
-    const int n_src = s_hi - s_lo + 1;   // <= kSrc (checked on the host)
-    const bool active = dx0 < dst.w;
-    const int dxc = active ? dx0 : 0;
-    const uint4 ta = reinterpret_cast<const uint4*>(tx + dxc)[0];
-    const uint4 tb = reinterpret_cast<const uint4*>(tx + dxc)[1];
-    const uint32_t tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
-    const int base = (int)(tw[0] & 0xffffu) & ~3;
-    const int xg = __builtin_amdgcn_readfirstlane(base) & ~15;   // lane 0 (always active): first granule of the chunk
-    const uint32_t o0 = (tw[0] & 0xffffu) - (uint32_t)base;
-    uint32_t sel[4], cw[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t r = (tw[2 * i] & 0xffffu) - (uint32_t)base - o0;
-        sel[i] = r | (0x0cu << 8) | ((r + 1) << 16) | (0x0cu << 24);
-        cw[i] = tw[2 * i + 1];
-    }
-    // stage: lane -> (row within the group of three, granule); granules past the end of the row re-read its last one
-    {
-        const int row3 = (lane * 49) >> 10, col = lane - row3 * kGran;
-        const uint8_t* sb = src.base + (size_t)img * src.img_stride + (size_t)min(xg + col * 16, src.pitch - 16);
-#pragma unroll
-        for (int j = 0; j < kSrc / 3; j++) {
-            if (j < 3 || j * 3 < n_src) {   // wave-uniform; the first 9 rows are always requested (clamped rows are harmless)
-                const uint8_t* g = sb + (size_t)min(s_lo + j * 3 + row3, s_hi) * src.pitch;
-                if (lane < 63)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                                     (__attribute__((address_space(3))) void*)&slab[wave][j * 3 * kRowB], 16, 0, 0);
-            }
-        }
-    }
-    const int woff = active ? base - xg : 0;   // this lane's window inside a staged row: 0 .. 324
-    // phase A
-#pragma unroll
-    for (int r = 0; r < kSrc; r++) {
-        if (r < 9 || r < n_src) {   // wave-uniform; rows 0..8 unconditionally, so that their LDS reads can be batched
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(&slab[wave][r * kRowB + woff]);
-            const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
-            const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, o0);
-            const uint32_t hi = __builtin_amdgcn_alignbyte(w2, w1, o0);
-            uint32_t H[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                H[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(hi, lo, sel[i])),
-                                              __builtin_bit_cast(ushort2v, cw[i]), 0u, false) >> 4;
-            park[wave][r][lane] = uint2{H[0] | (H[1] << 16), H[2] | (H[3] << 16)};
-        }
-    }
-    // phase B
-    uint8_t* d = dst_base + (size_t)img * dst.img_stride + (size_t)(uint32_t)dx0;
-    auto out_row = [&](int k) {
-        const int n0 = (int)(ti[k] & 0xffffu) - s_lo, n1 = (int)(ti[k] >> 16) - s_lo;
-        const uint32_t b0 = tc[k] & 0xffffu, b1 = tc[k] >> 16;
-        const uint2 A = park[wave][n0][lane], B = park[wave][n1][lane];
-        const uint32_t t0 = sdwa_hi_sum(sdwa_mul_lo(b0, A.x), sdwa_mul_lo(b1, B.x));
-        const uint32_t t1 = sdwa_hi_sum(sdwa_mul_hi(b0, A.x), sdwa_mul_hi(b1, B.x));
-        const uint32_t t2 = sdwa_hi_sum(sdwa_mul_lo(b0, A.y), sdwa_mul_lo(b1, B.y));
-        const uint32_t t3 = sdwa_hi_sum(sdwa_mul_hi(b0, A.y), sdwa_mul_hi(b1, B.y));
-        const ushort2v two = {2, 2};
-        const ushort2v p01 = (__builtin_bit_cast(ushort2v, t0 | (t1 << 16)) + two) >> 2;
-        const ushort2v p23 = (__builtin_bit_cast(ushort2v, t2 | (t3 << 16)) + two) >> 2;
-        const uint32_t packed = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p23), __builtin_bit_cast(uint32_t, p01), 0x06040200u);
-        if (active) *reinterpret_cast<uint32_t*>(d + (size_t)(dy0 + k) * dst.pitch) = packed;
-    };
-    if (n_out == R) {   // wave-uniform: every band but the last of an image
-#pragma unroll
-        for (int k = 0; k < R; k++) out_row(k);
-    } else {
-#pragma unroll
-        for (int k = 0; k < R; k++)
-            if (k < n_out) out_row(k);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1024,327 +717,6 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
         __syncthreads();
     }
     if (tid == 0) cell_count[(size_t)img * n_cells + cell_id] = n_emitted;
-}
-
-// ------------------------------------------------------------------------------------------------
-// FAST over a STRIP of up to K horizontally adjacent cells (StripDesc, orb_host.h) in one workgroup.
-// The detection areas of the cells of a cell row are contiguous, so staging, the quick test, the work list and the arc scores
-// treat the strip as one wide cell — one set-up and two block scans per wave for K / (T / 64) cells instead of one per
-// two waves and cell, fuller lanes in every loop, the 3-pixel column halo staged once per strip instead of once per cell.
-// What the reference defines per cell stays per cell:
-//   * NMS (cv::FAST runs on the cell's ROI, so a corner on the first / last detection column has no neighbour beyond it):
-//     the score plane gives every cell two apron columns of its own (score column = tile column + 2 * cell), never written;
-//   * emission order and slot run: kept corners set a bit in the cell's own row bitmap (64 bits per cell and detection row);
-//     rank = popcount prefix inside the cell;
-//   * the minThFAST fallback (ORBextractor.cc:843-847): a cell-activity mask selects the cells whose pixels the quick test
-//     lets through; the strip is run again at minThFAST for the cells that came out empty;
-//   * a strip with more quick-test survivors than the work list holds is redone one cell at a time (same mask; the list holds
-//     the flags of any single cell by construction).
-// ------------------------------------------------------------------------------------------------
-template <int K>
-struct StripGeo {
-    static constexpr int kMaxDw = (K * kStripMaxCellW + 6 + 3 + 3) / 4;  // dwords per staged ROI row (4-byte phase included)
-    static constexpr int P = 4 * kMaxDw + 8;                              // tile pitch, bytes
-    static constexpr int SP = (P + 2 * K + 3) & ~3;                       // score pitch (two apron columns per cell)
-    static constexpr int kTilePitch = P;                                  // (fast_arc_contrast's name for it)
-};
-struct StripLds {  // byte offsets of the dynamic LDS carve (host-computed from the geometry's tallest ROI / largest cell)
-    int tile, score, score_bytes, work, work_cap, kbits, kprefix, total;
-};
-template <int K>
-StripLds strip_lds_layout(int max_rh, int work_cap) {
-    StripLds L;
-    int o = 0;
-    // (the tile comes last: the kernel addresses it through a pointer biased by -(3 rows + 3 bytes), which must stay inside LDS)
-    L.score = o; L.score_bytes = ((max_rh - 6 + 3) * StripGeo<K>::SP + 15) & ~15; o += L.score_bytes;
-    L.work_cap = (work_cap + 7) & ~7;
-    L.work = o; o += L.work_cap * 2;
-    // the row bitmaps and their prefix live in the head of the TILE: the tile is dead once the arc scores are written; a strip that
-    // has to run again (cells redone at minThFAST, or one cell at a time) stages its ROI again
-    const int max_words = std::min(K * std::max(max_rh - 6, 1), kStripThreads);   // bitmap rows: cells x detection rows
-    L.tile = o;
-    L.kbits = o;
-    L.kprefix = o + 2 * max_words * 4;
-    o += std::max((kTileFront + (max_rh + 1) * StripGeo<K>::P + 8 + 15) & ~15, 2 * max_words * 4 + (((max_words + 1) * 4 + 15) & ~15));
-    L.total = (o + 15) & ~15;
-    return L;
-}
-
-template <int K, int T>
-__global__ __launch_bounds__(T) void fast_strip_kernel(PyramidView pyr, const StripDesc* __restrict__ strips, int n_strips, int ini_th,
-                                                       int min_th, int slots_per_image, Cand16* __restrict__ slots,
-                                                       int* __restrict__ cell_count, int n_cells, uint32_t gx_magic, StripLds L, int debug_stop) {
-    using GEO = StripGeo<K>;
-    constexpr int P = GEO::P, SP = GEO::SP, kMaxR = kStripMaxR;
-    constexpr int kIdBits = T == 256 ? 8 : 7;
-    static_assert(T == 128 || T == 256, "entry ids hold 7 or 8 thread bits");
-    extern __shared__ __attribute__((aligned(16))) uint8_t strip_mem[];
-    __shared__ int wave_tot[2][T / 64];
-    __shared__ uint16_t lut[32];
-    __shared__ uint16_t tbase[T];
-    __shared__ int slot_off_s[K];
-    uint8_t* const tile = strip_mem + L.tile + kTileFront;
-    const uint8_t* const tile_win = tile - 3 * GEO::P - 3;   // a pixel's 7 x 7 window starts here + its tile offset
-    uint8_t* const score = strip_mem + L.score;
-    uint16_t* const work = reinterpret_cast<uint16_t*>(strip_mem + L.work);
-    uint32_t* const kbits = reinterpret_cast<uint32_t*>(strip_mem + L.kbits);     // [cell * dh + row][2]
-    int* const kprefix = reinterpret_cast<int*>(strip_mem + L.kprefix);           // [cell * dh + row], + total at the end
-
-    // XCD-aware order (see fast_cells_kernel)
-    const unsigned total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-    const unsigned chunk = (total + 7) >> 3;
-    unsigned wg = (lin & 7u) * chunk + (lin >> 3);
-    if (total & 7u) wg = lin;
-    const int img = gx_magic ? (int)__umulhi(wg, gx_magic) : (int)(wg / gridDim.x);
-    const int strip_id = (int)(wg - (unsigned)img * gridDim.x);
-    const StripDesc sd = strips[strip_id];
-    const LevelView lv = pyr.lv[sd.level];
-    const int rw = sd.rw, rh = sd.rh, dh = rh - 6, ncell = sd.ncell, w_cell = sd.w_cell;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ga = sd.x0 & ~3;
-    const int x_lo = sd.x0 + 3, x_hi = sd.x0 + rw - 3;
-    const int gx0 = x_lo & ~3;
-    const int G = sd.G;
-    const int c_lo = gx0 - ga;
-    const uint32_t magic = sd.g_magic, wc_magic = sd.wc_magic;
-
-    // phase 0: stage the ROI with 16-byte lanes: lane (row r0 + 16 p, quad c) copies dwords 4c .. 4c + 3 of its row — 3-4 load
-    // instructions per thread for the whole strip, all in flight at once (the level rows are only 4-byte aligned for these loads,
-    // which the memory pipeline splits; the tile rows are written as dwords).  A quad may run up to 12 bytes past the ROI: still
-    // inside the level row (ROIs end 16 pixels before the border).
-    auto stage_tile = [&]() {
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const uint8_t* src = lv.base + (size_t)img * lv.img_stride + (size_t)sd.y0 * lv.pitch + ga;
-        const int nq = (sd.ndw + 3) >> 2;
-        constexpr int kRowsPerPass = T / 16, kPasses = (58 + kRowsPerPass - 1) / kRowsPerPass;
-        const int c = tid & 15, r0 = tid >> 4;
-        if (c < nq) {
-            u32x4 v[kPasses];
-#pragma unroll
-            for (int p = 0; p < kPasses; p++) {
-                const uint32_t row = (uint32_t)min(r0 + p * kRowsPerPass, rh - 1);
-                __builtin_memcpy(&v[p], __builtin_assume_aligned(src + (__umul24(row, (uint32_t)lv.pitch) + 16u * (uint32_t)c), 4), 16);
-            }
-            uint32_t* l0 = reinterpret_cast<uint32_t*>(tile + r0 * P + 16 * c);
-#pragma unroll
-            for (int p = 0; p < kPasses; p++)
-                if (r0 + p * kRowsPerPass < rh) {
-                    uint32_t* d = l0 + p * kRowsPerPass * (P / 4);
-                    d[0] = v[p].x; d[1] = v[p].y; d[2] = v[p].z; d[3] = v[p].w;
-                }
-        }
-    };
-    stage_tile();
-    if (tid < 32) lut[tid] = (uint16_t)((((tid >> 1) & 3) << 8) + (tid >> 3) + ((tid & 1) << 15));  // flag bit -> work entry offset
-    if (tid < K) slot_off_s[tid] = strips[strip_id].slot_off[tid];   // (indexing the register copy by lane would put it in scratch)
-
-    // quick-test mapping: thread (strip of rows, group) — uniform split
-    const int strip = (int)(__umul24((uint32_t)tid, magic) >> 20);
-    const int g_own = tid - strip * G;
-    const int R = sd.R;
-    const int y_b = strip * R;
-    const int nrows = min(max(dh - y_b, 0), R);
-    const int c_own = c_lo + 4 * g_own;
-    // per-pixel masks of the group: 0x80 in the bytes whose pixel lies in the detection range, split by the (at most two) cells
-    // the group touches; cA = cell of the group's first detection pixel
-    uint32_t HmA, HmB;
-    int cA;
-    {
-        const int xg = ga + c_own;
-        const int vlo = min(max(x_lo - xg, 0), 4), vhi = min(max(x_hi - xg, 0), 4);
-        uint32_t Hm = (0x80808080u << (8 * vlo)) & (uint32_t)(0x0080808080ull >> (8 * (4 - vhi)));  // shifts by 32 must give 0
-        if (vlo >= 4) Hm = 0;
-        cA = min((int)(__umul24((uint32_t)max(xg + vlo - x_lo, 0), wc_magic) >> 20), ncell - 1);
-        const int nb = min(max(x_lo + (cA + 1) * w_cell - xg, 0), 4);          // pixels of the group in front of cell cA + 1
-        const uint32_t low = (uint32_t)((1ull << (8 * nb)) - 1ull);
-        HmA = Hm & low; HmB = Hm & ~low;
-    }
-    tbase[tid] = (uint16_t)(((y_b + 3) << 8) | c_own);
-    auto quick_test = [&](int th, uint32_t Hm, uint32_t& wA, uint32_t& wB) {
-        wA = 0; wB = 0;
-        const uint8_t* colp = &tile[(int)__umul24((uint32_t)y_b, P) + c_own];
-        uint32_t cw[kMaxR + 6], lw[kMaxR], rw_[kMaxR];
-#pragma unroll
-        for (int r = 0; r < kMaxR + 6; r++)
-            if (r < 9 || r - 6 < R) cw[r] = *reinterpret_cast<const uint32_t*>(colp + r * P);
-#pragma unroll
-        for (int k = 0; k < kMaxR; k++)
-            if (k < 3 || k < R) {
-                lw[k] = *reinterpret_cast<const uint32_t*>(colp + (k + 3) * P - 4);
-                rw_[k] = *reinterpret_cast<const uint32_t*>(colp + (k + 3) * P + 4);
-            }
-        const ushort2v t2 = __builtin_bit_cast(ushort2v, (uint32_t)th * 0x00010001u);
-#pragma unroll
-        for (int k = 0; k < kMaxR; k++) {
-            if (k >= 3 && k >= R) break;  // workgroup-uniform
-            const uint32_t V = cw[k + 3], U = cw[k], D = cw[k + 6];
-            const uint32_t R3 = __builtin_amdgcn_alignbyte(rw_[k], V, 3);
-            const uint32_t L3 = __builtin_amdgcn_alignbyte(V, lw[k], 1);
-            const uint32_t Ve = V & 0x00ff00ffu, Vo = (V >> 8) & 0x00ff00ffu;
-            const uint32_t Ae = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, Ve), t2));
-            const uint32_t Ao = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, Vo), t2));
-            const uint32_t Qd = ~(Ae | (Ao << 8));
-            const uint32_t Be = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, Ve ^ 0x00ff00ffu), t2));
-            const uint32_t Bo = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, Vo ^ 0x00ff00ffu), t2));
-            const uint32_t Qb = Be | (Bo << 8);
-            const uint32_t one = 0x01010101u;
-            const uint32_t X = (__builtin_amdgcn_lerp(U, Qd, one) & __builtin_amdgcn_lerp(D, Qd, one)) |
-                               (__builtin_amdgcn_lerp(L3, Qd, one) & __builtin_amdgcn_lerp(R3, Qd, one));
-            const uint32_t Y = (__builtin_amdgcn_lerp(U, Qb, 0u) | __builtin_amdgcn_lerp(D, Qb, 0u)) &
-                               (__builtin_amdgcn_lerp(L3, Qb, 0u) | __builtin_amdgcn_lerp(R3, Qb, 0u));
-            const uint32_t hm = k < nrows ? Hm : 0u;
-            const uint32_t z = (Y & hm) | ((~X & hm) >> 1);
-            if (k < 4) wA |= z >> (6 - 2 * k);
-            else wB |= z >> (6 - 2 * (k - 4));
-        }
-    };
-    const int score_words = L.score_bytes >> 4;
-    const int n_words = ncell * dh;          // bitmap rows (64 bits each) of the strip, <= T
-    auto clear_score = [&]() {
-        for (int i = tid; i < score_words; i += T) reinterpret_cast<uint4*>(score)[i] = uint4{0, 0, 0, 0};
-    };
-    const int sc_off = 4 - c_lo;
-    Cand16* const out_img = slots + (size_t)img * slots_per_image;
-    int* const cnt_img = cell_count + (size_t)img * n_cells + sd.cell0;
-
-    // control: cells still to do at the current threshold; a saturated run is repeated one cell at a time
-    uint32_t todo = (1u << ncell) - 1u, empties = 0;
-    int th = ini_th;
-    bool minpass = false, single = false, tile_dirty = false;
-    for (;;) {
-        if (todo == 0) {
-            if (minpass || ini_th == min_th || empties == 0) break;
-            todo = empties; empties = 0; th = min_th; minpass = true; single = false;
-        }
-        const uint32_t mask = single ? (todo & (0u - todo)) : todo;
-        __syncthreads();       // staging done / the previous run's planes, lists and counts are no longer read
-        if (debug_stop == 1) return;
-        if (tile_dirty) {      // a run before this one put its bitmaps into the tile
-            stage_tile();
-            __syncthreads();
-        }
-        tile_dirty = true;
-        clear_score();
-        const uint32_t Hm = (((mask >> cA) & 1u) ? HmA : 0u) | (((mask >> (cA + 1)) & 1u) ? HmB : 0u);
-        uint32_t wA, wB;
-        quick_test(th, Hm, wA, wB);
-        const int cnt = __popc(wA) + __popc(wB);
-        int n_work = 0;
-        const int my_base = block_excl_scan<T / 64>(cnt, lane, wave, wave_tot[0], &n_work);   // (its barrier also covers the clear)
-        if (debug_stop == 2) return;
-        if (n_work > L.work_cap) {
-            tile_dirty = false;   // nothing was written over the tile
-            if (!single) { single = true; continue; }
-            // cannot happen (the list holds any single cell's flags); give the cell up rather than loop
-            if (tid == 0) cnt_img[__builtin_ctz(mask)] = 0;
-            todo &= ~mask;
-            continue;
-        }
-        {
-            uint16_t* wp = &work[my_base];
-            const uint32_t idA = (uint32_t)tid << 5, idB = idA | (1u << (5 + kIdBits));
-            for (uint32_t w = wA; w; w &= w - 1) *wp++ = (uint16_t)(idA | (uint32_t)__builtin_ctz(w));
-            for (uint32_t w = wB; w; w &= w - 1) *wp++ = (uint16_t)(idB | (uint32_t)__builtin_ctz(w));
-        }
-        __syncthreads();
-        if (debug_stop == 3) return;
-        // arc scores, all lanes busy.  A wave works through the chunks wave, wave + T / 64, ... of the list and leaves the corners
-        // it finds (cell << 14 | tile row << 8 | score column) packed at the front of its OWN chunks — it has read more entries
-        // than it writes, so nothing unread is overwritten —: NMS and emission then loop over corners only (a third of the list).
-        const int wbase = wave * 64;
-        int n_corner = 0;                                    // wave-uniform
-        for (int i0 = wbase; i0 < n_work; i0 += T) {
-            const int i = i0 + lane;
-            bool corner = false;
-            int ce = 0;
-            if (i < n_work) {
-                const int id = work[i];
-                const int e = tbase[(id >> 5) & (T - 1)] + lut[id & 31] + ((id >> (5 + kIdBits)) << 10);
-                const int ty = (e >> 8) & 127, tx = e & 255;
-                const int A = fast_arc_contrast_win<GEO>(tile_win + ((int)__umul24((uint32_t)ty, P) + tx), (e & 0x8000) ? -1 : 1);
-                if (A > th) {
-                    const int cell = (int)(__umul24((uint32_t)(tx + (ga - x_lo)), wc_magic) >> 20);
-                    const int sx = tx + sc_off + 2 * cell;
-                    score[(int)__umul24((uint32_t)(ty - 2), SP) + sx] = (uint8_t)(A - 1);
-                    ce = (cell << 14) | ((e & 0x3F00) + sx);
-                    corner = true;
-                }
-            }
-            const unsigned long long bm = __ballot(corner);
-            if (corner) {
-                const int m = n_corner + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-                work[(m >> 6) * T + wbase + (m & 63)] = (uint16_t)ce;
-            }
-            n_corner += __popcll(bm);
-        }
-        __syncthreads();
-        if (debug_stop == 4) return;
-        if (tid < n_words) *reinterpret_cast<uint2*>(&kbits[2 * tid]) = uint2{0, 0};   // (in the tile, which is dead from here on)
-        __syncthreads();
-        // NMS over the wave's own corners; kept corners set a bit in their cell's row bitmap
-        uint32_t mine_keep = 0;
-        {
-            int slot = 0;
-            for (int m0 = 0; m0 < n_corner; m0 += 64, slot++) {
-                if (m0 + lane >= n_corner) continue;
-                const int e = work[slot * T + wbase + lane];
-                const int cell = e >> 14, ty = (e >> 8) & 63, sx = e & 255;
-                const uint8_t* q = score + ((int)__umul24((uint32_t)(ty - 3), SP) + sx - 1);   // top-left neighbour
-                const int sv = q[SP + 1];
-                int m = max3i(q[0], q[1], q[2]);
-                m = max3i(m, q[SP], q[SP + 2]);
-                m = max(m, max3i(q[2 * SP], q[2 * SP + 1], q[2 * SP + 2]));
-                if (sv > m) {
-                    const int bit = sx - sc_off - 2 * cell + (ga - x_lo) - cell * w_cell;   // column inside the cell's detection area, < 64
-                    const int wi = cell * dh + (ty - 3);
-                    atomicOr(&kbits[2 * wi + (bit >> 5)], 1u << (bit & 31));
-                    mine_keep |= 1u << slot;
-                }
-            }
-        }
-        __syncthreads();
-        const uint32_t w0 = tid < n_words ? kbits[2 * tid] : 0u, w1 = tid < n_words ? kbits[2 * tid + 1] : 0u;
-        int n_out = 0;
-        const int wprefix = block_excl_scan<T / 64>(__popc(w0) + __popc(w1), lane, wave, wave_tot[1], &n_out);
-        if (tid < n_words) kprefix[tid] = wprefix;
-        if (tid == 0) kprefix[n_words] = n_out;
-        __syncthreads();
-        {
-            int slot = 0;
-            for (int m0 = 0; m0 < n_corner; m0 += 64, slot++) {
-                if (!(mine_keep & (1u << slot))) continue;
-                const int e = work[slot * T + wbase + lane];
-                const int cell = e >> 14, ty = (e >> 8) & 63, sx = e & 255;
-                const int tx = sx - sc_off - 2 * cell;
-                const int bit = tx + (ga - x_lo) - cell * w_cell;
-                const int wi = cell * dh + (ty - 3);
-                const uint32_t b0 = kbits[2 * wi], b1 = kbits[2 * wi + 1];
-                const int before = bit < 32 ? __popc(b0 & ((1u << bit) - 1u)) : __popc(b0) + __popc(b1 & ((1u << (bit - 32)) - 1u));
-                const int rank = kprefix[wi] - kprefix[cell * dh] + before;
-                Cand16 c;
-                c.x = (uint16_t)(ga + tx - kMinBorder);
-                c.y = (uint16_t)(sd.y0 + ty - kMinBorder);
-                c.score = score[(int)__umul24((uint32_t)(ty - 2), SP) + sx];
-                c.pad = 0;
-                out_img[slot_off_s[cell] + rank] = c;
-            }
-        }
-        // per-cell totals straight from the prefix (every thread reads the K + 1 cell boundaries: no further barrier)
-        {
-            int prev = 0;   // kprefix[0]
-#pragma unroll
-            for (int c = 0; c < K; c++) {
-                if (c >= ncell) break;
-                const int nxt = kprefix[(c + 1) * dh];
-                if ((mask >> c) & 1u) {
-                    if (tid == c) cnt_img[c] = nxt - prev;
-                    if (!minpass && nxt == prev) empties |= 1u << c;
-                }
-                prev = nxt;
-            }
-        }
-        todo &= ~mask;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2045,77 +1417,23 @@ void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_
                          (src.img_stride & 3) == 0 && src.pitch >= ((src.w + 3) & ~3) + 8 &&
                          (reinterpret_cast<uintptr_t>(tx) & 15) == 0;
     constexpr int R = 8;  // rows per wave
-    // test aids: MSORB_PYR_SINGLE -> one-row kernels, MSORB_PYR_ROWS -> row-streaming kernel, MSORB_PYR_DMA -> LDS-DMA band kernel
-    // (default = the register band kernel: 0.168 against 0.180 ms per 256 KITTI images for the LDS-DMA form once both share
-    // pyr_band_tile's arithmetic — and 25 instead of 40 KB of LDS per workgroup beside the other batch's kernels)
-    const bool rows_env = !getenv("MSORB_PYR_SINGLE");
-    const bool band_env = !getenv("MSORB_PYR_ROWS");
-    const bool dma_env = getenv("MSORB_PYR_DMA") != nullptr && !getenv("MSORB_PYR_BAND");
-    // the band kernels park the source rows of a band of R output rows: at most floor((R - 1) * scale) + 3 of them (<= 12),
-    // and decode the 4 taps of a lane out of an 8-byte window (horizontal scale <= 1.25)
+    // the band kernel parks the source rows of a band of R output rows: at most floor((R - 1) * scale) + 3 of them (<= 12),
+    // and decodes the 4 taps of a lane out of an 8-byte window (horizontal scale <= 1.25); batches only (a frame or two are
+    // launch latency, not throughput: the one-row kernel has the shorter dependent chain)
     const double sy = (double)src.h / (double)dst.h, sx = (double)src.w / (double)dst.w;
-    const bool band_ok = aligned && rows_env && band_env && n_images >= 16 && (int)std::floor((R - 1) * sy) + 3 <= 12 && sx <= 1.25;
-    // the LDS-DMA kernel stages 336-byte row segments as 16-byte granules: 16-byte aligned rows, 64 windows within 336 bytes
-    const bool dma_ok = band_ok && dma_env && (reinterpret_cast<uintptr_t>(src.base) & 15) == 0 && (src.pitch & 15) == 0 &&
-                        (src.img_stride & 15) == 0 && src.pitch >= 336 && 252.0 * sx + 28.0 <= 336.0;
-    const dim3 band_grid((dst.w + 255) / 256, (dst.h + 4 * R - 1) / (4 * R), n_images);
-    if (dma_ok) hipLaunchKernelGGL(pyr_resize_dma_kernel<R>, band_grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
-    else if (band_ok) {
-        // two waves (12 KB of LDS) per workgroup: beside the other batch's FAST / quadtree / describe, which fill a CU's LDS
-        // to within 5-12 KB, small workgroups find room sooner (1.310 against 1.324 ms per step with 4 waves, 1.336 with 1)
-        static const int bw = getenv("MSORB_PYR_BAND_WAVES") ? atoi(getenv("MSORB_PYR_BAND_WAVES")) : 2;
-        const bool lds_form = getenv("MSORB_PYR_BAND_LDS") != nullptr;   // the round-2 form (rows parked in LDS); test aid
-        if (!lds_form) {
-            if (bw == 1) hipLaunchKernelGGL((pyr_resize_bandreg_kernel<R, 12, 1>), dim3((dst.w + 255) / 256, (dst.h + R - 1) / R, n_images), dim3(64), 0, s, src, dst, dst_base, tx, ty);
-            else if (bw == 4) hipLaunchKernelGGL((pyr_resize_bandreg_kernel<R, 12, 4>), band_grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
-            else hipLaunchKernelGGL((pyr_resize_bandreg_kernel<R, 12, 2>), dim3((dst.w + 255) / 256, (dst.h + 2 * R - 1) / (2 * R), n_images), dim3(128), 0, s, src, dst, dst_base, tx, ty);
-        }
-        else if (bw == 1) hipLaunchKernelGGL((pyr_resize_band_kernel<R, 12, 1>), dim3((dst.w + 255) / 256, (dst.h + R - 1) / R, n_images), dim3(64), 0, s, src, dst, dst_base, tx, ty);
-        else if (bw == 2) hipLaunchKernelGGL((pyr_resize_band_kernel<R, 12, 2>), dim3((dst.w + 255) / 256, (dst.h + 2 * R - 1) / (2 * R), n_images), dim3(128), 0, s, src, dst, dst_base, tx, ty);
-        else hipLaunchKernelGGL((pyr_resize_band_kernel<R, 12, 4>), band_grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
-    }
-    else if (aligned && rows_env && n_images >= 16)
-        hipLaunchKernelGGL(pyr_resize_rows_kernel<R>, dim3((dst.w + 255) / 256, (dst.h + 4 * R - 1) / (4 * R), n_images), dim3(256),
-                           0, s, src, dst, dst_base, tx, ty);
+    const bool band_ok = aligned && n_images >= 16 && (int)std::floor((R - 1) * sy) + 3 <= 12 && sx <= 1.25;
+    if (band_ok)   // two waves per workgroup: small workgroups find room sooner beside the other batch's kernels
+        hipLaunchKernelGGL((pyr_resize_bandreg_kernel<R, 12, 2>), dim3((dst.w + 255) / 256, (dst.h + 2 * R - 1) / (2 * R), n_images), dim3(128), 0,
+                           s, src, dst, dst_base, tx, ty);
     else if (aligned) hipLaunchKernelGGL(pyr_resize_aligned_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
     else hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty, 0);
 }
 // ComputePyramid for a batch: levels 1 .. n-1, each from the one above (ORBextractor.cc:1179-1193), one launch per level.
-// MSORB_PYR_TAIL=1 puts the last up to three levels into one launch (pyr_resize_tail_kernel) — measured on MI355X, 256 KITTI
-// images: 33 us instead of 42 us for the three launches with the stage alone on the GPU, but the whole step gets slower
-// (1.366 vs 1.352 ms): a 16-wave workgroup with 98 KB of LDS per CU keeps the other stream's kernels out.  Off by default.
 void launch_pyramid(const PyramidView& pyr, const ResizeTap* taps, const size_t* tap_x_off, const size_t* tap_y_off, int n_images,
                     hipStream_t s, const Semantics& sem) {
-    const int nl = pyr.nlevels;
-    constexpr int R = 8;
-    int tail = 0;
-    if (!sem.resize_single_stage && n_images >= 64 && getenv("MSORB_PYR_TAIL") && !getenv("MSORB_PYR_SINGLE") && !getenv("MSORB_PYR_ROWS")) {
-        while (tail < 3 && nl - 1 - tail >= 2) {   // at least level 1 stays a launch of its own
-            const int l = nl - 1 - tail;
-            const LevelView &src = pyr.lv[l - 1], &dst = pyr.lv[l];
-            const ResizeTap* tx = taps + tap_x_off[l];
-            const bool aligned = (reinterpret_cast<uintptr_t>(src.base) & 3) == 0 && (src.pitch & 3) == 0 && (src.img_stride & 3) == 0 &&
-                                 src.pitch >= ((src.w + 3) & ~3) + 8 && (reinterpret_cast<uintptr_t>(tx) & 15) == 0;
-            const double sy = (double)src.h / (double)dst.h, sx = (double)src.w / (double)dst.w;
-            if (!aligned || (int)std::floor((R - 1) * sy) + 3 > 12 || sx > 1.25 || (size_t)dst.w * dst.h > 100000) break;
-            tail++;
-        }
-    }
-    for (int l = 1; l < nl - tail; l++)
+    for (int l = 1; l < pyr.nlevels; l++)
         launch_pyr_resize(pyr.lv[l - 1], pyr.lv[l], const_cast<uint8_t*>(pyr.lv[l].base), taps + tap_x_off[l], taps + tap_y_off[l], n_images, s,
                           sem.resize_single_stage);
-    if (tail) {
-        PyrTailArgs A{};
-        A.nl = tail;
-        const int first = nl - tail;
-        A.lv[0] = pyr.lv[first - 1];
-        for (int i = 0; i < tail; i++) {
-            A.lv[i + 1] = pyr.lv[first + i];
-            A.tx[i] = taps + tap_x_off[first + i];
-            A.ty[i] = taps + tap_y_off[first + i];
-        }
-        hipLaunchKernelGGL((pyr_resize_tail_kernel<R, 12>), dim3(n_images), dim3(1024), 0, s, A);
-    }
 }
 void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cells, int ini_th, int min_th,
                        int slots_per_image, Cand16* slots, int* cell_count, int n_images, bool small_cells, hipStream_t s) {
@@ -2124,7 +1442,7 @@ void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cell
         const LevelView& v = pyr.lv[l];
         aligned = aligned && (reinterpret_cast<uintptr_t>(v.base) & 3) == 0 && (v.pitch & 3) == 0 && (v.img_stride & 3) == 0;
     }
-    static const int dbg = getenv("MSORB_FAST_DEBUG_STOP") ? atoi(getenv("MSORB_FAST_DEBUG_STOP")) : 0;  // profiling only
+    const int dbg = 0;   // phase cut-off of the kernel (tools/fast_phases.py builds a variant with it set)
     const dim3 grid(n_cells, n_images);
     // q = mulhi(n, gx_magic) == n / n_cells for every n < n_cells * n_images (checked here, once per shape)
     uint32_t gx_magic = (uint32_t)((0x100000000ull + (unsigned)n_cells - 1) / (unsigned)n_cells);
@@ -2140,38 +1458,6 @@ void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cell
     else { if (aligned) MSORB_FAST_LAUNCH(true, GeoLarge); else MSORB_FAST_LAUNCH(false, GeoLarge); }
 #undef MSORB_FAST_LAUNCH
 }
-bool launch_fast_strips(const PyramidView& pyr, const StripDesc* strips, int n_strips, int n_small, const int* max_rh, const int* work_cap,
-                        int n_cells, int ini_th, int min_th, int slots_per_image, Cand16* slots, int* cell_count, int n_images,
-                        hipStream_t s) {
-    for (int l = 0; l < pyr.nlevels; l++) {
-        const LevelView& v = pyr.lv[l];
-        if ((reinterpret_cast<uintptr_t>(v.base) & 3) != 0 || (v.pitch & 3) != 0 || (v.img_stride & 3) != 0) return false;  // dword staging
-    }
-    if (n_strips < 1) return false;
-    static const int dbg = getenv("MSORB_FAST_DEBUG_STOP") ? atoi(getenv("MSORB_FAST_DEBUG_STOP")) : 0;  // profiling only
-    static const int cap_env = getenv("MSORB_STRIP_CAP") ? atoi(getenv("MSORB_STRIP_CAP")) : 0;          // tuning only
-    StripLds L[2];
-    const int count[2] = {n_small, n_strips - n_small};
-    for (int c = 0; c < 2; c++) {
-        if (count[c] <= 0) continue;
-        L[c] = strip_lds_layout<kStripCells>(max_rh[c], std::max(work_cap[c], cap_env));
-        if (L[c].total > 60 * 1024 || L[c].work_cap > 8192) return false;
-    }
-    // two launches, one per LDS class (orb_host.cc): first the bulk with the small footprint, then the few tall strips
-    for (int c = 0, first = 0; c < 2; first += count[c], c++) {
-        const int n = count[c];
-        if (n <= 0) continue;
-        uint32_t gx_magic = (uint32_t)((0x100000000ull + (unsigned)n - 1) / (unsigned)n);
-        {
-            const unsigned long long total = (unsigned long long)n * (unsigned)n_images;
-            const unsigned long long e = (unsigned long long)gx_magic * (unsigned)n - 0x100000000ull;
-            if (n < 2 || total >= 0x100000000ull || e * total >= 0x100000000ull) gx_magic = 0;
-        }
-        hipLaunchKernelGGL((fast_strip_kernel<kStripCells, kStripThreads>), dim3(n, n_images), dim3(kStripThreads), (size_t)L[c].total, s, pyr,
-                           strips + first, n, ini_th, min_th, slots_per_image, slots, cell_count, n_cells, gx_magic, L[c], dbg);
-    }
-    return true;
-}
 void launch_cand_compact(const CellDesc* cells, int n_cells, const int* level_cell_begin, int nlevels,
                          int slots_per_image, const Cand16* slots, const int* cell_count, int* cell_off,
                          int* level_count, int* img_total, int* img_base, Cand16* compact, int n_images,
@@ -2182,214 +1468,6 @@ void launch_cand_compact(const CellDesc* cells, int n_cells, const int* level_ce
     hipLaunchKernelGGL(cand_gather_kernel, dim3((n_cells + kGatherCells - 1) / kGatherCells, n_images), dim3(256), 0, s, cells, n_cells, slots_per_image,
                        slots, cell_count, cell_off, img_base, compact);
 }
-// ------------------------------------------------------------------------------------------------
-// The same 7 x 7 Gaussian on the matrix cores — an OPTION (`MSORB_BLUR_MFMA=1`), bit-equal to the VALU kernels, kept for what
-// it measured: a separable blur is two banded matrix products, the chain is bound by VALU issue and nothing in the front-end
-// uses the MFMA pipe.  The kernel needs 58 M VALU instructions per 256 images instead of gauss7_stream_kernel's 99 M and
-// 0.035 ms of matrix-pipe time — and 0.32 ms alone on the GPU against 0.18, 1.41 against 1.29 ms per pipelined step: it reads
-// every pixel three times (64 source columns per 32 outputs, strips of one image spread over the XCDs: 1.13 GB FETCH against
-// 0.45) and its waves are long dependent chains (load -> MFMA -> byte planes -> MFMA -> LDS turn -> store, with loads and stores
-// sharing the in-order vmcnt).  Two findings on the way: the fp32 MFMAs (v_mfma_f32_32x32x2_f32, 142 TFLOP/s measured,
-// tools/mfma_rate_f32.hip) run at exactly the vector ALUs' FMA rate and did not overlap with other waves' VALU work — the first,
-// fp32 form of the vertical pass cost more than the kernel it replaced —, and 16-byte stores of 32-byte row pieces from four
-// waves at four times cost 0.22 ms against whole 128-byte lines from one workgroup.
-//   horizontal pass  H = P x Bh :  v_mfma_i32_32x32x32_i8 x 2 (K = 64 source columns X-16 .. X+47 for the 32 output columns
-//       X .. X+31).  A operand = pixels: lane (row r = lane & 31, half = lane >> 5) loads 16 consecutive bytes of its row for
-//       each K step, xor 0x80 makes them signed (p - 128); B operand = the band matrix, built once per wave: byte j of
-//       lane (column n, half) is the weight of source column x for output column X + n — tap(x - (X + n) + 3) plus, in the first /
-//       last strip, the taps that BORDER_REFLECT_101 folds back onto x; columns that do not exist weigh 0.  Both operands use the
-//       same lane -> (row / column, k slot) rule, so the order of k inside the instruction does not matter.
-//   vertical pass  V = Bv x H :  i8 again (the fp32 MFMAs run on the vector ALUs' own FMA units — 142 TFLOP/s, the VALU rate —,
-//       so a fp32 form of this pass, built first, cost more vector time than the kernel it replaced; the i8 / bf16 forms run on
-//       the matrix cores proper).  H is 16 bits wide: it is fed as two byte planes, hi = H >> 8 and lo = H & 255, two MFMAs each
-//       (tile j, and rows 0 .. 6 of tile j + 1), and the planes are recombined as 256 * acc_hi + acc_lo.  The H tile sits in the
-//       accumulator layout — lane (column n, half) holds rows 4 half + (i & 3) + 8 (i >> 2) in register i — and the byte planes
-//       keep that order: byte 4 q + b of the operand = register 4 q + b, with the weights (a per-lane constant) in the same
-//       order.  An output block covers rows 32 j + 4 .. 32 j + 35, so it needs tile j and tile j + 1 and no tile above.
-//   Rows are reflected by LOADING the reflected source row (the horizontal pass is row independent), so no block has special
-//   weights; out = (V + 32768) >> 16 (saturated when the taps sum to more than 256).
-//   One wave = one 32-column strip x plan.chunk output blocks; 1 KB of LDS per wave (output transpose), no workgroup barrier.
-// ------------------------------------------------------------------------------------------------
-typedef int bm_v4i __attribute__((ext_vector_type(4)));
-typedef int bm_v16i __attribute__((ext_vector_type(16)));
-typedef float bm_v16f __attribute__((ext_vector_type(16)));
-struct BlurMfmaPlan {
-    int task_begin[kMaxLevels + 1];  // first task of each level (per image)
-    int strips[kMaxLevels];          // groups of four 32-column strips of the level
-    int nblocks[kMaxLevels];         // output blocks j = -1 .. nblocks - 2 of the level
-    int nlevels;
-    int chunk;                       // output blocks (32 rows each) per wave
-};
-
-__device__ __forceinline__ uint32_t bm_tap(int t, unsigned long long K) {   // k[t] for 0 <= t <= 6, else 0
-    return (t >= 0 && t <= 6) ? (uint32_t)(K >> (8 * t)) & 255u : 0u;
-}
-
-template <bool SAT>
-__global__ __launch_bounds__(256, 6) void gauss7_mfma_kernel(PyramidView src, PyramidView dst, BlurMfmaPlan plan, GaussTaps T, int tasks_per_image, int n_images, int dbg) {
-    // the workgroup's output tile (32 rows x 4 strips = 128 bytes per row) on its way to row-major, double buffered
-    __shared__ __attribute__((aligned(16))) uint32_t wg_tile[2][32 * 32];
-    const int lane = threadIdx.x & 63, half = lane >> 5, c = lane & 31, wv = threadIdx.x >> 6;
-    if (dbg & 8) __builtin_amdgcn_s_setprio(3);   // experiment
-    // One workgroup = four ADJACENT strips (128 columns) x plan.chunk blocks, its four waves in step: the finished 32 x 128 tile is
-    // stored as whole 128-byte lines.  (Every wave storing its own 32-byte row pieces left the L2 with quarter lines from four
-    // waves at four different times: 0.22 of that version's 0.42 ms.)  The grid may be smaller than the task list.
-    const int n_all = tasks_per_image * n_images;
-    int parity = 0;
-    for (int gt = (int)blockIdx.x; gt < n_all; gt += (int)gridDim.x) {
-    const int img = gt / tasks_per_image, task = gt - img * tasks_per_image;
-    int level = 0;
-    while (level + 1 < plan.nlevels && task >= plan.task_begin[level + 1]) level++;
-    const int idx = task - plan.task_begin[level];
-    const int n_groups = plan.strips[level];            // groups of four strips
-    const int rc = idx / n_groups, sg = idx - rc * n_groups;
-    const int cs = 4 * sg + wv;                         // (a strip past the level's last one works on columns >= w: nothing is stored)
-    const LevelView sv = src.lv[level], dv = dst.lv[level];
-    const int w = sv.w, h = sv.h, X = 32 * cs;
-    const uint8_t* sb = sv.base + (size_t)img * sv.img_stride;
-    uint8_t* db = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride;
-    unsigned long long K = 0;
-    uint32_t ksum = 0;
-#pragma unroll
-    for (int t = 0; t < 7; t++) { K |= (unsigned long long)(T.k[t] & 255u) << (8 * t); ksum += T.k[t]; }
-
-    // B operand of the horizontal pass (band matrix): 2 K steps x 16 bytes per lane
-    bm_v4i bh[2];
-    const int xn = X + c;
-    const bool edge = X == 0 || X + 32 + 3 >= w;   // wave-uniform: some output column of the strip reaches across a border
-#pragma unroll
-    for (int s = 0; s < 2; s++)
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            uint32_t word = 0;
-            const int x0 = X - 16 + 32 * s + 16 * half + 4 * d;
-            if (!edge) {
-                // interior: bytes t0 .. t0 + 3 of the zero-padded tap sequence, t0 = x0 - xn + 3
-                const int t0 = x0 - xn + 3;
-                if (t0 > -4 && t0 < 7) word = t0 >= 0 ? (uint32_t)(K >> (8 * t0)) : (uint32_t)(K << (8 * -t0));
-            } else {
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const int x = x0 + b;
-                    uint32_t wgt = 0;
-                    if (x >= 0 && x < w) {
-                        wgt = bm_tap(x - xn + 3, K);
-                        if (x >= 1) wgt += bm_tap(-x - xn + 3, K);                       // source column -x reflects onto x
-                        if (x <= w - 2) wgt += bm_tap(2 * (w - 1) - x - xn + 3, K);      // source column 2 (w - 1) - x too
-                    }
-                    word |= (wgt & 255u) << (8 * b);
-                }
-            }
-            bh[s][d] = (int)word;
-        }
-    // Weights of the vertical pass (B operand: lane = output row m = c of the block, byte 4 q + b <-> H row rho(half, 4 q + b) of
-    // tile j, resp. 32 + rho of tile j + 1), for output row 32 j + 4 + m
-    bm_v4i wv_own, wv_next;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        uint32_t wo = 0, wn = 0;
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int rho = 4 * half + b + 8 * q;
-            wo |= bm_tap(rho - c - 1, K) << (8 * b);
-            if (q == 0) wn |= bm_tap(31 + rho - c, K) << (8 * b);     // rows 0 .. 6 of the next tile sit in dword 0 of both halves
-        }
-        wv_own[q] = (int)wo; wv_next[q] = (int)wn;
-    }
-    bm_v16i czero;
-#pragma unroll
-    for (int i = 0; i < 16; i++) czero[i] = 0;
-    // Bookkeeping of the signed bytes.  Pixels enter as a = p - 128, so the row sums come out as H' = H - 128 ksum.  H' (16 bits,
-    // signed) is split into hi = H' >> 8 (signed byte) and lo = H' & 255, fed as lo - 128: with every output's weights summing to
-    // ksum,  V + 32768 = 256 * acc_hi + acc_lo + 128 ksum + 128 ksum^2 + 32768,  and the pixel is bits 16 .. 23 of that.
-    const uint32_t round_c = 128u * ksum + 128u * ksum * ksum + 32768u;
-
-    // source columns of this lane's two 16-byte loads (clamped loads only ever hold columns of weight 0)
-    int xoff[2];
-#pragma unroll
-    for (int s = 0; s < 2; s++) xoff[s] = min(max(X - 16 + 32 * s + 16 * half, 0), sv.pitch - 16);
-    struct Px { bm_v4i a0, a1; };
-    struct Hp { bm_v4i hi, lo; };   // an H tile as the two byte planes of the vertical pass's A operand
-    auto load_rows = [&](int J) {   // pixel rows 32 J .. 32 J + 31 (reflected), this lane's 2 x 16 bytes
-        int y = 32 * J + c;
-        y = y < 0 ? -y : (y >= h ? 2 * (h - 1) - y : y);
-        y = min(max(y, 0), h - 1);            // (far outside: feeds only outputs that are not stored)
-        const uint8_t* rp = sb + (size_t)y * sv.pitch;
-        Px p;
-        p.a0 = *reinterpret_cast<const bm_v4i*>(rp + xoff[0]);
-        p.a1 = *reinterpret_cast<const bm_v4i*>(rp + xoff[1]);
-        return p;
-    };
-    auto h_tile = [&](Px p) {   // the horizontal pass of those rows, split into byte planes
-#pragma unroll
-        for (int d = 0; d < 4; d++) { p.a0[d] ^= (int)0x80808080u; p.a1[d] ^= (int)0x80808080u; }
-        bm_v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(p.a0, bh[0], czero, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(p.a1, bh[1], acc, 0, 0, 0);
-        Hp t;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t t0 = __builtin_amdgcn_perm((uint32_t)acc[4 * q + 1], (uint32_t)acc[4 * q], 0x05040100u);       // lo0 hi0 lo1 hi1
-            const uint32_t t1 = __builtin_amdgcn_perm((uint32_t)acc[4 * q + 3], (uint32_t)acc[4 * q + 2], 0x05040100u);   // lo2 hi2 lo3 hi3
-            t.lo[q] = (int)(__builtin_amdgcn_perm(t1, t0, 0x06040200u) ^ 0x80808080u);
-            t.hi[q] = (int)__builtin_amdgcn_perm(t1, t0, 0x07050301u);
-        }
-        return t;
-    };
-    // The vertical product is formed TRANSPOSED (H as the A operand, the weights as B: same registers, same constants): a lane owns
-    // one output ROW (lane & 31) and the columns 4 half + 8 q + 0..3 of the strip.
-    auto out_block = [&](int j, const Hp& Hc, const Hp& Hn) {
-        bm_v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Hc.hi, wv_own, czero, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Hn.hi, wv_next, acc, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 16; i++) acc[i] = (int)(((uint32_t)acc[i] << 8) + round_c);   // the lo plane accumulates on top of 256 * hi + constant
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Hc.lo, wv_own, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Hn.lo, wv_next, acc, 0, 0, 0);
-        // acc[4 q + b] = row (lane & 31), column 4 half + 8 q + b of the wave's 32 x 32 tile: into the workgroup tile (dword column
-        // 8 wave + half + 2 q), barrier, then wave w stores rows 8 w .. 8 w + 7 of the whole 128-byte-wide tile, 16 bytes per lane.
-        uint32_t* const tw = wg_tile[parity] + (lane & 31) * 32 + 8 * wv + half;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t sum[4];
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                sum[b] = (uint32_t)acc[4 * q + b];    // V + 32768: the pixel is bits 16 .. 23
-                if (SAT) sum[b] = min(sum[b], 0x00FFFFFFu);
-            }
-            tw[2 * q] = __builtin_amdgcn_perm(sum[1], sum[0], 0x0c0c0602u) | __builtin_amdgcn_perm(sum[3], sum[2], 0x06020c0cu);   // the four bytes 2
-        }
-        __syncthreads();
-        const int row = 8 * wv + (lane >> 3);
-        const bm_v4i row16 = *reinterpret_cast<const bm_v4i*>(wg_tile[parity] + row * 32 + 4 * (lane & 7));
-        parity ^= 1;    // (the other buffer is free: its readers passed this block's barrier)
-        const int y = 32 * j + 4 + row, x = 128 * sg + 16 * (lane & 7);
-        if (y >= 0 && y < h && !(dbg & 1)) {
-            uint8_t* op = db + (size_t)y * dv.pitch + x;
-            if (x + 15 < w) *reinterpret_cast<bm_v4i*>(op) = row16;
-            else
-                for (int b = 0; b < 16; b++)
-                    if (x + b < w) op[b] = (uint8_t)((uint32_t)row16[b >> 2] >> (8 * (b & 3)));
-        }
-    };
-
-    const int jb = -1 + rc * plan.chunk, je = min(jb + plan.chunk, plan.nblocks[level] - 1);
-    // Loads and stores share one in-order counter on this chip (vmcnt), so a wave that waits for the next tile's rows also waits
-    // for its last store: a deep prefetch ring inside the wave (built, measured slower) does not hide that — many waves per SIMD
-    // do.  The loop therefore keeps its register footprint small: two H tiles alternate, the rows of the next tile are requested
-    // one block ahead.
-    Hp Ha = h_tile(load_rows(jb)), Hb;
-    Px pn = load_rows(jb + 1);
-    for (int j = jb; j < je; j += 2) {
-        Hb = h_tile(pn);
-        pn = load_rows(j + 2);
-        out_block(j, Ha, Hb);
-        if (j + 1 >= je) break;
-        Ha = h_tile(pn);
-        pn = load_rows(j + 3);
-        out_block(j + 1, Hb, Ha);
-    }
-    }
-}
-
 int launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images, hipStream_t s, const Semantics& sem) {
     BlurPlan plan{};
     plan.nlevels = src.nlevels;
@@ -2398,47 +1476,9 @@ int launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images, 
         const LevelView& v = src.lv[l];
         aligned = aligned && (reinterpret_cast<uintptr_t>(v.base) & 3) == 0 && (v.pitch & 3) == 0 && (v.img_stride & 3) == 0;
     }
-    // matrix-core form (batches on 16-byte aligned planes; any taps): see gauss7_mfma_kernel
-    {
-        const char* e = getenv("MSORB_BLUR_MFMA");   // read per call: the tests run both forms in one process
-        bool mfma = e ? atoi(e) != 0 : false;
-        GaussTaps Tm;
-        uint32_t ksum = 0;
-        for (int i = 0; i < 7; i++) { Tm.k[i] = (uint32_t)sem.gauss_taps[i]; ksum += Tm.k[i]; }
-        for (int l = 0; l < src.nlevels && mfma; l++) {
-            const LevelView& v = src.lv[l];
-            const LevelView& d = dst.lv[l];
-            mfma = (reinterpret_cast<uintptr_t>(v.base) & 15) == 0 && (v.pitch & 15) == 0 && (v.img_stride & 15) == 0 && v.w >= 8 && v.h >= 8 &&
-                   v.pitch >= 16 && d.w == v.w && d.h == v.h;
-        }
-        for (int i = 0; i < 7 && mfma; i++) mfma = Tm.k[i] <= 64;   // a folded border weight (two taps) must fit a signed byte
-        // (taps summing to more than 256 — a semantics variant — would need a 17-bit row sum: the VALU kernels take them)
-        if (mfma && ksum <= 256) {
-            BlurMfmaPlan mp{};
-            mp.nlevels = src.nlevels;
-            static const int chunk_env = getenv("MSORB_BLUR_MFMA_CHUNK") ? atoi(getenv("MSORB_BLUR_MFMA_CHUNK")) : 0;   // tuning only
-            mp.chunk = chunk_env > 0 ? chunk_env : 16;
-            static const int bm_dbg = getenv("MSORB_BLUR_MFMA_DEBUG") ? atoi(getenv("MSORB_BLUR_MFMA_DEBUG")) : 0;   // timing experiments only
-            int total = 0;
-            for (int l = 0; l < src.nlevels; l++) {
-                const LevelView& v = src.lv[l];
-                mp.task_begin[l] = total;
-                mp.strips[l] = ((v.w + 31) / 32 + 3) / 4;   // groups of four 32-column strips
-                const int jlast = v.h > 36 ? (v.h - 36 + 31) / 32 : 0;   // 32 jlast + 35 >= h - 1
-                mp.nblocks[l] = jlast + 2;                                // blocks -1 .. jlast
-                total += mp.strips[l] * ((mp.nblocks[l] + mp.chunk - 1) / mp.chunk);
-            }
-            mp.task_begin[src.nlevels] = total;
-            static const int wgs_env = getenv("MSORB_BLUR_MFMA_WGS") ? atoi(getenv("MSORB_BLUR_MFMA_WGS")) : 0;   // tuning only
-            const int n_wg = std::min(wgs_env > 0 ? wgs_env : 1 << 20, total * n_images);   // (a smaller grid: the workgroups loop over the tasks)
-            hipLaunchKernelGGL(gauss7_mfma_kernel<false>, dim3(n_wg), dim3(256), 0, s, src, dst, mp, Tm, total, n_images, bm_dbg);
-            return 1;
-        }
-    }
-    static const bool stream_env = !getenv("MSORB_BLUR_GENERIC");  // tuning / test aid
     // the streaming kernel has the default taps folded into its v_dot4 constants; other taps (Semantics::gauss_taps) take the
     // generic kernels, which read them at run time
-    const bool stream = aligned && stream_env && sem.default_taps();
+    const bool stream = aligned && sem.default_taps();
     GaussTaps T;
     for (int i = 0; i < 7; i++) T.k[i] = (uint32_t)sem.gauss_taps[i];
     // strip height 35: 21..35 rows measure the same (0.29 ms / 256 images), 70 and 140 are slower (too few waves)

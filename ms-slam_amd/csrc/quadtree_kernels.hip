@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <string>
+
 #include "orb_device.h"
 #include "quadtree_device.h"
 
@@ -323,44 +325,40 @@ __global__ __launch_bounds__(256) void quadtree_layout_kernel(QtLevels lv, const
     }
 }
 
-void launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_base, const int* level_count,
+int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_base, const int* level_count,
                      uint16_t* label, int* sel_pt, int* sel_n, int sel_stride, const LevelScale& scales, int lap0,
                      int lap1, int capacity, SelRec* sel, int* sel_count, int* mono, int n_images, hipStream_t s) {
     int maxN = 1, max_ini = 1;
     for (int l = 0; l < lv.nlevels; l++) { maxN = max(maxN, lv.quota[l]); max_ini = max(max_ini, lv.n_ini[l]); }
     const size_t lds = qt::workspace_bytes(maxN, max_ini);
-    static const int dbg = getenv("MSORB_QT_DEBUG") ? atoi(getenv("MSORB_QT_DEBUG")) : 0;  // profiling only
+    const int dbg = 0;   // phase cut-off of the kernels (profiling builds only)
     // Workgroup size by batch size: the generations are chains of dependent LDS round trips, hidden only by other
     // waves.  A big batch has other workgroups on the CU for that (256 threads: least barrier idling, best
     // throughput); a frame or two has nothing else, so the instance itself brings the waves (1024 threads).
-    static const int qt_env = getenv("MSORB_QT_THREADS") ? atoi(getenv("MSORB_QT_THREADS")) : 0;  // tuning only
-    int qt_threads = qt_env ? qt_env : n_images <= 4 ? 1024 : n_images <= 16 ? 512 : kQtThreads;
-    static const int big_env = getenv("MSORB_QT_BIG_LEVELS") ? atoi(getenv("MSORB_QT_BIG_LEVELS")) : 0;     // experiment
-    static const int big_nt_env = getenv("MSORB_QT_BIG_THREADS") ? atoi(getenv("MSORB_QT_BIG_THREADS")) : 512;
-    int big_levels = kMaxLevels, small_nt = qt_threads;
-    if (big_env && qt_threads == kQtThreads) { big_levels = big_env; qt_threads = big_nt_env; }
-    static const bool regs_env = !getenv("MSORB_QT_NO_REGS");  // tuning / test aid
-    if (lds > 64 * 1024) {   // quotas beyond ~700 keypoints per level (nfeatures > ~3000): past the default dynamic-LDS limit
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quadtree_select_kernel<kQtPointsPerThreadFrame>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quadtree_select_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-    }
-    static const int batch_pc = getenv("MSORB_QT_BATCH_REGS") ? atoi(getenv("MSORB_QT_BATCH_REGS")) : 1;  // 0: candidates through global memory in every pass (rounds 1-2)
-    if (qt_threads == 256 && regs_env && batch_pc) {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quadtree_select_batch_kernel<kQtPointsPerThreadBatch>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int qt_threads = n_images <= 4 ? 1024 : n_images <= 16 ? 512 : kQtThreads;
+    const int big_levels = kMaxLevels, small_nt = qt_threads;
+    auto raise_lds = [&](const void* fn) -> bool {   // quotas beyond ~700 keypoints per level: past the default dynamic-LDS limit
+        if (lds <= 64 * 1024) return true;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) return true;
+        set_last_error("quadtree: the device refuses " + std::to_string(lds) + " bytes of LDS per workgroup");
+        return false;
+    };
+    if (qt_threads == 256) {
+        if (!raise_lds(reinterpret_cast<const void*>(quadtree_select_batch_kernel<kQtPointsPerThreadBatch>))) return MSORB_E_HIP;
         hipLaunchKernelGGL(quadtree_select_batch_kernel<kQtPointsPerThreadBatch>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds, s, lv,
                            compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt);
-    } else if (qt_threads == 1024 && regs_env)
+    } else if (qt_threads == 1024) {
+        if (!raise_lds(reinterpret_cast<const void*>(quadtree_select_kernel<kQtPointsPerThreadFrame>))) return MSORB_E_HIP;
         hipLaunchKernelGGL(quadtree_select_kernel<kQtPointsPerThreadFrame>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds, s, lv,
                            compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt);
-    else
+    } else {
+        if (!raise_lds(reinterpret_cast<const void*>(quadtree_select_kernel<0>))) return MSORB_E_HIP;
         hipLaunchKernelGGL(quadtree_select_kernel<0>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds, s, lv, compact, img_base,
                            level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt);
+    }
     hipLaunchKernelGGL(quadtree_layout_kernel, dim3(n_images), dim3(256), 0, s, lv, compact, img_base, level_count, sel_pt,
                        sel_n, sel_stride, scales, lap0, lap1, capacity, sel, sel_count, mono);
+    return MSORB_OK;
 }
 size_t quadtree_lds_bytes(const QtLevels& lv) {
     int maxN = 1, max_ini = 1;

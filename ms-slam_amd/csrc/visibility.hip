@@ -358,7 +358,7 @@ extern "C" int msorb_visibility_csr(int device, int n_window_kf, const int* kf_s
         set_last_error("no usable HIP device (libmsorb has no CPU fallback)");
         return MSORB_E_NO_DEVICE;
     }
-    static const bool vis_timing = getenv("MSORB_VIS_TIMING") != nullptr;   // wall-clock breakdown on stderr (diagnostics)
+    static const bool vis_timing = getenv("MSORB_VIS_TIMING") != nullptr;   // read once per process: wall-clock breakdown on stderr
     auto now = [] { return std::chrono::steady_clock::now(); };
     std::chrono::steady_clock::time_point t1, t2, t3, t4;
     const auto t0 = now();

@@ -27,7 +27,7 @@ EXPORTS = (
     "msorb_last_error", "msorb_device_count", "msorb_extractor_create", "msorb_extractor_destroy",
     "msorb_extractor_tables", "msorb_extractor_capacity", "msorb_extract", "msorb_pyramid_level",
     "msorb_extract_batch", "msorb_extractor_set_profiling", "msorb_extractor_set_overlap", "msorb_extractor_stage_ms", "msorb_debug_level_size",
-    "msorb_debug_copy_level", "msorb_debug_candidates", "msorb_debug_fast_form", "msorb_debug_blur_form", "msorb_distribute_quadtree", "msorb_extract_stereo",
+    "msorb_debug_copy_level", "msorb_debug_candidates", "msorb_distribute_quadtree", "msorb_extract_stereo",
     "msorb_extract_stereo_split", "msorb_pyramid_batch", "msorb_stereo_matches_split", "msorb_extractor_set_host_pyramid",
     "msorb_extractor_set_semantics",
 )
@@ -74,8 +74,6 @@ def lib():
         L.msorb_debug_level_size.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
         L.msorb_debug_copy_level.argtypes = [vp, ci, ci, ci, vp]
         L.msorb_debug_candidates.argtypes = [vp, ci, ci, vp, ci, C.POINTER(ci)]
-        L.msorb_debug_fast_form.argtypes = [vp]
-        L.msorb_debug_blur_form.argtypes = [vp]
         L.msorb_distribute_quadtree.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, ci, C.POINTER(ci)]
         _LIB = L
     return _LIB
@@ -292,14 +290,6 @@ class ORBextractor:
         out = np.zeros((r.value, c.value), np.uint8)
         _check(self.L.msorb_debug_copy_level(self.h, image, level, int(blurred), _np_ptr(out)), "debug_copy_level")
         return out
-
-    def debug_fast_form(self):
-        """0: the last call's FAST stage ran one workgroup per cell, 1: one per strip of cells."""
-        return int(self.L.msorb_debug_fast_form(self.h))
-
-    def debug_blur_form(self):
-        """0: the last call's Gaussian ran on the VALU kernels, 1: on the matrix cores."""
-        return int(self.L.msorb_debug_blur_form(self.h))
 
     def debug_candidates(self, image, level):
         cap = 1 << 18
@@ -601,12 +591,16 @@ def visibility_csr(kf_slot_begin, slot_point, slot_cell, point_nobs, obs_begin, 
 EXPORTS = EXPORTS + ("msorb_hamming_dense_top2_batch",)
 
 
-def hamming_dense_top2_batch(d_query, d_train, d_nq, d_nt, repeats=1, device=0):
+DENSE_MATRIX_CORES, DENSE_POPCOUNT = 0, 1
+
+
+def hamming_dense_top2_batch(d_query, d_train, d_nq, d_nt, repeats=1, device=0, formulation=DENSE_MATRIX_CORES):
     """Dense brute-force top-2 on device tensors: d_query/d_train torch.uint8 [F, stride, 32], d_nq/d_nt torch.int32 [F].
+    formulation: DENSE_MATRIX_CORES (int8 MFMA) or DENSE_POPCOUNT (xor + popcount, BASELINE north_star's form).
     -> (best_idx, best_dist, second_dist) torch.int32 [F, q_stride], elapsed_ms over `repeats` launches."""
     import torch
     L = lib()
-    L.msorb_hamming_dense_top2_batch.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]
+    L.msorb_hamming_dense_top2_batch.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p]
     F, qs, _ = d_query.shape
     ts = d_train.shape[1]
     # rows >= d_nq[f] are not written by the kernels: best_idx -1, distances 256 there (a defined value, never stale memory)
@@ -614,7 +608,7 @@ def hamming_dense_top2_batch(d_query, d_train, d_nq, d_nt, repeats=1, device=0):
     ms = C.c_float()
     _check(L.msorb_hamming_dense_top2_batch(device, d_query.data_ptr(), d_train.data_ptr(), d_nq.data_ptr(), d_nt.data_ptr(),
                                             F, qs, ts, int(d_nq.max()), int(d_nt.max()), outs[0].data_ptr(),
-                                            outs[1].data_ptr(), outs[2].data_ptr(), repeats, C.byref(ms)),
+                                            outs[1].data_ptr(), outs[2].data_ptr(), repeats, int(formulation), C.byref(ms)),
            "msorb_hamming_dense_top2_batch")
     return outs[0], outs[1], outs[2], ms.value
 
@@ -1401,21 +1395,6 @@ class MotionFrontendRunner:
 
     def close(self):
         self.f.close()
-
-
-EXPORTS = EXPORTS + ("msorb_knn_match2",)
-
-
-def knn_match2(query, train, device=0):
-    """msorb_knn_match2: BFMatcher(NORM_HAMMING).knnMatch(k=2) -> (best_idx, best_dist, second_idx, second_dist)."""
-    lb = lib()
-    vp, ci = C.c_void_p, C.c_int
-    lb.msorb_knn_match2.argtypes = [ci, vp, ci, vp, ci, vp, vp, vp, vp]
-    q, t = _c(query, np.uint8).reshape(-1, 32), _c(train, np.uint8).reshape(-1, 32)
-    nq = len(q)
-    out = [np.zeros(max(nq, 1), np.int32) for _ in range(4)]
-    _check(lb.msorb_knn_match2(device, _np_ptr(q), nq, _np_ptr(t), len(t), *[_np_ptr(o) for o in out]), "msorb_knn_match2")
-    return tuple(o[:nq] for o in out)
 
 
 EXPORTS = EXPORTS + ("msorb_frame_search_rounds",)

@@ -86,18 +86,6 @@ def test_device_quadtree_algorithm_on_host(tmp_path):
     assert "bad=0" in out, out
 
 
-def test_fast_strip_table_is_consistent_with_the_cell_table(tmp_path):
-    """FrameGeom::strips (the strip form of the FAST cell table: up to four adjacent cells per workgroup, two LDS classes) covers
-    every cell exactly once with adjacent cells of one cell row, within the limits fast_strip_kernel's LDS layout and flag words
-    assume — on 99 image sizes / level counts / scale factors."""
-    import subprocess
-    exe = tmp_path / "strip_host_check"
-    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "strip_host_check.cc"),
-                           os.path.join(ROOT, "ms-slam_amd", "csrc", "orb_host.cc"), "-o", str(exe)])
-    out = subprocess.check_output([str(exe)]).decode()
-    assert "bad=0" in out and "with_strips=0" not in out, out
-
-
 def test_matcher_adapter_header_compiles(tmp_path):
     """ms-slam_amd/host/ORBmatcher_device.h against the stand-in Frame / MapPoint of tests/dropin_matcher_main.cc
     (syntax + template instantiation only: no GPU, no link)."""

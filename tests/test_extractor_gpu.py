@@ -185,20 +185,12 @@ def test_batch_kernels_full_size(msorb_mod, oracle, name):
 
 
 @pytest.mark.parametrize("name", ["kitti", "euroc", "fourseasons", "odd"])
-@pytest.mark.parametrize("kernel", ["dma", "band", "band_lds", "rows"])
-def test_batch_pyramid_kernels_on_padded_rows(msorb_mod, oracle, monkeypatch, name, kernel):
-    """The batch pyramid kernels (LDS-free band kernel with the parked rows in registers = default, the same with the rows
-    parked in LDS, LDS-DMA band kernel on 16-byte aligned rows, row-streaming kernel) on a batch whose rows are padded to a
-    multiple of 64 bytes, as bench.py lays its images out: every level of every distinct image is the oracle's cv::resize
-    restatement, bit for bit."""
+def test_batch_pyramid_kernel_on_padded_rows(msorb_mod, oracle, name):
+    """The batch pyramid kernel (pyr_resize_bandreg_kernel: a band of 8 output rows per wave, source rows parked in registers)
+    on a batch whose rows are padded to a multiple of 64 bytes, as bench.py lays its images out: every level of every distinct
+    image is the oracle's cv::resize restatement, bit for bit."""
     import torch
     cfg = CONFIGS[name] if name != "odd" else dict(rows=333, cols=517, nfeatures=700, scale=1.2, nlevels=8, ini_th=20, min_th=7)
-    if kernel == "dma":
-        monkeypatch.setenv("MSORB_PYR_DMA", "1")
-    elif kernel == "rows":
-        monkeypatch.setenv("MSORB_PYR_ROWS", "1")
-    elif kernel == "band_lds":
-        monkeypatch.setenv("MSORB_PYR_BAND_LDS", "1")
     ex, ref = _pair(msorb_mod, oracle, cfg)
     n = 16
     pitch = (cfg["cols"] + 63) // 64 * 64
@@ -212,37 +204,7 @@ def test_batch_pyramid_kernels_on_padded_rows(msorb_mod, oracle, monkeypatch, na
     for i in (0, 1, 2, n - 1):
         ref(batch[i])
         for lvl in range(1, cfg["nlevels"]):
-            assert np.array_equal(ex.debug_level(i, lvl), ref.level(lvl)), (kernel, i, lvl)
-    ex.close()
-
-
-@pytest.mark.parametrize("name", ["kitti", "euroc", "odd"])
-def test_batch_pyramid_fused_tail_levels(msorb_mod, oracle, monkeypatch, name):
-    """MSORB_PYR_TAIL=1: batches of >= 64 images build their last three pyramid levels in one launch (pyr_resize_tail_kernel: a
-    workgroup per image walks down the levels behind workgroup barriers; opt-in, see launch_pyramid): every level of a sample
-    of the images is the oracle's, and the default launch-per-level path gives the same bytes."""
-    import torch
-    cfg = CONFIGS[name] if name != "odd" else dict(rows=333, cols=517, nfeatures=700, scale=1.2, nlevels=8, ini_th=20, min_th=7)
-    ex, ref = _pair(msorb_mod, oracle, cfg)
-    n = 64
-    pitch = (cfg["cols"] + 63) // 64 * 64
-    batch = np.stack([synth.image(950 + (i % 5), cfg["rows"], cfg["cols"]) for i in range(n)])
-    store = torch.zeros((n, cfg["rows"], pitch), dtype=torch.uint8, device="cuda")
-    view = store[:, :, :cfg["cols"]]
-    view.copy_(torch.from_numpy(batch).cuda())
-    monkeypatch.setenv("MSORB_PYR_TAIL", "1")
-    ex.pyramid_batch(view)
-    torch.cuda.synchronize()
-    fused = {(i, l): ex.debug_level(i, l) for i in (0, 3, 4, 37, n - 1) for l in range(1, cfg["nlevels"])}
-    for i in (0, 3, 4, 37, n - 1):
-        ref(batch[i])
-        for lvl in range(1, cfg["nlevels"]):
-            assert np.array_equal(fused[(i, lvl)], ref.level(lvl)), (i, lvl)
-    monkeypatch.delenv("MSORB_PYR_TAIL")
-    ex.pyramid_batch(view)
-    torch.cuda.synchronize()
-    for (i, l), want in fused.items():
-        assert np.array_equal(ex.debug_level(i, l), want), (i, l)
+            assert np.array_equal(ex.debug_level(i, lvl), ref.level(lvl)), (i, lvl)
     ex.close()
 
 
@@ -348,96 +310,6 @@ def test_large_feature_quota_device_quadtree(msorb_mod, oracle, nfeat, nlev, kin
         ex.close()
 
 
-@pytest.mark.parametrize("name", ["kitti", "euroc", "fourseasons"])
-def test_fast_strip_and_cell_forms_agree_with_the_oracle(msorb_mod, oracle, monkeypatch, name):
-    """The FAST stage as strips of up to four cells per workgroup (fast_strip_kernel, batches) and as one workgroup per cell
-    (fast_cells_kernel): same candidates in the same order as the oracle's cell loop, on scenes, on noise (every strip has
-    more quick-test survivors than its work list holds: redone cell by cell), on low contrast (cells empty at iniThFAST are
-    redone at minThFAST, per cell), on half-flat images (strips with empty AND full cells) — and the dataset geometries
-    really take the strip form when it is asked for (MSORB_FAST_STRIP=1; the per-cell form is the default)."""
-    import torch
-    cfg = CONFIGS[name]
-    rows, cols = cfg["rows"], cfg["cols"]
-    rng = np.random.Generator(np.random.PCG64(41))
-    scene = synth.image(311, rows, cols)
-    noise = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
-    low = (scene.astype(np.int32) // 6 + 100).astype(np.uint8)
-    half = scene.copy(); half[:, : cols // 2] = 77
-    stripes = scene.copy(); stripes[:, ::97] = 255; stripes[::53, :] = 0
-    imgs = [scene, noise, low, half, stripes]
-    ex = msorb_mod.ORBextractor(cfg["nfeatures"], 1.2, 8, 20, 7)
-    ref = oracle.OracleExtractor(cfg["nfeatures"], 1.2, 8, 20, 7)
-    try:
-        want = []
-        for im in imgs:
-            ref(im)
-            want.append([ref.candidates(l) for l in range(8)])
-        # rows padded to a multiple of 64 bytes, as bench.py lays its images out (the strip form stages 16-byte quads: it needs
-        # 4-byte aligned rows; tightly packed 1241-byte rows take the per-cell kernel's byte path until a batch is big enough
-        # to be re-staged)
-        pitch = (cols + 63) // 64 * 64
-        store = torch.zeros((16, rows, pitch), dtype=torch.uint8, device="cuda")
-        d = store[:, :, :cols]
-        d.copy_(torch.from_numpy(np.stack([imgs[i % len(imgs)] for i in range(16)])).cuda())
-        ex.set_overlap(1, False)
-        for form in ("1", "default", "0"):
-            if form == "default":
-                monkeypatch.delenv("MSORB_FAST_STRIP", raising=False)
-            else:
-                monkeypatch.setenv("MSORB_FAST_STRIP", form)
-            monkeypatch.setenv("MSORB_GROUPS", "1")            # candidate inspection needs one sub-batch
-            counts, monos, d_kps, d_desc = ex.extract_batch(d)
-            assert ex.debug_fast_form() == (1 if form == "1" else 0), "the dataset geometries can take the strip form"
-            for i in (0, 1, 2, 3, 4, 15):
-                for l in range(8):
-                    assert np.array_equal(ex.debug_candidates(i, l), want[i % len(imgs)][l]), (form, i, l)
-        monkeypatch.delenv("MSORB_FAST_STRIP", raising=False)
-        mono, kps, desc = ex(scene)                             # one frame: the per-cell form
-        assert ex.debug_fast_form() == 0
-    finally:
-        ex.close()
-
-
-@pytest.mark.parametrize("name", ["kitti", "euroc", "fourseasons", "odd", "small"])
-def test_blur_on_the_matrix_cores_matches_the_oracle(msorb_mod, oracle, monkeypatch, name):
-    """gauss7_mfma_kernel (banded matrix products: i8 MFMA for the rows, fp32 MFMA for the columns) against the oracle's
-    GaussianBlur restatement, every level of a batch on 64-byte padded rows: scenes, noise, black / white / saturated images
-    (the -128 bias and the 2^24 exactness bound), widths and heights that are not multiples of 32 (partial strips / blocks, both
-    reflected borders inside one tile), default and alternative taps (sum 257: saturation); and the VALU form on the same batch."""
-    import torch
-    cfg = CONFIGS[name] if name != "odd" else dict(rows=333, cols=517, nfeatures=700, scale=1.2, nlevels=8, ini_th=20, min_th=7)
-    rows, cols = cfg["rows"], cfg["cols"]
-    rng = np.random.Generator(np.random.PCG64(5))
-    imgs = [synth.image(411, rows, cols), rng.integers(0, 256, (rows, cols), dtype=np.uint8), np.zeros((rows, cols), np.uint8),
-            np.full((rows, cols), 255, np.uint8), (rng.integers(0, 2, (rows, cols), dtype=np.uint8) * 255)]
-    pitch = (cols + 63) // 64 * 64
-    store = torch.zeros((16, rows, pitch), dtype=torch.uint8, device="cuda")
-    d = store[:, :, :cols]
-    d.copy_(torch.from_numpy(np.stack([imgs[i % len(imgs)] for i in range(16)])).cuda())
-    ex, ref = _pair(msorb_mod, oracle, cfg)
-    try:
-        ex.set_overlap(1, False)
-        for taps in (None, [18, 34, 49, 55, 49, 34, 18], [16, 32, 48, 64, 48, 32, 16]):
-            ex.set_semantics(taps)
-            oracle.set_semantics(taps)
-            want = []
-            for im in imgs:
-                ref(im)   # (an image without keypoints never reaches the oracle's blur: blur its levels directly)
-                want.append([oracle.gaussian7(ref.level(l)) for l in range(cfg["nlevels"])])
-            for form in ("1", "0"):
-                monkeypatch.setenv("MSORB_BLUR_MFMA", form)
-                ex.extract_batch(d)
-                # (taps summing to 257 need a 17-bit row sum: the matrix-core form leaves them to the VALU kernels)
-                assert ex.debug_blur_form() == (int(form) if taps is None or sum(taps) <= 256 else 0)
-                for i in (0, 1, 2, 3, 4, 15):
-                    for l in range(cfg["nlevels"]):
-                        got = ex.debug_level(i, l, blurred=True)
-                        assert np.array_equal(got, want[i % len(imgs)][l]), (name, taps, form, i, l, np.argwhere(got != want[i % len(imgs)][l])[:4])
-    finally:
-        oracle.set_semantics()
-        ex.close()
-
-
 @pytest.mark.parametrize("nfeat,nlev", [(40, 8), (12, 3), (100, 8)])
 def test_tiny_feature_counts_exceed_their_quota_like_the_reference(msorb_mod, oracle, nfeat, nlev):
     """DistributeOctTree's first pass divides every initial column before any quota check (ORBextractor.cc:610-681): with a
@@ -507,73 +379,29 @@ def test_full_bench_size_properties(msorb_mod, oracle):
     ex.close()
 
 
-def test_graph_replay_path_matches(tmp_path):
-    """MSORB_GRAPH=1: msorb_extract replays the captured chain (third call onwards); results must equal the plain path and
-    the oracle, also across a change of the lapping area (second cached graph) and of the geometry (graphs dropped)."""
-    import os
-    import subprocess
-    import sys
-    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r'''
-import os, sys
-import numpy as np
-sys.path[:0] = [os.path.join(ROOT, "ms-slam_amd"), os.path.join(ROOT, "oracle")]
-import msorb, orb_oracle
-from msorb import synth
-ex = msorb.ORBextractor(1000, 1.2, 8, 20, 7)
-ref = orb_oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
-def same(a, b):
-    return a[0] == b[0] and np.array_equal(a[1].view(np.uint8), b[1].view(np.uint8)) and np.array_equal(a[2], b[2])
-imgs = [synth.image(50 + i, 240, 320) for i in range(4)]
-for rep in range(3):
-    for i, im in enumerate(imgs):
-        assert same(ex(im), ref(im)), (rep, i)
-        assert same(ex(im, (100, 200)), ref(im, (100, 200))), (rep, i, "lap")
-big = synth.image(9, 376, 1241)
-for rep in range(3):
-    assert same(ex(big), ref(big))
-    assert same(ex(imgs[0]), ref(imgs[0]))
-lvl = ex.debug_level(0, 3)
-assert lvl.shape == ref.level(3).shape
-print("graph-ok")
-'''.replace("ROOT", repr(ROOT))
-    env = dict(os.environ, MSORB_GRAPH="1")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert "graph-ok" in out.stdout, out.stdout + out.stderr
-
-
 def test_misaligned_batch_staged_and_in_place(msorb_mod, oracle):
-    """Tightly packed rows that are not 4-byte aligned (KITTI: 1241 pixels): by default level 0 is staged once into the
-    handle's aligned planes and the aligned kernels run; MSORB_NO_STAGE0 keeps the byte-granular in-place variants.
-    Both must equal the oracle."""
-    import os
+    """Tightly packed rows that are not 4-byte aligned (EuRoC-sized images cut to 751 pixels): batches of 128 images and more
+    have level 0 staged once into the handle's aligned planes and run the aligned kernels, smaller batches keep the rows in
+    place and run the byte-granular variants.  Both must equal the oracle, and the caller's images stay untouched."""
     import torch
-    cfg = CONFIGS["kitti"]
+    cfg = dict(CONFIGS["euroc"], cols=751, rows=240)
     ex, ref = _pair(msorb_mod, oracle, cfg)
-    n = 16                                             # MSORB_STAGE0_MIN=1 below: staging normally starts at 128 images
-    batch = np.stack([synth.image(800 + (i % 3), cfg["rows"], cfg["cols"]) for i in range(n)])
-    d = torch.from_numpy(batch).cuda()
-    assert d.stride(1) % 4 != 0
-    want = [ref(batch[i]) for i in range(3)]
     try:
-        for mode in ("staged", "in_place"):
-            os.environ["MSORB_STAGE0_MIN"] = "1"
-            if mode == "in_place":
-                os.environ["MSORB_NO_STAGE0"] = "1"
-            else:
-                os.environ.pop("MSORB_NO_STAGE0", None)
+        imgs = [synth.image(800 + i, cfg["rows"], cfg["cols"]) for i in range(3)]
+        want = [ref(im) for im in imgs]
+        for n in (128, 16):          # staged / in place
+            batch = np.stack([imgs[i % 3] for i in range(n)])
+            d = torch.from_numpy(batch).cuda()
+            assert d.stride(1) % 4 != 0
             counts, mono, d_kps, d_desc = ex.extract_batch(d)
             kps_list = msorb_mod.keypoints_from_device(d_kps, counts)
             desc_all = d_desc.cpu().numpy()
-            for i in range(n):
+            for i in list(range(6)) + [n - 1]:
                 rmono, rkps, rdesc = want[i % 3]
-                assert counts[i] == len(rkps) and mono[i] == rmono, (mode, i)
+                assert counts[i] == len(rkps) and mono[i] == rmono, (n, i)
                 _assert_same(kps_list[i], desc_all[i, :counts[i]], rkps, rdesc)
-            # the staged copy must not touch the caller's images
             assert torch.equal(d, torch.from_numpy(batch).cuda())
     finally:
-        os.environ.pop("MSORB_NO_STAGE0", None)
-        os.environ.pop("MSORB_STAGE0_MIN", None)
         ex.close()
 
 

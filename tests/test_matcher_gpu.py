@@ -37,12 +37,20 @@ def test_stereo_matches_bit_exact(msorb_mod, oracle, stereo_frame):
     assert np.array_equal(dp.view(np.uint32), rdp.view(np.uint32))
     assert oob == roob
     # one extractor per GPU (MSORB_DEVICES=0,1): the right pyramid is pulled to the left device level by level, peer to peer;
-    # forced here with both handles on one device
+    # forced here with both handles on one device (the switch is read when a handle is created)
     os.environ["MSORB_FORCE_PEER_PYRAMID"] = "1"
     try:
-        ur2, dp2, oob2 = msorb_mod.stereo_matches(s["exl"], s["exr"], s["kl"], s["dl"], s["kr"], s["dr"], mb, mbf)
+        exl2 = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7)
+        exr2 = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7)
     finally:
         del os.environ["MSORB_FORCE_PEER_PYRAMID"]
+    try:
+        exl2(s["L"])
+        exr2(s["R"])
+        ur2, dp2, oob2 = msorb_mod.stereo_matches(exl2, exr2, s["kl"], s["dl"], s["kr"], s["dr"], mb, mbf)
+    finally:
+        exl2.close()
+        exr2.close()
     assert np.array_equal(ur2.view(np.uint32), rur.view(np.uint32)) and np.array_equal(dp2.view(np.uint32), rdp.view(np.uint32)) and oob2 == roob
     # degenerate: no right keypoints / no left keypoints
     ur0, dp0, _ = msorb_mod.stereo_matches(s["exl"], s["exr"], s["kl"], s["dl"], s["kr"][:0], s["dr"][:0], mb, mbf)
@@ -268,14 +276,13 @@ def test_stereo_random_keypoints_against_oracle(msorb_mod, oracle, seed, pad):
 
 
 @pytest.mark.parametrize("kernel", ["mfma", "valu"])
-def test_dense_top2_kernels_edge_cases(msorb_mod, oracle, monkeypatch, kernel):
+def test_dense_top2_kernels_edge_cases(msorb_mod, oracle, kernel):
     """The matrix-core kernel (default: +-32 int8 encoding, the MFMA accumulator is the (distance << 11 | index) key) and the
     xor / popcount kernel on the shapes that stress tiling: train counts around the 32-train tile and the 2048 cap, query
     counts around the 512-query workgroup and 32-query fragment, one train, identical descriptors everywhere (every distance
     ties: lowest index wins, second = the same distance), all-zero vs all-one descriptors (distance 256)."""
     import torch
-    if kernel == "valu":
-        monkeypatch.setenv("MSORB_DENSE_VARIANT", "24")
+    form = msorb_mod.DENSE_POPCOUNT if kernel == "valu" else msorb_mod.DENSE_MATRIX_CORES
     rng = np.random.Generator(np.random.PCG64(77))
     cap = 2048                                       # msorb_hamming_dense_top2_batch: at most 2048 trains per frame
     shapes = [(1, 1), (31, 33), (33, 31), (64, 32), (513, 2047), (2000, 2048), (2048, 1999), (5, 0), (300, 1), (129, 65)]
@@ -289,7 +296,7 @@ def test_dense_top2_kernels_edge_cases(msorb_mod, oracle, monkeypatch, kernel):
     t[4, 1000:1040] = t[4, 1000]                     # a run of duplicates across a tile boundary
     q[4, :100] = t[4, rng.integers(990, 1050, 100)]
     bi, bd, sd, _ = msorb_mod.hamming_dense_top2_batch(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda(),
-                                                      torch.from_numpy(nq).cuda(), torch.from_numpy(nt).cuda())
+                                                      torch.from_numpy(nq).cuda(), torch.from_numpy(nt).cuda(), formulation=form)
     bi, bd, sd = bi.cpu().numpy(), bd.cpu().numpy(), sd.cpu().numpy()
     for f in range(F):
         n_t = int(nt[f])
@@ -306,7 +313,7 @@ def test_dense_top2_kernels_edge_cases(msorb_mod, oracle, monkeypatch, kernel):
     assert np.all(bd[F - 1, :100] == 256) and np.all(sd[F - 1, :100] == 256) and np.all(bi[F - 1, :100] == -1)   # strict '<' from 256
 
 
-def test_dense_top2_kernels_on_extracted_descriptors_at_bench_size(msorb_mod, oracle, monkeypatch):
+def test_dense_top2_kernels_on_extracted_descriptors_at_bench_size(msorb_mod, oracle):
     """bench.py's hamming_match leg as a test: 128 stereo pairs of KITTI-sized images through the extractor, the left-eye
     descriptors of every pair against the right-eye ones (~2000 x ~2000 rBRIEF descriptors per frame, duplicates and all) on
     BOTH dense kernels — matrix cores and xor / popcount — compared with each other on every valid row and with the CPU oracle
@@ -324,10 +331,8 @@ def test_dense_top2_kernels_on_extracted_descriptors_at_bench_size(msorb_mod, or
         nq = torch.from_numpy(np.ascontiguousarray(counts[0::2])).cuda()
         nt = torch.from_numpy(np.ascontiguousarray(counts[1::2])).cuda()
         assert int(nq.min()) > 1500 and int(nt.min()) > 1500
-        mfma = msorb_mod.hamming_dense_top2_batch(dq, dt, nq, nt)[:3]
-        monkeypatch.setenv("MSORB_DENSE_VARIANT", "24")
-        valu = msorb_mod.hamming_dense_top2_batch(dq, dt, nq, nt)[:3]
-        monkeypatch.delenv("MSORB_DENSE_VARIANT")
+        mfma = msorb_mod.hamming_dense_top2_batch(dq, dt, nq, nt, formulation=msorb_mod.DENSE_MATRIX_CORES)[:3]
+        valu = msorb_mod.hamming_dense_top2_batch(dq, dt, nq, nt, formulation=msorb_mod.DENSE_POPCOUNT)[:3]
         live = torch.arange(dq.shape[1], device=dq.device)[None, :] < nq[:, None]
         for a, b, name in zip(mfma, valu, ("best_idx", "best_dist", "second_dist")):
             assert torch.equal(a[live], b[live]), name

@@ -122,16 +122,19 @@ def test_extract_stereo_split_without_peer_access(msorb_mod, oracle, monkeypatch
     L, R = synth.stereo_pair(47, rows, cols)
     exl = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7, device=dev_a)
     exr = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7, device=dev_b)
+    # the switch is read when a handle is created: a second pair of handles made under it takes the staged path
+    monkeypatch.setenv("MSORB_SPLIT_NO_PEER", "1")
+    sxl = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7, device=dev_a)
+    sxr = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7, device=dev_b)
+    monkeypatch.delenv("MSORB_SPLIT_NO_PEER")
     try:
         want = exl.extract_stereo_split(exr, L, R, mb, mbf)          # peer / device-local copies
-        monkeypatch.setenv("MSORB_SPLIT_NO_PEER", "1")
         for _ in range(2):
-            got = exl.extract_stereo_split(exr, L, R, mb, mbf)
+            got = sxl.extract_stereo_split(sxr, L, R, mb, mbf)
             for a, b in zip(got[:6], want[:6]):
                 assert np.array_equal(a.view(np.uint8) if a.dtype.fields else a.view(np.uint8), b.view(np.uint8))
             assert got[6] == want[6] and (got[4] > 0).sum() > 500
-        monkeypatch.delenv("MSORB_SPLIT_NO_PEER")
         again = exl.extract_stereo_split(exr, L, R, mb, mbf)
         assert np.array_equal(again[4].view(np.uint32), want[4].view(np.uint32))
     finally:
-        exl.close(); exr.close()
+        exl.close(); exr.close(); sxl.close(); sxr.close()
