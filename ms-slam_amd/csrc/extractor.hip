@@ -215,6 +215,7 @@ struct msorb_extractor {
     bool device_quadtree = true;
     bool small_cells = false;  // every cell ROI <= 46 x 57: the FAST kernel's compact LDS geometry applies
     bool compact_on_host = false;  // h_compact / h_level_count / h_img_base hold the last call's candidates
+    bool compact_fixed_stride = false;  // the last call left image i's candidates at i * slots_per_image on the device (device pipeline)
     // pinned host state
     PinBuf<int> h_level_count, h_img_base, h_sel_count, h_mono;
     PinBuf<Cand16> h_compact;
@@ -350,8 +351,30 @@ int fetch_candidates(msorb_extractor* h, int n_images) {
     HIPCHK(hipMemcpyAsync(h->h_img_base.p, h->d_img_base.p, (size_t)(n_images + 1) * sizeof(int),
                           hipMemcpyDeviceToHost, h->copy_stream));
     HIPCHK(hipStreamSynchronize(h->copy_stream));
-    const int total = h->h_img_base.p[n_images];
     int rc;
+    if (h->compact_fixed_stride) {
+        // the device pipeline leaves image i's run at i * slots_per_image: the host copy is packed all the same
+        std::vector<int> tot(n_images, 0);
+        int total = 0;
+        for (int i = 0; i < n_images; i++) {
+            for (int l = 0; l < nl; l++) tot[i] += h->h_level_count.p[(size_t)i * nl + l];
+            total += tot[i];
+        }
+        if ((rc = h->h_compact.ensure(std::max<size_t>((size_t)total + total / 4, 1024)))) return rc;
+        int at = 0;
+        for (int i = 0; i < n_images; i++) {
+            if (tot[i] > 0)
+                HIPCHK(hipMemcpyAsync(h->h_compact.p + at, h->d_compact.p + (size_t)h->h_img_base.p[i], (size_t)tot[i] * sizeof(Cand16),
+                                      hipMemcpyDeviceToHost, h->copy_stream));
+            h->h_img_base.p[i] = at;
+            at += tot[i];
+        }
+        h->h_img_base.p[n_images] = at;
+        HIPCHK(hipStreamSynchronize(h->copy_stream));
+        h->compact_on_host = true;
+        return MSORB_OK;
+    }
+    const int total = h->h_img_base.p[n_images];
     if ((rc = h->h_compact.ensure(std::max<size_t>((size_t)total + total / 4, 1024)))) return rc;
     if (total > 0) {
         HIPCHK(hipMemcpyAsync(h->h_compact.p, h->d_compact.p, (size_t)total * sizeof(Cand16), hipMemcpyDeviceToHost,
@@ -466,17 +489,24 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
                                       g.pyramid_bytes - g.lv[1].plane_off, hipMemcpyDeviceToHost, h->pyr_stream));
             h->h_pyr_async = true;
         }
-        mark(7, sb);
-        (void)launch_gauss7(pyr, blur, n, sb, h->sem);
-        mark(8, sb);
-        if (h->overlap_blur) HIPCHK(hipEventRecord(G.ev_blur, sb));
+        // with the blur on its own stream the critical chain goes first: FAST -> compaction -> quadtree is what describe waits
+        // for; the blur (needed by describe only) fills in beside it
+        auto blur_now = [&]() {
+            mark(7, sb);
+            (void)launch_gauss7(pyr, blur, n, sb, h->sem);
+            mark(8, sb);
+            if (h->overlap_blur) (void)hipEventRecord(G.ev_blur, sb);
+        };
+        if (!h->overlap_blur) blur_now();   // one stream: pyramid, blur, FAST (the stage events expect this order)
         launch_fast_cells(pyr, h->d_cells.p, ncells, h->P.ini_th, h->P.min_th, g.slots_per_image, h->d_slots.p + cslot,
                           h->d_cell_count.p + (size_t)first * ncells, n, h->small_cells, s);
         mark(2, s);
+        if (h->overlap_blur) blur_now();
         launch_cand_compact(h->d_cells.p, ncells, h->d_level_cell_begin.p, nl, g.slots_per_image, h->d_slots.p + cslot,
                             h->d_cell_count.p + (size_t)first * ncells, h->d_cell_off.p + (size_t)first * ncells,
                             h->d_level_count.p + (size_t)first * nl, h->d_img_total.p + first, img_base,
-                            h->d_compact.p + cslot, n, s);
+                            h->d_compact.p + cslot, n, s, /*packed=*/false);
+        h->compact_fixed_stride = true;
         mark(3, s);
         if ((rc = launch_quadtree(h->qt, h->d_compact.p + cslot, img_base, h->d_level_count.p + (size_t)first * nl,
                                   h->d_label.p + cslot, h->d_sel_pt.p + (size_t)first * sel_stride, h->d_sel_n.p + (size_t)first * nl,
@@ -536,7 +566,8 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
     mark(2);
     launch_cand_compact(h->d_cells.p, ncells, h->d_level_cell_begin.p, nl, g.slots_per_image, h->d_slots.p,
                         h->d_cell_count.p, h->d_cell_off.p, h->d_level_count.p, h->d_img_total.p, h->d_img_base.p,
-                        h->d_compact.p, n_images, s);
+                        h->d_compact.p, n_images, s, /*packed=*/true);
+    h->compact_fixed_stride = false;
     mark(3);
     HIPCHK(hipEventRecord(h->ev_compact, s));
     if (!overlap_blur) (void)launch_gauss7(pyr, blur, n_images, s, h->sem);
@@ -1003,12 +1034,12 @@ int msorb::extract_stereo_sink(msorb_extractor* h, const uint8_t* left, const ui
         (rc = h->h_img_pin.ensure(2 * plane)) || (rc = h->h_out_pin.ensure(out_bytes)) || (rc = h->d_st_sad.ensure(cap)) ||
         (rc = h->d_st_rows.ensure((size_t)rows + 1)) || (rc = h->d_st_list.ensure((size_t)row_cap * 2)))
         return rc;
-    for (int y = 0; y < rows; y++) {
-        memcpy(h->h_img_pin.p + (size_t)y * g0.pitch, left + (size_t)y * stride_left, cols);
-        memcpy(h->h_img_pin.p + plane + (size_t)y * g0.pitch, right + (size_t)y * stride_right, cols);
-    }
+    // pageable rows -> pinned planes -> device, one eye at a time: the left plane rides PCIe while the right one is staged
     hipStream_t s = h->stream;
-    HIPCHK(hipMemcpyAsync(h->d_st_img.p, h->h_img_pin.p, 2 * plane, hipMemcpyHostToDevice, s));
+    for (int y = 0; y < rows; y++) memcpy(h->h_img_pin.p + (size_t)y * g0.pitch, left + (size_t)y * stride_left, cols);
+    HIPCHK(hipMemcpyAsync(h->d_st_img.p, h->h_img_pin.p, plane, hipMemcpyHostToDevice, s));
+    for (int y = 0; y < rows; y++) memcpy(h->h_img_pin.p + plane + (size_t)y * g0.pitch, right + (size_t)y * stride_right, cols);
+    HIPCHK(hipMemcpyAsync(h->d_st_img.p + plane, h->h_img_pin.p + plane, plane, hipMemcpyHostToDevice, s));
     LevelView l0{h->d_st_img.p, plane, g0.pitch, cols, rows};
     uint8_t* const blk = h->d_st_block.p;
     msorb_keypoint* const d_kps = reinterpret_cast<msorb_keypoint*>(blk);

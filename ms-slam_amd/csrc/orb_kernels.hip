@@ -726,10 +726,16 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
 __global__ __launch_bounds__(256) void cand_scan_cells_kernel(const int* __restrict__ cell_count, int n_cells,
                                                               const int* __restrict__ level_cell_begin, int nlevels,
                                                               int* __restrict__ cell_off, int* __restrict__ level_count,
-                                                              int* __restrict__ img_total) {
+                                                              int* __restrict__ img_total, int* __restrict__ img_base,
+                                                              int fixed_stride) {
     __shared__ int wave_tot[4];
     __shared__ int lvl[kMaxLevels];
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // fixed_stride > 0: image i's compacted candidates start at i * fixed_stride (no scan over the images, no second launch)
+    if (fixed_stride > 0 && tid == 0) {
+        img_base[img] = img * fixed_stride;
+        if (img == (int)gridDim.x - 1) img_base[gridDim.x] = (int)gridDim.x * fixed_stride;
+    }
     const int* cnt = cell_count + (size_t)img * n_cells;
     int* off = cell_off + (size_t)img * n_cells;
     const int per = (n_cells + 255) / 256;
@@ -1458,13 +1464,15 @@ void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cell
     else { if (aligned) MSORB_FAST_LAUNCH(true, GeoLarge); else MSORB_FAST_LAUNCH(false, GeoLarge); }
 #undef MSORB_FAST_LAUNCH
 }
+// packed: the images' candidate runs follow each other without gaps (one contiguous read-back for the host quadtree: a scan
+// over the images in a launch of its own); otherwise image i's run starts at i * slots_per_image — two launches instead of three
 void launch_cand_compact(const CellDesc* cells, int n_cells, const int* level_cell_begin, int nlevels,
                          int slots_per_image, const Cand16* slots, const int* cell_count, int* cell_off,
                          int* level_count, int* img_total, int* img_base, Cand16* compact, int n_images,
-                         hipStream_t s) {
+                         hipStream_t s, bool packed) {
     hipLaunchKernelGGL(cand_scan_cells_kernel, dim3(n_images), dim3(256), 0, s, cell_count, n_cells, level_cell_begin,
-                       nlevels, cell_off, level_count, img_total);
-    hipLaunchKernelGGL(cand_scan_images_kernel, dim3(1), dim3(256), 0, s, img_total, n_images, img_base);
+                       nlevels, cell_off, level_count, img_total, img_base, packed ? 0 : slots_per_image);
+    if (packed) hipLaunchKernelGGL(cand_scan_images_kernel, dim3(1), dim3(256), 0, s, img_total, n_images, img_base);
     hipLaunchKernelGGL(cand_gather_kernel, dim3((n_cells + kGatherCells - 1) / kGatherCells, n_images), dim3(256), 0, s, cells, n_cells, slots_per_image,
                        slots, cell_count, cell_off, img_base, compact);
 }

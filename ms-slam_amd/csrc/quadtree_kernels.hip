@@ -331,7 +331,11 @@ int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_ba
     int maxN = 1, max_ini = 1;
     for (int l = 0; l < lv.nlevels; l++) { maxN = max(maxN, lv.quota[l]); max_ini = max(max_ini, lv.n_ini[l]); }
     const size_t lds = qt::workspace_bytes(maxN, max_ini);
-    const int dbg = 0;   // phase cut-off of the kernels (profiling builds only)
+#ifdef MSORB_QT_MARKS   // profiling build (tools/qt_marks.sh): MSORB_QT_DEBUG=3 prints the per-phase timestamps of instance (0, 0)
+    static const int dbg = getenv("MSORB_QT_DEBUG") ? atoi(getenv("MSORB_QT_DEBUG")) : 0;
+#else
+    const int dbg = 0;
+#endif
     // Workgroup size by batch size: the generations are chains of dependent LDS round trips, hidden only by other
     // waves.  A big batch has other workgroups on the CU for that (256 threads: least barrier idling, best
     // throughput); a frame or two has nothing else, so the instance itself brings the waves (1024 threads).

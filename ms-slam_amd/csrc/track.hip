@@ -115,13 +115,20 @@ __global__ __launch_bounds__(kGridThreads) void frame_grid_kernel(GridArgs A) {
     }
     __syncthreads();
     // the reference pushes indices in ascending order: restore it inside every cell.  Short runs (the normal case: about
-    // one keypoint per cell): insertion sort by the cell's thread.  Long runs (keypoints piled up in a cell): one wave per
-    // cell ranks every entry against the run (indices are unique) through cell_of, which is free from here on — a pile of
-    // k keypoints costs k^2 / 64 steps per lane instead of k^2 on one thread.
-    constexpr int kShortRun = 32;
+    // one keypoint per cell): insertion sort by the cell's thread.  Long runs (keypoints piled up in a cell) are noted in a
+    // small list and ranked afterwards by a whole wave each (indices are unique) through cell_of, which is free from here on
+    // — a pile of k keypoints costs k^2 / 64 steps per lane instead of k^2 on one thread; frames without piles (every real
+    // frame) pay one counter read for it.
+    constexpr int kShortRun = 32, kMaxLong = 64;
+    __shared__ int n_long, long_cell[kMaxLong];
+    if (tid == 0) n_long = 0;
+    __syncthreads();
     for (int c = tid; c < kNCell; c += kGridThreads) {
         const int s = cnt[c], e = cnt[c + 1];
-        if (e - s > kShortRun) continue;
+        if (e - s > kShortRun) {
+            const int k = atomicAdd(&n_long, 1);
+            if (k < kMaxLong) { long_cell[k] = c; continue; }   // (beyond the list — > 64 piles of > 32 keypoints — the thread sorts it itself)
+        }
         for (int i = s + 1; i < e; i++) {
             const uint16_t v = lst[i];
             int j = i - 1;
@@ -130,11 +137,11 @@ __global__ __launch_bounds__(kGridThreads) void frame_grid_kernel(GridArgs A) {
         }
     }
     __syncthreads();
-    {
+    const int nl = min(n_long, kMaxLong);   // block-uniform
+    if (nl > 0) {
         const int wave = tid >> 6, lane = tid & 63;
-        for (int c = wave; c < kNCell; c += kGridThreads / 64) {
-            const int s = cnt[c], e = cnt[c + 1];
-            if (e - s <= kShortRun) continue;   // wave-uniform
+        for (int k = wave; k < nl; k += kGridThreads / 64) {
+            const int c = long_cell[k], s = cnt[c], e = cnt[c + 1];
             for (int i = s + lane; i < e; i += 64) {
                 const uint16_t v = lst[i];
                 int r = 0;
@@ -143,13 +150,12 @@ __global__ __launch_bounds__(kGridThreads) void frame_grid_kernel(GridArgs A) {
             }
         }
         __syncthreads();
-        for (int c = wave; c < kNCell; c += kGridThreads / 64) {
-            const int s = cnt[c], e = cnt[c + 1];
-            if (e - s <= kShortRun) continue;
+        for (int k = wave; k < nl; k += kGridThreads / 64) {
+            const int c = long_cell[k], s = cnt[c], e = cnt[c + 1];
             for (int i = s + lane; i < e; i += 64) lst[i] = cell_of[i];
         }
+        __syncthreads();
     }
-    __syncthreads();
     const int total = cnt[kNCell];
     for (int j = tid; j < total; j += kGridThreads) cell_idx[j] = lst[j];
     if (A.n_out && tid == 0) A.n_out[b] = n;
