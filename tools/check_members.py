@@ -12,7 +12,11 @@ surface only at integration ("weak" item 3):
      reference type (pKF*, kf* -> KeyFrame; F, F1, F2, CurrentFrame, LastFrame -> Frame; pMP*, p -> MapPoint; *Camera ->
      GeometricCamera) and requires the member to exist in that class (or a base) and to be PUBLIC;
   3. it requires the drop-in declarations (host/ORBmatcher.h, host/ORBextractor.h) to offer every public method of the
-     reference classes with the same parameter count, and the same public data members the callers read.
+     reference classes with the same parameter count, and the same public data members the callers read;
+  4. TYPES: the declared type of every member / the return type of every method the host layer consumes (EXPECTED_TYPES:
+     mvKeysUn = std::vector<cv::KeyPoint>, mDescriptors = cv::Mat, GetFeatureGrids() three vectors deep, tuple<int,int>
+     observation indices, GetPose() = Sophus::SE3f ...) must be what the reference declares, and where the stand-ins of
+     tests/slam_stub declare the same member, their type must be the reference's too.
 
 Documented, deliberate additions the integration makes to the reference are listed in ALLOWED_MISSING.
 Runs in the build container only (the reference is not on the GPU box); `pytest -m "not gpu"` runs it through
@@ -34,13 +38,42 @@ ALLOWED_MISSING = {("MapPoint", "GetMaxDistance"), ("MapPoint", "GetMinDistance"
 # (objects held through shared_ptr / raw pointers count with `->` only: `pKF.get()`, `vpKFs.size()` are not member accesses;
 # Frame objects are references: `.` only)
 OBJECT_CLASS = [
-    (re.compile(r"^(pKF\w*|kf|pKFi)$"), "KeyFrame", "->"),
+    (re.compile(r"^(pKF\w*|kf|pKFi|kfs)$"), "KeyFrame", "->"),
     (re.compile(r"^(F|F1|F2|CurrentFrame|LastFrame)$"), "Frame", "."),
-    (re.compile(r"^(pMP\w*|p|pMPinKF)$"), "MapPoint", "->"),
+    (re.compile(r"^(pMP\w*|p|pMPinKF|points)$"), "MapPoint", "->"),
     (re.compile(r"^(mpCamera\w*|pCamera\w*)$"), "GeometricCamera", "->"),
 ]
 # names that look like member accesses on those objects but are not (local structs of the host layer)
 IGNORE_OBJECT_FILES = {}
+
+
+def split_top_level(text):
+    """split at commas that are not inside <...> or (...)"""
+    out, depth, cur = [], 0, ""
+    for ch in text:
+        depth += {"<": 1, ">": -1, "(": 1, ")": -1}.get(ch, 0)
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    out.append(cur)
+    return out
+
+
+TYPE_ALIASES = [(r"\bSophus::SE3<float>", "Sophus::SE3f"), (r"\bSophus::Sim3<float>", "Sophus::Sim3f"), (r"\bunsignedlong(int)?\b", "longunsignedint"),
+                (r"\bEigen::Matrix<float,3,1>", "Eigen::Vector3f"), (r"\bEigen::Matrix<float,3,3>", "Eigen::Matrix3f")]
+
+
+def norm_type(t):
+    """a declared type reduced to what a caller depends on: no storage / cv qualifiers, no references, no namespaces std / ORB_SLAM3"""
+    t = re.sub(r"\b(static|inline|virtual|const|constexpr|mutable|explicit|typename|EIGEN_\w+)\b", " ", t)
+    t = t.replace("&", " ")
+    t = re.sub(r"\b(std|ORB_SLAM3)::", "", t)
+    t = re.sub(r"\s+", "", t)
+    for pat, rep in TYPE_ALIASES:
+        t = re.sub(pat, rep, t)
+    return t
 
 
 def strip_comments(src):
@@ -107,16 +140,27 @@ def members(kind, body):
                     d2 += {"<": 1, ">": -1, "(": 1, ")": -1}.get(ch, 0)
                     if ch == "," and d2 == 0:
                         arity += 1
-            e = mem.setdefault(name, {"access": set(), "kind": "function", "arity": set()})
+            e = mem.setdefault(name, {"access": set(), "kind": "function", "arity": set(), "types": set()})
             e["access"].add(access)
             e["arity"].add(arity)
+            if "operator" not in head:   # return type = what stands in front of the name
+                rt = head[:head.rindex(name)] if name in head else ""
+                e["types"].add(norm_type(rt))
             return
         # data members: "type a, *b = 0, c[3];"
         text = re.sub(r"=[^,;]*", "", text)
         text = re.sub(r"\[[^\]]*\]", "", text)
+        full = text
+        text = re.sub(r"<[^<>]*>", " ", text)
         text = re.sub(r"<[^<>]*>", " ", text)
         text = re.sub(r"<[^<>]*>", " ", text)
         parts = text.split(",")
+        # the declared type: everything of the first declarator but its name (template arguments kept)
+        first_ids = re.findall(r"\w+", parts[0])
+        base_type = ""
+        if len(first_ids) >= 2:
+            head0 = split_top_level(full)[0]
+            base_type = head0[:head0.rindex(first_ids[-1])]
         for k, part in enumerate(parts):
             ids = re.findall(r"\w+", part)
             if not ids:
@@ -124,8 +168,11 @@ def members(kind, body):
             name = ids[-1]
             if k == 0 and len(ids) < 2:
                 continue   # a lone identifier is a macro (EIGEN_MAKE_ALIGNED_OPERATOR_NEW)
-            e = mem.setdefault(name, {"access": set(), "kind": "data", "arity": set()})
+            e = mem.setdefault(name, {"access": set(), "kind": "data", "arity": set(), "types": set()})
             e["access"].add(access)
+            ptr = "*" if "*" in part else ""
+            bt = re.sub(r"[*&\s]+$", "", base_type) if k else base_type
+            e["types"].add(norm_type(bt + (ptr if k else "")))
 
     while i < n:
         ch = body[i]
@@ -227,6 +274,63 @@ def dropin_check(classes):
     return problems
 
 
+# Types the host layer's code depends on (it copies vectors of 28-byte cv::KeyPoint, reads 32-byte cv::Mat rows, walks the
+# feature grid three levels deep, unpacks tuple<int,int> observation indices, takes Tcw as a Sophus::SE3f ...): the declared
+# type of a member / the return type of a method in the REFERENCE, normalised by norm_type().  Members the stand-ins of
+# tests/slam_stub also declare are compared with those as well, so a drift on either side fails here.
+EXPECTED_TYPES = {
+    ("Frame", "N"): "int", ("Frame", "Nleft"): "int", ("Frame", "mnId"): "longunsignedint",
+    ("Frame", "mvKeys"): "vector<cv::KeyPoint>", ("Frame", "mvKeysUn"): "vector<cv::KeyPoint>", ("Frame", "mvKeysRight"): "vector<cv::KeyPoint>",
+    ("Frame", "mDescriptors"): "cv::Mat", ("Frame", "mDescriptorsRight"): "cv::Mat",
+    ("Frame", "mvuRight"): "vector<float>", ("Frame", "mvDepth"): "vector<float>",
+    ("Frame", "mvpMapPoints"): "vector<shared_ptr<MapPoint>>", ("Frame", "mvbOutlier"): "vector<bool>",
+    ("Frame", "mvScaleFactors"): "vector<float>", ("Frame", "mb"): "float", ("Frame", "mbf"): "float",
+    ("Frame", "mnMinX"): "float", ("Frame", "mnMaxX"): "float", ("Frame", "mnMinY"): "float", ("Frame", "mnMaxY"): "float",
+    ("Frame", "mpCamera"): "GeometricCamera*", ("Frame", "GetPose"): "Sophus::SE3f",
+    ("Frame", "mFeatVec"): "DBoW2::FeatureVector", ("Frame", "mBowVec"): "DBoW2::BowVector",
+    ("Frame", "mmProjectPoints"): "map<longunsignedint,cv::Point2f>",
+    ("KeyFrame", "GetAllKeyUn"): "vector<cv::KeyPoint>", ("KeyFrame", "GetDescriptor"): "cv::Mat", ("KeyFrame", "GetuRight"): "float",
+    ("KeyFrame", "GetMapPoint"): "shared_ptr<MapPoint>", ("KeyFrame", "GetMapPointMatches"): "vector<shared_ptr<MapPoint>>",
+    ("KeyFrame", "GetFeatureVector"): "DBoW2::FeatureVector", ("KeyFrame", "GetFeatureGrids"): "vector<vector<vector<size_t>>>",
+    ("KeyFrame", "GetNumberMPs"): "int", ("KeyFrame", "GetPose"): "Sophus::SE3f", ("KeyFrame", "GetNLeft"): "int",
+    ("KeyFrame", "mnId"): "longunsignedint", ("KeyFrame", "mnMinX"): "int", ("KeyFrame", "mnMaxX"): "int",
+    ("KeyFrame", "mvScaleFactors"): "vector<float>", ("KeyFrame", "mbSparsified"): "bool",
+    ("MapPoint", "GetWorldPos"): "Eigen::Vector3f", ("MapPoint", "GetNormal"): "Eigen::Vector3f", ("MapPoint", "GetDescriptor"): "cv::Mat",
+    ("MapPoint", "Observations"): "int", ("MapPoint", "isBad"): "bool", ("MapPoint", "GetIndexInKeyFrame"): "tuple<int,int>",
+    ("MapPoint", "GetObservations"): "map<shared_ptr<KeyFrame>,tuple<int,int>>",
+    ("MapPoint", "mTrackProjX"): "float", ("MapPoint", "mTrackProjXR"): "float", ("MapPoint", "mbTrackInView"): "bool",
+    ("MapPoint", "mnTrackScaleLevel"): "int", ("MapPoint", "mnLastFrameSeen"): "longunsignedint", ("MapPoint", "mbSparsified"): "bool",
+    ("GeometricCamera", "project"): "Eigen::Vector2f",
+}
+
+
+def parse_stub():
+    path = os.path.join(ROOT, "tests", "slam_stub", "slam_stub_types.h")
+    src = strip_comments(open(path).read())
+    return {n: {"bases": b, "members": members(k, body), "file": "slam_stub_types.h"} for n, (k, b, body) in class_bodies(src).items()}
+
+
+def type_check(classes, accesses):
+    """-> (problems, number of type comparisons made)"""
+    problems, n = [], 0
+    stub = parse_stub()
+    for key, want in sorted(EXPECTED_TYPES.items()):
+        e = lookup(classes, *key)
+        n += 1
+        if e is None:
+            problems.append(f"{key[0]}::{key[1]}: the host layer expects type {want}, the reference has no such member")
+        elif want not in e["types"]:
+            problems.append(f"{key[0]}::{key[1]}: the host layer expects type {want}, the reference declares {sorted(e['types'])}")
+    for (cls, member) in sorted(accesses):
+        r, t = lookup(classes, cls, member), lookup(stub, cls, member)
+        if r is None or t is None:
+            continue
+        n += 1
+        if not t["types"] <= r["types"]:
+            problems.append(f"{cls}::{member}: the stand-in (tests/slam_stub) declares {sorted(t['types'])}, the reference {sorted(r['types'])}")
+    return problems, n
+
+
 def main():
     if not os.path.isdir(os.path.join(REF, "include")):
         print(json.dumps({"skipped": f"{REF}/include not present (the reference exists in the build container only)"}))
@@ -246,7 +350,9 @@ def main():
         elif any(u[1] for u in uses) and e["kind"] != "function":
             problems.append(f"{cls}::{member} is called like a function in {where} but is a data member in the reference")
     problems += dropin_check(classes)
-    report = {"reference": REF, "classes_parsed": {c: len(v["members"]) for c, v in classes.items() if c in
+    type_problems, n_types = type_check(classes, host_accesses())
+    problems += type_problems
+    report = {"type_comparisons": n_types, "reference": REF, "classes_parsed": {c: len(v["members"]) for c, v in classes.items() if c in
                                                   ("Frame", "KeyFrame", "MapPoint", "ORBextractor", "ORBmatcher", "GeometricCamera")},
               "member_accesses_checked": checked, "allowed_additions": sorted("::".join(a) for a in ALLOWED_MISSING), "problems": problems}
     print(json.dumps(report, indent=1))
