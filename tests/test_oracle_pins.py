@@ -75,6 +75,63 @@ def compare(oracle, pins_dir):
     return bad, meta
 
 
+def select_semantics(oracle, pins_dir):
+    """Which variant of the semantics table (oracle/cvprims.h `Semantics` == msorb_extractor_set_semantics) reproduces the
+    fixtures?  Each of the three variable primitives is decided on its own: the Gaussian's Q8 taps (symmetric 7-tap kernels
+    within +-2 of sigma 2's float taps, sum 255 .. 257), resize's vertical rounding (two-stage / single-stage), fastAtan2's
+    contraction (separate multiply-add / FMA).  FAST has no variant.  -> dict(gauss_taps, resize_single_stage, atan2_fma,
+    fast_ok, default) with None where NO variant matches (then parity is refuted, not merely unpinned)."""
+    kit = _kit()
+    meta = json.load(open(os.path.join(pins_dir, "meta.json")))
+    out = {"cv2_version": meta.get("cv2_version")}
+    try:
+        # resize
+        z = np.load(os.path.join(pins_dir, "resize_linear.npz"))
+        out["resize_single_stage"] = None
+        for single in (False, True):
+            oracle.set_semantics(resize_single_stage=single)
+            if all(np.array_equal(oracle.resize_linear_u8(kit.pin_image(100 + i, sr, sc), dr, dc), z[name])
+                   for i, (name, sr, sc, dr, dc) in enumerate(kit.RESIZE_CASES)):
+                out["resize_single_stage"] = single
+                break
+        # fastAtan2 (a sample decides, the full set confirms)
+        z = np.load(os.path.join(pins_dir, "fast_atan2.npz"))
+        y, x = kit.atan2_inputs()
+        out["atan2_fma"] = None
+        for fma in (False, True):
+            oracle.set_semantics(atan2_fma=fma)
+            sel = np.r_[0:len(y):53]
+            if not np.array_equal(np.array([oracle.fast_atan2(a, b) for a, b in zip(y[sel], x[sel])], np.float32).view(np.uint32), z["bits"][sel]):
+                continue
+            if np.array_equal(np.array([oracle.fast_atan2(a, b) for a, b in zip(y, x)], np.float32).view(np.uint32), z["bits"]):
+                out["atan2_fma"] = fma
+                break
+        # Gaussian taps: the small case first, every case to confirm
+        z = np.load(os.path.join(pins_dir, "gaussian7.npz"))
+        srcs = {name: kit.pin_image(200 + i, r, c) for i, (name, r, c) in enumerate(kit.BLUR_CASES)}
+        small = min(kit.BLUR_CASES, key=lambda c: c[1] * c[2])[0]
+        cands = [(18, 34, 48, 56)] + [(a, b, c, d) for a in range(16, 21) for b in range(32, 37) for c in range(46, 51) for d in range(53, 59)
+                                      if 255 <= 2 * (a + b + c) + d <= 257 and (a, b, c, d) != (18, 34, 48, 56)]
+        out["gauss_taps"] = None
+        for a, b, c, d in cands:
+            taps = [a, b, c, d, c, b, a]
+            oracle.set_semantics(gauss_taps=taps)
+            if not np.array_equal(oracle.gaussian7(srcs[small]), z[small]):
+                continue
+            if all(np.array_equal(oracle.gaussian7(srcs[n]), z[n]) for n in srcs):
+                out["gauss_taps"] = taps
+                break
+    finally:
+        oracle.set_semantics()
+    z = np.load(os.path.join(pins_dir, "fast9_nms.npz"))
+    rois = kit.fast_inputs()
+    out["fast_ok"] = all(np.array_equal(oracle.fast9_nms(roi, th).reshape(-1, 3), z[f"th{th}_roi{i}"].reshape(-1, 3))
+                         for th in kit.FAST_THRESHOLDS for i, roi in enumerate(rois))
+    out["default"] = (out["gauss_taps"] == [18, 34, 48, 56, 48, 34, 18] and out["resize_single_stage"] is False and
+                      out["atan2_fma"] is False and out["fast_ok"])
+    return out
+
+
 def test_pin_inputs_are_machine_independent():
     """pin_image / atan2_inputs are integer hashes: their bytes are constants of the kit (guards numpy drift)."""
     kit = _kit()
@@ -90,7 +147,13 @@ def test_pins_against_real_opencv(oracle):
         pytest.skip("no OpenCV pins committed yet: run tools/pin_opencv.py on a machine with cv2 (README) — "
                     "until then the oracle is PARITY UNPINNED for resize / FAST / GaussianBlur / fastAtan2")
     bad, meta = compare(oracle, PINS)
-    assert not bad, f"oracle differs from OpenCV {meta['cv2_version']}:\n" + "\n".join(bad)
+    sel = select_semantics(oracle, PINS)
+    with open(os.path.join(PINS, "selected_semantics.json"), "w") as f:   # what msorb_extractor_set_semantics must be given
+        json.dump(sel, f, indent=1, sort_keys=True)
+    print("semantics reproducing OpenCV", meta["cv2_version"], ":", sel)
+    assert None not in sel.values() and sel["fast_ok"], f"NO variant of the semantics table reproduces OpenCV {meta['cv2_version']}: {sel}\n" + "\n".join(bad)
+    assert not bad, (f"the DEFAULT semantics differ from OpenCV {meta['cv2_version']}; the variant {sel} reproduces it: make it the default "
+                     "(oracle/cvprims.h Semantics, csrc/orb_device.h Semantics) or pass it to msorb_extractor_set_semantics\n" + "\n".join(bad))
 
 
 def test_pins_live_cv2(oracle, tmp_path):
@@ -164,6 +227,29 @@ def test_pin_kit_plumbing(oracle, tmp_path):
     n7 = sum(len(z[f"th7_roi{i}"]) for i in range(kit.FAST_CELLS))
     assert n20 > 200 and n7 > n20
     assert any(len(z[f"th20_roi{i}"]) == 0 and len(z[f"th7_roi{i}"]) > 0 for i in range(0, kit.FAST_CELLS, 6))
+
+
+@pytest.mark.parametrize("variant", [dict(), dict(gauss_taps=[18, 34, 49, 55, 49, 34, 18], resize_single_stage=True, atan2_fma=True),
+                                     dict(gauss_taps=[19, 34, 48, 54, 48, 34, 19], resize_single_stage=False, atan2_fma=True)])
+def test_consumer_finds_the_semantics_variant_that_made_the_fixtures(oracle, tmp_path, variant):
+    """The day real fixtures arrive, a disagreement with the defaults must come with its remedy: fixtures made by a stand-in
+    "OpenCV" that runs a NON-default variant of the semantics table are recognised as exactly that variant (and the default
+    comparison reports the primitives that differ); fixtures of the default variant select the defaults."""
+    kit = _kit()
+    try:
+        oracle.set_semantics(**variant)
+        kit.generate(_OracleAsCv(oracle), str(tmp_path))
+    finally:
+        oracle.set_semantics()
+    sel = select_semantics(oracle, str(tmp_path))
+    assert sel["gauss_taps"] == variant.get("gauss_taps", [18, 34, 48, 56, 48, 34, 18])
+    assert sel["resize_single_stage"] is bool(variant.get("resize_single_stage", False))
+    assert sel["atan2_fma"] is bool(variant.get("atan2_fma", False))
+    assert sel["fast_ok"] and sel["default"] is (not variant)
+    bad, _ = compare(oracle, str(tmp_path))
+    assert (bad == []) is (not variant)
+    if variant:
+        assert any(b.startswith("blur") for b in bad) and any(b.startswith("fastAtan2") for b in bad)
 
 
 PIN_IMAGE_100_SHA16 = "fd55b5ceb08b6542"
