@@ -11,7 +11,7 @@ import csv,collections
 rows=list(csv.DictReader(open("$OUT/r_kernel_trace.csv")))
 d=collections.defaultdict(list)
 for r in rows:
-    n=r["Kernel_Name"].split("(")[0].replace("void ","").replace("msorb::","")
+    n=r["Kernel_Name"].replace("(anonymous namespace)::","").split("(")[0].replace("void ","").replace("msorb::","")
     d[(n,r["Grid_Size_X"],r["Grid_Size_Y"],r["Grid_Size_Z"])].append(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))
 for k,v in sorted(d.items()):
     print("%-40s grid=%-22s n=%-3d avg_us=%.1f" % (k[0], "x".join(k[1:]), len(v), sum(v)/len(v)/1000))

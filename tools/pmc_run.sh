@@ -13,7 +13,7 @@ f=glob.glob("$OUT/**/p_counter_collection.csv", recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
 d=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
-    n=r["Kernel_Name"].split("(")[0].replace("void ","").replace("msorb::","")
+    n=r["Kernel_Name"].replace("(anonymous namespace)::","").split("(")[0].replace("void ","").replace("msorb::","")
     if "$SUB" and "$SUB" not in n: continue
     d[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for n,c in sorted(d.items()):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The full measurement run of a round, on the GPU box:  gpurun --timeout 2400 -- 'bash tools/round_run.sh'
-# then, back in the container:  python tools/collect_profiles.py round2   (copies the summaries into profiles/)
+# then, back in the container:  python tools/collect_profiles.py round4   (copies the summaries into profiles/)
 # Every profiler pass runs under its own timeout: a counter set the hardware refuses leaves rocprofv3 waiting forever.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; O=gpurun_out/round; rm -rf $O; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.json
@@ -14,7 +14,10 @@ PMC_TIMEOUT=300 tools/pmc_run.sh round/pmc_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/fetch_calib.hip -o tools/_fetch_calib 2>/dev/null; tools/fetch_calib.sh > $O/fetch_calib.txt 2>&1; cat $O/fetch_calib.txt
 python tools/latency_bench.py > $O/latency.json 2> $O/latency.err; cat $O/latency.json
 python tools/bow_bench.py > $O/bow_bench.json 2>/dev/null; cat $O/bow_bench.json
-python tools/hamming_bench.py > $O/hamming_bench.txt 2>&1; tail -5 $O/hamming_bench.txt
+{ python tools/hamming_bench.py; python tools/hamming_bench.py --popcount; } > $O/hamming_bench.txt 2>&1; tail -5 $O/hamming_bench.txt
+python tools/frame_chain.py 300 > $O/frame_chain.json 2>/dev/null; cat $O/frame_chain.json
+tools/frame_trace.sh > $O/frame_trace.txt 2>&1; tail -45 $O/frame_trace.txt
+tools/qt_marks.sh 2>&1 | tail -26 > $O/qt_marks.txt; tail -26 $O/qt_marks.txt
 tools/batch_sweep.sh > $O/batch_sweep.jsonl 2>/dev/null; cat $O/batch_sweep.jsonl
 g++ -O2 -std=c++17 tools/latency_pair.cc -Iinclude -Lms-slam_amd -lmsorb -lpthread -o /tmp/latency_pair 2>/dev/null && LD_LIBRARY_PATH=ms-slam_amd:/opt/rocm/lib /tmp/latency_pair 300 > $O/latency_pair.json; cat $O/latency_pair.json
 g++ -O2 -std=c++17 -Itests/cv_stub -Ims-slam_amd/host -Iinclude tools/latency_class.cc ms-slam_amd/host/ORBextractor.cc -Lms-slam_amd -lmsorb -lpthread -o /tmp/latency_class 2>$O/latency_class.err && {

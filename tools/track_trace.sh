@@ -16,6 +16,6 @@ start=last
 while start>0 and int(rows[start]["Start_Timestamp"])-int(rows[start-1]["End_Timestamp"])<60000: start-=1
 t0=int(rows[start]["Start_Timestamp"])
 for r in rows[start:min(len(rows),last+6)]:
-    n=r["Kernel_Name"].split("(")[0].replace("void ","").replace("msorb::","")[:48]
+    n=r["Kernel_Name"].replace("(anonymous namespace)::","").split("(")[0].replace("void ","").replace("msorb::","")[:48]
     print("%-50s +%8.1f us  dur %7.1f us  grid %s" % (n,(int(r["Start_Timestamp"])-t0)/1e3,(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3,r["Grid_Size_X"]))
 PY
