@@ -750,6 +750,8 @@ def main():
         g_v = pairs * reps / (ms_v * 1e-3) / 1e9
         hamming = {"gpairs_per_s": round(g, 2), "pairs_per_launch": pairs,
                    "ms_per_launch": round(ms / reps, 4), "kernel": "dense_top2_mfma_kernel (v_mfma_i32_32x32x32_i8)",
+                   "formulation": "MSORB_DENSE_MATRIX_CORES: Hamming distance as an int8 dot product on the matrix cores — exact, identical "
+                                  "results, but NOT the north_star's formulation ('no MFMA'); the conformant figure is popcount_kernel below",
                    "ceiling_gpairs_per_s": round(ceil_mfma, 1), "frac": round(g / ceil_mfma, 3),
                    "ceiling_note": "i8 MFMA rate measured on this chip (4.3 POPS) / 512 operations per pair",
                    "valu_formulation_ceiling_gpairs_per_s": round(ceil_valu, 1),
@@ -922,7 +924,15 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
+            "metric_notes": {"inputs": "value assumes the images are already in HBM (bench contract); host_fed is the PCIe-inclusive batch "
+                                       "rate, per_frame what one frame at a time from host memory costs",
+                             "hamming_match": "gpairs_per_s is an int8 matrix-core formulation (a deviation from north_star's 'no MFMA'); "
+                                              "hamming_match.popcount_kernel is the north_star's xor + popcount form, same inputs, same run",
+                             "two_gpus": "the product's stereo split (msorb_extract_stereo_split) gathers with hipMemcpyPeerAsync inside one "
+                                         "process; RCCL (torch.distributed nccl) carries the exchange only in `bench.py --gpus N`",
+                             "see": "BASELINE.md section 3"},
             "config": {"workload": "configs[1]: KITTI-00 stereo 1241x376, 2000 feat/frame, pyramid+FAST+rBRIEF",
+                       "split_transport": None if world == 1 else "RCCL point-to-point (torch.distributed nccl backend), one rank per GPU",
                        "pairs_per_step_per_gpu": B if world == 1 else B, "images_per_step_per_gpu": n_img,
                        "batches_in_flight": depth if world == 1 else (1 if args.isolated or os.environ.get("MSORB_BENCH_SYNC") else 2),
                        "parallelism": ("1 GPU, both eyes; msorb_extract_batch_submit / _wait on two alternating handles: step k+1 is enqueued "
