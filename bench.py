@@ -728,7 +728,7 @@ def main():
         pairs = int((counts_h[0::2].astype(np.int64) * counts_h[1::2].astype(np.int64)).sum())
         # The kernel runs on the matrix cores (matcher.hip dense_top2_mfma_kernel): +-32 int8 encoding, 8 x v_mfma_i32_32x32x32_i8 per
         # 32 x 32 pairs = 512 int8 operations per pair.  Ceiling = the i8 MFMA rate this chip sustains with nothing else running
-        # (4.3 POPS: 37.5 cycles@2.4GHz per instruction and SIMD, tools/valu_ubench.hip's MFMA companion in DESIGN.md section 4).
+        # (4.3 POPS: 37.5 cycles@2.4GHz per instruction and SIMD, tools/mfma_rate.hip; docs/DESIGN_rounds1-3.md section 4).
         # For reference the integer-VALU formulation (8 x v_xor at 2.5 cycles + 8 x accumulating v_bcnt at 4.2 per 64 pairs, +
         # 3 slow-class instructions of top-2 bookkeeping) tops out at the two VALU figures; round 1's kernel reached 1.5-1.7 Tpairs/s.
         g = pairs * reps / (ms * 1e-3) / 1e9
