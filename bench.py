@@ -39,6 +39,42 @@ def self_check(ok, what):
         raise AssertionError("bench self-check failed: " + what)
 
 
+def live_pmc(kernel_substr, counters=("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"), timeout_s=150):
+    """roofline.traffic measured in THIS run: one rocprofv3 --pmc pass per counter (separate passes, kernel trace only — the
+    guide's recipe) over a child `bench.py --steps 2 --warmup 1 --lean --isolated --no-pmc` (the same batch, every kernel alone
+    on the GPU), per-launch average of the dominant kernel.  -> {counter: value} or None when rocprofv3 is missing, refuses the
+    counter or does not finish (the line then falls back to the committed PMC summary and says so)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None
+    out = {}
+    for ctr in counters:
+        d = tempfile.mkdtemp(prefix="msorb_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            subprocess.run([rp, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                            os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--lean", "--isolated", "--no-pmc", "--cpu-pairs", "0"],
+                           cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False)
+            files = glob.glob(os.path.join(d, "**", "p_counter_collection.csv"), recursive=True)
+            if not files:
+                return None
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
+                    if r["Counter_Name"] == ctr and kernel_substr in r["Kernel_Name"]]
+            if not vals:
+                return None
+            out[ctr] = sum(vals) / len(vals)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def level_bytes(cfg):
     """Algorithmic bytes per image: sum of level pixels etc."""
     import math
@@ -492,6 +528,7 @@ def main():
     ap.add_argument("--lean", action="store_true",
                     help="profiling aid: only the extraction loop (no Hamming / stereo / tracking / per-frame / host-fed / sparsification "
                          "legs, no CPU baseline), so that a kernel trace or a counter pass holds nothing else")
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic live with rocprofv3 (child passes of this script)")
     ap.add_argument("--isolated", action="store_true",
                     help="profiling aid: no sub-batch / blur overlap anywhere, so every kernel launch covers the whole "
                          "batch and runs alone (rocprofv3 per-kernel durations and PMC traffic are then per-launch clean)")
@@ -862,13 +899,31 @@ def main():
             tc = time.perf_counter()
             bi_c, bd_c, sd_c = orb_oracle.dense_top2(q0, t0_)
             dtc = time.perf_counter() - tc
+            # the same brute force over many frames: one core (16 frames) and every host core (all 128 frames, one frame per task)
+            from concurrent.futures import ThreadPoolExecutor
+            dq_h, dt_h = dq.cpu().numpy(), dtr.cpu().numpy()
+            frames16 = list(range(min(16, dq_h.shape[0])))
+            tc1 = time.perf_counter()
+            for f_ in frames16:
+                orb_oracle.dense_top2(dq_h[f_, :int(counts_h[2 * f_])], dt_h[f_, :int(counts_h[2 * f_ + 1])])
+            dt1 = time.perf_counter() - tc1
+            pairs1 = sum(int(counts_h[2 * f_]) * int(counts_h[2 * f_ + 1]) for f_ in frames16)
+            ncore = min(os.cpu_count() or 1, dq_h.shape[0])
+            tca = time.perf_counter()
+            with ThreadPoolExecutor(ncore) as pool:
+                list(pool.map(lambda f_: orb_oracle.dense_top2(dq_h[f_, :int(counts_h[2 * f_])], dt_h[f_, :int(counts_h[2 * f_ + 1])]),
+                              range(dq_h.shape[0])))
+            dta = time.perf_counter() - tca
             same = (np.array_equal(bi_c, bi_g[0, :n0].cpu().numpy()) and np.array_equal(bd_c, bd_g[0, :n0].cpu().numpy()) and
                     np.array_equal(sd_c, sd_g[0, :n0].cpu().numpy()))
             same_pop = all(np.array_equal(c, g[0, :n0].cpu().numpy()) for c, g in zip((bi_c, bd_c, sd_c), popcount_out))
             self_check(same, "hamming_match: the MFMA kernel differs from the CPU oracle")
             self_check(same_pop, "hamming_match: the popcount kernel differs from the CPU oracle")
-            hamming["cpu_baseline"] = {"gpairs_per_s": round(n0 * n1 / dtc / 1e9, 4), "cores": 1, "kind": "port",
-                                       "sample": f"{n0} x {n1} descriptors of one stereo pair, {dtc * 1e3:.1f} ms",
+            hamming["cpu_baseline"] = {"gpairs_per_s": round(pairs1 / dt1 / 1e9, 4), "cores": 1, "kind": "port",
+                                       "sample": f"{len(frames16)} stereo pairs of ~{n0} x {n1} descriptors, {dt1 * 1e3:.1f} ms "
+                                                 "(xor + __builtin_popcountll, -O3 x86-64-v3)",
+                                       "all_cores": {"gpairs_per_s": round(pairs / dta / 1e9, 3), "cores": ncore,
+                                                     "sample": f"all {dq_h.shape[0]} pairs, one frame per task, {dta * 1e3:.1f} ms"},
                                        "gpu_matches_cpu": bool(same), "popcount_kernel_matches_cpu": bool(same_pop)}
 
     if rank == 0:
@@ -911,6 +966,15 @@ def main():
                 valu_frac = pm.get("valu_fraction_of_measured_peak")
         except Exception:
             traffic = None
+        traffic_source = ("committed " + os.path.basename(pmc_file)) if (traffic is not None and pmc_file) else None
+        if aux and not args.no_pmc and not args.isolated and B == 128 and dom == "fast":
+            pm_live = live_pmc("fast_cells_kernel")
+            if pm_live:
+                scale = 2.0    # FETCH_SIZE reports half of the bytes a coalesced stream reads on gfx950 (profiles/round4_fetch_calib.txt)
+                traffic = int((pm_live["FETCH_SIZE"] * scale + pm_live["WRITE_SIZE"]) * 1024)
+                valu_frac = round(pm_live["SQ_INSTS_VALU"] * 64 / (stages[dom] * 1e-3) / 51.5e12, 3)
+                traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, one pass each, over a child "
+                                  "`bench.py --lean --isolated` of the same batch")
         out = {
             "metric": "Mkeypoints/s extract+describe, KITTI-00-like stereo 1241x376, 2000 feat/frame",
             "value": round(kp_total / dt / 1e6, 4),
@@ -950,13 +1014,14 @@ def main():
                                                     "compact": "cand_*"}[dom],
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch from rocprofv3 --pmc: FETCH_SIZE x fetch_scale + WRITE_SIZE (" +
-                                         (os.path.basename(pmc_file) if pmc_file else "no committed PMC summary") + "); FETCH_SIZE reports "
-                                         "half of the bytes a coalesced stream reads on gfx950 (tools/fetch_calib.hip, same run), WRITE_SIZE is exact",
+                         "traffic_source": traffic_source,
+                         "traffic_note": "HBM bytes per launch from rocprofv3 --pmc: FETCH_SIZE x 2 + WRITE_SIZE; FETCH_SIZE reports half of "
+                                         "the bytes a coalesced stream reads on gfx950 (tools/fetch_calib.hip, profiles/round4_fetch_calib.txt), "
+                                         "WRITE_SIZE is exact",
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "valu_fraction_of_measured_peak": valu_frac,
                          "valu_note": "what actually bounds this kernel: 64 x SQ_INSTS_VALU / duration against the 51.5 T lane-ops/s "
-                                      "the VALUs sustain (103 TFLOP/s v_fma_f32), from the committed PMC pass of the same command"},
+                                      "the VALUs sustain (103 TFLOP/s v_fma_f32); same source as traffic"},
             "pyramid_fast_gbs": round((sum(px[:-1]) + sum(px[1:]) + sum(px)) * n_img /
                                       ((stages["pyramid"] + stages["fast"]) * 1e-3) / 1e9, 2),
         }

@@ -1285,6 +1285,7 @@ def frame_set_last_points(frame, last):
     arrs = _last_arrays(last)
     frame.L.msorb_frame_set_last_points.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     _check(frame.L.msorb_frame_set_last_points(frame.h, len(arrs[0]), *[_np_ptr(a) for a in arrs]), "msorb_frame_set_last_points")
+    frame._last_n = len(arrs[0])
 
 
 def search_last_frame(frame, mm, obs, cur_mp, th, check_orientation=True, want_projection=False):
@@ -1294,11 +1295,12 @@ def search_last_frame(frame, mm, obs, cur_mp, th, check_orientation=True, want_p
     ob = _c(obs, np.int32)
     assert cur_mp.dtype == np.int32 and cur_mp.flags.c_contiguous
     nm = C.c_int()
-    n = len(ob)
+    n_obs = len(ob)
+    n = getattr(frame, "_last_n", n_obs)      # the projection arrays have one entry per last-frame keypoint
     pv = np.zeros(max(n, 1), np.uint8)
     pu, pvv, pur = [np.zeros(max(n, 1), np.float32) for _ in range(3)]
     proj = [_np_ptr(a) for a in (pv, pu, pvv, pur)] if want_projection else [None] * 4
-    _check(frame.L.msorb_search_last_frame(frame.h, C.addressof(mm), _np_ptr(ob), n, _np_ptr(cur_mp), th, int(check_orientation),
+    _check(frame.L.msorb_search_last_frame(frame.h, C.addressof(mm), _np_ptr(ob), n_obs, _np_ptr(cur_mp), th, int(check_orientation),
                                            C.byref(nm), *proj), "msorb_search_last_frame")
     if want_projection:
         return nm.value, dict(valid=pv[:n], u=pu[:n], v=pvv[:n], ur=pur[:n])

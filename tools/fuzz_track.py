@@ -3,7 +3,9 @@
 tests/test_track_gpu.py: image geometries (KITTI / EuRoC / 4Seasons / odd sizes), feature counts, camera intrinsics and poses,
 search radii, far-point gates, frames that already hold map points, local maps from empty to 5x the keypoints.  Every case checks
 msorb_track_frontend (one call) and msorb_extract_stereo_frame + msorb_search_local_points (two calls) against
-oracle extraction + isInFrustum + SearchByProjection.  usage (GPU box): python tools/fuzz_track.py [n_cases] [seed0]"""
+oracle extraction + isInFrustum + SearchByProjection, and msorb_track_frontend_motion + msorb_search_last_frame (a14, projection
+on the device, forward / backward bands, retry on the resident table, frame already holding points) against the oracle's
+projection + SearchByProjection(Current, Last).  usage (GPU box): python tools/fuzz_track.py [n_cases] [seed0]"""
 import os
 import sys
 
@@ -61,6 +63,7 @@ for case in range(n_cases):
                    level=r["level"], view_cos=r["view_cos"], desc=mp["desc"], obs=mp["obs"])
         return rf.SearchByProjection_mps(tab, frame_mp, th, far, th_far, nnratio)
     ok = True
+    parts = []
     try:
         # one call
         f, st, frame_mp, nm, out, rounds = msorb.track_frontend(ex, L, R, mb, mbf, fr, mp, th, far, th_far, nnratio, bounds=bounds)
@@ -69,6 +72,7 @@ for case in range(n_cases):
         want = np.full(len(okl), -1, np.int32)
         rnm = oracle_search(want)
         ok &= nm == rnm and np.array_equal(frame_mp, want)
+        parts = ["one_call" if ok else "ONE_CALL"]
         f.close()
         # two calls, frame already holding map points
         f2, st2 = msorb.extract_stereo_frame(ex, L, R, mb, mbf, bounds=bounds)
@@ -76,13 +80,55 @@ for case in range(n_cases):
         a, b = init.copy(), init.copy()
         nm2, _ = msorb.search_local_points(f2, fr, mp, a, th, far, th_far, nnratio)
         rnm2 = oracle_search(b)
-        ok &= nm2 == rnm2 and np.array_equal(a, b)
+        ok2 = nm2 == rnm2 and np.array_equal(a, b)
+        parts.append("two_calls" if ok2 else "TWO_CALLS")
+        ok &= ok2
         f2.close()
+        # TrackWithMotionModel's search with the projection on the device (a14): fused with the extraction, then the retry at
+        # 2 * th on the resident table with the frame already holding points, both against the oracle composition
+        last, q, tq, _, _ = synth.last_frame(9000 + seed0 + case, okl, odl, odp, point_frac=float(rng.uniform(0.3, 1.0)),
+                                              obs_zero_frac=float(rng.uniform(0, 0.5)), pixel_sigma=float(rng.uniform(0.5, 6.0)),
+                                              behind_frac=float(rng.uniform(0, 0.1)), cam=cam) if len(okl) else (None,) * 5
+        if last is not None:
+            fwd, bwd = bool(rng.random() < 0.25), False
+            if not fwd:
+                bwd = bool(rng.random() < 0.25)
+            th14 = float(rng.choice([7.0, 15.0, 3.0]))
+            ori = bool(rng.random() < 0.8)
+            mm = msorb.MotionModel.make(q, tq, cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["mbf"], fwd, bwd)
+            omm = orb_oracle.MotionModel()
+            omm.q[:] = [float(v) for v in q]
+            omm.t[:] = [float(v) for v in tq]
+            omm.fx, omm.fy, omm.cx, omm.cy, omm.mbf = cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["mbf"]
+            valid, pu, pv, pur = orb_oracle.project_last_frame(omm, bounds, last["has_point"], last["pos_w"])
+            nl = len(valid)
+
+            def oracle14(cur, obs, thx):
+                rf = orb_oracle.OracleFrame(okl, odl, our, bounds, scale)
+                tab = dict(valid=valid, u=pu, v=pv, ur=pur, octave=last["octave"], angle=last["angle"], desc=last["desc"],
+                           mp=np.arange(nl, dtype=np.int32), obs=obs)
+                return rf.SearchByProjection_frames(tab, cur, thx, fwd, bwd, ori)
+            f3, st3, cur, nm3 = msorb.track_frontend_motion(ex, L, R, mb, mbf, mm, last, last["obs"], th14, ori, bounds=bounds)
+            want = np.full(len(okl), -1, np.int32)
+            ok3 = nm3 == oracle14(want, last["obs"], th14) and np.array_equal(cur, want)
+            parts.append("motion" if ok3 else "MOTION")
+            ok &= ok3
+            held = rng.random(len(okl)) < 0.25
+            extra = np.where(rng.random(len(okl)) < 0.4, 0, rng.integers(1, 9, len(okl))).astype(np.int32)
+            obs2 = np.concatenate([last["obs"], extra])
+            c0 = np.where(held, nl + np.arange(len(okl)), -1).astype(np.int32)
+            a, b = c0.copy(), c0.copy()
+            nm4, proj = msorb.search_last_frame(f3, mm, obs2, a, 2 * th14, ori, want_projection=True)
+            ok4 = nm4 == oracle14(b, obs2, 2 * th14) and np.array_equal(a, b)
+            ok5 = all(np.array_equal(proj[k].view(np.uint8), w.view(np.uint8)) for k, w in (("valid", valid), ("u", pu), ("v", pv), ("ur", pur)))
+            parts += ["retry" if ok4 else "RETRY", "projection" if ok5 else "PROJECTION"]
+            ok &= ok4 and ok5
+            f3.close()
     except Exception as e:   # noqa: BLE001
         print("case", case, "exception", e)
         ok = False
     ex.close()
-    print(f"case {case}: {rows}x{cols} nfeat {nfeat} kps {len(okl)} M {M} th {th} far {far} -> matches {nm if ok else '?'} rounds {rounds if ok else '?'} {'ok' if ok else 'MISMATCH'}",
+    print(f"case {case}: {rows}x{cols} nfeat {nfeat} kps {len(okl)} M {M} th {th} far {far} -> matches {nm if ok else '?'} rounds {rounds if ok else '?'} {'ok' if ok else 'MISMATCH ' + ' '.join(parts)}",
           flush=True)
     bad += not ok
 print("cases", n_cases, "mismatches", bad)
