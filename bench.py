@@ -277,6 +277,66 @@ def tracking_loop_leg(msorb, synth, torch, ex, cfg, base, counts_h, d_kps, d_des
     return out
 
 
+def reference_keyframe_leg(msorb, cpu):
+    """TrackReferenceKeyFrame's device part per frame (Tracking.cc:2703-2713): Frame::ComputeBoW (Frame.cc:670-677: DBoW2
+    transform of the frame's descriptors, levelsup 4) + ORBmatcher(0.7).SearchByBoW(pReferenceKF, Frame) against a KeyFrame
+    resident on the device.  ORBvoc-shaped synthetic vocabulary (k = 10, L = 6: the real ORBvoc.txt is a missing blob of the
+    reference); 2000 descriptors = noisy vocabulary leaves, the KeyFrame's = the frame's with up to 25 bits flipped."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bow_cases
+    voc = bow_cases.make_vocabulary(0, k=10, L=6, stop_frac=0.01)
+    dev = msorb.Vocabulary(voc["k"], voc["L"], 0, 0, voc["parent"], voc["is_leaf"], voc["descriptors"], voc["weights"])
+    rng = np.random.default_rng(3)
+    n = 2000
+    d_frame = bow_cases.make_features(1, voc, n)
+    d_kf = bow_cases._flip_bits(rng, d_frame, rng.integers(0, 26, n))
+    kps = np.zeros(n, msorb.KP_DTYPE)
+    kps["angle"] = rng.uniform(0, 360, n)
+    a_kf = ((kps["angle"] + rng.normal(0, 5, n)) % 360).astype(np.float32)
+    kkf = kps.copy()
+    kkf["angle"] = a_kf
+    sc8 = np.array([1.2 ** i for i in range(8)], np.float32)
+    fv = lambda r: (r["fv_node"], r["fv_begin"], r["fv_feat"])
+    store = msorb.KeyFrameStore()
+    kid = store.add(kkf, d_kf, fv(dev.transform(d_kf)), sc8, sc8 * sc8)
+    valid1 = np.ones(n, np.uint8)
+    for _ in range(5):
+        rb = dev.transform(d_frame)
+        store.search_by_bow([dict(kf1=kid, kf2=-1, valid1=valid1)], dict(desc=d_frame, fv=fv(rb), angle=kps["angle"]))
+    tb, ts = [], []
+    for _ in range(40):
+        t0 = time.perf_counter()
+        rb = dev.transform(d_frame)
+        t1 = time.perf_counter()
+        out, _ = store.search_by_bow([dict(kf1=kid, kf2=-1, valid1=valid1)], dict(desc=d_frame, fv=fv(rb), angle=kps["angle"]))
+        tb.append(t1 - t0); ts.append(time.perf_counter() - t1)
+    res = {"what": "TrackReferenceKeyFrame's device part per frame (Tracking.cc:2703-2713): Frame::ComputeBoW (msorb_bow_transform, host "
+                   "arrays in and out) + SearchByBoW(pReferenceKF, Frame) against a resident KeyFrame (msorb_search_by_bow_kf); "
+                   "synthetic ORBvoc-shaped vocabulary (k 10, L 6), 2000 descriptors a side",
+           "ms_compute_bow": round(float(np.median(tb)) * 1e3, 4), "ms_search_by_bow": round(float(np.median(ts)) * 1e3, 4),
+           "words": int(len(rb["bow_word"])), "nodes": int(len(rb["fv_node"])), "matches": int(out[0][0])}
+    if cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import orb_oracle
+        orc = orb_oracle.OracleVocabulary(voc["k"], voc["L"], 0, 0, voc["parent"], voc["is_leaf"], voc["descriptors"], voc["weights"])
+        rk = orc.transform(d_kf)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            rf = orc.transform(d_frame)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            nm, m12, _ = orb_oracle.search_by_bow(d_kf, d_frame, valid1, None, fv(rk), fv(rf), a_kf, kps["angle"], 50, True, 0.7, True)
+        t2 = time.perf_counter()
+        same = (rf["bow_word"].tolist() == rb["bow_word"].tolist() and rf["bow_value"].tobytes() == rb["bow_value"].tobytes() and
+                nm == out[0][0] and m12.tolist() == out[0][1].tolist())
+        self_check(same, "tracking_loop.reference_keyframe: ComputeBoW / SearchByBoW differ from the CPU oracle")
+        res["cpu_baseline"] = {"ms_compute_bow": round((t1 - t0) / 5 * 1e3, 4), "ms_search_by_bow": round((t2 - t1) / 5 * 1e3, 4), "cores": 1,
+                               "kind": "port", "gpu_matches_cpu": True}
+    store.close()
+    dev.close()
+    return res
+
+
 def tracking_cpu_leg(tracking, msorb, oracle_dir):
     """CPU oracle leg of configs[2]'s matcher half: isInFrustum + SearchByProjection over one frame's local map, 1 thread (the
     reference's tracking thread), and the cross-check of the device chain's matches against it."""
@@ -1032,6 +1092,8 @@ def main():
         if tracking is not None:
             tracking.pop("_cpu", None)
             tracking.pop("_cpu_mm", None)
+        if tracking is not None:
+            tracking["reference_keyframe"] = reference_keyframe_leg(msorb, args.cpu_pairs > 0)
         out["tracking_loop"] = tracking
         if aux:
             out["sparsification"] = sparsification_leg(msorb, args.cpu_pairs > 0)
