@@ -197,7 +197,7 @@ def tracking_loop_leg(msorb, synth, torch, ex, cfg, base, counts_h, d_kps, d_des
     ms = np.array([msorb.track_batch(d_kps, d_desc, d_ur2, counts_h, 2, bounds, scale, frusta, d_mp, th, device=local)["ms"] for _ in range(15)])
     ms_grid, ms_frustum, ms_window = [float(x) for x in np.median(ms, axis=0)]
     g = n_eval / (ms_window * 1e-3) / 1e9
-    ceil_valu = 1024 * 2.4e9 * 64 / (8 * 2.5 + 8 * 4.2) / 1e9
+    ceil_valu = 1024 * 2.4e9 * 64 / (8 * 7.91) / 1e9   # 8 x (v_xor + v_bcnt) in a mixed stream, tools/valu_ubench2.hip
     in_view = int(r["in_view"].sum().item())
     with_cand = int((r["topk_idx"][:, :, 0] >= 0).sum().item())
     # (a) per frame, host images in, host features + matches out
@@ -826,13 +826,15 @@ def main():
         # The kernel runs on the matrix cores (matcher.hip dense_top2_mfma_kernel): +-32 int8 encoding, 8 x v_mfma_i32_32x32x32_i8 per
         # 32 x 32 pairs = 512 int8 operations per pair.  Ceiling = the i8 MFMA rate this chip sustains with nothing else running
         # (4.3 POPS: 37.5 cycles@2.4GHz per instruction and SIMD, tools/mfma_rate.hip; docs/DESIGN_rounds1-3.md section 4).
-        # For reference the integer-VALU formulation (8 x v_xor at 2.5 cycles + 8 x accumulating v_bcnt at 4.2 per 64 pairs, +
-        # 3 slow-class instructions of top-2 bookkeeping) tops out at the two VALU figures; round 1's kernel reached 1.5-1.7 Tpairs/s.
+        # For reference the integer-VALU formulation: 8 x (v_xor + accumulating v_bcnt) per 64 pairs at 7.91 cycles@2.4GHz per
+        # instruction PAIR (tools/valu_ubench2.hip, round 4: in a stream that mixes the two classes a fast-class instruction costs
+        # as much as a slow one, whether alternating or in runs of 16 — 2.5 cycles hold in pure fast-class streams only), + 3
+        # slow-class instructions of top-2 bookkeeping at 4.2.
         g = pairs * reps / (ms * 1e-3) / 1e9
         mfma_pops = 4.3e15
         ceil_mfma = mfma_pops / 512 / 1e9
-        ceil_valu = 1024 * 2.4e9 * 64 / (8 * 2.5 + 8 * 4.2) / 1e9
-        ceil_valu_top2 = 1024 * 2.4e9 * 64 / (8 * 2.5 + 11 * 4.2) / 1e9
+        ceil_valu = 1024 * 2.4e9 * 64 / (8 * 7.91) / 1e9
+        ceil_valu_top2 = 1024 * 2.4e9 * 64 / (8 * 7.91 + 3 * 4.2) / 1e9
         # the north_star's own formulation (xor + __builtin_popcount per pair, no MFMA) measured beside it on the same descriptors
         msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=2, device=local, formulation=msorb.DENSE_POPCOUNT)
         bi_v, bd_v, sd_v, ms_v = msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=reps, device=local,
@@ -859,6 +861,9 @@ def main():
                                                "dword, no MFMA (formulation MSORB_DENSE_POPCOUNT); same inputs, same launch count",
                                        "gpairs_per_s": round(g_v, 2), "ms_per_launch": round(ms_v / reps, 4),
                                        "frac_of_valu_ceiling_with_top2": round(g_v / ceil_valu_top2, 3),
+                                       "ceiling_note": "mixed-stream VALU issue rate measured on this chip (tools/valu_ubench2.hip: "
+                                                       "v_xor + v_bcnt = 7.91 cycles@2.4GHz per pair of instructions); PMC of this "
+                                                       "kernel in profiles/round4_dense_popcount_pmc.txt",
                                        "identical_results": same_kernels}}
     # third: Frame::ComputeStereoMatches for the whole batch, device resident (pair p = images 2p / 2p+1), median
     # rejection included; the outputs of the extraction above are its inputs

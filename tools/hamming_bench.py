@@ -33,9 +33,10 @@ wi, wd, ws = orb_oracle.dense_top2(q[3, :nq[3]], t[3, :nt[3]])
 ok = (np.array_equal(wi, bi[3, :nq[3]].cpu().numpy()) and np.array_equal(wd, bd[3, :nq[3]].cpu().numpy()) and
       np.array_equal(ws, sd[3, :nq[3]].cpu().numpy()))
 # ceiling of the matrix-core kernel: the i8 MFMA rate the chip sustains (4.3 POPS, tools/mfma_rate.hip) / 512 int8 operations per
-# pair; --popcount selects the xor / popcount kernel, whose integer-VALU ceiling is 2934 Gpairs/s (2376 with top-2)
+# pair; --popcount selects the xor / popcount kernel, whose integer-VALU ceiling is 2486 Gpairs/s (2072 with top-2;
+# v_xor + v_bcnt cost 7.91 cycles@2.4GHz per instruction pair in a mixed stream, tools/valu_ubench2.hip)
 valu = popcount
-ceiling = 1024 * 2.4e9 * 64 / (8 * 2.5 + 8 * 4.2) / 1e9 if valu else 4.3e15 / 512 / 1e9
+ceiling = 1024 * 2.4e9 * 64 / (8 * 7.91 + 3 * 4.2) / 1e9 if valu else 4.3e15 / 512 / 1e9
 g = pairs * reps / (ms * 1e-3) / 1e9
 print(json.dumps({"kernel": "dense_top2_kernel (VALU)" if valu else "dense_top2_mfma_kernel", "gpairs_per_s": round(g, 1),
                   "ms_per_launch": round(ms / reps, 4), "pairs_per_launch": pairs, "matches_oracle": bool(ok),

@@ -75,6 +75,28 @@ KERNEL(k_cndvcc32, 1, CNDVCC32) KERNEL(k_mad64, 2, MAD64) KERNEL(k_mbcnt, 1, MBC
 KERNEL(k_cvtub, 1, CVTUB) KERNEL(k_addco, 1, ADDCO) KERNEL(k_readl, 2, READL) KERNEL(k_lshl64, 2, LSHL64) KERNEL(k_madi24, 1, MADI24)
 KERNEL(k_subrev, 1, SUBREV) KERNEL(k_bfi, 1, BFI) KERNEL(k_or3, 1, OR3) KERNEL(k_pkfma, 1, PKFMA) KERNEL(k_addf, 1, ADDF)
 KERNEL(k_sdwaadd, 1, SDWAADD) KERNEL(k_ashr, 1, ASHR) KERNEL(k_not, 1, NOT) KERNEL(k_or, 1, OR)
+// fast + slow class mixes: alternating (xor, bcnt per chain) against runs (8 xor, then 8 bcnt), and runs of 16
+#define XB_ALT(i) "v_xor_b32 %" #i ", %" #i ", %8\nv_bcnt_u32_b32 %" #i ", %9, %" #i "\n"
+#define XONLY(i) "v_xor_b32 %" #i ", %" #i ", %8\n"
+#define BONLY(i) "v_bcnt_u32_b32 %" #i ", %9, %" #i "\n"
+#define XB_RUN8(i) XONLY(i)
+KERNEL(k_xb_alt, 2, XB_ALT)
+#define KERNEL_RUNS(NAME, NI, REPS)                                                               \
+    __global__ void NAME(uint32_t* out, int iters) {                                              \
+        uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+        uint32_t b = blockIdx.x * 3 + 1, c = 0x0c020c00u;                                         \
+        for (int it = 0; it < iters; it++) {                                                      \
+            REP8(asm volatile(REPS(XONLY(0) XONLY(1) XONLY(2) XONLY(3) XONLY(4) XONLY(5) XONLY(6) XONLY(7)) \
+                              REPS(BONLY(0) BONLY(1) BONLY(2) BONLY(3) BONLY(4) BONLY(5) BONLY(6) BONLY(7)) \
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
+                              : "v"(b), "v"(c));)                                                 \
+        }                                                                                         \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;      \
+    }                                                                                             \
+    static const int NAME##_ni = NI;
+#define ONCE(X) X
+#define TWICE(X) X X
+KERNEL_RUNS(k_xb_run8, 2, ONCE) KERNEL_RUNS(k_xb_run16, 4, TWICE)
 typedef void (*kern_t)(uint32_t*, int);
 static void run(const char* name, kern_t k, int ni) {
     static uint32_t* d = nullptr;
@@ -89,6 +111,8 @@ static void run(const char* name, kern_t k, int ni) {
 }
 #define RUN(label, k) run(label, k, k##_ni)
 int main() {
+    RUN("v_xor + v_bcnt alternating", k_xb_alt); RUN("8 x v_xor then 8 x v_bcnt (per chain: 1 + 1)", k_xb_run8);
+    RUN("16 x v_xor then 16 x v_bcnt (per chain: 2 + 2)", k_xb_run16);
     RUN("v_cmp (vcc) + v_cndmask_e32 (vcc)", k_cmpcnd); RUN("v_cmp (sgpr pair) + v_cndmask_e64 (sgpr pair)", k_cmpcnd64);
     RUN("v_cmp (vcc) + 2 x v_cndmask_e32 (vcc)", k_cmpcnd2); RUN("v_cmp (vcc) + v_add + v_cndmask_e32 (vcc)", k_cmpxcnd);
     RUN("v_cmp (vcc) + v_add + v_xor + v_cndmask_e32", k_cmpxxcnd); RUN("s_mov vcc + v_cndmask_e32 (1 VALU)", k_smovcnd);
