@@ -1171,14 +1171,16 @@ __device__ __forceinline__ int wave_sum_dpp(int v) {
 // are two slow-class ones): adding 1.5 * 2^23 leaves round-to-nearest-even of x in the low mantissa bits.
 __device__ __forceinline__ int rint_small(float x) { return __float_as_int(__fadd_rn(x, 12582912.0f)) - 0x4B400000; }
 
-constexpr int kPatchPitch = 44;  // bytes per staged patch row: 11 dwords
+constexpr int kPatchPitch = 40;  // bytes per staged patch row: 37 pixels from a 4-byte boundary
+constexpr int kPatchSlot = 37 * kPatchPitch + 8;  // one keypoint's blurred patch in LDS (8-byte aligned slots)
+typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from any 4-byte boundary
 constexpr int kKpPerWave = 4;  // keypoints handled back to back by one wave (amortises the per-lane table loads)
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void describe_kernel(PyramidView pyr, PyramidView blur, const SelRec* __restrict__ sel,
                                                        const int* __restrict__ sel_count, int sel_stride,
                                                        LevelScale scales, msorb_keypoint* __restrict__ kps,
                                                        uint8_t* __restrict__ desc, int out_stride, int atan2_fma) {
-    __shared__ __attribute__((aligned(16))) uint8_t patch[4 * kKpPerWave][37 * kPatchPitch + 4];  // one slot per (wave, keypoint)
+    __shared__ __attribute__((aligned(16))) uint8_t patch[4 * kKpPerWave][kPatchSlot];  // one slot per (wave, keypoint)
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs; give every image to ONE XCD so that the
     // overlapping keypoint patches of an image are served by a single L2 instead of being fetched by all eight.
     int img = blockIdx.y, bx = blockIdx.x;
@@ -1192,36 +1194,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const int k_first = __builtin_amdgcn_readfirstlane((bx * 4 + (int)(threadIdx.x >> 6)) * kKpPerWave);  // wave-uniform -> SALU
     const int n_sel = sel_count[img];
     if (k_first >= n_sel) return;
-    // per-lane constants, loaded once.  IC-angle patch: the 31 rows are read as 9 aligned dwords each (279 slots, slot =
-    // lane + 64 t); after the byte re-alignment below, slot (row, col < 8) holds the pixels u = 4 col - 15 .. 4 col - 12 of
-    // row v = row - 15.  wu = (u + 16) per byte inside the circle (0 outside), vm = 1 / 0: two udot4 give sum(u I), sum(I).
-    uint32_t wu[5], vm[5];
-    uint32_t rc[5], bc[6];  // slot -> row | byte column << 8 (lane constants; keeps the /9, /10 out of the keypoint loop)
+    // per-lane constants, loaded once.  Both patches are read with 16-byte loads, three lanes per patch row (lane = 3 row' +
+    // seg, 21 rows per load instruction, lane 63 idles): 2 + 2 load instructions per keypoint instead of 5 + 6 dword ones.
+    // The texture addresser spends its cycles per lane address, not per byte (PMC, round 4: TCP_TOTAL_CACHE_ACCESSES = 0.93
+    // per CU cycle with dword loads), so the same bytes in a quarter of the addresses is what shortens this kernel.
+    // IC-angle patch: row v = row - 15 from the 4-byte boundary at or below x - 15; after the byte re-alignment below, dword
+    // col = 4 seg + d (col < 8) holds the pixels u = 4 col - 15 .. 4 col - 12.  wu = (u + 16) per byte inside the circle
+    // (0 outside), vm = 1 / 0: two udot4 chains give sum(u I), sum(I).  seg 2 only feeds the alignment of col 7.
+    const int seg = lane % 3, row3 = lane / 3;
+    uint32_t wu[2][4], vm[2][4];
+    uint32_t rrow_c[2], brow_c[2];   // clamped row of this lane in load t (rows of no patch row repeat the last one: same line)
+    int vrow[2];
 #pragma unroll
-    for (int it = 0; it < 6; it++) {  // slots past row 36 repeat a slot of row 36 (same address, same value: no predication)
-        const int idx = lane + 64 * it;
-        bc[it] = (uint32_t)min(idx / 10, 36) | ((uint32_t)(4 * (idx % 10)) << 8);
-    }
-    uint32_t vrow03 = 0;  // v of slots 0..3, one signed byte each
-    int vrow4 = 0;
+    for (int t = 0; t < 2; t++) {
+        const int row = lane < 63 ? 21 * t + row3 : 63;
 #pragma unroll
-    for (int t = 0; t < 5; t++) {
-        // slot layout: a load instruction covers 7 whole rows of 9 dwords in lanes 0..62 (lane 63 idles), so "the next
-        // dword of the row" is always the next lane of the same register: 5 x 7 = 35 >= 31 rows in the same 5 loads
-        const int row = lane < 63 ? 7 * t + lane / 9 : 31, col = lane % 9;
-        uint32_t a = 0, m = 0;
-        if (row < 31 && col < 8) {
-            const int d = c_tab.umax[row < 15 ? 15 - row : row - 15];
-            for (int bb = 0; bb < 4; bb++) {
-                const int u = 4 * col + bb - 15;
-                if (u >= -d && u <= d) { a |= (uint32_t)(u + 16) << (8 * bb); m |= 1u << (8 * bb); }
+        for (int d = 0; d < 4; d++) {
+            const int col = 4 * seg + d;
+            uint32_t a = 0, m = 0;
+            if (row < 31 && col < 8) {
+                const int dd = c_tab.umax[row < 15 ? 15 - row : row - 15];
+                for (int bb = 0; bb < 4; bb++) {
+                    const int u = 4 * col + bb - 15;
+                    if (u >= -dd && u <= dd) { a |= (uint32_t)(u + 16) << (8 * bb); m |= 1u << (8 * bb); }
+                }
             }
+            wu[t][d] = a; vm[t][d] = m;
         }
-        wu[t] = a; vm[t] = m;
-        rc[t] = (uint32_t)min(row, 30) | ((uint32_t)(4 * col + 4) << 8);  // slots of no row: weights 0, any valid address
-        if (t < 4) vrow03 |= (uint32_t)((row - 15) & 255) << (8 * t);
-        else vrow4 = row - 15;
+        rrow_c[t] = (uint32_t)min(row, 30);
+        brow_c[t] = (uint32_t)min(row, 36);
+        vrow[t] = row - 15;
     }
+    const uint32_t seg16 = 16u * (uint32_t)seg;
     // the 4 pattern pairs of this lane as floats (lane constants: decoded once per wave, not once per keypoint)
     float patx0[4], paty0[4], patx1[4], paty1[4];
 #pragma unroll
@@ -1235,7 +1239,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     // Software pipeline over the wave's keypoints: while keypoint k is being processed the 11 patch loads of keypoint
     // k+1 are already in flight (and the record of k+2 is being fetched) — the kernel is bound by the latency of these
     // scattered loads, not by arithmetic.
-    struct Loads { uint32_t rp[5], rsh[5], bp[6]; int poff; };
+    struct Loads { u32x4u rp[2]; uint32_t rsh[2]; u32x4u bp[2]; int poff; };
     auto scalar_rec = [](const SelRec& v) {
         // every lane loaded the same record: move it to scalar registers so that everything derived from it (level view,
         // row pointers, strides) is SALU work and the loads use an SGPR base + 32-bit lane offset
@@ -1249,8 +1253,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     auto issue = [&](const SelRec& r, Loads& L) {
         // Both patches depend only on (x, y, level).  The 256 test pairs gather 512 bytes from the blurred 37x37
         // neighbourhood (|offset| <= 18 after rotation); a direct gather touches ~35 cache lines per load instruction,
-        // so that patch goes to LDS with row-coherent dword loads: 37 rows x 10 dwords from the 4-byte boundary below
-        // x-18 = 370 slots, slot = lane + 64 it.  The 31x31 IC-angle patch: 31 rows x 9 dwords, slot = lane + 64 t.
+        // so that patch goes to LDS with row-coherent loads: 37 rows x 48 bytes from the 4-byte boundary at or below
+        // x - 18 (40 are kept).  The 31x31 IC-angle patch: 31 rows x 48 bytes (36 used).  The bytes past the patch are in
+        // the same image: a keypoint is >= 19 pixels from the border, x + 29 <= width + 9 wraps into the next row at most.
         const LevelView lv = pyr.lv[r.level];
         const LevelView bv = blur.lv[r.level];
         const int px0 = (r.x - 18) & ~3;
@@ -1261,32 +1266,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         const uint8_t* rrow = lv.base + (size_t)img * lv.img_stride + (size_t)(r.y - 15) * lv.pitch + (r.x - 15) - 4;
         const uint32_t rlow = (uint32_t)reinterpret_cast<uintptr_t>(rrow);
 #pragma unroll
-        for (int t = 0; t < 5; t++) {
-            const uint32_t row = rc[t] & 255u, col4p4 = rc[t] >> 8;
-#ifdef MSORB_DESC_EXP_RAW_FLAT    // timing experiment only (wrong results): every IC-angle row from one line
-            const uint32_t o = 0u * row;
-#else
-            const uint32_t o = __umul24(row, (uint32_t)lv.pitch);  // full-rate 24-bit multiply
-#endif
+        for (int t = 0; t < 2; t++) {
+            const uint32_t o = __umul24(rrow_c[t], (uint32_t)lv.pitch);  // full-rate 24-bit multiply
             L.rsh[t] = (rlow + o) & 3u;
-            L.rp[t] = *reinterpret_cast<const uint32_t*>(rrow + (size_t)(o + col4p4 - L.rsh[t]));
+            L.rp[t] = *reinterpret_cast<const u32x4u*>(rrow + (size_t)(o + seg16 + 4u - L.rsh[t]));
         }
 #pragma unroll
-        for (int it = 0; it < 6; it++) {
-            const uint32_t row = bc[it] & 255u, col4 = bc[it] >> 8;
-#ifdef MSORB_DESC_EXP_BLUR_FLAT   // timing experiment only (wrong results): every blurred row from one line
-            L.bp[it] = *reinterpret_cast<const uint32_t*>(brow + (size_t)(col4));
-            (void)row;
-#elif defined(MSORB_DESC_EXP_BLUR_TILED)   // timing experiment only (wrong results): addresses of a 16 x 8-pixel tiled plane
-            {
-                const uint32_t yy = min((uint32_t)(r.y - 18) + row, (uint32_t)((bv.h & ~7) - 1)), xx = (uint32_t)px0 + col4;
-                const uint32_t off = (yy >> 3) * (uint32_t)(bv.pitch * 8) + (xx >> 4) * 128u + (yy & 7u) * 16u + (xx & 15u);
-                L.bp[it] = *reinterpret_cast<const uint32_t*>(bv.base + (size_t)img * bv.img_stride + off);
-            }
-#else
-            L.bp[it] = *reinterpret_cast<const uint32_t*>(brow + (size_t)(__umul24(row, (uint32_t)bv.pitch) + col4));
-#endif
-        }
+        for (int t = 0; t < 2; t++)
+            L.bp[t] = *reinterpret_cast<const u32x4u*>(brow + (size_t)(__umul24(brow_c[t], (uint32_t)bv.pitch) + seg16));
     };
     const SelRec* recs = sel + (size_t)img * sel_stride;
     SelRec r_cur = scalar_rec(recs[k_first]);
@@ -1313,30 +1300,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             issue(r_cur, L_next);
             r_pre = recs[min(k + 2, n_sel - 1)];
         }
-        const uint32_t* rp = L.rp;
-        const uint32_t* rsh = L.rsh;
-        const uint32_t* bp = L.bp;
         POFF[kk] = L.poff;
 
-        // IC_Angle: integer moments over the 749-pixel circular patch (un-blurred level).  The next lane holds the
-        // following 4 bytes of the row: alignbyte undoes the 4-byte
-        // alignment of the loads, so the per-lane weights do not depend on the keypoint.
+        // IC_Angle: integer moments over the 749-pixel circular patch (un-blurred level).  The next dword of the row is the
+        // next register, and for the last one the next lane's first: alignbyte undoes the 4-byte alignment of the loads, so
+        // the per-lane weights do not depend on the keypoint.
         int m10 = 0, m01 = 0;
 #pragma unroll
-        for (int t = 0; t < 5; t++) {
-            uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rp[t], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-            const uint32_t px = __builtin_amdgcn_alignbyte(nx, rp[t], rsh[t]);
-            const int sI = (int)__builtin_amdgcn_udot4(px, vm[t], 0u, false);
-            m10 += (int)__builtin_amdgcn_udot4(px, wu[t], 0u, false) - 16 * sI;
-            m01 += (t < 4 ? (int)(int8_t)(vrow03 >> (8 * t)) : vrow4) * sI;
+        for (int t = 0; t < 2; t++) {
+            const u32x4u v = L.rp[t];
+            const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+            const uint32_t sh = L.rsh[t];
+            const uint32_t px0 = __builtin_amdgcn_alignbyte(v.y, v.x, sh), px1 = __builtin_amdgcn_alignbyte(v.z, v.y, sh);
+            const uint32_t px2 = __builtin_amdgcn_alignbyte(v.w, v.z, sh), px3 = __builtin_amdgcn_alignbyte(nx, v.w, sh);
+            uint32_t sI = __builtin_amdgcn_udot4(px0, vm[t][0], 0u, false);
+            sI = __builtin_amdgcn_udot4(px1, vm[t][1], sI, false);
+            sI = __builtin_amdgcn_udot4(px2, vm[t][2], sI, false);
+            sI = __builtin_amdgcn_udot4(px3, vm[t][3], sI, false);
+            uint32_t su = __builtin_amdgcn_udot4(px0, wu[t][0], 0u, false);
+            su = __builtin_amdgcn_udot4(px1, wu[t][1], su, false);
+            su = __builtin_amdgcn_udot4(px2, wu[t][2], su, false);
+            su = __builtin_amdgcn_udot4(px3, wu[t][3], su, false);
+            m10 += (int)su - 16 * (int)sI;
+            m01 += vrow[t] * (int)sI;
         }
         M10[kk] = wave_sum_dpp(m10);  // wave-uniform (SGPR) totals
         M01[kk] = wave_sum_dpp(m01);
-        uint8_t* lp = lp0 + kk * (37 * kPatchPitch + 4);
+        uint8_t* lp = lp0 + kk * kPatchSlot;
 #pragma unroll
-        for (int it = 0; it < 6; it++) {
-            const uint32_t row = bc[it] & 255u, col4 = bc[it] >> 8;
-            *reinterpret_cast<uint32_t*>(lp + row * kPatchPitch + col4) = bp[it];
+        for (int t = 0; t < 2; t++) {
+            const u32x4u v = L.bp[t];
+            uint8_t* w = lp + brow_c[t] * kPatchPitch + seg16;
+            *reinterpret_cast<uint2*>(w) = make_uint2(v.x, v.y);
+            if (seg != 2) *reinterpret_cast<uint2*>(w + 8) = make_uint2(v.z, v.w);   // a row keeps 40 of its 48 bytes
         }
     }
     // Phase V
@@ -1356,7 +1352,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         const float angle = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angle_v), kk));
         const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_v), kk));
         const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_v), kk));
-        const uint8_t* bc = lp0 + kk * (37 * kPatchPitch + 4) + 18 * kPatchPitch + 18 + POFF[kk];
+        const uint8_t* bc = lp0 + kk * kPatchSlot + 18 * kPatchPitch + 18 + POFF[kk];
         unsigned long long word[4];
 #pragma unroll
         for (int w = 0; w < 4; w++) {
