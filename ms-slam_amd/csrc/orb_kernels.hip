@@ -927,11 +927,9 @@ constexpr int kGaussLanesOut = 62;
 // fix-ups by byte permutation); the common interior blocks are compiled without them (a block-uniform `if` inside the row
 // loop is if-converted into per-row v_cndmask work by the compiler, so the two cases are separate instantiations).
 // Per row and lane: 2 DPP moves (neighbour dwords), 10 v_dot4 (the 7 taps of the 4 pixels against the three dwords
-// {w0,w1,w2} with the kernel shifted inside the constants: no v_alignbyte), 4 v_cvt, 28 exact fp32 FMAs as 14 v_pk_fma_f32,
-// and for the output row 4 FMAs + 3 v_perm.  Rounding without a conversion: the accumulator is opened with the +32768 of
-// (acc + 32768) >> 16 already in it, and under round-toward-zero fma(acc, 2^-16, 2^23) = 2^23 + floor(acc / 65536) exactly
-// (0 <= acc < 2^24: every product and partial sum is an integer below 2^24, all other FMAs are exact in any rounding
-// mode): the result byte is the low byte of the float's bit pattern.
+// {w0,w1,w2} with the kernel shifted inside the constants: no v_alignbyte), then the vertical pass in integers (below): 4 packs,
+// 12 v_dot2_u32_u16, 4 v_mad_u32_u24, and for the output row 3 v_perm — 35 instructions per four pixels of a row (51 with the
+// fp32 accumulators of rounds 1-3).  Exactly OpenCV's fixed-point arithmetic: u16 row sums, u32 column sums, (x + 2^15) >> 16.
 template <int ROWS, bool EDGE>
 __device__ __forceinline__ void gauss7_strip(const uint8_t* __restrict__ sb, uint8_t* __restrict__ db, int src_pitch, int dst_pitch,
                                              int h, int y0, uint32_t xl, int x0, bool store, uint32_t sel_w1, uint32_t sel_w2a,
@@ -947,7 +945,7 @@ __device__ __forceinline__ void gauss7_strip(const uint8_t* __restrict__ sb, uin
     constexpr uint32_t A1 = (k0 << 16) | (k1 << 24), B1 = k2 | (k3 << 8) | (k2 << 16) | (k1 << 24), C1 = k0;                    // j = 1
     constexpr uint32_t A2 = (k0 << 24), B2 = k1 | (k2 << 8) | (k3 << 16) | (k2 << 24), C2 = k1 | (k0 << 8);                     // j = 2
     constexpr uint32_t B3 = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), C3 = k2 | (k1 << 8) | (k0 << 16);                         // j = 3
-    auto row_sums = [&](uint32_t w1, float hf[4]) {
+    auto row_sums = [&](uint32_t w1, uint32_t hs[4]) {
         // bound_ctrl: lanes without a source (0 for wave_shr, 63 for wave_shl) read 0 — they only provide halo bytes
         uint32_t w0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
         uint32_t w2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
@@ -958,30 +956,40 @@ __device__ __forceinline__ void gauss7_strip(const uint8_t* __restrict__ sb, uin
             w1 = __builtin_amdgcn_perm(w1, w0, sel_w1);
             w2 = n2;
         }
-        const uint32_t h0 = __builtin_amdgcn_udot4(w1, B0, __builtin_amdgcn_udot4(w0, A0, 0u, false), false);
-        const uint32_t h1 = __builtin_amdgcn_udot4(w2, C1, __builtin_amdgcn_udot4(w1, B1, __builtin_amdgcn_udot4(w0, A1, 0u, false), false), false);
-        const uint32_t h2 = __builtin_amdgcn_udot4(w2, C2, __builtin_amdgcn_udot4(w1, B2, __builtin_amdgcn_udot4(w0, A2, 0u, false), false), false);
-        const uint32_t h3 = __builtin_amdgcn_udot4(w2, C3, __builtin_amdgcn_udot4(w1, B3, 0u, false), false);
-        hf[0] = (float)h0; hf[1] = (float)h1; hf[2] = (float)h2; hf[3] = (float)h3;
+        hs[0] = __builtin_amdgcn_udot4(w1, B0, __builtin_amdgcn_udot4(w0, A0, 0u, false), false);
+        hs[1] = __builtin_amdgcn_udot4(w2, C1, __builtin_amdgcn_udot4(w1, B1, __builtin_amdgcn_udot4(w0, A1, 0u, false), false), false);
+        hs[2] = __builtin_amdgcn_udot4(w2, C2, __builtin_amdgcn_udot4(w1, B2, __builtin_amdgcn_udot4(w0, A2, 0u, false), false), false);
+        hs[3] = __builtin_amdgcn_udot4(w2, C3, __builtin_amdgcn_udot4(w1, B3, 0u, false), false);
     };
-    constexpr float Kf[7] = {18.f, 34.f, 48.f, 56.f, 48.f, 34.f, 18.f};
-    float acc[7][4];
-    float hf[4];
+    // Vertical pass in integers, two taps per instruction: a row sum is < 2^16 (255 * 256), so consecutive rows of a column
+    // travel as one register P_r = h_r | h_{r+1} << 16 and output row o = 2^15 + dot2(P_o, k0 k1) + dot2(P_{o+2}, k2 k3) +
+    // dot2(P_{o+4}, k4 k5) + k6 h_{o+6}: per input row and pixel 1 pack + 3 v_dot2_u32_u16 + 1 v_mad_u32_u24 (rounds 1-3 ran 7
+    // fp32 FMAs + a conversion here).  Accumulator o % 7 is opened by row o + 1 and closed by row o + 6.
+    const ushort2v K01 = {(unsigned short)k0, (unsigned short)k1}, K23 = {(unsigned short)k2, (unsigned short)k3},
+                   K45 = {(unsigned short)k2, (unsigned short)k1};
+    uint32_t acc[7][4];
+    uint32_t hs[4], hp[4] = {0, 0, 0, 0};
     uint32_t warm[6], nxt[7];
 #pragma unroll
     for (int r = 0; r < 6; r++) warm[r] = load_row(r);
 #pragma unroll
     for (int u = 0; u < 7; u++) nxt[u] = load_row(6 + u);
-    // warm-up: input rows 0..5 open accumulators 0..5
+    // warm-up: input rows 0..5
 #pragma unroll
     for (int r = 0; r < 6; r++) {
-        row_sums(warm[r], hf);
+        row_sums(warm[r], hs);
 #pragma unroll
-        for (int t = 0; t <= r; t++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[r - t][j] = __fmaf_rn(Kf[t], hf[j], t == 0 ? 32768.0f : acc[r - t][j]);
+        for (int j = 0; j < 4; j++) {
+            if (r >= 1) {
+                const ushort2v P = __builtin_bit_cast(ushort2v, hp[j] | (hs[j] << 16));
+                acc[(r - 1) % 7][j] = __builtin_amdgcn_udot2(P, K01, 32768u, false);
+                if (r >= 3) acc[(r - 3) % 7][j] = __builtin_amdgcn_udot2(P, K23, acc[(r - 3) % 7][j], false);
+                if (r >= 5) acc[(r - 5) % 7][j] = __builtin_amdgcn_udot2(P, K45, acc[(r - 5) % 7][j], false);
+            }
+            hp[j] = hs[j];
+        }
     }
-    // steady state: input row r = 6 + 7*it + u completes output row o = r - 6 and opens accumulator r % 7
+    // steady state: input row r = 6 + 7*it + u completes output row o = r - 6
     for (int it = 0; it < ROWS / 7; it++) {
         if (y0 + 7 * it >= h) break;   // wave-uniform: the last strip of a level ends with the level (4.8 % of all rows otherwise)
         uint32_t cur[7];
@@ -994,20 +1002,22 @@ __device__ __forceinline__ void gauss7_strip(const uint8_t* __restrict__ sb, uin
 #pragma unroll
         for (int u = 0; u < 7; u++) {
             const int r = 6 + 7 * it + u;
-            row_sums(cur[u], hf);
+            row_sums(cur[u], hs);
+            uint32_t q[4];
 #pragma unroll
-            for (int t = 0; t < 7; t++) {
-                const int a = (6 + u - t) % 7;  // == (r - t) % 7
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[a][j] = __fmaf_rn(Kf[t], hf[j], t == 0 ? 32768.0f : acc[a][j]);
+            for (int j = 0; j < 4; j++) {
+                const ushort2v P = __builtin_bit_cast(ushort2v, hp[j] | (hs[j] << 16));
+                q[j] = __umul24(hs[j], k0) + acc[u % 7][j];                                      // (r - 6) % 7 == u: closes row o
+                acc[(5 + u) % 7][j] = __builtin_amdgcn_udot2(P, K01, 32768u, false);             // (r - 1) % 7: opens row r - 1
+                acc[(3 + u) % 7][j] = __builtin_amdgcn_udot2(P, K23, acc[(3 + u) % 7][j], false);
+                acc[(1 + u) % 7][j] = __builtin_amdgcn_udot2(P, K45, acc[(1 + u) % 7][j], false);
+                hp[j] = hs[j];
             }
-            const int o = r - 6, a = u % 7;  // (r - 6) % 7 == u
+            const int o = r - 6;
             if (y0 + o < h) {   // wave-uniform
-                uint32_t q[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) q[j] = __float_as_uint(__fmaf_rn(acc[a][j], 1.0f / 65536.0f, 8388608.0f));   // RTZ (see above)
-                const uint32_t packed = __builtin_amdgcn_perm(__builtin_amdgcn_perm(q[3], q[2], 0x0c0c0400u),
-                                                              __builtin_amdgcn_perm(q[1], q[0], 0x0c0c0400u), 0x05040100u);
+                // (x + 2^15) >> 16 of a value < 2^24: byte 2 of each sum
+                const uint32_t packed = __builtin_amdgcn_perm(__builtin_amdgcn_perm(q[3], q[2], 0x0c0c0602u),
+                                                              __builtin_amdgcn_perm(q[1], q[0], 0x0c0c0602u), 0x05040100u);
                 if (store) *reinterpret_cast<uint32_t*>(db + (uint32_t)(y0 + o) * (uint32_t)dst_pitch + (uint32_t)x0) = packed;
             }
         }
@@ -1062,7 +1072,6 @@ __global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, Pyr
     const uint32_t xl = (uint32_t)min(max(x0, 0), sv.pitch - 4);
     const uint8_t* sb = sv.base + (size_t)img * sv.img_stride;
     uint8_t* db = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride;
-    __builtin_amdgcn_s_setreg(0x801 /* hwreg(HW_REG_MODE, 0, 2): FP32 rounding */, 3 /* toward zero */);
     if (border_block || bx == 0)   // block-uniform
         gauss7_strip<ROWS, true>(sb, db, sv.pitch, dv.pitch, sv.h, y0, xl, x0, store, sel_w1, sel_w2a, sel_w2b);
     else
