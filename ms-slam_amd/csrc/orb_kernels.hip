@@ -1214,21 +1214,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     uint32_t wu[2][4], vm[2][4];
     uint32_t rrow_c[2], brow_c[2];   // clamped row of this lane in load t (rows of no patch row repeat the last one: same line)
     int vrow[2];
+    // The weights of a dword, all four bytes at once: byte b of U is u + 16 = 16 seg + 4 d + 1 + b (1 .. 48); a pixel is inside
+    // the circle iff 16 - dd <= U_b <= 16 + dd, tested per byte through bit 7 of U + (0x7f - hi) ("above hi") and of
+    // U + (0x80 - lo) ("at or above lo") — no carries: 48 + 128 < 256.  dwords past column 7 (U_b >= 33 > hi) and rows past
+    // 30 (no lower bound added: bit 7 stays clear) come out empty by themselves.
+    const uint32_t U0 = (uint32_t)(16 * seg + 1) * 0x01010101u + 0x03020100u;
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const int row = lane < 63 ? 21 * t + row3 : 63;
+        const bool valid = row < 31;
+        const int dd = c_tab.umax[valid ? (row < 15 ? 15 - row : row - 15) : 0];
+        const uint32_t above = (uint32_t)(0x7f - 16 - dd) * 0x01010101u;
+        const uint32_t atlo = valid ? (uint32_t)(0x80 - 16 + dd) * 0x01010101u : 0u;
 #pragma unroll
         for (int d = 0; d < 4; d++) {
-            const int col = 4 * seg + d;
-            uint32_t a = 0, m = 0;
-            if (row < 31 && col < 8) {
-                const int dd = c_tab.umax[row < 15 ? 15 - row : row - 15];
-                for (int bb = 0; bb < 4; bb++) {
-                    const int u = 4 * col + bb - 15;
-                    if (u >= -dd && u <= dd) { a |= (uint32_t)(u + 16) << (8 * bb); m |= 1u << (8 * bb); }
-                }
-            }
-            wu[t][d] = a; vm[t][d] = m;
+            const uint32_t U = U0 + (uint32_t)d * 0x04040404u;
+            const uint32_t in7 = (U + atlo) & ~(U + above) & 0x80808080u;
+            const uint32_t m = in7 >> 7;
+            wu[t][d] = U & (in7 | (in7 - m));
+            vm[t][d] = m;
         }
         rrow_c[t] = (uint32_t)min(row, 30);
         brow_c[t] = (uint32_t)min(row, 36);

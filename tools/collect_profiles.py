@@ -77,7 +77,7 @@ try:
 except Exception as ex:
     print("latency extras missing:", ex)
 json.dump(lat, open(os.path.join(P, f"{rnd}_latency_per_frame.json"), "w"), indent=1)
-for src, dst in (("bow_bench.json", "bow_bench.json"), ("valu_ubench.txt", "valu_ubench.txt"), ("kf_store_bench.json", "kf_store_bench.json"),
+for src, dst in (("bow_bench.json", "bow_bench.json"), ("valu_ubench.txt", "valu_ubench.txt"), ("valu_ubench2.txt", "valu_ubench2.txt"), ("kf_store_bench.json", "kf_store_bench.json"),
                  ("bench_unique128.json", "bench_unique128.json"), ("bench_unique8_same_steps.json", "bench_unique8_same_steps.json"), ("fetch_calib.txt", "fetch_calib.txt"),
                  ("hamming_bench.txt", "hamming_bench.txt"), ("pytest_gpu.txt", "pytest_gpu.txt"),
                  ("batch_sweep.jsonl", "batch_sweep.jsonl"), ("visibility_bench.json", "visibility_bench.json"),

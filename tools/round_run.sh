@@ -25,6 +25,7 @@ g++ -O2 -std=c++17 -Itests/cv_stub -Ims-slam_amd/host -Iinclude tools/latency_cl
   MSORB_HOST_PYRAMID=0 LD_LIBRARY_PATH=ms-slam_amd:/opt/rocm/lib /tmp/latency_class 300 > $O/latency_class_off.json; cat $O/latency_class_on.json $O/latency_class_off.json; }
 g++ -O2 -std=c++17 tools/kf_store_bench.cc -Iinclude -Lms-slam_amd -lmsorb -lpthread -o /tmp/kf_store_bench 2>$O/kf_store.err && LD_LIBRARY_PATH=ms-slam_amd:/opt/rocm/lib /tmp/kf_store_bench > $O/kf_store_bench.json; cat $O/kf_store_bench.json
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/valu_ubench.hip -o /tmp/valu_ubench 2>/dev/null && /tmp/valu_ubench > $O/valu_ubench.txt; tail -3 $O/valu_ubench.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/valu_ubench2.hip -o /tmp/valu_ubench2 2>/dev/null && /tmp/valu_ubench2 > $O/valu_ubench2.txt; head -3 $O/valu_ubench2.txt
 g++ -O2 -std=c++17 tools/visibility_bench.cc -Iinclude -Lms-slam_amd -lmsorb -o /tmp/visibility_bench 2>/dev/null && LD_LIBRARY_PATH=ms-slam_amd:/opt/rocm/lib /tmp/visibility_bench 300 > $O/visibility_bench.json; cat $O/visibility_bench.json
 g++ -O2 -std=c++17 tools/latency_pair.cc -Iinclude -Lms-slam_amd -lmsorb -lpthread -o tools/_latency_pair 2>/dev/null; tools/track_trace.sh > $O/track_trace.txt 2>&1; tail -30 $O/track_trace.txt
 tools/timeline.sh > /dev/null 2>&1; python tools/timeline_summary.py gpurun_out/timeline > $O/timeline_pipelined.txt 2>&1; tail -2 $O/timeline_pipelined.txt
