@@ -305,7 +305,7 @@ int ensure_batch(msorb_extractor* h, int n_images) {
     int rc;
     // +256: row-coherent dword loads may run a few bytes past the last row of the last plane
     if ((rc = h->d_pyr.ensure((size_t)n_images * g.pyramid_bytes + 256))) return rc;
-    if ((rc = h->d_blur.ensure((size_t)n_images * g.pyramid_bytes + 256))) return rc;
+    if ((rc = h->d_blur.ensure((size_t)n_images * g.blur_bytes + 512))) return rc;
     if ((rc = h->d_slots.ensure((size_t)n_images * g.slots_per_image))) return rc;
     if ((rc = h->d_compact.ensure((size_t)n_images * g.slots_per_image))) return rc;
     if ((rc = h->d_cell_count.ensure((size_t)n_images * ncells))) return rc;
@@ -339,6 +339,20 @@ PyramidView make_view(const msorb_extractor* h, const uint8_t* base, const Level
         v.lv[l].h = g.lv[l].h;
     }
     if (level0) v.lv[0] = *level0;
+    return v;
+}
+
+PyramidView make_blur_view(const msorb_extractor* h, const uint8_t* base) {   // tiled planes (orb_device.h blur_tile_off)
+    PyramidView v{};
+    const FrameGeom& g = h->G;
+    v.nlevels = g.nlevels;
+    for (int l = 0; l < g.nlevels; l++) {
+        v.lv[l].base = base + g.lv[l].blur_off;
+        v.lv[l].img_stride = g.blur_bytes;
+        v.lv[l].pitch = g.lv[l].pitch;
+        v.lv[l].w = g.lv[l].w;
+        v.lv[l].h = g.lv[l].h;
+    }
     return v;
 }
 
@@ -440,7 +454,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
     int ng = n_images >= 16 ? std::min(h->n_groups, kMaxGroups) : 1;
     ng = std::max(1, std::min(ng, n_images));
     const PyramidView pyr_all = make_view(h, h->d_pyr.p, &level0);
-    const PyramidView blur_all = make_view(h, h->d_blur.p, nullptr);
+    const PyramidView blur_all = make_blur_view(h, h->d_blur.p);
     h->last_pyr = pyr_all; h->last_blur = blur_all; h->last_n_images = n_images;
     h->h_pyr_valid = false;
     h->h_pyr_async = false;
@@ -463,7 +477,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
         l0.base = level0.base + (size_t)first * level0.img_stride;
         uint8_t* pyr_base = h->d_pyr.p + (size_t)first * g.pyramid_bytes;
         const PyramidView pyr = make_view(h, pyr_base, &l0);
-        const PyramidView blur = make_view(h, h->d_blur.p + (size_t)first * g.pyramid_bytes, nullptr);
+        const PyramidView blur = make_blur_view(h, h->d_blur.p + (size_t)first * g.blur_bytes);
         int* img_base = h->d_img_base.p + first + gi;
         const size_t cslot = (size_t)first * g.slots_per_image;
         mark(0, s);
@@ -543,7 +557,7 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(h->pe[i], s); };
 
     const PyramidView pyr = make_view(h, h->d_pyr.p, &level0);
-    const PyramidView blur = make_view(h, h->d_blur.p, nullptr);
+    const PyramidView blur = make_blur_view(h, h->d_blur.p);
     h->last_pyr = pyr; h->last_blur = blur; h->last_n_images = n_images;
     h->h_pyr_valid = false;
 
@@ -1345,6 +1359,13 @@ int msorb_debug_copy_level(msorb_extractor* h, int image, int level, int blurred
         return MSORB_E_INVALID;
     HIPCHK(hipSetDevice(h->device));
     const LevelView& v = blurred ? h->last_blur.lv[level] : h->last_pyr.lv[level];
+    if (blurred) {   // tiled on the device: fetch the plane, undo the tiling here
+        std::vector<uint8_t> t((size_t)v.pitch * ((v.h + 7) & ~7));
+        HIPCHK(hipMemcpy(t.data(), v.base + (size_t)image * v.img_stride, t.size(), hipMemcpyDeviceToHost));
+        for (int y = 0; y < v.h; y++)
+            for (int x = 0; x < v.w; x++) dst[(size_t)y * v.w + x] = t[blur_tile_off((uint32_t)x, (uint32_t)y, (uint32_t)v.pitch)];
+        return MSORB_OK;
+    }
     HIPCHK(hipMemcpy2D(dst, v.w, v.base + (size_t)image * v.img_stride, v.pitch, v.w, v.h, hipMemcpyDeviceToHost));
     return MSORB_OK;
 }

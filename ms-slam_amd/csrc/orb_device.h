@@ -16,6 +16,14 @@ struct LevelView {  // one pyramid level of a batch: image i's plane at base + i
     size_t img_stride;
     int pitch, w, h;
 };
+// The blurred planes (read by describe_kernel only) are stored in 4 x 4-pixel blocks of 16 bytes (4 rows of 4 pixels), the blocks
+// of four image rows side by side: 128 bytes = 32 pixels x 4 rows.  The blur kernel writes a lane's block with one 16-byte
+// store (8 lanes = one full line), and the 37 x 37 neighbourhood a descriptor samples lies in 10 x 10 blocks = ~23 cache lines
+// instead of ~45 row segments of 40 bytes each.  In a blurred LevelView `pitch` is the row pitch of the raw plane (a multiple
+// of 64); the plane holds ceil8(h) rows.
+__host__ __device__ inline uint32_t blur_tile_off(uint32_t x, uint32_t y, uint32_t pitch) {
+    return (y >> 2) * (pitch * 4u) + (x >> 2) * 16u + (y & 3u) * 4u + (x & 3u);
+}
 struct PyramidView {
     LevelView lv[kMaxLevels];
     int nlevels;

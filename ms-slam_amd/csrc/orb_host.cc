@@ -75,7 +75,7 @@ std::vector<ResizeTap> make_resize_taps(int dst_len, int src_len, bool horizonta
 bool FrameGeom::build(const OrbParams& p, int rows_, int cols_) {
     rows = rows_; cols = cols_; nlevels = p.nlevels;
     cells.clear();
-    size_t off = 0;
+    size_t off = 0, boff = 0;
     int slot = 0;
     for (int l = 0; l < nlevels; l++) {
         LevelGeom& g = lv[l];
@@ -89,6 +89,8 @@ bool FrameGeom::build(const OrbParams& p, int rows_, int cols_) {
         const size_t plane = (size_t)g.pitch * g.h;
         if (l == 0) plane0_bytes = plane;
         off += plane;
+        g.blur_off = boff;
+        boff += (size_t)g.pitch * ((g.h + 7) & ~7);
         // cell grid (ORBextractor.cc:789-803)
         g.min_x = kMinBorder; g.min_y = kMinBorder;
         g.max_x = g.w - kEdgeThreshold + 3;
@@ -159,6 +161,7 @@ bool FrameGeom::build(const OrbParams& p, int rows_, int cols_) {
         g.cell_count = (int)cells.size() - g.cell_begin;
     }
     pyramid_bytes = off;
+    blur_bytes = boff;
     slots_per_image = slot;
     return true;
 }

@@ -59,6 +59,7 @@ struct LevelGeom {
     int w = 0, h = 0;    // level size (ComputePyramid, ORBextractor.cc:1174-1175)
     int pitch = 0;       // row pitch of the device planes (multiple of 64 bytes)
     size_t plane_off = 0;  // byte offset of the plane inside one image's pyramid block
+    size_t blur_off = 0;   // ... and of its blurred twin, stored in 4 x 4-pixel blocks (orb_device.h blur_tile_off): pitch x ceil8(h) bytes
     int n_cols = 0, n_rows = 0, w_cell = 0, h_cell = 0;
     int cell_begin = 0, cell_count = 0;  // slice of the per-image cell table
     int min_x = 0, max_x = 0, min_y = 0, max_y = 0;  // minBorderX.. maxBorderY
@@ -70,6 +71,7 @@ struct FrameGeom {
     LevelGeom lv[kMaxLevels];
     std::vector<CellDesc> cells;
     size_t pyramid_bytes = 0;  // per image, levels 1.. (level 0 may live in caller memory)
+    size_t blur_bytes = 0;     // per image, the tiled blurred planes of all levels
     size_t plane0_bytes = 0;
     int slots_per_image = 0;
     // false if the reference's arithmetic would divide by zero for this size

@@ -829,7 +829,7 @@ __global__ __launch_bounds__(256) void cand_gather_kernel(const CellDesc* __rest
 // pitch); otherwise a fourth dword + funnel shift by the row's byte phase.  Column groups whose window
 // reaches the right border (reflect-101 gather, byte loads) are left to gauss7_edge_kernel so that the
 // streaming waves stay divergence free and the unrolled body stays small (instruction cache).
-constexpr int kGaussRows = 35;  // 6 warm-up rows + 5 x 7 steady rows
+constexpr int kGaussRows = 28;  // 6 warm-up rows + 4 x 7 steady rows; a multiple of 4: the blurred plane is written in blocks of four rows
 struct GaussTaps { uint32_t k[7]; };   // the generic blur kernels take the Q8 taps at run time (Semantics::gauss_taps)
 
 struct BlurPlan {
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(256) void gauss7_kernel(PyramidView src, PyramidVie
     const int y0 = (by * 4 + (threadIdx.x >> 6)) * kGaussRows;
     if (x0 + 16 > sv.w || y0 >= sv.h) return;  // right-border groups belong to gauss7_edge_kernel
     const uint8_t* sb = sv.base + (size_t)img * sv.img_stride;
-    uint8_t* db = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride + x0;
+    uint8_t* db = const_cast<uint8_t*>(dv.base) + (size_t)img * dv.img_stride;   // tiled plane (blur_tile_off)
     uint32_t acc[7][4];
     uint32_t hs[4];
     // warm-up: input rows 0..5 (image rows y0-3 .. y0+2) open accumulators 0..5
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(256) void gauss7_kernel(PyramidView src, PyramidVie
                 uint32_t packed = 0;
 #pragma unroll
                 for (int j = 0; j < 4; j++) packed |= min((acc[a][j] + 32768u) >> 16, 255u) << (8 * j);   // saturate_cast (taps summing to 257)
-                *reinterpret_cast<uint32_t*>(db + (size_t)(y0 + o) * dv.pitch) = packed;
+                *reinterpret_cast<uint32_t*>(db + blur_tile_off((uint32_t)x0, (uint32_t)(y0 + o), (uint32_t)dv.pitch)) = packed;
             }
         }
     }
@@ -934,6 +934,9 @@ template <int ROWS, bool EDGE>
 __device__ __forceinline__ void gauss7_strip(const uint8_t* __restrict__ sb, uint8_t* __restrict__ db, int src_pitch, int dst_pitch,
                                              int h, int y0, uint32_t xl, int x0, bool store, uint32_t sel_w1, uint32_t sel_w2a,
                                              uint32_t sel_w2b) {
+    static_assert(ROWS % 28 == 0, "strips start on a multiple of 4 rows and the row loop is unrolled over 4 x 7 rows");
+    uint8_t* const dblk = db + blur_tile_off((uint32_t)max(x0, 0), 0u, (uint32_t)dst_pitch);   // the lane's 4 x 4 block column
+    uint32_t blk[4];   // packed output rows of the block being filled
     auto load_row = [&](int r) {  // input row r of the strip = image row y0 - 3 + r (reflect-101, then clamped)
         int yy = refl101(y0 - 3 + r, h);
         yy = min(max(yy, 0), h - 1);
@@ -990,6 +993,7 @@ __device__ __forceinline__ void gauss7_strip(const uint8_t* __restrict__ sb, uin
         }
     }
     // steady state: input row r = 6 + 7*it + u completes output row o = r - 6
+#pragma unroll
     for (int it = 0; it < ROWS / 7; it++) {
         if (y0 + 7 * it >= h) break;   // wave-uniform: the last strip of a level ends with the level (4.8 % of all rows otherwise)
         uint32_t cur[7];
@@ -1018,7 +1022,13 @@ __device__ __forceinline__ void gauss7_strip(const uint8_t* __restrict__ sb, uin
                 // (x + 2^15) >> 16 of a value < 2^24: byte 2 of each sum
                 const uint32_t packed = __builtin_amdgcn_perm(__builtin_amdgcn_perm(q[3], q[2], 0x0c0c0602u),
                                                               __builtin_amdgcn_perm(q[1], q[0], 0x0c0c0602u), 0x05040100u);
-                if (store) *reinterpret_cast<uint32_t*>(db + (uint32_t)(y0 + o) * (uint32_t)dst_pitch + (uint32_t)x0) = packed;
+                // blocked plane (orb_device.h blur_tile_off): four output rows of the lane's columns are one 16-byte store, 8 lanes
+                // one full line; y0 is a multiple of 4, so o & 3 is the row inside the block.  The level's last rows flush a
+                // partly filled block (the rows below h in it are never read).
+                blk[o & 3] = packed;
+                if ((o & 3) == 3 || y0 + o == h - 1) {
+                    if (store) *reinterpret_cast<uint4*>(dblk + (uint32_t)((y0 + o) >> 2) * ((uint32_t)dst_pitch * 4u)) = make_uint4(blk[0], blk[1], blk[2], blk[3]);
+                }
             }
         }
     }
@@ -1115,7 +1125,7 @@ __global__ __launch_bounds__(64) void gauss7_edge_kernel(PyramidView src, Pyrami
             uint32_t acc = 0;
 #pragma unroll
             for (int k = 0; k < 7; k++) acc += (uint32_t)K[k] * hs[r + k][j];
-            db[(size_t)(y0 + r) * dv.pitch + first + j] = (uint8_t)min((acc + 32768u) >> 16, 255u);
+            db[blur_tile_off((uint32_t)(first + j), (uint32_t)(y0 + r), (uint32_t)dv.pitch)] = (uint8_t)min((acc + 32768u) >> 16, 255u);
         }
     }
 }
@@ -1212,7 +1222,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     // (0 outside), vm = 1 / 0: two udot4 chains give sum(u I), sum(I).  seg 2 only feeds the alignment of col 7.
     const int seg = lane % 3, row3 = lane / 3;
     uint32_t wu[2][4], vm[2][4];
-    uint32_t rrow_c[2], brow_c[2];   // clamped row of this lane in load t (rows of no patch row repeat the last one: same line)
+    uint32_t rrow_c[2];   // clamped IC-angle row of this lane in load t (rows of no patch row repeat the last one: same line)
     int vrow[2];
     // The weights of a dword, all four bytes at once: byte b of U is u + 16 = 16 seg + 4 d + 1 + b (1 .. 48); a pixel is inside
     // the circle iff 16 - dd <= U_b <= 16 + dd, tested per byte through bit 7 of U + (0x7f - hi) ("above hi") and of
@@ -1235,10 +1245,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             vm[t][d] = m;
         }
         rrow_c[t] = (uint32_t)min(row, 30);
-        brow_c[t] = (uint32_t)min(row, 36);
         vrow[t] = row - 15;
     }
     const uint32_t seg16 = 16u * (uint32_t)seg;
+    // blurred patch (blocked plane, orb_device.h blur_tile_off): 10 x 10 blocks of 4 x 4 pixels hold the 37 x 37 neighbourhood
+    // wherever it starts; slot = lane + 64 t -> block row slot / 10, block column slot % 10 (slots past 99 repeat block row 9):
+    // ten neighbouring lanes read 160 contiguous bytes
+    uint32_t bbrow[2], bbcol16[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int slot = lane + 64 * t;
+        bbrow[t] = (uint32_t)min(slot / 10, 9);
+        bbcol16[t] = (uint32_t)(slot % 10) * 16u;
+    }
     // the 4 pattern pairs of this lane as floats (lane constants: decoded once per wave, not once per keypoint)
     float patx0[4], paty0[4], patx1[4], paty1[4];
 #pragma unroll
@@ -1252,7 +1271,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     // Software pipeline over the wave's keypoints: while keypoint k is being processed the 11 patch loads of keypoint
     // k+1 are already in flight (and the record of k+2 is being fetched) — the kernel is bound by the latency of these
     // scattered loads, not by arithmetic.
-    struct Loads { u32x4u rp[2]; uint32_t rsh[2]; u32x4u bp[2]; int poff; };
+    struct Loads { u32x4u rp[2]; uint32_t rsh[2]; uint4 bp[2]; int poff, oy; };
     auto scalar_rec = [](const SelRec& v) {
         // every lane loaded the same record: move it to scalar registers so that everything derived from it (level view,
         // row pointers, strides) is SALU work and the loads use an SGPR base + 32-bit lane offset
@@ -1271,9 +1290,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         // the same image: a keypoint is >= 19 pixels from the border, x + 29 <= width + 9 wraps into the next row at most.
         const LevelView lv = pyr.lv[r.level];
         const LevelView bv = blur.lv[r.level];
-        const int px0 = (r.x - 18) & ~3;
-        L.poff = (r.x - 18) - px0;
-        const uint8_t* brow = bv.base + (size_t)img * bv.img_stride + (size_t)(r.y - 18) * bv.pitch + px0;
+        // blurred: the blocks from (x - 18) >> 2, (y - 18) >> 2 on; poff / oy = where the neighbourhood starts inside the first one
+        L.poff = (r.x - 18) & 3;
+        L.oy = (r.y - 18) & 3;
+        const uint8_t* bbase = bv.base + (size_t)img * bv.img_stride + (size_t)((r.y - 18) >> 2) * ((size_t)bv.pitch * 4) +
+                               (size_t)((r.x - 18) >> 2) * 16;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+            L.bp[t] = *reinterpret_cast<const uint4*>(bbase + (size_t)(__umul24(bbrow[t], (uint32_t)bv.pitch * 4u) + bbcol16[t]));
         // (level 0 may be the caller's own image with any row stride: the 4-byte phase is taken per row)
         // addresses = scalar base + 32-bit lane offset (the global_load saddr form: no 64-bit VALU address math)
         const uint8_t* rrow = lv.base + (size_t)img * lv.img_stride + (size_t)(r.y - 15) * lv.pitch + (r.x - 15) - 4;
@@ -1284,9 +1308,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             L.rsh[t] = (rlow + o) & 3u;
             L.rp[t] = *reinterpret_cast<const u32x4u*>(rrow + (size_t)(o + seg16 + 4u - L.rsh[t]));
         }
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-            L.bp[t] = *reinterpret_cast<const u32x4u*>(brow + (size_t)(__umul24(brow_c[t], (uint32_t)bv.pitch) + seg16));
     };
     const SelRec* recs = sel + (size_t)img * sel_stride;
     SelRec r_cur = scalar_rec(recs[k_first]);
@@ -1340,12 +1361,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         M10[kk] = wave_sum_dpp(m10);  // wave-uniform (SGPR) totals
         M01[kk] = wave_sum_dpp(m01);
         uint8_t* lp = lp0 + kk * kPatchSlot;
+        // block (block row, block column) = rows 4 brow - oy .. + 3 of the patch, dword column bcol of each: kept if 0 <= row < 37
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-            const u32x4u v = L.bp[t];
-            uint8_t* w = lp + brow_c[t] * kPatchPitch + seg16;
-            *reinterpret_cast<uint2*>(w) = make_uint2(v.x, v.y);
-            if (seg != 2) *reinterpret_cast<uint2*>(w + 8) = make_uint2(v.z, v.w);   // a row keeps 40 of its 48 bytes
+            const uint4 v = L.bp[t];
+            const int pr = (int)(4u * bbrow[t]) - L.oy;
+            uint8_t* w = lp + pr * kPatchPitch + (bbcol16[t] >> 2);
+            if ((unsigned)pr < 37u) *reinterpret_cast<uint32_t*>(w) = v.x;
+            if ((unsigned)(pr + 1) < 37u) *reinterpret_cast<uint32_t*>(w + kPatchPitch) = v.y;
+            if ((unsigned)(pr + 2) < 37u) *reinterpret_cast<uint32_t*>(w + 2 * kPatchPitch) = v.z;
+            if ((unsigned)(pr + 3) < 37u) *reinterpret_cast<uint32_t*>(w + 3 * kPatchPitch) = v.w;
         }
     }
     // Phase V
