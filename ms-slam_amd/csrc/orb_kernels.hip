@@ -215,8 +215,21 @@ __global__ __launch_bounds__(64 * WAVES) void pyr_resize_bandreg_kernel(LevelVie
                                                                         const ResizeTap* __restrict__ tx,
                                                                         const ResizeTap* __restrict__ ty) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int dy0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * WAVES + wave) * R);
-    pyr_band_tile_reg<R, kSrc>(src, dst, dst_base, tx, ty, blockIdx.z, blockIdx.x, dy0, lane);
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (private L2 each); give every XCD whole images, so that
+    // the source rows two neighbouring bands share and the 12-byte windows neighbouring lanes re-request are fetched into one
+    // L2 instead of several (batches of a multiple of 8 images; others keep the plain order)
+    unsigned bx = blockIdx.x, by = blockIdx.y, img = blockIdx.z;
+    if ((gridDim.z & 7u) == 0) {
+        const unsigned per_img = gridDim.x * gridDim.y;
+        const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const unsigned xcd = lin & 7u, j = lin >> 3;
+        const unsigned q = j / per_img, rem = j - q * per_img;
+        img = q * 8u + xcd;
+        by = rem / gridDim.x;
+        bx = rem - by * gridDim.x;
+    }
+    const int dy0 = __builtin_amdgcn_readfirstlane((int)(by * WAVES + wave) * R);
+    pyr_band_tile_reg<R, kSrc>(src, dst, dst_base, tx, ty, (int)img, (int)bx, dy0, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
