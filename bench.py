@@ -731,6 +731,7 @@ def main():
             e.set_overlap(1, True)
     outs = [(d_kps, d_desc)] + [(torch.empty_like(d_kps), torch.empty_like(d_desc)) for _ in range(depth - 1)]
     inflight = []
+    refill = [True]   # from a fence until `depth` batches are in flight again
     # Phase between the two batches in flight: started together they stay in lock-step (both finish, and are resubmitted,
     # together: FAST beside FAST, descriptors beside descriptors); half a step apart, one batch's pyramid / FAST (VALU issue)
     # runs beside the other's quadtree (latency) and descriptors (line fills): 1.147 instead of 1.184 ms per step (round 4; a
@@ -743,6 +744,7 @@ def main():
 
     def drain():
         total = 0
+        refill[0] = True
         while inflight:
             counts, _, _, _ = inflight.pop(0).extract_batch_wait()
             total += int(counts.sum())
@@ -762,8 +764,10 @@ def main():
                 done = int(counts.sum())
             exp[k].extract_batch_submit(images, (0, 0), out=outs[k])
             inflight.append(exp[k])
+            if len(inflight) == depth:
+                refill[0] = False
             last_ex[0] = exp[k]
-            if len(inflight) == 1 and stagger[0]:
+            if 0 < len(inflight) < depth and refill[0] and stagger[0]:
                 time.sleep(stagger[0])   # first batch after a fence: hold the second one back (see `stagger` above)
             return done
         b = step_no[0] & 1
@@ -923,7 +927,7 @@ def main():
         step()
     if pipelined and stagger[0] is None:
         fence()
-        stagger[0] = 0.5 * (time.perf_counter() - t_w) / args.warmup if args.warmup >= 2 else 600e-6
+        stagger[0] = (time.perf_counter() - t_w) / args.warmup / depth if args.warmup >= 2 else 1200e-6 / depth
         stagger[0] = min(max(stagger[0], 200e-6), 2e-3)
     # timed region: the production shape (2 sub-batches in flight, blur on a second stream), stage events on
     for e in all_ex:
