@@ -1059,7 +1059,7 @@ int msorb::extract_stereo_sink(msorb_extractor* h, const uint8_t* left, const ui
     msorb_keypoint* const d_kps = reinterpret_cast<msorb_keypoint*>(blk);
     uint8_t* const d_desc = blk + o_desc;
     int counts[2] = {0, 0}, mono[2] = {0, 0};
-    HIPCHK(hipMemsetAsync(blk + o_oob, 0, sizeof(int), s));
+    // (n_oob is zeroed by the row-table kernel of launch_stereo_match_batch)
     h->defer_sync = h->skip_count_copies = true;
     rc = run_pipeline(h, l0, 2, 0, 0, d_kps, d_desc, cap, counts, mono);
     h->defer_sync = h->skip_count_copies = false;
@@ -1233,7 +1233,7 @@ int msorb_extract_stereo_split(msorb_extractor* L, msorb_extractor* R, const uin
     for (int y = 0; y < rows; y++) memcpy(L->h_img_pin.p + (size_t)y * g0.pitch, left + (size_t)y * stride_left, cols);
     hipStream_t s = L->stream;
     HIPCHK(hipMemcpyAsync(L->d_pyr.p + g0.plane_off, L->h_img_pin.p, plane, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(blk + o_oob, 0, sizeof(int), s));
+    // (n_oob is zeroed by the row-table kernel of launch_stereo_match_batch)
     {
         LevelView l0{L->d_pyr.p + g0.plane_off, g.pyramid_bytes, g0.pitch, cols, rows};
         L->defer_sync = L->skip_count_copies = true;

@@ -422,6 +422,7 @@ __global__ __launch_bounds__(T) void stereo_rowtable_kernel(StereoBatchArgs B) {
     int* row_begin = B.row_begin + (size_t)pair * (rows0 + 1);
     int2* row_list = B.row_list + (size_t)pair * B.row_cap;
     for (int r = t; r < rows0; r += T) cnt[r] = 0;
+    if (t == 0 && B.A.n_oob) B.A.n_oob[pair] = 0;   // the association's out-of-bounds counter starts here: no memset launch in front of a frame
     // each right keypoint's row band, computed once: the first kBandCache rounds of the 256-strided loop keep it in
     // registers (all their loads in flight together), later rounds (more than 2048 right keypoints) recompute it
     constexpr int kBandCache = 2048 / T;
