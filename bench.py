@@ -885,7 +885,7 @@ def main():
         n_left = int(counts_h[0::2].sum())
         stereo = {"pairs": int(len(counts_h) // 2), "left_keypoints": n_left, "matched": int((d_ur > 0).sum().item()),
                   "ms_per_batch": round(m, 4), "mkeypoints_per_s": round(n_left / (m * 1e-3) / 1e6, 2),
-                  "kernels": "stereo_match_batch_kernel + stereo_median_kernel"}
+                  "kernels": "stereo_rowtable_kernel + stereo_match_quad_kernel (four left keypoints per wave) + stereo_median_kernel"}
 
     # fourth: BASELINE configs[2] — the front-end of one tracking frame as a device-resident chain (csrc/track.hip): extraction of
     # both eyes + ComputeStereoMatches + AssignFeaturesToGrid + isInFrustum + the window search of SearchByProjection

@@ -513,6 +513,194 @@ __global__ __launch_bounds__(256) void stereo_match_batch_kernel(StereoBatchArgs
     stereo_match_one(B.A, V, iL, threadIdx.x & 63);
 }
 
+// Batches: sixteen lanes per left keypoint, four keypoints per wave.  A keypoint's association is a chain of five dependent
+// memory round trips (keypoint -> row bounds -> row entries -> right descriptors -> window rows) with a handful of
+// instructions between them: at one keypoint per wave the kernel ran at full occupancy and still waited (0.235 ms per 128
+// pairs); four keypoints per wave have four chains in flight for the same wave slot.  Same results as stereo_match_one:
+// the best candidate is the lexicographic minimum of (distance, iR) whatever the order, the SAD / parabola arithmetic is the
+// same.  Lane l of a group: candidates l, l + 16, ... of the row entry; then window row l (11 of 16 lanes) with the 11 offsets
+// as static byte shifts of its own 32-byte strip row — no LDS staging — and a 4-step DPP row reduction of the row SADs
+// (two 16-bit sums per register: a window SAD is < 2^15).
+typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ uint32_t row16_min_u32(uint32_t x) {   // minimum over the 16 lanes of a DPP row, in every lane
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false));
+    return x;
+}
+__device__ __forceinline__ uint32_t row16_sum_u32(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, false);
+    return x;
+}
+// 16 bytes from a 4-byte aligned address without touching anything past `lim` (the address of the plane's last dword): the
+// dwords beyond come out as the clamped dword shifted down (their bytes inside the plane) or zero — never part of a window
+__device__ __forceinline__ void load16_in_plane(uintptr_t a, uintptr_t lim, uint32_t out[4]) {
+    if (a + 12 <= lim) {
+        const u32x4a4 v = *reinterpret_cast<const u32x4a4*>(a);
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else {
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uintptr_t ad = a + 4 * d, b = min(ad, lim);
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(b);
+            const uint32_t back = (uint32_t)(ad - b);
+            out[d] = back == 0 ? v : (back < 4 ? v >> (8 * back) : 0u);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void stereo_match_quad_kernel(StereoBatchArgs B) {
+    const StereoArgs& G = B.A;
+    const int pair = blockIdx.y;
+    const size_t img = (size_t)pair * B.pair_step;
+    const int nL = B.countsL[img];
+    const int l = threadIdx.x & 15, grp_lane0 = (int)(threadIdx.x & 63u) & ~15;
+    const int iL = blockIdx.x * 16 + (int)(threadIdx.x >> 4);
+    if (iL >= nL) return;   // whole groups leave: every DPP row below has all 16 lanes or none
+    const msorb_keypoint* kpLp = G.kpL + img * B.capacity + iL;
+    const uint8_t* descR = G.descR + img * B.capacity * 32;
+    const int* row_begin = B.row_begin + (size_t)pair * (G.rows0 + 1);
+    const int2* row_list = B.row_list + (size_t)pair * B.row_cap;
+    const float uL = kpLp->x, vL = kpLp->y;
+    const int levelL = kpLp->octave;
+    float out_u = -1.0f, out_d = -1.0f;
+    int out_sad = -1;
+    const int row = (int)vL;
+    const float minD = 0.f, maxD = __fdiv_rn(G.mbf, G.mb);
+    const float minU = __fsub_rn(uL, maxD), maxU = __fsub_rn(uL, minD);
+    constexpr uint32_t kNoKey32 = 0xFFFFFFFFu;
+    uint32_t best = kNoKey32;
+    float best_x = 0.f;
+    if (row >= 0 && row < G.rows0 && !(maxU < 0)) {
+        const uint4* dl = reinterpret_cast<const uint4*>(G.descL + (img * B.capacity + iL) * 32);
+        const uint4 a0 = dl[0], a1 = dl[1];
+        const int rb = row_begin[row], n_cand = row_begin[row + 1] - rb;
+        const int2* list = row_list + rb;
+        for (int base = 0; base < n_cand; base += 64) {   // four entries per lane and round, their loads issued together
+            int2 e[4];
+            bool pass[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = base + 16 * k + l;
+                pass[k] = j < n_cand;
+                e[k] = list[pass[k] ? j : 0];
+            }
+            uint4 d0[4], d1[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int octR = (int)((uint32_t)e[k].x >> 24);
+                const float xR = __int_as_float(e[k].y);
+                pass[k] = pass[k] && !(octR < levelL - 1 || octR > levelL + 1) && (xR >= minU && xR <= maxU);
+                const uint4* dr = reinterpret_cast<const uint4*>(descR + (size_t)(e[k].x & 0xffffff) * 32);
+                if (pass[k]) { d0[k] = dr[0]; d1[k] = dr[1]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (!pass[k]) continue;
+                const int d = __popc(a0.x ^ d0[k].x) + __popc(a0.y ^ d0[k].y) + __popc(a0.z ^ d0[k].z) + __popc(a0.w ^ d0[k].w) +
+                              __popc(a1.x ^ d1[k].x) + __popc(a1.y ^ d1[k].y) + __popc(a1.z ^ d1[k].z) + __popc(a1.w ^ d1[k].w);
+                const uint32_t key = ((uint32_t)d << 22) | (uint32_t)(e[k].x & 0xffffff);
+                if (key < best) { best = key; best_x = __int_as_float(e[k].y); }
+            }
+        }
+    }
+    const uint32_t mine = best;
+    best = row16_min_u32(best);
+    const int bestDist = best == kNoKey32 ? 256 : (int)(best >> 22);
+    if (bestDist < kThHigh && bestDist < (kThHigh + kThLow) / 2) {
+        // x of the winner from the lane of the group that holds it (keys are unique)
+        const unsigned long long owner = __ballot(mine == best) >> grp_lane0;
+        const int src = grp_lane0 + (int)__builtin_ctz((uint32_t)owner & 0xffffu);
+        const float uR0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(best_x)));
+        const float sf = G.inv_scale[levelL];
+        const float scaleduL = roundf(__fmul_rn(uL, sf));
+        const float scaledvL = roundf(__fmul_rn(vL, sf));
+        const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
+        const int w = 5, L = 5;
+        const int cols = G.cols[levelL], rows = G.rows[levelL];
+        const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+        const int y0 = (int)(scaledvL - w), xL0 = (int)(scaleduL - w), xR0 = (int)(scaleduR0 - L - w);
+        const bool ok = !(iniu < 0 || endu >= cols) && y0 >= 0 && y0 + 2 * w + 1 <= rows && xL0 >= 0 &&
+                        xL0 + 2 * w + 1 <= cols && xR0 >= 0 && (int)(scaleduR0 + L + w + 1) <= cols;
+        if (ok) {
+            const int pitchL = G.pitchL[levelL], pitchR = G.pitchR[levelL];
+            const uint8_t* planeL = G.pyrL[levelL] + img * B.img_strideL[levelL];
+            const uint8_t* planeR = G.pyrR[levelL] + img * B.img_strideR[levelL];
+            const uintptr_t limL = reinterpret_cast<uintptr_t>(planeL) + (size_t)rows * pitchL - 4;
+            const uintptr_t limR = reinterpret_cast<uintptr_t>(planeR) + (size_t)rows * pitchR - 4;
+            const int wr = min(l, 10);   // lanes 11..15 repeat row 10 and count for nothing
+            const uintptr_t pl = reinterpret_cast<uintptr_t>(planeL + (size_t)(y0 + wr) * pitchL + xL0);
+            const uintptr_t pr = reinterpret_cast<uintptr_t>(planeR + (size_t)(y0 + wr) * pitchR + xR0);
+            const uint32_t phL = (uint32_t)(pl & 3), phR = (uint32_t)(pr & 3);
+            uint32_t lw[4], rw[8];
+            load16_in_plane(pl - phL, limL, lw);
+            load16_in_plane(pr - phR, limR, rw);
+            load16_in_plane(pr - phR + 16, limR, rw + 4);
+            // byte 0 of the normalised rows = first pixel of the window row / strip row
+            const uint32_t l0 = __builtin_amdgcn_alignbyte(lw[1], lw[0], phL), l1 = __builtin_amdgcn_alignbyte(lw[2], lw[1], phL);
+            const uint32_t l2 = __builtin_amdgcn_alignbyte(lw[3], lw[2], phL) & 0x00ffffffu;   // 11 bytes = 4 + 4 + 3
+            uint32_t rn[7];
+#pragma unroll
+            for (int d = 0; d < 7; d++) rn[d] = __builtin_amdgcn_alignbyte(rw[d + 1], rw[d], phR);   // 28 bytes >= 21
+            uint32_t rs[11];
+#pragma unroll
+            for (int inc = 0; inc < 11; inc++) {
+                const int d0 = inc >> 2, sh = inc & 3;
+                const uint32_t r0 = __builtin_amdgcn_alignbyte(rn[d0 + 1], rn[d0], sh);
+                const uint32_t r1 = __builtin_amdgcn_alignbyte(rn[d0 + 2], rn[d0 + 1], sh);
+                const uint32_t r2 = __builtin_amdgcn_alignbyte(d0 + 3 < 7 ? rn[d0 + 3] : 0u, rn[d0 + 2], sh) & 0x00ffffffu;
+                uint32_t sv = __builtin_amdgcn_sad_u8(l0, r0, 0u);
+                sv = __builtin_amdgcn_sad_u8(l1, r1, sv);
+                sv = __builtin_amdgcn_sad_u8(l2, r2, sv);
+                rs[inc] = l < 11 ? sv : 0u;
+            }
+            int sad[11];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const uint32_t t = row16_sum_u32(rs[2 * k] | (rs[2 * k + 1] << 16));
+                sad[2 * k] = (int)(t & 0xffffu); sad[2 * k + 1] = (int)(t >> 16);
+            }
+            sad[10] = (int)row16_sum_u32(rs[10]);
+            int bestS = 0x7fffffff, bestinc = 0;
+#pragma unroll
+            for (int inc = 0; inc < 11; inc++)
+                if (sad[inc] < bestS) { bestS = sad[inc]; bestinc = inc - L; }
+            if (!(bestinc == -L || bestinc == L)) {
+                float d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+                for (int inc = 1; inc < 10; inc++)
+                    if (inc == bestinc + L) { d1 = (float)sad[inc - 1]; d2 = (float)sad[inc]; d3 = (float)sad[inc + 1]; }
+                const float deltaR = __fdiv_rn(__fsub_rn(d1, d3),
+                                               __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
+                if (!(deltaR < -1 || deltaR > 1)) {
+                    float bestuR = __fmul_rn(G.scale[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
+                    float disparity = __fsub_rn(uL, bestuR);
+                    if (disparity >= minD && disparity < maxD) {
+                        if (disparity <= 0) {
+                            disparity = (float)0.01;
+                            bestuR = (float)((double)uL - 0.01);
+                        }
+                        out_d = __fdiv_rn(G.mbf, disparity);
+                        out_u = bestuR;
+                        out_sad = bestS;
+                    }
+                }
+            }
+        } else if (l == 0 && !(iniu < 0 || endu >= cols)) {
+            atomicAdd(G.n_oob + pair, 1);
+        }
+    }
+    if (l == 0) {
+        const size_t o = (size_t)pair * B.capacity + iL;
+        G.u_right[o] = out_u;
+        G.depth[o] = out_d;
+        G.sad[o] = out_sad;
+    }
+}
+
 // Frame.cc:899-912 for one pair per workgroup: median = vDistIdx[size/2].first of the ascending (SAD, iL) list — the
 // value of rank size/2 — found by a two-level histogram select (SAD <= 121*255 < 2^15); every match whose SAD is not
 // below thDist = 1.5f*1.4f*median is withdrawn (the reference walks the sorted list from the end and stops at the first
@@ -675,7 +863,9 @@ void launch_stereo_match_batch(const StereoBatchArgs& b, int n_pairs, int max_le
     if (n_pairs <= 0 || max_left <= 0) return;
     if (n_pairs <= 4) hipLaunchKernelGGL(stereo_rowtable_kernel<1024>, dim3(n_pairs), dim3(1024), (size_t)(2 * b.A.rows0 + 1) * sizeof(int), s, b);
     else hipLaunchKernelGGL(stereo_rowtable_kernel<256>, dim3(n_pairs), dim3(256), (size_t)(2 * b.A.rows0 + 1) * sizeof(int), s, b);
-    hipLaunchKernelGGL(stereo_match_batch_kernel, dim3((max_left + 3) / 4, n_pairs), dim3(256), 0, s, b);
+    // batches whose row table exists: four keypoints per wave (stereo_match_quad_kernel); frames: one per wave, every wave slot used
+    if (n_pairs > 4 && b.row_begin) hipLaunchKernelGGL(stereo_match_quad_kernel, dim3((max_left + 15) / 16, n_pairs), dim3(256), 0, s, b);
+    else hipLaunchKernelGGL(stereo_match_batch_kernel, dim3((max_left + 3) / 4, n_pairs), dim3(256), 0, s, b);
     hipLaunchKernelGGL(stereo_median_kernel, dim3(n_pairs), dim3(256), 0, s, b.countsL, b.countsR, b.pair_step, b.capacity, b.A.sad, b.A.u_right,
                        b.A.depth, b.counts_out);
 }
