@@ -141,9 +141,39 @@ __device__ int block_excl_last(int v, int* wtot) {
     return prev;
 }
 
+// Ascending bitonic sort of P keys in LDS (P a power of two >= 128, all kAsmThreads threads call it, keys complete and a barrier
+// passed before the call; ends with a barrier).  Comparators whose partners lie within 128 consecutive keys (j <= 64) run on
+// registers — a wave holds a chunk as two keys per lane, partners by __shfl_xor — so only the j >= 128 steps of each merge are
+// LDS passes with a workgroup barrier: 15 barriers for 2048 keys instead of 66.
+__device__ __forceinline__ void bitonic_chunk_steps(unsigned long long& a, unsigned long long& b, int i0, int k, int j_first) {
+    const int lane = threadIdx.x & 63;
+    for (int j = j_first; j > 0; j >>= 1) {
+        if (j == 64) {   // partner = the lane's other key (index i0 + 64)
+            const bool up = (i0 & k) == 0;
+            if ((a > b) == up) { const unsigned long long t = a; a = b; b = t; }
+        } else {
+            const unsigned long long pa = __shfl_xor(a, j, 64), pb = __shfl_xor(b, j, 64);
+            const bool lower = (lane & j) == 0;
+            const bool keep_min_a = lower == ((i0 & k) == 0), keep_min_b = lower == (((i0 + 64) & k) == 0);
+            a = keep_min_a ? (a < pa ? a : pa) : (a > pa ? a : pa);
+            b = keep_min_b ? (b < pb ? b : pb) : (b > pb ? b : pb);
+        }
+    }
+}
 __device__ void bitonic_sort(unsigned long long* keys, int P) {
-    for (int k = 2; k <= P; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int kWaves = kAsmThreads / 64;
+    const int n_chunks = P >> 7;
+    // merges up to 128 keys: entirely inside a chunk
+    for (int c = wave; c < n_chunks; c += kWaves) {
+        const int i0 = (c << 7) + lane;
+        unsigned long long a = keys[i0], b = keys[i0 + 64];
+        for (int k = 2; k <= 128; k <<= 1) bitonic_chunk_steps(a, b, i0, k, k >> 1);
+        keys[i0] = a; keys[i0 + 64] = b;
+    }
+    __syncthreads();
+    for (int k = 256; k <= P; k <<= 1) {
+        for (int j = k >> 1; j >= 128; j >>= 1) {
             for (int t = threadIdx.x; t < P / 2; t += kAsmThreads) {
                 const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // index with bit j clear
                 const int ixj = i | j;
@@ -153,6 +183,14 @@ __device__ void bitonic_sort(unsigned long long* keys, int P) {
             }
             __syncthreads();
         }
+        for (int c = wave; c < n_chunks; c += kWaves) {
+            const int i0 = (c << 7) + lane;
+            unsigned long long a = keys[i0], b = keys[i0 + 64];
+            bitonic_chunk_steps(a, b, i0, k, 64);
+            keys[i0] = a; keys[i0 + 64] = b;
+        }
+        __syncthreads();
+    }
 }
 
 constexpr int kPerMax = kMaxBowFeatures / kAsmThreads;  // slots per thread at the largest P
@@ -319,6 +357,16 @@ struct msorb_vocabulary {
     DevBuf<uint8_t> d_desc;
     DevBuf<int> d_out_i;
     DevBuf<double> d_out_d;
+    uint8_t* h_pin = nullptr;   // pinned staging of the single-frame call: descriptors in, every output out, one synchronisation
+    size_t h_pin_cap = 0;
+    hipError_t ensure_pin(size_t n) {
+        if (n <= h_pin_cap) return hipSuccess;
+        if (h_pin) (void)hipHostFree(h_pin);
+        h_pin = nullptr; h_pin_cap = 0;
+        const hipError_t e = hipHostMalloc((void**)&h_pin, n, hipHostMallocDefault);
+        if (e == hipSuccess) h_pin_cap = n;
+        return e;
+    }
 };
 
 extern "C" {
@@ -448,6 +496,7 @@ void msorb_vocabulary_destroy(msorb_vocabulary* v) {
     if (v->d_cweight) (void)hipFree(v->d_cweight);
     v->d_counts.release(); v->d_feat_word.release(); v->d_feat_node.release(); v->d_feat_weight.release();
     v->d_desc.release(); v->d_out_i.release(); v->d_out_d.release();
+    if (v->h_pin) (void)hipHostFree(v->h_pin);
     if (v->e0) (void)hipEventDestroy(v->e0);
     if (v->e1) (void)hipEventDestroy(v->e1);
     if (v->s) (void)hipStreamDestroy(v->s);
@@ -463,10 +512,23 @@ int msorb_vocabulary_info(const msorb_vocabulary* v, int* k, int* L, int* n_node
     return MSORB_OK;
 }
 
+static int bow_transform_enqueue(msorb_vocabulary* v, const uint8_t* d_descriptors, const int* h_counts, int n_frames,
+                                 int desc_stride, int levelsup, int stride, int* d_bow_word, double* d_bow_value,
+                                 int* d_n_bow, int* d_fv_node, int* d_fv_begin, int* d_fv_feat, int* d_n_fv,
+                                 float* elapsed_ms, bool synchronise, int* d_fw = nullptr, int* d_fn = nullptr, double* d_fwt = nullptr);
 int msorb_bow_transform_batch(msorb_vocabulary* v, const uint8_t* d_descriptors, const int* h_counts, int n_frames,
                               int desc_stride, int levelsup, int stride, int* d_bow_word, double* d_bow_value,
                               int* d_n_bow, int* d_fv_node, int* d_fv_begin, int* d_fv_feat, int* d_n_fv,
                               float* elapsed_ms) {
+    return bow_transform_enqueue(v, d_descriptors, h_counts, n_frames, desc_stride, levelsup, stride, d_bow_word, d_bow_value, d_n_bow,
+                                 d_fv_node, d_fv_begin, d_fv_feat, d_n_fv, elapsed_ms, true);
+}
+// synchronise = false: everything is enqueued on the vocabulary's stream, the caller appends its copies and waits once;
+// d_fw / d_fn / d_fwt: where the per-feature word, node and weight go (default: the handle's scratch)
+static int bow_transform_enqueue(msorb_vocabulary* v, const uint8_t* d_descriptors, const int* h_counts, int n_frames,
+                                 int desc_stride, int levelsup, int stride, int* d_bow_word, double* d_bow_value,
+                                 int* d_n_bow, int* d_fv_node, int* d_fv_begin, int* d_fv_feat, int* d_n_fv,
+                                 float* elapsed_ms, bool synchronise, int* d_fw, int* d_fn, double* d_fwt) {
     if (elapsed_ms) *elapsed_ms = 0;
     if (!v || n_frames < 0 || stride < 1 || stride > kMaxBowFeatures || desc_stride < 0 ||
         (n_frames > 0 && (!h_counts || !d_bow_word || !d_bow_value || !d_n_bow || !d_fv_node || !d_fv_begin ||
@@ -492,14 +554,17 @@ int msorb_bow_transform_batch(msorb_vocabulary* v, const uint8_t* d_descriptors,
         HIPCHK(hipMemsetAsync(d_n_bow, 0, (size_t)n_frames * sizeof(int), s));
         HIPCHK(hipMemsetAsync(d_n_fv, 0, (size_t)n_frames * sizeof(int), s));
         HIPCHK(hipMemset2DAsync(d_fv_begin, (size_t)(stride + 1) * sizeof(int), 0, sizeof(int), n_frames, s));
-        HIPCHK(hipStreamSynchronize(s));
+        if (synchronise) HIPCHK(hipStreamSynchronize(s));
         return MSORB_OK;
     }
     const size_t total = (size_t)n_frames * stride;
     HIPCHK(v->d_counts.ensure(n_frames));
-    HIPCHK(v->d_feat_word.ensure(total));
-    HIPCHK(v->d_feat_node.ensure(total));
-    HIPCHK(v->d_feat_weight.ensure(total));
+    if (!d_fw) {
+        HIPCHK(v->d_feat_word.ensure(total));
+        HIPCHK(v->d_feat_node.ensure(total));
+        HIPCHK(v->d_feat_weight.ensure(total));
+        d_fw = v->d_feat_word.p; d_fn = v->d_feat_node.p; d_fwt = v->d_feat_weight.p;
+    }
     HIPCHK(hipMemcpyAsync(v->d_counts.p, h_counts, (size_t)n_frames * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(v->e0, s));
     const int lpf = v->max_children <= 16 ? 16 : 32;
@@ -510,11 +575,11 @@ int msorb_bow_transform_batch(msorb_vocabulary* v, const uint8_t* d_descriptors,
     if (lpf == 16)
         hipLaunchKernelGGL(bow_descend_kernel<16>, dim3((unsigned)blocks), dim3(threads), 0, s, d_descriptors,
                            v->d_counts.p, n_frames, max_count, desc_stride, stride, v->d_cdesc, v->d_cinfo, v->d_cweight,
-                           v->root_count, nid_level, v->d_feat_word.p, v->d_feat_node.p, v->d_feat_weight.p);
+                           v->root_count, nid_level, d_fw, d_fn, d_fwt);
     else
         hipLaunchKernelGGL(bow_descend_kernel<32>, dim3((unsigned)blocks), dim3(threads), 0, s, d_descriptors,
                            v->d_counts.p, n_frames, max_count, desc_stride, stride, v->d_cdesc, v->d_cinfo, v->d_cweight,
-                           v->root_count, nid_level, v->d_feat_word.p, v->d_feat_node.p, v->d_feat_weight.p);
+                           v->root_count, nid_level, d_fw, d_fn, d_fwt);
     int P = kAsmThreads;  // >= one slot per thread keeps the chunk arithmetic simple
     while (P < max_count) P <<= 1;
     const size_t lds = (size_t)P * 8 + (size_t)(P + 1) * 4;
@@ -522,9 +587,10 @@ int msorb_bow_transform_batch(msorb_vocabulary* v, const uint8_t* d_descriptors,
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(bow_assemble_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBowFeatures * 12 + 4));
     hipLaunchKernelGGL(bow_assemble_kernel, dim3(n_frames), dim3(kAsmThreads), lds, s, v->d_counts.p, stride, P, tf_mode,
-                       must, l2, v->d_feat_word.p, v->d_feat_node.p, v->d_feat_weight.p, d_bow_word, d_bow_value, d_n_bow,
+                       must, l2, d_fw, d_fn, d_fwt, d_bow_word, d_bow_value, d_n_bow,
                        d_fv_node, d_fv_begin, d_fv_feat, d_n_fv);
     HIPCHK(hipEventRecord(v->e1, s));
+    if (!synchronise) return MSORB_OK;
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     if (elapsed_ms) HIPCHK(hipEventElapsedTime(elapsed_ms, v->e0, v->e1));
@@ -546,36 +612,49 @@ int msorb_bow_transform(msorb_vocabulary* v, const uint8_t* descriptors, int n, 
     const int stride = n;
     std::lock_guard<std::recursive_mutex> lock(v->mu);
     HIPCHK(hipSetDevice(v->device));
-    HIPCHK(v->d_desc.ensure((size_t)n * 32));
-    HIPCHK(v->d_out_i.ensure((size_t)4 * stride + 3));
-    HIPCHK(v->d_out_d.ensure(stride));
-    int* d_i = v->d_out_i.p;
-    double* d_d = v->d_out_d.p;
-    uint8_t* d_desc = v->d_desc.p;
-    HIPCHK(hipMemcpy(d_desc, descriptors, (size_t)n * 32, hipMemcpyHostToDevice));
+    // one device block and its pinned twin: [descriptors in][ints out 4 stride + 3][bow values][feat_word][feat_node][feat_weight]:
+    // one copy in, the kernels, one copy out, one synchronisation
+    const size_t n_int = (size_t)4 * stride + 3;
+    const size_t o_int = ((size_t)n * 32 + 15) & ~(size_t)15, o_val = (o_int + n_int * sizeof(int) + 7) & ~(size_t)7,
+                 o_fw = o_val + (size_t)stride * sizeof(double), o_fn = o_fw + (size_t)n * sizeof(int),
+                 o_fwt = (o_fn + (size_t)n * sizeof(int) + 7) & ~(size_t)7, blk_bytes = o_fwt + (size_t)n * sizeof(double);
+    HIPCHK(v->d_desc.ensure(blk_bytes));
+    HIPCHK(v->ensure_pin(blk_bytes));
+    uint8_t* const db = v->d_desc.p;
+    uint8_t* const hp = v->h_pin;
+    int* d_i = reinterpret_cast<int*>(db + o_int);
+    double* d_d = reinterpret_cast<double*>(db + o_val);
+    hipStream_t s = v->s;
+    std::memcpy(hp, descriptors, (size_t)n * 32);
+    HIPCHK(hipMemcpyAsync(db, hp, (size_t)n * 32, hipMemcpyHostToDevice, s));
     int* d_bow_word = d_i;
     int* d_fv_node = d_i + stride;
     int* d_fv_feat = d_i + 2 * stride;
     int* d_fv_begin = d_i + 3 * stride;       // stride + 1
     int* d_nb = d_i + 4 * stride + 1;
     int* d_nf = d_i + 4 * stride + 2;
-    const int rc = msorb_bow_transform_batch(v, d_desc, &n, 1, n, levelsup, stride, d_bow_word, d_d, d_nb, d_fv_node,
-                                             d_fv_begin, d_fv_feat, d_nf, nullptr);
+    const int rc = bow_transform_enqueue(v, db, &n, 1, n, levelsup, stride, d_bow_word, d_d, d_nb, d_fv_node, d_fv_begin, d_fv_feat, d_nf,
+                                         nullptr, false, reinterpret_cast<int*>(db + o_fw), reinterpret_cast<int*>(db + o_fn),
+                                         reinterpret_cast<double*>(db + o_fwt));
     if (rc) return rc;
-    std::vector<int> hi((size_t)4 * stride + 3);
-    HIPCHK(hipMemcpy(hi.data(), d_i, hi.size() * sizeof(int), hipMemcpyDeviceToHost));
+    const bool feats = v->n_words > 0;
+    const bool want_feats = feats && (feat_word || feat_node || feat_weight);
+    HIPCHK(hipMemcpyAsync(hp + o_int, db + o_int, (want_feats ? blk_bytes : o_fw) - o_int, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    const int* hi = reinterpret_cast<const int*>(hp + o_int);
     const int nb = hi[4 * stride + 1], nf = hi[4 * stride + 2];
     *n_bow = nb;
     *n_fv = nf;
-    std::memcpy(bow_word, hi.data(), (size_t)nb * sizeof(int));
-    std::memcpy(fv_node, hi.data() + stride, (size_t)nf * sizeof(int));
-    std::memcpy(fv_begin, hi.data() + 3 * stride, (size_t)(nf + 1) * sizeof(int));
-    std::memcpy(fv_feat, hi.data() + 2 * stride, (size_t)hi[3 * stride + nf] * sizeof(int));
-    if (nb) HIPCHK(hipMemcpy(bow_value, d_d, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost));
-    if (v->n_words > 0) {
-        if (feat_word) HIPCHK(hipMemcpy(feat_word, v->d_feat_word.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-        if (feat_node) HIPCHK(hipMemcpy(feat_node, v->d_feat_node.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-        if (feat_weight) HIPCHK(hipMemcpy(feat_weight, v->d_feat_weight.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    std::memcpy(bow_word, hi, (size_t)nb * sizeof(int));
+    std::memcpy(fv_node, hi + stride, (size_t)nf * sizeof(int));
+    std::memcpy(fv_begin, hi + 3 * stride, (size_t)(nf + 1) * sizeof(int));
+    std::memcpy(fv_feat, hi + 2 * stride, (size_t)hi[3 * stride + nf] * sizeof(int));
+    if (nb) std::memcpy(bow_value, hp + o_val, (size_t)nb * sizeof(double));
+    if (feats) {
+        if (feat_word) std::memcpy(feat_word, hp + o_fw, (size_t)n * sizeof(int));
+        if (feat_node) std::memcpy(feat_node, hp + o_fn, (size_t)n * sizeof(int));
+        if (feat_weight) std::memcpy(feat_weight, hp + o_fwt, (size_t)n * sizeof(double));
     }
     return MSORB_OK;
 }
