@@ -1310,7 +1310,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                                (size_t)((r.x - 18) >> 2) * 16;
 #pragma unroll
         for (int t = 0; t < 2; t++)
-            L.bp[t] = *reinterpret_cast<const uint4*>(bbase + (size_t)(__umul24(bbrow[t], (uint32_t)bv.pitch * 4u) + bbcol16[t]));
+            // (only the lanes that own a block ask for one: the texture addresser spends a cycle per lane address, needed or not)
+            if (t == 0 || lane < 100 - 64)
+                L.bp[t] = *reinterpret_cast<const uint4*>(bbase + (size_t)(__umul24(bbrow[t], (uint32_t)bv.pitch * 4u) + bbcol16[t]));
         // (level 0 may be the caller's own image with any row stride: the 4-byte phase is taken per row)
         // addresses = scalar base + 32-bit lane offset (the global_load saddr form: no 64-bit VALU address math)
         const uint8_t* rrow = lv.base + (size_t)img * lv.img_stride + (size_t)(r.y - 15) * lv.pitch + (r.x - 15) - 4;
@@ -1319,7 +1321,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         for (int t = 0; t < 2; t++) {
             const uint32_t o = __umul24(rrow_c[t], (uint32_t)lv.pitch);  // full-rate 24-bit multiply
             L.rsh[t] = (rlow + o) & 3u;
-            L.rp[t] = *reinterpret_cast<const u32x4u*>(rrow + (size_t)(o + seg16 + 4u - L.rsh[t]));
+            if (t == 0 ? lane < 63 : lane < 3 * (31 - 21))   // rows 0..20 / 21..30, three lanes each
+                L.rp[t] = *reinterpret_cast<const u32x4u*>(rrow + (size_t)(o + seg16 + 4u - L.rsh[t]));
         }
     };
     const SelRec* recs = sel + (size_t)img * sel_stride;
@@ -1378,7 +1381,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             const uint4 v = L.bp[t];
-            const int pr = (int)(4u * bbrow[t]) - L.oy;
+            const int pr = (t == 0 || lane < 100 - 64) ? (int)(4u * bbrow[t]) - L.oy : 64;   // lanes without a block write nothing
             uint8_t* w = lp + pr * kPatchPitch + (bbcol16[t] >> 2);
             if ((unsigned)pr < 37u) *reinterpret_cast<uint32_t*>(w) = v.x;
             if ((unsigned)(pr + 1) < 37u) *reinterpret_cast<uint32_t*>(w + kPatchPitch) = v.y;
