@@ -39,6 +39,26 @@ typedef struct msorb_keypoint {
 const char* msorb_last_error(void);
 int msorb_device_count(void);
 
+/* ABI version of the library that was loaded: MSORB_ABI_VERSION of the header it was BUILT from.  major * 1000 + minor; a new
+ * minor only appends entry points (or appends `_ex` forms with more parameters), a new major changes or removes one.  The host
+ * classes (host/ORBextractor.cc, host/ORBmatcher_device.h) and the Python mirror compare msorb_abi_version() with the header
+ * they were compiled against and refuse a library with another major or an older minor (msorb_abi_compatible). */
+#define MSORB_ABI_VERSION 5000
+int msorb_abi_version(void);
+/* 1 if a caller compiled against `header_version` may use this library (same major, library minor >= header minor). */
+int msorb_abi_compatible(int header_version);
+
+/* Process-wide fatal-error callback of the host layer.  The reference's ORBextractor / ORBmatcher cannot fail and their callers
+ * (Tracking.cc, LocalMapping.cc, LoopClosing.cc) have no handler around them, so the drop-in classes end the process on a lost
+ * GPU the way the reference ends it on its own fatal conditions (message + exit(-1), System.cc:117-120).  An embedding
+ * application registers a callback to get control FIRST (flush the map / atlas, log, raise its own flag): the host classes call
+ * msorb_notify_fatal(code, what) before their default action (MSORB_THROW=1: throw std::runtime_error, else message + exit(-1));
+ * the callback may itself not return (exit, longjmp, throw through C++ frames).  fn == NULL unregisters.  Thread safe; the
+ * callback runs on the thread that hit the error.  The C entry points themselves never call it: they return MSORB_E_*. */
+typedef void (*msorb_fatal_fn)(int code, const char* what, void* user);
+void msorb_set_fatal_callback(msorb_fatal_fn fn, void* user);
+void msorb_notify_fatal(int code, const char* what);
+
 /* ------------------------------------------------------------------------------------------------
  * Extractor — replaces ORB_SLAM3::ORBextractor (include/ORBextractor.h:43-109, src/ORBextractor.cc)
  * ---------------------------------------------------------------------------------------------- */
@@ -348,10 +368,26 @@ int msorb_hamming_top2(int device, const uint8_t* query_desc, int n_queries, con
  * receives the total.  max_train <= 2048. */
 #define MSORB_DENSE_MATRIX_CORES 0
 #define MSORB_DENSE_POPCOUNT 1
+int msorb_hamming_dense_top2_batch_ex(int device, const uint8_t* d_query, const uint8_t* d_train, const int* d_n_query,
+                                      const int* d_n_train, int n_frames, int query_stride, int train_stride, int max_query,
+                                      int max_train, int* d_best_idx, int* d_best_dist, int* d_second_dist, int repeats,
+                                      float* elapsed_ms, int formulation);
+/* The entry as rounds 1-3 shipped it (no formulation argument; it runs MSORB_DENSE_MATRIX_CORES, that entry's default then):
+ * kept with its original parameter list so that a caller built against the older header keeps working — ABI 5000 appends
+ * `_ex` instead of changing it. */
 int msorb_hamming_dense_top2_batch(int device, const uint8_t* d_query, const uint8_t* d_train, const int* d_n_query,
                                    const int* d_n_train, int n_frames, int query_stride, int train_stride, int max_query,
                                    int max_train, int* d_best_idx, int* d_best_dist, int* d_second_dist, int repeats,
-                                   int formulation, float* elapsed_ms);
+                                   float* elapsed_ms);
+
+/* cv::BFMatcher(cv::NORM_HAMMING).knnMatch(query, train, matches, 2) — the brute-force step of
+ * Frame::ComputeStereoFishEyeMatches (Frame.cc:1057-1076: left vs right descriptors of the lapping area) — on HOST arrays of
+ * 32-byte rows: best_idx / best_dist = matches[i][0] (trainIdx, distance), second_dist (and second_idx, may be NULL) =
+ * matches[i][1]; ties go to the lower train index.  -1 / 256 where the train set has fewer than one / two rows.  The Lowe
+ * ratio test and KannalaBrandt8::TriangulateMatches of :1082-1098 stay with the caller (host mirror:
+ * msorb_host::ComputeStereoFishEyeMatches).  Runs the popcount formulation of the dense kernel. */
+int msorb_knn_match2(int device, const uint8_t* query, int n_query, const uint8_t* train, int n_train, int* best_idx,
+                     int* best_dist, int* second_idx, int* second_dist);
 
 /* Frame::ComputeStereoMatches (Frame.cc:743-913).  left/right are the two extractor handles whose last
  * msorb_extract() call produced the images' pyramids (mpORBextractorLeft/Right->mvImagePyramid stay on
@@ -677,6 +713,8 @@ typedef struct msorb_motion_model {
  * the handle until the next msorb_frame_set_last_points.  May be called before the frame itself is set. */
 int msorb_frame_set_last_points(msorb_frame* cur, int n, const uint8_t* has_point, const float* pos_w, const int* octave,
                                 const float* angle, const uint8_t* mp_desc);
+/* n of the table resident on the handle (the length the proj_* arrays of msorb_search_last_frame need); -1: no table set. */
+int msorb_frame_last_points_count(const msorb_frame* cur);
 
 /* The search against the resident table: per point x3Dc = Tcw * x3Dw (Sophus' quaternion action, so3.hpp:358-367, in the
  * float convention stated in DESIGN.md), invzc < 0 / image-bounds rejections (:1973-1983), radius = th * mvScaleFactors[octave],

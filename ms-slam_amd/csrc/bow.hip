@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/msorb.h"
+#include "lds_limit.h"
 
 namespace msorb {
 void set_last_error(const std::string& s);
@@ -584,8 +585,10 @@ static int bow_transform_enqueue(msorb_vocabulary* v, const uint8_t* d_descripto
     while (P < max_count) P <<= 1;
     const size_t lds = (size_t)P * 8 + (size_t)(P + 1) * 4;
     const int must = v->scoring != 5, l2 = v->scoring == 1, tf_mode = v->weighting == 0 || v->weighting == 1;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(bow_assemble_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBowFeatures * 12 + 4));
+    if ((long long)lds > msorb::dynamic_lds_room(reinterpret_cast<const void*>(bow_assemble_kernel))) {   // raised once per device, never lowered
+        set_last_error("bow_assemble: the device refuses " + std::to_string(lds) + " bytes of LDS per workgroup");
+        return MSORB_E_HIP;
+    }
     hipLaunchKernelGGL(bow_assemble_kernel, dim3(n_frames), dim3(kAsmThreads), lds, s, v->d_counts.p, stride, P, tf_mode,
                        must, l2, d_fw, d_fn, d_fwt, d_bow_word, d_bow_value, d_n_bow,
                        d_fv_node, d_fv_begin, d_fv_feat, d_n_fv);

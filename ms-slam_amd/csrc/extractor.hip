@@ -712,6 +712,32 @@ extern "C" {
 
 const char* msorb_last_error(void) { return g_last_error.c_str(); }
 
+int msorb_abi_version(void) { return MSORB_ABI_VERSION; }
+int msorb_abi_compatible(int header_version) {
+    return header_version / 1000 == MSORB_ABI_VERSION / 1000 && header_version % 1000 <= MSORB_ABI_VERSION % 1000;
+}
+
+namespace {
+std::mutex g_fatal_mutex;
+msorb_fatal_fn g_fatal_fn = nullptr;
+void* g_fatal_user = nullptr;
+}  // namespace
+void msorb_set_fatal_callback(msorb_fatal_fn fn, void* user) {
+    std::lock_guard<std::mutex> lk(g_fatal_mutex);
+    g_fatal_fn = fn;
+    g_fatal_user = user;
+}
+void msorb_notify_fatal(int code, const char* what) {
+    msorb_fatal_fn fn;
+    void* user;
+    {
+        std::lock_guard<std::mutex> lk(g_fatal_mutex);   // not held across the call: the callback may not return
+        fn = g_fatal_fn;
+        user = g_fatal_user;
+    }
+    if (fn) fn(code, what ? what : "", user);
+}
+
 int msorb_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1374,7 +1400,7 @@ int msorb_debug_candidates(msorb_extractor* h, int image, int level, int* xyscor
     if (!h || !n || !h->geom_valid || image < 0 || image >= h->last_n_images || level < 0 || level >= h->G.nlevels)
         return MSORB_E_INVALID;
     const int nl = h->G.nlevels;
-    if (h->last_groups != 1) { set_error("candidate inspection needs a single sub-batch (n_images < 16 or MSORB_GROUPS=1)"); return MSORB_E_INVALID; }
+    if (h->last_groups != 1) { set_error("candidate inspection needs a single sub-batch (n_images < 16, or msorb_extractor_set_overlap(h, 1, ...) before the call)"); return MSORB_E_INVALID; }
     if (!h->compact_on_host) {
         HIPCHK(hipSetDevice(h->device));
         int rc;

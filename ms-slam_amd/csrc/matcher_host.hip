@@ -636,10 +636,107 @@ int msorb_hamming_top2(int device, const uint8_t* qdesc, int nq, const uint8_t* 
     return MSORB_OK;
 }
 
+// cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, matches, 2) as Frame::ComputeStereoFishEyeMatches uses it (Frame.cc:1076)
+// on host arrays: per query the nearest and the second nearest train row (ties -> lower train index, the order batchDistance
+// keeps).  The dense top-2 kernel holds 2048 train rows per launch; longer train sets go chunk by chunk and the per-chunk pairs
+// are merged lexicographically (distance, index) on the host.
+int msorb_knn_match2(int device, const uint8_t* query, int n_query, const uint8_t* train, int n_train, int* best_idx, int* best_dist,
+                     int* second_idx, int* second_dist) {
+    if (n_query < 0 || n_train < 0 || (n_query > 0 && (!query || !best_idx || !best_dist || !second_dist)) || (n_train > 0 && !train))
+        return MSORB_E_INVALID;
+    for (int i = 0; i < n_query; i++) { best_idx[i] = -1; best_dist[i] = 256; if (second_idx) second_idx[i] = -1; second_dist[i] = 256; }
+    if (n_query == 0 || n_train == 0) return MSORB_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        set_last_error("no usable HIP device (libmsorb has no CPU fallback)");
+        return MSORB_E_NO_DEVICE;
+    }
+    HIPCHK(hipSetDevice(device));
+    struct Scratch {
+        int device = -1;
+        hipStream_t s = nullptr;
+        DBuf<uint8_t> q, t;
+        DBuf<int> out, n;
+        HBuf<int> h;
+        void release() {
+            if (device < 0 || hipSetDevice(device) != hipSuccess) return;
+            q.release(); t.release(); out.release(); n.release(); h.release();
+            if (s) (void)hipStreamDestroy(s);
+            s = nullptr; device = -1;
+        }
+        ~Scratch() { release(); }
+    };
+    static thread_local Scratch S;
+    if (S.device != device) {
+        S.release();
+        S.device = device;
+        HIPCHK(hipStreamCreateWithFlags(&S.s, hipStreamNonBlocking));
+    }
+    constexpr int kChunk = 2048;
+    const int tc = std::min(n_train, kChunk);
+    int rc;
+    if ((rc = S.q.ensure((size_t)n_query * 32)) || (rc = S.t.ensure((size_t)tc * 32)) || (rc = S.out.ensure((size_t)3 * n_query)) ||
+        (rc = S.n.ensure(2)) || (rc = S.h.ensure((size_t)3 * n_query + 2)))
+        return rc;
+    hipStream_t s = S.s;
+    HIPCHK(hipMemcpyAsync(S.q.p, query, (size_t)n_query * 32, hipMemcpyHostToDevice, s));
+    // the kernel reports best (index, distance) and the second DISTANCE; the second index is recovered on the host from the
+    // train rows only when the caller asks for it
+    for (int t0 = 0; t0 < n_train; t0 += kChunk) {
+        const int nt = std::min(kChunk, n_train - t0);
+        int* hn = S.h.p + 3 * (size_t)n_query;
+        hn[0] = n_query; hn[1] = nt;
+        HIPCHK(hipMemcpyAsync(S.n.p, hn, 2 * sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(S.t.p, train + (size_t)t0 * 32, (size_t)nt * 32, hipMemcpyHostToDevice, s));
+        launch_dense_top2(S.q.p, S.t.p, S.n.p, S.n.p + 1, 1, n_query, nt, n_query, nt, S.out.p, S.out.p + n_query, S.out.p + 2 * (size_t)n_query, s,
+                          MSORB_DENSE_POPCOUNT);
+        HIPCHK(hipMemcpyAsync(S.h.p, S.out.p, (size_t)3 * n_query * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipGetLastError());
+        const int *bi = S.h.p, *bd = bi + n_query, *sd = bd + n_query;
+        for (int i = 0; i < n_query; i++) {
+            // merge {best, second} of this chunk into the running pair: all of a later chunk's indices are larger, so on equal
+            // distances the earlier chunk's entries stay in front
+            const int cb = bd[i], cs = sd[i], ci = bi[i] + t0;
+            if (cb < best_dist[i]) {
+                second_dist[i] = std::min(best_dist[i], cs);
+                best_dist[i] = cb; best_idx[i] = ci;
+            } else {
+                second_dist[i] = std::min(second_dist[i], cb);
+            }
+        }
+    }
+    if (second_idx) {   // first train row (lowest index) at the second distance that is not the best itself
+        for (int i = 0; i < n_query; i++) {
+            if (second_dist[i] > 255) continue;
+            uint64_t qa[4];
+            std::memcpy(qa, query + (size_t)i * 32, 32);
+            for (int j = 0; j < n_train; j++) {
+                if (j == best_idx[i]) continue;
+                uint64_t tb[4];
+                std::memcpy(tb, train + (size_t)j * 32, 32);
+                const int d = __builtin_popcountll(qa[0] ^ tb[0]) + __builtin_popcountll(qa[1] ^ tb[1]) + __builtin_popcountll(qa[2] ^ tb[2]) +
+                              __builtin_popcountll(qa[3] ^ tb[3]);
+                if (d == second_dist[i]) { second_idx[i] = j; break; }
+            }
+        }
+    }
+    return MSORB_OK;
+}
+
 int msorb_hamming_dense_top2_batch(int device, const uint8_t* d_query, const uint8_t* d_train, const int* d_n_query,
                                    const int* d_n_train, int n_frames, int query_stride, int train_stride, int max_query,
                                    int max_train, int* d_best_idx, int* d_best_dist, int* d_second_dist, int repeats,
-                                   int formulation, float* elapsed_ms) {
+                                   float* elapsed_ms) {
+    return msorb_hamming_dense_top2_batch_ex(device, d_query, d_train, d_n_query, d_n_train, n_frames, query_stride, train_stride,
+                                             max_query, max_train, d_best_idx, d_best_dist, d_second_dist, repeats, elapsed_ms,
+                                             MSORB_DENSE_MATRIX_CORES);
+}
+
+int msorb_hamming_dense_top2_batch_ex(int device, const uint8_t* d_query, const uint8_t* d_train, const int* d_n_query,
+                                      const int* d_n_train, int n_frames, int query_stride, int train_stride, int max_query,
+                                      int max_train, int* d_best_idx, int* d_best_dist, int* d_second_dist, int repeats,
+                                      float* elapsed_ms, int formulation) {
     if (formulation != MSORB_DENSE_MATRIX_CORES && formulation != MSORB_DENSE_POPCOUNT) return MSORB_E_INVALID;
     if (n_frames < 0 || query_stride < max_query || train_stride < max_train || max_train > 2048 || max_query < 0 ||
         (n_frames > 0 && (!d_query || !d_train || !d_n_query || !d_n_train || !d_best_idx || !d_best_dist || !d_second_dist)))

@@ -394,7 +394,7 @@ template <bool ALIGNED, class GEO>
 __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kernel(PyramidView pyr, const CellDesc* __restrict__ cells,
                                                          int ini_th, int min_th, int slots_per_image,
                                                          Cand16* __restrict__ slots, int* __restrict__ cell_count,
-                                                         int n_cells, uint32_t gx_magic, int debug_stop) {
+                                                         int n_cells, uint32_t gx_magic) {
     constexpr int T = GEO::kThreads, P = GEO::kTilePitch, SP = GEO::kScorePitch;
     constexpr int kScoreBytes = (GEO::kScoreRows * SP + 15) & ~15;
     constexpr int kBitWords = GEO::kWordsPerRow * GEO::kMaxDet;
@@ -549,7 +549,6 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
         }
     };
     __syncthreads();
-    if (debug_stop == 1) return;
 
     // Threshold passes (ORBextractor.cc:826,843-847): iniThFAST first; only a cell that ends up with no keypoint at all
     // is redone at minThFAST.  NMS at a threshold only sees the corners of that threshold (the others score 0 there),
@@ -565,7 +564,6 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
         const int cnt = __popc(wA) + __popc(wB);
         int n_work = 0;
         const int my_base = block_excl_scan<T / 64>(cnt, lane, wave, wave_tot[0], &n_work);
-        if (debug_stop == 2) return;
 
         // phase 2: every (pixel, polarity) that passed goes to the work list; the list is then processed with all lanes busy
         // (S = A' - 1 with A' = max over the 16 arcs of the min over 9 contiguous signed contrasts of the entry's polarity)
@@ -579,7 +577,6 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
             for (uint32_t w = wA; w; w &= w - 1) *wp++ = (uint16_t)(idA | (uint32_t)__builtin_ctz(w));
             for (uint32_t w = wB; w; w &= w - 1) *wp++ = (uint16_t)(idB | (uint32_t)__builtin_ctz(w));
             __syncthreads();
-            if (debug_stop == 3) return;
             // every wave takes one contiguous stretch of the list and leaves the corners it finds packed at the front of that
             // stretch (it has read more entries than it has written): NMS and emission then loop over corners only — about a
             // third of the quick-test survivors — instead of skipping the other two thirds lane by lane
@@ -619,7 +616,6 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
                 }
         }
         __syncthreads();
-        if (debug_stop == 4) return;
 
         if (n_work <= GEO::kWorkCap) {
             // phase 3 (common case: the whole work list fitted): NMS and ordered emission driven by the corner list.
@@ -949,7 +945,7 @@ __device__ __forceinline__ void gauss7_strip(const uint8_t* __restrict__ sb, uin
                                              uint32_t sel_w2b) {
     static_assert(ROWS % 28 == 0, "strips start on a multiple of 4 rows and the row loop is unrolled over 4 x 7 rows");
     uint8_t* const dblk = db + blur_tile_off((uint32_t)max(x0, 0), 0u, (uint32_t)dst_pitch);   // the lane's 4 x 4 block column
-    uint32_t blk[4];   // packed output rows of the block being filled
+    uint32_t blk[4] = {0u, 0u, 0u, 0u};   // packed output rows of the block being filled (a level's last block may be flushed part-filled: rows past h are zero)
     auto load_row = [&](int r) {  // input row r of the strip = image row y0 - 3 + r (reflect-101, then clamped)
         int yy = refl101(y0 - 3 + r, h);
         yy = min(max(yy, 0), h - 1);
@@ -1498,7 +1494,6 @@ void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cell
         const LevelView& v = pyr.lv[l];
         aligned = aligned && (reinterpret_cast<uintptr_t>(v.base) & 3) == 0 && (v.pitch & 3) == 0 && (v.img_stride & 3) == 0;
     }
-    const int dbg = 0;   // phase cut-off of the kernel (tools/fast_phases.py builds a variant with it set)
     const dim3 grid(n_cells, n_images);
     // q = mulhi(n, gx_magic) == n / n_cells for every n < n_cells * n_images (checked here, once per shape)
     uint32_t gx_magic = (uint32_t)((0x100000000ull + (unsigned)n_cells - 1) / (unsigned)n_cells);
@@ -1509,7 +1504,7 @@ void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cell
     }
 #define MSORB_FAST_LAUNCH(AL, GEO)                                                                                        \
     hipLaunchKernelGGL((fast_cells_kernel<AL, GEO>), grid, dim3(GEO::kThreads), 0, s, pyr, cells, ini_th, min_th, slots_per_image, slots, \
-                       cell_count, n_cells, gx_magic, dbg)
+                       cell_count, n_cells, gx_magic)
     if (small_cells) { if (aligned) MSORB_FAST_LAUNCH(true, GeoSmall); else MSORB_FAST_LAUNCH(false, GeoSmall); }
     else { if (aligned) MSORB_FAST_LAUNCH(true, GeoLarge); else MSORB_FAST_LAUNCH(false, GeoLarge); }
 #undef MSORB_FAST_LAUNCH

@@ -7,6 +7,7 @@
 
 #include <string>
 
+#include "lds_limit.h"
 #include "orb_device.h"
 #include "quadtree_device.h"
 
@@ -343,7 +344,7 @@ int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_ba
     const int big_levels = kMaxLevels, small_nt = qt_threads;
     auto raise_lds = [&](const void* fn) -> bool {   // quotas beyond ~700 keypoints per level: past the default dynamic-LDS limit
         if (lds <= 64 * 1024) return true;
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) return true;
+        if ((long long)lds <= dynamic_lds_room(fn)) return true;   // raised once per device to all the LDS there is, never lowered
         set_last_error("quadtree: the device refuses " + std::to_string(lds) + " bytes of LDS per workgroup");
         return false;
     };

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "frustum_device.h"
+#include "lds_limit.h"
 #include "matcher_host.h"
 
 using namespace msorb;
@@ -161,7 +162,9 @@ __global__ __launch_bounds__(kGridThreads) void frame_grid_kernel(GridArgs A) {
     if (A.n_out && tid == 0) A.n_out[b] = n;
 }
 
-size_t frame_grid_lds(int n_cap) { return (size_t)(2 * kNCell + 1) * sizeof(int) + (size_t)n_cap * 2 * sizeof(uint16_t) + 256; }
+// dynamic LDS of frame_grid_kernel for frames of up to n_cap keypoints (its static __shared__ comes on top: dynamic_lds_room
+// subtracts what hipFuncGetAttributes reports for the kernel)
+size_t frame_grid_lds(int n_cap) { return (size_t)(2 * kNCell + 1) * sizeof(int) + (size_t)n_cap * 2 * sizeof(uint16_t); }
 
 int launch_frame_grid(const GridArgs& A, int n_frames, hipStream_t s) {
     const int limit = msorb::frame_grid_max_keypoints();
@@ -170,14 +173,7 @@ int launch_frame_grid(const GridArgs& A, int n_frames, hipStream_t s) {
         set_last_error("frame grid: more than " + std::to_string(limit) + " keypoints per frame");
         return MSORB_E_CAPACITY;
     }
-    const size_t lds = frame_grid_lds(A.dst_stride) - 256;
-    if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit (frames of more than ~10 000 keypoints): raise it
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(frame_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) {
-            set_last_error("frame grid: cannot raise the dynamic LDS limit");
-            return MSORB_E_HIP;
-        }
-    }
+    const size_t lds = frame_grid_lds(A.dst_stride);   // <= the kernel's room: frame_grid_max_keypoints raised the limit once, for good
     hipLaunchKernelGGL(frame_grid_kernel, dim3(n_frames), dim3(kGridThreads), lds, s, A);
     return MSORB_OK;
 }
@@ -352,13 +348,12 @@ namespace msorb {
 // Largest keypoint count the grid kernel takes on the current device: its LDS holds 2 x 3073 ints and two uint16 per keypoint
 // (160 KB per workgroup on gfx950 -> 32768; the uint16 indices stop at 65535 anyway).  -1: the attribute query failed.
 int frame_grid_max_keypoints() {
-    int dev = 0, lds_max = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) {
-        set_last_error("frame grid: cannot query the device's LDS size");
+    const long long dyn = dynamic_lds_room(reinterpret_cast<const void*>(frame_grid_kernel));   // device LDS - the kernel's static part
+    if (dyn < 0) {
+        set_last_error("frame grid: cannot query / raise the kernel's LDS limit");
         return -1;
     }
-    const long long room = (long long)lds_max - (long long)frame_grid_lds(0);
+    const long long room = dyn - (long long)frame_grid_lds(0);
     return (int)std::max<long long>(0, std::min<long long>(room / (2 * (long long)sizeof(uint16_t)), 32768));
 }
 // A set that failed half way leaves the handle EMPTY — no keypoints, an empty (host-authoritative) grid — never a mix of the
@@ -738,6 +733,8 @@ int msorb_frame_set_last_points(msorb_frame* f, int n, const uint8_t* has_point,
     T.last_n = n;
     return MSORB_OK;
 }
+
+int msorb_frame_last_points_count(const msorb_frame* f) { return f && f->track ? f->track->last_n : -1; }
 
 int msorb_search_last_frame(msorb_frame* f, const msorb_motion_model* mm, const int* obs, int n_obs, int* cur_mp, float th,
                             int check_orientation, int* nmatches, uint8_t* proj_valid, float* proj_u, float* proj_v, float* proj_ur) {

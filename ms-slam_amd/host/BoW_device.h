@@ -23,12 +23,21 @@
 
 namespace ORB_SLAM3 {
 namespace msorb_host {
+#ifndef MSORB_HOST_FAIL_CALL
+#define MSORB_HOST_FAIL_CALL
+// a failed call of the C ABI: the application's fatal-error callback first (msorb_set_fatal_callback), then std::runtime_error
+[[noreturn]] inline void fail_call(const char* what) {
+    const std::string msg = std::string(what) + ": " + msorb_last_error();
+    msorb_notify_fatal(MSORB_E_HIP, msg.c_str());
+    throw std::runtime_error(msg);
+}
+#endif
 
 class Vocabulary {
 public:
     Vocabulary(const std::string& text_file, int device = 0) {
         if (msorb_vocabulary_load_text(device, text_file.c_str(), &h_) != MSORB_OK)
-            throw std::runtime_error(std::string("msorb_vocabulary_load_text: ") + msorb_last_error());
+            fail_call("msorb_vocabulary_load_text");
     }
     ~Vocabulary() { msorb_vocabulary_destroy(h_); }
     Vocabulary(const Vocabulary&) = delete;
@@ -54,7 +63,7 @@ void ComputeBoW(const Vocabulary& voc, FrameT& F, int levelsup = 4) {
     int nb = 0, nf = 0;
     if (msorb_bow_transform(voc.get(), desc.data(), n, levelsup, word.data(), value.data(), &nb, node.data(), fbeg.data(),
                             feat.data(), &nf, nullptr, nullptr, nullptr) != MSORB_OK)
-        throw std::runtime_error(std::string("msorb_bow_transform: ") + msorb_last_error());
+        fail_call("msorb_bow_transform");
     using BowValue = typename std::remove_reference<decltype(F.mBowVec)>::type::value_type;
     using FeatValue = typename std::remove_reference<decltype(F.mFeatVec)>::type::value_type;
     for (int i = 0; i < nb; i++)  // ascending word id: hinted insertion at the end is O(1)
@@ -78,7 +87,7 @@ std::vector<int> DistinctiveDescriptorIndices(const std::vector<std::vector<MatT
             std::memcpy(&desc[(size_t)(begin[p] + (int)k) * 32], perPoint[p][k].template ptr<unsigned char>(0), 32);
     std::vector<int> best(P, -1);
     if (P && msorb_distinctive_descriptors(device, desc.data(), begin.data(), P, best.data(), nullptr, nullptr) != MSORB_OK)
-        throw std::runtime_error(std::string("msorb_distinctive_descriptors: ") + msorb_last_error());
+        fail_call("msorb_distinctive_descriptors");
     return best;
 }
 

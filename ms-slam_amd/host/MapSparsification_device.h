@@ -22,6 +22,15 @@
 
 namespace ORB_SLAM3 {
 namespace msorb_host {
+#ifndef MSORB_HOST_FAIL_CALL
+#define MSORB_HOST_FAIL_CALL
+// a failed call of the C ABI: the application's fatal-error callback first (msorb_set_fatal_callback), then std::runtime_error
+[[noreturn]] inline void fail_call(const char* what) {
+    const std::string msg = std::string(what) + ": " + msorb_last_error();
+    msorb_notify_fatal(MSORB_E_HIP, msg.c_str());
+    throw std::runtime_error(msg);
+}
+#endif
 
 template <class KeyFrameT, class MapPointT>
 struct ConstraintMatrix {
@@ -107,7 +116,7 @@ ConstraintMatrix<KeyFrameT, MapPointT> BuildConstraintMatrix(const std::vector<s
                                         mnMinNum, floorObs, &cm.nCols, colPoint.data(), capCols, &cm.nRows, cm.rowBegin.data(),
                                         cm.rowKind.data(), rowOwner.data(), cm.rowRhs.data(), capRows, cm.colIdx.data(), capNnz,
                                         &nnz, cm.objCoef.data(), &cm.nMaxObservation);
-    if (rc != MSORB_OK) throw std::runtime_error(std::string("msorb_visibility_csr: ") + msorb_last_error());
+    if (rc != MSORB_OK) fail_call("msorb_visibility_csr");
     cm.objCoef.resize(cm.nCols); cm.rowBegin.resize(cm.nRows + 1); cm.rowKind.resize(cm.nRows); cm.rowRhs.resize(cm.nRows);
     cm.colIdx.resize(nnz);
     cm.colPoint.resize(cm.nCols);

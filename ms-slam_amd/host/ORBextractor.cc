@@ -19,10 +19,12 @@ static_assert(sizeof(cv::KeyPoint) == sizeof(msorb_keypoint), "cv::KeyPoint must
 
 namespace {
 // The reference's constructor and operator() cannot fail, and Tracking.cc has no handler around them.  A GPU that is missing
-// or a HIP error is fatal for a front-end without a CPU fallback: report it the way the reference reports its own fatal
-// conditions (message on cerr, exit(-1), e.g. System.cc:117-120); MSORB_THROW=1 throws std::runtime_error instead for
-// applications that want to handle it.
-[[noreturn]] void fatal(const std::string& what) {
+// or a HIP error is fatal for a front-end without a CPU fallback.  Order of events: (1) the application's callback, if one is
+// registered (msorb_set_fatal_callback / msorb_host::SetFatalErrorHandler in ORBextractor.h: save the map, log, exit its own
+// way — it need not return); (2) MSORB_THROW=1: std::runtime_error; (3) the default, what the reference does on its own fatal
+// conditions (message on cerr, exit(-1), e.g. System.cc:117-120) — so unchanged callers behave as before.
+[[noreturn]] void fatal(int code, const std::string& what) {
+    msorb_notify_fatal(code, what.c_str());
     if (std::getenv("MSORB_THROW")) throw std::runtime_error(what);
     std::cerr << "msorb (GPU ORB extractor): " << what << std::endl;
     std::exit(-1);
@@ -50,11 +52,18 @@ int next_device() {
 }
 }  // namespace
 
+namespace msorb_host {
+void SetFatalErrorHandler(FatalErrorHandler handler, void* user) { msorb_set_fatal_callback(handler, user); }
+}  // namespace msorb_host
+
 ORBextractor::ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
     : mHandle(nullptr), mLevels(nlevels), mCapacity(0), mScaleFactor(scaleFactor) {
+    if (!msorb_abi_compatible(MSORB_ABI_VERSION))
+        fatal(MSORB_E_INVALID, "libmsorb.so has ABI " + std::to_string(msorb_abi_version()) + ", this host layer was compiled against " +
+                                   std::to_string(MSORB_ABI_VERSION) + " (include/msorb.h): rebuild one of them");
     mDevice = next_device();
     const int rc = msorb_extractor_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, mDevice, &mHandle);
-    if (rc != MSORB_OK) fatal(std::string("msorb_extractor_create: ") + msorb_last_error());
+    if (rc != MSORB_OK) fatal(rc, std::string("msorb_extractor_create: ") + msorb_last_error());
     // mvImagePyramid is read on the host by an unchanged Frame::ComputeStereoMatches (Frame.cc:750,840-855): the levels
     // come back with one asynchronous copy that overlaps the extraction.  MSORB_HOST_PYRAMID=0 when the stereo
     // association runs on the device (msorb_host::ComputeStereoMatches / ExtractStereo): the vector then stays empty.
@@ -85,7 +94,7 @@ int ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*mask*/, std
     const int rc = msorb_extract(mHandle, image.ptr<unsigned char>(0), image.rows, image.cols, (size_t)image.step,
                                  vLappingArea[0], vLappingArea[1], kps, desc, mCapacity, &n, &mono);
     if (rc == MSORB_E_EMPTY) return -1;
-    if (rc != MSORB_OK) fatal(std::string("msorb_extract: ") + msorb_last_error());
+    if (rc != MSORB_OK) fatal(rc, std::string("msorb_extract: ") + msorb_last_error());
     if (n == 0) {
         _descriptors.release();
     } else {

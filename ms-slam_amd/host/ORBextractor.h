@@ -13,6 +13,17 @@ struct msorb_extractor;
 
 namespace ORB_SLAM3 {
 
+namespace msorb_host {
+// What happens when the GPU front-end cannot go on (no device, a HIP error, a library / header ABI mismatch).  The reference's
+// extractor and matcher cannot fail and Tracking.cc has no handler around them, so the default stays "message on cerr +
+// exit(-1)" (MSORB_THROW=1: std::runtime_error).  An application that wants to save its map first registers a handler once,
+// e.g. in main() before System is constructed: it is called on the failing thread with the MSORB_E_* code and the message,
+// BEFORE the default action, and may itself not return.  Process wide (kept inside libmsorb.so: msorb_set_fatal_callback), so
+// it also covers ORBmatcher and the msorb_host:: templates.  nullptr unregisters.
+using FatalErrorHandler = void (*)(int code, const char* what, void* user);
+void SetFatalErrorHandler(FatalErrorHandler handler, void* user = nullptr);
+}  // namespace msorb_host
+
 class ORBextractor {
 public:
     enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };

@@ -23,6 +23,9 @@
 //   ORB_SLAM3::msorb_host::ExtractStereoFrame(dev, F, left, imLeft, imRight)
 //                                                        ExtractStereo + Frame::AssignFeaturesToGrid (src/Frame.cc:385-416) on the
 //                                                        device: `dev` is ready for the searches without an upload
+//   ORB_SLAM3::msorb_host::ComputeStereoFishEyeMatches(F, triangulate)
+//                                                        body of Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1057-1101): the
+//                                                        BFMatcher knnMatch(k = 2) on the device, ratio test + triangulation as is
 //   ORB_SLAM3::msorb_host::ExtractStereoSplit(F, left, right, imLeft, imRight)
 //                                                        the same with one extractor object per GPU (left / right eye on
 //                                                        devices A / B, gather over xGMI, association on A)
@@ -64,14 +67,30 @@
 namespace ORB_SLAM3 {
 namespace msorb_host {
 
+// A failed call of the C ABI: the application's fatal-error callback first (msorb_set_fatal_callback, see ORBextractor.h),
+// then std::runtime_error — which nothing in Tracking.cc / LocalMapping.cc / LoopClosing.cc catches, i.e. std::terminate for
+// an unchanged caller, a catchable error for an embedding application.
 inline void check(int rc, const char* what) {
-    if (rc != MSORB_OK) throw std::runtime_error(std::string(what) + ": " + msorb_last_error());
+    if (rc == MSORB_OK) return;
+    const std::string msg = std::string(what) + ": " + msorb_last_error();
+    msorb_notify_fatal(rc, msg.c_str());
+    throw std::runtime_error(msg);
+}
+// the library that was loaded against the header this file was compiled with (MSORB_ABI_VERSION): checked once per process
+inline void check_abi() {
+    static const bool ok = msorb_abi_compatible(MSORB_ABI_VERSION) != 0;
+    if (!ok) {
+        const std::string msg = "libmsorb.so has ABI " + std::to_string(msorb_abi_version()) + ", the host layer was compiled against " +
+                                std::to_string(MSORB_ABI_VERSION) + " (include/msorb.h)";
+        msorb_notify_fatal(MSORB_E_INVALID, msg.c_str());
+        throw std::runtime_error(msg);
+    }
 }
 
 template <class FrameT>
 class DeviceFrame {
 public:
-    explicit DeviceFrame(int device = 0) { check(msorb_frame_create(device, &h_), "msorb_frame_create"); }
+    explicit DeviceFrame(int device = 0) { check_abi(); check(msorb_frame_create(device, &h_), "msorb_frame_create"); }
     ~DeviceFrame() { msorb_frame_destroy(h_); }
     DeviceFrame(const DeviceFrame&) = delete;
     DeviceFrame& operator=(const DeviceFrame&) = delete;
@@ -840,7 +859,7 @@ public:
     };
     using Lease = std::shared_ptr<Slot>;
 
-    explicit KeyFrameStore(int device = 0) : h_(std::make_shared<Handle>()) { check(msorb_kf_store_create(device, &h_->h), "msorb_kf_store_create"); }
+    explicit KeyFrameStore(int device = 0) : h_(std::make_shared<Handle>()) { check_abi(); check(msorb_kf_store_create(device, &h_->h), "msorb_kf_store_create"); }
     ~KeyFrameStore() { Shutdown(); }
     KeyFrameStore(const KeyFrameStore&) = delete;
     KeyFrameStore& operator=(const KeyFrameStore&) = delete;
@@ -1052,6 +1071,47 @@ void ExtractStereoFrame(DeviceFrame<FrameT>& dev, FrameT& F, const ExtractorT& l
     for (int i = 0; i < nr; i++) std::memcpy(F.mDescriptorsRight.template ptr<unsigned char>(i), &dr[(size_t)i * 32], 32);
     F.mvuRight.assign(ur.begin(), ur.begin() + nl);
     F.mvDepth.assign(depth.begin(), depth.begin() + nl);
+}
+
+// Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1057-1101; the two-camera fisheye constructor): the brute-force
+// BFmatcher.knnMatch(stereoDescLeft, stereoDescRight, matches, 2) over the lapping-area descriptors runs on the device
+// (msorb_knn_match2: dense top-2 Hamming kernel, ties to the lower train index like cv::BFMatcher); Lowe's ratio test and the
+// triangulation stay the reference's code.  `triangulate(kpLeft, kpRight, sigma1, sigma2, p3D) -> depth` is the caller's
+//     static_cast<KannalaBrandt8*>(mpCamera)->TriangulateMatches(mpCamera2, kpLeft, kpRight, mRlr, mtlr, sigma1, sigma2, p3D)
+// (:1089; the camera classes are not part of this path).  Fills mvLeftToRightMatch, mvRightToLeftMatch, mvDepth, mvuRight,
+// mvStereo3Dpoints exactly like the reference's loop; returns nMatches.
+template <class FrameT, class TriangulateFn>
+int ComputeStereoFishEyeMatches(FrameT& F, TriangulateFn triangulate, int device = 0) {
+    const int nl = (int)F.mvKeys.size() - F.monoLeft, nr = (int)F.mvKeysRight.size() - F.monoRight;   // :1059-1060
+    std::vector<uint8_t> dl((size_t)std::max(nl, 0) * 32), dr((size_t)std::max(nr, 0) * 32);
+    for (int i = 0; i < nl; i++) std::memcpy(&dl[(size_t)i * 32], F.mDescriptors.template ptr<unsigned char>(F.monoLeft + i), 32);
+    for (int i = 0; i < nr; i++) std::memcpy(&dr[(size_t)i * 32], F.mDescriptorsRight.template ptr<unsigned char>(F.monoRight + i), 32);
+    F.mvLeftToRightMatch.assign(F.Nleft, -1);                                 // :1065-1069
+    F.mvRightToLeftMatch.assign(F.Nright, -1);
+    F.mvDepth.assign(F.Nleft, -1.0f);
+    F.mvuRight.assign(F.Nleft, -1.0f);
+    F.mvStereo3Dpoints.resize(F.Nleft);
+    F.mnCloseMPs = 0;
+    std::vector<int> bi(std::max(nl, 1)), bd(std::max(nl, 1)), sd(std::max(nl, 1));
+    check(msorb_knn_match2(device, dl.data(), std::max(nl, 0), dr.data(), std::max(nr, 0), bi.data(), bd.data(), nullptr, sd.data()),
+          "msorb_knn_match2");
+    int nMatches = 0;
+    for (int q = 0; q < nl; q++) {
+        if (nr < 2 || bi[q] < 0) continue;                                    // (*it).size() >= 2
+        if (!((float)bd[q] < (float)sd[q] * 0.7)) continue;                   // :1082 (DMatch::distance is a float)
+        const int iL = q + F.monoLeft, iR = bi[q] + F.monoRight;
+        const float sigma1 = F.mvLevelSigma2[F.mvKeys[iL].octave], sigma2 = F.mvLevelSigma2[F.mvKeysRight[iR].octave];
+        auto p3D = F.mvStereo3Dpoints[iL];
+        const float depth = triangulate(F.mvKeys[iL], F.mvKeysRight[iR], sigma1, sigma2, p3D);
+        if (depth > 0.0001f) {                                                // :1090-1096
+            F.mvLeftToRightMatch[iL] = iR;
+            F.mvRightToLeftMatch[iR] = iL;
+            F.mvStereo3Dpoints[iL] = p3D;
+            F.mvDepth[iL] = depth;
+            nMatches++;
+        }
+    }
+    return nMatches;
 }
 
 // The same with one extractor object per GPU (BASELINE configs[3]): `left` lives on device A, `right` on device B

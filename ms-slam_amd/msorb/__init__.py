@@ -23,8 +23,10 @@ STAGES = ("pyramid", "fast", "compact", "blur", "select", "describe")
 OK, E_INVALID, E_NO_DEVICE, E_HIP, E_CAPACITY, E_GEOMETRY, E_EMPTY = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/msorb.h declares (tests check the library exports them all)
+ABI_VERSION = 5000   # MSORB_ABI_VERSION of the include/msorb.h this mirror was written against (tests hold the two together)
+
 EXPORTS = (
-    "msorb_last_error", "msorb_device_count", "msorb_extractor_create", "msorb_extractor_destroy",
+    "msorb_last_error", "msorb_device_count", "msorb_abi_version", "msorb_abi_compatible", "msorb_set_fatal_callback", "msorb_notify_fatal", "msorb_extractor_create", "msorb_extractor_destroy",
     "msorb_extractor_tables", "msorb_extractor_capacity", "msorb_extract", "msorb_pyramid_level",
     "msorb_extract_batch", "msorb_extractor_set_profiling", "msorb_extractor_set_overlap", "msorb_extractor_stage_ms", "msorb_debug_level_size",
     "msorb_debug_copy_level", "msorb_debug_candidates", "msorb_distribute_quadtree", "msorb_extract_stereo",
@@ -59,6 +61,14 @@ def lib():
                 pass
         L = C.CDLL(LIB_PATH)
         vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        if not hasattr(L, "msorb_abi_compatible") or not L.msorb_abi_compatible(ABI_VERSION):
+            have = L.msorb_abi_version() if hasattr(L, "msorb_abi_version") else "< 5000 (no version symbol)"
+            raise RuntimeError(f"{LIB_PATH} has ABI {have}, the Python mirror was written against {ABI_VERSION}: rebuild "
+                               "(python __graft_entry__.py)")
+        L.msorb_set_fatal_callback.argtypes = [vp, vp]
+        L.msorb_set_fatal_callback.restype = None
+        L.msorb_notify_fatal.argtypes = [ci, C.c_char_p]
+        L.msorb_notify_fatal.restype = None
         L.msorb_last_error.restype = C.c_char_p
         L.msorb_extractor_create.argtypes = [ci, cf, ci, ci, ci, ci, C.POINTER(vp)]
         L.msorb_extractor_destroy.argtypes = [vp]
@@ -588,7 +598,7 @@ def visibility_csr(kf_slot_begin, slot_point, slot_cell, point_nobs, obs_begin, 
                 n_max_obs=nmax.value)
 
 
-EXPORTS = EXPORTS + ("msorb_hamming_dense_top2_batch",)
+EXPORTS = EXPORTS + ("msorb_hamming_dense_top2_batch", "msorb_hamming_dense_top2_batch_ex", "msorb_knn_match2")
 
 
 DENSE_MATRIX_CORES, DENSE_POPCOUNT = 0, 1
@@ -600,16 +610,16 @@ def hamming_dense_top2_batch(d_query, d_train, d_nq, d_nt, repeats=1, device=0, 
     -> (best_idx, best_dist, second_dist) torch.int32 [F, q_stride], elapsed_ms over `repeats` launches."""
     import torch
     L = lib()
-    L.msorb_hamming_dense_top2_batch.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p]
+    L.msorb_hamming_dense_top2_batch_ex.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_int]
     F, qs, _ = d_query.shape
     ts = d_train.shape[1]
     # rows >= d_nq[f] are not written by the kernels: best_idx -1, distances 256 there (a defined value, never stale memory)
     outs = [torch.full((F, qs), v, dtype=torch.int32, device=d_query.device) for v in (-1, 256, 256)]
     ms = C.c_float()
-    _check(L.msorb_hamming_dense_top2_batch(device, d_query.data_ptr(), d_train.data_ptr(), d_nq.data_ptr(), d_nt.data_ptr(),
-                                            F, qs, ts, int(d_nq.max()), int(d_nt.max()), outs[0].data_ptr(),
-                                            outs[1].data_ptr(), outs[2].data_ptr(), repeats, int(formulation), C.byref(ms)),
-           "msorb_hamming_dense_top2_batch")
+    _check(L.msorb_hamming_dense_top2_batch_ex(device, d_query.data_ptr(), d_train.data_ptr(), d_nq.data_ptr(), d_nt.data_ptr(),
+                                               F, qs, ts, int(d_nq.max()), int(d_nt.max()), outs[0].data_ptr(),
+                                               outs[1].data_ptr(), outs[2].data_ptr(), repeats, C.byref(ms), int(formulation)),
+           "msorb_hamming_dense_top2_batch_ex")
     return outs[0], outs[1], outs[2], ms.value
 
 
@@ -1256,7 +1266,7 @@ class TrackFrontendRunner:
         self.f.close()
 
 
-EXPORTS = EXPORTS + ("msorb_frame_set_last_points", "msorb_search_last_frame", "msorb_track_frontend_motion")
+EXPORTS = EXPORTS + ("msorb_frame_set_last_points", "msorb_frame_last_points_count", "msorb_search_last_frame", "msorb_track_frontend_motion")
 
 
 class MotionModel(C.Structure):
@@ -1285,7 +1295,6 @@ def frame_set_last_points(frame, last):
     arrs = _last_arrays(last)
     frame.L.msorb_frame_set_last_points.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     _check(frame.L.msorb_frame_set_last_points(frame.h, len(arrs[0]), *[_np_ptr(a) for a in arrs]), "msorb_frame_set_last_points")
-    frame._last_n = len(arrs[0])
 
 
 def search_last_frame(frame, mm, obs, cur_mp, th, check_orientation=True, want_projection=False):
@@ -1296,7 +1305,10 @@ def search_last_frame(frame, mm, obs, cur_mp, th, check_orientation=True, want_p
     assert cur_mp.dtype == np.int32 and cur_mp.flags.c_contiguous
     nm = C.c_int()
     n_obs = len(ob)
-    n = getattr(frame, "_last_n", n_obs)      # the projection arrays have one entry per last-frame keypoint
+    frame.L.msorb_frame_last_points_count.argtypes = [vp]
+    n = frame.L.msorb_frame_last_points_count(frame.h)      # the projection arrays have one entry per last-frame keypoint
+    if n < 0:
+        raise MsorbError(E_INVALID, "msorb_search_last_frame: no last-frame table on the handle (msorb_frame_set_last_points)")
     pv = np.zeros(max(n, 1), np.uint8)
     pu, pvv, pur = [np.zeros(max(n, 1), np.float32) for _ in range(3)]
     proj = [_np_ptr(a) for a in (pv, pu, pvv, pur)] if want_projection else [None] * 4
@@ -1375,8 +1387,21 @@ class MotionFrontendRunner:
         return self.nm.value
 
     def attach_local_points(self, frustum, mp, th, bFarPoints=False, thFarPoints=50.0, nnratio=0.8, viewing_cos_limit=0.5):
-        """prepare the second call of the frame: msorb_search_local_points (TrackLocalMap's SearchLocalPoints) on the same handle"""
+        """prepare the second call of the frame: msorb_search_local_points (TrackLocalMap's SearchLocalPoints) on the same handle.
+        As in Tracking::Track the points TrackWithMotionModel matched stay in mvpMapPoints: their keypoints are occupied
+        (ORBmatcher.cc:99-101) and the points themselves are part of the local map, already seen in this frame and skipped by
+        SearchLocalPoints' loop (Tracking.cc:3316-3340: mnLastFrameSeen == mCurrentFrame.mnId).  The local-map table is a private
+        copy whose first rows stand for those held points (visit = 0, Observations() >= 1); frame_total() points frame_mp at them."""
         vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        mp = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in mp.items()}
+        self.one_call()
+        self.held_kp = np.flatnonzero(self.cur_mp[:self.nl.value] >= 0).astype(np.int64)[:len(mp["max_distance"])]
+        rows = np.arange(len(self.held_kp))
+        if mp.get("visit") is None:
+            mp["visit"] = np.ones(len(mp["max_distance"]), np.uint8)
+        mp["visit"][rows] = 0
+        mp["bad"][rows] = 0
+        mp["obs"][rows] = np.maximum(mp["obs"][rows], 1)
         self.m, self.arrs = _lp_arrays(mp)
         self.out = _lp_outputs(self.m)
         self.frame_mp = np.full(self.ex.capacity, -1, np.int32)
@@ -1392,11 +1417,25 @@ class MotionFrontendRunner:
         of the host sits here in the reference) SearchLocalPoints -> (motion-model matches, local-map matches)"""
         a = self.one_call()
         self.frame_mp[:] = -1
+        held = np.flatnonzero(self.cur_mp[:self.nl.value] >= 0)[:self.m]
+        self.frame_mp[held] = np.arange(len(held), dtype=np.int32)   # the motion-model matches stay in the frame: occupied keypoints
         _check(self.L.msorb_search_local_points(*self._lp), "msorb_search_local_points")
         return a, self.nm_lp.value
 
     def close(self):
         self.f.close()
+
+
+def knn_match2(query, train, device=0):
+    """msorb_knn_match2: BFMatcher(NORM_HAMMING).knnMatch(k=2) -> (best_idx, best_dist, second_idx, second_dist)."""
+    lb = lib()
+    vp, ci = C.c_void_p, C.c_int
+    lb.msorb_knn_match2.argtypes = [ci, vp, ci, vp, ci, vp, vp, vp, vp]
+    q, t = _c(query, np.uint8).reshape(-1, 32), _c(train, np.uint8).reshape(-1, 32)
+    nq = len(q)
+    out = [np.zeros(max(nq, 1), np.int32) for _ in range(4)]
+    _check(lb.msorb_knn_match2(device, _np_ptr(q), nq, _np_ptr(t), len(t), *[_np_ptr(o) for o in out]), "msorb_knn_match2")
+    return tuple(o[:nq] for o in out)
 
 
 EXPORTS = EXPORTS + ("msorb_frame_search_rounds",)
