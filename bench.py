@@ -29,6 +29,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "ms-slam_amd")]
 # The legs live in bench_legs/ (one module each); this file keeps the contract: the CLI, the timed loop, the JSON line.
 from bench_legs import HBM_PEAK_GBS, KITTI_MB, KITTI_MBF, optional_leg, self_check  # noqa: E402
 from bench_legs.cpu import cpu_baseline, level_bytes  # noqa: E402
+from bench_legs.density import density_sweep_leg, fourseasons_leg  # noqa: E402
 from bench_legs.hamming import hamming_cpu_leg, hamming_leg  # noqa: E402
 from bench_legs.host_fed import host_fed_leg  # noqa: E402
 from bench_legs.per_frame import per_frame_leg  # noqa: E402
@@ -76,11 +77,46 @@ def main():
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+
+        def die(stage, err):
+            # one clear line per rank, then a non-zero exit: a SCALE record is either a number or this diagnosis
+            sys.stderr.write(f"bench.py rank {rank}/{world} (cuda:{local}, backend {backend}): {stage} FAILED: {type(err).__name__}: {err}\n"
+                             f"  visible GPUs: {torch.cuda.device_count()}; MASTER_ADDR={os.environ.get('MASTER_ADDR')} "
+                             f"MASTER_PORT={os.environ.get('MASTER_PORT')} HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}\n"
+                             "  (RCCL needs one visible GPU per rank and dmabuf IPC: HSA_ENABLE_IPC_MODE_LEGACY=0; use 127.0.0.1 for the rendezvous)\n")
+            sys.stderr.flush()
+            time.sleep(1.0)   # the launcher kills the other ranks as soon as one exits: give them the time to print their own line
+            os._exit(3)
+        if backend == "nccl" and torch.cuda.device_count() < world:
+            die("device check", RuntimeError(f"--gpus {world} needs {world} visible GPUs, found {torch.cuda.device_count()} "
+                                             "(MSORB_DIST_BACKEND=gloo runs the N > 1 code path with the ranks sharing one GPU)"))
+        tmo = datetime.timedelta(seconds=int(os.environ.get("MSORB_DIST_TIMEOUT_S", "120")))
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, timeout=tmo)
+            else:
+                dist.init_process_group(backend, timeout=tmo)
+        except Exception as e:  # noqa: BLE001
+            die("init_process_group", e)
+        try:
+            # first contact, before any buffer is allocated: an all_reduce (every rank present) and the pair's send / receive
+            probe = torch.ones(1, dtype=torch.int32, device=dev)
+            dist.all_reduce(probe)
+            if int(probe.item()) != world:
+                raise RuntimeError(f"all_reduce over {world} ranks returned {int(probe.item())}")
+            peer = rank ^ 1
+            if peer < world:
+                token = torch.full((1,), rank, dtype=torch.int32, device=dev)
+                got = torch.zeros_like(token)
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, got, peer), dist.P2POp(dist.isend, token, peer)]):
+                    w.wait()
+                torch.cuda.synchronize()
+                if int(got.item()) != peer:
+                    raise RuntimeError(f"point-to-point probe with rank {peer} returned {int(got.item())}")
+        except Exception as e:  # noqa: BLE001
+            die("first collective / point-to-point exchange", e)
 
     B = args.pairs
     # images of this rank: N=1 -> L,R interleaved (2B images); N>1 -> one eye of 2B pairs (2B images): fixed per-GPU work
@@ -370,10 +406,17 @@ def main():
         all_ex.append(hf_ex[1])
         host_fed = optional_leg("host_fed", host_fed_leg, msorb, torch, hf_ex, host, dev, cfg, pitch)
 
+    # input-statistics sweep and configs[4]'s front-end geometry: after the timed region, on their own handles and batches
+    density = fourseasons = None
+    if aux and not args.isolated:
+        density = optional_leg("density_sweep", density_sweep_leg, msorb, synth, torch, make_ex, cfg, dev, B, uniq, args.cpu_pairs > 0)
+        fourseasons = optional_leg("fourseasons_frontend", fourseasons_leg, msorb, synth, torch, dev, B, uniq, local, args.cpu_pairs > 0)
+
     validation = None
     if world > 1:
         validation = split_self_validation(msorb, torch, dist, stereo_split, rank, world, eye, half, exs[0], ex_rp, make_ex, images,
-                                           other_images, mine[0], theirs[0], kp_total_rank / dt_rank if dt_rank > 0 else 0.0, dev)
+                                           other_images, mine[0], theirs[0], kp_total_rank / dt_rank if dt_rank > 0 else 0.0, dev,
+                                           rank_keypoints_per_step=int(round(kp_total_rank / max(args.steps, 1))))
 
     if hamming is not None and ham_ctx is not None and args.cpu_pairs > 0 and rank == 0:
         err = optional_leg("hamming_match.cpu_baseline", hamming_cpu_leg, msorb, hamming, ham_ctx)
@@ -437,6 +480,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / steps * 1e3, 4),
+            "keypoints_per_step": int(round(kp_total / steps)),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -505,6 +549,8 @@ def main():
                 "gathered_bytes_per_step_and_rank": theirs[0].nbytes() if theirs else None}
         out["per_frame"] = per_frame
         out["host_fed"] = host_fed
+        out["density_sweep"] = density
+        out["fourseasons_frontend"] = fourseasons
         if validation is not None:
             out["split_validation"] = validation
         if world == 1 and args.cpu_pairs > 0:

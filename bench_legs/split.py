@@ -9,7 +9,7 @@ from . import ROOT, KITTI_MB, KITTI_MBF, self_check, oracle_module, tests_dir
 
 
 def split_self_validation(msorb, torch, dist, stereo_split, rank, world, eye, half, ex_own, ex_other, make_ex, images, other_images,
-                          mine, theirs, rank_value, dev):
+                          mine, theirs, rank_value, dev, rank_keypoints_per_step=None):
     """Untimed, after the timed region of a --gpus N run: (1) who took part (ranks, devices, backend), (2) one more exchange, after
     which every rank checks the features it RECEIVED for its pairs against a local extraction of the same images (it holds the
     other eye's images of the pairs it joins) — bit for bit —, and that the stereo association on (own, gathered) features
@@ -18,7 +18,7 @@ def split_self_validation(msorb, torch, dist, stereo_split, rank, world, eye, ha
     backend = dist.get_backend()
     info = [None] * world
     dist.all_gather_object(info, {"rank": rank, "device": torch.cuda.get_device_name(dev), "cuda_index": dev.index,
-                                  "mkeypoints_per_s": round(rank_value / 1e6, 3)})
+                                  "mkeypoints_per_s": round(rank_value / 1e6, 3), "keypoints_per_step": rank_keypoints_per_step})
     ones = torch.ones(1, dtype=torch.int32, device=dev)
     dist.all_reduce(ones)
     # fresh extraction of this rank's images + exchange

@@ -100,7 +100,8 @@ def tracking_loop_leg(msorb, synth, torch, ex, cfg, base, counts_h, d_kps, d_des
                                "what": "both device calls of ONE tracking frame in the order Tracking::Track runs them: (1) Frame::Frame + "
                                        "TrackWithMotionModel's SearchByProjection (msorb_frame_set_last_points + msorb_track_frontend_motion), "
                                        "(2) TrackLocalMap's SearchLocalPoints (msorb_search_local_points: isInFrustum + SearchByProjection over "
-                                       "%d local map points).  The host's PoseOptimization between and after them is NOT included (g2o, out "
+                                       "%d local map points; the motion-model matches stay in the frame as in Tracking::Track: their "
+                                       "keypoints are occupied and their points — rows of the local map — are already seen and skipped).  The host's PoseOptimization between and after them is NOT included (g2o, out "
                                        "of scope); wall time through the C ABI from host images" % m_points},
            "batched": {"frames": n_frames, "map_points_per_frame": m_points, "ms_grid": round(ms_grid, 4), "ms_frustum_queries": round(ms_frustum, 4),
                        "ms_window_search": round(ms_window, 4), "ms_per_frame": round((ms_grid + ms_frustum + ms_window) / n_frames, 5),
@@ -113,6 +114,12 @@ def tracking_loop_leg(msorb, synth, torch, ex, cfg, base, counts_h, d_kps, d_des
            "_cpu": (maps[0], frusta[0], kps_h[0, :int(counts_h[0])].copy().view(msorb.KP_DTYPE).reshape(-1), desc_h[0, :int(counts_h[0])],
                     d_ur2[0, :int(counts_h[0])].cpu().numpy(), bounds, scale, th,
                     int((r["topk_idx"][0, :, 0] >= 0).sum().item()))}
+    # the same frame through the UNCHANGED call sites (drop-in classes, host-projected a14): bench_legs/unchanged.py
+    from . import optional_leg
+    from .unchanged import unchanged_callers_leg
+    out["unchanged_callers"] = optional_leg("tracking_loop.unchanged_callers", unchanged_callers_leg, msorb, synth, cfg, left, right, k0,
+                                            desc_h[0, :n0].copy(), d_ur2[0, :n0].cpu().numpy(), dp_h[0, :n0].copy(), np.asarray(scale, np.float32),
+                                            maps[0], frusta[0], last, th_mm, th, args.cpu_pairs > 0, device=local)
     out["_cpu_mm"] = (last, q_cw, t_cw, bool(fwd), bool(bwd), th_mm, int(nmm1), mm_cur, k0, desc_h[0, :n0].copy(),
                       d_ur2[0, :n0].cpu().numpy(), bounds, scale)
     run.close()

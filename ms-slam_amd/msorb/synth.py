@@ -13,7 +13,15 @@ EUROC_YAML = dict(EUROC, nfeatures=1200)
 FOURSEASONS = dict(rows=400, cols=800, nfeatures=2000, scale=1.2, nlevels=8, ini_th=20, min_th=7)
 
 
-def _scene(rng, rows, cols):
+# Input classes of the density sweep (bench.py density_sweep): the default recipe is corner-rich (5.8 % of the
+# pixels pass FAST at threshold 20); "low" is the street-imagery regime — 0.6 % corners, a third of the 35 x 35 cells without a
+# corner at 20 so that they take the minThFAST retry of ORBextractor.cc:843-847 — and "high" a cluttered one.  (count scale of the three
+# shape sizes, amplitude of a shape, noise sigma)
+TEXTURE = {"default": (1.0, 70.0, 3.0), "low": (0.2, 50.0, 2.0), "high": (2.5, 95.0, 4.0)}
+
+
+def _scene(rng, rows, cols, texture="default"):
+    density, amp, _ = TEXTURE[texture]
     img = np.full((rows, cols), 110.0, np.float32)
     yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float32)
     # low-frequency shading
@@ -24,10 +32,10 @@ def _scene(rng, rows, cols):
     # shapes at three scales
     area = rows * cols
     for size, count in ((60, area // 9000), (22, area // 1800), (8, area // 500)):
-        for _ in range(int(count)):
+        for _ in range(int(round(count * density))):
             cx, cy = rng.uniform(0, cols), rng.uniform(0, rows)
             w, h = rng.uniform(0.4, 1.6, 2) * size
-            val = rng.uniform(-70, 70)
+            val = rng.uniform(-amp, amp)
             x0, x1 = int(max(0, cx - w)), int(min(cols, cx + w))
             y0, y1 = int(max(0, cy - h)), int(min(rows, cy + h))
             if x1 <= x0 or y1 <= y0:
@@ -45,16 +53,17 @@ def _finish(rng, img, sigma=3.0):
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
 
-def image(seed, rows, cols, sigma=3.0):
-    """One u8 rows x cols image."""
+def image(seed, rows, cols, sigma=None, texture="default"):
+    """One u8 rows x cols image of the given input class (TEXTURE)."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    return _finish(rng, _scene(rng, rows, cols), sigma)
+    return _finish(rng, _scene(rng, rows, cols, texture), TEXTURE[texture][2] if sigma is None else sigma)
 
 
-def stereo_pair(seed, rows, cols, max_disp=48.0, sigma=3.0):
+def stereo_pair(seed, rows, cols, max_disp=48.0, sigma=None, texture="default"):
     """(left, right) u8 images; right = left resampled with a smooth positive disparity field."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    scene = _scene(rng, rows, cols)
+    sigma = TEXTURE[texture][2] if sigma is None else sigma
+    scene = _scene(rng, rows, cols, texture)
     yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float32)
     disp = max_disp * (0.15 + 0.85 * (yy / rows)) * (0.8 + 0.2 * np.sin(xx / cols * 3.1))
     # right(x) = left(x + d): a point at uL in the left eye appears at uR = uL - d
@@ -69,11 +78,11 @@ def stereo_pair(seed, rows, cols, max_disp=48.0, sigma=3.0):
     return left, right
 
 
-def stereo_batch(n_pairs, rows, cols, seed0=0):
+def stereo_batch(n_pairs, rows, cols, seed0=0, texture="default"):
     """uint8 array [2*n_pairs, rows, cols]: L0, R0, L1, R1, ..."""
     out = np.empty((2 * n_pairs, rows, cols), np.uint8)
     for i in range(n_pairs):
-        out[2 * i], out[2 * i + 1] = stereo_pair(seed0 + i, rows, cols)
+        out[2 * i], out[2 * i + 1] = stereo_pair(seed0 + i, rows, cols, texture=texture)
     return out
 
 
@@ -185,5 +194,7 @@ def last_frame(seed, kps, desc, depth, point_frac=0.75, outlier_frac=0.05, obs_z
     obs = np.where(rng.random(n) < obs_zero_frac, 0, rng.integers(1, 12, n)).astype(np.int32)
     tlc_z = float((Rlw @ (-(Rcw.T @ tcw)) + tlw)[2])   # tlc = Tlw * twc (ORBmatcher.cc:1954-1955)
     mb = cam["mbf"] / cam["fx"]
-    return (dict(has_point=has.astype(np.uint8), pos_w=Pw, octave=octv, angle=ang, desc=cp.astype(np.uint8), obs=obs),
+    # Rcw / tcw / Rlw / tlw ride along for callers that hold the poses as matrices (the host-projected class path)
+    return (dict(has_point=has.astype(np.uint8), pos_w=Pw, octave=octv, angle=ang, desc=cp.astype(np.uint8), obs=obs,
+                 Rcw=Rcw.astype(np.float32), tcw=tcw.astype(np.float32), Rlw=Rlw.astype(np.float32), tlw=tlw.astype(np.float32)),
             _quat_xyzw(Rcw).astype(np.float32), tcw.astype(np.float32), tlc_z > mb, -tlc_z > mb)

@@ -218,6 +218,7 @@ struct Extractor {
     std::vector<int> mnFeaturesPerLevel, umax;
     std::vector<Plane> pyramid, blurred;
     std::vector<std::vector<Cand>> candidates;     // vToDistributeKeys per level (last call)
+    std::vector<int> cells_total, cells_retried, cells_empty;   // per level (last call): cells visited, cells that took the minThFAST retry (:843-847), cells empty after it
     std::vector<std::vector<KeyPoint>> selected;   // allKeypoints per level (last call; level coords, angle set)
 
     Extractor(int nf, float sf, int nl, int ini, int mn)
@@ -279,6 +280,9 @@ struct Extractor {
     bool compute_keypoints_quadtree() {  // :781-896
         candidates.assign(nlevels, std::vector<Cand>());
         selected.assign(nlevels, std::vector<KeyPoint>());
+        cells_total.assign(nlevels, 0);
+        cells_retried.assign(nlevels, 0);
+        cells_empty.assign(nlevels, 0);
         const float W = 35;
         std::vector<FastPt> cell;
         for (int level = 0; level < nlevels; ++level) {
@@ -308,7 +312,12 @@ struct Extractor {
                     const uint8_t* roi = im.row((int)iniY) + (int)iniX;
                     const int rrows = (int)maxY - (int)iniY, rcols = (int)maxX - (int)iniX;
                     fast9_nms(roi, im.cols, rrows, rcols, iniThFAST, cell);
-                    if (cell.empty()) fast9_nms(roi, im.cols, rrows, rcols, minThFAST, cell);
+                    cells_total[level]++;
+                    if (cell.empty()) {   // the threshold fallback of :843-847
+                        cells_retried[level]++;
+                        fast9_nms(roi, im.cols, rrows, rcols, minThFAST, cell);
+                        if (cell.empty()) cells_empty[level]++;
+                    }
                     for (const FastPt& p : cell)
                         to_distribute.push_back({(float)p.x + j * wCell, (float)p.y + i * hCell, (float)p.score});
                 }
@@ -416,6 +425,14 @@ int orc_candidates(void* h, int level, int* xs, int* ys, int* scores, int cap) {
     const auto& c = e->candidates[level];
     for (size_t i = 0; i < c.size() && (int)i < cap; i++) { xs[i] = (int)c[i].x; ys[i] = (int)c[i].y; scores[i] = (int)c[i].response; }
     return (int)c.size();
+}
+// Input statistics of the last call (bench.py's density sweep): per level the cells the loop visited, those whose first
+// cv::FAST at iniThFAST found nothing (the minThFAST retry, :843-847) and those still empty after it.
+int orc_cell_stats(void* h, int level, int* total, int* retried, int* empty) {
+    Extractor* e = (Extractor*)h;
+    if (level < 0 || level >= (int)e->cells_total.size()) return -1;
+    *total = e->cells_total[level]; *retried = e->cells_retried[level]; *empty = e->cells_empty[level];
+    return 0;
 }
 // allKeypoints[level] of the last call (level coordinates, angle set), quadtree order.
 int orc_selected(void* h, int level, void* kps, int cap) {

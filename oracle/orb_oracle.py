@@ -40,6 +40,7 @@ def lib():
         L.orc_level_copy.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_selected.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_cell_stats.argtypes = [C.c_void_p, C.c_int, _ip, _ip, _ip]
         L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.orc_gaussian7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_fast9_nms.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -101,6 +102,15 @@ class OracleExtractor:
         xs, ys, sc = (np.zeros(cap, np.int32) for _ in range(3))
         n = self.L.orc_candidates(self.h, l, _ptr(xs), _ptr(ys), _ptr(sc), cap)
         return np.stack([xs[:n], ys[:n], sc[:n]], 1)
+
+    def cell_stats(self):
+        """per level of the last call: (cells visited, cells that took the minThFAST retry, cells empty after it)"""
+        out = []
+        for l in range(self.nlevels):
+            t, r, e = C.c_int(), C.c_int(), C.c_int()
+            assert self.L.orc_cell_stats(self.h, l, C.byref(t), C.byref(r), C.byref(e)) == 0
+            out.append((t.value, r.value, e.value))
+        return out
 
     def selected(self, l):
         cap = self.nfeatures + 64

@@ -440,3 +440,36 @@ def test_batch_submit_wait_two_handles_in_flight(msorb_mod, oracle):
             assert torch.equal(k[i, :c[i]], wk[i, :c[i]]) and torch.equal(d[i, :c[i]], wd[i, :c[i]])
     for e_ in ex + [ref]:
         e_.close()
+
+
+@pytest.mark.parametrize("n_images", [4, 32])
+def test_texture_classes_at_full_kitti_size_through_the_batch_kernels(msorb_mod, oracle, n_images):
+    """The input classes of bench.py's density sweep (msorb/synth.py TEXTURE) at 1241 x 376, 2000 features: on the LOW class a
+    third of the reference's cells finds no corner at iniThFAST and takes the minThFAST retry (ORBextractor.cc:843-847 — the second
+    pass of fast_cells_kernel, which the other tests of this file reach only at 320 x 240), half of those stay empty; the HIGH
+    class saturates cells.  n_images 4 = the frame kernels' shapes (1024-thread quadtree), 32 = the batch shapes, two sub-batches.
+    Candidates per level, keypoints and descriptors against the oracle."""
+    import torch
+    cfg = CONFIGS["kitti"]
+    ex, ref = _pair(msorb_mod, oracle, cfg)
+    try:
+        imgs = np.stack([synth.stereo_pair(880 + i // 2, cfg["rows"], cfg["cols"], texture=("low", "high", "low", "default")[i % 4])[i % 2]
+                         for i in range(n_images)])
+        counts, mono, d_kps, d_desc = ex.extract_batch(torch.from_numpy(imgs).cuda())
+        kps = msorb_mod.keypoints_from_device(d_kps, counts)
+        desc = d_desc.cpu().numpy()
+        retried = 0
+        for i in ([0, 1, 2, 3] if n_images == 4 else [0, 1, 2, 6, 17, 30, 31]):
+            rmono, rkps, rdesc = ref(imgs[i])
+            assert counts[i] == len(rkps) and mono[i] == rmono, i
+            _assert_same(kps[i], desc[i, :counts[i]], rkps, rdesc)
+            st = ref.cell_stats()
+            if i % 2 == 0:   # low class
+                retried += sum(s[1] for s in st)
+                assert sum(s[1] for s in st) > 0.2 * sum(s[0] for s in st), st
+            if n_images == 4:   # single sub-batch: the candidate lists are inspectable
+                for l in range(cfg["nlevels"]):
+                    assert np.array_equal(ex.debug_candidates(i, l), ref.candidates(l)), (i, l)
+        assert retried > 300
+    finally:
+        ex.close()

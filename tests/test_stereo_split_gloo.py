@@ -127,7 +127,7 @@ def _worker_halves(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])   # 4 = two eye pairs: (0, 1) and (2, 3) swap independently
 def test_stereo_split_swap_halves(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -138,3 +138,57 @@ def test_extract_stereo_split_without_peer_access(msorb_mod, oracle, monkeypatch
         assert np.array_equal(again[4].view(np.uint32), want[4].view(np.uint32))
     finally:
         exl.close(); exr.close(); sxl.close(); sxr.close()
+
+
+@pytest.mark.parametrize("no_peer,force_peer", [(False, False), (True, False), (False, True), (True, True)])
+def test_split_entries_under_both_test_hooks(msorb_mod, oracle, monkeypatch, no_peer, force_peer):
+    """Everything of configs[3]'s product path one GPU can execute, through the C ABI, with the two test hooks both ways:
+    msorb_extract_stereo_split (gather by peer copy / staged through pinned host memory: MSORB_SPLIT_NO_PEER), then the frame
+    form msorb_stereo_matches on the same two handles (the right pyramid pulled over the peer-copy path: MSORB_FORCE_PEER_PYRAMID),
+    then the batch form msorb_pyramid_batch + msorb_stereo_matches_split on 'gathered' blocks.  All against the oracle."""
+    import torch
+    cfg = synth.KITTI
+    rows, cols = cfg["rows"], cfg["cols"]
+    mbf, mb = mc.KITTI_BF, mc.KITTI_BF / mc.KITTI_FX
+    dev_a, dev_b = _devices(msorb_mod)
+    if no_peer:
+        monkeypatch.setenv("MSORB_SPLIT_NO_PEER", "1")
+    if force_peer:
+        monkeypatch.setenv("MSORB_FORCE_PEER_PYRAMID", "1")
+    exl = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7, device=dev_a)     # the switches are read at creation
+    exr = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7, device=dev_b)
+    exp = msorb_mod.ORBextractor(2000, 1.2, 8, 20, 7, device=dev_a)
+    monkeypatch.delenv("MSORB_SPLIT_NO_PEER", raising=False)
+    monkeypatch.delenv("MSORB_FORCE_PEER_PYRAMID", raising=False)
+    L, R = synth.stereo_pair(52 + 2 * int(no_peer) + int(force_peer), rows, cols)
+    orl, orr = oracle.OracleExtractor(2000, 1.2, 8, 20, 7), oracle.OracleExtractor(2000, 1.2, 8, 20, 7)
+    try:
+        _, okl, odl = orl(L)
+        _, okr, odr = orr(R)
+        tb = orl.tables()
+        rur, rdp, roob = oracle.compute_stereo_matches(okl, odl, okr, odr, [orl.level(l) for l in range(8)],
+                                                       [orr.level(l) for l in range(8)], tb["scale"], tb["inv_scale"], mb, mbf)
+        kl, dl, kr, dr, ur, dp, oob = exl.extract_stereo_split(exr, L, R, mb, mbf)
+        assert np.array_equal(kl.view(np.uint8), okl.view(np.uint8)) and np.array_equal(kr.view(np.uint8), okr.view(np.uint8))
+        assert np.array_equal(dl, odl) and np.array_equal(dr, odr)
+        assert np.array_equal(ur.view(np.uint32), rur.view(np.uint32)) and np.array_equal(dp.view(np.uint32), rdp.view(np.uint32)) and oob == roob
+        # frame form on the two handles (their last calls hold L and R)
+        exl(L)
+        exr(R)
+        ur2, dp2, oob2 = msorb_mod.stereo_matches(exl, exr, okl, odl, okr, odr, mb, mbf)
+        assert np.array_equal(ur2.view(np.uint32), rur.view(np.uint32)) and np.array_equal(dp2.view(np.uint32), rdp.view(np.uint32)) and oob2 == roob
+        # batch form: left eye extracted by exl, right eye's features arriving as separate blocks, its pyramid rebuilt by exp
+        if dev_a == dev_b:
+            d_l = torch.from_numpy(np.stack([L, L])).cuda(dev_a)
+            d_r = torch.from_numpy(np.stack([R, R])).cuda(dev_a)
+            cl, _, bkl, bdl = exl.extract_batch(d_l, (0, 0))
+            cr, _, bkr, bdr = exr.extract_batch(d_r, (0, 0))
+            exp.pyramid_batch(d_r)
+            gur, gdp, goob, _ = msorb_mod.stereo_matches_split(exl, exp, cl, bkl, bdl, cr, bkr.clone(), bdr.clone(), mb, mbf)
+            for p in range(2):
+                n = int(cl[p])
+                assert np.array_equal(gur[p, :n].cpu().numpy().view(np.uint32), rur.view(np.uint32)), p
+                assert np.array_equal(gdp[p, :n].cpu().numpy().view(np.uint32), rdp.view(np.uint32)), p
+            assert int(goob[0]) == roob
+    finally:
+        exl.close(); exr.close(); exp.close()
