@@ -28,7 +28,10 @@ def tracking_loop_leg(msorb, synth, torch, ex, cfg, base, counts_h, d_kps, d_des
     for b in range(n_frames):
         n = int(counts_h[2 * b])
         k = kps_h[b, :n].copy().view(msorb.KP_DTYPE).reshape(-1)
-        mp = synth.local_map(9000 + b, k, desc_h[b, :n], dp_h[b, :n], scale, m_points)
+        # spars_frac = 0: MapPoint::mbSparsified is initialised false and never set in MS-SLAM (only KeyFrame::mbSparsified is,
+        # KeyFrame.cc:359), so the bypass of ORBmatcher.cc:88 — a point that overwrites an occupied keypoint — never fires in the
+        # reference; the parity tests keep exercising it (5 % of the points), the timed workload does not
+        mp = synth.local_map(9000 + b, k, desc_h[b, :n], dp_h[b, :n], scale, m_points, spars_frac=0.0)
         maps.append(mp)
         frusta.append(msorb.Frustum.make(mp["Rcw"], mp["tcw"], mp["Ow"], cam["fx"], cam["fy"], cam["cx"], cam["cy"], bounds, cam["mbf"],
                                          float(np.log(np.float32(cfg["scale"]))), cfg["nlevels"]))

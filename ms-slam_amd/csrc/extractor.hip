@@ -169,7 +169,7 @@ struct msorb_extractor {
     // host-synchronised stages: debugging), MSORB_QUADTREE=host (DistributeOctTree on the host twin), MSORB_HOST_THREADS (its
     // worker threads), MSORB_SPLIT_NO_PEER (test hook: the two-device gather staged through the host), MSORB_FORCE_PEER_PYRAMID
     // (test hook: msorb_stereo_matches pulls the right pyramid over the peer path even on one device)
-    struct Knobs { bool serial_pipeline = false, quadtree_host = false, split_no_peer = false, force_peer_pyramid = false; int host_threads = 0; } knobs;
+    struct Knobs { bool serial_pipeline = false, quadtree_host = false, split_no_peer = false, force_peer_pyramid = false, frame_sdma = false; int host_threads = 0; } knobs;
     int lds_per_block = 64 * 1024;   // hipDeviceAttributeMaxSharedMemoryPerBlock of the handle's device
     static constexpr bool capturing = false;   // (no graph capture: plain launches; see tools/experiments/README.md)
     bool defer_sync = false;     // enqueue only, the caller appends more work and synchronises (msorb_extract[_stereo])
@@ -239,6 +239,16 @@ namespace {
 // reaches it), but its FIRST pass divides every initial column unconditionally (ORBextractor.cc:610-681 runs before any quota
 // check): a level returns up to max(quota + 3, 4 * nIni) keypoints, nIni = round(width / height) <= 4 for every camera the
 // reference is configured for.  16 more rows per level cover that whatever the quota (tiny nfeatures on wide images).
+// per-frame transfer between a pinned block and device memory on stream s: a copy kernel (launch_blit), or the SDMA engine under
+// MSORB_FRAME_COPIES=sdma.  Buffers are whole allocations (hipMalloc / hipHostMalloc: 256-byte aligned, sizes padded by the callers).
+int frame_copy(msorb_extractor* h, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
+    if (h->knobs.frame_sdma || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15)) {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, kind, s));
+        return MSORB_OK;
+    }
+    launch_blit(dst, src, bytes, s);
+    return MSORB_OK;
+}
 int capacity_of(const msorb_extractor* h) { return h->P.nfeatures + (3 + 16) * h->P.nlevels; }
 
 int ensure_geometry(msorb_extractor* h, int rows, int cols) {
@@ -313,17 +323,17 @@ int ensure_batch(msorb_extractor* h, int n_images) {
     if ((rc = h->d_level_count.ensure((size_t)n_images * g.nlevels))) return rc;
     if ((rc = h->d_img_total.ensure(n_images))) return rc;
     if ((rc = h->d_img_base.ensure(n_images + 1 + kMaxGroups))) return rc;
-    if ((rc = h->d_sel_count.ensure(n_images))) return rc;
+    if ((rc = h->d_sel_count.ensure(std::max(n_images, 4)))) return rc;
     if ((rc = h->d_sel.ensure((size_t)n_images * h->sel_stride))) return rc;
     if ((rc = h->h_level_count.ensure((size_t)n_images * g.nlevels))) return rc;
     if ((rc = h->h_img_base.ensure(n_images + 1))) return rc;
-    if ((rc = h->h_sel_count.ensure(n_images))) return rc;
+    if ((rc = h->h_sel_count.ensure(std::max(n_images, 4)))) return rc;
     if ((rc = h->h_sel.ensure((size_t)n_images * h->sel_stride))) return rc;
-    if ((rc = h->h_mono.ensure(n_images))) return rc;
+    if ((rc = h->h_mono.ensure(std::max(n_images, 4)))) return rc;
     if ((rc = h->d_label.ensure((size_t)n_images * g.slots_per_image))) return rc;
     if ((rc = h->d_sel_pt.ensure((size_t)n_images * h->sel_stride))) return rc;
     if ((rc = h->d_sel_n.ensure((size_t)n_images * g.nlevels))) return rc;
-    if ((rc = h->d_mono.ensure(n_images))) return rc;
+    if ((rc = h->d_mono.ensure(std::max(n_images, 4)))) return rc;
     return MSORB_OK;
 }
 
@@ -534,8 +544,15 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
                         std::min(capacity, sel_stride), n, s, h->sem);
         mark(6, s);
         if (!h->skip_count_copies) {  // a fused caller takes the counts from the device itself
-            HIPCHK(hipMemcpyAsync(h->h_sel_count.p + first, h->d_sel_count.p + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
-            HIPCHK(hipMemcpyAsync(h->h_mono.p + first, h->d_mono.p + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+            if (n_images <= 4 && first == 0) {   // per-frame call: by copy kernel (the buffers hold >= 4 ints)
+                int crc;
+                if ((crc = frame_copy(h, h->h_sel_count.p, h->d_sel_count.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s)) ||
+                    (crc = frame_copy(h, h->h_mono.p, h->d_mono.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s)))
+                    return crc;
+            } else {
+                HIPCHK(hipMemcpyAsync(h->h_sel_count.p + first, h->d_sel_count.p + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipMemcpyAsync(h->h_mono.p + first, h->d_mono.p + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+            }
         }
         first += n;
     }
@@ -793,6 +810,7 @@ int msorb_extractor_create(int nfeatures, float scale_factor, int nlevels, int i
         h->knobs.split_no_peer = getenv("MSORB_SPLIT_NO_PEER") != nullptr;
         h->knobs.force_peer_pyramid = getenv("MSORB_FORCE_PEER_PYRAMID") != nullptr;
         h->knobs.host_threads = (e = getenv("MSORB_HOST_THREADS")) ? atoi(e) : 0;
+        h->knobs.frame_sdma = (e = getenv("MSORB_FRAME_COPIES")) && std::string(e) == "sdma";   // per-frame uploads / read-backs by hipMemcpyAsync (A/B of launch_blit)
     }
     if (hipDeviceGetAttribute(&h->lds_per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || h->lds_per_block <= 0)
         h->lds_per_block = 64 * 1024;
@@ -989,13 +1007,12 @@ int msorb_extract(msorb_extractor* h, const uint8_t* image, int rows, int cols, 
         if ((rc = h->h_out_pin.ensure(blk_bytes))) return rc;
         pk = reinterpret_cast<msorb_keypoint*>(h->h_out_pin.p);
         pd = h->h_out_pin.p + o_desc;
-        HIPCHK(hipMemcpyAsync(h->d_pyr.p + g0.plane_off, h->h_img_pin.p, (size_t)g0.pitch * rows, hipMemcpyHostToDevice,
-                              h->stream));
+        if ((rc = frame_copy(h, h->d_pyr.p + g0.plane_off, h->h_img_pin.p, (size_t)g0.pitch * rows, hipMemcpyHostToDevice, h->stream))) return rc;
         h->defer_sync = true;
         rc = run_pipeline(h, l0, 1, lap0, lap1, reinterpret_cast<msorb_keypoint*>(h->d_out1.p), h->d_out1.p + o_desc, cap, &n, &mono);
         h->defer_sync = false;
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(h->h_out_pin.p, h->d_out1.p, blk_bytes, hipMemcpyDeviceToHost, h->stream));
+        if ((rc = frame_copy(h, h->h_out_pin.p, h->d_out1.p, blk_bytes, hipMemcpyDeviceToHost, h->stream))) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->h_pyr_async) HIPCHK(hipStreamSynchronize(h->pyr_stream));
         HIPCHK(hipGetLastError());
@@ -1077,9 +1094,9 @@ int msorb::extract_stereo_sink(msorb_extractor* h, const uint8_t* left, const ui
     // pageable rows -> pinned planes -> device, one eye at a time: the left plane rides PCIe while the right one is staged
     hipStream_t s = h->stream;
     for (int y = 0; y < rows; y++) memcpy(h->h_img_pin.p + (size_t)y * g0.pitch, left + (size_t)y * stride_left, cols);
-    HIPCHK(hipMemcpyAsync(h->d_st_img.p, h->h_img_pin.p, plane, hipMemcpyHostToDevice, s));
+    if ((rc = frame_copy(h, h->d_st_img.p, h->h_img_pin.p, plane, hipMemcpyHostToDevice, s))) return rc;
     for (int y = 0; y < rows; y++) memcpy(h->h_img_pin.p + plane + (size_t)y * g0.pitch, right + (size_t)y * stride_right, cols);
-    HIPCHK(hipMemcpyAsync(h->d_st_img.p + plane, h->h_img_pin.p + plane, plane, hipMemcpyHostToDevice, s));
+    if ((rc = frame_copy(h, h->d_st_img.p + plane, h->h_img_pin.p + plane, plane, hipMemcpyHostToDevice, s))) return rc;
     LevelView l0{h->d_st_img.p, plane, g0.pitch, cols, rows};
     uint8_t* const blk = h->d_st_block.p;
     msorb_keypoint* const d_kps = reinterpret_cast<msorb_keypoint*>(blk);
@@ -1125,7 +1142,7 @@ int msorb::extract_stereo_sink(msorb_extractor* h, const uint8_t* left, const ui
         if ((rc = sink(ctx, so))) { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(h->copy_stream); return rc; }
         HIPCHK(hipStreamSynchronize(h->copy_stream));
     } else {
-        HIPCHK(hipMemcpyAsync(o, blk, out_bytes, hipMemcpyDeviceToHost, s));
+        if ((rc = frame_copy(h, o, blk, out_bytes, hipMemcpyDeviceToHost, s))) return rc;
     }
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());

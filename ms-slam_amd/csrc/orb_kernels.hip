@@ -8,6 +8,8 @@
 //
 // Arithmetic follows SURVEY.md Appendix A / oracle/cvprims.h exactly (bit-exact contract).
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -1199,16 +1201,31 @@ __device__ __forceinline__ int wave_sum_dpp(int v) {
 // are two slow-class ones): adding 1.5 * 2^23 leaves round-to-nearest-even of x in the low mantissa bits.
 __device__ __forceinline__ int rint_small(float x) { return __float_as_int(__fadd_rn(x, 12582912.0f)) - 0x4B400000; }
 
-constexpr int kPatchPitch = 40;  // bytes per staged patch row: 37 pixels from a 4-byte boundary
-constexpr int kPatchSlot = 37 * kPatchPitch + 8;  // one keypoint's blurred patch in LDS (8-byte aligned slots)
+constexpr int kBlkSlot = 1600;  // one keypoint's blurred neighbourhood in LDS: 10 x 10 blocks of 16 bytes, block (a, b) at (10 a + b) * 16
 typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from any 4-byte boundary
-constexpr int kKpPerWave = 4;  // keypoints handled back to back by one wave (amortises the per-lane table loads)
+constexpr int kKpPerWave = 4;   // keypoints handled back to back by one wave (amortises the per-lane table loads)
+#ifndef MSORB_DESC_RAW_DEPTH
+#define MSORB_DESC_RAW_DEPTH 4  // keypoints whose IC-angle patch loads are in flight beyond the one being consumed (4 = all of the wave's, measured best: 0.2777 (r4 kernel) / 0.273 / 0.270 / 0.264 / 0.265 ms for r4 / 1 / 2 / 3 / 4)
+#endif
+
+// LDS-DMA (global_load_lds_dwordx4): lane l fetches the 16 bytes at sbase + voff(l) and the hardware writes them to
+// LDS[lds_dst + 16 l] — no VGPR is the destination, so a load in flight costs no register.  M0 carries the wave-uniform
+// destination; it is compiler-reserved, so it is saved, set and restored inside the one statement (guide section 5.7).  The
+// compiler does not count this load: the reader waits for vmcnt itself (glds_wait_all).
+__device__ __forceinline__ void glds16(const uint8_t* sbase, uint32_t voff, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void describe_kernel(PyramidView pyr, PyramidView blur, const SelRec* __restrict__ sel,
                                                        const int* __restrict__ sel_count, int sel_stride,
                                                        LevelScale scales, msorb_keypoint* __restrict__ kps,
                                                        uint8_t* __restrict__ desc, int out_stride, int atan2_fma) {
-    __shared__ __attribute__((aligned(16))) uint8_t patch[4 * kKpPerWave][kPatchSlot];  // one slot per (wave, keypoint)
+    __shared__ __attribute__((aligned(16))) uint8_t patch[4 * kKpPerWave][kBlkSlot];  // one slot per (wave, keypoint)
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs; give every image to ONE XCD so that the
     // overlapping keypoint patches of an image are served by a single L2 instead of being fetched by all eight.
     int img = blockIdx.y, bx = blockIdx.x;
@@ -1219,16 +1236,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         bx = (int)(j % gridDim.x);
     }
     const int lane = threadIdx.x & 63;
-    const int k_first = __builtin_amdgcn_readfirstlane((bx * 4 + (int)(threadIdx.x >> 6)) * kKpPerWave);  // wave-uniform -> SALU
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int k_first = (bx * 4 + wave) * kKpPerWave;  // wave-uniform -> SALU
     const int n_sel = sel_count[img];
     if (k_first >= n_sel) return;
-    // per-lane constants, loaded once.  Both patches are read with 16-byte loads, three lanes per patch row (lane = 3 row' +
-    // seg, 21 rows per load instruction, lane 63 idles): 2 + 2 load instructions per keypoint instead of 5 + 6 dword ones.
-    // The texture addresser spends its cycles per lane address, not per byte (PMC, round 4: TCP_TOTAL_CACHE_ACCESSES = 0.93
-    // per CU cycle with dword loads), so the same bytes in a quarter of the addresses is what shortens this kernel.
-    // IC-angle patch: row v = row - 15 from the 4-byte boundary at or below x - 15; after the byte re-alignment below, dword
-    // col = 4 seg + d (col < 8) holds the pixels u = 4 col - 15 .. 4 col - 12.  wu = (u + 16) per byte inside the circle
-    // (0 outside), vm = 1 / 0: two udot4 chains give sum(u I), sum(I).  seg 2 only feeds the alignment of col 7.
+    // IC-angle patch (raw level, registers): 16-byte loads, three lanes per patch row (lane = 3 row' + seg, 21 rows per load
+    // instruction, lane 63 idles): 2 load instructions per keypoint.  The texture addresser spends its cycles per lane address,
+    // not per byte (PMC, round 4), so the same bytes in a quarter of the addresses is what shortened this kernel in round 4.
+    // Row v = row - 15 from the 4-byte boundary at or below x - 15; after the byte re-alignment below, dword col = 4 seg + d
+    // (col < 8) holds the pixels u = 4 col - 15 .. 4 col - 12.  wu = (u + 16) per byte inside the circle (0 outside), vm = 1 / 0:
+    // two udot4 chains give sum(u I), sum(I).  seg 2 only feeds the alignment of col 7.
     const int seg = lane % 3, row3 = lane / 3;
     uint32_t wu[2][4], vm[2][4];
     uint32_t rrow_c[2];   // clamped IC-angle row of this lane in load t (rows of no patch row repeat the last one: same line)
@@ -1257,9 +1274,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         vrow[t] = row - 15;
     }
     const uint32_t seg16 = 16u * (uint32_t)seg;
-    // blurred patch (blocked plane, orb_device.h blur_tile_off): 10 x 10 blocks of 4 x 4 pixels hold the 37 x 37 neighbourhood
-    // wherever it starts; slot = lane + 64 t -> block row slot / 10, block column slot % 10 (slots past 99 repeat block row 9):
-    // ten neighbouring lanes read 160 contiguous bytes
+    // Blurred neighbourhood (blocked plane, orb_device.h blur_tile_off): the 37 x 37 pixels a descriptor samples lie in 10 x 10
+    // blocks of 4 x 4 pixels wherever they start.  They go straight from L2 / HBM into the keypoint's LDS slot by LDS-DMA: lane l
+    // of instruction t owns block l + 64 t = (block row (l + 64 t) / 10, block column (l + 64 t) % 10), which the hardware puts
+    // at slot + 16 (l + 64 t): the slot is block-indexed, a pixel (rr, qq) of the 40 x 40 block area sits at
+    // ((rr >> 2) 10 + (qq >> 2)) 16 + (rr & 3) 4 + (qq & 3).  Ten neighbouring lanes read 160 contiguous bytes.  (Rounds 1-4
+    // staged these blocks through registers and re-wrote them row-major: 8 VGPRs per keypoint in flight, 8 conditional ds_write.)
     uint32_t bbrow[2], bbcol16[2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -1277,40 +1297,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     }
     const float factor_pi = (float)(3.1415926535897932384626433832795 / 180.0);
 
-    // Software pipeline over the wave's keypoints: while keypoint k is being processed the 11 patch loads of keypoint
-    // k+1 are already in flight (and the record of k+2 is being fetched) — the kernel is bound by the latency of these
-    // scattered loads, not by arithmetic.
-    struct Loads { u32x4u rp[2]; uint32_t rsh[2]; uint4 bp[2]; int poff, oy; };
-    auto scalar_rec = [](const SelRec& v) {
-        // every lane loaded the same record: move it to scalar registers so that everything derived from it (level view,
-        // row pointers, strides) is SALU work and the loads use an SGPR base + 32-bit lane offset
-        SelRec r;
-        uint32_t w[3];
-        memcpy(w, &v, sizeof(w));
-        for (int i = 0; i < 3; i++) w[i] = __builtin_amdgcn_readfirstlane(w[i]);
-        memcpy(&r, w, sizeof(w));
-        return r;
-    };
-    auto issue = [&](const SelRec& r, Loads& L) {
-        // Both patches depend only on (x, y, level).  The 256 test pairs gather 512 bytes from the blurred 37x37
-        // neighbourhood (|offset| <= 18 after rotation); a direct gather touches ~35 cache lines per load instruction,
-        // so that patch goes to LDS with row-coherent loads: 37 rows x 48 bytes from the 4-byte boundary at or below
-        // x - 18 (40 are kept).  The 31x31 IC-angle patch: 31 rows x 48 bytes (36 used).  The bytes past the patch are in
-        // the same image: a keypoint is >= 19 pixels from the border, x + 29 <= width + 9 wraps into the next row at most.
-        const LevelView lv = pyr.lv[r.level];
+    // The wave's four selection records, fetched together and moved to scalar registers: everything derived from them (level
+    // view, row pointers, strides, the LDS-DMA bases) is SALU work, and no keypoint's addresses wait for an earlier keypoint.
+    // The last wave of an image repeats the image's last keypoint in its unused places (no exit inside the sequence: the four
+    // keypoints are one straight line of code; only the stores are conditional).
+    const SelRec* recs = sel + (size_t)img * sel_stride;
+    SelRec R[kKpPerWave];
+    {
+        SelRec rv[kKpPerWave];
+#pragma unroll
+        for (int kk = 0; kk < kKpPerWave; kk++) rv[kk] = recs[min(k_first + kk, n_sel - 1)];
+#pragma unroll
+        for (int kk = 0; kk < kKpPerWave; kk++) {
+            uint32_t w[3];
+            memcpy(w, &rv[kk], sizeof(w));
+            for (int i = 0; i < 3; i++) w[i] = __builtin_amdgcn_readfirstlane(w[i]);
+            memcpy(&R[kk], w, sizeof(w));
+        }
+    }
+    uint8_t* const lp0 = patch[wave * kKpPerWave];
+    // LDS byte address of the wave's first slot (a generic pointer to __shared__ is aperture base | offset: C-style cast to address space 3)
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lp0);
+    // blurred blocks of all four keypoints: on their way before anything else (no register holds them)
+    int RQ[kKpPerWave];   // (18 + oy) << 8 | (18 + poff): where the keypoint sits inside its 40 x 40 block area
+#pragma unroll
+    for (int kk = 0; kk < kKpPerWave; kk++) {
+        const SelRec& r = R[kk];
         const LevelView bv = blur.lv[r.level];
-        // blurred: the blocks from (x - 18) >> 2, (y - 18) >> 2 on; poff / oy = where the neighbourhood starts inside the first one
-        L.poff = (r.x - 18) & 3;
-        L.oy = (r.y - 18) & 3;
+        RQ[kk] = ((18 + ((r.y - 18) & 3)) << 8) | (18 + ((r.x - 18) & 3));
         const uint8_t* bbase = bv.base + (size_t)img * bv.img_stride + (size_t)((r.y - 18) >> 2) * ((size_t)bv.pitch * 4) +
                                (size_t)((r.x - 18) >> 2) * 16;
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-            // (only the lanes that own a block ask for one: the texture addresser spends a cycle per lane address, needed or not)
-            if (t == 0 || lane < 100 - 64)
-                L.bp[t] = *reinterpret_cast<const uint4*>(bbase + (size_t)(__umul24(bbrow[t], (uint32_t)bv.pitch * 4u) + bbcol16[t]));
-        // (level 0 may be the caller's own image with any row stride: the 4-byte phase is taken per row)
-        // addresses = scalar base + 32-bit lane offset (the global_load saddr form: no 64-bit VALU address math)
+        const uint32_t pitch4 = (uint32_t)bv.pitch * 4u;
+        const uint32_t dst = lds0 + (uint32_t)kk * kBlkSlot;
+        glds16(bbase, __umul24(bbrow[0], pitch4) + bbcol16[0], dst);
+        if (lane < 100 - 64) glds16(bbase, __umul24(bbrow[1], pitch4) + bbcol16[1], dst + 1024u);
+    }
+    // IC-angle patch loads, MSORB_DESC_RAW_DEPTH keypoints ahead of the one whose moments are being summed
+    struct Raw { u32x4u rp[2]; uint32_t rsh[2]; };
+    auto issue_raw = [&](const SelRec& r, Raw& L) {
+        // 31 rows x 48 bytes (36 used) from the 4-byte boundary at or below x - 15.  The bytes past the patch are in the same
+        // image: a keypoint is >= 19 pixels from the border.  (Level 0 may be the caller's own image with any row stride: the
+        // 4-byte phase is taken per row.)  Addresses = scalar base + 32-bit lane offset (the global_load saddr form).
+        const LevelView lv = pyr.lv[r.level];
         const uint8_t* rrow = lv.base + (size_t)img * lv.img_stride + (size_t)(r.y - 15) * lv.pitch + (r.x - 15) - 4;
         const uint32_t rlow = (uint32_t)reinterpret_cast<uintptr_t>(rrow);
 #pragma unroll
@@ -1321,33 +1349,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                 L.rp[t] = *reinterpret_cast<const u32x4u*>(rrow + (size_t)(o + seg16 + 4u - L.rsh[t]));
         }
     };
-    const SelRec* recs = sel + (size_t)img * sel_stride;
-    SelRec r_cur = scalar_rec(recs[k_first]);
-    Loads L_next;
-    issue(r_cur, L_next);
-    SelRec r_pre = recs[min(k_first + 1, n_sel - 1)];
-    // Phase A, per keypoint: moments of the IC-angle patch (wave-uniform totals) and the blurred patch into the keypoint's
-    // own LDS slot.  Phase V, once per wave: angle, cos, sin of all four keypoints at once — lane kk computes keypoint kk,
-    // so the atan2 polynomial and the double-precision sincos run once per wave instead of once per keypoint.
-    // Phase B, per keypoint: steered BRIEF from its LDS slot.
-    // The last wave of an image repeats the image's last keypoint in its unused places (no exit inside the sequence: the
-    // four keypoints are one straight line of code, so the pre-issued loads stay in flight across them; an early exit made
-    // the compiler copy them at the merge points, i.e. wait for them); only the stores are conditional.
-    SelRec R[kKpPerWave];
-    int M10[kKpPerWave], M01[kKpPerWave], POFF[kKpPerWave];
-    uint8_t* const lp0 = patch[(threadIdx.x >> 6) * kKpPerWave];
+    Raw Lq[kKpPerWave];
+#pragma unroll
+    for (int kk = 0; kk < MSORB_DESC_RAW_DEPTH && kk < kKpPerWave; kk++) issue_raw(R[kk], Lq[kk]);
+    // Phase A, per keypoint: moments of the IC-angle patch (wave-uniform totals).  Phase V, once per wave: angle, cos, sin of all
+    // four keypoints at once — lane kk computes keypoint kk, so the atan2 polynomial and the double-precision sincos run once
+    // per wave instead of once per keypoint.  Phase B, per keypoint: steered BRIEF from its LDS slot.
+    int M10[kKpPerWave], M01[kKpPerWave];
 #pragma unroll
     for (int kk = 0; kk < kKpPerWave; kk++) {
-        const int k = k_first + kk;
-        R[kk] = r_cur;
-        const Loads L = L_next;
-        if (kk + 1 < kKpPerWave) {
-            r_cur = scalar_rec(r_pre);
-            issue(r_cur, L_next);
-            r_pre = recs[min(k + 2, n_sel - 1)];
-        }
-        POFF[kk] = L.poff;
-
+        if (kk + MSORB_DESC_RAW_DEPTH < kKpPerWave) issue_raw(R[kk + MSORB_DESC_RAW_DEPTH], Lq[kk + MSORB_DESC_RAW_DEPTH]);
+        const Raw& L = Lq[kk];
         // IC_Angle: integer moments over the 749-pixel circular patch (un-blurred level).  The next dword of the row is the
         // next register, and for the last one the next lane's first: alignbyte undoes the 4-byte alignment of the loads, so
         // the per-lane weights do not depend on the keypoint.
@@ -1372,18 +1384,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         }
         M10[kk] = wave_sum_dpp(m10);  // wave-uniform (SGPR) totals
         M01[kk] = wave_sum_dpp(m01);
-        uint8_t* lp = lp0 + kk * kPatchSlot;
-        // block (block row, block column) = rows 4 brow - oy .. + 3 of the patch, dword column bcol of each: kept if 0 <= row < 37
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const uint4 v = L.bp[t];
-            const int pr = (t == 0 || lane < 100 - 64) ? (int)(4u * bbrow[t]) - L.oy : 64;   // lanes without a block write nothing
-            uint8_t* w = lp + pr * kPatchPitch + (bbcol16[t] >> 2);
-            if ((unsigned)pr < 37u) *reinterpret_cast<uint32_t*>(w) = v.x;
-            if ((unsigned)(pr + 1) < 37u) *reinterpret_cast<uint32_t*>(w + kPatchPitch) = v.y;
-            if ((unsigned)(pr + 2) < 37u) *reinterpret_cast<uint32_t*>(w + 2 * kPatchPitch) = v.z;
-            if ((unsigned)(pr + 3) < 37u) *reinterpret_cast<uint32_t*>(w + 3 * kPatchPitch) = v.w;
-        }
     }
     // Phase V
     int m10v = M10[0], m01v = M01[0];
@@ -1393,6 +1393,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const float angle_v = fast_atan2_deg((float)m01v, (float)m10v, atan2_fma);
     float a_v, b_v;
     glibc_sincosf<true>(__fmul_rn(angle_v, factor_pi), &b_v, &a_v);  // a = cos, b = sin (ORBextractor.cc:112)
+    glds_wait_all();   // the four slots have landed (the wave reads only what its own lanes' DMA wrote: no barrier needed)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // Phase B
@@ -1402,18 +1403,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         const float angle = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angle_v), kk));
         const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_v), kk));
         const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_v), kk));
-        const uint8_t* bc = lp0 + kk * kPatchSlot + 18 * kPatchPitch + 18 + POFF[kk];
+        const uint8_t* bc = lp0 + kk * kBlkSlot;
+        // cvRound(v) + offset in one subtract: the magic-number rounding leaves the integer in the low mantissa bits
+        const int r_bias = 0x4B400000 - (RQ[kk] >> 8), q_bias = 0x4B400000 - (RQ[kk] & 255);
+        auto tap = [&](float x, float y) -> int {
+            // rr = cvRound(x*b + y*a) + 18 + oy, qq = cvRound(x*a - y*b) + 18 + poff (contraction order of oracle/orb_extractor_oracle.cc),
+            // then the block-indexed address: 160 (rr >> 2) + 4 (rr & 3) + 16 (qq >> 2) + (qq & 3) = 4 rr + 144 (rr >> 2) + qq + 12 (qq >> 2)
+            const uint32_t rr = (uint32_t)(__float_as_int(__fadd_rn(__fmaf_rn(x, b, __fmul_rn(y, a)), 12582912.0f)) - r_bias);
+            const uint32_t qq = (uint32_t)(__float_as_int(__fadd_rn(__fmaf_rn(x, a, -__fmul_rn(y, b)), 12582912.0f)) - q_bias);
+            const uint32_t off = __umul24(rr >> 2, 144u) + __umul24(qq >> 2, 12u) + (rr << 2) + qq;
+            return bc[off];
+        };
         unsigned long long word[4];
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-            const float x0 = patx0[w], y0 = paty0[w], x1 = patx1[w], y1 = paty1[w];
-            // cvRound(x*b + y*a), cvRound(x*a - y*b) with the contraction order of oracle/orb_extractor_oracle.cc
-            const int r0 = rint_small(__fmaf_rn(x0, b, __fmul_rn(y0, a)));
-            const int q0 = rint_small(__fmaf_rn(x0, a, -__fmul_rn(y0, b)));
-            const int r1 = rint_small(__fmaf_rn(x1, b, __fmul_rn(y1, a)));
-            const int q1 = rint_small(__fmaf_rn(x1, a, -__fmul_rn(y1, b)));
-            const int t0 = bc[r0 * kPatchPitch + q0];
-            const int t1 = bc[r1 * kPatchPitch + q1];
+            const int t0 = tap(patx0[w], paty0[w]);
+            const int t1 = tap(patx1[w], paty1[w]);
             word[w] = __ballot(t0 < t1);
         }
         if (k_first + kk >= n_sel) break;  // wave-uniform; nothing but the stores is left
@@ -1452,6 +1457,21 @@ __global__ __launch_bounds__(256) void stage_level0_kernel(const uint8_t* __rest
     if (x + 2 < cols) v |= (uint32_t)s[2] << 16;
     if (x + 3 < cols) v |= (uint32_t)s[3] << 24;
     *reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.z * dst_image_stride + (size_t)blockIdx.y * dst_pitch + x) = v;
+}
+// Copies between pinned host memory and device memory done by the compute units instead of the SDMA engines, for the
+// per-frame calls: a frame's transfers are 0.1-1 MB, where an SDMA copy costs ~8-10 us of fixed latency before it moves a byte
+// and another ~10 us before the next command of the stream starts (profiles/round4_frame_trace.txt: three uploads = 68 us in
+// front of the first kernel).  A kernel that reads / writes the mapped host pointer (hipHostMalloc memory is device accessible)
+// queues behind and in front of the other kernels of the stream like any launch (~1.5 us boundaries) and moves the bytes at PCIe
+// rate.  16 bytes per lane, a grid-stride loop; both pointers 16-byte aligned, `bytes` rounded up to 16 by the caller's buffers.
+__global__ __launch_bounds__(256) void blit16_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+void launch_blit(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    const size_t n16 = (bytes + 15) / 16;
+    if (n16 == 0) return;
+    const int blocks = (int)std::min<size_t>((n16 + 255) / 256, 1024);
+    hipLaunchKernelGGL(blit16_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4*>(dst), reinterpret_cast<const uint4*>(src), n16);
 }
 void launch_stage_level0(const LevelView& src, uint8_t* dst, int dst_pitch, size_t dst_image_stride, int n_images, hipStream_t s) {
     hipLaunchKernelGGL(stage_level0_kernel, dim3((src.w + 1023) / 1024, src.h, n_images), dim3(256), 0, s, src.base, (size_t)src.pitch,
