@@ -125,7 +125,7 @@ struct DevBuf {
         if (count <= n) return MSORB_OK;
         if (p) (void)hipFree(p);
         p = nullptr; n = 0;
-        HIPCHK(hipMalloc((void**)&p, count * sizeof(T)));
+        HIPCHK(hipMalloc((void**)&p, count * sizeof(T) + 16));   // + 16: small_copy moves whole 16-byte units
         n = count;
         return MSORB_OK;
     }
@@ -139,7 +139,7 @@ struct PinBuf {
         if (count <= n) return MSORB_OK;
         if (p) (void)hipHostFree(p);
         p = nullptr; n = 0;
-        HIPCHK(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&p, count * sizeof(T) + 16, hipHostMallocDefault));
         n = count;
         return MSORB_OK;
     }
@@ -169,7 +169,7 @@ struct msorb_extractor {
     // host-synchronised stages: debugging), MSORB_QUADTREE=host (DistributeOctTree on the host twin), MSORB_HOST_THREADS (its
     // worker threads), MSORB_SPLIT_NO_PEER (test hook: the two-device gather staged through the host), MSORB_FORCE_PEER_PYRAMID
     // (test hook: msorb_stereo_matches pulls the right pyramid over the peer path even on one device)
-    struct Knobs { bool serial_pipeline = false, quadtree_host = false, split_no_peer = false, force_peer_pyramid = false, frame_sdma = false; int host_threads = 0; } knobs;
+    struct Knobs { bool serial_pipeline = false, quadtree_host = false, split_no_peer = false, force_peer_pyramid = false; int host_threads = 0; } knobs;
     int lds_per_block = 64 * 1024;   // hipDeviceAttributeMaxSharedMemoryPerBlock of the handle's device
     static constexpr bool capturing = false;   // (no graph capture: plain launches; see tools/experiments/README.md)
     bool defer_sync = false;     // enqueue only, the caller appends more work and synchronises (msorb_extract[_stereo])
@@ -239,14 +239,9 @@ namespace {
 // reaches it), but its FIRST pass divides every initial column unconditionally (ORBextractor.cc:610-681 runs before any quota
 // check): a level returns up to max(quota + 3, 4 * nIni) keypoints, nIni = round(width / height) <= 4 for every camera the
 // reference is configured for.  16 more rows per level cover that whatever the quota (tiny nfeatures on wide images).
-// per-frame transfer between a pinned block and device memory on stream s: a copy kernel (launch_blit), or the SDMA engine under
-// MSORB_FRAME_COPIES=sdma.  Buffers are whole allocations (hipMalloc / hipHostMalloc: 256-byte aligned, sizes padded by the callers).
-int frame_copy(msorb_extractor* h, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
-    if (h->knobs.frame_sdma || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15)) {
-        HIPCHK(hipMemcpyAsync(dst, src, bytes, kind, s));
-        return MSORB_OK;
-    }
-    launch_blit(dst, src, bytes, s);
+// per-frame transfer between a pinned block and device memory on stream s (orb_kernels.hip small_copy)
+int frame_copy(msorb_extractor*, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
+    HIPCHK(small_copy(dst, src, bytes, kind, s));
     return MSORB_OK;
 }
 int capacity_of(const msorb_extractor* h) { return h->P.nfeatures + (3 + 16) * h->P.nlevels; }
@@ -810,7 +805,6 @@ int msorb_extractor_create(int nfeatures, float scale_factor, int nlevels, int i
         h->knobs.split_no_peer = getenv("MSORB_SPLIT_NO_PEER") != nullptr;
         h->knobs.force_peer_pyramid = getenv("MSORB_FORCE_PEER_PYRAMID") != nullptr;
         h->knobs.host_threads = (e = getenv("MSORB_HOST_THREADS")) ? atoi(e) : 0;
-        h->knobs.frame_sdma = (e = getenv("MSORB_FRAME_COPIES")) && std::string(e) == "sdma";   // per-frame uploads / read-backs by hipMemcpyAsync (A/B of launch_blit)
     }
     if (hipDeviceGetAttribute(&h->lds_per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || h->lds_per_block <= 0)
         h->lds_per_block = 64 * 1024;

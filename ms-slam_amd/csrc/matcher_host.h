@@ -52,7 +52,7 @@ struct DBuf {
         if (count <= n) return MSORB_OK;
         if (p) (void)hipFree(p);
         p = nullptr; n = 0;
-        HIPCHK(hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)));
+        HIPCHK(hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T) + 16));   // + 16: small_copy moves whole 16-byte units
         n = std::max<size_t>(count, 1);
         return MSORB_OK;
     }
@@ -67,7 +67,7 @@ struct HBuf {
         if (count <= n) return MSORB_OK;
         if (p) (void)hipHostFree(p);
         p = nullptr; n = 0;
-        HIPCHK(hipHostMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T) + 16, hipHostMallocDefault));
         n = std::max<size_t>(count, 1);
         return MSORB_OK;
     }
@@ -153,11 +153,11 @@ int run_window_search(msorb_frame* f, int M, const WinQuery* q, const uint8_t* f
     }
     if (q) {
         std::memcpy(f->h_in.p, q, qb);
-        HIPCHK(hipMemcpyAsync(f->d_q.p, f->h_in.p, qb, hipMemcpyHostToDevice, s));
+        HIPCHK(small_copy(f->d_q.p, f->h_in.p, qb, hipMemcpyHostToDevice, s));
     }
     if (qdesc) {
         std::memcpy(f->h_in.p + qb, qdesc, db);
-        HIPCHK(hipMemcpyAsync(f->d_qdesc.p, f->h_in.p + qb, db, hipMemcpyHostToDevice, s));
+        HIPCHK(small_copy(f->d_qdesc.p, f->h_in.p + qb, db, hipMemcpyHostToDevice, s));
     }
     uint8_t* const h_occ = f->h_in.p + qb + db;
     TopK* const topk = f->h_topk.p;
@@ -167,10 +167,10 @@ int run_window_search(msorb_frame* f, int M, const WinQuery* q, const uint8_t* f
         if (!(ready && n_rounds == 0)) {
             if (f->N) {
                 std::memcpy(h_occ, occ.data(), f->N);  // the previous round's copy has completed (stream synchronised below)
-                HIPCHK(hipMemcpyAsync(f->d_occ.p, h_occ, f->N, hipMemcpyHostToDevice, s));
+                HIPCHK(small_copy(f->d_occ.p, h_occ, f->N, hipMemcpyHostToDevice, s));
             }
             launch_window_topk(f->view(), f->d_q.p, d_qdesc, q0, M, f->d_topk.p, s, 1, 0, 0, nullptr, lanes);
-            HIPCHK(hipMemcpyAsync(topk + q0, f->d_topk.p + q0, (size_t)(M - q0) * sizeof(TopK), hipMemcpyDeviceToHost, s));
+            HIPCHK(small_copy(topk + q0, f->d_topk.p + q0, (size_t)(M - q0) * sizeof(TopK), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
         }
         std::vector<uint8_t> snap = occ;

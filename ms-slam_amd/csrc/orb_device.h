@@ -51,6 +51,8 @@ size_t quadtree_lds_bytes(const QtLevels& lv);
 void upload_patch_tables(const int8_t* pattern, const int* umax, hipStream_t stream);
 // device <-> pinned-host copy by a kernel (per-frame calls; orb_kernels.hip blit16_kernel); 16-byte aligned pointers
 void launch_blit(void* dst, const void* src, size_t bytes, hipStream_t s);
+// pinned host <-> device on a stream: the copy kernel, or hipMemcpyAsync for unaligned pointers / MSORB_FRAME_COPIES=sdma
+hipError_t small_copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
 void launch_stage_level0(const LevelView& src, uint8_t* dst, int dst_pitch, size_t dst_image_stride, int n_images, hipStream_t s);
 // The [OpenCV-recall] semantics that a real OpenCV build could turn out to differ in, as one table (msorb_semantics of the C
 // ABI, oracle/cvprims.h Semantics): non-default entries route to the kernels that take them at run time.

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <string>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -1466,6 +1467,17 @@ __global__ __launch_bounds__(256) void stage_level0_kernel(const uint8_t* __rest
 // rate.  16 bytes per lane, a grid-stride loop; both pointers 16-byte aligned, `bytes` rounded up to 16 by the caller's buffers.
 __global__ __launch_bounds__(256) void blit16_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+// A per-frame transfer between a PINNED host block and device memory on stream s: the copy kernel when both pointers are 16-byte
+// aligned (whole hipMalloc / hipHostMalloc blocks and 16-byte offsets into them; the kernel moves whole 16-byte units, so the
+// allocations are padded to 16), hipMemcpyAsync otherwise — or always under MSORB_FRAME_COPIES=sdma (read once per process: the
+// A/B switch of this choice).
+hipError_t small_copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
+    static const bool sdma = [] { const char* e = getenv("MSORB_FRAME_COPIES"); return e && std::string(e) == "sdma"; }();
+    if (bytes == 0) return hipSuccess;
+    if (sdma || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15)) return hipMemcpyAsync(dst, src, bytes, kind, s);
+    launch_blit(dst, src, bytes, s);
+    return hipSuccess;
 }
 void launch_blit(void* dst, const void* src, size_t bytes, hipStream_t s) {
     const size_t n16 = (bytes + 15) / 16;

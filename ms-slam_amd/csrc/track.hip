@@ -311,11 +311,12 @@ struct LastLayout {
 
 // packed transfer blocks of one frame's local map points (m entries): one H2D, one D2H
 struct MpLayout {
-    size_t o_pos, o_nrm, o_max, o_min, o_desc, o_flags, in_bytes;                  // input block
+    size_t o_pos, o_nrm, o_max, o_min, o_desc, o_flags, o_frustum, in_bytes;       // input block (the frustum rides at its end: one upload)
     size_t o_topk, o_px, o_py, o_pxr, o_depth, o_level, o_vc, o_inview, out_bytes;  // output block
     explicit MpLayout(size_t m) {
         o_pos = 0; o_nrm = o_pos + 12 * m; o_max = o_nrm + 12 * m; o_min = o_max + 4 * m; o_desc = o_min + 4 * m;
-        o_flags = o_desc + 32 * m; in_bytes = (o_flags + m + 63) & ~(size_t)63;
+        o_flags = o_desc + 32 * m; o_frustum = (o_flags + m + 63) & ~(size_t)63;
+        in_bytes = (o_frustum + sizeof(msorb_frustum) + 63) & ~(size_t)63;
         o_topk = 0; o_px = o_topk + sizeof(TopK) * m; o_py = o_px + 4 * m; o_pxr = o_py + 4 * m; o_depth = o_pxr + 4 * m;
         o_level = o_depth + 4 * m; o_vc = o_level + 4 * m; o_inview = o_vc + 4 * m; out_bytes = (o_inview + m + 63) & ~(size_t)63;
     }
@@ -478,9 +479,9 @@ int upload_local_points(msorb_frame* f, const LocalPointsCall& c) {
     std::memcpy(h + L.o_desc, c.mp_desc, 32 * m);
     for (size_t i = 0; i < m; i++)
         h[L.o_flags + i] = (uint8_t)(((!c.visit || c.visit[i]) ? kMpVisit : 0) | (c.bad[i] ? kMpBad : 0) | (c.sparsified[i] ? kMpSparsified : 0));
+    std::memcpy(h + L.o_frustum, c.frustum, sizeof(msorb_frustum));
     hipStream_t s = f->stream;
-    if (m) HIPCHK(hipMemcpyAsync(T.d_in.p, h, L.in_bytes, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(T.d_frustum.p, c.frustum, sizeof(msorb_frustum), hipMemcpyHostToDevice, s));
+    HIPCHK(small_copy(T.d_in.p, h, L.in_bytes, hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(T.ev_in, s));
     return MSORB_OK;
 }
@@ -499,10 +500,10 @@ int enqueue_local_points(msorb_frame* f, const LocalPointsCall& c, hipStream_t s
     if (!m) return MSORB_OK;
     const MpLayout L(m);
     LocalPointsArgs A{};
-    A.frustum = T.d_frustum.p;
     A.cos_limit = c.cos_limit;
     A.m = c.m;
     uint8_t* di = T.d_in.p;
+    A.frustum = reinterpret_cast<const msorb_frustum*>(di + L.o_frustum);
     uint8_t* dout = T.d_out.p;
     A.pos_w = reinterpret_cast<const float*>(di + L.o_pos); A.normal = reinterpret_cast<const float*>(di + L.o_nrm);
     A.max_d = reinterpret_cast<const float*>(di + L.o_max); A.min_d = reinterpret_cast<const float*>(di + L.o_min);
@@ -517,7 +518,7 @@ int enqueue_local_points(msorb_frame* f, const LocalPointsCall& c, hipStream_t s
     hipLaunchKernelGGL(local_points_kernel, dim3((unsigned)((m + 255) / 256), 1), dim3(256), 0, s, A);
     launch_window_topk(f->view(), f->d_q.p, di + L.o_desc, 0, c.m, reinterpret_cast<TopK*>(dout + L.o_topk), s, 1, 0, 0, nullptr,
                        local_points_lanes(f, c.th));
-    HIPCHK(hipMemcpyAsync(T.h_out.p, dout, L.out_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(small_copy(T.h_out.p, dout, L.out_bytes, hipMemcpyDeviceToHost, s));
     return MSORB_OK;
 }
 
@@ -631,7 +632,7 @@ int enqueue_last_frame(msorb_frame* f, const LastFrameCall& c, hipStream_t s) {
     const float mid = f->scale.empty() ? 1.0f : f->scale[f->scale.size() / 2];
     launch_window_topk(f->view(), f->d_q.p, di + L.o_desc, 0, T.last_n, reinterpret_cast<TopK*>(dout + L.o_topk), s, 1, 0, 0, nullptr,
                        window_lanes_for(c.th * mid, f->gridWInv, f->gridHInv));
-    HIPCHK(hipMemcpyAsync(T.h_last_out.p, dout, L.out_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(small_copy(T.h_last_out.p, dout, L.out_bytes, hipMemcpyDeviceToHost, s));
     return MSORB_OK;
 }
 
@@ -726,7 +727,7 @@ int msorb_frame_set_last_points(msorb_frame* f, int n, const uint8_t* has_point,
         std::memcpy(h + L.o_oct, octave, 4 * m);
         std::memcpy(h + L.o_desc, mp_desc, 32 * m);
         for (size_t i = 0; i < m; i++) h[L.o_flags + i] = has_point[i] ? 1 : 0;
-        HIPCHK(hipMemcpyAsync(T.d_last.p, h, L.in_bytes, hipMemcpyHostToDevice, f->stream));
+        HIPCHK(small_copy(T.d_last.p, h, L.in_bytes, hipMemcpyHostToDevice, f->stream));
     }
     HIPCHK(hipEventRecord(T.ev_last, f->stream));
     T.last_angle.assign(angle, angle + n);
@@ -754,7 +755,7 @@ int msorb_search_last_frame(msorb_frame* f, const msorb_motion_model* mm, const 
     if (f->N) {
         if ((rc = f->h_in.ensure((size_t)f->N + 64))) return rc;
         std::memcpy(f->h_in.p, occ.data(), f->N);
-        HIPCHK(hipMemcpyAsync(f->d_occ.p, f->h_in.p, f->N, hipMemcpyHostToDevice, s));
+        HIPCHK(small_copy(f->d_occ.p, f->h_in.p, f->N, hipMemcpyHostToDevice, s));
     }
     if ((rc = enqueue_last_frame(f, c, s))) return rc;
     HIPCHK(hipStreamSynchronize(s));
@@ -859,7 +860,7 @@ int msorb_search_local_points(msorb_frame* f, const msorb_frustum* frustum, floa
     if (f->N) {  // the occupancy snapshot of round 0
         if ((rc = f->h_in.ensure((size_t)f->N + 64))) return rc;
         std::memcpy(f->h_in.p, occ.data(), f->N);
-        HIPCHK(hipMemcpyAsync(f->d_occ.p, f->h_in.p, f->N, hipMemcpyHostToDevice, s));
+        HIPCHK(small_copy(f->d_occ.p, f->h_in.p, f->N, hipMemcpyHostToDevice, s));
     }
     if ((rc = enqueue_local_points(f, c, s))) return rc;
     HIPCHK(hipStreamSynchronize(s));
