@@ -25,6 +25,7 @@
 
 #include "orb_device.h"
 #include "matcher_device.h"
+#include "stereo_rowtable_device.h"
 
 using namespace msorb;
 
@@ -169,6 +170,7 @@ struct msorb_extractor {
     // host-synchronised stages: debugging), MSORB_QUADTREE=host (DistributeOctTree on the host twin), MSORB_HOST_THREADS (its
     // worker threads), MSORB_SPLIT_NO_PEER (test hook: the two-device gather staged through the host), MSORB_FORCE_PEER_PYRAMID
     // (test hook: msorb_stereo_matches pulls the right pyramid over the peer path even on one device)
+    const StereoRowJob* row_job = nullptr;   // set by the stereo-frame calls around run_pipeline: the row table rides the layout launch
     struct Knobs { bool serial_pipeline = false, quadtree_host = false, split_no_peer = false, force_peer_pyramid = false; int host_threads = 0; } knobs;
     int lds_per_block = 64 * 1024;   // hipDeviceAttributeMaxSharedMemoryPerBlock of the handle's device
     static constexpr bool capturing = false;   // (no graph capture: plain launches; see tools/experiments/README.md)
@@ -530,7 +532,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
         if ((rc = launch_quadtree(h->qt, h->d_compact.p + cslot, img_base, h->d_level_count.p + (size_t)first * nl,
                                   h->d_label.p + cslot, h->d_sel_pt.p + (size_t)first * sel_stride, h->d_sel_n.p + (size_t)first * nl,
                                   sel_stride, h->scales, lap0, lap1, capacity, h->d_sel.p + (size_t)first * sel_stride,
-                                  h->d_sel_count.p + first, h->d_mono.p + first, n, s)))
+                                  h->d_sel_count.p + first, h->d_mono.p + first, n, s, ng == 1 ? h->row_job : nullptr)))
             return rc;
         mark(5, s);
         if (h->overlap_blur) HIPCHK(hipStreamWaitEvent(s, G.ev_blur, 0));
@@ -606,7 +608,7 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
         // selection stays on the device: quadtree per (level, image), output layout per image
         const int qrc = launch_quadtree(h->qt, h->d_compact.p, h->d_img_base.p, h->d_level_count.p, h->d_label.p, h->d_sel_pt.p,
                                         h->d_sel_n.p, sel_stride, h->scales, lap0, lap1, capacity, h->d_sel.p, h->d_sel_count.p,
-                                        h->d_mono.p, n_images, s);
+                                        h->d_mono.p, n_images, s, h->row_job);
         if (qrc) return qrc;
         mark(5);
         if (overlap_blur) HIPCHK(hipStreamWaitEvent(s, h->ev_blur, 0));
@@ -1097,9 +1099,13 @@ int msorb::extract_stereo_sink(msorb_extractor* h, const uint8_t* left, const ui
     uint8_t* const d_desc = blk + o_desc;
     int counts[2] = {0, 0}, mono[2] = {0, 0};
     // (n_oob is zeroed by the row-table kernel of launch_stereo_match_batch)
+    // the stereo row table (vRowIndices, Frame.cc:757-776) is built by an extra workgroup of the selection-layout launch
+    const StereoRowJob row_job{1, rows, row_cap, h->d_st_rows.p, reinterpret_cast<int2*>(h->d_st_list.p), reinterpret_cast<int*>(blk + o_oob)};
+    h->row_job = &row_job;
     h->defer_sync = h->skip_count_copies = true;
     rc = run_pipeline(h, l0, 2, 0, 0, d_kps, d_desc, cap, counts, mono);
     h->defer_sync = h->skip_count_copies = false;
+    h->row_job = nullptr;
     if (rc) return rc;
     // stereo association on the device outputs (pair 0 = images 0 / 1)
     StereoBatchArgs b{};
@@ -1123,7 +1129,7 @@ int msorb::extract_stereo_sink(msorb_extractor* h, const uint8_t* left, const ui
     b.countsL = h->d_sel_count.p; b.countsR = h->d_sel_count.p + 1;
     b.row_begin = h->d_st_rows.p; b.row_list = reinterpret_cast<int2*>(h->d_st_list.p); b.row_cap = row_cap;
     b.counts_out = reinterpret_cast<int*>(blk + o_cnt);
-    launch_stereo_match_batch(b, 1, cap, s);
+    launch_stereo_match_batch(b, 1, cap, s, /*row_table_built=*/true);
     uint8_t* o = h->h_out_pin.p;
     if (sink) {
         // the frame's read-back (190 KB) leaves on the side stream while the sink's kernels (frame grid, local points, window

@@ -18,6 +18,7 @@
 
 #include "../../include/msorb.h"
 #include "matcher_device.h"
+#include "stereo_rowtable_device.h"
 
 namespace msorb {
 
@@ -414,79 +415,15 @@ __global__ __launch_bounds__(T) void stereo_rowtable_kernel(StereoBatchArgs B) {
     extern __shared__ int rt[];  // [rows0] counts -> cursors, [rows0 + 1] begins
     const int pair = blockIdx.x, t = threadIdx.x;
     const int rows0 = B.A.rows0;
-    int* cnt = rt;
-    int* beg = rt + rows0;
     const size_t img = (size_t)pair * B.pair_step;
     const int nR = B.countsR ? B.countsR[img] : B.A.nR;
     const msorb_keypoint* kpR = B.A.kpR + img * B.capacity;
-    int* row_begin = B.row_begin + (size_t)pair * (rows0 + 1);
-    int2* row_list = B.row_list + (size_t)pair * B.row_cap;
-    for (int r = t; r < rows0; r += T) cnt[r] = 0;
     if (t == 0 && B.A.n_oob) B.A.n_oob[pair] = 0;   // the association's out-of-bounds counter starts here: no memset launch in front of a frame
-    // each right keypoint's row band, computed once: the first kBandCache rounds of the 256-strided loop keep it in
-    // registers (all their loads in flight together), later rounds (more than 2048 right keypoints) recompute it
-    constexpr int kBandCache = 2048 / T;
-    int band[kBandCache];  // minr | maxr << 16, -1 = no keypoint
-    int2 entry[kBandCache];  // the keypoint's table entry: {iR | octave << 24, bits of x}
-    auto band_of = [&](int iR, int2& e) -> int {
-        const msorb_keypoint kr = kpR[iR];
-        e = int2{iR | (kr.octave << 24), __float_as_int(kr.x)};
-        const float r = __fmul_rn(2.0f, B.A.scale[kr.octave]);
-        const int maxr = min((int)ceilf(__fadd_rn(kr.y, r)), rows0 - 1), minr = max((int)floorf(__fsub_rn(kr.y, r)), 0);
-        return maxr >= minr ? (minr | (maxr << 16)) : -1;
-    };
-#pragma unroll
-    for (int k = 0; k < kBandCache; k++) {
-        const int iR = t + k * T;
-        band[k] = iR < nR ? band_of(iR, entry[k]) : -1;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kBandCache; k++)
-        if (band[k] >= 0)
-            for (int y = band[k] & 0xffff; y <= (band[k] >> 16); y++) atomicAdd(&cnt[y], 1);
-    for (int iR = t + kBandCache * T; iR < nR; iR += T) {
-        int2 e;
-        const int bd = band_of(iR, e);
-        if (bd >= 0)
-            for (int y = bd & 0xffff; y <= (bd >> 16); y++) atomicAdd(&cnt[y], 1);
-    }
-    __syncthreads();
-    // exclusive scan of cnt over the rows (rows0 is a few hundred: one wave, sequential chunks)
-    if (t < 64) {
-        int carry = 0;
-        for (int base = 0; base < rows0; base += 64) {
-            const int r = base + t;
-            const int v = r < rows0 ? cnt[r] : 0;
-            int inc = v;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int u = __shfl_up(inc, off);
-                if (t >= off) inc += u;
-            }
-            if (r < rows0) beg[r] = carry + inc - v;
-            carry += __shfl(inc, 63);
-        }
-        if (t == 0) beg[rows0] = carry;
-    }
-    __syncthreads();
-    for (int r = t; r <= rows0; r += T) row_begin[r] = beg[r];
-    for (int r = t; r < rows0; r += T) cnt[r] = beg[r];
-    __syncthreads();
-    auto fill = [&](const int2& e, int bd) {
-        for (int y = bd & 0xffff; y <= (bd >> 16); y++) {
-            const int pos = atomicAdd(&cnt[y], 1);
-            if (pos < B.row_cap) row_list[pos] = e;
-        }
-    };
-#pragma unroll
-    for (int k = 0; k < kBandCache; k++)
-        if (band[k] >= 0) fill(entry[k], band[k]);
-    for (int iR = t + kBandCache * T; iR < nR; iR += T) {
-        int2 e;
-        const int bd = band_of(iR, e);
-        if (bd >= 0) fill(e, bd);
-    }
+    stereo_rowtable_build<T>(rt, t, rows0, nR, B.A.scale, B.row_begin + (size_t)pair * (rows0 + 1), B.row_list + (size_t)pair * B.row_cap, B.row_cap,
+                             [&](int iR, float& x, float& y, int& octave) {
+                                 const msorb_keypoint kr = kpR[iR];
+                                 x = kr.x; y = kr.y; octave = kr.octave;
+                             });
 }
 
 // The same for every stereo pair of a batch (pair p = images 2p / 2p+1 of msorb_extract_batch): blockIdx.y = pair.
@@ -859,9 +796,10 @@ void launch_stereo_match(const StereoArgs& a, hipStream_t s) {
     if (a.nL <= 0) return;
     hipLaunchKernelGGL(stereo_match_kernel, dim3((a.nL + 3) / 4), dim3(256), 0, s, a);
 }
-void launch_stereo_match_batch(const StereoBatchArgs& b, int n_pairs, int max_left, hipStream_t s) {
+void launch_stereo_match_batch(const StereoBatchArgs& b, int n_pairs, int max_left, hipStream_t s, bool row_table_built) {
     if (n_pairs <= 0 || max_left <= 0) return;
-    if (n_pairs <= 4) hipLaunchKernelGGL(stereo_rowtable_kernel<1024>, dim3(n_pairs), dim3(1024), (size_t)(2 * b.A.rows0 + 1) * sizeof(int), s, b);
+    if (row_table_built) {}   // a stereo frame: the table came out of the selection-layout launch (StereoRowJob)
+    else if (n_pairs <= 4) hipLaunchKernelGGL(stereo_rowtable_kernel<1024>, dim3(n_pairs), dim3(1024), (size_t)(2 * b.A.rows0 + 1) * sizeof(int), s, b);
     else hipLaunchKernelGGL(stereo_rowtable_kernel<256>, dim3(n_pairs), dim3(256), (size_t)(2 * b.A.rows0 + 1) * sizeof(int), s, b);
     // batches whose row table exists: four keypoints per wave (stereo_match_quad_kernel); frames: one per wave, every wave slot used
     if (n_pairs > 4 && b.row_begin) hipLaunchKernelGGL(stereo_match_quad_kernel, dim3((max_left + 15) / 16, n_pairs), dim3(256), 0, s, b);

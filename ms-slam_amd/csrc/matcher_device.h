@@ -97,7 +97,7 @@ void launch_window_list(const FrameView& F, const WinQuery* q, const uint8_t* qd
 void launch_list_top2(const uint8_t* qdesc, const uint8_t* tdesc, const int* cand_begin, const int* cand_idx, int nq,
                       int* bi, int* bd, int* si, int* sd, hipStream_t s);
 void launch_stereo_match(const StereoArgs& a, hipStream_t s);
-void launch_stereo_match_batch(const StereoBatchArgs& b, int n_pairs, int max_left, hipStream_t s);
+void launch_stereo_match_batch(const StereoBatchArgs& b, int n_pairs, int max_left, hipStream_t s, bool row_table_built = false);
 void launch_dense_top2(const uint8_t* q, const uint8_t* t, const int* n_q, const int* n_t, int n_frames, int q_stride,
                        int t_stride, int max_q, int max_t, int* bi, int* bd, int* sd, hipStream_t s, int formulation = 0);
 

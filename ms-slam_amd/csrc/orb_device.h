@@ -44,9 +44,11 @@ struct QtLevels {  // per-level geometry of the quadtree stage
     int nlevels;
 };
 
+struct StereoRowJob;   // stereo_rowtable_device.h: the stereo row table of a frame, built beside the selection layout (nullptr: none)
 int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_base, const int* level_count,
                      uint16_t* label, int* sel_pt, int* sel_n, int sel_stride, const LevelScale& scales, int lap0,
-                     int lap1, int capacity, SelRec* sel, int* sel_count, int* mono, int n_images, hipStream_t s);
+                     int lap1, int capacity, SelRec* sel, int* sel_count, int* mono, int n_images, hipStream_t s,
+                     const StereoRowJob* row_job = nullptr);
 size_t quadtree_lds_bytes(const QtLevels& lv);
 void upload_patch_tables(const int8_t* pattern, const int* umax, hipStream_t stream);
 // device <-> pinned-host copy by a kernel (per-frame calls; orb_kernels.hip blit16_kernel); 16-byte aligned pointers

@@ -352,20 +352,47 @@ QT_HD void lsort_par_partitions(Ex& ex, QT_LDS SortItem* v, int n, QT_LDS int* s
 }
 
 // __final_insertion_sort == stable sort of the arrangement the introsort loop left behind (rank counting); any
-// number of threads
+// number of threads.  With more threads than items every item's comparisons are split over `parts` threads (each takes a
+// stretch of j, the partial ranks meet in an LDS accumulator): the O(n^2 / threads) loop is the longest single step of a
+// careful sweep otherwise (255 items on 255 of 1024 threads: 9.8 us; split four ways: see DESIGN.md section 5).
+// The accumulators live in the partition position lists (gpos / lpos are contiguous, 4-byte aligned, 2 (m + 4) uint16 >= n ints),
+// which nothing uses once the partitions are done.
 template <class Ex>
 QT_HD void final_stable_sort(Ex& ex, QT_LDS SortItem* v, int n, ParScratch& ps) {
     const int tid = ex.tid(), nt = ex.nthreads();
-    for (int i = tid; i < n; i += nt) {
+    if (n <= 0) return;
+    int parts = nt / n;
+    parts = parts < 1 ? 1 : parts > 8 ? 8 : parts;
+    QT_LDS int* const acc = (QT_LDS int*)ps.gpos;
+    if (parts > 1) {
+        for (int i = tid; i < n; i += nt) acc[i] = 0;
+        ex.sync();
+    }
+    for (int idx = tid; idx < n * parts; idx += nt) {
+        const int i = idx % n, part = idx / n;
+        const int j0 = (int)((long long)part * n / parts), j1 = (int)((long long)(part + 1) * n / parts);
         const uint32_t key = v[i].key;
         int rank = 0;
-        for (int j = 0; j < n; j++) {
+        int j = j0;
+        for (; j + 4 <= j1; j += 4) {   // four independent LDS reads in flight (every lane of a wave reads the same j: broadcasts)
+            const uint32_t k0 = v[j].key, k1 = v[j + 1].key, k2 = v[j + 2].key, k3 = v[j + 3].key;
+            rank += (k0 < key) || (k0 == key && j < i);
+            rank += (k1 < key) || (k1 == key && j + 1 < i);
+            rank += (k2 < key) || (k2 == key && j + 2 < i);
+            rank += (k3 < key) || (k3 == key && j + 3 < i);
+        }
+        for (; j < j1; j++) {
             const uint32_t kj = v[j].key;
             rank += (kj < key) || (kj == key && j < i);
         }
-        ps.tmp[rank] = v[i];
+        if (parts > 1) ex.atomic_add(acc + i, rank);
+        else ps.tmp[rank] = v[i];
     }
     ex.sync();
+    if (parts > 1) {
+        for (int i = tid; i < n; i += nt) ps.tmp[acc[i]] = v[i];
+        ex.sync();
+    }
     for (int i = tid; i < n; i += nt) v[i] = ps.tmp[i];
     ex.sync();
 }
@@ -602,6 +629,7 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
             }
             ex.sync();
             for (int r = tid; r < S; r += nt) nb_par[r] = nb_np[r];
+            ex.mark(23);
         }
         ex.mark(0);
         for (int i = tid; i < 4 * S; i += nt) cnt_np[i] = 0;
@@ -810,16 +838,19 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
         par_base = genbase;
     }
     // result order = descending creation sequence: rank sort (all seq are distinct)
+    // (splitting a result's comparisons over several threads with an LDS accumulator, as final_stable_sort does, was slower here:
+    // 6.6 against 4.8 us for the 434 results of a KITTI level 0 — two parts do not pay for the extra barrier and the atomics)
     const int nres = sc[kScNres];
-    // (read four at a time: the list is padded to a multiple of four with a value below every sequence number)
-    for (int i = nres + tid; i < ((nres + 3) & ~3); i += nt) w.res_seq[i] = -0x7FFFFFFF - 1;
+    // (read eight at a time: the list is padded to a multiple of eight with a value below every sequence number)
+    for (int i = nres + tid; i < ((nres + 7) & ~7); i += nt) w.res_seq[i] = -0x7FFFFFFF - 1;
     ex.sync();
     for (int i = tid; i < nres; i += nt) {
         const int s = w.res_seq[i];
         int rank = 0;
-        for (int j = 0; j < nres; j += 4) {
-            const Int4 v = load_int4(w.res_seq + j);
+        for (int j = 0; j < nres; j += 8) {
+            const Int4 v = load_int4(w.res_seq + j), u = load_int4(w.res_seq + j + 4);
             rank += (v.x > s) + (v.y > s) + (v.z > s) + (v.w > s);
+            rank += (u.x > s) + (u.y > s) + (u.z > s) + (u.w > s);
         }
         out_pt[rank] = w.res_pt[i];
     }

@@ -10,6 +10,7 @@
 #include "lds_limit.h"
 #include "orb_device.h"
 #include "quadtree_device.h"
+#include "stereo_rowtable_device.h"
 
 namespace msorb {
 
@@ -34,13 +35,20 @@ __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
     return v;
 }
 
+#ifdef MSORB_QT_SORTCHECK
+__device__ int g_sortcheck_bad = 0;
+#endif
 struct DevEx {
     // std::sort restatement, data-parallel form (quadtree_device.h lsort_par), executed by wave 0 only: inside one
     // wave there is no s_barrier to pay and LDS operations complete in program order.
     struct WaveEx {
         __device__ int tid() const { return threadIdx.x & 63; }
         __device__ int nthreads() const { return 64; }
+#ifdef MSORB_QT_SYNC_WAIT
+        __device__ void sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+#else
         __device__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+#endif
         __device__ int excl_count(bool p, int* total) {
             const unsigned long long m = __ballot(p);
             *total = __popcll(m);
@@ -52,35 +60,66 @@ struct DevEx {
             return incl - v;
         }
     };
-    // The introsort loop as level-synchronous rounds: the sub-ranges a partition leaves behind are independent, so every
-    // round hands the current ranges (> 16 elements) to the workgroup's waves, one range per wave at a time; inside a wave
-    // a partition is data-parallel (ballots, no s_barrier).  Which wave partitions which range, and in which order, cannot
-    // change the result: ranges are disjoint and a partition only looks at its own range.  `stack` holds two range lists
-    // of stack_ranges(m) entries (first, last, depth); ps.sc[0/1] their lengths.
+    // The introsort loop without workgroup barriers.  The sub-ranges a partition leaves behind are independent (disjoint, and a
+    // partition only looks at its own range), so which wave partitions which range, and when, cannot change the result.  A wave
+    // that has partitioned a range keeps the left part and goes on with it (depth first); the right part goes into a ring of open
+    // ranges in LDS that idle waves poll.  `pending` counts the chains that are still running or queued: the sort is over when it
+    // reaches zero.  Rounds 2-4 ran the same partitions as level-synchronous rounds with two __syncthreads each: 22 us for the
+    // ~150 nodes of a KITTI level-0 careful sweep, almost all of it barrier and hand-over latency; the critical path is now the
+    // depth of the recursion (3-4 partitions).  Inside a wave a partition is data-parallel (ballots, no s_barrier).
+    // `stack`: ring of 2 * stack_ranges(m) entries (first, last, depth) — at any time the open ranges are disjoint and longer
+    // than 16 elements, i.e. fewer than the ring holds; ps.sc[0] = head (next to take), ps.sc[1] = tail (published entries),
+    // ps.sc[2] = pending, ps.sc[3] = reserved entries (>= tail: an entry is written, then published in reservation order).
     __device__ void sort(QT_LDS qt::SortItem* items, int n, QT_LDS int* stack, qt::ParScratch& ps) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = nt >> 6;
+        mark(20);
+        const int lane = threadIdx.x & 63;
+        const int ring = 2 * ps.stack_half / 3;
         int lg = 0;
         for (int t = n; t > 1; t >>= 1) lg++;
         if (threadIdx.x == 0) {
             stack[0] = 0; stack[1] = n; stack[2] = 2 * lg;
-            ps.sc[0] = n > 16 ? 1 : 0;
-            ps.sc[1] = 0;
+            ps.sc[0] = 0;
+            ps.sc[1] = n > 16 ? 1 : 0;
+            ps.sc[2] = n > 16 ? 1 : 0;
+            ps.sc[3] = n > 16 ? 1 : 0;
         }
         __syncthreads();
-        int which = 0;
+        WaveEx wex;
+#ifdef MSORB_QT_ONE_WAVE
+        if ((threadIdx.x >> 6) == 0)
+#endif
         for (;;) {
-            const int nr = ps.sc[which];
-            if (nr == 0) break;
-            QT_LDS int* cur = stack + which * ps.stack_half;
-            QT_LDS int* nxt = stack + (which ^ 1) * ps.stack_half;
-            WaveEx wex;
-            for (int i = wave; i < nr; i += nwaves) {
-                const int first = cur[3 * i], last = cur[3 * i + 1];
-                int depth = cur[3 * i + 2];
-                if (depth == 0) {  // __partial_sort fallback (:introsort depth limit)
+            // Take an open range.  The polling loop is executed by the WHOLE wave (every lane reads the same LDS words, so the
+            // loop's control flow is wave-uniform); only the claim itself is lane 0's.  (A first form ran the loop inside
+            // `if (lane == 0)` with breaks out of it: hipcc then kept the code after the loop — readfirstlane, the partition with its
+            // ballots and DPP scans — under lane 0's execution mask, and every partition saw one element.)
+            int first = 0, last = 0, depth = -1;
+            for (;;) {
+                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ps.sc[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) break;   // nothing running, nothing queued
+                const int hd = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ps.sc[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                const int tl = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ps.sc[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (hd < tl) {
+                    QT_LDS const int* e = stack + 3 * (hd % ring);
+                    const int f = e[0], l = e[1], d = e[2];   // read before the claim: an unclaimed entry is never overwritten
+                    int won = 0;
+                    if (lane == 0) {
+                        int expect = hd;
+                        won = __hip_atomic_compare_exchange_strong(&ps.sc[0], &expect, hd + 1, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0;
+                    }
+                    if (__builtin_amdgcn_readfirstlane(won)) {
+                        first = __builtin_amdgcn_readfirstlane(f); last = __builtin_amdgcn_readfirstlane(l); depth = __builtin_amdgcn_readfirstlane(d);
+                        break;
+                    }
+                } else {
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            if (depth < 0) break;
+            while (last - first > 16) {   // __introsort_loop on [first, last)
+                if (depth == 0) {  // __partial_sort fallback (the introsort depth limit)
                     if (lane == 0) { qt::ArrayAcc a{items}; qt::heap_sort(a, first, last); }
                     wex.sync();
-                    continue;
+                    break;
                 }
                 --depth;
                 if (lane == 0) {  // __move_median_to_first(first, first+1, mid, last-1)
@@ -99,24 +138,67 @@ struct DevEx {
                 qt::ParScratch pl = ps;  // this range's private stretch of the position lists
                 pl.gpos = ps.gpos + first;
                 pl.lpos = ps.lpos + first;
+#ifdef MSORB_QT_SORTCHECK
+                unsigned cs0 = 0, cx0 = 0;
+                if (lane == 0) for (int i = first; i < last; i++) { cs0 += items[i].node; cx0 ^= items[i].node * 2654435761u; }
+                const uint32_t pivot_chk = items[first].key;
+                wex.sync();
+#endif
                 const int cut = qt::partition_par(wex, items, first, last, pl);
+#ifdef MSORB_QT_SORTCHECK
                 if (lane == 0) {
-                    if (last - cut > 16) {
-                        const int k = __hip_atomic_fetch_add(&ps.sc[which ^ 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        nxt[3 * k] = cut; nxt[3 * k + 1] = last; nxt[3 * k + 2] = depth;
-                    }
-                    if (cut - first > 16) {
-                        const int k = __hip_atomic_fetch_add(&ps.sc[which ^ 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        nxt[3 * k] = first; nxt[3 * k + 1] = cut; nxt[3 * k + 2] = depth;
-                    }
+                    unsigned cs1 = 0, cx1 = 0; int badl = 0, badr = 0;
+                    for (int i = first; i < last; i++) { cs1 += items[i].node; cx1 ^= items[i].node * 2654435761u; }
+                    for (int i = first + 1; i < cut; i++) badl += items[i].key > pivot_chk;
+                    for (int i = cut; i < last; i++) badr += items[i].key < pivot_chk;
+                    if (cs0 != cs1 || cx0 != cx1 || badl || badr)
+                        printf("PARTCHECK blk(%d,%d) wave %d [%d,%d) cut=%d multiset %s badl=%d badr=%d exec=%llx\n", blockIdx.x, blockIdx.y, (int)(threadIdx.x >> 6),
+                               first, last, cut, (cs0 != cs1 || cx0 != cx1) ? "CHANGED" : "ok", badl, badr, (unsigned long long)__builtin_amdgcn_read_exec());
                 }
+                wex.sync();
+#endif
+                if (last - cut > 16) {   // [cut, last) becomes an open range: the entry first, then the tail that publishes it
+                    int slot = 0;
+                    if (lane == 0) {
+                        (void)__hip_atomic_fetch_add(&ps.sc[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        slot = __hip_atomic_fetch_add(&ps.sc[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // several waves may push at once: reserve a slot
+                        QT_LDS int* e = stack + 3 * (slot % ring);
+                        e[0] = cut; e[1] = last; e[2] = depth;
+                    }
+                    slot = __builtin_amdgcn_readfirstlane(slot);
+                    // publish in reservation order: wait (whole wave, uniform loop) until every earlier reservation has been published
+                    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ps.sc[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != slot) __builtin_amdgcn_s_sleep(0);
+                    if (lane == 0) __hip_atomic_store(&ps.sc[1], slot + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                last = cut;
             }
-            __syncthreads();
-            if (threadIdx.x == 0) ps.sc[which] = 0;
-            which ^= 1;
-            __syncthreads();
+            if (lane == 0) (void)__hip_atomic_fetch_sub(&ps.sc[2], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);   // this chain has ended
         }
+        __syncthreads();
+        mark(21);
+#ifdef MSORB_QT_SORTCHECK
+        if (threadIdx.x == 0) {
+            int pend = ps.sc[2], hd = ps.sc[0], tl = ps.sc[1], rs = ps.sc[3];
+            int bad_flag = 0;
+            unsigned long long seen_lo = 0; int dup = 0, oob = 0;
+            for (int i = 0; i < n; i++) { const unsigned nd = items[i].node; if (nd >= (unsigned)n) oob++; else if (nd < 64) { if (seen_lo >> nd & 1) dup++; seen_lo |= 1ull << nd; } }
+            // every range left behind must be "nearly sorted": element i is >= every element more than 16 places before it is NOT required;
+            // check the weaker invariant of the introsort loop: max of a prefix block <= min of later blocks cannot be stated simply -> only report counters
+            if (pend != 0 || hd != tl || tl != rs || oob || dup) bad_flag = 1;
+            if (bad_flag) { printf("SORTCHECK blk(%d,%d) n=%d pend=%d hd=%d tl=%d rs=%d oob=%d dup=%d\n", blockIdx.x, blockIdx.y, n, pend, hd, tl, rs, oob, dup); atomicExch(&g_sortcheck_bad, 1); }
+        }
+        __syncthreads();
+#endif
         qt::final_stable_sort(*this, items, n, ps);  // rank counting: all threads
+        mark(22);
+#ifdef MSORB_QT_SORTCHECK
+        if (threadIdx.x == 0) {
+            int bad = 0;
+            for (int i = 1; i < n; i++) bad += items[i - 1].key > items[i].key;
+            if (bad) { printf("SORTCHECK blk(%d,%d) n=%d NOT SORTED: %d inversions\n", blockIdx.x, blockIdx.y, n, bad); atomicExch(&g_sortcheck_bad, 1); }
+        }
+        __syncthreads();
+#endif
     }
     int dbg = 0;
     int nt = 0;  // threads of this instance: blockDim.x, or fewer for the small levels of a mixed launch (the other waves have left)
@@ -215,7 +297,11 @@ __device__ __forceinline__ void quadtree_select_body(const QtLevels& lv, const C
     int* out = sel_pt + (size_t)img * sel_stride + lv.sel_off[level];
     const int kept = qt::select<PC>(ex, reinterpret_cast<const qt::Pt*>(compact + off), n, label + off, lv.W[level], lv.H[level],
                                 lv.quota[level], w, out, debug);
+#ifdef MSORB_QT_SORTCHECK
+    if (threadIdx.x == 0) sel_n[(size_t)img * lv.nlevels + level] = g_sortcheck_bad ? 0 : kept;
+#else
     if (threadIdx.x == 0) sel_n[(size_t)img * lv.nlevels + level] = kept;
+#endif
     ex.dump();
 }
 template <int PC>
@@ -237,16 +323,23 @@ __global__ __launch_bounds__(256, 4) void quadtree_select_batch_kernel(QtLevels 
 
 // One workgroup per image: records in level-major / quadtree order; output row = mono index from the front for
 // keypoints outside [lap0, lap1], stereo index from the back for those inside (ORBextractor.cc:1153-1162).
-__global__ __launch_bounds__(256) void quadtree_layout_kernel(QtLevels lv, const Cand16* __restrict__ compact,
+// kLayoutThreads = 256: the layout's own work.  A stereo frame launches the kernel with 1024 threads and one workgroup more
+// (n_images + 1): the layout workgroups use their first 256 threads (the other waves leave at once), the extra one builds the
+// stereo row table of the right image from the same selection records (StereoRowJob, stereo_rowtable_device.h) with all 1024.
+__global__ __launch_bounds__(1024) void quadtree_layout_kernel(QtLevels lv, const Cand16* __restrict__ compact,
                                                               const int* __restrict__ img_base,
                                                               const int* __restrict__ level_count,
                                                               const int* __restrict__ sel_pt, const int* __restrict__ sel_n,
                                                               int sel_stride, LevelScale scales, int lap0, int lap1,
                                                               int capacity, SelRec* __restrict__ sel,
-                                                              int* __restrict__ sel_count, int* __restrict__ mono_out) {
+                                                              int* __restrict__ sel_count, int* __restrict__ mono_out, int n_images,
+                                                              StereoRowJob job) {
     __shared__ int lvl_begin[kMaxLevels + 1], cand_begin[kMaxLevels + 1];
     __shared__ int part[256];
-    const int img = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ int row_lds[];   // the row-table workgroup's counters (2 * rows0 + 1 ints); none for a plain launch
+    const bool row_block = (int)blockIdx.x >= n_images;
+    const int img = row_block ? job.right_img : (int)blockIdx.x, tid = threadIdx.x;
+    if (!row_block && tid >= 256) return;
     if (tid == 0) {
         int a = 0, c = img_base[img];
         for (int l = 0; l < lv.nlevels; l++) {
@@ -259,6 +352,24 @@ __global__ __launch_bounds__(256) void quadtree_layout_kernel(QtLevels lv, const
     __syncthreads();
     const int n_all = lvl_begin[lv.nlevels];
     const int n = min(n_all, min(capacity, sel_stride));
+    if (row_block) {
+        // vRowIndices of the right eye (Frame.cc:757-776): keypoint iR of the output = selection record iR (no lapping area: the
+        // output row is the selection order), its kp.pt = level coordinates times the level's scale factor exactly as the
+        // descriptor stage writes them (ORBextractor.cc:1149-1151)
+        if (tid == 0 && job.n_oob) *job.n_oob = 0;
+        stereo_rowtable_build<1024>(row_lds, tid, job.rows0, n, scales.scale, job.row_begin, job.row_list, job.row_cap,
+                                    [&](int iR, float& x, float& y, int& octave) {
+                                        int l = 0;
+                                        while (iR >= lvl_begin[l + 1]) l++;
+                                        const int pt = sel_pt[(size_t)img * sel_stride + lv.sel_off[l] + (iR - lvl_begin[l])];
+                                        const Cand16 c = compact[cand_begin[l] + pt];
+                                        const float fx = (float)(c.x + kMinBorder), fy = (float)(c.y + kMinBorder);
+                                        x = l ? __fmul_rn(fx, scales.scale[l]) : fx;
+                                        y = l ? __fmul_rn(fy, scales.scale[l]) : fy;
+                                        octave = l;
+                                    });
+        return;
+    }
     const int per = (n + 255) / 256;
     const int b = tid * per, e = min(b + per, n);
     SelRec* out = sel + (size_t)img * sel_stride;
@@ -328,7 +439,8 @@ __global__ __launch_bounds__(256) void quadtree_layout_kernel(QtLevels lv, const
 
 int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_base, const int* level_count,
                      uint16_t* label, int* sel_pt, int* sel_n, int sel_stride, const LevelScale& scales, int lap0,
-                     int lap1, int capacity, SelRec* sel, int* sel_count, int* mono, int n_images, hipStream_t s) {
+                     int lap1, int capacity, SelRec* sel, int* sel_count, int* mono, int n_images, hipStream_t s,
+                     const StereoRowJob* row_job) {
     int maxN = 1, max_ini = 1;
     for (int l = 0; l < lv.nlevels; l++) { maxN = max(maxN, lv.quota[l]); max_ini = max(max_ini, lv.n_ini[l]); }
     const size_t lds = qt::workspace_bytes(maxN, max_ini);
@@ -361,8 +473,12 @@ int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_ba
         hipLaunchKernelGGL(quadtree_select_kernel<0>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds, s, lv, compact, img_base,
                            level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt);
     }
-    hipLaunchKernelGGL(quadtree_layout_kernel, dim3(n_images), dim3(256), 0, s, lv, compact, img_base, level_count, sel_pt,
-                       sel_n, sel_stride, scales, lap0, lap1, capacity, sel, sel_count, mono);
+    if (row_job && lap1 < kMinBorder && row_job->right_img < n_images)
+        hipLaunchKernelGGL(quadtree_layout_kernel, dim3(n_images + 1), dim3(1024), (size_t)(2 * row_job->rows0 + 1) * sizeof(int), s, lv, compact,
+                           img_base, level_count, sel_pt, sel_n, sel_stride, scales, lap0, lap1, capacity, sel, sel_count, mono, n_images, *row_job);
+    else
+        hipLaunchKernelGGL(quadtree_layout_kernel, dim3(n_images), dim3(256), 0, s, lv, compact, img_base, level_count, sel_pt,
+                           sel_n, sel_stride, scales, lap0, lap1, capacity, sel, sel_count, mono, n_images, StereoRowJob{});
     return MSORB_OK;
 }
 size_t quadtree_lds_bytes(const QtLevels& lv) {
