@@ -1,10 +1,15 @@
 """GPU parity tests: HIP extractor (through the C ABI) vs the CPU oracle, stage by stage and end to end.
 Bit-exact for every integer/byte product (pyramid, blur, candidates incl. FAST scores, descriptors) and for
 the float keypoint fields (same IEEE operations in the same order)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
 from msorb import synth
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))   # the pin-kit consumers live in test_oracle_pins.py
 
 pytestmark = pytest.mark.gpu
 
@@ -473,3 +478,33 @@ def test_texture_classes_at_full_kitti_size_through_the_batch_kernels(msorb_mod,
         assert retried > 300
     finally:
         ex.close()
+
+
+def _hip_extract(msorb_mod):
+    def run(img, nfeat):
+        ex = msorb_mod.ORBextractor(nfeat, 1.2, 8, 20, 7)
+        try:
+            _, kps, desc = ex(img)
+        finally:
+            ex.close()
+        return kps, desc
+    return run
+
+
+def test_hip_extractor_against_the_pin_kit_plumbing_fixtures(msorb_mod, oracle, tmp_path):
+    """The consumer the whole-extractor OpenCV fixtures will meet on the GPU box, exercised today on fixtures made by the kit's
+    Python restatement around the oracle's primitives (tools/pin_opencv.py --extractor, tests/test_oracle_pins.py): the HIP
+    path must reproduce them — four geometries of the kit's integer-hash texture, which no other GPU test uses."""
+    import test_oracle_pins as top
+    kit = top._kit()
+    kit.generate_extractor(top._OracleAsCv(oracle), str(tmp_path))
+    bad, _ = top.compare_extractor(_hip_extract(msorb_mod), str(tmp_path))
+    assert bad == []
+
+
+def test_hip_extractor_against_real_opencv_extractor_pins(msorb_mod):
+    import test_oracle_pins as top
+    if not os.path.exists(os.path.join(top.PINS, "extractor_meta.json")):
+        pytest.skip("no whole-extractor OpenCV pins committed yet (python tools/pin_opencv.py --extractor on a machine with cv2)")
+    bad, meta = top.compare_extractor(_hip_extract(msorb_mod), top.PINS)
+    assert not bad, f"the HIP extractor differs from the kit's run on OpenCV {meta['cv2_version']}:\n" + "\n".join(bad)

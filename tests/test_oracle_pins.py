@@ -339,3 +339,102 @@ def test_fast_atan2_against_numpy(oracle):
     d = np.minimum(d, 360.0 - d)
     assert d[nz].max() < 0.3, d[nz].max()
     assert np.all(got[(y[sel] == 0) & (x[sel] == 0)] == 0.0)
+
+
+# ---- the WHOLE extractor around the real primitives (tools/pin_opencv.py --extractor) --------------------------------------
+def compare_extractor(extract, pins_dir):
+    """extract(image, nfeatures) -> (keypoints KP_DTYPE [n], descriptors u8 [n, 32]) of ORBextractor(nfeatures, 1.2, 8, 20, 7) with
+    vLappingArea (0, 0), compared with the fixtures extractor.npz / extractor_meta.json of pins_dir.  -> list of mismatches."""
+    kit = _kit()
+    meta = json.load(open(os.path.join(pins_dir, "extractor_meta.json")))
+    z = np.load(os.path.join(pins_dir, "extractor.npz"))
+    bad = []
+    for i, (name, rows, cols, nfeat) in enumerate(meta["cases"]):
+        img = kit.pin_image(700 + i, rows, cols)
+        assert kit.sha(img) == meta["inputs_sha256"][name], f"input of {name} differs from the generating run"
+        kps, desc = extract(img, nfeat)
+        want_k = z[f"{name}_kps"].reshape(-1, 28).view(kit.KP_DTYPE).reshape(-1)
+        want_d = z[f"{name}_desc"]
+        if len(kps) != len(want_k):
+            bad.append(f"extractor {name}: {len(kps)} keypoints vs {len(want_k)} in the fixtures")
+            continue
+        for f in kit.KP_DTYPE.names:
+            d = np.flatnonzero(np.asarray(kps[f]).view(np.uint32) != want_k[f].view(np.uint32))
+            if len(d):
+                bad.append(f"extractor {name}: keypoint field {f} differs on {len(d)} of {len(kps)} keypoints, first {d[0]}: "
+                           f"{kps[f][d[0]]!r} vs {want_k[f][d[0]]!r}")
+        d = np.flatnonzero((np.asarray(desc) != want_d).any(1))
+        if len(d):
+            bad.append(f"extractor {name}: {len(d)} of {len(kps)} descriptors differ, first {d[0]} "
+                       f"({int(np.unpackbits(np.asarray(desc)[d[0]] ^ want_d[d[0]]).sum())} bits)")
+    return bad, meta
+
+
+def _oracle_extract(oracle):
+    def run(img, nfeat):
+        _, kps, desc = oracle.OracleExtractor(nfeat, 1.2, 8, 20, 7)(img)
+        return kps, desc
+    return run
+
+
+def test_kit_pattern_table_is_the_references(oracle):
+    """the kit carries bit_pattern_31_ compressed inside its one file: it must be the table the product and the oracle compile in"""
+    import re
+    kit = _kit()
+    txt = re.sub(r"//.*", "", open(os.path.join(ROOT, "ms-slam_amd", "csrc", "orb_pattern.inc")).read())
+    want = np.array([int(x) for x in re.findall(r"-?\d+", txt)], np.int8).reshape(256, 4)
+    assert np.array_equal(kit.orb_pattern(), want)
+
+
+def test_extractor_kit_plumbing(oracle, tmp_path):
+    """The kit's plain-Python restatement of everything AROUND the four primitives (level sizes, cell loop + threshold fallback,
+    DistributeOctTree with libstdc++'s std::sort, IC_Angle, steered BRIEF), driven by a stand-in "cv2" backed by the oracle's
+    primitives, must reproduce the C++ oracle's extractor bit for bit — two independent restatements of ORBextractor.cc, one in
+    C++ (oracle/orb_extractor_oracle.cc), one in Python (tools/pin_opencv.py) — so that the first real run differs from the
+    oracle only where real OpenCV differs from the restated primitives."""
+    kit = _kit()
+    meta = kit.generate_extractor(_OracleAsCv(oracle), str(tmp_path))
+    assert [c[0] for c in meta["cases"]] == ["kitti", "euroc", "4seasons", "small_odd"] and "cosf" in meta["trig"]
+    bad, _ = compare_extractor(_oracle_extract(oracle), str(tmp_path))
+    assert bad == []
+    z = np.load(os.path.join(str(tmp_path), "extractor.npz"))
+    assert len(z["kitti_kps"]) > 2000 and len(z["euroc_kps"]) > 1000 and z["kitti_cand"].sum() > 10000
+    # teeth: one flipped descriptor bit, one keypoint moved by one ulp
+    arrs = dict(z)
+    arrs["euroc_desc"] = arrs["euroc_desc"].copy(); arrs["euroc_desc"][7, 3] ^= 16
+    k = arrs["kitti_kps"].copy().reshape(-1, 28); k[11, 12] ^= 1; arrs["kitti_kps"] = k     # byte 12 = lowest byte of `angle`
+    np.savez_compressed(os.path.join(str(tmp_path), "extractor.npz"), **arrs)
+    bad, _ = compare_extractor(_oracle_extract(oracle), str(tmp_path))
+    assert len(bad) == 2 and "keypoint field angle" in bad[0] and "descriptors differ" in bad[1]
+
+
+def test_extractor_kit_follows_a_non_default_semantics_variant(oracle, tmp_path):
+    """fixtures made with another Gaussian / resize / atan2 variant of the semantics table differ from the default oracle and are
+    reproduced by the oracle once it is set to that variant: what the consumer of real fixtures would do after select_semantics()"""
+    kit = _kit()
+    variant = dict(gauss_taps=[18, 34, 49, 55, 49, 34, 18], resize_single_stage=True, atan2_fma=True)
+    try:
+        oracle.set_semantics(**variant)
+        kit.generate_extractor(_OracleAsCv(oracle), str(tmp_path), cases=kit.EXTRACTOR_CASES[3:])
+        bad, _ = compare_extractor(_oracle_extract(oracle), str(tmp_path))
+        assert bad == []
+    finally:
+        oracle.set_semantics()
+    bad, _ = compare_extractor(_oracle_extract(oracle), str(tmp_path))
+    assert bad, "the default semantics reproduced fixtures of another variant"
+
+
+def test_extractor_pins_against_real_opencv(oracle):
+    if not os.path.exists(os.path.join(PINS, "extractor_meta.json")):
+        pytest.skip("no whole-extractor OpenCV pins committed yet: run `python tools/pin_opencv.py --extractor` on a machine with cv2 — "
+                    "until then keypoints and descriptors are bit-exact against the oracle only (PARITY UNPINNED)")
+    sel = os.path.join(PINS, "selected_semantics.json")
+    try:
+        if os.path.exists(sel):   # the variant the primitive fixtures selected (written by test_pins_against_real_opencv)
+            s = json.load(open(sel))
+            if s.get("gauss_taps") and s.get("resize_single_stage") is not None and s.get("atan2_fma") is not None:
+                oracle.set_semantics(gauss_taps=s["gauss_taps"], resize_single_stage=s["resize_single_stage"], atan2_fma=s["atan2_fma"])
+        bad, meta = compare_extractor(_oracle_extract(oracle), PINS)
+    finally:
+        oracle.set_semantics()
+    assert not bad, f"the oracle's extractor differs from the kit's run on OpenCV {meta['cv2_version']} ({meta['trig']}):\n" + "\n".join(bad)
