@@ -5,7 +5,7 @@ profiles/: the bench line, the rocprofv3 --kernel-trace --stats per-kernel table
 import ast, csv, json, os, re, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
-rnd = sys.argv[1] if len(sys.argv) > 1 else "round4"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "round5"
 VALU_LANE_OPS_PER_S = 51.5e12   # measured v_fma_f32 rate 103 TFLOP/s / 2 (MI355X_MICROARCH / cdna_hip_programming guide)
 
 
@@ -82,7 +82,8 @@ for src, dst in (("bow_bench.json", "bow_bench.json"), ("valu_ubench.txt", "valu
                  ("hamming_bench.txt", "hamming_bench.txt"), ("pytest_gpu.txt", "pytest_gpu.txt"),
                  ("batch_sweep.jsonl", "batch_sweep.jsonl"), ("visibility_bench.json", "visibility_bench.json"),
                  ("track_trace.txt", "tracking_chain_kernel_trace.txt"), ("timeline_pipelined.txt", "timeline_pipelined.txt"),
-                 ("frame_chain.json", "frame_chain.json"), ("frame_trace.txt", "frame_trace.txt"), ("qt_marks.txt", "quadtree_phase_marks.txt")):
+                 ("frame_chain.json", "frame_chain.json"), ("frame_trace.txt", "frame_trace.txt"), ("qt_marks.txt", "quadtree_phase_marks.txt"),
+                 ("describe_pmc.txt", "describe_pmc_raw.txt"), ("frame_copies_ab.txt", "frame_copies_ab.txt")):
     if os.path.exists(os.path.join(G, src)):
         shutil.copy(os.path.join(G, src), os.path.join(P, f"{rnd}_{dst}"))
 print("value", bench["value"], "ms/step", bench["ms_per_step"], bench["stage_ms_per_step"])

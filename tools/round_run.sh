@@ -1,6 +1,6 @@
 #!/bin/bash
 # The full measurement run of a round, on the GPU box:  gpurun --timeout 2400 -- 'bash tools/round_run.sh'
-# then, back in the container:  python tools/collect_profiles.py round4   (copies the summaries into profiles/)
+# then, back in the container:  python tools/collect_profiles.py round5   (copies the summaries into profiles/)
 # Every profiler pass runs under its own timeout: a counter set the hardware refuses leaves rocprofv3 waiting forever.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; O=gpurun_out/round; rm -rf $O; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.json
@@ -29,3 +29,9 @@ g++ -O2 -std=c++17 tools/kf_store_bench.cc -Iinclude -Lms-slam_amd -lmsorb -lpth
 g++ -O2 -std=c++17 tools/visibility_bench.cc -Iinclude -Lms-slam_amd -lmsorb -o /tmp/visibility_bench 2>/dev/null && LD_LIBRARY_PATH=ms-slam_amd:/opt/rocm/lib /tmp/visibility_bench 300 > $O/visibility_bench.json; cat $O/visibility_bench.json
 g++ -O2 -std=c++17 tools/latency_pair.cc -Iinclude -Lms-slam_amd -lmsorb -lpthread -o tools/_latency_pair 2>/dev/null; tools/track_trace.sh > $O/track_trace.txt 2>&1; tail -30 $O/track_trace.txt
 tools/timeline.sh > /dev/null 2>&1; python tools/timeline_summary.py gpurun_out/timeline > $O/timeline_pipelined.txt 2>&1; tail -2 $O/timeline_pipelined.txt
+# round 5: describe_kernel's L2 -> L1 fills and wait cycles, per-frame copies by kernel against SDMA
+for set in "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
+  n=$(echo $set | tr ' ' '_' | cut -c1-40)
+  PMC_TIMEOUT=200 tools/pmc_run.sh round/dpmc_$n "$set" "describe" -- python bench.py --steps 2 --warmup 1 --lean --isolated 2>&1 | tail -2
+done > $O/describe_pmc.txt 2>&1; cat $O/describe_pmc.txt
+{ for i in 1 2; do python tools/per_frame_ab.py | tail -1; MSORB_FRAME_COPIES=sdma python tools/per_frame_ab.py | tail -1; done; } > $O/frame_copies_ab.txt 2>&1; cat $O/frame_copies_ab.txt
