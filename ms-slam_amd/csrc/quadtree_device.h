@@ -361,8 +361,11 @@ template <class Ex>
 QT_HD void final_stable_sort(Ex& ex, QT_LDS SortItem* v, int n, ParScratch& ps) {
     const int tid = ex.tid(), nt = ex.nthreads();
     if (n <= 0) return;
-    int parts = nt / n;
-    parts = parts < 1 ? 1 : parts > 8 ? 8 : parts;
+    int parts = 1;
+    if constexpr (Ex::kSplitRank) {   // (an execution model without spare threads compiles the plain form only)
+        parts = nt / n;
+        parts = parts < 1 ? 1 : parts > 8 ? 8 : parts;
+    }
     QT_LDS int* const acc = (QT_LDS int*)ps.gpos;
     if (parts > 1) {
         for (int i = tid; i < n; i += nt) acc[i] = 0;

@@ -38,7 +38,11 @@ __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
 #ifdef MSORB_QT_SORTCHECK
 __device__ int g_sortcheck_bad = 0;
 #endif
-struct DevEx {
+template <bool FRAME>
+struct DevExT {
+    // FRAME: a 1024-thread instance that has its CU to itself (single frames); otherwise a batch instance (256 / 512 threads, several
+    // workgroups per CU, register budget of 128 with 24 resident candidates per thread: only the code it runs is compiled into it)
+    static constexpr bool kSplitRank = FRAME;
     // std::sort restatement, data-parallel form (quadtree_device.h lsort_par), executed by wave 0 only: inside one
     // wave there is no s_barrier to pay and LDS operations complete in program order.
     struct WaveEx {
@@ -60,7 +64,76 @@ struct DevEx {
             return incl - v;
         }
     };
-    // The introsort loop without workgroup barriers.  The sub-ranges a partition leaves behind are independent (disjoint, and a
+    // Batches (256- and 512-thread instances, several workgroups per CU): the introsort loop as level-synchronous rounds —
+    // waves without a range wait at the workgroup barrier, which costs the other workgroups of the CU nothing (the polling waves
+    // of the barrier-free form below took issue slots from them: select stage 0.136 -> 0.186 ms per 256 images).
+    // The introsort loop as level-synchronous rounds: the sub-ranges a partition leaves behind are independent, so every
+    // round hands the current ranges (> 16 elements) to the workgroup's waves, one range per wave at a time; inside a wave
+    // a partition is data-parallel (ballots, no s_barrier).  Which wave partitions which range, and in which order, cannot
+    // change the result: ranges are disjoint and a partition only looks at its own range.  `stack` holds two range lists
+    // of stack_ranges(m) entries (first, last, depth); ps.sc[0/1] their lengths.
+    __device__ void sort_rounds(QT_LDS qt::SortItem* items, int n, QT_LDS int* stack, qt::ParScratch& ps) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = nt >> 6;
+        int lg = 0;
+        for (int t = n; t > 1; t >>= 1) lg++;
+        if (threadIdx.x == 0) {
+            stack[0] = 0; stack[1] = n; stack[2] = 2 * lg;
+            ps.sc[0] = n > 16 ? 1 : 0;
+            ps.sc[1] = 0;
+        }
+        __syncthreads();
+        int which = 0;
+        for (;;) {
+            const int nr = ps.sc[which];
+            if (nr == 0) break;
+            QT_LDS int* cur = stack + which * ps.stack_half;
+            QT_LDS int* nxt = stack + (which ^ 1) * ps.stack_half;
+            WaveEx wex;
+            for (int i = wave; i < nr; i += nwaves) {
+                const int first = cur[3 * i], last = cur[3 * i + 1];
+                int depth = cur[3 * i + 2];
+                if (depth == 0) {  // __partial_sort fallback (:introsort depth limit)
+                    if (lane == 0) { qt::ArrayAcc a{items}; qt::heap_sort(a, first, last); }
+                    wex.sync();
+                    continue;
+                }
+                --depth;
+                if (lane == 0) {  // __move_median_to_first(first, first+1, mid, last-1)
+                    qt::ArrayAcc acc{items};
+                    const int a = first + 1, b = first + (last - first) / 2, c = last - 1;
+                    const uint32_t ka = items[a].key, kb = items[b].key, kc = items[c].key;
+                    if (ka < kb) {
+                        if (kb < kc) qt::sort_swap(acc, first, b);
+                        else if (ka < kc) qt::sort_swap(acc, first, c);
+                        else qt::sort_swap(acc, first, a);
+                    } else if (ka < kc) qt::sort_swap(acc, first, a);
+                    else if (kb < kc) qt::sort_swap(acc, first, c);
+                    else qt::sort_swap(acc, first, b);
+                }
+                wex.sync();
+                qt::ParScratch pl = ps;  // this range's private stretch of the position lists
+                pl.gpos = ps.gpos + first;
+                pl.lpos = ps.lpos + first;
+                const int cut = qt::partition_par(wex, items, first, last, pl);
+                if (lane == 0) {
+                    if (last - cut > 16) {
+                        const int k = __hip_atomic_fetch_add(&ps.sc[which ^ 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        nxt[3 * k] = cut; nxt[3 * k + 1] = last; nxt[3 * k + 2] = depth;
+                    }
+                    if (cut - first > 16) {
+                        const int k = __hip_atomic_fetch_add(&ps.sc[which ^ 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        nxt[3 * k] = first; nxt[3 * k + 1] = cut; nxt[3 * k + 2] = depth;
+                    }
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) ps.sc[which] = 0;
+            which ^= 1;
+            __syncthreads();
+        }
+        qt::final_stable_sort(*this, items, n, ps);  // rank counting: all threads
+    }
+    // Single frames (1024-thread instances, the workgroup has its CU to itself): the introsort loop without workgroup barriers.  The sub-ranges a partition leaves behind are independent (disjoint, and a
     // partition only looks at its own range), so which wave partitions which range, and when, cannot change the result.  A wave
     // that has partitioned a range keeps the left part and goes on with it (depth first); the right part goes into a ring of open
     // ranges in LDS that idle waves poll.  `pending` counts the chains that are still running or queued: the sort is over when it
@@ -71,6 +144,10 @@ struct DevEx {
     // than 16 elements, i.e. fewer than the ring holds; ps.sc[0] = head (next to take), ps.sc[1] = tail (published entries),
     // ps.sc[2] = pending, ps.sc[3] = reserved entries (>= tail: an entry is written, then published in reservation order).
     __device__ void sort(QT_LDS qt::SortItem* items, int n, QT_LDS int* stack, qt::ParScratch& ps) {
+        if constexpr (FRAME) sort_queue(items, n, stack, ps);
+        else sort_rounds(items, n, stack, ps);
+    }
+    __device__ void sort_queue(QT_LDS qt::SortItem* items, int n, QT_LDS int* stack, qt::ParScratch& ps) {
         mark(20);
         const int lane = threadIdx.x & 63;
         const int ring = 2 * ps.stack_half / 3;
@@ -270,7 +347,7 @@ struct DevEx {
     }
 };
 
-template <int PC>
+template <int PC, bool FRAME>
 __device__ __forceinline__ void quadtree_select_body(const QtLevels& lv, const Cand16* __restrict__ compact,
                                                      const int* __restrict__ img_base,
                                                      const int* __restrict__ level_count, uint16_t* __restrict__ label,
@@ -291,7 +368,7 @@ __device__ __forceinline__ void quadtree_select_body(const QtLevels& lv, const C
     if ((int)threadIdx.x >= nt_eff) return;
     qt::Workspace w;
     qt::workspace_carve(w, qt_mem, ws_N, ws_nini);
-    DevEx ex;
+    DevExT<FRAME> ex;
     ex.dbg = debug;
     ex.nt = nt_eff;
     int* out = sel_pt + (size_t)img * sel_stride + lv.sel_off[level];
@@ -309,7 +386,7 @@ __global__ __launch_bounds__(1024) void quadtree_select_kernel(QtLevels lv, cons
                                                               const int* __restrict__ level_count, uint16_t* __restrict__ label,
                                                               int* __restrict__ sel_pt, int* __restrict__ sel_n, int sel_stride, int ws_N,
                                                               int ws_nini, int debug, int big_levels, int small_nt) {
-    quadtree_select_body<PC>(lv, compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, ws_N, ws_nini, debug, big_levels, small_nt);
+    quadtree_select_body<PC, PC == kQtPointsPerThreadFrame>(lv, compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, ws_N, ws_nini, debug, big_levels, small_nt);
 }
 // Batch form: 256-thread instances whose first PC x 256 candidates stay in registers for the whole selection (a level-0 instance of
 // the BASELINE geometries has ~6 800): the per-generation point passes then touch no global memory at all.
@@ -318,7 +395,7 @@ __global__ __launch_bounds__(256, 4) void quadtree_select_batch_kernel(QtLevels 
                                                                    const int* __restrict__ level_count, uint16_t* __restrict__ label,
                                                                    int* __restrict__ sel_pt, int* __restrict__ sel_n, int sel_stride, int ws_N,
                                                                    int ws_nini, int debug, int big_levels, int small_nt) {
-    quadtree_select_body<PC>(lv, compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, ws_N, ws_nini, debug, big_levels, small_nt);
+    quadtree_select_body<PC, false>(lv, compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, ws_N, ws_nini, debug, big_levels, small_nt);
 }
 
 // One workgroup per image: records in level-major / quadtree order; output row = mono index from the front for

@@ -14,6 +14,7 @@
 using namespace msorb;
 
 struct HostEx {
+    static constexpr bool kSplitRank = true;
     int tid() const { return 0; }
     int nthreads() const { return 1; }
     void sync() {}
