@@ -135,6 +135,25 @@ int msorb_pyramid_level(msorb_extractor* h, int level, const uint8_t** data, int
  * mvImagePyramid on the host (an unchanged Frame::ComputeStereoMatches, Frame.cc:840-855).  Default off. */
 int msorb_extractor_set_host_pyramid(msorb_extractor* h, int enable);
 
+/* TWO images of the same size through ONE kernel chain (the batch pipeline with two images) — what the two extractor threads of
+ * Frame::Frame (Frame.cc:122-125) compute with two concurrent operator() calls, for callers that can hand both images over at
+ * once WITHOUT the stereo match (msorb_extract_stereo is the call that also matches).  0.204 ms per pair against 2 x 0.18 for
+ * two calls.  (A rendezvous of the two eye threads inside the drop-in class onto this call was measured and retired:
+ * tools/experiments/README.md.)  Both images share the lapping area [lap0, lap1] (rectified stereo: 0, 0).  Results identical to two
+ * msorb_extract calls on two handles.  With msorb_extractor_set_host_pyramid the levels 1.. of BOTH pyramids come back to pinned
+ * memory as in msorb_extract (msorb_pyramid_level_image).  capacity = entries available in each of the caller's arrays.
+ * staged: bit 0 / bit 1 = image_a / image_b is a pointer msorb_stage_image returned (from ANY handle on this device, with the
+ * same geometry): the image already lies in pinned memory at the library's row pitch and is uploaded from there. */
+int msorb_extract_pair(msorb_extractor* h, const uint8_t* image_a, const uint8_t* image_b, int rows, int cols, size_t stride_a,
+                       size_t stride_b, int lap0, int lap1, msorb_keypoint* kps_a, uint8_t* desc_a, int* n_a, int* mono_a,
+                       msorb_keypoint* kps_b, uint8_t* desc_b, int* n_b, int* mono_b, int capacity, int staged);
+/* Copies a host image into the handle's pinned staging plane (what msorb_extract does first) and returns that plane: *pinned
+ * (valid until the handle's next stage / extract call), *pitch its row pitch.  msorb_extract on the SAME handle recognises
+ * the pointer and skips its own copy; msorb_extract_pair takes it with the `staged` bits. */
+int msorb_stage_image(msorb_extractor* h, const uint8_t* image, int rows, int cols, size_t stride, const uint8_t** pinned, size_t* pitch);
+/* msorb_pyramid_level for image 0 / 1 of the last msorb_extract_pair call (image 0 only after any other extract call). */
+int msorb_pyramid_level_image(msorb_extractor* h, int image, int level, const uint8_t** data, int* rows, int* cols, size_t* stride);
+
 /* The OpenCV primitives the extractor restates (resize, GaussianBlur, fastAtan2) are un-vendored dependencies of the reference
  * (CMakeLists.txt:35: OpenCV >= 4.4, no pinned version).  Their semantics follow SURVEY.md Appendix A; the three places where
  * a real OpenCV build could differ are ONE runtime-selectable table, in the kernels (here) and in the oracle

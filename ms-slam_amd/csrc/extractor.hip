@@ -191,6 +191,9 @@ struct msorb_extractor {
     hipStream_t pyr_stream = nullptr;
     hipEvent_t ev_pyr_done = nullptr;
     bool h_pyr_async = false;  // h_pyr holds levels 1.. of the last msorb_extract call, level 0 = h_img_pin
+    const uint8_t* pair_l0[2] = {nullptr, nullptr};   // host level 0 of the two images of the last msorb_extract_pair call
+    int pair_request = 0;      // one-shot: set by msorb_extract_pair around its run_pipeline call
+    int pair_pyramids = 0;     // msorb_extract_pair: host pyramids of this many images are wanted / were copied (image i at h_pyr + i * pyramid_bytes)
     unsigned long long buffers_epoch = 0;  // bumped whenever a device / pinned buffer may have moved
     hipEvent_t ev_compact = nullptr, ev_pyramid = nullptr, ev_blur = nullptr;
     hipEvent_t pe[10] = {};
@@ -495,6 +498,23 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
             HIPCHK(hipEventRecord(G.ev_pyr, s));
             HIPCHK(hipStreamWaitEvent(sb, G.ev_pyr, 0));
         }
+        if (h->host_pyramid && h->pair_pyramids == 2 && n_images == 2 && ng == 1 && !h->capturing) {
+            // msorb_extract_pair with the host pyramids requested: levels 1.. of both images leave on the pyramid stream
+            int prc;
+            if ((prc = h->h_pyr.ensure(2 * g.pyramid_bytes))) return prc;
+            if (!h->pyr_stream) {
+                HIPCHK(hipStreamCreateWithFlags(&h->pyr_stream, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&h->ev_pyr_done, hipEventDisableTiming));
+            }
+            if (!h->overlap_blur) HIPCHK(hipEventRecord(G.ev_pyr, s));
+            HIPCHK(hipStreamWaitEvent(h->pyr_stream, G.ev_pyr, 0));
+            if (nl > 1)
+                for (int i = 0; i < 2; i++)
+                    HIPCHK(hipMemcpyAsync(h->h_pyr.p + (size_t)i * g.pyramid_bytes + g.lv[1].plane_off,
+                                          h->d_pyr.p + (size_t)i * g.pyramid_bytes + g.lv[1].plane_off, g.pyramid_bytes - g.lv[1].plane_off,
+                                          hipMemcpyDeviceToHost, h->pyr_stream));
+            h->h_pyr_async = true;
+        }
         if (h->host_pyramid && n_images == 1 && !h->capturing && level0.base == h->d_pyr.p + g.lv[0].plane_off) {
             // per-frame call with the host pyramid requested: levels 1.. leave for pinned memory now, on their own stream
             int prc;
@@ -560,6 +580,8 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
 // The pipeline proper.  level0: where level 0 of every image lives (device memory).
 int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int lap0, int lap1,
                  msorb_keypoint* d_kps, uint8_t* d_desc, int capacity, int* h_counts, int* h_mono) {
+    h->pair_pyramids = h->pair_request;   // (any other call forgets the pair state of an earlier msorb_extract_pair)
+    h->pair_request = 0;
     if (h->device_quadtree && !h->knobs.serial_pipeline)
         return run_pipeline_groups(h, level0, n_images, lap0, lap1, d_kps, d_desc, capacity, h_counts, h_mono);
     h->last_groups = 1;
@@ -987,9 +1009,11 @@ int msorb_extract(msorb_extractor* h, const uint8_t* image, int rows, int cols, 
     // level 0 = copy of the caller's image (ORBextractor.cc:1190: the input is never modified or aliased).  Pageable
     // memory is staged through pinned buffers owned by the handle: a plain hipMemcpy from pageable memory makes the
     // driver pin/unpin per call, which costs more than the whole kernel chain.
-    if ((rc = h->h_img_pin.ensure((size_t)g0.pitch * rows))) return rc;
+    const bool staged = h->h_img_pin.p && image == h->h_img_pin.p && stride == (size_t)g0.pitch;   // msorb_stage_image did the copy
+    if ((rc = h->h_img_pin.ensure(staged ? 1 : (size_t)g0.pitch * rows))) return rc;
     if ((rc = h->h_out_pin.ensure((size_t)cap * (sizeof(msorb_keypoint) + 32)))) return rc;
-    for (int y = 0; y < rows; y++) memcpy(h->h_img_pin.p + (size_t)y * g0.pitch, image + (size_t)y * stride, cols);
+    if (!staged)
+        for (int y = 0; y < rows; y++) memcpy(h->h_img_pin.p + (size_t)y * g0.pitch, image + (size_t)y * stride, cols);
     LevelView l0{h->d_pyr.p + g0.plane_off, h->G.pyramid_bytes, g0.pitch, cols, rows};
     msorb_keypoint* pk = reinterpret_cast<msorb_keypoint*>(h->h_out_pin.p);
     uint8_t* pd = h->h_out_pin.p + (size_t)cap * sizeof(msorb_keypoint);
@@ -1033,6 +1057,109 @@ int msorb_extract(msorb_extractor* h, const uint8_t* image, int rows, int cols, 
     }
     *n_keypoints = n;
     *mono_index = mono;
+    return MSORB_OK;
+}
+
+int msorb_extract_pair(msorb_extractor* h, const uint8_t* image_a, const uint8_t* image_b, int rows, int cols, size_t stride_a,
+                       size_t stride_b, int lap0, int lap1, msorb_keypoint* kps_a, uint8_t* desc_a, int* n_a, int* mono_a,
+                       msorb_keypoint* kps_b, uint8_t* desc_b, int* n_b, int* mono_b, int capacity, int staged) {
+    if (h && h->pending_batch) { set_error("a submitted batch of this handle has not been waited for"); return MSORB_E_INVALID; }
+    if (!h || !n_a || !n_b || !mono_a || !mono_b) return MSORB_E_INVALID;
+    *n_a = *n_b = 0;
+    *mono_a = *mono_b = -1;
+    if (!image_a || !image_b || rows <= 0 || cols <= 0) return MSORB_E_EMPTY;
+    if (!kps_a || !desc_a || !kps_b || !desc_b || (int)stride_a < cols || (int)stride_b < cols) return MSORB_E_INVALID;
+    if (!h->device_quadtree || h->knobs.serial_pipeline || h->profiling) { set_error("msorb_extract_pair needs the device pipeline"); return MSORB_E_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure_geometry(h, rows, cols))) return rc;
+    if ((rc = ensure_batch(h, 2))) return rc;
+    const int cap = capacity_of(h);
+    const FrameGeom& g = h->G;
+    const LevelGeom& g0 = g.lv[0];
+    const size_t kp_bytes = (size_t)cap * sizeof(msorb_keypoint), o_desc = 2 * kp_bytes, out_bytes = o_desc + (size_t)2 * cap * 32;
+    const size_t plane = (size_t)g0.pitch * rows;
+    if ((rc = h->d_st_block.ensure(out_bytes)) || (rc = h->d_st_img.ensure(2 * plane + 256)) || (rc = h->h_img_pin.ensure(2 * plane)) ||
+        (rc = h->h_out_pin.ensure(out_bytes)))
+        return rc;
+    hipStream_t s = h->stream;
+    const uint8_t* src[2] = {image_a, image_b};
+    const size_t stride[2] = {stride_a, stride_b};
+    for (int i = 0; i < 2; i++) {
+        const uint8_t* pin = h->h_img_pin.p + (size_t)i * plane;
+        if (staged & (1 << i)) {   // already in pinned memory at the library's pitch (msorb_stage_image)
+            if (stride[i] != (size_t)g0.pitch) { set_error("msorb_extract_pair: a staged image must have the staging pitch"); return MSORB_E_INVALID; }
+            pin = src[i];
+        } else {
+            for (int y = 0; y < rows; y++) memcpy(h->h_img_pin.p + (size_t)i * plane + (size_t)y * g0.pitch, src[i] + (size_t)y * stride[i], cols);
+        }
+        h->pair_l0[i] = pin;
+        if ((rc = frame_copy(h, h->d_st_img.p + (size_t)i * plane, pin, plane, hipMemcpyHostToDevice, s))) return rc;
+    }
+    LevelView l0{h->d_st_img.p, plane, g0.pitch, cols, rows};
+    uint8_t* const blk = h->d_st_block.p;
+    int counts[2] = {0, 0}, mono[2] = {0, 0};
+    h->pair_request = 2;
+    h->defer_sync = true;
+    rc = run_pipeline(h, l0, 2, lap0, lap1, reinterpret_cast<msorb_keypoint*>(blk), blk + o_desc, cap, counts, mono);
+    h->defer_sync = false;
+    if (rc) { h->pair_pyramids = 0; return rc; }
+    uint8_t* o = h->h_out_pin.p;
+    if ((rc = frame_copy(h, o, blk, out_bytes, hipMemcpyDeviceToHost, s))) return rc;
+    HIPCHK(hipStreamSynchronize(s));
+    if (h->h_pyr_async) HIPCHK(hipStreamSynchronize(h->pyr_stream));
+    HIPCHK(hipGetLastError());
+    const int na = h->h_sel_count.p[0], nb = h->h_sel_count.p[1];
+    if (na < 0 || nb < 0) { set_error("keypoint capacity exceeded"); return MSORB_E_CAPACITY; }
+    if (na > capacity || nb > capacity) { set_error("caller capacity too small"); return MSORB_E_CAPACITY; }
+    memcpy(kps_a, o, (size_t)na * sizeof(msorb_keypoint));
+    memcpy(kps_b, o + kp_bytes, (size_t)nb * sizeof(msorb_keypoint));
+    memcpy(desc_a, o + o_desc, (size_t)na * 32);
+    memcpy(desc_b, o + o_desc + (size_t)cap * 32, (size_t)nb * 32);
+    *n_a = na; *n_b = nb;
+    *mono_a = h->h_mono.p[0]; *mono_b = h->h_mono.p[1];
+    return MSORB_OK;
+}
+
+int msorb_stage_image(msorb_extractor* h, const uint8_t* image, int rows, int cols, size_t stride, const uint8_t** pinned, size_t* pitch) {
+    if (!h || !pinned || !image || rows <= 0 || cols <= 0 || (int)stride < cols) return MSORB_E_INVALID;
+    if (h->pending_batch) { set_error("a submitted batch of this handle has not been waited for"); return MSORB_E_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure_geometry(h, rows, cols))) return rc;
+    const LevelGeom& g0 = h->G.lv[0];
+    if ((rc = h->h_img_pin.ensure(2 * (size_t)g0.pitch * rows))) return rc;   // (two planes: msorb_extract_pair stages here too)
+    for (int y = 0; y < rows; y++) memcpy(h->h_img_pin.p + (size_t)y * g0.pitch, image + (size_t)y * stride, cols);
+    *pinned = h->h_img_pin.p;
+    if (pitch) *pitch = (size_t)g0.pitch;
+    return MSORB_OK;
+}
+
+int msorb_pyramid_level_image(msorb_extractor* h, int image, int level, const uint8_t** data, int* rows, int* cols, size_t* stride) {
+    if (image == 0 && !(h && h->pair_pyramids == 2)) return msorb_pyramid_level(h, level, data, rows, cols, stride);
+    if (!h || !data || !h->geom_valid || h->pair_pyramids != 2 || h->last_n_images != 2 || image < 0 || image > 1 || level < 0 ||
+        level >= h->G.nlevels)
+        return MSORB_E_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    const FrameGeom& g = h->G;
+    if (!h->h_pyr_async) {   // the pair call ran without msorb_extractor_set_host_pyramid: fetch both pyramids now, once
+        int rc;
+        if ((rc = h->h_pyr.ensure(2 * g.pyramid_bytes))) return rc;
+        if (g.nlevels > 1)
+            for (int i = 0; i < 2; i++)
+                HIPCHK(hipMemcpy(h->h_pyr.p + (size_t)i * g.pyramid_bytes + g.lv[1].plane_off,
+                                 h->d_pyr.p + (size_t)i * g.pyramid_bytes + g.lv[1].plane_off, g.pyramid_bytes - g.lv[1].plane_off, hipMemcpyDeviceToHost));
+        if (!h->pyr_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&h->pyr_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_pyr_done, hipEventDisableTiming));
+        }
+        h->h_pyr_async = true;
+    }
+    HIPCHK(hipStreamSynchronize(h->pyr_stream));
+    *data = level == 0 ? h->pair_l0[image] : h->h_pyr.p + (size_t)image * g.pyramid_bytes + g.lv[level].plane_off;
+    if (rows) *rows = g.lv[level].h;
+    if (cols) *cols = g.lv[level].w;
+    if (stride) *stride = g.lv[level].pitch;
     return MSORB_OK;
 }
 
@@ -1356,7 +1483,7 @@ int msorb_pyramid_batch(msorb_extractor* h, const uint8_t* d_images, int n_image
     launch_pyramid(pyr, h->d_taps.p, h->tap_x_off.data(), h->tap_y_off.data(), n_images, h->stream, h->sem);
     HIPCHK(hipGetLastError());
     h->last_pyr = pyr; h->last_n_images = n_images;
-    h->h_pyr_valid = false; h->compact_on_host = false;
+    h->pair_pyramids = 0; h->h_pyr_valid = false; h->compact_on_host = false;
     return MSORB_OK;
 }
 

@@ -31,7 +31,7 @@ EXPORTS = (
     "msorb_extract_batch", "msorb_extractor_set_profiling", "msorb_extractor_set_overlap", "msorb_extractor_stage_ms", "msorb_debug_level_size",
     "msorb_debug_copy_level", "msorb_debug_candidates", "msorb_distribute_quadtree", "msorb_extract_stereo",
     "msorb_extract_stereo_split", "msorb_pyramid_batch", "msorb_stereo_matches_split", "msorb_extractor_set_host_pyramid",
-    "msorb_extractor_set_semantics",
+    "msorb_extractor_set_semantics", "msorb_extract_pair", "msorb_stage_image", "msorb_pyramid_level_image",
 )
 
 
@@ -182,6 +182,38 @@ class ORBextractor:
                                            _np_ptr(dp), C.byref(oob)), "msorb_extract_stereo")
         a, b = nl.value, nr.value
         return kl[:a].copy(), dl[:a].copy(), kr[:b].copy(), dr[:b].copy(), ur[:a].copy(), dp[:a].copy(), oob.value
+
+    def extract_pair(self, image_a, image_b, lapping=(0, 0), stage=False):
+        """msorb_extract_pair: two same-sized images through one kernel chain, no stereo match.
+        -> ((mono_a, kps_a, desc_a), (mono_b, kps_b, desc_b)); stage=True goes through msorb_stage_image for image_a."""
+        image_a, image_b = np.ascontiguousarray(image_a, np.uint8), np.ascontiguousarray(image_b, np.uint8)
+        assert image_a.shape == image_b.shape and image_a.ndim == 2
+        rows, cols = image_a.shape
+        cap = self.capacity
+        vp, ci, sz = C.c_void_p, C.c_int, C.c_size_t
+        ka, kb = np.zeros(cap, KP_DTYPE), np.zeros(cap, KP_DTYPE)
+        da, db = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
+        na, nb, ma, mb = ci(0), ci(0), ci(0), ci(0)
+        pa, stride_a, staged = _np_ptr(image_a), cols, 0
+        if stage:
+            pin, pitch = vp(), sz()
+            self.L.msorb_stage_image.argtypes = [vp, vp, ci, ci, sz, vp, vp]
+            _check(self.L.msorb_stage_image(self.h, pa, rows, cols, cols, C.byref(pin), C.byref(pitch)), "msorb_stage_image")
+            pa, stride_a, staged = pin, pitch.value, 1
+        self.L.msorb_extract_pair.argtypes = [vp, vp, vp, ci, ci, sz, sz, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci]
+        _check(self.L.msorb_extract_pair(self.h, pa, _np_ptr(image_b), rows, cols, stride_a, cols, lapping[0], lapping[1],
+                                         _np_ptr(ka), _np_ptr(da), C.byref(na), C.byref(ma), _np_ptr(kb), _np_ptr(db),
+                                         C.byref(nb), C.byref(mb), cap, staged), "msorb_extract_pair")
+        a, b = na.value, nb.value
+        return (ma.value, ka[:a].copy(), da[:a].copy()), (mb.value, kb[:b].copy(), db[:b].copy())
+
+    def pyramid_level_image(self, image, level):
+        """mvImagePyramid[level] of image 0 / 1 of the last extract_pair (needs set_host_pyramid for levels >= 1)."""
+        p, r, c, s = C.c_void_p(), C.c_int(), C.c_int(), C.c_size_t()
+        _check(self.L.msorb_pyramid_level_image(self.h, image, level, C.byref(p), C.byref(r), C.byref(c), C.byref(s)),
+               "msorb_pyramid_level_image")
+        buf = (C.c_uint8 * (s.value * r.value)).from_address(p.value)
+        return np.frombuffer(buf, np.uint8).reshape(r.value, s.value)[:, :c.value].copy()
 
     def extract_stereo_split(self, right_ex, left, right, mb, mbf):
         """msorb_extract_stereo_split: self = the left extractor (device A), right_ex = the right extractor (device B, may

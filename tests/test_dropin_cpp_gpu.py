@@ -809,3 +809,4 @@ def test_cpp_search_local_points_chain_matches_oracle(tmp_path, oracle, msorb_mo
     assert n_to_match == int(iv.sum())
     assert np.array_equal(rec["inview"].astype(bool), iv)
     assert np.array_equal(rec["visible"], iv.astype(np.int32)) and np.array_equal(rec["proj"], iv.astype(np.int32))
+

@@ -508,3 +508,38 @@ def test_hip_extractor_against_real_opencv_extractor_pins(msorb_mod):
         pytest.skip("no whole-extractor OpenCV pins committed yet (python tools/pin_opencv.py --extractor on a machine with cv2)")
     bad, meta = top.compare_extractor(_hip_extract(msorb_mod), top.PINS)
     assert not bad, f"the HIP extractor differs from the kit's run on OpenCV {meta['cv2_version']}:\n" + "\n".join(bad)
+
+
+def oracle_level(ref, img, level):
+    ref(img)
+    return ref.level(level)
+
+
+@pytest.mark.parametrize("name", ["kitti", "small", "fourseasons"])
+def test_extract_pair_is_two_operator_calls(msorb_mod, oracle, name):
+    """msorb_extract_pair (two images, one kernel chain, no stereo match) == two ORBextractor::operator() calls
+    (Frame.cc:122-125's two threads): keypoints, descriptors, monoIndex with a lapping area, and both host pyramids; the
+    staged form (msorb_stage_image) and a plain call on the same handle afterwards give the same."""
+    cfg = CONFIGS[name]
+    ex, ref = _pair(msorb_mod, oracle, cfg)
+    ex.set_host_pyramid(True)
+    L, R = synth.stereo_pair(321, cfg["rows"], cfg["cols"])
+    for lap, stage in (((0, 0), False), ((40, cfg["cols"] // 2), False), ((0, 0), True)):
+        (ma, ka, da), (mb, kb, db) = ex.extract_pair(L, R, lap, stage=stage)
+        for img, which, mono, kps, desc in ((L, 0, ma, ka, da), (R, 1, mb, kb, db)):
+            rmono, rkps, rdesc = ref(img, lap)
+            assert mono == rmono
+            _assert_same(kps, desc, rkps, rdesc)
+            for l in range(cfg["nlevels"]):
+                assert np.array_equal(ex.pyramid_level_image(which, l), ref.level(l)), f"image {which} host pyramid level {l}"
+    ex.set_host_pyramid(False)                    # without it the pyramids are fetched on first request
+    ex.extract_pair(L, R)
+    assert np.array_equal(ex.pyramid_level_image(1, 2), oracle_level(ref, R, 2))
+    assert np.array_equal(ex.pyramid_level_image(0, cfg["nlevels"] - 1), oracle_level(ref, L, cfg["nlevels"] - 1))
+    mono, kps, desc = ex(R)                       # the handle goes back to single-image calls
+    rmono, rkps, rdesc = ref(R)
+    _assert_same(kps, desc, rkps, rdesc)
+    assert np.array_equal(ex.pyramid_level(3), ref.level(3))
+    with pytest.raises(msorb_mod.MsorbError):
+        ex.pyramid_level_image(1, 0)              # image 1 exists only after a pair call
+    ex.close()
