@@ -10,6 +10,7 @@
 #include "lds_limit.h"
 #include "orb_device.h"
 #include "quadtree_device.h"
+#include "quadtree_paths_device.h"
 #include "stereo_rowtable_device.h"
 
 namespace msorb {
@@ -314,6 +315,15 @@ struct DevExT {
             (void)__hip_atomic_fetch_add(arr + idx, len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
+    // the path tables' 16-bit counters, two to a word (LDS has no 16-bit atomics): idx counts entries from the 4-byte aligned base
+    __device__ void add16(QT_LDS uint16_t* arr, int idx) {
+        (void)__hip_atomic_fetch_add((QT_LDS int*)arr + (idx >> 1), 1 << ((idx & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // *p += sum of v over the wave (one atomic per wave that has anything to add)
+    __device__ void wave_sum_add(QT_LDS int* p, int v, int) {
+        const int incl = wave_incl_scan_dpp(v);
+        if ((threadIdx.x & 63) == 63 && incl != 0) (void)__hip_atomic_fetch_add(p, incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     // claim: *ctr += (number of lanes with pred); returns a distinct value of the claimed range to every lane with pred
     __device__ int claim(QT_LDS int* ctr, bool pred) {
         const uint64_t m = __ballot(pred);
@@ -353,7 +363,7 @@ __device__ __forceinline__ void quadtree_select_body(const QtLevels& lv, const C
                                                      const int* __restrict__ level_count, uint16_t* __restrict__ label,
                                                      int* __restrict__ sel_pt /* [img][sel_stride] candidate idx */,
                                                      int* __restrict__ sel_n /* [img][nlevels] */, int sel_stride,
-                                                     int ws_N, int ws_nini, int debug, int big_levels, int small_nt) {
+                                                     int ws_N, int ws_nini, int debug, int big_levels, int small_nt, int path_cap) {
     extern __shared__ __attribute__((aligned(16))) char qt_mem[];
     // grid = (image, level): consecutive workgroups (dealt round-robin to the 8 XCDs) are different images of one
     // level, so the heavy level-0 instances are spread over all XCDs instead of piling up on one
@@ -372,8 +382,27 @@ __device__ __forceinline__ void quadtree_select_body(const QtLevels& lv, const C
     ex.dbg = debug;
     ex.nt = nt_eff;
     int* out = sel_pt + (size_t)img * sel_stride + lv.sel_off[level];
-    const int kept = qt::select<PC>(ex, reinterpret_cast<const qt::Pt*>(compact + off), n, label + off, lv.W[level], lv.H[level],
-                                lv.quota[level], w, out, debug);
+    int kept = -1;
+    if constexpr (FRAME) {
+        // single frames: selection by quadrant path (quadtree_paths_device.h) when the tree fits the tables the LDS behind the
+        // workspace holds — a level with few candidates (n <= 2 N: the tree grows until every point is alone) gets the deepest
+        if (path_cap > 0 && (debug == 0 || debug == 3)) {
+            const int N = lv.quota[level], n_ini = lv.n_ini[level];
+            qt::PathTables pt;
+            qt::path_tables_carve(pt, qt_mem + qt::workspace_bytes(ws_N, ws_nini), n_ini, qt::path_gmax(n <= 2 * N ? (1 << 20) : N, n_ini, path_cap), lv.W[level], lv.H[level]);
+            kept = qt::select_paths<PC>(ex, reinterpret_cast<const qt::Pt*>(compact + off), n, lv.W[level], lv.H[level], N, w, pt, out);
+        }
+    }
+    if (kept < 0) {
+        if constexpr (FRAME) {
+            // (opaque to the optimiser: with the candidate loads and the workspace pointers of the two forms merged, their bodies
+            // shared one register allocation — 113 VGPRs + 104 bytes of scratch per lane against 82 / 95 and none on their own)
+            asm volatile("" : "+s"(off) :: "memory");
+            qt::workspace_carve(w, qt_mem, ws_N, ws_nini);
+        }
+        kept = qt::select<PC>(ex, reinterpret_cast<const qt::Pt*>(compact + off), n, label + off, lv.W[level], lv.H[level],
+                              lv.quota[level], w, out, debug);
+    }
 #ifdef MSORB_QT_SORTCHECK
     if (threadIdx.x == 0) sel_n[(size_t)img * lv.nlevels + level] = g_sortcheck_bad ? 0 : kept;
 #else
@@ -385,8 +414,8 @@ template <int PC>
 __global__ __launch_bounds__(1024) void quadtree_select_kernel(QtLevels lv, const Cand16* __restrict__ compact, const int* __restrict__ img_base,
                                                               const int* __restrict__ level_count, uint16_t* __restrict__ label,
                                                               int* __restrict__ sel_pt, int* __restrict__ sel_n, int sel_stride, int ws_N,
-                                                              int ws_nini, int debug, int big_levels, int small_nt) {
-    quadtree_select_body<PC, PC == kQtPointsPerThreadFrame>(lv, compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, ws_N, ws_nini, debug, big_levels, small_nt);
+                                                              int ws_nini, int debug, int big_levels, int small_nt, int path_cap) {
+    quadtree_select_body<PC, PC == kQtPointsPerThreadFrame>(lv, compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, ws_N, ws_nini, debug, big_levels, small_nt, path_cap);
 }
 // Batch form: 256-thread instances whose first PC x 256 candidates stay in registers for the whole selection (a level-0 instance of
 // the BASELINE geometries has ~6 800): the per-generation point passes then touch no global memory at all.
@@ -395,7 +424,7 @@ __global__ __launch_bounds__(256, 4) void quadtree_select_batch_kernel(QtLevels 
                                                                    const int* __restrict__ level_count, uint16_t* __restrict__ label,
                                                                    int* __restrict__ sel_pt, int* __restrict__ sel_n, int sel_stride, int ws_N,
                                                                    int ws_nini, int debug, int big_levels, int small_nt) {
-    quadtree_select_body<PC, false>(lv, compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, ws_N, ws_nini, debug, big_levels, small_nt);
+    quadtree_select_body<PC, false>(lv, compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, ws_N, ws_nini, debug, big_levels, small_nt, 0);
 }
 
 // One workgroup per image: records in level-major / quadtree order; output row = mono index from the front for
@@ -542,13 +571,27 @@ int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_ba
         hipLaunchKernelGGL(quadtree_select_batch_kernel<kQtPointsPerThreadBatch>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds, s, lv,
                            compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt);
     } else if (qt_threads == 1024) {
-        if (!raise_lds(reinterpret_cast<const void*>(quadtree_select_kernel<kQtPointsPerThreadFrame>))) return MSORB_E_HIP;
-        hipLaunchKernelGGL(quadtree_select_kernel<kQtPointsPerThreadFrame>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds, s, lv,
-                           compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt);
+        const void* fn = reinterpret_cast<const void*>(quadtree_select_kernel<kQtPointsPerThreadFrame>);
+        // path tables behind the workspace: the deepest generation (<= 6) whose tables the LDS still holds for every level
+        static const bool paths_off = getenv("MSORB_QT_PATHS") && atoi(getenv("MSORB_QT_PATHS")) == 0;
+        int path_cap = 0;
+        size_t lds_paths = 0;
+        if (!paths_off) {
+            const long long room = dynamic_lds_room(fn);
+            for (int cap = 6; cap >= 2 && !path_cap; cap--) {
+                size_t need = 0;
+                for (int l = 0; l < lv.nlevels; l++)
+                    need = max(need, qt::path_tables_bytes(lv.n_ini[l], qt::path_gmax(1 << 20, lv.n_ini[l], cap), lv.W[l], lv.H[l]));
+                if ((long long)(lds + need) <= room) { path_cap = cap; lds_paths = need; }
+            }
+        }
+        if (!path_cap && !raise_lds(fn)) return MSORB_E_HIP;
+        hipLaunchKernelGGL(quadtree_select_kernel<kQtPointsPerThreadFrame>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds + lds_paths, s, lv,
+                           compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt, path_cap);
     } else {
         if (!raise_lds(reinterpret_cast<const void*>(quadtree_select_kernel<0>))) return MSORB_E_HIP;
         hipLaunchKernelGGL(quadtree_select_kernel<0>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds, s, lv, compact, img_base,
-                           level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt);
+                           level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt, 0);
     }
     if (row_job && lap1 < kMinBorder && row_job->right_img < n_images)
         hipLaunchKernelGGL(quadtree_layout_kernel, dim3(n_images + 1), dim3(1024), (size_t)(2 * row_job->rows0 + 1) * sizeof(int), s, lv, compact,

@@ -10,6 +10,7 @@
 
 #include "../ms-slam_amd/csrc/orb_host.h"
 #include "../ms-slam_amd/csrc/quadtree_device.h"
+#include "../ms-slam_amd/csrc/quadtree_paths_device.h"
 
 using namespace msorb;
 
@@ -21,6 +22,8 @@ struct HostEx {
     void mark(int) {}
     int atomic_add(int* p, int v) { const int o = *p; *p = o + v; return o; }
     void add_runs(int* arr, int idx) { if (idx >= 0) arr[idx]++; }
+    void add16(uint16_t* arr, int idx) { arr[idx]++; }
+    void wave_sum_add(int* p, int v, int) { *p += v; }
     int claim(int* ctr, bool pred) { return pred ? (*ctr)++ : 0; }
     void atomic_max(int* p, int v) { if (v > *p) *p = v; }
     void atomic_min(int* p, int v) { if (v < *p) *p = v; }
@@ -29,6 +32,7 @@ struct HostEx {
     void sort(qt::SortItem* v, int n, int* stack, qt::ParScratch&) { qt::lsort(v, n, stack); }
 };
 
+static int g_path_cap = qt::kMaxPathGen, g_path_fallbacks = 0, g_path_runs = 0;
 static int run_case(const std::vector<Cand16>& c, int W, int H, int N, bool verbose) {
     std::vector<int> kept;
     distribute_quadtree(c.data(), (int)c.size(), 16, 16 + W, 16, 16 + H, N, kept);
@@ -45,6 +49,25 @@ static int run_case(const std::vector<Cand16>& c, int W, int H, int N, bool verb
     const int n2 = qt::select<16>(ex, reinterpret_cast<const qt::Pt*>(c.data()), (int)c.size(), label.data(), W, H, N, w, out2.data());
     if (n2 != n) return 1;
     for (int i = 0; i < n; i++) if (out[i] != out2[i]) return 1;
+    // selection by quadrant path (what single frames run on the GPU; -1 = tree deeper than its tables: the general form runs)
+    for (int pc : {0, 16}) {
+        const int g_cap = g_path_cap;
+        const int gmax = qt::path_gmax(N, n_ini, g_cap);
+        std::vector<char> tmem(qt::path_tables_bytes(n_ini, gmax, W, H) + 64);
+        qt::PathTables pt;
+        qt::path_tables_carve(pt, tmem.data(), n_ini, gmax, W, H);
+        std::vector<int> out3(c.size() + 8, -7);
+        const int n3 = pc ? qt::select_paths<16>(ex, reinterpret_cast<const qt::Pt*>(c.data()), (int)c.size(), W, H, N, w, pt, out3.data())
+                          : qt::select_paths<0>(ex, reinterpret_cast<const qt::Pt*>(c.data()), (int)c.size(), W, H, N, w, pt, out3.data());
+        if (n3 < 0) { g_path_fallbacks++; continue; }
+        g_path_runs++;
+        bool same = n3 == n;
+        for (int i = 0; same && i < n; i++) same = out[i] == out3[i];
+        if (!same) {
+            if (verbose) fprintf(stderr, "PATH MISMATCH n=%zu W=%d H=%d N=%d got=%d want=%d (pc %d)\n", c.size(), W, H, N, n3, n, pc);
+            return 1;
+        }
+    }
     bool ok = n == (int)kept.size();
     for (int i = 0; ok && i < n; i++) ok = out[i] == kept[i];
     if (!ok && verbose) fprintf(stderr, "MISMATCH n=%zu W=%d H=%d N=%d got=%d want=%zu\n", c.size(), W, H, N, n, kept.size());
@@ -53,6 +76,21 @@ static int run_case(const std::vector<Cand16>& c, int W, int H, int N, bool verb
 
 int main(int argc, char** argv) {
     const int trials = argc > 1 ? atoi(argv[1]) : 3000;
+    if (argc > 3) g_path_cap = atoi(argv[3]);
+    if (argc > 2 && argv[2][0]) {   // candidate sets from a file (records: int32 W, H, N, n; n x {u16 x, y, score, pad}) instead of the random ones
+        FILE* f = fopen(argv[2], "rb");
+        if (!f) { perror(argv[2]); return 2; }
+        int hdr[4], bad = 0, total = 0;
+        while (fread(hdr, sizeof(int), 4, f) == 4) {
+            std::vector<Cand16> c(hdr[3]);
+            if (hdr[3] && fread(c.data(), sizeof(Cand16), c.size(), f) != c.size()) return 2;
+            bad += run_case(c, hdr[0], hdr[1], hdr[2], bad < 5);
+            total++;
+        }
+        fclose(f);
+        printf("cases=%d bad=%d path_runs=%d path_fallbacks=%d\n", total, bad, g_path_runs, g_path_fallbacks);
+        return bad != 0;
+    }
     std::mt19937 rng(12345);
     int bad = 0, total = 0;
     // 1. sort restatement
@@ -108,6 +146,6 @@ int main(int argc, char** argv) {
         bad += run_case(c, W, H, N, bad < 5);
         total++;
     }
-    printf("cases=%d bad=%d\n", total, bad);
+    printf("cases=%d bad=%d path_runs=%d path_fallbacks=%d\n", total, bad, g_path_runs, g_path_fallbacks);
     return bad != 0;
 }
