@@ -148,6 +148,24 @@ struct DevExT {
         if constexpr (FRAME) sort_queue(items, n, stack, ps);
         else sort_rounds(items, n, stack, ps);
     }
+    // __final_insertion_sort, leaf by leaf: the introsort loop leaves ranges of at most 16 elements unsorted, and every cut it made
+    // separates keys <= pivot from keys >= pivot — the stable insertion sort that libstdc++ runs over the whole array afterwards never
+    // moves an element across a cut, i.e. it is a stable sort of each leaf on its own.  The wave that ends up with a leaf sorts it at
+    // once (rank counting on keys held in lanes: no LDS traffic, no pass over the array at the end, no workgroup barrier).
+    __device__ void finish_leaf(QT_LDS qt::SortItem* items, int first, int last) {   // wave collective; last - first <= 64
+        const int lane = threadIdx.x & 63, len = last - first;
+        if (len <= 1) return;
+        qt::SortItem it{0xFFFFFFFFu, 0u};
+        if (lane < len) it = items[first + lane];
+        int rank = 0;
+        for (int j = 0; j < len; j++) {
+            const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)it.key, j);
+            rank += (kj < it.key) || (kj == it.key && j < lane);
+        }
+        if (lane < len) items[first + rank] = it;
+        WaveEx wex;
+        wex.sync();
+    }
     __device__ void sort_queue(QT_LDS qt::SortItem* items, int n, QT_LDS int* stack, qt::ParScratch& ps) {
         mark(20);
         const int lane = threadIdx.x & 63;
@@ -193,10 +211,13 @@ struct DevExT {
                 }
             }
             if (depth < 0) break;
+            mark(30);
+            bool sorted = false;
             while (last - first > 16) {   // __introsort_loop on [first, last)
                 if (depth == 0) {  // __partial_sort fallback (the introsort depth limit)
                     if (lane == 0) { qt::ArrayAcc a{items}; qt::heap_sort(a, first, last); }
                     wex.sync();
+                    sorted = true;
                     break;
                 }
                 --depth;
@@ -213,6 +234,7 @@ struct DevExT {
                     else qt::sort_swap(acc, first, b);
                 }
                 wex.sync();
+                mark(31);
                 qt::ParScratch pl = ps;  // this range's private stretch of the position lists
                 pl.gpos = ps.gpos + first;
                 pl.lpos = ps.lpos + first;
@@ -235,6 +257,7 @@ struct DevExT {
                 }
                 wex.sync();
 #endif
+                mark(32);
                 if (last - cut > 16) {   // [cut, last) becomes an open range: the entry first, then the tail that publishes it
                     int slot = 0;
                     if (lane == 0) {
@@ -247,9 +270,13 @@ struct DevExT {
                     // publish in reservation order: wait (whole wave, uniform loop) until every earlier reservation has been published
                     while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ps.sc[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != slot) __builtin_amdgcn_s_sleep(0);
                     if (lane == 0) __hip_atomic_store(&ps.sc[1], slot + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    finish_leaf(items, cut, last);
                 }
                 last = cut;
+                mark(33);
             }
+            if (!sorted) finish_leaf(items, first, last);
             if (lane == 0) (void)__hip_atomic_fetch_sub(&ps.sc[2], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);   // this chain has ended
         }
         __syncthreads();
@@ -267,7 +294,10 @@ struct DevExT {
         }
         __syncthreads();
 #endif
-        qt::final_stable_sort(*this, items, n, ps);  // rank counting: all threads
+        if (n <= 16) {   // no range was ever opened: the whole array is one leaf
+            if (threadIdx.x < 64) finish_leaf(items, 0, n);
+            __syncthreads();
+        }
         mark(22);
 #ifdef MSORB_QT_SORTCHECK
         if (threadIdx.x == 0) {
@@ -282,10 +312,10 @@ struct DevExT {
     int nt = 0;  // threads of this instance: blockDim.x, or fewer for the small levels of a mixed launch (the other waves have left)
 #ifdef MSORB_QT_MARKS  // per-phase timestamps of instance (0,0) (build with -DMSORB_QT_MARKS, run with MSORB_QT_DEBUG=3):
     int n_marks = 0;   // compiled out by default, the arrays would cost every wave 600 bytes of scratch
-    long long t_mark[48];
-    int id_mark[48];
+    long long t_mark[96];
+    int id_mark[96];
     __device__ void mark(int id) {
-        if (dbg == 3 && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && n_marks < 48) {
+        if (dbg == 3 && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && n_marks < 96) {
             t_mark[n_marks] = wall_clock64(); id_mark[n_marks] = id; n_marks++;
         }
     }
