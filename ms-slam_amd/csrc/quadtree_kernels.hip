@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <string>
 
 #include "lds_limit.h"
@@ -366,6 +367,7 @@ struct DevExT {
         return base + __popcll(m & ((1ull << lane) - 1ull));
     }
     __device__ void atomic_max(QT_LDS int* p, int v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __device__ void atomic_or(QT_LDS int* p, int v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     __device__ void atomic_min(QT_LDS int* p, int v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     __device__ int excl_count(bool p, int* total) { int t = 0; const int r = excl_scan((int)p, nullptr, &t); *total = t; return r; }  // unused
     // block-wide exclusive prefix of v over threads (<= 16 waves); tmp = 16 ints of LDS
@@ -413,18 +415,16 @@ __device__ __forceinline__ void quadtree_select_body(const QtLevels& lv, const C
     ex.nt = nt_eff;
     int* out = sel_pt + (size_t)img * sel_stride + lv.sel_off[level];
     int kept = -1;
-    if constexpr (FRAME) {
-        // single frames: selection by quadrant path (quadtree_paths_device.h) when the tree fits the tables the LDS behind the
-        // workspace holds — a level with few candidates (n <= 2 N: the tree grows until every point is alone) gets the deepest
-        if (path_cap > 0 && (debug == 0 || debug == 3)) {
-            const int N = lv.quota[level], n_ini = lv.n_ini[level];
-            qt::PathTables pt;
-            qt::path_tables_carve(pt, qt_mem + qt::workspace_bytes(ws_N, ws_nini), n_ini, qt::path_gmax(n <= 2 * N ? (1 << 20) : N, n_ini, path_cap), lv.W[level], lv.H[level]);
-            kept = qt::select_paths<PC>(ex, reinterpret_cast<const qt::Pt*>(compact + off), n, lv.W[level], lv.H[level], N, w, pt, out);
-        }
+    // selection by quadrant path (quadtree_paths_device.h) when the tree fits the tables the LDS behind the workspace holds — a
+    // level with few candidates (n <= 2 N: the tree grows until every point is alone) gets the deepest
+    if (path_cap > 0 && (debug == 0 || debug == 3)) {
+        const int N = lv.quota[level], n_ini = lv.n_ini[level];
+        qt::PathTables pt;
+        qt::path_tables_carve(pt, qt_mem + qt::workspace_bytes(ws_N, ws_nini), n_ini, qt::path_gmax(n <= 2 * N ? (1 << 20) : N, n_ini, path_cap), lv.W[level], lv.H[level]);
+        kept = qt::select_paths<PC>(ex, reinterpret_cast<const qt::Pt*>(compact + off), n, lv.W[level], lv.H[level], N, w, pt, out);
     }
     if (kept < 0) {
-        if constexpr (FRAME) {
+        {
             // (opaque to the optimiser: with the candidate loads and the workspace pointers of the two forms merged, their bodies
             // shared one register allocation — 113 VGPRs + 104 bytes of scratch per lane against 82 / 95 and none on their own)
             asm volatile("" : "+s"(off) :: "memory");
@@ -453,8 +453,8 @@ template <int PC>
 __global__ __launch_bounds__(256, 4) void quadtree_select_batch_kernel(QtLevels lv, const Cand16* __restrict__ compact, const int* __restrict__ img_base,
                                                                    const int* __restrict__ level_count, uint16_t* __restrict__ label,
                                                                    int* __restrict__ sel_pt, int* __restrict__ sel_n, int sel_stride, int ws_N,
-                                                                   int ws_nini, int debug, int big_levels, int small_nt) {
-    quadtree_select_body<PC, false>(lv, compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, ws_N, ws_nini, debug, big_levels, small_nt, 0);
+                                                                   int ws_nini, int debug, int big_levels, int small_nt, int path_cap) {
+    quadtree_select_body<PC, false>(lv, compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, ws_N, ws_nini, debug, big_levels, small_nt, path_cap);
 }
 
 // One workgroup per image: records in level-major / quadtree order; output row = mono index from the front for
@@ -596,32 +596,42 @@ int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_ba
         set_last_error("quadtree: the device refuses " + std::to_string(lds) + " bytes of LDS per workgroup");
         return false;
     };
+    // path tables behind the workspace: the deepest generation (<= max_cap) whose tables the LDS still holds for every level
+    static const bool paths_off = getenv("MSORB_QT_PATHS") && atoi(getenv("MSORB_QT_PATHS")) == 0;
+    auto path_tables = [&](const void* fn, int max_cap, long long budget, int& path_cap, size_t& lds_paths) {
+        path_cap = 0; lds_paths = 0;
+        if (paths_off) return;
+        const long long room = std::min<long long>(dynamic_lds_room(fn), budget);
+        for (int cap = max_cap; cap >= 2 && !path_cap; cap--) {
+            size_t need = 0;
+            for (int l = 0; l < lv.nlevels; l++)
+                need = max(need, qt::path_tables_bytes(lv.n_ini[l], qt::path_gmax(1 << 20, lv.n_ini[l], cap), lv.W[l], lv.H[l]));
+            if ((long long)(lds + need) <= room) { path_cap = cap; lds_paths = need; }
+        }
+    };
+    int path_cap = 0;
+    size_t lds_paths = 0;
     if (qt_threads == 256) {
-        if (!raise_lds(reinterpret_cast<const void*>(quadtree_select_batch_kernel<kQtPointsPerThreadBatch>))) return MSORB_E_HIP;
-        hipLaunchKernelGGL(quadtree_select_batch_kernel<kQtPointsPerThreadBatch>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds, s, lv,
-                           compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt);
+        const void* fn = reinterpret_cast<const void*>(quadtree_select_batch_kernel<kQtPointsPerThreadBatch>);
+        // batches: tables of four generations keep three workgroups on a CU (workspace 39.7 KB + 11.7 KB at the KITTI quota; five
+        // generations leave two: select stage alone 0.120 / 0.159 ms per 256 images against 0.139 without tables, pipelined step
+        // 1.091 / 1.095 against 1.131 ms); a level whose tree grows deeper runs the general form
+        static const int batch_cap = getenv("MSORB_QT_BATCH_PATHS") ? atoi(getenv("MSORB_QT_BATCH_PATHS")) : 4;
+        if (batch_cap > 0) path_tables(fn, batch_cap, 80 * 1024, path_cap, lds_paths);
+        if (!path_cap && !raise_lds(fn)) return MSORB_E_HIP;
+        hipLaunchKernelGGL(quadtree_select_batch_kernel<kQtPointsPerThreadBatch>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds + lds_paths, s, lv,
+                           compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt, path_cap);
     } else if (qt_threads == 1024) {
         const void* fn = reinterpret_cast<const void*>(quadtree_select_kernel<kQtPointsPerThreadFrame>);
-        // path tables behind the workspace: the deepest generation (<= 6) whose tables the LDS still holds for every level
-        static const bool paths_off = getenv("MSORB_QT_PATHS") && atoi(getenv("MSORB_QT_PATHS")) == 0;
-        int path_cap = 0;
-        size_t lds_paths = 0;
-        if (!paths_off) {
-            const long long room = dynamic_lds_room(fn);
-            for (int cap = 6; cap >= 2 && !path_cap; cap--) {
-                size_t need = 0;
-                for (int l = 0; l < lv.nlevels; l++)
-                    need = max(need, qt::path_tables_bytes(lv.n_ini[l], qt::path_gmax(1 << 20, lv.n_ini[l], cap), lv.W[l], lv.H[l]));
-                if ((long long)(lds + need) <= room) { path_cap = cap; lds_paths = need; }
-            }
-        }
+        path_tables(fn, 6, 1 << 30, path_cap, lds_paths);
         if (!path_cap && !raise_lds(fn)) return MSORB_E_HIP;
         hipLaunchKernelGGL(quadtree_select_kernel<kQtPointsPerThreadFrame>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds + lds_paths, s, lv,
                            compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt, path_cap);
     } else {
         if (!raise_lds(reinterpret_cast<const void*>(quadtree_select_kernel<0>))) return MSORB_E_HIP;
-        hipLaunchKernelGGL(quadtree_select_kernel<0>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds, s, lv, compact, img_base,
-                           level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt, 0);
+        path_tables(reinterpret_cast<const void*>(quadtree_select_kernel<0>), 5, 80 * 1024, path_cap, lds_paths);
+        hipLaunchKernelGGL(quadtree_select_kernel<0>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds + lds_paths, s, lv, compact, img_base,
+                           level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt, path_cap);
     }
     if (row_job && lap1 < kMinBorder && row_job->right_img < n_images)
         hipLaunchKernelGGL(quadtree_layout_kernel, dim3(n_images + 1), dim3(1024), (size_t)(2 * row_job->rows0 + 1) * sizeof(int), s, lv, compact,

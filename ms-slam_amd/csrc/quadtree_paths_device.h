@@ -91,6 +91,13 @@ struct PathBox {   // a node's box while a candidate (or a node builder) walks d
         y0 = (q & 2) ? my : y0; y1 = (q & 2) ? y1 : my;
     }
 };
+QT_HD int popc32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popc(v);
+#else
+    return __builtin_popcount(v);
+#endif
+}
 // position in generation g's processing order -> natural path index (an involution)
 QT_HD int path_of_position(int pos, int g, int n_ini) {
     const int low = (1 << (2 * g)) - 1;
@@ -398,49 +405,81 @@ QT_HD int select_paths(Ex& ex, const Pt* pts, int n, int W, int H, int N, Worksp
     }
     ex.mark(3);
 
-    // ---- 5. what becomes of the candidates of each entry of the deepest generation reached ----
+    // ---- 5. what becomes of the candidates of each entry of the deepest generation reached, and where in the output ----
+    // The output order is descending creation sequence (the node list from its front).  Sequence numbers are distinct integers
+    // below base[last_gen + 1]: every result sets its bit in a bitmap, a prefix population count over the words turns a sequence
+    // number into its output position — no pairwise comparison of the results (434 x 434 for a KITTI level 0: 5 us).
     const int nsplit_L = L >= 0 ? t.nsplit[L] : 0;
     const int n_unsplit = L >= 0 ? S_last - nsplit_L : 0;
     const int last_gen = L >= 0 ? L + 1 : F;                       // generation of the deepest final nodes
     const int n_deep = L >= 0 ? sc[(par ^ 1) ? kScS1 : kScS0] : (t.stat[F] >> 16);
+    const int n_nodes = n_unsplit + n_deep;
+    const int R = t.base[last_gen + 1] + n_ini;                    // sequence numbers + n_ini lie in [0, R)
+    const int words = (R + 31) >> 5;
+    if (R >= 0x8000 || 2 * words > w.cap || n_nodes > w.res_cap) return -1;
     QT_LDS int* const best = par ? w.cnt[0] : w.cnt[1];           // (cnt_np of the last sweep: its counts are used up)
-    for (int i = tid; i < n_unsplit + n_deep; i += nt) best[i] = 0;
-    {
-        // Walk from the column down to the entry: alone at some generation -> a result (slot claimed here, the candidate adds its
-        // index); a node that was not split -> its ordinal among the final nodes, | 0x8000.  The verdict replaces the entry's rank
-        // (only ranks of OTHER generations are read on the way, its own one before it is overwritten).
-        const int e = n_ini << (2 * last_gen);
-        QT_LDS const uint16_t* const tab = t.cnt + path_off(n_ini, last_gen);
-        QT_LDS uint16_t* const verdict = t.rank + path_off(n_ini, last_gen);
-        for (int i0 = 0; i0 < e; i0 += nt) {
-            const int i = i0 + tid;
-            const bool in = i < e && tab[i < e ? i : 0] > 0;
-            bool settle = false;
-            int seq = 0, node = 0;
-            if (in) {
-                const int c = i >> (2 * last_gen);
-                if (t.cnt[c] == 1) {
-                    settle = true; seq = -1 - c;                   // a single-point column (:590-594)
-                } else {
-                    for (int g = 0;; g++) {
-                        const int a = i >> (2 * (last_gen - g));
-                        const int r = t.rank[path_off(n_ini, g) + a];
-                        const bool split = g < last_gen && (g != L || r < nsplit_L);
-                        if (!split) { node = g == last_gen ? n_unsplit + r : r - nsplit_L; break; }
-                        const int ch = i >> (2 * (last_gen - g - 1));
-                        if (t.cnt[path_off(n_ini, g + 1) + ch] == 1) { settle = true; seq = t.base[g + 1] + 4 * r + (ch & 3); break; }
-                    }
+    QT_LDS int* const bits = par ? w.cnt[1] : w.cnt[0];           // [words] bitmap, [words] bits below each word
+    QT_LDS int* const below = bits + words;
+    QT_LDS int* const node_pos = w.res_seq;                        // a final node's sequence number, then its output position
+    QT_LDS const uint16_t* const tab_last = t.cnt + path_off(n_ini, last_gen);
+    QT_LDS uint16_t* const verdict = t.rank + path_off(n_ini, last_gen);
+    const int e_last = n_ini << (2 * last_gen);
+    for (int i = tid; i < n_nodes; i += nt) best[i] = 0;
+    for (int i = tid; i < words; i += nt) bits[i] = 0;
+    ex.sync();
+    // Walk from the column down to the entry: alone at some generation -> a result with that node's sequence number; a node that
+    // was not split -> its ordinal among the final nodes, | 0x8000.  The verdict replaces the entry's rank (only ranks of OTHER
+    // generations are read on the way, its own one before it is overwritten).
+    for (int i = tid; i < e_last; i += nt) {
+        if (tab_last[i] == 0) continue;
+        const int c = i >> (2 * last_gen);
+        int v;
+        if (t.cnt[c] == 1) {
+            v = n_ini - 1 - c;                                     // a single-point column (:590-594): sequence -1 - c
+            ex.atomic_or(&bits[v >> 5], 1 << (v & 31));
+        } else {
+            int seq = 0;                                           // of the node the walk stands on (generation >= 1)
+            for (int g = 0;; g++) {
+                const int a = i >> (2 * (last_gen - g));
+                const int r = t.rank[path_off(n_ini, g) + a];
+                const bool split = g < last_gen && (g != L || r < nsplit_L);
+                if (!split) {   // (g >= 1: a column with several points is always split)
+                    const int node = g == last_gen ? n_unsplit + r : r - nsplit_L;
+                    node_pos[node] = seq;                          // (every entry below the node writes the same value)
+                    ex.atomic_or(&bits[seq >> 5], 1 << (seq & 31));
+                    v = 0x8000 | node;
+                    break;
                 }
+                const int ch = i >> (2 * (last_gen - g - 1));
+                seq = t.base[g + 1] + 4 * r + (ch & 3) + n_ini;
+                if (t.cnt[path_off(n_ini, g + 1) + ch] == 1) { v = seq; ex.atomic_or(&bits[seq >> 5], 1 << (seq & 31)); break; }
             }
-            const int k = ex.claim(&sc[kScNres], settle);
-            if (settle) w.res_seq[k] = seq;
-            if (in) verdict[i] = (uint16_t)(settle ? k : 0x8000 | node);
         }
+        verdict[i] = (uint16_t)v;
     }
     ex.sync();
     ex.mark(4);
+    int nres = 0;
     {
-        QT_LDS const uint16_t* const verdict = t.rank + path_off(n_ini, last_gen);
+        const int per = (words + nt - 1) / nt;
+        const int wb = tid * per, we = wb + per < words ? wb + per : words;
+        int local = 0;
+        for (int i = wb; i < we; i++) local += popc32((uint32_t)bits[i]);
+        int before = ex.excl_scan(local, w.scan_tmp, &nres);
+        for (int i = wb; i < we; i++) { below[i] = before; before += popc32((uint32_t)bits[i]); }
+    }
+    ex.sync();
+    auto position = [&](int seq) {   // results with a larger sequence number come first
+        return nres - 1 - (below[seq >> 5] + popc32((uint32_t)bits[seq >> 5] & ((1u << (seq & 31)) - 1u)));
+    };
+    for (int i = tid; i < e_last; i += nt) {
+        if (tab_last[i] == 0) continue;
+        const int v = verdict[i];
+        if (!(v & 0x8000)) verdict[i] = (uint16_t)position(v);
+    }
+    for (int i = tid; i < n_nodes; i += nt) node_pos[i] = position(node_pos[i]);
+    ex.sync();
+    {
         const int sh = 2 * (G - last_gen);
         for_points(Again{}, [&](int p, bool valid, uint32_t path, int score) {
             if (!valid) return 0u;
@@ -448,45 +487,14 @@ QT_HD int select_paths(Ex& ex, const Pt* pts, int n, int W, int H, int N, Worksp
             if (v & 0x8000)   // first strictly greater response wins (:757-776): max over (response, -candidate index)
                 ex.atomic_max(&best[v & 0x7FFF], (int)(((uint32_t)score << 22) | (uint32_t)(0x3FFFFF - p)));
             else
-                w.res_pt[v] = p;
+                out_pt[v] = p;
             return 0u;
         });
     }
     ex.sync();
     ex.mark(5);
-    if (L >= 0) {
-        QT_LDS NodeB* const nb_par = par ? w.nb[1] : w.nb[0];
-        QT_LDS NodeB* const nb_np = par ? w.nb[0] : w.nb[1];
-        const int base_par = t.base[L], base_np = t.base[L + 1];
-        for (int i0 = 0; i0 < n_unsplit + n_deep; i0 += nt) {
-            const int i = i0 + tid;
-            const bool in = i < n_unsplit + n_deep;
-            const int k = ex.claim(&sc[kScNres], in);
-            if (in) {
-                w.res_seq[k] = i < n_unsplit ? base_par + (int)nb_par[nsplit_L + i].slot : base_np + (int)nb_np[i - n_unsplit].slot;
-                w.res_pt[k] = 0x3FFFFF - (best[i] & 0x3FFFFF);
-            }
-        }
-    } else {
-        // (the entries' ranks of generation F are verdicts by now: 0x8000 | ordinal for a multi-point entry)
-        const int e = n_ini << (2 * F);
-        QT_LDS const uint16_t* const tab = t.cnt + path_off(n_ini, F);
-        QT_LDS const uint16_t* const verdict = t.rank + path_off(n_ini, F);
-        QT_LDS const uint16_t* const rk_up = t.rank + path_off(n_ini, F - 1);
-        const int base_F = t.base[F];
-        for (int i0 = 0; i0 < e; i0 += nt) {
-            const int i = i0 + tid;
-            const bool in = i < e && tab[i < e ? i : 0] > 1;
-            const int k = ex.claim(&sc[kScNres], in);
-            if (in) {
-                w.res_seq[k] = base_F + 4 * (int)rk_up[i >> 2] + (i & 3);
-                w.res_pt[k] = 0x3FFFFF - (best[verdict[i] & 0x7FFF] & 0x3FFFFF);
-            }
-        }
-    }
+    for (int i = tid; i < n_nodes; i += nt) out_pt[node_pos[i]] = 0x3FFFFF - (best[i] & 0x3FFFFF);
     ex.sync();
-    const int nres = sc[kScNres];
-    rank_results(ex, w, nres, out_pt);
     ex.mark(6);
     return nres;
 }

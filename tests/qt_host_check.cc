@@ -26,6 +26,7 @@ struct HostEx {
     void wave_sum_add(int* p, int v, int) { *p += v; }
     int claim(int* ctr, bool pred) { return pred ? (*ctr)++ : 0; }
     void atomic_max(int* p, int v) { if (v > *p) *p = v; }
+    void atomic_or(int* p, int v) { *p |= v; }
     void atomic_min(int* p, int v) { if (v < *p) *p = v; }
     int excl_scan(int v, int*, int* total) { *total = v; return 0; }
     int excl_count(bool p, int* total) { *total = p; return 0; }
