@@ -208,6 +208,7 @@ struct msorb_extractor {
     // device state
     DevBuf<uint8_t> d_pyr, d_blur, d_desc1;
     DevBuf<ResizeTap> d_taps;
+    TowerPlan tower;           // the pyramid of a frame or two as one launch (orb_device.h); ntx == 0: not available for this geometry
     std::vector<size_t> tap_x_off, tap_y_off;
     DevBuf<CellDesc> d_cells;
     DevBuf<int> d_level_cell_begin, d_cell_count, d_cell_off, d_level_count, d_img_total, d_img_base, d_sel_count;
@@ -266,17 +267,25 @@ int ensure_geometry(msorb_extractor* h, int rows, int cols) {
     for (const CellDesc& c : g.cells) h->small_cells = h->small_cells && c.rw <= 46 && c.rh <= 57;
     // resize taps for levels 1..n-1
     std::vector<ResizeTap> all;
+    std::vector<std::vector<ResizeTap>> taps_x(g.nlevels), taps_y(g.nlevels);
     h->tap_x_off.assign(g.nlevels, 0);
     h->tap_y_off.assign(g.nlevels, 0);
     for (int l = 1; l < g.nlevels; l++) {
         auto tx = make_resize_taps(g.lv[l].w, g.lv[l - 1].w, true);
         auto ty = make_resize_taps(g.lv[l].h, g.lv[l - 1].h, false);
+        taps_x[l] = tx; taps_y[l] = ty;
         while (all.size() & 3) all.push_back(ResizeTap{0, 0, 0, 0});  // 32-byte aligned x tables (uint4 loads)
         h->tap_x_off[l] = all.size();
         all.insert(all.end(), tx.begin(), tx.end());
         while (all.size() & 3) all.push_back(tx.back());             // a group of 4 taps may run past the last column
         h->tap_y_off[l] = all.size();
         all.insert(all.end(), ty.begin(), ty.end());
+    }
+    for (int k = 0; k < 4; k++) all.push_back(ResizeTap{0, 0, 0, 0});   // (the tower's tap fetch may read one entry past a y table)
+    {   // single frames: the whole pyramid as one launch (TowerPlan)
+        int lw[kMaxLevels], lh[kMaxLevels], lp[kMaxLevels];
+        for (int l = 0; l < g.nlevels; l++) { lw[l] = g.lv[l].w; lh[l] = g.lv[l].h; lp[l] = g.lv[l].pitch; }
+        if (!build_tower_plan(h->tower, g.nlevels, lw, lh, lp, taps_x, taps_y, 150 * 1024)) h->tower = TowerPlan{};
     }
     int rc;
     if ((rc = h->d_taps.ensure(std::max<size_t>(all.size(), 1)))) return rc;
@@ -491,7 +500,8 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
         int* img_base = h->d_img_base.p + first + gi;
         const size_t cslot = (size_t)first * g.slots_per_image;
         mark(0, s);
-        launch_pyramid(pyr, h->d_taps.p, h->tap_x_off.data(), h->tap_y_off.data(), n, s, h->sem);
+        if (!(n <= 4 && !h->sem.resize_single_stage && launch_pyramid_tower(pyr, h->tower, h->d_taps.p, h->tap_x_off.data(), h->tap_y_off.data(), n, s)))
+            launch_pyramid(pyr, h->d_taps.p, h->tap_x_off.data(), h->tap_y_off.data(), n, s, h->sem);
         mark(1, s);
         hipStream_t sb = h->overlap_blur ? h->copy_stream : s;
         if (h->overlap_blur) {
@@ -598,7 +608,8 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
     h->h_pyr_valid = false;
 
     mark(0);
-    launch_pyramid(pyr, h->d_taps.p, h->tap_x_off.data(), h->tap_y_off.data(), n_images, s, h->sem);
+    if (!(n_images <= 4 && !h->sem.resize_single_stage && launch_pyramid_tower(pyr, h->tower, h->d_taps.p, h->tap_x_off.data(), h->tap_y_off.data(), n_images, s)))
+        launch_pyramid(pyr, h->d_taps.p, h->tap_x_off.data(), h->tap_y_off.data(), n_images, s, h->sem);
     mark(1);
     // the blur only feeds the descriptor stage: unless stage timing is on, it runs on the second stream, overlapping
     // the (VALU-bound) FAST kernel and the (latency-bound) quadtree with a bandwidth-bound kernel
@@ -1203,7 +1214,7 @@ int msorb::extract_stereo_sink(msorb_extractor* h, const uint8_t* left, const ui
     float smax = 0;
     for (int l = 0; l < g.nlevels; l++) smax = std::max(smax, h->scales.scale[l]);
     const int row_cap = cap * ((int)std::ceil(4.0f * smax) + 3);
-    if ((size_t)(2 * rows + 1) * sizeof(int) > 60000) { set_error("image too tall for the stereo row table"); return MSORB_E_INVALID; }
+    if (rows > 4095) { set_error("image too tall for the stereo band records"); return MSORB_E_INVALID; }
     // one device block for everything that travels back: [kps 2*cap][desc 2*cap*32][u_right cap][depth cap][n_oob], and
     // one device block for the two level-0 planes (read in place by the pipeline): one copy each way
     const size_t kp_bytes = (size_t)cap * sizeof(msorb_keypoint);
@@ -1226,8 +1237,8 @@ int msorb::extract_stereo_sink(msorb_extractor* h, const uint8_t* left, const ui
     uint8_t* const d_desc = blk + o_desc;
     int counts[2] = {0, 0}, mono[2] = {0, 0};
     // (n_oob is zeroed by the row-table kernel of launch_stereo_match_batch)
-    // the stereo row table (vRowIndices, Frame.cc:757-776) is built by an extra workgroup of the selection-layout launch
-    const StereoRowJob row_job{1, rows, row_cap, h->d_st_rows.p, reinterpret_cast<int2*>(h->d_st_list.p), reinterpret_cast<int*>(blk + o_oob)};
+    // what vRowIndices (Frame.cc:757-776) would hold about the right keypoints leaves the selection-layout launch as band records
+    const StereoRowJob row_job{1, rows, reinterpret_cast<int2*>(h->d_st_list.p), h->d_st_list.p + 2 * (size_t)cap, reinterpret_cast<int*>(blk + o_oob)};
     h->row_job = &row_job;
     h->defer_sync = h->skip_count_copies = true;
     rc = run_pipeline(h, l0, 2, 0, 0, d_kps, d_desc, cap, counts, mono);
@@ -1254,7 +1265,9 @@ int msorb::extract_stereo_sink(msorb_extractor* h, const uint8_t* left, const ui
     b.pair_step = 2;
     b.A.kpR = d_kps + cap; b.A.descR = d_desc + (size_t)cap * 32;
     b.countsL = h->d_sel_count.p; b.countsR = h->d_sel_count.p + 1;
-    b.row_begin = h->d_st_rows.p; b.row_list = reinterpret_cast<int2*>(h->d_st_list.p); b.row_cap = row_cap;
+    b.row_begin = nullptr; b.row_list = nullptr; b.row_cap = 0;
+    b.band = reinterpret_cast<const int2*>(h->d_st_list.p);
+    b.band_level_begin = h->d_st_list.p + 2 * (size_t)cap;
     b.counts_out = reinterpret_cast<int*>(blk + o_cnt);
     launch_stereo_match_batch(b, 1, cap, s, /*row_table_built=*/true);
     uint8_t* o = h->h_out_pin.p;

@@ -233,10 +233,13 @@ struct StereoPairView {
     int *sad, *n_oob;
     const int* row_begin;
     const int2* row_list;
+    const int2* band;           // no row table: one band record per right keypoint (stereo frames), or nullptr: bands from the keypoints
+    const int* band_level_begin;   // [MSORB_MAX_LEVELS + 1] first record of each octave (level-major order; = nR past the last level), or nullptr
     size_t img;                 // image index of the pair inside the batch arrays (0 for the per-frame call)
     const size_t *img_strideL, *img_strideR;  // per level, nullptr for the per-frame call
 };
-__device__ __forceinline__ void stereo_match_one(const StereoArgs& G, const StereoPairView& A, const int iL, const int lane) {
+__device__ __forceinline__ void stereo_match_one(const StereoArgs& G, const StereoPairView& A, const int iL, const int lane, const bool active = true) {
+    if (!active) return;
     const msorb_keypoint kpL = A.kpL[iL];
     const int levelL = kpL.octave;
     const float vL = kpL.y, uL = kpL.x;
@@ -256,6 +259,48 @@ __device__ __forceinline__ void stereo_match_one(const StereoArgs& G, const Ster
         // the lexicographic minimum of (distance, iR)), else every right keypoint with the band test done here
         const int2* list = A.row_begin ? A.row_list + A.row_begin[row] : nullptr;
         const int n_cand = A.row_begin ? A.row_begin[row + 1] - A.row_begin[row] : A.nR;
+        if (!list && A.band) {
+            // Every right keypoint's band against this row (8 bytes each: the 2 000 of a KITTI frame are 16 KB per left keypoint, from
+            // L2 / L1), four records per lane in flight; the few that pass row, octave and x range (the table's row entry after its
+            // filters) are compacted into a per-wave LDS list by ballot, and the descriptor distances are taken over the dense list
+            // — with the distance inside the scan every one of the 32 tests of a lane was its own divergent round of descriptor loads.
+            __shared__ int2 cand_all[4][512];
+            int2* const cand = cand_all[threadIdx.x >> 6];
+            int n_list = 0;   // wave-uniform
+            auto drain = [&]() {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int j = lane; j < n_list; j += 64) {
+                    const int2 e = cand[j];
+                    const int d = hamming256(a, reinterpret_cast<const uint64_t*>(A.descR + (size_t)e.x * 32));
+                    const uint32_t key = ((uint32_t)d << 22) | (uint32_t)e.x;
+                    if (key < best) { best = key; best_x = __int_as_float(e.y); }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                n_list = 0;
+            };
+            // (the records are in level-major order and only octaves levelL - 1 .. levelL + 1 can pass: their stretch of the list)
+            const int j_begin = A.band_level_begin ? A.band_level_begin[max(levelL - 1, 0)] : 0;
+            const int j_end = A.band_level_begin ? min(A.band_level_begin[min(levelL + 2, MSORB_MAX_LEVELS)], n_cand) : n_cand;
+            for (int j0 = j_begin; j0 < j_end; j0 += 256) {
+                int2 e[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int j = j0 + 64 * k + lane; e[k] = A.band[j < j_end ? j : 0]; }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int iR = j0 + 64 * k + lane;
+                    const int minr = e[k].x & 0xfff, maxr = (e[k].x >> 12) & 0xfff, octR = (int)((uint32_t)e[k].x >> 24);
+                    const float xR = __int_as_float(e[k].y);
+                    const bool pass = iR < j_end && row >= minr && row <= maxr && !(octR < levelL - 1 || octR > levelL + 1) && (xR >= minU && xR <= maxU);
+                    const unsigned long long m = __ballot(pass);
+                    if (pass) cand[n_list + __popcll(m & ((1ull << lane) - 1ull))] = int2{iR, e[k].y};
+                    n_list += __popcll(m);
+                }
+                if (n_list > 256) drain();   // (room for the next four ballots)
+            }
+            drain();
+        } else
         for (int j = lane; j < n_cand; j += 64) {
             int iR, octR;
             float xR;
@@ -443,11 +488,13 @@ __global__ __launch_bounds__(256) void stereo_match_batch_kernel(StereoBatchArgs
     V.depth = B.A.depth + (size_t)pair * B.capacity;
     V.sad = B.A.sad + (size_t)pair * B.capacity;
     V.n_oob = B.A.n_oob + pair;
-    V.row_begin = B.row_begin + (size_t)pair * (B.A.rows0 + 1);
-    V.row_list = B.row_list + (size_t)pair * B.row_cap;
+    V.row_begin = B.row_begin ? B.row_begin + (size_t)pair * (B.A.rows0 + 1) : nullptr;
+    V.row_list = B.row_list ? B.row_list + (size_t)pair * B.row_cap : nullptr;
+    V.band = B.band ? B.band + (size_t)pair * B.capacity : nullptr;
+    V.band_level_begin = B.band ? B.band_level_begin : nullptr;
     V.img = img;
     V.img_strideL = B.img_strideL; V.img_strideR = B.img_strideR;
-    stereo_match_one(B.A, V, iL, threadIdx.x & 63);
+    stereo_match_one(B.A, V, iL, threadIdx.x & 63, iL < nL);
 }
 
 // Batches: sixteen lanes per left keypoint, four keypoints per wave.  A keypoint's association is a chain of five dependent
@@ -798,7 +845,7 @@ void launch_stereo_match(const StereoArgs& a, hipStream_t s) {
 }
 void launch_stereo_match_batch(const StereoBatchArgs& b, int n_pairs, int max_left, hipStream_t s, bool row_table_built) {
     if (n_pairs <= 0 || max_left <= 0) return;
-    if (row_table_built) {}   // a stereo frame: the table came out of the selection-layout launch (StereoRowJob)
+    if (row_table_built) {}   // a stereo frame: band records from the selection-layout launch (StereoRowJob) instead of a table
     else if (n_pairs <= 4) hipLaunchKernelGGL(stereo_rowtable_kernel<1024>, dim3(n_pairs), dim3(1024), (size_t)(2 * b.A.rows0 + 1) * sizeof(int), s, b);
     else hipLaunchKernelGGL(stereo_rowtable_kernel<256>, dim3(n_pairs), dim3(256), (size_t)(2 * b.A.rows0 + 1) * sizeof(int), s, b);
     // batches whose row table exists: four keypoints per wave (stereo_match_quad_kernel); frames: one per wave, every wave slot used

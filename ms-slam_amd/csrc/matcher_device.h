@@ -63,6 +63,8 @@ struct StereoBatchArgs {
     int* row_begin;             // per pair: [rows0 + 1]
     int2* row_list;             // per pair: [row_cap] entries {iR | octave << 24, bits of x}
     int row_cap;
+    const int2* band;           // stereo frames (row_begin == nullptr): per right keypoint {minr | maxr << 12 | octave << 24, bits of x}, pair p at [p * capacity]
+    const int* band_level_begin;   // with band: [MSORB_MAX_LEVELS + 1] first record of each octave (the records are in level-major order)
     int* counts_out;            // optional: the median kernel copies the counts of pair p to [2p], [2p+1] (fused per-frame calls)
 };
 

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/msorb.h"
 #include "orb_host.h"
@@ -68,6 +69,30 @@ struct Semantics {
         return true;
     }
 };
+// ComputePyramid of a frame or two as ONE launch ("tower"): the image is cut into ntx x nty tiles; a workgroup
+// produces its tile of EVERY level, level l from its own copy of level l-1 in LDS — the part of level l-1 its tiles of the
+// levels above need (`need`, a few pixels of halo more per level on the way down) — and stores the part it owns (`own`, the
+// tiles partition each level).  No dependency between workgroups, so no launch boundary between levels: seven launches of
+// ~5 us each (the levels of a frame are tiny: fixed cost) become one.
+constexpr int kTowerTiles = 16;   // 16 x 8 tiles x the two images of a stereo frame = one workgroup per CU
+struct TowerAxis {   // one axis of one level: tile k of n owns [tower_own(k, n, len), tower_own(k + 1, n, len)) and computes [need0[k], need1[k])
+    int16_t need0[kTowerTiles], need1[kTowerTiles];
+};
+// x: boundaries at dword columns, the last one past the row's last dword; y: plain
+__host__ __device__ inline int tower_own_x(int k, int n, int w) { return k >= n ? (w + 3) & ~3 : (int)((long long)k * w / n) & ~3; }
+__host__ __device__ inline int tower_own_y(int k, int n, int h) { return k >= n ? h : (int)((long long)k * h / n); }
+struct TowerPlan {
+    TowerAxis x[kMaxLevels], y[kMaxLevels];   // x ranges are multiples of 4 (dword columns)
+    int ntx = 0, nty = 0;                      // tiles used on each axis (0: no plan — per-level launches)
+    int lds_even = 0, lds_odd = 0;             // bytes of the two ping-pong buffers (levels 0, 2, .. / 1, 3, ..)
+    int lds_taps = 0;                          // bytes of the tile's taps of all levels
+};
+// taps_x / taps_y: HOST copies of the tap tables of level l (from level l - 1), as make_resize_taps returns them
+bool build_tower_plan(TowerPlan& plan, int nlevels, const int* w, const int* h, const int* pitch, const std::vector<std::vector<ResizeTap>>& taps_x,
+                      const std::vector<std::vector<ResizeTap>>& taps_y, size_t lds_limit);
+// false: not applicable here (unaligned level 0, no plan, LDS) — the caller launches the levels one by one
+bool launch_pyramid_tower(const PyramidView& pyr, const TowerPlan& plan, const ResizeTap* taps, const size_t* tap_x_off, const size_t* tap_y_off,
+                          int n_images, hipStream_t s);
 void launch_pyramid(const PyramidView& pyr, const ResizeTap* taps, const size_t* tap_x_off, const size_t* tap_y_off, int n_images,
                     hipStream_t s, const Semantics& sem = Semantics());
 void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_base, const ResizeTap* tx,

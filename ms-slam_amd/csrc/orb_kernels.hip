@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "lds_limit.h"
 #include "orb_device.h"
 #include "sincosf_restated.h"
 
@@ -1511,6 +1512,209 @@ void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_
                            s, src, dst, dst_base, tx, ty);
     else if (aligned) hipLaunchKernelGGL(pyr_resize_aligned_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
     else hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty, 0);
+}
+// ------------------------------------------------------------------------------------------------
+// The pyramid of a frame as one launch (TowerPlan, orb_device.h).  grid = (tile x, tile y, image), 1024 threads.
+// A level's region of a tile lives in LDS as rows of `pitch` bytes starting at column need0 (a multiple of 4: dword columns of
+// the region are dword columns of the plane).  The arithmetic of an output dword is pyr_resize_aligned_kernel's, its two source
+// rows read from LDS instead of global memory.
+// ------------------------------------------------------------------------------------------------
+struct TowerTaps { const ResizeTap* x[kMaxLevels]; const ResizeTap* y[kMaxLevels]; };
+enum { kTpX0 = 0, kTpX1, kTpY0, kTpY1, kTpOx0, kTpOx1, kTpOy0, kTpOy1, kTpW, kTpH, kTpPitch, kTpPlaneLo, kTpPlaneHi, kTpTapXLo, kTpTapXHi, kTpTapYLo, kTpTapYHi, kTpCount };
+__device__ __forceinline__ int tower_div(int i, int wd, uint32_t magic) { return wd == 1 ? i : (int)__umulhi((uint32_t)i, magic); }   // i / wd for i, wd < 2^16, magic = ceil(2^32 / wd)
+__global__ __launch_bounds__(1024) void pyr_tower_kernel(PyramidView pyr, TowerPlan plan, TowerTaps taps) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t tower_lds[];
+    __shared__ int lvp[kMaxLevels][kTpCount];   // per level: what this tile needs to know about it
+    const int tx = blockIdx.x, ty = blockIdx.y, img = blockIdx.z, tid = threadIdx.x;
+    uint8_t* const buf_even = tower_lds;
+    uint8_t* const buf_odd = tower_lds + plan.lds_even;
+    uint2* const tap_lds = reinterpret_cast<uint2*>(tower_lds + plan.lds_even + plan.lds_odd);
+    // The per-level parameters sit in kernel-argument memory: indexed by a level that is only known at run time they would be
+    // fetched level by level, each fetch a scalar-cache miss in front of that level's work (24 us for seven levels whatever the
+    // tile size).  Thread l fetches level l's once; everybody reads them from LDS.
+    if (tid < pyr.nlevels) {
+        const int l = tid;
+        const LevelView& v = pyr.lv[l];
+        int* q = lvp[l];
+        q[kTpX0] = plan.x[l].need0[tx]; q[kTpX1] = plan.x[l].need1[tx]; q[kTpY0] = plan.y[l].need0[ty]; q[kTpY1] = plan.y[l].need1[ty];
+        q[kTpOx0] = tower_own_x(tx, plan.ntx, v.w); q[kTpOx1] = tower_own_x(tx + 1, plan.ntx, v.w);
+        q[kTpOy0] = tower_own_y(ty, plan.nty, v.h); q[kTpOy1] = tower_own_y(ty + 1, plan.nty, v.h);
+        q[kTpW] = v.w; q[kTpH] = v.h; q[kTpPitch] = v.pitch;
+        const uintptr_t plane = reinterpret_cast<uintptr_t>(v.base) + (size_t)img * v.img_stride;
+        q[kTpPlaneLo] = (int)(uint32_t)plane; q[kTpPlaneHi] = (int)(uint32_t)(plane >> 32);
+        const uintptr_t px = reinterpret_cast<uintptr_t>(taps.x[l]), py = reinterpret_cast<uintptr_t>(taps.y[l]);
+        q[kTpTapXLo] = (int)(uint32_t)px; q[kTpTapXHi] = (int)(uint32_t)(px >> 32);
+        q[kTpTapYLo] = (int)(uint32_t)py; q[kTpTapYHi] = (int)(uint32_t)(py >> 32);
+    }
+    __syncthreads();
+    auto ptr_of = [&](int l, int lo) { return (uintptr_t)(uint32_t)lvp[l][lo] | ((uintptr_t)(uint32_t)lvp[l][lo + 1] << 32); };
+    // Everything that comes from global memory is requested before anything is waited for (a workgroup is alone on its CU: a
+    // load it waits for is ~1 us during which nothing else happens): the taps of the tile's regions of all levels — segment
+    // 2 (l - 1) = the x taps [need0, need1) of level l, 2 (l - 1) + 1 its y taps — and the tile's region of level 0.
+    int seg_begin[2 * kMaxLevels + 1];
+    seg_begin[0] = 0;
+#pragma unroll
+    for (int l = 1; l < kMaxLevels; l++) {
+        const bool on = l < pyr.nlevels;
+        seg_begin[2 * l - 1] = seg_begin[2 * l - 2] + (on ? lvp[l][kTpX1] - lvp[l][kTpX0] : 0);
+        seg_begin[2 * l] = seg_begin[2 * l - 1] + (on ? (lvp[l][kTpY1] - lvp[l][kTpY0] + 1) & ~1 : 0);   // (even: the x taps are read four at a time, 16-byte aligned)
+    }
+    const int n_taps = seg_begin[2 * kMaxLevels - 2];
+    constexpr int kTapRounds = 2;   // x 1024 threads >= the taps of a tile (checked by the host: build_tower_plan)
+    uint2 tap_v[kTapRounds];
+#pragma unroll
+    for (int k = 0; k < kTapRounds; k++) {
+        const int i = tid + k * 1024;
+        int lsel = 1, axis = 0, off = 0;
+#pragma unroll
+        for (int l = 1; l < kMaxLevels; l++) {
+            if (l < pyr.nlevels && i >= seg_begin[2 * l - 2]) { lsel = l; axis = 0; off = seg_begin[2 * l - 2]; }
+            if (l < pyr.nlevels && i >= seg_begin[2 * l - 1]) { lsel = l; axis = 1; off = seg_begin[2 * l - 1]; }
+        }
+        const ResizeTap* src = reinterpret_cast<const ResizeTap*>(ptr_of(lsel, axis ? kTpTapYLo : kTpTapXLo)) + lvp[lsel][axis ? kTpY0 : kTpX0];
+        tap_v[k] = i < n_taps ? *reinterpret_cast<const uint2*>(src + (i - off)) : uint2{0u, 0u};
+    }
+    {
+        const int x0 = lvp[0][kTpX0], x1 = lvp[0][kTpX1], y0 = lvp[0][kTpY0], y1 = lvp[0][kTpY1], pitch = lvp[0][kTpPitch];
+        const int wd = (x1 - x0) >> 2, lp = (x1 - x0) + 8, total = wd * (y1 - y0);
+        const uint32_t magic = wd > 1 ? (uint32_t)(0xFFFFFFFFu / (uint32_t)wd) + 1u : 0u;
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(ptr_of(0, kTpPlaneLo));
+        constexpr int kStage = 4;
+        for (int i0 = 0; i0 < total; i0 += kStage * 1024) {
+            uint32_t val[kStage];
+            int dst[kStage];
+#pragma unroll
+            for (int k = 0; k < kStage; k++) {
+                const int i = i0 + k * 1024 + tid;
+                const int r = tower_div(i, wd, magic), c = i - r * wd;
+                dst[k] = i < total ? r * lp + 4 * c : -1;
+                val[k] = i < total ? *reinterpret_cast<const uint32_t*>(src + (size_t)(y0 + r) * pitch + x0 + 4 * c) : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < kStage; k++)
+                if (dst[k] >= 0) *reinterpret_cast<uint32_t*>(buf_even + dst[k]) = val[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kTapRounds; k++)
+        if (tid + k * 1024 < n_taps) tap_lds[tid + k * 1024] = tap_v[k];
+    __syncthreads();
+    int xb = 0;   // this level's x taps in tap_lds (its y taps follow them)
+    for (int l = 1; l < pyr.nlevels; l++) {
+        const uint8_t* sbuf = (l & 1) ? buf_even : buf_odd;
+        uint8_t* dbuf = (l & 1) ? buf_odd : buf_even;
+        const int sx0 = lvp[l - 1][kTpX0], sy0 = lvp[l - 1][kTpY0];
+        const int sp = (lvp[l - 1][kTpX1] - sx0) + 8;
+        const int x0 = lvp[l][kTpX0], x1 = lvp[l][kTpX1], y0 = lvp[l][kTpY0], y1 = lvp[l][kTpY1];
+        const int ox0 = lvp[l][kTpOx0], ox1 = lvp[l][kTpOx1], oy0 = lvp[l][kTpOy0], oy1 = lvp[l][kTpOy1];
+        const int dw = lvp[l][kTpW], dpitch = lvp[l][kTpPitch];
+        const int wd = (x1 - x0) >> 2, dp = (x1 - x0) + 8, total = wd * (y1 - y0);
+        const uint32_t magic = wd > 1 ? (uint32_t)(0xFFFFFFFFu / (uint32_t)wd) + 1u : 0u;
+        const uint2* __restrict__ tapx = tap_lds + xb;               // entry j = tap of column x0 + j
+        const uint2* __restrict__ tapy = tap_lds + xb + (x1 - x0);   // entry j = tap of row y0 + j
+        xb += (x1 - x0) + ((y1 - y0 + 1) & ~1);
+        uint8_t* dplane = reinterpret_cast<uint8_t*>(ptr_of(l, kTpPlaneLo));
+        for (int i = tid; i < total; i += 1024) {
+            const int r = tower_div(i, wd, magic), c = i - r * wd;
+            const int dy = y0 + r, dx0 = x0 + 4 * c;
+            const uint2 vyw = tapy[r];
+            const int vy_i0 = (int)(vyw.x & 0xffffu), vy_i1 = (int)(vyw.x >> 16);
+            const int b0 = (int)(int16_t)(vyw.y & 0xffffu), b1 = (int)(int16_t)(vyw.y >> 16);
+            const uint4 ta = reinterpret_cast<const uint4*>(tapx + 4 * c)[0];
+            const uint4 tb = reinterpret_cast<const uint4*>(tapx + 4 * c)[1];
+            const uint32_t tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};  // per tap: {i0|i1<<16, c0|c1<<16}
+            const int base = (int)(tw[0] & 0xffffu) & ~3;  // aligned column of the first source pixel
+            const uint8_t* s0 = sbuf + (vy_i0 - sy0) * sp + (base - sx0);
+            const uint8_t* s1 = sbuf + (vy_i1 - sy0) * sp + (base - sx0);
+            const uint32_t a0 = reinterpret_cast<const uint32_t*>(s0)[0], a1 = reinterpret_cast<const uint32_t*>(s0)[1],
+                           a2 = reinterpret_cast<const uint32_t*>(s0)[2];
+            const uint32_t b0w = reinterpret_cast<const uint32_t*>(s1)[0], b1w = reinterpret_cast<const uint32_t*>(s1)[1],
+                           b2w = reinterpret_cast<const uint32_t*>(s1)[2];
+            uint32_t packed = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i0 = (int)(tw[2 * k] & 0xffffu), i1 = (int)(tw[2 * k] >> 16);
+                const int c0 = (int)(int16_t)(tw[2 * k + 1] & 0xffffu), c1 = (int)(int16_t)(tw[2 * k + 1] >> 16);
+                const int o = i0 - base;
+                const uint32_t pa = pick2(a0, a1, a2, o), pb = pick2(b0w, b1w, b2w, o);
+                const int sh = (i1 != i0) ? 8 : 0;   // second tap = next pixel, except at the right edge where i1 == i0 (and c1 == 0)
+                const int h0 = (int)(pa & 255u) * c0 + (int)((pa >> sh) & 255u) * c1;
+                const int h1 = (int)(pb & 255u) * c0 + (int)((pb >> sh) & 255u) * c1;
+                const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                if (dx0 + k < dw) packed |= (uint32_t)(v & 255) << (8 * k);
+            }
+            *reinterpret_cast<uint32_t*>(dbuf + r * dp + 4 * c) = packed;
+            if (dy >= oy0 && dy < oy1 && dx0 >= ox0 && dx0 < ox1) *reinterpret_cast<uint32_t*>(dplane + (size_t)dy * dpitch + dx0) = packed;
+        }
+        __syncthreads();
+    }
+}
+
+// Regions top-down: the top level's tiles are its `own` ranges; a level's region = its own range and whatever the region of the
+// level above reads of it (first tap of the first pixel .. second tap of the last).  x ranges grow to dword columns.
+bool build_tower_plan(TowerPlan& plan, int nlevels, const int* w, const int* h, const int* pitch, const std::vector<std::vector<ResizeTap>>& taps_x,
+                      const std::vector<std::vector<ResizeTap>>& taps_y, size_t lds_limit) {
+    plan = TowerPlan{};
+    if (nlevels < 2) return false;
+    const int ntx = kTowerTiles, nty = w[0] >= 2 * h[0] ? kTowerTiles / 2 : kTowerTiles;
+    for (int l = 0; l < nlevels; l++)
+        if (pitch[l] < ((w[l] + 3) & ~3)) return false;
+    size_t lds[2] = {0, 0};
+    for (int tyi = 0; tyi < kTowerTiles; tyi++)
+        for (int l = nlevels - 1; l >= 0; l--) {
+            int a = l ? tower_own_y(tyi, nty, h[l]) : 32767, b = l ? tower_own_y(tyi + 1, nty, h[l]) : -1;
+            if (l + 1 < nlevels && plan.y[l + 1].need1[tyi] > plan.y[l + 1].need0[tyi]) {
+                const auto& t = taps_y[l + 1];
+                a = std::min<int>(a, t[plan.y[l + 1].need0[tyi]].i0);
+                b = std::max<int>(b, t[std::min<int>(plan.y[l + 1].need1[tyi], h[l + 1]) - 1].i1 + 1);
+            }
+            if (b <= a) { a = 0; b = 0; }
+            plan.y[l].need0[tyi] = (int16_t)a; plan.y[l].need1[tyi] = (int16_t)b;
+        }
+    for (int txi = 0; txi < kTowerTiles; txi++)
+        for (int l = nlevels - 1; l >= 0; l--) {
+            int a = l ? tower_own_x(txi, ntx, w[l]) : 32767, b = l ? tower_own_x(txi + 1, ntx, w[l]) : -1;
+            if (l + 1 < nlevels && plan.x[l + 1].need1[txi] > plan.x[l + 1].need0[txi]) {
+                const auto& t = taps_x[l + 1];
+                a = std::min<int>(a, t[std::min<int>(plan.x[l + 1].need0[txi], w[l + 1] - 1)].i0);
+                // (an output dword reads three source dwords from the aligned column of its first tap: up to 11 bytes past it)
+                b = std::max<int>(b, (t[std::min<int>(plan.x[l + 1].need1[txi], w[l + 1]) - 1].i1 + 1));
+            }
+            if (b <= a) { a = 0; b = 0; }
+            a &= ~3; b = (b + 3) & ~3;
+            plan.x[l].need0[txi] = (int16_t)a; plan.x[l].need1[txi] = (int16_t)b;
+        }
+    for (int l = 0; l < nlevels; l++)
+        for (int tyi = 0; tyi < nty; tyi++)
+            for (int txi = 0; txi < ntx; txi++) {
+                const size_t bytes = (size_t)(plan.x[l].need1[txi] - plan.x[l].need0[txi] + 8) * (plan.y[l].need1[tyi] - plan.y[l].need0[tyi]) + 16;
+                lds[l & 1] = std::max(lds[l & 1], (bytes + 15) & ~size_t(15));
+            }
+    size_t n_taps = 0;   // taps of a tile's regions, all levels (the kernel fetches them in two rounds of 1024)
+    for (int tyi = 0; tyi < nty; tyi++)
+        for (int txi = 0; txi < ntx; txi++) {
+            size_t t = 0;
+            for (int l = 1; l < nlevels; l++) t += (size_t)(plan.x[l].need1[txi] - plan.x[l].need0[txi]) + ((plan.y[l].need1[tyi] - plan.y[l].need0[tyi] + 1) & ~1);
+            n_taps = std::max(n_taps, t);
+        }
+    if (n_taps > 2048 || lds[0] + lds[1] + (n_taps + 8) * sizeof(ResizeTap) > lds_limit) return false;
+    plan.ntx = ntx; plan.nty = nty;
+    plan.lds_even = (int)lds[0]; plan.lds_odd = (int)lds[1]; plan.lds_taps = (int)((n_taps + 8) * sizeof(ResizeTap));
+    return true;
+}
+bool launch_pyramid_tower(const PyramidView& pyr, const TowerPlan& plan, const ResizeTap* taps, const size_t* tap_x_off, const size_t* tap_y_off,
+                          int n_images, hipStream_t s) {
+    static const bool off = getenv("MSORB_PYR_TOWER") && atoi(getenv("MSORB_PYR_TOWER")) == 0;
+    const LevelView& v0 = pyr.lv[0];   // level 0 may be the caller's buffer: dword rows, readable up to the next multiple of 4 past w
+    if (off || plan.ntx <= 0 || (reinterpret_cast<uintptr_t>(v0.base) & 3) || (v0.pitch & 3) || (v0.img_stride & 3) || v0.pitch < ((v0.w + 3) & ~3) ||
+        (reinterpret_cast<uintptr_t>(taps) & 31))
+        return false;
+    const size_t lds = (size_t)plan.lds_even + plan.lds_odd + plan.lds_taps;
+    if (lds > 64 * 1024 && (long long)lds > dynamic_lds_room(reinterpret_cast<const void*>(pyr_tower_kernel))) return false;
+    TowerTaps t{};
+    for (int l = 1; l < pyr.nlevels; l++) { t.x[l] = taps + tap_x_off[l]; t.y[l] = taps + tap_y_off[l]; }
+    hipLaunchKernelGGL(pyr_tower_kernel, dim3(plan.ntx, plan.nty, n_images), dim3(1024), lds, s, pyr, plan, t);
+    return true;
 }
 // ComputePyramid for a batch: levels 1 .. n-1, each from the one above (ORBextractor.cc:1179-1193), one launch per level.
 void launch_pyramid(const PyramidView& pyr, const ResizeTap* taps, const size_t* tap_x_off, const size_t* tap_y_off, int n_images,

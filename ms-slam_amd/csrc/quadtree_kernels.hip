@@ -459,10 +459,9 @@ __global__ __launch_bounds__(256, 4) void quadtree_select_batch_kernel(QtLevels 
 
 // One workgroup per image: records in level-major / quadtree order; output row = mono index from the front for
 // keypoints outside [lap0, lap1], stereo index from the back for those inside (ORBextractor.cc:1153-1162).
-// kLayoutThreads = 256: the layout's own work.  A stereo frame launches the kernel with 1024 threads and one workgroup more
-// (n_images + 1): the layout workgroups use their first 256 threads (the other waves leave at once), the extra one builds the
-// stereo row table of the right image from the same selection records (StereoRowJob, stereo_rowtable_device.h) with all 1024.
-__global__ __launch_bounds__(1024) void quadtree_layout_kernel(QtLevels lv, const Cand16* __restrict__ compact,
+// A stereo frame's launch also writes the band record of every right keypoint (StereoRowJob, stereo_rowtable_device.h): what
+// Frame::ComputeStereoMatches' vRowIndices would hold about it, from the same selection records.
+__global__ __launch_bounds__(256) void quadtree_layout_kernel(QtLevels lv, const Cand16* __restrict__ compact,
                                                               const int* __restrict__ img_base,
                                                               const int* __restrict__ level_count,
                                                               const int* __restrict__ sel_pt, const int* __restrict__ sel_n,
@@ -472,10 +471,7 @@ __global__ __launch_bounds__(1024) void quadtree_layout_kernel(QtLevels lv, cons
                                                               StereoRowJob job) {
     __shared__ int lvl_begin[kMaxLevels + 1], cand_begin[kMaxLevels + 1];
     __shared__ int part[256];
-    extern __shared__ int row_lds[];   // the row-table workgroup's counters (2 * rows0 + 1 ints); none for a plain launch
-    const bool row_block = (int)blockIdx.x >= n_images;
-    const int img = row_block ? job.right_img : (int)blockIdx.x, tid = threadIdx.x;
-    if (!row_block && tid >= 256) return;
+    const int img = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) {
         int a = 0, c = img_base[img];
         for (int l = 0; l < lv.nlevels; l++) {
@@ -488,27 +484,11 @@ __global__ __launch_bounds__(1024) void quadtree_layout_kernel(QtLevels lv, cons
     __syncthreads();
     const int n_all = lvl_begin[lv.nlevels];
     const int n = min(n_all, min(capacity, sel_stride));
-    if (row_block) {
-        // vRowIndices of the right eye (Frame.cc:757-776): keypoint iR of the output = selection record iR (no lapping area: the
-        // output row is the selection order), its kp.pt = level coordinates times the level's scale factor exactly as the
-        // descriptor stage writes them (ORBextractor.cc:1149-1151)
-        if (tid == 0 && job.n_oob) *job.n_oob = 0;
-        stereo_rowtable_build<1024>(row_lds, tid, job.rows0, n, scales.scale, job.row_begin, job.row_list, job.row_cap,
-                                    [&](int iR, float& x, float& y, int& octave) {
-                                        int l = 0;
-                                        while (iR >= lvl_begin[l + 1]) l++;
-                                        const int pt = sel_pt[(size_t)img * sel_stride + lv.sel_off[l] + (iR - lvl_begin[l])];
-                                        const Cand16 c = compact[cand_begin[l] + pt];
-                                        const float fx = (float)(c.x + kMinBorder), fy = (float)(c.y + kMinBorder);
-                                        x = l ? __fmul_rn(fx, scales.scale[l]) : fx;
-                                        y = l ? __fmul_rn(fy, scales.scale[l]) : fy;
-                                        octave = l;
-                                    });
-        return;
-    }
     const int per = (n + 255) / 256;
     const int b = tid * per, e = min(b + per, n);
     SelRec* out = sel + (size_t)img * sel_stride;
+    int2* const bands = job.band && img == job.right_img ? job.band : nullptr;
+    if (bands && tid == 0 && job.n_oob) *job.n_oob = 0;
     if (lap1 < kMinBorder) {
         // no lapping area (mono / rectified stereo: every x is >= kMinBorder, so fx <= lap1 never holds): output row =
         // selection order, no second pass.  Items are taken 256 apart, four at a time, so that the two dependent loads
@@ -534,6 +514,11 @@ __global__ __launch_bounds__(1024) void quadtree_layout_kernel(QtLevels lv, cons
                 r.score = cc[u].score; r.level = (uint8_t)ll[u]; r.pad = 0;
                 r.dst = gg[u];
                 out[gg[u]] = r;
+                if (bands) {   // kp.pt = level coordinates times the level's scale factor, as the descriptor stage writes them (ORBextractor.cc:1149-1151)
+                    const float fx = (float)r.x, fy = (float)r.y;
+                    const int l = ll[u];
+                    bands[gg[u]] = stereo_band_record(l ? __fmul_rn(fx, scales.scale[l]) : fx, l ? __fmul_rn(fy, scales.scale[l]) : fy, l, scales.scale, job.rows0);
+                }
             }
         }
         if (tid == 0) {
@@ -570,6 +555,76 @@ __global__ __launch_bounds__(1024) void quadtree_layout_kernel(QtLevels lv, cons
     for (int g = b; g < e; g++) {
         if (out[g].dst < 0) { out[g].dst = n - 1 - laps; laps++; }
         else out[g].dst = g - laps;
+    }
+}
+
+// The layout of a frame or two without a lapping area: 1024 threads (two records each, both dependent load pairs in flight), the
+// per-level offsets from uniform loads in every thread (no LDS, no barrier) — the 256-thread form above spent 11 us of a stereo
+// frame here, most of it one thread's chain of sixteen dependent loads and four sequential rounds of two.
+__global__ __launch_bounds__(1024) void quadtree_layout_frame_kernel(QtLevels lv, const Cand16* __restrict__ compact, const int* __restrict__ img_base,
+                                                                    const int* __restrict__ level_count, const int* __restrict__ sel_pt,
+                                                                    const int* __restrict__ sel_n, int sel_stride, LevelScale scales, int capacity,
+                                                                    SelRec* __restrict__ sel, int* __restrict__ sel_count, int* __restrict__ mono_out,
+                                                                    StereoRowJob job) {
+    const int img = blockIdx.x, tid = threadIdx.x;
+    int lb[kMaxLevels + 1], cb[kMaxLevels];
+    {
+        int sn[kMaxLevels], lc[kMaxLevels];
+#pragma unroll
+        for (int l = 0; l < kMaxLevels; l++) {
+            sn[l] = l < lv.nlevels ? sel_n[(size_t)img * lv.nlevels + l] : 0;
+            lc[l] = l < lv.nlevels ? level_count[(size_t)img * lv.nlevels + l] : 0;
+        }
+        int a = 0, c = img_base[img];
+#pragma unroll
+        for (int l = 0; l < kMaxLevels; l++) { lb[l] = a; cb[l] = c; a += sn[l]; c += lc[l]; }
+        lb[kMaxLevels] = a;
+    }
+    const int n_all = lb[kMaxLevels];
+    const int n = min(n_all, min(capacity, sel_stride));
+    SelRec* out = sel + (size_t)img * sel_stride;
+    int2* const bands = job.band && img == job.right_img ? job.band : nullptr;
+    if (bands && tid == 0 && job.n_oob) *job.n_oob = 0;
+    if (bands && job.level_begin && tid <= kMaxLevels) {
+        int v = n;
+#pragma unroll
+        for (int k = 0; k <= kMaxLevels; k++) if (tid == k) v = min(lb[k], n);
+        job.level_begin[tid] = v;
+    }
+    for (int base = 0; base < n; base += 2 * 1024) {
+        int gg[2], ll[2], pt[2], cbeg[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            gg[u] = base + u * 1024 + tid;
+            int l = 0, lbeg = 0, off = lv.sel_off[0];
+            cbeg[u] = cb[0];
+#pragma unroll
+            for (int k = 1; k < kMaxLevels; k++)
+                if (k < lv.nlevels && gg[u] >= lb[k]) { l = k; lbeg = lb[k]; off = lv.sel_off[k]; cbeg[u] = cb[k]; }
+            ll[u] = l;
+            pt[u] = gg[u] < n ? sel_pt[(size_t)img * sel_stride + off + (gg[u] - lbeg)] : 0;
+        }
+        Cand16 cc[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) cc[u] = gg[u] < n ? compact[cbeg[u] + pt[u]] : Cand16{};
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (gg[u] >= n) continue;
+            SelRec r;
+            r.x = (uint16_t)(cc[u].x + kMinBorder); r.y = (uint16_t)(cc[u].y + kMinBorder);
+            r.score = cc[u].score; r.level = (uint8_t)ll[u]; r.pad = 0;
+            r.dst = gg[u];
+            out[gg[u]] = r;
+            if (bands) {   // kp.pt = level coordinates times the level's scale factor, as the descriptor stage writes them (ORBextractor.cc:1149-1151)
+                const float fx = (float)r.x, fy = (float)r.y;
+                const int l = ll[u];
+                bands[gg[u]] = stereo_band_record(l ? __fmul_rn(fx, scales.scale[l]) : fx, l ? __fmul_rn(fy, scales.scale[l]) : fy, l, scales.scale, job.rows0);
+            }
+        }
+    }
+    if (tid == 0) {
+        sel_count[img] = n_all > n ? -n_all : n;   // negative = capacity exceeded (host turns it into an error)
+        mono_out[img] = n;
     }
 }
 
@@ -633,12 +688,13 @@ int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_ba
         hipLaunchKernelGGL(quadtree_select_kernel<0>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds + lds_paths, s, lv, compact, img_base,
                            level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt, path_cap);
     }
-    if (row_job && lap1 < kMinBorder && row_job->right_img < n_images)
-        hipLaunchKernelGGL(quadtree_layout_kernel, dim3(n_images + 1), dim3(1024), (size_t)(2 * row_job->rows0 + 1) * sizeof(int), s, lv, compact,
-                           img_base, level_count, sel_pt, sel_n, sel_stride, scales, lap0, lap1, capacity, sel, sel_count, mono, n_images, *row_job);
+    const StereoRowJob job = row_job && lap1 < kMinBorder && row_job->right_img < n_images ? *row_job : StereoRowJob{};
+    if (n_images <= 4 && lap1 < kMinBorder)
+        hipLaunchKernelGGL(quadtree_layout_frame_kernel, dim3(n_images), dim3(1024), 0, s, lv, compact, img_base, level_count, sel_pt, sel_n,
+                           sel_stride, scales, capacity, sel, sel_count, mono, job);
     else
         hipLaunchKernelGGL(quadtree_layout_kernel, dim3(n_images), dim3(256), 0, s, lv, compact, img_base, level_count, sel_pt,
-                           sel_n, sel_stride, scales, lap0, lap1, capacity, sel, sel_count, mono, n_images, StereoRowJob{});
+                           sel_n, sel_stride, scales, lap0, lap1, capacity, sel, sel_count, mono, n_images, job);
     return MSORB_OK;
 }
 size_t quadtree_lds_bytes(const QtLevels& lv) {

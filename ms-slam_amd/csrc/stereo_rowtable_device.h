@@ -85,16 +85,21 @@ __device__ __forceinline__ void stereo_rowtable_build(int* rt, int t, int rows0,
     }
 }
 
-// The row table of a stereo FRAME, built by an extra workgroup of the selection-layout launch (launch_quadtree): the right image's
-// keypoints in output order are its selection records in level-major order (no lapping area), so the table needs neither the layout's
-// output nor the descriptor stage.
+// A stereo FRAME does without the table: the selection-layout kernel (quadtree_kernels.hip) writes one BAND record per right
+// keypoint — the rows [floor(y - r), ceil(y + r)] it would be entered in (Frame.cc:757-776), its octave and its x — and the
+// association of a left keypoint tests every right keypoint's band against its row (stereo_match_one, matcher.hip): 2 000 x 2 000
+// 8-byte tests cost the match kernel ~2 us, the table (counts, scan, scattered fill, by one workgroup) cost the frame 13.
 struct StereoRowJob {
     int right_img;      // image of the launch whose keypoints are the right eye's (1 for a stereo frame)
-    int rows0;          // rows of level 0
-    int row_cap;
-    int* row_begin;     // [rows0 + 1]
-    int2* row_list;     // [row_cap]
+    int rows0;          // rows of level 0 (< 4096)
+    int2* band;         // [capacity]: {minr | maxr << 12 | octave << 24, bits of x}; minr > maxr = no row
+    int* level_begin;   // [kMaxLevels + 1]: first record of each octave (the association scans the three octaves it can accept)
     int* n_oob;         // zeroed here (the association's out-of-bounds counter), may be nullptr
 };
+__device__ __forceinline__ int2 stereo_band_record(float x, float y, int octave, const float* __restrict__ scale, int rows0) {
+    const float r = __fmul_rn(2.0f, scale[octave]);
+    const int maxr = min((int)ceilf(__fadd_rn(y, r)), rows0 - 1), minr = max((int)floorf(__fsub_rn(y, r)), 0);
+    return int2{(maxr >= minr ? (minr | (maxr << 12)) : 1) | (octave << 24), __float_as_int(x)};
+}
 
 }  // namespace msorb
