@@ -1522,7 +1522,11 @@ void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_
 struct TowerTaps { const ResizeTap* x[kMaxLevels]; const ResizeTap* y[kMaxLevels]; };
 enum { kTpX0 = 0, kTpX1, kTpY0, kTpY1, kTpOx0, kTpOx1, kTpOy0, kTpOy1, kTpW, kTpH, kTpPitch, kTpPlaneLo, kTpPlaneHi, kTpTapXLo, kTpTapXHi, kTpTapYLo, kTpTapYHi, kTpCount };
 __device__ __forceinline__ int tower_div(int i, int wd, uint32_t magic) { return wd == 1 ? i : (int)__umulhi((uint32_t)i, magic); }   // i / wd for i, wd < 2^16, magic = ceil(2^32 / wd)
-__global__ __launch_bounds__(1024) void pyr_tower_kernel(PyramidView pyr, TowerPlan plan, TowerTaps taps) {
+#ifndef MSORB_TOWER_THREADS
+#define MSORB_TOWER_THREADS 1024
+#endif
+constexpr int kTowerThreads = MSORB_TOWER_THREADS;
+__global__ __launch_bounds__(kTowerThreads) void pyr_tower_kernel(PyramidView pyr, TowerPlan plan, TowerTaps taps) {
     extern __shared__ __attribute__((aligned(16))) uint8_t tower_lds[];
     __shared__ int lvp[kMaxLevels][kTpCount];   // per level: what this tile needs to know about it
     const int tx = blockIdx.x, ty = blockIdx.y, img = blockIdx.z, tid = threadIdx.x;
@@ -1560,11 +1564,11 @@ __global__ __launch_bounds__(1024) void pyr_tower_kernel(PyramidView pyr, TowerP
         seg_begin[2 * l] = seg_begin[2 * l - 1] + (on ? (lvp[l][kTpY1] - lvp[l][kTpY0] + 1) & ~1 : 0);   // (even: the x taps are read four at a time, 16-byte aligned)
     }
     const int n_taps = seg_begin[2 * kMaxLevels - 2];
-    constexpr int kTapRounds = 2;   // x 1024 threads >= the taps of a tile (checked by the host: build_tower_plan)
+    constexpr int kTapRounds = 2048 / kTowerThreads;   // x kTowerThreads >= the taps of a tile (checked by the host: build_tower_plan)
     uint2 tap_v[kTapRounds];
 #pragma unroll
     for (int k = 0; k < kTapRounds; k++) {
-        const int i = tid + k * 1024;
+        const int i = tid + k * kTowerThreads;
         int lsel = 1, axis = 0, off = 0;
 #pragma unroll
         for (int l = 1; l < kMaxLevels; l++) {
@@ -1579,13 +1583,13 @@ __global__ __launch_bounds__(1024) void pyr_tower_kernel(PyramidView pyr, TowerP
         const int wd = (x1 - x0) >> 2, lp = (x1 - x0) + 8, total = wd * (y1 - y0);
         const uint32_t magic = wd > 1 ? (uint32_t)(0xFFFFFFFFu / (uint32_t)wd) + 1u : 0u;
         const uint8_t* src = reinterpret_cast<const uint8_t*>(ptr_of(0, kTpPlaneLo));
-        constexpr int kStage = 4;
-        for (int i0 = 0; i0 < total; i0 += kStage * 1024) {
+        constexpr int kStage = 4096 / kTowerThreads;
+        for (int i0 = 0; i0 < total; i0 += kStage * kTowerThreads) {
             uint32_t val[kStage];
             int dst[kStage];
 #pragma unroll
             for (int k = 0; k < kStage; k++) {
-                const int i = i0 + k * 1024 + tid;
+                const int i = i0 + k * kTowerThreads + tid;
                 const int r = tower_div(i, wd, magic), c = i - r * wd;
                 dst[k] = i < total ? r * lp + 4 * c : -1;
                 val[k] = i < total ? *reinterpret_cast<const uint32_t*>(src + (size_t)(y0 + r) * pitch + x0 + 4 * c) : 0u;
@@ -1597,7 +1601,7 @@ __global__ __launch_bounds__(1024) void pyr_tower_kernel(PyramidView pyr, TowerP
     }
 #pragma unroll
     for (int k = 0; k < kTapRounds; k++)
-        if (tid + k * 1024 < n_taps) tap_lds[tid + k * 1024] = tap_v[k];
+        if (tid + k * kTowerThreads < n_taps) tap_lds[tid + k * kTowerThreads] = tap_v[k];
     __syncthreads();
     int xb = 0;   // this level's x taps in tap_lds (its y taps follow them)
     for (int l = 1; l < pyr.nlevels; l++) {
@@ -1614,7 +1618,7 @@ __global__ __launch_bounds__(1024) void pyr_tower_kernel(PyramidView pyr, TowerP
         const uint2* __restrict__ tapy = tap_lds + xb + (x1 - x0);   // entry j = tap of row y0 + j
         xb += (x1 - x0) + ((y1 - y0 + 1) & ~1);
         uint8_t* dplane = reinterpret_cast<uint8_t*>(ptr_of(l, kTpPlaneLo));
-        for (int i = tid; i < total; i += 1024) {
+        for (int i = tid; i < total; i += kTowerThreads) {
             const int r = tower_div(i, wd, magic), c = i - r * wd;
             const int dy = y0 + r, dx0 = x0 + 4 * c;
             const uint2 vyw = tapy[r];
@@ -1713,7 +1717,7 @@ bool launch_pyramid_tower(const PyramidView& pyr, const TowerPlan& plan, const R
     if (lds > 64 * 1024 && (long long)lds > dynamic_lds_room(reinterpret_cast<const void*>(pyr_tower_kernel))) return false;
     TowerTaps t{};
     for (int l = 1; l < pyr.nlevels; l++) { t.x[l] = taps + tap_x_off[l]; t.y[l] = taps + tap_y_off[l]; }
-    hipLaunchKernelGGL(pyr_tower_kernel, dim3(plan.ntx, plan.nty, n_images), dim3(1024), lds, s, pyr, plan, t);
+    hipLaunchKernelGGL(pyr_tower_kernel, dim3(plan.ntx, plan.nty, n_images), dim3(kTowerThreads), lds, s, pyr, plan, t);
     return true;
 }
 // ComputePyramid for a batch: levels 1 .. n-1, each from the one above (ORBextractor.cc:1179-1193), one launch per level.

@@ -35,3 +35,6 @@ for set in "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "SQ_WAIT_INST_ANY
   PMC_TIMEOUT=200 tools/pmc_run.sh round/dpmc_$n "$set" "describe" -- python bench.py --steps 2 --warmup 1 --lean --isolated 2>&1 | tail -2
 done > $O/describe_pmc.txt 2>&1; cat $O/describe_pmc.txt
 { for i in 1 2; do python tools/per_frame_ab.py | tail -1; MSORB_FRAME_COPIES=sdma python tools/per_frame_ab.py | tail -1; done; } > $O/frame_copies_ab.txt 2>&1; cat $O/frame_copies_ab.txt
+# round 5: what the frame's quadtree by quadrant path and the one-launch pyramid buy (the same process start to end per line: ms one image, ms stereo frame)
+{ for i in 1 2; do echo "default           $(python tools/per_frame_ab.py | tail -1)"; echo "MSORB_QT_PATHS=0  $(MSORB_QT_PATHS=0 python tools/per_frame_ab.py | tail -1)"; echo "MSORB_PYR_TOWER=0 $(MSORB_PYR_TOWER=0 python tools/per_frame_ab.py | tail -1)"; echo "both off          $(MSORB_QT_PATHS=0 MSORB_PYR_TOWER=0 python tools/per_frame_ab.py | tail -1)"; done; } > $O/frame_paths_tower_ab.txt 2>&1; cat $O/frame_paths_tower_ab.txt
+{ for c in 4 0 5 4 0; do echo "MSORB_QT_BATCH_PATHS=$c $(MSORB_QT_BATCH_PATHS=$c python bench.py --lean 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('stage_ms_per_step'))")"; done; } > $O/batch_paths_ab.txt 2>&1; cat $O/batch_paths_ab.txt
