@@ -19,7 +19,7 @@ def resident(torch, dev, host_imgs):
     return v
 
 
-def pipelined_rate(torch, exs, images, steps=40, warmup=10):
+def pipelined_rate(torch, exs, images, steps=200, warmup=20):
     """bench.py's N = 1 loop in small: two batches in flight on two handles (msorb_extract_batch_submit / _wait), the second
     one half a step behind the first.  -> (keypoints per second, ms per step, keypoints per image)."""
     outs = [None, None]

@@ -28,12 +28,19 @@ def per_frame_leg(msorb, ex, left, right):
                                        C.c_void_p, C.c_void_p]
     st = (ex.h, p(left), p(right), rows, cols, cols, cols, KITTI_MB, KITTI_MBF, p(kl), p(dl), C.byref(nl), p(kr), p(dr), C.byref(nr), cap,
           p(ur), p(dp), C.byref(oob))
-    t1, t2 = [], []
+    vp, ci = C.c_void_p, C.c_int
+    L.msorb_extract_pair.argtypes = [vp, vp, vp, ci, ci, C.c_size_t, C.c_size_t, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci]
+    mono_r = C.c_int()
+    pr = (ex.h, p(left), p(right), rows, cols, cols, cols, 0, 0, p(kl), p(dl), C.byref(nl), C.byref(mono), p(kr), p(dr), C.byref(nr), C.byref(mono_r), cap, 0)
+    t1, t2, t3 = [], [], []
     for i in range(45):
         t0 = time.perf_counter(); L.msorb_extract(*one); t1.append(time.perf_counter() - t0)
+    for i in range(45):
+        t0 = time.perf_counter(); L.msorb_extract_pair(*pr); t3.append(time.perf_counter() - t0)
     for i in range(45):
         t0 = time.perf_counter(); L.msorb_extract_stereo(*st); t2.append(time.perf_counter() - t0)
     m1, m2 = float(np.median(t1[5:])), float(np.median(t2[5:]))
     return {"what": "one frame at a time through the C ABI from host images (B = 1): what the drop-in ORBextractor::operator() costs",
-            "ms_one_image": round(m1 * 1e3, 4), "ms_stereo_frame_one_call": round(m2 * 1e3, 4),
+            "ms_one_image": round(m1 * 1e3, 4), "ms_two_images_one_call_no_match": round(float(np.median(t3[5:])) * 1e3, 4),
+            "ms_stereo_frame_one_call": round(m2 * 1e3, 4),
             "keypoints_stereo_frame": int(nl.value + nr.value), "mkeypoints_per_s_stereo_frame": round((nl.value + nr.value) / m2 / 1e6, 2)}

@@ -1214,7 +1214,8 @@ int msorb::extract_stereo_sink(msorb_extractor* h, const uint8_t* left, const ui
     float smax = 0;
     for (int l = 0; l < g.nlevels; l++) smax = std::max(smax, h->scales.scale[l]);
     const int row_cap = cap * ((int)std::ceil(4.0f * smax) + 3);
-    if (rows > 4095) { set_error("image too tall for the stereo band records"); return MSORB_E_INVALID; }
+    const bool bands = rows <= 4095;   // (a band record holds 12-bit rows; taller images — none of the BASELINE configs — take the row table)
+    if (!bands && (size_t)(2 * rows + 1) * sizeof(int) > 60000) { set_error("image too tall for the stereo row table"); return MSORB_E_INVALID; }
     // one device block for everything that travels back: [kps 2*cap][desc 2*cap*32][u_right cap][depth cap][n_oob], and
     // one device block for the two level-0 planes (read in place by the pipeline): one copy each way
     const size_t kp_bytes = (size_t)cap * sizeof(msorb_keypoint);
@@ -1239,7 +1240,7 @@ int msorb::extract_stereo_sink(msorb_extractor* h, const uint8_t* left, const ui
     // (n_oob is zeroed by the row-table kernel of launch_stereo_match_batch)
     // what vRowIndices (Frame.cc:757-776) would hold about the right keypoints leaves the selection-layout launch as band records
     const StereoRowJob row_job{1, rows, reinterpret_cast<int2*>(h->d_st_list.p), h->d_st_list.p + 2 * (size_t)cap, reinterpret_cast<int*>(blk + o_oob)};
-    h->row_job = &row_job;
+    h->row_job = bands ? &row_job : nullptr;
     h->defer_sync = h->skip_count_copies = true;
     rc = run_pipeline(h, l0, 2, 0, 0, d_kps, d_desc, cap, counts, mono);
     h->defer_sync = h->skip_count_copies = false;
@@ -1265,11 +1266,14 @@ int msorb::extract_stereo_sink(msorb_extractor* h, const uint8_t* left, const ui
     b.pair_step = 2;
     b.A.kpR = d_kps + cap; b.A.descR = d_desc + (size_t)cap * 32;
     b.countsL = h->d_sel_count.p; b.countsR = h->d_sel_count.p + 1;
-    b.row_begin = nullptr; b.row_list = nullptr; b.row_cap = 0;
-    b.band = reinterpret_cast<const int2*>(h->d_st_list.p);
-    b.band_level_begin = h->d_st_list.p + 2 * (size_t)cap;
+    if (bands) {
+        b.band = reinterpret_cast<const int2*>(h->d_st_list.p);
+        b.band_level_begin = h->d_st_list.p + 2 * (size_t)cap;
+    } else {
+        b.row_begin = h->d_st_rows.p; b.row_list = reinterpret_cast<int2*>(h->d_st_list.p); b.row_cap = row_cap;
+    }
     b.counts_out = reinterpret_cast<int*>(blk + o_cnt);
-    launch_stereo_match_batch(b, 1, cap, s, /*row_table_built=*/true);
+    launch_stereo_match_batch(b, 1, cap, s, /*row_table_built=*/bands);
     uint8_t* o = h->h_out_pin.p;
     if (sink) {
         // the frame's read-back (190 KB) leaves on the side stream while the sink's kernels (frame grid, local points, window

@@ -10,4 +10,4 @@ L, R = synth.stereo_pair(1000, cfg["rows"], cfg["cols"])
 ex = msorb.ORBextractor(cfg["nfeatures"], cfg["scale"], cfg["nlevels"], cfg["ini_th"], cfg["min_th"])
 for i in range(3):
     r = per_frame_leg(msorb, ex, L, R)
-    print(os.environ.get("MSORB_FRAME_COPIES", "blit"), r["ms_one_image"], r["ms_stereo_frame_one_call"], flush=True)
+    print(os.environ.get("MSORB_FRAME_COPIES", "blit"), r["ms_one_image"], r["ms_two_images_one_call_no_match"], r["ms_stereo_frame_one_call"], flush=True)
