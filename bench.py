@@ -409,8 +409,11 @@ def main():
     # input-statistics sweep and configs[4]'s front-end geometry: after the timed region, on their own handles and batches
     density = fourseasons = None
     if aux and not args.isolated:
-        density = optional_leg("density_sweep", density_sweep_leg, msorb, synth, torch, make_ex, cfg, dev, B, uniq, args.cpu_pairs > 0)
-        fourseasons = optional_leg("fourseasons_frontend", fourseasons_leg, msorb, synth, torch, dev, B, uniq, local, args.cpu_pairs > 0)
+        density = optional_leg("density_sweep", density_sweep_leg, msorb, synth, torch, make_ex, cfg, dev, B, uniq, args.cpu_pairs > 0,
+                               exp[:2] if world == 1 and pipelined and len(exp) >= 2 else None)
+        same_params = all(synth.FOURSEASONS[k] == cfg[k] for k in ("nfeatures", "scale", "nlevels", "ini_th", "min_th"))
+        fourseasons = optional_leg("fourseasons_frontend", fourseasons_leg, msorb, synth, torch, dev, B, uniq, local, args.cpu_pairs > 0,
+                                   exp[:2] if world == 1 and pipelined and len(exp) >= 2 and same_params else None)
 
     validation = None
     if world > 1:

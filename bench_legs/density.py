@@ -81,9 +81,14 @@ def input_statistics(cfg, left):
                 candidates_per_image=int(sum(len(ex.candidates(l)) for l in range(cfg["nlevels"])))), kps, desc
 
 
-def density_sweep_leg(msorb, synth, torch, make_ex, cfg, dev, pairs, uniq, cpu):
-    """-> the `density_sweep` list of the bench line."""
-    exs = [make_ex(), make_ex()]
+def density_sweep_leg(msorb, synth, torch, make_ex, cfg, dev, pairs, uniq, cpu, handles=None):
+    """-> the `density_sweep` list of the bench line.
+    handles: the two extractor handles of the main loop.  The sweep runs on THEM: a process that has created a dozen handles (every
+    leg of bench.py makes its own) has more HIP streams than the runtime has hardware queues, the streams of two new handles share
+    queues, and their two batches in flight serialise — the same loop on fresh handles read 411 Mkeypoints/s on the default class
+    inside bench.py and 472-483 alone in a process (the main loop: 469)."""
+    own = handles is None
+    exs = [make_ex(), make_ex()] if own else list(handles)
     out = []
     try:
         for tex in ("low", "default", "high"):
@@ -109,15 +114,21 @@ def density_sweep_leg(msorb, synth, torch, make_ex, cfg, dev, pairs, uniq, cpu):
             del images
     finally:
         for e in exs:
-            e.close()
+            if own:
+                e.close()
+            else:
+                e.set_profiling(False)
+                e.set_overlap(1, True)
     return out
 
 
-def fourseasons_leg(msorb, synth, torch, dev, pairs, uniq, local, cpu):
-    """configs[4]'s front-end half at the 4Seasons geometry: batch extraction rate (inputs in HBM) and the per-frame calls."""
+def fourseasons_leg(msorb, synth, torch, dev, pairs, uniq, local, cpu, handles=None):
+    """configs[4]'s front-end half at the 4Seasons geometry: batch extraction rate (inputs in HBM) and the per-frame calls.
+    handles: as density_sweep_leg (the parameters of 4season.yaml are KITTI's: a handle takes the new image size on its next call)."""
     from .per_frame import per_frame_leg
     cfg = synth.FOURSEASONS
-    exs = [msorb.ORBextractor(cfg["nfeatures"], cfg["scale"], cfg["nlevels"], cfg["ini_th"], cfg["min_th"], device=local) for _ in range(2)]
+    own = handles is None
+    exs = [msorb.ORBextractor(cfg["nfeatures"], cfg["scale"], cfg["nlevels"], cfg["ini_th"], cfg["min_th"], device=local) for _ in range(2)] if own else list(handles)
     try:
         base = synth.stereo_batch(uniq, cfg["rows"], cfg["cols"], seed0=4400)
         host = np.concatenate([base] * (pairs // uniq + 1))[:2 * pairs]
@@ -147,4 +158,8 @@ def fourseasons_leg(msorb, synth, torch, dev, pairs, uniq, local, cpu):
         return res
     finally:
         for e in exs:
-            e.close()
+            if own:
+                e.close()
+            else:
+                e.set_profiling(False)
+                e.set_overlap(1, True)

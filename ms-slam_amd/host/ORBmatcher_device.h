@@ -135,46 +135,90 @@ private:
     std::vector<uint8_t> desc_;
 };
 
+// pointer -> index table of one call (open addressing, power-of-two capacity, no allocation per entry: the std::unordered_map it
+// replaces cost more per tracking frame than the device search it prepares)
+class PointerIndex {
+public:
+    void reset(size_t n) {
+        size_t cap = 64;
+        while (cap < 2 * n + 2) cap <<= 1;
+        if (key_.size() != cap) { key_.assign(cap, nullptr); val_.resize(cap); }
+        else std::fill(key_.begin(), key_.end(), nullptr);
+        mask_ = cap - 1;
+    }
+    // first insertion wins; returns the stored index
+    int emplace(const void* k, int v) {
+        size_t i = slot(k);
+        while (key_[i] && key_[i] != k) i = (i + 1) & mask_;
+        if (!key_[i]) { key_[i] = k; val_[i] = v; }
+        return val_[i];
+    }
+    int find(const void* k) const {
+        size_t i = slot(k);
+        while (key_[i] && key_[i] != k) i = (i + 1) & mask_;
+        return key_[i] ? val_[i] : -1;
+    }
+private:
+    size_t slot(const void* k) const { return (size_t)((reinterpret_cast<uintptr_t>(k) >> 4) * 0x9E3779B97F4A7C15ull >> 20) & mask_; }
+    std::vector<const void*> key_;
+    std::vector<int> val_;
+    size_t mask_ = 0;
+};
+// the marshalling arrays of SearchByProjection(F, vpMapPoints): kept per calling thread between frames (13 vectors of a few
+// thousand entries: allocating and clearing them every frame was a third of the call)
+struct LocalPointsScratch {
+    PointerIndex index;
+    std::vector<int> frameMp, before, extraObs, level, obs;
+    std::vector<uint8_t> inView, bad, spars, desc;
+    std::vector<float> px, py, pxr, depth, vcos;
+};
+
 // ORBmatcher::SearchByProjection(Frame &F, const vector<shared_ptr<MapPoint>> &vpMapPoints, th, bFarPoints, thFarPoints)
 template <class FrameT, class MapPointPtr>
 int SearchByProjection(DeviceFrame<FrameT>& dev, FrameT& F, const std::vector<MapPointPtr>& vpMapPoints, const float th,
                        const bool bFarPoints, const float thFarPoints, const float mfNNratio) {
     const int M = (int)vpMapPoints.size(), N = (int)F.mvpMapPoints.size();
+    static thread_local LocalPointsScratch S;
     // table = the local map points in call order, then the map points the frame already holds that are not among them
     // (they are never queries — track_in_view 0 — but their Observations() decides whether a keypoint is taken, :89-91)
-    std::unordered_map<const void*, int> index;
-    index.reserve((size_t)M * 2);
-    for (int i = 0; i < M; i++) index.emplace(vpMapPoints[i].get(), i);  // first occurrence wins, like the scan order
-    std::vector<int> frameMp(N, -1), extraObs;
+    S.index.reset((size_t)M + N);
+    for (int i = 0; i < M; i++) S.index.emplace(vpMapPoints[i].get(), i);  // first occurrence wins, like the scan order
+    S.frameMp.assign(N, -1);
+    S.extraObs.clear();
     for (int i = 0; i < N; i++) {
         if (!F.mvpMapPoints[i]) continue;
-        auto it = index.find(F.mvpMapPoints[i].get());
-        if (it != index.end()) { frameMp[i] = it->second; continue; }
-        frameMp[i] = M + (int)extraObs.size();
-        index.emplace(F.mvpMapPoints[i].get(), frameMp[i]);
-        extraObs.push_back(F.mvpMapPoints[i]->Observations());
+        const int at = S.index.emplace(F.mvpMapPoints[i].get(), M + (int)S.extraObs.size());
+        S.frameMp[i] = at;
+        if (at == M + (int)S.extraObs.size()) S.extraObs.push_back(F.mvpMapPoints[i]->Observations());
     }
-    const int T = M + (int)extraObs.size();
-    std::vector<uint8_t> inView(T, 0), bad(T, 0), spars(T, 0), desc((size_t)T * 32, 0);
-    std::vector<float> px(T, 0), py(T, 0), pxr(T, 0), depth(T, 0), vcos(T, 0);
-    std::vector<int> level(T, 0), obs(T, 0);
+    const int T = M + (int)S.extraObs.size();
+    S.inView.assign(T, 0); S.bad.assign(T, 0); S.spars.assign(T, 0); S.desc.resize((size_t)T * 32);
+    S.px.resize(T); S.py.resize(T); S.pxr.resize(T); S.depth.resize(T); S.vcos.resize(T);
+    S.level.resize(T); S.obs.resize(T);
     for (int i = 0; i < M; i++) {
         const auto& p = vpMapPoints[i];
-        inView[i] = p->mbTrackInView; bad[i] = p->isBad(); spars[i] = p->mbSparsified;
-        px[i] = p->mTrackProjX; py[i] = p->mTrackProjY; pxr[i] = p->mTrackProjXR; depth[i] = p->mTrackDepth;
-        level[i] = p->mnTrackScaleLevel; vcos[i] = p->mTrackViewCos; obs[i] = p->Observations();
-        const auto d = p->GetDescriptor();
-        std::memcpy(&desc[(size_t)i * 32], d.template ptr<unsigned char>(0), 32);
+        S.inView[i] = p->mbTrackInView; S.bad[i] = p->isBad(); S.spars[i] = p->mbSparsified;
+        S.px[i] = p->mTrackProjX; S.py[i] = p->mTrackProjY; S.pxr[i] = p->mTrackProjXR; S.depth[i] = p->mTrackDepth;
+        S.level[i] = p->mnTrackScaleLevel; S.vcos[i] = p->mTrackViewCos; S.obs[i] = p->Observations();
+        // MapPoint::GetDescriptor clones under the point's mutex (MapPoint.cc:431-435): only for the points that are queries
+        // (ORBmatcher.cc:53-59 skips the others before it would fetch theirs)
+        if (S.inView[i] && !S.bad[i]) {
+            const auto d = p->GetDescriptor();
+            std::memcpy(&S.desc[(size_t)i * 32], d.template ptr<unsigned char>(0), 32);
+        }
     }
-    for (int k = 0; k < (int)extraObs.size(); k++) obs[M + k] = extraObs[k];
-    const std::vector<int> before = frameMp;
+    for (int k = 0; k < (int)S.extraObs.size(); k++) {
+        S.obs[M + k] = S.extraObs[k];
+        S.px[M + k] = S.py[M + k] = S.pxr[M + k] = S.depth[M + k] = S.vcos[M + k] = 0.f; S.level[M + k] = 0;
+    }
+    S.before = S.frameMp;
     int nmatches = 0;
-    check(msorb_search_by_projection_mps(dev.get(), T, inView.data(), bad.data(), spars.data(), px.data(), py.data(),
-                                         pxr.data(), depth.data(), level.data(), vcos.data(), desc.data(), obs.data(),
-                                         frameMp.data(), th, bFarPoints ? 1 : 0, thFarPoints, mfNNratio, &nmatches),
+    check(msorb_search_by_projection_mps(dev.get(), T, S.inView.data(), S.bad.data(), S.spars.data(), S.px.data(), S.py.data(),
+                                         S.pxr.data(), S.depth.data(), S.level.data(), S.vcos.data(), S.desc.data(), S.obs.data(),
+                                         S.frameMp.data(), th, bFarPoints ? 1 : 0, thFarPoints, mfNNratio, &nmatches),
           "msorb_search_by_projection_mps");
     for (int i = 0; i < N; i++)
-        if (frameMp[i] != before[i] && frameMp[i] >= 0 && frameMp[i] < M) F.mvpMapPoints[i] = vpMapPoints[frameMp[i]];
+        if (S.frameMp[i] != S.before[i] && S.frameMp[i] >= 0 && S.frameMp[i] < M) F.mvpMapPoints[i] = vpMapPoints[S.frameMp[i]];
     return nmatches;
 }
 
