@@ -170,7 +170,7 @@ struct msorb_extractor {
     // host-synchronised stages: debugging), MSORB_QUADTREE=host (DistributeOctTree on the host twin), MSORB_HOST_THREADS (its
     // worker threads), MSORB_SPLIT_NO_PEER (test hook: the two-device gather staged through the host), MSORB_FORCE_PEER_PYRAMID
     // (test hook: msorb_stereo_matches pulls the right pyramid over the peer path even on one device)
-    const StereoRowJob* row_job = nullptr;   // set by the stereo-frame calls around run_pipeline: the row table rides the layout launch
+    const StereoRowJob* row_job = nullptr;   // set by the stereo-frame calls around run_pipeline: the right eye's band records leave the layout launch
     struct Knobs { bool serial_pipeline = false, quadtree_host = false, split_no_peer = false, force_peer_pyramid = false; int host_threads = 0; } knobs;
     int lds_per_block = 64 * 1024;   // hipDeviceAttributeMaxSharedMemoryPerBlock of the handle's device
     static constexpr bool capturing = false;   // (no graph capture: plain launches; see tools/experiments/README.md)
@@ -1176,7 +1176,7 @@ int msorb_pyramid_level_image(msorb_extractor* h, int image, int level, const ui
 
 // Both eyes of one stereo frame in one call: the two images go through the batch pipeline together (one chain of
 // launches instead of two racing on two host threads), Frame::ComputeStereoMatches runs on the device outputs
-// (row table + match + median kernels of msorb_stereo_matches_batch) and everything comes back with one synchronisation.
+// (band records from the layout launch, match + median kernels of msorb_stereo_matches_batch) and everything comes back with one synchronisation.
 int msorb_extract_stereo(msorb_extractor* h, const uint8_t* left, const uint8_t* right, int rows, int cols, size_t stride_left,
                          size_t stride_right, float mb, float mbf, msorb_keypoint* kps_left, uint8_t* desc_left, int* n_left,
                          msorb_keypoint* kps_right, uint8_t* desc_right, int* n_right, int capacity, float* u_right,
@@ -1237,7 +1237,7 @@ int msorb::extract_stereo_sink(msorb_extractor* h, const uint8_t* left, const ui
     msorb_keypoint* const d_kps = reinterpret_cast<msorb_keypoint*>(blk);
     uint8_t* const d_desc = blk + o_desc;
     int counts[2] = {0, 0}, mono[2] = {0, 0};
-    // (n_oob is zeroed by the row-table kernel of launch_stereo_match_batch)
+    // (n_oob is zeroed by the layout launch that writes the band records — or by the row-table kernel of launch_stereo_match_batch)
     // what vRowIndices (Frame.cc:757-776) would hold about the right keypoints leaves the selection-layout launch as band records
     const StereoRowJob row_job{1, rows, reinterpret_cast<int2*>(h->d_st_list.p), h->d_st_list.p + 2 * (size_t)cap, reinterpret_cast<int*>(blk + o_oob)};
     h->row_job = bands ? &row_job : nullptr;

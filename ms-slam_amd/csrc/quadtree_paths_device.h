@@ -105,25 +105,6 @@ QT_HD int path_of_position(int pos, int g, int n_ini) {
     return (((g & 1) ? n_ini - 1 - c : c) << (2 * g)) | ((pos & low) ^ (0x33333333 & low));
 }
 
-// result order = descending creation sequence: rank sort (all sequence numbers are distinct)
-template <class Ex>
-QT_HD void rank_results(Ex& ex, Workspace& w, int nres, int* out_pt) {
-    const int tid = ex.tid(), nt = ex.nthreads();
-    for (int i = nres + tid; i < ((nres + 7) & ~7); i += nt) w.res_seq[i] = -0x7FFFFFFF - 1;
-    ex.sync();
-    for (int i = tid; i < nres; i += nt) {
-        const int s = w.res_seq[i];
-        int rank = 0;
-        for (int j = 0; j < nres; j += 8) {
-            const Int4 v = load_int4(w.res_seq + j), u = load_int4(w.res_seq + j + 4);
-            rank += (v.x > s) + (v.y > s) + (v.z > s) + (v.w > s);
-            rank += (u.x > s) + (u.y > s) + (u.z > s) + (u.w > s);
-        }
-        out_pt[rank] = w.res_pt[i];
-    }
-    ex.sync();
-}
-
 struct PathPassFirst { static constexpr bool value = true; };
 struct PathPassAgain { static constexpr bool value = false; };
 

@@ -545,3 +545,26 @@ def test_extract_stereo_equals_two_extractions_plus_stereo_matches(msorb_mod, or
             assert np.array_equal(k1.view(np.uint8), wkl.view(np.uint8)) and np.array_equal(d1, wdl)
         finally:
             ex.close(); exl.close(); exr.close()
+
+
+def test_extract_stereo_on_a_tall_image_takes_the_row_table(msorb_mod, oracle):
+    """rows > 4095: the band records of a stereo frame hold 12-bit rows, the fused call builds the row table instead
+    (extractor.hip extract_stereo_sink) — same contract as above."""
+    mbf, mb = mc.KITTI_BF, mc.KITTI_BF / mc.KITTI_FX
+    rows, cols, nfeat = 4200, 2200, 3000
+    L, R = synth.stereo_pair(77, rows, cols)
+    ex = msorb_mod.ORBextractor(nfeat, 1.2, 8, 20, 7)
+    exl = msorb_mod.ORBextractor(nfeat, 1.2, 8, 20, 7)
+    exr = msorb_mod.ORBextractor(nfeat, 1.2, 8, 20, 7)
+    try:
+        kl, dl, kr, dr, ur, dp, oob = ex.extract_stereo(L, R, mb, mbf)
+        _, wkl, wdl = exl(L)
+        _, wkr, wdr = exr(R)
+        assert np.array_equal(kl.view(np.uint8), wkl.view(np.uint8)) and np.array_equal(dl, wdl)
+        assert np.array_equal(kr.view(np.uint8), wkr.view(np.uint8)) and np.array_equal(dr, wdr)
+        wur, wdp, woob = msorb_mod.stereo_matches(exl, exr, wkl, wdl, wkr, wdr, mb, mbf)
+        assert np.array_equal(ur.view(np.uint32), wur.view(np.uint32))
+        assert np.array_equal(dp.view(np.uint32), wdp.view(np.uint32))
+        assert oob == woob and (ur > 0).sum() > 20
+    finally:
+        ex.close(); exl.close(); exr.close()
