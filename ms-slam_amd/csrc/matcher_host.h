@@ -29,9 +29,15 @@ int frame_host_grid(msorb_frame* f);
 int frame_grid_max_keypoints();        // largest keypoint count the device grid takes on the current device (-1: query failed)
 void frame_invalidate(msorb_frame* f);  // a failed set leaves the handle empty, never half new / half old
 // sets the frame's device side (train arrays + grid) from device arrays: enqueue only, on stream s (track.hip)
+// the motion-model projection that rides the frame's grid launch (track.hip frame_grid_kernel): `prepare` fills the kernel's
+// LastFrameArgs (behind `args`) once the frame's fields are set, right before the launch
+struct LastFrameProjector {
+    int (*prepare)(void* ctx, hipStream_t s, void* args);
+    void* ctx;
+};
 int enqueue_frame_from_device(msorb_frame* f, hipStream_t s, const msorb_keypoint* d_kps, const uint8_t* d_desc,
                               const float* d_u_right, const int* d_count, int n_fixed, int n_cap, float min_x, float max_x,
-                              float min_y, float max_y, const float* scale_factors, int nlevels);
+                              float min_y, float max_y, const float* scale_factors, int nlevels, const LastFrameProjector* proj = nullptr);
 }  // namespace msorb
 
 #define HIPCHK(expr)                                                               \

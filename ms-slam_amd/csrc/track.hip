@@ -32,6 +32,70 @@ constexpr int kNCell = kGridCols * kGridRows;
 constexpr int kGridThreads = 1024;
 
 // ---------------------------------------------------------------------------------------------------------------------
+// TrackWithMotionModel's search, ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (ORBmatcher.cc:1941-2152):
+// the per-point part of the loop up to the window (:1962-1998) — one thread per last-frame keypoint, window query out.
+//   x3Dc = Tcw * x3Dw is Sophus' SE3 action (se3.hpp:321-324 -> so3.hpp:358-367): uv = q.vec x p; uv += uv;
+//   p + q.w * uv + q.vec x uv, then + translation.  Float convention (DESIGN.md, as for isInFrustum): of a difference of two
+//   products the first one is fused (a*b - c*d -> fma(a, b, -(c*d))), a product added to a term is fused (p + w*uv ->
+//   fma(w, uv, p)); sums stay sums.  Which products an actual -O3 -march=native build contracts is the compiler's choice (GCC 11
+//   SLP-vectorises this very expression with fmsub in some lanes and fnmadd in others): msorb_search_by_projection_frames takes
+//   coordinates projected by the caller's own build when the last ulp matters.
+// ---------------------------------------------------------------------------------------------------------------------
+struct LastFrameArgs {
+    float qx, qy, qz, qw, tx, ty, tz;
+    float fx, fy, cx, cy, mbf;
+    float min_x, max_x, min_y, max_y;
+    float th;
+    int forward, backward, n;
+    float scale[MSORB_MAX_LEVELS];
+    const float* pos_w;      // [3n]
+    const int* octave;       // [n]
+    const uint8_t* flags;    // [n] bit 0: the keypoint holds a map point that is not an outlier
+    WinQuery* q;
+    float *u, *v, *ur;
+    uint8_t* valid;
+};
+
+__device__ __forceinline__ float diff_of_products(float a, float b, float c, float d) { return __fmaf_rn(a, b, -__fmul_rn(c, d)); }
+
+__device__ __forceinline__ void last_frame_point(const LastFrameArgs& A, const int i) {
+    if (i >= A.n) return;
+    WinQuery w;
+    w.x = 0; w.y = 0; w.r = 0; w.ur = 0; w.min_level = 0; w.max_level = 0; w.flags = 0; w.pad[0] = w.pad[1] = w.pad[2] = 0;
+    float u = 0.0f, v = 0.0f, ur = 0.0f;
+    uint8_t ok = 0;
+    if (A.flags[i] & 1) {
+        const float px = A.pos_w[3 * i], py = A.pos_w[3 * i + 1], pz = A.pos_w[3 * i + 2];
+        float uvx = diff_of_products(A.qy, pz, A.qz, py), uvy = diff_of_products(A.qz, px, A.qx, pz), uvz = diff_of_products(A.qx, py, A.qy, px);
+        uvx = __fadd_rn(uvx, uvx); uvy = __fadd_rn(uvy, uvy); uvz = __fadd_rn(uvz, uvz);
+        const float cx_ = diff_of_products(A.qy, uvz, A.qz, uvy), cy_ = diff_of_products(A.qz, uvx, A.qx, uvz), cz_ = diff_of_products(A.qx, uvy, A.qy, uvx);
+        const float xc = __fadd_rn(__fadd_rn(__fmaf_rn(A.qw, uvx, px), cx_), A.tx);
+        const float yc = __fadd_rn(__fadd_rn(__fmaf_rn(A.qw, uvy, py), cy_), A.ty);
+        const float zc = __fadd_rn(__fadd_rn(__fmaf_rn(A.qw, uvz, pz), cz_), A.tz);
+        // :1973 `const float invzc = 1.0/x3Dc(2)`: the double quotient rounded to float IS the float quotient (53 >= 2*24 + 2)
+        const float invzc = __fdiv_rn(1.0f, zc);
+        if (!(invzc < 0.0f)) {
+            u = __fadd_rn(__fdiv_rn(__fmul_rn(A.fx, xc), zc), A.cx);   // Pinhole::project, Pinhole.cpp:43-49
+            v = __fadd_rn(__fdiv_rn(__fmul_rn(A.fy, yc), zc), A.cy);
+            if (!(u < A.min_x || u > A.max_x) && !(v < A.min_y || v > A.max_y)) {   // :1980-1983
+                const int oct = A.octave[i];
+                ok = 1;
+                ur = __fmaf_rn(-A.mbf, invzc, u);                                  // :2019
+                w.x = u; w.y = v; w.ur = ur;
+                w.r = __fmul_rn(A.th, A.scale[oct]);                               // :1989
+                if (A.forward) { w.min_level = (int16_t)oct; w.max_level = -1; }  // :1993-1998
+                else if (A.backward) { w.min_level = 0; w.max_level = (int16_t)oct; }
+                else { w.min_level = (int16_t)(oct - 1); w.max_level = (int16_t)(oct + 1); }
+                w.flags = kQValid | kQSkipOccupied;
+            }
+        }
+    }
+    A.q[i] = w;
+    A.u[i] = u; A.v[i] = v; A.ur[i] = ur; A.valid[i] = ok;
+}
+__global__ __launch_bounds__(256) void last_frame_kernel(LastFrameArgs A) { last_frame_point(A, blockIdx.x * blockDim.x + threadIdx.x); }
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Frame::AssignFeaturesToGrid (Frame.cc:385-416) for a batch of frames, one workgroup per frame.  Sources: the extractor's
 // device outputs (28-byte keypoints, 32-byte descriptors, mvuRight).  Products: the matcher's train arrays (KpLite,
 // descriptors, occupancy cleared) and mGrid as CSR (cell = ix * 48 + iy, ascending keypoint index inside a cell).
@@ -53,8 +117,15 @@ struct GridArgs {
     int dst_stride;              // also the upper bound of n
 };
 
-__global__ __launch_bounds__(kGridThreads) void frame_grid_kernel(GridArgs A) {
+// n_grid_blocks < gridDim.x: the blocks behind the frames' project the last frame's map points (last_frame_point, kGridThreads
+// each) — TrackWithMotionModel's projection needs nothing of the grid, so it rides the same launch instead of a kernel of its own
+// behind it (a tracking frame: one launch and ~10 us less on the chain).
+__global__ __launch_bounds__(kGridThreads) void frame_grid_kernel(GridArgs A, LastFrameArgs P, int n_grid_blocks) {
     extern __shared__ int lds[];
+    if ((int)blockIdx.x >= n_grid_blocks) {
+        last_frame_point(P, ((int)blockIdx.x - n_grid_blocks) * kGridThreads + (int)threadIdx.x);
+        return;
+    }
     int* const cnt = lds;                    // kNCell + 1
     int* const cur = cnt + (kNCell + 1);     // kNCell
     uint16_t* const cell_of = reinterpret_cast<uint16_t*>(cur + kNCell);  // dst_stride
@@ -166,7 +237,7 @@ __global__ __launch_bounds__(kGridThreads) void frame_grid_kernel(GridArgs A) {
 // subtracts what hipFuncGetAttributes reports for the kernel)
 size_t frame_grid_lds(int n_cap) { return (size_t)(2 * kNCell + 1) * sizeof(int) + (size_t)n_cap * 2 * sizeof(uint16_t); }
 
-int launch_frame_grid(const GridArgs& A, int n_frames, hipStream_t s) {
+int launch_frame_grid(const GridArgs& A, int n_frames, hipStream_t s, const LastFrameArgs* proj = nullptr) {
     const int limit = msorb::frame_grid_max_keypoints();
     if (limit < 0) return MSORB_E_HIP;
     if (A.dst_stride > limit) {
@@ -174,7 +245,8 @@ int launch_frame_grid(const GridArgs& A, int n_frames, hipStream_t s) {
         return MSORB_E_CAPACITY;
     }
     const size_t lds = frame_grid_lds(A.dst_stride);   // <= the kernel's room: frame_grid_max_keypoints raised the limit once, for good
-    hipLaunchKernelGGL(frame_grid_kernel, dim3(n_frames), dim3(kGridThreads), lds, s, A);
+    const int n_proj = proj && proj->n > 0 ? (proj->n + kGridThreads - 1) / kGridThreads : 0;
+    hipLaunchKernelGGL(frame_grid_kernel, dim3(n_frames + n_proj), dim3(kGridThreads), lds, s, A, proj ? *proj : LastFrameArgs{}, n_frames);
     return MSORB_OK;
 }
 
@@ -234,69 +306,6 @@ __global__ __launch_bounds__(256) void local_points_kernel(LocalPointsArgs A) {
     A.q[o] = w;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// TrackWithMotionModel's search, ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (ORBmatcher.cc:1941-2152):
-// the per-point part of the loop up to the window (:1962-1998) — one thread per last-frame keypoint, window query out.
-//   x3Dc = Tcw * x3Dw is Sophus' SE3 action (se3.hpp:321-324 -> so3.hpp:358-367): uv = q.vec x p; uv += uv;
-//   p + q.w * uv + q.vec x uv, then + translation.  Float convention (DESIGN.md, as for isInFrustum): of a difference of two
-//   products the first one is fused (a*b - c*d -> fma(a, b, -(c*d))), a product added to a term is fused (p + w*uv ->
-//   fma(w, uv, p)); sums stay sums.  Which products an actual -O3 -march=native build contracts is the compiler's choice (GCC 11
-//   SLP-vectorises this very expression with fmsub in some lanes and fnmadd in others): msorb_search_by_projection_frames takes
-//   coordinates projected by the caller's own build when the last ulp matters.
-// ---------------------------------------------------------------------------------------------------------------------
-struct LastFrameArgs {
-    float qx, qy, qz, qw, tx, ty, tz;
-    float fx, fy, cx, cy, mbf;
-    float min_x, max_x, min_y, max_y;
-    float th;
-    int forward, backward, n;
-    float scale[MSORB_MAX_LEVELS];
-    const float* pos_w;      // [3n]
-    const int* octave;       // [n]
-    const uint8_t* flags;    // [n] bit 0: the keypoint holds a map point that is not an outlier
-    WinQuery* q;
-    float *u, *v, *ur;
-    uint8_t* valid;
-};
-
-__device__ __forceinline__ float diff_of_products(float a, float b, float c, float d) { return __fmaf_rn(a, b, -__fmul_rn(c, d)); }
-
-__global__ __launch_bounds__(256) void last_frame_kernel(LastFrameArgs A) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.n) return;
-    WinQuery w;
-    w.x = 0; w.y = 0; w.r = 0; w.ur = 0; w.min_level = 0; w.max_level = 0; w.flags = 0; w.pad[0] = w.pad[1] = w.pad[2] = 0;
-    float u = 0.0f, v = 0.0f, ur = 0.0f;
-    uint8_t ok = 0;
-    if (A.flags[i] & 1) {
-        const float px = A.pos_w[3 * i], py = A.pos_w[3 * i + 1], pz = A.pos_w[3 * i + 2];
-        float uvx = diff_of_products(A.qy, pz, A.qz, py), uvy = diff_of_products(A.qz, px, A.qx, pz), uvz = diff_of_products(A.qx, py, A.qy, px);
-        uvx = __fadd_rn(uvx, uvx); uvy = __fadd_rn(uvy, uvy); uvz = __fadd_rn(uvz, uvz);
-        const float cx_ = diff_of_products(A.qy, uvz, A.qz, uvy), cy_ = diff_of_products(A.qz, uvx, A.qx, uvz), cz_ = diff_of_products(A.qx, uvy, A.qy, uvx);
-        const float xc = __fadd_rn(__fadd_rn(__fmaf_rn(A.qw, uvx, px), cx_), A.tx);
-        const float yc = __fadd_rn(__fadd_rn(__fmaf_rn(A.qw, uvy, py), cy_), A.ty);
-        const float zc = __fadd_rn(__fadd_rn(__fmaf_rn(A.qw, uvz, pz), cz_), A.tz);
-        // :1973 `const float invzc = 1.0/x3Dc(2)`: the double quotient rounded to float IS the float quotient (53 >= 2*24 + 2)
-        const float invzc = __fdiv_rn(1.0f, zc);
-        if (!(invzc < 0.0f)) {
-            u = __fadd_rn(__fdiv_rn(__fmul_rn(A.fx, xc), zc), A.cx);   // Pinhole::project, Pinhole.cpp:43-49
-            v = __fadd_rn(__fdiv_rn(__fmul_rn(A.fy, yc), zc), A.cy);
-            if (!(u < A.min_x || u > A.max_x) && !(v < A.min_y || v > A.max_y)) {   // :1980-1983
-                const int oct = A.octave[i];
-                ok = 1;
-                ur = __fmaf_rn(-A.mbf, invzc, u);                                  // :2019
-                w.x = u; w.y = v; w.ur = ur;
-                w.r = __fmul_rn(A.th, A.scale[oct]);                               // :1989
-                if (A.forward) { w.min_level = (int16_t)oct; w.max_level = -1; }  // :1993-1998
-                else if (A.backward) { w.min_level = 0; w.max_level = (int16_t)oct; }
-                else { w.min_level = (int16_t)(oct - 1); w.max_level = (int16_t)(oct + 1); }
-                w.flags = kQValid | kQSkipOccupied;
-            }
-        }
-    }
-    A.q[i] = w;
-    A.u[i] = u; A.v[i] = v; A.ur[i] = ur; A.valid[i] = ok;
-}
 
 // packed transfer blocks of the last frame's points (n entries)
 struct LastLayout {
@@ -395,7 +404,7 @@ namespace msorb {
 // Sets the frame from device arrays: enqueue only, on stream s.  n_cap = upper bound of the keypoint count.
 int enqueue_frame_from_device(msorb_frame* f, hipStream_t s, const msorb_keypoint* d_kps, const uint8_t* d_desc,
                               const float* d_u_right, const int* d_count, int n_fixed, int n_cap, float min_x, float max_x,
-                              float min_y, float max_y, const float* scale_factors, int nlevels) {
+                              float min_y, float max_y, const float* scale_factors, int nlevels, const LastFrameProjector* proj) {
     int rc;
     n_cap = std::max(n_cap, 1);
     if ((rc = f->d_kp.ensure(n_cap)) || (rc = f->d_desc.ensure((size_t)n_cap * 32)) || (rc = f->d_cell_begin.ensure(kNCell + 1)) ||
@@ -415,6 +424,11 @@ int enqueue_frame_from_device(msorb_frame* f, hipStream_t s, const msorb_keypoin
     A.n_out = f->d_n.p;
     A.dst_stride = n_cap;
     f->host_grid_valid = false;
+    if (proj) {   // the motion-model projection rides the grid launch (frame_grid_kernel): its arguments need the frame fields set above
+        LastFrameArgs P{};
+        if ((rc = proj->prepare(proj->ctx, s, &P))) return rc;
+        return launch_frame_grid(A, 1, s, &P);
+    }
     return launch_frame_grid(A, 1, s);
 }
 }  // namespace msorb
@@ -603,9 +617,11 @@ struct LastFrameCall {
 
 // projection + queries + round 0 of the window search + the read-back, enqueued on stream s (ordered behind whatever produced
 // the frame's device arrays; the table's upload is waited for here).  d_occ must hold the occupancy snapshot.
-int enqueue_last_frame(msorb_frame* f, const LastFrameCall& c, hipStream_t s) {
+// buffers, the wait for the table's upload, the projection kernel's arguments
+int prepare_last_frame(msorb_frame* f, const LastFrameCall& c, hipStream_t s, LastFrameArgs& A) {
     msorb_frame_track& T = *f->track;
     const size_t n = (size_t)T.last_n;
+    A = LastFrameArgs{};
     if (!n) return MSORB_OK;
     const LastLayout L(n);
     int rc;
@@ -614,7 +630,6 @@ int enqueue_last_frame(msorb_frame* f, const LastFrameCall& c, hipStream_t s) {
         return rc;
     HIPCHK(hipStreamWaitEvent(s, T.ev_last, 0));
     const msorb_motion_model& m = *c.mm;
-    LastFrameArgs A{};
     A.qx = m.q[0]; A.qy = m.q[1]; A.qz = m.q[2]; A.qw = m.q[3];
     A.tx = m.t[0]; A.ty = m.t[1]; A.tz = m.t[2];
     A.fx = m.fx; A.fy = m.fy; A.cx = m.cx; A.cy = m.cy; A.mbf = m.mbf;
@@ -628,7 +643,24 @@ int enqueue_last_frame(msorb_frame* f, const LastFrameCall& c, hipStream_t s) {
     A.q = f->d_q.p;
     A.u = reinterpret_cast<float*>(dout + L.o_u); A.v = reinterpret_cast<float*>(dout + L.o_v);
     A.ur = reinterpret_cast<float*>(dout + L.o_ur); A.valid = dout + L.o_valid;
-    hipLaunchKernelGGL(last_frame_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A);
+    return MSORB_OK;
+}
+// projection + queries + round 0 of the window search + the read-back, enqueued on stream s (ordered behind whatever produced
+// the frame's device arrays; the table's upload is waited for here).  d_occ must hold the occupancy snapshot.
+// projected: the projection already ran with the frame's grid launch (prepare_last_frame through LastFrameProjector)
+int enqueue_last_frame(msorb_frame* f, const LastFrameCall& c, hipStream_t s, bool projected = false) {
+    msorb_frame_track& T = *f->track;
+    const size_t n = (size_t)T.last_n;
+    if (!n) return MSORB_OK;
+    const LastLayout L(n);
+    if (!projected) {
+        LastFrameArgs A{};
+        int rc;
+        if ((rc = prepare_last_frame(f, c, s, A))) return rc;
+        hipLaunchKernelGGL(last_frame_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A);
+    }
+    const uint8_t* di = T.d_last.p;
+    uint8_t* dout = T.d_last_out.p;
     const float mid = f->scale.empty() ? 1.0f : f->scale[f->scale.size() / 2];
     launch_window_topk(f->view(), f->d_q.p, di + L.o_desc, 0, T.last_n, reinterpret_cast<TopK*>(dout + L.o_topk), s, 1, 0, 0, nullptr,
                        window_lanes_for(c.th * mid, f->gridWInv, f->gridHInv));
@@ -812,10 +844,15 @@ struct FrameSinkCtx {
 };
 int frame_sink(void* ctx, const StereoDeviceOutputs& o) {
     FrameSinkCtx& C = *static_cast<FrameSinkCtx*>(ctx);
+    const LastFrameProjector proj{[](void* ctx, hipStream_t s, void* args) {
+                                      FrameSinkCtx& X = *static_cast<FrameSinkCtx*>(ctx);
+                                      return prepare_last_frame(X.f, *X.lf, s, *static_cast<LastFrameArgs*>(args));
+                                  },
+                                  ctx};
     int rc = enqueue_frame_from_device(C.f, o.stream, o.kps_left, o.desc_left, o.u_right, o.n_left, 0, o.capacity, C.min_x, C.max_x,
-                                       C.min_y, C.max_y, C.scale, C.nlevels);
+                                       C.min_y, C.max_y, C.scale, C.nlevels, C.lf ? &proj : nullptr);
     if (rc) return rc;
-    if (C.lf) return enqueue_last_frame(C.f, *C.lf, o.stream);
+    if (C.lf) return enqueue_last_frame(C.f, *C.lf, o.stream, /*projected=*/true);
     if (!C.lp) return rc;
     HIPCHK(hipStreamWaitEvent(o.stream, C.f->track->ev_in, 0));
     return enqueue_local_points(C.f, *C.lp, o.stream);
