@@ -37,9 +37,6 @@ __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
     return v;
 }
 
-#ifdef MSORB_QT_SORTCHECK
-__device__ int g_sortcheck_bad = 0;
-#endif
 template <bool FRAME>
 struct DevExT {
     // FRAME: a 1024-thread instance that has its CU to itself (single frames); otherwise a batch instance (256 / 512 threads, several
@@ -50,11 +47,7 @@ struct DevExT {
     struct WaveEx {
         __device__ int tid() const { return threadIdx.x & 63; }
         __device__ int nthreads() const { return 64; }
-#ifdef MSORB_QT_SYNC_WAIT
-        __device__ void sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
-#else
         __device__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-#endif
         __device__ int excl_count(bool p, int* total) {
             const unsigned long long m = __ballot(p);
             *total = __popcll(m);
@@ -182,9 +175,6 @@ struct DevExT {
         }
         __syncthreads();
         WaveEx wex;
-#ifdef MSORB_QT_ONE_WAVE
-        if ((threadIdx.x >> 6) == 0)
-#endif
         for (;;) {
             // Take an open range.  The polling loop is executed by the WHOLE wave (every lane reads the same LDS words, so the
             // loop's control flow is wave-uniform); only the claim itself is lane 0's.  (A first form ran the loop inside
@@ -239,25 +229,7 @@ struct DevExT {
                 qt::ParScratch pl = ps;  // this range's private stretch of the position lists
                 pl.gpos = ps.gpos + first;
                 pl.lpos = ps.lpos + first;
-#ifdef MSORB_QT_SORTCHECK
-                unsigned cs0 = 0, cx0 = 0;
-                if (lane == 0) for (int i = first; i < last; i++) { cs0 += items[i].node; cx0 ^= items[i].node * 2654435761u; }
-                const uint32_t pivot_chk = items[first].key;
-                wex.sync();
-#endif
                 const int cut = qt::partition_par(wex, items, first, last, pl);
-#ifdef MSORB_QT_SORTCHECK
-                if (lane == 0) {
-                    unsigned cs1 = 0, cx1 = 0; int badl = 0, badr = 0;
-                    for (int i = first; i < last; i++) { cs1 += items[i].node; cx1 ^= items[i].node * 2654435761u; }
-                    for (int i = first + 1; i < cut; i++) badl += items[i].key > pivot_chk;
-                    for (int i = cut; i < last; i++) badr += items[i].key < pivot_chk;
-                    if (cs0 != cs1 || cx0 != cx1 || badl || badr)
-                        printf("PARTCHECK blk(%d,%d) wave %d [%d,%d) cut=%d multiset %s badl=%d badr=%d exec=%llx\n", blockIdx.x, blockIdx.y, (int)(threadIdx.x >> 6),
-                               first, last, cut, (cs0 != cs1 || cx0 != cx1) ? "CHANGED" : "ok", badl, badr, (unsigned long long)__builtin_amdgcn_read_exec());
-                }
-                wex.sync();
-#endif
                 mark(32);
                 if (last - cut > 16) {   // [cut, last) becomes an open range: the entry first, then the tail that publishes it
                     int slot = 0;
@@ -282,32 +254,11 @@ struct DevExT {
         }
         __syncthreads();
         mark(21);
-#ifdef MSORB_QT_SORTCHECK
-        if (threadIdx.x == 0) {
-            int pend = ps.sc[2], hd = ps.sc[0], tl = ps.sc[1], rs = ps.sc[3];
-            int bad_flag = 0;
-            unsigned long long seen_lo = 0; int dup = 0, oob = 0;
-            for (int i = 0; i < n; i++) { const unsigned nd = items[i].node; if (nd >= (unsigned)n) oob++; else if (nd < 64) { if (seen_lo >> nd & 1) dup++; seen_lo |= 1ull << nd; } }
-            // every range left behind must be "nearly sorted": element i is >= every element more than 16 places before it is NOT required;
-            // check the weaker invariant of the introsort loop: max of a prefix block <= min of later blocks cannot be stated simply -> only report counters
-            if (pend != 0 || hd != tl || tl != rs || oob || dup) bad_flag = 1;
-            if (bad_flag) { printf("SORTCHECK blk(%d,%d) n=%d pend=%d hd=%d tl=%d rs=%d oob=%d dup=%d\n", blockIdx.x, blockIdx.y, n, pend, hd, tl, rs, oob, dup); atomicExch(&g_sortcheck_bad, 1); }
-        }
-        __syncthreads();
-#endif
         if (n <= 16) {   // no range was ever opened: the whole array is one leaf
             if (threadIdx.x < 64) finish_leaf(items, 0, n);
             __syncthreads();
         }
         mark(22);
-#ifdef MSORB_QT_SORTCHECK
-        if (threadIdx.x == 0) {
-            int bad = 0;
-            for (int i = 1; i < n; i++) bad += items[i - 1].key > items[i].key;
-            if (bad) { printf("SORTCHECK blk(%d,%d) n=%d NOT SORTED: %d inversions\n", blockIdx.x, blockIdx.y, n, bad); atomicExch(&g_sortcheck_bad, 1); }
-        }
-        __syncthreads();
-#endif
     }
     int dbg = 0;
     int nt = 0;  // threads of this instance: blockDim.x, or fewer for the small levels of a mixed launch (the other waves have left)
@@ -433,11 +384,7 @@ __device__ __forceinline__ void quadtree_select_body(const QtLevels& lv, const C
         kept = qt::select<PC>(ex, reinterpret_cast<const qt::Pt*>(compact + off), n, label + off, lv.W[level], lv.H[level],
                               lv.quota[level], w, out, debug);
     }
-#ifdef MSORB_QT_SORTCHECK
-    if (threadIdx.x == 0) sel_n[(size_t)img * lv.nlevels + level] = g_sortcheck_bad ? 0 : kept;
-#else
     if (threadIdx.x == 0) sel_n[(size_t)img * lv.nlevels + level] = kept;
-#endif
     ex.dump();
 }
 template <int PC>

@@ -25,15 +25,17 @@ for r in load("t_memory_copy_trace.csv"):
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "C", r.get("Direction", "") + "  " + r.get("Bytes", r.get("Size", "")) + " B"))
 api = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "A", r["Function"]) for r in load("t_hip_api_trace.csv")]
 ev.sort()
-idx = [i for i, e in enumerate(ev) if "last_frame_kernel" in e[3]]
+# anchor: the frame grid launch of the last tracking frame (since round 5 it carries the motion-model projection's blocks too)
+kern = [i for i, e in enumerate(ev) if e[2] == "K" and "copyBuffer" not in e[3]]
+idx = [kern[j] for j in range(1, len(kern)) if "window_topk" in ev[kern[j]][3] and ("frame_grid_kernel" in ev[kern[j - 1]][3] or "last_frame_kernel" in ev[kern[j - 1]][3])]
 if not idx:
-    raise SystemExit("no last_frame_kernel in the trace")
+    raise SystemExit("no motion-model search (frame_grid_kernel -> window_topk_kernel) in the trace")
 last = idx[-1]
 start = last
-while start > 0 and ev[start][0] - ev[start - 1][1] < 80000:
+while start > 0 and ev[start][0] - ev[start - 1][1] < 45000:
     start -= 1
 end = last
-while end + 1 < len(ev) and ev[end + 1][0] - ev[end][1] < 80000 and "pyr_resize" not in ev[end + 1][3]:
+while end + 1 < len(ev) and ev[end + 1][0] - ev[end][1] < 45000 and "pyr_resize" not in ev[end + 1][3] and "pyr_tower" not in ev[end + 1][3]:
     end += 1
 t0 = ev[start][0]
 print("-- device timeline of the last tracking frame (us from the first event)")
