@@ -340,6 +340,9 @@ struct DevExT {
     }
 };
 
+#ifndef MSORB_QT_PATH_MIN_N_FACTOR
+#define MSORB_QT_PATH_MIN_N_FACTOR 2
+#endif
 template <int PC, bool FRAME>
 __device__ __forceinline__ void quadtree_select_body(const QtLevels& lv, const Cand16* __restrict__ compact,
                                                      const int* __restrict__ img_base,
@@ -366,12 +369,16 @@ __device__ __forceinline__ void quadtree_select_body(const QtLevels& lv, const C
     ex.nt = nt_eff;
     int* out = sel_pt + (size_t)img * sel_stride + lv.sel_off[level];
     int kept = -1;
-    // selection by quadrant path (quadtree_paths_device.h) when the tree fits the tables the LDS behind the workspace holds — a
-    // level with few candidates (n <= 2 N: the tree grows until every point is alone) gets the deepest
-    if (path_cap > 0 && (debug == 0 || debug == 3)) {
+    // selection by quadrant path (quadtree_paths_device.h) when the tree fits the tables the LDS behind the workspace holds
+    // A sparse level (n <= 2 N) takes the general form at once: its tree grows until (almost) every candidate is alone — 8-10
+    // generations for neighbours two pixels apart, below any table the LDS holds, or tables of six generations whose zeroing and
+    // summing cost more than the general form's passes over a few hundred candidates (low-texture stereo frame: 0.206 ms with an
+    // attempt on every level, 0.196 with attempts on N < n <= 2 N only, general form everywhere 0.188-0.193).
+    const int path_min_n = MSORB_QT_PATH_MIN_N_FACTOR * lv.quota[level];
+    if (path_cap > 0 && n > path_min_n && (debug == 0 || debug == 3)) {
         const int N = lv.quota[level], n_ini = lv.n_ini[level];
         qt::PathTables pt;
-        qt::path_tables_carve(pt, qt_mem + qt::workspace_bytes(ws_N, ws_nini), n_ini, qt::path_gmax(n <= 2 * N ? (1 << 20) : N, n_ini, path_cap), lv.W[level], lv.H[level]);
+        qt::path_tables_carve(pt, qt_mem + qt::workspace_bytes(ws_N, ws_nini), n_ini, qt::path_gmax(N, n_ini, path_cap), lv.W[level], lv.H[level]);
         kept = qt::select_paths<PC>(ex, reinterpret_cast<const qt::Pt*>(compact + off), n, lv.W[level], lv.H[level], N, w, pt, out);
     }
     if (kept < 0) {
