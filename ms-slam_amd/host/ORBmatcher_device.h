@@ -99,9 +99,15 @@ public:
     void Upload(const FrameT& F) {
         static_assert(sizeof(F.mvKeysUn[0]) == sizeof(msorb_keypoint), "cv::KeyPoint must be the 28-byte layout");
         const int n = (int)F.mvKeysUn.size();
-        desc_.resize((size_t)n * 32);
-        for (int i = 0; i < n; i++) std::memcpy(&desc_[(size_t)i * 32], F.mDescriptors.template ptr<unsigned char>(i), 32);
-        check(msorb_frame_set(h_, reinterpret_cast<const msorb_keypoint*>(F.mvKeysUn.data()), n, desc_.data(),
+        const uint8_t* desc = nullptr;
+        if (n > 0 && F.mDescriptors.isContinuous()) {   // the extractor's output: one block of n x 32 bytes, handed over as it is
+            desc = F.mDescriptors.template ptr<unsigned char>(0);
+        } else {
+            desc_.resize((size_t)n * 32);
+            for (int i = 0; i < n; i++) std::memcpy(&desc_[(size_t)i * 32], F.mDescriptors.template ptr<unsigned char>(i), 32);
+            desc = desc_.data();
+        }
+        check(msorb_frame_set(h_, reinterpret_cast<const msorb_keypoint*>(F.mvKeysUn.data()), n, desc,
                               F.mvuRight.empty() ? nullptr : F.mvuRight.data(), F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY,
                               F.mvScaleFactors.data(), (int)F.mvScaleFactors.size()),
               "msorb_frame_set");
@@ -241,7 +247,7 @@ void ProjectLastFrame(const FrameT& CurrentFrame, const FrameT& LastFrame, bool 
     P.forward = tlc(2) > CurrentFrame.mb && !bMono;                       // :1957
     P.backward = -tlc(2) > CurrentFrame.mb && !bMono;                     // :1958
     const int n = LastFrame.N;
-    P.valid.assign(n, 0); P.desc.assign((size_t)n * 32, 0);
+    P.valid.assign(n, 0); P.desc.resize((size_t)n * 32);   // (descriptors of invalid entries are never read)
     P.u.assign(n, 0); P.v.assign(n, 0); P.ur.assign(n, 0); P.angle.assign(n, 0);
     P.octave.assign(n, 0); P.obs.assign(n, 0);
     for (int i = 0; i < n; i++) {
@@ -269,19 +275,21 @@ void ProjectLastFrame(const FrameT& CurrentFrame, const FrameT& LastFrame, bool 
 template <class FrameT>
 int SearchByProjection(DeviceFrame<FrameT>& dev, FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono,
                        const bool mbCheckOrientation) {
-    LastFrameProjection P;
+    // (the marshalling arrays live per calling thread between frames, like LocalPointsScratch)
+    static thread_local LastFrameProjection P;
+    static thread_local std::vector<int> lastMp, obs, curMp, before;
     ProjectLastFrame(CurrentFrame, LastFrame, bMono, P);
     const int nL = LastFrame.N, N = CurrentFrame.N;
     // ids: last-frame keypoint i -> i; map points the current frame already holds -> nL + k (only their Observations()
     // matter: a keypoint whose point has observations is never overwritten, :2011-2013)
-    std::vector<int> lastMp(nL), obs(P.obs), curMp(N, -1);
+    lastMp.resize(nL); obs.assign(P.obs.begin(), P.obs.end()); curMp.assign(N, -1);
     for (int i = 0; i < nL; i++) lastMp[i] = i;
     for (int j = 0; j < N; j++)
         if (CurrentFrame.mvpMapPoints[j]) {
             curMp[j] = (int)obs.size();
             obs.push_back(CurrentFrame.mvpMapPoints[j]->Observations());
         }
-    const std::vector<int> before(curMp);
+    before = curMp;
     int nmatches = 0;
     check(msorb_search_by_projection_frames(dev.get(), nL, P.valid.data(), P.u.data(), P.v.data(), P.ur.data(), P.octave.data(),
                                             P.angle.data(), P.desc.data(), lastMp.data(), obs.data(), (int)obs.size(), curMp.data(), th,
@@ -642,7 +650,7 @@ void ProjectKeyFramePoints(FrameT& CurrentFrame, const KeyFramePtr& pKF, const M
     const auto Ow = Tcw.inverse().translation();
     const auto vpMPs = pKF->GetMapPointMatches();
     const int n = (int)vpMPs.size();
-    P.valid.assign(n, 0); P.desc.assign((size_t)n * 32, 0);
+    P.valid.assign(n, 0); P.desc.resize((size_t)n * 32);   // (descriptors of invalid entries are never read)
     P.u.assign(n, 0); P.v.assign(n, 0); P.angle.assign(n, 0); P.level.assign(n, 0);
     for (int i = 0; i < n; i++) {
         const auto& pMP = vpMPs[i];

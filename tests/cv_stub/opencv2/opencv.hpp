@@ -21,6 +21,7 @@ public:
     void create(int r, int c, int) { rows = r; cols = c; step = (size_t)c; own.assign((size_t)r * c, 0); data = own.data(); }
     void release() { rows = cols = 0; step = 0; own.clear(); data = nullptr; }
     bool empty() const { return rows == 0 || cols == 0 || !data; }
+    bool isContinuous() const { return step == (size_t)cols || rows <= 1; }
     int type() const { return CV_8UC1; }
     Mat row(int r) const { return Mat(1, cols, CV_8UC1, data + (size_t)r * step, step); }
     template <typename T> T* ptr(int r) { return (T*)(data + (size_t)r * step); }

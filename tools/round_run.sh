@@ -38,3 +38,5 @@ done > $O/describe_pmc.txt 2>&1; cat $O/describe_pmc.txt
 # round 5: what the frame's quadtree by quadrant path and the one-launch pyramid buy (the same process start to end per line: ms one image, ms stereo frame)
 { for i in 1 2; do echo "default           $(python tools/per_frame_ab.py | tail -1)"; echo "MSORB_QT_PATHS=0  $(MSORB_QT_PATHS=0 python tools/per_frame_ab.py | tail -1)"; echo "MSORB_PYR_TOWER=0 $(MSORB_PYR_TOWER=0 python tools/per_frame_ab.py | tail -1)"; echo "both off          $(MSORB_QT_PATHS=0 MSORB_PYR_TOWER=0 python tools/per_frame_ab.py | tail -1)"; done; } > $O/frame_paths_tower_ab.txt 2>&1; cat $O/frame_paths_tower_ab.txt
 { for c in 4 0 5 4 0; do echo "MSORB_QT_BATCH_PATHS=$c $(MSORB_QT_BATCH_PATHS=$c python bench.py --lean 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('stage_ms_per_step'))")"; done; } > $O/batch_paths_ab.txt 2>&1; cat $O/batch_paths_ab.txt
+# per-frame latency on the three input classes (ms one image, two images, stereo frame, keypoints), with and without the path form
+{ echo "default build:"; python tools/per_frame_classes.py 2>/dev/null | tail -4; echo "MSORB_QT_PATHS=0:"; MSORB_QT_PATHS=0 python tools/per_frame_classes.py 2>/dev/null | tail -4; } > $O/per_frame_classes.txt 2>&1; cat $O/per_frame_classes.txt
