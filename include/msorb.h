@@ -137,7 +137,7 @@ int msorb_extractor_set_host_pyramid(msorb_extractor* h, int enable);
 
 /* TWO images of the same size through ONE kernel chain (the batch pipeline with two images) — what the two extractor threads of
  * Frame::Frame (Frame.cc:122-125) compute with two concurrent operator() calls, for callers that can hand both images over at
- * once WITHOUT the stereo match (msorb_extract_stereo is the call that also matches).  0.158 ms per pair against 2 x 0.13 for
+ * once WITHOUT the stereo match (msorb_extract_stereo is the call that also matches).  0.159 ms per pair against 2 x 0.13 for
  * two calls.  (A rendezvous of the two eye threads inside the drop-in class onto this call was measured and retired:
  * tools/experiments/README.md.)  Both images share the lapping area [lap0, lap1] (rectified stereo: 0, 0).  Results identical to two
  * msorb_extract calls on two handles.  With msorb_extractor_set_host_pyramid the levels 1.. of BOTH pyramids come back to pinned
