@@ -262,17 +262,20 @@ struct DevExT {
     }
     int dbg = 0;
     int nt = 0;  // threads of this instance: blockDim.x, or fewer for the small levels of a mixed launch (the other waves have left)
-#ifdef MSORB_QT_MARKS  // per-phase timestamps of instance (0,0) (build with -DMSORB_QT_MARKS, run with MSORB_QT_DEBUG=3):
+#ifndef MSORB_QT_MARK_Y
+#define MSORB_QT_MARK_Y 0   // the level whose instance is timed (marks build only)
+#endif
+#ifdef MSORB_QT_MARKS  // per-phase timestamps of instance (0, MSORB_QT_MARK_Y) (build with -DMSORB_QT_MARKS, run with MSORB_QT_DEBUG=3):
     int n_marks = 0;   // compiled out by default, the arrays would cost every wave 600 bytes of scratch
     long long t_mark[96];
     int id_mark[96];
     __device__ void mark(int id) {
-        if (dbg == 3 && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && n_marks < 96) {
+        if (dbg == 3 && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == MSORB_QT_MARK_Y && n_marks < 96) {
             t_mark[n_marks] = wall_clock64(); id_mark[n_marks] = id; n_marks++;
         }
     }
     __device__ void dump() {
-        if (dbg == 3 && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0)
+        if (dbg == 3 && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == MSORB_QT_MARK_Y)
             for (int i = 1; i < n_marks; i++) printf("mark %d dt_us=%.2f\n", id_mark[i], (double)(t_mark[i] - t_mark[i - 1]) * 0.01);
     }
 #else

@@ -19,7 +19,7 @@ sys.path[:0] = ["ms-slam_amd"]
 import msorb
 from msorb import synth
 cfg = synth.KITTI
-L, R = synth.stereo_pair(0, cfg["rows"], cfg["cols"])
+L, R = synth.stereo_pair(0, cfg["rows"], cfg["cols"], texture=os.environ.get("QT_TEXTURE", "default"))
 ex = msorb.ORBextractor(2000, 1.2, 8, 20, 7)
 for i in range(3):
     print("--- frame", i, flush=True)
