@@ -283,81 +283,53 @@ struct GeoSmall {
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(a, min(b, c)); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(a, max(b, c)); }
-// The arc network below is 32 x min3 + 8 x max3.  Written with min()/max() the compiler re-associates it into ~48 two-input
-// v_min_i32 + 12 max (all issue at the same slow-class VALU rate as the three-input forms), so the three-input
-// instructions are spelled out.
-__device__ __forceinline__ int vmin3(int a, int b, int c) { int r; asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ int vmax3(int a, int b, int c) { int r; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
-// max over the 16 arcs of 9 contiguous circle pixels of min(sgn * (v - p)); p = LDS pointer to the centre
-template <class GEO>
-__device__ __forceinline__ int fast_arc_contrast(const uint8_t* p, int sgn) {
-    // circle offsets (x,y): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
-    const int sv = sgn * (int)p[0], ns = -sgn;
-    int d[16];
-    d[0] = (int)p[3 * GEO::kTilePitch] * ns + sv;
-    d[1] = (int)p[3 * GEO::kTilePitch + 1] * ns + sv;
-    d[2] = (int)p[2 * GEO::kTilePitch + 2] * ns + sv;
-    d[3] = (int)p[1 * GEO::kTilePitch + 3] * ns + sv;
-    d[4] = (int)p[3] * ns + sv;
-    d[5] = (int)p[-1 * GEO::kTilePitch + 3] * ns + sv;
-    d[6] = (int)p[-2 * GEO::kTilePitch + 2] * ns + sv;
-    d[7] = (int)p[-3 * GEO::kTilePitch + 1] * ns + sv;
-    d[8] = (int)p[-3 * GEO::kTilePitch] * ns + sv;
-    d[9] = (int)p[-3 * GEO::kTilePitch - 1] * ns + sv;
-    d[10] = (int)p[-2 * GEO::kTilePitch - 2] * ns + sv;
-    d[11] = (int)p[-1 * GEO::kTilePitch - 3] * ns + sv;
-    d[12] = (int)p[-3] * ns + sv;
-    d[13] = (int)p[1 * GEO::kTilePitch - 3] * ns + sv;
-    d[14] = (int)p[2 * GEO::kTilePitch - 2] * ns + sv;
-    d[15] = (int)p[3 * GEO::kTilePitch - 1] * ns + sv;
-    int mn3[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) mn3[i] = vmin3(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
-    int A = -512;
-#pragma unroll
-    for (int i = 0; i < 16; i += 2) {  // arcs i..i+8 and i+1..i+9
-        const int a0 = vmin3(mn3[i], mn3[(i + 3) & 15], mn3[(i + 6) & 15]);
-        const int a1 = vmin3(mn3[(i + 1) & 15], mn3[(i + 4) & 15], mn3[(i + 7) & 15]);
-        A = vmax3(A, a0, a1);
-    }
-    return A;
+// FAST corner score: max over the 16 arcs of 9 contiguous circle pixels of min(sgn * (v - p)); p = LDS pointer to the centre.
+// circle offsets (x,y): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
+// (Rounds 1-4 ran the network on 32-bit lanes: 16 v_mad + 32 v_min3_i32 + 8 v_max3_i32; `git show f40730a` has it.)
+// Packed form (round 5): the sixteen signed contrasts live two to a register as 16-bit halves,
+// D[k] = (d[k], d[k + 8]), so "eight positions further round the circle" is the other half of the same register and costs
+// nothing (VOP3P op_sel picks the halves of an operand: D[k + 8] is D[k] read swapped).  OpenCV's own decomposition
+// (`cornerScore<16>`: arcs i and i + 1 share d[i+1 .. i+8], max(min(c, a), min(c, b)) = min(c, max(a, b))) on packed pairs:
+//   m2[j] = min(d[j], d[j+1]), m4[j] = min(m2[j], m2[j+2]) (j odd), c8[i] = min(m4[i+1], m4[i+5]),
+//   e[i] = max(d[i], d[i+9]), pair[i] = min(c8[i], e[i]) (i even), A = max over pair[]
+// = 5 x 4 packed instructions + 4 for the maximum, after 8 v_lshl_or (pack) + 8 v_pk_mad_i16 (sign and centre): 40
+// VALU instructions per work entry against 16 v_mad + 32 v_min3 + 8 v_max3 = 56.  |d| <= 255: nothing saturates.
+#define MSORB_PK2(NAME, OPC)                                                                                                   \
+    __device__ __forceinline__ uint32_t NAME(uint32_t a, uint32_t b) {                                                         \
+        uint32_t r; asm(OPC " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }                                             \
+    __device__ __forceinline__ uint32_t NAME##_sw(uint32_t a, uint32_t b) { /* b's halves swapped */                           \
+        uint32_t r; asm(OPC " %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+MSORB_PK2(pk_min16, "v_pk_min_i16")
+MSORB_PK2(pk_max16, "v_pk_max_i16")
+#undef MSORB_PK2
+__device__ __forceinline__ uint32_t pk_mad16(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r; asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
 }
 
-// the same with a window pointer w = centre - 3 * pitch - 3: every ds_read offset is non-negative, which matters when the tile
-// lives in dynamic LDS (runtime base: negative offsets cannot be folded into the instruction's unsigned offset field)
 template <class GEO>
-__device__ __forceinline__ int fast_arc_contrast_win(const uint8_t* w, int sgn) {
+__device__ __forceinline__ int fast_arc_contrast_pk(const uint8_t* p, int sgn) {
     constexpr int P = GEO::kTilePitch;
-    const int sv = sgn * (int)w[3 * P + 3], ns = -sgn;
-    int d[16];
-    d[0] = (int)w[6 * P + 3] * ns + sv;
-    d[1] = (int)w[6 * P + 4] * ns + sv;
-    d[2] = (int)w[5 * P + 5] * ns + sv;
-    d[3] = (int)w[4 * P + 6] * ns + sv;
-    d[4] = (int)w[3 * P + 6] * ns + sv;
-    d[5] = (int)w[2 * P + 6] * ns + sv;
-    d[6] = (int)w[1 * P + 5] * ns + sv;
-    d[7] = (int)w[0 * P + 4] * ns + sv;
-    d[8] = (int)w[0 * P + 3] * ns + sv;
-    d[9] = (int)w[0 * P + 2] * ns + sv;
-    d[10] = (int)w[1 * P + 1] * ns + sv;
-    d[11] = (int)w[2 * P + 0] * ns + sv;
-    d[12] = (int)w[3 * P + 0] * ns + sv;
-    d[13] = (int)w[4 * P + 0] * ns + sv;
-    d[14] = (int)w[5 * P + 1] * ns + sv;
-    d[15] = (int)w[6 * P + 2] * ns + sv;
-    int mn3[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) mn3[i] = vmin3(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
-    int A = -512;
-#pragma unroll
-    for (int i = 0; i < 16; i += 2) {
-        const int a0 = vmin3(mn3[i], mn3[(i + 3) & 15], mn3[(i + 6) & 15]);
-        const int a1 = vmin3(mn3[(i + 1) & 15], mn3[(i + 4) & 15], mn3[(i + 7) & 15]);
-        A = vmax3(A, a0, a1);
-    }
-    return A;
+    const uint32_t sv = ((uint32_t)(sgn * (int)p[0]) & 0xffffu) * 0x10001u, ns = ((uint32_t)(-sgn) & 0xffffu) * 0x10001u;
+    uint32_t D[8];
+    D[0] = pk_mad16(((uint32_t)p[-3 * P] << 16) | p[3 * P], ns, sv);            // (0,3)   | (0,-3)
+    D[1] = pk_mad16(((uint32_t)p[-3 * P - 1] << 16) | p[3 * P + 1], ns, sv);    // (1,3)   | (-1,-3)
+    D[2] = pk_mad16(((uint32_t)p[-2 * P - 2] << 16) | p[2 * P + 2], ns, sv);    // (2,2)   | (-2,-2)
+    D[3] = pk_mad16(((uint32_t)p[-1 * P - 3] << 16) | p[1 * P + 3], ns, sv);    // (3,1)   | (-3,-1)
+    D[4] = pk_mad16(((uint32_t)p[-3] << 16) | p[3], ns, sv);                    // (3,0)   | (-3,0)
+    D[5] = pk_mad16(((uint32_t)p[1 * P - 3] << 16) | p[-1 * P + 3], ns, sv);    // (3,-1)  | (-3,1)
+    D[6] = pk_mad16(((uint32_t)p[2 * P - 2] << 16) | p[-2 * P + 2], ns, sv);    // (2,-2)  | (-2,2)
+    D[7] = pk_mad16(((uint32_t)p[3 * P - 1] << 16) | p[-3 * P + 1], ns, sv);    // (1,-3)  | (-1,3)
+    const uint32_t m2_1 = pk_min16(D[1], D[2]), m2_3 = pk_min16(D[3], D[4]), m2_5 = pk_min16(D[5], D[6]),
+                   m2_7 = pk_min16_sw(D[7], D[0]);
+    const uint32_t m4_1 = pk_min16(m2_1, m2_3), m4_3 = pk_min16(m2_3, m2_5), m4_5 = pk_min16(m2_5, m2_7),
+                   m4_7 = pk_min16_sw(m2_7, m2_1);
+    const uint32_t c8_0 = pk_min16(m4_1, m4_5), c8_2 = pk_min16(m4_3, m4_7), c8_4 = pk_min16_sw(m4_5, m4_1),
+                   c8_6 = pk_min16_sw(m4_7, m4_3);
+    const uint32_t e0 = pk_max16_sw(D[0], D[1]), e2 = pk_max16_sw(D[2], D[3]), e4 = pk_max16_sw(D[4], D[5]),
+                   e6 = pk_max16_sw(D[6], D[7]);
+    const uint32_t a = pk_max16(pk_max16(pk_min16(c8_0, e0), pk_min16(c8_2, e2)), pk_max16(pk_min16(c8_4, e4), pk_min16(c8_6, e6)));
+    return (int)(short)(pk_max16_sw(a, a) & 0xffffu);
 }
 
 // inclusive prefix sum over the wave with DPP adds only (no LDS crossbar round trips): shifts inside each row of 16
@@ -595,7 +567,7 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
                     const int id = work[i];
                     const int e = tbase[(id >> 5) & (T - 1)] + lut[id & 31] + ((id >> (5 + (T == 128 ? 7 : 8))) << 9);
                     const int ty = (e >> 7) & 127, tx = e & 127;
-                    const int A = fast_arc_contrast<GEO>(&tile[(int)__umul24((uint32_t)ty, P) + tx], (e & 0x8000) ? -1 : 1);
+                    const int A = fast_arc_contrast_pk<GEO>(&tile[(int)__umul24((uint32_t)ty, P) + tx], (e & 0x8000) ? -1 : 1);
                     if (A > th) {
                         score[(int)__umul24((uint32_t)(ty - 2), SP) + tx + sc_off] = (uint8_t)(A - 1);  // score row = y + 1
                         ce = e & 0x3FFF;
@@ -615,7 +587,7 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
                 for (uint32_t w = half ? wB : wA; w; w &= w - 1) {
                     const int e = lut[__builtin_ctz(w)] + (half ? baseB : baseA);
                     const int ty = (e >> 7) & 127, tx = e & 127;
-                    const int A = fast_arc_contrast<GEO>(&tile[(int)__umul24((uint32_t)ty, P) + tx], (e & 0x8000) ? -1 : 1);
+                    const int A = fast_arc_contrast_pk<GEO>(&tile[(int)__umul24((uint32_t)ty, P) + tx], (e & 0x8000) ? -1 : 1);
                     if (A > th) score[(int)__umul24((uint32_t)(ty - 2), SP) + tx + sc_off] = (uint8_t)(A - 1);
                 }
         }
