@@ -217,7 +217,8 @@ __device__ __forceinline__ void pyr_band_tile_reg(const LevelView& src, const Le
 template <int R, int kSrc, int WAVES = 2>
 __global__ __launch_bounds__(64 * WAVES) void pyr_resize_bandreg_kernel(LevelView src, LevelView dst, uint8_t* __restrict__ dst_base,
                                                                         const ResizeTap* __restrict__ tx,
-                                                                        const ResizeTap* __restrict__ ty) {
+                                                                        const ResizeTap* __restrict__ ty, uint32_t per_img_magic,
+                                                                        uint32_t gx_magic) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (private L2 each); give every XCD whole images, so that
     // the source rows two neighbouring bands share and the 12-byte windows neighbouring lanes re-request are fetched into one
@@ -227,9 +228,10 @@ __global__ __launch_bounds__(64 * WAVES) void pyr_resize_bandreg_kernel(LevelVie
         const unsigned per_img = gridDim.x * gridDim.y;
         const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         const unsigned xcd = lin & 7u, j = lin >> 3;
-        const unsigned q = j / per_img, rem = j - q * per_img;
+        // (host-checked exact reciprocals, exact_div_magic: two divisions per wave were 4 % of this kernel's instructions)
+        const unsigned q = per_img_magic ? __umulhi(j, per_img_magic) : j / per_img, rem = j - q * per_img;
         img = q * 8u + xcd;
-        by = rem / gridDim.x;
+        by = gx_magic ? __umulhi(rem, gx_magic) : rem / gridDim.x;
         bx = rem - by * gridDim.x;
     }
     const int dy0 = __builtin_amdgcn_readfirstlane((int)(by * WAVES + wave) * R);
@@ -821,6 +823,8 @@ struct BlurPlan {
     int block_begin[kMaxLevels + 1];  // first blockIdx.x of each level
     int bx_count[kMaxLevels];         // blocks per strip-row of the level
     int nlevels;
+    uint32_t bx_magic[kMaxLevels];    // exact_div_magic(bx_count[l], blocks of the level), 0 = divide
+    uint32_t image_magic;             // exact_div_magic(blocks per image, blocks of the launch)
 };
 
 __device__ __forceinline__ int refl101(int p, int len) { return p < 0 ? -p : (p >= len ? 2 * (len - 1) - p : p); }
@@ -1029,11 +1033,12 @@ __global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, Pyr
     const int tile = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
     if (tile >= total_blocks) return;
     const int blocks_per_image = plan.block_begin[plan.nlevels];
-    const int img = tile / blocks_per_image, blk = tile - img * blocks_per_image;
+    const int img = plan.image_magic ? (int)__umulhi((uint32_t)tile, plan.image_magic) : tile / blocks_per_image, blk = tile - img * blocks_per_image;
     int level = 0;
     while (level + 1 < plan.nlevels && blk >= plan.block_begin[level + 1]) level++;
     const int rem = blk - plan.block_begin[level];
-    const int bx = rem % plan.bx_count[level], by = rem / plan.bx_count[level];
+    const int by = plan.bx_magic[level] ? (int)__umulhi((uint32_t)rem, plan.bx_magic[level]) : rem / plan.bx_count[level];
+    const int bx = rem - by * plan.bx_count[level];
     const LevelView sv = src.lv[level], dv = dst.lv[level];
     const int lane = threadIdx.x & 63;
     const int x0 = (bx * kGaussLanesOut + lane - 1) * 4;
@@ -1177,6 +1182,7 @@ __device__ __forceinline__ int rint_small(float x) { return __float_as_int(__fad
 
 constexpr int kBlkSlot = 1600;  // one keypoint's blurred neighbourhood in LDS: 10 x 10 blocks of 16 bytes, block (a, b) at (10 a + b) * 16
 typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from any 4-byte boundary
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kKpPerWave = 4;   // keypoints handled back to back by one wave (amortises the per-lane table loads)
 #ifndef MSORB_DESC_RAW_DEPTH
 #define MSORB_DESC_RAW_DEPTH 4  // keypoints whose IC-angle patch loads are in flight beyond the one being consumed (4 = all of the wave's, measured best: 0.2777 (r4 kernel) / 0.273 / 0.270 / 0.264 / 0.265 ms for r4 / 1 / 2 / 3 / 4)
@@ -1195,10 +1201,20 @@ __device__ __forceinline__ void glds16(const uint8_t* sbase, uint32_t voff, uint
 }
 __device__ __forceinline__ void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// v_pk_add_f32 with the second operand's low half broadcast from a scalar pair, and v_mad_u32_u24 with a scalar multiplier
+// (the compiler splits the one into two v_add_f32 and the other into v_mul_u32_u24 + v_add3_u32 when left to itself)
+constexpr unsigned long long kRoundMagic = 0x4B4000004B400000ull;   // 12582912.0f twice: 1.5 * 2^23
+__device__ __forceinline__ f32x2 pk_add_bcast(f32x2 v, unsigned long long s) {
+    f32x2 r; asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(v), "s"(s)); return r;
+}
+__device__ __forceinline__ uint32_t mad24s(uint32_t a, uint32_t s, uint32_t c) {
+    uint32_t r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(s), "v"(c)); return r;
+}
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void describe_kernel(PyramidView pyr, PyramidView blur, const SelRec* __restrict__ sel,
                                                        const int* __restrict__ sel_count, int sel_stride,
                                                        LevelScale scales, msorb_keypoint* __restrict__ kps,
-                                                       uint8_t* __restrict__ desc, int out_stride, int atan2_fma) {
+                                                       uint8_t* __restrict__ desc, int out_stride, int atan2_fma, uint32_t gx_magic) {
     __shared__ __attribute__((aligned(16))) uint8_t patch[4 * kKpPerWave][kBlkSlot];  // one slot per (wave, keypoint)
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs; give every image to ONE XCD so that the
     // overlapping keypoint patches of an image are served by a single L2 instead of being fetched by all eight.
@@ -1206,8 +1222,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     if ((gridDim.y & 7u) == 0) {
         const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
         const unsigned xcd = lin & 7u, j = lin >> 3;
-        img = (int)((j / gridDim.x) * 8 + xcd);
-        bx = (int)(j % gridDim.x);
+        const unsigned q = gx_magic ? __umulhi(j, gx_magic) : j / gridDim.x;   // host-checked exact reciprocal (a division costs 25 VALU instructions per wave)
+        img = (int)(q * 8 + xcd);
+        bx = (int)(j - q * gridDim.x);
     }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1262,12 +1279,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         bbcol16[t] = (uint32_t)(slot % 10) * 16u;
     }
     // the 4 pattern pairs of this lane as floats (lane constants: decoded once per wave, not once per keypoint)
-    float patx0[4], paty0[4], patx1[4], paty1[4];
+    // (kept as (tap 0, tap 1) pairs: the two taps of a test go through the rotation as packed fp32, v_pk_mul / v_pk_fma / v_pk_add)
+    f32x2 patx[4], paty[4];
 #pragma unroll
     for (int w = 0; w < 4; w++) {
         const uint32_t pw = *reinterpret_cast<const uint32_t*>(&c_tab.pattern[(w * 64 + lane) * 4]);
-        patx0[w] = (float)(int8_t)(pw & 255u); paty0[w] = (float)(int8_t)((pw >> 8) & 255u);
-        patx1[w] = (float)(int8_t)((pw >> 16) & 255u); paty1[w] = (float)(int8_t)(pw >> 24);
+        patx[w] = f32x2{(float)(int8_t)(pw & 255u), (float)(int8_t)((pw >> 16) & 255u)};
+        paty[w] = f32x2{(float)(int8_t)((pw >> 8) & 255u), (float)(int8_t)(pw >> 24)};
     }
     const float factor_pi = (float)(3.1415926535897932384626433832795 / 180.0);
 
@@ -1377,23 +1395,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         const float angle = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angle_v), kk));
         const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_v), kk));
         const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_v), kk));
-        const uint8_t* bc = lp0 + kk * kBlkSlot;
-        // cvRound(v) + offset in one subtract: the magic-number rounding leaves the integer in the low mantissa bits
-        const int r_bias = 0x4B400000 - (RQ[kk] >> 8), q_bias = 0x4B400000 - (RQ[kk] & 255);
-        auto tap = [&](float x, float y) -> int {
-            // rr = cvRound(x*b + y*a) + 18 + oy, qq = cvRound(x*a - y*b) + 18 + poff (contraction order of oracle/orb_extractor_oracle.cc),
-            // then the block-indexed address: 160 (rr >> 2) + 4 (rr & 3) + 16 (qq >> 2) + (qq & 3) = 4 rr + 144 (rr >> 2) + qq + 12 (qq >> 2)
-            const uint32_t rr = (uint32_t)(__float_as_int(__fadd_rn(__fmaf_rn(x, b, __fmul_rn(y, a)), 12582912.0f)) - r_bias);
-            const uint32_t qq = (uint32_t)(__float_as_int(__fadd_rn(__fmaf_rn(x, a, -__fmul_rn(y, b)), 12582912.0f)) - q_bias);
-            const uint32_t off = __umul24(rr >> 2, 144u) + __umul24(qq >> 2, 12u) + (rr << 2) + qq;
-            return bc[off];
-        };
+        // rr = cvRound(x*b + y*a) + 18 + oy, qq = cvRound(x*a - y*b) + 18 + poff (contraction order of oracle/orb_extractor_oracle.cc:
+        // fma(x, b, y*a) and fma(x, a, -(y*b)); y * (-b) is -(y*b) bit for bit), both taps of a test at once as packed fp32.
+        // cvRound + offset in one subtract: the magic-number rounding leaves the integer in the low mantissa bits.  Then the
+        // block-indexed address 160 (rr >> 2) + 4 (rr & 3) + 16 (qq >> 2) + (qq & 3) = 4 rr + 144 (rr >> 2) + qq + 12 (qq >> 2) as
+        // two v_mad_u32_u24 and a v_lshl_add.  The wave's slot base rides in qq: the slots of wave w start 6400 w bytes into
+        // `patch`, and qq + 1600 w contributes 12 (400 w) + 1600 w = 6400 w to the sum (1600 w is a multiple of 4: the shift
+        // takes it whole), so the address is relative to the array and keypoint kk's slot is an immediate offset.
+        const uint8_t* bc = &patch[0][0] + kk * kBlkSlot;
+        const int r_bias = 0x4B400000 - (RQ[kk] >> 8), q_bias = 0x4B400000 - (RQ[kk] & 255) - wave * (kKpPerWave * kBlkSlot / 4);
+        const f32x2 a2 = {a, a}, b2 = {b, b}, nb2 = {-b, -b};
         unsigned long long word[4];
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-            const int t0 = tap(patx0[w], paty0[w]);
-            const int t1 = tap(patx1[w], paty1[w]);
-            word[w] = __ballot(t0 < t1);
+            const f32x2 rf = pk_add_bcast(__builtin_elementwise_fma(patx[w], b2, paty[w] * a2), kRoundMagic);
+            const f32x2 qf = pk_add_bcast(__builtin_elementwise_fma(patx[w], a2, paty[w] * nb2), kRoundMagic);
+            int tv[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const uint32_t rr = (uint32_t)(__float_as_int(rf[j]) - r_bias), qq = (uint32_t)(__float_as_int(qf[j]) - q_bias);
+                const uint32_t off = (rr << 2) + mad24s(rr >> 2, 144u, mad24s(qq >> 2, 12u, qq));
+                tv[j] = bc[off];
+            }
+            word[w] = __ballot(tv[0] < tv[1]);
         }
         if (k_first + kk >= n_sel) break;  // wave-uniform; nothing but the stores is left
         if (lane < 4) {
@@ -1462,6 +1486,13 @@ void launch_stage_level0(const LevelView& src, uint8_t* dst, int dst_pitch, size
     hipLaunchKernelGGL(stage_level0_kernel, dim3((src.w + 1023) / 1024, src.h, n_images), dim3(256), 0, s, src.base, (size_t)src.pitch,
                        src.img_stride, dst, dst_pitch, dst_image_stride, src.w);
 }
+// magic with mulhi(n, magic) == n / d for every n < total, or 0 when there is none of this form (the kernel divides instead)
+static uint32_t exact_div_magic(unsigned d, unsigned long long total) {
+    if (d < 2 || total >= 0x100000000ull) return 0;
+    const uint32_t magic = (uint32_t)((0x100000000ull + d - 1) / d);
+    const unsigned long long e = (unsigned long long)magic * d - 0x100000000ull;  // < d
+    return e * total >= 0x100000000ull ? 0 : magic;
+}
 void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_base, const ResizeTap* tx,
                        const ResizeTap* ty, int n_images, hipStream_t s, int single_stage) {
     dim3 grid((dst.w + 255) / 256, (dst.h + 3) / 4, n_images);
@@ -1479,9 +1510,12 @@ void launch_pyr_resize(const LevelView& src, const LevelView& dst, uint8_t* dst_
     // launch latency, not throughput: the one-row kernel has the shorter dependent chain)
     const double sy = (double)src.h / (double)dst.h, sx = (double)src.w / (double)dst.w;
     const bool band_ok = aligned && n_images >= 16 && (int)std::floor((R - 1) * sy) + 3 <= 12 && sx <= 1.25;
-    if (band_ok)   // two waves per workgroup: small workgroups find room sooner beside the other batch's kernels
-        hipLaunchKernelGGL((pyr_resize_bandreg_kernel<R, 12, 2>), dim3((dst.w + 255) / 256, (dst.h + 2 * R - 1) / (2 * R), n_images), dim3(128), 0,
-                           s, src, dst, dst_base, tx, ty);
+    if (band_ok) {   // two waves per workgroup: small workgroups find room sooner beside the other batch's kernels
+        const unsigned gx = (unsigned)(dst.w + 255) / 256, gy = (unsigned)(dst.h + 2 * R - 1) / (2 * R);
+        const unsigned long long total = (unsigned long long)gx * gy * (unsigned)n_images;
+        hipLaunchKernelGGL((pyr_resize_bandreg_kernel<R, 12, 2>), dim3(gx, gy, n_images), dim3(128), 0,
+                           s, src, dst, dst_base, tx, ty, exact_div_magic(gx * gy, total), exact_div_magic(gx, (unsigned long long)gx * gy));
+    }
     else if (aligned) hipLaunchKernelGGL(pyr_resize_aligned_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty);
     else hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), 0, s, src, dst, dst_base, tx, ty, 0);
 }
@@ -1707,13 +1741,7 @@ void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cell
         aligned = aligned && (reinterpret_cast<uintptr_t>(v.base) & 3) == 0 && (v.pitch & 3) == 0 && (v.img_stride & 3) == 0;
     }
     const dim3 grid(n_cells, n_images);
-    // q = mulhi(n, gx_magic) == n / n_cells for every n < n_cells * n_images (checked here, once per shape)
-    uint32_t gx_magic = (uint32_t)((0x100000000ull + (unsigned)n_cells - 1) / (unsigned)n_cells);
-    {
-        const unsigned long long total = (unsigned long long)n_cells * (unsigned)n_images;
-        const unsigned long long e = (unsigned long long)gx_magic * (unsigned)n_cells - 0x100000000ull;  // < n_cells
-        if (n_cells < 2 || total >= 0x100000000ull || e * total >= 0x100000000ull) gx_magic = 0;  // kernel divides instead
-    }
+    const uint32_t gx_magic = exact_div_magic((unsigned)n_cells, (unsigned long long)n_cells * (unsigned)n_images);
 #define MSORB_FAST_LAUNCH(AL, GEO)                                                                                        \
     hipLaunchKernelGGL((fast_cells_kernel<AL, GEO>), grid, dim3(GEO::kThreads), 0, s, pyr, cells, ini_th, min_th, slots_per_image, slots, \
                        cell_count, n_cells, gx_magic)
@@ -1761,6 +1789,10 @@ int launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images, 
         max_h = max(max_h, v.h);
     }
     plan.block_begin[src.nlevels] = total;
+    for (int l = 0; l < src.nlevels; l++)
+        plan.bx_magic[l] = exact_div_magic((unsigned)plan.bx_count[l], (unsigned long long)(plan.block_begin[l + 1] - plan.block_begin[l]));
+    for (int l = src.nlevels; l < kMaxLevels; l++) plan.bx_magic[l] = 0;
+    plan.image_magic = exact_div_magic((unsigned)total, (unsigned long long)total * (unsigned)n_images + 8);
     if (stream) {
         const int all = total * n_images, per_xcd = (all + 7) / 8;
         hipLaunchKernelGGL(gauss7_stream_kernel<kGaussRows>, dim3(per_xcd * 8), dim3(256), 0, s, src, dst, plan, per_xcd, all);
@@ -1775,8 +1807,9 @@ void launch_describe(const PyramidView& pyr, const PyramidView& blur, const SelR
                      int sel_stride, const LevelScale& scales, msorb_keypoint* kps, uint8_t* desc, int out_stride,
                      int max_sel, int n_images, hipStream_t s, const Semantics& sem) {
     if (max_sel <= 0) return;
-    hipLaunchKernelGGL(describe_kernel, dim3((max_sel + 4 * kKpPerWave - 1) / (4 * kKpPerWave), n_images), dim3(256), 0, s, pyr, blur, sel, sel_count,
-                       sel_stride, scales, kps, desc, out_stride, sem.atan2_fma);
+    const unsigned gx = (unsigned)((max_sel + 4 * kKpPerWave - 1) / (4 * kKpPerWave));
+    hipLaunchKernelGGL(describe_kernel, dim3(gx, n_images), dim3(256), 0, s, pyr, blur, sel, sel_count,
+                       sel_stride, scales, kps, desc, out_stride, sem.atan2_fma, exact_div_magic(gx, (unsigned long long)gx * (unsigned)n_images));
 }
 
 }  // namespace msorb
