@@ -515,6 +515,103 @@ __global__ __launch_bounds__(256) void quadtree_layout_kernel(QtLevels lv, const
     }
 }
 
+// Batches without a lapping area: the same records, but stored in the order the DESCRIPTOR stage should work through them —
+// level-major as before, inside a level by tiles of 64 x 32 pixels, rows of tiles in serpentine order.  Output rows do not
+// move (`dst` is the selection order, as in the plain form): only which keypoints the four waves of a descriptor workgroup,
+// and the workgroups that share a CU, hold at the same time.  Keypoints in quadtree order are scattered over the level; in
+// tile order their IC-angle patches and blurred neighbourhoods share cache lines, and describe_kernel — bound by the lines
+// it pulls from L2 — is 8-9 % shorter (tools/experiments/README.md has the tile shapes that were measured).
+// A counting sort in LDS: a pass that builds the records and takes a rank inside the record's tile (LDS atomic: the order
+// inside a tile is whatever the atomics make it, and irrelevant), a scan over the tiles, a pass that stores.
+struct TileOrder {
+    int bin_begin[kMaxLevels + 1];   // first bin of each level; bins of a level = its tiles, row-major
+    int ntx[kMaxLevels];             // tiles per row of tiles
+    int cap;                         // records the LDS block holds (>= min(capacity, sel_stride))
+};
+__global__ __launch_bounds__(256) void quadtree_layout_sorted_kernel(QtLevels lv, const Cand16* __restrict__ compact,
+                                                                     const int* __restrict__ img_base, const int* __restrict__ level_count,
+                                                                     const int* __restrict__ sel_pt, const int* __restrict__ sel_n,
+                                                                     int sel_stride, int capacity, SelRec* __restrict__ sel,
+                                                                     int* __restrict__ sel_count, int* __restrict__ mono_out, TileOrder order) {
+    extern __shared__ uint32_t tile_lds[];   // [bins] counters, then starts | [cap] records (3 dwords) | [cap] ranks (16 bit)
+    __shared__ int lvl_begin[kMaxLevels + 1], cand_begin[kMaxLevels + 1], bin_begin[kMaxLevels + 1], ntx[kMaxLevels];
+    __shared__ int part[256];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int nb = order.bin_begin[lv.nlevels];
+    uint32_t* const cnt = tile_lds;
+    uint32_t* const rec = tile_lds + ((nb + 3) & ~3);
+    uint16_t* const rank = reinterpret_cast<uint16_t*>(rec + 3 * (size_t)order.cap);
+    if (tid == 0) {
+        int a = 0, c = img_base[img];
+        for (int l = 0; l < lv.nlevels; l++) {
+            lvl_begin[l] = a; cand_begin[l] = c;
+            a += sel_n[(size_t)img * lv.nlevels + l];
+            c += level_count[(size_t)img * lv.nlevels + l];
+        }
+        lvl_begin[lv.nlevels] = a;
+    }
+    if (tid <= lv.nlevels) bin_begin[tid] = order.bin_begin[tid];
+    if (tid < lv.nlevels) ntx[tid] = order.ntx[tid];
+    for (int i = tid; i < nb; i += 256) cnt[i] = 0;
+    __syncthreads();
+    const int n_all = lvl_begin[lv.nlevels];
+    const int n = min(n_all, min(capacity, sel_stride));
+    SelRec* out = sel + (size_t)img * sel_stride;
+    auto bin_of = [&](uint32_t x, uint32_t y, int l) -> int {
+        const int w = ntx[l], ty = (int)(y >> 5);
+        int tx = min((int)(x >> 6), w - 1);
+        if (ty & 1) tx = w - 1 - tx;
+        return min(bin_begin[l] + ty * w + tx, bin_begin[l + 1] - 1);
+    };
+    // pass 1 (items 256 apart, four at a time: the two dependent loads of an item are in flight for four items at once)
+    for (int base = 0; base < n; base += 4 * 256) {
+        int gg[4], ll[4], pt[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            gg[u] = base + u * 256 + tid;
+            int l = 0;
+            if (gg[u] < n) while (gg[u] >= lvl_begin[l + 1]) l++;
+            ll[u] = l;
+            pt[u] = gg[u] < n ? sel_pt[(size_t)img * sel_stride + lv.sel_off[l] + (gg[u] - lvl_begin[l])] : 0;
+        }
+        Cand16 cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) cc[u] = gg[u] < n ? compact[cand_begin[ll[u]] + pt[u]] : Cand16{};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (gg[u] >= n) continue;
+            const uint32_t x = (uint32_t)cc[u].x + kMinBorder, y = (uint32_t)cc[u].y + kMinBorder;
+            rec[3 * gg[u] + 0] = x | (y << 16);
+            rec[3 * gg[u] + 1] = (uint32_t)cc[u].score | ((uint32_t)ll[u] << 16);
+            rank[gg[u]] = (uint16_t)atomicAdd(&cnt[bin_of(x, y, ll[u])], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan over the tiles: a run of consecutive bins per thread
+    const int per = (nb + 255) / 256, b0 = min(tid * per, nb), b1 = min(b0 + per, nb);
+    int mine = 0;
+    for (int i = b0; i < b1; i++) mine += (int)cnt[i];
+    part[tid] = mine;
+    __syncthreads();
+    int run = 0;
+    for (int i = 0; i < tid; i++) run += part[i];
+    for (int i = b0; i < b1; i++) { const int c = (int)cnt[i]; cnt[i] = (uint32_t)run; run += c; }
+    __syncthreads();
+    // pass 2
+    for (int g = tid; g < n; g += 256) {
+        const uint32_t xy = rec[3 * g], sl = rec[3 * g + 1];
+        SelRec r;
+        r.x = (uint16_t)(xy & 0xffffu); r.y = (uint16_t)(xy >> 16);
+        r.score = (uint16_t)(sl & 0xffffu); r.level = (uint8_t)(sl >> 16); r.pad = 0;
+        r.dst = g;
+        out[(int)cnt[bin_of(r.x, r.y, r.level)] + (int)rank[g]] = r;
+    }
+    if (tid == 0) {
+        sel_count[img] = n_all > n ? -n_all : n;   // negative = capacity exceeded (host turns it into an error)
+        mono_out[img] = n;
+    }
+}
+
 // The layout of a frame or two without a lapping area: 1024 threads (two records each, both dependent load pairs in flight), the
 // per-level offsets from uniform loads in every thread (no LDS, no barrier) — the 256-thread form above spent 11 us of a stereo
 // frame here, most of it one thread's chain of sixteen dependent loads and four sequential rounds of two.
@@ -649,9 +746,30 @@ int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_ba
     if (n_images <= 4 && lap1 < kMinBorder)
         hipLaunchKernelGGL(quadtree_layout_frame_kernel, dim3(n_images), dim3(1024), 0, s, lv, compact, img_base, level_count, sel_pt, sel_n,
                            sel_stride, scales, capacity, sel, sel_count, mono, job);
-    else
-        hipLaunchKernelGGL(quadtree_layout_kernel, dim3(n_images), dim3(256), 0, s, lv, compact, img_base, level_count, sel_pt,
-                           sel_n, sel_stride, scales, lap0, lap1, capacity, sel, sel_count, mono, n_images, job);
+    else {
+        // batches without a lapping area: records in the descriptor stage's tile order (MSORB_DESC_ORDER=0: selection order)
+        static const bool tile_order_off = getenv("MSORB_DESC_ORDER") && atoi(getenv("MSORB_DESC_ORDER")) == 0;
+        TileOrder order{};
+        size_t order_lds = 0;
+        if (!tile_order_off && n_images > 4 && lap1 < kMinBorder && !job.band) {
+            int nb = 0;
+            for (int l = 0; l < lv.nlevels; l++) {
+                order.bin_begin[l] = nb;
+                order.ntx[l] = ((lv.W[l] + 2 * kMinBorder) >> 6) + 1;
+                nb += order.ntx[l] * (((lv.H[l] + 2 * kMinBorder) >> 5) + 1);
+            }
+            order.bin_begin[lv.nlevels] = nb;
+            order.cap = std::min(capacity, sel_stride);
+            order_lds = ((size_t)((nb + 3) & ~3) + 3 * (size_t)order.cap) * 4 + 2 * (size_t)order.cap + 8;
+            if (order.cap <= 0 || order.cap > 65535 || order_lds > 60 * 1024) order_lds = 0;   // (a geometry this form was not sized for: plain order)
+        }
+        if (order_lds)
+            hipLaunchKernelGGL(quadtree_layout_sorted_kernel, dim3(n_images), dim3(256), order_lds, s, lv, compact, img_base, level_count, sel_pt,
+                               sel_n, sel_stride, capacity, sel, sel_count, mono, order);
+        else
+            hipLaunchKernelGGL(quadtree_layout_kernel, dim3(n_images), dim3(256), 0, s, lv, compact, img_base, level_count, sel_pt,
+                               sel_n, sel_stride, scales, lap0, lap1, capacity, sel, sel_count, mono, n_images, job);
+    }
     return MSORB_OK;
 }
 size_t quadtree_lds_bytes(const QtLevels& lv) {

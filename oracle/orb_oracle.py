@@ -81,7 +81,8 @@ class OracleExtractor:
     def __call__(self, img, lapping=(0, 0)):
         """-> (mono_index, keypoints[KP_DTYPE], descriptors[n,32] u8)"""
         img = np.ascontiguousarray(img, np.uint8)
-        cap = self.nfeatures + 4 * self.nlevels + 64
+        # a level's tree can end above its quota by up to 3 nodes per initial column: the library's own bound is nfeatures + 19 per level
+        cap = self.nfeatures + 19 * self.nlevels + 64
         kps = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         n = C.c_int(0)
