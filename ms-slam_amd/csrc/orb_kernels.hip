@@ -1211,11 +1211,12 @@ __device__ __forceinline__ uint32_t mad24s(uint32_t a, uint32_t s, uint32_t c) {
     uint32_t r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(s), "v"(c)); return r;
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void describe_kernel(PyramidView pyr, PyramidView blur, const SelRec* __restrict__ sel,
+constexpr int kDescWaves = 4;   // waves per descriptor workgroup (2: 0.262 ms alone; 8: 0.239 alone but 1.088 instead of 1.057 ms per pipelined step — a 51 KB workgroup finds room later)
+__global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu(6, 6))) void describe_kernel(PyramidView pyr, PyramidView blur, const SelRec* __restrict__ sel,
                                                        const int* __restrict__ sel_count, int sel_stride,
                                                        LevelScale scales, msorb_keypoint* __restrict__ kps,
                                                        uint8_t* __restrict__ desc, int out_stride, int atan2_fma, uint32_t gx_magic) {
-    __shared__ __attribute__((aligned(16))) uint8_t patch[4 * kKpPerWave][kBlkSlot];  // one slot per (wave, keypoint)
+    __shared__ __attribute__((aligned(16))) uint8_t patch[kDescWaves * kKpPerWave][kBlkSlot];  // one slot per (wave, keypoint)
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs; give every image to ONE XCD so that the
     // overlapping keypoint patches of an image are served by a single L2 instead of being fetched by all eight.
     int img = blockIdx.y, bx = blockIdx.x;
@@ -1228,7 +1229,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int k_first = (bx * 4 + wave) * kKpPerWave;  // wave-uniform -> SALU
+    const int k_first = (bx * kDescWaves + wave) * kKpPerWave;  // wave-uniform -> SALU
     const int n_sel = sel_count[img];
     if (k_first >= n_sel) return;
     // IC-angle patch (raw level, registers): 16-byte loads, three lanes per patch row (lane = 3 row' + seg, 21 rows per load
@@ -1807,8 +1808,8 @@ void launch_describe(const PyramidView& pyr, const PyramidView& blur, const SelR
                      int sel_stride, const LevelScale& scales, msorb_keypoint* kps, uint8_t* desc, int out_stride,
                      int max_sel, int n_images, hipStream_t s, const Semantics& sem) {
     if (max_sel <= 0) return;
-    const unsigned gx = (unsigned)((max_sel + 4 * kKpPerWave - 1) / (4 * kKpPerWave));
-    hipLaunchKernelGGL(describe_kernel, dim3(gx, n_images), dim3(256), 0, s, pyr, blur, sel, sel_count,
+    const unsigned gx = (unsigned)((max_sel + kDescWaves * kKpPerWave - 1) / (kDescWaves * kKpPerWave));
+    hipLaunchKernelGGL(describe_kernel, dim3(gx, n_images), dim3(64 * kDescWaves), 0, s, pyr, blur, sel, sel_count,
                        sel_stride, scales, kps, desc, out_stride, sem.atan2_fma, exact_div_magic(gx, (unsigned long long)gx * (unsigned)n_images));
 }
 
