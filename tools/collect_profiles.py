@@ -84,7 +84,8 @@ for src, dst in (("bow_bench.json", "bow_bench.json"), ("valu_ubench.txt", "valu
                  ("track_trace.txt", "tracking_chain_kernel_trace.txt"), ("timeline_pipelined.txt", "timeline_pipelined.txt"),
                  ("frame_chain.json", "frame_chain.json"), ("frame_trace.txt", "frame_trace.txt"), ("qt_marks.txt", "quadtree_phase_marks.txt"),
                  ("describe_pmc.txt", "describe_pmc_raw.txt"), ("frame_copies_ab.txt", "frame_copies_ab.txt"),
-                 ("frame_paths_tower_ab.txt", "frame_paths_tower_ab.txt"), ("batch_paths_ab.txt", "batch_paths_ab.txt"), ("per_frame_classes.txt", "per_frame_classes.txt")):
+                 ("frame_paths_tower_ab.txt", "frame_paths_tower_ab.txt"), ("batch_paths_ab.txt", "batch_paths_ab.txt"), ("per_frame_classes.txt", "per_frame_classes.txt"),
+                 ("fast_pmc.txt", "fast_pmc.txt"), ("describe_order_ab.txt", "describe_order_ab.txt")):
     if os.path.exists(os.path.join(G, src)):
         shutil.copy(os.path.join(G, src), os.path.join(P, f"{rnd}_{dst}"))
 print("value", bench["value"], "ms/step", bench["ms_per_step"], bench["stage_ms_per_step"])

@@ -40,3 +40,7 @@ done > $O/describe_pmc.txt 2>&1; cat $O/describe_pmc.txt
 { for c in 4 0 5 4 0; do echo "MSORB_QT_BATCH_PATHS=$c $(MSORB_QT_BATCH_PATHS=$c python bench.py --lean 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('stage_ms_per_step'))")"; done; } > $O/batch_paths_ab.txt 2>&1; cat $O/batch_paths_ab.txt
 # per-frame latency on the three input classes (ms one image, two images, stereo frame, keypoints), with and without the path form
 { echo "default build:"; python tools/per_frame_classes.py 2>/dev/null | tail -4; echo "MSORB_QT_PATHS=0:"; MSORB_QT_PATHS=0 python tools/per_frame_classes.py 2>/dev/null | tail -4; } > $O/per_frame_classes.txt 2>&1; cat $O/per_frame_classes.txt
+# round 5 (late): fast_cells_kernel's LDS pipe beside its VALU (the arc phase is bound by both), the descriptor stage's processing order
+{ PMC_TIMEOUT=200 tools/pmc_run.sh round/fpmc_lds "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "fast_cells" -- python bench.py --steps 2 --warmup 1 --lean --isolated 2>&1 | tail -1
+  PMC_TIMEOUT=200 tools/pmc_run.sh round/fpmc_valu "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "fast_cells" -- python bench.py --steps 2 --warmup 1 --lean --isolated 2>&1 | tail -1; } > $O/fast_pmc.txt 2>&1; cat $O/fast_pmc.txt
+{ for i in 1 2 3; do for o in 1 0; do echo "MSORB_DESC_ORDER=$o $(MSORB_DESC_ORDER=$o python bench.py --lean --steps 60 --warmup 10 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('stage_ms_per_step'))")"; done; done; } > $O/describe_order_ab.txt 2>&1; cat $O/describe_order_ab.txt
