@@ -528,19 +528,21 @@ struct TileOrder {
     int ntx[kMaxLevels];             // tiles per row of tiles
     int cap;                         // records the LDS block holds (>= min(capacity, sel_stride))
 };
-__global__ __launch_bounds__(256) void quadtree_layout_sorted_kernel(QtLevels lv, const Cand16* __restrict__ compact,
+constexpr int kSortedLayoutThreads = 1024;   // every record's two dependent loads in flight at once (256 threads: 18 instead of 14 us per launch)
+__global__ __launch_bounds__(kSortedLayoutThreads) void quadtree_layout_sorted_kernel(QtLevels lv, const Cand16* __restrict__ compact,
                                                                      const int* __restrict__ img_base, const int* __restrict__ level_count,
                                                                      const int* __restrict__ sel_pt, const int* __restrict__ sel_n,
                                                                      int sel_stride, int capacity, SelRec* __restrict__ sel,
                                                                      int* __restrict__ sel_count, int* __restrict__ mono_out, TileOrder order) {
-    extern __shared__ uint32_t tile_lds[];   // [bins] counters, then starts | [cap] records (3 dwords) | [cap] ranks (16 bit)
+    extern __shared__ uint32_t tile_lds[];   // [bins] counters, then starts | [cap] records (2 dwords) | [cap] ranks (16 bit)
     __shared__ int lvl_begin[kMaxLevels + 1], cand_begin[kMaxLevels + 1], bin_begin[kMaxLevels + 1], ntx[kMaxLevels];
     __shared__ int part[256];
+    constexpr int T = kSortedLayoutThreads;
     const int img = blockIdx.x, tid = threadIdx.x;
     const int nb = order.bin_begin[lv.nlevels];
     uint32_t* const cnt = tile_lds;
     uint32_t* const rec = tile_lds + ((nb + 3) & ~3);
-    uint16_t* const rank = reinterpret_cast<uint16_t*>(rec + 3 * (size_t)order.cap);
+    uint16_t* const rank = reinterpret_cast<uint16_t*>(rec + 2 * (size_t)order.cap);
     if (tid == 0) {
         int a = 0, c = img_base[img];
         for (int l = 0; l < lv.nlevels; l++) {
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(256) void quadtree_layout_sorted_kernel(QtLevels lv
     }
     if (tid <= lv.nlevels) bin_begin[tid] = order.bin_begin[tid];
     if (tid < lv.nlevels) ntx[tid] = order.ntx[tid];
-    for (int i = tid; i < nb; i += 256) cnt[i] = 0;
+    for (int i = tid; i < nb; i += T) cnt[i] = 0;
     __syncthreads();
     const int n_all = lvl_begin[lv.nlevels];
     const int n = min(n_all, min(capacity, sel_stride));
@@ -563,43 +565,45 @@ __global__ __launch_bounds__(256) void quadtree_layout_sorted_kernel(QtLevels lv
         if (ty & 1) tx = w - 1 - tx;
         return min(bin_begin[l] + ty * w + tx, bin_begin[l + 1] - 1);
     };
-    // pass 1 (items 256 apart, four at a time: the two dependent loads of an item are in flight for four items at once)
-    for (int base = 0; base < n; base += 4 * 256) {
-        int gg[4], ll[4], pt[4];
+    // pass 1 (items T apart, two at a time: the two dependent loads of an item are in flight for all items at once)
+    for (int base = 0; base < n; base += 2 * T) {
+        int gg[2], ll[2], pt[2];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            gg[u] = base + u * 256 + tid;
+        for (int u = 0; u < 2; u++) {
+            gg[u] = base + u * T + tid;
             int l = 0;
             if (gg[u] < n) while (gg[u] >= lvl_begin[l + 1]) l++;
             ll[u] = l;
             pt[u] = gg[u] < n ? sel_pt[(size_t)img * sel_stride + lv.sel_off[l] + (gg[u] - lvl_begin[l])] : 0;
         }
-        Cand16 cc[4];
+        Cand16 cc[2];
 #pragma unroll
-        for (int u = 0; u < 4; u++) cc[u] = gg[u] < n ? compact[cand_begin[ll[u]] + pt[u]] : Cand16{};
+        for (int u = 0; u < 2; u++) cc[u] = gg[u] < n ? compact[cand_begin[ll[u]] + pt[u]] : Cand16{};
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < 2; u++) {
             if (gg[u] >= n) continue;
             const uint32_t x = (uint32_t)cc[u].x + kMinBorder, y = (uint32_t)cc[u].y + kMinBorder;
-            rec[3 * gg[u] + 0] = x | (y << 16);
-            rec[3 * gg[u] + 1] = (uint32_t)cc[u].score | ((uint32_t)ll[u] << 16);
+            rec[2 * gg[u] + 0] = x | (y << 16);
+            rec[2 * gg[u] + 1] = (uint32_t)cc[u].score | ((uint32_t)ll[u] << 16);
             rank[gg[u]] = (uint16_t)atomicAdd(&cnt[bin_of(x, y, ll[u])], 1u);
         }
     }
     __syncthreads();
-    // exclusive scan over the tiles: a run of consecutive bins per thread
-    const int per = (nb + 255) / 256, b0 = min(tid * per, nb), b1 = min(b0 + per, nb);
+    // exclusive scan over the tiles: a run of consecutive bins per thread of the first four waves
+    const int per = (nb + 255) / 256, b0 = min(tid * per, nb), b1 = tid < 256 ? min(b0 + per, nb) : b0;
     int mine = 0;
     for (int i = b0; i < b1; i++) mine += (int)cnt[i];
-    part[tid] = mine;
+    if (tid < 256) part[tid] = mine;
     __syncthreads();
-    int run = 0;
-    for (int i = 0; i < tid; i++) run += part[i];
-    for (int i = b0; i < b1; i++) { const int c = (int)cnt[i]; cnt[i] = (uint32_t)run; run += c; }
+    if (tid < 256) {
+        int run = 0;
+        for (int i = 0; i < tid; i++) run += part[i];
+        for (int i = b0; i < b1; i++) { const int c = (int)cnt[i]; cnt[i] = (uint32_t)run; run += c; }
+    }
     __syncthreads();
     // pass 2
-    for (int g = tid; g < n; g += 256) {
-        const uint32_t xy = rec[3 * g], sl = rec[3 * g + 1];
+    for (int g = tid; g < n; g += T) {
+        const uint32_t xy = rec[2 * g], sl = rec[2 * g + 1];
         SelRec r;
         r.x = (uint16_t)(xy & 0xffffu); r.y = (uint16_t)(xy >> 16);
         r.score = (uint16_t)(sl & 0xffffu); r.level = (uint8_t)(sl >> 16); r.pad = 0;
@@ -760,11 +764,11 @@ int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_ba
             }
             order.bin_begin[lv.nlevels] = nb;
             order.cap = std::min(capacity, sel_stride);
-            order_lds = ((size_t)((nb + 3) & ~3) + 3 * (size_t)order.cap) * 4 + 2 * (size_t)order.cap + 8;
+            order_lds = ((size_t)((nb + 3) & ~3) + 2 * (size_t)order.cap) * 4 + 2 * (size_t)order.cap + 8;
             if (order.cap <= 0 || order.cap > 65535 || order_lds > 60 * 1024) order_lds = 0;   // (a geometry this form was not sized for: plain order)
         }
         if (order_lds)
-            hipLaunchKernelGGL(quadtree_layout_sorted_kernel, dim3(n_images), dim3(256), order_lds, s, lv, compact, img_base, level_count, sel_pt,
+            hipLaunchKernelGGL(quadtree_layout_sorted_kernel, dim3(n_images), dim3(kSortedLayoutThreads), order_lds, s, lv, compact, img_base, level_count, sel_pt,
                                sel_n, sel_stride, capacity, sel, sel_count, mono, order);
         else
             hipLaunchKernelGGL(quadtree_layout_kernel, dim3(n_images), dim3(256), 0, s, lv, compact, img_base, level_count, sel_pt,
