@@ -528,7 +528,10 @@ struct TileOrder {
     int ntx[kMaxLevels];             // tiles per row of tiles
     int cap;                         // records the LDS block holds (>= min(capacity, sel_stride))
 };
-constexpr int kSortedLayoutThreads = 1024;   // every record's two dependent loads in flight at once (256 threads: 18 instead of 14 us per launch)
+// 256 threads: alone the launch takes 18 us where 1024 threads take 14.5 (every record's two dependent loads in flight at once),
+// but a 16-wave workgroup has to wait for a CU with sixteen free wave slots beside the other batch's kernels: the pipelined step
+// reads 1.048 ms with 256 threads, 1.079 with 1024 and 1.069 in selection order (five alternations on one box).
+constexpr int kSortedLayoutThreads = 256;
 __global__ __launch_bounds__(kSortedLayoutThreads) void quadtree_layout_sorted_kernel(QtLevels lv, const Cand16* __restrict__ compact,
                                                                      const int* __restrict__ img_base, const int* __restrict__ level_count,
                                                                      const int* __restrict__ sel_pt, const int* __restrict__ sel_n,
