@@ -232,9 +232,8 @@ def main():
     # Phase between the two batches in flight: started together they stay in lock-step (both finish, and are resubmitted,
     # together: FAST beside FAST, descriptors beside descriptors); half a step apart, one batch's pyramid / FAST (VALU issue)
     # runs beside the other's quadtree (latency) and descriptors (line fills): 1.147 instead of 1.184 ms per step (round 4; a
-    # capture pipeline whose batches arrive evenly spaced is in this state by itself).  The offset is half of the step time
-    # measured over the warm-up steps (MSORB_BENCH_STAGGER_US overrides; 0 = lock-step), applied once after every fence, inside
-    # the timed region.
+    # capture pipeline whose batches arrive evenly spaced is in this state by itself).  The offset is half of the sum of the
+    # stages' own times (MSORB_BENCH_STAGGER_US overrides; 0 = lock-step), applied once after every fence, inside the timed region.
     stagger = [float(os.environ["MSORB_BENCH_STAGGER_US"]) * 1e-6 if "MSORB_BENCH_STAGGER_US" in os.environ else None]
     if not pipelined or args.steps < 8:   # (a handful of steps cannot pay for the half step the offset costs once)
         stagger[0] = 0.0
@@ -367,13 +366,17 @@ def main():
 
 
 
+    if pipelined and stagger[0] is None:
+        # half a step, taken from the stages' own times (HIP events, kernels alone on the GPU, measured above) BEFORE the warm-up
+        # steps, so that they already run in the timed region's shape.  It used to be half of the warm-up steps' wall time, which
+        # reads two to three times too long on a box whose host is slow to start, and an offset of a step and a half is lock-step
+        # again: 1.08 instead of 1.05 ms per step (offsets of 0.53-0.80 ms measured equal, 0 / 0.25 / 1.5 ms 3 % slower); and a
+        # warm-up in lock-step left a 20-step timed region 8 % slower than a staggered one did (tools/experiments/README.md)
+        iso = sum(float(np.median(v)) for v in stage_acc.values() if len(v)) * 1e-3
+        stagger[0] = min(max(iso / depth if iso > 0 else 1200e-6 / depth, 200e-6), 2e-3)
     t_w = time.perf_counter()
     for _ in range(args.warmup):
         step()
-    if pipelined and stagger[0] is None:
-        fence()
-        stagger[0] = (time.perf_counter() - t_w) / args.warmup / depth if args.warmup >= 2 else 1200e-6 / depth
-        stagger[0] = min(max(stagger[0], 200e-6), 2e-3)
     # timed region: the production shape (2 sub-batches in flight, blur on a second stream), stage events on
     for e in all_ex:
         e.set_profiling(True)

@@ -779,8 +779,12 @@ __global__ __launch_bounds__(256) void cand_scan_images_kernel(const int* __rest
 
 // 8 cells per 256-thread workgroup, 32 lanes per cell (a cell keeps ~20-40 candidates: one block of 64 threads per cell was
 // 230 k nearly empty workgroups per batch, 56 us of launch machinery for 48 MB)
-constexpr int kGatherCells = 16;   // 8 groups of 32 lanes, two cells each (their loads in flight together)
-__global__ __launch_bounds__(256) void cand_gather_kernel(const CellDesc* __restrict__ cells, int n_cells,
+#ifndef MSORB_GATHER_THREADS
+#define MSORB_GATHER_THREADS 256
+#endif
+constexpr int kGatherThreads = MSORB_GATHER_THREADS;
+constexpr int kGatherCells = kGatherThreads / 16;   // groups of 32 lanes, two cells each (their loads in flight together)
+__global__ __launch_bounds__(kGatherThreads) void cand_gather_kernel(const CellDesc* __restrict__ cells, int n_cells,
                                                           int slots_per_image, const Cand16* __restrict__ slots,
                                                           const int* __restrict__ cell_count,
                                                           const int* __restrict__ cell_off,
@@ -1759,7 +1763,7 @@ void launch_cand_compact(const CellDesc* cells, int n_cells, const int* level_ce
     hipLaunchKernelGGL(cand_scan_cells_kernel, dim3(n_images), dim3(256), 0, s, cell_count, n_cells, level_cell_begin,
                        nlevels, cell_off, level_count, img_total, img_base, packed ? 0 : slots_per_image);
     if (packed) hipLaunchKernelGGL(cand_scan_images_kernel, dim3(1), dim3(256), 0, s, img_total, n_images, img_base);
-    hipLaunchKernelGGL(cand_gather_kernel, dim3((n_cells + kGatherCells - 1) / kGatherCells, n_images), dim3(256), 0, s, cells, n_cells, slots_per_image,
+    hipLaunchKernelGGL(cand_gather_kernel, dim3((n_cells + kGatherCells - 1) / kGatherCells, n_images), dim3(kGatherThreads), 0, s, cells, n_cells, slots_per_image,
                        slots, cell_count, cell_off, img_base, compact);
 }
 int launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images, hipStream_t s, const Semantics& sem) {
