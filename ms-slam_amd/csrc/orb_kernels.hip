@@ -779,10 +779,7 @@ __global__ __launch_bounds__(256) void cand_scan_images_kernel(const int* __rest
 
 // 8 cells per 256-thread workgroup, 32 lanes per cell (a cell keeps ~20-40 candidates: one block of 64 threads per cell was
 // 230 k nearly empty workgroups per batch, 56 us of launch machinery for 48 MB)
-#ifndef MSORB_GATHER_THREADS
-#define MSORB_GATHER_THREADS 256
-#endif
-constexpr int kGatherThreads = MSORB_GATHER_THREADS;
+constexpr int kGatherThreads = 256;   // (64 / 128 measured inside the pipelined step: no different)
 constexpr int kGatherCells = kGatherThreads / 16;   // groups of 32 lanes, two cells each (their loads in flight together)
 __global__ __launch_bounds__(kGatherThreads) void cand_gather_kernel(const CellDesc* __restrict__ cells, int n_cells,
                                                           int slots_per_image, const Cand16* __restrict__ slots,
