@@ -1404,6 +1404,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
         // two v_mad_u32_u24 and a v_lshl_add.  The wave's slot base rides in qq: the slots of wave w start 6400 w bytes into
         // `patch`, and qq + 1600 w contributes 12 (400 w) + 1600 w = 6400 w to the sum (1600 w is a multiple of 4: the shift
         // takes it whole), so the address is relative to the array and keypoint kk's slot is an immediate offset.
+        static_assert((kKpPerWave * kBlkSlot) % 16 == 0, "a wave's slots must start on a multiple of 16 bytes for the base to ride in qq");
         const uint8_t* bc = &patch[0][0] + kk * kBlkSlot;
         const int r_bias = 0x4B400000 - (RQ[kk] >> 8), q_bias = 0x4B400000 - (RQ[kk] & 255) - wave * (kKpPerWave * kBlkSlot / 4);
         const f32x2 a2 = {a, a}, b2 = {b, b}, nb2 = {-b, -b};
