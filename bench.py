@@ -374,6 +374,16 @@ def main():
         # warm-up in lock-step left a 20-step timed region 8 % slower than a staggered one did (tools/experiments/README.md)
         iso = sum(float(np.median(v)) for v in stage_acc.values() if len(v)) * 1e-3
         stagger[0] = min(max(iso / depth if iso > 0 else 1200e-6 / depth, 200e-6), 2e-3)
+    # The stage measurement above runs one synchronous batch at a time: the GPU is half idle through it, and after that its
+    # clocks need ~25-40 ms of continuous work to settle (a traced `--steps 20 --warmup 5` run: the first pair of steps of the
+    # timed region took 2.37 ms, the tenth pair 2.09, same kernels).  A run with a short warm-up therefore gets the production
+    # loop for `settle` steps first — untimed, like the stage measurement — so that `--warmup W` means W steps of a settled loop.
+    import gc
+    gc.collect()
+    gc.disable()   # (one traced 20-step run in eight had a 4 ms hole in the host loop: no collector pass inside the timed region)
+    settle = int(os.environ.get("MSORB_BENCH_SETTLE_STEPS", "80")) if pipelined else 0
+    for _ in range(max(0, settle - args.warmup)):
+        step()
     t_w = time.perf_counter()
     for _ in range(args.warmup):
         step()
@@ -386,13 +396,19 @@ def main():
     fence_kp[0] = 0
     t0 = time.perf_counter()
     kp_total = 0
+    trace = [] if os.environ.get("MSORB_BENCH_TRACE") else None   # diagnostic: wall time at the end of every step() call, to stderr
     for _ in range(args.steps):
         kp_total += step()
+        if trace is not None:
+            trace.append(time.perf_counter())
         if not pipelined and (world == 1 or mode["sync_nccl"]):
             for k, v in last_ex[0].stage_ms().items():
                 overlapped_acc[k] += v
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
+    if trace:
+        sys.stderr.write("step ends (us after t0): " + " ".join(f"{(t - t0) * 1e6:.0f}" for t in trace) + f" | fence {dt * 1e6:.0f}\n")
     kp_total += fence_kp[0]
     join = dict(assoc)   # association statistics of the timed region only
 
