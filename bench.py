@@ -381,7 +381,7 @@ def main():
     import gc
     gc.collect()
     gc.disable()   # (one traced 20-step run in eight had a 4 ms hole in the host loop: no collector pass inside the timed region)
-    settle = int(os.environ.get("MSORB_BENCH_SETTLE_STEPS", "80")) if pipelined else 0
+    settle = int(os.environ.get("MSORB_BENCH_SETTLE_STEPS", "80")) if (pipelined or (world > 1 and not mode["sync_nccl"])) else 0
     for _ in range(max(0, settle - args.warmup)):
         step()
     t_w = time.perf_counter()
