@@ -519,6 +519,7 @@ def main():
                        "split_transport": None if world == 1 else "RCCL point-to-point (torch.distributed nccl backend), one rank per GPU",
                        "pairs_per_step_per_gpu": B if world == 1 else B, "images_per_step_per_gpu": n_img,
                        "stagger_us": round((stagger[0] or 0.0) * 1e6, 1),
+                       "untimed_steps_before_warmup": max(0, settle - args.warmup),
                        "batches_in_flight": depth if world == 1 else (1 if args.isolated or os.environ.get("MSORB_BENCH_SYNC") else 2),
                        "parallelism": ("1 GPU, both eyes; msorb_extract_batch_submit / _wait on two alternating handles: step k+1 is enqueued "
                                        "before step k is waited for" if pipelined else "1 GPU, both eyes") if world == 1 else f"stereo L/R split over {world} GPUs: one eye per rank; partners swap the keypoints / "

@@ -541,6 +541,7 @@ __global__ __launch_bounds__(kSortedLayoutThreads) void quadtree_layout_sorted_k
     __shared__ int lvl_begin[kMaxLevels + 1], cand_begin[kMaxLevels + 1], bin_begin[kMaxLevels + 1], ntx[kMaxLevels];
     __shared__ int part[256];
     constexpr int T = kSortedLayoutThreads;
+    static_assert(T >= 256, "the scan over the tiles runs on the first 256 threads");
     const int img = blockIdx.x, tid = threadIdx.x;
     const int nb = order.bin_begin[lv.nlevels];
     uint32_t* const cnt = tile_lds;
