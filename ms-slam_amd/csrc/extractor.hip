@@ -1273,8 +1273,14 @@ int msorb::extract_stereo_sink(msorb_extractor* h, const uint8_t* left, const ui
         b.row_begin = h->d_st_rows.p; b.row_list = reinterpret_cast<int2*>(h->d_st_list.p); b.row_cap = row_cap;
     }
     b.counts_out = reinterpret_cast<int*>(blk + o_cnt);
-    launch_stereo_match_batch(b, 1, cap, s, /*row_table_built=*/bands);
     uint8_t* o = h->h_out_pin.p;
+    // Without a sink the median rule rides the read-back launch (stereo_median_readback_kernel; in-process A/B, alternating blocks
+    // of 100 frames, three processes: msorb_extract_stereo through the Python mirror 0.2404 / 0.2450 / 0.2414 -> 0.2368 / 0.2407 /
+    // 0.2376 ms) — unless the copies are SDMA's (MSORB_FRAME_COPIES=sdma) or the block's tail is not 16-byte aligned (odd capacity).
+    static const bool sdma_copies = [] { const char* e = getenv("MSORB_FRAME_COPIES"); return e && std::string(e) == "sdma"; }();
+    b.median_with_readback = !sink && !sdma_copies && (o_ur & 15) == 0 &&
+                             ((reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(blk)) & 15) == 0;
+    launch_stereo_match_batch(b, 1, cap, s, /*row_table_built=*/bands);
     if (sink) {
         // the frame's read-back (190 KB) leaves on the side stream while the sink's kernels (frame grid, local points, window
         // search) run on the main one: 25 us of copy that would otherwise sit between the stereo kernels and the grid
@@ -1289,7 +1295,8 @@ int msorb::extract_stereo_sink(msorb_extractor* h, const uint8_t* left, const ui
         HIPCHK(small_copy(o, blk, out_bytes, hipMemcpyDeviceToHost, h->copy_stream));
         HIPCHK(hipStreamSynchronize(h->copy_stream));
     } else {
-        if ((rc = frame_copy(h, o, blk, out_bytes, hipMemcpyDeviceToHost, s))) return rc;
+        if (b.median_with_readback) launch_stereo_median_readback(b, o, blk, o_ur, out_bytes, s);
+        else if ((rc = frame_copy(h, o, blk, out_bytes, hipMemcpyDeviceToHost, s))) return rc;
     }
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());

@@ -689,13 +689,13 @@ __global__ __launch_bounds__(256) void stereo_match_quad_kernel(StereoBatchArgs 
 // value of rank size/2 — found by a two-level histogram select (SAD <= 121*255 < 2^15); every match whose SAD is not
 // below thDist = 1.5f*1.4f*median is withdrawn (the reference walks the sorted list from the end and stops at the first
 // smaller value: the same set).
-__global__ __launch_bounds__(256) void stereo_median_kernel(const int* __restrict__ countsL, const int* __restrict__ countsR,
-                                                            int pair_step, int capacity,
-                                                            const int* __restrict__ sad_all, float* __restrict__ u_right_all,
-                                                            float* __restrict__ depth_all, int* __restrict__ counts_out) {
+__device__ __forceinline__ void stereo_median_body(const int pair, const int* __restrict__ countsL, const int* __restrict__ countsR,
+                                                   int pair_step, int capacity,
+                                                   const int* __restrict__ sad_all, float* __restrict__ u_right_all,
+                                                   float* __restrict__ depth_all, int* __restrict__ counts_out) {
     __shared__ int hist[256];
     __shared__ int sel[3];  // chosen high bin, rank inside it, number of valid SADs
-    const int pair = blockIdx.x, t = threadIdx.x;
+    const int t = threadIdx.x;
     const int nL = countsL[(size_t)pair * pair_step];
     if (counts_out && t < 2) counts_out[2 * pair + t] = t ? countsR[(size_t)pair * pair_step] : nL;
     const int* sad = sad_all + (size_t)pair * capacity;
@@ -763,6 +763,32 @@ __global__ __launch_bounds__(256) void stereo_median_kernel(const int* __restric
     for (int i = t + kSadCache * 256; i < nL; i += 256) {
         const int v = sad[i];
         if (v >= 0 && !((float)v < thDist)) { u_right[i] = -1.0f; depth[i] = -1.0f; }
+    }
+}
+
+__global__ __launch_bounds__(256) void stereo_median_kernel(const int* __restrict__ countsL, const int* __restrict__ countsR,
+                                                            int pair_step, int capacity,
+                                                            const int* __restrict__ sad_all, float* __restrict__ u_right_all,
+                                                            float* __restrict__ depth_all, int* __restrict__ counts_out) {
+    stereo_median_body(blockIdx.x, countsL, countsR, pair_step, capacity, sad_all, u_right_all, depth_all, counts_out);
+}
+
+// A stereo frame without a sink: the median rule and the frame's read-back as ONE launch (the host is bound by its launches on
+// this chain).  Workgroup 0 applies the rule and then copies what the rule touches — the block's tail from `n16_head` on:
+// u_right, depth, counters —; the other workgroups copy the keypoints and descriptors in front of it, which the rule never
+// touches.  No dependency between workgroups.  dst: the pinned block, src: the device block, whole 16-byte units.
+__global__ __launch_bounds__(256) void stereo_median_readback_kernel(const int* __restrict__ countsL, const int* __restrict__ countsR,
+                                                                     int pair_step, int capacity, const int* __restrict__ sad_all,
+                                                                     float* u_right_all, float* depth_all, int* counts_out,
+                                                                     uint4* __restrict__ dst, const uint4* src, size_t n16_head,
+                                                                     size_t n16_all) {
+    if (blockIdx.x == 0) {
+        stereo_median_body(0, countsL, countsR, pair_step, capacity, sad_all, u_right_all, depth_all, counts_out);
+        __threadfence_block();
+        __syncthreads();
+        for (size_t i = n16_head + threadIdx.x; i < n16_all; i += 256) dst[i] = src[i];
+    } else {
+        for (size_t i = (size_t)(blockIdx.x - 1) * 256 + threadIdx.x; i < n16_head; i += (size_t)(gridDim.x - 1) * 256) dst[i] = src[i];
     }
 }
 
@@ -851,8 +877,15 @@ void launch_stereo_match_batch(const StereoBatchArgs& b, int n_pairs, int max_le
     // batches whose row table exists: four keypoints per wave (stereo_match_quad_kernel); frames: one per wave, every wave slot used
     if (n_pairs > 4 && b.row_begin) hipLaunchKernelGGL(stereo_match_quad_kernel, dim3((max_left + 15) / 16, n_pairs), dim3(256), 0, s, b);
     else hipLaunchKernelGGL(stereo_match_batch_kernel, dim3((max_left + 3) / 4, n_pairs), dim3(256), 0, s, b);
+    if (b.median_with_readback) return;   // the caller follows up with launch_stereo_median_readback
     hipLaunchKernelGGL(stereo_median_kernel, dim3(n_pairs), dim3(256), 0, s, b.countsL, b.countsR, b.pair_step, b.capacity, b.A.sad, b.A.u_right,
                        b.A.depth, b.counts_out);
+}
+void launch_stereo_median_readback(const StereoBatchArgs& b, void* dst, const void* src, size_t head_bytes, size_t all_bytes, hipStream_t s) {
+    const size_t n16_head = head_bytes / 16, n16_all = (all_bytes + 15) / 16;
+    const int blocks = 1 + (int)std::min<size_t>((n16_head + 255) / 256, 1024);
+    hipLaunchKernelGGL(stereo_median_readback_kernel, dim3(blocks), dim3(256), 0, s, b.countsL, b.countsR, b.pair_step, b.capacity, b.A.sad,
+                       b.A.u_right, b.A.depth, b.counts_out, reinterpret_cast<uint4*>(dst), reinterpret_cast<const uint4*>(src), n16_head, n16_all);
 }
 
 // Dense brute-force top-2 (SURVEY.md K6 "dense mode"; the knnMatch(k=2) shape of Frame.cc:1076): every query

@@ -66,6 +66,7 @@ struct StereoBatchArgs {
     const int2* band;           // stereo frames (row_begin == nullptr): per right keypoint {minr | maxr << 12 | octave << 24, bits of x}, pair p at [p * capacity]
     const int* band_level_begin;   // with band: [MSORB_MAX_LEVELS + 1] first record of each octave (the records are in level-major order)
     int* counts_out;            // optional: the median kernel copies the counts of pair p to [2p], [2p+1] (fused per-frame calls)
+    bool median_with_readback;  // one pair, no sink: launch_stereo_match_batch leaves the median rule to launch_stereo_median_readback
 };
 
 // n_frames > 1: a batch, frame b's arrays frame_stride keypoints / q_stride queries behind frame b-1's (grid: 3073 ints);
@@ -100,6 +101,9 @@ void launch_list_top2(const uint8_t* qdesc, const uint8_t* tdesc, const int* can
                       int* bi, int* bd, int* si, int* sd, hipStream_t s);
 void launch_stereo_match(const StereoArgs& a, hipStream_t s);
 void launch_stereo_match_batch(const StereoBatchArgs& b, int n_pairs, int max_left, hipStream_t s, bool row_table_built = false);
+// the median rule of pair 0 + the copy of the frame's output block [0, all_bytes) to pinned memory, head_bytes (a multiple of 16)
+// of it untouched by the rule; both pointers 16-byte aligned
+void launch_stereo_median_readback(const StereoBatchArgs& b, void* dst, const void* src, size_t head_bytes, size_t all_bytes, hipStream_t s);
 void launch_dense_top2(const uint8_t* q, const uint8_t* t, const int* n_q, const int* n_t, int n_frames, int q_stride,
                        int t_stride, int max_q, int max_t, int* bi, int* bd, int* sd, hipStream_t s, int formulation = 0);
 
