@@ -524,7 +524,9 @@ def test_extract_stereo_equals_two_extractions_plus_stereo_matches(msorb_mod, or
     """msorb_extract_stereo (both eyes through the batch pipeline + device-resident ComputeStereoMatches, one call) gives
     exactly what two msorb_extract calls followed by msorb_stereo_matches give (which is pinned to the oracle above)."""
     mbf, mb = mc.KITTI_BF, mc.KITTI_BF / mc.KITTI_FX
-    for seed, (rows, cols), nfeat in ((40, (376, 1241), 2000), (41, (480, 752), 1000), (42, (240, 320), 500)):
+    # (nfeatures 501: an odd capacity — the output block's tail is not 16-byte aligned, so the median rule keeps its own launch
+    # instead of riding the read-back: extractor.hip extract_stereo_sink, stereo_median_readback_kernel)
+    for seed, (rows, cols), nfeat in ((40, (376, 1241), 2000), (41, (480, 752), 1000), (42, (240, 320), 500), (43, (240, 320), 501)):
         L, R = synth.stereo_pair(seed, rows, cols)
         ex = msorb_mod.ORBextractor(nfeat, 1.2, 8, 20, 7)
         exl = msorb_mod.ORBextractor(nfeat, 1.2, 8, 20, 7)
