@@ -510,8 +510,8 @@ def main():
             "data": "synthetic",
             "metric_notes": {"inputs": "value assumes the images are already in HBM (bench contract); host_fed is the PCIe-inclusive batch "
                                        "rate, per_frame what one frame at a time from host memory costs",
-                             "hamming_match": "gpairs_per_s is an int8 matrix-core formulation (a deviation from north_star's 'no MFMA'); "
-                                              "hamming_match.popcount_kernel is the north_star's xor + popcount form, same inputs, same run",
+                             "hamming_match": "gpairs_per_s is the north_star's xor + popcount kernel (no MFMA); the opt-in int8 matrix-core "
+                                              "variant is reported under hamming_match.matrix_core_variant, same inputs, same run",
                              "two_gpus": "the product's stereo split (msorb_extract_stereo_split) gathers with hipMemcpyPeerAsync inside one "
                                          "process; RCCL (torch.distributed nccl) carries the exchange only in `bench.py --gpus N`",
                              "see": "BASELINE.md section 3"},
@@ -531,7 +531,12 @@ def main():
             "stage_ms_per_step_overlapped_note": "timed region: sum over the 2 concurrent sub-batches of each stage's event "
                                                  "interval (intervals overlap, so the sum exceeds ms_per_step); not recorded when "
                                                  "two batches are in flight (MSORB_BENCH_SYNC=1 for the one-batch-at-a-time loop)",
-            "roofline": {"bound": "hbm", "kernel": {"fast": "fast_cells_kernel", "pyramid": "pyr_resize_bandreg_kernel (x7)",
+            "roofline": {"bound": "valu+lds" if dom == "fast" else "hbm",
+                         "bound_note": "what the counters say limits this kernel (profiles/round5_fast_pmc.txt: VALU at 0.82 of its measured "
+                                       "issue rate, LDS pipe busy 61 % of the launch, HBM traffic 1.05 x algorithmic); achieved / peak / frac "
+                                       "are still the HBM yardstick the bench contract prescribes" if dom == "fast" else
+                                       "streaming kernel: HBM bandwidth",
+                         "kernel": {"fast": "fast_cells_kernel", "pyramid": "pyr_resize_bandreg_kernel (x7)",
                                                     "blur": "gauss7_kernel (x8)", "describe": "describe_kernel",
                                                     "compact": "cand_*"}[dom],
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -580,6 +585,8 @@ def main():
             out["cpu_baseline"] = optional_leg("cpu_baseline", cpu_baseline, cfg, args.cpu_pairs, 5000)
         else:
             out["cpu_baseline"] = None
+        import bench_legs
+        out["degraded_legs"] = list(bench_legs.DEGRADED)   # optional legs the ENVIRONMENT cost (each holds an "error" field); library failures never get here
         print(json.dumps(out), flush=True)
     for e in all_ex + ([ex_rp] if ex_rp is not None else []):
         e.close()

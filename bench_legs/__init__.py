@@ -3,9 +3,12 @@ file was split in round 5).  Two kinds of failure:
 
   * a PARITY self-check (`self_check`: a `*_matches_cpu`, `identical_results`, `same_matches_*` that does not hold) raises
     SelfCheckError and aborts the run — a bench line is only printed when every cross-check it reports holds;
-  * anything else that goes wrong inside an OPTIONAL leg (a missing rocprofv3, a compiler that is not there, a timeout of a
-    child process, an out-of-memory in a side measurement) is caught by `optional_leg` and becomes {"error": "..."} in that
-    leg's place: the headline `value` / `roofline` / `cpu_baseline` still reach the driver.
+  * a failure of the LIBRARY or the device inside any leg (msorb.MsorbError from a C-ABI entry, a HIP error surfacing through
+    torch) propagates too: a regression in a kernel must fail the run, not hide in a field of a line that exits 0;
+  * an ENVIRONMENT failure inside an OPTIONAL leg (a missing rocprofv3, a compiler that is not there, a timeout of a child
+    process, an out-of-memory in a side measurement) is caught by `optional_leg` and becomes {"error": "..."} in that leg's
+    place, and the leg's name is listed in the line's top-level "degraded_legs": the headline `value` / `roofline` /
+    `cpu_baseline` still reach the driver.
 """
 import os
 import sys
@@ -32,18 +35,38 @@ def self_check(ok, what):
         raise SelfCheckError("bench self-check failed: " + what)
 
 
+DEGRADED = []   # names of the optional legs that ended as an "error" field in this process (bench.py prints them as "degraded_legs")
+
+
+def is_library_failure(e):
+    """A failure of libmsorb or of the device (never degraded): msorb.MsorbError — an error code of a C-ABI entry — or a HIP error
+    torch reports (a kernel fault shows up at the next synchronising torch call)."""
+    if any(c.__name__ == "MsorbError" for c in type(e).__mro__):
+        return True
+    msg = str(e)
+    return isinstance(e, RuntimeError) and ("HIP error" in msg or "hipError" in msg or "CUDA error" in msg)
+
+
 def optional_leg(name, fn, *args, **kwargs):
-    """Run an optional leg; a parity failure (SelfCheckError / AssertionError) propagates, any other exception becomes the leg's
-    value: {"error": "<type>: <message>", "leg": name}.  MSORB_BENCH_FAIL_LEG=<name> makes the named leg fail on purpose (test
-    hook of tests/test_bench_legs.py)."""
+    """Run an optional leg; a parity failure (SelfCheckError / AssertionError) and a library / device failure (is_library_failure)
+    propagate, any other exception — the environment's — becomes the leg's value: {"error": "<type>: <message>", "leg": name} and the
+    name is appended to DEGRADED.  MSORB_BENCH_FAIL_LEG=<name> makes the named leg fail on purpose with an environment-type error,
+    MSORB_BENCH_FAIL_LEG=<name>:library with a library-type one (test hooks of tests/test_bench_legs_cpu.py)."""
     try:
-        if os.environ.get("MSORB_BENCH_FAIL_LEG") == name:
-            raise RuntimeError("forced failure of the optional leg (MSORB_BENCH_FAIL_LEG)")
+        hook = os.environ.get("MSORB_BENCH_FAIL_LEG", "")
+        if hook == name:
+            raise OSError("forced failure of the optional leg (MSORB_BENCH_FAIL_LEG)")
+        if hook == name + ":library":
+            raise type("MsorbError", (RuntimeError,), {})("forced library failure of the leg (MSORB_BENCH_FAIL_LEG)")
         return fn(*args, **kwargs)
     except AssertionError:
         raise
     except Exception as e:  # noqa: BLE001 — the point of the wrapper
+        if is_library_failure(e):
+            sys.stderr.write(f"bench.py: leg '{name}' hit a library / device failure — not degraded, the run fails:\n")
+            raise
         sys.stderr.write(f"bench.py: optional leg '{name}' failed and is reported as an error field:\n{traceback.format_exc()}\n")
+        DEGRADED.append(name)
         return {"error": f"{type(e).__name__}: {e}"[:400], "leg": name}
 
 

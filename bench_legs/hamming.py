@@ -14,51 +14,49 @@ def hamming_leg(msorb, torch, d_desc, counts_h, dev, local, reps=60):
     dtr = d_desc[1::2].contiguous()
     nq = torch.from_numpy(np.ascontiguousarray(counts_h[0::2])).to(dev)
     nt = torch.from_numpy(np.ascontiguousarray(counts_h[1::2])).to(dev)
-    msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=2, device=local)   # warm-up
-    _, _, _, ms = msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=reps, device=local)
     pairs = int((counts_h[0::2].astype(np.int64) * counts_h[1::2].astype(np.int64)).sum())
-    # The kernel runs on the matrix cores (matcher.hip dense_top2_mfma_kernel): +-32 int8 encoding, 8 x v_mfma_i32_32x32x32_i8 per
-    # 32 x 32 pairs = 512 int8 operations per pair.  Ceiling = the i8 MFMA rate this chip sustains with nothing else running
-    # (4.3 POPS: 37.5 cycles@2.4GHz per instruction and SIMD, tools/mfma_rate.hip; docs/DESIGN_rounds1-3.md section 4).
-    # For reference the integer-VALU formulation: 8 x (v_xor + accumulating v_bcnt) per 64 pairs at 7.91 cycles@2.4GHz per
-    # instruction PAIR (tools/valu_ubench2.hip, round 4: in a stream that mixes the two classes a fast-class instruction costs
-    # as much as a slow one, whether alternating or in runs of 16 — 2.5 cycles hold in pure fast-class streams only), + 3
-    # slow-class instructions of top-2 bookkeeping at 4.2.
-    g = pairs * reps / (ms * 1e-3) / 1e9
-    mfma_pops = 4.3e15
-    ceil_mfma = mfma_pops / 512 / 1e9
+    # The metric's kernel is the north_star's formulation: dense_top2_kernel<2, 4>, v_xor + accumulating v_bcnt per dword and a
+    # per-lane top-2, no MFMA (MSORB_DENSE_POPCOUNT, the library default).  Ceiling: 8 x (v_xor + v_bcnt) per 64 pairs at 7.91
+    # cycles@2.4GHz per instruction PAIR (tools/valu_ubench2.hip, round 4: in a stream that mixes the two classes a fast-class
+    # instruction costs as much as a slow one, whether alternating or in runs of 16 — 2.5 cycles hold in pure fast-class streams
+    # only), + 3 slow-class instructions of top-2 bookkeeping at 4.2.
     ceil_valu = 1024 * 2.4e9 * 64 / (8 * 7.91) / 1e9
     ceil_valu_top2 = 1024 * 2.4e9 * 64 / (8 * 7.91 + 3 * 4.2) / 1e9
-    # the north_star's own formulation (xor + __builtin_popcount per pair, no MFMA) measured beside it on the same descriptors
-    msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=2, device=local, formulation=msorb.DENSE_POPCOUNT)
+    msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=2, device=local, formulation=msorb.DENSE_POPCOUNT)   # warm-up
     bi_v, bd_v, sd_v, ms_v = msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=reps, device=local,
                                                             formulation=msorb.DENSE_POPCOUNT)
-    bi_m, bd_m, sd_m, _ = msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=1, device=local)
+    g_v = pairs * reps / (ms_v * 1e-3) / 1e9
+    # The opt-in matrix-core variant (matcher.hip dense_top2_mfma_kernel: +-32 int8 encoding, 8 x v_mfma_i32_32x32x32_i8 per 32 x 32
+    # pairs = 512 int8 operations per pair), reported beside it, never as the metric: north_star rules MFMA out for this path.
+    # Its ceiling = the i8 MFMA rate this chip sustains with nothing else running (4.3 POPS: 37.5 cycles@2.4GHz per instruction
+    # and SIMD, tools/mfma_rate.hip; docs/DESIGN_rounds1-3.md section 4).
+    mfma_pops = 4.3e15
+    ceil_mfma = mfma_pops / 512 / 1e9
+    msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=2, device=local, formulation=msorb.DENSE_MATRIX_CORES)
+    bi_m, bd_m, sd_m, ms = msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=reps, device=local, formulation=msorb.DENSE_MATRIX_CORES)
+    g = pairs * reps / (ms * 1e-3) / 1e9
     # rows >= nq[f] of a frame are never written by either kernel: only the valid rows are results
     live = torch.arange(dq.shape[1], device=dev)[None, :] < nq[:, None]
     same_kernels = bool(torch.equal(bi_v[live], bi_m[live]) and torch.equal(bd_v[live], bd_m[live]) and
                         torch.equal(sd_v[live], sd_m[live]))
     self_check(same_kernels, "hamming_match: the popcount and the MFMA kernel disagree on a valid row")
-    g_v = pairs * reps / (ms_v * 1e-3) / 1e9
-    hamming = {"gpairs_per_s": round(g, 2), "pairs_per_launch": pairs,
-               "ms_per_launch": round(ms / reps, 4), "kernel": "dense_top2_mfma_kernel (v_mfma_i32_32x32x32_i8)",
-               "formulation": "MSORB_DENSE_MATRIX_CORES: Hamming distance as an int8 dot product on the matrix cores — exact, identical "
-                              "results, but NOT the north_star's formulation ('no MFMA'); the conformant figure is popcount_kernel below",
-               "ceiling_gpairs_per_s": round(ceil_mfma, 1), "frac": round(g / ceil_mfma, 3),
-               "ceiling_note": "i8 MFMA rate measured on this chip (4.3 POPS) / 512 operations per pair",
-               "valu_formulation_ceiling_gpairs_per_s": round(ceil_valu, 1),
-               "valu_formulation_ceiling_with_top2_gpairs_per_s": round(ceil_valu_top2, 1),
-               "bound": "matrix-core issue (MFMA) with the top-2 bookkeeping (v_med3 + v_min per pair) interleaved under it; "
-                        "not HBM: (Q+T)*32 B per frame are reused Q*T times",
-               "popcount_kernel": {"what": "the north_star's formulation: dense_top2_kernel<2, 4>, v_xor + accumulating v_bcnt per "
-                                           "dword, no MFMA (formulation MSORB_DENSE_POPCOUNT); same inputs, same launch count",
-                                   "gpairs_per_s": round(g_v, 2), "ms_per_launch": round(ms_v / reps, 4),
-                                   "frac_of_valu_ceiling_with_top2": round(g_v / ceil_valu_top2, 3),
-                                   "ceiling_note": "mixed-stream VALU issue rate measured on this chip (tools/valu_ubench2.hip: "
-                                                   "v_xor + v_bcnt = 7.91 cycles@2.4GHz per pair of instructions); PMC of this "
-                                                   "kernel in profiles/round4_dense_popcount_pmc.txt",
-                                   "identical_results": same_kernels}}
-    ctx = dict(dq=dq, dtr=dtr, nq=nq, nt=nt, pairs=pairs, popcount_out=(bi_v, bd_v, sd_v), counts_h=counts_h, local=local)
+    hamming = {"gpairs_per_s": round(g_v, 2), "pairs_per_launch": pairs, "ms_per_launch": round(ms_v / reps, 4),
+               "kernel": "dense_top2_kernel<2, 4> (v_xor_b32 + accumulating v_bcnt_u32_b32 per dword, per-lane top-2; no MFMA)",
+               "formulation": "MSORB_DENSE_POPCOUNT: the north_star's formulation and the library default",
+               "ceiling_gpairs_per_s": round(ceil_valu_top2, 1), "frac": round(g_v / ceil_valu_top2, 3),
+               "ceiling_note": "mixed-stream VALU issue rate measured on this chip (tools/valu_ubench2.hip: v_xor + v_bcnt = 7.91 "
+                               "cycles@2.4GHz per pair of instructions) + 3 top-2 instructions per 64 pairs; PMC of this kernel in "
+                               "profiles/round4_dense_popcount_pmc.txt",
+               "ceiling_without_top2_gpairs_per_s": round(ceil_valu, 1),
+               "bound": "integer VALU issue (xor + popcount + top-2); not HBM: (Q+T)*32 B per frame are reused Q*T times",
+               "matrix_core_variant": {"what": "opt-in MSORB_DENSE_MATRIX_CORES: Hamming distance as an int8 dot product on the matrix "
+                                               "cores (dense_top2_mfma_kernel, v_mfma_i32_32x32x32_i8) — exact, identical results, "
+                                               "outside north_star's 'no MFMA' rule, hence not the metric",
+                                       "gpairs_per_s": round(g, 2), "ms_per_launch": round(ms / reps, 4),
+                                       "ceiling_gpairs_per_s": round(ceil_mfma, 1), "frac": round(g / ceil_mfma, 3),
+                                       "ceiling_note": "i8 MFMA rate measured on this chip (4.3 POPS) / 512 operations per pair",
+                                       "identical_results": same_kernels}}
+    ctx = dict(dq=dq, dtr=dtr, nq=nq, nt=nt, pairs=pairs, popcount_out=(bi_v, bd_v, sd_v), mfma_out=(bi_m, bd_m, sd_m), counts_h=counts_h, local=local)
     return hamming, ctx
 
 
@@ -67,7 +65,7 @@ def hamming_cpu_leg(msorb, hamming, ctx):
     stereo pair's descriptors; its result also cross-checks the GPU's indices and distances of BOTH kernels."""
     orb_oracle = oracle_module()
     dq, dtr, nq, nt, counts_h, pairs = ctx["dq"], ctx["dtr"], ctx["nq"], ctx["nt"], ctx["counts_h"], ctx["pairs"]
-    bi_g, bd_g, sd_g, _ = msorb.hamming_dense_top2_batch(dq, dtr, nq, nt, repeats=1, device=ctx["local"])
+    bi_g, bd_g, sd_g = ctx["mfma_out"]
     n0, n1 = int(counts_h[0]), int(counts_h[1])
     q0, t0_ = dq[0, :n0].cpu().numpy(), dtr[0, :n1].cpu().numpy()
     bi_c, bd_c, sd_c = orb_oracle.dense_top2(q0, t0_)
@@ -96,4 +94,4 @@ def hamming_cpu_leg(msorb, hamming, ctx):
                                          "(xor + __builtin_popcountll, -O3 x86-64-v3)",
                                "all_cores": {"gpairs_per_s": round(pairs / dta / 1e9, 3), "cores": ncore,
                                              "sample": f"all {dq_h.shape[0]} pairs, one frame per task, {dta * 1e3:.1f} ms"},
-                               "gpu_matches_cpu": bool(same), "popcount_kernel_matches_cpu": bool(same_pop)}
+                               "gpu_matches_cpu": bool(same_pop), "matrix_core_variant_matches_cpu": bool(same)}

@@ -43,7 +43,7 @@ int msorb_device_count(void);
  * minor only appends entry points (or appends `_ex` forms with more parameters), a new major changes or removes one.  The host
  * classes (host/ORBextractor.cc, host/ORBmatcher_device.h) and the Python mirror compare msorb_abi_version() with the header
  * they were compiled against and refuse a library with another major or an older minor (msorb_abi_compatible). */
-#define MSORB_ABI_VERSION 5000
+#define MSORB_ABI_VERSION 6000
 int msorb_abi_version(void);
 /* 1 if a caller compiled against `header_version` may use this library (same major, library minor >= header minor). */
 int msorb_abi_compatible(int header_version);
@@ -156,7 +156,8 @@ int msorb_pyramid_level_image(msorb_extractor* h, int image, int level, const ui
 
 /* The OpenCV primitives the extractor restates (resize, GaussianBlur, fastAtan2) are un-vendored dependencies of the reference
  * (CMakeLists.txt:35: OpenCV >= 4.4, no pinned version).  Their semantics follow SURVEY.md Appendix A; the three places where
- * a real OpenCV build could differ are ONE runtime-selectable table, in the kernels (here) and in the oracle
+ * a real OpenCV build could differ — and the one float expression of the reference itself whose rounding its COMPILER decides
+ * (brief_tap) — are ONE runtime-selectable table, in the kernels (here) and in the oracle
  * (oracle/cvprims.h Semantics) alike — if a pin run (tools/pin_opencv.py) disagrees with a default, the fix is this call:
  *   gauss_taps       Q8 taps of GaussianBlur(7x7, sigma 2) (ORBextractor.cc:1133).  Default {18,34,48,56,48,34,18}: the
  *                    bit-exact fixed-point path of OpenCV >= 4.2; sum(taps) <= 257.  Other taps run the generic blur kernels.
@@ -165,11 +166,19 @@ int msorb_pyramid_level_image(msorb_extractor* h, int image, int level, const ui
  *                    (generic resize kernel).
  *   atan2_fma        polynomial of fastAtan2 (ORBextractor.cc:102).  0 (default): separate multiply / add (x86-64 baseline
  *                    build); 1: contracted Horner steps (aarch64, -ffp-contract=fast builds).
+ *   brief_tap        the rotated rBRIEF tap cvRound(x*b + y*a), cvRound(x*a - y*b) (ORBextractor.cc:117-119), built with -O3
+ *                    -march=native (CMakeLists.txt:10-13), i.e. with whatever contraction that compiler and target choose.
+ *                    0 (default): the FIRST product fused, fma(x, b, y*a) / fma(x, a, -(y*b)) — g++ and clang on an FMA target
+ *                    (tools/probe_brief_tap.cc, compiled with the reference's flags, prints which one a given build has);
+ *                    1: the SECOND product fused, fma(y, a, x*b) / fma(-y, b, x*a);  2: no contraction (a target without FMA,
+ *                    -ffp-contract=off).  The conventions differ on about 3 of 10^7 (pattern point, angle) pairs
+ *                    (tests/test_semantics_variants.py counts them).
  * sem == NULL restores the defaults.  Applies to every later call on the handle. */
 typedef struct msorb_semantics {
     int gauss_taps[7];
     int resize_rounding;
     int atan2_fma;
+    int brief_tap;   /* since ABI 6000 */
 } msorb_semantics;
 int msorb_extractor_set_semantics(msorb_extractor* h, const msorb_semantics* sem);
 
@@ -217,6 +226,10 @@ int msorb_debug_copy_level(msorb_extractor* h, int image, int level, int blurred
 /* FAST candidates handed to the quadtree (vToDistributeKeys, ORBextractor.cc:795-869) of one image
  * and level, reference order; coordinates relative to (16,16); xyscore[3*i..3*i+2]. */
 int msorb_debug_candidates(msorb_extractor* h, int image, int level, int* xyscore, int capacity, int* n);
+/* The tables describe_kernel reads, copied back FROM THE DEVICE's constant memory: the 256 x 4 rBRIEF pattern (bit_pattern_31_,
+ * ORBextractor.cc:149-406) and umax[16] (:453-468).  For tests that hold what the chip holds to constants recorded independently
+ * of this library's sources (tests/golden/reference_constants.json).  Since ABI 6000. */
+int msorb_debug_patch_tables(msorb_extractor* h, int8_t* pattern /* 1024 */, int8_t* umax /* 16 */);
 /* Host-only: DistributeOctTree (ORBextractor.cc:555-779) on explicit candidates; writes the indices of
  * the kept candidates in result order.  Needs no GPU. */
 int msorb_distribute_quadtree(const uint16_t* xs, const uint16_t* ys, const uint16_t* scores, int n, int min_x,
@@ -380,9 +393,10 @@ int msorb_hamming_top2(int device, const uint8_t* query_desc, int n_queries, con
  * ORBmatcher::DescriptorDistance (ORBmatcher.cc:2323-2339); candidates scanned in index order with strict '<' (ties -> lowest
  * index).  d_* are DEVICE pointers: descriptors [n_frames][stride][32], counts [n_frames], outputs [n_frames][query_stride]
  * (rows past a frame's query count are not written).  Two formulations with identical results:
- *   MSORB_DENSE_MATRIX_CORES  distances as int8 dot products (v_mfma_i32_32x32x32_i8; the accumulator is the (distance, index)
- *                             key) — 2.9x the rate of the popcount form; a deviation from BASELINE north_star's "no MFMA"
- *   MSORB_DENSE_POPCOUNT      v_xor + v_bcnt per dword, the north_star's own formulation
+ *   MSORB_DENSE_POPCOUNT      v_xor + v_bcnt per dword: BASELINE north_star's formulation ("per-wavefront popcount ... no MFMA"),
+ *                             the DEFAULT of every entry that does not take the argument (since ABI 6000)
+ *   MSORB_DENSE_MATRIX_CORES  an opt-in variant: distances as int8 dot products (v_mfma_i32_32x32x32_i8; the accumulator is the
+ *                             (distance, index) key) — 2.9x the rate of the popcount form, outside the north_star's design rule
  * The launch is repeated `repeats` times on a private stream between two HIP events; *elapsed_ms (may be NULL)
  * receives the total.  max_train <= 2048. */
 #define MSORB_DENSE_MATRIX_CORES 0
@@ -391,9 +405,8 @@ int msorb_hamming_dense_top2_batch_ex(int device, const uint8_t* d_query, const 
                                       const int* d_n_train, int n_frames, int query_stride, int train_stride, int max_query,
                                       int max_train, int* d_best_idx, int* d_best_dist, int* d_second_dist, int repeats,
                                       float* elapsed_ms, int formulation);
-/* The entry as rounds 1-3 shipped it (no formulation argument; it runs MSORB_DENSE_MATRIX_CORES, that entry's default then):
- * kept with its original parameter list so that a caller built against the older header keeps working — ABI 5000 appends
- * `_ex` instead of changing it. */
+/* The entry without the formulation argument: MSORB_DENSE_POPCOUNT since ABI 6000 (rounds 1-5 ran the matrix-core variant
+ * here; results are identical, only the rate differs). */
 int msorb_hamming_dense_top2_batch(int device, const uint8_t* d_query, const uint8_t* d_train, const int* d_n_query,
                                    const int* d_n_train, int n_frames, int query_stride, int train_stride, int max_query,
                                    int max_train, int* d_best_idx, int* d_best_dist, int* d_second_dist, int repeats,

@@ -922,6 +922,8 @@ int msorb_extractor_set_semantics(msorb_extractor* h, const msorb_semantics* sem
         if (sum < 1 || sum > 257) { set_error("gauss taps: the 16-bit horizontal sums need sum(taps) <= 257"); return MSORB_E_INVALID; }
         s.resize_single_stage = sem->resize_rounding != 0;
         s.atan2_fma = sem->atan2_fma != 0;
+        if (sem->brief_tap < 0 || sem->brief_tap > 2) { set_error("brief_tap must be 0 (first product fused), 1 (second product fused) or 2 (no contraction)"); return MSORB_E_INVALID; }
+        s.brief_tap = sem->brief_tap;
     }
     h->sem = s;
     return MSORB_OK;
@@ -1096,13 +1098,28 @@ int msorb_extract_pair(msorb_extractor* h, const uint8_t* image_a, const uint8_t
     hipStream_t s = h->stream;
     const uint8_t* src[2] = {image_a, image_b};
     const size_t stride[2] = {stride_a, stride_b};
+    // A staged image may lie in THIS handle's own staging block (msorb_stage_image stages into plane 0): the plane an un-staged
+    // image is copied into must not be one a staged image of this call still has to be uploaded from.
+    int own_plane[2] = {-1, -1};   // plane of h_img_pin a staged image occupies (overlaps), -1: memory of another handle
     for (int i = 0; i < 2; i++) {
-        const uint8_t* pin = h->h_img_pin.p + (size_t)i * plane;
+        if (!(staged & (1 << i))) continue;
+        if (stride[i] != (size_t)g0.pitch) { set_error("msorb_extract_pair: a staged image must have the staging pitch"); return MSORB_E_INVALID; }
+        const uint8_t* lo = h->h_img_pin.p;
+        if (src[i] + plane > lo && src[i] < lo + 2 * plane) {
+            if (src[i] != lo && src[i] != lo + plane) { set_error("msorb_extract_pair: a staged pointer inside this handle's staging block must be a plane msorb_stage_image returned"); return MSORB_E_INVALID; }
+            own_plane[i] = src[i] == lo ? 0 : 1;
+        }
+    }
+    for (int i = 0; i < 2; i++) {
+        const uint8_t* pin;
         if (staged & (1 << i)) {   // already in pinned memory at the library's pitch (msorb_stage_image)
-            if (stride[i] != (size_t)g0.pitch) { set_error("msorb_extract_pair: a staged image must have the staging pitch"); return MSORB_E_INVALID; }
             pin = src[i];
         } else {
-            for (int y = 0; y < rows; y++) memcpy(h->h_img_pin.p + (size_t)i * plane + (size_t)y * g0.pitch, src[i] + (size_t)y * stride[i], cols);
+            const int other = own_plane[1 - i];
+            const int dst_plane = other == i ? 1 - i : i;   // the partner's staged image sits in this image's usual plane: take the other one
+            uint8_t* d = h->h_img_pin.p + (size_t)dst_plane * plane;
+            for (int y = 0; y < rows; y++) memcpy(d + (size_t)y * g0.pitch, src[i] + (size_t)y * stride[i], cols);
+            pin = d;
         }
         h->pair_l0[i] = pin;
         if ((rc = frame_copy(h, h->d_st_img.p + (size_t)i * plane, pin, plane, hipMemcpyHostToDevice, s))) return rc;
@@ -1521,7 +1538,9 @@ int msorb_pyramid_level(msorb_extractor* h, int level, const uint8_t** data, int
     const FrameGeom& g = h->G;
     if (h->h_pyr_async) {  // filled by the last msorb_extract call itself (msorb_extractor_set_host_pyramid)
         HIPCHK(hipStreamSynchronize(h->pyr_stream));
-        *data = level == 0 ? h->h_img_pin.p : h->h_pyr.p + g.lv[level].plane_off;
+        // level 0 is the caller's image where the last call left it in pinned memory: image 0 of a pair call may have been a staged
+        // pointer or have been moved to the second plane (msorb_extract_pair)
+        *data = level == 0 ? (h->pair_pyramids == 2 && h->pair_l0[0] ? h->pair_l0[0] : h->h_img_pin.p) : h->h_pyr.p + g.lv[level].plane_off;
         if (rows) *rows = g.lv[level].h;
         if (cols) *cols = g.lv[level].w;
         if (stride) *stride = g.lv[level].pitch;
@@ -1541,6 +1560,13 @@ int msorb_pyramid_level(msorb_extractor* h, int level, const uint8_t** data, int
     if (rows) *rows = g.lv[level].h;
     if (cols) *cols = g.lv[level].w;
     if (stride) *stride = g.lv[level].pitch;
+    return MSORB_OK;
+}
+
+int msorb_debug_patch_tables(msorb_extractor* h, int8_t* pattern, int8_t* umax) {
+    if (!h || !pattern || !umax) return MSORB_E_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(download_patch_tables(pattern, umax, h->stream));
     return MSORB_OK;
 }
 

@@ -730,7 +730,7 @@ int msorb_hamming_dense_top2_batch(int device, const uint8_t* d_query, const uin
                                    float* elapsed_ms) {
     return msorb_hamming_dense_top2_batch_ex(device, d_query, d_train, d_n_query, d_n_train, n_frames, query_stride, train_stride,
                                              max_query, max_train, d_best_idx, d_best_dist, d_second_dist, repeats, elapsed_ms,
-                                             MSORB_DENSE_MATRIX_CORES);
+                                             MSORB_DENSE_POPCOUNT);
 }
 
 int msorb_hamming_dense_top2_batch_ex(int device, const uint8_t* d_query, const uint8_t* d_train, const int* d_n_query,

@@ -52,6 +52,7 @@ int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_ba
                      const StereoRowJob* row_job = nullptr);
 size_t quadtree_lds_bytes(const QtLevels& lv);
 void upload_patch_tables(const int8_t* pattern, const int* umax, hipStream_t stream);
+hipError_t download_patch_tables(int8_t* pattern /* 1024 */, int8_t* umax /* 16 */, hipStream_t stream);   // back from the device's constant memory
 // device <-> pinned-host copy by a kernel (per-frame calls; orb_kernels.hip blit16_kernel); 16-byte aligned pointers
 void launch_blit(void* dst, const void* src, size_t bytes, hipStream_t s);
 // pinned host <-> device on a stream: the copy kernel, or hipMemcpyAsync for unaligned pointers / MSORB_FRAME_COPIES=sdma
@@ -63,6 +64,7 @@ struct Semantics {
     int gauss_taps[7] = {18, 34, 48, 56, 48, 34, 18};
     int resize_single_stage = 0;
     int atan2_fma = 0;
+    int brief_tap = 0;   // rotated BRIEF tap: 0 fma(x, b, y*a) / fma(x, a, -(y*b)), 1 fma(y, a, x*b) / fma(-y, b, x*a), 2 no contraction (describe_kernel<kTap>)
     bool default_taps() const {
         static const int d[7] = {18, 34, 48, 56, 48, 34, 18};
         for (int i = 0; i < 7; i++) if (gauss_taps[i] != d[i]) return false;

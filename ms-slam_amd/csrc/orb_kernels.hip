@@ -1138,6 +1138,16 @@ void upload_patch_tables(const int8_t* pattern, const int* umax, hipStream_t str
     (void)hipStreamSynchronize(stream);
 }
 
+hipError_t download_patch_tables(int8_t* pattern, int8_t* umax, hipStream_t stream) {
+    PatchTables t;
+    hipError_t e = hipMemcpyFromSymbolAsync(&t, HIP_SYMBOL(c_tab), sizeof(t), 0, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    memcpy(pattern, t.pattern, sizeof(t.pattern));
+    memcpy(umax, t.umax, sizeof(t.umax));
+    return hipSuccess;
+}
+
 // cv::fastAtan2 — separate multiply/add, no contraction (oracle/cvprims.h fast_atan2); fma != 0: the Horner steps contracted
 // (Semantics::atan2_fma).
 __device__ __forceinline__ float fast_atan2_deg(float y, float x, int fma) {
@@ -1213,6 +1223,10 @@ __device__ __forceinline__ uint32_t mad24s(uint32_t a, uint32_t s, uint32_t c) {
 }
 
 constexpr int kDescWaves = 4;   // waves per descriptor workgroup (2: 0.262 ms alone; 8: 0.239 alone but 1.088 instead of 1.057 ms per pipelined step — a 51 KB workgroup finds room later)
+// kTap = Semantics::brief_tap: which product of the rotated tap  x*b + y*a / x*a - y*b  (ORBextractor.cc:117-119) the reference's
+// compiler fused — 0: the first (fma(x, b, y*a); default), 1: the second (fma(y, a, x*b)), 2: none.  A template parameter: the
+// default costs what it did before the variants existed.
+template <int kTap>
 __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu(6, 6))) void describe_kernel(PyramidView pyr, PyramidView blur, const SelRec* __restrict__ sel,
                                                        const int* __restrict__ sel_count, int sel_stride,
                                                        LevelScale scales, msorb_keypoint* __restrict__ kps,
@@ -1411,8 +1425,19 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
         unsigned long long word[4];
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-            const f32x2 rf = pk_add_bcast(__builtin_elementwise_fma(patx[w], b2, paty[w] * a2), kRoundMagic);
-            const f32x2 qf = pk_add_bcast(__builtin_elementwise_fma(patx[w], a2, paty[w] * nb2), kRoundMagic);
+            f32x2 rv, qv;
+            if (kTap == 1) {        // second product fused: fma(y, a, x*b), fma(-y, b, x*a)  (y * (-b) is -(y*b) bit for bit)
+                rv = __builtin_elementwise_fma(paty[w], a2, patx[w] * b2);
+                qv = __builtin_elementwise_fma(paty[w], nb2, patx[w] * a2);
+            } else if (kTap == 2) { // no contraction: (x*b) + (y*a), (x*a) - (y*b)  (-ffp-contract=off keeps these apart)
+                rv = patx[w] * b2 + paty[w] * a2;
+                qv = patx[w] * a2 + paty[w] * nb2;
+            } else {                // first product fused: fma(x, b, y*a), fma(x, a, -(y*b))
+                rv = __builtin_elementwise_fma(patx[w], b2, paty[w] * a2);
+                qv = __builtin_elementwise_fma(patx[w], a2, paty[w] * nb2);
+            }
+            const f32x2 rf = pk_add_bcast(rv, kRoundMagic);
+            const f32x2 qf = pk_add_bcast(qv, kRoundMagic);
             int tv[2];
 #pragma unroll
             for (int j = 0; j < 2; j++) {
@@ -1464,13 +1489,15 @@ __global__ __launch_bounds__(256) void stage_level0_kernel(const uint8_t* __rest
 // and another ~10 us before the next command of the stream starts (profiles/round4_frame_trace.txt: three uploads = 68 us in
 // front of the first kernel).  A kernel that reads / writes the mapped host pointer (hipHostMalloc memory is device accessible)
 // queues behind and in front of the other kernels of the stream like any launch (~1.5 us boundaries) and moves the bytes at PCIe
-// rate.  16 bytes per lane, a grid-stride loop; both pointers 16-byte aligned, `bytes` rounded up to 16 by the caller's buffers.
-__global__ __launch_bounds__(256) void blit16_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
+// rate.  16 bytes per lane, a grid-stride loop; both pointers 16-byte aligned; the last bytes % 16 bytes go one by one (the first
+// lanes of workgroup 0), so exactly `bytes` bytes are read and written whatever follows them in either buffer.
+__global__ __launch_bounds__(256) void blit16_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16, unsigned tail) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x < tail)
+        reinterpret_cast<uint8_t*>(dst + n16)[threadIdx.x] = reinterpret_cast<const uint8_t*>(src + n16)[threadIdx.x];
 }
 // A per-frame transfer between a PINNED host block and device memory on stream s: the copy kernel when both pointers are 16-byte
-// aligned (whole hipMalloc / hipHostMalloc blocks and 16-byte offsets into them; the kernel moves whole 16-byte units, so the
-// allocations are padded to 16), hipMemcpyAsync otherwise — or always under MSORB_FRAME_COPIES=sdma (read once per process: the
+// aligned (whole hipMalloc / hipHostMalloc blocks and 16-byte offsets into them), hipMemcpyAsync otherwise — or always under MSORB_FRAME_COPIES=sdma (read once per process: the
 // A/B switch of this choice).
 hipError_t small_copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
     static const bool sdma = [] { const char* e = getenv("MSORB_FRAME_COPIES"); return e && std::string(e) == "sdma"; }();
@@ -1480,10 +1507,11 @@ hipError_t small_copy(void* dst, const void* src, size_t bytes, hipMemcpyKind ki
     return hipSuccess;
 }
 void launch_blit(void* dst, const void* src, size_t bytes, hipStream_t s) {
-    const size_t n16 = (bytes + 15) / 16;
-    if (n16 == 0) return;
-    const int blocks = (int)std::min<size_t>((n16 + 255) / 256, 1024);
-    hipLaunchKernelGGL(blit16_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4*>(dst), reinterpret_cast<const uint4*>(src), n16);
+    const size_t n16 = bytes / 16;
+    if (bytes == 0) return;
+    const int blocks = (int)std::min<size_t>(std::max<size_t>((n16 + 255) / 256, 1), 1024);
+    hipLaunchKernelGGL(blit16_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4*>(dst), reinterpret_cast<const uint4*>(src), n16,
+                       (unsigned)(bytes & 15));
 }
 void launch_stage_level0(const LevelView& src, uint8_t* dst, int dst_pitch, size_t dst_image_stride, int n_images, hipStream_t s) {
     hipLaunchKernelGGL(stage_level0_kernel, dim3((src.w + 1023) / 1024, src.h, n_images), dim3(256), 0, s, src.base, (size_t)src.pitch,
@@ -1723,7 +1751,7 @@ bool launch_pyramid_tower(const PyramidView& pyr, const TowerPlan& plan, const R
         (reinterpret_cast<uintptr_t>(taps) & 31))
         return false;
     const size_t lds = (size_t)plan.lds_even + plan.lds_odd + plan.lds_taps;
-    if (lds > 64 * 1024 && (long long)lds > dynamic_lds_room(reinterpret_cast<const void*>(pyr_tower_kernel))) return false;
+    if ((long long)lds > dynamic_lds_room(reinterpret_cast<const void*>(pyr_tower_kernel))) return false;   // (the room already excludes the kernel's static __shared__)
     TowerTaps t{};
     for (int l = 1; l < pyr.nlevels; l++) { t.x[l] = taps + tap_x_off[l]; t.y[l] = taps + tap_y_off[l]; }
     hipLaunchKernelGGL(pyr_tower_kernel, dim3(plan.ntx, plan.nty, n_images), dim3(kTowerThreads), lds, s, pyr, plan, t);
@@ -1811,8 +1839,14 @@ void launch_describe(const PyramidView& pyr, const PyramidView& blur, const SelR
                      int max_sel, int n_images, hipStream_t s, const Semantics& sem) {
     if (max_sel <= 0) return;
     const unsigned gx = (unsigned)((max_sel + kDescWaves * kKpPerWave - 1) / (kDescWaves * kKpPerWave));
-    hipLaunchKernelGGL(describe_kernel, dim3(gx, n_images), dim3(64 * kDescWaves), 0, s, pyr, blur, sel, sel_count,
-                       sel_stride, scales, kps, desc, out_stride, sem.atan2_fma, exact_div_magic(gx, (unsigned long long)gx * (unsigned)n_images));
+    const uint32_t magic = exact_div_magic(gx, (unsigned long long)gx * (unsigned)n_images);
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(gx, n_images), dim3(64 * kDescWaves), 0, s, pyr, blur, sel, sel_count, sel_stride, scales, kps, desc,
+                           out_stride, sem.atan2_fma, magic);
+    };
+    if (sem.brief_tap == 1) go(describe_kernel<1>);
+    else if (sem.brief_tap == 2) go(describe_kernel<2>);
+    else go(describe_kernel<0>);
 }
 
 }  // namespace msorb

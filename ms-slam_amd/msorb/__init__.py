@@ -23,13 +23,13 @@ STAGES = ("pyramid", "fast", "compact", "blur", "select", "describe")
 OK, E_INVALID, E_NO_DEVICE, E_HIP, E_CAPACITY, E_GEOMETRY, E_EMPTY = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/msorb.h declares (tests check the library exports them all)
-ABI_VERSION = 5000   # MSORB_ABI_VERSION of the include/msorb.h this mirror was written against (tests hold the two together)
+ABI_VERSION = 6000   # MSORB_ABI_VERSION of the include/msorb.h this mirror was written against (tests hold the two together)
 
 EXPORTS = (
     "msorb_last_error", "msorb_device_count", "msorb_abi_version", "msorb_abi_compatible", "msorb_set_fatal_callback", "msorb_notify_fatal", "msorb_extractor_create", "msorb_extractor_destroy",
     "msorb_extractor_tables", "msorb_extractor_capacity", "msorb_extract", "msorb_pyramid_level",
     "msorb_extract_batch", "msorb_extractor_set_profiling", "msorb_extractor_set_overlap", "msorb_extractor_stage_ms", "msorb_debug_level_size",
-    "msorb_debug_copy_level", "msorb_debug_candidates", "msorb_distribute_quadtree", "msorb_extract_stereo",
+    "msorb_debug_copy_level", "msorb_debug_candidates", "msorb_debug_patch_tables", "msorb_distribute_quadtree", "msorb_extract_stereo",
     "msorb_extract_stereo_split", "msorb_pyramid_batch", "msorb_stereo_matches_split", "msorb_extractor_set_host_pyramid",
     "msorb_extractor_set_semantics", "msorb_extract_pair", "msorb_stage_image", "msorb_pyramid_level_image",
 )
@@ -185,7 +185,8 @@ class ORBextractor:
 
     def extract_pair(self, image_a, image_b, lapping=(0, 0), stage=False):
         """msorb_extract_pair: two same-sized images through one kernel chain, no stereo match.
-        -> ((mono_a, kps_a, desc_a), (mono_b, kps_b, desc_b)); stage=True goes through msorb_stage_image for image_a."""
+        -> ((mono_a, kps_a, desc_a), (mono_b, kps_b, desc_b)); stage=True goes through msorb_stage_image for image_a; a pair
+        (ex_a, ex_b) of extractors / None stages image_a on ex_a and image_b on ex_b (the `staged` bits; ex may be self)."""
         image_a, image_b = np.ascontiguousarray(image_a, np.uint8), np.ascontiguousarray(image_b, np.uint8)
         assert image_a.shape == image_b.shape and image_a.ndim == 2
         rows, cols = image_a.shape
@@ -194,14 +195,17 @@ class ORBextractor:
         ka, kb = np.zeros(cap, KP_DTYPE), np.zeros(cap, KP_DTYPE)
         da, db = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
         na, nb, ma, mb = ci(0), ci(0), ci(0), ci(0)
-        pa, stride_a, staged = _np_ptr(image_a), cols, 0
-        if stage:
+        ptr, stride, staged = [_np_ptr(image_a), _np_ptr(image_b)], [cols, cols], 0
+        stagers = stage if isinstance(stage, (tuple, list)) else ((self if stage else None), None)
+        self.L.msorb_stage_image.argtypes = [vp, vp, ci, ci, sz, vp, vp]
+        for i, ex in enumerate(stagers):
+            if ex is None:
+                continue
             pin, pitch = vp(), sz()
-            self.L.msorb_stage_image.argtypes = [vp, vp, ci, ci, sz, vp, vp]
-            _check(self.L.msorb_stage_image(self.h, pa, rows, cols, cols, C.byref(pin), C.byref(pitch)), "msorb_stage_image")
-            pa, stride_a, staged = pin, pitch.value, 1
+            _check(self.L.msorb_stage_image(ex.h, ptr[i], rows, cols, cols, C.byref(pin), C.byref(pitch)), "msorb_stage_image")
+            ptr[i], stride[i], staged = pin, pitch.value, staged | (1 << i)
         self.L.msorb_extract_pair.argtypes = [vp, vp, vp, ci, ci, sz, sz, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci]
-        _check(self.L.msorb_extract_pair(self.h, pa, _np_ptr(image_b), rows, cols, stride_a, cols, lapping[0], lapping[1],
+        _check(self.L.msorb_extract_pair(self.h, ptr[0], ptr[1], rows, cols, stride[0], stride[1], lapping[0], lapping[1],
                                          _np_ptr(ka), _np_ptr(da), C.byref(na), C.byref(ma), _np_ptr(kb), _np_ptr(db),
                                          C.byref(nb), C.byref(mb), cap, staged), "msorb_extract_pair")
         a, b = na.value, nb.value
@@ -297,17 +301,17 @@ class ORBextractor:
         self._pending = None
         return counts[:n], mono[:n], out[0], out[1]
 
-    def set_semantics(self, gauss_taps=None, resize_single_stage=False, atan2_fma=False):
+    def set_semantics(self, gauss_taps=None, resize_single_stage=False, atan2_fma=False, brief_tap=0):
         """msorb_extractor_set_semantics: variants of the [OpenCV-recall] primitives; set_semantics() restores the defaults."""
         class Sem(C.Structure):
-            _fields_ = [("gauss_taps", C.c_int * 7), ("resize_rounding", C.c_int), ("atan2_fma", C.c_int)]
+            _fields_ = [("gauss_taps", C.c_int * 7), ("resize_rounding", C.c_int), ("atan2_fma", C.c_int), ("brief_tap", C.c_int)]
         self.L.msorb_extractor_set_semantics.argtypes = [C.c_void_p, C.c_void_p]
-        if gauss_taps is None and not resize_single_stage and not atan2_fma:
+        if gauss_taps is None and not resize_single_stage and not atan2_fma and not brief_tap:
             _check(self.L.msorb_extractor_set_semantics(self.h, None), "msorb_extractor_set_semantics")
             return
         sm = Sem()
         sm.gauss_taps[:] = [int(t) for t in (gauss_taps if gauss_taps is not None else (18, 34, 48, 56, 48, 34, 18))]
-        sm.resize_rounding, sm.atan2_fma = int(resize_single_stage), int(atan2_fma)
+        sm.resize_rounding, sm.atan2_fma, sm.brief_tap = int(resize_single_stage), int(atan2_fma), int(brief_tap)
         _check(self.L.msorb_extractor_set_semantics(self.h, C.addressof(sm)), "msorb_extractor_set_semantics")
 
     def set_host_pyramid(self, on=True):
@@ -332,6 +336,18 @@ class ORBextractor:
         out = np.zeros((r.value, c.value), np.uint8)
         _check(self.L.msorb_debug_copy_level(self.h, image, level, int(blurred), _np_ptr(out)), "debug_copy_level")
         return out
+
+    def debug_patch_tables(self):
+        """(pattern int8 [256, 4], umax int8 [16]) as they sit in the device's constant memory (msorb_debug_patch_tables)."""
+        pat, um = np.zeros(1024, np.int8), np.zeros(16, np.int8)
+        self.L.msorb_debug_patch_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(self.L.msorb_debug_patch_tables(self.h, _np_ptr(pat), _np_ptr(um)), "debug_patch_tables")
+        return pat.reshape(256, 4), um
+
+    def debug_level_size(self, level):
+        r, c = C.c_int(), C.c_int()
+        _check(self.L.msorb_debug_level_size(self.h, level, C.byref(r), C.byref(c)), "debug_level_size")
+        return r.value, c.value
 
     def debug_candidates(self, image, level):
         cap = 1 << 18
@@ -636,9 +652,9 @@ EXPORTS = EXPORTS + ("msorb_hamming_dense_top2_batch", "msorb_hamming_dense_top2
 DENSE_MATRIX_CORES, DENSE_POPCOUNT = 0, 1
 
 
-def hamming_dense_top2_batch(d_query, d_train, d_nq, d_nt, repeats=1, device=0, formulation=DENSE_MATRIX_CORES):
+def hamming_dense_top2_batch(d_query, d_train, d_nq, d_nt, repeats=1, device=0, formulation=DENSE_POPCOUNT):
     """Dense brute-force top-2 on device tensors: d_query/d_train torch.uint8 [F, stride, 32], d_nq/d_nt torch.int32 [F].
-    formulation: DENSE_MATRIX_CORES (int8 MFMA) or DENSE_POPCOUNT (xor + popcount, BASELINE north_star's form).
+    formulation: DENSE_POPCOUNT (xor + popcount, BASELINE north_star's form: the default) or DENSE_MATRIX_CORES (int8 MFMA, opt-in).
     -> (best_idx, best_dist, second_dist) torch.int32 [F, q_stride], elapsed_ms over `repeats` launches."""
     import torch
     L = lib()

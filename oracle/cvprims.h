@@ -92,6 +92,11 @@ struct Semantics {
     int resize_single_stage = 0;  // 0: VResizeLinear<uchar>: ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2) >> 2
                                   // 1: generic FixedPtCast: (S0*b0 + S1*b1 + (1 << 21)) >> 22
     int atan2_fma = 0;            // 0: separate multiply / add (x86-64 baseline build); 1: contracted Horner steps (aarch64, -ffp-contract=fast)
+    int brief_tap = 0;            // rounding of the rotated BRIEF tap cvRound(x*b + y*a), cvRound(x*a - y*b) (ORBextractor.cc:117-119), which the
+                                  // reference leaves to its compiler (-O3 -march=native, CMakeLists.txt:10-13):
+                                  // 0: FIRST product fused   fma(x, b, y*a), fma(x, a, -(y*b))   (g++ / clang on an FMA target: probed, tools/probe_brief_tap.cc)
+                                  // 1: SECOND product fused  fma(y, a, x*b), fma(-y, b, x*a)
+                                  // 2: no contraction        (x*b) + (y*a), (x*a) - (y*b)        (no-FMA target, -ffp-contract=off, MSVC /fp:precise)
 };
 static inline Semantics& semantics() { static Semantics s; return s; }
 

@@ -8,7 +8,8 @@
 // /root/reference/CMakeLists.txt:10-13) are made explicit here and compiled with -ffp-contract=off:
 //   * the rotated BRIEF tap  cvRound(x*b + y*a), cvRound(x*a - y*b)  (ORBextractor.cc:117-119) is
 //     evaluated as fmaf(x, b, y*a) and fmaf(x, a, -(y*b)) — what g++ 11 -O3 -march=native emits on an
-//     FMA-capable x86-64 (probed on this image's compiler with an equivalent expression);
+//     FMA-capable x86-64 (probed on this image's compiler: tools/probe_brief_tap.cc) — by default; the two other
+//     contractions a build could have are Semantics::brief_tap 1 and 2 (cvprims.h; rotated_tap below);
 //   * cos/sin are glibc's cosf/sinf (std::cos(float) via `using namespace std`, ORBextractor.cc:66,112).
 #include <cstdio>
 #include <list>
@@ -189,18 +190,32 @@ static float ic_angle(const Plane& image, float ptx, float pty, const std::vecto
 
 static const float kFactorPI = (float)(3.1415926535897932384626433832795 / 180.f);  // :106
 
+// (row, column) offset of one rotated pattern point: cvRound(x*b + y*a), cvRound(x*a - y*b) (ORBextractor.cc:117-119) under the
+// contraction Semantics::brief_tap names.  y * (-b) is -(y*b) bit for bit, so "fma(-y, b, .)" needs no form of its own.
+static inline void rotated_tap(int mode, float x, float y, float a, float b, int* row, int* col) {
+    float r, c;
+    if (mode == 1) { r = fmaf(y, a, x * b); c = fmaf(-y, b, x * a); }
+    else if (mode == 2) { r = x * b + y * a; c = x * a - y * b; }
+    else { r = fmaf(x, b, y * a); c = fmaf(x, a, -(y * b)); }
+    *row = cv_round(r);
+    *col = cv_round(c);
+}
+
 static void orb_descriptor(const KeyPoint& kpt, const Plane& img, uint8_t* desc) {
     const float angle = (float)kpt.angle * kFactorPI;
     const float a = cosf(angle), b = sinf(angle);
     const uint8_t* center = img.row(cv_round(kpt.y)) + cv_round(kpt.x);
     const int step = img.cols;
     const signed char* pat = kPattern;
+    const int mode = semantics().brief_tap;
     for (int i = 0; i < 32; ++i) {
         int val = 0;
         for (int k = 0; k < 8; ++k, pat += 4) {
-            const float x0 = (float)pat[0], y0 = (float)pat[1], x1 = (float)pat[2], y1 = (float)pat[3];
-            const int t0 = center[cv_round(fmaf(x0, b, y0 * a)) * step + cv_round(fmaf(x0, a, -(y0 * b)))];
-            const int t1 = center[cv_round(fmaf(x1, b, y1 * a)) * step + cv_round(fmaf(x1, a, -(y1 * b)))];
+            int r0, c0, r1, c1;
+            rotated_tap(mode, (float)pat[0], (float)pat[1], a, b, &r0, &c0);
+            rotated_tap(mode, (float)pat[2], (float)pat[3], a, b, &r1, &c1);
+            const int t0 = center[r0 * step + c0];
+            const int t1 = center[r1 * step + c1];
             val |= (t0 < t1) << k;
         }
         desc[i] = (uint8_t)val;
@@ -480,20 +495,58 @@ void orc_fast9_planes(const uint8_t* img, int stride, int rows, int cols, int th
         }
 }
 float orc_fast_atan2(float y, float x) { return orc::fast_atan2(y, x); }
+void orc_fast_atan2_n(const float* y, const float* x, long long n, float* out) { for (long long i = 0; i < n; i++) out[i] = orc::fast_atan2(y[i], x[i]); }
 
 // The semantics table of cvprims.h (process-wide in the oracle: test infrastructure).  taps == NULL restores the defaults.
 // Returns 0, or -1 for taps the Q8.8 pipeline cannot hold (horizontal sums are 16 bit: 255 * sum(taps) must stay <= 65535).
-int orc_set_semantics(const int* gauss_taps, int resize_single_stage, int atan2_fma) {
+int orc_set_semantics(const int* gauss_taps, int resize_single_stage, int atan2_fma, int brief_tap) {
     orc::Semantics s;
     if (gauss_taps) {
         int sum = 0;
         for (int i = 0; i < 7; i++) { if (gauss_taps[i] < 0 || gauss_taps[i] > 255) return -1; sum += gauss_taps[i]; s.gauss_taps[i] = gauss_taps[i]; }
         if (sum > 257 || sum < 1) return -1;
+        if (brief_tap < 0 || brief_tap > 2) return -1;
         s.resize_single_stage = resize_single_stage != 0;
         s.atan2_fma = atan2_fma != 0;
+        s.brief_tap = brief_tap;
     }
     orc::semantics() = s;
     return 0;
+}
+// One rotated pattern point under one contraction (Semantics::brief_tap numbering): tests/test_semantics_variants.py.
+void orc_rotated_tap(int mode, int x, int y, float a, float b, int* row, int* col) { orc::rotated_tap(mode, (float)x, (float)y, a, b, row, col); }
+// The exposure of the descriptor to that compiler choice: over n angles (degrees, as fastAtan2 returns them) and the 512 pattern
+// points, how many (point, angle) pairs land on a different pixel under contraction m than under contraction 0 — flips[m] for
+// m = 1, 2, flips[0] = pairs where 1 and 2 differ from each other; flipped_angles[m] = angles with at least one such point.
+// first_* receive up to cap examples (angle bits, point index, mode) for the probe's discriminating set.
+long long orc_brief_tap_sweep(const float* angles_deg, long long n, long long* flips, long long* flipped_angles, unsigned* ex_angle_bits,
+                              int* ex_point, int* ex_mode, int cap, int* n_ex) {
+    long long f[3] = {0, 0, 0}, fa[3] = {0, 0, 0};
+    int ne = 0;
+    for (long long i = 0; i < n; i++) {
+        const float r = angles_deg[i] * orc::kFactorPI;
+        const float a = cosf(r), b = sinf(r);
+        bool any[3] = {false, false, false};
+        for (int p = 0; p < 512; p++) {
+            const float x = (float)orc::kPattern[2 * p], y = (float)orc::kPattern[2 * p + 1];
+            int r0, c0, r1, c1, r2, c2;
+            orc::rotated_tap(0, x, y, a, b, &r0, &c0);
+            orc::rotated_tap(1, x, y, a, b, &r1, &c1);
+            orc::rotated_tap(2, x, y, a, b, &r2, &c2);
+            const bool d1 = r1 != r0 || c1 != c0, d2 = r2 != r0 || c2 != c0, d12 = r1 != r2 || c1 != c2;
+            if (d1) { f[1]++; any[1] = true; }
+            if (d2) { f[2]++; any[2] = true; }
+            if (d12) { f[0]++; any[0] = true; }
+            if ((d1 || d2) && ne < cap) {
+                unsigned bits; memcpy(&bits, &angles_deg[i], 4);
+                ex_angle_bits[ne] = bits; ex_point[ne] = p; ex_mode[ne] = (d1 ? 1 : 0) | (d2 ? 2 : 0); ne++;
+            }
+        }
+        for (int m = 0; m < 3; m++) fa[m] += any[m];
+    }
+    for (int m = 0; m < 3; m++) { flips[m] = f[m]; flipped_angles[m] = fa[m]; }
+    *n_ex = ne;
+    return n * 512;
 }
 void orc_cos_sin(float angle_deg, float* a, float* b) {
     const float r = angle_deg * orc::kFactorPI;

@@ -155,22 +155,62 @@ def fast9_planes(roi, threshold):
     return corner, score
 
 
-def set_semantics(gauss_taps=None, resize_single_stage=False, atan2_fma=False):
+def set_semantics(gauss_taps=None, resize_single_stage=False, atan2_fma=False, brief_tap=0):
     """The [OpenCV-recall] variant table of oracle/cvprims.h (process-wide).  set_semantics() restores the defaults."""
     L = lib()
-    L.orc_set_semantics.argtypes = [C.c_void_p, C.c_int, C.c_int]
-    if gauss_taps is None and not resize_single_stage and not atan2_fma:
-        rc = L.orc_set_semantics(None, 0, 0)
+    L.orc_set_semantics.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    if gauss_taps is None and not resize_single_stage and not atan2_fma and not brief_tap:
+        rc = L.orc_set_semantics(None, 0, 0, 0)
     else:
         t = np.ascontiguousarray(gauss_taps if gauss_taps is not None else [18, 34, 48, 56, 48, 34, 18], np.int32)
         assert len(t) == 7
-        rc = L.orc_set_semantics(_ptr(t), int(resize_single_stage), int(atan2_fma))
+        rc = L.orc_set_semantics(_ptr(t), int(resize_single_stage), int(atan2_fma), int(brief_tap))
     if rc:
         raise ValueError("taps outside the Q8.8 pipeline's range")
 
 
 def fast_atan2(y, x):
     return float(lib().orc_fast_atan2(float(y), float(x)))
+
+
+def fast_atan2_n(y, x):
+    """fast_atan2 over arrays (float32 in, float32 degrees out)."""
+    y, x = np.ascontiguousarray(y, np.float32).ravel(), np.ascontiguousarray(x, np.float32).ravel()
+    out = np.empty(len(y), np.float32)
+    L = lib()
+    L.orc_fast_atan2_n.restype = None
+    L.orc_fast_atan2_n.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
+    L.orc_fast_atan2_n(_ptr(y), _ptr(x), len(y), _ptr(out))
+    return out
+
+
+def rotated_tap(mode, x, y, a, b):
+    """(row, col) = cvRound(x*b + y*a), cvRound(x*a - y*b) (ORBextractor.cc:117-119) under contraction `mode` (Semantics::brief_tap)."""
+    L = lib()
+    L.orc_rotated_tap.restype = None
+    L.orc_rotated_tap.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    r, c = C.c_int(), C.c_int()
+    L.orc_rotated_tap(int(mode), int(x), int(y), float(a), float(b), C.byref(r), C.byref(c))
+    return r.value, c.value
+
+
+def brief_tap_sweep(angles_deg, cap=4096):
+    """Exposure of the descriptor to the tap contraction over `angles_deg` x the 512 pattern points: dict with the number of
+    (point, angle) pairs evaluated, the pairs / angles that land on another pixel under contraction 1 or 2 than under 0
+    (`vs0`), under 1 than under 2 (`between_1_2`), and up to `cap` examples (angle bits, point, bit mask of the modes that differ)."""
+    ang = np.ascontiguousarray(angles_deg, np.float32)
+    L = lib()
+    L.orc_brief_tap_sweep.restype = C.c_longlong
+    L.orc_brief_tap_sweep.argtypes = [C.c_void_p, C.c_longlong] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
+    flips, fang = np.zeros(3, np.int64), np.zeros(3, np.int64)
+    ex_a, ex_p, ex_m = np.zeros(cap, np.uint32), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    n_ex = C.c_int()
+    pairs = L.orc_brief_tap_sweep(_ptr(ang), len(ang), _ptr(flips), _ptr(fang), _ptr(ex_a), _ptr(ex_p), _ptr(ex_m), cap, C.byref(n_ex))
+    k = n_ex.value
+    return {"pairs": int(pairs), "angles": int(len(ang)),
+            "flips_vs0": {1: int(flips[1]), 2: int(flips[2])}, "flips_between_1_2": int(flips[0]),
+            "angles_vs0": {1: int(fang[1]), 2: int(fang[2])}, "angles_between_1_2": int(fang[0]),
+            "examples": list(zip(ex_a[:k].tolist(), ex_p[:k].tolist(), ex_m[:k].tolist()))}
 
 
 def cos_sin(angle_deg):

@@ -1,4 +1,5 @@
-"""bench_legs.optional_leg: a parity self-check always propagates, anything else becomes the leg's "error" field."""
+"""bench_legs.optional_leg: a parity self-check and a library / device failure always propagate, an environment failure becomes
+the leg's "error" field and is listed in the line's "degraded_legs"."""
 import os
 import sys
 
@@ -20,6 +21,17 @@ def test_optional_leg_semantics(monkeypatch, capsys):
         bl.optional_leg("assert", lambda: (_ for _ in ()).throw(AssertionError("x")))
     monkeypatch.setenv("MSORB_BENCH_FAIL_LEG", "forced")
     assert bl.optional_leg("forced", lambda: 1)["leg"] == "forced" and bl.optional_leg("other", lambda: 1) == 1
+    assert bl.DEGRADED[-2:] == ["boom", "forced"]
+    # a failure of libmsorb (an error code of a C-ABI entry) or of the device is a regression, not an environment problem: never degraded
+    import msorb
+    with pytest.raises(msorb.MsorbError):
+        bl.optional_leg("lib", lambda: (_ for _ in ()).throw(msorb.MsorbError(-5, "msorb_extract_batch")))
+    with pytest.raises(RuntimeError, match="HIP error"):
+        bl.optional_leg("hip", lambda: (_ for _ in ()).throw(RuntimeError("HIP error: an illegal memory access was encountered")))
+    monkeypatch.setenv("MSORB_BENCH_FAIL_LEG", "forced:library")
+    with pytest.raises(RuntimeError, match="forced library failure"):
+        bl.optional_leg("forced", lambda: 1)
+    assert "lib" not in bl.DEGRADED and "hip" not in bl.DEGRADED
 
 
 def test_every_leg_module_imports_without_a_gpu():

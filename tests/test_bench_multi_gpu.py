@@ -79,4 +79,13 @@ def test_a_failing_optional_leg_costs_the_leg_not_the_line():
     out = _last_json(q.stdout)
     assert out["value"] > 0 and out["roofline"]["achieved"] > 0
     assert out["per_frame"]["leg"] == "per_frame" and "forced failure" in out["per_frame"]["error"]
+    assert out["degraded_legs"] == ["per_frame"]
     assert out["tracking_loop"]["per_frame"]["ms_one_call"] > 0 and out["sparsification"]["ms_per_window"] > 0   # the other legs ran
+
+
+def test_a_library_failure_inside_a_leg_fails_the_run():
+    """round-5 advice: optional_leg used to turn an MsorbError of a core leg into an "error" field of a line that exits 0"""
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "16", "--steps", "4", "--warmup", "2", "--cpu-pairs", "0",
+                        "--no-pmc"], cwd=ROOT, env=_env(MSORB_BENCH_FAIL_LEG="hamming_match:library"), capture_output=True, text=True, timeout=900)
+    assert q.returncode != 0 and "forced library failure" in q.stderr
+    assert not [l for l in q.stdout.splitlines() if l.startswith("{")]

@@ -480,10 +480,12 @@ def test_texture_classes_at_full_kitti_size_through_the_batch_kernels(msorb_mod,
         ex.close()
 
 
-def _hip_extract(msorb_mod):
+def _hip_extract(msorb_mod, **semantics):
     def run(img, nfeat):
         ex = msorb_mod.ORBextractor(nfeat, 1.2, 8, 20, 7)
         try:
+            if semantics:
+                ex.set_semantics(**semantics)     # msorb_extractor_set_semantics: what the fixtures call for (pinned_semantics)
             _, kps, desc = ex(img)
         finally:
             ex.close()
@@ -506,8 +508,37 @@ def test_hip_extractor_against_real_opencv_extractor_pins(msorb_mod):
     import test_oracle_pins as top
     if not os.path.exists(os.path.join(top.PINS, "extractor_meta.json")):
         pytest.skip("no whole-extractor OpenCV pins committed yet (python tools/pin_opencv.py --extractor on a machine with cv2)")
-    bad, meta = top.compare_extractor(_hip_extract(msorb_mod), top.PINS)
-    assert not bad, f"the HIP extractor differs from the kit's run on OpenCV {meta['cv2_version']}:\n" + "\n".join(bad)
+    sem = top.pinned_semantics(top.PINS)     # the primitives' selected variant + the tap contraction the fixtures were made with
+    bad, meta = top.compare_extractor(_hip_extract(msorb_mod, **sem), top.PINS)
+    assert not bad, f"the HIP extractor under {sem} differs from the kit's run on OpenCV {meta['cv2_version']}:\n" + "\n".join(bad)
+
+
+def test_extract_pair_staged_images_on_the_handles_own_staging_block(msorb_mod, oracle):
+    """msorb_stage_image always stages into plane 0 of the handle's pinned block; msorb_extract_pair must not copy an un-staged image
+    over a staged one it still has to upload (round-5 advice: staged = 2 on ONE handle returned image a's keypoints for image b).
+    Every staged combination, with the host pyramid's level 0 pointing at the right image afterwards."""
+    cfg = CONFIGS["small"]
+    ex, ref = _pair(msorb_mod, oracle, cfg)
+    other = msorb_mod.ORBextractor(cfg["nfeatures"], cfg["scale"], cfg["nlevels"], cfg["ini_th"], cfg["min_th"])
+    ex.set_host_pyramid(True)
+    L, R = synth.stereo_pair(77, cfg["rows"], cfg["cols"])
+    want = [ref(L), ref(R)]
+    try:
+        for stagers in ((None, ex), (ex, None), (other, ex), (ex, other), (other, None), (None, other), (None, None)):
+            (ma, ka, da), (mb, kb, db) = ex.extract_pair(L, R, stage=stagers)
+            for which, img, (mono, kps, desc) in ((0, L, (ma, ka, da)), (1, R, (mb, kb, db))):
+                rmono, rkps, rdesc = want[which]
+                assert mono == rmono, stagers
+                _assert_same(kps, desc, rkps, rdesc)
+                assert np.array_equal(ex.pyramid_level_image(which, 0), img), f"level 0 of image {which} under staging {stagers}"
+            assert np.array_equal(ex.pyramid_level(0), L)      # msorb_pyramid_level = image 0 of the pair
+        # the same image staged once and passed for both eyes (staged = 3, one handle)
+        (ma, ka, da), (mb, kb, db) = ex.extract_pair(R, R, stage=(ex, ex))
+        _assert_same(ka, da, want[1][1], want[1][2])
+        _assert_same(kb, db, want[1][1], want[1][2])
+    finally:
+        ex.close()
+        other.close()
 
 
 def oracle_level(ref, img, level):

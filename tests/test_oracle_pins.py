@@ -12,6 +12,7 @@ import hashlib
 import importlib.util
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -342,15 +343,16 @@ def test_fast_atan2_against_numpy(oracle):
 
 
 # ---- the WHOLE extractor around the real primitives (tools/pin_opencv.py --extractor) --------------------------------------
-def compare_extractor(extract, pins_dir):
+def compare_extractor(extract, pins_dir, images=None):
     """extract(image, nfeatures) -> (keypoints KP_DTYPE [n], descriptors u8 [n, 32]) of ORBextractor(nfeatures, 1.2, 8, 20, 7) with
-    vLappingArea (0, 0), compared with the fixtures extractor.npz / extractor_meta.json of pins_dir.  -> list of mismatches."""
+    vLappingArea (0, 0), compared with the fixtures extractor.npz / extractor_meta.json of pins_dir.  -> list of mismatches.
+    images: {case name: image} for cases whose input is not one of the kit's pin images (hash checked all the same)."""
     kit = _kit()
     meta = json.load(open(os.path.join(pins_dir, "extractor_meta.json")))
     z = np.load(os.path.join(pins_dir, "extractor.npz"))
     bad = []
     for i, (name, rows, cols, nfeat) in enumerate(meta["cases"]):
-        img = kit.pin_image(700 + i, rows, cols)
+        img = images[name] if images and name in images else kit.pin_image(700 + i, rows, cols)
         assert kit.sha(img) == meta["inputs_sha256"][name], f"input of {name} differs from the generating run"
         kps, desc = extract(img, nfeat)
         want_k = z[f"{name}_kps"].reshape(-1, 28).view(kit.KP_DTYPE).reshape(-1)
@@ -408,6 +410,37 @@ def test_extractor_kit_plumbing(oracle, tmp_path):
     assert len(bad) == 2 and "keypoint field angle" in bad[0] and "descriptors differ" in bad[1]
 
 
+def test_extractor_kit_and_consumer_follow_brief_tap(oracle, tmp_path):
+    """Fixtures made under tap contraction 1 on a frame whose descriptors depend on it (test_semantics_variants.BRIEF_TAP_SEEDS):
+    the kit's Python extractor reproduces the oracle under that contraction, the meta data carries it, pinned_semantics hands it to
+    the consumer, and select_brief_tap recovers it from the descriptors alone."""
+    from msorb import synth
+    from test_semantics_variants import BRIEF_TAP_SEEDS
+    kit = _kit()
+    mode, seed = BRIEF_TAP_SEEDS[0]
+    img = synth.image(seed, synth.KITTI["rows"], synth.KITTI["cols"])
+    kps, desc, _ = kit.extract_orb(_OracleAsCv(oracle), img, 2000, brief_tap=mode)
+    np.savez_compressed(os.path.join(str(tmp_path), "extractor.npz"), frame_kps=kps.view(np.uint8).reshape(-1, 28), frame_desc=desc)
+    meta = {"kit_version": kit.KIT_VERSION, "cv2_version": "oracle-stand-in", "trig": "libm", "brief_tap": mode, "brief_tap_source": "test",
+            "inputs_sha256": {"frame": kit.sha(img)}, "cases": [["frame", img.shape[0], img.shape[1], 2000]]}
+    json.dump(meta, open(os.path.join(str(tmp_path), "extractor_meta.json"), "w"))
+
+    def extract_under(**sem):
+        def run(image, nfeat):
+            try:
+                oracle.set_semantics(**sem)
+                _, k, d = oracle.OracleExtractor(nfeat, 1.2, 8, 20, 7)(image)
+                return k, d
+            finally:
+                oracle.set_semantics()
+        return run
+    images = {"frame": img}
+    assert pinned_semantics(str(tmp_path)) == {"brief_tap": mode}
+    assert select_brief_tap(extract_under, str(tmp_path), images=images) == [mode]
+    bad, _ = compare_extractor(extract_under(), str(tmp_path), images)
+    assert len(bad) == 1 and "descriptors differ" in bad[0]
+
+
 def test_extractor_kit_follows_a_non_default_semantics_variant(oracle, tmp_path):
     """fixtures made with another Gaussian / resize / atan2 variant of the semantics table differ from the default oracle and are
     reproduced by the oracle once it is set to that variant: what the consumer of real fixtures would do after select_semantics()"""
@@ -424,16 +457,43 @@ def test_extractor_kit_follows_a_non_default_semantics_variant(oracle, tmp_path)
     assert bad, "the default semantics reproduced fixtures of another variant"
 
 
+def pinned_semantics(pins_dir):
+    """The semantics table the fixtures of pins_dir call for, as keyword arguments of set_semantics (oracle and msorb alike): the
+    variant the primitive fixtures selected (selected_semantics.json, written by test_pins_against_real_opencv) + the tap contraction
+    the extractor fixtures were made with (extractor_meta.json "brief_tap": stated or probed by the generating run, kit version >= 2)."""
+    kw = {}
+    sel = os.path.join(pins_dir, "selected_semantics.json")
+    if os.path.exists(sel):
+        s = json.load(open(sel))
+        if s.get("gauss_taps") and s.get("resize_single_stage") is not None and s.get("atan2_fma") is not None:
+            kw.update(gauss_taps=s["gauss_taps"], resize_single_stage=s["resize_single_stage"], atan2_fma=s["atan2_fma"])
+    meta = os.path.join(pins_dir, "extractor_meta.json")
+    if os.path.exists(meta):
+        kw["brief_tap"] = int(json.load(open(meta)).get("brief_tap", 0))
+    return kw
+
+
+def select_brief_tap(extract_under, pins_dir, base=None, images=None):
+    """Which tap contractions reproduce the extractor fixtures?  extract_under(**semantics) -> extract(image, nfeatures).  For
+    fixtures whose descriptors come from a compiled build of the reference (a dump of the real ORBextractor in the kit's format),
+    whose contraction nobody stated: -> the list of brief_tap values with no mismatch (often all three — the conventions differ
+    on ~1 descriptor in 40 frames — and [] when something else is wrong)."""
+    base = dict(base or {})
+    ok = []
+    for m in (0, 1, 2):
+        base["brief_tap"] = m
+        bad, _ = compare_extractor(extract_under(**base), pins_dir, images)
+        if not bad:
+            ok.append(m)
+    return ok
+
+
 def test_extractor_pins_against_real_opencv(oracle):
     if not os.path.exists(os.path.join(PINS, "extractor_meta.json")):
         pytest.skip("no whole-extractor OpenCV pins committed yet: run `python tools/pin_opencv.py --extractor` on a machine with cv2 — "
                     "until then keypoints and descriptors are bit-exact against the oracle only (PARITY UNPINNED)")
-    sel = os.path.join(PINS, "selected_semantics.json")
     try:
-        if os.path.exists(sel):   # the variant the primitive fixtures selected (written by test_pins_against_real_opencv)
-            s = json.load(open(sel))
-            if s.get("gauss_taps") and s.get("resize_single_stage") is not None and s.get("atan2_fma") is not None:
-                oracle.set_semantics(gauss_taps=s["gauss_taps"], resize_single_stage=s["resize_single_stage"], atan2_fma=s["atan2_fma"])
+        oracle.set_semantics(**pinned_semantics(PINS))
         bad, meta = compare_extractor(_oracle_extract(oracle), PINS)
     finally:
         oracle.set_semantics()
