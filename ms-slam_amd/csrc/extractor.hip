@@ -171,7 +171,7 @@ struct msorb_extractor {
     // worker threads), MSORB_SPLIT_NO_PEER (test hook: the two-device gather staged through the host), MSORB_FORCE_PEER_PYRAMID
     // (test hook: msorb_stereo_matches pulls the right pyramid over the peer path even on one device)
     const StereoRowJob* row_job = nullptr;   // set by the stereo-frame calls around run_pipeline: the right eye's band records leave the layout launch
-    struct Knobs { bool serial_pipeline = false, quadtree_host = false, split_no_peer = false, force_peer_pyramid = false; int host_threads = 0; } knobs;
+    struct Knobs { bool serial_pipeline = false, quadtree_host = false, split_no_peer = false, force_peer_pyramid = false, frame_fuse = true, frame_compact = true; int host_threads = 0; } knobs;
     int lds_per_block = 64 * 1024;   // hipDeviceAttributeMaxSharedMemoryPerBlock of the handle's device
     static constexpr bool capturing = false;   // (no graph capture: plain launches; see tools/experiments/README.md)
     bool defer_sync = false;     // enqueue only, the caller appends more work and synchronises (msorb_extract[_stereo])
@@ -503,11 +503,14 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
         if (!(n <= 4 && !h->sem.resize_single_stage && launch_pyramid_tower(pyr, h->tower, h->d_taps.p, h->tap_x_off.data(), h->tap_y_off.data(), n, s)))
             launch_pyramid(pyr, h->d_taps.p, h->tap_x_off.data(), h->tap_y_off.data(), n, s, h->sem);
         mark(1, s);
-        hipStream_t sb = h->overlap_blur ? h->copy_stream : s;
-        if (h->overlap_blur) {
-            HIPCHK(hipEventRecord(G.ev_pyr, s));
-            HIPCHK(hipStreamWaitEvent(sb, G.ev_pyr, 0));
-        }
+        // A frame (<= 4 images, one group): FAST and the blur leave as ONE launch on the main stream (frame_fast_blur_kernel) — no side
+        // stream, no fork / join.  Not with stage timing on (the stage events want the two kernels apart), not for variants of the
+        // table the streaming blur does not serve (launch_frame_fast_blur then returns false before launching anything).
+        const bool fuse_fb = h->knobs.frame_fuse && ng == 1 && n <= 4 && !prof && h->overlap_blur && h->sem.default_taps();
+        hipStream_t sb = h->overlap_blur && !fuse_fb ? h->copy_stream : s;
+        const bool side_blur = h->overlap_blur && !fuse_fb;
+        if (side_blur || h->host_pyramid) HIPCHK(hipEventRecord(G.ev_pyr, s));   // the pyramid is complete: the side stream's blur and the host-pyramid copies wait for this
+        if (side_blur) HIPCHK(hipStreamWaitEvent(sb, G.ev_pyr, 0));
         if (h->host_pyramid && h->pair_pyramids == 2 && n_images == 2 && ng == 1 && !h->capturing) {
             // msorb_extract_pair with the host pyramids requested: levels 1.. of both images leave on the pyramid stream
             int prc;
@@ -516,7 +519,6 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
                 HIPCHK(hipStreamCreateWithFlags(&h->pyr_stream, hipStreamNonBlocking));
                 HIPCHK(hipEventCreateWithFlags(&h->ev_pyr_done, hipEventDisableTiming));
             }
-            if (!h->overlap_blur) HIPCHK(hipEventRecord(G.ev_pyr, s));
             HIPCHK(hipStreamWaitEvent(h->pyr_stream, G.ev_pyr, 0));
             if (nl > 1)
                 for (int i = 0; i < 2; i++)
@@ -533,7 +535,6 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
                 HIPCHK(hipStreamCreateWithFlags(&h->pyr_stream, hipStreamNonBlocking));
                 HIPCHK(hipEventCreateWithFlags(&h->ev_pyr_done, hipEventDisableTiming));
             }
-            if (!h->overlap_blur) HIPCHK(hipEventRecord(G.ev_pyr, s));
             HIPCHK(hipStreamWaitEvent(h->pyr_stream, G.ev_pyr, 0));
             if (nl > 1)
                 HIPCHK(hipMemcpyAsync(h->h_pyr.p + g.lv[1].plane_off, h->d_pyr.p + g.lv[1].plane_off,
@@ -546,17 +547,20 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
             mark(7, sb);
             (void)launch_gauss7(pyr, blur, n, sb, h->sem);
             mark(8, sb);
-            if (h->overlap_blur) (void)hipEventRecord(G.ev_blur, sb);
+            if (side_blur) (void)hipEventRecord(G.ev_blur, sb);
         };
-        if (!h->overlap_blur) blur_now();   // one stream: pyramid, blur, FAST (the stage events expect this order)
-        launch_fast_cells(pyr, h->d_cells.p, ncells, h->P.ini_th, h->P.min_th, g.slots_per_image, h->d_slots.p + cslot,
-                          h->d_cell_count.p + (size_t)first * ncells, n, h->small_cells, s);
-        mark(2, s);
-        if (h->overlap_blur) blur_now();
+        if (!(fuse_fb && launch_frame_fast_blur(pyr, blur, h->d_cells.p, ncells, h->P.ini_th, h->P.min_th, g.slots_per_image, h->d_slots.p + cslot,
+                                                h->d_cell_count.p + (size_t)first * ncells, n, h->small_cells, s, h->sem))) {
+            if (!h->overlap_blur) blur_now();   // one stream: pyramid, blur, FAST (the stage events expect this order)
+            launch_fast_cells(pyr, h->d_cells.p, ncells, h->P.ini_th, h->P.min_th, g.slots_per_image, h->d_slots.p + cslot,
+                              h->d_cell_count.p + (size_t)first * ncells, n, h->small_cells, s);
+            mark(2, s);
+            if (h->overlap_blur) blur_now();
+        }
         launch_cand_compact(h->d_cells.p, ncells, h->d_level_cell_begin.p, nl, g.slots_per_image, h->d_slots.p + cslot,
                             h->d_cell_count.p + (size_t)first * ncells, h->d_cell_off.p + (size_t)first * ncells,
                             h->d_level_count.p + (size_t)first * nl, h->d_img_total.p + first, img_base,
-                            h->d_compact.p + cslot, n, s, /*packed=*/false);
+                            h->d_compact.p + cslot, n, s, /*packed=*/false, /*frame_form=*/h->knobs.frame_compact && ng == 1);
         h->compact_fixed_stride = true;
         mark(3, s);
         if ((rc = launch_quadtree(h->qt, h->d_compact.p + cslot, img_base, h->d_level_count.p + (size_t)first * nl,
@@ -565,7 +569,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
                                   h->d_sel_count.p + first, h->d_mono.p + first, n, s, ng == 1 ? h->row_job : nullptr)))
             return rc;
         mark(5, s);
-        if (h->overlap_blur) HIPCHK(hipStreamWaitEvent(s, G.ev_blur, 0));
+        if (side_blur) HIPCHK(hipStreamWaitEvent(s, G.ev_blur, 0));
         launch_describe(pyr, blur, h->d_sel.p + (size_t)first * sel_stride, h->d_sel_count.p + first, sel_stride, h->scales,
                         d_kps + (size_t)first * capacity, d_desc + (size_t)first * capacity * 32, capacity,
                         std::min(capacity, sel_stride), n, s, h->sem);
@@ -697,6 +701,10 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
             h_counts[img] = n;
             if (h_mono) h_mono[img] = mono;
         };
+        if (!h->pool) {   // the worker threads of the host-quadtree path (MSORB_QUADTREE=host) exist only once that path has run
+            int nthreads = h->knobs.host_threads > 0 ? h->knobs.host_threads : (int)std::thread::hardware_concurrency();
+            h->pool.reset(new Pool(std::max(1, std::min(nthreads, 64))));
+        }
         h->pool->parallel_for(n_images, task);
         if (overflow.load()) { set_error("keypoint capacity exceeded"); return MSORB_E_CAPACITY; }
         int max_sel = 0;
@@ -840,12 +848,12 @@ int msorb_extractor_create(int nfeatures, float scale_factor, int nlevels, int i
         h->knobs.split_no_peer = getenv("MSORB_SPLIT_NO_PEER") != nullptr;
         h->knobs.force_peer_pyramid = getenv("MSORB_FORCE_PEER_PYRAMID") != nullptr;
         h->knobs.host_threads = (e = getenv("MSORB_HOST_THREADS")) ? atoi(e) : 0;
+        // A/B switches of the frame chain's two fused launches (FAST + blur; candidate scan + gather): "0" = the separate launches
+        h->knobs.frame_fuse = !((e = getenv("MSORB_FRAME_FUSE")) && e[0] == '0');
+        h->knobs.frame_compact = !((e = getenv("MSORB_FRAME_COMPACT")) && e[0] == '0');
     }
     if (hipDeviceGetAttribute(&h->lds_per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || h->lds_per_block <= 0)
         h->lds_per_block = 64 * 1024;
-    int nthreads = h->knobs.host_threads > 0 ? h->knobs.host_threads : (int)std::thread::hardware_concurrency();
-    nthreads = std::max(1, std::min(nthreads, 64));
-    h->pool.reset(new Pool(nthreads));
     *out = h;
     return MSORB_OK;
 }

@@ -104,8 +104,12 @@ void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cell
 void launch_cand_compact(const CellDesc* cells, int n_cells, const int* level_cell_begin, int nlevels,
                          int slots_per_image, const Cand16* slots, const int* cell_count, int* cell_off,
                          int* level_count, int* img_total, int* img_base, Cand16* compact, int n_images,
-                         hipStream_t s, bool packed = true);
+                         hipStream_t s, bool packed = true, bool frame_form = false);   // frame_form: <= 4 images, !packed: scan + gather as one launch
 int launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images, hipStream_t s, const Semantics& sem = Semantics());
+// FAST + blur of a frame (1-4 images) as one launch; false = not applicable (unaligned rows, non-default taps), nothing launched
+bool launch_frame_fast_blur(const PyramidView& pyr, const PyramidView& blur, const CellDesc* cells, int n_cells, int ini_th, int min_th,
+                            int slots_per_image, Cand16* slots, int* cell_count, int n_images, bool small_cells, hipStream_t s,
+                            const Semantics& sem = Semantics());
 void launch_describe(const PyramidView& pyr, const PyramidView& blur, const SelRec* sel, const int* sel_count,
                      int sel_stride, const LevelScale& scales, msorb_keypoint* kps, uint8_t* desc, int out_stride,
                      int max_sel, int n_images, hipStream_t s, const Semantics& sem = Semantics());

@@ -368,11 +368,13 @@ __device__ __forceinline__ int block_excl_scan(int cnt, int lane, int wave, int*
     return before + incl - cnt;
 }
 
+// The kernel's body, on a workgroup's LINEAR index among `total` = cells_x * n_images workgroups (so that the frame kernel below can
+// run it on a sub-range of its grid).
 template <bool ALIGNED, class GEO>
-__global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kernel(PyramidView pyr, const CellDesc* __restrict__ cells,
+__device__ __forceinline__ void fast_cells_body(const PyramidView& pyr, const CellDesc* __restrict__ cells,
                                                          int ini_th, int min_th, int slots_per_image,
                                                          Cand16* __restrict__ slots, int* __restrict__ cell_count,
-                                                         int n_cells, uint32_t gx_magic) {
+                                                         int n_cells, uint32_t gx_magic, const unsigned lin, const unsigned grid_x, const unsigned total) {
     constexpr int T = GEO::kThreads, P = GEO::kTilePitch, SP = GEO::kScorePitch;
     constexpr int kScoreBytes = (GEO::kScoreRows * SP + 15) & ~15;
     constexpr int kBitWords = GEO::kWordsPerRow * GEO::kMaxDet;
@@ -390,12 +392,11 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
     // XCD-aware order: consecutive workgroups are dealt round-robin to the 8 XCDs (each with a private L2); remap
     // the linear id so that every XCD works through one contiguous run of (image, cell) pairs and neighbouring
     // cells — which share their 3-pixel halo and 128-byte lines — hit the same L2.
-    const unsigned total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
     const unsigned chunk = (total + 7) >> 3;
     unsigned wg = (lin & 7u) * chunk + (lin >> 3);
     if (total & 7u) wg = lin;  // ragged totals keep the plain order (bench / test geometries are multiples of 8 images)
-    const int img = gx_magic ? (int)__umulhi(wg, gx_magic) : (int)(wg / gridDim.x);  // host-checked exact reciprocal
-    const int cell_id = (int)(wg - (unsigned)img * gridDim.x);
+    const int img = gx_magic ? (int)__umulhi(wg, gx_magic) : (int)(wg / grid_x);  // host-checked exact reciprocal
+    const int cell_id = (int)(wg - (unsigned)img * grid_x);
     const CellDesc cd = cells[cell_id];
     const LevelView lv = pyr.lv[cd.level];
     const int rw = cd.rw, rh = cd.rh;
@@ -706,6 +707,15 @@ __global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kern
     if (tid == 0) cell_count[(size_t)img * n_cells + cell_id] = n_emitted;
 }
 
+template <bool ALIGNED, class GEO>
+__global__ __launch_bounds__(GEO::kThreads, GEO::kMinWaves) void fast_cells_kernel(PyramidView pyr, const CellDesc* __restrict__ cells,
+                                                         int ini_th, int min_th, int slots_per_image,
+                                                         Cand16* __restrict__ slots, int* __restrict__ cell_count,
+                                                         int n_cells, uint32_t gx_magic) {
+    fast_cells_body<ALIGNED, GEO>(pyr, cells, ini_th, min_th, slots_per_image, slots, cell_count, n_cells, gx_magic,
+                                  blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.x * gridDim.y);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Candidate compaction: per image exclusive scan of the cell counts (cells are already in the
 // reference's row-major cell order), a one-block scan over images, then a gather.
@@ -795,6 +805,83 @@ __global__ __launch_bounds__(kGatherThreads) void cand_gather_kernel(const CellD
     const int o0 = off[c0], o1 = off[c1], s0 = cells[c0].slot_off, s1 = cells[c1].slot_off, base = img_base[img];
     const Cand16* sp = slots + (size_t)img * slots_per_image;
     Cand16* d = compact + base;
+    Cand16 v0{}, v1{};
+    if (l < n0) v0 = sp[s0 + l];
+    if (l < n1) v1 = sp[s1 + l];
+    if (l < n0) d[o0 + l] = v0;
+    if (l < n1) d[o1 + l] = v1;
+    for (int i = l + 32; i < n0; i += 32) d[o0 + i] = sp[s0 + i];
+    for (int i = l + 32; i < n1; i += 32) d[o1 + i] = sp[s1 + i];
+}
+
+// Compaction of a FRAME (1-4 images) as ONE launch: every gather workgroup repeats the scan over its image's cell counts (a few
+// hundred integers from L2, the offsets kept in LDS) instead of waiting for a scan launch — the frame chain loses a launch and the
+// boundary in front of it; workgroup 0 of an image also writes what the scan kernel writes (cell_off, level_count, img_total,
+// img_base).  Image i's run starts at i * fixed_stride, as in the two-launch form with packed = false.
+constexpr int kFrameCompactCells = 2048;   // cells of one image the LDS offset table holds (KITTI 902, EuRoC 700)
+__global__ __launch_bounds__(kGatherThreads) void cand_compact_frame_kernel(const CellDesc* __restrict__ cells, int n_cells,
+                                                                            const int* __restrict__ level_cell_begin, int nlevels, int fixed_stride,
+                                                                            const Cand16* __restrict__ slots, const int* __restrict__ cell_count,
+                                                                            int* __restrict__ cell_off, int* __restrict__ level_count,
+                                                                            int* __restrict__ img_total, int* __restrict__ img_base,
+                                                                            Cand16* __restrict__ compact) {
+    static_assert(kGatherThreads == 256, "the scan below is written for four waves");
+    __shared__ int wave_tot[4];
+    __shared__ int lvl[kMaxLevels];
+    __shared__ int off_s[kFrameCompactCells];
+    const int img = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool writer = blockIdx.x == 0;
+    const int* cnt = cell_count + (size_t)img * n_cells;
+    int* off = cell_off + (size_t)img * n_cells;
+    const int per = (n_cells + 255) / 256;
+    const int b = tid * per, e = min(b + per, n_cells);
+    constexpr int kCache = 4;
+    int c[kCache];
+#pragma unroll
+    for (int k = 0; k < kCache; k++) c[k] = b + k < e ? cnt[b + k] : 0;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < kCache; k++) s += c[k];
+    for (int i = b + kCache; i < e; i++) s += cnt[i];
+    if (tid < kMaxLevels) lvl[tid] = 0;
+    int total = 0;
+    int acc = block_excl_scan<4>(s, lane, wave, wave_tot, &total);
+    int cur_l = 0, cur_t = 0;
+    auto visit = [&](int i, int v) {
+        off_s[i] = acc;
+        if (writer) {
+            off[i] = acc;
+            while (i >= level_cell_begin[cur_l + 1]) {
+                if (cur_t) atomicAdd(&lvl[cur_l], cur_t);
+                cur_t = 0;
+                cur_l++;
+            }
+            cur_t += v;
+        }
+        acc += v;
+    };
+#pragma unroll
+    for (int k = 0; k < kCache; k++)
+        if (b + k < e) visit(b + k, c[k]);
+    for (int i = b + kCache; i < e; i++) visit(i, cnt[i]);
+    if (writer && cur_t) atomicAdd(&lvl[cur_l], cur_t);
+    __syncthreads();
+    if (writer) {
+        if (tid < nlevels) level_count[(size_t)img * nlevels + tid] = lvl[tid];
+        if (tid == 0) {
+            img_total[img] = total;
+            img_base[img] = img * fixed_stride;
+            if (img == (int)gridDim.y - 1) img_base[gridDim.y] = (int)gridDim.y * fixed_stride;
+        }
+    }
+    // the gather of cand_gather_kernel, offsets from LDS
+    const int c0 = blockIdx.x * kGatherCells + 2 * (int)(threadIdx.x >> 5), l = threadIdx.x & 31;
+    if (c0 >= n_cells) return;
+    const int c1 = min(c0 + 1, n_cells - 1);
+    const int n0 = cnt[c0], n1 = c0 + 1 < n_cells ? cnt[c1] : 0;
+    const int o0 = off_s[c0], o1 = off_s[c1], s0 = cells[c0].slot_off, s1 = cells[c1].slot_off;
+    const Cand16* sp = slots + (size_t)img * fixed_stride;
+    Cand16* d = compact + (size_t)img * fixed_stride;
     Cand16 v0{}, v1{};
     if (l < n0) v0 = sp[s0 + l];
     if (l < n1) v1 = sp[s1 + l];
@@ -1024,15 +1111,10 @@ __device__ __forceinline__ void gauss7_strip(const uint8_t* __restrict__ sb, uin
     }
 }
 
+// One wave's strip: `tile` = the 256-thread block the wave belongs to in the streaming kernel's numbering, wave_in_block = 0..3
+// (waves are independent: no barrier, no LDS).
 template <int ROWS>
-__global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, PyramidView dst, BlurPlan plan, int per_xcd,
-                                                            int total_blocks) {
-    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (private L2 each).  A wave-row reads 256 bytes that
-    // start 4 bytes before a multiple of 248, i.e. three 128-byte lines of which the outer two are shared with the
-    // neighbouring column blocks; giving every XCD one contiguous run of (image, block) pairs keeps those neighbours —
-    // and the strips above / below — on one L2 (FETCH_SIZE 334 -> 242 MB per launch).
-    const int tile = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
-    if (tile >= total_blocks) return;
+__device__ __forceinline__ void gauss7_stream_body(const PyramidView& src, const PyramidView& dst, const BlurPlan& plan, const int tile, const int wave_in_block) {
     const int blocks_per_image = plan.block_begin[plan.nlevels];
     const int img = plan.image_magic ? (int)__umulhi((uint32_t)tile, plan.image_magic) : tile / blocks_per_image, blk = tile - img * blocks_per_image;
     int level = 0;
@@ -1045,7 +1127,7 @@ __global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, Pyr
     const int x0 = (bx * kGaussLanesOut + lane - 1) * 4;
     // the wave index through readfirstlane: everything derived from y0 (row reflection, row offsets, the row bound of the
     // stores) is then scalar work
-    const int y0 = (by * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * ROWS;
+    const int y0 = (by * 4 + __builtin_amdgcn_readfirstlane(wave_in_block)) * ROWS;
     if (y0 >= sv.h) return;  // wave-uniform
     // lanes 0 / 63 and lanes past the row: halo only — except that lane 63 can take the row's last group: columns x0 + 4 .. are
     // all beyond the border then, i.e. reflections out of {w1, w0}, and the missing right neighbour is not needed (a row of
@@ -1077,6 +1159,39 @@ __global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, Pyr
         gauss7_strip<ROWS, true>(sb, db, sv.pitch, dv.pitch, sv.h, y0, xl, x0, store, sel_w1, sel_w2a, sel_w2b);
     else
         gauss7_strip<ROWS, false>(sb, db, sv.pitch, dv.pitch, sv.h, y0, xl, x0, store, sel_w1, sel_w2a, sel_w2b);
+}
+
+template <int ROWS>
+__global__ __launch_bounds__(256) void gauss7_stream_kernel(PyramidView src, PyramidView dst, BlurPlan plan, int per_xcd,
+                                                            int total_blocks) {
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (private L2 each).  A wave-row reads 256 bytes that
+    // start 4 bytes before a multiple of 248, i.e. three 128-byte lines of which the outer two are shared with the
+    // neighbouring column blocks; giving every XCD one contiguous run of (image, block) pairs keeps those neighbours —
+    // and the strips above / below — on one L2 (FETCH_SIZE 334 -> 242 MB per launch).
+    const int tile = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+    if (tile >= total_blocks) return;
+    gauss7_stream_body<ROWS>(src, dst, plan, tile, (int)(threadIdx.x >> 6));
+}
+
+// FAST and the blur of a FRAME (1-4 images) as ONE launch: both only need the pyramid, and as two launches the blur ran on a side
+// stream — an event record, two stream waits and a launch per frame, and a fork / join that costs the chain ~8 us on this
+// runtime whatever runs in it (tools/launch_ubench.hip, profiles/round6_launch_ubench.txt).  Workgroups [0, n_fast) run
+// fast_cells_body on their cell, the rest gauss7_stream_body: GEO::kThreads / 64 waves of a blur block each (the blur's waves are
+// independent).  The blur's registers (88) set the allocation: no minimum-waves bound here — a frame does not fill the chip.
+template <bool ALIGNED, class GEO>
+__global__ __launch_bounds__(GEO::kThreads) void frame_fast_blur_kernel(PyramidView pyr, const CellDesc* __restrict__ cells, int ini_th, int min_th,
+                                                                        int slots_per_image, Cand16* __restrict__ slots, int* __restrict__ cell_count,
+                                                                        int n_cells, uint32_t gx_magic, unsigned n_fast, PyramidView blur, BlurPlan plan,
+                                                                        int blur_blocks) {
+    if (blockIdx.x < n_fast) {
+        fast_cells_body<ALIGNED, GEO>(pyr, cells, ini_th, min_th, slots_per_image, slots, cell_count, n_cells, gx_magic, blockIdx.x, (unsigned)n_cells, n_fast);
+        return;
+    }
+    constexpr int kWavesPerWg = GEO::kThreads / 64, kWgPerTile = 4 / kWavesPerWg;   // 128 threads: two workgroups per blur block
+    const unsigned b = blockIdx.x - n_fast;
+    const int tile = (int)(b / kWgPerTile);
+    if (tile >= blur_blocks) return;
+    gauss7_stream_body<kGaussRows>(pyr, blur, plan, tile, (int)(b % kWgPerTile) * kWavesPerWg + (int)(threadIdx.x >> 6));
 }
 
 // Right-border column groups (x0 + 16 > w: at most four groups = 16 columns per row): per-byte reflect-101 gather.
@@ -1785,26 +1900,30 @@ void launch_fast_cells(const PyramidView& pyr, const CellDesc* cells, int n_cell
 void launch_cand_compact(const CellDesc* cells, int n_cells, const int* level_cell_begin, int nlevels,
                          int slots_per_image, const Cand16* slots, const int* cell_count, int* cell_off,
                          int* level_count, int* img_total, int* img_base, Cand16* compact, int n_images,
-                         hipStream_t s, bool packed) {
+                         hipStream_t s, bool packed, bool frame_form) {
+    if (!packed && frame_form && n_images <= 4 && n_cells <= kFrameCompactCells) {   // a frame: scan + gather as one launch
+        hipLaunchKernelGGL(cand_compact_frame_kernel, dim3((n_cells + kGatherCells - 1) / kGatherCells, n_images), dim3(kGatherThreads), 0, s, cells, n_cells,
+                           level_cell_begin, nlevels, slots_per_image, slots, cell_count, cell_off, level_count, img_total, img_base, compact);
+        return;
+    }
     hipLaunchKernelGGL(cand_scan_cells_kernel, dim3(n_images), dim3(256), 0, s, cell_count, n_cells, level_cell_begin,
                        nlevels, cell_off, level_count, img_total, img_base, packed ? 0 : slots_per_image);
     if (packed) hipLaunchKernelGGL(cand_scan_images_kernel, dim3(1), dim3(256), 0, s, img_total, n_images, img_base);
     hipLaunchKernelGGL(cand_gather_kernel, dim3((n_cells + kGatherCells - 1) / kGatherCells, n_images), dim3(kGatherThreads), 0, s, cells, n_cells, slots_per_image,
                        slots, cell_count, cell_off, img_base, compact);
 }
-int launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images, hipStream_t s, const Semantics& sem) {
+static bool levels_aligned(const PyramidView& v) {
+    bool aligned = true;
+    for (int l = 0; l < v.nlevels; l++) {
+        const LevelView& lv = v.lv[l];
+        aligned = aligned && (reinterpret_cast<uintptr_t>(lv.base) & 3) == 0 && (lv.pitch & 3) == 0 && (lv.img_stride & 3) == 0;
+    }
+    return aligned;
+}
+// The blur kernels' block table: per level bx_count column blocks x ceil(strips / 4) row blocks of four wave-strips.
+static BlurPlan make_blur_plan(const PyramidView& src, int n_images, bool stream, int* total_out, int* max_h_out) {
     BlurPlan plan{};
     plan.nlevels = src.nlevels;
-    bool aligned = true;
-    for (int l = 0; l < src.nlevels; l++) {
-        const LevelView& v = src.lv[l];
-        aligned = aligned && (reinterpret_cast<uintptr_t>(v.base) & 3) == 0 && (v.pitch & 3) == 0 && (v.img_stride & 3) == 0;
-    }
-    // the streaming kernel has the default taps folded into its v_dot4 constants; other taps (Semantics::gauss_taps) take the
-    // generic kernels, which read them at run time
-    const bool stream = aligned && sem.default_taps();
-    GaussTaps T;
-    for (int i = 0; i < 7; i++) T.k[i] = (uint32_t)sem.gauss_taps[i];
     // strip height 35: 21..35 rows measure the same (0.29 ms / 256 images), 70 and 140 are slower (too few waves)
     const int rows = kGaussRows;
     int total = 0, max_h = 0;
@@ -1824,6 +1943,19 @@ int launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images, 
         plan.bx_magic[l] = exact_div_magic((unsigned)plan.bx_count[l], (unsigned long long)(plan.block_begin[l + 1] - plan.block_begin[l]));
     for (int l = src.nlevels; l < kMaxLevels; l++) plan.bx_magic[l] = 0;
     plan.image_magic = exact_div_magic((unsigned)total, (unsigned long long)total * (unsigned)n_images + 8);
+    *total_out = total;
+    *max_h_out = max_h;
+    return plan;
+}
+int launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images, hipStream_t s, const Semantics& sem) {
+    const bool aligned = levels_aligned(src);
+    // the streaming kernel has the default taps folded into its v_dot4 constants; other taps (Semantics::gauss_taps) take the
+    // generic kernels, which read them at run time
+    const bool stream = aligned && sem.default_taps();
+    GaussTaps T;
+    for (int i = 0; i < 7; i++) T.k[i] = (uint32_t)sem.gauss_taps[i];
+    int total = 0, max_h = 0;
+    const BlurPlan plan = make_blur_plan(src, n_images, stream, &total, &max_h);
     if (stream) {
         const int all = total * n_images, per_xcd = (all + 7) / 8;
         hipLaunchKernelGGL(gauss7_stream_kernel<kGaussRows>, dim3(per_xcd * 8), dim3(256), 0, s, src, dst, plan, per_xcd, all);
@@ -1833,6 +1965,25 @@ int launch_gauss7(const PyramidView& src, const PyramidView& dst, int n_images, 
     if (!stream)  // the streaming kernel handles the right border itself
         hipLaunchKernelGGL(gauss7_edge_kernel, dim3((max_h + kEdgeRows - 1) / kEdgeRows, src.nlevels, n_images), dim3(64), 0, s, src, dst, T);
     return 0;
+}
+// FAST + blur of a frame as one launch (frame_fast_blur_kernel); false: the conditions of the one-launch form do not hold (rows
+// not 4-byte aligned, non-default Gaussian taps) and nothing was launched — the caller issues the two launches.
+bool launch_frame_fast_blur(const PyramidView& pyr, const PyramidView& blur, const CellDesc* cells, int n_cells, int ini_th, int min_th,
+                            int slots_per_image, Cand16* slots, int* cell_count, int n_images, bool small_cells, hipStream_t s,
+                            const Semantics& sem) {
+    if (!levels_aligned(pyr) || !sem.default_taps()) return false;
+    int total = 0, max_h = 0;
+    const BlurPlan plan = make_blur_plan(pyr, n_images, true, &total, &max_h);
+    const int blur_blocks = total * n_images;
+    const unsigned n_fast = (unsigned)n_cells * (unsigned)n_images;
+    const uint32_t gx_magic = exact_div_magic((unsigned)n_cells, (unsigned long long)n_cells * (unsigned)n_images);
+    if (small_cells)
+        hipLaunchKernelGGL((frame_fast_blur_kernel<true, GeoSmall>), dim3(n_fast + (unsigned)blur_blocks * (256 / GeoSmall::kThreads)), dim3(GeoSmall::kThreads), 0, s,
+                           pyr, cells, ini_th, min_th, slots_per_image, slots, cell_count, n_cells, gx_magic, n_fast, blur, plan, blur_blocks);
+    else
+        hipLaunchKernelGGL((frame_fast_blur_kernel<true, GeoLarge>), dim3(n_fast + (unsigned)blur_blocks * (256 / GeoLarge::kThreads)), dim3(GeoLarge::kThreads), 0, s,
+                           pyr, cells, ini_th, min_th, slots_per_image, slots, cell_count, n_cells, gx_magic, n_fast, blur, plan, blur_blocks);
+    return true;
 }
 void launch_describe(const PyramidView& pyr, const PyramidView& blur, const SelRec* sel, const int* sel_count,
                      int sel_stride, const LevelScale& scales, msorb_keypoint* kps, uint8_t* desc, int out_stride,
