@@ -230,6 +230,13 @@ int msorb_debug_candidates(msorb_extractor* h, int image, int level, int* xyscor
  * ORBextractor.cc:149-406) and umax[16] (:453-468).  For tests that hold what the chip holds to constants recorded independently
  * of this library's sources (tests/golden/reference_constants.json).  Since ABI 6000. */
 int msorb_debug_patch_tables(msorb_extractor* h, int8_t* pattern /* 1024 */, int8_t* umax /* 16 */);
+/* The std::sort restatement of DistributeOctTree's careful loop (ORBextractor.cc:700: std::sort(vPrevSizeAndPointerToNode, compareNodes),
+ * unstable — libstdc++'s introsort decides the order of equal keys, and with it which nodes are split before the quota is reached)
+ * ALONE, as the selection kernels run it, on n <= 4000 explicit keys: frame_form != 0 the 1024-thread form of single frames
+ * (ranges of <= 64 items sorted in the lanes of one wave; | 2: without that, round 5's form), 0 the 256-thread form of batches.
+ * order[i] = input position of the item that ends at position i; sorted_keys and sort_us (the sort alone, timed on the device's
+ * constant clock) may be NULL.  Since ABI 6000. */
+int msorb_debug_std_sort(int device, const uint32_t* keys, int n, int frame_form, uint32_t* order, uint32_t* sorted_keys, float* sort_us);
 /* Host-only: DistributeOctTree (ORBextractor.cc:555-779) on explicit candidates; writes the indices of
  * the kept candidates in result order.  Needs no GPU. */
 int msorb_distribute_quadtree(const uint16_t* xs, const uint16_t* ys, const uint16_t* scores, int n, int min_x,

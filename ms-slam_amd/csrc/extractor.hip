@@ -1571,6 +1571,14 @@ int msorb_pyramid_level(msorb_extractor* h, int level, const uint8_t** data, int
     return MSORB_OK;
 }
 
+int msorb_debug_std_sort(int device, const uint32_t* keys, int n, int frame_form, uint32_t* order, uint32_t* sorted_keys, float* sort_us) {
+    if (!keys || !order || n < 0) return MSORB_E_INVALID;
+    HIPCHK(hipSetDevice(device));
+    const int rc = launch_debug_sort(keys, n, frame_form, order, sorted_keys, sort_us);
+    if (rc == MSORB_E_HIP) set_error(std::string("msorb_debug_std_sort: ") + hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
 int msorb_debug_patch_tables(msorb_extractor* h, int8_t* pattern, int8_t* umax) {
     if (!h || !pattern || !umax) return MSORB_E_INVALID;
     HIPCHK(hipSetDevice(h->device));

@@ -51,6 +51,7 @@ int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_ba
                      int lap1, int capacity, SelRec* sel, int* sel_count, int* mono, int n_images, hipStream_t s,
                      const StereoRowJob* row_job = nullptr);
 size_t quadtree_lds_bytes(const QtLevels& lv);
+int launch_debug_sort(const uint32_t* h_keys, int n, int frame_form, uint32_t* h_nodes, uint32_t* h_keys_out, float* sort_us);   // msorb_debug_std_sort
 void upload_patch_tables(const int8_t* pattern, const int* umax, hipStream_t stream);
 hipError_t download_patch_tables(int8_t* pattern /* 1024 */, int8_t* umax /* 16 */, hipStream_t stream);   // back from the device's constant memory
 // device <-> pinned-host copy by a kernel (per-frame calls; orb_kernels.hip blit16_kernel); 16-byte aligned pointers

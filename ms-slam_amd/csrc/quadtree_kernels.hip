@@ -37,11 +37,98 @@ __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
     return v;
 }
 
+// std::sort of a range of at most 64 items ENTIRELY IN THE LANES of one wave: item i of the range lives in lane i, the whole
+// recursion tree of libstdc++'s __introsort_loop is walked one LEVEL at a time — every open sub-range ("segment") of the level
+// does its median-of-three and its __unguarded_partition at once, side by side in the same instructions — and
+// __final_insertion_sort (a stable sort of every leaf, see finish_leaf) ends it.  No LDS round trip for the items, no hand-over
+// of sub-ranges between waves, no barrier: a level is ~13 crossbar operations (ds_bpermute / ds_permute: they move registers
+// between lanes through the LDS crossbar without touching LDS memory) instead of a median by lane 0 (0.4 us) + a partition
+// through position lists in LDS (0.7 us) + a queue hand-over (0.5 us) per RANGE.  Same comparison outcomes, same swaps, same
+// permutation as qt::lsort_acc (quadtree_device.h) — tests/test_quadtree_sort_gpu.py holds it to libstdc++'s std::sort.
+// Wave collective: all 64 lanes call it in convergent code.  depth0 = the introsort depth budget left for this range.
+__device__ __forceinline__ int lane_fetch(int v, int from_lane) { return __builtin_amdgcn_ds_bpermute(from_lane << 2, v); }
+__device__ __forceinline__ int lane_send(int v, int to_lane) { return __builtin_amdgcn_ds_permute(to_lane << 2, v); }
+__device__ __forceinline__ unsigned long long lanes_between(int a, int b) {   // bits a .. b-1, 0 <= a <= b <= 64
+    const unsigned long long hi = b >= 64 ? ~0ull : ((1ull << b) - 1ull);
+    return hi & ~((1ull << a) - 1ull);
+}
+__device__ void wave_introsort64(QT_LDS qt::SortItem* items, int first0, int last0, int depth0) {
+    const int lane = threadIdx.x & 63;
+    const int n = last0 - first0;
+    if (n <= 1) return;
+    const bool have = lane < n;
+    uint32_t key = 0xFFFFFFFFu, node = 0;
+    if (have) { const qt::SortItem it = items[first0 + lane]; key = it.key; node = it.node; }
+    int sf = have ? 0 : lane, sl = have ? n : lane + 1;   // the lane's segment [sf, sl) in lane coordinates; lanes past the range: one of their own
+    int depth = depth0;
+    const unsigned long long below = (1ull << lane) - 1ull, above = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
+    for (;;) {
+        bool active = sl - sf > 16;                        // while (last - first > 16)
+        if (__ballot(active) == 0) break;
+        if (__ballot(active && depth == 0)) {
+            // __partial_sort fallback of a segment whose depth budget is used up (never seen on these inputs; kept exact): through LDS,
+            // serially, by the segment's first lane; its lanes then form finished one-item segments
+            if (have) items[first0 + lane] = qt::SortItem{key, node};
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            if (active && depth == 0 && lane == sf) { qt::ArrayAcc a{items}; qt::heap_sort(a, first0 + sf, first0 + sl); }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            if (have) { const qt::SortItem it = items[first0 + lane]; key = it.key; node = it.node; }
+            if (active && depth == 0) { sf = lane; sl = lane + 1; active = false; }
+            if (__ballot(active) == 0) break;
+        }
+        --depth;
+        // __move_median_to_first(first, first + 1, mid, last - 1)
+        const int a = sf + 1, b = sf + ((sl - sf) >> 1), c = sl - 1;
+        const uint32_t ka = (uint32_t)lane_fetch((int)key, a), kb = (uint32_t)lane_fetch((int)key, b), kc = (uint32_t)lane_fetch((int)key, c);
+        int m;
+        if (ka < kb) m = kb < kc ? b : (ka < kc ? c : a);
+        else m = ka < kc ? a : (kb < kc ? c : b);
+        const uint32_t pivot = m == a ? ka : (m == b ? kb : kc);
+        int src = lane;
+        if (active) src = lane == sf ? m : (lane == m ? sf : lane);
+        key = (uint32_t)lane_fetch((int)key, src);
+        node = (uint32_t)lane_fetch((int)node, src);
+        // __unguarded_partition(first + 1, last, pivot = *first), as qt::partition_par counts it: G = positions with key >= pivot
+        // ascending, L = positions with key <= pivot descending, swap (G[t], L[t]) while G[t] < L[t]
+        const unsigned long long seg = lanes_between(sf, sl);
+        const bool in = active && lane > sf;
+        const bool is_g = in && key >= pivot, is_l = in && key <= pivot;
+        const unsigned long long bg = __ballot(is_g) & seg, bl = __ballot(is_l) & seg;
+        const int rg = __popcll(bg & below), NG = __popcll(bg), rl = __popcll(bl & above), NL = __popcll(bl);
+        // slot t of a segment's lists lives in lane sf + 1 + t; lanes with nothing to send hit their segment's first lane (never read)
+        const int G_t = lane_send(lane, is_g ? sf + 1 + rg : sf), L_t = lane_send(lane, is_l ? sf + 1 + rl : sf);
+        const int t = lane - sf - 1, T = NG < NL ? NG : NL;
+        const bool sw = in && t < T && G_t < L_t;
+        const int k = __popcll(__ballot(sw) & seg);        // G[t] < L[t] is monotone in t: the count is the number of swaps
+        const int g_k = lane_fetch(G_t, sf + 1 + k), l_k1 = lane_fetch(L_t, sf + k);
+        int cut = sl;
+        if (k < NG) cut = g_k;
+        if (k > 0 && l_k1 < cut) cut = l_k1;
+        const int part_g = lane_fetch(L_t, sf + 1 + rg), part_l = lane_fetch(G_t, sf + 1 + rl);
+        src = lane;
+        if (is_g && rg < k) src = part_g;
+        else if (is_l && rl < k) src = part_l;
+        key = (uint32_t)lane_fetch((int)key, src);
+        node = (uint32_t)lane_fetch((int)node, src);
+        if (active) { if (lane < cut) sl = cut; else sf = cut; }   // __introsort_loop(cut, last, depth); last = cut
+    }
+    // __final_insertion_sort: a stable sort of every segment (rank counting on the keys in lanes)
+    int rank = 0;
+    for (int j = 0; j < n; j++) {
+        const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, j);
+        rank += (j >= sf && j < sl) && ((kj < key) || (kj == key && j < lane));
+    }
+    const uint32_t key2 = (uint32_t)lane_send((int)key, sf + rank), node2 = (uint32_t)lane_send((int)node, sf + rank);
+    if (have) items[first0 + lane] = qt::SortItem{key2, node2};
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+}
+
 template <bool FRAME>
 struct DevExT {
     // FRAME: a 1024-thread instance that has its CU to itself (single frames); otherwise a batch instance (256 / 512 threads, several
     // workgroups per CU, register budget of 128 with 24 resident candidates per thread: only the code it runs is compiled into it)
     static constexpr bool kSplitRank = FRAME;
+    bool kLaneSort = true;   // ranges of <= 64 items finish in the lanes of one wave (wave_introsort64); false (MSORB_QT_LANE_SORT=0, an A/B switch): round 5's queue all the way down
     // std::sort restatement, data-parallel form (quadtree_device.h lsort_par), executed by wave 0 only: inside one
     // wave there is no s_barrier to pay and LDS operations complete in program order.
     struct WaveEx {
@@ -166,6 +253,13 @@ struct DevExT {
         const int ring = 2 * ps.stack_half / 3;
         int lg = 0;
         for (int t = n; t > 1; t >>= 1) lg++;
+        if (kLaneSort && n <= 64) {   // the whole sort in the lanes of wave 0: no queue, no ring, one barrier
+            if (threadIdx.x < 64) wave_introsort64(items, 0, n, 2 * lg);
+            __syncthreads();
+            mark(21);
+            mark(22);
+            return;
+        }
         if (threadIdx.x == 0) {
             stack[0] = 0; stack[1] = n; stack[2] = 2 * lg;
             ps.sc[0] = 0;
@@ -205,6 +299,11 @@ struct DevExT {
             mark(30);
             bool sorted = false;
             while (last - first > 16) {   // __introsort_loop on [first, last)
+                if (kLaneSort && last - first <= 64) {   // the rest of this range's recursion, and its leaves, in the wave's lanes
+                    wave_introsort64(items, first, last, depth);
+                    sorted = true;
+                    break;
+                }
                 if (depth == 0) {  // __partial_sort fallback (the introsort depth limit)
                     if (lane == 0) { qt::ArrayAcc a{items}; qt::heap_sort(a, first, last); }
                     wex.sync();
@@ -368,6 +467,8 @@ __device__ __forceinline__ void quadtree_select_body(const QtLevels& lv, const C
     qt::Workspace w;
     qt::workspace_carve(w, qt_mem, ws_N, ws_nini);
     DevExT<FRAME> ex;
+    ex.kLaneSort = !(debug & 0x100);
+    debug &= 0xff;
     ex.dbg = debug;
     ex.nt = nt_eff;
     int* out = sel_pt + (size_t)img * sel_stride + lv.sel_off[level];
@@ -698,10 +799,16 @@ int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_ba
     for (int l = 0; l < lv.nlevels; l++) { maxN = max(maxN, lv.quota[l]); max_ini = max(max_ini, lv.n_ini[l]); }
     const size_t lds = qt::workspace_bytes(maxN, max_ini);
 #ifdef MSORB_QT_MARKS   // profiling build (tools/qt_marks.sh): MSORB_QT_DEBUG=3 prints the per-phase timestamps of instance (0, 0)
-    static const int dbg = getenv("MSORB_QT_DEBUG") ? atoi(getenv("MSORB_QT_DEBUG")) : 0;
+    static const int dbg0 = getenv("MSORB_QT_DEBUG") ? atoi(getenv("MSORB_QT_DEBUG")) : 0;
 #else
-    const int dbg = 0;
+    const int dbg0 = 0;
 #endif
+#ifdef MSORB_AB_BUILD    // in-process A/B builds (tools/ab_inprocess.py) read the switch per call; the library proper once
+    const bool lane_sort_off = getenv("MSORB_QT_LANE_SORT") && atoi(getenv("MSORB_QT_LANE_SORT")) == 0;
+#else
+    static const bool lane_sort_off = getenv("MSORB_QT_LANE_SORT") && atoi(getenv("MSORB_QT_LANE_SORT")) == 0;
+#endif
+    const int dbg = dbg0 | (lane_sort_off ? 0x100 : 0);
     // Workgroup size by batch size: the generations are chains of dependent LDS round trips, hidden only by other
     // waves.  A big batch has other workgroups on the CU for that (256 threads: least barrier idling, best
     // throughput); a frame or two has nothing else, so the instance itself brings the waves (1024 threads).
@@ -780,6 +887,65 @@ int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_ba
     }
     return MSORB_OK;
 }
+// Test hook (msorb_debug_std_sort): the careful loop's std::sort restatement ALONE, as the selection kernels run it — FRAME: the
+// 1024-thread queue form with wave_introsort64 below 65 items; otherwise the 256-thread level-synchronous form — on explicit keys;
+// items = (key, position in the input).  The result must be the permutation libstdc++'s std::sort produces (tests/test_quadtree_sort_gpu.py).
+template <bool FRAME>
+__global__ __launch_bounds__(FRAME ? 1024 : 256) void debug_sort_kernel(const uint32_t* __restrict__ keys, int n, int m, uint32_t* __restrict__ out_key,
+                                                                        uint32_t* __restrict__ out_node, int lane_sort, long long* __restrict__ ticks) {
+    extern __shared__ __attribute__((aligned(16))) char mem[];
+    char* p = mem;
+    QT_LDS qt::SortItem* items = (QT_LDS qt::SortItem*)p; p += (size_t)(m + 4) * sizeof(qt::SortItem);
+    qt::ParScratch ps;
+    ps.tmp = (QT_LDS qt::SortItem*)p; p += (size_t)(m + 4) * sizeof(qt::SortItem);
+    ps.gpos = (QT_LDS uint16_t*)p; p += (size_t)(m + 4) * sizeof(uint16_t);
+    ps.lpos = (QT_LDS uint16_t*)p; p += (size_t)(m + 4) * sizeof(uint16_t);
+    QT_LDS int* stack = (QT_LDS int*)p; p += 2 * 3 * (size_t)qt::stack_ranges(m) * sizeof(int);
+    ps.stack_half = 3 * qt::stack_ranges(m);
+    ps.scan_tmp = (QT_LDS int*)p; p += 16 * sizeof(int);
+    ps.sc = (QT_LDS int*)p;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) items[i] = qt::SortItem{keys[i], (uint32_t)i};
+    __syncthreads();
+    DevExT<FRAME> ex;
+    ex.nt = (int)blockDim.x;
+    ex.kLaneSort = lane_sort != 0;
+    const long long t0 = wall_clock64();
+    ex.sort(items, n, stack, ps);
+    __syncthreads();
+    if (threadIdx.x == 0 && ticks) *ticks = wall_clock64() - t0;   // 100 MHz constant clock: 10 ns per tick
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { out_key[i] = items[i].key; out_node[i] = items[i].node; }
+}
+int launch_debug_sort(const uint32_t* h_keys, int n, int frame_form, uint32_t* h_nodes, uint32_t* h_keys_out, float* sort_us) {
+    if (n < 0 || n > 4000) return MSORB_E_INVALID;
+    if (n == 0) return MSORB_OK;
+    const int m = ((n + 15) & ~1) | 0;   // (m + 4 items; gpos / lpos stay 4-byte aligned for an even m)
+    const size_t lds = 2 * (size_t)(m + 4) * sizeof(qt::SortItem) + 2 * (size_t)(m + 4) * sizeof(uint16_t) +
+                       2 * 3 * (size_t)qt::stack_ranges(m) * sizeof(int) + 20 * sizeof(int) + 64;
+    uint32_t *d_in = nullptr, *d_k = nullptr, *d_n = nullptr;
+    hipError_t e = hipMalloc((void**)&d_in, 3 * (size_t)n * sizeof(uint32_t) + 16);
+    if (e != hipSuccess) return MSORB_E_HIP;
+    d_k = d_in + n; d_n = d_k + n;
+    long long* d_ticks = reinterpret_cast<long long*>(d_in + ((3 * (size_t)n + 1) & ~size_t(1)));
+    const int lane_sort = !(frame_form & 2);
+    frame_form &= 1;
+    e = hipMemcpy(d_in, h_keys, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        if (frame_form) {
+            if ((long long)lds > dynamic_lds_room(reinterpret_cast<const void*>(debug_sort_kernel<true>))) { (void)hipFree(d_in); return MSORB_E_INVALID; }
+            hipLaunchKernelGGL(debug_sort_kernel<true>, dim3(1), dim3(1024), lds, 0, d_in, n, m, d_k, d_n, lane_sort, d_ticks);
+        } else {
+            if ((long long)lds > dynamic_lds_room(reinterpret_cast<const void*>(debug_sort_kernel<false>))) { (void)hipFree(d_in); return MSORB_E_INVALID; }
+            hipLaunchKernelGGL(debug_sort_kernel<false>, dim3(1), dim3(256), lds, 0, d_in, n, m, d_k, d_n, lane_sort, d_ticks);
+        }
+        e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess) e = hipMemcpy(h_nodes, d_n, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && h_keys_out) e = hipMemcpy(h_keys_out, d_k, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && sort_us) { long long t = 0; e = hipMemcpy(&t, d_ticks, sizeof(t), hipMemcpyDeviceToHost); *sort_us = (float)t * 0.01f; }
+    (void)hipFree(d_in);
+    return e == hipSuccess ? MSORB_OK : MSORB_E_HIP;
+}
+
 size_t quadtree_lds_bytes(const QtLevels& lv) {
     int maxN = 1, max_ini = 1;
     for (int l = 0; l < lv.nlevels; l++) { maxN = max(maxN, lv.quota[l]); max_ini = max(max_ini, lv.n_ini[l]); }

@@ -29,7 +29,7 @@ EXPORTS = (
     "msorb_last_error", "msorb_device_count", "msorb_abi_version", "msorb_abi_compatible", "msorb_set_fatal_callback", "msorb_notify_fatal", "msorb_extractor_create", "msorb_extractor_destroy",
     "msorb_extractor_tables", "msorb_extractor_capacity", "msorb_extract", "msorb_pyramid_level",
     "msorb_extract_batch", "msorb_extractor_set_profiling", "msorb_extractor_set_overlap", "msorb_extractor_stage_ms", "msorb_debug_level_size",
-    "msorb_debug_copy_level", "msorb_debug_candidates", "msorb_debug_patch_tables", "msorb_distribute_quadtree", "msorb_extract_stereo",
+    "msorb_debug_copy_level", "msorb_debug_candidates", "msorb_debug_patch_tables", "msorb_debug_std_sort", "msorb_distribute_quadtree", "msorb_extract_stereo",
     "msorb_extract_stereo_split", "msorb_pyramid_batch", "msorb_stereo_matches_split", "msorb_extractor_set_host_pyramid",
     "msorb_extractor_set_semantics", "msorb_extract_pair", "msorb_stage_image", "msorb_pyramid_level_image",
 )
@@ -355,6 +355,18 @@ class ORBextractor:
         n = C.c_int()
         _check(self.L.msorb_debug_candidates(self.h, image, level, _np_ptr(buf), cap, C.byref(n)), "debug_candidates")
         return buf[:n.value].copy()
+
+
+def debug_std_sort(keys, frame_form=True, device=0, lane_sort=True, timing=False):
+    """msorb_debug_std_sort: the device's restatement of libstdc++ std::sort on uint32 keys -> (order, sorted_keys[, microseconds])."""
+    keys = np.ascontiguousarray(keys, np.uint32)
+    order, out = np.zeros(len(keys), np.uint32), np.zeros(len(keys), np.uint32)
+    L = lib()
+    L.msorb_debug_std_sort.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    us = C.c_float()
+    _check(L.msorb_debug_std_sort(device, _np_ptr(keys), len(keys), int(bool(frame_form)) | (0 if lane_sort else 2), _np_ptr(order), _np_ptr(out),
+                                  C.byref(us)), "msorb_debug_std_sort")
+    return (order, out, us.value) if timing else (order, out)
 
 
 def keypoints_from_device(d_kps, counts):

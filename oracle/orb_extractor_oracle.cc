@@ -552,6 +552,15 @@ void orc_cos_sin(float angle_deg, float* a, float* b) {
     const float r = angle_deg * orc::kFactorPI;
     *a = cosf(r); *b = sinf(r);
 }
+// libstdc++'s std::sort itself on (key, input position) items compared by key alone — the shape of ORBextractor.cc:700's
+// std::sort(vPrevSizeAndPointerToNode, compareNodes): unstable, the order of equal keys is the algorithm's.  order[i] = input
+// position of the item that ends at position i.  (tests/test_quadtree_sort_gpu.py: the device's restatement against this.)
+void orc_std_sort_order(const unsigned* keys, int n, unsigned* order) {
+    std::vector<std::pair<unsigned, unsigned>> v(n);
+    for (int i = 0; i < n; i++) v[i] = {keys[i], (unsigned)i};
+    std::sort(v.begin(), v.end(), [](const std::pair<unsigned, unsigned>& a, const std::pair<unsigned, unsigned>& b) { return a.first < b.first; });
+    for (int i = 0; i < n; i++) order[i] = v[i].second;
+}
 // quadtree alone: candidates (x,y,response) relative to min border -> kept candidates in list order
 int orc_distribute_quadtree(const float* xs, const float* ys, const float* resp, int n, int minX, int maxX, int minY,
                             int maxY, int N, float* oxs, float* oys, float* oresp, int cap) {

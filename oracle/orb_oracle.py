@@ -219,6 +219,17 @@ def cos_sin(angle_deg):
     return a.value, b.value
 
 
+def std_sort_order(keys):
+    """libstdc++ std::sort on (key, position) items compared by key only -> the input position of the item at each output position."""
+    keys = np.ascontiguousarray(keys, np.uint32)
+    order = np.zeros(len(keys), np.uint32)
+    L = lib()
+    L.orc_std_sort_order.restype = None
+    L.orc_std_sort_order.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_std_sort_order(_ptr(keys), len(keys), _ptr(order))
+    return order
+
+
 def distribute_quadtree(xs, ys, resp, minX, maxX, minY, maxY, N):
     xs, ys, resp = (np.ascontiguousarray(v, np.float32) for v in (xs, ys, resp))
     n = len(xs)
