@@ -38,6 +38,9 @@ typedef struct msorb_keypoint {
 
 const char* msorb_last_error(void);
 int msorb_device_count(void);
+/* Free / total memory of a device in bytes (hipMemGetInfo): what a long-running integration watches to see that the library's
+ * resident state — extractor handles, matcher frames, the KeyFrame store — stays bounded (tests/soak_main.cc).  Since ABI 6000. */
+int msorb_device_memory(int device, size_t* free_bytes, size_t* total_bytes);
 
 /* ABI version of the library that was loaded: MSORB_ABI_VERSION of the header it was BUILT from.  major * 1000 + minor; a new
  * minor only appends entry points (or appends `_ex` forms with more parameters), a new major changes or removes one.  The host
@@ -517,7 +520,11 @@ int msorb_kf_store_count(const msorb_kf_store* s);
 int msorb_kf_store_add(msorb_kf_store* s, int n, const msorb_keypoint* kps, const uint8_t* desc, int fv_nodes, const int* fv_node,
                        const int* fv_begin, const int* fv_feat, const float* scale_factors, const float* level_sigma2, int n_levels,
                        int* kf_id);
+/* The KeyFrame's rows and its id go back to the store: the next add takes them (first fit over the freed ranges), so that the
+ * store's footprint follows the LIVE KeyFrames of a sequence, not its length (tests/soak_main.cc).  kf_id is invalid afterwards. */
 int msorb_kf_store_remove(msorb_kf_store* s, int kf_id);
+/* Feature rows in use / reserved on the device (one row = 92 bytes over four arrays).  Since ABI 6000. */
+int msorb_kf_store_rows(const msorb_kf_store* s, size_t* rows_in_use, size_t* rows_reserved);
 
 /* msorb_search_by_bow with resident KeyFrames: kf1 = the query KeyFrame, kf2 = the train KeyFrame (KeyFrame-KeyFrame forms,
  * ORBmatcher.cc:872-1166) or -1 = the frame passed to the call (SearchByBoW(pKF, F, ...), :223-421; then every pair of the

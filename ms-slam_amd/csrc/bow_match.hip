@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
+#include <map>
 #include <mutex>
 #include <shared_mutex>
 #include <string>
@@ -650,19 +652,55 @@ extern "C" int msorb_search_for_triangulation(int device, msorb_triangulation_pa
 // device; a search then uploads only the visit / availability flags (1 B per feature), the (pair, common node) work
 // items and, for the KeyFrame-vs-Frame form, the frame; it downloads match12.
 // ------------------------------------------------------------------------------------------------------------------
+// Offsets inside one of the store's arenas (feature rows; FeatureVector entries): first fit over the free ranges, neighbours merged on
+// release, the arena's end pulled back when its last range is released.  A KeyFrame that is removed (culled, compacted by map
+// sparsification, evicted) gives its rows back — a sequence inserts and culls KeyFrames for as long as it runs (tests/soak_main.cc:
+// 268 MB after 100 000 frames when removed rows stayed allocated).
+struct RangeAlloc {
+    size_t end = 0;                    // first offset past the highest range in use
+    std::map<size_t, size_t> free_;    // offset -> length, disjoint, non-adjacent, all below `end`
+    size_t take(size_t n) {
+        if (n == 0) return 0;
+        for (auto it = free_.begin(); it != free_.end(); ++it)
+            if (it->second >= n) {
+                const size_t off = it->first, rest = it->second - n;
+                free_.erase(it);
+                if (rest) free_[off + n] = rest;
+                return off;
+            }
+        const size_t off = end;
+        end += n;
+        return off;
+    }
+    void give(size_t off, size_t n) {
+        if (n == 0) return;
+        auto nx = free_.lower_bound(off);
+        if (nx != free_.begin()) {
+            auto pv = std::prev(nx);
+            if (pv->first + pv->second == off) { off = pv->first; n += pv->second; free_.erase(pv); }
+        }
+        if (nx != free_.end() && off + n == nx->first) { n += nx->second; free_.erase(nx); }
+        if (off + n == end) end = off;
+        else free_[off] = n;
+    }
+    size_t free_total() const { size_t t = 0; for (auto& e : free_) t += e.second; return t; }
+};
+
 struct msorb_kf_store {
     int device = 0;
     mutable std::shared_mutex mu;  // searches hold it shared (the buffers must not move under a running kernel), add / remove exclusive
     struct Entry {
         bool alive = false;
-        int row0 = 0, n = 0, feat0 = 0;
+        int row0 = 0, n = 0, feat0 = 0, nfeat = 0;
         std::vector<int> node, begin;   // FeatureVector: node ids ascending, list r = feat[begin[r] .. begin[r+1]) (offsets relative to feat0)
         std::vector<int> feat;          // host copy of the lists (the rotation-histogram replay walks them)
         std::vector<float> angle;
     };
     std::vector<Entry> kf;
+    std::vector<int> dead_ids;   // indices of `kf` whose KeyFrame was removed: handed out again by the next add
     int n_alive = 0;
-    size_t rows = 0, rows_cap = 0, feats = 0, feats_cap = 0;
+    RangeAlloc rows_a, feats_a;  // which rows / FeatureVector entries of the device arrays are in use
+    size_t rows_cap = 0, feats_cap = 0;
     uint4* d_desc = nullptr;    // 2 per row
     float2* d_xy = nullptr;     // keypoint position (SearchForTriangulation, set 1)
     float4* d_tr = nullptr;     // x, y, 100 * scale[octave], sigma2[octave] (SearchForTriangulation, set 2)
@@ -736,35 +774,47 @@ extern "C" int msorb_kf_store_add(msorb_kf_store* s, int n, const msorb_keypoint
     std::unique_lock<std::shared_mutex> lk(s->mu);
     if (hipSetDevice(s->device) != hipSuccess) return MSORB_E_HIP;
     hipError_t e = hipSuccess;
+    // rows / FeatureVector entries: a free range of an earlier KeyFrame first, the end of the arena otherwise
+    const size_t used_rows = s->rows_a.end, used_feats = s->feats_a.end;   // what a reallocation has to carry over
+    const size_t row0 = s->rows_a.take((size_t)n), feat0 = s->feats_a.take((size_t)nf);
     size_t cap2 = s->rows_cap, cap3 = s->rows_cap, cap1 = s->rows_cap, cap4 = s->rows_cap;
-    e = grow(s->d_desc, s->rows, cap1, s->rows + n, 2);
-    if (e == hipSuccess) e = grow(s->d_xy, s->rows, cap2, s->rows + n, 1);
-    if (e == hipSuccess) e = grow(s->d_tr, s->rows, cap3, s->rows + n, 1);
-    if (e == hipSuccess) e = grow(s->d_angle, s->rows, cap4, s->rows + n, 1);
+    e = grow(s->d_desc, used_rows, cap1, s->rows_a.end, 2);
+    if (e == hipSuccess) e = grow(s->d_xy, used_rows, cap2, s->rows_a.end, 1);
+    if (e == hipSuccess) e = grow(s->d_tr, used_rows, cap3, s->rows_a.end, 1);
+    if (e == hipSuccess) e = grow(s->d_angle, used_rows, cap4, s->rows_a.end, 1);
     if (e == hipSuccess) s->rows_cap = std::min(std::min(cap1, cap4), std::min(cap2, cap3));
-    if (e == hipSuccess) e = grow(s->d_feat, s->feats, s->feats_cap, s->feats + nf, 1);
-    if (e == hipSuccess && n) e = hipMemcpy(s->d_desc + 2 * s->rows, desc, (size_t)n * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess && n) e = hipMemcpy(s->d_xy + s->rows, xy.data(), (size_t)n * 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess && n) e = hipMemcpy(s->d_tr + s->rows, tr.data(), (size_t)n * 16, hipMemcpyHostToDevice);
-    if (e == hipSuccess && nf) e = hipMemcpy(s->d_feat + s->feats, fv_feat + f_lo, (size_t)nf * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = grow(s->d_feat, used_feats, s->feats_cap, s->feats_a.end, 1);
+    if (e == hipSuccess && n) e = hipMemcpy(s->d_desc + 2 * row0, desc, (size_t)n * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n) e = hipMemcpy(s->d_xy + row0, xy.data(), (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n) e = hipMemcpy(s->d_tr + row0, tr.data(), (size_t)n * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nf) e = hipMemcpy(s->d_feat + feat0, fv_feat + f_lo, (size_t)nf * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess && n) {
         std::vector<float> ang(n);
         for (int i = 0; i < n; i++) ang[i] = kps[i].angle;
-        e = hipMemcpy(s->d_angle + s->rows, ang.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+        e = hipMemcpy(s->d_angle + row0, ang.data(), (size_t)n * 4, hipMemcpyHostToDevice);
     }
-    if (e != hipSuccess) { set_last_error(std::string("kf_store_add: ") + hipGetErrorString(e)); return MSORB_E_HIP; }
+    if (e != hipSuccess) {
+        s->rows_a.give(row0, (size_t)n); s->feats_a.give(feat0, (size_t)nf);
+        set_last_error(std::string("kf_store_add: ") + hipGetErrorString(e));
+        return MSORB_E_HIP;
+    }
     msorb_kf_store::Entry E;
-    E.alive = true; E.row0 = (int)s->rows; E.n = n; E.feat0 = (int)s->feats;
+    E.alive = true; E.row0 = (int)row0; E.n = n; E.feat0 = (int)feat0; E.nfeat = nf;
     E.node.assign(fv_node, fv_node + fv_nodes);
     E.begin.resize(fv_nodes + 1);
     for (int r = 0; r <= fv_nodes; r++) E.begin[r] = (fv_nodes ? fv_begin[r] : 0) - f_lo;
     E.feat.assign(fv_feat + f_lo, fv_feat + f_hi);
     E.angle.resize(n);
     for (int i = 0; i < n; i++) E.angle[i] = kps[i].angle;
-    s->rows += n; s->feats += nf;
-    s->kf.push_back(std::move(E));
     s->n_alive++;
-    *kf_id = (int)s->kf.size() - 1;
+    if (!s->dead_ids.empty()) {   // ids of removed KeyFrames come back: the table does not grow with the length of the sequence
+        *kf_id = s->dead_ids.back();
+        s->dead_ids.pop_back();
+        s->kf[*kf_id] = std::move(E);
+    } else {
+        s->kf.push_back(std::move(E));
+        *kf_id = (int)s->kf.size() - 1;
+    }
     return MSORB_OK;
 }
 
@@ -772,9 +822,23 @@ extern "C" int msorb_kf_store_remove(msorb_kf_store* s, int kf_id) {
     if (!s) return MSORB_E_INVALID;
     std::unique_lock<std::shared_mutex> lk(s->mu);
     if (kf_id < 0 || kf_id >= (int)s->kf.size() || !s->kf[kf_id].alive) { set_last_error("kf_store_remove: unknown KeyFrame id"); return MSORB_E_INVALID; }
-    s->kf[kf_id].alive = false;  // its rows stay allocated (a culled KeyFrame is ~100 KB; ids stay stable)
-    s->kf[kf_id].node.clear(); s->kf[kf_id].begin.assign(1, 0); s->kf[kf_id].angle.clear(); s->kf[kf_id].feat.clear();
+    msorb_kf_store::Entry& E = s->kf[kf_id];
+    E.alive = false;
+    s->rows_a.give((size_t)E.row0, (size_t)E.n);       // the rows and the id are free for the next add (no kernel is running: the lock is exclusive)
+    s->feats_a.give((size_t)E.feat0, (size_t)E.nfeat);
+    E.n = 0; E.nfeat = 0;
+    std::vector<int>().swap(E.node); E.begin.assign(1, 0); std::vector<float>().swap(E.angle); std::vector<int>().swap(E.feat);
+    s->dead_ids.push_back(kf_id);
     s->n_alive--;
+    return MSORB_OK;
+}
+
+// Rows of the device arrays in use / reserved (rows of 64 + 8 + 16 + 4 bytes): a store's footprint for long-run checks.
+extern "C" int msorb_kf_store_rows(const msorb_kf_store* s, size_t* rows_in_use, size_t* rows_reserved) {
+    if (!s || !rows_in_use || !rows_reserved) return MSORB_E_INVALID;
+    std::shared_lock<std::shared_mutex> lk(s->mu);
+    *rows_in_use = s->rows_a.end - s->rows_a.free_total();
+    *rows_reserved = s->rows_cap;
     return MSORB_OK;
 }
 

@@ -799,6 +799,13 @@ int msorb_device_count(void) {
     return n;
 }
 
+int msorb_device_memory(int device, size_t* free_bytes, size_t* total_bytes) {
+    if (!free_bytes || !total_bytes) return MSORB_E_INVALID;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemGetInfo(free_bytes, total_bytes));
+    return MSORB_OK;
+}
+
 int msorb_extractor_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, int device,
                            msorb_extractor** out) {
     if (!out) return MSORB_E_INVALID;

@@ -92,6 +92,14 @@ namespace msorb_host {
 void ForgetKeyFrame(unsigned long mnId) { keyframe_store().Forget(mnId); }
 void ResetKeyFrames() { keyframe_store().Reset(); }
 size_t ResidentKeyFrames() { return keyframe_store().Resident(); }
+size_t ResidentKeyFrameBytes() { return keyframe_store().ResidentBytes(); }
+void SetKeyFrameBudget(size_t max_keyframes, size_t max_bytes) { keyframe_store().SetBudget(max_keyframes, max_bytes); }
+void KeyFrameStoreStats(unsigned long long* uploads, unsigned long long* expired, unsigned long long* evicted) {
+    const auto c = keyframe_store().Stats();
+    if (uploads) *uploads = c.adds;
+    if (expired) *expired = c.expired;
+    if (evicted) *evicted = c.evicted;
+}
 void ReleaseThread() { drop_thread_cache(); }
 void Shutdown() {
     drop_thread_cache();

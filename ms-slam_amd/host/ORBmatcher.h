@@ -89,20 +89,24 @@ protected:
 
 }  // namespace ORB_SLAM3
 
-// Lifetime hooks of the device-side state behind the class (ORBmatcher.cc).  The matcher keeps KeyFrames resident on the GPU
-// from their first BoW-node search on; the reference has no place that tells it when one dies, so the code around it does
-// ("Lifetime hooks"; each is one line in the reference's sources):
-//   KeyFrame::SetBadFlag (KeyFrame.cc)                      ORB_SLAM3::msorb_host::ForgetKeyFrame(mnId);
-//   Tracking::Reset / ResetActiveMap (Tracking.cc:3848)     ORB_SLAM3::msorb_host::ResetKeyFrames();   // KeyFrame::nNextId restarts at 0
-//   System::Shutdown (System.cc), after the threads joined  ORB_SLAM3::msorb_host::Shutdown();         // frees while the HIP runtime is alive
-//   a worker thread that stops using the matcher            ORB_SLAM3::msorb_host::ReleaseThread();    // its four device frames
-// Without the first two the store still answers correctly (entries are checked against the KeyFrame object's identity,
-// mbSparsified and N) but dead KeyFrames stay resident until Shutdown().
+// Lifetime of the device-side state behind the class (ORBmatcher.cc).  The matcher keeps KeyFrames resident on the GPU from
+// their first BoW-node search on.  NO edit of the reference's sources is needed to keep that bounded: MS-SLAM holds every KeyFrame
+// in a std::shared_ptr (include/ORBmatcher.h:47-96), the store watches each resident KeyFrame through a std::weak_ptr and drops
+// the entry once the object is gone (KeyFrame::SetBadFlag -> the map erases it -> the last shared_ptr goes: KeyFrame.cc:311-361,
+// LocalMapping.cc KeyFrameCulling), and SetKeyFrameBudget() caps what may stay (least recently searched first).  The hooks
+// below are accelerators and housekeeping, each one line where it is used ("Lifetime"):
+//   KeyFrame::SetBadFlag (KeyFrame.cc)                      ORB_SLAM3::msorb_host::ForgetKeyFrame(mnId);   // frees the slot at once instead of at the next add
+//   Tracking::Reset / ResetActiveMap (Tracking.cc:3848)     ORB_SLAM3::msorb_host::ResetKeyFrames();       // (entries of dead objects go by themselves; this frees them at once)
+//   System::Shutdown (System.cc), after the threads joined  ORB_SLAM3::msorb_host::Shutdown();             // frees while the HIP runtime is alive
+//   a worker thread that stops using the matcher            ORB_SLAM3::msorb_host::ReleaseThread();        // its four device frames
 namespace ORB_SLAM3 {
 namespace msorb_host {
 void ForgetKeyFrame(unsigned long mnId);
 void ResetKeyFrames();
-size_t ResidentKeyFrames();
+size_t ResidentKeyFrames();                                          // live entries (dead KeyFrames are swept before counting)
+size_t ResidentKeyFrameBytes();                                      // estimate of the device memory behind them
+void SetKeyFrameBudget(size_t max_keyframes, size_t max_bytes);     // 0 = unlimited (default): beyond it the least recently searched leave
+void KeyFrameStoreStats(unsigned long long* uploads, unsigned long long* expired, unsigned long long* evicted);   // since the process started; NULL = skip
 void ReleaseThread();
 void Shutdown();
 }  // namespace msorb_host

@@ -889,14 +889,36 @@ int SearchForTriangulation(const KeyFramePtr& pKF1, const KeyFramePtr& pKF2, std
 
 // ---- resident KeyFrames ------------------------------------------------------------------------------------------
 // msorb_kf_store behind the reference's types: a KeyFrame enters the store the first time it is searched (its features are
-// fixed once ComputeBoW has run) and stays until Forget() (KeyFrame::SetBadFlag) — or until map sparsification compacts it
-// (mbSparsified flips, N shrinks: re-added under a new id).  The searches below then move one flag byte per feature per
-// call instead of both KeyFrames: 0.12-0.15 ms instead of 0.65-1.1 ms for 16 neighbours / 32 candidates (profiles/).
+// fixed once ComputeBoW has run) and leaves it
+//   * when the KeyFrame object dies: MS-SLAM holds its KeyFrames in std::shared_ptr everywhere (include/ORBmatcher.h:47-96 — the
+//     fork's defining change), so a slot keeps a std::weak_ptr to its KeyFrame and is dropped once that has expired (checked
+//     on every add and on Resident(); no edit of the reference's sources is needed for this);
+//   * when the optional budget is exceeded (SetBudget: resident KeyFrames / estimated device bytes): least recently searched
+//     first; an evicted KeyFrame that is searched again is simply uploaded again;
+//   * on Forget() (a one-line hook in KeyFrame::SetBadFlag: frees the slot at the moment of culling instead of at the next
+//     add), Reset() and Shutdown();
+//   * when map sparsification compacts it (mbSparsified flips, N shrinks: re-added under a new id).
+// The searches below then move one flag byte per feature per call instead of both KeyFrames: 0.12-0.15 ms instead of
+// 0.65-1.1 ms for 16 neighbours / 32 candidates (profiles/).
+namespace detail {
+// the owner a slot watches: a weak reference for std::shared_ptr<KeyFrame>, nothing for other pointer types (raw KeyFrame*:
+// upstream ORB-SLAM3 — there the hooks are the only way out)
+template <class P> struct OwnerOf {
+    static constexpr bool tracked = false;
+    static std::weak_ptr<const void> get(const P&) { return {}; }
+};
+template <class T> struct OwnerOf<std::shared_ptr<T>> {
+    static constexpr bool tracked = true;
+    static std::weak_ptr<const void> get(const std::shared_ptr<T>& p) { return std::weak_ptr<const void>(std::shared_ptr<const void>(p)); }
+};
+inline bool same_owner(const std::weak_ptr<const void>& a, const std::weak_ptr<const void>& b) { return !a.owner_before(b) && !b.owner_before(a); }
+}  // namespace detail
+
 class KeyFrameStore {
 public:
     // One resident KeyFrame.  A search holds a Lease (shared ownership) from Ensure() until its kernels have returned: the
-    // device rows are removed when the LAST holder lets go — a re-add after map sparsification, Forget() or Reset() on
-    // another thread only drops the table's reference, it never pulls an id out from under a running search.
+    // device rows are removed when the LAST holder lets go — a re-add after map sparsification, an eviction, Forget() or Reset()
+    // on another thread only drops the table's reference, it never pulls an id out from under a running search.
     struct Handle {  // the C handle; shared with the slots so that a lease that outlives Shutdown() never touches a freed store
         msorb_kf_store* h = nullptr;
         ~Handle() { if (h) msorb_kf_store_destroy(h); }
@@ -907,6 +929,11 @@ public:
         const void* identity;  // the KeyFrame object: mnId alone is not an identity (KeyFrame::nNextId restarts at 0 in Tracking::Reset)
         bool sparsified;
         int n;
+        bool tracked = false;                // owner is meaningful (the caller holds its KeyFrames in std::shared_ptr)
+        std::weak_ptr<const void> owner;     // the KeyFrame object's ownership group: expired = the KeyFrame is gone; and the exact
+                                             // identity test (a new object at a recycled address has another control block)
+        size_t bytes = 0;                    // estimate of the device memory behind the slot
+        unsigned long long last_use = 0;     // tick of the last Ensure() that returned it (guarded by the store's mutex)
         ~Slot() { if (store && store->h && id >= 0) msorb_kf_store_remove(store->h, id); }
     };
     using Lease = std::shared_ptr<Slot>;
@@ -922,13 +949,20 @@ public:
     // and finds the first one's slot.
     template <class KeyFramePtr>
     Lease Ensure(const KeyFramePtr& pKF) {
+        using Owner = detail::OwnerOf<KeyFramePtr>;
         const int n = pKF->GetN();
         const void* identity = static_cast<const void*>(&*pKF);
+        const std::weak_ptr<const void> owner = Owner::get(pKF);
         std::lock_guard<std::mutex> lk(mu_);
         if (!h_) throw std::runtime_error("msorb KeyFrameStore used after Shutdown()");
         auto it = ids_.find(pKF->mnId);
-        if (it != ids_.end() && it->second->identity == identity && it->second->sparsified == pKF->mbSparsified && it->second->n == n)
+        if (it != ids_.end() && it->second->identity == identity && it->second->sparsified == pKF->mbSparsified && it->second->n == n &&
+            (!Owner::tracked || !it->second->tracked || detail::same_owner(it->second->owner, owner))) {
+            it->second->last_use = ++tick_;
             return it->second;
+        }
+        sweep_expired_locked();   // an add is the moment the store grows: dead KeyFrames leave first
+        stats_.adds++;
         BowSide side;
         side.FillKeyFrame(pKF);
         const auto keys = pKF->GetAllKeyUn();
@@ -939,33 +973,81 @@ public:
                                  pKF->mvLevelSigma2.data(), (int)pKF->mvScaleFactors.size(), &id),
               "msorb_kf_store_add");
         Lease slot(new Slot{h_, id, identity, (bool)pKF->mbSparsified, n});
-        ids_[pKF->mnId] = slot;  // the compacted / recycled predecessor loses the table's reference; running searches keep theirs
+        slot->tracked = Owner::tracked;
+        slot->owner = owner;
+        slot->bytes = (size_t)n * (32 + sizeof(msorb_keypoint) + 8) + side.node.size() * 8 + side.feat.size() * 4;
+        slot->last_use = ++tick_;
+        auto old = ids_.find(pKF->mnId);
+        if (old != ids_.end()) bytes_ -= old->second->bytes;   // the compacted / recycled predecessor loses the table's reference; running searches keep theirs
+        ids_[pKF->mnId] = slot;
+        bytes_ += slot->bytes;
+        enforce_budget_locked(slot.get());
         return slot;
     }
-    void Forget(unsigned long mnId) {  // KeyFrame::SetBadFlag
+    void Forget(unsigned long mnId) {  // KeyFrame::SetBadFlag (optional hook: frees the slot at once)
         std::lock_guard<std::mutex> lk(mu_);
-        ids_.erase(mnId);
+        auto it = ids_.find(mnId);
+        if (it != ids_.end()) { bytes_ -= it->second->bytes; ids_.erase(it); }
     }
     void Reset() {  // Tracking::Reset / ResetActiveMap: KeyFrame ids start again at 0
         std::lock_guard<std::mutex> lk(mu_);
         ids_.clear();
+        bytes_ = 0;
     }
-    size_t Resident() {
+    // Upper bounds on what stays resident (0 = unlimited, the default): beyond them the least recently searched KeyFrames leave.
+    void SetBudget(size_t max_keyframes, size_t max_bytes) {
         std::lock_guard<std::mutex> lk(mu_);
+        max_kfs_ = max_keyframes; max_bytes_ = max_bytes;
+        enforce_budget_locked(nullptr);
+    }
+    size_t Resident() {   // live entries: KeyFrames that have died since the last add are swept first
+        std::lock_guard<std::mutex> lk(mu_);
+        sweep_expired_locked();
         return ids_.size();
+    }
+    size_t ResidentBytes() {
+        std::lock_guard<std::mutex> lk(mu_);
+        sweep_expired_locked();
+        return bytes_;
+    }
+    struct Counters { unsigned long long adds = 0, expired = 0, evicted = 0; };
+    Counters Stats() {
+        std::lock_guard<std::mutex> lk(mu_);
+        return stats_;
     }
     // System::Shutdown: free the device side while the HIP runtime is still alive.  The C handle goes when its last holder
     // does — here, unless a lease is still out (there should be none: the worker threads have been joined).
     void Shutdown() {
         std::lock_guard<std::mutex> lk(mu_);
         ids_.clear();
+        bytes_ = 0;
         h_.reset();
     }
 
 private:
+    void sweep_expired_locked() {
+        for (auto it = ids_.begin(); it != ids_.end();) {
+            if (it->second->tracked && it->second->owner.expired()) { bytes_ -= it->second->bytes; it = ids_.erase(it); stats_.expired++; }
+            else ++it;
+        }
+    }
+    void enforce_budget_locked(const Slot* keep) {
+        while ((max_kfs_ && ids_.size() > max_kfs_) || (max_bytes_ && bytes_ > max_bytes_)) {
+            auto victim = ids_.end();
+            for (auto it = ids_.begin(); it != ids_.end(); ++it)
+                if (it->second.get() != keep && (victim == ids_.end() || it->second->last_use < victim->second->last_use)) victim = it;
+            if (victim == ids_.end()) break;   // only the entry just added is left
+            bytes_ -= victim->second->bytes;
+            ids_.erase(victim);
+            stats_.evicted++;
+        }
+    }
     std::shared_ptr<Handle> h_;
     std::mutex mu_;
     std::unordered_map<unsigned long, Lease> ids_;
+    size_t bytes_ = 0, max_kfs_ = 0, max_bytes_ = 0;
+    unsigned long long tick_ = 0;
+    Counters stats_;
 };
 
 // SearchForTriangulationBatch with the KeyFrames resident (same results)

@@ -26,7 +26,7 @@ OK, E_INVALID, E_NO_DEVICE, E_HIP, E_CAPACITY, E_GEOMETRY, E_EMPTY = 0, -1, -2, 
 ABI_VERSION = 6000   # MSORB_ABI_VERSION of the include/msorb.h this mirror was written against (tests hold the two together)
 
 EXPORTS = (
-    "msorb_last_error", "msorb_device_count", "msorb_abi_version", "msorb_abi_compatible", "msorb_set_fatal_callback", "msorb_notify_fatal", "msorb_extractor_create", "msorb_extractor_destroy",
+    "msorb_last_error", "msorb_device_count", "msorb_device_memory", "msorb_abi_version", "msorb_abi_compatible", "msorb_set_fatal_callback", "msorb_notify_fatal", "msorb_extractor_create", "msorb_extractor_destroy",
     "msorb_extractor_tables", "msorb_extractor_capacity", "msorb_extract", "msorb_pyramid_level",
     "msorb_extract_batch", "msorb_extractor_set_profiling", "msorb_extractor_set_overlap", "msorb_extractor_stage_ms", "msorb_debug_level_size",
     "msorb_debug_copy_level", "msorb_debug_candidates", "msorb_debug_patch_tables", "msorb_debug_std_sort", "msorb_distribute_quadtree", "msorb_extract_stereo",
@@ -930,7 +930,7 @@ def search_for_triangulation(pairs, coarse=False, check_orientation=True, device
 
 
 EXPORTS = EXPORTS + ("msorb_kf_store_create", "msorb_kf_store_destroy", "msorb_kf_store_count", "msorb_kf_store_add",
-                     "msorb_kf_store_remove", "msorb_search_by_bow_kf", "msorb_search_for_triangulation_kf")
+                     "msorb_kf_store_remove", "msorb_kf_store_rows", "msorb_search_by_bow_kf", "msorb_search_for_triangulation_kf")
 
 
 class BowKfPair(C.Structure):
@@ -984,7 +984,15 @@ class KeyFrameStore:
 
     def remove(self, kf_id):
         self.L.msorb_kf_store_remove.argtypes = [C.c_void_p, C.c_int]
-        _check(self.L.msorb_kf_store_remove(self.h, kf_id), "msorb_kf_store_remove")   # (self.n keeps the size: ids are never reused)
+        _check(self.L.msorb_kf_store_remove(self.h, kf_id), "msorb_kf_store_remove")   # (the id and its rows go to the next add, which
+        # overwrites self.n[id]; until then the stale size lets a search on the dead id reach the library, which refuses it)
+
+    def rows(self):
+        """(feature rows in use, rows reserved on the device)"""
+        a, b = C.c_size_t(), C.c_size_t()
+        self.L.msorb_kf_store_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(self.L.msorb_kf_store_rows(self.h, C.byref(a), C.byref(b)), "msorb_kf_store_rows")
+        return a.value, b.value
 
     def search_by_bow(self, pairs, frame=None, th_low=50, inclusive=True, nnratio=0.7, check_orientation=True):
         """pairs: dicts kf1, kf2 (or -1 with `frame`), valid1, avail2 (or None).  frame: dict desc, fv, angle.

@@ -97,3 +97,48 @@ def test_search_for_triangulation_resident_equals_per_call():
         assert one[0][0] == nm and one[0][1].tolist() == m12.tolist()
     finally:
         st.close()
+
+
+def test_removed_keyframes_give_their_rows_and_ids_back():
+    """A sequence adds and removes KeyFrames for as long as it runs (culling, sparsification re-adds, evictions): the store's
+    footprint must follow the live set.  Rounds of add / remove / add with mixed sizes: rows reserved stay where the first round
+    left them, ids are reused, searches on the survivors keep their results, and a search on a removed id is refused."""
+    import msorb
+    rng = np.random.default_rng(9)
+    pairs = [bmc.make_pair(700 + i, n1=600 + 97 * (i % 7), n2=900, n_nodes=40) for i in range(24)]
+    frame = dict(desc=pairs[0]["desc2"], fv=pairs[0]["fv2"], angle=pairs[0]["angle2"])
+    st = msorb.KeyFrameStore()
+    try:
+        def add(i):
+            p = pairs[i]
+            return st.add(_kps(len(p["desc1"]), p["angle1"]), p["desc1"], p["fv1"], SCALE, SIGMA2)
+
+        def search(kid, i):
+            (r,), _ = st.search_by_bow([dict(kf1=kid, kf2=-1, valid1=pairs[i]["valid1"])], frame, 50, True, 0.7, True)
+            return r[0], r[2].copy()
+        live = {i: add(i) for i in range(24)}
+        want = {i: search(live[i], i) for i in range(24)}
+        used0, reserved0 = st.rows()
+        assert used0 == sum(len(pairs[i]["desc1"]) for i in range(24)) and reserved0 >= used0
+        max_id = max(live.values())
+        for rnd in range(30):
+            out = [int(i) for i in rng.choice(sorted(live), 9, replace=False)]
+            dead = {i: live.pop(i) for i in out}
+            for kid in dead.values():
+                st.remove(kid)
+            assert st.count() == len(live)
+            with pytest.raises(msorb.MsorbError):
+                search(dead[out[0]], out[0])                       # a removed id is unknown to the store
+            for i in rng.permutation(out):
+                live[int(i)] = add(int(i))                         # (another order than they were removed in: other ranges)
+            assert max(live.values()) <= max_id, "ids of removed KeyFrames were not reused"
+            used, reserved = st.rows()
+            assert used == used0 and reserved == reserved0, f"round {rnd}: {used} rows in use, {reserved} reserved (was {reserved0})"
+            for i in (out[0], out[-1], sorted(live)[0]):
+                n, m21 = search(live[i], i)
+                assert n == want[i][0] and np.array_equal(m21, want[i][1])
+        for kid in live.values():
+            st.remove(kid)
+        assert st.count() == 0 and st.rows()[0] == 0
+    finally:
+        st.close()
