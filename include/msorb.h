@@ -293,6 +293,23 @@ int msorb_search_by_projection_mps(msorb_frame* f, int m, const uint8_t* track_i
                                    const float* view_cos, const uint8_t* mp_desc, const int* obs, int* frame_mp,
                                    float th, int far_points, float th_far_points, float nnratio, int* nmatches);
 
+/* The same search on a TWO-CAMERA frame (F.Nleft != -1, the KannalaBrandt8 stereo rig): ORBmatcher.cc:43-213 with both arms —
+ * per map point a left pass (:61-142; no mvuRight test for such a frame, :92) and a right pass (:144-210; radius not scaled by th,
+ * no mbSparsified bypass), coupled through mvLeftToRightMatch / mvRightToLeftMatch (a match on one side also claims the stereo
+ * partner on the other, :130-134 / :196-200) and through the `continue` of a failed left ratio test (:125-126: no right pass for
+ * that point).  `left` / `right`: two msorb_frame handles on one device, set from F.mvKeys[0, Nleft) / F.mvKeysRight with their
+ * descriptor rows and WITHOUT mvuRight (what Frame::GetFeaturesInArea(..., bRight) walks, Frame.cc:589-655).  The table has, beside
+ * the entries of msorb_search_by_projection_mps, the right camera's scratch: track_in_view_r=mbTrackInViewR,
+ * proj_xr / proj_yr=mTrackProjXR / mTrackProjYR, level_r=mnTrackScaleLevelR (-1: no right pass), view_cos_r=mTrackViewCosR.
+ * left_to_right[n_left] / right_to_left[n_right] = F.mvLeftToRightMatch / F.mvRightToLeftMatch (-1 none).
+ * frame_mp[n_left + n_right] = F.mvpMapPoints as table indices, updated in place.  Since ABI 6000. */
+int msorb_search_by_projection_mps_rig(msorb_frame* left, msorb_frame* right, int m, const uint8_t* track_in_view,
+                                       const uint8_t* track_in_view_r, const uint8_t* bad, const uint8_t* sparsified, const float* proj_x,
+                                       const float* proj_y, const float* proj_xr, const float* proj_yr, const float* track_depth,
+                                       const int* level, const int* level_r, const float* view_cos, const float* view_cos_r,
+                                       const uint8_t* mp_desc, const int* obs, const int* left_to_right, const int* right_to_left,
+                                       int* frame_mp, float th, int far_points, float th_far_points, float nnratio, int* nmatches);
+
 /* The window search on its own, for the SearchByProjection variants that keep their accept rules in the caller
  * (KeyFrame / Sim3 / relocalisation forms, ORBmatcher.cc:423-753, 2154-2275): for each query the 4 nearest
  * descriptors among GetFeaturesInArea(x, y, r, min_level, max_level) in the reference's scan order (ties ->

@@ -204,6 +204,201 @@ int msorb_search_by_projection_mps(msorb_frame* f, int M, const uint8_t* track_i
     return rc;
 }
 
+// ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint>&, th, bFarPoints, thFarPoints) on a TWO-CAMERA frame (F.Nleft != -1:
+// the KannalaBrandt8 stereo rig), ORBmatcher.cc:43-213 with both arms: per map point a LEFT pass (mbTrackInView: window in the left
+// camera's grid, best / second over the left keypoints, :61-142) and a RIGHT pass (mbTrackInViewR: window in the right camera's grid,
+// :144-210).  The two cameras are two device frames (left: F.mvKeys[0, Nleft), right: F.mvKeysRight — what Frame::GetFeaturesInArea
+// walks for such a frame, Frame.cc:589-655 with bRight); F.mvpMapPoints is one array of n_left + n_right entries.  What couples
+// the passes, all replayed here in map-point order:
+//   * a left match also claims the right keypoint it is stereo-matched with (mvLeftToRightMatch, :130-134), a right match the left
+//     one (mvRightToLeftMatch, :196-200): the occupancy each LATER map point sees on either side;
+//   * a left pass that fails its ratio test `continue`s the map-point loop (:125-126): the right pass of that point is skipped;
+//   * the right pass does not scale its radius by th (:148) and has no mbSparsified bypass (:169-171).
+// Both device searches run against occupancy snapshots; the replay drops candidates claimed since and re-runs a side from the first
+// query whose list is exhausted (run_window_search's rule, per side).
+namespace {
+struct RigSide {
+    msorb_frame* f = nullptr;
+    std::vector<WinQuery> q;
+    std::vector<uint8_t> occ, snap;
+    std::vector<int8_t> diff;   // occupancy now vs the snapshot the side's lists were computed against
+    int n_freed = 0, next = 0, fresh_from = 0, lanes = 16, rounds = 0;
+    uint8_t* h_occ = nullptr;
+    int prepare(int M, const uint8_t* mp_desc) {   // queries + query descriptors to the device, once
+        int rc;
+        if ((rc = f->d_q.ensure(M)) || (rc = f->d_qdesc.ensure((size_t)M * 32)) || (rc = f->d_topk.ensure(M)) || (rc = f->d_occ.ensure(std::max(f->N, 1))))
+            return rc;
+        const size_t qb = (size_t)M * sizeof(WinQuery), db = (size_t)M * 32;
+        if ((rc = f->h_in.ensure(qb + db + (size_t)f->N + 64)) || (rc = f->h_topk.ensure(M))) return rc;
+        double sum = 0;
+        int nv = 0;
+        for (int i = 0; i < M; i++)
+            if (q[i].flags & kQValid) { sum += q[i].r; nv++; }
+        if (nv) lanes = window_lanes_for((float)(sum / nv), f->gridWInv, f->gridHInv);
+        std::memcpy(f->h_in.p, q.data(), qb);
+        std::memcpy(f->h_in.p + qb, mp_desc, db);
+        HIPCHK(small_copy(f->d_q.p, f->h_in.p, qb, hipMemcpyHostToDevice, f->stream));
+        HIPCHK(small_copy(f->d_qdesc.p, f->h_in.p + qb, db, hipMemcpyHostToDevice, f->stream));
+        h_occ = f->h_in.p + qb + db;
+        diff.assign(f->N, 0);
+        return MSORB_OK;
+    }
+    int round(int M) {   // the side's lists for queries [next, M) against its occupancy as it is now
+        if (f->N > 0 && next < M) {
+            std::memcpy(h_occ, occ.data(), f->N);
+            HIPCHK(small_copy(f->d_occ.p, h_occ, f->N, hipMemcpyHostToDevice, f->stream));
+            launch_window_topk(f->view(), f->d_q.p, f->d_qdesc.p, next, M, f->d_topk.p, f->stream, 1, 0, 0, nullptr, lanes);
+            HIPCHK(small_copy(f->h_topk.p + next, f->d_topk.p + next, (size_t)(M - next) * sizeof(TopK), hipMemcpyDeviceToHost, f->stream));
+            HIPCHK(hipStreamSynchronize(f->stream));
+        }
+        snap = occ;
+        std::fill(diff.begin(), diff.end(), 0);
+        n_freed = 0;
+        fresh_from = next;
+        rounds++;
+        return MSORB_OK;
+    }
+    void set_occ(int idx, int v) {
+        occ[idx] = (uint8_t)v;
+        const int8_t d = (int8_t)((int)occ[idx] - (int)snap[idx]);
+        if (diff[idx] < 0) n_freed--;
+        diff[idx] = d;
+        if (d < 0) n_freed++;
+    }
+    // the exact candidate prefix of query qi (>= need entries unless the true candidate set is smaller); false: the list cannot be
+    // trusted any more (exhausted by claims, or a keypoint was freed): the side needs a new round from qi
+    bool prefix(int qi, int need, int* idx, int* dist, int* n_out) const {
+        const bool skip = q[qi].flags & kQSkipOccupied;
+        if (f->N <= 0) { *n_out = 0; return true; }
+        if (skip && n_freed > 0 && qi > fresh_from) return false;
+        const TopK& t = f->h_topk.p[qi];
+        int n = 0, n_dev = 0;
+        for (int k = 0; k < kTopK; k++) {
+            if (t.idx[k] < 0) break;
+            n_dev++;
+            if (skip && diff[t.idx[k]] > 0) continue;
+            idx[n] = t.idx[k]; dist[n] = t.dist[k]; n++;
+        }
+        if (n < need && n < n_dev && n_dev == kTopK && qi > fresh_from) return false;
+        *n_out = n;
+        return true;
+    }
+};
+}  // namespace
+
+int msorb_search_by_projection_mps_rig(msorb_frame* left, msorb_frame* right, int M, const uint8_t* track_in_view, const uint8_t* track_in_view_r,
+                                       const uint8_t* bad, const uint8_t* sparsified, const float* proj_x, const float* proj_y,
+                                       const float* proj_xr, const float* proj_yr, const float* track_depth, const int* level, const int* level_r,
+                                       const float* view_cos, const float* view_cos_r, const uint8_t* mp_desc, const int* obs,
+                                       const int* left_to_right, const int* right_to_left, int* frame_mp, float th, int far_points, float th_far,
+                                       float nnratio, int* nmatches) {
+    if (!left || !right || M < 0 || !nmatches ||
+        (M > 0 && (!track_in_view || !track_in_view_r || !bad || !sparsified || !proj_x || !proj_y || !proj_xr || !proj_yr || !track_depth || !level ||
+                   !level_r || !view_cos || !view_cos_r || !mp_desc || !obs)) ||
+        (left->N + right->N > 0 && !frame_mp) || (left->N > 0 && !left_to_right) || (right->N > 0 && !right_to_left) || left->device != right->device)
+        return MSORB_E_INVALID;
+    HIPCHK(hipSetDevice(left->device));
+    *nmatches = 0;
+    const int NL = left->N, NR = right->N;
+    const bool bFactor = th != 1.0;
+    RigSide L, R;
+    L.f = left; R.f = right;
+    L.q.assign(M, WinQuery{}); R.q.assign(M, WinQuery{});
+    std::vector<uint8_t> live(M, 0);
+    for (int i = 0; i < M; i++) {
+        if (!track_in_view[i] && !track_in_view_r[i]) continue;          // :50-51
+        if (far_points && track_depth[i] > th_far) continue;             // :53-54
+        if (bad[i]) continue;                                            // :56-57
+        live[i] = 1;
+        if (track_in_view[i]) {
+            if (level[i] < 0 || level[i] >= left->nlevels) { set_last_error("predicted level out of range"); return MSORB_E_INVALID; }
+            float r = (view_cos[i] > 0.998) ? 2.5 : 4.0;                 // RadiusByViewingCos, :215-221
+            if (bFactor) r *= th;
+            WinQuery& w = L.q[i];
+            w.x = proj_x[i]; w.y = proj_y[i]; w.r = r * left->scale[level[i]]; w.ur = 0.0f;
+            w.min_level = (int16_t)(level[i] - 1); w.max_level = (int16_t)level[i];
+            w.flags = kQValid | (sparsified[i] ? 0 : kQSkipOccupied);
+        }
+        if (track_in_view_r[i] && level_r[i] != -1) {                    // :144-146
+            if (level_r[i] < 0 || level_r[i] >= right->nlevels) { set_last_error("predicted level (right camera) out of range"); return MSORB_E_INVALID; }
+            const float r = (view_cos_r[i] > 0.998) ? 2.5 : 4.0;         // (:147: not scaled by th)
+            WinQuery& w = R.q[i];
+            w.x = proj_xr[i]; w.y = proj_yr[i]; w.r = r * right->scale[level_r[i]]; w.ur = 0.0f;
+            w.min_level = (int16_t)(level_r[i] - 1); w.max_level = (int16_t)level_r[i];
+            w.flags = kQValid | kQSkipOccupied;
+        }
+    }
+    L.occ.assign(NL, 0); R.occ.assign(NR, 0);
+    for (int i = 0; i < NL + NR; i++) {
+        if (frame_mp[i] >= M) { set_last_error("frame_mp holds an id outside the map-point table"); return MSORB_E_INVALID; }
+        const uint8_t o = frame_mp[i] >= 0 && obs[frame_mp[i]] > 0;
+        if (i < NL) L.occ[i] = o; else R.occ[i - NL] = o;
+    }
+    for (int i = 0; i < NL; i++) if (left_to_right[i] < -1 || left_to_right[i] >= NR) { set_last_error("left_to_right out of range"); return MSORB_E_INVALID; }
+    for (int i = 0; i < NR; i++) if (right_to_left[i] < -1 || right_to_left[i] >= NL) { set_last_error("right_to_left out of range"); return MSORB_E_INVALID; }
+    if (M == 0) return MSORB_OK;
+    int rc;
+    if ((rc = L.prepare(M, mp_desc)) || (rc = R.prepare(M, mp_desc))) return rc;
+    int nm = 0;
+    // one side's accept rule on a candidate prefix: -1 no match, -2 the ratio test failed (:125-126 / :191-192), else the keypoint
+    auto pick = [&](const msorb_frame* f, const int* idx, const int* dist, int n) -> int {
+        if (n == 0) return -1;
+        const int bestDist = dist[0], bestIdx = idx[0];
+        const int bestLevel = f->kps[bestIdx].octave;
+        const int bestDist2 = n > 1 ? dist[1] : 256;
+        const int bestLevel2 = n > 1 ? f->kps[idx[1]].octave : -1;
+        if (bestDist > kThHigh) return -1;
+        if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) return -2;
+        return bestIdx;   // (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2 holds here)
+    };
+    bool needL = true, needR = true;
+    std::vector<uint8_t> skip_right(M, 0);   // the left pass of the point `continue`d the loop
+    for (;;) {
+        if (needL && (rc = L.round(M))) return rc;
+        if (needR && (rc = R.round(M))) return rc;
+        needL = needR = false;
+        for (int i = std::min(L.next, R.next); i < M; i++) {
+            int idx[kTopK], dist[kTopK], n = 0;
+            if (i >= L.next) {
+                if (live[i] && (L.q[i].flags & kQValid)) {
+                    if (!L.prefix(i, 2, idx, dist, &n)) { needL = true; break; }
+                    const int b = pick(left, idx, dist, n);
+                    if (b == -2) skip_right[i] = 1;
+                    if (b >= 0) {
+                        frame_mp[b] = i; nm++;
+                        L.set_occ(b, obs[i] > 0);
+                        if (left_to_right[b] != -1) {                    // :130-134
+                            frame_mp[NL + left_to_right[b]] = i; nm++;
+                            R.set_occ(left_to_right[b], obs[i] > 0);
+                        }
+                    }
+                }
+                L.next = i + 1;
+            }
+            if (i >= R.next) {
+                if (live[i] && !skip_right[i] && (R.q[i].flags & kQValid)) {
+                    if (!R.prefix(i, 2, idx, dist, &n)) { needR = true; break; }
+                    const int b = pick(right, idx, dist, n);
+                    if (b >= 0) {
+                        if (right_to_left[b] != -1) {                    // :196-200
+                            frame_mp[right_to_left[b]] = i; nm++;
+                            L.set_occ(right_to_left[b], obs[i] > 0);
+                        }
+                        frame_mp[NL + b] = i; nm++;
+                        R.set_occ(b, obs[i] > 0);
+                    }
+                }
+                R.next = i + 1;
+            }
+        }
+        if (!needL && !needR) break;
+    }
+    left->last_rounds = L.rounds; left->total_rounds += L.rounds; left->total_searches++;
+    right->last_rounds = R.rounds; right->total_rounds += R.rounds; right->total_searches++;
+    *nmatches = nm;
+    return MSORB_OK;
+}
+
 namespace {
 // Shared body of the two frame-against-projected-points searches: SearchByProjection(Current, Last, th, bMono)
 // (:1941-2152) and SearchByProjection(Current, pKF, sAlreadyFound, th, ORBdist) (:2154-2275).  ur == nullptr: no

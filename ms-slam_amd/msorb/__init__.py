@@ -658,6 +658,26 @@ def visibility_csr(kf_slot_begin, slot_point, slot_cell, point_nobs, obs_begin, 
                 n_max_obs=nmax.value)
 
 
+_RIG_FIELDS = (("track_in_view", np.uint8), ("track_in_view_r", np.uint8), ("bad", np.uint8), ("sparsified", np.uint8), ("proj_x", np.float32),
+               ("proj_y", np.float32), ("proj_xr", np.float32), ("proj_yr", np.float32), ("track_depth", np.float32), ("level", np.int32),
+               ("level_r", np.int32), ("view_cos", np.float32), ("view_cos_r", np.float32), ("desc", np.uint8), ("obs", np.int32))
+
+
+def search_by_projection_mps_rig(left, right, mp, left_to_right, right_to_left, frame_mp, th, bFarPoints=False, thFarPoints=50.0, nnratio=0.8):
+    """msorb_search_by_projection_mps_rig: ORBmatcher::SearchByProjection(F, vpMapPoints, ...) on a two-camera frame (F.Nleft != -1):
+    left / right are Frame handles of the two cameras' keypoints, mp a dict of per-map-point arrays (_RIG_FIELDS), frame_mp
+    (int32 [n_left + n_right]) is updated in place.  -> nmatches"""
+    L = lib()
+    arrs = [_c(mp[k], dt) for k, dt in _RIG_FIELDS] + [_c(left_to_right, np.int32), _c(right_to_left, np.int32)]
+    assert frame_mp.dtype == np.int32 and frame_mp.flags.c_contiguous and len(frame_mp) == left.n + right.n
+    nm = C.c_int()
+    L.msorb_search_by_projection_mps_rig.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 18 + [C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p]
+    _check(L.msorb_search_by_projection_mps_rig(left.h, right.h, len(arrs[0]), *[_np_ptr(a) for a in arrs], _np_ptr(frame_mp), th, int(bFarPoints),
+                                                thFarPoints, nnratio, C.byref(nm)), "msorb_search_by_projection_mps_rig")
+    return nm.value
+
+
+EXPORTS = EXPORTS + ("msorb_search_by_projection_mps_rig",)
 EXPORTS = EXPORTS + ("msorb_hamming_dense_top2_batch", "msorb_hamming_dense_top2_batch_ex", "msorb_knn_match2")
 
 

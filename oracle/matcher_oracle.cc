@@ -214,6 +214,99 @@ int orc_search_by_projection_mps(void* fp, int M, const uint8_t* track_in_view, 
     return nmatches;
 }
 
+// The same function on a two-camera frame (F.Nleft != -1), ORBmatcher.cc:43-213 statement by statement with both arms.  fl / fr:
+// the left camera's keypoints (F.mvKeys[0, Nleft), descriptor rows [0, Nleft)) and the right camera's (F.mvKeysRight, rows
+// [Nleft, N)) as two FrameSoA — what Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel, bRight) walks (Frame.cc:589-655).
+// frame_mp[NL + NR] = F.mvpMapPoints as table ids.  *_r: mbTrackInViewR, mTrackProjXR / YR, mnTrackScaleLevelR, mTrackViewCosR.
+int orc_search_by_projection_mps_rig(void* fl, void* fr, int M, const uint8_t* track_in_view, const uint8_t* track_in_view_r,
+                                     const uint8_t* bad, const uint8_t* sparsified, const float* proj_x, const float* proj_y,
+                                     const float* proj_xr, const float* proj_yr, const float* track_depth, const int* level, const int* level_r,
+                                     const float* view_cos, const float* view_cos_r, const uint8_t* mp_desc, const int* obs,
+                                     const int* left_to_right, const int* right_to_left, int* frame_mp, float th, int bFarPoints,
+                                     float thFarPoints, float nnratio) {
+    FrameSoA& FL = *(FrameSoA*)fl;
+    FrameSoA& FR = *(FrameSoA*)fr;
+    const int Nleft = FL.N;
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    for (int iMP = 0; iMP < M; iMP++) {
+        if (!track_in_view[iMP] && !track_in_view_r[iMP]) continue;
+        if (bFarPoints && track_depth[iMP] > thFarPoints) continue;
+        if (bad[iMP]) continue;
+        const uint8_t* MPdescriptor = mp_desc + (size_t)iMP * 32;
+        if (track_in_view[iMP]) {
+            const int nPredictedLevel = level[iMP];
+            float r = (view_cos[iMP] > 0.998) ? 2.5 : 4.0;
+            if (bFactor) r *= th;
+            const std::vector<size_t> vIndices =
+                FL.features_in_area(proj_x[iMP], proj_y[iMP], r * FL.scaleFactors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel);
+            if (!vIndices.empty()) {
+                int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+                for (size_t k = 0; k < vIndices.size(); k++) {
+                    const size_t idx = vIndices[k];
+                    if (frame_mp[idx] >= 0 && !sparsified[iMP])
+                        if (obs[frame_mp[idx]] > 0) continue;
+                    // (F.Nleft == -1 && F.mvuRight[idx] > 0: not on such a frame, :92)
+                    const int dist = orc::descriptor_distance(MPdescriptor, &FL.desc[idx * 32]);
+                    if (dist < bestDist) {
+                        bestDist2 = bestDist; bestDist = dist;
+                        bestLevel2 = bestLevel; bestLevel = FL.kps[idx].octave;   // F.mvKeys[idx].octave (idx < Nleft)
+                        bestIdx = (int)idx;
+                    } else if (dist < bestDist2) {
+                        bestLevel2 = FL.kps[idx].octave;
+                        bestDist2 = dist;
+                    }
+                }
+                if (bestDist <= orc::TH_HIGH) {
+                    if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;   // (leaves the map-point loop: no right pass)
+                    if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+                        frame_mp[bestIdx] = iMP;
+                        if (left_to_right[bestIdx] != -1) {   // also match with the stereo observation at the right camera
+                            frame_mp[left_to_right[bestIdx] + Nleft] = iMP;
+                            nmatches++;
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+        }
+        if (track_in_view_r[iMP]) {
+            const int nPredictedLevel = level_r[iMP];
+            if (nPredictedLevel != -1) {
+                const float r = (view_cos_r[iMP] > 0.998) ? 2.5 : 4.0;
+                const std::vector<size_t> vIndices =
+                    FR.features_in_area(proj_xr[iMP], proj_yr[iMP], r * FR.scaleFactors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel);
+                if (vIndices.empty()) continue;
+                int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+                for (size_t k = 0; k < vIndices.size(); k++) {
+                    const size_t idx = vIndices[k];
+                    if (frame_mp[idx + Nleft] >= 0)
+                        if (obs[frame_mp[idx + Nleft]] > 0) continue;
+                    const int dist = orc::descriptor_distance(MPdescriptor, &FR.desc[idx * 32]);
+                    if (dist < bestDist) {
+                        bestDist2 = bestDist; bestDist = dist;
+                        bestLevel2 = bestLevel; bestLevel = FR.kps[idx].octave;
+                        bestIdx = (int)idx;
+                    } else if (dist < bestDist2) {
+                        bestLevel2 = FR.kps[idx].octave;
+                        bestDist2 = dist;
+                    }
+                }
+                if (bestDist <= orc::TH_HIGH) {
+                    if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+                    if (right_to_left[bestIdx] != -1) {
+                        frame_mp[right_to_left[bestIdx]] = iMP;
+                        nmatches++;
+                    }
+                    frame_mp[bestIdx + Nleft] = iMP;
+                    nmatches++;
+                }
+            }
+        }
+    }
+    return nmatches;
+}
+
 // ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono), ORBmatcher.cc:1941-2057 and
 // 2129-2152, from the projected coordinates onward.  One entry per last-frame keypoint i:
 //   valid[i]   pMP exists, !mvbOutlier, invzc >= 0, uv inside the image bounds (:1961-1983)

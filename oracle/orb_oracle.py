@@ -219,6 +219,20 @@ def cos_sin(angle_deg):
     return a.value, b.value
 
 
+_RIG_FIELDS = (("track_in_view", np.uint8), ("track_in_view_r", np.uint8), ("bad", np.uint8), ("sparsified", np.uint8), ("proj_x", np.float32),
+               ("proj_y", np.float32), ("proj_xr", np.float32), ("proj_yr", np.float32), ("track_depth", np.float32), ("level", np.int32),
+               ("level_r", np.int32), ("view_cos", np.float32), ("view_cos_r", np.float32), ("desc", np.uint8), ("obs", np.int32))
+
+
+def search_by_projection_mps_rig(left, right, mp, left_to_right, right_to_left, frame_mp, th, bFarPoints=False, thFarPoints=50.0, nnratio=0.8):
+    """orc_search_by_projection_mps_rig (ORBmatcher.cc:43-213, F.Nleft != -1); left / right: OracleFrame of the two cameras."""
+    L = lib()
+    arrs = [_c(mp[k], dt) for k, dt in _RIG_FIELDS] + [_c(left_to_right, np.int32), _c(right_to_left, np.int32)]
+    L.orc_search_by_projection_mps_rig.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 18 + [C.c_float, C.c_int, C.c_float, C.c_float]
+    return L.orc_search_by_projection_mps_rig(left.h, right.h, len(arrs[0]), *[_ptr(a) for a in arrs], _ptr(frame_mp), th, int(bFarPoints),
+                                              thFarPoints, nnratio)
+
+
 def std_sort_order(keys):
     """libstdc++ std::sort on (key, position) items compared by key only -> the input position of the item at each output position."""
     keys = np.ascontiguousarray(keys, np.uint32)
