@@ -344,6 +344,17 @@ int msorb_search_by_projection_frames(msorb_frame* cur, int n_last, const uint8_
                                       const int* obs, int n_obs, int* cur_mp, float th, int forward, int backward,
                                       int check_orientation, int* nmatches);
 
+/* The same search on a two-camera CurrentFrame (Nleft != -1; ORBmatcher.cc:1941-2152 with the right-camera arm :2059-2124), from
+ * the projected coordinates on.  left / right: the current frame's two cameras as in msorb_search_by_projection_mps_rig.  Per
+ * last-frame keypoint: valid (the tests of :1962-1983, on the LEFT projection), u, v (left camera), u_r, v_r
+ * (mpCamera->project(GetRelativePoseTrl() * x3Dc), :2060-2061), last_octave / last_angle (the Nleft-aware keypoint of LastFrame).
+ * cur_mp[n_left + n_right] in / out.  The right window of a keypoint is searched only when its left window held a candidate
+ * (:2003-2004); one rotation histogram over both arms.  Since ABI 6000. */
+int msorb_search_by_projection_frames_rig(msorb_frame* left, msorb_frame* right, int n_last, const uint8_t* valid, const float* u,
+                                          const float* v, const float* u_r, const float* v_r, const int* last_octave,
+                                          const float* last_angle, const uint8_t* mp_desc, const int* last_mp, const int* obs, int n_obs,
+                                          int* cur_mp, float th, int forward, int backward, int check_orientation, int* nmatches);
+
 /* ORBmatcher::SearchByProjection(Frame& Current, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:2154-2275,
  * Tracking::Relocalization :3672, :3695) from the projected coordinates on.  Per map point of the KeyFrame that the
  * loop reaches (not bad, not in sAlreadyFound, inside the image, distance inside the scale pyramid, :2173-2196):

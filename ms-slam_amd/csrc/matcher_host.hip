@@ -407,7 +407,9 @@ namespace {
 int search_projected(msorb_frame* f, int NL, const uint8_t* valid, const float* u, const float* v, const float* ur,
                      const int* octave, const float* angle, const uint8_t* mp_desc, const int* ids, const int* obs, int n_obs,
                      int* cur_mp, float th, int forward, int backward, int check_orientation, float accept_dist, int* nmatches,
-                     bool band_below = false) {
+                     bool band_below = false, std::vector<std::pair<int, int>>* push_log = nullptr) {
+    // push_log: the (query, keypoint) pairs the rotation histogram would receive, in the order of the loop, INSTEAD of the histogram
+    // (the two-camera form merges the logs of its two cameras into one histogram)
     *nmatches = 0;
     std::vector<WinQuery> q(NL);
     for (int i = 0; i < NL; i++) {
@@ -443,7 +445,8 @@ int search_projected(msorb_frame* f, int NL, const uint8_t* valid, const float* 
             const int bestIdx2 = idx[0];
             cur_mp[bestIdx2] = ids[qi];
             nm++;
-            if (check_orientation && angle) {
+            if (push_log) push_log->push_back({qi, bestIdx2});
+            else if (check_orientation && angle) {
                 float rot = angle[qi] - f->kps[bestIdx2].angle;
                 if (rot < 0.0) rot += 360.0f;
                 int bin = (int)std::round(rot * factor);
@@ -457,7 +460,7 @@ int search_projected(msorb_frame* f, int NL, const uint8_t* valid, const float* 
     };
     const int rc = run_window_search(f, NL, q.data(), nullptr, mp_desc, occ, 1, accept);
     if (rc) return rc;
-    if (check_orientation) {  // ORBmatcher.cc:2129-2149 / :2253-2272
+    if (check_orientation && !push_log) {  // ORBmatcher.cc:2129-2149 / :2253-2272
         int sizes[kHistoLength], ind[3];
         for (int i = 0; i < kHistoLength; i++) sizes[i] = (int)rotHist[i].size();
         msorb_three_maxima(sizes, kHistoLength, ind);
@@ -480,6 +483,69 @@ int msorb_search_by_projection_frames(msorb_frame* f, int NL, const uint8_t* val
     HIPCHK(hipSetDevice(f->device));
     return search_projected(f, NL, valid, u, v, ur, last_octave, last_angle, mp_desc, last_mp, obs, n_obs, cur_mp, th, forward,
                             backward, check_orientation, (float)kThHigh, nmatches);
+}
+
+// SearchByProjection(Current, Last, th, bMono) on a two-camera CurrentFrame (ORBmatcher.cc:1941-2152, right arm :2059-2124).  The
+// two arms claim disjoint halves of CurrentFrame.mvpMapPoints, so each is search_projected on its camera's frame; what couples
+// them: the right window of a last keypoint is only searched when its LEFT window held a candidate (:2003-2004 `continue`s before
+// the right arm is reached — GetFeaturesInArea before any occupancy test: the host walk of the same grid), and one rotation
+// histogram receives both arms' matches, per last keypoint the left one first (:2054, :2121 — right entries as idx + Nleft).
+int msorb_search_by_projection_frames_rig(msorb_frame* left, msorb_frame* right, int NLast, const uint8_t* valid, const float* u, const float* v,
+                                          const float* u_r, const float* v_r, const int* last_octave, const float* last_angle,
+                                          const uint8_t* mp_desc, const int* last_mp, const int* obs, int n_obs, int* cur_mp, float th,
+                                          int forward, int backward, int check_orientation, int* nmatches) {
+    if (!left || !right || NLast < 0 || n_obs < 0 || !nmatches || left->device != right->device ||
+        (NLast > 0 && (!valid || !u || !v || !u_r || !v_r || !last_octave || !last_angle || !mp_desc || !last_mp || !obs)) ||
+        (left->N + right->N > 0 && !cur_mp))
+        return MSORB_E_INVALID;
+    HIPCHK(hipSetDevice(left->device));
+    *nmatches = 0;
+    const int NL = left->N;
+    std::vector<uint8_t> valid_r(NLast, 0);
+    for (int i = 0; i < NLast; i++) {
+        if (!valid[i]) continue;
+        const int oct = last_octave[i];
+        if (oct < 0 || oct >= left->nlevels) { set_last_error("octave out of range"); return MSORB_E_INVALID; }
+        const float radius = th * left->scale[oct];
+        const int lo = forward ? oct : backward ? 0 : oct - 1, hi = forward ? -1 : backward ? oct : oct + 1;
+        int one = 0, n = 0;
+        const int rc = msorb_frame_features_in_area(left, u[i], v[i], radius, lo, hi, &one, 1, &n);   // (only the count is wanted)
+        if (rc && rc != MSORB_E_CAPACITY) return rc;
+        valid_r[i] = n > 0;
+    }
+    std::vector<std::pair<int, int>> pl, pr;
+    int nl = 0, nr = 0, rc;
+    if ((rc = search_projected(left, NLast, valid, u, v, nullptr, last_octave, last_angle, mp_desc, last_mp, obs, n_obs, cur_mp, th, forward,
+                               backward, 0, (float)kThHigh, &nl, false, &pl)))
+        return rc;
+    if ((rc = search_projected(right, NLast, valid_r.data(), u_r, v_r, nullptr, last_octave, last_angle, mp_desc, last_mp, obs, n_obs,
+                               cur_mp + NL, th, forward, backward, 0, (float)kThHigh, &nr, false, &pr)))
+        return rc;
+    int nm = nl + nr;
+    if (check_orientation) {
+        std::vector<int> rotHist[kHistoLength];
+        const float factor = 1.0f / kHistoLength;
+        auto push = [&](int qi, float kp_angle, int entry) {
+            float rot = last_angle[qi] - kp_angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)std::round(rot * factor);
+            if (bin == kHistoLength) bin = 0;
+            if (bin >= 0 && bin < kHistoLength) rotHist[bin].push_back(entry);
+        };
+        size_t a = 0, b = 0;   // both logs are in query order: merge, the left entry of a query first
+        while (a < pl.size() || b < pr.size()) {
+            if (b >= pr.size() || (a < pl.size() && pl[a].first <= pr[b].first)) { push(pl[a].first, left->kps[pl[a].second].angle, pl[a].second); a++; }
+            else { push(pr[b].first, right->kps[pr[b].second].angle, NL + pr[b].second); b++; }
+        }
+        int sizes[kHistoLength], ind[3];
+        for (int i = 0; i < kHistoLength; i++) sizes[i] = (int)rotHist[i].size();
+        msorb_three_maxima(sizes, kHistoLength, ind);
+        for (int i = 0; i < kHistoLength; i++)
+            if (i != ind[0] && i != ind[1] && i != ind[2])
+                for (int k : rotHist[i]) { cur_mp[k] = -1; nm--; }
+    }
+    *nmatches = nm;
+    return MSORB_OK;
 }
 
 int msorb_search_by_projection_kf(msorb_frame* f, int n, const uint8_t* valid, const float* u, const float* v,

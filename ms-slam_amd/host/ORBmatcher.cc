@@ -15,6 +15,7 @@
 
 #include "ORBmatcher_device.h"
 #include "ORBmatcher_loop_device.h"
+#include "ORBmatcher_rig_device.h"
 
 namespace ORB_SLAM3 {
 
@@ -41,6 +42,10 @@ struct ThreadCache {
     long unsigned int frame_id = ~0ul;
     const void* frame2_key = nullptr;
     long unsigned int frame2_id = ~0ul;
+    // the two cameras of a two-camera frame (Frame::Nleft != -1): ORBmatcher_rig_device.h
+    msorb_host::DeviceFrame<Frame> rig[2] = {msorb_host::DeviceFrame<Frame>(matcher_device()), msorb_host::DeviceFrame<Frame>(matcher_device())};
+    const void* rig_key = nullptr;
+    long unsigned int rig_id = ~0ul;
     const void* kf_key[2] = {nullptr, nullptr};
     long unsigned int kf_id[2] = {~0ul, ~0ul};
     bool kf_sparsified[2] = {false, false};
@@ -64,8 +69,9 @@ void drop_thread_cache() { g_thread_cache.reset(); }
 // the capability gap is reported like every other failure of the host layer (msorb_host::check throws std::runtime_error): the
 // application decides what to do with a rig this build does not serve; it is never answered with left-camera associations
 [[noreturn]] void unsupported_rig(const char* what) {
-    throw std::runtime_error(std::string("msorb: ") + what + " — the fisheye / two-camera branches (Nleft != -1, ORBmatcher.cc:144-210, "
-                             "1421-1426) are not served by this build");
+    throw std::runtime_error(std::string("msorb: ") + what + " — of the two-camera branches (Nleft != -1) this build serves SearchByProjection(F, "
+                             "vpMapPoints) and SearchByProjection(Current, Last) (ORBmatcher.cc:144-210, 2059-2124); SearchByBoW(pKF, F) on such a frame, "
+                             "the second-camera arms of SearchForTriangulation and Fuse(..., bRight = true) are not served (ORBmatcher_rig_device.h)");
 }
 msorb_host::DeviceFrame<Frame>& device_frame(const Frame& F, bool second = false) {
     ThreadCache& c = cache();
@@ -74,6 +80,16 @@ msorb_host::DeviceFrame<Frame>& device_frame(const Frame& F, bool second = false
     msorb_host::DeviceFrame<Frame>& d = second ? c.frame2 : c.frame;
     if (key != &F || id != F.mnId) { d.Upload(F); key = &F; id = F.mnId; }
     return d;
+}
+// both cameras of a two-camera frame, uploaded once per Frame object
+msorb_host::DeviceFrame<Frame>* device_rig(const Frame& F) {
+    ThreadCache& c = cache();
+    if (c.rig_key != &F || c.rig_id != F.mnId) {
+        msorb_host::UploadCamera(c.rig[0], F, false);
+        msorb_host::UploadCamera(c.rig[1], F, true);
+        c.rig_key = &F; c.rig_id = F.mnId;
+    }
+    return c.rig;
 }
 msorb_host::DeviceFrame<Frame>& device_keyframe(const std::shared_ptr<KeyFrame>& pKF, int slot = 0) {
     ThreadCache& c = cache();
@@ -111,11 +127,18 @@ ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbChe
 
 int ORBmatcher::SearchByProjection(Frame& F, const std::vector<std::shared_ptr<MapPoint>>& vpMapPoints, const float th,
                                    const bool bFarPoints, const float thFarPoints) {
-    if (F.Nleft != -1) unsupported_rig("ORBmatcher::SearchByProjection on a Frame with Nleft != -1");
+    if (F.Nleft != -1) {   // two cameras: both arms of :43-213 (ORBmatcher_rig_device.h)
+        msorb_host::DeviceFrame<Frame>* rig = device_rig(F);
+        return msorb_host::SearchByProjectionRig(rig[0], rig[1], F, vpMapPoints, th, bFarPoints, thFarPoints, mfNNratio);
+    }
     return msorb_host::SearchByProjection(device_frame(F), F, vpMapPoints, th, bFarPoints, thFarPoints, mfNNratio);
 }
 
 int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono) {
+    if (CurrentFrame.Nleft != -1) {   // two cameras: :1941-2152 with the right arm :2059-2124
+        msorb_host::DeviceFrame<Frame>* rig = device_rig(CurrentFrame);
+        return msorb_host::SearchByProjectionRig(rig[0], rig[1], CurrentFrame, LastFrame, th, bMono, mbCheckOrientation);
+    }
     return msorb_host::SearchByProjection(device_frame(CurrentFrame), CurrentFrame, LastFrame, th, bMono, mbCheckOrientation);
 }
 
@@ -146,6 +169,9 @@ int ORBmatcher::SearchByProjection(std::shared_ptr<KeyFrame> pKF, Sophus::Sim3<f
 }
 
 int ORBmatcher::SearchByBoW(std::shared_ptr<KeyFrame> pKF, Frame& F, std::vector<std::shared_ptr<MapPoint>>& vpMapPointMatches) {
+    // (:276-309: on a two-camera frame every KeyFrame feature keeps a best / second per camera inside its BoW node — never answered
+    // with the one-camera search)
+    if (F.Nleft != -1) unsupported_rig("ORBmatcher::SearchByBoW(pKF, F, ...) on a Frame with Nleft != -1");
     std::vector<std::vector<std::shared_ptr<MapPoint>>> out;
     const int n = msorb_host::SearchByBoWBatch(keyframe_store(), std::vector<std::shared_ptr<KeyFrame>>{pKF}, F, out, mfNNratio,
                                                mbCheckOrientation)[0];
@@ -175,6 +201,7 @@ int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Po
 
 int ORBmatcher::SearchForTriangulation(std::shared_ptr<KeyFrame> pKF1, std::shared_ptr<KeyFrame> pKF2,
                                        std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo, const bool bCoarse) {
+    if (pKF1->GetNLeft() != -1 || pKF2->GetNLeft() != -1) unsupported_rig("ORBmatcher::SearchForTriangulation on KeyFrames with NLeft != -1");
     std::vector<std::vector<std::pair<size_t, size_t>>> out;
     const int n = msorb_host::SearchForTriangulationBatch(keyframe_store(), pKF1, std::vector<std::shared_ptr<KeyFrame>>{pKF2}, out,
                                                           bOnlyStereo, bCoarse, mbCheckOrientation)[0];

@@ -1,0 +1,162 @@
+// Two-camera frames (Frame::Nleft != -1: the KannalaBrandt8 stereo rig of ORB-SLAM3) behind the drop-in ORBmatcher:
+//   ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint>&, th, bFarPoints, thFarPoints)   ORBmatcher.cc:43-213 (right arm :144-210)
+//   ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, th, bMono)                    ORBmatcher.cc:1941-2152 (right arm :2059-2124)
+// The two cameras of such a frame are two device frames: the left one holds F.mvKeys[0, Nleft) with descriptor rows [0, Nleft), the
+// right one F.mvKeysRight with rows [Nleft, N) — what Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel, bRight) walks
+// (Frame.cc:589-655: the raw keypoints, not mvKeysUn, for such a frame) — both without mvuRight (the rectified-stereo test of
+// :92 / :2015 is `Nleft == -1` only).  F.mvpMapPoints stays ONE array of N = Nleft + Nright entries.
+// No shipped configuration of MS-SLAM builds such frames (every YAML is Rectified / PinHole); the arms exist so that the class
+// answers what the reference's class answers.  Not served for such a rig (the class throws, ORBmatcher.cc `unsupported_rig`):
+// SearchByBoW(pKF, F) with F.Nleft != -1 (:223-421, the per-camera best / second of one BoW node), SearchForTriangulation's
+// second-camera arms (:1168-1402: KannalaBrandt8::epipolarConstrain, a camera model outside this build), Fuse(..., bRight = true)
+// (:1404-1597: its gates read GetKeyPoint(idx) with a RIGHT-grid index, i.e. a left keypoint, before idx += NLeft).
+#ifndef MSORB_ORBMATCHER_RIG_DEVICE_H
+#define MSORB_ORBMATCHER_RIG_DEVICE_H
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "ORBmatcher_device.h"
+
+namespace ORB_SLAM3 {
+namespace msorb_host {
+
+// one camera of a two-camera frame -> device frame + 64 x 48 grid (Frame.cc:385-416 with Nleft != -1: mGrid / mGridRight)
+template <class FrameT>
+void UploadCamera(DeviceFrame<FrameT>& dev, const FrameT& F, bool right) {
+    const std::vector<cv::KeyPoint>& keys = right ? F.mvKeysRight : F.mvKeys;
+    static_assert(sizeof(keys[0]) == sizeof(msorb_keypoint), "cv::KeyPoint must be the 28-byte layout");
+    const int n = right ? (int)F.mvKeysRight.size() : F.Nleft, row0 = right ? F.Nleft : 0;
+    std::vector<uint8_t> desc((size_t)n * 32);
+    for (int i = 0; i < n; i++) std::memcpy(&desc[(size_t)i * 32], F.mDescriptors.template ptr<unsigned char>(row0 + i), 32);
+    check(msorb_frame_set(dev.get(), reinterpret_cast<const msorb_keypoint*>(keys.data()), n, desc.data(), nullptr, F.mnMinX, F.mnMaxX, F.mnMinY,
+                          F.mnMaxY, F.mvScaleFactors.data(), (int)F.mvScaleFactors.size()),
+          "msorb_frame_set");
+}
+
+// ORBmatcher::SearchByProjection(Frame &F, const vector<shared_ptr<MapPoint>> &vpMapPoints, th, bFarPoints, thFarPoints), F.Nleft != -1.
+// devL / devR hold F's two cameras (UploadCamera).
+template <class FrameT, class MapPointPtr>
+int SearchByProjectionRig(DeviceFrame<FrameT>& devL, DeviceFrame<FrameT>& devR, FrameT& F, const std::vector<MapPointPtr>& vpMapPoints,
+                          const float th, const bool bFarPoints, const float thFarPoints, const float mfNNratio) {
+    const int M = (int)vpMapPoints.size(), N = (int)F.mvpMapPoints.size();
+    // table = the local map points in call order, then the map points the frame already holds that are not among them (never
+    // queries; their Observations() decides whether a keypoint is taken, :89-91 / :169-171)
+    PointerIndex index;
+    index.reset((size_t)M + N);
+    for (int i = 0; i < M; i++) index.emplace(vpMapPoints[i].get(), i);
+    std::vector<int> frameMp(N, -1), extraObs;
+    for (int i = 0; i < N; i++) {
+        if (!F.mvpMapPoints[i]) continue;
+        const int at = index.emplace(F.mvpMapPoints[i].get(), M + (int)extraObs.size());
+        frameMp[i] = at;
+        if (at == M + (int)extraObs.size()) extraObs.push_back(F.mvpMapPoints[i]->Observations());
+    }
+    const int T = M + (int)extraObs.size();
+    std::vector<uint8_t> inView(T, 0), inViewR(T, 0), bad(T, 0), spars(T, 0), desc((size_t)T * 32, 0);
+    std::vector<float> px(T, 0.f), py(T, 0.f), pxr(T, 0.f), pyr(T, 0.f), depth(T, 0.f), vcos(T, 0.f), vcosR(T, 0.f);
+    std::vector<int> level(T, 0), levelR(T, -1), obs(T, 0);
+    for (int i = 0; i < M; i++) {
+        const auto& p = vpMapPoints[i];
+        inView[i] = p->mbTrackInView; inViewR[i] = p->mbTrackInViewR; bad[i] = p->isBad(); spars[i] = p->mbSparsified;
+        px[i] = p->mTrackProjX; py[i] = p->mTrackProjY; pxr[i] = p->mTrackProjXR; pyr[i] = p->mTrackProjYR; depth[i] = p->mTrackDepth;
+        level[i] = p->mnTrackScaleLevel; levelR[i] = p->mnTrackScaleLevelR; vcos[i] = p->mTrackViewCos; vcosR[i] = p->mTrackViewCosR;
+        obs[i] = p->Observations();
+        if ((inView[i] || inViewR[i]) && !bad[i]) {
+            const auto d = p->GetDescriptor();
+            std::memcpy(&desc[(size_t)i * 32], d.template ptr<unsigned char>(0), 32);
+        }
+    }
+    for (int k = 0; k < (int)extraObs.size(); k++) obs[M + k] = extraObs[k];
+    const std::vector<int> before = frameMp;
+    int nmatches = 0;
+    check(msorb_search_by_projection_mps_rig(devL.get(), devR.get(), T, inView.data(), inViewR.data(), bad.data(), spars.data(), px.data(), py.data(),
+                                             pxr.data(), pyr.data(), depth.data(), level.data(), levelR.data(), vcos.data(), vcosR.data(), desc.data(),
+                                             obs.data(), F.mvLeftToRightMatch.data(), F.mvRightToLeftMatch.data(), frameMp.data(), th,
+                                             bFarPoints ? 1 : 0, thFarPoints, mfNNratio, &nmatches),
+          "msorb_search_by_projection_mps_rig");
+    for (int i = 0; i < N; i++)
+        if (frameMp[i] != before[i] && frameMp[i] >= 0 && frameMp[i] < M) F.mvpMapPoints[i] = vpMapPoints[frameMp[i]];
+    return nmatches;
+}
+
+// What :1962-1990 and :2060-2063 compute per last-frame keypoint for a two-camera CurrentFrame (the reference's own expressions,
+// compiled with the application's flags)
+struct LastFrameProjectionRig {
+    std::vector<uint8_t> valid, desc;
+    std::vector<float> u, v, ur, vr, angle;
+    std::vector<int> octave, obs;
+    bool forward = false, backward = false;
+};
+template <class FrameT>
+void ProjectLastFrameRig(FrameT& CurrentFrame, const FrameT& LastFrame, bool bMono, LastFrameProjectionRig& P) {
+    const auto Tcw = CurrentFrame.GetPose();
+    const auto twc = Tcw.inverse().translation();
+    const auto Tlw = LastFrame.GetPose();
+    const auto tlc = Tlw * twc;
+    P.forward = tlc(2) > CurrentFrame.mb && !bMono;                       // :1957
+    P.backward = -tlc(2) > CurrentFrame.mb && !bMono;                     // :1958
+    const auto Trl = CurrentFrame.GetRelativePoseTrl();
+    const int n = LastFrame.N;
+    P.valid.assign(n, 0); P.desc.assign((size_t)n * 32, 0);
+    P.u.assign(n, 0); P.v.assign(n, 0); P.ur.assign(n, 0); P.vr.assign(n, 0); P.angle.assign(n, 0);
+    P.octave.assign(n, 0); P.obs.assign(n, 0);
+    for (int i = 0; i < n; i++) {
+        const auto& pMP = LastFrame.mvpMapPoints[i];
+        if (!pMP) continue;
+        if (LastFrame.mvbOutlier[i]) continue;
+        const auto x3Dw = pMP->GetWorldPos();
+        const auto x3Dc = Tcw * x3Dw;
+        const float invzc = 1.0 / x3Dc(2);                                // :1973
+        if (invzc < 0) continue;
+        const auto uv = CurrentFrame.mpCamera->project(x3Dc);
+        if (uv(0) < CurrentFrame.mnMinX || uv(0) > CurrentFrame.mnMaxX) continue;
+        if (uv(1) < CurrentFrame.mnMinY || uv(1) > CurrentFrame.mnMaxY) continue;
+        const auto x3Dr = Trl * x3Dc;                                     // :2060
+        const auto uvr = CurrentFrame.mpCamera->project(x3Dr);            // :2061 (mpCamera, as the reference has it)
+        const bool lastLeft = LastFrame.Nleft == -1 || i < LastFrame.Nleft;
+        const cv::KeyPoint& kpLast = lastLeft ? LastFrame.mvKeys[i] : LastFrame.mvKeysRight[i - LastFrame.Nleft];
+        P.valid[i] = 1;
+        P.u[i] = uv(0); P.v[i] = uv(1); P.ur[i] = uvr(0); P.vr[i] = uvr(1);
+        P.octave[i] = kpLast.octave;                                      // :1986 / :2063
+        P.angle[i] = LastFrame.Nleft == -1 ? LastFrame.mvKeysUn[i].angle : kpLast.angle;   // :2043-2045
+        P.obs[i] = pMP->Observations();
+        const auto d = pMP->GetDescriptor();
+        std::memcpy(&P.desc[(size_t)i * 32], d.template ptr<unsigned char>(0), 32);
+    }
+}
+
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono), CurrentFrame.Nleft != -1: the projection
+// above, then msorb_search_by_projection_frames_rig (the two arms' window searches and claims, the left-window-empty rule of
+// :2003-2004, the one rotation histogram of :2129-2149).
+template <class FrameT>
+int SearchByProjectionRig(DeviceFrame<FrameT>& devL, DeviceFrame<FrameT>& devR, FrameT& CurrentFrame, const FrameT& LastFrame, const float th,
+                          const bool bMono, const bool mbCheckOrientation) {
+    LastFrameProjectionRig P;
+    ProjectLastFrameRig(CurrentFrame, LastFrame, bMono, P);
+    const int nL = LastFrame.N, N = CurrentFrame.N;
+    std::vector<int> lastMp(nL), obs(P.obs.begin(), P.obs.end()), curMp(N, -1);
+    for (int i = 0; i < nL; i++) lastMp[i] = i;
+    for (int j = 0; j < N; j++)
+        if (CurrentFrame.mvpMapPoints[j]) {
+            curMp[j] = (int)obs.size();
+            obs.push_back(CurrentFrame.mvpMapPoints[j]->Observations());
+        }
+    const std::vector<int> before = curMp;
+    int nmatches = 0;
+    check(msorb_search_by_projection_frames_rig(devL.get(), devR.get(), nL, P.valid.data(), P.u.data(), P.v.data(), P.ur.data(), P.vr.data(),
+                                                P.octave.data(), P.angle.data(), P.desc.data(), lastMp.data(), obs.data(), (int)obs.size(),
+                                                curMp.data(), th, P.forward, P.backward, mbCheckOrientation, &nmatches),
+          "msorb_search_by_projection_frames_rig");
+    for (int j = 0; j < N; j++) {
+        if (curMp[j] == before[j]) continue;
+        if (curMp[j] < 0) CurrentFrame.mvpMapPoints[j] = nullptr;         // removed by the histogram filter (:2143)
+        else CurrentFrame.mvpMapPoints[j] = LastFrame.mvpMapPoints[curMp[j]];
+    }
+    return nmatches;
+}
+
+}  // namespace msorb_host
+}  // namespace ORB_SLAM3
+#endif

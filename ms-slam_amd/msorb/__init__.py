@@ -677,7 +677,24 @@ def search_by_projection_mps_rig(left, right, mp, left_to_right, right_to_left, 
     return nm.value
 
 
-EXPORTS = EXPORTS + ("msorb_search_by_projection_mps_rig",)
+def search_by_projection_frames_rig(left, right, last, cur_mp, th, forward=False, backward=False, check_orientation=True):
+    """msorb_search_by_projection_frames_rig: SearchByProjection(Current, Last, th, bMono) on a two-camera CurrentFrame; last: dict valid,
+    u, v, u_r, v_r, octave, angle, desc, mp, obs (obs indexed by map-point id); cur_mp int32 [n_left + n_right] in / out -> nmatches"""
+    L = lib()
+    arrs = [_c(last["valid"], np.uint8), _c(last["u"], np.float32), _c(last["v"], np.float32), _c(last["u_r"], np.float32),
+            _c(last["v_r"], np.float32), _c(last["octave"], np.int32), _c(last["angle"], np.float32), _c(last["desc"], np.uint8),
+            _c(last["mp"], np.int32), _c(last["obs"], np.int32)]
+    assert cur_mp.dtype == np.int32 and cur_mp.flags.c_contiguous and len(cur_mp) == left.n + right.n
+    nm = C.c_int()
+    L.msorb_search_by_projection_frames_rig.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_void_p, C.c_float, C.c_int,
+                                                                                                              C.c_int, C.c_int, C.c_void_p]
+    _check(L.msorb_search_by_projection_frames_rig(left.h, right.h, len(arrs[0]), *[_np_ptr(a) for a in arrs], len(arrs[9]), _np_ptr(cur_mp), th,
+                                                   int(forward), int(backward), int(check_orientation), C.byref(nm)),
+           "msorb_search_by_projection_frames_rig")
+    return nm.value
+
+
+EXPORTS = EXPORTS + ("msorb_search_by_projection_mps_rig", "msorb_search_by_projection_frames_rig")
 EXPORTS = EXPORTS + ("msorb_hamming_dense_top2_batch", "msorb_hamming_dense_top2_batch_ex", "msorb_knn_match2")
 
 

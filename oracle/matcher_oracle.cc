@@ -366,6 +366,90 @@ int orc_search_by_projection_frames(void* fp, int NL, const uint8_t* valid, cons
     return nmatches;
 }
 
+// ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono) on a two-camera CurrentFrame (Nleft != -1),
+// ORBmatcher.cc:1941-2152 with the right-camera arm :2059-2124, from the projected coordinates on.  Per last-frame keypoint i:
+// valid (:1962-1983: map point, not an outlier, invzc >= 0, the LEFT projection inside the image), u, v (left camera), u_r, v_r
+// (CurrentFrame.mpCamera->project(GetRelativePoseTrl() * x3Dc), :2060-2061), last_octave, last_angle (the Nleft-aware keypoint of
+// LastFrame, :1986 / :2043-2045), mp_desc, last_mp, obs.  fl / fr: the current frame's two cameras; cur_mp[NL + NR].
+// What the arm inherits from the statement order: the right window is only searched when the left one held a candidate (:2003-2004
+// `continue`s on an empty left window); both arms feed ONE rotation histogram (:2054, :2121: right entries as idx + Nleft).
+int orc_search_by_projection_frames_rig(void* fl, void* fr, int NLast, const uint8_t* valid, const float* u, const float* v, const float* u_r,
+                                        const float* v_r, const int* last_octave, const float* last_angle, const uint8_t* mp_desc,
+                                        const int* last_mp, const int* obs, int* cur_mp, float th, int bForward, int bBackward,
+                                        int check_orientation) {
+    FrameSoA& CL = *(FrameSoA*)fl;
+    FrameSoA& CR = *(FrameSoA*)fr;
+    const int Nleft = CL.N;
+    int nmatches = 0;
+    std::vector<int> rotHist[orc::HISTO_LENGTH];
+    const float factor = 1.0f / orc::HISTO_LENGTH;
+    auto window = [&](FrameSoA& C, float x, float y, float radius, int oct) {
+        if (bForward) return C.features_in_area(x, y, radius, oct, -1);
+        if (bBackward) return C.features_in_area(x, y, radius, 0, oct);
+        return C.features_in_area(x, y, radius, oct - 1, oct + 1);
+    };
+    for (int i = 0; i < NLast; i++) {
+        if (!valid[i]) continue;
+        const int nLastOctave = last_octave[i];
+        const float radius = th * CL.scaleFactors[nLastOctave];
+        const uint8_t* dMP = mp_desc + (size_t)i * 32;
+        {
+            const std::vector<size_t> vIndices2 = window(CL, u[i], v[i], radius, nLastOctave);
+            if (vIndices2.empty()) continue;
+            int bestDist = 256, bestIdx2 = -1;
+            for (size_t k = 0; k < vIndices2.size(); k++) {
+                const size_t i2 = vIndices2[k];
+                if (cur_mp[i2] >= 0)
+                    if (obs[cur_mp[i2]] > 0) continue;
+                // (CurrentFrame.Nleft == -1 && mvuRight[i2] > 0: not on such a frame, :2015)
+                const int dist = orc::descriptor_distance(dMP, &CL.desc[i2 * 32]);
+                if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+            }
+            if (bestDist <= orc::TH_HIGH) {
+                cur_mp[bestIdx2] = last_mp[i];
+                nmatches++;
+                if (check_orientation) {
+                    float rot = last_angle[i] - CL.kps[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == orc::HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(bestIdx2);
+                }
+            }
+        }
+        {   // :2059-2124
+            const std::vector<size_t> vIndices2 = window(CR, u_r[i], v_r[i], radius, nLastOctave);
+            int bestDist = 256, bestIdx2 = -1;
+            for (size_t k = 0; k < vIndices2.size(); k++) {
+                const size_t i2 = vIndices2[k];
+                if (cur_mp[i2 + Nleft] >= 0)
+                    if (obs[cur_mp[i2 + Nleft]] > 0) continue;
+                const int dist = orc::descriptor_distance(dMP, &CR.desc[i2 * 32]);
+                if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+            }
+            if (bestDist <= orc::TH_HIGH) {
+                cur_mp[bestIdx2 + Nleft] = last_mp[i];
+                nmatches++;
+                if (check_orientation) {
+                    float rot = last_angle[i] - CR.kps[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == orc::HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(bestIdx2 + Nleft);
+                }
+            }
+        }
+    }
+    if (check_orientation) {  // :2129-2149
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc::three_maxima(rotHist, orc::HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < orc::HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0; j < rotHist[i].size(); j++) { cur_mp[rotHist[i][j]] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
 // The search of ORBmatcher::Fuse(pKF, vpMapPoints, th, false), ORBmatcher.cc:1499-1561, for map points that passed
 // the geometric tests of :1436-1497.  fp = the KeyFrame's features (KeyFrame::GetFeaturesInArea, KeyFrame.cc:796-845,
 // is Frame::GetFeaturesInArea without level arguments).  Float convention as elsewhere in this file: the products of a

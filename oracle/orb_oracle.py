@@ -233,6 +233,18 @@ def search_by_projection_mps_rig(left, right, mp, left_to_right, right_to_left, 
                                               thFarPoints, nnratio)
 
 
+def search_by_projection_frames_rig(left, right, last, cur_mp, th, forward=False, backward=False, check_orientation=True):
+    """orc_search_by_projection_frames_rig (ORBmatcher.cc:1941-2152 on a two-camera CurrentFrame); last: dict valid, u, v, u_r, v_r,
+    octave, angle, desc, mp, obs; cur_mp int32 [n_left + n_right] in / out."""
+    L = lib()
+    arrs = [_c(last["valid"], np.uint8), _c(last["u"], np.float32), _c(last["v"], np.float32), _c(last["u_r"], np.float32),
+            _c(last["v_r"], np.float32), _c(last["octave"], np.int32), _c(last["angle"], np.float32), _c(last["desc"], np.uint8),
+            _c(last["mp"], np.int32), _c(last["obs"], np.int32)]
+    L.orc_search_by_projection_frames_rig.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 11 + [C.c_float, C.c_int, C.c_int, C.c_int]
+    return L.orc_search_by_projection_frames_rig(left.h, right.h, len(arrs[0]), *[_ptr(a) for a in arrs], _ptr(cur_mp), th, int(forward),
+                                                 int(backward), int(check_orientation))
+
+
 def std_sort_order(keys):
     """libstdc++ std::sort on (key, position) items compared by key only -> the input position of the item at each output position."""
     keys = np.ascontiguousarray(keys, np.uint32)

@@ -1,0 +1,153 @@
+// The two-camera arms of the drop-in ORB_SLAM3::ORBmatcher (ms-slam_amd/host/ORBmatcher.cc -> ORBmatcher_rig_device.h) through the CLASS,
+// compiled against the stand-ins of tests/slam_stub: a Frame with Nleft != -1 (mvKeys / mvKeysRight, mvLeftToRightMatch /
+// mvRightToLeftMatch, GetRelativePoseTrl) goes through
+//   ORBmatcher::SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints)     (ORBmatcher.cc:43-213)
+//   ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono)              (ORBmatcher.cc:1941-2152)
+// and the results are written out together with the projections the host mirror computed for the second one (the Python test
+// hands those to the oracle's arm).  It also checks that the calls this build does NOT serve for such a rig throw.
+// usage: dropin_rig <in.bin> <out.bin>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include "ORBmatcher.h"
+#include "ORBmatcher_rig_device.h"
+
+using namespace ORB_SLAM3;
+typedef std::shared_ptr<MapPoint> MP;
+
+template <class T>
+static std::vector<T> rd(FILE* f, size_t n) {
+    std::vector<T> v(n);
+    if (n && fread(v.data(), sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(3); }
+    return v;
+}
+template <class T>
+static void wr(FILE* f, const std::vector<T>& v) { if (!v.empty()) fwrite(v.data(), sizeof(T), v.size(), f); }
+static void wri(FILE* f, int v) { fwrite(&v, 4, 1, f); }
+
+static void set_rig(Frame& F, const std::vector<cv::KeyPoint>& kl, const std::vector<cv::KeyPoint>& kr, const std::vector<unsigned char>& d,
+                    const std::vector<int>& l2r, const std::vector<int>& r2l, const std::vector<float>& scale, GeometricCamera* cam, const float* bounds) {
+    std::vector<cv::KeyPoint> all = kl;
+    all.insert(all.end(), kr.begin(), kr.end());
+    F.SetFeatures(all, d.data());            // N = Nleft + Nright rows of descriptors and map points
+    F.mvKeys = kl; F.mvKeysUn = kl;          // (a two-camera frame keeps mvKeys = the left camera's keypoints; mvKeysUn is not read for it)
+    F.mvKeysRight = kr;
+    F.Nleft = (int)kl.size(); F.Nright = (int)kr.size();
+    F.mvLeftToRightMatch = l2r; F.mvRightToLeftMatch = r2l;
+    F.mvScaleFactors = scale; F.mnScaleLevels = (int)scale.size(); F.mfLogScaleFactor = std::log(1.2f);
+    F.mpCamera = cam; F.mpCamera2 = cam;
+    F.mnMinX = bounds[0]; F.mnMaxX = bounds[1]; F.mnMinY = bounds[2]; F.mnMaxY = bounds[3];
+    F.mvbOutlier.assign(F.N, false);
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) return 2;
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) return 3;
+    const auto hdr = rd<int>(f, 6);   // n_left, n_right, M, n_last_left, n_last_right, nlevels
+    const int NL = hdr[0], NR = hdr[1], M = hdr[2], LL = hdr[3], LR = hdr[4], nl = hdr[5], N = NL + NR, NLAST = LL + LR;
+    const auto fl = rd<float>(f, 16);  // fx fy cx cy | minX maxX minY maxY | th13 thFar ratio far | th14 mb bMono checkOri
+    const auto scale = rd<float>(f, nl);
+    GeometricCamera cam;
+    cam.fx = fl[0]; cam.fy = fl[1]; cam.cx = fl[2]; cam.cy = fl[3];
+    const auto kl = rd<cv::KeyPoint>(f, NL), kr = rd<cv::KeyPoint>(f, NR);
+    const auto desc = rd<unsigned char>(f, (size_t)N * 32);
+    const auto l2r = rd<int>(f, NL), r2l = rd<int>(f, NR);
+    // ---- a13: the local map points with their scratch, the map points the frame already holds
+    const auto inView = rd<unsigned char>(f, M), inViewR = rd<unsigned char>(f, M), bad = rd<unsigned char>(f, M), spars = rd<unsigned char>(f, M);
+    const auto px = rd<float>(f, M), py = rd<float>(f, M), pxr = rd<float>(f, M), pyr = rd<float>(f, M), depth = rd<float>(f, M);
+    const auto level = rd<int>(f, M), levelR = rd<int>(f, M);
+    const auto vcos = rd<float>(f, M), vcosR = rd<float>(f, M);
+    const auto mdesc = rd<unsigned char>(f, (size_t)M * 32);
+    const auto obs = rd<int>(f, M);
+    const auto frame_mp0 = rd<int>(f, N);
+    std::vector<MP> pts(M);
+    for (int i = 0; i < M; i++) {
+        auto p = std::make_shared<MapPoint>();
+        p->mnId = (unsigned long)i;
+        p->mbTrackInView = inView[i]; p->mbTrackInViewR = inViewR[i]; p->mbBad = bad[i]; p->mbSparsified = spars[i];
+        p->mTrackProjX = px[i]; p->mTrackProjY = py[i]; p->mTrackProjXR = pxr[i]; p->mTrackProjYR = pyr[i]; p->mTrackDepth = depth[i];
+        p->mnTrackScaleLevel = level[i]; p->mnTrackScaleLevelR = levelR[i]; p->mTrackViewCos = vcos[i]; p->mTrackViewCosR = vcosR[i];
+        p->nObs = obs[i];
+        memcpy(p->descriptor, &mdesc[(size_t)i * 32], 32);
+        pts[i] = p;
+    }
+    FILE* o = fopen(argv[2], "wb");
+    ORBmatcher matcher(fl[10], fl[15] != 0);
+    {
+        Frame F;
+        set_rig(F, kl, kr, desc, l2r, r2l, scale, &cam, &fl[4]);
+        F.mnId = 77;
+        for (int j = 0; j < N; j++) if (frame_mp0[j] >= 0) F.mvpMapPoints[j] = pts[frame_mp0[j]];
+        const int nm = matcher.SearchByProjection(F, pts, fl[8], fl[11] != 0, fl[9]);
+        wri(o, nm);
+        std::vector<int> ids(N, -1);
+        for (int j = 0; j < N; j++) if (F.mvpMapPoints[j]) ids[j] = (int)F.mvpMapPoints[j]->mnId;
+        wr(o, ids);
+        // the calls this build refuses for such a rig
+        int refused = 0;
+        auto kf = std::make_shared<KeyFrame>();
+        std::vector<MP> m;
+        try { matcher.SearchByBoW(kf, F, m); } catch (const std::runtime_error&) { refused++; }
+        wri(o, refused);
+    }
+    // ---- a14: LastFrame (two cameras as well) with map points in the world, CurrentFrame with a pose and the rig's Trl
+    const auto lkl = rd<cv::KeyPoint>(f, LL), lkr = rd<cv::KeyPoint>(f, LR);
+    const auto has = rd<unsigned char>(f, NLAST), outlier = rd<unsigned char>(f, NLAST);
+    const auto pos = rd<float>(f, (size_t)3 * NLAST);
+    const auto ldesc = rd<unsigned char>(f, (size_t)NLAST * 32);
+    const auto lobs = rd<int>(f, NLAST);
+    const auto pose = rd<float>(f, 36);   // Rcw(9) tcw(3) Rlw(9) tlw(3) Rrl(9) trl(3)
+    const auto cur_hold = rd<int>(f, N);  // Observations() of a map point the current frame already holds at keypoint j, -1: none
+    fclose(f);
+    {
+        Frame L, C;
+        std::vector<unsigned char> dl((size_t)NLAST * 32, 0);
+        set_rig(L, lkl, lkr, dl, std::vector<int>(LL, -1), std::vector<int>(LR, -1), scale, &cam, &fl[4]);
+        std::vector<MP> lpts(NLAST);
+        for (int i = 0; i < NLAST; i++) {
+            if (!has[i]) continue;
+            auto p = std::make_shared<MapPoint>();
+            p->mnId = 100000ul + (unsigned long)i;
+            memcpy(p->pos.v, &pos[(size_t)3 * i], 12);
+            p->nObs = lobs[i];
+            memcpy(p->descriptor, &ldesc[(size_t)i * 32], 32);
+            lpts[i] = p;
+            L.mvpMapPoints[i] = p;
+            L.mvbOutlier[i] = outlier[i] != 0;
+        }
+        auto se3 = [&](int at) {
+            Eigen::Matrix3f R; Eigen::Vector3f t;
+            memcpy(R.m, &pose[at], 36); memcpy(t.v, &pose[at + 9], 12);
+            return Sophus::SE3f(R, t);
+        };
+        L.mTcw = se3(12);
+        set_rig(C, kl, kr, desc, l2r, r2l, scale, &cam, &fl[4]);
+        C.mnId = 78;
+        C.mTcw = se3(0);
+        C.mTrl = se3(24);
+        C.mb = fl[13];
+        std::vector<MP> held;
+        for (int j = 0; j < N; j++)
+            if (cur_hold[j] >= 0) { auto p = std::make_shared<MapPoint>(); p->mnId = 200000ul + (unsigned long)j; p->nObs = cur_hold[j]; held.push_back(p); C.mvpMapPoints[j] = p; }
+        msorb_host::LastFrameProjectionRig P;
+        msorb_host::ProjectLastFrameRig(C, L, fl[14] != 0, P);
+        const int nm = matcher.SearchByProjection(C, L, fl[12], fl[14] != 0);
+        wri(o, nm);
+        std::vector<int> ids(N, -1);   // index of the last-frame keypoint whose point sits at j; -2: a point the frame held before
+        for (int j = 0; j < N; j++) {
+            if (!C.mvpMapPoints[j]) continue;
+            const unsigned long id = C.mvpMapPoints[j]->mnId;
+            ids[j] = id >= 200000ul ? -2 : (int)(id - 100000ul);
+        }
+        wr(o, ids);
+        wri(o, P.forward); wri(o, P.backward);
+        wr(o, P.valid); wr(o, P.u); wr(o, P.v); wr(o, P.ur); wr(o, P.vr); wr(o, P.octave); wr(o, P.angle);
+    }
+    fclose(o);
+    msorb_host::Shutdown();
+    return 0;
+}

@@ -127,8 +127,9 @@ public:
     unsigned char descriptor[32] = {0};
     // scratch written by Frame::isInFrustum / read by SearchByProjection (MapPoint.h:132-141)
     float mTrackProjX = 0, mTrackProjY = 0, mTrackDepth = 0, mTrackProjXR = 0, mTrackViewCos = 0;
+    float mTrackProjYR = 0, mTrackViewCosR = 0;   // the right camera's scratch of a two-camera frame (MapPoint.h:109-112)
     bool mbTrackInView = false, mbTrackInViewR = false, mbSparsified = false;
-    int mnTrackScaleLevel = 0;
+    int mnTrackScaleLevel = 0, mnTrackScaleLevelR = -1;
     long unsigned int mnLastFrameSeen = 0, mnLoopPointForKF = 0;
     int nVisible = 0;
     static inline std::vector<long>* log = nullptr;  // (kind, a, b): 1 = a->Replace(b), 2 = a->AddObservation(kf, idx b)
@@ -224,7 +225,14 @@ public:
 class Frame : public FeatureSide {
 public:
     long unsigned int mnId = 0;
-    int Nleft = -1;
+    // two-camera (KannalaBrandt8 stereo) frames: mvKeys = the left camera's Nleft keypoints, mvKeysRight the right camera's Nright,
+    // mDescriptors / mvpMapPoints N = Nleft + Nright rows, left first (Frame.h:226, 324-332)
+    int Nleft = -1, Nright = -1;
+    std::vector<cv::KeyPoint> mvKeysRight;
+    std::vector<int> mvLeftToRightMatch, mvRightToLeftMatch;
+    GeometricCamera* mpCamera2 = nullptr;
+    Sophus::SE3f mTrl;
+    Sophus::SE3f GetRelativePoseTrl() { return mTrl; }
     float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0;
     std::vector<bool> mvbOutlier;
     std::map<long unsigned int, cv::Point2f> mmProjectPoints;

@@ -125,3 +125,145 @@ def test_two_camera_search_argument_checks(msorb_mod, oracle):
             msorb_mod.search_by_projection_mps_rig(dfl, dfr, mp, R["l2r"], R["r2l"], R["frame_mp"].copy(), 1.0)
     finally:
         dfl.close(); dfr.close()
+
+
+# ---- through the drop-in CLASS (tests/dropin_rig_main.cc): Frame objects with Nleft != -1 ---------------------------------------
+import os
+import struct
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CAM = (718.856, 718.856, 607.19, 185.2)
+
+
+def _scene(oracle, seed, motion):
+    """A two-camera current frame whose right camera really is the left one moved by Trl (so both arms of SearchByProjection(Current,
+    Last) find their points), a two-camera last frame with map points in the world, the local map of make_rig on top."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    fx, fy, cx, cy = CAM
+    n_left = 1300
+    kl = np.zeros(n_left, oracle.KP_DTYPE)
+    kl["x"] = rng.uniform(30, 1210, n_left); kl["y"] = rng.uniform(30, 346, n_left)
+    kl["octave"] = rng.integers(0, 8, n_left); kl["angle"] = rng.uniform(0, 360, n_left); kl["size"] = 31
+    dl = rng.integers(0, 256, (n_left, 32), dtype=np.uint8)
+    z = rng.uniform(4, 40, n_left).astype(np.float32)
+    trl = np.array([-0.12, 0.0, 0.0], np.float32)
+    Xc = np.stack([(kl["x"] - cx) * z / fx, (kl["y"] - cy) * z / fy, z], 1).astype(np.float32)
+    ur = fx * (Xc[:, 0] + trl[0]) / Xc[:, 2] + cx
+    part = np.flatnonzero((rng.random(n_left) < 0.6) & (ur > 25) & (ur < 1215))
+    n_extra = 300
+    n_right = len(part) + n_extra
+    kr = np.zeros(n_right, oracle.KP_DTYPE)
+    kr["x"][:len(part)] = ur[part] + rng.normal(0, 0.7, len(part)); kr["y"][:len(part)] = kl["y"][part] + rng.normal(0, 0.7, len(part))
+    kr["octave"][:len(part)] = kl["octave"][part]; kr["angle"][:len(part)] = (kl["angle"][part] + rng.normal(0, 5, len(part))) % 360
+    kr["x"][len(part):] = rng.uniform(30, 1210, n_extra); kr["y"][len(part):] = rng.uniform(30, 346, n_extra)
+    kr["octave"][len(part):] = rng.integers(0, 8, n_extra); kr["angle"][len(part):] = rng.uniform(0, 360, n_extra); kr["size"] = 31
+    dr = np.concatenate([mc.flip_bits(rng, dl[part], 20), rng.integers(0, 256, (n_extra, 32), dtype=np.uint8)])
+    perm = rng.permutation(n_right)          # (partners must not sit at the front of the right camera's arrays)
+    kr, dr = kr[perm], dr[perm]
+    inv = np.empty(n_right, np.int64); inv[perm] = np.arange(n_right)
+    l2r = np.full(n_left, -1, np.int32); r2l = np.full(n_right, -1, np.int32)
+    l2r[part] = inv[np.arange(len(part))]; r2l[l2r[part]] = part
+    # poses: current camera = identity rotation; the last frame a step behind / ahead / beside it
+    tcw = np.array([0.3, -0.1, 0.2], np.float32)
+    tlw = tcw + np.array({"forward": [0, 0, 1.5], "backward": [0, 0, -1.5], "side": [0.2, 0, 0.1]}[motion], np.float32)
+    Xw = Xc - tcw
+    n_last = 1500
+    src = rng.integers(0, n_left, n_last)
+    on_kp = rng.random(n_last) < 0.75
+    pos = np.where(on_kp[:, None], Xw[src] + rng.normal(0, 0.01, (n_last, 3)), rng.uniform([-8, -3, 3], [8, 3, 50], (n_last, 3))).astype(np.float32)
+    ll = 900
+    lk = np.zeros(n_last, oracle.KP_DTYPE)
+    lk["octave"] = np.clip(kl["octave"][src] + rng.integers(-1, 2, n_last), 0, 7); lk["angle"] = (kl["angle"][src] + rng.normal(0, 8, n_last)) % 360
+    lk["x"] = rng.uniform(30, 1210, n_last); lk["y"] = rng.uniform(30, 346, n_last); lk["size"] = 31
+    last = dict(kl=lk[:ll], kr=lk[ll:], has=(rng.random(n_last) < 0.85).astype(np.uint8), outlier=(rng.random(n_last) < 0.05).astype(np.uint8),
+                pos=pos, desc=np.where(on_kp[:, None], mc.flip_bits(rng, dl[src], 30), rng.integers(0, 256, (n_last, 32), dtype=np.uint8)).astype(np.uint8),
+                obs=np.where(rng.random(n_last) < 0.2, 0, rng.integers(1, 9, n_last)).astype(np.int32))
+    eye = np.eye(3, dtype=np.float32).reshape(9)
+    pose = np.concatenate([eye, tcw, eye, tlw, eye, trl]).astype(np.float32)
+    cur_hold = np.where(rng.random(n_left + n_right) < 0.12, rng.integers(0, 4, n_left + n_right), -1).astype(np.int32)
+    return dict(kl=kl, dl=dl, kr=kr, dr=dr, l2r=l2r, r2l=r2l, last=last, pose=pose, cur_hold=cur_hold, ll=ll)
+
+
+@pytest.mark.parametrize("seed,motion,check_ori", [(21, "forward", True), (22, "backward", True), (23, "side", True), (24, "side", False)])
+def test_class_search_by_projection_on_two_camera_frames(msorb_mod, oracle, tmp_path, seed, motion, check_ori):
+    exe = str(tmp_path / "dropin_rig")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", f"-I{ROOT}/tests/slam_stub", f"-I{ROOT}/tests/cv_stub", f"-I{ROOT}/ms-slam_amd/host",
+                           f"-I{ROOT}/include", f"{ROOT}/tests/dropin_rig_main.cc", f"{ROOT}/ms-slam_amd/host/ORBmatcher.cc", f"-L{ROOT}/ms-slam_amd",
+                           "-lmsorb", f"-Wl,-rpath,{ROOT}/ms-slam_amd", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", exe])
+    S = _scene(oracle, seed, motion)
+    nl, nr = len(S["kl"]), len(S["kr"])
+    N = nl + nr
+    M = 3500
+    R = make_rig(oracle, seed + 100, nl, nr, M)          # only its map-point table and frame_mp are used, re-aimed at THIS frame's keypoints
+    rng = np.random.Generator(np.random.PCG64(seed + 200))
+    sl, sr = rng.integers(0, nl, M), rng.integers(0, nr, M)
+    mp = R["mp"]
+    mp["proj_x"] = (S["kl"]["x"][sl] + rng.normal(0, 2.5, M)).astype(np.float32); mp["proj_y"] = (S["kl"]["y"][sl] + rng.normal(0, 2.5, M)).astype(np.float32)
+    has_p = S["l2r"][sl] >= 0
+    sr = np.where(has_p, S["l2r"][sl], sr)
+    mp["proj_xr"] = (S["kr"]["x"][sr] + rng.normal(0, 2.5, M)).astype(np.float32); mp["proj_yr"] = (S["kr"]["y"][sr] + rng.normal(0, 2.5, M)).astype(np.float32)
+    mp["level"] = np.clip(S["kl"]["octave"][sl] + rng.integers(0, 2, M), 0, 7).astype(np.int32)
+    mp["level_r"] = np.where(rng.random(M) < 0.05, -1, np.clip(S["kr"]["octave"][sr] + rng.integers(0, 2, M), 0, 7)).astype(np.int32)
+    mp["desc"] = np.where((rng.random(M) < 0.85)[:, None], mc.flip_bits(rng, S["dl"][sl], 45), rng.integers(0, 256, (M, 32), dtype=np.uint8)).astype(np.uint8)
+    frame_mp0 = R["frame_mp"]
+    th13, th_far, ratio, far, th14, mb, mono = 2.0, 45.0, 0.8, 1, 7.0, 0.537, 0
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(struct.pack("<6i", nl, nr, M, S["ll"], len(S["last"]["has"]) - S["ll"], 8))
+        f.write(struct.pack("<16f", *CAM, *BOUNDS, th13, th_far, ratio, far, th14, mb, mono, float(check_ori)))
+        f.write(SCALE.tobytes())
+        for a in (S["kl"], S["kr"], np.concatenate([S["dl"], S["dr"]]), S["l2r"], S["r2l"]):
+            f.write(np.ascontiguousarray(a).tobytes())
+        for k, dt in (("track_in_view", np.uint8), ("track_in_view_r", np.uint8), ("bad", np.uint8), ("sparsified", np.uint8), ("proj_x", np.float32),
+                      ("proj_y", np.float32), ("proj_xr", np.float32), ("proj_yr", np.float32), ("track_depth", np.float32), ("level", np.int32),
+                      ("level_r", np.int32), ("view_cos", np.float32), ("view_cos_r", np.float32), ("desc", np.uint8), ("obs", np.int32)):
+            f.write(np.ascontiguousarray(mp[k], dt).tobytes())
+        f.write(frame_mp0.tobytes())
+        L = S["last"]
+        for a in (L["kl"], L["kr"], L["has"], L["outlier"], L["pos"], L["desc"], L["obs"], S["pose"], S["cur_hold"]):
+            f.write(np.ascontiguousarray(a).tobytes())
+    p = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    blob = (tmp_path / "out.bin").read_bytes()
+    pos = 0
+
+    def take(dt, n):
+        nonlocal pos
+        a = np.frombuffer(blob, dt, n, pos)
+        pos += a.nbytes
+        return a
+    # ---- SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints) through the class == the oracle's two-camera arm
+    nm13 = int(take(np.int32, 1)[0]); got13 = take(np.int32, N); refused = int(take(np.int32, 1)[0])
+    ofl, ofr = oracle.OracleFrame(S["kl"], S["dl"], None, BOUNDS, SCALE), oracle.OracleFrame(S["kr"], S["dr"], None, BOUNDS, SCALE)
+    want13 = frame_mp0.copy()
+    wn13 = oracle.search_by_projection_mps_rig(ofl, ofr, mp, S["l2r"], S["r2l"], want13, th13, bool(far), th_far, ratio)
+    assert nm13 == wn13 and np.array_equal(got13, want13)
+    assert (want13[:nl] != frame_mp0[:nl]).sum() > 200 and (want13[nl:] != frame_mp0[nl:]).sum() > 100 and refused == 1
+    # ---- SearchByProjection(CurrentFrame, LastFrame, th, bMono) through the class == the oracle's arm on the class's own projections
+    nm14 = int(take(np.int32, 1)[0]); got14 = take(np.int32, N)
+    fwd, bwd = (int(x) for x in take(np.int32, 2))
+    n_last = len(S["last"]["has"])
+    last = dict(valid=take(np.uint8, n_last), u=take(np.float32, n_last), v=take(np.float32, n_last), u_r=take(np.float32, n_last),
+                v_r=take(np.float32, n_last), octave=take(np.int32, n_last), angle=take(np.float32, n_last), desc=S["last"]["desc"],
+                mp=np.arange(n_last, dtype=np.int32))
+    assert pos == len(blob)
+    assert (fwd, bwd) == {"forward": (1, 0), "backward": (0, 1), "side": (0, 0)}[motion]
+    assert last["valid"].sum() > 600 and np.array_equal(last["octave"][last["valid"] > 0],
+                                                        np.concatenate([S["last"]["kl"], S["last"]["kr"]])["octave"][last["valid"] > 0])
+    held = np.flatnonzero(S["cur_hold"] >= 0)
+    cur = np.full(N, -1, np.int32)
+    cur[held] = n_last + np.arange(len(held))
+    last["obs"] = np.concatenate([S["last"]["obs"], S["cur_hold"][held]]).astype(np.int32)
+    want14 = cur.copy()
+    wn14 = oracle.search_by_projection_frames_rig(ofl, ofr, last, want14, th14, bool(fwd), bool(bwd), check_ori)
+    want_ids = np.where(want14 >= n_last, -2, want14)
+    assert nm14 == wn14 and np.array_equal(got14, want_ids), (nm14, wn14, int((got14 != want_ids).sum()))
+    newl, newr = ((want14[:nl] >= 0) & (want14[:nl] < n_last)).sum(), ((want14[nl:] >= 0) & (want14[nl:] < n_last)).sum()
+    assert newl > 150 and newr > 60, (newl, newr)                      # both arms matched
+    # and the flat C entry on the same projections gives the same (the class adds nothing to it but the projection)
+    dfl, dfr = msorb_mod.Frame(S["kl"], S["dl"], None, BOUNDS, SCALE), msorb_mod.Frame(S["kr"], S["dr"], None, BOUNDS, SCALE)
+    try:
+        c2 = cur.copy()
+        assert msorb_mod.search_by_projection_frames_rig(dfl, dfr, last, c2, th14, bool(fwd), bool(bwd), check_ori) == wn14 and np.array_equal(c2, want14)
+    finally:
+        dfl.close(); dfr.close()
