@@ -499,6 +499,15 @@ typedef struct msorb_bow_pair {
 } msorb_bow_pair;
 int msorb_search_by_bow(int device, msorb_bow_pair* pairs, int n_pairs, int th_low, int inclusive, float nnratio,
                         int check_orientation, float* elapsed_ms);
+/* ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) on a two-camera frame (F.Nleft != -1; ORBmatcher.cc:223-421 with the arms of
+ * :276-309 / :357-382): inside a BoW node every KeyFrame feature keeps a best / second over the frame's LEFT features (rows
+ * < n_left) and a best over its RIGHT features, each among the features no earlier KeyFrame feature has claimed; the left match as on
+ * a one-camera frame (<= th_low, ratio test), the right match at <= th_low WITHOUT a ratio test and only when the left best distance
+ * was <= th_low (:330 encloses :357).  pair: set 1 = the KeyFrame (valid1 = map point present and good), set 2 = the frame's
+ * n2 = N features, left camera first, angle2 = [mvKeys angles | mvKeysRight angles]; avail2 is not read.  match21[n2] (required):
+ * the KeyFrame feature whose map point frame feature j receives, -1 none; match12 (optional): the LEFT partner of each KeyFrame
+ * feature; nmatches counts both cameras.  One rotation histogram over both (:338-353, :361-378, :396-418).  Since ABI 6000. */
+int msorb_search_by_bow_rig(int device, msorb_bow_pair* pair, int n_left, int th_low, float nnratio, int check_orientation);
 
 /* ORBmatcher::SearchForTriangulation (ORBmatcher.cc:1168-1402; LocalMapping::CreateNewMapPoints, LocalMapping.cc:492)
  * for pinhole KeyFrames without a second camera.  One msorb_triangulation_pair per (mpCurrentKeyFrame, neighbour)

@@ -56,8 +56,13 @@ constexpr int kNoKey = 0x7fffffff;
 __global__ __launch_bounds__(64) void bow_match_kernel(const BowItem* __restrict__ items, const uint4* __restrict__ desc1,
                                                        const uint4* __restrict__ desc2, const uint8_t* __restrict__ valid1,
                                                        const uint8_t* __restrict__ avail2, const int* __restrict__ feat1,
-                                                       const int* __restrict__ feat2, int th_low, int inclusive,
-                                                       float nnratio, int* __restrict__ match12) {
+                                                       const int* __restrict__ feat2, int th_low, int flags,
+                                                       float nnratio, int* __restrict__ match12, int* __restrict__ best1 = nullptr) {
+    // flags: bit 0 = inclusive (best <= th_low, :332; else best < th_low, :959), bit 1 = no ratio test (the right-camera arm of
+    // SearchByBoW(pKF, F) on a two-camera frame, :357-359: `|| true`).  best1 (optional): per query feature the distance of its best
+    // unclaimed train at the time it is processed — before the threshold and the ratio test — or 256.
+    const int inclusive = flags & 1;
+    const bool no_ratio = (flags & 2) != 0;
     extern __shared__ unsigned free_bits[];  // bit p: train at list position p is unclaimed
     const BowItem it = items[blockIdx.x];
     const int lane = threadIdx.x;
@@ -106,8 +111,9 @@ __global__ __launch_bounds__(64) void bow_match_kernel(const BowItem* __restrict
         }
         second = min(second, 256);
         const int best = key >> 20;
+        if (best1 && lane == 0) best1[it.m1 + f1] = key != kNoKey ? best : 256;
         const bool pass = key != kNoKey && (inclusive ? best <= th_low : best < th_low) &&
-                          (float)best < nnratio * (float)second;  // :332-336, :959-961
+                          (no_ratio || (float)best < nnratio * (float)second);  // :332-336, :959-961
         if (pass) {
             const int p = key & 0xFFFFF;
             if (lane == 0) {
@@ -432,8 +438,12 @@ int hip_fail(Scratch& scr, const char* what, hipError_t e) {
 
 }  // namespace
 
-extern "C" int msorb_search_by_bow(int device, msorb_bow_pair* pairs, int n_pairs, int th_low, int inclusive, float nnratio,
-                                   int check_orientation, float* elapsed_ms) {
+namespace {
+// msorb_search_by_bow's body.  flags: bit 0 inclusive, bit 1 no ratio test; best1 (optional): per pair the kernel's best1 output.
+int search_by_bow_impl(int device, msorb_bow_pair* pairs, int n_pairs, int th_low, int flags, float nnratio, int check_orientation,
+                       float* elapsed_ms, std::vector<std::vector<int>>* best1) {
+    const int inclusive = flags;   // (passed through to the kernel, which reads the bits)
+    if (best1) { best1->assign(n_pairs, {}); for (int pi = 0; pi < n_pairs; pi++) (*best1)[pi].assign(std::max(pairs[pi].n1, 0), 256); }
     if (elapsed_ms) *elapsed_ms = 0;
     if (n_pairs < 0 || (n_pairs > 0 && !pairs)) return MSORB_E_INVALID;
     if (n_pairs == 0) return MSORB_OK;
@@ -471,7 +481,7 @@ extern "C" int msorb_search_by_bow(int device, msorb_bow_pair* pairs, int n_pair
     // ---- staging: [desc1 | desc2 | feat1 | feat2 | items | valid1 | avail2] in, [match12] out ----
     const size_t o_d1 = 0, o_d2 = o_d1 + tot1 * 32, o_f1 = o_d2 + tot2 * 32, o_f2 = o_f1 + up16(totf1 * 4),
                  o_it = o_f2 + up16(totf2 * 4), o_v1 = o_it + up16(n_items * sizeof(BowItem)), o_a2 = o_v1 + up16(tot1),
-                 in_bytes = o_a2 + up16(tot2), o_m = in_bytes, total = o_m + up16(tot1 * 4);
+                 in_bytes = o_a2 + up16(tot2), o_m = in_bytes, o_b = o_m + up16(tot1 * 4), total = o_b + (best1 ? up16(tot1 * 4) : 0);
     static thread_local Scratch scr;
     hipError_t e = scr.acquire(device, total);
     if (e != hipSuccess) return hip_fail(scr, "search_by_bow", e);
@@ -502,14 +512,26 @@ extern "C" int msorb_search_by_bow(int device, msorb_bow_pair* pairs, int n_pair
         hipLaunchKernelGGL(bow_match_kernel, dim3((unsigned)n_items), dim3(64), (size_t)max_chunks * 8, s,
                            (const BowItem*)(d + o_it), (const uint4*)(d + o_d1), (const uint4*)(d + o_d2),
                            (const uint8_t*)(d + o_v1), (const uint8_t*)(d + o_a2), (const int*)(d + o_f1),
-                           (const int*)(d + o_f2), th_low, inclusive, nnratio, (int*)(d + o_m));
+                           (const int*)(d + o_f2), th_low, inclusive, nnratio, (int*)(d + o_m), best1 ? (int*)(d + o_b) : nullptr);
         e = hipGetLastError();
     }
     if (e == hipSuccess && elapsed_ms) e = hipEventRecord(scr.e1, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(scr.h + o_m, d + o_m, tot1 * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(scr.h + o_m, d + o_m, (best1 ? o_b - o_m : 0) + tot1 * 4, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess && elapsed_ms) e = hipEventElapsedTime(elapsed_ms, scr.e0, scr.e1);
     if (e != hipSuccess) return hip_fail(scr, "search_by_bow", e);
+    if (best1) {   // (features of nodes the two vectors do not share were never visited: they keep 256)
+        size_t r = 0;
+        for (int pi = 0; pi < n_pairs; pi++) {
+            const int* b = (const int*)(scr.h + o_b) + r;
+            for (const Common& c : common[pi])
+                for (int k = fa[pi].begin[c.r1]; k < fa[pi].begin[c.r1 + 1]; k++) {
+                    const int i1 = fa[pi].feat[k];
+                    if (pairs[pi].valid1[i1]) (*best1)[pi][i1] = b[i1];
+                }
+            r += (size_t)pairs[pi].n1;
+        }
+    }
     // the raw matches are read feature by feature below: out of the pinned block first (one streaming copy) — scattered 4-byte
     // reads of pinned host memory cost ~10 ns each, 0.8 ms for a 32-pair batch
     static thread_local std::vector<int> m_local;
@@ -527,6 +549,100 @@ extern "C" int msorb_search_by_bow(int device, msorb_bow_pair* pairs, int n_pair
             for (int i = 0; i < P.n1; i++)
                 if (P.match12[i] >= 0) P.match21[P.match12[i]] = i;
     }
+    return MSORB_OK;
+}
+}  // namespace
+
+extern "C" int msorb_search_by_bow(int device, msorb_bow_pair* pairs, int n_pairs, int th_low, int inclusive, float nnratio,
+                                   int check_orientation, float* elapsed_ms) {
+    return search_by_bow_impl(device, pairs, n_pairs, th_low, inclusive ? 1 : 0, nnratio, check_orientation, elapsed_ms, nullptr);
+}
+
+// ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) on a two-camera frame (F.Nleft != -1), ORBmatcher.cc:223-421 with the arms of
+// :276-309 and :357-382: inside a BoW node every KeyFrame feature keeps a best / second over the frame's LEFT features and a best
+// over its RIGHT features (rows >= n_left), both among the features no earlier KeyFrame feature has claimed.  The left match is
+// taken as on a one-camera frame (<= TH_LOW, ratio test); the right match — only looked at when the LEFT best distance was <= TH_LOW,
+// whatever the ratio test said (:330 encloses :357) — is taken at <= TH_LOW without a ratio test (`|| true`).  Left and right claims
+// touch disjoint features, so the two arms are two runs of the node kernel: the left one also reports every KeyFrame feature's
+// left best distance, which gates the right one.  Both feed ONE rotation histogram, per KeyFrame feature the left entry first.
+//   pair: as msorb_search_by_bow (set 1 = the KeyFrame, set 2 = the frame's n2 = N features, left camera first; avail2 unused);
+//   match21[n2]: the KeyFrame feature matched to frame feature j (vpMapPointMatches[j] = its map point), -1 none.
+extern "C" int msorb_search_by_bow_rig(int device, msorb_bow_pair* pair, int n_left, int th_low, float nnratio, int check_orientation) {
+    if (!pair || n_left < 0 || n_left > pair->n2 || !pair->match21 || (pair->n1 > 0 && !pair->valid1)) return MSORB_E_INVALID;
+    msorb_bow_pair& P = *pair;
+    P.nmatches = 0;
+    FeatVec fb{P.fv2_nodes, P.fv2_node, P.fv2_begin, P.fv2_feat}, fa{P.fv1_nodes, P.fv1_node, P.fv1_begin, P.fv1_feat};
+    std::vector<uint8_t> seen;
+    if (P.n1 < 0 || P.n2 < 0 || !check_feature_vector(P.n2, fb, seen) || !check_feature_vector(P.n1, fa, seen) ||
+        (check_orientation && ((P.n1 > 0 && !P.angle1) || (P.n2 > 0 && !P.angle2)))) {
+        set_last_error("search_by_bow_rig: bad sizes / null arrays / feature vector not ascending, out of range or with a repeated feature");
+        return MSORB_E_INVALID;
+    }
+    // the frame's FeatureVector split by camera (the node ids and the order inside a node stay)
+    std::vector<int> nodeL, beginL{0}, featL, nodeR, beginR{0}, featR;
+    for (int r = 0; r < fb.nodes; r++) {
+        const size_t l0 = featL.size(), r0 = featR.size();
+        for (int k = fb.begin[r]; k < fb.begin[r + 1]; k++) (fb.feat[k] < n_left ? featL : featR).push_back(fb.feat[k]);
+        if (featL.size() > l0) { nodeL.push_back(fb.node[r]); beginL.push_back((int)featL.size()); }
+        if (featR.size() > r0) { nodeR.push_back(fb.node[r]); beginR.push_back((int)featR.size()); }
+    }
+    std::vector<int> m12L(std::max(P.n1, 1), -1), m12R(std::max(P.n1, 1), -1), m21(std::max(P.n2, 1), -1);
+    msorb_bow_pair A = P;
+    A.avail2 = nullptr; A.match12 = m12L.data(); A.match21 = nullptr;
+    A.fv2_nodes = (int)nodeL.size(); A.fv2_node = nodeL.data(); A.fv2_begin = beginL.data(); A.fv2_feat = featL.data();
+    std::vector<std::vector<int>> best1;
+    int rc = search_by_bow_impl(device, &A, 1, th_low, 1, nnratio, 0, nullptr, &best1);
+    if (rc) return rc;
+    std::vector<uint8_t> validR(std::max(P.n1, 1), 0);
+    for (int i = 0; i < P.n1; i++) validR[i] = P.valid1[i] && best1[0][i] <= th_low;                // :330
+    msorb_bow_pair B = P;
+    B.valid1 = validR.data(); B.avail2 = nullptr; B.match12 = m12R.data(); B.match21 = nullptr;
+    B.fv2_nodes = (int)nodeR.size(); B.fv2_node = nodeR.data(); B.fv2_begin = beginR.data(); B.fv2_feat = featR.data();
+    rc = search_by_bow_impl(device, &B, 1, th_low, 1 | 2, nnratio, 0, nullptr, nullptr);
+    if (rc) return rc;
+    // the rotation histogram in the reference's order: the nodes both full vectors hold, the KeyFrame's features of a node in list
+    // order, the left match of a feature before its right match (:338-353, :361-378); then ComputeThreeMaxima (:396-418)
+    for (int j = 0; j < P.n2; j++) P.match21[j] = -1;
+    std::vector<std::pair<int, int>> hist[kHistoLength];   // (frame feature, KeyFrame feature)
+    const float factor = 1.0f / kHistoLength;
+    int nm = 0;
+    int i = 0, j = 0;
+    while (i < fa.nodes && j < fb.nodes) {
+        if (fa.node[i] == fb.node[j]) {
+            for (int k = fa.begin[i]; k < fa.begin[i + 1]; k++) {
+                const int i1 = fa.feat[k];
+                for (int side = 0; side < 2; side++) {
+                    const int i2 = side ? m12R[i1] : m12L[i1];
+                    if (i2 < 0) continue;
+                    P.match21[i2] = i1;
+                    nm++;
+                    if (check_orientation) {
+                        float rot = P.angle1[i1] - P.angle2[i2];
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)std::round(rot * factor);
+                        if (bin == kHistoLength) bin = 0;
+                        if (bin >= 0 && bin < kHistoLength) hist[bin].push_back({i2, i1});
+                        else { P.match21[i2] = -1; nm--; }
+                    }
+                }
+            }
+            i++; j++;
+        } else if (fa.node[i] < fb.node[j]) i++;
+        else j++;
+    }
+    if (check_orientation) {
+        int sizes[kHistoLength], ind[3];
+        for (int b = 0; b < kHistoLength; b++) sizes[b] = (int)hist[b].size();
+        msorb_three_maxima(sizes, kHistoLength, ind);
+        for (int b = 0; b < kHistoLength; b++)
+            if (b != ind[0] && b != ind[1] && b != ind[2])
+                for (auto& e : hist[b]) { P.match21[e.first] = -1; nm--; }
+    }
+    if (P.match12) {   // the left partner of every KeyFrame feature (the right one is in match21 only)
+        for (int k = 0; k < P.n1; k++) P.match12[k] = -1;
+        for (int f2 = 0; f2 < n_left; f2++) if (P.match21[f2] >= 0) P.match12[P.match21[f2]] = f2;
+    }
+    P.nmatches = nm;
     return MSORB_OK;
 }
 
@@ -966,7 +1082,7 @@ extern "C" int msorb_search_by_bow_kf(msorb_kf_store* st, msorb_bow_kf_pair* pai
         const int* feat2 = frame ? (const int*)(d + o_ff) : st->d_feat;
         hipLaunchKernelGGL(bow_match_kernel, dim3((unsigned)n_items), dim3(64), (size_t)max_chunks * 8, s, (const BowItem*)(d + o_it),
                            st->d_desc, desc2, (const uint8_t*)(d + o_v1), (const uint8_t*)(d + o_a2), st->d_feat, feat2, th_low,
-                           inclusive, nnratio, (int*)(d + o_m));
+                           inclusive ? 1 : 0, nnratio, (int*)(d + o_m));
         hipLaunchKernelGGL(pair_histogram_kernel, dim3((unsigned)n_pairs), dim3(256), 0, s, (const PairPost*)(d + o_po), st->d_angle,
                            frame ? (const float*)(d + o_fa) : st->d_angle, check_orientation, (int*)(d + o_m), (int*)(d + o_m21),
                            (int*)(d + o_nm));

@@ -70,8 +70,8 @@ void drop_thread_cache() { g_thread_cache.reset(); }
 // application decides what to do with a rig this build does not serve; it is never answered with left-camera associations
 [[noreturn]] void unsupported_rig(const char* what) {
     throw std::runtime_error(std::string("msorb: ") + what + " — of the two-camera branches (Nleft != -1) this build serves SearchByProjection(F, "
-                             "vpMapPoints) and SearchByProjection(Current, Last) (ORBmatcher.cc:144-210, 2059-2124); SearchByBoW(pKF, F) on such a frame, "
-                             "the second-camera arms of SearchForTriangulation and Fuse(..., bRight = true) are not served (ORBmatcher_rig_device.h)");
+                             "vpMapPoints), SearchByProjection(Current, Last) and SearchByBoW(pKF, F) (ORBmatcher.cc:144-210, 2059-2124, 276-382); the "
+                             "second-camera arms of SearchForTriangulation and Fuse(..., bRight = true) are not served (ORBmatcher_rig_device.h)");
 }
 msorb_host::DeviceFrame<Frame>& device_frame(const Frame& F, bool second = false) {
     ThreadCache& c = cache();
@@ -169,9 +169,8 @@ int ORBmatcher::SearchByProjection(std::shared_ptr<KeyFrame> pKF, Sophus::Sim3<f
 }
 
 int ORBmatcher::SearchByBoW(std::shared_ptr<KeyFrame> pKF, Frame& F, std::vector<std::shared_ptr<MapPoint>>& vpMapPointMatches) {
-    // (:276-309: on a two-camera frame every KeyFrame feature keeps a best / second per camera inside its BoW node — never answered
-    // with the one-camera search)
-    if (F.Nleft != -1) unsupported_rig("ORBmatcher::SearchByBoW(pKF, F, ...) on a Frame with Nleft != -1");
+    // (:276-309: on a two-camera frame every KeyFrame feature keeps a best / second per camera inside its BoW node)
+    if (F.Nleft != -1) return msorb_host::SearchByBoWRig(pKF, F, vpMapPointMatches, mfNNratio, mbCheckOrientation, matcher_device());
     std::vector<std::vector<std::shared_ptr<MapPoint>>> out;
     const int n = msorb_host::SearchByBoWBatch(keyframe_store(), std::vector<std::shared_ptr<KeyFrame>>{pKF}, F, out, mfNNratio,
                                                mbCheckOrientation)[0];

@@ -5,11 +5,12 @@
 // right one F.mvKeysRight with rows [Nleft, N) — what Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel, bRight) walks
 // (Frame.cc:589-655: the raw keypoints, not mvKeysUn, for such a frame) — both without mvuRight (the rectified-stereo test of
 // :92 / :2015 is `Nleft == -1` only).  F.mvpMapPoints stays ONE array of N = Nleft + Nright entries.
+//   ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches)                                              ORBmatcher.cc:223-421 (arms :276-309, :357-382)
 // No shipped configuration of MS-SLAM builds such frames (every YAML is Rectified / PinHole); the arms exist so that the class
 // answers what the reference's class answers.  Not served for such a rig (the class throws, ORBmatcher.cc `unsupported_rig`):
-// SearchByBoW(pKF, F) with F.Nleft != -1 (:223-421, the per-camera best / second of one BoW node), SearchForTriangulation's
-// second-camera arms (:1168-1402: KannalaBrandt8::epipolarConstrain, a camera model outside this build), Fuse(..., bRight = true)
-// (:1404-1597: its gates read GetKeyPoint(idx) with a RIGHT-grid index, i.e. a left keypoint, before idx += NLeft).
+// SearchForTriangulation's second-camera arms (:1168-1402: KannalaBrandt8::epipolarConstrain, a camera model outside this
+// build) and Fuse(..., bRight = true) (:1404-1597: its gates read GetKeyPoint(idx) with a RIGHT-grid index, i.e. a left
+// keypoint, before idx += NLeft).
 #ifndef MSORB_ORBMATCHER_RIG_DEVICE_H
 #define MSORB_ORBMATCHER_RIG_DEVICE_H
 
@@ -155,6 +156,29 @@ int SearchByProjectionRig(DeviceFrame<FrameT>& devL, DeviceFrame<FrameT>& devR, 
         else CurrentFrame.mvpMapPoints[j] = LastFrame.mvpMapPoints[curMp[j]];
     }
     return nmatches;
+}
+
+// ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches), F.Nleft != -1 (:223-421): msorb_search_by_bow_rig on the KeyFrame's and the
+// frame's descriptors / FeatureVectors (per call; the resident-KeyFrame form serves one-camera frames).
+template <class KeyFramePtr, class FrameT, class MapPointPtr>
+int SearchByBoWRig(const KeyFramePtr& pKF, FrameT& F, std::vector<MapPointPtr>& vpMapPointMatches, float mfNNratio, bool mbCheckOrientation,
+                   int device = 0) {
+    const auto mpsKF = pKF->GetMapPointMatches();                          // :225
+    BowSide kf, frame;
+    kf.FillKeyFrame(pKF);
+    kf.FlagGood(mpsKF);                                                    // :253-259
+    frame.Fill(F.N, [&](int i) { return F.mDescriptors.row(i); }, F.mFeatVec, F.mvKeys);
+    // the angle of a frame feature: mvKeys for the left camera's rows, mvKeysRight for the right camera's (:344-346, :365-367)
+    frame.angle.resize(F.N);
+    for (int i = 0; i < F.N; i++) frame.angle[i] = i < F.Nleft ? F.mvKeys[i].angle : F.mvKeysRight[i - F.Nleft].angle;
+    msorb_bow_pair P;
+    std::vector<int> m12, m21;
+    BindBowPair(P, kf, frame, true, m12, m21);
+    check(msorb_search_by_bow_rig(device, &P, F.Nleft, 50 /* TH_LOW */, mfNNratio, mbCheckOrientation), "msorb_search_by_bow_rig");
+    vpMapPointMatches.assign(F.N, MapPointPtr());                          // :227
+    for (int j = 0; j < F.N && j < (int)m21.size(); j++)
+        if (m21[j] >= 0) vpMapPointMatches[j] = mpsKF[m21[j]];             // :336, :359
+    return P.nmatches;
 }
 
 }  // namespace msorb_host

@@ -918,7 +918,29 @@ def search_by_bow(pairs, th_low=50, inclusive=True, nnratio=0.7, check_orientati
     return [(arr[k].nmatches, o[0][:o[2]], o[1][:o[3]]) for k, o in enumerate(outs)], ms.value
 
 
-EXPORTS = EXPORTS + ("msorb_search_for_triangulation",)
+def search_by_bow_rig(p, n_left, th_low=50, nnratio=0.7, check_orientation=True, device=0):
+    """msorb_search_by_bow_rig: SearchByBoW(pKF, F) on a two-camera frame; p as in search_by_bow (set 2 = the frame's N features, the
+    left camera's n_left rows first).  -> (nmatches, match21, match12 = the left partner of each KeyFrame feature)"""
+    lb = lib()
+    lb.msorb_search_by_bow_rig.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]
+    q = BowPair()
+    d1, d2 = _c(p["desc1"], np.uint8).reshape(-1, 32), _c(p["desc2"], np.uint8).reshape(-1, 32)
+    v1 = _c(p["valid1"], np.uint8)
+    f1 = [_c(a, np.int32) for a in p["fv1"]]
+    f2 = [_c(a, np.int32) for a in p["fv2"]]
+    g1, g2 = _c(p["angle1"], np.float32), _c(p["angle2"], np.float32)
+    m12, m21 = np.zeros(max(len(d1), 1), np.int32), np.zeros(max(len(d2), 1), np.int32)
+    q.n1, q.n2 = len(d1), len(d2)
+    q.desc1, q.desc2, q.valid1, q.avail2 = _np_ptr(d1), _np_ptr(d2), _np_ptr(v1), None
+    q.fv1_nodes, q.fv1_node, q.fv1_begin, q.fv1_feat = len(f1[0]), _np_ptr(f1[0]), _np_ptr(f1[1]), _np_ptr(f1[2])
+    q.fv2_nodes, q.fv2_node, q.fv2_begin, q.fv2_feat = len(f2[0]), _np_ptr(f2[0]), _np_ptr(f2[1]), _np_ptr(f2[2])
+    q.angle1, q.angle2, q.match12, q.match21 = _np_ptr(g1), _np_ptr(g2), _np_ptr(m12), _np_ptr(m21)
+    _check(lb.msorb_search_by_bow_rig(device, C.addressof(q), int(n_left), int(th_low), float(nnratio), int(bool(check_orientation))),
+           "msorb_search_by_bow_rig")
+    return q.nmatches, m21[:len(d2)], m12[:len(d1)]
+
+
+EXPORTS = EXPORTS + ("msorb_search_for_triangulation", "msorb_search_by_bow_rig")
 
 
 class TriangulationPair(C.Structure):

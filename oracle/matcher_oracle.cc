@@ -930,6 +930,73 @@ int orc_search_by_bow(int n1, int n2, const uint8_t* desc1, const uint8_t* desc2
     return nmatches;
 }
 
+// ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) on a two-camera frame (F.Nleft != -1), ORBmatcher.cc:223-421 statement by
+// statement with the arms of :276-309 and :357-382.  Set 1 = the KeyFrame (valid1 = pMP && !pMP->isBad()), set 2 = the frame's
+// n2 = N features (left camera's rows first), angle2 = mvKeys / mvKeysRight angles in row order.  match21[n2] = vpMapPointMatches as
+// KeyFrame feature indices.  Returns nmatches.
+int orc_search_by_bow_rig(int n1, int n2, int n_left, const uint8_t* desc1, const uint8_t* desc2, const uint8_t* valid1, int nn1,
+                          const int* node1, const int* begin1, const int* feat1, int nn2, const int* node2, const int* begin2,
+                          const int* feat2, const float* angle1, const float* angle2, int th_low, float nnratio, int check_orientation,
+                          int* match21) {
+    for (int j = 0; j < n2; j++) match21[j] = -1;
+    std::vector<int> rotHist[orc::HISTO_LENGTH];
+    const float factor = 1.0f / orc::HISTO_LENGTH;
+    int nmatches = 0;
+    int it1 = 0, it2 = 0;
+    while (it1 != nn1 && it2 != nn2) {
+        if (node1[it1] == node2[it2]) {
+            for (int iKF = begin1[it1]; iKF < begin1[it1 + 1]; iKF++) {
+                const int realIdxKF = feat1[iKF];
+                if (!valid1[realIdxKF]) continue;
+                const uint8_t* dKF = desc1 + (size_t)realIdxKF * 32;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                int bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
+                for (int iF = begin2[it2]; iF < begin2[it2 + 1]; iF++) {
+                    const int realIdxF = feat2[iF];
+                    if (match21[realIdxF] >= 0) continue;
+                    const int dist = orc::descriptor_distance(dKF, desc2 + (size_t)realIdxF * 32);
+                    if (realIdxF < n_left && dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                    else if (realIdxF < n_left && dist < bestDist2) bestDist2 = dist;
+                    if (realIdxF >= n_left && dist < bestDist1R) { bestDist2R = bestDist1R; bestDist1R = dist; bestIdxFR = realIdxF; }
+                    else if (realIdxF >= n_left && dist < bestDist2R) bestDist2R = dist;
+                }
+                auto push = [&](int idxF) {
+                    if (!check_orientation) return;
+                    float rot = angle1[realIdxKF] - angle2[idxF];
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == orc::HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(idxF);
+                };
+                if (bestDist1 <= th_low) {
+                    if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                        match21[bestIdxF] = realIdxKF;
+                        push(bestIdxF);
+                        nmatches++;
+                    }
+                    if (bestDist1R <= th_low) {   // (`|| true`: no ratio test)
+                        match21[bestIdxFR] = realIdxKF;
+                        push(bestIdxFR);
+                        nmatches++;
+                    }
+                }
+                (void)bestDist2R;
+            }
+            it1++; it2++;
+        } else if (node1[it1] < node2[it2]) it1++;   // lower_bound on ascending ids
+        else it2++;
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc::three_maxima(rotHist, orc::HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < orc::HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { match21[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 // ORBmatcher::SearchForTriangulation (ORBmatcher.cc:1168-1402), pinhole cameras without a second camera
 // (mpCamera2 == nullptr).  valid1[i]: the query is visited (no map point :1237-1241, stereo when bOnlyStereo :1245-1247,
 // descriptor not empty); avail2[j]: the train is eligible apart from the running vbMatched2 (:1264, 1269-1271);

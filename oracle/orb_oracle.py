@@ -603,6 +603,24 @@ def search_by_bow(desc1, desc2, valid1, avail2, fv1, fv2, angle1, angle2, th_low
     return nm, m12[:n1], m21[:n2]
 
 
+def search_by_bow_rig(p, n_left, th_low=50, nnratio=0.7, check_orientation=True):
+    """orc_search_by_bow_rig (ORBmatcher.cc:223-421, F.Nleft != -1); p as for search_by_bow -> (nmatches, match21)"""
+    Lb = _mlib()
+    Lb.orc_search_by_bow_rig.argtypes = ([C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5 +
+                                         [C.c_int, C.c_float, C.c_int, C.c_void_p])
+    Lb.orc_search_by_bow_rig.restype = C.c_int
+    d1, d2 = _c(p["desc1"], np.uint8).reshape(-1, 32), _c(p["desc2"], np.uint8).reshape(-1, 32)
+    v1 = _c(p["valid1"], np.uint8)
+    f1 = [_c(a, np.int32) for a in p["fv1"]]
+    f2 = [_c(a, np.int32) for a in p["fv2"]]
+    g1, g2 = _c(p["angle1"], np.float32), _c(p["angle2"], np.float32)
+    m21 = np.zeros(max(len(d2), 1), np.int32)
+    nm = Lb.orc_search_by_bow_rig(len(d1), len(d2), int(n_left), _ptr(d1), _ptr(d2), _ptr(v1), len(f1[0]), _ptr(f1[0]), _ptr(f1[1]), _ptr(f1[2]),
+                                  len(f2[0]), _ptr(f2[0]), _ptr(f2[1]), _ptr(f2[2]), _ptr(g1), _ptr(g2), int(th_low), float(nnratio),
+                                  int(bool(check_orientation)), _ptr(m21))
+    return nm, m21[:len(d2)]
+
+
 def search_for_triangulation(p, coarse=False, check_orientation=True):
     """oracle/matcher_oracle.cc orc_search_for_triangulation (ORBmatcher.cc:1168-1402).  p: dict as made by
     tests/bow_match_cases.make_triangulation_pair.  -> (nmatches, match12)"""

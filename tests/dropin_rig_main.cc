@@ -87,11 +87,10 @@ int main(int argc, char** argv) {
         std::vector<int> ids(N, -1);
         for (int j = 0; j < N; j++) if (F.mvpMapPoints[j]) ids[j] = (int)F.mvpMapPoints[j]->mnId;
         wr(o, ids);
-        // the calls this build refuses for such a rig
+        // the calls this build refuses for a two-camera rig: Fuse(..., bRight = true)
         int refused = 0;
         auto kf = std::make_shared<KeyFrame>();
-        std::vector<MP> m;
-        try { matcher.SearchByBoW(kf, F, m); } catch (const std::runtime_error&) { refused++; }
+        try { matcher.Fuse(kf, pts, 3.0f, true); } catch (const std::runtime_error&) { refused++; }
         wri(o, refused);
     }
     // ---- a14: LastFrame (two cameras as well) with map points in the world, CurrentFrame with a pose and the rig's Trl
@@ -146,6 +145,41 @@ int main(int argc, char** argv) {
         wr(o, ids);
         wri(o, P.forward); wri(o, P.backward);
         wr(o, P.valid); wr(o, P.u); wr(o, P.v); wr(o, P.ur); wr(o, P.vr); wr(o, P.octave); wr(o, P.angle);
+    }
+    // ---- SearchByBoW(pKF, F, vpMapPointMatches) on the two-camera frame: a KeyFrame from the scene file's tail
+    {
+        FILE* g = fopen(argv[1], "rb");
+        fseek(g, -(long)sizeof(long), SEEK_END);
+        long tail = 0;
+        if (fread(&tail, sizeof(long), 1, g) != 1) return 3;
+        fseek(g, tail, SEEK_SET);
+        const auto h2 = rd<int>(g, 1);
+        const int NK = h2[0];
+        const auto kk = rd<cv::KeyPoint>(g, NK);
+        const auto kd = rd<unsigned char>(g, (size_t)NK * 32);
+        const auto knode = rd<int>(g, NK);
+        const auto kstate = rd<unsigned char>(g, NK);     // 0 no map point, 1 good, 2 bad
+        const auto fnode = rd<int>(g, N);
+        fclose(g);
+        auto kf = std::make_shared<KeyFrame>();
+        kf->SetFeatures(kk, kd.data());
+        kf->mvScaleFactors = scale;
+        DBoW2::FeatureVector fv;
+        for (int i = 0; i < NK; i++) if (knode[i] >= 0) fv.addFeature((DBoW2::NodeId)knode[i], (unsigned)i);
+        kf->SetFeatureVector(fv);
+        for (int i = 0; i < NK; i++)
+            if (kstate[i]) { auto p = std::make_shared<MapPoint>(); p->mnId = 300000ul + (unsigned long)i; p->mbBad = kstate[i] == 2; kf->AddMapPoint(p, i); }
+        Frame F;
+        set_rig(F, kl, kr, desc, l2r, r2l, scale, &cam, &fl[4]);
+        F.mnId = 79;
+        for (int j = 0; j < N; j++) if (fnode[j] >= 0) F.mFeatVec.addFeature((DBoW2::NodeId)fnode[j], (unsigned)j);
+        ORBmatcher m07(0.7f, fl[15] != 0);
+        std::vector<MP> matches;
+        const int nm = m07.SearchByBoW(kf, F, matches);
+        wri(o, nm);
+        std::vector<int> ids(N, -1);
+        for (int j = 0; j < N; j++) if (matches[j]) ids[j] = (int)(matches[j]->mnId - 300000ul);
+        wr(o, ids);
     }
     fclose(o);
     msorb_host::Shutdown();

@@ -222,6 +222,22 @@ def test_class_search_by_projection_on_two_camera_frames(msorb_mod, oracle, tmp_
         L = S["last"]
         for a in (L["kl"], L["kr"], L["has"], L["outlier"], L["pos"], L["desc"], L["obs"], S["pose"], S["cur_hold"]):
             f.write(np.ascontiguousarray(a).tobytes())
+        # tail: a KeyFrame for SearchByBoW(pKF, F) — its features are noisy copies of the frame's (both cameras), BoW nodes by source
+        tail = f.tell()
+        NK = 1100
+        allk = np.concatenate([S["kl"], S["kr"]]); alld = np.concatenate([S["dl"], S["dr"]])
+        fnode = (np.arange(N) * 7919 % 60).astype(np.int32)
+        part = np.flatnonzero(S["l2r"] >= 0)
+        fnode[nl + S["l2r"][part]] = fnode[part]                       # stereo partners share their node
+        ksrc = rng.integers(0, nl, NK)
+        kk = np.zeros(NK, oracle.KP_DTYPE); kk["angle"] = (allk["angle"][ksrc] + 30 + rng.normal(0, 4, NK)) % 360; kk["octave"] = allk["octave"][ksrc]
+        kd = mc.flip_bits(rng, alld[ksrc], 20)
+        knode = np.where(rng.random(NK) < 0.05, -1, fnode[ksrc]).astype(np.int32)
+        kstate = rng.choice(np.array([0, 1, 1, 1, 1, 2], np.uint8), NK)
+        f.write(struct.pack("<i", NK))
+        for a in (kk, kd, knode, kstate, fnode):
+            f.write(np.ascontiguousarray(a).tobytes())
+        f.write(struct.pack("<q", tail))
     p = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     blob = (tmp_path / "out.bin").read_bytes()
@@ -246,7 +262,13 @@ def test_class_search_by_projection_on_two_camera_frames(msorb_mod, oracle, tmp_
     last = dict(valid=take(np.uint8, n_last), u=take(np.float32, n_last), v=take(np.float32, n_last), u_r=take(np.float32, n_last),
                 v_r=take(np.float32, n_last), octave=take(np.int32, n_last), angle=take(np.float32, n_last), desc=S["last"]["desc"],
                 mp=np.arange(n_last, dtype=np.int32))
+    nm_bow = int(take(np.int32, 1)[0]); got_bow = take(np.int32, N)
     assert pos == len(blob)
+    pb = dict(desc1=kd, desc2=alld, valid1=(kstate == 1).astype(np.uint8), fv1=bmc.feature_vector_from_nodes(knode),
+              fv2=bmc.feature_vector_from_nodes(fnode), angle1=kk["angle"], angle2=allk["angle"])
+    wn_bow, w21 = oracle.search_by_bow_rig(pb, nl, 50, 0.7, check_ori)
+    assert nm_bow == wn_bow and np.array_equal(got_bow, w21), (nm_bow, wn_bow)
+    assert (w21[:nl] >= 0).sum() > 100 and (w21[nl:] >= 0).sum() > 50
     assert (fwd, bwd) == {"forward": (1, 0), "backward": (0, 1), "side": (0, 0)}[motion]
     assert last["valid"].sum() > 600 and np.array_equal(last["octave"][last["valid"] > 0],
                                                         np.concatenate([S["last"]["kl"], S["last"]["kr"]])["octave"][last["valid"] > 0])
@@ -267,3 +289,51 @@ def test_class_search_by_projection_on_two_camera_frames(msorb_mod, oracle, tmp_
         assert msorb_mod.search_by_projection_frames_rig(dfl, dfr, last, c2, th14, bool(fwd), bool(bwd), check_ori) == wn14 and np.array_equal(c2, want14)
     finally:
         dfl.close(); dfr.close()
+
+
+# ---- SearchByBoW(pKF, F, vpMapPointMatches) on a two-camera frame (ORBmatcher.cc:223-421 with the Nleft arms) -----------------
+import bow_match_cases as bmc
+
+
+def _bow_rig_pair(seed, n1, n2, n_left, n_nodes=50, shuffle=False):
+    p = bmc.make_pair(seed, n1=n1, n2=n2, n_nodes=n_nodes, shuffle_lists=shuffle)
+    rng = np.random.default_rng(seed + 5000)
+    node2 = np.full(n2, -1, np.int64)
+    nodes, begin, feat = p["fv2"]
+    for r in range(len(nodes)):
+        node2[feat[begin[r]:begin[r + 1]]] = nodes[r]
+    # right-camera rows that are the stereo partners of left rows: the same node, a near descriptor
+    if 0 < n_left < n2:
+        right = np.arange(n_left, n2)
+        twin = right[rng.random(len(right)) < 0.6]
+        src = rng.integers(0, n_left, len(twin))
+        p["desc2"][twin] = bmc.bow_cases._flip_bits(rng, p["desc2"][src], rng.integers(0, 14, len(twin)))
+        node2[twin] = node2[src]
+        p["angle2"][twin] = np.mod(p["angle2"][src] + rng.normal(0, 3, len(twin)), 360).astype(np.float32)
+    p["fv2"] = bmc.feature_vector_from_nodes(node2)
+    if shuffle:
+        for r in range(len(p["fv2"][0])):
+            rng.shuffle(p["fv2"][2][p["fv2"][1][r]:p["fv2"][1][r + 1]])
+    p["avail2"] = None
+    return p
+
+
+@pytest.mark.parametrize("seed,n1,n2,n_left,shuffle", [(1, 1200, 2400, 1300, False), (2, 900, 1800, 900, True), (3, 1500, 1000, 1000, False),
+                                                      (4, 700, 1400, 0, False), (5, 800, 1600, 30, True), (6, 0, 500, 250, False),
+                                                      (7, 600, 0, 0, False), (8, 2000, 3000, 1500, True)])
+def test_search_by_bow_two_camera_frame(msorb_mod, oracle, seed, n1, n2, n_left, shuffle):
+    p = _bow_rig_pair(seed, n1, n2, n_left, shuffle=shuffle)
+    for ratio, ori in ((0.7, True), (0.9, False), (0.6, True)):
+        wn, w21 = oracle.search_by_bow_rig(p, n_left, 50, ratio, ori)
+        gn, g21, g12 = msorb_mod.search_by_bow_rig(p, n_left, 50, ratio, ori)
+        assert gn == wn and np.array_equal(g21, w21), (seed, ratio, ori, gn, wn, int((g21 != w21).sum()))
+        for k in np.flatnonzero(g12 >= 0):                       # match12 = the left partner
+            assert g12[k] < n_left and g21[g12[k]] == k
+        if n1 >= 900 and n_left >= 900 and n2 - n_left >= 900:
+            assert (w21[:n_left] >= 0).sum() > 100 and (w21[n_left:] >= 0).sum() > 50      # both cameras matched
+            both = set(w21[:n_left][w21[:n_left] >= 0]) & set(w21[n_left:][w21[n_left:] >= 0])
+            assert len(both) > 30                                # KeyFrame features matched in BOTH cameras
+    if n1 >= 900 and n_left >= 900 and n2 - n_left >= 900:
+        # the arm is not two one-camera searches: a right match needs the LEFT best distance <= TH_LOW and passes without a ratio test
+        _, _, m21_all = oracle.search_by_bow(p["desc1"], p["desc2"], p["valid1"], None, p["fv1"], p["fv2"], p["angle1"], p["angle2"], 50, True, 0.7, True)
+        assert not np.array_equal(m21_all, oracle.search_by_bow_rig(p, n_left, 50, 0.7, True)[1])
