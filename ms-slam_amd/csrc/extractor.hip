@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "orb_device.h"
+#include "gauss7_stream_device.h"
 #include "matcher_device.h"
 #include "stereo_rowtable_device.h"
 
@@ -171,7 +172,7 @@ struct msorb_extractor {
     // worker threads), MSORB_SPLIT_NO_PEER (test hook: the two-device gather staged through the host), MSORB_FORCE_PEER_PYRAMID
     // (test hook: msorb_stereo_matches pulls the right pyramid over the peer path even on one device)
     const StereoRowJob* row_job = nullptr;   // set by the stereo-frame calls around run_pipeline: the right eye's band records leave the layout launch
-    struct Knobs { bool serial_pipeline = false, quadtree_host = false, split_no_peer = false, force_peer_pyramid = false, frame_fuse = true, frame_compact = true; int host_threads = 0; } knobs;
+    struct Knobs { bool serial_pipeline = false, quadtree_host = false, split_no_peer = false, force_peer_pyramid = false, frame_compact = true; int host_threads = 0, frame_fuse = 2; } knobs;
     int lds_per_block = 64 * 1024;   // hipDeviceAttributeMaxSharedMemoryPerBlock of the handle's device
     static constexpr bool capturing = false;   // (no graph capture: plain launches; see tools/experiments/README.md)
     bool defer_sync = false;     // enqueue only, the caller appends more work and synchronises (msorb_extract[_stereo])
@@ -506,9 +507,14 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
         // A frame (<= 4 images, one group): FAST and the blur leave as ONE launch on the main stream (frame_fast_blur_kernel) — no side
         // stream, no fork / join.  Not with stage timing on (the stage events want the two kernels apart), not for variants of the
         // table the streaming blur does not serve (launch_frame_fast_blur then returns false before launching anything).
-        const bool fuse_fb = h->knobs.frame_fuse && ng == 1 && n <= 4 && !prof && h->overlap_blur && h->sem.default_taps();
-        hipStream_t sb = h->overlap_blur && !fuse_fb ? h->copy_stream : s;
-        const bool side_blur = h->overlap_blur && !fuse_fb;
+        // frame_fuse (MSORB_FRAME_FUSE, read once per handle): 2 (default) the blur rides the SELECTION launch (quadtree_select_blur_kernel:
+        // off the critical path — the selection leaves 240 CUs idle), 1 it rides FAST's launch (frame_fast_blur_kernel), 0 side stream.
+        const bool fuse_ok = ng == 1 && n <= 4 && !prof && h->overlap_blur && h->sem.default_taps();
+        FrameBlurJob blur_job;
+        const bool fuse_qt = fuse_ok && h->knobs.frame_fuse == 2 && n_images <= 4 && make_frame_blur_job(pyr, blur, n, h->sem, &blur_job);
+        const bool fuse_fb = fuse_ok && !fuse_qt && h->knobs.frame_fuse >= 1;
+        hipStream_t sb = h->overlap_blur && !fuse_fb && !fuse_qt ? h->copy_stream : s;
+        const bool side_blur = h->overlap_blur && !fuse_fb && !fuse_qt;
         if (side_blur || h->host_pyramid) HIPCHK(hipEventRecord(G.ev_pyr, s));   // the pyramid is complete: the side stream's blur and the host-pyramid copies wait for this
         if (side_blur) HIPCHK(hipStreamWaitEvent(sb, G.ev_pyr, 0));
         if (h->host_pyramid && h->pair_pyramids == 2 && n_images == 2 && ng == 1 && !h->capturing) {
@@ -543,6 +549,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
         }
         // with the blur on its own stream the critical chain goes first: FAST -> compaction -> quadtree is what describe waits
         // for; the blur (needed by describe only) fills in beside it
+        bool blur_carried = false;
         auto blur_now = [&]() {
             mark(7, sb);
             (void)launch_gauss7(pyr, blur, n, sb, h->sem);
@@ -555,7 +562,7 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
             launch_fast_cells(pyr, h->d_cells.p, ncells, h->P.ini_th, h->P.min_th, g.slots_per_image, h->d_slots.p + cslot,
                               h->d_cell_count.p + (size_t)first * ncells, n, h->small_cells, s);
             mark(2, s);
-            if (h->overlap_blur) blur_now();
+            if (h->overlap_blur && !fuse_qt) blur_now();
         }
         launch_cand_compact(h->d_cells.p, ncells, h->d_level_cell_begin.p, nl, g.slots_per_image, h->d_slots.p + cslot,
                             h->d_cell_count.p + (size_t)first * ncells, h->d_cell_off.p + (size_t)first * ncells,
@@ -566,8 +573,10 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
         if ((rc = launch_quadtree(h->qt, h->d_compact.p + cslot, img_base, h->d_level_count.p + (size_t)first * nl,
                                   h->d_label.p + cslot, h->d_sel_pt.p + (size_t)first * sel_stride, h->d_sel_n.p + (size_t)first * nl,
                                   sel_stride, h->scales, lap0, lap1, capacity, h->d_sel.p + (size_t)first * sel_stride,
-                                  h->d_sel_count.p + first, h->d_mono.p + first, n, s, ng == 1 ? h->row_job : nullptr)))
+                                  h->d_sel_count.p + first, h->d_mono.p + first, n, s, ng == 1 ? h->row_job : nullptr,
+                                  fuse_qt ? &blur_job : nullptr, &blur_carried)))
             return rc;
+        if (fuse_qt && !blur_carried) blur_now();   // (the selection ran a form that does not carry the blur: on this stream, before describe)
         mark(5, s);
         if (side_blur) HIPCHK(hipStreamWaitEvent(s, G.ev_blur, 0));
         launch_describe(pyr, blur, h->d_sel.p + (size_t)first * sel_stride, h->d_sel_count.p + first, sel_stride, h->scales,
@@ -855,8 +864,9 @@ int msorb_extractor_create(int nfeatures, float scale_factor, int nlevels, int i
         h->knobs.split_no_peer = getenv("MSORB_SPLIT_NO_PEER") != nullptr;
         h->knobs.force_peer_pyramid = getenv("MSORB_FORCE_PEER_PYRAMID") != nullptr;
         h->knobs.host_threads = (e = getenv("MSORB_HOST_THREADS")) ? atoi(e) : 0;
-        // A/B switches of the frame chain's two fused launches (FAST + blur; candidate scan + gather): "0" = the separate launches
-        h->knobs.frame_fuse = !((e = getenv("MSORB_FRAME_FUSE")) && e[0] == '0');
+        // A/B switches of the frame chain's fused launches: MSORB_FRAME_FUSE = where a frame's blur runs (2 default: inside the selection
+        // launch, 1: inside FAST's launch, 0: side stream); MSORB_FRAME_COMPACT=0: candidate scan + gather as two launches
+        h->knobs.frame_fuse = (e = getenv("MSORB_FRAME_FUSE")) ? std::max(0, std::min(2, atoi(e))) : 2;
         h->knobs.frame_compact = !((e = getenv("MSORB_FRAME_COMPACT")) && e[0] == '0');
     }
     if (hipDeviceGetAttribute(&h->lds_per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || h->lds_per_block <= 0)

@@ -46,10 +46,12 @@ struct QtLevels {  // per-level geometry of the quadtree stage
 };
 
 struct StereoRowJob;   // stereo_rowtable_device.h: the stereo row table of a frame, built beside the selection layout (nullptr: none)
+struct FrameBlurJob;   // gauss7_stream_device.h: the blur of a frame's levels, carried by the selection launch of a frame (nullptr: none).
+                       // *blur_carried (if given) tells whether it was: only the 1024-thread frame form carries it
 int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_base, const int* level_count,
                      uint16_t* label, int* sel_pt, int* sel_n, int sel_stride, const LevelScale& scales, int lap0,
                      int lap1, int capacity, SelRec* sel, int* sel_count, int* mono, int n_images, hipStream_t s,
-                     const StereoRowJob* row_job = nullptr);
+                     const StereoRowJob* row_job = nullptr, const FrameBlurJob* blur_job = nullptr, bool* blur_carried = nullptr);
 size_t quadtree_lds_bytes(const QtLevels& lv);
 int launch_debug_sort(const uint32_t* h_keys, int n, int frame_form, uint32_t* h_nodes, uint32_t* h_keys_out, float* sort_us);   // msorb_debug_std_sort
 void upload_patch_tables(const int8_t* pattern, const int* umax, hipStream_t stream);

@@ -12,6 +12,7 @@
 #include "orb_device.h"
 #include "quadtree_device.h"
 #include "quadtree_paths_device.h"
+#include "gauss7_stream_device.h"
 #include "stereo_rowtable_device.h"
 
 namespace msorb {
@@ -505,6 +506,25 @@ __global__ __launch_bounds__(1024) void quadtree_select_kernel(QtLevels lv, cons
                                                               int ws_nini, int debug, int big_levels, int small_nt, int path_cap) {
     quadtree_select_body<PC, PC == kQtPointsPerThreadFrame>(lv, compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, ws_N, ws_nini, debug, big_levels, small_nt, path_cap);
 }
+// The selection of a FRAME with the blur of its levels in the same launch: the selection keeps n_images x nlevels workgroups = 16
+// of the chip's 256 CUs busy for 35-40 us (its level-0 instance is a chain of dependent steps), the blur — 9 us of bandwidth
+// work that only the descriptor stage reads — runs on the others and leaves the frame's critical path (it sat beside FAST, which
+// it lengthened by 3.5 us, and on a side stream before that: an event record, two stream waits, ~8 us of fork / join).  Blocks
+// (x, y >= nlevels) are blur blocks: 1024 threads = four 256-thread blocks of gauss7_stream_kernel's numbering, waves independent.
+template <int PC>
+__global__ __launch_bounds__(1024) void quadtree_select_blur_kernel(QtLevels lv, const Cand16* __restrict__ compact, const int* __restrict__ img_base,
+                                                                   const int* __restrict__ level_count, uint16_t* __restrict__ label,
+                                                                   int* __restrict__ sel_pt, int* __restrict__ sel_n, int sel_stride, int ws_N,
+                                                                   int ws_nini, int debug, int big_levels, int small_nt, int path_cap,
+                                                                   FrameBlurJob blur) {
+    if ((int)blockIdx.y >= lv.nlevels) {
+        const int b = ((int)blockIdx.y - lv.nlevels) * (int)gridDim.x + (int)blockIdx.x;
+        const int tile = 4 * b + (int)(threadIdx.x >> 8);
+        if (tile < blur.blocks) gauss7_stream_body<kGaussRows>(blur.src, blur.dst, blur.plan, tile, (int)((threadIdx.x >> 6) & 3));
+        return;
+    }
+    quadtree_select_body<PC, true>(lv, compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, ws_N, ws_nini, debug, big_levels, small_nt, path_cap);
+}
 // Batch form: 256-thread instances whose first PC x 256 candidates stay in registers for the whole selection (a level-0 instance of
 // the BASELINE geometries has ~6 800): the per-generation point passes then touch no global memory at all.
 template <int PC>
@@ -794,7 +814,8 @@ __global__ __launch_bounds__(1024) void quadtree_layout_frame_kernel(QtLevels lv
 int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_base, const int* level_count,
                      uint16_t* label, int* sel_pt, int* sel_n, int sel_stride, const LevelScale& scales, int lap0,
                      int lap1, int capacity, SelRec* sel, int* sel_count, int* mono, int n_images, hipStream_t s,
-                     const StereoRowJob* row_job) {
+                     const StereoRowJob* row_job, const FrameBlurJob* blur_job, bool* blur_carried) {
+    if (blur_carried) *blur_carried = false;
     int maxN = 1, max_ini = 1;
     for (int l = 0; l < lv.nlevels; l++) { maxN = max(maxN, lv.quota[l]); max_ini = max(max_ini, lv.n_ini[l]); }
     const size_t lds = qt::workspace_bytes(maxN, max_ini);
@@ -846,11 +867,22 @@ int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_ba
         hipLaunchKernelGGL(quadtree_select_batch_kernel<kQtPointsPerThreadBatch>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds + lds_paths, s, lv,
                            compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt, path_cap);
     } else if (qt_threads == 1024) {
+        if (blur_job && blur_job->blocks > 0) {   // the frame's blur rides this launch (quadtree_select_blur_kernel)
+            const void* fn = reinterpret_cast<const void*>(quadtree_select_blur_kernel<kQtPointsPerThreadFrame>);
+            path_tables(fn, 6, 1 << 30, path_cap, lds_paths);
+            if (!path_cap && !raise_lds(fn)) return MSORB_E_HIP;
+            const int wgs = (blur_job->blocks + 3) / 4, extra_rows = (wgs + n_images - 1) / n_images;
+            hipLaunchKernelGGL(quadtree_select_blur_kernel<kQtPointsPerThreadFrame>, dim3(n_images, lv.nlevels + extra_rows), dim3(qt_threads),
+                               lds + lds_paths, s, lv, compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg,
+                               big_levels, small_nt, path_cap, *blur_job);
+            if (blur_carried) *blur_carried = true;
+        } else {
         const void* fn = reinterpret_cast<const void*>(quadtree_select_kernel<kQtPointsPerThreadFrame>);
         path_tables(fn, 6, 1 << 30, path_cap, lds_paths);
         if (!path_cap && !raise_lds(fn)) return MSORB_E_HIP;
         hipLaunchKernelGGL(quadtree_select_kernel<kQtPointsPerThreadFrame>, dim3(n_images, lv.nlevels), dim3(qt_threads), lds + lds_paths, s, lv,
                            compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, maxN, max_ini, dbg, big_levels, small_nt, path_cap);
+        }
     } else {
         if (!raise_lds(reinterpret_cast<const void*>(quadtree_select_kernel<0>))) return MSORB_E_HIP;
         path_tables(reinterpret_cast<const void*>(quadtree_select_kernel<0>), 5, 80 * 1024, path_cap, lds_paths);
