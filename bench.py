@@ -489,7 +489,7 @@ def main():
         if aux and not args.no_pmc and not args.isolated and B == 128 and dom == "fast":
             pm_live = optional_leg("roofline.live_pmc", live_pmc, "fast_cells_kernel")
             if pm_live and "error" not in pm_live:
-                scale = 2.0    # FETCH_SIZE reports half of the bytes a coalesced stream reads on gfx950 (profiles/round4_fetch_calib.txt)
+                scale = 2.0    # FETCH_SIZE reports half of the bytes a coalesced stream reads on gfx950 (profiles/round6_fetch_calib.txt)
                 traffic = int((pm_live["FETCH_SIZE"] * scale + pm_live["WRITE_SIZE"]) * 1024)
                 valu_frac = round(pm_live["SQ_INSTS_VALU"] * 64 / (stages[dom] * 1e-3) / 51.5e12, 3)
                 traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, one pass each, over a child "
@@ -532,7 +532,7 @@ def main():
                                                  "interval (intervals overlap, so the sum exceeds ms_per_step); not recorded when "
                                                  "two batches are in flight (MSORB_BENCH_SYNC=1 for the one-batch-at-a-time loop)",
             "roofline": {"bound": "valu+lds" if dom == "fast" else "hbm",
-                         "bound_note": "what the counters say limits this kernel (profiles/round5_fast_pmc.txt: VALU at 0.82 of its measured "
+                         "bound_note": "what the counters say limits this kernel (profiles/round6_fast_pmc.txt: VALU at 0.82 of its measured "
                                        "issue rate, LDS pipe busy 61 % of the launch, HBM traffic 1.05 x algorithmic); achieved / peak / frac "
                                        "are still the HBM yardstick the bench contract prescribes" if dom == "fast" else
                                        "streaming kernel: HBM bandwidth",
@@ -543,7 +543,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_source,
                          "traffic_note": "HBM bytes per launch from rocprofv3 --pmc: FETCH_SIZE x 2 + WRITE_SIZE; FETCH_SIZE reports half of "
-                                         "the bytes a coalesced stream reads on gfx950 (tools/fetch_calib.hip, profiles/round4_fetch_calib.txt), "
+                                         "the bytes a coalesced stream reads on gfx950 (tools/fetch_calib.hip, profiles/round6_fetch_calib.txt), "
                                          "WRITE_SIZE is exact",
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "valu_fraction_of_measured_peak": valu_frac,

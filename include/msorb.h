@@ -46,7 +46,7 @@ int msorb_device_memory(int device, size_t* free_bytes, size_t* total_bytes);
  * minor only appends entry points (or appends `_ex` forms with more parameters), a new major changes or removes one.  The host
  * classes (host/ORBextractor.cc, host/ORBmatcher_device.h) and the Python mirror compare msorb_abi_version() with the header
  * they were compiled against and refuse a library with another major or an older minor (msorb_abi_compatible). */
-#define MSORB_ABI_VERSION 6000
+#define MSORB_ABI_VERSION 6001
 int msorb_abi_version(void);
 /* 1 if a caller compiled against `header_version` may use this library (same major, library minor >= header minor). */
 int msorb_abi_compatible(int header_version);
@@ -333,6 +333,18 @@ int msorb_fuse_search(msorb_frame* f, const float* inv_level_sigma2, int n_level
                       const float* u, const float* v, const float* ur, const int* predicted_level, const float* radius,
                       const uint8_t* mp_desc, int* best_idx, int* best_dist);
 
+/* The same search for ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight = true) on a two-camera KeyFrame (NLeft != -1;
+ * LocalMapping.cc:794-795, 825-826).  There the window is KeyFrame::GetFeaturesInArea(u, v, radius, true): the RIGHT camera's
+ * grid and keypoints (KeyFrame.cc:826-836) — `f` = that camera loaded with msorb_frame_set — while the level band and the
+ * reprojection-error gate read pKF->GetKeyPoint(idx) and pKF->GetuRight(idx) with the right-camera index idx as it comes out
+ * of the grid (ORBmatcher.cc:1509-1545; `idx += NLeft` follows at :1547), i.e. mvKeys[idx] for idx < NLeft and
+ * mvKeysRight[idx - NLeft] beyond (KeyFrame.h:377-385).  gate_kps[f->N] / gate_uright[f->N] are those values per right-camera
+ * index (gate_uright NULL = -1 everywhere); everything else as msorb_fuse_search, best_idx in right-camera indices (the caller adds
+ * NLeft).  With gate_kps = the frame's own keypoints and gate_uright = its mvuRight this is msorb_fuse_search.  Since ABI 6001. */
+int msorb_fuse_search_gated(msorb_frame* f, const msorb_keypoint* gate_kps, const float* gate_uright, const float* inv_level_sigma2,
+                            int n_levels, int n, const uint8_t* valid, const float* u, const float* v, const float* ur,
+                            const int* predicted_level, const float* radius, const uint8_t* mp_desc, int* best_idx, int* best_dist);
+
 /* ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, th, bMono) (ORBmatcher.cc:1941-2057,
  * 2129-2152) from the projected coordinates on.  Per last-frame keypoint i: valid (map point present, not
  * outlier, positive depth, inside the image), u,v (projection), ur (u - mbf/z), last_octave, last_angle,
@@ -508,6 +520,23 @@ int msorb_search_by_bow(int device, msorb_bow_pair* pairs, int n_pairs, int th_l
  * the KeyFrame feature whose map point frame feature j receives, -1 none; match12 (optional): the LEFT partner of each KeyFrame
  * feature; nmatches counts both cameras.  One rotation histogram over both (:338-353, :361-378, :396-418).  Since ABI 6000. */
 int msorb_search_by_bow_rig(int device, msorb_bow_pair* pair, int n_left, int th_low, float nnratio, int check_orientation);
+
+/* ORBmatcher::SearchForTriangulation (ORBmatcher.cc:1168-1402) with the geometric test of :1332 —
+ * pCamera1->epipolarConstrain(pCamera2, kp1, kp2, R12, t12, sigma1, sigma2) — left to the CALLER: the form for the two-camera
+ * KeyFrames of a fisheye rig (:1294-1330 pick one of four relative poses and two camera models per candidate pair;
+ * KannalaBrandt8::epipolarConstrain triangulates, KannalaBrandt8.cpp:216-220) and for any camera model this library does not
+ * restate.  pair: as msorb_search_by_bow — set 1 = pKF1's N features (valid1 = no map point, stereo when bOnlyStereo, :1237-1247),
+ * set 2 = pKF2's (avail2 = the same for pKF2, :1259-1271; NULL = all), the two FeatureVectors, angle1 / angle2 = GetKeyPoint(idx).angle.
+ * Per common node and visited query, in the reference's order, the library finds the trains within th_low (TH_LOW) on the device
+ * and calls accept(ctx, idx1, idx2) on them — smallest distance first, among equal distances the LATER train first (the scan's
+ * `dist > bestDist` rule, :1277, lets a later equal candidate replace an earlier one) — skipping trains an earlier query took,
+ * until one passes: that train is the query's match.  accept must be a pure predicate of (idx1, idx2) (the reference's is); it is
+ * called on the calling thread, between the device passes and the return.  Not applied: the epipole-distance test of :1283-1291
+ * (`!pKF1->mpCamera2` guards it: a caller that wants it puts it into accept).  match12 / match21 / nmatches after the rotation
+ * histogram (:1360-1381).  Since ABI 6001. */
+typedef int (*msorb_pair_accept)(void* ctx, int idx1, int idx2);
+int msorb_search_for_triangulation_cb(int device, msorb_bow_pair* pair, int th_low, int check_orientation, msorb_pair_accept accept,
+                                      void* ctx);
 
 /* ORBmatcher::SearchForTriangulation (ORBmatcher.cc:1168-1402; LocalMapping::CreateNewMapPoints, LocalMapping.cc:492)
  * for pinhole KeyFrames without a second camera.  One msorb_triangulation_pair per (mpCurrentKeyFrame, neighbour)

@@ -217,6 +217,46 @@ __global__ __launch_bounds__(64) void triangulation_match_kernel(
     }
 }
 
+// Every (query, train) of a node with distance <= th_low among the visited queries / eligible trains, in the reference's scan order
+// (queries in list order, trains in list order): the candidates of a search whose accept test lives with the CALLER
+// (msorb_search_for_triangulation_cb: GeometricCamera::epipolarConstrain of a camera model this library does not hold).
+// FILL = false counts per item, FILL = true writes (query, train, dist, train position) at list + begin[item].
+template <bool FILL>
+__global__ __launch_bounds__(64) void node_candidates_kernel(const BowItem* __restrict__ items, const uint4* __restrict__ desc1,
+                                                             const uint4* __restrict__ desc2, const uint8_t* __restrict__ valid1,
+                                                             const uint8_t* __restrict__ avail2, const int* __restrict__ feat1,
+                                                             const int* __restrict__ feat2, int th_low, int* __restrict__ count,
+                                                             const int* __restrict__ begin, int4* __restrict__ list) {
+    const BowItem it = items[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int chunks = (it.n2l + 63) >> 6;
+    int total = 0;
+    int4* out = FILL ? list + begin[blockIdx.x] : nullptr;
+    for (int k1 = 0; k1 < it.n1l; k1++) {
+        const int f1 = feat1[it.b1 + k1];
+        if (!valid1[it.m1 + f1]) continue;  // wave uniform
+        const int idx1 = it.base1 + f1;
+        const uint4 q0 = desc1[(size_t)idx1 * 2], q1 = desc1[(size_t)idx1 * 2 + 1];
+        for (int c = 0; c < chunks; c++) {
+            const int p = c * 64 + lane;
+            bool ok = false;
+            int f2 = 0, dist = 0;
+            if (p < it.n2l) {
+                f2 = feat2[it.b2 + p];
+                if (avail2[it.m2 + f2]) {
+                    const int idx2 = it.base2 + f2;
+                    dist = hamming256(q0, q1, desc2[(size_t)idx2 * 2], desc2[(size_t)idx2 * 2 + 1]);
+                    ok = dist <= th_low;
+                }
+            }
+            const unsigned long long m = __ballot(ok);
+            if (FILL && ok) out[total + __popcll(m & ((1ull << lane) - 1))] = make_int4(f1, f2, dist, p);
+            total += __popcll(m);
+        }
+    }
+    if (!FILL && lane == 0) count[blockIdx.x] = total;
+}
+
 // The rotation-consistency filter of a pair on the device (resident-KeyFrame entries): histogram of round((angle1 - angle2) / 12
 // degrees) over the pair's raw matches, ComputeThreeMaxima (ORBmatcher.cc:2277-2318) on the 30 counts, matches outside the
 // three fullest bins withdrawn (:396-418, :1360-1381), match21 and the count written.  The survivors do not depend on the
@@ -643,6 +683,114 @@ extern "C" int msorb_search_by_bow_rig(int device, msorb_bow_pair* pair, int n_l
         for (int f2 = 0; f2 < n_left; f2++) if (P.match21[f2] >= 0) P.match12[P.match21[f2]] = f2;
     }
     P.nmatches = nm;
+    return MSORB_OK;
+}
+
+// ORBmatcher::SearchForTriangulation (:1168-1402) with the geometric test of :1332 left to the caller — the form the two-camera arms
+// (:1294-1330: one of four relative poses and two camera models per candidate, KannalaBrandt8::epipolarConstrain) need, and any
+// camera model this library does not restate.  The device lists, per common node, every (query, train) within th_low among the
+// visited / eligible features (node_candidates_kernel: count, then fill); the replay below walks them in the reference's order.
+// For one query the reference scans the trains in list order, keeps `bestDist` (initially th_low) and takes a train when
+// dist <= bestDist and the test passes: the winner is the passing train of smallest distance, the LAST of equal ones — here the
+// candidates sorted by (distance, position descending), the first unclaimed one that accept() passes.  accept() is a pure
+// predicate of the two features (the reference's is: a const camera, two keypoints, a relative pose), so asking it for fewer
+// or other candidates than the reference's running-minimum scan reaches changes nothing.
+extern "C" int msorb_search_for_triangulation_cb(int device, msorb_bow_pair* pair, int th_low, int check_orientation, msorb_pair_accept accept,
+                                                 void* ctx) {
+    if (!pair || !accept || th_low < 0) return MSORB_E_INVALID;
+    msorb_bow_pair& P = *pair;
+    P.nmatches = 0;
+    FeatVec fa{P.fv1_nodes, P.fv1_node, P.fv1_begin, P.fv1_feat}, fb{P.fv2_nodes, P.fv2_node, P.fv2_begin, P.fv2_feat};
+    std::vector<Common> common;
+    std::vector<uint8_t> seen;
+    size_t totf1 = 0, totf2 = 0;
+    int max_chunks = 1;
+    if (P.n1 < 0 || P.n2 < 0 || (!P.match12 && P.n1 > 0) || (P.n1 > 0 && (!P.desc1 || !P.valid1)) || (P.n2 > 0 && !P.desc2) ||
+        (check_orientation && ((P.n1 > 0 && !P.angle1) || (P.n2 > 0 && !P.angle2))) || !check_feature_vector(P.n1, fa, seen) ||
+        !check_feature_vector(P.n2, fb, seen) || !merge_walk(fa, fb, common, totf1, totf2, max_chunks)) {
+        set_last_error("search_for_triangulation_cb: bad sizes / null arrays / feature vector not ascending, out of range or with a repeated feature");
+        return MSORB_E_INVALID;
+    }
+    for (int i = 0; i < P.n1; i++) P.match12[i] = -1;
+    if (P.match21) for (int j = 0; j < P.n2; j++) P.match21[j] = -1;
+    const size_t n_items = common.size(), tot1 = (size_t)P.n1, tot2 = (size_t)P.n2;
+    if (n_items == 0) return MSORB_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return no_device();
+    // ---- staging: [desc1 | desc2 | feat1 | feat2 | items | valid1 | avail2 | begin] in, [count] out; the lists in their own block ----
+    const size_t o_d1 = 0, o_d2 = o_d1 + tot1 * 32, o_f1 = o_d2 + tot2 * 32, o_f2 = o_f1 + up16(totf1 * 4), o_it = o_f2 + up16(totf2 * 4),
+                 o_v1 = o_it + up16(n_items * sizeof(BowItem)), o_a2 = o_v1 + up16(tot1), in_bytes = o_a2 + up16(tot2), o_cnt = in_bytes,
+                 o_beg = o_cnt + up16(n_items * 4), total = o_beg + up16(n_items * 4);
+    static thread_local Scratch scr, lists;
+    hipError_t e = scr.acquire(device, total);
+    if (e != hipSuccess) return hip_fail(scr, "search_for_triangulation_cb", e);
+    {
+        char* h = scr.h;
+        size_t k1 = 0, k2 = 0, ni = 0;
+        if (P.n1) { std::memcpy(h + o_d1, P.desc1, tot1 * 32); std::memcpy(h + o_v1, P.valid1, tot1); }
+        if (P.n2) {
+            std::memcpy(h + o_d2, P.desc2, tot2 * 32);
+            if (P.avail2) std::memcpy(h + o_a2, P.avail2, tot2);
+            else std::memset(h + o_a2, 1, tot2);
+        }
+        stage_lists(fa, fb, common, 0, 0, 0, (int*)(h + o_f1), (int*)(h + o_f2), k1, k2, (BowItem*)(h + o_it), ni);
+    }
+    hipStream_t s = scr.s;
+    char* d = scr.d;
+    e = hipMemcpyAsync(d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(node_candidates_kernel<false>, dim3((unsigned)n_items), dim3(64), 0, s, (const BowItem*)(d + o_it), (const uint4*)(d + o_d1),
+                           (const uint4*)(d + o_d2), (const uint8_t*)(d + o_v1), (const uint8_t*)(d + o_a2), (const int*)(d + o_f1),
+                           (const int*)(d + o_f2), th_low, (int*)(d + o_cnt), (const int*)nullptr, (int4*)nullptr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(scr.h + o_cnt, d + o_cnt, n_items * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return hip_fail(scr, "search_for_triangulation_cb", e);
+    const int* cnt = (const int*)(scr.h + o_cnt);
+    int* beg = (int*)(scr.h + o_beg);
+    size_t n_cand = 0;
+    for (size_t i = 0; i < n_items; i++) { beg[i] = (int)n_cand; n_cand += (size_t)cnt[i]; }
+    std::vector<int> raw(tot1, -1);
+    if (n_cand > 0) {
+        if (n_cand > (size_t)INT32_MAX / 16) { set_last_error("search_for_triangulation_cb: too many candidates"); return MSORB_E_CAPACITY; }
+        e = lists.acquire(device, n_cand * sizeof(int4));
+        if (e != hipSuccess) return hip_fail(lists, "search_for_triangulation_cb", e);
+        e = hipMemcpyAsync(d + o_beg, beg, n_items * 4, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(node_candidates_kernel<true>, dim3((unsigned)n_items), dim3(64), 0, s, (const BowItem*)(d + o_it), (const uint4*)(d + o_d1),
+                               (const uint4*)(d + o_d2), (const uint8_t*)(d + o_v1), (const uint8_t*)(d + o_a2), (const int*)(d + o_f1),
+                               (const int*)(d + o_f2), th_low, (int*)nullptr, (const int*)(d + o_beg), (int4*)lists.d);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(lists.h, lists.d, n_cand * sizeof(int4), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return hip_fail(scr, "search_for_triangulation_cb", e);
+        // ---- the replay: nodes ascending, a node's queries in list order (:1230-1358) ----
+        std::vector<int4> all((const int4*)lists.h, (const int4*)lists.h + n_cand);   // (out of the pinned block: read repeatedly below)
+        std::vector<uint8_t> matched2(tot2, 0);                                        // vbMatched2 (:1212)
+        std::vector<int4> group;
+        size_t k = 0;
+        while (k < n_cand) {
+            size_t k_end = k;
+            while (k_end < n_cand && all[k_end].x == all[k].x) k_end++;                // one query's candidates (contiguous: the fill order)
+            group.assign(all.begin() + k, all.begin() + k_end);
+            std::sort(group.begin(), group.end(), [](const int4& a, const int4& b) { return a.z != b.z ? a.z < b.z : a.w > b.w; });
+            for (const int4& c : group) {
+                if (matched2[c.y]) continue;                                            // :1262
+                if (!accept(ctx, c.x, c.y)) continue;                                  // :1332
+                raw[c.x] = c.y;
+                matched2[c.y] = 1;                                                      // :1345
+                break;
+            }
+            k = k_end;
+        }
+    }
+    P.nmatches = replay_histogram(fa, common, raw.data(), check_orientation,
+                                  [&](int i1, int i2, float& a1, float& a2) { a1 = P.angle1[i1]; a2 = P.angle2[i2]; }, P.match12);
+    if (P.match21)
+        for (int i = 0; i < P.n1; i++)
+            if (P.match12[i] >= 0) P.match21[P.match12[i]] = i;
     return MSORB_OK;
 }
 

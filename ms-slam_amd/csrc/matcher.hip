@@ -138,22 +138,23 @@ __global__ __launch_bounds__(256) void window_topk_kernel(FrameView F, const Win
             for (int j = b; j < e; j++) {
                 const int idx = F.cell_idx[j];
                 const KpLite kp = F.kp[idx];
+                const KpLite g = F.gate_kp ? F.gate_kp[idx] : kp;   // (wave uniform: a kernel argument)
                 if (check_levels) {
-                    if (kp.octave < Q.min_level) continue;
-                    if (Q.max_level >= 0 && kp.octave > Q.max_level) continue;
+                    if (g.octave < Q.min_level) continue;
+                    if (Q.max_level >= 0 && g.octave > Q.max_level) continue;
                 }
                 if (!(fabsf(__fsub_rn(kp.x, Q.x)) < Q.r && fabsf(__fsub_rn(kp.y, Q.y)) < Q.r)) continue;
                 if ((Q.flags & kQSkipOccupied) && F.occupied[idx]) continue;       // ORBmatcher.cc:88-90
                 if (Q.flags & kQFuseGate) {  // reprojection-error gate of ORBmatcher::Fuse, ORBmatcher.cc:1520-1545
-                    const float ex = __fsub_rn(Q.x, kp.x), ey = __fsub_rn(Q.y, kp.y);
+                    const float ex = __fsub_rn(Q.x, g.x), ey = __fsub_rn(Q.y, g.y);
                     float e2 = __fmaf_rn(ex, ex, __fmul_rn(ey, ey));
                     double lim = 5.99;
-                    if (kp.u_right >= 0) {
-                        const float er = __fsub_rn(Q.ur, kp.u_right);
+                    if (g.u_right >= 0) {
+                        const float er = __fsub_rn(Q.ur, g.u_right);
                         e2 = __fmaf_rn(er, er, e2);
                         lim = 7.8;
                     }
-                    if ((double)__fmul_rn(e2, F.inv_sigma2[kp.octave]) > lim) continue;
+                    if ((double)__fmul_rn(e2, F.inv_sigma2[g.octave]) > lim) continue;
                 } else if (!(Q.flags & kQNoUr) && kp.u_right > 0 && fabsf(__fsub_rn(Q.ur, kp.u_right)) > Q.r) continue;  // :92-97
                 const int d = hamming256(a, reinterpret_cast<const uint64_t*>(F.desc + (size_t)idx * 32));
                 if (kCount) n_pairs++;

@@ -24,6 +24,9 @@ struct FrameView {
     float minX, minY, gridWInv, gridHInv;
     int n;
     float inv_sigma2[MSORB_MAX_LEVELS];  // mvInvLevelSigma2, read by the kQFuseGate queries only
+    const KpLite* gate_kp;  // nullptr, or n keypoints the level band and the kQFuseGate error test read INSTEAD of kp (the window test
+                            // stays on kp): ORBmatcher::Fuse(..., bRight = true) walks the right camera's grid but reads
+                            // pKF->GetKeyPoint(idx) / GetuRight(idx) with that right-camera index (ORBmatcher.cc:1502, 1509-1545)
 };
 constexpr uint8_t kQValid = 1, kQSkipOccupied = 2, kQFuseGate = 4, kQNoUr = 8;
 struct WinQuery {

@@ -89,7 +89,7 @@ struct msorb_frame {
     std::vector<msorb_keypoint> kps;
     std::vector<float> u_right, scale;
     std::vector<int> cell_begin, cell_idx;
-    msorb::DBuf<msorb::KpLite> d_kp;
+    msorb::DBuf<msorb::KpLite> d_kp, d_gate;   // d_gate: msorb_fuse_search_gated's per-call gate keypoints
     msorb::DBuf<uint8_t> d_desc, d_occ, d_qdesc, d_stage;
     msorb::DBuf<int> d_cell_begin, d_cell_idx, d_n;
     msorb::DBuf<int> d_init_cnt, d_init_beg;   // msorb_search_for_initialization: candidate counts / list offsets / lists
@@ -108,6 +108,7 @@ struct msorb_frame {
         v.kp = d_kp.p; v.desc = d_desc.p; v.cell_begin = d_cell_begin.p; v.cell_idx = d_cell_idx.p;
         v.occupied = d_occ.p; v.minX = minX; v.minY = minY; v.gridWInv = gridWInv; v.gridHInv = gridHInv; v.n = N;
         for (int l = 0; l < MSORB_MAX_LEVELS; l++) v.inv_sigma2[l] = 0.0f;
+        v.gate_kp = nullptr;
         return v;
     }
 };

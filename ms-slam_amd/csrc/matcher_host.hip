@@ -49,7 +49,7 @@ void msorb_frame_destroy(msorb_frame* f) {
     // already shut down nothing can be freed any more — and nothing needs to be
     if (hipSetDevice(f->device) != hipSuccess) { delete f; return; }
     if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
-    f->d_kp.release(); f->d_desc.release(); f->d_occ.release(); f->d_qdesc.release(); f->d_cell_begin.release();
+    f->d_kp.release(); f->d_gate.release(); f->d_desc.release(); f->d_occ.release(); f->d_qdesc.release(); f->d_cell_begin.release();
     f->d_cell_idx.release(); f->d_q.release(); f->d_topk.release(); f->h_in.release(); f->h_topk.release(); f->d_n.release(); f->d_stage.release(); f->d_init_cnt.release(); f->d_init_beg.release(); f->d_init_list.release();
     frame_track_release(f);
     delete f;
@@ -607,15 +607,17 @@ int msorb_window_top4(msorb_frame* f, int n_queries, const float* x, const float
     return MSORB_OK;
 }
 
-int msorb_fuse_search(msorb_frame* f, const float* inv_level_sigma2, int n_levels, int n, const uint8_t* valid,
-                      const float* u, const float* v, const float* ur, const int* predicted_level, const float* radius,
-                      const uint8_t* mp_desc, int* best_idx, int* best_dist) {
+namespace {
+int fuse_search_impl(msorb_frame* f, const msorb_keypoint* gate_kps, const float* gate_uright, const float* inv_level_sigma2, int n_levels,
+                     int n, const uint8_t* valid, const float* u, const float* v, const float* ur, const int* predicted_level,
+                     const float* radius, const uint8_t* mp_desc, int* best_idx, int* best_dist) {
     if (!f || n < 0 || !inv_level_sigma2 || n_levels < 1 || n_levels > MSORB_MAX_LEVELS ||
         (n > 0 && (!valid || !u || !v || !ur || !predicted_level || !radius || !mp_desc || !best_idx || !best_dist)))
         return MSORB_E_INVALID;
     if (n == 0) return MSORB_OK;
+    const msorb_keypoint* gk = gate_kps ? gate_kps : f->kps.data();
     for (int i = 0; i < f->N; i++)
-        if (f->kps[i].octave < 0 || f->kps[i].octave >= n_levels) { set_last_error("fuse_search: keypoint octave outside inv_level_sigma2"); return MSORB_E_INVALID; }
+        if (gk[i].octave < 0 || gk[i].octave >= n_levels) { set_last_error("fuse_search: keypoint octave outside inv_level_sigma2"); return MSORB_E_INVALID; }
     HIPCHK(hipSetDevice(f->device));
     std::vector<WinQuery> q(n);
     for (int i = 0; i < n; i++) {
@@ -634,9 +636,17 @@ int msorb_fuse_search(msorb_frame* f, const float* inv_level_sigma2, int n_level
         return rc;
     hipStream_t s = f->stream;
     std::vector<TopK> topk(n);
+    std::vector<KpLite> gate;
+    FrameView view = f->view();
+    if (gate_kps && f->N) {
+        gate.resize(f->N);
+        for (int i = 0; i < f->N; i++) gate[i] = KpLite{gate_kps[i].x, gate_kps[i].y, gate_uright ? gate_uright[i] : -1.0f, gate_kps[i].octave};
+        if ((rc = f->d_gate.ensure(f->N))) return rc;
+        HIPCHK(hipMemcpyAsync(f->d_gate.p, gate.data(), (size_t)f->N * sizeof(KpLite), hipMemcpyHostToDevice, s));
+        view.gate_kp = f->d_gate.p;
+    }
     HIPCHK(hipMemcpyAsync(f->d_q.p, q.data(), (size_t)n * sizeof(WinQuery), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(f->d_qdesc.p, mp_desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
-    FrameView view = f->view();
     for (int l = 0; l < n_levels; l++) view.inv_sigma2[l] = inv_level_sigma2[l];
     launch_window_topk(view, f->d_q.p, f->d_qdesc.p, 0, n, f->d_topk.p, s);
     HIPCHK(hipGetLastError());
@@ -644,6 +654,20 @@ int msorb_fuse_search(msorb_frame* f, const float* inv_level_sigma2, int n_level
     HIPCHK(hipStreamSynchronize(s));
     for (int i = 0; i < n; i++) { best_idx[i] = topk[i].idx[0]; best_dist[i] = topk[i].dist[0]; }
     return MSORB_OK;
+}
+}  // namespace
+
+int msorb_fuse_search(msorb_frame* f, const float* inv_level_sigma2, int n_levels, int n, const uint8_t* valid,
+                      const float* u, const float* v, const float* ur, const int* predicted_level, const float* radius,
+                      const uint8_t* mp_desc, int* best_idx, int* best_dist) {
+    return fuse_search_impl(f, nullptr, nullptr, inv_level_sigma2, n_levels, n, valid, u, v, ur, predicted_level, radius, mp_desc, best_idx, best_dist);
+}
+
+int msorb_fuse_search_gated(msorb_frame* f, const msorb_keypoint* gate_kps, const float* gate_uright, const float* inv_level_sigma2,
+                            int n_levels, int n, const uint8_t* valid, const float* u, const float* v, const float* ur,
+                            const int* predicted_level, const float* radius, const uint8_t* mp_desc, int* best_idx, int* best_dist) {
+    if (f && f->N > 0 && !gate_kps) { set_last_error("fuse_search_gated: gate_kps is null"); return MSORB_E_INVALID; }
+    return fuse_search_impl(f, gate_kps, gate_uright, inv_level_sigma2, n_levels, n, valid, u, v, ur, predicted_level, radius, mp_desc, best_idx, best_dist);
 }
 
 namespace {

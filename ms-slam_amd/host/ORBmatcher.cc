@@ -46,6 +46,12 @@ struct ThreadCache {
     msorb_host::DeviceFrame<Frame> rig[2] = {msorb_host::DeviceFrame<Frame>(matcher_device()), msorb_host::DeviceFrame<Frame>(matcher_device())};
     const void* rig_key = nullptr;
     long unsigned int rig_id = ~0ul;
+    // the two cameras of a two-camera KeyFrame (Fuse(pKF, ..., bRight), ORBmatcher_rig_device.h FuseRig)
+    msorb_host::DeviceFrame<Frame> kfcam[2] = {msorb_host::DeviceFrame<Frame>(matcher_device()), msorb_host::DeviceFrame<Frame>(matcher_device())};
+    const void* kfcam_key[2] = {nullptr, nullptr};
+    long unsigned int kfcam_id[2] = {~0ul, ~0ul};
+    bool kfcam_sparsified[2] = {false, false};
+    int kfcam_n[2] = {-1, -1};
     const void* kf_key[2] = {nullptr, nullptr};
     long unsigned int kf_id[2] = {~0ul, ~0ul};
     bool kf_sparsified[2] = {false, false};
@@ -69,9 +75,8 @@ void drop_thread_cache() { g_thread_cache.reset(); }
 // the capability gap is reported like every other failure of the host layer (msorb_host::check throws std::runtime_error): the
 // application decides what to do with a rig this build does not serve; it is never answered with left-camera associations
 [[noreturn]] void unsupported_rig(const char* what) {
-    throw std::runtime_error(std::string("msorb: ") + what + " — of the two-camera branches (Nleft != -1) this build serves SearchByProjection(F, "
-                             "vpMapPoints), SearchByProjection(Current, Last) and SearchByBoW(pKF, F) (ORBmatcher.cc:144-210, 2059-2124, 276-382); the "
-                             "second-camera arms of SearchForTriangulation and Fuse(..., bRight = true) are not served (ORBmatcher_rig_device.h)");
+    throw std::runtime_error(std::string("msorb: ") + what + " — a call the reference itself cannot answer (it reads a camera / pose the KeyFrame "
+                             "does not have); the two-camera branches this build serves are listed in ORBmatcher_rig_device.h");
 }
 msorb_host::DeviceFrame<Frame>& device_frame(const Frame& F, bool second = false) {
     ThreadCache& c = cache();
@@ -100,6 +105,17 @@ msorb_host::DeviceFrame<Frame>& device_keyframe(const std::shared_ptr<KeyFrame>&
         c.kf_key[slot] = pKF.get(); c.kf_id[slot] = pKF->mnId; c.kf_sparsified[slot] = pKF->mbSparsified; c.kf_n[slot] = pKF->GetN();
     }
     return c.kf[slot];
+}
+// one camera of a two-camera KeyFrame, uploaded once per KeyFrame and camera (LocalMapping::SearchInNeighbors calls Fuse for the
+// left, then for the right camera of every neighbour, LocalMapping.cc:793-795)
+msorb_host::DeviceFrame<Frame>& device_keyframe_camera(const std::shared_ptr<KeyFrame>& pKF, bool right) {
+    ThreadCache& c = cache();
+    const int k = right ? 1 : 0;
+    if (c.kfcam_key[k] != pKF.get() || c.kfcam_id[k] != pKF->mnId || c.kfcam_sparsified[k] != pKF->mbSparsified || c.kfcam_n[k] != pKF->GetN()) {
+        msorb_host::UploadKeyFrameCamera(c.kfcam[k], pKF, right);
+        c.kfcam_key[k] = pKF.get(); c.kfcam_id[k] = pKF->mnId; c.kfcam_sparsified[k] = pKF->mbSparsified; c.kfcam_n[k] = pKF->GetN();
+    }
+    return c.kfcam[k];
 }
 }  // namespace
 
@@ -200,7 +216,11 @@ int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Po
 
 int ORBmatcher::SearchForTriangulation(std::shared_ptr<KeyFrame> pKF1, std::shared_ptr<KeyFrame> pKF2,
                                        std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo, const bool bCoarse) {
-    if (pKF1->GetNLeft() != -1 || pKF2->GetNLeft() != -1) unsupported_rig("ORBmatcher::SearchForTriangulation on KeyFrames with NLeft != -1");
+    if (pKF1->mpCamera2 || pKF2->mpCamera2) {   // two-camera KeyFrames: the arms of :1195-1201 / :1294-1330 (ORBmatcher_rig_device.h)
+        // one KeyFrame with a second camera and one without: the reference runs on with R12 / t12 never assigned (:1187-1201 vs :1294)
+        if (!pKF1->mpCamera2 || !pKF2->mpCamera2) unsupported_rig("ORBmatcher::SearchForTriangulation between a two-camera KeyFrame and a one-camera KeyFrame");
+        return msorb_host::SearchForTriangulationRig(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse, mbCheckOrientation, matcher_device());
+    }
     std::vector<std::vector<std::pair<size_t, size_t>>> out;
     const int n = msorb_host::SearchForTriangulationBatch(keyframe_store(), pKF1, std::vector<std::shared_ptr<KeyFrame>>{pKF2}, out,
                                                           bOnlyStereo, bCoarse, mbCheckOrientation)[0];
@@ -215,9 +235,10 @@ int ORBmatcher::SearchBySim3(std::shared_ptr<KeyFrame> pKF1, std::shared_ptr<Key
 
 int ORBmatcher::Fuse(std::shared_ptr<KeyFrame> pKF, const std::vector<std::shared_ptr<MapPoint>>& vpMapPoints, const float th,
                      const bool bRight) {
-    // the right-camera pass (:1421-1426) exists for the fisheye two-camera rig only (NLeft != -1): never answer it with the
-    // left-camera search
-    if (bRight || pKF->GetNLeft() != -1) unsupported_rig("ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight = true) / a KeyFrame with NLeft != -1");
+    if (pKF->GetNLeft() != -1) return msorb_host::FuseRig(device_keyframe_camera(pKF, bRight), pKF, vpMapPoints, th, bRight);   // two cameras
+    // the right-camera pass (:1410-1414) reads GetRightPose() / mpCamera2, which a one-camera KeyFrame does not have (the reference
+    // dereferences a null camera there): never answer it with the left-camera search
+    if (bRight) unsupported_rig("ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight = true) on a KeyFrame without a second camera (NLeft == -1)");
     return msorb_host::Fuse(device_keyframe(pKF), pKF, vpMapPoints, th);
 }
 

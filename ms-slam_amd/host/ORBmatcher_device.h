@@ -712,11 +712,11 @@ struct FuseQueries {  // what :1448-1500 computes per map point
     std::vector<float> u, v, ur, radius;
     std::vector<int> level;
 };
-template <class KeyFramePtr, class MapPointPtr>
-void FuseGeometry(const KeyFramePtr& pKF, const std::vector<MapPointPtr>& vpMapPoints, const float th, FuseQueries& Q) {
-    const auto Tcw = pKF->GetPose();
-    const auto Ow = pKF->GetCameraCenter();
-    auto* pCamera = pKF->mpCamera;
+// Tcw / Ow / pCamera: the camera the call searches (:1410-1421) — GetPose / GetCameraCenter / mpCamera, or the right camera's of a
+// two-camera KeyFrame (ORBmatcher_rig_device.h)
+template <class KeyFramePtr, class MapPointPtr, class PoseT, class CenterT, class CameraT>
+void FuseGeometryOf(const KeyFramePtr& pKF, const PoseT& Tcw, const CenterT& Ow, CameraT* pCamera, const std::vector<MapPointPtr>& vpMapPoints,
+                    const float th, FuseQueries& Q) {
     const float& bf = pKF->mbf;
     const int nMPs = (int)vpMapPoints.size();
     Q.valid.assign(nMPs, 0); Q.desc.assign((size_t)nMPs * 32, 0);
@@ -751,6 +751,40 @@ void FuseGeometry(const KeyFramePtr& pKF, const std::vector<MapPointPtr>& vpMapP
         std::memcpy(&Q.desc[(size_t)i * 32], dMP.template ptr<unsigned char>(0), 32);
     }
 }
+// pass 2: the reference's loop with the search replaced by a lookup (:1563-1590).  idxOffset = NLeft for the right camera of a
+// two-camera KeyFrame (`if(bRight) idx += pKF->GetNLeft()`, :1547), 0 otherwise.
+template <class KeyFramePtr, class MapPointPtr>
+int FuseCommit(const KeyFramePtr& pKF, const std::vector<MapPointPtr>& vpMapPoints, const std::vector<uint8_t>& valid,
+               const std::vector<int>& bestIdx, const std::vector<int>& bestDist, const int idxOffset) {
+    const int nMPs = (int)vpMapPoints.size();
+    int nFused = 0;
+    for (int i = 0; i < nMPs; i++) {
+        MapPointPtr pMP = vpMapPoints[i];
+        if (!pMP) continue;
+        if (pMP->isBad()) continue;
+        else if (pMP->IsInKeyFrame(pKF)) continue;
+        if (!valid[i]) continue;
+        if (bestDist[i] <= 50 /* TH_LOW */) {                              // :1563-1590
+            const int bestIdxKF = bestIdx[i] + idxOffset;
+            auto pMPinKF = pKF->GetMapPoint(bestIdxKF);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) {
+                    if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                    else pMPinKF->Replace(pMP);
+                }
+            } else {
+                pMP->AddObservation(pKF, bestIdxKF);
+                pKF->AddMapPoint(pMP, bestIdxKF);
+            }
+            nFused++;
+        }
+    }
+    return nFused;
+}
+template <class KeyFramePtr, class MapPointPtr>
+void FuseGeometry(const KeyFramePtr& pKF, const std::vector<MapPointPtr>& vpMapPoints, const float th, FuseQueries& Q) {
+    FuseGeometryOf(pKF, pKF->GetPose(), pKF->GetCameraCenter(), pKF->mpCamera, vpMapPoints, th, Q);
+}
 template <class FrameT, class KeyFramePtr, class MapPointPtr>
 int Fuse(DeviceFrame<FrameT>& dev, const KeyFramePtr& pKF, const std::vector<MapPointPtr>& vpMapPoints, const float th) {
     FuseQueries Q;
@@ -762,28 +796,7 @@ int Fuse(DeviceFrame<FrameT>& dev, const KeyFramePtr& pKF, const std::vector<Map
                             Q.u.data(), Q.v.data(), Q.ur.data(), Q.level.data(), Q.radius.data(), Q.desc.data(),
                             bestIdx.data(), bestDist.data()),
           "msorb_fuse_search");
-    int nFused = 0;
-    for (int i = 0; i < nMPs; i++) {
-        MapPointPtr pMP = vpMapPoints[i];
-        if (!pMP) continue;
-        if (pMP->isBad()) continue;
-        else if (pMP->IsInKeyFrame(pKF)) continue;
-        if (!valid[i]) continue;
-        if (bestDist[i] <= 50 /* TH_LOW */) {                              // :1563-1590
-            auto pMPinKF = pKF->GetMapPoint(bestIdx[i]);
-            if (pMPinKF) {
-                if (!pMPinKF->isBad()) {
-                    if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
-                    else pMPinKF->Replace(pMP);
-                }
-            } else {
-                pMP->AddObservation(pKF, bestIdx[i]);
-                pKF->AddMapPoint(pMP, bestIdx[i]);
-            }
-            nFused++;
-        }
-    }
-    return nFused;
+    return FuseCommit(pKF, vpMapPoints, valid, bestIdx, bestDist, 0);
 }
 
 // ---- SearchForTriangulation ---------------------------------------------------------------------------------

@@ -6,16 +6,17 @@
 // (Frame.cc:589-655: the raw keypoints, not mvKeysUn, for such a frame) — both without mvuRight (the rectified-stereo test of
 // :92 / :2015 is `Nleft == -1` only).  F.mvpMapPoints stays ONE array of N = Nleft + Nright entries.
 //   ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches)                                              ORBmatcher.cc:223-421 (arms :276-309, :357-382)
+//   ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight) on a KeyFrame with NLeft != -1, both cameras         ORBmatcher.cc:1404-1597
+//   ORBmatcher::SearchForTriangulation(pKF1, pKF2, ...) between two such KeyFrames                   ORBmatcher.cc:1168-1402 (arms :1195-1201, :1294-1330)
 // No shipped configuration of MS-SLAM builds such frames (every YAML is Rectified / PinHole); the arms exist so that the class
-// answers what the reference's class answers.  Not served for such a rig (the class throws, ORBmatcher.cc `unsupported_rig`):
-// SearchForTriangulation's second-camera arms (:1168-1402: KannalaBrandt8::epipolarConstrain, a camera model outside this
-// build) and Fuse(..., bRight = true) (:1404-1597: its gates read GetKeyPoint(idx) with a RIGHT-grid index, i.e. a left
-// keypoint, before idx += NLeft).
+// answers what the reference's class answers.
 #ifndef MSORB_ORBMATCHER_RIG_DEVICE_H
 #define MSORB_ORBMATCHER_RIG_DEVICE_H
 
 #include <cmath>
 #include <cstring>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "ORBmatcher_device.h"
@@ -178,6 +179,137 @@ int SearchByBoWRig(const KeyFramePtr& pKF, FrameT& F, std::vector<MapPointPtr>& 
     vpMapPointMatches.assign(F.N, MapPointPtr());                          // :227
     for (int j = 0; j < F.N && j < (int)m21.size(); j++)
         if (m21[j] >= 0) vpMapPointMatches[j] = mpsKF[m21[j]];             // :336, :359
+    return P.nmatches;
+}
+
+// ---- Fuse on a two-camera KeyFrame (pKF->GetNLeft() != -1): ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight), ORBmatcher.cc:1404-1597,
+// called once per camera by LocalMapping::SearchInNeighbors (LocalMapping.cc:793-795, 824-826).
+// One camera of such a KeyFrame -> device frame + grid: what KeyFrame::GetFeaturesInArea(x, y, r, bRight) walks (KeyFrame.cc:826-836:
+// mGrid / mvKeys for the left camera, mGridRight / mvKeysRight for the right one; descriptor rows [0, NLeft) / [NLeft, N)).  The left
+// camera carries GetuRight (the stereo term of the error gate, :1515-1530); MS-SLAM's KeyFrame keeps its feature arrays private,
+// hence the accessors (KeyFrame.h:357-405).
+template <class FrameT, class KeyFramePtr>
+void UploadKeyFrameCamera(DeviceFrame<FrameT>& dev, const KeyFramePtr& pKF, bool right) {
+    const int NL = pKF->GetNLeft(), N = pKF->GetN();
+    const int n = pKF->mbSparsified ? 0 : (right ? N - NL : NL), row0 = right ? NL : 0;
+    std::vector<cv::KeyPoint> keys(n);
+    static_assert(sizeof(keys[0]) == sizeof(msorb_keypoint), "cv::KeyPoint must be the 28-byte layout");
+    std::vector<uint8_t> desc((size_t)n * 32, 0);
+    std::vector<float> ur(n, -1.0f);
+    for (int i = 0; i < n; i++) {
+        keys[i] = right ? pKF->GetKeyRight(i) : pKF->GetKey(i);
+        const auto d = pKF->GetDescriptor(row0 + i);
+        if (!d.empty()) std::memcpy(&desc[(size_t)i * 32], d.template ptr<unsigned char>(0), 32);
+        if (!right) ur[i] = pKF->GetuRight(i);
+    }
+    check(msorb_frame_set(dev.get(), reinterpret_cast<const msorb_keypoint*>(keys.data()), n, desc.data(), ur.data(), (float)pKF->mnMinX,
+                          (float)pKF->mnMaxX, (float)pKF->mnMinY, (float)pKF->mnMaxY, pKF->mvScaleFactors.data(), (int)pKF->mvScaleFactors.size()),
+          "msorb_frame_set");
+}
+
+// `devCam` holds the camera the call searches (UploadKeyFrameCamera(devCam, pKF, bRight)).  Geometry (:1410-1500, with the right
+// camera's pose / centre / model for bRight) and the map mutation (:1563-1590) are the reference's statements (FuseGeometry /
+// FuseCommit, ORBmatcher_device.h); the window search runs on the device.  bRight = false: the left camera's own keypoints gate
+// (GetKeyPoint(idx) = mvKeys[idx] for idx < NLeft) — msorb_fuse_search.  bRight = true: the reference reads GetKeyPoint(idx) and
+// GetuRight(idx) with the RIGHT-camera index idx before `idx += NLeft` (:1509, :1515, :1547), i.e. the LEFT keypoint of the same
+// number while idx < NLeft and mvKeysRight[idx - NLeft] beyond (KeyFrame.h:377-385) — msorb_fuse_search_gated with exactly those
+// values.  (GetuRight(idx) indexes mvuRight, which has NLeft entries for such a KeyFrame, Frame.cc:1069: for idx >= NLeft the
+// reference reads past its end; here that reads as -1, "no stereo term", what every entry of that array holds.)
+template <class KeyFramePtr, class MapPointPtr>
+void FuseGeometryRig(const KeyFramePtr& pKF, const std::vector<MapPointPtr>& vpMapPoints, const float th, FuseQueries& Q, const bool bRight) {
+    if (bRight) FuseGeometryOf(pKF, pKF->GetRightPose(), pKF->GetRightCameraCenter(), pKF->mpCamera2, vpMapPoints, th, Q);   // :1410-1414
+    else FuseGeometry(pKF, vpMapPoints, th, Q);
+}
+template <class FrameT, class KeyFramePtr, class MapPointPtr>
+int FuseRig(DeviceFrame<FrameT>& devCam, const KeyFramePtr& pKF, const std::vector<MapPointPtr>& vpMapPoints, const float th, const bool bRight) {
+    FuseQueries Q;
+    FuseGeometryRig(pKF, vpMapPoints, th, Q, bRight);
+    const int nMPs = (int)vpMapPoints.size(), NL = pKF->GetNLeft();
+    std::vector<int> bestIdx(nMPs, -1), bestDist(nMPs, 256);
+    if (!bRight) {
+        check(msorb_fuse_search(devCam.get(), pKF->mvInvLevelSigma2.data(), (int)pKF->mvInvLevelSigma2.size(), nMPs, Q.valid.data(), Q.u.data(),
+                                Q.v.data(), Q.ur.data(), Q.level.data(), Q.radius.data(), Q.desc.data(), bestIdx.data(), bestDist.data()),
+              "msorb_fuse_search");
+        return FuseCommit(pKF, vpMapPoints, Q.valid, bestIdx, bestDist, 0);
+    }
+    const int nR = pKF->mbSparsified ? 0 : pKF->GetN() - NL;
+    std::vector<cv::KeyPoint> gate(nR);
+    std::vector<float> gateUr(nR, -1.0f);
+    for (int j = 0; j < nR; j++) {
+        gate[j] = pKF->GetKeyPoint(j);                                     // :1509, with the index GetFeaturesInArea(..., true) returned
+        if (j < NL) gateUr[j] = pKF->GetuRight(j);                         // :1515
+    }
+    check(msorb_fuse_search_gated(devCam.get(), reinterpret_cast<const msorb_keypoint*>(gate.data()), gateUr.data(), pKF->mvInvLevelSigma2.data(),
+                                  (int)pKF->mvInvLevelSigma2.size(), nMPs, Q.valid.data(), Q.u.data(), Q.v.data(), Q.ur.data(), Q.level.data(),
+                                  Q.radius.data(), Q.desc.data(), bestIdx.data(), bestDist.data()),
+          "msorb_fuse_search_gated");
+    return FuseCommit(pKF, vpMapPoints, Q.valid, bestIdx, bestDist, NL);   // :1547
+}
+
+// ---- SearchForTriangulation between two KeyFrames of a two-camera rig (both have mpCamera2): ORBmatcher.cc:1168-1402 with the arms
+// of :1195-1201 and :1294-1330.  Every feature of either camera takes part (the FeatureVector indexes all N rows; GetKeyPoint(idx)
+// answers for both cameras).  For such KeyFrames bStereo1 / bStereo2 are false (`!pKF->mpCamera2 && ...`, :1243, :1267: with
+// bOnlyStereo nothing is visited) and the epipole-distance test is off (`&& !pKF1->mpCamera2`, :1283).  The geometric test of :1332
+// is the CAMERA MODEL's — pCamera1->epipolarConstrain(pCamera2, kp1, kp2, R12, t12, sigma1, sigma2), KannalaBrandt8 triangulates
+// there — with the cameras and the relative pose picked per candidate from the side of the two features (:1294-1330): it stays the
+// application's code, called back by msorb_search_for_triangulation_cb on the candidates the device found (descriptor distance
+// <= TH_LOW inside a common BoW node), best distance first.  bCoarse short-circuits it as in the reference (`bCoarse || ...`).
+template <class KeyFramePtr>
+struct TriangulationRigTest {
+    KeyFramePtr pKF1, pKF2;
+    std::vector<cv::KeyPoint> kp1, kp2;
+    bool bCoarse;
+    // Tll, Tlr, Trl, Trr of :1196-1200 as rotation / translation (:1203-1204), indexed [bRight1][bRight2]
+    typename std::decay<decltype(std::declval<KeyFramePtr>()->GetPose().rotationMatrix())>::type R[2][2];
+    typename std::decay<decltype(std::declval<KeyFramePtr>()->GetPose().translation())>::type t[2][2];
+    static int Accept(void* ctx, int idx1, int idx2) {
+        TriangulationRigTest& T = *static_cast<TriangulationRigTest*>(ctx);
+        if (T.bCoarse) return 1;
+        const bool bRight1 = T.pKF1->FromRightImage(idx1), bRight2 = T.pKF2->FromRightImage(idx2);          // :1255, :1281
+        auto* pCamera1 = bRight1 ? T.pKF1->mpCamera2 : T.pKF1->mpCamera;                                        // :1300-1327
+        auto* pCamera2 = bRight2 ? T.pKF2->mpCamera2 : T.pKF2->mpCamera;
+        const cv::KeyPoint &kp1 = T.kp1[idx1], &kp2 = T.kp2[idx2];
+        return pCamera1->epipolarConstrain(pCamera2, kp1, kp2, T.R[bRight1][bRight2], T.t[bRight1][bRight2], T.pKF1->mvLevelSigma2[kp1.octave],
+                                           T.pKF2->mvLevelSigma2[kp2.octave]) ? 1 : 0;                          // :1332
+    }
+};
+template <class KeyFramePtr>
+int SearchForTriangulationRig(const KeyFramePtr& pKF1, const KeyFramePtr& pKF2, std::vector<std::pair<size_t, size_t>>& vMatchedPairs,
+                              const bool bOnlyStereo, const bool bCoarse, const bool mbCheckOrientation, int device = 0) {
+    TriangulationRigTest<KeyFramePtr> T;
+    T.pKF1 = pKF1; T.pKF2 = pKF2; T.bCoarse = bCoarse;
+    {
+        const auto T1w = pKF1->GetPose();                                                                       // :1175-1177, :1193-1200
+        const auto Tw2 = pKF2->GetPoseInverse();
+        const auto Tr1w = pKF1->GetRightPose();
+        const auto Twr2 = pKF2->GetRightPoseInverse();
+        const auto Tll = T1w * Tw2, Tlr = T1w * Twr2, Trl = Tr1w * Tw2, Trr = Tr1w * Twr2;
+        T.R[0][0] = Tll.rotationMatrix(); T.t[0][0] = Tll.translation();
+        T.R[0][1] = Tlr.rotationMatrix(); T.t[0][1] = Tlr.translation();
+        T.R[1][0] = Trl.rotationMatrix(); T.t[1][0] = Trl.translation();
+        T.R[1][1] = Trr.rotationMatrix(); T.t[1][1] = Trr.translation();
+    }
+    BowSide a, b;
+    auto fill = [&](BowSide& side, const KeyFramePtr& pKF, std::vector<cv::KeyPoint>& kp) {
+        const int n = pKF->GetN();
+        kp.resize(n);
+        for (int i = 0; i < n; i++) kp[i] = pKF->GetKeyPoint(i);                                                // :1254, :1280 (both cameras)
+        side.Fill(n, [&](int i) { return pKF->GetDescriptor(i); }, pKF->GetFeatureVector(), kp);
+        const auto mps = pKF->GetMapPointMatches();
+        side.flag.assign(n, 0);
+        for (int i = 0; i < n; i++) side.flag[i] = !mps[i] && !bOnlyStereo;                                     // :1237-1247 / :1259-1271, bStereo = false
+    };
+    fill(a, pKF1, T.kp1);
+    fill(b, pKF2, T.kp2);
+    msorb_bow_pair P;
+    std::vector<int> m12, m21;
+    BindBowPair(P, a, b, false, m12, m21);
+    check(msorb_search_for_triangulation_cb(device, &P, 50 /* TH_LOW */, mbCheckOrientation, &TriangulationRigTest<KeyFramePtr>::Accept, &T),
+          "msorb_search_for_triangulation_cb");
+    vMatchedPairs.clear();                                                                                      // :1385-1393
+    vMatchedPairs.reserve(P.nmatches);
+    for (size_t i = 0; i < m12.size(); i++)
+        if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair(i, (size_t)m12[i]));
     return P.nmatches;
 }
 

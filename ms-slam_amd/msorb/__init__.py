@@ -23,7 +23,7 @@ STAGES = ("pyramid", "fast", "compact", "blur", "select", "describe")
 OK, E_INVALID, E_NO_DEVICE, E_HIP, E_CAPACITY, E_GEOMETRY, E_EMPTY = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/msorb.h declares (tests check the library exports them all)
-ABI_VERSION = 6000   # MSORB_ABI_VERSION of the include/msorb.h this mirror was written against (tests hold the two together)
+ABI_VERSION = 6001   # MSORB_ABI_VERSION of the include/msorb.h this mirror was written against (tests hold the two together)
 
 EXPORTS = (
     "msorb_last_error", "msorb_device_count", "msorb_device_memory", "msorb_abi_version", "msorb_abi_compatible", "msorb_set_fatal_callback", "msorb_notify_fatal", "msorb_extractor_create", "msorb_extractor_destroy",
@@ -526,6 +526,22 @@ class Frame:
         return bi[:n], bd[:n]
 
 
+    def FuseSearchGated(self, gate_kps, gate_uright, inv_level_sigma2, valid, u, v, ur, predicted_level, radius, mp_desc):
+        """msorb_fuse_search_gated: ORBmatcher::Fuse(..., bRight = true) on a two-camera KeyFrame — this frame = the right camera, the
+        level band and the error gate read gate_kps / gate_uright (pKF->GetKeyPoint(idx) / GetuRight(idx)).  -> (best_idx, best_dist)"""
+        arrs = [_c(valid, np.uint8), _c(u, np.float32), _c(v, np.float32), _c(ur, np.float32), _c(predicted_level, np.int32),
+                _c(radius, np.float32), _c(mp_desc, np.uint8)]
+        n = len(arrs[0])
+        inv = _c(inv_level_sigma2, np.float32)
+        gk = np.ascontiguousarray(gate_kps)
+        gu = None if gate_uright is None else _c(gate_uright, np.float32)
+        bi, bd = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        self.L.msorb_fuse_search_gated.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 9
+        _check(self.L.msorb_fuse_search_gated(self.h, gk.ctypes.data_as(C.c_void_p), None if gu is None else _np_ptr(gu), _np_ptr(inv),
+                                              len(inv), n, *[_np_ptr(a) for a in arrs], _np_ptr(bi), _np_ptr(bd)), "fuse_search_gated")
+        return bi[:n], bd[:n]
+
+
 def _sim3_side(p):
     return [_c(p["valid"], np.uint8), _c(p["u"], np.float32), _c(p["v"], np.float32), _c(p["level"], np.int32),
             _c(p["desc"], np.uint8)]
@@ -940,7 +956,40 @@ def search_by_bow_rig(p, n_left, th_low=50, nnratio=0.7, check_orientation=True,
     return q.nmatches, m21[:len(d2)], m12[:len(d1)]
 
 
-EXPORTS = EXPORTS + ("msorb_search_for_triangulation", "msorb_search_by_bow_rig")
+PAIR_ACCEPT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)   # msorb_pair_accept
+
+
+def search_for_triangulation_cb(p, accept, th_low=50, check_orientation=True, device=0):
+    """msorb_search_for_triangulation_cb: SearchForTriangulation with the geometric test left to the caller (the two-camera arms,
+    ORBmatcher.cc:1294-1332).  p: desc1/2, valid1, avail2 (or None), fv1/fv2, angle1/2; accept(idx1, idx2) -> bool, called for
+    the candidates the library tries.  -> (nmatches, match12, calls = the (idx1, idx2) accept saw, in order)"""
+    lb = lib()
+    lb.msorb_search_for_triangulation_cb.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, PAIR_ACCEPT, C.c_void_p]
+    q = BowPair()
+    d1, d2 = _c(p["desc1"], np.uint8).reshape(-1, 32), _c(p["desc2"], np.uint8).reshape(-1, 32)
+    v1 = _c(p["valid1"], np.uint8)
+    a2 = None if p.get("avail2") is None else _c(p["avail2"], np.uint8)
+    f1 = [_c(a, np.int32) for a in p["fv1"]]
+    f2 = [_c(a, np.int32) for a in p["fv2"]]
+    g1, g2 = _c(p["angle1"], np.float32), _c(p["angle2"], np.float32)
+    m12, m21 = np.zeros(max(len(d1), 1), np.int32), np.zeros(max(len(d2), 1), np.int32)
+    q.n1, q.n2 = len(d1), len(d2)
+    q.desc1, q.desc2, q.valid1, q.avail2 = _np_ptr(d1), _np_ptr(d2), _np_ptr(v1), None if a2 is None else _np_ptr(a2)
+    q.fv1_nodes, q.fv1_node, q.fv1_begin, q.fv1_feat = len(f1[0]), _np_ptr(f1[0]), _np_ptr(f1[1]), _np_ptr(f1[2])
+    q.fv2_nodes, q.fv2_node, q.fv2_begin, q.fv2_feat = len(f2[0]), _np_ptr(f2[0]), _np_ptr(f2[1]), _np_ptr(f2[2])
+    q.angle1, q.angle2, q.match12, q.match21 = _np_ptr(g1), _np_ptr(g2), _np_ptr(m12), _np_ptr(m21)
+    calls = []
+
+    def cb(_ctx, i1, i2):
+        calls.append((i1, i2))
+        return int(bool(accept(i1, i2)))
+    fn = PAIR_ACCEPT(cb)
+    _check(lb.msorb_search_for_triangulation_cb(device, C.addressof(q), int(th_low), int(bool(check_orientation)), fn, None),
+           "msorb_search_for_triangulation_cb")
+    return q.nmatches, m12[:len(d1)], calls
+
+
+EXPORTS = EXPORTS + ("msorb_search_for_triangulation", "msorb_search_by_bow_rig", "msorb_search_for_triangulation_cb")
 
 
 class TriangulationPair(C.Structure):
@@ -1166,7 +1215,7 @@ def stereo_matches_split(ex_left, ex_right, counts_left, d_kps_left, d_desc_left
     return d_ur, d_dp, d_oob[:n_pairs].cpu().numpy(), ms.value
 
 
-EXPORTS = EXPORTS + ("msorb_fuse_search", "msorb_search_by_projection_kf", "msorb_search_by_projection_sim3",
+EXPORTS = EXPORTS + ("msorb_fuse_search", "msorb_fuse_search_gated", "msorb_search_by_projection_kf", "msorb_search_by_projection_sim3",
                      "msorb_extract_batch_submit", "msorb_extract_batch_wait")
 
 

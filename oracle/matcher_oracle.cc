@@ -490,6 +490,48 @@ void orc_fuse_search(void* fp, const float* inv_level_sigma2, int n, const uint8
     }
 }
 
+// The search of ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight = true) on a two-camera KeyFrame, ORBmatcher.cc:1499-1561.  fp = the
+// RIGHT camera's features (what KeyFrame::GetFeaturesInArea(u, v, r, true) walks, KeyFrame.cc:826-836: mGridRight / mvKeysRight).
+// The loop then reads `pKF->GetKeyPoint(idx)` and `pKF->GetuRight(idx)` with the right-camera index as the grid returned it
+// (:1509, :1515; `idx += pKF->GetNLeft()` only follows at :1547) — KeyFrame.h:377-385 answers mvKeys[idx] for idx < NLeft,
+// mvKeysRight[idx - NLeft] beyond.  gate_kps / gate_uright hold those answers per right-camera index.  best_idx is returned in
+// right-camera indices (the caller adds NLeft for GetMapPoint / AddObservation, :1565-1586).
+void orc_fuse_search_gated(void* fp, const KeyPoint* gate_kps, const float* gate_uright, const float* inv_level_sigma2, int n,
+                           const uint8_t* valid, const float* u, const float* v, const float* ur, const int* predicted_level,
+                           const float* radius, const uint8_t* mp_desc, int* best_idx, int* best_dist) {
+    const FrameSoA& K = *(const FrameSoA*)fp;
+    for (int i = 0; i < n; i++) {
+        best_idx[i] = -1;
+        best_dist[i] = 256;
+        if (!valid[i]) continue;
+        const int nPredictedLevel = predicted_level[i];
+        const std::vector<size_t> vIndices = K.features_in_area(u[i], v[i], radius[i], -1, -1);
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = mp_desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx = -1;
+        for (size_t k = 0; k < vIndices.size(); k++) {
+            const size_t idx = vIndices[k];
+            const KeyPoint& kp = gate_kps[idx];                       // pKF->GetKeyPoint(idx)
+            const int kpLevel = kp.octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            const float kpr = gate_uright ? gate_uright[idx] : -1.0f;  // pKF->GetuRight(idx)
+            const float ex = u[i] - kp.x, ey = v[i] - kp.y;
+            if (kpr >= 0) {
+                const float er = ur[i] - kpr;
+                const float e2 = fmaf(er, er, fmaf(ex, ex, ey * ey));
+                if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+            } else {
+                const float e2 = fmaf(ex, ex, ey * ey);
+                if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+            }
+            const int dist = orc::descriptor_distance(dMP, &K.desc[idx * 32]);   // row idx + NLeft of mDescriptors = row idx of the right camera
+            if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+        }
+        best_idx[i] = bestIdx;
+        best_dist[i] = bestDist;
+    }
+}
+
 // ORBmatcher::SearchByProjection(Frame& CurrentFrame, pKF, sAlreadyFound, th, ORBdist), ORBmatcher.cc:2154-2275, from the
 // projected coordinates on.  One entry per KeyFrame map point that passed :2173-2196 (valid), with its projection u, v,
 // predicted level (:2198), the KeyFrame keypoint's angle (:2237), descriptor and id.  cur_mp[N] in/out.
@@ -1083,6 +1125,75 @@ int orc_search_for_triangulation(int n1, int n2, const uint8_t* desc1, const uin
             for (size_t j = 0; j < rotHist[i].size(); j++) { match12[rotHist[i][j]] = -1; nmatches--; }
         }
     }
+    return nmatches;
+}
+
+// ORBmatcher::SearchForTriangulation (ORBmatcher.cc:1168-1402) for two KeyFrames of a two-camera rig (pKF1->mpCamera2 &&
+// pKF2->mpCamera2): bStereo1 / bStereo2 are false (`!pKF->mpCamera2 && ...`, :1243, :1267 — valid1 / avail2 carry the bOnlyStereo
+// consequence, nothing visited), the epipole-distance test is skipped (`&& !pKF1->mpCamera2`, :1283), and the geometric test of
+// :1332 is pCamera1->epipolarConstrain(pCamera2, kp1, kp2, R12, t12, ...) with cameras and relative pose chosen per candidate from
+// the side (left / right image) of the two features (:1294-1330).  accept(ctx, idx1, idx2) stands for that call — a camera model
+// is not part of this oracle; the tests' accept reproduces what the harness's camera answers.  The scan, the running
+// `dist > TH_LOW || dist > bestDist` rule (:1277), vbMatched2 and the rotation histogram are the reference's statements; accept is
+// only asked where the reference asks (after :1277).
+typedef int (*orc_pair_accept)(void* ctx, int idx1, int idx2);
+int orc_search_for_triangulation_rig(int n1, int n2, const uint8_t* desc1, const uint8_t* desc2, const uint8_t* valid1, const uint8_t* avail2,
+                                     int nn1, const int* node1, const int* begin1, const int* feat1, int nn2, const int* node2,
+                                     const int* begin2, const int* feat2, const float* angle1, const float* angle2, int coarse,
+                                     int check_orientation, orc_pair_accept accept, void* ctx, int* match12, long* n_accept_calls) {
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    std::vector<char> matched2(n2, 0);
+    std::vector<int> rotHist[orc::HISTO_LENGTH];
+    const float factor = 1.0f / orc::HISTO_LENGTH;
+    int nmatches = 0;
+    long calls = 0;
+    int it1 = 0, it2 = 0;
+    while (it1 != nn1 && it2 != nn2) {
+        if (node1[it1] == node2[it2]) {
+            for (int k1 = begin1[it1]; k1 < begin1[it1 + 1]; k1++) {
+                const int idx1 = feat1[k1];
+                if (!valid1[idx1]) continue;
+                const uint8_t* d1 = desc1 + (size_t)idx1 * 32;
+                int bestDist = orc::TH_LOW, bestIdx2 = -1;
+                for (int k2 = begin2[it2]; k2 < begin2[it2 + 1]; k2++) {
+                    const int idx2 = feat2[k2];
+                    if (matched2[idx2] || (avail2 && !avail2[idx2])) continue;
+                    const int dist = orc::descriptor_distance(d1, desc2 + (size_t)idx2 * 32);
+                    if (dist > orc::TH_LOW || dist > bestDist) continue;
+                    bool ok = coarse != 0;
+                    if (!ok) { ok = accept(ctx, idx1, idx2) != 0; calls++; }
+                    if (ok) { bestIdx2 = idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    match12[idx1] = bestIdx2;
+                    matched2[bestIdx2] = 1;
+                    nmatches++;
+                    if (check_orientation) {
+                        float rot = angle1[idx1] - angle2[bestIdx2];
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)std::round(rot * factor);
+                        if (bin == orc::HISTO_LENGTH) bin = 0;
+                        rotHist[bin].push_back(idx1);
+                    }
+                }
+            }
+            it1++;
+            it2++;
+        } else if (node1[it1] < node2[it2]) {
+            it1 = (int)(std::lower_bound(node1, node1 + nn1, node2[it2]) - node1);
+        } else {
+            it2 = (int)(std::lower_bound(node2, node2 + nn2, node1[it1]) - node2);
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc::three_maxima(rotHist, orc::HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < orc::HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { match12[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    if (n_accept_calls) *n_accept_calls = calls;
     return nmatches;
 }
 

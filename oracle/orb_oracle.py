@@ -375,6 +375,23 @@ class OracleFrame:
         return bi[:n], bd[:n]
 
 
+    def FuseSearchGated(self, gate_kps, gate_uright, inv_level_sigma2, valid, u, v, ur, predicted_level, radius, mp_desc):
+        """orc_fuse_search_gated (ORBmatcher.cc:1499-1561 with bRight = true: window on this — the right camera's — features, level band
+        and error gate on gate_kps / gate_uright = pKF->GetKeyPoint(idx) / GetuRight(idx)) -> (best_idx, best_dist)"""
+        arrs = [_c(valid, np.uint8), _c(u, np.float32), _c(v, np.float32), _c(ur, np.float32), _c(predicted_level, np.int32),
+                _c(radius, np.float32), _c(mp_desc, np.uint8)]
+        n = len(arrs[0])
+        inv = _c(inv_level_sigma2, np.float32)
+        gk = np.ascontiguousarray(gate_kps)
+        gu = None if gate_uright is None else _c(gate_uright, np.float32)
+        bi, bd = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        self.L.orc_fuse_search_gated.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 9
+        self.L.orc_fuse_search_gated.restype = None
+        self.L.orc_fuse_search_gated(self.h, gk.ctypes.data_as(C.c_void_p), None if gu is None else _ptr(gu), _ptr(inv), n,
+                                     *[_ptr(a) for a in arrs], _ptr(bi), _ptr(bd))
+        return bi[:n], bd[:n]
+
+
 def _sim3_side(p):
     return [_c(p["valid"], np.uint8), _c(p["u"], np.float32), _c(p["v"], np.float32), _c(p["level"], np.int32),
             _c(p["desc"], np.uint8)]
@@ -619,6 +636,33 @@ def search_by_bow_rig(p, n_left, th_low=50, nnratio=0.7, check_orientation=True)
                                   len(f2[0]), _ptr(f2[0]), _ptr(f2[1]), _ptr(f2[2]), _ptr(g1), _ptr(g2), int(th_low), float(nnratio),
                                   int(bool(check_orientation)), _ptr(m21))
     return nm, m21[:len(d2)]
+
+
+PAIR_ACCEPT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
+
+
+def search_for_triangulation_rig(p, accept, coarse=False, check_orientation=True):
+    """orc_search_for_triangulation_rig (ORBmatcher.cc:1168-1402 for KeyFrames of a two-camera rig; accept(idx1, idx2) stands for
+    pCamera1->epipolarConstrain of :1332).  p: desc1/2, valid1, avail2 (or None), fv1/fv2, angle1/2.
+    -> (nmatches, match12, number of accept calls)"""
+    Lb = _mlib()
+    Lb.orc_search_for_triangulation_rig.argtypes = ([C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] +
+                                                    [C.c_void_p] * 5 + [C.c_int, C.c_int, PAIR_ACCEPT, C.c_void_p, C.c_void_p, C.c_void_p])
+    Lb.orc_search_for_triangulation_rig.restype = C.c_int
+    d1, d2 = _c(p["desc1"], np.uint8).reshape(-1, 32), _c(p["desc2"], np.uint8).reshape(-1, 32)
+    n1, n2 = len(d1), len(d2)
+    v1 = _c(p["valid1"], np.uint8)
+    a2 = None if p.get("avail2") is None else _c(p["avail2"], np.uint8)
+    f1 = [_c(a, np.int32) for a in p["fv1"]]
+    f2 = [_c(a, np.int32) for a in p["fv2"]]
+    g1, g2 = _c(p["angle1"], np.float32), _c(p["angle2"], np.float32)
+    m12 = np.zeros(max(n1, 1), np.int32)
+    ncalls = C.c_long(0)
+    fn = PAIR_ACCEPT(lambda _ctx, i1, i2: int(bool(accept(i1, i2))))
+    nm = Lb.orc_search_for_triangulation_rig(n1, n2, _ptr(d1), _ptr(d2), _ptr(v1), None if a2 is None else _ptr(a2), len(f1[0]), _ptr(f1[0]),
+                                             _ptr(f1[1]), _ptr(f1[2]), len(f2[0]), _ptr(f2[0]), _ptr(f2[1]), _ptr(f2[2]), _ptr(g1), _ptr(g2),
+                                             int(bool(coarse)), int(bool(check_orientation)), fn, None, _ptr(m12), C.byref(ncalls))
+    return nm, m12[:n1], ncalls.value
 
 
 def search_for_triangulation(p, coarse=False, check_orientation=True):

@@ -111,9 +111,26 @@ class Frame;
 class GeometricCamera {  // Pinhole (Pinhole.cpp:43-49)
 public:
     float fx = 0, fy = 0, cx = 0, cy = 0;
+    int id = 0;
     Eigen::Vector2f project(const Eigen::Vector3f& p) { return Eigen::Vector2f{{fx * p.v[0] / p.v[2] + cx, fy * p.v[1] / p.v[2] + cy}}; }
     float getParameter(int i) { return i == 0 ? fx : i == 1 ? fy : i == 2 ? cx : cy; }
     Eigen::Matrix3f toK_() { return Eigen::Matrix3f{{fx, 0, cx, 0, fy, cy, 0, 0, 1}}; }
+    // GeometricCamera::epipolarConstrain (GeometricCamera.h; KannalaBrandt8.cpp:216-220 triangulates): a stand-in that is a pure
+    // function of its arguments — the two keypoints, WHICH cameras, the signs of t12 — and logs every call (kp1.pt, kp2.pt, the two
+    // camera ids, R12, t12, sigmaLevel, unc, answer: 21 floats) so that a test can check what the matcher handed it
+    static inline std::vector<float>* epipolar_log = nullptr;
+    bool epipolarConstrain(GeometricCamera* pCamera2, const cv::KeyPoint& kp1, const cv::KeyPoint& kp2, const Eigen::Matrix3f& R12,
+                           const Eigen::Vector3f& t12, const float sigmaLevel, const float unc) {
+        const long h = (long)kp1.pt.x * 7 + (long)kp1.pt.y * 13 + (long)kp2.pt.x * 29 + (long)kp2.pt.y * 31 + id * 5 + pCamera2->id * 11 +
+                       (t12.v[0] > 0 ? 3 : 0) + (t12.v[1] > 0 ? 17 : 0);
+        const bool ok = h % 3 != 0;
+        if (epipolar_log) {
+            const float row[21] = {kp1.pt.x, kp1.pt.y, kp2.pt.x, kp2.pt.y, (float)id, (float)pCamera2->id, R12.m[0], R12.m[1], R12.m[2], R12.m[3],
+                                   R12.m[4], R12.m[5], R12.m[6], R12.m[7], R12.m[8], t12.v[0], t12.v[1], t12.v[2], sigmaLevel, unc, ok ? 1.0f : 0.0f};
+            epipolar_log->insert(epipolar_log->end(), row, row + 21);
+        }
+        return ok;
+    }
 };
 
 class MapPoint {  // the members ORBmatcher touches; Replace / AddObservation keep a small model of the map and a log
@@ -198,7 +215,27 @@ public:
     bool mbSparsified = false;
     GeometricCamera* mpCamera2 = nullptr;
     int GetN() { return N; }
-    int GetNLeft() { return -1; }
+    // a KeyFrame of a two-camera rig (KeyFrame.h:345-355, 377-410): mvKeys = the left camera's NLeft keypoints, mvKeysRight the right
+    // camera's, N = NLeft + NRight descriptor rows / map points, mvuRight NLeft entries of -1 (Frame.cc:1069), mTrl / mTlr the rig
+    int NLeft = -1;
+    std::vector<cv::KeyPoint> mvKeysRight;
+    Sophus::SE3f mTrl, mTlr;
+    void SetRig(const std::vector<cv::KeyPoint>& kl, const std::vector<cv::KeyPoint>& kr, const unsigned char* desc, const Sophus::SE3f& Trl) {
+        std::vector<cv::KeyPoint> all = kl;
+        all.insert(all.end(), kr.begin(), kr.end());
+        SetFeatures(all, desc);
+        mvKeys = kl; mvKeysUn = kl; mvKeysRight = kr;
+        NLeft = (int)kl.size();
+        mvuRight.assign(kl.size(), -1.0f);
+        mTrl = Trl; mTlr = Trl.inverse();
+    }
+    int GetNLeft() { return NLeft; }
+    cv::KeyPoint GetKey(size_t idx) { return mvKeys[idx]; }
+    cv::KeyPoint GetKeyRight(size_t idx) { return mvKeysRight[idx]; }
+    bool FromRightImage(size_t idx) { return !(NLeft == -1 || (int)idx < NLeft); }
+    Sophus::SE3f GetRightPose() { return mTrl * mTcw; }                             // KeyFrame.cc:952-956
+    Sophus::SE3f GetRightPoseInverse() { return mTcw.inverse() * mTlr; }            // :958-962
+    Eigen::Vector3f GetRightCameraCenter() { return (mTcw.inverse() * mTlr).translation(); }   // :964-968
     void SetPose(const Sophus::SE3f& T) { mTcw = T; }
     Sophus::SE3f GetPose() { return mTcw; }
     Sophus::SE3f GetPoseInverse() { return mTcw.inverse(); }
@@ -216,7 +253,11 @@ public:
     void SetFeatureVector(const DBoW2::FeatureVector& fv) { mFeatVec = fv; }
     std::vector<cv::KeyPoint> GetAllKeyUn() { return mvKeysUn; }
     cv::KeyPoint GetKeyUn(size_t idx) { return mvKeysUn[idx]; }
-    cv::KeyPoint GetKeyPoint(size_t idx) { return mvKeys[idx]; }
+    cv::KeyPoint GetKeyPoint(size_t idx) {                                          // KeyFrame.h:377-385
+        if (NLeft == -1) return mvKeysUn[idx];
+        else if ((int)idx < NLeft) return mvKeys[idx];
+        else return mvKeysRight[idx - NLeft];
+    }
     float GetuRight(size_t idx) { return mvuRight[idx]; }
     void SetuRight(const std::vector<float>& ur) { mvuRight = ur; }
     bool IsInImage(const float& x, const float& y) const { return x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY; }

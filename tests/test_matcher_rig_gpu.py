@@ -127,6 +127,71 @@ def test_two_camera_search_argument_checks(msorb_mod, oracle):
         dfl.close(); dfr.close()
 
 
+def gate_of(kl, kr):
+    """pKF->GetKeyPoint(idx) for a right-camera index idx (KeyFrame.h:377-385): mvKeys[idx] below NLeft, mvKeysRight[idx - NLeft] beyond"""
+    nl, nr = len(kl), len(kr)
+    gate = np.zeros(nr, kl.dtype)
+    j = np.arange(nr)
+    gate[j < nl] = kl[j[j < nl]]
+    gate[j >= nl] = kr[j[j >= nl] - nl]
+    return gate
+
+
+@pytest.mark.parametrize("seed,n_left,n_right,th", [(1, 1500, 1400, 3.0), (2, 600, 1500, 4.0), (3, 1500, 1400, 2.5), (4, 0, 700, 3.0)])
+def test_fuse_search_right_camera_of_a_two_camera_keyframe(msorb_mod, oracle, seed, n_left, n_right, th):
+    """msorb_fuse_search_gated = ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight = true) (ORBmatcher.cc:1499-1561): the window walks the right
+    camera's grid, the level band and the reprojection-error gate read GetKeyPoint(idx) / GetuRight(idx) with that right-camera index —
+    a LEFT keypoint for idx < NLeft, mvKeysRight[idx - NLeft] beyond (n_left < n_right in case 2 reaches that arm)."""
+    R = make_rig(oracle, seed=40 + seed, n_left=n_left, n_right=n_right, M=0)
+    rng = np.random.Generator(np.random.PCG64(400 + seed))
+    kl, kr, dr = R["kl"], R["kr"], R["dr"]
+    if seed != 3 and n_left:  # the gate keypoint near the window keypoint (else the error gate rejects nearly everything): left keypoint j ~ right keypoint j
+        m = min(n_left, n_right)
+        kl["x"][:m] = kr["x"][:m] + rng.normal(0, 1.0, m); kl["y"][:m] = kr["y"][:m] + rng.normal(0, 1.0, m)
+        kl["octave"][:m] = np.clip(kr["octave"][:m] + rng.integers(-1, 2, m), 0, 7)
+    gate = gate_of(kl, kr)
+    # the reference's KeyFrame has mvuRight = -1 for such a rig (Frame.cc:1069); the gate array is general: a third with a stereo term
+    gur = np.where(rng.random(n_right) < (0.0 if seed == 1 else 0.3), gate["x"] - rng.uniform(1, 30, n_right), -1).astype(np.float32)
+    inv_sigma2 = (np.float32(1.0) / (SCALE * SCALE)).astype(np.float32)
+    M = 3000
+    src = rng.integers(0, n_right, M)
+    sig = rng.choice([0.3, 1.0, 3.0], M)
+    u = (kr["x"][src] + rng.normal(0, sig)).astype(np.float32)
+    v = (kr["y"][src] + rng.normal(0, sig)).astype(np.float32)
+    ur = np.where(gur[src] >= 0, gur[src] + rng.normal(0, sig), u - 20).astype(np.float32)
+    level = np.clip(gate["octave"][src] + rng.integers(0, 2, M), 0, 7).astype(np.int32)
+    radius = (np.float32(th) * SCALE[level]).astype(np.float32)
+    valid = (rng.random(M) < 0.9).astype(np.uint8)
+    u[rng.random(M) < 0.02] = -50.0
+    desc = mc.flip_bits(rng, dr[src], 40)
+    F, O = msorb_mod.Frame(kr, dr, None, BOUNDS, SCALE), oracle.OracleFrame(kr, dr, None, BOUNDS, SCALE)
+    try:
+        bi, bd = F.FuseSearchGated(gate, None if seed == 1 else gur, inv_sigma2, valid, u, v, ur, level, radius, desc)
+        wi, wd = O.FuseSearchGated(gate, None if seed == 1 else gur, inv_sigma2, valid, u, v, ur, level, radius, desc)
+        assert np.array_equal(bi, wi) and np.array_equal(bd, wd)
+        assert np.all(bi[valid == 0] == -1)
+        # the gate array is what is read: gating on the right camera's own keypoints (= msorb_fuse_search) answers differently ...
+        oi, od = F.FuseSearch(inv_sigma2, valid, u, v, ur, level, radius, desc)
+        si, sd = F.FuseSearchGated(kr, None, inv_sigma2, valid, u, v, ur, level, radius, desc)
+        assert np.array_equal(oi, si) and np.array_equal(od, sd)          # ... and with the frame's own keypoints it IS msorb_fuse_search
+        if n_left:
+            assert not np.array_equal(wi, oi)
+            assert seed == 3 or (wi >= 0).sum() > 100                      # (case 3: unrelated gate keypoints, the error gate rejects nearly all)
+        else:
+            # NLeft = 0: GetKeyPoint(idx) = mvKeysRight[idx] — the plain search on a frame that carries the gate's mvuRight
+            assert np.array_equal(wi, oracle.OracleFrame(kr, dr, gur, BOUNDS, SCALE).FuseSearch(inv_sigma2, valid, u, v, ur, level, radius, desc)[0])
+        with pytest.raises(msorb_mod.MsorbError):
+            F.FuseSearchGated(_bad_octave(gate), None, inv_sigma2, valid, u, v, ur, level, radius, desc)   # octave outside mvInvLevelSigma2
+    finally:
+        F.close()
+
+
+def _bad_octave(gate):
+    g = gate.copy()
+    g["octave"][3] = 9
+    return g
+
+
 # ---- through the drop-in CLASS (tests/dropin_rig_main.cc): Frame objects with Nleft != -1 ---------------------------------------
 import os
 import struct
@@ -337,3 +402,257 @@ def test_search_by_bow_two_camera_frame(msorb_mod, oracle, seed, n1, n2, n_left,
         # the arm is not two one-camera searches: a right match needs the LEFT best distance <= TH_LOW and passes without a ratio test
         _, _, m21_all = oracle.search_by_bow(p["desc1"], p["desc2"], p["valid1"], None, p["fv1"], p["fv2"], p["angle1"], p["angle2"], 50, True, 0.7, True)
         assert not np.array_equal(m21_all, oracle.search_by_bow_rig(p, n_left, 50, 0.7, True)[1])
+
+
+# ---- SearchForTriangulation between KeyFrames of a two-camera rig: the geometric test stays with the caller -----------------------
+def _accept_fn(seed, n1, n2, rate):
+    """a stand-in for pCamera1->epipolarConstrain(pCamera2, kp1, kp2, R12, t12, ...) (ORBmatcher.cc:1332): a pure, pseudo-random predicate
+    of the two feature indices"""
+    table = np.random.default_rng(seed).random((max(n1, 1), max(n2, 1))) < rate
+    return lambda i1, i2: bool(table[i1, i2])
+
+
+@pytest.mark.parametrize("seed,n1,n2,rate,shuffle", [(1, 1200, 1300, 0.5, False), (2, 900, 2000, 0.2, True), (3, 1500, 1000, 0.9, False),
+                                                     (4, 0, 500, 0.5, False), (5, 600, 0, 0.5, False), (6, 2500, 2500, 0.5, True),
+                                                     (7, 800, 900, 0.0, False), (8, 800, 900, 1.0, True)])
+def test_search_for_triangulation_with_the_callers_geometric_test(msorb_mod, oracle, seed, n1, n2, rate, shuffle):
+    """msorb_search_for_triangulation_cb vs the oracle's statement-by-statement arm (orc_search_for_triangulation_rig): same matches
+    although the library asks accept() in another order (best distance first) than the reference's running-minimum scan."""
+    import bow_match_cases as bmc
+    p = bmc.make_pair(300 + seed, n1, n2, n_nodes=25, flip=30, dup_frac=0.25, shuffle_lists=shuffle)
+    acc = _accept_fn(seed, n1, n2, rate)
+    for ori in (True, False):
+        wn, w12, wcalls = oracle.search_for_triangulation_rig(p, acc, False, ori)
+        gn, g12, calls = msorb_mod.search_for_triangulation_cb(p, acc, 50, ori)
+        assert gn == wn and np.array_equal(g12, w12), (seed, ori, gn, wn, int((g12 != w12).sum()))
+        if n1 >= 800 and n2 >= 900:
+            assert (wn > 30) == (rate > 0) and len(calls) > 0
+            d1, d2 = p["desc1"], p["desc2"]
+            for i1, i2 in calls[:200]:                             # accept is only asked about eligible pairs within TH_LOW
+                assert p["valid1"][i1] and p["avail2"][i2] and int(np.unpackbits(d1[i1] ^ d2[i2]).sum()) <= 50
+    # bCoarse (:1332 `bCoarse || ...`): every candidate passes
+    wn, w12, _ = oracle.search_for_triangulation_rig(p, acc, True, True)
+    gn, g12, _ = msorb_mod.search_for_triangulation_cb(p, lambda i1, i2: True, 50, True)
+    assert gn == wn and np.array_equal(g12, w12)
+    # all trains eligible (avail2 = NULL)
+    q = dict(p, avail2=None)
+    wn, w12, _ = oracle.search_for_triangulation_rig(q, acc, False, True)
+    gn, g12, _ = msorb_mod.search_for_triangulation_cb(q, acc, 50, True)
+    assert gn == wn and np.array_equal(g12, w12)
+
+
+def test_the_accept_order_matters_only_through_purity(msorb_mod, oracle):
+    """ties in distance: the LAST train of equal distance wins in the reference (`dist > bestDist` lets an equal one replace, :1277); an accept
+    that rejects that one hands the match to the earlier one"""
+    import bow_match_cases as bmc
+    p = bmc.make_pair(77, 600, 700, n_nodes=6, flip=0, dup_frac=1.0, mask_frac=0.0, far_frac=0.0)   # exact duplicates: many ties at distance 0
+    every = lambda i1, i2: True
+    wn, w12, _ = oracle.search_for_triangulation_rig(p, every, False, False)
+    gn, g12, _ = msorb_mod.search_for_triangulation_cb(p, every, 50, False)
+    assert gn == wn and np.array_equal(g12, w12) and wn > 300
+    odd = lambda i1, i2: (i1 + i2) % 2 == 1
+    wn, w12, _ = oracle.search_for_triangulation_rig(p, odd, False, False)
+    gn, g12, _ = msorb_mod.search_for_triangulation_cb(p, odd, 50, False)
+    assert gn == wn and np.array_equal(g12, w12)
+    with pytest.raises(msorb_mod.MsorbError):
+        bad = dict(p, fv1=(p["fv1"][0][::-1].copy(), p["fv1"][1], p["fv1"][2]))
+        msorb_mod.search_for_triangulation_cb(bad, every, 50, False)
+
+
+# ---- KeyFrames of a two-camera rig through the drop-in CLASS (tests/dropin_rig_kf_main.cc) ---------------------------------------
+def _kf_cam(rng, oracle, n):
+    k = np.zeros(n, oracle.KP_DTYPE)
+    xs = rng.permutation(np.arange(40, 40 + 4 * n))[:n] * 0.25 + 0.125        # distinct coordinates: the epipolar log is keyed on them
+    k["x"] = 20 + xs % 1190; k["y"] = 20 + rng.uniform(0, 330, n)
+    k["octave"] = rng.integers(0, 8, n); k["angle"] = rng.uniform(0, 360, n); k["size"] = 31
+    return k
+
+
+@pytest.mark.parametrize("seed,check_ori", [(31, True), (32, False)])
+def test_class_triangulation_and_fuse_on_two_camera_keyframes(msorb_mod, oracle, tmp_path, seed, check_ori):
+    """ORBmatcher::SearchForTriangulation between two KeyFrames of a two-camera rig (ORBmatcher.cc:1168-1402: the camera model's
+    epipolarConstrain called back with the cameras / relative pose of :1294-1330) and ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight) for
+    both cameras (:1404-1597), against the oracle's arms."""
+    exe = str(tmp_path / "dropin_rig_kf")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", f"-I{ROOT}/tests/slam_stub", f"-I{ROOT}/tests/cv_stub", f"-I{ROOT}/ms-slam_amd/host",
+                           f"-I{ROOT}/include", f"{ROOT}/tests/dropin_rig_kf_main.cc", f"{ROOT}/ms-slam_amd/host/ORBmatcher.cc", f"-L{ROOT}/ms-slam_amd",
+                           "-lmsorb", f"-Wl,-rpath,{ROOT}/ms-slam_amd", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", exe])
+    rng = np.random.Generator(np.random.PCG64(seed))
+    NL1, NR1, NL2, NR2, M = 900, 800, 850, 900, 2500
+    N1, N2 = NL1 + NR1, NL2 + NR2
+    cam0 = np.array(CAM, np.float32); cam1 = np.array([CAM[0] * 1.01, CAM[1] * 0.99, CAM[2] + 3.0, CAM[3] - 2.0], np.float32)
+    sigma2 = (SCALE * SCALE).astype(np.float32)
+    # KeyFrame 2: random features; KeyFrame 1: noisy copies of KeyFrame 2's (either camera of either KeyFrame: all four side pairs occur)
+    k2l, k2r = _kf_cam(rng, oracle, NL2), _kf_cam(rng, oracle, NR2)
+    k2 = np.concatenate([k2l, k2r])
+    d2 = rng.integers(0, 256, (N2, 32), dtype=np.uint8)
+    node2 = (rng.integers(0, 40, N2) * 3 + 5).astype(np.int32)
+    twin = rng.integers(0, N2, N2 // 4)                               # near-duplicates: several trains within TH_LOW of one query
+    d2[twin] = mc.flip_bits(rng, d2[(twin + 1) % N2], 8); node2[twin] = node2[(twin + 1) % N2]
+    node2[rng.random(N2) < 0.03] = -1
+    k1l, k1r = _kf_cam(rng, oracle, NL1), _kf_cam(rng, oracle, NR1)
+    # the right-camera Fuse pass gates on GetKeyPoint(idx) with a right-camera index: the LEFT keypoint of the same number (KeyFrame.h:377-385).
+    # Left keypoint j near right keypoint j for a share of them, so that this gate passes often enough to be seen
+    m = min(NL1, NR1)
+    near = rng.random(m) < 0.6
+    k1l["x"][:m][near] = k1r["x"][:m][near] + rng.normal(0, 0.8, int(near.sum())); k1l["y"][:m][near] = k1r["y"][:m][near] + rng.normal(0, 0.8, int(near.sum()))
+    k1l["octave"][:m][near] = k1r["octave"][:m][near]
+    k1 = np.concatenate([k1l, k1r])
+    src = rng.integers(0, N2, N1)
+    d1 = mc.flip_bits(rng, d2[src], 25)
+    node1 = np.where(rng.random(N1) < 0.08, rng.integers(0, 40, N1) * 3 + 6, node2[src]).astype(np.int32)
+    k1["angle"] = (k2["angle"][src] + 40 + rng.normal(0, 5, N1)) % 360
+    k1l, k1r = k1[:NL1], k1[NL1:]
+    held1 = (rng.random(N1) < 0.3).astype(np.uint8); held2 = (rng.random(N2) < 0.3).astype(np.uint8)
+    obs1 = rng.integers(1, 6, N1).astype(np.int32); obs2 = rng.integers(1, 6, N2).astype(np.int32)
+    eye = np.eye(3)
+    t1 = np.array([0.3, -0.2, 0.1]); t2 = np.array([-0.4, 0.15, 0.25]); trl = np.array([-0.12, 0.013, 0.004])
+    c, s_ = np.cos(0.05), np.sin(0.05)
+    R2 = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]])
+
+    def pose_bytes(R, t):
+        return np.concatenate([R.reshape(9), t, eye.reshape(9), trl]).astype(np.float32)
+    # ---- Fuse candidates for KeyFrame 1 (Tcw = [I | t1]): points in front of either camera that project near one of its keypoints
+    side = rng.random(M) < 0.5                                        # True: aimed at the right camera
+    il, ir = rng.integers(0, NL1, M), rng.integers(0, NR1, M)         # the keypoint aimed at, per camera
+    gate1 = gate_of(k1l, k1r)
+    px = np.where(side, k1r["x"][ir], k1l["x"][il]) + rng.normal(0, 0.7, M)
+    py = np.where(side, k1r["y"][ir], k1l["y"][il]) + rng.normal(0, 0.7, M)
+    cm = np.where(side[:, None], cam1[None, :], cam0[None, :]).astype(np.float64)
+    z = rng.uniform(5, 40, M)
+    Xcam = np.stack([(px - cm[:, 2]) / cm[:, 0] * z, (py - cm[:, 3]) / cm[:, 1] * z, z], 1)
+    Xcam[rng.random(M) < 0.03, 2] *= -1
+    Xw = np.where(side[:, None], Xcam - trl - t1, Xcam - t1).astype(np.float32)
+    Ow = np.where(side[:, None], -(t1 + trl), -t1)
+    PO = Xw - Ow
+    dist = np.linalg.norm(PO, axis=1)
+    normal = PO / dist[:, None] + rng.normal(0, 0.3, (M, 3))
+    normal = (normal / np.linalg.norm(normal, axis=1, keepdims=True)).astype(np.float32)
+    lvl = np.where(side, gate1["octave"][ir], k1l["octave"][il])      # the level the gate will read (right pass: the gate keypoint's)
+    maxd = (dist * SCALE[lvl] * rng.uniform(0.95, 1.05, M)).astype(np.float32)
+    mind = (maxd / SCALE[7] * rng.uniform(0.5, 1.2, M)).astype(np.float32)
+    state = rng.choice([0, 1, 2, 3], M, p=[0.03, 0.87, 0.05, 0.05]).astype(np.uint8)
+    obs = rng.integers(0, 6, M).astype(np.int32)
+    dsrc = np.where(side[:, None], d1[NL1:][ir], d1[:NL1][il])
+    mdesc = mc.flip_bits(rng, dsrc, 30)
+    th_fuse, mbf = 3.0, 386.1448
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(struct.pack("<6i", NL1, NR1, NL2, NR2, M, 8))
+        f.write(struct.pack("<16f", *cam0, *cam1, *BOUNDS, th_fuse, mbf, float(check_ori), 0.0))
+        f.write(SCALE.tobytes()); f.write(sigma2.tobytes())
+        for (kl_, kr_, d_, node_, held_, obs_, pose_) in ((k1l, k1r, d1, node1, held1, obs1, pose_bytes(eye, t1)), (k2l, k2r, d2, node2, held2, obs2, pose_bytes(R2, t2))):
+            for a in (kl_, kr_, d_, node_, held_, obs_, pose_):
+                f.write(np.ascontiguousarray(a).tobytes())
+        for a in (state, Xw, normal, maxd, mind, obs, mdesc):
+            f.write(np.ascontiguousarray(a).tobytes())
+    p = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    blob = (tmp_path / "out.bin").read_bytes()
+    pos = 0
+
+    def take(dt, n):
+        nonlocal pos
+        a = np.frombuffer(blob, dt, n, pos)
+        pos += a.nbytes
+        return a
+    # ---- SearchForTriangulation: the four relative poses of :1196-1200 in float64 (Tcw1 = [I | t1], Tcw2 = [R2 | t2], Trl = [I | trl])
+    def se3(R, t): return (np.asarray(R, np.float64), np.asarray(t, np.float64))
+    def mul(a, b): return (a[0] @ b[0], a[0] @ b[1] + a[1])
+    def inv(a): return (a[0].T, -a[0].T @ a[1])
+    T1w, T2w, Trl_ = se3(eye, t1), se3(R2, t2), se3(eye, trl)
+    Tw2, Tr1w, Twr2 = inv(T2w), mul(Trl_, T1w), mul(inv(T2w), inv(Trl_))
+    T12 = {(0, 0): mul(T1w, Tw2), (0, 1): mul(T1w, Twr2), (1, 0): mul(Tr1w, Tw2), (1, 1): mul(Tr1w, Twr2)}
+    for T in T12.values():
+        assert abs(T[1][0]) > 1e-3 and abs(T[1][1]) > 1e-3            # the stand-in predicate reads these signs
+
+    def accept(i1, i2):
+        r1, r2 = int(i1 >= NL1), int(i2 >= NL2)
+        t12 = T12[(r1, r2)][1]
+        h = (int(k1["x"][i1]) * 7 + int(k1["y"][i1]) * 13 + int(k2["x"][i2]) * 29 + int(k2["y"][i2]) * 31 + (1 + r1) * 5 + (1 + r2) * 11 +
+             (3 if t12[0] > 0 else 0) + (17 if t12[1] > 0 else 0))
+        return h % 3 != 0
+    fv1, fv2 = bmc.feature_vector_from_nodes(node1), bmc.feature_vector_from_nodes(node2)
+    at1 = {(float(k1["x"][i]), float(k1["y"][i])): i for i in range(N1)}
+    at2 = {(float(k2["x"][i]), float(k2["y"][i])): i for i in range(N2)}
+    assert len(at1) == N1 and len(at2) == N2
+    for only_stereo, coarse in ((0, 0), (0, 1), (1, 0)):
+        nm = int(take(np.int32, 1)[0]); npairs = int(take(np.int32, 1)[0]); pairs = take(np.int32, 2 * npairs).reshape(-1, 2)
+        nrows = int(take(np.int32, 1)[0]); rows = take(np.float32, 21 * nrows).reshape(-1, 21)
+        q = dict(desc1=d1, desc2=d2, valid1=((held1 == 0) & (not only_stereo)).astype(np.uint8), avail2=((held2 == 0) & (not only_stereo)).astype(np.uint8),
+                 fv1=fv1, fv2=fv2, angle1=k1["angle"], angle2=k2["angle"])
+        wn, w12, _ = oracle.search_for_triangulation_rig(q, accept, bool(coarse), check_ori)
+        want = np.stack([np.flatnonzero(w12 >= 0), w12[w12 >= 0]], 1)
+        assert nm == wn == npairs and np.array_equal(pairs, want), (only_stereo, coarse, nm, wn)
+        if only_stereo:
+            assert nm == 0 and nrows == 0                              # bStereo is false for every feature of such a KeyFrame (:1243-1247)
+        elif coarse:
+            assert nm > 200 and nrows == 0                             # `bCoarse || ...`: the camera model is never asked (:1332)
+        else:
+            assert nm > 150 and nrows >= nm
+            sides = set()
+            for r in rows:
+                i1, i2 = at1[(float(r[0]), float(r[1]))], at2[(float(r[2]), float(r[3]))]
+                r1, r2 = int(i1 >= NL1), int(i2 >= NL2)
+                sides.add((r1, r2))
+                assert (int(r[4]), int(r[5])) == (1 + r1, 1 + r2)                                        # mpCamera / mpCamera2 by the feature's image
+                assert np.allclose(r[6:15], T12[(r1, r2)][0].reshape(9), atol=1e-5) and np.allclose(r[15:18], T12[(r1, r2)][1], atol=1e-5)
+                assert r[18] == sigma2[k1["octave"][i1]] and r[19] == sigma2[k2["octave"][i2]]
+                assert bool(r[20]) == accept(i1, i2)
+            assert sides == {(0, 0), (0, 1), (1, 0), (1, 1)}
+            assert (pairs[:, 0] >= NL1).sum() > 30 and (pairs[:, 1] >= NL2).sum() > 30
+    assert int(take(np.int32, 1)[0]) == 2                              # two-camera against one-camera KeyFrame: refused both ways
+    # ---- Fuse, left camera then right camera on the map the left pass left
+    inv_sigma2 = (np.float32(1.0) / sigma2).astype(np.float32)
+    ofl = oracle.OracleFrame(k1l, d1[:NL1], np.full(NL1, -1, np.float32), BOUNDS, SCALE)
+    ofr = oracle.OracleFrame(k1r, d1[NL1:], None, BOUNDS, SCALE)
+    gate, gur = gate1, np.full(NR1, -1, np.float32)
+    pts = {i: dict(obs=int(obs[i]), bad=state[i] == 2, inkf=state[i] == 3) for i in range(M) if state[i]}
+    kf_mp = {}
+    for j in range(N1):
+        if held1[j]:
+            pts[100000 + j] = dict(obs=int(obs1[j]), bad=False, inkf=True)
+            kf_mp[j] = 100000 + j
+    for right in (0, 1):
+        n_fused = int(take(np.int32, 1)[0])
+        valid = take(np.uint8, M); u = take(np.float32, M); v = take(np.float32, M); ur = take(np.float32, M)
+        level = take(np.int32, M); radius = take(np.float32, M)
+        nlog = int(take(np.int32, 1)[0]); log = take(np.int64, 3 * nlog).reshape(-1, 3)
+        alive = np.array([bool(state[i]) and not pts[i]["bad"] and not pts[i]["inkf"] for i in range(M)])
+        assert np.all(valid[~alive] == 0) and valid.sum() > 600
+        ok = (valid > 0) & (side == bool(right))                      # the geometry against float64, for the points aimed at this camera
+        cmr = cam1 if right else cam0
+        Xc = Xw.astype(np.float64) + t1 + (trl if right else 0)
+        assert np.allclose(u[ok], cmr[0] * Xc[ok, 0] / Xc[ok, 2] + cmr[2], atol=3e-2) and np.allclose(v[ok], cmr[1] * Xc[ok, 1] / Xc[ok, 2] + cmr[3], atol=3e-2)
+        assert ok.sum() > 400
+        if right:
+            bi, bd = ofr.FuseSearchGated(gate, gur, inv_sigma2, valid, u, v, ur, level, radius, mdesc)
+        else:
+            bi, bd = ofl.FuseSearch(inv_sigma2, valid, u, v, ur, level, radius, mdesc)
+        off = NL1 if right else 0
+        want_log, want_fused = [], 0
+        for i in range(M):
+            if not state[i] or pts[i]["bad"] or pts[i]["inkf"] or not valid[i]:
+                continue
+            if bd[i] <= 50:
+                j = int(bi[i]) + off                                   # `if(bRight) idx += pKF->GetNLeft()` (:1547)
+                if j in kf_mp:
+                    x = kf_mp[j]
+                    if not pts[x]["bad"]:
+                        a, b = (i, x) if pts[x]["obs"] > pts[i]["obs"] else (x, i)       # a->Replace(b)
+                        want_log.append((1, a, b))
+                        pts[a]["bad"] = True
+                        pts[b]["obs"] += pts[a]["obs"]
+                        pts[b]["inkf"] = pts[b]["inkf"] or pts[a]["inkf"]
+                else:
+                    want_log.append((2, i, j))
+                    pts[i]["inkf"] = True
+                    pts[i]["obs"] += 2
+                    kf_mp[j] = i
+                want_fused += 1
+        ids = lambda e: (e[0], e[1] - 5000000 if e[1] >= 5000000 else e[1], (e[2] - 5000000 if e[2] >= 5000000 else e[2]) if e[0] == 1 else e[2])
+        got_log = [ids(tuple(int(x) for x in e)) for e in log]
+        assert n_fused == want_fused and got_log == want_log, (right, n_fused, want_fused)
+        assert n_fused > (60 if right else 250), (right, n_fused)
+        if right:
+            assert all(e[2] >= NL1 for e in want_log if e[0] == 2)     # right-camera observations land at idx + NLeft
+    assert pos == len(blob)
