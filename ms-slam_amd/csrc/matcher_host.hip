@@ -223,6 +223,9 @@ struct RigSide {
     std::vector<uint8_t> occ, snap;
     std::vector<int8_t> diff;   // occupancy now vs the snapshot the side's lists were computed against
     int n_freed = 0, next = 0, fresh_from = 0, lanes = 16, rounds = 0;
+    bool pristine = true;   // no occupancy change since the last round: only then is the list of query `fresh_from` exact as it stands.  (The
+                            // OTHER camera's pass of the same map point can change this side between its round and its first query: a left
+                            // match of a point without observations frees the right partner it overwrites, ORBmatcher.cc:130-134.)
     uint8_t* h_occ = nullptr;
     int prepare(int M, const uint8_t* mp_desc) {   // queries + query descriptors to the device, once
         int rc;
@@ -255,10 +258,12 @@ struct RigSide {
         std::fill(diff.begin(), diff.end(), 0);
         n_freed = 0;
         fresh_from = next;
+        pristine = true;
         rounds++;
         return MSORB_OK;
     }
     void set_occ(int idx, int v) {
+        pristine = false;
         occ[idx] = (uint8_t)v;
         const int8_t d = (int8_t)((int)occ[idx] - (int)snap[idx]);
         if (diff[idx] < 0) n_freed--;
@@ -270,7 +275,8 @@ struct RigSide {
     bool prefix(int qi, int need, int* idx, int* dist, int* n_out) const {
         const bool skip = q[qi].flags & kQSkipOccupied;
         if (f->N <= 0) { *n_out = 0; return true; }
-        if (skip && n_freed > 0 && qi > fresh_from) return false;
+        const bool stale = qi > fresh_from || !pristine;   // claims may lie between the round and this query
+        if (skip && n_freed > 0 && stale) return false;
         const TopK& t = f->h_topk.p[qi];
         int n = 0, n_dev = 0;
         for (int k = 0; k < kTopK; k++) {
@@ -279,7 +285,7 @@ struct RigSide {
             if (skip && diff[t.idx[k]] > 0) continue;
             idx[n] = t.idx[k]; dist[n] = t.dist[k]; n++;
         }
-        if (n < need && n < n_dev && n_dev == kTopK && qi > fresh_from) return false;
+        if (n < need && n < n_dev && n_dev == kTopK && stale) return false;
         *n_out = n;
         return true;
     }

@@ -157,3 +157,39 @@ def test_fz_sparsify(msorb_mod, oracle, i):
     assert (got["n_cols"], got["n_rows"], got["n_max_obs"]) == (want["n_cols"], want["n_rows"], want["n_max_obs"]), kw
     for k in ts.KEYS:
         assert np.array_equal(got[k], want[k]), (k, kw)
+
+
+# ---- the two-camera arms (tests/test_matcher_rig_gpu.py) ----------------------------------------------------------------------------
+@pytest.mark.parametrize("i", range(N))
+def test_fz_rig_mps(msorb_mod, oracle, i):
+    import test_matcher_rig_gpu as tr
+    r = _rng(i, 15)
+    case = dict(seed=int(r.integers(10, 10 ** 6)), n_left=int(r.integers(0, 2500)), n_right=int(r.integers(0, 2500)), M=int(r.integers(0, 7000)),
+                dense=bool(r.integers(0, 2)), th=float(r.uniform(0.5, 6)))
+    _call(tr.test_search_by_projection_two_camera_frame, msorb_mod, oracle, case)
+
+
+@pytest.mark.parametrize("i", range(N))
+def test_fz_rig_bow(msorb_mod, oracle, i):
+    import test_matcher_rig_gpu as tr
+    r = _rng(i, 16)
+    n2 = int(r.integers(0, 4000))
+    _call(tr.test_search_by_bow_two_camera_frame, msorb_mod, oracle, int(r.integers(10, 10 ** 6)), int(r.integers(0, 2500)), n2,
+          int(r.integers(0, n2 + 1)), bool(r.integers(0, 2)))
+
+
+@pytest.mark.parametrize("i", range(N))
+def test_fz_rig_fuse(msorb_mod, oracle, i):
+    import test_matcher_rig_gpu as tr
+    r = _rng(i, 17)
+    # (seeds 1 and 3 of the regular test select its special arms: draw from the others)
+    _call(tr.test_fuse_search_right_camera_of_a_two_camera_keyframe, msorb_mod, oracle, int(r.integers(4, 10 ** 6)), int(r.integers(0, 2500)),
+          int(r.integers(1, 2500)), float(r.uniform(1, 8)))
+
+
+@pytest.mark.parametrize("i", range(N))
+def test_fz_rig_triangulation(msorb_mod, oracle, i):
+    import test_matcher_rig_gpu as tr
+    r = _rng(i, 18)
+    _call(tr.test_search_for_triangulation_with_the_callers_geometric_test, msorb_mod, oracle, int(r.integers(10, 10 ** 6)), int(r.integers(0, 3000)),
+          int(r.integers(0, 4000)), float(r.uniform(0, 1)), bool(r.integers(0, 2)))
