@@ -193,3 +193,11 @@ def test_fz_rig_triangulation(msorb_mod, oracle, i):
     r = _rng(i, 18)
     _call(tr.test_search_for_triangulation_with_the_callers_geometric_test, msorb_mod, oracle, int(r.integers(10, 10 ** 6)), int(r.integers(0, 3000)),
           int(r.integers(0, 4000)), float(r.uniform(0, 1)), bool(r.integers(0, 2)))
+
+
+@pytest.mark.parametrize("i", range(N))
+def test_fz_rig_last_frame(msorb_mod, oracle, i):
+    import test_matcher_rig_gpu as tr
+    r = _rng(i, 19)
+    _call(tr.test_search_by_projection_last_frame_two_camera_tables, msorb_mod, oracle, int(r.integers(10, 10 ** 6)), int(r.integers(0, 2500)),
+          int(r.integers(0, 2500)), int(r.integers(0, 5000)), float(r.uniform(1, 25)))

@@ -660,3 +660,53 @@ def test_class_triangulation_and_fuse_on_two_camera_keyframes(msorb_mod, oracle,
         if right:
             assert all(e[2] >= NL1 for e in want_log if e[0] == 2)     # right-camera observations land at idx + NLeft
     assert pos == len(blob)
+
+
+# ---- SearchByProjection(CurrentFrame, LastFrame, th, bMono) on a two-camera CurrentFrame, at the C ABI on synthetic projection tables ----
+def make_last_table(oracle, seed, n_left, n_right, n_last, th):
+    """a last frame's projected map points aimed at the current frame's keypoints: several per keypoint (claims collide), some only
+    seen by one camera, keypoints the frame already holds (with and without observations)"""
+    R = make_rig(oracle, seed, n_left, n_right, 0, dense=seed % 2 == 0)
+    rng = np.random.Generator(np.random.PCG64(seed + 5))
+    kl, kr, dl, dr = R["kl"], R["kr"], R["dl"], R["dr"]
+    il, ir = rng.integers(0, max(n_left, 1), n_last), rng.integers(0, max(n_right, 1), n_last)
+    partner = (R["l2r"][il] >= 0) if n_left else np.zeros(n_last, bool)
+    if n_left and n_right:
+        ir = np.where(partner, R["l2r"][il], ir)
+    noise = th * 0.4
+    last = dict(valid=(rng.random(n_last) < 0.9).astype(np.uint8),
+                u=((kl["x"][il] if n_left else np.full(n_last, -500.0)) + rng.normal(0, noise, n_last)).astype(np.float32),
+                v=((kl["y"][il] if n_left else np.full(n_last, -500.0)) + rng.normal(0, noise, n_last)).astype(np.float32),
+                u_r=((kr["x"][ir] if n_right else np.full(n_last, -500.0)) + rng.normal(0, noise, n_last)).astype(np.float32),
+                v_r=((kr["y"][ir] if n_right else np.full(n_last, -500.0)) + rng.normal(0, noise, n_last)).astype(np.float32),
+                octave=np.clip((kl["octave"][il] if n_left else kr["octave"][ir] if n_right else np.zeros(n_last, np.int32)) + rng.integers(-1, 2, n_last), 0, 7).astype(np.int32),
+                angle=(((kl["angle"][il] if n_left else np.zeros(n_last)) + 20 + rng.normal(0, 6, n_last)) % 360).astype(np.float32),
+                desc=(mc.flip_bits(rng, dl[il], 35) if n_left else rng.integers(0, 256, (n_last, 32), dtype=np.uint8)), mp=np.arange(n_last, dtype=np.int32))
+    wide = rng.random(n_last) < 0.1
+    last["u"][wide] += rng.normal(0, 6 * th, int(wide.sum())).astype(np.float32)          # left window empty for some: their right arm must not run (:2003-2004)
+    N = n_left + n_right
+    held = np.flatnonzero(rng.random(N) < 0.12)
+    cur = np.full(N, -1, np.int32)
+    cur[held] = n_last + np.arange(len(held))
+    last["obs"] = np.concatenate([np.where(rng.random(n_last) < 0.2, 0, rng.integers(1, 9, n_last)), rng.integers(0, 3, len(held))]).astype(np.int32)
+    return R, last, cur
+
+
+@pytest.mark.parametrize("seed,n_left,n_right,n_last,th", [(51, 1500, 1400, 1800, 7.0), (52, 900, 1000, 3000, 15.0), (53, 1200, 0, 1500, 7.0), (54, 0, 900, 1200, 7.0),
+                                                           (55, 2000, 1900, 0, 7.0), (56, 600, 700, 4000, 3.0)])
+def test_search_by_projection_last_frame_two_camera_tables(msorb_mod, oracle, seed, n_left, n_right, n_last, th):
+    """msorb_search_by_projection_frames_rig (ORBmatcher.cc:1941-2152 with the right arm :2059-2124) vs the oracle's arm"""
+    R, last, cur = make_last_table(oracle, seed, n_left, n_right, n_last, th)
+    ofl, ofr = oracle.OracleFrame(R["kl"], R["dl"], None, BOUNDS, SCALE), oracle.OracleFrame(R["kr"], R["dr"], None, BOUNDS, SCALE)
+    dfl, dfr = msorb_mod.Frame(R["kl"], R["dl"], None, BOUNDS, SCALE), msorb_mod.Frame(R["kr"], R["dr"], None, BOUNDS, SCALE)
+    try:
+        for fwd, bwd, ori in ((False, False, True), (True, False, True), (False, True, False)):
+            want, got = cur.copy(), cur.copy()
+            wn = oracle.search_by_projection_frames_rig(ofl, ofr, last, want, th, fwd, bwd, ori)
+            gn = msorb_mod.search_by_projection_frames_rig(dfl, dfr, last, got, th, fwd, bwd, ori)
+            assert gn == wn and np.array_equal(got, want), (seed, fwd, bwd, ori, gn, wn, int((got != want).sum()))
+            if n_last >= 1500 and n_left >= 600 and n_right >= 600 and not fwd and not bwd:
+                new = (want >= 0) & (want < n_last)
+                assert new[:n_left].sum() > 100 and new[n_left:].sum() > 40
+    finally:
+        dfl.close(); dfr.close()
