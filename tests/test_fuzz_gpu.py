@@ -52,3 +52,34 @@ def test_bounded_fuzz(msorb_mod, oracle, script, args, verdict):
     code, out = _run(script, argv)
     assert code == 0 and verdict in out and "MISMATCH" not in out and "EXC" not in out, \
         f"reproduce with: python tools/{script} {' '.join(str(a) for a in argv)}\n{out[-3000:]}"
+
+
+def test_bounded_fuzz_two_camera_arms(msorb_mod, oracle):
+    """the two-camera matcher arms on drawn rigs (the draws of tests/_fuzz_matcher.py's rig entries, 6 per arm and tree): the first run of
+    that driver over them found a claim-replay case no hand-written rig had (a point without observations freeing its own right partner)"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_matcher_rig_gpu as tr
+    seed = _seed(msorb_mod)
+
+    def tolerant(fn, *a):
+        try:
+            fn(*a)
+        except AssertionError as e:          # population asserts ("enough matches") of the regular tests may fail on a drawn size; parity asserts carry an `==` / array_equal
+            msg = str(e)
+            if "array_equal" in msg or "==" in msg:
+                raise AssertionError(f"MSORB_FUZZ_SEED={seed} {fn.__name__}{a[2:]}: {msg[:1500]}")
+    for i in range(6):
+        r = np.random.Generator(np.random.PCG64(seed * 100 + i))
+        case = dict(seed=int(r.integers(10, 10 ** 6)), n_left=int(r.integers(0, 2500)), n_right=int(r.integers(0, 2500)), M=int(r.integers(0, 7000)),
+                    dense=bool(r.integers(0, 2)), th=float(r.uniform(0.5, 6)))
+        tolerant(tr.test_search_by_projection_two_camera_frame, msorb_mod, oracle, case)
+        tolerant(tr.test_search_by_projection_last_frame_two_camera_tables, msorb_mod, oracle, int(r.integers(10, 10 ** 6)), int(r.integers(0, 2500)),
+                 int(r.integers(0, 2500)), int(r.integers(0, 5000)), float(r.uniform(1, 25)))
+        n2 = int(r.integers(0, 4000))
+        tolerant(tr.test_search_by_bow_two_camera_frame, msorb_mod, oracle, int(r.integers(10, 10 ** 6)), int(r.integers(0, 2500)), n2, int(r.integers(0, n2 + 1)),
+                 bool(r.integers(0, 2)))
+        tolerant(tr.test_fuse_search_right_camera_of_a_two_camera_keyframe, msorb_mod, oracle, int(r.integers(4, 10 ** 6)), int(r.integers(0, 2500)),
+                 int(r.integers(1, 2500)), float(r.uniform(1, 8)))
+        tolerant(tr.test_search_for_triangulation_with_the_callers_geometric_test, msorb_mod, oracle, int(r.integers(10, 10 ** 6)), int(r.integers(0, 3000)),
+                 int(r.integers(0, 4000)), float(r.uniform(0, 1)), bool(r.integers(0, 2)))
