@@ -83,3 +83,21 @@ def test_bounded_fuzz_two_camera_arms(msorb_mod, oracle):
                  int(r.integers(1, 2500)), float(r.uniform(1, 8)))
         tolerant(tr.test_search_for_triangulation_with_the_callers_geometric_test, msorb_mod, oracle, int(r.integers(10, 10 ** 6)), int(r.integers(0, 3000)),
                  int(r.integers(0, 4000)), float(r.uniform(0, 1)), bool(r.integers(0, 2)))
+
+
+def test_drawn_scenes_through_the_two_camera_class_paths(msorb_mod, oracle, tmp_path):
+    """the class-level two-camera tests (Frame / KeyFrame stand-ins through ORB_SLAM3::ORBmatcher) on scenes drawn from this tree's seed"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_matcher_rig_gpu as tr
+    seed = 1000 + _seed(msorb_mod) % 1000000
+
+    def tolerant(fn, *a):
+        try:
+            fn(*a)
+        except AssertionError as e:
+            msg = str(e)
+            if "array_equal" in msg or "==" in msg:
+                raise AssertionError(f"{fn.__name__} with seed {a[3:]}: {msg[:1500]}")
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    tolerant(tr.test_class_search_by_projection_on_two_camera_frames, msorb_mod, oracle, tmp_path / "a", seed, ["forward", "backward", "side"][seed % 3], bool(seed & 8))
+    tolerant(tr.test_class_triangulation_and_fuse_on_two_camera_keyframes, msorb_mod, oracle, tmp_path / "b", seed + 1, bool(seed & 16))
