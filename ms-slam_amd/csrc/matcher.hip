@@ -93,7 +93,9 @@ __device__ __forceinline__ uint64_t group_min_u64(uint64_t v) {
     }
     return v;
 }
-template <bool kCount, int kWinLanes>
+// kGate: F.gate_kp holds the keypoints the level band and the kQFuseGate test read (msorb_fuse_search_gated); a template parameter so
+// that the searches of every frame pay nothing for it.
+template <bool kCount, int kWinLanes, bool kGate = false>
 __global__ __launch_bounds__(256) void window_topk_kernel(FrameView F, const WinQuery* __restrict__ q,
                                                           const uint8_t* __restrict__ qdesc, int q_begin, int q_end,
                                                           TopK* __restrict__ out, int frame_stride, int q_stride,
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void window_topk_kernel(FrameView F, const Win
             for (int j = b; j < e; j++) {
                 const int idx = F.cell_idx[j];
                 const KpLite kp = F.kp[idx];
-                const KpLite g = F.gate_kp ? F.gate_kp[idx] : kp;   // (wave uniform: a kernel argument)
+                const KpLite g = kGate ? F.gate_kp[idx] : kp;
                 if (check_levels) {
                     if (g.octave < Q.min_level) continue;
                     if (Q.max_level >= 0 && g.octave > Q.max_level) continue;
@@ -856,6 +858,11 @@ void launch_window_topk(const FrameView& F, const WinQuery* q, const uint8_t* qd
     hipLaunchKernelGGL((window_topk_kernel<COUNT, LANES>), dim3((n + 256 / LANES - 1) / (256 / LANES), n_frames), dim3(256), 0, s, F, q, \
                        qdesc, q_begin, q_end, out, frame_stride, q_stride, n_eval)
     // (a single frame's few thousand queries are latency, not throughput: 12.5 us with 16 lanes, 19.7 with 4)
+    if (F.gate_kp) {   // Fuse(..., bRight = true): a few thousand queries of one KeyFrame
+        hipLaunchKernelGGL((window_topk_kernel<false, 16, true>), dim3((n + 15) / 16, n_frames), dim3(256), 0, s, F, q, qdesc, q_begin, q_end, out,
+                           frame_stride, q_stride, n_eval);
+        return;
+    }
     if (lanes <= 4 && (long long)n * n_frames >= 32768) { if (n_eval) MSORB_WIN_LAUNCH(true, 4); else MSORB_WIN_LAUNCH(false, 4); }
     else { if (n_eval) MSORB_WIN_LAUNCH(true, 16); else MSORB_WIN_LAUNCH(false, 16); }
 #undef MSORB_WIN_LAUNCH
