@@ -172,7 +172,7 @@ struct msorb_extractor {
     // worker threads), MSORB_SPLIT_NO_PEER (test hook: the two-device gather staged through the host), MSORB_FORCE_PEER_PYRAMID
     // (test hook: msorb_stereo_matches pulls the right pyramid over the peer path even on one device)
     const StereoRowJob* row_job = nullptr;   // set by the stereo-frame calls around run_pipeline: the right eye's band records leave the layout launch
-    struct Knobs { bool serial_pipeline = false, quadtree_host = false, split_no_peer = false, force_peer_pyramid = false, frame_compact = true; int host_threads = 0, frame_fuse = 2; } knobs;
+    struct Knobs { bool serial_pipeline = false, quadtree_host = false, quadtree_global = false, split_no_peer = false, force_peer_pyramid = false, frame_compact = true; int host_threads = 0, frame_fuse = 2; } knobs;
     int lds_per_block = 64 * 1024;   // hipDeviceAttributeMaxSharedMemoryPerBlock of the handle's device
     static constexpr bool capturing = false;   // (no graph capture: plain launches; see tools/experiments/README.md)
     bool defer_sync = false;     // enqueue only, the caller appends more work and synchronises (msorb_extract[_stereo])
@@ -220,6 +220,8 @@ struct msorb_extractor {
     DevBuf<int> d_sel_pt, d_sel_n, d_mono;
     QtLevels qt{};
     bool device_quadtree = true;
+    bool qt_global = false;   // the selection's workspace lives in global memory (d_qt_ws): quotas beyond a workgroup's LDS, or MSORB_QT_GLOBAL=1
+    DevBuf<char> d_qt_ws;
     bool small_cells = false;  // every cell ROI <= 46 x 57: the FAST kernel's compact LDS geometry applies
     bool compact_on_host = false;  // h_compact / h_level_count / h_img_base hold the last call's candidates
     bool compact_fixed_stride = false;  // the last call left image i's candidates at i * slots_per_image on the device (device pipeline)
@@ -311,9 +313,17 @@ int ensure_geometry(msorb_extractor* h, int rows, int cols) {
         sel_off += std::max(lg.quota, h->qt.n_ini[l]) + 8 + 4 * h->qt.n_ini[l];
     }
     h->sel_stride = sel_off;
-    // the device quadtree keeps a level's candidates in one workgroup's LDS (160 KB per CU on gfx950: nfeatures up to ~8000);
-    // beyond the device's limit the host twin takes over
-    h->device_quadtree = !h->knobs.quadtree_host && (long long)quadtree_lds_bytes(h->qt) + 10 * 1024 <= (long long)h->lds_per_block;
+    // the device quadtree keeps a level's workspace in one workgroup's LDS (160 KB per CU on gfx950: nfeatures up to ~8000); beyond
+    // that the same selection runs over a workspace in global memory (quadtree_global_kernels.hip) — up to the 14-bit node slots of
+    // its candidate labels (quadtree_device.h kSlotMask: 4 N + 16 slots, i.e. a level quota N <= 4092: nfeatures ~18 800 at
+    // 1.2 / 8 levels; Tracking.cc:601's 5 x nFeatures initialisation extractor asks for 6 000 - 10 000).  The host twin
+    // (orb_host.cc) is a checker (MSORB_QUADTREE=host) and what is left for quotas beyond that.
+    int max_quota = 1;
+    for (int l = 0; l < g.nlevels; l++) max_quota = std::max(max_quota, std::max(h->qt.quota[l], h->qt.n_ini[l]));
+    const bool fits_lds = (long long)quadtree_lds_bytes(h->qt) + 10 * 1024 <= (long long)h->lds_per_block;
+    const bool fits_labels = 4 * max_quota + 16 <= 16384;
+    h->device_quadtree = !h->knobs.quadtree_host && (fits_lds || fits_labels);
+    h->qt_global = h->device_quadtree && (!fits_lds || h->knobs.quadtree_global) && fits_labels;
     h->geom_valid = true;
     h->last_n_images = 0;
     return MSORB_OK;
@@ -343,6 +353,7 @@ int ensure_batch(msorb_extractor* h, int n_images) {
     if ((rc = h->d_label.ensure((size_t)n_images * g.slots_per_image))) return rc;
     if ((rc = h->d_sel_pt.ensure((size_t)n_images * h->sel_stride))) return rc;
     if ((rc = h->d_sel_n.ensure((size_t)n_images * g.nlevels))) return rc;
+    if (h->qt_global && (rc = h->d_qt_ws.ensure((size_t)n_images * g.nlevels * quadtree_global_workspace_stride(h->qt)))) return rc;
     if ((rc = h->d_mono.ensure(std::max(n_images, 4)))) return rc;
     return MSORB_OK;
 }
@@ -574,7 +585,8 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
                                   h->d_label.p + cslot, h->d_sel_pt.p + (size_t)first * sel_stride, h->d_sel_n.p + (size_t)first * nl,
                                   sel_stride, h->scales, lap0, lap1, capacity, h->d_sel.p + (size_t)first * sel_stride,
                                   h->d_sel_count.p + first, h->d_mono.p + first, n, s, ng == 1 ? h->row_job : nullptr,
-                                  fuse_qt ? &blur_job : nullptr, &blur_carried)))
+                                  fuse_qt ? &blur_job : nullptr, &blur_carried,
+                                  h->qt_global ? h->d_qt_ws.p + (size_t)first * nl * quadtree_global_workspace_stride(h->qt) : nullptr)))   // (groups run side by side: a slice each)
             return rc;
         if (fuse_qt && !blur_carried) blur_now();   // (the selection ran a form that does not carry the blur: on this stream, before describe)
         mark(5, s);
@@ -654,7 +666,7 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
         // selection stays on the device: quadtree per (level, image), output layout per image
         const int qrc = launch_quadtree(h->qt, h->d_compact.p, h->d_img_base.p, h->d_level_count.p, h->d_label.p, h->d_sel_pt.p,
                                         h->d_sel_n.p, sel_stride, h->scales, lap0, lap1, capacity, h->d_sel.p, h->d_sel_count.p,
-                                        h->d_mono.p, n_images, s, h->row_job);
+                                        h->d_mono.p, n_images, s, h->row_job, nullptr, nullptr, h->qt_global ? h->d_qt_ws.p : nullptr);
         if (qrc) return qrc;
         mark(5);
         if (overlap_blur) HIPCHK(hipStreamWaitEvent(s, h->ev_blur, 0));
@@ -861,6 +873,7 @@ int msorb_extractor_create(int nfeatures, float scale_factor, int nlevels, int i
         const char* e;
         h->knobs.serial_pipeline = getenv("MSORB_SERIAL_PIPELINE") != nullptr;
         h->knobs.quadtree_host = (e = getenv("MSORB_QUADTREE")) && std::string(e) == "host";
+        h->knobs.quadtree_global = (e = getenv("MSORB_QUADTREE")) && std::string(e) == "global";   // (test switch: the global-workspace selection at any quota)
         h->knobs.split_no_peer = getenv("MSORB_SPLIT_NO_PEER") != nullptr;
         h->knobs.force_peer_pyramid = getenv("MSORB_FORCE_PEER_PYRAMID") != nullptr;
         h->knobs.host_threads = (e = getenv("MSORB_HOST_THREADS")) ? atoi(e) : 0;

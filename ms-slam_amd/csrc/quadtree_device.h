@@ -33,7 +33,9 @@
 #endif
 // The workspace lives in LDS on the device.  Its pointers carry the LDS address space in the device pass: through generic
 // pointers every access becomes a FLAT instruction (and the LDS atomics flat atomics), several times slower than ds_*.
-#if defined(__HIP_DEVICE_COMPILE__)
+// (MSORB_QT_GLOBAL_WORKSPACE, defined by quadtree_global_kernels.hip before this header: the same code over a workspace in
+// global memory — plain pointers — for quotas whose workspace exceeds a workgroup's LDS.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MSORB_QT_GLOBAL_WORKSPACE)
 #define QT_LDS __attribute__((address_space(3)))
 #else
 #define QT_LDS

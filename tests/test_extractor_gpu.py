@@ -285,6 +285,56 @@ def test_saturated_single_cell(msorb_mod, oracle):
         ex.close()
 
 
+@pytest.mark.parametrize("nfeat,nlev,kind", [(10000, 8, "noise"), (10000, 8, "scene"), (12000, 8, "noise"), (6000, 2, "noise")])
+def test_quotas_beyond_a_workgroups_lds_stay_on_the_device(msorb_mod, oracle, nfeat, nlev, kind):
+    """Level quotas above ~1 800 keypoints (the monocular initialisation extractor of Tracking.cc:601 asks for 5 * nFeatures = 10 000):
+    the selection's workspace does not fit 160 KB of LDS; the SAME selection code runs over a workspace in global memory
+    (quadtree_global_kernels.hip) — on the device, in the full pipeline (per frame, batches, pairs), where rounds 1-5 handed these
+    quotas to the host twin."""
+    import torch
+    cfg = synth.KITTI
+    rng = np.random.Generator(np.random.PCG64(nfeat + nlev))
+    imgs = [rng.integers(0, 256, (cfg["rows"], cfg["cols"]), dtype=np.uint8) if kind == "noise" else synth.image(190 + i, cfg["rows"], cfg["cols"])
+            for i in range(2)]
+    ex = msorb_mod.ORBextractor(nfeat, 1.2, nlev, 20, 7)
+    ref = oracle.OracleExtractor(nfeat, 1.2, nlev, 20, 7)
+    try:
+        want = [ref(im) for im in imgs]
+        for im, (rmono, rkps, rdesc) in zip(imgs, want):
+            mono, kps, desc = ex(im)
+            assert mono == rmono and len(kps) >= (nfeat * 9 // 10 if kind == "noise" else 2000)
+            _assert_same(kps, desc, rkps, rdesc)
+        d = torch.from_numpy(np.stack(imgs * 4)).cuda()       # 8 images: the batch path (device pipeline: it used to be refused here)
+        counts, monos, d_kps, d_desc = ex.extract_batch(d)
+        got = msorb_mod.keypoints_from_device(d_kps, counts)
+        for i in (0, 1, 7):
+            rmono, rkps, rdesc = want[i % 2]
+            assert monos[i] == rmono
+            _assert_same(got[i], d_desc[i, :counts[i]].cpu().numpy(), rkps, rdesc)
+    finally:
+        ex.close()
+
+
+@pytest.mark.parametrize("name", ["kitti", "euroc", "small"])
+def test_global_workspace_selection_at_ordinary_quotas(msorb_mod, oracle, monkeypatch, name):
+    """MSORB_QUADTREE=global: the global-memory form of the selection at quotas the LDS form serves — one source, two address spaces,
+    same keypoints (dense and low-texture levels, the careful sweep's sort included)."""
+    monkeypatch.setenv("MSORB_QUADTREE", "global")
+    cfg = CONFIGS[name]
+    ex, ref = _pair(msorb_mod, oracle, cfg)
+    try:
+        for seed, kind in ((61, "scene"), (62, "low")):
+            img = synth.image(seed, cfg["rows"], cfg["cols"])
+            if kind == "low":
+                img = (img.astype(np.float32) * 0.25 + 96).astype(np.uint8)      # low contrast: sparse levels, deep trees
+            mono, kps, desc = ex(img)
+            rmono, rkps, rdesc = ref(img)
+            assert mono == rmono
+            _assert_same(kps, desc, rkps, rdesc)
+    finally:
+        ex.close()
+
+
 @pytest.mark.parametrize("nfeat,nlev,kind", [(3500, 8, "scene"), (3500, 8, "noise"), (8000, 8, "noise"), (3000, 2, "noise")])
 def test_large_feature_quota_device_quadtree(msorb_mod, oracle, nfeat, nlev, kind):
     """Quotas whose quadtree workspace exceeds the 64 KB default LDS window (nfeatures > ~3300 at 1.2 / 8 levels): the

@@ -526,7 +526,8 @@ def test_extract_stereo_equals_two_extractions_plus_stereo_matches(msorb_mod, or
     mbf, mb = mc.KITTI_BF, mc.KITTI_BF / mc.KITTI_FX
     # (nfeatures 501: an odd capacity — the output block's tail is not 16-byte aligned, so the median rule keeps its own launch
     # instead of riding the read-back: extractor.hip extract_stereo_sink, stereo_median_readback_kernel)
-    for seed, (rows, cols), nfeat in ((40, (376, 1241), 2000), (41, (480, 752), 1000), (42, (240, 320), 500), (43, (240, 320), 501)):
+    for seed, (rows, cols), nfeat in ((40, (376, 1241), 2000), (41, (480, 752), 1000), (42, (240, 320), 500), (43, (240, 320), 501),
+                                       (44, (376, 1241), 10000)):    # (a quota beyond a workgroup's LDS: the selection over global memory)
         L, R = synth.stereo_pair(seed, rows, cols)
         ex = msorb_mod.ORBextractor(nfeat, 1.2, 8, 20, 7)
         exl = msorb_mod.ORBextractor(nfeat, 1.2, 8, 20, 7)

@@ -9,7 +9,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
     rows = int(rng.integers(200, 500)); cols = int(rng.integers(300, 1300))
-    nfeat = int(rng.choice([50, 300, 777, 1000, 1500, 2000, 3000, 5000]))
+    nfeat = int(rng.choice([50, 300, 777, 1000, 1500, 2000, 3000, 5000, 10000]))
     sf = float(rng.choice([1.1, 1.2, 1.25, 1.3, 1.5, 2.0])); nlev = int(rng.integers(1, 9))
     ini = int(rng.integers(5, 60)); mn = int(rng.integers(1, ini + 1))
     kind = int(rng.integers(0, 4))
