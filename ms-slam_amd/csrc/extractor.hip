@@ -222,6 +222,7 @@ struct msorb_extractor {
     bool device_quadtree = true;
     bool qt_global = false;   // the selection's workspace lives in global memory (d_qt_ws): quotas beyond a workgroup's LDS, or MSORB_QT_GLOBAL=1
     DevBuf<char> d_qt_ws;
+    DevBuf<uint32_t> d_label_wide;   // the global form's 32-bit candidate labels (one per candidate slot, like d_label)
     bool small_cells = false;  // every cell ROI <= 46 x 57: the FAST kernel's compact LDS geometry applies
     bool compact_on_host = false;  // h_compact / h_level_count / h_img_base hold the last call's candidates
     bool compact_fixed_stride = false;  // the last call left image i's candidates at i * slots_per_image on the device (device pipeline)
@@ -314,15 +315,19 @@ int ensure_geometry(msorb_extractor* h, int rows, int cols) {
     }
     h->sel_stride = sel_off;
     // the device quadtree keeps a level's workspace in one workgroup's LDS (160 KB per CU on gfx950: nfeatures up to ~8000); beyond
-    // that the same selection runs over a workspace in global memory (quadtree_global_kernels.hip) — up to the 14-bit node slots of
-    // its candidate labels (quadtree_device.h kSlotMask: 4 N + 16 slots, i.e. a level quota N <= 4092: nfeatures ~18 800 at
-    // 1.2 / 8 levels; Tracking.cc:601's 5 x nFeatures initialisation extractor asks for 6 000 - 10 000).  The host twin
-    // (orb_host.cc) is a checker (MSORB_QUADTREE=host) and what is left for quotas beyond that.
+    // that the same selection runs over a workspace in global memory (quadtree_global_kernels.hip) — up to the 16-bit rank tables
+    // of that workspace (4 N + 16 slots <= 65535: a level quota N <= 16 379, nfeatures ~75 000 at 1.2 / 8 levels; Tracking.cc:601's
+    // 5 x nFeatures initialisation extractor asks for 6 000 - 10 000).  The host twin (orb_host.cc) is a checker
+    // (MSORB_QUADTREE=host); quotas beyond the global form are refused when the geometry is set (MSORB_E_CAPACITY).
     int max_quota = 1;
     for (int l = 0; l < g.nlevels; l++) max_quota = std::max(max_quota, std::max(h->qt.quota[l], h->qt.n_ini[l]));
     const bool fits_lds = (long long)quadtree_lds_bytes(h->qt) + 10 * 1024 <= (long long)h->lds_per_block;
-    const bool fits_labels = 4 * max_quota + 16 <= 16384;
-    h->device_quadtree = !h->knobs.quadtree_host && (fits_lds || fits_labels);
+    const bool fits_labels = 4 * max_quota + 16 <= 65535;   // (the 16-bit rank tables of the workspace; labels are 32 bits in the global form)
+    if (!h->knobs.quadtree_host && !fits_lds && !fits_labels) {
+        set_error("a level quota of " + std::to_string(max_quota) + " keypoints is beyond the device selection (16 379 per level); MSORB_QUADTREE=host runs it on the host twin");
+        return MSORB_E_CAPACITY;
+    }
+    h->device_quadtree = !h->knobs.quadtree_host;
     h->qt_global = h->device_quadtree && (!fits_lds || h->knobs.quadtree_global) && fits_labels;
     h->geom_valid = true;
     h->last_n_images = 0;
@@ -354,6 +359,7 @@ int ensure_batch(msorb_extractor* h, int n_images) {
     if ((rc = h->d_sel_pt.ensure((size_t)n_images * h->sel_stride))) return rc;
     if ((rc = h->d_sel_n.ensure((size_t)n_images * g.nlevels))) return rc;
     if (h->qt_global && (rc = h->d_qt_ws.ensure((size_t)n_images * g.nlevels * quadtree_global_workspace_stride(h->qt)))) return rc;
+    if (h->qt_global && (rc = h->d_label_wide.ensure((size_t)n_images * g.slots_per_image))) return rc;
     if ((rc = h->d_mono.ensure(std::max(n_images, 4)))) return rc;
     return MSORB_OK;
 }
@@ -586,7 +592,8 @@ int run_pipeline_groups(msorb_extractor* h, const LevelView& level0, int n_image
                                   sel_stride, h->scales, lap0, lap1, capacity, h->d_sel.p + (size_t)first * sel_stride,
                                   h->d_sel_count.p + first, h->d_mono.p + first, n, s, ng == 1 ? h->row_job : nullptr,
                                   fuse_qt ? &blur_job : nullptr, &blur_carried,
-                                  h->qt_global ? h->d_qt_ws.p + (size_t)first * nl * quadtree_global_workspace_stride(h->qt) : nullptr)))   // (groups run side by side: a slice each)
+                                  h->qt_global ? h->d_qt_ws.p + (size_t)first * nl * quadtree_global_workspace_stride(h->qt) : nullptr,   // (groups run side by side: a slice each)
+                                  h->qt_global ? h->d_label_wide.p + cslot : nullptr)))
             return rc;
         if (fuse_qt && !blur_carried) blur_now();   // (the selection ran a form that does not carry the blur: on this stream, before describe)
         mark(5, s);
@@ -666,7 +673,8 @@ int run_pipeline(msorb_extractor* h, const LevelView& level0, int n_images, int 
         // selection stays on the device: quadtree per (level, image), output layout per image
         const int qrc = launch_quadtree(h->qt, h->d_compact.p, h->d_img_base.p, h->d_level_count.p, h->d_label.p, h->d_sel_pt.p,
                                         h->d_sel_n.p, sel_stride, h->scales, lap0, lap1, capacity, h->d_sel.p, h->d_sel_count.p,
-                                        h->d_mono.p, n_images, s, h->row_job, nullptr, nullptr, h->qt_global ? h->d_qt_ws.p : nullptr);
+                                        h->d_mono.p, n_images, s, h->row_job, nullptr, nullptr, h->qt_global ? h->d_qt_ws.p : nullptr,
+                                        h->qt_global ? h->d_label_wide.p : nullptr);
         if (qrc) return qrc;
         mark(5);
         if (overlap_blur) HIPCHK(hipStreamWaitEvent(s, h->ev_blur, 0));

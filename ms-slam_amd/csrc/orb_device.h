@@ -52,10 +52,11 @@ int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_ba
                      uint16_t* label, int* sel_pt, int* sel_n, int sel_stride, const LevelScale& scales, int lap0,
                      int lap1, int capacity, SelRec* sel, int* sel_count, int* mono, int n_images, hipStream_t s,
                      const StereoRowJob* row_job = nullptr, const FrameBlurJob* blur_job = nullptr, bool* blur_carried = nullptr,
-                     char* global_ws = nullptr);   // global_ws: n_images * nlevels * quadtree_global_workspace_stride(lv) bytes -> the selection runs over a
-                                                   // workspace in global memory (quotas beyond a workgroup's LDS, quadtree_global_kernels.hip)
+                     char* global_ws = nullptr, uint32_t* global_label = nullptr);
+                     // global_ws: n_images * nlevels * quadtree_global_workspace_stride(lv) bytes, global_label: one word per candidate slot (as
+                     // `label`) -> the selection runs over a workspace in global memory (quotas beyond a workgroup's LDS, quadtree_global_kernels.hip)
 size_t quadtree_global_workspace_stride(const QtLevels& lv);
-void launch_quadtree_select_global(const QtLevels& lv, const Cand16* compact, const int* img_base, const int* level_count, uint16_t* label, int* sel_pt,
+void launch_quadtree_select_global(const QtLevels& lv, const Cand16* compact, const int* img_base, const int* level_count, uint32_t* label, int* sel_pt,
                                    int* sel_n, int sel_stride, int n_images, char* ws, hipStream_t s);
 size_t quadtree_lds_bytes(const QtLevels& lv);
 int launch_debug_sort(const uint32_t* h_keys, int n, int frame_form, uint32_t* h_nodes, uint32_t* h_keys_out, float* sort_us);   // msorb_debug_std_sort

@@ -61,9 +61,21 @@ QT_HD Int4 load_int4(QT_LDS const int* p) {   // p is 16-byte aligned
     return Int4{p[0], p[1], p[2], p[3]};
 #endif
 }
-constexpr int kLabelSettled = 0xFFFF;
-constexpr int kParityBit = 0x4000;
-constexpr int kSlotMask = 0x3FFF;
+// A candidate's label: the node it sits in — parity of the node's generation | the node's slot (or rank) — or "settled".  16 bits
+// in the LDS build (14-bit slots: 4 N + 16 <= 16384, more than any quota a workgroup's LDS holds; two labels share a register with the
+// response in the register-resident form); 32 bits in the global-workspace build (MSORB_QT_GLOBAL_WORKSPACE: quotas up to what the
+// 16-bit rank tables allow, 4 N + 16 <= 65535).
+#if defined(MSORB_QT_GLOBAL_WORKSPACE)
+typedef uint32_t Label;
+constexpr uint32_t kLabelSettled = 0xFFFFFFFFu;
+constexpr int kParityShift = 30;
+#else
+typedef uint16_t Label;
+constexpr uint32_t kLabelSettled = 0xFFFFu;
+constexpr int kParityShift = 14;
+#endif
+constexpr uint32_t kParityBit = 1u << kParityShift;
+constexpr uint32_t kSlotMask = kParityBit - 1u;
 
 // ---- libstdc++ std::sort restated for SortItem with compareNodes (ORBextractor.cc:538-553) -------------
 QT_HD bool sort_less(const SortItem& a, const SortItem& b) { return a.key < b.key; }
@@ -490,7 +502,7 @@ QT_HD int quadrant_of(const Pt& p, const NodeB& b) {  // DivideNode's assignment
 // Returns the number of kept candidates; out_pt[i] = candidate index of the i-th keypoint in the reference's
 // result order.  `label` is an n-entry scratch array (global memory on the device).
 template <int PC, class Ex>
-QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, int N, Workspace& w, int* out_pt,
+QT_HD int select(Ex& ex, const Pt* pts, int n, Label* label, int W, int H, int N, Workspace& w, int* out_pt,
                  int debug = 0) {
     if (n <= 0) return 0;
     const int tid = ex.tid(), nt = ex.nthreads();
@@ -508,7 +520,7 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
         const int p = tid + k * nt;
         const Pt t = pts[p < n ? p : 0];
         cxy[k] = (uint32_t)t.x | ((uint32_t)t.y << 16);
-        cls[k] = (uint32_t)kLabelSettled | ((uint32_t)t.score << 16);
+        cls[k] = (kLabelSettled & 0xFFFFu) | ((uint32_t)t.score << 16);
     }
     // Every thread of the workgroup makes the same sequence of body() calls (`valid` says whether the call carries a point), so
     // the bodies may use the wave-collective forms of the counters (Ex::add_runs / Ex::claim).
@@ -523,7 +535,7 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
 #endif
             Pt q;
             q.x = (uint16_t)(cxy[k] & 0xFFFFu); q.y = (uint16_t)(cxy[k] >> 16); q.score = (uint16_t)(cls[k] >> 16); q.pad = 0;
-            uint16_t lab = (uint16_t)(cls[k] & 0xFFFFu);
+            Label lab = (Label)(cls[k] & 0xFFFFu);   // (the register-resident form is 16-bit labels only: PC = 0 in the global-workspace build)
             body(p, valid, q, lab);
             cls[k] = (cls[k] & 0xFFFF0000u) | lab;
         }
@@ -533,7 +545,7 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
         constexpr int kBatch = kPassBatch;
         for (int b0 = PC * nt; b0 < n; b0 += kBatch * nt) {    // workgroup-uniform bounds
             Pt q[kBatch];
-            uint16_t l[kBatch], l0[kBatch];
+            Label l[kBatch], l0[kBatch];
 #pragma unroll
             for (int u = 0; u < kBatch; u++) {
                 const int p = b0 + u * nt + tid;
@@ -556,9 +568,9 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
     for (int i = tid; i < n_ini; i += nt) w.cnt[0][i] = 0;
     if (tid == 0) { sc[kScNres] = 0; sc[kScFinish] = 0; sc[kScCareful] = 0; sc[kScGenBase] = 0; }
     ex.sync();
-    for_points([&](int, bool valid, const Pt& q, uint16_t& lab) {
+    for_points([&](int, bool valid, const Pt& q, Label& lab) {
         const int c = (int)((float)q.x / hX);                      // vpIniNodes[kp.pt.x/hX]
-        if (valid) lab = (uint16_t)c;
+        if (valid) lab = (Label)c;
         ex.add_runs(w.cnt[0], valid ? c : -1);                     // (candidates arrive in cell order: a wave holds one or two columns)
     });
     ex.sync();
@@ -580,7 +592,7 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
         sc[kScSize] = size; sc[kScS0] = S;
     }
     ex.sync();
-    for_points([&](int p, bool valid, const Pt&, uint16_t& lab) {  // single-point columns are final (bNoMore, :590-594)
+    for_points([&](int p, bool valid, const Pt&, Label& lab) {  // single-point columns are final (bNoMore, :590-594)
         const int c = valid ? (int)lab : 0;
         const int t = w.rankof[0][c];          // 0xFFFF <=> exactly one point (the column holds this one)
         const bool settle = valid && t == 0xFFFF;
@@ -589,7 +601,7 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
             w.res_seq[r] = -1 - c; w.res_pt[r] = p;
             lab = kLabelSettled;
         } else if (valid) {
-            lab = (uint16_t)t;                 // labels name a node by its RANK in its generation's processing order
+            lab = (Label)t;                    // labels name a node by its RANK in its generation's processing order
         }
     });
     ex.sync();
@@ -648,14 +660,15 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
             for (int b0 = 0; b0 < n; b0 += kPassBatch * nt) {      // workgroup-uniform bounds: the counters are wave collectives
                 const int p0 = b0 + tid;
                 Pt q[kPassBatch];
-                int lab[kPassBatch], r[kPassBatch];
+                uint32_t lab[kPassBatch];
+                int r[kPassBatch];
                 bool act[kPassBatch];
 #pragma unroll
                 for (int u = 0; u < kPassBatch; u++) {
                     const int p = p0 + u * nt, pc = p < n ? p : b0;
                     q[u] = pts[pc];
                     lab[u] = label[pc];
-                    act[u] = p < n && (lab[u] >> 14) == par;   // settled (0xFFFF) has both top bits set
+                    act[u] = p < n && (int)(lab[u] >> kParityShift) == par;   // settled (all ones) has both top bits set
                 }
                 if (careful) {
 #pragma unroll
@@ -674,17 +687,17 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
                     // candidates arrive in cell order, so the lanes of a wave fall into a handful of nodes: one atomic per run
                     // of equal slots instead of 64 serialised ones on the same LDS address
                     ex.add_runs(cnt_np, act[u] ? slot : -1);
-                    if (act[u]) label[p0 + u * nt] = (uint16_t)((par ? kParityBit : 0) | slot);  // pass B needs neither the point nor the node again
+                    if (act[u]) label[p0 + u * nt] = (Label)((par ? kParityBit : 0u) | slot);  // pass B needs neither the point nor the node again
                 }
             }
         } else {
-        for_points([&](int, bool valid, const Pt& q, uint16_t& lab_) {
+        for_points([&](int, bool valid, const Pt& q, Label& lab_) {
             const int lab = lab_;
-            const bool act = valid && (lab >> 14) == par;   // settled (0xFFFF) has both top bits set
+            const bool act = valid && (int)((uint32_t)lab >> kParityShift) == par;   // settled (all ones) has both top bits set
             const int r = !act ? 0 : careful ? (int)rk_par[lab & kSlotMask] : (lab & kSlotMask);
             const int slot = 4 * r + quadrant_of_mid((uint32_t)q.x | ((uint32_t)q.y << 16), nb_par[r].mid);
             ex.add_runs(cnt_np, act ? slot : -1);
-            if (act) lab_ = (uint16_t)((par ? kParityBit : 0) | slot);
+            if (act) lab_ = (Label)((par ? kParityBit : 0u) | slot);
         });
         }
         ex.sync();
@@ -754,13 +767,14 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
         if (PC == 0) {
             for (int b0 = 0; b0 < n; b0 += kPassBatch * nt) {  // phased like pass A
                 const int p0 = b0 + tid;
-                int lab[kPassBatch], t[kPassBatch];
+                uint32_t lab[kPassBatch];
+                int t[kPassBatch];
                 bool act[kPassBatch];
 #pragma unroll
                 for (int u = 0; u < kPassBatch; u++) {
                     const int p = p0 + u * nt, pc = p < n ? p : b0;
                     lab[u] = label[pc];
-                    act[u] = p < n && (lab[u] >> 14) == par;   // settled (0xFFFF) has both top bits set
+                    act[u] = p < n && (int)(lab[u] >> kParityShift) == par;   // settled (all ones) has both top bits set
                 }
 #pragma unroll
                 for (int u = 0; u < kPassBatch; u++) {
@@ -779,16 +793,16 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
                         w.res_seq[k] = genbase + slot; w.res_pt[k] = p;
                         label[p] = kLabelSettled;
                     } else if (whole) {
-                        label[p] = (uint16_t)((par ? kParityBit : 0) | (slot >> 2));
+                        label[p] = (Label)((par ? kParityBit : 0u) | (slot >> 2));
                     } else if (act[u]) {
-                        label[p] = (uint16_t)((np ? kParityBit : 0) | t[u]);
+                        label[p] = (Label)((np ? kParityBit : 0u) | t[u]);
                     }
                 }
             }
         } else {
-        for_points([&](int p, bool valid, const Pt&, uint16_t& lab_) {
+        for_points([&](int p, bool valid, const Pt&, Label& lab_) {
             const int lab = lab_;
-            const bool act = valid && (lab >> 14) == par;   // settled (0xFFFF) has both top bits set
+            const bool act = valid && (int)((uint32_t)lab >> kParityShift) == par;   // settled (all ones) has both top bits set
             const int slot = lab & kSlotMask;
             const bool whole = act && (slot >> 2) >= nsplit;             // stays whole
             const int t = act && !whole ? (int)rk_np[slot] : 0;
@@ -798,9 +812,9 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
                 w.res_seq[k] = genbase + slot; w.res_pt[k] = p;
                 lab_ = kLabelSettled;
             } else if (whole) {
-                lab_ = (uint16_t)((par ? kParityBit : 0) | (slot >> 2));
+                lab_ = (Label)((par ? kParityBit : 0u) | (slot >> 2));
             } else if (act) {
-                lab_ = (uint16_t)((np ? kParityBit : 0) | t);
+                lab_ = (Label)((np ? kParityBit : 0u) | t);
             }
         });
         }
@@ -815,7 +829,7 @@ QT_HD int select(Ex& ex, const Pt* pts, int n, uint16_t* label, int W, int H, in
             for (int i = tid; i < S; i += nt) cnt_par[i] = 0;   // re-used as best-point keys, by rank
             for (int i = tid; i < Sn; i += nt) cnt_np[i] = 0;
             ex.sync();
-            for_points([&](int p, bool valid, const Pt& q, uint16_t& lab_) {  // first strictly greater response wins (:757-776)
+            for_points([&](int p, bool valid, const Pt& q, Label& lab_) {  // first strictly greater response wins (:757-776)
                 const int lab = lab_;
                 if (!valid || lab == kLabelSettled) return;
                 const int lp = (lab & kParityBit) ? 1 : 0;

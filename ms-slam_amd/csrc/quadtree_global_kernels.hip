@@ -4,7 +4,8 @@
 // pointers, its workspace a slice of a global-memory buffer per (image, level) instance.  Every access of the workspace is a
 // global load / store / atomic (L2-resident: 200 KB per instance) instead of a ds_* instruction — several times slower per
 // generation than the LDS form, and still on the device: rounds 1-5 handed such quotas to the host twin (orb_host.cc), a CPU
-// stage in the middle of the product path.  Same results by construction: one source, two address spaces.
+// stage in the middle of the product path.  Same results by construction: one source, two address spaces (and 32-bit candidate
+// labels, qt::Label, where the LDS build packs 16: their 14-bit node slots end at a level quota of 4 092).
 #define MSORB_QT_GLOBAL_WORKSPACE 1
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,10 +17,11 @@
 namespace msorb {
 
 constexpr int kQtGlobalThreads = 256;
-constexpr int kQtGlobalPC = 8;   // candidates per thread kept in registers across the point passes
+constexpr int kQtGlobalPC = 0;   // no register-resident candidates: that form packs a 16-bit label beside the response; here labels are 32 bits
+                                 // (qt::Label: node slots up to 4 N + 16 <= 65535, a level quota of 16 379) and live in global memory
 
 __global__ __launch_bounds__(kQtGlobalThreads) void quadtree_select_global_kernel(QtLevels lv, const Cand16* __restrict__ compact, const int* __restrict__ img_base,
-                                                                                 const int* __restrict__ level_count, uint16_t* __restrict__ label,
+                                                                                 const int* __restrict__ level_count, qt::Label* __restrict__ label,
                                                                                  int* __restrict__ sel_pt, int* __restrict__ sel_n, int sel_stride, int ws_N,
                                                                                  int ws_nini, char* __restrict__ ws, size_t ws_stride) {
     const int level = blockIdx.y, img = blockIdx.x;
@@ -45,7 +47,7 @@ size_t quadtree_global_workspace_stride(const QtLevels& lv) {
     return (qt::workspace_bytes(maxN, max_ini) + 255) & ~(size_t)255;
 }
 
-void launch_quadtree_select_global(const QtLevels& lv, const Cand16* compact, const int* img_base, const int* level_count, uint16_t* label, int* sel_pt,
+void launch_quadtree_select_global(const QtLevels& lv, const Cand16* compact, const int* img_base, const int* level_count, uint32_t* label, int* sel_pt,
                                    int* sel_n, int sel_stride, int n_images, char* ws, hipStream_t s) {
     int maxN = 1, max_ini = 1;
     for (int l = 0; l < lv.nlevels; l++) { maxN = max(maxN, lv.quota[l]); max_ini = max(max_ini, lv.n_ini[l]); }

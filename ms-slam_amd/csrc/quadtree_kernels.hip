@@ -399,7 +399,7 @@ __global__ __launch_bounds__(1024) void quadtree_layout_frame_kernel(QtLevels lv
 int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_base, const int* level_count,
                      uint16_t* label, int* sel_pt, int* sel_n, int sel_stride, const LevelScale& scales, int lap0,
                      int lap1, int capacity, SelRec* sel, int* sel_count, int* mono, int n_images, hipStream_t s,
-                     const StereoRowJob* row_job, const FrameBlurJob* blur_job, bool* blur_carried, char* global_ws) {
+                     const StereoRowJob* row_job, const FrameBlurJob* blur_job, bool* blur_carried, char* global_ws, uint32_t* global_label) {
     if (blur_carried) *blur_carried = false;
     int maxN = 1, max_ini = 1;
     for (int l = 0; l < lv.nlevels; l++) { maxN = max(maxN, lv.quota[l]); max_ini = max(max_ini, lv.n_ini[l]); }
@@ -441,8 +441,8 @@ int launch_quadtree(const QtLevels& lv, const Cand16* compact, const int* img_ba
     };
     int path_cap = 0;
     size_t lds_paths = 0;
-    if (global_ws) {   // the workspace of these quotas does not fit a workgroup's LDS: the selection over global memory
-        launch_quadtree_select_global(lv, compact, img_base, level_count, label, sel_pt, sel_n, sel_stride, n_images, global_ws, s);
+    if (global_ws && global_label) {   // the workspace of these quotas does not fit a workgroup's LDS: the selection over global memory
+        launch_quadtree_select_global(lv, compact, img_base, level_count, global_label, sel_pt, sel_n, sel_stride, n_images, global_ws, s);
     } else if (qt_threads == 256) {
         const void* fn = reinterpret_cast<const void*>(quadtree_select_batch_kernel<kQtPointsPerThreadBatch>);
         // batches: tables of four generations keep three workgroups on a CU (workspace 39.7 KB + 11.7 KB at the KITTI quota; five

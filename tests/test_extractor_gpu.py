@@ -285,12 +285,13 @@ def test_saturated_single_cell(msorb_mod, oracle):
         ex.close()
 
 
-@pytest.mark.parametrize("nfeat,nlev,kind", [(10000, 8, "noise"), (10000, 8, "scene"), (12000, 8, "noise"), (6000, 2, "noise")])
+@pytest.mark.parametrize("nfeat,nlev,kind", [(10000, 8, "noise"), (10000, 8, "scene"), (12000, 8, "noise"), (6000, 2, "noise"), (11000, 1, "noise")])
 def test_quotas_beyond_a_workgroups_lds_stay_on_the_device(msorb_mod, oracle, nfeat, nlev, kind):
     """Level quotas above ~1 800 keypoints (the monocular initialisation extractor of Tracking.cc:601 asks for 5 * nFeatures = 10 000):
     the selection's workspace does not fit 160 KB of LDS; the SAME selection code runs over a workspace in global memory
     (quadtree_global_kernels.hip) — on the device, in the full pipeline (per frame, batches, pairs), where rounds 1-5 handed these
-    quotas to the host twin."""
+    quotas to the host twin.  (11000 features on ONE level: 44 016 node slots — past the 14 bits of the LDS build's 16-bit labels; the
+    global build's labels are 32 bits.)"""
     import torch
     cfg = synth.KITTI
     rng = np.random.Generator(np.random.PCG64(nfeat + nlev))
