@@ -173,3 +173,37 @@ def test_a17_entries_reject_bad_arguments(msorb_mod, two_keyframes):
         assert e.value.code == msorb_mod.E_INVALID
     finally:
         f1.close()
+
+
+def test_monocular_initialisation_at_the_initialisation_extractors_size(msorb_mod, oracle):
+    """Tracking::MonocularInitialization at the size the reference runs it: mpIniORBextractor = ORBextractor(5 * nFeatures, ...)
+    (Tracking.cc:601: 10 000 features for a 2 000-feature configuration — a level quota beyond a workgroup's LDS, selected over the
+    global-memory workspace), then ORBmatcher(0.9, true).SearchForInitialization(mInitialFrame, mCurrentFrame, mvbPrevMatched,
+    mvIniMatches, 100) (Tracking.cc:2417-2440).  Extraction and matching against the oracle, two rounds of the search."""
+    from msorb import synth
+    cfg = synth.KITTI
+    a = synth.image(77, cfg["rows"], cfg["cols"])
+    b = np.roll(a, (2, 9), (0, 1))                                   # the next frame: the scene moved by (9, 2) pixels
+    ex = msorb_mod.ORBextractor(5 * cfg["nfeatures"], cfg["scale"], cfg["nlevels"], cfg["ini_th"], cfg["min_th"])
+    ref = oracle.OracleExtractor(5 * cfg["nfeatures"], cfg["scale"], cfg["nlevels"], cfg["ini_th"], cfg["min_th"])
+    try:
+        (_, k1, d1), (_, k2, d2) = ex(a), ex(b)
+        for (k, d), im in (((k1, d1), a), ((k2, d2), b)):
+            _, rk, rd = ref(im)
+            assert len(k) > 8000 and np.array_equal(k.view(np.uint8), rk.view(np.uint8)) and np.array_equal(d, rd)
+        scale = np.asarray(ex.GetScaleFactors(), np.float32)
+    finally:
+        ex.close()
+    bounds = (0.0, float(cfg["cols"]), 0.0, float(cfg["rows"]))
+    f1, f2 = msorb_mod.Frame(k1, d1, None, bounds, scale), msorb_mod.Frame(k2, d2, None, bounds, scale)
+    r1, r2 = oracle.OracleFrame(k1, d1, None, bounds, scale), oracle.OracleFrame(k2, d2, None, bounds, scale)
+    try:
+        prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)      # mvbPrevMatched = the initial frame's keypoint positions
+        got_prev, want_prev = prev.copy(), prev.copy()
+        for _ in range(2):
+            got, nm = msorb_mod.search_for_initialization(f1, f2, got_prev, 100, 0.9, True)
+            want, wn = oracle.search_for_initialization(r1, r2, want_prev, 100, 0.9, True)
+            assert nm == wn and np.array_equal(got, want) and np.array_equal(got_prev.view(np.uint32), want_prev.view(np.uint32))
+        assert nm > 500                                                  # (Tracking.cc:2426 wants 100 to go on)
+    finally:
+        f1.close(); f2.close()
