@@ -90,7 +90,7 @@ struct msorb_frame {
     std::vector<float> u_right, scale;
     std::vector<int> cell_begin, cell_idx;
     msorb::DBuf<msorb::KpLite> d_kp, d_gate;   // d_gate: msorb_fuse_search_gated's per-call gate keypoints
-    msorb::DBuf<uint8_t> d_desc, d_occ, d_qdesc, d_stage;
+    msorb::DBuf<uint8_t> d_desc, d_occ, d_qdesc, d_stage, d_win;   // d_win: queries | descriptors | occupancy of a host-fed window search, one upload
     msorb::DBuf<int> d_cell_begin, d_cell_idx, d_n;
     msorb::DBuf<int> d_init_cnt, d_init_beg;   // msorb_search_for_initialization: candidate counts / list offsets / lists
     msorb::DBuf<int2> d_init_list;
@@ -137,10 +137,19 @@ int run_window_search(msorb_frame* f, int M, const WinQuery* q, const uint8_t* f
     if ((rc = f->d_q.ensure(M)) || (!d_qdesc && (rc = f->d_qdesc.ensure((size_t)M * 32))) || (rc = f->d_topk.ensure(M)) ||
         (rc = f->d_occ.ensure(f->N)))
         return rc;
+    // host queries + host descriptors (the class paths: ORBmatcher::SearchByProjection with unchanged callers): queries, descriptors
+    // and the occupancy snapshot are staged side by side and go up as ONE copy into one device block (three copy launches before:
+    // each costs the host ~6 us to issue and the chain ~3 us)
+    const bool one_block = q && qdesc && !d_qdesc;
     if (!d_qdesc) d_qdesc = f->d_qdesc.p;
     hipStream_t s = f->stream;
     const size_t qb = q ? (size_t)M * sizeof(WinQuery) : 0, db = qdesc ? (size_t)M * 32 : 0;
-    if ((rc = f->h_in.ensure(qb + db + (size_t)f->N + 64)) || (rc = f->h_topk.ensure(M))) return rc;
+    const size_t qb16 = (qb + 15) & ~(size_t)15;
+    if ((rc = f->h_in.ensure(qb16 + db + (size_t)f->N + 64)) || (rc = f->h_topk.ensure(M))) return rc;
+    if (one_block && (rc = f->d_win.ensure(qb16 + db + (size_t)f->N + 64))) return rc;
+    const WinQuery* const q_dev = one_block ? reinterpret_cast<const WinQuery*>(f->d_win.p) : f->d_q.p;
+    if (one_block) d_qdesc = f->d_win.p + qb16;
+    uint8_t* const occ_dev = one_block ? f->d_win.p + qb16 + db : f->d_occ.p;
     std::vector<uint8_t> flags_own;
     if (!flags) {
         if (!q) return MSORB_E_INVALID;
@@ -158,25 +167,33 @@ int run_window_search(msorb_frame* f, int M, const WinQuery* q, const uint8_t* f
             if (nv) lanes = window_lanes_for((float)(sum / nv), f->gridWInv, f->gridHInv);
         }
     }
-    if (q) {
+    if (one_block) {
         std::memcpy(f->h_in.p, q, qb);
-        HIPCHK(small_copy(f->d_q.p, f->h_in.p, qb, hipMemcpyHostToDevice, s));
+        std::memcpy(f->h_in.p + qb16, qdesc, db);
+    } else {
+        if (q) {
+            std::memcpy(f->h_in.p, q, qb);
+            HIPCHK(small_copy(f->d_q.p, f->h_in.p, qb, hipMemcpyHostToDevice, s));
+        }
+        if (qdesc) {
+            std::memcpy(f->h_in.p + qb16, qdesc, db);
+            HIPCHK(small_copy(f->d_qdesc.p, f->h_in.p + qb16, db, hipMemcpyHostToDevice, s));
+        }
     }
-    if (qdesc) {
-        std::memcpy(f->h_in.p + qb, qdesc, db);
-        HIPCHK(small_copy(f->d_qdesc.p, f->h_in.p + qb, db, hipMemcpyHostToDevice, s));
-    }
-    uint8_t* const h_occ = f->h_in.p + qb + db;
+    uint8_t* const h_occ = f->h_in.p + qb16 + db;
     TopK* const topk = f->h_topk.p;
     std::vector<int8_t> diff(f->N, 0);  // occupancy now vs snapshot: +1 claimed since, -1 freed since
     int q0 = 0, n_rounds = 0;
     while (q0 < M) {
         if (!(ready && n_rounds == 0)) {
-            if (f->N) {
-                std::memcpy(h_occ, occ.data(), f->N);  // the previous round's copy has completed (stream synchronised below)
-                HIPCHK(small_copy(f->d_occ.p, h_occ, f->N, hipMemcpyHostToDevice, s));
-            }
-            launch_window_topk(f->view(), f->d_q.p, d_qdesc, q0, M, f->d_topk.p, s, 1, 0, 0, nullptr, lanes);
+            if (f->N) std::memcpy(h_occ, occ.data(), f->N);  // the previous round's copy has completed (stream synchronised below)
+            if (one_block && n_rounds == 0)
+                HIPCHK(small_copy(f->d_win.p, f->h_in.p, qb16 + db + (size_t)f->N, hipMemcpyHostToDevice, s));   // queries | descriptors | occupancy
+            else if (f->N)
+                HIPCHK(small_copy(occ_dev, h_occ, f->N, hipMemcpyHostToDevice, s));
+            FrameView view = f->view();
+            view.occupied = occ_dev;
+            launch_window_topk(view, q_dev, d_qdesc, q0, M, f->d_topk.p, s, 1, 0, 0, nullptr, lanes);
             HIPCHK(small_copy(topk + q0, f->d_topk.p + q0, (size_t)(M - q0) * sizeof(TopK), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
         }

@@ -49,7 +49,7 @@ void msorb_frame_destroy(msorb_frame* f) {
     // already shut down nothing can be freed any more — and nothing needs to be
     if (hipSetDevice(f->device) != hipSuccess) { delete f; return; }
     if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
-    f->d_kp.release(); f->d_gate.release(); f->d_desc.release(); f->d_occ.release(); f->d_qdesc.release(); f->d_cell_begin.release();
+    f->d_kp.release(); f->d_gate.release(); f->d_win.release(); f->d_desc.release(); f->d_occ.release(); f->d_qdesc.release(); f->d_cell_begin.release();
     f->d_cell_idx.release(); f->d_q.release(); f->d_topk.release(); f->h_in.release(); f->h_topk.release(); f->d_n.release(); f->d_stage.release(); f->d_init_cnt.release(); f->d_init_beg.release(); f->d_init_list.release();
     frame_track_release(f);
     delete f;
