@@ -89,7 +89,7 @@ struct msorb_frame {
     std::vector<msorb_keypoint> kps;
     std::vector<float> u_right, scale;
     std::vector<int> cell_begin, cell_idx;
-    msorb::DBuf<msorb::KpLite> d_kp, d_gate;   // d_gate: msorb_fuse_search_gated's per-call gate keypoints
+    msorb::DBuf<msorb::KpLite> d_kp;
     msorb::DBuf<uint8_t> d_desc, d_occ, d_qdesc, d_stage, d_win;   // d_win: queries | descriptors | occupancy of a host-fed window search, one upload
     msorb::DBuf<int> d_cell_begin, d_cell_idx, d_n;
     msorb::DBuf<int> d_init_cnt, d_init_beg;   // msorb_search_for_initialization: candidate counts / list offsets / lists

@@ -49,7 +49,7 @@ void msorb_frame_destroy(msorb_frame* f) {
     // already shut down nothing can be freed any more — and nothing needs to be
     if (hipSetDevice(f->device) != hipSuccess) { delete f; return; }
     if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
-    f->d_kp.release(); f->d_gate.release(); f->d_win.release(); f->d_desc.release(); f->d_occ.release(); f->d_qdesc.release(); f->d_cell_begin.release();
+    f->d_kp.release(); f->d_win.release(); f->d_desc.release(); f->d_occ.release(); f->d_qdesc.release(); f->d_cell_begin.release();
     f->d_cell_idx.release(); f->d_q.release(); f->d_topk.release(); f->h_in.release(); f->h_topk.release(); f->d_n.release(); f->d_stage.release(); f->d_init_cnt.release(); f->d_init_beg.release(); f->d_init_list.release();
     frame_track_release(f);
     delete f;
@@ -84,7 +84,7 @@ int msorb_frame_set(msorb_frame* f, const msorb_keypoint* kps, int n, const uint
         std::memcpy(f->h_in.p, kps, kb);
         std::memcpy(f->h_in.p + o_desc, desc, db);
         if (u_right) std::memcpy(f->h_in.p + o_ur, u_right, ub);
-        HIPCHK(hipMemcpyAsync(f->d_stage.p, f->h_in.p, o_ur + ub, hipMemcpyHostToDevice, s));
+        HIPCHK(small_copy(f->d_stage.p, f->h_in.p, o_ur + ub, hipMemcpyHostToDevice, s));   // (the copy kernel: a pinned block of ~130 KB is up before an SDMA copy has started)
     }
     if ((rc = enqueue_frame_from_device(f, s, reinterpret_cast<const msorb_keypoint*>(f->d_stage.p), f->d_stage.p + o_desc,
                                         u_right ? reinterpret_cast<const float*>(f->d_stage.p + o_ur) : nullptr, nullptr, n, n, min_x,
@@ -576,6 +576,36 @@ int msorb_search_by_projection_sim3(msorb_frame* f, int n, const uint8_t* valid,
                             max_dist, nmatches, true);
 }
 
+namespace {
+// One host-fed window search without claims (Fuse, SearchBySim3, the loop / Sim3 projection forms, msorb_window_top4): queries,
+// descriptors, the occupancy / skip flags (null = none set) and an optional gate array are staged side by side in the frame's pinned
+// block and go up as ONE copy-kernel launch; the lists come back the same way into f->h_topk.  (Three to four hipMemcpyAsync from
+// pageable vectors before: each one staged and synchronised by the runtime.)
+int window_search_once(msorb_frame* f, int n, const WinQuery* q, const uint8_t* qdesc, const uint8_t* occ, const KpLite* gate,
+                       const float* inv_level_sigma2, int n_levels) {
+    int rc;
+    const size_t qb = ((size_t)n * sizeof(WinQuery) + 15) & ~(size_t)15, db = (size_t)n * 32, ob = ((size_t)std::max(f->N, 1) + 15) & ~(size_t)15,
+                 gb = gate ? (size_t)f->N * sizeof(KpLite) : 0, total = qb + db + ob + gb;
+    if ((rc = f->h_in.ensure(total + 64)) || (rc = f->d_win.ensure(total + 64)) || (rc = f->d_topk.ensure(n)) || (rc = f->h_topk.ensure(n))) return rc;
+    uint8_t* h = f->h_in.p;
+    std::memcpy(h, q, (size_t)n * sizeof(WinQuery));
+    std::memcpy(h + qb, qdesc, db);
+    if (occ && f->N) std::memcpy(h + qb + db, occ, (size_t)f->N); else std::memset(h + qb + db, 0, ob);
+    if (gate) std::memcpy(h + qb + db + ob, gate, gb);
+    hipStream_t s = f->stream;
+    HIPCHK(small_copy(f->d_win.p, h, total, hipMemcpyHostToDevice, s));
+    FrameView view = f->view();
+    view.occupied = f->d_win.p + qb + db;
+    if (gate) view.gate_kp = reinterpret_cast<const KpLite*>(f->d_win.p + qb + db + ob);
+    if (inv_level_sigma2) for (int l = 0; l < n_levels; l++) view.inv_sigma2[l] = inv_level_sigma2[l];
+    launch_window_topk(view, reinterpret_cast<const WinQuery*>(f->d_win.p), f->d_win.p + qb, 0, n, f->d_topk.p, s);
+    HIPCHK(hipGetLastError());
+    HIPCHK(small_copy(f->h_topk.p, f->d_topk.p, (size_t)n * sizeof(TopK), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return MSORB_OK;
+}
+}  // namespace
+
 int msorb_window_top4(msorb_frame* f, int n_queries, const float* x, const float* y, const float* r, const float* ur,
                       const int* min_level, const int* max_level, const uint8_t* skip_occupied, const uint8_t* query_desc,
                       const uint8_t* occupied, int* best_idx, int* best_dist) {
@@ -593,21 +623,9 @@ int msorb_window_top4(msorb_frame* f, int n_queries, const float* x, const float
         w.flags = kQValid | ((skip_occupied && skip_occupied[i]) ? kQSkipOccupied : 0);
         q[i] = w;
     }
-    int rc;
-    if ((rc = f->d_q.ensure(n_queries)) || (rc = f->d_qdesc.ensure((size_t)n_queries * 32)) ||
-        (rc = f->d_topk.ensure(n_queries)) || (rc = f->d_occ.ensure(f->N)))
-        return rc;
-    hipStream_t s = f->stream;
-    std::vector<TopK> topk(n_queries);
-    HIPCHK(hipMemcpyAsync(f->d_q.p, q.data(), (size_t)n_queries * sizeof(WinQuery), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(f->d_qdesc.p, query_desc, (size_t)n_queries * 32, hipMemcpyHostToDevice, s));
-    if (f->N) {
-        if (occupied) HIPCHK(hipMemcpyAsync(f->d_occ.p, occupied, f->N, hipMemcpyHostToDevice, s));
-        else HIPCHK(hipMemsetAsync(f->d_occ.p, 0, f->N, s));
-    }
-    launch_window_topk(f->view(), f->d_q.p, f->d_qdesc.p, 0, n_queries, f->d_topk.p, s);
-    HIPCHK(hipMemcpyAsync(topk.data(), f->d_topk.p, (size_t)n_queries * sizeof(TopK), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    const int rc = window_search_once(f, n_queries, q.data(), query_desc, occupied, nullptr, nullptr, 0);
+    if (rc) return rc;
+    const TopK* const topk = f->h_topk.p;
     for (int i = 0; i < n_queries; i++)
         for (int k = 0; k < 4; k++) { best_idx[4 * i + k] = topk[i].idx[k]; best_dist[4 * i + k] = topk[i].dist[k]; }
     return MSORB_OK;
@@ -636,28 +654,14 @@ int fuse_search_impl(msorb_frame* f, const msorb_keypoint* gate_kps, const float
         }
         q[i] = w;
     }
-    int rc;
-    if ((rc = f->d_q.ensure(n)) || (rc = f->d_qdesc.ensure((size_t)n * 32)) || (rc = f->d_topk.ensure(n)) ||
-        (rc = f->d_occ.ensure(std::max(f->N, 1))))
-        return rc;
-    hipStream_t s = f->stream;
-    std::vector<TopK> topk(n);
     std::vector<KpLite> gate;
-    FrameView view = f->view();
     if (gate_kps && f->N) {
         gate.resize(f->N);
         for (int i = 0; i < f->N; i++) gate[i] = KpLite{gate_kps[i].x, gate_kps[i].y, gate_uright ? gate_uright[i] : -1.0f, gate_kps[i].octave};
-        if ((rc = f->d_gate.ensure(f->N))) return rc;
-        HIPCHK(hipMemcpyAsync(f->d_gate.p, gate.data(), (size_t)f->N * sizeof(KpLite), hipMemcpyHostToDevice, s));
-        view.gate_kp = f->d_gate.p;
     }
-    HIPCHK(hipMemcpyAsync(f->d_q.p, q.data(), (size_t)n * sizeof(WinQuery), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(f->d_qdesc.p, mp_desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
-    for (int l = 0; l < n_levels; l++) view.inv_sigma2[l] = inv_level_sigma2[l];
-    launch_window_topk(view, f->d_q.p, f->d_qdesc.p, 0, n, f->d_topk.p, s);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(topk.data(), f->d_topk.p, (size_t)n * sizeof(TopK), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    const int rc = window_search_once(f, n, q.data(), mp_desc, nullptr, gate.empty() ? nullptr : gate.data(), inv_level_sigma2, n_levels);
+    if (rc) return rc;
+    const TopK* const topk = f->h_topk.p;
     for (int i = 0; i < n; i++) { best_idx[i] = topk[i].idx[0]; best_dist[i] = topk[i].dist[0]; }
     return MSORB_OK;
 }
@@ -699,18 +703,8 @@ int plain_window_best(msorb_frame* f, int n, const uint8_t* valid, const float* 
         }
         q[i] = w;
     }
-    int rc;
-    if ((rc = f->d_q.ensure(n)) || (rc = f->d_qdesc.ensure((size_t)n * 32)) || (rc = f->d_topk.ensure(n)) ||
-        (rc = f->d_occ.ensure(std::max(f->N, 1))) || (rc = f->h_topk.ensure(n)))
-        return rc;
-    hipStream_t s = f->stream;
-    if (train_skip && f->N) HIPCHK(hipMemcpyAsync(f->d_occ.p, train_skip, (size_t)f->N, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(f->d_q.p, q.data(), (size_t)n * sizeof(WinQuery), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(f->d_qdesc.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
-    launch_window_topk(f->view(), f->d_q.p, f->d_qdesc.p, 0, n, f->d_topk.p, s);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(f->h_topk.p, f->d_topk.p, (size_t)n * sizeof(TopK), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    const int rc = window_search_once(f, n, q.data(), desc, train_skip, nullptr, nullptr, 0);
+    if (rc) return rc;
     for (int i = 0; i < n; i++)
         if (f->h_topk.p[i].idx[0] >= 0) { best_idx[i] = f->h_topk.p[i].idx[0]; best_dist[i] = f->h_topk.p[i].dist[0]; }
     return MSORB_OK;
