@@ -1149,7 +1149,7 @@ int msorb_stereo_matches(msorb_extractor* left, msorb_extractor* right, const ms
     }
     float* d_ur = reinterpret_cast<float*>(scr.d_out.p);
     int* d_sad = reinterpret_cast<int*>(scr.d_out.p) + 2 * nL;
-    hipError_t e = hipMemcpyAsync(scr.d_in.p, scr.h_in.p, in_bytes, hipMemcpyHostToDevice, s);
+    hipError_t e = small_copy(scr.d_in.p, scr.h_in.p, in_bytes, hipMemcpyHostToDevice, s);   // (pinned blocks: the copy kernel, as for the frames)
     if (e == hipSuccess) e = hipMemsetAsync(d_sad + nL, 0, sizeof(int), s);
     if (e == hipSuccess) {
         StereoArgs a{};
@@ -1166,7 +1166,7 @@ int msorb_stereo_matches(msorb_extractor* left, msorb_extractor* right, const ms
         a.mb = mb; a.mbf = mbf;
         a.u_right = d_ur; a.depth = d_ur + nL; a.sad = d_sad; a.n_oob = d_sad + nL;
         launch_stereo_match(a, s);
-        e = hipMemcpyAsync(scr.h_out.p, scr.d_out.p, out_bytes, hipMemcpyDeviceToHost, s);
+        e = small_copy(scr.h_out.p, scr.d_out.p, out_bytes, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
     }
     if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return MSORB_E_HIP; }
