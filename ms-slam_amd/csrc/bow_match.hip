@@ -30,6 +30,9 @@
 
 namespace msorb {
 void set_last_error(const std::string& s);
+// pinned host <-> device on a stream by the copy kernel (orb_kernels.hip; hipMemcpyAsync for unaligned pointers / MSORB_FRAME_COPIES=sdma):
+// a block of 100-300 KB is across before an SDMA copy has started
+hipError_t small_copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
 }
 using msorb::set_last_error;
 using msorb::kHistoLength;
@@ -545,7 +548,7 @@ int search_by_bow_impl(int device, msorb_bow_pair* pairs, int n_pairs, int th_lo
     }
     hipStream_t s = scr.s;
     char* d = scr.d;
-    e = hipMemcpyAsync(d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
+    e = msorb::small_copy(d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d + o_m, 0xFF, tot1 * 4, s);
     if (e == hipSuccess && elapsed_ms) e = hipEventRecord(scr.e0, s);
     if (e == hipSuccess) {
@@ -556,7 +559,7 @@ int search_by_bow_impl(int device, msorb_bow_pair* pairs, int n_pairs, int th_lo
         e = hipGetLastError();
     }
     if (e == hipSuccess && elapsed_ms) e = hipEventRecord(scr.e1, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(scr.h + o_m, d + o_m, (best1 ? o_b - o_m : 0) + tot1 * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = msorb::small_copy(scr.h + o_m, d + o_m, (best1 ? o_b - o_m : 0) + tot1 * 4, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess && elapsed_ms) e = hipEventElapsedTime(elapsed_ms, scr.e0, scr.e1);
     if (e != hipSuccess) return hip_fail(scr, "search_by_bow", e);
@@ -737,14 +740,14 @@ extern "C" int msorb_search_for_triangulation_cb(int device, msorb_bow_pair* pai
     }
     hipStream_t s = scr.s;
     char* d = scr.d;
-    e = hipMemcpyAsync(d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
+    e = msorb::small_copy(d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(node_candidates_kernel<false>, dim3((unsigned)n_items), dim3(64), 0, s, (const BowItem*)(d + o_it), (const uint4*)(d + o_d1),
                            (const uint4*)(d + o_d2), (const uint8_t*)(d + o_v1), (const uint8_t*)(d + o_a2), (const int*)(d + o_f1),
                            (const int*)(d + o_f2), th_low, (int*)(d + o_cnt), (const int*)nullptr, (int4*)nullptr);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(scr.h + o_cnt, d + o_cnt, n_items * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = msorb::small_copy(scr.h + o_cnt, d + o_cnt, n_items * 4, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return hip_fail(scr, "search_for_triangulation_cb", e);
     const int* cnt = (const int*)(scr.h + o_cnt);
@@ -756,14 +759,14 @@ extern "C" int msorb_search_for_triangulation_cb(int device, msorb_bow_pair* pai
         if (n_cand > (size_t)INT32_MAX / 16) { set_last_error("search_for_triangulation_cb: too many candidates"); return MSORB_E_CAPACITY; }
         e = lists.acquire(device, n_cand * sizeof(int4));
         if (e != hipSuccess) return hip_fail(lists, "search_for_triangulation_cb", e);
-        e = hipMemcpyAsync(d + o_beg, beg, n_items * 4, hipMemcpyHostToDevice, s);
+        e = msorb::small_copy(d + o_beg, beg, n_items * 4, hipMemcpyHostToDevice, s);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(node_candidates_kernel<true>, dim3((unsigned)n_items), dim3(64), 0, s, (const BowItem*)(d + o_it), (const uint4*)(d + o_d1),
                                (const uint4*)(d + o_d2), (const uint8_t*)(d + o_v1), (const uint8_t*)(d + o_a2), (const int*)(d + o_f1),
                                (const int*)(d + o_f2), th_low, (int*)nullptr, (const int*)(d + o_beg), (int4*)lists.d);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(lists.h, lists.d, n_cand * sizeof(int4), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = msorb::small_copy(lists.h, lists.d, n_cand * sizeof(int4), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return hip_fail(scr, "search_for_triangulation_cb", e);
         // ---- the replay: nodes ascending, a node's queries in list order (:1230-1358) ----
@@ -874,7 +877,7 @@ extern "C" int msorb_search_for_triangulation(int device, msorb_triangulation_pa
     }
     hipStream_t s = scr.s;
     char* d = scr.d;
-    e = hipMemcpyAsync(d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
+    e = msorb::small_copy(d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d + o_m, 0xFF, tot1 * 4, s);
     if (e == hipSuccess && elapsed_ms) e = hipEventRecord(scr.e0, s);
     if (e == hipSuccess) {
@@ -886,7 +889,7 @@ extern "C" int msorb_search_for_triangulation(int device, msorb_triangulation_pa
         e = hipGetLastError();
     }
     if (e == hipSuccess && elapsed_ms) e = hipEventRecord(scr.e1, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(scr.h + o_m, d + o_m, tot1 * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = msorb::small_copy(scr.h + o_m, d + o_m, tot1 * 4, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess && elapsed_ms) e = hipEventElapsedTime(elapsed_ms, scr.e0, scr.e1);
     if (e != hipSuccess) return hip_fail(scr, "search_for_triangulation", e);
@@ -1222,7 +1225,7 @@ extern "C" int msorb_search_by_bow_kf(msorb_kf_store* st, msorb_bow_kf_pair* pai
     }
     hipStream_t s = scr.s;
     char* d = scr.d;
-    e = hipMemcpyAsync(d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
+    e = msorb::small_copy(d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d + o_m, 0xFF, o_nm - o_m, s);   // match12 and match21 = -1
     if (e == hipSuccess && elapsed_ms) e = hipEventRecord(scr.e0, s);
     if (e == hipSuccess) {
@@ -1237,7 +1240,7 @@ extern "C" int msorb_search_by_bow_kf(msorb_kf_store* st, msorb_bow_kf_pair* pai
         e = hipGetLastError();
     }
     if (e == hipSuccess && elapsed_ms) e = hipEventRecord(scr.e1, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(scr.h + o_m, d + o_m, out_bytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = msorb::small_copy(scr.h + o_m, d + o_m, out_bytes, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess && elapsed_ms) e = hipEventElapsedTime(elapsed_ms, scr.e0, scr.e1);
     if (e != hipSuccess) return hip_fail(scr, "search_by_bow_kf", e);
@@ -1316,7 +1319,7 @@ extern "C" int msorb_search_for_triangulation_kf(msorb_kf_store* st, msorb_trian
     }
     hipStream_t s = scr.s;
     char* d = scr.d;
-    e = hipMemcpyAsync(d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
+    e = msorb::small_copy(d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d + o_m, 0xFF, tot1 * 4, s);
     if (e == hipSuccess && elapsed_ms) e = hipEventRecord(scr.e0, s);
     if (e == hipSuccess) {
@@ -1328,7 +1331,7 @@ extern "C" int msorb_search_for_triangulation_kf(msorb_kf_store* st, msorb_trian
         e = hipGetLastError();
     }
     if (e == hipSuccess && elapsed_ms) e = hipEventRecord(scr.e1, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(scr.h + o_m, d + o_m, out_bytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = msorb::small_copy(scr.h + o_m, d + o_m, out_bytes, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess && elapsed_ms) e = hipEventElapsedTime(elapsed_ms, scr.e0, scr.e1);
     if (e != hipSuccess) return hip_fail(scr, "search_for_triangulation_kf", e);
