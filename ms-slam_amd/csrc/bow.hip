@@ -29,6 +29,11 @@
 #include "lds_limit.h"
 
 namespace msorb {
+// pinned host <-> device on a stream by the copy kernel (orb_kernels.hip; hipMemcpyAsync for unaligned pointers / MSORB_FRAME_COPIES=sdma)
+hipError_t small_copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
+}
+
+namespace msorb {
 void set_last_error(const std::string& s);
 }
 using msorb::set_last_error;
@@ -629,7 +634,7 @@ int msorb_bow_transform(msorb_vocabulary* v, const uint8_t* descriptors, int n, 
     double* d_d = reinterpret_cast<double*>(db + o_val);
     hipStream_t s = v->s;
     std::memcpy(hp, descriptors, (size_t)n * 32);
-    HIPCHK(hipMemcpyAsync(db, hp, (size_t)n * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(msorb::small_copy(db, hp, (size_t)n * 32, hipMemcpyHostToDevice, s));
     int* d_bow_word = d_i;
     int* d_fv_node = d_i + stride;
     int* d_fv_feat = d_i + 2 * stride;
@@ -642,7 +647,7 @@ int msorb_bow_transform(msorb_vocabulary* v, const uint8_t* descriptors, int n, 
     if (rc) return rc;
     const bool feats = v->n_words > 0;
     const bool want_feats = feats && (feat_word || feat_node || feat_weight);
-    HIPCHK(hipMemcpyAsync(hp + o_int, db + o_int, (want_feats ? blk_bytes : o_fw) - o_int, hipMemcpyDeviceToHost, s));
+    HIPCHK(msorb::small_copy(hp + o_int, db + o_int, (want_feats ? blk_bytes : o_fw) - o_int, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     const int* hi = reinterpret_cast<const int*>(hp + o_int);

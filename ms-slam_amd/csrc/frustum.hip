@@ -15,6 +15,11 @@
 #include "frustum_device.h"
 
 namespace msorb {
+// pinned host <-> device on a stream by the copy kernel (orb_kernels.hip; hipMemcpyAsync for unaligned pointers / MSORB_FRAME_COPIES=sdma)
+hipError_t small_copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
+}
+
+namespace msorb {
 void set_last_error(const std::string& s);
 }
 using msorb::set_last_error;
@@ -115,13 +120,13 @@ extern "C" int msorb_is_in_frustum(int device, const msorb_frustum* f, float vie
         std::memcpy(h_f + 3 * N, normal, N * 12);
         std::memcpy(h_f + 6 * N, max_distance, N * 4);
         std::memcpy(h_f + 7 * N, min_distance, N * 4);
-        e = hipMemcpyAsync(scr.d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
+        e = msorb::small_copy(scr.d, scr.h, in_bytes, hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = hipEventRecord(scr.e0, s);
         if (e == hipSuccess)
             hipLaunchKernelGGL(frustum_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, *f, viewing_cos_limit, n, d_pos,
                                d_nrm, d_max, d_min, d_in, d_px, d_py, d_pxr, d_depth, d_level, d_vc);
         if (e == hipSuccess) e = hipEventRecord(scr.e1, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(scr.h + in_bytes, scr.d + in_bytes, out_bytes, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = msorb::small_copy(scr.h + in_bytes, scr.d + in_bytes, out_bytes, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess && elapsed_ms) e = hipEventElapsedTime(elapsed_ms, scr.e0, scr.e1);
