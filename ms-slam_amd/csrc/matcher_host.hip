@@ -587,6 +587,11 @@ int window_search_once(msorb_frame* f, int n, const WinQuery* q, const uint8_t* 
     const size_t qb = ((size_t)n * sizeof(WinQuery) + 15) & ~(size_t)15, db = (size_t)n * 32, ob = ((size_t)std::max(f->N, 1) + 15) & ~(size_t)15,
                  gb = gate ? (size_t)f->N * sizeof(KpLite) : 0, total = qb + db + ob + gb;
     if ((rc = f->h_in.ensure(total + 64)) || (rc = f->d_win.ensure(total + 64)) || (rc = f->d_topk.ensure(n)) || (rc = f->h_topk.ensure(n))) return rc;
+    if (f->N <= 0) {   // no train keypoints (also a handle that was never set, or whose set failed): every list is empty
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < kTopK; k++) { f->h_topk.p[i].idx[k] = -1; f->h_topk.p[i].dist[k] = 256; }
+        return MSORB_OK;
+    }
     uint8_t* h = f->h_in.p;
     std::memcpy(h, q, (size_t)n * sizeof(WinQuery));
     std::memcpy(h + qb, qdesc, db);
