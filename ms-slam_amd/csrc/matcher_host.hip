@@ -582,9 +582,9 @@ namespace {
 // block and go up as ONE copy-kernel launch; the lists come back the same way into f->h_topk.  (Three to four hipMemcpyAsync from
 // pageable vectors before: each one staged and synchronised by the runtime.)
 int window_search_once(msorb_frame* f, int n, const WinQuery* q, const uint8_t* qdesc, const uint8_t* occ, const KpLite* gate,
-                       const float* inv_level_sigma2, int n_levels) {
+                       const float* inv_level_sigma2, int n_levels, const uint8_t* qdesc_dev = nullptr) {   // qdesc_dev: the descriptors already lie on f's device
     int rc;
-    const size_t qb = ((size_t)n * sizeof(WinQuery) + 15) & ~(size_t)15, db = (size_t)n * 32, ob = ((size_t)std::max(f->N, 1) + 15) & ~(size_t)15,
+    const size_t qb = ((size_t)n * sizeof(WinQuery) + 15) & ~(size_t)15, db = qdesc_dev ? 0 : (size_t)n * 32, ob = ((size_t)std::max(f->N, 1) + 15) & ~(size_t)15,
                  gb = gate ? (size_t)f->N * sizeof(KpLite) : 0, total = qb + db + ob + gb;
     if ((rc = f->h_in.ensure(total + 64)) || (rc = f->d_win.ensure(total + 64)) || (rc = f->d_topk.ensure(n)) || (rc = f->h_topk.ensure(n))) return rc;
     if (f->N <= 0) {   // no train keypoints (also a handle that was never set, or whose set failed): every list is empty
@@ -594,7 +594,7 @@ int window_search_once(msorb_frame* f, int n, const WinQuery* q, const uint8_t* 
     }
     uint8_t* h = f->h_in.p;
     std::memcpy(h, q, (size_t)n * sizeof(WinQuery));
-    std::memcpy(h + qb, qdesc, db);
+    if (db) std::memcpy(h + qb, qdesc, db);
     if (occ && f->N) std::memcpy(h + qb + db, occ, (size_t)f->N); else std::memset(h + qb + db, 0, ob);
     if (gate) std::memcpy(h + qb + db + ob, gate, gb);
     hipStream_t s = f->stream;
@@ -603,7 +603,7 @@ int window_search_once(msorb_frame* f, int n, const WinQuery* q, const uint8_t* 
     view.occupied = f->d_win.p + qb + db;
     if (gate) view.gate_kp = reinterpret_cast<const KpLite*>(f->d_win.p + qb + db + ob);
     if (inv_level_sigma2) for (int l = 0; l < n_levels; l++) view.inv_sigma2[l] = inv_level_sigma2[l];
-    launch_window_topk(view, reinterpret_cast<const WinQuery*>(f->d_win.p), f->d_win.p + qb, 0, n, f->d_topk.p, s);
+    launch_window_topk(view, reinterpret_cast<const WinQuery*>(f->d_win.p), qdesc_dev ? qdesc_dev : f->d_win.p + qb, 0, n, f->d_topk.p, s);
     HIPCHK(hipGetLastError());
     HIPCHK(small_copy(f->h_topk.p, f->d_topk.p, (size_t)n * sizeof(TopK), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -769,30 +769,17 @@ int msorb_search_by_sim3(msorb_frame* kf1, msorb_frame* kf2, int n1, const uint8
     return MSORB_OK;
 }
 
-int msorb_search_for_initialization(msorb_frame* f1, msorb_frame* f2, float* prev_xy, int window_size, float nnratio,
-                                    int check_orientation, int* matches12, int* nmatches) {
-    if (!f1 || !f2 || !nmatches || (f1->N > 0 && (!prev_xy || !matches12))) return MSORB_E_INVALID;
-    *nmatches = 0;
-    const int N1 = f1->N, N2 = f2->N;
-    for (int i = 0; i < N1; i++) matches12[i] = -1;
-    if (N1 == 0) return MSORB_OK;
-    HIPCHK(hipSetDevice(f2->device));
-    std::vector<WinQuery> q(N1);
+namespace {
+// Every candidate of every window from query `from` on, with its distance, in the reference's scan order (window_list_kernel:
+// count, then fill) — the complete form of the search below, taken when a top-8 list cannot settle a query.
+int init_full_lists(msorb_frame* f1, msorb_frame* f2, std::vector<WinQuery> q, int from, std::vector<int>& cnt, std::vector<int>& beg,
+                    std::vector<int2>& list) {
+    const int N1 = (int)q.size();
+    for (int i = 0; i < from; i++) q[i].flags = 0;
     std::vector<uint8_t> qdesc((size_t)N1 * 32);
     HIPCHK(hipSetDevice(f1->device));
     HIPCHK(hipMemcpy(qdesc.data(), f1->d_desc.p, (size_t)N1 * 32, hipMemcpyDeviceToHost));  // F1.mDescriptors as uploaded
     HIPCHK(hipSetDevice(f2->device));
-    for (int i = 0; i < N1; i++) {
-        WinQuery w{};
-        const int level1 = f1->kps[i].octave;
-        if (level1 <= 0) {                                            // :769-771 (only level-0 keypoints are matched)
-            w.x = prev_xy[2 * i]; w.y = prev_xy[2 * i + 1];
-            w.r = (float)window_size;
-            w.min_level = (int16_t)level1; w.max_level = (int16_t)level1;  // GetFeaturesInArea(x, y, windowSize, level1, level1)
-            w.flags = kQValid | kQNoUr;
-        }
-        q[i] = w;
-    }
     int rc;
     // grow-only scratch on the train frame's handle (a per-call hipMalloc / hipFree pair synchronises the whole device
     // while the other SLAM threads have kernels in flight, and leaked on the early returns)
@@ -802,8 +789,7 @@ int msorb_search_for_initialization(msorb_frame* f1, msorb_frame* f2, float* pre
         (rc = d_beg.ensure(N1 + 1)))
         return rc;
     hipStream_t s = f2->stream;
-    std::vector<int> cnt(N1), beg(N1 + 1, 0);
-    std::vector<int2> list;
+    cnt.assign(N1, 0); beg.assign(N1 + 1, 0);
     hipError_t e = hipMemcpyAsync(f2->d_q.p, q.data(), (size_t)N1 * sizeof(WinQuery), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(f2->d_qdesc.p, qdesc.data(), (size_t)N1 * 32, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
@@ -825,22 +811,89 @@ int msorb_search_for_initialization(msorb_frame* f1, msorb_frame* f2, float* pre
         }
     }
     if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return MSORB_E_HIP; }
-    if (rc) return rc;
-    // the reference's loop (:767-835) on the lists: every distance is known, the sequential part is compare / select
+    return rc;
+}
+}  // namespace
+
+// ORBmatcher::SearchForInitialization (ORBmatcher.cc:755-870).  A query's scan keeps best / second best over the window's
+// candidates that no earlier query holds at a smaller or equal distance (vMatchedDistance, :791-792): only the LOW end of a
+// window's distances ever decides anything.  The device ranks each window's eight best candidates (window_topk_kernel: distance,
+// then scan position — the first strict minimum of the scan is the first of the ranked list, and the second best VALUE is the next
+// one's); the replay walks a list past the candidates the rule skips.  A list is conclusive when it ends before eight entries, when
+// its first survivor is above TH_LOW, when two survivors are found, when the one survivor passes the ratio test against the
+// EIGHTH distance (every unlisted candidate is at least that far), or when nothing survives and the eighth is already above TH_LOW.  The first query whose list is not switches the rest of the
+// call to the complete lists (window_list_kernel: rounds 1-5 took them for every query — 4 MB and 4 ms at 10 000 features).
+int msorb_search_for_initialization(msorb_frame* f1, msorb_frame* f2, float* prev_xy, int window_size, float nnratio,
+                                    int check_orientation, int* matches12, int* nmatches) {
+    if (!f1 || !f2 || !nmatches || (f1->N > 0 && (!prev_xy || !matches12))) return MSORB_E_INVALID;
+    *nmatches = 0;
+    const int N1 = f1->N, N2 = f2->N;
+    for (int i = 0; i < N1; i++) matches12[i] = -1;
+    if (N1 == 0) return MSORB_OK;
+    HIPCHK(hipSetDevice(f2->device));
+    std::vector<WinQuery> q(N1);
+    for (int i = 0; i < N1; i++) {
+        WinQuery w{};
+        const int level1 = f1->kps[i].octave;
+        if (level1 <= 0) {                                            // :769-771 (only level-0 keypoints are matched)
+            w.x = prev_xy[2 * i]; w.y = prev_xy[2 * i + 1];
+            w.r = (float)window_size;
+            w.min_level = (int16_t)level1; w.max_level = (int16_t)level1;  // GetFeaturesInArea(x, y, windowSize, level1, level1)
+            w.flags = kQValid | kQNoUr;
+        }
+        q[i] = w;
+    }
+    int rc;
+    int full_from = N1;                 // queries from here on take the complete lists
+    std::vector<int> cnt, beg;
+    std::vector<int2> list;
+    if (f1->device == f2->device && f1->d_desc.p) {
+        if ((rc = window_search_once(f2, N1, q.data(), nullptr, nullptr, nullptr, nullptr, 0, f1->d_desc.p))) return rc;   // F1.mDescriptors as uploaded
+    } else {
+        full_from = 0;
+        if ((rc = init_full_lists(f1, f2, q, 0, cnt, beg, list))) return rc;
+    }
+    const TopK* const topk = f2->h_topk.p;
+    // the reference's loop (:767-835): every distance that can matter is known, the sequential part is compare / select
     int nm = 0;
     std::vector<int> rotHist[kHistoLength];
     const float factor = 1.0f / kHistoLength;
     std::vector<int> vMatchedDistance(N2, INT_MAX), vnMatches21(N2, -1);
     for (int i1 = 0; i1 < N1; i1++) {
-        if (!(q[i1].flags & kQValid) || cnt[i1] == 0) continue;
+        if (!(q[i1].flags & kQValid)) continue;
         int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
-        for (int k = beg[i1]; k < beg[i1 + 1]; k++) {
-            const int i2 = list[k].x, dist = list[k].y;
-            if (vMatchedDistance[i2] <= dist) continue;
-            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
-            else if (dist < bestDist2) bestDist2 = dist;
+        if (i1 < full_from) {
+            const TopK& t = topk[i1];
+            int n_listed = 0, survivors = 0;
+            for (int k = 0; k < kTopK && t.idx[k] >= 0; k++) {
+                n_listed++;
+                if (vMatchedDistance[t.idx[k]] <= t.dist[k]) continue;                 // :791-792
+                if (survivors == 0) { bestDist = t.dist[k]; bestIdx2 = t.idx[k]; }
+                else if (survivors == 1) bestDist2 = t.dist[k];
+                if (++survivors == 2) break;
+            }
+            bool settled = n_listed < kTopK || survivors == 2 || (survivors == 1 && bestDist > kThLow) ||
+                           (survivors == 0 && t.dist[kTopK - 1] > kThLow);   // (nothing listed survives and every unlisted candidate is beyond TH_LOW: no match)
+            if (!settled && survivors == 1 && (float)bestDist < (float)t.dist[kTopK - 1] * nnratio) {
+                // one survivor, every unlisted candidate at least as far as the eighth: the ratio test passes whatever the second is
+                settled = true;
+                bestDist2 = t.dist[kTopK - 1];   // (a lower bound of it: only its product with nnratio is used, and that test is decided)
+            }
+            if (!settled) {
+                full_from = i1;
+                if ((rc = init_full_lists(f1, f2, q, full_from, cnt, beg, list))) return rc;
+            }
         }
-        if (bestDist <= kThLow) {
+        if (i1 >= full_from) {
+            bestDist = INT_MAX; bestDist2 = INT_MAX; bestIdx2 = -1;
+            for (int k = beg[i1]; k < beg[i1 + 1]; k++) {
+                const int i2 = list[k].x, dist = list[k].y;
+                if (vMatchedDistance[i2] <= dist) continue;
+                if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+                else if (dist < bestDist2) bestDist2 = dist;
+            }
+        }
+        if (bestIdx2 >= 0 && bestDist <= kThLow) {
             if (bestDist < (float)bestDist2 * nnratio) {
                 if (vnMatches21[bestIdx2] >= 0) { matches12[vnMatches21[bestIdx2]] = -1; nm--; }
                 matches12[i1] = bestIdx2;

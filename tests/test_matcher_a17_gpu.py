@@ -207,3 +207,47 @@ def test_monocular_initialisation_at_the_initialisation_extractors_size(msorb_mo
         assert nm > 500                                                  # (Tracking.cc:2426 wants 100 to go on)
     finally:
         f1.close(); f2.close()
+
+
+@pytest.mark.parametrize("ratio", [1.0, 0.9])
+def test_search_for_initialization_past_the_ranked_lists(msorb_mod, oracle, ratio):
+    """Fifteen queries with ONE descriptor in one window over twenty trains at Hamming distances 1 .. 20 from it: query k finds
+    trains 1 .. k-1 held at smaller distances (vMatchedDistance, ORBmatcher.cc:791-792) and takes train k — from the ninth query on
+    every entry of the device's eight-deep ranked list is skipped, and the search must go on over the complete lists
+    (msorb_search_for_initialization's fallback) to answer like the reference; other windows around it stay on the ranked lists."""
+    rng = np.random.Generator(np.random.PCG64(17))
+    scale = np.array([1.2 ** i for i in range(8)], np.float32)
+    bounds = (0.0, 1241.0, 0.0, 376.0)
+    base = rng.integers(0, 256, 32, dtype=np.uint8)
+    nq, nt, n_other = 15, 20, 300
+    k1 = np.zeros(nq + n_other, oracle.KP_DTYPE); k2 = np.zeros(nt + n_other, oracle.KP_DTYPE)
+    k1["x"][:nq] = 600 + rng.uniform(-5, 5, nq); k1["y"][:nq] = 180 + rng.uniform(-5, 5, nq)
+    k2["x"][:nt] = 600 + rng.uniform(-30, 30, nt); k2["y"][:nt] = 180 + rng.uniform(-30, 30, nt)
+    k1["x"][nq:] = rng.uniform(30, 1200, n_other); k1["y"][nq:] = rng.uniform(30, 340, n_other)
+    k1["octave"][nq:] = rng.integers(0, 3, n_other)
+    k2["x"][nt:] = k1["x"][nq:] + rng.normal(0, 3, n_other); k2["y"][nt:] = k1["y"][nq:] + rng.normal(0, 3, n_other)
+    k2["octave"][nt:] = k1["octave"][nq:]
+    for k in (k1, k2):
+        k["angle"] = rng.uniform(0, 360, len(k)); k["size"] = 31
+    d1 = rng.integers(0, 256, (nq + n_other, 32), dtype=np.uint8); d2 = d1[nq:][rng.permutation(n_other)][:0]
+    d1[:nq] = base
+    d2 = np.zeros((nt + n_other, 32), np.uint8)
+    for j in range(nt):                                            # train j: the base descriptor with j + 1 bits flipped
+        bits = np.unpackbits(base).copy(); bits[rng.permutation(256)[:j + 1]] ^= 1
+        d2[j] = np.packbits(bits)
+    d2[nt:] = mc.flip_bits(rng, d1[nq:], 12)
+    f1, f2 = msorb_mod.Frame(k1, d1, None, bounds, scale), msorb_mod.Frame(k2, d2, None, bounds, scale)
+    r1, r2 = oracle.OracleFrame(k1, d1, None, bounds, scale), oracle.OracleFrame(k2, d2, None, bounds, scale)
+    try:
+        prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+        gp, wp = prev.copy(), prev.copy()
+        got, nm = msorb_mod.search_for_initialization(f1, f2, gp, 100, ratio, False)
+        want, wn = oracle.search_for_initialization(r1, r2, wp, 100, ratio, False)
+        assert nm == wn and np.array_equal(got, want) and np.array_equal(gp.view(np.uint32), wp.view(np.uint32))
+        if ratio == 1.0:
+            assert np.array_equal(want[:nq], np.arange(nq))        # query k took train k: nine of them past the ranked lists
+        else:
+            assert np.array_equal(want[:8], np.arange(8)) and np.all(want[8:nq] == -1)   # k < 0.9 (k + 1) ends at k = 8
+        assert (want[nq:] >= 0).sum() > 50
+    finally:
+        f1.close(); f2.close()
