@@ -955,27 +955,49 @@ int msorb_hamming_top2(int device, const uint8_t* qdesc, int nq, const uint8_t* 
     const int total = cand_begin[nq];
     for (int i = 0; i < total; i++)
         if (cand_idx[i] < 0 || cand_idx[i] >= nt) { set_last_error("candidate index out of range"); return MSORB_E_INVALID; }
-    DBuf<uint8_t> dq, dt;
-    DBuf<int> dcb, dci, dout;
-    int rc;
-    if ((rc = dq.ensure((size_t)nq * 32)) || (rc = dt.ensure((size_t)nt * 32)) || (rc = dcb.ensure(nq + 1)) ||
-        (rc = dci.ensure(total)) || (rc = dout.ensure((size_t)4 * nq)))
-        return rc;
-    auto cleanup = [&] { dq.release(); dt.release(); dcb.release(); dci.release(); dout.release(); };
-    hipError_t e = hipMemcpy(dq.p, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess && nt) e = hipMemcpy(dt.p, tdesc, (size_t)nt * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dcb.p, cand_begin, (size_t)(nq + 1) * sizeof(int), hipMemcpyHostToDevice);
-    if (e == hipSuccess && total) e = hipMemcpy(dci.p, cand_idx, (size_t)total * sizeof(int), hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        launch_list_top2(dq.p, dt.p, dcb.p, dci.p, nq, dout.p, dout.p + nq, dout.p + 2 * nq, dout.p + 3 * nq, nullptr);
-        e = hipDeviceSynchronize();
+    // per-thread grow-only scratch, one staged block up ([queries | trains | list offsets | list]) and one down (rounds 1-5: five
+    // hipMalloc / hipFree and eight synchronous copies on the null stream per call)
+    struct Scratch {
+        int device = -1;
+        hipStream_t s = nullptr;
+        DBuf<uint8_t> d;
+        HBuf<uint8_t> h;
+        void release() {
+            if (device < 0 || hipSetDevice(device) != hipSuccess) return;
+            d.release(); h.release();
+            if (s) (void)hipStreamDestroy(s);
+            s = nullptr; device = -1;
+        }
+        ~Scratch() { release(); }
+    };
+    static thread_local Scratch S;
+    if (S.device != device) {
+        S.release();
+        S.device = device;
+        HIPCHK(hipStreamCreateWithFlags(&S.s, hipStreamNonBlocking));
     }
-    if (e == hipSuccess) e = hipMemcpy(best_idx, dout.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(best_dist, dout.p + nq, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(second_idx, dout.p + 2 * nq, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(second_dist, dout.p + 3 * nq, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost);
-    cleanup();
-    if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return MSORB_E_HIP; }
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_t = up16((size_t)nq * 32), o_cb = o_t + up16((size_t)nt * 32), o_ci = o_cb + up16((size_t)(nq + 1) * 4),
+                 in_bytes = o_ci + up16((size_t)total * 4), o_out = in_bytes, bytes = o_out + up16((size_t)4 * nq * 4);
+    int rc;
+    if ((rc = S.d.ensure(bytes)) || (rc = S.h.ensure(bytes))) return rc;
+    std::memcpy(S.h.p, qdesc, (size_t)nq * 32);
+    if (nt) std::memcpy(S.h.p + o_t, tdesc, (size_t)nt * 32);
+    std::memcpy(S.h.p + o_cb, cand_begin, (size_t)(nq + 1) * sizeof(int));
+    if (total) std::memcpy(S.h.p + o_ci, cand_idx, (size_t)total * sizeof(int));
+    hipStream_t s = S.s;
+    HIPCHK(small_copy(S.d.p, S.h.p, in_bytes, hipMemcpyHostToDevice, s));
+    int* const dout = reinterpret_cast<int*>(S.d.p + o_out);
+    launch_list_top2(S.d.p, S.d.p + o_t, reinterpret_cast<const int*>(S.d.p + o_cb), reinterpret_cast<const int*>(S.d.p + o_ci), nq, dout, dout + nq,
+                     dout + 2 * nq, dout + 3 * nq, s);
+    HIPCHK(hipGetLastError());
+    HIPCHK(small_copy(S.h.p + o_out, S.d.p + o_out, (size_t)4 * nq * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const int* ho = reinterpret_cast<const int*>(S.h.p + o_out);
+    std::memcpy(best_idx, ho, (size_t)nq * sizeof(int));
+    std::memcpy(best_dist, ho + nq, (size_t)nq * sizeof(int));
+    std::memcpy(second_idx, ho + 2 * nq, (size_t)nq * sizeof(int));
+    std::memcpy(second_dist, ho + 3 * nq, (size_t)nq * sizeof(int));
     return MSORB_OK;
 }
 
