@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -183,6 +184,18 @@ int run_window_search(msorb_frame* f, int M, const WinQuery* q, const uint8_t* f
     uint8_t* const h_occ = f->h_in.p + qb16 + db;
     TopK* const topk = f->h_topk.p;
     std::vector<int8_t> diff(f->N, 0);  // occupancy now vs snapshot: +1 claimed since, -1 freed since
+    // a keypoint that was occupied at the snapshot and is free now is missing from the lists of exactly those queries whose window
+    // (box and level band as window_topk_kernel tests them; its mvuRight test can only drop more) holds it: only they need a new round
+    std::vector<int> freed;
+    auto holds_freed = [&](const WinQuery& w) {
+        for (int idx : freed) {
+            if (diff[idx] >= 0) continue;
+            const msorb_keypoint& kp = f->kps[idx];
+            if (kp.octave < w.min_level || (w.max_level >= 0 && kp.octave > w.max_level)) continue;
+            if (fabsf(kp.x - w.x) < w.r && fabsf(kp.y - w.y) < w.r) return true;
+        }
+        return false;
+    };
     int q0 = 0, n_rounds = 0;
     while (q0 < M) {
         if (!(ready && n_rounds == 0)) {
@@ -200,12 +213,13 @@ int run_window_search(msorb_frame* f, int M, const WinQuery* q, const uint8_t* f
         std::vector<uint8_t> snap = occ;
         std::fill(diff.begin(), diff.end(), 0);
         int n_freed = 0;
+        freed.clear();
         int qi = q0;
         bool resync = false;
         for (; qi < M; qi++) {
             if (!(flags[qi] & kQValid)) continue;
             const bool skip = flags[qi] & kQSkipOccupied;
-            if (skip && n_freed > 0 && qi > q0) { resync = true; break; }
+            if (skip && n_freed > 0 && qi > q0 && (!q || holds_freed(q[qi]))) { resync = true; break; }   // (queries built on the device: windows unknown here)
             const TopK& t = topk[qi];
             int idx[kTopK], dist[kTopK], n = 0, n_dev = 0;
             for (int k = 0; k < kTopK; k++) {
@@ -222,7 +236,7 @@ int run_window_search(msorb_frame* f, int M, const WinQuery* q, const uint8_t* f
                 const int8_t d = (int8_t)((int)occ[assigned] - (int)snap[assigned]);
                 if (diff[assigned] < 0) n_freed--;
                 diff[assigned] = d;
-                if (d < 0) n_freed++;
+                if (d < 0) { n_freed++; freed.push_back(assigned); }
             }
         }
         n_rounds++;

@@ -259,16 +259,29 @@ struct RigSide {
         n_freed = 0;
         fresh_from = next;
         pristine = true;
+        freed.clear();
         rounds++;
         return MSORB_OK;
     }
+    std::vector<int> freed;   // keypoints freed since the round (entries whose diff is no longer negative were claimed again)
     void set_occ(int idx, int v) {
         pristine = false;
         occ[idx] = (uint8_t)v;
         const int8_t d = (int8_t)((int)occ[idx] - (int)snap[idx]);
         if (diff[idx] < 0) n_freed--;
         diff[idx] = d;
-        if (d < 0) n_freed++;
+        if (d < 0) { n_freed++; freed.push_back(idx); }
+    }
+    // a keypoint that was occupied at the round and is free now is missing from the lists of exactly those queries whose window
+    // (box and level band, as window_topk_kernel tests them) holds it: only such a query needs a new round
+    bool window_holds_a_freed_keypoint(const WinQuery& w) const {
+        for (int idx : freed) {
+            if (diff[idx] >= 0) continue;
+            const msorb_keypoint& kp = f->kps[idx];
+            if (kp.octave < w.min_level || (w.max_level >= 0 && kp.octave > w.max_level)) continue;
+            if (fabsf(kp.x - w.x) < w.r && fabsf(kp.y - w.y) < w.r) return true;
+        }
+        return false;
     }
     // the exact candidate prefix of query qi (>= need entries unless the true candidate set is smaller); false: the list cannot be
     // trusted any more (exhausted by claims, or a keypoint was freed): the side needs a new round from qi
@@ -276,7 +289,7 @@ struct RigSide {
         const bool skip = q[qi].flags & kQSkipOccupied;
         if (f->N <= 0) { *n_out = 0; return true; }
         const bool stale = qi > fresh_from || !pristine;   // claims may lie between the round and this query
-        if (skip && n_freed > 0 && stale) return false;
+        if (skip && n_freed > 0 && stale && window_holds_a_freed_keypoint(q[qi])) return false;
         const TopK& t = f->h_topk.p[qi];
         int n = 0, n_dev = 0;
         for (int k = 0; k < kTopK; k++) {

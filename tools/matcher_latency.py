@@ -57,3 +57,23 @@ sizes = np.random.default_rng(0).integers(2, 12, 2000).tolist()
 desc, ob = bow_cases.make_observations(7, sizes)
 row("ComputeDistinctiveDescriptors (2000 points, 2-11 observations)", lambda: msorb.distinctive_descriptors(desc, ob), lambda: oracle.distinctive_descriptors(desc, ob))
 f1.close(); f2.close()
+
+# ---- the two-camera arms (tests/test_matcher_rig_gpu.py's synthetic rigs) ----
+import test_matcher_rig_gpu as tr
+import bow_match_cases as bmc
+R = tr.make_rig(oracle, 1, 1500, 1400, 4096)
+ofl, ofr = oracle.OracleFrame(R["kl"], R["dl"], None, tr.BOUNDS, tr.SCALE), oracle.OracleFrame(R["kr"], R["dr"], None, tr.BOUNDS, tr.SCALE)
+dfl, dfr = msorb.Frame(R["kl"], R["dl"], None, tr.BOUNDS, tr.SCALE), msorb.Frame(R["kr"], R["dr"], None, tr.BOUNDS, tr.SCALE)
+row("two cameras: SearchByProjection(F, 4096 map points)", lambda: msorb.search_by_projection_mps_rig(dfl, dfr, R["mp"], R["l2r"], R["r2l"], R["frame_mp"].copy(), 1.0, False, 40.0, 0.8),
+    lambda: oracle.search_by_projection_mps_rig(ofl, ofr, R["mp"], R["l2r"], R["r2l"], R["frame_mp"].copy(), 1.0, False, 40.0, 0.8))
+R2, last, cur = tr.make_last_table(oracle, 51, 1500, 1400, 1800, 7.0)
+ofl2, ofr2 = oracle.OracleFrame(R2["kl"], R2["dl"], None, tr.BOUNDS, tr.SCALE), oracle.OracleFrame(R2["kr"], R2["dr"], None, tr.BOUNDS, tr.SCALE)
+dfl2, dfr2 = msorb.Frame(R2["kl"], R2["dl"], None, tr.BOUNDS, tr.SCALE), msorb.Frame(R2["kr"], R2["dr"], None, tr.BOUNDS, tr.SCALE)
+row("two cameras: SearchByProjection(Current, Last) (1800 points)", lambda: msorb.search_by_projection_frames_rig(dfl2, dfr2, last, cur.copy(), 7.0, False, False, True),
+    lambda: oracle.search_by_projection_frames_rig(ofl2, ofr2, last, cur.copy(), 7.0, False, False, True))
+pb = tr._bow_rig_pair(1, 1200, 2400, 1300)
+row("two cameras: SearchByBoW(pKF, F) (1200 x 2400)", lambda: msorb.search_by_bow_rig(pb, 1300, 50, 0.7, True), lambda: oracle.search_by_bow_rig(pb, 1300, 50, 0.7, True))
+pt = bmc.make_pair(301, 1200, 1300, n_nodes=25, flip=30, dup_frac=0.25)
+acc = tr._accept_fn(1, 1200, 1300, 0.5)
+row("two cameras: SearchForTriangulation with a Python callback", lambda: msorb.search_for_triangulation_cb(pt, acc, 50, True), lambda: oracle.search_for_triangulation_rig(pt, acc, False, True))
+for f in (dfl, dfr, dfl2, dfr2): f.close()
