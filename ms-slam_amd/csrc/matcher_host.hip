@@ -521,16 +521,44 @@ int msorb_search_by_projection_frames_rig(msorb_frame* left, msorb_frame* right,
     *nmatches = 0;
     const int NL = left->N;
     std::vector<uint8_t> valid_r(NLast, 0);
+    {
+        int rc0;
+        if ((rc0 = frame_host_grid(left))) return rc0;   // the left camera's grid on the host, fetched once
+    }
+    // `vIndices2.empty()` of the left window (:2001-2004), whatever its keypoints hold: GetFeaturesInArea's walk (Frame.cc:589-655) cut
+    // short at the first keypoint found
+    auto left_window_has_a_keypoint = [&](float x, float y, float r, int min_level, int max_level) {
+        const msorb_frame* f = left;
+        const int minCX = std::max(0, (int)std::floor((x - f->minX - r) * f->gridWInv));
+        if (minCX >= kGridCols) return false;
+        const int maxCX = std::min(kGridCols - 1, (int)std::ceil((x - f->minX + r) * f->gridWInv));
+        if (maxCX < 0) return false;
+        const int minCY = std::max(0, (int)std::floor((y - f->minY - r) * f->gridHInv));
+        if (minCY >= kGridRows) return false;
+        const int maxCY = std::min(kGridRows - 1, (int)std::ceil((y - f->minY + r) * f->gridHInv));
+        if (maxCY < 0) return false;
+        const bool check = (min_level > 0) || (max_level >= 0);
+        for (int ix = minCX; ix <= maxCX; ix++)
+            for (int iy = minCY; iy <= maxCY; iy++) {
+                const int c = ix * kGridRows + iy;
+                for (int j = f->cell_begin[c]; j < f->cell_begin[c + 1]; j++) {
+                    const msorb_keypoint& kp = f->kps[f->cell_idx[j]];
+                    if (check) {
+                        if (kp.octave < min_level) continue;
+                        if (max_level >= 0 && kp.octave > max_level) continue;
+                    }
+                    if (std::fabs(kp.x - x) < r && std::fabs(kp.y - y) < r) return true;
+                }
+            }
+        return false;
+    };
     for (int i = 0; i < NLast; i++) {
         if (!valid[i]) continue;
         const int oct = last_octave[i];
         if (oct < 0 || oct >= left->nlevels) { set_last_error("octave out of range"); return MSORB_E_INVALID; }
         const float radius = th * left->scale[oct];
         const int lo = forward ? oct : backward ? 0 : oct - 1, hi = forward ? -1 : backward ? oct : oct + 1;
-        int one = 0, n = 0;
-        const int rc = msorb_frame_features_in_area(left, u[i], v[i], radius, lo, hi, &one, 1, &n);   // (only the count is wanted)
-        if (rc && rc != MSORB_E_CAPACITY) return rc;
-        valid_r[i] = n > 0;
+        valid_r[i] = left_window_has_a_keypoint(u[i], v[i], radius, lo, hi);
     }
     std::vector<std::pair<int, int>> pl, pr;
     int nl = 0, nr = 0, rc;
